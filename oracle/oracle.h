@@ -1,0 +1,57 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, scalar restatement of the reference's hot-path kernels (lh3/minimap2 v2.30). Nothing in the
+ * product library (minimap2_amd/) may include, link or call this; only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg do, and only as the checker.
+ *
+ * Parity status: PINNED. Every function here is fuzz-checked against the compiled, unmodified reference
+ * (oracle/_ref/libminimap2_ref.so, built by oracle/Makefile from /root/reference) in tests/test_oracle_*.py;
+ * the reference ships no golden vectors of its own for this path.
+ */
+#ifndef MM2AMD_ORACLE_H
+#define MM2AMD_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flag bits, same numeric values as the reference's KSW_EZ_* (ksw2.h:8-19) */
+#define ORA_EZ_SCORE_ONLY   0x01
+#define ORA_EZ_RIGHT        0x02
+#define ORA_EZ_GENERIC_SC   0x04
+#define ORA_EZ_APPROX_MAX   0x08
+#define ORA_EZ_APPROX_DROP  0x10
+#define ORA_EZ_EXTZ_ONLY    0x40
+#define ORA_EZ_REV_CIGAR    0x80
+#define ORA_EZ_SPLICE_FOR   0x100
+#define ORA_EZ_SPLICE_REV   0x200
+#define ORA_EZ_SPLICE_FLANK 0x400
+#define ORA_EZ_SPLICE_CMPLX 0x800
+#define ORA_EZ_SPLICE_SCORE 0x1000
+#define ORA_NEG_INF         (-0x40000000)
+
+/* result of one extension/global DP; field meaning as ksw_extz_t (ksw2.h:34-43) */
+typedef struct {
+	int32_t max, zdropped;
+	int32_t max_q, max_t;
+	int32_t mqe, mqe_t;
+	int32_t mte, mte_q;
+	int32_t score;
+	int32_t n_cigar;
+	int32_t reach_end;
+	int32_t cigar_overflow;   /* set if cigar_cap was too small (n_cigar then counts what would be needed) */
+} ora_ez_t;
+
+typedef struct { uint64_t x, y; } ora128_t;
+
+/* ksw2_extd2_sse.c:34-401, lane-exact (16-lane block garbage included) */
+void ora_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag,
+                   ora_ez_t *ez, uint32_t *cigar, int cigar_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
