@@ -1,0 +1,124 @@
+// C ABI of libmm2amd.so (declared in include/mm2amd.h).
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstring>
+#include "../../include/mm2amd.h"
+#include "hip_util.hpp"
+#include "ksw_host.hpp"
+
+using namespace mm2amd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+struct Device {
+	std::mutex mu;
+	bool ready = false;
+	hipStream_t stream = nullptr;
+	KswRunner ksw;
+	DevBuf<uint8_t> d_qpool, d_tpool;
+};
+
+Device &dev()
+{
+	static Device d;
+	return d;
+}
+
+// Bring up device 0 (or $MM2AMD_DEVICE); throws HipError with ENODEV semantics if impossible.
+void ensure_device(Device &d)
+{
+	if (d.ready) return;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) throw HipError("[mm2amd] no HIP device visible: this library has no CPU path");
+	int id = 0;
+	if (const char *s = getenv("MM2AMD_DEVICE")) id = atoi(s);
+	else if (const char *s = getenv("LOCAL_RANK")) id = atoi(s) % n;
+	HIP_CHECK(hipSetDevice(id));
+	hipDeviceProp_t prop;
+	HIP_CHECK(hipGetDeviceProperties(&prop, id));
+	d.ksw.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+	d.ready = true;
+}
+
+template <typename F>
+int guarded(F &&f)
+{
+	try {
+		return f();
+	} catch (const HipError &e) {
+		std::string s = e.what();
+		return fail(s.find("no HIP device") != std::string::npos ? MM2AMD_ENODEV : MM2AMD_EHIP, s);
+	} catch (const std::exception &e) {
+		return fail(MM2AMD_EINVAL, e.what());
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mm2amd_last_error(void) { return g_err.c_str(); }
+int mm2amd_version(void) { return 1; }
+
+int mm2amd_device_count(void)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) return fail(MM2AMD_ENODEV, std::string("[mm2amd] hipGetDeviceCount: ") + hipGetErrorString(e));
+	return n;
+}
+
+int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat,
+                           int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2,
+                           mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
+{
+	if (n_jobs < 0 || (n_jobs > 0 && (!jobs || !res)) || !mat || m != 5) return fail(MM2AMD_EINVAL, "[mm2amd] ksw_extd2_batch: bad arguments (m must be 5)");
+	if (n_jobs == 0) return 0;
+	return guarded([&]() -> int {
+		Device &d = dev();
+		std::lock_guard<std::mutex> lk(d.mu);
+		ensure_device(d);
+		std::vector<KswJob> dj(n_jobs);
+		size_t qtot = 0, ttot = 0, ctot = 0;
+		for (int i = 0; i < n_jobs; ++i) {
+			const mm2amd_ksw_job_t &j = jobs[i];
+			KswJob &o = dj[i];
+			o.q_off = qtot, o.t_off = ttot, o.qlen = j.qlen, o.tlen = j.tlen, o.w = j.w, o.zdrop = j.zdrop, o.end_bonus = j.end_bonus;
+			o.flag = j.flag & 0x1fff;
+			o.cigar_off = (uint32_t)ctot;
+			o.cigar_cap = (o.flag & KSW_SCORE_ONLY) || j.qlen <= 0 || j.tlen <= 0 ? 0 : (uint32_t)(j.qlen + j.tlen);
+			qtot += j.qlen > 0 ? j.qlen : 0, ttot += j.tlen > 0 ? j.tlen : 0, ctot += o.cigar_cap;
+		}
+		if (ctot > cigar_pool_cap || ctot >= (1ull << 32)) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (need sum(qlen+tlen))");
+		std::vector<uint8_t> hq(qtot + 1), ht(ttot + 1);
+		for (int i = 0; i < n_jobs; ++i) {
+			if (jobs[i].qlen > 0) memcpy(&hq[dj[i].q_off], jobs[i].query, jobs[i].qlen);
+			if (jobs[i].tlen > 0) memcpy(&ht[dj[i].t_off], jobs[i].target, jobs[i].tlen);
+		}
+		d.d_qpool.ensure(qtot + 1), d.d_tpool.ensure(ttot + 1);
+		HIP_CHECK(hipMemcpyAsync(d.d_qpool.p, hq.data(), qtot + 1, hipMemcpyHostToDevice, d.stream));
+		HIP_CHECK(hipMemcpyAsync(d.d_tpool.p, ht.data(), ttot + 1, hipMemcpyHostToDevice, d.stream));
+		KswScoring sc;
+		memcpy(sc.mat, mat, 25);
+		sc.m = m, sc.q = gapo, sc.e = gape, sc.q2 = gapo2, sc.e2 = gape2, sc.pad[0] = sc.pad[1] = 0;
+		std::vector<KswRes> r(n_jobs);
+		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cigar_pool, ctot, d.stream);
+		for (int i = 0; i < n_jobs; ++i) {
+			if (r[i].cigar_overflow) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: internal CIGAR capacity exceeded");
+			mm2amd_ksw_res_t &o = res[i];
+			o.max = r[i].max, o.zdropped = r[i].zdropped, o.max_q = r[i].max_q, o.max_t = r[i].max_t;
+			o.mqe = r[i].mqe, o.mqe_t = r[i].mqe_t, o.mte = r[i].mte, o.mte_q = r[i].mte_q;
+			o.score = r[i].score, o.n_cigar = r[i].n_cigar, o.reach_end = r[i].reach_end, o.cigar_off = dj[i].cigar_off;
+		}
+		return 0;
+	});
+}
+
+} // extern "C"

@@ -1,0 +1,69 @@
+// Small HIP runtime helpers shared by the product's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace mm2amd {
+
+struct HipError : std::runtime_error {
+	using std::runtime_error::runtime_error;
+};
+
+inline void hip_check(hipError_t e, const char *what, const char *file, int line)
+{
+	if (e != hipSuccess) {
+		char buf[512];
+		snprintf(buf, sizeof buf, "[mm2amd] HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+		throw HipError(buf);
+	}
+}
+#define HIP_CHECK(x) ::mm2amd::hip_check((x), #x, __FILE__, __LINE__)
+
+// Grow-only device buffer; contents are NOT preserved across a grow.
+template <typename T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	T *ensure(size_t n, double slack = 1.25)
+	{
+		if (n > cap) {
+			if (p) HIP_CHECK(hipFree(p));
+			p = nullptr;
+			cap = (size_t)(n * slack) + 64;
+			HIP_CHECK(hipMalloc((void **)&p, cap * sizeof(T)));
+		}
+		return p;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// Grow-only pinned host buffer.
+template <typename T>
+struct PinBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	PinBuf() = default;
+	PinBuf(const PinBuf &) = delete;
+	PinBuf &operator=(const PinBuf &) = delete;
+	~PinBuf() { if (p) (void)hipHostFree(p); }
+	T *ensure(size_t n, double slack = 1.25)
+	{
+		if (n > cap) {
+			if (p) HIP_CHECK(hipHostFree(p));
+			p = nullptr;
+			cap = (size_t)(n * slack) + 64;
+			HIP_CHECK(hipHostMalloc((void **)&p, cap * sizeof(T), hipHostMallocDefault));
+		}
+		return p;
+	}
+};
+
+} // namespace mm2amd

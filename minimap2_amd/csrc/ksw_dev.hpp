@@ -1,0 +1,81 @@
+// Device-side job/result records of the batched extension-DP kernels (host <-> device contract).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#ifndef __HIPCC__
+#define __host__
+#define __device__
+#endif
+
+namespace mm2amd {
+
+// flag bits 0..12 are the reference's KSW_EZ_* (ksw2.h:8-19); the bits below are ours
+enum : int32_t {
+	KSW_SCORE_ONLY = 0x01, KSW_RIGHT = 0x02, KSW_GENERIC_SC = 0x04, KSW_APPROX_MAX = 0x08, KSW_APPROX_DROP = 0x10,
+	KSW_EXTZ_ONLY = 0x40, KSW_REV_CIGAR = 0x80,
+	KSW_SPLICE_FOR = 0x100, KSW_SPLICE_REV = 0x200, KSW_SPLICE_FLANK = 0x400, KSW_SPLICE_CMPLX = 0x800, KSW_SPLICE_SCORE = 0x1000,
+	KSWJ_Q_REVERSED = 1 << 16,  // query bytes are read backwards from q_off (left extension, align.c:787)
+	KSWJ_T_PACKED   = 1 << 17,  // target comes from the 4-bit packed reference (mi->S); t_off is a base index
+	KSWJ_T_REVERSED = 1 << 18,  // target is read backwards (left extension, align.c:788)
+	KSWJ_SKIP       = 1 << 19,  // max_sw_mat guard hit (align.c:349-351): reset + zdropped=1, no DP
+};
+constexpr int32_t KSW_NEG_INF = -0x40000000;
+
+struct KswJob {             // 48 B
+	uint64_t q_off;         // byte offset into the query pool (nt4 codes, 1 B/base); first base read (last if Q_REVERSED)
+	uint64_t t_off;         // byte offset into the target pool, or base index into packed S; first base read (last if T_REVERSED)
+	int32_t qlen, tlen;
+	int32_t w, zdrop, end_bonus, flag;
+	uint32_t cigar_off;     // where this job's CIGAR goes in the cigar pool (uint32 units)
+	uint32_t cigar_cap;
+};
+
+struct KswRes {             // 48 B; field meaning as ksw_extz_t (ksw2.h:34-43)
+	int32_t max, zdropped;
+	int32_t max_q, max_t;
+	int32_t mqe, mqe_t;
+	int32_t mte, mte_q;
+	int32_t score;
+	int32_t n_cigar;
+	int32_t reach_end;
+	int32_t cigar_overflow;
+};
+
+struct KswScoring {         // uniform over a launch
+	int8_t mat[25];
+	int8_t m;
+	int8_t q, e, q2, e2;    // as passed by the caller, BEFORE the swap at ksw2_extd2_sse.c:78
+	int8_t pad[2];
+};
+
+struct KswLaunch {
+	const KswJob *jobs;     // device, sorted by decreasing cost
+	KswRes *res;            // device
+	int32_t n_jobs;
+	const uint8_t *qpool;   // device nt4 bytes
+	const uint8_t *tpool;   // device nt4 bytes (may be null when every job is T_PACKED)
+	const uint32_t *S;      // device 4-bit packed reference (may be null)
+	uint32_t *cigar_pool;   // device
+	uint8_t *dir_pool;      // device scratch for direction matrices: n_slots * slot_bytes
+	size_t slot_bytes;
+	int32_t *counter;       // device, zeroed before launch: persistent-wave job queue head
+	int32_t max_T16, max_Q16; // LDS sizing: largest 16-rounded tlen / qlen in the launch
+	KswScoring sc;
+};
+
+// LDS bytes one wave needs for a job class (A,B,H int32 arrays + sf|qr bytes)
+__host__ __device__ inline size_t ksw_lds_per_wave(int max_T16, int max_Q16) { return (size_t)13 * max_T16 + max_Q16 + 16; }
+
+// rows * bytes-per-row of the direction matrix of one job (ksw2_extd2_sse.c:94-95,122)
+__host__ __device__ inline size_t ksw_dir_bytes(int qlen, int tlen, int w)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	long n = qlen < tlen ? qlen : tlen;
+	n = ((n < (long)w + 1 ? n : (long)w + 1) + 15) / 16 + 1;
+	return (size_t)(qlen + tlen - 1) * (size_t)n * 16;
+}
+
+// host launcher (ksw_extd2.hip); n_slots persistent waves, waves_per_block in {1,4}
+void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream /* hipStream_t */);
+
+} // namespace mm2amd

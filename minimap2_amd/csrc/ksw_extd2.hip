@@ -1,0 +1,352 @@
+// Batched dual-affine extension DP for gfx950 -- the device counterpart of the reference's
+// ksw_extd2_sse (/root/reference/ksw2_extd2_sse.c:34-401) and ksw_backtrack (ksw2.h:130-162).
+//
+// Mapping.  One wavefront owns one DP job at a time (persistent waves pull jobs from a queue head with
+// one atomic per job).  An anti-diagonal r is swept by the 64 lanes in chunks of 64 target positions t;
+// the per-position difference state (u,v,x,y | x2,y2,s) lives in LDS as two packed dwords per t, the
+// target/reversed-query bytes next to it, so a row costs 4 ds_read_b32 + 2 ds_write_b32 per cell and no
+// HBM traffic except the 1 B/cell direction byte.  No MFMA: this is int8 max/add with data-dependent
+// control, not a contraction.
+//
+// Exactness.  The reference evaluates 16-lane blocks over the block-aligned interval [st,en] around the
+// valid interval [st0,en0]; with a binding band valid cells read those out-of-range lanes (SURVEY.md
+// section 7, hard part 1).  We therefore sweep exactly [st,en], keep state bytes for all of
+// [0,16*ceil(tlen/16)), reproduce the 16-byte chunked score fill including its overshoot past en0 (and
+// past the end of s[] into the target copy, ksw2_extd2_sse.c:166-180 with the layout of :107-110), and do
+// all arithmetic mod 256 with signed 8-bit compares.  Row maxima use the reference's scan order (:326-358).
+#include <hip/hip_runtime.h>
+#include "hip_util.hpp"
+#include "ksw_dev.hpp"
+
+namespace mm2amd {
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ __forceinline__ int sx8(int v) { return (int)(int8_t)v; }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
+{
+	return (uint32_t)(a & 0xff) | (uint32_t)(b & 0xff) << 8 | (uint32_t)(c & 0xff) << 16 | (uint32_t)(d & 0xff) << 24;
+}
+
+__device__ __forceinline__ int wave_bcast_i32(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// max-reduce a 64-bit key over the wave; every lane returns the maximum
+__device__ __forceinline__ long long wave_max_i64(long long k)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		long long o = __shfl_xor(k, off, 64);
+		k = o > k ? o : k;
+	}
+	return k;
+}
+
+struct RowIv { int st0, en0, st, en; };
+
+// valid and block-aligned interval of anti-diagonal r (ksw2_extd2_sse.c:137-147); st0>en0 means "band closed"
+__device__ __forceinline__ RowIv row_interval(int r, int qlen, int tlen, int w)
+{
+	RowIv iv;
+	int st = 0, en = tlen - 1;
+	if (st < r - qlen + 1) st = r - qlen + 1;
+	if (en > r) en = r;
+	if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+	if (en > (r + w) >> 1) en = (r + w) >> 1;
+	iv.st0 = st, iv.en0 = en;
+	iv.st = st / 16 * 16, iv.en = (en + 16) / 16 * 16 - 1;
+	return iv;
+}
+
+struct EzState { int max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end; };
+
+// ksw_apply_zdrop with is_rot=1 (ksw2.h:171-187)
+__device__ __forceinline__ bool zdrop_test(EzState &ez, int H, int r, int t, int zdrop, int e)
+{
+	if (H > ez.max) {
+		ez.max = H, ez.max_t = t, ez.max_q = r - t;
+	} else if (t >= ez.max_t && r - t >= ez.max_q) {
+		int tl = t - ez.max_t, ql = (r - t) - ez.max_q, l = tl > ql ? tl - ql : ql - tl;
+		if (zdrop >= 0 && ez.max - H > zdrop + l * e) { ez.zdropped = 1; return true; }
+	}
+	return false;
+}
+
+struct CigOut { uint32_t *c; int n, cap, ovf; uint32_t last_op; };
+
+__device__ __forceinline__ void cig_push(CigOut &g, uint32_t op, int len) // ksw_push_cigar, ksw2.h:114-124
+{
+	if (g.n == 0 || op != g.last_op) {
+		if (g.n < g.cap) g.c[g.n] = (uint32_t)len << 4 | op; else g.ovf = 1;
+		++g.n, g.last_op = op;
+	} else if (g.n <= g.cap) g.c[g.n - 1] += (uint32_t)len << 4;
+}
+
+// Traceback by one lane over the direction matrix in HBM (ksw2.h:130-162, is_rot=1, min_intron_len=0).
+// off[r]/off_end[r] of the reference are st/en of row r, recomputed here instead of stored.
+__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, bool is_rev, int i0, int j0, CigOut &g)
+{
+	int i = i0, j = j0, state = 0;
+	while (i >= 0 && j >= 0) {
+		int r = i + j, force = -1, tmp;
+		RowIv iv = row_interval(r, qlen, tlen, w);
+		if (i < iv.st) force = 2;
+		if (i > iv.en) force = 1;
+		tmp = force < 0 ? dir[(size_t)r * ncol + (size_t)(i - iv.st)] : 0;
+		if (state == 0) state = tmp & 7;
+		else if (!(tmp >> (state + 2) & 1)) state = 0;
+		if (state == 0) state = tmp & 7;
+		if (force >= 0) state = force;
+		if (state == 0) cig_push(g, 0, 1), --i, --j;
+		else if (state == 1 || state == 3) cig_push(g, 2, 1), --i;
+		else cig_push(g, 1, 1), --j;
+	}
+	if (i >= 0) cig_push(g, 2, i + 1);
+	if (j >= 0) cig_push(g, 1, j + 1);
+	if (!is_rev && !g.ovf)
+		for (int k = 0; k < g.n >> 1; ++k) { uint32_t t = g.c[k]; g.c[k] = g.c[g.n - 1 - k]; g.c[g.n - 1 - k] = t; }
+}
+
+__global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+	const int slot = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
+	uint8_t *my = lds_raw + (size_t)wave_in_block * region;
+	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
+	const int m = L.sc.m;
+
+	for (;;) {
+		int jid = 0;
+		if (lane == 0) jid = atomicAdd(L.counter, 1);
+		jid = __builtin_amdgcn_readfirstlane(jid);
+		if (jid >= L.n_jobs) break;
+		const KswJob J = L.jobs[jid];
+		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag;
+		EzState ez;
+		ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+		ez.max = 0, ez.score = ez.mqe = ez.mte = KSW_NEG_INF, ez.zdropped = 0, ez.reach_end = 0;
+		CigOut g = { L.cigar_pool + J.cigar_off, 0, (int)J.cigar_cap, 0, 0xfu };
+
+		int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
+		const int qe_in = q + e; // taken before the swap (ksw2_extd2_sse.c:68 vs :78); seeds H(0,0)
+		if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
+		const int qe = q + e, qe2 = q2 + e2;
+		int min_sc = L.sc.mat[1];
+		for (int t = 1; t < m * m; ++t) min_sc = min_sc < L.sc.mat[t] ? min_sc : L.sc.mat[t];
+		const bool degenerate = m <= 1 || qlen <= 0 || tlen <= 0 || -min_sc > 2 * (q + e);
+		int w = J.w;
+		if (w < 0) w = tlen > qlen ? tlen : qlen;
+
+		if (flag & KSWJ_SKIP) ez.zdropped = 1;
+		else if (!degenerate) {
+			const bool with_cigar = !(flag & KSW_SCORE_ONLY), approx_max = flag & KSW_APPROX_MAX, right = flag & KSW_RIGHT;
+			const int sc_mch = L.sc.mat[0], sc_mis = L.sc.mat[1];
+			const int sc_N = L.sc.mat[m * m - 1] == 0 ? sx8(-e2) : L.sc.mat[m * m - 1];
+			const int T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
+			size_t ncol = qlen < tlen ? qlen : tlen;
+			ncol = (((ncol < (size_t)w + 1 ? ncol : (size_t)w + 1) + 15) / 16 + 1) * 16;
+			int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+			if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+			const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+			uint32_t *A = (uint32_t *)my;      // byte0 u, byte1 v, byte2 x, byte3 y
+			uint32_t *B = A + T16;             // byte0 x2, byte1 y2, byte2 s
+			int32_t *H = (int32_t *)(B + T16);
+			uint8_t *SFQ = (uint8_t *)(H + T16); // [0,T16): target copy; [T16, T16+Q16+16): reversed query, zero padded
+			const int nqe = sx8(-q - e), nqe2 = sx8(-q2 - e2);
+
+			// ---- per-job initialisation (ksw2_extd2_sse.c:107-128) ----
+			for (int t = lane; t < T16; t += 64) {
+				A[t] = pack4(nqe, nqe, nqe, nqe);
+				B[t] = pack4(nqe2, nqe2, 0, 0);
+				H[t] = KSW_NEG_INF;
+				uint8_t c = 0;
+				if (t < tlen) {
+					uint64_t pos = (flag & KSWJ_T_REVERSED) ? J.t_off - (uint64_t)t : J.t_off + (uint64_t)t;
+					c = (flag & KSWJ_T_PACKED) ? (uint8_t)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : L.tpool[pos];
+				}
+				SFQ[t] = c;
+			}
+			for (int i = lane; i < Q16 + 16; i += 64) {
+				uint8_t c = 0;
+				if (i < qlen) { // qr[i] = query[qlen-1-i]
+					int k = qlen - 1 - i;
+					c = L.qpool[(flag & KSWJ_Q_REVERSED) ? J.q_off - (uint64_t)k : J.q_off + (uint64_t)k];
+				}
+				SFQ[T16 + i] = c;
+			}
+			WAVE_SYNC();
+
+			int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+			const int n_rows = qlen + tlen - 1;
+			for (int r = 0; r < n_rows; ++r) {
+				const RowIv iv = row_interval(r, qlen, tlen, w);
+				const int st0 = iv.st0, en0 = iv.en0, st = iv.st, en = iv.en;
+				if (st0 > en0) { ez.zdropped = 1; break; }
+				// boundary values (:148-163)
+				const int bnd = r == 0 ? nqe : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : sx8(-e2);
+				int x1 = nqe, x21 = nqe2, v1 = st > 0 ? nqe : bnd;
+				if (st > 0 && st - 1 >= last_st && st - 1 <= last_en) {
+					uint32_t a = A[st - 1], b = B[st - 1];
+					x1 = sx8(a >> 16), v1 = sx8(a >> 8), x21 = sx8(b);
+				}
+				if (en >= r && lane == 0) {
+					A[r] = (A[r] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(nqe & 0xff) << 24; // u[r], y[r]
+					B[r] = (B[r] & 0xffff00ffu) | (uint32_t)(nqe2 & 0xff) << 8;                            // y2[r]
+				}
+				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes,
+				// and past T16 in the first bytes of the target copy exactly as in the reference's layout
+				{
+					const int qoff = T16 + (qlen - 1 - r);
+					if (!(flag & KSW_GENERIC_SC)) {
+						const int total = ((en0 - st0) / 16 + 1) * 16;
+						for (int i = lane; i < total; i += 64) {
+							const int idx = st0 + i;
+							const int a = SFQ[idx], b = SFQ[qoff + idx];
+							const int sc = (a == m - 1 || b == m - 1) ? sc_N : a == b ? sc_mch : sc_mis;
+							if (idx < T16) ((uint8_t *)&B[idx])[2] = (uint8_t)sc;
+							else SFQ[idx - T16] = (uint8_t)sc;
+						}
+					} else {
+						for (int t = st0 + lane; t <= en0; t += 64)
+							((uint8_t *)&B[t])[2] = (uint8_t)L.sc.mat[SFQ[t] * m + SFQ[qoff + t]];
+					}
+				}
+				WAVE_SYNC();
+				// one sweep over [st,en], highest chunk first so that lane t still sees row r-1 at t-1
+				uint8_t *pr = dir + (size_t)r * ncol;
+				const int n_chunk = (en - st + 64) >> 6;
+				for (int c = n_chunk - 1; c >= 0; --c) {
+					const int t = st + (c << 6) + lane;
+					if (t <= en) {
+						const uint32_t a_cur = A[t], b_cur = B[t];
+						int xt1 = x1, vt1 = v1, x2t1 = x21;
+						if (t > st) {
+							const uint32_t a_prev = A[t - 1], b_prev = B[t - 1];
+							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
+						}
+						const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), y2t = sx8(b_cur >> 8);
+						int z = sx8(b_cur >> 16);
+						int a = sx8(xt1 + vt1), b = sx8(yt + ut), a2 = sx8(x2t1 + vt1), b2 = sx8(y2t + ut), d;
+						if (!right) { // strictly greater wins (:235-243)
+							d = a > z ? 1 : 0;   z = z > a ? z : a;
+							d = b > z ? 2 : d;   z = z > b ? z : b;
+							d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
+							d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
+						} else {      // ties go to the gap state (:282-290)
+							d = z > a ? 0 : 1;   z = z > a ? z : a;
+							d = z > b ? d : 2;   z = z > b ? z : b;
+							d = z > a2 ? d : 3;  z = z > a2 ? z : a2;
+							d = z > b2 ? d : 4;  z = z > b2 ? z : b2;
+						}
+						z = z < sc_mch ? z : sc_mch;
+						const int un = z - vt1, vn = z - ut;
+						int tmp = sx8(z - q);   a = sx8(a - tmp),   b = sx8(b - tmp);
+						tmp = sx8(z - q2);      a2 = sx8(a2 - tmp), b2 = sx8(b2 - tmp);
+						int xn, yn, x2n, y2n;
+						if (!right) {
+							xn = (a > 0 ? a : 0) - qe;     d |= a > 0 ? 0x08 : 0;
+							yn = (b > 0 ? b : 0) - qe;     d |= b > 0 ? 0x10 : 0;
+							x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 > 0 ? 0x20 : 0;
+							y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 > 0 ? 0x40 : 0;
+						} else {
+							xn = (a > 0 ? a : 0) - qe;     d |= a >= 0 ? 0x08 : 0;
+							yn = (b > 0 ? b : 0) - qe;     d |= b >= 0 ? 0x10 : 0;
+							x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 >= 0 ? 0x20 : 0;
+							y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 >= 0 ? 0x40 : 0;
+						}
+						A[t] = pack4(un, vn, xn, yn);
+						B[t] = (b_cur & 0xffff0000u) | (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8;
+						if (with_cigar) pr[t - st] = (uint8_t)d;
+					}
+				}
+				WAVE_SYNC();
+				if (!approx_max) { // exact row maximum in the reference's scan order (:325-365)
+					int max_H, max_t;
+					if (r > 0) {
+						const int Hen = en0 > 0 ? H[en0 - 1] + sx8(A[en0]) : H[en0] + sx8(A[en0] >> 8);
+						const int en1 = st0 + (en0 - st0) / 4 * 4;
+						WAVE_SYNC();
+						// candidate order: en0 first, then the 4-lane strided scan of [st0,en1), then the tail [en1,en0)
+						long long best = (long long)Hen << 32 | 0x7fffffffLL;
+						const int nq = (en1 - st0) >> 2;
+						for (int t = st0 + lane; t < en0; t += 64) {
+							const int h = H[t] + sx8(A[t] >> 8);
+							H[t] = h;
+							const int k = t - st0;
+							const int rank = t < en1 ? 1 + (k & 3) * (nq + 1) + (k >> 2) : 1 + 4 * (nq + 1) + (t - en1);
+							const long long key = (long long)h << 32 | (long long)(0x7fffffff - rank);
+							best = key > best ? key : best;
+						}
+						best = wave_max_i64(best);
+						max_H = (int)(best >> 32);
+						{
+							const int rank = 0x7fffffff - (int)(best & 0x7fffffffLL);
+							if (rank == 0) max_t = en0;
+							else if (rank < 1 + 4 * (nq + 1)) { const int k = rank - 1; max_t = st0 + (k % (nq + 1)) * 4 + k / (nq + 1); }
+							else max_t = en1 + (rank - 1 - 4 * (nq + 1));
+						}
+						if (lane == 0) H[en0] = Hen;
+						WAVE_SYNC();
+					} else {
+						max_H = sx8(A[0] >> 8) - qe_in, max_t = 0;
+						if (lane == 0) H[0] = max_H;
+						WAVE_SYNC();
+					}
+					const int Hen0 = H[en0], Hst0 = H[st0];
+					if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en0;
+					if (r - st0 == qlen - 1 && Hst0 > ez.mqe) ez.mqe = Hst0, ez.mqe_t = st0;
+					if (zdrop_test(ez, max_H, r, max_t, J.zdrop, e2)) break;
+					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
+				} else { // follow one cell (:366-383)
+					if (r > 0) {
+						if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+							const int d0 = sx8(A[last_H0_t] >> 8), d1 = sx8(A[last_H0_t + 1]);
+							if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
+						} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += sx8(A[last_H0_t] >> 8);
+						else ++last_H0_t, H0 += sx8(A[last_H0_t]);
+					} else H0 = sx8(A[0] >> 8) - qe_in, last_H0_t = 0;
+					if ((flag & KSW_APPROX_DROP) && zdrop_test(ez, H0, r, last_H0_t, J.zdrop, e2)) break;
+					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+				}
+				last_st = st, last_en = en;
+			}
+			// ---- traceback (:385-399) ----
+			if (with_cigar) {
+				__threadfence_block(); // the direction bytes were written by all lanes of this wave
+				const bool rev = flag & KSW_REV_CIGAR;
+				if (lane == 0) {
+					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, rev, tlen - 1, qlen - 1, g);
+					else if (!ez.zdropped && (flag & KSW_EXTZ_ONLY) && ez.mqe + J.end_bonus > ez.max) {
+						ez.reach_end = 1;
+						traceback(dir, ncol, qlen, tlen, w, rev, ez.mqe_t, qlen - 1, g);
+					} else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, rev, ez.max_t, ez.max_q, g);
+				}
+			}
+			WAVE_SYNC();
+		}
+		if (lane == 0) {
+			KswRes R;
+			R.max = ez.max, R.zdropped = ez.zdropped, R.max_q = ez.max_q, R.max_t = ez.max_t;
+			R.mqe = ez.mqe, R.mqe_t = ez.mqe_t, R.mte = ez.mte, R.mte_q = ez.mte_q;
+			R.score = ez.score, R.n_cigar = g.n, R.reach_end = ez.reach_end, R.cigar_overflow = g.ovf;
+			L.res[jid] = R;
+		}
+	}
+}
+
+void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream)
+{
+	if (L.n_jobs <= 0) return;
+	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
+	const size_t lds = region * waves_per_block;
+	if (lds > 160 * 1024) throw std::runtime_error("[mm2amd] ksw_extd2: job class does not fit LDS");
+	if (lds > 64 * 1024)
+		HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
+	hipLaunchKernelGGL(ksw_extd2_kernel, dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
+	HIP_CHECK(hipGetLastError());
+}
+
+} // namespace mm2amd

@@ -1,0 +1,28 @@
+// Host-side driver of the batched extension-DP kernels: tiers jobs by LDS footprint, orders them by cost,
+// sizes the direction-matrix scratch and launches persistent waves.
+#pragma once
+#include <vector>
+#include "hip_util.hpp"
+#include "ksw_dev.hpp"
+
+namespace mm2amd {
+
+struct KswRunner {
+	DevBuf<KswJob> d_jobs;
+	DevBuf<KswRes> d_res;
+	DevBuf<uint32_t> d_cigar;
+	DevBuf<uint8_t> d_dir;
+	DevBuf<int32_t> d_counter;
+	std::vector<KswJob> sorted;
+	std::vector<uint32_t> perm;
+	std::vector<KswRes> tmp_res;
+	size_t dir_budget = (size_t)12 << 30; // bytes of HBM we allow for direction matrices
+	int n_cu = 256;
+
+	// jobs[i].cigar_off/cigar_cap must be set; pools are device pointers.  Results land in res[i] (input order),
+	// CIGARs in cigar_out (host, cigar_total entries, same offsets as the jobs').
+	void run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
+	         const KswScoring &sc, KswRes *res, uint32_t *cigar_out, size_t cigar_total, hipStream_t stream);
+};
+
+} // namespace mm2amd

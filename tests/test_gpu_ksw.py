@@ -1,0 +1,85 @@
+"""HIP ksw_extd2 (through the C ABI) against the oracle restatement and, when present, the compiled reference."""
+import os
+import numpy as np
+import pytest
+
+import reflib
+from reflib import ora_extd2, ts_mat
+from seqsim import random_pair
+
+pytestmark = pytest.mark.gpu
+
+PRESETS = {"ont": (2, 4, 4, 2, 24, 1), "hifi": (1, 4, 6, 2, 26, 1), "swap": (2, 4, 24, 1, 4, 2), "asm5": (1, 19, 39, 3, 81, 1)}
+
+
+def _run(jobs, preset, transition=0):
+    import minimap2_amd as mm
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    mat = ts_mat(a, b, 1, transition)
+    got = mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+    have_ref = os.path.exists(reflib.REF_SO)
+    for k, (q, t, w, zdrop, eb, flag) in enumerate(jobs):
+        want = ora_extd2(q, t, mat, go, ge, go2, ge2, w, zdrop, eb, flag)
+        assert got[k] == want, ("oracle", k, len(q), len(t), w, zdrop, eb, hex(flag), preset)
+        if have_ref and k % 7 == 0:
+            assert got[k] == reflib.ref_extd2(q, t, mat, go, ge, go2, ge2, w, zdrop, eb, flag), ("reference", k)
+
+
+@pytest.mark.parametrize("preset", list(PRESETS))
+def test_unbanded_all_flags(preset):
+    rng = np.random.default_rng(42)
+    jobs = []
+    for it in range(400):
+        q, t = random_pair(rng, int(rng.integers(1, 500)), float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.02])))
+        jobs.append((q, t, 30001, int(rng.choice([-1, 200, 400])), int(rng.choice([-1, 10])), int(rng.choice([0x08, 0x00, 0x40, 0xC2, 0x41]))))
+    _run(jobs, preset)
+
+
+def test_generic_scoring_matrix():
+    rng = np.random.default_rng(5)
+    jobs = []
+    for it in range(100):
+        q, t = random_pair(rng, int(rng.integers(1, 300)), 0.1, 0.02)
+        jobs.append((q, t, 30001, 400, 10, int(rng.choice([0x0C, 0x04, 0x44, 0xC6]))))
+    _run(jobs, "ont", transition=3)
+
+
+def test_band_binding_lane_exact():
+    rng = np.random.default_rng(9)
+    jobs = []
+    for it in range(400):
+        q, t = random_pair(rng, int(rng.integers(20, 900)), float(rng.choice([0.02, 0.12])), 0.0, int(rng.choice([0, 0, 30, -30, 150, -150])))
+        jobs.append((q, t, int(rng.integers(1, 120)), int(rng.choice([-1, 100, 400])), int(rng.choice([-1, 10])), int(rng.choice([0x40, 0xC2, 0x00, 0x08]))))
+    _run(jobs, "ont")
+
+
+def test_multiple_of_16_targets():
+    rng = np.random.default_rng(7)
+    jobs = []
+    for tl in (16, 32, 48, 64, 256, 512):
+        for it in range(10):
+            t = rng.integers(0, 4, tl, dtype=np.uint8)
+            q = rng.integers(0, 4, int(rng.integers(1, min(2 * tl, 512))), dtype=np.uint8)
+            for flag in (0x08, 0x40, 0xC2, 0):
+                for w in (5, 751, 30001):
+                    jobs.append((q, t, w, 400, 10, flag))
+    _run(jobs, "ont")
+
+
+def test_long_extensions_band_751():
+    rng = np.random.default_rng(11)
+    jobs = []
+    for it in range(12):
+        q, t = random_pair(rng, int(rng.integers(1500, 5000)), 0.12, 0.0, int(rng.choice([0, 700, -700, 900])))
+        jobs.append((q, t, 751, 400, 10, [0x40, 0xC2][it & 1]))
+    _run(jobs, "ont")
+
+
+def test_degenerate_jobs():
+    z = np.zeros(0, dtype=np.uint8)
+    one = np.array([1], dtype=np.uint8)
+    jobs = [(one, one, 751, 400, 10, 0x40), (one, np.array([2], dtype=np.uint8), 30001, 400, -1, 0x08), (one, one, 0, 400, -1, 0)]
+    _run(jobs, "ont")
+    import minimap2_amd as mm
+    got = mm.ksw_extd2_batch([(z, one, 10, 400, -1, 0)], ts_mat(2, 4), 4, 2, 24, 1)
+    assert got[0][0] == 0 and got[0][10] == ()
