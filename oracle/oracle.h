@@ -51,6 +51,26 @@ void ora_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
                    int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag,
                    ora_ez_t *ez, uint32_t *cigar, int cigar_cap);
 
+/* mm_sketch, sketch.c:77-143 (non-HPC and HPC).  Appends to out[*n_out..cap); returns the number of
+ * minimizers the sequence has (which may exceed cap - then only the first cap were stored). */
+int64_t ora_sketch(const char *seq, int len, int w, int k, uint32_t rid, int is_hpc, ora128_t *out, int64_t cap);
+
+/* radix_sort_128x / radix_sort_64, ksort.h:101-151 + misc.c:155-159: in-place UNSTABLE MSD radix sort with
+ * insertion sort below 65 elements; the permutation of equal keys is reproduced exactly. */
+void ora_radix_sort_128x(ora128_t *beg, ora128_t *end);
+void ora_radix_sort_64(uint64_t *beg, uint64_t *end);
+
+/* mg_lchain_dp fill only, lchain.c:169-207: f,p,v for sorted anchors a[0..n) (t is scratch, zeroed here). */
+void ora_lchain_fill(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, float chn_pen_gap, float chn_pen_skip,
+                     int is_cdna, int n_seg, int64_t n, const ora128_t *a, int32_t *f, int64_t *p, int32_t *v, int32_t *t);
+
+/* mg_lchain_dp, lchain.c:148-217 (fill + mg_chain_backtrack :27-76 + compact_a :78-111).
+ * a[] is overwritten with the compacted anchors; u_out (capacity n) receives score<<32|cnt per chain.
+ * Returns n_u; *n_a_out = number of anchors kept. */
+int ora_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc,
+                  float chn_pen_gap, float chn_pen_skip, int is_cdna, int n_seg, int64_t n, ora128_t *a,
+                  uint64_t *u_out, int64_t *n_a_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,101 @@ def ts_mat(a, b, sc_ambi=1, transition=0):
         tr = -abs(transition)
         m[0, 2] = m[1, 3] = m[2, 0] = m[3, 1] = tr
     return m.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# sketch / sort / chaining bindings
+# ---------------------------------------------------------------------------------------------------------
+import numpy as np
+
+
+class MM128V(C.Structure):  # mm128_v, minimap.h:78
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+_libc = C.CDLL(None)
+_libc.malloc.restype = C.c_void_p
+_libc.malloc.argtypes = [C.c_size_t]
+_libc.free.argtypes = [C.c_void_p]
+
+
+def ref_sketch(seq, w, k, rid=0, is_hpc=0):
+    """mm_sketch of an ASCII sequence -> uint64 array of shape (n, 2)"""
+    R = ref()
+    R.mm_sketch.restype = None
+    R.mm_sketch.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(MM128V)]
+    v = MM128V(0, 0, None)
+    R.mm_sketch(None, seq, len(seq), w, k, rid, is_hpc, C.byref(v))
+    out = np.ctypeslib.as_array(C.cast(v.a, C.POINTER(C.c_uint64)), shape=(v.n, 2)).copy() if v.n else np.zeros((0, 2), np.uint64)
+    if v.a:
+        _libc.free(v.a)
+    return out
+
+
+def ora_sketch(seq, w, k, rid=0, is_hpc=0):
+    O = ora()
+    O.ora_sketch.restype = C.c_int64
+    O.ora_sketch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int64]
+    cap = len(seq) + 1
+    buf = np.zeros((cap, 2), np.uint64)
+    n = O.ora_sketch(seq, len(seq), w, k, rid, is_hpc, buf.ctypes.data, cap)
+    assert n <= cap
+    return buf[:n].copy()
+
+
+def _sorter(libf, name):
+    f = getattr(libf(), name)
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p]
+
+    def run(arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).copy()
+        f(a.ctypes.data, a.ctypes.data + a.nbytes)
+        return a
+    return run
+
+
+def ref_sort128(arr): return _sorter(ref, "radix_sort_128x")(arr)
+def ora_sort128(arr): return _sorter(ora, "ora_radix_sort_128x")(arr)
+def ref_sort64(arr): return _sorter(ref, "radix_sort_64")(arr)
+def ora_sort64(arr): return _sorter(ora, "ora_radix_sort_64")(arr)
+
+
+CHAIN_ARGS = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int64]
+
+
+def ref_lchain_dp(a, max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, pen_gap, pen_skip, is_cdna, n_seg):
+    """mg_lchain_dp -> (u array, compacted anchors (n,2))"""
+    R = ref()
+    R.mg_lchain_dp.restype = C.c_void_p
+    R.mg_lchain_dp.argtypes = CHAIN_ARGS + [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p]
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    n = a.shape[0]
+    if n == 0:
+        return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+    mem = _libc.malloc(a.nbytes)
+    C.memmove(mem, a.ctypes.data, a.nbytes)
+    n_u = C.c_int(0)
+    u = C.c_void_p()
+    b = R.mg_lchain_dp(max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, pen_gap, pen_skip, is_cdna, n_seg, n, mem,
+                       C.byref(n_u), C.byref(u), None)
+    if n_u.value == 0:
+        return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+    uu = np.ctypeslib.as_array(C.cast(u, C.POINTER(C.c_uint64)), shape=(n_u.value,)).copy()
+    na = int((uu & np.uint64(0xffffffff)).sum())
+    bb = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(na, 2)).copy()
+    _libc.free(u); _libc.free(b)
+    return uu, bb
+
+
+def ora_lchain_dp(a, max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, pen_gap, pen_skip, is_cdna, n_seg):
+    O = ora()
+    O.ora_lchain_dp.restype = C.c_int
+    O.ora_lchain_dp.argtypes = CHAIN_ARGS + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    n = a.shape[0]
+    u = np.zeros(max(n, 1), np.uint64)
+    na = C.c_int64(0)
+    n_u = O.ora_lchain_dp(max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, pen_gap, pen_skip, is_cdna, n_seg, n,
+                          a.ctypes.data, u.ctypes.data, C.byref(na))
+    return u[:n_u].copy(), a[:na.value].copy()

@@ -8,7 +8,7 @@ import minimap2_amd as mm
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = np.random.default_rng(1)
-base = [random_pair(rng, int(rng.normal(235, 40).clip(50, 480)), 0.12) for _ in range(500)]
+base = [random_pair(rng, int(np.clip(rng.normal(235, 40), 50, 480)), 0.12) for _ in range(500)]
 jobs = [(base[i % 500][0], base[i % 500][1], 30001, 400, -1, 0x08) for i in range(n)]
 cells = sum(len(q) * len(t) for q, t, *_ in jobs)
 mat = ts_mat(2, 4)
