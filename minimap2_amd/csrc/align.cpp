@@ -1,0 +1,778 @@
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include "align.hpp"
+#include "chain_host.hpp"
+
+namespace mm2amd {
+
+using namespace ref;
+
+extern const uint8_t kNt4Table[256];
+
+namespace {
+inline int span_of(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
+inline uint32_t roundup32(uint32_t x) { --x; x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16; return ++x; }
+constexpr uint32_t kExtraWords = sizeof(Extra) / 4; // 7
+}
+
+void gen_score_matrix(const MapOpt &opt, int8_t mat[25])
+{
+	int8_t a = (int8_t)opt.a, b = (int8_t)opt.b, amb = (int8_t)opt.sc_ambi, ts = (int8_t)opt.transition;
+	a = a < 0 ? -a : a, b = b > 0 ? -b : b, amb = amb > 0 ? -amb : amb;
+	for (int i = 0; i < 4; ++i) {
+		for (int j = 0; j < 4; ++j) mat[i * 5 + j] = i == j ? a : b;
+		mat[i * 5 + 4] = amb;
+	}
+	for (int j = 0; j < 5; ++j) mat[20 + j] = amb;
+	if (ts == 0 || ts == b) return; // NB: compared with the negated b, as in the reference (align.c:30)
+	ts = ts > 0 ? -ts : ts;
+	mat[0 * 5 + 2] = mat[1 * 5 + 3] = mat[2 * 5 + 0] = mat[3 * 5 + 1] = ts;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CIGAR container (mm_extra_t) handling; storage comes from libc because the caller frees it (map.c:629-630)
+// ---------------------------------------------------------------------------------------------------------
+static void enlarge_cigar(Reg &r, uint32_t n_cigar) // align.c:305-318
+{
+	if (n_cigar == 0) return;
+	if (r.p == nullptr) {
+		uint32_t cap = roundup32(n_cigar + kExtraWords);
+		r.p = (Extra *)calloc(cap, 4);
+		r.p->capacity = cap;
+	} else if (r.p->n_cigar + n_cigar + kExtraWords > r.p->capacity) {
+		r.p->capacity = roundup32(r.p->n_cigar + n_cigar + kExtraWords);
+		r.p = (Extra *)realloc(r.p, (size_t)r.p->capacity * 4);
+	}
+}
+
+void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar) // align.c:320-334
+{
+	if (n_cigar == 0) return;
+	enlarge_cigar(r, n_cigar);
+	Extra *p = r.p;
+	if (p->n_cigar > 0 && (p->cigar[p->n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
+		p->cigar[p->n_cigar - 1] += cigar[0] >> 4 << 4;
+		if (n_cigar > 1) memcpy(p->cigar + p->n_cigar, cigar + 1, (n_cigar - 1) * 4);
+		p->n_cigar += n_cigar - 1;
+	} else {
+		memcpy(p->cigar + p->n_cigar, cigar, n_cigar * 4);
+		p->n_cigar += n_cigar;
+	}
+}
+
+// left-align indels, merge I/D clusters, drop empty ops and a leading gap (mm_fix_cigar, align.c:105-181)
+static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
+{
+	Extra *p = r.p;
+	int32_t toff = 0, qoff = 0;
+	bool shrink = false;
+	*qshift = *tshift = 0;
+	if (p->n_cigar <= 1) return;
+	for (uint32_t k = 0; k < p->n_cigar; ++k) {
+		const uint32_t op = p->cigar[k] & 0xf, len = p->cigar[k] >> 4;
+		if (len == 0) shrink = true;
+		if (op == 0) toff += len, qoff += len;
+		else if (op == 1 || op == 2) {
+			if (k > 0 && k < p->n_cigar - 1 && (p->cigar[k - 1] & 0xf) == 0 && (p->cigar[k + 1] & 0xf) == 0) {
+				int l;
+				const int prev_len = p->cigar[k - 1] >> 4;
+				if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
+				else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
+				if (l > 0) p->cigar[k - 1] -= l << 4, p->cigar[k + 1] += l << 4, qoff -= l, toff -= l;
+				if (l == prev_len) shrink = true;
+			}
+			if (op == 1) qoff += len; else toff += len;
+		} else if (op == 3) toff += len;
+	}
+	assert(qoff == r.qe - r.qs && toff == r.re - r.rs);
+	for (uint32_t k = 0; k + 2 < p->n_cigar; ++k) { // runs like 5I6D7I become one I and one D
+		if ((p->cigar[k] & 0xf) > 0 && (p->cigar[k] & 0xf) + (p->cigar[k + 1] & 0xf) == 3) {
+			uint32_t l, s[3] = {0, 0, 0};
+			for (l = k; l < p->n_cigar; ++l) {
+				const uint32_t op = p->cigar[l] & 0xf;
+				if (op == 1 || op == 2 || p->cigar[l] >> 4 == 0) s[op] += p->cigar[l] >> 4;
+				else break;
+			}
+			if (s[1] > 0 && s[2] > 0 && l - k > 2) {
+				p->cigar[k] = s[1] << 4 | 1;
+				p->cigar[k + 1] = s[2] << 4 | 2;
+				for (k += 2; k < l; ++k) p->cigar[k] &= 0xf;
+				shrink = true;
+			}
+			k = l;
+		}
+	}
+	if (shrink) {
+		uint32_t l = 0;
+		for (uint32_t k = 0; k < p->n_cigar; ++k)
+			if (p->cigar[k] >> 4 != 0) p->cigar[l++] = p->cigar[k];
+		p->n_cigar = l;
+		l = 0;
+		for (uint32_t k = 0; k < p->n_cigar; ++k)
+			if (k == p->n_cigar - 1 || (p->cigar[k] & 0xf) != (p->cigar[k + 1] & 0xf)) p->cigar[l++] = p->cigar[k];
+			else p->cigar[k + 1] += p->cigar[k] >> 4 << 4;
+		p->n_cigar = l;
+	}
+	if ((p->cigar[0] & 0xf) == 1 || (p->cigar[0] & 0xf) == 2) { // an alignment never starts with a gap
+		const int32_t l = p->cigar[0] >> 4;
+		if ((p->cigar[0] & 0xf) == 1) {
+			if (r.rev) r.qe -= l; else r.qs += l;
+			*qshift = l;
+		} else r.rs += l, *tshift = l;
+		--p->n_cigar;
+		memmove(p->cigar, p->cigar + 1, p->n_cigar * 4);
+	}
+}
+
+static void cigar_to_eqx(Reg &r, const uint8_t *qseq, const uint8_t *tseq) // mm_update_cigar_eqx, align.c:183-252
+{
+	if (!r.p) return;
+	uint32_t n_eqx = 0, n_m = 0, toff = 0, qoff = 0;
+	for (uint32_t k = 0; k < r.p->n_cigar; ++k) {
+		uint32_t op = r.p->cigar[k] & 0xf, len = r.p->cigar[k] >> 4, l;
+		if (op == 0) {
+			while (len > 0) {
+				for (l = 0; l < len && qseq[qoff + l] == tseq[toff + l]; ++l) {}
+				if (l > 0) { ++n_eqx; len -= l; toff += l; qoff += l; }
+				for (l = 0; l < len && qseq[qoff + l] != tseq[toff + l]; ++l) {}
+				if (l > 0) { ++n_eqx; len -= l; toff += l; qoff += l; }
+			}
+			++n_m;
+		} else if (op == 1) qoff += len;
+		else if (op == 2 || op == 3) toff += len;
+	}
+	if (n_eqx == n_m) {
+		for (uint32_t k = 0; k < r.p->n_cigar; ++k)
+			if ((r.p->cigar[k] & 0xf) == 0) r.p->cigar[k] = (r.p->cigar[k] >> 4) << 4 | 7;
+		return;
+	}
+	uint32_t cap = roundup32(r.p->n_cigar + (n_eqx - n_m) + (uint32_t)sizeof(Extra));
+	Extra *p = (Extra *)calloc(cap, 4);
+	memcpy(p, r.p, sizeof(Extra));
+	p->capacity = cap;
+	uint32_t m = 0;
+	toff = qoff = 0;
+	for (uint32_t k = 0; k < r.p->n_cigar; ++k) {
+		uint32_t op = r.p->cigar[k] & 0xf, len = r.p->cigar[k] >> 4, l;
+		if (op == 0) {
+			while (len > 0) {
+				for (l = 0; l < len && qseq[qoff + l] == tseq[toff + l]; ++l) {}
+				if (l > 0) p->cigar[m++] = l << 4 | 7;
+				len -= l, toff += l, qoff += l;
+				for (l = 0; l < len && qseq[qoff + l] != tseq[toff + l]; ++l) {}
+				if (l > 0) p->cigar[m++] = l << 4 | 8;
+				len -= l, toff += l, qoff += l;
+			}
+			continue;
+		} else if (op == 1) qoff += len;
+		else if (op == 2 || op == 3) toff += len;
+		p->cigar[m++] = r.p->cigar[k];
+	}
+	p->n_cigar = m;
+	free(r.p);
+	r.p = p;
+}
+
+void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, bool is_eqx, bool log_gap)
+{
+	Extra *p = r.p;
+	if (!p) return;
+	int qshift, tshift;
+	int32_t toff = 0, qoff = 0;
+	double s = 0.0, max = 0.0;
+	fix_cigar(r, qseq, tseq, &qshift, &tshift);
+	qseq += qshift, tseq += tshift;
+	r.blen = r.mlen = 0, r.is_spliced = 0;
+	for (uint32_t k = 0; k < p->n_cigar; ++k) {
+		const uint32_t op = p->cigar[k] & 0xf, len = p->cigar[k] >> 4;
+		if (op == 0) {
+			int n_ambi = 0, n_diff = 0;
+			for (uint32_t l = 0; l < len; ++l) {
+				const int cq = qseq[qoff + l], ct = tseq[toff + l];
+				if (ct > 3 || cq > 3) ++n_ambi;
+				else if (ct != cq) ++n_diff;
+				s += mat[ct * 5 + cq];
+				if (s < 0) s = 0;
+				else max = max > s ? max : s;
+			}
+			r.blen += len - n_ambi, r.mlen += len - (n_ambi + n_diff), p->n_ambi += n_ambi;
+			toff += len, qoff += len;
+		} else if (op == 1 || op == 2) {
+			int n_ambi = 0;
+			const uint8_t *sq = op == 1 ? qseq + qoff : tseq + toff;
+			for (uint32_t l = 0; l < len; ++l) if (sq[l] > 3) ++n_ambi;
+			r.blen += len - n_ambi, p->n_ambi += n_ambi;
+			if (log_gap) s -= q + (double)e * fast_log2(1.0 + len);
+			else s -= q + e;
+			if (s < 0) s = 0;
+			if (op == 1) qoff += len; else toff += len;
+		} else if (op == 3) r.is_spliced = 1, toff += len;
+	}
+	p->dp_max = p->dp_max0 = (int32_t)(max + .499);
+	assert(qoff == r.qe - r.qs && toff == r.re - r.rs);
+	if (is_eqx) cigar_to_eqx(r, qseq, tseq);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Z-drop / inversion test on a finished gap-fill alignment (mm_test_zdrop, align.c:61-103)
+// ---------------------------------------------------------------------------------------------------------
+int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat)
+{
+	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+	int pos[2][2] = {{-1, -1}, {-1, -1}};
+	auto track = [&](int32_t sc, int ci, int cj) { // update_max_zdrop, align.c:46-59
+		if (sc < max) {
+			const int li = ci - max_i, lj = cj - max_j, diff = li > lj ? li - lj : lj - li, z = max - sc - diff * opt.e;
+			if (z > max_zdrop) max_zdrop = z, pos[0][0] = max_i, pos[0][1] = ci, pos[1][0] = max_j, pos[1][1] = cj;
+		} else max = sc, max_i = ci, max_j = cj;
+	};
+	for (uint32_t k = 0; k < n_cigar; ++k) {
+		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (op == 0) {
+			for (uint32_t l = 0; l < len; ++l) {
+				score += mat[tseq[i + l] * 5 + qseq[j + l]];
+				track(score, i + l, j + l);
+			}
+			i += len, j += len;
+		} else if (op == 1 || op == 2 || op == 3) {
+			score -= opt.q + opt.e * len;
+			if (op == 1) j += len; else i += len;
+			track(score, i, j);
+		}
+	}
+	const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
+	if (!(opt.flag & (F_SPLICE | F_SR | F_FOR_ONLY | F_REV_ONLY)) && max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap) {
+		std::vector<uint8_t> rc(q_len > 0 ? q_len : 0); // reverse complement of the dropped query segment
+		for (int x = 0; x < q_len; ++x) { const int c = qseq[pos[1][1] - x - 1]; rc[x] = c >= 4 ? 4 : 3 - c; }
+		int q_off, t_off;
+		const int sc = ll_local_score(q_len, rc.data(), t_len, tseq + pos[0][0], mat, opt.q, opt.e, &q_off, &t_off);
+		if (sc >= opt.min_chain_score * opt.a && sc >= opt.min_dp_max) return 2;
+	}
+	return max_zdrop > opt.zdrop ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Seed clean-up before window selection (align.c:435-561)
+// ---------------------------------------------------------------------------------------------------------
+static inline int gap_at(const Anchor *a, int i) // query advance minus target advance between anchors i-1 and i
+{
+	return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - (int32_t)(a[i].x - a[i - 1].x);
+}
+
+static void long_gap_sites(int as1, int cnt1, const Anchor *a, int min_gap, std::vector<int> &K) // collect_long_gaps, align.c:435-452
+{
+	K.clear();
+	int n = 0;
+	for (int i = 1; i < cnt1; ++i) { const int g = gap_at(a + as1, i); if (g < -min_gap || g > min_gap) ++n; }
+	if (n <= 1) return;
+	for (int i = 1; i < cnt1; ++i) { const int g = gap_at(a + as1, i); if (g < -min_gap || g > min_gap) K.push_back(i); }
+}
+
+static void drop_compensating_gap_seeds(int as1, int cnt1, Anchor *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) // mm_filter_bad_seeds, align.c:454-489
+{
+	std::vector<int> K;
+	long_gap_sites(as1, cnt1, a, min_gap, K);
+	const int n = (int)K.size();
+	if (n == 0) return;
+	int max = 0, max_st = -1, max_en = -1;
+	for (int k = 0;; ++k) {
+		if (k == n || k >= max_en) {
+			if (max_en > 0)
+				for (int i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= SEED_IGNORE;
+			max = 0, max_st = max_en = -1;
+			if (k == n) break;
+		}
+		const int i = K[k];
+		int gap = gap_at(a + as1, i), n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1;
+		if (gap > 0) n_ins += gap; else n_del += -gap;
+		const int qs = (int32_t)a[as1 + i - 1].y, rs = (int32_t)a[as1 + i - 1].x;
+		for (int l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+			const int j = K[l];
+			if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
+			gap = gap_at(a + as1, j);
+			if (gap > 0) n_ins += gap; else n_del += -gap;
+			const int diff = n_ins + n_del - abs(n_ins - n_del);
+			if (max_diff < diff) max_diff = diff, max_diff_l = l;
+		}
+		if (max_diff > diff_thres && max_diff > max) max = max_diff, max_st = k, max_en = max_diff_l;
+	}
+}
+
+static void join_over_gap_clusters(int as1, int cnt1, Anchor *a, int min_gap, int max_ext) // mm_filter_bad_seeds_alt, align.c:491-525
+{
+	std::vector<int> K;
+	long_gap_sites(as1, cnt1, a, min_gap, K);
+	const int n = (int)K.size();
+	for (int k = 0; k < n;) {
+		const int i = K[k];
+		int l, gap1 = gap_at(a + as1, i);
+		int re1 = (int32_t)a[as1 + i].x, qe1 = (int32_t)a[as1 + i].y;
+		gap1 = gap1 > 0 ? gap1 : -gap1;
+		for (l = k + 1; l < n; ++l) {
+			const int j = K[l];
+			if ((int32_t)a[as1 + j].y - qe1 > max_ext || (int32_t)a[as1 + j].x - re1 > max_ext) break;
+			int gap2 = gap_at(a + as1, j);
+			const int span_pre = span_of(a[as1 + j - 1]);
+			const int rs2 = (int32_t)a[as1 + j - 1].x + span_pre, qs2 = (int32_t)a[as1 + j - 1].y + span_pre;
+			const int m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+			gap2 = gap2 > 0 ? gap2 : -gap2;
+			if (m > gap1 + gap2) break;
+			re1 = (int32_t)a[as1 + j].x, qe1 = (int32_t)a[as1 + j].y;
+			gap1 = gap2;
+		}
+		if (l > k + 1) {
+			const int end = K[l - 1];
+			for (int j = K[k]; j < end; ++j) a[as1 + j].y |= SEED_IGNORE;
+			a[as1 + end].y |= SEED_LONG_JOIN;
+		}
+		k = l;
+	}
+}
+
+static void trim_bad_ends(const Reg &r, const Anchor *a, int bw, int min_match, int32_t *as, int32_t *cnt) // mm_fix_bad_ends, align.c:527-561
+{
+	*as = r.as, *cnt = r.cnt;
+	if (r.cnt < 3) return;
+	int32_t m, l;
+	m = l = span_of(a[r.as]);
+	for (int32_t i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
+		const int32_t q_span = span_of(a[i]);
+		if (a[i].y & SEED_LONG_JOIN) break;
+		const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+		if (mx - mn > l >> 1) *as = i;
+		l += mn;
+		m += mn < q_span ? mn : q_span;
+		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+	}
+	*cnt = r.as + r.cnt - *as;
+	m = l = span_of(a[r.as + r.cnt - 1]);
+	for (int32_t i = r.as + r.cnt - 2; i > *as; --i) {
+		const int32_t q_span = span_of(a[i + 1]);
+		if (a[i + 1].y & SEED_LONG_JOIN) break;
+		const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+		if (mx - mn > l >> 1) *cnt = i + 1 - *as;
+		l += mn;
+		m += mn < q_span ? mn : q_span;
+		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Aligner
+// ---------------------------------------------------------------------------------------------------------
+Aligner::Aligner(const MapOpt &opt, const FlatIndex &fi) : opt_(opt), fi_(fi)
+{
+	gen_score_matrix(opt, mat_);
+	bw_ = (int)(opt.bw * 1.5 + 1.);
+	bw_long_ = (int)(opt.bw_long * 1.5 + 1.);
+	if (bw_long_ < bw_) bw_long_ = bw_;
+}
+
+void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, std::vector<Anchor> &a, uint64_t qpool_off)
+{
+	ra.qlen = qlen, ra.qpool_off = qpool_off, ra.a = &a;
+	ra.q4.resize((size_t)qlen * 2);
+	for (int i = 0; i < qlen; ++i) {
+		const uint8_t c = kNt4Table[(uint8_t)seq[i]];
+		ra.q4[i] = c;
+		ra.q4[2 * (size_t)qlen - 1 - i] = c < 4 ? 3 - c : 4;
+	}
+	ra.n_a = squeeze_anchors(regs, a.data());
+	ra.tasks.clear(); ra.order.clear();
+	ra.tasks.resize(regs.size());
+	for (size_t i = 0; i < regs.size(); ++i) {
+		ra.tasks[i] = RegionTask();
+		ra.tasks[i].r = regs[i];
+		ra.order.push_back((int)i);
+	}
+}
+
+// where an anchor's window boundary sits: the middle of the k-mer, or for HPC indices the start of the
+// homopolymer run holding the anchor's last base (mm_adjust_minier, align.c:418-433)
+static void anchor_boundary(const FlatIndex &fi, const uint8_t *q4, int qlen, const Anchor &a, int32_t *r, int32_t *q)
+{
+	if (fi.flag & I_HPC) {
+		const uint8_t *qseq = q4 + (size_t)(a.x >> 63) * qlen;
+		int i, c;
+		*q = (int32_t)a.y;
+		for (i = *q - 1, c = qseq[*q]; i > 0; --i) if (qseq[i] != c) break;
+		*q = i + 1;
+		const uint32_t rid = (uint32_t)(a.x << 1 >> 33);
+		const int64_t x = (int32_t)a.x;
+		const int cb = fi.base(rid, (uint32_t)x);
+		int64_t j;
+		for (j = x - 1; j >= 0; --j) if (fi.base(rid, (uint32_t)j) != cb) break;
+		*r = (int32_t)a.x + 1 - (int)(x - j);
+	} else {
+		*r = (int32_t)a.x - (fi.k >> 1);
+		*q = (int32_t)a.y - (fi.k >> 1);
+	}
+}
+
+void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
+{
+	Reg &r = t.r;
+	Anchor *a = ra.a->data();
+	const int qlen = ra.qlen;
+	t.planned = true;
+	t.r2.cnt = 0;
+	if (r.cnt == 0) { t.done = true; return; }
+	if (opt_.flag & (F_SR | F_SPLICE | F_QSTRAND)) throw std::runtime_error("[mm2amd] sr/splice/qstrand alignment is not supported by this build");
+	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+	const int32_t ref_len = (int32_t)fi_.seq_len[rid];
+	t.rid = rid, t.rev = rev;
+	int32_t as1, cnt1, rs, qs, re, qe, rs0, qs0, re0, qe0, rs1, qs1, re1, qe1, l;
+
+	if (!(opt_.flag & F_NO_END_FLT)) trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
+	else as1 = r.as, cnt1 = r.cnt;
+	drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
+	join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
+	anchor_boundary(fi_, ra.q4.data(), qlen, a[as1], &rs, &qs);
+	anchor_boundary(fi_, ra.q4.data(), qlen, a[as1 + cnt1 - 1], &re, &qe);
+	assert(cnt1 > 0);
+
+	// how far the two extensions may reach (align.c:695-767)
+	rs0 = (int32_t)a[r.as].x + 1 - span_of(a[r.as]);
+	qs0 = (int32_t)a[r.as].y + 1 - span_of(a[r.as]);
+	if (rs0 < 0) rs0 = 0;
+	assert(qs0 >= 0);
+	rs1 = qs1 = 0;
+	l = 0;
+	for (int32_t i = r.as - 1; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) { // earlier seeds on the same target/strand bound the extension
+		const int32_t x = (int32_t)a[i].x + 1 - span_of(a[i]), y = (int32_t)a[i].y + 1 - span_of(a[i]);
+		if (x < rs0 && y < qs0) {
+			if (++l > opt_.min_cnt) {
+				l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+				rs1 = rs0 - l, qs1 = qs0 - l;
+				if (rs1 < 0) rs1 = 0;
+				break;
+			}
+		}
+	}
+	if (qs > 0 && rs > 0) {
+		l = qs < opt_.max_gap ? qs : opt_.max_gap;
+		qs1 = qs1 > qs - l ? qs1 : qs - l;
+		qs0 = qs0 < qs1 ? qs0 : qs1;
+		l += l * opt_.a > opt_.q ? (l * opt_.a - opt_.q) / opt_.e : 0;
+		l = l < opt_.max_gap ? l : opt_.max_gap;
+		l = l < rs ? l : rs;
+		rs1 = rs1 > rs - l ? rs1 : rs - l;
+		rs0 = rs0 < rs1 ? rs0 : rs1;
+		rs0 = rs0 < rs ? rs0 : rs;
+	} else rs0 = rs, qs0 = qs;
+	re0 = (int32_t)a[r.as + r.cnt - 1].x + 1;
+	qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+	re1 = ref_len, qe1 = qlen;
+	l = 0;
+	for (int32_t i = r.as + r.cnt; i < ra.n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
+		const int32_t x = (int32_t)a[i].x + 1, y = (int32_t)a[i].y + 1;
+		if (x > re0 && y > qe0) {
+			if (++l > opt_.min_cnt) {
+				l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+				re1 = re0 + l, qe1 = qe0 + l;
+				break;
+			}
+		}
+	}
+	if (qe < qlen && re < ref_len) {
+		l = qlen - qe < opt_.max_gap ? qlen - qe : opt_.max_gap;
+		qe1 = qe1 < qe + l ? qe1 : qe + l;
+		qe0 = qe0 > qe1 ? qe0 : qe1;
+		l += l * opt_.a > opt_.q ? (l * opt_.a - opt_.q) / opt_.e : 0;
+		l = l < opt_.max_gap ? l : opt_.max_gap;
+		l = l < ref_len - re ? l : ref_len - re;
+		re1 = re1 < re + l ? re1 : re + l;
+		re0 = re0 > re1 ? re0 : re1;
+	} else re0 = re, qe0 = qe;
+	if (a[r.as].y & SEED_SELF) {
+		int max_ext = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs;
+		if (r.rs - rs0 > max_ext) rs0 = r.rs - max_ext;
+		if (r.qs - qs0 > max_ext) qs0 = r.qs - max_ext;
+		max_ext = r.qe > r.re ? r.qe - r.re : r.re - r.qe;
+		if (re0 - r.re > max_ext) re0 = r.re + max_ext;
+		if (qe0 - r.qe > max_ext) qe0 = r.qe + max_ext;
+	}
+	assert(re0 > rs0);
+	t.as1 = as1, t.cnt1 = cnt1;
+	t.rs0 = rs0, t.qs0 = qs0, t.re0 = re0, t.qe0 = qe0;
+
+	// the windows, in the order the reference aligns them (align.c:779-890)
+	t.win.clear();
+	t.has_left = t.has_right = false;
+	if (qs > 0 && rs > 0) {
+		Window w; w.kind = W_LEFT, w.qs = qs0, w.qe = qs, w.rs = rs0, w.re = rs, w.bw = bw_, w.anchor_i = 0;
+		t.win.push_back(w), t.has_left = true;
+	}
+	t.rs = rs, t.qs = qs; // start of the first gap window
+	for (int32_t i = 1; i < cnt1; ++i) {
+		if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+		anchor_boundary(fi_, ra.q4.data(), qlen, a[as1 + i], &re, &qe);
+		if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt_.min_ksw_len && re - rs >= opt_.min_ksw_len)) {
+			Window w; w.kind = W_GAP, w.qs = qs, w.qe = qe, w.rs = rs, w.re = re, w.anchor_i = i;
+			w.bw = bw_long_;
+			if (a[as1 + i].y & SEED_LONG_JOIN) w.bw = qe - qs > re - rs ? qe - qs : re - rs;
+			t.win.push_back(w);
+			rs = re, qs = qe;
+		}
+	}
+	t.re = re, t.qe = qe; // end of the last gap window == where the right extension starts
+	if (qe < qe0 && re < re0) {
+		Window w; w.kind = W_RIGHT, w.qs = qe, w.qe = qe0, w.rs = re, w.re = re0, w.bw = bw_, w.anchor_i = 0;
+		t.win.push_back(w), t.has_right = true;
+	}
+	t.next_win = 0, t.dropped = false;
+	t.rs1 = t.rs, t.qs1 = t.qs;  // no left extension: the alignment starts at the first anchor (align.c:800)
+	t.re1 = t.rs, t.qe1 = t.qs;  // (align.c:801)
+}
+
+void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdrop, int end_bonus, std::vector<KswJob> &jobs)
+{
+	KswJob j;
+	const bool reversed = w.kind == W_LEFT;
+	j.qlen = w.qe - w.qs, j.tlen = w.re - w.rs;
+	j.w = w.bw, j.zdrop = zdrop, j.end_bonus = end_bonus;
+	if (opt_.transition != 0 && opt_.b != opt_.transition) flag |= KSW_GENERIC_SC;             // align.c:347-348
+	if (opt_.max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > opt_.max_sw_mat) flag |= KSWJ_SKIP;   // align.c:349-351
+	const uint64_t qbase = ra.qpool_off + (uint64_t)t.rev * ra.qlen, tbase = fi_.seq_off[t.rid];
+	j.q_off = reversed ? qbase + w.qe - 1 : qbase + w.qs;
+	j.t_off = reversed ? tbase + w.re - 1 : tbase + w.rs;
+	j.flag = flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);
+	j.tag = 0, j.reserved = 0;
+	w.job = (int32_t)jobs.size(), w.saved = -1;
+	jobs.push_back(j);
+}
+
+void Aligner::schedule(ReadAlign &ra, std::vector<KswJob> &jobs)
+{
+	for (size_t ti = 0; ti < ra.tasks.size(); ++ti) {
+		RegionTask &t = ra.tasks[ti];
+		if (t.done) continue;
+		if (t.r.inv) { // inversion rescue: one forward extension from the local-alignment start (align.c:944)
+			Window &w = t.win[0];
+			if (w.job < 0 && w.saved < 0) add_job(ra, t, w, KSW_EXTZ_ONLY, opt_.zdrop, -1, jobs);
+			continue;
+		}
+		if (!t.planned) {
+			plan_region(ra, t);
+			if (t.done) continue;
+			for (Window &w : t.win) {
+				if (w.kind == W_LEFT) add_job(ra, t, w, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, t.r.split_inv ? opt_.zdrop_inv : opt_.zdrop, opt_.end_bonus, jobs);
+				else if (w.kind == W_GAP) add_job(ra, t, w, KSW_APPROX_MAX, opt_.zdrop, -1, jobs);
+				else add_job(ra, t, w, KSW_EXTZ_ONLY, opt_.zdrop, opt_.end_bonus, jobs);
+			}
+		} else if (t.next_win < t.win.size()) { // stalled on a second pass (align.c:843-844)
+			Window &w = t.win[t.next_win];
+			if (w.pass2 && w.job < 0 && w.saved < 0) add_job(ra, t, w, 0, w.zdrop_code == 2 ? opt_.zdrop_inv : opt_.zdrop, -1, jobs);
+		}
+	}
+}
+
+bool Aligner::consume(ReadAlign &ra, const KswRes *res, const uint32_t *cigar_pool)
+{
+	bool pending = false;
+	const size_t n0 = ra.tasks.size(); // tasks appended while consuming are picked up by the next schedule()
+	for (size_t ti = 0; ti < n0; ++ti) {
+		if (ra.tasks[ti].done) continue;
+		if (ra.tasks[ti].r.inv) consume_inversion(ra, (int)ti, res, cigar_pool);
+		else pending |= consume_region(ra, (int)ti, res, cigar_pool);
+	}
+	for (size_t ti = n0; ti < ra.tasks.size(); ++ti) pending |= !ra.tasks[ti].done;
+	return pending;
+}
+
+bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool)
+{
+	Anchor *a = ra.a->data();
+	const int qlen = ra.qlen;
+	{
+		RegionTask &t = ra.tasks[ti];
+		Reg &r = t.r;
+		while (t.next_win < t.win.size()) {
+			Window &w = t.win[t.next_win];
+			if (w.job < 0 && w.saved < 0) return true; // its job has not run yet
+			const KswRes &ez = w.saved >= 0 ? t.saved[w.saved].res : res[w.job];
+			const uint32_t *cg = w.saved >= 0 ? t.saved[w.saved].cigar.data() : cigar_pool + ez.cigar_off;
+			if (w.kind == W_LEFT) {
+				if (ez.n_cigar > 0) { append_cigar(r, ez.n_cigar, cg); r.p->dp_score += ez.max; }
+				t.rs1 = w.re - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+				t.qs1 = w.qe - (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
+				++t.next_win;
+			} else if (w.kind == W_GAP) {
+				if (!w.pass2) { // the approximate pass: test it (align.c:843)
+					const uint8_t *qseq = ra.q4.data() + (size_t)t.rev * qlen + w.qs;
+					tbuf_.resize(w.re - w.rs);
+					fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+					const int code = test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
+					if (code != 0) {
+						// keep the results of the later windows of this region: they belong to this round
+						for (size_t k = t.next_win + 1; k < t.win.size(); ++k) {
+							Window &wk = t.win[k];
+							if (wk.job >= 0 && wk.saved < 0) {
+								SavedResult sr;
+								sr.res = res[wk.job];
+								sr.cigar.assign(cigar_pool + sr.res.cigar_off, cigar_pool + sr.res.cigar_off + sr.res.n_cigar);
+								t.saved.push_back(std::move(sr));
+								wk.saved = (int32_t)t.saved.size() - 1, wk.job = -1;
+							}
+						}
+						w.pass2 = true, w.zdrop_code = code, w.job = -1, w.saved = -1;
+						return true;
+					}
+				}
+				if (ez.n_cigar > 0) append_cigar(r, ez.n_cigar, cg);
+				if (ez.zdropped) { // truncated: cut the region here, maybe split off the rest (align.c:848-868)
+					if (!r.p) {
+						const uint32_t cap = roundup32(kExtraWords);
+						r.p = (Extra *)calloc(cap, 4);
+						r.p->capacity = cap;
+					}
+					int j;
+					for (j = w.anchor_i - 1; j >= 0; --j)
+						if ((int32_t)a[t.as1 + j].x <= w.rs + ez.max_t) break;
+					t.dropped = true;
+					if (j < 0) j = 0;
+					r.p->dp_score += ez.max;
+					t.re1 = w.rs + (ez.max_t + 1);
+					t.qe1 = w.qs + (ez.max_q + 1);
+					if (t.cnt1 - (j + 1) >= opt_.min_cnt) {
+						split_reg(r, t.r2, t.as1 + j + 1 - r.as, qlen, a, false);
+						if (w.zdrop_code == 2) t.r2.split_inv = 1;
+					}
+					t.next_win = t.win.size();
+					break;
+				}
+				r.p->dp_score += ez.score;
+				t.re1 = w.re, t.qe1 = w.qe;
+				++t.next_win;
+			} else { // W_RIGHT; only reached when nothing was dropped (align.c:874)
+				if (ez.n_cigar > 0) { append_cigar(r, ez.n_cigar, cg); r.p->dp_score += ez.max; }
+				t.re1 = w.rs + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+				t.qe1 = w.qs + (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
+				++t.next_win;
+			}
+		}
+		finalize_region(ra, t);
+	}
+	// follow-up work.  NB: ra.tasks may reallocate below, so no references are held across push_back.
+	const int self_pos = (int)(std::find(ra.order.begin(), ra.order.end(), ti) - ra.order.begin());
+	bool more = false;
+	if (ra.tasks[ti].r2.cnt > 0) { // the split-off tail becomes a region right after this one (align.c:1102)
+		RegionTask nt;
+		nt.r = ra.tasks[ti].r2;
+		ra.tasks.push_back(std::move(nt));
+		ra.order.insert(ra.order.begin() + self_pos + 1, (int)ra.tasks.size() - 1);
+		more = true;
+	}
+	if (self_pos > 0 && ra.tasks[ti].r.split_inv && !(opt_.flag & F_NO_INV)) { // inversion rescue (align.c:1103-1108)
+		const size_t before = ra.tasks.size();
+		try_inversion(ra, ra.order[self_pos - 1], ti, self_pos);
+		more |= ra.tasks.size() > before;
+	}
+	return more;
+}
+
+void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
+{
+	Reg &r = t.r;
+	const int qlen = ra.qlen;
+	assert(t.qe1 <= qlen);
+	r.rs = t.rs1, r.re = t.re1;
+	if (!t.rev) r.qs = t.qs1, r.qe = t.qe1;
+	else r.qs = qlen - t.qe1, r.qe = qlen - t.qs1;
+	if (r.p) {
+		tbuf_.resize(t.re1 - t.rs1);
+		fi_.getseq(t.rid, t.rs1, t.re1, tbuf_.data());
+		const uint8_t *qseq = ra.q4.data() + (size_t)r.rev * qlen + t.qs1;
+		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
+	}
+	t.saved.clear();
+	t.done = true;
+}
+
+// mm_align1_inv (align.c:916-971), first half: decide whether the gap between a region and its split-off
+// successor looks like an inversion (local alignment of the reverse strand), and if so queue the extension.
+void Aligner::try_inversion(ReadAlign &ra, int prev_ti, int ti, int pos_in_order)
+{
+	const Reg r1 = ra.tasks[prev_ti].r, r2 = ra.tasks[ti].r;
+	const int qlen = ra.qlen;
+	if (!(r1.split & 1) || !(r2.split & 2)) return;
+	if (r1.id != r1.parent && r1.parent != PARENT_TMP_PRI) return;
+	if (r2.id != r2.parent && r2.parent != PARENT_TMP_PRI) return;
+	if (r1.rid != r2.rid || r1.rev != r2.rev) return;
+	const int ql = r1.rev ? r1.qs - r2.qe : r2.qs - r1.qe, tl = r2.rs - r1.re;
+	if (ql < opt_.min_chain_score || ql > opt_.max_gap) return;
+	if (tl < opt_.min_chain_score || tl > opt_.max_gap) return;
+	const int strand = r1.rev ? 0 : 1;                      // the query is read on the strand opposite to the flanks
+	const int q0 = r1.rev ? r2.qe : qlen - r2.qs;
+	std::vector<uint8_t> qrev(ql), trev(tl);
+	const uint8_t *qseq = ra.q4.data() + (size_t)strand * qlen + q0;
+	for (int i = 0; i < ql; ++i) qrev[i] = qseq[ql - 1 - i];
+	fi_.getseq(r1.rid, r1.re, r2.rs, trev.data());
+	std::reverse(trev.begin(), trev.end());
+	int q_off, t_off;
+	const int score = ll_local_score(ql, qrev.data(), tl, trev.data(), mat_, opt_.q, opt_.e, &q_off, &t_off);
+	if (score < opt_.min_dp_max) return;
+	q_off = ql - (q_off + 1), t_off = tl - (t_off + 1);
+	RegionTask nt;
+	memset(&nt.r, 0, sizeof(Reg));
+	nt.r.inv = 1; // marks the task kind; the remaining fields are filled when the extension comes back
+	nt.planned = true;
+	nt.rev = strand, nt.rid = r1.rid;
+	nt.inv_q0 = q0, nt.inv_qoff = q_off, nt.inv_toff = t_off;
+	nt.inv_r2_qs = r2.qs, nt.inv_r2_qe = r2.qe, nt.inv_r1_re = r1.re;
+	nt.r.rev = !r1.rev, nt.r.rid = r1.rid;
+	Window w;
+	w.kind = W_INV, w.qs = q0 + q_off, w.qe = q0 + ql, w.rs = r1.re + t_off, w.re = r2.rs, w.bw = (int)(opt_.bw * 1.5), w.anchor_i = 0;
+	nt.win.push_back(w);
+	ra.tasks.push_back(std::move(nt));
+	// if it succeeds it is reported right after region `ti`, before anything split off from `ti` (align.c:1105-1106)
+	ra.order.insert(ra.order.begin() + pos_in_order + 1, -(int)ra.tasks.size()); // negative = provisional, see consume_inversion
+}
+
+// mm_align1_inv, second half: turn the extension result into an inversion hit, or drop it.
+void Aligner::consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool)
+{
+	RegionTask &t = ra.tasks[ti];
+	Window &w = t.win[0];
+	if (w.job < 0) return;
+	const KswRes &ez = res[w.job];
+	auto slot = std::find(ra.order.begin(), ra.order.end(), -(ti + 1));
+	t.done = true;
+	if (ez.n_cigar == 0) { if (slot != ra.order.end()) ra.order.erase(slot); return; }
+	Reg &ri = t.r;
+	const bool rev = ri.rev;
+	const int32_t rid = ri.rid;
+	memset(&ri, 0, sizeof(Reg));
+	append_cigar(ri, ez.n_cigar, cigar_pool + ez.cigar_off);
+	ri.p->dp_score = ez.max;
+	ri.id = -1, ri.parent = PARENT_UNSET, ri.inv = 1, ri.rev = rev, ri.rid = rid, ri.div = -1.0f;
+	if (ri.rev == 0) ri.qs = t.inv_r2_qe + t.inv_qoff, ri.qe = ri.qs + ez.max_q + 1;
+	else ri.qe = t.inv_r2_qs - t.inv_qoff, ri.qs = ri.qe - (ez.max_q + 1);
+	ri.rs = t.inv_r1_re + t.inv_toff, ri.re = ri.rs + ez.max_t + 1;
+	tbuf_.resize(w.re - w.rs);
+	fi_.getseq(rid, w.rs, w.re, tbuf_.data());
+	update_extra(ri, ra.q4.data() + (size_t)t.rev * ra.qlen + w.qs, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX,
+	             !(opt_.flag & (F_SR | F_SR_RNA)));
+	if (slot != ra.order.end()) *slot = ti;
+}
+
+void Aligner::finish_read(ReadAlign &ra, RegVec &out)
+{
+	out.clear();
+	for (int ti : ra.order)
+		if (ti >= 0) out.push_back(ra.tasks[ti].r);
+	filter_regs(opt_, ra.qlen, out);
+	if (!(opt_.flag & (F_SR | F_SR_RNA | F_ALL_CHAINS)) && !opt_.split_prefix && ra.qlen >= opt_.rank_min_len) {
+		update_dp_max(ra.qlen, out, opt_.rank_frac, opt_.a, opt_.b);
+		filter_regs(opt_, ra.qlen, out);
+	}
+	hit_sort(out, opt_.alt_drop);
+}
+
+} // namespace mm2amd

@@ -1,0 +1,96 @@
+// Base-level alignment of chained regions, restructured for batched DP: the reference's mm_align1
+// (align.c:645-914) interleaves window selection, ksw2 calls and CIGAR stitching per region; here every region is
+// PLANNED first (pure integer work on the anchors: which (query,target) windows need a DP and with which flags),
+// all planned windows of all reads go to the GPU as one job list, and the results are CONSUMED in the reference's
+// order (Z-drop test, append, split, extension end points).  Work that the results themselves trigger (second-pass
+// re-alignment, split-off regions, inversion rescue) is queued for the next round.
+#pragma once
+#include <vector>
+#include "types.hpp"
+#include "hits.hpp"
+#include "flat_index.hpp"
+#include "ksw_dev.hpp"
+
+namespace mm2amd {
+
+void gen_score_matrix(const ref::MapOpt &opt, int8_t mat[25]);       // ksw_gen_ts_mat, align.c:26-36
+
+// ksw_ll_qinit + ksw_ll_i16 (ksw2_ll_sse.c:37-152): striped local SW, score and end coordinates only
+int ll_local_score(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t mat[25], int gapo, int gape, int *qe, int *te);
+
+enum WindowKind : uint8_t { W_LEFT = 0, W_GAP = 1, W_RIGHT = 2, W_INV = 3 };
+
+struct Window {            // one planned DP problem of a region
+	int32_t qs, qe, rs, re; // half-open windows on the (strand-adjusted) query and on the reference
+	int32_t bw;
+	int32_t anchor_i;       // gap fills: index i of the anchor closing the window (relative to as1)
+	int32_t job = -1;       // index into the current round's job list (-1 = none in this round)
+	int32_t saved = -1;     // index into RegionTask::saved when the result was computed in an earlier round
+	WindowKind kind;
+	bool pass2 = false;     // (to be) re-aligned exactly after the approximate pass tripped the Z-drop test
+	int32_t zdrop_code = 0;
+};
+
+struct SavedResult { KswRes res; std::vector<uint32_t> cigar; };
+
+struct RegionTask {
+	Reg r{}, r2{};
+	int32_t as1 = 0, cnt1 = 0;
+	int32_t rid = 0, rev = 0;
+	int32_t rs = 0, qs = 0, re = 0, qe = 0;      // running window ends (as in mm_align1)
+	int32_t rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;  // extension limits
+	int32_t rs1 = 0, qs1 = 0, re1 = 0, qe1 = 0;  // final alignment ends
+	std::vector<Window> win;                     // [left?] gap... [right?]
+	size_t next_win = 0;                         // consumption cursor
+	bool has_left = false, has_right = false, dropped = false, done = false, planned = false;
+	std::vector<SavedResult> saved;              // results carried over a round boundary (only when a region stalls)
+	// inversion-rescue tasks only (mm_align1_inv): where the extension starts and what it is anchored to
+	int32_t inv_q0 = 0, inv_t0 = 0, inv_r2_qs = 0, inv_r2_qe = 0, inv_r1_re = 0, inv_qoff = 0, inv_toff = 0;
+};
+
+struct ReadAlign {        // per-read alignment state
+	int qlen = 0;
+	uint64_t qpool_off = 0;                      // where this read's nt4 fwd|rev bytes start in the device query pool
+	std::vector<uint8_t> q4;                     // fwd (qlen) then reverse complement (qlen), nt4 codes
+	std::vector<Anchor> *a = nullptr;
+	int n_a = 0;
+	std::vector<RegionTask> tasks;               // in creation order
+	std::vector<int> order;                      // output order: indices into tasks (inversions included)
+};
+
+class Aligner {
+public:
+	Aligner(const ref::MapOpt &opt, const FlatIndex &fi);
+	// Prepare a read: encode, squeeze anchors, create one task per region (mm_align_skeleton, align.c:1048-1066).
+	void begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, std::vector<Anchor> &a, uint64_t qpool_off);
+	// Plan everything plannable and append the DP jobs of this round to `jobs`.
+	void schedule(ReadAlign &ra, std::vector<KswJob> &jobs);
+	// Consume results; returns true when the read still has unfinished work (another round needed).
+	bool consume(ReadAlign &ra, const KswRes *res, const uint32_t *cigar_pool);
+	// Collect the regions in output order and run the post-alignment steps of mm_align_skeleton (:1110-1118).
+	void finish_read(ReadAlign &ra, RegVec &out);
+
+	const int8_t *mat() const { return mat_; }
+private:
+	void plan_region(ReadAlign &ra, RegionTask &t);
+	void add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdrop, int end_bonus, std::vector<KswJob> &jobs);
+	bool consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
+	void consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
+	void finalize_region(ReadAlign &ra, RegionTask &t);
+	void try_inversion(ReadAlign &ra, int prev_ti, int ti, int pos_in_order);
+
+	const ref::MapOpt &opt_;
+	const FlatIndex &fi_;
+	int8_t mat_[25];
+	int bw_, bw_long_;
+	std::vector<uint8_t> tbuf_;
+};
+
+// mm_extra_t management (align.c:305-334)
+void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar);
+// mm_update_extra (align.c:254-303) incl. mm_fix_cigar (:105-181)
+void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, bool is_eqx, bool log_gap);
+// mm_test_zdrop (align.c:61-103)
+int test_zdrop(const ref::MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat);
+
+} // namespace mm2amd

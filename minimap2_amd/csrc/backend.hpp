@@ -1,0 +1,35 @@
+// The device-side stages of the mapper behind one interface.  The product library links exactly one
+// implementation (HipBackend: hand-written gfx950 kernels).  tests/ may build the same host pipeline against a
+// checker implementation made of the oracle's C restatement to validate the host logic without a GPU; that
+// checker is never part of libmm2amd.so.
+#pragma once
+#include <vector>
+#include "types.hpp"
+#include "flat_index.hpp"
+#include "ksw_dev.hpp"
+
+namespace mm2amd {
+
+struct SeedChainParams {          // what mm_map_frag_core passes to seeding and chaining (map.c:250-281)
+	int k, w, is_hpc;
+	int mid_occ, max_max_occ, occ_dist;
+	float q_occ_frac;
+	int64_t flag;                 // mm_mapopt_t::flag (FOR_ONLY / REV_ONLY / NO_DIAG ... for skip_seed)
+	int max_gap_ref, max_gap_qry, bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+	float chn_pen_gap, chn_pen_skip;
+	int is_cdna;
+};
+
+class Backend {
+public:
+	virtual ~Backend() {}
+	// Make the batch's sequences resident; the nt4 forward|reverse-complement pool places read i at
+	// qpool_off[i] (2*len bytes).  Must be called before seed_chain()/ksw() of that batch.
+	virtual void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) = 0;
+	// sketch -> seed lookup -> anchor sort -> chaining DP -> chains, for every read of the batch
+	virtual void seed_chain(const SeedChainParams &p, std::vector<ReadChains> &out) = 0;
+	// batched extension DP (ksw_extd2 semantics); CIGARs packed into `cigar`, addressed by res[i].cigar_off
+	virtual void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) = 0;
+};
+
+} // namespace mm2amd

@@ -92,11 +92,10 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 			KswJob &o = dj[i];
 			o.q_off = qtot, o.t_off = ttot, o.qlen = j.qlen, o.tlen = j.tlen, o.w = j.w, o.zdrop = j.zdrop, o.end_bonus = j.end_bonus;
 			o.flag = j.flag & 0x1fff;
-			o.cigar_off = (uint32_t)ctot;
-			o.cigar_cap = (o.flag & KSW_SCORE_ONLY) || j.qlen <= 0 || j.tlen <= 0 ? 0 : (uint32_t)(j.qlen + j.tlen);
-			qtot += j.qlen > 0 ? j.qlen : 0, ttot += j.tlen > 0 ? j.tlen : 0, ctot += o.cigar_cap;
+			o.tag = (uint32_t)i, o.reserved = 0;
+			qtot += j.qlen > 0 ? j.qlen : 0, ttot += j.tlen > 0 ? j.tlen : 0;
 		}
-		if (ctot > cigar_pool_cap || ctot >= (1ull << 32)) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (need sum(qlen+tlen))");
+		(void)ctot;
 		std::vector<uint8_t> hq(qtot + 1), ht(ttot + 1);
 		for (int i = 0; i < n_jobs; ++i) {
 			if (jobs[i].qlen > 0) memcpy(&hq[dj[i].q_off], jobs[i].query, jobs[i].qlen);
@@ -109,13 +108,15 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 		memcpy(sc.mat, mat, 25);
 		sc.m = m, sc.q = gapo, sc.e = gape, sc.q2 = gapo2, sc.e2 = gape2, sc.pad[0] = sc.pad[1] = 0;
 		std::vector<KswRes> r(n_jobs);
-		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cigar_pool, ctot, d.stream);
+		std::vector<uint32_t> cig;
+		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cig, d.stream);
+		if (cig.size() > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
+		if (!cig.empty()) memcpy(cigar_pool, cig.data(), cig.size() * sizeof(uint32_t));
 		for (int i = 0; i < n_jobs; ++i) {
-			if (r[i].cigar_overflow) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: internal CIGAR capacity exceeded");
 			mm2amd_ksw_res_t &o = res[i];
 			o.max = r[i].max, o.zdropped = r[i].zdropped, o.max_q = r[i].max_q, o.max_t = r[i].max_t;
 			o.mqe = r[i].mqe, o.mqe_t = r[i].mqe_t, o.mte = r[i].mte, o.mte_q = r[i].mte_q;
-			o.score = r[i].score, o.n_cigar = r[i].n_cigar, o.reach_end = r[i].reach_end, o.cigar_off = dj[i].cigar_off;
+			o.score = r[i].score, o.n_cigar = r[i].n_cigar, o.reach_end = r[i].reach_end, o.cigar_off = r[i].cigar_off;
 		}
 		return 0;
 	});

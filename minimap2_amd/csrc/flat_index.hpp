@@ -1,0 +1,62 @@
+// Flat, position-independent minimizer index: the device-friendly mirror of the reference's bucketed khash
+// (mm_idx_t::B, index.c:28-33,93-110).  Any layout is allowed as long as a lookup returns the same
+// (count, ascending position list) as mm_idx_get; we use a two-level direct table:
+//     bucket_start[hash >> key_shift]  ->  run of distinct keys (sorted)  ->  val_off[]  ->  pos[]
+// so a lookup costs one dependent load per level and touches 1-2 sectors per level.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "abi_ref.hpp"
+
+namespace mm2amd {
+
+struct FlatIndex {
+	int k = 0, w = 0, flag = 0;
+	uint32_t n_seq = 0;
+	int n_alt = 0;
+	std::vector<std::string> names;
+	std::vector<uint64_t> seq_off;      // offset of each sequence in S (bases)
+	std::vector<uint32_t> seq_len;
+	const uint32_t *S = nullptr;        // 4-bit packed bases, 8 per word (mmpriv.h:34-35); borrowed or owned
+	std::vector<uint32_t> S_own;
+	uint64_t sum_len = 0;
+
+	int bucket_bits = 0, key_shift = 0; // bucket id = hash >> key_shift
+	std::vector<uint32_t> bucket_start; // (1<<bucket_bits) + 1 entries into keys[]
+	std::vector<uint64_t> keys;         // distinct minimizer hashes, ascending
+	std::vector<uint32_t> val_off;      // keys.size() + 1 entries into pos[]
+	std::vector<uint64_t> pos;          // rid<<32 | last_pos<<1 | strand, ascending within a key (index.c:265)
+
+	// mm_idx_get (index.c:93-110)
+	const uint64_t *get(uint64_t hash, int *n) const
+	{
+		*n = 0;
+		if (keys.empty()) return nullptr;
+		const uint64_t b = hash >> key_shift;
+		if (b >= (1ull << bucket_bits)) return nullptr;
+		for (uint32_t i = bucket_start[b], e = bucket_start[b + 1]; i < e; ++i)
+			if (keys[i] == hash) { *n = (int)(val_off[i + 1] - val_off[i]); return &pos[val_off[i]]; }
+		return nullptr;
+	}
+	uint8_t base(uint32_t rid, uint32_t p) const // mm_seq4_get via mm_idx_getseq (index.c:164-174)
+	{
+		const uint64_t o = seq_off[rid] + p;
+		return (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
+	}
+	void getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const
+	{
+		for (uint32_t i = st; i < en; ++i) out[i - st] = base(rid, i);
+	}
+	int32_t cal_max_occ(float f) const; // mm_idx_cal_max_occ (index.c:198-220)
+
+	// (hash, pos) pairs -> tables.  pairs must be sorted by (hash, pos).
+	void build_tables(const std::vector<std::pair<uint64_t, uint64_t>> &sorted_pairs);
+	// Flatten a reference-built index (read-only view of its private hash buckets).
+	void from_reference(const ref::Idx *mi);
+	// Build from raw sequences with our own minimizer code path (host version; used when no reference index exists).
+	void from_sequences(int k, int w, int flag, int n, const char *const *seqs, const char *const *names,
+	                    void (*sketch)(const char *, int, int, int, uint32_t, int, std::vector<ref::mm128> &));
+};
+
+} // namespace mm2amd

@@ -1,0 +1,446 @@
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include "hits.hpp"
+#include "chain_host.hpp"
+
+namespace mm2amd {
+
+namespace {
+
+uint64_t mix64_full(uint64_t key) // hit.c:40-50 (unmasked variant of the sketch hash)
+{
+	key = (~key + (key << 21));
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4));
+	key = key ^ key >> 28;
+	key = (key + (key << 31));
+	return key;
+}
+
+inline int span_of(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
+
+int alt_score(int score, float alt_diff_frac) // hit.c:99-104
+{
+	if (score < 0) return score;
+	score = (int)(score * (1.0 - alt_diff_frac) + .499);
+	return score > 0 ? score : 1;
+}
+
+} // namespace
+
+void reg_set_coor(Reg &r, int32_t qlen, const Anchor *a, bool is_qstrand)
+{
+	const int32_t k = r.as, q_span = span_of(a[k]);
+	r.rev = a[k].x >> 63;
+	r.rid = (int32_t)(a[k].x << 1 >> 33);
+	r.rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
+	r.re = (int32_t)a[k + r.cnt - 1].x + 1;
+	if (!r.rev || is_qstrand) {
+		r.qs = (int32_t)a[k].y + 1 - q_span;
+		r.qe = (int32_t)a[k + r.cnt - 1].y + 1;
+	} else {
+		r.qs = qlen - ((int32_t)a[k + r.cnt - 1].y + 1);
+		r.qe = qlen - ((int32_t)a[k].y + 1 - q_span);
+	}
+	// fuzzy matching/block lengths from anchor spacing (hit.c:8-22)
+	r.mlen = r.blen = 0;
+	if (r.cnt <= 0) return;
+	r.mlen = r.blen = span_of(a[r.as]);
+	for (int i = r.as + 1; i < r.as + r.cnt; ++i) {
+		const int span = span_of(a[i]);
+		const int tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+		r.blen += tl > ql ? tl : ql;
+		r.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+	}
+}
+
+void gen_regs(uint32_t hash, int qlen, const std::vector<uint64_t> &u, const Anchor *a, bool is_qstrand, RegVec &out)
+{
+	const int n_u = (int)u.size();
+	out.clear();
+	if (n_u <= 0) return;
+	std::vector<Anchor> z(n_u);
+	for (int i = 0, k = 0; i < n_u; ++i) { // sort key: chain score, ties broken by a per-read hash of the first anchor
+		const uint32_t h = (uint32_t)mix64_full((mix64_full(a[k].x) + mix64_full(a[k].y)) ^ hash);
+		z[i].x = u[i] ^ h;
+		z[i].y = (uint64_t)k << 32 | (uint32_t)u[i];
+		k += (int32_t)u[i];
+	}
+	sort_by_x(z.data(), z.data() + n_u);
+	std::reverse(z.begin(), z.end());
+	out.resize(n_u);
+	for (int i = 0; i < n_u; ++i) {
+		Reg &r = out[i];
+		memset(&r, 0, sizeof(Reg));
+		r.id = i, r.parent = ref::PARENT_UNSET;
+		r.score = r.score0 = (int32_t)(z[i].x >> 32);
+		r.hash = (uint32_t)z[i].x;
+		r.cnt = (int32_t)z[i].y, r.as = (int32_t)(z[i].y >> 32);
+		r.div = -1.0f;
+		reg_set_coor(r, qlen, a, is_qstrand);
+	}
+}
+
+void split_reg(Reg &r, Reg &r2, int n, int qlen, const Anchor *a, bool is_qstrand)
+{
+	if (n <= 0 || n >= r.cnt) return;
+	r2 = r;
+	r2.id = -1, r2.sam_pri = 0, r2.p = nullptr, r2.split_inv = 0;
+	r2.cnt = r.cnt - n;
+	r2.score = (int32_t)(r.score * ((float)r2.cnt / r.cnt) + .499);
+	r2.as = r.as + n;
+	if (r.parent == r.id) r2.parent = ref::PARENT_TMP_PRI;
+	reg_set_coor(r2, qlen, a, is_qstrand);
+	r.cnt -= r2.cnt, r.score -= r2.score;
+	reg_set_coor(r, qlen, a, is_qstrand);
+	r.split |= 1, r2.split |= 2;
+}
+
+void set_parent(float mask_level, int mask_len, RegVec &r, int sub_diff, bool hard_mask_level, float alt_diff_frac)
+{
+	const int n = (int)r.size();
+	if (n <= 0) return;
+	for (int i = 0; i < n; ++i) r[i].id = i;
+	std::vector<uint64_t> cov(n);
+	std::vector<int> prim(n); // indices of hits that are primary so far
+	int n_prim = 1;
+	prim[0] = 0, r[0].parent = 0;
+	for (int i = 1; i < n; ++i) {
+		Reg &ri = r[i];
+		const int si = ri.qs, ei = ri.qe;
+		int n_cov = 0, uncov_len = 0, j = 0;
+		bool scan = true;
+		if (!hard_mask_level) {
+			for (j = 0; j < n_prim; ++j) { // query intervals of primaries overlapping hit i, clipped to it
+				const Reg &rp = r[prim[j]];
+				int sj = rp.qs, ej = rp.qe;
+				if (ej <= si || sj >= ei) continue;
+				if (sj < si) sj = si;
+				if (ej > ei) ej = ei;
+				cov[n_cov++] = (uint64_t)sj << 32 | (uint32_t)ej;
+			}
+			if (n_cov == 0) scan = false, j = n_prim; // overlaps nothing: a new primary
+			else {
+				int x = si;
+				sort_u64(cov.data(), cov.data() + n_cov);
+				for (int c = 0; c < n_cov; ++c) {
+					if ((int)(cov[c] >> 32) > x) uncov_len += (int)(cov[c] >> 32) - x;
+					x = (int32_t)cov[c] > x ? (int32_t)cov[c] : x;
+				}
+				if (ei > x) uncov_len += ei - x;
+			}
+		}
+		if (scan) {
+			for (j = 0; j < n_prim; ++j) {
+				Reg &rp = r[prim[j]];
+				const int sj = rp.qs, ej = rp.qe;
+				if (ej <= si || sj >= ei) continue;
+				const int mn = ej - sj < ei - si ? ej - sj : ei - si, mx = ej - sj > ei - si ? ej - sj : ei - si;
+				const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+				if ((float)ol / mn - (float)uncov_len / mx > mask_level && uncov_len <= mask_len) { // hit i is secondary to rp
+					int cnt_sub = 0, sci = ri.score;
+					ri.parent = rp.parent;
+					if (!rp.is_alt && ri.is_alt) sci = alt_score(sci, alt_diff_frac);
+					rp.subsc = rp.subsc > sci ? rp.subsc : sci;
+					if (ri.cnt >= rp.cnt) cnt_sub = 1;
+					if (rp.p && ri.p && (rp.rid != ri.rid || rp.rs != ri.rs || rp.re != ri.re || ol != mn)) {
+						sci = ri.p->dp_max;
+						if (!rp.is_alt && ri.is_alt) sci = alt_score(sci, alt_diff_frac);
+						rp.p->dp_max2 = rp.p->dp_max2 > sci ? rp.p->dp_max2 : sci;
+						if (rp.p->dp_max - ri.p->dp_max <= sub_diff) cnt_sub = 1;
+					}
+					if (cnt_sub) ++rp.n_sub;
+					break;
+				}
+			}
+		}
+		if (j == n_prim) prim[n_prim++] = i, ri.parent = i, ri.n_sub = 0;
+	}
+}
+
+void hit_sort(RegVec &r, float alt_diff_frac)
+{
+	const int n = (int)r.size();
+	if (n <= 1) return;
+	std::vector<Anchor> aux;
+	aux.reserve(n);
+	int has_cigar = 0, no_cigar = 0;
+	for (int i = 0; i < n; ++i) {
+		if (r[i].inv || r[i].cnt > 0) { // cnt==0 marks a soft-deleted hit
+			int score;
+			if (r[i].p) score = r[i].p->dp_max, has_cigar = 1;
+			else score = r[i].score, no_cigar = 1;
+			if (r[i].is_alt) score = alt_score(score, alt_diff_frac);
+			aux.push_back(Anchor{(uint64_t)score << 32 | r[i].hash, (uint64_t)i});
+		} else if (r[i].p) {
+			free(r[i].p);
+			r[i].p = nullptr;
+		}
+	}
+	assert(has_cigar + no_cigar == 1);
+	(void)has_cigar; (void)no_cigar;
+	sort_by_x(aux.data(), aux.data() + aux.size());
+	RegVec t(aux.size());
+	for (int i = (int)aux.size() - 1; i >= 0; --i) t[aux.size() - 1 - i] = r[aux[i].y];
+	r.swap(t);
+}
+
+int set_sam_pri(RegVec &r)
+{
+	int n_pri = 0;
+	for (Reg &x : r)
+		if (x.id == x.parent) { ++n_pri; x.sam_pri = (n_pri == 1); }
+		else x.sam_pri = 0;
+	return n_pri;
+}
+
+void sync_regs(RegVec &r)
+{
+	const int n = (int)r.size();
+	if (n <= 0) return;
+	int max_id = -1;
+	for (const Reg &x : r) max_id = max_id > x.id ? max_id : x.id;
+	std::vector<int> where(max_id + 1, -1);
+	for (int i = 0; i < n; ++i)
+		if (r[i].id >= 0) where[r[i].id] = i;
+	for (int i = 0; i < n; ++i) {
+		Reg &x = r[i];
+		x.id = i;
+		if (x.parent == ref::PARENT_TMP_PRI) x.parent = i;
+		else if (x.parent >= 0 && where[x.parent] >= 0) x.parent = where[x.parent];
+		else x.parent = ref::PARENT_UNSET;
+	}
+	set_sam_pri(r);
+}
+
+void select_sub(float pri_ratio, int min_diff, int best_n, bool check_strand, int min_strand_sc, RegVec &r)
+{
+	if (!(pri_ratio > 0.0f) || r.empty()) return;
+	const int n = (int)r.size();
+	int n_2nd = 0, k = 0;
+	std::vector<uint8_t> keep(n, 0);
+	for (int i = 0; i < n; ++i) {
+		const int p = r[i].parent;
+		if (p == i || r[i].inv) keep[i] = 1;
+		else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
+			if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re))
+				keep[i] = 1, ++n_2nd;
+		} else if (check_strand && n_2nd < best_n && r[i].score > min_strand_sc && r[i].rev != r[p].rev) {
+			r[i].strand_retained = 1;
+			keep[i] = 1, ++n_2nd;
+		}
+	}
+	for (int i = 0; i < n; ++i) {
+		if (keep[i]) r[k++] = r[i];
+		else if (r[i].p) free(r[i].p);
+	}
+	r.resize(k);
+	if (k != n) sync_regs(r);
+}
+
+void filter_strand_retained(RegVec &r)
+{
+	const int n = (int)r.size();
+	std::vector<uint8_t> keep(n);
+	for (int i = 0; i < n; ++i) {
+		const int p = r[i].parent;
+		keep[i] = (!r[i].strand_retained || r[i].div < r[p].div * 5.0f || r[i].div < 0.01f);
+	}
+	int k = 0;
+	for (int i = 0; i < n; ++i)
+		if (keep[i]) { if (k < i) r[k] = r[i]; ++k; }
+	r.resize(k);
+}
+
+void filter_regs(const ref::MapOpt &opt, int qlen, RegVec &regs)
+{
+	int k = 0;
+	for (size_t i = 0; i < regs.size(); ++i) {
+		Reg &r = regs[i];
+		bool flt = false;
+		if (!r.inv && !r.seg_split && r.cnt < opt.min_cnt) flt = true;
+		if (r.p) {
+			if (r.mlen < opt.min_chain_score) flt = true;
+			else if (r.p->dp_max < opt.min_dp_max) flt = true;
+			else if (r.qs > qlen * opt.max_clip_ratio && qlen - r.qe > qlen * opt.max_clip_ratio) flt = true;
+			if (flt) free(r.p);
+		}
+		if (!flt) { if (k < (int)i) regs[k] = regs[i]; ++k; }
+	}
+	regs.resize(k);
+}
+
+int squeeze_anchors(RegVec &regs, Anchor *a)
+{
+	const int n = (int)regs.size();
+	int as = 0;
+	std::vector<uint64_t> aux(n);
+	for (int i = 0; i < n; ++i) aux[i] = (uint64_t)regs[i].as << 32 | (uint32_t)i;
+	sort_u64(aux.data(), aux.data() + n);
+	for (int i = 0; i < n; ++i) {
+		Reg &r = regs[(int32_t)aux[i]];
+		if (r.as != as) {
+			memmove(&a[as], &a[r.as], (size_t)r.cnt * sizeof(Anchor));
+			r.as = as;
+		}
+		as += r.cnt;
+	}
+	return as;
+}
+
+void set_mapq(RegVec &regs, int min_chain_sc, int match_sc, int rep_len, bool is_sr, bool is_splice)
+{
+	static const float q_coef = 40.0f;
+	const int n = (int)regs.size();
+	if (n == 0) return;
+	int64_t sum_sc = 0;
+	int n_2nd_splice = 0;
+	for (const Reg &r : regs) {
+		if (r.parent == r.id) sum_sc += r.score;
+		else if (r.is_spliced) ++n_2nd_splice;
+	}
+	const float uniq_ratio = (float)sum_sc / (sum_sc + rep_len);
+	for (Reg &r : regs) {
+		if (r.inv) { r.mapq = 0; continue; }
+		if (r.parent != r.id) { r.mapq = 0; continue; }
+		int mapq;
+		const float pen_s1 = (r.score > 100 ? 1.0f : 0.01f * r.score) * uniq_ratio;
+		float pen_cm = r.cnt > 10 ? 1.0f : 0.1f * r.cnt;
+		pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+		const int subsc = r.subsc > min_chain_sc ? r.subsc : min_chain_sc;
+		if (r.p && r.p->dp_max2 > 0 && r.p->dp_max > 0) {
+			float x;
+			const float identity = (float)r.mlen / r.blen;
+			if (is_sr && is_splice) x = (float)r.p->dp_max2 / r.p->dp_max;
+			else x = (float)r.p->dp_max2 * subsc / r.p->dp_max / r.score0;
+			mapq = (int)(identity * pen_cm * q_coef * (1.0f - x * x) * logf((float)r.p->dp_max / match_sc));
+			if (!is_sr) {
+				const int mapq_alt = (int)(6.02f * identity * identity * (r.p->dp_max - r.p->dp_max2) / match_sc + .499f);
+				mapq = mapq < mapq_alt ? mapq : mapq_alt;
+			}
+			if (is_splice && is_sr && r.is_spliced && n_2nd_splice == 0) mapq += 10;
+		} else {
+			const float x = (float)subsc / r.score0;
+			if (r.p) {
+				const float identity = (float)r.mlen / r.blen;
+				mapq = (int)(identity * pen_cm * q_coef * (1.0f - x) * logf((float)r.p->dp_max / match_sc));
+			} else mapq = (int)(pen_cm * q_coef * (1.0f - x) * logf(r.score));
+		}
+		mapq -= (int)(4.343f * logf(r.n_sub + 1) + .499f);
+		mapq = mapq > 0 ? mapq : 0;
+		r.mapq = mapq < 60 ? mapq : 60;
+		if (r.p && r.p->dp_max > r.p->dp_max2 && r.mapq == 0) r.mapq = 1;
+	}
+	// inversions inherit the lower MAPQ of their two neighbours on the reference (hit.c:406-430)
+	if (n < 3) return;
+	bool any_inv = false;
+	for (const Reg &r : regs) any_inv |= r.inv;
+	if (!any_inv) return;
+	std::vector<Anchor> aux;
+	for (int i = 0; i < n; ++i)
+		if (regs[i].parent == i || regs[i].parent < 0) aux.push_back(Anchor{(uint64_t)regs[i].rid << 32 | (uint32_t)regs[i].rs, (uint64_t)i});
+	sort_by_x(aux.data(), aux.data() + aux.size());
+	for (int i = 1; i < (int)aux.size() - 1; ++i) {
+		Reg &inv = regs[aux[i].y];
+		if (inv.inv) {
+			const Reg &l = regs[aux[i - 1].y], &rr = regs[aux[i + 1].y];
+			inv.mapq = l.mapq < rr.mapq ? l.mapq : rr.mapq;
+		}
+	}
+}
+
+namespace {
+inline int32_t fwd_qpos(int32_t qlen, const Anchor &a) // esterr.c:7-14
+{
+	int32_t x = (int32_t)a.y;
+	if (a.x >> 63) x = qlen - 1 - (x + 1 - span_of(a));
+	return x;
+}
+}
+
+void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const std::vector<uint64_t> &mini_pos)
+{
+	const int32_t n = (int32_t)mini_pos.size();
+	if (n == 0) return;
+	uint64_t sum_k = 0;
+	for (uint64_t m : mini_pos) sum_k += m >> 32 & 0xff;
+	const float avg_k = (float)sum_k / n;
+	for (Reg &r : regs) {
+		r.div = -1.0f;
+		if (r.cnt == 0) continue;
+		// locate the hit's first minimizer (in read order) in mini_pos by binary search
+		const int32_t x0 = fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1] : a[r.as]);
+		int32_t L = 0, R = n - 1, st = -1;
+		while (L <= R) {
+			const int32_t m = (int32_t)(((uint64_t)L + R) >> 1), y = (int32_t)mini_pos[m];
+			if (y < x0) L = m + 1;
+			else if (y > x0) R = m - 1;
+			else { st = m; break; }
+		}
+		if (st < 0) continue;
+		int32_t en = st, n_match = 1, k = 1;
+		const int32_t l_ref = (int32_t)fi.seq_len[r.rid];
+		for (int32_t j = st + 1; j < n && k < r.cnt; ++j) {
+			const int32_t x = fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k]);
+			if (x == (int32_t)mini_pos[j]) ++k, en = j, ++n_match;
+		}
+		int32_t n_tot = en - st + 1;
+		if (r.qs > avg_k && r.rs > avg_k) ++n_tot;
+		if (qlen - r.qs > avg_k && l_ref - r.re > avg_k) ++n_tot;
+		r.div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
+	}
+}
+
+namespace {
+void count_gaps(const Reg &r, int32_t &n_gap, int32_t &n_gapo) // align.c:983-995
+{
+	n_gap = n_gapo = 0;
+	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
+		const int32_t op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
+		if (op == 1 || op == 2) ++n_gapo, n_gap += len;
+	}
+}
+}
+
+void update_dp_max(int qlen, RegVec &regs, float frac, int a, int b)
+{
+	const int n = (int)regs.size();
+	if (n < 2) return;
+	int32_t max = -1, max2 = -1, max_i = -1;
+	for (int i = 0; i < n; ++i) {
+		const Reg &r = regs[i];
+		if (!r.p) continue;
+		if (r.p->dp_max > max) max2 = max, max = r.p->dp_max, max_i = i;
+		else if (r.p->dp_max > max2) max2 = r.p->dp_max;
+	}
+	if (max_i < 0 || max < 0 || max2 < 0) return;
+	if (regs[max_i].qe - regs[max_i].qs < (double)qlen * frac) return;
+	if (max2 < (double)max * frac) return;
+	int32_t n_gap, n_gapo;
+	count_gaps(regs[max_i], n_gap, n_gapo);
+	const Reg &rm = regs[max_i];
+	double div = 1. - (double)rm.mlen / (rm.blen + rm.p->n_ambi - n_gap + n_gapo); // 1 - mm_event_identity (align.c:997-1003)
+	if (div < 0.02) div = 0.02;
+	double b2 = 0.5 / div;
+	if (b2 * a < b) b2 = (double)a / b;
+	for (Reg &r : regs) {
+		if (!r.p) continue;
+		// rescore the alignment with a divergence-adapted mismatch penalty and log gap cost (align.c:1005-1020)
+		int32_t gaps = 0;
+		double gap_cost = 0.0;
+		for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
+			const int32_t op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
+			if (op == 1 || op == 2) gap_cost += b2 + (double)fast_log2(1.0 + len), gaps += len;
+		}
+		const int32_t n_mis = r.blen + r.p->n_ambi - r.mlen - gaps;
+		r.p->dp_max = (int32_t)(a * (r.mlen - b2 * n_mis - gap_cost) + .499);
+		if (r.p->dp_max < 0) r.p->dp_max = 0;
+	}
+}
+
+} // namespace mm2amd

@@ -26,8 +26,8 @@ struct KswJob {             // 48 B
 	uint64_t t_off;         // byte offset into the target pool, or base index into packed S; first base read (last if T_REVERSED)
 	int32_t qlen, tlen;
 	int32_t w, zdrop, end_bonus, flag;
-	uint32_t cigar_off;     // where this job's CIGAR goes in the cigar pool (uint32 units)
-	uint32_t cigar_cap;
+	uint32_t tag;           // free for the host (e.g. owner of the job)
+	uint32_t reserved;
 };
 
 struct KswRes {             // 48 B; field meaning as ksw_extz_t (ksw2.h:34-43)
@@ -38,7 +38,7 @@ struct KswRes {             // 48 B; field meaning as ksw_extz_t (ksw2.h:34-43)
 	int32_t score;
 	int32_t n_cigar;
 	int32_t reach_end;
-	int32_t cigar_overflow;
+	uint32_t cigar_off;     // where the CIGAR was placed in the cigar pool (allocated by the kernel)
 };
 
 struct KswScoring {         // uniform over a launch
@@ -55,7 +55,11 @@ struct KswLaunch {
 	const uint8_t *qpool;   // device nt4 bytes
 	const uint8_t *tpool;   // device nt4 bytes (may be null when every job is T_PACKED)
 	const uint32_t *S;      // device 4-bit packed reference (may be null)
-	uint32_t *cigar_pool;   // device
+	uint32_t *cigar_pool;   // device; CIGARs are packed back to back, space handed out by an atomic cursor
+	uint32_t cigar_pool_cap;
+	uint32_t *cigar_cursor; // device: [0] = next free entry, [1] = set to 1 when the pool overflowed
+	uint32_t *cigar_tmp;    // device scratch: n_slots * cigar_tmp_cap (traceback output before it is packed)
+	uint32_t cigar_tmp_cap;
 	uint8_t *dir_pool;      // device scratch for direction matrices: n_slots * slot_bytes
 	size_t slot_bytes;
 	int32_t *counter;       // device, zeroed before launch: persistent-wave job queue head

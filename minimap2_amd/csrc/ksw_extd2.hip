@@ -71,19 +71,21 @@ __device__ __forceinline__ bool zdrop_test(EzState &ez, int H, int r, int t, int
 	return false;
 }
 
-struct CigOut { uint32_t *c; int n, cap, ovf; uint32_t last_op; };
+struct CigOut { uint32_t *c; int n; uint32_t last; };
 
-__device__ __forceinline__ void cig_push(CigOut &g, uint32_t op, int len) // ksw_push_cigar, ksw2.h:114-124
+// ksw_push_cigar (ksw2.h:114-124); the scratch buffer holds qlen+tlen entries, which a traceback cannot exceed
+__device__ __forceinline__ void cig_push(CigOut &g, uint32_t op, int len)
 {
-	if (g.n == 0 || op != g.last_op) {
-		if (g.n < g.cap) g.c[g.n] = (uint32_t)len << 4 | op; else g.ovf = 1;
-		++g.n, g.last_op = op;
-	} else if (g.n <= g.cap) g.c[g.n - 1] += (uint32_t)len << 4;
+	if (g.n == 0 || op != (g.last & 0xf)) {
+		if (g.n > 0) g.c[g.n - 1] = g.last;
+		g.last = (uint32_t)len << 4 | op;
+		++g.n;
+	} else g.last += (uint32_t)len << 4;
 }
 
 // Traceback by one lane over the direction matrix in HBM (ksw2.h:130-162, is_rot=1, min_intron_len=0).
 // off[r]/off_end[r] of the reference are st/en of row r, recomputed here instead of stored.
-__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, bool is_rev, int i0, int j0, CigOut &g)
+__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, int i0, int j0, CigOut &g)
 {
 	int i = i0, j = j0, state = 0;
 	while (i >= 0 && j >= 0) {
@@ -102,8 +104,7 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 	}
 	if (i >= 0) cig_push(g, 2, i + 1);
 	if (j >= 0) cig_push(g, 1, j + 1);
-	if (!is_rev && !g.ovf)
-		for (int k = 0; k < g.n >> 1; ++k) { uint32_t t = g.c[k]; g.c[k] = g.c[g.n - 1 - k]; g.c[g.n - 1 - k] = t; }
+	if (g.n > 0) g.c[g.n - 1] = g.last; // flush the run being accumulated
 }
 
 __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
@@ -126,7 +127,8 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 		EzState ez;
 		ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
 		ez.max = 0, ez.score = ez.mqe = ez.mte = KSW_NEG_INF, ez.zdropped = 0, ez.reach_end = 0;
-		CigOut g = { L.cigar_pool + J.cigar_off, 0, (int)J.cigar_cap, 0, 0xfu };
+		CigOut g = { L.cigar_tmp + (size_t)slot * L.cigar_tmp_cap, 0, 0u };
+		uint32_t cig_off = 0;
 
 		int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
 		const int qe_in = q + e; // taken before the swap (ksw2_extd2_sse.c:68 vs :78); seeds H(0,0)
@@ -315,13 +317,23 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 			// ---- traceback (:385-399) ----
 			if (with_cigar) {
 				__threadfence_block(); // the direction bytes were written by all lanes of this wave
-				const bool rev = flag & KSW_REV_CIGAR;
+				if (!ez.zdropped && (flag & KSW_EXTZ_ONLY) && ez.mqe + J.end_bonus > ez.max) ez.reach_end = 1;
 				if (lane == 0) {
-					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, rev, tlen - 1, qlen - 1, g);
-					else if (!ez.zdropped && (flag & KSW_EXTZ_ONLY) && ez.mqe + J.end_bonus > ez.max) {
-						ez.reach_end = 1;
-						traceback(dir, ncol, qlen, tlen, w, rev, ez.mqe_t, qlen - 1, g);
-					} else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, rev, ez.max_t, ez.max_q, g);
+					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, g);
+					else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, g);
+					else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, g);
+					if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
+				}
+				// pack the CIGAR into the pool: forward order unless the caller asked for the traceback order (:153-155 of ksw2.h)
+				const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
+				cig_off = __builtin_amdgcn_readfirstlane(cig_off);
+				__threadfence_block();
+				if (n_cig > 0) {
+					if ((unsigned long long)cig_off + (unsigned)n_cig > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
+					else {
+						const bool keep_order = flag & KSW_REV_CIGAR;
+						for (int k = lane; k < n_cig; k += 64) L.cigar_pool[cig_off + k] = g.c[keep_order ? k : n_cig - 1 - k];
+					}
 				}
 			}
 			WAVE_SYNC();
@@ -330,7 +342,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 			KswRes R;
 			R.max = ez.max, R.zdropped = ez.zdropped, R.max_q = ez.max_q, R.max_t = ez.max_t;
 			R.mqe = ez.mqe, R.mqe_t = ez.mqe_t, R.mte = ez.mte, R.mte_q = ez.mte_q;
-			R.score = ez.score, R.n_cigar = g.n, R.reach_end = ez.reach_end, R.cigar_overflow = g.ovf;
+			R.score = ez.score, R.n_cigar = g.n, R.reach_end = ez.reach_end, R.cigar_off = cig_off;
 			L.res[jid] = R;
 		}
 	}

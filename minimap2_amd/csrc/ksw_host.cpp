@@ -13,15 +13,17 @@ constexpr int kMaxWavesPerCU = 20; // 81 VGPRs -> 5 waves/SIMD
 }
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-                    const KswScoring &sc, KswRes *res, uint32_t *cigar_out, size_t cigar_total, hipStream_t stream)
+                    const KswScoring &sc, KswRes *res, std::vector<uint32_t> &cigar_out, hipStream_t stream)
 {
 	const size_t n = jobs.size();
+	cigar_out.clear();
 	if (n == 0) return;
 	// order: tier ascending, then cost (rows * row width) descending for longest-job-first scheduling
 	perm.resize(n);
 	std::iota(perm.begin(), perm.end(), 0u);
 	std::vector<uint64_t> key(n);
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
+	size_t sum_len = 0;
 	for (size_t i = 0; i < n; ++i) {
 		const KswJob &j = jobs[i];
 		int dim = std::max(r16(j.qlen), r16(j.tlen)), tier = 0;
@@ -30,6 +32,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		uint64_t cost = (j.flag & KSWJ_SKIP) ? 0 : (uint64_t)(j.qlen + j.tlen) * (uint64_t)std::min(std::min(j.qlen, j.tlen), j.w < 0 ? INT32_MAX : j.w + 1);
 		if (cost >> 56) cost = (1ull << 56) - 1;
 		key[i] = (uint64_t)tier << 60 | ((1ull << 56) - 1 - cost);
+		if (!(j.flag & (KSWJ_SKIP | KSW_SCORE_ONLY)) && j.qlen > 0 && j.tlen > 0) sum_len += (size_t)j.qlen + j.tlen;
 	}
 	std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
 	sorted.resize(n);
@@ -37,47 +40,68 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 
 	d_jobs.ensure(n);
 	d_res.ensure(n);
-	d_cigar.ensure(cigar_total ? cigar_total : 1);
 	d_counter.ensure(8);
+	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sorted.data(), n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 8 * sizeof(int32_t), stream));
-
-	size_t beg = 0;
-	for (int tier = 0; tier < 3; ++tier) {
-		size_t end = beg;
-		while (end < n && (key[perm[end]] >> 60) == (uint64_t)tier) ++end;
-		if (end == beg) continue;
-		int max_T16 = 16, max_Q16 = 16;
-		size_t slot_bytes = 16;
-		for (size_t i = beg; i < end; ++i) {
-			const KswJob &j = sorted[i];
-			if (j.flag & KSWJ_SKIP) continue;
-			max_T16 = std::max(max_T16, r16(j.tlen)), max_Q16 = std::max(max_Q16, r16(j.qlen));
-			if (!(j.flag & KSW_SCORE_ONLY)) slot_bytes = std::max(slot_bytes, ksw_dir_bytes(j.qlen, j.tlen, j.w));
-		}
-		slot_bytes = (slot_bytes + 255) / 256 * 256;
-		const int wpb = kTiers[tier].waves_per_block;
-		const size_t region = (ksw_lds_per_wave(max_T16, max_Q16) + 15) / 16 * 16;
-		int blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
-		if (blocks_per_cu < 1) blocks_per_cu = 1;
-		size_t n_slots = std::min<size_t>(end - beg, (size_t)n_cu * blocks_per_cu * wpb);
-		n_slots = std::min<size_t>(n_slots, std::max<size_t>(1, dir_budget / slot_bytes));
-		n_slots = (n_slots + wpb - 1) / wpb * wpb;
-		d_dir.ensure(n_slots * slot_bytes, 1.0);
-
-		KswLaunch L;
-		L.jobs = d_jobs.p + beg, L.res = d_res.p + beg, L.n_jobs = (int32_t)(end - beg);
-		L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
-		L.cigar_pool = d_cigar.p, L.dir_pool = d_dir.p, L.slot_bytes = slot_bytes;
-		L.counter = d_counter.p + tier;
-		L.max_T16 = max_T16, L.max_Q16 = max_Q16, L.sc = sc;
-		ksw_extd2_launch(L, (int)n_slots, wpb, stream);
-		beg = end;
-	}
 	tmp_res.resize(n);
-	HIP_CHECK(hipMemcpyAsync(tmp_res.data(), d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
-	if (cigar_total) HIP_CHECK(hipMemcpyAsync(cigar_out, d_cigar.p, cigar_total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+
+	// CIGARs are much shorter than qlen+tlen; start with a quarter of the worst case and retry in full on overflow
+	size_t pool_cap = std::min<size_t>(sum_len, sum_len / 4 + 64 * n) + 16;
+	for (int attempt = 0;; ++attempt) {
+		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
+		d_cigar.ensure(pool_cap);
+		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 8 * sizeof(int32_t), stream));
+		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
+		size_t beg = 0;
+		for (int tier = 0; tier < 3; ++tier) {
+			size_t end = beg;
+			while (end < n && (key[perm[end]] >> 60) == (uint64_t)tier) ++end;
+			if (end == beg) continue;
+			int max_T16 = 16, max_Q16 = 16;
+			size_t slot_bytes = 16, tmp_cap = 16;
+			for (size_t i = beg; i < end; ++i) {
+				const KswJob &j = sorted[i];
+				if ((j.flag & KSWJ_SKIP) || j.qlen <= 0 || j.tlen <= 0) continue;
+				max_T16 = std::max(max_T16, r16(j.tlen)), max_Q16 = std::max(max_Q16, r16(j.qlen));
+				if (!(j.flag & KSW_SCORE_ONLY)) {
+					slot_bytes = std::max(slot_bytes, ksw_dir_bytes(j.qlen, j.tlen, j.w));
+					tmp_cap = std::max(tmp_cap, (size_t)j.qlen + j.tlen);
+				}
+			}
+			slot_bytes = (slot_bytes + 255) / 256 * 256;
+			const int wpb = kTiers[tier].waves_per_block;
+			const size_t region = (ksw_lds_per_wave(max_T16, max_Q16) + 15) / 16 * 16;
+			int blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
+			if (blocks_per_cu < 1) blocks_per_cu = 1;
+			size_t n_slots = std::min<size_t>(end - beg, (size_t)n_cu * blocks_per_cu * wpb);
+			n_slots = std::min<size_t>(n_slots, std::max<size_t>(1, dir_budget / slot_bytes));
+			n_slots = (n_slots + wpb - 1) / wpb * wpb;
+			d_dir.ensure(n_slots * slot_bytes, 1.0);
+			d_cigar_tmp.ensure(n_slots * tmp_cap, 1.0);
+
+			KswLaunch L;
+			L.jobs = d_jobs.p + beg, L.res = d_res.p + beg, L.n_jobs = (int32_t)(end - beg);
+			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
+			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
+			L.cigar_tmp = d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)tmp_cap;
+			L.dir_pool = d_dir.p, L.slot_bytes = slot_bytes;
+			L.counter = d_counter.p + tier;
+			L.max_T16 = max_T16, L.max_Q16 = max_Q16, L.sc = sc;
+			ksw_extd2_launch(L, (int)n_slots, wpb, stream);
+			beg = end;
+		}
+		uint32_t cursor[2];
+		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(tmp_res.data(), d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		if (cursor[1] == 0) {
+			cigar_out.resize(cursor[0]);
+			if (cursor[0]) HIP_CHECK(hipMemcpy(cigar_out.data(), d_cigar.p, (size_t)cursor[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			break;
+		}
+		if (attempt > 0) throw std::runtime_error("[mm2amd] CIGAR pool overflow even at worst-case size");
+		pool_cap = sum_len + 16;
+	}
 	for (size_t i = 0; i < n; ++i) res[perm[i]] = tmp_res[i];
 }
 

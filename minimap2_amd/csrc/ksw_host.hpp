@@ -10,7 +10,7 @@ namespace mm2amd {
 struct KswRunner {
 	DevBuf<KswJob> d_jobs;
 	DevBuf<KswRes> d_res;
-	DevBuf<uint32_t> d_cigar;
+	DevBuf<uint32_t> d_cigar, d_cigar_tmp, d_cursor;
 	DevBuf<uint8_t> d_dir;
 	DevBuf<int32_t> d_counter;
 	std::vector<KswJob> sorted;
@@ -19,10 +19,10 @@ struct KswRunner {
 	size_t dir_budget = (size_t)12 << 30; // bytes of HBM we allow for direction matrices
 	int n_cu = 256;
 
-	// jobs[i].cigar_off/cigar_cap must be set; pools are device pointers.  Results land in res[i] (input order),
-	// CIGARs in cigar_out (host, cigar_total entries, same offsets as the jobs').
+	// Pools are device pointers.  Results land in res[i] (input order); the CIGARs are packed into cigar_out
+	// (resized here) and addressed by res[i].cigar_off / n_cigar.
 	void run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-	         const KswScoring &sc, KswRes *res, uint32_t *cigar_out, size_t cigar_total, hipStream_t stream);
+	         const KswScoring &sc, KswRes *res, std::vector<uint32_t> &cigar_out, hipStream_t stream);
 };
 
 } // namespace mm2amd

@@ -1,0 +1,39 @@
+// The batched replacement of the reference's per-read driver: what kt_for(worker_for) + mm_map_frag_core
+// (map.c:227-378, :425-474) compute for a mini-batch of reads, restructured into whole-batch stages.
+#pragma once
+#include <memory>
+#include <vector>
+#include "types.hpp"
+#include "hits.hpp"
+#include "align.hpp"
+#include "backend.hpp"
+
+namespace mm2amd {
+
+struct ReadResult {
+	RegVec regs;       // final hits; each regs[i].p is libc-allocated (caller frees)
+	int rep_len = 0;   // mm_tbuf_t::rep_len (map.c:318)
+	int frag_gap = 0;  // mm_tbuf_t::frag_gap (map.c:317)
+};
+
+struct MapperStats { // wall-clock seconds per stage of the last map_batch (for bench / DESIGN.md)
+	double t_seed_chain = 0, t_host_pre = 0, t_plan = 0, t_ksw = 0, t_consume = 0, t_finish = 0;
+	long n_jobs = 0, n_rounds = 0;
+	double dp_cells = 0;
+};
+
+class Mapper {
+public:
+	Mapper(const FlatIndex &fi, const ref::MapOpt &opt, Backend &be, int n_threads);
+	void map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out);
+	MapperStats stats;
+private:
+	const FlatIndex &fi_;
+	ref::MapOpt opt_;
+	Backend &be_;
+	int n_threads_;
+};
+
+uint32_t read_hash(const char *qname, int qlen, const ref::MapOpt &opt); // map.c:246-248
+
+} // namespace mm2amd

@@ -1,0 +1,40 @@
+// Shared host-side records of the batched mapper.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include "abi_ref.hpp"
+#include "exact_rsort.hpp"
+
+namespace mm2amd {
+
+using Anchor = ref::mm128;   // x = rev<<63 | rid<<32 | rpos ; y = flags | seg<<48 | q_span<<32 | qpos   (lchain.c:140-143)
+
+struct KeyX { MM2_HD uint64_t operator()(const Anchor &a) const { return a.x; } };
+struct KeyU64 { MM2_HD uint64_t operator()(uint64_t a) const { return a; } };
+
+inline void sort_by_x(Anchor *b, Anchor *e) { RsortScratch sc; exact_radix_sort(b, e, KeyX(), sc); }   // radix_sort_128x
+inline void sort_u64(uint64_t *b, uint64_t *e) { RsortScratch sc; exact_radix_sort(b, e, KeyU64(), sc); } // radix_sort_64
+
+// Parameters of the per-read path that come from the index rather than from mm_mapopt_t.
+struct IdxParams {
+	int k = 15, w = 10, flag = 0;
+};
+
+// One read (single segment) handed to the mapper.
+struct ReadView {
+	const char *seq = nullptr;   // ASCII
+	int len = 0;
+	const char *name = nullptr;  // may be null
+};
+
+// What seeding + chaining produces for one read (the state of mm_map_frag_core after map.c:316).
+struct ReadChains {
+	std::vector<uint64_t> u;        // per chain: score<<32 | n_anchors
+	std::vector<Anchor> a;          // anchors of all chains, chain by chain
+	std::vector<uint64_t> mini_pos; // q_span<<32 | q_pos of every minimizer that was looked up and kept (seed.c:124)
+	int rep_len = 0;
+};
+
+} // namespace mm2amd

@@ -71,6 +71,19 @@ int ora_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_
                   float chn_pen_gap, float chn_pen_skip, int is_cdna, int n_seg, int64_t n, ora128_t *a,
                   uint64_t *u_out, int64_t *n_a_out);
 
+/* index lookup callback with mm_idx_get semantics (index.c:93-110): returns the ascending position list and its length */
+typedef const uint64_t *(*ora_idx_get_f)(const void *idx, uint64_t minier, int *n);
+
+/* Seeding of one read: mm_seed_mz_flt (seed.c:5-28) + mm_collect_matches (seed.c:98-132, incl. mm_seed_collect_all
+ * :30-52 and mm_seed_select :56-96) + the anchor expansion and sort of collect_seed_hits (map.c:168-204; skip_seed
+ * :78-100 restricted to the FOR_ONLY/REV_ONLY flags - the qname-dependent NO_DIAG/NO_DUAL rules are not restated).
+ * mv[0..n_mv) are the read's minimizers (modified in place by the query-occurrence filter).
+ * Outputs: anchors (malloc'd, *n_a entries, sorted with the reference's unstable sort), mini_pos (malloc'd,
+ * *n_mini_pos entries), *rep_len.  Returns the number of minimizers left after the filter. */
+int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_flag, int qlen, int mid_occ, int max_max_occ, int occ_dist,
+                              float q_occ_frac, ora128_t *mv, int64_t n_mv, ora128_t **anchors, int64_t *n_a,
+                              uint64_t **mini_pos, int *n_mini_pos, int *rep_len);
+
 #ifdef __cplusplus
 }
 #endif

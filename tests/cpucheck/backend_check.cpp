@@ -1,0 +1,110 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libmm2amd.so.
+//
+// A Backend made of the oracle's plain-C restatement (oracle/*.c).  It lets the CPU-only test suite drive the
+// product's host pipeline (chains -> hits -> window planning -> CIGAR stitching -> MAPQ) end to end and compare
+// its SAM output with the reference binary, in a container that has no GPU.  The GPU tests exercise the same host
+// pipeline with the real HipBackend.
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include "../../minimap2_amd/csrc/backend.hpp"
+#include "../../oracle/oracle.h"
+
+extern "C" const uint8_t *ora_nt4_table(void);
+
+namespace mm2amd {
+
+namespace {
+
+const uint64_t *flat_get(const void *idx, uint64_t minier, int *n) { return ((const FlatIndex *)idx)->get(minier, n); }
+
+class CheckBackend : public Backend {
+public:
+	explicit CheckBackend(const FlatIndex &fi) : fi_(fi) {}
+	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
+	{
+		reads_ = reads;
+		qpool_off.resize(reads.size());
+		size_t tot = 0;
+		for (size_t i = 0; i < reads.size(); ++i) qpool_off[i] = tot, tot += 2 * (size_t)reads[i].len;
+		qpool_.assign(tot + 1, 0);
+		const uint8_t *nt4 = ora_nt4_table();
+		for (size_t i = 0; i < reads.size(); ++i) {
+			uint8_t *f = &qpool_[qpool_off[i]];
+			const int len = reads[i].len;
+			for (int j = 0; j < len; ++j) {
+				const uint8_t c = nt4[(uint8_t)reads[i].seq[j]];
+				f[j] = c, f[2 * (size_t)len - 1 - j] = c < 4 ? 3 - c : 4;
+			}
+		}
+	}
+	void seed_chain(const SeedChainParams &p, std::vector<ReadChains> &out) override
+	{
+		out.clear();
+		out.resize(reads_.size());
+		std::vector<ora128_t> mv;
+		for (size_t i = 0; i < reads_.size(); ++i) {
+			const int len = reads_[i].len;
+			mv.resize((size_t)len + 1);
+			int64_t n_mv = ora_sketch(reads_[i].seq, len, p.w, p.k, 0, p.is_hpc, mv.data(), (int64_t)mv.size());
+			ora128_t *a = nullptr;
+			uint64_t *mp = nullptr;
+			int64_t n_a = 0;
+			int n_mp = 0, rep_len = 0;
+			ora_collect_seed_hits(&fi_, flat_get, p.flag, len, p.mid_occ, p.max_max_occ, p.occ_dist, p.q_occ_frac, mv.data(), n_mv, &a, &n_a, &mp, &n_mp, &rep_len);
+			ReadChains &c = out[i];
+			c.rep_len = rep_len;
+			c.mini_pos.assign(mp, mp + n_mp);
+			c.u.resize(n_a > 0 ? n_a : 1);
+			int64_t n_kept = 0;
+			const int n_u = ora_lchain_dp(p.max_gap_ref, p.max_gap_qry, p.bw, p.max_chain_skip, p.max_chain_iter, p.min_cnt, p.min_chain_score,
+			                              p.chn_pen_gap, p.chn_pen_skip, p.is_cdna, 1, n_a, a, c.u.data(), &n_kept);
+			c.u.resize(n_u);
+			c.a.resize(n_kept);
+			if (n_kept) memcpy(c.a.data(), a, n_kept * sizeof(ora128_t));
+			free(a); free(mp);
+		}
+	}
+	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) override
+	{
+		res.resize(jobs.size());
+		cigar.clear();
+		std::vector<uint8_t> q, t;
+		std::vector<uint32_t> cg;
+		for (size_t k = 0; k < jobs.size(); ++k) {
+			const KswJob &j = jobs[k];
+			KswRes &r = res[k];
+			q.resize(j.qlen > 0 ? j.qlen : 0), t.resize(j.tlen > 0 ? j.tlen : 0);
+			for (int i = 0; i < j.qlen; ++i) q[i] = qpool_[(j.flag & KSWJ_Q_REVERSED) ? j.q_off - i : j.q_off + i];
+			for (int i = 0; i < j.tlen; ++i) {
+				const uint64_t pos = (j.flag & KSWJ_T_REVERSED) ? j.t_off - i : j.t_off + i;
+				if (!(j.flag & KSWJ_T_PACKED)) throw std::runtime_error("check backend: byte targets are not used by the mapper");
+				t[i] = (uint8_t)(fi_.S[pos >> 3] >> ((pos & 7) << 2) & 0xf);
+			}
+			ora_ez_t ez;
+			if (j.flag & KSWJ_SKIP) {
+				memset(&ez, 0, sizeof ez);
+				ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1, ez.score = ez.mqe = ez.mte = ORA_NEG_INF, ez.zdropped = 1;
+			} else {
+				cg.resize((size_t)j.qlen + j.tlen + 8);
+				ora_ksw_extd2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff,
+				              &ez, cg.data(), (int)cg.size());
+			}
+			r.max = ez.max, r.zdropped = ez.zdropped, r.max_q = ez.max_q, r.max_t = ez.max_t, r.mqe = ez.mqe, r.mqe_t = ez.mqe_t;
+			r.mte = ez.mte, r.mte_q = ez.mte_q, r.score = ez.score, r.n_cigar = ez.n_cigar, r.reach_end = ez.reach_end;
+			r.cigar_off = (uint32_t)cigar.size();
+			cigar.insert(cigar.end(), cg.begin(), cg.begin() + ez.n_cigar);
+		}
+	}
+private:
+	const FlatIndex &fi_;
+	std::vector<ReadView> reads_;
+	std::vector<uint8_t> qpool_;
+};
+
+} // namespace
+
+Backend *make_backend(const FlatIndex &fi, int /*device*/) { return new CheckBackend(fi); }
+const char *backend_name() { return "cpu-check(oracle)"; }
+
+} // namespace mm2amd

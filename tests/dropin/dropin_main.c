@@ -1,0 +1,109 @@
+/* tests/dropin/dropin_main.c -- TEST HARNESS.
+ *
+ * A minimal minimap2-like front end that keeps the reference's own host code for everything outside the hot path
+ * (option presets, index reader, FASTA reader, SAM/PAF writer -- linked from oracle/_ref/libminimap2_ref.a) and
+ * calls OUR mapper through the drop-in C ABI (include/mm2amd.h) where the reference runs kt_for(worker_for)
+ * (map.c:576).  Its output is diffed against oracle/_ref/minimap2_ref: this is the "SAM diff == 0" gate, and it is
+ * also exactly the binding INTEGRATION.md proposes.  Compiled against the reference headers where they lie
+ * (/root/reference), so it is built in the dev container and travels to the GPU box as a prebuilt binary.
+ *
+ * usage: dropin [-x preset] [-a|-c] [-t threads] [-K batch_bases] [-s seed] [-z zdrop[,inv]] [--stats] ref.fa|ref.mmi reads.fa
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "minimap.h"
+#include "mmpriv.h"
+#include "bseq.h"
+#include "mm2amd.h"
+
+int main(int argc, char *argv[])
+{
+	mm_idxopt_t iopt;
+	mm_mapopt_t mopt;
+	const char *preset = 0;
+	int n_threads = 3, i, k = 1, print_stats = 0;
+	int64_t batch = 500000000;
+	kstring_t str = {0, 0, 0};
+
+	mm_verbose = 2;
+	mm_set_opt(0, &iopt, &mopt);
+	for (i = 1; i < argc; ++i) /* presets first, like main.c:150-163 */
+		if (strcmp(argv[i], "-x") == 0 && i + 1 < argc) preset = argv[i + 1];
+	if (preset && mm_set_opt(preset, &iopt, &mopt) < 0) { fprintf(stderr, "unknown preset %s\n", preset); return 1; }
+	for (k = 1; k < argc && argv[k][0] == '-'; ++k) {
+		if (strcmp(argv[k], "-x") == 0) ++k;
+		else if (strcmp(argv[k], "-a") == 0) mopt.flag |= MM_F_OUT_SAM | MM_F_CIGAR;
+		else if (strcmp(argv[k], "-c") == 0) mopt.flag |= MM_F_OUT_CG | MM_F_CIGAR;
+		else if (strcmp(argv[k], "-t") == 0) n_threads = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-K") == 0) batch = atoll(argv[++k]);
+		else if (strcmp(argv[k], "-s") == 0) mopt.seed = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--stats") == 0) print_stats = 1;
+		else if (strcmp(argv[k], "--cs") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_CIGAR;
+		else if (strcmp(argv[k], "--MD") == 0) mopt.flag |= MM_F_OUT_MD;
+		else if (strcmp(argv[k], "--eqx") == 0) mopt.flag |= MM_F_EQX;
+		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
+	}
+	if (argc - k < 2) { fprintf(stderr, "usage: dropin [options] ref reads\n"); return 1; }
+	if (mm_check_opt(&iopt, &mopt) < 0) return 1;
+
+	mm_idx_reader_t *rd = mm_idx_reader_open(argv[k], &iopt, 0);
+	if (rd == 0) { fprintf(stderr, "failed to open %s\n", argv[k]); return 1; }
+	mm_idx_t *mi;
+	while ((mi = mm_idx_reader_read(rd, n_threads)) != 0) {
+		if (mopt.flag & MM_F_OUT_SAM) mm_write_sam_hdr(mi, 0, MM_VERSION, 0, 0);
+		mm_mapopt_update(&mopt, mi);
+		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
+		mm_bseq_file_t *fp = mm_bseq_open(argv[k + 1]);
+		if (fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
+		int with_qual = (!!(mopt.flag & MM_F_OUT_SAM) && !(mopt.flag & MM_F_NO_QUAL)), n_seq;
+		mm_bseq1_t *seq;
+		while ((seq = mm_bseq_read3(fp, batch, with_qual, 0, 0, &n_seq)) != 0) {
+			int *n_reg = (int*)calloc(5 * (size_t)n_seq, sizeof(int));
+			int *seg_off = n_reg + n_seq, *n_seg = seg_off + n_seq, *rep_len = n_seg + n_seq, *frag_gap = rep_len + n_seq;
+			mm_reg1_t **reg = (mm_reg1_t**)calloc(n_seq, sizeof(mm_reg1_t*));
+			int j;
+			for (i = 0; i < n_seq; ++i) seg_off[i] = i, n_seg[i] = 1;
+			if (mm_gpu_map_batch(n_seq, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {
+				fprintf(stderr, "mm_gpu_map_batch: %s\n", mm2amd_last_error());
+				return 2;
+			}
+			if (print_stats) {
+				double v[16];
+				int nv = mm2amd_last_stats(v, 16);
+				fprintf(stderr, "[dropin] backend=%s reads=%d", mm2amd_backend_name(), n_seq);
+				for (i = 0; i < nv; ++i) fprintf(stderr, " %.4g", v[i]);
+				fputc('\n', stderr);
+			}
+			for (i = 0; i < n_seq; ++i) { /* output, as step 2 of worker_pipeline (map.c:585-636) for single-segment reads */
+				mm_bseq1_t *t = &seq[i];
+				if (n_reg[i] > 0) {
+					for (j = 0; j < n_reg[i]; ++j) {
+						const mm_reg1_t *r = &reg[i][j];
+						if ((mopt.flag & MM_F_NO_PRINT_2ND) && r->id != r->parent) continue;
+						if (mopt.flag & MM_F_OUT_SAM) mm_write_sam3(&str, mi, t, 0, j, 1, &n_reg[i], (const mm_reg1_t*const*)&reg[i], 0, mopt.flag, rep_len[i]);
+						else mm_write_paf4(&str, mi, t, r, 0, mopt.flag, rep_len[i], 1, 0);
+						mm_err_puts(str.s);
+					}
+				} else if ((mopt.flag & MM_F_PAF_NO_HIT) || ((mopt.flag & MM_F_OUT_SAM) && !(mopt.flag & MM_F_SAM_HIT_ONLY))) {
+					if (mopt.flag & MM_F_OUT_SAM) mm_write_sam3(&str, mi, t, 0, -1, 1, &n_reg[i], (const mm_reg1_t*const*)&reg[i], 0, mopt.flag, rep_len[i]);
+					else mm_write_paf4(&str, mi, t, 0, 0, mopt.flag, rep_len[i], 1, 0);
+					mm_err_puts(str.s);
+				}
+				for (j = 0; j < n_reg[i]; ++j) free(reg[i][j].p);
+				free(reg[i]);
+				free(t->seq); free(t->name);
+				if (t->qual) free(t->qual);
+				if (t->comment) free(t->comment);
+			}
+			free(reg); free(n_reg); free(seq);
+		}
+		mm_bseq_close(fp);
+		mm_gpu_destroy();
+		mm_idx_destroy(mi);
+	}
+	mm_idx_reader_close(rd);
+	free(str.s);
+	if (fflush(stdout) == EOF) return 1;
+	return 0;
+}

@@ -1,0 +1,92 @@
+"""Seeded synthetic workloads shaped like BASELINE.json's configs, at any scale.
+
+    python tests/synth.py ont  OUTDIR --ref-mb 2 --reads 200 [--seed 11]
+    python tests/synth.py hifi OUTDIR --ref-mb 2 --reads 100
+
+Reference: uniform i.i.d. ACGT in contigs chr1..N.  Reads: uniformly placed substrings, half reverse-complemented,
+per-base error split 1/3 substitution, 1/3 insertion, 1/3 deletion.  Vectorised so that the full-size workloads
+(3 Gb, 100k reads) are generated in tens of seconds."""
+import argparse
+import os
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+
+def gen_reference(rng, total, n_contig):
+    per = total // n_contig
+    return [rng.integers(0, 4, per, dtype=np.uint8) for _ in range(n_contig)]
+
+
+def mutate_read(rng, s, err):
+    """s: uint8 codes 0..3; returns mutated copy."""
+    n = len(s)
+    r = rng.random(n)
+    kind = rng.integers(0, 3, n)
+    sub = (r < err) & (kind == 0)
+    ins = (r < err) & (kind == 1)
+    dele = (r < err) & (kind == 2)
+    out = s.copy()
+    out[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
+    keep = ~dele
+    # insertion: emit a random base before the kept base
+    reps = np.where(ins, 2, 1)[keep]
+    base = np.repeat(out[keep], reps)
+    idx = np.cumsum(reps) - reps  # first slot of each group
+    ins_kept = ins[keep]
+    base[idx[ins_kept]] = rng.integers(0, 4, int(ins_kept.sum()), dtype=np.uint8)
+    return base
+
+
+def gen_reads(rng, contigs, n_reads, mean_len, sd_len, err, min_len=1000):
+    reads = []
+    lens = np.clip(rng.normal(mean_len, sd_len, n_reads).astype(np.int64), min_len, None)
+    for i in range(n_reads):
+        c = int(rng.integers(0, len(contigs)))
+        L = int(min(lens[i], len(contigs[c])))
+        st = int(rng.integers(0, len(contigs[c]) - L + 1))
+        s = contigs[c][st:st + L]
+        if rng.random() < 0.5:
+            s = COMP[s[::-1]]
+        reads.append(mutate_read(rng, s, err))
+    return reads
+
+
+def write_fasta(path, names, seqs, width=0):
+    with open(path, "wb") as f:
+        for nm, s in zip(names, seqs):
+            f.write(b">" + nm.encode() + b"\n")
+            f.write(ACGT[s].tobytes())
+            f.write(b"\n")
+
+
+PROFILES = {"ont": (10000, 1000, 0.12), "hifi": (15000, 1500, 0.005)}
+
+
+def make(kind, outdir, ref_mb, n_reads, seed=11, n_contig=None):
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    total = int(ref_mb * 1e6)
+    if n_contig is None:
+        n_contig = max(1, min(24, total // 1000000))
+    contigs = gen_reference(rng, total, n_contig)
+    mean, sd, err = PROFILES[kind]
+    reads = gen_reads(rng, contigs, n_reads, mean, sd, err)
+    ref = os.path.join(outdir, "ref.fa")
+    rd = os.path.join(outdir, "reads.fa")
+    write_fasta(ref, ["chr%d" % (i + 1) for i in range(n_contig)], contigs)
+    write_fasta(rd, ["read%d" % i for i in range(n_reads)], reads)
+    return ref, rd, contigs, reads
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kind", choices=list(PROFILES))
+    ap.add_argument("outdir")
+    ap.add_argument("--ref-mb", type=float, default=2.0)
+    ap.add_argument("--reads", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=11)
+    a = ap.parse_args()
+    ref, rd, _, _ = make(a.kind, a.outdir, a.ref_mb, a.reads, a.seed)
+    print(ref, rd)
