@@ -1,0 +1,176 @@
+// The product's Backend: hand-written gfx950 kernels (seed_chain.hip, ksw_extd2.hip) plus the buffer management
+// around them.  There is deliberately no CPU path here: constructing it without a usable HIP device throws.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include "backend.hpp"
+#include "chain_host.hpp"
+#include "device_ctx.hpp"
+#include "ksw_host.hpp"
+#include "seed_chain_dev.hpp"
+#include "threads.hpp"
+#include <thread>
+
+namespace mm2amd {
+
+namespace {
+
+template <typename T>
+void upload(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
+{
+	d.ensure(h.size() ? h.size() : 1, 1.0);
+	if (!h.empty()) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+class HipBackend : public Backend {
+public:
+	explicit HipBackend(const FlatIndex &fi) : fi_(fi)
+	{
+		DeviceCtx &d = device_ctx();
+		std::lock_guard<std::mutex> lk(d.mu);
+		ensure_device(d);
+		stream_ = d.stream;
+		ksw_.n_cu = d.n_cu;
+		n_threads_ = std::max(1u, std::thread::hardware_concurrency());
+		// device mirror of the index (flat minimizer table + packed reference)
+		upload(d_bucket_start_, fi.bucket_start, stream_);
+		upload(d_keys_, fi.keys, stream_);
+		upload(d_val_off_, fi.val_off, stream_);
+		upload(d_pos_, fi.pos, stream_);
+		const size_t s_words = (fi.sum_len + 7) / 8;
+		d_S_.ensure(s_words ? s_words : 1, 1.0);
+		if (s_words) HIP_CHECK(hipMemcpyAsync(d_S_.p, fi.S, s_words * 4, hipMemcpyHostToDevice, stream_));
+		HIP_CHECK(hipStreamSynchronize(stream_));
+		I_.bucket_start = d_bucket_start_.p, I_.keys = d_keys_.p, I_.val_off = d_val_off_.p, I_.pos = d_pos_.p, I_.S = d_S_.p;
+		I_.bucket_bits = fi.bucket_bits, I_.key_shift = fi.key_shift;
+	}
+
+	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
+	{
+		const size_t n = reads.size();
+		n_reads_ = (int)n;
+		seq_off_.resize(n + 1);
+		seq_off_[0] = 0;
+		for (size_t i = 0; i < n; ++i) seq_off_[i + 1] = seq_off_[i] + (uint64_t)reads[i].len;
+		const uint64_t total = seq_off_[n];
+		qpool_off.resize(n);
+		for (size_t i = 0; i < n; ++i) qpool_off[i] = 2 * seq_off_[i];
+		char *h = h_ascii_.ensure(total + 1);
+		parallel_for(n_threads_, (long)n, [&](long i, int) { memcpy(h + seq_off_[i], reads[i].seq, reads[i].len); }, 64);
+		d_ascii_.ensure(total + 1);
+		d_qpool_.ensure(2 * total + 16);
+		d_seq_off_.ensure(n + 1);
+		HIP_CHECK(hipMemcpyAsync(d_ascii_.p, h, total, hipMemcpyHostToDevice, stream_));
+		HIP_CHECK(hipMemcpyAsync(d_seq_off_.p, seq_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+		B_ = SeedChainBuffers();
+		B_.n_reads = n_reads_, B_.seq_off = d_seq_off_.p, B_.ascii = d_ascii_.p, B_.qpool = d_qpool_.p;
+		launch_encode(B_, stream_);
+	}
+
+	void seed_chain(const SeedChainParams &P, std::vector<ReadChains> &out) override
+	{
+		const size_t n = (size_t)n_reads_;
+		out.clear();
+		out.resize(n);
+		if (n == 0) return;
+		if (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY)) throw std::invalid_argument("[mm2amd] --for-only/--rev-only are not implemented on the device path");
+		// 1. minimizers: count, scan, emit
+		d_mz_cnt_.ensure(n);
+		B_.mz_cnt = d_mz_cnt_.p;
+		launch_sketch(B_, P, false, stream_);
+		h_cnt_.resize(n);
+		HIP_CHECK(hipMemcpyAsync(h_cnt_.data(), d_mz_cnt_.p, n * 4, hipMemcpyDeviceToHost, stream_));
+		HIP_CHECK(hipStreamSynchronize(stream_));
+		mz_off_.resize(n + 1);
+		mz_off_[0] = 0;
+		for (size_t i = 0; i < n; ++i) mz_off_[i + 1] = mz_off_[i] + h_cnt_[i];
+		const uint64_t n_mz = mz_off_[n];
+		d_mz_off_.ensure(n + 1);
+		HIP_CHECK(hipMemcpyAsync(d_mz_off_.p, mz_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+		d_mz_x_.ensure(n_mz + 1), d_mz_y_.ensure(n_mz + 1);
+		d_sd_n_.ensure(n_mz + 1), d_sd_off_.ensure(n_mz + 1), d_sd_aoff_.ensure(n_mz + 1), d_sd_qpos_.ensure(n_mz + 1), d_sd_info_.ensure(n_mz + 1);
+		B_.mz_off = d_mz_off_.p, B_.mz_x = d_mz_x_.p, B_.mz_y = d_mz_y_.p;
+		B_.sd_n = d_sd_n_.p, B_.sd_off = d_sd_off_.p, B_.sd_aoff = d_sd_aoff_.p, B_.sd_qpos = d_sd_qpos_.p, B_.sd_info = d_sd_info_.p;
+		launch_sketch(B_, P, true, stream_);
+		// 2. seeds: probe, filter, count anchors
+		d_n_anchor_.ensure(n), d_n_minipos_.ensure(n), d_n_seedhit_.ensure(n), d_rep_len_.ensure(n);
+		B_.n_anchor = d_n_anchor_.p, B_.n_minipos = d_n_minipos_.p, B_.n_seedhit = d_n_seedhit_.p, B_.rep_len = d_rep_len_.p;
+		launch_seed_collect(B_, I_, P, stream_);
+		h_na_.resize(n), h_nmp_.resize(n), h_rep_.resize(n);
+		HIP_CHECK(hipMemcpyAsync(h_na_.data(), d_n_anchor_.p, n * 4, hipMemcpyDeviceToHost, stream_));
+		HIP_CHECK(hipMemcpyAsync(h_nmp_.data(), d_n_minipos_.p, n * 4, hipMemcpyDeviceToHost, stream_));
+		HIP_CHECK(hipMemcpyAsync(h_rep_.data(), d_rep_len_.p, n * 4, hipMemcpyDeviceToHost, stream_));
+		HIP_CHECK(hipStreamSynchronize(stream_));
+		a_off_.resize(n + 1), mp_off_.resize(n + 1);
+		a_off_[0] = mp_off_[0] = 0;
+		for (size_t i = 0; i < n; ++i) a_off_[i + 1] = a_off_[i] + h_na_[i], mp_off_[i + 1] = mp_off_[i] + h_nmp_[i];
+		const uint64_t n_a = a_off_[n], n_mp = mp_off_[n];
+		d_a_off_.ensure(n + 1), d_mp_off_.ensure(n + 1);
+		HIP_CHECK(hipMemcpyAsync(d_a_off_.p, a_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+		HIP_CHECK(hipMemcpyAsync(d_mp_off_.p, mp_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+		d_anchors_.ensure(n_a + 1), d_minipos_.ensure(n_mp + 1), d_f_.ensure(n_a + 1), d_p_.ensure(n_a + 1), d_t_.ensure(n_a + 1);
+		B_.a_off = d_a_off_.p, B_.mp_off = d_mp_off_.p, B_.anchors = d_anchors_.p, B_.mini_pos = d_minipos_.p;
+		B_.f = d_f_.p, B_.p = d_p_.p, B_.t = d_t_.p;
+		// 3. anchors: expand, sort, chain
+		launch_seed_expand(B_, I_, P, stream_);
+		launch_anchor_sort(B_, stream_);
+		launch_chain_fill(B_, P, stream_);
+		// 4. back to the host for the (scalar, order-sensitive) backtrack
+		Anchor *ha = h_anchors_.ensure(n_a + 1);
+		int32_t *hf = h_f_.ensure(n_a + 1), *hp = h_p_.ensure(n_a + 1);
+		uint64_t *hmp = h_minipos_.ensure(n_mp + 1);
+		if (n_a) {
+			HIP_CHECK(hipMemcpyAsync(ha, d_anchors_.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost, stream_));
+			HIP_CHECK(hipMemcpyAsync(hf, d_f_.p, n_a * 4, hipMemcpyDeviceToHost, stream_));
+			HIP_CHECK(hipMemcpyAsync(hp, d_p_.p, n_a * 4, hipMemcpyDeviceToHost, stream_));
+		}
+		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, d_minipos_.p, n_mp * 8, hipMemcpyDeviceToHost, stream_));
+		HIP_CHECK(hipStreamSynchronize(stream_));
+		const int max_drop = P.is_cdna ? INT32_MAX : P.bw;
+		std::vector<ChainScratch> scratch(n_threads_);
+		parallel_for(n_threads_, (long)n, [&](long i, int tid) {
+			ReadChains &c = out[i];
+			c.rep_len = h_rep_[i];
+			c.mini_pos.assign(hmp + mp_off_[i], hmp + mp_off_[i + 1]);
+			const int64_t na = (int64_t)(a_off_[i + 1] - a_off_[i]);
+			chain_backtrack_compact(na, ha + a_off_[i], hf + a_off_[i], hp + a_off_[i], P.min_cnt, P.min_chain_score, max_drop, c.u, c.a, scratch[tid]);
+		});
+	}
+
+	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) override
+	{
+		res.resize(jobs.size());
+		ksw_.run(jobs, d_qpool_.p, nullptr, d_S_.p, sc, res.data(), cigar, stream_);
+	}
+
+private:
+	const FlatIndex &fi_;
+	hipStream_t stream_ = nullptr;
+	int n_threads_ = 1, n_reads_ = 0;
+	DevIndex I_{};
+	SeedChainBuffers B_{};
+	KswRunner ksw_;
+	DevBuf<uint32_t> d_bucket_start_, d_val_off_, d_S_;
+	DevBuf<uint64_t> d_keys_, d_pos_;
+	DevBuf<char> d_ascii_;
+	DevBuf<uint8_t> d_qpool_;
+	DevBuf<uint64_t> d_seq_off_, d_mz_off_, d_a_off_, d_mp_off_, d_mz_x_, d_mz_y_, d_minipos_;
+	DevBuf<uint32_t> d_mz_cnt_, d_sd_n_, d_sd_off_, d_sd_aoff_, d_sd_qpos_, d_sd_info_, d_n_anchor_, d_n_minipos_, d_n_seedhit_;
+	DevBuf<int32_t> d_rep_len_, d_f_, d_p_, d_t_;
+	DevBuf<Anchor> d_anchors_;
+	PinBuf<char> h_ascii_;
+	PinBuf<Anchor> h_anchors_;
+	PinBuf<int32_t> h_f_, h_p_;
+	PinBuf<uint64_t> h_minipos_;
+	std::vector<uint64_t> seq_off_, mz_off_, a_off_, mp_off_;
+	std::vector<uint32_t> h_cnt_, h_na_, h_nmp_;
+	std::vector<int32_t> h_rep_;
+};
+
+} // namespace
+
+Backend *make_backend(const FlatIndex &fi, int /*device*/) { return new HipBackend(fi); }
+const char *backend_name() { return "hip:gfx950"; }
+
+} // namespace mm2amd

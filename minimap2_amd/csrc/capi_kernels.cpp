@@ -5,47 +5,21 @@
 #include <cstring>
 #include "../../include/mm2amd.h"
 #include "hip_util.hpp"
+#include "device_ctx.hpp"
 #include "ksw_host.hpp"
 
+namespace mm2amd { int capi_fail(int code, const std::string &msg); }
 using namespace mm2amd;
 
 namespace {
 
-thread_local std::string g_err;
+int fail(int code, const std::string &msg) { return capi_fail(code, msg); }
 
-int fail(int code, const std::string &msg) { g_err = msg; return code; }
-
-struct Device {
-	std::mutex mu;
-	bool ready = false;
-	hipStream_t stream = nullptr;
+struct KernelApiState { // buffers of the kernel-level entry points
 	KswRunner ksw;
 	DevBuf<uint8_t> d_qpool, d_tpool;
 };
-
-Device &dev()
-{
-	static Device d;
-	return d;
-}
-
-// Bring up device 0 (or $MM2AMD_DEVICE); throws HipError with ENODEV semantics if impossible.
-void ensure_device(Device &d)
-{
-	if (d.ready) return;
-	int n = 0;
-	hipError_t e = hipGetDeviceCount(&n);
-	if (e != hipSuccess || n <= 0) throw HipError("[mm2amd] no HIP device visible: this library has no CPU path");
-	int id = 0;
-	if (const char *s = getenv("MM2AMD_DEVICE")) id = atoi(s);
-	else if (const char *s = getenv("LOCAL_RANK")) id = atoi(s) % n;
-	HIP_CHECK(hipSetDevice(id));
-	hipDeviceProp_t prop;
-	HIP_CHECK(hipGetDeviceProperties(&prop, id));
-	d.ksw.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-	d.ready = true;
-}
+KernelApiState &kstate() { static KernelApiState s; return s; }
 
 template <typename F>
 int guarded(F &&f)
@@ -64,9 +38,6 @@ int guarded(F &&f)
 
 extern "C" {
 
-const char *mm2amd_last_error(void) { return g_err.c_str(); }
-int mm2amd_version(void) { return 1; }
-
 int mm2amd_device_count(void)
 {
 	int n = 0;
@@ -82,9 +53,11 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 	if (n_jobs < 0 || (n_jobs > 0 && (!jobs || !res)) || !mat || m != 5) return fail(MM2AMD_EINVAL, "[mm2amd] ksw_extd2_batch: bad arguments (m must be 5)");
 	if (n_jobs == 0) return 0;
 	return guarded([&]() -> int {
-		Device &d = dev();
-		std::lock_guard<std::mutex> lk(d.mu);
-		ensure_device(d);
+		DeviceCtx &dc = device_ctx();
+		std::lock_guard<std::mutex> lk(dc.mu);
+		ensure_device(dc);
+		KernelApiState &d = kstate();
+		d.ksw.n_cu = dc.n_cu;
 		std::vector<KswJob> dj(n_jobs);
 		size_t qtot = 0, ttot = 0, ctot = 0;
 		for (int i = 0; i < n_jobs; ++i) {
@@ -102,14 +75,14 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 			if (jobs[i].tlen > 0) memcpy(&ht[dj[i].t_off], jobs[i].target, jobs[i].tlen);
 		}
 		d.d_qpool.ensure(qtot + 1), d.d_tpool.ensure(ttot + 1);
-		HIP_CHECK(hipMemcpyAsync(d.d_qpool.p, hq.data(), qtot + 1, hipMemcpyHostToDevice, d.stream));
-		HIP_CHECK(hipMemcpyAsync(d.d_tpool.p, ht.data(), ttot + 1, hipMemcpyHostToDevice, d.stream));
+		HIP_CHECK(hipMemcpyAsync(d.d_qpool.p, hq.data(), qtot + 1, hipMemcpyHostToDevice, dc.stream));
+		HIP_CHECK(hipMemcpyAsync(d.d_tpool.p, ht.data(), ttot + 1, hipMemcpyHostToDevice, dc.stream));
 		KswScoring sc;
 		memcpy(sc.mat, mat, 25);
 		sc.m = m, sc.q = gapo, sc.e = gape, sc.q2 = gapo2, sc.e2 = gape2, sc.pad[0] = sc.pad[1] = 0;
 		std::vector<KswRes> r(n_jobs);
 		std::vector<uint32_t> cig;
-		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cig, d.stream);
+		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cig, dc.stream);
 		if (cig.size() > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
 		if (!cig.empty()) memcpy(cigar_pool, cig.data(), cig.size() * sizeof(uint32_t));
 		for (int i = 0; i < n_jobs; ++i) {

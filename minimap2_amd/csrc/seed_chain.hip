@@ -1,0 +1,531 @@
+// Seeding and chaining kernels for gfx950: the device counterparts of mm_sketch (sketch.c:77-143),
+// mm_seed_mz_flt / mm_collect_matches (seed.c:5-132), collect_seed_hits (map.c:168-204) and the fill loop of
+// mg_lchain_dp (lchain.c:169-207).
+//
+// These stages are integer, branchy and latency-bound (random index probes, sequential state machines), not
+// bandwidth- or FLOP-bound, so the mapping favours many independent reads in flight over intra-read tricks:
+//   * sketch        : one lane per read runs the window state machine; the ring buffer lives in private memory.
+//   * seed collect  : one wavefront per read; lanes stride over the read's minimizers for the index probes
+//                     (2-3 dependent 32-64 B sector reads each), ballots/prefix sums do the order-preserving compaction.
+//   * anchor sort   : one lane per read replays the reference's unstable in-place radix sort (exact_rsort.hpp).
+//   * chain fill    : one wavefront per read; 64 predecessors are scored per step, then the reference's sequential
+//                     rules (running maximum, skip counter, early exit) are resolved with ballots and a prefix max.
+#include <hip/hip_runtime.h>
+#include "hip_util.hpp"
+#include "seed_chain_dev.hpp"
+
+namespace mm2amd {
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__constant__ uint8_t c_nt4[256];
+extern const uint8_t kNt4Table[256];
+static bool g_nt4_uploaded = false;
+
+static void upload_tables(hipStream_t s)
+{
+	if (g_nt4_uploaded) return;
+	HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_nt4), kNt4Table, 256, 0, hipMemcpyHostToDevice, s));
+	g_nt4_uploaded = true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ASCII -> nt4 forward and reverse complement (align.c:1056-1061)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) encode_kernel(SeedChainBuffers B)
+{
+	const int r = blockIdx.x;
+	const uint64_t o = B.seq_off[r];
+	const int64_t len = (int64_t)(B.seq_off[r + 1] - o);
+	const char *src = B.ascii + o;
+	uint8_t *f = B.qpool + 2 * o;
+	for (int64_t j = threadIdx.x; j < len; j += blockDim.x) {
+		const uint8_t c = c_nt4[(uint8_t)src[j]];
+		f[j] = c;
+		f[2 * len - 1 - j] = c < 4 ? 3 - c : 4;
+	}
+}
+
+void launch_encode(const SeedChainBuffers &B, void *stream)
+{
+	upload_tables((hipStream_t)stream);
+	hipLaunchKernelGGL(encode_kernel, dim3(B.n_reads), dim3(256), 0, (hipStream_t)stream, B);
+	HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// (w,k)-minimizers (sketch.c:77-143), one lane per read
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t key, uint64_t mask) // hash64, sketch.c:28-38
+{
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask;
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask;
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+template <bool EMIT, int WMAX>
+__global__ void __launch_bounds__(64) sketch_kernel(SeedChainBuffers B, int w, int k, int is_hpc)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= B.n_reads) return;
+	const uint64_t o = B.seq_off[r];
+	const int len = (int)(B.seq_off[r + 1] - o);
+	const uint8_t *seq = B.qpool + 2 * o; // forward nt4 codes
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	uint64_t kmer0 = 0, kmer1 = 0, min_x = UINT64_MAX, min_y = UINT64_MAX;
+	uint64_t bx[WMAX], by[WMAX];
+	int hq[32], hq_front = 0, hq_count = 0;
+	int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
+	uint32_t n_out = 0;
+	uint64_t *ox = nullptr, *oy = nullptr;
+	if (EMIT) ox = B.mz_x + B.mz_off[r], oy = B.mz_y + B.mz_off[r];
+#define EMIT_MZ(X, Y) do { if (EMIT) { ox[n_out] = (X); oy[n_out] = (Y); } ++n_out; } while (0)
+	for (int j = 0; j < w; ++j) bx[j] = by[j] = UINT64_MAX;
+	for (int i = 0; i < len; ++i) {
+		const int c = seq[i];
+		uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
+		if (c < 4) {
+			if (is_hpc) {
+				int run = 1;
+				if (i + 1 < len && seq[i + 1] == c) {
+					for (run = 2; i + run < len; ++run) if (seq[i + run] != c) break;
+					i += run - 1;
+				}
+				hq[(hq_count++ + hq_front) & 0x1f] = run;
+				kmer_span += run;
+				if (hq_count > k) { kmer_span -= hq[hq_front++]; hq_front &= 0x1f; --hq_count; }
+			} else kmer_span = l + 1 < k ? l + 1 : k;
+			kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+			kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+			if (kmer0 == kmer1) continue; // strand-symmetric k-mer: no slot is consumed (sketch.c:108)
+			const int z = kmer0 < kmer1 ? 0 : 1;
+			++l;
+			if (l >= k && kmer_span < 256) {
+				ix = mix64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+				iy = (uint64_t)(uint32_t)i << 1 | (uint64_t)z; // rid is 0 for reads
+			}
+		} else l = 0, hq_count = hq_front = 0, kmer_span = 0;
+		bx[buf_pos] = ix, by[buf_pos] = iy;
+		if (l == w + k - 1 && min_x != UINT64_MAX) { // first full window (:117-122)
+			for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j] && by[j] != min_y) EMIT_MZ(bx[j], by[j]);
+			for (int j = 0; j < buf_pos; ++j)     if (min_x == bx[j] && by[j] != min_y) EMIT_MZ(bx[j], by[j]);
+		}
+		if (ix <= min_x) {
+			if (l >= w + k && min_x != UINT64_MAX) EMIT_MZ(min_x, min_y);
+			min_x = ix, min_y = iy, min_pos = buf_pos;
+		} else if (buf_pos == min_pos) {
+			if (l >= w + k - 1 && min_x != UINT64_MAX) EMIT_MZ(min_x, min_y);
+			min_x = UINT64_MAX;
+			for (int j = buf_pos + 1; j < w; ++j) if (min_x >= bx[j]) min_x = bx[j], min_y = by[j], min_pos = j;
+			for (int j = 0; j <= buf_pos; ++j)    if (min_x >= bx[j]) min_x = bx[j], min_y = by[j], min_pos = j;
+			if (l >= w + k - 1 && min_x != UINT64_MAX) {
+				for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j] && min_y != by[j]) EMIT_MZ(bx[j], by[j]);
+				for (int j = 0; j <= buf_pos; ++j)    if (min_x == bx[j] && min_y != by[j]) EMIT_MZ(bx[j], by[j]);
+			}
+		}
+		if (++buf_pos == w) buf_pos = 0;
+	}
+	if (min_x != UINT64_MAX) EMIT_MZ(min_x, min_y);
+#undef EMIT_MZ
+	if (!EMIT) B.mz_cnt[r] = n_out;
+}
+
+void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, bool emit, void *stream)
+{
+	const dim3 grid((B.n_reads + 63) / 64), block(64);
+	hipStream_t s = (hipStream_t)stream;
+	if (P.w <= 32) {
+		if (emit) hipLaunchKernelGGL((sketch_kernel<true, 32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+		else hipLaunchKernelGGL((sketch_kernel<false, 32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+	} else {
+		if (emit) hipLaunchKernelGGL((sketch_kernel<true, 256>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+		else hipLaunchKernelGGL((sketch_kernel<false, 256>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+	}
+	HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Seed collection, one wavefront per read
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t idx_lookup(const DevIndex &I, uint64_t hash, uint32_t *off) // mm_idx_get, index.c:93-110
+{
+	const uint64_t b = hash >> I.key_shift;
+	if (b >= (1ull << I.bucket_bits)) return 0;
+	const uint32_t s = I.bucket_start[b], e = I.bucket_start[b + 1];
+	for (uint32_t i = s; i < e; ++i)
+		if (I.keys[i] == hash) { *off = I.val_off[i]; return I.val_off[i + 1] - I.val_off[i]; }
+	return 0;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int popc_below(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
+
+constexpr int HIST_N = 2048;
+constexpr uint32_t SD_TANDEM = 1u << 8, SD_FLT = 1u << 9;
+
+// max-heap sift-down on (n<<32 | index) keys, used by the rare high-occurrence thinning (seed.c:56-96)
+__device__ void heap_down(uint64_t *h, int i, int n)
+{
+	int k = i;
+	const uint64_t tmp = h[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && h[k] < h[k + 1]) ++k;
+		if (h[k] < tmp) break;
+		h[i] = h[k]; i = k;
+	}
+	h[i] = tmp;
+}
+
+__global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, DevIndex I, SeedChainParams P)
+{
+	__shared__ uint32_t s_hist[4][HIST_N];
+	const int wave = threadIdx.x >> 6, lane = lane_id();
+	const int r = blockIdx.x * 4 + wave;
+	if (r >= B.n_reads) return;
+	const uint64_t mo = B.mz_off[r];
+	uint64_t *mx = B.mz_x + mo, *my = B.mz_y + mo;
+	uint32_t *sd_n = B.sd_n + mo, *sd_off = B.sd_off + mo, *sd_aoff = B.sd_aoff + mo, *sd_qpos = B.sd_qpos + mo, *sd_info = B.sd_info + mo;
+	int n = (int)B.mz_cnt[r];
+	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
+	uint32_t *hist = s_hist[wave];
+
+	// ---- query-side filter of over-represented minimizers (mm_seed_mz_flt, seed.c:5-28) ----
+	if (P.q_occ_frac > 0.0f && n > P.mid_occ && P.mid_occ > 0) {
+		for (int i = lane; i < HIST_N; i += 64) hist[i] = 0;
+		WAVE_SYNC();
+		for (int i = lane; i < n; i += 64) atomicAdd(&hist[(uint32_t)((mx[i] * 0x9E3779B97F4A7C15ull) >> 53)], 1u);
+		WAVE_SYNC();
+		const float thr = (float)n * P.q_occ_frac;
+		bool hot = false;
+		for (int i = lane; i < HIST_N; i += 64) { const uint32_t c = hist[i]; hot |= ((int)c > P.mid_occ && (float)c > thr); }
+		if (__ballot(hot)) { // exact counts, only for minimizers that fall into a crowded bucket
+			// pass 1: decide on the untouched list
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + lane;
+				if (i < n) {
+					const uint64_t x = mx[i];
+					bool keep = true;
+					const uint32_t c = hist[(uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 53)];
+					if ((int)c > P.mid_occ && (float)c > thr) {
+						int cnt = 0;
+						for (int j = 0; j < n; ++j) cnt += (mx[j] == x);
+						keep = !(cnt > P.mid_occ && (float)cnt > thr);
+					}
+					sd_info[i] = keep ? 1u : 0u;
+				}
+			}
+			WAVE_SYNC();
+			// pass 2: order-preserving compaction (destination never passes the chunk being read)
+			int dst = 0;
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + lane;
+				uint64_t x = 0, y = 0;
+				bool keep = false;
+				if (i < n) { x = mx[i], y = my[i]; keep = sd_info[i] != 0; }
+				const unsigned long long km = __ballot(keep);
+				WAVE_SYNC();
+				if (keep) { const int d = dst + popc_below(km, lane); mx[d] = x, my[d] = y; }
+				dst += __popcll(km);
+				WAVE_SYNC();
+			}
+			n = dst;
+		}
+	}
+	// ---- index probes (mm_seed_collect_all, seed.c:30-52); entries without a hit get n = 0 ----
+	for (int i = lane; i < n; i += 64) {
+		const uint64_t x = mx[i];
+		uint32_t off = 0;
+		const uint32_t cnt = idx_lookup(I, x >> 8, &off);
+		uint32_t info = (uint32_t)(x & 0xff);
+		if (i > 0 && x >> 8 == mx[i - 1] >> 8) info |= SD_TANDEM;
+		if (i < n - 1 && x >> 8 == mx[i + 1] >> 8) info |= SD_TANDEM;
+		sd_n[i] = cnt, sd_off[i] = off, sd_info[i] = info, sd_qpos[i] = (uint32_t)my[i];
+	}
+	WAVE_SYNC();
+	// ---- compact to the seeds that hit (the reference's m[] array), preserving order ----
+	int n_m0 = 0;
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + lane;
+		uint32_t cnt = 0, off = 0, info = 0, qp = 0;
+		if (i < n) cnt = sd_n[i], off = sd_off[i], info = sd_info[i], qp = sd_qpos[i];
+		const unsigned long long hm = __ballot(cnt > 0);
+		WAVE_SYNC();
+		if (cnt > 0) { const int d = n_m0 + popc_below(hm, lane); sd_n[d] = cnt, sd_off[d] = off, sd_info[d] = info, sd_qpos[d] = qp; }
+		n_m0 += __popcll(hm);
+		WAVE_SYNC();
+	}
+	// ---- occurrence filter (seed.c:106-112) ----
+	int n_high = 0;
+	for (int i = lane; i < n_m0; i += 64) n_high += sd_n[i] > (uint32_t)P.mid_occ;
+	for (int o = 32; o > 0; o >>= 1) n_high += __shfl_xor(n_high, o, 64);
+	if (n_high > 0) {
+		if (P.occ_dist > 0 && P.max_max_occ > P.mid_occ) {
+			if (n_m0 > 1 && lane == 0) { // rare, sequential: keep ~1 low-occurrence seed per occ_dist bases in each high-occurrence streak
+				uint64_t hb[128];
+				int last0 = -1;
+				for (int i = 0; i <= n_m0; ++i) {
+					if (i == n_m0 || sd_n[i] <= (uint32_t)P.mid_occ) {
+						if (i - last0 > 1) {
+							const int ps = last0 < 0 ? 0 : (int)(sd_qpos[last0] >> 1), pe = i == n_m0 ? qlen : (int)(sd_qpos[i] >> 1);
+							const int st = last0 + 1, en = i;
+							int keep = (int)((double)(pe - ps) / P.occ_dist + .499), j, kk;
+							if (keep > 0) {
+								if (keep > 128) keep = 128;
+								for (j = st, kk = 0; j < en && kk < keep; ++j, ++kk) hb[kk] = (uint64_t)sd_n[j] << 32 | (uint32_t)j;
+								for (int q = kk >> 1; q-- > 0;) heap_down(hb, q, kk);
+								for (; j < en; ++j)
+									if ((int32_t)sd_n[j] < (int32_t)(hb[0] >> 32)) { hb[0] = (uint64_t)sd_n[j] << 32 | (uint32_t)j; heap_down(hb, 0, kk); }
+								for (j = 0; j < kk; ++j) sd_info[(uint32_t)hb[j]] |= SD_FLT;
+							}
+							for (j = st; j < en; ++j) sd_info[j] ^= SD_FLT;
+							for (j = st; j < en; ++j) if (sd_n[j] > (uint32_t)P.max_max_occ) sd_info[j] |= SD_FLT;
+						}
+						last0 = i;
+					}
+				}
+			}
+		} else {
+			for (int i = lane; i < n_m0; i += 64) if (sd_n[i] > (uint32_t)P.mid_occ) sd_info[i] |= SD_FLT;
+		}
+		WAVE_SYNC();
+	}
+	// ---- repetitive length (seed.c:117-123,129): only filtered seeds contribute ----
+	int rep_len = 0;
+	if (n_high > 0 && lane == 0) {
+		int rep_st = 0, rep_en = 0;
+		for (int i = 0; i < n_m0; ++i) {
+			if (!(sd_info[i] & SD_FLT)) continue;
+			const int en = (int)(sd_qpos[i] >> 1) + 1, st = en - (int)(sd_info[i] & 0xff);
+			if (st > rep_en) rep_len += rep_en - rep_st, rep_st = st, rep_en = en;
+			else rep_en = en;
+		}
+		rep_len += rep_en - rep_st;
+	}
+	rep_len = __shfl(rep_len, 0, 64);
+	// ---- kept seeds: anchor offsets (exclusive prefix of n) and their rank for mini_pos ----
+	uint32_t n_a = 0, n_kept = 0;
+	for (int base = 0; base < n_m0; base += 64) {
+		const int i = base + lane;
+		const bool kept = i < n_m0 && !(sd_info[i] & SD_FLT);
+		uint32_t c = kept ? sd_n[i] : 0, incl = c;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+		const unsigned long long km = __ballot(kept);
+		if (i < n_m0) sd_aoff[i] = kept ? n_a + incl - c : 0xffffffffu;
+		// rank among kept seeds goes into the high bits of info (bits 10..31): up to 4M seeds per read
+		if (kept) sd_info[i] = (sd_info[i] & 0x3ffu) | ((n_kept + (uint32_t)popc_below(km, lane)) << 10);
+		n_a += __shfl(incl, 63, 64);
+		n_kept += (uint32_t)__popcll(km);
+	}
+	if (lane == 0) {
+		B.n_anchor[r] = n_a, B.n_minipos[r] = n_kept, B.n_seedhit[r] = (uint32_t)n_m0, B.rep_len[r] = rep_len;
+	}
+}
+
+void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream)
+{
+	hipLaunchKernelGGL(seed_collect_kernel, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, I, P);
+	HIP_CHECK(hipGetLastError());
+}
+
+// anchors and mini_pos from the kept seeds (map.c:176-200, seed.c:124); one wavefront per read
+__global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, DevIndex I, SeedChainParams P)
+{
+	const int wave = threadIdx.x >> 6, lane = lane_id();
+	const int r = blockIdx.x * 4 + wave;
+	if (r >= B.n_reads) return;
+	const uint64_t mo = B.mz_off[r];
+	const uint32_t *sd_n = B.sd_n + mo, *sd_off = B.sd_off + mo, *sd_aoff = B.sd_aoff + mo, *sd_qpos = B.sd_qpos + mo, *sd_info = B.sd_info + mo;
+	const int n_m0 = (int)B.n_seedhit[r];
+	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
+	Anchor *a = B.anchors + B.a_off[r];
+	uint64_t *mp = B.mini_pos + B.mp_off[r];
+	for (int i = lane; i < n_m0; i += 64) {
+		const uint32_t ao = sd_aoff[i];
+		if (ao == 0xffffffffu) continue;
+		const uint32_t info = sd_info[i], span = info & 0xff, qp = sd_qpos[i], cnt = sd_n[i];
+		mp[info >> 10] = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
+		const uint64_t *cr = I.pos + sd_off[i];
+		for (uint32_t c = 0; c < cnt; ++c) {
+			const uint64_t rr = cr[c];
+			const uint32_t rpos = (uint32_t)rr >> 1;
+			Anchor p;
+			if ((rr & 1) == (qp & 1)) { // same strand
+				p.x = (rr & 0xffffffff00000000ULL) | rpos;
+				p.y = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
+			} else {
+				p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
+				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
+			}
+			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
+			a[ao + c] = p;
+		}
+	}
+}
+
+void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream)
+{
+	hipLaunchKernelGGL(seed_expand_kernel, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, I, P);
+	HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Anchor sort (map.c:202): permutation-exact replay of the reference's unstable radix sort, one lane per read
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) anchor_sort_kernel(SeedChainBuffers B)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= B.n_reads) return;
+	Anchor *a = B.anchors + B.a_off[r];
+	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	RsortScratch sc;
+	exact_radix_sort(a, a + n, KeyX(), sc);
+}
+
+void launch_anchor_sort(const SeedChainBuffers &B, void *stream)
+{
+	hipLaunchKernelGGL(anchor_sort_kernel, dim3((B.n_reads + 63) / 64), dim3(64), 0, (hipStream_t)stream, B);
+	HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Chaining DP fill (lchain.c:169-207), one wavefront per read
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_log2_dev(float x) // mg_log2, mmpriv.h:139-147
+{
+	uint32_t zi = __float_as_uint(x);
+	float l = (float)((int)((zi >> 23) & 255) - 128);
+	zi &= ~(255u << 23);
+	zi += 127u << 23;
+	const float zf = __uint_as_float(zi);
+	l += (-0.34484843f * zf + 2.02466578f) * zf - 0.67487759f;
+	return l;
+}
+
+// comput_sc (lchain.c:113-138) for single-segment reads
+__device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, int32_t max_dist_x, int32_t max_dist_y, int32_t bw,
+                                              float pen_gap, float pen_skip, int is_cdna)
+{
+	const int32_t dq = (int32_t)iy - (int32_t)jy;
+	if (dq <= 0 || dq > max_dist_x) return INT32_MIN;
+	const int32_t dr = (int32_t)(ix - jx);
+	if (dr == 0 || dq > max_dist_y) return INT32_MIN;
+	const int32_t dd = dr > dq ? dr - dq : dq - dr;
+	if (dd > bw) return INT32_MIN;
+	const int32_t dg = dr < dq ? dr : dq, span = (int32_t)(jy >> 32 & 0xff);
+	int32_t sc = span < dg ? span : dg;
+	if (dd || dg > span) {
+		const float lin = pen_gap * (float)dd + pen_skip * (float)dg;
+		const float lg = dd >= 1 ? fast_log2_dev((float)(dd + 1)) : 0.0f;
+		if (is_cdna) {
+			if (dr > dq) sc -= (int)(lin < lg ? lin : lg);
+			else sc -= (int)(lin + .5f * lg);
+		} else sc -= (int)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+__global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
+{
+	const int wave = threadIdx.x >> 6, lane = lane_id();
+	const int r = blockIdx.x * 4 + wave;
+	if (r >= B.n_reads) return;
+	const Anchor *a = B.anchors + B.a_off[r];
+	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
+	int32_t max_dist_x = P.max_gap_ref, max_dist_y = P.max_gap_qry;
+	const int32_t bw = P.bw;
+	if (max_dist_x < bw) max_dist_x = bw;
+	if (max_dist_y < bw && !P.is_cdna) max_dist_y = bw;
+	for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+	__threadfence_block();
+
+	int64_t st = 0, max_ii = -1;
+	for (int64_t i = 0; i < n; ++i) {
+		const uint64_t ix = a[i].x, iy = a[i].y;
+		// advance the window start (lchain.c:172): first st in [st,i) on the same target/strand within max_dist_x
+		while (st < i) {
+			const int64_t c = st + lane;
+			bool stop = true; // lanes past i stop the scan
+			if (c < i) { const uint64_t cx = a[c].x; stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)max_dist_x); }
+			const unsigned long long m = __ballot(stop);
+			if (m) { st += __ffsll((long long)m) - 1; break; }
+			st += 64;
+		}
+		if (st > i) st = i;
+		if (i - st > P.max_chain_iter) st = i - P.max_chain_iter;
+
+		int32_t max_f = (int32_t)(iy >> 32 & 0xff), n_skip = 0;
+		int64_t max_j = -1, end_j = st - 1;
+		bool broke = false;
+		for (int64_t base = i - 1; base >= st && !broke; base -= 64) {
+			const int64_t j = base - lane;
+			int32_t sc = INT32_MIN, pj = -1;
+			if (j >= st) {
+				sc = link_score(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
+				if (sc != INT32_MIN) sc += f[j], pj = p[j];
+			}
+			const bool has = sc != INT32_MIN;
+			// exclusive prefix maximum in processing order (lane 0 first)
+			int32_t pm = has ? sc : INT32_MIN;
+			for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(pm, o, 64); if (lane >= o) pm = v > pm ? v : pm; }
+			int32_t excl = __shfl_up(pm, 1, 64);
+			if (lane == 0) excl = INT32_MIN;
+			excl = excl > max_f ? excl : max_f;
+			const bool improve = has && sc > excl;
+			// marks left by predecessors examined earlier in this iteration (lchain.c:186)
+			if (has && pj >= 0) t[pj] = (int32_t)i;
+			__threadfence_block();
+			const bool marked = has && !improve && t[j >= st ? j : st] == (int32_t)i;
+			unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
+			int stop_lane = 64;
+			while (ev) { // the skip counter is inherently sequential; events are sparse
+				const int b = __ffsll((long long)ev) - 1;
+				ev &= ev - 1;
+				if (imp >> b & 1) { if (n_skip > 0) --n_skip; }
+				else if (++n_skip > P.max_chain_skip) { stop_lane = b; break; }
+			}
+			if (stop_lane < 64) {
+				broke = true;
+				end_j = base - stop_lane;
+				imp &= (1ull << stop_lane) - 1ull;
+			}
+			if (imp) { // improvements are increasing, so the last one before the stop holds the running maximum
+				const int last = 63 - __clzll((long long)imp);
+				max_f = __shfl(sc, last, 64);
+				max_j = base - last;
+			}
+		}
+		// the best-scoring anchor in range may lie beyond the early exit (lchain.c:189-200)
+		bool recompute = max_ii < 0;
+		if (!recompute) recompute = ix - a[max_ii].x > (uint64_t)(int64_t)max_dist_x;
+		if (recompute) {
+			long long best = INT64_MIN; // (f, j): larger f first, then larger j
+			for (int64_t base = i - 1; base >= st; base -= 64) {
+				const int64_t j = base - lane;
+				if (j >= st) { const long long key = (long long)f[j] << 32 | (long long)(uint32_t)j; best = key > best ? key : best; }
+			}
+			for (int o = 32; o > 0; o >>= 1) { const long long v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
+			max_ii = best == INT64_MIN ? -1 : (int64_t)(uint32_t)(best & 0xffffffffLL);
+		}
+		if (max_ii >= 0 && max_ii < end_j) {
+			const int32_t tmp = link_score(ix, iy, a[max_ii].x, a[max_ii].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
+			if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) max_f = tmp + f[max_ii], max_j = max_ii;
+		}
+		if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
+		__threadfence_block();
+		if (max_ii < 0 || (ix - a[max_ii].x <= (uint64_t)(int64_t)max_dist_x && f[max_ii] < max_f)) max_ii = i;
+	}
+}
+
+void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
+{
+	hipLaunchKernelGGL(chain_fill_kernel, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
+	HIP_CHECK(hipGetLastError());
+}
+
+} // namespace mm2amd

@@ -1,0 +1,47 @@
+// Device-side contract of the seeding + chaining stages (seed_chain.hip).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include "types.hpp"
+#include "backend.hpp"
+
+namespace mm2amd {
+
+struct DevIndex {             // device mirror of FlatIndex
+	const uint32_t *bucket_start;
+	const uint64_t *keys;
+	const uint32_t *val_off;
+	const uint64_t *pos;
+	const uint32_t *S;
+	int bucket_bits, key_shift;
+};
+
+struct SeedChainBuffers {     // all device pointers; per-read slices addressed through the offset arrays
+	int n_reads;
+	const uint64_t *seq_off;  // n_reads+1: base offset of read r in the ASCII pool; the nt4 pool places it at 2*seq_off[r]
+	const char *ascii;
+	uint8_t *qpool;           // nt4 forward | reverse complement per read
+	// minimizers
+	uint32_t *mz_cnt;         // n_reads
+	const uint64_t *mz_off;   // n_reads+1
+	uint64_t *mz_x, *mz_y;
+	// per-minimizer seed info (same indexing as mz_*)
+	uint32_t *sd_n, *sd_off, *sd_aoff, *sd_qpos, *sd_info; // info: bits0-7 span, bit8 tandem, bit9 filtered
+	// per-read seed results
+	uint32_t *n_anchor, *n_minipos, *n_seedhit;
+	int32_t *rep_len;
+	const uint64_t *a_off;    // n_reads+1 anchor offsets
+	const uint64_t *mp_off;   // n_reads+1 mini_pos offsets
+	Anchor *anchors;
+	uint64_t *mini_pos;
+	int32_t *f, *p, *t;       // chaining DP arrays, indexed like anchors
+};
+
+void launch_encode(const SeedChainBuffers &B, void *stream);
+void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, bool emit, void *stream);
+void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
+void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
+void launch_anchor_sort(const SeedChainBuffers &B, void *stream);
+void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
+
+} // namespace mm2amd

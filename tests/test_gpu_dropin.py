@@ -1,0 +1,57 @@
+"""End-to-end parity on the GPU: the reference's own I/O + SAM writer around OUR mapper (tests/_build/dropin_gpu, linked
+against libmm2amd.so) must produce byte-identical SAM/PAF to oracle/_ref/minimap2_ref on the same inputs (only the @PG
+header line, which embeds argv, is excluded)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
+DROPIN = os.path.join(HERE, "_build", "dropin_gpu")
+
+
+def _run(cmd):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, (cmd, p.stderr.decode()[-2000:])
+    return b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")), p.stderr.decode()
+
+
+def _compare(tmp_path, kind, preset, ref_mb, n_reads, seed, extra=()):
+    ref, reads, _, _ = synth.make(kind, str(tmp_path), ref_mb, n_reads, seed)
+    want, _ = _run([REF_BIN, "-x", preset, "-t", "8"] + list(extra) + [ref, reads])
+    got, err = _run([DROPIN, "-x", preset, "-t", "8", "--stats"] + list(extra) + [ref, reads])
+    assert "backend=hip:gfx950" in err, err[-500:]
+    if want != got:
+        wl, gl = want.split(b"\n"), got.split(b"\n")
+        bad = [i for i in range(min(len(wl), len(gl))) if wl[i] != gl[i]]
+        raise AssertionError("%d/%d lines differ; first: %r" % (len(bad), len(wl), wl[bad[0]][:300] if bad else None))
+    return len(want)
+
+
+def test_prebuilt_binaries_present():
+    assert os.path.exists(REF_BIN), "oracle/_ref/minimap2_ref must be built in the dev container (make -C oracle ref)"
+    assert os.path.exists(DROPIN), "tests/_build/dropin_gpu must be built in the dev container (make -C tests/cpucheck)"
+
+
+def test_ont_sam_identical(tmp_path):
+    assert _compare(tmp_path, "ont", "map-ont", 8, 400, 11, ["-a"]) > 1000
+
+
+def test_ont_paf_cigar_identical(tmp_path):
+    _compare(tmp_path, "ont", "map-ont", 4, 150, 12, ["-c"])
+
+
+def test_hifi_sam_identical(tmp_path):
+    _compare(tmp_path, "hifi", "map-hifi", 8, 150, 13, ["-a"])
+
+
+def test_ont_second_batch_and_tiny_reads(tmp_path):
+    # -K forces several mini-batches through the same device context
+    _compare(tmp_path, "ont", "map-ont", 2, 120, 14, ["-a", "-K", "300000"])
