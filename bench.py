@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py -- aligned Gbases/s of the seed-chain-extend hot path on MI355X (BASELINE.json: map-ont, ~10 kb reads, -a).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ref-mb 3000] [--reads 100000]
+
+One "step" = one pass of the hot path (mm_gpu_map_staged: encode -> sketch -> seed -> sort -> chain -> extend -> hits)
+over one batch of --reads synthetic ONT-like reads per GPU, already resident in HBM when the clock starts.  The workload
+is BASELINE.json configs[1]: uniform-random reference of --ref-mb megabases in 24 contigs, reads ~N(10 kb, 1 kb) with 12 %
+error (1/3 substitution, 1/3 insertion, 1/3 deletion), preset map-ont, CIGAR output.  N > 1 (one process per GPU under
+torch.distributed.run): every rank builds the same index replica and maps its own batch (weak scaling: per-GPU work fixed);
+the packed hit records are gathered to rank 0 over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line.  "roofline" is the dominant kernel's algorithmic bytes / its HIP-event time on the launch
+stream; "cpu_baseline" is the UNMODIFIED reference's mm_map on all host cores over a bounded sample of the same batch
+against the same index contents (oracle/_ref; N=1 only)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def gen_reference(torch, dev, seed, total, n_contig):
+    """uniform i.i.d. ACGT; returns (flat uint8 code tensor on dev, list of ASCII byte strings, contig length)"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    per = total // n_contig
+    codes = torch.randint(0, 4, (per * n_contig,), dtype=torch.uint8, device=dev, generator=g)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    asc = lut[codes.long()] if codes.numel() < (1 << 28) else torch.cat([lut[c.long()] for c in codes.split(1 << 28)])
+    host = asc.cpu().numpy()
+    del asc
+    return codes, [host[i * per:(i + 1) * per].tobytes() for i in range(n_contig)], per
+
+
+def gen_reads(torch, dev, seed, codes, per, n_contig, n_reads, mean_len, sd_len, err):
+    """ONT-like reads, all at once on the device: uniformly placed substrings, half reverse-complemented, per-base error
+    split 1/3 substitution, 1/3 insertion (random base before the kept base), 1/3 deletion.  Returns ASCII byte strings."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lens = torch.clamp((torch.randn(n_reads, device=dev, generator=g) * sd_len + mean_len).long(), 1000, per)
+    cid = torch.randint(0, n_contig, (n_reads,), device=dev, generator=g)
+    st = (torch.rand(n_reads, device=dev, generator=g, dtype=torch.float64) * (per - lens + 1).double()).long()
+    rev = torch.rand(n_reads, device=dev, generator=g) < 0.5
+    bounds = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(lens, 0)])
+    n = int(bounds[-1].item())
+    rid = torch.repeat_interleave(torch.arange(n_reads, device=dev), lens)
+    j = torch.arange(n, device=dev) - bounds[:-1][rid]
+    revb = rev[rid]
+    idx = (cid * per + st)[rid] + torch.where(revb, lens[rid] - 1 - j, j)
+    src = codes[idx]
+    src = torch.where(revb, 3 - src, src)
+    del idx, j
+    hit = torch.rand(n, device=dev, generator=g) < err
+    kind = torch.randint(0, 3, (n,), device=dev, generator=g, dtype=torch.uint8)
+    sub, ins, dele = hit & (kind == 0), hit & (kind == 1), hit & (kind == 2)
+    del hit, kind
+    src = torch.where(sub, (src + torch.randint(1, 4, (n,), device=dev, generator=g, dtype=torch.uint8)) & 3, src)
+    reps = 1 + ins.long() - dele.long()
+    out = torch.repeat_interleave(src, reps)
+    first = torch.cumsum(reps, 0) - reps
+    ins_at = first[ins]
+    out[ins_at] = torch.randint(0, 4, (int(ins_at.numel()),), device=dev, generator=g, dtype=torch.uint8)
+    cum = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(reps, 0)])
+    ob = cum[bounds].cpu().numpy()
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    asc = lut[out.long()].cpu().numpy()
+    return [asc[ob[i]:ob[i + 1]].tobytes() for i in range(n_reads)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ref-mb", type=float, default=3000.0)
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step")
+    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: all cores / gpus)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    os.environ.setdefault("MM2AMD_DEVICE", str(local_rank))
+    ncpu = os.cpu_count() or 1
+    n_threads = a.threads if a.threads > 0 else max(1, ncpu // max(world, 1))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import minimap2_amd as mm
+    from minimap2_amd import shard
+
+    t0 = time.time()
+    total = int(a.ref_mb * 1e6)
+    n_contig = max(1, min(24, total // 1000000))
+    codes, refs, per = gen_reference(torch, dev, 11, total, n_contig)
+    total = per * n_contig
+    names = ["chr%d" % (i + 1) for i in range(n_contig)]
+    log("rank %d: reference %d Mb in %d contigs generated in %.1f s" % (rank, total // 1000000, n_contig, time.time() - t0))
+    t0 = time.time()
+    reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, 10000, 1000, 0.12)
+    del codes
+    torch.cuda.empty_cache()
+    batch_bases = sum(len(r) for r in reads)
+    log("rank %d: %d reads, %.3f Gbases generated in %.1f s" % (rank, len(reads), batch_bases / 1e9, time.time() - t0))
+    t0 = time.time()
+    al = mm.Aligner(refs, preset="map-ont", names=names, n_threads=n_threads, sam=True)
+    t_index = time.time() - t0
+    st = al.index_stat()
+    log("rank %d: device index built in %.1f s: %d distinct minimizers, %d positions, mid_occ=%d" % (rank, t_index, st["n_distinct"], st["n_minimizers"], al.map_opt.mid_occ))
+    named = [("read%d" % i, s) for i, s in enumerate(reads)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = mm.lib()
+    n_mapped = n_hits = 0
+
+    def one_step(step):
+        nonlocal n_mapped, n_hits
+        k = (step * 997) % len(named)  # same pool of reads every step, rotated; nothing is cached between steps
+        al.stage(named[k:] + named[:k])
+        barrier()
+        t = time.time()
+        n_reg, reg, _ = al.run(raw=True)
+        if world > 1:  # final hit gather to the formatting rank
+            payload = shard.pack_hits(L, n_reg, reg).to(dev)
+            shard.gather_payloads(payload, dst=0, device=dev)
+        barrier()
+        dt = time.time() - t
+        n_mapped = sum(1 for i in range(len(named)) if n_reg[i] > 0)
+        n_hits = sum(n_reg)
+        al.free_raw(n_reg, reg)
+        return dt
+
+    for s in range(a.warmup):
+        dt = one_step(s)
+        log("rank %d warmup %d: %.3f s  stats=%s" % (rank, s, dt, {k: round(v, 3) for k, v in al.last_stats().items()}))
+    mm.profile_enable(True)
+    times = []
+    for s in range(a.steps):
+        times.append(one_step(a.warmup + s))
+        log("rank %d step %d: %.3f s  stats=%s" % (rank, s, times[-1], {k: round(v, 3) for k, v in al.last_stats().items()}))
+    prof = mm.profile_get()
+    mm.profile_enable(False)
+    total_t = sum(times)
+    if world > 1:
+        tt = torch.tensor([total_t], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total_t = float(tt.item())
+        bb = torch.tensor([batch_bases], dtype=torch.float64, device=dev)
+        dist.all_reduce(bb, op=dist.ReduceOp.SUM)
+        all_bases = float(bb.item())
+    else:
+        all_bases = float(batch_bases)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = all_bases * a.steps / total_t / 1e9
+    # roofline of the dominant kernel: algorithmic bytes / HIP-event time on the launch stream
+    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
+    roof = None
+    if dom:
+        fam = dom_name.split("[")[0]
+        fam_ms = sum(v["ms"] for k, v in prof.items() if k.split("[")[0] == fam)
+        fam_bytes = sum(v["alg_bytes"] for k, v in prof.items() if k.split("[")[0] == fam)
+        fam_launch = sum(v["launches"] for k, v in prof.items() if k.split("[")[0] == fam)
+        ach = fam_bytes / (fam_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": fam, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6),
+                "traffic": None, "avg_launch_ms": round(fam_ms / max(fam_launch, 1), 4), "launches": fam_launch,
+                "alg_bytes_per_launch": round(fam_bytes / max(fam_launch, 1), 1),
+                "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())}}
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                roof["traffic"] = json.load(open(tj)).get(fam)
+            except Exception:
+                pass
+
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import reflib
+            if not os.path.exists(reflib.REFDRV_SO):
+                raise RuntimeError("oracle/_ref/librefdrv.so not present")
+            t0 = time.time()
+            S, keys, val_off, pos = reflib.export_index(al)
+            drv = reflib.RefDriver(st["w"], st["k"], st["flag"], names, al.lens, S, keys, val_off, pos, ncpu)
+            del keys, val_off, pos
+            mo = drv.map_opt("map-ont", extra_flag=mm.F_OUT_SAM)
+            log("reference mm_idx_t adopted from the exported tables in %.1f s (mid_occ %d)" % (time.time() - t0, mo.mid_occ))
+            n_s = a.cpu_sample
+            if n_s <= 0:
+                t_probe, nr, rg = drv.map(mo, named[:min(2000, len(named))])
+                L.mm2amd_free_regs(len(nr), nr, rg)
+                rate = min(2000, len(named)) / max(t_probe, 1e-3)
+                n_s = int(min(len(named), max(2000, rate * 10.0)))
+            sample = named[:n_s]
+            t_cpu, nr, rg = drv.map(mo, sample)
+            # parity spot check on the sample: the GPU path must reproduce the reference's hit records byte for byte
+            want = shard.pack_hits(L, nr, rg).numpy().tobytes()
+            L.mm2amd_free_regs(len(nr), nr, rg)
+            al.stage(sample)
+            n_reg, reg, _ = al.run(raw=True)
+            got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
+            al.free_raw(n_reg, reg)
+            sb = sum(len(r[1]) for r in sample)
+            cpu = {"value": round(sb / t_cpu / 1e9, 5), "unit": "Gbases/s", "cores": ncpu, "kind": "reference",
+                   "sample": "%d of the batch's reads (%.3f Gbases), mm_map on %d threads (kt_for), mapping loop only, same index contents" % (n_s, sb / 1e9, ncpu),
+                   "hits_identical_to_gpu": got == want}
+            drv.close()
+        except Exception as e:  # the baseline is reported, never required
+            cpu = {"value": None, "unit": "Gbases/s", "cores": ncpu, "kind": "reference", "sample": "unavailable: %s" % e}
+
+    out = {"metric": "aligned Gbases/sec (map-ont, 10 kb reads, -a)", "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
+           "config": {"workload": "map-ont: %d synthetic ~10 kb 12%%-error reads per GPU vs %d Mb synthetic ref (24 contigs), -a" % (a.reads, total // 1000000),
+                      "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads,
+                      "parallelism": "replicated index, reads sharded %d-way, RCCL hit gather" % world if world > 1 else "1 GPU",
+                      "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},
+           "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out), flush=True)
+    al.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

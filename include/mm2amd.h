@@ -79,6 +79,29 @@ typedef void mm2amd_idx_t; typedef void mm2amd_mapopt_t;
 #define MM2AMD_REG_PP   void **
 #endif
 
+/* ------------------------------------------------------------------------------------------------
+ * Options (options.c).  io = mm_idxopt_t* (minimap.h:130-134), mo = mm_mapopt_t* (minimap.h:136-192).
+ * ------------------------------------------------------------------------------------------------ */
+void mm2amd_idxopt_init(void *io);                                /* mm_idxopt_init, options.c:5 */
+void mm2amd_mapopt_init(void *mo);                                /* mm_mapopt_init, options.c:14 */
+int mm2amd_set_opt(const char *preset, void *io, void *mo);       /* mm_set_opt, options.c:91; -1 for an unknown preset */
+int mm2amd_check_opt(const void *io, const void *mo);             /* mm_check_opt, options.c:202 (per-read-path subset) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Index built on the device from in-memory sequences: the counterpart of mm_idx_str (index.c:421,
+ * minimap.h:324).  seq[i] are NUL-terminated; name may be NULL.  Returns NULL on failure.  A lookup in
+ * this index yields the same (count, ascending position list) as mm_idx_get on the reference's index.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mm2amd_index_s mm2amd_index_t;
+mm2amd_index_t *mm2amd_idx_str(int w, int k, int is_hpc, int bucket_bits, int n, const char **seq, const char **name);
+void mm2amd_idx_destroy(mm2amd_index_t *idx);                     /* mm_idx_destroy, index.c:50 */
+int mm2amd_idx_stat(const mm2amd_index_t *idx, int *k, int *w, int *flag, uint32_t *n_seq, uint64_t *sum_len,
+                    uint64_t *n_distinct, uint64_t *n_minimizers); /* the figures mm_idx_stat prints, index.c:112-134 */
+int32_t mm2amd_idx_cal_max_occ(const mm2amd_index_t *idx, float f); /* mm_idx_cal_max_occ, index.c:198 */
+int mm2amd_mapopt_update(void *mo, const mm2amd_index_t *idx);    /* mm_mapopt_update, options.c:69 */
+int mm2amd_idx_table_shape(const mm2amd_index_t *idx, int *bucket_bits, int *key_shift);
+int mm2amd_idx_export(const mm2amd_index_t *idx, uint32_t *bucket_start, uint64_t *keys, uint32_t *val_off, uint64_t *pos, uint32_t *S);
+
 /* Call once per index part after mm_mapopt_update() (main.c:465): builds the device mirror of the index
  * (flat minimizer table + 4-bit packed reference) and captures the mapping options.  n_threads sizes the host
  * worker pool (<=0: all hardware threads).  Replaces nothing in the reference; it is the set-up the GPU path needs. */
@@ -90,11 +113,33 @@ int mm_gpu_init(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_thread
 int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq,
                      int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
 
+/* As mm_gpu_init, for an index built by mm2amd_idx_str (which must outlive the mapper). */
+int mm_gpu_init_index(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int n_threads);
+
+/* mm_gpu_map_batch in two halves: mm_gpu_batch_stage copies the batch's sequences to the device (the hand-over the
+ * reference's pipeline step 0 makes, map.c:543-575) and returns when they are resident; mm_gpu_map_staged runs the
+ * hot path on the staged batch (results indexed by fragment, as with seg_off[i] == i).  seq must stay valid in between. */
+int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq);
+int mm_gpu_map_staged(int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
+
+/* free() every reg[i][j].p and reg[i] (what the reference's step 2 does, map.c:629-631); for non-C callers. */
+void mm2amd_free_regs(int n_frag, int *n_reg, MM2AMD_REG_PP reg);
+
+/* Hit records of a (shard of a) batch as one flat payload -- the unit of the multi-GPU hit gather.  pack returns the
+ * number of bytes needed/written (call with buf == NULL to size it); unpack rebuilds libc-allocated reg[] arrays. */
+int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t *buf, int64_t cap);
+int mm2amd_unpack_regs(const uint8_t *buf, int64_t size, int n_frag, int *n_reg, MM2AMD_REG_PP reg);
+
 /* Releases the device mirror; call before mm_idx_destroy (main.c:501). */
 void mm_gpu_destroy(void);
 
 const char *mm2amd_backend_name(void);           /* "hip:gfx950" in the product library */
 int mm2amd_last_stats(double *v, int n);         /* per-stage wall times of the last batch (diagnostics) */
+
+/* Per-kernel timing (HIP events on the launch stream) and algorithmic bytes, accumulated while enabled. */
+typedef struct { char name[48]; double ms; double alg_bytes; int64_t launches; } mm2amd_kernel_stat_t;
+void mm2amd_profile_enable(int on);              /* also clears the accumulated statistics */
+int mm2amd_profile_get(mm2amd_kernel_stat_t *out, int cap); /* returns the number of kernels written */
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,9 @@
 """minimap2_amd -- MI355X-native seed-chain-extend engine behind minimap2's API.
 
-This package is a thin ctypes mirror of the C ABI in include/mm2amd.h; all compute happens in
-libmm2amd.so (hand-written HIP for gfx950).  There is no CPU fallback: if the library is not built or no
-GPU is visible, calls raise."""
+This package is a thin ctypes mirror of the C ABI in include/mm2amd.h, shaped like the reference's own Python
+binding (python/mappy.pyx: Aligner(seq=..., preset=...).map(...)).  All compute happens in libmm2amd.so
+(hand-written HIP for gfx950).  There is no CPU fallback: if the library is not built or no GPU is visible,
+calls raise Mm2AmdError."""
 import ctypes as C
 import os
 
@@ -14,6 +15,9 @@ class Mm2AmdError(RuntimeError):
     pass
 
 
+# ---------------------------------------------------------------------------------------------------------
+# struct mirrors (layouts: minimap2_amd/csrc/abi_ref.hpp, checked against the reference headers in tests/)
+# ---------------------------------------------------------------------------------------------------------
 class KswJob(C.Structure):  # mm2amd_ksw_job_t
     _fields_ = [("query", C.c_void_p), ("target", C.c_void_p), ("qlen", C.c_int32), ("tlen", C.c_int32), ("w", C.c_int32),
                 ("zdrop", C.c_int32), ("end_bonus", C.c_int32), ("flag", C.c_int32)]
@@ -24,27 +28,118 @@ class KswRes(C.Structure):  # mm2amd_ksw_res_t
                                          "n_cigar", "reach_end")] + [("cigar_off", C.c_uint32)]
 
 
+class IdxOpt(C.Structure):  # mm_idxopt_t, minimap.h:130-134
+    _fields_ = [("k", C.c_short), ("w", C.c_short), ("flag", C.c_short), ("bucket_bits", C.c_short),
+                ("mini_batch_size", C.c_int64), ("batch_size", C.c_uint64)]
+
+
+class MapOpt(C.Structure):  # mm_mapopt_t, minimap.h:136-192
+    _fields_ = [("flag", C.c_int64), ("seed", C.c_int), ("sdust_thres", C.c_int), ("max_qlen", C.c_int), ("bw", C.c_int),
+                ("bw_long", C.c_int), ("max_gap", C.c_int), ("max_gap_ref", C.c_int), ("max_frag_len", C.c_int),
+                ("max_chain_skip", C.c_int), ("max_chain_iter", C.c_int), ("min_cnt", C.c_int), ("min_chain_score", C.c_int),
+                ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float), ("rmq_size_cap", C.c_int),
+                ("rmq_inner_dist", C.c_int), ("rmq_rescue_size", C.c_int), ("rmq_rescue_ratio", C.c_float),
+                ("mask_level", C.c_float), ("mask_len", C.c_int), ("pri_ratio", C.c_float), ("best_n", C.c_int),
+                ("alt_drop", C.c_float), ("a", C.c_int), ("b", C.c_int), ("q", C.c_int), ("e", C.c_int), ("q2", C.c_int),
+                ("e2", C.c_int), ("transition", C.c_int), ("sc_ambi", C.c_int), ("noncan", C.c_int), ("junc_bonus", C.c_int),
+                ("junc_pen", C.c_int), ("zdrop", C.c_int), ("zdrop_inv", C.c_int), ("end_bonus", C.c_int),
+                ("min_dp_max", C.c_int), ("min_ksw_len", C.c_int), ("anchor_ext_len", C.c_int), ("anchor_ext_shift", C.c_int),
+                ("max_clip_ratio", C.c_float), ("rank_min_len", C.c_int), ("rank_frac", C.c_float), ("pe_ori", C.c_int),
+                ("pe_bonus", C.c_int), ("jump_min_match", C.c_int32), ("mid_occ_frac", C.c_float), ("q_occ_frac", C.c_float),
+                ("min_mid_occ", C.c_int32), ("max_mid_occ", C.c_int32), ("mid_occ", C.c_int32), ("max_occ", C.c_int32),
+                ("max_max_occ", C.c_int32), ("occ_dist", C.c_int32), ("mini_batch_size", C.c_int64), ("max_sw_mat", C.c_int64),
+                ("cap_kalloc", C.c_int64), ("split_prefix", C.c_char_p)]
+
+
+class Extra(C.Structure):  # mm_extra_t header, minimap.h:103-110 (cigar[] follows)
+    _fields_ = [("capacity", C.c_uint32), ("dp_score", C.c_int32), ("dp_max", C.c_int32), ("dp_max2", C.c_int32),
+                ("dp_max0", C.c_int32), ("n_ambi_strand", C.c_uint32), ("n_cigar", C.c_uint32)]
+
+
+class Reg1(C.Structure):  # mm_reg1_t, minimap.h:112-127
+    _fields_ = [("id", C.c_int32), ("cnt", C.c_int32), ("rid", C.c_int32), ("score", C.c_int32), ("qs", C.c_int32),
+                ("qe", C.c_int32), ("rs", C.c_int32), ("re", C.c_int32), ("parent", C.c_int32), ("subsc", C.c_int32),
+                ("as_", C.c_int32), ("mlen", C.c_int32), ("blen", C.c_int32), ("n_sub", C.c_int32), ("score0", C.c_int32),
+                ("bits", C.c_uint32), ("hash", C.c_uint32), ("div", C.c_float), ("p", C.POINTER(Extra))]
+
+    mapq = property(lambda s: s.bits & 0xff)
+    split = property(lambda s: s.bits >> 8 & 3)
+    rev = property(lambda s: s.bits >> 10 & 1)
+    inv = property(lambda s: s.bits >> 11 & 1)
+    sam_pri = property(lambda s: s.bits >> 12 & 1)
+
+
+class Bseq1(C.Structure):  # mm_bseq1_t, bseq.h:14-17
+    _fields_ = [("l_seq", C.c_int), ("rid", C.c_int), ("name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_char_p),
+                ("comment", C.c_char_p)]
+
+
+class KernelStat(C.Structure):  # mm2amd_kernel_stat_t
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("alg_bytes", C.c_double), ("launches", C.c_int64)]
+
+
+assert C.sizeof(MapOpt) == 264 and C.sizeof(Reg1) == 80 and C.sizeof(Extra) == 28 and C.sizeof(Bseq1) == 40 and C.sizeof(IdxOpt) == 24
+
+F_CIGAR, F_OUT_SAM = 0x004, 0x008  # MM_F_CIGAR, MM_F_OUT_SAM (minimap.h:12-13)
+
 _lib = None
 
 
-def lib():
-    """Load libmm2amd.so (built in-tree by minimap2_amd.build); raises if it is missing."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise Mm2AmdError("libmm2amd.so is not built (run `python -m minimap2_amd.build`); there is no CPU fallback")
-        L = C.CDLL(LIB_PATH)
-        L.mm2amd_last_error.restype = C.c_char_p
+def _bind(L):
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.mm2amd_last_error.restype = C.c_char_p
+    L.mm2amd_backend_name.restype = C.c_char_p
+    L.mm_gpu_init.argtypes = [vp, vp, C.c_int]
+    L.mm_gpu_map_batch.argtypes = [C.c_int, ip, ip, vp, ip, C.POINTER(vp), ip, ip]
+    L.mm_gpu_batch_stage.argtypes = [C.c_int, ip, ip, vp]
+    L.mm_gpu_map_staged.argtypes = [ip, C.POINTER(vp), ip, ip]
+    L.mm2amd_free_regs.argtypes = [C.c_int, ip, C.POINTER(vp)]
+    L.mm2amd_free_regs.restype = None
+    L.mm2amd_last_stats.argtypes = [C.POINTER(C.c_double), C.c_int]
+    L.mm2amd_pack_regs.argtypes = [C.c_int, ip, C.POINTER(vp), vp, C.c_int64]
+    L.mm2amd_pack_regs.restype = C.c_int64
+    L.mm2amd_unpack_regs.argtypes = [vp, C.c_int64, C.c_int, ip, C.POINTER(vp)]
+    if hasattr(L, "mm2amd_idx_str"):  # the product library (the CPU check library used by tests has no device index)
         L.mm2amd_ksw_extd2_batch.restype = C.c_int
         L.mm2amd_ksw_extd2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int8,
                                              C.c_int8, C.POINTER(KswRes), C.POINTER(C.c_uint32), C.c_size_t]
-        _lib = L
+        L.mm2amd_idx_str.restype = vp
+        L.mm2amd_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+        L.mm2amd_idx_destroy.argtypes = [vp]
+        L.mm2amd_idx_destroy.restype = None
+        L.mm2amd_idx_stat.argtypes = [vp, ip, ip, ip, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)]
+        L.mm2amd_idx_cal_max_occ.argtypes = [vp, C.c_float]
+        L.mm2amd_idx_cal_max_occ.restype = C.c_int32
+        L.mm2amd_mapopt_update.argtypes = [vp, vp]
+        L.mm2amd_idx_table_shape.argtypes = [vp, ip, ip]
+        L.mm2amd_idx_export.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.mm_gpu_init_index.argtypes = [vp, vp, C.c_int]
+        L.mm2amd_set_opt.argtypes = [C.c_char_p, vp, vp]
+        L.mm2amd_check_opt.argtypes = [vp, vp]
+        L.mm2amd_idxopt_init.argtypes = [vp]
+        L.mm2amd_mapopt_init.argtypes = [vp]
+        L.mm2amd_profile_enable.argtypes = [C.c_int]
+        L.mm2amd_profile_enable.restype = None
+        L.mm2amd_profile_get.argtypes = [C.POINTER(KernelStat), C.c_int]
+    return L
+
+
+def lib(path=None):
+    """Load libmm2amd.so (built in-tree by minimap2_amd.build); raises if it is missing."""
+    global _lib
+    if path is not None:
+        return _bind(C.CDLL(path))
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mm2AmdError("libmm2amd.so is not built (run `python -m minimap2_amd.build`); there is no CPU fallback")
+        _lib = _bind(C.CDLL(LIB_PATH))
     return _lib
 
 
-def _check(rc):
+def _check(rc, L=None):
     if rc != 0:
-        raise Mm2AmdError("mm2amd error %d: %s" % (rc, lib().mm2amd_last_error().decode()))
+        raise Mm2AmdError("mm2amd error %d: %s" % (rc, (L or lib()).mm2amd_last_error().decode()))
 
 
 def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2):
@@ -70,3 +165,163 @@ def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2):
         out.append((r.max, r.zdropped, r.max_q, r.max_t, r.mqe, r.mqe_t, r.mte, r.mte_q, r.score, r.reach_end,
                     tuple(pool[r.cigar_off:r.cigar_off + r.n_cigar])))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mappy-shaped front end
+# ---------------------------------------------------------------------------------------------------------
+class Alignment(object):
+    """One hit; field names follow mappy.Alignment (python/mappy.pyx:30-90)."""
+    __slots__ = ("ctg", "ctg_len", "r_st", "r_en", "q_st", "q_en", "strand", "mapq", "is_primary", "mlen", "blen", "NM",
+                 "cigar", "score", "dp_score", "rid", "sam_pri", "div", "parent", "id")
+
+    @property
+    def cigar_str(self):
+        return "".join("%d%s" % (c >> 4, "MIDNSHP=XB"[c & 0xf]) for c in self.cigar)
+
+    def key(self):
+        """Everything the SAM/PAF writer reads from mm_reg1_t for this hit, as a comparable tuple."""
+        return (self.rid, self.r_st, self.r_en, self.q_st, self.q_en, self.strand, self.mapq, self.is_primary, self.sam_pri,
+                self.mlen, self.blen, self.score, self.dp_score, self.parent, self.id, tuple(self.cigar))
+
+
+def _regs_to_alignments(n, regs, names, lens):
+    out = []
+    for j in range(n):
+        r = regs[j]
+        a = Alignment()
+        a.rid, a.ctg, a.ctg_len = r.rid, names[r.rid] if names else None, lens[r.rid] if lens else None
+        a.r_st, a.r_en, a.q_st, a.q_en = r.rs, r.re, r.qs, r.qe
+        a.strand = -1 if r.rev else 1
+        a.mapq, a.is_primary, a.sam_pri = r.mapq, int(r.id == r.parent), r.sam_pri
+        a.mlen, a.blen, a.score, a.div, a.parent, a.id = r.mlen, r.blen, r.score, r.div, r.parent, r.id
+        if r.p:
+            ex = r.p.contents
+            a.dp_score = ex.dp_score
+            cig = C.cast(C.addressof(ex) + C.sizeof(Extra), C.POINTER(C.c_uint32 * ex.n_cigar)).contents if ex.n_cigar else ()
+            a.cigar = list(cig)
+            a.NM = r.blen - r.mlen + (ex.n_ambi_strand & 0x3fffffff)
+        else:
+            a.dp_score, a.cigar, a.NM = 0, [], 0
+        out.append(a)
+    return out
+
+
+class Aligner(object):
+    """Index built on the GPU from in-memory sequences + batched mapping; mirrors mappy.Aligner(seq=..., preset=...).
+
+    seq: a sequence string/bytes or a list of them (the reference); names: optional list of contig names.
+    Only one Aligner can be the active mapper of the process at a time (the drop-in boundary is a process-wide context,
+    like the reference's pipeline)."""
+
+    def __init__(self, seq, preset=None, names=None, k=None, w=None, n_threads=0, cigar=True, sam=False):
+        L = lib()
+        seqs = [seq] if isinstance(seq, (bytes, str)) else list(seq)
+        self._seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(self._seqs)
+        self.names = [x if isinstance(x, str) else x.decode() for x in names] if names else ["ref%d" % i for i in range(n)]
+        self.lens = [len(s) for s in self._seqs]
+        self.idx_opt, self.map_opt = IdxOpt(), MapOpt()
+        L.mm2amd_set_opt(None, C.byref(self.idx_opt), C.byref(self.map_opt))
+        if preset is not None and L.mm2amd_set_opt(preset.encode(), C.byref(self.idx_opt), C.byref(self.map_opt)) != 0:
+            raise Mm2AmdError("unknown preset %r" % preset)
+        if k:
+            self.idx_opt.k = k
+        if w:
+            self.idx_opt.w = w
+        if cigar:
+            self.map_opt.flag |= F_CIGAR
+        if sam:
+            self.map_opt.flag |= F_OUT_SAM | F_CIGAR
+        _check(L.mm2amd_check_opt(C.byref(self.idx_opt), C.byref(self.map_opt)))
+        sarr = (C.c_char_p * n)(*self._seqs)
+        self._name_bytes = [x.encode() for x in self.names]
+        narr = (C.c_char_p * n)(*self._name_bytes)
+        self._idx = L.mm2amd_idx_str(self.idx_opt.w, self.idx_opt.k, self.idx_opt.flag & 1, self.idx_opt.bucket_bits, n, sarr, narr)
+        if not self._idx:
+            raise Mm2AmdError("index construction failed: %s" % L.mm2amd_last_error().decode())
+        _check(L.mm2amd_mapopt_update(C.byref(self.map_opt), self._idx))
+        _check(L.mm_gpu_init_index(self._idx, C.byref(self.map_opt), n_threads))
+        self._staged = None
+
+    def close(self):
+        if getattr(self, "_idx", None):
+            lib().mm_gpu_destroy()
+            lib().mm2amd_idx_destroy(self._idx)
+            self._idx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def index_stat(self):
+        k, w, flag, n_seq = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+        sl, nd, nm = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().mm2amd_idx_stat(self._idx, k, w, flag, n_seq, sl, nd, nm))
+        return {"k": k.value, "w": w.value, "flag": flag.value, "n_seq": n_seq.value, "sum_len": sl.value,
+                "n_distinct": nd.value, "n_minimizers": nm.value}
+
+    # -- batch interface: stage() + run() == map_batch() ------------------------------------------------
+    def stage(self, reads):
+        """reads: list of (name, sequence) or of sequences (bytes/str).  Copies them to the GPU."""
+        n = len(reads)
+        arr = (Bseq1 * n)()
+        keep = []
+        for i, r in enumerate(reads):
+            nm, s = r if isinstance(r, tuple) else ("read%d" % i, r)
+            nb = nm.encode() if isinstance(nm, str) else nm
+            sb = s.encode() if isinstance(s, str) else bytes(s)
+            keep.append((nb, sb))
+            arr[i].l_seq, arr[i].rid, arr[i].name, arr[i].seq = len(sb), i, nb, sb
+        seg_off = (C.c_int * n)(*range(n))
+        n_seg = (C.c_int * n)(*([1] * n))
+        _check(lib().mm_gpu_batch_stage(n, seg_off, n_seg, arr))
+        self._staged = (n, arr, keep, seg_off, n_seg)
+
+    def run(self, raw=False):
+        """Maps the staged batch.  raw=True returns (n_reg, reg) ctypes arrays that must be passed to free_raw()."""
+        if self._staged is None:
+            raise Mm2AmdError("run() without stage()")
+        n = self._staged[0]
+        n_reg = (C.c_int * n)()
+        reg = (C.c_void_p * n)()
+        rep_len = (C.c_int * n)()
+        frag_gap = (C.c_int * n)()
+        _check(lib().mm_gpu_map_staged(n_reg, reg, rep_len, frag_gap))
+        if raw:
+            return n_reg, reg, rep_len
+        out = []
+        for i in range(n):
+            regs = C.cast(reg[i], C.POINTER(Reg1)) if n_reg[i] else None
+            out.append(_regs_to_alignments(n_reg[i], regs, self.names, self.lens))
+        lib().mm2amd_free_regs(n, n_reg, reg)
+        return out
+
+    def free_raw(self, n_reg, reg):
+        lib().mm2amd_free_regs(len(n_reg), n_reg, reg)
+
+    def map_batch(self, reads):
+        self.stage(reads)
+        return self.run()
+
+    def map(self, seq, name="query"):
+        """Single-read convenience wrapper (mappy.Aligner.map); a batch of one."""
+        return self.map_batch([(name, seq)])[0]
+
+    def last_stats(self):
+        v = (C.c_double * 16)()
+        k = lib().mm2amd_last_stats(v, 16)
+        names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells"]
+        return dict(zip(names, list(v)[:k]))
+
+
+def profile_enable(on=True):
+    lib().mm2amd_profile_enable(1 if on else 0)
+
+
+def profile_get():
+    arr = (KernelStat * 64)()
+    n = lib().mm2amd_profile_get(arr, 64)
+    return {arr[i].name.decode(): {"ms": arr[i].ms, "alg_bytes": arr[i].alg_bytes, "launches": arr[i].launches} for i in range(n)}

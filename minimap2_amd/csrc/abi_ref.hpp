@@ -119,6 +119,12 @@ struct MapOpt {                                        // mm_mapopt_t, minimap.h
 	const char *split_prefix;
 };
 
+struct IdxOpt {                                        // mm_idxopt_t, minimap.h:130-134
+	short k, w, flag, bucket_bits;
+	int64_t mini_batch_size;
+	uint64_t batch_size;
+};
+
 struct Bseq1 {                                         // mm_bseq1_t, bseq.h:14-17
 	int l_seq, rid;
 	char *name, *seq, *qual, *comment;
@@ -128,9 +134,11 @@ static_assert(sizeof(Reg1) == 80, "mm_reg1_t is 80 bytes");
 static_assert(sizeof(Extra) == 28, "mm_extra_t header is 28 bytes");
 static_assert(sizeof(IdxSeq) == 24, "mm_idx_seq_t is 24 bytes");
 static_assert(sizeof(Bseq1) == 40, "mm_bseq1_t is 40 bytes");
+static_assert(sizeof(IdxOpt) == 24, "mm_idxopt_t is 24 bytes");
+static_assert(sizeof(MapOpt) == 264, "mm_mapopt_t is 264 bytes");
 
 // option flags, minimap.h:10-50
-constexpr int64_t F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_CIGAR = 0x004, F_OUT_SAM = 0x008, F_SPLICE = 0x080,
+constexpr int64_t F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_CIGAR = 0x004, F_OUT_SAM = 0x008, F_NO_PRINT_2ND = 0x4000, F_2_IO_THREADS = 0x8000, F_SPLICE = 0x080,
 	F_SPLICE_FOR = 0x100, F_SPLICE_REV = 0x200, F_NO_LJOIN = 0x400, F_SR = 0x1000, F_FRAG_MODE = 0x2000,
 	F_INDEPEND_SEG = 0x20000, F_SPLICE_FLANK = 0x40000, F_FOR_ONLY = 0x100000, F_REV_ONLY = 0x200000,
 	F_HEAP_SORT = 0x400000, F_ALL_CHAINS = 0x800000, F_EQX = 0x4000000, F_NO_END_FLT = 0x10000000,

@@ -26,8 +26,8 @@ public:
 	// Make the batch's sequences resident; the nt4 forward|reverse-complement pool places read i at
 	// qpool_off[i] (2*len bytes).  Must be called before seed_chain()/ksw() of that batch.
 	virtual void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) = 0;
-	// sketch -> seed lookup -> anchor sort -> chaining DP -> chains, for every read of the batch
-	virtual void seed_chain(const SeedChainParams &p, std::vector<ReadChains> &out) = 0;
+	// sketch -> seed lookup -> anchor sort -> chaining DP -> chains, for reads [lo, hi) of the batch (out[i] is read lo+i)
+	virtual void seed_chain(const SeedChainParams &p, long lo, long hi, std::vector<ReadChains> &out) = 0;
 	// batched extension DP (ksw_extd2 semantics); CIGARs packed into `cigar`, addressed by res[i].cigar_off
 	virtual void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) = 0;
 };

@@ -9,6 +9,8 @@
 #include "device_ctx.hpp"
 #include "ksw_host.hpp"
 #include "seed_chain_dev.hpp"
+#include "index_build.hpp"
+#include "kernel_prof.hpp"
 #include "threads.hpp"
 #include <thread>
 
@@ -25,7 +27,8 @@ void upload(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
 
 class HipBackend : public Backend {
 public:
-	explicit HipBackend(const FlatIndex &fi) : fi_(fi)
+	// `tables` may be null: the backend then mirrors the host tables of `fi` (an index flattened from a reference mm_idx_t)
+	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables) : fi_(fi), T_(tables)
 	{
 		DeviceCtx &d = device_ctx();
 		std::lock_guard<std::mutex> lk(d.mu);
@@ -33,17 +36,9 @@ public:
 		stream_ = d.stream;
 		ksw_.n_cu = d.n_cu;
 		n_threads_ = std::max(1u, std::thread::hardware_concurrency());
-		// device mirror of the index (flat minimizer table + packed reference)
-		upload(d_bucket_start_, fi.bucket_start, stream_);
-		upload(d_keys_, fi.keys, stream_);
-		upload(d_val_off_, fi.val_off, stream_);
-		upload(d_pos_, fi.pos, stream_);
-		const size_t s_words = (fi.sum_len + 7) / 8;
-		d_S_.ensure(s_words ? s_words : 1, 1.0);
-		if (s_words) HIP_CHECK(hipMemcpyAsync(d_S_.p, fi.S, s_words * 4, hipMemcpyHostToDevice, stream_));
-		HIP_CHECK(hipStreamSynchronize(stream_));
-		I_.bucket_start = d_bucket_start_.p, I_.keys = d_keys_.p, I_.val_off = d_val_off_.p, I_.pos = d_pos_.p, I_.S = d_S_.p;
-		I_.bucket_bits = fi.bucket_bits, I_.key_shift = fi.key_shift;
+		if (!T_) { own_.upload(fi, stream_); T_ = &own_; }
+		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
+		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
 	}
 
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
@@ -65,20 +60,24 @@ public:
 		HIP_CHECK(hipMemcpyAsync(d_seq_off_.p, seq_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
 		B_ = SeedChainBuffers();
 		B_.n_reads = n_reads_, B_.seq_off = d_seq_off_.p, B_.ascii = d_ascii_.p, B_.qpool = d_qpool_.p;
-		launch_encode(B_, stream_);
+		HIP_CHECK(hipStreamSynchronize(stream_)); // the batch is resident; everything after this is the hot path
 	}
 
-	void seed_chain(const SeedChainParams &P, std::vector<ReadChains> &out) override
+	void seed_chain(const SeedChainParams &P, long lo, long hi, std::vector<ReadChains> &out) override
 	{
-		const size_t n = (size_t)n_reads_;
+		const size_t n = (size_t)(hi - lo);
+		B_.n_reads = (int)n, B_.seq_off = d_seq_off_.p + lo;
 		out.clear();
 		out.resize(n);
 		if (n == 0) return;
 		if (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY)) throw std::invalid_argument("[mm2amd] --for-only/--rev-only are not implemented on the device path");
+		KernelProfiler &kp = kernel_profiler();
+		const double L = (double)(seq_off_[hi] - seq_off_[lo]);
+		kp.begin(stream_); launch_encode(B_, stream_); kp.end(stream_, "encode_kernel", 3 * L);
 		// 1. minimizers: count, scan, emit
 		d_mz_cnt_.ensure(n);
 		B_.mz_cnt = d_mz_cnt_.p;
-		launch_sketch(B_, P, false, stream_);
+		kp.begin(stream_); launch_sketch(B_, P, false, stream_); kp.end(stream_, "sketch_kernel<count>", L);
 		h_cnt_.resize(n);
 		HIP_CHECK(hipMemcpyAsync(h_cnt_.data(), d_mz_cnt_.p, n * 4, hipMemcpyDeviceToHost, stream_));
 		HIP_CHECK(hipStreamSynchronize(stream_));
@@ -92,11 +91,11 @@ public:
 		d_sd_n_.ensure(n_mz + 1), d_sd_off_.ensure(n_mz + 1), d_sd_aoff_.ensure(n_mz + 1), d_sd_qpos_.ensure(n_mz + 1), d_sd_info_.ensure(n_mz + 1);
 		B_.mz_off = d_mz_off_.p, B_.mz_x = d_mz_x_.p, B_.mz_y = d_mz_y_.p;
 		B_.sd_n = d_sd_n_.p, B_.sd_off = d_sd_off_.p, B_.sd_aoff = d_sd_aoff_.p, B_.sd_qpos = d_sd_qpos_.p, B_.sd_info = d_sd_info_.p;
-		launch_sketch(B_, P, true, stream_);
+		kp.begin(stream_); launch_sketch(B_, P, true, stream_); kp.end(stream_, "sketch_kernel<emit>", L + 16.0 * n_mz);
 		// 2. seeds: probe, filter, count anchors
 		d_n_anchor_.ensure(n), d_n_minipos_.ensure(n), d_n_seedhit_.ensure(n), d_rep_len_.ensure(n);
 		B_.n_anchor = d_n_anchor_.p, B_.n_minipos = d_n_minipos_.p, B_.n_seedhit = d_n_seedhit_.p, B_.rep_len = d_rep_len_.p;
-		launch_seed_collect(B_, I_, P, stream_);
+		kp.begin(stream_); launch_seed_collect(B_, I_, P, stream_); kp.end(stream_, "seed_collect_kernel", 36.0 * n_mz); // 16 B minimizer + 8 key + 8 val + 4 flags
 		h_na_.resize(n), h_nmp_.resize(n), h_rep_.resize(n);
 		HIP_CHECK(hipMemcpyAsync(h_na_.data(), d_n_anchor_.p, n * 4, hipMemcpyDeviceToHost, stream_));
 		HIP_CHECK(hipMemcpyAsync(h_nmp_.data(), d_n_minipos_.p, n * 4, hipMemcpyDeviceToHost, stream_));
@@ -113,9 +112,9 @@ public:
 		B_.a_off = d_a_off_.p, B_.mp_off = d_mp_off_.p, B_.anchors = d_anchors_.p, B_.mini_pos = d_minipos_.p;
 		B_.f = d_f_.p, B_.p = d_p_.p, B_.t = d_t_.p;
 		// 3. anchors: expand, sort, chain
-		launch_seed_expand(B_, I_, P, stream_);
-		launch_anchor_sort(B_, stream_);
-		launch_chain_fill(B_, P, stream_);
+		kp.begin(stream_); launch_seed_expand(B_, I_, P, stream_); kp.end(stream_, "seed_expand_kernel", 24.0 * n_a);
+		kp.begin(stream_); launch_anchor_sort(B_, stream_); kp.end(stream_, "anchor_sort_kernel", 32.0 * n_a);
+		kp.begin(stream_); launch_chain_fill(B_, P, stream_); kp.end(stream_, "chain_fill_kernel", 24.0 * n_a);
 		// 4. back to the host for the (scalar, order-sensitive) backtrack
 		Anchor *ha = h_anchors_.ensure(n_a + 1);
 		int32_t *hf = h_f_.ensure(n_a + 1), *hp = h_p_.ensure(n_a + 1);
@@ -127,6 +126,7 @@ public:
 		}
 		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, d_minipos_.p, n_mp * 8, hipMemcpyDeviceToHost, stream_));
 		HIP_CHECK(hipStreamSynchronize(stream_));
+		kp.collect();
 		const int max_drop = P.is_cdna ? INT32_MAX : P.bw;
 		std::vector<ChainScratch> scratch(n_threads_);
 		parallel_for(n_threads_, (long)n, [&](long i, int tid) {
@@ -141,7 +141,8 @@ public:
 	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) override
 	{
 		res.resize(jobs.size());
-		ksw_.run(jobs, d_qpool_.p, nullptr, d_S_.p, sc, res.data(), cigar, stream_);
+		ksw_.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, stream_);
+		kernel_profiler().collect();
 	}
 
 private:
@@ -151,8 +152,8 @@ private:
 	DevIndex I_{};
 	SeedChainBuffers B_{};
 	KswRunner ksw_;
-	DevBuf<uint32_t> d_bucket_start_, d_val_off_, d_S_;
-	DevBuf<uint64_t> d_keys_, d_pos_;
+	DeviceIndexTables own_;
+	DeviceIndexTables *T_ = nullptr;
 	DevBuf<char> d_ascii_;
 	DevBuf<uint8_t> d_qpool_;
 	DevBuf<uint64_t> d_seq_off_, d_mz_off_, d_a_off_, d_mp_off_, d_mz_x_, d_mz_y_, d_minipos_;
@@ -170,7 +171,7 @@ private:
 
 } // namespace
 
-Backend *make_backend(const FlatIndex &fi, int /*device*/) { return new HipBackend(fi); }
+Backend *make_backend(const FlatIndex &fi, void *device_tables) { return new HipBackend(fi, (DeviceIndexTables *)device_tables); }
 const char *backend_name() { return "hip:gfx950"; }
 
 } // namespace mm2amd

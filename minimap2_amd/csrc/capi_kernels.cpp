@@ -7,6 +7,7 @@
 #include "hip_util.hpp"
 #include "device_ctx.hpp"
 #include "ksw_host.hpp"
+#include "kernel_prof.hpp"
 
 namespace mm2amd { int capi_fail(int code, const std::string &msg); }
 using namespace mm2amd;
@@ -83,6 +84,7 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 		std::vector<KswRes> r(n_jobs);
 		std::vector<uint32_t> cig;
 		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cig, dc.stream);
+		kernel_profiler().collect();
 		if (cig.size() > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
 		if (!cig.empty()) memcpy(cigar_pool, cig.data(), cig.size() * sizeof(uint32_t));
 		for (int i = 0; i < n_jobs; ++i) {
@@ -93,6 +95,26 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 		}
 		return 0;
 	});
+}
+
+void mm2amd_profile_enable(int on)
+{
+	KernelProfiler &p = kernel_profiler();
+	p.reset();
+	p.enabled = on != 0;
+}
+
+int mm2amd_profile_get(mm2amd_kernel_stat_t *out, int cap)
+{
+	int n = 0;
+	for (const auto &kv : kernel_profiler().stats()) {
+		if (n >= cap) break;
+		mm2amd_kernel_stat_t &o = out[n++];
+		memset(&o, 0, sizeof o);
+		strncpy(o.name, kv.first.c_str(), sizeof o.name - 1);
+		o.ms = kv.second.ms, o.alg_bytes = kv.second.alg_bytes, o.launches = kv.second.launches;
+	}
+	return n;
 }
 
 } // extern "C"

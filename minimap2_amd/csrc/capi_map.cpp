@@ -8,9 +8,10 @@
 #include <thread>
 #include "../../include/mm2amd.h"
 #include "mapper.hpp"
+#include "index_handle.hpp"
 
 namespace mm2amd {
-Backend *make_backend(const FlatIndex &fi, int device); // backend_hip.cpp in the product
+Backend *make_backend(const FlatIndex &fi, void *device_tables); // backend_hip.cpp in the product
 const char *backend_name();
 void capi_set_error(const std::string &msg);              // capi_common.cpp
 int capi_fail(int code, const std::string &msg);
@@ -20,8 +21,11 @@ using namespace mm2amd;
 
 namespace {
 struct MapContext {
-	FlatIndex fi;
+	FlatIndex fi_own;                 // index flattened from a reference mm_idx_t (mm_gpu_init)
+	const FlatIndex *fi = nullptr;    // the index in use (fi_own, or the one inside an mm2amd_index_t)
 	ref::MapOpt opt;
+	std::vector<ReadView> staged;
+	bool has_staged = false;
 	std::unique_ptr<Backend> be;
 	std::unique_ptr<Mapper> mapper;
 };
@@ -38,10 +42,11 @@ int mm_gpu_init(const void *mi, const void *opt, int n_threads)
 	try {
 		std::unique_ptr<MapContext> c(new MapContext);
 		c->opt = *(const ref::MapOpt *)opt;
-		c->fi.from_reference((const ref::Idx *)mi);
+		c->fi_own.from_reference((const ref::Idx *)mi);
+		c->fi = &c->fi_own;
 		if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
-		c->be.reset(make_backend(c->fi, -1));
-		c->mapper.reset(new Mapper(c->fi, c->opt, *c->be, n_threads));
+		c->be.reset(make_backend(*c->fi, nullptr));
+		c->mapper.reset(new Mapper(*c->fi, c->opt, *c->be, n_threads));
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -52,33 +57,179 @@ int mm_gpu_init(const void *mi, const void *opt, int n_threads)
 	}
 }
 
+int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
+{
+	if (!idx || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_init_index: null index or options");
+	std::lock_guard<std::mutex> lk(g_mu);
+	try {
+		std::unique_ptr<MapContext> c(new MapContext);
+		c->opt = *(const ref::MapOpt *)opt;
+		c->fi = &index_flat((const IndexHandle *)idx);
+		if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+		c->be.reset(make_backend(*c->fi, index_device_tables((const IndexHandle *)idx)));
+		c->mapper.reset(new Mapper(*c->fi, c->opt, *c->be, n_threads));
+		g_ctx = std::move(c);
+		return 0;
+	} catch (const std::invalid_argument &e) {
+		return capi_fail(MM2AMD_EINVAL, e.what());
+	} catch (const std::exception &e) {
+		const std::string s = e.what();
+		return capi_fail(s.find("no HIP device") != std::string::npos ? MM2AMD_ENODEV : MM2AMD_EHIP, s);
+	}
+}
+
+static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, std::vector<ReadView> &reads)
+{
+	const ref::Bseq1 *seq = (const ref::Bseq1 *)seq_;
+	reads.resize(n_frag);
+	for (int i = 0; i < n_frag; ++i) {
+		if (n_seg[i] != 1) return capi_fail(MM2AMD_EINVAL, "[mm2amd] multi-segment fragments (paired-end) are not implemented");
+		const ref::Bseq1 &s = seq[seg_off[i]];
+		reads[i].seq = s.seq, reads[i].len = s.l_seq, reads[i].name = s.name;
+	}
+	return 0;
+}
+
+static void hand_over(int n_frag, const int *seg_off, std::vector<ReadResult> &out, int *n_reg, void **reg, int *rep_len, int *frag_gap)
+{
+	for (int i = 0; i < n_frag; ++i) {
+		const int o = seg_off ? seg_off[i] : i;
+		const size_t n = out[i].regs.size();
+		n_reg[o] = (int)n;
+		reg[o] = nullptr;
+		if (n) { // handed over as one libc block, like the reference's realloc'd array (map.c:340)
+			reg[o] = malloc(n * sizeof(ref::Reg1));
+			memcpy(reg[o], out[i].regs.data(), n * sizeof(ref::Reg1));
+		}
+		if (rep_len) rep_len[o] = out[i].rep_len;
+		if (frag_gap) frag_gap[o] = out[i].frag_gap;
+	}
+}
+
+int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const void *seq_)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_batch_stage called before mm_gpu_init");
+	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_batch_stage: bad arguments");
+	try {
+		g_ctx->has_staged = false;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->staged)) return rc;
+		g_ctx->mapper->stage(g_ctx->staged);
+		g_ctx->has_staged = true;
+		return 0;
+	} catch (const std::invalid_argument &e) {
+		return capi_fail(MM2AMD_EINVAL, e.what());
+	} catch (const std::exception &e) {
+		return capi_fail(MM2AMD_EHIP, e.what());
+	}
+}
+
+int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_ctx || !g_ctx->has_staged) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_staged: no staged batch");
+	if (!n_reg || !reg) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_staged: bad arguments");
+	try {
+		std::vector<ReadResult> out;
+		g_ctx->mapper->run(out);
+		hand_over((int)out.size(), nullptr, out, n_reg, reg, rep_len, frag_gap);
+		return 0;
+	} catch (const std::invalid_argument &e) {
+		return capi_fail(MM2AMD_EINVAL, e.what());
+	} catch (const std::exception &e) {
+		return capi_fail(MM2AMD_EHIP, e.what());
+	}
+}
+
+void mm2amd_free_regs(int n_frag, int *n_reg, void **reg)
+{
+	if (!n_reg || !reg) return;
+	for (int i = 0; i < n_frag; ++i) {
+		ref::Reg1 *r = (ref::Reg1 *)reg[i];
+		for (int j = 0; j < n_reg[i]; ++j) free(r[j].p);
+		free(r);
+		reg[i] = nullptr, n_reg[i] = 0;
+	}
+}
+
+// ---- hit records as one flat byte payload: the unit of the multi-GPU gather ----
+// per fragment: int32 n_reg, then per hit the 80-byte mm_reg1_t (pointer field zeroed), a uint32 "has extra", and when
+// set the 28-byte mm_extra_t header followed by n_cigar uint32 CIGAR words.
+int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t *buf, int64_t cap)
+{
+	if (n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_pack_regs: bad arguments");
+	int64_t need = 0;
+	for (int i = 0; i < n_frag; ++i) {
+		need += 4;
+		const ref::Reg1 *r = (const ref::Reg1 *)reg[i];
+		for (int j = 0; j < n_reg[i]; ++j) need += (int64_t)sizeof(ref::Reg1) + 4 + (r[j].p ? (int64_t)sizeof(ref::Extra) + 4ll * r[j].p->n_cigar : 0);
+	}
+	if (!buf) return need;
+	if (cap < need) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm2amd_pack_regs: buffer too small");
+	uint8_t *o = buf;
+	for (int i = 0; i < n_frag; ++i) {
+		const int32_t n = n_reg[i];
+		memcpy(o, &n, 4), o += 4;
+		const ref::Reg1 *r = (const ref::Reg1 *)reg[i];
+		for (int j = 0; j < n; ++j) {
+			ref::Reg1 t = r[j];
+			const ref::Extra *ex = t.p;
+			t.p = nullptr;
+			memcpy(o, &t, sizeof t), o += sizeof t;
+			const uint32_t has = ex ? 1u : 0u;
+			memcpy(o, &has, 4), o += 4;
+			if (ex) { const size_t nb = sizeof(ref::Extra) + 4ull * ex->n_cigar; memcpy(o, ex, nb), o += nb; }
+		}
+	}
+	return need;
+}
+
+int mm2amd_unpack_regs(const uint8_t *buf, int64_t size, int n_frag, int *n_reg, void **reg)
+{
+	if (!buf || n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: bad arguments");
+	const uint8_t *o = buf, *end = buf + size;
+	for (int i = 0; i < n_frag; ++i) {
+		int32_t n;
+		if (end - o < 4) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+		memcpy(&n, o, 4), o += 4;
+		n_reg[i] = n, reg[i] = nullptr;
+		if (n <= 0) continue;
+		ref::Reg1 *r = (ref::Reg1 *)calloc(n, sizeof(ref::Reg1));
+		reg[i] = r;
+		for (int j = 0; j < n; ++j) {
+			uint32_t has;
+			if (end - o < (int64_t)sizeof(ref::Reg1) + 4) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+			memcpy(&r[j], o, sizeof(ref::Reg1)), o += sizeof(ref::Reg1);
+			memcpy(&has, o, 4), o += 4;
+			r[j].p = nullptr;
+			if (has) {
+				ref::Extra hd;
+				if (end - o < (int64_t)sizeof hd) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+				memcpy(&hd, o, sizeof hd);
+				const size_t nb = sizeof(ref::Extra) + 4ull * hd.n_cigar;
+				if ((size_t)(end - o) < nb) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+				size_t words = hd.capacity;
+				if (words * 4 < nb) words = (nb + 3) / 4;
+				r[j].p = (ref::Extra *)calloc(words, 4);
+				memcpy(r[j].p, o, nb), o += nb;
+				r[j].p->capacity = (uint32_t)words;
+			}
+		}
+	}
+	return 0;
+}
+
 int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_batch called before mm_gpu_init");
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch: bad arguments");
-	const ref::Bseq1 *seq = (const ref::Bseq1 *)seq_;
 	try {
-		std::vector<ReadView> reads(n_frag);
-		for (int i = 0; i < n_frag; ++i) {
-			if (n_seg[i] != 1) return capi_fail(MM2AMD_EINVAL, "[mm2amd] multi-segment fragments (paired-end) are not implemented");
-			const ref::Bseq1 &s = seq[seg_off[i]];
-			reads[i].seq = s.seq, reads[i].len = s.l_seq, reads[i].name = s.name;
-		}
+		std::vector<ReadView> reads;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, reads)) return rc;
 		std::vector<ReadResult> out;
 		g_ctx->mapper->map_batch(reads, out);
-		for (int i = 0; i < n_frag; ++i) {
-			const int o = seg_off[i];
-			const size_t n = out[i].regs.size();
-			n_reg[o] = (int)n;
-			reg[o] = nullptr;
-			if (n) { // handed over as one libc block, like the reference's realloc'd array (map.c:340)
-				reg[o] = malloc(n * sizeof(ref::Reg1));
-				memcpy(reg[o], out[i].regs.data(), n * sizeof(ref::Reg1));
-			}
-			if (rep_len) rep_len[o] = out[i].rep_len;
-			if (frag_gap) frag_gap[o] = out[i].frag_gap;
-		}
+		hand_over(n_frag, seg_off, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());

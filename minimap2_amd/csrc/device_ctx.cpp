@@ -1,5 +1,6 @@
 #include <cstdlib>
 #include "device_ctx.hpp"
+#include "kernel_prof.hpp"
 
 namespace mm2amd {
 
@@ -7,6 +8,12 @@ DeviceCtx &device_ctx()
 {
 	static DeviceCtx d;
 	return d;
+}
+
+KernelProfiler &kernel_profiler()
+{
+	static KernelProfiler p;
+	return p;
 }
 
 void ensure_device(DeviceCtx &d)

@@ -1,0 +1,336 @@
+// Device-side index construction: the GPU counterpart of mm_idx_gen's sketch -> bucket -> sort -> hash pipeline
+// (index.c:226-278, :369-408), producing the flat tables of flat_index.hpp directly in HBM.
+//
+//   1. encode   : ASCII -> nt4 (1 B/base) and 4-bit packed S (mmpriv.h:34-35)
+//   2. sketch   : mm_sketch (sketch.c:77-143) over fixed-size chunks.  The reference's window automaton is
+//                 sequential, but its state after any stretch of w+k consecutive valid slots is a function of that
+//                 stretch alone (hard part 7), so a lane that starts early enough before its
+//                 chunk reaches the true state before its first owned position; each lane emits only minimizers
+//                 whose position lies in its own chunk, which partitions the reference's output exactly.
+//   3. sort     : (hash, position) pairs by hash then position (two stable LSD radix passes, rocPRIM)
+//   4. tables   : distinct keys, value offsets, top-bits direct table
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <vector>
+#include "hip_util.hpp"
+#include "index_build.hpp"
+
+namespace mm2amd {
+
+extern const uint8_t kNt4Table[256];
+__constant__ uint8_t c_nt4_idx[256];
+
+__global__ void __launch_bounds__(256) idx_encode_kernel(const char *ascii, uint8_t *nt4, uint32_t *S, uint64_t total)
+{
+	// one thread per packed word (8 bases)
+	const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t b0 = wi * 8;
+	if (b0 >= total) return;
+	uint32_t word = 0;
+	for (int j = 0; j < 8 && b0 + j < total; ++j) {
+		const uint8_t c = c_nt4_idx[(uint8_t)ascii[b0 + j]];
+		nt4[b0 + j] = c;
+		word |= (uint32_t)c << (j << 2);
+	}
+	S[wi] = word;
+}
+
+__device__ __forceinline__ uint64_t mix64i(uint64_t key, uint64_t mask)
+{
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask;
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask;
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+struct ChunkDesc { uint32_t rid; uint32_t start; }; // chunk = [start, start + CHUNK) clipped to the sequence
+
+// one lane per chunk; non-HPC indices only (HPC needs run-length look-ahead across chunk borders)
+template <bool EMIT, int WMAX>
+__global__ void __launch_bounds__(64) idx_sketch_kernel(const uint8_t *nt4, const uint64_t *seq_off, const uint32_t *seq_len, const ChunkDesc *chunks,
+                                                         uint64_t n_chunks, int chunk_len, int w, int k, uint32_t *cnt, const uint64_t *out_off,
+                                                         uint64_t *out_hash, uint64_t *out_pos)
+{
+	const uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (ci >= n_chunks) return;
+	const uint32_t rid = chunks[ci].rid;
+	const int64_t cs = chunks[ci].start, len = seq_len[rid];
+	const int64_t ce = cs + chunk_len < len ? cs + chunk_len : len;
+	const uint8_t *seq = nt4 + seq_off[rid];
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	uint64_t bx[WMAX], by[WMAX];
+	uint64_t n_out = 0;
+	uint64_t *oh = nullptr, *op = nullptr;
+	if (EMIT) oh = out_hash + out_off[ci], op = out_pos + out_off[ci];
+
+	int64_t warm = 2 * (w + k) + 32;
+	for (;;) {
+		int64_t ws = cs - warm;
+		if (ws < 0) ws = 0;
+		// exact k-mer registers at ws: the last k non-N bases before it (N's do not shift the registers, sketch.c:105-106)
+		uint64_t kmer0 = 0, kmer1 = 0;
+		if (ws > 0) {
+			uint8_t last[32];
+			int got = 0;
+			for (int64_t j = ws - 1; j >= 0 && got < k; --j) { const uint8_t c = seq[j]; if (c < 4) last[got++] = c; }
+			for (int j = got - 1; j >= 0; --j) {
+				kmer0 = (kmer0 << 2 | (uint64_t)last[j]) & mask;
+				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)last[j]) << shift1;
+			}
+		}
+		uint64_t min_x = UINT64_MAX, min_y = UINT64_MAX;
+		int l = 0, buf_pos = 0, min_pos = 0;
+		bool synced = ws == 0; // at the sequence start the automaton is in its true initial state
+		n_out = 0;
+		for (int j = 0; j < w; ++j) bx[j] = by[j] = UINT64_MAX;
+		bool restart = false;
+#define EMIT_IDX(X, Y) do { const int64_t pp_ = (int64_t)((uint32_t)(Y) >> 1); if (pp_ >= cs && pp_ < ce) { if (EMIT) { oh[n_out] = (X) >> 8; op[n_out] = (Y); } ++n_out; } } while (0)
+		for (int64_t i = ws; i < len; ++i) {
+			if (i == cs && !synced) { restart = true; break; } // not enough clean history: start further back
+			// everything owned has been emitted: the window holds no valid k-mer, or its minimum lies past the chunk and the
+			// first-full-window rule (which may still emit an older equal-hash slot) can no longer fire on owned slots
+			if (i >= ce && (min_x == UINT64_MAX || ((int64_t)((uint32_t)min_y >> 1) >= ce && l >= w + k - 1))) break;
+			const int c = seq[i];
+			uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
+			if (c < 4) {
+				const int kmer_span = l + 1 < k ? l + 1 : k;
+				kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+				if (kmer0 == kmer1) continue;
+				const int z = kmer0 < kmer1 ? 0 : 1;
+				++l;
+				if (l >= k) {
+					ix = mix64i(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+					iy = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z;
+				}
+				if (l >= w + k) synced = true; // state now depends only on the last w+k valid slots
+			} else l = 0;
+			bx[buf_pos] = ix, by[buf_pos] = iy;
+			if (l == w + k - 1 && min_x != UINT64_MAX) {
+				for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j] && by[j] != min_y) EMIT_IDX(bx[j], by[j]);
+				for (int j = 0; j < buf_pos; ++j)     if (min_x == bx[j] && by[j] != min_y) EMIT_IDX(bx[j], by[j]);
+			}
+			if (ix <= min_x) {
+				if (l >= w + k && min_x != UINT64_MAX) EMIT_IDX(min_x, min_y);
+				min_x = ix, min_y = iy, min_pos = buf_pos;
+			} else if (buf_pos == min_pos) {
+				if (l >= w + k - 1 && min_x != UINT64_MAX) EMIT_IDX(min_x, min_y);
+				min_x = UINT64_MAX;
+				for (int j = buf_pos + 1; j < w; ++j) if (min_x >= bx[j]) min_x = bx[j], min_y = by[j], min_pos = j;
+				for (int j = 0; j <= buf_pos; ++j)    if (min_x >= bx[j]) min_x = bx[j], min_y = by[j], min_pos = j;
+				if (l >= w + k - 1 && min_x != UINT64_MAX) {
+					for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j] && min_y != by[j]) EMIT_IDX(bx[j], by[j]);
+					for (int j = 0; j <= buf_pos; ++j)    if (min_x == bx[j] && min_y != by[j]) EMIT_IDX(bx[j], by[j]);
+				}
+			}
+			if (++buf_pos == w) buf_pos = 0;
+		}
+		if (restart) { warm = warm * 4 + 1024; continue; }
+		if (min_x != UINT64_MAX) EMIT_IDX(min_x, min_y); // reached the end of the sequence (or the early exit with nothing owned pending)
+#undef EMIT_IDX
+		break;
+	}
+	if (!EMIT) cnt[ci] = (uint32_t)n_out;
+}
+
+__global__ void __launch_bounds__(256) idx_mark_heads_kernel(const uint64_t *hash, uint64_t n, uint32_t *is_head)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) is_head[i] = (i == 0 || hash[i] != hash[i - 1]) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) idx_scatter_keys_kernel(const uint64_t *hash, const uint32_t *is_head, const uint32_t *rank, uint64_t n,
+                                                                uint64_t *keys, uint32_t *val_off, uint64_t n_keys)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && is_head[i]) { keys[rank[i]] = hash[i]; val_off[rank[i]] = (uint32_t)i; }
+	if (i == 0) val_off[n_keys] = (uint32_t)n;
+}
+
+__global__ void __launch_bounds__(256) idx_bucket_start_kernel(const uint64_t *keys, uint64_t n_keys, int key_shift, uint64_t n_buckets, uint32_t *bucket_start)
+{
+	const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > n_buckets) return;
+	// first key whose bucket id is >= b
+	uint64_t lo = 0, hi = n_keys;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if ((keys[mid] >> key_shift) < b) lo = mid + 1; else hi = mid;
+	}
+	bucket_start[b] = (uint32_t)lo;
+}
+
+__global__ void __launch_bounds__(256) idx_occ_hist_kernel(const uint32_t *val_off, uint64_t n_keys, unsigned long long *hist, int n_bins)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_keys) return;
+	uint32_t c = val_off[i + 1] - val_off[i];
+	if (c >= (uint32_t)n_bins) c = n_bins - 1;
+	atomicAdd(&hist[c], 1ull);
+}
+
+void DeviceIndexBuilder::build(FlatIndex &fi, DeviceIndexTables &T, int k, int w, int flag, int n_seq, const char *const *seqs, const uint64_t *lens,
+                               const char *const *names, hipStream_t stream)
+{
+	if (flag & ref::I_HPC) throw std::invalid_argument("[mm2amd] device index build does not support HPC minimizers");
+	if (w <= 0 || w >= 256 || k <= 0 || k > 28) throw std::invalid_argument("[mm2amd] index build: need 0<w<256 and 0<k<=28");
+	HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_nt4_idx), kNt4Table, 256, 0, hipMemcpyHostToDevice, stream));
+	fi.k = k, fi.w = w, fi.flag = flag, fi.n_seq = (uint32_t)n_seq, fi.n_alt = 0;
+	fi.names.resize(n_seq), fi.seq_off.resize(n_seq), fi.seq_len.resize(n_seq);
+	uint64_t total = 0;
+	for (int i = 0; i < n_seq; ++i) {
+		if (lens[i] >= (1ull << 31)) throw std::invalid_argument("[mm2amd] reference sequences must be shorter than 2^31 bases");
+		fi.names[i] = names && names[i] ? names[i] : "";
+		fi.seq_off[i] = total, fi.seq_len[i] = (uint32_t)lens[i];
+		total += lens[i];
+	}
+	fi.sum_len = total;
+	const uint64_t n_words = (total + 7) / 8;
+	// 1. upload + encode
+	DevBuf<char> d_ascii;
+	DevBuf<uint8_t> d_nt4;
+	d_ascii.ensure(total + 8, 1.0), d_nt4.ensure(total + 8, 1.0);
+	T.S.ensure(n_words + 1, 1.0);
+	for (int i = 0; i < n_seq; ++i)
+		if (lens[i]) HIP_CHECK(hipMemcpyAsync(d_ascii.p + fi.seq_off[i], seqs[i], lens[i], hipMemcpyHostToDevice, stream));
+	if (n_words) hipLaunchKernelGGL(idx_encode_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, d_ascii.p, d_nt4.p, T.S.p, total);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipStreamSynchronize(stream));
+	d_ascii.release();
+	fi.S_own.resize(n_words);
+	if (n_words) HIP_CHECK(hipMemcpy(fi.S_own.data(), T.S.p, n_words * 4, hipMemcpyDeviceToHost));
+	fi.S = fi.S_own.data();
+	// 2. chunked sketch: count, scan, emit
+	const int chunk_len = 2048;
+	std::vector<ChunkDesc> chunks;
+	for (int i = 0; i < n_seq; ++i)
+		for (uint64_t s = 0; s < lens[i]; s += chunk_len) chunks.push_back(ChunkDesc{(uint32_t)i, (uint32_t)s});
+	const uint64_t n_chunks = chunks.size();
+	DevBuf<ChunkDesc> d_chunks;
+	DevBuf<uint64_t> d_seq_off, d_out_off;
+	DevBuf<uint32_t> d_seq_len, d_cnt;
+	d_chunks.ensure(n_chunks + 1, 1.0), d_seq_off.ensure(n_seq + 1, 1.0), d_seq_len.ensure(n_seq + 1, 1.0), d_cnt.ensure(n_chunks + 1, 1.0), d_out_off.ensure(n_chunks + 2, 1.0);
+	if (n_chunks) HIP_CHECK(hipMemcpyAsync(d_chunks.p, chunks.data(), n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(d_seq_off.p, fi.seq_off.data(), n_seq * 8, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(d_seq_len.p, fi.seq_len.data(), n_seq * 4, hipMemcpyHostToDevice, stream));
+	const dim3 sgrid((unsigned)((n_chunks + 63) / 64)), sblock(64);
+	auto run_sketch = [&](bool emit, uint64_t *oh, uint64_t *op) {
+		if (n_chunks == 0) return;
+		if (w <= 32) {
+			if (emit) hipLaunchKernelGGL((idx_sketch_kernel<true, 32>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
+			else hipLaunchKernelGGL((idx_sketch_kernel<false, 32>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
+		} else {
+			if (emit) hipLaunchKernelGGL((idx_sketch_kernel<true, 256>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
+			else hipLaunchKernelGGL((idx_sketch_kernel<false, 256>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
+		}
+		HIP_CHECK(hipGetLastError());
+	};
+	run_sketch(false, nullptr, nullptr);
+	std::vector<uint32_t> h_cnt(n_chunks);
+	if (n_chunks) HIP_CHECK(hipMemcpyAsync(h_cnt.data(), d_cnt.p, n_chunks * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	std::vector<uint64_t> h_off(n_chunks + 1);
+	h_off[0] = 0;
+	for (uint64_t i = 0; i < n_chunks; ++i) h_off[i + 1] = h_off[i] + h_cnt[i];
+	const uint64_t n_mz = h_off[n_chunks];
+	if (n_mz >= (1ull << 32)) throw std::invalid_argument("[mm2amd] more than 2^32 minimizers: split the reference (the reference's -I does the same)");
+	HIP_CHECK(hipMemcpyAsync(d_out_off.p, h_off.data(), (n_chunks + 1) * 8, hipMemcpyHostToDevice, stream));
+	DevBuf<uint64_t> d_hash, d_pos, d_hash2, d_pos2;
+	d_hash.ensure(n_mz + 1, 1.0), d_pos.ensure(n_mz + 1, 1.0), d_hash2.ensure(n_mz + 1, 1.0), d_pos2.ensure(n_mz + 1, 1.0);
+	run_sketch(true, d_hash.p, d_pos.p);
+	d_nt4.release();
+	// 3. sort by (hash, pos): positions are already ascending within a chunk and chunks are in (rid, start) order, so the
+	//    pairs are sorted by pos; one stable sort by hash finishes the job (index.c:236 + :265 yield the same order).
+	{
+		size_t tmp_bytes = 0;
+		hipcub::DoubleBuffer<uint64_t> kb(d_hash.p, d_hash2.p), vb(d_pos.p, d_pos2.p);
+		HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, (int64_t)n_mz, 0, 2 * k, stream));
+		DevBuf<uint8_t> d_tmp;
+		d_tmp.ensure(tmp_bytes + 16, 1.0);
+		HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, kb, vb, (int64_t)n_mz, 0, 2 * k, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		if (kb.Current() != d_hash.p) std::swap(d_hash.p, d_hash2.p), std::swap(d_hash.cap, d_hash2.cap);
+		if (vb.Current() != d_pos.p) std::swap(d_pos.p, d_pos2.p), std::swap(d_pos.cap, d_pos2.cap);
+	}
+	d_hash2.release(), d_pos2.release();
+	// 4. tables
+	DevBuf<uint32_t> d_head, d_rank;
+	d_head.ensure(n_mz + 1, 1.0), d_rank.ensure(n_mz + 1, 1.0);
+	const unsigned gb = (unsigned)((n_mz + 255) / 256);
+	uint64_t n_keys = 0;
+	if (n_mz) {
+		hipLaunchKernelGGL(idx_mark_heads_kernel, dim3(gb), dim3(256), 0, stream, d_hash.p, n_mz, d_head.p);
+		size_t tmp_bytes = 0;
+		HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_head.p, d_rank.p, (int64_t)n_mz, stream));
+		DevBuf<uint8_t> d_tmp;
+		d_tmp.ensure(tmp_bytes + 16, 1.0);
+		HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_head.p, d_rank.p, (int64_t)n_mz, stream));
+		uint32_t last_rank = 0, last_head = 0;
+		HIP_CHECK(hipMemcpyAsync(&last_rank, d_rank.p + n_mz - 1, 4, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(&last_head, d_head.p + n_mz - 1, 4, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		n_keys = (uint64_t)last_rank + last_head;
+	}
+	T.keys.ensure(n_keys + 1, 1.0), T.val_off.ensure(n_keys + 2, 1.0);
+	if (n_mz) hipLaunchKernelGGL(idx_scatter_keys_kernel, dim3(gb), dim3(256), 0, stream, d_hash.p, d_head.p, d_rank.p, n_mz, T.keys.p, T.val_off.p, n_keys);
+	else HIP_CHECK(hipMemsetAsync(T.val_off.p, 0, 4, stream));
+	HIP_CHECK(hipGetLastError());
+	// hand the sorted positions over
+	T.pos.release();
+	T.pos.p = d_pos.p, T.pos.cap = d_pos.cap, d_pos.p = nullptr, d_pos.cap = 0;
+	int hash_bits = 2 * k, want = 1;
+	while ((1ull << want) < n_keys && want < 28) ++want;
+	T.bucket_bits = std::min(hash_bits, std::max(8, want));
+	T.key_shift = hash_bits - T.bucket_bits;
+	const uint64_t n_buckets = 1ull << T.bucket_bits;
+	T.bucket_start.ensure(n_buckets + 2, 1.0);
+	hipLaunchKernelGGL(idx_bucket_start_kernel, dim3((unsigned)((n_buckets + 1 + 255) / 256)), dim3(256), 0, stream, T.keys.p, n_keys, T.key_shift, n_buckets, T.bucket_start.p);
+	HIP_CHECK(hipGetLastError());
+	T.n_keys = n_keys, T.n_pos = n_mz;
+	// occurrence histogram for mm_idx_cal_max_occ (index.c:198-220)
+	const int n_bins = 1 << 16;
+	DevBuf<unsigned long long> d_hist;
+	d_hist.ensure(n_bins, 1.0);
+	HIP_CHECK(hipMemsetAsync(d_hist.p, 0, n_bins * 8, stream));
+	if (n_keys) hipLaunchKernelGGL(idx_occ_hist_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, stream, T.val_off.p, n_keys, d_hist.p, n_bins);
+	T.occ_hist.resize(n_bins);
+	HIP_CHECK(hipMemcpyAsync(T.occ_hist.data(), d_hist.p, n_bins * 8, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	fi.bucket_bits = T.bucket_bits, fi.key_shift = T.key_shift;
+}
+
+void DeviceIndexTables::upload(const FlatIndex &fi, hipStream_t stream)
+{
+	auto up32 = [&](DevBuf<uint32_t> &d, const std::vector<uint32_t> &h) { d.ensure(h.size() + 1, 1.0); if (!h.empty()) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream)); };
+	auto up64 = [&](DevBuf<uint64_t> &d, const std::vector<uint64_t> &h) { d.ensure(h.size() + 1, 1.0); if (!h.empty()) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream)); };
+	up32(bucket_start, fi.bucket_start), up32(val_off, fi.val_off), up64(keys, fi.keys), up64(pos, fi.pos);
+	const size_t s_words = (fi.sum_len + 7) / 8;
+	S.ensure(s_words + 1, 1.0);
+	if (s_words) HIP_CHECK(hipMemcpyAsync(S.p, fi.S, s_words * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	n_keys = fi.keys.size(), n_pos = fi.pos.size(), bucket_bits = fi.bucket_bits, key_shift = fi.key_shift;
+	occ_hist.assign(1 << 16, 0);
+	for (size_t i = 0; i < fi.keys.size(); ++i) { uint32_t c = fi.val_off[i + 1] - fi.val_off[i]; ++occ_hist[c < occ_hist.size() ? c : occ_hist.size() - 1]; }
+}
+
+int32_t DeviceIndexTables::cal_max_occ(float f) const
+{
+	if (f <= 0.f || n_keys == 0) return INT32_MAX;
+	const uint64_t kk = (uint32_t)((1. - f) * n_keys); // 0-based rank of the wanted occurrence count
+	uint64_t acc = 0;
+	for (size_t c = 0; c < occ_hist.size(); ++c) {
+		acc += occ_hist[c];
+		if (acc > kk) {
+			if (c + 1 == occ_hist.size()) throw std::runtime_error("[mm2amd] occurrence count beyond histogram range");
+			return (int32_t)c + 1;
+		}
+	}
+	return INT32_MAX;
+}
+
+} // namespace mm2amd

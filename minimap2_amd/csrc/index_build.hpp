@@ -1,0 +1,28 @@
+// Device-resident index tables and their construction on the GPU (index_build.hip).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "hip_util.hpp"
+#include "flat_index.hpp"
+
+namespace mm2amd {
+
+// The flat minimizer tables of flat_index.hpp living in HBM, plus the 4-bit packed reference.
+struct DeviceIndexTables {
+	DevBuf<uint32_t> bucket_start, val_off, S;
+	DevBuf<uint64_t> keys, pos;
+	uint64_t n_keys = 0, n_pos = 0;
+	int bucket_bits = 0, key_shift = 0;
+	std::vector<unsigned long long> occ_hist; // occ_hist[c] = number of distinct minimizers occurring c times (last bin: >=)
+	int32_t cal_max_occ(float f) const;       // mm_idx_cal_max_occ (index.c:198-220) from the histogram
+	void upload(const FlatIndex &fi, hipStream_t stream); // mirror host-side tables (index flattened from a reference mm_idx_t)
+};
+
+struct DeviceIndexBuilder {
+	// In-memory index construction, the device counterpart of mm_idx_str (index.c:421-470) / mm_idx_gen (index.c:389-408).
+	// Fills the host-side part of `fi` (names, lengths, packed S; no host hash tables) and the device tables `T`.
+	static void build(FlatIndex &fi, DeviceIndexTables &T, int k, int w, int flag, int n_seq, const char *const *seqs, const uint64_t *lens,
+	                  const char *const *names, hipStream_t stream);
+};
+
+} // namespace mm2amd

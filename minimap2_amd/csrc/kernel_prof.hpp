@@ -1,0 +1,63 @@
+// Per-kernel timing with HIP events on the stream the kernels are launched on, plus the algorithmic byte count of each
+// launch -- the numbers behind bench.py's "roofline" object.  Off by default; enabling it costs
+// two hipEventRecord calls per launch.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "hip_util.hpp"
+
+namespace mm2amd {
+
+struct KernelStat { double ms = 0, alg_bytes = 0; long launches = 0; };
+
+class KernelProfiler {
+public:
+	bool enabled = false;
+	void begin(hipStream_t s)
+	{
+		if (!enabled) return;
+		Pending p;
+		p.e0 = get_event(), p.e1 = get_event();
+		HIP_CHECK(hipEventRecord(p.e0, s));
+		pending_.push_back(p);
+	}
+	void end(hipStream_t s, const char *name, double alg_bytes)
+	{
+		if (!enabled) return;
+		Pending &p = pending_.back();
+		p.name = name, p.bytes = alg_bytes;
+		HIP_CHECK(hipEventRecord(p.e1, s));
+	}
+	// call after the stream has been synchronised
+	void collect()
+	{
+		for (Pending &p : pending_) {
+			float ms = 0;
+			if (p.name && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+				KernelStat &k = stats_[p.name];
+				k.ms += ms, k.alg_bytes += p.bytes, ++k.launches;
+			}
+			free_.push_back(p.e0), free_.push_back(p.e1);
+		}
+		pending_.clear();
+	}
+	void reset() { collect(); stats_.clear(); }
+	const std::map<std::string, KernelStat> &stats() const { return stats_; }
+private:
+	struct Pending { hipEvent_t e0, e1; const char *name = nullptr; double bytes = 0; };
+	hipEvent_t get_event()
+	{
+		if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; }
+		hipEvent_t e;
+		HIP_CHECK(hipEventCreate(&e));
+		return e;
+	}
+	std::vector<Pending> pending_;
+	std::vector<hipEvent_t> free_;
+	std::map<std::string, KernelStat> stats_;
+};
+
+KernelProfiler &kernel_profiler(); // device_ctx.cpp
+
+} // namespace mm2amd

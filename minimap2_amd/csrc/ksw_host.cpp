@@ -2,6 +2,7 @@
 #include <numeric>
 #include <cstring>
 #include "ksw_host.hpp"
+#include "kernel_prof.hpp"
 
 namespace mm2amd {
 
@@ -59,9 +60,14 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (end == beg) continue;
 			int max_T16 = 16, max_Q16 = 16;
 			size_t slot_bytes = 16, tmp_cap = 16;
+			double alg_bytes = 0; // query bytes + packed target + result record; the 1 B/cell direction matrix only
+			                      // counts when it cannot stay on chip (> 160 KB of LDS); CIGAR bytes are added after the launch
 			for (size_t i = beg; i < end; ++i) {
 				const KswJob &j = sorted[i];
+				alg_bytes += sizeof(KswJob) + sizeof(KswRes);
 				if ((j.flag & KSWJ_SKIP) || j.qlen <= 0 || j.tlen <= 0) continue;
+				alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
+				if (!(j.flag & KSW_SCORE_ONLY)) { const size_t db = ksw_dir_bytes(j.qlen, j.tlen, j.w); if (db > 160 * 1024) alg_bytes += (double)db; }
 				max_T16 = std::max(max_T16, r16(j.tlen)), max_Q16 = std::max(max_Q16, r16(j.qlen));
 				if (!(j.flag & KSW_SCORE_ONLY)) {
 					slot_bytes = std::max(slot_bytes, ksw_dir_bytes(j.qlen, j.tlen, j.w));
@@ -87,7 +93,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.dir_pool = d_dir.p, L.slot_bytes = slot_bytes;
 			L.counter = d_counter.p + tier;
 			L.max_T16 = max_T16, L.max_Q16 = max_Q16, L.sc = sc;
+			kernel_profiler().begin(stream);
 			ksw_extd2_launch(L, (int)n_slots, wpb, stream);
+			kernel_profiler().end(stream, tier == 0 ? "ksw_extd2_kernel[t0]" : tier == 1 ? "ksw_extd2_kernel[t1]" : "ksw_extd2_kernel[t2]", alg_bytes);
 			beg = end;
 		}
 		uint32_t cursor[2];

@@ -1,4 +1,5 @@
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include "mapper.hpp"
@@ -41,25 +42,28 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	if (fi.n_alt) throw std::invalid_argument("[mm2amd] ALT-aware mapping is not implemented");
 }
 
-void Mapper::map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out)
+void Mapper::stage(const std::vector<ReadView> &reads)
 {
-	const long n = (long)reads.size();
+	n_staged_ = (long)reads.size();
+	live_.clear(), live_id_.clear(), qoff_.clear();
+	// which reads are mapped at all (map.c:243-244)
+	for (long i = 0; i < n_staged_; ++i)
+		if (reads[i].len > 0 && !(opt_.max_qlen > 0 && reads[i].len > opt_.max_qlen)) live_.push_back(reads[i]), live_id_.push_back(i);
+	if (!live_.empty()) be_.begin_batch(live_, qoff_);
+}
+
+void Mapper::run(std::vector<ReadResult> &out)
+{
+	const long n = n_staged_;
 	out.clear();
 	out.resize(n);
 	stats = MapperStats();
-	if (n == 0) return;
+	const std::vector<ReadView> &live = live_;
+	const std::vector<long> &live_id = live_id_;
+	const std::vector<uint64_t> &qoff = qoff_;
+	const long m_all = (long)live.size();
+	if (m_all == 0) return;
 	double t0 = now();
-
-	// which reads are mapped at all (map.c:243-244)
-	std::vector<ReadView> live;
-	std::vector<long> live_id;
-	for (long i = 0; i < n; ++i)
-		if (reads[i].len > 0 && !(opt_.max_qlen > 0 && reads[i].len > opt_.max_qlen)) live.push_back(reads[i]), live_id.push_back(i);
-	const long m = (long)live.size();
-	if (m == 0) return;
-
-	std::vector<uint64_t> qoff;
-	be_.begin_batch(live, qoff);
 
 	// chaining parameters (map.c:262-274); single segment, not sr
 	SeedChainParams sp;
@@ -75,96 +79,105 @@ void Mapper::map_batch(const std::vector<ReadView> &reads, std::vector<ReadResul
 	sp.is_cdna = 0;
 	if (opt_.max_gap_ref <= 0 && opt_.max_frag_len > 0) throw std::invalid_argument("[mm2amd] max_frag_len-derived chaining gap is a paired-end feature and is not implemented");
 
-	std::vector<ReadChains> chains;
-	be_.seed_chain(sp, chains);
-	stats.t_seed_chain = now() - t0; t0 = now();
+	// sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight)
+	long sub_bases = 200000000;
+	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
+	for (long lo = 0, hi; lo < m_all; lo = hi) {
+		long bases = 0;
+		for (hi = lo; hi < m_all && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
+		const long m = hi - lo;
+		t0 = now();
+		std::vector<ReadChains> chains;
+		be_.seed_chain(sp, lo, hi, chains);
+		stats.t_seed_chain += now() - t0; t0 = now();
 
-	// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
-	Aligner aligner(opt_, fi_);
-	std::vector<ReadAlign> ra(m);
-	std::vector<RegVec> regs0(m);
-	parallel_for(n_threads_, m, [&](long i, int) {
-		ReadChains &c = chains[i];
-		const int qlen = live[i].len;
-		ReadResult &res = out[live_id[i]];
-		const uint32_t hash = read_hash(live[i].name, qlen, opt_);
-		if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && c.u.size() > 1) { // long-join re-chaining (map.c:283-292)
-			const int32_t st = (int32_t)c.a[0].y, en = (int32_t)c.a[(int32_t)c.u[0] - 1].y;
-			if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {
-				ChainScratch sc;
-				std::vector<Anchor> a2(c.a);
-				sort_by_x(a2.data(), a2.data() + a2.size());
-				std::vector<uint64_t> u2;
-				std::vector<Anchor> out_a;
-				chain_rmq(opt_.max_gap, opt_.rmq_inner_dist, opt_.bw_long, opt_.max_chain_skip, opt_.rmq_size_cap, opt_.min_cnt, opt_.min_chain_score,
-				          sp.chn_pen_gap, sp.chn_pen_skip, (int64_t)a2.size(), a2.data(), u2, out_a, sc);
-				c.u.swap(u2), c.a.swap(out_a);
+		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
+		Aligner aligner(opt_, fi_);
+		std::vector<ReadAlign> ra(m);
+		std::vector<RegVec> regs0(m);
+		parallel_for(n_threads_, m, [&](long i, int) {
+			ReadChains &c = chains[i];
+			const int qlen = live[lo + i].len;
+			ReadResult &res = out[live_id[lo + i]];
+			const uint32_t hash = read_hash(live[lo + i].name, qlen, opt_);
+			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && c.u.size() > 1) { // long-join re-chaining (map.c:283-292)
+				const int32_t st = (int32_t)c.a[0].y, en = (int32_t)c.a[(int32_t)c.u[0] - 1].y;
+				if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {
+					ChainScratch sc;
+					std::vector<Anchor> a2(c.a);
+					sort_by_x(a2.data(), a2.data() + a2.size());
+					std::vector<uint64_t> u2;
+					std::vector<Anchor> out_a;
+					chain_rmq(opt_.max_gap, opt_.rmq_inner_dist, opt_.bw_long, opt_.max_chain_skip, opt_.rmq_size_cap, opt_.min_cnt, opt_.min_chain_score,
+					          sp.chn_pen_gap, sp.chn_pen_skip, (int64_t)a2.size(), a2.data(), u2, out_a, sc);
+					c.u.swap(u2), c.a.swap(out_a);
+				}
 			}
-		}
-		res.frag_gap = sp.max_gap_ref, res.rep_len = c.rep_len;
-		RegVec &r0 = regs0[i];
-		gen_regs(hash, qlen, c.u, c.a.data(), false, r0);
-		if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
-			set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
-			select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
-		}
-		est_err(fi_, qlen, r0, c.a.data(), c.mini_pos);
-		filter_strand_retained(r0);
-		aligner.begin_read(ra[i], live[i].seq, qlen, r0, c.a, qoff[i]);
-	});
-	stats.t_host_pre = now() - t0;
+			res.frag_gap = sp.max_gap_ref, res.rep_len = c.rep_len;
+			RegVec &r0 = regs0[i];
+			gen_regs(hash, qlen, c.u, c.a.data(), false, r0);
+			if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
+				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
+				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
+			}
+			est_err(fi_, qlen, r0, c.a.data(), c.mini_pos);
+			filter_strand_retained(r0);
+			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a, qoff[lo + i]);
+		});
+		stats.t_host_pre += now() - t0;
 
-	// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
-	KswScoring sc;
-	memcpy(sc.mat, aligner.mat(), 25);
-	sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.pad[0] = sc.pad[1] = 0;
-	std::vector<std::vector<KswJob>> per_read_jobs(m);
-	std::vector<size_t> job_base(m + 1);
-	std::vector<KswJob> jobs;
-	std::vector<KswRes> kres;
-	std::vector<uint32_t> cigars;
-	std::vector<uint8_t> active(m, 1);
-	// Aligner holds a scratch buffer, so each worker thread gets its own instance
-	std::vector<std::unique_ptr<Aligner>> al(n_threads_);
-	for (auto &p : al) p.reset(new Aligner(opt_, fi_));
-	for (int round = 0;; ++round) {
+		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
+		KswScoring sc;
+		memcpy(sc.mat, aligner.mat(), 25);
+		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.pad[0] = sc.pad[1] = 0;
+		std::vector<std::vector<KswJob>> per_read_jobs(m);
+		std::vector<size_t> job_base(m + 1);
+		std::vector<KswJob> jobs;
+		std::vector<KswRes> kres;
+		std::vector<uint32_t> cigars;
+		std::vector<uint8_t> active(m, 1);
+		// Aligner holds a scratch buffer, so each worker thread gets its own instance
+		std::vector<std::unique_ptr<Aligner>> al(n_threads_);
+		for (auto &p : al) p.reset(new Aligner(opt_, fi_));
+		for (int round = 0;; ++round) {
+			t0 = now();
+			parallel_for(n_threads_, m, [&](long i, int tid) {
+				per_read_jobs[i].clear();
+				if (active[i]) al[tid]->schedule(ra[i], per_read_jobs[i]);
+			});
+			job_base[0] = 0;
+			for (long i = 0; i < m; ++i) job_base[i + 1] = job_base[i] + per_read_jobs[i].size();
+			if (job_base[m] == 0) break;
+			jobs.resize(job_base[m]);
+			parallel_for(n_threads_, m, [&](long i, int) {
+				if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
+			}, 256);
+			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
+			stats.t_plan += now() - t0; t0 = now();
+			be_.ksw(jobs, sc, kres, cigars);
+			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
+			stats.t_ksw += now() - t0; t0 = now();
+			parallel_for(n_threads_, m, [&](long i, int tid) {
+				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars.data()) ? 1 : 0;
+			});
+			stats.t_consume += now() - t0;
+			if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");
+		}
+
+		// ---- final hit selection and MAPQ (map.c:215-225, :339-342) ----
 		t0 = now();
 		parallel_for(n_threads_, m, [&](long i, int tid) {
-			per_read_jobs[i].clear();
-			if (active[i]) al[tid]->schedule(ra[i], per_read_jobs[i]);
+			ReadResult &res = out[live_id[lo + i]];
+			al[tid]->finish_read(ra[i], res.regs);
+			if (!(opt_.flag & F_ALL_CHAINS)) {
+				set_parent(opt_.mask_level, opt_.mask_len, res.regs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
+				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), res.regs);
+				set_sam_pri(res.regs);
+			}
+			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, false);
 		});
-		job_base[0] = 0;
-		for (long i = 0; i < m; ++i) job_base[i + 1] = job_base[i] + per_read_jobs[i].size();
-		if (job_base[m] == 0) break;
-		jobs.resize(job_base[m]);
-		parallel_for(n_threads_, m, [&](long i, int) {
-			if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
-		}, 256);
-		for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
-		stats.t_plan += now() - t0; t0 = now();
-		be_.ksw(jobs, sc, kres, cigars);
-		stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
-		stats.t_ksw += now() - t0; t0 = now();
-		parallel_for(n_threads_, m, [&](long i, int tid) {
-			if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars.data()) ? 1 : 0;
-		});
-		stats.t_consume += now() - t0;
-		if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");
+		stats.t_finish += now() - t0;
 	}
-
-	// ---- final hit selection and MAPQ (map.c:215-225, :339-342) ----
-	t0 = now();
-	parallel_for(n_threads_, m, [&](long i, int tid) {
-		ReadResult &res = out[live_id[i]];
-		al[tid]->finish_read(ra[i], res.regs);
-		if (!(opt_.flag & F_ALL_CHAINS)) {
-			set_parent(opt_.mask_level, opt_.mask_len, res.regs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
-			select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), res.regs);
-			set_sam_pri(res.regs);
-		}
-		set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, false);
-	});
-	stats.t_finish = now() - t0;
 }
 
 } // namespace mm2amd

@@ -25,13 +25,21 @@ struct MapperStats { // wall-clock seconds per stage of the last map_batch (for 
 class Mapper {
 public:
 	Mapper(const FlatIndex &fi, const ref::MapOpt &opt, Backend &be, int n_threads);
-	void map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out);
+	void map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out) { stage(reads); run(out); }
+	// the two halves of map_batch: stage() makes the batch resident on the device (the hand-over the reference's pipeline
+	// step 0 performs), run() is the hot path proper.  The ReadViews must stay valid until run() returns.
+	void stage(const std::vector<ReadView> &reads);
+	void run(std::vector<ReadResult> &out);
 	MapperStats stats;
 private:
 	const FlatIndex &fi_;
 	ref::MapOpt opt_;
 	Backend &be_;
 	int n_threads_;
+	long n_staged_ = 0;
+	std::vector<ReadView> live_;
+	std::vector<long> live_id_;
+	std::vector<uint64_t> qoff_;
 };
 
 uint32_t read_hash(const char *qname, int qlen, const ref::MapOpt &opt); // map.c:246-248

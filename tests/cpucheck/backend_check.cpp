@@ -38,12 +38,12 @@ public:
 			}
 		}
 	}
-	void seed_chain(const SeedChainParams &p, std::vector<ReadChains> &out) override
+	void seed_chain(const SeedChainParams &p, long lo, long hi, std::vector<ReadChains> &out) override
 	{
 		out.clear();
-		out.resize(reads_.size());
+		out.resize((size_t)(hi - lo));
 		std::vector<ora128_t> mv;
-		for (size_t i = 0; i < reads_.size(); ++i) {
+		for (size_t i = (size_t)lo; i < (size_t)hi; ++i) {
 			const int len = reads_[i].len;
 			mv.resize((size_t)len + 1);
 			int64_t n_mv = ora_sketch(reads_[i].seq, len, p.w, p.k, 0, p.is_hpc, mv.data(), (int64_t)mv.size());
@@ -52,7 +52,7 @@ public:
 			int64_t n_a = 0;
 			int n_mp = 0, rep_len = 0;
 			ora_collect_seed_hits(&fi_, flat_get, p.flag, len, p.mid_occ, p.max_max_occ, p.occ_dist, p.q_occ_frac, mv.data(), n_mv, &a, &n_a, &mp, &n_mp, &rep_len);
-			ReadChains &c = out[i];
+			ReadChains &c = out[i - (size_t)lo];
 			c.rep_len = rep_len;
 			c.mini_pos.assign(mp, mp + n_mp);
 			c.u.resize(n_a > 0 ? n_a : 1);
@@ -104,7 +104,11 @@ private:
 
 } // namespace
 
-Backend *make_backend(const FlatIndex &fi, int /*device*/) { return new CheckBackend(fi); }
+Backend *make_backend(const FlatIndex &fi, void * /*device_tables*/) { return new CheckBackend(fi); }
 const char *backend_name() { return "cpu-check(oracle)"; }
+// the check library has no device-built index objects
+struct IndexHandle;
+const FlatIndex &index_flat(const IndexHandle *) { throw std::runtime_error("check backend: no device index"); }
+void *index_device_tables(const IndexHandle *) { return nullptr; }
 
 } // namespace mm2amd

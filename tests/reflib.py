@@ -203,3 +203,131 @@ def ora_lchain_dp(a, max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, mi
     n_u = O.ora_lchain_dp(max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, pen_gap, pen_skip, is_cdna, n_seg, n,
                           a.ctypes.data, u.ctypes.data, C.byref(na))
     return u[:n_u].copy(), a[:na.value].copy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole-read mapping with the compiled reference: mm_idx_str + mm_map (minimap.h:324, :350)
+# ---------------------------------------------------------------------------------------------------------
+class RefMapper(object):
+    def __init__(self, refs, preset, names=None, cigar=True, extra_flag=0):
+        import minimap2_amd as mm  # struct mirrors only
+        self.mm = mm
+        R = self.R = C.CDLL(REF_SO)
+        self.io, self.mo = mm.IdxOpt(), mm.MapOpt()
+        R.mm_set_opt(None, C.byref(self.io), C.byref(self.mo))
+        if preset is not None:
+            assert R.mm_set_opt(preset.encode(), C.byref(self.io), C.byref(self.mo)) == 0
+        if cigar:
+            self.mo.flag |= mm.F_CIGAR
+        self.mo.flag |= extra_flag
+        R.mm_idx_str.restype = C.c_void_p
+        R.mm_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+        n = len(refs)
+        nm = [(x.encode() if isinstance(x, str) else x) for x in (names or ["ref%d" % i for i in range(n)])]
+        self._keep = (list(refs), nm)
+        self.mi = R.mm_idx_str(self.io.w, self.io.k, self.io.flag & 1, self.io.bucket_bits, n, (C.c_char_p * n)(*refs), (C.c_char_p * n)(*nm))
+        R.mm_mapopt_update.argtypes = [C.c_void_p, C.c_void_p]
+        R.mm_mapopt_update(C.byref(self.mo), self.mi)
+        R.mm_tbuf_init.restype = C.c_void_p
+        R.mm_tbuf_destroy.argtypes = [C.c_void_p]
+        R.mm_map.restype = C.POINTER(mm.Reg1)
+        R.mm_map.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_char_p]
+        R.mm_idx_destroy.argtypes = [C.c_void_p]
+        self.tbuf = R.mm_tbuf_init()
+
+    def map(self, name, seq):
+        """-> list of Alignment.key()-shaped tuples"""
+        mm = self.mm
+        n = C.c_int(0)
+        nb = name.encode() if isinstance(name, str) else name
+        regs = self.R.mm_map(self.mi, len(seq), seq, C.byref(n), self.tbuf, C.byref(self.mo), nb)
+        out = [a.key() for a in mm._regs_to_alignments(n.value, regs, None, None)]
+        for j in range(n.value):
+            if regs[j].p:
+                _libc.free(C.cast(regs[j].p, C.c_void_p))
+        if regs:
+            _libc.free(C.cast(regs, C.c_void_p))
+        return out
+
+    def close(self):
+        if self.mi:
+            self.R.mm_tbuf_destroy(self.tbuf)
+            self.R.mm_idx_destroy(self.mi)
+            self.mi = None
+
+
+def ref_map_reads(refs, reads, preset, names=None):
+    m = RefMapper(refs, preset, names)
+    out = [m.map(nm, s) for nm, s in reads]
+    m.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# oracle/_ref/librefdrv.so: adopt a flat minimizer table as a reference mm_idx_t, and a threaded mm_map loop
+# ---------------------------------------------------------------------------------------------------------
+REFDRV_SO = os.path.join(ORACLE_DIR, "_ref", "librefdrv.so")
+
+
+class RefDriver(object):
+    """The reference's mm_map over many reads on n_threads host threads, against an mm_idx_t adopted from flat tables
+    (keys/val_off/pos as exported by mm2amd_idx_export or computed by any other means)."""
+
+    def __init__(self, w, k, flag, names, lens, S, keys, val_off, pos, n_threads):
+        import minimap2_amd as mm
+        self.mm = mm
+        D = self.D = C.CDLL(REFDRV_SO)
+        D.refdrv_idx_from_flat.restype = C.c_void_p
+        D.refdrv_idx_from_flat.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p,
+                                           C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        D.refdrv_map.restype = C.c_double
+        D.refdrv_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.c_int,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        D.mm_idx_destroy.argtypes = [C.c_void_p]
+        D.mm_mapopt_update.argtypes = [C.c_void_p, C.c_void_p]
+        n = len(names)
+        nm = [(x.encode() if isinstance(x, str) else x) for x in names]
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.n_threads = n_threads
+        self.mi = D.refdrv_idx_from_flat(w, k, flag, 14, n, (C.c_char_p * n)(*nm), lens.ctypes.data, S.ctypes.data, len(keys), keys.ctypes.data,
+                                         val_off.ctypes.data, pos.ctypes.data, n_threads)
+
+    def map_opt(self, preset, cigar=True, extra_flag=0):
+        mm = self.mm
+        io, mo = mm.IdxOpt(), mm.MapOpt()
+        self.D.mm_set_opt(None, C.byref(io), C.byref(mo))
+        if preset is not None:
+            assert self.D.mm_set_opt(preset.encode(), C.byref(io), C.byref(mo)) == 0
+        if cigar:
+            mo.flag |= mm.F_CIGAR
+        mo.flag |= extra_flag
+        self.D.mm_mapopt_update(C.byref(mo), self.mi)
+        return mo
+
+    def map(self, mo, reads):
+        """reads: list of (name, seq) -> (wall seconds of the mm_map loop, n_reg, reg) ; free with mm2amd_free_regs-like free_regs()"""
+        n = len(reads)
+        names = (C.c_char_p * n)(*[(r[0].encode() if isinstance(r[0], str) else r[0]) for r in reads])
+        seqs = (C.c_char_p * n)(*[r[1] for r in reads])
+        lens = (C.c_int * n)(*[len(r[1]) for r in reads])
+        n_reg, reg = (C.c_int * n)(), (C.c_void_p * n)()
+        t = self.D.refdrv_map(self.mi, C.byref(mo), n, seqs, lens, names, self.n_threads, n_reg, reg)
+        return t, n_reg, reg
+
+    def close(self):
+        if self.mi:
+            self.D.mm_idx_destroy(self.mi)
+            self.mi = None
+
+
+def export_index(al):
+    """numpy copies of an Aligner's device-built tables: (S, keys, val_off, pos)"""
+    import minimap2_amd as mm
+    st = al.index_stat()
+    keys = np.zeros(st["n_distinct"], np.uint64)
+    val_off = np.zeros(st["n_distinct"] + 1, np.uint32)
+    pos = np.zeros(st["n_minimizers"], np.uint64)
+    S = np.zeros((st["sum_len"] + 7) // 8, np.uint32)
+    rc = mm.lib().mm2amd_idx_export(al._idx, None, keys.ctypes.data, val_off.ctypes.data, pos.ctypes.data, S.ctypes.data)
+    assert rc == 0, mm.lib().mm2amd_last_error()
+    return S, keys, val_off, pos

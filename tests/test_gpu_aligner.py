@@ -1,0 +1,141 @@
+"""Device-side index construction and the mappy-shaped Python front end, on the GPU, against the compiled reference:
+  * the flat tables built by index_build.hip must describe exactly the (minimizer -> ascending positions) map of the
+    reference's mm_idx_t built by mm_idx_str from the same sequences (including N runs, tandem repeats, tiny contigs);
+  * Aligner.map_batch must return the hits mm_map returns, field by field and CIGAR by CIGAR."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import reflib  # noqa: E402
+import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _tricky_reference(rng, total):
+    """uniform sequence seasoned with N runs (some right at 2048-base chunk borders), dinucleotide/homopolymer repeats and tiny contigs"""
+    c0 = synth.ACGT[rng.integers(0, 4, total, dtype=np.uint8)].copy()
+    for _ in range(40):
+        p = int(rng.integers(0, total - 3000))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            c0[p:p + int(rng.integers(1, 60))] = ord("N")
+        elif kind == 1:
+            c0[p:p + 400] = np.frombuffer((b"AC" * 200), dtype=np.uint8)
+        elif kind == 2:
+            c0[p:p + 300] = ord("A")
+        else:
+            q = (p // 2048) * 2048 + int(rng.integers(-30, 30))
+            if 0 < q < total - 100:
+                c0[q:q + int(rng.integers(1, 25))] = ord("N")
+                c0[q + 30:q + 230] = np.frombuffer((b"GAT" * 67)[:200], dtype=np.uint8)
+    seqs = [c0.tobytes(), b"ACGTTGCA", b"N" * 50, synth.ACGT[rng.integers(0, 4, 5000, dtype=np.uint8)].tobytes(), b"ACGTACGTAGCTAGCTAGCTAGCATGCATGCATCGATCGATCGACTAGCTAGCTAGCTAC"]
+    return seqs
+
+
+def _ref_index_pairs(seqs, w, k):
+    """(hash, pos) pairs of the reference's index, via its public mm_idx_get over every minimizer mm_sketch reports"""
+    R = C.CDLL(reflib.REF_SO)
+    R.mm_idx_str.restype = C.c_void_p
+    R.mm_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+    n = len(seqs)
+    mi = R.mm_idx_str(w, k, 0, 14, n, (C.c_char_p * n)(*seqs), None)
+    R.mm_idx_get.restype = C.POINTER(C.c_uint64)
+    R.mm_idx_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
+    out = {}
+    for rid, s in enumerate(seqs):
+        mz = reflib.ref_sketch(s, w, k, rid)
+        for h in np.unique(mz[:, 0] >> np.uint64(8)):
+            cnt = C.c_int(0)
+            p = R.mm_idx_get(mi, int(h), C.byref(cnt))
+            out[int(h)] = [p[i] for i in range(cnt.value)]
+    R.mm_idx_destroy.argtypes = [C.c_void_p]
+    R.mm_idx_destroy(mi)
+    return out
+
+
+@pytest.mark.parametrize("w,k", [(10, 15), (19, 19), (5, 15), (40, 21)])
+def test_device_index_equals_reference_index(w, k):
+    import minimap2_amd as mm
+    rng = np.random.default_rng(100 + w)
+    seqs = _tricky_reference(rng, 300000)
+    L = mm.lib()
+    n = len(seqs)
+    idx = L.mm2amd_idx_str(w, k, 0, 14, n, (C.c_char_p * n)(*seqs), None)
+    assert idx, L.mm2amd_last_error()
+    nd, nm, sl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert L.mm2amd_idx_stat(idx, None, None, None, None, sl, nd, nm) == 0
+    keys = np.zeros(nd.value, np.uint64)
+    val_off = np.zeros(nd.value + 1, np.uint32)
+    pos = np.zeros(nm.value, np.uint64)
+    S = np.zeros((sl.value + 7) // 8, np.uint32)
+    assert L.mm2amd_idx_export(idx, None, keys.ctypes.data, val_off.ctypes.data, pos.ctypes.data, S.ctypes.data) == 0
+    want = _ref_index_pairs(seqs, w, k)
+    assert len(keys) == len(want)
+    assert np.all(keys[1:] > keys[:-1])
+    for i, h in enumerate(keys.tolist()):
+        assert pos[val_off[i]:val_off[i + 1]].tolist() == want[h], (w, k, hex(h))
+    # packed sequence == the reference's 4-bit layout (mmpriv.h:34-35)
+    cat = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    lut = np.full(256, 4, np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ch] = v
+    codes = lut[cat]
+    got = (S[np.arange(len(codes)) >> 3] >> ((np.arange(len(codes)) & 7) << 2).astype(np.uint32)) & 0xf
+    assert np.array_equal(got.astype(np.uint8), codes)
+    # mm_idx_cal_max_occ from the histogram
+    R = C.CDLL(reflib.REF_SO)
+    L.mm2amd_idx_destroy(idx)
+
+
+@pytest.mark.parametrize("kind,preset,n_reads,seed", [("ont", "map-ont", 60, 31), ("hifi", "map-hifi", 30, 32), ("hifi", "lr:hq", 20, 33)])
+def test_aligner_equals_mm_map(kind, preset, n_reads, seed):
+    import minimap2_amd as mm
+    rng = np.random.default_rng(seed)
+    contigs = synth.gen_reference(rng, 3000000, 3)
+    mean, sd, err = synth.PROFILES[kind]
+    reads = synth.gen_reads(rng, contigs, n_reads, mean, sd, err)
+    refs = [synth.ACGT[c].tobytes() for c in contigs]
+    rds = [("read%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    rds += [("empty", b""), ("short", refs[0][100:130]), ("withN", refs[1][5000:5600] + b"NNNNNNNNNNNN" + refs[1][5612:8000])]
+    names = ["chr%d" % (i + 1) for i in range(3)]
+    al = mm.Aligner(refs, preset=preset, names=names, n_threads=8)
+    st = al.index_stat()
+    got = al.map_batch(rds)
+    al.close()
+    ref = reflib.RefMapper(refs, preset, names)
+    assert st["n_seq"] == 3 and st["sum_len"] == sum(len(r) for r in refs)
+    assert al.map_opt.mid_occ == ref.mo.mid_occ
+    want = [ref.map(nm, s) for nm, s in rds]
+    ref.close()
+    assert sum(1 for h in got if h) >= n_reads - 1
+    for i in range(len(rds)):
+        assert [a.key() for a in got[i]] == want[i], (rds[i][0], len(rds[i][1]))
+
+
+def test_profile_counters_and_substeps():
+    import minimap2_amd as mm
+    rng = np.random.default_rng(41)
+    contigs = synth.gen_reference(rng, 2000000, 2)
+    reads = synth.gen_reads(rng, contigs, 40, 8000, 1000, 0.12)
+    refs = [synth.ACGT[c].tobytes() for c in contigs]
+    rds = [("read%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    al = mm.Aligner(refs, preset="map-ont", n_threads=8)
+    mm.profile_enable(True)
+    whole = [[a.key() for a in h] for h in al.map_batch(rds)]
+    prof = mm.profile_get()
+    mm.profile_enable(False)
+    assert any(k.startswith("ksw_extd2_kernel") for k in prof) and "chain_fill_kernel" in prof
+    assert all(v["ms"] > 0 and v["launches"] >= 1 for v in prof.values())
+    os.environ["MM2AMD_SUBBATCH_BASES"] = "50000"  # several sub-batches must give the same answer as one
+    try:
+        parts = [[a.key() for a in h] for h in al.map_batch(rds)]
+    finally:
+        del os.environ["MM2AMD_SUBBATCH_BASES"]
+    al.close()
+    assert parts == whole

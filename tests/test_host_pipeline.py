@@ -1,0 +1,83 @@
+"""CPU-only end-to-end check of the product's HOST pipeline (chains -> hits -> window planning -> CIGAR stitching -> MAPQ):
+tests/_build/dropin_check links the same host sources as libmm2amd.so against the oracle-backed checker backend
+(tests/cpucheck/backend_check.cpp) and must reproduce the committed golden output of the unmodified reference
+(tests/golden/*.out, made by tests/golden/make_golden.py).  When the compiled reference is present it is re-run too, which
+pins the goldens themselves."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as G  # noqa: E402
+
+CHECK = os.path.join(HERE, "_build", "dropin_check")
+REFTEST = "/root/reference/test"
+
+
+def _build():
+    if os.path.exists("/root/reference/minimap.h") or not os.path.exists(CHECK):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpucheck")], stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    _build()
+    if not os.path.exists(CHECK):
+        pytest.skip("tests/_build/dropin_check needs the reference headers to build (dev container only)")
+
+
+@pytest.mark.parametrize("case", list(G.CASES))
+def test_golden(case, tmp_path):
+    meta = json.load(open(os.path.join(HERE, "golden", "inputs.json")))
+    want = open(os.path.join(HERE, "golden", case + ".out"), "rb").read()
+    got, m = G.run_case(CHECK, case, str(tmp_path))
+    assert m == meta[case], "synthetic inputs drifted from the ones the golden was made with"
+    assert got == want
+    if os.path.exists(G.REF_BIN):
+        ref, _ = G.run_case(G.REF_BIN, case, str(tmp_path))
+        assert ref == want, "golden fixture no longer matches the compiled reference"
+
+
+def _pair(args, a, b):
+    outs = []
+    for binary in (G.REF_BIN, CHECK):
+        p = subprocess.run([binary] + args + [a, b], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        outs.append(G.strip_pg(p.stdout))
+    assert outs[0] == outs[1]
+    return outs[0]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFTEST), reason="reference test data only exists in the dev container")
+def test_reference_fixture_mt():  # BASELINE.json configs[0]
+    out = _pair(["-a"], os.path.join(REFTEST, "MT-human.fa"), os.path.join(REFTEST, "MT-orang.fa"))
+    assert b"\t577\t60\t" in out  # one record, pos 577, MAPQ 60
+
+
+@pytest.mark.skipif(not os.path.isdir(REFTEST), reason="reference test data only exists in the dev container")
+def test_reference_fixture_inversion():
+    out = _pair(["-c"], os.path.join(REFTEST, "t-inv.fa"), os.path.join(REFTEST, "q-inv.fa"))
+    assert b"tp:A:I" in out  # the inversion rescue path (align.c:916-971)
+
+
+def test_empty_and_tiny_reads(tmp_path):
+    import numpy as np
+    import synth
+    rng = np.random.default_rng(5)
+    contigs = synth.gen_reference(rng, 300000, 2)
+    reads = synth.gen_reads(rng, contigs, 6, 3000, 300, 0.1)
+    reads += [np.zeros(0, dtype=np.uint8), contigs[0][:10].copy(), contigs[1][100:140].copy()]
+    ref, rd = str(tmp_path / "r.fa"), str(tmp_path / "q.fa")
+    synth.write_fasta(ref, ["c1", "c2"], contigs)
+    with open(rd, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">r%d\n" % i + synth.ACGT[s].tobytes() + b"\n")
+        f.write(b">withN\n" + synth.ACGT[contigs[0][5000:6000]].tobytes()[:500] + b"NNNNNNNNNN" + synth.ACGT[contigs[0][5510:7000]].tobytes() + b"\n")
+    if os.path.exists(G.REF_BIN):
+        _pair(["-a"], ref, rd)
