@@ -39,7 +39,10 @@ public:
 		if (!T_) { own_.upload(fi, stream_); T_ = &own_; }
 		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
+		while ((1ull << rid_bits_) < fi.n_seq) ++rid_bits_;
 	}
+
+	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
 
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
 	{
@@ -74,28 +77,19 @@ public:
 		KernelProfiler &kp = kernel_profiler();
 		const double L = (double)(seq_off_[hi] - seq_off_[lo]);
 		kp.begin(stream_); launch_encode(B_, stream_); kp.end(stream_, "encode_kernel", 3 * L);
-		// 1. minimizers: count, scan, emit
+		// 1. minimizers, written from slot seq_off[r] of the minimizer arrays (at most one per base)
+		const uint64_t base0 = seq_off_[lo], cap_mz = seq_off_[hi] - base0;
 		d_mz_cnt_.ensure(n);
-		B_.mz_cnt = d_mz_cnt_.p;
-		kp.begin(stream_); launch_sketch(B_, P, false, stream_); kp.end(stream_, "sketch_kernel<count>", L);
-		h_cnt_.resize(n);
-		HIP_CHECK(hipMemcpyAsync(h_cnt_.data(), d_mz_cnt_.p, n * 4, hipMemcpyDeviceToHost, stream_));
-		HIP_CHECK(hipStreamSynchronize(stream_));
-		mz_off_.resize(n + 1);
-		mz_off_[0] = 0;
-		for (size_t i = 0; i < n; ++i) mz_off_[i + 1] = mz_off_[i] + h_cnt_[i];
-		const uint64_t n_mz = mz_off_[n];
-		d_mz_off_.ensure(n + 1);
-		HIP_CHECK(hipMemcpyAsync(d_mz_off_.p, mz_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-		d_mz_x_.ensure(n_mz + 1), d_mz_y_.ensure(n_mz + 1);
-		d_sd_n_.ensure(n_mz + 1), d_sd_off_.ensure(n_mz + 1), d_sd_aoff_.ensure(n_mz + 1), d_sd_qpos_.ensure(n_mz + 1), d_sd_info_.ensure(n_mz + 1);
-		B_.mz_off = d_mz_off_.p, B_.mz_x = d_mz_x_.p, B_.mz_y = d_mz_y_.p;
-		B_.sd_n = d_sd_n_.p, B_.sd_off = d_sd_off_.p, B_.sd_aoff = d_sd_aoff_.p, B_.sd_qpos = d_sd_qpos_.p, B_.sd_info = d_sd_info_.p;
-		kp.begin(stream_); launch_sketch(B_, P, true, stream_); kp.end(stream_, "sketch_kernel<emit>", L + 16.0 * n_mz);
+		d_mz_x_.ensure(cap_mz + 1), d_mz_y_.ensure(cap_mz + 1);
+		d_sd_n_.ensure(cap_mz + 1), d_sd_off_.ensure(cap_mz + 1), d_sd_aoff_.ensure(cap_mz + 1), d_sd_qpos_.ensure(cap_mz + 1), d_sd_info_.ensure(cap_mz + 1);
+		// the per-read slot offsets are the batch-wide base offsets; shifting the array bases by the sub-batch's first offset makes them local
+		B_.mz_cnt = d_mz_cnt_.p, B_.mz_off = B_.seq_off, B_.mz_x = d_mz_x_.p - base0, B_.mz_y = d_mz_y_.p - base0;
+		B_.sd_n = d_sd_n_.p - base0, B_.sd_off = d_sd_off_.p - base0, B_.sd_aoff = d_sd_aoff_.p - base0, B_.sd_qpos = d_sd_qpos_.p - base0, B_.sd_info = d_sd_info_.p - base0;
+		kp.begin(stream_); launch_sketch(B_, P, stream_); kp.end(stream_, "sketch_kernel", L + 16.0 * (2.0 * L / (P.w + 1)));
 		// 2. seeds: probe, filter, count anchors
 		d_n_anchor_.ensure(n), d_n_minipos_.ensure(n), d_n_seedhit_.ensure(n), d_rep_len_.ensure(n);
 		B_.n_anchor = d_n_anchor_.p, B_.n_minipos = d_n_minipos_.p, B_.n_seedhit = d_n_seedhit_.p, B_.rep_len = d_rep_len_.p;
-		kp.begin(stream_); launch_seed_collect(B_, I_, P, stream_); kp.end(stream_, "seed_collect_kernel", 36.0 * n_mz); // 16 B minimizer + 8 key + 8 val + 4 flags
+		kp.begin(stream_); launch_seed_collect(B_, I_, P, stream_); kp.end(stream_, "seed_collect_kernel", 36.0 * (2.0 * L / (P.w + 1))); // per minimizer: 16 B record + 8 key + 8 val + 4 flags
 		h_na_.resize(n), h_nmp_.resize(n), h_rep_.resize(n);
 		HIP_CHECK(hipMemcpyAsync(h_na_.data(), d_n_anchor_.p, n * 4, hipMemcpyDeviceToHost, stream_));
 		HIP_CHECK(hipMemcpyAsync(h_nmp_.data(), d_n_minipos_.p, n * 4, hipMemcpyDeviceToHost, stream_));
@@ -109,11 +103,19 @@ public:
 		HIP_CHECK(hipMemcpyAsync(d_a_off_.p, a_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
 		HIP_CHECK(hipMemcpyAsync(d_mp_off_.p, mp_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
 		d_anchors_.ensure(n_a + 1), d_minipos_.ensure(n_mp + 1), d_f_.ensure(n_a + 1), d_p_.ensure(n_a + 1), d_t_.ensure(n_a + 1);
+		d_skey_in_.ensure(n_a + 1), d_sval_in_.ensure(n_a + 1), d_skey_out_.ensure(n_a + 1), d_sval_out_.ensure(n_a + 1), d_tie_.ensure(n);
+		B_.sort_key_in = d_skey_in_.p, B_.sort_val_in = d_sval_in_.p, B_.sort_key_out = d_skey_out_.p, B_.sort_val_out = d_sval_out_.p, B_.tie_flag = d_tie_.p;
+		B_.rid_bits = rid_bits_;
+		int read_bits = 1;
+		while ((1ull << read_bits) < n) ++read_bits;
+		const int end_bit = 33 + rid_bits_ + read_bits;
+		const size_t sort_tmp = anchor_sort_temp_bytes(n_a, end_bit);
+		d_sort_tmp_.ensure(sort_tmp + 16);
 		B_.a_off = d_a_off_.p, B_.mp_off = d_mp_off_.p, B_.anchors = d_anchors_.p, B_.mini_pos = d_minipos_.p;
 		B_.f = d_f_.p, B_.p = d_p_.p, B_.t = d_t_.p;
 		// 3. anchors: expand, sort, chain
 		kp.begin(stream_); launch_seed_expand(B_, I_, P, stream_); kp.end(stream_, "seed_expand_kernel", 24.0 * n_a);
-		kp.begin(stream_); launch_anchor_sort(B_, stream_); kp.end(stream_, "anchor_sort_kernel", 32.0 * n_a);
+		kp.begin(stream_); launch_anchor_sort(B_, n_a, end_bit, d_sort_tmp_.p, sort_tmp, stream_); kp.end(stream_, "anchor_sort", 32.0 * n_a);
 		kp.begin(stream_); launch_chain_fill(B_, P, stream_); kp.end(stream_, "chain_fill_kernel", 24.0 * n_a);
 		// 4. back to the host for the (scalar, order-sensitive) backtrack
 		Anchor *ha = h_anchors_.ensure(n_a + 1);
@@ -138,10 +140,12 @@ public:
 		});
 	}
 
-	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) override
+	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, const uint32_t **cigar) override
 	{
 		res.resize(jobs.size());
-		ksw_.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, stream_);
+		size_t n_cig = 0;
+		ksw_.n_threads = n_threads_;
+		ksw_.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, stream_);
 		kernel_profiler().collect();
 	}
 
@@ -160,6 +164,10 @@ private:
 	DevBuf<uint32_t> d_mz_cnt_, d_sd_n_, d_sd_off_, d_sd_aoff_, d_sd_qpos_, d_sd_info_, d_n_anchor_, d_n_minipos_, d_n_seedhit_;
 	DevBuf<int32_t> d_rep_len_, d_f_, d_p_, d_t_;
 	DevBuf<Anchor> d_anchors_;
+	DevBuf<uint64_t> d_skey_in_, d_sval_in_, d_skey_out_, d_sval_out_;
+	DevBuf<uint32_t> d_tie_;
+	DevBuf<uint8_t> d_sort_tmp_;
+	int rid_bits_ = 1;
 	PinBuf<char> h_ascii_;
 	PinBuf<Anchor> h_anchors_;
 	PinBuf<int32_t> h_f_, h_p_;

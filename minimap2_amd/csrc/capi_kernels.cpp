@@ -82,11 +82,12 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 		memcpy(sc.mat, mat, 25);
 		sc.m = m, sc.q = gapo, sc.e = gape, sc.q2 = gapo2, sc.e2 = gape2, sc.pad[0] = sc.pad[1] = 0;
 		std::vector<KswRes> r(n_jobs);
-		std::vector<uint32_t> cig;
-		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), cig, dc.stream);
+		const uint32_t *cig = nullptr;
+		size_t n_cig = 0;
+		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), &cig, &n_cig, dc.stream);
 		kernel_profiler().collect();
-		if (cig.size() > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
-		if (!cig.empty()) memcpy(cigar_pool, cig.data(), cig.size() * sizeof(uint32_t));
+		if (n_cig > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
+		if (n_cig) memcpy(cigar_pool, cig, n_cig * sizeof(uint32_t));
 		for (int i = 0; i < n_jobs; ++i) {
 			mm2amd_ksw_res_t &o = res[i];
 			o.max = r[i].max, o.zdropped = r[i].zdropped, o.max_q = r[i].max_q, o.max_t = r[i].max_t;

@@ -15,6 +15,7 @@
 #include <vector>
 #include "hip_util.hpp"
 #include "index_build.hpp"
+#include "sketch_dev.hpp"
 
 namespace mm2amd {
 
@@ -36,21 +37,9 @@ __global__ void __launch_bounds__(256) idx_encode_kernel(const char *ascii, uint
 	S[wi] = word;
 }
 
-__device__ __forceinline__ uint64_t mix64i(uint64_t key, uint64_t mask)
-{
-	key = (~key + (key << 21)) & mask;
-	key = key ^ key >> 24;
-	key = ((key + (key << 3)) + (key << 8)) & mask;
-	key = key ^ key >> 14;
-	key = ((key + (key << 2)) + (key << 4)) & mask;
-	key = key ^ key >> 28;
-	key = (key + (key << 31)) & mask;
-	return key;
-}
-
 struct ChunkDesc { uint32_t rid; uint32_t start; }; // chunk = [start, start + CHUNK) clipped to the sequence
 
-// one lane per chunk; non-HPC indices only (HPC needs run-length look-ahead across chunk borders)
+// one lane per chunk (sketch_dev.hpp); non-HPC indices only
 template <bool EMIT, int WMAX>
 __global__ void __launch_bounds__(64) idx_sketch_kernel(const uint8_t *nt4, const uint64_t *seq_off, const uint32_t *seq_len, const ChunkDesc *chunks,
                                                          uint64_t n_chunks, int chunk_len, int w, int k, uint32_t *cnt, const uint64_t *out_off,
@@ -61,81 +50,15 @@ __global__ void __launch_bounds__(64) idx_sketch_kernel(const uint8_t *nt4, cons
 	const uint32_t rid = chunks[ci].rid;
 	const int64_t cs = chunks[ci].start, len = seq_len[rid];
 	const int64_t ce = cs + chunk_len < len ? cs + chunk_len : len;
-	const uint8_t *seq = nt4 + seq_off[rid];
-	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
 	uint64_t bx[WMAX], by[WMAX];
-	uint64_t n_out = 0;
+	uint32_t n_out = 0;
 	uint64_t *oh = nullptr, *op = nullptr;
 	if (EMIT) oh = out_hash + out_off[ci], op = out_pos + out_off[ci];
-
-	int64_t warm = 2 * (w + k) + 32;
-	for (;;) {
-		int64_t ws = cs - warm;
-		if (ws < 0) ws = 0;
-		// exact k-mer registers at ws: the last k non-N bases before it (N's do not shift the registers, sketch.c:105-106)
-		uint64_t kmer0 = 0, kmer1 = 0;
-		if (ws > 0) {
-			uint8_t last[32];
-			int got = 0;
-			for (int64_t j = ws - 1; j >= 0 && got < k; --j) { const uint8_t c = seq[j]; if (c < 4) last[got++] = c; }
-			for (int j = got - 1; j >= 0; --j) {
-				kmer0 = (kmer0 << 2 | (uint64_t)last[j]) & mask;
-				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)last[j]) << shift1;
-			}
-		}
-		uint64_t min_x = UINT64_MAX, min_y = UINT64_MAX;
-		int l = 0, buf_pos = 0, min_pos = 0;
-		bool synced = ws == 0; // at the sequence start the automaton is in its true initial state
-		n_out = 0;
-		for (int j = 0; j < w; ++j) bx[j] = by[j] = UINT64_MAX;
-		bool restart = false;
-#define EMIT_IDX(X, Y) do { const int64_t pp_ = (int64_t)((uint32_t)(Y) >> 1); if (pp_ >= cs && pp_ < ce) { if (EMIT) { oh[n_out] = (X) >> 8; op[n_out] = (Y); } ++n_out; } } while (0)
-		for (int64_t i = ws; i < len; ++i) {
-			if (i == cs && !synced) { restart = true; break; } // not enough clean history: start further back
-			// everything owned has been emitted: the window holds no valid k-mer, or its minimum lies past the chunk and the
-			// first-full-window rule (which may still emit an older equal-hash slot) can no longer fire on owned slots
-			if (i >= ce && (min_x == UINT64_MAX || ((int64_t)((uint32_t)min_y >> 1) >= ce && l >= w + k - 1))) break;
-			const int c = seq[i];
-			uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
-			if (c < 4) {
-				const int kmer_span = l + 1 < k ? l + 1 : k;
-				kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
-				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
-				if (kmer0 == kmer1) continue;
-				const int z = kmer0 < kmer1 ? 0 : 1;
-				++l;
-				if (l >= k) {
-					ix = mix64i(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
-					iy = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z;
-				}
-				if (l >= w + k) synced = true; // state now depends only on the last w+k valid slots
-			} else l = 0;
-			bx[buf_pos] = ix, by[buf_pos] = iy;
-			if (l == w + k - 1 && min_x != UINT64_MAX) {
-				for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j] && by[j] != min_y) EMIT_IDX(bx[j], by[j]);
-				for (int j = 0; j < buf_pos; ++j)     if (min_x == bx[j] && by[j] != min_y) EMIT_IDX(bx[j], by[j]);
-			}
-			if (ix <= min_x) {
-				if (l >= w + k && min_x != UINT64_MAX) EMIT_IDX(min_x, min_y);
-				min_x = ix, min_y = iy, min_pos = buf_pos;
-			} else if (buf_pos == min_pos) {
-				if (l >= w + k - 1 && min_x != UINT64_MAX) EMIT_IDX(min_x, min_y);
-				min_x = UINT64_MAX;
-				for (int j = buf_pos + 1; j < w; ++j) if (min_x >= bx[j]) min_x = bx[j], min_y = by[j], min_pos = j;
-				for (int j = 0; j <= buf_pos; ++j)    if (min_x >= bx[j]) min_x = bx[j], min_y = by[j], min_pos = j;
-				if (l >= w + k - 1 && min_x != UINT64_MAX) {
-					for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j] && min_y != by[j]) EMIT_IDX(bx[j], by[j]);
-					for (int j = 0; j <= buf_pos; ++j)    if (min_x == bx[j] && min_y != by[j]) EMIT_IDX(bx[j], by[j]);
-				}
-			}
-			if (++buf_pos == w) buf_pos = 0;
-		}
-		if (restart) { warm = warm * 4 + 1024; continue; }
-		if (min_x != UINT64_MAX) EMIT_IDX(min_x, min_y); // reached the end of the sequence (or the early exit with nothing owned pending)
-#undef EMIT_IDX
-		break;
-	}
-	if (!EMIT) cnt[ci] = (uint32_t)n_out;
+	sketch_chunk(nt4 + seq_off[rid], len, cs, ce, w, k, rid, bx, by, 1, [&](uint64_t x, uint64_t y) {
+		if (EMIT) { oh[n_out] = x >> 8; op[n_out] = y; }
+		++n_out;
+	});
+	if (!EMIT) cnt[ci] = n_out;
 }
 
 __global__ void __launch_bounds__(256) idx_mark_heads_kernel(const uint64_t *hash, uint64_t n, uint32_t *is_head)
@@ -167,11 +90,18 @@ __global__ void __launch_bounds__(256) idx_bucket_start_kernel(const uint64_t *k
 
 __global__ void __launch_bounds__(256) idx_occ_hist_kernel(const uint32_t *val_off, uint64_t n_keys, unsigned long long *hist, int n_bins)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_keys) return;
-	uint32_t c = val_off[i + 1] - val_off[i];
-	if (c >= (uint32_t)n_bins) c = n_bins - 1;
-	atomicAdd(&hist[c], 1ull);
+	// almost every minimizer occurs a handful of times: count the low bins per block in LDS, the tail with global atomics
+	__shared__ unsigned int low[256];
+	low[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) {
+		uint32_t c = val_off[i + 1] - val_off[i];
+		if (c < 256) atomicAdd(&low[c], 1u);
+		else atomicAdd(&hist[c < (uint32_t)n_bins ? c : (uint32_t)n_bins - 1], 1ull);
+	}
+	__syncthreads();
+	if (low[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)low[threadIdx.x]);
 }
 
 void DeviceIndexBuilder::build(FlatIndex &fi, DeviceIndexTables &T, int k, int w, int flag, int n_seq, const char *const *seqs, const uint64_t *lens,
@@ -297,7 +227,7 @@ void DeviceIndexBuilder::build(FlatIndex &fi, DeviceIndexTables &T, int k, int w
 	DevBuf<unsigned long long> d_hist;
 	d_hist.ensure(n_bins, 1.0);
 	HIP_CHECK(hipMemsetAsync(d_hist.p, 0, n_bins * 8, stream));
-	if (n_keys) hipLaunchKernelGGL(idx_occ_hist_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, stream, T.val_off.p, n_keys, d_hist.p, n_bins);
+	if (n_keys) hipLaunchKernelGGL(idx_occ_hist_kernel, dim3((unsigned)std::min<uint64_t>((n_keys + 255) / 256, 4096)), dim3(256), 0, stream, T.val_off.p, n_keys, d_hist.p, n_bins);
 	T.occ_hist.resize(n_bins);
 	HIP_CHECK(hipMemcpyAsync(T.occ_hist.data(), d_hist.p, n_bins * 8, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));

@@ -13,16 +13,18 @@ struct KswRunner {
 	DevBuf<uint32_t> d_cigar, d_cigar_tmp, d_cursor;
 	DevBuf<uint8_t> d_dir;
 	DevBuf<int32_t> d_counter;
-	std::vector<KswJob> sorted;
-	std::vector<uint32_t> perm;
-	std::vector<KswRes> tmp_res;
+	PinBuf<KswJob> sorted;            // jobs in launch order (tier, then decreasing cost), pinned for the H2D copy
+	PinBuf<KswRes> tmp_res;
+	PinBuf<uint32_t> cigar_host;      // the batch's CIGARs as the kernel packed them
+	std::vector<uint32_t> perm, bucket;
+	int n_threads = 1;
 	size_t dir_budget = (size_t)12 << 30; // bytes of HBM we allow for direction matrices
 	int n_cu = 256;
 
-	// Pools are device pointers.  Results land in res[i] (input order); the CIGARs are packed into cigar_out
-	// (resized here) and addressed by res[i].cigar_off / n_cigar.
+	// Pools are device pointers.  Results land in res[i] (input order); the CIGARs stay in this runner's pinned buffer
+	// (*cigar_out, valid until the next run) and are addressed by res[i].cigar_off / n_cigar.
 	void run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-	         const KswScoring &sc, KswRes *res, std::vector<uint32_t> &cigar_out, hipStream_t stream);
+	         const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream);
 };
 
 } // namespace mm2amd

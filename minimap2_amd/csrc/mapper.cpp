@@ -84,7 +84,8 @@ void Mapper::run(std::vector<ReadResult> &out)
 	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
 	for (long lo = 0, hi; lo < m_all; lo = hi) {
 		long bases = 0;
-		for (hi = lo; hi < m_all && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
+		const long max_reads = be_.max_reads_per_call();
+		for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
 		const long m = hi - lo;
 		t0 = now();
 		std::vector<ReadChains> chains;
@@ -134,7 +135,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 		std::vector<size_t> job_base(m + 1);
 		std::vector<KswJob> jobs;
 		std::vector<KswRes> kres;
-		std::vector<uint32_t> cigars;
+		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(m, 1);
 		// Aligner holds a scratch buffer, so each worker thread gets its own instance
 		std::vector<std::unique_ptr<Aligner>> al(n_threads_);
@@ -154,11 +155,11 @@ void Mapper::run(std::vector<ReadResult> &out)
 			}, 256);
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
 			stats.t_plan += now() - t0; t0 = now();
-			be_.ksw(jobs, sc, kres, cigars);
+			be_.ksw(jobs, sc, kres, &cigars);
 			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
 			stats.t_ksw += now() - t0; t0 = now();
 			parallel_for(n_threads_, m, [&](long i, int tid) {
-				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars.data()) ? 1 : 0;
+				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
 			stats.t_consume += now() - t0;
 			if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "seed_chain_dev.hpp"
+#include "sketch_dev.hpp"
+#include <hipcub/hipcub.hpp>
 
 namespace mm2amd {
 
@@ -54,21 +56,14 @@ void launch_encode(const SeedChainBuffers &B, void *stream)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// (w,k)-minimizers (sketch.c:77-143), one lane per read
+// (w,k)-minimizers (sketch.c:77-143).  Minimizers of read r are written from slot seq_off[r] of the minimizer arrays (a read
+// of L bases has at most L minimizers: every slot is reported at most once), so no count/scan pass is needed.
+//   * sketch_wave_kernel : one wavefront per read, each lane owns len/64 consecutive positions (sketch_dev.hpp)
+//   * sketch_kernel      : one lane per read, the plain sequential automaton (HPC minimizers, w > 32)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t mix64(uint64_t key, uint64_t mask) // hash64, sketch.c:28-38
-{
-	key = (~key + (key << 21)) & mask;
-	key = key ^ key >> 24;
-	key = ((key + (key << 3)) + (key << 8)) & mask;
-	key = key ^ key >> 14;
-	key = ((key + (key << 2)) + (key << 4)) & mask;
-	key = key ^ key >> 28;
-	key = (key + (key << 31)) & mask;
-	return key;
-}
+__device__ __forceinline__ uint64_t mix64(uint64_t key, uint64_t mask) { return mm_hash64(key, mask); }
 
-template <bool EMIT, int WMAX>
+template <int WMAX>
 __global__ void __launch_bounds__(64) sketch_kernel(SeedChainBuffers B, int w, int k, int is_hpc)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,9 +77,8 @@ __global__ void __launch_bounds__(64) sketch_kernel(SeedChainBuffers B, int w, i
 	int hq[32], hq_front = 0, hq_count = 0;
 	int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
 	uint32_t n_out = 0;
-	uint64_t *ox = nullptr, *oy = nullptr;
-	if (EMIT) ox = B.mz_x + B.mz_off[r], oy = B.mz_y + B.mz_off[r];
-#define EMIT_MZ(X, Y) do { if (EMIT) { ox[n_out] = (X); oy[n_out] = (Y); } ++n_out; } while (0)
+	uint64_t *ox = B.mz_x + B.mz_off[r], *oy = B.mz_y + B.mz_off[r];
+#define EMIT_MZ(X, Y) do { ox[n_out] = (X); oy[n_out] = (Y); ++n_out; } while (0)
 	for (int j = 0; j < w; ++j) bx[j] = by[j] = UINT64_MAX;
 	for (int i = 0; i < len; ++i) {
 		const int c = seq[i];
@@ -132,19 +126,42 @@ __global__ void __launch_bounds__(64) sketch_kernel(SeedChainBuffers B, int w, i
 	}
 	if (min_x != UINT64_MAX) EMIT_MZ(min_x, min_y);
 #undef EMIT_MZ
-	if (!EMIT) B.mz_cnt[r] = n_out;
+	B.mz_cnt[r] = n_out;
 }
 
-void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, bool emit, void *stream)
+__global__ void __launch_bounds__(256) sketch_wave_kernel(SeedChainBuffers B, int w, int k)
 {
-	const dim3 grid((B.n_reads + 63) / 64), block(64);
+	extern __shared__ __attribute__((aligned(16))) uint64_t ring[]; // per wave: bx[w][64] then by[w][64], lane-interleaved (conflict-free)
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int r = blockIdx.x * 4 + wave;
+	if (r >= B.n_reads) return;
+	const uint64_t o = B.seq_off[r];
+	const int64_t len = (int64_t)(B.seq_off[r + 1] - o);
+	const uint8_t *seq = B.qpool + 2 * o;
+	uint64_t *bx = ring + (size_t)wave * 2 * w * 64 + lane, *by = bx + (size_t)w * 64;
+	int64_t chunk = (len + 63) / 64;
+	if (chunk < 32) chunk = 32;
+	const int64_t cs = (int64_t)lane * chunk, ce = cs + chunk < len ? cs + chunk : len;
+	uint32_t n = 0;
+	if (cs < len) sketch_chunk(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t) { ++n; });
+	uint32_t incl = n;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+	uint64_t *ox = B.mz_x + B.mz_off[r] + (incl - n), *oy = B.mz_y + B.mz_off[r] + (incl - n);
+	if (n) sketch_chunk(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t x, uint64_t y) { *ox++ = x; *oy++ = y; });
+	if (lane == 63) B.mz_cnt[r] = incl;
+}
+
+void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
+{
 	hipStream_t s = (hipStream_t)stream;
-	if (P.w <= 32) {
-		if (emit) hipLaunchKernelGGL((sketch_kernel<true, 32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
-		else hipLaunchKernelGGL((sketch_kernel<false, 32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+	if (!P.is_hpc && P.w <= 32) {
+		const size_t lds = (size_t)4 * 2 * P.w * 64 * 8;
+		if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)sketch_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(sketch_wave_kernel, dim3((B.n_reads + 3) / 4), dim3(256), lds, s, B, P.w, P.k);
 	} else {
-		if (emit) hipLaunchKernelGGL((sketch_kernel<true, 256>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
-		else hipLaunchKernelGGL((sketch_kernel<false, 256>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+		const dim3 grid((B.n_reads + 63) / 64), block(64);
+		if (P.w <= 32) hipLaunchKernelGGL((sketch_kernel<32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
+		else hipLaunchKernelGGL((sketch_kernel<256>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
 	}
 	HIP_CHECK(hipGetLastError());
 }
@@ -342,7 +359,8 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 	const uint32_t *sd_n = B.sd_n + mo, *sd_off = B.sd_off + mo, *sd_aoff = B.sd_aoff + mo, *sd_qpos = B.sd_qpos + mo, *sd_info = B.sd_info + mo;
 	const int n_m0 = (int)B.n_seedhit[r];
 	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
-	Anchor *a = B.anchors + B.a_off[r];
+	uint64_t *akey = B.sort_key_in + B.a_off[r], *aval = B.sort_val_in + B.a_off[r];
+	const uint64_t read_tag = (uint64_t)r << (33 + B.rid_bits); // composite sort key: read | strand | rid | rpos (see launch_anchor_sort)
 	uint64_t *mp = B.mini_pos + B.mp_off[r];
 	for (int i = lane; i < n_m0; i += 64) {
 		const uint32_t ao = sd_aoff[i];
@@ -362,7 +380,8 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
 			}
 			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
-			a[ao + c] = p;
+			akey[ao + c] = read_tag | (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL);
+			aval[ao + c] = p.y;
 		}
 	}
 }
@@ -374,21 +393,82 @@ void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const Seed
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Anchor sort (map.c:202): permutation-exact replay of the reference's unstable radix sort, one lane per read
+// Anchor sort (map.c:202: radix_sort_128x by x, an UNSTABLE in-place sort whose tie order is observable)
+//
+// All anchors of the sub-batch are sorted at once by a composite 64-bit key  read | strand | rid | rpos  -- within a read this
+// is the order of x = strand<<63 | rid<<32 | rpos -- with the device-wide radix sort.  Where a read has no two anchors with the
+// same x the sorted order is unique and therefore equal to the reference's.  Reads that do have equal x (the same reference
+// position hit from two query positions; ~0.1 % of ONT reads) are re-sorted from their original order by a permutation-exact
+// replay of the reference's algorithm (exact_rsort.hpp), run by one lane on an LDS-resident copy.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) anchor_sort_kernel(SeedChainBuffers B)
+__device__ __forceinline__ uint64_t key_to_x(uint64_t key, int rid_bits)
 {
-	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= B.n_reads) return;
-	Anchor *a = B.anchors + B.a_off[r];
-	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
-	RsortScratch sc;
-	exact_radix_sort(a, a + n, KeyX(), sc);
+	const uint64_t low = key & ((1ULL << (32 + rid_bits)) - 1ULL);
+	return (key >> (32 + rid_bits) & 1ULL) << 63 | low;
 }
 
-void launch_anchor_sort(const SeedChainBuffers &B, void *stream)
+__global__ void __launch_bounds__(256) anchor_finalize_kernel(SeedChainBuffers B, uint64_t n_a)
 {
-	hipLaunchKernelGGL(anchor_sort_kernel, dim3((B.n_reads + 63) / 64), dim3(64), 0, (hipStream_t)stream, B);
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_a; i += stride) {
+		const uint64_t key = B.sort_key_out[i];
+		Anchor a;
+		a.x = key_to_x(key, B.rid_bits), a.y = B.sort_val_out[i];
+		B.anchors[i] = a;
+		if (i > 0 && B.sort_key_out[i - 1] == key) B.tie_flag[key >> (33 + B.rid_bits)] = 1u;
+	}
+}
+
+constexpr int TIE_LDS_CAP = 8192; // anchors of one read that fit the LDS-resident replay (16 B each)
+
+__global__ void __launch_bounds__(64) anchor_tie_fix_kernel(SeedChainBuffers B)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t tie_lds[];
+	Anchor *la = (Anchor *)tie_lds;
+	RsortScratch *sc = (RsortScratch *)(tie_lds + sizeof(Anchor) * TIE_LDS_CAP);
+	const int lane = threadIdx.x;
+	for (int r = blockIdx.x; r < B.n_reads; r += gridDim.x) {
+		if (!B.tie_flag[r]) continue;
+		const uint64_t ao = B.a_off[r];
+		const int64_t n = (int64_t)(B.a_off[r + 1] - ao);
+		Anchor *ga = B.anchors + ao;
+		Anchor *work = n <= TIE_LDS_CAP ? la : ga;
+		for (int64_t i = lane; i < n; i += 64) { // original (pre-sort) order
+			Anchor a;
+			a.x = key_to_x(B.sort_key_in[ao + i], B.rid_bits), a.y = B.sort_val_in[ao + i];
+			work[i] = a;
+		}
+		__threadfence_block();
+		__syncthreads();
+		if (lane == 0) exact_radix_sort(work, work + n, KeyX(), *sc);
+		__threadfence_block();
+		__syncthreads();
+		if (work != ga) for (int64_t i = lane; i < n; i += 64) ga[i] = work[i];
+		__syncthreads();
+	}
+}
+
+size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit)
+{
+	size_t bytes = 0;
+	HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+	                                             (int64_t)n_a, 0, end_bit, (hipStream_t)0));
+	return bytes;
+}
+
+void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
+	if (n_a == 0) return;
+	HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint64_t *)B.sort_key_in, B.sort_key_out, (const uint64_t *)B.sort_val_in, B.sort_val_out,
+	                                             (int64_t)n_a, 0, end_bit, s));
+	const unsigned grid = (unsigned)std::min<uint64_t>((n_a + 255) / 256, 65536);
+	hipLaunchKernelGGL(anchor_finalize_kernel, dim3(grid), dim3(256), 0, s, B, n_a);
+	const size_t lds = sizeof(Anchor) * TIE_LDS_CAP + sizeof(RsortScratch);
+	static bool attr_set = false;
+	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_tie_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+	hipLaunchKernelGGL(anchor_tie_fix_kernel, dim3(std::min(B.n_reads, 512)), dim3(64), lds, s, B);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -23,7 +23,7 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	uint8_t *qpool;           // nt4 forward | reverse complement per read
 	// minimizers
 	uint32_t *mz_cnt;         // n_reads
-	const uint64_t *mz_off;   // n_reads+1
+	const uint64_t *mz_off;   // n_reads (+1): first minimizer slot of each read (the read's base offset: at most one minimizer per base)
 	uint64_t *mz_x, *mz_y;
 	// per-minimizer seed info (same indexing as mz_*)
 	uint32_t *sd_n, *sd_off, *sd_aoff, *sd_qpos, *sd_info; // info: bits0-7 span, bit8 tandem, bit9 filtered
@@ -33,15 +33,19 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	const uint64_t *a_off;    // n_reads+1 anchor offsets
 	const uint64_t *mp_off;   // n_reads+1 mini_pos offsets
 	Anchor *anchors;
+	uint64_t *sort_key_in, *sort_val_in, *sort_key_out, *sort_val_out; // anchors as (composite key, y) pairs before / after the device sort
+	uint32_t *tie_flag;       // n_reads: set when a read has two anchors with equal x
+	int rid_bits;             // bits needed for a reference sequence id in the composite key
 	uint64_t *mini_pos;
 	int32_t *f, *p, *t;       // chaining DP arrays, indexed like anchors
 };
 
 void launch_encode(const SeedChainBuffers &B, void *stream);
-void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, bool emit, void *stream);
+void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
 void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
-void launch_anchor_sort(const SeedChainBuffers &B, void *stream);
+size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit);
+void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream);
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 
 } // namespace mm2amd

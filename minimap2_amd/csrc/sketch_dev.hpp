@@ -1,0 +1,108 @@
+// The (w,k)-minimizer window automaton of mm_sketch (sketch.c:77-143) as a device routine that can start in the
+// middle of a sequence.
+//
+// The reference walks a sequence once, carrying (k-mer registers, ring buffer of the last w slots, current minimum, run
+// length l).  Its state after any stretch of w+k consecutive slot-consuming bases is a function of that stretch alone: the
+// ring buffer then holds only slots from the stretch (their age order, not their ring position, is what the scans use), the
+// tracked minimum is always the right-most minimum of the last w slots, and l is only ever compared with k, w+k-1 and w+k.
+// So a lane that owns positions [cs,ce) starts `warm` bases earlier with exact k-mer registers, runs the unmodified automaton,
+// reports only minimizers whose position it owns, and restarts further back in the rare case the warm-up did not reach a
+// synchronised state before cs (N runs, strand-symmetric k-mers).  The union over chunks is the reference's output, in order.
+//
+// Non-HPC only (HPC needs run-length look-ahead across chunk borders; callers use the sequential kernel for it).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mm2amd {
+
+__device__ __forceinline__ uint64_t mm_hash64(uint64_t key, uint64_t mask) // hash64, sketch.c:28-38
+{
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask;
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask;
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+// Runs the automaton for the chunk [cs,ce) of seq[0,len) (nt4 codes, 4 = ambiguous) and calls emit(x, y) for every
+// minimizer the reference would report at a position in [cs,ce), in the reference's order.  x = hash<<8|span,
+// y = rid<<32 | pos<<1 | strand.  bx/by are caller-provided ring storage of at least w entries, accessed as bx[slot*stride].
+template <typename Emit>
+__device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, int64_t cs, int64_t ce, int w, int k, uint32_t rid,
+                                             uint64_t *bx, uint64_t *by, int stride, Emit emit)
+{
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	int64_t warm = 2 * (w + k) + 32;
+	for (;;) {
+		int64_t ws = cs - warm;
+		if (ws < 0) ws = 0;
+		// exact k-mer registers at ws: the last k unambiguous bases before it (ambiguous bases do not shift them, sketch.c:96-116)
+		uint64_t kmer0 = 0, kmer1 = 0;
+		if (ws > 0) {
+			int got = 0;
+			uint64_t packed = 0; // digit d = the valid base at distance d+1 before ws
+			for (int64_t j = ws - 1; j >= 0 && got < k; --j) { const uint8_t c = seq[j]; if (c < 4) { packed |= (uint64_t)c << (2 * got); ++got; } }
+			for (int d = got - 1; d >= 0; --d) { // replay the reference's shifts, oldest base first
+				const uint64_t c = packed >> (2 * d) & 3ULL;
+				kmer0 = (kmer0 << 2 | c) & mask;
+				kmer1 = (kmer1 >> 2) | (3ULL ^ c) << shift1;
+			}
+		}
+		uint64_t min_x = UINT64_MAX, min_y = UINT64_MAX;
+		int l = 0, buf_pos = 0, min_pos = 0;
+		bool synced = ws == 0; // at the sequence start the automaton is in its true initial state
+		bool restart = false;
+		for (int j = 0; j < w; ++j) bx[j * stride] = by[j * stride] = UINT64_MAX;
+#define MM2_EMIT(X, Y) do { const int64_t pp_ = (int64_t)((uint32_t)(Y) >> 1); if (pp_ >= cs && pp_ < ce) emit((X), (Y)); } while (0)
+		for (int64_t i = ws; i < len; ++i) {
+			if (i == cs && !synced) { restart = true; break; } // not enough clean history: start further back
+			// everything owned has been emitted: the window holds no valid k-mer, or its minimum lies past the chunk and the
+			// first-full-window rule (which may still emit an older equal-hash slot) can no longer fire on owned slots
+			if (i >= ce && (min_x == UINT64_MAX || ((int64_t)((uint32_t)min_y >> 1) >= ce && l >= w + k - 1))) break;
+			const int c = seq[i];
+			uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
+			if (c < 4) {
+				const int kmer_span = l + 1 < k ? l + 1 : k;
+				kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+				if (kmer0 == kmer1) continue; // strand-symmetric k-mer: no slot is consumed (sketch.c:108)
+				const int z = kmer0 < kmer1 ? 0 : 1;
+				++l;
+				if (l >= k) {
+					ix = mm_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+					iy = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z;
+				}
+				if (l >= w + k) synced = true; // state now depends only on the last w+k slots
+			} else l = 0;
+			bx[buf_pos * stride] = ix, by[buf_pos * stride] = iy;
+			if (l == w + k - 1 && min_x != UINT64_MAX) { // first full window (:117-122)
+				for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j * stride] && by[j * stride] != min_y) MM2_EMIT(bx[j * stride], by[j * stride]);
+				for (int j = 0; j < buf_pos; ++j)     if (min_x == bx[j * stride] && by[j * stride] != min_y) MM2_EMIT(bx[j * stride], by[j * stride]);
+			}
+			if (ix <= min_x) {
+				if (l >= w + k && min_x != UINT64_MAX) MM2_EMIT(min_x, min_y);
+				min_x = ix, min_y = iy, min_pos = buf_pos;
+			} else if (buf_pos == min_pos) {
+				if (l >= w + k - 1 && min_x != UINT64_MAX) MM2_EMIT(min_x, min_y);
+				min_x = UINT64_MAX;
+				for (int j = buf_pos + 1; j < w; ++j) if (min_x >= bx[j * stride]) min_x = bx[j * stride], min_y = by[j * stride], min_pos = j;
+				for (int j = 0; j <= buf_pos; ++j)    if (min_x >= bx[j * stride]) min_x = bx[j * stride], min_y = by[j * stride], min_pos = j;
+				if (l >= w + k - 1 && min_x != UINT64_MAX) {
+					for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j * stride] && min_y != by[j * stride]) MM2_EMIT(bx[j * stride], by[j * stride]);
+					for (int j = 0; j <= buf_pos; ++j)    if (min_x == bx[j * stride] && min_y != by[j * stride]) MM2_EMIT(bx[j * stride], by[j * stride]);
+				}
+			}
+			if (++buf_pos == w) buf_pos = 0;
+		}
+		if (restart) { warm = warm * 4 + 1024; continue; }
+		if (min_x != UINT64_MAX) MM2_EMIT(min_x, min_y); // end of the sequence, or an early exit with nothing owned pending
+#undef MM2_EMIT
+		return;
+	}
+}
+
+} // namespace mm2amd

@@ -65,8 +65,9 @@ public:
 			free(a); free(mp);
 		}
 	}
-	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, std::vector<uint32_t> &cigar) override
+	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, const uint32_t **cigar_out) override
 	{
+		std::vector<uint32_t> &cigar = cigar_store_;
 		res.resize(jobs.size());
 		cigar.clear();
 		std::vector<uint8_t> q, t;
@@ -95,11 +96,13 @@ public:
 			r.cigar_off = (uint32_t)cigar.size();
 			cigar.insert(cigar.end(), cg.begin(), cg.begin() + ez.n_cigar);
 		}
+		*cigar_out = cigar.data();
 	}
 private:
 	const FlatIndex &fi_;
 	std::vector<ReadView> reads_;
 	std::vector<uint8_t> qpool_;
+	std::vector<uint32_t> cigar_store_;
 };
 
 } // namespace

@@ -103,6 +103,11 @@ def test_aligner_equals_mm_map(kind, preset, n_reads, seed):
     refs = [synth.ACGT[c].tobytes() for c in contigs]
     rds = [("read%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
     rds += [("empty", b""), ("short", refs[0][100:130]), ("withN", refs[1][5000:5600] + b"NNNNNNNNNNNN" + refs[1][5612:8000])]
+    # tandem duplications inside the read: the same minimizers at two query positions hit the same reference positions, i.e.
+    # anchors with equal sort keys -- the case where the reference's unstable sort order is observable
+    for t in range(6):
+        p0 = 20000 + 7000 * t
+        rds.append(("dup%d" % t, refs[2][p0:p0 + 3000] + refs[2][p0 + 2000:p0 + 3000] * (1 + t % 3) + refs[2][p0 + 3000:p0 + 6000]))
     names = ["chr%d" % (i + 1) for i in range(3)]
     al = mm.Aligner(refs, preset=preset, names=names, n_threads=8)
     st = al.index_stat()
@@ -139,3 +144,28 @@ def test_profile_counters_and_substeps():
         del os.environ["MM2AMD_SUBBATCH_BASES"]
     al.close()
     assert parts == whole
+
+
+def test_repeat_rich_reference_ties_and_long_anchor_lists():
+    """a reference with many diverged copies of one element: thousands of anchors per read, equal-x ties, high-occurrence seeds"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(55)
+    elem = rng.integers(0, 4, 1500, dtype=np.uint8)
+    parts = []
+    for c in range(60):
+        e = elem.copy()
+        mut = rng.random(len(e)) < 0.03
+        e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+        parts += [rng.integers(0, 4, int(rng.integers(200, 3000)), dtype=np.uint8), e]
+    contig = np.concatenate(parts)
+    refs = [synth.ACGT[contig].tobytes(), synth.ACGT[rng.integers(0, 4, 200000, dtype=np.uint8)].tobytes()]
+    reads = synth.gen_reads(rng, [contig], 40, 6000, 2000, 0.08)
+    rds = [("rep%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    al = mm.Aligner(refs, preset="map-ont", n_threads=8)
+    got = al.map_batch(rds)
+    al.close()
+    ref = reflib.RefMapper(refs, "map-ont")
+    want = [ref.map(nm, s) for nm, s in rds]
+    ref.close()
+    for i in range(len(rds)):
+        assert [a.key() for a in got[i]] == want[i], rds[i][0]
