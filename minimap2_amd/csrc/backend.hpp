@@ -27,11 +27,14 @@ public:
 	// qpool_off[i] (2*len bytes).  Must be called before seed_chain()/ksw() of that batch.
 	virtual void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) = 0;
 	// sketch -> seed lookup -> anchor sort -> chaining DP -> chains, for reads [lo, hi) of the batch (out[i] is read lo+i)
-	virtual void seed_chain(const SeedChainParams &p, long lo, long hi, std::vector<ReadChains> &out) = 0;
+	// `lane` selects one of n_lanes() independent sets of work buffers (one host thread per lane at a time); host-side parts use
+	// up to n_threads pool threads.
+	virtual void seed_chain(const SeedChainParams &p, long lo, long hi, int lane, int n_threads, std::vector<ReadChains> &out) = 0;
+	virtual int n_lanes() const { return 1; }
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off
-	virtual void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, const uint32_t **cigar) = 0;
+	virtual void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) = 0;
 };
 
 } // namespace mm2amd

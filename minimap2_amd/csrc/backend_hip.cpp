@@ -1,9 +1,15 @@
 // The product's Backend: hand-written gfx950 kernels (seed_chain.hip, ksw_extd2.hip) plus the buffer management
 // around them.  There is deliberately no CPU path here: constructing it without a usable HIP device throws.
+//
+// A batch's sequences are made resident once (begin_batch).  The mapper then runs sub-batches of reads through
+// seed_chain()/ksw() on independent LANES: each lane owns a HIP stream and its device/pinned work buffers, so several host
+// driver threads can keep different sub-batches in flight and the GPU stages of one overlap the host stages of another.
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 #include "backend.hpp"
 #include "chain_host.hpp"
 #include "device_ctx.hpp"
@@ -12,18 +18,29 @@
 #include "index_build.hpp"
 #include "kernel_prof.hpp"
 #include "threads.hpp"
-#include <thread>
 
 namespace mm2amd {
 
 namespace {
 
-template <typename T>
-void upload(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
-{
-	d.ensure(h.size() ? h.size() : 1, 1.0);
-	if (!h.empty()) HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
-}
+struct Lane {
+	int id = 0;
+	hipStream_t stream = nullptr;
+	SeedChainBuffers B{};
+	KswRunner ksw;
+	DevBuf<uint64_t> d_a_off, d_mp_off, d_mz_x, d_mz_y, d_minipos, d_skey_in, d_sval_in, d_skey_out, d_sval_out;
+	DevBuf<uint32_t> d_mz_cnt, d_sd_n, d_sd_off, d_sd_aoff, d_sd_qpos, d_sd_info, d_n_anchor, d_n_minipos, d_n_seedhit, d_tie;
+	DevBuf<int32_t> d_rep_len, d_f, d_p, d_t;
+	DevBuf<Anchor> d_anchors;
+	DevBuf<uint8_t> d_sort_tmp;
+	PinBuf<Anchor> h_anchors;
+	PinBuf<int32_t> h_f, h_p, h_rep;
+	PinBuf<uint64_t> h_minipos, h_off;
+	PinBuf<uint32_t> h_na, h_nmp;
+	std::vector<uint64_t> a_off, mp_off;
+	std::vector<ChainScratch> scratch;
+	~Lane() { if (stream) (void)hipStreamDestroy(stream); }
+};
 
 class HipBackend : public Backend {
 public:
@@ -34,20 +51,28 @@ public:
 		std::lock_guard<std::mutex> lk(d.mu);
 		ensure_device(d);
 		stream_ = d.stream;
-		ksw_.n_cu = d.n_cu;
+		n_cu_ = d.n_cu;
 		n_threads_ = std::max(1u, std::thread::hardware_concurrency());
 		if (!T_) { own_.upload(fi, stream_); T_ = &own_; }
 		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
 		while ((1ull << rid_bits_) < fi.n_seq) ++rid_bits_;
+		n_lanes_ = 3;
+		if (const char *e = getenv("MM2AMD_LANES")) n_lanes_ = std::max(1, std::min(kMaxProfLanes, atoi(e)));
+		for (int i = 0; i < n_lanes_; ++i) {
+			lanes_.emplace_back(new Lane);
+			lanes_.back()->id = i;
+			HIP_CHECK(hipStreamCreateWithFlags(&lanes_.back()->stream, hipStreamNonBlocking));
+			lanes_.back()->ksw.n_cu = n_cu_;
+		}
 	}
 
+	int n_lanes() const override { return n_lanes_; }
 	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
 
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
 	{
 		const size_t n = reads.size();
-		n_reads_ = (int)n;
 		seq_off_.resize(n + 1);
 		seq_off_[0] = 0;
 		for (size_t i = 0; i < n; ++i) seq_off_[i + 1] = seq_off_[i] + (uint64_t)reads[i].len;
@@ -61,120 +86,119 @@ public:
 		d_seq_off_.ensure(n + 1);
 		HIP_CHECK(hipMemcpyAsync(d_ascii_.p, h, total, hipMemcpyHostToDevice, stream_));
 		HIP_CHECK(hipMemcpyAsync(d_seq_off_.p, seq_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-		B_ = SeedChainBuffers();
-		B_.n_reads = n_reads_, B_.seq_off = d_seq_off_.p, B_.ascii = d_ascii_.p, B_.qpool = d_qpool_.p;
 		HIP_CHECK(hipStreamSynchronize(stream_)); // the batch is resident; everything after this is the hot path
 	}
 
-	void seed_chain(const SeedChainParams &P, long lo, long hi, std::vector<ReadChains> &out) override
+	void seed_chain(const SeedChainParams &P, long lo, long hi, int lane_id, int n_threads, std::vector<ReadChains> &out) override
 	{
+		Lane &ln = *lanes_.at(lane_id);
+		hipStream_t st = ln.stream;
+		SeedChainBuffers &B = ln.B;
 		const size_t n = (size_t)(hi - lo);
-		B_.n_reads = (int)n, B_.seq_off = d_seq_off_.p + lo;
 		out.clear();
 		out.resize(n);
 		if (n == 0) return;
 		if (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY)) throw std::invalid_argument("[mm2amd] --for-only/--rev-only are not implemented on the device path");
-		KernelProfiler &kp = kernel_profiler();
+		B = SeedChainBuffers();
+		B.n_reads = (int)n, B.seq_off = d_seq_off_.p + lo, B.ascii = d_ascii_.p, B.qpool = d_qpool_.p;
+		KernelProfiler &kp = kernel_profiler(lane_id);
 		const double L = (double)(seq_off_[hi] - seq_off_[lo]);
-		kp.begin(stream_); launch_encode(B_, stream_); kp.end(stream_, "encode_kernel", 3 * L);
+		kp.begin(st); launch_encode(B, st); kp.end(st, "encode_kernel", 3 * L);
 		// 1. minimizers, written from slot seq_off[r] of the minimizer arrays (at most one per base)
 		const uint64_t base0 = seq_off_[lo], cap_mz = seq_off_[hi] - base0;
-		d_mz_cnt_.ensure(n);
-		d_mz_x_.ensure(cap_mz + 1), d_mz_y_.ensure(cap_mz + 1);
-		d_sd_n_.ensure(cap_mz + 1), d_sd_off_.ensure(cap_mz + 1), d_sd_aoff_.ensure(cap_mz + 1), d_sd_qpos_.ensure(cap_mz + 1), d_sd_info_.ensure(cap_mz + 1);
+		ln.d_mz_cnt.ensure(n);
+		ln.d_mz_x.ensure(cap_mz + 1), ln.d_mz_y.ensure(cap_mz + 1);
+		ln.d_sd_n.ensure(cap_mz + 1), ln.d_sd_off.ensure(cap_mz + 1), ln.d_sd_aoff.ensure(cap_mz + 1), ln.d_sd_qpos.ensure(cap_mz + 1), ln.d_sd_info.ensure(cap_mz + 1);
 		// the per-read slot offsets are the batch-wide base offsets; shifting the array bases by the sub-batch's first offset makes them local
-		B_.mz_cnt = d_mz_cnt_.p, B_.mz_off = B_.seq_off, B_.mz_x = d_mz_x_.p - base0, B_.mz_y = d_mz_y_.p - base0;
-		B_.sd_n = d_sd_n_.p - base0, B_.sd_off = d_sd_off_.p - base0, B_.sd_aoff = d_sd_aoff_.p - base0, B_.sd_qpos = d_sd_qpos_.p - base0, B_.sd_info = d_sd_info_.p - base0;
-		kp.begin(stream_); launch_sketch(B_, P, stream_); kp.end(stream_, "sketch_kernel", L + 16.0 * (2.0 * L / (P.w + 1)));
+		B.mz_cnt = ln.d_mz_cnt.p, B.mz_off = B.seq_off, B.mz_x = ln.d_mz_x.p - base0, B.mz_y = ln.d_mz_y.p - base0;
+		B.sd_n = ln.d_sd_n.p - base0, B.sd_off = ln.d_sd_off.p - base0, B.sd_aoff = ln.d_sd_aoff.p - base0, B.sd_qpos = ln.d_sd_qpos.p - base0, B.sd_info = ln.d_sd_info.p - base0;
+		const double est_mz = 2.0 * L / (P.w + 1);
+		kp.begin(st); launch_sketch(B, P, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
 		// 2. seeds: probe, filter, count anchors
-		d_n_anchor_.ensure(n), d_n_minipos_.ensure(n), d_n_seedhit_.ensure(n), d_rep_len_.ensure(n);
-		B_.n_anchor = d_n_anchor_.p, B_.n_minipos = d_n_minipos_.p, B_.n_seedhit = d_n_seedhit_.p, B_.rep_len = d_rep_len_.p;
-		kp.begin(stream_); launch_seed_collect(B_, I_, P, stream_); kp.end(stream_, "seed_collect_kernel", 36.0 * (2.0 * L / (P.w + 1))); // per minimizer: 16 B record + 8 key + 8 val + 4 flags
-		h_na_.resize(n), h_nmp_.resize(n), h_rep_.resize(n);
-		HIP_CHECK(hipMemcpyAsync(h_na_.data(), d_n_anchor_.p, n * 4, hipMemcpyDeviceToHost, stream_));
-		HIP_CHECK(hipMemcpyAsync(h_nmp_.data(), d_n_minipos_.p, n * 4, hipMemcpyDeviceToHost, stream_));
-		HIP_CHECK(hipMemcpyAsync(h_rep_.data(), d_rep_len_.p, n * 4, hipMemcpyDeviceToHost, stream_));
-		HIP_CHECK(hipStreamSynchronize(stream_));
-		a_off_.resize(n + 1), mp_off_.resize(n + 1);
-		a_off_[0] = mp_off_[0] = 0;
-		for (size_t i = 0; i < n; ++i) a_off_[i + 1] = a_off_[i] + h_na_[i], mp_off_[i + 1] = mp_off_[i] + h_nmp_[i];
-		const uint64_t n_a = a_off_[n], n_mp = mp_off_[n];
-		d_a_off_.ensure(n + 1), d_mp_off_.ensure(n + 1);
-		HIP_CHECK(hipMemcpyAsync(d_a_off_.p, a_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-		HIP_CHECK(hipMemcpyAsync(d_mp_off_.p, mp_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-		d_anchors_.ensure(n_a + 1), d_minipos_.ensure(n_mp + 1), d_f_.ensure(n_a + 1), d_p_.ensure(n_a + 1), d_t_.ensure(n_a + 1);
-		d_skey_in_.ensure(n_a + 1), d_sval_in_.ensure(n_a + 1), d_skey_out_.ensure(n_a + 1), d_sval_out_.ensure(n_a + 1), d_tie_.ensure(n);
-		B_.sort_key_in = d_skey_in_.p, B_.sort_val_in = d_sval_in_.p, B_.sort_key_out = d_skey_out_.p, B_.sort_val_out = d_sval_out_.p, B_.tie_flag = d_tie_.p;
-		B_.rid_bits = rid_bits_;
+		ln.d_n_anchor.ensure(n), ln.d_n_minipos.ensure(n), ln.d_n_seedhit.ensure(n), ln.d_rep_len.ensure(n);
+		B.n_anchor = ln.d_n_anchor.p, B.n_minipos = ln.d_n_minipos.p, B.n_seedhit = ln.d_n_seedhit.p, B.rep_len = ln.d_rep_len.p;
+		kp.begin(st); launch_seed_collect(B, I_, P, st); kp.end(st, "seed_collect_kernel", 36.0 * est_mz); // per minimizer: 16 B record + 8 key + 8 val + 4 flags
+		uint32_t *h_na = ln.h_na.ensure(n), *h_nmp = ln.h_nmp.ensure(n);
+		int32_t *h_rep = ln.h_rep.ensure(n);
+		HIP_CHECK(hipMemcpyAsync(h_na, ln.d_n_anchor.p, n * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_nmp, ln.d_n_minipos.p, n * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_rep, ln.d_rep_len.p, n * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipStreamSynchronize(st));
+		std::vector<uint64_t> &a_off = ln.a_off, &mp_off = ln.mp_off;
+		a_off.resize(n + 1), mp_off.resize(n + 1);
+		a_off[0] = mp_off[0] = 0;
+		for (size_t i = 0; i < n; ++i) a_off[i + 1] = a_off[i] + h_na[i], mp_off[i + 1] = mp_off[i] + h_nmp[i];
+		const uint64_t n_a = a_off[n], n_mp = mp_off[n];
+		uint64_t *h_off = ln.h_off.ensure(2 * (n + 1));
+		memcpy(h_off, a_off.data(), (n + 1) * 8), memcpy(h_off + n + 1, mp_off.data(), (n + 1) * 8);
+		ln.d_a_off.ensure(n + 1), ln.d_mp_off.ensure(n + 1);
+		HIP_CHECK(hipMemcpyAsync(ln.d_a_off.p, h_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+		HIP_CHECK(hipMemcpyAsync(ln.d_mp_off.p, h_off + n + 1, (n + 1) * 8, hipMemcpyHostToDevice, st));
+		ln.d_anchors.ensure(n_a + 1), ln.d_minipos.ensure(n_mp + 1), ln.d_f.ensure(n_a + 1), ln.d_p.ensure(n_a + 1), ln.d_t.ensure(n_a + 1);
+		ln.d_skey_in.ensure(n_a + 1), ln.d_sval_in.ensure(n_a + 1), ln.d_skey_out.ensure(n_a + 1), ln.d_sval_out.ensure(n_a + 1), ln.d_tie.ensure(n);
+		B.sort_key_in = ln.d_skey_in.p, B.sort_val_in = ln.d_sval_in.p, B.sort_key_out = ln.d_skey_out.p, B.sort_val_out = ln.d_sval_out.p, B.tie_flag = ln.d_tie.p;
+		B.rid_bits = rid_bits_;
 		int read_bits = 1;
 		while ((1ull << read_bits) < n) ++read_bits;
 		const int end_bit = 33 + rid_bits_ + read_bits;
 		const size_t sort_tmp = anchor_sort_temp_bytes(n_a, end_bit);
-		d_sort_tmp_.ensure(sort_tmp + 16);
-		B_.a_off = d_a_off_.p, B_.mp_off = d_mp_off_.p, B_.anchors = d_anchors_.p, B_.mini_pos = d_minipos_.p;
-		B_.f = d_f_.p, B_.p = d_p_.p, B_.t = d_t_.p;
+		ln.d_sort_tmp.ensure(sort_tmp + 16);
+		B.a_off = ln.d_a_off.p, B.mp_off = ln.d_mp_off.p, B.anchors = ln.d_anchors.p, B.mini_pos = ln.d_minipos.p;
+		B.f = ln.d_f.p, B.p = ln.d_p.p, B.t = ln.d_t.p;
 		// 3. anchors: expand, sort, chain
-		kp.begin(stream_); launch_seed_expand(B_, I_, P, stream_); kp.end(stream_, "seed_expand_kernel", 24.0 * n_a);
-		kp.begin(stream_); launch_anchor_sort(B_, n_a, end_bit, d_sort_tmp_.p, sort_tmp, stream_); kp.end(stream_, "anchor_sort", 32.0 * n_a);
-		kp.begin(stream_); launch_chain_fill(B_, P, stream_); kp.end(stream_, "chain_fill_kernel", 24.0 * n_a);
+		kp.begin(st); launch_seed_expand(B, I_, P, st); kp.end(st, "seed_expand_kernel", 24.0 * n_a);
+		launch_anchor_sort(B, n_a, end_bit, ln.d_sort_tmp.p, sort_tmp, st, &kp);
+		kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a);
 		// 4. back to the host for the (scalar, order-sensitive) backtrack
-		Anchor *ha = h_anchors_.ensure(n_a + 1);
-		int32_t *hf = h_f_.ensure(n_a + 1), *hp = h_p_.ensure(n_a + 1);
-		uint64_t *hmp = h_minipos_.ensure(n_mp + 1);
+		Anchor *ha = ln.h_anchors.ensure(n_a + 1);
+		int32_t *hf = ln.h_f.ensure(n_a + 1), *hp = ln.h_p.ensure(n_a + 1);
+		uint64_t *hmp = ln.h_minipos.ensure(n_mp + 1);
 		if (n_a) {
-			HIP_CHECK(hipMemcpyAsync(ha, d_anchors_.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost, stream_));
-			HIP_CHECK(hipMemcpyAsync(hf, d_f_.p, n_a * 4, hipMemcpyDeviceToHost, stream_));
-			HIP_CHECK(hipMemcpyAsync(hp, d_p_.p, n_a * 4, hipMemcpyDeviceToHost, stream_));
+			HIP_CHECK(hipMemcpyAsync(ha, ln.d_anchors.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(hf, ln.d_f.p, n_a * 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(hp, ln.d_p.p, n_a * 4, hipMemcpyDeviceToHost, st));
 		}
-		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, d_minipos_.p, n_mp * 8, hipMemcpyDeviceToHost, stream_));
-		HIP_CHECK(hipStreamSynchronize(stream_));
+		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipStreamSynchronize(st));
 		kp.collect();
 		const int max_drop = P.is_cdna ? INT32_MAX : P.bw;
-		std::vector<ChainScratch> scratch(n_threads_);
-		parallel_for(n_threads_, (long)n, [&](long i, int tid) {
+		if ((int)ln.scratch.size() < n_threads) ln.scratch.resize(n_threads);
+		parallel_for(n_threads, (long)n, [&](long i, int tid) {
 			ReadChains &c = out[i];
-			c.rep_len = h_rep_[i];
-			c.mini_pos.assign(hmp + mp_off_[i], hmp + mp_off_[i + 1]);
-			const int64_t na = (int64_t)(a_off_[i + 1] - a_off_[i]);
-			chain_backtrack_compact(na, ha + a_off_[i], hf + a_off_[i], hp + a_off_[i], P.min_cnt, P.min_chain_score, max_drop, c.u, c.a, scratch[tid]);
+			c.rep_len = h_rep[i];
+			c.mini_pos.assign(hmp + mp_off[i], hmp + mp_off[i + 1]);
+			const int64_t na = (int64_t)(a_off[i + 1] - a_off[i]);
+			chain_backtrack_compact(na, ha + a_off[i], hf + a_off[i], hp + a_off[i], P.min_cnt, P.min_chain_score, max_drop, c.u, c.a, ln.scratch[tid]);
 		});
 	}
 
-	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, const uint32_t **cigar) override
+	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane_id, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) override
 	{
+		Lane &ln = *lanes_.at(lane_id);
 		res.resize(jobs.size());
 		size_t n_cig = 0;
-		ksw_.n_threads = n_threads_;
-		ksw_.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, stream_);
-		kernel_profiler().collect();
+		ln.ksw.n_threads = n_threads;
+		ln.ksw.prof = &kernel_profiler(lane_id);
+		// the DP scratch (one direction-matrix slot per persistent wave) is the big per-lane allocation: split the budget
+		ln.ksw.dir_budget = ((size_t)12 << 30) / (size_t)n_lanes_;
+		ln.ksw.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
+		kernel_profiler(lane_id).collect();
 	}
 
 private:
 	const FlatIndex &fi_;
 	hipStream_t stream_ = nullptr;
-	int n_threads_ = 1, n_reads_ = 0;
+	int n_threads_ = 1, n_cu_ = 256, n_lanes_ = 1, rid_bits_ = 1;
 	DevIndex I_{};
-	SeedChainBuffers B_{};
-	KswRunner ksw_;
 	DeviceIndexTables own_;
 	DeviceIndexTables *T_ = nullptr;
+	std::vector<std::unique_ptr<Lane>> lanes_;
+	// the resident batch (shared by all lanes, read-only during run)
 	DevBuf<char> d_ascii_;
 	DevBuf<uint8_t> d_qpool_;
-	DevBuf<uint64_t> d_seq_off_, d_mz_off_, d_a_off_, d_mp_off_, d_mz_x_, d_mz_y_, d_minipos_;
-	DevBuf<uint32_t> d_mz_cnt_, d_sd_n_, d_sd_off_, d_sd_aoff_, d_sd_qpos_, d_sd_info_, d_n_anchor_, d_n_minipos_, d_n_seedhit_;
-	DevBuf<int32_t> d_rep_len_, d_f_, d_p_, d_t_;
-	DevBuf<Anchor> d_anchors_;
-	DevBuf<uint64_t> d_skey_in_, d_sval_in_, d_skey_out_, d_sval_out_;
-	DevBuf<uint32_t> d_tie_;
-	DevBuf<uint8_t> d_sort_tmp_;
-	int rid_bits_ = 1;
+	DevBuf<uint64_t> d_seq_off_;
 	PinBuf<char> h_ascii_;
-	PinBuf<Anchor> h_anchors_;
-	PinBuf<int32_t> h_f_, h_p_;
-	PinBuf<uint64_t> h_minipos_;
-	std::vector<uint64_t> seq_off_, mz_off_, a_off_, mp_off_;
-	std::vector<uint32_t> h_cnt_, h_na_, h_nmp_;
-	std::vector<int32_t> h_rep_;
+	std::vector<uint64_t> seq_off_;
 };
 
 } // namespace

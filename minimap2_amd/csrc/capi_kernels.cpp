@@ -8,6 +8,7 @@
 #include "device_ctx.hpp"
 #include "ksw_host.hpp"
 #include "kernel_prof.hpp"
+#include <map>
 
 namespace mm2amd { int capi_fail(int code, const std::string &msg); }
 using namespace mm2amd;
@@ -84,6 +85,7 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 		std::vector<KswRes> r(n_jobs);
 		const uint32_t *cig = nullptr;
 		size_t n_cig = 0;
+		d.ksw.prof = &kernel_profiler(0);
 		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), &cig, &n_cig, dc.stream);
 		kernel_profiler().collect();
 		if (n_cig > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
@@ -100,15 +102,20 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 
 void mm2amd_profile_enable(int on)
 {
-	KernelProfiler &p = kernel_profiler();
-	p.reset();
-	p.enabled = on != 0;
+	for (int l = 0; l < kMaxProfLanes; ++l) kernel_profiler(l).reset();
+	KernelProfiler::enabled_flag() = on != 0;
 }
 
 int mm2amd_profile_get(mm2amd_kernel_stat_t *out, int cap)
 {
+	std::map<std::string, KernelStat> all;
+	for (int l = 0; l < kMaxProfLanes; ++l)
+		for (const auto &kv : kernel_profiler(l).stats()) {
+			KernelStat &k = all[kv.first];
+			k.ms += kv.second.ms, k.alg_bytes += kv.second.alg_bytes, k.launches += kv.second.launches;
+		}
 	int n = 0;
-	for (const auto &kv : kernel_profiler().stats()) {
+	for (const auto &kv : all) {
 		if (n >= cap) break;
 		mm2amd_kernel_stat_t &o = out[n++];
 		memset(&o, 0, sizeof o);

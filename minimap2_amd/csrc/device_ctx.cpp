@@ -10,10 +10,10 @@ DeviceCtx &device_ctx()
 	return d;
 }
 
-KernelProfiler &kernel_profiler()
+KernelProfiler &kernel_profiler(int lane)
 {
-	static KernelProfiler p;
-	return p;
+	static KernelProfiler p[kMaxProfLanes];
+	return p[lane < 0 || lane >= kMaxProfLanes ? 0 : lane];
 }
 
 void ensure_device(DeviceCtx &d)

@@ -13,10 +13,12 @@ struct KernelStat { double ms = 0, alg_bytes = 0; long launches = 0; };
 
 class KernelProfiler {
 public:
-	bool enabled = false;
+	static bool &enabled_flag() { static bool on = false; return on; } // one switch for all lanes
+	bool active_ = false; // latched at begin() so that an end() always matches its begin()
 	void begin(hipStream_t s)
 	{
-		if (!enabled) return;
+		active_ = enabled_flag();
+		if (!active_) return;
 		Pending p;
 		p.e0 = get_event(), p.e1 = get_event();
 		HIP_CHECK(hipEventRecord(p.e0, s));
@@ -24,7 +26,7 @@ public:
 	}
 	void end(hipStream_t s, const char *name, double alg_bytes)
 	{
-		if (!enabled) return;
+		if (!active_) return;
 		Pending &p = pending_.back();
 		p.name = name, p.bytes = alg_bytes;
 		HIP_CHECK(hipEventRecord(p.e1, s));
@@ -58,6 +60,7 @@ private:
 	std::map<std::string, KernelStat> stats_;
 };
 
-KernelProfiler &kernel_profiler(); // device_ctx.cpp
+constexpr int kMaxProfLanes = 8;
+KernelProfiler &kernel_profiler(int lane = 0); // device_ctx.cpp; one per backend lane (each is used by one host thread at a time)
 
 } // namespace mm2amd

@@ -103,9 +103,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.dir_pool = d_dir.p, L.slot_bytes = slot_bytes;
 			L.counter = d_counter.p + tier;
 			L.max_T16 = max_T16, L.max_Q16 = max_Q16, L.sc = sc;
-			kernel_profiler().begin(stream);
+			if (prof) prof->begin(stream);
 			ksw_extd2_launch(L, (int)n_slots, wpb, stream);
-			kernel_profiler().end(stream, tier == 0 ? "ksw_extd2_kernel[t0]" : tier == 1 ? "ksw_extd2_kernel[t1]" : "ksw_extd2_kernel[t2]", alg_bytes);
+			if (prof) prof->end(stream, tier == 0 ? "ksw_extd2_kernel[t0]" : tier == 1 ? "ksw_extd2_kernel[t1]" : "ksw_extd2_kernel[t2]", alg_bytes);
 		}
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));

@@ -18,6 +18,7 @@ struct KswRunner {
 	PinBuf<uint32_t> cigar_host;      // the batch's CIGARs as the kernel packed them
 	std::vector<uint32_t> perm, bucket;
 	int n_threads = 1;
+	class KernelProfiler *prof = nullptr; // optional per-launch timing
 	size_t dir_budget = (size_t)12 << 30; // bytes of HBM we allow for direction matrices
 	int n_cu = 256;
 

@@ -5,6 +5,9 @@
 #include "mapper.hpp"
 #include "chain_host.hpp"
 #include "threads.hpp"
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 namespace mm2amd {
 
@@ -59,8 +62,6 @@ void Mapper::run(std::vector<ReadResult> &out)
 	out.resize(n);
 	stats = MapperStats();
 	const std::vector<ReadView> &live = live_;
-	const std::vector<long> &live_id = live_id_;
-	const std::vector<uint64_t> &qoff = qoff_;
 	const long m_all = (long)live.size();
 	if (m_all == 0) return;
 	double t0 = now();
@@ -79,17 +80,62 @@ void Mapper::run(std::vector<ReadResult> &out)
 	sp.is_cdna = 0;
 	if (opt_.max_gap_ref <= 0 && opt_.max_frag_len > 0) throw std::invalid_argument("[mm2amd] max_frag_len-derived chaining gap is a paired-end feature and is not implemented");
 
-	// sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight)
-	long sub_bases = 200000000;
+	// Sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight) and are the
+	// unit of pipelining: each of the backend's lanes is driven by one host thread that takes the next sub-batch through all of
+	// its stages, so the GPU stages of one sub-batch overlap the host stages of the others.
+	long sub_bases = 100000000;
 	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
-	for (long lo = 0, hi; lo < m_all; lo = hi) {
-		long bases = 0;
+	std::vector<std::pair<long, long>> subs;
+	{
 		const long max_reads = be_.max_reads_per_call();
-		for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
+		for (long lo = 0, hi; lo < m_all; lo = hi) {
+			long bases = 0;
+			for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
+			subs.emplace_back(lo, hi);
+		}
+	}
+	const int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), subs.size());
+	std::atomic<size_t> next_sub(0);
+	std::mutex stats_mu;
+	std::exception_ptr first_err;
+	auto driver = [&](int lane) {
+		MapperStats st; // this driver's share, merged at the end
+		// Aligner holds scratch buffers, so each pool thread of this driver gets its own instance
+		std::vector<std::unique_ptr<Aligner>> al(n_threads_);
+		for (auto &p : al) p.reset(new Aligner(opt_, fi_));
+		try {
+			for (;;) {
+				const size_t si = next_sub.fetch_add(1);
+				if (si >= subs.size()) break;
+				process_sub(sp, subs[si].first, subs[si].second, lane, al, out, st);
+			}
+		} catch (...) {
+			std::lock_guard<std::mutex> lk(stats_mu);
+			if (!first_err) first_err = std::current_exception();
+			next_sub.store(subs.size());
+		}
+		std::lock_guard<std::mutex> lk(stats_mu);
+		stats.t_seed_chain += st.t_seed_chain, stats.t_host_pre += st.t_host_pre, stats.t_plan += st.t_plan, stats.t_ksw += st.t_ksw;
+		stats.t_consume += st.t_consume, stats.t_finish += st.t_finish, stats.n_jobs += st.n_jobs, stats.n_rounds += st.n_rounds, stats.dp_cells += st.dp_cells;
+	};
+	std::vector<std::thread> th;
+	for (int l = 1; l < n_drivers; ++l) th.emplace_back(driver, l);
+	driver(0);
+	for (auto &t : th) t.join();
+	if (first_err) std::rethrow_exception(first_err);
+	(void)t0;
+}
+
+void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, std::vector<ReadResult> &out, MapperStats &stats)
+{
+	const std::vector<ReadView> &live = live_;
+	const std::vector<long> &live_id = live_id_;
+	const std::vector<uint64_t> &qoff = qoff_;
+	{
 		const long m = hi - lo;
-		t0 = now();
+		double t0 = now();
 		std::vector<ReadChains> chains;
-		be_.seed_chain(sp, lo, hi, chains);
+		be_.seed_chain(sp, lo, hi, lane, n_threads_, chains);
 		stats.t_seed_chain += now() - t0; t0 = now();
 
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
@@ -137,9 +183,6 @@ void Mapper::run(std::vector<ReadResult> &out)
 		std::vector<KswRes> kres;
 		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(m, 1);
-		// Aligner holds a scratch buffer, so each worker thread gets its own instance
-		std::vector<std::unique_ptr<Aligner>> al(n_threads_);
-		for (auto &p : al) p.reset(new Aligner(opt_, fi_));
 		for (int round = 0;; ++round) {
 			t0 = now();
 			parallel_for(n_threads_, m, [&](long i, int tid) {
@@ -155,7 +198,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 			}, 256);
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
 			stats.t_plan += now() - t0; t0 = now();
-			be_.ksw(jobs, sc, kres, &cigars);
+			be_.ksw(jobs, sc, lane, n_threads_, kres, &cigars);
 			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
 			stats.t_ksw += now() - t0; t0 = now();
 			parallel_for(n_threads_, m, [&](long i, int tid) {

@@ -32,6 +32,7 @@ public:
 	void run(std::vector<ReadResult> &out);
 	MapperStats stats;
 private:
+	void process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, std::vector<ReadResult> &out, MapperStats &st);
 	const FlatIndex &fi_;
 	ref::MapOpt opt_;
 	Backend &be_;

@@ -14,6 +14,7 @@
 #include "hip_util.hpp"
 #include "seed_chain_dev.hpp"
 #include "sketch_dev.hpp"
+#include "kernel_prof.hpp"
 #include <hipcub/hipcub.hpp>
 
 namespace mm2amd {
@@ -456,19 +457,27 @@ size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit)
 	return bytes;
 }
 
-void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream)
+void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream, KernelProfiler *kp)
 {
 	hipStream_t s = (hipStream_t)stream;
+	KernelProfiler none;
+	if (!kp) kp = &none;
 	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
 	if (n_a == 0) return;
+	kp->begin(s);
 	HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint64_t *)B.sort_key_in, B.sort_key_out, (const uint64_t *)B.sort_val_in, B.sort_val_out,
 	                                             (int64_t)n_a, 0, end_bit, s));
+	kp->end(s, "anchor_radix_sort(rocprim)", 32.0 * n_a);
 	const unsigned grid = (unsigned)std::min<uint64_t>((n_a + 255) / 256, 65536);
+	kp->begin(s);
 	hipLaunchKernelGGL(anchor_finalize_kernel, dim3(grid), dim3(256), 0, s, B, n_a);
+	kp->end(s, "anchor_finalize_kernel", 32.0 * n_a);
 	const size_t lds = sizeof(Anchor) * TIE_LDS_CAP + sizeof(RsortScratch);
 	static bool attr_set = false;
 	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_tie_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+	kp->begin(s);
 	hipLaunchKernelGGL(anchor_tie_fix_kernel, dim3(std::min(B.n_reads, 512)), dim3(64), lds, s, B);
+	kp->end(s, "anchor_tie_fix_kernel", 0.0);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -38,7 +38,7 @@ public:
 			}
 		}
 	}
-	void seed_chain(const SeedChainParams &p, long lo, long hi, std::vector<ReadChains> &out) override
+	void seed_chain(const SeedChainParams &p, long lo, long hi, int /*lane*/, int /*n_threads*/, std::vector<ReadChains> &out) override
 	{
 		out.clear();
 		out.resize((size_t)(hi - lo));
@@ -65,7 +65,7 @@ public:
 			free(a); free(mp);
 		}
 	}
-	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, std::vector<KswRes> &res, const uint32_t **cigar_out) override
+	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int /*lane*/, int /*n_threads*/, std::vector<KswRes> &res, const uint32_t **cigar_out) override
 	{
 		std::vector<uint32_t> &cigar = cigar_store_;
 		res.resize(jobs.size());
