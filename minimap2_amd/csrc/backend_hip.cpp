@@ -34,11 +34,15 @@ struct Lane {
 	DevBuf<Anchor> d_anchors;
 	DevBuf<uint8_t> d_sort_tmp;
 	PinBuf<Anchor> h_anchors;
-	PinBuf<int32_t> h_f, h_p, h_rep;
-	PinBuf<uint64_t> h_minipos, h_off;
+	PinBuf<int32_t> h_rep, h_nu, h_nv;
+	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
+	PinBuf<unsigned long long> h_cursor;
+	DevBuf<unsigned long long> d_bt_cursor;
+	DevBuf<Anchor> d_bt_out_a;
+	DevBuf<uint64_t> d_bt_out_u, d_bt_aoff, d_bt_uoff;
+	DevBuf<int32_t> d_bt_nu, d_bt_nv;
 	PinBuf<uint32_t> h_na, h_nmp;
 	std::vector<uint64_t> a_off, mp_off;
-	std::vector<ChainScratch> scratch;
 	~Lane() { if (stream) (void)hipStreamDestroy(stream); }
 };
 
@@ -149,27 +153,37 @@ public:
 		kp.begin(st); launch_seed_expand(B, I_, P, st); kp.end(st, "seed_expand_kernel", 24.0 * n_a);
 		launch_anchor_sort(B, n_a, end_bit, ln.d_sort_tmp.p, sort_tmp, st, &kp);
 		kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a);
-		// 4. back to the host for the (scalar, order-sensitive) backtrack
-		Anchor *ha = ln.h_anchors.ensure(n_a + 1);
-		int32_t *hf = ln.h_f.ensure(n_a + 1), *hp = ln.h_p.ensure(n_a + 1);
+		// 4. chains: backtrack + compaction on the device, then only the chained anchors travel to the host
+		ln.d_bt_cursor.ensure(2), ln.d_bt_out_a.ensure(n_a + 1), ln.d_bt_out_u.ensure(n_a / 2 + n + 1);
+		ln.d_bt_nu.ensure(n), ln.d_bt_nv.ensure(n), ln.d_bt_aoff.ensure(n), ln.d_bt_uoff.ensure(n);
+		B.bt_cursor = ln.d_bt_cursor.p, B.bt_out_a = ln.d_bt_out_a.p, B.bt_out_u = ln.d_bt_out_u.p;
+		B.bt_nu = ln.d_bt_nu.p, B.bt_nv = ln.d_bt_nv.p, B.bt_aoff = ln.d_bt_aoff.p, B.bt_uoff = ln.d_bt_uoff.p;
+		kp.begin(st); launch_chain_backtrack(B, P, st); kp.end(st, "chain_backtrack_kernel", 8.0 * n_a);
+		unsigned long long *h_cur = ln.h_cursor.ensure(2);
+		int32_t *h_nu = ln.h_nu.ensure(n), *h_nv = ln.h_nv.ensure(n);
+		uint64_t *h_aoff = ln.h_aoff.ensure(n), *h_uoff = ln.h_uoff.ensure(n);
 		uint64_t *hmp = ln.h_minipos.ensure(n_mp + 1);
-		if (n_a) {
-			HIP_CHECK(hipMemcpyAsync(ha, ln.d_anchors.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(hf, ln.d_f.p, n_a * 4, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(hp, ln.d_p.p, n_a * 4, hipMemcpyDeviceToHost, st));
-		}
+		HIP_CHECK(hipMemcpyAsync(h_cur, ln.d_bt_cursor.p, 16, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_nu, ln.d_bt_nu.p, n * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_nv, ln.d_bt_nv.p, n * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_aoff, ln.d_bt_aoff.p, n * 8, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_uoff, ln.d_bt_uoff.p, n * 8, hipMemcpyDeviceToHost, st));
 		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipStreamSynchronize(st));
+		const uint64_t n_v = h_cur[0], n_u = h_cur[1];
+		Anchor *ha = ln.h_anchors.ensure(n_v + 1);
+		uint64_t *hu = ln.h_u.ensure(n_u + 1);
+		if (n_v) HIP_CHECK(hipMemcpyAsync(ha, ln.d_bt_out_a.p, n_v * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+		if (n_u) HIP_CHECK(hipMemcpyAsync(hu, ln.d_bt_out_u.p, n_u * 8, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipStreamSynchronize(st));
 		kp.collect();
-		const int max_drop = P.is_cdna ? INT32_MAX : P.bw;
-		if ((int)ln.scratch.size() < n_threads) ln.scratch.resize(n_threads);
-		parallel_for(n_threads, (long)n, [&](long i, int tid) {
+		parallel_for(n_threads, (long)n, [&](long i, int) {
 			ReadChains &c = out[i];
 			c.rep_len = h_rep[i];
 			c.mini_pos.assign(hmp + mp_off[i], hmp + mp_off[i + 1]);
-			const int64_t na = (int64_t)(a_off[i + 1] - a_off[i]);
-			chain_backtrack_compact(na, ha + a_off[i], hf + a_off[i], hp + a_off[i], P.min_cnt, P.min_chain_score, max_drop, c.u, c.a, ln.scratch[tid]);
-		});
+			c.u.assign(hu + h_uoff[i], hu + h_uoff[i] + h_nu[i]);
+			c.a.assign(ha + h_aoff[i], ha + h_aoff[i] + h_nv[i]);
+		}, 64);
 	}
 
 	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane_id, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) override

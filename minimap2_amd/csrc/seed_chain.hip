@@ -420,31 +420,142 @@ __global__ void __launch_bounds__(256) anchor_finalize_kernel(SeedChainBuffers B
 	}
 }
 
-constexpr int TIE_LDS_CAP = 8192; // anchors of one read that fit the LDS-resident replay (16 B each)
+constexpr int TIE_LDS_CAP = 8192;   // anchors of one read whose (key, index) pairs fit the LDS-resident replay
+constexpr int TIE_MAX_KEYS = 64;    // distinct tied keys tracked per read; more => every bucket is replayed
+constexpr int TIE_STACK = 2304;     // replay-all worst case: 255 siblings on each of 8 levels, plus one
+
+struct TieFrame { int32_t b, e, shift; };
+
+// Wave-cooperative, permutation-exact replay of radix_sort_128x (ksort.h:101-151) restricted to what can matter.
+//
+// K[0..n) / I[0..n) hold the keys in the ORIGINAL (pre-sort) order and their original indices.  The reference's MSD radix
+// sort partitions a range by one key byte with an in-place cycle-leader walk (sequential, replayed here by lane 0; the byte
+// histogram before it is computed by all lanes), then recurses into buckets of more than 64 elements and insertion-sorts
+// (stably) the smaller ones.  Sibling buckets are independent, and a bucket that contains no duplicated key ends in the unique
+// sorted order whatever its incoming order was -- which the device-wide sort already produced.  So only the chain of buckets
+// leading to duplicated keys is replayed; everything else is skipped.  Afterwards the elements with duplicated keys sit at
+// their final positions in K/I.
+__device__ void tie_exact_replay(uint64_t *K, uint32_t *I, int32_t n, const uint64_t *tied, int n_tied, bool replay_all,
+                                 uint32_t *cnt, uint32_t *head, uint32_t *start, TieFrame *stack, int stack_cap, int lane)
+{
+	auto insertion = [&](int32_t b, int32_t e) { // rs_insertsort (ksort.h:105-115): stable
+		for (int32_t i = b + 1; i < e; ++i)
+			if (K[i] < K[i - 1]) {
+				const uint64_t tk = K[i];
+				const uint32_t ti = I[i];
+				int32_t j;
+				for (j = i; j > b && tk < K[j - 1]; --j) K[j] = K[j - 1], I[j] = I[j - 1];
+				K[j] = tk, I[j] = ti;
+			}
+	};
+	if (n <= 64) { // radix_sort top level (ksort.h:149)
+		if (lane == 0) insertion(0, n);
+		__syncthreads();
+		return;
+	}
+	int sp = 0;
+	if (lane == 0) stack[0] = TieFrame{0, n, 56};
+	sp = 1;
+	__syncthreads();
+	while (sp > 0) {
+		const TieFrame fr = stack[--sp];
+		const int32_t len = fr.e - fr.b;
+		for (int k = lane; k < 256; k += 64) cnt[k] = 0;
+		__syncthreads();
+		for (int32_t i = fr.b + lane; i < fr.e; i += 64) atomicAdd(&cnt[K[i] >> fr.shift & 255], 1u);
+		__syncthreads();
+		if (lane == 0) {
+			uint32_t acc = 0, mx = 0;
+			for (int k = 0; k < 256; ++k) { start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; } // cnt becomes the bucket end
+			if ((int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
+				uint64_t *kb = K + fr.b;
+				uint32_t *ib = I + fr.b;
+				for (int k = 0; k < 256;) {
+					if (head[k] != cnt[k]) {
+						int l = (int)(kb[head[k]] >> fr.shift & 255);
+						if (l != k) {
+							uint64_t tk = kb[head[k]], sk;
+							uint32_t ti = ib[head[k]], si;
+							do {
+								sk = tk, si = ti;
+								tk = kb[head[l]], ti = ib[head[l]];
+								kb[head[l]] = sk, ib[head[l]] = si;
+								++head[l];
+								l = (int)(tk >> fr.shift & 255);
+							} while (l != k);
+							kb[head[k]] = tk, ib[head[k]] = ti;
+							++head[k];
+						} else ++head[k];
+					} else ++k;
+				}
+			}
+		}
+		__syncthreads();
+		if (fr.shift == 0) continue;
+		const int ns = fr.shift > 8 ? fr.shift - 8 : 0;
+		for (int k = 0; k < 256; ++k) { // children (uniform control flow across the wave)
+			const int32_t cb = fr.b + (int32_t)start[k], ce = fr.b + (int32_t)cnt[k];
+			if (ce - cb <= 1) continue;
+			bool has = replay_all;
+			if (!has) {
+				const uint64_t prefix = K[cb] >> fr.shift;
+				bool mine = false;
+				for (int t = lane; t < n_tied; t += 64) mine |= (tied[t] >> fr.shift) == prefix;
+				has = __ballot(mine) != 0ull;
+			}
+			if (!has) continue;
+			if (ce - cb > 64) {
+				if (sp < stack_cap) { if (lane == 0) stack[sp] = TieFrame{cb, ce, ns}; ++sp; } // cannot overflow: callers size the stack for n/65 frames per level
+			} else if (lane == 0) insertion(cb, ce);
+		}
+		__syncthreads();
+	}
+}
 
 __global__ void __launch_bounds__(64) anchor_tie_fix_kernel(SeedChainBuffers B)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t tie_lds[];
-	Anchor *la = (Anchor *)tie_lds;
-	RsortScratch *sc = (RsortScratch *)(tie_lds + sizeof(Anchor) * TIE_LDS_CAP);
+	uint64_t *lK = (uint64_t *)tie_lds;
+	uint32_t *lI = (uint32_t *)(lK + TIE_LDS_CAP);
+	uint32_t *cnt = lI + TIE_LDS_CAP, *head = cnt + 256, *start = head + 256;
+	uint64_t *tied = (uint64_t *)(start + 256);
+	TieFrame *stack = (TieFrame *)(tied + TIE_MAX_KEYS);
+	__shared__ uint32_t n_tied_s;
 	const int lane = threadIdx.x;
 	for (int r = blockIdx.x; r < B.n_reads; r += gridDim.x) {
 		if (!B.tie_flag[r]) continue;
 		const uint64_t ao = B.a_off[r];
-		const int64_t n = (int64_t)(B.a_off[r + 1] - ao);
-		Anchor *ga = B.anchors + ao;
-		Anchor *work = n <= TIE_LDS_CAP ? la : ga;
-		for (int64_t i = lane; i < n; i += 64) { // original (pre-sort) order
-			Anchor a;
-			a.x = key_to_x(B.sort_key_in[ao + i], B.rid_bits), a.y = B.sort_val_in[ao + i];
-			work[i] = a;
+		const int32_t n = (int32_t)(B.a_off[r + 1] - ao);
+		// 1. the duplicated keys, from the sorted output
+		if (lane == 0) n_tied_s = 0;
+		__syncthreads();
+		const uint64_t *so = B.sort_key_out + ao;
+		for (int32_t i = lane; i + 1 < n; i += 64)
+			if (so[i] == so[i + 1] && (i == 0 || so[i - 1] != so[i])) {
+				const uint32_t slot = atomicAdd(&n_tied_s, 1u);
+				if (slot < TIE_MAX_KEYS) tied[slot] = key_to_x(so[i], B.rid_bits);
+			}
+		__syncthreads();
+		const uint32_t n_tied_all = n_tied_s;
+		const bool replay_all = n_tied_all > TIE_MAX_KEYS;
+		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
+		// 2. keys in original order + their indices; large reads use the (no longer needed) sorted arrays as scratch
+		uint64_t *K = n <= TIE_LDS_CAP ? lK : B.sort_key_out + ao;
+		uint32_t *I = n <= TIE_LDS_CAP ? lI : (uint32_t *)(B.sort_val_out + ao);
+		__syncthreads();
+		for (int32_t i = lane; i < n; i += 64) K[i] = key_to_x(B.sort_key_in[ao + i], B.rid_bits), I[i] = (uint32_t)i;
+		__threadfence_block();
+		__syncthreads();
+		tie_exact_replay(K, I, n, tied, n_tied, replay_all, cnt, head, start, stack, TIE_STACK, lane);
+		__threadfence_block();
+		__syncthreads();
+		// 3. elements carrying a duplicated key are now at their final positions
+		for (int32_t i = lane; i < n; i += 64) {
+			const uint64_t x = K[i];
+			bool dup = replay_all;
+			for (int t = 0; t < n_tied && !dup; ++t) dup = tied[t] == x;
+			if (dup) { Anchor a; a.x = x, a.y = B.sort_val_in[ao + I[i]]; B.anchors[ao + i] = a; }
 		}
-		__threadfence_block();
-		__syncthreads();
-		if (lane == 0) exact_radix_sort(work, work + n, KeyX(), *sc);
-		__threadfence_block();
-		__syncthreads();
-		if (work != ga) for (int64_t i = lane; i < n; i += 64) ga[i] = work[i];
 		__syncthreads();
 	}
 }
@@ -472,7 +583,7 @@ void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, vo
 	kp->begin(s);
 	hipLaunchKernelGGL(anchor_finalize_kernel, dim3(grid), dim3(256), 0, s, B, n_a);
 	kp->end(s, "anchor_finalize_kernel", 32.0 * n_a);
-	const size_t lds = sizeof(Anchor) * TIE_LDS_CAP + sizeof(RsortScratch);
+	const size_t lds = (size_t)12 * TIE_LDS_CAP + 3 * 256 * 4 + TIE_MAX_KEYS * 8 + TIE_STACK * sizeof(TieFrame) + 64;
 	static bool attr_set = false;
 	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_tie_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
 	kp->begin(s);
@@ -609,6 +720,132 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 		__threadfence_block();
 		if (max_ii < 0 || (ix - a[max_ii].x <= (uint64_t)(int64_t)max_dist_x && f[max_ii] < max_f)) max_ii = i;
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Chain backtrack + compaction (mg_chain_backtrack lchain.c:27-76, mg_chain_bk_end :9-25, compact_a :78-111), one wavefront
+// per read.  Chain ends are visited in the order the reference's unstable radix sort leaves them in (equal scores are common),
+// so that sort is replayed exactly (tie_exact_replay, all buckets); the walk itself is sequential (lane 0) and latency-bound,
+// which is why the kernel keeps its footprint small: thousands of reads are in flight per GPU.
+// Per-read scratch lives in arrays that are dead by now (the pre/post-sort key/value arrays and t[]); results go to dense
+// output arrays through two atomic cursors.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BT_LDS_CAP = 1024; // chain ends (or chains) whose sort runs in LDS
+constexpr int BT_STACK = 320;
+
+__device__ void bt_sort(uint64_t *K, uint32_t *I, int32_t n, uint32_t *cnt, uint32_t *head, uint32_t *start, TieFrame *stack, int stack_cap, int lane)
+{
+	tie_exact_replay(K, I, n, nullptr, 0, true, cnt, head, start, stack, stack_cap, lane);
+}
+
+__global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B, int min_cnt, int min_sc, int max_drop)
+{
+	__shared__ uint64_t lK[BT_LDS_CAP];
+	__shared__ uint32_t lI[BT_LDS_CAP];
+	__shared__ uint32_t cnt[256], head[256], start[256];
+	__shared__ TieFrame stack[BT_STACK];
+	__shared__ int32_t s_nu, s_nv;
+	__shared__ uint64_t s_aoff, s_uoff;
+	const int lane = threadIdx.x;
+	const int r = blockIdx.x;
+	const uint64_t ao = B.a_off[r];
+	const int32_t n = (int32_t)(B.a_off[r + 1] - ao);
+	const Anchor *a = B.anchors + ao;
+	const int32_t *f = B.f + ao, *p = B.p + ao;
+	int32_t *t = B.t + ao;
+	if (n == 0) { if (lane == 0) B.bt_nu[r] = 0, B.bt_nv[r] = 0, B.bt_aoff[r] = 0, B.bt_uoff[r] = 0; return; }
+	// ---- chain ends z = {(f[i], i) : f[i] >= min_sc} in index order (lchain.c:35-40) ----
+	int32_t n_z = 0;
+	for (int32_t i = lane; i < n; i += 64) { t[i] = 0; n_z += f[i] >= min_sc; }
+	for (int o = 32; o > 0; o >>= 1) n_z += __shfl_xor(n_z, o, 64);
+	if (n_z == 0) { if (lane == 0) B.bt_nu[r] = 0, B.bt_nv[r] = 0, B.bt_aoff[r] = 0, B.bt_uoff[r] = 0; return; }
+	uint64_t *K = n_z <= BT_LDS_CAP ? lK : B.sort_key_out + ao;
+	uint32_t *I = n_z <= BT_LDS_CAP ? lI : (uint32_t *)(B.sort_val_out + ao);
+	int32_t *v = (int32_t *)(B.sort_val_in + ao);
+	uint64_t *u = B.sort_key_in + ao;
+	{
+		int32_t dst = 0;
+		for (int32_t base = 0; base < n; base += 64) {
+			const int32_t i = base + lane;
+			const bool keep = i < n && f[i] >= min_sc;
+			const unsigned long long m = __ballot(keep);
+			if (keep) { const int32_t d = dst + popc_below(m, lane); K[d] = (uint64_t)(uint32_t)f[i], I[d] = (uint32_t)i; }
+			dst += __popcll(m);
+		}
+	}
+	__threadfence_block();
+	__syncthreads();
+	// frames hold buckets of more than 64 elements, so at most n/65 per level; large inputs keep the stack in the upper half of u[]'s
+	// scratch region (u needs at most n/3 entries)
+	TieFrame *big_stack = (TieFrame *)(B.sort_key_in + ao + (size_t)n / 2);
+	const int big_cap = (int)(((size_t)n - (size_t)n / 2) * 8 / sizeof(TieFrame));
+	bt_sort(K, I, n_z, cnt, head, start, n_z <= BT_LDS_CAP ? stack : big_stack, n_z <= BT_LDS_CAP ? BT_STACK : big_cap, lane); // radix_sort_128x(z, z + n_z), lchain.c:41
+	__threadfence_block();
+	__syncthreads();
+	// ---- walk the ends best-first, claim anchors (lchain.c:57-72 with mg_chain_bk_end inlined) ----
+	if (lane == 0) {
+		int32_t n_v = 0, n_u = 0;
+		for (int32_t k = n_z - 1; k >= 0; --k) {
+			const int32_t zi = (int32_t)I[k], zx = (int32_t)K[k];
+			if (t[zi] != 0) continue;
+			// where the chain is cut: an anchor already claimed, or a score drop of more than max_drop below the running peak
+			int32_t i = zi, end_i = -1, max_i = zi, max_s = 0;
+			do {
+				t[i] = 2;
+				end_i = i = p[i];
+				const int32_t sc = i < 0 ? zx : zx - f[i];
+				if (sc > max_s) max_s = sc, max_i = i;
+				else if (max_s - sc > max_drop) break;
+			} while (i >= 0 && t[i] == 0);
+			for (i = zi; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
+			const int32_t n_v0 = n_v;
+			for (i = zi; i != max_i; i = p[i]) v[n_v++] = i, t[i] = 1;
+			const int32_t sc = i < 0 ? zx : zx - f[i];
+			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
+			else n_v = n_v0;
+		}
+		s_nu = n_u, s_nv = n_v;
+		s_aoff = n_v ? atomicAdd((unsigned long long *)&B.bt_cursor[0], (unsigned long long)n_v) : 0;
+		s_uoff = n_u ? atomicAdd((unsigned long long *)&B.bt_cursor[1], (unsigned long long)n_u) : 0;
+		B.bt_nu[r] = n_u, B.bt_nv[r] = n_v, B.bt_aoff[r] = s_aoff, B.bt_uoff[r] = s_uoff;
+	}
+	__threadfence_block();
+	__syncthreads();
+	const int32_t n_u = s_nu;
+	if (n_u == 0) return;
+	// ---- compact_a: chains in ascending anchor order, chains ordered by the reference position of their first anchor ----
+	uint32_t *cst = (uint32_t *)t; // start of each chain inside v[] (t[] is dead now)
+	if (lane == 0) { uint32_t k = 0; for (int32_t i = 0; i < n_u; ++i) { cst[i] = k; k += (uint32_t)u[i]; } }
+	__threadfence_block();
+	__syncthreads();
+	uint64_t *K2 = n_u <= BT_LDS_CAP ? lK : B.sort_key_out + ao;
+	uint32_t *I2 = n_u <= BT_LDS_CAP ? lI : (uint32_t *)(B.sort_val_out + ao);
+	for (int32_t i = lane; i < n_u; i += 64) { // w[i].x = b[k].x : first anchor of chain i after reversal = last entry of its v segment
+		const uint32_t ni = (uint32_t)u[i];
+		K2[i] = a[v[cst[i] + ni - 1]].x, I2[i] = (uint32_t)i;
+	}
+	__threadfence_block();
+	__syncthreads();
+	bt_sort(K2, I2, n_u, cnt, head, start, n_u <= BT_LDS_CAP ? stack : big_stack, n_u <= BT_LDS_CAP ? BT_STACK : big_cap, lane); // radix_sort_128x(w, w + n_u), lchain.c:99
+	__threadfence_block();
+	__syncthreads();
+	Anchor *oa = B.bt_out_a + s_aoff;
+	uint64_t *ou = B.bt_out_u + s_uoff;
+	uint32_t k = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const uint32_t j = I2[i], c = (uint32_t)u[j], s0 = cst[j];
+		if (lane == 0) ou[i] = u[j];
+		for (uint32_t q = lane; q < c; q += 64) oa[k + q] = a[v[s0 + (c - 1 - q)]];
+		k += c;
+	}
+}
+
+void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
+{
+	const int max_drop = P.is_cdna ? INT32_MAX : P.bw;
+	HIP_CHECK(hipMemsetAsync(B.bt_cursor, 0, 16, (hipStream_t)stream));
+	hipLaunchKernelGGL(chain_backtrack_kernel, dim3(B.n_reads), dim3(64), 0, (hipStream_t)stream, B, P.min_cnt, P.min_chain_score, max_drop);
+	HIP_CHECK(hipGetLastError());
 }
 
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)

@@ -38,6 +38,12 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	int rid_bits;             // bits needed for a reference sequence id in the composite key
 	uint64_t *mini_pos;
 	int32_t *f, *p, *t;       // chaining DP arrays, indexed like anchors
+	// chain backtrack results: dense outputs handed out by two atomic cursors ([0] anchors, [1] chains)
+	unsigned long long *bt_cursor;
+	Anchor *bt_out_a;         // compacted anchors of all chains, chain by chain, read by read (in completion order)
+	uint64_t *bt_out_u;       // score<<32 | n_anchors per chain
+	int32_t *bt_nu, *bt_nv;   // per read: chains, anchors
+	uint64_t *bt_aoff, *bt_uoff; // per read: where its results start in bt_out_a / bt_out_u
 };
 
 void launch_encode(const SeedChainBuffers &B, void *stream);
@@ -48,5 +54,6 @@ size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit);
 class KernelProfiler;
 void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream, KernelProfiler *kp);
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
+void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 
 } // namespace mm2amd

@@ -108,6 +108,7 @@ def test_aligner_equals_mm_map(kind, preset, n_reads, seed):
     for t in range(6):
         p0 = 20000 + 7000 * t
         rds.append(("dup%d" % t, refs[2][p0:p0 + 3000] + refs[2][p0 + 2000:p0 + 3000] * (1 + t % 3) + refs[2][p0 + 3000:p0 + 6000]))
+        rds.append(("sdup%d" % t, refs[1][p0:p0 + 2500] + refs[1][p0 + 2350:p0 + 2500] + refs[1][p0 + 2500:p0 + 5000]))  # few duplicated keys
     names = ["chr%d" % (i + 1) for i in range(3)]
     al = mm.Aligner(refs, preset=preset, names=names, n_threads=8)
     st = al.index_stat()
@@ -161,6 +162,36 @@ def test_repeat_rich_reference_ties_and_long_anchor_lists():
     refs = [synth.ACGT[contig].tobytes(), synth.ACGT[rng.integers(0, 4, 200000, dtype=np.uint8)].tobytes()]
     reads = synth.gen_reads(rng, [contig], 40, 6000, 2000, 0.08)
     rds = [("rep%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    al = mm.Aligner(refs, preset="map-ont", n_threads=8)
+    got = al.map_batch(rds)
+    al.close()
+    ref = reflib.RefMapper(refs, "map-ont")
+    want = [ref.map(nm, s) for nm, s in rds]
+    ref.close()
+    for i in range(len(rds)):
+        assert [a.key() for a in got[i]] == want[i], rds[i][0]
+
+
+def test_tandem_array_many_anchors_with_ties():
+    """reads across a tandem array of 8 near-identical copies: > 8192 anchors per read (the replay leaves LDS) and many equal keys"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(56)
+    elem = rng.integers(0, 4, 1500, dtype=np.uint8)
+    copies = []
+    for c in range(8):
+        e = elem.copy()
+        mut = rng.random(len(e)) < 0.01
+        e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+        copies.append(e)
+    contig = np.concatenate([rng.integers(0, 4, 30000, dtype=np.uint8)] + copies + [rng.integers(0, 4, 30000, dtype=np.uint8)])
+    refs = [synth.ACGT[contig].tobytes(), synth.ACGT[rng.integers(0, 4, 100000, dtype=np.uint8)].tobytes()]
+    rds = []
+    for i in range(12):
+        st = 24000 + 500 * i
+        r = synth.mutate_read(rng, contig[st:st + 16000 + 300 * i], 0.03)
+        if i % 2:
+            r = synth.COMP[r[::-1]]
+        rds.append(("arr%d" % i, synth.ACGT[r].tobytes()))
     al = mm.Aligner(refs, preset="map-ont", n_threads=8)
     got = al.map_batch(rds)
     al.close()
