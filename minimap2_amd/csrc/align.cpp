@@ -374,16 +374,16 @@ Aligner::Aligner(const MapOpt &opt, const FlatIndex &fi) : opt_(opt), fi_(fi)
 	if (bw_long_ < bw_) bw_long_ = bw_;
 }
 
-void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, std::vector<Anchor> &a, uint64_t qpool_off)
+void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_off)
 {
-	ra.qlen = qlen, ra.qpool_off = qpool_off, ra.a = &a;
+	ra.qlen = qlen, ra.qpool_off = qpool_off, ra.a = a;
 	ra.q4.resize((size_t)qlen * 2);
 	for (int i = 0; i < qlen; ++i) {
 		const uint8_t c = kNt4Table[(uint8_t)seq[i]];
 		ra.q4[i] = c;
 		ra.q4[2 * (size_t)qlen - 1 - i] = c < 4 ? 3 - c : 4;
 	}
-	ra.n_a = squeeze_anchors(regs, a.data());
+	ra.n_a = squeeze_anchors(regs, a);
 	ra.tasks.clear(); ra.order.clear();
 	ra.tasks.resize(regs.size());
 	for (size_t i = 0; i < regs.size(); ++i) {
@@ -418,7 +418,7 @@ static void anchor_boundary(const FlatIndex &fi, const uint8_t *q4, int qlen, co
 void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 {
 	Reg &r = t.r;
-	Anchor *a = ra.a->data();
+	Anchor *a = ra.a;
 	const int qlen = ra.qlen;
 	t.planned = true;
 	t.r2.cnt = 0;
@@ -588,7 +588,7 @@ bool Aligner::consume(ReadAlign &ra, const KswRes *res, const uint32_t *cigar_po
 
 bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool)
 {
-	Anchor *a = ra.a->data();
+	Anchor *a = ra.a;
 	const int qlen = ra.qlen;
 	{
 		RegionTask &t = ra.tasks[ti];

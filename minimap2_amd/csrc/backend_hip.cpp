@@ -18,6 +18,7 @@
 #include "index_build.hpp"
 #include "kernel_prof.hpp"
 #include "threads.hpp"
+#include "trace.hpp"
 
 namespace mm2amd {
 
@@ -68,6 +69,7 @@ public:
 			lanes_.back()->id = i;
 			HIP_CHECK(hipStreamCreateWithFlags(&lanes_.back()->stream, hipStreamNonBlocking));
 			lanes_.back()->ksw.n_cu = n_cu_;
+			lanes_.back()->ksw.disable_fast = getenv("MM2AMD_KSW_EXACT_ONLY") != nullptr;
 		}
 	}
 
@@ -106,6 +108,7 @@ public:
 		B = SeedChainBuffers();
 		B.n_reads = (int)n, B.seq_off = d_seq_off_.p + lo, B.ascii = d_ascii_.p, B.qpool = d_qpool_.p;
 		KernelProfiler &kp = kernel_profiler(lane_id);
+		double tt = Trace::now();
 		const double L = (double)(seq_off_[hi] - seq_off_[lo]);
 		kp.begin(st); launch_encode(B, st); kp.end(st, "encode_kernel", 3 * L);
 		// 1. minimizers, written from slot seq_off[r] of the minimizer arrays (at most one per base)
@@ -128,6 +131,7 @@ public:
 		HIP_CHECK(hipMemcpyAsync(h_nmp, ln.d_n_minipos.p, n * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_rep, ln.d_rep_len.p, n * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipStreamSynchronize(st));
+		Trace::get().add(lane_id, "gpu:sketch+collect", tt, Trace::now()); tt = Trace::now();
 		std::vector<uint64_t> &a_off = ln.a_off, &mp_off = ln.mp_off;
 		a_off.resize(n + 1), mp_off.resize(n + 1);
 		a_off[0] = mp_off[0] = 0;
@@ -170,19 +174,22 @@ public:
 		HIP_CHECK(hipMemcpyAsync(h_uoff, ln.d_bt_uoff.p, n * 8, hipMemcpyDeviceToHost, st));
 		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipStreamSynchronize(st));
+		Trace::get().add(lane_id, "gpu:expand..backtrack", tt, Trace::now()); tt = Trace::now();
 		const uint64_t n_v = h_cur[0], n_u = h_cur[1];
 		Anchor *ha = ln.h_anchors.ensure(n_v + 1);
 		uint64_t *hu = ln.h_u.ensure(n_u + 1);
 		if (n_v) HIP_CHECK(hipMemcpyAsync(ha, ln.d_bt_out_a.p, n_v * sizeof(Anchor), hipMemcpyDeviceToHost, st));
 		if (n_u) HIP_CHECK(hipMemcpyAsync(hu, ln.d_bt_out_u.p, n_u * 8, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipStreamSynchronize(st));
+		Trace::get().add(lane_id, "d2h:chains", tt, Trace::now()); tt = Trace::now();
 		kp.collect();
+		TraceScope ts(lane_id, "host:chains->vectors");
 		parallel_for(n_threads, (long)n, [&](long i, int) {
 			ReadChains &c = out[i];
 			c.rep_len = h_rep[i];
-			c.mini_pos.assign(hmp + mp_off[i], hmp + mp_off[i + 1]);
-			c.u.assign(hu + h_uoff[i], hu + h_uoff[i] + h_nu[i]);
-			c.a.assign(ha + h_aoff[i], ha + h_aoff[i] + h_nv[i]);
+			c.mp_p = hmp + mp_off[i], c.n_mp = (int32_t)(mp_off[i + 1] - mp_off[i]);
+			c.u_p = hu + h_uoff[i], c.n_u = h_nu[i];
+			c.a_p = ha + h_aoff[i], c.n_a = h_nv[i];
 		}, 64);
 	}
 
@@ -195,6 +202,7 @@ public:
 		ln.ksw.prof = &kernel_profiler(lane_id);
 		// the DP scratch (one direction-matrix slot per persistent wave) is the big per-lane allocation: split the budget
 		ln.ksw.dir_budget = ((size_t)12 << 30) / (size_t)n_lanes_;
+		ln.ksw.lane = lane_id;
 		ln.ksw.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id).collect();
 	}

@@ -86,6 +86,7 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 		const uint32_t *cig = nullptr;
 		size_t n_cig = 0;
 		d.ksw.prof = &kernel_profiler(0);
+		d.ksw.disable_fast = getenv("MM2AMD_KSW_EXACT_ONLY") != nullptr;
 		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), &cig, &n_cig, dc.stream);
 		kernel_profiler().collect();
 		if (n_cig > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");

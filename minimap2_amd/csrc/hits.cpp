@@ -59,9 +59,8 @@ void reg_set_coor(Reg &r, int32_t qlen, const Anchor *a, bool is_qstrand)
 	}
 }
 
-void gen_regs(uint32_t hash, int qlen, const std::vector<uint64_t> &u, const Anchor *a, bool is_qstrand, RegVec &out)
+void gen_regs(uint32_t hash, int qlen, const uint64_t *u, int n_u, const Anchor *a, bool is_qstrand, RegVec &out)
 {
-	const int n_u = (int)u.size();
 	out.clear();
 	if (n_u <= 0) return;
 	std::vector<Anchor> z(n_u);
@@ -363,12 +362,12 @@ inline int32_t fwd_qpos(int32_t qlen, const Anchor &a) // esterr.c:7-14
 }
 }
 
-void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const std::vector<uint64_t> &mini_pos)
+void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const uint64_t *mini_pos, int32_t n_mini_pos)
 {
-	const int32_t n = (int32_t)mini_pos.size();
+	const int32_t n = n_mini_pos;
 	if (n == 0) return;
 	uint64_t sum_k = 0;
-	for (uint64_t m : mini_pos) sum_k += m >> 32 & 0xff;
+	for (int32_t i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
 	const float avg_k = (float)sum_k / n;
 	for (Reg &r : regs) {
 		r.div = -1.0f;

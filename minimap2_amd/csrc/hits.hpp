@@ -11,7 +11,7 @@ using Reg = ref::Reg1;
 using RegVec = std::vector<Reg>;
 
 void reg_set_coor(Reg &r, int32_t qlen, const Anchor *a, bool is_qstrand);                         // hit.c:24-38
-void gen_regs(uint32_t hash, int qlen, const std::vector<uint64_t> &u, const Anchor *a, bool is_qstrand, RegVec &out); // hit.c:52-88
+void gen_regs(uint32_t hash, int qlen, const uint64_t *u, int n_u, const Anchor *a, bool is_qstrand, RegVec &out); // hit.c:52-88
 void split_reg(Reg &r, Reg &r2, int n, int qlen, const Anchor *a, bool is_qstrand);                // hit.c:106-123
 void set_parent(float mask_level, int mask_len, RegVec &r, int sub_diff, bool hard_mask_level, float alt_diff_frac); // hit.c:125-186
 void hit_sort(RegVec &r, float alt_diff_frac);                                                      // hit.c:188-218
@@ -22,7 +22,7 @@ void filter_strand_retained(RegVec &r);                                         
 void filter_regs(const ref::MapOpt &opt, int qlen, RegVec &r);                                      // hit.c:301-320
 int squeeze_anchors(RegVec &r, Anchor *a);                                                          // hit.c:322-340
 void set_mapq(RegVec &r, int min_chain_sc, int match_sc, int rep_len, bool is_sr, bool is_splice);  // hit.c:432-485
-void est_err(const FlatIndex &fi, int qlen, RegVec &r, const Anchor *a, const std::vector<uint64_t> &mini_pos); // esterr.c:30-64
+void est_err(const FlatIndex &fi, int qlen, RegVec &r, const Anchor *a, const uint64_t *mini_pos, int32_t n_mini_pos); // esterr.c:30-64
 void update_dp_max(int qlen, RegVec &r, float frac, int a, int b);                                  // align.c:1022-1046
 
 } // namespace mm2amd

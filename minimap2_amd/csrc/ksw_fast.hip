@@ -1,0 +1,191 @@
+// Register-resident gap-fill DP for gfx950: the device counterpart of ksw_extd2_sse (ksw2_extd2_sse.c:34-401) +
+// ksw_backtrack (ksw2.h:130-162) for the calls that make up >95 % of the DP cells of long-read mapping -- the global
+// alignments between adjacent anchors (align.c:810-842: flag KSW_EZ_APPROX_MAX, band 1.5*bw_long+1, i.e. never binding).
+//
+// Why a second kernel.  ksw_extd2.hip reproduces the reference lane by lane (16-aligned row blocks, stale lanes, mod-256
+// wrap) because a *binding* band lets valid cells read out-of-band garbage (hard part 1).  When the band
+// cannot bind (w >= qlen + tlen) the valid cells of anti-diagonal r are exactly t in [max(0,r-qlen+1), min(tlen-1,r)], their
+// neighbours are valid cells or the documented boundary values, and no 8-bit overflow occurs in valid cells (the scoring
+// constraints mm_check_opt enforces, options.c:246-255, exist to guarantee that).  Only valid cells matter, so the layout is
+// ours to choose:
+//
+//   * lane = target position: column t lives in lane t%64 of register set t/64 for the whole job, so the six difference
+//     states (u,v,x,y,x2,y2) never leave VGPRs; the t-1 neighbour comes from a DPP wave shift (lane 0 takes the last lane of
+//     the previous register set), the query base from a byte in LDS.  No LDS round trip, no barrier per row.
+//   * one wavefront per job, persistent waves pulling jobs from a queue; the only HBM traffic is the 1 B/cell direction
+//     byte (row-major, 64 B coalesced per active register set) and the sequential traceback over it.
+//
+// tests/test_gpu_ksw.py checks this kernel against the lane-exact oracle on every preset's scoring; jobs that are not
+// eligible (binding band, extension flags, exact-max mode, generic matrices, long sequences) take the exact kernel.
+#include <hip/hip_runtime.h>
+#include "hip_util.hpp"
+#include "ksw_dev.hpp"
+
+namespace mm2amd {
+
+constexpr int FAST_QCAP = 1024; // query bytes kept in LDS per wave
+
+__device__ __forceinline__ int dpp_shr1(int carry_in, int v) // lane i <- v[i-1], lane 0 <- carry_in
+{
+	return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+struct FastCig { uint32_t *c; int n; uint32_t last; };
+__device__ __forceinline__ void fast_cig_push(FastCig &g, uint32_t op, int len) // ksw_push_cigar (ksw2.h:114-124)
+{
+	if (g.n == 0 || op != (g.last & 0xf)) {
+		if (g.n > 0) g.c[g.n - 1] = g.last;
+		g.last = (uint32_t)len << 4 | op;
+		++g.n;
+	} else g.last += (uint32_t)len << 4;
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256) ksw_fast_kernel(KswLaunch L)
+{
+	__shared__ uint8_t s_q[4][FAST_QCAP];
+	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+	const int slot = blockIdx.x * 4 + wave_in_block;
+	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
+	uint8_t *qb = s_q[wave_in_block];
+	const int m = L.sc.m;
+	int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
+	const int qe_in = q + e; // before the swap (ksw2_extd2_sse.c:68 vs :78)
+	if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
+	const int qe = q + e, qe2 = q2 + e2, nqe = -qe, nqe2 = -qe2;
+	const int sc_mch = L.sc.mat[0], sc_mis = L.sc.mat[1];
+	const int sc_N = L.sc.mat[m * m - 1] == 0 ? -e2 : L.sc.mat[m * m - 1];
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+	for (;;) {
+		int jid = 0;
+		if (lane == 0) jid = atomicAdd(L.counter, 1);
+		jid = __builtin_amdgcn_readfirstlane(jid);
+		if (jid >= L.n_jobs) break;
+		const KswJob J = L.jobs[jid];
+		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag;
+		const int ncol = (tlen + 63) & ~63;
+		// ---- operands: query bytes to LDS, one target base per (register set, lane) ----
+		for (int i = lane; i < qlen; i += 64) qb[i] = L.qpool[(flag & KSWJ_Q_REVERSED) ? J.q_off - (uint64_t)i : J.q_off + (uint64_t)i];
+		int T[NC], U[NC], V[NC], X[NC], Y[NC], X2[NC], Y2[NC];
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int t = c * 64 + lane;
+			int b = 4;
+			if (t < tlen) {
+				const uint64_t pos = (flag & KSWJ_T_REVERSED) ? J.t_off - (uint64_t)t : J.t_off + (uint64_t)t;
+				b = (flag & KSWJ_T_PACKED) ? (int)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (int)L.tpool[pos];
+			}
+			T[c] = b;
+			U[c] = V[c] = X[c] = Y[c] = nqe, X2[c] = Y2[c] = nqe2; // ksw2_extd2_sse.c:111-116
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+
+		int H0 = 0, last_t = 0;
+		const int n_rows = qlen + tlen - 1;
+		for (int r = 0; r < n_rows; ++r) {
+			const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
+			// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163)
+			const int bnd = r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+			// carry-ins: row r-1 values of the column left of each register set
+			int cV[NC], cX[NC], cX2[NC];
+			cV[0] = bnd, cX[0] = nqe, cX2[0] = nqe2;
+#pragma unroll
+			for (int c = 1; c < NC; ++c) {
+				cV[c] = __builtin_amdgcn_readlane(V[c - 1], 63);
+				cX[c] = __builtin_amdgcn_readlane(X[c - 1], 63);
+				cX2[c] = __builtin_amdgcn_readlane(X2[c - 1], 63);
+			}
+			uint8_t *pr = dir + (size_t)r * ncol;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				if (c * 64 > en0 || c * 64 + 63 < st0) continue; // register set outside the anti-diagonal (uniform)
+				const int t = c * 64 + lane;
+				const bool act = t >= st0 && t <= en0;
+				const int vp = dpp_shr1(cV[c], V[c]), xp = dpp_shr1(cX[c], X[c]), x2p = dpp_shr1(cX2[c], X2[c]);
+				if (act) {
+					const bool edge = t == r; // u[r], y[r], y2[r] are border values on their first use (:156-163)
+					const int ut = edge ? bnd : U[c], yt = edge ? nqe : Y[c], y2t = edge ? nqe2 : Y2[c];
+					const int qv = qb[r - t], tv = T[c];
+					int z = (tv == m - 1 || qv == m - 1) ? sc_N : tv == qv ? sc_mch : sc_mis;
+					int a = xp + vp, b = yt + ut, a2 = x2p + vp, b2 = y2t + ut, d;
+					d = a > z ? 1 : 0;   z = z > a ? z : a;    // strictly greater wins (:235-243)
+					d = b > z ? 2 : d;   z = z > b ? z : b;
+					d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
+					d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
+					z = z < sc_mch ? z : sc_mch;
+					U[c] = z - vp, V[c] = z - ut;
+					int tmp = z - q;  a -= tmp, b -= tmp;
+					tmp = z - q2;     a2 -= tmp, b2 -= tmp;
+					X[c] = (a > 0 ? a : 0) - qe;      d |= a > 0 ? 0x08 : 0;
+					Y[c] = (b > 0 ? b : 0) - qe;      d |= b > 0 ? 0x10 : 0;
+					X2[c] = (a2 > 0 ? a2 : 0) - qe2;  d |= a2 > 0 ? 0x20 : 0;
+					Y2[c] = (b2 > 0 ? b2 : 0) - qe2;  d |= b2 > 0 ? 0x40 : 0;
+					pr[t] = (uint8_t)d;
+				}
+			}
+			// approximate score: follow one cell down the matrix (ksw2_extd2_sse.c:366-383)
+			if (r > 0) {
+				const bool in0 = last_t >= st0 && last_t <= en0, in1 = last_t + 1 >= st0 && last_t + 1 <= en0;
+				int d0 = 0, d1 = 0;
+#pragma unroll
+				for (int c = 0; c < NC; ++c) {
+					if ((last_t >> 6) == c) d0 = __builtin_amdgcn_readlane(V[c], last_t & 63);
+					if (((last_t + 1) >> 6) == c) d1 = __builtin_amdgcn_readlane(U[c], (last_t + 1) & 63);
+				}
+				if (in0 && in1) { if (d0 > d1) H0 += d0; else H0 += d1, ++last_t; }
+				else if (in0) H0 += d0;
+				else ++last_t, H0 += d1;
+			} else H0 = __builtin_amdgcn_readlane(V[0], 0) - qe_in, last_t = 0;
+		}
+		// ---- traceback from (tlen-1, qlen-1) (ksw2_extd2_sse.c:389-391; ksw_backtrack with every cell inside the matrix) ----
+		__threadfence_block();
+		FastCig g = { L.cigar_tmp + (size_t)slot * L.cigar_tmp_cap, 0, 0u };
+		uint32_t cig_off = 0;
+		if (lane == 0) {
+			int i = tlen - 1, j = qlen - 1, state = 0;
+			while (i >= 0 && j >= 0) {
+				const int tmp = dir[(size_t)(i + j) * ncol + i];
+				if (state == 0) state = tmp & 7;
+				else if (!(tmp >> (state + 2) & 1)) state = 0;
+				if (state == 0) state = tmp & 7;
+				if (state == 0) fast_cig_push(g, 0, 1), --i, --j;
+				else if (state == 1 || state == 3) fast_cig_push(g, 2, 1), --i;
+				else fast_cig_push(g, 1, 1), --j;
+			}
+			if (i >= 0) fast_cig_push(g, 2, i + 1);
+			if (j >= 0) fast_cig_push(g, 1, j + 1);
+			if (g.n > 0) g.c[g.n - 1] = g.last;
+			if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
+		}
+		const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
+		cig_off = __builtin_amdgcn_readfirstlane(cig_off);
+		__threadfence_block();
+		if (n_cig > 0) {
+			if ((unsigned long long)cig_off + (unsigned)n_cig > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
+			else for (int k = lane; k < n_cig; k += 64) L.cigar_pool[cig_off + k] = g.c[n_cig - 1 - k]; // forward order
+		}
+		if (lane == 0) {
+			KswRes R;
+			R.max = 0, R.zdropped = 0, R.max_q = R.max_t = -1, R.mqe = R.mte = KSW_NEG_INF, R.mqe_t = R.mte_q = -1;
+			R.score = H0, R.n_cigar = n_cig, R.reach_end = 0, R.cigar_off = cig_off;
+			L.res[jid] = R;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream)
+{
+	if (L.n_jobs <= 0) return;
+	const int n_blocks = (n_slots + 3) / 4;
+	if (n_sets <= 4) hipLaunchKernelGGL((ksw_fast_kernel<4>), dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, L);
+	else hipLaunchKernelGGL((ksw_fast_kernel<8>), dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, L);
+	HIP_CHECK(hipGetLastError());
+}
+
+} // namespace mm2amd

@@ -4,6 +4,7 @@
 #include "ksw_host.hpp"
 #include "kernel_prof.hpp"
 #include "threads.hpp"
+#include "trace.hpp"
 #include <atomic>
 #include <cmath>
 
@@ -11,10 +12,26 @@ namespace mm2amd {
 
 namespace {
 struct Tier { int max_dim; int waves_per_block; };
-// jobs whose 16-rounded max(qlen,tlen) is <= max_dim share a launch; LDS per wave = 13*T16 + Q16 + 16
-const Tier kTiers[] = { {512, 4}, {2048, 1}, {11264, 1} };
-constexpr int kMaxWavesPerCU = 20; // 81 VGPRs -> 5 waves/SIMD
+// Launch classes.  0,1: the register-resident gap-fill kernel (ksw_fast.hip) with 4 / 8 register sets (tlen <= 256 / 512);
+// 2..4: the lane-exact kernel (ksw_extd2.hip), jobs grouped by 16-rounded max(qlen,tlen) because its LDS need per wave is
+// 13*T16 + Q16 + 16.
+constexpr int kNTiers = 5, kFirstExact = 2;
+const Tier kTiers[kNTiers] = { {256, 4}, {512, 4}, {512, 4}, {2048, 1}, {11264, 1} };
+constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
+constexpr int kMaxWavesPerCU = 20;    // exact kernel: 81 VGPRs -> 5 waves/SIMD
+const int kFastBlocksPerCU[2] = { 5, 3 }; // 94 / 150 VGPRs -> 5 / 3 waves per SIMD
+
+// A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
+// score (the gap-fill call, align.c:838), default substitution scores, and a band that cannot bind.
+inline bool fast_eligible(const KswJob &j, bool scoring_ok)
+{
+	if (!scoring_ok || (j.flag & 0x1fff) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
+	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastQCap || j.tlen > 512) return false;
+	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
 }
+}
+
+void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_fast.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                     const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
@@ -22,18 +39,26 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	const size_t n = jobs.size();
 	*cigar_out = nullptr, *n_cigar_out = 0;
 	if (n == 0) return;
+	double tt = Trace::now();
 	// launch order: tier ascending, then cost (rows * row width) roughly descending (longest-job-first for the persistent
 	// waves).  An exact order is not needed, so a counting sort on sqrt(cost) does it in two parallel passes over the jobs.
 	constexpr int NB = 4096; // cost buckets per tier
+	int min_sc = sc.mat[1];
+	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
+	const bool scoring_ok = sc.m == 5 && !disable_fast && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
 	bucket.resize(n), perm.resize(n);
 	std::vector<size_t> sum_len_t((size_t)n_threads + 1, 0);
 	std::atomic<bool> too_big(false);
 	parallel_for(n_threads, (long)n, [&](long i, int tid) {
 		const KswJob &j = jobs[i];
-		int dim = std::max(r16(j.qlen), r16(j.tlen)), tier = 0;
-		while (tier < 3 && dim > kTiers[tier].max_dim) ++tier;
-		if (tier == 3) { too_big = true; tier = 2; }
+		int dim = std::max(r16(j.qlen), r16(j.tlen)), tier;
+		if (fast_eligible(j, scoring_ok)) tier = j.tlen <= 256 ? 0 : 1;
+		else {
+			tier = kFirstExact;
+			while (tier < kNTiers && dim > kTiers[tier].max_dim) ++tier;
+			if (tier == kNTiers) { too_big = true; tier = kNTiers - 1; }
+		}
 		const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 ? INT32_MAX : j.w + 1);
 		int cb = (int)std::sqrt(cost);
 		if (cb >= NB) cb = NB - 1;
@@ -43,14 +68,16 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	if (too_big) throw std::runtime_error("[mm2amd] ksw job larger than the LDS-resident kernel supports (qlen/tlen > 11264)");
 	size_t sum_len = 0;
 	for (size_t v : sum_len_t) sum_len += v;
-	std::vector<uint32_t> start(3 * NB + 1, 0);
+	std::vector<uint32_t> start(kNTiers * NB + 1, 0);
 	for (size_t i = 0; i < n; ++i) ++start[bucket[i] + 1];
-	for (int k = 0; k < 3 * NB; ++k) start[k + 1] += start[k];
-	size_t tier_beg[4] = { start[0], start[NB], start[2 * NB], start[3 * NB] };
+	for (int k = 0; k < kNTiers * NB; ++k) start[k + 1] += start[k];
+	size_t tier_beg[kNTiers + 1];
+	for (int t = 0; t <= kNTiers; ++t) tier_beg[t] = start[(size_t)t * NB];
 	for (size_t i = 0; i < n; ++i) perm[i] = start[bucket[i]]++; // perm[i] = launch position of job i (stable within a bucket)
 	KswJob *sj = sorted.ensure(n);
 	parallel_for(n_threads, (long)n, [&](long i, int) { sj[perm[i]] = jobs[i]; }, 4096);
 
+	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_jobs.ensure(n);
 	d_res.ensure(n);
 	d_counter.ensure(8);
@@ -65,52 +92,68 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		d_cigar.ensure(pool_cap);
 		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 8 * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
-		for (int tier = 0; tier < 3; ++tier) {
-			const size_t beg = tier_beg[tier], end = tier_beg[tier + 1];
-			if (end == beg) continue;
-			int max_T16 = 16, max_Q16 = 16;
-			size_t slot_bytes = 16, tmp_cap = 16;
-			double alg_bytes = 0; // query bytes + packed target + result record; the 1 B/cell direction matrix only
-			                      // counts when it cannot stay on chip (> 160 KB of LDS); CIGAR bytes are added after the launch
-			for (size_t i = beg; i < end; ++i) {
+		// size every launch class first (one scratch allocation serves them all: the launches run back to back on one stream)
+		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
+		Plan plan[kNTiers];
+		size_t need_dir = 16, need_tmp = 16;
+		for (int tier = 0; tier < kNTiers; ++tier) {
+			Plan &P = plan[tier];
+			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
+			if (P.end == P.beg) continue;
+			const bool fast = tier < kFirstExact;
+			// query bytes + packed target + result record; the 1 B/cell direction matrix only counts when it cannot
+			// stay on chip (> 160 KB of LDS)
+			for (size_t i = P.beg; i < P.end; ++i) {
 				const KswJob &j = sj[i];
-				alg_bytes += sizeof(KswJob) + sizeof(KswRes);
+				P.alg_bytes += sizeof(KswJob) + sizeof(KswRes);
 				if ((j.flag & KSWJ_SKIP) || j.qlen <= 0 || j.tlen <= 0) continue;
-				alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
-				if (!(j.flag & KSW_SCORE_ONLY)) { const size_t db = ksw_dir_bytes(j.qlen, j.tlen, j.w); if (db > 160 * 1024) alg_bytes += (double)db; }
-				max_T16 = std::max(max_T16, r16(j.tlen)), max_Q16 = std::max(max_Q16, r16(j.qlen));
+				P.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
+				const size_t db = fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, j.w);
+				if (!(j.flag & KSW_SCORE_ONLY)) { if (db > 160 * 1024) P.alg_bytes += (double)db; }
+				P.max_T16 = std::max(P.max_T16, r16(j.tlen)), P.max_Q16 = std::max(P.max_Q16, r16(j.qlen));
 				if (!(j.flag & KSW_SCORE_ONLY)) {
-					slot_bytes = std::max(slot_bytes, ksw_dir_bytes(j.qlen, j.tlen, j.w));
-					tmp_cap = std::max(tmp_cap, (size_t)j.qlen + j.tlen);
+					P.slot_bytes = std::max(P.slot_bytes, db);
+					P.tmp_cap = std::max(P.tmp_cap, (size_t)j.qlen + j.tlen);
 				}
 			}
-			slot_bytes = (slot_bytes + 255) / 256 * 256;
+			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			const int wpb = kTiers[tier].waves_per_block;
-			const size_t region = (ksw_lds_per_wave(max_T16, max_Q16) + 15) / 16 * 16;
-			int blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
+			int blocks_per_cu;
+			if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
+			else {
+				const size_t region = (ksw_lds_per_wave(P.max_T16, P.max_Q16) + 15) / 16 * 16;
+				blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
+			}
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
-			size_t n_slots = std::min<size_t>(end - beg, (size_t)n_cu * blocks_per_cu * wpb);
-			n_slots = std::min<size_t>(n_slots, std::max<size_t>(1, dir_budget / slot_bytes));
-			n_slots = (n_slots + wpb - 1) / wpb * wpb;
-			d_dir.ensure(n_slots * slot_bytes, 1.0);
-			d_cigar_tmp.ensure(n_slots * tmp_cap, 1.0);
-
+			P.n_slots = std::min<size_t>(P.end - P.beg, (size_t)n_cu * blocks_per_cu * wpb);
+			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / P.slot_bytes));
+			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
+			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap);
+		}
+		d_dir.ensure(need_dir, 1.0);
+		d_cigar_tmp.ensure(need_tmp, 1.0);
+		static const char *kNames[kNTiers] = { "ksw_fast_kernel<4>", "ksw_fast_kernel<8>", "ksw_extd2_kernel[t0]", "ksw_extd2_kernel[t1]", "ksw_extd2_kernel[t2]" };
+		for (int tier = 0; tier < kNTiers; ++tier) {
+			const Plan &P = plan[tier];
+			if (P.end == P.beg) continue;
 			KswLaunch L;
-			L.jobs = d_jobs.p + beg, L.res = d_res.p + beg, L.n_jobs = (int32_t)(end - beg);
+			L.jobs = d_jobs.p + P.beg, L.res = d_res.p + P.beg, L.n_jobs = (int32_t)(P.end - P.beg);
 			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
 			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
-			L.cigar_tmp = d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)tmp_cap;
-			L.dir_pool = d_dir.p, L.slot_bytes = slot_bytes;
+			L.cigar_tmp = d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap;
+			L.dir_pool = d_dir.p, L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
-			L.max_T16 = max_T16, L.max_Q16 = max_Q16, L.sc = sc;
+			L.max_T16 = P.max_T16, L.max_Q16 = P.max_Q16, L.sc = sc;
 			if (prof) prof->begin(stream);
-			ksw_extd2_launch(L, (int)n_slots, wpb, stream);
-			if (prof) prof->end(stream, tier == 0 ? "ksw_extd2_kernel[t0]" : tier == 1 ? "ksw_extd2_kernel[t1]" : "ksw_extd2_kernel[t2]", alg_bytes);
+			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, tier == 0 ? 4 : 8, stream);
+			else ksw_extd2_launch(L, (int)P.n_slots, kTiers[tier].waves_per_block, stream);
+			if (prof) prof->end(stream, kNames[tier], P.alg_bytes);
 		}
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
+		Trace::get().add(lane, "gpu:ksw", tt, Trace::now()); tt = Trace::now();
 		if (cursor[1] == 0) {
 			uint32_t *hc = cigar_host.ensure((size_t)cursor[0] + 1);
 			if (cursor[0]) {
@@ -118,12 +161,14 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 				HIP_CHECK(hipStreamSynchronize(stream));
 			}
 			*cigar_out = hc, *n_cigar_out = cursor[0];
+			Trace::get().add(lane, "d2h:cigar", tt, Trace::now()); tt = Trace::now();
 			break;
 		}
 		if (attempt > 0) throw std::runtime_error("[mm2amd] CIGAR pool overflow even at worst-case size");
 		pool_cap = sum_len + 16;
 	}
 	parallel_for(n_threads, (long)n, [&](long i, int) { res[i] = tr[perm[i]]; }, 4096);
+	Trace::get().add(lane, "host:ksw-unperm", tt, Trace::now());
 }
 
 } // namespace mm2amd

@@ -5,6 +5,7 @@
 #include "mapper.hpp"
 #include "chain_host.hpp"
 #include "threads.hpp"
+#include "trace.hpp"
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -122,6 +123,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	for (int l = 1; l < n_drivers; ++l) th.emplace_back(driver, l);
 	driver(0);
 	for (auto &t : th) t.join();
+	Trace::get().flush();
 	if (first_err) std::rethrow_exception(first_err);
 	(void)t0;
 }
@@ -147,30 +149,32 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			const int qlen = live[lo + i].len;
 			ReadResult &res = out[live_id[lo + i]];
 			const uint32_t hash = read_hash(live[lo + i].name, qlen, opt_);
-			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && c.u.size() > 1) { // long-join re-chaining (map.c:283-292)
-				const int32_t st = (int32_t)c.a[0].y, en = (int32_t)c.a[(int32_t)c.u[0] - 1].y;
+			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && c.n_u > 1) { // long-join re-chaining (map.c:283-292)
+				const int32_t st = (int32_t)c.a_p[0].y, en = (int32_t)c.a_p[(int32_t)c.u_p[0] - 1].y;
 				if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {
 					ChainScratch sc;
-					std::vector<Anchor> a2(c.a);
+					std::vector<Anchor> a2(c.a_p, c.a_p + c.n_a);
 					sort_by_x(a2.data(), a2.data() + a2.size());
 					std::vector<uint64_t> u2;
 					std::vector<Anchor> out_a;
 					chain_rmq(opt_.max_gap, opt_.rmq_inner_dist, opt_.bw_long, opt_.max_chain_skip, opt_.rmq_size_cap, opt_.min_cnt, opt_.min_chain_score,
 					          sp.chn_pen_gap, sp.chn_pen_skip, (int64_t)a2.size(), a2.data(), u2, out_a, sc);
 					c.u.swap(u2), c.a.swap(out_a);
+					c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
 				}
 			}
 			res.frag_gap = sp.max_gap_ref, res.rep_len = c.rep_len;
 			RegVec &r0 = regs0[i];
-			gen_regs(hash, qlen, c.u, c.a.data(), false, r0);
+			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, false, r0);
 			if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
 				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
 				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
 			}
-			est_err(fi_, qlen, r0, c.a.data(), c.mini_pos);
+			est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 			filter_strand_retained(r0);
-			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a, qoff[lo + i]);
+			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i]);
 		});
+		Trace::get().add(lane, "host:pre", t0, now());
 		stats.t_host_pre += now() - t0;
 
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
@@ -197,6 +201,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
 			}, 256);
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
+			Trace::get().add(lane, "host:plan", t0, now());
 			stats.t_plan += now() - t0; t0 = now();
 			be_.ksw(jobs, sc, lane, n_threads_, kres, &cigars);
 			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
@@ -204,6 +209,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			parallel_for(n_threads_, m, [&](long i, int tid) {
 				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
+			Trace::get().add(lane, "host:consume", t0, now());
 			stats.t_consume += now() - t0;
 			if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");
 		}
@@ -220,6 +226,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, false);
 		});
+		Trace::get().add(lane, "host:finish", t0, now());
 		stats.t_finish += now() - t0;
 	}
 }

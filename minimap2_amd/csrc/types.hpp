@@ -31,6 +31,13 @@ struct ReadView {
 
 // What seeding + chaining produces for one read (the state of mm_map_frag_core after map.c:316).
 struct ReadChains {
+	// Views of the results; they point either into the owned vectors below (view_own()) or into backend-owned buffers that
+	// stay valid until the backend lane is used for the next sub-batch.  The anchors are modified in place by the aligner.
+	const uint64_t *u_p = nullptr, *mp_p = nullptr;
+	Anchor *a_p = nullptr;
+	int32_t n_u = 0, n_mp = 0;
+	int64_t n_a = 0;
+	void view_own() { u_p = u.data(), n_u = (int32_t)u.size(), a_p = a.data(), n_a = (int64_t)a.size(), mp_p = mini_pos.data(), n_mp = (int32_t)mini_pos.size(); }
 	std::vector<uint64_t> u;        // per chain: score<<32 | n_anchors
 	std::vector<Anchor> a;          // anchors of all chains, chain by chain
 	std::vector<uint64_t> mini_pos; // q_span<<32 | q_pos of every minimizer that was looked up and kept (seed.c:124)

@@ -62,6 +62,7 @@ public:
 			c.u.resize(n_u);
 			c.a.resize(n_kept);
 			if (n_kept) memcpy(c.a.data(), a, n_kept * sizeof(ora128_t));
+			c.view_own();
 			free(a); free(mp);
 		}
 	}

@@ -83,3 +83,45 @@ def test_degenerate_jobs():
     import minimap2_amd as mm
     got = mm.ksw_extd2_batch([(z, one, 10, 400, -1, 0)], ts_mat(2, 4), 4, 2, 24, 1)
     assert got[0][0] == 0 and got[0][10] == ()
+
+
+@pytest.mark.parametrize("preset", list(PRESETS))
+def test_register_resident_gap_fill_kernel(preset):
+    """jobs that take ksw_fast.hip (flag 0x08, non-binding band): every register-set boundary, N bases, long indels, unrelated
+    sequences, extreme aspect ratios -- against the lane-exact oracle, and A/B against the exact HIP kernel"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(77)
+    jobs = []
+    for tl in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 383, 384, 385, 447, 448, 449, 511, 512):
+        for rep in range(3):
+            t = rng.integers(0, 4, tl, dtype=np.uint8)
+            if rep == 0:
+                q = t.copy()
+            elif rep == 1:
+                q, _ = random_pair(rng, tl, 0.15, 0.02)
+                q = q[:1024]
+            else:
+                q = rng.integers(0, 4, int(rng.integers(1, 1025)), dtype=np.uint8)  # unrelated, any aspect ratio
+            jobs.append((q, t, 30001, int(rng.choice([-1, 200, 400])), int(rng.choice([-1, 10])), 0x08))
+    for it in range(300):
+        q, t = random_pair(rng, int(rng.integers(1, 512)), float(rng.choice([0.0, 0.05, 0.12, 0.3, 0.6])), float(rng.choice([0, 0, 0.03])),
+                           int(rng.choice([0, 0, 0, 40, -40, 200, -200])))
+        if len(q) > 1024 or len(t) > 512:
+            continue
+        w = int(rng.choice([30001, len(q) + len(t), len(q) + len(t) + 5, -1]))
+        jobs.append((q, t, w, 400, -1, 0x08))
+    # not eligible (band could bind / other flags): must still be exact
+    for it in range(40):
+        q, t = random_pair(rng, int(rng.integers(50, 400)), 0.12)
+        jobs.append((q, t, len(q) + len(t) - 1, 400, -1, 0x08))
+        jobs.append((q, t, 30001, 400, -1, 0x18))
+    _run(jobs, preset)
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    mat = ts_mat(a, b, 1, 0)
+    fast = mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+    os.environ["MM2AMD_KSW_EXACT_ONLY"] = "1"
+    try:
+        exact = mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+    finally:
+        del os.environ["MM2AMD_KSW_EXACT_ONLY"]
+    assert fast == exact
