@@ -40,8 +40,9 @@ __device__ __forceinline__ void fast_cig_push(FastCig &g, uint32_t op, int len) 
 	} else g.last += (uint32_t)len << 4;
 }
 
+// second launch bound = waves per SIMD to compile for: 5 (<= 96 VGPRs) up to 4 register sets, 4 (<= 128) for 5-6, 3 for 8
 template <int NC>
-__global__ void __launch_bounds__(256) ksw_fast_kernel(KswLaunch L)
+__global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast_kernel(KswLaunch L)
 {
 	__shared__ uint8_t s_q[4][FAST_QCAP];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
@@ -84,28 +85,31 @@ __global__ void __launch_bounds__(256) ksw_fast_kernel(KswLaunch L)
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 
-		int H0 = 0, last_t = 0;
+		// H[c] accumulates the true score of each column's current cell from the difference values: a column's first cell takes
+		// its left neighbour's previous score plus u, every later cell adds v.  The reference's approximate-score walk
+		// (ksw2_extd2_sse.c:366-383) sums the same exact differences along one particular path and, without KSW_EZ_APPROX_DROP,
+		// only its end point H(tlen-1, qlen-1) is reported -- which is path-independent.
+		int H[NC];
+#pragma unroll
+		for (int c = 0; c < NC; ++c) H[c] = 0;
 		const int n_rows = qlen + tlen - 1;
 		for (int r = 0; r < n_rows; ++r) {
 			const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
 			// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163)
 			const int bnd = r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-			// carry-ins: row r-1 values of the column left of each register set
-			int cV[NC], cX[NC], cX2[NC];
-			cV[0] = bnd, cX[0] = nqe, cX2[0] = nqe2;
-#pragma unroll
-			for (int c = 1; c < NC; ++c) {
-				cV[c] = __builtin_amdgcn_readlane(V[c - 1], 63);
-				cX[c] = __builtin_amdgcn_readlane(X[c - 1], 63);
-				cX2[c] = __builtin_amdgcn_readlane(X2[c - 1], 63);
-			}
 			uint8_t *pr = dir + (size_t)r * ncol;
+			// register sets from the highest down, so that set c still sees row r-1 in set c-1 when it fetches its carry-ins
 #pragma unroll
-			for (int c = 0; c < NC; ++c) {
+			for (int c = NC - 1; c >= 0; --c) {
 				if (c * 64 > en0 || c * 64 + 63 < st0) continue; // register set outside the anti-diagonal (uniform)
 				const int t = c * 64 + lane;
 				const bool act = t >= st0 && t <= en0;
-				const int vp = dpp_shr1(cV[c], V[c]), xp = dpp_shr1(cX[c], X[c]), x2p = dpp_shr1(cX2[c], X2[c]);
+				int cV = bnd, cX = nqe, cX2 = nqe2, cH = -qe_in; // column -1: the matrix border; H(-1,-1) makes H(0,0) = v - (q+e)
+				if (c > 0) {
+					cV = __builtin_amdgcn_readlane(V[c - 1], 63), cX = __builtin_amdgcn_readlane(X[c - 1], 63);
+					cX2 = __builtin_amdgcn_readlane(X2[c - 1], 63), cH = __builtin_amdgcn_readlane(H[c - 1], 63);
+				}
+				const int vp = dpp_shr1(cV, V[c]), xp = dpp_shr1(cX, X[c]), x2p = dpp_shr1(cX2, X2[c]), hp = dpp_shr1(cH, H[c]);
 				if (act) {
 					const bool edge = t == r; // u[r], y[r], y2[r] are border values on their first use (:156-163)
 					const int ut = edge ? bnd : U[c], yt = edge ? nqe : Y[c], y2t = edge ? nqe2 : Y2[c];
@@ -117,7 +121,11 @@ __global__ void __launch_bounds__(256) ksw_fast_kernel(KswLaunch L)
 					d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
 					d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
 					z = z < sc_mch ? z : sc_mch;
-					U[c] = z - vp, V[c] = z - ut;
+					const int un = z - vp, vn = z - ut;
+					U[c] = un, V[c] = vn;
+					// first cell of a column: from the left neighbour's previous cell by u (for r = 0 the border makes this v - (q+e));
+					// afterwards straight down the column by v
+					H[c] = edge ? (r == 0 ? vn - qe_in : hp + un) : H[c] + vn;
 					int tmp = z - q;  a -= tmp, b -= tmp;
 					tmp = z - q2;     a2 -= tmp, b2 -= tmp;
 					X[c] = (a > 0 ? a : 0) - qe;      d |= a > 0 ? 0x08 : 0;
@@ -127,20 +135,10 @@ __global__ void __launch_bounds__(256) ksw_fast_kernel(KswLaunch L)
 					pr[t] = (uint8_t)d;
 				}
 			}
-			// approximate score: follow one cell down the matrix (ksw2_extd2_sse.c:366-383)
-			if (r > 0) {
-				const bool in0 = last_t >= st0 && last_t <= en0, in1 = last_t + 1 >= st0 && last_t + 1 <= en0;
-				int d0 = 0, d1 = 0;
-#pragma unroll
-				for (int c = 0; c < NC; ++c) {
-					if ((last_t >> 6) == c) d0 = __builtin_amdgcn_readlane(V[c], last_t & 63);
-					if (((last_t + 1) >> 6) == c) d1 = __builtin_amdgcn_readlane(U[c], (last_t + 1) & 63);
-				}
-				if (in0 && in1) { if (d0 > d1) H0 += d0; else H0 += d1, ++last_t; }
-				else if (in0) H0 += d0;
-				else ++last_t, H0 += d1;
-			} else H0 = __builtin_amdgcn_readlane(V[0], 0) - qe_in, last_t = 0;
 		}
+		int H0 = 0; // H(tlen-1, qlen-1)
+#pragma unroll
+		for (int c = 0; c < NC; ++c) if (((tlen - 1) >> 6) == c) H0 = __builtin_amdgcn_readlane(H[c], (tlen - 1) & 63);
 		// ---- traceback from (tlen-1, qlen-1) (ksw2_extd2_sse.c:389-391; ksw_backtrack with every cell inside the matrix) ----
 		__threadfence_block();
 		FastCig g = { L.cigar_tmp + (size_t)slot * L.cigar_tmp_cap, 0, 0u };
@@ -183,8 +181,16 @@ void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream)
 {
 	if (L.n_jobs <= 0) return;
 	const int n_blocks = (n_slots + 3) / 4;
-	if (n_sets <= 4) hipLaunchKernelGGL((ksw_fast_kernel<4>), dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, L);
-	else hipLaunchKernelGGL((ksw_fast_kernel<8>), dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, L);
+	hipStream_t s = (hipStream_t)stream;
+	switch (n_sets) {
+	case 2: hipLaunchKernelGGL((ksw_fast_kernel<2>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 3: hipLaunchKernelGGL((ksw_fast_kernel<3>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 4: hipLaunchKernelGGL((ksw_fast_kernel<4>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 5: hipLaunchKernelGGL((ksw_fast_kernel<5>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 6: hipLaunchKernelGGL((ksw_fast_kernel<6>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 8: hipLaunchKernelGGL((ksw_fast_kernel<8>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	default: throw std::runtime_error("[mm2amd] ksw_fast_launch: unsupported register-set count");
+	}
 	HIP_CHECK(hipGetLastError());
 }
 

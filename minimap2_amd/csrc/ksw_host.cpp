@@ -12,14 +12,16 @@ namespace mm2amd {
 
 namespace {
 struct Tier { int max_dim; int waves_per_block; };
-// Launch classes.  0,1: the register-resident gap-fill kernel (ksw_fast.hip) with 4 / 8 register sets (tlen <= 256 / 512);
-// 2..4: the lane-exact kernel (ksw_extd2.hip), jobs grouped by 16-rounded max(qlen,tlen) because its LDS need per wave is
+// Launch classes.  0..5: the register-resident gap-fill kernel (ksw_fast.hip) with 2,3,4,5,6,8 register sets of 64 target
+// columns (its VGPR need, hence its occupancy, grows with the set count, so jobs run with the fewest sets that hold them);
+// 6..8: the lane-exact kernel (ksw_extd2.hip), jobs grouped by 16-rounded max(qlen,tlen) because its LDS need per wave is
 // 13*T16 + Q16 + 16.
-constexpr int kNTiers = 5, kFirstExact = 2;
-const Tier kTiers[kNTiers] = { {256, 4}, {512, 4}, {512, 4}, {2048, 1}, {11264, 1} };
+constexpr int kNTiers = 9, kFirstExact = 6;
+const Tier kTiers[kNTiers] = { {128, 4}, {192, 4}, {256, 4}, {320, 4}, {384, 4}, {512, 4}, {512, 4}, {2048, 1}, {11264, 1} };
+const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
 constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: 81 VGPRs -> 5 waves/SIMD
-const int kFastBlocksPerCU[2] = { 5, 3 }; // 94 / 150 VGPRs -> 5 / 3 waves per SIMD
+const int kFastBlocksPerCU[kFirstExact] = { 5, 5, 5, 4, 4, 3 } /* waves per SIMD the kernels are compiled for */;
 
 // A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
 // score (the gap-fill call, align.c:838), default substitution scores, and a band that cannot bind.
@@ -41,46 +43,89 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	if (n == 0) return;
 	double tt = Trace::now();
 	// launch order: tier ascending, then cost (rows * row width) roughly descending (longest-job-first for the persistent
-	// waves).  An exact order is not needed, so a counting sort on sqrt(cost) does it in two parallel passes over the jobs.
-	constexpr int NB = 4096; // cost buckets per tier
+	// waves).  An exact order is not needed, so a counting sort on sqrt(cost) does it: jobs are cut into chunks, each chunk is
+	// classified and histogrammed by one pool thread (which also gathers the per-class sizing figures), a short serial prefix
+	// turns the histograms into stable scatter offsets, and the chunks scatter in parallel.
+	constexpr int NB = 1024; // cost buckets per tier
+	constexpr size_t NBINS = (size_t)kNTiers * NB, CH = 16384;
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool scoring_ok = sc.m == 5 && !disable_fast && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
+	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
+	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
+	const size_t n_chunks = (n + CH - 1) / CH;
 	bucket.resize(n), perm.resize(n);
-	std::vector<size_t> sum_len_t((size_t)n_threads + 1, 0);
-	std::atomic<bool> too_big(false);
-	parallel_for(n_threads, (long)n, [&](long i, int tid) {
-		const KswJob &j = jobs[i];
-		int dim = std::max(r16(j.qlen), r16(j.tlen)), tier;
-		if (fast_eligible(j, scoring_ok)) tier = j.tlen <= 256 ? 0 : 1;
-		else {
-			tier = kFirstExact;
-			while (tier < kNTiers && dim > kTiers[tier].max_dim) ++tier;
-			if (tier == kNTiers) { too_big = true; tier = kNTiers - 1; }
+	chunk_hist.assign(n_chunks * NBINS, 0);
+	std::vector<ChunkStat> cstat(n_chunks);
+	parallel_for(n_threads, (long)n_chunks, [&](long c, int) {
+		ChunkStat st;
+		uint32_t *hist = &chunk_hist[(size_t)c * NBINS];
+		const size_t e = std::min(n, ((size_t)c + 1) * CH);
+		for (size_t i = (size_t)c * CH; i < e; ++i) {
+			const KswJob &j = jobs[i];
+			const int dim = std::max(r16(j.qlen), r16(j.tlen));
+			int tier;
+			const bool fast = fast_eligible(j, scoring_ok);
+			if (fast) { tier = 0; while (j.tlen > kTiers[tier].max_dim) ++tier; }
+			else {
+				tier = kFirstExact;
+				while (tier < kNTiers && dim > kTiers[tier].max_dim) ++tier;
+				if (tier == kNTiers) { st.too_big = true; tier = kNTiers - 1; }
+			}
+			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 ? INT32_MAX : j.w + 1);
+			int cb = (int)(std::sqrt(cost) * (fast ? 1.0 : 0.25)); // fast classes: cost <= 1536*512; exact classes reach 11264*752
+			if (cb >= NB) cb = NB - 1;
+			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
+			bucket[i] = bk;
+			++hist[bk];
+			// sizing and accounting for the class (query bytes + packed target + job/result records; the 1 B/cell
+			// direction matrix only counts when it cannot stay on chip, i.e. exceeds 160 KB of LDS)
+			ClassStat &cs = st.cls[tier];
+			cs.alg_bytes += sizeof(KswJob) + sizeof(KswRes);
+			if ((j.flag & KSWJ_SKIP) || j.qlen <= 0 || j.tlen <= 0) continue;
+			cs.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
+			cs.max_T16 = std::max(cs.max_T16, r16(j.tlen)), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
+			if (!(j.flag & KSW_SCORE_ONLY)) {
+				const size_t db = fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, j.w);
+				if (db > 160 * 1024) cs.alg_bytes += (double)db;
+				cs.slot_bytes = std::max(cs.slot_bytes, db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
+				st.sum_len += (size_t)j.qlen + j.tlen;
+			}
 		}
-		const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 ? INT32_MAX : j.w + 1);
-		int cb = (int)std::sqrt(cost);
-		if (cb >= NB) cb = NB - 1;
-		bucket[i] = (uint32_t)(tier * NB + (NB - 1 - cb));
-		if (!(j.flag & (KSWJ_SKIP | KSW_SCORE_ONLY)) && j.qlen > 0 && j.tlen > 0) sum_len_t[tid] += (size_t)j.qlen + j.tlen;
-	}, 4096);
-	if (too_big) throw std::runtime_error("[mm2amd] ksw job larger than the LDS-resident kernel supports (qlen/tlen > 11264)");
+		cstat[c] = st;
+	}, 1);
 	size_t sum_len = 0;
-	for (size_t v : sum_len_t) sum_len += v;
-	std::vector<uint32_t> start(kNTiers * NB + 1, 0);
-	for (size_t i = 0; i < n; ++i) ++start[bucket[i] + 1];
-	for (int k = 0; k < kNTiers * NB; ++k) start[k + 1] += start[k];
+	ClassStat cls[kNTiers];
+	for (const ChunkStat &st : cstat) {
+		if (st.too_big) throw std::runtime_error("[mm2amd] ksw job larger than the LDS-resident kernel supports (qlen/tlen > 11264)");
+		sum_len += st.sum_len;
+		for (int t = 0; t < kNTiers; ++t) {
+			cls[t].alg_bytes += st.cls[t].alg_bytes;
+			cls[t].slot_bytes = std::max(cls[t].slot_bytes, st.cls[t].slot_bytes), cls[t].tmp_cap = std::max(cls[t].tmp_cap, st.cls[t].tmp_cap);
+			cls[t].max_T16 = std::max(cls[t].max_T16, st.cls[t].max_T16), cls[t].max_Q16 = std::max(cls[t].max_Q16, st.cls[t].max_Q16);
+		}
+	}
 	size_t tier_beg[kNTiers + 1];
-	for (int t = 0; t <= kNTiers; ++t) tier_beg[t] = start[(size_t)t * NB];
-	for (size_t i = 0; i < n; ++i) perm[i] = start[bucket[i]]++; // perm[i] = launch position of job i (stable within a bucket)
+	{
+		uint32_t acc = 0;
+		for (size_t b = 0; b < NBINS; ++b) {
+			if (b % NB == 0) tier_beg[b / NB] = acc;
+			for (size_t c = 0; c < n_chunks; ++c) { uint32_t &h = chunk_hist[c * NBINS + b]; const uint32_t v = h; h = acc; acc += v; }
+		}
+		tier_beg[kNTiers] = acc;
+	}
 	KswJob *sj = sorted.ensure(n);
-	parallel_for(n_threads, (long)n, [&](long i, int) { sj[perm[i]] = jobs[i]; }, 4096);
+	parallel_for(n_threads, (long)n_chunks, [&](long c, int) {
+		uint32_t *off = &chunk_hist[(size_t)c * NBINS];
+		const size_t e = std::min(n, ((size_t)c + 1) * CH);
+		for (size_t i = (size_t)c * CH; i < e; ++i) { const uint32_t pos = off[bucket[i]]++; perm[i] = pos; sj[pos] = jobs[i]; } // perm[i] = launch position of job i
+	}, 1);
 
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_jobs.ensure(n);
 	d_res.ensure(n);
-	d_counter.ensure(8);
+	d_counter.ensure(16);
 	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
 	KswRes *tr = tmp_res.ensure(n);
@@ -90,7 +135,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	for (int attempt = 0;; ++attempt) {
 		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
 		d_cigar.ensure(pool_cap);
-		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 8 * sizeof(int32_t), stream));
+		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 16 * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
 		// size every launch class first (one scratch allocation serves them all: the launches run back to back on one stream)
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
@@ -101,21 +146,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
 			const bool fast = tier < kFirstExact;
-			// query bytes + packed target + result record; the 1 B/cell direction matrix only counts when it cannot
-			// stay on chip (> 160 KB of LDS)
-			for (size_t i = P.beg; i < P.end; ++i) {
-				const KswJob &j = sj[i];
-				P.alg_bytes += sizeof(KswJob) + sizeof(KswRes);
-				if ((j.flag & KSWJ_SKIP) || j.qlen <= 0 || j.tlen <= 0) continue;
-				P.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
-				const size_t db = fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, j.w);
-				if (!(j.flag & KSW_SCORE_ONLY)) { if (db > 160 * 1024) P.alg_bytes += (double)db; }
-				P.max_T16 = std::max(P.max_T16, r16(j.tlen)), P.max_Q16 = std::max(P.max_Q16, r16(j.qlen));
-				if (!(j.flag & KSW_SCORE_ONLY)) {
-					P.slot_bytes = std::max(P.slot_bytes, db);
-					P.tmp_cap = std::max(P.tmp_cap, (size_t)j.qlen + j.tlen);
-				}
-			}
+			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_T16 = cls[tier].max_T16, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			const int wpb = kTiers[tier].waves_per_block;
 			int blocks_per_cu;
@@ -132,7 +163,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		}
 		d_dir.ensure(need_dir, 1.0);
 		d_cigar_tmp.ensure(need_tmp, 1.0);
-		static const char *kNames[kNTiers] = { "ksw_fast_kernel<4>", "ksw_fast_kernel<8>", "ksw_extd2_kernel[t0]", "ksw_extd2_kernel[t1]", "ksw_extd2_kernel[t2]" };
+		static const char *kNames[kNTiers] = { "ksw_fast_kernel<2>", "ksw_fast_kernel<3>", "ksw_fast_kernel<4>", "ksw_fast_kernel<5>", "ksw_fast_kernel<6>", "ksw_fast_kernel<8>",
+		                                       "ksw_extd2_kernel[t0]", "ksw_extd2_kernel[t1]", "ksw_extd2_kernel[t2]" };
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
 			if (P.end == P.beg) continue;
@@ -145,7 +177,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.counter = d_counter.p + tier;
 			L.max_T16 = P.max_T16, L.max_Q16 = P.max_Q16, L.sc = sc;
 			if (prof) prof->begin(stream);
-			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, tier == 0 ? 4 : 8, stream);
+			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, kTiers[tier].waves_per_block, stream);
 			if (prof) prof->end(stream, kNames[tier], P.alg_bytes);
 		}
