@@ -313,7 +313,8 @@ class Aligner(object):
     def last_stats(self):
         v = (C.c_double * 16)()
         k = lib().mm2amd_last_stats(v, 16)
-        names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells"]
+        names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells", "dev_allocs", "pin_allocs",
+                 "alloc_ns"]
         return dict(zip(names, list(v)[:k]))
 
 

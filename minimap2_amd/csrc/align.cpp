@@ -374,10 +374,10 @@ Aligner::Aligner(const MapOpt &opt, const FlatIndex &fi) : opt_(opt), fi_(fi)
 	if (bw_long_ < bw_) bw_long_ = bw_;
 }
 
-void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_off)
+void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_off, uint8_t *q4)
 {
 	ra.qlen = qlen, ra.qpool_off = qpool_off, ra.a = a;
-	ra.q4.resize((size_t)qlen * 2);
+	ra.q4 = q4;
 	for (int i = 0; i < qlen; ++i) {
 		const uint8_t c = kNt4Table[(uint8_t)seq[i]];
 		ra.q4[i] = c;
@@ -433,8 +433,8 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	else as1 = r.as, cnt1 = r.cnt;
 	drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
 	join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
-	anchor_boundary(fi_, ra.q4.data(), qlen, a[as1], &rs, &qs);
-	anchor_boundary(fi_, ra.q4.data(), qlen, a[as1 + cnt1 - 1], &re, &qe);
+	anchor_boundary(fi_, ra.q4, qlen, a[as1], &rs, &qs);
+	anchor_boundary(fi_, ra.q4, qlen, a[as1 + cnt1 - 1], &re, &qe);
 	assert(cnt1 > 0);
 
 	// how far the two extensions may reach (align.c:695-767)
@@ -512,7 +512,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	t.rs = rs, t.qs = qs; // start of the first gap window
 	for (int32_t i = 1; i < cnt1; ++i) {
 		if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
-		anchor_boundary(fi_, ra.q4.data(), qlen, a[as1 + i], &re, &qe);
+		anchor_boundary(fi_, ra.q4, qlen, a[as1 + i], &re, &qe);
 		if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt_.min_ksw_len && re - rs >= opt_.min_ksw_len)) {
 			Window w; w.kind = W_GAP, w.qs = qs, w.qe = qe, w.rs = rs, w.re = re, w.anchor_i = i;
 			w.bw = bw_long_;
@@ -605,10 +605,11 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 				++t.next_win;
 			} else if (w.kind == W_GAP) {
 				if (!w.pass2) { // the approximate pass: test it (align.c:843)
-					const uint8_t *qseq = ra.q4.data() + (size_t)t.rev * qlen + w.qs;
+					const uint8_t *qseq = ra.q4 + (size_t)t.rev * qlen + w.qs;
 					tbuf_.resize(w.re - w.rs);
-					fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
-					const int code = test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
+					static const int dbg_skip = getenv("MM2AMD_DBG_SKIP") ? atoi(getenv("MM2AMD_DBG_SKIP")) : 0;
+					if (!(dbg_skip & 2)) fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+					const int code = (dbg_skip & 1) ? 0 : test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
 					if (code != 0) {
 						// keep the results of the later windows of this region: they belong to this round
 						for (size_t k = t.next_win + 1; k < t.win.size(); ++k) {
@@ -688,8 +689,9 @@ void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
 	if (r.p) {
 		tbuf_.resize(t.re1 - t.rs1);
 		fi_.getseq(t.rid, t.rs1, t.re1, tbuf_.data());
-		const uint8_t *qseq = ra.q4.data() + (size_t)r.rev * qlen + t.qs1;
-		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
+		const uint8_t *qseq = ra.q4 + (size_t)r.rev * qlen + t.qs1;
+		static const int dbg_skip2 = getenv("MM2AMD_DBG_SKIP") ? atoi(getenv("MM2AMD_DBG_SKIP")) : 0;
+		if (!(dbg_skip2 & 4)) update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
 	}
 	t.saved.clear();
 	t.done = true;
@@ -711,7 +713,7 @@ void Aligner::try_inversion(ReadAlign &ra, int prev_ti, int ti, int pos_in_order
 	const int strand = r1.rev ? 0 : 1;                      // the query is read on the strand opposite to the flanks
 	const int q0 = r1.rev ? r2.qe : qlen - r2.qs;
 	std::vector<uint8_t> qrev(ql), trev(tl);
-	const uint8_t *qseq = ra.q4.data() + (size_t)strand * qlen + q0;
+	const uint8_t *qseq = ra.q4 + (size_t)strand * qlen + q0;
 	for (int i = 0; i < ql; ++i) qrev[i] = qseq[ql - 1 - i];
 	fi_.getseq(r1.rid, r1.re, r2.rs, trev.data());
 	std::reverse(trev.begin(), trev.end());
@@ -757,7 +759,7 @@ void Aligner::consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const 
 	ri.rs = t.inv_r1_re + t.inv_toff, ri.re = ri.rs + ez.max_t + 1;
 	tbuf_.resize(w.re - w.rs);
 	fi_.getseq(rid, w.rs, w.re, tbuf_.data());
-	update_extra(ri, ra.q4.data() + (size_t)t.rev * ra.qlen + w.qs, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX,
+	update_extra(ri, ra.q4 + (size_t)t.rev * ra.qlen + w.qs, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX,
 	             !(opt_.flag & (F_SR | F_SR_RNA)));
 	if (slot != ra.order.end()) *slot = ti;
 }

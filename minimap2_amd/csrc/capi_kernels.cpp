@@ -101,6 +101,12 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 	});
 }
 
+long long mm2amd_alloc_counter(int which)
+{
+	AllocStats &a = alloc_stats();
+	return which == 0 ? a.dev_allocs.load() : which == 1 ? a.pin_allocs.load() : a.ns.load();
+}
+
 void mm2amd_profile_enable(int on)
 {
 	for (int l = 0; l < kMaxProfLanes; ++l) kernel_profiler(l).reset();

@@ -9,6 +9,7 @@
 #include "../../include/mm2amd.h"
 #include "mapper.hpp"
 #include "index_handle.hpp"
+#include "threads.hpp"
 
 namespace mm2amd {
 Backend *make_backend(const FlatIndex &fi, void *device_tables); // backend_hip.cpp in the product
@@ -18,6 +19,8 @@ int capi_fail(int code, const std::string &msg);
 }
 
 using namespace mm2amd;
+
+extern "C" long long mm2amd_alloc_counter(int which); // device allocations, pinned allocations, nanoseconds spent in them
 
 namespace {
 struct MapContext {
@@ -92,7 +95,7 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 
 static void hand_over(int n_frag, const int *seg_off, std::vector<ReadResult> &out, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
-	for (int i = 0; i < n_frag; ++i) {
+	parallel_for((int)std::thread::hardware_concurrency(), n_frag, [&](long i, int) {
 		const int o = seg_off ? seg_off[i] : i;
 		const size_t n = out[i].regs.size();
 		n_reg[o] = (int)n;
@@ -103,7 +106,7 @@ static void hand_over(int n_frag, const int *seg_off, std::vector<ReadResult> &o
 		}
 		if (rep_len) rep_len[o] = out[i].rep_len;
 		if (frag_gap) frag_gap[o] = out[i].frag_gap;
-	}
+	}, 256);
 }
 
 int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const void *seq_)
@@ -251,7 +254,8 @@ int mm2amd_last_stats(double *v, int n)
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!g_ctx) return 0;
 	const MapperStats &s = g_ctx->mapper->stats;
-	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells };
+	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
+	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2) };
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <atomic>
+#include <chrono>
 
 namespace mm2amd {
 
@@ -23,6 +25,9 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define HIP_CHECK(x) ::mm2amd::hip_check((x), #x, __FILE__, __LINE__)
 
+struct AllocStats { std::atomic<long> dev_allocs{0}, pin_allocs{0}; std::atomic<double> dummy{0}; std::atomic<long long> dev_bytes{0}, pin_bytes{0}; std::atomic<long long> ns{0}; };
+inline AllocStats &alloc_stats() { static AllocStats s; return s; }
+
 // Grow-only device buffer; contents are NOT preserved across a grow.
 template <typename T>
 struct DevBuf {
@@ -38,7 +43,10 @@ struct DevBuf {
 			if (p) HIP_CHECK(hipFree(p));
 			p = nullptr;
 			cap = (size_t)(n * slack) + 64;
+			const auto t0_ = std::chrono::steady_clock::now();
 			HIP_CHECK(hipMalloc((void **)&p, cap * sizeof(T)));
+			alloc_stats().dev_allocs++, alloc_stats().dev_bytes += (long long)(cap * sizeof(T));
+			alloc_stats().ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
 		}
 		return p;
 	}
@@ -60,7 +68,10 @@ struct PinBuf {
 			if (p) HIP_CHECK(hipHostFree(p));
 			p = nullptr;
 			cap = (size_t)(n * slack) + 64;
+			const auto t0_ = std::chrono::steady_clock::now();
 			HIP_CHECK(hipHostMalloc((void **)&p, cap * sizeof(T), hipHostMallocDefault));
+			alloc_stats().pin_allocs++, alloc_stats().pin_bytes += (long long)(cap * sizeof(T));
+			alloc_stats().ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
 		}
 		return p;
 	}

@@ -1,6 +1,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <malloc.h>
 #include <stdexcept>
 #include "mapper.hpp"
 #include "chain_host.hpp"
@@ -44,6 +45,14 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	if (opt.q == opt.q2 && opt.e == opt.e2) throw std::invalid_argument("[mm2amd] single-affine scoring (ksw_extz2) is not implemented; use dual-affine gap costs");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	if (fi.n_alt) throw std::invalid_argument("[mm2amd] ALT-aware mapping is not implemented");
+	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
+	// hand that memory back to the kernel every time turns into page-fault and mmap-lock storms (the reference sidesteps the same
+	// problem with its own kalloc arenas).  Keep freed memory in the process instead.  MM2AMD_NO_MALLOPT=1 leaves malloc alone.
+	if (!getenv("MM2AMD_NO_MALLOPT")) {
+		mallopt(M_MMAP_THRESHOLD, 32 << 20);
+		mallopt(M_TRIM_THRESHOLD, 1 << 30);
+		mallopt(M_TOP_PAD, 64 << 20);
+	}
 }
 
 void Mapper::stage(const std::vector<ReadView> &reads)
@@ -96,19 +105,22 @@ void Mapper::run(std::vector<ReadResult> &out)
 		}
 	}
 	const int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), subs.size());
+	while ((int)scratch_.size() < n_drivers) scratch_.emplace_back(new DriverScratch);
 	std::atomic<size_t> next_sub(0);
 	std::mutex stats_mu;
 	std::exception_ptr first_err;
 	auto driver = [&](int lane) {
 		MapperStats st; // this driver's share, merged at the end
-		// Aligner holds scratch buffers, so each pool thread of this driver gets its own instance
-		std::vector<std::unique_ptr<Aligner>> al(n_threads_);
-		for (auto &p : al) p.reset(new Aligner(opt_, fi_));
+		// per-lane state that lives as long as the mapper: one Aligner per pool thread (they hold scratch buffers) and the big
+		// per-sub-batch arrays, so that steady-state batches allocate (and page-fault) nothing
+		DriverScratch &ds = *scratch_.at(lane);
+		std::vector<std::unique_ptr<Aligner>> &al = ds.al;
+		if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)); }
 		try {
 			for (;;) {
 				const size_t si = next_sub.fetch_add(1);
 				if (si >= subs.size()) break;
-				process_sub(sp, subs[si].first, subs[si].second, lane, al, out, st);
+				process_sub(sp, subs[si].first, subs[si].second, lane, al, ds, out, st);
 			}
 		} catch (...) {
 			std::lock_guard<std::mutex> lk(stats_mu);
@@ -128,7 +140,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	(void)t0;
 }
 
-void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, std::vector<ReadResult> &out, MapperStats &stats)
+void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, std::vector<ReadResult> &out, MapperStats &stats)
 {
 	const std::vector<ReadView> &live = live_;
 	const std::vector<long> &live_id = live_id_;
@@ -136,14 +148,21 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 	{
 		const long m = hi - lo;
 		double t0 = now();
-		std::vector<ReadChains> chains;
+		std::vector<ReadChains> &chains = ds.chains;
 		be_.seed_chain(sp, lo, hi, lane, n_threads_, chains);
 		stats.t_seed_chain += now() - t0; t0 = now();
 
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
 		Aligner aligner(opt_, fi_);
-		std::vector<ReadAlign> ra(m);
-		std::vector<RegVec> regs0(m);
+		std::vector<ReadAlign> &ra = ds.ra;
+		std::vector<RegVec> &regs0 = ds.regs0;
+		if ((long)ra.size() < m) ra.resize(m), regs0.resize(m);
+		// nt4 copies of the reads for the host-side checks (Z-drop rescoring, CIGAR fixes): one arena per driver instead of one
+		// heap block per read
+		uint64_t q4_total = 0;
+		ds.q4_off.resize(m + 1);
+		for (long i = 0; i < m; ++i) ds.q4_off[i] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len;
+		if (ds.q4.size() < q4_total) ds.q4.resize(q4_total + q4_total / 4);
 		parallel_for(n_threads_, m, [&](long i, int) {
 			ReadChains &c = chains[i];
 			const int qlen = live[lo + i].len;
@@ -172,7 +191,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 			filter_strand_retained(r0);
-			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i]);
+			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i], ds.q4.data() + ds.q4_off[i]);
 		});
 		Trace::get().add(lane, "host:pre", t0, now());
 		stats.t_host_pre += now() - t0;
@@ -181,10 +200,12 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		KswScoring sc;
 		memcpy(sc.mat, aligner.mat(), 25);
 		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.pad[0] = sc.pad[1] = 0;
-		std::vector<std::vector<KswJob>> per_read_jobs(m);
-		std::vector<size_t> job_base(m + 1);
-		std::vector<KswJob> jobs;
-		std::vector<KswRes> kres;
+		std::vector<std::vector<KswJob>> &per_read_jobs = ds.per_read_jobs;
+		if ((long)per_read_jobs.size() < m) per_read_jobs.resize(m);
+		std::vector<size_t> &job_base = ds.job_base;
+		job_base.resize(m + 1);
+		std::vector<KswJob> &jobs = ds.jobs;
+		std::vector<KswRes> &kres = ds.kres;
 		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(m, 1);
 		for (int round = 0;; ++round) {

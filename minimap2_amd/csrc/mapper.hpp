@@ -32,7 +32,20 @@ public:
 	void run(std::vector<ReadResult> &out);
 	MapperStats stats;
 private:
-	void process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, std::vector<ReadResult> &out, MapperStats &st);
+	struct DriverScratch {
+		std::vector<ReadChains> chains;
+		std::vector<ReadAlign> ra;
+		std::vector<RegVec> regs0;
+		std::vector<std::vector<KswJob>> per_read_jobs;
+		std::vector<size_t> job_base;
+		std::vector<KswJob> jobs;
+		std::vector<KswRes> kres;
+		std::vector<uint8_t> q4;
+		std::vector<uint64_t> q4_off;
+		std::vector<std::unique_ptr<Aligner>> al;
+	};
+	std::vector<std::unique_ptr<DriverScratch>> scratch_;
+	void process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, std::vector<ReadResult> &out, MapperStats &st);
 	const FlatIndex &fi_;
 	ref::MapOpt opt_;
 	Backend &be_;

@@ -1,16 +1,19 @@
 // Fork-join helper for the host stages (the reference uses kt_for, kthread.c:54-72), backed by a process-wide pool of
-// persistent worker threads: the mapper issues a dozen parallel loops per sub-batch and spawning hundreds of threads for each
-// costs more than some of the loops themselves.
+// persistent worker threads.  The mapper issues a dozen short parallel loops per sub-batch from several driver threads at
+// once, so dispatch has to be cheap: jobs live in a small fixed table of slots that workers poll with plain atomics; a worker
+// spins for a short while after running out of work and only then sleeps on a condition variable (one wake-up per idle period,
+// not one mutex hand-off per loop per thread).
 #pragma once
 #include <atomic>
 #include <condition_variable>
-#include <deque>
 #include <exception>
 #include <functional>
-#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace mm2amd {
 
@@ -27,48 +30,62 @@ public:
 		if (n <= 0) return;
 		if (n_threads <= 1 || n <= chunk) { for (long i = 0; i < n; ++i) fn(i, 0); return; }
 		const int want = (int)std::min<long>(n_threads, (n + chunk - 1) / chunk);
-		auto job = std::make_shared<Job>();
-		job->fn = &fn, job->n = n, job->chunk = chunk, job->next_tid.store(1);
-		{
-			std::lock_guard<std::mutex> lk(mu_);
-			ensure_workers(want - 1);
-			job->helpers_wanted = std::min<int>(want - 1, (int)workers_.size());
-			if (job->helpers_wanted > 0) queue_.push_back(job);
+		ensure_workers(want - 1);
+		Slot *s = nullptr;
+		for (;;) { // claim a free slot (there are more slots than driver threads)
+			for (Slot &c : slots_) { bool f = false; if (c.in_use.compare_exchange_strong(f, true, std::memory_order_acquire)) { s = &c; break; } }
+			if (s) break;
+			std::this_thread::yield();
 		}
-		cv_.notify_all();
-		work(*job, 0);
-		{ // no new helper may join once the caller has drained the range; wait for the ones still inside
-			std::unique_lock<std::mutex> lk(mu_);
-			job->closed = true;
-			for (auto it = queue_.begin(); it != queue_.end(); ++it) if (it->get() == job.get()) { queue_.erase(it); break; }
-			done_cv_.wait(lk, [&] { return job->active == 0; });
-		}
-		if (job->err) std::rethrow_exception(job->err);
+		s->fn = &fn, s->n = n, s->chunk = chunk, s->err = nullptr;
+		s->next.store(0, std::memory_order_relaxed), s->next_tid.store(1, std::memory_order_relaxed);
+		s->helpers_wanted.store(std::min<int>(want - 1, n_workers_.load()), std::memory_order_relaxed);
+		s->open.store(true, std::memory_order_release);
+		n_open_.fetch_add(1, std::memory_order_release);
+		if (n_sleeping_.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
+		work(*s, 0);
+		// the range is exhausted: no helper can claim another chunk; wait for those still inside their last one
+		s->open.store(false, std::memory_order_release);
+		n_open_.fetch_sub(1, std::memory_order_release);
+		while (s->active.load(std::memory_order_acquire) != 0) cpu_relax();
+		std::exception_ptr err = s->err;
+		s->err = nullptr;
+		s->in_use.store(false, std::memory_order_release);
+		if (err) std::rethrow_exception(err);
 	}
 	~ThreadPool()
 	{
-		{ std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+		{ std::lock_guard<std::mutex> lk(mu_); stop_.store(true); }
 		cv_.notify_all();
 		for (auto &t : workers_) t.join();
 	}
 private:
-	struct Job {
+	struct alignas(128) Slot {
+		std::atomic<bool> in_use{false}, open{false};
 		const std::function<void(long, int)> *fn = nullptr;
 		long n = 0, chunk = 1;
-		std::atomic<long> next{0};
-		std::atomic<int> next_tid{1};
-		int helpers_wanted = 0, active = 0; // guarded by mu_
-		bool closed = false;                // guarded by mu_
+		alignas(64) std::atomic<long> next{0};
+		alignas(64) std::atomic<int> next_tid{1};
+		std::atomic<int> helpers_wanted{0}, active{0};
 		std::exception_ptr err;
 		std::mutex err_mu;
 	};
-	void work(Job &j, int tid)
+	static void cpu_relax()
+	{
+#if defined(__x86_64__)
+		_mm_pause();
+#else
+		std::this_thread::yield();
+#endif
+	}
+	void work(Slot &j, int tid)
 	{
 		try {
+			const long n = j.n, chunk = j.chunk;
 			for (;;) {
-				const long b = j.next.fetch_add(j.chunk);
-				if (b >= j.n) break;
-				const long e = b + j.chunk < j.n ? b + j.chunk : j.n;
+				const long b = j.next.fetch_add(chunk, std::memory_order_relaxed);
+				if (b >= n) break;
+				const long e = b + chunk < n ? b + chunk : n;
 				for (long i = b; i < e; ++i) (*j.fn)(i, tid);
 			}
 		} catch (...) {
@@ -77,34 +94,53 @@ private:
 			j.next.store(j.n);
 		}
 	}
-	void ensure_workers(int n) // mu_ held
+	bool try_help()
 	{
+		bool helped = false;
+		for (Slot &s : slots_) {
+			if (!s.open.load(std::memory_order_acquire) || s.helpers_wanted.load(std::memory_order_relaxed) <= 0) continue;
+			s.active.fetch_add(1, std::memory_order_acq_rel); // announce first, then re-check: run() closes before it waits for active == 0
+			if (s.open.load(std::memory_order_acquire) && s.helpers_wanted.fetch_sub(1, std::memory_order_acq_rel) > 0) {
+				work(s, s.next_tid.fetch_add(1, std::memory_order_relaxed));
+				helped = true;
+			}
+			s.active.fetch_sub(1, std::memory_order_acq_rel);
+		}
+		return helped;
+	}
+	void ensure_workers(int n)
+	{
+		if (n_workers_.load(std::memory_order_acquire) >= n) return;
+		std::lock_guard<std::mutex> lk(mu_);
 		const int cap = std::max(1u, std::thread::hardware_concurrency());
 		if (n > cap) n = cap;
 		while ((int)workers_.size() < n) workers_.emplace_back([this] { loop(); });
+		n_workers_.store((int)workers_.size(), std::memory_order_release);
 	}
 	void loop()
 	{
-		std::unique_lock<std::mutex> lk(mu_);
 		for (;;) {
-			cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
-			if (stop_) return;
-			std::shared_ptr<Job> j = queue_.front();
-			if (j->closed || j->helpers_wanted <= 0) { queue_.pop_front(); continue; }
-			if (--j->helpers_wanted == 0) queue_.pop_front();
-			++j->active;
-			const int tid = j->next_tid.fetch_add(1);
-			lk.unlock();
-			work(*j, tid);
-			lk.lock();
-			if (--j->active == 0) done_cv_.notify_all();
+			if (try_help()) continue;
+			// nothing to do: spin briefly (the next loop of the same sub-batch is usually microseconds away), then sleep
+			bool found = false;
+			for (int spin = 0; spin < 4000 && !found; ++spin) {
+				if (stop_.load(std::memory_order_relaxed)) return;
+				if (n_open_.load(std::memory_order_acquire) > 0) found = true; else cpu_relax();
+			}
+			if (found) { if (!try_help()) std::this_thread::yield(); continue; }
+			std::unique_lock<std::mutex> lk(mu_);
+			n_sleeping_.fetch_add(1, std::memory_order_acq_rel);
+			cv_.wait(lk, [&] { return stop_.load() || n_open_.load(std::memory_order_acquire) > 0; });
+			n_sleeping_.fetch_sub(1, std::memory_order_acq_rel);
+			if (stop_.load()) return;
 		}
 	}
+	Slot slots_[16];
+	std::atomic<int> n_open_{0}, n_sleeping_{0}, n_workers_{0};
+	std::atomic<bool> stop_{false};
 	std::mutex mu_;
-	std::condition_variable cv_, done_cv_;
-	std::deque<std::shared_ptr<Job>> queue_;
+	std::condition_variable cv_;
 	std::vector<std::thread> workers_;
-	bool stop_ = false;
 };
 
 // Runs fn(i, tid) for i in [0,n) on n_threads threads with dynamic chunking; rethrows the first exception.

@@ -114,5 +114,8 @@ const char *backend_name() { return "cpu-check(oracle)"; }
 struct IndexHandle;
 const FlatIndex &index_flat(const IndexHandle *) { throw std::runtime_error("check backend: no device index"); }
 void *index_device_tables(const IndexHandle *) { return nullptr; }
+}
+extern "C" long long mm2amd_alloc_counter(int) { return 0; }
+namespace mm2amd {
 
 } // namespace mm2amd
