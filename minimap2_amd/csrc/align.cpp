@@ -220,14 +220,17 @@ void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t
 // ---------------------------------------------------------------------------------------------------------
 // Z-drop / inversion test on a finished gap-fill alignment (mm_test_zdrop, align.c:61-103)
 // ---------------------------------------------------------------------------------------------------------
-int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat)
+struct ZdropScan { int32_t max_zdrop = 0; int pos[2][2] = {{-1, -1}, {-1, -1}}; }; // pos[0] target, pos[1] query: [peak, trough]
+
+// the scan half of mm_test_zdrop (align.c:61-84): the same loop runs inside ksw_fast.hip for the jobs that kernel handles
+static ZdropScan zdrop_scan(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat)
 {
-	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
-	int pos[2][2] = {{-1, -1}, {-1, -1}};
+	ZdropScan z;
+	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0;
 	auto track = [&](int32_t sc, int ci, int cj) { // update_max_zdrop, align.c:46-59
 		if (sc < max) {
-			const int li = ci - max_i, lj = cj - max_j, diff = li > lj ? li - lj : lj - li, z = max - sc - diff * opt.e;
-			if (z > max_zdrop) max_zdrop = z, pos[0][0] = max_i, pos[0][1] = ci, pos[1][0] = max_j, pos[1][1] = cj;
+			const int li = ci - max_i, lj = cj - max_j, diff = li > lj ? li - lj : lj - li, zd = max - sc - diff * opt.e;
+			if (zd > z.max_zdrop) z.max_zdrop = zd, z.pos[0][0] = max_i, z.pos[0][1] = ci, z.pos[1][0] = max_j, z.pos[1][1] = cj;
 		} else max = sc, max_i = ci, max_j = cj;
 	};
 	for (uint32_t k = 0; k < n_cigar; ++k) {
@@ -244,15 +247,26 @@ int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint
 			track(score, i, j);
 		}
 	}
-	const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
-	if (!(opt.flag & (F_SPLICE | F_SR | F_FOR_ONLY | F_REV_ONLY)) && max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap) {
+	return z;
+}
+
+// the decision half (align.c:86-103): 2 = the dropped stretch aligns on the reverse strand (inversion), 1 = plain Z-drop
+static int zdrop_decide(const MapOpt &opt, const ZdropScan &z, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat)
+{
+	const int q_len = z.pos[1][1] - z.pos[1][0], t_len = z.pos[0][1] - z.pos[0][0];
+	if (!(opt.flag & (F_SPLICE | F_SR | F_FOR_ONLY | F_REV_ONLY)) && z.max_zdrop > opt.zdrop_inv && q_len < opt.max_gap && t_len < opt.max_gap) {
 		std::vector<uint8_t> rc(q_len > 0 ? q_len : 0); // reverse complement of the dropped query segment
-		for (int x = 0; x < q_len; ++x) { const int c = qseq[pos[1][1] - x - 1]; rc[x] = c >= 4 ? 4 : 3 - c; }
+		for (int x = 0; x < q_len; ++x) { const int c = qseq[z.pos[1][1] - x - 1]; rc[x] = c >= 4 ? 4 : 3 - c; }
 		int q_off, t_off;
-		const int sc = ll_local_score(q_len, rc.data(), t_len, tseq + pos[0][0], mat, opt.q, opt.e, &q_off, &t_off);
+		const int sc = ll_local_score(q_len, rc.data(), t_len, tseq + z.pos[0][0], mat, opt.q, opt.e, &q_off, &t_off);
 		if (sc >= opt.min_chain_score * opt.a && sc >= opt.min_dp_max) return 2;
 	}
-	return max_zdrop > opt.zdrop ? 1 : 0;
+	return z.max_zdrop > opt.zdrop ? 1 : 0;
+}
+
+int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, const uint32_t *cigar, const int8_t *mat)
+{
+	return zdrop_decide(opt, zdrop_scan(opt, qseq, tseq, n_cigar, cigar, mat), qseq, tseq, mat);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -606,10 +620,20 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 			} else if (w.kind == W_GAP) {
 				if (!w.pass2) { // the approximate pass: test it (align.c:843)
 					const uint8_t *qseq = ra.q4 + (size_t)t.rev * qlen + w.qs;
-					tbuf_.resize(w.re - w.rs);
-					static const int dbg_skip = getenv("MM2AMD_DBG_SKIP") ? atoi(getenv("MM2AMD_DBG_SKIP")) : 0;
-					if (!(dbg_skip & 2)) fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
-					const int code = (dbg_skip & 1) ? 0 : test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
+					int code;
+					if (ez.zd_max != KSW_ZD_NONE) { // the kernel scanned its own alignment; sequences are only needed for the rare inversion check
+						ZdropScan z;
+						z.max_zdrop = ez.zd_max, z.pos[0][0] = ez.zd_t0, z.pos[0][1] = ez.zd_t1, z.pos[1][0] = ez.zd_q0, z.pos[1][1] = ez.zd_q1;
+						if (z.max_zdrop > opt_.zdrop_inv) {
+							tbuf_.resize(w.re - w.rs);
+							fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+							code = zdrop_decide(opt_, z, qseq, tbuf_.data(), mat_);
+						} else code = z.max_zdrop > opt_.zdrop ? 1 : 0;
+					} else {
+						tbuf_.resize(w.re - w.rs);
+						fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+						code = test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
+					}
 					if (code != 0) {
 						// keep the results of the later windows of this region: they belong to this round
 						for (size_t k = t.next_win + 1; k < t.win.size(); ++k) {
@@ -690,8 +714,7 @@ void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
 		tbuf_.resize(t.re1 - t.rs1);
 		fi_.getseq(t.rid, t.rs1, t.re1, tbuf_.data());
 		const uint8_t *qseq = ra.q4 + (size_t)r.rev * qlen + t.qs1;
-		static const int dbg_skip2 = getenv("MM2AMD_DBG_SKIP") ? atoi(getenv("MM2AMD_DBG_SKIP")) : 0;
-		if (!(dbg_skip2 & 4)) update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
+		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
 	}
 	t.saved.clear();
 	t.done = true;

@@ -44,9 +44,17 @@ struct FlatIndex {
 		const uint64_t o = seq_off[rid] + p;
 		return (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
 	}
-	void getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const
+	void getseq(uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const // one packed word (8 bases) at a time
 	{
-		for (uint32_t i = st; i < en; ++i) out[i - st] = base(rid, i);
+		uint64_t o = seq_off[rid] + st;
+		const uint64_t oe = seq_off[rid] + en;
+		for (; o < oe && (o & 7); ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
+		for (; o + 8 <= oe; o += 8, out += 8) {
+			const uint32_t w = S[o >> 3];
+			out[0] = w & 0xf, out[1] = w >> 4 & 0xf, out[2] = w >> 8 & 0xf, out[3] = w >> 12 & 0xf;
+			out[4] = w >> 16 & 0xf, out[5] = w >> 20 & 0xf, out[6] = w >> 24 & 0xf, out[7] = w >> 28;
+		}
+		for (; o < oe; ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
 	}
 	int32_t cal_max_occ(float f) const; // mm_idx_cal_max_occ (index.c:198-220)
 

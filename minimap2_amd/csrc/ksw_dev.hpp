@@ -30,7 +30,7 @@ struct KswJob {             // 48 B
 	uint32_t reserved;
 };
 
-struct KswRes {             // 48 B; field meaning as ksw_extz_t (ksw2.h:34-43)
+struct KswRes {             // 68 B; the first 12 fields have the meaning of ksw_extz_t (ksw2.h:34-43)
 	int32_t max, zdropped;
 	int32_t max_q, max_t;
 	int32_t mqe, mqe_t;
@@ -39,7 +39,12 @@ struct KswRes {             // 48 B; field meaning as ksw_extz_t (ksw2.h:34-43)
 	int32_t n_cigar;
 	int32_t reach_end;
 	uint32_t cigar_off;     // where the CIGAR was placed in the cigar pool (allocated by the kernel)
+	// mm_test_zdrop's scan of the finished alignment (align.c:61-84), done by the kernel that produced it: the largest
+	// diagonal-adjusted score drop and where it happened (target/query offsets inside the window).  zd_max == KSW_ZD_NONE: not
+	// computed (the host scans the CIGAR itself).
+	int32_t zd_max, zd_t0, zd_t1, zd_q0, zd_q1;
 };
+constexpr int32_t KSW_ZD_NONE = INT32_MIN;
 
 struct KswScoring {         // uniform over a launch
 	int8_t mat[25];

@@ -343,6 +343,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 			R.max = ez.max, R.zdropped = ez.zdropped, R.max_q = ez.max_q, R.max_t = ez.max_t;
 			R.mqe = ez.mqe, R.mqe_t = ez.mqe_t, R.mte = ez.mte, R.mte_q = ez.mte_q;
 			R.score = ez.score, R.n_cigar = g.n, R.reach_end = ez.reach_end, R.cigar_off = cig_off;
+			R.zd_max = KSW_ZD_NONE, R.zd_t0 = R.zd_t1 = R.zd_q0 = R.zd_q1 = -1;
 			L.res[jid] = R;
 		}
 	}

@@ -45,10 +45,14 @@ template <int NC>
 __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast_kernel(KswLaunch L)
 {
 	__shared__ uint8_t s_q[4][FAST_QCAP];
+	__shared__ uint8_t s_t[4][512];
+	__shared__ int8_t s_mat[32];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
 	const int slot = blockIdx.x * 4 + wave_in_block;
 	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
-	uint8_t *qb = s_q[wave_in_block];
+	uint8_t *qb = s_q[wave_in_block], *tb = s_t[wave_in_block];
+	if (threadIdx.x < 25) s_mat[threadIdx.x] = L.sc.mat[threadIdx.x];
+	__syncthreads();
 	const int m = L.sc.m;
 	int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
 	const int qe_in = q + e; // before the swap (ksw2_extd2_sse.c:68 vs :78)
@@ -80,23 +84,24 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 				b = (flag & KSWJ_T_PACKED) ? (int)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (int)L.tpool[pos];
 			}
 			T[c] = b;
+			if (t < tlen) tb[t] = (uint8_t)b;
 			U[c] = V[c] = X[c] = Y[c] = nqe, X2[c] = Y2[c] = nqe2; // ksw2_extd2_sse.c:111-116
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 
-		// H[c] accumulates the true score of each column's current cell from the difference values: a column's first cell takes
-		// its left neighbour's previous score plus u, every later cell adds v.  The reference's approximate-score walk
-		// (ksw2_extd2_sse.c:366-383) sums the same exact differences along one particular path and, without KSW_EZ_APPROX_DROP,
-		// only its end point H(tlen-1, qlen-1) is reported -- which is path-independent.
-		int H[NC];
-#pragma unroll
-		for (int c = 0; c < NC; ++c) H[c] = 0;
-		const int n_rows = qlen + tlen - 1;
+		// Score of the corner cell H(tlen-1, qlen-1).  The reference's approximate-score walk (ksw2_extd2_sse.c:366-383) sums exact
+		// score differences along one particular monotone path and, without KSW_EZ_APPROX_DROP, reports only its end point, which
+		// is path-independent.  We sum along the matrix border instead: u of the first cell of every column along the top row
+		// (H(0,0) = u - (q+e) by the border convention, :358), then v down the last column -- one scalar add per anti-diagonal.
+		int H0 = -qe_in;
+		const int n_rows = qlen + tlen - 1, last_set = (tlen - 1) >> 6, last_lane = (tlen - 1) & 63;
 		for (int r = 0; r < n_rows; ++r) {
 			const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
 			// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163)
 			const int bnd = r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+			const bool top = r < tlen; // this anti-diagonal still starts a new column (t = r)
+			const int edge_set = r >> 6, edge_lane = r & 63;
 			uint8_t *pr = dir + (size_t)r * ncol;
 			// register sets from the highest down, so that set c still sees row r-1 in set c-1 when it fetches its carry-ins
 #pragma unroll
@@ -104,28 +109,23 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 				if (c * 64 > en0 || c * 64 + 63 < st0) continue; // register set outside the anti-diagonal (uniform)
 				const int t = c * 64 + lane;
 				const bool act = t >= st0 && t <= en0;
-				int cV = bnd, cX = nqe, cX2 = nqe2, cH = -qe_in; // column -1: the matrix border; H(-1,-1) makes H(0,0) = v - (q+e)
-				if (c > 0) {
-					cV = __builtin_amdgcn_readlane(V[c - 1], 63), cX = __builtin_amdgcn_readlane(X[c - 1], 63);
-					cX2 = __builtin_amdgcn_readlane(X2[c - 1], 63), cH = __builtin_amdgcn_readlane(H[c - 1], 63);
+				int cV = bnd, cX = nqe, cX2 = nqe2; // column -1: the matrix border
+				if (c > 0) cV = __builtin_amdgcn_readlane(V[c - 1], 63), cX = __builtin_amdgcn_readlane(X[c - 1], 63), cX2 = __builtin_amdgcn_readlane(X2[c - 1], 63);
+				const int vp = dpp_shr1(cV, V[c]), xp = dpp_shr1(cX, X[c]), x2p = dpp_shr1(cX2, X2[c]);
+				if (top && edge_set == c) { // u[r], y[r], y2[r] take their border values on first use (:156-163)
+					const bool edge = lane == edge_lane;
+					U[c] = edge ? bnd : U[c], Y[c] = edge ? nqe : Y[c], Y2[c] = edge ? nqe2 : Y2[c];
 				}
-				const int vp = dpp_shr1(cV, V[c]), xp = dpp_shr1(cX, X[c]), x2p = dpp_shr1(cX2, X2[c]), hp = dpp_shr1(cH, H[c]);
 				if (act) {
-					const bool edge = t == r; // u[r], y[r], y2[r] are border values on their first use (:156-163)
-					const int ut = edge ? bnd : U[c], yt = edge ? nqe : Y[c], y2t = edge ? nqe2 : Y2[c];
-					const int qv = qb[r - t], tv = T[c];
+					const int ut = U[c], qv = qb[r - t], tv = T[c];
 					int z = (tv == m - 1 || qv == m - 1) ? sc_N : tv == qv ? sc_mch : sc_mis;
-					int a = xp + vp, b = yt + ut, a2 = x2p + vp, b2 = y2t + ut, d;
+					int a = xp + vp, b = Y[c] + ut, a2 = x2p + vp, b2 = Y2[c] + ut, d;
 					d = a > z ? 1 : 0;   z = z > a ? z : a;    // strictly greater wins (:235-243)
 					d = b > z ? 2 : d;   z = z > b ? z : b;
 					d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
 					d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
 					z = z < sc_mch ? z : sc_mch;
-					const int un = z - vp, vn = z - ut;
-					U[c] = un, V[c] = vn;
-					// first cell of a column: from the left neighbour's previous cell by u (for r = 0 the border makes this v - (q+e));
-					// afterwards straight down the column by v
-					H[c] = edge ? (r == 0 ? vn - qe_in : hp + un) : H[c] + vn;
+					U[c] = z - vp, V[c] = z - ut;
 					int tmp = z - q;  a -= tmp, b -= tmp;
 					tmp = z - q2;     a2 -= tmp, b2 -= tmp;
 					X[c] = (a > 0 ? a : 0) - qe;      d |= a > 0 ? 0x08 : 0;
@@ -134,15 +134,15 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 					Y2[c] = (b2 > 0 ? b2 : 0) - qe2;  d |= b2 > 0 ? 0x40 : 0;
 					pr[t] = (uint8_t)d;
 				}
+				if (top) { if (edge_set == c) H0 += __builtin_amdgcn_readlane(U[c], edge_lane); }
+				else if (last_set == c) H0 += __builtin_amdgcn_readlane(V[c], last_lane);
 			}
 		}
-		int H0 = 0; // H(tlen-1, qlen-1)
-#pragma unroll
-		for (int c = 0; c < NC; ++c) if (((tlen - 1) >> 6) == c) H0 = __builtin_amdgcn_readlane(H[c], (tlen - 1) & 63);
 		// ---- traceback from (tlen-1, qlen-1) (ksw2_extd2_sse.c:389-391; ksw_backtrack with every cell inside the matrix) ----
 		__threadfence_block();
 		FastCig g = { L.cigar_tmp + (size_t)slot * L.cigar_tmp_cap, 0, 0u };
 		uint32_t cig_off = 0;
+		int32_t zd_max = 0, zd_t0 = -1, zd_t1 = -1, zd_q0 = -1, zd_q1 = -1;
 		if (lane == 0) {
 			int i = tlen - 1, j = qlen - 1, state = 0;
 			while (i >= 0 && j >= 0) {
@@ -158,6 +158,27 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 			if (j >= 0) fast_cig_push(g, 1, j + 1);
 			if (g.n > 0) g.c[g.n - 1] = g.last;
 			if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
+			// mm_test_zdrop's scan (align.c:61-84 with update_max_zdrop :46-59) over the alignment just produced, start to end
+			// (g.c holds the operations in traceback order, i.e. last first)
+			int32_t score = 0, mx = INT32_MIN, mx_i = -1, mx_j = -1, ci = 0, cj = 0;
+			const int gq = L.sc.q, ge = L.sc.e;
+			auto track = [&](int32_t sc, int pi, int pj) {
+				if (sc < mx) {
+					const int li = pi - mx_i, lj = pj - mx_j, diff = li > lj ? li - lj : lj - li, z = mx - sc - diff * ge;
+					if (z > zd_max) zd_max = z, zd_t0 = mx_i, zd_t1 = pi, zd_q0 = mx_j, zd_q1 = pj;
+				} else mx = sc, mx_i = pi, mx_j = pj;
+			};
+			for (int k = g.n - 1; k >= 0; --k) {
+				const uint32_t op = g.c[k] & 0xf, len = g.c[k] >> 4;
+				if (op == 0) {
+					for (uint32_t l = 0; l < len; ++l) { score += s_mat[tb[ci + l] * 5 + qb[cj + l]]; track(score, ci + (int)l, cj + (int)l); }
+					ci += len, cj += len;
+				} else {
+					score -= gq + ge * (int)len;
+					if (op == 1) cj += len; else ci += len;
+					track(score, ci, cj);
+				}
+			}
 		}
 		const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
 		cig_off = __builtin_amdgcn_readfirstlane(cig_off);
@@ -170,6 +191,7 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 			KswRes R;
 			R.max = 0, R.zdropped = 0, R.max_q = R.max_t = -1, R.mqe = R.mte = KSW_NEG_INF, R.mqe_t = R.mte_q = -1;
 			R.score = H0, R.n_cigar = n_cig, R.reach_end = 0, R.cigar_off = cig_off;
+			R.zd_max = zd_max, R.zd_t0 = zd_t0, R.zd_t1 = zd_t1, R.zd_q0 = zd_q0, R.zd_q1 = zd_q1;
 			L.res[jid] = R;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

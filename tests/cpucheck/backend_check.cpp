@@ -95,6 +95,7 @@ public:
 			r.max = ez.max, r.zdropped = ez.zdropped, r.max_q = ez.max_q, r.max_t = ez.max_t, r.mqe = ez.mqe, r.mqe_t = ez.mqe_t;
 			r.mte = ez.mte, r.mte_q = ez.mte_q, r.score = ez.score, r.n_cigar = ez.n_cigar, r.reach_end = ez.reach_end;
 			r.cigar_off = (uint32_t)cigar.size();
+			r.zd_max = KSW_ZD_NONE, r.zd_t0 = r.zd_t1 = r.zd_q0 = r.zd_q1 = -1;
 			cigar.insert(cigar.end(), cg.begin(), cg.begin() + ez.n_cigar);
 		}
 		*cigar_out = cigar.data();
