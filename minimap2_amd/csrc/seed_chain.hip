@@ -629,6 +629,13 @@ __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t
 	return sc;
 }
 
+// The DP is sequential in i, but only inside a CLUSTER of anchors.  Anchor i is "isolated" when its predecessor a[i-1] is
+// already outside its look-back window (another target/strand, or more than max_dist_x upstream): the anchors are sorted, so
+// then the whole window is empty, f[i] = q_span, p[i] = -1, and the loop state after i (window start st = i, best-scoring
+// anchor max_ii = i) does not depend on anything before it.  With a 3 Gb reference ~85 % of a read's anchors are such random
+// isolated hits.  Isolation is a purely local test, so each block of 64 anchors settles its isolated members in parallel and
+// only the members of real clusters (the true chains) go through the sequential rules, restarting from that known state at
+// every cluster head.
 __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
 {
 	const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -645,81 +652,116 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	__threadfence_block();
 
 	int64_t st = 0, max_ii = -1;
-	for (int64_t i = 0; i < n; ++i) {
-		const uint64_t ix = a[i].x, iy = a[i].y;
-		// advance the window start (lchain.c:172): first st in [st,i) on the same target/strand within max_dist_x
-		while (st < i) {
-			const int64_t c = st + lane;
-			bool stop = true; // lanes past i stop the scan
-			if (c < i) { const uint64_t cx = a[c].x; stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)max_dist_x); }
-			const unsigned long long m = __ballot(stop);
-			if (m) { st += __ffsll((long long)m) - 1; break; }
-			st += 64;
-		}
-		if (st > i) st = i;
-		if (i - st > P.max_chain_iter) st = i - P.max_chain_iter;
+	uint64_t mii_x = 0, mii_y = 0;   // a[max_ii]
+	int32_t mii_f = 0;               // f[max_ii]
+	uint64_t last_x = 0, last_y = 0; // the anchor just before the current block
+	bool last_iso = false;           // ... and whether it was isolated
+	for (int64_t blk = 0; blk < n; blk += 64) {
+		const int64_t g = blk + lane;
+		uint64_t bx = 0, by = 0;
+		if (g < n) { const Anchor v = a[g]; bx = v.x, by = v.y; }
+		uint64_t px = __shfl_up(bx, 1, 64), py = __shfl_up(by, 1, 64); // a[g-1]
+		if (lane == 0) px = last_x, py = last_y;
+		const bool iso = g < n && (g == 0 || (bx >> 32 != px >> 32 || bx > px + (uint64_t)(int64_t)max_dist_x));
+		if (iso) f[g] = (int32_t)(by >> 32 & 0xff), p[g] = -1;
+		__threadfence_block(); // cluster members read their head's f through memory
+		unsigned long long todo = __ballot(g < n && !iso);
+		const unsigned long long iso_mask = __ballot(iso);
+		while (todo) {
+			const int bl = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			const int64_t i = blk + bl;
+			const uint64_t ix = __shfl(bx, bl, 64), iy = __shfl(by, bl, 64);
+			const bool head_before = bl == 0 ? last_iso : (iso_mask >> (bl - 1) & 1) != 0; // a[i-1] isolated: a cluster starts here
+			if (head_before) { // the state the sequential loop is in right after an isolated anchor (see above)
+				const uint64_t hx = __shfl(px, bl, 64), hy = __shfl(py, bl, 64);
+				st = i - 1, max_ii = i - 1, mii_x = hx, mii_y = hy, mii_f = (int32_t)(hy >> 32 & 0xff);
+			}
+			// advance the window start (lchain.c:172): first st in [st,i) on the same target/strand within max_dist_x
+			while (st < i) {
+				const int64_t c = st + lane;
+				bool stop = true; // lanes past i stop the scan
+				if (c < i) { const uint64_t cx = a[c].x; stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)max_dist_x); }
+				const unsigned long long m = __ballot(stop);
+				if (m) { st += __ffsll((long long)m) - 1; break; }
+				st += 64;
+			}
+			if (st > i) st = i;
+			if (i - st > P.max_chain_iter) st = i - P.max_chain_iter;
 
-		int32_t max_f = (int32_t)(iy >> 32 & 0xff), n_skip = 0;
-		int64_t max_j = -1, end_j = st - 1;
-		bool broke = false;
-		for (int64_t base = i - 1; base >= st && !broke; base -= 64) {
-			const int64_t j = base - lane;
-			int32_t sc = INT32_MIN, pj = -1;
-			if (j >= st) {
-				sc = link_score(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
-				if (sc != INT32_MIN) sc += f[j], pj = p[j];
-			}
-			const bool has = sc != INT32_MIN;
-			// exclusive prefix maximum in processing order (lane 0 first)
-			int32_t pm = has ? sc : INT32_MIN;
-			for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(pm, o, 64); if (lane >= o) pm = v > pm ? v : pm; }
-			int32_t excl = __shfl_up(pm, 1, 64);
-			if (lane == 0) excl = INT32_MIN;
-			excl = excl > max_f ? excl : max_f;
-			const bool improve = has && sc > excl;
-			// marks left by predecessors examined earlier in this iteration (lchain.c:186)
-			if (has && pj >= 0) t[pj] = (int32_t)i;
-			__threadfence_block();
-			const bool marked = has && !improve && t[j >= st ? j : st] == (int32_t)i;
-			unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
-			int stop_lane = 64;
-			while (ev) { // the skip counter is inherently sequential; events are sparse
-				const int b = __ffsll((long long)ev) - 1;
-				ev &= ev - 1;
-				if (imp >> b & 1) { if (n_skip > 0) --n_skip; }
-				else if (++n_skip > P.max_chain_skip) { stop_lane = b; break; }
-			}
-			if (stop_lane < 64) {
-				broke = true;
-				end_j = base - stop_lane;
-				imp &= (1ull << stop_lane) - 1ull;
-			}
-			if (imp) { // improvements are increasing, so the last one before the stop holds the running maximum
-				const int last = 63 - __clzll((long long)imp);
-				max_f = __shfl(sc, last, 64);
-				max_j = base - last;
-			}
-		}
-		// the best-scoring anchor in range may lie beyond the early exit (lchain.c:189-200)
-		bool recompute = max_ii < 0;
-		if (!recompute) recompute = ix - a[max_ii].x > (uint64_t)(int64_t)max_dist_x;
-		if (recompute) {
-			long long best = INT64_MIN; // (f, j): larger f first, then larger j
-			for (int64_t base = i - 1; base >= st; base -= 64) {
+			int32_t max_f = (int32_t)(iy >> 32 & 0xff), n_skip = 0;
+			int64_t max_j = -1, end_j = st - 1;
+			bool broke = false;
+			for (int64_t base = i - 1; base >= st && !broke; base -= 64) {
 				const int64_t j = base - lane;
-				if (j >= st) { const long long key = (long long)f[j] << 32 | (long long)(uint32_t)j; best = key > best ? key : best; }
+				int32_t sc = INT32_MIN, pj = -1;
+				if (j >= st) {
+					sc = link_score(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
+					if (sc != INT32_MIN) sc += f[j], pj = p[j];
+				}
+				const bool has = sc != INT32_MIN;
+				// exclusive prefix maximum in processing order (lane 0 first)
+				int32_t pm = has ? sc : INT32_MIN;
+				for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(pm, o, 64); if (lane >= o) pm = v > pm ? v : pm; }
+				int32_t excl = __shfl_up(pm, 1, 64);
+				if (lane == 0) excl = INT32_MIN;
+				excl = excl > max_f ? excl : max_f;
+				const bool improve = has && sc > excl;
+				// marks left by predecessors examined earlier in this iteration (lchain.c:186)
+				if (has && pj >= 0) t[pj] = (int32_t)i;
+				__threadfence_block();
+				const bool marked = has && !improve && t[j >= st ? j : st] == (int32_t)i;
+				unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
+				int stop_lane = 64;
+				while (ev) { // the skip counter is inherently sequential; events are sparse
+					const int b = __ffsll((long long)ev) - 1;
+					ev &= ev - 1;
+					if (imp >> b & 1) { if (n_skip > 0) --n_skip; }
+					else if (++n_skip > P.max_chain_skip) { stop_lane = b; break; }
+				}
+				if (stop_lane < 64) {
+					broke = true;
+					end_j = base - stop_lane;
+					imp &= (1ull << stop_lane) - 1ull;
+				}
+				if (imp) { // improvements are increasing, so the last one before the stop holds the running maximum
+					const int last = 63 - __clzll((long long)imp);
+					max_f = __shfl(sc, last, 64);
+					max_j = base - last;
+				}
 			}
-			for (int o = 32; o > 0; o >>= 1) { const long long v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
-			max_ii = best == INT64_MIN ? -1 : (int64_t)(uint32_t)(best & 0xffffffffLL);
+			// the best-scoring anchor in range may lie beyond the early exit (lchain.c:189-200)
+			bool recompute = max_ii < 0;
+			if (!recompute) recompute = ix - mii_x > (uint64_t)(int64_t)max_dist_x;
+			if (recompute) {
+				long long best = INT64_MIN; // (f, j): larger f first, then larger j
+				for (int64_t base = i - 1; base >= st; base -= 64) {
+					const int64_t j = base - lane;
+					if (j >= st) { const long long key = (long long)f[j] << 32 | (long long)(uint32_t)j; best = key > best ? key : best; }
+				}
+				for (int o = 32; o > 0; o >>= 1) { const long long v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
+				max_ii = best == INT64_MIN ? -1 : (int64_t)(uint32_t)(best & 0xffffffffLL);
+				if (max_ii >= 0) { const Anchor m = a[max_ii]; mii_x = m.x, mii_y = m.y, mii_f = (int32_t)(best >> 32); }
+			}
+			if (max_ii >= 0 && max_ii < end_j) {
+				const int32_t tmp = link_score(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
+				if (tmp != INT32_MIN && max_f < tmp + mii_f) max_f = tmp + mii_f, max_j = max_ii;
+			}
+			if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
+			__threadfence_block();
+			if (max_ii < 0 || (ix - mii_x <= (uint64_t)(int64_t)max_dist_x && mii_f < max_f)) max_ii = i, mii_x = ix, mii_y = iy, mii_f = max_f;
 		}
-		if (max_ii >= 0 && max_ii < end_j) {
-			const int32_t tmp = link_score(ix, iy, a[max_ii].x, a[max_ii].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
-			if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) max_f = tmp + f[max_ii], max_j = max_ii;
-		}
-		if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
-		__threadfence_block();
-		if (max_ii < 0 || (ix - a[max_ii].x <= (uint64_t)(int64_t)max_dist_x && f[max_ii] < max_f)) max_ii = i;
+		// carry the block's last anchor (and whether it was isolated) into the next block
+		const int last_lane = (int)((n - blk < 64 ? n - blk : 64) - 1);
+		last_x = __shfl(bx, last_lane, 64), last_y = __shfl(by, last_lane, 64);
+		last_iso = (iso_mask >> last_lane & 1) != 0;
 	}
+}
+
+void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
+{
+	hipLaunchKernelGGL(chain_fill_kernel, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
+	HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -848,10 +890,5 @@ void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P,
 	HIP_CHECK(hipGetLastError());
 }
 
-void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
-{
-	hipLaunchKernelGGL(chain_fill_kernel, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
-	HIP_CHECK(hipGetLastError());
-}
 
 } // namespace mm2amd
