@@ -187,19 +187,23 @@ def main():
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
     roof = None
     if dom:
-        fam = dom_name.split("[")[0]
-        fam_ms = sum(v["ms"] for k, v in prof.items() if k.split("[")[0] == fam)
-        fam_bytes = sum(v["alg_bytes"] for k, v in prof.items() if k.split("[")[0] == fam)
-        fam_launch = sum(v["launches"] for k, v in prof.items() if k.split("[")[0] == fam)
+        fam = dom_name.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_fast_kernel<4>, <5>, ...) count together
+        same = {k: v for k, v in prof.items() if k.split("[")[0].split("<")[0] == fam}
+        fam_ms = sum(v["ms"] for v in same.values())
+        fam_bytes = sum(v["alg_bytes"] for v in same.values())
+        fam_launch = sum(v["launches"] for v in same.values())
         ach = fam_bytes / (fam_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": fam, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6),
                 "traffic": None, "avg_launch_ms": round(fam_ms / max(fam_launch, 1), 4), "launches": fam_launch,
                 "alg_bytes_per_launch": round(fam_bytes / max(fam_launch, 1), 1),
+                "note": "integer DP: VALU-issue-bound, not HBM-bound (DESIGN.md section 4); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())}}
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
-                roof["traffic"] = json.load(open(tj)).get(fam)
+                t = json.load(open(tj)).get(fam)
+                if t:
+                    roof["traffic"] = round(t["fetch_bytes_x2"] + t["write_bytes_per_launch"], 1)
             except Exception:
                 pass
 

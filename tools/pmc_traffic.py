@@ -1,0 +1,69 @@
+"""HBM traffic of each kernel family from rocprofv3 PMC passes (separate passes for FETCH_SIZE and WRITE_SIZE, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes: they do not fit one pass on gfx950).
+
+    python tools/pmc_traffic.py [--reads 20000] [--ref-mb 3000]
+
+Runs `bench.py --steps 1 --warmup 0 --no-cpu-baseline` with MM2AMD_LANES=1 under `rocprofv3 --pmc <counter> --kernel-trace`,
+sums each counter per kernel name, divides by the launch count and writes profiles/pmc_traffic.json:
+    { "<kernel family>": {"fetch_bytes_per_launch": .., "write_bytes_per_launch": .., "launches": .., "note": ..}, ... }
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction from the guide: FETCH_SIZE counts 128-B requests
+as 64 B for wide coalesced streaming reads, so the doubled value is given as well ("fetch_bytes_x2"); other access widths
+and WRITE_SIZE are uncalibrated on this part -- treat them as lower bounds / ratios."""
+import argparse
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def family(name):
+    n = name.split("(")[0].replace("void ", "").replace("mm2amd::", "")
+    return n.split("<")[0] if n.startswith("ksw_fast_kernel") else n
+
+
+def collect(counter, args):
+    out = os.path.join(ROOT, "gpurun_out", "pmc_" + counter)
+    subprocess.run(["rm", "-rf", out])
+    env = dict(os.environ, MM2AMD_LANES="1", TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--reads", str(args.reads), "--ref-mb", str(args.ref_mb)]
+    subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    db = sqlite3.connect(glob.glob(os.path.join(out, "*.db"))[0])
+    cols = [c[1] for c in db.execute("pragma table_info('counters_collection')")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    val_col = "value" if "value" in cols else "counter_value"
+    cnt_col = "counter_name" if "counter_name" in cols else "pmc_name"
+    res = {}
+    for kn, cn, v, disp in db.execute("select %s, %s, sum(%s), count(distinct dispatch_id) from counters_collection group by %s, %s" % (name_col, cnt_col, val_col, name_col, cnt_col)):
+        if cn != counter:
+            continue
+        f = family(kn)
+        a = res.setdefault(f, [0.0, 0])
+        a[0] += v
+        a[1] += disp
+    subprocess.run(["rm", "-rf", out])
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--ref-mb", type=float, default=3000)
+    a = ap.parse_args()
+    fetch = collect("FETCH_SIZE", a)
+    write = collect("WRITE_SIZE", a)
+    out = {}
+    for f in sorted(set(fetch) | set(write)):
+        if not any(f.startswith(p) for p in ("ksw_", "chain_", "seed_", "sketch", "anchor_", "encode")):
+            continue
+        fb, fl = fetch.get(f, [0.0, 0])
+        wb, wl = write.get(f, [0.0, 0])
+        n = max(fl, wl, 1)
+        out[f] = {"fetch_bytes_per_launch": fb * 1024 / n, "fetch_bytes_x2": 2 * fb * 1024 / n, "write_bytes_per_launch": wb * 1024 / n, "launches": n,
+                  "note": "per launch at %d reads vs %d Mb; FETCH_SIZE/WRITE_SIZE in KiB -> bytes; x2 = gfx950 wide-read correction; WRITE_SIZE uncalibrated" % (a.reads, a.ref_mb)}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
