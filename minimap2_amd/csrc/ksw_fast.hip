@@ -15,6 +15,8 @@
 //   * one wavefront per job, persistent waves pulling jobs from a queue; the only HBM traffic is the 1 B/cell direction
 //     byte (row-major, 64 B coalesced per active register set) and the sequential traceback over it.
 //
+//   * two jobs per wavefront in the halves of packed 16-bit registers (see below).
+//
 // tests/test_gpu_ksw.py checks this kernel against the lane-exact oracle on every preset's scoring; jobs that are not
 // eligible (binding band, extension flags, exact-max mode, generic matrices, long sequences) take the exact kernel.
 #include <hip/hip_runtime.h>
@@ -40,17 +42,44 @@ __device__ __forceinline__ void fast_cig_push(FastCig &g, uint32_t op, int len) 
 	} else g.last += (uint32_t)len << 4;
 }
 
-// second launch bound = waves per SIMD to compile for: 5 (<= 96 VGPRs) up to 4 register sets, 4 (<= 128) for 5-6, 3 for 8
+// ---------------------------------------------------------------------------------------------------------
+// Two jobs per wavefront, packed 16-bit arithmetic.
+//
+// The row loop is bound by VALU issue (about 70 instructions per 64 cells), and every quantity in it fits in 8 bits.  gfx950
+// executes 2 x 16-bit packed integer ops (v_pk_add/sub/max/min/mad_u16) at the rate of one 32-bit op, so each lane carries the
+// same column of TWO jobs: job A in the low halves of the state registers, job B in the high halves.  The jobs of a launch are
+// ordered by cost, so the two members of a pair have nearly the same shape and advance in lockstep; DPP shifts, carries and
+// border values act on both halves at once, and only the activity masks, the query bytes and the direction-byte stores are
+// per job.  The direction index d ("first candidate that reaches the maximum", = the reference's strictly-greater update
+// chain, ksw2_extd2_sse.c:235-243) and the continuation flags are computed arithmetically, because packed compares do not
+// exist.  The packed instructions are issued through inline asm: written as C++ vector code the optimiser rewrites the
+// min/mul idioms back into compares and de-vectorises them.
+// ---------------------------------------------------------------------------------------------------------
+#define MM2_PK2(name, ins) \
+	__device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b) { uint32_t r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MM2_PK2(pk_add, "v_pk_add_u16")
+MM2_PK2(pk_sub, "v_pk_sub_u16")
+MM2_PK2(pk_max, "v_pk_max_i16")
+MM2_PK2(pk_min, "v_pk_min_i16")
+MM2_PK2(pk_minu, "v_pk_min_u16")
+MM2_PK2(pk_mul, "v_pk_mul_lo_u16")
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t pk_shr2(uint32_t a) { uint32_t r; asm("v_pk_lshrrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; } // the inline constant feeds both halves
+__device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | (uint32_t)v << 16; }
+// a uniform constant pinned in a VGPR (the asm wrappers take VGPR operands; without this every use re-copies it from an SGPR)
+__device__ __forceinline__ uint32_t pk2v(int v) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(pk2(v))); return r; }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
+__device__ __forceinline__ uint32_t dpp_shr1u(uint32_t carry_in, uint32_t v) { return (uint32_t)dpp_shr1((int)carry_in, (int)v); }
+
+// second launch bound = waves per SIMD to compile for: 4 (<= 128 VGPRs) up to 4 register sets, 3 (<= 168) for 5-6, 2 for 8
 template <int NC>
-__global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast_kernel(KswLaunch L)
+__global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast_kernel(KswLaunch L)
 {
-	__shared__ uint8_t s_q[4][FAST_QCAP];
-	__shared__ uint8_t s_t[4][512];
+	__shared__ uint8_t s_q[4][2][FAST_QCAP];
+	__shared__ uint8_t s_t[4][2][512];
 	__shared__ int8_t s_mat[32];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
 	const int slot = blockIdx.x * 4 + wave_in_block;
-	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
-	uint8_t *qb = s_q[wave_in_block], *tb = s_t[wave_in_block];
 	if (threadIdx.x < 25) s_mat[threadIdx.x] = L.sc.mat[threadIdx.x];
 	__syncthreads();
 	const int m = L.sc.m;
@@ -63,90 +92,129 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const uint32_t P_ONE = pk2v(1), P_ZERO = pk2v(0), P_MCH = pk2v(sc_mch), P_MISD = pk2v(sc_mis - sc_mch), P_SCN = pk2v(sc_N);
+	const uint32_t P_Q = pk2v(q), P_Q2 = pk2v(q2), P_QE = pk2v(qe), P_QE2 = pk2v(qe2), P_NQE = pk2(nqe), P_NQE2 = pk2(nqe2);
+	const uint32_t P_8 = pk2v(8), P_16 = pk2v(16), P_32 = pk2v(32), P_64 = pk2v(64);
 
 	for (;;) {
-		int jid = 0;
-		if (lane == 0) jid = atomicAdd(L.counter, 1);
-		jid = __builtin_amdgcn_readfirstlane(jid);
-		if (jid >= L.n_jobs) break;
-		const KswJob J = L.jobs[jid];
-		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag;
-		const int ncol = (tlen + 63) & ~63;
-		// ---- operands: query bytes to LDS, one target base per (register set, lane) ----
-		for (int i = lane; i < qlen; i += 64) qb[i] = L.qpool[(flag & KSWJ_Q_REVERSED) ? J.q_off - (uint64_t)i : J.q_off + (uint64_t)i];
-		int T[NC], U[NC], V[NC], X[NC], Y[NC], X2[NC], Y2[NC];
+		int pid = 0;
+		if (lane == 0) pid = atomicAdd(L.counter, 1);
+		pid = __builtin_amdgcn_readfirstlane(pid);
+		if (2 * pid >= L.n_jobs) break;
+		const int jidA = 2 * pid, jidB = 2 * pid + 1;
+		const bool hasB = jidB < L.n_jobs;
+		const KswJob JA = L.jobs[jidA], JB = L.jobs[hasB ? jidB : jidA];
+		const int qlenA = JA.qlen, tlenA = JA.tlen, qlenB = hasB ? JB.qlen : 0, tlenB = hasB ? JB.tlen : 0;
+		const int ncolA = (tlenA + 63) & ~63, ncolB = (tlenB + 63) & ~63;
+		uint8_t *dirA = L.dir_pool + (size_t)(2 * slot) * L.slot_bytes, *dirB = dirA + L.slot_bytes;
+		uint8_t *qbA = s_q[wave_in_block][0], *qbB = s_q[wave_in_block][1], *tbA = s_t[wave_in_block][0], *tbB = s_t[wave_in_block][1];
+		// ---- operands: query bytes to LDS, one packed target base pair per (register set, lane) ----
+		for (int i = lane; i < qlenA; i += 64) qbA[i] = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)i : JA.q_off + (uint64_t)i];
+		for (int i = lane; i < qlenB; i += 64) qbB[i] = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)i : JB.q_off + (uint64_t)i];
+		uint32_t T[NC], U[NC], V[NC], X[NC], Y[NC], X2[NC], Y2[NC];
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
 			const int t = c * 64 + lane;
-			int b = 4;
-			if (t < tlen) {
-				const uint64_t pos = (flag & KSWJ_T_REVERSED) ? J.t_off - (uint64_t)t : J.t_off + (uint64_t)t;
-				b = (flag & KSWJ_T_PACKED) ? (int)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (int)L.tpool[pos];
+			uint32_t bA = 4, bB = 4;
+			if (t < tlenA) {
+				const uint64_t pos = (JA.flag & KSWJ_T_REVERSED) ? JA.t_off - (uint64_t)t : JA.t_off + (uint64_t)t;
+				bA = (JA.flag & KSWJ_T_PACKED) ? (L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (uint32_t)L.tpool[pos];
+				tbA[t] = (uint8_t)bA;
 			}
-			T[c] = b;
-			if (t < tlen) tb[t] = (uint8_t)b;
-			U[c] = V[c] = X[c] = Y[c] = nqe, X2[c] = Y2[c] = nqe2; // ksw2_extd2_sse.c:111-116
+			if (t < tlenB) {
+				const uint64_t pos = (JB.flag & KSWJ_T_REVERSED) ? JB.t_off - (uint64_t)t : JB.t_off + (uint64_t)t;
+				bB = (JB.flag & KSWJ_T_PACKED) ? (L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (uint32_t)L.tpool[pos];
+				tbB[t] = (uint8_t)bB;
+			}
+			T[c] = bA | bB << 16;
+			U[c] = V[c] = X[c] = Y[c] = P_NQE, X2[c] = Y2[c] = P_NQE2; // ksw2_extd2_sse.c:111-116
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 
-		// Score of the corner cell H(tlen-1, qlen-1).  The reference's approximate-score walk (ksw2_extd2_sse.c:366-383) sums exact
-		// score differences along one particular monotone path and, without KSW_EZ_APPROX_DROP, reports only its end point, which
-		// is path-independent.  We sum along the matrix border instead: u of the first cell of every column along the top row
-		// (H(0,0) = u - (q+e) by the border convention, :358), then v down the last column -- one scalar add per anti-diagonal.
-		int H0 = -qe_in;
-		const int n_rows = qlen + tlen - 1, last_set = (tlen - 1) >> 6, last_lane = (tlen - 1) & 63;
+		// Score of each job's corner cell H(tlen-1, qlen-1): the reference's approximate-score walk (ksw2_extd2_sse.c:366-383) sums
+		// exact score differences along one monotone path and, without KSW_EZ_APPROX_DROP, reports only its path-independent end
+		// point.  We sum along the matrix border: u of the first cell of every column along the top row (H(0,0) = u - (q+e) by the
+		// border convention, :358), then v down the last column -- one scalar add per job and anti-diagonal.
+		int H0A = -qe_in, H0B = -qe_in;
+		const int n_rowsA = qlenA + tlenA - 1, n_rowsB = hasB ? qlenB + tlenB - 1 : 0, n_rows = n_rowsA > n_rowsB ? n_rowsA : n_rowsB;
+		const int last_setA = (tlenA - 1) >> 6, last_laneA = (tlenA - 1) & 63, last_setB = (tlenB - 1) >> 6, last_laneB = (tlenB - 1) & 63;
 		for (int r = 0; r < n_rows; ++r) {
-			const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = r < tlen - 1 ? r : tlen - 1;
-			// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163)
+			// valid cells of this anti-diagonal, per job (empty once a job has run out of rows)
+			int st0A = r - qlenA + 1 > 0 ? r - qlenA + 1 : 0, en0A = r < tlenA - 1 ? r : tlenA - 1;
+			int st0B = r - qlenB + 1 > 0 ? r - qlenB + 1 : 0, en0B = r < tlenB - 1 ? r : tlenB - 1;
+			if (r >= n_rowsA) st0A = 1, en0A = 0;
+			if (r >= n_rowsB) st0B = 1, en0B = 0;
+			const int lo = st0A <= en0A ? (st0B <= en0B && st0B < st0A ? st0B : st0A) : st0B, hi = en0A > en0B ? en0A : en0B; // union (hi < lo if both empty)
+			// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163): depends on r only, so it is shared
 			const int bnd = r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-			const bool top = r < tlen; // this anti-diagonal still starts a new column (t = r)
+			const uint32_t P_BND = pk2(bnd);
+			const bool topA = r < tlenA && r < n_rowsA, topB = r < tlenB && r < n_rowsB; // the anti-diagonal still starts a new column (t = r)
 			const int edge_set = r >> 6, edge_lane = r & 63;
-			uint8_t *pr = dir + (size_t)r * ncol;
+			const uint32_t edge_halves = (topA ? 0xffffu : 0u) | (topB ? 0xffff0000u : 0u);
+			uint8_t *prA = dirA + (size_t)r * ncolA, *prB = dirB + (size_t)r * ncolB;
 			// register sets from the highest down, so that set c still sees row r-1 in set c-1 when it fetches its carry-ins
 #pragma unroll
 			for (int c = NC - 1; c >= 0; --c) {
-				if (c * 64 > en0 || c * 64 + 63 < st0) continue; // register set outside the anti-diagonal (uniform)
+				if (c * 64 > hi || c * 64 + 63 < lo) continue; // register set outside both anti-diagonals (uniform)
 				const int t = c * 64 + lane;
-				const bool act = t >= st0 && t <= en0;
-				int cV = bnd, cX = nqe, cX2 = nqe2; // column -1: the matrix border
+				const bool actA = t >= st0A && t <= en0A, actB = t >= st0B && t <= en0B;
+				uint32_t cV = P_BND, cX = P_NQE, cX2 = P_NQE2; // column -1: the matrix border
 				if (c > 0) cV = __builtin_amdgcn_readlane(V[c - 1], 63), cX = __builtin_amdgcn_readlane(X[c - 1], 63), cX2 = __builtin_amdgcn_readlane(X2[c - 1], 63);
-				const int vp = dpp_shr1(cV, V[c]), xp = dpp_shr1(cX, X[c]), x2p = dpp_shr1(cX2, X2[c]);
-				if (top && edge_set == c) { // u[r], y[r], y2[r] take their border values on first use (:156-163)
-					const bool edge = lane == edge_lane;
-					U[c] = edge ? bnd : U[c], Y[c] = edge ? nqe : Y[c], Y2[c] = edge ? nqe2 : Y2[c];
+				const uint32_t vp = dpp_shr1u(cV, V[c]), xp = dpp_shr1u(cX, X[c]), x2p = dpp_shr1u(cX2, X2[c]);
+				if (edge_halves && edge_set == c) { // u[r], y[r], y2[r] take their border values on first use (:156-163)
+					const uint32_t em = lane == edge_lane ? edge_halves : 0u;
+					U[c] = bfi(em, P_BND, U[c]), Y[c] = bfi(em, P_NQE, Y[c]), Y2[c] = bfi(em, P_NQE2, Y2[c]);
 				}
-				if (act) {
-					const int ut = U[c], qv = qb[r - t], tv = T[c];
-					int z = (tv == m - 1 || qv == m - 1) ? sc_N : tv == qv ? sc_mch : sc_mis;
-					int a = xp + vp, b = Y[c] + ut, a2 = x2p + vp, b2 = Y2[c] + ut, d;
-					d = a > z ? 1 : 0;   z = z > a ? z : a;    // strictly greater wins (:235-243)
-					d = b > z ? 2 : d;   z = z > b ? z : b;
-					d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
-					d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
-					z = z < sc_mch ? z : sc_mch;
-					U[c] = z - vp, V[c] = z - ut;
-					int tmp = z - q;  a -= tmp, b -= tmp;
-					tmp = z - q2;     a2 -= tmp, b2 -= tmp;
-					X[c] = (a > 0 ? a : 0) - qe;      d |= a > 0 ? 0x08 : 0;
-					Y[c] = (b > 0 ? b : 0) - qe;      d |= b > 0 ? 0x10 : 0;
-					X2[c] = (a2 > 0 ? a2 : 0) - qe2;  d |= a2 > 0 ? 0x20 : 0;
-					Y2[c] = (b2 > 0 ? b2 : 0) - qe2;  d |= b2 > 0 ? 0x40 : 0;
-					pr[t] = (uint8_t)d;
+				if (actA || actB) {
+					const uint32_t mask = (actA ? 0xffffu : 0u) | (actB ? 0xffff0000u : 0u);
+					const uint32_t qv = (uint32_t)qbA[actA ? r - t : 0] | (uint32_t)qbB[actB ? r - t : 0] << 16, tv = T[c];
+					// substitution score: match / mismatch, overridden by sc_N when either base is ambiguous (code 4: bit 2)
+					uint32_t z = pk_mad(pk_minu(tv ^ qv, P_ONE), P_MISD, P_MCH);
+					z = pk_mad(pk_shr2(tv | qv), pk_sub(P_SCN, z), z);
+					const uint32_t ut = U[c];
+					uint32_t a = pk_add(xp, vp), b = pk_add(Y[c], ut), a2 = pk_add(x2p, vp), b2 = pk_add(Y2[c], ut);
+					const uint32_t z1 = pk_max(z, a), z2 = pk_max(z1, b), z3 = pk_max(z2, a2), z4 = pk_max(z3, b2);
+					// d = index of the first of (s, a, b, a2, b2) equal to the maximum
+					const uint32_t ne_s = pk_minu(pk_sub(z4, z), P_ONE), ne_a = pk_minu(pk_sub(z4, a), P_ONE);
+					const uint32_t ne_b = pk_minu(pk_sub(z4, b), P_ONE), ne_a2 = pk_minu(pk_sub(z4, a2), P_ONE);
+					uint32_t d = pk_mul(ne_s, pk_mad(ne_a, pk_mad(ne_b, pk_add(ne_a2, P_ONE), P_ONE), P_ONE));
+					z = pk_min(z4, P_MCH);
+					const uint32_t un = pk_sub(z, vp), vn = pk_sub(z, ut);
+					uint32_t tmp = pk_sub(z, P_Q);
+					a = pk_sub(a, tmp), b = pk_sub(b, tmp);
+					tmp = pk_sub(z, P_Q2);
+					a2 = pk_sub(a2, tmp), b2 = pk_sub(b2, tmp);
+					const uint32_t ma = pk_max(a, P_ZERO), mb = pk_max(b, P_ZERO), ma2 = pk_max(a2, P_ZERO), mb2 = pk_max(b2, P_ZERO);
+					d = pk_mad(pk_minu(ma, P_ONE), P_8, d);   // a > 0: the gap can be extended (continuation bits 0x08..0x40, :261-272)
+					d = pk_mad(pk_minu(mb, P_ONE), P_16, d);
+					d = pk_mad(pk_minu(ma2, P_ONE), P_32, d);
+					d = pk_mad(pk_minu(mb2, P_ONE), P_64, d);
+					U[c] = bfi(mask, un, U[c]), V[c] = bfi(mask, vn, V[c]);
+					X[c] = bfi(mask, pk_sub(ma, P_QE), X[c]), Y[c] = bfi(mask, pk_sub(mb, P_QE), Y[c]);
+					X2[c] = bfi(mask, pk_sub(ma2, P_QE2), X2[c]), Y2[c] = bfi(mask, pk_sub(mb2, P_QE2), Y2[c]);
+					if (actA) prA[t] = (uint8_t)d;
+					if (actB) prB[t] = (uint8_t)(d >> 16);
 				}
-				if (top) { if (edge_set == c) H0 += __builtin_amdgcn_readlane(U[c], edge_lane); }
-				else if (last_set == c) H0 += __builtin_amdgcn_readlane(V[c], last_lane);
+				if (topA) { if (edge_set == c) H0A += (int16_t)__builtin_amdgcn_readlane(U[c], edge_lane); }
+				else if (r < n_rowsA && last_setA == c) H0A += (int16_t)__builtin_amdgcn_readlane(V[c], last_laneA);
+				if (topB) { if (edge_set == c) H0B += (int16_t)(__builtin_amdgcn_readlane(U[c], edge_lane) >> 16); }
+				else if (r < n_rowsB && last_setB == c) H0B += (int16_t)(__builtin_amdgcn_readlane(V[c], last_laneB) >> 16);
 			}
 		}
-		// ---- traceback from (tlen-1, qlen-1) (ksw2_extd2_sse.c:389-391; ksw_backtrack with every cell inside the matrix) ----
+		// ---- tracebacks from (tlen-1, qlen-1) (ksw2_extd2_sse.c:389-391; ksw_backtrack with every cell inside the matrix) and
+		//      mm_test_zdrop's scan of the result (align.c:61-84): lane 0 serves job A, lane 32 job B, concurrently ----
 		__threadfence_block();
-		FastCig g = { L.cigar_tmp + (size_t)slot * L.cigar_tmp_cap, 0, 0u };
+		const bool isB = lane >= 32;
+		const int my_qlen = isB ? qlenB : qlenA, my_tlen = isB ? tlenB : tlenA, my_ncol = isB ? ncolB : ncolA;
+		const uint8_t *my_dir = isB ? dirB : dirA, *my_qb = isB ? qbB : qbA, *my_tb = isB ? tbB : tbA;
+		FastCig g = { L.cigar_tmp + (size_t)(2 * slot + (isB ? 1 : 0)) * L.cigar_tmp_cap, 0, 0u };
 		uint32_t cig_off = 0;
 		int32_t zd_max = 0, zd_t0 = -1, zd_t1 = -1, zd_q0 = -1, zd_q1 = -1;
-		if (lane == 0) {
-			int i = tlen - 1, j = qlen - 1, state = 0;
+		if ((lane == 0 || (lane == 32 && hasB))) {
+			int i = my_tlen - 1, j = my_qlen - 1, state = 0;
 			while (i >= 0 && j >= 0) {
-				const int tmp = dir[(size_t)(i + j) * ncol + i];
+				const int tmp = my_dir[(size_t)(i + j) * my_ncol + i];
 				if (state == 0) state = tmp & 7;
 				else if (!(tmp >> (state + 2) & 1)) state = 0;
 				if (state == 0) state = tmp & 7;
@@ -158,20 +226,19 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 			if (j >= 0) fast_cig_push(g, 1, j + 1);
 			if (g.n > 0) g.c[g.n - 1] = g.last;
 			if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
-			// mm_test_zdrop's scan (align.c:61-84 with update_max_zdrop :46-59) over the alignment just produced, start to end
-			// (g.c holds the operations in traceback order, i.e. last first)
+			// update_max_zdrop (align.c:46-59) over the alignment, start to end (g.c holds the operations last first)
 			int32_t score = 0, mx = INT32_MIN, mx_i = -1, mx_j = -1, ci = 0, cj = 0;
 			const int gq = L.sc.q, ge = L.sc.e;
 			auto track = [&](int32_t sc, int pi, int pj) {
 				if (sc < mx) {
-					const int li = pi - mx_i, lj = pj - mx_j, diff = li > lj ? li - lj : lj - li, z = mx - sc - diff * ge;
-					if (z > zd_max) zd_max = z, zd_t0 = mx_i, zd_t1 = pi, zd_q0 = mx_j, zd_q1 = pj;
+					const int li = pi - mx_i, lj = pj - mx_j, diff = li > lj ? li - lj : lj - li, zz = mx - sc - diff * ge;
+					if (zz > zd_max) zd_max = zz, zd_t0 = mx_i, zd_t1 = pi, zd_q0 = mx_j, zd_q1 = pj;
 				} else mx = sc, mx_i = pi, mx_j = pj;
 			};
 			for (int k = g.n - 1; k >= 0; --k) {
 				const uint32_t op = g.c[k] & 0xf, len = g.c[k] >> 4;
 				if (op == 0) {
-					for (uint32_t l = 0; l < len; ++l) { score += s_mat[tb[ci + l] * 5 + qb[cj + l]]; track(score, ci + (int)l, cj + (int)l); }
+					for (uint32_t l = 0; l < len; ++l) { score += s_mat[my_tb[ci + l] * 5 + my_qb[cj + l]]; track(score, ci + (int)l, cj + (int)l); }
 					ci += len, cj += len;
 				} else {
 					score -= gq + ge * (int)len;
@@ -180,19 +247,26 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 5 : NC <= 6 ? 4 : 3)) ksw_fast
 				}
 			}
 		}
-		const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
-		cig_off = __builtin_amdgcn_readfirstlane(cig_off);
 		__threadfence_block();
-		if (n_cig > 0) {
-			if ((unsigned long long)cig_off + (unsigned)n_cig > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
-			else for (int k = lane; k < n_cig; k += 64) L.cigar_pool[cig_off + k] = g.c[n_cig - 1 - k]; // forward order
+		// pack the CIGARs into the pool in forward order, job A then job B, all lanes copying
+#pragma unroll
+		for (int which = 0; which < 2; ++which) {
+			if (which == 1 && !hasB) break;
+			const int src = which * 32;
+			const int n_cig = __builtin_amdgcn_readlane(g.n, src);
+			const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)cig_off, src);
+			const uint32_t *tmpc = L.cigar_tmp + (size_t)(2 * slot + which) * L.cigar_tmp_cap;
+			if (n_cig > 0) {
+				if ((unsigned long long)off + (unsigned)n_cig > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
+				else for (int k = lane; k < n_cig; k += 64) L.cigar_pool[off + k] = tmpc[n_cig - 1 - k];
+			}
 		}
-		if (lane == 0) {
+		if (lane == 0 || (lane == 32 && hasB)) {
 			KswRes R;
 			R.max = 0, R.zdropped = 0, R.max_q = R.max_t = -1, R.mqe = R.mte = KSW_NEG_INF, R.mqe_t = R.mte_q = -1;
-			R.score = H0, R.n_cigar = n_cig, R.reach_end = 0, R.cigar_off = cig_off;
+			R.score = isB ? H0B : H0A, R.n_cigar = g.n, R.reach_end = 0, R.cigar_off = cig_off;
 			R.zd_max = zd_max, R.zd_t0 = zd_t0, R.zd_t1 = zd_t1, R.zd_q0 = zd_q0, R.zd_q1 = zd_q1;
-			L.res[jid] = R;
+			L.res[isB ? jidB : jidA] = R;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();

@@ -21,7 +21,7 @@ const Tier kTiers[kNTiers] = { {128, 4}, {192, 4}, {256, 4}, {320, 4}, {384, 4},
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
 constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: 81 VGPRs -> 5 waves/SIMD
-const int kFastBlocksPerCU[kFirstExact] = { 5, 5, 5, 4, 4, 3 } /* waves per SIMD the kernels are compiled for */;
+const int kFastBlocksPerCU[kFirstExact] = { 4, 4, 4, 3, 3, 2 } /* waves per SIMD the kernels are compiled for */;
 
 // A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
 // score (the gap-fill call, align.c:838), default substitution scores, and a band that cannot bind.
@@ -156,10 +156,11 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 				blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
 			}
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
-			P.n_slots = std::min<size_t>(P.end - P.beg, (size_t)n_cu * blocks_per_cu * wpb);
-			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / P.slot_bytes));
+			const size_t per_slot = fast ? 2 : 1; // the gap-fill kernel runs two jobs per wave
+			P.n_slots = std::min<size_t>((P.end - P.beg + per_slot - 1) / per_slot, (size_t)n_cu * blocks_per_cu * wpb);
+			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
-			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap);
+			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
 		}
 		d_dir.ensure(need_dir, 1.0);
 		d_cigar_tmp.ensure(need_tmp, 1.0);

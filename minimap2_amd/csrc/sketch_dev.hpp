@@ -36,6 +36,16 @@ __device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, in
                                              uint64_t *bx, uint64_t *by, int stride, Emit emit)
 {
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	// bases are fetched eight at a time (one aligned 64-bit load per eight positions instead of a byte load per position: lanes
+	// walk different chunks, so every byte load is its own memory transaction).  The buffers this runs on are 256-byte aligned
+	// and padded, which makes the aligned-down / aligned-up accesses safe.
+	uint64_t wbuf = 0;
+	uintptr_t wcur = ~(uintptr_t)0;
+	auto base_at = [&](int64_t i) -> int {
+		const uintptr_t adr = (uintptr_t)(seq + i), al = adr & ~(uintptr_t)7;
+		if (al != wcur) { wbuf = *(const uint64_t *)al; wcur = al; }
+		return (int)(wbuf >> ((adr & 7) << 3) & 0xff);
+	};
 	int64_t warm = 2 * (w + k) + 32;
 	for (;;) {
 		int64_t ws = cs - warm;
@@ -45,7 +55,7 @@ __device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, in
 		if (ws > 0) {
 			int got = 0;
 			uint64_t packed = 0; // digit d = the valid base at distance d+1 before ws
-			for (int64_t j = ws - 1; j >= 0 && got < k; --j) { const uint8_t c = seq[j]; if (c < 4) { packed |= (uint64_t)c << (2 * got); ++got; } }
+			for (int64_t j = ws - 1; j >= 0 && got < k; --j) { const int c = base_at(j); if (c < 4) { packed |= (uint64_t)c << (2 * got); ++got; } }
 			for (int d = got - 1; d >= 0; --d) { // replay the reference's shifts, oldest base first
 				const uint64_t c = packed >> (2 * d) & 3ULL;
 				kmer0 = (kmer0 << 2 | c) & mask;
@@ -63,7 +73,7 @@ __device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, in
 			// everything owned has been emitted: the window holds no valid k-mer, or its minimum lies past the chunk and the
 			// first-full-window rule (which may still emit an older equal-hash slot) can no longer fire on owned slots
 			if (i >= ce && (min_x == UINT64_MAX || ((int64_t)((uint32_t)min_y >> 1) >= ce && l >= w + k - 1))) break;
-			const int c = seq[i];
+			const int c = base_at(i);
 			uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
 			if (c < 4) {
 				const int kmer_span = l + 1 < k ? l + 1 : k;
