@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast
 		const int qlenA = JA.qlen, tlenA = JA.tlen, qlenB = hasB ? JB.qlen : 0, tlenB = hasB ? JB.tlen : 0;
 		const int ncolA = (tlenA + 63) & ~63, ncolB = (tlenB + 63) & ~63;
 		uint8_t *dirA = L.dir_pool + (size_t)(2 * slot) * L.slot_bytes, *dirB = dirA + L.slot_bytes;
-		uint8_t *qbA = s_q[wave_in_block][0], *qbB = s_q[wave_in_block][1], *tbA = s_t[wave_in_block][0], *tbB = s_t[wave_in_block][1];
+		uint8_t *qbA = s_q[wave_in_block][0], *qbB = s_q[wave_in_block][1], /* qbB == qbA + FAST_QCAP */ *tbA = s_t[wave_in_block][0], *tbB = s_t[wave_in_block][1];
 		// ---- operands: query bytes to LDS, one packed target base pair per (register set, lane) ----
 		for (int i = lane; i < qlenA; i += 64) qbA[i] = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)i : JA.q_off + (uint64_t)i];
 		for (int i = lane; i < qlenB; i += 64) qbB[i] = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)i : JB.q_off + (uint64_t)i];
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast
 			int st0B = r - qlenB + 1 > 0 ? r - qlenB + 1 : 0, en0B = r < tlenB - 1 ? r : tlenB - 1;
 			if (r >= n_rowsA) st0A = 1, en0A = 0;
 			if (r >= n_rowsB) st0B = 1, en0B = 0;
+			const uint32_t wA = (uint32_t)(en0A - st0A + 1), wB = (uint32_t)(en0B - st0B + 1); // widths (0 when empty)
 			const int lo = st0A <= en0A ? (st0B <= en0B && st0B < st0A ? st0B : st0A) : st0B, hi = en0A > en0B ? en0A : en0B; // union (hi < lo if both empty)
 			// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163): depends on r only, so it is shared
 			const int bnd = r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
@@ -158,7 +159,9 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast
 			for (int c = NC - 1; c >= 0; --c) {
 				if (c * 64 > hi || c * 64 + 63 < lo) continue; // register set outside both anti-diagonals (uniform)
 				const int t = c * 64 + lane;
-				const bool actA = t >= st0A && t <= en0A, actB = t >= st0B && t <= en0B;
+				// one unsigned compare per job: st0 <= t <= en0 (an empty interval has en0 - st0 = -1 -> no lane passes... as unsigned it
+				// would pass everything, so empty intervals are encoded with wA/wB = 0 and an impossible start)
+				const bool actA = (uint32_t)(t - st0A) < wA, actB = (uint32_t)(t - st0B) < wB;
 				uint32_t cV = P_BND, cX = P_NQE, cX2 = P_NQE2; // column -1: the matrix border
 				if (c > 0) cV = __builtin_amdgcn_readlane(V[c - 1], 63), cX = __builtin_amdgcn_readlane(X[c - 1], 63), cX2 = __builtin_amdgcn_readlane(X2[c - 1], 63);
 				const uint32_t vp = dpp_shr1u(cV, V[c]), xp = dpp_shr1u(cX, X[c]), x2p = dpp_shr1u(cX2, X2[c]);
@@ -166,9 +169,14 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast
 					const uint32_t em = lane == edge_lane ? edge_halves : 0u;
 					U[c] = bfi(em, P_BND, U[c]), Y[c] = bfi(em, P_NQE, Y[c]), Y2[c] = bfi(em, P_NQE2, Y2[c]);
 				}
-				if (actA || actB) {
-					const uint32_t mask = (actA ? 0xffffu : 0u) | (actB ? 0xffff0000u : 0u);
-					const uint32_t qv = (uint32_t)qbA[actA ? r - t : 0] | (uint32_t)qbB[actB ? r - t : 0] << 16, tv = T[c];
+				{
+					// Every lane of the set computes, active or not: a column's registers are only ever read while the column (or its
+					// right neighbour's next cell) is valid -- a column that has not started yet gets u,y,y2 from the border and x,v from
+					// its left neighbour on its first cell, a finished one is never looked at again -- so whatever idle lanes leave in
+					// their registers is harmless, and no per-lane masking of the state update is needed.  Only the stores are guarded.
+					int rt = r - t;
+					rt = rt < 0 ? 0 : rt > FAST_QCAP - 1 ? FAST_QCAP - 1 : rt;
+					const uint32_t qv = (uint32_t)qbA[rt] | (uint32_t)qbA[rt + FAST_QCAP] << 16, tv = T[c]; // qbB = qbA + FAST_QCAP
 					// substitution score: match / mismatch, overridden by sc_N when either base is ambiguous (code 4: bit 2)
 					uint32_t z = pk_mad(pk_minu(tv ^ qv, P_ONE), P_MISD, P_MCH);
 					z = pk_mad(pk_shr2(tv | qv), pk_sub(P_SCN, z), z);
@@ -180,7 +188,7 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast
 					const uint32_t ne_b = pk_minu(pk_sub(z4, b), P_ONE), ne_a2 = pk_minu(pk_sub(z4, a2), P_ONE);
 					uint32_t d = pk_mul(ne_s, pk_mad(ne_a, pk_mad(ne_b, pk_add(ne_a2, P_ONE), P_ONE), P_ONE));
 					z = pk_min(z4, P_MCH);
-					const uint32_t un = pk_sub(z, vp), vn = pk_sub(z, ut);
+					U[c] = pk_sub(z, vp), V[c] = pk_sub(z, ut);
 					uint32_t tmp = pk_sub(z, P_Q);
 					a = pk_sub(a, tmp), b = pk_sub(b, tmp);
 					tmp = pk_sub(z, P_Q2);
@@ -190,11 +198,9 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : NC <= 6 ? 3 : 2)) ksw_fast
 					d = pk_mad(pk_minu(mb, P_ONE), P_16, d);
 					d = pk_mad(pk_minu(ma2, P_ONE), P_32, d);
 					d = pk_mad(pk_minu(mb2, P_ONE), P_64, d);
-					U[c] = bfi(mask, un, U[c]), V[c] = bfi(mask, vn, V[c]);
-					X[c] = bfi(mask, pk_sub(ma, P_QE), X[c]), Y[c] = bfi(mask, pk_sub(mb, P_QE), Y[c]);
-					X2[c] = bfi(mask, pk_sub(ma2, P_QE2), X2[c]), Y2[c] = bfi(mask, pk_sub(mb2, P_QE2), Y2[c]);
-					if (actA) prA[t] = (uint8_t)d;
-					if (actB) prB[t] = (uint8_t)(d >> 16);
+					X[c] = pk_sub(ma, P_QE), Y[c] = pk_sub(mb, P_QE), X2[c] = pk_sub(ma2, P_QE2), Y2[c] = pk_sub(mb2, P_QE2);
+					if (actA) prA[(uint32_t)t] = (uint8_t)d;
+					if (actB) prB[(uint32_t)t] = (uint8_t)(d >> 16);
 				}
 				if (topA) { if (edge_set == c) H0A += (int16_t)__builtin_amdgcn_readlane(U[c], edge_lane); }
 				else if (r < n_rowsA && last_setA == c) H0A += (int16_t)__builtin_amdgcn_readlane(V[c], last_laneA);
