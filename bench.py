@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ref-mb", type=float, default=3000.0)
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step")
-    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: all cores / gpus)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / gpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
     a = ap.parse_args()
@@ -98,7 +98,7 @@ def main():
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     os.environ.setdefault("MM2AMD_DEVICE", str(local_rank))
     ncpu = os.cpu_count() or 1
-    n_threads = a.threads if a.threads > 0 else max(1, ncpu // max(world, 1))
+    n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
 
     import torch
     import torch.distributed as dist
@@ -220,14 +220,21 @@ def main():
             del keys, val_off, pos
             mo = drv.map_opt("map-ont", extra_flag=mm.F_OUT_SAM)
             log("reference mm_idx_t adopted from the exported tables in %.1f s (mid_occ %d)" % (time.time() - t0, mo.mid_occ))
+            # give the reference its best thread count on this host (it does not always scale to every hardware thread)
+            probe = named[:min(2000, len(named))]
+            best_thr, best_rate = ncpu, 0.0
+            for thr in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4)}, reverse=True):
+                t_probe, nr, rg = drv.map(mo, probe, thr)
+                L.mm2amd_free_regs(len(nr), nr, rg)
+                rate = len(probe) / max(t_probe, 1e-3)
+                log("reference probe: %d threads -> %.0f reads/s" % (thr, rate))
+                if rate > best_rate:
+                    best_thr, best_rate = thr, rate
             n_s = a.cpu_sample
             if n_s <= 0:
-                t_probe, nr, rg = drv.map(mo, named[:min(2000, len(named))])
-                L.mm2amd_free_regs(len(nr), nr, rg)
-                rate = min(2000, len(named)) / max(t_probe, 1e-3)
-                n_s = int(min(len(named), max(2000, rate * 10.0)))
+                n_s = int(min(len(named), max(2000, best_rate * 10.0)))
             sample = named[:n_s]
-            t_cpu, nr, rg = drv.map(mo, sample)
+            t_cpu, nr, rg = drv.map(mo, sample, best_thr)
             # parity spot check on the sample: the GPU path must reproduce the reference's hit records byte for byte
             want = shard.pack_hits(L, nr, rg).numpy().tobytes()
             L.mm2amd_free_regs(len(nr), nr, rg)
@@ -236,8 +243,8 @@ def main():
             got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
             al.free_raw(n_reg, reg)
             sb = sum(len(r[1]) for r in sample)
-            cpu = {"value": round(sb / t_cpu / 1e9, 5), "unit": "Gbases/s", "cores": ncpu, "kind": "reference",
-                   "sample": "%d of the batch's reads (%.3f Gbases), mm_map on %d threads (kt_for), mapping loop only, same index contents" % (n_s, sb / 1e9, ncpu),
+            cpu = {"value": round(sb / t_cpu / 1e9, 5), "unit": "Gbases/s", "cores": best_thr, "kind": "reference",
+                   "sample": "%d of the batch's reads (%.3f Gbases), mm_map on %d threads (kt_for; best of %d/%d/%d threads on a 2000-read probe), mapping loop only, same index contents" % (n_s, sb / 1e9, best_thr, ncpu, ncpu // 2, ncpu // 4),
                    "hits_identical_to_gpu": got == want}
             drv.close()
         except Exception as e:  # the baseline is reported, never required

@@ -50,14 +50,14 @@ struct Lane {
 class HipBackend : public Backend {
 public:
 	// `tables` may be null: the backend then mirrors the host tables of `fi` (an index flattened from a reference mm_idx_t)
-	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables) : fi_(fi), T_(tables)
+	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables, int n_threads) : fi_(fi), T_(tables)
 	{
 		DeviceCtx &d = device_ctx();
 		std::lock_guard<std::mutex> lk(d.mu);
 		ensure_device(d);
 		stream_ = d.stream;
 		n_cu_ = d.n_cu;
-		n_threads_ = std::max(1u, std::thread::hardware_concurrency());
+		n_threads_ = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
 		if (!T_) { own_.upload(fi, stream_); T_ = &own_; }
 		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
@@ -225,7 +225,7 @@ private:
 
 } // namespace
 
-Backend *make_backend(const FlatIndex &fi, void *device_tables) { return new HipBackend(fi, (DeviceIndexTables *)device_tables); }
+Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads) { return new HipBackend(fi, (DeviceIndexTables *)device_tables, n_threads); }
 const char *backend_name() { return "hip:gfx950"; }
 
 } // namespace mm2amd

@@ -1,5 +1,6 @@
 // Drop-in boundary: the entry points a minimap2 build calls instead of kt_for(worker_for) (map.c:576).
 // Declared in include/mm2amd.h; the backend (HIP in the product) is supplied by make_backend().
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -12,7 +13,7 @@
 #include "threads.hpp"
 
 namespace mm2amd {
-Backend *make_backend(const FlatIndex &fi, void *device_tables); // backend_hip.cpp in the product
+Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads); // backend_hip.cpp in the product
 const char *backend_name();
 void capi_set_error(const std::string &msg);              // capi_common.cpp
 int capi_fail(int code, const std::string &msg);
@@ -29,6 +30,7 @@ struct MapContext {
 	ref::MapOpt opt;
 	std::vector<ReadView> staged;
 	bool has_staged = false;
+	int n_threads = 1;
 	std::unique_ptr<Backend> be;
 	std::unique_ptr<Mapper> mapper;
 };
@@ -47,9 +49,10 @@ int mm_gpu_init(const void *mi, const void *opt, int n_threads)
 		c->opt = *(const ref::MapOpt *)opt;
 		c->fi_own.from_reference((const ref::Idx *)mi);
 		c->fi = &c->fi_own;
-		if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
-		c->be.reset(make_backend(*c->fi, nullptr));
+		if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU
+		c->be.reset(make_backend(*c->fi, nullptr, n_threads));
 		c->mapper.reset(new Mapper(*c->fi, c->opt, *c->be, n_threads));
+		c->n_threads = n_threads;
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -68,9 +71,10 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
 		std::unique_ptr<MapContext> c(new MapContext);
 		c->opt = *(const ref::MapOpt *)opt;
 		c->fi = &index_flat((const IndexHandle *)idx);
-		if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
-		c->be.reset(make_backend(*c->fi, index_device_tables((const IndexHandle *)idx)));
+		if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU
+		c->be.reset(make_backend(*c->fi, index_device_tables((const IndexHandle *)idx), n_threads));
 		c->mapper.reset(new Mapper(*c->fi, c->opt, *c->be, n_threads));
+		c->n_threads = n_threads;
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -95,7 +99,7 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 
 static void hand_over(int n_frag, const int *seg_off, std::vector<ReadResult> &out, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
-	parallel_for((int)std::thread::hardware_concurrency(), n_frag, [&](long i, int) {
+	parallel_for(g_ctx ? g_ctx->n_threads : 1, n_frag, [&](long i, int) {
 		const int o = seg_off ? seg_off[i] : i;
 		const size_t n = out[i].regs.size();
 		n_reg[o] = (int)n;

@@ -109,7 +109,7 @@ private:
 
 } // namespace
 
-Backend *make_backend(const FlatIndex &fi, void * /*device_tables*/) { return new CheckBackend(fi); }
+Backend *make_backend(const FlatIndex &fi, void * /*device_tables*/, int /*n_threads*/) { return new CheckBackend(fi); }
 const char *backend_name() { return "cpu-check(oracle)"; }
 // the check library has no device-built index objects
 struct IndexHandle;

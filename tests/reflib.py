@@ -304,14 +304,14 @@ class RefDriver(object):
         self.D.mm_mapopt_update(C.byref(mo), self.mi)
         return mo
 
-    def map(self, mo, reads):
+    def map(self, mo, reads, n_threads=None):
         """reads: list of (name, seq) -> (wall seconds of the mm_map loop, n_reg, reg) ; free with mm2amd_free_regs-like free_regs()"""
         n = len(reads)
         names = (C.c_char_p * n)(*[(r[0].encode() if isinstance(r[0], str) else r[0]) for r in reads])
         seqs = (C.c_char_p * n)(*[r[1] for r in reads])
         lens = (C.c_int * n)(*[len(r[1]) for r in reads])
         n_reg, reg = (C.c_int * n)(), (C.c_void_p * n)()
-        t = self.D.refdrv_map(self.mi, C.byref(mo), n, seqs, lens, names, self.n_threads, n_reg, reg)
+        t = self.D.refdrv_map(self.mi, C.byref(mo), n, seqs, lens, names, n_threads or self.n_threads, n_reg, reg)
         return t, n_reg, reg
 
     def close(self):
