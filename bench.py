@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step")
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / gpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "map-hifi", "lr:hq"], help="map-ont is the BASELINE.json metric; the others are for experiments")
+    ap.add_argument("--read-len", type=int, default=0, help="mean read length (0: 10000 for map-ont, 15000 otherwise)")
+    ap.add_argument("--err", type=float, default=-1.0, help="per-base error rate (<0: 0.12 for map-ont, 0.005 otherwise)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
     a = ap.parse_args()
 
@@ -118,13 +121,15 @@ def main():
     names = ["chr%d" % (i + 1) for i in range(n_contig)]
     log("rank %d: reference %d Mb in %d contigs generated in %.1f s" % (rank, total // 1000000, n_contig, time.time() - t0))
     t0 = time.time()
-    reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, 10000, 1000, 0.12)
+    mean_len = a.read_len if a.read_len > 0 else (10000 if a.preset == "map-ont" else 15000)
+    err = a.err if a.err >= 0 else (0.12 if a.preset == "map-ont" else 0.005)
+    reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, mean_len // 10, err)
     del codes
     torch.cuda.empty_cache()
     batch_bases = sum(len(r) for r in reads)
     log("rank %d: %d reads, %.3f Gbases generated in %.1f s" % (rank, len(reads), batch_bases / 1e9, time.time() - t0))
     t0 = time.time()
-    al = mm.Aligner(refs, preset="map-ont", names=names, n_threads=n_threads, sam=True)
+    al = mm.Aligner(refs, preset=a.preset, names=names, n_threads=n_threads, sam=True)
     t_index = time.time() - t0
     st = al.index_stat()
     log("rank %d: device index built in %.1f s: %d distinct minimizers, %d positions, mid_occ=%d" % (rank, t_index, st["n_distinct"], st["n_minimizers"], al.map_opt.mid_occ))
@@ -145,7 +150,7 @@ def main():
         barrier()
         t = time.time()
         n_reg, reg, _ = al.run(raw=True)
-        if world > 1:  # final hit gather to the formatting rank
+        if world > 1 or os.environ.get("MM2AMD_BENCH_FORCE_GATHER"):  # final hit gather to the formatting rank
             payload = shard.pack_hits(L, n_reg, reg).to(dev)
             shard.gather_payloads(payload, dst=0, device=dev)
         barrier()
@@ -218,7 +223,7 @@ def main():
             S, keys, val_off, pos = reflib.export_index(al)
             drv = reflib.RefDriver(st["w"], st["k"], st["flag"], names, al.lens, S, keys, val_off, pos, ncpu)
             del keys, val_off, pos
-            mo = drv.map_opt("map-ont", extra_flag=mm.F_OUT_SAM)
+            mo = drv.map_opt(a.preset, extra_flag=mm.F_OUT_SAM)
             log("reference mm_idx_t adopted from the exported tables in %.1f s (mid_occ %d)" % (time.time() - t0, mo.mid_occ))
             # give the reference its best thread count on this host (it does not always scale to every hardware thread)
             probe = named[:min(2000, len(named))]
@@ -250,10 +255,10 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "Gbases/s", "cores": ncpu, "kind": "reference", "sample": "unavailable: %s" % e}
 
-    out = {"metric": "aligned Gbases/sec (map-ont, 10 kb reads, -a)", "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
+    out = {"metric": "aligned Gbases/sec (%s, %d kb reads, -a)" % (a.preset, mean_len // 1000), "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
-           "config": {"workload": "map-ont: %d synthetic ~10 kb 12%%-error reads per GPU vs %d Mb synthetic ref (24 contigs), -a" % (a.reads, total // 1000000),
+           "config": {"workload": "%s: %d synthetic ~%d kb %g%%-error reads per GPU vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, mean_len // 1000, err * 100, total // 1000000),
                       "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads,
                       "parallelism": "replicated index, reads sharded %d-way, RCCL hit gather" % world if world > 1 else "1 GPU",
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},

@@ -54,6 +54,8 @@ def gather_payloads(payload, dst=0, device=None):
     """The final hit gather: every rank contributes one uint8 payload, rank `dst` receives them in rank order.
     Sizes travel in one all_gather; the data in one gather of equally padded buffers (one xGMI hop per peer).
     Returns the list of payload tensors on dst, None elsewhere."""
+    if not dist.is_initialized():  # single process: the gather is the identity
+        return [payload]
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else payload.device
     size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)

@@ -1,0 +1,112 @@
+"""BASELINE.json's full-size configuration on the GPU (3 Gb reference, ~10 kb ONT-like reads), checked through properties that
+do not need an oracle run over everything -- plus exact parity with the reference on a sample, through the reference's own
+mm_map against an mm_idx_t adopted from our device-built tables (oracle/_ref/librefdrv.so):
+  * every read maps, its primary hit lands on the position it was generated from, on the right strand;
+  * each CIGAR consumes exactly the query span and the reference span its hit reports;
+  * mapping the same batch twice, and in a different read order, gives identical hit records (no cross-read state);
+  * the packed hit records survive pack -> unpack -> pack unchanged."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import reflib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    import bench
+    import minimap2_amd as mm
+    dev = torch.device("cuda", 0)
+    n_contig, total = 24, 3000 * 1000 * 1000
+    codes, refs, per = bench.gen_reference(torch, dev, 11, total, n_contig)
+    # reads with known origin: same generator as bench.py, but we keep the placement
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    n_reads = 6000
+    reads = bench.gen_reads(torch, dev, 4242, codes, per, n_contig, n_reads, 10000, 1000, 0.12)
+    # replay the generator's placement draws (same seed, same call order as bench.gen_reads)
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(4242)
+    lens = torch.clamp((torch.randn(n_reads, device=dev, generator=g2) * 1000 + 10000).long(), 1000, per)
+    cid = torch.randint(0, n_contig, (n_reads,), device=dev, generator=g2)
+    st = (torch.rand(n_reads, device=dev, generator=g2, dtype=torch.float64) * (per - lens + 1).double()).long()
+    rev = torch.rand(n_reads, device=dev, generator=g2) < 0.5
+    truth = list(zip(cid.cpu().tolist(), st.cpu().tolist(), lens.cpu().tolist(), rev.cpu().tolist()))
+    del codes
+    torch.cuda.empty_cache()
+    names = ["chr%d" % (i + 1) for i in range(n_contig)]
+    al = mm.Aligner(refs, preset="map-ont", names=names, n_threads=32, sam=True)
+    named = [("read%d" % i, s) for i, s in enumerate(reads)]
+    yield al, named, truth, names
+    al.close()
+
+
+def _keys(hits):
+    return [[a.key() for a in h] for h in hits]
+
+
+def test_reads_map_to_their_origin_and_cigars_are_consistent(world):
+    al, named, truth, names = world
+    hits = al.map_batch(named)
+    n_right = 0
+    for (nm, seq), h, (c, st, ln, rev) in zip(named, hits, truth):
+        assert h, nm
+        p = h[0]
+        assert p.is_primary
+        q_used = sum(x >> 4 for x in p.cigar if (x & 0xf) in (0, 1, 7, 8))
+        r_used = sum(x >> 4 for x in p.cigar if (x & 0xf) in (0, 2, 3, 7, 8))
+        assert q_used == p.q_en - p.q_st and r_used == p.r_en - p.r_st, nm
+        assert 0 <= p.q_st < p.q_en <= len(seq)
+        if p.rid == c and p.strand == (-1 if rev else 1) and p.r_st < st + ln and p.r_en > st and min(p.r_en, st + ln) - max(p.r_st, st) > 0.8 * ln:
+            n_right += 1
+    assert n_right >= 0.995 * len(named)
+
+
+def test_batch_order_and_repetition_do_not_change_results(world):
+    al, named, truth, names = world
+    sub = named[:1500]
+    a = _keys(al.map_batch(sub))
+    b = _keys(al.map_batch(sub))
+    perm = np.random.default_rng(3).permutation(len(sub))
+    c = _keys(al.map_batch([sub[i] for i in perm]))
+    assert a == b
+    assert [c[k] for k in np.argsort(perm)] == a
+
+
+def test_sample_parity_with_reference_and_payload_round_trip(world):
+    import minimap2_amd as mm
+    from minimap2_amd import shard
+    al, named, truth, names = world
+    if not os.path.exists(reflib.REFDRV_SO):
+        pytest.skip("oracle/_ref/librefdrv.so not present")
+    L = mm.lib()
+    st = al.index_stat()
+    S, keys, val_off, pos = reflib.export_index(al)
+    drv = reflib.RefDriver(st["w"], st["k"], st["flag"], names, al.lens, S, keys, val_off, pos, 64)
+    del keys, val_off, pos
+    mo = drv.map_opt("map-ont", extra_flag=mm.F_OUT_SAM)
+    assert mo.mid_occ == al.map_opt.mid_occ
+    sample = named[:2500]
+    _, nr, rg = drv.map(mo, sample, 64)
+    want = shard.pack_hits(L, nr, rg).numpy().tobytes()
+    L.mm2amd_free_regs(len(nr), nr, rg)
+    drv.close()
+    al.stage(sample)
+    n_reg, reg, _ = al.run(raw=True)
+    got = shard.pack_hits(L, n_reg, reg).numpy()
+    al.free_raw(n_reg, reg)
+    assert got.tobytes() == want
+    n2, r2 = shard.unpack_hits(L, got, len(sample))
+    again = shard.pack_hits(L, n2, r2).numpy().tobytes()
+    L.mm2amd_free_regs(len(n2), n2, r2)
+    assert again == want
