@@ -165,16 +165,21 @@ void mm2amd_free_regs(int n_frag, int *n_reg, void **reg)
 int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t *buf, int64_t cap)
 {
 	if (n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_pack_regs: bad arguments");
-	int64_t need = 0;
-	for (int i = 0; i < n_frag; ++i) {
-		need += 4;
+	// sizes first (prefix sums give every fragment its slot), then the copies, both on the pool threads
+	const int nt = g_ctx ? g_ctx->n_threads : 1;
+	std::vector<int64_t> off((size_t)n_frag + 1, 0);
+	parallel_for(nt, n_frag, [&](long i, int) {
+		int64_t sz = 4;
 		const ref::Reg1 *r = (const ref::Reg1 *)reg[i];
-		for (int j = 0; j < n_reg[i]; ++j) need += (int64_t)sizeof(ref::Reg1) + 4 + (r[j].p ? (int64_t)sizeof(ref::Extra) + 4ll * r[j].p->n_cigar : 0);
-	}
+		for (int j = 0; j < n_reg[i]; ++j) sz += (int64_t)sizeof(ref::Reg1) + 4 + (r[j].p ? (int64_t)sizeof(ref::Extra) + 4ll * r[j].p->n_cigar : 0);
+		off[i + 1] = sz;
+	}, 1024);
+	for (int i = 0; i < n_frag; ++i) off[i + 1] += off[i];
+	const int64_t need = off[n_frag];
 	if (!buf) return need;
 	if (cap < need) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm2amd_pack_regs: buffer too small");
-	uint8_t *o = buf;
-	for (int i = 0; i < n_frag; ++i) {
+	parallel_for(nt, n_frag, [&](long i, int) {
+		uint8_t *o = buf + off[i];
 		const int32_t n = n_reg[i];
 		memcpy(o, &n, 4), o += 4;
 		const ref::Reg1 *r = (const ref::Reg1 *)reg[i];
@@ -187,7 +192,7 @@ int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t
 			memcpy(o, &has, 4), o += 4;
 			if (ex) { const size_t nb = sizeof(ref::Extra) + 4ull * ex->n_cigar; memcpy(o, ex, nb), o += nb; }
 		}
-	}
+	}, 1024);
 	return need;
 }
 
