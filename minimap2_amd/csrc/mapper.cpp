@@ -28,7 +28,6 @@ inline uint32_t x31_hash(const char *s) // __ac_X31_hash_string, khash.h:383-388
 	if (h) for (++s; *s; ++s) h = (h << 5) - h + (uint32_t)*s;
 	return h;
 }
-std::atomic<long long> g_dbg[8];
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 
@@ -137,7 +136,6 @@ void Mapper::run(std::vector<ReadResult> &out)
 	for (int l = 1; l < n_drivers; ++l) th.emplace_back(driver, l);
 	driver(0);
 	for (auto &t : th) t.join();
-	if (getenv("MM2AMD_DBG_PRE")) { fprintf(stderr, "[pre] gen_regs %.3f parent/sub %.3f est_err %.3f begin_read %.3f thread-s\n", g_dbg[0] * 1e-9, g_dbg[1] * 1e-9, g_dbg[2] * 1e-9, g_dbg[3] * 1e-9); for (auto &x : g_dbg) x = 0; }
 	Trace::get().flush();
 	if (first_err) std::rethrow_exception(first_err);
 	(void)t0;
@@ -187,19 +185,14 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			res.frag_gap = sp.max_gap_ref, res.rep_len = c.rep_len;
 			RegVec &r0 = regs0[i];
-			double tq = now();
 			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, false, r0);
-			g_dbg[0] += (long long)((now() - tq) * 1e9); tq = now();
 			if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
 				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
 				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
 			}
-			g_dbg[1] += (long long)((now() - tq) * 1e9); tq = now();
 			est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 			filter_strand_retained(r0);
-			g_dbg[2] += (long long)((now() - tq) * 1e9); tq = now();
 			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i], ds.q4.data() + ds.q4_off[i]);
-			g_dbg[3] += (long long)((now() - tq) * 1e9);
 		});
 		Trace::get().add(lane, "host:pre", t0, now());
 		stats.t_host_pre += now() - t0;
