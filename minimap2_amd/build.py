@@ -14,7 +14,6 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmm2amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HOSTCXX = os.environ.get("CXX", "g++")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
@@ -39,8 +38,8 @@ def _compile(src, force, hdr_t):
         return obj
     if src.endswith(".hip"):
         cmd = [HIPCC] + COMMON + ["-x", "hip", "-c", path, "-o", obj]
-    else:  # host-only translation units: plain C++ with the HIP runtime headers
-        cmd = [HOSTCXX, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+    else:  # host-only translation units: the same compiler driver, host pass only
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-I" + os.path.join(os.path.dirname(HERE), "include"), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

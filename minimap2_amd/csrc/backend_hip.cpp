@@ -50,7 +50,7 @@ struct Lane {
 class HipBackend : public Backend {
 public:
 	// `tables` may be null: the backend then mirrors the host tables of `fi` (an index flattened from a reference mm_idx_t)
-	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables, int n_threads) : fi_(fi), T_(tables)
+	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables, int n_threads) : T_(tables)
 	{
 		DeviceCtx &d = device_ctx();
 		std::lock_guard<std::mutex> lk(d.mu);
@@ -62,7 +62,7 @@ public:
 		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
 		while ((1ull << rid_bits_) < fi.n_seq) ++rid_bits_;
-		n_lanes_ = 3;
+		n_lanes_ = 5; // sub-batches in flight; beyond ~5 the GPU is saturated
 		if (const char *e = getenv("MM2AMD_LANES")) n_lanes_ = std::max(1, std::min(kMaxProfLanes, atoi(e)));
 		for (int i = 0; i < n_lanes_; ++i) {
 			lanes_.emplace_back(new Lane);
@@ -208,7 +208,6 @@ public:
 	}
 
 private:
-	const FlatIndex &fi_;
 	hipStream_t stream_ = nullptr;
 	int n_threads_ = 1, n_cu_ = 256, n_lanes_ = 1, rid_bits_ = 1;
 	DevIndex I_{};
