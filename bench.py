@@ -99,16 +99,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
-    os.environ.setdefault("MM2AMD_DEVICE", str(local_rank))
+    backend = os.environ.get("MM2AMD_BENCH_BACKEND", "nccl")  # "gloo": ranks share whatever GPUs exist (plumbing tests only)
     ncpu = os.cpu_count() or 1
     n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_id = local_rank % max(torch.cuda.device_count(), 1)
+    os.environ.setdefault("MM2AMD_DEVICE", str(dev_id))
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import minimap2_amd as mm
     from minimap2_amd import shard
@@ -151,8 +157,8 @@ def main():
         t = time.time()
         n_reg, reg, _ = al.run(raw=True)
         if world > 1 or os.environ.get("MM2AMD_BENCH_FORCE_GATHER"):  # final hit gather to the formatting rank
-            payload = shard.pack_hits(L, n_reg, reg).to(dev)
-            shard.gather_payloads(payload, dst=0, device=dev)
+            payload = shard.pack_hits(L, n_reg, reg).to(comm_dev)
+            shard.gather_payloads(payload, dst=0, device=comm_dev)
         barrier()
         dt = time.time() - t
         n_mapped = sum(1 for i in range(len(named)) if n_reg[i] > 0)
@@ -172,10 +178,10 @@ def main():
     mm.profile_enable(False)
     total_t = sum(times)
     if world > 1:
-        tt = torch.tensor([total_t], dtype=torch.float64, device=dev)
+        tt = torch.tensor([total_t], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         total_t = float(tt.item())
-        bb = torch.tensor([batch_bases], dtype=torch.float64, device=dev)
+        bb = torch.tensor([batch_bases], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(bb, op=dist.ReduceOp.SUM)
         all_bases = float(bb.item())
     else:
