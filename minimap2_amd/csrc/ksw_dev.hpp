@@ -69,6 +69,7 @@ struct KswLaunch {
 	size_t slot_bytes;
 	int32_t *counter;       // device, zeroed before launch: persistent-wave job queue head
 	int32_t max_T16, max_Q16; // LDS sizing: largest 16-rounded tlen / qlen in the launch
+	uint8_t *state_pool = nullptr; // when set: per-slot state slabs in HBM (ksw_lds_per_wave bytes each) instead of LDS
 	KswScoring sc;
 };
 

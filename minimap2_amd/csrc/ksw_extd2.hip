@@ -107,13 +107,21 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 	if (g.n > 0) g.c[g.n - 1] = g.last; // flush the run being accumulated
 }
 
+// LDS_STATE: the per-position state lives in LDS (jobs up to ~11 k positions).  The other instantiation keeps it in a per-wave
+// slab of HBM instead: slower, but it takes jobs of any length (very long gaps on real genomes), so that no input makes the
+// library give up.
+// ordering between the lanes of the wave: LDS needs a wavefront fence, the HBM-resident state a workgroup-scope one
+#define STATE_SYNC() do { if (LDS_STATE) { WAVE_SYNC(); } else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } } while (0)
+template <bool LDS_STATE>
 __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
 	const int slot = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
 	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
-	uint8_t *my = lds_raw + (size_t)wave_in_block * region;
+	uint8_t *my;
+	if (LDS_STATE) my = lds_raw + (size_t)wave_in_block * region;
+	else my = L.state_pool + (size_t)slot * region;
 	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
 	const int m = L.sc.m;
 
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				}
 				SFQ[T16 + i] = c;
 			}
-			WAVE_SYNC();
+			STATE_SYNC();
 
 			int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 			const int n_rows = qlen + tlen - 1;
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							((uint8_t *)&B[t])[2] = (uint8_t)L.sc.mat[SFQ[t] * m + SFQ[qoff + t]];
 					}
 				}
-				WAVE_SYNC();
+				STATE_SYNC();
 				// one sweep over [st,en], highest chunk first so that lane t still sees row r-1 at t-1
 				uint8_t *pr = dir + (size_t)r * ncol;
 				const int n_chunk = (en - st + 64) >> 6;
@@ -263,13 +271,13 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 						if (with_cigar) pr[t - st] = (uint8_t)d;
 					}
 				}
-				WAVE_SYNC();
+				STATE_SYNC();
 				if (!approx_max) { // exact row maximum in the reference's scan order (:325-365)
 					int max_H, max_t;
 					if (r > 0) {
 						const int Hen = en0 > 0 ? H[en0 - 1] + sx8(A[en0]) : H[en0] + sx8(A[en0] >> 8);
 						const int en1 = st0 + (en0 - st0) / 4 * 4;
-						WAVE_SYNC();
+						STATE_SYNC();
 						// candidate order: en0 first, then the 4-lane strided scan of [st0,en1), then the tail [en1,en0)
 						long long best = (long long)Hen << 32 | 0x7fffffffLL;
 						const int nq = (en1 - st0) >> 2;
@@ -290,11 +298,11 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							else max_t = en1 + (rank - 1 - 4 * (nq + 1));
 						}
 						if (lane == 0) H[en0] = Hen;
-						WAVE_SYNC();
+						STATE_SYNC();
 					} else {
 						max_H = sx8(A[0] >> 8) - qe_in, max_t = 0;
 						if (lane == 0) H[0] = max_H;
-						WAVE_SYNC();
+						STATE_SYNC();
 					}
 					const int Hen0 = H[en0], Hst0 = H[st0];
 					if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en0;
@@ -336,7 +344,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 					}
 				}
 			}
-			WAVE_SYNC();
+			STATE_SYNC();
 		}
 		if (lane == 0) {
 			KswRes R;
@@ -349,16 +357,23 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 	}
 }
 
+#undef STATE_SYNC
+
 void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream)
 {
 	if (L.n_jobs <= 0) return;
 	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
 	const size_t lds = region * waves_per_block;
+	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
+	if (L.state_pool) { // state in HBM: any job length
+		hipLaunchKernelGGL((ksw_extd2_kernel<false>), dim3(n_blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, L);
+		HIP_CHECK(hipGetLastError());
+		return;
+	}
 	if (lds > 160 * 1024) throw std::runtime_error("[mm2amd] ksw_extd2: job class does not fit LDS");
 	if (lds > 64 * 1024)
-		HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
-	hipLaunchKernelGGL(ksw_extd2_kernel, dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
+		HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((ksw_extd2_kernel<true>), dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -16,8 +16,8 @@ struct Tier { int max_dim; int waves_per_block; };
 // columns (its VGPR need, hence its occupancy, grows with the set count, so jobs run with the fewest sets that hold them);
 // 6..8: the lane-exact kernel (ksw_extd2.hip), jobs grouped by 16-rounded max(qlen,tlen) because its LDS need per wave is
 // 13*T16 + Q16 + 16.
-constexpr int kNTiers = 9, kFirstExact = 6;
-const Tier kTiers[kNTiers] = { {128, 4}, {192, 4}, {256, 4}, {320, 4}, {384, 4}, {512, 4}, {512, 4}, {2048, 1}, {11264, 1} };
+constexpr int kNTiers = 10, kFirstExact = 6, kHbmTier = 9; // the last class keeps its state in HBM and takes any length
+const Tier kTiers[kNTiers] = { {128, 4}, {192, 4}, {256, 4}, {320, 4}, {384, 4}, {512, 4}, {512, 4}, {2048, 1}, {11264, 1}, {1 << 30, 4} };
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
 constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: 81 VGPRs -> 5 waves/SIMD
@@ -70,8 +70,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (fast) { tier = 0; while (j.tlen > kTiers[tier].max_dim) ++tier; }
 			else {
 				tier = kFirstExact;
-				while (tier < kNTiers && dim > kTiers[tier].max_dim) ++tier;
-				if (tier == kNTiers) { st.too_big = true; tier = kNTiers - 1; }
+				while (tier < kNTiers - 1 && dim > kTiers[tier].max_dim) ++tier;
 			}
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 ? INT32_MAX : j.w + 1);
 			int cb = (int)(std::sqrt(cost) * (fast ? 1.0 : 0.25)); // fast classes: cost <= 1536*512; exact classes reach 11264*752
@@ -98,7 +97,6 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	size_t sum_len = 0;
 	ClassStat cls[kNTiers];
 	for (const ChunkStat &st : cstat) {
-		if (st.too_big) throw std::runtime_error("[mm2amd] ksw job larger than the LDS-resident kernel supports (qlen/tlen > 11264)");
 		sum_len += st.sum_len;
 		for (int t = 0; t < kNTiers; ++t) {
 			cls[t].alg_bytes += st.cls[t].alg_bytes;
@@ -126,6 +124,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	d_jobs.ensure(n);
 	d_res.ensure(n);
 	d_counter.ensure(16);
+	static_assert(kNTiers <= 16, "one queue counter per launch class");
 	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
 	KswRes *tr = tmp_res.ensure(n);
@@ -140,7 +139,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		// size every launch class first (one scratch allocation serves them all: the launches run back to back on one stream)
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
 		Plan plan[kNTiers];
-		size_t need_dir = 16, need_tmp = 16;
+		size_t need_dir = 16, need_tmp = 16, need_state = 0;
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			Plan &P = plan[tier];
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
@@ -151,6 +150,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const int wpb = kTiers[tier].waves_per_block;
 			int blocks_per_cu;
 			if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
+			else if (tier == kHbmTier) blocks_per_cu = 4;
 			else {
 				const size_t region = (ksw_lds_per_wave(P.max_T16, P.max_Q16) + 15) / 16 * 16;
 				blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
@@ -161,11 +161,13 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
+			if (tier == kHbmTier) need_state = P.n_slots * ((ksw_lds_per_wave(P.max_T16, P.max_Q16) + 15) / 16 * 16);
 		}
 		d_dir.ensure(need_dir, 1.0);
 		d_cigar_tmp.ensure(need_tmp, 1.0);
+		if (need_state) d_state.ensure(need_state, 1.0);
 		static const char *kNames[kNTiers] = { "ksw_fast_kernel<2>", "ksw_fast_kernel<3>", "ksw_fast_kernel<4>", "ksw_fast_kernel<5>", "ksw_fast_kernel<6>", "ksw_fast_kernel<8>",
-		                                       "ksw_extd2_kernel[t0]", "ksw_extd2_kernel[t1]", "ksw_extd2_kernel[t2]" };
+		                                       "ksw_extd2_kernel[t0]", "ksw_extd2_kernel[t1]", "ksw_extd2_kernel[t2]", "ksw_extd2_kernel[hbm]" };
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
 			if (P.end == P.beg) continue;
@@ -177,6 +179,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.dir_pool = d_dir.p, L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
 			L.max_T16 = P.max_T16, L.max_Q16 = P.max_Q16, L.sc = sc;
+			L.state_pool = tier == kHbmTier ? d_state.p : nullptr;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, kTiers[tier].waves_per_block, stream);

@@ -125,3 +125,16 @@ def test_register_resident_gap_fill_kernel(preset):
     finally:
         del os.environ["MM2AMD_KSW_EXACT_ONLY"]
     assert fast == exact
+
+
+def test_jobs_longer_than_lds_use_the_hbm_state_kernel():
+    """targets beyond the ~11 k positions the LDS-resident kernel holds: banded extension across a long gap and a long thin global job"""
+    rng = np.random.default_rng(21)
+    jobs = []
+    t = rng.integers(0, 4, 15000, dtype=np.uint8)
+    q = np.concatenate([t[:600], t[13000:13800]])            # 12.4 kb deletion in the query
+    jobs.append((q, t, 30001, 400, -1, 0x08))                # global, approximate score
+    jobs.append((q, t, 751, 400, 10, 0x40))                  # banded extension, exact maxima + Z-drop
+    q2, t2 = random_pair(rng, 12500, 0.1)
+    jobs.append((q2[:12000], t2[:12800], 751, 400, -1, 0xC2))
+    _run(jobs, "ont")
