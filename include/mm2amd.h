@@ -60,6 +60,10 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
                            int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
 
+/* Batched ksw_extz2_sse (ksw2_extz2_sse.c:25, ksw2.h:70-71): single-affine gap cost; same contract as above. */
+int mm2amd_ksw_extz2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape,
+                           mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
+
 /* ------------------------------------------------------------------------------------------------
  * Drop-in boundary: the batched replacement of kt_for(n_threads, worker_for, step, n_frag) (map.c:576).
  *

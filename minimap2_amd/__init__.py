@@ -103,6 +103,9 @@ def _bind(L):
         L.mm2amd_ksw_extd2_batch.restype = C.c_int
         L.mm2amd_ksw_extd2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int8,
                                              C.c_int8, C.POINTER(KswRes), C.POINTER(C.c_uint32), C.c_size_t]
+        L.mm2amd_ksw_extz2_batch.restype = C.c_int
+        L.mm2amd_ksw_extz2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.POINTER(KswRes),
+                                             C.POINTER(C.c_uint32), C.c_size_t]
         L.mm2amd_idx_str.restype = vp
         L.mm2amd_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.mm2amd_idx_destroy.argtypes = [vp]
@@ -142,6 +145,11 @@ def _check(rc, L=None):
         raise Mm2AmdError("mm2amd error %d: %s" % (rc, (L or lib()).mm2amd_last_error().decode()))
 
 
+def ksw_extz2_batch(jobs, mat, gapo, gape):
+    """single-affine twin of ksw_extd2_batch (ksw_extz2_sse)"""
+    return ksw_extd2_batch(jobs, mat, gapo, gape, None, None)
+
+
 def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2):
     """jobs: list of (query_bytes, target_bytes, w, zdrop, end_bonus, flag) with nt4 codes 0..4.
     Returns a list of (max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, cigar_tuple),
@@ -159,7 +167,10 @@ def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2):
         tot += len(qb) + len(tb)
     res = (KswRes * n)()
     pool = (C.c_uint32 * max(tot, 1))()
-    _check(lib().mm2amd_ksw_extd2_batch(n, arr, 5, bytes(mat), gapo, gape, gapo2, gape2, res, pool, max(tot, 1)))
+    if gapo2 is None:
+        _check(lib().mm2amd_ksw_extz2_batch(n, arr, 5, bytes(mat), gapo, gape, res, pool, max(tot, 1)))
+    else:
+        _check(lib().mm2amd_ksw_extd2_batch(n, arr, 5, bytes(mat), gapo, gape, gapo2, gape2, res, pool, max(tot, 1)))
     out = []
     for r in res:
         out.append((r.max, r.zdropped, r.max_q, r.max_t, r.mqe, r.mqe_t, r.mte, r.mte_q, r.score, r.reach_end,

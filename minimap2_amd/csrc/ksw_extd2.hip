@@ -112,7 +112,9 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 // library give up.
 // ordering between the lanes of the wave: LDS needs a wavefront fence, the HBM-resident state a workgroup-scope one
 #define STATE_SYNC() do { if (LDS_STATE) { WAVE_SYNC(); } else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } } while (0)
-template <bool LDS_STATE>
+// SINGLE: the single-affine recurrences of ksw_extz2_sse (ksw2_extz2_sse.c:25-311) instead of the dual-affine ones: scores
+// shifted by 2(q+e), unsigned second maximum and clamp (:49-50), zero-initialised state, two gap states only.
+template <bool LDS_STATE, bool SINGLE>
 __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -140,11 +142,11 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 
 		int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
 		const int qe_in = q + e; // taken before the swap (ksw2_extd2_sse.c:68 vs :78); seeds H(0,0)
-		if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
+		if (!SINGLE && q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
 		const int qe = q + e, qe2 = q2 + e2;
 		int min_sc = L.sc.mat[1];
 		for (int t = 1; t < m * m; ++t) min_sc = min_sc < L.sc.mat[t] ? min_sc : L.sc.mat[t];
-		const bool degenerate = m <= 1 || qlen <= 0 || tlen <= 0 || -min_sc > 2 * (q + e);
+		const bool degenerate = (SINGLE ? m <= 0 : m <= 1) || qlen <= 0 || tlen <= 0 || -min_sc > 2 * (q + e);
 		int w = J.w;
 		if (w < 0) w = tlen > qlen ? tlen : qlen;
 
@@ -152,7 +154,8 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 		else if (!degenerate) {
 			const bool with_cigar = !(flag & KSW_SCORE_ONLY), approx_max = flag & KSW_APPROX_MAX, right = flag & KSW_RIGHT;
 			const int sc_mch = L.sc.mat[0], sc_mis = L.sc.mat[1];
-			const int sc_N = L.sc.mat[m * m - 1] == 0 ? sx8(-e2) : L.sc.mat[m * m - 1];
+			const int sc_N = L.sc.mat[m * m - 1] == 0 ? sx8(SINGLE ? -e : -e2) : L.sc.mat[m * m - 1];
+			const int qe2s = (q + e) * 2, max_scu = (L.sc.mat[0] + (q + e) * 2) & 0xff; // single-affine: score shift and unsigned clamp (:69,:79)
 			const int T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
 			size_t ncol = qlen < tlen ? qlen : tlen;
 			ncol = (((ncol < (size_t)w + 1 ? ncol : (size_t)w + 1) + 15) / 16 + 1) * 16;
@@ -168,8 +171,8 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 
 			// ---- per-job initialisation (ksw2_extd2_sse.c:107-128) ----
 			for (int t = lane; t < T16; t += 64) {
-				A[t] = pack4(nqe, nqe, nqe, nqe);
-				B[t] = pack4(nqe2, nqe2, 0, 0);
+				A[t] = SINGLE ? 0u : pack4(nqe, nqe, nqe, nqe);
+				B[t] = SINGLE ? 0u : pack4(nqe2, nqe2, 0, 0);
 				H[t] = KSW_NEG_INF;
 				uint8_t c = 0;
 				if (t < tlen) {
@@ -195,15 +198,16 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				const int st0 = iv.st0, en0 = iv.en0, st = iv.st, en = iv.en;
 				if (st0 > en0) { ez.zdropped = 1; break; }
 				// boundary values (:148-163)
-				const int bnd = r == 0 ? nqe : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : sx8(-e2);
-				int x1 = nqe, x21 = nqe2, v1 = st > 0 ? nqe : bnd;
+				const int bnd = SINGLE ? (r ? q : 0) : r == 0 ? nqe : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : sx8(-e2);
+				const int init1 = SINGLE ? 0 : nqe, init2 = SINGLE ? 0 : nqe2; // value of a state byte that was never computed
+				int x1 = init1, x21 = init2, v1 = st > 0 ? init1 : bnd;
 				if (st > 0 && st - 1 >= last_st && st - 1 <= last_en) {
 					uint32_t a = A[st - 1], b = B[st - 1];
 					x1 = sx8(a >> 16), v1 = sx8(a >> 8), x21 = sx8(b);
 				}
 				if (en >= r && lane == 0) {
-					A[r] = (A[r] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(nqe & 0xff) << 24; // u[r], y[r]
-					B[r] = (B[r] & 0xffff00ffu) | (uint32_t)(nqe2 & 0xff) << 8;                            // y2[r]
+					A[r] = (A[r] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24; // u[r], y[r]
+					B[r] = (B[r] & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;                            // y2[r]
 				}
 				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes,
 				// and past T16 in the first bytes of the target copy exactly as in the reference's layout
@@ -236,53 +240,81 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							const uint32_t a_prev = A[t - 1], b_prev = B[t - 1];
 							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
 						}
-						const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), y2t = sx8(b_cur >> 8);
-						int z = sx8(b_cur >> 16);
-						int a = sx8(xt1 + vt1), b = sx8(yt + ut), a2 = sx8(x2t1 + vt1), b2 = sx8(y2t + ut), d;
-						if (!right) { // strictly greater wins (:235-243)
-							d = a > z ? 1 : 0;   z = z > a ? z : a;
-							d = b > z ? 2 : d;   z = z > b ? z : b;
-							d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
-							d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
-						} else {      // ties go to the gap state (:282-290)
-							d = z > a ? 0 : 1;   z = z > a ? z : a;
-							d = z > b ? d : 2;   z = z > b ? z : b;
-							d = z > a2 ? d : 3;  z = z > a2 ? z : a2;
-							d = z > b2 ? d : 4;  z = z > b2 ? z : b2;
-						}
-						z = z < sc_mch ? z : sc_mch;
-						const int un = z - vt1, vn = z - ut;
-						int tmp = sx8(z - q);   a = sx8(a - tmp),   b = sx8(b - tmp);
-						tmp = sx8(z - q2);      a2 = sx8(a2 - tmp), b2 = sx8(b2 - tmp);
-						int xn, yn, x2n, y2n;
-						if (!right) {
-							xn = (a > 0 ? a : 0) - qe;     d |= a > 0 ? 0x08 : 0;
-							yn = (b > 0 ? b : 0) - qe;     d |= b > 0 ? 0x10 : 0;
-							x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 > 0 ? 0x20 : 0;
-							y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 > 0 ? 0x40 : 0;
+						if (SINGLE) { // ksw2_extz2_sse.c:34-55 with the left/right variants at :186-204 / :213-231 (and :164-170 score-only)
+							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24);
+							int z = sx8(sx8(b_cur >> 16) + qe2s);
+							int a = sx8(xt1 + vt1), b = sx8(yt + ut), d = 0;
+							if (!with_cigar) z = z > a ? z : a;
+							else if (!right) { d = a > z ? 1 : 0; z = z > a ? z : a; d = b > z ? 2 : d; }
+							else { d = z > a ? 0 : 1; z = z > a ? z : a; d = z > b ? d : 2; }
+							int zu = (z & 0xff) > (b & 0xff) ? (z & 0xff) : (b & 0xff); // unsigned maximum, then unsigned clamp
+							zu = zu < max_scu ? zu : max_scu;
+							const int un = zu - vt1, vn = zu - ut;
+							z = sx8(zu - q);
+							a = sx8(a - z), b = sx8(b - z);
+							int xn, yn;
+							if (!with_cigar || !right) {
+								xn = a > 0 ? a : 0; d |= a > 0 ? 0x08 : 0;
+								yn = b > 0 ? b : 0; d |= b > 0 ? 0x10 : 0;
+							} else {
+								xn = 0 > a ? 0 : a; d |= 0 > a ? 0 : 0x08;
+								yn = 0 > b ? 0 : b; d |= 0 > b ? 0 : 0x10;
+							}
+							A[t] = pack4(un, vn, xn, yn);
+							if (with_cigar) pr[t - st] = (uint8_t)d;
 						} else {
-							xn = (a > 0 ? a : 0) - qe;     d |= a >= 0 ? 0x08 : 0;
-							yn = (b > 0 ? b : 0) - qe;     d |= b >= 0 ? 0x10 : 0;
-							x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 >= 0 ? 0x20 : 0;
-							y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 >= 0 ? 0x40 : 0;
+							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), y2t = sx8(b_cur >> 8);
+							int z = sx8(b_cur >> 16);
+							int a = sx8(xt1 + vt1), b = sx8(yt + ut), a2 = sx8(x2t1 + vt1), b2 = sx8(y2t + ut), d;
+							if (!right) { // strictly greater wins (:235-243)
+								d = a > z ? 1 : 0;   z = z > a ? z : a;
+								d = b > z ? 2 : d;   z = z > b ? z : b;
+								d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
+								d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
+							} else {      // ties go to the gap state (:282-290)
+								d = z > a ? 0 : 1;   z = z > a ? z : a;
+								d = z > b ? d : 2;   z = z > b ? z : b;
+								d = z > a2 ? d : 3;  z = z > a2 ? z : a2;
+								d = z > b2 ? d : 4;  z = z > b2 ? z : b2;
+							}
+							z = z < sc_mch ? z : sc_mch;
+							const int un = z - vt1, vn = z - ut;
+							int tmp = sx8(z - q);   a = sx8(a - tmp),   b = sx8(b - tmp);
+							tmp = sx8(z - q2);      a2 = sx8(a2 - tmp), b2 = sx8(b2 - tmp);
+							int xn, yn, x2n, y2n;
+							if (!right) {
+								xn = (a > 0 ? a : 0) - qe;     d |= a > 0 ? 0x08 : 0;
+								yn = (b > 0 ? b : 0) - qe;     d |= b > 0 ? 0x10 : 0;
+								x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 > 0 ? 0x20 : 0;
+								y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 > 0 ? 0x40 : 0;
+							} else {
+								xn = (a > 0 ? a : 0) - qe;     d |= a >= 0 ? 0x08 : 0;
+								yn = (b > 0 ? b : 0) - qe;     d |= b >= 0 ? 0x10 : 0;
+								x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 >= 0 ? 0x20 : 0;
+								y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 >= 0 ? 0x40 : 0;
+							}
+							A[t] = pack4(un, vn, xn, yn);
+							B[t] = (b_cur & 0xffff0000u) | (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8;
+							if (with_cigar) pr[t - st] = (uint8_t)d;
 						}
-						A[t] = pack4(un, vn, xn, yn);
-						B[t] = (b_cur & 0xffff0000u) | (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8;
-						if (with_cigar) pr[t - st] = (uint8_t)d;
 					}
 				}
 				STATE_SYNC();
+				// score differences read back from the state: signed bytes (dual-affine) or unsigned bytes minus (q+e) (single, :236-262)
+				auto du = [&](uint32_t w) { return SINGLE ? (int)(w & 0xff) - qe : sx8((int)w); };
+				auto dv = [&](uint32_t w) { return SINGLE ? (int)(w >> 8 & 0xff) - qe : sx8((int)(w >> 8)); };
+				const int zd_e = SINGLE ? e : e2, h00 = SINGLE ? qe : qe_in;
 				if (!approx_max) { // exact row maximum in the reference's scan order (:325-365)
 					int max_H, max_t;
 					if (r > 0) {
-						const int Hen = en0 > 0 ? H[en0 - 1] + sx8(A[en0]) : H[en0] + sx8(A[en0] >> 8);
+						const int Hen = en0 > 0 ? H[en0 - 1] + du(A[en0]) : H[en0] + dv(A[en0]);
 						const int en1 = st0 + (en0 - st0) / 4 * 4;
 						STATE_SYNC();
 						// candidate order: en0 first, then the 4-lane strided scan of [st0,en1), then the tail [en1,en0)
 						long long best = (long long)Hen << 32 | 0x7fffffffLL;
 						const int nq = (en1 - st0) >> 2;
 						for (int t = st0 + lane; t < en0; t += 64) {
-							const int h = H[t] + sx8(A[t] >> 8);
+							const int h = H[t] + dv(A[t]);
 							H[t] = h;
 							const int k = t - st0;
 							const int rank = t < en1 ? 1 + (k & 3) * (nq + 1) + (k >> 2) : 1 + 4 * (nq + 1) + (t - en1);
@@ -300,24 +332,25 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 						if (lane == 0) H[en0] = Hen;
 						STATE_SYNC();
 					} else {
-						max_H = sx8(A[0] >> 8) - qe_in, max_t = 0;
+						max_H = dv(A[0]) - h00, max_t = 0;
 						if (lane == 0) H[0] = max_H;
 						STATE_SYNC();
 					}
 					const int Hen0 = H[en0], Hst0 = H[st0];
 					if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en0;
 					if (r - st0 == qlen - 1 && Hst0 > ez.mqe) ez.mqe = Hst0, ez.mqe_t = st0;
-					if (zdrop_test(ez, max_H, r, max_t, J.zdrop, e2)) break;
+					if (zdrop_test(ez, max_H, r, max_t, J.zdrop, zd_e)) break;
 					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
 				} else { // follow one cell (:366-383)
 					if (r > 0) {
 						if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-							const int d0 = sx8(A[last_H0_t] >> 8), d1 = sx8(A[last_H0_t + 1]);
+							const int d0 = dv(A[last_H0_t]), d1 = du(A[last_H0_t + 1]);
 							if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
-						} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += sx8(A[last_H0_t] >> 8);
-						else ++last_H0_t, H0 += sx8(A[last_H0_t]);
-					} else H0 = sx8(A[0] >> 8) - qe_in, last_H0_t = 0;
-					if ((flag & KSW_APPROX_DROP) && zdrop_test(ez, H0, r, last_H0_t, J.zdrop, e2)) break;
+						} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += dv(A[last_H0_t]);
+						else ++last_H0_t, H0 += du(A[last_H0_t]);
+					} else H0 = dv(A[0]) - h00, last_H0_t = 0;
+					// the single-affine code tests the drop only from the second anti-diagonal on (ksw2_extz2_sse.c:291 sits inside r > 0)
+					if ((flag & KSW_APPROX_DROP) && (!SINGLE || r > 0) && zdrop_test(ez, H0, r, last_H0_t, J.zdrop, zd_e)) break;
 					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
 				}
 				last_st = st, last_en = en;
@@ -361,19 +394,24 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 
 void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream)
 {
+	const bool single = L.single_affine;
 	if (L.n_jobs <= 0) return;
 	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
 	const size_t lds = region * waves_per_block;
 	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
 	if (L.state_pool) { // state in HBM: any job length
-		hipLaunchKernelGGL((ksw_extd2_kernel<false>), dim3(n_blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, L);
+		if (single) hipLaunchKernelGGL((ksw_extd2_kernel<false, true>), dim3(n_blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, L);
+		else hipLaunchKernelGGL((ksw_extd2_kernel<false, false>), dim3(n_blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, L);
 		HIP_CHECK(hipGetLastError());
 		return;
 	}
 	if (lds > 160 * 1024) throw std::runtime_error("[mm2amd] ksw_extd2: job class does not fit LDS");
-	if (lds > 64 * 1024)
-		HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL((ksw_extd2_kernel<true>), dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
+	if (lds > 64 * 1024) {
+		if (single) HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		else HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	}
+	if (single) hipLaunchKernelGGL((ksw_extd2_kernel<true, true>), dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
+	else hipLaunchKernelGGL((ksw_extd2_kernel<true, false>), dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
 	HIP_CHECK(hipGetLastError());
 }
 

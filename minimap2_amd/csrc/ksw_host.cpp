@@ -50,7 +50,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	constexpr size_t NBINS = (size_t)kNTiers * NB, CH = 16384;
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
-	const bool scoring_ok = sc.m == 5 && !disable_fast && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
+	const bool scoring_ok = sc.m == 5 && !disable_fast && !single_affine && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
 	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
@@ -180,6 +180,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.counter = d_counter.p + tier;
 			L.max_T16 = P.max_T16, L.max_Q16 = P.max_Q16, L.sc = sc;
 			L.state_pool = tier == kHbmTier ? d_state.p : nullptr;
+			L.single_affine = single_affine;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, kTiers[tier].waves_per_block, stream);

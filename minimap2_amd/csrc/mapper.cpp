@@ -43,7 +43,6 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	const int64_t unsupported = F_SR | F_SPLICE | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_RMQ | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
 	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads with dual-affine scoring (map-ont / map-hifi class presets); sr, splice, qstrand, heap-sort, RMQ-primary and all-vs-all modes are not implemented");
 	if (!(opt.flag & F_CIGAR)) throw std::invalid_argument("[mm2amd] only base-level alignment mode (MM_F_CIGAR, -c/-a) is implemented");
-	if (opt.q == opt.q2 && opt.e == opt.e2) throw std::invalid_argument("[mm2amd] single-affine scoring (ksw_extz2) is not implemented; use dual-affine gap costs");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	if (fi.n_alt) throw std::invalid_argument("[mm2amd] ALT-aware mapping is not implemented");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
@@ -200,7 +199,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
 		KswScoring sc;
 		memcpy(sc.mat, aligner.mat(), 25);
-		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.pad[0] = sc.pad[1] = 0;
+		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.single = (opt_.q == opt_.q2 && opt_.e == opt_.e2) ? 1 : 0, sc.pad = 0;
 		std::vector<std::vector<KswJob>> &per_read_jobs = ds.per_read_jobs;
 		if ((long)per_read_jobs.size() < m) per_read_jobs.resize(m);
 		std::vector<size_t> &job_base = ds.job_base;

@@ -51,6 +51,10 @@ void ora_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
                    int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag,
                    ora_ez_t *ez, uint32_t *cigar, int cigar_cap);
 
+/* ksw2_extz2_sse.c:25-311 (single-affine), lane-exact, SSE4.1 code path */
+void ora_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ora_ez_t *ez, uint32_t *cigar, int cigar_cap);
+
 /* mm_sketch, sketch.c:77-143 (non-HPC and HPC).  Appends to out[*n_out..cap); returns the number of
  * minimizers the sequence has (which may exceed cap - then only the first cap were stored). */
 int64_t ora_sketch(const char *seq, int len, int w, int k, uint32_t rid, int is_hpc, ora128_t *out, int64_t cap);

@@ -89,8 +89,9 @@ public:
 				ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1, ez.score = ez.mqe = ez.mte = ORA_NEG_INF, ez.zdropped = 1;
 			} else {
 				cg.resize((size_t)j.qlen + j.tlen + 8);
-				ora_ksw_extd2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff,
-				              &ez, cg.data(), (int)cg.size());
+				if (sc.single) ora_ksw_extz2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez, cg.data(), (int)cg.size());
+				else ora_ksw_extd2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff,
+				                   &ez, cg.data(), (int)cg.size());
 			}
 			r.max = ez.max, r.zdropped = ez.zdropped, r.max_q = ez.max_q, r.max_t = ez.max_t, r.mqe = ez.mqe, r.mqe_t = ez.mqe_t;
 			r.mte = ez.mte, r.mte_q = ez.mte_q, r.score = ez.score, r.n_cigar = ez.n_cigar, r.reach_end = ez.reach_end;

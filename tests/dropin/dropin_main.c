@@ -39,6 +39,10 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-K") == 0) batch = atoll(argv[++k]);
 		else if (strcmp(argv[k], "-s") == 0) mopt.seed = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--stats") == 0) print_stats = 1;
+		else if (strcmp(argv[k], "-O") == 0) { char *s; mopt.q = mopt.q2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.q2 = strtol(s + 1, &s, 10); }
+		else if (strcmp(argv[k], "-E") == 0) { char *s; mopt.e = mopt.e2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.e2 = strtol(s + 1, &s, 10); }
+		else if (strcmp(argv[k], "-A") == 0) mopt.a = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-B") == 0) mopt.b = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--cs") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_CIGAR;
 		else if (strcmp(argv[k], "--MD") == 0) mopt.flag |= MM_F_OUT_MD;
 		else if (strcmp(argv[k], "--eqx") == 0) mopt.flag |= MM_F_EQX;

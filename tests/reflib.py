@@ -92,6 +92,34 @@ def ora_extd2(q, t, mat, go, ge, go2, ge2, w, zdrop, end_bonus, flag):
             tuple(buf[i] for i in range(ez.n_cigar)))
 
 
+def ref_extz2(q, t, mat, go, ge, w, zdrop, end_bonus, flag):
+    """the reference's ksw_extz2_sse (single-affine)"""
+    R = ref()
+    R.ksw_extz2_sse.restype = None
+    R.ksw_extz2_sse.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.POINTER(KswExtz)]
+    ez = KswExtz()
+    R.ksw_extz2_sse(None, len(q), bytes(q), len(t), bytes(t), 5, bytes(mat), go, ge, w, zdrop, end_bonus, flag, C.byref(ez))
+    out = ez_tuple_ref(ez)
+    if ez.cigar:
+        R.free(ez.cigar)
+    return out
+
+
+def ora_extz2(q, t, mat, go, ge, w, zdrop, end_bonus, flag):
+    O = ora()
+    O.ora_ksw_extz2.restype = None
+    O.ora_ksw_extz2.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(OraEz), C.POINTER(C.c_uint32), C.c_int]
+    ez = OraEz()
+    cap = len(q) + len(t) + 8
+    buf = (C.c_uint32 * cap)()
+    O.ora_ksw_extz2(len(q), bytes(q), len(t), bytes(t), 5, bytes(mat), go, ge, w, zdrop, end_bonus, flag, C.byref(ez), buf, cap)
+    assert not ez.cigar_overflow
+    return (ez.max, ez.zdropped, ez.max_q, ez.max_t, ez.mqe, ez.mqe_t, ez.mte, ez.mte_q, ez.score, ez.reach_end,
+            tuple(buf[i] for i in range(ez.n_cigar)))
+
+
 def ts_mat(a, b, sc_ambi=1, transition=0):
     """ksw_gen_ts_mat, align.c:10-36 -> 25 signed bytes"""
     import numpy as np

@@ -55,3 +55,9 @@ def test_hifi_sam_identical(tmp_path):
 def test_ont_second_batch_and_tiny_reads(tmp_path):
     # -K forces several mini-batches through the same device context
     _compare(tmp_path, "ont", "map-ont", 2, 120, 14, ["-a", "-K", "300000"])
+
+
+def test_single_affine_scoring_sam_identical(tmp_path):
+    # -O4 -E2 with equal second gap cost: mm_align_pair takes ksw_extz2_sse (align.c:353-354)
+    _compare(tmp_path, "ont", "map-ont", 3, 120, 15, ["-a", "-O", "4", "-E", "2"])
+    _compare(tmp_path, "hifi", "map-hifi", 3, 60, 16, ["-c", "-O", "6,6", "-E", "2,2"])

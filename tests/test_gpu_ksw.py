@@ -138,3 +138,34 @@ def test_jobs_longer_than_lds_use_the_hbm_state_kernel():
     q2, t2 = random_pair(rng, 12500, 0.1)
     jobs.append((q2[:12000], t2[:12800], 751, 400, -1, 0xC2))
     _run(jobs, "ont")
+
+
+@pytest.mark.parametrize("sc", [(2, 4, 4, 2), (1, 4, 6, 2), (1, 9, 16, 2), (1, 2, 2, 1)])
+def test_single_affine_extz2(sc):
+    """the single-affine instantiation of the exact kernel (ksw_extz2_sse semantics) against its oracle and the reference"""
+    import minimap2_amd as mm
+    from reflib import ora_extz2, ref_extz2
+    a, b, go, ge = sc
+    rng = np.random.default_rng(sum(sc))
+    mat = ts_mat(a, b, 1, 0)
+    jobs = []
+    for it in range(250):
+        q, t = random_pair(rng, int(rng.integers(1, 500)), float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.02])))
+        jobs.append((q, t, 30001, int(rng.choice([-1, 100, 400])), int(rng.choice([-1, 10])), int(rng.choice([0x08, 0x00, 0x40, 0xC2, 0x41, 0x18]))))
+    for it in range(150):  # binding bands
+        q, t = random_pair(rng, int(rng.integers(20, 900)), float(rng.choice([0.02, 0.12])), 0.0, int(rng.choice([0, 0, 30, -30, 150, -150])))
+        jobs.append((q, t, int(rng.integers(1, 120)), int(rng.choice([-1, 100, 400])), int(rng.choice([-1, 10])), int(rng.choice([0x40, 0xC2, 0x00, 0x08]))))
+    for tl in (16, 64, 256):
+        t = rng.integers(0, 4, tl, dtype=np.uint8)
+        q = rng.integers(0, 4, int(rng.integers(1, 2 * tl)), dtype=np.uint8)
+        for flag in (0x08, 0x40, 0xC2, 0):
+            for w in (5, 751, 30001):
+                jobs.append((q, t, w, 400, 10, flag))
+    q, t = random_pair(rng, 2500, 0.12, 0.0, 700)
+    jobs.append((q, t, 751, 400, 10, 0x40))
+    got = mm.ksw_extz2_batch(jobs, mat, go, ge)
+    have_ref = os.path.exists(reflib.REF_SO)
+    for k, (q, t, w, zdrop, eb, flag) in enumerate(jobs):
+        assert got[k] == ora_extz2(q, t, mat, go, ge, w, zdrop, eb, flag), (k, len(q), len(t), w, hex(flag))
+        if have_ref and k % 9 == 0:
+            assert got[k] == ref_extz2(q, t, mat, go, ge, w, zdrop, eb, flag)

@@ -81,3 +81,12 @@ def test_empty_and_tiny_reads(tmp_path):
         f.write(b">withN\n" + synth.ACGT[contigs[0][5000:6000]].tobytes()[:500] + b"NNNNNNNNNN" + synth.ACGT[contigs[0][5510:7000]].tobytes() + b"\n")
     if os.path.exists(G.REF_BIN):
         _pair(["-a"], ref, rd)
+
+
+def test_single_affine_scoring(tmp_path):
+    """equal first/second gap costs route the DP through ksw_extz2 (align.c:353-354); host logic + oracle backend vs the reference"""
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 0.5, 20, 105)
+    _pair(["-x", "map-ont", "-a", "-O", "4", "-E", "2"], ref, reads)
