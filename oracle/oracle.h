@@ -55,6 +55,11 @@ void ora_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 void ora_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                    int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ora_ez_t *ez, uint32_t *cigar, int cigar_cap);
 
+/* ksw2_exts2_sse.c:33-465 (splice-aware), lane-exact, SSE4.1 code path; junc may be NULL */
+void ora_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int end_bonus, int8_t junc_bonus, int8_t junc_pen, int flag,
+                   const uint8_t *junc, ora_ez_t *ez, uint32_t *cigar, int cigar_cap);
+
 /* mm_sketch, sketch.c:77-143 (non-HPC and HPC).  Appends to out[*n_out..cap); returns the number of
  * minimizers the sequence has (which may exceed cap - then only the first cap were stored). */
 int64_t ora_sketch(const char *seq, int len, int w, int k, uint32_t rid, int is_hpc, ora128_t *out, int64_t cap);

@@ -120,6 +120,38 @@ def ora_extz2(q, t, mat, go, ge, w, zdrop, end_bonus, flag):
             tuple(buf[i] for i in range(ez.n_cigar)))
 
 
+EXTS_ARGS = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int8, C.c_int8,
+             C.c_int, C.c_char_p]
+
+
+def ref_exts2(q, t, mat, go, ge, go2, noncan, zdrop, end_bonus, junc_bonus, junc_pen, flag, junc=None):
+    """the reference's ksw_exts2_sse (splice-aware)"""
+    R = ref()
+    R.ksw_exts2_sse.restype = None
+    R.ksw_exts2_sse.argtypes = [C.c_void_p] + EXTS_ARGS + [C.POINTER(KswExtz)]
+    ez = KswExtz()
+    R.ksw_exts2_sse(None, len(q), bytes(q), len(t), bytes(t), 5, bytes(mat), go, ge, go2, noncan, zdrop, end_bonus, junc_bonus, junc_pen, flag,
+                    None if junc is None else bytes(junc), C.byref(ez))
+    out = ez_tuple_ref(ez)
+    if ez.cigar:
+        R.free(ez.cigar)
+    return out
+
+
+def ora_exts2(q, t, mat, go, ge, go2, noncan, zdrop, end_bonus, junc_bonus, junc_pen, flag, junc=None):
+    O = ora()
+    O.ora_ksw_exts2.restype = None
+    O.ora_ksw_exts2.argtypes = EXTS_ARGS + [C.POINTER(OraEz), C.POINTER(C.c_uint32), C.c_int]
+    ez = OraEz()
+    cap = len(q) + len(t) + 8
+    buf = (C.c_uint32 * cap)()
+    O.ora_ksw_exts2(len(q), bytes(q), len(t), bytes(t), 5, bytes(mat), go, ge, go2, noncan, zdrop, end_bonus, junc_bonus, junc_pen, flag,
+                    None if junc is None else bytes(junc), C.byref(ez), buf, cap)
+    assert not ez.cigar_overflow
+    return (ez.max, ez.zdropped, ez.max_q, ez.max_t, ez.mqe, ez.mqe_t, ez.mte, ez.mte_q, ez.score, ez.reach_end,
+            tuple(buf[i] for i in range(ez.n_cigar)))
+
+
 def ts_mat(a, b, sc_ambi=1, transition=0):
     """ksw_gen_ts_mat, align.c:10-36 -> 25 signed bytes"""
     import numpy as np
