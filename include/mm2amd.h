@@ -64,6 +64,13 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
 int mm2amd_ksw_extz2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
 
+/* Batched ksw_exts2_sse (ksw2_exts2_sse.c:33, ksw2.h:77-79): splice-aware alignment (intron state on the target, N operations;
+ * flag carries KSW_EZ_SPLICE_FOR/REV/FLANK/CMPLX as in the reference; the job's w is ignored: this DP has no band).  Junction
+ * annotation (the reference's junc/junc_bonus/junc_pen arguments) is not taken at this boundary: the call equals the
+ * reference's with junc == NULL.  Same contract as above otherwise. */
+int mm2amd_ksw_exts2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan,
+                           mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
+
 /* ------------------------------------------------------------------------------------------------
  * Drop-in boundary: the batched replacement of kt_for(n_threads, worker_for, step, n_frag) (map.c:576).
  *

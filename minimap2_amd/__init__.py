@@ -106,6 +106,9 @@ def _bind(L):
         L.mm2amd_ksw_extz2_batch.restype = C.c_int
         L.mm2amd_ksw_extz2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.POINTER(KswRes),
                                              C.POINTER(C.c_uint32), C.c_size_t]
+        L.mm2amd_ksw_exts2_batch.restype = C.c_int
+        L.mm2amd_ksw_exts2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                             C.POINTER(KswRes), C.POINTER(C.c_uint32), C.c_size_t]
         L.mm2amd_idx_str.restype = vp
         L.mm2amd_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.mm2amd_idx_destroy.argtypes = [vp]
@@ -150,7 +153,12 @@ def ksw_extz2_batch(jobs, mat, gapo, gape):
     return ksw_extd2_batch(jobs, mat, gapo, gape, None, None)
 
 
-def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2):
+def ksw_exts2_batch(jobs, mat, gapo, gape, gapo2, noncan):
+    """splice-aware twin of ksw_extd2_batch (ksw_exts2_sse with junc == NULL); a job's w is ignored"""
+    return ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, None, noncan=noncan)
+
+
+def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2, noncan=None):
     """jobs: list of (query_bytes, target_bytes, w, zdrop, end_bonus, flag) with nt4 codes 0..4.
     Returns a list of (max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, cigar_tuple),
     the same tuple layout tests/reflib.py produces for the reference's ksw_extd2_sse."""
@@ -167,7 +175,9 @@ def ksw_extd2_batch(jobs, mat, gapo, gape, gapo2, gape2):
         tot += len(qb) + len(tb)
     res = (KswRes * n)()
     pool = (C.c_uint32 * max(tot, 1))()
-    if gapo2 is None:
+    if noncan is not None:
+        _check(lib().mm2amd_ksw_exts2_batch(n, arr, 5, bytes(mat), gapo, gape, gapo2, noncan, res, pool, max(tot, 1)))
+    elif gapo2 is None:
         _check(lib().mm2amd_ksw_extz2_batch(n, arr, 5, bytes(mat), gapo, gape, res, pool, max(tot, 1)))
     else:
         _check(lib().mm2amd_ksw_extd2_batch(n, arr, 5, bytes(mat), gapo, gape, gapo2, gape2, res, pool, max(tot, 1)))

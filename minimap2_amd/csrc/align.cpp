@@ -399,11 +399,76 @@ void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs,
 	}
 	ra.n_a = squeeze_anchors(regs, a);
 	ra.tasks.clear(); ra.order.clear();
-	ra.tasks.resize(regs.size());
-	for (size_t i = 0; i < regs.size(); ++i) {
-		ra.tasks[i] = RegionTask();
-		ra.tasks[i].r = regs[i];
-		ra.order.push_back((int)i);
+	for (size_t i = 0; i < regs.size(); ++i) add_region(ra, regs[i], -1);
+}
+
+// One region to align: one task, or one task per assumed transcript strand (align.c:1068-1077).  order_pos < 0 appends.
+void Aligner::add_region(ReadAlign &ra, const Reg &r, int order_pos)
+{
+	const bool splice = opt_.flag & F_SPLICE, both = splice && (opt_.flag & F_SPLICE_FOR) && (opt_.flag & F_SPLICE_REV);
+	const int ti = (int)ra.tasks.size();
+	RegionTask t;
+	t.r = r;
+	if (both) t.splice_flag = (int32_t)F_SPLICE_FOR, t.twin = ti + 1;
+	else if (splice) t.splice_flag = (int32_t)(opt_.flag & (F_SPLICE_FOR | F_SPLICE_REV));
+	ra.tasks.push_back(t);
+	if (both) {
+		t.splice_flag = (int32_t)F_SPLICE_REV, t.twin = ti, t.lead = false;
+		ra.tasks.push_back(std::move(t));
+	}
+	if (order_pos < 0) ra.order.push_back(ti);
+	else ra.order.insert(ra.order.begin() + order_pos, ti);
+}
+
+// Both strand attempts of a region are finished: keep the better one (align.c:1078-1096)
+void Aligner::join_strands(ReadAlign &ra, int lead_ti)
+{
+	RegionTask &s0 = ra.tasks[lead_ti], &s1 = ra.tasks[s0.twin];
+	if (!s0.r.p || !s1.r.p) throw std::runtime_error("[mm2amd] spliced alignment produced no CIGAR for a region (the reference dereferences a null pointer here)");
+	int which, trans_strand;
+	if (s0.r.p->dp_score > s1.r.p->dp_score) which = 0, trans_strand = 1;
+	else if (s0.r.p->dp_score < s1.r.p->dp_score) which = 1, trans_strand = 2;
+	else trans_strand = 3, which = (ra.qlen + s0.r.p->dp_score) & 1;
+	if (which == 1) std::swap(s0.r, s1.r), std::swap(s0.r2, s1.r2);
+	free(s1.r.p), s1.r.p = nullptr;
+	Reg &r = s0.r;
+	r.p->trans_strand = trans_strand;
+	if (r.is_spliced) {
+		if (trans_strand == 1 || trans_strand == 2) r.p->dp_max += (opt_.a + opt_.b) + ((opt_.a + opt_.b) >> 1);
+		else r.p->dp_max -= opt_.a + opt_.b;
+	}
+}
+
+// ksw_ll_i16 score of an anchor's k-mer extended by anchor_ext_len on both sides (mm_seed_ext_score, align.c:591-616)
+static int seed_ext_score(const MapOpt &opt, const FlatIndex &fi, const int8_t *mat, int qlen, const uint8_t *q4, const Anchor &a, std::vector<uint8_t> &tbuf)
+{
+	const int q_span = span_of(a), ext_len = opt.anchor_ext_len;
+	const uint32_t rid = (uint32_t)(a.x << 1 >> 33);
+	int re = (int)((uint32_t)a.x + 1), rs = re - q_span, qe = (int)((uint32_t)a.y + 1), qs = qe - q_span, q_off, t_off;
+	rs = rs - ext_len > 0 ? rs - ext_len : 0;
+	qs = qs - ext_len > 0 ? qs - ext_len : 0;
+	re = re + ext_len < (int32_t)fi.seq_len[rid] ? re + ext_len : (int32_t)fi.seq_len[rid];
+	qe = qe + ext_len < qlen ? qe + ext_len : qlen;
+	tbuf.resize(re - rs);
+	fi.getseq(rid, rs, re, tbuf.data());
+	return ll_local_score(qe - qs, q4 + (size_t)(a.x >> 63) * qlen + qs, re - rs, tbuf.data(), mat, opt.q, opt.e, &q_off, &t_off);
+}
+
+// boundary exons held by one weak anchor far from the rest are dropped (mm_fix_bad_ends_splice, align.c:618-636)
+static void trim_bad_ends_splice(const MapOpt &opt, const FlatIndex &fi, const Reg &r, const int8_t *mat, int qlen, const uint8_t *q4, const Anchor *a,
+                                 std::vector<uint8_t> &tbuf, int32_t *as1, int32_t *cnt1)
+{
+	*as1 = r.as, *cnt1 = r.cnt;
+	if (r.cnt < 3) return;
+	double log_gap = log((double)((int32_t)a[r.as + 1].x - (int32_t)a[r.as].x));
+	if (span_of(a[r.as]) < log_gap + opt.anchor_ext_shift) {
+		const int score = seed_ext_score(opt, fi, mat, qlen, q4, a[r.as], tbuf);
+		if ((double)score / mat[0] < log_gap + opt.anchor_ext_shift) ++(*as1), --(*cnt1);
+	}
+	log_gap = log((double)((int32_t)a[r.as + r.cnt - 1].x - (int32_t)a[r.as + r.cnt - 2].x));
+	if (span_of(a[r.as + r.cnt - 1]) < log_gap + opt.anchor_ext_shift) {
+		const int score = seed_ext_score(opt, fi, mat, qlen, q4, a[r.as + r.cnt - 1], tbuf);
+		if ((double)score / mat[0] < log_gap + opt.anchor_ext_shift) --(*cnt1);
 	}
 }
 
@@ -437,19 +502,29 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	t.planned = true;
 	t.r2.cnt = 0;
 	if (r.cnt == 0) { t.done = true; return; }
-	if (opt_.flag & (F_SR | F_SPLICE | F_QSTRAND)) throw std::runtime_error("[mm2amd] sr/splice/qstrand alignment is not supported by this build");
+	if (opt_.flag & (F_SR | F_SR_RNA | F_QSTRAND)) throw std::runtime_error("[mm2amd] sr/qstrand alignment is not supported by this build");
+	const bool is_splice = opt_.flag & F_SPLICE;
 	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 	const int32_t ref_len = (int32_t)fi_.seq_len[rid];
 	t.rid = rid, t.rev = rev;
 	int32_t as1, cnt1, rs, qs, re, qe, rs0, qs0, re0, qe0, rs1, qs1, re1, qe1, l;
 
-	if (!(opt_.flag & F_NO_END_FLT)) trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
-	else as1 = r.as, cnt1 = r.cnt;
+	if (!(opt_.flag & F_NO_END_FLT)) {
+		if (is_splice) trim_bad_ends_splice(opt_, fi_, r, mat_, qlen, ra.q4, a, tbuf_, &as1, &cnt1);
+		else trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
+	} else as1 = r.as, cnt1 = r.cnt;
 	drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
 	join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
 	anchor_boundary(fi_, ra.q4, qlen, a[as1], &rs, &qs);
 	anchor_boundary(fi_, ra.q4, qlen, a[as1 + cnt1 - 1], &re, &qe);
 	assert(cnt1 > 0);
+	t.ksw_flag = 0;
+	if (is_splice) { // align.c:684-689 and :354
+		if (t.splice_flag & F_SPLICE_FOR) t.ksw_flag |= rev ? KSW_SPLICE_REV : KSW_SPLICE_FOR;
+		if (t.splice_flag & F_SPLICE_REV) t.ksw_flag |= rev ? KSW_SPLICE_FOR : KSW_SPLICE_REV;
+		if (opt_.flag & F_SPLICE_FLANK) t.ksw_flag |= KSW_SPLICE_FLANK;
+		if (!(opt_.flag & F_SPLICE_OLD)) t.ksw_flag |= KSW_SPLICE_CMPLX;
+	}
 
 	// how far the two extensions may reach (align.c:695-767)
 	rs0 = (int32_t)a[r.as].x + 1 - span_of(a[r.as]);
@@ -556,7 +631,7 @@ void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdr
 	const uint64_t qbase = ra.qpool_off + (uint64_t)t.rev * ra.qlen, tbase = fi_.seq_off[t.rid];
 	j.q_off = reversed ? qbase + w.qe - 1 : qbase + w.qs;
 	j.t_off = reversed ? tbase + w.re - 1 : tbase + w.rs;
-	j.flag = flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);
+	j.flag = flag | t.ksw_flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);
 	j.tag = 0, j.reserved = 0;
 	w.job = (int32_t)jobs.size(), w.saved = -1;
 	jobs.push_back(j);
@@ -684,14 +759,20 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 		}
 		finalize_region(ra, t);
 	}
+	if (opt_.flag & F_SPLICE) {
+		const int twin = ra.tasks[ti].twin;
+		if (twin >= 0) { // two strand attempts: the second one to finish picks the winner (align.c:1078-1096)
+			if (!ra.tasks[twin].done) return false;
+			if (!ra.tasks[ti].lead) ti = twin;
+			join_strands(ra, ti);
+		} else ra.tasks[ti].r.p->trans_strand = (opt_.flag & F_SPLICE_FOR) ? 1 : 2; // align.c:1099-1100
+	}
 	// follow-up work.  NB: ra.tasks may reallocate below, so no references are held across push_back.
 	const int self_pos = (int)(std::find(ra.order.begin(), ra.order.end(), ti) - ra.order.begin());
 	bool more = false;
 	if (ra.tasks[ti].r2.cnt > 0) { // the split-off tail becomes a region right after this one (align.c:1102)
-		RegionTask nt;
-		nt.r = ra.tasks[ti].r2;
-		ra.tasks.push_back(std::move(nt));
-		ra.order.insert(ra.order.begin() + self_pos + 1, (int)ra.tasks.size() - 1);
+		const Reg tail = ra.tasks[ti].r2;
+		add_region(ra, tail, self_pos + 1);
 		more = true;
 	}
 	if (self_pos > 0 && ra.tasks[ti].r.split_inv && !(opt_.flag & F_NO_INV)) { // inversion rescue (align.c:1103-1108)
@@ -715,6 +796,7 @@ void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
 		fi_.getseq(t.rid, t.rs1, t.re1, tbuf_.data());
 		const uint8_t *qseq = ra.q4 + (size_t)r.rev * qlen + t.qs1;
 		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
+		if (t.rev && r.p->trans_strand) r.p->trans_strand ^= 3; // align.c:907-908
 	}
 	t.saved.clear();
 	t.done = true;

@@ -43,6 +43,12 @@ struct RegionTask {
 	std::vector<Window> win;                     // [left?] gap... [right?]
 	size_t next_win = 0;                         // consumption cursor
 	bool has_left = false, has_right = false, dropped = false, done = false, planned = false;
+	// spliced alignment (align.c:1068-1096): with both transcript strands enabled a region is aligned twice, once per assumed
+	// strand, by two tasks that point at each other; the lead task sits in ReadAlign::order and receives the winner
+	int32_t splice_flag = 0;                     // F_SPLICE_FOR / F_SPLICE_REV as passed to mm_align1
+	int32_t ksw_flag = 0;                        // KSW_SPLICE_* bits every DP job of this task carries (align.c:684-689, :354)
+	int32_t twin = -1;
+	bool lead = true;
 	std::vector<SavedResult> saved;              // results carried over a round boundary (only when a region stalls)
 	// inversion-rescue tasks only (mm_align1_inv): where the extension starts and what it is anchored to
 	int32_t inv_q0 = 0, inv_t0 = 0, inv_r2_qs = 0, inv_r2_qe = 0, inv_r1_re = 0, inv_qoff = 0, inv_toff = 0;
@@ -73,6 +79,8 @@ public:
 
 	const int8_t *mat() const { return mat_; }
 private:
+	void add_region(ReadAlign &ra, const Reg &r, int order_pos);
+	void join_strands(ReadAlign &ra, int lead_ti);
 	void plan_region(ReadAlign &ra, RegionTask &t);
 	void add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdrop, int end_bonus, std::vector<KswJob> &jobs);
 	bool consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);

@@ -203,7 +203,6 @@ public:
 		// the DP scratch (one direction-matrix slot per persistent wave) is the big per-lane allocation: split the budget
 		ln.ksw.dir_budget = ((size_t)12 << 30) / (size_t)n_lanes_;
 		ln.ksw.lane = lane_id;
-		ln.ksw.single_affine = sc.single != 0;
 		ln.ksw.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id).collect();
 	}

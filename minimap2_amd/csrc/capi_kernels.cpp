@@ -48,7 +48,7 @@ int mm2amd_device_count(void)
 	return n;
 }
 
-static int ksw_batch(bool single, int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat,
+static int ksw_batch(int mode, int8_t noncan, int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat,
                      int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2,
                      mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
 {
@@ -81,13 +81,12 @@ static int ksw_batch(bool single, int n_jobs, const mm2amd_ksw_job_t *jobs, int8
 		HIP_CHECK(hipMemcpyAsync(d.d_tpool.p, ht.data(), ttot + 1, hipMemcpyHostToDevice, dc.stream));
 		KswScoring sc;
 		memcpy(sc.mat, mat, 25);
-		sc.m = m, sc.q = gapo, sc.e = gape, sc.q2 = gapo2, sc.e2 = gape2, sc.single = single ? 1 : 0, sc.pad = 0;
+		sc.m = m, sc.q = gapo, sc.e = gape, sc.q2 = gapo2, sc.e2 = gape2, sc.single = (int8_t)mode, sc.noncan = noncan;
 		std::vector<KswRes> r(n_jobs);
 		const uint32_t *cig = nullptr;
 		size_t n_cig = 0;
 		d.ksw.prof = &kernel_profiler(0);
 		d.ksw.disable_fast = getenv("MM2AMD_KSW_EXACT_ONLY") != nullptr;
-		d.ksw.single_affine = single;
 		d.ksw.run(dj, d.d_qpool.p, d.d_tpool.p, nullptr, sc, r.data(), &cig, &n_cig, dc.stream);
 		kernel_profiler().collect();
 		if (n_cig > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] ksw_extd2_batch: cigar_pool too small (sum(qlen+tlen) always suffices)");
@@ -106,13 +105,19 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
                            int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
 {
-	return ksw_batch(false, n_jobs, jobs, m, mat, gapo, gape, gapo2, gape2, res, cigar_pool, cigar_pool_cap);
+	return ksw_batch(0, 0, n_jobs, jobs, m, mat, gapo, gape, gapo2, gape2, res, cigar_pool, cigar_pool_cap);
 }
 
 int mm2amd_ksw_extz2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
 {
-	return ksw_batch(true, n_jobs, jobs, m, mat, gapo, gape, gapo, gape, res, cigar_pool, cigar_pool_cap);
+	return ksw_batch(1, 0, n_jobs, jobs, m, mat, gapo, gape, gapo, gape, res, cigar_pool, cigar_pool_cap);
+}
+
+int mm2amd_ksw_exts2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan,
+                           mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
+{
+	return ksw_batch(2, noncan, n_jobs, jobs, m, mat, gapo, gape, gapo2, 0, res, cigar_pool, cigar_pool_cap);
 }
 
 long long mm2amd_alloc_counter(int which)

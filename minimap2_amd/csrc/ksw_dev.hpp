@@ -50,8 +50,8 @@ struct KswScoring {         // uniform over a launch
 	int8_t mat[25];
 	int8_t m;
 	int8_t q, e, q2, e2;    // as passed by the caller, BEFORE the swap at ksw2_extd2_sse.c:78
-	int8_t single;          // 1: single-affine recurrences (ksw_extz2_sse; q2/e2 unused), the rule of mm_align_pair (align.c:353-356)
-	int8_t pad;
+	int8_t single;          // 1: single-affine recurrences (ksw_extz2_sse; q2/e2 unused), the rule of mm_align_pair (align.c:353-356); 2: splice (ksw_exts2_sse)
+	int8_t noncan;          // splice mode: cost of a non-canonical splice site (ksw2_exts2_sse.c:33, opt->noncan); gapo2 = q2, e2 unused
 };
 
 struct KswLaunch {
@@ -71,6 +71,7 @@ struct KswLaunch {
 	int32_t *counter;       // device, zeroed before launch: persistent-wave job queue head
 	int32_t max_T16, max_Q16; // LDS sizing: largest 16-rounded tlen / qlen in the launch
 	bool single_affine = false;    // ksw_extz2 recurrences (q2/e2 ignored) instead of ksw_extd2
+	bool splice = false;           // ksw_exts2 recurrences (no band, intron state, N operations)
 	uint8_t *state_pool = nullptr; // when set: per-slot state slabs in HBM (ksw_lds_per_wave bytes each) instead of LDS
 	KswScoring sc;
 };

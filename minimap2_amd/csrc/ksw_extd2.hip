@@ -83,9 +83,9 @@ __device__ __forceinline__ void cig_push(CigOut &g, uint32_t op, int len)
 	} else g.last += (uint32_t)len << 4;
 }
 
-// Traceback by one lane over the direction matrix in HBM (ksw2.h:130-162, is_rot=1, min_intron_len=0).
-// off[r]/off_end[r] of the reference are st/en of row r, recomputed here instead of stored.
-__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, int i0, int j0, CigOut &g)
+// Traceback by one lane over the direction matrix in HBM (ksw2.h:130-162, is_rot=1).  min_intron_len > 0 (splice mode): state
+// 3 is an intron and becomes an N operation.  off[r]/off_end[r] of the reference are st/en of row r, recomputed here.
+__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, int i0, int j0, int min_intron_len, CigOut &g)
 {
 	int i = i0, j = j0, state = 0;
 	while (i >= 0 && j >= 0) {
@@ -99,10 +99,11 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 		if (state == 0) state = tmp & 7;
 		if (force >= 0) state = force;
 		if (state == 0) cig_push(g, 0, 1), --i, --j;
-		else if (state == 1 || state == 3) cig_push(g, 2, 1), --i;
+		else if (state == 1 || (state == 3 && min_intron_len <= 0)) cig_push(g, 2, 1), --i;
+		else if (state == 3) cig_push(g, 3, 1), --i;
 		else cig_push(g, 1, 1), --j;
 	}
-	if (i >= 0) cig_push(g, 2, i + 1);
+	if (i >= 0) cig_push(g, min_intron_len > 0 && i >= min_intron_len ? 3 : 2, i + 1);
 	if (j >= 0) cig_push(g, 1, j + 1);
 	if (g.n > 0) g.c[g.n - 1] = g.last; // flush the run being accumulated
 }
@@ -112,11 +113,15 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 // library give up.
 // ordering between the lanes of the wave: LDS needs a wavefront fence, the HBM-resident state a workgroup-scope one
 #define STATE_SYNC() do { if (LDS_STATE) { WAVE_SYNC(); } else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } } while (0)
-// SINGLE: the single-affine recurrences of ksw_extz2_sse (ksw2_extz2_sse.c:25-311) instead of the dual-affine ones: scores
-// shifted by 2(q+e), unsigned second maximum and clamp (:49-50), zero-initialised state, two gap states only.
-template <bool LDS_STATE, bool SINGLE>
+// MODE 1 (SINGLE): the single-affine recurrences of ksw_extz2_sse (ksw2_extz2_sse.c:25-311) instead of the dual-affine ones:
+// scores shifted by 2(q+e), unsigned second maximum and clamp (:49-50), zero-initialised state, two gap states only.
+// MODE 2 (SPLICE): the splice-aware recurrences of ksw_exts2_sse (ksw2_exts2_sse.c:33-465): no band, the second gap state is an
+// intron on the target (x2 only; opening costs q2, extension nothing) priced per position by donor/acceptor bytes that take the
+// place of y2 and of the spare byte in the second state dword; no clamp; Z-drop without the diagonal term; N in the CIGAR.
+template <bool LDS_STATE, int MODE>
 __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 {
+	constexpr bool SINGLE = MODE == 1, SPLICE = MODE == 2;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
 	const int slot = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
@@ -142,37 +147,44 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 
 		int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
 		const int qe_in = q + e; // taken before the swap (ksw2_extd2_sse.c:68 vs :78); seeds H(0,0)
-		if (!SINGLE && q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
+		if (MODE == 0 && q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
 		const int qe = q + e, qe2 = q2 + e2;
 		int min_sc = L.sc.mat[1];
 		for (int t = 1; t < m * m; ++t) min_sc = min_sc < L.sc.mat[t] ? min_sc : L.sc.mat[t];
-		const bool degenerate = (SINGLE ? m <= 0 : m <= 1) || qlen <= 0 || tlen <= 0 || -min_sc > 2 * (q + e);
+		const bool degenerate = (SINGLE ? m <= 0 : m <= 1) || qlen <= 0 || tlen <= 0 || -min_sc > 2 * (q + e) || (SPLICE && (q2 <= q + e || e <= 0));
 		int w = J.w;
-		if (w < 0) w = tlen > qlen ? tlen : qlen;
+		if (w < 0 || SPLICE) w = tlen > qlen ? tlen : qlen; // a band this wide never binds
 
 		if (flag & KSWJ_SKIP) ez.zdropped = 1;
 		else if (!degenerate) {
 			const bool with_cigar = !(flag & KSW_SCORE_ONLY), approx_max = flag & KSW_APPROX_MAX, right = flag & KSW_RIGHT;
 			const int sc_mch = L.sc.mat[0], sc_mis = L.sc.mat[1];
-			const int sc_N = L.sc.mat[m * m - 1] == 0 ? sx8(SINGLE ? -e : -e2) : L.sc.mat[m * m - 1];
+			const int sc_N = L.sc.mat[m * m - 1] == 0 ? sx8(MODE ? -e : -e2) : L.sc.mat[m * m - 1];
 			const int qe2s = (q + e) * 2, max_scu = (L.sc.mat[0] + (q + e) * 2) & 0xff; // single-affine: score shift and unsigned clamp (:69,:79)
 			const int T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
 			size_t ncol = qlen < tlen ? qlen : tlen;
 			ncol = (((ncol < (size_t)w + 1 ? ncol : (size_t)w + 1) + 15) / 16 + 1) * 16;
-			int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
-			if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
-			const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+			int long_thres, long_diff;
+			if (SPLICE) { // ksw2_exts2_sse.c:98-101
+				long_thres = (q2 - q) / e - 1;
+				if (q2 > q + e + long_thres * e) ++long_thres;
+				long_diff = long_thres * e - (q2 - q);
+			} else {
+				long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+				if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+				long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+			}
 
 			uint32_t *A = (uint32_t *)my;      // byte0 u, byte1 v, byte2 x, byte3 y
-			uint32_t *B = A + T16;             // byte0 x2, byte1 y2, byte2 s
+			uint32_t *B = A + T16;             // byte0 x2, byte1 y2 (splice: donor), byte2 s, (splice: byte3 acceptor)
 			int32_t *H = (int32_t *)(B + T16);
 			uint8_t *SFQ = (uint8_t *)(H + T16); // [0,T16): target copy; [T16, T16+Q16+16): reversed query, zero padded
-			const int nqe = sx8(-q - e), nqe2 = sx8(-q2 - e2);
+			const int nqe = sx8(-q - e), nqe2 = SPLICE ? sx8(-q2) : sx8(-q2 - e2);
 
 			// ---- per-job initialisation (ksw2_extd2_sse.c:107-128) ----
 			for (int t = lane; t < T16; t += 64) {
 				A[t] = SINGLE ? 0u : pack4(nqe, nqe, nqe, nqe);
-				B[t] = SINGLE ? 0u : pack4(nqe2, nqe2, 0, 0);
+				B[t] = SINGLE ? 0u : SPLICE ? (uint32_t)(nqe2 & 0xff) : pack4(nqe2, nqe2, 0, 0); // splice: donor = acceptor = 0 unless a strand is given
 				H[t] = KSW_NEG_INF;
 				uint8_t c = 0;
 				if (t < tlen) {
@@ -190,6 +202,62 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				SFQ[T16 + i] = c;
 			}
 			STATE_SYNC();
+			if (SPLICE && (flag & (KSW_SPLICE_FOR | KSW_SPLICE_REV))) { // donor / acceptor costs from the neighbouring bases (:120-194)
+				const bool is_for = flag & KSW_SPLICE_FOR, revc = flag & KSW_REV_CIGAR;
+				int sp0, sp1, sp2, sp3;
+				if (flag & KSW_SPLICE_CMPLX) sp0 = 3, sp1 = 5, sp2 = 7, sp3 = 10; // (int)({8,15,21,30} / 3. + .499)
+				else sp0 = (flag & KSW_SPLICE_FLANK) ? L.sc.noncan / 2 : 0, sp1 = sp2 = sp3 = L.sc.noncan;
+				auto cost = [&](int z) { return z < 0 ? 0 : z == 0 ? -sp0 : z == 1 ? -sp1 : z == 2 ? -sp2 : -sp3; };
+				for (int t = lane; t < T16; t += 64) {
+					int zd = 3, za = 3;
+					if (t < tlen - 4) {
+						const int c1 = SFQ[t + 1], c2 = SFQ[t + 2], c3 = SFQ[t + 3];
+						if (!revc) {
+							if (is_for) {
+								if (c1 == 2 && c2 == 3) zd = (c3 == 0 || c3 == 2) ? -1 : 0;
+								else if (c1 == 2 && c2 == 1) zd = 1;
+								else if (c1 == 0 && c2 == 3) zd = 2;
+							} else {
+								if (c1 == 1 && c2 == 3) zd = (c3 == 0 || c3 == 2) ? -1 : 0;
+								else if (c1 == 2 && c2 == 3) zd = 2;
+							}
+						} else {
+							if (is_for) {
+								if (c1 == 2 && c2 == 0) zd = (c3 == 1 || c3 == 3) ? -1 : 0;
+								else if (c1 == 1 && c2 == 0) zd = 2;
+							} else {
+								if (c1 == 1 && c2 == 0) zd = (c3 == 1 || c3 == 3) ? -1 : 0;
+								else if (c1 == 1 && c2 == 2) zd = 1;
+								else if (c1 == 3 && c2 == 0) zd = 2;
+							}
+						}
+					}
+					if (t >= 2 && t < tlen) {
+						const int c0 = SFQ[t], c1 = SFQ[t - 1], c2 = SFQ[t - 2];
+						if (!revc) {
+							if (is_for) {
+								if (c1 == 0 && c0 == 2) za = (c2 == 1 || c2 == 3) ? -1 : 0;
+								else if (c1 == 0 && c0 == 1) za = 2;
+							} else {
+								if (c1 == 0 && c0 == 1) za = (c2 == 1 || c2 == 3) ? -1 : 0;
+								else if (c1 == 2 && c0 == 1) za = 1;
+								else if (c1 == 0 && c0 == 3) za = 2;
+							}
+						} else {
+							if (is_for) {
+								if (c1 == 3 && c0 == 2) za = (c2 == 0 || c2 == 2) ? -1 : 0;
+								else if (c1 == 1 && c0 == 2) za = 1;
+								else if (c1 == 3 && c0 == 0) za = 2;
+							} else {
+								if (c1 == 3 && c0 == 1) za = (c2 == 0 || c2 == 2) ? -1 : 0;
+								else if (c1 == 3 && c0 == 2) za = 2;
+							}
+						}
+					}
+					B[t] = (B[t] & 0x00ff00ffu) | (uint32_t)(cost(zd) & 0xff) << 8 | (uint32_t)(cost(za) & 0xff) << 24;
+				}
+				STATE_SYNC();
+			}
 
 			int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 			const int n_rows = qlen + tlen - 1;
@@ -198,7 +266,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				const int st0 = iv.st0, en0 = iv.en0, st = iv.st, en = iv.en;
 				if (st0 > en0) { ez.zdropped = 1; break; }
 				// boundary values (:148-163)
-				const int bnd = SINGLE ? (r ? q : 0) : r == 0 ? nqe : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : sx8(-e2);
+				const int bnd = SINGLE ? (r ? q : 0) : r == 0 ? nqe : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : SPLICE ? 0 : sx8(-e2);
 				const int init1 = SINGLE ? 0 : nqe, init2 = SINGLE ? 0 : nqe2; // value of a state byte that was never computed
 				int x1 = init1, x21 = init2, v1 = st > 0 ? init1 : bnd;
 				if (st > 0 && st - 1 >= last_st && st - 1 <= last_en) {
@@ -207,7 +275,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				}
 				if (en >= r && lane == 0) {
 					A[r] = (A[r] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24; // u[r], y[r]
-					B[r] = (B[r] & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;                            // y2[r]
+					if (!SPLICE) B[r] = (B[r] & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;              // y2[r]
 				}
 				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes,
 				// and past T16 in the first bytes of the target copy exactly as in the reference's layout
@@ -262,6 +330,37 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							}
 							A[t] = pack4(un, vn, xn, yn);
 							if (with_cigar) pr[t - st] = (uint8_t)d;
+						} else if (SPLICE) { // ksw2_exts2_sse.c:37-64 with the variants at :283-285 (score only), :312-348 (left), :355-392 (right)
+							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), dn = sx8(b_cur >> 8), ac = sx8(b_cur >> 24);
+							int z = sx8(b_cur >> 16);
+							int a = sx8(xt1 + vt1), b = sx8(yt + ut), a2 = sx8(x2t1 + vt1), d = 0;
+							const int a2a = sx8(a2 + ac);
+							if (!with_cigar) { z = z > a ? z : a; z = z > b ? z : b; z = z > a2a ? z : a2a; }
+							else if (!right) {
+								d = a > z ? 1 : 0;    z = z > a ? z : a;
+								d = b > z ? 2 : d;    z = z > b ? z : b;
+								d = a2a > z ? 3 : d;  z = z > a2a ? z : a2a;
+							} else {
+								d = z > a ? 0 : 1;    z = z > a ? z : a;
+								d = z > b ? d : 2;    z = z > b ? z : b;
+								d = z > a2a ? d : 3;  z = z > a2a ? z : a2a;
+							}
+							const int un = z - vt1, vn = z - ut;
+							const int tmp = sx8(z - q);
+							a = sx8(a - tmp), b = sx8(b - tmp), a2 = sx8(a2 - sx8(z - q2));
+							int xn, yn, x2n;
+							if (!with_cigar || !right) {
+								xn = (a > 0 ? a : 0) - qe;      d |= a > 0 ? 0x08 : 0;
+								yn = (b > 0 ? b : 0) - qe;      d |= b > 0 ? 0x10 : 0;
+								x2n = (a2 > dn ? a2 : dn) - q2; d |= a2 > dn ? 0x20 : 0;
+							} else {
+								xn = (a > 0 ? a : 0) - qe;      d |= a >= 0 ? 0x08 : 0;
+								yn = (b > 0 ? b : 0) - qe;      d |= b >= 0 ? 0x10 : 0;
+								x2n = (a2 > dn ? a2 : dn) - q2; d |= a2 >= dn ? 0x20 : 0;
+							}
+							A[t] = pack4(un, vn, xn, yn);
+							B[t] = (b_cur & 0xffffff00u) | (uint32_t)(x2n & 0xff);
+							if (with_cigar) pr[t - st] = (uint8_t)d;
 						} else {
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), y2t = sx8(b_cur >> 8);
 							int z = sx8(b_cur >> 16);
@@ -303,7 +402,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				// score differences read back from the state: signed bytes (dual-affine) or unsigned bytes minus (q+e) (single, :236-262)
 				auto du = [&](uint32_t w) { return SINGLE ? (int)(w & 0xff) - qe : sx8((int)w); };
 				auto dv = [&](uint32_t w) { return SINGLE ? (int)(w >> 8 & 0xff) - qe : sx8((int)(w >> 8)); };
-				const int zd_e = SINGLE ? e : e2, h00 = SINGLE ? qe : qe_in;
+				const int zd_e = SINGLE ? e : SPLICE ? 0 : e2, h00 = SINGLE ? qe : qe_in;
 				if (!approx_max) { // exact row maximum in the reference's scan order (:325-365)
 					int max_H, max_t;
 					if (r > 0) {
@@ -359,10 +458,11 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 			if (with_cigar) {
 				__threadfence_block(); // the direction bytes were written by all lanes of this wave
 				if (!ez.zdropped && (flag & KSW_EXTZ_ONLY) && ez.mqe + J.end_bonus > ez.max) ez.reach_end = 1;
+				const int min_intron = SPLICE ? long_thres : 0;
 				if (lane == 0) {
-					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, g);
-					else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, g);
-					else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, g);
+					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, min_intron, g);
+					else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, min_intron, g);
+					else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, min_intron, g);
 					if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
 				}
 				// pack the CIGAR into the pool: forward order unless the caller asked for the traceback order (:153-155 of ksw2.h)
@@ -392,27 +492,32 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 
 #undef STATE_SYNC
 
+namespace {
+template <bool LDS_STATE, int MODE>
+void launch_mode(const KswLaunch &L, int n_blocks, int waves_per_block, size_t lds, hipStream_t stream)
+{
+	if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<LDS_STATE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((ksw_extd2_kernel<LDS_STATE, MODE>), dim3(n_blocks), dim3(64 * waves_per_block), lds, stream, L);
+	HIP_CHECK(hipGetLastError());
+}
+template <bool LDS_STATE>
+void launch_any(const KswLaunch &L, int n_blocks, int waves_per_block, size_t lds, hipStream_t stream)
+{
+	if (L.splice) launch_mode<LDS_STATE, 2>(L, n_blocks, waves_per_block, lds, stream);
+	else if (L.single_affine) launch_mode<LDS_STATE, 1>(L, n_blocks, waves_per_block, lds, stream);
+	else launch_mode<LDS_STATE, 0>(L, n_blocks, waves_per_block, lds, stream);
+}
+}
+
 void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream)
 {
-	const bool single = L.single_affine;
 	if (L.n_jobs <= 0) return;
 	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
 	const size_t lds = region * waves_per_block;
 	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
-	if (L.state_pool) { // state in HBM: any job length
-		if (single) hipLaunchKernelGGL((ksw_extd2_kernel<false, true>), dim3(n_blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, L);
-		else hipLaunchKernelGGL((ksw_extd2_kernel<false, false>), dim3(n_blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, L);
-		HIP_CHECK(hipGetLastError());
-		return;
-	}
+	if (L.state_pool) { launch_any<false>(L, n_blocks, waves_per_block, 0, (hipStream_t)stream); return; } // state in HBM: any job length
 	if (lds > 160 * 1024) throw std::runtime_error("[mm2amd] ksw_extd2: job class does not fit LDS");
-	if (lds > 64 * 1024) {
-		if (single) HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		else HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	}
-	if (single) hipLaunchKernelGGL((ksw_extd2_kernel<true, true>), dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
-	else hipLaunchKernelGGL((ksw_extd2_kernel<true, false>), dim3(n_blocks), dim3(64 * waves_per_block), lds, (hipStream_t)stream, L);
-	HIP_CHECK(hipGetLastError());
+	launch_any<true>(L, n_blocks, waves_per_block, lds, (hipStream_t)stream);
 }
 
 } // namespace mm2amd

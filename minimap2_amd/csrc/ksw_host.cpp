@@ -50,7 +50,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	constexpr size_t NBINS = (size_t)kNTiers * NB, CH = 16384;
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
-	const bool scoring_ok = sc.m == 5 && !disable_fast && !single_affine && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
+	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
+	const bool scoring_ok = sc.m == 5 && !disable_fast && !single_affine && !splice && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
 	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
@@ -72,7 +73,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 				tier = kFirstExact;
 				while (tier < kNTiers - 1 && dim > kTiers[tier].max_dim) ++tier;
 			}
-			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 ? INT32_MAX : j.w + 1);
+			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
 			int cb = (int)(std::sqrt(cost) * (fast ? 1.0 : 0.25)); // fast classes: cost <= 1536*512; exact classes reach 11264*752
 			if (cb >= NB) cb = NB - 1;
 			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
@@ -86,7 +87,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			cs.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
 			cs.max_T16 = std::max(cs.max_T16, r16(j.tlen)), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
 			if (!(j.flag & KSW_SCORE_ONLY)) {
-				const size_t db = fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, j.w);
+				const size_t db = fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 				if (db > 160 * 1024) cs.alg_bytes += (double)db;
 				cs.slot_bytes = std::max(cs.slot_bytes, db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
 				st.sum_len += (size_t)j.qlen + j.tlen;
@@ -180,7 +181,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.counter = d_counter.p + tier;
 			L.max_T16 = P.max_T16, L.max_Q16 = P.max_Q16, L.sc = sc;
 			L.state_pool = tier == kHbmTier ? d_state.p : nullptr;
-			L.single_affine = single_affine;
+			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, kTiers[tier].waves_per_block, stream);

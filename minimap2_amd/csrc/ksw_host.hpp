@@ -18,7 +18,6 @@ struct KswRunner {
 	PinBuf<uint32_t> cigar_host;      // the batch's CIGARs as the kernel packed them
 	std::vector<uint32_t> perm, bucket, chunk_hist;
 	int n_threads = 1, lane = 0;
-	bool single_affine = false;      // run the batch with the single-affine recurrences (ksw_extz2_sse); the gap-fill kernel is dual-affine only
 	bool disable_fast = false;       // route every job through the lane-exact kernel (MM2AMD_KSW_EXACT_ONLY=1; for A/B checks)
 	class KernelProfiler *prof = nullptr; // optional per-launch timing
 	size_t dir_budget = (size_t)12 << 30; // bytes of HBM we allow for direction matrices

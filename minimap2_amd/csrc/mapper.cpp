@@ -40,8 +40,9 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	const int64_t unsupported = F_SR | F_SPLICE | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_RMQ | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
-	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads with dual-affine scoring (map-ont / map-hifi class presets); sr, splice, qstrand, heap-sort, RMQ-primary and all-vs-all modes are not implemented");
+	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_RMQ | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
+	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice class presets); sr, splice:sr, qstrand, heap-sort, RMQ-primary and all-vs-all modes are not implemented");
+	if (opt.max_occ > opt.mid_occ) throw std::invalid_argument("[mm2amd] re-chaining with a raised occurrence cap (max_occ > mid_occ, map.c:293) is a short-read feature and is not implemented");
 	if (!(opt.flag & F_CIGAR)) throw std::invalid_argument("[mm2amd] only base-level alignment mode (MM_F_CIGAR, -c/-a) is implemented");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	if (fi.n_alt) throw std::invalid_argument("[mm2amd] ALT-aware mapping is not implemented");
@@ -87,7 +88,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	sp.min_cnt = opt_.min_cnt, sp.min_chain_score = opt_.min_chain_score;
 	sp.chn_pen_gap = (float)(opt_.chain_gap_scale * 0.01 * fi_.k);
 	sp.chn_pen_skip = (float)(opt_.chain_skip_scale * 0.01 * fi_.k);
-	sp.is_cdna = 0;
+	sp.is_cdna = (opt_.flag & F_SPLICE) ? 1 : 0; // map.c:230,280
 	if (opt_.max_gap_ref <= 0 && opt_.max_frag_len > 0) throw std::invalid_argument("[mm2amd] max_frag_len-derived chaining gap is a paired-end feature and is not implemented");
 
 	// Sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight) and are the
@@ -199,7 +200,8 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
 		KswScoring sc;
 		memcpy(sc.mat, aligner.mat(), 25);
-		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.single = (opt_.q == opt_.q2 && opt_.e == opt_.e2) ? 1 : 0, sc.pad = 0;
+		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.noncan = (int8_t)opt_.noncan;
+		sc.single = (opt_.flag & F_SPLICE) ? 2 : (opt_.q == opt_.q2 && opt_.e == opt_.e2) ? 1 : 0; // which DP mm_align_pair picks (align.c:352-360)
 		std::vector<std::vector<KswJob>> &per_read_jobs = ds.per_read_jobs;
 		if ((long)per_read_jobs.size() < m) per_read_jobs.resize(m);
 		std::vector<size_t> &job_base = ds.job_base;
@@ -245,7 +247,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), res.regs);
 				set_sam_pri(res.regs);
 			}
-			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, false);
+			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, opt_.flag & F_SPLICE);
 		});
 		Trace::get().add(lane, "host:finish", t0, now());
 		stats.t_finish += now() - t0;

@@ -89,7 +89,9 @@ public:
 				ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1, ez.score = ez.mqe = ez.mte = ORA_NEG_INF, ez.zdropped = 1;
 			} else {
 				cg.resize((size_t)j.qlen + j.tlen + 8);
-				if (sc.single) ora_ksw_extz2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez, cg.data(), (int)cg.size());
+				if (sc.single == 2) ora_ksw_exts2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.noncan, j.zdrop, j.end_bonus, 0, 0, j.flag & 0x1fff, nullptr,
+				                                  &ez, cg.data(), (int)cg.size());
+				else if (sc.single) ora_ksw_extz2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez, cg.data(), (int)cg.size());
 				else ora_ksw_extd2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff,
 				                   &ez, cg.data(), (int)cg.size());
 			}

@@ -43,6 +43,17 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-E") == 0) { char *s; mopt.e = mopt.e2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.e2 = strtol(s + 1, &s, 10); }
 		else if (strcmp(argv[k], "-A") == 0) mopt.a = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-B") == 0) mopt.b = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-u") == 0) { /* main.c:332-336 */
+			const char c = argv[++k][0];
+			if (c == 'b') mopt.flag |= MM_F_SPLICE_FOR | MM_F_SPLICE_REV;
+			else if (c == 'f') mopt.flag |= MM_F_SPLICE_FOR, mopt.flag &= ~MM_F_SPLICE_REV;
+			else if (c == 'r') mopt.flag |= MM_F_SPLICE_REV, mopt.flag &= ~MM_F_SPLICE_FOR;
+			else mopt.flag &= ~(MM_F_SPLICE_FOR | MM_F_SPLICE_REV);
+		} else if (strcmp(argv[k], "-G") == 0) mm_mapopt_max_intron_len(&mopt, atoi(argv[++k]));
+		else if (strcmp(argv[k], "-C") == 0) mopt.noncan = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-z") == 0) { char *s; mopt.zdrop = mopt.zdrop_inv = strtol(argv[++k], &s, 10); if (*s == ',') mopt.zdrop_inv = strtol(s + 1, &s, 10); }
+		else if (strcmp(argv[k], "--splice-flank=no") == 0) mopt.flag &= ~MM_F_SPLICE_FLANK;
+		else if (strcmp(argv[k], "-J") == 0) { if (atoi(argv[++k]) == 0) mopt.flag |= MM_F_SPLICE_OLD; else mopt.flag &= ~MM_F_SPLICE_OLD; }
 		else if (strcmp(argv[k], "--cs") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_CIGAR;
 		else if (strcmp(argv[k], "--MD") == 0) mopt.flag |= MM_F_OUT_MD;
 		else if (strcmp(argv[k], "--eqx") == 0) mopt.flag |= MM_F_EQX;

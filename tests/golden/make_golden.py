@@ -25,6 +25,7 @@ CASES = {
     "ont_paf": ("ont", "map-ont", 0.5, 25, 102, ["-c"]),
     "hifi_sam": ("hifi", "map-hifi", 1.0, 20, 103, ["-a"]),
     "lrhq_paf_cs": ("hifi", "lr:hq", 0.5, 15, 104, ["-c", "--cs"]),
+    "cdna_sam": ("cdna", "splice", 1.0, 60, 107, ["-a"]),
 }
 
 

@@ -39,3 +39,22 @@ def random_pair(rng, qlen, err=0.12, n_frac=0.0, indel=0):
     if len(q) == 0:
         q = np.array([0], dtype=np.uint8)
     return q, t
+
+
+def spliced_pair(rng, n_exon, err, with_signals=True, exon=(20, 160), intron=(30, 700)):
+    """a target made of exons and introns (GT..AG or CT..AC at the intron ends), and the spliced, mutated query"""
+    exons = [rng.integers(0, 4, int(rng.integers(exon[0], exon[1])), dtype=np.uint8) for _ in range(n_exon)]
+    t = [exons[0]]
+    strand = int(rng.integers(0, 2))
+    for ex in exons[1:]:
+        iv = rng.integers(0, 4, int(rng.integers(intron[0], intron[1])), dtype=np.uint8)
+        if with_signals and rng.random() < 0.8:
+            if strand == 0:
+                iv[:2] = [2, 3]; iv[-2:] = [0, 2]
+            else:
+                iv[:2] = [1, 3]; iv[-2:] = [0, 1]
+        t += [iv, ex]
+    q = mutate(rng, np.concatenate(exons), err)
+    if len(q) == 0:
+        q = np.array([0], dtype=np.uint8)
+    return q, np.concatenate(t)

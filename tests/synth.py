@@ -53,6 +53,40 @@ def gen_reads(rng, contigs, n_reads, mean_len, sd_len, err, min_len=1000):
     return reads
 
 
+def gen_transcripts(rng, contigs, n_reads, err, max_intron=6000):
+    """Spliced reads: 2..8 exons of 60..500 bases separated by introns (mostly 80..max_intron, some ~20 kb), concatenated.  The
+    reference is edited in place so that most introns carry the canonical signals (GT..AG for a gene on the + strand, CT..AC
+    for one on the - strand); a read is the transcript or its reverse complement, with per-base error `err`."""
+    reads = []
+    for _ in range(n_reads):
+        c = int(rng.integers(0, len(contigs)))
+        ctg = contigs[c]
+        n_exon = int(rng.integers(2, 9))
+        ex = rng.integers(60, 500, n_exon)
+        it = rng.integers(80, max_intron, n_exon - 1)
+        it[rng.random(n_exon - 1) < 0.1] = int(rng.integers(15000, 25000))
+        span = int(ex.sum() + it.sum())
+        if span + 10 > len(ctg):
+            it = np.minimum(it, 300)
+            span = int(ex.sum() + it.sum())
+        pos = int(rng.integers(0, len(ctg) - span))
+        minus = rng.random() < 0.5
+        parts = []
+        for k in range(n_exon):
+            parts.append((pos, pos + int(ex[k])))
+            pos += int(ex[k])
+            if k < n_exon - 1:
+                if rng.random() < 0.9:
+                    ctg[pos:pos + 2] = [1, 3] if minus else [2, 3]
+                    ctg[pos + int(it[k]) - 2:pos + int(it[k])] = [0, 1] if minus else [0, 2]
+                pos += int(it[k])
+        s = np.concatenate([ctg[a:b] for a, b in parts])
+        if rng.random() < 0.5:
+            s = COMP[s[::-1]]
+        reads.append((s, err))
+    return [mutate_read(rng, s, e) for s, e in reads]  # after all edits of the reference
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):
@@ -61,7 +95,7 @@ def write_fasta(path, names, seqs, width=0):
             f.write(b"\n")
 
 
-PROFILES = {"ont": (10000, 1000, 0.12), "hifi": (15000, 1500, 0.005)}
+PROFILES = {"ont": (10000, 1000, 0.12), "hifi": (15000, 1500, 0.005), "cdna": (0, 0, 0.04)}
 
 
 def make(kind, outdir, ref_mb, n_reads, seed=11, n_contig=None):
@@ -72,7 +106,7 @@ def make(kind, outdir, ref_mb, n_reads, seed=11, n_contig=None):
         n_contig = max(1, min(24, total // 1000000))
     contigs = gen_reference(rng, total, n_contig)
     mean, sd, err = PROFILES[kind]
-    reads = gen_reads(rng, contigs, n_reads, mean, sd, err)
+    reads = gen_transcripts(rng, contigs, n_reads, err) if kind == "cdna" else gen_reads(rng, contigs, n_reads, mean, sd, err)
     ref = os.path.join(outdir, "ref.fa")
     rd = os.path.join(outdir, "reads.fa")
     write_fasta(ref, ["chr%d" % (i + 1) for i in range(n_contig)], contigs)

@@ -61,3 +61,16 @@ def test_single_affine_scoring_sam_identical(tmp_path):
     # -O4 -E2 with equal second gap cost: mm_align_pair takes ksw_extz2_sse (align.c:353-354)
     _compare(tmp_path, "ont", "map-ont", 3, 120, 15, ["-a", "-O", "4", "-E", "2"])
     _compare(tmp_path, "hifi", "map-hifi", 3, 60, 16, ["-c", "-O", "6,6", "-E", "2,2"])
+
+
+def test_splice_sam_identical(tmp_path):
+    # -x splice: chaining with is_cdna, both transcript strands aligned with the splice-aware DP (ksw_exts2), N in CIGARs, ts:A tags
+    assert _compare(tmp_path, "cdna", "splice", 6, 500, 17, ["-a"]) > 500
+    _compare(tmp_path, "cdna", "splice:hq", 4, 300, 18, ["-c", "--cs"])
+
+
+def test_splice_variants_identical(tmp_path):
+    # one strand only / no signal matching / old splice model / shorter maximum intron
+    _compare(tmp_path, "cdna", "splice", 3, 200, 19, ["-a", "-u", "f"])
+    _compare(tmp_path, "cdna", "splice", 3, 200, 19, ["-c", "-u", "n", "-J", "0"])
+    _compare(tmp_path, "cdna", "splice", 3, 200, 19, ["-a", "-G", "10000", "-C", "5", "--splice-flank=no"])

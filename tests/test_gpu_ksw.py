@@ -169,3 +169,40 @@ def test_single_affine_extz2(sc):
         assert got[k] == ora_extz2(q, t, mat, go, ge, w, zdrop, eb, flag), (k, len(q), len(t), w, hex(flag))
         if have_ref and k % 9 == 0:
             assert got[k] == ref_extz2(q, t, mat, go, ge, w, zdrop, eb, flag)
+
+
+@pytest.mark.parametrize("sc", [(1, 2, 2, 1, 32, 9), (1, 4, 6, 1, 24, 5)])
+def test_splice_exts2(sc):
+    """the splice instantiation of the exact kernel (ksw_exts2_sse semantics, junc == NULL) against its oracle and the reference:
+    both transcript strands, both splice models, left/right extension and gap fill, multi-exon targets, an intron long enough
+    for the HBM-state variant"""
+    import minimap2_amd as mm
+    from reflib import ora_exts2, ref_exts2
+    from seqsim import spliced_pair
+    a, b, go, ge, go2, noncan = sc
+    rng = np.random.default_rng(sum(sc))
+    mat = ts_mat(a, b, 1, 0)
+    jobs = []
+    for it in range(300):
+        q, t = spliced_pair(rng, int(rng.integers(1, 5)), float(rng.choice([0.0, 0.03, 0.1])))
+        base = int(rng.choice([0x08, 0x00, 0x40, 0xC2, 0x41, 0x18]))
+        if base & 0x80:
+            q, t = q[::-1].copy(), t[::-1].copy()
+        flag = base | int(rng.choice([0x100, 0x200])) | 0x400 | (0x800 if it % 3 else 0)
+        jobs.append((q, t, -1, int(rng.choice([-1, 100, 200])), int(rng.choice([-1, 5])), flag))
+    for tl in (16, 64, 256):
+        t = rng.integers(0, 4, tl, dtype=np.uint8)
+        q = rng.integers(0, 4, int(rng.integers(1, 2 * tl)), dtype=np.uint8)
+        for flag in (0x08, 0x40, 0xC2, 0):
+            jobs.append((q, t, -1, 200, 5, flag | 0x100 | 0x400 | 0x800))
+            jobs.append((q, t, 7, 200, 5, flag))  # no strand: no splice signal costs; w is ignored
+    q, t = spliced_pair(rng, 3, 0.03, exon=(100, 200), intron=(9000, 14000))
+    jobs.append((q, t, -1, 200, -1, 0x100 | 0x400 | 0x800))
+    jobs.append((q, t, -1, 200, -1, 0x200 | 0x400 | 0x08))
+    got = mm.ksw_exts2_batch(jobs, mat, go, ge, go2, noncan)
+    have_ref = os.path.exists(reflib.REF_SO)
+    for k, (q, t, w, zdrop, eb, flag) in enumerate(jobs):
+        assert got[k] == ora_exts2(q, t, mat, go, ge, go2, noncan, zdrop, eb, 9, 5, flag), (k, len(q), len(t), hex(flag))
+        if have_ref and k % 9 == 0:
+            assert got[k] == ref_exts2(q, t, mat, go, ge, go2, noncan, zdrop, eb, 9, 5, flag)
+    assert any(c & 0xf == 3 for r in got for c in r[10])  # introns were found

@@ -90,3 +90,16 @@ def test_single_affine_scoring(tmp_path):
         pytest.skip("needs oracle/_ref")
     ref, reads, _, _ = synth.make("ont", str(tmp_path), 0.5, 20, 105)
     _pair(["-x", "map-ont", "-a", "-O", "4", "-E", "2"], ref, reads)
+
+
+@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice:hq", "-c", "--cs"], ["-x", "splice", "-a", "-u", "f"],
+                                  ["-x", "splice", "-c", "-u", "n", "-J", "0"], ["-x", "splice", "-a", "-G", "10000", "-C", "5", "--splice-flank=no"]])
+def test_splice(tmp_path, args):
+    """spliced alignment (-x splice): cDNA chaining, per-strand alignment with the splice-aware DP (oracle backend), strand pick,
+    N operations and ts tags -- host logic vs the reference on synthetic multi-exon transcripts"""
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, reads, _, _ = synth.make("cdna", str(tmp_path), 2.0, 150, 106)
+    out = _pair(args, ref, reads)
+    assert any(b"N" in l.split(b"\t")[5] for l in out.split(b"\n") if l and not l.startswith(b"@") and b"\t" in l) or "-c" in args

@@ -8,31 +8,12 @@ import pytest
 
 import reflib
 from reflib import ref_exts2, ora_exts2, ts_mat
-from seqsim import mutate
+from seqsim import spliced_pair
 
 pytestmark = pytest.mark.skipif(not os.path.exists(reflib.REF_SO), reason="needs oracle/_ref (dev container)")
 
 SPL = [(1, 2, 2, 1, 32, 9), (1, 4, 6, 1, 24, 5)]  # (a, b, q, e, q2, noncan): -x splice, -x splice:hq
 FOR, REV, FLANK, CMPLX, SCORE = 0x100, 0x200, 0x400, 0x800, 0x1000
-
-
-def spliced_pair(rng, n_exon, err, with_signals=True):
-    """a target made of exons and introns (GT..AG or CT..AC at the intron ends), and the spliced, mutated query"""
-    exons = [rng.integers(0, 4, int(rng.integers(20, 160)), dtype=np.uint8) for _ in range(n_exon)]
-    t = [exons[0]]
-    strand = int(rng.integers(0, 2))
-    for ex in exons[1:]:
-        intron = rng.integers(0, 4, int(rng.integers(30, 700)), dtype=np.uint8)
-        if with_signals and rng.random() < 0.8:
-            if strand == 0:
-                intron[:2] = [2, 3]; intron[-2:] = [0, 2]
-            else:
-                intron[:2] = [1, 3]; intron[-2:] = [0, 1]
-        t += [intron, ex]
-    q = mutate(rng, np.concatenate(exons), err)
-    if len(q) == 0:
-        q = np.array([0], dtype=np.uint8)
-    return q, np.concatenate(t)
 
 
 @pytest.mark.parametrize("strand", [FOR, REV])
