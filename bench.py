@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line.  "roofline" is the dominant kernel's algorithmic by
 stream; "cpu_baseline" is the UNMODIFIED reference's mm_map on all host cores over a bounded sample of the same batch
 against the same index contents (oracle/_ref; N=1 only)."""
 import argparse
+import math
 import ctypes as C
 import json
 import os
@@ -33,16 +34,96 @@ def log(*a):
 
 
 def gen_reference(torch, dev, seed, total, n_contig):
-    """uniform i.i.d. ACGT; returns (flat uint8 code tensor on dev, list of ASCII byte strings, contig length)"""
+    """uniform i.i.d. ACGT; returns (flat uint8 code tensor on dev, contig length)"""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     per = total // n_contig
-    codes = torch.randint(0, 4, (per * n_contig,), dtype=torch.uint8, device=dev, generator=g)
+    return torch.randint(0, 4, (per * n_contig,), dtype=torch.uint8, device=dev, generator=g), per
+
+
+def reference_ascii(torch, dev, codes, per, n_contig):
+    """the contigs as ASCII byte strings (what the index builder takes)"""
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     asc = lut[codes.long()] if codes.numel() < (1 << 28) else torch.cat([lut[c.long()] for c in codes.split(1 << 28)])
     host = asc.cpu().numpy()
     del asc
-    return codes, [host[i * per:(i + 1) * per].tobytes() for i in range(n_contig)], per
+    return [host[i * per:(i + 1) * per].tobytes() for i in range(n_contig)]
+
+
+def plant_genes(torch, dev, seed, codes, per, n_contig, n_genes):
+    """SURVEY.md 8(d) SPL: synthetic genes of 4-10 exons (80-400 bp) separated by introns of 200 bp - 50 kb (log-uniform) that
+    carry GT..AG (gene on the + strand) or CT..AC (- strand) at their ends; the signals are written into the reference.
+    Returns the gene table the read generator samples from."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    E = 10
+    n_exon = torch.randint(4, E + 1, (n_genes,), device=dev, generator=g)
+    col = torch.arange(E, device=dev)[None, :]
+    ex = torch.randint(80, 401, (n_genes, E), device=dev, generator=g) * (col < n_exon[:, None])
+    lo, hi = math.log(200.0), math.log(50000.0)
+    it = torch.exp(torch.rand(n_genes, E, device=dev, generator=g) * (hi - lo) + lo).long() * (col < (n_exon - 1)[:, None])
+    step = ex + it
+    span = step.sum(1)
+    cid = torch.randint(0, n_contig, (n_genes,), device=dev, generator=g)
+    st = (torch.rand(n_genes, device=dev, generator=g, dtype=torch.float64) * (per - span - 1).double()).long()
+    ex_st = cid[:, None] * per + st[:, None] + torch.cumsum(step, 1) - step  # flat start of every exon
+    minus = torch.rand(n_genes, device=dev, generator=g) < 0.5
+    has = it > 0
+    i0 = (ex_st + ex)[has]
+    i1 = i0 + it[has]
+    first = torch.where(minus[:, None].expand(-1, E)[has], 1, 2).to(torch.uint8)  # C or G
+    codes[i0] = first
+    codes[i0 + 1] = 3
+    codes[i1 - 2] = 0
+    codes[i1 - 1] = first
+    return {"ex_st": ex_st, "ex_len": ex, "minus": minus}
+
+
+def mutate_reads(torch, dev, g, src, bounds, err):
+    """per-base error split 1/3 substitution, 1/3 insertion (random base before the kept base), 1/3 deletion; returns ASCII strings"""
+    n = int(src.numel())
+    hit = torch.rand(n, device=dev, generator=g) < err
+    kind = torch.randint(0, 3, (n,), device=dev, generator=g, dtype=torch.uint8)
+    sub, ins, dele = hit & (kind == 0), hit & (kind == 1), hit & (kind == 2)
+    del hit, kind
+    src = torch.where(sub, (src + torch.randint(1, 4, (n,), device=dev, generator=g, dtype=torch.uint8)) & 3, src)
+    reps = 1 + ins.long() - dele.long()
+    out = torch.repeat_interleave(src, reps)
+    first = torch.cumsum(reps, 0) - reps
+    ins_at = first[ins]
+    out[ins_at] = torch.randint(0, 4, (int(ins_at.numel()),), device=dev, generator=g, dtype=torch.uint8)
+    cum = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(reps, 0)])
+    ob = cum[bounds].cpu().numpy()
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    asc = lut[out.long()].cpu().numpy()
+    return [asc[ob[i]:ob[i + 1]].tobytes() for i in range(len(ob) - 1)]
+
+
+def gen_transcripts(torch, dev, seed, codes, genes, n_reads, err):
+    """cDNA reads: the concatenated exons of a random gene, in transcript orientation or its reverse complement"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    pick = torch.randint(0, genes["ex_st"].shape[0], (n_reads,), device=dev, generator=g)
+    ex_st, ex_len = genes["ex_st"][pick], genes["ex_len"][pick]
+    E = ex_len.shape[1]
+    lens = ex_len.sum(1)
+    rev = torch.rand(n_reads, device=dev, generator=g) < 0.5
+    bounds = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(lens, 0)])
+    # per exon segment: (read, exon) flattened; base k of the segment comes from ex_st + k
+    seg_len = ex_len.reshape(-1)
+    seg_st = ex_st.reshape(-1)
+    seg_id = torch.repeat_interleave(torch.arange(n_reads * E, device=dev), seg_len)
+    seg_b = torch.cumsum(seg_len, 0) - seg_len
+    idx = seg_st[seg_id] + (torch.arange(int(seg_len.sum().item()), device=dev) - seg_b[seg_id])
+    src = codes[idx]  # genomic + strand, exon order
+    rid = seg_id // E
+    j = torch.arange(src.numel(), device=dev) - bounds[:-1][rid]
+    revb = rev[rid]
+    src = torch.where(revb, 3 - src, src)
+    dst = bounds[:-1][rid] + torch.where(revb, lens[rid] - 1 - j, j)
+    out = torch.empty_like(src)
+    out[dst] = src
+    return mutate_reads(torch, dev, g, out, bounds, err)
 
 
 def gen_reads(torch, dev, seed, codes, per, n_contig, n_reads, mean_len, sd_len, err):
@@ -63,21 +144,7 @@ def gen_reads(torch, dev, seed, codes, per, n_contig, n_reads, mean_len, sd_len,
     src = codes[idx]
     src = torch.where(revb, 3 - src, src)
     del idx, j
-    hit = torch.rand(n, device=dev, generator=g) < err
-    kind = torch.randint(0, 3, (n,), device=dev, generator=g, dtype=torch.uint8)
-    sub, ins, dele = hit & (kind == 0), hit & (kind == 1), hit & (kind == 2)
-    del hit, kind
-    src = torch.where(sub, (src + torch.randint(1, 4, (n,), device=dev, generator=g, dtype=torch.uint8)) & 3, src)
-    reps = 1 + ins.long() - dele.long()
-    out = torch.repeat_interleave(src, reps)
-    first = torch.cumsum(reps, 0) - reps
-    ins_at = first[ins]
-    out[ins_at] = torch.randint(0, 4, (int(ins_at.numel()),), device=dev, generator=g, dtype=torch.uint8)
-    cum = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(reps, 0)])
-    ob = cum[bounds].cpu().numpy()
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    asc = lut[out.long()].cpu().numpy()
-    return [asc[ob[i]:ob[i + 1]].tobytes() for i in range(n_reads)]
+    return mutate_reads(torch, dev, g, src, bounds, err)
 
 
 def main():
@@ -89,7 +156,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step")
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / gpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "map-hifi", "lr:hq"], help="map-ont is the BASELINE.json metric; the others are for experiments")
+    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "map-hifi", "lr:hq", "splice"], help="map-ont is the BASELINE.json metric; the others are BASELINE.json's further configs / experiments")
     ap.add_argument("--read-len", type=int, default=0, help="mean read length (0: 10000 for map-ont, 15000 otherwise)")
     ap.add_argument("--err", type=float, default=-1.0, help="per-base error rate (<0: 0.12 for map-ont, 0.005 otherwise)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
@@ -122,14 +189,19 @@ def main():
     t0 = time.time()
     total = int(a.ref_mb * 1e6)
     n_contig = max(1, min(24, total // 1000000))
-    codes, refs, per = gen_reference(torch, dev, 11, total, n_contig)
+    codes, per = gen_reference(torch, dev, 11, total, n_contig)
     total = per * n_contig
+    genes = plant_genes(torch, dev, 12, codes, per, n_contig, max(100, min(20000, total // 150000))) if a.preset == "splice" else None
+    refs = reference_ascii(torch, dev, codes, per, n_contig)
     names = ["chr%d" % (i + 1) for i in range(n_contig)]
     log("rank %d: reference %d Mb in %d contigs generated in %.1f s" % (rank, total // 1000000, n_contig, time.time() - t0))
     t0 = time.time()
-    mean_len = a.read_len if a.read_len > 0 else (10000 if a.preset == "map-ont" else 15000)
-    err = a.err if a.err >= 0 else (0.12 if a.preset == "map-ont" else 0.005)
-    reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, mean_len // 10, err)
+    mean_len = a.read_len if a.read_len > 0 else {"map-ont": 10000, "splice": 2000}.get(a.preset, 15000)
+    err = a.err if a.err >= 0 else {"map-ont": 0.12, "splice": 0.05}.get(a.preset, 0.005)
+    if a.preset == "splice":
+        reads = gen_transcripts(torch, dev, 1000 + rank, codes, genes, a.reads, err)
+    else:
+        reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, mean_len // 10, err)
     del codes
     torch.cuda.empty_cache()
     batch_bases = sum(len(r) for r in reads)

@@ -69,15 +69,15 @@ struct KswLaunch {
 	uint8_t *dir_pool;      // device scratch for direction matrices: n_slots * slot_bytes
 	size_t slot_bytes;
 	int32_t *counter;       // device, zeroed before launch: persistent-wave job queue head
-	int32_t max_T16, max_Q16; // LDS sizing: largest 16-rounded tlen / qlen in the launch
+	int32_t ring, max_Q16;    // LDS sizing: slots in the per-position state rings (a power of two), largest 16-rounded qlen in the launch
 	bool single_affine = false;    // ksw_extz2 recurrences (q2/e2 ignored) instead of ksw_extd2
 	bool splice = false;           // ksw_exts2 recurrences (no band, intron state, N operations)
 	uint8_t *state_pool = nullptr; // when set: per-slot state slabs in HBM (ksw_lds_per_wave bytes each) instead of LDS
 	KswScoring sc;
 };
 
-// LDS bytes one wave needs for a job class (A,B,H int32 arrays + sf|qr bytes)
-__host__ __device__ inline size_t ksw_lds_per_wave(int max_T16, int max_Q16) { return (size_t)13 * max_T16 + max_Q16 + 16; }
+// LDS bytes one wave needs for a job class (A,B,H int32 rings + target ring + reversed query)
+__host__ __device__ inline size_t ksw_lds_per_wave(int ring, int max_Q16) { return (size_t)13 * ring + max_Q16 + 16; }
 
 // rows * bytes-per-row of the direction matrix of one job (ksw2_extd2_sse.c:94-95,122)
 __host__ __device__ inline size_t ksw_dir_bytes(int qlen, int tlen, int w)

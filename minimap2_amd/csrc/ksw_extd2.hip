@@ -10,10 +10,17 @@
 //
 // Exactness.  The reference evaluates 16-lane blocks over the block-aligned interval [st,en] around the
 // valid interval [st0,en0]; with a binding band valid cells read those out-of-range lanes (SURVEY.md
-// section 7, hard part 1).  We therefore sweep exactly [st,en], keep state bytes for all of
-// [0,16*ceil(tlen/16)), reproduce the 16-byte chunked score fill including its overshoot past en0 (and
+// section 7, hard part 1).  We therefore sweep exactly [st,en], keep the state bytes of every position a
+// later row can still read, reproduce the 16-byte chunked score fill including its overshoot past en0 (and
 // past the end of s[] into the target copy, ksw2_extd2_sse.c:166-180 with the layout of :107-110), and do
 // all arithmetic mod 256 with signed 8-bit compares.  Row maxima use the reference's scan order (:326-358).
+//
+// State window.  Row r touches positions [st-1, en+15] only, st and en never decrease, and a position is first
+// touched when it comes within 16 of en.  The per-position arrays are therefore rings of L.ring slots (a power of
+// two >= the widest row + 64): slot t & (ring-1) belongs to position t from the moment the frontier reaches it
+// (when it gets the values the reference's arrays are filled with up front) until position t + ring takes it over,
+// by which time no row can read t any more.  The footprint depends on min(qlen, tlen, band), not on tlen: a
+// 300 x 50000 splice gap fill needs the same 7 KB of LDS as a 300 x 300 one.
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "ksw_dev.hpp"
@@ -125,12 +132,13 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
 	const int slot = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
+	const size_t region = (ksw_lds_per_wave(L.ring, L.max_Q16) + 15) / 16 * 16;
 	uint8_t *my;
 	if (LDS_STATE) my = lds_raw + (size_t)wave_in_block * region;
 	else my = L.state_pool + (size_t)slot * region;
 	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
 	const int m = L.sc.m;
+	const int RS = L.ring, RM = RS - 1;
 
 	for (;;) {
 		int jid = 0;
@@ -175,89 +183,98 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 			}
 
-			uint32_t *A = (uint32_t *)my;      // byte0 u, byte1 v, byte2 x, byte3 y
-			uint32_t *B = A + T16;             // byte0 x2, byte1 y2 (splice: donor), byte2 s, (splice: byte3 acceptor)
-			int32_t *H = (int32_t *)(B + T16);
-			uint8_t *SFQ = (uint8_t *)(H + T16); // [0,T16): target copy; [T16, T16+Q16+16): reversed query, zero padded
+			uint32_t *A = (uint32_t *)my;      // rings of RS slots: byte0 u, byte1 v, byte2 x, byte3 y
+			uint32_t *B = A + RS;              // byte0 x2, byte1 y2 (splice: donor), byte2 s, (splice: byte3 acceptor)
+			int32_t *H = (int32_t *)(B + RS);
+			uint8_t *TG = (uint8_t *)(H + RS); // target copy (the reference's sf[])
+			uint8_t *QR = TG + RS;             // [0, Q16+16): reversed query, zero padded (the reference's qr[], which follows sf[])
 			const int nqe = sx8(-q - e), nqe2 = SPLICE ? sx8(-q2) : sx8(-q2 - e2);
+			auto tfetch = [&](int t) -> int { // target base t straight from the pools
+				const uint64_t pos = (flag & KSWJ_T_REVERSED) ? J.t_off - (uint64_t)t : J.t_off + (uint64_t)t;
+				return (flag & KSWJ_T_PACKED) ? (int)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (int)L.tpool[pos];
+			};
+			const bool sp_strand = SPLICE && (flag & (KSW_SPLICE_FOR | KSW_SPLICE_REV));
+			const bool sp_for = flag & KSW_SPLICE_FOR, sp_revc = flag & KSW_REV_CIGAR;
+			int sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0;
+			if (SPLICE) {
+				if (flag & KSW_SPLICE_CMPLX) sp0 = 3, sp1 = 5, sp2 = 7, sp3 = 10; // (int)({8,15,21,30} / 3. + .499)
+				else sp0 = (flag & KSW_SPLICE_FLANK) ? L.sc.noncan / 2 : 0, sp1 = sp2 = sp3 = L.sc.noncan;
+			}
+			auto sp_cost = [&](int z) { return z < 0 ? 0 : z == 0 ? -sp0 : z == 1 ? -sp1 : z == 2 ? -sp2 : -sp3; };
+			// Take positions (frontier, upto] into the window with the values the reference's up-front fill gives them
+			// (:107-128; splice: donor / acceptor costs from the neighbouring bases, ksw2_exts2_sse.c:120-194).
+			int frontier = -1;
+			auto admit = [&](int upto) {
+				for (int t = frontier + 1 + lane; t <= upto; t += 64) {
+					const int k = t & RM;
+					uint32_t bv = SINGLE ? 0u : SPLICE ? (uint32_t)(nqe2 & 0xff) : pack4(nqe2, nqe2, 0, 0);
+					if (sp_strand) {
+						int zd = 3, za = 3;
+						if (t < tlen - 4) {
+							const int c1 = tfetch(t + 1), c2 = tfetch(t + 2), c3 = tfetch(t + 3);
+							if (!sp_revc) {
+								if (sp_for) {
+									if (c1 == 2 && c2 == 3) zd = (c3 == 0 || c3 == 2) ? -1 : 0;
+									else if (c1 == 2 && c2 == 1) zd = 1;
+									else if (c1 == 0 && c2 == 3) zd = 2;
+								} else {
+									if (c1 == 1 && c2 == 3) zd = (c3 == 0 || c3 == 2) ? -1 : 0;
+									else if (c1 == 2 && c2 == 3) zd = 2;
+								}
+							} else {
+								if (sp_for) {
+									if (c1 == 2 && c2 == 0) zd = (c3 == 1 || c3 == 3) ? -1 : 0;
+									else if (c1 == 1 && c2 == 0) zd = 2;
+								} else {
+									if (c1 == 1 && c2 == 0) zd = (c3 == 1 || c3 == 3) ? -1 : 0;
+									else if (c1 == 1 && c2 == 2) zd = 1;
+									else if (c1 == 3 && c2 == 0) zd = 2;
+								}
+							}
+						}
+						if (t >= 2 && t < tlen) {
+							const int c0 = tfetch(t), c1 = tfetch(t - 1), c2 = tfetch(t - 2);
+							if (!sp_revc) {
+								if (sp_for) {
+									if (c1 == 0 && c0 == 2) za = (c2 == 1 || c2 == 3) ? -1 : 0;
+									else if (c1 == 0 && c0 == 1) za = 2;
+								} else {
+									if (c1 == 0 && c0 == 1) za = (c2 == 1 || c2 == 3) ? -1 : 0;
+									else if (c1 == 2 && c0 == 1) za = 1;
+									else if (c1 == 0 && c0 == 3) za = 2;
+								}
+							} else {
+								if (sp_for) {
+									if (c1 == 3 && c0 == 2) za = (c2 == 0 || c2 == 2) ? -1 : 0;
+									else if (c1 == 1 && c0 == 2) za = 1;
+									else if (c1 == 3 && c0 == 0) za = 2;
+								} else {
+									if (c1 == 3 && c0 == 1) za = (c2 == 0 || c2 == 2) ? -1 : 0;
+									else if (c1 == 3 && c0 == 2) za = 2;
+								}
+							}
+						}
+						bv |= (uint32_t)(sp_cost(zd) & 0xff) << 8 | (uint32_t)(sp_cost(za) & 0xff) << 24;
+					}
+					A[k] = SINGLE ? 0u : pack4(nqe, nqe, nqe, nqe);
+					B[k] = bv;
+					H[k] = KSW_NEG_INF;
+					TG[k] = t < tlen ? (uint8_t)tfetch(t) : (uint8_t)0;
+				}
+				if (upto > frontier) frontier = upto;
+			};
 
 			// ---- per-job initialisation (ksw2_extd2_sse.c:107-128) ----
-			for (int t = lane; t < T16; t += 64) {
-				A[t] = SINGLE ? 0u : pack4(nqe, nqe, nqe, nqe);
-				B[t] = SINGLE ? 0u : SPLICE ? (uint32_t)(nqe2 & 0xff) : pack4(nqe2, nqe2, 0, 0); // splice: donor = acceptor = 0 unless a strand is given
-				H[t] = KSW_NEG_INF;
-				uint8_t c = 0;
-				if (t < tlen) {
-					uint64_t pos = (flag & KSWJ_T_REVERSED) ? J.t_off - (uint64_t)t : J.t_off + (uint64_t)t;
-					c = (flag & KSWJ_T_PACKED) ? (uint8_t)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : L.tpool[pos];
-				}
-				SFQ[t] = c;
-			}
 			for (int i = lane; i < Q16 + 16; i += 64) {
 				uint8_t c = 0;
 				if (i < qlen) { // qr[i] = query[qlen-1-i]
 					int k = qlen - 1 - i;
 					c = L.qpool[(flag & KSWJ_Q_REVERSED) ? J.q_off - (uint64_t)k : J.q_off + (uint64_t)k];
 				}
-				SFQ[T16 + i] = c;
+				QR[i] = c;
 			}
+			admit(T16 - 1 < 31 ? T16 - 1 : 31);
 			STATE_SYNC();
-			if (SPLICE && (flag & (KSW_SPLICE_FOR | KSW_SPLICE_REV))) { // donor / acceptor costs from the neighbouring bases (:120-194)
-				const bool is_for = flag & KSW_SPLICE_FOR, revc = flag & KSW_REV_CIGAR;
-				int sp0, sp1, sp2, sp3;
-				if (flag & KSW_SPLICE_CMPLX) sp0 = 3, sp1 = 5, sp2 = 7, sp3 = 10; // (int)({8,15,21,30} / 3. + .499)
-				else sp0 = (flag & KSW_SPLICE_FLANK) ? L.sc.noncan / 2 : 0, sp1 = sp2 = sp3 = L.sc.noncan;
-				auto cost = [&](int z) { return z < 0 ? 0 : z == 0 ? -sp0 : z == 1 ? -sp1 : z == 2 ? -sp2 : -sp3; };
-				for (int t = lane; t < T16; t += 64) {
-					int zd = 3, za = 3;
-					if (t < tlen - 4) {
-						const int c1 = SFQ[t + 1], c2 = SFQ[t + 2], c3 = SFQ[t + 3];
-						if (!revc) {
-							if (is_for) {
-								if (c1 == 2 && c2 == 3) zd = (c3 == 0 || c3 == 2) ? -1 : 0;
-								else if (c1 == 2 && c2 == 1) zd = 1;
-								else if (c1 == 0 && c2 == 3) zd = 2;
-							} else {
-								if (c1 == 1 && c2 == 3) zd = (c3 == 0 || c3 == 2) ? -1 : 0;
-								else if (c1 == 2 && c2 == 3) zd = 2;
-							}
-						} else {
-							if (is_for) {
-								if (c1 == 2 && c2 == 0) zd = (c3 == 1 || c3 == 3) ? -1 : 0;
-								else if (c1 == 1 && c2 == 0) zd = 2;
-							} else {
-								if (c1 == 1 && c2 == 0) zd = (c3 == 1 || c3 == 3) ? -1 : 0;
-								else if (c1 == 1 && c2 == 2) zd = 1;
-								else if (c1 == 3 && c2 == 0) zd = 2;
-							}
-						}
-					}
-					if (t >= 2 && t < tlen) {
-						const int c0 = SFQ[t], c1 = SFQ[t - 1], c2 = SFQ[t - 2];
-						if (!revc) {
-							if (is_for) {
-								if (c1 == 0 && c0 == 2) za = (c2 == 1 || c2 == 3) ? -1 : 0;
-								else if (c1 == 0 && c0 == 1) za = 2;
-							} else {
-								if (c1 == 0 && c0 == 1) za = (c2 == 1 || c2 == 3) ? -1 : 0;
-								else if (c1 == 2 && c0 == 1) za = 1;
-								else if (c1 == 0 && c0 == 3) za = 2;
-							}
-						} else {
-							if (is_for) {
-								if (c1 == 3 && c0 == 2) za = (c2 == 0 || c2 == 2) ? -1 : 0;
-								else if (c1 == 1 && c0 == 2) za = 1;
-								else if (c1 == 3 && c0 == 0) za = 2;
-							} else {
-								if (c1 == 3 && c0 == 1) za = (c2 == 0 || c2 == 2) ? -1 : 0;
-								else if (c1 == 3 && c0 == 2) za = 2;
-							}
-						}
-					}
-					B[t] = (B[t] & 0x00ff00ffu) | (uint32_t)(cost(zd) & 0xff) << 8 | (uint32_t)(cost(za) & 0xff) << 24;
-				}
-				STATE_SYNC();
-			}
 
 			int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
 			const int n_rows = qlen + tlen - 1;
@@ -265,34 +282,40 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				const RowIv iv = row_interval(r, qlen, tlen, w);
 				const int st0 = iv.st0, en0 = iv.en0, st = iv.st, en = iv.en;
 				if (st0 > en0) { ez.zdropped = 1; break; }
+				if (en + 16 > frontier && frontier < T16 - 1) { // the window moves on (a wave-uniform condition)
+					admit(en + 16 < T16 - 1 ? en + 16 : T16 - 1);
+					STATE_SYNC();
+				}
 				// boundary values (:148-163)
 				const int bnd = SINGLE ? (r ? q : 0) : r == 0 ? nqe : r < long_thres ? sx8(-e) : r == long_thres ? sx8(long_diff) : SPLICE ? 0 : sx8(-e2);
 				const int init1 = SINGLE ? 0 : nqe, init2 = SINGLE ? 0 : nqe2; // value of a state byte that was never computed
 				int x1 = init1, x21 = init2, v1 = st > 0 ? init1 : bnd;
 				if (st > 0 && st - 1 >= last_st && st - 1 <= last_en) {
-					uint32_t a = A[st - 1], b = B[st - 1];
+					uint32_t a = A[(st - 1) & RM], b = B[(st - 1) & RM];
 					x1 = sx8(a >> 16), v1 = sx8(a >> 8), x21 = sx8(b);
 				}
 				if (en >= r && lane == 0) {
-					A[r] = (A[r] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24; // u[r], y[r]
-					if (!SPLICE) B[r] = (B[r] & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;              // y2[r]
+					A[r & RM] = (A[r & RM] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24; // u[r], y[r]
+					if (!SPLICE) B[r & RM] = (B[r & RM] & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;          // y2[r]
 				}
-				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes,
-				// and past T16 in the first bytes of the target copy exactly as in the reference's layout
+				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes, and past
+				// T16 the reference reads the start of qr[] as target bytes and writes into the first bytes of the target
+				// copy (its arrays are contiguous: s | sf | qr).  Such a write only matters while position idx-T16 can
+				// still be read, which is exactly while it still owns its slot.
 				{
-					const int qoff = T16 + (qlen - 1 - r);
+					const int qoff = qlen - 1 - r;
 					if (!(flag & KSW_GENERIC_SC)) {
 						const int total = ((en0 - st0) / 16 + 1) * 16;
 						for (int i = lane; i < total; i += 64) {
 							const int idx = st0 + i;
-							const int a = SFQ[idx], b = SFQ[qoff + idx];
+							const int a = idx < T16 ? TG[idx & RM] : QR[idx - T16], b = QR[qoff + idx];
 							const int sc = (a == m - 1 || b == m - 1) ? sc_N : a == b ? sc_mch : sc_mis;
-							if (idx < T16) ((uint8_t *)&B[idx])[2] = (uint8_t)sc;
-							else SFQ[idx - T16] = (uint8_t)sc;
+							if (idx < T16) ((uint8_t *)&B[idx & RM])[2] = (uint8_t)sc;
+							else if (frontier < idx - T16 + RS) TG[(idx - T16) & RM] = (uint8_t)sc;
 						}
 					} else {
 						for (int t = st0 + lane; t <= en0; t += 64)
-							((uint8_t *)&B[t])[2] = (uint8_t)L.sc.mat[SFQ[t] * m + SFQ[qoff + t]];
+							((uint8_t *)&B[t & RM])[2] = (uint8_t)L.sc.mat[TG[t & RM] * m + QR[qoff + t]];
 					}
 				}
 				STATE_SYNC();
@@ -302,10 +325,11 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				for (int c = n_chunk - 1; c >= 0; --c) {
 					const int t = st + (c << 6) + lane;
 					if (t <= en) {
-						const uint32_t a_cur = A[t], b_cur = B[t];
+						const int tk = t & RM;
+						const uint32_t a_cur = A[tk], b_cur = B[tk];
 						int xt1 = x1, vt1 = v1, x2t1 = x21;
 						if (t > st) {
-							const uint32_t a_prev = A[t - 1], b_prev = B[t - 1];
+							const uint32_t a_prev = A[(t - 1) & RM], b_prev = B[(t - 1) & RM];
 							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
 						}
 						if (SINGLE) { // ksw2_extz2_sse.c:34-55 with the left/right variants at :186-204 / :213-231 (and :164-170 score-only)
@@ -328,7 +352,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 								xn = 0 > a ? 0 : a; d |= 0 > a ? 0 : 0x08;
 								yn = 0 > b ? 0 : b; d |= 0 > b ? 0 : 0x10;
 							}
-							A[t] = pack4(un, vn, xn, yn);
+							A[tk] = pack4(un, vn, xn, yn);
 							if (with_cigar) pr[t - st] = (uint8_t)d;
 						} else if (SPLICE) { // ksw2_exts2_sse.c:37-64 with the variants at :283-285 (score only), :312-348 (left), :355-392 (right)
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), dn = sx8(b_cur >> 8), ac = sx8(b_cur >> 24);
@@ -358,8 +382,8 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 								yn = (b > 0 ? b : 0) - qe;      d |= b >= 0 ? 0x10 : 0;
 								x2n = (a2 > dn ? a2 : dn) - q2; d |= a2 >= dn ? 0x20 : 0;
 							}
-							A[t] = pack4(un, vn, xn, yn);
-							B[t] = (b_cur & 0xffffff00u) | (uint32_t)(x2n & 0xff);
+							A[tk] = pack4(un, vn, xn, yn);
+							B[tk] = (b_cur & 0xffffff00u) | (uint32_t)(x2n & 0xff);
 							if (with_cigar) pr[t - st] = (uint8_t)d;
 						} else {
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), y2t = sx8(b_cur >> 8);
@@ -392,8 +416,8 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 								x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 >= 0 ? 0x20 : 0;
 								y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 >= 0 ? 0x40 : 0;
 							}
-							A[t] = pack4(un, vn, xn, yn);
-							B[t] = (b_cur & 0xffff0000u) | (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8;
+							A[tk] = pack4(un, vn, xn, yn);
+							B[tk] = (b_cur & 0xffff0000u) | (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8;
 							if (with_cigar) pr[t - st] = (uint8_t)d;
 						}
 					}
@@ -406,15 +430,15 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				if (!approx_max) { // exact row maximum in the reference's scan order (:325-365)
 					int max_H, max_t;
 					if (r > 0) {
-						const int Hen = en0 > 0 ? H[en0 - 1] + du(A[en0]) : H[en0] + dv(A[en0]);
+						const int Hen = en0 > 0 ? H[(en0 - 1) & RM] + du(A[en0 & RM]) : H[en0 & RM] + dv(A[en0 & RM]);
 						const int en1 = st0 + (en0 - st0) / 4 * 4;
 						STATE_SYNC();
 						// candidate order: en0 first, then the 4-lane strided scan of [st0,en1), then the tail [en1,en0)
 						long long best = (long long)Hen << 32 | 0x7fffffffLL;
 						const int nq = (en1 - st0) >> 2;
 						for (int t = st0 + lane; t < en0; t += 64) {
-							const int h = H[t] + dv(A[t]);
-							H[t] = h;
+							const int h = H[t & RM] + dv(A[t & RM]);
+							H[t & RM] = h;
 							const int k = t - st0;
 							const int rank = t < en1 ? 1 + (k & 3) * (nq + 1) + (k >> 2) : 1 + 4 * (nq + 1) + (t - en1);
 							const long long key = (long long)h << 32 | (long long)(0x7fffffff - rank);
@@ -428,25 +452,25 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							else if (rank < 1 + 4 * (nq + 1)) { const int k = rank - 1; max_t = st0 + (k % (nq + 1)) * 4 + k / (nq + 1); }
 							else max_t = en1 + (rank - 1 - 4 * (nq + 1));
 						}
-						if (lane == 0) H[en0] = Hen;
+						if (lane == 0) H[en0 & RM] = Hen;
 						STATE_SYNC();
 					} else {
 						max_H = dv(A[0]) - h00, max_t = 0;
 						if (lane == 0) H[0] = max_H;
 						STATE_SYNC();
 					}
-					const int Hen0 = H[en0], Hst0 = H[st0];
+					const int Hen0 = H[en0 & RM], Hst0 = H[st0 & RM];
 					if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en0;
 					if (r - st0 == qlen - 1 && Hst0 > ez.mqe) ez.mqe = Hst0, ez.mqe_t = st0;
 					if (zdrop_test(ez, max_H, r, max_t, J.zdrop, zd_e)) break;
-					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
+					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[(tlen - 1) & RM];
 				} else { // follow one cell (:366-383)
 					if (r > 0) {
 						if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
-							const int d0 = dv(A[last_H0_t]), d1 = du(A[last_H0_t + 1]);
+							const int d0 = dv(A[last_H0_t & RM]), d1 = du(A[(last_H0_t + 1) & RM]);
 							if (d0 > d1) H0 += d0; else H0 += d1, ++last_H0_t;
-						} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += dv(A[last_H0_t]);
-						else ++last_H0_t, H0 += du(A[last_H0_t]);
+						} else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += dv(A[last_H0_t & RM]);
+						else ++last_H0_t, H0 += du(A[last_H0_t & RM]);
 					} else H0 = dv(A[0]) - h00, last_H0_t = 0;
 					// the single-affine code tests the drop only from the second anti-diagonal on (ksw2_extz2_sse.c:291 sits inside r > 0)
 					if ((flag & KSW_APPROX_DROP) && (!SINGLE || r > 0) && zdrop_test(ez, H0, r, last_H0_t, J.zdrop, zd_e)) break;
@@ -512,7 +536,7 @@ void launch_any(const KswLaunch &L, int n_blocks, int waves_per_block, size_t ld
 void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream)
 {
 	if (L.n_jobs <= 0) return;
-	const size_t region = (ksw_lds_per_wave(L.max_T16, L.max_Q16) + 15) / 16 * 16;
+	const size_t region = (ksw_lds_per_wave(L.ring, L.max_Q16) + 15) / 16 * 16;
 	const size_t lds = region * waves_per_block;
 	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
 	if (L.state_pool) { launch_any<false>(L, n_blocks, waves_per_block, 0, (hipStream_t)stream); return; } // state in HBM: any job length

@@ -11,16 +11,20 @@
 namespace mm2amd {
 
 namespace {
-struct Tier { int max_dim; int waves_per_block; };
 // Launch classes.  0..5: the register-resident gap-fill kernel (ksw_fast.hip) with 2,3,4,5,6,8 register sets of 64 target
-// columns (its VGPR need, hence its occupancy, grows with the set count, so jobs run with the fewest sets that hold them);
-// 6..8: the lane-exact kernel (ksw_extd2.hip), jobs grouped by 16-rounded max(qlen,tlen) because its LDS need per wave is
-// 13*T16 + Q16 + 16.
-constexpr int kNTiers = 10, kFirstExact = 6, kHbmTier = 9; // the last class keeps its state in HBM and takes any length
-const Tier kTiers[kNTiers] = { {128, 4}, {192, 4}, {256, 4}, {320, 4}, {384, 4}, {512, 4}, {512, 4}, {2048, 1}, {11264, 1}, {1 << 30, 4} };
+// columns (its VGPR need, hence its occupancy, grows with the set count, so jobs run with the fewest sets that hold them).
+// 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 512..8192 positions in
+// LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
+// direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
+constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 3, kNTiers = kFirstExact + kRingClasses * kDirClasses;
+constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
+const int kFastMaxT[kFirstExact] = { 128, 192, 256, 320, 384, 512 };
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
+const int kRingSize[kRingClasses] = { 512, 1024, 2048, 4096, 8192, 0 };
+const int kRingWaves[kRingClasses] = { 4, 4, 1, 1, 1, 4 }; // waves per block
+const size_t kDirLimit[kDirClasses] = { (size_t)1 << 20, (size_t)32 << 20, SIZE_MAX };
 constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
-constexpr int kMaxWavesPerCU = 20;    // exact kernel: 81 VGPRs -> 5 waves/SIMD
+constexpr int kMaxWavesPerCU = 20;    // exact kernel: <= 96 VGPRs -> 5 waves/SIMD
 const int kFastBlocksPerCU[kFirstExact] = { 4, 4, 4, 3, 3, 2 } /* waves per SIMD the kernels are compiled for */;
 
 // A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
@@ -31,6 +35,7 @@ inline bool fast_eligible(const KswJob &j, bool scoring_ok)
 	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastQCap || j.tlen > 512) return false;
 	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
 }
+inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
 void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_fast.hip
@@ -46,14 +51,14 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	// waves).  An exact order is not needed, so a counting sort on sqrt(cost) does it: jobs are cut into chunks, each chunk is
 	// classified and histogrammed by one pool thread (which also gathers the per-class sizing figures), a short serial prefix
 	// turns the histograms into stable scatter offsets, and the chunks scatter in parallel.
-	constexpr int NB = 1024; // cost buckets per tier
+	constexpr int NB = 256; // cost buckets per tier
 	constexpr size_t NBINS = (size_t)kNTiers * NB, CH = 16384;
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
 	const bool scoring_ok = sc.m == 5 && !disable_fast && !single_affine && !splice && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
-	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
+	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16; double alg_bytes = 0; };
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
 	const size_t n_chunks = (n + CH - 1) / CH;
 	bucket.resize(n), perm.resize(n);
@@ -65,16 +70,22 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		const size_t e = std::min(n, ((size_t)c + 1) * CH);
 		for (size_t i = (size_t)c * CH; i < e; ++i) {
 			const KswJob &j = jobs[i];
-			const int dim = std::max(r16(j.qlen), r16(j.tlen));
-			int tier;
+			int tier, ring_need = 64;
 			const bool fast = fast_eligible(j, scoring_ok);
-			if (fast) { tier = 0; while (j.tlen > kTiers[tier].max_dim) ++tier; }
+			const bool live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
+			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
+			if (fast) { tier = 0; while (j.tlen > kFastMaxT[tier]) ++tier; }
 			else {
-				tier = kFirstExact;
-				while (tier < kNTiers - 1 && dim > kTiers[tier].max_dim) ++tier;
+				int width = std::min(j.qlen, j.tlen); // widest anti-diagonal
+				if (!splice && j.w >= 0 && j.w + 2 < width) width = j.w + 2;
+				ring_need = pow2ceil((live ? width : 0) + 64);
+				int rc = 0, dc = 0;
+				while (rc < kHbmRing && ring_need > kRingSize[rc]) ++rc;
+				while (db > kDirLimit[dc]) ++dc;
+				tier = kFirstExact + rc * kDirClasses + dc;
 			}
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
-			int cb = (int)(std::sqrt(cost) * (fast ? 1.0 : 0.25)); // fast classes: cost <= 1536*512; exact classes reach 11264*752
+			int cb = fast ? (int)(std::sqrt(cost) * 0.25) : (int)(8.0 * std::log2(cost + 1.0)); // fast classes: cost <= 1536*512; exact classes: any (9 % steps)
 			if (cb >= NB) cb = NB - 1;
 			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
 			bucket[i] = bk;
@@ -83,11 +94,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			// direction matrix only counts when it cannot stay on chip, i.e. exceeds 160 KB of LDS)
 			ClassStat &cs = st.cls[tier];
 			cs.alg_bytes += sizeof(KswJob) + sizeof(KswRes);
-			if ((j.flag & KSWJ_SKIP) || j.qlen <= 0 || j.tlen <= 0) continue;
+			if (!live) continue;
 			cs.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
-			cs.max_T16 = std::max(cs.max_T16, r16(j.tlen)), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
+			cs.max_ring = std::max(cs.max_ring, ring_need), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
 			if (!(j.flag & KSW_SCORE_ONLY)) {
-				const size_t db = fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 				if (db > 160 * 1024) cs.alg_bytes += (double)db;
 				cs.slot_bytes = std::max(cs.slot_bytes, db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
 				st.sum_len += (size_t)j.qlen + j.tlen;
@@ -102,7 +112,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		for (int t = 0; t < kNTiers; ++t) {
 			cls[t].alg_bytes += st.cls[t].alg_bytes;
 			cls[t].slot_bytes = std::max(cls[t].slot_bytes, st.cls[t].slot_bytes), cls[t].tmp_cap = std::max(cls[t].tmp_cap, st.cls[t].tmp_cap);
-			cls[t].max_T16 = std::max(cls[t].max_T16, st.cls[t].max_T16), cls[t].max_Q16 = std::max(cls[t].max_Q16, st.cls[t].max_Q16);
+			cls[t].max_ring = std::max(cls[t].max_ring, st.cls[t].max_ring), cls[t].max_Q16 = std::max(cls[t].max_Q16, st.cls[t].max_Q16);
 		}
 	}
 	size_t tier_beg[kNTiers + 1];
@@ -124,8 +134,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_jobs.ensure(n);
 	d_res.ensure(n);
-	d_counter.ensure(16);
-	static_assert(kNTiers <= 16, "one queue counter per launch class");
+	d_counter.ensure(32);
+	static_assert(kNTiers <= 32, "one queue counter per launch class");
 	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
 	KswRes *tr = tmp_res.ensure(n);
@@ -135,10 +145,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	for (int attempt = 0;; ++attempt) {
 		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
 		d_cigar.ensure(pool_cap);
-		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 16 * sizeof(int32_t), stream));
+		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 32 * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
 		// size every launch class first (one scratch allocation serves them all: the launches run back to back on one stream)
-		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int max_T16 = 16, max_Q16 = 16; double alg_bytes = 0; };
+		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4; bool hbm = false; double alg_bytes = 0; };
 		Plan plan[kNTiers];
 		size_t need_dir = 16, need_tmp = 16, need_state = 0;
 		for (int tier = 0; tier < kNTiers; ++tier) {
@@ -146,29 +156,34 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
 			const bool fast = tier < kFirstExact;
-			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_T16 = cls[tier].max_T16, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
+			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
+			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
-			const int wpb = kTiers[tier].waves_per_block;
+			P.hbm = !fast && rc == kHbmRing;
+			P.ring = fast ? 64 : P.hbm ? cls[tier].max_ring : kRingSize[rc];
+			P.wpb = fast ? 4 : kRingWaves[rc];
+			const size_t region = (ksw_lds_per_wave(P.ring, P.max_Q16) + 15) / 16 * 16;
+			if (!fast && !P.hbm && region > 160 * 1024) P.hbm = true; // a very long query next to a wide window: state goes to HBM
+			if (P.hbm) P.wpb = 4;
+			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
 			if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
-			else if (tier == kHbmTier) blocks_per_cu = 4;
-			else {
-				const size_t region = (ksw_lds_per_wave(P.max_T16, P.max_Q16) + 15) / 16 * 16;
-				blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * wpb), kMaxWavesPerCU / wpb);
-			}
+			else if (P.hbm) blocks_per_cu = 4;
+			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
+			const int wpb = P.wpb;
 			const size_t per_slot = fast ? 2 : 1; // the gap-fill kernel runs two jobs per wave
 			P.n_slots = std::min<size_t>((P.end - P.beg + per_slot - 1) / per_slot, (size_t)n_cu * blocks_per_cu * wpb);
 			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
-			if (tier == kHbmTier) need_state = P.n_slots * ((ksw_lds_per_wave(P.max_T16, P.max_Q16) + 15) / 16 * 16);
+			if (P.hbm) need_state = std::max(need_state, P.n_slots * region);
 		}
 		d_dir.ensure(need_dir, 1.0);
 		d_cigar_tmp.ensure(need_tmp, 1.0);
 		if (need_state) d_state.ensure(need_state, 1.0);
-		static const char *kNames[kNTiers] = { "ksw_fast_kernel<2>", "ksw_fast_kernel<3>", "ksw_fast_kernel<4>", "ksw_fast_kernel<5>", "ksw_fast_kernel<6>", "ksw_fast_kernel<8>",
-		                                       "ksw_extd2_kernel[t0]", "ksw_extd2_kernel[t1]", "ksw_extd2_kernel[t2]", "ksw_extd2_kernel[hbm]" };
+		static const char *kFastNames[kFirstExact] = { "ksw_fast_kernel<2>", "ksw_fast_kernel<3>", "ksw_fast_kernel<4>", "ksw_fast_kernel<5>", "ksw_fast_kernel<6>", "ksw_fast_kernel<8>" };
+		static const char *kRingNames[kRingClasses] = { "ksw_extd2_kernel[r512]", "ksw_extd2_kernel[r1k]", "ksw_extd2_kernel[r2k]", "ksw_extd2_kernel[r4k]", "ksw_extd2_kernel[r8k]", "ksw_extd2_kernel[hbm]" };
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
 			if (P.end == P.beg) continue;
@@ -179,13 +194,13 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.cigar_tmp = d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap;
 			L.dir_pool = d_dir.p, L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
-			L.max_T16 = P.max_T16, L.max_Q16 = P.max_Q16, L.sc = sc;
-			L.state_pool = tier == kHbmTier ? d_state.p : nullptr;
+			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc;
+			L.state_pool = P.hbm ? d_state.p : nullptr;
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
-			else ksw_extd2_launch(L, (int)P.n_slots, kTiers[tier].waves_per_block, stream);
-			if (prof) prof->end(stream, kNames[tier], P.alg_bytes);
+			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
+			if (prof) prof->end(stream, tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
 		}
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));

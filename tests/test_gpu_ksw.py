@@ -206,3 +206,23 @@ def test_splice_exts2(sc):
         if have_ref and k % 9 == 0:
             assert got[k] == ref_exts2(q, t, mat, go, ge, go2, noncan, zdrop, eb, 9, 5, flag)
     assert any(c & 0xf == 3 for r in got for c in r[10])  # introns were found
+
+
+def test_state_window_wraps_with_overshoot_past_the_arrays():
+    """jobs whose target is much longer than the exact kernel's state window (the rings wrap many times) and whose length is a
+    multiple of 16 or just below one, with a query longer than the target: the reference's score fill then runs past its s[]
+    array into the target copy (ksw2_extd2_sse.c:166-180); narrow, medium and absent bands"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(77)
+    mat = ts_mat(2, 4, 1, 0)
+    jobs = []
+    for tl in (1024, 1023, 1017, 2048, 1536):
+        for ql in (tl + 300, tl - 200, tl // 2):
+            for w in (5, 100, 400, -1):
+                q, t = random_pair(rng, tl, 0.1, 0.0, 0)
+                t = t[:tl] if len(t) >= tl else np.concatenate([t, rng.integers(0, 4, tl - len(t), dtype=np.uint8)])
+                q = q[:ql] if len(q) >= ql else np.concatenate([q, rng.integers(0, 4, ql - len(q), dtype=np.uint8)])
+                jobs.append((q, t, w, 400, 10, int(rng.choice([0x40, 0xC2, 0x00, 0x08]))))
+    got = mm.ksw_extd2_batch(jobs, mat, 4, 2, 24, 1)
+    for k, (q, t, w, zdrop, eb, flag) in enumerate(jobs):
+        assert got[k] == ora_extd2(q, t, mat, 4, 2, 24, 1, w, zdrop, eb, flag), (k, len(q), len(t), w, hex(flag))
