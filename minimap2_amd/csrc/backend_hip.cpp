@@ -203,7 +203,7 @@ public:
 		// the DP scratch (one direction-matrix slot per persistent wave) is the big per-lane allocation: split the budget
 		// HBM the lanes may spend on direction matrices (1 B per DP cell, one slot per persistent wave); splice gap fills have
 		// matrices of tens of MB each, and 288 GB of HBM is what lets thousands of them be in flight
-		size_t dir_gb = 64;
+		size_t dir_gb = 160;
 		if (const char *e = getenv("MM2AMD_DIR_BUDGET_GB")) dir_gb = atol(e) > 0 ? (size_t)atol(e) : dir_gb;
 		ln.ksw.dir_budget = (dir_gb << 30) / (size_t)n_lanes_;
 		ln.ksw.lane = lane_id;

@@ -16,13 +16,13 @@ namespace {
 // 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 512..8192 positions in
 // LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
 // direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
-constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 3, kNTiers = kFirstExact + kRingClasses * kDirClasses;
+constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kNTiers = kFirstExact + kRingClasses * kDirClasses;
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 const int kFastMaxT[kFirstExact] = { 128, 192, 256, 320, 384, 512 };
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
 const int kRingSize[kRingClasses] = { 512, 1024, 2048, 4096, 8192, 0 };
 const int kRingWaves[kRingClasses] = { 4, 4, 1, 1, 1, 4 }; // waves per block
-const size_t kDirLimit[kDirClasses] = { (size_t)1 << 20, (size_t)32 << 20, SIZE_MAX };
+inline size_t dir_limit(int dc) { return dc == kDirClasses - 1 ? SIZE_MAX : (size_t)256 << (10 + dc); } // 256 KB, 512 KB, ... 128 MB, any
 constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: <= 96 VGPRs -> 5 waves/SIMD
 const int kFastBlocksPerCU[kFirstExact] = { 4, 4, 4, 3, 3, 2 } /* waves per SIMD the kernels are compiled for */;
@@ -81,7 +81,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 				ring_need = pow2ceil((live ? width : 0) + 64);
 				int rc = 0, dc = 0;
 				while (rc < kHbmRing && ring_need > kRingSize[rc]) ++rc;
-				while (db > kDirLimit[dc]) ++dc;
+				while (db > dir_limit(dc)) ++dc;
 				tier = kFirstExact + rc * kDirClasses + dc;
 			}
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
@@ -134,8 +134,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_jobs.ensure(n);
 	d_res.ensure(n);
-	d_counter.ensure(32);
-	static_assert(kNTiers <= 32, "one queue counter per launch class");
+	d_counter.ensure(128);
+	static_assert(kNTiers <= 128, "one queue counter per launch class");
 	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
 	KswRes *tr = tmp_res.ensure(n);
@@ -145,7 +145,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	for (int attempt = 0;; ++attempt) {
 		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
 		d_cigar.ensure(pool_cap);
-		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 32 * sizeof(int32_t), stream));
+		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 128 * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
 		// size every launch class first (one scratch allocation serves them all: the launches run back to back on one stream)
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4; bool hbm = false; double alg_bytes = 0; };

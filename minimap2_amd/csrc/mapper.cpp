@@ -98,7 +98,9 @@ void Mapper::run(std::vector<ReadResult> &out)
 	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
 	std::vector<std::pair<long, long>> subs;
 	{
-		const long max_reads = be_.max_reads_per_call();
+		long max_reads = be_.max_reads_per_call(), sub_reads = 10000; // short reads: bound the read count too, so that every lane gets work
+		if (const char *e = getenv("MM2AMD_SUBBATCH_READS")) sub_reads = atol(e) > 0 ? atol(e) : sub_reads;
+		if (sub_reads < max_reads) max_reads = sub_reads;
 		for (long lo = 0, hi; lo < m_all; lo = hi) {
 			long bases = 0;
 			for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
