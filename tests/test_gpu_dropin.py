@@ -74,3 +74,9 @@ def test_splice_variants_identical(tmp_path):
     _compare(tmp_path, "cdna", "splice", 3, 200, 19, ["-a", "-u", "f"])
     _compare(tmp_path, "cdna", "splice", 3, 200, 19, ["-c", "-u", "n", "-J", "0"])
     _compare(tmp_path, "cdna", "splice", 3, 200, 19, ["-a", "-G", "10000", "-C", "5", "--splice-flank=no"])
+
+
+def test_hpc_index_sam_identical(tmp_path):
+    # -x map-pb: homopolymer-compressed minimizers (sketch.c:95-101), index built by the reference and adopted by mm_gpu_init
+    _compare(tmp_path, "hifi", "map-pb", 3, 60, 20, ["-a"])
+    _compare(tmp_path, "ont", "map-pb", 3, 60, 21, ["-c"])
