@@ -16,7 +16,12 @@ namespace {
 // 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 512..8192 positions in
 // LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
 // direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
-constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kNTiers = kFirstExact + kRingClasses * kDirClasses;
+constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice = kFirstExact + kRingClasses * kDirClasses;
+// kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip) with 2, 4 or 8 register sets of 64 QUERY
+// positions, classed by direction-matrix size like the exact kernel.
+constexpr int kSpliceClasses = 3, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
+const int kSpliceSets[kSpliceClasses] = { 2, 4, 8 };
+const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 2 };
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 const int kFastMaxT[kFirstExact] = { 128, 192, 256, 320, 384, 512 };
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
@@ -35,10 +40,20 @@ inline bool fast_eligible(const KswJob &j, bool scoring_ok)
 	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastQCap || j.tlen > 512) return false;
 	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
 }
+// The splice gap fill (align.c:840 with -x splice) may take the register-resident splice kernel: global alignment with the
+// approximate score, default substitution scores, forward CIGAR, no junction scores, at most 512 query bases; the scoring must
+// keep every intermediate of a valid cell inside 8 bits (what the reference's int8 lanes assume).
+inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
+{
+	constexpr int kSpliceBits = KSW_SPLICE_FOR | KSW_SPLICE_REV | KSW_SPLICE_FLANK | KSW_SPLICE_CMPLX;
+	if (!scoring_ok || ((j.flag & 0x1fff) & ~kSpliceBits) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
+	return j.qlen > 0 && j.tlen > 0 && j.qlen <= 512;
+}
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
 void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_fast.hip
+void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_splice.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                     const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
@@ -52,11 +67,16 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	// classified and histogrammed by one pool thread (which also gathers the per-class sizing figures), a short serial prefix
 	// turns the histograms into stable scatter offsets, and the chunks scatter in parallel.
 	constexpr int NB = 256; // cost buckets per tier
-	constexpr size_t NBINS = (size_t)kNTiers * NB, CH = 16384;
+	constexpr size_t CH = 32768;
+	const size_t NBINS = (size_t)(sc.single == 2 ? kNTiers : kFirstSplice) * NB; // the splice classes only exist in splice mode
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
 	const bool scoring_ok = sc.m == 5 && !disable_fast && !single_affine && !splice && -min_sc <= 2 * (std::min(sc.q + sc.e, sc.q2 + sc.e2)); // else ksw_extd2 returns early (ksw2_extd2_sse.c:73)
+	int max_abs = 0;
+	for (int t = 0; t < sc.m * sc.m; ++t) max_abs = std::max<int>(max_abs, std::abs((int)sc.mat[t]));
+	const bool splice_ok = sc.m == 5 && !disable_fast && splice && -min_sc <= 2 * (sc.q + sc.e) && sc.q2 > sc.q + sc.e && sc.e > 0 && sc.q >= 0 && sc.noncan >= 0 &&
+	                       sc.q + sc.e + sc.q2 + sc.noncan + max_abs <= 100;
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
 	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16; double alg_bytes = 0; };
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
@@ -71,11 +91,17 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		for (size_t i = (size_t)c * CH; i < e; ++i) {
 			const KswJob &j = jobs[i];
 			int tier, ring_need = 64;
-			const bool fast = fast_eligible(j, scoring_ok);
+			const bool fast = fast_eligible(j, scoring_ok), sfast = splice_fast_eligible(j, splice_ok);
 			const bool live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
-			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
+			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
+			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 			if (fast) { tier = 0; while (j.tlen > kFastMaxT[tier]) ++tier; }
-			else {
+			else if (sfast) {
+				int nc = 0, dc = 0;
+				while (j.qlen > 64 * kSpliceSets[nc]) ++nc;
+				while (db > dir_limit(dc)) ++dc;
+				tier = kFirstSplice + nc * kDirClasses + dc;
+			} else {
 				int width = std::min(j.qlen, j.tlen); // widest anti-diagonal
 				if (!splice && j.w >= 0 && j.w + 2 < width) width = j.w + 2;
 				ring_need = pow2ceil((live ? width : 0) + 64);
@@ -86,6 +112,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			}
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
 			int cb = fast ? (int)(std::sqrt(cost) * 0.25) : (int)(8.0 * std::log2(cost + 1.0)); // fast classes: cost <= 1536*512; exact classes: any (9 % steps)
+			if (sfast) cb = (int)(12.0 * std::log2((double)(j.qlen + j.tlen))); // the two jobs of a wave advance row by row: order by row count (6 % steps)
 			if (cb >= NB) cb = NB - 1;
 			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
 			bucket[i] = bk;
@@ -122,7 +149,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (b % NB == 0) tier_beg[b / NB] = acc;
 			for (size_t c = 0; c < n_chunks; ++c) { uint32_t &h = chunk_hist[c * NBINS + b]; const uint32_t v = h; h = acc; acc += v; }
 		}
-		tier_beg[kNTiers] = acc;
+		for (size_t t = NBINS / NB; t <= (size_t)kNTiers; ++t) tier_beg[t] = acc;
 	}
 	KswJob *sj = sorted.ensure(n);
 	parallel_for(n_threads, (long)n_chunks, [&](long c, int) {
@@ -155,7 +182,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			Plan &P = plan[tier];
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
-			const bool fast = tier < kFirstExact;
+			const bool sfast = tier >= kFirstSplice, fast = tier < kFirstExact || sfast; // the register-resident kernels
 			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
 			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
@@ -167,12 +194,13 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (P.hbm) P.wpb = 4;
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
+			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[(tier - kFirstSplice) / kDirClasses];
+			else if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
 			else if (P.hbm) blocks_per_cu = 4;
 			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
 			const int wpb = P.wpb;
-			const size_t per_slot = fast ? 2 : 1; // the gap-fill kernel runs two jobs per wave
+			const size_t per_slot = fast ? 2 : 1; // the gap-fill kernels run two jobs per wave
 			P.n_slots = std::min<size_t>((P.end - P.beg + per_slot - 1) / per_slot, (size_t)n_cu * blocks_per_cu * wpb);
 			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
@@ -199,8 +227,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
+			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
-			if (prof) prof->end(stream, tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
+			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2>", "ksw_splice_kernel<4>", "ksw_splice_kernel<8>" };
+			if (prof) prof->end(stream, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
 		}
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));

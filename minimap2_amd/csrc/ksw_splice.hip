@@ -1,0 +1,277 @@
+// Register-resident splice gap-fill DP for gfx950: the device counterpart of ksw_exts2_sse (ksw2_exts2_sse.c:33-465) +
+// ksw_backtrack (ksw2.h:130-162) for the calls that hold most of the DP cells of spliced alignment -- the global alignments
+// between adjacent anchors across introns (align.c:840: flag KSW_EZ_APPROX_MAX): a query stretch of a few hundred bases against
+// a target window as long as the intron (up to 200 kb with -x splice).
+//
+// ksw_exts2 has no band, so the valid cells of anti-diagonal r are exactly t in [max(0,r-qlen+1), min(tlen-1,r)], their
+// neighbours are valid cells or the documented boundary values, and (under the scoring limits the host checks) no 8-bit
+// overflow happens in a valid cell.  Only valid cells matter, so the layout is ours (the lane-exact SPLICE mode of
+// ksw_extd2.hip remains the kernel for every other splice call and the one this kernel is tested against):
+//
+//   * lane = QUERY position: query base j lives in lane j%64 of register set j/64 for the whole job; the five difference
+//     states never leave VGPRs.  Cell (r, j) sits on target position t = r - j: what the reference reads at t-1 (x, v, x2) was
+//     written by the same lane one row earlier, what it reads at t (u, y) by lane j-1 -- one DPP wave shift each.
+//   * the target streams through: every 64 rows the wave admits the next 64 target positions into an LDS ring, each entry
+//     holding the base and the donor / acceptor cost of its position (ksw2_exts2_sse.c:120-194) ready for packed use.
+//   * two jobs per wavefront in the halves of packed 16-bit registers, as in ksw_fast.hip; the launch is ordered by row count.
+//   * the 1 B/cell direction matrix is the only HBM traffic (row-major by query position: 64 B coalesced per register set);
+//     the traceback is done by the whole wave: lane k looks k cells ahead along the current run (match diagonal, gap, intron)
+//     and one ballot tells how long the run lasts, so an intron of 50 000 bases costs 800 loads in sequence, not 50 000.
+#include <hip/hip_runtime.h>
+#include "hip_util.hpp"
+#include "ksw_dev.hpp"
+#include "ksw_pk.hpp"
+
+namespace mm2amd {
+
+namespace {
+struct SpliceParams { int is_for, has_strand, sp0, sp1, sp2, sp3; };
+
+// donor cost of position t from the three bases after it, acceptor cost from the base at t and the two before it
+// (ksw2_exts2_sse.c:133-170, the variants for the forward CIGAR order: gap fills are never reversed)
+__device__ __forceinline__ int site_cost(const SpliceParams &P, int z) { return z < 0 ? 0 : z == 0 ? -P.sp0 : z == 1 ? -P.sp1 : z == 2 ? -P.sp2 : -P.sp3; }
+__device__ __forceinline__ int donor_class(const SpliceParams &P, int c1, int c2, int c3)
+{
+	int z = 3;
+	if (P.is_for) {
+		if (c1 == 2 && c2 == 3) z = (c3 == 0 || c3 == 2) ? -1 : 0;
+		else if (c1 == 2 && c2 == 1) z = 1;
+		else if (c1 == 0 && c2 == 3) z = 2;
+	} else {
+		if (c1 == 1 && c2 == 3) z = (c3 == 0 || c3 == 2) ? -1 : 0;
+		else if (c1 == 2 && c2 == 3) z = 2;
+	}
+	return z;
+}
+__device__ __forceinline__ int acceptor_class(const SpliceParams &P, int c0, int c1, int c2) // c0 = base at t, c1 = t-1, c2 = t-2
+{
+	int z = 3;
+	if (P.is_for) {
+		if (c1 == 0 && c0 == 2) z = (c2 == 1 || c2 == 3) ? -1 : 0;
+		else if (c1 == 0 && c0 == 1) z = 2;
+	} else {
+		if (c1 == 0 && c0 == 1) z = (c2 == 1 || c2 == 3) ? -1 : 0;
+		else if (c1 == 2 && c0 == 1) z = 1;
+		else if (c1 == 0 && c0 == 3) z = 2;
+	}
+	return z;
+}
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswLaunch L)
+{
+	constexpr int RING = NC <= 1 ? 128 : NC <= 3 ? 256 : NC <= 7 ? 512 : 1024, RM = RING - 1; // >= 64*NC + 64 positions
+	__shared__ uint4 s_ring[4][RING]; // per wave and target position: {base, donor, acceptor} as packed halves (job A low, job B high)
+	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+	const int slot = blockIdx.x * 4 + wave_in_block;
+	uint4 *ring = s_ring[wave_in_block];
+	const int m = L.sc.m;
+	const int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, qe = q + e;
+	const int sc_mch = L.sc.mat[0], sc_mis = L.sc.mat[1];
+	const int sc_N = L.sc.mat[m * m - 1] == 0 ? -e : L.sc.mat[m * m - 1];
+	int long_thres = (q2 - q) / e - 1; // ksw2_exts2_sse.c:98-101
+	if (q2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * e - (q2 - q);
+	const uint32_t P_ONE = pk2v(1), P_ZERO = pk2v(0), P_MCH = pk2v(sc_mch), P_MISD = pk2v(sc_mis - sc_mch), P_SCN = pk2v(sc_N);
+	const uint32_t P_Q = pk2v(q), P_Q2 = pk2v(q2), P_QE = pk2v(qe), P_NQE = pk2(-qe), P_NQ2 = pk2(-q2);
+	const uint32_t P_8 = pk2v(8), P_16 = pk2v(16), P_32 = pk2v(32);
+
+	for (;;) {
+		int pid = 0;
+		if (lane == 0) pid = atomicAdd(L.counter, 1);
+		pid = __builtin_amdgcn_readfirstlane(pid);
+		if (2 * pid >= L.n_jobs) break;
+		const int jidA = 2 * pid, jidB = 2 * pid + 1;
+		const bool hasB = jidB < L.n_jobs;
+		const KswJob JA = L.jobs[jidA], JB = L.jobs[hasB ? jidB : jidA];
+		const int qlenA = JA.qlen, tlenA = JA.tlen, qlenB = hasB ? JB.qlen : 0, tlenB = hasB ? JB.tlen : 0;
+		const int qsA = (qlenA + 63) & ~63, qsB = (qlenB + 63) & ~63; // row stride of the direction matrices
+		uint8_t *dirA = L.dir_pool + (size_t)(2 * slot) * L.slot_bytes, *dirB = dirA + L.slot_bytes;
+		auto splice_params = [&](int flag) {
+			SpliceParams P;
+			P.is_for = (flag & KSW_SPLICE_FOR) ? 1 : 0, P.has_strand = (flag & (KSW_SPLICE_FOR | KSW_SPLICE_REV)) ? 1 : 0;
+			if (flag & KSW_SPLICE_CMPLX) P.sp0 = 3, P.sp1 = 5, P.sp2 = 7, P.sp3 = 10; // (int)({8,15,21,30} / 3. + .499)
+			else P.sp0 = (flag & KSW_SPLICE_FLANK) ? L.sc.noncan / 2 : 0, P.sp1 = P.sp2 = P.sp3 = L.sc.noncan;
+			return P;
+		};
+		const SpliceParams SA = splice_params(JA.flag), SB = splice_params(JB.flag);
+		auto tfetch = [&](const KswJob &J, int t) -> int {
+			const uint64_t pos = (J.flag & KSWJ_T_REVERSED) ? J.t_off - (uint64_t)t : J.t_off + (uint64_t)t;
+			return (J.flag & KSWJ_T_PACKED) ? (int)(L.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : (int)L.tpool[pos];
+		};
+		// base, donor and acceptor cost of target position t of one job (0 costs when no transcript strand is assumed)
+		auto target_entry = [&](const KswJob &J, const SpliceParams &P, int tlen, int t, int &dn, int &ac) -> int {
+			dn = ac = 0;
+			if (t >= tlen) return 4;
+			const int c0 = tfetch(J, t);
+			if (P.has_strand) {
+				int zd = 3, za = 3;
+				if (t < tlen - 4) zd = donor_class(P, tfetch(J, t + 1), tfetch(J, t + 2), tfetch(J, t + 3));
+				if (t >= 2) za = acceptor_class(P, c0, tfetch(J, t - 1), tfetch(J, t - 2));
+				dn = site_cost(P, zd), ac = site_cost(P, za);
+			}
+			return c0;
+		};
+		// ---- operands: one packed query base pair per (register set, lane); the states start at the values of :108-109 ----
+		uint32_t Q[NC], U[NC], V[NC], X[NC], Y[NC], X2[NC];
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int j = c * 64 + lane;
+			uint32_t bA = 4, bB = 4;
+			if (j < qlenA) bA = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)j : JA.q_off + (uint64_t)j];
+			if (j < qlenB) bB = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)j : JB.q_off + (uint64_t)j];
+			Q[c] = bA | bB << 16;
+			U[c] = V[c] = X[c] = Y[c] = P_NQE, X2[c] = P_NQ2;
+		}
+		int frontier = -1; // target positions <= frontier are in the ring
+
+		// Corner score H(tlen-1, qlen-1) of each job, summed along the matrix border (path-independent; see ksw_fast.hip): u of the
+		// first query row's cells while the anti-diagonal still starts a new target column, then v down the last column.
+		int H0A = -qe, H0B = -qe;
+		const int n_rowsA = qlenA + tlenA - 1, n_rowsB = hasB ? qlenB + tlenB - 1 : 0, n_rows = n_rowsA > n_rowsB ? n_rowsA : n_rowsB;
+		for (int r = 0; r < n_rows; ++r) {
+			if (r > frontier) { // admit the next 64 target positions (wave-uniform)
+				const int t = frontier + 1 + lane;
+				int dnA, acA, dnB, acB;
+				const int cA = target_entry(JA, SA, tlenA, t, dnA, acA), cB = target_entry(JB, SB, tlenB, t, dnB, acB);
+				ring[t & RM] = make_uint4((uint32_t)cA | (uint32_t)cB << 16, ((uint32_t)dnA & 0xffffu) | (uint32_t)dnB << 16, ((uint32_t)acA & 0xffffu) | (uint32_t)acB << 16, 0u);
+				frontier += 64;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+			// query positions with a valid cell on this anti-diagonal, per job: j in [max(0, r-tlen+1), min(qlen-1, r)]
+			int jloA = r - tlenA + 1 > 0 ? r - tlenA + 1 : 0, jhiA = r < qlenA - 1 ? r : qlenA - 1;
+			int jloB = r - tlenB + 1 > 0 ? r - tlenB + 1 : 0, jhiB = r < qlenB - 1 ? r : qlenB - 1;
+			if (r >= n_rowsA) jloA = 1, jhiA = 0;
+			if (r >= n_rowsB) jloB = 1, jhiB = 0;
+			const uint32_t wA = (uint32_t)(jhiA - jloA + 1), wB = (uint32_t)(jhiB - jloB + 1);
+			const int lo = jloA <= jhiA ? (jloB <= jhiB && jloB < jloA ? jloB : jloA) : jloB, hi = jhiA > jhiB ? jhiA : jhiB;
+			// v[-1] / u[r] on the matrix border (ksw2_exts2_sse.c:234-247): depends on r only
+			const int bnd = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : 0;
+			const uint32_t P_BND = pk2(bnd);
+			// query position r starts its column on this row (t = 0): x, v, x2 of "t = -1" are border values
+			const bool newA = r < qlenA && r < n_rowsA, newB = r < qlenB && r < n_rowsB;
+			const int edge_set = r >> 6, edge_lane = r & 63;
+			const uint32_t edge_halves = (newA ? 0xffffu : 0u) | (newB ? 0xffff0000u : 0u);
+			const bool topA = r < tlenA && r < n_rowsA, topB = r < tlenB && r < n_rowsB; // query position 0 still has a cell (t = r)
+			const int lastA = r - tlenA + 1, lastB = r - tlenB + 1;                    // query position on the last target column
+			uint8_t *prA = dirA + (size_t)r * qsA, *prB = dirB + (size_t)r * qsB;
+			// register sets from the highest down, so that set c still sees row r-1 in set c-1 when it fetches its carry-ins
+#pragma unroll
+			for (int c = NC - 1; c >= 0; --c) {
+				if (c * 64 > hi || c * 64 + 63 < lo) continue; // register set outside both anti-diagonals (uniform)
+				const int j = c * 64 + lane;
+				const bool actA = (uint32_t)(j - jloA) < wA, actB = (uint32_t)(j - jloB) < wB;
+				uint32_t cU = P_BND, cY = P_NQE; // query position -1: the matrix border (u[r], y[r], :241-247)
+				if (c > 0) cU = __builtin_amdgcn_readlane(U[c - 1], 63), cY = __builtin_amdgcn_readlane(Y[c - 1], 63);
+				const uint32_t up = dpp_shr1u(cU, U[c]), yp = dpp_shr1u(cY, Y[c]);
+				if (edge_halves && edge_set == c) {
+					const uint32_t em = lane == edge_lane ? edge_halves : 0u;
+					V[c] = bfi(em, P_BND, V[c]), X[c] = bfi(em, P_NQE, X[c]), X2[c] = bfi(em, P_NQ2, X2[c]);
+				}
+				{
+					// every lane computes, active or not (see ksw_fast.hip: a lane's registers are only read while its cell, or the
+					// next cell of its right neighbour, is valid); only the stores are guarded
+					const uint4 te = ring[(r - j) & RM];
+					const uint32_t tv = te.x, dn = te.y, ac = te.z, qv = Q[c];
+					uint32_t z = pk_mad(pk_minu(tv ^ qv, P_ONE), P_MISD, P_MCH);
+					z = pk_mad(pk_shr2(tv | qv), pk_sub(P_SCN, z), z);
+					const uint32_t vt = V[c];
+					uint32_t a = pk_add(X[c], vt), b = pk_add(yp, up), a2 = pk_add(X2[c], vt);
+					const uint32_t a2a = pk_add(a2, ac);
+					const uint32_t z1 = pk_max(z, a), z2 = pk_max(z1, b), z3 = pk_max(z2, a2a);
+					// d = index of the first of (s, a, b, a2a) equal to the maximum (the strictly-greater chain of :312-318)
+					const uint32_t ne_s = pk_minu(pk_sub(z3, z), P_ONE), ne_a = pk_minu(pk_sub(z3, a), P_ONE), ne_b = pk_minu(pk_sub(z3, b), P_ONE);
+					uint32_t d = pk_mul(ne_s, pk_mad(ne_a, pk_add(ne_b, P_ONE), P_ONE));
+					U[c] = pk_sub(z3, vt), V[c] = pk_sub(z3, up); // no clamp in this recurrence
+					uint32_t tmp = pk_sub(z3, P_Q);
+					a = pk_sub(a, tmp), b = pk_sub(b, tmp);
+					a2 = pk_sub(a2, pk_sub(z3, P_Q2));
+					const uint32_t ma = pk_max(a, P_ZERO), mb = pk_max(b, P_ZERO), m2 = pk_max(a2, dn);
+					d = pk_mad(pk_minu(ma, P_ONE), P_8, d);              // a > 0, b > 0: the gap can be extended (:333-338)
+					d = pk_mad(pk_minu(mb, P_ONE), P_16, d);
+					d = pk_mad(pk_minu(pk_sub(m2, dn), P_ONE), P_32, d); // a2 > donor: the intron goes on (:340-348)
+					X[c] = pk_sub(ma, P_QE), Y[c] = pk_sub(mb, P_QE), X2[c] = pk_sub(m2, P_Q2);
+					if (actA) prA[(uint32_t)j] = (uint8_t)d;
+					if (actB) prB[(uint32_t)j] = (uint8_t)(d >> 16);
+				}
+				if (topA) { if (c == 0) H0A += (int16_t)__builtin_amdgcn_readlane(U[c], 0); }
+				else if (r < n_rowsA && (lastA >> 6) == c) H0A += (int16_t)__builtin_amdgcn_readlane(V[c], lastA & 63);
+				if (topB) { if (c == 0) H0B += (int16_t)(__builtin_amdgcn_readlane(U[c], 0) >> 16); }
+				else if (r < n_rowsB && (lastB >> 6) == c) H0B += (int16_t)(__builtin_amdgcn_readlane(V[c], lastB & 63) >> 16);
+			}
+		}
+		// ---- tracebacks from (tlen-1, qlen-1) (ksw2_exts2_sse.c:459-461; every cell on the way is inside the matrix), one job
+		//      after the other, by the whole wave: a run is followed 64 cells at a time ----
+		__threadfence_block();
+		int n_cigA = 0, n_cigB = 0;
+		uint32_t cig_offA = 0, cig_offB = 0;
+#pragma unroll
+		for (int which = 0; which < 2; ++which) {
+			if (which == 1 && !hasB) break;
+			const uint8_t *dir = which ? dirB : dirA;
+			const int qs = which ? qsB : qsA;
+			FastCig g = { L.cigar_tmp + (size_t)(2 * slot + which) * L.cigar_tmp_cap, 0, 0u };
+			int i = (which ? tlenB : tlenA) - 1, j = (which ? qlenB : qlenA) - 1, state = 0;
+			const uint32_t op3 = long_thres > 0 ? 3u : 2u; // min_intron_len = long_thres (ksw2.h:147-148)
+			while (i >= 0 && j >= 0) {
+				const int di = state == 2 ? 0 : 1, dj = (state == 0 || state == 2) ? 1 : 0;
+				const int ii = i - lane * di, jj = j - lane * dj;
+				const bool valid = ii >= 0 && jj >= 0;
+				const int tmp = valid ? dir[(size_t)(ii + jj) * qs + jj] : 0;
+				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
+				const unsigned long long stop = ~__ballot(cont);
+				const int run = stop ? __builtin_ctzll(stop) : 64;
+				if (run > 0) {
+					fast_cig_push(g, state == 0 ? 0u : state == 2 ? 1u : state == 3 ? op3 : 2u, run);
+					i -= run * di, j -= run * dj;
+					continue;
+				}
+				state = __builtin_amdgcn_readfirstlane(tmp) & 7; // the run ends on this cell: it names the next state (ksw2.h:141-144)
+				if (state == 0) fast_cig_push(g, 0, 1), --i, --j;
+				else if (state == 1) fast_cig_push(g, 2, 1), --i;
+				else if (state == 3) fast_cig_push(g, op3, 1), --i;
+				else fast_cig_push(g, 1, 1), --j;
+			}
+			if (i >= 0) fast_cig_push(g, long_thres > 0 && i >= long_thres ? 3u : 2u, i + 1);
+			if (j >= 0) fast_cig_push(g, 1, j + 1);
+			if (g.n > 0 && lane == 0) g.c[g.n - 1] = g.last;
+			uint32_t off = 0;
+			if (g.n > 0 && lane == 0) off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
+			off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+			__threadfence_block();
+			if (g.n > 0) { // forward order into the pool, all lanes copying
+				if ((unsigned long long)off + (unsigned)g.n > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
+				else for (int k = lane; k < g.n; k += 64) L.cigar_pool[off + k] = g.c[g.n - 1 - k];
+			}
+			if (which) n_cigB = g.n, cig_offB = off; else n_cigA = g.n, cig_offA = off;
+		}
+		if (lane == 0 || (lane == 32 && hasB)) {
+			const bool isB = lane >= 32;
+			KswRes R;
+			R.max = 0, R.zdropped = 0, R.max_q = R.max_t = -1, R.mqe = R.mte = KSW_NEG_INF, R.mqe_t = R.mte_q = -1;
+			R.score = isB ? H0B : H0A, R.n_cigar = isB ? n_cigB : n_cigA, R.reach_end = 0, R.cigar_off = isB ? cig_offB : cig_offA;
+			R.zd_max = KSW_ZD_NONE, R.zd_t0 = R.zd_t1 = R.zd_q0 = R.zd_q1 = -1; // the host scans the alignment (mm_test_zdrop)
+			L.res[isB ? jidB : jidA] = R;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream)
+{
+	if (L.n_jobs <= 0) return;
+	const int n_blocks = (n_slots + 3) / 4;
+	hipStream_t s = (hipStream_t)stream;
+	switch (n_sets) {
+	case 2: hipLaunchKernelGGL((ksw_splice_kernel<2>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 4: hipLaunchKernelGGL((ksw_splice_kernel<4>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	case 8: hipLaunchKernelGGL((ksw_splice_kernel<8>), dim3(n_blocks), dim3(256), 0, s, L); break;
+	default: throw std::runtime_error("[mm2amd] ksw_splice_launch: unsupported register-set count");
+	}
+	HIP_CHECK(hipGetLastError());
+}
+
+} // namespace mm2amd

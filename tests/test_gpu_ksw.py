@@ -226,3 +226,39 @@ def test_state_window_wraps_with_overshoot_past_the_arrays():
     got = mm.ksw_extd2_batch(jobs, mat, 4, 2, 24, 1)
     for k, (q, t, w, zdrop, eb, flag) in enumerate(jobs):
         assert got[k] == ora_extd2(q, t, mat, 4, 2, 24, 1, w, zdrop, eb, flag), (k, len(q), len(t), w, hex(flag))
+
+
+@pytest.mark.parametrize("sc", [(1, 2, 2, 1, 32, 9), (1, 4, 6, 1, 24, 5)])
+def test_splice_gap_fill_kernel(sc, monkeypatch):
+    """the register-resident splice kernel (ksw_splice.hip: gap-fill calls, flag APPROX_MAX) against the oracle: paired jobs of
+    different shapes, queries from 1 to 512 bases (all register-set counts), introns up to 30 kb, both strands / splice models /
+    no strand, target shorter than the query; and the same jobs through the lane-exact kernel (MM2AMD_KSW_EXACT_ONLY)"""
+    import minimap2_amd as mm
+    from reflib import ora_exts2
+    from seqsim import spliced_pair
+    a, b, go, ge, go2, noncan = sc
+    rng = np.random.default_rng(100 + sum(sc))
+    mat = ts_mat(a, b, 1, 0)
+    jobs = []
+    for it in range(260):
+        n_exon = int(rng.integers(1, 4))
+        q, t = spliced_pair(rng, n_exon, float(rng.choice([0.0, 0.03, 0.1])), exon=(10, 170), intron=(30, 3000))
+        strand = int(rng.choice([0x100, 0x200, 0x100, 0x200, 0]))
+        flag = 0x08 | strand | (0x400 if it % 4 else 0) | (0x800 if it % 3 else 0)
+        jobs.append((q[:512], t, -1, 200, -1, flag))
+    for ql in (1, 2, 63, 64, 65, 128, 129, 256, 257, 511, 512):
+        q = rng.integers(0, 4, ql, dtype=np.uint8)
+        for tl in (1, 5, 64, 200, 1000):
+            t = rng.integers(0, 4, tl, dtype=np.uint8)
+            jobs.append((q, t, -1, 200, -1, 0x08 | 0x100 | 0x400 | 0x800))
+    for it in range(6):
+        q, t = spliced_pair(rng, 3, 0.04, exon=(60, 120), intron=(8000, 30000))
+        jobs.append((q, t, -1, 200, -1, 0x08 | [0x100, 0x200][it & 1] | 0x400 | 0x800))
+    q, t = spliced_pair(rng, 2, 0.02, exon=(100, 101), intron=(300, 301))
+    t[rng.random(len(t)) < 0.05] = 4  # ambiguous bases
+    jobs.append((q, t, -1, 200, -1, 0x08 | 0x100 | 0x400 | 0x800))
+    got = mm.ksw_exts2_batch(jobs, mat, go, ge, go2, noncan)
+    for k, (q, t, w, zdrop, eb, flag) in enumerate(jobs):
+        assert got[k] == ora_exts2(q, t, mat, go, ge, go2, noncan, zdrop, eb, 9, 5, flag), (k, len(q), len(t), hex(flag))
+    monkeypatch.setenv("MM2AMD_KSW_EXACT_ONLY", "1")
+    assert mm.ksw_exts2_batch(jobs, mat, go, ge, go2, noncan) == got
