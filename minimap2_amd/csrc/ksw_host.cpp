@@ -17,11 +17,15 @@ namespace {
 // LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
 // direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
 constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice = kFirstExact + kRingClasses * kDirClasses;
-// kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip) with 2, 4 or 8 register sets of 64 QUERY
-// positions, classed by direction-matrix size like the exact kernel.
-constexpr int kSpliceClasses = 3, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
-const int kSpliceSets[kSpliceClasses] = { 2, 4, 8 };
-const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 2 };
+// kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip): two jobs per wave with 2 or 4 register sets of
+// 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves with 4, 8 or 16 sets (up to
+// 512 / 1024 / 2048); classed by direction-matrix size like the exact kernel.
+constexpr int kSpliceClasses = 5, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
+const int kSpliceSets[kSpliceClasses] = { 2, 4, 4, 8, 16 };
+const bool kSpliceSelf[kSpliceClasses] = { false, false, true, true, true };
+const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 512, 1024, 2048 };
+const int kSpliceWaves[kSpliceClasses] = { 4, 4, 4, 4, 2 };       // waves per block (splice_wpb in ksw_splice.hip)
+const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 4, 2, 2 };
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 const int kFastMaxT[kFirstExact] = { 128, 192, 256, 320, 384, 512 };
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
@@ -41,19 +45,19 @@ inline bool fast_eligible(const KswJob &j, bool scoring_ok)
 	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
 }
 // The splice gap fill (align.c:840 with -x splice) may take the register-resident splice kernel: global alignment with the
-// approximate score, default substitution scores, forward CIGAR, no junction scores, at most 512 query bases; the scoring must
+// approximate score, default substitution scores, forward CIGAR, no junction scores, at most 2048 query bases; the scoring must
 // keep every intermediate of a valid cell inside 8 bits (what the reference's int8 lanes assume).
 inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
 {
 	constexpr int kSpliceBits = KSW_SPLICE_FOR | KSW_SPLICE_REV | KSW_SPLICE_FLANK | KSW_SPLICE_CMPLX;
 	if (!scoring_ok || ((j.flag & 0x1fff) & ~kSpliceBits) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
-	return j.qlen > 0 && j.tlen > 0 && j.qlen <= 512;
+	return j.qlen > 0 && j.tlen > 0 && j.qlen <= 2048;
 }
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
 void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_fast.hip
-void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_splice.hip
+void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                     const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
@@ -98,7 +102,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (fast) { tier = 0; while (j.tlen > kFastMaxT[tier]) ++tier; }
 			else if (sfast) {
 				int nc = 0, dc = 0;
-				while (j.qlen > 64 * kSpliceSets[nc]) ++nc;
+				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
 				while (db > dir_limit(dc)) ++dc;
 				tier = kFirstSplice + nc * kDirClasses + dc;
 			} else {
@@ -188,19 +192,20 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			P.hbm = !fast && rc == kHbmRing;
 			P.ring = fast ? 64 : P.hbm ? cls[tier].max_ring : kRingSize[rc];
-			P.wpb = fast ? 4 : kRingWaves[rc];
+			const int sclass = sfast ? (tier - kFirstSplice) / kDirClasses : 0;
+			P.wpb = sfast ? kSpliceWaves[sclass] : fast ? 4 : kRingWaves[rc];
 			const size_t region = (ksw_lds_per_wave(P.ring, P.max_Q16) + 15) / 16 * 16;
 			if (!fast && !P.hbm && region > 160 * 1024) P.hbm = true; // a very long query next to a wide window: state goes to HBM
 			if (P.hbm) P.wpb = 4;
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[(tier - kFirstSplice) / kDirClasses];
+			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
 			else if (P.hbm) blocks_per_cu = 4;
 			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
 			const int wpb = P.wpb;
-			const size_t per_slot = fast ? 2 : 1; // the gap-fill kernels run two jobs per wave
+			const size_t per_slot = fast && !(sfast && kSpliceSelf[sclass]) ? 2 : 1; // the paired gap-fill kernels run two jobs per wave
 			P.n_slots = std::min<size_t>((P.end - P.beg + per_slot - 1) / per_slot, (size_t)n_cu * blocks_per_cu * wpb);
 			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
@@ -227,9 +232,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
-			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], stream);
+			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
-			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2>", "ksw_splice_kernel<4>", "ksw_splice_kernel<8>" };
+			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,self>", "ksw_splice_kernel<8,self>", "ksw_splice_kernel<16,self>" };
 			if (prof) prof->end(stream, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
 		}
 		uint32_t cursor[2];

@@ -13,7 +13,10 @@
 //     written by the same lane one row earlier, what it reads at t (u, y) by lane j-1 -- one DPP wave shift each.
 //   * the target streams through: every 64 rows the wave admits the next 64 target positions into an LDS ring, each entry
 //     holding the base and the donor / acceptor cost of its position (ksw2_exts2_sse.c:120-194) ready for packed use.
-//   * two jobs per wavefront in the halves of packed 16-bit registers, as in ksw_fast.hip; the launch is ordered by row count.
+//   * two jobs per wavefront in the halves of packed 16-bit registers, as in ksw_fast.hip (the launch is ordered by row count);
+//     or, for queries longer than 512 (SELF): ONE job whose query positions j and j + 64*NC share a register -- the high
+//     half is then a continuation of the low half (its left neighbour at lane 0 is the low half's last lane, its target
+//     position lags 64*NC behind), which doubles the query length a register set covers without pairing unequal jobs.
 //   * the 1 B/cell direction matrix is the only HBM traffic (row-major by query position: 64 B coalesced per register set);
 //     the traceback is done by the whole wave: lane k looks k cells ahead along the current run (match diagonal, gap, intron)
 //     and one ballot tells how long the run lasts, so an intron of 50 000 bases costs 800 loads in sequence, not 50 000.
@@ -58,14 +61,20 @@ __device__ __forceinline__ int acceptor_class(const SpliceParams &P, int c0, int
 }
 }
 
-template <int NC>
-__global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswLaunch L)
+constexpr int splice_ring(int nc, bool self) { int need = (self ? 128 : 64) * nc + 64, p = 128; while (p < need) p <<= 1; return p; }
+constexpr int splice_wpb(int nc, bool self) { const int b = splice_ring(nc, self) * (self ? 8 : 16); return b * 4 <= 65536 ? 4 : b * 2 <= 65536 ? 2 : 1; }
+
+template <int NC, bool SELF>
+__global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) * 4 / splice_wpb(NC, SELF)) ksw_splice_kernel(KswLaunch L)
 {
-	constexpr int RING = NC <= 1 ? 128 : NC <= 3 ? 256 : NC <= 7 ? 512 : 1024, RM = RING - 1; // >= 64*NC + 64 positions
-	__shared__ uint4 s_ring[4][RING]; // per wave and target position: {base, donor, acceptor} as packed halves (job A low, job B high)
+	constexpr int RING = splice_ring(NC, SELF), RM = RING - 1, WPB = splice_wpb(NC, SELF), QOFF = 64 * NC;
+	// per wave and target position: {base, donor, acceptor}; paired: 16 B of packed halves (job A low, job B high);
+	// SELF: 8 B {base | donor << 16, acceptor} of the one job, read at two positions and merged
+	__shared__ __attribute__((aligned(16))) uint8_t s_raw[WPB * RING * (SELF ? 8 : 16)];
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
-	const int slot = blockIdx.x * 4 + wave_in_block;
-	uint4 *ring = s_ring[wave_in_block];
+	const int slot = blockIdx.x * WPB + wave_in_block;
+	uint4 *ring = (uint4 *)s_raw + (SELF ? 0 : wave_in_block * RING);
+	uint2 *ring2 = (uint2 *)s_raw + (SELF ? wave_in_block * RING : 0);
 	const int m = L.sc.m;
 	const int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, qe = q + e;
 	const int sc_mch = L.sc.mat[0], sc_mis = L.sc.mat[1];
@@ -81,13 +90,13 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 		int pid = 0;
 		if (lane == 0) pid = atomicAdd(L.counter, 1);
 		pid = __builtin_amdgcn_readfirstlane(pid);
-		if (2 * pid >= L.n_jobs) break;
-		const int jidA = 2 * pid, jidB = 2 * pid + 1;
-		const bool hasB = jidB < L.n_jobs;
+		if ((SELF ? pid : 2 * pid) >= L.n_jobs) break;
+		const int jidA = SELF ? pid : 2 * pid, jidB = SELF ? pid : 2 * pid + 1;
+		const bool hasB = !SELF && jidB < L.n_jobs; // a second JOB in the high halves
 		const KswJob JA = L.jobs[jidA], JB = L.jobs[hasB ? jidB : jidA];
 		const int qlenA = JA.qlen, tlenA = JA.tlen, qlenB = hasB ? JB.qlen : 0, tlenB = hasB ? JB.tlen : 0;
-		const int qsA = (qlenA + 63) & ~63, qsB = (qlenB + 63) & ~63; // row stride of the direction matrices
-		uint8_t *dirA = L.dir_pool + (size_t)(2 * slot) * L.slot_bytes, *dirB = dirA + L.slot_bytes;
+		const int qsA = (qlenA + 63) & ~63, qsB = SELF ? qsA : (qlenB + 63) & ~63; // row stride of the direction matrices
+		uint8_t *dirA = L.dir_pool + (size_t)(SELF ? slot : 2 * slot) * L.slot_bytes, *dirB = SELF ? dirA + QOFF : dirA + L.slot_bytes;
 		auto splice_params = [&](int flag) {
 			SpliceParams P;
 			P.is_for = (flag & KSW_SPLICE_FOR) ? 1 : 0, P.has_strand = (flag & (KSW_SPLICE_FOR | KSW_SPLICE_REV)) ? 1 : 0;
@@ -120,7 +129,8 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 			const int j = c * 64 + lane;
 			uint32_t bA = 4, bB = 4;
 			if (j < qlenA) bA = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)j : JA.q_off + (uint64_t)j];
-			if (j < qlenB) bB = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)j : JB.q_off + (uint64_t)j];
+			if (SELF) { if (j + QOFF < qlenA) bB = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)(j + QOFF) : JA.q_off + (uint64_t)(j + QOFF)]; }
+			else if (j < qlenB) bB = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)j : JB.q_off + (uint64_t)j];
 			Q[c] = bA | bB << 16;
 			U[c] = V[c] = X[c] = Y[c] = P_NQE, X2[c] = P_NQ2;
 		}
@@ -133,9 +143,10 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 		for (int r = 0; r < n_rows; ++r) {
 			if (r > frontier) { // admit the next 64 target positions (wave-uniform)
 				const int t = frontier + 1 + lane;
-				int dnA, acA, dnB, acB;
-				const int cA = target_entry(JA, SA, tlenA, t, dnA, acA), cB = target_entry(JB, SB, tlenB, t, dnB, acB);
-				ring[t & RM] = make_uint4((uint32_t)cA | (uint32_t)cB << 16, ((uint32_t)dnA & 0xffffu) | (uint32_t)dnB << 16, ((uint32_t)acA & 0xffffu) | (uint32_t)acB << 16, 0u);
+				int dnA, acA, dnB = 0, acB = 0;
+				const int cA = target_entry(JA, SA, tlenA, t, dnA, acA), cB = SELF ? 0 : target_entry(JB, SB, tlenB, t, dnB, acB);
+				if (SELF) ring2[t & RM] = make_uint2((uint32_t)cA | (uint32_t)dnA << 16, (uint32_t)acA & 0xffffu);
+				else ring[t & RM] = make_uint4((uint32_t)cA | (uint32_t)cB << 16, ((uint32_t)dnA & 0xffffu) | (uint32_t)dnB << 16, ((uint32_t)acA & 0xffffu) | (uint32_t)acB << 16, 0u);
 				frontier += 64;
 				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 				__builtin_amdgcn_wave_barrier();
@@ -145,15 +156,21 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 			int jloB = r - tlenB + 1 > 0 ? r - tlenB + 1 : 0, jhiB = r < qlenB - 1 ? r : qlenB - 1;
 			if (r >= n_rowsA) jloA = 1, jhiA = 0;
 			if (r >= n_rowsB) jloB = 1, jhiB = 0;
+			if (SELF) jloB = jloA - QOFF, jhiB = jhiA - QOFF; // the high halves hold query positions lane + QOFF of the same job
 			const uint32_t wA = (uint32_t)(jhiA - jloA + 1), wB = (uint32_t)(jhiB - jloB + 1);
-			const int lo = jloA <= jhiA ? (jloB <= jhiB && jloB < jloA ? jloB : jloA) : jloB, hi = jhiA > jhiB ? jhiA : jhiB;
+			int lo = jloA <= jhiA ? (jloB <= jhiB && jloB < jloA ? jloB : jloA) : jloB, hi = jhiA > jhiB ? jhiA : jhiB;
+			if (SELF) lo = 0, hi = jhiA < QOFF ? jhiA : QOFF - 1; // register sets 0..: the low halves' range covers the high halves' (both start at their lane 0 region)
 			// v[-1] / u[r] on the matrix border (ksw2_exts2_sse.c:234-247): depends on r only
 			const int bnd = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : 0;
 			const uint32_t P_BND = pk2(bnd);
 			// query position r starts its column on this row (t = 0): x, v, x2 of "t = -1" are border values
 			const bool newA = r < qlenA && r < n_rowsA, newB = r < qlenB && r < n_rowsB;
-			const int edge_set = r >> 6, edge_lane = r & 63;
-			const uint32_t edge_halves = (newA ? 0xffffu : 0u) | (newB ? 0xffff0000u : 0u);
+			const int edge_j = SELF && r >= QOFF ? r - QOFF : r;
+			const int edge_set = edge_j >> 6, edge_lane = edge_j & 63;
+			const uint32_t edge_halves = SELF ? (newA ? (r >= QOFF ? 0xffff0000u : 0xffffu) : 0u) : (newA ? 0xffffu : 0u) | (newB ? 0xffff0000u : 0u);
+			// SELF: the high halves continue the low halves -- query position QOFF's left neighbour is the last lane of the last set
+			uint32_t selfU = 0, selfY = 0;
+			if (SELF) selfU = (uint32_t)__builtin_amdgcn_readlane(U[NC - 1], 63) << 16, selfY = (uint32_t)__builtin_amdgcn_readlane(Y[NC - 1], 63) << 16;
 			const bool topA = r < tlenA && r < n_rowsA, topB = r < tlenB && r < n_rowsB; // query position 0 still has a cell (t = r)
 			const int lastA = r - tlenA + 1, lastB = r - tlenB + 1;                    // query position on the last target column
 			uint8_t *prA = dirA + (size_t)r * qsA, *prB = dirB + (size_t)r * qsB;
@@ -165,6 +182,7 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 				const bool actA = (uint32_t)(j - jloA) < wA, actB = (uint32_t)(j - jloB) < wB;
 				uint32_t cU = P_BND, cY = P_NQE; // query position -1: the matrix border (u[r], y[r], :241-247)
 				if (c > 0) cU = __builtin_amdgcn_readlane(U[c - 1], 63), cY = __builtin_amdgcn_readlane(Y[c - 1], 63);
+				else if (SELF) cU = (P_BND & 0xffffu) | selfU, cY = (P_NQE & 0xffffu) | selfY;
 				const uint32_t up = dpp_shr1u(cU, U[c]), yp = dpp_shr1u(cY, Y[c]);
 				if (edge_halves && edge_set == c) {
 					const uint32_t em = lane == edge_lane ? edge_halves : 0u;
@@ -173,8 +191,15 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 				{
 					// every lane computes, active or not (see ksw_fast.hip: a lane's registers are only read while its cell, or the
 					// next cell of its right neighbour, is valid); only the stores are guarded
-					const uint4 te = ring[(r - j) & RM];
-					const uint32_t tv = te.x, dn = te.y, ac = te.z, qv = Q[c];
+					uint32_t tv, dn, ac;
+					if (SELF) {
+						const uint2 el = ring2[(r - j) & RM], eh = ring2[(r - j - QOFF) & RM];
+						tv = __builtin_amdgcn_perm(eh.x, el.x, 0x05040100u), dn = __builtin_amdgcn_perm(eh.x, el.x, 0x07060302u), ac = __builtin_amdgcn_perm(eh.y, el.y, 0x05040100u);
+					} else {
+						const uint4 te = ring[(r - j) & RM];
+						tv = te.x, dn = te.y, ac = te.z;
+					}
+					const uint32_t qv = Q[c];
 					uint32_t z = pk_mad(pk_minu(tv ^ qv, P_ONE), P_MISD, P_MCH);
 					z = pk_mad(pk_shr2(tv | qv), pk_sub(P_SCN, z), z);
 					const uint32_t vt = V[c];
@@ -197,9 +222,16 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 					if (actB) prB[(uint32_t)j] = (uint8_t)(d >> 16);
 				}
 				if (topA) { if (c == 0) H0A += (int16_t)__builtin_amdgcn_readlane(U[c], 0); }
-				else if (r < n_rowsA && (lastA >> 6) == c) H0A += (int16_t)__builtin_amdgcn_readlane(V[c], lastA & 63);
-				if (topB) { if (c == 0) H0B += (int16_t)(__builtin_amdgcn_readlane(U[c], 0) >> 16); }
-				else if (r < n_rowsB && (lastB >> 6) == c) H0B += (int16_t)(__builtin_amdgcn_readlane(V[c], lastB & 63) >> 16);
+				else if (SELF) {
+					if (r < n_rowsA && ((lastA >= QOFF ? lastA - QOFF : lastA) >> 6) == c) {
+						const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(V[c], lastA & 63);
+						H0A += lastA >= QOFF ? (int16_t)(v >> 16) : (int16_t)v;
+					}
+				} else if (r < n_rowsA && (lastA >> 6) == c) H0A += (int16_t)__builtin_amdgcn_readlane(V[c], lastA & 63);
+				if (!SELF) {
+					if (topB) { if (c == 0) H0B += (int16_t)(__builtin_amdgcn_readlane(U[c], 0) >> 16); }
+					else if (r < n_rowsB && (lastB >> 6) == c) H0B += (int16_t)(__builtin_amdgcn_readlane(V[c], lastB & 63) >> 16);
+				}
 			}
 		}
 		// ---- tracebacks from (tlen-1, qlen-1) (ksw2_exts2_sse.c:459-461; every cell on the way is inside the matrix), one job
@@ -212,7 +244,7 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 			if (which == 1 && !hasB) break;
 			const uint8_t *dir = which ? dirB : dirA;
 			const int qs = which ? qsB : qsA;
-			FastCig g = { L.cigar_tmp + (size_t)(2 * slot + which) * L.cigar_tmp_cap, 0, 0u };
+			FastCig g = { L.cigar_tmp + (size_t)((SELF ? slot : 2 * slot) + which) * L.cigar_tmp_cap, 0, 0u };
 			int i = (which ? tlenB : tlenA) - 1, j = (which ? qlenB : qlenA) - 1, state = 0;
 			const uint32_t op3 = long_thres > 0 ? 3u : 2u; // min_intron_len = long_thres (ksw2.h:147-148)
 			while (i >= 0 && j >= 0) {
@@ -260,17 +292,26 @@ __global__ void __launch_bounds__(256, (NC <= 4 ? 4 : 2)) ksw_splice_kernel(KswL
 	}
 }
 
-void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream)
+namespace {
+template <int NC, bool SELF>
+void launch_splice(const KswLaunch &L, int n_slots, hipStream_t s)
+{
+	constexpr int WPB = splice_wpb(NC, SELF);
+	hipLaunchKernelGGL((ksw_splice_kernel<NC, SELF>), dim3((n_slots + WPB - 1) / WPB), dim3(64 * WPB), 0, s, L);
+}
+}
+
+// n_sets register sets of 64 lanes; self: one job per wave using both register halves (queries up to 128 * n_sets), else two
+void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream)
 {
 	if (L.n_jobs <= 0) return;
-	const int n_blocks = (n_slots + 3) / 4;
 	hipStream_t s = (hipStream_t)stream;
-	switch (n_sets) {
-	case 2: hipLaunchKernelGGL((ksw_splice_kernel<2>), dim3(n_blocks), dim3(256), 0, s, L); break;
-	case 4: hipLaunchKernelGGL((ksw_splice_kernel<4>), dim3(n_blocks), dim3(256), 0, s, L); break;
-	case 8: hipLaunchKernelGGL((ksw_splice_kernel<8>), dim3(n_blocks), dim3(256), 0, s, L); break;
-	default: throw std::runtime_error("[mm2amd] ksw_splice_launch: unsupported register-set count");
-	}
+	if (!self && n_sets == 2) launch_splice<2, false>(L, n_slots, s);
+	else if (!self && n_sets == 4) launch_splice<4, false>(L, n_slots, s);
+	else if (self && n_sets == 4) launch_splice<4, true>(L, n_slots, s);
+	else if (self && n_sets == 8) launch_splice<8, true>(L, n_slots, s);
+	else if (self && n_sets == 16) launch_splice<16, true>(L, n_slots, s);
+	else throw std::runtime_error("[mm2amd] ksw_splice_launch: unsupported register-set count");
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -226,6 +226,10 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
 			}, 256);
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
+			if (const char *dump = getenv("MM2AMD_DUMP_JOBS")) { // debugging aid: the shapes of the DP jobs of every round
+				FILE *fp = fopen(dump, "a");
+				if (fp) { for (const KswJob &j : jobs) fprintf(fp, "%d\t%d\t%d\t0x%x\t%d\n", round, j.qlen, j.tlen, j.flag & 0x1fff, j.w); fclose(fp); }
+			}
 			Trace::get().add(lane, "host:plan", t0, now());
 			stats.t_plan += now() - t0; t0 = now();
 			be_.ksw(jobs, sc, lane, n_threads_, kres, &cigars);
