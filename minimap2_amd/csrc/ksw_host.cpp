@@ -112,6 +112,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 				int rc = 0, dc = 0;
 				while (rc < kHbmRing && ring_need > kRingSize[rc]) ++rc;
 				while (db > dir_limit(dc)) ++dc;
+				if (!splice) dc = dc == 0 ? 0 : dc <= 3 ? 3 : dc <= 6 ? 6 : kDirClasses - 1; // banded matrices vary little: 256 KB / 2 MB / 16 MB / any, fewer and fuller launches
 				tier = kFirstExact + rc * kDirClasses + dc;
 			}
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
@@ -212,6 +213,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
 			if (P.hbm) need_state = std::max(need_state, P.n_slots * region);
 		}
+		if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
 		d_dir.ensure(need_dir, 1.0);
 		d_cigar_tmp.ensure(need_tmp, 1.0);
 		if (need_state) d_state.ensure(need_state, 1.0);

@@ -98,7 +98,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
 	std::vector<std::pair<long, long>> subs;
 	{
-		long max_reads = be_.max_reads_per_call(), sub_reads = 10000; // short reads: bound the read count too, so that every lane gets work
+		long max_reads = be_.max_reads_per_call(), sub_reads = 25000; // short reads: bound the read count too, so that a second lane overlaps the host stages; larger sub-batches keep the DP launches' tails short
 		if (const char *e = getenv("MM2AMD_SUBBATCH_READS")) sub_reads = atol(e) > 0 ? atol(e) : sub_reads;
 		if (sub_reads < max_reads) max_reads = sub_reads;
 		for (long lo = 0, hi; lo < m_all; lo = hi) {
