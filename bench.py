@@ -248,6 +248,19 @@ def main():
         log("rank %d step %d: %.3f s  stats=%s" % (rank, s, times[-1], {k: round(v, 3) for k, v in al.last_stats().items()}))
     prof = mm.profile_get()
     mm.profile_enable(False)
+    # host output stage, outside the timed region: SAM text of one batch's hits on the pool threads
+    fmt = None
+    try:
+        al.stage(named)
+        n_reg, reg, rep = al.run(raw=True)
+        t = time.time()
+        text = al.format_raw(n_reg, reg, rep)
+        dt = time.time() - t
+        al.free_raw(n_reg, reg)
+        fmt = {"sam_bytes": len(text), "seconds": round(dt, 3), "GB_per_s": round(len(text) / dt / 1e9, 3), "threads": n_threads}
+        del text
+    except Exception as e:
+        fmt = {"error": str(e)}
     total_t = sum(times)
     if world > 1:
         tt = torch.tensor([total_t], dtype=torch.float64, device=comm_dev)
@@ -340,7 +353,7 @@ def main():
                       "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads,
                       "parallelism": "replicated index, reads sharded %d-way, RCCL hit gather" % world if world > 1 else "1 GPU",
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},
-           "roofline": roof, "cpu_baseline": cpu}
+           "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
     print(json.dumps(out), flush=True)
     al.close()
     if world > 1:

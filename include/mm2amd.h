@@ -133,6 +133,16 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int
 int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq);
 int mm_gpu_map_staged(int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
 
+/* Host output stage: replaces the record-writing loop of the reference's pipeline step 2
+ * (map.c:585-623: mm_write_sam3, format.c:522, or mm_write_paf4, format.c:425, per hit, then mm_err_puts) for one mini-batch.
+ * The text is byte-identical to what that loop prints -- SAM or PAF by MM_F_OUT_SAM, cg/cs/ds/MD/ts/SA tags, unmapped records
+ * by MM_F_PAF_NO_HIT / MM_F_SAM_HIT_ONLY, secondaries by MM_F_NO_PRINT_2ND -- but produced on the host thread pool.
+ * Arguments as for mm_gpu_map_batch (results as it returned them); *out receives ONE malloc'd block of '\n'-terminated
+ * records in input order (free() it), *out_len its length.  Single-segment fragments only; no RG tag; uses the index and
+ * options given to mm_gpu_init. */
+int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq, const int *n_reg, void *const *reg,
+                        const int *rep_len, char **out, size_t *out_len);
+
 /* free() every reg[i][j].p and reg[i] (what the reference's step 2 does, map.c:629-631); for non-C callers. */
 void mm2amd_free_regs(int n_frag, int *n_reg, MM2AMD_REG_PP reg);
 

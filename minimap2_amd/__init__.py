@@ -125,10 +125,17 @@ def _bind(L):
         L.mm2amd_check_opt.argtypes = [vp, vp]
         L.mm2amd_idxopt_init.argtypes = [vp]
         L.mm2amd_mapopt_init.argtypes = [vp]
+        L.mm_gpu_format_batch.argtypes = [C.c_int, ip, ip, vp, ip, C.POINTER(vp), ip, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.mm2amd_profile_enable.argtypes = [C.c_int]
         L.mm2amd_profile_enable.restype = None
         L.mm2amd_profile_get.argtypes = [C.POINTER(KernelStat), C.c_int]
     return L
+
+
+def _libc_free(p):
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(p)
 
 
 def lib(path=None):
@@ -322,6 +329,17 @@ class Aligner(object):
 
     def free_raw(self, n_reg, reg):
         lib().mm2amd_free_regs(len(n_reg), n_reg, reg)
+
+    def format_raw(self, n_reg, reg, rep_len=None):
+        """SAM (or PAF, by the aligner's options) records of the staged batch's raw results, as bytes: what the reference's
+        output step writes for these reads (mm_gpu_format_batch)."""
+        n, arr, _, seg_off, n_seg = self._staged
+        out, out_len = C.c_void_p(), C.c_size_t()
+        _check(lib().mm_gpu_format_batch(n, seg_off, n_seg, arr, n_reg, reg, rep_len, C.byref(out), C.byref(out_len)))
+        try:
+            return C.string_at(out, out_len.value)
+        finally:
+            _libc_free(out)
 
     def map_batch(self, reads):
         self.stage(reads)

@@ -9,6 +9,7 @@
 #include <thread>
 #include "../../include/mm2amd.h"
 #include "mapper.hpp"
+#include "format.hpp"
 #include "index_handle.hpp"
 #include "threads.hpp"
 
@@ -145,6 +146,24 @@ int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 		return capi_fail(MM2AMD_EINVAL, e.what());
 	} catch (const std::exception &e) {
 		return capi_fail(MM2AMD_EHIP, e.what());
+	}
+}
+
+int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const int *n_reg, void *const *reg, const int *rep_len, char **out, size_t *out_len)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_format_batch called before mm_gpu_init");
+	if (n_frag < 0 || !out || !out_len || (n_frag > 0 && (!seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: bad arguments");
+	for (int i = 0; i < n_frag; ++i)
+		if ((n_seg && n_seg[i] != 1) || (seg_off && seg_off[i] != i)) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: single-segment fragments only");
+	const std::string why = format_check(g_ctx->opt);
+	if (!why.empty()) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: " + why);
+	try {
+		*out = format_batch(*g_ctx->fi, g_ctx->opt, g_ctx->n_threads, n_frag, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, out_len);
+		if (!*out) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm_gpu_format_batch: out of memory");
+		return 0;
+	} catch (const std::exception &e) {
+		return capi_fail(MM2AMD_EINVAL, e.what());
 	}
 }
 

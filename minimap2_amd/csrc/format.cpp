@@ -1,0 +1,378 @@
+// Host output stage: the text the reference writes in step 2 of its pipeline (map.c:585-623) -- SAM
+// records as mm_write_sam3 (format.c:522-679) and PAF records as mm_write_paf4 (format.c:425-458) produce them, with the tag
+// block of write_tags (:397-423) and the cs / ds / MD strings of write_cs_ds_core / write_MD_core (:171-254, :302-331) --
+// formatted for a whole mini-batch on the host thread pool instead of by the single pipeline thread.  Once mapping is an
+// order of magnitude faster, that single thread is the Amdahl term; records are independent, so reads are cut into chunks,
+// every chunk is formatted into its own buffer by one pool thread, and the buffers are concatenated in input order.
+// Single-segment fragments only (the mapper's scope); no read-group tag (-R is CLI state of the reference).
+#include <array>
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "format.hpp"
+#include "threads.hpp"
+
+namespace mm2amd {
+
+using namespace ref;
+
+extern const uint8_t kNt4Table[256];
+
+namespace {
+
+constexpr int64_t F_OUT_CG = 0x020, F_OUT_CS = 0x040, F_OUT_CS_LONG = 0x800, F_LONG_CIGAR = 0x10000, F_SOFTCLIP = 0x80000, F_OUT_MD = 0x1000000,
+	F_COPY_COMMENT = 0x2000000, F_PAF_NO_HIT = 0x8000000, F_SAM_HIT_ONLY = 0x40000000, F_SECONDARY_SEQ = 0x1000000000LL, F_OUT_DS = 0x2000000000LL,
+	F_OUT_JUNC = 0x10000000000LL;
+const char kCigarOps[] = "MIDNSHP=XB";
+
+struct Text { // append-only byte buffer
+	std::string s;
+	void ch(char c) { s.push_back(c); }
+	void str(const char *p) { s.append(p); }
+	void str(const char *p, size_t n) { s.append(p, n); }
+	void num(int64_t v)
+	{
+		char buf[24];
+		int l = 0;
+		uint64_t x = v < 0 ? (uint64_t)(-v) : (uint64_t)v;
+		do buf[l++] = (char)('0' + x % 10), x /= 10; while (x);
+		if (v < 0) buf[l++] = '-';
+		while (l) s.push_back(buf[--l]);
+	}
+	void tag(const char *name, int64_t v) { ch('\t'), str(name), num(v); } // "\tNM:i:" + value
+};
+
+struct Seqs { std::vector<uint8_t> q, t; std::string tmp; }; // per-thread scratch for cs/ds/MD
+
+void count_gaps(const Reg1 &r, int *n_gap, int *n_gapo) // mm_count_gaps (align.c:985-995)
+{
+	*n_gap = *n_gapo = 0;
+	if (!r.p) return;
+	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
+		const int op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
+		if (op == 1 || op == 2) ++*n_gapo, *n_gap += len;
+	}
+}
+
+double event_identity(const Reg1 &r) // mm_event_identity (align.c:997-1003)
+{
+	if (!r.p) return -1.0f;
+	int n_gap, n_gapo;
+	count_gaps(r, &n_gap, &n_gapo);
+	return (double)r.mlen / (r.blen + r.p->n_ambi - n_gap + n_gapo);
+}
+
+void put_fraction(Text &o, double v) // "0" or %.4f (format.c:413-414, :418-419)
+{
+	if (v == 0.0) { o.ch('0'); return; }
+	char buf[16];
+	snprintf(buf, 16, "%.4f", v);
+	o.str(buf);
+}
+
+void put_tags(Text &o, const Reg1 &r) // write_tags
+{
+	const char type = r.id == r.parent ? (r.inv ? 'I' : 'P') : (r.inv ? 'i' : 'S');
+	if (r.p) {
+		o.tag("NM:i:", r.blen - r.mlen + (int)r.p->n_ambi), o.tag("ms:i:", r.p->dp_max0), o.tag("AS:i:", r.p->dp_score), o.tag("nn:i:", (int)r.p->n_ambi);
+		if (r.p->trans_strand == 1 || r.p->trans_strand == 2) o.str("\tts:A:"), o.ch("?+-?"[r.p->trans_strand]);
+	}
+	o.str("\ttp:A:"), o.ch(type), o.tag("cm:i:", r.cnt), o.tag("s1:i:", r.score);
+	if (r.parent == r.id) o.tag("s2:i:", r.subsc);
+	if (r.p) {
+		o.str("\tde:f:");
+		const double div = 1.0 - event_identity(r);
+		if (div == 0.0) o.ch('0'); else put_fraction(o, 1.0 - event_identity(r));
+	} else if (r.div >= 0.0f && r.div <= 1.0f) {
+		o.str("\tdv:f:");
+		if (r.div == 0.0f) o.ch('0'); else put_fraction(o, r.div);
+	}
+	if (r.split) o.tag("zd:i:", r.split);
+}
+
+// the aligned stretches of query and target as nt4 codes, query on the alignment strand (write_cs_ds_or_MD, format.c:333-362)
+void fetch_pair(const FlatIndex &fi, const Bseq1 &t, const Reg1 &r, Seqs &sq)
+{
+	sq.q.resize(r.qe - r.qs), sq.t.resize(r.re - r.rs);
+	fi.getseq(r.rid, r.rs, r.re, sq.t.data());
+	if (!r.rev) for (int i = r.qs; i < r.qe; ++i) sq.q[i - r.qs] = kNt4Table[(uint8_t)t.seq[i]];
+	else for (int i = r.qs; i < r.qe; ++i) { const uint8_t c = kNt4Table[(uint8_t)t.seq[i]]; sq.q[r.qe - i - 1] = c >= 4 ? 4 : 3 - c; }
+}
+
+void put_bases(Text &o, const char *alphabet, const uint8_t *s, int64_t n) { for (int64_t i = 0; i < n; ++i) o.ch(alphabet[s[i]]); }
+
+void put_ds_indel(Text &o, int64_t len, const uint8_t *seq, int64_t ll, int64_t lr) // write_indel_ds (format.c:142-169)
+{
+	if (ll + lr >= len) { o.ch('['), put_bases(o, "acgtn", seq, len), o.ch(']'); return; }
+	int64_t k = 0;
+	if (ll > 0) o.ch('['), put_bases(o, "acgtn", seq, ll), o.ch(']'), k += ll;
+	put_bases(o, "acgtn", seq + k, len - lr - ll), k += len - lr - ll;
+	if (lr > 0) o.ch('['), put_bases(o, "acgtn", seq + k, lr), o.ch(']');
+}
+
+void put_cs(Text &o, const Reg1 &r, const Seqs &sq, bool no_iden, bool is_ds) // write_cs_ds_core
+{
+	const uint8_t *qs = sq.q.data(), *ts = sq.t.data();
+	o.str(is_ds ? "\tds:Z:" : "\tcs:Z:");
+	int q_len = 0, t_len = 0;
+	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
+		const int op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
+		if (op == 0 || op == 7 || op == 8) q_len += len, t_len += len;
+		else if (op == 1) q_len += len;
+		else if (op == 2 || op == 3) t_len += len;
+	}
+	int q_off = 0, t_off = 0;
+	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
+		const int op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
+		if (op == 0 || op == 7 || op == 8) {
+			int run = 0; // identical bases seen since the last difference
+			auto flush = [&](int end) {
+				if (run == 0) return;
+				if (no_iden) o.ch(':'), o.num(run);
+				else o.ch('='), put_bases(o, "ACGTN", qs + q_off + end - run, run);
+				run = 0;
+			};
+			for (int j = 0; j < len; ++j) {
+				if (qs[q_off + j] != ts[t_off + j]) flush(j), o.ch('*'), o.ch("acgtn"[ts[t_off + j]]), o.ch("acgtn"[qs[q_off + j]]);
+				else ++run;
+			}
+			flush(len);
+			q_off += len, t_off += len;
+		} else if (op == 1) {
+			o.ch('+');
+			if (is_ds) { // how far the inserted bases could be shifted right / left (format.c:214-222)
+				int z, y = q_off;
+				for (z = 1; z <= len; ++z) if (y - z < 0 || qs[y + len - z] != qs[y - z]) break;
+				const int lr = z - 1;
+				for (z = 0; z < len; ++z) if (y + len + z >= q_len || qs[y + len + z] != qs[y + z]) break;
+				put_ds_indel(o, len, qs + y, z, lr);
+			} else put_bases(o, "acgtn", qs + q_off, len);
+			q_off += len;
+		} else if (op == 2) {
+			o.ch('-');
+			if (is_ds) {
+				int z, x = t_off;
+				for (z = 1; z <= len; ++z) if (x - z < 0 || ts[x + len - z] != ts[x - z]) break;
+				const int lr = z - 1;
+				for (z = 0; z < len; ++z) if (x + len + z >= t_len || ts[x + z] != ts[x + len + z]) break;
+				put_ds_indel(o, len, ts + x, z, lr);
+			} else put_bases(o, "acgtn", ts + t_off, len);
+			t_off += len;
+		} else { // intron: its first and last two bases
+			o.ch('~'), o.ch("acgtn"[ts[t_off]]), o.ch("acgtn"[ts[t_off + 1]]), o.num(len), o.ch("acgtn"[ts[t_off + len - 2]]), o.ch("acgtn"[ts[t_off + len - 1]]);
+			t_off += len;
+		}
+	}
+}
+
+void put_md(Text &o, const Reg1 &r, const Seqs &sq) // write_MD_core
+{
+	const uint8_t *qs = sq.q.data(), *ts = sq.t.data();
+	o.str("\tMD:Z:");
+	int q_off = 0, t_off = 0, l_md = 0;
+	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
+		const int op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
+		if (op == 0 || op == 7 || op == 8) {
+			for (int j = 0; j < len; ++j) {
+				if (qs[q_off + j] != ts[t_off + j]) o.num(l_md), o.ch("ACGTN"[ts[t_off + j]]), l_md = 0;
+				else ++l_md;
+			}
+			q_off += len, t_off += len;
+		} else if (op == 1) q_off += len;
+		else if (op == 2) o.num(l_md), o.ch('^'), put_bases(o, "ACGTN", ts + t_off, len), l_md = 0, t_off += len;
+		else if (op == 3) t_off += len;
+	}
+	if (l_md > 0) o.num(l_md);
+}
+
+void put_cs_or_md(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 &r, int64_t flag, Seqs &sq)
+{
+	if (!r.p) return;
+	fetch_pair(fi, t, r, sq);
+	if (flag & F_OUT_MD) put_md(o, r, sq);
+	else put_cs(o, r, sq, !(flag & F_OUT_CS_LONG), flag & F_OUT_DS);
+}
+
+void put_paf(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 *r, int64_t flag, int rep_len, Seqs &sq) // mm_write_paf4, n_seg == 1
+{
+	o.str(t.name);
+	if (!r) {
+		o.ch('\t'), o.num(t.l_seq), o.str("\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0");
+		if (rep_len >= 0) o.tag("rl:i:", rep_len);
+		return;
+	}
+	o.ch('\t'), o.num(t.l_seq), o.ch('\t'), o.num(r->qs), o.ch('\t'), o.num(r->qe), o.ch('\t'), o.ch("+-"[r->rev]), o.ch('\t');
+	if (!fi.names[r->rid].empty()) o.str(fi.names[r->rid].c_str()); else o.num(r->rid);
+	o.ch('\t'), o.num(fi.seq_len[r->rid]), o.ch('\t'), o.num(r->rs), o.ch('\t'), o.num(r->re);
+	o.ch('\t'), o.num(r->mlen), o.ch('\t'), o.num(r->blen), o.ch('\t'), o.num(r->mapq);
+	put_tags(o, *r);
+	if (rep_len >= 0) o.tag("rl:i:", rep_len);
+	if (r->p && (flag & F_OUT_CG)) {
+		o.str("\tcg:Z:");
+		for (uint32_t k = 0; k < r->p->n_cigar; ++k) o.num(r->p->cigar[k] >> 4), o.ch(kCigarOps[r->p->cigar[k] & 0xf]);
+	}
+	if (r->p && (flag & (F_OUT_CS | F_OUT_DS | F_OUT_MD))) put_cs_or_md(o, fi, t, *r, flag, sq);
+	if ((flag & F_COPY_COMMENT) && t.comment) o.ch('\t'), o.str(t.comment);
+}
+
+void put_seq(Text &o, const char *seq, int l, bool rev, bool comp) // sam_write_sq (format.c:470-482)
+{
+	static const std::array<char, 128> kComp = [] { // seq_comp_table (bseq.c:11-28) for ASCII: IUPAC complements, case preserved
+		std::array<char, 128> t;
+		for (int c = 0; c < 128; ++c) t[c] = (char)c;
+		const char *a = "ACGTUMRWSYKVHDBNacgtumrwsykvhdbn", *b = "TGCAAKYWSRMBDHVNtgcaakywsrmbdhvn";
+		for (int i = 0; a[i]; ++i) t[(int)a[i]] = b[i];
+		return t;
+	}();
+	if (!rev) { o.str(seq, l); return; }
+	for (int i = 0; i < l; ++i) { const int c = (unsigned char)seq[l - 1 - i]; o.ch(c < 128 && comp ? kComp[c] : (char)c); }
+}
+
+void put_sam_cigar(Text &o, int sam_flag, bool in_tag, int qlen, const Reg1 &r, int64_t flag) // write_sam_cigar (format.c:494-520)
+{
+	if (!r.p) { o.ch('*'); return; }
+	const uint32_t clip0 = r.rev ? qlen - r.qe : r.qs, clip1 = r.rev ? r.qs : qlen - r.qe;
+	const bool hard = ((sam_flag & 0x800) || ((sam_flag & 0x100) && (flag & F_SECONDARY_SEQ))) && !(flag & F_SOFTCLIP);
+	if (in_tag) {
+		const uint32_t op = hard ? 5 : 4;
+		o.str("\tCG:B:I");
+		if (clip0) o.ch(','), o.num(clip0 << 4 | op);
+		for (uint32_t k = 0; k < r.p->n_cigar; ++k) o.ch(','), o.num(r.p->cigar[k]);
+		if (clip1) o.ch(','), o.num(clip1 << 4 | op);
+	} else {
+		const char c = hard ? 'H' : 'S';
+		if (clip0) o.num(clip0), o.ch(c);
+		for (uint32_t k = 0; k < r.p->n_cigar; ++k) o.num(r.p->cigar[k] >> 4), o.ch(kCigarOps[r.p->cigar[k] & 0xf]);
+		if (clip1) o.num(clip1), o.ch(c);
+	}
+}
+
+// mm_write_sam3 for a single-segment read: reg_idx < 0 writes the unmapped record
+void put_sam(Text &o, const FlatIndex &fi, const Bseq1 &t, int reg_idx, int n_regs, const Reg1 *regs, int64_t flag, int rep_len, Seqs &sq)
+{
+	const Reg1 *r = n_regs > 0 && reg_idx >= 0 && reg_idx < n_regs ? &regs[reg_idx] : nullptr;
+	o.str(t.name);
+	int sf = 0;
+	if (!r) sf |= 0x4;
+	else {
+		if (r->rev) sf |= 0x10;
+		if (r->parent != r->id) sf |= 0x100;
+		else if (!r->sam_pri) sf |= 0x800;
+	}
+	o.ch('\t'), o.num(sf);
+	bool cigar_in_tag = false;
+	if (!r) o.str("\t*\t0\t0\t*");
+	else {
+		o.ch('\t'), o.str(fi.names[r->rid].c_str()), o.ch('\t'), o.num(r->rs + 1), o.ch('\t'), o.num(r->mapq), o.ch('\t');
+		if ((flag & F_LONG_CIGAR) && r->p && r->p->n_cigar > 65535 - 2) {
+			int n_cigar = (int)r->p->n_cigar;
+			if (r->qs != 0) ++n_cigar;
+			if (r->qe != t.l_seq) ++n_cigar;
+			cigar_in_tag = n_cigar > 65535;
+		}
+		if (cigar_in_tag) {
+			int slen;
+			if ((sf & 0x900) == 0 || (flag & F_SOFTCLIP)) slen = t.l_seq;
+			else if ((sf & 0x100) && !(flag & F_SECONDARY_SEQ)) slen = 0;
+			else slen = r->qe - r->qs;
+			o.num(slen), o.ch('S'), o.num(r->re - r->rs), o.ch('N');
+		} else put_sam_cigar(o, sf, false, t.l_seq, *r, flag);
+	}
+	o.str("\t*\t0\t0\t"); // no mate
+	if (!r) {
+		put_seq(o, t.seq, t.l_seq, false, false), o.ch('\t');
+		if (t.qual) put_seq(o, t.qual, t.l_seq, false, false); else o.ch('*');
+	} else if ((sf & 0x900) == 0 || (flag & F_SOFTCLIP)) {
+		put_seq(o, t.seq, t.l_seq, r->rev, r->rev), o.ch('\t');
+		if (t.qual) put_seq(o, t.qual, t.l_seq, r->rev, false); else o.ch('*');
+	} else if ((sf & 0x100) && !(flag & F_SECONDARY_SEQ)) o.str("*\t*");
+	else {
+		put_seq(o, t.seq + r->qs, r->qe - r->qs, r->rev, r->rev), o.ch('\t');
+		if (t.qual) put_seq(o, t.qual + r->qs, r->qe - r->qs, r->rev, false); else o.ch('*');
+	}
+	if (r) {
+		put_tags(o, *r);
+		if (r->parent == r->id && r->p && n_regs > 1) { // supplementary alignments of the same read (format.c:638-664)
+			int n_sa = 0;
+			for (int i = 0; i < n_regs; ++i) if (i != reg_idx && regs[i].parent == regs[i].id && regs[i].p) ++n_sa;
+			if (n_sa > 0) {
+				o.str("\tSA:Z:");
+				for (int i = 0; i < n_regs; ++i) {
+					const Reg1 &q = regs[i];
+					if (i == reg_idx || q.parent != q.id || !q.p) continue;
+					int l_M, l_I = 0, l_D = 0;
+					if (q.qe - q.qs < q.re - q.rs) l_M = q.qe - q.qs, l_D = (q.re - q.rs) - l_M;
+					else l_M = q.re - q.rs, l_I = (q.qe - q.qs) - l_M;
+					const int clip5 = q.rev ? t.l_seq - q.qe : q.qs, clip3 = q.rev ? q.qs : t.l_seq - q.qe;
+					o.str(fi.names[q.rid].c_str()), o.ch(','), o.num(q.rs + 1), o.ch(','), o.ch("+-"[q.rev]), o.ch(',');
+					if (clip5) o.num(clip5), o.ch('S');
+					if (l_M) o.num(l_M), o.ch('M');
+					if (l_I) o.num(l_I), o.ch('I');
+					if (l_D) o.num(l_D), o.ch('D');
+					if (clip3) o.num(clip3), o.ch('S');
+					o.ch(','), o.num(q.mapq), o.ch(','), o.num(q.blen - q.mlen + (int)q.p->n_ambi), o.ch(';');
+				}
+			}
+		}
+		if (r->p && (flag & (F_OUT_CS | F_OUT_DS | F_OUT_MD))) put_cs_or_md(o, fi, t, *r, flag, sq);
+		if (cigar_in_tag) put_sam_cigar(o, sf, true, t.l_seq, *r, flag);
+	}
+	if (rep_len >= 0) o.tag("rl:i:", rep_len);
+	if ((flag & F_COPY_COMMENT) && t.comment) o.ch('\t'), o.str(t.comment);
+}
+
+} // namespace
+
+std::string format_check(const MapOpt &opt)
+{
+	if (opt.flag & F_OUT_JUNC) return "--write-junc output is not implemented";
+	if (opt.flag & F_QSTRAND) return "--qstrand output is not implemented";
+	if (opt.split_prefix) return "split-index output is not implemented";
+	return "";
+}
+
+// the records of reads [lo, hi), in order (the per-read rules of map.c:603-622)
+static void format_range(const FlatIndex &fi, const MapOpt &opt, const Bseq1 *seq, const int *n_reg, void *const *reg, const int *rep_len, long lo, long hi, Text &o)
+{
+	Seqs sq;
+	const int64_t flag = opt.flag;
+	for (long i = lo; i < hi; ++i) {
+		const Bseq1 &t = seq[i];
+		const Reg1 *regs = (const Reg1 *)reg[i];
+		const int rl = rep_len ? rep_len[i] : -1;
+		if (n_reg[i] > 0) {
+			for (int j = 0; j < n_reg[i]; ++j) {
+				if ((flag & F_NO_PRINT_2ND) && regs[j].id != regs[j].parent) continue;
+				if (flag & F_OUT_SAM) put_sam(o, fi, t, j, n_reg[i], regs, flag, rl, sq);
+				else put_paf(o, fi, t, &regs[j], flag, rl, sq);
+				o.ch('\n');
+			}
+		} else if ((flag & F_PAF_NO_HIT) || ((flag & F_OUT_SAM) && !(flag & F_SAM_HIT_ONLY))) {
+			if (flag & F_OUT_SAM) put_sam(o, fi, t, -1, 0, nullptr, flag, rl, sq);
+			else put_paf(o, fi, t, nullptr, flag, rl, sq);
+			o.ch('\n');
+		}
+	}
+}
+
+char *format_batch(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n, const Bseq1 *seq, const int *n_reg, void *const *reg, const int *rep_len, size_t *out_len)
+{
+	const long chunk = 64, n_chunks = (n + chunk - 1) / chunk;
+	std::vector<Text> parts(n_chunks);
+	parallel_for(n_threads, n_chunks, [&](long c, int) {
+		const long lo = c * chunk, hi = std::min(n, lo + chunk);
+		format_range(fi, opt, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
+	}, 1);
+	std::vector<size_t> off(n_chunks + 1, 0);
+	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].s.size();
+	char *out = (char *)malloc(off[n_chunks] + 1);
+	if (!out) return nullptr;
+	parallel_for(n_threads, n_chunks, [&](long c, int) { memcpy(out + off[c], parts[c].s.data(), parts[c].s.size()); }, 8);
+	out[off[n_chunks]] = 0;
+	*out_len = off[n_chunks];
+	return out;
+}
+
+} // namespace mm2amd

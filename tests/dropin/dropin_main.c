@@ -22,7 +22,7 @@ int main(int argc, char *argv[])
 	mm_idxopt_t iopt;
 	mm_mapopt_t mopt;
 	const char *preset = 0;
-	int n_threads = 3, i, k = 1, print_stats = 0;
+	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0;
 	int64_t batch = 500000000;
 	kstring_t str = {0, 0, 0};
 
@@ -57,6 +57,16 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--cs") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_CIGAR;
 		else if (strcmp(argv[k], "--MD") == 0) mopt.flag |= MM_F_OUT_MD;
 		else if (strcmp(argv[k], "--eqx") == 0) mopt.flag |= MM_F_EQX;
+		else if (strcmp(argv[k], "--ds") == 0) mopt.flag |= MM_F_OUT_DS | MM_F_CIGAR;
+		else if (strcmp(argv[k], "--cs=long") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_OUT_CS_LONG | MM_F_CIGAR;
+		else if (strcmp(argv[k], "-Y") == 0) mopt.flag |= MM_F_SOFTCLIP;
+		else if (strcmp(argv[k], "-L") == 0) mopt.flag |= MM_F_LONG_CIGAR;
+		else if (strcmp(argv[k], "-y") == 0) mopt.flag |= MM_F_COPY_COMMENT;
+		else if (strcmp(argv[k], "--secondary=no") == 0) mopt.flag |= MM_F_NO_PRINT_2ND;
+		else if (strcmp(argv[k], "--secondary-seq") == 0) mopt.flag |= MM_F_SECONDARY_SEQ;
+		else if (strcmp(argv[k], "--paf-no-hit") == 0) mopt.flag |= MM_F_PAF_NO_HIT;
+		else if (strcmp(argv[k], "--sam-hit-only") == 0) mopt.flag |= MM_F_SAM_HIT_ONLY;
+		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
 	if (argc - k < 2) { fprintf(stderr, "usage: dropin [options] ref reads\n"); return 1; }
@@ -73,7 +83,7 @@ int main(int argc, char *argv[])
 		if (fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
 		int with_qual = (!!(mopt.flag & MM_F_OUT_SAM) && !(mopt.flag & MM_F_NO_QUAL)), n_seq;
 		mm_bseq1_t *seq;
-		while ((seq = mm_bseq_read3(fp, batch, with_qual, 0, 0, &n_seq)) != 0) {
+		while ((seq = mm_bseq_read3(fp, batch, with_qual, !!(mopt.flag & MM_F_COPY_COMMENT), 0, &n_seq)) != 0) {
 			int *n_reg = (int*)calloc(5 * (size_t)n_seq, sizeof(int));
 			int *seg_off = n_reg + n_seq, *n_seg = seg_off + n_seq, *rep_len = n_seg + n_seq, *frag_gap = rep_len + n_seq;
 			mm_reg1_t **reg = (mm_reg1_t**)calloc(n_seq, sizeof(mm_reg1_t*));
@@ -90,9 +100,20 @@ int main(int argc, char *argv[])
 				for (i = 0; i < nv; ++i) fprintf(stderr, " %.4g", v[i]);
 				fputc('\n', stderr);
 			}
+			if (format_lib) {
+				char *text = 0;
+				size_t text_len = 0;
+				if (mm_gpu_format_batch(n_seq, seg_off, n_seg, seq, n_reg, (void *const*)reg, rep_len, &text, &text_len) != 0) {
+					fprintf(stderr, "mm_gpu_format_batch: %s\n", mm2amd_last_error());
+					return 2;
+				}
+				fwrite(text, 1, text_len, stdout);
+				free(text);
+			}
 			for (i = 0; i < n_seq; ++i) { /* output, as step 2 of worker_pipeline (map.c:585-636) for single-segment reads */
 				mm_bseq1_t *t = &seq[i];
-				if (n_reg[i] > 0) {
+				if (format_lib) {
+				} else if (n_reg[i] > 0) {
 					for (j = 0; j < n_reg[i]; ++j) {
 						const mm_reg1_t *r = &reg[i][j];
 						if ((mopt.flag & MM_F_NO_PRINT_2ND) && r->id != r->parent) continue;

@@ -80,3 +80,12 @@ def test_hpc_index_sam_identical(tmp_path):
     # -x map-pb: homopolymer-compressed minimizers (sketch.c:95-101), index built by the reference and adopted by mm_gpu_init
     _compare(tmp_path, "hifi", "map-pb", 3, 60, 20, ["-a"])
     _compare(tmp_path, "ont", "map-pb", 3, 60, 21, ["-c"])
+
+
+def test_output_stage_on_gpu_results(tmp_path):
+    # the records written by mm_gpu_format_batch from the GPU path's hits == the reference binary's output
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 4, 200, 23)
+    for extra in (["-a"], ["-c", "--cs"]):
+        want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, reads])
+        got, _ = _run([DROPIN, "--format-lib", "-x", "map-ont", "-t", "8"] + extra + [ref, reads])
+        assert want == got

@@ -103,3 +103,41 @@ def test_splice(tmp_path, args):
     ref, reads, _, _ = synth.make("cdna", str(tmp_path), 2.0, 150, 106)
     out = _pair(args, ref, reads)
     assert any(b"N" in l.split(b"\t")[5] for l in out.split(b"\n") if l and not l.startswith(b"@") and b"\t" in l) or "-c" in args
+
+
+FORMAT_CASES = [("ont", ["-x", "map-ont", "-a"]), ("ont", ["-x", "map-ont", "-c", "--cs"]), ("ont", ["-x", "map-ont", "-a", "--MD", "-Y"]),
+                ("ont", ["-x", "map-ont", "-c", "--ds"]), ("ont", ["-x", "map-ont", "-a", "--cs=long", "--eqx"]), ("cdna", ["-x", "splice", "-a", "--cs"]),
+                ("cdna", ["-x", "splice", "-c", "--MD", "--secondary=no"]), ("hifi", ["-x", "map-hifi", "-a", "--secondary-seq", "-L"]),
+                ("hifi", ["-x", "map-hifi", "--paf-no-hit", "-c"]), ("fastq", ["-x", "map-ont", "-a", "-y"]), ("fastq", ["-x", "map-ont", "-c", "-y", "--cs"])]
+
+
+@pytest.mark.parametrize("kind,args", FORMAT_CASES)
+def test_output_stage(tmp_path, kind, args):
+    """mm_gpu_format_batch (the parallel host output stage) against the reference's own writers: SAM and PAF,
+    cg/cs/ds/MD/ts/SA tags, clipping modes, comments and qualities, unmapped records"""
+    import numpy as np
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    if kind == "fastq":  # qualities, comments, chimeric reads (supplementary records with SA tags), a read that maps nowhere
+        rng = np.random.default_rng(3)
+        contigs = synth.gen_reference(rng, 1500000, 2)
+        reads = synth.gen_reads(rng, contigs, 20, 4000, 500, 0.08)
+        for i in range(8):
+            a, b = contigs[0][10000 * i + 5000:10000 * i + 8000], synth.COMP[contigs[1][20000 * i + 100:20000 * i + 2600][::-1]]
+            reads.append(synth.mutate_read(rng, np.concatenate([a, b]), 0.05))
+        reads.append(rng.integers(0, 4, 3000, dtype=np.uint8))
+        ref, rd = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+        synth.write_fasta(ref, ["c1", "c2"], contigs)
+        with open(rd, "wb") as f:
+            for i, s in enumerate(reads):
+                f.write(b"@r%d comment %d\n" % (i, i) + synth.ACGT[s].tobytes() + b"\n+\n" + bytes(rng.integers(35, 74, len(s), dtype=np.uint8)) + b"\n")
+    else:
+        ref, rd, _, _ = synth.make(kind, str(tmp_path), 1.5, 40, 108)
+    outs = []
+    for cmd in ([G.REF_BIN] + args, [CHECK, "--format-lib"] + args):
+        p = subprocess.run(cmd + ["-t", "4", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        outs.append(G.strip_pg(p.stdout))
+    assert outs[0] == outs[1]
+    assert len(outs[0]) > 1000
