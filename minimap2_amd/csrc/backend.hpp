@@ -31,6 +31,8 @@ public:
 	// up to n_threads pool threads.
 	virtual void seed_chain(const SeedChainParams &p, long lo, long hi, int lane, int n_threads, std::vector<ReadChains> &out) = 0;
 	virtual int n_lanes() const { return 1; }
+	// how many lanes the caller is about to drive concurrently (<= n_lanes()): shared budgets are split among these only
+	virtual void set_active_lanes(int /*n*/) {}
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off

@@ -4,6 +4,7 @@
 // A batch's sequences are made resident once (begin_batch).  The mapper then runs sub-batches of reads through
 // seed_chain()/ksw() on independent LANES: each lane owns a HIP stream and its device/pinned work buffers, so several host
 // driver threads can keep different sub-batches in flight and the GPU stages of one overlap the host stages of another.
+#include <atomic>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -74,6 +75,7 @@ public:
 	}
 
 	int n_lanes() const override { return n_lanes_; }
+	void set_active_lanes(int n) override { active_lanes_ = std::max(1, std::min(n, n_lanes_)); }
 	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
 
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
@@ -205,7 +207,7 @@ public:
 		// matrices of tens of MB each, and 288 GB of HBM is what lets thousands of them be in flight
 		size_t dir_gb = 160;
 		if (const char *e = getenv("MM2AMD_DIR_BUDGET_GB")) dir_gb = atol(e) > 0 ? (size_t)atol(e) : dir_gb;
-		ln.ksw.dir_budget = (dir_gb << 30) / (size_t)n_lanes_;
+		ln.ksw.dir_budget = std::min<size_t>((dir_gb << 30) / (size_t)active_lanes_, (size_t)96 << 30); // scratch only grows: keep one lane's share bounded
 		ln.ksw.lane = lane_id;
 		ln.ksw.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id).collect();
@@ -214,6 +216,7 @@ public:
 private:
 	hipStream_t stream_ = nullptr;
 	int n_threads_ = 1, n_cu_ = 256, n_lanes_ = 1, rid_bits_ = 1;
+	std::atomic<int> active_lanes_{1};
 	DevIndex I_{};
 	DeviceIndexTables own_;
 	DeviceIndexTables *T_ = nullptr;

@@ -18,14 +18,14 @@ namespace {
 // direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
 constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice = kFirstExact + kRingClasses * kDirClasses;
 // kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip): two jobs per wave with 2 or 4 register sets of
-// 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves with 4, 8 or 16 sets (up to
-// 512 / 1024 / 2048); classed by direction-matrix size like the exact kernel.
-constexpr int kSpliceClasses = 5, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
-const int kSpliceSets[kSpliceClasses] = { 2, 4, 4, 8, 16 };
-const bool kSpliceSelf[kSpliceClasses] = { false, false, true, true, true };
-const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 512, 1024, 2048 };
-const int kSpliceWaves[kSpliceClasses] = { 4, 4, 4, 4, 2 };       // waves per block (splice_wpb in ksw_splice.hip)
-const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 4, 2, 2 };
+// 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves of 4 sets (512 positions per
+// sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
+constexpr int kSpliceClasses = 3, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
+const int kSpliceSets[kSpliceClasses] = { 2, 4, 4 };
+const bool kSpliceSelf[kSpliceClasses] = { false, false, true };
+const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
+const int kSpliceWaves[kSpliceClasses] = { 4, 4, 4 };             // waves per block (splice_wpb in ksw_splice.hip)
+const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 4 };
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 const int kFastMaxT[kFirstExact] = { 128, 192, 256, 320, 384, 512 };
 const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
@@ -45,13 +45,13 @@ inline bool fast_eligible(const KswJob &j, bool scoring_ok)
 	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
 }
 // The splice gap fill (align.c:840 with -x splice) may take the register-resident splice kernel: global alignment with the
-// approximate score, default substitution scores, forward CIGAR, no junction scores, at most 2048 query bases; the scoring must
+// approximate score, default substitution scores, forward CIGAR, no junction scores; the scoring must
 // keep every intermediate of a valid cell inside 8 bits (what the reference's int8 lanes assume).
 inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
 {
 	constexpr int kSpliceBits = KSW_SPLICE_FOR | KSW_SPLICE_REV | KSW_SPLICE_FLANK | KSW_SPLICE_CMPLX;
 	if (!scoring_ok || ((j.flag & 0x1fff) & ~kSpliceBits) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
-	return j.qlen > 0 && j.tlen > 0 && j.qlen <= 2048;
+	return j.qlen > 0 && j.tlen > 0;
 }
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
@@ -236,7 +236,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
-			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,self>", "ksw_splice_kernel<8,self>", "ksw_splice_kernel<16,self>" };
+			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			if (prof) prof->end(stream, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
 		}
 		uint32_t cursor[2];

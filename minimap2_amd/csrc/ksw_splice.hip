@@ -14,9 +14,10 @@
 //   * the target streams through: every 64 rows the wave admits the next 64 target positions into an LDS ring, each entry
 //     holding the base and the donor / acceptor cost of its position (ksw2_exts2_sse.c:120-194) ready for packed use.
 //   * two jobs per wavefront in the halves of packed 16-bit registers, as in ksw_fast.hip (the launch is ordered by row count);
-//     or, for queries longer than 512 (SELF): ONE job whose query positions j and j + 64*NC share a register -- the high
+//     or, for queries longer than 256 (SELF): ONE job whose query positions j and j + 64*NC share a register -- the high
 //     half is then a continuation of the low half (its left neighbour at lane 0 is the low half's last lane, its target
-//     position lags 64*NC behind), which doubles the query length a register set covers without pairing unequal jobs.
+//     position lags 64*NC behind).  Queries beyond those 128*NC positions are cut into strips that sweep the target one
+//     after the other, the (u, y) column between two strips going through HBM; register use stays at 4 waves per SIMD.
 //   * the 1 B/cell direction matrix is the only HBM traffic (row-major by query position: 64 B coalesced per register set);
 //     the traceback is done by the whole wave: lane k looks k cells ahead along the current run (match diagonal, gap, intron)
 //     and one ballot tells how long the run lasts, so an intron of 50 000 bases costs 800 loads in sequence, not 50 000.
@@ -122,25 +123,36 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 			}
 			return c0;
 		};
+		// Corner score H(tlen-1, qlen-1) of each job, summed along the matrix border (path-independent; see ksw_fast.hip): u of the
+		// first query row's cells while the anti-diagonal still starts a new target column, then v down the last column.
+		int H0A = -qe, H0B = -qe;
+		// SELF: a query longer than the 2*QOFF positions the registers hold is processed in STRIPS of that many positions, one full
+		// sweep over the target per strip.  What a strip's first query position reads from its left neighbour -- (u, y) of the
+		// previous strip's last position, one pair per target position -- is handed over through a per-slot array in HBM (the
+		// slot's CIGAR scratch, free until the traceback), written and read 64 positions at a time.
+		constexpr int STRIP = 2 * QOFF;
+		const int qlen_all = qlenA, n_pass = SELF ? (qlen_all + STRIP - 1) / STRIP : 1;
+		uint32_t *handover = L.cigar_tmp + (size_t)(SELF ? slot : 2 * slot) * L.cigar_tmp_cap;
+		for (int pass = 0; pass < n_pass; ++pass) {
+		const int QB = pass * STRIP;                                             // first query position of this strip
+		const int qlenA = SELF ? (qlen_all - QB < STRIP ? qlen_all - QB : STRIP) : qlen_all; // shadows the job's query length inside the strip
+		const bool hand_on = SELF && pass + 1 < n_pass;
 		// ---- operands: one packed query base pair per (register set, lane); the states start at the values of :108-109 ----
 		uint32_t Q[NC], U[NC], V[NC], X[NC], Y[NC], X2[NC];
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
 			const int j = c * 64 + lane;
 			uint32_t bA = 4, bB = 4;
-			if (j < qlenA) bA = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)j : JA.q_off + (uint64_t)j];
-			if (SELF) { if (j + QOFF < qlenA) bB = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)(j + QOFF) : JA.q_off + (uint64_t)(j + QOFF)]; }
+			if (j < qlenA) bA = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)(QB + j) : JA.q_off + (uint64_t)(QB + j)];
+			if (SELF) { if (j + QOFF < qlenA) bB = L.qpool[(JA.flag & KSWJ_Q_REVERSED) ? JA.q_off - (uint64_t)(QB + j + QOFF) : JA.q_off + (uint64_t)(QB + j + QOFF)]; }
 			else if (j < qlenB) bB = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)j : JB.q_off + (uint64_t)j];
 			Q[c] = bA | bB << 16;
 			U[c] = V[c] = X[c] = Y[c] = P_NQE, X2[c] = P_NQ2;
 		}
 		int frontier = -1; // target positions <= frontier are in the ring
-
-		// Corner score H(tlen-1, qlen-1) of each job, summed along the matrix border (path-independent; see ksw_fast.hip): u of the
-		// first query row's cells while the anti-diagonal still starts a new target column, then v down the last column.
-		int H0A = -qe, H0B = -qe;
+		uint32_t hand_in = 0, hand_out = 0;
 		const int n_rowsA = qlenA + tlenA - 1, n_rowsB = hasB ? qlenB + tlenB - 1 : 0, n_rows = n_rowsA > n_rowsB ? n_rowsA : n_rowsB;
-		for (int r = 0; r < n_rows; ++r) {
+		for (int r = 0; r < n_rows; ++r) { // r: anti-diagonal within the strip; the matrix's anti-diagonal is r + QB
 			if (r > frontier) { // admit the next 64 target positions (wave-uniform)
 				const int t = frontier + 1 + lane;
 				int dnA, acA, dnB = 0, acB = 0;
@@ -150,6 +162,7 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 				frontier += 64;
 				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 				__builtin_amdgcn_wave_barrier();
+				if (SELF && pass > 0) hand_in = t < tlenA ? handover[t] : 0u; // (u | y << 16) left of this strip, for target positions r..r+63
 			}
 			// query positions with a valid cell on this anti-diagonal, per job: j in [max(0, r-tlen+1), min(qlen-1, r)]
 			int jloA = r - tlenA + 1 > 0 ? r - tlenA + 1 : 0, jhiA = r < qlenA - 1 ? r : qlenA - 1;
@@ -161,7 +174,8 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 			int lo = jloA <= jhiA ? (jloB <= jhiB && jloB < jloA ? jloB : jloA) : jloB, hi = jhiA > jhiB ? jhiA : jhiB;
 			if (SELF) lo = 0, hi = jhiA < QOFF ? jhiA : QOFF - 1; // register sets 0..: the low halves' range covers the high halves' (both start at their lane 0 region)
 			// v[-1] / u[r] on the matrix border (ksw2_exts2_sse.c:234-247): depends on r only
-			const int bnd = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : 0;
+			const int rg = r + QB;
+			const int bnd = rg == 0 ? -qe : rg < long_thres ? -e : rg == long_thres ? long_diff : 0;
 			const uint32_t P_BND = pk2(bnd);
 			// query position r starts its column on this row (t = 0): x, v, x2 of "t = -1" are border values
 			const bool newA = r < qlenA && r < n_rowsA, newB = r < qlenB && r < n_rowsB;
@@ -171,9 +185,11 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 			// SELF: the high halves continue the low halves -- query position QOFF's left neighbour is the last lane of the last set
 			uint32_t selfU = 0, selfY = 0;
 			if (SELF) selfU = (uint32_t)__builtin_amdgcn_readlane(U[NC - 1], 63) << 16, selfY = (uint32_t)__builtin_amdgcn_readlane(Y[NC - 1], 63) << 16;
-			const bool topA = r < tlenA && r < n_rowsA, topB = r < tlenB && r < n_rowsB; // query position 0 still has a cell (t = r)
+			const bool topA = pass == 0 && r < tlenA && r < n_rowsA, topB = r < tlenB && r < n_rowsB; // query position 0 still has a cell (t = r)
 			const int lastA = r - tlenA + 1, lastB = r - tlenB + 1;                    // query position on the last target column
-			uint8_t *prA = dirA + (size_t)r * qsA, *prB = dirB + (size_t)r * qsB;
+			uint8_t *prA = dirA + (size_t)rg * qsA + QB, *prB = dirB + (size_t)rg * qsB + QB;
+			uint32_t leftU = P_BND & 0xffffu, leftY = P_NQE & 0xffffu; // SELF: what query position QB - 1 hands to position QB
+			if (SELF && pass > 0) { const uint32_t h = (uint32_t)__builtin_amdgcn_readlane(hand_in, r & 63); leftU = h & 0xffffu, leftY = h >> 16; }
 			// register sets from the highest down, so that set c still sees row r-1 in set c-1 when it fetches its carry-ins
 #pragma unroll
 			for (int c = NC - 1; c >= 0; --c) {
@@ -182,7 +198,7 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 				const bool actA = (uint32_t)(j - jloA) < wA, actB = (uint32_t)(j - jloB) < wB;
 				uint32_t cU = P_BND, cY = P_NQE; // query position -1: the matrix border (u[r], y[r], :241-247)
 				if (c > 0) cU = __builtin_amdgcn_readlane(U[c - 1], 63), cY = __builtin_amdgcn_readlane(Y[c - 1], 63);
-				else if (SELF) cU = (P_BND & 0xffffu) | selfU, cY = (P_NQE & 0xffffu) | selfY;
+				else if (SELF) cU = leftU | selfU, cY = leftY | selfY;
 				const uint32_t up = dpp_shr1u(cU, U[c]), yp = dpp_shr1u(cY, Y[c]);
 				if (edge_halves && edge_set == c) {
 					const uint32_t em = lane == edge_lane ? edge_halves : 0u;
@@ -233,7 +249,20 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 					else if (r < n_rowsB && (lastB >> 6) == c) H0B += (int16_t)(__builtin_amdgcn_readlane(V[c], lastB & 63) >> 16);
 				}
 			}
+			if (hand_on) { // (u, y) of the strip's last query position (high half of the last lane) at target position r - (STRIP - 1)
+				const int th = r - (STRIP - 1);
+				if (th >= 0) {
+					const uint32_t h = ((uint32_t)__builtin_amdgcn_readlane(U[NC - 1], 63) >> 16) | ((uint32_t)__builtin_amdgcn_readlane(Y[NC - 1], 63) & 0xffff0000u);
+					if (lane == (th & 63)) hand_out = h;
+					if ((th & 63) == 63 || r == n_rows - 1) { // in place: these positions were consumed STRIP - 1 rows ago
+						const int tw = (th & ~63) + lane;
+						if (tw <= th) handover[tw] = hand_out;
+					}
+				}
+			}
 		}
+		if (hand_on) __threadfence_block(); // the next strip reads what other lanes of this wave wrote
+		} // strips
 		// ---- tracebacks from (tlen-1, qlen-1) (ksw2_exts2_sse.c:459-461; every cell on the way is inside the matrix), one job
 		//      after the other, by the whole wave: a run is followed 64 cells at a time ----
 		__threadfence_block();
@@ -309,8 +338,6 @@ void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, v
 	if (!self && n_sets == 2) launch_splice<2, false>(L, n_slots, s);
 	else if (!self && n_sets == 4) launch_splice<4, false>(L, n_slots, s);
 	else if (self && n_sets == 4) launch_splice<4, true>(L, n_slots, s);
-	else if (self && n_sets == 8) launch_splice<8, true>(L, n_slots, s);
-	else if (self && n_sets == 16) launch_splice<16, true>(L, n_slots, s);
 	else throw std::runtime_error("[mm2amd] ksw_splice_launch: unsupported register-set count");
 	HIP_CHECK(hipGetLastError());
 }

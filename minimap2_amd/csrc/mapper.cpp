@@ -109,6 +109,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	}
 	const int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), subs.size());
 	while ((int)scratch_.size() < n_drivers) scratch_.emplace_back(new DriverScratch);
+	be_.set_active_lanes(n_drivers);
 	std::atomic<size_t> next_sub(0);
 	std::mutex stats_mu;
 	std::exception_ptr first_err;

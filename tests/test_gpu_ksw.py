@@ -231,7 +231,7 @@ def test_state_window_wraps_with_overshoot_past_the_arrays():
 @pytest.mark.parametrize("sc", [(1, 2, 2, 1, 32, 9), (1, 4, 6, 1, 24, 5)])
 def test_splice_gap_fill_kernel(sc, monkeypatch):
     """the register-resident splice kernel (ksw_splice.hip: gap-fill calls, flag APPROX_MAX) against the oracle: paired jobs of
-    different shapes, queries from 1 to 2049 bases (every kernel variant, and the exact kernel beyond 2048), introns up to 30 kb, both strands / splice models /
+    different shapes, queries from 1 to 2049 bases (the paired variants, the one-job variant and its multi-strip sweeps), introns up to 30 kb, both strands / splice models /
     no strand, target shorter than the query; and the same jobs through the lane-exact kernel (MM2AMD_KSW_EXACT_ONLY)"""
     import minimap2_amd as mm
     from reflib import ora_exts2
@@ -251,7 +251,7 @@ def test_splice_gap_fill_kernel(sc, monkeypatch):
         for tl in (1, 5, 64, 200, 1000):
             t = rng.integers(0, 4, tl, dtype=np.uint8)
             jobs.append((q, t, -1, 200, -1, 0x08 | 0x100 | 0x400 | 0x800))
-    for ql in (257, 300, 511, 513, 700, 1023, 1024, 1025, 1500, 2047, 2048, 2049):  # one job per wave, both register halves
+    for ql in (257, 300, 511, 512, 513, 700, 1023, 1024, 1025, 1500, 2047, 2048, 2049):  # one job per wave, both register halves, 1..5 strips
         n_exon = 3
         q, t = spliced_pair(rng, n_exon, 0.04, exon=(ql // n_exon + 2, ql // n_exon + 3), intron=(100, 2500))
         q = q[:ql] if len(q) >= ql else np.concatenate([q, rng.integers(0, 4, ql - len(q), dtype=np.uint8)])
