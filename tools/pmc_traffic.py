@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name):
     n = name.split("(")[0].replace("void ", "").replace("mm2amd::", "")
-    return n.split("<")[0] if n.startswith("ksw_fast_kernel") else n
+    return n.split("<")[0] if n.startswith(("ksw_fast_kernel", "ksw_splice_kernel", "ksw_extd2_kernel")) else n
 
 
 def collect(counter, args):
@@ -30,7 +30,7 @@ def collect(counter, args):
     subprocess.run(["rm", "-rf", out])
     env = dict(os.environ, MM2AMD_LANES="1", TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-           "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--reads", str(args.reads), "--ref-mb", str(args.ref_mb)]
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--reads", str(args.reads), "--ref-mb", str(args.ref_mb), "--preset", args.preset]
     subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
     db = sqlite3.connect(glob.glob(os.path.join(out, "*.db"))[0])
     cols = [c[1] for c in db.execute("pragma table_info('counters_collection')")]
@@ -53,17 +53,21 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--ref-mb", type=float, default=3000)
+    ap.add_argument("--preset", default="map-ont", help="map-ont (default) or splice; results of a run are merged into the existing JSON")
     a = ap.parse_args()
     fetch = collect("FETCH_SIZE", a)
     write = collect("WRITE_SIZE", a)
-    out = {}
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    out = json.load(open(path)) if os.path.exists(path) and a.preset != "map-ont" else {}
     for f in sorted(set(fetch) | set(write)):
         if not any(f.startswith(p) for p in ("ksw_", "chain_", "seed_", "sketch", "anchor_", "encode")):
             continue
+        if a.preset != "map-ont" and not f.startswith("ksw_splice"):
+            continue  # a splice run only contributes the kernel that the map-ont run does not exercise
         fb, fl = fetch.get(f, [0.0, 0])
         wb, wl = write.get(f, [0.0, 0])
         n = max(fl, wl, 1)
         out[f] = {"fetch_bytes_per_launch": fb * 1024 / n, "fetch_bytes_x2": 2 * fb * 1024 / n, "write_bytes_per_launch": wb * 1024 / n, "launches": n,
-                  "note": "per launch at %d reads vs %d Mb; FETCH_SIZE/WRITE_SIZE in KiB -> bytes; x2 = gfx950 wide-read correction; WRITE_SIZE uncalibrated" % (a.reads, a.ref_mb)}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+                  "note": "%s: per launch at %d reads vs %d Mb; FETCH_SIZE/WRITE_SIZE in KiB -> bytes; x2 = gfx950 wide-read correction; WRITE_SIZE uncalibrated" % (a.preset, a.reads, a.ref_mb)}
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
