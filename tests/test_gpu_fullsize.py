@@ -21,6 +21,9 @@ import reflib  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+SPLICE = {}  # filled by the fixture: the same reference serves the spliced-alignment test
+
+
 @pytest.fixture(scope="module")
 def world():
     import torch
@@ -28,7 +31,17 @@ def world():
     import minimap2_amd as mm
     dev = torch.device("cuda", 0)
     n_contig, total = 24, 3000 * 1000 * 1000
-    codes, refs, per = bench.gen_reference(torch, dev, 11, total, n_contig)
+    codes, per = bench.gen_reference(torch, dev, 11, total, n_contig)
+    genes = bench.plant_genes(torch, dev, 12, codes, per, n_contig, 20000)  # splice signals for the cDNA test; harmless for map-ont
+    refs = bench.reference_ascii(torch, dev, codes, per, n_contig)
+    n_cdna = 3000
+    cdna = bench.gen_transcripts(torch, dev, 777, codes, genes, n_cdna, 0.05)
+    g3 = torch.Generator(device=dev)
+    g3.manual_seed(777)
+    pick = torch.randint(0, genes["ex_st"].shape[0], (n_cdna,), device=dev, generator=g3)  # the generator's first draw
+    span_lo = genes["ex_st"][pick][:, 0].cpu().tolist()
+    span_hi = (genes["ex_st"][pick] + genes["ex_len"][pick]).max(1).values.cpu().tolist()
+    SPLICE.update(refs=refs, per=per, reads=[("cdna%d" % i, s) for i, s in enumerate(cdna)], spans=list(zip(span_lo, span_hi)))
     # reads with known origin: same generator as bench.py, but we keep the placement
     g = torch.Generator(device=dev)
     g.manual_seed(4242)
@@ -110,3 +123,48 @@ def test_sample_parity_with_reference_and_payload_round_trip(world):
     again = shard.pack_hits(L, n2, r2).numpy().tobytes()
     L.mm2amd_free_regs(len(n2), n2, r2)
     assert again == want
+
+
+def test_splice_full_size_properties_and_sample_parity(world):
+    """BASELINE.json configs[4] at full reference size: cDNA reads of planted multi-exon genes (introns up to 50 kb) against the
+    3 Gb reference with -x splice.  Properties: every read maps inside its gene's span on the right contig, CIGARs consume
+    exactly the aligned query / reference stretches and contain introns; and hit records identical to the reference's mm_map
+    on a sample."""
+    import minimap2_amd as mm
+    from minimap2_amd import shard
+    _, _, _, names = world
+    al = mm.Aligner(SPLICE["refs"], preset="splice", names=names, n_threads=32, sam=True)
+    try:
+        reads, per = SPLICE["reads"], SPLICE["per"]
+        hits = al.map_batch(reads)
+        n_right = n_spliced = 0
+        for (nm, seq), h, (lo, hi) in zip(reads, hits, SPLICE["spans"]):
+            assert h, nm
+            p = h[0]
+            q_used = sum(x >> 4 for x in p.cigar if (x & 0xf) in (0, 1, 7, 8))
+            r_used = sum(x >> 4 for x in p.cigar if (x & 0xf) in (0, 2, 3, 7, 8))
+            assert q_used == p.q_en - p.q_st and r_used == p.r_en - p.r_st, nm
+            n_spliced += any((x & 0xf) == 3 for x in p.cigar)
+            g0 = p.rid * per + p.r_st
+            if lo - 50 <= g0 and p.rid * per + p.r_en <= hi + 50 and p.q_en - p.q_st > 0.7 * len(seq):
+                n_right += 1
+        assert n_right >= 0.97 * len(reads) and n_spliced >= 0.97 * len(reads)
+        if os.path.exists(reflib.REFDRV_SO):
+            L = mm.lib()
+            st = al.index_stat()
+            S, keys, val_off, pos = reflib.export_index(al)
+            drv = reflib.RefDriver(st["w"], st["k"], st["flag"], names, al.lens, S, keys, val_off, pos, 64)
+            del keys, val_off, pos
+            mo = drv.map_opt("splice", extra_flag=mm.F_OUT_SAM)
+            sample = reads[:800]
+            _, nr, rg = drv.map(mo, sample, 64)
+            want = shard.pack_hits(L, nr, rg).numpy().tobytes()
+            L.mm2amd_free_regs(len(nr), nr, rg)
+            drv.close()
+            al.stage(sample)
+            n_reg, reg, _ = al.run(raw=True)
+            got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
+            al.free_raw(n_reg, reg)
+            assert got == want
+    finally:
+        al.close()
