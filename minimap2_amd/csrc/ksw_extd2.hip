@@ -90,21 +90,39 @@ __device__ __forceinline__ void cig_push(CigOut &g, uint32_t op, int len)
 	} else g.last += (uint32_t)len << 4;
 }
 
-// Traceback by one lane over the direction matrix in HBM (ksw2.h:130-162, is_rot=1).  min_intron_len > 0 (splice mode): state
-// 3 is an intron and becomes an N operation.  off[r]/off_end[r] of the reference are st/en of row r, recomputed here.
-__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, int i0, int j0, int min_intron_len, CigOut &g)
+// Traceback over the direction matrix in HBM by the whole wave (ksw2.h:130-162, is_rot=1): lane k looks k cells ahead along the
+// run of the current state (match diagonal, or one of the gap states) and a ballot tells how far the run goes, so a run costs one
+// round of loads however long it is.  The cell that ends a run is handled exactly as the reference handles every cell, including
+// the forced moves outside the band.  min_intron_len > 0 (splice mode): state 3 is an intron and becomes an N operation.
+// off[r]/off_end[r] of the reference are st/en of row r, recomputed here.  All lanes keep identical copies of (i, j, state, g).
+__device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, int w, int i0, int j0, int min_intron_len, CigOut &g, int lane)
 {
 	int i = i0, j = j0, state = 0;
+	const uint32_t op3 = min_intron_len > 0 ? 3u : 2u;
 	while (i >= 0 && j >= 0) {
-		int r = i + j, force = -1, tmp;
-		RowIv iv = row_interval(r, qlen, tlen, w);
-		if (i < iv.st) force = 2;
-		if (i > iv.en) force = 1;
-		tmp = force < 0 ? dir[(size_t)r * ncol + (size_t)(i - iv.st)] : 0;
-		if (state == 0) state = tmp & 7;
-		else if (!(tmp >> (state + 2) & 1)) state = 0;
-		if (state == 0) state = tmp & 7;
-		if (force >= 0) state = force;
+		const int di = (state == 2 || state == 4) ? 0 : 1, dj = (state == 1 || state == 3) ? 0 : 1;
+		const int ii = i - lane * di, jj = j - lane * dj;
+		const bool valid = ii >= 0 && jj >= 0;
+		int force = -1, tmp = 0;
+		if (valid) {
+			const RowIv iv = row_interval(ii + jj, qlen, tlen, w);
+			if (ii < iv.st) force = 2;
+			if (ii > iv.en) force = 1;
+			if (force < 0) tmp = dir[(size_t)(ii + jj) * ncol + (size_t)(ii - iv.st)];
+		}
+		const bool cont = valid && force < 0 && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
+		const unsigned long long stop = ~__ballot(cont);
+		const int run = stop ? __builtin_ctzll(stop) : 64;
+		if (run > 0) {
+			cig_push(g, state == 0 ? 0u : state == 1 ? 2u : state == 3 ? op3 : 1u, run);
+			i -= run * di, j -= run * dj;
+			continue;
+		}
+		const int f0 = __builtin_amdgcn_readfirstlane(force), t0 = __builtin_amdgcn_readfirstlane(tmp); // the cell we stand on
+		if (state == 0) state = t0 & 7;
+		else if (!(t0 >> (state + 2) & 1)) state = 0;
+		if (state == 0) state = t0 & 7;
+		if (f0 >= 0) state = f0;
 		if (state == 0) cig_push(g, 0, 1), --i, --j;
 		else if (state == 1 || (state == 3 && min_intron_len <= 0)) cig_push(g, 2, 1), --i;
 		else if (state == 3) cig_push(g, 3, 1), --i;
@@ -483,12 +501,10 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				__threadfence_block(); // the direction bytes were written by all lanes of this wave
 				if (!ez.zdropped && (flag & KSW_EXTZ_ONLY) && ez.mqe + J.end_bonus > ez.max) ez.reach_end = 1;
 				const int min_intron = SPLICE ? long_thres : 0;
-				if (lane == 0) {
-					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, min_intron, g);
-					else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, min_intron, g);
-					else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, min_intron, g);
-					if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
-				}
+				if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, min_intron, g, lane);
+				else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, min_intron, g, lane);
+				else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, min_intron, g, lane);
+				if (lane == 0 && g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
 				// pack the CIGAR into the pool: forward order unless the caller asked for the traceback order (:153-155 of ksw2.h)
 				const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
 				cig_off = __builtin_amdgcn_readfirstlane(cig_off);
