@@ -92,7 +92,8 @@ def test_register_resident_gap_fill_kernel(preset):
     import minimap2_amd as mm
     rng = np.random.default_rng(77)
     jobs = []
-    for tl in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 383, 384, 385, 447, 448, 449, 511, 512):
+    for tl in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 383, 384, 385, 447, 448, 449, 511, 512, 513, 600, 639, 640,
+               641, 700, 767, 768, 769):
         for rep in range(3):
             t = rng.integers(0, 4, tl, dtype=np.uint8)
             if rep == 0:
@@ -104,9 +105,9 @@ def test_register_resident_gap_fill_kernel(preset):
                 q = rng.integers(0, 4, int(rng.integers(1, 1025)), dtype=np.uint8)  # unrelated, any aspect ratio
             jobs.append((q, t, 30001, int(rng.choice([-1, 200, 400])), int(rng.choice([-1, 10])), 0x08))
     for it in range(300):
-        q, t = random_pair(rng, int(rng.integers(1, 512)), float(rng.choice([0.0, 0.05, 0.12, 0.3, 0.6])), float(rng.choice([0, 0, 0.03])),
+        q, t = random_pair(rng, int(rng.integers(1, 768)), float(rng.choice([0.0, 0.05, 0.12, 0.3, 0.6])), float(rng.choice([0, 0, 0.03])),
                            int(rng.choice([0, 0, 0, 40, -40, 200, -200])))
-        if len(q) > 1024 or len(t) > 512:
+        if len(q) > 1024 or len(t) > 768:
             continue
         w = int(rng.choice([30001, len(q) + len(t), len(q) + len(t) + 5, -1]))
         jobs.append((q, t, w, 400, -1, 0x08))
