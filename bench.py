@@ -280,11 +280,14 @@ def main():
 
     value = all_bases * a.steps / total_t / 1e9
     # roofline of the dominant kernel: algorithmic bytes / HIP-event time on the launch stream
-    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
     roof = None
-    if dom:
-        fam = dom_name.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_fast_kernel<4>, <5>, ...) count together
-        same = {k: v for k, v in prof.items() if k.split("[")[0].split("<")[0] == fam}
+    if prof:
+        family = lambda k: k.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_fast_kernel<4>, <5>, ...) count together
+        fam_total = {}
+        for k, v in prof.items():
+            fam_total[family(k)] = fam_total.get(family(k), 0.0) + v["ms"]
+        fam = max(fam_total, key=fam_total.get)
+        same = {k: v for k, v in prof.items() if family(k) == fam}
         fam_ms = sum(v["ms"] for v in same.values())
         fam_bytes = sum(v["alg_bytes"] for v in same.values())
         fam_launch = sum(v["launches"] for v in same.values())
