@@ -18,6 +18,7 @@ struct SeedChainParams {          // what mm_map_frag_core passes to seeding and
 	int max_gap_ref, max_gap_qry, bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
 	float chn_pen_gap, chn_pen_skip;
 	int is_cdna;
+	int anchors_only = 0;         // 1: stop after the anchor sort and return every read's sorted anchors (n_u = 0): the caller chains them (MM_F_RMQ)
 };
 
 class Backend {

@@ -158,6 +158,23 @@ public:
 		// 3. anchors: expand, sort, chain
 		kp.begin(st); launch_seed_expand(B, I_, P, st); kp.end(st, "seed_expand_kernel", 24.0 * n_a);
 		launch_anchor_sort(B, n_a, end_bit, ln.d_sort_tmp.p, sort_tmp, st, &kp);
+		if (P.anchors_only) { // the caller chains (RMQ): hand over the sorted anchors as they are
+			Anchor *ha = ln.h_anchors.ensure(n_a + 1);
+			uint64_t *hmp = ln.h_minipos.ensure(n_mp + 1);
+			if (n_a) HIP_CHECK(hipMemcpyAsync(ha, ln.d_anchors.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+			if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+			Trace::get().add(lane_id, "gpu:expand+sort, d2h:anchors", tt, Trace::now());
+			kp.collect();
+			parallel_for(n_threads, (long)n, [&](long i, int) {
+				ReadChains &c = out[i];
+				c.rep_len = h_rep[i];
+				c.mp_p = hmp + mp_off[i], c.n_mp = (int32_t)(mp_off[i + 1] - mp_off[i]);
+				c.u_p = nullptr, c.n_u = 0;
+				c.a_p = ha + a_off[i], c.n_a = (int64_t)(a_off[i + 1] - a_off[i]);
+			}, 64);
+			return;
+		}
 		kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a);
 		// 4. chains: backtrack + compaction on the device, then only the chained anchors travel to the host
 		ln.d_bt_cursor.ensure(2), ln.d_bt_out_a.ensure(n_a + 1), ln.d_bt_out_u.ensure(n_a / 2 + n + 1);

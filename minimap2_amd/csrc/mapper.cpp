@@ -40,8 +40,8 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_RMQ | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
-	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice class presets); sr, splice:sr, qstrand, heap-sort, RMQ-primary and all-vs-all modes are not implemented");
+	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
+	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice class presets); sr, splice:sr, qstrand, heap-sort and all-vs-all modes are not implemented");
 	if (opt.max_occ > opt.mid_occ) throw std::invalid_argument("[mm2amd] re-chaining with a raised occurrence cap (max_occ > mid_occ, map.c:293) is a short-read feature and is not implemented");
 	if (!(opt.flag & F_CIGAR)) throw std::invalid_argument("[mm2amd] only base-level alignment mode (MM_F_CIGAR, -c/-a) is implemented");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
@@ -89,6 +89,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	sp.chn_pen_gap = (float)(opt_.chain_gap_scale * 0.01 * fi_.k);
 	sp.chn_pen_skip = (float)(opt_.chain_skip_scale * 0.01 * fi_.k);
 	sp.is_cdna = (opt_.flag & F_SPLICE) ? 1 : 0; // map.c:230,280
+	sp.anchors_only = (opt_.flag & F_RMQ) ? 1 : 0; // map.c:275-277: RMQ chaining runs on the host over the device-sorted anchors
 	if (opt_.max_gap_ref <= 0 && opt_.max_frag_len > 0) throw std::invalid_argument("[mm2amd] max_frag_len-derived chaining gap is a paired-end feature and is not implemented");
 
 	// Sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight) and are the
@@ -172,6 +173,15 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			const int qlen = live[lo + i].len;
 			ReadResult &res = out[live_id[lo + i]];
 			const uint32_t hash = read_hash(live[lo + i].name, qlen, opt_);
+			if (opt_.flag & F_RMQ) { // mg_lchain_rmq as the primary chainer (map.c:275-277)
+				ChainScratch sc;
+				std::vector<uint64_t> u2;
+				std::vector<Anchor> out_a;
+				chain_rmq(opt_.max_gap, opt_.rmq_inner_dist, opt_.bw, opt_.max_chain_skip, opt_.rmq_size_cap, opt_.min_cnt, opt_.min_chain_score,
+				          sp.chn_pen_gap, sp.chn_pen_skip, c.n_a, c.a_p, u2, out_a, sc);
+				c.u.swap(u2), c.a.swap(out_a);
+				c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
+			}
 			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && c.n_u > 1) { // long-join re-chaining (map.c:283-292)
 				const int32_t st = (int32_t)c.a_p[0].y, en = (int32_t)c.a_p[(int32_t)c.u_p[0] - 1].y;
 				if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {

@@ -55,6 +55,14 @@ public:
 			ReadChains &c = out[i - (size_t)lo];
 			c.rep_len = rep_len;
 			c.mini_pos.assign(mp, mp + n_mp);
+			if (p.anchors_only) {
+				c.u.clear();
+				c.a.resize(n_a);
+				if (n_a) memcpy(c.a.data(), a, n_a * sizeof(ora128_t));
+				c.view_own();
+				free(a); free(mp);
+				continue;
+			}
 			c.u.resize(n_a > 0 ? n_a : 1);
 			int64_t n_kept = 0;
 			const int n_u = ora_lchain_dp(p.max_gap_ref, p.max_gap_qry, p.bw, p.max_chain_skip, p.max_chain_iter, p.min_cnt, p.min_chain_score,

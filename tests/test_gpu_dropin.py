@@ -89,3 +89,26 @@ def test_output_stage_on_gpu_results(tmp_path):
         want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, reads])
         got, _ = _run([DROPIN, "--format-lib", "-x", "map-ont", "-t", "8"] + extra + [ref, reads])
         assert want == got
+
+
+def test_rmq_presets_identical(tmp_path):
+    # asm20 / lr:hqae: RMQ chaining on the host over the device-sorted anchors; 100-300 kb queries with a deletion and an inversion
+    import numpy as np
+    rng = np.random.default_rng(41)
+    contigs = synth.gen_reference(rng, 3000000, 2)
+    reads = synth.gen_reads(rng, contigs, 5, 250000, 30000, 0.02, min_len=100000)
+    s = contigs[0][200000:600000].copy()
+    s = np.concatenate([s[:100000], s[105000:250000], synth.COMP[s[250000:253000][::-1]], s[253000:]])
+    reads.append(synth.mutate_read(rng, s, 0.01))
+    ref, rd = str(tmp_path / "ref.fa"), str(tmp_path / "contigs.fa")
+    synth.write_fasta(ref, ["c1", "c2"], contigs)
+    synth.write_fasta(rd, ["q%d" % i for i in range(len(reads))], reads)
+    for preset, extra in (("asm20", ["-c"]), ("lr:hqae", ["-a"]), ("asm5", ["-c", "--cs"])):
+        want, _ = _run([REF_BIN, "-x", preset, "-t", "8"] + extra + [ref, rd])
+        got, err = _run([DROPIN, "-x", preset, "-t", "8", "--stats"] + extra + [ref, rd])
+        assert "backend=hip:gfx950" in err
+        assert want == got, preset
+    ref2, reads2, _, _ = synth.make("hifi", str(tmp_path), 3, 80, 24)
+    want, _ = _run([REF_BIN, "-x", "lr:hqae", "-t", "8", "-a", ref2, reads2])
+    got, _ = _run([DROPIN, "-x", "lr:hqae", "-t", "8", "-a", ref2, reads2])
+    assert want == got

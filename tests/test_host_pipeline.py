@@ -141,3 +141,29 @@ def test_output_stage(tmp_path, kind, args):
         outs.append(G.strip_pg(p.stdout))
     assert outs[0] == outs[1]
     assert len(outs[0]) > 1000
+
+
+def _contigs(tmp_path):
+    """assembly-like queries: 100-300 kb pieces of the reference at 1-2 % divergence, one carrying a 5 kb deletion and a 3 kb inversion"""
+    import numpy as np
+    import synth
+    rng = np.random.default_rng(41)
+    contigs = synth.gen_reference(rng, 3000000, 2)
+    reads = synth.gen_reads(rng, contigs, 5, 250000, 30000, 0.02, min_len=100000)
+    s = contigs[0][200000:600000].copy()
+    s = np.concatenate([s[:100000], s[105000:250000], synth.COMP[s[250000:253000][::-1]], s[253000:]])
+    reads.append(synth.mutate_read(rng, s, 0.01))
+    ref, rd = str(tmp_path / "ref.fa"), str(tmp_path / "contigs.fa")
+    synth.write_fasta(ref, ["c1", "c2"], contigs)
+    synth.write_fasta(rd, ["q%d" % i for i in range(len(reads))], reads)
+    return ref, rd
+
+
+@pytest.mark.parametrize("args", [["-x", "asm20", "-c"], ["-x", "asm5", "-a"], ["-x", "lr:hqae", "-c", "--cs"]])
+def test_rmq_presets(tmp_path, args):
+    """MM_F_RMQ presets: mg_lchain_rmq as the primary chainer (map.c:275-277), here on the host over the backend's sorted anchors"""
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, rd = _contigs(tmp_path)
+    out = _pair(args, ref, rd)
+    assert len(out) > 500
