@@ -39,8 +39,8 @@ __global__ void __launch_bounds__(256) idx_encode_kernel(const char *ascii, uint
 
 struct ChunkDesc { uint32_t rid; uint32_t start; }; // chunk = [start, start + CHUNK) clipped to the sequence
 
-// one lane per chunk (sketch_dev.hpp); non-HPC indices only
-template <bool EMIT, int WMAX>
+// one lane per chunk (sketch_dev.hpp)
+template <bool EMIT, int WMAX, bool HPC>
 __global__ void __launch_bounds__(64) idx_sketch_kernel(const uint8_t *nt4, const uint64_t *seq_off, const uint32_t *seq_len, const ChunkDesc *chunks,
                                                          uint64_t n_chunks, int chunk_len, int w, int k, uint32_t *cnt, const uint64_t *out_off,
                                                          uint64_t *out_hash, uint64_t *out_pos)
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64) idx_sketch_kernel(const uint8_t *nt4, cons
 	uint32_t n_out = 0;
 	uint64_t *oh = nullptr, *op = nullptr;
 	if (EMIT) oh = out_hash + out_off[ci], op = out_pos + out_off[ci];
-	sketch_chunk(nt4 + seq_off[rid], len, cs, ce, w, k, rid, bx, by, 1, [&](uint64_t x, uint64_t y) {
+	sketch_chunk<HPC>(nt4 + seq_off[rid], len, cs, ce, w, k, rid, bx, by, 1, [&](uint64_t x, uint64_t y) {
 		if (EMIT) { oh[n_out] = x >> 8; op[n_out] = y; }
 		++n_out;
 	});
@@ -107,7 +107,6 @@ __global__ void __launch_bounds__(256) idx_occ_hist_kernel(const uint32_t *val_o
 void DeviceIndexBuilder::build(FlatIndex &fi, DeviceIndexTables &T, int k, int w, int flag, int n_seq, const char *const *seqs, const uint64_t *lens,
                                const char *const *names, hipStream_t stream)
 {
-	if (flag & ref::I_HPC) throw std::invalid_argument("[mm2amd] device index build does not support HPC minimizers");
 	if (w <= 0 || w >= 256 || k <= 0 || k > 28) throw std::invalid_argument("[mm2amd] index build: need 0<w<256 and 0<k<=28");
 	HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_nt4_idx), kNt4Table, 256, 0, hipMemcpyHostToDevice, stream));
 	fi.k = k, fi.w = w, fi.flag = flag, fi.n_seq = (uint32_t)n_seq, fi.n_alt = 0;
@@ -149,15 +148,18 @@ void DeviceIndexBuilder::build(FlatIndex &fi, DeviceIndexTables &T, int k, int w
 	HIP_CHECK(hipMemcpyAsync(d_seq_off.p, fi.seq_off.data(), n_seq * 8, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(d_seq_len.p, fi.seq_len.data(), n_seq * 4, hipMemcpyHostToDevice, stream));
 	const dim3 sgrid((unsigned)((n_chunks + 63) / 64)), sblock(64);
+	const bool hpc = flag & ref::I_HPC;
 	auto run_sketch = [&](bool emit, uint64_t *oh, uint64_t *op) {
 		if (n_chunks == 0) return;
+#define MM2_IDX_SKETCH(E, W, H) hipLaunchKernelGGL((idx_sketch_kernel<E, W, H>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op)
 		if (w <= 32) {
-			if (emit) hipLaunchKernelGGL((idx_sketch_kernel<true, 32>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
-			else hipLaunchKernelGGL((idx_sketch_kernel<false, 32>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
+			if (hpc) { if (emit) MM2_IDX_SKETCH(true, 32, true); else MM2_IDX_SKETCH(false, 32, true); }
+			else { if (emit) MM2_IDX_SKETCH(true, 32, false); else MM2_IDX_SKETCH(false, 32, false); }
 		} else {
-			if (emit) hipLaunchKernelGGL((idx_sketch_kernel<true, 256>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
-			else hipLaunchKernelGGL((idx_sketch_kernel<false, 256>), sgrid, sblock, 0, stream, d_nt4.p, d_seq_off.p, d_seq_len.p, d_chunks.p, n_chunks, chunk_len, w, k, d_cnt.p, d_out_off.p, oh, op);
+			if (hpc) { if (emit) MM2_IDX_SKETCH(true, 256, true); else MM2_IDX_SKETCH(false, 256, true); }
+			else { if (emit) MM2_IDX_SKETCH(true, 256, false); else MM2_IDX_SKETCH(false, 256, false); }
 		}
+#undef MM2_IDX_SKETCH
 		HIP_CHECK(hipGetLastError());
 	};
 	run_sketch(false, nullptr, nullptr);

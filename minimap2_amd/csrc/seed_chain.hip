@@ -144,11 +144,11 @@ __global__ void __launch_bounds__(256) sketch_wave_kernel(SeedChainBuffers B, in
 	if (chunk < 32) chunk = 32;
 	const int64_t cs = (int64_t)lane * chunk, ce = cs + chunk < len ? cs + chunk : len;
 	uint32_t n = 0;
-	if (cs < len) sketch_chunk(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t) { ++n; });
+	if (cs < len) sketch_chunk<false>(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t) { ++n; });
 	uint32_t incl = n;
 	for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
 	uint64_t *ox = B.mz_x + B.mz_off[r] + (incl - n), *oy = B.mz_y + B.mz_off[r] + (incl - n);
-	if (n) sketch_chunk(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t x, uint64_t y) { *ox++ = x; *oy++ = y; });
+	if (n) sketch_chunk<false>(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t x, uint64_t y) { *ox++ = x; *oy++ = y; });
 	if (lane == 63) B.mz_cnt[r] = incl;
 }
 

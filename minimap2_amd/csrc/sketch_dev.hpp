@@ -9,7 +9,10 @@
 // reports only minimizers whose position it owns, and restarts further back in the rare case the warm-up did not reach a
 // synchronised state before cs (N runs, strand-symmetric k-mers).  The union over chunks is the reference's output, in order.
 //
-// Non-HPC only (HPC needs run-length look-ahead across chunk borders; callers use the sequential kernel for it).
+// HPC (homopolymer-compressed k-mers, sketch.c:95-105): a run of equal bases is one symbol whose position is the run's last
+// base; the k-mer's span is the total length of its k runs.  The same argument holds on the run-compressed sequence: a chunk
+// starts its warm-up on a run boundary, takes its k-mer registers from the k runs before it, owns the runs that END inside it,
+// and walks a run that straddles its end to completion like the reference does.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -31,7 +34,7 @@ __device__ __forceinline__ uint64_t mm_hash64(uint64_t key, uint64_t mask) // ha
 // Runs the automaton for the chunk [cs,ce) of seq[0,len) (nt4 codes, 4 = ambiguous) and calls emit(x, y) for every
 // minimizer the reference would report at a position in [cs,ce), in the reference's order.  x = hash<<8|span,
 // y = rid<<32 | pos<<1 | strand.  bx/by are caller-provided ring storage of at least w entries, accessed as bx[slot*stride].
-template <typename Emit>
+template <bool HPC, typename Emit>
 __device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, int64_t cs, int64_t ce, int w, int k, uint32_t rid,
                                              uint64_t *bx, uint64_t *by, int stride, Emit emit)
 {
@@ -50,12 +53,18 @@ __device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, in
 	for (;;) {
 		int64_t ws = cs - warm;
 		if (ws < 0) ws = 0;
+		if (HPC) while (ws > 0 && base_at(ws) < 4 && base_at(ws) == base_at(ws - 1)) --ws; // start on a run boundary
 		// exact k-mer registers at ws: the last k unambiguous bases before it (ambiguous bases do not shift them, sketch.c:96-116)
 		uint64_t kmer0 = 0, kmer1 = 0;
 		if (ws > 0) {
 			int got = 0;
 			uint64_t packed = 0; // digit d = the valid base at distance d+1 before ws
-			for (int64_t j = ws - 1; j >= 0 && got < k; --j) { const int c = base_at(j); if (c < 4) { packed |= (uint64_t)c << (2 * got); ++got; } }
+			for (int64_t j = ws - 1; j >= 0 && got < k; --j) {
+				const int c = base_at(j);
+				if (c >= 4) continue;
+				packed |= (uint64_t)c << (2 * got), ++got;
+				if (HPC) while (j - 1 >= 0 && base_at(j - 1) == c) --j; // the whole run is one symbol
+			}
 			for (int d = got - 1; d >= 0; --d) { // replay the reference's shifts, oldest base first
 				const uint64_t c = packed >> (2 * d) & 3ULL;
 				kmer0 = (kmer0 << 2 | c) & mask;
@@ -64,30 +73,43 @@ __device__ __forceinline__ void sketch_chunk(const uint8_t *seq, int64_t len, in
 		}
 		uint64_t min_x = UINT64_MAX, min_y = UINT64_MAX;
 		int l = 0, buf_pos = 0, min_pos = 0;
+		uint16_t tq[32];                       // HPC: lengths of the last <= k runs (tiny_queue_t, sketch.c:42-60), and their sum
+		int tq_front = 0, tq_count = 0, hpc_span = 0;
 		bool synced = ws == 0; // at the sequence start the automaton is in its true initial state
 		bool restart = false;
 		for (int j = 0; j < w; ++j) bx[j * stride] = by[j * stride] = UINT64_MAX;
 #define MM2_EMIT(X, Y) do { const int64_t pp_ = (int64_t)((uint32_t)(Y) >> 1); if (pp_ >= cs && pp_ < ce) emit((X), (Y)); } while (0)
 		for (int64_t i = ws; i < len; ++i) {
-			if (i == cs && !synced) { restart = true; break; } // not enough clean history: start further back
+			if (i >= cs && !synced) { restart = true; break; } // not enough clean history: start further back
 			// everything owned has been emitted: the window holds no valid k-mer, or its minimum lies past the chunk and the
 			// first-full-window rule (which may still emit an older equal-hash slot) can no longer fire on owned slots
 			if (i >= ce && (min_x == UINT64_MAX || ((int64_t)((uint32_t)min_y >> 1) >= ce && l >= w + k - 1))) break;
 			const int c = base_at(i);
 			uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
 			if (c < 4) {
-				const int kmer_span = l + 1 < k ? l + 1 : k;
+				int kmer_span = l + 1 < k ? l + 1 : k;
+				if (HPC) {
+					int skip_len = 1;
+					if (i + 1 < len && base_at(i + 1) == c) {
+						for (skip_len = 2; i + skip_len < len; ++skip_len) if (base_at(i + skip_len) != c) break;
+						i += skip_len - 1; // i = the last base of the run
+					}
+					const int sl = skip_len < 256 ? skip_len : 256; // only "span < 256" is ever asked of the sum
+					tq[(tq_count++ + tq_front) & 0x1f] = (uint16_t)sl, hpc_span += sl;
+					if (tq_count > k) hpc_span -= tq[tq_front], tq_front = (tq_front + 1) & 0x1f, --tq_count;
+					kmer_span = hpc_span;
+				}
 				kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
 				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
 				if (kmer0 == kmer1) continue; // strand-symmetric k-mer: no slot is consumed (sketch.c:108)
 				const int z = kmer0 < kmer1 ? 0 : 1;
 				++l;
-				if (l >= k) {
+				if (l >= k && (!HPC || kmer_span < 256)) {
 					ix = mm_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
 					iy = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z;
 				}
 				if (l >= w + k) synced = true; // state now depends only on the last w+k slots
-			} else l = 0;
+			} else l = 0, tq_front = tq_count = 0, hpc_span = 0;
 			bx[buf_pos * stride] = ix, by[buf_pos * stride] = iy;
 			if (l == w + k - 1 && min_x != UINT64_MAX) { // first full window (:117-122)
 				for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j * stride] && by[j * stride] != min_y) MM2_EMIT(bx[j * stride], by[j * stride]);

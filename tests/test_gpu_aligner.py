@@ -38,18 +38,18 @@ def _tricky_reference(rng, total):
     return seqs
 
 
-def _ref_index_pairs(seqs, w, k):
+def _ref_index_pairs(seqs, w, k, hpc=0):
     """(hash, pos) pairs of the reference's index, via its public mm_idx_get over every minimizer mm_sketch reports"""
     R = C.CDLL(reflib.REF_SO)
     R.mm_idx_str.restype = C.c_void_p
     R.mm_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
     n = len(seqs)
-    mi = R.mm_idx_str(w, k, 0, 14, n, (C.c_char_p * n)(*seqs), None)
+    mi = R.mm_idx_str(w, k, hpc, 14, n, (C.c_char_p * n)(*seqs), None)
     R.mm_idx_get.restype = C.POINTER(C.c_uint64)
     R.mm_idx_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
     out = {}
     for rid, s in enumerate(seqs):
-        mz = reflib.ref_sketch(s, w, k, rid)
+        mz = reflib.ref_sketch(s, w, k, rid, hpc)
         for h in np.unique(mz[:, 0] >> np.uint64(8)):
             cnt = C.c_int(0)
             p = R.mm_idx_get(mi, int(h), C.byref(cnt))
@@ -59,14 +59,14 @@ def _ref_index_pairs(seqs, w, k):
     return out
 
 
-@pytest.mark.parametrize("w,k", [(10, 15), (19, 19), (5, 15), (40, 21)])
-def test_device_index_equals_reference_index(w, k):
+@pytest.mark.parametrize("w,k,hpc", [(10, 15, 0), (19, 19, 0), (5, 15, 0), (40, 21, 0), (10, 19, 1), (10, 15, 1), (40, 21, 1)])
+def test_device_index_equals_reference_index(w, k, hpc):
     import minimap2_amd as mm
     rng = np.random.default_rng(100 + w)
     seqs = _tricky_reference(rng, 300000)
     L = mm.lib()
     n = len(seqs)
-    idx = L.mm2amd_idx_str(w, k, 0, 14, n, (C.c_char_p * n)(*seqs), None)
+    idx = L.mm2amd_idx_str(w, k, hpc, 14, n, (C.c_char_p * n)(*seqs), None)
     assert idx, L.mm2amd_last_error()
     nd, nm, sl = C.c_uint64(), C.c_uint64(), C.c_uint64()
     assert L.mm2amd_idx_stat(idx, None, None, None, None, sl, nd, nm) == 0
@@ -75,7 +75,7 @@ def test_device_index_equals_reference_index(w, k):
     pos = np.zeros(nm.value, np.uint64)
     S = np.zeros((sl.value + 7) // 8, np.uint32)
     assert L.mm2amd_idx_export(idx, None, keys.ctypes.data, val_off.ctypes.data, pos.ctypes.data, S.ctypes.data) == 0
-    want = _ref_index_pairs(seqs, w, k)
+    want = _ref_index_pairs(seqs, w, k, hpc)
     assert len(keys) == len(want)
     assert np.all(keys[1:] > keys[:-1])
     for i, h in enumerate(keys.tolist()):
@@ -93,7 +93,7 @@ def test_device_index_equals_reference_index(w, k):
     L.mm2amd_idx_destroy(idx)
 
 
-@pytest.mark.parametrize("kind,preset,n_reads,seed", [("ont", "map-ont", 60, 31), ("hifi", "map-hifi", 30, 32), ("hifi", "lr:hq", 20, 33)])
+@pytest.mark.parametrize("kind,preset,n_reads,seed", [("ont", "map-ont", 60, 31), ("hifi", "map-hifi", 30, 32), ("hifi", "lr:hq", 20, 33), ("hifi", "map-pb", 20, 34)])
 def test_aligner_equals_mm_map(kind, preset, n_reads, seed):
     import minimap2_amd as mm
     rng = np.random.default_rng(seed)
