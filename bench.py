@@ -243,9 +243,14 @@ def main():
         log("rank %d warmup %d: %.3f s  stats=%s" % (rank, s, dt, {k: round(v, 3) for k, v in al.last_stats().items()}))
     mm.profile_enable(True)
     times = []
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     for s in range(a.steps):
         times.append(one_step(a.warmup + s))
         log("rank %d step %d: %.3f s  stats=%s" % (rank, s, times[-1], {k: round(v, 3) for k, v in al.last_stats().items()}))
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
+    log("rank %d: host CPU time per step %.2f core-seconds (%d threads)" % (rank, host_cpu_s, n_threads))
     prof = mm.profile_get()
     mm.profile_enable(False)
     # host output stage, outside the timed region: SAM text of one batch's hits on the pool threads
@@ -353,7 +358,7 @@ def main():
            "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
            "config": {"workload": "%s: %d synthetic ~%d kb %g%%-error reads per GPU vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, mean_len // 1000, err * 100, total // 1000000),
-                      "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads,
+                      "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads, "host_cpu_s_per_step": round(host_cpu_s, 2),
                       "parallelism": "replicated index, reads sharded %d-way, RCCL hit gather" % world if world > 1 else "1 GPU",
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},
            "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
