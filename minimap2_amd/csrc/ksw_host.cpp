@@ -20,12 +20,7 @@ constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice 
 // kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip): two jobs per wave with 2 or 4 register sets of
 // 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves of 4 sets (512 positions per
 // sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
-constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
-// kFirstExt..: the register-resident extension kernel (ksw_ext.hip), right extensions then left extensions (the KSW_EZ_RIGHT
-// flavour), each with 2, 4 or 8 register sets of 64 target columns.
-constexpr int kExtClasses = 3, kNTiers = kFirstExt + 2 * kExtClasses;
-const int kExtSets[kExtClasses] = { 2, 4, 8 };
-const int kExtBlocksPerCU[kExtClasses] = { 3, 3, 2 };
+constexpr int kSpliceClasses = 3, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
 const int kSpliceSets[kSpliceClasses] = { 2, 4, 4 };
 const bool kSpliceSelf[kSpliceClasses] = { false, false, true };
 const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
@@ -58,24 +53,11 @@ inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
 	if (!scoring_ok || ((j.flag & 0x1fff) & ~kSpliceBits) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
 	return j.qlen > 0 && j.tlen > 0;
 }
-// An extension call (align.c:791 / :883) may take the register-resident extension kernel when its band cannot clip any row
-// (qlen <= w and tlen <= w + 1; checked exhaustively against the row-interval formula in tools/band_rule_check.py), scoring is
-// the default match/mismatch kind, and it fits 512 target columns / 1024 query bases.  Returns 0 = no, 1 = right extension,
-// 2 = left extension (KSW_EZ_RIGHT | KSW_EZ_REV_CIGAR).
-inline int ext_fast_kind(const KswJob &j, bool scoring_ok)
-{
-	const int f = j.flag & 0x1fff;
-	if (!scoring_ok || (j.flag & KSWJ_SKIP) || (f != KSW_EXTZ_ONLY && f != (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR))) return 0;
-	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastQCap || j.tlen > 512) return 0;
-	if (j.w >= 0 && (j.qlen > j.w || j.tlen > j.w + 1)) return 0;
-	return f == KSW_EXTZ_ONLY ? 1 : 2;
-}
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
 void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_fast.hip
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
-void ksw_ext_launch(const KswLaunch &L, int n_slots, int n_sets, bool right, void *stream);   // ksw_ext.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                     const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
@@ -90,7 +72,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	// turns the histograms into stable scatter offsets, and the chunks scatter in parallel.
 	constexpr int NB = 256; // cost buckets per tier
 	constexpr size_t CH = 32768;
-	const size_t NBINS = (size_t)kNTiers * NB;
+	const size_t NBINS = (size_t)(sc.single == 2 ? kNTiers : kFirstSplice) * NB; // the splice classes only exist in splice mode
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
@@ -113,14 +95,11 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		for (size_t i = (size_t)c * CH; i < e; ++i) {
 			const KswJob &j = jobs[i];
 			int tier, ring_need = 64;
-			const bool sfast = splice_fast_eligible(j, splice_ok);
-			const int ext = ext_fast_kind(j, scoring_ok);
-			const bool fast = fast_eligible(j, scoring_ok) || ext != 0; // the column-per-lane kernels: same matrix layout and cost order
+			const bool fast = fast_eligible(j, scoring_ok), sfast = splice_fast_eligible(j, splice_ok);
 			const bool live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
 			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
-			if (ext) { int nc = 0; while (j.tlen > 64 * kExtSets[nc]) ++nc; tier = kFirstExt + (ext - 1) * kExtClasses + nc; }
-			else if (fast) { tier = 0; while (j.tlen > kFastMaxT[tier]) ++tier; }
+			if (fast) { tier = 0; while (j.tlen > kFastMaxT[tier]) ++tier; }
 			else if (sfast) {
 				int nc = 0, dc = 0;
 				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
@@ -208,7 +187,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			Plan &P = plan[tier];
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
-			const bool xfast = tier >= kFirstExt, sfast = tier >= kFirstSplice && !xfast, fast = tier < kFirstExact || sfast || xfast; // the register-resident kernels
+			const bool sfast = tier >= kFirstSplice, fast = tier < kFirstExact || sfast; // the register-resident kernels
 			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
 			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
@@ -221,8 +200,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (P.hbm) P.wpb = 4;
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (xfast) blocks_per_cu = kExtBlocksPerCU[(tier - kFirstExt) % kExtClasses];
-			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
+			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
 			else if (P.hbm) blocks_per_cu = 4;
 			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
@@ -256,12 +234,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);
 			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
-			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, kExtSets[(tier - kFirstExt) % kExtClasses], tier >= kFirstExt + kExtClasses, stream);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
-			static const char *kExtNames[2 * kExtClasses] = { "ksw_ext_kernel<2,right-ext>", "ksw_ext_kernel<4,right-ext>", "ksw_ext_kernel<8,right-ext>", "ksw_ext_kernel<2,left-ext>", "ksw_ext_kernel<4,left-ext>", "ksw_ext_kernel<8,left-ext>" };
-			if (prof) prof->end(stream, tier >= kFirstExt ? kExtNames[tier - kFirstExt] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
+			if (prof) prof->end(stream, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
 		}
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));
