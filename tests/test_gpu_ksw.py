@@ -269,3 +269,47 @@ def test_splice_gap_fill_kernel(sc, monkeypatch):
         assert got[k] == ora_exts2(q, t, mat, go, ge, go2, noncan, zdrop, eb, 9, 5, flag), (k, len(q), len(t), hex(flag))
     monkeypatch.setenv("MM2AMD_KSW_EXACT_ONLY", "1")
     assert mm.ksw_exts2_batch(jobs, mat, go, ge, go2, noncan) == got
+
+
+@pytest.mark.parametrize("preset", list(PRESETS))
+def test_extension_calls(preset):
+    """the two extension calls of mm_align1 (right extension 0x40, left extension 0xC2) at every size up to 512 x 1024: Z-drops
+    (unrelated tails), end bonuses that decide between the best local end and the query end, N bases, extreme aspect ratios,
+    bands that can and cannot clip a row -- against the lane-exact oracle"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(99)
+    jobs = []
+
+    def add(q, t, flag=None):
+        q, t = q[:1024], t[:512]
+        if len(q) == 0 or len(t) == 0:
+            return
+        w = int(rng.choice([751, -1, max(len(q), len(t) - 1), 30001])) if max(len(q), len(t) - 1) <= 751 else -1
+        f = int(rng.choice([0x40, 0xC2])) if flag is None else flag
+        jobs.append((q, t, w, int(rng.choice([-1, 30, 100, 400])), int(rng.choice([-1, 0, 10, 100])), f))
+
+    for tl in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 511, 512):
+        for rep in range(4):
+            t = rng.integers(0, 4, tl, dtype=np.uint8)
+            if rep == 0:
+                add(t.copy(), t)
+            elif rep == 1:
+                q, _ = random_pair(rng, tl, 0.15, 0.02)
+                add(q, t)
+            elif rep == 2:
+                add(rng.integers(0, 4, int(rng.integers(1, 1025)), dtype=np.uint8), t)  # unrelated: Z-drop or nothing to extend
+            else:  # a good start, then an unrelated tail
+                q, _ = random_pair(rng, tl, 0.08)
+                k = max(1, len(q) // 2)
+                add(np.concatenate([q[:k], rng.integers(0, 4, len(q) - k + 20, dtype=np.uint8)]), t)
+    for it in range(400):
+        q, t = random_pair(rng, int(rng.integers(1, 400)), float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.03])),
+                           int(rng.choice([0, 0, 0, 30, -30, 120, -120])))
+        add(q, t)
+    for it in range(30):  # not eligible (the band can clip): still exact
+        q, t = random_pair(rng, int(rng.integers(100, 400)), 0.12)
+        jobs.append((q, t, int(rng.integers(5, 80)), 400, 10, int(rng.choice([0x40, 0xC2]))))
+    _run(jobs, preset)
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    got = mm.ksw_extd2_batch(jobs, ts_mat(a, b, 1, 0), go, ge, go2, ge2)
+    assert sum(r[1] for r in got) > 10 and sum(r[9] for r in got) > 10  # Z-drops and reach_end both occur
