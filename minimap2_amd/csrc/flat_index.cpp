@@ -28,10 +28,11 @@ void FlatIndex::from_reference(const ref::Idx *mi)
 {
 	if (!mi || !mi->B) throw std::invalid_argument("[mm2amd] null reference index");
 	k = mi->k, w = mi->w, flag = mi->flag, n_seq = mi->n_seq, n_alt = mi->n_alt;
-	names.resize(n_seq); seq_off.resize(n_seq); seq_len.resize(n_seq);
+	names.resize(n_seq); seq_off.resize(n_seq); seq_len.resize(n_seq); is_alt.assign(n_seq, 0);
 	sum_len = 0;
 	for (uint32_t i = 0; i < n_seq; ++i) {
 		names[i] = mi->seq[i].name ? mi->seq[i].name : "";
+		is_alt[i] = mi->seq[i].is_alt ? 1 : 0;
 		seq_off[i] = mi->seq[i].offset, seq_len[i] = mi->seq[i].len;
 		sum_len += mi->seq[i].len;
 	}

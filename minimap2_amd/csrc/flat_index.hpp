@@ -15,6 +15,7 @@ struct FlatIndex {
 	int k = 0, w = 0, flag = 0;
 	uint32_t n_seq = 0;
 	int n_alt = 0;
+	std::vector<uint8_t> is_alt;        // per sequence: ALT contig (mm_idx_seq_t::is_alt, set by mm_idx_alt_read, index.c:648-670)
 	std::vector<std::string> names;
 	std::vector<uint64_t> seq_off;      // offset of each sequence in S (bases)
 	std::vector<uint32_t> seq_len;

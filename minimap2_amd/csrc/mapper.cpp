@@ -45,7 +45,6 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	if (opt.max_occ > opt.mid_occ) throw std::invalid_argument("[mm2amd] re-chaining with a raised occurrence cap (max_occ > mid_occ, map.c:293) is a short-read feature and is not implemented");
 	if (!(opt.flag & F_CIGAR)) throw std::invalid_argument("[mm2amd] only base-level alignment mode (MM_F_CIGAR, -c/-a) is implemented");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
-	if (fi.n_alt) throw std::invalid_argument("[mm2amd] ALT-aware mapping is not implemented");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
 	// hand that memory back to the kernel every time turns into page-fault and mmap-lock storms (the reference sidesteps the same
 	// problem with its own kalloc arenas).  Keep freed memory in the process instead.  MM2AMD_NO_MALLOPT=1 leaves malloc alone.
@@ -199,6 +198,10 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			res.frag_gap = sp.max_gap_ref, res.rep_len = c.rep_len;
 			RegVec &r0 = regs0[i];
 			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, false, r0);
+			if (fi_.n_alt) { // mm_mark_alt + re-sort with ALT hits handicapped (map.c:321-324)
+				for (Reg &r : r0) if (fi_.is_alt[r.rid]) r.is_alt = 1;
+				hit_sort(r0, opt_.alt_drop);
+			}
 			if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
 				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
 				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);

@@ -23,6 +23,7 @@ int main(int argc, char *argv[])
 	mm_mapopt_t mopt;
 	const char *preset = 0;
 	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0;
+	const char *alt_fn = 0;
 	int64_t batch = 500000000;
 	kstring_t str = {0, 0, 0};
 
@@ -66,6 +67,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--secondary-seq") == 0) mopt.flag |= MM_F_SECONDARY_SEQ;
 		else if (strcmp(argv[k], "--paf-no-hit") == 0) mopt.flag |= MM_F_PAF_NO_HIT;
 		else if (strcmp(argv[k], "--sam-hit-only") == 0) mopt.flag |= MM_F_SAM_HIT_ONLY;
+		else if (strcmp(argv[k], "--alt") == 0) alt_fn = argv[++k];
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
@@ -78,6 +80,7 @@ int main(int argc, char *argv[])
 	while ((mi = mm_idx_reader_read(rd, n_threads)) != 0) {
 		if (mopt.flag & MM_F_OUT_SAM) mm_write_sam_hdr(mi, 0, MM_VERSION, 0, 0);
 		mm_mapopt_update(&mopt, mi);
+		if (alt_fn) mm_idx_alt_read(mi, alt_fn); /* main.c:480 */
 		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
 		mm_bseq_file_t *fp = mm_bseq_open(argv[k + 1]);
 		if (fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }

@@ -87,6 +87,31 @@ def gen_transcripts(rng, contigs, n_reads, err, max_intron=6000):
     return [mutate_read(rng, s, e) for s, e in reads]  # after all edits of the reference
 
 
+def make_alt(outdir, seed=51):
+    """A primary assembly with two ALT contigs (diverged copies of primary regions, one with an insertion), reads from everywhere
+    and from the duplicated regions in particular, and the ALT name list.  Returns (ref.fa, reads.fa, alt.txt)."""
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    contigs = gen_reference(rng, 2000000, 2)
+    alt1 = mutate_read(rng, contigs[0][300000:380000], 0.015)
+    a2 = contigs[1][500000:560000]
+    alt2 = mutate_read(rng, np.concatenate([a2[:30000], rng.integers(0, 4, 2000, dtype=np.uint8), a2[30000:]]), 0.01)
+    allc = contigs + [alt1, alt2]
+    reads = gen_reads(rng, allc, 80, 8000, 1500, 0.10, min_len=2000)
+    for i in range(40):
+        src = [contigs[0][300000:380000], alt1, a2, alt2][i % 4]
+        st = int(rng.integers(0, len(src) - 9000))
+        s = src[st:st + 8000]
+        if rng.random() < 0.5:
+            s = COMP[s[::-1]]
+        reads.append(mutate_read(rng, s, 0.08))
+    ref, rd, alt = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa"), os.path.join(outdir, "alt.txt")
+    write_fasta(ref, ["chr1", "chr2", "chr1_alt1", "chr2_alt1"], allc)
+    write_fasta(rd, ["r%d" % i for i in range(len(reads))], reads)
+    open(alt, "w").write("chr1_alt1\nchr2_alt1\n")
+    return ref, rd, alt
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):

@@ -112,3 +112,11 @@ def test_rmq_presets_identical(tmp_path):
     want, _ = _run([REF_BIN, "-x", "lr:hqae", "-t", "8", "-a", ref2, reads2])
     got, _ = _run([DROPIN, "-x", "lr:hqae", "-t", "8", "-a", ref2, reads2])
     assert want == got
+
+
+def test_alt_contigs_identical(tmp_path):
+    ref, rd, alt = synth.make_alt(str(tmp_path))
+    for extra in (["-a", "--alt", alt], ["-c", "--alt", alt]):
+        want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        got, _ = _run([DROPIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        assert want == got

@@ -167,3 +167,14 @@ def test_rmq_presets(tmp_path, args):
     ref, rd = _contigs(tmp_path)
     out = _pair(args, ref, rd)
     assert len(out) > 500
+
+
+def test_alt_contigs(tmp_path):
+    """--alt: hits on ALT contigs are marked (mm_mark_alt, hit.c:90-98) and handicapped in the sorts and the parent assignment"""
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, rd, alt = synth.make_alt(str(tmp_path))
+    with_alt = _pair(["-x", "map-ont", "-a", "--alt", alt], ref, rd)
+    without = _pair(["-x", "map-ont", "-a"], ref, rd)
+    assert with_alt != without  # the list matters on these inputs
