@@ -300,7 +300,8 @@ def main():
         roof = {"bound": "hbm", "kernel": fam, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6),
                 "traffic": None, "avg_launch_ms": round(fam_ms / max(fam_launch, 1), 4), "launches": fam_launch,
                 "alg_bytes_per_launch": round(fam_bytes / max(fam_launch, 1), 1),
-                "note": "integer DP: VALU-issue-bound, not HBM-bound (DESIGN.md section 4); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
+                "dp_gcups": round(al.last_stats().get("dp_cells", 0.0) * a.steps / max(sum(v["ms"] for k, v in prof.items() if k.startswith("ksw_")), 1e-9) / 1e6, 1),
+                "note": "integer DP: VALU-issue-bound, not HBM-bound (DESIGN.md section 4); dp_gcups = DP cells of the timed steps / summed DP kernel time (kernels of concurrent lanes overlap, so this understates the device rate); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())}}
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
