@@ -42,7 +42,6 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 {
 	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
 	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice class presets); sr, splice:sr, qstrand, heap-sort and all-vs-all modes are not implemented");
-	if (opt.max_occ > opt.mid_occ) throw std::invalid_argument("[mm2amd] re-chaining with a raised occurrence cap (max_occ > mid_occ, map.c:293) is a short-read feature and is not implemented");
 	if (!(opt.flag & F_CIGAR)) throw std::invalid_argument("[mm2amd] only base-level alignment mode (MM_F_CIGAR, -c/-a) is implemented");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
@@ -154,6 +153,21 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		double t0 = now();
 		std::vector<ReadChains> &chains = ds.chains;
 		be_.seed_chain(sp, lo, hi, lane, n_threads_, chains);
+		if (opt_.max_occ > opt_.mid_occ && !(opt_.flag & F_RMQ)) {
+			// map.c:293-316 for single-segment reads: a read that found no chain although it has repetitive minimizers is seeded
+			// again with the occurrence cap raised to max_occ and chained again.  Rare (only with -f x,y): the whole sub-batch is
+			// seeded a second time and the results of the reads concerned replace the first ones.
+			std::vector<long> again;
+			for (long i = 0; i < m; ++i) if (chains[i].n_u == 0 && chains[i].rep_len > 0) again.push_back(i);
+			if (!again.empty()) {
+				for (long i = 0; i < m; ++i) chains[i].take_ownership(); // the backend's buffers are about to be reused
+				SeedChainParams sp2 = sp;
+				sp2.mid_occ = opt_.max_occ;
+				std::vector<ReadChains> second;
+				be_.seed_chain(sp2, lo, hi, lane, n_threads_, second);
+				for (long i : again) { chains[i] = second[i]; chains[i].take_ownership(); }
+			}
+		}
 		stats.t_seed_chain += now() - t0; t0 = now();
 
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----

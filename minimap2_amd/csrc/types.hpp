@@ -37,6 +37,13 @@ struct ReadChains {
 	Anchor *a_p = nullptr;
 	int32_t n_u = 0, n_mp = 0;
 	int64_t n_a = 0;
+	void take_ownership() // copy the viewed results into the owned vectors (no-op for what is already owned)
+	{
+		if (u_p != u.data()) u.assign(u_p, u_p + n_u);
+		if (a_p != a.data()) a.assign(a_p, a_p + n_a);
+		if (mp_p != mini_pos.data()) mini_pos.assign(mp_p, mp_p + n_mp);
+		view_own();
+	}
 	void view_own() { u_p = u.data(), n_u = (int32_t)u.size(), a_p = a.data(), n_a = (int64_t)a.size(), mp_p = mini_pos.data(), n_mp = (int32_t)mini_pos.size(); }
 	std::vector<uint64_t> u;        // per chain: score<<32 | n_anchors
 	std::vector<Anchor> a;          // anchors of all chains, chain by chain

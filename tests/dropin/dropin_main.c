@@ -67,6 +67,40 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--secondary-seq") == 0) mopt.flag |= MM_F_SECONDARY_SEQ;
 		else if (strcmp(argv[k], "--paf-no-hit") == 0) mopt.flag |= MM_F_PAF_NO_HIT;
 		else if (strcmp(argv[k], "--sam-hit-only") == 0) mopt.flag |= MM_F_SAM_HIT_ONLY;
+		/* more of main.c's mapping options (main.c:168-352), for the option-fuzzing parity test */
+		else if (strcmp(argv[k], "-k") == 0) iopt.k = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-w") == 0) iopt.w = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-H") == 0) iopt.flag |= MM_I_HPC;
+		else if (strcmp(argv[k], "-g") == 0) mopt.max_gap = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-r") == 0) { char *e; mopt.bw = (int)strtol(argv[++k], &e, 10); if (*e == ',') mopt.bw_long = (int)strtol(e + 1, &e, 10); }
+		else if (strcmp(argv[k], "-U") == 0) { char *e; mopt.min_mid_occ = (int)strtol(argv[++k], &e, 10); if (*e == ',') mopt.max_mid_occ = (int)strtol(e + 1, &e, 10); }
+		else if (strcmp(argv[k], "-f") == 0) { char *e; double x = strtod(argv[++k], &e); if (x < 1.0) mopt.mid_occ_frac = (float)x, mopt.mid_occ = 0; else mopt.mid_occ = (int)(x + .499); if (*e == ',') mopt.max_occ = (int)(strtod(e + 1, &e) + .499); }
+		else if (strcmp(argv[k], "-N") == 0) mopt.best_n = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-p") == 0) mopt.pri_ratio = (float)atof(argv[++k]);
+		else if (strcmp(argv[k], "-M") == 0) mopt.mask_level = (float)atof(argv[++k]);
+		else if (strcmp(argv[k], "-n") == 0) mopt.min_cnt = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-m") == 0) mopt.min_chain_score = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-b") == 0) mopt.transition = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-P") == 0) mopt.flag |= MM_F_ALL_CHAINS;
+		else if (strcmp(argv[k], "-e") == 0) mopt.occ_dist = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--max-chain-skip") == 0) mopt.max_chain_skip = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--max-chain-iter") == 0) mopt.max_chain_iter = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--min-dp-len") == 0) mopt.min_ksw_len = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--no-long-join") == 0) mopt.flag |= MM_F_NO_LJOIN;
+		else if (strcmp(argv[k], "--end-bonus") == 0) mopt.end_bonus = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--end-seed-pen") == 0) mopt.anchor_ext_shift = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--min-occ-floor") == 0) mopt.min_mid_occ = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--score-N") == 0) mopt.sc_ambi = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--no-end-flt") == 0) mopt.flag |= MM_F_NO_END_FLT;
+		else if (strcmp(argv[k], "--hard-mask-level") == 0) mopt.flag |= MM_F_HARD_MLEVEL;
+		else if (strcmp(argv[k], "--cap-sw-mat") == 0) mopt.max_sw_mat = atoll(argv[++k]);
+		else if (strcmp(argv[k], "--max-qlen") == 0) mopt.max_qlen = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--chain-gap-scale") == 0) mopt.chain_gap_scale = (float)atof(argv[++k]);
+		else if (strcmp(argv[k], "--chain-skip-scale") == 0) mopt.chain_skip_scale = (float)atof(argv[++k]);
+		else if (strcmp(argv[k], "--alt-drop") == 0) mopt.alt_drop = (float)atof(argv[++k]);
+		else if (strcmp(argv[k], "--mask-len") == 0) mopt.mask_len = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--q-occ-frac") == 0) mopt.q_occ_frac = (float)atof(argv[++k]);
+		else if (strcmp(argv[k], "--no-hash-name") == 0) mopt.flag |= MM_F_NO_HASH_NAME;
 		else if (strcmp(argv[k], "--alt") == 0) alt_fn = argv[++k];
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }

@@ -112,6 +112,26 @@ def make_alt(outdir, seed=51):
     return ref, rd, alt
 
 
+def make_repeats(outdir, seed=61):
+    """One contig carrying 12 identical copies of a 3 kb unit, ordinary reads, and reads that lie entirely inside a copy: their
+    minimizers all occur 12 times.  Returns (ref.fa, reads.fa)."""
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    c = gen_reference(rng, 1500000, 1)[0]
+    unit = rng.integers(0, 4, 3000, dtype=np.uint8)
+    starts = [100000 + 110000 * i for i in range(12)]
+    for st in starts:
+        c[st:st + 3000] = unit
+    reads = gen_reads(rng, [c], 30, 6000, 1000, 0.08, min_len=2000)
+    for i, st in enumerate(starts):
+        s = c[st + 200:st + 2800]
+        reads.append(mutate_read(rng, s if i % 2 else COMP[s[::-1]], 0.05))
+    ref, rd = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa")
+    write_fasta(ref, ["c1"], [c])
+    write_fasta(rd, ["r%d" % i for i in range(len(reads))], reads)
+    return ref, rd
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):

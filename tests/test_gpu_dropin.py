@@ -120,3 +120,11 @@ def test_alt_contigs_identical(tmp_path):
         want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
         got, _ = _run([DROPIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
         assert want == got
+
+
+def test_rechain_with_raised_occurrence_cap_identical(tmp_path):
+    ref, rd = synth.make_repeats(str(tmp_path))
+    for extra in (["-c", "-f", "3,50", "-e", "0"], ["-a", "-f", "3,50"]):
+        want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        got, _ = _run([DROPIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        assert want == got

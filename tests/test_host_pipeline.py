@@ -178,3 +178,15 @@ def test_alt_contigs(tmp_path):
     with_alt = _pair(["-x", "map-ont", "-a", "--alt", alt], ref, rd)
     without = _pair(["-x", "map-ont", "-a"], ref, rd)
     assert with_alt != without  # the list matters on these inputs
+
+
+def test_rechain_with_raised_occurrence_cap(tmp_path):
+    """-f mid,max: reads that find no chain because all their minimizers are too frequent are seeded again with the cap raised to
+    max_occ (map.c:293-316)"""
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, rd = synth.make_repeats(str(tmp_path))
+    raised = _pair(["-x", "map-ont", "-c", "-f", "3,50", "-e", "0"], ref, rd)
+    plain = _pair(["-x", "map-ont", "-c", "-f", "3", "-e", "0"], ref, rd)
+    assert raised.count(b"\n") > 2 * plain.count(b"\n")  # the repeat-only reads map only with the raised cap
