@@ -22,7 +22,7 @@ int main(int argc, char *argv[])
 	mm_idxopt_t iopt;
 	mm_mapopt_t mopt;
 	const char *preset = 0;
-	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0;
+	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, old_best_n = -1;
 	const char *alt_fn = 0;
 	int64_t batch = 500000000;
 	kstring_t str = {0, 0, 0};
@@ -38,7 +38,8 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-c") == 0) mopt.flag |= MM_F_OUT_CG | MM_F_CIGAR;
 		else if (strcmp(argv[k], "-t") == 0) n_threads = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-K") == 0) batch = atoll(argv[++k]);
-		else if (strcmp(argv[k], "-s") == 0) mopt.seed = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-s") == 0) mopt.min_dp_max = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--seed") == 0) mopt.seed = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--stats") == 0) print_stats = 1;
 		else if (strcmp(argv[k], "-O") == 0) { char *s; mopt.q = mopt.q2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.q2 = strtol(s + 1, &s, 10); }
 		else if (strcmp(argv[k], "-E") == 0) { char *s; mopt.e = mopt.e2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.e2 = strtol(s + 1, &s, 10); }
@@ -55,10 +56,10 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-z") == 0) { char *s; mopt.zdrop = mopt.zdrop_inv = strtol(argv[++k], &s, 10); if (*s == ',') mopt.zdrop_inv = strtol(s + 1, &s, 10); }
 		else if (strcmp(argv[k], "--splice-flank=no") == 0) mopt.flag &= ~MM_F_SPLICE_FLANK;
 		else if (strcmp(argv[k], "-J") == 0) { if (atoi(argv[++k]) == 0) mopt.flag |= MM_F_SPLICE_OLD; else mopt.flag &= ~MM_F_SPLICE_OLD; }
-		else if (strcmp(argv[k], "--cs") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_CIGAR;
+		else if (strcmp(argv[k], "--cs") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_CIGAR, mopt.flag &= ~MM_F_OUT_CS_LONG; /* main.c:284-287 */
 		else if (strcmp(argv[k], "--MD") == 0) mopt.flag |= MM_F_OUT_MD;
 		else if (strcmp(argv[k], "--eqx") == 0) mopt.flag |= MM_F_EQX;
-		else if (strcmp(argv[k], "--ds") == 0) mopt.flag |= MM_F_OUT_DS | MM_F_CIGAR;
+		else if (strcmp(argv[k], "--ds") == 0) mopt.flag |= MM_F_OUT_DS; /* main.c:258 */
 		else if (strcmp(argv[k], "--cs=long") == 0) mopt.flag |= MM_F_OUT_CS | MM_F_OUT_CS_LONG | MM_F_CIGAR;
 		else if (strcmp(argv[k], "-Y") == 0) mopt.flag |= MM_F_SOFTCLIP;
 		else if (strcmp(argv[k], "-L") == 0) mopt.flag |= MM_F_LONG_CIGAR;
@@ -75,7 +76,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-r") == 0) { char *e; mopt.bw = (int)strtol(argv[++k], &e, 10); if (*e == ',') mopt.bw_long = (int)strtol(e + 1, &e, 10); }
 		else if (strcmp(argv[k], "-U") == 0) { char *e; mopt.min_mid_occ = (int)strtol(argv[++k], &e, 10); if (*e == ',') mopt.max_mid_occ = (int)strtol(e + 1, &e, 10); }
 		else if (strcmp(argv[k], "-f") == 0) { char *e; double x = strtod(argv[++k], &e); if (x < 1.0) mopt.mid_occ_frac = (float)x, mopt.mid_occ = 0; else mopt.mid_occ = (int)(x + .499); if (*e == ',') mopt.max_occ = (int)(strtod(e + 1, &e) + .499); }
-		else if (strcmp(argv[k], "-N") == 0) mopt.best_n = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-N") == 0) old_best_n = mopt.best_n, mopt.best_n = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-p") == 0) mopt.pri_ratio = (float)atof(argv[++k]);
 		else if (strcmp(argv[k], "-M") == 0) mopt.mask_level = (float)atof(argv[++k]);
 		else if (strcmp(argv[k], "-n") == 0) mopt.min_cnt = atoi(argv[++k]);
@@ -107,6 +108,7 @@ int main(int argc, char *argv[])
 	}
 	if (argc - k < 2) { fprintf(stderr, "usage: dropin [options] ref reads\n"); return 1; }
 	if (mm_check_opt(&iopt, &mopt) < 0) return 1;
+	if (mopt.best_n == 0) mopt.best_n = old_best_n, mopt.flag |= MM_F_NO_PRINT_2ND; /* main.c:356-359: '-N 0' becomes '-N <preset> --secondary=no' */
 
 	mm_idx_reader_t *rd = mm_idx_reader_open(argv[k], &iopt, 0);
 	if (rd == 0) { fprintf(stderr, "failed to open %s\n", argv[k]); return 1; }

@@ -1,0 +1,77 @@
+"""Option fuzzing of the drop-in against the reference binary (CPU, oracle-backed check backend): random subsets of minimap2's
+mapping and output options with random values -- chaining thresholds, scoring, Z-drop, occurrence filters, hit selection,
+output flavours -- on small ONT / HiFi / cDNA / ALT / repeat inputs.  The seeds are fixed, so this is a regression test; a
+wider sweep of the same generator (hundreds of seeds) was run during development."""
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as G  # noqa: E402
+import synth  # noqa: E402
+
+CHECK = os.path.join(HERE, "_build", "dropin_check")
+pytestmark = pytest.mark.skipif(not (os.path.exists(G.REF_BIN) and os.path.exists(CHECK)), reason="needs oracle/_ref and tests/_build (dev container)")
+
+C = random.Random.choice
+OPTS = [("-g", lambda r: C(r, ["500", "2000", "5000", "10000"])), ("-r", lambda r: C(r, ["100", "500,2000", "2000,20000", "50,50"])),
+        ("-N", lambda r: C(r, ["0", "1", "5", "20"])), ("-p", lambda r: C(r, ["0.5", "0.8", "0.95", "0.2"])), ("-M", lambda r: C(r, ["0.2", "0.5", "0.9"])),
+        ("-n", lambda r: C(r, ["1", "2", "3", "6"])), ("-m", lambda r: C(r, ["20", "40", "100"])), ("-s", lambda r: C(r, ["40", "80", "200", "1000"])),
+        ("-z", lambda r: C(r, ["100", "400,200", "50,30", "1000,100"])), ("-A", lambda r: C(r, ["1", "2", "3"])), ("-B", lambda r: C(r, ["2", "4", "6"])),
+        ("-O", lambda r: C(r, ["4,24", "6,26", "3", "5,12"])), ("-E", lambda r: C(r, ["2,1", "3,1", "2", "1,0"])), ("-b", lambda r: C(r, ["0", "2", "3"])),
+        ("-P", None), ("-e", lambda r: C(r, ["0", "100", "500", "2000"])), ("--max-chain-skip", lambda r: C(r, ["5", "25", "100"])),
+        ("--max-chain-iter", lambda r: C(r, ["50", "500", "5000"])), ("--min-dp-len", lambda r: C(r, ["50", "200", "500"])), ("--no-long-join", None),
+        ("--end-bonus", lambda r: C(r, ["0", "5", "20", "100"])), ("--score-N", lambda r: C(r, ["0", "1", "3"])), ("--no-end-flt", None),
+        ("--hard-mask-level", None), ("--max-qlen", lambda r: C(r, ["5000", "9000", "0"])), ("--chain-gap-scale", lambda r: C(r, ["0.5", "1.0", "2.0"])),
+        ("--chain-skip-scale", lambda r: C(r, ["0.0", "0.5", "1.5"])), ("--mask-len", lambda r: C(r, ["100", "1000", "100000"])),
+        ("--q-occ-frac", lambda r: C(r, ["0", "0.01", "0.1"])), ("--no-hash-name", None), ("-U", lambda r: C(r, ["10,100", "2,5", "50,500"])),
+        ("-f", lambda r: C(r, ["0.0002", "0.01", "20", "3,50"])), ("--eqx", None), ("-Y", None), ("--secondary=no", None),
+        ("-k", lambda r: C(r, ["13", "15", "17", "21"])), ("-w", lambda r: C(r, ["5", "10", "19", "40"]))]
+FORMAT_OPTS = [("--MD", None), ("--cs", None), ("--ds", None), ("--cs=long", None), ("-L", None), ("-y", None), ("--secondary-seq", None), ("--paf-no-hit", None),
+               ("--sam-hit-only", None)]
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fuzz")
+    out = {}
+    for kind, preset, mb, n, seed in (("ont", "map-ont", 1.0, 25, 201), ("hifi", "map-hifi", 1.0, 15, 202), ("cdna", "splice", 1.0, 40, 203)):
+        ref, rd, _, _ = synth.make(kind, str(d / kind), mb, n, seed)
+        out[kind] = (ref, rd, preset, [])
+    ref, rd, alt = synth.make_alt(str(d / "alt"))
+    out["alt"] = (ref, rd, "map-ont", ["--alt", alt])
+    ref, rd = synth.make_repeats(str(d / "rep"))
+    out["rep"] = (ref, rd, "map-ont", [])
+    return out
+
+
+def _case(inputs, seed, table, format_lib):
+    r = random.Random(seed)
+    ref, rd, preset, extra = inputs[["ont", "hifi", "cdna", "alt", "rep"][seed % 5]]
+    args = ["-x", preset, r.choice(["-a", "-c"])] + extra
+    for name, gen in r.sample(table, r.randint(1, 6)):
+        args.append(name)
+        if gen:
+            args.append(gen(r))
+    outs = []
+    for binary, pre in ((G.REF_BIN, []), (CHECK, ["--format-lib"] if format_lib else [])):
+        p = subprocess.run([binary] + pre + args + ["-t", "4", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        outs.append((p.returncode, G.strip_pg(p.stdout)))
+    if outs[0][0] != 0:  # an option combination mm_check_opt rejects: we must reject it too
+        assert outs[1][0] != 0, args
+    else:
+        assert outs[1][0] == 0 and outs[0][1] == outs[1][1], args
+
+
+@pytest.mark.parametrize("seed", range(1000, 1016))
+def test_mapping_options(inputs, seed):
+    _case(inputs, seed, OPTS, False)
+
+
+@pytest.mark.parametrize("seed", range(2000, 2010))
+def test_output_options_through_the_library_formatter(inputs, seed):
+    _case(inputs, seed, OPTS + FORMAT_OPTS * 3, True)
