@@ -15,7 +15,7 @@ import make_golden as G  # noqa: E402
 import synth  # noqa: E402
 
 CHECK = os.path.join(HERE, "_build", "dropin_check")
-pytestmark = pytest.mark.skipif(not (os.path.exists(G.REF_BIN) and os.path.exists(CHECK)), reason="needs oracle/_ref and tests/_build (dev container)")
+needs_dev = pytest.mark.skipif(not (os.path.exists(G.REF_BIN) and os.path.exists(CHECK)), reason="needs oracle/_ref and tests/_build (dev container)")
 
 C = random.Random.choice
 OPTS = [("-g", lambda r: C(r, ["500", "2000", "5000", "10000"])), ("-r", lambda r: C(r, ["100", "500,2000", "2000,20000", "50,50"])),
@@ -67,11 +67,13 @@ def _case(inputs, seed, table, format_lib):
         assert outs[1][0] == 0 and outs[0][1] == outs[1][1], args
 
 
+@needs_dev
 @pytest.mark.parametrize("seed", range(1000, 1016))
 def test_mapping_options(inputs, seed):
     _case(inputs, seed, OPTS, False)
 
 
+@needs_dev
 @pytest.mark.parametrize("seed", range(2000, 2010))
 def test_output_options_through_the_library_formatter(inputs, seed):
     _case(inputs, seed, OPTS + FORMAT_OPTS * 3, True)
