@@ -132,6 +132,42 @@ def make_repeats(outdir, seed=61):
     return ref, rd
 
 
+def make_weird(outdir, seed=71):
+    """Edge-case reads against a reference with low-complexity islands ((AC)n, poly-A, a 7-mer tandem): lengths 1..100 around k,
+    all-N, lower case, IUPAC codes, reads spanning / inside the islands, a homopolymer, every second base N, a read that is a
+    whole contig, a 250 kb reverse-strand read, a three-piece chimera, an unrelated read, duplicate names.  Returns (ref.fa, reads.fa)."""
+    rng = np.random.default_rng(seed)
+    contigs = gen_reference(rng, 600000, 2)
+    contigs[0][100000:103000] = np.tile(np.array([0, 1], dtype=np.uint8), 1500)
+    contigs[0][200000:202000] = 0
+    contigs[1][50000:56000] = np.tile(np.array([2, 0, 3, 3, 0, 1, 0], dtype=np.uint8), 858)[:6000]
+    ref0, ref1 = ACGT[contigs[0]].tobytes(), ACGT[contigs[1]].tobytes()
+    reads = [ref1[250000:250000 + L] for L in (1, 2, 5, 14, 15, 16, 17, 29, 30, 31, 40, 60, 100)]
+    reads.append(b"N" * 500)
+    reads.append(ref0[10000:12000].lower())
+    iu = bytearray(ref0[20000:23000])
+    for p in range(0, 3000, 97):
+        iu[p] = b"RYKMSWBDHVN"[p % 11]
+    reads.append(bytes(iu))
+    reads += [ref0[99000:104000], ref0[100500:102500], ref0[199000:203000], b"A" * 3000, ref1[49000:57000], ref1[51000:55000]]
+    half = bytearray(ref0[250000:254000])
+    for p in range(0, 4000, 2):
+        half[p] = ord("N")
+    reads.append(bytes(half))
+    reads.append(ref1)
+    reads.append(ACGT[COMP[contigs[0][::-1]]].tobytes()[:250000])
+    reads.append(ref0[150000:155000] + ref1[100000:105000] + ref0[160000:165000])
+    reads.append(ACGT[rng.integers(0, 4, 8000, dtype=np.uint8)].tobytes())
+    os.makedirs(outdir, exist_ok=True)
+    ref, rd = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa")
+    write_fasta(ref, ["c1", "c2"], contigs)
+    with open(rd, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">w%d\n" % i + s + b"\n")
+        f.write(b">dup\n" + ref0[5000:9000] + b"\n>dup\n" + ref0[5000:9000] + b"\n")
+    return ref, rd
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):

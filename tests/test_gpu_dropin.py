@@ -128,3 +128,12 @@ def test_rechain_with_raised_occurrence_cap_identical(tmp_path):
         want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
         got, _ = _run([DROPIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
         assert want == got
+
+
+def test_edge_case_reads_identical(tmp_path):
+    # tiny reads around k, all-N, IUPAC, lower case, low-complexity islands, a homopolymer, a whole-contig read, a chimera ...
+    ref, rd = synth.make_weird(str(tmp_path))
+    for preset, extra in (("map-ont", ["-a"]), ("map-hifi", ["-c", "--cs"]), ("asm20", ["-c"]), ("map-pb", ["-a"]), ("splice", ["-a"])):
+        want, _ = _run([REF_BIN, "-x", preset, "-t", "8"] + extra + [ref, rd])
+        got, _ = _run([DROPIN, "-x", preset, "-t", "8"] + extra + [ref, rd])
+        assert want == got, preset

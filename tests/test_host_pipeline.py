@@ -190,3 +190,12 @@ def test_rechain_with_raised_occurrence_cap(tmp_path):
     raised = _pair(["-x", "map-ont", "-c", "-f", "3,50", "-e", "0"], ref, rd)
     plain = _pair(["-x", "map-ont", "-c", "-f", "3", "-e", "0"], ref, rd)
     assert raised.count(b"\n") > 2 * plain.count(b"\n")  # the repeat-only reads map only with the raised cap
+
+
+@pytest.mark.parametrize("args", [["-x", "map-ont", "-a"], ["-x", "map-hifi", "-c", "--cs"], ["-x", "asm20", "-c"], ["-x", "map-pb", "-a"]])
+def test_edge_case_reads(tmp_path, args):
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, rd = synth.make_weird(str(tmp_path))
+    _pair(args, ref, rd)
