@@ -243,7 +243,7 @@ void DeviceIndexTables::upload(const FlatIndex &fi, hipStream_t stream)
 	up32(bucket_start, fi.bucket_start), up32(val_off, fi.val_off), up64(keys, fi.keys), up64(pos, fi.pos);
 	const size_t s_words = (fi.sum_len + 7) / 8;
 	S.ensure(s_words + 1, 1.0);
-	if (s_words) HIP_CHECK(hipMemcpyAsync(S.p, fi.S, s_words * 4, hipMemcpyHostToDevice, stream));
+	if (s_words && fi.S) HIP_CHECK(hipMemcpyAsync(S.p, fi.S, s_words * 4, hipMemcpyHostToDevice, stream)); // an index without sequence (MM_I_NO_SEQ) only serves chain-level mapping
 	HIP_CHECK(hipStreamSynchronize(stream));
 	n_keys = fi.keys.size(), n_pos = fi.pos.size(), bucket_bits = fi.bucket_bits, key_shift = fi.key_shift;
 	occ_hist.assign(1 << 16, 0);

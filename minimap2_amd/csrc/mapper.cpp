@@ -42,7 +42,7 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 {
 	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
 	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice class presets); sr, splice:sr, qstrand, heap-sort and all-vs-all modes are not implemented");
-	if (!(opt.flag & F_CIGAR)) throw std::invalid_argument("[mm2amd] only base-level alignment mode (MM_F_CIGAR, -c/-a) is implemented");
+	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
 	// hand that memory back to the kernel every time turns into page-fault and mmap-lock storms (the reference sidesteps the same
@@ -222,11 +222,17 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 			filter_strand_retained(r0);
+			if (!(opt_.flag & F_CIGAR)) { // mapping without base-level alignment: the chains are the hits (align_regs returns early, map.c:217)
+				res.regs = r0;
+				set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, opt_.flag & F_SPLICE);
+				return;
+			}
 			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i], ds.q4.data() + ds.q4_off[i]);
 		});
 		Trace::get().add(lane, "host:pre", t0, now());
 		stats.t_host_pre += now() - t0;
 
+		if (!(opt_.flag & F_CIGAR)) return; // no base-level alignment asked for
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
 		KswScoring sc;
 		memcpy(sc.mat, aligner.mat(), 25);

@@ -107,6 +107,7 @@ int main(int argc, char *argv[])
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
 	if (argc - k < 2) { fprintf(stderr, "usage: dropin [options] ref reads\n"); return 1; }
+	if (!(mopt.flag & MM_F_CIGAR)) iopt.flag |= MM_I_NO_SEQ; /* main.c:352-353 */
 	if (mm_check_opt(&iopt, &mopt) < 0) return 1;
 	if (mopt.best_n == 0) mopt.best_n = old_best_n, mopt.flag |= MM_F_NO_PRINT_2ND; /* main.c:356-359: '-N 0' becomes '-N <preset> --secondary=no' */
 

@@ -137,3 +137,10 @@ def test_edge_case_reads_identical(tmp_path):
         want, _ = _run([REF_BIN, "-x", preset, "-t", "8"] + extra + [ref, rd])
         got, _ = _run([DROPIN, "-x", preset, "-t", "8"] + extra + [ref, rd])
         assert want == got, preset
+
+
+def test_chain_level_mapping_identical(tmp_path):
+    # PAF without CIGAR: seeding and chaining only
+    _compare(tmp_path, "ont", "map-ont", 4, 300, 25, [])
+    _compare(tmp_path, "cdna", "splice", 3, 200, 26, [])
+    _compare(tmp_path, "hifi", "asm20", 3, 40, 27, [])

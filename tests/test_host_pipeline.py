@@ -199,3 +199,14 @@ def test_edge_case_reads(tmp_path, args):
         pytest.skip("needs oracle/_ref")
     ref, rd = synth.make_weird(str(tmp_path))
     _pair(args, ref, rd)
+
+
+@pytest.mark.parametrize("kind,args", [("ont", ["-x", "map-ont"]), ("cdna", ["-x", "splice"]), ("hifi", ["-x", "asm20"]), ("ont", ["-x", "map-ont", "--paf-no-hit", "-P"])])
+def test_chain_level_mapping(tmp_path, kind, args):
+    """no -c / -a: the hits are the chains (align_regs returns early, map.c:217), dv instead of de, index built without sequence"""
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, rd, _, _ = synth.make(kind, str(tmp_path), 1.0, 40, 109)
+    out = _pair(args, ref, rd)
+    assert b"dv:f:" in out and b"cg:Z:" not in out

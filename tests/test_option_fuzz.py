@@ -52,7 +52,10 @@ def inputs(tmp_path_factory):
 def _case(inputs, seed, table, format_lib):
     r = random.Random(seed)
     ref, rd, preset, extra = inputs[["ont", "hifi", "cdna", "alt", "rep"][seed % 5]]
-    args = ["-x", preset, r.choice(["-a", "-c"])] + extra
+    args = ["-x", preset] + extra
+    mode = r.choice(["-a", "-c", "-a", "-c", ""])  # "": chain-level mapping, PAF without CIGAR
+    if mode:
+        args.append(mode)
     for name, gen in r.sample(table, r.randint(1, 6)):
         args.append(name)
         if gen:
