@@ -106,7 +106,6 @@ public:
 		out.clear();
 		out.resize(n);
 		if (n == 0) return;
-		if (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY)) throw std::invalid_argument("[mm2amd] --for-only/--rev-only are not implemented on the device path");
 		B = SeedChainBuffers();
 		B.n_reads = (int)n, B.seq_off = d_seq_off_.p + lo, B.ascii = d_ascii_.p, B.qpool = d_qpool_.p;
 		KernelProfiler &kp = kernel_profiler(lane_id);

@@ -330,7 +330,18 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 	for (int base = 0; base < n_m0; base += 64) {
 		const int i = base + lane;
 		const bool kept = i < n_m0 && !(sd_info[i] & SD_FLT);
-		uint32_t c = kept ? sd_n[i] : 0, incl = c;
+		uint32_t c = kept ? sd_n[i] : 0;
+		if (kept && (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY))) { // --for-only / --rev-only: hits on the other strand are skipped (skip_seed, map.c:91-97)
+			const uint64_t *cr = I.pos + sd_off[i];
+			const uint32_t qp = sd_qpos[i];
+			uint32_t pass = 0;
+			for (uint32_t h = 0; h < c; ++h) {
+				const bool fwd = (cr[h] & 1) == (qp & 1);
+				if (fwd ? !(P.flag & ref::F_REV_ONLY) : !(P.flag & ref::F_FOR_ONLY)) ++pass;
+			}
+			c = pass;
+		}
+		uint32_t incl = c;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
 		const unsigned long long km = __ballot(kept);
 		if (i < n_m0) sd_aoff[i] = kept ? n_a + incl - c : 0xffffffffu;
@@ -369,9 +380,12 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 		const uint32_t info = sd_info[i], span = info & 0xff, qp = sd_qpos[i], cnt = sd_n[i];
 		mp[info >> 10] = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
 		const uint64_t *cr = I.pos + sd_off[i];
+		const bool one_strand = P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY);
+		uint32_t w = 0; // anchors written for this seed
 		for (uint32_t c = 0; c < cnt; ++c) {
 			const uint64_t rr = cr[c];
 			const uint32_t rpos = (uint32_t)rr >> 1;
+			if (one_strand && (((rr & 1) == (qp & 1)) ? (P.flag & ref::F_REV_ONLY) != 0 : (P.flag & ref::F_FOR_ONLY) != 0)) continue;
 			Anchor p;
 			if ((rr & 1) == (qp & 1)) { // same strand
 				p.x = (rr & 0xffffffff00000000ULL) | rpos;
@@ -381,8 +395,9 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
 			}
 			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
-			akey[ao + c] = read_tag | (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL);
-			aval[ao + c] = p.y;
+			akey[ao + w] = read_tag | (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL);
+			aval[ao + w] = p.y;
+			++w;
 		}
 	}
 }

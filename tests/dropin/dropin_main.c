@@ -102,6 +102,8 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--mask-len") == 0) mopt.mask_len = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--q-occ-frac") == 0) mopt.q_occ_frac = (float)atof(argv[++k]);
 		else if (strcmp(argv[k], "--no-hash-name") == 0) mopt.flag |= MM_F_NO_HASH_NAME;
+		else if (strcmp(argv[k], "--for-only") == 0) mopt.flag |= MM_F_FOR_ONLY;
+		else if (strcmp(argv[k], "--rev-only") == 0) mopt.flag |= MM_F_REV_ONLY;
 		else if (strcmp(argv[k], "--alt") == 0) alt_fn = argv[++k];
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }

@@ -144,3 +144,9 @@ def test_chain_level_mapping_identical(tmp_path):
     _compare(tmp_path, "ont", "map-ont", 4, 300, 25, [])
     _compare(tmp_path, "cdna", "splice", 3, 200, 26, [])
     _compare(tmp_path, "hifi", "asm20", 3, 40, 27, [])
+
+
+def test_one_strand_only_identical(tmp_path):
+    # --for-only / --rev-only: seed hits on the other strand are skipped before chaining (skip_seed, map.c:91-97)
+    _compare(tmp_path, "ont", "map-ont", 3, 150, 28, ["-a", "--for-only"])
+    _compare(tmp_path, "hifi", "map-hifi", 3, 60, 29, ["-c", "--rev-only"])

@@ -210,3 +210,14 @@ def test_chain_level_mapping(tmp_path, kind, args):
     ref, rd, _, _ = synth.make(kind, str(tmp_path), 1.0, 40, 109)
     out = _pair(args, ref, rd)
     assert b"dv:f:" in out and b"cg:Z:" not in out
+
+
+@pytest.mark.parametrize("flag", ["--for-only", "--rev-only"])
+def test_one_strand_only(tmp_path, flag):
+    import synth
+    if not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref")
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 1.0, 40, 110)
+    out = _pair(["-x", "map-ont", "-c", flag], ref, rd)
+    strands = {l.split(b"\t")[4] for l in out.split(b"\n") if l}
+    assert strands == ({b"+"} if flag == "--for-only" else {b"-"})
