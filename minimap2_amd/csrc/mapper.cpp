@@ -40,8 +40,10 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_NO_DIAG | F_NO_DUAL | F_INDEPEND_SEG | F_FRAG_MODE;
-	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice class presets); sr, splice:sr, qstrand, heap-sort and all-vs-all modes are not implemented");
+	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_INDEPEND_SEG | F_FRAG_MODE;
+	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice / asm / ava class presets); sr, splice:sr, qstrand and heap-sort modes are not implemented");
+	if ((opt.flag & (F_NO_DIAG | F_NO_DUAL)) && !be.enable_name_rules()) // all-vs-all: skip_seed compares read and target names (map.c:81-91)
+		throw std::invalid_argument("[mm2amd] all-vs-all mapping (-X / -D / --dual=no, ava-* presets) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc

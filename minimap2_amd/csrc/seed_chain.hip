@@ -199,6 +199,32 @@ __device__ void heap_down(uint64_t *h, int i, int n)
 	h[i] = tmp;
 }
 
+// skip_seed (map.c:78-100) for one index hit rr of a query minimizer at qp (pos<<1 | strand).  The reference compares the read's
+// name with the target's (strcmp); here both are ranks among the distinct sorted reference names: cmp > 0 <=> rank < nm_lb,
+// cmp == 0 <=> rank == nm_eq.  *is_self: same-strand hit of a read on its own copy in the index (MM_SEED_SELF).
+__device__ __forceinline__ bool skip_hit(int64_t flag, uint64_t rr, uint32_t qp, int qlen, int32_t nm_lb, int32_t nm_eq, const DevIndex &I, bool *is_self)
+{
+	*is_self = false;
+	const bool fwd = (rr & 1) == (qp & 1);
+	if (nm_lb >= 0 && (flag & (ref::F_NO_DIAG | ref::F_NO_DUAL))) {
+		const uint32_t rid = (uint32_t)(rr >> 32);
+		const int32_t rank = I.name_rank[rid];
+		if ((flag & ref::F_NO_DIAG) && rank == nm_eq && (int)I.seq_len[rid] == qlen) {
+			if ((uint32_t)rr >> 1 == qp >> 1) return true; // the diagonal itself
+			if (fwd) *is_self = true;
+		}
+		if ((flag & ref::F_NO_DUAL) && rank < nm_lb) return true; // each pair once: the read's name sorts after the target's
+	}
+	if (fwd ? (flag & ref::F_REV_ONLY) != 0 : (flag & ref::F_FOR_ONLY) != 0) return true;
+	return false;
+}
+
+// the per-read inputs of skip_hit: nm_lb < 0 switches the name rules off (no read names in this batch, or no reference names)
+#define HIT_RULES_SETUP() \
+	const bool name_rules = (P.flag & (ref::F_NO_DIAG | ref::F_NO_DUAL)) && B.name_lb && I.name_rank; \
+	const int32_t nm_lb = name_rules ? B.name_lb[r] : -1, nm_eq = name_rules ? B.name_eq[r] : -1; \
+	const bool hit_rules = (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY)) || nm_lb >= 0
+
 __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, DevIndex I, SeedChainParams P)
 {
 	__shared__ uint32_t s_hist[4][HIST_N];
@@ -211,6 +237,7 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 	int n = (int)B.mz_cnt[r];
 	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
 	uint32_t *hist = s_hist[wave];
+	HIT_RULES_SETUP();
 
 	// ---- query-side filter of over-represented minimizers (mm_seed_mz_flt, seed.c:5-28) ----
 	if (P.q_occ_frac > 0.0f && n > P.mid_occ && P.mid_occ > 0) {
@@ -331,13 +358,13 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 		const int i = base + lane;
 		const bool kept = i < n_m0 && !(sd_info[i] & SD_FLT);
 		uint32_t c = kept ? sd_n[i] : 0;
-		if (kept && (P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY))) { // --for-only / --rev-only: hits on the other strand are skipped (skip_seed, map.c:91-97)
+		if (kept && hit_rules) { // hits that skip_seed (map.c:78-100) drops are not counted
 			const uint64_t *cr = I.pos + sd_off[i];
 			const uint32_t qp = sd_qpos[i];
 			uint32_t pass = 0;
 			for (uint32_t h = 0; h < c; ++h) {
-				const bool fwd = (cr[h] & 1) == (qp & 1);
-				if (fwd ? !(P.flag & ref::F_REV_ONLY) : !(P.flag & ref::F_FOR_ONLY)) ++pass;
+				bool is_self;
+				if (!skip_hit(P.flag, cr[h], qp, qlen, nm_lb, nm_eq, I, &is_self)) ++pass;
 			}
 			c = pass;
 		}
@@ -371,6 +398,7 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 	const uint32_t *sd_n = B.sd_n + mo, *sd_off = B.sd_off + mo, *sd_aoff = B.sd_aoff + mo, *sd_qpos = B.sd_qpos + mo, *sd_info = B.sd_info + mo;
 	const int n_m0 = (int)B.n_seedhit[r];
 	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
+	HIT_RULES_SETUP();
 	uint64_t *akey = B.sort_key_in + B.a_off[r], *aval = B.sort_val_in + B.a_off[r];
 	const uint64_t read_tag = (uint64_t)r << (33 + B.rid_bits); // composite sort key: read | strand | rid | rpos (see launch_anchor_sort)
 	uint64_t *mp = B.mini_pos + B.mp_off[r];
@@ -380,12 +408,12 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 		const uint32_t info = sd_info[i], span = info & 0xff, qp = sd_qpos[i], cnt = sd_n[i];
 		mp[info >> 10] = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
 		const uint64_t *cr = I.pos + sd_off[i];
-		const bool one_strand = P.flag & (ref::F_FOR_ONLY | ref::F_REV_ONLY);
 		uint32_t w = 0; // anchors written for this seed
 		for (uint32_t c = 0; c < cnt; ++c) {
 			const uint64_t rr = cr[c];
 			const uint32_t rpos = (uint32_t)rr >> 1;
-			if (one_strand && (((rr & 1) == (qp & 1)) ? (P.flag & ref::F_REV_ONLY) != 0 : (P.flag & ref::F_FOR_ONLY) != 0)) continue;
+			bool is_self = false;
+			if (hit_rules && skip_hit(P.flag, rr, qp, qlen, nm_lb, nm_eq, I, &is_self)) continue;
 			Anchor p;
 			if ((rr & 1) == (qp & 1)) { // same strand
 				p.x = (rr & 0xffffffff00000000ULL) | rpos;
@@ -395,6 +423,7 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
 			}
 			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
+			if (is_self) p.y |= ref::SEED_SELF;
 			akey[ao + w] = read_tag | (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL);
 			aval[ao + w] = p.y;
 			++w;

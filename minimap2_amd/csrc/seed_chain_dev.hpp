@@ -14,6 +14,9 @@ struct DevIndex {             // device mirror of FlatIndex
 	const uint64_t *pos;
 	const uint32_t *S;
 	int bucket_bits, key_shift;
+	// all-vs-all rules (skip_seed, map.c:81-91): rank of each sequence's name among the distinct sorted names, and its length
+	const int32_t *name_rank;
+	const uint32_t *seq_len;
 };
 
 struct SeedChainBuffers {     // all device pointers; per-read slices addressed through the offset arrays
@@ -21,6 +24,9 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	const uint64_t *seq_off;  // n_reads+1: base offset of read r in the ASCII pool; the nt4 pool places it at 2*seq_off[r]
 	const char *ascii;
 	uint8_t *qpool;           // nt4 forward | reverse complement per read
+	// per read, for the all-vs-all rules: number of distinct reference names that sort before the read's name, and the rank of
+	// the reference name equal to it (-1: none).  Null when the batch carries no read names.
+	const int32_t *name_lb, *name_eq;
 	// minimizers
 	uint32_t *mz_cnt;         // n_reads
 	const uint64_t *mz_off;   // n_reads (+1): first minimizer slot of each read (the read's base offset: at most one minimizer per base)

@@ -85,13 +85,19 @@ typedef const uint64_t *(*ora_idx_get_f)(const void *idx, uint64_t minier, int *
 
 /* Seeding of one read: mm_seed_mz_flt (seed.c:5-28) + mm_collect_matches (seed.c:98-132, incl. mm_seed_collect_all
  * :30-52 and mm_seed_select :56-96) + the anchor expansion and sort of collect_seed_hits (map.c:168-204; skip_seed
- * :78-100 restricted to the FOR_ONLY/REV_ONLY flags - the qname-dependent NO_DIAG/NO_DUAL rules are not restated).
+ * :78-100; the qname-dependent NO_DIAG/NO_DUAL rules need the _named variant).
  * mv[0..n_mv) are the read's minimizers (modified in place by the query-occurrence filter).
  * Outputs: anchors (malloc'd, *n_a entries, sorted with the reference's unstable sort), mini_pos (malloc'd,
  * *n_mini_pos entries), *rep_len.  Returns the number of minimizers left after the filter. */
 int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_flag, int qlen, int mid_occ, int max_max_occ, int occ_dist,
                               float q_occ_frac, ora128_t *mv, int64_t n_mv, ora128_t **anchors, int64_t *n_a,
                               uint64_t **mini_pos, int *n_mini_pos, int *rep_len);
+/* the same with the all-vs-all rules of skip_seed (map.c:81-91): qname is the read's name, seq_name returns the name and length
+ * of reference sequence rid.  Either may be null (then the rules are off, as in the reference when qname is null). */
+typedef const char *(*ora_seq_name_f)(const void *idx, uint32_t rid, uint32_t *len);
+int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const char *qname, ora_seq_name_f seq_name, int64_t opt_flag, int qlen,
+                                    int mid_occ, int max_max_occ, int occ_dist, float q_occ_frac, ora128_t *mv, int64_t n_mv,
+                                    ora128_t **anchors, int64_t *n_a, uint64_t **mini_pos, int *n_mini_pos, int *rep_len);
 
 #ifdef __cplusplus
 }

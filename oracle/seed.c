@@ -4,9 +4,12 @@
 #include <string.h>
 #include "oracle.h"
 
+#define F_NO_DIAG  0x001LL
+#define F_NO_DUAL  0x002LL
 #define F_FOR_ONLY 0x100000LL
 #define F_REV_ONLY 0x200000LL
 #define SEED_TANDEM (1ULL << 42)
+#define SEED_SELF   (1ULL << 43)
 #define MAX_HIGH_OCC 128
 
 typedef struct { uint32_t n, q_pos, q_span, flt, seg_id, is_tandem; const uint64_t *cr; } seed_t;
@@ -57,6 +60,14 @@ static void thin_high_occ(int32_t n, seed_t *a, int len, int max_occ, int max_ma
 int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_flag, int qlen, int mid_occ, int max_max_occ, int occ_dist,
                               float q_occ_frac, ora128_t *mv, int64_t n_mv, ora128_t **anchors, int64_t *n_a_out,
                               uint64_t **mini_pos_out, int *n_mini_pos_out, int *rep_len_out)
+{
+	return ora_collect_seed_hits_named(idx, get, 0, 0, opt_flag, qlen, mid_occ, max_max_occ, occ_dist, q_occ_frac, mv, n_mv, anchors, n_a_out,
+	                                   mini_pos_out, n_mini_pos_out, rep_len_out);
+}
+
+int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const char *qname, ora_seq_name_f seq_name, int64_t opt_flag, int qlen,
+                                    int mid_occ, int max_max_occ, int occ_dist, float q_occ_frac, ora128_t *mv, int64_t n_mv,
+                                    ora128_t **anchors, int64_t *n_a_out, uint64_t **mini_pos_out, int *n_mini_pos_out, int *rep_len_out)
 {
 	int64_t i, j, n_a = 0, k;
 	int32_t n_m0 = 0, n_m = 0, rep_st = 0, rep_en = 0, rep_len = 0, n_mini_pos = 0;
@@ -122,7 +133,18 @@ int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_fl
 			const uint64_t r = q->cr[c];
 			const int32_t rpos = (int32_t)((uint32_t)r >> 1);
 			const int fwd = (r & 1) == (q->q_pos & 1);
+			int is_self = 0;
 			ora128_t *p;
+			if (qname && seq_name && (opt_flag & (F_NO_DIAG | F_NO_DUAL))) { /* all-vs-all rules (skip_seed, map.c:81-91) */
+				uint32_t tl = 0;
+				const char *tn = seq_name(idx, (uint32_t)(r >> 32), &tl);
+				const int cmp = strcmp(qname, tn);
+				if ((opt_flag & F_NO_DIAG) && cmp == 0 && (int)tl == qlen) {
+					if ((uint32_t)r >> 1 == q->q_pos >> 1) continue; /* the diagonal itself */
+					if (fwd) is_self = 1;
+				}
+				if ((opt_flag & F_NO_DUAL) && cmp > 0) continue; /* each pair once */
+			}
 			if (opt_flag & (F_FOR_ONLY | F_REV_ONLY)) {
 				if (fwd && (opt_flag & F_REV_ONLY)) continue;
 				if (!fwd && (opt_flag & F_FOR_ONLY)) continue;
@@ -137,6 +159,7 @@ int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_fl
 			}
 			p->y |= (uint64_t)q->seg_id << 48;
 			if (q->is_tandem) p->y |= SEED_TANDEM;
+			if (is_self) p->y |= SEED_SELF;
 		}
 	}
 	free(m);

@@ -17,6 +17,12 @@ namespace mm2amd {
 namespace {
 
 const uint64_t *flat_get(const void *idx, uint64_t minier, int *n) { return ((const FlatIndex *)idx)->get(minier, n); }
+const char *flat_name(const void *idx, uint32_t rid, uint32_t *len)
+{
+	const FlatIndex *fi = (const FlatIndex *)idx;
+	*len = fi->seq_len[rid];
+	return fi->names[rid].c_str();
+}
 
 class CheckBackend : public Backend {
 public:
@@ -51,7 +57,7 @@ public:
 			uint64_t *mp = nullptr;
 			int64_t n_a = 0;
 			int n_mp = 0, rep_len = 0;
-			ora_collect_seed_hits(&fi_, flat_get, p.flag, len, p.mid_occ, p.max_max_occ, p.occ_dist, p.q_occ_frac, mv.data(), n_mv, &a, &n_a, &mp, &n_mp, &rep_len);
+			ora_collect_seed_hits_named(&fi_, flat_get, reads_[i].name, fi_.names.empty() ? nullptr : flat_name, p.flag, len, p.mid_occ, p.max_max_occ, p.occ_dist, p.q_occ_frac, mv.data(), n_mv, &a, &n_a, &mp, &n_mp, &rep_len);
 			ReadChains &c = out[i - (size_t)lo];
 			c.rep_len = rep_len;
 			c.mini_pos.assign(mp, mp + n_mp);

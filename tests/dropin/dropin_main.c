@@ -104,6 +104,10 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--no-hash-name") == 0) mopt.flag |= MM_F_NO_HASH_NAME;
 		else if (strcmp(argv[k], "--for-only") == 0) mopt.flag |= MM_F_FOR_ONLY;
 		else if (strcmp(argv[k], "--rev-only") == 0) mopt.flag |= MM_F_REV_ONLY;
+		else if (strcmp(argv[k], "-D") == 0) mopt.flag |= MM_F_NO_DIAG; /* main.c:180 */
+		else if (strcmp(argv[k], "-X") == 0) mopt.flag |= MM_F_ALL_CHAINS | MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_NO_LJOIN; /* main.c:182 */
+		else if (strcmp(argv[k], "--dual=no") == 0) mopt.flag |= MM_F_NO_DUAL; /* main.c:300 */
+		else if (strcmp(argv[k], "--dual=yes") == 0) mopt.flag &= ~(int64_t)MM_F_NO_DUAL;
 		else if (strcmp(argv[k], "--alt") == 0) alt_fn = argv[++k];
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }

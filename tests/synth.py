@@ -168,6 +168,28 @@ def make_weird(outdir, seed=71):
     return ref, rd
 
 
+def make_overlaps(outdir, seed=81, n_reads=60, genome=120000):
+    """An all-vs-all read set: noisy reads drawn densely from a small genome (every read overlaps several others, on either
+    strand), names in an order unrelated to position, two reads sharing one name, one read contained in another, a read
+    that is an exact copy of another under a different name, and a read with an internal duplication.  The same file is target and query.  Returns reads.fa."""
+    rng = np.random.default_rng(seed)
+    g = gen_reference(rng, genome, 1)
+    reads = gen_reads(rng, g, n_reads, 8000, 2000, 0.06, min_len=2500)
+    names = ["rd%03d" % i for i in rng.permutation(len(reads))]
+    names[7] = names[3]                      # duplicate name, different sequences
+    reads.append(reads[5][1000:3500].copy()) # contained read
+    names.append("inner")
+    reads.append(reads[9].copy())            # identical sequence, another name
+    names.append("twin")
+    u = reads[11][500:2300]                  # a read with an internal duplication: off-diagonal hits on itself (MM_SEED_SELF)
+    reads.append(np.concatenate([reads[11][:2300], rng.integers(0, 4, 900, dtype=np.uint8), mutate_read(rng, u, 0.03), reads[11][2300:4000]]))
+    names.append("selfdup")
+    os.makedirs(outdir, exist_ok=True)
+    fa = os.path.join(outdir, "ovl.fa")
+    write_fasta(fa, names, reads)
+    return fa
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):

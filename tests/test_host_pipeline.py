@@ -221,3 +221,13 @@ def test_one_strand_only(tmp_path, flag):
     out = _pair(["-x", "map-ont", "-c", flag], ref, rd)
     strands = {l.split(b"\t")[4] for l in out.split(b"\n") if l}
     assert strands == ({b"+"} if flag == "--for-only" else {b"-"})
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args", [["-x", "ava-ont"], ["-x", "ava-pb"], ["-x", "ava-ont", "-c"], ["-x", "map-ont", "-D", "-c"],
+                                  ["-x", "map-ont", "--dual=no"], ["-X", "-a"]])
+def test_all_vs_all(args, tmp_path):  # skip_seed's read-name rules (map.c:81-91), MM_SEED_SELF (align.c:760-767)
+    import synth
+    fa = synth.make_overlaps(str(tmp_path))
+    out = _pair(args, fa, fa)
+    assert out.count(b"\n") > 50
