@@ -347,6 +347,25 @@ static void join_over_gap_clusters(int as1, int cnt1, Anchor *a, int min_gap, in
 	}
 }
 
+// the best-scoring run of consecutive seeds on one diagonal (mm_max_stretch, align.c:563-589): what a short read is aligned from
+static void longest_ungapped_run(const Reg &r, const Anchor *a, int32_t *as, int32_t *cnt)
+{
+	*as = r.as, *cnt = r.cnt;
+	if (r.cnt < 2) return;
+	int32_t max_score = -1, max_i = -1, max_len = 0, score = span_of(a[r.as]), len = 1, i;
+	for (i = r.as + 1; i < r.as + r.cnt; ++i) {
+		const int32_t q_span = span_of(a[i]);
+		const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+		if (lq == lr) score += lq < q_span ? lq : q_span, ++len;
+		else {
+			if (score > max_score) max_score = score, max_len = len, max_i = i - len;
+			score = q_span, len = 1;
+		}
+	}
+	if (score > max_score) max_score = score, max_len = len, max_i = i - len;
+	*as = max_i, *cnt = max_len;
+}
+
 static void trim_bad_ends(const Reg &r, const Anchor *a, int bw, int min_match, int32_t *as, int32_t *cnt) // mm_fix_bad_ends, align.c:527-561
 {
 	*as = r.as, *cnt = r.cnt;
@@ -502,21 +521,27 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	t.planned = true;
 	t.r2.cnt = 0;
 	if (r.cnt == 0) { t.done = true; return; }
-	if (opt_.flag & (F_SR | F_SR_RNA | F_QSTRAND)) throw std::runtime_error("[mm2amd] sr/qstrand alignment is not supported by this build");
-	const bool is_splice = opt_.flag & F_SPLICE;
+	if (opt_.flag & (F_SR_RNA | F_QSTRAND)) throw std::runtime_error("[mm2amd] splice:sr/qstrand alignment is not supported by this build");
+	const bool is_splice = opt_.flag & F_SPLICE, is_sr = opt_.flag & F_SR;
 	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 	const int32_t ref_len = (int32_t)fi_.seq_len[rid];
 	t.rid = rid, t.rev = rev;
 	int32_t as1, cnt1, rs, qs, re, qe, rs0, qs0, re0, qe0, rs1, qs1, re1, qe1, l;
 
-	if (!(opt_.flag & F_NO_END_FLT)) {
-		if (is_splice) trim_bad_ends_splice(opt_, fi_, r, mat_, qlen, ra.q4, a, tbuf_, &as1, &cnt1);
-		else trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
-	} else as1 = r.as, cnt1 = r.cnt;
-	drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
-	join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
-	anchor_boundary(fi_, ra.q4, qlen, a[as1], &rs, &qs);
-	anchor_boundary(fi_, ra.q4, qlen, a[as1 + cnt1 - 1], &re, &qe);
+	if (is_sr) { // align.c:664-669: a short read is aligned from its best run of seeds on one diagonal
+		longest_ungapped_run(r, a, &as1, &cnt1);
+		rs = (int32_t)a[as1].x + 1 - span_of(a[as1]), qs = (int32_t)a[as1].y + 1 - span_of(a[as1]);
+		re = (int32_t)a[as1 + cnt1 - 1].x + 1, qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+	} else {
+		if (!(opt_.flag & F_NO_END_FLT)) {
+			if (is_splice) trim_bad_ends_splice(opt_, fi_, r, mat_, qlen, ra.q4, a, tbuf_, &as1, &cnt1);
+			else trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
+		} else as1 = r.as, cnt1 = r.cnt;
+		drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
+		join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
+		anchor_boundary(fi_, ra.q4, qlen, a[as1], &rs, &qs);
+		anchor_boundary(fi_, ra.q4, qlen, a[as1 + cnt1 - 1], &re, &qe);
+	}
 	assert(cnt1 > 0);
 	t.ksw_flag = 0;
 	if (is_splice) { // align.c:684-689 and :354
@@ -527,6 +552,16 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	}
 
 	// how far the two extensions may reach (align.c:695-767)
+	if (is_sr) { // the whole read, and as much reference as its unaligned ends could span with gaps (align.c:696-704)
+		qs0 = 0, qe0 = qlen;
+		l = qs;
+		l += l * opt_.a + opt_.end_bonus > opt_.q ? (l * opt_.a + opt_.end_bonus - opt_.q) / opt_.e : 0;
+		rs0 = rs - l > 0 ? rs - l : 0;
+		l = qlen - qe;
+		l += l * opt_.a + opt_.end_bonus > opt_.q ? (l * opt_.a + opt_.end_bonus - opt_.q) / opt_.e : 0;
+		re0 = re + l < ref_len ? re + l : ref_len;
+		rs1 = qs1 = re1 = qe1 = 0;
+	} else {
 	rs0 = (int32_t)a[r.as].x + 1 - span_of(a[r.as]);
 	qs0 = (int32_t)a[r.as].y + 1 - span_of(a[r.as]);
 	if (rs0 < 0) rs0 = 0;
@@ -579,6 +614,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 		re1 = re1 < re + l ? re1 : re + l;
 		re0 = re0 > re1 ? re0 : re1;
 	} else re0 = re, qe0 = qe;
+	}
 	if (a[r.as].y & SEED_SELF) {
 		int max_ext = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs;
 		if (r.rs - rs0 > max_ext) rs0 = r.rs - max_ext;
@@ -599,13 +635,38 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 		t.win.push_back(w), t.has_left = true;
 	}
 	t.rs = rs, t.qs = qs; // start of the first gap window
-	for (int32_t i = 1; i < cnt1; ++i) {
+	for (int32_t i = is_sr ? cnt1 - 1 : 1; i < cnt1; ++i) { // a short read has one window, from its first seed to its last (align.c:803)
 		if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
-		anchor_boundary(fi_, ra.q4, qlen, a[as1 + i], &re, &qe);
+		if (is_sr) re = (int32_t)a[as1 + i].x + 1, qe = (int32_t)a[as1 + i].y + 1;
+		else anchor_boundary(fi_, ra.q4, qlen, a[as1 + i], &re, &qe);
 		if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt_.min_ksw_len && re - rs >= opt_.min_ksw_len)) {
 			Window w; w.kind = W_GAP, w.qs = qs, w.qe = qe, w.rs = rs, w.re = re, w.anchor_i = i;
 			w.bw = bw_long_;
 			if (a[as1 + i].y & SEED_LONG_JOIN) w.bw = qe - qs > re - rs ? qe - qs : re - rs;
+			w.job = w.saved = -1;
+			if (is_sr) { // align.c:823-833: the seeds lie on one diagonal; if the ungapped alignment beats any gapped one, it is the result
+				assert(qe - qs == re - rs);
+				const int32_t len = qe - qs, max_gapped_score = (len - 2) * opt_.a - 2 * (opt_.q + opt_.e);
+				const uint8_t *qseq = ra.q4 + (size_t)rev * qlen + qs;
+				tbuf_.resize(len);
+				fi_.getseq(rid, rs, re, tbuf_.data());
+				int32_t score = 0;
+				for (int32_t j = 0; j < len; ++j) {
+					if (qseq[j] >= 4 || tbuf_[j] >= 4) score += opt_.sc_ambi > 0 ? -opt_.sc_ambi : opt_.sc_ambi;
+					else score += qseq[j] == tbuf_[j] ? opt_.a : -opt_.b;
+				}
+				if (score > max_gapped_score) {
+					SavedResult sr;
+					memset(&sr.res, 0, sizeof sr.res);
+					sr.res.max_q = sr.res.max_t = sr.res.mqe_t = sr.res.mte_q = -1; // ksw_reset_extz (ksw2.h:164-169)
+					sr.res.mqe = sr.res.mte = KSW_NEG_INF;
+					sr.res.score = score, sr.res.n_cigar = 1;
+					sr.res.zd_max = KSW_ZD_NONE, sr.res.zd_t0 = sr.res.zd_t1 = sr.res.zd_q0 = sr.res.zd_q1 = -1;
+					sr.cigar.assign(1, (uint32_t)len << 4 | 0u);
+					t.saved.push_back(std::move(sr));
+					w.saved = (int32_t)t.saved.size() - 1;
+				}
+			}
 			t.win.push_back(w);
 			rs = re, qs = qe;
 		}
@@ -651,6 +712,7 @@ void Aligner::schedule(ReadAlign &ra, std::vector<KswJob> &jobs)
 			plan_region(ra, t);
 			if (t.done) continue;
 			for (Window &w : t.win) {
+				if (w.saved >= 0) continue; // resolved while planning (the ungapped short-read case)
 				if (w.kind == W_LEFT) add_job(ra, t, w, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, t.r.split_inv ? opt_.zdrop_inv : opt_.zdrop, opt_.end_bonus, jobs);
 				else if (w.kind == W_GAP) add_job(ra, t, w, KSW_APPROX_MAX, opt_.zdrop, -1, jobs);
 				else add_job(ra, t, w, KSW_EXTZ_ONLY, opt_.zdrop, opt_.end_bonus, jobs);
@@ -795,7 +857,7 @@ void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
 		tbuf_.resize(t.re1 - t.rs1);
 		fi_.getseq(t.rid, t.rs1, t.re1, tbuf_.data());
 		const uint8_t *qseq = ra.q4 + (size_t)r.rev * qlen + t.qs1;
-		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, true);
+		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, !(opt_.flag & (F_SR | F_SR_RNA)));
 		if (t.rev && r.p->trans_strand) r.p->trans_strand ^= 3; // align.c:907-908
 	}
 	t.saved.clear();

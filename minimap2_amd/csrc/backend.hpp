@@ -8,18 +8,36 @@
 #include "flat_index.hpp"
 #include "ksw_dev.hpp"
 
+#ifdef __HIPCC__
+#define MM2AMD_HD __host__ __device__
+#else
+#define MM2AMD_HD
+#endif
+
 namespace mm2amd {
 
 struct SeedChainParams {          // what mm_map_frag_core passes to seeding and chaining (map.c:250-281)
 	int k, w, is_hpc;
 	int mid_occ, max_max_occ, occ_dist;
+	int q_mid_occ;                // threshold of the query-side filter mm_seed_mz_flt (map.c:251): mm_mapopt_t::mid_occ also in the max_occ pass (map.c:311)
 	float q_occ_frac;
 	int64_t flag;                 // mm_mapopt_t::flag (FOR_ONLY / REV_ONLY / NO_DIAG ... for skip_seed)
-	int max_gap_ref, max_gap_qry, bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+	int max_gap, max_gap_ref, max_frag_len, is_sr; // mm_mapopt_t::max_gap / max_gap_ref / max_frag_len as given, MM_F_SR: see chain_gaps()
+	int bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
 	float chn_pen_gap, chn_pen_skip;
 	int is_cdna;
 	int anchors_only = 0;         // 1: stop after the anchor sort and return every read's sorted anchors (n_u = 0): the caller chains them (MM_F_RMQ)
 };
+
+// the two chaining distance limits of a read of qlen bases (map.c:262-271): the query-side limit grows with the read for short
+// reads, the reference-side limit follows max_frag_len when no explicit max_gap_ref is set
+MM2AMD_HD inline void chain_gaps(const SeedChainParams &p, int qlen, int *gap_ref, int *gap_qry)
+{
+	*gap_qry = p.is_sr && qlen > p.max_gap ? qlen : p.max_gap;
+	if (p.max_gap_ref > 0) *gap_ref = p.max_gap_ref;
+	else if (p.max_frag_len > 0) { const int g = p.max_frag_len - qlen; *gap_ref = g < p.max_gap ? p.max_gap : g; }
+	else *gap_ref = p.max_gap;
+}
 
 class Backend {
 public:
@@ -36,8 +54,9 @@ public:
 	virtual void set_active_lanes(int /*n*/) {}
 	// all-vs-all mapping (MM_F_NO_DIAG / MM_F_NO_DUAL): seed_chain() then applies skip_seed's read-name rules (map.c:81-91), which
 	// need the reads' names in begin_batch().  Call once, before the first batch.
-	// Returns false when the backend does not offer them.
-	virtual bool enable_name_rules() { return true; }
+	virtual void enable_name_rules() {}
+	// Device code paths that have not been run on hardware yet stay opt-in (see HipBackend); the mapper asks before using one.
+	virtual bool pending_paths_enabled() const { return true; }
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off

@@ -6,8 +6,10 @@
 // driver threads can keep different sub-batches in flight and the GPU stages of one overlap the host stages of another.
 #include <atomic>
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <thread>
@@ -77,13 +79,14 @@ public:
 	}
 
 	int n_lanes() const override { return n_lanes_; }
-	bool enable_name_rules() override
+	// The device side of the all-vs-all rules (skip_hit), of MM_F_HEAP_SORT (anchor_heap_order_kernel) and of the short-read
+	// chaining distances (chain_gaps) was written after this round's GPU budget ran out: it is checked against the reference
+	// through the host pipeline tests and a host build of the shared headers only, so it stays opt-in until
+	// tests/test_gpu_pending.py has passed on an MI355X.
+	bool pending_paths_enabled() const override { return getenv("MM2AMD_PENDING") != nullptr; }
+	void enable_name_rules() override
 	{
-		// the device side of the all-vs-all rules (skip_hit in seed_chain.hip) was written after this round's GPU budget ran out: it
-		// is checked against the reference through the host pipeline tests only, so it stays opt-in until tests/test_gpu_pending.py
-		// has passed on an MI355X
-		if (!getenv("MM2AMD_PENDING")) return false;
-		if (name_rules_ || fi_names_->empty()) return true;
+		if (name_rules_ || fi_names_->empty()) return;
 		const std::vector<std::string> &nm = *fi_names_;
 		sorted_names_ = nm;
 		std::sort(sorted_names_.begin(), sorted_names_.end());
@@ -96,7 +99,6 @@ public:
 		HIP_CHECK(hipStreamSynchronize(stream_));
 		I_.name_rank = d_name_rank_.p, I_.seq_len = d_ref_len_.p;
 		name_rules_ = true;
-		return true;
 	}
 	void set_active_lanes(int n) override { active_lanes_ = std::max(1, std::min(n, n_lanes_)); }
 	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
@@ -117,6 +119,8 @@ public:
 		d_seq_off_.ensure(n + 1);
 		HIP_CHECK(hipMemcpyAsync(d_ascii_.p, h, total, hipMemcpyHostToDevice, stream_));
 		HIP_CHECK(hipMemcpyAsync(d_seq_off_.p, seq_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+		read_names_.clear();
+		if (getenv("MM2AMD_SEED_DUMP")) for (size_t i = 0; i < n; ++i) read_names_.push_back(reads[i].name);
 		have_read_names_ = false;
 		if (name_rules_ && n > 0) { // strcmp(qname, target name) as two ranks per read (see skip_hit in seed_chain.hip)
 			have_read_names_ = true;
@@ -196,7 +200,25 @@ public:
 		B.f = ln.d_f.p, B.p = ln.d_p.p, B.t = ln.d_t.p;
 		// 3. anchors: expand, sort, chain
 		kp.begin(st); launch_seed_expand(B, I_, P, st); kp.end(st, "seed_expand_kernel", 24.0 * n_a);
-		launch_anchor_sort(B, n_a, end_bit, ln.d_sort_tmp.p, sort_tmp, st, &kp);
+		launch_anchor_sort(B, I_, P, n_a, end_bit, ln.d_sort_tmp.p, sort_tmp, st, &kp);
+		if (const char *dump = getenv("MM2AMD_SEED_DUMP")) { // diagnostics: every read's sorted anchors, as the reference's --print-seeds prints them (map.c:255-260)
+			std::vector<Anchor> all(n_a + 1);
+			HIP_CHECK(hipStreamSynchronize(st));
+			if (n_a) HIP_CHECK(hipMemcpy(all.data(), ln.d_anchors.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost));
+			static std::mutex dump_mu;
+			std::lock_guard<std::mutex> lk(dump_mu);
+			if (FILE *fp = fopen(dump, "a")) {
+				for (size_t i = 0; i < n; ++i) {
+					fprintf(fp, "QR\t%s\t%d\nRS\t%d\n", read_names_.empty() || !read_names_[lo + i] ? "*" : read_names_[lo + i], P.mid_occ, h_rep[i]);
+					for (uint64_t j = a_off[i]; j < a_off[i + 1]; ++j) {
+						const Anchor &a = all[j];
+						fprintf(fp, "SD\t%s\t%d\t%c\t%d\t%d\t%d\n", (*fi_names_)[a.x << 1 >> 33].c_str(), (int32_t)a.x, "+-"[a.x >> 63], (int32_t)a.y, (int32_t)(a.y >> 32 & 0xff),
+						        j == a_off[i] ? 0 : ((int32_t)a.y - (int32_t)all[j - 1].y) - ((int32_t)a.x - (int32_t)all[j - 1].x));
+					}
+				}
+				fclose(fp);
+			}
+		}
 		if (P.anchors_only) { // the caller chains (RMQ): hand over the sorted anchors as they are
 			Anchor *ha = ln.h_anchors.ensure(n_a + 1);
 			uint64_t *hmp = ln.h_minipos.ensure(n_mp + 1);
@@ -287,6 +309,7 @@ private:
 	const std::vector<uint32_t> *fi_seq_len_ = nullptr;
 	std::vector<std::string> sorted_names_;
 	std::vector<int32_t> name_key_;
+	std::vector<const char *> read_names_; // MM2AMD_SEED_DUMP only
 	DevBuf<int32_t> d_name_rank_, d_name_key_;
 	DevBuf<uint32_t> d_ref_len_;
 	PinBuf<char> h_ascii_;

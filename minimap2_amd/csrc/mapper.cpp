@@ -40,10 +40,13 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	const int64_t unsupported = F_SR | F_QSTRAND | F_HEAP_SORT | F_SR_RNA | F_INDEPEND_SEG | F_FRAG_MODE;
-	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment long reads (map-ont / map-hifi / splice / asm / ava class presets); sr, splice:sr, qstrand and heap-sort modes are not implemented");
-	if ((opt.flag & (F_NO_DIAG | F_NO_DUAL)) && !be.enable_name_rules()) // all-vs-all: skip_seed compares read and target names (map.c:81-91)
-		throw std::invalid_argument("[mm2amd] all-vs-all mapping (-X / -D / --dual=no, ava-* presets) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+	const int64_t unsupported = F_QSTRAND | F_SR_RNA | F_INDEPEND_SEG;
+	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr, --qstrand and multi-segment modes are not implemented");
+	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
+	const bool pending = (opt.flag & (F_NO_DIAG | F_NO_DUAL | F_SR | F_HEAP_SORT)) || (opt.max_gap_ref <= 0 && opt.max_frag_len > 0);
+	if (pending && !be.pending_paths_enabled())
+		throw std::invalid_argument("[mm2amd] all-vs-all (-X / -D / --dual=no, ava-*), short-read (sr) and --heap-sort / --frag mapping on the device are not validated on hardware yet; MM2AMD_PENDING=1 enables them");
+	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
@@ -80,17 +83,15 @@ void Mapper::run(std::vector<ReadResult> &out)
 	// chaining parameters (map.c:262-274); single segment, not sr
 	SeedChainParams sp;
 	sp.k = fi_.k, sp.w = fi_.w, sp.is_hpc = fi_.flag & I_HPC;
-	sp.mid_occ = opt_.mid_occ, sp.max_max_occ = opt_.max_max_occ, sp.occ_dist = opt_.occ_dist, sp.q_occ_frac = opt_.q_occ_frac;
+	sp.mid_occ = sp.q_mid_occ = opt_.mid_occ, sp.max_max_occ = opt_.max_max_occ, sp.occ_dist = opt_.occ_dist, sp.q_occ_frac = opt_.q_occ_frac;
 	sp.flag = opt_.flag;
-	sp.max_gap_qry = opt_.max_gap;
-	sp.max_gap_ref = opt_.max_gap_ref > 0 ? opt_.max_gap_ref : opt_.max_gap; // max_frag_len only matters for paired reads (qlen-dependent); handled below
+	sp.max_gap = opt_.max_gap, sp.max_gap_ref = opt_.max_gap_ref, sp.max_frag_len = opt_.max_frag_len, sp.is_sr = (opt_.flag & F_SR) ? 1 : 0; // per read: chain_gaps()
 	sp.bw = opt_.bw, sp.max_chain_skip = opt_.max_chain_skip, sp.max_chain_iter = opt_.max_chain_iter;
 	sp.min_cnt = opt_.min_cnt, sp.min_chain_score = opt_.min_chain_score;
 	sp.chn_pen_gap = (float)(opt_.chain_gap_scale * 0.01 * fi_.k);
 	sp.chn_pen_skip = (float)(opt_.chain_skip_scale * 0.01 * fi_.k);
 	sp.is_cdna = (opt_.flag & F_SPLICE) ? 1 : 0; // map.c:230,280
 	sp.anchors_only = (opt_.flag & F_RMQ) ? 1 : 0; // map.c:275-277: RMQ chaining runs on the host over the device-sorted anchors
-	if (opt_.max_gap_ref <= 0 && opt_.max_frag_len > 0) throw std::invalid_argument("[mm2amd] max_frag_len-derived chaining gap is a paired-end feature and is not implemented");
 
 	// Sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight) and are the
 	// unit of pipelining: each of the backend's lanes is driven by one host thread that takes the next sub-batch through all of
@@ -211,7 +212,9 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 					c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
 				}
 			}
-			res.frag_gap = sp.max_gap_ref, res.rep_len = c.rep_len;
+			int gap_ref, gap_qry;
+			chain_gaps(sp, qlen, &gap_ref, &gap_qry);
+			res.frag_gap = gap_ref, res.rep_len = c.rep_len; // map.c:317-318
 			RegVec &r0 = regs0[i];
 			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, false, r0);
 			if (fi_.n_alt) { // mm_mark_alt + re-sort with ALT hits handicapped (map.c:321-324)
@@ -222,11 +225,13 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
 				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
 			}
-			est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
-			filter_strand_retained(r0);
+			if (!(opt_.flag & F_SR)) { // map.c:333-336
+				est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
+				filter_strand_retained(r0);
+			}
 			if (!(opt_.flag & F_CIGAR)) { // mapping without base-level alignment: the chains are the hits (align_regs returns early, map.c:217)
 				res.regs = r0;
-				set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, opt_.flag & F_SPLICE);
+				set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, (opt_.flag & (F_SR | F_SR_RNA)) != 0, opt_.flag & F_SPLICE);
 				return;
 			}
 			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i], ds.q4.data() + ds.q4_off[i]);
@@ -289,7 +294,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), res.regs);
 				set_sam_pri(res.regs);
 			}
-			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, false, opt_.flag & F_SPLICE);
+			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, (opt_.flag & (F_SR | F_SR_RNA)) != 0, opt_.flag & F_SPLICE);
 		});
 		Trace::get().add(lane, "host:finish", t0, now());
 		stats.t_finish += now() - t0;

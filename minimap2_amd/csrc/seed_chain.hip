@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "seed_chain_dev.hpp"
+#include "heap_order.hpp"
 #include "sketch_dev.hpp"
 #include "kernel_prof.hpp"
 #include <hipcub/hipcub.hpp>
@@ -240,14 +241,14 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 	HIT_RULES_SETUP();
 
 	// ---- query-side filter of over-represented minimizers (mm_seed_mz_flt, seed.c:5-28) ----
-	if (P.q_occ_frac > 0.0f && n > P.mid_occ && P.mid_occ > 0) {
+	if (P.q_occ_frac > 0.0f && n > P.q_mid_occ && P.q_mid_occ > 0) {
 		for (int i = lane; i < HIST_N; i += 64) hist[i] = 0;
 		WAVE_SYNC();
 		for (int i = lane; i < n; i += 64) atomicAdd(&hist[(uint32_t)((mx[i] * 0x9E3779B97F4A7C15ull) >> 53)], 1u);
 		WAVE_SYNC();
 		const float thr = (float)n * P.q_occ_frac;
 		bool hot = false;
-		for (int i = lane; i < HIST_N; i += 64) { const uint32_t c = hist[i]; hot |= ((int)c > P.mid_occ && (float)c > thr); }
+		for (int i = lane; i < HIST_N; i += 64) { const uint32_t c = hist[i]; hot |= ((int)c > P.q_mid_occ && (float)c > thr); }
 		if (__ballot(hot)) { // exact counts, only for minimizers that fall into a crowded bucket
 			// pass 1: decide on the untouched list
 			for (int base = 0; base < n; base += 64) {
@@ -256,10 +257,10 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 					const uint64_t x = mx[i];
 					bool keep = true;
 					const uint32_t c = hist[(uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 53)];
-					if ((int)c > P.mid_occ && (float)c > thr) {
+					if ((int)c > P.q_mid_occ && (float)c > thr) {
 						int cnt = 0;
 						for (int j = 0; j < n; ++j) cnt += (mx[j] == x);
-						keep = !(cnt > P.mid_occ && (float)cnt > thr);
+						keep = !(cnt > P.q_mid_occ && (float)cnt > thr);
 					}
 					sd_info[i] = keep ? 1u : 0u;
 				}
@@ -604,6 +605,47 @@ __global__ void __launch_bounds__(64) anchor_tie_fix_kernel(SeedChainBuffers B)
 	}
 }
 
+// MM_F_HEAP_SORT (collect_seed_hits_heap, map.c:102-166): reads that have two anchors with equal x get the order the reference's
+// heap merge gives them (heap_order.hpp); one thread per such read, the minimizer arrays (dead after seed_collect) are the heap.
+__global__ void __launch_bounds__(64) anchor_heap_order_kernel(SeedChainBuffers B, DevIndex I, SeedChainParams P)
+{
+	for (int r = blockIdx.x * 64 + threadIdx.x; r < B.n_reads; r += gridDim.x * 64) {
+		if (!B.tie_flag[r]) continue;
+		const uint64_t mo = B.mz_off[r], ao = B.a_off[r];
+		const uint32_t *sd_n = B.sd_n + mo, *sd_off = B.sd_off + mo, *sd_aoff = B.sd_aoff + mo, *sd_qpos = B.sd_qpos + mo, *sd_info = B.sd_info + mo;
+		const uint32_t n_m0 = B.n_seedhit[r];
+		const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
+		const uint32_t n = (uint32_t)(B.a_off[r + 1] - ao);
+		HIT_RULES_SETUP();
+		Anchor *out = B.anchors + ao;
+		uint32_t n_for = 0, n_rev = 0;
+		heap_merge_order(n_m0, B.mz_x + mo, B.mz_y + mo,
+			[&](uint32_t i, uint32_t *cnt) { *cnt = sd_aoff[i] == 0xffffffffu ? 0u : sd_n[i]; return I.pos + sd_off[i]; },
+			[&](uint32_t i, uint64_t rr) {
+				const uint32_t info = sd_info[i], span = info & 0xff, qp = sd_qpos[i], rpos = (uint32_t)rr >> 1;
+				bool is_self = false;
+				if (hit_rules && skip_hit(P.flag, rr, qp, qlen, nm_lb, nm_eq, I, &is_self)) return;
+				Anchor p;
+				if ((rr & 1) == (qp & 1)) {
+					p.x = (rr & 0xffffffff00000000ULL) | rpos;
+					p.y = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
+				} else {
+					p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
+					p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
+				}
+				if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
+				if (is_self) p.y |= ref::SEED_SELF;
+				if (p.x >> 63) { if (n_for + n_rev < n) out[n - (++n_rev)] = p; }
+				else if (n_for + n_rev < n) out[n_for++] = p;
+			});
+		for (uint32_t j = 0; j < n_rev >> 1; ++j) { // the other-strand hits were laid down back to front (map.c:155-160)
+			const Anchor t = out[n - 1 - j];
+			out[n - 1 - j] = out[n - n_rev + j];
+			out[n - n_rev + j] = t;
+		}
+	}
+}
+
 size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit)
 {
 	size_t bytes = 0;
@@ -612,7 +654,8 @@ size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit)
 	return bytes;
 }
 
-void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream, KernelProfiler *kp)
+void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream,
+                        KernelProfiler *kp)
 {
 	hipStream_t s = (hipStream_t)stream;
 	KernelProfiler none;
@@ -627,6 +670,13 @@ void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, vo
 	kp->begin(s);
 	hipLaunchKernelGGL(anchor_finalize_kernel, dim3(grid), dim3(256), 0, s, B, n_a);
 	kp->end(s, "anchor_finalize_kernel", 32.0 * n_a);
+	if (P.flag & ref::F_HEAP_SORT) { // equal-x order of the heap merge instead of the radix sort's
+		kp->begin(s);
+		hipLaunchKernelGGL(anchor_heap_order_kernel, dim3(std::min((B.n_reads + 63) / 64, 4096)), dim3(64), 0, s, B, I, P);
+		kp->end(s, "anchor_heap_order_kernel", 0.0);
+		HIP_CHECK(hipGetLastError());
+		return;
+	}
 	const size_t lds = (size_t)12 * TIE_LDS_CAP + 3 * 256 * 4 + TIE_MAX_KEYS * 8 + TIE_STACK * sizeof(TieFrame) + 64;
 	static bool attr_set = false;
 	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_tie_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
@@ -688,7 +738,8 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	const Anchor *a = B.anchors + B.a_off[r];
 	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
 	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
-	int32_t max_dist_x = P.max_gap_ref, max_dist_y = P.max_gap_qry;
+	int32_t max_dist_x, max_dist_y;
+	chain_gaps(P, (int)(B.seq_off[r + 1] - B.seq_off[r]), &max_dist_x, &max_dist_y);
 	const int32_t bw = P.bw;
 	if (max_dist_x < bw) max_dist_x = bw;
 	if (max_dist_y < bw && !P.is_cdna) max_dist_y = bw;

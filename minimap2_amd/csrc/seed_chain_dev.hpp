@@ -58,7 +58,8 @@ void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const See
 void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
 size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit);
 class KernelProfiler;
-void launch_anchor_sort(const SeedChainBuffers &B, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream, KernelProfiler *kp);
+void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream,
+                        KernelProfiler *kp);
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 

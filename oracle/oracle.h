@@ -93,10 +93,12 @@ int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_fl
                               float q_occ_frac, ora128_t *mv, int64_t n_mv, ora128_t **anchors, int64_t *n_a,
                               uint64_t **mini_pos, int *n_mini_pos, int *rep_len);
 /* the same with the all-vs-all rules of skip_seed (map.c:81-91): qname is the read's name, seq_name returns the name and length
- * of reference sequence rid.  Either may be null (then the rules are off, as in the reference when qname is null). */
+ * of reference sequence rid.  Either may be null (then the rules are off, as in the reference when qname is null).
+ * q_mid_occ is the threshold of the query-side filter, mid_occ that of the index-side one: they differ in the second seeding
+ * pass of map.c:311, which raises the latter to max_occ but works on the minimizers the first pass already filtered (:251). */
 typedef const char *(*ora_seq_name_f)(const void *idx, uint32_t rid, uint32_t *len);
 int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const char *qname, ora_seq_name_f seq_name, int64_t opt_flag, int qlen,
-                                    int mid_occ, int max_max_occ, int occ_dist, float q_occ_frac, ora128_t *mv, int64_t n_mv,
+                                    int q_mid_occ, int mid_occ, int max_max_occ, int occ_dist, float q_occ_frac, ora128_t *mv, int64_t n_mv,
                                     ora128_t **anchors, int64_t *n_a, uint64_t **mini_pos, int *n_mini_pos, int *rep_len);
 
 #ifdef __cplusplus

@@ -7,6 +7,7 @@
 #define F_NO_DIAG  0x001LL
 #define F_NO_DUAL  0x002LL
 #define F_FOR_ONLY 0x100000LL
+#define F_HEAP_SORT 0x400000LL
 #define F_REV_ONLY 0x200000LL
 #define SEED_TANDEM (1ULL << 42)
 #define SEED_SELF   (1ULL << 43)
@@ -57,16 +58,63 @@ static void thin_high_occ(int32_t n, seed_t *a, int len, int max_occ, int max_ma
 	}
 }
 
+/* one index hit r of seed q as an anchor; returns 0 when skip_seed (map.c:78-100) drops it */
+static int make_anchor(ora128_t *p, uint64_t r, const seed_t *q, const char *qname, ora_seq_name_f seq_name, const void *idx, int64_t opt_flag, int qlen)
+{
+	const int32_t rpos = (int32_t)((uint32_t)r >> 1);
+	const int fwd = (r & 1) == (q->q_pos & 1);
+	int is_self = 0;
+	if (qname && seq_name && (opt_flag & (F_NO_DIAG | F_NO_DUAL))) { /* all-vs-all rules (map.c:81-91) */
+		uint32_t tl = 0;
+		const char *tn = seq_name(idx, (uint32_t)(r >> 32), &tl);
+		const int cmp = strcmp(qname, tn);
+		if ((opt_flag & F_NO_DIAG) && cmp == 0 && (int)tl == qlen) {
+			if ((uint32_t)r >> 1 == q->q_pos >> 1) return 0; /* the diagonal itself */
+			if (fwd) is_self = 1;
+		}
+		if ((opt_flag & F_NO_DUAL) && cmp > 0) return 0; /* each pair once */
+	}
+	if (opt_flag & (F_FOR_ONLY | F_REV_ONLY)) {
+		if (fwd && (opt_flag & F_REV_ONLY)) return 0;
+		if (!fwd && (opt_flag & F_FOR_ONLY)) return 0;
+	}
+	if (fwd) {
+		p->x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+		p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
+	} else {
+		p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+		p->y = (uint64_t)q->q_span << 32 | (uint32_t)(qlen - ((int32_t)(q->q_pos >> 1) + 1 - (int32_t)q->q_span) - 1);
+	}
+	p->y |= (uint64_t)q->seg_id << 48;
+	if (q->is_tandem) p->y |= SEED_TANDEM;
+	if (is_self) p->y |= SEED_SELF;
+	return 1;
+}
+
+/* min-heap on x only (heap_lt, map.c:75; ks_heapdown, ksort.h:43-53): the order of equal keys is whatever sifting leaves */
+typedef struct { uint64_t x, y; } hp_t;
+static void hp_down(hp_t *l, int64_t i, int64_t n)
+{
+	int64_t k = i;
+	hp_t tmp = l[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && l[k].x > l[k + 1].x) ++k;
+		if (l[k].x > tmp.x) break;
+		l[i] = l[k]; i = k;
+	}
+	l[i] = tmp;
+}
+
 int64_t ora_collect_seed_hits(const void *idx, ora_idx_get_f get, int64_t opt_flag, int qlen, int mid_occ, int max_max_occ, int occ_dist,
                               float q_occ_frac, ora128_t *mv, int64_t n_mv, ora128_t **anchors, int64_t *n_a_out,
                               uint64_t **mini_pos_out, int *n_mini_pos_out, int *rep_len_out)
 {
-	return ora_collect_seed_hits_named(idx, get, 0, 0, opt_flag, qlen, mid_occ, max_max_occ, occ_dist, q_occ_frac, mv, n_mv, anchors, n_a_out,
+	return ora_collect_seed_hits_named(idx, get, 0, 0, opt_flag, qlen, mid_occ, mid_occ, max_max_occ, occ_dist, q_occ_frac, mv, n_mv, anchors, n_a_out,
 	                                   mini_pos_out, n_mini_pos_out, rep_len_out);
 }
 
 int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const char *qname, ora_seq_name_f seq_name, int64_t opt_flag, int qlen,
-                                    int mid_occ, int max_max_occ, int occ_dist, float q_occ_frac, ora128_t *mv, int64_t n_mv,
+                                    int q_mid_occ, int mid_occ, int max_max_occ, int occ_dist, float q_occ_frac, ora128_t *mv, int64_t n_mv,
                                     ora128_t **anchors, int64_t *n_a_out, uint64_t **mini_pos_out, int *n_mini_pos_out, int *rep_len_out)
 {
 	int64_t i, j, n_a = 0, k;
@@ -76,7 +124,7 @@ int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const ch
 	ora128_t *a;
 
 	/* query-side filter of over-represented minimizers (mm_seed_mz_flt, seed.c:5-28) */
-	if (q_occ_frac > 0.0f && n_mv > mid_occ && mid_occ > 0) {
+	if (q_occ_frac > 0.0f && n_mv > q_mid_occ && q_mid_occ > 0) {
 		ora128_t *s = (ora128_t*)malloc(n_mv * sizeof(ora128_t));
 		int64_t st;
 		for (i = 0; i < n_mv; ++i) s[i].x = mv[i].x, s[i].y = (uint64_t)i;
@@ -84,7 +132,7 @@ int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const ch
 		for (st = 0, i = 1; i <= n_mv; ++i) {
 			if (i == n_mv || s[i].x != s[st].x) {
 				int32_t cnt = (int32_t)(i - st);
-				if (cnt > mid_occ && cnt > n_mv * q_occ_frac)
+				if (cnt > q_mid_occ && cnt > n_mv * q_occ_frac)
 					for (j = st; j < i; ++j) mv[s[j].y].x = 0;
 				st = i;
 			}
@@ -124,46 +172,44 @@ int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const ch
 		}
 	}
 	rep_len += rep_en - rep_st;
-	/* expand to anchors (map.c:176-200) and sort by target position (:202) */
+	/* expand to anchors and order them by target position: collect_seed_hits (map.c:168-204) or, with MM_F_HEAP_SORT,
+	 * collect_seed_hits_heap (map.c:102-166) */
 	a = (ora128_t*)malloc((n_a ? n_a : 1) * sizeof(ora128_t));
-	for (i = 0, k = 0; i < n_m; ++i) {
-		const seed_t *q = &m[i];
-		uint32_t c;
-		for (c = 0; c < q->n; ++c) {
-			const uint64_t r = q->cr[c];
-			const int32_t rpos = (int32_t)((uint32_t)r >> 1);
-			const int fwd = (r & 1) == (q->q_pos & 1);
-			int is_self = 0;
-			ora128_t *p;
-			if (qname && seq_name && (opt_flag & (F_NO_DIAG | F_NO_DUAL))) { /* all-vs-all rules (skip_seed, map.c:81-91) */
-				uint32_t tl = 0;
-				const char *tn = seq_name(idx, (uint32_t)(r >> 32), &tl);
-				const int cmp = strcmp(qname, tn);
-				if ((opt_flag & F_NO_DIAG) && cmp == 0 && (int)tl == qlen) {
-					if ((uint32_t)r >> 1 == q->q_pos >> 1) continue; /* the diagonal itself */
-					if (fwd) is_self = 1;
-				}
-				if ((opt_flag & F_NO_DUAL) && cmp > 0) continue; /* each pair once */
+	if (opt_flag & F_HEAP_SORT) {
+		hp_t *heap = (hp_t*)malloc((n_m ? n_m : 1) * sizeof(hp_t));
+		int64_t n_for = 0, n_rev = 0, hs = 0;
+		for (i = 0; i < n_m; ++i)
+			if (m[i].n > 0) heap[hs].x = m[i].cr[0], heap[hs].y = (uint64_t)i << 32, ++hs;
+		if (hs > 1) for (i = (hs >> 1) - 1; i >= 0; --i) hp_down(heap, i, hs);
+		while (hs > 0) {
+			const seed_t *q = &m[heap[0].y >> 32];
+			ora128_t t;
+			if (make_anchor(&t, heap[0].x, q, qname, seq_name, idx, opt_flag, qlen)) {
+				if (t.x >> 63) a[n_a - (++n_rev)] = t; /* the other strand is laid down back to front ... */
+				else a[n_for++] = t;
 			}
-			if (opt_flag & (F_FOR_ONLY | F_REV_ONLY)) {
-				if (fwd && (opt_flag & F_REV_ONLY)) continue;
-				if (!fwd && (opt_flag & F_FOR_ONLY)) continue;
-			}
-			p = &a[k++];
-			if (fwd) {
-				p->x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-				p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
-			} else {
-				p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-				p->y = (uint64_t)q->q_span << 32 | (uint32_t)(qlen - ((int32_t)(q->q_pos >> 1) + 1 - (int32_t)q->q_span) - 1);
-			}
-			p->y |= (uint64_t)q->seg_id << 48;
-			if (q->is_tandem) p->y |= SEED_TANDEM;
-			if (is_self) p->y |= SEED_SELF;
+			if ((uint32_t)heap[0].y < q->n - 1) ++heap[0].y, heap[0].x = q->cr[(uint32_t)heap[0].y];
+			else heap[0] = heap[hs - 1], --hs;
+			hp_down(heap, 0, hs);
 		}
+		free(heap);
+		for (j = 0; j < n_rev >> 1; ++j) { /* ... and turned around afterwards (map.c:155-160) */
+			ora128_t t = a[n_a - 1 - j];
+			a[n_a - 1 - j] = a[n_a - (n_rev - j)];
+			a[n_a - (n_rev - j)] = t;
+		}
+		if (n_a > n_for + n_rev) memmove(a + n_for, a + n_a - n_rev, n_rev * sizeof(ora128_t));
+		k = n_for + n_rev;
+	} else {
+		for (i = 0, k = 0; i < n_m; ++i) {
+			const seed_t *q = &m[i];
+			uint32_t c;
+			for (c = 0; c < q->n; ++c)
+				if (make_anchor(&a[k], q->cr[c], q, qname, seq_name, idx, opt_flag, qlen)) ++k;
+		}
+		ora_radix_sort_128x(a, a + k);
 	}
 	free(m);
-	ora_radix_sort_128x(a, a + k);
 	*anchors = a, *n_a_out = k, *mini_pos_out = mini_pos, *n_mini_pos_out = n_mini_pos, *rep_len_out = rep_len;
 	return n_mv;
 }

@@ -4,6 +4,7 @@
 // product's host pipeline (chains -> hits -> window planning -> CIGAR stitching -> MAPQ) end to end and compare
 // its SAM output with the reference binary, in a container that has no GPU.  The GPU tests exercise the same host
 // pipeline with the real HipBackend.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -57,7 +58,15 @@ public:
 			uint64_t *mp = nullptr;
 			int64_t n_a = 0;
 			int n_mp = 0, rep_len = 0;
-			ora_collect_seed_hits_named(&fi_, flat_get, reads_[i].name, fi_.names.empty() ? nullptr : flat_name, p.flag, len, p.mid_occ, p.max_max_occ, p.occ_dist, p.q_occ_frac, mv.data(), n_mv, &a, &n_a, &mp, &n_mp, &rep_len);
+			ora_collect_seed_hits_named(&fi_, flat_get, reads_[i].name, fi_.names.empty() ? nullptr : flat_name, p.flag, len, p.q_mid_occ, p.mid_occ, p.max_max_occ, p.occ_dist, p.q_occ_frac, mv.data(), n_mv, &a, &n_a, &mp, &n_mp, &rep_len);
+			if (const char *dump = getenv("MM2AMD_CHECK_SEED_DUMP")) { // the anchors as the reference's --print-seeds shows them (map.c:255-260)
+				FILE *fp = fopen(dump, "a");
+				fprintf(fp, "QR\t%s\t%d\nRS\t%d\n", reads_[i].name ? reads_[i].name : "*", p.mid_occ, rep_len);
+				for (int64_t j = 0; j < n_a; ++j)
+					fprintf(fp, "SD\t%s\t%d\t%c\t%d\t%d\t%d\n", fi_.names[a[j].x << 1 >> 33].c_str(), (int32_t)a[j].x, "+-"[a[j].x >> 63], (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff),
+					        j == 0 ? 0 : ((int32_t)a[j].y - (int32_t)a[j - 1].y) - ((int32_t)a[j].x - (int32_t)a[j - 1].x));
+				fclose(fp);
+			}
 			ReadChains &c = out[i - (size_t)lo];
 			c.rep_len = rep_len;
 			c.mini_pos.assign(mp, mp + n_mp);
@@ -71,7 +80,9 @@ public:
 			}
 			c.u.resize(n_a > 0 ? n_a : 1);
 			int64_t n_kept = 0;
-			const int n_u = ora_lchain_dp(p.max_gap_ref, p.max_gap_qry, p.bw, p.max_chain_skip, p.max_chain_iter, p.min_cnt, p.min_chain_score,
+			int gap_ref, gap_qry;
+			chain_gaps(p, len, &gap_ref, &gap_qry);
+			const int n_u = ora_lchain_dp(gap_ref, gap_qry, p.bw, p.max_chain_skip, p.max_chain_iter, p.min_cnt, p.min_chain_score,
 			                              p.chn_pen_gap, p.chn_pen_skip, p.is_cdna, 1, n_a, a, c.u.data(), &n_kept);
 			c.u.resize(n_u);
 			c.a.resize(n_kept);

@@ -190,6 +190,59 @@ def make_overlaps(outdir, seed=81, n_reads=60, genome=120000):
     return fa
 
 
+def make_short(outdir, seed=91, n_reads=400, genome=400000):
+    """Single-end short reads (100-250 bp, ~1 % substitutions, occasional small indels) on both strands of a two-contig
+    reference that carries a few exact duplications (2 kb units copied 3-6 times) and short tandem arrays (a 40-mer repeated
+    6 times: reads across them contain the same minimizer more than once, which is what makes the order of equal index hits
+    observable).  Also: reads with a 15 bp deletion / insertion in the middle, reads lying entirely inside a duplicated unit, a
+    read with Ns, reads too short to seed.  Returns (ref.fa, reads.fa)."""
+    rng = np.random.default_rng(seed)
+    contigs = gen_reference(rng, genome, 2)
+    for c in contigs:
+        for _ in range(3):
+            unit = rng.integers(0, 4, 2000, dtype=np.uint8)
+            for _ in range(int(rng.integers(3, 7))):
+                st = int(rng.integers(0, len(c) - 2000))
+                c[st:st + 2000] = unit
+        tand = []
+        for _ in range(12):
+            st = int(rng.integers(1000, len(c) - 1000))
+            c[st:st + 240] = np.tile(rng.integers(0, 4, 40, dtype=np.uint8), 6)
+            tand.append(st)
+        c_tand = tand
+    reads = []
+    def take(ci, st, ln):
+        s = contigs[ci][st:st + ln].copy()
+        return s
+    for i in range(n_reads):
+        ci = int(rng.integers(0, 2))
+        ln = int(rng.integers(100, 251))
+        st = int(rng.integers(0, len(contigs[ci]) - ln))
+        if i % 10 == 0:  # across a tandem array of the second contig
+            ci, st = 1, c_tand[(i // 10) % len(c_tand)] - int(rng.integers(20, 120))
+        s = take(ci, st, ln)
+        sub = rng.random(ln) < 0.01
+        s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
+        if i % 7 == 3:
+            m = ln // 2
+            s = np.concatenate([s[:m], s[m + 15:]]) if i % 2 else np.concatenate([s[:m], rng.integers(0, 4, 15, dtype=np.uint8), s[m:]])
+        elif i % 9 == 4:
+            m = int(rng.integers(20, ln - 20))
+            s = np.concatenate([s[:m], s[m + 1:]])
+        if rng.random() < 0.5:
+            s = COMP[s[::-1]]
+        reads.append(ACGT[s].tobytes())
+    nn = bytearray(reads[5]); nn[40:44] = b"NNNN"; reads.append(bytes(nn))
+    reads += [reads[8][:20], reads[9][:30], b"ACGT" * 30]
+    os.makedirs(outdir, exist_ok=True)
+    ref, rd = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa")
+    write_fasta(ref, ["s1", "s2"], contigs)
+    with open(rd, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">sr%d\n" % i + s + b"\n")
+    return ref, rd
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):

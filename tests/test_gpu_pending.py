@@ -28,3 +28,48 @@ def _run(cmd):
 def test_all_vs_all(args, tmp_path):  # skip_seed's read-name rules (map.c:81-91), MM_SEED_SELF (align.c:760-767)
     fa = synth.make_overlaps(str(tmp_path))
     assert _run([REF_BIN, "-t", "8"] + args + [fa, fa]) == _run([DROPIN, "-t", "8"] + args + [fa, fa])
+
+
+SR_CASES = [["-x", "sr", "-a"], ["-x", "sr", "-c"], ["-x", "sr"], ["-x", "sr", "-a", "--heap-sort=no"], ["-x", "map-ont", "--heap-sort=yes", "-c"],
+            ["-x", "map-ont", "-F", "2000", "-c"], ["-x", "sr", "-a", "-F", "300", "-g", "60"], ["-x", "sr", "-a", "-f", "2,20", "-N", "3"]]
+
+
+@pytest.mark.parametrize("args", SR_CASES)
+def test_short_reads_single_end(args, tmp_path):  # MM_F_SR / MM_F_HEAP_SORT / max_frag_len (anchor_heap_order_kernel, chain_gaps)
+    ref, rd = synth.make_short(str(tmp_path))
+    assert _run([REF_BIN, "-t", "8"] + args + [ref, rd]) == _run([DROPIN, "-t", "8"] + args + [ref, rd])
+
+
+def test_short_reads_larger_set(tmp_path):
+    ref, rd = synth.make_short(str(tmp_path), seed=93, n_reads=3000, genome=2000000)
+    for args in (["-x", "sr", "-a"], ["-x", "sr", "-c", "--heap-sort=no"]):
+        assert _run([REF_BIN, "-t", "8"] + args + [ref, rd]) == _run([DROPIN, "-t", "8"] + args + [ref, rd])
+
+
+def _seed_blocks(lines):
+    out, cur = {}, None
+    for l in lines:
+        f = l.split("\t")
+        if f[0] == "QR":
+            cur = f[1] if f[1] not in out else None  # a read seeded twice (max_occ pass): the reference prints the first pass only
+            if cur is not None:
+                out[cur] = []
+        elif f[0] in ("SD", "RS") and cur is not None:
+            out[cur].append(l)
+    return out
+
+
+@pytest.mark.parametrize("args", [["-x", "sr"], ["-x", "sr", "--heap-sort=no"], ["-x", "map-ont", "--heap-sort=yes"]])
+def test_anchor_order_matches_print_seeds(args, tmp_path):
+    """Every read's anchors, in order, from the device (MM2AMD_SEED_DUMP) against the reference's --print-seeds: the order of equal
+    index hits (heap merge vs radix sort) is only visible here."""
+    ref, rd = synth.make_short(str(tmp_path))
+    p = subprocess.run([REF_BIN] + args + ["-t", "1", "--print-qname", "--print-seeds", ref, rd], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert p.returncode == 0
+    want = _seed_blocks(p.stderr.decode().split("\n"))
+    dump = str(tmp_path / "seeds.txt")
+    subprocess.run([DROPIN] + args + ["-t", "4", ref, rd], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MM2AMD_SEED_DUMP=dump), check=True)
+    got = _seed_blocks(open(dump).read().split("\n"))
+    assert len(want) > 300 and set(want) == set(got)
+    bad = [k for k in want if want[k] != got[k]]
+    assert not bad, bad[:5]

@@ -231,3 +231,59 @@ def test_all_vs_all(args, tmp_path):  # skip_seed's read-name rules (map.c:81-91
     fa = synth.make_overlaps(str(tmp_path))
     out = _pair(args, fa, fa)
     assert out.count(b"\n") > 50
+
+
+SR_CASES = [["-x", "sr", "-a"], ["-x", "sr", "-c"], ["-x", "sr"], ["-x", "sr", "-a", "--heap-sort=no"], ["-x", "map-ont", "--heap-sort=yes", "-c"],
+            ["-x", "map-ont", "-F", "2000", "-c"], ["-x", "sr", "-a", "-F", "300", "-g", "60"], ["-x", "sr", "-a", "-f", "2,20", "-N", "3"]]
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args", SR_CASES)
+def test_short_reads_single_end(args, tmp_path):  # MM_F_SR / MM_F_HEAP_SORT / max_frag_len paths (map.c:102-166,262-271; align.c:563-589,696-704,803-833)
+    import synth
+    ref, rd = synth.make_short(str(tmp_path))
+    out = _pair(args, ref, rd)
+    assert out.count(b"\n") > 300
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("heap", ["yes", "no"])
+def test_anchor_order_matches_print_seeds(heap, tmp_path):
+    """The anchors of every read, in order, against the reference's --print-seeds dump: the only place where the order of equal
+    index hits (heap merge vs radix sort) is directly visible."""
+    import synth
+    ref, rd = synth.make_short(str(tmp_path))
+
+    def blocks(lines):
+        out, cur = {}, None
+        for l in lines:
+            f = l.split("\t")
+            if f[0] == "QR":
+                cur = f[1] if f[1] not in out else None  # a read seeded twice (max_occ pass): the first dump is the one the reference prints
+                if cur is not None:
+                    out[cur] = []
+            elif f[0] in ("SD", "RS") and cur is not None:
+                out[cur].append(l)
+        return out
+
+    args = ["-x", "sr", "--heap-sort=" + heap, "-t", "1"]
+    p = subprocess.run([G.REF_BIN] + args + ["--print-qname", "--print-seeds", ref, rd], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert p.returncode == 0
+    want = blocks(p.stderr.decode().split("\n"))
+    dump = str(tmp_path / "seeds.txt")
+    env = dict(os.environ, MM2AMD_CHECK_SEED_DUMP=dump)
+    subprocess.run([CHECK] + args + [ref, rd], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, check=True)
+    got = blocks(open(dump).read().split("\n"))
+    assert len(want) > 300 and set(want) == set(got)
+    assert sum(1 for k in want if any(a.split("\t")[1:3] == b.split("\t")[1:3] for a, b in zip(want[k][1:], want[k][2:]))) > 10  # reads with equal hits exist
+    bad = [k for k in want if want[k] != got[k]]
+    assert not bad, bad[:5]
+
+
+def test_device_heap_order_header_against_oracle():
+    """minimap2_amd/csrc/heap_order.hpp (what anchor_heap_order_kernel runs per read) compiled for the host, vs the oracle."""
+    exe = os.path.join(HERE, "_build", "heap_order_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/heap_order_test not built")
+    out = subprocess.run([exe, "3000"], stdout=subprocess.PIPE, check=True).stdout.split()
+    assert out[0] == b"OK" and int(out[2]) > 1000
