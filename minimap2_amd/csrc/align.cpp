@@ -407,9 +407,9 @@ Aligner::Aligner(const MapOpt &opt, const FlatIndex &fi) : opt_(opt), fi_(fi)
 	if (bw_long_ < bw_) bw_long_ = bw_;
 }
 
-void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_off, uint8_t *q4)
+void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_fwd, uint64_t qpool_rev, uint8_t *q4)
 {
-	ra.qlen = qlen, ra.qpool_off = qpool_off, ra.a = a;
+	ra.qlen = qlen, ra.qpool_off = qpool_fwd, ra.qpool_rev = qpool_rev, ra.a = a;
 	ra.q4 = q4;
 	for (int i = 0; i < qlen; ++i) {
 		const uint8_t c = kNt4Table[(uint8_t)seq[i]];
@@ -689,7 +689,7 @@ void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdr
 	j.w = w.bw, j.zdrop = zdrop, j.end_bonus = end_bonus;
 	if (opt_.transition != 0 && opt_.b != opt_.transition) flag |= KSW_GENERIC_SC;             // align.c:347-348
 	if (opt_.max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > opt_.max_sw_mat) flag |= KSWJ_SKIP;   // align.c:349-351
-	const uint64_t qbase = ra.qpool_off + (uint64_t)t.rev * ra.qlen, tbase = fi_.seq_off[t.rid];
+	const uint64_t qbase = t.rev ? ra.qpool_rev : ra.qpool_off, tbase = fi_.seq_off[t.rid];
 	j.q_off = reversed ? qbase + w.qe - 1 : qbase + w.qs;
 	j.t_off = reversed ? tbase + w.re - 1 : tbase + w.rs;
 	j.flag = flag | t.ksw_flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);

@@ -56,7 +56,7 @@ struct RegionTask {
 
 struct ReadAlign {        // per-read alignment state
 	int qlen = 0;
-	uint64_t qpool_off = 0;                      // where this read's nt4 fwd|rev bytes start in the device query pool
+	uint64_t qpool_off = 0, qpool_rev = 0;       // where this read's nt4 forward / reverse-complement bytes start in the device query pool
 	uint8_t *q4 = nullptr;                       // fwd (qlen) then reverse complement (qlen), nt4 codes; 2*qlen bytes owned by the caller
 	Anchor *a = nullptr;             // the read's chained anchors (modified in place; owned by the caller)
 	int n_a = 0;
@@ -69,7 +69,7 @@ public:
 	Aligner(const ref::MapOpt &opt, const FlatIndex &fi);
 	// Prepare a read: encode, squeeze anchors, create one task per region (mm_align_skeleton, align.c:1048-1066).
 	// q4: 2*qlen bytes of caller-owned storage that must outlive the read's rounds
-	void begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_off, uint8_t *q4);
+	void begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_fwd, uint64_t qpool_rev, uint8_t *q4);
 	// Plan everything plannable and append the DP jobs of this round to `jobs`.
 	void schedule(ReadAlign &ra, std::vector<KswJob> &jobs);
 	// Consume results; returns true when the read still has unfinished work (another round needed).

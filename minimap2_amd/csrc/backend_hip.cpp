@@ -106,17 +106,40 @@ public:
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
 	{
 		const size_t n = reads.size();
+		// fragment-level offsets (what seeding and chaining see: a pair is one query, the concatenation of its two reads) ...
 		seq_off_.resize(n + 1);
 		seq_off_[0] = 0;
-		for (size_t i = 0; i < n; ++i) seq_off_[i + 1] = seq_off_[i] + (uint64_t)reads[i].len;
+		has_pairs_ = false;
+		for (size_t i = 0; i < n; ++i) seq_off_[i + 1] = seq_off_[i] + (uint64_t)reads[i].total(), has_pairs_ |= reads[i].paired();
 		const uint64_t total = seq_off_[n];
 		qpool_off.resize(n);
 		for (size_t i = 0; i < n; ++i) qpool_off[i] = 2 * seq_off_[i];
 		char *h = h_ascii_.ensure(total + 1);
-		parallel_for(n_threads_, (long)n, [&](long i, int) { memcpy(h + seq_off_[i], reads[i].seq, reads[i].len); }, 64);
+		parallel_for(n_threads_, (long)n, [&](long i, int) {
+			memcpy(h + seq_off_[i], reads[i].seq, reads[i].len);
+			if (reads[i].paired()) memcpy(h + seq_off_[i] + reads[i].len, reads[i].seq2, reads[i].len2);
+		}, 64);
 		d_ascii_.ensure(total + 1);
 		d_qpool_.ensure(2 * total + 16);
 		d_seq_off_.ensure(n + 1);
+		// ... and unit-level offsets (what encoding and sketching see: every read of a pair on its own, so that no k-mer spans the
+		// two and each has its own forward | reverse-complement block in the query pool)
+		n_units_ = n;
+		if (has_pairs_) {
+			unit_first_.resize(n + 1);
+			unit_first_[0] = 0;
+			for (size_t i = 0; i < n; ++i) unit_first_[i + 1] = unit_first_[i] + (reads[i].paired() ? 2 : 1);
+			n_units_ = (size_t)unit_first_[n];
+			unit_off_.resize(n_units_ + 1);
+			for (size_t i = 0; i < n; ++i) {
+				unit_off_[unit_first_[i]] = seq_off_[i];
+				if (reads[i].paired()) unit_off_[unit_first_[i] + 1] = seq_off_[i] + (uint64_t)reads[i].len;
+			}
+			unit_off_[n_units_] = total;
+			d_unit_off_.ensure(n_units_ + 1), d_unit_first_.ensure(n + 1);
+			HIP_CHECK(hipMemcpyAsync(d_unit_off_.p, unit_off_.data(), (n_units_ + 1) * 8, hipMemcpyHostToDevice, stream_));
+			HIP_CHECK(hipMemcpyAsync(d_unit_first_.p, unit_first_.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream_));
+		}
 		HIP_CHECK(hipMemcpyAsync(d_ascii_.p, h, total, hipMemcpyHostToDevice, stream_));
 		HIP_CHECK(hipMemcpyAsync(d_seq_off_.p, seq_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
 		read_names_.clear();
@@ -155,17 +178,24 @@ public:
 		KernelProfiler &kp = kernel_profiler(lane_id);
 		double tt = Trace::now();
 		const double L = (double)(seq_off_[hi] - seq_off_[lo]);
-		kp.begin(st); launch_encode(B, st); kp.end(st, "encode_kernel", 3 * L);
+		// encoding and sketching run over units (see begin_batch); without pairs a unit is a fragment
+		SeedChainBuffers Bu = B;
+		const size_t ulo = has_pairs_ ? (size_t)unit_first_[lo] : (size_t)lo, n_unit = has_pairs_ ? (size_t)unit_first_[hi] - ulo : n;
+		if (has_pairs_) Bu.n_reads = (int)n_unit, Bu.seq_off = d_unit_off_.p + ulo;
+		kp.begin(st); launch_encode(Bu, st); kp.end(st, "encode_kernel", 3 * L);
 		// 1. minimizers, written from slot seq_off[r] of the minimizer arrays (at most one per base)
 		const uint64_t base0 = seq_off_[lo], cap_mz = seq_off_[hi] - base0;
-		ln.d_mz_cnt.ensure(n);
+		ln.d_mz_cnt.ensure(n_unit);
 		ln.d_mz_x.ensure(cap_mz + 1), ln.d_mz_y.ensure(cap_mz + 1);
 		ln.d_sd_n.ensure(cap_mz + 1), ln.d_sd_off.ensure(cap_mz + 1), ln.d_sd_aoff.ensure(cap_mz + 1), ln.d_sd_qpos.ensure(cap_mz + 1), ln.d_sd_info.ensure(cap_mz + 1);
 		// the per-read slot offsets are the batch-wide base offsets; shifting the array bases by the sub-batch's first offset makes them local
 		B.mz_cnt = ln.d_mz_cnt.p, B.mz_off = B.seq_off, B.mz_x = ln.d_mz_x.p - base0, B.mz_y = ln.d_mz_y.p - base0;
 		B.sd_n = ln.d_sd_n.p - base0, B.sd_off = ln.d_sd_off.p - base0, B.sd_aoff = ln.d_sd_aoff.p - base0, B.sd_qpos = ln.d_sd_qpos.p - base0, B.sd_info = ln.d_sd_info.p - base0;
 		const double est_mz = 2.0 * L / (P.w + 1);
-		kp.begin(st); launch_sketch(B, P, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
+		Bu.mz_cnt = B.mz_cnt, Bu.mz_off = Bu.seq_off, Bu.mz_x = B.mz_x, Bu.mz_y = B.mz_y;
+		kp.begin(st); launch_sketch(Bu, P, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
+		if (has_pairs_) // seed_collect joins the minimizer lists of a pair's two units (collect_minimizers, map.c:59-72); indices are batch-wide
+			B.unit_first = d_unit_first_.p + lo, B.unit_off = d_unit_off_.p, B.unit_cnt = ln.d_mz_cnt.p - ulo, B.mz_cnt = nullptr;
 		// 2. seeds: probe, filter, count anchors
 		ln.d_n_anchor.ensure(n), ln.d_n_minipos.ensure(n), ln.d_n_seedhit.ensure(n), ln.d_rep_len.ensure(n);
 		B.n_anchor = ln.d_n_anchor.p, B.n_minipos = ln.d_n_minipos.p, B.n_seedhit = ln.d_n_seedhit.p, B.rep_len = ln.d_rep_len.p;
@@ -303,6 +333,13 @@ private:
 	DevBuf<char> d_ascii_;
 	DevBuf<uint8_t> d_qpool_;
 	DevBuf<uint64_t> d_seq_off_;
+	// pairs: unit = one read of a pair (or a single read); see begin_batch
+	bool has_pairs_ = false;
+	size_t n_units_ = 0;
+	std::vector<uint64_t> unit_off_;
+	std::vector<int32_t> unit_first_;
+	DevBuf<uint64_t> d_unit_off_;
+	DevBuf<int32_t> d_unit_first_;
 	// all-vs-all name rules
 	bool name_rules_ = false, have_read_names_ = false;
 	const std::vector<std::string> *fi_names_ = nullptr;

@@ -86,31 +86,85 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
 	}
 }
 
-static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, std::vector<ReadView> &reads)
+// mm_revcomp_bseq (mmpriv.h) on a copy: complement table of bseq.c:11-28 (IUPAC codes, case kept, other bytes unchanged)
+static void revcomp_into(const char *seq, int len, std::string &out)
+{
+	static const struct Table {
+		unsigned char t[256];
+		Table()
+		{
+			for (int i = 0; i < 256; ++i) t[i] = (unsigned char)i;
+			const char *from = "ACGTUMRWSYKVHDBN", *to = "TGCAAKYWSRMBDHVN";
+			for (int i = 0; from[i]; ++i) t[(unsigned char)from[i]] = (unsigned char)to[i], t[(unsigned char)(from[i] + 32)] = (unsigned char)(to[i] + 32);
+		}
+	} tab;
+	out.resize(len);
+	for (int i = 0; i < len; ++i) out[len - 1 - i] = (char)tab.t[(unsigned char)seq[i]];
+}
+
+// The fragments of a batch as the mapper sees them.  A two-segment fragment (paired-end reads) is handed over in mapping
+// orientation: worker_for reverse-complements a mate in place according to pe_ori before mapping and back afterwards
+// (map.c:436-442, 457-473); here the flipped copy lives in `flipped` and the caller's buffers are left alone.
+static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, int pe_ori, bool allow_pairs, std::vector<ReadView> &reads,
+                         std::vector<std::string> &flipped)
 {
 	const ref::Bseq1 *seq = (const ref::Bseq1 *)seq_;
-	reads.resize(n_frag);
+	reads.assign(n_frag, ReadView());
+	flipped.clear();
+	size_t n_flip = 0;
 	for (int i = 0; i < n_frag; ++i) {
-		if (n_seg[i] != 1) return capi_fail(MM2AMD_EINVAL, "[mm2amd] multi-segment fragments (paired-end) are not implemented");
+		if (n_seg[i] == 2 && !allow_pairs) return capi_fail(MM2AMD_EINVAL, "[mm2amd] two-segment fragments go through mm_gpu_map_batch, not the staged calls");
+		if (n_seg[i] != 1 && n_seg[i] != 2) return capi_fail(MM2AMD_EINVAL, "[mm2amd] fragments of more than two segments are not implemented");
+		if (n_seg[i] == 2) n_flip += (pe_ori >> 1 & 1) + (pe_ori & 1);
+	}
+	flipped.resize(n_flip); // sized first: the views point into it
+	n_flip = 0;
+	for (int i = 0; i < n_frag; ++i) {
 		const ref::Bseq1 &s = seq[seg_off[i]];
 		reads[i].seq = s.seq, reads[i].len = s.l_seq, reads[i].name = s.name;
+		if (n_seg[i] == 2) {
+			const ref::Bseq1 &s2 = seq[seg_off[i] + 1];
+			reads[i].seq2 = s2.seq, reads[i].len2 = s2.l_seq;
+			if (pe_ori >> 1 & 1) { revcomp_into(s.seq, s.l_seq, flipped[n_flip]); reads[i].seq = flipped[n_flip++].data(); }
+			if (pe_ori & 1) { revcomp_into(s2.seq, s2.l_seq, flipped[n_flip]); reads[i].seq2 = flipped[n_flip++].data(); }
+		}
 	}
 	return 0;
 }
 
-static void hand_over(int n_frag, const int *seg_off, std::vector<ReadResult> &out, int *n_reg, void **reg, int *rep_len, int *frag_gap)
+static void *regs_block(const RegVec &v)
+{
+	if (v.empty()) return nullptr;
+	void *p = malloc(v.size() * sizeof(ref::Reg1)); // handed over as one libc block, like the reference's realloc'd array (map.c:340)
+	memcpy(p, v.data(), v.size() * sizeof(ref::Reg1));
+	return p;
+}
+
+static void hand_over(int n_frag, const int *seg_off, const std::vector<ReadView> *views, int pe_ori, std::vector<ReadResult> &out, int *n_reg, void **reg,
+                      int *rep_len, int *frag_gap)
 {
 	parallel_for(g_ctx ? g_ctx->n_threads : 1, n_frag, [&](long i, int) {
 		const int o = seg_off ? seg_off[i] : i;
-		const size_t n = out[i].regs.size();
-		n_reg[o] = (int)n;
-		reg[o] = nullptr;
-		if (n) { // handed over as one libc block, like the reference's realloc'd array (map.c:340)
-			reg[o] = malloc(n * sizeof(ref::Reg1));
-			memcpy(reg[o], out[i].regs.data(), n * sizeof(ref::Reg1));
+		const int n_segs = views && (*views)[i].paired() ? 2 : 1;
+		for (int j = 0; j < n_segs; ++j) {
+			RegVec &regs = j == 0 ? out[i].regs : out[i].regs2;
+			if (n_segs == 2 && ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1)))) { // back to the strand the read was given in (map.c:457-473)
+				const int qlen = j == 0 ? (*views)[i].len : (*views)[i].len2;
+				for (ref::Reg1 &r : regs) {
+					const int t = r.qs;
+					r.qs = qlen - r.qe, r.qe = qlen - t;
+					r.rev = !r.rev;
+					if (r.p) {
+						if (r.p->trans_strand == 1) r.p->trans_strand = 2;
+						else if (r.p->trans_strand == 2) r.p->trans_strand = 1;
+					}
+				}
+			}
+			n_reg[o + j] = (int)regs.size();
+			reg[o + j] = regs_block(regs);
+			if (rep_len) rep_len[o + j] = out[i].rep_len;
+			if (frag_gap) frag_gap[o + j] = out[i].frag_gap;
 		}
-		if (rep_len) rep_len[o] = out[i].rep_len;
-		if (frag_gap) frag_gap[o] = out[i].frag_gap;
 	}, 256);
 }
 
@@ -121,7 +175,8 @@ int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const v
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_batch_stage: bad arguments");
 	try {
 		g_ctx->has_staged = false;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->staged)) return rc;
+		std::vector<std::string> none;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt.pe_ori, false, g_ctx->staged, none)) return rc;
 		g_ctx->mapper->stage(g_ctx->staged);
 		g_ctx->has_staged = true;
 		return 0;
@@ -140,7 +195,7 @@ int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 	try {
 		std::vector<ReadResult> out;
 		g_ctx->mapper->run(out);
-		hand_over((int)out.size(), nullptr, out, n_reg, reg, rep_len, frag_gap);
+		hand_over((int)out.size(), nullptr, nullptr, 0, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());
@@ -257,10 +312,12 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch: bad arguments");
 	try {
 		std::vector<ReadView> reads;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, reads)) return rc;
+		std::vector<std::string> flipped;
+		const int pe_ori = g_ctx->opt.pe_ori;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, pe_ori, true, reads, flipped)) return rc;
 		std::vector<ReadResult> out;
 		g_ctx->mapper->map_batch(reads, out);
-		hand_over(n_frag, seg_off, out, n_reg, reg, rep_len, frag_gap);
+		hand_over(n_frag, seg_off, &reads, pe_ori, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());

@@ -443,3 +443,178 @@ void update_dp_max(int qlen, RegVec &regs, float frac, int a, int b)
 }
 
 } // namespace mm2amd
+
+// ---------------------------------------------------------------------------------------------------------
+// Two-segment fragments (paired-end reads): hit.c:342-396 and pe.c
+// ---------------------------------------------------------------------------------------------------------
+namespace mm2amd {
+
+// mm_seg_gen (hit.c:342-396): the chains of a fragment, found on the concatenation of its segments, are cut into one set of
+// chains per segment; anchors are copied with the query coordinate made relative to their own segment.
+void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, const Anchor *a, RegVec *regs, std::vector<Anchor> *seg_a)
+{
+	const int n_regs0 = (int)regs0.size();
+	int acc_qlen[3] = {0, 0, 0}, qlen_sum;
+	for (int s = 1; s < n_segs; ++s) acc_qlen[s] = acc_qlen[s - 1] + qlens[s - 1];
+	qlen_sum = acc_qlen[n_segs - 1] + qlens[n_segs - 1];
+	std::vector<uint64_t> u[2];
+	size_t n_a[2] = {0, 0};
+	for (int s = 0; s < n_segs; ++s) {
+		u[s].resize(n_regs0);
+		for (int i = 0; i < n_regs0; ++i) u[s][i] = (uint64_t)regs0[i].score << 32;
+	}
+	for (int i = 0; i < n_regs0; ++i)
+		for (int j = 0; j < regs0[i].cnt; ++j) {
+			const int sid = (int)((a[regs0[i].as + j].y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT);
+			++u[sid][i], ++n_a[sid];
+		}
+	for (int s = 0; s < n_segs; ++s) {
+		size_t k = 0;
+		for (int i = 0; i < n_regs0; ++i) if ((int32_t)u[s][i] != 0) u[s][k++] = u[s][i]; // chains with no anchor on this segment vanish
+		u[s].resize(k);
+		seg_a[s].clear();
+		seg_a[s].reserve(n_a[s]);
+	}
+	for (int i = 0; i < n_regs0; ++i)
+		for (int j = 0; j < regs0[i].cnt; ++j) {
+			Anchor a1 = a[regs0[i].as + j];
+			const int sid = (int)((a1.y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT);
+			a1.y -= a1.x >> 63 ? (uint64_t)(qlen_sum - (qlens[sid] + acc_qlen[sid])) : (uint64_t)acc_qlen[sid];
+			seg_a[sid].push_back(a1);
+		}
+	for (int s = 0; s < n_segs; ++s) {
+		gen_regs(hash, qlens[s], u[s].data(), (int)u[s].size(), seg_a[s].data(), false, regs[s]);
+		for (Reg &r : regs[s]) r.seg_split = 1, r.seg_id = (uint32_t)s;
+	}
+}
+
+// mm_select_sub_multi (pe.c:6-50)
+void select_sub_multi(float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs, const int *qlens, RegVec &r)
+{
+	if (!(pri_ratio > 0.0f) || r.empty()) return;
+	const int n = (int)r.size(), max_dist = n_segs == 2 ? qlens[0] + qlens[1] + max_gap_ref : 0;
+	int n_2nd = 0, k = 0;
+	std::vector<uint8_t> keep(n, 0);
+	for (int i = 0; i < n; ++i) {
+		int to_keep = 0;
+		if (r[i].parent == i) to_keep = 1;
+		else if (r[i].score + min_diff >= r[r[i].parent].score) to_keep = 1;
+		else {
+			const Reg &p = r[r[i].parent], &q = r[i];
+			if (p.rev == q.rev && p.rid == q.rid && q.re - p.rs < max_dist && p.re - q.rs < max_dist) { // child and parent are close on the reference
+				if (q.score >= p.score * pri1) to_keep = 1;
+			} else {
+				const int is_par_both = (n_segs == 2 && p.qs < qlens[0] && p.qe > qlens[0]);
+				const int is_chi_both = (n_segs == 2 && q.qs < qlens[0] && q.qe > qlens[0]);
+				if (is_chi_both || is_chi_both == is_par_both) {
+					if (q.score >= p.score * pri_ratio) to_keep = 1;
+				} else if (q.score >= p.score * pri2) to_keep = 1;
+			}
+		}
+		if (to_keep && r[i].parent != i && n_2nd++ >= best_n) to_keep = 0;
+		keep[i] = (uint8_t)to_keep;
+	}
+	for (int i = 0; i < n; ++i) {
+		if (keep[i]) r[k++] = r[i];
+		else if (r[i].p) free(r[i].p);
+	}
+	r.resize(k);
+	if (k != n) sync_regs(r);
+}
+
+// mm_set_pe_thru (pe.c:52-71)
+static void set_pe_thru(const int *qlens, RegVec *regs)
+{
+	int n_pri[2] = {0, 0}, pri[2] = {-1, -1};
+	for (int s = 0; s < 2; ++s)
+		for (int i = 0; i < (int)regs[s].size(); ++i)
+			if (regs[s][i].id == regs[s][i].parent) ++n_pri[s], pri[s] = i;
+	if (n_pri[0] == 1 && n_pri[1] == 1) {
+		Reg &p = regs[0][pri[0]], &q = regs[1][pri[1]];
+		if (p.rid == q.rid && p.rev == q.rev && abs(p.rs - q.rs) < 3 && abs(p.re - q.re) < 3
+		    && ((p.qs == 0 && qlens[1] - q.qe == 0) || (q.qs == 0 && qlens[0] - p.qe == 0)))
+			p.pe_thru = q.pe_thru = 1;
+	}
+}
+
+namespace {
+struct PairEnt { int s, rev; uint64_t key; Reg *r; };
+struct PairKey { uint64_t operator()(const PairEnt &e) const { return e.key; } };
+}
+
+// mm_pair (pe.c:81-182): choose the best properly oriented pair of hits within max_gap_ref and adjust primaries / MAPQ
+void pair_hits(int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int *qlens, RegVec *regs)
+{
+	std::vector<PairEnt> a;
+	int dp_thres = 0, segs = 0;
+	for (int s = 0; s < 2; ++s) {
+		int max = 0;
+		for (Reg &r : regs[s]) {
+			PairEnt e;
+			e.s = s, e.r = &r, e.rev = r.rev;
+			e.key = (uint64_t)r.rid << 32 | (uint64_t)(int64_t)(r.rs << 1 | (s ^ e.rev)); // pe.c:97: int operands widened into the key
+			max = max > r.p->dp_max ? max : r.p->dp_max;
+			a.push_back(e);
+			segs |= 1 << s;
+		}
+		dp_thres += max;
+	}
+	if (segs != 3) return; // only one end is mapped
+	dp_thres -= pe_bonus;
+	if (dp_thres < 0) dp_thres = 0;
+	const int n = (int)a.size();
+	{ RsortScratch sc; exact_radix_sort(a.data(), a.data() + n, PairKey(), sc); } // radix_sort_pair: the unstable sort, replayed exactly
+	int64_t max = -1;
+	int max_idx[2] = {-1, -1}, last[2] = {-1, -1};
+	std::vector<uint64_t> sc;
+	for (int i = 0; i < n; ++i) {
+		if (a[i].key & 1) { // reverse first read or forward second read
+			if (last[a[i].rev] < 0) continue;
+			Reg *r = a[i].r, *q = a[last[a[i].rev]].r;
+			if (r->rid != q->rid || r->rs - q->re > max_gap_ref) continue;
+			for (int j = last[a[i].rev]; j >= 0; --j) {
+				if (a[j].rev != a[i].rev || a[j].s == a[i].s) continue;
+				q = a[j].r;
+				if (r->rid != q->rid || r->rs - q->re > max_gap_ref) break;
+				if (r->p->dp_max + q->p->dp_max < dp_thres) continue;
+				const int64_t score = (int64_t)(r->p->dp_max + q->p->dp_max) << 32 | (r->hash + q->hash);
+				if (score > max) max = score, max_idx[a[j].s] = j, max_idx[a[i].s] = i;
+				sc.push_back((uint64_t)score);
+			}
+		} else last[a[i].rev] = i; // forward first read or reverse second read
+	}
+	if (sc.size() > 1) sort_u64(sc.data(), sc.data() + sc.size());
+	if (!sc.empty() && max > 0) { // found at least one pair
+		Reg *r[2] = { a[max_idx[0]].r, a[max_idx[1]].r };
+		r[0]->proper_frag = r[1]->proper_frag = 1;
+		for (int s = 0; s < 2; ++s) {
+			if (r[s]->id != r[s]->parent) { // lift to primary and update the parents
+				Reg &p = regs[s][r[s]->parent];
+				for (Reg &x : regs[s]) if (x.parent == p.id) x.parent = r[s]->id;
+				p.mapq = 0;
+			}
+			if (!r[s]->sam_pri) {
+				for (Reg &x : regs[s]) x.sam_pri = 0;
+				r[s]->sam_pri = 1;
+			}
+		}
+		int mapq_pe = r[0]->mapq > r[1]->mapq ? r[0]->mapq : r[1]->mapq, n_sub = 0;
+		for (uint64_t v : sc) if ((v >> 32) + sub_diff >= (uint64_t)max >> 32) ++n_sub;
+		if (sc.size() > 1) {
+			const int mapq_pe_alt = (int)(6.02f * ((max >> 32) - (sc[sc.size() - 2] >> 32)) / match_sc - 4.343f * logf(n_sub));
+			mapq_pe = mapq_pe < mapq_pe_alt ? mapq_pe : mapq_pe_alt;
+		}
+		if ((int)r[0]->mapq < mapq_pe) r[0]->mapq = (int)(.2f * r[0]->mapq + .8f * mapq_pe + .499f);
+		if ((int)r[1]->mapq < mapq_pe) r[1]->mapq = (int)(.2f * r[1]->mapq + .8f * mapq_pe + .499f);
+		if (sc.size() == 1) {
+			if (r[0]->mapq < 2) r[0]->mapq = 2;
+			if (r[1]->mapq < 2) r[1]->mapq = 2;
+		} else if ((uint64_t)max >> 32 > sc[sc.size() - 2] >> 32) {
+			if (r[0]->mapq < 1) r[0]->mapq = 1;
+			if (r[1]->mapq < 1) r[1]->mapq = 1;
+		}
+	}
+	set_pe_thru(qlens, regs);
+}
+
+} // namespace mm2amd

@@ -23,6 +23,10 @@ void filter_regs(const ref::MapOpt &opt, int qlen, RegVec &r);                  
 int squeeze_anchors(RegVec &r, Anchor *a);                                                          // hit.c:322-340
 void set_mapq(RegVec &r, int min_chain_sc, int match_sc, int rep_len, bool is_sr, bool is_splice);  // hit.c:432-485
 void est_err(const FlatIndex &fi, int qlen, RegVec &r, const Anchor *a, const uint64_t *mini_pos, int32_t n_mini_pos); // esterr.c:30-64
+// two-segment fragments (paired-end reads)
+void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, const Anchor *a, RegVec *regs, std::vector<Anchor> *seg_a); // hit.c:342-396
+void select_sub_multi(float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs, const int *qlens, RegVec &r); // pe.c:6-50
+void pair_hits(int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int *qlens, RegVec *regs); // mm_pair, pe.c:81-182
 void update_dp_max(int qlen, RegVec &r, float frac, int a, int b);                                  // align.c:1022-1046
 
 } // namespace mm2amd

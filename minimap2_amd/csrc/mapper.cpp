@@ -65,7 +65,10 @@ void Mapper::stage(const std::vector<ReadView> &reads)
 	live_.clear(), live_id_.clear(), qoff_.clear();
 	// which reads are mapped at all (map.c:243-244)
 	for (long i = 0; i < n_staged_; ++i)
-		if (reads[i].len > 0 && !(opt_.max_qlen > 0 && reads[i].len > opt_.max_qlen)) live_.push_back(reads[i]), live_id_.push_back(i);
+		if (reads[i].total() > 0 && !(opt_.max_qlen > 0 && reads[i].total() > opt_.max_qlen)) live_.push_back(reads[i]), live_id_.push_back(i);
+	for (const ReadView &r : live_)
+		if (r.paired() && !be_.pending_paths_enabled())
+			throw std::invalid_argument("[mm2amd] paired-end fragments on the device are not validated on hardware yet; MM2AMD_PENDING=1 enables them");
 	if (!live_.empty()) be_.begin_batch(live_, qoff_);
 }
 
@@ -105,7 +108,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 		if (sub_reads < max_reads) max_reads = sub_reads;
 		for (long lo = 0, hi; lo < m_all; lo = hi) {
 			long bases = 0;
-			for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].len <= sub_bases); ++hi) bases += live[hi].len;
+			for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].total() <= sub_bases); ++hi) bases += live[hi].total();
 			subs.emplace_back(lo, hi);
 		}
 	}
@@ -161,7 +164,24 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			// again with the occurrence cap raised to max_occ and chained again.  Rare (only with -f x,y): the whole sub-batch is
 			// seeded a second time and the results of the reads concerned replace the first ones.
 			std::vector<long> again;
-			for (long i = 0; i < m; ++i) if (chains[i].n_u == 0 && chains[i].rep_len > 0) again.push_back(i);
+			for (long i = 0; i < m; ++i) {
+				const ReadChains &c = chains[i];
+				if (c.rep_len <= 0) continue;
+				bool rechain = c.n_u == 0;
+				if (!rechain && live[lo + i].paired()) { // does the best chain hold anchors of both segments? (map.c:295-306)
+					int max = 0, max_i = -1, n_chained_segs = 1;
+					int64_t max_off = -1, off = 0;
+					for (int32_t k = 0; k < c.n_u; ++k) {
+						if (max < (int)(c.u_p[k] >> 32)) max = (int)(c.u_p[k] >> 32), max_i = k, max_off = off;
+						off += (uint32_t)c.u_p[k];
+					}
+					if (max_i >= 0)
+						for (int32_t k = 1; k < (int32_t)c.u_p[max_i]; ++k)
+							if ((c.a_p[max_off + k].y & SEED_SEG_MASK) != (c.a_p[max_off + k - 1].y & SEED_SEG_MASK)) ++n_chained_segs;
+					rechain = n_chained_segs < 2;
+				}
+				if (rechain) again.push_back(i);
+			}
 			if (!again.empty()) {
 				for (long i = 0; i < m; ++i) chains[i].take_ownership(); // the backend's buffers are about to be reused
 				SeedChainParams sp2 = sp;
@@ -174,21 +194,36 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		stats.t_seed_chain += now() - t0; t0 = now();
 
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
+		// A two-segment fragment (paired-end reads) is seeded and chained as one query -- the concatenation of its segments -- and
+		// then split: each segment becomes an alignment UNIT of its own (map.c:343-351); a plain read is one unit.
 		Aligner aligner(opt_, fi_);
 		std::vector<ReadAlign> &ra = ds.ra;
 		std::vector<RegVec> &regs0 = ds.regs0;
-		if ((long)ra.size() < m) ra.resize(m), regs0.resize(m);
+		std::vector<long> &unit0 = ds.unit0;
+		unit0.resize(m + 1);
+		unit0[0] = 0;
+		for (long i = 0; i < m; ++i) unit0[i + 1] = unit0[i] + (live[lo + i].paired() ? 2 : 1);
+		const long mu = unit0[m];
+		if ((long)regs0.size() < m) regs0.resize(m);
+		if ((long)ra.size() < mu) ra.resize(mu);
+		if ((long)ds.seg_regs.size() < mu) ds.seg_regs.resize(mu), ds.seg_a.resize(mu);
 		// nt4 copies of the reads for the host-side checks (Z-drop rescoring, CIGAR fixes): one arena per driver instead of one
 		// heap block per read
 		uint64_t q4_total = 0;
-		ds.q4_off.resize(m + 1);
-		for (long i = 0; i < m; ++i) ds.q4_off[i] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len;
+		ds.q4_off.resize(mu + 1);
+		for (long i = 0; i < m; ++i) {
+			ds.q4_off[unit0[i]] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len;
+			if (live[lo + i].paired()) ds.q4_off[unit0[i] + 1] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len2;
+		}
 		if (ds.q4.size() < q4_total) ds.q4.resize(q4_total + q4_total / 4);
+		const bool is_sr = (opt_.flag & (F_SR | F_SR_RNA)) != 0;
 		parallel_for(n_threads_, m, [&](long i, int) {
 			ReadChains &c = chains[i];
-			const int qlen = live[lo + i].len;
+			const ReadView &rv = live[lo + i];
+			const int qlen = rv.total(), n_segs = rv.paired() ? 2 : 1, qlens[2] = { rv.len, rv.len2 };
+			const long u0 = unit0[i];
 			ReadResult &res = out[live_id[lo + i]];
-			const uint32_t hash = read_hash(live[lo + i].name, qlen, opt_);
+			const uint32_t hash = read_hash(rv.name, qlen, opt_);
 			if (opt_.flag & F_RMQ) { // mg_lchain_rmq as the primary chainer (map.c:275-277)
 				ChainScratch sc;
 				std::vector<uint64_t> u2;
@@ -198,7 +233,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				c.u.swap(u2), c.a.swap(out_a);
 				c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
 			}
-			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && c.n_u > 1) { // long-join re-chaining (map.c:283-292)
+			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && n_segs == 1 && c.n_u > 1) { // long-join re-chaining (map.c:283-292)
 				const int32_t st = (int32_t)c.a_p[0].y, en = (int32_t)c.a_p[(int32_t)c.u_p[0] - 1].y;
 				if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {
 					ChainScratch sc;
@@ -223,18 +258,37 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
 				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
-				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
+				if (n_segs <= 1) select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
+				else select_sub_multi(opt_.pri_ratio, 0.2f, 0.7f, gap_ref, fi_.k * 2, opt_.best_n, n_segs, qlens, r0);
 			}
 			if (!(opt_.flag & F_SR)) { // map.c:333-336
 				est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 				filter_strand_retained(r0);
 			}
-			if (!(opt_.flag & F_CIGAR)) { // mapping without base-level alignment: the chains are the hits (align_regs returns early, map.c:217)
-				res.regs = r0;
-				set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, (opt_.flag & (F_SR | F_SR_RNA)) != 0, opt_.flag & F_SPLICE);
+			if (n_segs == 1) {
+				if (!(opt_.flag & F_CIGAR)) { // mapping without base-level alignment: the chains are the hits (align_regs returns early, map.c:217)
+					res.regs = r0;
+					set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, is_sr, opt_.flag & F_SPLICE);
+					return;
+				}
+				aligner.begin_read(ra[u0], rv.seq, qlen, r0, c.a_p, qoff[lo + i], qoff[lo + i] + (uint64_t)qlen, ds.q4.data() + ds.q4_off[u0]);
 				return;
 			}
-			aligner.begin_read(ra[i], live[lo + i].seq, qlen, r0, c.a_p, qoff[lo + i], ds.q4.data() + ds.q4_off[i]);
+			// two segments (map.c:343-351): per-segment chains and anchors, primaries chosen again per segment
+			seg_gen(hash, 2, qlens, r0, c.a_p, &ds.seg_regs[u0], &ds.seg_a[u0]);
+			for (int s = 0; s < 2; ++s) {
+				RegVec &rs = ds.seg_regs[u0 + s];
+				set_parent(opt_.mask_level, opt_.mask_len, rs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
+				if (!(opt_.flag & F_CIGAR)) {
+					RegVec &dst = s == 0 ? res.regs : res.regs2;
+					dst = rs;
+					set_mapq(dst, opt_.min_chain_score, opt_.a, res.rep_len, is_sr, opt_.flag & F_SPLICE);
+					continue;
+				}
+				// in the query pool every read of a pair has its own  forward | reverse-complement  block, one after the other
+				const uint64_t fwd = qoff[lo + i] + (s == 0 ? 0 : 2 * (uint64_t)rv.len), rev = fwd + (uint64_t)qlens[s];
+				aligner.begin_read(ra[u0 + s], s == 0 ? rv.seq : rv.seq2, qlens[s], rs, ds.seg_a[u0 + s].data(), fwd, rev, ds.q4.data() + ds.q4_off[u0 + s]);
+			}
 		});
 		Trace::get().add(lane, "host:pre", t0, now());
 		stats.t_host_pre += now() - t0;
@@ -246,24 +300,24 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.noncan = (int8_t)opt_.noncan;
 		sc.single = (opt_.flag & F_SPLICE) ? 2 : (opt_.q == opt_.q2 && opt_.e == opt_.e2) ? 1 : 0; // which DP mm_align_pair picks (align.c:352-360)
 		std::vector<std::vector<KswJob>> &per_read_jobs = ds.per_read_jobs;
-		if ((long)per_read_jobs.size() < m) per_read_jobs.resize(m);
+		if ((long)per_read_jobs.size() < mu) per_read_jobs.resize(mu);
 		std::vector<size_t> &job_base = ds.job_base;
-		job_base.resize(m + 1);
+		job_base.resize(mu + 1);
 		std::vector<KswJob> &jobs = ds.jobs;
 		std::vector<KswRes> &kres = ds.kres;
 		const uint32_t *cigars = nullptr;
-		std::vector<uint8_t> active(m, 1);
+		std::vector<uint8_t> active(mu, 1);
 		for (int round = 0;; ++round) {
 			t0 = now();
-			parallel_for(n_threads_, m, [&](long i, int tid) {
+			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				per_read_jobs[i].clear();
 				if (active[i]) al[tid]->schedule(ra[i], per_read_jobs[i]);
 			});
 			job_base[0] = 0;
-			for (long i = 0; i < m; ++i) job_base[i + 1] = job_base[i] + per_read_jobs[i].size();
-			if (job_base[m] == 0) break;
-			jobs.resize(job_base[m]);
-			parallel_for(n_threads_, m, [&](long i, int) {
+			for (long i = 0; i < mu; ++i) job_base[i + 1] = job_base[i] + per_read_jobs[i].size();
+			if (job_base[mu] == 0) break;
+			jobs.resize(job_base[mu]);
+			parallel_for(n_threads_, mu, [&](long i, int) {
 				if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
 			}, 256);
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
@@ -276,7 +330,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			be_.ksw(jobs, sc, lane, n_threads_, kres, &cigars);
 			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
 			stats.t_ksw += now() - t0; t0 = now();
-			parallel_for(n_threads_, m, [&](long i, int tid) {
+			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
 			Trace::get().add(lane, "host:consume", t0, now());
@@ -284,17 +338,29 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");
 		}
 
-		// ---- final hit selection and MAPQ (map.c:215-225, :339-342) ----
+		// ---- final hit selection and MAPQ (map.c:215-225, :339-342), pairing (map.c:353-354) ----
 		t0 = now();
 		parallel_for(n_threads_, m, [&](long i, int tid) {
 			ReadResult &res = out[live_id[lo + i]];
-			al[tid]->finish_read(ra[i], res.regs);
-			if (!(opt_.flag & F_ALL_CHAINS)) {
-				set_parent(opt_.mask_level, opt_.mask_len, res.regs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
-				select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), res.regs);
-				set_sam_pri(res.regs);
+			const ReadView &rv = live[lo + i];
+			const int n_segs = rv.paired() ? 2 : 1;
+			for (int s = 0; s < n_segs; ++s) {
+				RegVec &regs = s == 0 ? res.regs : res.regs2;
+				al[tid]->finish_read(ra[unit0[i] + s], regs);
+				if (!(opt_.flag & F_ALL_CHAINS)) {
+					set_parent(opt_.mask_level, opt_.mask_len, regs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
+					select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), regs);
+					set_sam_pri(regs);
+				}
+				set_mapq(regs, opt_.min_chain_score, opt_.a, res.rep_len, is_sr, opt_.flag & F_SPLICE);
 			}
-			set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, (opt_.flag & (F_SR | F_SR_RNA)) != 0, opt_.flag & F_SPLICE);
+			if (n_segs == 2 && opt_.pe_ori >= 0) {
+				const int qlens[2] = { rv.len, rv.len2 };
+				RegVec both[2];
+				both[0].swap(res.regs), both[1].swap(res.regs2);
+				pair_hits(res.frag_gap, opt_.pe_bonus, opt_.a * 2 + opt_.b, opt_.a, qlens, both);
+				both[0].swap(res.regs), both[1].swap(res.regs2);
+			}
 		});
 		Trace::get().add(lane, "host:finish", t0, now());
 		stats.t_finish += now() - t0;

@@ -12,6 +12,7 @@ namespace mm2amd {
 
 struct ReadResult {
 	RegVec regs;       // final hits; each regs[i].p is libc-allocated (caller frees)
+	RegVec regs2;      // ... of the second segment of a two-segment fragment
 	int rep_len = 0;   // mm_tbuf_t::rep_len (map.c:318)
 	int frag_gap = 0;  // mm_tbuf_t::frag_gap (map.c:317)
 };
@@ -36,6 +37,9 @@ private:
 		std::vector<ReadChains> chains;
 		std::vector<ReadAlign> ra;
 		std::vector<RegVec> regs0;
+		std::vector<long> unit0;                 // first alignment unit of each fragment of the sub-batch (a pair has two)
+		std::vector<RegVec> seg_regs;            // per unit: the segment's chains (pairs only)
+		std::vector<std::vector<Anchor>> seg_a;  // per unit: the segment's anchors (pairs only)
 		std::vector<std::vector<KswJob>> per_read_jobs;
 		std::vector<size_t> job_base;
 		std::vector<KswJob> jobs;

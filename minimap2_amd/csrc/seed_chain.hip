@@ -185,7 +185,7 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int popc_below(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
 
 constexpr int HIST_N = 2048;
-constexpr uint32_t SD_TANDEM = 1u << 8, SD_FLT = 1u << 9;
+constexpr uint32_t SD_TANDEM = 1u << 8, SD_FLT = 1u << 9, SD_SEG1 = 1u << 31; // SD_SEG1: the seed comes from the second read of a pair
 
 // max-heap sift-down on (n<<32 | index) keys, used by the rare high-occurrence thinning (seed.c:56-96)
 __device__ void heap_down(uint64_t *h, int i, int n)
@@ -235,10 +235,28 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 	const uint64_t mo = B.mz_off[r];
 	uint64_t *mx = B.mz_x + mo, *my = B.mz_y + mo;
 	uint32_t *sd_n = B.sd_n + mo, *sd_off = B.sd_off + mo, *sd_aoff = B.sd_aoff + mo, *sd_qpos = B.sd_qpos + mo, *sd_info = B.sd_info + mo;
-	int n = (int)B.mz_cnt[r];
+	int n;
 	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
 	uint32_t *hist = s_hist[wave];
 	HIT_RULES_SETUP();
+	if (B.unit_first) { // a fragment of one or two units; a pair's second list joins the first (collect_minimizers, map.c:59-72)
+		const int32_t u0 = B.unit_first[r];
+		n = (int)B.unit_cnt[u0];
+		if (B.unit_first[r + 1] - u0 == 2) {
+			const int n1 = (int)B.unit_cnt[u0 + 1];
+			const uint64_t len0 = B.unit_off[u0 + 1] - B.unit_off[u0];
+			const uint64_t *sx = mx + len0, *sy = my + len0; // the second unit's minimizers sit at its own slots, len0 further on
+			for (int base = 0; base < n1; base += 64) {
+				const int i = base + lane;
+				uint64_t x = 0, y = 0;
+				if (i < n1) x = sx[i], y = sy[i];
+				WAVE_SYNC();
+				if (i < n1) mx[n + i] = x, my[n + i] = y + (len0 << 1) + (1ULL << 32); // position within the fragment, segment id 1
+				WAVE_SYNC();
+			}
+			n += n1;
+		}
+	} else n = (int)B.mz_cnt[r];
 
 	// ---- query-side filter of over-represented minimizers (mm_seed_mz_flt, seed.c:5-28) ----
 	if (P.q_occ_frac > 0.0f && n > P.q_mid_occ && P.q_mid_occ > 0) {
@@ -288,6 +306,7 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 		uint32_t off = 0;
 		const uint32_t cnt = idx_lookup(I, x >> 8, &off);
 		uint32_t info = (uint32_t)(x & 0xff);
+		if (my[i] >> 32) info |= SD_SEG1;
 		if (i > 0 && x >> 8 == mx[i - 1] >> 8) info |= SD_TANDEM;
 		if (i < n - 1 && x >> 8 == mx[i + 1] >> 8) info |= SD_TANDEM;
 		sd_n[i] = cnt, sd_off[i] = off, sd_info[i] = info, sd_qpos[i] = (uint32_t)my[i];
@@ -373,8 +392,8 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
 		const unsigned long long km = __ballot(kept);
 		if (i < n_m0) sd_aoff[i] = kept ? n_a + incl - c : 0xffffffffu;
-		// rank among kept seeds goes into the high bits of info (bits 10..31): up to 4M seeds per read
-		if (kept) sd_info[i] = (sd_info[i] & 0x3ffu) | ((n_kept + (uint32_t)popc_below(km, lane)) << 10);
+		// rank among kept seeds goes into bits 10..30 of info: up to 2M seeds per read
+		if (kept) sd_info[i] = (sd_info[i] & (0x3ffu | SD_SEG1)) | ((n_kept + (uint32_t)popc_below(km, lane)) << 10);
 		n_a += __shfl(incl, 63, 64);
 		n_kept += (uint32_t)__popcll(km);
 	}
@@ -407,7 +426,7 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 		const uint32_t ao = sd_aoff[i];
 		if (ao == 0xffffffffu) continue;
 		const uint32_t info = sd_info[i], span = info & 0xff, qp = sd_qpos[i], cnt = sd_n[i];
-		mp[info >> 10] = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
+		mp[info << 1 >> 11] = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
 		const uint64_t *cr = I.pos + sd_off[i];
 		uint32_t w = 0; // anchors written for this seed
 		for (uint32_t c = 0; c < cnt; ++c) {
@@ -423,6 +442,7 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 				p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
 				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
 			}
+			if (info & SD_SEG1) p.y |= 1ULL << ref::SEED_SEG_SHIFT;
 			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
 			if (is_self) p.y |= ref::SEED_SELF;
 			akey[ao + w] = read_tag | (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL);
@@ -633,6 +653,7 @@ __global__ void __launch_bounds__(64) anchor_heap_order_kernel(SeedChainBuffers 
 					p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
 					p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
 				}
+				if (info & SD_SEG1) p.y |= 1ULL << ref::SEED_SEG_SHIFT;
 				if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
 				if (is_self) p.y |= ref::SEED_SELF;
 				if (p.x >> 63) { if (n_for + n_rev < n) out[n - (++n_rev)] = p; }
@@ -700,23 +721,27 @@ __device__ __forceinline__ float fast_log2_dev(float x) // mg_log2, mmpriv.h:139
 	return l;
 }
 
-// comput_sc (lchain.c:113-138) for single-segment reads
+// comput_sc (lchain.c:113-138).  n_seg = 2 for a read pair: its anchors carry the segment (read) they come from, the distance
+// and bandwidth limits only hold between anchors of one read, and a jump from one read to its mate is charged like a deletion.
 __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, int32_t max_dist_x, int32_t max_dist_y, int32_t bw,
-                                              float pen_gap, float pen_skip, int is_cdna)
+                                              float pen_gap, float pen_skip, int is_cdna, int n_seg)
 {
 	const int32_t dq = (int32_t)iy - (int32_t)jy;
+	const bool same = ((iy ^ jy) & ref::SEED_SEG_MASK) == 0;
 	if (dq <= 0 || dq > max_dist_x) return INT32_MIN;
 	const int32_t dr = (int32_t)(ix - jx);
-	if (dr == 0 || dq > max_dist_y) return INT32_MIN;
+	if (same && (dr == 0 || dq > max_dist_y)) return INT32_MIN;
 	const int32_t dd = dr > dq ? dr - dq : dq - dr;
-	if (dd > bw) return INT32_MIN;
+	if (same && dd > bw) return INT32_MIN;
+	if (n_seg > 1 && !is_cdna && same && dr > max_dist_y) return INT32_MIN;
 	const int32_t dg = dr < dq ? dr : dq, span = (int32_t)(jy >> 32 & 0xff);
 	int32_t sc = span < dg ? span : dg;
 	if (dd || dg > span) {
 		const float lin = pen_gap * (float)dd + pen_skip * (float)dg;
 		const float lg = dd >= 1 ? fast_log2_dev((float)(dd + 1)) : 0.0f;
-		if (is_cdna) {
-			if (dr > dq) sc -= (int)(lin < lg ? lin : lg);
+		if (is_cdna || !same) {
+			if (!same && dr == 0) ++sc; // overlapping mates
+			else if (dr > dq || !same) sc -= (int)(lin < lg ? lin : lg);
 			else sc -= (int)(lin + .5f * lg);
 		} else sc -= (int)(lin + .5f * lg);
 	}
@@ -740,6 +765,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
 	int32_t max_dist_x, max_dist_y;
 	chain_gaps(P, (int)(B.seq_off[r + 1] - B.seq_off[r]), &max_dist_x, &max_dist_y);
+	const int n_seg = B.unit_first ? B.unit_first[r + 1] - B.unit_first[r] : 1;
 	const int32_t bw = P.bw;
 	if (max_dist_x < bw) max_dist_x = bw;
 	if (max_dist_y < bw && !P.is_cdna) max_dist_y = bw;
@@ -791,7 +817,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				const int64_t j = base - lane;
 				int32_t sc = INT32_MIN, pj = -1;
 				if (j >= st) {
-					sc = link_score(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
+					sc = link_score(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
 					if (sc != INT32_MIN) sc += f[j], pj = p[j];
 				}
 				const bool has = sc != INT32_MIN;
@@ -839,7 +865,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				if (max_ii >= 0) { const Anchor m = a[max_ii]; mii_x = m.x, mii_y = m.y, mii_f = (int32_t)(best >> 32); }
 			}
 			if (max_ii >= 0 && max_ii < end_j) {
-				const int32_t tmp = link_score(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna);
+				const int32_t tmp = link_score(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
 				if (tmp != INT32_MIN && max_f < tmp + mii_f) max_f = tmp + mii_f, max_j = max_ii;
 			}
 			if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;

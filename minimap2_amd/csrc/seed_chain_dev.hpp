@@ -27,6 +27,11 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	// per read, for the all-vs-all rules: number of distinct reference names that sort before the read's name, and the rank of
 	// the reference name equal to it (-1: none).  Null when the batch carries no read names.
 	const int32_t *name_lb, *name_eq;
+	// pairs (null otherwise): fragment r consists of units unit_first[r] .. unit_first[r+1]-1 (one or two reads), unit u starts at
+	// base unit_off[u] of the batch and has unit_cnt[u] minimizers, written from slot unit_off[u]
+	const int32_t *unit_first;
+	const uint64_t *unit_off;
+	const uint32_t *unit_cnt;
 	// minimizers
 	uint32_t *mz_cnt;         // n_reads
 	const uint64_t *mz_off;   // n_reads (+1): first minimizer slot of each read (the read's base offset: at most one minimizer per base)

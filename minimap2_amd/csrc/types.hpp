@@ -22,11 +22,16 @@ struct IdxParams {
 	int k = 15, w = 10, flag = 0;
 };
 
-// One read (single segment) handed to the mapper.
+// One fragment handed to the mapper: a read, or the two reads of a pair (seq2/len2 set) already in the orientation they are
+// mapped in (worker_for reverse-complements a mate according to pe_ori before mapping, map.c:436-442).
 struct ReadView {
 	const char *seq = nullptr;   // ASCII
 	int len = 0;
 	const char *name = nullptr;  // may be null
+	const char *seq2 = nullptr;  // second segment of a two-segment fragment
+	int len2 = 0;
+	bool paired() const { return seq2 != nullptr; }
+	int total() const { return len + len2; }
 };
 
 // What seeding + chaining produces for one read (the state of mm_map_frag_core after map.c:316).

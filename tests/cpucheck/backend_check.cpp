@@ -33,15 +33,18 @@ public:
 		reads_ = reads;
 		qpool_off.resize(reads.size());
 		size_t tot = 0;
-		for (size_t i = 0; i < reads.size(); ++i) qpool_off[i] = tot, tot += 2 * (size_t)reads[i].len;
+		for (size_t i = 0; i < reads.size(); ++i) qpool_off[i] = tot, tot += 2 * (size_t)reads[i].total();
 		qpool_.assign(tot + 1, 0);
 		const uint8_t *nt4 = ora_nt4_table();
-		for (size_t i = 0; i < reads.size(); ++i) {
-			uint8_t *f = &qpool_[qpool_off[i]];
-			const int len = reads[i].len;
-			for (int j = 0; j < len; ++j) {
-				const uint8_t c = nt4[(uint8_t)reads[i].seq[j]];
-				f[j] = c, f[2 * (size_t)len - 1 - j] = c < 4 ? 3 - c : 4;
+		for (size_t i = 0; i < reads.size(); ++i) { // every read of a pair gets its own  forward | reverse-complement  block
+			for (int s = 0; s < (reads[i].paired() ? 2 : 1); ++s) {
+				uint8_t *f = &qpool_[qpool_off[i] + (s ? 2 * (size_t)reads[i].len : 0)];
+				const char *seq = s ? reads[i].seq2 : reads[i].seq;
+				const int len = s ? reads[i].len2 : reads[i].len;
+				for (int j = 0; j < len; ++j) {
+					const uint8_t c = nt4[(uint8_t)seq[j]];
+					f[j] = c, f[2 * (size_t)len - 1 - j] = c < 4 ? 3 - c : 4;
+				}
 			}
 		}
 	}
@@ -51,9 +54,14 @@ public:
 		out.resize((size_t)(hi - lo));
 		std::vector<ora128_t> mv;
 		for (size_t i = (size_t)lo; i < (size_t)hi; ++i) {
-			const int len = reads_[i].len;
-			mv.resize((size_t)len + 1);
-			int64_t n_mv = ora_sketch(reads_[i].seq, len, p.w, p.k, 0, p.is_hpc, mv.data(), (int64_t)mv.size());
+			const int len = reads_[i].total(), n_seg = reads_[i].paired() ? 2 : 1;
+			mv.resize((size_t)len + 2);
+			int64_t n_mv = ora_sketch(reads_[i].seq, reads_[i].len, p.w, p.k, 0, p.is_hpc, mv.data(), (int64_t)mv.size());
+			if (n_seg == 2) { // collect_minimizers (map.c:59-72): segment id in the rid field, positions offset by the earlier segments
+				const int64_t n1 = ora_sketch(reads_[i].seq2, reads_[i].len2, p.w, p.k, 1, p.is_hpc, mv.data() + n_mv, (int64_t)mv.size() - n_mv);
+				for (int64_t j = n_mv; j < n_mv + n1; ++j) mv[j].y += (uint64_t)reads_[i].len << 1;
+				n_mv += n1;
+			}
 			ora128_t *a = nullptr;
 			uint64_t *mp = nullptr;
 			int64_t n_a = 0;
@@ -83,7 +91,7 @@ public:
 			int gap_ref, gap_qry;
 			chain_gaps(p, len, &gap_ref, &gap_qry);
 			const int n_u = ora_lchain_dp(gap_ref, gap_qry, p.bw, p.max_chain_skip, p.max_chain_iter, p.min_cnt, p.min_chain_score,
-			                              p.chn_pen_gap, p.chn_pen_skip, p.is_cdna, 1, n_a, a, c.u.data(), &n_kept);
+			                              p.chn_pen_gap, p.chn_pen_skip, p.is_cdna, n_seg, n_a, a, c.u.data(), &n_kept);
 			c.u.resize(n_u);
 			c.a.resize(n_kept);
 			if (n_kept) memcpy(c.a.data(), a, n_kept * sizeof(ora128_t));

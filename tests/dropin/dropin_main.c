@@ -116,7 +116,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
-	if (argc - k < 2) { fprintf(stderr, "usage: dropin [options] ref reads\n"); return 1; }
+	if (argc - k < 2) { fprintf(stderr, "usage: dropin [options] ref reads [mates]\n"); return 1; }
 	if (!(mopt.flag & MM_F_CIGAR)) iopt.flag |= MM_I_NO_SEQ; /* main.c:352-353 */
 	if (mm_check_opt(&iopt, &mopt) < 0) return 1;
 	if (mopt.best_n == 0) mopt.best_n = old_best_n, mopt.flag |= MM_F_NO_PRINT_2ND; /* main.c:356-359: '-N 0' becomes '-N <preset> --secondary=no' */
@@ -129,17 +129,29 @@ int main(int argc, char *argv[])
 		mm_mapopt_update(&mopt, mi);
 		if (alt_fn) mm_idx_alt_read(mi, alt_fn); /* main.c:480 */
 		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
-		mm_bseq_file_t *fp = mm_bseq_open(argv[k + 1]);
-		if (fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
+		/* one read file, or two for paired-end reads (worker_pipeline step 0, map.c:545-569) */
+		/* without MM_F_FRAG_MODE several query files are mapped one after the other (main.c:493-500) */
+		int n_files = argc - (k + 1) >= 2 ? 2 : 1, file0;
+		for (file0 = 0; file0 < n_files; file0 += (mopt.flag & MM_F_FRAG_MODE) ? n_files : 1) {
+		int n_fp = (mopt.flag & MM_F_FRAG_MODE) ? n_files : 1, n_frag;
+		int frag_mode = (n_fp > 1 || !!(mopt.flag & MM_F_FRAG_MODE));
+		mm_bseq_file_t *fp, *fps[2];
+		for (i = 0; i < n_fp; ++i) {
+			fps[i] = mm_bseq_open(argv[k + 1 + file0 + i]);
+			if (fps[i] == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1 + file0 + i]); return 1; }
+		}
+		fp = fps[0];
 		int with_qual = (!!(mopt.flag & MM_F_OUT_SAM) && !(mopt.flag & MM_F_NO_QUAL)), n_seq;
 		mm_bseq1_t *seq;
-		while ((seq = mm_bseq_read3(fp, batch, with_qual, !!(mopt.flag & MM_F_COPY_COMMENT), 0, &n_seq)) != 0) {
+		while ((seq = n_fp > 1 ? mm_bseq_read_frag2(n_fp, fps, batch, with_qual, !!(mopt.flag & MM_F_COPY_COMMENT), &n_seq)
+		                       : mm_bseq_read3(fp, batch, with_qual, !!(mopt.flag & MM_F_COPY_COMMENT), frag_mode, &n_seq)) != 0) {
 			int *n_reg = (int*)calloc(5 * (size_t)n_seq, sizeof(int));
 			int *seg_off = n_reg + n_seq, *n_seg = seg_off + n_seq, *rep_len = n_seg + n_seq, *frag_gap = rep_len + n_seq;
 			mm_reg1_t **reg = (mm_reg1_t**)calloc(n_seq, sizeof(mm_reg1_t*));
-			int j;
-			for (i = 0; i < n_seq; ++i) seg_off[i] = i, n_seg[i] = 1;
-			if (mm_gpu_map_batch(n_seq, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {
+			int j, f;
+			for (i = 1, j = 0, n_frag = 0; i <= n_seq; ++i)
+				if (i == n_seq || !frag_mode || !mm_qname_same(seq[i-1].name, seq[i].name)) n_seg[n_frag] = i - j, seg_off[n_frag++] = j, j = i;
+			if (mm_gpu_map_batch(n_frag, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {
 				fprintf(stderr, "mm_gpu_map_batch: %s\n", mm2amd_last_error());
 				return 2;
 			}
@@ -153,38 +165,45 @@ int main(int argc, char *argv[])
 			if (format_lib) {
 				char *text = 0;
 				size_t text_len = 0;
-				if (mm_gpu_format_batch(n_seq, seg_off, n_seg, seq, n_reg, (void *const*)reg, rep_len, &text, &text_len) != 0) {
+				if (mm_gpu_format_batch(n_frag, seg_off, n_seg, seq, n_reg, (void *const*)reg, rep_len, &text, &text_len) != 0) {
 					fprintf(stderr, "mm_gpu_format_batch: %s\n", mm2amd_last_error());
 					return 2;
 				}
 				fwrite(text, 1, text_len, stdout);
 				free(text);
 			}
-			for (i = 0; i < n_seq; ++i) { /* output, as step 2 of worker_pipeline (map.c:585-636) for single-segment reads */
-				mm_bseq1_t *t = &seq[i];
-				if (format_lib) {
-				} else if (n_reg[i] > 0) {
-					for (j = 0; j < n_reg[i]; ++j) {
-						const mm_reg1_t *r = &reg[i][j];
-						if ((mopt.flag & MM_F_NO_PRINT_2ND) && r->id != r->parent) continue;
-						if (mopt.flag & MM_F_OUT_SAM) mm_write_sam3(&str, mi, t, 0, j, 1, &n_reg[i], (const mm_reg1_t*const*)&reg[i], 0, mopt.flag, rep_len[i]);
-						else mm_write_paf4(&str, mi, t, r, 0, mopt.flag, rep_len[i], 1, 0);
+			for (f = 0; f < n_frag; ++f) { /* output, as step 2 of worker_pipeline (map.c:585-636) */
+				int seg_st = seg_off[f], seg_en = seg_off[f] + n_seg[f];
+				for (i = seg_st; i < seg_en; ++i) {
+					mm_bseq1_t *t = &seq[i];
+					if (format_lib) {
+					} else if (n_reg[i] > 0) {
+						for (j = 0; j < n_reg[i]; ++j) {
+							const mm_reg1_t *r = &reg[i][j];
+							if ((mopt.flag & MM_F_NO_PRINT_2ND) && r->id != r->parent) continue;
+							if (mopt.flag & MM_F_OUT_SAM) mm_write_sam3(&str, mi, t, i - seg_st, j, n_seg[f], &n_reg[seg_st], (const mm_reg1_t*const*)&reg[seg_st], 0, mopt.flag, rep_len[i]);
+							else mm_write_paf4(&str, mi, t, r, 0, mopt.flag, rep_len[i], n_seg[f], i - seg_st);
+							mm_err_puts(str.s);
+						}
+					} else if ((mopt.flag & MM_F_PAF_NO_HIT) || ((mopt.flag & MM_F_OUT_SAM) && !(mopt.flag & MM_F_SAM_HIT_ONLY))) {
+						if (mopt.flag & MM_F_OUT_SAM) mm_write_sam3(&str, mi, t, i - seg_st, -1, n_seg[f], &n_reg[seg_st], (const mm_reg1_t*const*)&reg[seg_st], 0, mopt.flag, rep_len[i]);
+						else mm_write_paf4(&str, mi, t, 0, 0, mopt.flag, rep_len[i], n_seg[f], i - seg_st);
 						mm_err_puts(str.s);
 					}
-				} else if ((mopt.flag & MM_F_PAF_NO_HIT) || ((mopt.flag & MM_F_OUT_SAM) && !(mopt.flag & MM_F_SAM_HIT_ONLY))) {
-					if (mopt.flag & MM_F_OUT_SAM) mm_write_sam3(&str, mi, t, 0, -1, 1, &n_reg[i], (const mm_reg1_t*const*)&reg[i], 0, mopt.flag, rep_len[i]);
-					else mm_write_paf4(&str, mi, t, 0, 0, mopt.flag, rep_len[i], 1, 0);
-					mm_err_puts(str.s);
 				}
-				for (j = 0; j < n_reg[i]; ++j) free(reg[i][j].p);
-				free(reg[i]);
-				free(t->seq); free(t->name);
-				if (t->qual) free(t->qual);
-				if (t->comment) free(t->comment);
+				for (i = seg_st; i < seg_en; ++i) {
+					mm_bseq1_t *t = &seq[i];
+					for (j = 0; j < n_reg[i]; ++j) free(reg[i][j].p);
+					free(reg[i]);
+					free(t->seq); free(t->name);
+					if (t->qual) free(t->qual);
+					if (t->comment) free(t->comment);
+				}
 			}
 			free(reg); free(n_reg); free(seq);
 		}
-		mm_bseq_close(fp);
+		for (i = 0; i < n_fp; ++i) mm_bseq_close(fps[i]);
+		}
 		mm_gpu_destroy();
 		mm_idx_destroy(mi);
 	}

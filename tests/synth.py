@@ -243,6 +243,64 @@ def make_short(outdir, seed=91, n_reads=400, genome=400000):
     return ref, rd
 
 
+def make_pairs(outdir, seed=95, n_pairs=300, genome=400000):
+    """Paired-end reads (FR, 2 x 100-150 bp, inserts 250-700 bp, ~1 % substitutions, some small indels) from the reference of
+    make_short (duplications, tandem arrays).  Also: pairs whose mates overlap or contain each other, pairs with one unmappable
+    mate, mates on different contigs, a pair too far apart, a pair in the wrong orientation, mates of 30 bp.  Returns
+    (ref.fa, r1.fa, r2.fa, interleaved.fa)."""
+    ref, _ = make_short(outdir, seed=seed, n_reads=12, genome=genome)
+    rng = np.random.default_rng(seed + 1000)
+    contigs = []
+    cur = []
+    for line in open(ref, "rb"):
+        if line.startswith(b">"):
+            continue
+        contigs.append(np.frombuffer(line.strip(), dtype=np.uint8))
+    lut = np.zeros(256, dtype=np.uint8)
+    lut[ord("C")], lut[ord("G")], lut[ord("T")] = 1, 2, 3
+    contigs = [lut[c] for c in contigs]
+
+    def noisy(s, k):
+        s = s.copy()
+        sub = rng.random(len(s)) < 0.01
+        s[sub] = (s[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
+        if k % 8 == 5 and len(s) > 60:
+            m = len(s) // 2
+            s = np.concatenate([s[:m], s[m + 6:]]) if k % 16 == 5 else np.concatenate([s[:m], rng.integers(0, 4, 6, dtype=np.uint8), s[m:]])
+        return s
+
+    r1, r2 = [], []
+    for k in range(n_pairs):
+        ci = int(rng.integers(0, 2))
+        c = contigs[ci]
+        l1, l2 = int(rng.integers(100, 151)), int(rng.integers(100, 151))
+        ins = int(rng.integers(250, 701))
+        if k % 13 == 3: ins = int(rng.integers(80, 200))      # overlapping mates
+        if k % 17 == 4: ins = 5000                            # too far apart
+        if k % 29 == 7: l1 = l2 = 30
+        ins = max(ins, l1, l2)
+        st = int(rng.integers(0, len(c) - ins))
+        a = c[st:st + l1]
+        b = COMP[c[st + ins - l2:st + ins][::-1]]
+        if k % 19 == 6:                                       # mate from the other contig
+            o = contigs[1 - ci]; so = int(rng.integers(0, len(o) - l2)); b = COMP[o[so:so + l2][::-1]]
+        if k % 23 == 8: b = rng.integers(0, 4, l2, dtype=np.uint8)  # unmappable mate
+        if k % 31 == 9: b = COMP[b[::-1]]                     # wrong orientation (FF)
+        a, b = noisy(a, k), noisy(b, k + 3)
+        if rng.random() < 0.5:                                # the fragment comes from the other strand: mates swap roles
+            a, b = b, a
+        r1.append(a), r2.append(b)
+    f1, f2, fi = (os.path.join(outdir, n) for n in ("r1.fa", "r2.fa", "inter.fa"))
+    names = ["pe%d" % k for k in range(n_pairs)]
+    write_fasta(f1, [n + "/1" for n in names], r1)
+    write_fasta(f2, [n + "/2" for n in names], r2)
+    with open(fi, "wb") as f:
+        for n, a, b in zip(names, r1, r2):
+            f.write(b">" + n.encode() + b"/1\n" + ACGT[a].tobytes() + b"\n>" + n.encode() + b"/2\n" + ACGT[b].tobytes() + b"\n")
+        f.write(b">lonely\n" + ACGT[r1[0]].tobytes() + b"\n")   # a single read among the pairs
+    return ref, f1, f2, fi
+
+
 def write_fasta(path, names, seqs, width=0):
     with open(path, "wb") as f:
         for nm, s in zip(names, seqs):

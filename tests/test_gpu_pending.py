@@ -73,3 +73,21 @@ def test_anchor_order_matches_print_seeds(args, tmp_path):
     assert len(want) > 300 and set(want) == set(got)
     bad = [k for k in want if want[k] != got[k]]
     assert not bad, bad[:5]
+
+
+PE_CASES = [(["-x", "sr", "-a"], 2), (["-x", "sr", "-a"], 1), (["-x", "sr"], 2), (["-x", "sr", "-c"], 1), (["-x", "sr", "-a", "-F", "400"], 2),
+            (["-x", "sr", "-a", "--heap-sort=no"], 2), (["-x", "sr", "-a", "-f", "2,20"], 1), (["-x", "sr", "-k", "15", "-w", "5", "-a"], 2)]
+
+
+@pytest.mark.parametrize("args,n_files", PE_CASES)
+def test_paired_end(args, n_files, tmp_path):
+    """Read pairs: the mates' minimizer lists joined in seed_collect_kernel, segment-aware link_score, then the host's mm_seg_gen /
+    mm_pair; two files or one interleaved file."""
+    ref, f1, f2, inter = synth.make_pairs(str(tmp_path))
+    files = [f1, f2] if n_files == 2 else [inter]
+    assert _run([REF_BIN, "-t", "8"] + args + [ref] + files) == _run([DROPIN, "-t", "8"] + args + [ref] + files)
+
+
+def test_paired_end_larger_set(tmp_path):
+    ref, f1, f2, inter = synth.make_pairs(str(tmp_path), seed=97, n_pairs=4000, genome=3000000)
+    assert _run([REF_BIN, "-t", "8", "-x", "sr", "-a", ref, f1, f2]) == _run([DROPIN, "-t", "8", "-x", "sr", "-a", ref, f1, f2])

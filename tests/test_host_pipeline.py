@@ -287,3 +287,26 @@ def test_device_heap_order_header_against_oracle():
         pytest.skip("tests/_build/heap_order_test not built")
     out = subprocess.run([exe, "3000"], stdout=subprocess.PIPE, check=True).stdout.split()
     assert out[0] == b"OK" and int(out[2]) > 1000
+
+
+PE_CASES = [(["-x", "sr", "-a"], 2), (["-x", "sr", "-a"], 1), (["-x", "sr"], 2), (["-x", "sr", "-c"], 1), (["-x", "sr", "-a", "-F", "400"], 2),
+            (["-x", "sr", "-a", "--heap-sort=no"], 2), (["-x", "sr", "-a", "-f", "2,20"], 1), (["-x", "sr", "-a", "-p", "0.3", "-N", "4"], 1),
+            (["-x", "sr", "-a", "-g", "300", "-r", "50"], 2), (["-x", "sr", "-k", "15", "-w", "5", "-a"], 2), (["-x", "sr", "-a", "-A", "1", "-B", "3"], 2),
+            (["-x", "map-ont", "-a"], 2)]
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args,n_files", PE_CASES)
+def test_paired_end(args, n_files, tmp_path):
+    """Two-segment fragments: joint seeding/chaining of the mates, mm_seg_gen, per-mate alignment, mm_pair (map.c:343-354, hit.c:342-396,
+    pe.c), from two files or one interleaved file; SAM mate fields come from the reference's writer fed with our hit records."""
+    import synth
+    ref, f1, f2, inter = synth.make_pairs(str(tmp_path))
+    outs = []
+    for binary in (G.REF_BIN, CHECK):
+        p = subprocess.run([binary] + args + [ref] + ([f1, f2] if n_files == 2 else [inter]), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, MM2AMD_PENDING="1"))
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        outs.append(G.strip_pg(p.stdout))
+    assert outs[0] == outs[1]
+    assert outs[0].count(b"\n") > 500
