@@ -210,11 +210,11 @@ int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, const 
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_format_batch called before mm_gpu_init");
 	if (n_frag < 0 || !out || !out_len || (n_frag > 0 && (!seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: bad arguments");
 	for (int i = 0; i < n_frag; ++i)
-		if ((n_seg && n_seg[i] != 1) || (seg_off && seg_off[i] != i)) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: single-segment fragments only");
+		if (n_seg && n_seg[i] != 1 && n_seg[i] != 2) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: fragments of one or two segments only");
 	const std::string why = format_check(g_ctx->opt);
 	if (!why.empty()) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: " + why);
 	try {
-		*out = format_batch(*g_ctx->fi, g_ctx->opt, g_ctx->n_threads, n_frag, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, out_len);
+		*out = format_batch(*g_ctx->fi, g_ctx->opt, g_ctx->n_threads, n_frag, seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, out_len);
 		if (!*out) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm_gpu_format_batch: out of memory");
 		return 0;
 	} catch (const std::exception &e) {

@@ -195,9 +195,10 @@ void put_cs_or_md(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 &r, i
 	else put_cs(o, r, sq, !(flag & F_OUT_CS_LONG), flag & F_OUT_DS);
 }
 
-void put_paf(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 *r, int64_t flag, int rep_len, Seqs &sq) // mm_write_paf4, n_seg == 1
+void put_paf(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 *r, int64_t flag, int rep_len, int n_seg, int seg_idx, Seqs &sq) // mm_write_paf4
 {
 	o.str(t.name);
+	if ((flag & F_FRAG_MODE) && n_seg >= 2 && seg_idx >= 0) o.ch('/'), o.num(seg_idx + 1);
 	if (!r) {
 		o.ch('\t'), o.num(t.l_seq), o.str("\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0");
 		if (rep_len >= 0) o.tag("rl:i:", rep_len);
@@ -250,21 +251,52 @@ void put_sam_cigar(Text &o, int sam_flag, bool in_tag, int qlen, const Reg1 &r, 
 }
 
 // mm_write_sam3 for a single-segment read: reg_idx < 0 writes the unmapped record
-void put_sam(Text &o, const FlatIndex &fi, const Bseq1 &t, int reg_idx, int n_regs, const Reg1 *regs, int64_t flag, int rep_len, Seqs &sq)
+const Reg1 *sam_primary(int n_regs, const Reg1 *regs) // get_sam_pri (format.c:484-492)
 {
+	for (int i = 0; i < n_regs; ++i) if (regs[i].sam_pri) return &regs[i];
+	return nullptr;
+}
+
+// mm_write_sam3 (format.c:522-700) for fragments of one or two segments
+void put_sam(Text &o, const FlatIndex &fi, const Bseq1 &t, int seg_idx, int reg_idx, int n_seg, const int *n_regss, void *const *regss, int64_t flag, int rep_len, Seqs &sq)
+{
+	const int n_regs = n_regss[seg_idx];
+	const Reg1 *regs = (const Reg1 *)regss[seg_idx];
 	const Reg1 *r = n_regs > 0 && reg_idx >= 0 && reg_idx < n_regs ? &regs[reg_idx] : nullptr;
-	o.str(t.name);
-	int sf = 0;
+	const Reg1 *r_next = nullptr, *r_prev = nullptr; // the mate's primary, if it is mapped
+	if (n_seg > 1) {
+		const int next_sid = (seg_idx + 1) % n_seg;
+		r_prev = r_next = sam_primary(n_regss[next_sid], (const Reg1 *)regss[next_sid]);
+	}
+	if (n_seg > 1) { // the name without a /1 or /2 suffix (mm_qname_len, bseq.h:31-36)
+		size_t l = strlen(t.name);
+		if (l >= 3 && t.name[l - 1] >= '0' && t.name[l - 1] <= '9' && t.name[l - 2] == '/') l -= 2;
+		for (size_t i = 0; i < l; ++i) o.ch(t.name[i]);
+	} else o.str(t.name);
+	int sf = n_seg > 1 ? 0x1 : 0x0;
 	if (!r) sf |= 0x4;
 	else {
 		if (r->rev) sf |= 0x10;
 		if (r->parent != r->id) sf |= 0x100;
 		else if (!r->sam_pri) sf |= 0x800;
 	}
+	if (n_seg > 1) {
+		if (r && r->proper_frag) sf |= 0x2;
+		if (seg_idx == 0) sf |= 0x40;
+		else if (seg_idx == n_seg - 1) sf |= 0x80;
+		if (!r_next) sf |= 0x8;
+		else if (r_next->rev) sf |= 0x20;
+	}
+	int this_rid = -1, this_pos = -1;
 	o.ch('\t'), o.num(sf);
 	bool cigar_in_tag = false;
-	if (!r) o.str("\t*\t0\t0\t*");
-	else {
+	if (!r) {
+		if (r_prev) { // an unmapped read is placed at its mate's position
+			this_rid = r_prev->rid, this_pos = r_prev->rs;
+			o.ch('\t'), o.str(fi.names[this_rid].c_str()), o.ch('\t'), o.num(this_pos + 1), o.str("\t0\t*");
+		} else o.str("\t*\t0\t0\t*");
+	} else {
+		this_rid = r->rid, this_pos = r->rs;
 		o.ch('\t'), o.str(fi.names[r->rid].c_str()), o.ch('\t'), o.num(r->rs + 1), o.ch('\t'), o.num(r->mapq), o.ch('\t');
 		if ((flag & F_LONG_CIGAR) && r->p && r->p->n_cigar > 65535 - 2) {
 			int n_cigar = (int)r->p->n_cigar;
@@ -280,7 +312,24 @@ void put_sam(Text &o, const FlatIndex &fi, const Bseq1 &t, int reg_idx, int n_re
 			o.num(slen), o.ch('S'), o.num(r->re - r->rs), o.ch('N');
 		} else put_sam_cigar(o, sf, false, t.l_seq, *r, flag);
 	}
-	o.str("\t*\t0\t0\t"); // no mate
+	if (n_seg > 1) { // mate position and template length (format.c:592-613)
+		int tlen = 0;
+		if (this_rid >= 0 && r_next) {
+			if (this_rid == r_next->rid) {
+				if (r) {
+					const int this_pos5 = r->rev ? r->re - 1 : this_pos, next_pos5 = r_next->rev ? r_next->re - 1 : r_next->rs;
+					tlen = next_pos5 - this_pos5;
+				}
+				o.str("\t=\t");
+			} else o.ch('\t'), o.str(fi.names[r_next->rid].c_str()), o.ch('\t');
+			o.num(r_next->rs + 1), o.ch('\t');
+		} else if (r_next) o.ch('\t'), o.str(fi.names[r_next->rid].c_str()), o.ch('\t'), o.num(r_next->rs + 1), o.ch('\t');
+		else if (this_rid >= 0) o.str("\t=\t"), o.num(this_pos + 1), o.ch('\t');
+		else o.str("\t*\t0\t");
+		if (tlen > 0) ++tlen;
+		else if (tlen < 0) --tlen;
+		o.num(tlen), o.ch('\t');
+	} else o.str("\t*\t0\t0\t"); // no mate
 	if (!r) {
 		put_seq(o, t.seq, t.l_seq, false, false), o.ch('\t');
 		if (t.qual) put_seq(o, t.qual, t.l_seq, false, false); else o.ch('*');
@@ -333,37 +382,42 @@ std::string format_check(const MapOpt &opt)
 	return "";
 }
 
-// the records of reads [lo, hi), in order (the per-read rules of map.c:603-622)
-static void format_range(const FlatIndex &fi, const MapOpt &opt, const Bseq1 *seq, const int *n_reg, void *const *reg, const int *rep_len, long lo, long hi, Text &o)
+// the records of fragments [lo, hi), in order (map.c:585-623)
+static void format_range(const FlatIndex &fi, const MapOpt &opt, const int *seg_off, const int *n_seg, const Bseq1 *seq, const int *n_reg, void *const *reg,
+                         const int *rep_len, long lo, long hi, Text &o)
 {
 	Seqs sq;
 	const int64_t flag = opt.flag;
-	for (long i = lo; i < hi; ++i) {
-		const Bseq1 &t = seq[i];
-		const Reg1 *regs = (const Reg1 *)reg[i];
-		const int rl = rep_len ? rep_len[i] : -1;
-		if (n_reg[i] > 0) {
-			for (int j = 0; j < n_reg[i]; ++j) {
-				if ((flag & F_NO_PRINT_2ND) && regs[j].id != regs[j].parent) continue;
-				if (flag & F_OUT_SAM) put_sam(o, fi, t, j, n_reg[i], regs, flag, rl, sq);
-				else put_paf(o, fi, t, &regs[j], flag, rl, sq);
+	for (long f = lo; f < hi; ++f) {
+		const int seg_st = seg_off ? seg_off[f] : (int)f, ns = n_seg ? n_seg[f] : 1;
+		for (int i = seg_st; i < seg_st + ns; ++i) {
+			const Bseq1 &t = seq[i];
+			const Reg1 *regs = (const Reg1 *)reg[i];
+			const int rl = rep_len ? rep_len[i] : -1;
+			if (n_reg[i] > 0) {
+				for (int j = 0; j < n_reg[i]; ++j) {
+					if ((flag & F_NO_PRINT_2ND) && regs[j].id != regs[j].parent) continue;
+					if (flag & F_OUT_SAM) put_sam(o, fi, t, i - seg_st, j, ns, &n_reg[seg_st], &reg[seg_st], flag, rl, sq);
+					else put_paf(o, fi, t, &regs[j], flag, rl, ns, i - seg_st, sq);
+					o.ch('\n');
+				}
+			} else if ((flag & F_PAF_NO_HIT) || ((flag & F_OUT_SAM) && !(flag & F_SAM_HIT_ONLY))) {
+				if (flag & F_OUT_SAM) put_sam(o, fi, t, i - seg_st, -1, ns, &n_reg[seg_st], &reg[seg_st], flag, rl, sq);
+				else put_paf(o, fi, t, nullptr, flag, rl, ns, i - seg_st, sq);
 				o.ch('\n');
 			}
-		} else if ((flag & F_PAF_NO_HIT) || ((flag & F_OUT_SAM) && !(flag & F_SAM_HIT_ONLY))) {
-			if (flag & F_OUT_SAM) put_sam(o, fi, t, -1, 0, nullptr, flag, rl, sq);
-			else put_paf(o, fi, t, nullptr, flag, rl, sq);
-			o.ch('\n');
 		}
 	}
 }
 
-char *format_batch(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n, const Bseq1 *seq, const int *n_reg, void *const *reg, const int *rep_len, size_t *out_len)
+char *format_batch(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const Bseq1 *seq, const int *n_reg,
+                   void *const *reg, const int *rep_len, size_t *out_len)
 {
-	const long chunk = 64, n_chunks = (n + chunk - 1) / chunk;
+	const long n = n_frag, chunk = 64, n_chunks = (n + chunk - 1) / chunk;
 	std::vector<Text> parts(n_chunks);
 	parallel_for(n_threads, n_chunks, [&](long c, int) {
 		const long lo = c * chunk, hi = std::min(n, lo + chunk);
-		format_range(fi, opt, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
+		format_range(fi, opt, seg_off, n_seg, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
 	}, 1);
 	std::vector<size_t> off(n_chunks + 1, 0);
 	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].s.size();

@@ -8,7 +8,9 @@ namespace mm2amd {
 
 // "" when the options can be formatted here, else what is missing
 std::string format_check(const ref::MapOpt &opt);
-// One malloc'd block ('\n'-terminated records of reads 0..n-1 in order, NUL after the last byte), or nullptr when out of memory.
-char *format_batch(const FlatIndex &fi, const ref::MapOpt &opt, int n_threads, long n, const ref::Bseq1 *seq, const int *n_reg, void *const *reg, const int *rep_len, size_t *out_len);
+// One malloc'd block ('\n'-terminated records of fragments 0..n_frag-1 in order, NUL after the last byte), or nullptr when out of
+// memory.  Fragment f consists of reads seg_off[f] .. seg_off[f]+n_seg[f]-1 of seq[] (null arrays: one read per fragment).
+char *format_batch(const FlatIndex &fi, const ref::MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const ref::Bseq1 *seq, const int *n_reg,
+                   void *const *reg, const int *rep_len, size_t *out_len);
 
 } // namespace mm2amd

@@ -310,3 +310,16 @@ def test_paired_end(args, n_files, tmp_path):
         outs.append(G.strip_pg(p.stdout))
     assert outs[0] == outs[1]
     assert outs[0].count(b"\n") > 500
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args,n_files", [(["-x", "sr", "-a"], 2), (["-x", "sr", "-a"], 1), (["-x", "sr"], 2), (["-x", "sr", "-c", "--cs"], 1),
+                                          (["-x", "sr", "-a", "--MD", "-Y"], 2), (["-x", "sr", "-a", "-N", "3", "-p", "0.3", "--secondary-seq"], 2),
+                                          (["-x", "sr", "-a", "--sam-hit-only"], 2), (["-x", "sr", "--paf-no-hit"], 1)])
+def test_paired_end_records_from_the_library(args, n_files, tmp_path):  # mm_gpu_format_batch: mate fields of mm_write_sam3 (format.c:529-613), /1 /2 of mm_write_paf4
+    import synth
+    ref, f1, f2, inter = synth.make_pairs(str(tmp_path))
+    files = [f1, f2] if n_files == 2 else [inter]
+    want = subprocess.run([G.REF_BIN] + args + [ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    got = subprocess.run([CHECK] + args + ["--format-lib", ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(want) == G.strip_pg(got)
