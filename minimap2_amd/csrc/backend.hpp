@@ -55,8 +55,6 @@ public:
 	// all-vs-all mapping (MM_F_NO_DIAG / MM_F_NO_DUAL): seed_chain() then applies skip_seed's read-name rules (map.c:81-91), which
 	// need the reads' names in begin_batch().  Call once, before the first batch.
 	virtual void enable_name_rules() {}
-	// Device code paths that have not been run on hardware yet stay opt-in (see HipBackend); the mapper asks before using one.
-	virtual bool pending_paths_enabled() const { return true; }
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off

@@ -79,11 +79,6 @@ public:
 	}
 
 	int n_lanes() const override { return n_lanes_; }
-	// The device side of the all-vs-all rules (skip_hit), of MM_F_HEAP_SORT (anchor_heap_order_kernel) and of the short-read
-	// chaining distances (chain_gaps) was written after this round's GPU budget ran out: it is checked against the reference
-	// through the host pipeline tests and a host build of the shared headers only, so it stays opt-in until
-	// tests/test_gpu_pending.py has passed on an MI355X.
-	bool pending_paths_enabled() const override { return getenv("MM2AMD_PENDING") != nullptr; }
 	void enable_name_rules() override
 	{
 		if (name_rules_ || fi_names_->empty()) return;

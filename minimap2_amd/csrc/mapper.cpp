@@ -43,9 +43,6 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	const int64_t unsupported = F_QSTRAND | F_SR_RNA | F_INDEPEND_SEG;
 	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr, --qstrand and multi-segment modes are not implemented");
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
-	const bool pending = (opt.flag & (F_NO_DIAG | F_NO_DUAL | F_SR | F_HEAP_SORT)) || (opt.max_gap_ref <= 0 && opt.max_frag_len > 0);
-	if (pending && !be.pending_paths_enabled())
-		throw std::invalid_argument("[mm2amd] all-vs-all (-X / -D / --dual=no, ava-*), short-read (sr) and --heap-sort / --frag mapping on the device are not validated on hardware yet; MM2AMD_PENDING=1 enables them");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
@@ -66,9 +63,6 @@ void Mapper::stage(const std::vector<ReadView> &reads)
 	// which reads are mapped at all (map.c:243-244)
 	for (long i = 0; i < n_staged_; ++i)
 		if (reads[i].total() > 0 && !(opt_.max_qlen > 0 && reads[i].total() > opt_.max_qlen)) live_.push_back(reads[i]), live_id_.push_back(i);
-	for (const ReadView &r : live_)
-		if (r.paired() && !be_.pending_paths_enabled())
-			throw std::invalid_argument("[mm2amd] paired-end fragments on the device are not validated on hardware yet; MM2AMD_PENDING=1 enables them");
 	if (!live_.empty()) be_.begin_batch(live_, qoff_);
 }
 

@@ -1,6 +1,6 @@
-"""Device features written after the round's GPU budget was spent: validated against the reference through the host pipeline
-(tests/test_host_pipeline.py, oracle-backed) but not yet on an MI355X.  They are opt-in in the library (MM2AMD_PENDING=1) and so
-are these tests; once they have passed on hardware the gate goes away and the cases move into test_gpu_dropin.py."""
+"""Short reads (single- and paired-end, MM_F_SR / MM_F_HEAP_SORT / max_frag_len) and all-vs-all mapping on the GPU: SAM/PAF of
+tests/_build/dropin_gpu (the reference's I/O around libmm2amd.so) against oracle/_ref/minimap2_ref on the same inputs, and the
+device's sorted anchors (MM2AMD_SEED_DUMP) against the reference's --print-seeds."""
 import os
 import subprocess
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import synth  # noqa: E402
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("MM2AMD_PENDING"), reason="opt-in: MM2AMD_PENDING=1")]
+pytestmark = pytest.mark.gpu
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
 DROPIN = os.path.join(HERE, "_build", "dropin_gpu")
 

@@ -304,8 +304,7 @@ def test_paired_end(args, n_files, tmp_path):
     ref, f1, f2, inter = synth.make_pairs(str(tmp_path))
     outs = []
     for binary in (G.REF_BIN, CHECK):
-        p = subprocess.run([binary] + args + [ref] + ([f1, f2] if n_files == 2 else [inter]), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           env=dict(os.environ, MM2AMD_PENDING="1"))
+        p = subprocess.run([binary] + args + [ref] + ([f1, f2] if n_files == 2 else [inter]), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr.decode()[-1500:]
         outs.append(G.strip_pg(p.stdout))
     assert outs[0] == outs[1]
