@@ -97,7 +97,12 @@ void Mapper::run(std::vector<ReadResult> &out)
 	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
 	std::vector<std::pair<long, long>> subs;
 	{
-		long max_reads = be_.max_reads_per_call(), sub_reads = 25000; // short reads: bound the read count too, so that a second lane overlaps the host stages; larger sub-batches keep the DP launches' tails short
+		long max_reads = be_.max_reads_per_call(), sub_reads = 25000; // bound the read count too, so that a second lane overlaps the host stages; larger sub-batches keep the DP launches' tails short
+		if (m_all > 0) { // Illumina-sized reads: 25 k of them are a few Mbases, far too little work per kernel launch -- let the base budget decide
+			uint64_t tot = 0;
+			for (long i = 0; i < m_all; ++i) tot += (uint64_t)live[i].total();
+			if (tot / (uint64_t)m_all < 1000) sub_reads = 400000;
+		}
 		if (const char *e = getenv("MM2AMD_SUBBATCH_READS")) sub_reads = atol(e) > 0 ? atol(e) : sub_reads;
 		if (sub_reads < max_reads) max_reads = sub_reads;
 		for (long lo = 0, hi; lo < m_all; lo = hi) {

@@ -22,7 +22,7 @@ int main(int argc, char *argv[])
 	mm_idxopt_t iopt;
 	mm_mapopt_t mopt;
 	const char *preset = 0;
-	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, old_best_n = -1;
+	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, staged = 0, old_best_n = -1;
 	const char *alt_fn = 0;
 	int64_t batch = 500000000;
 	kstring_t str = {0, 0, 0};
@@ -113,6 +113,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--dual=no") == 0) mopt.flag |= MM_F_NO_DUAL; /* main.c:300 */
 		else if (strcmp(argv[k], "--dual=yes") == 0) mopt.flag &= ~(int64_t)MM_F_NO_DUAL;
 		else if (strcmp(argv[k], "--alt") == 0) alt_fn = argv[++k];
+		else if (strcmp(argv[k], "--staged") == 0) staged = 1; /* mm_gpu_batch_stage + mm_gpu_map_staged instead of mm_gpu_map_batch */
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
@@ -151,7 +152,12 @@ int main(int argc, char *argv[])
 			int j, f;
 			for (i = 1, j = 0, n_frag = 0; i <= n_seq; ++i)
 				if (i == n_seq || !frag_mode || !mm_qname_same(seq[i-1].name, seq[i].name)) n_seg[n_frag] = i - j, seg_off[n_frag++] = j, j = i;
-			if (mm_gpu_map_batch(n_frag, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {
+			if (staged) {
+				if (mm_gpu_batch_stage(n_frag, seg_off, n_seg, seq) != 0 || mm_gpu_map_staged(n_reg, (void**)reg, rep_len, frag_gap) != 0) {
+					fprintf(stderr, "staged mapping: %s\n", mm2amd_last_error());
+					return 2;
+				}
+			} else if (mm_gpu_map_batch(n_frag, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {
 				fprintf(stderr, "mm_gpu_map_batch: %s\n", mm2amd_last_error());
 				return 2;
 			}

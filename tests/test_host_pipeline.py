@@ -322,3 +322,11 @@ def test_paired_end_records_from_the_library(args, n_files, tmp_path):  # mm_gpu
     want = subprocess.run([G.REF_BIN] + args + [ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     got = subprocess.run([CHECK] + args + ["--format-lib", ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     assert G.strip_pg(want) == G.strip_pg(got)
+
+
+def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm_gpu_map_staged (what bench.py and the Python Aligner use)
+    import synth
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 2, 60, 21)
+    a = subprocess.run([CHECK, "-x", "map-ont", "-a", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    b = subprocess.run([CHECK, "-x", "map-ont", "-a", "--staged", "-K", "200000", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 50
