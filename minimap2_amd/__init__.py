@@ -345,9 +345,52 @@ class Aligner(object):
         self.stage(reads)
         return self.run()
 
-    def map(self, seq, name="query"):
-        """Single-read convenience wrapper (mappy.Aligner.map); a batch of one."""
+    def map(self, seq, seq2=None, name="query"):
+        """Single-read (or, with seq2, single-pair) convenience wrapper (mappy.Aligner.map); a batch of one."""
+        if seq2 is not None:
+            return self.map_pairs([(name, seq, seq2)])[0]
         return self.map_batch([(name, seq)])[0]
+
+    def map_pairs(self, pairs, text=False):
+        """Paired-end reads: pairs = list of (name, seq1, seq2), mapped as two-segment fragments (mm_map_frag with n_segs == 2;
+        use preset "sr").  Returns a list of (alignments of read 1, alignments of read 2); with text=True the SAM/PAF records of the
+        batch instead (mm_gpu_format_batch, mate fields included)."""
+        n = len(pairs)
+        arr = (Bseq1 * (2 * n))()
+        keep = []
+        for i, (nm, s1, s2) in enumerate(pairs):
+            nb = nm.encode() if isinstance(nm, str) else nm
+            for j, s in enumerate((s1, s2)):
+                sb = s.encode() if isinstance(s, str) else bytes(s)
+                keep.append((nb, sb))
+                a = arr[2 * i + j]
+                a.l_seq, a.rid, a.name, a.seq = len(sb), 2 * i + j, nb, sb
+        seg_off = (C.c_int * n)(*range(0, 2 * n, 2))
+        n_seg = (C.c_int * n)(*([2] * n))
+        n_reg = (C.c_int * (2 * n))()
+        reg = (C.c_void_p * (2 * n))()
+        rep_len = (C.c_int * (2 * n))()
+        frag_gap = (C.c_int * (2 * n))()
+        _check(lib().mm_gpu_map_batch(n, seg_off, n_seg, arr, n_reg, reg, rep_len, frag_gap))
+        try:
+            if text:
+                out, out_len = C.c_void_p(), C.c_size_t()
+                _check(lib().mm_gpu_format_batch(n, seg_off, n_seg, arr, n_reg, reg, rep_len, C.byref(out), C.byref(out_len)))
+                try:
+                    return C.string_at(out, out_len.value)
+                finally:
+                    _libc_free(out)
+            res = []
+            for i in range(n):
+                both = []
+                for j in (0, 1):
+                    k = 2 * i + j
+                    regs = C.cast(reg[k], C.POINTER(Reg1)) if n_reg[k] else None
+                    both.append(_regs_to_alignments(n_reg[k], regs, self.names, self.lens))
+                res.append(tuple(both))
+            return res
+        finally:
+            lib().mm2amd_free_regs(2 * n, n_reg, reg)
 
     def last_stats(self):
         v = (C.c_double * 16)()

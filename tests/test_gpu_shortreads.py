@@ -91,3 +91,28 @@ def test_paired_end(args, n_files, tmp_path):
 def test_paired_end_larger_set(tmp_path):
     ref, f1, f2, inter = synth.make_pairs(str(tmp_path), seed=97, n_pairs=4000, genome=3000000)
     assert _run([REF_BIN, "-t", "8", "-x", "sr", "-a", ref, f1, f2]) == _run([DROPIN, "-t", "8", "-x", "sr", "-a", ref, f1, f2])
+
+
+def test_python_map_pairs_equals_the_reference_sam(tmp_path):
+    """The mappy-shaped front end: Aligner(preset="sr").map_pairs(..., text=True) must print the reference's SAM records."""
+    import minimap2_amd as mm
+    ref, f1, f2, _ = synth.make_pairs(str(tmp_path), n_pairs=120)
+
+    def fasta(path):
+        names, seqs = [], []
+        for line in open(path, "rb"):
+            (names if line.startswith(b">") else seqs).append(line.strip().lstrip(b">"))
+        return names, seqs
+
+    rn, rs = fasta(ref)
+    n1, s1 = fasta(f1)
+    _, s2 = fasta(f2)
+    al = mm.Aligner(rs, preset="sr", names=[x.decode() for x in rn], sam=True, n_threads=4)
+    try:
+        got = al.map_pairs([(nm[:-2], a, b) for nm, a, b in zip(n1, s1, s2)], text=True)
+        hits = al.map_pairs([(nm[:-2], a, b) for nm, a, b in zip(n1[:10], s1[:10], s2[:10])])
+    finally:
+        al.close()
+    want = b"\n".join(l for l in _run([REF_BIN, "-t", "4", "-x", "sr", "-a", ref, f1, f2]).split(b"\n") if not l.startswith(b"@"))
+    assert got.rstrip(b"\n") == want.rstrip(b"\n")
+    assert len(hits) == 10 and all(len(h) == 2 for h in hits)
