@@ -25,11 +25,16 @@ using namespace mm2amd;
 extern "C" long long mm2amd_alloc_counter(int which); // device allocations, pinned allocations, nanoseconds spent in them
 
 namespace {
+// Where the results of one mapper fragment go: reads o .. o+n_out-1 of the caller's arrays; flip_len[j] >= 0 when read o+j was
+// mapped reverse-complemented and its hits have to be turned back (length of that read), see hand_over().
+struct OutSlot { int o, n_out, flip_len[2]; };
+
 struct MapContext {
 	FlatIndex fi_own;                 // index flattened from a reference mm_idx_t (mm_gpu_init)
 	const FlatIndex *fi = nullptr;    // the index in use (fi_own, or the one inside an mm2amd_index_t)
 	ref::MapOpt opt;
 	std::vector<ReadView> staged;
+	std::vector<OutSlot> staged_slots;
 	bool has_staged = false;
 	int n_threads = 1;
 	std::unique_ptr<Backend> be;
@@ -104,13 +109,15 @@ static void revcomp_into(const char *seq, int len, std::string &out)
 
 // The fragments of a batch as the mapper sees them.  A two-segment fragment (paired-end reads) is handed over in mapping
 // orientation: worker_for reverse-complements a mate in place according to pe_ori before mapping and back afterwards
-// (map.c:436-442, 457-473); here the flipped copy lives in `flipped` and the caller's buffers are left alone.
-static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, int pe_ori, bool allow_pairs, std::vector<ReadView> &reads,
-                         std::vector<std::string> &flipped)
+// (map.c:436-442, 457-473); here the flipped copy lives in `flipped` and the caller's buffers are left alone.  With
+// MM_F_INDEPEND_SEG the two reads of a pair are mapped as two single reads (map.c:443-448), still in flipped orientation.
+static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const ref::MapOpt &opt, bool allow_pairs, std::vector<ReadView> &reads,
+                         std::vector<OutSlot> &slots, std::vector<std::string> &flipped)
 {
 	const ref::Bseq1 *seq = (const ref::Bseq1 *)seq_;
-	reads.assign(n_frag, ReadView());
-	flipped.clear();
+	const int pe_ori = opt.pe_ori;
+	const bool independent = (opt.flag & ref::F_INDEPEND_SEG) != 0;
+	reads.clear(), slots.clear(), flipped.clear();
 	size_t n_flip = 0;
 	for (int i = 0; i < n_frag; ++i) {
 		if (n_seg[i] == 2 && !allow_pairs) return capi_fail(MM2AMD_EINVAL, "[mm2amd] two-segment fragments go through mm_gpu_map_batch, not the staged calls");
@@ -120,14 +127,28 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 	flipped.resize(n_flip); // sized first: the views point into it
 	n_flip = 0;
 	for (int i = 0; i < n_frag; ++i) {
-		const ref::Bseq1 &s = seq[seg_off[i]];
-		reads[i].seq = s.seq, reads[i].len = s.l_seq, reads[i].name = s.name;
+		const int o = seg_off[i];
+		const ref::Bseq1 &s = seq[o];
+		ReadView v;
+		OutSlot sl = { o, 1, { -1, -1 } };
+		v.seq = s.seq, v.len = s.l_seq, v.name = s.name;
 		if (n_seg[i] == 2) {
-			const ref::Bseq1 &s2 = seq[seg_off[i] + 1];
-			reads[i].seq2 = s2.seq, reads[i].len2 = s2.l_seq;
-			if (pe_ori >> 1 & 1) { revcomp_into(s.seq, s.l_seq, flipped[n_flip]); reads[i].seq = flipped[n_flip++].data(); }
-			if (pe_ori & 1) { revcomp_into(s2.seq, s2.l_seq, flipped[n_flip]); reads[i].seq2 = flipped[n_flip++].data(); }
+			const ref::Bseq1 &s2 = seq[o + 1];
+			const char *q2 = s2.seq;
+			if (pe_ori >> 1 & 1) { revcomp_into(s.seq, s.l_seq, flipped[n_flip]); v.seq = flipped[n_flip++].data(); sl.flip_len[0] = s.l_seq; }
+			if (pe_ori & 1) { revcomp_into(s2.seq, s2.l_seq, flipped[n_flip]); q2 = flipped[n_flip++].data(); sl.flip_len[1] = s2.l_seq; }
+			if (independent) {
+				ReadView v2;
+				OutSlot sl2 = { o + 1, 1, { sl.flip_len[1], -1 } };
+				v2.seq = q2, v2.len = s2.l_seq, v2.name = s2.name;
+				sl.flip_len[1] = -1;
+				reads.push_back(v), slots.push_back(sl);
+				reads.push_back(v2), slots.push_back(sl2);
+				continue;
+			}
+			v.seq2 = q2, v.len2 = s2.l_seq, sl.n_out = 2;
 		}
+		reads.push_back(v), slots.push_back(sl);
 	}
 	return 0;
 }
@@ -140,16 +161,14 @@ static void *regs_block(const RegVec &v)
 	return p;
 }
 
-static void hand_over(int n_frag, const int *seg_off, const std::vector<ReadView> *views, int pe_ori, std::vector<ReadResult> &out, int *n_reg, void **reg,
-                      int *rep_len, int *frag_gap)
+static void hand_over(const std::vector<OutSlot> &slots, std::vector<ReadResult> &out, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
-	parallel_for(g_ctx ? g_ctx->n_threads : 1, n_frag, [&](long i, int) {
-		const int o = seg_off ? seg_off[i] : i;
-		const int n_segs = views && (*views)[i].paired() ? 2 : 1;
-		for (int j = 0; j < n_segs; ++j) {
+	parallel_for(g_ctx ? g_ctx->n_threads : 1, (long)slots.size(), [&](long i, int) {
+		const OutSlot &sl = slots[i];
+		for (int j = 0; j < sl.n_out; ++j) {
 			RegVec &regs = j == 0 ? out[i].regs : out[i].regs2;
-			if (n_segs == 2 && ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1)))) { // back to the strand the read was given in (map.c:457-473)
-				const int qlen = j == 0 ? (*views)[i].len : (*views)[i].len2;
+			if (sl.flip_len[j] >= 0) { // back to the strand the read was given in (map.c:457-473)
+				const int qlen = sl.flip_len[j];
 				for (ref::Reg1 &r : regs) {
 					const int t = r.qs;
 					r.qs = qlen - r.qe, r.qe = qlen - t;
@@ -160,10 +179,10 @@ static void hand_over(int n_frag, const int *seg_off, const std::vector<ReadView
 					}
 				}
 			}
-			n_reg[o + j] = (int)regs.size();
-			reg[o + j] = regs_block(regs);
-			if (rep_len) rep_len[o + j] = out[i].rep_len;
-			if (frag_gap) frag_gap[o + j] = out[i].frag_gap;
+			n_reg[sl.o + j] = (int)regs.size();
+			reg[sl.o + j] = regs_block(regs);
+			if (rep_len) rep_len[sl.o + j] = out[i].rep_len;
+			if (frag_gap) frag_gap[sl.o + j] = out[i].frag_gap;
 		}
 	}, 256);
 }
@@ -176,7 +195,7 @@ int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const v
 	try {
 		g_ctx->has_staged = false;
 		std::vector<std::string> none;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt.pe_ori, false, g_ctx->staged, none)) return rc;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, false, g_ctx->staged, g_ctx->staged_slots, none)) return rc;
 		g_ctx->mapper->stage(g_ctx->staged);
 		g_ctx->has_staged = true;
 		return 0;
@@ -195,7 +214,7 @@ int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 	try {
 		std::vector<ReadResult> out;
 		g_ctx->mapper->run(out);
-		hand_over((int)out.size(), nullptr, nullptr, 0, out, n_reg, reg, rep_len, frag_gap);
+		hand_over(g_ctx->staged_slots, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());
@@ -312,12 +331,12 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch: bad arguments");
 	try {
 		std::vector<ReadView> reads;
+		std::vector<OutSlot> slots;
 		std::vector<std::string> flipped;
-		const int pe_ori = g_ctx->opt.pe_ori;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, pe_ori, true, reads, flipped)) return rc;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, true, reads, slots, flipped)) return rc;
 		std::vector<ReadResult> out;
 		g_ctx->mapper->map_batch(reads, out);
-		hand_over(n_frag, seg_off, &reads, pe_ori, out, n_reg, reg, rep_len, frag_gap);
+		hand_over(slots, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());

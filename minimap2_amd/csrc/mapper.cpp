@@ -40,8 +40,8 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	const int64_t unsupported = F_QSTRAND | F_SR_RNA | F_INDEPEND_SEG;
-	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr, --qstrand and multi-segment modes are not implemented");
+	const int64_t unsupported = F_QSTRAND | F_SR_RNA; // MM_F_INDEPEND_SEG is resolved at the boundary (capi_map.cpp)
+	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr and --qstrand are not implemented");
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");

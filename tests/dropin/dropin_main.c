@@ -107,6 +107,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--heap-sort=yes") == 0) mopt.flag |= MM_F_HEAP_SORT; /* main.c:298 */
 		else if (strcmp(argv[k], "--heap-sort=no") == 0) mopt.flag &= ~(int64_t)MM_F_HEAP_SORT;
 		else if (strcmp(argv[k], "--sr") == 0) mopt.flag |= MM_F_SR;
+		else if (strcmp(argv[k], "--no-pairing") == 0) mopt.flag |= MM_F_INDEPEND_SEG; /* main.c:228 */
 		else if (strcmp(argv[k], "-F") == 0) mopt.max_frag_len = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-D") == 0) mopt.flag |= MM_F_NO_DIAG; /* main.c:180 */
 		else if (strcmp(argv[k], "-X") == 0) mopt.flag |= MM_F_ALL_CHAINS | MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_NO_LJOIN; /* main.c:182 */

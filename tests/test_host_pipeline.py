@@ -292,7 +292,7 @@ def test_device_heap_order_header_against_oracle():
 PE_CASES = [(["-x", "sr", "-a"], 2), (["-x", "sr", "-a"], 1), (["-x", "sr"], 2), (["-x", "sr", "-c"], 1), (["-x", "sr", "-a", "-F", "400"], 2),
             (["-x", "sr", "-a", "--heap-sort=no"], 2), (["-x", "sr", "-a", "-f", "2,20"], 1), (["-x", "sr", "-a", "-p", "0.3", "-N", "4"], 1),
             (["-x", "sr", "-a", "-g", "300", "-r", "50"], 2), (["-x", "sr", "-k", "15", "-w", "5", "-a"], 2), (["-x", "sr", "-a", "-A", "1", "-B", "3"], 2),
-            (["-x", "map-ont", "-a"], 2)]
+            (["-x", "map-ont", "-a"], 2), (["-x", "sr", "-a", "--no-pairing"], 2), (["-x", "sr", "-c", "--no-pairing"], 1)]
 
 
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
