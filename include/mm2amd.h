@@ -129,7 +129,8 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int
 
 /* mm_gpu_map_batch in two halves: mm_gpu_batch_stage copies the batch's sequences to the device (the hand-over the
  * reference's pipeline step 0 makes, map.c:543-575) and returns when they are resident; mm_gpu_map_staged runs the
- * hot path on the staged batch (results indexed by fragment, as with seg_off[i] == i).  seq must stay valid in between. */
+ * hot path on the staged batch (results placed as mm_gpu_map_batch places them: read seg_off[i] + j of fragment i).  seq, and the
+ * seg_off / n_seg the batch was staged with, describe the result arrays; seq must stay valid in between. */
 int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq);
 int mm_gpu_map_staged(int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
 

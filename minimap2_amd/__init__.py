@@ -293,38 +293,42 @@ class Aligner(object):
 
     # -- batch interface: stage() + run() == map_batch() ------------------------------------------------
     def stage(self, reads):
-        """reads: list of (name, sequence) or of sequences (bytes/str).  Copies them to the GPU."""
+        """reads: list of (name, sequence), of sequences (bytes/str), or of (name, sequence1, sequence2) for read pairs (mapped as
+        two-segment fragments, mm_map_frag with n_segs == 2).  Copies them to the GPU."""
         n = len(reads)
-        arr = (Bseq1 * n)()
-        keep = []
+        items, seg_off, n_seg = [], [], []
         for i, r in enumerate(reads):
-            nm, s = r if isinstance(r, tuple) else ("read%d" % i, r)
-            nb = nm.encode() if isinstance(nm, str) else nm
-            sb = s.encode() if isinstance(s, str) else bytes(s)
-            keep.append((nb, sb))
-            arr[i].l_seq, arr[i].rid, arr[i].name, arr[i].seq = len(sb), i, nb, sb
-        seg_off = (C.c_int * n)(*range(n))
-        n_seg = (C.c_int * n)(*([1] * n))
-        _check(lib().mm_gpu_batch_stage(n, seg_off, n_seg, arr))
-        self._staged = (n, arr, keep, seg_off, n_seg)
+            r = r if isinstance(r, tuple) else ("read%d" % i, r)
+            nb = r[0].encode() if isinstance(r[0], str) else r[0]
+            seg_off.append(len(items)), n_seg.append(len(r) - 1)
+            for s in r[1:]:
+                items.append((nb, s.encode() if isinstance(s, str) else bytes(s)))
+        arr = (Bseq1 * max(1, len(items)))()
+        for k, (nb, sb) in enumerate(items):
+            arr[k].l_seq, arr[k].rid, arr[k].name, arr[k].seq = len(sb), k, nb, sb
+        seg_off_a, n_seg_a = (C.c_int * max(1, n))(*seg_off), (C.c_int * max(1, n))(*n_seg)
+        _check(lib().mm_gpu_batch_stage(n, seg_off_a, n_seg_a, arr))
+        self._staged = (n, arr, items, seg_off_a, n_seg_a)
 
     def run(self, raw=False):
-        """Maps the staged batch.  raw=True returns (n_reg, reg) ctypes arrays that must be passed to free_raw()."""
+        """Maps the staged batch.  Returns one list of alignments per read, or a pair of lists for a read pair.  raw=True returns
+        (n_reg, reg, rep_len) ctypes arrays (one entry per read, pairs adjacent) that must be passed to free_raw()."""
         if self._staged is None:
             raise Mm2AmdError("run() without stage()")
-        n = self._staged[0]
-        n_reg = (C.c_int * n)()
-        reg = (C.c_void_p * n)()
-        rep_len = (C.c_int * n)()
-        frag_gap = (C.c_int * n)()
+        n, _, items, seg_off, n_seg = self._staged
+        m = max(1, len(items))
+        n_reg, reg, rep_len, frag_gap = (C.c_int * m)(), (C.c_void_p * m)(), (C.c_int * m)(), (C.c_int * m)()
         _check(lib().mm_gpu_map_staged(n_reg, reg, rep_len, frag_gap))
         if raw:
             return n_reg, reg, rep_len
         out = []
         for i in range(n):
-            regs = C.cast(reg[i], C.POINTER(Reg1)) if n_reg[i] else None
-            out.append(_regs_to_alignments(n_reg[i], regs, self.names, self.lens))
-        lib().mm2amd_free_regs(n, n_reg, reg)
+            per = []
+            for k in range(seg_off[i], seg_off[i] + n_seg[i]):
+                regs = C.cast(reg[k], C.POINTER(Reg1)) if n_reg[k] else None
+                per.append(_regs_to_alignments(n_reg[k], regs, self.names, self.lens))
+            out.append(per[0] if n_seg[i] == 1 else tuple(per))
+        lib().mm2amd_free_regs(len(items), n_reg, reg)
         return out
 
     def free_raw(self, n_reg, reg):
@@ -352,45 +356,16 @@ class Aligner(object):
         return self.map_batch([(name, seq)])[0]
 
     def map_pairs(self, pairs, text=False):
-        """Paired-end reads: pairs = list of (name, seq1, seq2), mapped as two-segment fragments (mm_map_frag with n_segs == 2;
-        use preset "sr").  Returns a list of (alignments of read 1, alignments of read 2); with text=True the SAM/PAF records of the
-        batch instead (mm_gpu_format_batch, mate fields included)."""
-        n = len(pairs)
-        arr = (Bseq1 * (2 * n))()
-        keep = []
-        for i, (nm, s1, s2) in enumerate(pairs):
-            nb = nm.encode() if isinstance(nm, str) else nm
-            for j, s in enumerate((s1, s2)):
-                sb = s.encode() if isinstance(s, str) else bytes(s)
-                keep.append((nb, sb))
-                a = arr[2 * i + j]
-                a.l_seq, a.rid, a.name, a.seq = len(sb), 2 * i + j, nb, sb
-        seg_off = (C.c_int * n)(*range(0, 2 * n, 2))
-        n_seg = (C.c_int * n)(*([2] * n))
-        n_reg = (C.c_int * (2 * n))()
-        reg = (C.c_void_p * (2 * n))()
-        rep_len = (C.c_int * (2 * n))()
-        frag_gap = (C.c_int * (2 * n))()
-        _check(lib().mm_gpu_map_batch(n, seg_off, n_seg, arr, n_reg, reg, rep_len, frag_gap))
+        """Paired-end reads: pairs = list of (name, seq1, seq2) (use preset "sr").  Returns a list of (alignments of read 1,
+        alignments of read 2); with text=True the SAM/PAF records of the batch instead (mm_gpu_format_batch, mate fields included)."""
+        self.stage(pairs)
+        if not text:
+            return self.run()
+        n_reg, reg, rep_len = self.run(raw=True)
         try:
-            if text:
-                out, out_len = C.c_void_p(), C.c_size_t()
-                _check(lib().mm_gpu_format_batch(n, seg_off, n_seg, arr, n_reg, reg, rep_len, C.byref(out), C.byref(out_len)))
-                try:
-                    return C.string_at(out, out_len.value)
-                finally:
-                    _libc_free(out)
-            res = []
-            for i in range(n):
-                both = []
-                for j in (0, 1):
-                    k = 2 * i + j
-                    regs = C.cast(reg[k], C.POINTER(Reg1)) if n_reg[k] else None
-                    both.append(_regs_to_alignments(n_reg[k], regs, self.names, self.lens))
-                res.append(tuple(both))
-            return res
+            return self.format_raw(n_reg, reg, rep_len)
         finally:
-            lib().mm2amd_free_regs(2 * n, n_reg, reg)
+            self.free_raw(n_reg, reg)
 
     def last_stats(self):
         v = (C.c_double * 16)()

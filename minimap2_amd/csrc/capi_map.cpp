@@ -35,6 +35,7 @@ struct MapContext {
 	ref::MapOpt opt;
 	std::vector<ReadView> staged;
 	std::vector<OutSlot> staged_slots;
+	std::vector<std::string> staged_flipped;
 	bool has_staged = false;
 	int n_threads = 1;
 	std::unique_ptr<Backend> be;
@@ -111,7 +112,7 @@ static void revcomp_into(const char *seq, int len, std::string &out)
 // orientation: worker_for reverse-complements a mate in place according to pe_ori before mapping and back afterwards
 // (map.c:436-442, 457-473); here the flipped copy lives in `flipped` and the caller's buffers are left alone.  With
 // MM_F_INDEPEND_SEG the two reads of a pair are mapped as two single reads (map.c:443-448), still in flipped orientation.
-static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const ref::MapOpt &opt, bool allow_pairs, std::vector<ReadView> &reads,
+static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const ref::MapOpt &opt, std::vector<ReadView> &reads,
                          std::vector<OutSlot> &slots, std::vector<std::string> &flipped)
 {
 	const ref::Bseq1 *seq = (const ref::Bseq1 *)seq_;
@@ -120,7 +121,6 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 	reads.clear(), slots.clear(), flipped.clear();
 	size_t n_flip = 0;
 	for (int i = 0; i < n_frag; ++i) {
-		if (n_seg[i] == 2 && !allow_pairs) return capi_fail(MM2AMD_EINVAL, "[mm2amd] two-segment fragments go through mm_gpu_map_batch, not the staged calls");
 		if (n_seg[i] != 1 && n_seg[i] != 2) return capi_fail(MM2AMD_EINVAL, "[mm2amd] fragments of more than two segments are not implemented");
 		if (n_seg[i] == 2) n_flip += (pe_ori >> 1 & 1) + (pe_ori & 1);
 	}
@@ -194,8 +194,7 @@ int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const v
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_batch_stage: bad arguments");
 	try {
 		g_ctx->has_staged = false;
-		std::vector<std::string> none;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, false, g_ctx->staged, g_ctx->staged_slots, none)) return rc;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, g_ctx->staged, g_ctx->staged_slots, g_ctx->staged_flipped)) return rc;
 		g_ctx->mapper->stage(g_ctx->staged);
 		g_ctx->has_staged = true;
 		return 0;
@@ -333,7 +332,7 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 		std::vector<ReadView> reads;
 		std::vector<OutSlot> slots;
 		std::vector<std::string> flipped;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, true, reads, slots, flipped)) return rc;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, reads, slots, flipped)) return rc;
 		std::vector<ReadResult> out;
 		g_ctx->mapper->map_batch(reads, out);
 		hand_over(slots, out, n_reg, reg, rep_len, frag_gap);

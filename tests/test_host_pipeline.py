@@ -330,3 +330,7 @@ def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm
     a = subprocess.run([CHECK, "-x", "map-ont", "-a", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     b = subprocess.run([CHECK, "-x", "map-ont", "-a", "--staged", "-K", "200000", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 50
+    ref, f1, f2, _ = synth.make_pairs(str(tmp_path / "pe"), n_pairs=80)  # read pairs through the staged calls
+    a = subprocess.run([CHECK, "-x", "sr", "-a", ref, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    b = subprocess.run([CHECK, "-x", "sr", "-a", "--staged", "--format-lib", ref, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 100
