@@ -8,12 +8,6 @@
 #include "flat_index.hpp"
 #include "ksw_dev.hpp"
 
-#ifdef __HIPCC__
-#define MM2AMD_HD __host__ __device__
-#else
-#define MM2AMD_HD
-#endif
-
 namespace mm2amd {
 
 struct SeedChainParams {          // what mm_map_frag_core passes to seeding and chaining (map.c:250-281)
@@ -31,7 +25,7 @@ struct SeedChainParams {          // what mm_map_frag_core passes to seeding and
 
 // the two chaining distance limits of a read of qlen bases (map.c:262-271): the query-side limit grows with the read for short
 // reads, the reference-side limit follows max_frag_len when no explicit max_gap_ref is set
-MM2AMD_HD inline void chain_gaps(const SeedChainParams &p, int qlen, int *gap_ref, int *gap_qry)
+MM2_HD inline void chain_gaps(const SeedChainParams &p, int qlen, int *gap_ref, int *gap_qry)
 {
 	*gap_qry = p.is_sr && qlen > p.max_gap ? qlen : p.max_gap;
 	if (p.max_gap_ref > 0) *gap_ref = p.max_gap_ref;

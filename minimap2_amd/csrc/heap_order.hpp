@@ -6,14 +6,14 @@
 // produces -- EXCEPT among hits with equal r, whose relative order is whatever the sift-down (ksort.h:43-53) made of it.  Equal r
 // means two seeds with the same minimizer (a k-mer repeated in the read); only reads that have such seeds need this replay.
 //
-// One thread replays the heap for one read.  Shared by the device kernel and by a host unit test (tests/test_heap_order.py).
+// One thread replays the heap for one read.  Shared by the device kernel and by a host unit test (tests/cpucheck/heap_order_test.cpp).
 #pragma once
 #include <cstdint>
 #include "backend.hpp"
 
 namespace mm2amd {
 
-MM2AMD_HD inline void heap_sift_down(uint64_t *hx, uint64_t *hy, uint32_t i, uint32_t n) // ks_heapdown with heap_lt(a, b) = a.x > b.x
+MM2_HD inline void heap_sift_down(uint64_t *hx, uint64_t *hy, uint32_t i, uint32_t n) // ks_heapdown with heap_lt(a, b) = a.x > b.x
 {
 	uint32_t k = i;
 	const uint64_t tx = hx[i], ty = hy[i];
@@ -28,7 +28,7 @@ MM2AMD_HD inline void heap_sift_down(uint64_t *hx, uint64_t *hy, uint32_t i, uin
 // n_seed seeds; list(i, &cnt) returns seed i's ascending position list.  hx/hy: scratch for n_seed heap entries.
 // emit(i, r) is called once per hit, in pop order.
 template <class ListOf, class Emit>
-MM2AMD_HD inline void heap_merge_order(uint32_t n_seed, uint64_t *hx, uint64_t *hy, ListOf list, Emit emit)
+MM2_HD inline void heap_merge_order(uint32_t n_seed, uint64_t *hx, uint64_t *hy, ListOf list, Emit emit)
 {
 	uint32_t hs = 0;
 	for (uint32_t i = 0; i < n_seed; ++i) {
