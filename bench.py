@@ -147,6 +147,32 @@ def gen_reads(torch, dev, seed, codes, per, n_contig, n_reads, mean_len, sd_len,
     return mutate_reads(torch, dev, g, src, bounds, err)
 
 
+def gen_pairs(torch, dev, seed, codes, per, n_contig, n_pairs, read_len, err):
+    """Illumina-like read pairs (FR): fragments of ~N(450, 60) bases placed uniformly, a read of read_len bases from each end (the
+    second one reverse-complemented), the fragment taken from either strand, substitutions only at rate err.  Returns
+    (reads 1, reads 2) as ASCII byte strings."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    frag = torch.clamp((torch.randn(n_pairs, device=dev, generator=g) * 60 + 450).long(), read_len, per)
+    cid = torch.randint(0, n_contig, (n_pairs,), device=dev, generator=g)
+    st = (torch.rand(n_pairs, device=dev, generator=g, dtype=torch.float64) * (per - frag + 1).double()).long()
+    swap = torch.rand(n_pairs, device=dev, generator=g) < 0.5   # fragment from the reverse strand: the mates swap roles
+    j = torch.arange(read_len, device=dev)[None, :]
+    base = (cid * per + st)[:, None]
+    left = codes[base + j]                                        # forward read at the fragment's left end
+    right = 3 - codes[base + (frag[:, None] - 1 - j)]             # reverse-complemented read at its right end
+    r1 = torch.where(swap[:, None], right, left)
+    r2 = torch.where(swap[:, None], left, right)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    out = []
+    for r in (r1, r2):
+        sub = torch.rand(r.shape, device=dev, generator=g) < err
+        r = torch.where(sub, (r + torch.randint(1, 4, r.shape, device=dev, generator=g, dtype=torch.uint8)) & 3, r)
+        asc = lut[r.long()].cpu().numpy()
+        out.append([asc[i].tobytes() for i in range(n_pairs)])
+    return out[0], out[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +182,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step")
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / gpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "map-hifi", "lr:hq", "splice"], help="map-ont is the BASELINE.json metric; the others are BASELINE.json's further configs / experiments")
+    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "map-hifi", "lr:hq", "splice", "sr"],
+                    help="map-ont is the BASELINE.json metric; the others are BASELINE.json's further configs / experiments (sr: --reads read PAIRS of 2 x --read-len bases)")
     ap.add_argument("--read-len", type=int, default=0, help="mean read length (0: 10000 for map-ont, 15000 otherwise)")
     ap.add_argument("--err", type=float, default=-1.0, help="per-base error rate (<0: 0.12 for map-ont, 0.005 otherwise)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
@@ -196,22 +223,25 @@ def main():
     names = ["chr%d" % (i + 1) for i in range(n_contig)]
     log("rank %d: reference %d Mb in %d contigs generated in %.1f s" % (rank, total // 1000000, n_contig, time.time() - t0))
     t0 = time.time()
-    mean_len = a.read_len if a.read_len > 0 else {"map-ont": 10000, "splice": 2000}.get(a.preset, 15000)
+    mean_len = a.read_len if a.read_len > 0 else {"map-ont": 10000, "splice": 2000, "sr": 150}.get(a.preset, 15000)
     err = a.err if a.err >= 0 else {"map-ont": 0.12, "splice": 0.05}.get(a.preset, 0.005)
-    if a.preset == "splice":
+    pairs = a.preset == "sr"
+    if pairs:
+        reads, mates = gen_pairs(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, err)
+    elif a.preset == "splice":
         reads = gen_transcripts(torch, dev, 1000 + rank, codes, genes, a.reads, err)
     else:
         reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, mean_len // 10, err)
     del codes
     torch.cuda.empty_cache()
-    batch_bases = sum(len(r) for r in reads)
-    log("rank %d: %d reads, %.3f Gbases generated in %.1f s" % (rank, len(reads), batch_bases / 1e9, time.time() - t0))
+    batch_bases = sum(len(r) for r in reads) + (sum(len(r) for r in mates) if pairs else 0)
+    log("rank %d: %d %s, %.3f Gbases generated in %.1f s" % (rank, len(reads), "read pairs" if pairs else "reads", batch_bases / 1e9, time.time() - t0))
     t0 = time.time()
     al = mm.Aligner(refs, preset=a.preset, names=names, n_threads=n_threads, sam=True)
     t_index = time.time() - t0
     st = al.index_stat()
     log("rank %d: device index built in %.1f s: %d distinct minimizers, %d positions, mid_occ=%d" % (rank, t_index, st["n_distinct"], st["n_minimizers"], al.map_opt.mid_occ))
-    named = [("read%d" % i, s) for i, s in enumerate(reads)]
+    named = [("read%d" % i, s, mates[i]) for i, s in enumerate(reads)] if pairs else [("read%d" % i, s) for i, s in enumerate(reads)]
 
     def barrier():
         if world > 1:
@@ -233,7 +263,7 @@ def main():
             shard.gather_payloads(payload, dst=0, device=comm_dev)
         barrier()
         dt = time.time() - t
-        n_mapped = sum(1 for i in range(len(named)) if n_reg[i] > 0)
+        n_mapped = sum(1 for i in range(len(n_reg)) if n_reg[i] > 0)
         n_hits = sum(n_reg)
         al.free_raw(n_reg, reg)
         return dt
@@ -347,18 +377,19 @@ def main():
             n_reg, reg, _ = al.run(raw=True)
             got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
             al.free_raw(n_reg, reg)
-            sb = sum(len(r[1]) for r in sample)
+            sb = sum(sum(len(x) for x in r[1:]) for r in sample)
             cpu = {"value": round(sb / t_cpu / 1e9, 5), "unit": "Gbases/s", "cores": best_thr, "kind": "reference",
-                   "sample": "%d of the batch's reads (%.3f Gbases), mm_map on %d threads (kt_for; best of %d/%d/%d threads on a 2000-read probe), mapping loop only, same index contents" % (n_s, sb / 1e9, best_thr, ncpu, ncpu // 2, ncpu // 4),
+                   "sample": "%d of the batch's reads or read pairs (%.3f Gbases), mm_map / mm_map_frag on %d threads (kt_for; best of %d/%d/%d threads on a 2000-read probe), mapping loop only, same index contents" % (n_s, sb / 1e9, best_thr, ncpu, ncpu // 2, ncpu // 4),
                    "hits_identical_to_gpu": got == want}
             drv.close()
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "Gbases/s", "cores": ncpu, "kind": "reference", "sample": "unavailable: %s" % e}
 
-    out = {"metric": "aligned Gbases/sec (%s, %d kb reads, -a)" % (a.preset, mean_len // 1000), "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
+    rl = "2 x %d b reads" % mean_len if pairs else "%d kb reads" % (mean_len // 1000)
+    out = {"metric": "aligned Gbases/sec (%s, %s, -a)" % (a.preset, rl), "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
-           "config": {"workload": "%s: %d synthetic ~%d kb %g%%-error reads per GPU vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, mean_len // 1000, err * 100, total // 1000000),
+           "config": {"workload": "%s: %d synthetic %s per GPU (%g%% error) vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, ("read pairs, " + rl) if pairs else ("~" + rl), err * 100, total // 1000000),
                       "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads, "host_cpu_s_per_step": round(host_cpu_s, 2),
                       "parallelism": "replicated index, reads sharded %d-way, RCCL hit gather" % world if world > 1 else "1 GPU",
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},

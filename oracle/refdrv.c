@@ -151,3 +151,58 @@ double refdrv_map(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_reads, const
 	free(m.tbuf);
 	return t0;
 }
+
+/* Read pairs: what worker_for (map.c:425-474) does for a two-segment fragment -- reverse-complement a mate as pe_ori says,
+ * mm_map_frag() on the two reads, turn the hits of a flipped mate back -- on copies of the reads.
+ * seqs / lens / n_reg / reg hold 2 * n_pairs entries (mates adjacent), names n_pairs. */
+static void map_pair(void *data, long i, int tid)
+{
+	map_t *m = (map_t*)data;
+	const int pe_ori = m->opt->pe_ori;
+	int j, qlens[2];
+	const char *qseqs[2];
+	mm_bseq1_t t[2];
+	for (j = 0; j < 2; ++j) {
+		memset(&t[j], 0, sizeof(mm_bseq1_t));
+		t[j].l_seq = m->lens[2 * i + j];
+		t[j].seq = (char*)malloc(t[j].l_seq + 1);
+		memcpy(t[j].seq, m->seqs[2 * i + j], t[j].l_seq);
+		t[j].seq[t[j].l_seq] = 0;
+		if ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1))) mm_revcomp_bseq(&t[j]);
+		qlens[j] = t[j].l_seq, qseqs[j] = t[j].seq;
+	}
+	mm_map_frag(m->mi, 2, qlens, qseqs, &m->n_reg[2 * i], &m->reg[2 * i], m->tbuf[tid], m->opt, m->names ? m->names[i] : 0);
+	for (j = 0; j < 2; ++j) {
+		if ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1))) {
+			int k;
+			for (k = 0; k < m->n_reg[2 * i + j]; ++k) {
+				mm_reg1_t *r = &m->reg[2 * i + j][k];
+				int s = r->qs;
+				r->qs = qlens[j] - r->qe, r->qe = qlens[j] - s, r->rev = !r->rev;
+				if (r->p) {
+					if (r->p->trans_strand == 1) r->p->trans_strand = 2;
+					else if (r->p->trans_strand == 2) r->p->trans_strand = 1;
+				}
+			}
+		}
+		free(t[j].seq);
+	}
+}
+
+double refdrv_map_pairs(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_pairs, const char **seqs, const int *lens, const char **names,
+                        int n_threads, int *n_reg, mm_reg1_t **reg)
+{
+	map_t m;
+	int t;
+	double t0;
+	if (n_threads < 1) n_threads = 1;
+	m.mi = mi, m.opt = opt, m.seqs = seqs, m.names = names, m.lens = lens, m.n_reg = n_reg, m.reg = reg;
+	m.tbuf = (mm_tbuf_t**)calloc(n_threads, sizeof(mm_tbuf_t*));
+	for (t = 0; t < n_threads; ++t) m.tbuf[t] = mm_tbuf_init();
+	t0 = now_s();
+	kt_for(n_threads, map_pair, &m, n_pairs);
+	t0 = now_s() - t0;
+	for (t = 0; t < n_threads; ++t) mm_tbuf_destroy(m.tbuf[t]);
+	free(m.tbuf);
+	return t0;
+}

@@ -365,8 +365,20 @@ class RefDriver(object):
         return mo
 
     def map(self, mo, reads, n_threads=None):
-        """reads: list of (name, seq) -> (wall seconds of the mm_map loop, n_reg, reg) ; free with mm2amd_free_regs-like free_regs()"""
+        """reads: list of (name, seq) -> (wall seconds of the mm_map loop, n_reg, reg) ; free with mm2amd_free_regs-like free_regs().
+        A list of (name, seq1, seq2) is mapped as read pairs (mm_map_frag with two segments); n_reg / reg then hold 2 entries per pair."""
         n = len(reads)
+        if n and len(reads[0]) == 3:
+            D = self.D
+            D.refdrv_map_pairs.restype = C.c_double
+            D.refdrv_map_pairs.argtypes = D.refdrv_map.argtypes
+            names = (C.c_char_p * n)(*[(r[0].encode() if isinstance(r[0], str) else r[0]) for r in reads])
+            flat = [s for r in reads for s in r[1:]]
+            seqs = (C.c_char_p * (2 * n))(*flat)
+            lens = (C.c_int * (2 * n))(*[len(s) for s in flat])
+            n_reg, reg = (C.c_int * (2 * n))(), (C.c_void_p * (2 * n))()
+            t = D.refdrv_map_pairs(self.mi, C.byref(mo), n, seqs, lens, names, n_threads or self.n_threads, n_reg, reg)
+            return t, n_reg, reg
         names = (C.c_char_p * n)(*[(r[0].encode() if isinstance(r[0], str) else r[0]) for r in reads])
         seqs = (C.c_char_p * n)(*[r[1] for r in reads])
         lens = (C.c_int * n)(*[len(r[1]) for r in reads])
