@@ -334,3 +334,14 @@ def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm
     a = subprocess.run([CHECK, "-x", "sr", "-a", ref, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     b = subprocess.run([CHECK, "-x", "sr", "-a", "--staged", "--format-lib", ref, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 100
+
+
+def test_junction_annotation_is_refused_not_ignored(tmp_path):  # mi->I from mm_idx_bed_read changes spliced alignment (align.c:642)
+    import synth
+    ref, rd = synth.make_weird(str(tmp_path))
+    bed = str(tmp_path / "j.bed")
+    open(bed, "w").write("c1\t1000\t5000\tj1\t0\t+\n")
+    p = subprocess.run([CHECK, "-x", "splice", "-a", "--junc-bed", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 2 and b"junction annotation" in p.stderr
+    p = subprocess.run([CHECK, "-x", "map-ont", "-a", "--junc-bed", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0  # unused without MM_F_SPLICE
