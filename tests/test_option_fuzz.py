@@ -80,3 +80,46 @@ def test_mapping_options(inputs, seed):
 @pytest.mark.parametrize("seed", range(2000, 2010))
 def test_output_options_through_the_library_formatter(inputs, seed):
     _case(inputs, seed, OPTS + FORMAT_OPTS * 3, True)
+
+
+SR_OPTS = [("-F", lambda r: C(r, ["200", "400", "800", "2000"])), ("--heap-sort=no", None), ("--heap-sort=yes", None), ("-f", lambda r: C(r, ["2,20", "5,50", "0.001", "3"])),
+           ("-g", lambda r: C(r, ["50", "100", "300"])), ("-r", lambda r: C(r, ["50", "100", "30,30"])), ("-s", lambda r: C(r, ["20", "40", "80"])),
+           ("-n", lambda r: C(r, ["1", "2", "3"])), ("-m", lambda r: C(r, ["15", "25", "40"])), ("-k", lambda r: C(r, ["15", "19", "21"])), ("-w", lambda r: C(r, ["5", "8", "11"])),
+           ("--no-pairing", None)]
+SR_SKIP = ("-P", "-g", "-r", "-s", "-n", "-m", "-k", "-w", "-f", "--max-qlen")
+
+
+@pytest.fixture(scope="module")
+def short_inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fuzz_sr")
+    ref, rd = synth.make_short(str(d / "se"), n_reads=150)
+    pref, f1, f2, inter = synth.make_pairs(str(d / "pe"), n_pairs=100)
+    ovl = synth.make_overlaps(str(d / "ovl"), n_reads=40)
+    return {"se": (ref, [rd]), "pe2": (pref, [f1, f2]), "pe1": (pref, [inter]), "ovl": (ovl, [ovl])}
+
+
+@needs_dev
+@pytest.mark.parametrize("seed", range(3000, 3016))
+def test_short_read_pair_and_overlap_options(short_inputs, seed):
+    """The same generator over the short-read (single-end, two files, interleaved) and all-vs-all inputs; every other case goes
+    through the library's formatter (mate fields)."""
+    r = random.Random(seed)
+    kind = ["se", "pe2", "pe1", "ovl"][seed % 4]
+    ref, files = short_inputs[kind]
+    args = ["-x", r.choice(["ava-ont", "ava-pb"]) if kind == "ovl" else "sr"]
+    mode = r.choice(["-a", "-c", "-a", ""])
+    if mode:
+        args.append(mode)
+    table = [o for o in OPTS if o[0] != "--max-qlen"] if kind == "ovl" else SR_OPTS + [o for o in OPTS + FORMAT_OPTS if o[0] not in SR_SKIP]
+    for name, gen in r.sample(table, r.randint(1, 5)):
+        args.append(name)
+        if gen:
+            args.append(gen(r))
+    outs = []
+    for binary, pre in ((G.REF_BIN, []), (CHECK, ["--format-lib"] if seed % 2 else [])):
+        p = subprocess.run([binary] + pre + args + ["-t", "4", ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        outs.append((p.returncode, G.strip_pg(p.stdout)))
+    if outs[0][0] != 0:
+        assert outs[1][0] != 0, args
+    else:
+        assert outs[1][0] == 0 and outs[0][1] == outs[1][1], args
