@@ -44,6 +44,9 @@ struct Idx {                                           // mm_idx_t, minimap.h:88
 	void *km, *h;
 };
 
+struct Intv1 { int32_t st, en, cnt; int32_t score : 30, strand : 2; };   // mm_idx_intv1_t, index.c:35-38
+struct IntvList { int32_t n, m; Intv1 *a; };                              // mm_idx_intv_t, index.c:40-43 (mm_idx_t::I: one per sequence)
+
 struct Extra {                                         // mm_extra_t, minimap.h:103-110
 	uint32_t capacity;
 	int32_t dp_score, dp_max, dp_max2;

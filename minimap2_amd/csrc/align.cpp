@@ -694,12 +694,34 @@ void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdr
 	j.t_off = reversed ? tbase + w.re - 1 : tbase + w.rs;
 	j.flag = flag | t.ksw_flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);
 	j.tag = 0, j.reserved = 0;
+	if ((opt_.flag & F_SPLICE) && fi_.has_junc && w.kind != W_INV) { // mm_get_junc -> mm_idx_bed_junc (align.c:638-643, index.c:803-826): introns lying entirely inside the window
+		const std::vector<FlatIndex::Junc> &J = fi_.junc[t.rid];
+		const size_t first = ra.juncs.size();
+		size_t lo = 0, hi = J.size();
+		while (hi > lo) { const size_t mid = lo + ((hi - lo) >> 1); if (J[mid].st >= w.rs) hi = mid; else lo = mid + 1; }
+		for (size_t i = lo; i < J.size() && J[i].st < w.re; ++i) {
+			if (J[i].en > w.re || J[i].strand == 0) continue;
+			ra.juncs.push_back((uint32_t)(J[i].st - w.rs) << 4 | (J[i].strand > 0 ? 1u : 8u));
+			ra.juncs.push_back((uint32_t)(J[i].en - 1 - w.rs) << 4 | (J[i].strand > 0 ? 2u : 4u));
+		}
+		if (ra.juncs.size() > first) { // ascending positions, one entry per position
+			std::sort(ra.juncs.begin() + first, ra.juncs.end());
+			size_t k = first;
+			for (size_t i = first + 1; i < ra.juncs.size(); ++i) {
+				if (ra.juncs[i] >> 4 == ra.juncs[k] >> 4) ra.juncs[k] |= ra.juncs[i] & 15u;
+				else ra.juncs[++k] = ra.juncs[i];
+			}
+			ra.juncs.resize(k + 1);
+			j.tag = (uint32_t)first, j.reserved = (uint32_t)(k + 1 - first);
+		}
+	}
 	w.job = (int32_t)jobs.size(), w.saved = -1;
 	jobs.push_back(j);
 }
 
 void Aligner::schedule(ReadAlign &ra, std::vector<KswJob> &jobs)
 {
+	ra.juncs.clear();
 	for (size_t ti = 0; ti < ra.tasks.size(); ++ti) {
 		RegionTask &t = ra.tasks[ti];
 		if (t.done) continue;

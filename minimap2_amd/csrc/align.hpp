@@ -62,6 +62,7 @@ struct ReadAlign {        // per-read alignment state
 	int n_a = 0;
 	std::vector<RegionTask> tasks;               // in creation order
 	std::vector<int> order;                      // output order: indices into tasks (inversions included)
+	std::vector<uint32_t> juncs;                 // annotated splice sites inside this round's DP windows (KswScoring::juncs entries; a job's tag indexes it)
 };
 
 class Aligner {

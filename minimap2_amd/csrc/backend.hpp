@@ -49,6 +49,7 @@ public:
 	// all-vs-all mapping (MM_F_NO_DIAG / MM_F_NO_DUAL): seed_chain() then applies skip_seed's read-name rules (map.c:81-91), which
 	// need the reads' names in begin_batch().  Call once, before the first batch.
 	virtual void enable_name_rules() {}
+	virtual bool supports_junctions() const { return true; } // KswScoring::juncs honoured by ksw()
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off

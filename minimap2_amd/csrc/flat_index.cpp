@@ -37,6 +37,14 @@ void FlatIndex::from_reference(const ref::Idx *mi)
 		sum_len += mi->seq[i].len;
 	}
 	S = mi->S; // borrowed: the reference index outlives the mapper (map.c:663-686)
+	junc.clear(), has_junc = false;
+	if (mi->I) { // junction annotation (--junc-bed): copied, the mapper makes the per-window junc[] of mm_idx_bed_junc from it
+		const ref::IntvList *I = (const ref::IntvList *)mi->I;
+		junc.resize(n_seq);
+		for (uint32_t i = 0; i < n_seq; ++i)
+			for (int32_t j = 0; j < I[i].n; ++j) junc[i].push_back(Junc{I[i].a[j].st, I[i].a[j].en, I[i].a[j].strand});
+		has_junc = true;
+	}
 	std::vector<std::pair<uint64_t, uint64_t>> pairs;
 	const uint32_t nb = 1u << mi->b;
 	for (uint32_t b = 0; b < nb; ++b) {

@@ -16,6 +16,10 @@ struct FlatIndex {
 	uint32_t n_seq = 0;
 	int n_alt = 0;
 	std::vector<uint8_t> is_alt;        // per sequence: ALT contig (mm_idx_seq_t::is_alt, set by mm_idx_alt_read, index.c:648-670)
+	// annotated introns per sequence, ascending start (mm_idx_t::I as mm_idx_bed_read leaves it, index.c:797-801): st, en, strand
+	struct Junc { int32_t st, en, strand; };
+	std::vector<std::vector<Junc>> junc;
+	bool has_junc = false;
 	std::vector<std::string> names;
 	std::vector<uint64_t> seq_off;      // offset of each sequence in S (bases)
 	std::vector<uint32_t> seq_len;

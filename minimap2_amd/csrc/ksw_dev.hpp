@@ -52,6 +52,12 @@ struct KswScoring {         // uniform over a launch
 	int8_t q, e, q2, e2;    // as passed by the caller, BEFORE the swap at ksw2_extd2_sse.c:78
 	int8_t single;          // 1: single-affine recurrences (ksw_extz2_sse; q2/e2 unused), the rule of mm_align_pair (align.c:353-356); 2: splice (ksw_exts2_sse)
 	int8_t noncan;          // splice mode: cost of a non-canonical splice site (ksw2_exts2_sse.c:33, opt->noncan); gapo2 = q2, e2 unused
+	// splice mode with junction annotation (ksw2_exts2_sse.c:201-217, the junc[] of mm_idx_bed_junc): a job with reserved > 0 owns
+	// juncs[tag .. tag + reserved), entries  t << 4 | bits  ascending in t, t = offset of the base in the window as stored in the
+	// index (NOT reversed for a T_REVERSED job), bits as in junc[]: 1 / 8 first base of a + / - strand intron, 2 / 4 its last base
+	int8_t junc_bonus = 0;
+	const uint32_t *juncs = nullptr;
+	size_t n_juncs = 0;
 };
 
 struct KswLaunch {

@@ -219,6 +219,18 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				else sp0 = (flag & KSW_SPLICE_FLANK) ? L.sc.noncan / 2 : 0, sp1 = sp2 = sp3 = L.sc.noncan;
 			}
 			auto sp_cost = [&](int z) { return z < 0 ? 0 : z == 0 ? -sp0 : z == 1 ? -sp1 : z == 2 ? -sp2 : -sp3; };
+			// annotated splice sites of this window (ksw2_exts2_sse.c:201-217): junc[i] of the target as the job reads it
+			const uint32_t nj = SPLICE && L.sc.juncs ? J.reserved : 0u;
+			const uint32_t *jent = nj ? L.sc.juncs + J.tag : nullptr;
+			auto jbits = [&](int i) -> uint32_t {
+				if (i < 0 || i >= tlen) return 0u;
+				const uint32_t pos = (flag & KSWJ_T_REVERSED) ? (uint32_t)(tlen - 1 - i) : (uint32_t)i;
+				uint32_t lo = 0, hi = nj;
+				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jent[mid] >> 4 < pos) lo = mid + 1; else hi = mid; }
+				return lo < nj && jent[lo] >> 4 == pos ? jent[lo] & 15u : 0u;
+			};
+			const uint32_t jd_mask = !sp_revc ? (sp_for ? 1u : 0u) | ((flag & KSW_SPLICE_REV) ? 8u : 0u) : (sp_for ? 2u : 0u) | ((flag & KSW_SPLICE_REV) ? 4u : 0u);
+			const uint32_t ja_mask = !sp_revc ? (sp_for ? 2u : 0u) | ((flag & KSW_SPLICE_REV) ? 4u : 0u) : (sp_for ? 1u : 0u) | ((flag & KSW_SPLICE_REV) ? 8u : 0u);
 			// Take positions (frontier, upto] into the window with the values the reference's up-front fill gives them
 			// (:107-128; splice: donor / acceptor costs from the neighbouring bases, ksw2_exts2_sse.c:120-194).
 			int frontier = -1;
@@ -272,7 +284,12 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 								}
 							}
 						}
-						bv |= (uint32_t)(sp_cost(zd) & 0xff) << 8 | (uint32_t)(sp_cost(za) & 0xff) << 24;
+						int dcost = sp_cost(zd), acost = sp_cost(za);
+						if (nj) { // the bonus is added in the 8-bit lanes (int8 wrap) wherever the annotation has the site on the assumed strand
+							if (t < tlen - 1 && (jbits(t + 1) & jd_mask)) dcost = sx8(dcost + L.sc.junc_bonus);
+							if (t < tlen && (jbits(t) & ja_mask)) acost = sx8(acost + L.sc.junc_bonus);
+						}
+						bv |= (uint32_t)(dcost & 0xff) << 8 | (uint32_t)(acost & 0xff) << 24;
 					}
 					A[k] = SINGLE ? 0u : pack4(nqe, nqe, nqe, nqe);
 					B[k] = bv;

@@ -51,6 +51,7 @@ inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
 {
 	constexpr int kSpliceBits = KSW_SPLICE_FOR | KSW_SPLICE_REV | KSW_SPLICE_FLANK | KSW_SPLICE_CMPLX;
 	if (!scoring_ok || ((j.flag & 0x1fff) & ~kSpliceBits) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
+	if (j.reserved) return false; // windows with annotated splice sites (KswScoring::juncs) are priced by the lane-exact kernel only
 	return j.qlen > 0 && j.tlen > 0;
 }
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
@@ -170,6 +171,13 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	static_assert(kNTiers <= 128, "one queue counter per launch class");
 	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
+	KswScoring sc_dev = sc; // the junction entries travel with the jobs
+	sc_dev.juncs = nullptr;
+	if (sc.n_juncs) {
+		d_juncs.ensure(sc.n_juncs);
+		HIP_CHECK(hipMemcpyAsync(d_juncs.p, sc.juncs, sc.n_juncs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		sc_dev.juncs = d_juncs.p;
+	}
 	KswRes *tr = tmp_res.ensure(n);
 
 	// CIGARs are much shorter than qlen+tlen; start with a quarter of the worst case and retry in full on overflow
@@ -229,7 +237,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.cigar_tmp = d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap;
 			L.dir_pool = d_dir.p, L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
-			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc;
+			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc_dev;
 			L.state_pool = P.hbm ? d_state.p : nullptr;
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);

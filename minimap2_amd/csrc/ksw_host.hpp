@@ -10,7 +10,7 @@ namespace mm2amd {
 struct KswRunner {
 	DevBuf<KswJob> d_jobs;
 	DevBuf<KswRes> d_res;
-	DevBuf<uint32_t> d_cigar, d_cigar_tmp, d_cursor;
+	DevBuf<uint32_t> d_cigar, d_cigar_tmp, d_cursor, d_juncs;
 	DevBuf<uint8_t> d_dir, d_state;
 	DevBuf<int32_t> d_counter;
 	PinBuf<KswJob> sorted;            // jobs in launch order (tier, then decreasing cost), pinned for the H2D copy

@@ -43,6 +43,8 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	const int64_t unsupported = F_QSTRAND | F_SR_RNA; // MM_F_INDEPEND_SEG is resolved at the boundary (capi_map.cpp)
 	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr and --qstrand are not implemented");
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
+	if ((opt.flag & F_SPLICE) && fi.has_junc && !be.supports_junctions())
+		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation (--junc-bed) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
@@ -319,6 +321,19 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			parallel_for(n_threads_, mu, [&](long i, int) {
 				if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
 			}, 256);
+			if (fi_.has_junc && (opt_.flag & F_SPLICE)) { // the units' junction entries as one pool; the jobs' offsets become pool-wide
+				std::vector<size_t> &jb = ds.junc_base;
+				jb.resize(mu + 1);
+				jb[0] = 0;
+				for (long i = 0; i < mu; ++i) jb[i + 1] = jb[i] + (per_read_jobs[i].empty() ? 0 : ra[i].juncs.size());
+				ds.juncs.resize(jb[mu] + 1);
+				parallel_for(n_threads_, mu, [&](long i, int) {
+					if (per_read_jobs[i].empty()) return;
+					if (!ra[i].juncs.empty()) memcpy(&ds.juncs[jb[i]], ra[i].juncs.data(), ra[i].juncs.size() * 4);
+					for (size_t k = job_base[i]; k < job_base[i + 1]; ++k) if (jobs[k].reserved) jobs[k].tag += (uint32_t)jb[i];
+				}, 256);
+				sc.juncs = ds.juncs.data(), sc.n_juncs = jb[mu], sc.junc_bonus = (int8_t)opt_.junc_bonus;
+			}
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
 			if (const char *dump = getenv("MM2AMD_DUMP_JOBS")) { // debugging aid: the shapes of the DP jobs of every round
 				FILE *fp = fopen(dump, "a");

@@ -43,6 +43,8 @@ private:
 		std::vector<std::vector<KswJob>> per_read_jobs;
 		std::vector<size_t> job_base;
 		std::vector<KswJob> jobs;
+		std::vector<uint32_t> juncs;             // junction annotation entries of the round's jobs (KswScoring::juncs)
+		std::vector<size_t> junc_base;
 		std::vector<KswRes> kres;
 		std::vector<uint8_t> q4;
 		std::vector<uint64_t> q4_off;

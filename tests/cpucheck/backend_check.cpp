@@ -104,7 +104,7 @@ public:
 		std::vector<uint32_t> &cigar = cigar_store_;
 		res.resize(jobs.size());
 		cigar.clear();
-		std::vector<uint8_t> q, t;
+		std::vector<uint8_t> q, t, jbuf;
 		std::vector<uint32_t> cg;
 		for (size_t k = 0; k < jobs.size(); ++k) {
 			const KswJob &j = jobs[k];
@@ -122,8 +122,19 @@ public:
 				ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1, ez.score = ez.mqe = ez.mte = ORA_NEG_INF, ez.zdropped = 1;
 			} else {
 				cg.resize((size_t)j.qlen + j.tlen + 8);
-				if (sc.single == 2) ora_ksw_exts2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.noncan, j.zdrop, j.end_bonus, 0, 0, j.flag & 0x1fff, nullptr,
-				                                  &ez, cg.data(), (int)cg.size());
+				if (sc.single == 2) {
+					const uint8_t *junc = nullptr;
+					if (j.reserved) { // the window's junc[] as mm_idx_bed_junc fills it, in the order the job reads the target
+						jbuf.assign((size_t)j.tlen, 0);
+						for (uint32_t e = 0; e < j.reserved; ++e) {
+							const uint32_t v = sc.juncs[j.tag + e], pos = v >> 4;
+							jbuf[(j.flag & KSWJ_T_REVERSED) ? (uint32_t)j.tlen - 1 - pos : pos] |= (uint8_t)(v & 15u);
+						}
+						junc = jbuf.data();
+					}
+					ora_ksw_exts2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.noncan, j.zdrop, j.end_bonus, sc.junc_bonus, 0, j.flag & 0x1fff, junc,
+					              &ez, cg.data(), (int)cg.size());
+				}
 				else if (sc.single) ora_ksw_extz2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez, cg.data(), (int)cg.size());
 				else ora_ksw_extd2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff,
 				                   &ez, cg.data(), (int)cg.size());

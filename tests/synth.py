@@ -53,7 +53,7 @@ def gen_reads(rng, contigs, n_reads, mean_len, sd_len, err, min_len=1000):
     return reads
 
 
-def gen_transcripts(rng, contigs, n_reads, err, max_intron=6000):
+def gen_transcripts(rng, contigs, n_reads, err, max_intron=6000, introns=None):
     """Spliced reads: 2..8 exons of 60..500 bases separated by introns (mostly 80..max_intron, some ~20 kb), concatenated.  The
     reference is edited in place so that most introns carry the canonical signals (GT..AG for a gene on the + strand, CT..AC
     for one on the - strand); a read is the transcript or its reverse complement, with per-base error `err`."""
@@ -79,12 +79,47 @@ def gen_transcripts(rng, contigs, n_reads, err, max_intron=6000):
                 if rng.random() < 0.9:
                     ctg[pos:pos + 2] = [1, 3] if minus else [2, 3]
                     ctg[pos + int(it[k]) - 2:pos + int(it[k])] = [0, 1] if minus else [0, 2]
+                if introns is not None:
+                    introns.append((c, pos, pos + int(it[k]), minus))
                 pos += int(it[k])
         s = np.concatenate([ctg[a:b] for a, b in parts])
         if rng.random() < 0.5:
             s = COMP[s[::-1]]
         reads.append((s, err))
     return [mutate_read(rng, s, e) for s, e in reads]  # after all edits of the reference
+
+
+def make_junctions(outdir, seed=31, n_reads=60, ref_mb=1.0):
+    """cDNA reads plus a junction annotation in BED6 (one intron per line, as --junc-bed reads it): most of the true introns
+    (including the ones without canonical signals, where the annotation bonus decides), some with the wrong strand, some shifted
+    by a few bases, duplicates, and decoys elsewhere.  Returns (ref.fa, reads.fa, junc.bed)."""
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    contigs = gen_reference(rng, int(ref_mb * 1e6), 2)
+    introns = []
+    reads = gen_transcripts(rng, contigs, n_reads, 0.04, introns=introns)
+    ref, rd, bed = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa"), os.path.join(outdir, "junc.bed")
+    write_fasta(ref, ["chr1", "chr2"], contigs)
+    write_fasta(rd, ["read%d" % i for i in range(n_reads)], reads)
+    r2 = np.random.default_rng(seed + 1)
+    with open(bed, "w") as f:
+        for k, (c, st, en, minus) in enumerate(introns):
+            u = r2.random()
+            strand = "-" if minus else "+"
+            if u < 0.15:
+                continue                                   # not annotated
+            if u < 0.22:
+                strand = "+" if minus else "-"             # annotated on the wrong strand
+            if u > 0.93:
+                st, en = st + int(r2.integers(-6, 7)), en + int(r2.integers(-6, 7))  # slightly off
+            f.write("chr%d\t%d\t%d\tj%d\t0\t%s\n" % (c + 1, st, en, k, strand))
+            if k % 11 == 0:
+                f.write("chr%d\t%d\t%d\tj%d_dup\t0\t%s\n" % (c + 1, st, en, k, strand))
+        for k in range(40):                                # decoys
+            c = int(r2.integers(0, 2)); st = int(r2.integers(0, len(contigs[c]) - 9000)); en = st + int(r2.integers(60, 8000))
+            f.write("chr%d\t%d\t%d\tdecoy%d\t0\t%s\n" % (c + 1, st, en, k, "+-"[k % 2]))
+        f.write("chr1\t100\t900\tnostrand\t0\t.\n")
+    return ref, rd, bed
 
 
 def make_alt(outdir, seed=51):

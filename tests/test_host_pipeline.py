@@ -336,12 +336,25 @@ def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm
     assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 100
 
 
-def test_junction_annotation_is_refused_not_ignored(tmp_path):  # mi->I from mm_idx_bed_read changes spliced alignment (align.c:642)
+JUNC_CASES = [["-x", "splice", "-a"], ["-x", "splice", "-c"], ["-x", "splice", "-a", "--junc-bonus", "20"], ["-x", "splice:hq", "-a"], ["-x", "splice", "-a", "-u", "n"],
+              ["-x", "splice", "-c", "--cs", "-u", "f"]]
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args", JUNC_CASES)
+def test_junction_annotation(args, tmp_path):
+    """--junc-bed: the annotated introns inside each DP window (mm_idx_bed_junc, index.c:803-826) reach the splice DP as bonus on
+    donor / acceptor costs (ksw2_exts2_sse.c:201-217); most output lines change with the annotation, and must change the same way."""
     import synth
-    ref, rd = synth.make_weird(str(tmp_path))
-    bed = str(tmp_path / "j.bed")
-    open(bed, "w").write("c1\t1000\t5000\tj1\t0\t+\n")
-    p = subprocess.run([CHECK, "-x", "splice", "-a", "--junc-bed", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert p.returncode == 2 and b"junction annotation" in p.stderr
-    p = subprocess.run([CHECK, "-x", "map-ont", "-a", "--junc-bed", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert p.returncode == 0  # unused without MM_F_SPLICE
+    ref, rd, bed = synth.make_junctions(str(tmp_path))
+    out = _pair(args + ["--junc-bed", bed], ref, rd)
+    plain = subprocess.run([G.REF_BIN] + args + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    if "n" not in args:  # without an assumed transcript strand (-u n) there are no donor / acceptor costs to add the bonus to
+        assert sum(1 for a, b in zip(out.split(b"\n"), G.strip_pg(plain).split(b"\n")) if a != b) > 10
+
+
+def test_jump_annotation_is_refused_not_ignored(tmp_path):  # mi->J (-j / --pass1) changes spliced alignment (map.c:362-364): not implemented
+    import synth
+    ref, rd, bed = synth.make_junctions(str(tmp_path), n_reads=5)
+    p = subprocess.run([CHECK, "-x", "splice", "-a", "-j", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 2 and b"jump annotation" in p.stderr
