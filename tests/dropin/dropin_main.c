@@ -38,6 +38,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-c") == 0) mopt.flag |= MM_F_OUT_CG | MM_F_CIGAR;
 		else if (strcmp(argv[k], "-t") == 0) n_threads = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-K") == 0) batch = atoll(argv[++k]);
+		else if (strcmp(argv[k], "-I") == 0) iopt.batch_size = atoll(argv[++k]); /* main.c:196: a multi-part index, one mm_gpu_init / mm_gpu_destroy per part */
 		else if (strcmp(argv[k], "-s") == 0) mopt.min_dp_max = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--seed") == 0) mopt.seed = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--stats") == 0) print_stats = 1;
@@ -129,8 +130,10 @@ int main(int argc, char *argv[])
 	mm_idx_reader_t *rd = mm_idx_reader_open(argv[k], &iopt, 0);
 	if (rd == 0) { fprintf(stderr, "failed to open %s\n", argv[k]); return 1; }
 	mm_idx_t *mi;
+	int n_parts = 0;
 	while ((mi = mm_idx_reader_read(rd, n_threads)) != 0) {
-		if (mopt.flag & MM_F_OUT_SAM) mm_write_sam_hdr(mi, 0, MM_VERSION, 0, 0);
+		if ((mopt.flag & MM_F_OUT_SAM) && n_parts++ == 0) /* main.c:443-455: one header, with @SQ lines only for a single-part index */
+			mm_write_sam_hdr(mm_idx_reader_eof(rd) ? mi : 0, 0, MM_VERSION, 0, 0);
 		mm_mapopt_update(&mopt, mi);
 		if (junc_fn) mm_idx_bed_read(mi, junc_fn, 1); /* main.c:468 */
 		if (jump_fn) mm_idx_jjump_read(mi, jump_fn, MM_JUNC_ANNO, -1); /* main.c:473 */

@@ -358,3 +358,12 @@ def test_jump_annotation_is_refused_not_ignored(tmp_path):  # mi->J (-j / --pass
     ref, rd, bed = synth.make_junctions(str(tmp_path), n_reads=5)
     p = subprocess.run([CHECK, "-x", "splice", "-a", "-j", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 2 and b"jump annotation" in p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+def test_multi_part_index(tmp_path):  # -I: mm_gpu_init / mm_gpu_map_batch / mm_gpu_destroy once per index part (main.c:438-503)
+    import synth
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 3, 40, 23)
+    for args in (["-x", "map-ont", "-a", "-I", "1200000"], ["-x", "map-ont", "-c", "-I", "1000000"]):
+        out = _pair(args, ref, rd)
+        assert out.count(b"\n") >= 40
