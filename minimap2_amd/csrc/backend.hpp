@@ -13,6 +13,7 @@ namespace mm2amd {
 struct SeedChainParams {          // what mm_map_frag_core passes to seeding and chaining (map.c:250-281)
 	int k, w, is_hpc;
 	int mid_occ, max_max_occ, occ_dist;
+	int sdust_thres = 0;          // > 0: minimizers lying mostly in SDUST-masked regions are dropped (mm_dust_minier, map.c:34-57,68)
 	int q_mid_occ;                // threshold of the query-side filter mm_seed_mz_flt (map.c:251): mm_mapopt_t::mid_occ also in the max_occ pass (map.c:311)
 	float q_occ_frac;
 	int64_t flag;                 // mm_mapopt_t::flag (FOR_ONLY / REV_ONLY / NO_DIAG ... for skip_seed)
@@ -50,6 +51,7 @@ public:
 	// need the reads' names in begin_batch().  Call once, before the first batch.
 	virtual void enable_name_rules() {}
 	virtual bool supports_junctions() const { return true; } // KswScoring::juncs honoured by ksw()
+	virtual bool supports_sdust() const { return true; }     // SeedChainParams::sdust_thres honoured by seed_chain()
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off

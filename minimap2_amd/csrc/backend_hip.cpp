@@ -36,7 +36,7 @@ struct Lane {
 	DevBuf<uint32_t> d_mz_cnt, d_sd_n, d_sd_off, d_sd_aoff, d_sd_qpos, d_sd_info, d_n_anchor, d_n_minipos, d_n_seedhit, d_tie;
 	DevBuf<int32_t> d_rep_len, d_f, d_p, d_t;
 	DevBuf<Anchor> d_anchors;
-	DevBuf<uint8_t> d_sort_tmp;
+	DevBuf<uint8_t> d_sort_tmp, d_dust;
 	PinBuf<Anchor> h_anchors;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
@@ -82,6 +82,7 @@ public:
 	// The lane-exact kernel applies the annotation bonus (ksw_extd2.hip, admit()); written after the round's GPU minutes were spent,
 	// so it stays opt-in until tests/test_gpu_pending.py has passed on an MI355X.
 	bool supports_junctions() const override { return getenv("MM2AMD_PENDING") != nullptr; }
+	bool supports_sdust() const override { return getenv("MM2AMD_PENDING") != nullptr; } // dust_filter_kernel: same status
 	void enable_name_rules() override
 	{
 		if (name_rules_ || fi_names_->empty()) return;
@@ -194,6 +195,10 @@ public:
 		kp.begin(st); launch_sketch(Bu, P, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
 		if (has_pairs_) // seed_collect joins the minimizer lists of a pair's two units (collect_minimizers, map.c:59-72); indices are batch-wide
 			B.unit_first = d_unit_first_.p + lo, B.unit_off = d_unit_off_.p, B.unit_cnt = ln.d_mz_cnt.p - ulo, B.mz_cnt = nullptr;
+		if (P.sdust_thres > 0) { // -T: drop minimizers in low-complexity regions (needs the seed arrays as scratch: assigned above)
+			ln.d_dust.ensure(dust_scratch_bytes(dust_threads()));
+			kp.begin(st); launch_dust_filter(B, P, ln.d_dust.p, st); kp.end(st, "dust_filter_kernel", L);
+		}
 		// 2. seeds: probe, filter, count anchors
 		ln.d_n_anchor.ensure(n), ln.d_n_minipos.ensure(n), ln.d_n_seedhit.ensure(n), ln.d_rep_len.ensure(n);
 		B.n_anchor = ln.d_n_anchor.p, B.n_minipos = ln.d_n_minipos.p, B.n_seedhit = ln.d_n_seedhit.p, B.rep_len = ln.d_rep_len.p;

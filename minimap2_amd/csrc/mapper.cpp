@@ -47,7 +47,8 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation (--junc-bed) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
-	if (opt.sdust_thres > 0) throw std::invalid_argument("[mm2amd] SDUST masking is not implemented");
+	if (opt.sdust_thres > 0 && !be.supports_sdust())
+		throw std::invalid_argument("[mm2amd] SDUST masking (-T) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
 	// hand that memory back to the kernel every time turns into page-fault and mmap-lock storms (the reference sidesteps the same
 	// problem with its own kalloc arenas).  Keep freed memory in the process instead.  MM2AMD_NO_MALLOPT=1 leaves malloc alone.
@@ -82,6 +83,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	// chaining parameters (map.c:262-274); single segment, not sr
 	SeedChainParams sp;
 	sp.k = fi_.k, sp.w = fi_.w, sp.is_hpc = fi_.flag & I_HPC;
+	sp.sdust_thres = opt_.sdust_thres;
 	sp.mid_occ = sp.q_mid_occ = opt_.mid_occ, sp.max_max_occ = opt_.max_max_occ, sp.occ_dist = opt_.occ_dist, sp.q_occ_frac = opt_.q_occ_frac;
 	sp.flag = opt_.flag;
 	sp.max_gap = opt_.max_gap, sp.max_gap_ref = opt_.max_gap_ref, sp.max_frag_len = opt_.max_frag_len, sp.is_sr = (opt_.flag & F_SR) ? 1 : 0; // per read: chain_gaps()

@@ -14,6 +14,7 @@
 #include "hip_util.hpp"
 #include "seed_chain_dev.hpp"
 #include "heap_order.hpp"
+#include "sdust_core.hpp"
 #include "sketch_dev.hpp"
 #include "kernel_prof.hpp"
 #include <hipcub/hipcub.hpp>
@@ -165,6 +166,43 @@ void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *st
 		if (P.w <= 32) hipLaunchKernelGGL((sketch_kernel<32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
 		else hipLaunchKernelGGL((sketch_kernel<256>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);
 	}
+	HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SDUST (-T): one thread per fragment masks each of its reads (sdust_core.hpp) and drops the minimizers that lie mostly inside masked
+// regions (mm_dust_minier, map.c:34-57).  The regions go to the seed arrays' slots of the read (unused until seed_collect); the
+// perfect-interval list of a thread lives in `scratch`.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DUST_THREADS = 8192;
+int dust_threads() { return DUST_THREADS; }
+size_t dust_scratch_bytes(int n_threads) { return (size_t)n_threads * SdustState::PCAP * sizeof(SdustState::Perf); }
+
+__global__ void __launch_bounds__(64) dust_filter_kernel(SeedChainBuffers B, int T, SdustState::Perf *scratch)
+{
+	const int tid = blockIdx.x * 64 + threadIdx.x;
+	SdustState S;
+	S.P = scratch + (size_t)tid * SdustState::PCAP;
+	for (int r = tid; r < B.n_reads; r += gridDim.x * 64) {
+		const int32_t u0 = B.unit_first ? B.unit_first[r] : 0, nu = B.unit_first ? B.unit_first[r + 1] - u0 : 1;
+		for (int32_t k = 0; k < nu; ++k) {
+			const uint64_t o = B.unit_first ? B.unit_off[u0 + k] : B.seq_off[r];
+			const int len = (int)((B.unit_first ? B.unit_off[u0 + k + 1] : B.seq_off[r + 1]) - o);
+			uint32_t *cnt = B.unit_first ? const_cast<uint32_t *>(B.unit_cnt) + (u0 + k) : B.mz_cnt + r;
+			uint32_t *rs = B.sd_off + o, *re = B.sd_aoff + o; // the masked regions of this read
+			int n_reg = 0;
+			sdust_scan(B.qpool + 2 * o, len, T, S, [&](int st, int en) { rs[n_reg] = (uint32_t)st, re[n_reg] = (uint32_t)en; ++n_reg; });
+			if (n_reg == 0) continue;
+			const int pos_off = B.unit_first ? (int)(o - B.unit_off[u0]) : 0;
+			*cnt = (uint32_t)dust_filter_minimizers((int)*cnt, B.mz_x + o, B.mz_y + o, n_reg,
+				[&](int u, int32_t *st, int32_t *en) { *st = (int32_t)rs[u], *en = (int32_t)re[u]; }, pos_off);
+		}
+	}
+}
+
+void launch_dust_filter(const SeedChainBuffers &B, const SeedChainParams &P, void *scratch, void *stream)
+{
+	hipLaunchKernelGGL(dust_filter_kernel, dim3(DUST_THREADS / 64), dim3(64), 0, (hipStream_t)stream, B, P.sdust_thres, (SdustState::Perf *)scratch);
 	HIP_CHECK(hipGetLastError());
 }
 

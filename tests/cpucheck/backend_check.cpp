@@ -10,6 +10,7 @@
 #include <stdexcept>
 #include "../../minimap2_amd/csrc/backend.hpp"
 #include "../../oracle/oracle.h"
+#include "../../minimap2_amd/csrc/sdust_core.hpp"
 
 extern "C" const uint8_t *ora_nt4_table(void);
 
@@ -34,6 +35,7 @@ public:
 		qpool_off.resize(reads.size());
 		size_t tot = 0;
 		for (size_t i = 0; i < reads.size(); ++i) qpool_off[i] = tot, tot += 2 * (size_t)reads[i].total();
+		qpool_off_ = qpool_off;
 		qpool_.assign(tot + 1, 0);
 		const uint8_t *nt4 = ora_nt4_table();
 		for (size_t i = 0; i < reads.size(); ++i) { // every read of a pair gets its own  forward | reverse-complement  block
@@ -61,6 +63,27 @@ public:
 				const int64_t n1 = ora_sketch(reads_[i].seq2, reads_[i].len2, p.w, p.k, 1, p.is_hpc, mv.data() + n_mv, (int64_t)mv.size() - n_mv);
 				for (int64_t j = n_mv; j < n_mv + n1; ++j) mv[j].y += (uint64_t)reads_[i].len << 1;
 				n_mv += n1;
+			}
+			if (p.sdust_thres > 0) { // mm_dust_minier per read, after the second read's positions have been shifted (map.c:64-69)
+				int64_t base = 0, kept = 0;
+				for (int sgm = 0; sgm < n_seg; ++sgm) {
+					const int slen = sgm ? reads_[i].len2 : reads_[i].len;
+					const uint8_t *codes = &qpool_[qpool_off_[i] + (sgm ? 2 * (size_t)reads_[i].len : 0)];
+					int64_t n_this = 0;
+					while (base + n_this < n_mv && (int)(mv[base + n_this].y >> 32) == sgm) ++n_this;
+					std::vector<int32_t> rs, re;
+					std::vector<SdustState::Perf> pbuf(SdustState::PCAP);
+					SdustState S;
+					S.P = pbuf.data();
+					sdust_scan(codes, slen, p.sdust_thres, S, [&](int st, int en) { rs.push_back(st), re.push_back(en); });
+					std::vector<uint64_t> x(n_this), y(n_this);
+					for (int64_t j = 0; j < n_this; ++j) x[j] = mv[base + j].x, y[j] = mv[base + j].y;
+					const int k = dust_filter_minimizers((int)n_this, x.data(), y.data(), (int)rs.size(),
+						[&](int u, int32_t *st, int32_t *en) { *st = rs[u], *en = re[u]; }, 0);
+					for (int j = 0; j < k; ++j) mv[kept + j].x = x[j], mv[kept + j].y = y[j];
+					kept += k, base += n_this;
+				}
+				n_mv = kept;
 			}
 			ora128_t *a = nullptr;
 			uint64_t *mp = nullptr;
@@ -151,6 +174,7 @@ private:
 	const FlatIndex &fi_;
 	std::vector<ReadView> reads_;
 	std::vector<uint8_t> qpool_;
+	std::vector<uint64_t> qpool_off_;
 	std::vector<uint32_t> cigar_store_;
 };
 

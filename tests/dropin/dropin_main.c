@@ -110,6 +110,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--sr") == 0) mopt.flag |= MM_F_SR;
 		else if (strcmp(argv[k], "--no-pairing") == 0) mopt.flag |= MM_F_INDEPEND_SEG; /* main.c:228 */
 		else if (strcmp(argv[k], "-F") == 0) mopt.max_frag_len = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-T") == 0) mopt.sdust_thres = atoi(argv[++k]); /* main.c:171 */
 		else if (strcmp(argv[k], "-D") == 0) mopt.flag |= MM_F_NO_DIAG; /* main.c:180 */
 		else if (strcmp(argv[k], "-X") == 0) mopt.flag |= MM_F_ALL_CHAINS | MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_NO_LJOIN; /* main.c:182 */
 		else if (strcmp(argv[k], "--dual=no") == 0) mopt.flag |= MM_F_NO_DUAL; /* main.c:300 */

@@ -35,3 +35,15 @@ def test_junction_annotation_larger_set(tmp_path):
     ref, rd, bed = synth.make_junctions(str(tmp_path), seed=37, n_reads=600, ref_mb=4.0)
     args = ["-x", "splice", "-a", "--junc-bed", bed]
     assert _run([REF_BIN, "-t", "8"] + args + [ref, rd]) == _run([DROPIN, "-t", "8"] + args + [ref, rd])
+
+
+@pytest.mark.parametrize("kind,args", [("weird", ["-x", "map-ont", "-a", "-T", "20"]), ("weird", ["-x", "map-ont", "-c", "-T", "5"]), ("weird", ["-x", "map-hifi", "-a", "-T", "30"]),
+                                       ("pairs2", ["-x", "sr", "-a", "-T", "15"]), ("pairs1", ["-x", "sr", "-a", "-T", "10"]), ("weird", ["-x", "splice", "-a", "-T", "20"])])
+def test_sdust_masking(kind, args, tmp_path):  # -T: dust_filter_kernel (sdust_core.hpp), one thread per read
+    if kind == "weird":
+        ref, rd = synth.make_weird(str(tmp_path))
+        files = [rd]
+    else:
+        ref, f1, f2, inter = synth.make_pairs(str(tmp_path))
+        files = [f1, f2] if kind == "pairs2" else [inter]
+    assert _run([REF_BIN, "-t", "8"] + args + [ref] + files) == _run([DROPIN, "-t", "8"] + args + [ref] + files)

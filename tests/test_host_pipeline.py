@@ -367,3 +367,33 @@ def test_multi_part_index(tmp_path):  # -I: mm_gpu_init / mm_gpu_map_batch / mm_
     for args in (["-x", "map-ont", "-a", "-I", "1200000"], ["-x", "map-ont", "-c", "-I", "1000000"]):
         out = _pair(args, ref, rd)
         assert out.count(b"\n") >= 40
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("kind,args", [("weird", ["-x", "map-ont", "-a", "-T", "20"]), ("weird", ["-x", "map-ont", "-c", "-T", "5"]), ("weird", ["-x", "map-hifi", "-a", "-T", "30"]),
+                                       ("pairs2", ["-x", "sr", "-a", "-T", "15"]), ("pairs1", ["-x", "sr", "-a", "-T", "10"]), ("weird", ["-x", "splice", "-a", "-T", "20"])])
+def test_sdust_masking(kind, args, tmp_path):
+    """-T: minimizers lying mostly in SDUST-masked regions are dropped before seeding (sdust.c, mm_dust_minier map.c:34-57) -- on reads
+    with (AC)n / poly-A / tandem islands, and on read pairs, where the reference filters the second read with shifted positions."""
+    import synth
+    if kind == "weird":
+        ref, rd = synth.make_weird(str(tmp_path))
+        files = [rd]
+    else:
+        ref, f1, f2, inter = synth.make_pairs(str(tmp_path))
+        files = [f1, f2] if kind == "pairs2" else [inter]
+    outs = []
+    for binary in (G.REF_BIN, CHECK):
+        p = subprocess.run([binary] + args + [ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        outs.append(G.strip_pg(p.stdout))
+    assert outs[0] == outs[1]
+
+
+def test_device_sdust_header_against_the_reference():
+    """minimap2_amd/csrc/sdust_core.hpp (what dust_filter_kernel runs per read) compiled for the host, vs the reference's sdust()."""
+    exe = os.path.join(HERE, "_build", "sdust_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/sdust_test not built (needs the compiled reference)")
+    out = subprocess.run([exe, "700"], stdout=subprocess.PIPE, check=True).stdout.split()
+    assert out[0] == b"OK" and int(out[2]) > 300
