@@ -326,13 +326,23 @@ def make_pairs(outdir, seed=95, n_pairs=300, genome=400000):
             a, b = b, a
         r1.append(a), r2.append(b)
     f1, f2, fi = (os.path.join(outdir, n) for n in ("r1.fa", "r2.fa", "inter.fa"))
-    names = ["pe%d" % k for k in range(n_pairs)]
-    write_fasta(f1, [n + "/1" for n in names], r1)
-    write_fasta(f2, [n + "/2" for n in names], r2)
+    r1 = [ACGT[a].tobytes() for a in r1]
+    r2 = [ACGT[b].tobytes() for b in r2]
+    # odd mates: a 5-base read, an all-N read, a homopolymer, an 18-base read, lower case, N-rich, a doubled read
+    k = min(40, n_pairs - 1)
+    odd = [(b"ACGTA", r2[k]), (r1[k + 1 - 1], b"N" * 120), (b"A" * 100, r2[k - 2]), (r1[k - 3], r2[k - 3][:18]), (r1[k - 4].lower(), r2[k - 4]),
+           (r1[k - 5], b"ACGTNNNNACGT" * 10), (r1[k - 6] + r1[k - 6], r2[k - 6])]
+    for a, b in odd:
+        r1.append(a), r2.append(b)
+    names = ["pe%d" % k for k in range(len(r1))]
+    for path, rr, suffix in ((f1, r1, b"/1"), (f2, r2, b"/2")):
+        with open(path, "wb") as f:
+            for n, s in zip(names, rr):
+                f.write(b">" + n.encode() + suffix + b"\n" + s + b"\n")
     with open(fi, "wb") as f:
         for n, a, b in zip(names, r1, r2):
-            f.write(b">" + n.encode() + b"/1\n" + ACGT[a].tobytes() + b"\n>" + n.encode() + b"/2\n" + ACGT[b].tobytes() + b"\n")
-        f.write(b">lonely\n" + ACGT[r1[0]].tobytes() + b"\n")   # a single read among the pairs
+            f.write(b">" + n.encode() + b"/1\n" + a + b"\n>" + n.encode() + b"/2\n" + b + b"\n")
+        f.write(b">lonely\n" + r1[0] + b"\n")   # a single read among the pairs
     return ref, f1, f2, fi
 
 
