@@ -47,6 +47,10 @@ struct Idx {                                           // mm_idx_t, minimap.h:88
 struct Intv1 { int32_t st, en, cnt; int32_t score : 30, strand : 2; };   // mm_idx_intv1_t, index.c:35-38
 struct IntvList { int32_t n, m; Intv1 *a; };                              // mm_idx_intv_t, index.c:40-43 (mm_idx_t::I: one per sequence)
 
+struct JJump1 { int32_t off, off2, cnt; int16_t strand; uint16_t flag; };  // mm_idx_jjump1_t, mmpriv.h:58-62
+struct JJumpList { int32_t n, m; JJump1 *a; };                            // mm_idx_jjump_t, index.c:45-48 (mm_idx_t::J: one per sequence)
+constexpr uint16_t JUNC_ANNO = 0x1;                                       // MM_JUNC_ANNO, mmpriv.h:27
+
 struct Extra {                                         // mm_extra_t, minimap.h:103-110
 	uint32_t capacity;
 	int32_t dp_score, dp_max, dp_max2;

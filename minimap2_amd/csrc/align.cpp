@@ -49,6 +49,173 @@ static void enlarge_cigar(Reg &r, uint32_t n_cigar) // align.c:305-318
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// mm_jump_split (jump.c): a clipped end of a spliced alignment is carried across an annotated junction when the clipped bases
+// match the other side of the junction exactly (at most one mismatch on the near side).  No DP: byte comparisons only.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMinExonLen = 20; // MM_MIN_EXON_LEN
+
+// mm_idx_jump_get (index.c:932-959): the jumps whose off lies in (st, en]
+const ref::JJump1 *jumps_between(const FlatIndex &fi, int32_t cid, int32_t st, int32_t en, int32_t *n)
+{
+	*n = 0;
+	if (cid < 0 || cid >= (int32_t)fi.n_seq || !fi.has_jump) return nullptr;
+	if (en < 0 || en > (int32_t)fi.seq_len[cid]) en = (int32_t)fi.seq_len[cid];
+	const std::vector<ref::JJump1> &a = fi.jump[cid];
+	if (a.empty()) return nullptr;
+	auto last_le = [&](int32_t x) -> int32_t { // index of the last element with off <= x, -1 if none
+		int32_t lo = 0, hi = (int32_t)a.size();
+		while (lo < hi) { const int32_t mid = lo + (hi - lo) / 2; if (a[mid].off <= x) lo = mid + 1; else hi = mid; }
+		return lo - 1;
+	};
+	const int32_t l = last_le(st), r = last_le(en);
+	*n = r - l;
+	return a.data() + (l + 1);
+}
+
+bool jump_applicable(const FlatIndex &fi, int32_t qlen, const Reg &r, int32_t ext, bool is_left) // mm_jump_check (jump.c:7-23)
+{
+	const int e = !r.rev ^ !is_left; // 0: the left end of the alignment is the read's start
+	if (!r.p || r.p->n_cigar <= 0) return false;
+	const int32_t clip = e == 0 ? r.qs : qlen - r.qe;
+	const uint32_t cigar = r.p->cigar[is_left ? 0 : r.p->n_cigar - 1];
+	const int32_t clen = (cigar & 0xf) == 0 ? (int32_t)(cigar >> 4) : 0;
+	if (clen <= ext) return false;
+	if (is_left) { if (clip >= r.rs) return false; }
+	else if (clip >= (int32_t)fi.seq_len[r.rid] - r.re) return false;
+	return true;
+}
+
+// the first (is_left) or last ql0 bases of the read in alignment orientation (mm_jump_get_qseq_seq, jump.c:25-51)
+void jump_query(int32_t qlen, const char *qseq0, const Reg &r, bool is_left, int32_t ql0, uint8_t *qseq)
+{
+	int32_t k = 0;
+	if (!r.rev) {
+		if (is_left) for (int32_t i = 0; i < ql0; ++i) qseq[k++] = kNt4Table[(uint8_t)qseq0[i]];
+		else for (int32_t i = qlen - ql0; i < qlen; ++i) qseq[k++] = kNt4Table[(uint8_t)qseq0[i]];
+	} else {
+		if (is_left) for (int32_t i = qlen - 1; i >= qlen - ql0; --i) { const uint8_t c = kNt4Table[(uint8_t)qseq0[i]]; qseq[k++] = c >= 4 ? c : 3 - c; }
+		else for (int32_t i = ql0 - 1; i >= 0; --i) { const uint8_t c = kNt4Table[(uint8_t)qseq0[i]]; qseq[k++] = c >= 4 ? c : 3 - c; }
+	}
+}
+
+void jump_left(const FlatIndex &fi, const MapOpt &opt, int32_t qlen, const char *qseq0, Reg &r, int32_t ts_strand) // mm_jump_split_left (jump.c:53-122)
+{
+	int32_t n, i0_anno = -1, n_anno = 0, mm0_anno = 0, i0_misc = -1, n_misc = 0, mm0_misc = 0, m, i0, mm0;
+	const int32_t ext = 1 + (opt.b + opt.a - 1) / opt.a + 1;
+	const int32_t clip = !r.rev ? r.qs : qlen - r.qe, extt = clip < ext ? clip : ext;
+	if (!jump_applicable(fi, qlen, r, ext + kMinExonLen, true)) return;
+	const ref::JJump1 *a = jumps_between(fi, r.rid, r.rs - extt, r.rs + ext, &n);
+	if (n == 0) return;
+	std::vector<uint8_t> buf;
+	uint8_t *tseq = nullptr, *qseq = nullptr;
+	for (int32_t i = 0; i < n; ++i) {
+		const ref::JJump1 &ai = a[i];
+		if (ts_strand * ai.strand < 0) continue; // wrong strand
+		if (ai.off2 >= ai.off) continue;         // wrong direction
+		if (ai.off - ai.off2 < 6) continue;      // intron too small
+		if (ai.off2 < clip + ext) continue;      // not long enough
+		if (!tseq) {
+			buf.assign((size_t)(clip + ext) * 2, 0);
+			tseq = buf.data(), qseq = tseq + clip + ext;
+			jump_query(qlen, qseq0, r, true, clip + ext, qseq);
+		}
+		const int32_t tl1 = clip + (ai.off - r.rs);
+		fi.getseq(r.rid, ai.off, r.rs + ext, &tseq[tl1]);
+		fi.getseq(r.rid, ai.off2 - tl1, ai.off2, tseq);
+		int32_t j, mm1 = 0, mm2 = 0;
+		for (j = 0; j < tl1; ++j) if (qseq[j] != tseq[j] || qseq[j] > 3 || tseq[j] > 3) ++mm1;
+		for (; j < clip + ext; ++j) if (qseq[j] != tseq[j] || qseq[j] > 3 || tseq[j] > 3) ++mm2;
+		if (mm1 == 0 && mm2 <= 1) {
+			if (ai.flag & ref::JUNC_ANNO) i0_anno = i, mm0_anno = mm1 + mm2, ++n_anno; // the rightmost one
+			else i0_misc = i, mm0_misc = mm1 + mm2, ++n_misc;
+		}
+	}
+	if (n_anno > 0) m = n_anno, i0 = i0_anno, mm0 = mm0_anno;
+	else m = n_misc, i0 = i0_misc, mm0 = mm0_misc;
+	const int32_t l = m > 0 ? a[i0].off - r.rs : 0; // may be negative
+	if (m == 1 && clip + l >= opt.jump_min_match) { // one more exon
+		enlarge_cigar(r, 2);
+		memmove(r.p->cigar + 2, r.p->cigar, (size_t)r.p->n_cigar * 4);
+		r.p->cigar[0] = (uint32_t)(clip + l) << 4 | 0u;
+		r.p->cigar[1] = (uint32_t)(a[i0].off - a[i0].off2) << 4 | 3u; // N
+		r.p->cigar[2] = ((r.p->cigar[2] >> 4) - (uint32_t)l) << 4 | 0u;
+		r.p->n_cigar += 2;
+		r.rs = a[i0].off2 - (clip + l);
+		if (!r.rev) r.qs = 0; else r.qe = qlen;
+		r.blen += clip, r.mlen += clip - mm0;
+		r.p->dp_max0 += (clip - mm0) * opt.a - mm0 * opt.b;
+		r.p->dp_max += (clip - mm0) * opt.a - mm0 * opt.b;
+		if (!r.is_spliced) r.is_spliced = 1, r.p->dp_max += (opt.a + opt.b) + ((opt.a + opt.b) >> 1);
+	} else if (m > 0 && a[i0].off > r.rs) { // trim by l (positive here)
+		r.p->cigar[0] -= (uint32_t)l << 4 | 0u;
+		r.rs += l;
+		if (!r.rev) r.qs += l; else r.qe -= l;
+	}
+}
+
+void jump_right(const FlatIndex &fi, const MapOpt &opt, int32_t qlen, const char *qseq0, Reg &r, int32_t ts_strand) // mm_jump_split_right (jump.c:124-193)
+{
+	int32_t n, i0_anno = -1, n_anno = 0, mm0_anno = 0, i0_misc = -1, n_misc = 0, mm0_misc = 0, m, i0, mm0;
+	const int32_t ext = 1 + (opt.b + opt.a - 1) / opt.a + 1;
+	const int32_t clip = !r.rev ? qlen - r.qe : r.qs, extt = clip < ext ? clip : ext;
+	if (!jump_applicable(fi, qlen, r, ext + kMinExonLen, false)) return;
+	const ref::JJump1 *a = jumps_between(fi, r.rid, r.re - ext, r.re + extt, &n);
+	if (n == 0) return;
+	std::vector<uint8_t> buf;
+	uint8_t *tseq = nullptr, *qseq = nullptr;
+	for (int32_t i = 0; i < n; ++i) {
+		const ref::JJump1 &ai = a[i];
+		if (ts_strand * ai.strand < 0) continue;
+		if (ai.off2 <= ai.off) continue;
+		if (ai.off2 - ai.off < 6) continue;
+		if (ai.off2 + clip + ext > (int32_t)fi.seq_len[r.rid]) continue;
+		if (!tseq) {
+			buf.assign((size_t)(clip + ext) * 2, 0);
+			tseq = buf.data(), qseq = tseq + clip + ext;
+			jump_query(qlen, qseq0, r, false, clip + ext, qseq);
+		}
+		const int32_t tl1 = clip + (r.re - ai.off);
+		fi.getseq(r.rid, r.re - ext, ai.off, tseq);
+		fi.getseq(r.rid, ai.off2, ai.off2 + tl1, &tseq[clip + ext - tl1]);
+		int32_t j, mm1 = 0, mm2 = 0;
+		for (j = 0; j < clip + ext - tl1; ++j) if (qseq[j] != tseq[j] || qseq[j] > 3 || tseq[j] > 3) ++mm2;
+		for (; j < clip + ext; ++j) if (qseq[j] != tseq[j] || qseq[j] > 3 || tseq[j] > 3) ++mm1;
+		if (mm1 == 0 && mm2 <= 1) {
+			if (ai.flag & ref::JUNC_ANNO) { if (i0_anno < 0) i0_anno = i, mm0_anno = mm1 + mm2; ++n_anno; } // the leftmost one
+			else { if (i0_misc < 0) i0_misc = i, mm0_misc = mm1 + mm2; ++n_misc; }
+		}
+	}
+	if (n_anno > 0) m = n_anno, i0 = i0_anno, mm0 = mm0_anno;
+	else m = n_misc, i0 = i0_misc, mm0 = mm0_misc;
+	const int32_t l = m > 0 ? r.re - a[i0].off : 0;
+	if (m == 1 && clip + l >= opt.jump_min_match) {
+		enlarge_cigar(r, 2);
+		r.p->cigar[r.p->n_cigar - 1] = ((r.p->cigar[r.p->n_cigar - 1] >> 4) - (uint32_t)l) << 4 | 0u;
+		r.p->cigar[r.p->n_cigar] = (uint32_t)(a[i0].off2 - a[i0].off) << 4 | 3u;
+		r.p->cigar[r.p->n_cigar + 1] = (uint32_t)(clip + l) << 4 | 0u;
+		r.p->n_cigar += 2;
+		r.re = a[i0].off2 + (clip + l);
+		if (!r.rev) r.qe = qlen; else r.qs = 0;
+		r.blen += clip, r.mlen += clip - mm0;
+		r.p->dp_max0 += (clip - mm0) * opt.a - mm0 * opt.b;
+		r.p->dp_max += (clip - mm0) * opt.a - mm0 * opt.b;
+		if (!r.is_spliced) r.is_spliced = 1, r.p->dp_max += (opt.a + opt.b) + ((opt.a + opt.b) >> 1);
+	} else if (m > 0 && r.re > a[i0].off) {
+		r.p->cigar[r.p->n_cigar - 1] -= (uint32_t)l << 4 | 0u;
+		r.re -= l;
+		if (!r.rev) r.qe -= l; else r.qs += l;
+	}
+}
+} // namespace
+
+void jump_split(const FlatIndex &fi, const MapOpt &opt, int32_t qlen, const char *qseq, Reg &r, int32_t ts_strand) // mm_jump_split (jump.c:195-200)
+{
+	jump_left(fi, opt, qlen, qseq, r, ts_strand);
+	jump_right(fi, opt, qlen, qseq, r, ts_strand);
+}
+
 void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar) // align.c:320-334
 {
 	if (n_cigar == 0) return;

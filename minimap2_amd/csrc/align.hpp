@@ -98,6 +98,8 @@ private:
 
 // mm_extra_t management (align.c:305-334)
 void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar);
+// mm_jump_split (jump.c): extend clipped alignment ends across annotated junctions (FlatIndex::jump); qseq is the read as mapped (ASCII)
+void jump_split(const FlatIndex &fi, const ref::MapOpt &opt, int32_t qlen, const char *qseq, Reg &r, int32_t ts_strand);
 // mm_update_extra (align.c:254-303) incl. mm_fix_cigar (:105-181)
 void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, bool is_eqx, bool log_gap);
 // mm_test_zdrop (align.c:61-103)

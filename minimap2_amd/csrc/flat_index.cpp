@@ -45,6 +45,13 @@ void FlatIndex::from_reference(const ref::Idx *mi)
 			for (int32_t j = 0; j < I[i].n; ++j) junc[i].push_back(Junc{I[i].a[j].st, I[i].a[j].en, I[i].a[j].strand});
 		has_junc = true;
 	}
+	jump.clear(), has_jump = false;
+	if (mi->J) { // jump annotation (-j / --pass1): used by the host's mm_jump_split step only
+		const ref::JJumpList *J = (const ref::JJumpList *)mi->J;
+		jump.resize(n_seq);
+		for (uint32_t i = 0; i < n_seq; ++i) jump[i].assign(J[i].a, J[i].a + J[i].n);
+		has_jump = true;
+	}
 	std::vector<std::pair<uint64_t, uint64_t>> pairs;
 	const uint32_t nb = 1u << mi->b;
 	for (uint32_t b = 0; b < nb; ++b) {

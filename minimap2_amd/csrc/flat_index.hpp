@@ -20,6 +20,9 @@ struct FlatIndex {
 	struct Junc { int32_t st, en, strand; };
 	std::vector<std::vector<Junc>> junc;
 	bool has_junc = false;
+	// junctions a clipped alignment end may jump across (mm_idx_t::J as mm_idx_jjump_read leaves it: ascending off), per sequence
+	std::vector<std::vector<ref::JJump1>> jump;
+	bool has_jump = false;
 	std::vector<std::string> names;
 	std::vector<uint64_t> seq_off;      // offset of each sequence in S (bases)
 	std::vector<uint32_t> seq_len;

@@ -43,6 +43,7 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	const int64_t unsupported = F_QSTRAND | F_SR_RNA; // MM_F_INDEPEND_SEG is resolved at the boundary (capi_map.cpp)
 	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr and --qstrand are not implemented");
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
+	if ((opt.flag & F_SPLICE) && fi.has_jump && (opt.flag & F_EQX)) throw std::invalid_argument("[mm2amd] jump annotation (-j) does not work with --eqx (jump.c:197)");
 	if ((opt.flag & F_SPLICE) && fi.has_junc && !be.supports_junctions())
 		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation (--junc-bed) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
@@ -370,6 +371,8 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				}
 				set_mapq(regs, opt_.min_chain_score, opt_.a, res.rep_len, is_sr, opt_.flag & F_SPLICE);
 			}
+			if (fi_.has_jump && n_segs == 1 && (opt_.flag & F_SPLICE)) // map.c:362-364: clipped ends hop over annotated junctions
+				for (Reg &r : res.regs) jump_split(fi_, opt_, rv.len, rv.seq, r, 0);
 			if (n_segs == 2 && opt_.pe_ori >= 0) {
 				const int qlens[2] = { rv.len, rv.len2 };
 				RegVec both[2];

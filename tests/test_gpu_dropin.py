@@ -150,3 +150,12 @@ def test_one_strand_only_identical(tmp_path):
     # --for-only / --rev-only: seed hits on the other strand are skipped before chaining (skip_seed, map.c:91-97)
     _compare(tmp_path, "ont", "map-ont", 3, 150, 28, ["-a", "--for-only"])
     _compare(tmp_path, "hifi", "map-hifi", 3, 60, 29, ["-c", "--rev-only"])
+
+
+def test_jump_annotation_identical(tmp_path):
+    # -j: clipped alignment ends hop over annotated junctions (mm_jump_split; host post-processing after the GPU stages)
+    ref, rd, bed = synth.make_junctions(str(tmp_path))
+    for extra in (["-a"], ["-c", "-u", "f"]):
+        want, _ = _run([REF_BIN, "-x", "splice", "-t", "8", "-j", bed] + extra + [ref, rd])
+        got, _ = _run([DROPIN, "-x", "splice", "-t", "8", "-j", bed] + extra + [ref, rd])
+        assert want == got

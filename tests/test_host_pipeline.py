@@ -353,11 +353,20 @@ def test_junction_annotation(args, tmp_path):
         assert sum(1 for a, b in zip(out.split(b"\n"), G.strip_pg(plain).split(b"\n")) if a != b) > 10
 
 
-def test_jump_annotation_is_refused_not_ignored(tmp_path):  # mi->J (-j / --pass1) changes spliced alignment (map.c:362-364): not implemented
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice", "-c"], ["-x", "splice:hq", "-a", "--format-lib"], ["-x", "splice", "-a", "-u", "f"],
+                                  ["-x", "splice", "-a", "--junc-bed", "BED"]])
+def test_jump_annotation(args, tmp_path):
+    """-j: alignment ends clipped next to an annotated junction hop over it when the clipped bases match the other side
+    (mm_jump_split, jump.c; host-only post-processing, map.c:362-364).  The fixture has 80 reads with 3-15 bases beyond an intron."""
     import synth
-    ref, rd, bed = synth.make_junctions(str(tmp_path), n_reads=5)
-    p = subprocess.run([CHECK, "-x", "splice", "-a", "-j", bed, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert p.returncode == 2 and b"jump annotation" in p.stderr
+    ref, rd, bed = synth.make_junctions(str(tmp_path))
+    args = [bed if a == "BED" else a for a in args] + ["-j", bed]
+    want = subprocess.run([G.REF_BIN] + [a for a in args if a != "--format-lib"] + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    got = subprocess.run([CHECK] + args + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(want) == G.strip_pg(got)
+    plain = subprocess.run([G.REF_BIN] + [a for a in args[:-2] if a != "--format-lib"] + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert sum(1 for a, b in zip(G.strip_pg(want).split(b"\n"), G.strip_pg(plain).split(b"\n")) if a != b) > 20
 
 
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
