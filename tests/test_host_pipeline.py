@@ -406,3 +406,15 @@ def test_device_sdust_header_against_the_reference():
         pytest.skip("tests/_build/sdust_test not built (needs the compiled reference)")
     out = subprocess.run([exe, "700"], stdout=subprocess.PIPE, check=True).stdout.split()
     assert out[0] == b"OK" and int(out[2]) > 300
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+def test_pass1_junctions_mix_with_annotation(tmp_path):  # --pass1: MM_JUNC_MISC jumps with a score filter (main.c:478), annotated ones win (jump.c:90-95)
+    import synth
+    ref, rd, bed = synth.make_junctions(str(tmp_path))
+    lines = [l for l in open(bed).read().split("\n") if l]
+    p1, anno = str(tmp_path / "pass1.bed"), str(tmp_path / "anno.bed")
+    open(p1, "w").write("\n".join("\t".join(l.split("\t")[:4] + ["9" if i % 3 else "3"] + l.split("\t")[5:]) for i, l in enumerate(lines) if i % 2 == 0) + "\n")
+    open(anno, "w").write("\n".join(l for i, l in enumerate(lines) if i % 2 == 1) + "\n")
+    _pair(["-x", "splice", "-a", "--pass1", p1], ref, rd)
+    _pair(["-x", "splice", "-a", "-j", anno, "--pass1", p1], ref, rd)
