@@ -595,6 +595,7 @@ void Aligner::add_region(ReadAlign &ra, const Reg &r, int order_pos)
 	const int ti = (int)ra.tasks.size();
 	RegionTask t;
 	t.r = r;
+	t.chain_ungapped = r.qe - r.qs == r.re - r.rs;
 	if (both) t.splice_flag = (int32_t)F_SPLICE_FOR, t.twin = ti + 1;
 	else if (splice) t.splice_flag = (int32_t)(opt_.flag & (F_SPLICE_FOR | F_SPLICE_REV));
 	ra.tasks.push_back(t);
@@ -610,6 +611,13 @@ void Aligner::add_region(ReadAlign &ra, const Reg &r, int order_pos)
 void Aligner::join_strands(ReadAlign &ra, int lead_ti)
 {
 	RegionTask &s0 = ra.tasks[lead_ti], &s1 = ra.tasks[s0.twin];
+	if ((opt_.flag & F_SR_RNA) && s0.r.p && s0.chain_ungapped && s0.r.qe - s0.r.qs == s0.r.re - s0.r.rs && s0.r.qs == 0 && s0.r.qe == ra.qlen) {
+		// splice:sr (align.c:1072-1074): an end-to-end ungapped alignment says nothing about the transcript strand; the reference does
+		// not even try the other one
+		free(s1.r.p), s1.r.p = nullptr;
+		s0.r.p->trans_strand = 0;
+		return;
+	}
 	if (!s0.r.p || !s1.r.p) throw std::runtime_error("[mm2amd] spliced alignment produced no CIGAR for a region (the reference dereferences a null pointer here)");
 	int which, trans_strand;
 	if (s0.r.p->dp_score > s1.r.p->dp_score) which = 0, trans_strand = 1;
@@ -688,7 +696,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	t.planned = true;
 	t.r2.cnt = 0;
 	if (r.cnt == 0) { t.done = true; return; }
-	if (opt_.flag & (F_SR_RNA | F_QSTRAND)) throw std::runtime_error("[mm2amd] splice:sr/qstrand alignment is not supported by this build");
+	if (opt_.flag & F_QSTRAND) throw std::runtime_error("[mm2amd] qstrand alignment is not supported by this build");
 	const bool is_splice = opt_.flag & F_SPLICE, is_sr = opt_.flag & F_SR;
 	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 	const int32_t ref_len = (int32_t)fi_.seq_len[rid];
@@ -811,7 +819,20 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 			w.bw = bw_long_;
 			if (a[as1 + i].y & SEED_LONG_JOIN) w.bw = qe - qs > re - rs ? qe - qs : re - rs;
 			w.job = w.saved = -1;
-			if (is_sr) { // align.c:823-833: the seeds lie on one diagonal; if the ungapped alignment beats any gapped one, it is the result
+			const bool is_sr_rna = (opt_.flag & F_SR_RNA) && is_splice;
+			if (is_sr_rna && qe - qs != re - rs) { // mm_align_sr_rna's own preconditions (align.c:376-384): a short query whose two ends match the window's ends
+				const int32_t ql = qe - qs, tl = re - rs, ilen = opt_.q2 * 2;
+				if (ql <= 100 && ql * 2 + ilen <= tl) {
+					const uint8_t *qseq = ra.q4 + (size_t)rev * qlen + qs;
+					tbuf_.resize(tl);
+					fi_.getseq(rid, rs, re, tbuf_.data());
+					int32_t ll = 0, lr = 0;
+					for (int32_t j = 0; j < ql; ++j) if (qseq[j] == tbuf_[j] && qseq[j] < 4) ++ll;
+					for (int32_t j = 0; j < ql; ++j) if (qseq[ql - 1 - j] == tbuf_[tl - 1 - j] && qseq[ql - 1 - j] < 4) ++lr;
+					if (ql - (ll + lr) <= 9) w.pre = 1;
+				}
+			}
+			if (is_sr || (is_sr_rna && qe - qs == re - rs)) { // align.c:823-833: the seeds lie on one diagonal; if the ungapped alignment beats any gapped one, it is the result
 				assert(qe - qs == re - rs);
 				const int32_t len = qe - qs, max_gapped_score = (len - 2) * opt_.a - 2 * (opt_.q + opt_.e);
 				const uint8_t *qseq = ra.q4 + (size_t)rev * qlen + qs;
@@ -886,9 +907,34 @@ void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdr
 	jobs.push_back(j);
 }
 
+// mm_align_sr_rna (align.c:370-400): a short query across a long window is first aligned to the window's two ends only -- qlen bases
+// from each, 2*q2 Ns in between -- which answers "one clean intron?" with a tiny DP instead of a window-sized one.
+void Aligner::add_flank_job(ReadAlign &ra, RegionTask &t, Window &w, std::vector<KswJob> &jobs)
+{
+	const int32_t ql = w.qe - w.qs, tl = w.re - w.rs, ilen = opt_.q2 * 2, tl2 = ql * 2 + ilen;
+	KswJob j;
+	j.qlen = ql, j.tlen = tl2;
+	j.w = w.bw, j.zdrop = opt_.zdrop, j.end_bonus = -1;
+	int flag = KSW_APPROX_MAX;
+	if (opt_.transition != 0 && opt_.b != opt_.transition) flag |= KSW_GENERIC_SC;
+	j.q_off = (t.rev ? ra.qpool_rev : ra.qpool_off) + w.qs;
+	j.t_off = ra.tbytes.size();
+	ra.tbytes.resize(ra.tbytes.size() + tl2);
+	uint8_t *dst = &ra.tbytes[j.t_off];
+	tbuf_.resize(tl);
+	fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+	memcpy(dst, tbuf_.data(), ql);
+	memset(dst + ql, 4, ilen);
+	memcpy(dst + ql + ilen, tbuf_.data() + tl - ql, ql);
+	j.flag = flag | t.ksw_flag; // a byte target: no KSWJ_T_PACKED
+	j.tag = 0, j.reserved = 0;
+	w.job = (int32_t)jobs.size(), w.saved = -1;
+	jobs.push_back(j);
+}
+
 void Aligner::schedule(ReadAlign &ra, std::vector<KswJob> &jobs)
 {
-	ra.juncs.clear();
+	ra.juncs.clear(), ra.tbytes.clear();
 	for (size_t ti = 0; ti < ra.tasks.size(); ++ti) {
 		RegionTask &t = ra.tasks[ti];
 		if (t.done) continue;
@@ -903,12 +949,14 @@ void Aligner::schedule(ReadAlign &ra, std::vector<KswJob> &jobs)
 			for (Window &w : t.win) {
 				if (w.saved >= 0) continue; // resolved while planning (the ungapped short-read case)
 				if (w.kind == W_LEFT) add_job(ra, t, w, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, t.r.split_inv ? opt_.zdrop_inv : opt_.zdrop, opt_.end_bonus, jobs);
+				else if (w.kind == W_GAP && w.pre == 1) add_flank_job(ra, t, w, jobs);
 				else if (w.kind == W_GAP) add_job(ra, t, w, KSW_APPROX_MAX, opt_.zdrop, -1, jobs);
 				else add_job(ra, t, w, KSW_EXTZ_ONLY, opt_.zdrop, opt_.end_bonus, jobs);
 			}
 		} else if (t.next_win < t.win.size()) { // stalled on a second pass (align.c:843-844)
 			Window &w = t.win[t.next_win];
 			if (w.pass2 && w.job < 0 && w.saved < 0) add_job(ra, t, w, 0, w.zdrop_code == 2 ? opt_.zdrop_inv : opt_.zdrop, -1, jobs);
+			else if (!w.pass2 && w.pre == 2 && w.job < 0 && w.saved < 0) add_job(ra, t, w, KSW_APPROX_MAX, opt_.zdrop, -1, jobs); // the flank-only attempt failed (align.c:839-840)
 		}
 	}
 }
@@ -944,6 +992,36 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 				t.qs1 = w.qe - (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
 				++t.next_win;
 			} else if (w.kind == W_GAP) {
+				if (w.pre == 1) { // the flank-only attempt came back (align.c:394-399): it counts only as one clean intron between two matches
+					bool ok = !ez.zdropped && ez.n_cigar > 0 && (cg[0] & 0xf) == 0 && (cg[ez.n_cigar - 1] & 0xf) == 0;
+					int nn = 0, n_ins = 0;
+					for (int32_t k = 0; ok && k < ez.n_cigar; ++k) nn += (cg[k] & 0xf) == 3, n_ins += (cg[k] & 0xf) == 1;
+					ok = ok && nn == 1 && n_ins == 0;
+					w.pre = 2;
+					if (ok) { // becomes the window's first-pass result, the intron stretched back to the window's length
+						SavedResult sr;
+						sr.res = ez;
+						sr.res.zd_max = KSW_ZD_NONE; // the kernel scanned the composed target; the host rescans the real window
+						sr.cigar.assign(cg, cg + ez.n_cigar);
+						const int32_t tl = w.re - w.rs, tl2 = (w.qe - w.qs) * 2 + opt_.q2 * 2;
+						for (uint32_t &c : sr.cigar) if ((c & 0xf) == 3) c += (uint32_t)(tl - tl2) << 4;
+						t.saved.push_back(std::move(sr));
+						w.saved = (int32_t)t.saved.size() - 1, w.job = -1;
+						continue; // re-enter with the saved result
+					}
+					for (size_t k = t.next_win + 1; k < t.win.size(); ++k) { // keep the later windows' results of this round
+						Window &wk = t.win[k];
+						if (wk.job >= 0 && wk.saved < 0) {
+							SavedResult sr;
+							sr.res = res[wk.job];
+							sr.cigar.assign(cigar_pool + sr.res.cigar_off, cigar_pool + sr.res.cigar_off + sr.res.n_cigar);
+							t.saved.push_back(std::move(sr));
+							wk.saved = (int32_t)t.saved.size() - 1, wk.job = -1;
+						}
+					}
+					w.job = -1, w.saved = -1;
+					return true;
+				}
 				if (!w.pass2) { // the approximate pass: test it (align.c:843)
 					const uint8_t *qseq = ra.q4 + (size_t)t.rev * qlen + w.qs;
 					int code;

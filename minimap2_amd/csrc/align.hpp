@@ -29,6 +29,7 @@ struct Window {            // one planned DP problem of a region
 	WindowKind kind;
 	bool pass2 = false;     // (to be) re-aligned exactly after the approximate pass tripped the Z-drop test
 	int32_t zdrop_code = 0;
+	int8_t pre = 0;         // splice:sr (mm_align_sr_rna, align.c:370-400): 1 = the flank-only alignment is tried first, 2 = it has been tried
 };
 
 struct SavedResult { KswRes res; std::vector<uint32_t> cigar; };
@@ -49,6 +50,7 @@ struct RegionTask {
 	int32_t ksw_flag = 0;                        // KSW_SPLICE_* bits every DP job of this task carries (align.c:684-689, :354)
 	int32_t twin = -1;
 	bool lead = true;
+	bool chain_ungapped = false;                 // the chain spans equally many query and reference bases (splice:sr rule, align.c:1072)
 	std::vector<SavedResult> saved;              // results carried over a round boundary (only when a region stalls)
 	// inversion-rescue tasks only (mm_align1_inv): where the extension starts and what it is anchored to
 	int32_t inv_q0 = 0, inv_t0 = 0, inv_r2_qs = 0, inv_r2_qe = 0, inv_r1_re = 0, inv_qoff = 0, inv_toff = 0;
@@ -62,6 +64,7 @@ struct ReadAlign {        // per-read alignment state
 	int n_a = 0;
 	std::vector<RegionTask> tasks;               // in creation order
 	std::vector<int> order;                      // output order: indices into tasks (inversions included)
+	std::vector<uint8_t> tbytes;                 // composed targets of this round's jobs without KSWJ_T_PACKED (KswScoring::tbytes; a job's t_off indexes it)
 	std::vector<uint32_t> juncs;                 // annotated splice sites inside this round's DP windows (KswScoring::juncs entries; a job's tag indexes it)
 };
 
@@ -84,6 +87,7 @@ private:
 	void join_strands(ReadAlign &ra, int lead_ti);
 	void plan_region(ReadAlign &ra, RegionTask &t);
 	void add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdrop, int end_bonus, std::vector<KswJob> &jobs);
+	void add_flank_job(ReadAlign &ra, RegionTask &t, Window &w, std::vector<KswJob> &jobs);
 	bool consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
 	void consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
 	void finalize_region(ReadAlign &ra, RegionTask &t);

@@ -51,7 +51,8 @@ public:
 	// need the reads' names in begin_batch().  Call once, before the first batch.
 	virtual void enable_name_rules() {}
 	virtual bool supports_junctions() const { return true; } // KswScoring::juncs honoured by ksw()
-	virtual bool supports_sdust() const { return true; }     // SeedChainParams::sdust_thres honoured by seed_chain()
+	virtual bool supports_sdust() const { return true; }
+	virtual bool supports_byte_targets() const { return true; } // KswScoring::tbytes honoured by ksw() (splice:sr)     // SeedChainParams::sdust_thres honoured by seed_chain()
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off

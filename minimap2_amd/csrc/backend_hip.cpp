@@ -36,7 +36,7 @@ struct Lane {
 	DevBuf<uint32_t> d_mz_cnt, d_sd_n, d_sd_off, d_sd_aoff, d_sd_qpos, d_sd_info, d_n_anchor, d_n_minipos, d_n_seedhit, d_tie;
 	DevBuf<int32_t> d_rep_len, d_f, d_p, d_t;
 	DevBuf<Anchor> d_anchors;
-	DevBuf<uint8_t> d_sort_tmp, d_dust;
+	DevBuf<uint8_t> d_sort_tmp, d_dust, d_tbytes;
 	PinBuf<Anchor> h_anchors;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
@@ -83,6 +83,7 @@ public:
 	// so it stays opt-in until tests/test_gpu_pending.py has passed on an MI355X.
 	bool supports_junctions() const override { return getenv("MM2AMD_PENDING") != nullptr; }
 	bool supports_sdust() const override { return getenv("MM2AMD_PENDING") != nullptr; } // dust_filter_kernel: same status
+	bool supports_byte_targets() const override { return getenv("MM2AMD_PENDING") != nullptr; } // splice:sr through the mapper: same status
 	void enable_name_rules() override
 	{
 		if (name_rules_ || fi_names_->empty()) return;
@@ -320,7 +321,13 @@ public:
 		if (const char *e = getenv("MM2AMD_DIR_BUDGET_GB")) dir_gb = atol(e) > 0 ? (size_t)atol(e) : dir_gb;
 		ln.ksw.dir_budget = std::min<size_t>((dir_gb << 30) / (size_t)active_lanes_, (size_t)96 << 30); // scratch only grows: keep one lane's share bounded
 		ln.ksw.lane = lane_id;
-		ln.ksw.run(jobs, d_qpool_.p, nullptr, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
+		const uint8_t *d_tbytes = nullptr;
+		if (sc.n_tbytes) { // composed targets (mm_align_sr_rna): a small byte pool per call
+			ln.d_tbytes.ensure(sc.n_tbytes + 1);
+			HIP_CHECK(hipMemcpyAsync(ln.d_tbytes.p, sc.tbytes, sc.n_tbytes, hipMemcpyHostToDevice, ln.stream));
+			d_tbytes = ln.d_tbytes.p;
+		}
+		ln.ksw.run(jobs, d_qpool_.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id).collect();
 	}
 

@@ -27,7 +27,7 @@ extern "C" long long mm2amd_alloc_counter(int which); // device allocations, pin
 namespace {
 // Where the results of one mapper fragment go: reads o .. o+n_out-1 of the caller's arrays; flip_len[j] >= 0 when read o+j was
 // mapped reverse-complemented and its hits have to be turned back (length of that read), see hand_over().
-struct OutSlot { int o, n_out, flip_len[2]; };
+struct OutSlot { int o, n_out, flip_len[2]; int weak = 0, len0 = 0; }; // weak: 1 / 2 = first / second mate of a pair mapped separately and paired afterwards (MM_F_WEAK_PAIRING)
 
 struct MapContext {
 	FlatIndex fi_own;                 // index flattened from a reference mm_idx_t (mm_gpu_init)
@@ -143,11 +143,14 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 			const char *q2 = s2.seq;
 			if (pe_ori >> 1 & 1) { revcomp_into(s.seq, s.l_seq, flipped[n_flip]); v.seq = flipped[n_flip++].data(); sl.flip_len[0] = s.l_seq; }
 			if (pe_ori & 1) { revcomp_into(s2.seq, s2.l_seq, flipped[n_flip]); q2 = flipped[n_flip++].data(); sl.flip_len[1] = s2.l_seq; }
-			if (independent) {
+			const bool weak = !independent && (opt.flag & ref::F_WEAK_PAIRING) && pe_ori >= 0 && (opt.flag & ref::F_CIGAR); // mm_map_frag, map.c:382-387
+			if (independent || weak) {
 				ReadView v2;
 				OutSlot sl2 = { o + 1, 1, { sl.flip_len[1], -1 } };
-				v2.seq = q2, v2.len = s2.l_seq, v2.name = s2.name;
+				v2.seq = q2, v2.len = s2.l_seq, v2.name = weak ? s.name : s2.name; // mm_map_frag hands the fragment's (first) name to both calls
 				sl.flip_len[1] = -1;
+				if (weak) sl.weak = 1, sl2.weak = 2;
+				sl.len0 = s.l_seq, sl2.len0 = s2.l_seq;
 				reads.push_back(v), slots.push_back(sl);
 				reads.push_back(v2), slots.push_back(sl2);
 				continue;
@@ -169,6 +172,18 @@ static void *regs_block(const RegVec &v)
 
 static void hand_over(const std::vector<OutSlot> &slots, std::vector<ReadResult> &out, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
+	const ref::MapOpt &opt = g_ctx->opt;
+	parallel_for(g_ctx ? g_ctx->n_threads : 1, (long)slots.size(), [&](long i, int) {
+		const OutSlot &sl = slots[i];
+		if (sl.weak == 1) { // the two mates were mapped on their own: pair them now (map.c:386), in mapping orientation
+			const int qlens[2] = { slots[i].len0, slots[i + 1].len0 };
+			RegVec both[2];
+			both[0].swap(out[i].regs), both[1].swap(out[i + 1].regs);
+			pair_hits(opt.max_gap_ref, opt.pe_bonus, opt.a * 2 + opt.b, opt.a, qlens, both);
+			both[0].swap(out[i].regs), both[1].swap(out[i + 1].regs);
+			out[i].rep_len = out[i + 1].rep_len, out[i].frag_gap = out[i + 1].frag_gap; // mm_tbuf_t keeps the last call's values (map.c:450-453)
+		}
+	}, 256);
 	parallel_for(g_ctx ? g_ctx->n_threads : 1, (long)slots.size(), [&](long i, int) {
 		const OutSlot &sl = slots[i];
 		for (int j = 0; j < sl.n_out; ++j) {

@@ -58,6 +58,9 @@ struct KswScoring {         // uniform over a launch
 	int8_t junc_bonus = 0;
 	const uint32_t *juncs = nullptr;
 	size_t n_juncs = 0;
+	// targets that are not windows of the reference (jobs without KSWJ_T_PACKED): t_off indexes this pool of nt4 bytes
+	const uint8_t *tbytes = nullptr;
+	size_t n_tbytes = 0;
 };
 
 struct KswLaunch {

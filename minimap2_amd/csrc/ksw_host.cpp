@@ -172,7 +172,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	d_cursor.ensure(2);
 	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
 	KswScoring sc_dev = sc; // the junction entries travel with the jobs
-	sc_dev.juncs = nullptr;
+	sc_dev.juncs = nullptr, sc_dev.tbytes = nullptr;
 	if (sc.n_juncs) {
 		d_juncs.ensure(sc.n_juncs);
 		HIP_CHECK(hipMemcpyAsync(d_juncs.p, sc.juncs, sc.n_juncs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));

@@ -40,8 +40,11 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	const int64_t unsupported = F_QSTRAND | F_SR_RNA; // MM_F_INDEPEND_SEG is resolved at the boundary (capi_map.cpp)
-	if (opt.flag & unsupported) throw std::invalid_argument("[mm2amd] this build maps single-segment reads (map-ont / map-hifi / splice / asm / ava class presets, single-end sr); splice:sr and --qstrand are not implemented");
+	if (opt.flag & F_QSTRAND) throw std::invalid_argument("[mm2amd] --qstrand is not implemented"); // MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
+	if ((opt.flag & F_SR_RNA) && (opt.flag & F_SPLICE)) {
+		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] splice:sr on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+		if (fi.has_junc) throw std::invalid_argument("[mm2amd] splice:sr with --junc-bed is not implemented (use -j)");
+	}
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
 	if ((opt.flag & F_SPLICE) && fi.has_jump && (opt.flag & F_EQX)) throw std::invalid_argument("[mm2amd] jump annotation (-j) does not work with --eqx (jump.c:197)");
 	if ((opt.flag & F_SPLICE) && fi.has_junc && !be.supports_junctions())
@@ -336,6 +339,19 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 					for (size_t k = job_base[i]; k < job_base[i + 1]; ++k) if (jobs[k].reserved) jobs[k].tag += (uint32_t)jb[i];
 				}, 256);
 				sc.juncs = ds.juncs.data(), sc.n_juncs = jb[mu], sc.junc_bonus = (int8_t)opt_.junc_bonus;
+			}
+			if (opt_.flag & F_SR_RNA) { // composed targets (Aligner::add_flank_job) as one byte pool; the jobs' offsets become pool-wide
+				std::vector<size_t> &tb = ds.tbyte_base;
+				tb.resize(mu + 1);
+				tb[0] = 0;
+				for (long i = 0; i < mu; ++i) tb[i + 1] = tb[i] + (per_read_jobs[i].empty() ? 0 : ra[i].tbytes.size());
+				ds.tbytes.resize(tb[mu] + 1);
+				parallel_for(n_threads_, mu, [&](long i, int) {
+					if (per_read_jobs[i].empty() || ra[i].tbytes.empty()) return;
+					memcpy(&ds.tbytes[tb[i]], ra[i].tbytes.data(), ra[i].tbytes.size());
+					for (size_t k = job_base[i]; k < job_base[i + 1]; ++k) if (!(jobs[k].flag & KSWJ_T_PACKED)) jobs[k].t_off += tb[i];
+				}, 256);
+				sc.tbytes = ds.tbytes.data(), sc.n_tbytes = tb[mu];
 			}
 			for (const KswJob &j : jobs) stats.dp_cells += (double)j.qlen * j.tlen;
 			if (const char *dump = getenv("MM2AMD_DUMP_JOBS")) { // debugging aid: the shapes of the DP jobs of every round

@@ -45,6 +45,8 @@ private:
 		std::vector<KswJob> jobs;
 		std::vector<uint32_t> juncs;             // junction annotation entries of the round's jobs (KswScoring::juncs)
 		std::vector<size_t> junc_base;
+		std::vector<uint8_t> tbytes;             // composed DP targets of the round's jobs (KswScoring::tbytes)
+		std::vector<size_t> tbyte_base;
 		std::vector<KswRes> kres;
 		std::vector<uint8_t> q4;
 		std::vector<uint64_t> q4_off;

@@ -136,8 +136,7 @@ public:
 			for (int i = 0; i < j.qlen; ++i) q[i] = qpool_[(j.flag & KSWJ_Q_REVERSED) ? j.q_off - i : j.q_off + i];
 			for (int i = 0; i < j.tlen; ++i) {
 				const uint64_t pos = (j.flag & KSWJ_T_REVERSED) ? j.t_off - i : j.t_off + i;
-				if (!(j.flag & KSWJ_T_PACKED)) throw std::runtime_error("check backend: byte targets are not used by the mapper");
-				t[i] = (uint8_t)(fi_.S[pos >> 3] >> ((pos & 7) << 2) & 0xf);
+				t[i] = (j.flag & KSWJ_T_PACKED) ? (uint8_t)(fi_.S[pos >> 3] >> ((pos & 7) << 2) & 0xf) : sc.tbytes[pos];
 			}
 			ora_ez_t ez;
 			if (j.flag & KSWJ_SKIP) {

@@ -134,6 +134,42 @@ def make_junctions(outdir, seed=31, n_reads=60, ref_mb=1.0):
     return ref, rd, bed
 
 
+def make_rna_pairs(outdir, seed=41, n_tx=50, pairs_per_tx=4, ref_mb=1.0):
+    """Short RNA-seq read pairs (2 x 60-100 bases, FR, 0.5 % substitutions) sampled from spliced transcripts: most reads cross
+    exon junctions, some by a few bases only.  Returns (ref.fa, r1.fa, r2.fa, introns.bed)."""
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    contigs = gen_reference(rng, int(ref_mb * 1e6), 2)
+    introns = []
+    txs = gen_transcripts(rng, contigs, n_tx, 0.0, max_intron=3000, introns=introns)
+    r1, r2 = [], []
+    for tx in txs:
+        if len(tx) < 260:
+            continue
+        for _ in range(pairs_per_tx):
+            L = int(rng.integers(60, 101))
+            frag = int(rng.integers(2 * L - 30, min(len(tx), 400) + 1)) if min(len(tx), 400) >= 2 * L - 30 else len(tx)
+            frag = max(frag, L)
+            p = int(rng.integers(0, len(tx) - frag + 1))
+            a, b = tx[p:p + L].copy(), COMP[tx[p + frag - L:p + frag][::-1]].copy()
+            for r in (a, b):
+                sub = rng.random(len(r)) < 0.005
+                r[sub] = (r[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
+            if rng.random() < 0.5:
+                a, b = b, a
+            r1.append(a), r2.append(b)
+    ref, f1, f2, bed = (os.path.join(outdir, n) for n in ("ref.fa", "r1.fa", "r2.fa", "introns.bed"))
+    write_fasta(ref, ["chr1", "chr2"], contigs)
+    names = ["rp%d" % k for k in range(len(r1))]
+    write_fasta(f1, [n + "/1" for n in names], r1)
+    write_fasta(f2, [n + "/2" for n in names], r2)
+    with open(bed, "w") as f:
+        for k, (c, st, en, minus) in enumerate(introns):
+            if k % 7:
+                f.write("chr%d\t%d\t%d\tj%d\t0\t%s\n" % (c + 1, st, en, k, "-" if minus else "+"))
+    return ref, f1, f2, bed
+
+
 def make_alt(outdir, seed=51):
     """A primary assembly with two ALT contigs (diverged copies of primary regions, one with an insertion), reads from everywhere
     and from the duplicated regions in particular, and the ALT name list.  Returns (ref.fa, reads.fa, alt.txt)."""

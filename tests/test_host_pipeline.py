@@ -418,3 +418,22 @@ def test_pass1_junctions_mix_with_annotation(tmp_path):  # --pass1: MM_JUNC_MISC
     open(anno, "w").write("\n".join(l for i, l in enumerate(lines) if i % 2 == 1) + "\n")
     _pair(["-x", "splice", "-a", "--pass1", p1], ref, rd)
     _pair(["-x", "splice", "-a", "-j", anno, "--pass1", p1], ref, rd)
+
+
+RNA_CASES = [(["-x", "splice:sr", "-a"], 2, False), (["-x", "splice:sr", "-a"], 1, False), (["-x", "splice:sr", "-a"], 2, True), (["-x", "splice:sr", "-c"], 2, True),
+             (["-x", "splice:sr"], 2, False), (["-x", "splice:sr", "-a", "--format-lib"], 2, True), (["-x", "splice:sr", "-a", "-u", "f"], 2, False)]
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args,n_files,jump", RNA_CASES)
+def test_short_rna_seq_pairs(args, n_files, jump, tmp_path):
+    """-x splice:sr (MM_F_SR_RNA + MM_F_WEAK_PAIRING): mates mapped on their own and paired afterwards (map.c:382-387), the flank-only
+    first attempt of mm_align_sr_rna (align.c:370-400), the ungapped shortcut, the one-strand rule (align.c:1072), optionally -j."""
+    import synth
+    ref, f1, f2, bed = synth.make_rna_pairs(str(tmp_path))
+    args = args + (["-j", bed] if jump else [])
+    files = [f1, f2] if n_files == 2 else [f1]
+    want = subprocess.run([G.REF_BIN] + [a for a in args if a != "--format-lib"] + [ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    got = subprocess.run([CHECK] + args + [ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(want) == G.strip_pg(got)
+    assert want.count(b"\n") > 150
