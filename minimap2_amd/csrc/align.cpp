@@ -915,8 +915,7 @@ void Aligner::add_flank_job(ReadAlign &ra, RegionTask &t, Window &w, std::vector
 	KswJob j;
 	j.qlen = ql, j.tlen = tl2;
 	j.w = w.bw, j.zdrop = opt_.zdrop, j.end_bonus = -1;
-	int flag = KSW_APPROX_MAX;
-	if (opt_.transition != 0 && opt_.b != opt_.transition) flag |= KSW_GENERIC_SC;
+	const int flag = KSW_APPROX_MAX; // ksw_exts2_sse is called directly here (align.c:393): neither KSW_EZ_GENERIC_SC nor the max_sw_mat guard of mm_align_pair
 	j.q_off = (t.rev ? ra.qpool_rev : ra.qpool_off) + w.qs;
 	j.t_off = ra.tbytes.size();
 	ra.tbytes.resize(ra.tbytes.size() + tl2);

@@ -50,7 +50,7 @@ def test_sdust_masking(kind, args, tmp_path):  # -T: dust_filter_kernel (sdust_c
 
 
 @pytest.mark.parametrize("args,n_files,jump", [(["-x", "splice:sr", "-a"], 2, False), (["-x", "splice:sr", "-a"], 1, False), (["-x", "splice:sr", "-a"], 2, True),
-                                               (["-x", "splice:sr", "-c"], 2, True), (["-x", "splice:sr"], 2, False)])
+                                               (["-x", "splice:sr", "-c"], 2, True), (["-x", "splice:sr"], 2, False), (["-x", "splice:sr", "-a", "-b", "3"], 2, False)])
 def test_short_rna_seq_pairs(args, n_files, jump, tmp_path):  # splice:sr: flank-only DP jobs with composed byte targets (KswScoring::tbytes), weak pairing
     ref, f1, f2, bed = synth.make_rna_pairs(str(tmp_path))
     args = args + (["-j", bed] if jump else [])

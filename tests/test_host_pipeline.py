@@ -421,7 +421,8 @@ def test_pass1_junctions_mix_with_annotation(tmp_path):  # --pass1: MM_JUNC_MISC
 
 
 RNA_CASES = [(["-x", "splice:sr", "-a"], 2, False), (["-x", "splice:sr", "-a"], 1, False), (["-x", "splice:sr", "-a"], 2, True), (["-x", "splice:sr", "-c"], 2, True),
-             (["-x", "splice:sr"], 2, False), (["-x", "splice:sr", "-a", "--format-lib"], 2, True), (["-x", "splice:sr", "-a", "-u", "f"], 2, False)]
+             (["-x", "splice:sr"], 2, False), (["-x", "splice:sr", "-a", "--format-lib"], 2, True), (["-x", "splice:sr", "-a", "-u", "f"], 2, False),
+             (["-x", "splice:sr", "-a", "-b", "3"], 2, False)]  # -b: the flank-only job goes to ksw_exts2 without KSW_EZ_GENERIC_SC (align.c:393), the full window with it
 
 
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
