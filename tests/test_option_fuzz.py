@@ -123,3 +123,48 @@ def test_short_read_pair_and_overlap_options(short_inputs, seed):
         assert outs[1][0] != 0, args
     else:
         assert outs[1][0] == 0 and outs[0][1] == outs[1][1], args
+
+
+@pytest.fixture(scope="module")
+def annotated_inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fuzz_anno")
+    return {"rna": synth.make_rna_pairs(str(d / "rna"), n_tx=30), "junc": synth.make_junctions(str(d / "junc"), n_reads=30), "weird": synth.make_weird(str(d / "weird"))}
+
+
+@needs_dev
+@pytest.mark.parametrize("seed", range(4000, 4012))
+def test_rna_seq_annotation_and_masking_options(annotated_inputs, seed):
+    """splice:sr pairs (with / without -j), long cDNA reads with --junc-bed / -j / --junc-bonus, and SDUST masking (-T), each with
+    random further options."""
+    r = random.Random(seed)
+    kind = seed % 3
+    if kind == 0:
+        ref, f1, f2, bed = annotated_inputs["rna"]
+        files = r.choice([[f1, f2], [f1]])
+        args = ["-x", "splice:sr"] + (["-j", bed] if r.random() < 0.5 else [])
+        skip = ("--max-qlen", "-P", "-g", "-r", "-k", "-w", "--eqx")
+    elif kind == 1:
+        ref, rd, bed = annotated_inputs["junc"]
+        files = [rd]
+        args = ["-x", r.choice(["splice", "splice:hq"])] + r.choice([["--junc-bed", bed], ["-j", bed], ["--junc-bed", bed, "-j", bed, "--junc-bonus", "15"]])
+        skip = ("--max-qlen", "-P", "--eqx")
+    else:
+        ref, rd = annotated_inputs["weird"]
+        files = [rd]
+        args = ["-x", r.choice(["map-ont", "map-hifi", "asm20"]), "-T", r.choice(["5", "10", "20", "40"])]
+        skip = ("--max-qlen", "-P")
+    mode = r.choice(["-a", "-c", "-a", ""])
+    if mode:
+        args.append(mode)
+    for name, gen in r.sample([o for o in OPTS if o[0] not in skip], r.randint(0, 4)):
+        args.append(name)
+        if gen:
+            args.append(gen(r))
+    outs = []
+    for binary, pre in ((G.REF_BIN, []), (CHECK, ["--format-lib"] if seed % 2 else [])):
+        p = subprocess.run([binary] + pre + args + ["-t", "4", ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        outs.append((p.returncode, G.strip_pg(p.stdout)))
+    if outs[0][0] != 0:
+        assert outs[1][0] != 0, args
+    else:
+        assert outs[1][0] == 0 and outs[0][1] == outs[1][1], args
