@@ -2,8 +2,8 @@
 # Host pipeline under the sanitizers (dev container only: needs /root/reference headers and oracle/_ref).
 # Builds tests/cpucheck (host sources + oracle-backed check backend + the reference-I/O driver) twice, with
 # -fsanitize=address,undefined and with -fsanitize=thread, into scratch directories, and runs the driver over synthetic
-# inputs of every mode (long reads, splice + junction annotation, short reads single / paired / unpaired, all-vs-all, staged
-# calls, library formatter).  Prints one line per run; any sanitizer report makes the script fail.
+# inputs of every mode (long reads, splice + junction / jump annotation, short reads single / paired / unpaired, splice:sr, SDUST,
+# all-vs-all, staged calls, library formatter).  Prints one line per run; any sanitizer report makes the script fail.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=${1:-/tmp/mm2amd_sanitize}
@@ -18,6 +18,8 @@ synth.make_pairs(d + "/pe")
 synth.make_short(d + "/se")
 synth.make_overlaps(d + "/ovl")
 synth.make_junctions(d + "/jn")
+synth.make_rna_pairs(d + "/rna")
+synth.make_weird(d + "/weird")
 PY
 fail=0
 for san in address,undefined thread; do
@@ -43,6 +45,9 @@ for san in address,undefined thread; do
 -x sr -a -t 8 $D/se/ref.fa $D/se/reads.fa
 -x ava-ont -c -t 8 $D/ovl/ovl.fa $D/ovl/ovl.fa
 -x splice -a -t 8 --junc-bed $D/jn/junc.bed $D/jn/ref.fa $D/jn/reads.fa
+-x splice -c -t 8 -j $D/jn/junc.bed $D/jn/ref.fa $D/jn/reads.fa
+-x splice:sr -a -t 8 -j $D/rna/introns.bed $D/rna/ref.fa $D/rna/r1.fa $D/rna/r2.fa
+-x map-ont -a -t 8 -T 10 $D/weird/ref.fa $D/weird/reads.fa
 EOF2
 done
 exit $fail
