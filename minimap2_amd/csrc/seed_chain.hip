@@ -761,11 +761,12 @@ __device__ __forceinline__ float fast_log2_dev(float x) // mg_log2, mmpriv.h:139
 
 // comput_sc (lchain.c:113-138).  n_seg = 2 for a read pair: its anchors carry the segment (read) they come from, the distance
 // and bandwidth limits only hold between anchors of one read, and a jump from one read to its mate is charged like a deletion.
+template <bool PAIRS>
 __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, int32_t max_dist_x, int32_t max_dist_y, int32_t bw,
                                               float pen_gap, float pen_skip, int is_cdna, int n_seg)
 {
 	const int32_t dq = (int32_t)iy - (int32_t)jy;
-	const bool same = ((iy ^ jy) & ref::SEED_SEG_MASK) == 0;
+	const bool same = PAIRS ? ((iy ^ jy) & ref::SEED_SEG_MASK) == 0 : true; // batches without pairs compile to the single-segment rules
 	if (dq <= 0 || dq > max_dist_x) return INT32_MIN;
 	const int32_t dr = (int32_t)(ix - jx);
 	if (same && (dr == 0 || dq > max_dist_y)) return INT32_MIN;
@@ -793,6 +794,7 @@ __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t
 // isolated hits.  Isolation is a purely local test, so each block of 64 anchors settles its isolated members in parallel and
 // only the members of real clusters (the true chains) go through the sequential rules, restarting from that known state at
 // every cluster head.
+template <bool PAIRS>
 __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
 {
 	const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -803,7 +805,8 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
 	int32_t max_dist_x, max_dist_y;
 	chain_gaps(P, (int)(B.seq_off[r + 1] - B.seq_off[r]), &max_dist_x, &max_dist_y);
-	const int n_seg = B.unit_first ? B.unit_first[r + 1] - B.unit_first[r] : 1;
+	max_dist_x = __builtin_amdgcn_readfirstlane(max_dist_x), max_dist_y = __builtin_amdgcn_readfirstlane(max_dist_y); // one read per wavefront: keep the limits in scalar registers, as when they were launch constants
+	const int n_seg = PAIRS ? B.unit_first[r + 1] - B.unit_first[r] : 1;
 	const int32_t bw = P.bw;
 	if (max_dist_x < bw) max_dist_x = bw;
 	if (max_dist_y < bw && !P.is_cdna) max_dist_y = bw;
@@ -855,7 +858,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				const int64_t j = base - lane;
 				int32_t sc = INT32_MIN, pj = -1;
 				if (j >= st) {
-					sc = link_score(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
+					sc = link_score<PAIRS>(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
 					if (sc != INT32_MIN) sc += f[j], pj = p[j];
 				}
 				const bool has = sc != INT32_MIN;
@@ -903,7 +906,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				if (max_ii >= 0) { const Anchor m = a[max_ii]; mii_x = m.x, mii_y = m.y, mii_f = (int32_t)(best >> 32); }
 			}
 			if (max_ii >= 0 && max_ii < end_j) {
-				const int32_t tmp = link_score(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
+				const int32_t tmp = link_score<PAIRS>(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
 				if (tmp != INT32_MIN && max_f < tmp + mii_f) max_f = tmp + mii_f, max_j = max_ii;
 			}
 			if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
@@ -919,7 +922,8 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
-	hipLaunchKernelGGL(chain_fill_kernel, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
+	if (B.unit_first) hipLaunchKernelGGL(chain_fill_kernel<true>, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
+	else hipLaunchKernelGGL(chain_fill_kernel<false>, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
 	HIP_CHECK(hipGetLastError());
 }
 
