@@ -101,7 +101,7 @@ def make_junctions(outdir, seed=31, n_reads=60, ref_mb=1.0):
     # reads with a few bases on the far side of an intron: too few to be aligned across it, they end up clipped -- unless the
     # jump annotation (-j) lets the alignment end hop over the junction (mm_jump_split)
     r3 = np.random.default_rng(seed + 2)
-    for k, (c, st, en, minus) in enumerate(introns[:80]):
+    for k, (c, st, en, minus) in enumerate(introns[:50]):
         ctg = contigs[c]
         few = int(r3.integers(3, 16))
         if st < 400 or en + 400 > len(ctg):
