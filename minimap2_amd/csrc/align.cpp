@@ -572,6 +572,7 @@ Aligner::Aligner(const MapOpt &opt, const FlatIndex &fi) : opt_(opt), fi_(fi)
 	bw_ = (int)(opt.bw * 1.5 + 1.);
 	bw_long_ = (int)(opt.bw_long * 1.5 + 1.);
 	if (bw_long_ < bw_) bw_long_ = bw_;
+	qstrand_ = (opt.flag & F_QSTRAND) != 0;
 }
 
 void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_fwd, uint64_t qpool_rev, uint8_t *q4)
@@ -696,7 +697,6 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	t.planned = true;
 	t.r2.cnt = 0;
 	if (r.cnt == 0) { t.done = true; return; }
-	if (opt_.flag & F_QSTRAND) throw std::runtime_error("[mm2amd] qstrand alignment is not supported by this build");
 	const bool is_splice = opt_.flag & F_SPLICE, is_sr = opt_.flag & F_SR;
 	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 	const int32_t ref_len = (int32_t)fi_.seq_len[rid];
@@ -823,9 +823,9 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 			if (is_sr_rna && qe - qs != re - rs) { // mm_align_sr_rna's own preconditions (align.c:376-384): a short query whose two ends match the window's ends
 				const int32_t ql = qe - qs, tl = re - rs, ilen = opt_.q2 * 2;
 				if (ql <= 100 && ql * 2 + ilen <= tl) {
-					const uint8_t *qseq = ra.q4 + (size_t)rev * qlen + qs;
+					const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : rev) * qlen + qs;
 					tbuf_.resize(tl);
-					fi_.getseq(rid, rs, re, tbuf_.data());
+					fi_.getseq2(qstrand_ && rev, rid, rs, re, tbuf_.data());
 					int32_t ll = 0, lr = 0;
 					for (int32_t j = 0; j < ql; ++j) if (qseq[j] == tbuf_[j] && qseq[j] < 4) ++ll;
 					for (int32_t j = 0; j < ql; ++j) if (qseq[ql - 1 - j] == tbuf_[tl - 1 - j] && qseq[ql - 1 - j] < 4) ++lr;
@@ -835,9 +835,9 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 			if (is_sr || (is_sr_rna && qe - qs == re - rs)) { // align.c:823-833: the seeds lie on one diagonal; if the ungapped alignment beats any gapped one, it is the result
 				assert(qe - qs == re - rs);
 				const int32_t len = qe - qs, max_gapped_score = (len - 2) * opt_.a - 2 * (opt_.q + opt_.e);
-				const uint8_t *qseq = ra.q4 + (size_t)rev * qlen + qs;
+				const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : rev) * qlen + qs;
 				tbuf_.resize(len);
-				fi_.getseq(rid, rs, re, tbuf_.data());
+				fi_.getseq2(qstrand_ && rev, rid, rs, re, tbuf_.data());
 				int32_t score = 0;
 				for (int32_t j = 0; j < len; ++j) {
 					if (qseq[j] >= 4 || tbuf_[j] >= 4) score += opt_.sc_ambi > 0 ? -opt_.sc_ambi : opt_.sc_ambi;
@@ -877,10 +877,17 @@ void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdr
 	j.w = w.bw, j.zdrop = zdrop, j.end_bonus = end_bonus;
 	if (opt_.transition != 0 && opt_.b != opt_.transition) flag |= KSW_GENERIC_SC;             // align.c:347-348
 	if (opt_.max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > opt_.max_sw_mat) flag |= KSWJ_SKIP;   // align.c:349-351
-	const uint64_t qbase = t.rev ? ra.qpool_rev : ra.qpool_off, tbase = fi_.seq_off[t.rid];
+	const uint64_t qbase = (t.rev && (!qstrand_ || w.kind == W_INV)) ? ra.qpool_rev : ra.qpool_off, tbase = fi_.seq_off[t.rid]; // the inversion rescue is not query-strand aware in the reference either
 	j.q_off = reversed ? qbase + w.qe - 1 : qbase + w.qs;
 	j.t_off = reversed ? tbase + w.re - 1 : tbase + w.rs;
 	j.flag = flag | t.ksw_flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);
+	if (qstrand_ && t.rev && w.kind != W_INV) { // --qstrand: the query stays as given and the TARGET is reverse-complemented (mm_idx_getseq2, align.c:780-786):
+		const size_t o = ra.tbytes.size();      // such a window is not a run of the packed reference, it is composed into the byte pool
+		ra.tbytes.resize(o + (size_t)j.tlen);
+		fi_.getseq2(true, t.rid, w.rs, w.re, &ra.tbytes[o]);
+		j.t_off = reversed ? o + (uint64_t)j.tlen - 1 : o;
+		j.flag &= ~KSWJ_T_PACKED;
+	}
 	j.tag = 0, j.reserved = 0;
 	if ((opt_.flag & F_SPLICE) && fi_.has_junc && w.kind != W_INV) { // mm_get_junc -> mm_idx_bed_junc (align.c:638-643, index.c:803-826): introns lying entirely inside the window
 		const std::vector<FlatIndex::Junc> &J = fi_.junc[t.rid];
@@ -921,7 +928,7 @@ void Aligner::add_flank_job(ReadAlign &ra, RegionTask &t, Window &w, std::vector
 	ra.tbytes.resize(ra.tbytes.size() + tl2);
 	uint8_t *dst = &ra.tbytes[j.t_off];
 	tbuf_.resize(tl);
-	fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+	fi_.getseq2(qstrand_ && t.rev, t.rid, w.rs, w.re, tbuf_.data());
 	memcpy(dst, tbuf_.data(), ql);
 	memset(dst + ql, 4, ilen);
 	memcpy(dst + ql + ilen, tbuf_.data() + tl - ql, ql);
@@ -1022,19 +1029,19 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 					return true;
 				}
 				if (!w.pass2) { // the approximate pass: test it (align.c:843)
-					const uint8_t *qseq = ra.q4 + (size_t)t.rev * qlen + w.qs;
+					const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : t.rev) * qlen + w.qs;
 					int code;
 					if (ez.zd_max != KSW_ZD_NONE) { // the kernel scanned its own alignment; sequences are only needed for the rare inversion check
 						ZdropScan z;
 						z.max_zdrop = ez.zd_max, z.pos[0][0] = ez.zd_t0, z.pos[0][1] = ez.zd_t1, z.pos[1][0] = ez.zd_q0, z.pos[1][1] = ez.zd_q1;
 						if (z.max_zdrop > opt_.zdrop_inv) {
 							tbuf_.resize(w.re - w.rs);
-							fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+							fi_.getseq2(qstrand_ && t.rev, t.rid, w.rs, w.re, tbuf_.data());
 							code = zdrop_decide(opt_, z, qseq, tbuf_.data(), mat_);
 						} else code = z.max_zdrop > opt_.zdrop ? 1 : 0;
 					} else {
 						tbuf_.resize(w.re - w.rs);
-						fi_.getseq(t.rid, w.rs, w.re, tbuf_.data());
+						fi_.getseq2(qstrand_ && t.rev, t.rid, w.rs, w.re, tbuf_.data());
 						code = test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
 					}
 					if (code != 0) {
@@ -1069,7 +1076,7 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 					t.re1 = w.rs + (ez.max_t + 1);
 					t.qe1 = w.qs + (ez.max_q + 1);
 					if (t.cnt1 - (j + 1) >= opt_.min_cnt) {
-						split_reg(r, t.r2, t.as1 + j + 1 - r.as, qlen, a, false);
+						split_reg(r, t.r2, t.as1 + j + 1 - r.as, qlen, a, qstrand_);
 						if (w.zdrop_code == 2) t.r2.split_inv = 1;
 					}
 					t.next_win = t.win.size();
@@ -1117,12 +1124,12 @@ void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
 	const int qlen = ra.qlen;
 	assert(t.qe1 <= qlen);
 	r.rs = t.rs1, r.re = t.re1;
-	if (!t.rev) r.qs = t.qs1, r.qe = t.qe1;
+	if (!t.rev || qstrand_) r.qs = t.qs1, r.qe = t.qe1; // align.c:894
 	else r.qs = qlen - t.qe1, r.qe = qlen - t.qs1;
 	if (r.p) {
 		tbuf_.resize(t.re1 - t.rs1);
-		fi_.getseq(t.rid, t.rs1, t.re1, tbuf_.data());
-		const uint8_t *qseq = ra.q4 + (size_t)r.rev * qlen + t.qs1;
+		fi_.getseq2(qstrand_ && t.rev, t.rid, t.rs1, t.re1, tbuf_.data());
+		const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : r.rev) * qlen + t.qs1;
 		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, !(opt_.flag & (F_SR | F_SR_RNA)));
 		if (t.rev && r.p->trans_strand) r.p->trans_strand ^= 3; // align.c:907-908
 	}

@@ -87,6 +87,7 @@ private:
 	void join_strands(ReadAlign &ra, int lead_ti);
 	void plan_region(ReadAlign &ra, RegionTask &t);
 	void add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdrop, int end_bonus, std::vector<KswJob> &jobs);
+	bool qstrand_ = false; // MM_F_QSTRAND: reverse-strand hits keep the query as given and reverse-complement the reference
 	void add_flank_job(ReadAlign &ra, RegionTask &t, Window &w, std::vector<KswJob> &jobs);
 	bool consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
 	void consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);

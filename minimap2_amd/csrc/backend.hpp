@@ -50,6 +50,7 @@ public:
 	// all-vs-all mapping (MM_F_NO_DIAG / MM_F_NO_DUAL): seed_chain() then applies skip_seed's read-name rules (map.c:81-91), which
 	// need the reads' names in begin_batch().  Call once, before the first batch.
 	virtual void enable_name_rules() {}
+	virtual void enable_seq_len() {} // --qstrand: seed_chain() needs the reference sequence lengths (reverse-strand anchors in query-strand coordinates)
 	virtual bool supports_junctions() const { return true; } // KswScoring::juncs honoured by ksw()
 	virtual bool supports_sdust() const { return true; }
 	virtual bool supports_byte_targets() const { return true; } // KswScoring::tbytes honoured by ksw() (splice:sr)     // SeedChainParams::sdust_thres honoured by seed_chain()

@@ -100,6 +100,14 @@ public:
 		I_.name_rank = d_name_rank_.p, I_.seq_len = d_ref_len_.p;
 		name_rules_ = true;
 	}
+	void enable_seq_len() override
+	{
+		if (I_.seq_len) return;
+		d_ref_len_.ensure(fi_seq_len_->size());
+		HIP_CHECK(hipMemcpyAsync(d_ref_len_.p, fi_seq_len_->data(), fi_seq_len_->size() * 4, hipMemcpyHostToDevice, stream_));
+		HIP_CHECK(hipStreamSynchronize(stream_));
+		I_.seq_len = d_ref_len_.p;
+	}
 	void set_active_lanes(int n) override { active_lanes_ = std::max(1, std::min(n, n_lanes_)); }
 	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
 

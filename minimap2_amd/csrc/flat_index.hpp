@@ -64,6 +64,16 @@ struct FlatIndex {
 		}
 		for (; o < oe; ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
 	}
+	void getseq2(bool is_rev, uint32_t rid, uint32_t st, uint32_t en, uint8_t *out) const // mm_idx_getseq2 (index.c:176-196): the window [st, en) of the reverse-complemented sequence when is_rev
+	{
+		if (!is_rev) { getseq(rid, st, en, out); return; }
+		const uint32_t len = seq_len[rid];
+		getseq(rid, len - en, len - st, out);
+		if (en <= st) return;
+		uint32_t i = 0, j = en - st - 1;
+		for (; i < j; ++i, --j) { const uint8_t a = out[i], b = out[j]; out[i] = b < 4 ? 3 - b : b, out[j] = a < 4 ? 3 - a : a; }
+		if (i == j) out[i] = out[i] < 4 ? 3 - out[i] : out[i];
+	}
 	int32_t cal_max_occ(float f) const; // mm_idx_cal_max_occ (index.c:198-220)
 
 	// (hash, pos) pairs -> tables.  pairs must be sorted by (hash, pos).

@@ -93,11 +93,11 @@ void put_tags(Text &o, const Reg1 &r) // write_tags
 }
 
 // the aligned stretches of query and target as nt4 codes, query on the alignment strand (write_cs_ds_or_MD, format.c:333-362)
-void fetch_pair(const FlatIndex &fi, const Bseq1 &t, const Reg1 &r, Seqs &sq)
+void fetch_pair(const FlatIndex &fi, const Bseq1 &t, const Reg1 &r, Seqs &sq, bool is_qstrand)
 {
 	sq.q.resize(r.qe - r.qs), sq.t.resize(r.re - r.rs);
-	fi.getseq(r.rid, r.rs, r.re, sq.t.data());
-	if (!r.rev) for (int i = r.qs; i < r.qe; ++i) sq.q[i - r.qs] = kNt4Table[(uint8_t)t.seq[i]];
+	fi.getseq2(is_qstrand && r.rev, r.rid, r.rs, r.re, sq.t.data()); // format.c:343-346: query as given, reference reverse-complemented
+	if (!r.rev || is_qstrand) for (int i = r.qs; i < r.qe; ++i) sq.q[i - r.qs] = kNt4Table[(uint8_t)t.seq[i]];
 	else for (int i = r.qs; i < r.qe; ++i) { const uint8_t c = kNt4Table[(uint8_t)t.seq[i]]; sq.q[r.qe - i - 1] = c >= 4 ? 4 : 3 - c; }
 }
 
@@ -190,7 +190,7 @@ void put_md(Text &o, const Reg1 &r, const Seqs &sq) // write_MD_core
 void put_cs_or_md(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 &r, int64_t flag, Seqs &sq)
 {
 	if (!r.p) return;
-	fetch_pair(fi, t, r, sq);
+	fetch_pair(fi, t, r, sq, (flag & F_QSTRAND) != 0);
 	if (flag & F_OUT_MD) put_md(o, r, sq);
 	else put_cs(o, r, sq, !(flag & F_OUT_CS_LONG), flag & F_OUT_DS);
 }
@@ -206,7 +206,9 @@ void put_paf(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 *r, int64_
 	}
 	o.ch('\t'), o.num(t.l_seq), o.ch('\t'), o.num(r->qs), o.ch('\t'), o.num(r->qe), o.ch('\t'), o.ch("+-"[r->rev]), o.ch('\t');
 	if (!fi.names[r->rid].empty()) o.str(fi.names[r->rid].c_str()); else o.num(r->rid);
-	o.ch('\t'), o.num(fi.seq_len[r->rid]), o.ch('\t'), o.num(r->rs), o.ch('\t'), o.num(r->re);
+	o.ch('\t'), o.num(fi.seq_len[r->rid]), o.ch('\t');
+	if ((flag & F_QSTRAND) && r->rev) o.num((int)fi.seq_len[r->rid] - r->re), o.ch('\t'), o.num((int)fi.seq_len[r->rid] - r->rs); // format.c:440-443
+	else o.num(r->rs), o.ch('\t'), o.num(r->re);
 	o.ch('\t'), o.num(r->mlen), o.ch('\t'), o.num(r->blen), o.ch('\t'), o.num(r->mapq);
 	put_tags(o, *r);
 	if (rep_len >= 0) o.tag("rl:i:", rep_len);
@@ -377,7 +379,6 @@ void put_sam(Text &o, const FlatIndex &fi, const Bseq1 &t, int seg_idx, int reg_
 std::string format_check(const MapOpt &opt)
 {
 	if (opt.flag & F_OUT_JUNC) return "--write-junc output is not implemented";
-	if (opt.flag & F_QSTRAND) return "--qstrand output is not implemented";
 	if (opt.split_prefix) return "split-index output is not implemented";
 	return "";
 }

@@ -40,7 +40,13 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
-	if (opt.flag & F_QSTRAND) throw std::invalid_argument("[mm2amd] --qstrand is not implemented"); // MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
+	// MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
+	if (opt.flag & F_QSTRAND) { // reverse-strand hits in query-strand coordinates: DP targets are composed (reverse-complemented) into the byte pool
+		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] --qstrand on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+		be.enable_seq_len();
+		if ((opt.flag & (F_OUT_SAM | F_SPLICE | F_FRAG_MODE | F_SR | F_HEAP_SORT)) || (fi.flag & I_HPC))
+			throw std::invalid_argument("[mm2amd] --qstrand doesn't work with -a, -H, --frag, --sr, --heap-sort or --splice (options.c:271)");
+	}
 	if ((opt.flag & F_SR_RNA) && (opt.flag & F_SPLICE)) {
 		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] splice:sr on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 		if (fi.has_junc) throw std::invalid_argument("[mm2amd] splice:sr with --junc-bed is not implemented (use -j)");
@@ -258,7 +264,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			chain_gaps(sp, qlen, &gap_ref, &gap_qry);
 			res.frag_gap = gap_ref, res.rep_len = c.rep_len; // map.c:317-318
 			RegVec &r0 = regs0[i];
-			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, false, r0);
+			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, (opt_.flag & F_QSTRAND) != 0, r0);
 			if (fi_.n_alt) { // mm_mark_alt + re-sort with ALT hits handicapped (map.c:321-324)
 				for (Reg &r : r0) if (fi_.is_alt[r.rid]) r.is_alt = 1;
 				hit_sort(r0, opt_.alt_drop);
@@ -268,7 +274,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				if (n_segs <= 1) select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
 				else select_sub_multi(opt_.pri_ratio, 0.2f, 0.7f, gap_ref, fi_.k * 2, opt_.best_n, n_segs, qlens, r0);
 			}
-			if (!(opt_.flag & F_SR)) { // map.c:333-336
+			if (!(opt_.flag & (F_SR | F_QSTRAND))) { // map.c:333-336
 				est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 				filter_strand_retained(r0);
 			}
@@ -340,7 +346,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				}, 256);
 				sc.juncs = ds.juncs.data(), sc.n_juncs = jb[mu], sc.junc_bonus = (int8_t)opt_.junc_bonus;
 			}
-			if (opt_.flag & F_SR_RNA) { // composed targets (Aligner::add_flank_job) as one byte pool; the jobs' offsets become pool-wide
+			if (opt_.flag & (F_SR_RNA | F_QSTRAND)) { // composed targets (Aligner::add_flank_job, --qstrand windows) as one byte pool; the jobs' offsets become pool-wide
 				std::vector<size_t> &tb = ds.tbyte_base;
 				tb.resize(mu + 1);
 				tb[0] = 0;

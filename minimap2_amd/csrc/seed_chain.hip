@@ -476,9 +476,12 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 			if ((rr & 1) == (qp & 1)) { // same strand
 				p.x = (rr & 0xffffffff00000000ULL) | rpos;
 				p.y = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
-			} else {
+			} else if (!(P.flag & ref::F_QSTRAND)) {
 				p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
 				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
+			} else { // --qstrand (map.c:192-196): the reference coordinate is flipped, the query's is kept
+				p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | (uint32_t)((int)I.seq_len[rr >> 32] - ((int)rpos + 1 - (int)span) - 1);
+				p.y = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
 			}
 			if (info & SD_SEG1) p.y |= 1ULL << ref::SEED_SEG_SHIFT;
 			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;

@@ -8,6 +8,7 @@
 #define F_NO_DUAL  0x002LL
 #define F_FOR_ONLY 0x100000LL
 #define F_HEAP_SORT 0x400000LL
+#define F_QSTRAND   0x100000000LL
 #define F_REV_ONLY 0x200000LL
 #define SEED_TANDEM (1ULL << 42)
 #define SEED_SELF   (1ULL << 43)
@@ -59,7 +60,7 @@ static void thin_high_occ(int32_t n, seed_t *a, int len, int max_occ, int max_ma
 }
 
 /* one index hit r of seed q as an anchor; returns 0 when skip_seed (map.c:78-100) drops it */
-static int make_anchor(ora128_t *p, uint64_t r, const seed_t *q, const char *qname, ora_seq_name_f seq_name, const void *idx, int64_t opt_flag, int qlen)
+static int make_anchor(ora128_t *p, uint64_t r, const seed_t *q, const char *qname, ora_seq_name_f seq_name, const void *idx, int64_t opt_flag, int qlen, int heap)
 {
 	const int32_t rpos = (int32_t)((uint32_t)r >> 1);
 	const int fwd = (r & 1) == (q->q_pos & 1);
@@ -81,9 +82,14 @@ static int make_anchor(ora128_t *p, uint64_t r, const seed_t *q, const char *qna
 	if (fwd) {
 		p->x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
 		p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
-	} else {
+	} else if (!(opt_flag & F_QSTRAND) || heap) {
 		p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
 		p->y = (uint64_t)q->q_span << 32 | (uint32_t)(qlen - ((int32_t)(q->q_pos >> 1) + 1 - (int32_t)q->q_span) - 1);
+	} else { /* query-strand mode (map.c:192-196): the reference coordinate is flipped instead of the query's */
+		uint32_t tl = 0;
+		seq_name(idx, (uint32_t)(r >> 32), &tl);
+		p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)((int32_t)tl - (rpos + 1 - (int32_t)q->q_span) - 1);
+		p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
 	}
 	p->y |= (uint64_t)q->seg_id << 48;
 	if (q->is_tandem) p->y |= SEED_TANDEM;
@@ -184,7 +190,7 @@ int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const ch
 		while (hs > 0) {
 			const seed_t *q = &m[heap[0].y >> 32];
 			ora128_t t;
-			if (make_anchor(&t, heap[0].x, q, qname, seq_name, idx, opt_flag, qlen)) {
+			if (make_anchor(&t, heap[0].x, q, qname, seq_name, idx, opt_flag, qlen, 1) /* the heap path has no query-strand branch (map.c:129-137) */) {
 				if (t.x >> 63) a[n_a - (++n_rev)] = t; /* the other strand is laid down back to front ... */
 				else a[n_for++] = t;
 			}
@@ -205,7 +211,7 @@ int64_t ora_collect_seed_hits_named(const void *idx, ora_idx_get_f get, const ch
 			const seed_t *q = &m[i];
 			uint32_t c;
 			for (c = 0; c < q->n; ++c)
-				if (make_anchor(&a[k], q->cr[c], q, qname, seq_name, idx, opt_flag, qlen)) ++k;
+				if (make_anchor(&a[k], q->cr[c], q, qname, seq_name, idx, opt_flag, qlen, 0)) ++k;
 		}
 		ora_radix_sort_128x(a, a + k);
 	}

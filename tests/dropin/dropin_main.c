@@ -108,6 +108,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--heap-sort=yes") == 0) mopt.flag |= MM_F_HEAP_SORT; /* main.c:298 */
 		else if (strcmp(argv[k], "--heap-sort=no") == 0) mopt.flag &= ~(int64_t)MM_F_HEAP_SORT;
 		else if (strcmp(argv[k], "--sr") == 0) mopt.flag |= MM_F_SR;
+		else if (strcmp(argv[k], "--qstrand") == 0) mopt.flag |= MM_F_QSTRAND | MM_F_NO_INV; /* main.c:252 */
 		else if (strcmp(argv[k], "--no-pairing") == 0) mopt.flag |= MM_F_INDEPEND_SEG; /* main.c:228 */
 		else if (strcmp(argv[k], "-F") == 0) mopt.max_frag_len = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-T") == 0) mopt.sdust_thres = atoi(argv[++k]); /* main.c:171 */

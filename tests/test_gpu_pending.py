@@ -56,3 +56,13 @@ def test_short_rna_seq_pairs(args, n_files, jump, tmp_path):  # splice:sr: flank
     args = args + (["-j", bed] if jump else [])
     files = [f1, f2] if n_files == 2 else [f1]
     assert _run([REF_BIN, "-t", "8"] + args + [ref] + files) == _run([DROPIN, "-t", "8"] + args + [ref] + files)
+
+
+@pytest.mark.parametrize("kind,args", [("ont", ["-x", "map-ont", "-c", "--qstrand"]), ("ont", ["-x", "map-ont", "--qstrand"]), ("ont", ["-x", "map-hifi", "-c", "--cs", "--qstrand"]),
+                                       ("weird", ["-x", "map-ont", "-c", "--qstrand"])])
+def test_query_strand_mode(kind, args, tmp_path):  # --qstrand: flipped reference coordinates in seed_expand_kernel, reverse-complemented DP targets through the byte pool
+    if kind == "ont":
+        ref, rd, _, _ = synth.make("ont", str(tmp_path), 2, 60, 29)
+    else:
+        ref, rd = synth.make_weird(str(tmp_path))
+    assert _run([REF_BIN, "-t", "8"] + args + [ref, rd]) == _run([DROPIN, "-t", "8"] + args + [ref, rd])

@@ -438,3 +438,21 @@ def test_short_rna_seq_pairs(args, n_files, jump, tmp_path):
     got = subprocess.run([CHECK] + args + [ref] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     assert G.strip_pg(want) == G.strip_pg(got)
     assert want.count(b"\n") > 150
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("kind,args", [("ont", ["-x", "map-ont", "-c", "--qstrand"]), ("ont", ["-x", "map-ont", "--qstrand"]), ("ont", ["-x", "map-hifi", "-c", "--cs", "--qstrand", "--format-lib"]),
+                                       ("weird", ["-x", "map-ont", "-c", "--qstrand"]), ("weird", ["-x", "asm20", "-c", "--qstrand", "--MD", "--format-lib"]),
+                                       ("ont", ["-x", "map-ont", "-c", "--qstrand", "-P", "-z", "100,50"])])
+def test_query_strand_mode(kind, args, tmp_path):
+    """--qstrand: reverse-strand hits keep the query as given; anchors, DP targets and PAF coordinates are those of the
+    reverse-complemented reference (map.c:192-196, align.c:780-786,894, format.c:343-346,440-443)."""
+    import synth
+    if kind == "ont":
+        ref, rd, _, _ = synth.make("ont", str(tmp_path), 2, 60, 29)
+    else:
+        ref, rd = synth.make_weird(str(tmp_path))
+    want = subprocess.run([G.REF_BIN] + [a for a in args if a != "--format-lib"] + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    got = subprocess.run([CHECK] + args + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(want) == G.strip_pg(got)
+    assert sum(1 for l in want.split(b"\n") if b"\t-\t" in l) > 0  # reverse-strand hits are what the mode is about
