@@ -48,6 +48,7 @@ for san in address,undefined thread; do
 -x splice -c -t 8 -j $D/jn/junc.bed $D/jn/ref.fa $D/jn/reads.fa
 -x splice:sr -a -t 8 -j $D/rna/introns.bed $D/rna/ref.fa $D/rna/r1.fa $D/rna/r2.fa
 -x map-ont -a -t 8 -T 10 $D/weird/ref.fa $D/weird/reads.fa
+-x map-ont -c -t 8 --qstrand --cs $D/ont/ref.fa $D/ont/reads.fa
 EOF2
 done
 exit $fail
