@@ -123,3 +123,39 @@ def test_struct_layouts_match_reference_headers(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-Wno-invalid-offsetof", str(probe), "-o", exe2])
     got = dict(l.split() for l in subprocess.check_output([exe2]).decode().splitlines())
     assert got == want
+
+
+def test_python_stage_run_marshalling_with_a_fake_library(monkeypatch):
+    """Aligner.stage()/run() without a GPU: a stand-in for the C library records what the ctypes layer hands over -- fragment
+    table, read records -- for single reads and for read pairs, and hands back empty results."""
+    import ctypes as C
+    import minimap2_amd as mm
+
+    calls = {}
+
+    class Fake:
+        def mm_gpu_batch_stage(self, n, seg_off, n_seg, arr):
+            calls["stage"] = (n, list(seg_off)[:n], list(n_seg)[:n], [(arr[k].l_seq, arr[k].name, arr[k].seq) for k in range(sum(list(n_seg)[:n]))])
+            return 0
+
+        def mm_gpu_map_staged(self, n_reg, reg, rep_len, frag_gap):
+            calls["run"] = len(n_reg)
+            return 0
+
+        def mm2amd_free_regs(self, n, n_reg, reg):
+            calls["free"] = n
+
+        def mm2amd_last_error(self):
+            return b""
+
+    monkeypatch.setattr(mm, "lib", lambda path=None: Fake())
+    al = object.__new__(mm.Aligner)
+    al.names, al.lens, al._staged, al._idx = ["c1"], [100], None, None
+    out = al.map_batch([("a", b"ACGT"), "GGCC", ("c", "TTTTT")])
+    assert calls["stage"] == (3, [0, 1, 2], [1, 1, 1], [(4, b"a", b"ACGT"), (4, b"read1", b"GGCC"), (5, b"c", b"TTTTT")])
+    assert calls["run"] == 3 and calls["free"] == 3 and out == [[], [], []]
+    out = al.map_pairs([("p0", b"ACGT", b"TTGCA"), ("p1", "AAA", "CC")])
+    assert calls["stage"] == (2, [0, 2], [2, 2], [(4, b"p0", b"ACGT"), (5, b"p0", b"TTGCA"), (3, b"p1", b"AAA"), (2, b"p1", b"CC")])
+    assert calls["run"] == 4 and calls["free"] == 4 and out == [([], []), ([], [])]
+    n_reg, reg, rep = (al.stage([("x", b"ACGT")]), al.run(raw=True))[1]
+    assert len(n_reg) == 1 and len(reg) == 1 and len(rep) == 1
