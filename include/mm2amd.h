@@ -120,7 +120,11 @@ int mm_gpu_init(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_thread
 
 /* Same contract as calling worker_for(step, i, tid) for i in [0, n_frag) (map.c:425-474): for fragment i with
  * segments seq[seg_off[i] .. seg_off[i]+n_seg[i]) fills n_reg[], reg[] (libc-allocated, caller frees reg[k] and each
- * reg[k][j].p), rep_len[] and frag_gap[] at the segment's index.  Output order == input order. */
+ * reg[k][j].p), rep_len[] and frag_gap[] at the segment's index.  Output order == input order.
+ * n_seg[i] is 1 or 2.  For a read pair the library does what worker_for does around mm_map_frag (map.c:436-473): the mates are
+ * mapped in the orientation mm_mapopt_t::pe_ori prescribes (on copies; seq is not modified), jointly, or each on its own with
+ * MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING, paired by mm_pair's rules, and their hits are turned back to the given orientation.
+ * mm_gpu_init refuses (MM2AMD_EINVAL) the configurations the library does not handle; see INTEGRATION.md section 2. */
 int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq,
                      int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
 
