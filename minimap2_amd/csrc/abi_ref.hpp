@@ -49,6 +49,7 @@ struct IntvList { int32_t n, m; Intv1 *a; };                              // mm_
 
 struct JJump1 { int32_t off, off2, cnt; int16_t strand; uint16_t flag; };  // mm_idx_jjump1_t, mmpriv.h:58-62
 struct JJumpList { int32_t n, m; JJump1 *a; };                            // mm_idx_jjump_t, index.c:45-48 (mm_idx_t::J: one per sequence)
+struct SpscList { uint32_t n, m; uint64_t *a; };                          // mm_idx_spsc_t, index.c:965-968 (mm_idx_t::spsc: two per sequence, + then - strand)
 constexpr uint16_t JUNC_ANNO = 0x1;                                       // MM_JUNC_ANNO, mmpriv.h:27
 
 struct Extra {                                         // mm_extra_t, minimap.h:103-110

@@ -724,6 +724,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 		if (t.splice_flag & F_SPLICE_REV) t.ksw_flag |= rev ? KSW_SPLICE_FOR : KSW_SPLICE_REV;
 		if (opt_.flag & F_SPLICE_FLANK) t.ksw_flag |= KSW_SPLICE_FLANK;
 		if (!(opt_.flag & F_SPLICE_OLD)) t.ksw_flag |= KSW_SPLICE_CMPLX;
+		if (fi_.has_spsc) t.ksw_flag |= KSW_SPLICE_SCORE; // align.c:688
 	}
 
 	// how far the two extensions may reach (align.c:695-767)
@@ -889,7 +890,26 @@ void Aligner::add_job(ReadAlign &ra, RegionTask &t, Window &w, int flag, int zdr
 		j.flag &= ~KSWJ_T_PACKED;
 	}
 	j.tag = 0, j.reserved = 0;
-	if ((opt_.flag & F_SPLICE) && fi_.has_junc && w.kind != W_INV) { // mm_get_junc -> mm_idx_bed_junc (align.c:638-643, index.c:803-826): introns lying entirely inside the window
+	if ((opt_.flag & F_SPLICE) && fi_.has_spsc && w.kind != W_INV) { // mm_get_junc -> mm_idx_spsc_get (align.c:640, index.c:1045-1066): the scored sites strictly inside the window
+		const std::vector<uint64_t> &S = fi_.spsc[(size_t)t.rid << 1 | ((t.ksw_flag & KSW_SPLICE_REV) ? 1 : 0)];
+		const size_t first = ra.juncs.size();
+		auto last_le = [&](int64_t x) -> int64_t { // index of the last entry at a position <= x, -1 if none (mm_idx_find_intv)
+			size_t lo = 0, hi = S.size();
+			while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if ((int64_t)(S[mid] >> 8) <= x) lo = mid + 1; else hi = mid; }
+			return (int64_t)lo - 1;
+		};
+		if (!S.empty()) {
+			const int64_t l = last_le(w.rs), r = last_le(w.re);
+			for (int64_t k = l + 1; k <= r; ++k) {
+				const int64_t x = (int64_t)(S[k] >> 8) - w.rs;
+				if (x == w.re - w.rs) continue;
+				const uint32_t e = (uint32_t)x << 8 | (uint32_t)(S[k] & 0xff);
+				if (ra.juncs.size() > first && ra.juncs.back() >> 8 == (uint32_t)x) { if ((ra.juncs.back() & 0xff) < (e & 0xff)) ra.juncs.back() = e; } // the best score of a position
+				else ra.juncs.push_back(e);
+			}
+		}
+		j.tag = (uint32_t)first, j.reserved = (uint32_t)(ra.juncs.size() - first);
+	} else if ((opt_.flag & F_SPLICE) && fi_.has_junc && w.kind != W_INV) { // mm_get_junc -> mm_idx_bed_junc (align.c:638-643, index.c:803-826): introns lying entirely inside the window
 		const std::vector<FlatIndex::Junc> &J = fi_.junc[t.rid];
 		const size_t first = ra.juncs.size();
 		size_t lo = 0, hi = J.size();

@@ -54,12 +54,6 @@ int mm_gpu_init(const void *mi, const void *opt, int n_threads)
 	try {
 		std::unique_ptr<MapContext> c(new MapContext);
 		c->opt = *(const ref::MapOpt *)opt;
-		{ // junction annotation loaded into the index (mm_idx_bed_read / mm_idx_jjump_read / mm_idx_spsc_read2, main.c:468-486) changes
-		  // what spliced alignment computes (mm_get_junc, align.c:642; mm_jump_split, map.c:362-364): refuse rather than ignore it
-			const ref::Idx *ri = (const ref::Idx *)mi;
-			if ((c->opt.flag & ref::F_SPLICE) && ri->spsc)
-				return capi_fail(MM2AMD_EINVAL, "[mm2amd] spliced alignment with splice scores (--spsc) is not implemented");
-		}
 		c->fi_own.from_reference((const ref::Idx *)mi);
 		c->fi = &c->fi_own;
 		if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU

@@ -52,6 +52,13 @@ void FlatIndex::from_reference(const ref::Idx *mi)
 		for (uint32_t i = 0; i < n_seq; ++i) jump[i].assign(J[i].a, J[i].a + J[i].n);
 		has_jump = true;
 	}
+	spsc.clear(), has_spsc = false;
+	if (mi->spsc) { // splice scores (--spsc): what mm_idx_spsc_get reads
+		const ref::SpscList *P = (const ref::SpscList *)mi->spsc;
+		spsc.resize((size_t)n_seq * 2);
+		for (uint32_t i = 0; i < n_seq * 2; ++i) if (P[i].n) spsc[i].assign(P[i].a, P[i].a + P[i].n);
+		has_spsc = true;
+	}
 	std::vector<std::pair<uint64_t, uint64_t>> pairs;
 	const uint32_t nb = 1u << mi->b;
 	for (uint32_t b = 0; b < nb; ++b) {

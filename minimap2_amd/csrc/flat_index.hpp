@@ -23,6 +23,9 @@ struct FlatIndex {
 	// junctions a clipped alignment end may jump across (mm_idx_t::J as mm_idx_jjump_read leaves it: ascending off), per sequence
 	std::vector<std::vector<ref::JJump1>> jump;
 	bool has_jump = false;
+	// splice scores (--spsc): per sequence and strand (index rid << 1 | minus), ascending  pos << 8 | (score + 64) << 1 | is_acceptor
+	std::vector<std::vector<uint64_t>> spsc;
+	bool has_spsc = false;
 	std::vector<std::string> names;
 	std::vector<uint64_t> seq_off;      // offset of each sequence in S (bases)
 	std::vector<uint32_t> seq_len;

@@ -55,7 +55,9 @@ struct KswScoring {         // uniform over a launch
 	// splice mode with junction annotation (ksw2_exts2_sse.c:201-217, the junc[] of mm_idx_bed_junc): a job with reserved > 0 owns
 	// juncs[tag .. tag + reserved), entries  t << 4 | bits  ascending in t, t = offset of the base in the window as stored in the
 	// index (NOT reversed for a T_REVERSED job), bits as in junc[]: 1 / 8 first base of a + / - strand intron, 2 / 4 its last base
-	int8_t junc_bonus = 0;
+	// Jobs with KSW_SPLICE_SCORE (--spsc, ksw2_exts2_sse.c:196-200) use the same pool with entries  t << 8 | score byte  (the junc[]
+	// of mm_idx_spsc_get: (score + 64) << 1 | is_acceptor); positions without an entry cost junc_pen.
+	int8_t junc_bonus = 0, junc_pen = 0;
 	const uint32_t *juncs = nullptr;
 	size_t n_juncs = 0;
 	// targets that are not windows of the reference (jobs without KSWJ_T_PACKED): t_off indexes this pool of nt4 bytes

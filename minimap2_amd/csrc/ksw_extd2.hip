@@ -229,6 +229,12 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jent[mid] >> 4 < pos) lo = mid + 1; else hi = mid; }
 				return lo < nj && jent[lo] >> 4 == pos ? jent[lo] & 15u : 0u;
 			};
+			auto jscore = [&](int i) -> int { // the score byte of position i, 0xff when the window has none there (entries  t << 8 | byte)
+				const uint32_t pos = (flag & KSWJ_T_REVERSED) ? (uint32_t)(tlen - 1 - i) : (uint32_t)i;
+				uint32_t lo = 0, hi = nj;
+				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jent[mid] >> 8 < pos) lo = mid + 1; else hi = mid; }
+				return lo < nj && jent[lo] >> 8 == pos ? (int)(jent[lo] & 0xffu) : 0xff;
+			};
 			const uint32_t jd_mask = !sp_revc ? (sp_for ? 1u : 0u) | ((flag & KSW_SPLICE_REV) ? 8u : 0u) : (sp_for ? 2u : 0u) | ((flag & KSW_SPLICE_REV) ? 4u : 0u);
 			const uint32_t ja_mask = !sp_revc ? (sp_for ? 2u : 0u) | ((flag & KSW_SPLICE_REV) ? 4u : 0u) : (sp_for ? 1u : 0u) | ((flag & KSW_SPLICE_REV) ? 8u : 0u);
 			// Take positions (frontier, upto] into the window with the values the reference's up-front fill gives them
@@ -285,7 +291,13 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							}
 						}
 						int dcost = sp_cost(zd), acost = sp_cost(za);
-						if (nj) { // the bonus is added in the 8-bit lanes (int8 wrap) wherever the annotation has the site on the assumed strand
+						if (flag & KSW_SPLICE_SCORE) { // --spsc (ksw2_exts2_sse.c:196-200): every site is priced, by its score or by junc_pen
+							if (t < tlen - 1) {
+								const int b = jscore(t + 1), donor_val = (sp_for == !sp_revc) ? 0 : 1;
+								dcost = sx8(dcost + ((b == 0xff || (b & 1) != donor_val) ? -L.sc.junc_pen : (b >> 1) - 64));
+								acost = sx8(acost + ((b == 0xff || (b & 1) != !donor_val) ? -L.sc.junc_pen : (b >> 1) - 64));
+							}
+						} else if (nj) { // the bonus is added in the 8-bit lanes (int8 wrap) wherever the annotation has the site on the assumed strand
 							if (t < tlen - 1 && (jbits(t + 1) & jd_mask)) dcost = sx8(dcost + L.sc.junc_bonus);
 							if (t < tlen && (jbits(t) & ja_mask)) acost = sx8(acost + L.sc.junc_bonus);
 						}

@@ -49,12 +49,12 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	}
 	if ((opt.flag & F_SR_RNA) && (opt.flag & F_SPLICE)) {
 		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] splice:sr on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
-		if (fi.has_junc) throw std::invalid_argument("[mm2amd] splice:sr with --junc-bed is not implemented (use -j)");
+		if (fi.has_junc || fi.has_spsc) throw std::invalid_argument("[mm2amd] splice:sr with --junc-bed / --spsc is not implemented (use -j)");
 	}
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
 	if ((opt.flag & F_SPLICE) && fi.has_jump && (opt.flag & F_EQX)) throw std::invalid_argument("[mm2amd] jump annotation (-j) does not work with --eqx (jump.c:197)");
-	if ((opt.flag & F_SPLICE) && fi.has_junc && !be.supports_junctions())
-		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation (--junc-bed) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+	if ((opt.flag & F_SPLICE) && (fi.has_junc || fi.has_spsc) && !be.supports_junctions())
+		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation or splice scores (--junc-bed, --spsc) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0 && !be.supports_sdust())
@@ -333,7 +333,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			parallel_for(n_threads_, mu, [&](long i, int) {
 				if (!per_read_jobs[i].empty()) memcpy(&jobs[job_base[i]], per_read_jobs[i].data(), per_read_jobs[i].size() * sizeof(KswJob));
 			}, 256);
-			if (fi_.has_junc && (opt_.flag & F_SPLICE)) { // the units' junction entries as one pool; the jobs' offsets become pool-wide
+			if ((fi_.has_junc || fi_.has_spsc) && (opt_.flag & F_SPLICE)) { // the units' junction / splice-score entries as one pool; the jobs' offsets become pool-wide
 				std::vector<size_t> &jb = ds.junc_base;
 				jb.resize(mu + 1);
 				jb[0] = 0;
@@ -344,7 +344,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 					if (!ra[i].juncs.empty()) memcpy(&ds.juncs[jb[i]], ra[i].juncs.data(), ra[i].juncs.size() * 4);
 					for (size_t k = job_base[i]; k < job_base[i + 1]; ++k) if (jobs[k].reserved) jobs[k].tag += (uint32_t)jb[i];
 				}, 256);
-				sc.juncs = ds.juncs.data(), sc.n_juncs = jb[mu], sc.junc_bonus = (int8_t)opt_.junc_bonus;
+				sc.juncs = ds.juncs.data(), sc.n_juncs = jb[mu], sc.junc_bonus = (int8_t)opt_.junc_bonus, sc.junc_pen = (int8_t)opt_.junc_pen;
 			}
 			if (opt_.flag & (F_SR_RNA | F_QSTRAND)) { // composed targets (Aligner::add_flank_job, --qstrand windows) as one byte pool; the jobs' offsets become pool-wide
 				std::vector<size_t> &tb = ds.tbyte_base;

@@ -146,7 +146,14 @@ public:
 				cg.resize((size_t)j.qlen + j.tlen + 8);
 				if (sc.single == 2) {
 					const uint8_t *junc = nullptr;
-					if (j.reserved) { // the window's junc[] as mm_idx_bed_junc fills it, in the order the job reads the target
+					if (j.flag & KSW_SPLICE_SCORE) { // the window's junc[] as mm_idx_spsc_get fills it: 0xff where no score is known
+						jbuf.assign((size_t)j.tlen, 0xff);
+						for (uint32_t e = 0; e < j.reserved; ++e) {
+							const uint32_t v = sc.juncs[j.tag + e], pos = v >> 8;
+							jbuf[(j.flag & KSWJ_T_REVERSED) ? (uint32_t)j.tlen - 1 - pos : pos] = (uint8_t)(v & 0xff);
+						}
+						junc = jbuf.data();
+					} else if (j.reserved) { // the window's junc[] as mm_idx_bed_junc fills it, in the order the job reads the target
 						jbuf.assign((size_t)j.tlen, 0);
 						for (uint32_t e = 0; e < j.reserved; ++e) {
 							const uint32_t v = sc.juncs[j.tag + e], pos = v >> 4;
@@ -154,7 +161,7 @@ public:
 						}
 						junc = jbuf.data();
 					}
-					ora_ksw_exts2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.noncan, j.zdrop, j.end_bonus, sc.junc_bonus, 0, j.flag & 0x1fff, junc,
+					ora_ksw_exts2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.noncan, j.zdrop, j.end_bonus, sc.junc_bonus, sc.junc_pen, j.flag & 0x1fff, junc,
 					              &ez, cg.data(), (int)cg.size());
 				}
 				else if (sc.single) ora_ksw_extz2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez, cg.data(), (int)cg.size());

@@ -23,7 +23,8 @@ int main(int argc, char *argv[])
 	mm_mapopt_t mopt;
 	const char *preset = 0;
 	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, staged = 0, old_best_n = -1;
-	const char *alt_fn = 0, *junc_fn = 0, *jump_fn = 0, *pass1_fn = 0;
+	const char *alt_fn = 0, *junc_fn = 0, *jump_fn = 0, *pass1_fn = 0, *spsc_fn = 0;
+	float spsc_scale = 0.7f;
 	int64_t batch = 500000000;
 	kstring_t str = {0, 0, 0};
 
@@ -120,6 +121,9 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--junc-bed") == 0) junc_fn = argv[++k]; /* main.c:244,468 */
 		else if (strcmp(argv[k], "-j") == 0) jump_fn = argv[++k]; /* main.c:202,473 */
 		else if (strcmp(argv[k], "--pass1") == 0) pass1_fn = argv[++k]; /* main.c:478 */
+		else if (strcmp(argv[k], "--spsc") == 0) spsc_fn = argv[++k]; /* main.c:260 */
+		else if (strcmp(argv[k], "--spsc-scale") == 0) spsc_scale = (float)atof(argv[++k]); /* main.c:265 */
+		else if (strcmp(argv[k], "--spsc0") == 0 || strcmp(argv[k], "--junc-pen") == 0) mopt.junc_pen = atoi(argv[++k]); /* main.c:266 */
 		else if (strcmp(argv[k], "--junc-bonus") == 0) mopt.junc_bonus = atoi(argv[++k]); /* main.c:245 */
 		else if (strcmp(argv[k], "--staged") == 0) staged = 1; /* mm_gpu_batch_stage + mm_gpu_map_staged instead of mm_gpu_map_batch */
 		else if (strcmp(argv[k], "--format-lib") == 0) format_lib = 1; /* records written by mm_gpu_format_batch instead of the reference's writers */
@@ -141,6 +145,7 @@ int main(int argc, char *argv[])
 		if (junc_fn) mm_idx_bed_read(mi, junc_fn, 1); /* main.c:468 */
 		if (jump_fn) mm_idx_jjump_read(mi, jump_fn, MM_JUNC_ANNO, -1); /* main.c:473 */
 		if (pass1_fn) mm_idx_jjump_read(mi, pass1_fn, MM_JUNC_MISC, 5); /* main.c:478 */
+		if (spsc_fn) mm_idx_spsc_read2(mi, spsc_fn, mm_max_spsc_bonus(&mopt), spsc_scale); /* main.c:483 */
 		if (alt_fn) mm_idx_alt_read(mi, alt_fn); /* main.c:480 */
 		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
 		/* one read file, or two for paired-end reads (worker_pipeline step 0, map.c:545-569) */

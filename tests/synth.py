@@ -170,6 +170,27 @@ def make_rna_pairs(outdir, seed=41, n_tx=50, pairs_per_tx=4, ref_mb=1.0):
     return ref, f1, f2, bed
 
 
+def make_splice_scores(ref_fa, path, seed=77, every=5):
+    """A splice-score table as --spsc reads it (contig, position, strand, D|A, score): a random site about every `every` bases,
+    random strand / type, scores in [-12, 20], some positions listed twice with different scores."""
+    rng = np.random.default_rng(seed)
+    names, lens = [], []
+    for line in open(ref_fa, "rb"):
+        if line.startswith(b">"):
+            names.append(line[1:].strip().decode())
+        else:
+            lens.append(len(line.strip()))
+    with open(path, "w") as f:
+        for nm, ln in zip(names, lens):
+            pos = np.flatnonzero(rng.random(ln) < 1.0 / every)
+            strand = rng.integers(0, 2, len(pos)); typ = rng.integers(0, 2, len(pos)); sc = rng.integers(-12, 21, len(pos))
+            for k in range(len(pos)):
+                f.write("%s\t%d\t%s\t%s\t%d\n" % (nm, pos[k], "+-"[strand[k]], "DA"[typ[k]], sc[k]))
+                if k % 17 == 0:
+                    f.write("%s\t%d\t%s\t%s\t%d\n" % (nm, pos[k], "+-"[strand[k]], "DA"[typ[k]], sc[k] - 5))
+    return path
+
+
 def make_alt(outdir, seed=51):
     """A primary assembly with two ALT contigs (diverged copies of primary regions, one with an insertion), reads from everywhere
     and from the duplicated regions in particular, and the ALT name list.  Returns (ref.fa, reads.fa, alt.txt)."""

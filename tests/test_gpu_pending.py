@@ -66,3 +66,11 @@ def test_query_strand_mode(kind, args, tmp_path):  # --qstrand: flipped referenc
     else:
         ref, rd = synth.make_weird(str(tmp_path))
     assert _run([REF_BIN, "-t", "8"] + args + [ref, rd]) == _run([DROPIN, "-t", "8"] + args + [ref, rd])
+
+
+@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice", "-c", "--spsc-scale", "1.0"], ["-x", "splice:hq", "-a", "--spsc0", "3"], ["-x", "splice", "-a", "-u", "f"]])
+def test_splice_scores(args, tmp_path):  # --spsc: per-position score lookups in the lane-exact kernel's admit()
+    ref, rd, bed = synth.make_junctions(str(tmp_path), n_reads=40)
+    sp = synth.make_splice_scores(ref, str(tmp_path / "spsc.tsv"))
+    args = args + ["--spsc", sp]
+    assert _run([REF_BIN, "-t", "8"] + args + [ref, rd]) == _run([DROPIN, "-t", "8"] + args + [ref, rd])

@@ -456,3 +456,18 @@ def test_query_strand_mode(kind, args, tmp_path):
     got = subprocess.run([CHECK] + args + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     assert G.strip_pg(want) == G.strip_pg(got)
     assert sum(1 for l in want.split(b"\n") if b"\t-\t" in l) > 0  # reverse-strand hits are what the mode is about
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice", "-c", "--spsc-scale", "1.0"], ["-x", "splice:hq", "-a", "--spsc0", "3"], ["-x", "splice", "-a", "-u", "f"],
+                                  ["-x", "splice", "-a", "--junc-bed", "BED", "-j", "BED"]])
+def test_splice_scores(args, tmp_path):
+    """--spsc: every position of a splice DP window is priced by its score in the table or by junc_pen (mm_idx_spsc_get,
+    index.c:1045-1066; ksw2_exts2_sse.c:196-200); the table takes precedence over --junc-bed (align.c:640-641)."""
+    import synth
+    ref, rd, bed = synth.make_junctions(str(tmp_path), n_reads=40)
+    sp = synth.make_splice_scores(ref, str(tmp_path / "spsc.tsv"))
+    args = [bed if a == "BED" else a for a in args] + ["--spsc", sp]
+    out = _pair(args, ref, rd)
+    plain = subprocess.run([G.REF_BIN] + args[:-2] + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert sum(1 for a, b in zip(out.split(b"\n"), G.strip_pg(plain).split(b"\n")) if a != b) > 20
