@@ -336,8 +336,7 @@ def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm
     assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 100
 
 
-JUNC_CASES = [["-x", "splice", "-a"], ["-x", "splice", "-c"], ["-x", "splice", "-a", "--junc-bonus", "20"], ["-x", "splice:hq", "-a"], ["-x", "splice", "-a", "-u", "n"],
-              ["-x", "splice", "-c", "--cs", "-u", "f"]]
+JUNC_CASES = [["-x", "splice", "-a"], ["-x", "splice", "-a", "--junc-bonus", "20"], ["-x", "splice:hq", "-a", "-u", "n"], ["-x", "splice", "-c", "--cs", "-u", "f"]]
 
 
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
@@ -354,8 +353,7 @@ def test_junction_annotation(args, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
-@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice", "-c"], ["-x", "splice:hq", "-a", "--format-lib"], ["-x", "splice", "-a", "-u", "f"],
-                                  ["-x", "splice", "-a", "--junc-bed", "BED"]])
+@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice:hq", "-c", "--format-lib"], ["-x", "splice", "-a", "-u", "f", "--junc-bed", "BED"]])
 def test_jump_annotation(args, tmp_path):
     """-j: alignment ends clipped next to an annotated junction hop over it when the clipped bases match the other side
     (mm_jump_split, jump.c; host-only post-processing, map.c:362-364).  The fixture has ~50 reads with 3-15 bases beyond an intron."""
@@ -459,8 +457,7 @@ def test_query_strand_mode(kind, args, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
-@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice", "-c", "--spsc-scale", "1.0"], ["-x", "splice:hq", "-a", "--spsc0", "3"], ["-x", "splice", "-a", "-u", "f"],
-                                  ["-x", "splice", "-a", "--junc-bed", "BED", "-j", "BED"]])
+@pytest.mark.parametrize("args", [["-x", "splice", "-a"], ["-x", "splice:hq", "-c", "--spsc-scale", "1.0", "--spsc0", "3", "-u", "f"], ["-x", "splice", "-a", "--junc-bed", "BED", "-j", "BED"]])
 def test_splice_scores(args, tmp_path):
     """--spsc: every position of a splice DP window is priced by its score in the table or by junc_pen (mm_idx_spsc_get,
     index.c:1045-1066; ksw2_exts2_sse.c:196-200); the table takes precedence over --junc-bed (align.c:640-641)."""
