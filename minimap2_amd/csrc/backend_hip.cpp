@@ -22,8 +22,11 @@
 #include "kernel_prof.hpp"
 #include "threads.hpp"
 #include "trace.hpp"
+#include "sdust_core.hpp"
 
 namespace mm2amd {
+
+extern const uint8_t kNt4Table[256];
 
 namespace {
 
@@ -36,7 +39,7 @@ struct Lane {
 	DevBuf<uint32_t> d_mz_cnt, d_sd_n, d_sd_off, d_sd_aoff, d_sd_qpos, d_sd_info, d_n_anchor, d_n_minipos, d_n_seedhit, d_tie;
 	DevBuf<int32_t> d_rep_len, d_f, d_p, d_t;
 	DevBuf<Anchor> d_anchors;
-	DevBuf<uint8_t> d_sort_tmp, d_dust, d_tbytes;
+	DevBuf<uint8_t> d_sort_tmp, d_tbytes;
 	PinBuf<Anchor> h_anchors;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
@@ -45,7 +48,7 @@ struct Lane {
 	DevBuf<Anchor> d_bt_out_a;
 	DevBuf<uint64_t> d_bt_out_u, d_bt_aoff, d_bt_uoff;
 	DevBuf<int32_t> d_bt_nu, d_bt_nv;
-	PinBuf<uint32_t> h_na, h_nmp;
+	PinBuf<uint32_t> h_na, h_nmp, h_dust_n, h_dust_s, h_dust_e;
 	std::vector<uint64_t> a_off, mp_off;
 	~Lane() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -204,9 +207,26 @@ public:
 		kp.begin(st); launch_sketch(Bu, P, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
 		if (has_pairs_) // seed_collect joins the minimizer lists of a pair's two units (collect_minimizers, map.c:59-72); indices are batch-wide
 			B.unit_first = d_unit_first_.p + lo, B.unit_off = d_unit_off_.p, B.unit_cnt = ln.d_mz_cnt.p - ulo, B.mz_cnt = nullptr;
-		if (P.sdust_thres > 0) { // -T: drop minimizers in low-complexity regions (needs the seed arrays as scratch: assigned above)
-			ln.d_dust.ensure(dust_scratch_bytes(dust_threads()));
-			kp.begin(st); launch_dust_filter(B, P, ln.d_dust.p, st); kp.end(st, "dust_filter_kernel", L);
+		if (P.sdust_thres > 0) { // -T: drop minimizers in low-complexity regions (the seed arrays are still unused: they carry the regions)
+			uint32_t *h_n = ln.h_dust_n.ensure(cap_mz + 1), *h_s = ln.h_dust_s.ensure(cap_mz + 1), *h_e = ln.h_dust_e.ensure(cap_mz + 1);
+			const char *asc = h_ascii_.p;
+			parallel_for(n_threads, (long)n_unit, [&](long u, int) { // sdust_core per read on the host, while the sketch kernel runs
+				const uint64_t o = has_pairs_ ? unit_off_[ulo + u] : seq_off_[lo + u];
+				const int len = (int)((has_pairs_ ? unit_off_[ulo + u + 1] : seq_off_[lo + u + 1]) - o);
+				thread_local std::vector<SdustState::Perf> perf(SdustState::PCAP);
+				thread_local std::vector<uint8_t> codes;
+				codes.resize((size_t)len + 1);
+				for (int j = 0; j < len; ++j) codes[j] = kNt4Table[(uint8_t)asc[o + j]];
+				SdustState S;
+				S.P = perf.data();
+				uint32_t k = 0;
+				sdust_scan(codes.data(), len, P.sdust_thres, S, [&](int s0, int e0) { h_s[o - base0 + k] = (uint32_t)s0, h_e[o - base0 + k] = (uint32_t)e0; ++k; });
+				if (len > 0) h_n[o - base0] = k;
+			}, 16);
+			HIP_CHECK(hipMemcpyAsync(ln.d_sd_n.p, h_n, cap_mz * 4, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(ln.d_sd_off.p, h_s, cap_mz * 4, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(ln.d_sd_aoff.p, h_e, cap_mz * 4, hipMemcpyHostToDevice, st));
+			kp.begin(st); launch_dust_filter(B, st); kp.end(st, "dust_filter_kernel", 16.0 * est_mz);
 		}
 		// 2. seeds: probe, filter, count anchors
 		ln.d_n_anchor.ensure(n), ln.d_n_minipos.ensure(n), ln.d_n_seedhit.ensure(n), ln.d_rep_len.ensure(n);
@@ -280,7 +300,7 @@ public:
 		}
 		kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a);
 		// 4. chains: backtrack + compaction on the device, then only the chained anchors travel to the host
-		ln.d_bt_cursor.ensure(2), ln.d_bt_out_a.ensure(n_a + 1), ln.d_bt_out_u.ensure(n_a / 2 + n + 1);
+		ln.d_bt_cursor.ensure(2), ln.d_bt_out_a.ensure(n_a + 1), ln.d_bt_out_u.ensure((P.min_cnt >= 2 ? n_a / 2 : n_a) + n + 1); // a chain has at least max(1, min_cnt) anchors (lchain.c:66)
 		ln.d_bt_nu.ensure(n), ln.d_bt_nv.ensure(n), ln.d_bt_aoff.ensure(n), ln.d_bt_uoff.ensure(n);
 		B.bt_cursor = ln.d_bt_cursor.p, B.bt_out_a = ln.d_bt_out_a.p, B.bt_out_u = ln.d_bt_out_u.p;
 		B.bt_nu = ln.d_bt_nu.p, B.bt_nv = ln.d_bt_nv.p, B.bt_aoff = ln.d_bt_aoff.p, B.bt_uoff = ln.d_bt_uoff.p;

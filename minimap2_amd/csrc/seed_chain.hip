@@ -170,39 +170,31 @@ void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *st
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// SDUST (-T): one thread per fragment masks each of its reads (sdust_core.hpp) and drops the minimizers that lie mostly inside masked
-// regions (mm_dust_minier, map.c:34-57).  The regions go to the seed arrays' slots of the read (unused until seed_collect); the
-// perfect-interval list of a thread lives in `scratch`.
+// SDUST (-T): the masked regions of every read are found on host threads (sdust_core.hpp: a sequential automaton with a sorted
+// interval list that is rewritten at every base -- the wrong shape for a lane) while the sketch kernel runs, and uploaded into the
+// read's still-unused seed slots: sd_n[o] = number of regions, sd_off[o + u] / sd_aoff[o + u] = start / end of region u.  This kernel
+// only drops the minimizers that lie mostly inside masked regions (mm_dust_minier, map.c:34-57), one thread per read.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DUST_THREADS = 8192;
-int dust_threads() { return DUST_THREADS; }
-size_t dust_scratch_bytes(int n_threads) { return (size_t)n_threads * SdustState::PCAP * sizeof(SdustState::Perf); }
-
-__global__ void __launch_bounds__(64) dust_filter_kernel(SeedChainBuffers B, int T, SdustState::Perf *scratch)
+__global__ void __launch_bounds__(64) dust_filter_kernel(SeedChainBuffers B)
 {
-	const int tid = blockIdx.x * 64 + threadIdx.x;
-	SdustState S;
-	S.P = scratch + (size_t)tid * SdustState::PCAP;
-	for (int r = tid; r < B.n_reads; r += gridDim.x * 64) {
-		const int32_t u0 = B.unit_first ? B.unit_first[r] : 0, nu = B.unit_first ? B.unit_first[r + 1] - u0 : 1;
-		for (int32_t k = 0; k < nu; ++k) {
-			const uint64_t o = B.unit_first ? B.unit_off[u0 + k] : B.seq_off[r];
-			const int len = (int)((B.unit_first ? B.unit_off[u0 + k + 1] : B.seq_off[r + 1]) - o);
-			uint32_t *cnt = B.unit_first ? const_cast<uint32_t *>(B.unit_cnt) + (u0 + k) : B.mz_cnt + r;
-			uint32_t *rs = B.sd_off + o, *re = B.sd_aoff + o; // the masked regions of this read
-			int n_reg = 0;
-			sdust_scan(B.qpool + 2 * o, len, T, S, [&](int st, int en) { rs[n_reg] = (uint32_t)st, re[n_reg] = (uint32_t)en; ++n_reg; });
-			if (n_reg == 0) continue;
-			const int pos_off = B.unit_first ? (int)(o - B.unit_off[u0]) : 0;
-			*cnt = (uint32_t)dust_filter_minimizers((int)*cnt, B.mz_x + o, B.mz_y + o, n_reg,
-				[&](int u, int32_t *st, int32_t *en) { *st = (int32_t)rs[u], *en = (int32_t)re[u]; }, pos_off);
-		}
+	const int r = blockIdx.x * 64 + threadIdx.x;
+	if (r >= B.n_reads) return;
+	const int32_t u0 = B.unit_first ? B.unit_first[r] : 0, nu = B.unit_first ? B.unit_first[r + 1] - u0 : 1;
+	for (int32_t k = 0; k < nu; ++k) {
+		const uint64_t o = B.unit_first ? B.unit_off[u0 + k] : B.seq_off[r];
+		uint32_t *cnt = B.unit_first ? const_cast<uint32_t *>(B.unit_cnt) + (u0 + k) : B.mz_cnt + r;
+		const uint32_t *rs = B.sd_off + o, *re = B.sd_aoff + o; // the masked regions of this read
+		const int n_reg = (int)B.sd_n[o];
+		if (n_reg == 0) continue;
+		const int pos_off = B.unit_first ? (int)(o - B.unit_off[u0]) : 0;
+		*cnt = (uint32_t)dust_filter_minimizers((int)*cnt, B.mz_x + o, B.mz_y + o, n_reg,
+			[&](int u, int32_t *st, int32_t *en) { *st = (int32_t)rs[u], *en = (int32_t)re[u]; }, pos_off);
 	}
 }
 
-void launch_dust_filter(const SeedChainBuffers &B, const SeedChainParams &P, void *scratch, void *stream)
+void launch_dust_filter(const SeedChainBuffers &B, void *stream)
 {
-	hipLaunchKernelGGL(dust_filter_kernel, dim3(DUST_THREADS / 64), dim3(64), 0, (hipStream_t)stream, B, P.sdust_thres, (SdustState::Perf *)scratch);
+	hipLaunchKernelGGL(dust_filter_kernel, dim3((B.n_reads + 63) / 64), dim3(64), 0, (hipStream_t)stream, B);
 	HIP_CHECK(hipGetLastError());
 }
 
@@ -983,10 +975,10 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	}
 	__threadfence_block();
 	__syncthreads();
-	// frames hold buckets of more than 64 elements, so at most n/65 per level; large inputs keep the stack in the upper half of u[]'s
-	// scratch region (u needs at most n/3 entries)
-	TieFrame *big_stack = (TieFrame *)(B.sort_key_in + ao + (size_t)n / 2);
-	const int big_cap = (int)(((size_t)n - (size_t)n / 2) * 8 / sizeof(TieFrame));
+	// frames hold buckets of more than 64 elements, so at most n/65 per level; large inputs keep the stack in the upper half of v[]'s
+	// scratch region (v holds at most n 32-bit entries in a region of n 64-bit ones; u[] can need all n entries when min_cnt < 2)
+	TieFrame *big_stack = (TieFrame *)(B.sort_val_in + ao + ((size_t)n + 1) / 2);
+	const int big_cap = (int)(((size_t)n - ((size_t)n + 1) / 2) * 8 / sizeof(TieFrame));
 	bt_sort(K, I, n_z, cnt, head, start, n_z <= BT_LDS_CAP ? stack : big_stack, n_z <= BT_LDS_CAP ? BT_STACK : big_cap, lane); // radix_sort_128x(z, z + n_z), lchain.c:41
 	__threadfence_block();
 	__syncthreads();

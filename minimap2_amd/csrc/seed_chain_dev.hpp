@@ -59,10 +59,7 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 
 void launch_encode(const SeedChainBuffers &B, void *stream);
 void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
-struct SdustPerfSlot; // 4096 perfect-interval entries per thread (sdust_core.hpp)
-size_t dust_scratch_bytes(int n_threads);
-int dust_threads();
-void launch_dust_filter(const SeedChainBuffers &B, const SeedChainParams &P, void *scratch, void *stream);
+void launch_dust_filter(const SeedChainBuffers &B, void *stream); // regions in sd_n / sd_off / sd_aoff (see seed_chain.hip)
 void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
 void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
 size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit);

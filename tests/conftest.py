@@ -8,3 +8,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a GPU case that hangs must cost seconds of box time, not the whole call (pytest-timeout; the full-size cases set their own)
+    for it in items:
+        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(180))

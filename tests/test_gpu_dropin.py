@@ -63,6 +63,12 @@ def test_single_affine_scoring_sam_identical(tmp_path):
     _compare(tmp_path, "hifi", "map-hifi", 3, 60, 16, ["-c", "-O", "6,6", "-E", "2,2"])
 
 
+def test_single_anchor_chains_identical(tmp_path):
+    # -n 1 with a small -m: every anchor may be its own chain (lchain.c:66), so a read has up to as many chains as anchors
+    _compare(tmp_path, "ont", "map-ont", 2, 60, 41, ["-a", "-n", "1", "-m", "10"])
+    _compare(tmp_path, "ont", "map-ont", 2, 60, 42, ["-n", "1", "-m", "10", "-s", "20"])
+
+
 def test_splice_sam_identical(tmp_path):
     # -x splice: chaining with is_cdna, both transcript strands aligned with the splice-aware DP (ksw_exts2), N in CIGARs, ts:A tags
     assert _compare(tmp_path, "cdna", "splice", 6, 500, 17, ["-a"]) > 500

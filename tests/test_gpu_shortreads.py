@@ -109,8 +109,10 @@ def test_python_map_pairs_equals_the_reference_sam(tmp_path):
     _, s2 = fasta(f2)
     al = mm.Aligner(rs, preset="sr", names=[x.decode() for x in rn], sam=True, n_threads=4)
     try:
-        got = al.map_pairs([(nm[:-2], a, b) for nm, a, b in zip(n1, s1, s2)], text=True)
-        hits = al.map_pairs([(nm[:-2], a, b) for nm, a, b in zip(n1[:10], s1[:10], s2[:10])])
+        # the first mate's name goes in as the reader hands it over (with its /1): map.c:246 hashes it into the tie-break, the
+        # formatter trims the suffix (format.c:529)
+        got = al.map_pairs([(nm, a, b) for nm, a, b in zip(n1, s1, s2)], text=True)
+        hits = al.map_pairs([(nm, a, b) for nm, a, b in zip(n1[:10], s1[:10], s2[:10])])
     finally:
         al.close()
     want = b"\n".join(l for l in _run([REF_BIN, "-t", "4", "-x", "sr", "-a", ref, f1, f2]).split(b"\n") if not l.startswith(b"@"))
