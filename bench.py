@@ -24,6 +24,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("MM2AMD_MALLOPT", "1")  # the bench owns its process: let the library keep freed host memory
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md

@@ -82,11 +82,6 @@ public:
 	}
 
 	int n_lanes() const override { return n_lanes_; }
-	// The lane-exact kernel applies the annotation bonus (ksw_extd2.hip, admit()); written after the round's GPU minutes were spent,
-	// so it stays opt-in until tests/test_gpu_pending.py has passed on an MI355X.
-	bool supports_junctions() const override { return getenv("MM2AMD_PENDING") != nullptr; }
-	bool supports_sdust() const override { return getenv("MM2AMD_PENDING") != nullptr; } // dust_filter_kernel: same status
-	bool supports_byte_targets() const override { return getenv("MM2AMD_PENDING") != nullptr; } // splice:sr through the mapper: same status
 	void enable_name_rules() override
 	{
 		if (name_rules_ || fi_names_->empty()) return;

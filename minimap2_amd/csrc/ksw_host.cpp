@@ -11,8 +11,9 @@
 namespace mm2amd {
 
 namespace {
-// Launch classes.  0..5: the register-resident gap-fill kernel (ksw_fast.hip) with 2,3,4,5,6,8 register sets of 64 target
-// columns (its VGPR need, hence its occupancy, grows with the set count, so jobs run with the fewest sets that hold them).
+// Launch classes.  0..5: the register-resident gap-fill kernel (ksw_gapfill.hip), classed by query capacity (512 / 1024 bytes of
+// LDS per job: eight / four waves per SIMD) and by target length (one strip of 256 columns, up to 2-4 strips, more), so that the
+// two jobs of a wave have the same strip count and a class's direction-matrix slots are not sized by its rare giants.
 // 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 512..8192 positions in
 // LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
 // direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
@@ -27,21 +28,22 @@ const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
 const int kSpliceWaves[kSpliceClasses] = { 4, 4, 4 };             // waves per block (splice_wpb in ksw_splice.hip)
 const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 4 };
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
-const int kFastMaxT[kFirstExact] = { 128, 192, 256, 320, 384, 512 };
-const int kFastSets[kFirstExact] = { 2, 3, 4, 5, 6, 8 };
+const int kFastQCap[kFirstExact] = { 512, 512, 512, 1024, 1024, 1024 };
+const int kFastMaxT[kFirstExact] = { 256, 512, 1536, 256, 1024, 3072 };   // <= 3 * query capacity: the kernel's LDS holds the target bytes for the Z-drop scan
 const int kRingSize[kRingClasses] = { 512, 1024, 2048, 4096, 8192, 0 };
 const int kRingWaves[kRingClasses] = { 4, 4, 1, 1, 1, 4 }; // waves per block
 inline size_t dir_limit(int dc) { return dc == kDirClasses - 1 ? SIZE_MAX : (size_t)256 << (10 + dc); } // 256 KB, 512 KB, ... 128 MB, any
-constexpr int kFastQCap = 1024;       // FAST_QCAP of ksw_fast.hip
+constexpr int kFastMaxQ = 1024, kFastMaxTAny = 3072;
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: <= 96 VGPRs -> 5 waves/SIMD
-const int kFastBlocksPerCU[kFirstExact] = { 4, 4, 4, 3, 3, 2 } /* waves per SIMD the kernels are compiled for */;
+inline int fast_waves(int tier) { return kFastQCap[tier] > 512 ? 4 : 6; } // waves per SIMD the gap-fill kernel is compiled for (= blocks of four waves per CU)
+inline int fast_tier(const KswJob &j) { int t = j.qlen <= 512 && j.tlen <= 1536 ? 0 : 3; while (j.tlen > kFastMaxT[t]) ++t; return t; }
 
 // A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
 // score (the gap-fill call, align.c:838), default substitution scores, and a band that cannot bind.
 inline bool fast_eligible(const KswJob &j, bool scoring_ok)
 {
 	if (!scoring_ok || (j.flag & 0x1fff) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
-	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastQCap || j.tlen > 512) return false;
+	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastMaxQ || j.tlen > kFastMaxTAny) return false;
 	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
 }
 // The splice gap fill (align.c:840 with -x splice) may take the register-resident splice kernel: global alignment with the
@@ -57,7 +59,7 @@ inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
-void ksw_fast_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream); // ksw_fast.hip
+void ksw_gapfill_launch(const KswLaunch &L, int n_slots, int qcap, void *stream); // ksw_gapfill.hip
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
@@ -83,7 +85,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	const bool splice_ok = sc.m == 5 && !disable_fast && splice && -min_sc <= 2 * (sc.q + sc.e) && sc.q2 > sc.q + sc.e && sc.e > 0 && sc.q >= 0 && sc.noncan >= 0 &&
 	                       sc.q + sc.e + sc.q2 + sc.noncan + max_abs <= 100;
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
-	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16; double alg_bytes = 0; };
+	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0; };
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
 	const size_t n_chunks = (n + CH - 1) / CH;
 	bucket.resize(n), perm.resize(n);
@@ -100,7 +102,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const bool live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
 			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
-			if (fast) { tier = 0; while (j.tlen > kFastMaxT[tier]) ++tier; }
+			if (fast) tier = fast_tier(j);
 			else if (sfast) {
 				int nc = 0, dc = 0;
 				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
@@ -117,7 +119,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 				tier = kFirstExact + rc * kDirClasses + dc;
 			}
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
-			int cb = fast ? (int)(std::sqrt(cost) * 0.25) : (int)(8.0 * std::log2(cost + 1.0)); // fast classes: cost <= 1536*512; exact classes: any (9 % steps)
+			int cb = fast && j.tlen <= 512 && j.qlen <= 512 ? (int)(std::sqrt(cost) * 0.25) : (int)(8.0 * std::log2(cost + 1.0)); // small gap fills: cost <= 1024*512; other classes: any (9 % steps)
 			if (sfast) cb = (int)(12.0 * std::log2((double)(j.qlen + j.tlen))); // the two jobs of a wave advance row by row: order by row count (6 % steps)
 			if (cb >= NB) cb = NB - 1;
 			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
@@ -133,6 +135,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (!(j.flag & KSW_SCORE_ONLY)) {
 				if (db > 160 * 1024) cs.alg_bytes += (double)db;
 				cs.slot_bytes = std::max(cs.slot_bytes, db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
+				if (fast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
 				st.sum_len += (size_t)j.qlen + j.tlen;
 			}
 		}
@@ -146,6 +149,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			cls[t].alg_bytes += st.cls[t].alg_bytes;
 			cls[t].slot_bytes = std::max(cls[t].slot_bytes, st.cls[t].slot_bytes), cls[t].tmp_cap = std::max(cls[t].tmp_cap, st.cls[t].tmp_cap);
 			cls[t].max_ring = std::max(cls[t].max_ring, st.cls[t].max_ring), cls[t].max_Q16 = std::max(cls[t].max_Q16, st.cls[t].max_Q16);
+			cls[t].max_rows = std::max(cls[t].max_rows, st.cls[t].max_rows), cls[t].max_ncol = std::max(cls[t].max_ncol, st.cls[t].max_ncol);
 		}
 	}
 	size_t tier_beg[kNTiers + 1];
@@ -198,6 +202,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const bool sfast = tier >= kFirstSplice, fast = tier < kFirstExact || sfast; // the register-resident kernels
 			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
 			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
+			// the gap-fill kernel keeps ONE matrix per wave for its two jobs, as many rows as the longer and as many columns as the wider
+			// of the two needs (two rows x two jobs per dword): a pair's two slots together must hold (rows / 2 + 1) x columns dwords
+			if (tier < kFirstExact) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			P.hbm = !fast && rc == kHbmRing;
 			P.ring = fast ? 64 : P.hbm ? cls[tier].max_ring : kRingSize[rc];
@@ -209,7 +216,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
 			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
-			else if (fast) blocks_per_cu = kFastBlocksPerCU[tier];
+			else if (fast) blocks_per_cu = fast_waves(tier);
 			else if (P.hbm) blocks_per_cu = 4;
 			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -225,7 +232,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		d_dir.ensure(need_dir, 1.0);
 		d_cigar_tmp.ensure(need_tmp, 1.0);
 		if (need_state) d_state.ensure(need_state, 1.0);
-		static const char *kFastNames[kFirstExact] = { "ksw_fast_kernel<2>", "ksw_fast_kernel<3>", "ksw_fast_kernel<4>", "ksw_fast_kernel<5>", "ksw_fast_kernel<6>", "ksw_fast_kernel<8>" };
+		static const char *kFastNames[kFirstExact] = { "ksw_gapfill_kernel<512>[t256]", "ksw_gapfill_kernel<512>[t512]", "ksw_gapfill_kernel<512>[t1536]",
+		                                               "ksw_gapfill_kernel<1024>[t256]", "ksw_gapfill_kernel<1024>[t1024]", "ksw_gapfill_kernel<1024>[t3072]" };
 		static const char *kRingNames[kRingClasses] = { "ksw_extd2_kernel[r512]", "ksw_extd2_kernel[r1k]", "ksw_extd2_kernel[r2k]", "ksw_extd2_kernel[r4k]", "ksw_extd2_kernel[r8k]", "ksw_extd2_kernel[hbm]" };
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
@@ -241,7 +249,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.state_pool = P.hbm ? d_state.p : nullptr;
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream);
-			if (tier < kFirstExact) ksw_fast_launch(L, (int)P.n_slots, kFastSets[tier], stream);
+			if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };

@@ -42,27 +42,28 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 {
 	// MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
 	if (opt.flag & F_QSTRAND) { // reverse-strand hits in query-strand coordinates: DP targets are composed (reverse-complemented) into the byte pool
-		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] --qstrand on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] --qstrand needs a backend with composed DP targets");
 		be.enable_seq_len();
 		if ((opt.flag & (F_OUT_SAM | F_SPLICE | F_FRAG_MODE | F_SR | F_HEAP_SORT)) || (fi.flag & I_HPC))
 			throw std::invalid_argument("[mm2amd] --qstrand doesn't work with -a, -H, --frag, --sr, --heap-sort or --splice (options.c:271)");
 	}
 	if ((opt.flag & F_SR_RNA) && (opt.flag & F_SPLICE)) {
-		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] splice:sr on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] splice:sr needs a backend with composed DP targets");
 		if (fi.has_junc || fi.has_spsc) throw std::invalid_argument("[mm2amd] splice:sr with --junc-bed / --spsc is not implemented (use -j)");
 	}
 	if ((opt.flag & F_SR) && (fi.flag & I_HPC)) throw std::invalid_argument("[mm2amd] short-read mode does not work with an HPC index (align.c:655)");
 	if ((opt.flag & F_SPLICE) && fi.has_jump && (opt.flag & F_EQX)) throw std::invalid_argument("[mm2amd] jump annotation (-j) does not work with --eqx (jump.c:197)");
 	if ((opt.flag & F_SPLICE) && (fi.has_junc || fi.has_spsc) && !be.supports_junctions())
-		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation or splice scores (--junc-bed, --spsc) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+		throw std::invalid_argument("[mm2amd] spliced alignment with junction annotation or splice scores (--junc-bed, --spsc) is not supported by this backend");
 	if (opt.flag & (F_NO_DIAG | F_NO_DUAL)) be.enable_name_rules(); // all-vs-all: skip_seed compares read and target names (map.c:81-91)
 	if ((opt.flag & F_CIGAR) && !fi.S) throw std::invalid_argument("[mm2amd] base-level alignment needs an index with sequence (MM_I_NO_SEQ is set)");
 	if (opt.sdust_thres > 0 && !be.supports_sdust())
-		throw std::invalid_argument("[mm2amd] SDUST masking (-T) on the device is not validated on hardware yet; MM2AMD_PENDING=1 enables it");
+		throw std::invalid_argument("[mm2amd] SDUST masking (-T) is not supported by this backend");
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
 	// hand that memory back to the kernel every time turns into page-fault and mmap-lock storms (the reference sidesteps the same
-	// problem with its own kalloc arenas).  Keep freed memory in the process instead.  MM2AMD_NO_MALLOPT=1 leaves malloc alone.
-	if (!getenv("MM2AMD_NO_MALLOPT")) {
+	// problem with its own kalloc arenas).  MM2AMD_MALLOPT=1 keeps freed memory in the process instead.  It is opt-in because it
+	// changes malloc behaviour of the whole embedding process (bench.py and the drop-in driver set it).
+	if (const char *e = getenv("MM2AMD_MALLOPT")) if (atoi(e) > 0) {
 		mallopt(M_MMAP_THRESHOLD, 32 << 20);
 		mallopt(M_TRIM_THRESHOLD, 1 << 30);
 		mallopt(M_TOP_PAD, 64 << 20);

@@ -87,7 +87,7 @@ def test_degenerate_jobs():
 
 @pytest.mark.parametrize("preset", list(PRESETS))
 def test_register_resident_gap_fill_kernel(preset):
-    """jobs that take ksw_fast.hip (flag 0x08, non-binding band): every register-set boundary, N bases, long indels, unrelated
+    """jobs that take ksw_gapfill.hip (flag 0x08, non-binding band): every register-set boundary, N bases, long indels, unrelated
     sequences, extreme aspect ratios -- against the lane-exact oracle, and A/B against the exact HIP kernel"""
     import minimap2_amd as mm
     rng = np.random.default_rng(77)
@@ -126,6 +126,35 @@ def test_register_resident_gap_fill_kernel(preset):
     finally:
         del os.environ["MM2AMD_KSW_EXACT_ONLY"]
     assert fast == exact
+
+
+@pytest.mark.parametrize("preset", ["ont", "asm5"])
+def test_gap_fill_kernel_column_strips(preset):
+    """ksw_gapfill.hip sweeps targets wider than 256 columns in strips of 256 (boundary column handed over through LDS), with two
+    query capacities (512 / 1024) and targets up to three times that: strip boundaries, class boundaries, pairs whose jobs need
+    different strip counts, queries shorter than / as long as / longer than the capacity -- against the lane-exact oracle"""
+    rng = np.random.default_rng(79)
+    jobs = []
+    for tl in (257, 511, 512, 513, 767, 768, 769, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2049, 3071, 3072, 3073):
+        for ql in (1, 40, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025):
+            if rng.random() < 0.55:
+                continue
+            if rng.random() < 0.5:
+                q, t = random_pair(rng, max(ql, tl), 0.12, 0.02)
+                q, t = q[:ql], t[:tl]
+            else:
+                q, t = rng.integers(0, 4, ql, dtype=np.uint8), rng.integers(0, 4, tl, dtype=np.uint8)
+            jobs.append((q, t, 30001, 400, -1, 0x08))
+    for it in range(60):  # related sequences with a long indel crossing a strip boundary, some N bases
+        n = int(rng.integers(300, 1000))
+        q, t = random_pair(rng, n, float(rng.choice([0.05, 0.12])), 0.02, int(rng.choice([0, 60, -60, 300, -300])))
+        if len(q) > 1024:
+            q = q[:1024]
+        if it % 5 == 0:
+            t = t.copy()
+            t[rng.integers(0, len(t), 5)] = 4
+        jobs.append((q, t, -1 if it % 2 else len(q) + len(t), 400, -1, 0x08))
+    _run(jobs, preset)
 
 
 def test_jobs_longer_than_lds_use_the_hbm_state_kernel():

@@ -18,7 +18,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int ITERS = 2048;
+constexpr int ITERS = 32768; // x16 instructions: milliseconds per launch, long enough for the clocks to settle after the warm-up
 
 #define REP16_2OP(ins) \
 	asm volatile(ins " %0, %0, %8\n" ins " %1, %1, %8\n" ins " %2, %2, %8\n" ins " %3, %3, %8\n" \
@@ -40,25 +40,56 @@ constexpr int ITERS = 2048;
 	             "v_mov_b32_dpp %4, %5 " mod "\nv_mov_b32_dpp %5, %6 " mod "\nv_mov_b32_dpp %6, %7 " mod "\nv_mov_b32_dpp %7, %0 " mod "\n" \
 	             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
 
-enum Kind { K_ADD_U32, K_PK_ADD, K_PK_SUB, K_PK_MAX, K_PK_MINU, K_PK_MUL, K_PK_MAD, K_PK_SHR, K_BFI, K_XOR, K_PERM, K_DPP_WAVE_SHR, K_DPP_ROW_SHR,
-            K_READLANE, K_READLANE_DPP_PAIR, K_LDS_U8, K_LDS_B32, K_ST_BYTE, K_ST_DWORD, K_ST_DWORDX4, K_MIX_DP, K_N };
-static const char *kNames[K_N] = { "v_add_u32", "v_pk_add_u16", "v_pk_sub_u16", "v_pk_max_i16", "v_pk_min_u16", "v_pk_mul_lo_u16", "v_pk_mad_u16",
+enum Kind { K_ADD_U32, K_ADD_U32_E64, K_MAX_I32, K_ADD_U16, K_MAX_I16, K_ADD3, K_AND_OR, K_CNDMASK, K_CMP, K_SDWA, K_ALT_VOP2_PK, K_PK_ADD, K_PK_SUB, K_PK_MAX, K_PK_MINU, K_PK_MUL, K_PK_MAD, K_PK_SHR, K_BFI, K_XOR, K_PERM, K_DPP_WAVE_SHR, K_DPP_ROW_SHR,
+            K_READLANE, K_READLANE_DPP_PAIR, K_LDS_U8, K_LDS_B32, K_ST_BYTE, K_ST_DWORD, K_ST_DWORDX4, K_MIX_DP, K_MIX_NOP, K_MIX_SALU, K_N };
+static const char *kNames[K_N] = { "v_add_u32", "v_add_u32_e64 (VOP3 encoding)", "v_max_i32", "v_add_u16", "v_max_i16", "v_add3_u32", "v_and_or_b32", "v_cndmask_b32 (vcc)", "v_cmp_lt_i32 (-> vcc)", "v_add_u32_sdwa", "alternating v_add_u32 / v_pk_add_u16", "v_pk_add_u16", "v_pk_sub_u16", "v_pk_max_i16", "v_pk_min_u16", "v_pk_mul_lo_u16", "v_pk_mad_u16",
 	"v_pk_lshrrev_b16", "v_bfi_b32", "v_xor_b32", "v_perm_b32", "v_mov_b32_dpp wave_shr:1", "v_mov_b32_dpp row_shr:1", "v_readlane_b32",
 	"v_readlane_b32 + v_mov_dpp wave_shr (carry idiom)", "ds_read_u8", "ds_read_b32", "global_store_byte (64 B / wave-instr)",
-	"global_store_dword (256 B / wave-instr)", "global_store_dwordx4 (1 KiB / wave-instr)", "DP cell body of ksw_fast (52 pk ops)" };
+	"global_store_dword (256 B / wave-instr)", "global_store_dwordx4 (1 KiB / wave-instr)", "DP cell body of ksw_fast (52 pk ops)", "DP cell body + s_nop 0 after every 2-operand op", "DP cell body + 2 SALU after every 2-operand op" };
 
 template <int KIND>
-__global__ void __launch_bounds__(256) bench_kernel(uint32_t *out, unsigned long long *cyc, uint8_t *scratch, int iters)
+__global__ void __launch_bounds__(256, 2) bench_kernel(uint32_t *out, unsigned long long *cyc, uint8_t *scratch, int iters)
 {
-	__shared__ uint32_t lds[4096];
+	__shared__ uint32_t lds[4096]; // 16 KiB: eight blocks per CU fit
 	const int tid = blockIdx.x * 256 + threadIdx.x;
 	for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * 2654435761u;
 	__syncthreads();
 	uint32_t a0 = tid, a1 = tid + 1, a2 = tid + 2, a3 = tid + 3, a4 = tid + 4, a5 = tid + 5, a6 = tid + 6, a7 = tid + 7, b = 0x00010003u;
 	uint8_t *wbase = scratch + (size_t)(tid >> 6) * 65536; // 64 KiB of scratch per wave, rewritten over and over (stays in L2)
+	const unsigned long long w0 = wall_clock64();
 	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 	for (int it = 0; it < iters; ++it) {
 		if (KIND == K_ADD_U32) REP16_2OP("v_add_u32");
+		else if (KIND == K_ADD_U32_E64) REP16_2OP("v_add_u32_e64");
+		else if (KIND == K_MAX_I32) REP16_2OP("v_max_i32");
+		else if (KIND == K_ADD_U16) REP16_2OP("v_add_u16");
+		else if (KIND == K_MAX_I16) REP16_2OP("v_max_i16");
+		else if (KIND == K_ADD3) REP16_3OP("v_add3_u32");
+		else if (KIND == K_AND_OR) REP16_3OP("v_and_or_b32");
+		else if (KIND == K_CNDMASK) {
+			asm volatile("v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
+			             "v_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n"
+			             "v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
+			             "v_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+		} else if (KIND == K_CMP) {
+			asm volatile("v_cmp_lt_i32 vcc, %0, %8\nv_cmp_lt_i32 vcc, %1, %8\nv_cmp_lt_i32 vcc, %2, %8\nv_cmp_lt_i32 vcc, %3, %8\n"
+			             "v_cmp_lt_i32 vcc, %4, %8\nv_cmp_lt_i32 vcc, %5, %8\nv_cmp_lt_i32 vcc, %6, %8\nv_cmp_lt_i32 vcc, %7, %8\n"
+			             "v_cmp_lt_i32 vcc, %0, %8\nv_cmp_lt_i32 vcc, %1, %8\nv_cmp_lt_i32 vcc, %2, %8\nv_cmp_lt_i32 vcc, %3, %8\n"
+			             "v_cmp_lt_i32 vcc, %4, %8\nv_cmp_lt_i32 vcc, %5, %8\nv_cmp_lt_i32 vcc, %6, %8\nv_cmp_lt_i32 vcc, %7, %8\n"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+		} else if (KIND == K_SDWA) {
+#define SD(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+			asm volatile(SD("%0") SD("%1") SD("%2") SD("%3") SD("%4") SD("%5") SD("%6") SD("%7") SD("%0") SD("%1") SD("%2") SD("%3") SD("%4") SD("%5") SD("%6") SD("%7")
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+#undef SD
+		} else if (KIND == K_ALT_VOP2_PK) {
+			asm volatile("v_add_u32 %0, %0, %8\nv_pk_add_u16 %1, %1, %8\nv_add_u32 %2, %2, %8\nv_pk_add_u16 %3, %3, %8\n"
+			             "v_add_u32 %4, %4, %8\nv_pk_add_u16 %5, %5, %8\nv_add_u32 %6, %6, %8\nv_pk_add_u16 %7, %7, %8\n"
+			             "v_add_u32 %0, %0, %8\nv_pk_add_u16 %1, %1, %8\nv_add_u32 %2, %2, %8\nv_pk_add_u16 %3, %3, %8\n"
+			             "v_add_u32 %4, %4, %8\nv_pk_add_u16 %5, %5, %8\nv_add_u32 %6, %6, %8\nv_pk_add_u16 %7, %7, %8\n"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+		}
 		else if (KIND == K_PK_ADD) REP16_2OP("v_pk_add_u16");
 		else if (KIND == K_PK_SUB) REP16_2OP("v_pk_sub_u16");
 		else if (KIND == K_PK_MAX) REP16_2OP("v_pk_max_i16");
@@ -108,12 +139,14 @@ __global__ void __launch_bounds__(256) bench_kernel(uint32_t *out, unsigned long
 				u32x4 v = { a0, a1, a2, a3 };
 				__builtin_nontemporal_store(v, (u32x4 *)wbase + (((it * 16 + k) * 64 & 4095) + (threadIdx.x & 63)));
 			}
-		} else if (KIND == K_MIX_DP) { // the arithmetic of one DP cell pair (ksw_fast.hip row body without operand fetch / stores): 52 packed ops
+		} else if (KIND == K_MIX_DP || KIND == K_MIX_NOP || KIND == K_MIX_SALU) { // the arithmetic of one DP cell pair (ksw_fast.hip row body without operand fetch / stores): 52 packed ops
 #pragma unroll
 			for (int k = 0; k < 2; ++k) {
+				uint32_t sacc = b;
 				uint32_t z, a, bb, a2_, b2_, z1, z2, z3, z4, d, tmp;
 				const uint32_t ONE = 0x00010001u;
-#define P2(r, ins, x, y) asm volatile(ins " %0, %1, %2" : "=v"(r) : "v"(x), "v"(y))
+#define XTRA (KIND == K_MIX_NOP ? "\n\ts_nop 0" : KIND == K_MIX_SALU ? "\n\ts_add_u32 %3, %3, 1\n\ts_nop 0" : "")
+#define P2(r, ins, x, y) do { if (KIND == K_MIX_DP) asm volatile(ins " %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); else if (KIND == K_MIX_NOP) asm volatile(ins " %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(x), "v"(y)); else asm volatile(ins " %0, %1, %2\n\ts_add_u32 %3, %3, 1\n\ts_and_b32 %3, %3, 0xffff" : "=v"(r) : "v"(x), "v"(y), "s"(sacc)); } while (0)
 #define P3(r, ins, x, y, w) asm volatile(ins " %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(w))
 				uint32_t tq; P2(tq, "v_xor_b32", a0, a1);
 				P2(z, "v_pk_min_u16", tq, ONE); P3(z, "v_pk_mad_u16", z, b, b);
@@ -134,6 +167,7 @@ __global__ void __launch_bounds__(256) bench_kernel(uint32_t *out, unsigned long
 				P2(f, "v_pk_min_u16", m2, ONE); P3(d, "v_pk_mad_u16", f, b, d); P2(f, "v_pk_min_u16", m3, ONE); P3(d, "v_pk_mad_u16", f, b, d);
 				P2(a2, "v_pk_sub_u16", m0, b); P2(a4, "v_pk_sub_u16", m1, b); P2(a6, "v_pk_sub_u16", m2, b); P2(a7, "v_pk_sub_u16", m3, b);
 				a0 ^= d;
+#undef XTRA
 #undef P2
 #undef P3
 			}
@@ -142,34 +176,33 @@ __global__ void __launch_bounds__(256) bench_kernel(uint32_t *out, unsigned long
 	__builtin_amdgcn_s_waitcnt(0);
 	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 	out[tid] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ b;
-	if ((threadIdx.x & 63) == 0) cyc[tid >> 6] = t1 - t0;
+	const unsigned long long w1 = wall_clock64();
+	if ((threadIdx.x & 63) == 0) cyc[tid >> 6] = t1 - t0, cyc[(size_t)gridDim.x * 4 + (tid >> 6)] = w1 - w0;
 }
+
+static double g_wall_hz = 1e8;
 
 template <int KIND>
 static void run(int n_cu, uint32_t *d_out, unsigned long long *d_cyc, uint8_t *d_scratch, double per_iter, FILE *fp)
 {
-	double res[3], wall[3];
-	const int wps[3] = { 1, 2, 4 };
-	for (int wi = 0; wi < 3; ++wi) {
+	const int wps[4] = { 1, 2, 4, 8 };
+	const bool slow = KIND == K_ST_BYTE || KIND == K_ST_DWORD || KIND == K_ST_DWORDX4 || KIND == K_LDS_U8 || KIND == K_LDS_B32 || KIND == K_MIX_DP || KIND == K_MIX_NOP || KIND == K_MIX_SALU || KIND == K_READLANE_DPP_PAIR;
+	const int iters = slow ? ITERS / 16 : ITERS;
+	fprintf(fp, "%-50s", kNames[KIND]);
+	for (int wi = 0; wi < 4; ++wi) {
 		const int blocks = n_cu * wps[wi];
-		hipEvent_t e0, e1;
-		CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, 64); // warm-up
-		CHECK(hipEventRecord(e0));
-		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, ITERS);
-		CHECK(hipEventRecord(e1));
+		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters / 8); // warm-up
+		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters);
 		CHECK(hipDeviceSynchronize());
-		float ms;
-		CHECK(hipEventElapsedTime(&ms, e0, e1));
-		std::vector<unsigned long long> c((size_t)blocks * 4);
+		std::vector<unsigned long long> c((size_t)blocks * 8);
 		CHECK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
-		std::sort(c.begin(), c.end());
-		const double med = (double)c[c.size() / 2];
-		res[wi] = med / ((double)ITERS * per_iter * wps[wi]); // s_memtime ticks per wave-instruction per SIMD (all waves of a SIMD progress together)
-		wall[wi] = ms * 1e-3 / ((double)ITERS * per_iter * wps[wi]); // seconds per wave-instruction per SIMD
+		std::vector<unsigned long long> mt(c.begin(), c.begin() + (size_t)blocks * 4), wl(c.begin() + (size_t)blocks * 4, c.end());
+		std::sort(mt.begin(), mt.end()); std::sort(wl.begin(), wl.end());
+		const double n_instr = (double)iters * per_iter * wps[wi]; // wave-instructions one SIMD issues while a wave runs
+		const double ns = (double)wl[wl.size() / 2] / g_wall_hz * 1e9 / n_instr, ticks = (double)mt[mt.size() / 2] / n_instr;
+		fprintf(fp, " | W=%d %6.3f ns %6.3f tk", wps[wi], ns, ticks);
 	}
-	fprintf(fp, "%-52s  memtime ticks/instr/SIMD @1,2,4 waves: %7.3f %7.3f %7.3f   wall ns/instr/SIMD: %6.3f %6.3f %6.3f\n", kNames[KIND], res[0], res[1], res[2],
-	        wall[0] * 1e9, wall[1] * 1e9, wall[2] * 1e9);
+	fprintf(fp, "\n");
 	fflush(fp);
 }
 
@@ -179,13 +212,26 @@ int main()
 	CHECK(hipGetDeviceProperties(&p, 0));
 	const int n_cu = p.multiProcessorCount;
 	printf("device %s, %d CUs, clockRate %d kHz; ITERS %d; blocks of 256 threads (one wave per SIMD), W blocks per CU\n", p.gcnArchName, n_cu, p.clockRate, ITERS);
-	printf("s_memtime ticks: see the v_add_u32 row for the tick <-> issue-cycle ratio (a full-rate wave64 VALU op = 2 shader cycles)\n");
 	uint32_t *d_out; unsigned long long *d_cyc; uint8_t *d_scratch;
-	const size_t n_waves = (size_t)n_cu * 4 * 4;
-	CHECK(hipMalloc(&d_out, n_waves * 64 * 4)); CHECK(hipMalloc(&d_cyc, n_waves * 8)); CHECK(hipMalloc(&d_scratch, n_waves * 65536));
+	const size_t n_waves = (size_t)n_cu * 4 * 8;
+	CHECK(hipMalloc(&d_out, n_waves * 64 * 4)); CHECK(hipMalloc(&d_cyc, n_waves * 16)); CHECK(hipMalloc(&d_scratch, n_waves * 65536));
 	FILE *fp = stdout;
+	int wall_khz = 100000;
+	if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && wall_khz > 0) g_wall_hz = wall_khz * 1e3;
+	printf("wall_clock64 rate %d kHz; columns: W waves per SIMD -> ns and s_memtime ticks per wave-instruction per SIMD (median wave)\n", wall_khz);
+	for (int k = 0; k < 40; ++k) hipLaunchKernelGGL((bench_kernel<K_PK_ADD>), dim3(n_cu * 4), dim3(256), 0, 0, d_out, d_cyc, d_scratch, ITERS); // clocks up
+	CHECK(hipDeviceSynchronize());
 	run<K_ADD_U32>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_ADD_U32_E64>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_MAX_I32>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_ADD_U16>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_MAX_I16>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_XOR>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_CNDMASK>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_CMP>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_SDWA>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_ADD3>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_AND_OR>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_BFI>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_PERM>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_PK_ADD>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
@@ -195,6 +241,7 @@ int main()
 	run<K_PK_MUL>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_PK_MAD>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_PK_SHR>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
+	run<K_ALT_VOP2_PK>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_DPP_WAVE_SHR>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_DPP_ROW_SHR>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_READLANE>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
@@ -205,5 +252,6 @@ int main()
 	run<K_ST_DWORD>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_ST_DWORDX4>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
 	run<K_MIX_DP>(n_cu, d_out, d_cyc, d_scratch, 2, fp); // per cell-pair body (52 packed ops + 3 plain)
+	run<K_MIX_NOP>(n_cu, d_out, d_cyc, d_scratch, 2, fp);
 	return 0;
 }
