@@ -1,14 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- aligned Gbases/s of the seed-chain-extend hot path on MI355X (BASELINE.json: map-ont, ~10 kb reads, -a).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--ref-mb 3000] [--reads 100000]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ref-mb 3000] [--reads 100000] [--scaling strong|weak]
 
 One "step" = one pass of the hot path (mm_gpu_map_staged: encode -> sketch -> seed -> sort -> chain -> extend -> hits)
-over one batch of --reads synthetic ONT-like reads per GPU, already resident in HBM when the clock starts.  The workload
+over one batch of --reads synthetic ONT-like reads, already resident in HBM when the clock starts.  The workload
 is BASELINE.json configs[1]: uniform-random reference of --ref-mb megabases in 24 contigs, reads ~N(10 kb, 1 kb) with 12 %
 error (1/3 substitution, 1/3 insertion, 1/3 deletion), preset map-ont, CIGAR output.  N > 1 (one process per GPU under
-torch.distributed.run): every rank builds the same index replica and maps its own batch (weak scaling: per-GPU work fixed);
-the packed hit records are gathered to rank 0 over RCCL inside the timed region.
+torch.distributed.run): every rank builds the same index replica; with --scaling strong (the default: BASELINE.json configs[2],
+"same workload sharded across 8 GPUs") all ranks generate the SAME batch and each maps its contiguous, base-balanced share
+(minimap2_amd/shard.py: split_by_bases); with --scaling weak every rank maps a batch of --reads of its own.  The packed hit
+records are gathered to rank 0 over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line.  "roofline" is the dominant kernel's algorithmic bytes / its HIP-event time on the launch
 stream; "cpu_baseline" is the UNMODIFIED reference's mm_map on all host cores over a bounded sample of the same batch
@@ -180,7 +182,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ref-mb", type=float, default=3000.0)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=100000, help="reads per step (strong scaling: of the whole job; weak: per GPU)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: shard one batch (strong) or give every rank its own (weak)")
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (0: min(64, cores / gpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", default="map-ont", choices=["map-ont", "map-hifi", "lr:hq", "splice", "sr"],
@@ -227,14 +230,24 @@ def main():
     mean_len = a.read_len if a.read_len > 0 else {"map-ont": 10000, "splice": 2000, "sr": 150}.get(a.preset, 15000)
     err = a.err if a.err >= 0 else {"map-ont": 0.12, "splice": 0.05}.get(a.preset, 0.005)
     pairs = a.preset == "sr"
+    strong = a.scaling == "strong" and world > 1
+    rseed = 1000 if strong else 1000 + rank  # strong scaling: one batch, the same on every rank
     if pairs:
-        reads, mates = gen_pairs(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, err)
+        reads, mates = gen_pairs(torch, dev, rseed, codes, per, n_contig, a.reads, mean_len, err)
     elif a.preset == "splice":
-        reads = gen_transcripts(torch, dev, 1000 + rank, codes, genes, a.reads, err)
+        reads = gen_transcripts(torch, dev, rseed, codes, genes, a.reads, err)
     else:
-        reads = gen_reads(torch, dev, 1000 + rank, codes, per, n_contig, a.reads, mean_len, mean_len // 10, err)
+        reads = gen_reads(torch, dev, rseed, codes, per, n_contig, a.reads, mean_len, mean_len // 10, err)
     del codes
     torch.cuda.empty_cache()
+    if strong:  # this rank's share: contiguous, balanced by bases (pairs stay together: both mates in one entry)
+        cut = shard.split_by_bases([len(r) + (len(mates[i]) if pairs else 0) for i, r in enumerate(reads)], world)
+        first_read = cut[rank]
+        reads = reads[cut[rank]:cut[rank + 1]]
+        if pairs:
+            mates = mates[cut[rank]:cut[rank + 1]]
+    else:
+        first_read = 0
     batch_bases = sum(len(r) for r in reads) + (sum(len(r) for r in mates) if pairs else 0)
     log("rank %d: %d %s, %.3f Gbases generated in %.1f s" % (rank, len(reads), "read pairs" if pairs else "reads", batch_bases / 1e9, time.time() - t0))
     t0 = time.time()
@@ -242,7 +255,7 @@ def main():
     t_index = time.time() - t0
     st = al.index_stat()
     log("rank %d: device index built in %.1f s: %d distinct minimizers, %d positions, mid_occ=%d" % (rank, t_index, st["n_distinct"], st["n_minimizers"], al.map_opt.mid_occ))
-    named = [("read%d" % i, s, mates[i]) for i, s in enumerate(reads)] if pairs else [("read%d" % i, s) for i, s in enumerate(reads)]
+    named = [("read%d" % (first_read + i), s, mates[i]) for i, s in enumerate(reads)] if pairs else [("read%d" % (first_read + i), s) for i, s in enumerate(reads)]
 
     def barrier():
         if world > 1:
@@ -284,6 +297,24 @@ def main():
     log("rank %d: host CPU time per step %.2f core-seconds (%d threads)" % (rank, host_cpu_s, n_threads))
     prof = mm.profile_get()
     mm.profile_enable(False)
+    # un-overlapped kernel times: one more pass over the same batch with ONE lane (sub-batches one after the other, so no two
+    # kernels of the path run at the same time and HIP-event spans are costs); feeds roofline.valu and roofline.unoverlapped_ms
+    prof1 = None
+    if rank == 0:
+        os.environ["MM2AMD_ACTIVE_LANES"] = "1"
+        mm.profile_enable(True)
+        t_one = one_step(a.warmup + a.steps) if world == 1 else None
+        prof1 = mm.profile_get() if world == 1 else None
+        mm.profile_enable(False)
+        del os.environ["MM2AMD_ACTIVE_LANES"]
+    # the boundary hands over host buffers: one pass with the hand-over (pack + H2D of the reads) inside the clock
+    pcie = None
+    if world == 1:
+        t = time.time()
+        al.stage(named)
+        n_reg, reg, _ = al.run(raw=True)
+        pcie = time.time() - t
+        al.free_raw(n_reg, reg)
     # host output stage, outside the timed region: SAM text of one batch's hits on the pool threads
     fmt = None
     try:
@@ -315,25 +346,37 @@ def main():
         return
 
     value = all_bases * a.steps / total_t / 1e9
-    # roofline of the dominant kernel: algorithmic bytes / HIP-event time on the launch stream
+    # roofline of the dominant kernel.  "hbm": algorithmic bytes / HIP-event time on the launch stream,
+    # from the timed steps.  "valu": what actually bounds it -- DP cells per second of the un-overlapped pass against the VALU issue
+    # peak of its own instruction stream (72 VALU instructions per 128 cells in the ISA, a wave64 VALU
+    # instruction = 2 cycles on a SIMD-32, 1024 SIMDs at 2.4 GHz, every lane useful).
     roof = None
     if prof:
-        family = lambda k: k.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_fast_kernel<4>, <5>, ...) count together
+        family = lambda k: k.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_gapfill_kernel<512>[t256], ...) count together
+        src = prof1 or prof  # dominance by un-overlapped cost when we have it
         fam_total = {}
-        for k, v in prof.items():
+        for k, v in src.items():
             fam_total[family(k)] = fam_total.get(family(k), 0.0) + v["ms"]
         fam = max(fam_total, key=fam_total.get)
         same = {k: v for k, v in prof.items() if family(k) == fam}
         fam_ms = sum(v["ms"] for v in same.values())
         fam_bytes = sum(v["alg_bytes"] for v in same.values())
         fam_launch = sum(v["launches"] for v in same.values())
-        ach = fam_bytes / (fam_ms * 1e-3) / 1e9
+        ach = fam_bytes / max(fam_ms * 1e-3, 1e-12) / 1e9
         roof = {"bound": "hbm", "kernel": fam, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6),
                 "traffic": None, "avg_launch_ms": round(fam_ms / max(fam_launch, 1), 4), "launches": fam_launch,
                 "alg_bytes_per_launch": round(fam_bytes / max(fam_launch, 1), 1),
-                "dp_gcups": round(al.last_stats().get("dp_cells", 0.0) * a.steps / max(sum(v["ms"] for k, v in prof.items() if k.startswith("ksw_")), 1e-9) / 1e6, 1),
-                "note": "integer DP: VALU-issue-bound, not HBM-bound (DESIGN.md section 4); dp_gcups = DP cells of the timed steps / summed DP kernel time (kernels of concurrent lanes overlap, so this understates the device rate); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
+                "note": "integer DP: bound by VALU issue, not by HBM (see 'valu'; DESIGN.md section 4); hbm figures = algorithmic bytes of the timed steps / HIP-event time of the family on its launch streams (lanes overlap); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())}}
+        if prof1:
+            one = {k: v for k, v in prof1.items() if family(k) == fam}
+            ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
+            peak_cells = 1024 * 2.4e9 * 128 / (72 * 2.0)
+            roof["valu"] = {"bound": "valu", "kernel": fam, "cells_per_s": round(cells1 / max(ms1 * 1e-3, 1e-12), 1), "issue_peak_cells_per_s": round(peak_cells, 1),
+                            "frac": round(cells1 / max(ms1 * 1e-3, 1e-12) / peak_cells, 4), "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
+                            "basis": "one extra pass with a single lane (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / (72 VALU instructions x 2 cycles), i.e. every lane useful (the measured lane utilisation of the anti-diagonal sweep is 0.73)"}
+            roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
+            roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1)
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
@@ -388,11 +431,12 @@ def main():
 
     rl = "2 x %d b reads" % mean_len if pairs else "%d kb reads" % (mean_len // 1000)
     out = {"metric": "aligned Gbases/sec (%s, %s, -a)" % (a.preset, rl), "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
-           "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None,
            "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
-           "config": {"workload": "%s: %d synthetic %s per GPU (%g%% error) vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, ("read pairs, " + rl) if pairs else ("~" + rl), err * 100, total // 1000000),
-                      "reads_per_gpu": a.reads, "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads, "host_cpu_s_per_step": round(host_cpu_s, 2),
-                      "parallelism": "replicated index, reads sharded %d-way, RCCL hit gather" % world if world > 1 else "1 GPU",
+           "config": {"workload": "%s: %d synthetic %s %s (%g%% error) vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, ("read pairs, " + rl) if pairs else ("~" + rl), "per GPU" if (world > 1 and not strong) else "per step", err * 100, total // 1000000),
+                      "reads_per_step": a.reads * (world if (world > 1 and not strong) else 1), "reads_this_rank": len(reads), "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads, "host_cpu_s_per_step": round(host_cpu_s, 2),
+                      "parallelism": "replicated index, %s, RCCL hit gather" % ("one batch sharded %d-way by bases" % world if strong else "%d independent batches" % world) if world > 1 else "1 GPU",
+                      "pcie_inclusive_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},
            "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
     print(json.dumps(out), flush=True)

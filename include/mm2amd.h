@@ -131,6 +131,16 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BS
 /* As mm_gpu_init, for an index built by mm2amd_idx_str (which must outlive the mapper). */
 int mm_gpu_init_index(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int n_threads);
 
+/* Several GPUs behind the same hook (the reference has ONE kt_for call per mini-batch, map.c:576, so the
+ * dispatcher lives below it): n_gpus replicas, each with a full copy of the index in its device's HBM, map contiguous shares of
+ * every batch cut by cumulative bases -- independent shares, no exchange between devices, results straight into the caller's
+ * host arrays.  device_ids: HIP ordinals (NULL: 0 .. n_gpus-1); an ordinal may repeat (several replicas on one device: tests on
+ * a single-GPU machine).  n_gpus <= 0: $MM2AMD_GPUS, else 1 -- which is what mm_gpu_init / mm_gpu_init_index pass.  n_threads
+ * is the host pool of the whole context (<= 0: 64 per GPU, capped by the hardware threads), divided among the replicas. */
+int mm_gpu_init_multi(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_threads, int n_gpus, const int *device_ids);
+int mm_gpu_init_index_multi(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int n_threads, int n_gpus, const int *device_ids);
+int mm_gpu_n_replicas(void);                     /* replicas of the live context (0: none) */
+
 /* mm_gpu_map_batch in two halves: mm_gpu_batch_stage copies the batch's sequences to the device (the hand-over the
  * reference's pipeline step 0 makes, map.c:543-575) and returns when they are resident; mm_gpu_map_staged runs the
  * hot path on the staged batch (results placed as mm_gpu_map_batch places them: read seg_off[i] + j of fragment i).  seq, and the
@@ -143,7 +153,8 @@ int mm_gpu_map_staged(int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap
  * The text is byte-identical to what that loop prints -- SAM or PAF by MM_F_OUT_SAM, cg/cs/ds/MD/ts/SA tags, unmapped records
  * by MM_F_PAF_NO_HIT / MM_F_SAM_HIT_ONLY, secondaries by MM_F_NO_PRINT_2ND -- but produced on the host thread pool.
  * Arguments as for mm_gpu_map_batch (results as it returned them); *out receives ONE malloc'd block of '\n'-terminated
- * records in input order (free() it), *out_len its length.  Single-segment fragments only; no RG tag; uses the index and
+ * records in input order (free() it), *out_len its length.  Fragments of one or two segments (mate fields of mm_write_sam3,
+ * /1 /2 names of mm_write_paf4); no RG tag; uses the index and
  * options given to mm_gpu_init. */
 int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq, const int *n_reg, void *const *reg,
                         const int *rep_len, char **out, size_t *out_len);
@@ -158,12 +169,16 @@ int mm2amd_unpack_regs(const uint8_t *buf, int64_t size, int n_frag, int *n_reg,
 
 /* Releases the device mirror; call before mm_idx_destroy (main.c:501). */
 void mm_gpu_destroy(void);
+/* The mapping context is process-wide, like the reference's pipeline: a later mm_gpu_init* replaces it.  Bindings whose objects
+ * can outlive each other (two Python Aligner objects) remember the generation their init produced and tear down only that one. */
+uint64_t mm_gpu_context_generation(void);        /* of the live context; 0: none */
+int mm_gpu_destroy_if(uint64_t generation);      /* 1: it was the live context and is gone now; 0: left alone */
 
 const char *mm2amd_backend_name(void);           /* "hip:gfx950" in the product library */
 int mm2amd_last_stats(double *v, int n);         /* per-stage wall times of the last batch (diagnostics) */
 
 /* Per-kernel timing (HIP events on the launch stream) and algorithmic bytes, accumulated while enabled. */
-typedef struct { char name[48]; double ms; double alg_bytes; int64_t launches; } mm2amd_kernel_stat_t;
+typedef struct { char name[48]; double ms; double alg_bytes; int64_t launches; double units; } mm2amd_kernel_stat_t; /* units: DP cells (DP kernels) */
 void mm2amd_profile_enable(int on);              /* also clears the accumulated statistics */
 int mm2amd_profile_get(mm2amd_kernel_stat_t *out, int cap); /* returns the number of kernels written */
 

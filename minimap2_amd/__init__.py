@@ -75,7 +75,7 @@ class Bseq1(C.Structure):  # mm_bseq1_t, bseq.h:14-17
 
 
 class KernelStat(C.Structure):  # mm2amd_kernel_stat_t
-    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("alg_bytes", C.c_double), ("launches", C.c_int64)]
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("alg_bytes", C.c_double), ("launches", C.c_int64), ("units", C.c_double)]
 
 
 assert C.sizeof(MapOpt) == 264 and C.sizeof(Reg1) == 80 and C.sizeof(Extra) == 28 and C.sizeof(Bseq1) == 40 and C.sizeof(IdxOpt) == 24
@@ -99,6 +99,9 @@ def _bind(L):
     L.mm2amd_pack_regs.argtypes = [C.c_int, ip, C.POINTER(vp), vp, C.c_int64]
     L.mm2amd_pack_regs.restype = C.c_int64
     L.mm2amd_unpack_regs.argtypes = [vp, C.c_int64, C.c_int, ip, C.POINTER(vp)]
+    L.mm_gpu_init_multi.argtypes = [vp, vp, C.c_int, C.c_int, ip]
+    L.mm_gpu_context_generation.restype = C.c_uint64
+    L.mm_gpu_destroy_if.argtypes = [C.c_uint64]
     if hasattr(L, "mm2amd_idx_str"):  # the product library (the CPU check library used by tests has no device index)
         L.mm2amd_ksw_extd2_batch.restype = C.c_int
         L.mm2amd_ksw_extd2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int8,
@@ -121,6 +124,7 @@ def _bind(L):
         L.mm2amd_idx_table_shape.argtypes = [vp, ip, ip]
         L.mm2amd_idx_export.argtypes = [vp, vp, vp, vp, vp, vp]
         L.mm_gpu_init_index.argtypes = [vp, vp, C.c_int]
+        L.mm_gpu_init_index_multi.argtypes = [vp, vp, C.c_int, C.c_int, ip]
         L.mm2amd_set_opt.argtypes = [C.c_char_p, vp, vp]
         L.mm2amd_check_opt.argtypes = [vp, vp]
         L.mm2amd_idxopt_init.argtypes = [vp]
@@ -239,10 +243,12 @@ class Aligner(object):
     """Index built on the GPU from in-memory sequences + batched mapping; mirrors mappy.Aligner(seq=..., preset=...).
 
     seq: a sequence string/bytes or a list of them (the reference); names: optional list of contig names.
-    Only one Aligner can be the active mapper of the process at a time (the drop-in boundary is a process-wide context,
-    like the reference's pipeline)."""
+    n_gpus / device_ids: map every batch on several GPUs of this process (mm_gpu_init_index_multi: index replicated, reads sharded
+    by bases; an ordinal may repeat).  Only one Aligner can be the active mapper of the process at a time (the drop-in boundary is
+    a process-wide context, like the reference's pipeline): creating a second one makes the first inactive -- its map calls raise,
+    and closing or collecting it leaves the new context alone."""
 
-    def __init__(self, seq, preset=None, names=None, k=None, w=None, n_threads=0, cigar=True, sam=False):
+    def __init__(self, seq, preset=None, names=None, k=None, w=None, n_threads=0, cigar=True, sam=False, n_gpus=0, device_ids=None):
         L = lib()
         seqs = [seq] if isinstance(seq, (bytes, str)) else list(seq)
         self._seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
@@ -269,12 +275,18 @@ class Aligner(object):
         if not self._idx:
             raise Mm2AmdError("index construction failed: %s" % L.mm2amd_last_error().decode())
         _check(L.mm2amd_mapopt_update(C.byref(self.map_opt), self._idx))
-        _check(L.mm_gpu_init_index(self._idx, C.byref(self.map_opt), n_threads))
+        ids = (C.c_int * len(device_ids))(*device_ids) if device_ids else None
+        _check(L.mm_gpu_init_index_multi(self._idx, C.byref(self.map_opt), n_threads, len(device_ids) if device_ids else n_gpus, ids))
+        self._generation = L.mm_gpu_context_generation()
         self._staged = None
+
+    def _active(self):
+        if lib().mm_gpu_context_generation() != self._generation:
+            raise Mm2AmdError("this Aligner is no longer the process's active mapper (a later Aligner or mm_gpu_init replaced its context)")
 
     def close(self):
         if getattr(self, "_idx", None):
-            lib().mm_gpu_destroy()
+            lib().mm_gpu_destroy_if(self._generation)  # only the context this object installed
             lib().mm2amd_idx_destroy(self._idx)
             self._idx = None
 
@@ -295,6 +307,7 @@ class Aligner(object):
     def stage(self, reads):
         """reads: list of (name, sequence), of sequences (bytes/str), or of (name, sequence1, sequence2) for read pairs (mapped as
         two-segment fragments, mm_map_frag with n_segs == 2).  Copies them to the GPU."""
+        self._active()
         n = len(reads)
         items, seg_off, n_seg = [], [], []
         for i, r in enumerate(reads):
@@ -315,6 +328,7 @@ class Aligner(object):
         (n_reg, reg, rep_len) ctypes arrays (one entry per read, pairs adjacent) that must be passed to free_raw()."""
         if self._staged is None:
             raise Mm2AmdError("run() without stage()")
+        self._active()
         n, _, items, seg_off, n_seg = self._staged
         m = max(1, len(items))
         n_reg, reg, rep_len, frag_gap = (C.c_int * m)(), (C.c_void_p * m)(), (C.c_int * m)(), (C.c_int * m)()
@@ -382,4 +396,4 @@ def profile_enable(on=True):
 def profile_get():
     arr = (KernelStat * 64)()
     n = lib().mm2amd_profile_get(arr, 64)
-    return {arr[i].name.decode(): {"ms": arr[i].ms, "alg_bytes": arr[i].alg_bytes, "launches": arr[i].launches} for i in range(n)}
+    return {arr[i].name.decode(): {"ms": arr[i].ms, "alg_bytes": arr[i].alg_bytes, "launches": arr[i].launches, "units": arr[i].units} for i in range(n)}

@@ -1,7 +1,8 @@
 // Layout-compatible views of the reference's public structs (lh3/minimap2 v2.30).  The drop-in boundary
 // exchanges these by pointer with host code compiled against the reference's own minimap.h, so the field
 // order, widths and bit-field packing below must match it exactly (x86-64 SysV ABI).  Citations are to
-// /root/reference; tests/test_abi_layout.py compares sizeof/offsetof against the real headers.
+// /root/reference; tests/test_capi.py::test_struct_layouts_match_reference_headers compares sizeof and every offsetof (the ctypes
+// mirrors and these C++ ones) against a probe compiled with the real headers.
 #pragma once
 #include <cstdint>
 #include <cstddef>

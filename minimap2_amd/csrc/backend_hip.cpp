@@ -56,15 +56,20 @@ struct Lane {
 class HipBackend : public Backend {
 public:
 	// `tables` may be null: the backend then mirrors the host tables of `fi` (an index flattened from a reference mm_idx_t)
-	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables, int n_threads) : T_(tables)
+	// `device` < 0: the process's default device.  `tables_device`: where `tables` live; a replica on another device copies them
+	// (hipMemcpyPeer over xGMI), one on the same device shares them.
+	HipBackend(const FlatIndex &fi, DeviceIndexTables *tables, int n_threads, int device, int replica, int tables_device) : T_(tables)
 	{
-		DeviceCtx &d = device_ctx();
+		replica_ = replica;
+		DeviceCtx &d = device_ctx(device);
 		std::lock_guard<std::mutex> lk(d.mu);
 		ensure_device(d);
+		dev_ = d.device_id;
 		stream_ = d.stream;
 		n_cu_ = d.n_cu;
 		n_threads_ = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
 		if (!T_) { own_.upload(fi, stream_); T_ = &own_; }
+		else if (tables_device >= 0 && tables_device != dev_) { own_.clone_from(*T_, tables_device, dev_); T_ = &own_; }
 		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
 		I_.name_rank = nullptr, I_.seq_len = nullptr;
@@ -81,9 +86,11 @@ public:
 		}
 	}
 
+	~HipBackend() override { (void)hipSetDevice(dev_); }
 	int n_lanes() const override { return n_lanes_; }
 	void enable_name_rules() override
 	{
+		HIP_CHECK(hipSetDevice(dev_)); // HIP's current device is per thread, and the mapper drives every lane from a thread of its own
 		if (name_rules_ || fi_names_->empty()) return;
 		const std::vector<std::string> &nm = *fi_names_;
 		sorted_names_ = nm;
@@ -100,6 +107,7 @@ public:
 	}
 	void enable_seq_len() override
 	{
+		HIP_CHECK(hipSetDevice(dev_)); // HIP's current device is per thread, and the mapper drives every lane from a thread of its own
 		if (I_.seq_len) return;
 		d_ref_len_.ensure(fi_seq_len_->size());
 		HIP_CHECK(hipMemcpyAsync(d_ref_len_.p, fi_seq_len_->data(), fi_seq_len_->size() * 4, hipMemcpyHostToDevice, stream_));
@@ -111,6 +119,7 @@ public:
 
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
 	{
+		HIP_CHECK(hipSetDevice(dev_)); // HIP's current device is per thread, and the mapper drives every lane from a thread of its own
 		const size_t n = reads.size();
 		// fragment-level offsets (what seeding and chaining see: a pair is one query, the concatenation of its two reads) ...
 		seq_off_.resize(n + 1);
@@ -171,6 +180,7 @@ public:
 
 	void seed_chain(const SeedChainParams &P, long lo, long hi, int lane_id, int n_threads, std::vector<ReadChains> &out) override
 	{
+		HIP_CHECK(hipSetDevice(dev_)); // HIP's current device is per thread, and the mapper drives every lane from a thread of its own
 		Lane &ln = *lanes_.at(lane_id);
 		hipStream_t st = ln.stream;
 		SeedChainBuffers &B = ln.B;
@@ -181,7 +191,7 @@ public:
 		B = SeedChainBuffers();
 		B.n_reads = (int)n, B.seq_off = d_seq_off_.p + lo, B.ascii = d_ascii_.p, B.qpool = d_qpool_.p;
 		if (have_read_names_) B.name_lb = d_name_key_.p + lo, B.name_eq = d_name_key_.p + seq_off_.size() - 1 + lo;
-		KernelProfiler &kp = kernel_profiler(lane_id);
+		KernelProfiler &kp = kernel_profiler(lane_id, replica_);
 		double tt = Trace::now();
 		const double L = (double)(seq_off_[hi] - seq_off_[lo]);
 		// encoding and sketching run over units (see begin_batch); without pairs a unit is a fragment
@@ -332,11 +342,12 @@ public:
 
 	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane_id, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) override
 	{
+		HIP_CHECK(hipSetDevice(dev_)); // HIP's current device is per thread, and the mapper drives every lane from a thread of its own
 		Lane &ln = *lanes_.at(lane_id);
 		res.resize(jobs.size());
 		size_t n_cig = 0;
 		ln.ksw.n_threads = n_threads;
-		ln.ksw.prof = &kernel_profiler(lane_id);
+		ln.ksw.prof = &kernel_profiler(lane_id, replica_);
 		// the DP scratch (one direction-matrix slot per persistent wave) is the big per-lane allocation: split the budget
 		// HBM the lanes may spend on direction matrices (1 B per DP cell, one slot per persistent wave); splice gap fills have
 		// matrices of tens of MB each, and 288 GB of HBM is what lets thousands of them be in flight
@@ -351,12 +362,12 @@ public:
 			d_tbytes = ln.d_tbytes.p;
 		}
 		ln.ksw.run(jobs, d_qpool_.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
-		kernel_profiler(lane_id).collect();
+		kernel_profiler(lane_id, replica_).collect();
 	}
 
 private:
 	hipStream_t stream_ = nullptr;
-	int n_threads_ = 1, n_cu_ = 256, n_lanes_ = 1, rid_bits_ = 1;
+	int n_threads_ = 1, n_cu_ = 256, n_lanes_ = 1, rid_bits_ = 1, dev_ = 0, replica_ = 0;
 	std::atomic<int> active_lanes_{1};
 	DevIndex I_{};
 	DeviceIndexTables own_;
@@ -388,7 +399,11 @@ private:
 
 } // namespace
 
-Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads) { return new HipBackend(fi, (DeviceIndexTables *)device_tables, n_threads); }
+Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads, int device, int replica, int tables_device)
+{
+	return new HipBackend(fi, (DeviceIndexTables *)device_tables, n_threads, device, replica, tables_device);
+}
+int backend_device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 const char *backend_name() { return "hip:gfx950"; }
 
 } // namespace mm2amd

@@ -16,9 +16,11 @@ int capi_fail(int code, const std::string &msg);
 struct IndexHandle {
 	FlatIndex fi;
 	DeviceIndexTables T;
+	int device = 0;
 };
 const FlatIndex &index_flat(const IndexHandle *h) { return h->fi; }
 void *index_device_tables(const IndexHandle *h) { return (void *)&h->T; }
+int index_device(const IndexHandle *h) { return h->device; }
 }
 
 using namespace mm2amd;
@@ -38,6 +40,7 @@ mm2amd_index_t *mm2amd_idx_str(int w, int k, int is_hpc, int bucket_bits, int n,
 		std::lock_guard<std::mutex> lk(dc.mu);
 		ensure_device(dc);
 		std::unique_ptr<IndexHandle> h(new IndexHandle);
+		h->device = dc.device_id;
 		std::vector<uint64_t> lens(n);
 		for (int i = 0; i < n; ++i) lens[i] = seq[i] ? strlen(seq[i]) : 0;
 		int flag = 0;
@@ -92,7 +95,7 @@ int mm2amd_idx_export(const mm2amd_index_t *idx, uint32_t *bucket_start, uint64_
 	if (!idx) return capi_fail(MM2AMD_EINVAL, "[mm2amd] null index");
 	const IndexHandle *h = (const IndexHandle *)idx;
 	try {
-		DeviceCtx &dc = device_ctx();
+		DeviceCtx &dc = device_ctx(h->device);
 		std::lock_guard<std::mutex> lk(dc.mu);
 		ensure_device(dc);
 		if (bucket_start) HIP_CHECK(hipMemcpy(bucket_start, h->T.bucket_start.p, ((1ull << h->T.bucket_bits) + 1) * 4, hipMemcpyDeviceToHost));

@@ -128,17 +128,17 @@ long long mm2amd_alloc_counter(int which)
 
 void mm2amd_profile_enable(int on)
 {
-	for (int l = 0; l < kMaxProfLanes; ++l) kernel_profiler(l).reset();
+	for (int r = 0; r < kMaxReplicas; ++r) for (int l = 0; l < kMaxProfLanes; ++l) kernel_profiler(l, r).reset();
 	KernelProfiler::enabled_flag() = on != 0;
 }
 
 int mm2amd_profile_get(mm2amd_kernel_stat_t *out, int cap)
 {
 	std::map<std::string, KernelStat> all;
-	for (int l = 0; l < kMaxProfLanes; ++l)
-		for (const auto &kv : kernel_profiler(l).stats()) {
+	for (int r = 0; r < kMaxReplicas; ++r) for (int l = 0; l < kMaxProfLanes; ++l)
+		for (const auto &kv : kernel_profiler(l, r).stats()) {
 			KernelStat &k = all[kv.first];
-			k.ms += kv.second.ms, k.alg_bytes += kv.second.alg_bytes, k.launches += kv.second.launches;
+			k.ms += kv.second.ms, k.alg_bytes += kv.second.alg_bytes, k.units += kv.second.units, k.launches += kv.second.launches;
 		}
 	int n = 0;
 	for (const auto &kv : all) {
@@ -146,7 +146,7 @@ int mm2amd_profile_get(mm2amd_kernel_stat_t *out, int cap)
 		mm2amd_kernel_stat_t &o = out[n++];
 		memset(&o, 0, sizeof o);
 		strncpy(o.name, kv.first.c_str(), sizeof o.name - 1);
-		o.ms = kv.second.ms, o.alg_bytes = kv.second.alg_bytes, o.launches = kv.second.launches;
+		o.ms = kv.second.ms, o.alg_bytes = kv.second.alg_bytes, o.launches = kv.second.launches, o.units = kv.second.units;
 	}
 	return n;
 }

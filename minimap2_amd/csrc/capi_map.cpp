@@ -14,7 +14,10 @@
 #include "threads.hpp"
 
 namespace mm2amd {
-Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads); // backend_hip.cpp in the product
+// backend_hip.cpp in the product: `device` < 0 = the process's default device; `replica` numbers the backends of one context;
+// `tables_device` is where `device_tables` live (a backend on another device copies them)
+Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads, int device, int replica, int tables_device);
+int backend_device_count();
 const char *backend_name();
 void capi_set_error(const std::string &msg);              // capi_common.cpp
 int capi_fail(int code, const std::string &msg);
@@ -29,6 +32,17 @@ namespace {
 // mapped reverse-complemented and its hits have to be turned back (length of that read), see hand_over().
 struct OutSlot { int o, n_out, flip_len[2]; int weak = 0, len0 = 0; }; // weak: 1 / 2 = first / second mate of a pair mapped separately and paired afterwards (MM_F_WEAK_PAIRING)
 
+// One mapper per GPU the context uses (mm_gpu_init_multi): every replica holds a full copy of the index in its device's HBM and
+// maps a contiguous share of each batch, cut by cumulative bases; the shares are independent, so there is no exchange between
+// devices -- results land in the caller's arrays, which are host memory (the hit gather is only needed across processes).
+struct Replica {
+	int device = -1;
+	std::unique_ptr<Backend> be;
+	std::unique_ptr<Mapper> mapper;
+	std::vector<ReadView> staged;     // this replica's share of the staged batch
+	long lo = 0, hi = 0;              // ... = fragments [lo, hi) of the mapper-side fragment list
+};
+
 struct MapContext {
 	FlatIndex fi_own;                 // index flattened from a reference mm_idx_t (mm_gpu_init)
 	const FlatIndex *fi = nullptr;    // the index in use (fi_own, or the one inside an mm2amd_index_t)
@@ -38,16 +52,99 @@ struct MapContext {
 	std::vector<std::string> staged_flipped;
 	bool has_staged = false;
 	int n_threads = 1;
-	std::unique_ptr<Backend> be;
-	std::unique_ptr<Mapper> mapper;
+	uint64_t generation = 0;
+	std::vector<Replica> reps;
+	MapperStats stats;                // summed over the replicas of the last run
 };
 std::mutex g_mu;
 std::unique_ptr<MapContext> g_ctx;
+uint64_t g_generation = 0;
+
+// fragments [0, n) -> one contiguous range per replica with about the same number of bases (shard.py: split_by_bases); a pair
+// of mates mapped separately and paired afterwards (OutSlot::weak) stays in one share
+void shard_by_bases(const std::vector<ReadView> &reads, const std::vector<OutSlot> &slots, int n_parts, std::vector<long> &cut)
+{
+	const long n = (long)reads.size();
+	std::vector<uint64_t> acc((size_t)n + 1, 0);
+	for (long i = 0; i < n; ++i) acc[i + 1] = acc[i] + (uint64_t)reads[i].total();
+	cut.assign((size_t)n_parts + 1, n);
+	cut[0] = 0;
+	for (int p = 1; p < n_parts; ++p) {
+		const uint64_t want = acc[n] * (uint64_t)p / (uint64_t)n_parts;
+		long c = (long)(std::lower_bound(acc.begin(), acc.end(), want) - acc.begin());
+		c = std::max(c, cut[p - 1]);
+		if (c < n && slots[c].weak == 2) ++c;
+		cut[p] = std::min(c, n);
+	}
+}
+
+// every replica maps its share on a host thread of its own
+template <typename F>
+void for_each_replica(MapContext &c, F &&f)
+{
+	std::vector<std::thread> th;
+	std::vector<std::exception_ptr> err(c.reps.size());
+	for (size_t r = 1; r < c.reps.size(); ++r) th.emplace_back([&, r] { try { f(c.reps[r]); } catch (...) { err[r] = std::current_exception(); } });
+	try { f(c.reps[0]); } catch (...) { err[0] = std::current_exception(); }
+	for (auto &t : th) t.join();
+	for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+void run_replicas(MapContext &c, std::vector<ReadResult> &out, size_t n_frag_mapper)
+{
+	std::vector<std::vector<ReadResult>> part(c.reps.size());
+	for_each_replica(c, [&](Replica &rp) { rp.mapper->run(part[&rp - c.reps.data()]); });
+	out.clear();
+	out.resize(n_frag_mapper);
+	c.stats = MapperStats();
+	for (size_t r = 0; r < c.reps.size(); ++r) {
+		for (long i = c.reps[r].lo; i < c.reps[r].hi; ++i) out[i] = std::move(part[r][i - c.reps[r].lo]);
+		const MapperStats &s = c.reps[r].mapper->stats;
+		c.stats.t_seed_chain += s.t_seed_chain, c.stats.t_host_pre += s.t_host_pre, c.stats.t_plan += s.t_plan, c.stats.t_ksw += s.t_ksw, c.stats.t_consume += s.t_consume;
+		c.stats.t_finish += s.t_finish, c.stats.n_jobs += s.n_jobs, c.stats.n_rounds += s.n_rounds, c.stats.dp_cells += s.dp_cells;
+	}
+}
+
+void stage_replicas(MapContext &c, const std::vector<ReadView> &reads, const std::vector<OutSlot> &slots)
+{
+	std::vector<long> cut;
+	shard_by_bases(reads, slots, (int)c.reps.size(), cut);
+	for (size_t r = 0; r < c.reps.size(); ++r) {
+		Replica &rp = c.reps[r];
+		rp.lo = cut[r], rp.hi = cut[r + 1];
+		rp.staged.assign(reads.begin() + rp.lo, reads.begin() + rp.hi);
+	}
+	for_each_replica(c, [&](Replica &rp) { rp.mapper->stage(rp.staged); });
+}
+
+int build_context(std::unique_ptr<MapContext> &c, void *device_tables, int tables_device, int n_threads, int n_gpus, const int *device_ids)
+{
+	if (n_gpus <= 0) { n_gpus = 1; if (const char *e = getenv("MM2AMD_GPUS")) n_gpus = std::max(1, atoi(e)); }
+	std::vector<int> env_ids;
+	if (!device_ids && getenv("MM2AMD_DEVICE_IDS")) { // "0,0" or "3,2,1,0": ordinals for the replicas when the caller names none
+		for (const char *p = getenv("MM2AMD_DEVICE_IDS"); *p;) { env_ids.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+		if ((int)env_ids.size() >= n_gpus) device_ids = env_ids.data();
+	}
+	if (n_gpus > 16) return capi_fail(MM2AMD_EINVAL, "[mm2amd] at most 16 replicas per context");
+	if (!device_ids && n_gpus > 1 && n_gpus > backend_device_count()) return capi_fail(MM2AMD_ENODEV, "[mm2amd] more GPUs requested than this process can see");
+	if (n_threads <= 0) n_threads = std::min(64 * n_gpus, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU
+	c->n_threads = n_threads;
+	const int per = std::max(1, n_threads / n_gpus);
+	c->reps.resize(n_gpus);
+	for (int r = 0; r < n_gpus; ++r) {
+		Replica &rp = c->reps[r];
+		rp.device = device_ids ? device_ids[r] : n_gpus > 1 ? r : -1;
+		rp.be.reset(make_backend(*c->fi, device_tables, per, rp.device, r, tables_device));
+		rp.mapper.reset(new Mapper(*c->fi, c->opt, *rp.be, per));
+	}
+	c->generation = ++g_generation;
+	return 0;
+}
 }
 
 extern "C" {
 
-int mm_gpu_init(const void *mi, const void *opt, int n_threads)
+int mm_gpu_init_multi(const void *mi, const void *opt, int n_threads, int n_gpus, const int *device_ids)
 {
 	if (!mi || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_init: null index or options");
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -56,10 +153,7 @@ int mm_gpu_init(const void *mi, const void *opt, int n_threads)
 		c->opt = *(const ref::MapOpt *)opt;
 		c->fi_own.from_reference((const ref::Idx *)mi);
 		c->fi = &c->fi_own;
-		if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU
-		c->be.reset(make_backend(*c->fi, nullptr, n_threads));
-		c->mapper.reset(new Mapper(*c->fi, c->opt, *c->be, n_threads));
-		c->n_threads = n_threads;
+		if (int rc = build_context(c, nullptr, -1, n_threads, n_gpus, device_ids)) return rc;
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -70,7 +164,7 @@ int mm_gpu_init(const void *mi, const void *opt, int n_threads)
 	}
 }
 
-int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
+int mm_gpu_init_index_multi(const mm2amd_index_t *idx, const void *opt, int n_threads, int n_gpus, const int *device_ids)
 {
 	if (!idx || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_init_index: null index or options");
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -78,10 +172,7 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
 		std::unique_ptr<MapContext> c(new MapContext);
 		c->opt = *(const ref::MapOpt *)opt;
 		c->fi = &index_flat((const IndexHandle *)idx);
-		if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU
-		c->be.reset(make_backend(*c->fi, index_device_tables((const IndexHandle *)idx), n_threads));
-		c->mapper.reset(new Mapper(*c->fi, c->opt, *c->be, n_threads));
-		c->n_threads = n_threads;
+		if (int rc = build_context(c, index_device_tables((const IndexHandle *)idx), index_device((const IndexHandle *)idx), n_threads, n_gpus, device_ids)) return rc;
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -90,6 +181,21 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
 		const std::string s = e.what();
 		return capi_fail(s.find("no HIP device") != std::string::npos ? MM2AMD_ENODEV : MM2AMD_EHIP, s);
 	}
+}
+
+int mm_gpu_init(const void *mi, const void *opt, int n_threads) { return mm_gpu_init_multi(mi, opt, n_threads, 0, nullptr); }
+int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads) { return mm_gpu_init_index_multi(idx, opt, n_threads, 0, nullptr); }
+
+uint64_t mm_gpu_context_generation(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	return g_ctx ? g_ctx->generation : 0;
+}
+
+int mm_gpu_n_replicas(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	return g_ctx ? (int)g_ctx->reps.size() : 0;
 }
 
 // mm_revcomp_bseq (mmpriv.h) on a copy: complement table of bseq.c:11-28 (IUPAC codes, case kept, other bytes unchanged)
@@ -210,7 +316,7 @@ int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const v
 	try {
 		g_ctx->has_staged = false;
 		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, g_ctx->staged, g_ctx->staged_slots, g_ctx->staged_flipped)) return rc;
-		g_ctx->mapper->stage(g_ctx->staged);
+		stage_replicas(*g_ctx, g_ctx->staged, g_ctx->staged_slots);
 		g_ctx->has_staged = true;
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -227,7 +333,7 @@ int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 	if (!n_reg || !reg) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_staged: bad arguments");
 	try {
 		std::vector<ReadResult> out;
-		g_ctx->mapper->run(out);
+		run_replicas(*g_ctx, out, g_ctx->staged.size());
 		hand_over(g_ctx->staged_slots, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -273,7 +379,8 @@ int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t
 {
 	if (n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_pack_regs: bad arguments");
 	// sizes first (prefix sums give every fragment its slot), then the copies, both on the pool threads
-	const int nt = g_ctx ? g_ctx->n_threads : 1;
+	int nt = 1;
+	{ std::lock_guard<std::mutex> lk(g_mu); if (g_ctx) nt = g_ctx->n_threads; }
 	std::vector<int64_t> off((size_t)n_frag + 1, 0);
 	parallel_for(nt, n_frag, [&](long i, int) {
 		int64_t sz = 4;
@@ -305,31 +412,35 @@ int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t
 
 int mm2amd_unpack_regs(const uint8_t *buf, int64_t size, int n_frag, int *n_reg, void **reg)
 {
-	if (!buf || n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: bad arguments");
+	if (!buf || size < 0 || n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: bad arguments");
+	for (int i = 0; i < n_frag; ++i) n_reg[i] = 0, reg[i] = nullptr; // whatever happens below, the caller can hand the arrays to mm2amd_free_regs
+	auto bail = [&](int code, const char *msg) { mm2amd_free_regs(n_frag, n_reg, reg); return capi_fail(code, msg); };
 	const uint8_t *o = buf, *end = buf + size;
 	for (int i = 0; i < n_frag; ++i) {
 		int32_t n;
-		if (end - o < 4) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+		if (end - o < 4) return bail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
 		memcpy(&n, o, 4), o += 4;
-		n_reg[i] = n, reg[i] = nullptr;
-		if (n <= 0) continue;
+		if (n < 0 || (int64_t)n > (end - o) / (int64_t)(sizeof(ref::Reg1) + 4)) return bail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: hit count beyond the payload");
+		if (n == 0) continue;
 		ref::Reg1 *r = (ref::Reg1 *)calloc(n, sizeof(ref::Reg1));
-		reg[i] = r;
+		if (!r) return bail(MM2AMD_ENOMEM, "[mm2amd] mm2amd_unpack_regs: out of memory");
+		reg[i] = r, n_reg[i] = n; // the array is zeroed: unfilled entries have no extra block
 		for (int j = 0; j < n; ++j) {
 			uint32_t has;
-			if (end - o < (int64_t)sizeof(ref::Reg1) + 4) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+			if (end - o < (int64_t)sizeof(ref::Reg1) + 4) return bail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
 			memcpy(&r[j], o, sizeof(ref::Reg1)), o += sizeof(ref::Reg1);
 			memcpy(&has, o, 4), o += 4;
 			r[j].p = nullptr;
 			if (has) {
 				ref::Extra hd;
-				if (end - o < (int64_t)sizeof hd) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+				if (end - o < (int64_t)sizeof hd) return bail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
 				memcpy(&hd, o, sizeof hd);
 				const size_t nb = sizeof(ref::Extra) + 4ull * hd.n_cigar;
-				if ((size_t)(end - o) < nb) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
-				size_t words = hd.capacity;
-				if (words * 4 < nb) words = (nb + 3) / 4;
+				if ((size_t)(end - o) < nb) return bail(MM2AMD_EINVAL, "[mm2amd] mm2amd_unpack_regs: truncated payload");
+				size_t words = (nb + 3) / 4; // what the CIGAR needs; the sender's capacity (the reference rounds it up to a power of two, align.c:199-207) is kept only while it is plausible
+				if ((size_t)hd.capacity >= words && (size_t)hd.capacity <= 2 * words + 16) words = hd.capacity;
 				r[j].p = (ref::Extra *)calloc(words, 4);
+				if (!r[j].p) return bail(MM2AMD_ENOMEM, "[mm2amd] mm2amd_unpack_regs: out of memory");
 				memcpy(r[j].p, o, nb), o += nb;
 				r[j].p->capacity = (uint32_t)words;
 			}
@@ -349,7 +460,9 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 		std::vector<std::string> flipped;
 		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, reads, slots, flipped)) return rc;
 		std::vector<ReadResult> out;
-		g_ctx->mapper->map_batch(reads, out);
+		g_ctx->has_staged = false; // the replicas' staged shares are replaced
+		stage_replicas(*g_ctx, reads, slots);
+		run_replicas(*g_ctx, out, reads.size());
 		hand_over(slots, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -365,13 +478,23 @@ void mm_gpu_destroy(void)
 	g_ctx.reset();
 }
 
+// for bindings with several owners (two Python Aligner objects): tears the context down only if it is still the one the
+// caller installed; returns 1 when it did
+int mm_gpu_destroy_if(uint64_t generation)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_ctx || g_ctx->generation != generation) return 0;
+	g_ctx.reset();
+	return 1;
+}
+
 const char *mm2amd_backend_name(void) { return backend_name(); }
 
 int mm2amd_last_stats(double *v, int n)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!g_ctx) return 0;
-	const MapperStats &s = g_ctx->mapper->stats;
+	const MapperStats &s = g_ctx->stats;
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
 	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2) };
 	int k = 0;

@@ -4,31 +4,48 @@
 
 namespace mm2amd {
 
-DeviceCtx &device_ctx()
+namespace {
+int device_count()
 {
-	static DeviceCtx d;
-	return d;
+	int n = 0;
+	const hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) throw HipError("[mm2amd] no HIP device visible: this library has no CPU path");
+	return n;
+}
 }
 
-KernelProfiler &kernel_profiler(int lane)
+int default_device()
 {
-	static KernelProfiler p[kMaxProfLanes];
-	return p[lane < 0 || lane >= kMaxProfLanes ? 0 : lane];
+	const int n = device_count();
+	int id = 0;
+	if (const char *s = getenv("MM2AMD_DEVICE")) id = atoi(s);
+	else if (const char *s = getenv("LOCAL_RANK")) id = atoi(s) % n;
+	if (id < 0 || id >= n) throw HipError("[mm2amd] MM2AMD_DEVICE names a device this process cannot see");
+	return id;
+}
+
+DeviceCtx &device_ctx(int id)
+{
+	static DeviceCtx d[kMaxDevices];
+	if (id < 0) id = default_device();
+	if (id >= kMaxDevices) throw HipError("[mm2amd] device ordinal beyond the supported range");
+	d[id].device_id = id;
+	return d[id];
+}
+
+KernelProfiler &kernel_profiler(int lane, int replica)
+{
+	static KernelProfiler p[kMaxReplicas][kMaxProfLanes];
+	return p[replica < 0 || replica >= kMaxReplicas ? 0 : replica][lane < 0 || lane >= kMaxProfLanes ? 0 : lane];
 }
 
 void ensure_device(DeviceCtx &d)
 {
+	if (d.device_id >= device_count()) throw HipError("[mm2amd] device ordinal beyond the devices this process can see");
+	HIP_CHECK(hipSetDevice(d.device_id));
 	if (d.ready) return;
-	int n = 0;
-	hipError_t e = hipGetDeviceCount(&n);
-	if (e != hipSuccess || n <= 0) throw HipError("[mm2amd] no HIP device visible: this library has no CPU path");
-	int id = 0;
-	if (const char *s = getenv("MM2AMD_DEVICE")) id = atoi(s);
-	else if (const char *s = getenv("LOCAL_RANK")) id = atoi(s) % n;
-	HIP_CHECK(hipSetDevice(id));
 	hipDeviceProp_t prop;
-	HIP_CHECK(hipGetDeviceProperties(&prop, id));
-	d.device_id = id;
+	HIP_CHECK(hipGetDeviceProperties(&prop, d.device_id));
 	d.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
 	d.ready = true;

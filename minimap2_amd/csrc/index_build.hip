@@ -250,6 +250,19 @@ void DeviceIndexTables::upload(const FlatIndex &fi, hipStream_t stream)
 	for (size_t i = 0; i < fi.keys.size(); ++i) { uint32_t c = fi.val_off[i + 1] - fi.val_off[i]; ++occ_hist[c < occ_hist.size() ? c : occ_hist.size() - 1]; }
 }
 
+void DeviceIndexTables::clone_from(const DeviceIndexTables &src, int src_device, int dst_device)
+{
+	n_keys = src.n_keys, n_pos = src.n_pos, bucket_bits = src.bucket_bits, key_shift = src.key_shift, occ_hist = src.occ_hist;
+	auto cp = [&](void *dst, const void *from, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyPeer(dst, dst_device, from, src_device, bytes)); };
+	bucket_start.ensure(((size_t)1 << bucket_bits) + 2, 1.0), cp(bucket_start.p, src.bucket_start.p, (((size_t)1 << bucket_bits) + 1) * 4);
+	keys.ensure(n_keys + 1, 1.0), cp(keys.p, src.keys.p, n_keys * 8);
+	val_off.ensure(n_keys + 2, 1.0), cp(val_off.p, src.val_off.p, (n_keys + 1) * 4);
+	pos.ensure(n_pos + 1, 1.0), cp(pos.p, src.pos.p, n_pos * 8);
+	const size_t s_words = src.S.cap; // the packed reference as allocated (its exact length lives in the host index)
+	S.ensure(s_words + 1, 1.0), cp(S.p, src.S.p, s_words * 4);
+	HIP_CHECK(hipDeviceSynchronize());
+}
+
 int32_t DeviceIndexTables::cal_max_occ(float f) const
 {
 	if (f <= 0.f || n_keys == 0) return INT32_MAX;

@@ -16,6 +16,7 @@ struct DeviceIndexTables {
 	std::vector<unsigned long long> occ_hist; // occ_hist[c] = number of distinct minimizers occurring c times (last bin: >=)
 	int32_t cal_max_occ(float f) const;       // mm_idx_cal_max_occ (index.c:198-220) from the histogram
 	void upload(const FlatIndex &fi, hipStream_t stream); // mirror host-side tables (index flattened from a reference mm_idx_t)
+	void clone_from(const DeviceIndexTables &src, int src_device, int dst_device); // replica on another GPU: device-to-device copies (xGMI); the calling thread's current device must be dst_device
 };
 
 struct DeviceIndexBuilder {

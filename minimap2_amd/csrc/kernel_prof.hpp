@@ -9,7 +9,7 @@
 
 namespace mm2amd {
 
-struct KernelStat { double ms = 0, alg_bytes = 0; long launches = 0; };
+struct KernelStat { double ms = 0, alg_bytes = 0, units = 0; long launches = 0; }; // units: DP cells for the DP kernels (0 elsewhere)
 
 class KernelProfiler {
 public:
@@ -24,11 +24,11 @@ public:
 		HIP_CHECK(hipEventRecord(p.e0, s));
 		pending_.push_back(p);
 	}
-	void end(hipStream_t s, const char *name, double alg_bytes)
+	void end(hipStream_t s, const char *name, double alg_bytes, double units = 0)
 	{
 		if (!active_) return;
 		Pending &p = pending_.back();
-		p.name = name, p.bytes = alg_bytes;
+		p.name = name, p.bytes = alg_bytes, p.units = units;
 		HIP_CHECK(hipEventRecord(p.e1, s));
 	}
 	// call after the stream has been synchronised
@@ -38,7 +38,7 @@ public:
 			float ms = 0;
 			if (p.name && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
 				KernelStat &k = stats_[p.name];
-				k.ms += ms, k.alg_bytes += p.bytes, ++k.launches;
+				k.ms += ms, k.alg_bytes += p.bytes, k.units += p.units, ++k.launches;
 			}
 			free_.push_back(p.e0), free_.push_back(p.e1);
 		}
@@ -47,7 +47,7 @@ public:
 	void reset() { collect(); stats_.clear(); }
 	const std::map<std::string, KernelStat> &stats() const { return stats_; }
 private:
-	struct Pending { hipEvent_t e0, e1; const char *name = nullptr; double bytes = 0; };
+	struct Pending { hipEvent_t e0, e1; const char *name = nullptr; double bytes = 0, units = 0; };
 	hipEvent_t get_event()
 	{
 		if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; }
@@ -60,7 +60,7 @@ private:
 	std::map<std::string, KernelStat> stats_;
 };
 
-constexpr int kMaxProfLanes = 8;
-KernelProfiler &kernel_profiler(int lane = 0); // device_ctx.cpp; one per backend lane (each is used by one host thread at a time)
+constexpr int kMaxProfLanes = 8, kMaxReplicas = 16;
+KernelProfiler &kernel_profiler(int lane = 0, int replica = 0); // device_ctx.cpp; one per backend lane of every replica (each is used by one host thread at a time)
 
 } // namespace mm2amd

@@ -85,7 +85,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	const bool splice_ok = sc.m == 5 && !disable_fast && splice && -min_sc <= 2 * (sc.q + sc.e) && sc.q2 > sc.q + sc.e && sc.e > 0 && sc.q >= 0 && sc.noncan >= 0 &&
 	                       sc.q + sc.e + sc.q2 + sc.noncan + max_abs <= 100;
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
-	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0; };
+	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0, cells = 0; };
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
 	const size_t n_chunks = (n + CH - 1) / CH;
 	bucket.resize(n), perm.resize(n);
@@ -131,6 +131,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			cs.alg_bytes += sizeof(KswJob) + sizeof(KswRes);
 			if (!live) continue;
 			cs.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
+			cs.cells += (double)j.qlen * (double)j.tlen;
 			cs.max_ring = std::max(cs.max_ring, ring_need), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
 			if (!(j.flag & KSW_SCORE_ONLY)) {
 				if (db > 160 * 1024) cs.alg_bytes += (double)db;
@@ -146,7 +147,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	for (const ChunkStat &st : cstat) {
 		sum_len += st.sum_len;
 		for (int t = 0; t < kNTiers; ++t) {
-			cls[t].alg_bytes += st.cls[t].alg_bytes;
+			cls[t].alg_bytes += st.cls[t].alg_bytes, cls[t].cells += st.cls[t].cells;
 			cls[t].slot_bytes = std::max(cls[t].slot_bytes, st.cls[t].slot_bytes), cls[t].tmp_cap = std::max(cls[t].tmp_cap, st.cls[t].tmp_cap);
 			cls[t].max_ring = std::max(cls[t].max_ring, st.cls[t].max_ring), cls[t].max_Q16 = std::max(cls[t].max_Q16, st.cls[t].max_Q16);
 			cls[t].max_rows = std::max(cls[t].max_rows, st.cls[t].max_rows), cls[t].max_ncol = std::max(cls[t].max_ncol, st.cls[t].max_ncol);
@@ -191,17 +192,22 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		d_cigar.ensure(pool_cap);
 		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 128 * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
-		// size every launch class first (one scratch allocation serves them all: the launches run back to back on one stream)
-		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4; bool hbm = false; double alg_bytes = 0; };
+		// size every launch class first.  The launches form two groups that run CONCURRENTLY: the register-resident kernels back to
+		// back on the caller's stream, the lane-exact kernel's classes back to back on a side stream of higher priority (a few long
+		// banded extensions per read: launches with a long tail and few busy CUs, which would otherwise sit between the gap-fill
+		// kernel and the copy-back of every sub-batch).  One scratch allocation per group serves all of its launches.
+		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4; bool hbm = false; double alg_bytes = 0, cells = 0; };
 		Plan plan[kNTiers];
-		size_t need_dir = 16, need_tmp = 16, need_state = 0;
+		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
+		auto group_of = [](int tier) { return tier >= kFirstExact && tier < kFirstSplice ? 1 : 0; };
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			Plan &P = plan[tier];
+			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
 			const bool sfast = tier >= kFirstSplice, fast = tier < kFirstExact || sfast; // the register-resident kernels
 			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
-			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes;
+			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes, P.cells = cls[tier].cells;
 			// the gap-fill kernel keeps ONE matrix per wave for its two jobs, as many rows as the longer and as many columns as the wider
 			// of the two needs (two rows x two jobs per dword): a pair's two slots together must hold (rows / 2 + 1) x columns dwords
 			if (tier < kFirstExact) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
@@ -228,32 +234,53 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
 			if (P.hbm) need_state = std::max(need_state, P.n_slots * region);
 		}
-		if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
-		d_dir.ensure(need_dir, 1.0);
-		d_cigar_tmp.ensure(need_tmp, 1.0);
+		for (size_t &need_dir : need_dir_g)
+			if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
+		d_dir.ensure(need_dir_g[0], 1.0), d_dir2.ensure(need_dir_g[1], 1.0);
+		d_cigar_tmp.ensure(need_tmp_g[0], 1.0), d_cigar_tmp2.ensure(need_tmp_g[1], 1.0);
 		if (need_state) d_state.ensure(need_state, 1.0);
+		bool any_side = false;
+		for (int tier = kFirstExact; tier < kFirstSplice; ++tier) any_side |= plan[tier].end != plan[tier].beg;
+		if (any_side) {
+			if (!side) {
+				int lo_prio = 0, hi_prio = 0;
+				HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+				HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi_prio));
+				HIP_CHECK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+				HIP_CHECK(hipEventCreateWithFlags(&ev_side_done, hipEventDisableTiming));
+			}
+			HIP_CHECK(hipEventRecord(ev_ready, stream)); // job records uploaded, queue heads and cursors zeroed
+			HIP_CHECK(hipStreamWaitEvent(side, ev_ready, 0));
+		}
 		static const char *kFastNames[kFirstExact] = { "ksw_gapfill_kernel<512>[t256]", "ksw_gapfill_kernel<512>[t512]", "ksw_gapfill_kernel<512>[t1536]",
 		                                               "ksw_gapfill_kernel<1024>[t256]", "ksw_gapfill_kernel<1024>[t1024]", "ksw_gapfill_kernel<1024>[t3072]" };
 		static const char *kRingNames[kRingClasses] = { "ksw_extd2_kernel[r512]", "ksw_extd2_kernel[r1k]", "ksw_extd2_kernel[r2k]", "ksw_extd2_kernel[r4k]", "ksw_extd2_kernel[r8k]", "ksw_extd2_kernel[hbm]" };
+		for (int pass = 0; pass < 2; ++pass) // the side-stream group first: its long jobs should start as early as possible
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
-			if (P.end == P.beg) continue;
+			if (P.end == P.beg || group_of(tier) != 1 - pass) continue;
+			const bool on_side = group_of(tier) == 1;
+			hipStream_t stream_ = on_side ? side : stream;
 			KswLaunch L;
 			L.jobs = d_jobs.p + P.beg, L.res = d_res.p + P.beg, L.n_jobs = (int32_t)(P.end - P.beg);
 			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
 			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
-			L.cigar_tmp = d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap;
-			L.dir_pool = d_dir.p, L.slot_bytes = P.slot_bytes;
+			L.cigar_tmp = on_side ? d_cigar_tmp2.p : d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap;
+			L.dir_pool = on_side ? d_dir2.p : d_dir.p, L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
 			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc_dev;
 			L.state_pool = P.hbm ? d_state.p : nullptr;
 			L.single_affine = single_affine, L.splice = splice;
-			if (prof) prof->begin(stream);
-			if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream);
-			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream);
-			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream);
+			if (prof) prof->begin(stream_);
+			if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
+			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
+			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
-			if (prof) prof->end(stream, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes);
+			if (prof) prof->end(stream_, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+		}
+		if (any_side) {
+			HIP_CHECK(hipEventRecord(ev_side_done, side));
+			HIP_CHECK(hipStreamWaitEvent(stream, ev_side_done, 0));
 		}
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));

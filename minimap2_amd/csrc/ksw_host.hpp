@@ -11,7 +11,11 @@ struct KswRunner {
 	DevBuf<KswJob> d_jobs;
 	DevBuf<KswRes> d_res;
 	DevBuf<uint32_t> d_cigar, d_cigar_tmp, d_cursor, d_juncs;
-	DevBuf<uint8_t> d_dir, d_state;
+	DevBuf<uint8_t> d_dir, d_dir2, d_state;   // direction-matrix scratch of the two concurrent launch groups (ksw_host.cpp)
+	DevBuf<uint32_t> d_cigar_tmp2;
+	hipStream_t side = nullptr;               // the lane-exact kernel's launches run here, beside the register-resident kernels on the caller's stream
+	hipEvent_t ev_ready = nullptr, ev_side_done = nullptr;
+	~KswRunner() { if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_ready); (void)hipEventDestroy(ev_side_done); } }
 	DevBuf<int32_t> d_counter;
 	PinBuf<KswJob> sorted;            // jobs in launch order (tier, then decreasing cost), pinned for the H2D copy
 	PinBuf<KswRes> tmp_res;

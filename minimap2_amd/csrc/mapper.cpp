@@ -113,20 +113,24 @@ void Mapper::run(std::vector<ReadResult> &out)
 	std::vector<std::pair<long, long>> subs;
 	{
 		long max_reads = be_.max_reads_per_call(), sub_reads = 25000; // bound the read count too, so that a second lane overlaps the host stages; larger sub-batches keep the DP launches' tails short
-		if (m_all > 0) { // Illumina-sized reads: 25 k of them are a few Mbases, far too little work per kernel launch -- let the base budget decide
-			uint64_t tot = 0;
-			for (long i = 0; i < m_all; ++i) tot += (uint64_t)live[i].total();
-			if (tot / (uint64_t)m_all < 1000) sub_reads = 400000;
-		}
+		uint64_t tot = 0;
+		for (long i = 0; i < m_all; ++i) tot += (uint64_t)live[i].total();
+		if (m_all > 0 && tot / (uint64_t)m_all < 1000) sub_reads = 400000; // Illumina-sized reads: 25 k of them are a few Mbases, far too little work per kernel launch -- let the base budget decide
 		if (const char *e = getenv("MM2AMD_SUBBATCH_READS")) sub_reads = atol(e) > 0 ? atol(e) : sub_reads;
 		if (sub_reads < max_reads) max_reads = sub_reads;
+		// equal shares instead of full sub-batches plus a remainder, and at least two of them when there is enough work to overlap
+		// (a rank of an 8-GPU job gets an eighth of the batch: 125 Mbases map 6 % faster as 2 x 62 than as 100 + 25)
+		long n_sub = (long)((tot + (uint64_t)sub_bases - 1) / (uint64_t)sub_bases);
+		if (n_sub < 2 && tot >= 40000000) n_sub = 2;
+		if (n_sub > 0) sub_bases = (long)((tot + (uint64_t)n_sub - 1) / (uint64_t)n_sub);
 		for (long lo = 0, hi; lo < m_all; lo = hi) {
 			long bases = 0;
-			for (hi = lo; hi < m_all && hi - lo < max_reads && (hi == lo || bases + live[hi].total() <= sub_bases); ++hi) bases += live[hi].total();
+			for (hi = lo; hi < m_all && hi - lo < max_reads && bases < sub_bases; ++hi) bases += live[hi].total(); // the read that crosses the share's end still belongs to it
 			subs.emplace_back(lo, hi);
 		}
 	}
-	const int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), subs.size());
+	int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), subs.size());
+	if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) n_drivers = std::max(1, std::min(n_drivers, atoi(e))); // read per run: bench.py takes its un-overlapped kernel times with one lane
 	while ((int)scratch_.size() < n_drivers) scratch_.emplace_back(new DriverScratch);
 	be_.set_active_lanes(n_drivers);
 	std::atomic<size_t> next_sub(0);

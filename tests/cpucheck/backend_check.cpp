@@ -186,12 +186,14 @@ private:
 
 } // namespace
 
-Backend *make_backend(const FlatIndex &fi, void * /*device_tables*/, int /*n_threads*/) { return new CheckBackend(fi); }
+Backend *make_backend(const FlatIndex &fi, void * /*device_tables*/, int /*n_threads*/, int /*device*/, int /*replica*/, int /*tables_device*/) { return new CheckBackend(fi); }
+int backend_device_count() { return 16; } // replicas of the check backend are plain objects: any count goes
 const char *backend_name() { return "cpu-check(oracle)"; }
 // the check library has no device-built index objects
 struct IndexHandle;
 const FlatIndex &index_flat(const IndexHandle *) { throw std::runtime_error("check backend: no device index"); }
 void *index_device_tables(const IndexHandle *) { return nullptr; }
+int index_device(const IndexHandle *) { return 0; }
 }
 extern "C" long long mm2amd_alloc_counter(int) { return 0; }
 namespace mm2amd {

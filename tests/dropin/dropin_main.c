@@ -183,7 +183,7 @@ int main(int argc, char *argv[])
 			if (print_stats) {
 				double v[16];
 				int nv = mm2amd_last_stats(v, 16);
-				fprintf(stderr, "[dropin] backend=%s reads=%d", mm2amd_backend_name(), n_seq);
+				fprintf(stderr, "[dropin] backend=%s replicas=%d reads=%d", mm2amd_backend_name(), mm_gpu_n_replicas(), n_seq);
 				for (i = 0; i < nv; ++i) fprintf(stderr, " %.4g", v[i]);
 				fputc('\n', stderr);
 			}

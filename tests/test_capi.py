@@ -148,9 +148,12 @@ def test_python_stage_run_marshalling_with_a_fake_library(monkeypatch):
         def mm2amd_last_error(self):
             return b""
 
+        def mm_gpu_context_generation(self):
+            return calls.get("generation", 7)
+
     monkeypatch.setattr(mm, "lib", lambda path=None: Fake())
     al = object.__new__(mm.Aligner)
-    al.names, al.lens, al._staged, al._idx = ["c1"], [100], None, None
+    al.names, al.lens, al._staged, al._idx, al._generation = ["c1"], [100], None, None, 7
     out = al.map_batch([("a", b"ACGT"), "GGCC", ("c", "TTTTT")])
     assert calls["stage"] == (3, [0, 1, 2], [1, 1, 1], [(4, b"a", b"ACGT"), (4, b"read1", b"GGCC"), (5, b"c", b"TTTTT")])
     assert calls["run"] == 3 and calls["free"] == 3 and out == [[], [], []]
@@ -159,3 +162,6 @@ def test_python_stage_run_marshalling_with_a_fake_library(monkeypatch):
     assert calls["run"] == 4 and calls["free"] == 4 and out == [([], []), ([], [])]
     n_reg, reg, rep = (al.stage([("x", b"ACGT")]), al.run(raw=True))[1]
     assert len(n_reg) == 1 and len(reg) == 1 and len(rep) == 1
+    calls["generation"] = 8  # another Aligner / mm_gpu_init replaced the process-wide context: this one must say so, not map on the wrong index
+    with pytest.raises(mm.Mm2AmdError, match="no longer the process's active mapper"):
+        al.map_batch([("a", b"ACGT")])

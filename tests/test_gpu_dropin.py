@@ -165,3 +165,16 @@ def test_jump_annotation_identical(tmp_path):
         want, _ = _run([REF_BIN, "-x", "splice", "-t", "8", "-j", bed] + extra + [ref, rd])
         got, _ = _run([DROPIN, "-x", "splice", "-t", "8", "-j", bed] + extra + [ref, rd])
         assert want == got
+
+
+def test_two_replicas_on_one_device_identical(tmp_path):
+    # mm_gpu_init_multi with the same ordinal twice: two backends (own streams, buffers, index copy) on one GPU map the two halves of
+    # every mini-batch concurrently -- the in-process multi-GPU path as far as a single-GPU box can run it
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 4, 120, 51)
+    want, _ = _run([REF_BIN, "-x", "map-ont", "-a", "-t", "8", ref, reads])
+    env = dict(os.environ, MM2AMD_GPUS="2", MM2AMD_DEVICE_IDS="0,0")
+    p = subprocess.run([DROPIN, "-x", "map-ont", "-a", "-t", "8", "--stats", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG"))
+    assert "replicas=2" in p.stderr.decode(), p.stderr.decode()[-500:]
+    assert got == want

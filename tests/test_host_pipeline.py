@@ -336,6 +336,27 @@ def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm
     assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 100
 
 
+def test_in_process_replicas_equal_one_mapper(tmp_path):
+    """mm_gpu_init_multi's dispatcher (capi_map.cpp: shard_by_bases, one Mapper per replica on its own host thread, results into the
+    caller's arrays): 1, 2 and 5 replicas print the same records -- long reads, staged calls, read pairs (joint, and mates mapped
+    separately and paired afterwards, which must not be cut apart), more replicas than reads."""
+    import synth
+    def run(args, n):
+        return G.strip_pg(subprocess.run([CHECK] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=dict(os.environ, MM2AMD_GPUS=str(n))).stdout)
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 2, 45, 23)
+    one = run(["-x", "map-ont", "-a", ref, rd], 1)
+    assert one.count(b"\n") > 40
+    for n in (2, 5):
+        assert run(["-x", "map-ont", "-a", ref, rd], n) == one
+        assert run(["-x", "map-ont", "-a", "--staged", "-K", "150000", ref, rd], n) == one
+    assert run(["-x", "map-ont", "-a", "-K", "12000", ref, rd], 16) == one  # mini-batches of one or two reads: most replicas get nothing
+    ref, f1, f2, _ = synth.make_pairs(str(tmp_path / "pe"), n_pairs=70)
+    for args in (["-x", "sr", "-a", ref, f1, f2], ["-x", "sr", "-a", "--no-pairing", ref, f1, f2]):
+        assert run(args, 3) == run(args, 1)
+    ref, r1, r2, bed = synth.make_rna_pairs(str(tmp_path / "rna"))
+    assert run(["-x", "splice:sr", "-a", ref, r1, r2], 4) == run(["-x", "splice:sr", "-a", ref, r1, r2], 1)  # MM_F_WEAK_PAIRING
+
+
 JUNC_CASES = [["-x", "splice", "-a"], ["-x", "splice", "-a", "--junc-bonus", "20"], ["-x", "splice:hq", "-a", "-u", "n"], ["-x", "splice", "-c", "--cs", "-u", "f"]]
 
 
