@@ -1,11 +1,20 @@
-// RMQ-based chaining for the long-join re-chain branch (mg_lchain_rmq, lchain.c:250-368).
+// RMQ-based chaining (mg_lchain_rmq, lchain.c:250-368): the primary chainer of the MM_F_RMQ presets (asm5/10/20, lr:hqae) and
+// the long-join re-chain of map-ont / map-hifi (map.c:283-292), on the host.
 //
-// The reference keeps the active anchors in an AVL tree ordered by (query position, index) whose nodes carry the
-// minimum-priority node of their subtree (krmq.h); a range-minimum query returns one node, and when several nodes
-// share the minimum priority the one returned depends on the tree's shape and on the direction in which subtree
-// minima are combined.  To give the same chains we maintain the same balanced tree: same insertion/erasure
-// rebalancing cases, same "left, then right" combination rule for subtree minima, same query walk.
-#include <cassert>
+// What the reference computes.  Anchors are sorted by target coordinate; while anchor i is scored, the anchors of a sliding index
+// window [st, i0) -- everything already scored whose target coordinate is smaller and at most max_dist away -- are candidates.
+// Two look-ups per anchor:
+//   (1) among the window's anchors with query coordinate in (y_i - max_dist, y_i): the one with the smallest priority
+//       -(f + 0.5 * pen_gap * (x + y));
+//   (2) when that one is not an exact diagonal extension: the anchors of a second, narrower window (max_dist_inner) in
+//       descending (query coordinate, index) order, scored one by one with the skip rule of the chaining DP.
+// Look-up (2) depends only on the ORDER of the keys, so any ordered container gives the reference's answer: a sorted vector here.
+// Look-up (1) is a range-minimum query, and its answer is unique only while the minimum is: the reference keeps the window in an
+// AVL tree whose nodes remember the minimum-priority node of their subtree (krmq.h), and with equal priorities (two anchors
+// with the same chain score on the same anti-diagonal x + y: repeats produce them) the node it returns depends on that tree's
+// shape and on how every earlier insertion, removal and rotation happened to break the tie.  To return the same anchor we keep
+// a tree that evolves through the same states -- see TieExactMinTree below for the rules that matter and where they come from.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "chain_host.hpp"
@@ -14,270 +23,221 @@ namespace mm2amd {
 
 namespace {
 
-struct Node {
-	int32_t y;            // query position of the anchor
-	int64_t i;            // anchor index
-	double pri;           // -(f + 0.5 * pen_gap * (x + y)): smaller is better
-	Node *c[2];           // children
-	Node *best;           // node with the smallest pri in this subtree
-	signed char bal;      // height(right) - height(left)
-	unsigned size;
-};
+// ---------------------------------------------------------------------------------------------------------
+// Height-balanced search tree over (y, idx) with a per-subtree "best" (smallest-priority) node, kept in an index arena.
+//
+// Behaviour that must agree with krmq.h for the range minimum to break ties the same way:
+//   * shape: textbook AVL insertion; removal replaces a node that has a right subtree by its in-order successor
+//     (krmq.h:262-284) and rebalances bottom-up (:287-307).  Any implementation of these rules passes through the same shapes.
+//   * best-node bookkeeping is NOT a function of the shape.  combine(node, first, second) takes the node itself unless
+//     first's best is at least as good, then second's best unless the current pick is strictly better -- the later operand
+//     wins ties (krmq_update_min, :154-157).  It is called with (left, right) after an insertion -- upwards from the new node,
+//     stopping at the first ancestor whose best is not the new node (:226-229) -- and for every ancestor after a removal (:285-286);
+//     a rotation recombines only the node(s) that moved down, with the operands in the order (child that stays, child that is
+//     handed over) (:165,179-180), and the new subtree root INHERITS the old root's best without a recombination (:166,181).
+//   * the query visits the split node, then the lower boundary path top-down (node, then its right child's best), then the upper
+//     boundary path (node, then its left child's best), and replaces its pick only by a strictly better node (:134-149).
+// ---------------------------------------------------------------------------------------------------------
+class TieExactMinTree {
+public:
+	explicit TieExactMinTree(size_t capacity) { pool_.reserve(capacity + 1); pool_.emplace_back(); } // slot 0 is "no node"
+	uint32_t size() const { return pool_[root_].count; }
+	bool empty() const { return root_ == 0; }
 
-inline int cmp_node(const Node *a, const Node *b) // lc_elem_cmp, lchain.c:226
-{
-	return a->y < b->y ? -1 : a->y > b->y ? 1 : (a->i > b->i) - (a->i < b->i);
-}
-inline bool better(const Node *a, const Node *b) { return a->pri < b->pri; } // lc_elem_lt2
-inline unsigned size_of(const Node *p) { return p ? p->size : 0; }
-
-constexpr int MAXD = 64;
-
-struct Tree {
-	Node *root = nullptr;
-
-	static void pull_best(Node *p, const Node *q, const Node *r) // krmq_update_min: left subtree first, then right; ties keep the later operand
+	void insert(int32_t y, int64_t idx, double pri)
 	{
-		p->best = !q || better(p, q->best) ? p : q->best;
-		p->best = !r || better(p->best, r->best) ? p->best : r->best;
-	}
-	// single rotation: (a,(b,c)q)p => ((a,b)p,c)q  ; dir=0 rotates to the left
-	static Node *rot1(Node *p, int dir)
-	{
-		const int opp = 1 - dir;
-		Node *q = p->c[opp], *s = p->best;
-		const unsigned size_p = p->size;
-		p->size -= q->size - size_of(q->c[dir]);
-		q->size = size_p;
-		pull_best(p, p->c[dir], q->c[dir]);
-		q->best = s;
-		p->c[opp] = q->c[dir];
-		q->c[dir] = p;
-		return q;
-	}
-	// double rotation: (a,((b,c)r,d)q)p => ((a,b)p,(c,d)q)r
-	static Node *rot2(Node *p, int dir)
-	{
-		const int opp = 1 - dir;
-		Node *q = p->c[opp], *r = q->c[dir], *s = p->best;
-		const unsigned size_x_dir = size_of(r->c[dir]);
-		r->size = p->size;
-		p->size -= q->size - size_x_dir;
-		q->size -= size_x_dir + 1;
-		pull_best(p, p->c[dir], r->c[dir]);
-		pull_best(q, q->c[opp], r->c[opp]);
-		r->best = s;
-		p->c[opp] = r->c[dir];
-		r->c[dir] = p;
-		q->c[dir] = r->c[opp];
-		r->c[opp] = q;
-		const int b1 = dir == 0 ? +1 : -1;
-		if (r->bal == b1) q->bal = 0, p->bal = (signed char)-b1;
-		else if (r->bal == 0) q->bal = p->bal = 0;
-		else q->bal = (signed char)b1, p->bal = 0;
-		r->bal = 0;
-		return r;
-	}
-	void insert(Node *x)
-	{
-		unsigned char stack[MAXD];
-		Node *path[MAXD];
-		Node *bp = root, *bq = nullptr, *p, *q, *r = nullptr;
-		int which = 0, top = 0, path_len = 0;
-		for (p = bp, q = bq; p; q = p, p = p->c[which]) {
-			const int cmp = cmp_node(x, p);
-			if (cmp == 0) return; // keys are unique here
-			if (p->bal != 0) bq = q, bp = p, top = 0;
-			stack[top++] = which = (cmp > 0);
-			path[path_len++] = p;
+		const int32_t fresh = alloc(y, idx, pri);
+		trail_.clear();
+		for (int32_t cur = root_; cur;) {
+			const int side = key_less(cur, y, idx) ? 1 : 0; // keys are unique: (y, idx) with idx the anchor's index
+			trail_.push_back({ cur, side });
+			cur = pool_[cur].kid[side];
 		}
-		x->bal = 0, x->size = 1, x->c[0] = x->c[1] = nullptr, x->best = x;
-		if (q == nullptr) root = x;
-		else q->c[which] = x;
-		if (bp == nullptr) return;
-		for (int k = 0; k < path_len; ++k) ++path[k]->size;
-		for (int k = path_len - 1; k >= 0; --k) {
-			pull_best(path[k], path[k]->c[0], path[k]->c[1]);
-			if (path[k]->best != x) break;
+		if (trail_.empty()) { root_ = fresh; return; }
+		pool_[trail_.back().node].kid[trail_.back().side] = fresh;
+		for (const Step &s : trail_) ++pool_[s.node].count;
+		for (size_t k = trail_.size(); k-- > 0;) { // the new node announces itself upwards while it is the best of the subtree
+			combine(trail_[k].node, pool_[trail_[k].node].kid[0], pool_[trail_[k].node].kid[1]);
+			if (pool_[trail_[k].node].best != fresh) break;
 		}
-		for (p = bp, top = 0; p != x; p = p->c[stack[top]], ++top)
-			if (stack[top] == 0) --p->bal; else ++p->bal;
-		if (bp->bal > -2 && bp->bal < 2) return;
-		which = (bp->bal < 0);
-		const int b1 = which == 0 ? +1 : -1;
-		q = bp->c[1 - which];
-		if (q->bal == b1) {
-			r = rot1(bp, which);
-			q->bal = bp->bal = 0;
-		} else r = rot2(bp, which);
-		if (bq == nullptr) root = r;
-		else bq->c[bp != bq->c[0]] = r;
+		for (size_t k = trail_.size(); k-- > 0;) { // retrace: the subtree below trail_[k] on its `side` grew by one level
+			Node &a = pool_[trail_[k].node];
+			a.tilt += trail_[k].side ? 1 : -1;
+			if (a.tilt == 0) break;
+			if (a.tilt == 1 || a.tilt == -1) continue;
+			const int heavy = trail_[k].side;
+			const int32_t sub = pool_[a.kid[heavy]].tilt == (heavy ? 1 : -1) ? rotate_once(trail_[k].node, 1 - heavy, true) : rotate_twice(trail_[k].node, 1 - heavy);
+			relink(k, sub);
+			break;
+		}
 	}
-	Node *find(const Node *x) const
+
+	// removes (y, idx) if present
+	bool erase(int32_t y, int64_t idx)
 	{
-		Node *p = root;
-		while (p) {
-			const int cmp = cmp_node(x, p);
-			if (cmp < 0) p = p->c[0];
-			else if (cmp > 0) p = p->c[1];
+		trail_.clear();
+		int32_t cur = root_;
+		while (cur && !key_equal(cur, y, idx)) {
+			const int side = key_less(cur, y, idx) ? 1 : 0;
+			trail_.push_back({ cur, side });
+			cur = pool_[cur].kid[side];
+		}
+		if (!cur) return false;
+		for (const Step &s : trail_) --pool_[s.node].count;
+		const int32_t gone = cur;
+		const size_t at = trail_.size(); // position of the removed node in the trail
+		if (pool_[gone].kid[1] == 0) {
+			relink(at, pool_[gone].kid[0]);
+		} else {
+			int32_t succ = pool_[gone].kid[1];
+			if (pool_[succ].kid[0] == 0) { // the right child is the successor: it moves up with its own right subtree
+				pool_[succ].kid[0] = pool_[gone].kid[0];
+				pool_[succ].tilt = pool_[gone].tilt;
+				pool_[succ].count = pool_[gone].count - 1;
+				relink(at, succ);
+				trail_.push_back({ succ, 1 });
+			} else { // the successor is the leftmost node of the right subtree: it takes the removed node's place
+				trail_.push_back({ 0, 1 }); // placeholder for the successor
+				int32_t parent = succ;
+				for (;;) {
+					trail_.push_back({ parent, 0 });
+					succ = pool_[parent].kid[0];
+					if (pool_[succ].kid[0] == 0) break;
+					parent = succ;
+				}
+				pool_[parent].kid[0] = pool_[succ].kid[1];
+				pool_[succ].kid[0] = pool_[gone].kid[0], pool_[succ].kid[1] = pool_[gone].kid[1];
+				pool_[succ].tilt = pool_[gone].tilt;
+				for (size_t k = at + 1; k < trail_.size(); ++k) --pool_[trail_[k].node].count;
+				pool_[succ].count = pool_[gone].count - 1;
+				trail_[at].node = succ;
+				relink(at, succ);
+			}
+		}
+		for (size_t k = trail_.size(); k-- > 0;) combine(trail_[k].node, pool_[trail_[k].node].kid[0], pool_[trail_[k].node].kid[1]);
+		for (size_t k = trail_.size(); k-- > 0;) { // retrace: the subtree below trail_[k] on its `side` lost one level
+			const int32_t a = trail_[k].node;
+			const int side = trail_[k].side, away = side ? -1 : 1; // the tilt moves away from the side that shrank
+			pool_[a].tilt += away;
+			if (pool_[a].tilt == away) break;      // it was balanced: its height is unchanged
+			if (pool_[a].tilt == 0) continue;      // it leaned to the shrunk side: one level shorter now
+			const int32_t other = pool_[a].kid[1 - side];
+			if (pool_[other].tilt == -away) { relink(k, rotate_twice(a, side)); continue; }
+			const bool level = pool_[other].tilt == 0;
+			relink(k, rotate_once(a, side, !level));
+			if (level) { pool_[other].tilt = -away, pool_[a].tilt = away; break; } // the rotated subtree kept its height
+		}
+		recycle(gone);
+		return true;
+	}
+
+	// minimum-priority node with lo < key <= hi as the reference delimits it: keys (y_lo, INT32_MAX) .. (y_hi, 0), closed
+	int64_t range_min(int32_t y_lo, int32_t y_hi) const
+	{
+		const int64_t i_lo = INT32_MAX, i_hi = 0;
+		int32_t split = root_;
+		while (split) { // the first node inside the interval on the way down
+			if (order(y_lo, i_lo, split) > 0) split = pool_[split].kid[1];
+			else if (order(y_hi, i_hi, split) < 0) split = pool_[split].kid[0];
 			else break;
 		}
-		return p;
-	}
-	Node *erase(const Node *x)
-	{
-		Node *p, *path[MAXD], fake;
-		unsigned char dir[MAXD];
-		int d = 0, cmp;
-		fake = *root, fake.c[0] = root, fake.c[1] = nullptr;
-		for (cmp = -1, p = &fake; cmp; cmp = cmp_node(x, p)) {
-			const int which = (cmp > 0);
-			dir[d] = (unsigned char)which;
-			path[d++] = p;
-			p = p->c[which];
-			if (p == nullptr) return nullptr;
-		}
-		for (int k = 1; k < d; ++k) --path[k]->size;
-		if (p->c[1] == nullptr) {
-			path[d - 1]->c[dir[d - 1]] = p->c[0];
-		} else {
-			Node *q = p->c[1];
-			if (q->c[0] == nullptr) {
-				q->c[0] = p->c[0];
-				q->bal = p->bal;
-				path[d - 1]->c[dir[d - 1]] = q;
-				path[d] = q, dir[d++] = 1;
-				q->size = p->size - 1;
-			} else {
-				Node *r;
-				const int e = d++;
-				for (;;) {
-					dir[d] = 0;
-					path[d++] = q;
-					r = q->c[0];
-					if (r->c[0] == nullptr) break;
-					q = r;
-				}
-				r->c[0] = p->c[0];
-				q->c[0] = r->c[1];
-				r->c[1] = p->c[1];
-				r->bal = p->bal;
-				path[e - 1]->c[dir[e - 1]] = r;
-				path[e] = r, dir[e] = 1;
-				for (int k = e + 1; k < d; ++k) --path[k]->size;
-				r->size = p->size - 1;
+		if (!split) return -1;
+		int32_t pick = split;
+		auto offer = [&](int32_t c) { if (c && pool_[c].pri < pool_[pick].pri) pick = c; };
+		if (order(y_lo, i_lo, split) != 0) // lower boundary: nodes at or above the bound count, together with everything to their right
+			for (int32_t cur = pool_[split].kid[0]; cur;) {
+				const int c = order(y_lo, i_lo, cur);
+				if (c <= 0) { offer(cur); offer(pool_[pool_[cur].kid[1]].best_or_nil(pool_[cur].kid[1])); }
+				if (c == 0) break;
+				cur = pool_[cur].kid[c < 0 ? 0 : 1];
 			}
-		}
-		for (int k = d - 1; k >= 0; --k) pull_best(path[k], path[k]->c[0], path[k]->c[1]);
-		while (--d > 0) {
-			Node *q = path[d];
-			int b1 = 1, b2 = 2;
-			const int which = dir[d], other = 1 - which;
-			if (which) b1 = -b1, b2 = -b2;
-			q->bal = (signed char)(q->bal + b1);
-			if (q->bal == b1) break;
-			else if (q->bal == b2) {
-				Node *r = q->c[other];
-				if (r->bal == -b1) {
-					path[d - 1]->c[dir[d - 1]] = rot2(q, which);
-				} else {
-					path[d - 1]->c[dir[d - 1]] = rot1(q, which);
-					if (r->bal == 0) {
-						r->bal = (signed char)-b1;
-						q->bal = (signed char)b1;
-						break;
-					} else r->bal = q->bal = 0;
-				}
+		if (order(y_hi, i_hi, split) != 0) // upper boundary, mirrored
+			for (int32_t cur = pool_[split].kid[1]; cur;) {
+				const int c = order(y_hi, i_hi, cur);
+				if (c >= 0) { offer(cur); offer(pool_[pool_[cur].kid[0]].best_or_nil(pool_[cur].kid[0])); }
+				if (c == 0) break;
+				cur = pool_[cur].kid[c < 0 ? 0 : 1];
 			}
-		}
-		root = fake.c[0];
-		return p;
+		return pool_[pick].idx;
 	}
-	// minimum-priority node with lo <= key <= up (closed interval); krmq_rmq
-	const Node *range_min(const Node *lo, const Node *up) const
-	{
-		const Node *p = root, *path[2][MAXD], *min;
-		int plen[2] = {0, 0}, pcmp[2][MAXD], i, cmp, lca;
-		if (root == nullptr) return nullptr;
-		while (p) {
-			cmp = cmp_node(lo, p);
-			path[0][plen[0]] = p, pcmp[0][plen[0]++] = cmp;
-			if (cmp < 0) p = p->c[0]; else if (cmp > 0) p = p->c[1]; else break;
-		}
-		p = root;
-		while (p) {
-			cmp = cmp_node(up, p);
-			path[1][plen[1]] = p, pcmp[1][plen[1]++] = cmp;
-			if (cmp < 0) p = p->c[0]; else if (cmp > 0) p = p->c[1]; else break;
-		}
-		for (i = 0; i < plen[0] && i < plen[1]; ++i)
-			if (path[0][i] == path[1][i] && pcmp[0][i] <= 0 && pcmp[1][i] >= 0) break;
-		if (i == plen[0] || i == plen[1]) return nullptr;
-		lca = i, min = path[0][lca];
-		for (i = lca + 1; i < plen[0]; ++i) {
-			if (pcmp[0][i] <= 0) {
-				if (better(path[0][i], min)) min = path[0][i];
-				if (path[0][i]->c[1] && better(path[0][i]->c[1]->best, min)) min = path[0][i]->c[1]->best;
-			}
-		}
-		for (i = lca + 1; i < plen[1]; ++i) {
-			if (pcmp[1][i] >= 0) {
-				if (better(path[1][i], min)) min = path[1][i];
-				if (path[1][i]->c[0] && better(path[1][i]->c[0]->best, min)) min = path[1][i]->c[0]->best;
-			}
-		}
-		return min;
-	}
-	// largest node <= x (krmq_interval's lower bound)
-	const Node *floor(const Node *x) const
-	{
-		const Node *p = root, *l = nullptr;
-		while (p) {
-			const int cmp = cmp_node(x, p);
-			if (cmp < 0) p = p->c[0];
-			else if (cmp > 0) l = p, p = p->c[1];
-			else { l = p; break; }
-		}
-		return l;
-	}
-};
 
-// in-order iterator that can step backwards (krmq_itr_find + krmq_itr_prev)
-struct Iter {
-	const Node *stack[MAXD];
-	int top = -1;
-	bool seek(const Node *root, const Node *x)
-	{
-		const Node *p = root;
-		top = -1;
-		while (p) {
-			stack[++top] = p;
-			const int cmp = cmp_node(x, p);
-			if (cmp < 0) p = p->c[0]; else if (cmp > 0) p = p->c[1]; else break;
-		}
-		return p != nullptr;
-	}
-	const Node *at() const { return top < 0 ? nullptr : stack[top]; }
-	bool prev()
-	{
-		if (top < 0) return false;
-		const Node *p = stack[top]->c[0];
-		if (p) {
-			for (; p; p = p->c[1]) stack[++top] = p;
-			return true;
-		}
-		do { p = stack[top--]; } while (top >= 0 && p == stack[top]->c[0]);
-		return top >= 0;
-	}
-};
+private:
+	struct Node {
+		int32_t y = 0, kid[2] = { 0, 0 }, best = 0;
+		int32_t tilt = 0;       // height(right) - height(left)
+		uint32_t count = 0;     // nodes in the subtree
+		int64_t idx = 0;
+		double pri = 0;
+		int32_t best_or_nil(int32_t self) const { return self ? best : 0; }
+	};
+	struct Step { int32_t node; int side; };
+	std::vector<Node> pool_;
+	std::vector<int32_t> spare_;
+	mutable std::vector<Step> trail_;
+	int32_t root_ = 0;
 
-struct Pool { // fixed-capacity node pool with a free list (kmp_*_rmq)
-	std::vector<Node> mem;
-	std::vector<Node *> free_list;
-	size_t used = 0;
-	explicit Pool(size_t cap) : mem(cap) {}
-	Node *get() { if (!free_list.empty()) { Node *p = free_list.back(); free_list.pop_back(); return p; } return &mem[used++]; }
-	void put(Node *p) { free_list.push_back(p); }
+	int32_t alloc(int32_t y, int64_t idx, double pri)
+	{
+		int32_t id;
+		if (!spare_.empty()) id = spare_.back(), spare_.pop_back();
+		else id = (int32_t)pool_.size(), pool_.emplace_back();
+		Node &n = pool_[id];
+		n = Node();
+		n.y = y, n.idx = idx, n.pri = pri, n.best = id, n.count = 1;
+		return id;
+	}
+	void recycle(int32_t id) { spare_.push_back(id); }
+	bool key_less(int32_t n, int32_t y, int64_t idx) const { return pool_[n].y < y || (pool_[n].y == y && pool_[n].idx < idx); } // node key < (y, idx)
+	bool key_equal(int32_t n, int32_t y, int64_t idx) const { return pool_[n].y == y && pool_[n].idx == idx; }
+	int order(int32_t y, int64_t idx, int32_t n) const { return y < pool_[n].y ? -1 : y > pool_[n].y ? 1 : (idx > pool_[n].idx) - (idx < pool_[n].idx); } // (y, idx) vs node key
+	// the node hanging where trail_[k] hangs (k == trail_.size(): below the last step) is replaced by `sub`
+	void relink(size_t k, int32_t sub)
+	{
+		if (k == 0) root_ = sub;
+		else pool_[trail_[k - 1].node].kid[trail_[k - 1].side] = sub;
+	}
+	void combine(int32_t n, int32_t first, int32_t second)
+	{
+		int32_t pick = n;
+		if (first && !(pool_[n].pri < pool_[pool_[first].best].pri)) pick = pool_[first].best;
+		if (second && !(pool_[pick].pri < pool_[pool_[second].best].pri)) pick = pool_[second].best;
+		pool_[n].best = pick;
+	}
+	// `top` sinks towards `dir`, its child on the other side comes up.  flatten: both end up balanced (the caller fixes the tilts otherwise)
+	int32_t rotate_once(int32_t top, int dir, bool flatten)
+	{
+		const int32_t up = pool_[top].kid[1 - dir], whole = pool_[top].best;
+		const uint32_t all = pool_[top].count;
+		pool_[top].count -= pool_[up].count - pool_[pool_[up].kid[dir]].count;
+		pool_[up].count = all;
+		combine(top, pool_[top].kid[dir], pool_[up].kid[dir]);
+		pool_[up].best = whole;
+		pool_[top].kid[1 - dir] = pool_[up].kid[dir];
+		pool_[up].kid[dir] = top;
+		if (flatten) pool_[up].tilt = pool_[top].tilt = 0;
+		return up;
+	}
+	// the grandchild between `top` and its child on the far side comes up; `top` sinks towards `dir`
+	int32_t rotate_twice(int32_t top, int dir)
+	{
+		const int far = 1 - dir;
+		const int32_t mid = pool_[top].kid[far], up = pool_[mid].kid[dir], whole = pool_[top].best;
+		const uint32_t handed = pool_[pool_[up].kid[dir]].count;
+		pool_[up].count = pool_[top].count;
+		pool_[top].count -= pool_[mid].count - handed;
+		pool_[mid].count -= handed + 1;
+		combine(top, pool_[top].kid[dir], pool_[up].kid[dir]);
+		combine(mid, pool_[mid].kid[far], pool_[up].kid[far]);
+		pool_[up].best = whole;
+		pool_[top].kid[far] = pool_[up].kid[dir], pool_[up].kid[dir] = top;
+		pool_[mid].kid[dir] = pool_[up].kid[far], pool_[up].kid[far] = mid;
+		const int lean = dir == 0 ? 1 : -1; // the tilt `up` had decides which of the two takes the shorter half
+		if (pool_[up].tilt == lean) pool_[mid].tilt = 0, pool_[top].tilt = -lean;
+		else if (pool_[up].tilt == 0) pool_[mid].tilt = pool_[top].tilt = 0;
+		else pool_[mid].tilt = lean, pool_[top].tilt = 0;
+		pool_[up].tilt = 0;
+		return up;
+	}
 };
 
 // comput_sc_simple, lchain.c:229-248
@@ -296,6 +256,9 @@ inline int32_t simple_score(const Anchor &ai, const Anchor &aj, float pen_gap, f
 	return sc;
 }
 
+inline uint64_t near_key(int32_t y, int64_t idx) { return (uint64_t)((uint32_t)y ^ 0x80000000u) << 32 | (uint64_t)(uint32_t)idx; } // sorts like (y, idx)
+inline int32_t near_y(uint64_t k) { return (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); }
+
 } // namespace
 
 void chain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
@@ -308,66 +271,48 @@ void chain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int c
 	if (max_dist_inner < 0) max_dist_inner = 0;
 	if (max_dist_inner > max_dist) max_dist_inner = max_dist;
 	std::vector<int32_t> f(n), p(n), t(n, 0);
-	Tree outer, inner;
-	Pool pool((size_t)n * 2 + 4);
-	int64_t i0 = 0, st = 0, st_inner = 0;
+	TieExactMinTree far((size_t)std::min<int64_t>(n, (int64_t)cap_rmq_size + 2));
+	std::vector<uint64_t> near; // the narrow window's keys, ascending
+	int64_t i0 = 0, st = 0, st_near = 0;
 	for (int64_t i = 0; i < n; ++i) {
 		int64_t max_j = -1;
-		const int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff);
-		int32_t max_f = q_span;
-		Node key, lo, hi;
-		if (i0 < i && a[i0].x != a[i].x) { // anchors with a smaller target coordinate become candidates
+		const int32_t y_i = (int32_t)a[i].y;
+		int32_t max_f = (int32_t)(a[i].y >> 32 & 0xff);
+		if (i0 < i && a[i0].x != a[i].x) { // anchors with a smaller target coordinate become candidates (lchain.c:285-298)
 			for (int64_t j = i0; j < i; ++j) {
-				Node *q = pool.get();
-				q->y = (int32_t)a[j].y, q->i = j, q->pri = -(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y));
-				outer.insert(q);
-				if (max_dist_inner > 0) {
-					Node *r = pool.get();
-					r->y = q->y, r->i = q->i, r->pri = q->pri;
-					inner.insert(r);
-				}
+				far.insert((int32_t)a[j].y, j, -(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y)));
+				if (max_dist_inner > 0) { const uint64_t k = near_key((int32_t)a[j].y, j); near.insert(std::lower_bound(near.begin(), near.end(), k), k); }
 			}
 			i0 = i;
 		}
-		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + max_dist || (int)size_of(outer.root) > cap_rmq_size)) {
-			key.y = (int32_t)a[st].y, key.i = st;
-			if (outer.root && outer.find(&key)) pool.put(outer.erase(&key));
-			++st;
-		}
-		if (max_dist_inner > 0) {
-			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + max_dist_inner || (int)size_of(inner.root) > cap_rmq_size)) {
-				key.y = (int32_t)a[st_inner].y, key.i = st_inner;
-				if (inner.root && inner.find(&key)) pool.put(inner.erase(&key));
-				++st_inner;
+		// candidates out of reach -- another sequence, too far back, or more of them than the cap -- leave in index order (:300-318)
+		for (; st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + max_dist || (int64_t)far.size() > cap_rmq_size); ++st)
+			far.erase((int32_t)a[st].y, st);
+		if (max_dist_inner > 0)
+			for (; st_near < i && (a[i].x >> 32 != a[st_near].x >> 32 || a[i].x > a[st_near].x + max_dist_inner || (int64_t)near.size() > cap_rmq_size); ++st_near) {
+				const uint64_t k = near_key((int32_t)a[st_near].y, st_near);
+				const auto it = std::lower_bound(near.begin(), near.end(), k);
+				if (it != near.end() && *it == k) near.erase(it);
 			}
-		}
-		lo.i = INT32_MAX, lo.y = (int32_t)a[i].y - max_dist;
-		hi.i = 0, hi.y = (int32_t)a[i].y;
-		if (const Node *q = outer.range_min(&lo, &hi)) {
-			int32_t s, exact, width, n_skip = 0;
-			int64_t j = q->i;
-			s = f[j] + simple_score(a[i], a[j], pen_gap, pen_skip, &exact, &width);
-			if (width <= bw && s > max_f) max_f = s, max_j = j;
-			if (!exact && inner.root && (int32_t)a[i].y > 0) { // exhaustive look at the close neighbourhood
-				key.y = (int32_t)a[i].y - 1, key.i = n;
-				if (const Node *lower = inner.floor(&key)) {
-					Iter it;
-					it.seek(inner.root, lower);
-					const Node *c;
-					while ((c = it.at()) != nullptr) {
-						if (c->y < (int32_t)a[i].y - max_dist_inner) break;
-						j = c->i;
-						s = f[j] + simple_score(a[i], a[j], pen_gap, pen_skip, nullptr, &width);
-						if (width <= bw) {
-							if (s > max_f) {
-								max_f = s, max_j = j;
-								if (n_skip > 0) --n_skip;
-							} else if (t[j] == (int32_t)i) {
-								if (++n_skip > max_chn_skip) break;
-							}
-							if (p[j] >= 0) t[p[j]] = (int32_t)i;
+		const int64_t best = far.range_min(y_i - max_dist, y_i); // :320-322
+		if (best >= 0) {
+			int32_t exact, width, n_skip = 0;
+			int32_t s = f[best] + simple_score(a[i], a[best], pen_gap, pen_skip, &exact, &width);
+			if (width <= bw && s > max_f) max_f = s, max_j = best;
+			if (!exact && !near.empty() && y_i > 0) { // the close neighbourhood one by one, nearest query coordinate first (:328-354)
+				size_t k = (size_t)(std::upper_bound(near.begin(), near.end(), near_key(y_i - 1, n)) - near.begin());
+				while (k-- > 0) {
+					if (near_y(near[k]) < y_i - max_dist_inner) break;
+					const int64_t j = (int64_t)(uint32_t)near[k];
+					s = f[j] + simple_score(a[i], a[j], pen_gap, pen_skip, nullptr, &width);
+					if (width <= bw) {
+						if (s > max_f) {
+							max_f = s, max_j = j;
+							if (n_skip > 0) --n_skip;
+						} else if (t[j] == (int32_t)i) {
+							if (++n_skip > max_chn_skip) break;
 						}
-						if (!it.prev()) break;
+						if (p[j] >= 0) t[p[j]] = (int32_t)i;
 					}
 				}
 			}

@@ -418,6 +418,16 @@ def test_sdust_masking(kind, args, tmp_path):
     assert outs[0] == outs[1]
 
 
+def test_rmq_chainer_breaks_ties_like_the_reference():
+    """minimap2_amd/csrc/rmq_chain.cpp against the reference's mg_lchain_rmq (lchain.c:250-368 over krmq.h) on anchor sets built to make
+    range-minimum priorities tie, with constant eviction and size caps below the window (tests/cpucheck/rmq_test.cpp)."""
+    exe = os.path.join(HERE, "_build", "rmq_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/rmq_test not built (needs the compiled reference)")
+    out = subprocess.run([exe, "3000"], stdout=subprocess.PIPE, check=True).stdout.split()
+    assert out[0] == b"OK" and int(out[2]) > 500000
+
+
 def test_device_sdust_header_against_the_reference():
     """minimap2_amd/csrc/sdust_core.hpp (what dust_filter_kernel runs per read) compiled for the host, vs the reference's sdust()."""
     exe = os.path.join(HERE, "_build", "sdust_test")
