@@ -141,6 +141,15 @@ int mm_gpu_init_multi(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_
 int mm_gpu_init_index_multi(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int n_threads, int n_gpus, const int *device_ids);
 int mm_gpu_n_replicas(void);                     /* replicas of the live context (0: none) */
 
+/* Batch-of-one calls with the reference's signatures: mm_gpu_map for mm_map (map.c:380-392, minimap.h:375-376), mm_gpu_map_frag for
+ * mm_map_frag (map.c:227-378, minimap.h:378-379; n_segs 1 or 2).  Results as the reference returns them (libc blocks; NULL / 0 when
+ * nothing maps or on failure -- mm2amd_last_error() tells which); b, when not NULL, receives rep_len and frag_gap (mm_tbuf_t,
+ * minimap.h:207-210).  The device context is built on first use and rebuilt when (mi, *opt) change.  One GPU pipeline pass per
+ * call: the convenience path of a binding that maps read by read (python/cmappy.h:74-102), not the fast path. */
+void *mm_gpu_map(const mm2amd_idx_t *mi, int qlen, const char *seq, int *n_regs, void *b, const mm2amd_mapopt_t *opt, const char *qname);
+void mm_gpu_map_frag(const mm2amd_idx_t *mi, int n_segs, const int *qlens, const char **seqs, int *n_regs, MM2AMD_REG_PP regs, void *b,
+                     const mm2amd_mapopt_t *opt, const char *qname);
+
 /* mm_gpu_map_batch in two halves: mm_gpu_batch_stage copies the batch's sequences to the device (the hand-over the
  * reference's pipeline step 0 makes, map.c:543-575) and returns when they are resident; mm_gpu_map_staged runs the
  * hot path on the staged batch (results placed as mm_gpu_map_batch places them: read seg_off[i] + j of fragment i).  seq, and the

@@ -21,7 +21,9 @@ struct SeedChainParams {          // what mm_map_frag_core passes to seeding and
 	int bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
 	float chn_pen_gap, chn_pen_skip;
 	int is_cdna;
-	int anchors_only = 0;         // 1: stop after the anchor sort and return every read's sorted anchors (n_u = 0): the caller chains them (MM_F_RMQ)
+	int anchors_only = 0;         // 1: stop after the anchor sort and return every read's sorted anchors (n_u = 0): the caller chains them (a backend without an RMQ chainer)
+	int rmq = 0;                  // 1: chain with mg_lchain_rmq's rules (MM_F_RMQ, map.c:275-277) instead of mg_lchain_dp's
+	int rmq_inner_dist = 0, rmq_size_cap = 0; // mm_mapopt_t::rmq_inner_dist / rmq_size_cap
 };
 
 // the two chaining distance limits of a read of qlen bases (map.c:262-271): the query-side limit grows with the read for short
@@ -53,6 +55,7 @@ public:
 	virtual void enable_seq_len() {} // --qstrand: seed_chain() needs the reference sequence lengths (reverse-strand anchors in query-strand coordinates)
 	virtual bool supports_junctions() const { return true; } // KswScoring::juncs honoured by ksw()
 	virtual bool supports_sdust() const { return true; }
+	virtual bool supports_rmq() const { return false; }    // SeedChainParams::rmq honoured by seed_chain(); otherwise the mapper asks for anchors_only and chains on the host
 	virtual bool supports_byte_targets() const { return true; } // KswScoring::tbytes honoured by ksw() (splice:sr)     // SeedChainParams::sdust_thres honoured by seed_chain()
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next

@@ -40,7 +40,7 @@ struct Lane {
 	DevBuf<int32_t> d_rep_len, d_f, d_p, d_t;
 	DevBuf<Anchor> d_anchors;
 	DevBuf<uint8_t> d_sort_tmp, d_tbytes;
-	PinBuf<Anchor> h_anchors;
+	PinBuf<Anchor> h_anchors, h_redo;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
 	PinBuf<unsigned long long> h_cursor;
@@ -48,7 +48,7 @@ struct Lane {
 	DevBuf<Anchor> d_bt_out_a;
 	DevBuf<uint64_t> d_bt_out_u, d_bt_aoff, d_bt_uoff;
 	DevBuf<int32_t> d_bt_nu, d_bt_nv;
-	PinBuf<uint32_t> h_na, h_nmp, h_dust_n, h_dust_s, h_dust_e;
+	PinBuf<uint32_t> h_na, h_nmp, h_dust_n, h_dust_s, h_dust_e, h_tie;
 	std::vector<uint64_t> a_off, mp_off;
 	~Lane() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -114,6 +114,7 @@ public:
 		HIP_CHECK(hipStreamSynchronize(stream_));
 		I_.seq_len = d_ref_len_.p;
 	}
+	bool supports_rmq() const override { return getenv("MM2AMD_RMQ_ON_HOST") == nullptr; } // chain_rmq_kernel; MM2AMD_RMQ_ON_HOST=1: A/B against rmq_chain.cpp
 	void set_active_lanes(int n) override { active_lanes_ = std::max(1, std::min(n, n_lanes_)); }
 	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
 
@@ -298,12 +299,13 @@ public:
 				ReadChains &c = out[i];
 				c.rep_len = h_rep[i];
 				c.mp_p = hmp + mp_off[i], c.n_mp = (int32_t)(mp_off[i + 1] - mp_off[i]);
-				c.u_p = nullptr, c.n_u = 0;
+				c.u_p = nullptr, c.n_u = 0, c.chained = false;
 				c.a_p = ha + a_off[i], c.n_a = (int64_t)(a_off[i + 1] - a_off[i]);
 			}, 64);
 			return;
 		}
-		kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a);
+		if (P.rmq) { kp.begin(st); launch_chain_rmq(B, P, st); kp.end(st, "chain_rmq_kernel", 32.0 * n_a); }
+		else { kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a); }
 		// 4. chains: backtrack + compaction on the device, then only the chained anchors travel to the host
 		ln.d_bt_cursor.ensure(2), ln.d_bt_out_a.ensure(n_a + 1), ln.d_bt_out_u.ensure((P.min_cnt >= 2 ? n_a / 2 : n_a) + n + 1); // a chain has at least max(1, min_cnt) anchors (lchain.c:66)
 		ln.d_bt_nu.ensure(n), ln.d_bt_nv.ensure(n), ln.d_bt_aoff.ensure(n), ln.d_bt_uoff.ensure(n);
@@ -314,11 +316,13 @@ public:
 		int32_t *h_nu = ln.h_nu.ensure(n), *h_nv = ln.h_nv.ensure(n);
 		uint64_t *h_aoff = ln.h_aoff.ensure(n), *h_uoff = ln.h_uoff.ensure(n);
 		uint64_t *hmp = ln.h_minipos.ensure(n_mp + 1);
+		uint32_t *h_tie = P.rmq ? ln.h_tie.ensure(n) : nullptr;
 		HIP_CHECK(hipMemcpyAsync(h_cur, ln.d_bt_cursor.p, 16, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_nu, ln.d_bt_nu.p, n * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_nv, ln.d_bt_nv.p, n * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_aoff, ln.d_bt_aoff.p, n * 8, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_uoff, ln.d_bt_uoff.p, n * 8, hipMemcpyDeviceToHost, st));
+		if (h_tie) HIP_CHECK(hipMemcpyAsync(h_tie, ln.d_tie.p, n * 4, hipMemcpyDeviceToHost, st));
 		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipStreamSynchronize(st));
 		Trace::get().add(lane_id, "gpu:expand..backtrack", tt, Trace::now()); tt = Trace::now();
@@ -327,6 +331,16 @@ public:
 		uint64_t *hu = ln.h_u.ensure(n_u + 1);
 		if (n_v) HIP_CHECK(hipMemcpyAsync(ha, ln.d_bt_out_a.p, n_v * sizeof(Anchor), hipMemcpyDeviceToHost, st));
 		if (n_u) HIP_CHECK(hipMemcpyAsync(hu, ln.d_bt_out_u.p, n_u * 8, hipMemcpyDeviceToHost, st));
+		// reads the RMQ kernel left to the host (a tie in a range minimum, an over-full neighbourhood, a whole contig): their sorted
+		// anchors travel as they are and ReadChains::chained stays false -- the mapper chains them with rmq_chain.cpp
+		std::vector<std::pair<size_t, size_t>> redo; // (read, offset into the fallback buffer)
+		size_t redo_total = 0;
+		if (h_tie) for (size_t i = 0; i < n; ++i) if (h_tie[i]) redo.emplace_back(i, redo_total), redo_total += (size_t)(a_off[i + 1] - a_off[i]);
+		Anchor *h_redo = redo_total ? ln.h_redo.ensure(redo_total + 1) : nullptr;
+		for (const auto &rd : redo) {
+			const size_t cnt = (size_t)(a_off[rd.first + 1] - a_off[rd.first]);
+			if (cnt) HIP_CHECK(hipMemcpyAsync(h_redo + rd.second, ln.d_anchors.p + a_off[rd.first], cnt * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+		}
 		HIP_CHECK(hipStreamSynchronize(st));
 		Trace::get().add(lane_id, "d2h:chains", tt, Trace::now()); tt = Trace::now();
 		kp.collect();
@@ -337,7 +351,13 @@ public:
 			c.mp_p = hmp + mp_off[i], c.n_mp = (int32_t)(mp_off[i + 1] - mp_off[i]);
 			c.u_p = hu + h_uoff[i], c.n_u = h_nu[i];
 			c.a_p = ha + h_aoff[i], c.n_a = h_nv[i];
+			c.chained = true;
 		}, 64);
+		for (const auto &rd : redo) {
+			ReadChains &c = out[rd.first];
+			c.u_p = nullptr, c.n_u = 0, c.chained = false;
+			c.a_p = h_redo + rd.second, c.n_a = (int64_t)(a_off[rd.first + 1] - a_off[rd.first]);
+		}
 	}
 
 	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane_id, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) override
@@ -404,6 +424,18 @@ Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads, i
 	return new HipBackend(fi, (DeviceIndexTables *)device_tables, n_threads, device, replica, tables_device);
 }
 int backend_device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+void *backend_build_index_tables(FlatIndex &fi, int device, int *on_device)
+{
+	DeviceCtx &d = device_ctx(device);
+	std::lock_guard<std::mutex> lk(d.mu);
+	ensure_device(d);
+	std::unique_ptr<DeviceIndexTables> T(new DeviceIndexTables);
+	DeviceIndexBuilder::build_from_packed(fi, *T, d.stream);
+	if (on_device) *on_device = d.device_id;
+	return T.release();
+}
+void backend_free_index_tables(void *tables) { delete (DeviceIndexTables *)tables; }
 const char *backend_name() { return "hip:gfx950"; }
 
 } // namespace mm2amd

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include "../../include/mm2amd.h"
@@ -18,6 +19,10 @@ namespace mm2amd {
 // `tables_device` is where `device_tables` live (a backend on another device copies them)
 Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads, int device, int replica, int tables_device);
 int backend_device_count();
+// The minimizer tables of `fi` (sequence table and packed sequence set) built by the backend on `device` (< 0: the default one);
+// returns the tables (for make_backend's device_tables; *on_device = their device) or nullptr when this backend wants host tables.
+void *backend_build_index_tables(FlatIndex &fi, int device, int *on_device);
+void backend_free_index_tables(void *tables);
 const char *backend_name();
 void capi_set_error(const std::string &msg);              // capi_common.cpp
 int capi_fail(int code, const std::string &msg);
@@ -53,10 +58,17 @@ struct MapContext {
 	bool has_staged = false;
 	int n_threads = 1;
 	uint64_t generation = 0;
+	const void *mi_ptr = nullptr;     // the reference index this context mirrors (mm_gpu_init; the batch-of-one calls compare it)
+	void *built_tables = nullptr;     // minimizer tables the backend built for fi_own (mm_gpu_init); freed with the context
 	std::vector<Replica> reps;
+	~MapContext() { reps.clear(); if (built_tables) backend_free_index_tables(built_tables); }
 	MapperStats stats;                // summed over the replicas of the last run
 };
-std::mutex g_mu;
+// g_ctx_mu guards the context's lifetime (init / destroy take it exclusively, every other call shared); g_map_mu serialises the
+// calls that stage or map (one batch at a time, like the reference's pipeline step 1).  mm_gpu_format_batch only reads the
+// context, so the output stage of batch k runs beside the mapping of batch k+1 (map.c:541-643: steps 1 and 2 of worker_pipeline).
+std::shared_mutex g_ctx_mu;
+std::mutex g_map_mu;
 std::unique_ptr<MapContext> g_ctx;
 uint64_t g_generation = 0;
 
@@ -147,13 +159,27 @@ extern "C" {
 int mm_gpu_init_multi(const void *mi, const void *opt, int n_threads, int n_gpus, const int *device_ids)
 {
 	if (!mi || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_init: null index or options");
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::unique_lock<std::shared_mutex> lk(g_ctx_mu);
 	try {
 		std::unique_ptr<MapContext> c(new MapContext);
 		c->opt = *(const ref::MapOpt *)opt;
-		c->fi_own.from_reference((const ref::Idx *)mi);
+		// the index's minimizer tables: rebuilt on the device from its packed sequence (about a second for 3 Gb) rather than collected
+		// from the reference's hash tables on the host (most of a minute); MM2AMD_INIT_FROM_HASH=1 or an index without sequence
+		// (MM_I_NO_SEQ) takes the host route
+		const ref::Idx *rmi = (const ref::Idx *)mi;
+		const bool on_device = rmi->S && !(rmi->flag & ref::I_NO_SEQ) && !getenv("MM2AMD_INIT_FROM_HASH");
+		c->fi_own.from_reference(rmi, !on_device);
 		c->fi = &c->fi_own;
-		if (int rc = build_context(c, nullptr, -1, n_threads, n_gpus, device_ids)) return rc;
+		int tables_device = -1;
+		if (on_device) {
+			int first = -1;
+			if (device_ids && n_gpus > 0) first = device_ids[0];
+			else if (n_gpus > 1 || (n_gpus <= 0 && getenv("MM2AMD_GPUS") && atoi(getenv("MM2AMD_GPUS")) > 1)) first = getenv("MM2AMD_DEVICE_IDS") ? atoi(getenv("MM2AMD_DEVICE_IDS")) : 0;
+			c->built_tables = backend_build_index_tables(c->fi_own, first, &tables_device);
+			if (!c->built_tables) c->fi_own.from_reference(rmi, true); // a backend that works from host tables
+		}
+		if (int rc = build_context(c, c->built_tables, tables_device, n_threads, n_gpus, device_ids)) return rc;
+		c->mi_ptr = mi;
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -167,7 +193,7 @@ int mm_gpu_init_multi(const void *mi, const void *opt, int n_threads, int n_gpus
 int mm_gpu_init_index_multi(const mm2amd_index_t *idx, const void *opt, int n_threads, int n_gpus, const int *device_ids)
 {
 	if (!idx || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_init_index: null index or options");
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::unique_lock<std::shared_mutex> lk(g_ctx_mu);
 	try {
 		std::unique_ptr<MapContext> c(new MapContext);
 		c->opt = *(const ref::MapOpt *)opt;
@@ -188,13 +214,13 @@ int mm_gpu_init_index(const mm2amd_index_t *idx, const void *opt, int n_threads)
 
 uint64_t mm_gpu_context_generation(void)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	return g_ctx ? g_ctx->generation : 0;
 }
 
 int mm_gpu_n_replicas(void)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	return g_ctx ? (int)g_ctx->reps.size() : 0;
 }
 
@@ -310,7 +336,8 @@ static void hand_over(const std::vector<OutSlot> &slots, std::vector<ReadResult>
 
 int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const void *seq_)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
+	std::lock_guard<std::mutex> lk_map(g_map_mu);
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_batch_stage called before mm_gpu_init");
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_batch_stage: bad arguments");
 	try {
@@ -328,7 +355,8 @@ int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const v
 
 int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
+	std::lock_guard<std::mutex> lk_map(g_map_mu);
 	if (!g_ctx || !g_ctx->has_staged) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_staged: no staged batch");
 	if (!n_reg || !reg) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_staged: bad arguments");
 	try {
@@ -345,7 +373,7 @@ int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 
 int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const int *n_reg, void *const *reg, const int *rep_len, char **out, size_t *out_len)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_format_batch called before mm_gpu_init");
 	if (n_frag < 0 || !out || !out_len || (n_frag > 0 && (!seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch: bad arguments");
 	for (int i = 0; i < n_frag; ++i)
@@ -380,7 +408,7 @@ int64_t mm2amd_pack_regs(int n_frag, const int *n_reg, void *const *reg, uint8_t
 	if (n_frag < 0 || (n_frag > 0 && (!n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm2amd_pack_regs: bad arguments");
 	// sizes first (prefix sums give every fragment its slot), then the copies, both on the pool threads
 	int nt = 1;
-	{ std::lock_guard<std::mutex> lk(g_mu); if (g_ctx) nt = g_ctx->n_threads; }
+	{ std::shared_lock<std::shared_mutex> lk(g_ctx_mu); if (g_ctx) nt = g_ctx->n_threads; }
 	std::vector<int64_t> off((size_t)n_frag + 1, 0);
 	parallel_for(nt, n_frag, [&](long i, int) {
 		int64_t sz = 4;
@@ -451,7 +479,8 @@ int mm2amd_unpack_regs(const uint8_t *buf, int64_t size, int n_frag, int *n_reg,
 
 int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
+	std::lock_guard<std::mutex> lk_map(g_map_mu);
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_batch called before mm_gpu_init");
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch: bad arguments");
 	try {
@@ -472,9 +501,50 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 	}
 }
 
+// ---- batch-of-one calls with the reference's own signatures (mm_map, map.c:380-392; mm_map_frag, map.c:227-378 / :394-397): what a
+// binding that maps read by read calls (python/cmappy.h:74-102 wraps mm_map).  They go through mm_gpu_map_batch with one fragment:
+// correct and convenient, slow (a GPU pipeline pass per read) -- batch wherever the caller can.  The context is (re)built when
+// (mi, opt) differ from the live one.  b, when given, receives rep_len / frag_gap like the reference's mm_tbuf_t (minimap.h:207-210).
+struct TbufView { void *km; int rep_len, frag_gap; };
+
+static int ensure_context_for(const void *mi, const void *opt)
+{
+	{
+		std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
+		if (g_ctx && g_ctx->mi_ptr == mi && memcmp(&g_ctx->opt, opt, sizeof(ref::MapOpt)) == 0) return 0;
+	}
+	return mm_gpu_init(mi, opt, 0);
+}
+
+void mm_gpu_map_frag(const void *mi, int n_segs, const int *qlens, const char **seqs, int *n_regs, void **regs, void *b, const void *opt, const char *qname)
+{
+	for (int s = 0; s < n_segs; ++s) n_regs[s] = 0, regs[s] = nullptr;
+	if (!mi || !opt || n_segs < 1 || n_segs > 2) { capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_frag: one or two segments, non-null index and options"); return; }
+	if (ensure_context_for(mi, opt) != 0) return;
+	ref::Bseq1 rec[2];
+	for (int s = 0; s < n_segs; ++s) {
+		rec[s].l_seq = qlens[s], rec[s].rid = s;
+		rec[s].name = const_cast<char *>(qname), rec[s].seq = const_cast<char *>(seqs[s]), rec[s].qual = rec[s].comment = nullptr;
+	}
+	const int seg_off = 0;
+	int rep_len[2] = { 0, 0 }, frag_gap[2] = { 0, 0 };
+	if (mm_gpu_map_batch(1, &seg_off, &n_segs, rec, n_regs, regs, rep_len, frag_gap) != 0) {
+		for (int s = 0; s < n_segs; ++s) n_regs[s] = 0, regs[s] = nullptr;
+		return;
+	}
+	if (b) ((TbufView *)b)->rep_len = rep_len[0], ((TbufView *)b)->frag_gap = frag_gap[0];
+}
+
+void *mm_gpu_map(const void *mi, int qlen, const char *seq, int *n_regs, void *b, const void *opt, const char *qname)
+{
+	void *regs = nullptr;
+	mm_gpu_map_frag(mi, 1, &qlen, &seq, n_regs, &regs, b, opt, qname);
+	return regs;
+}
+
 void mm_gpu_destroy(void)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::unique_lock<std::shared_mutex> lk(g_ctx_mu);
 	g_ctx.reset();
 }
 
@@ -482,7 +552,7 @@ void mm_gpu_destroy(void)
 // caller installed; returns 1 when it did
 int mm_gpu_destroy_if(uint64_t generation)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::unique_lock<std::shared_mutex> lk(g_ctx_mu);
 	if (!g_ctx || g_ctx->generation != generation) return 0;
 	g_ctx.reset();
 	return 1;
@@ -492,7 +562,7 @@ const char *mm2amd_backend_name(void) { return backend_name(); }
 
 int mm2amd_last_stats(double *v, int n)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	if (!g_ctx) return 0;
 	const MapperStats &s = g_ctx->stats;
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,

@@ -24,7 +24,7 @@ void FlatIndex::build_tables(const std::vector<std::pair<uint64_t, uint64_t>> &s
 	for (size_t i = 1; i < bucket_start.size(); ++i) bucket_start[i] += bucket_start[i - 1];
 }
 
-void FlatIndex::from_reference(const ref::Idx *mi)
+void FlatIndex::from_reference(const ref::Idx *mi, bool tables)
 {
 	if (!mi || !mi->B) throw std::invalid_argument("[mm2amd] null reference index");
 	k = mi->k, w = mi->w, flag = mi->flag, n_seq = mi->n_seq, n_alt = mi->n_alt;
@@ -59,6 +59,7 @@ void FlatIndex::from_reference(const ref::Idx *mi)
 		for (uint32_t i = 0; i < n_seq * 2; ++i) if (P[i].n) spsc[i].assign(P[i].a, P[i].a + P[i].n);
 		has_spsc = true;
 	}
+	if (!tables) { keys.clear(), val_off.assign(1, 0), pos.clear(), bucket_start.clear(); return; }
 	std::vector<std::pair<uint64_t, uint64_t>> pairs;
 	const uint32_t nb = 1u << mi->b;
 	for (uint32_t b = 0; b < nb; ++b) {

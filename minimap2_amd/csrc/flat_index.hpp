@@ -82,7 +82,10 @@ struct FlatIndex {
 	// (hash, pos) pairs -> tables.  pairs must be sorted by (hash, pos).
 	void build_tables(const std::vector<std::pair<uint64_t, uint64_t>> &sorted_pairs);
 	// Flatten a reference-built index (read-only view of its private hash buckets).
-	void from_reference(const ref::Idx *mi);
+	// from a reference mm_idx_t: sequence table, packed sequence (borrowed) and annotations always; the minimizer tables only with
+	// `tables` (walking the reference's 2^b hash tables and sorting their content: ~40 s on one thread for a 3 Gb index -- the HIP
+	// product rebuilds them on the device from the packed sequence instead, DeviceIndexBuilder::build_from_packed)
+	void from_reference(const ref::Idx *mi, bool tables = true);
 	// Build from raw sequences with our own minimizer code path (host version; used when no reference index exists).
 	void from_sequences(int k, int w, int flag, int n, const char *const *seqs, const char *const *names,
 	                    void (*sketch)(const char *, int, int, int, uint32_t, int, std::vector<ref::mm128> &));

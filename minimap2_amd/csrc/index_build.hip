@@ -37,6 +37,16 @@ __global__ void __launch_bounds__(256) idx_encode_kernel(const char *ascii, uint
 	S[wi] = word;
 }
 
+// the reverse: 4-bit packed S (an index loaded from a .mmi or built by the reference carries it, index.c:242-246) -> nt4 bytes
+__global__ void __launch_bounds__(256) idx_decode_kernel(const uint32_t *S, uint8_t *nt4, uint64_t total)
+{
+	const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t b0 = wi * 8;
+	if (b0 >= total) return;
+	const uint32_t word = S[wi];
+	for (int j = 0; j < 8 && b0 + j < total; ++j) nt4[b0 + j] = (uint8_t)(word >> (j << 2) & 0xf);
+}
+
 struct ChunkDesc { uint32_t rid; uint32_t start; }; // chunk = [start, start + CHUNK) clipped to the sequence
 
 // one lane per chunk (sketch_dev.hpp)
@@ -134,11 +144,35 @@ void DeviceIndexBuilder::build(FlatIndex &fi, DeviceIndexTables &T, int k, int w
 	fi.S_own.resize(n_words);
 	if (n_words) HIP_CHECK(hipMemcpy(fi.S_own.data(), T.S.p, n_words * 4, hipMemcpyDeviceToHost));
 	fi.S = fi.S_own.data();
+	tables_from_nt4(fi, T, d_nt4, stream);
+}
+
+// The minimizer tables of an index whose sequence is already packed (fi.S; k, w, flag, the sequence table and sum_len set): what
+// mm_gpu_init does with a reference mm_idx_t instead of walking its 2^14 hash tables on the host -- a 3 Gb index is rebuilt in
+// about a second, and tools/e2e_wall.py checks once at full size that the result equals the reference's own mm_idx_gen.
+void DeviceIndexBuilder::build_from_packed(FlatIndex &fi, DeviceIndexTables &T, hipStream_t stream)
+{
+	if (fi.w <= 0 || fi.w >= 256 || fi.k <= 0 || fi.k > 28) throw std::invalid_argument("[mm2amd] index build: need 0<w<256 and 0<k<=28");
+	if (!fi.S) throw std::invalid_argument("[mm2amd] index without sequence");
+	const uint64_t total = fi.sum_len, n_words = (total + 7) / 8;
+	DevBuf<uint8_t> d_nt4;
+	d_nt4.ensure(total + 8, 1.0);
+	T.S.ensure(n_words + 1, 1.0);
+	if (n_words) HIP_CHECK(hipMemcpyAsync(T.S.p, fi.S, n_words * 4, hipMemcpyHostToDevice, stream));
+	if (n_words) hipLaunchKernelGGL(idx_decode_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, T.S.p, d_nt4.p, total);
+	HIP_CHECK(hipGetLastError());
+	tables_from_nt4(fi, T, d_nt4, stream);
+}
+
+// steps 2-4: sketch -> sort -> tables, from the nt4 bytes of the concatenated sequences
+void DeviceIndexBuilder::tables_from_nt4(FlatIndex &fi, DeviceIndexTables &T, DevBuf<uint8_t> &d_nt4, hipStream_t stream)
+{
+	const int k = fi.k, w = fi.w, flag = fi.flag, n_seq = (int)fi.n_seq;
 	// 2. chunked sketch: count, scan, emit
 	const int chunk_len = 2048;
 	std::vector<ChunkDesc> chunks;
 	for (int i = 0; i < n_seq; ++i)
-		for (uint64_t s = 0; s < lens[i]; s += chunk_len) chunks.push_back(ChunkDesc{(uint32_t)i, (uint32_t)s});
+		for (uint64_t s = 0; s < fi.seq_len[i]; s += chunk_len) chunks.push_back(ChunkDesc{(uint32_t)i, (uint32_t)s});
 	const uint64_t n_chunks = chunks.size();
 	DevBuf<ChunkDesc> d_chunks;
 	DevBuf<uint64_t> d_seq_off, d_out_off;

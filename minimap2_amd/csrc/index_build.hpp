@@ -24,6 +24,11 @@ struct DeviceIndexBuilder {
 	// Fills the host-side part of `fi` (names, lengths, packed S; no host hash tables) and the device tables `T`.
 	static void build(FlatIndex &fi, DeviceIndexTables &T, int k, int w, int flag, int n_seq, const char *const *seqs, const uint64_t *lens,
 	                  const char *const *names, hipStream_t stream);
+	// Same tables from an index that already carries its packed sequence (fi.S and the sequence table set: FlatIndex::from_reference
+	// without the host tables): the device part of mm_gpu_init.
+	static void build_from_packed(FlatIndex &fi, DeviceIndexTables &T, hipStream_t stream);
+private:
+	static void tables_from_nt4(FlatIndex &fi, DeviceIndexTables &T, DevBuf<uint8_t> &d_nt4, hipStream_t stream);
 };
 
 } // namespace mm2amd

@@ -103,7 +103,11 @@ void Mapper::run(std::vector<ReadResult> &out)
 	sp.chn_pen_gap = (float)(opt_.chain_gap_scale * 0.01 * fi_.k);
 	sp.chn_pen_skip = (float)(opt_.chain_skip_scale * 0.01 * fi_.k);
 	sp.is_cdna = (opt_.flag & F_SPLICE) ? 1 : 0; // map.c:230,280
-	sp.anchors_only = (opt_.flag & F_RMQ) ? 1 : 0; // map.c:275-277: RMQ chaining runs on the host over the device-sorted anchors
+	// map.c:275-277: mg_lchain_rmq instead of mg_lchain_dp -- on the device when the backend has the kernel (reads it hands back arrive
+	// with their sorted anchors and ReadChains::chained unset), otherwise on the host over the device-sorted anchors
+	sp.rmq = (opt_.flag & F_RMQ) && be_.supports_rmq() ? 1 : 0;
+	sp.anchors_only = (opt_.flag & F_RMQ) && !sp.rmq ? 1 : 0;
+	sp.rmq_inner_dist = opt_.rmq_inner_dist, sp.rmq_size_cap = opt_.rmq_size_cap;
 
 	// Sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight) and are the
 	// unit of pipelining: each of the backend's lanes is driven by one host thread that takes the next sub-batch through all of
@@ -242,7 +246,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			const long u0 = unit0[i];
 			ReadResult &res = out[live_id[lo + i]];
 			const uint32_t hash = read_hash(rv.name, qlen, opt_);
-			if (opt_.flag & F_RMQ) { // mg_lchain_rmq as the primary chainer (map.c:275-277)
+			if ((opt_.flag & F_RMQ) && !c.chained) { // mg_lchain_rmq as the primary chainer (map.c:275-277), for the reads the backend did not chain
 				ChainScratch sc;
 				std::vector<uint64_t> u2;
 				std::vector<Anchor> out_a;

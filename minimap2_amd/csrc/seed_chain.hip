@@ -923,6 +923,201 @@ void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// RMQ chaining fill (mg_lchain_rmq, lchain.c:250-368): the primary chainer of the MM_F_RMQ presets (asm5/10/20, lr:hqae), one
+// wavefront per read.
+//
+// The reference scores anchor i against candidates it keeps in two balanced trees over the query coordinate.  Both trees hold
+// exactly the anchors of a sliding INDEX window [st, i0) of the target-sorted array (insertion at i0, removal at st, lchain.c:285-
+// 318), so no tree is needed to reproduce what they answer:
+//   * the range-minimum look-up (:320-322) = the smallest priority among the window's anchors with query coordinate in
+//     (y_i - max_dist, y_i): all 64 lanes scan the window and reduce.  The priority of an anchor, -(f + 0.5 * pen_gap * (x + y)) in
+//     double precision, is fixed once its score is, so it is computed when the anchor enters the window.  If TWO anchors share the
+//     smallest priority the reference's answer depends on the history of its tree (rmq_chain.cpp): the kernel then gives the read up
+//     and flags it, and the host chains that read with the tie-exact tree (rare: equal chain scores on the same anti-diagonal);
+//   * the scan of the close neighbourhood (:328-354) visits the narrow window's anchors in descending (query coordinate, index)
+//     order: they are gathered into LDS, sorted there by the wave (bitonic, padded to a power of two), and scored 64 at a time with
+//     the skip rule resolved from ballots exactly as in chain_fill_kernel (an anchor is only ever marked by candidates visited
+//     before it: its chain successors have larger query coordinates).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RMQ_NEAR_CAP = 4096; // anchors of the narrow window scored per anchor; more: the read goes to the host
+constexpr int64_t RMQ_DEV_MAX_ANCHORS = 1 << 17; // one wavefront walks a read's anchors one by one (microseconds each): whole contigs are faster on a host thread
+
+__device__ __forceinline__ int32_t simple_score_dev(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, float pen_gap, float pen_skip, bool *exact, int32_t *width) // comput_sc_simple, lchain.c:229-248
+{
+	const int32_t dq = (int32_t)iy - (int32_t)jy, dr = (int32_t)(ix - jx);
+	const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq, span = (int32_t)(jy >> 32 & 0xff);
+	int32_t sc = span < dg ? span : dg;
+	*width = dd;
+	*exact = dd == 0 && dg <= span;
+	if (dd || dq > span) {
+		const float lin = pen_gap * (float)dd + pen_skip * (float)dg;
+		const float lg = dd >= 1 ? fast_log2_dev((float)(dd + 1)) : 0.0f;
+		sc -= (int)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+__global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedChainParams P)
+{
+	__shared__ uint64_t s_near[RMQ_NEAR_CAP];
+	const int lane = threadIdx.x, r = blockIdx.x;
+	const Anchor *a = B.anchors + B.a_off[r];
+	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
+	double *pri = (double *)(B.sort_key_out + B.a_off[r]); // dead since the anchor sort; the backtrack reuses it afterwards
+	int32_t max_dist = P.max_gap, max_dist_inner = P.rmq_inner_dist;
+	const int32_t bw = P.bw, cap = P.rmq_size_cap;
+	if (max_dist < bw) max_dist = bw;
+	if (max_dist_inner < 0) max_dist_inner = 0;
+	if (max_dist_inner > max_dist) max_dist_inner = max_dist;
+	for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+	__threadfence_block();
+	int64_t i0 = 0, st = 0, st_in = 0;
+	bool give_up = n > RMQ_DEV_MAX_ANCHORS;
+	for (int64_t i = 0; i < n && !give_up; ++i) {
+		const Anchor ai = a[i];
+		const uint64_t ix = ai.x, iy = ai.y;
+		const int32_t y_i = (int32_t)iy;
+		if (i0 < i && a[i0].x != ix) { // the anchors with a smaller target coordinate become candidates (:285-298)
+			for (int64_t j = i0 + lane; j < i; j += 64) pri[j] = -((double)f[j] + 0.5 * (double)P.chn_pen_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y));
+			i0 = i;
+			__threadfence_block();
+		}
+		// candidates out of reach leave in index order (:300-318): "out of reach" is monotone in the index, the size cap a plain bound
+		auto advance = [&](int64_t s0, int32_t dist) {
+			int64_t s = s0;
+			while (s < i) {
+				const int64_t c = s + lane;
+				bool stop = true;
+				if (c < i) { const uint64_t cx = a[c].x; stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)dist); }
+				const unsigned long long m = __ballot(stop);
+				if (m) { s += __ffsll((long long)m) - 1; break; }
+				s += 64;
+			}
+			if (s > i) s = i;
+			if (i0 - s > (int64_t)cap) s = i0 - cap;
+			return s;
+		};
+		st = advance(st, max_dist);
+		if (max_dist_inner > 0) st_in = advance(st_in, max_dist_inner);
+		// ---- range minimum over [st, i0) ----
+		double best = 0;
+		int64_t best_j = -1;
+		int n_best = 0;
+		for (int64_t base = st; base < i0; base += 64) {
+			const int64_t j = base + lane;
+			if (j < i0) {
+				const int32_t y_j = (int32_t)a[j].y;
+				if ((y_j > y_i - max_dist && y_j < y_i) || (y_j == y_i && j == 0)) { // keys (y_i - max_dist, INT32_MAX) .. (y_i, 0), closed (:320-321)
+					const double v = pri[j];
+					if (best_j < 0 || v < best) best = v, best_j = j, n_best = 1;
+					else if (v == best) ++n_best;
+				}
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1) { // combine (value, count): equal minima add up
+			const double ov = __shfl_xor(best, o, 64);
+			const int64_t oj = __shfl_xor(best_j, o, 64);
+			const int on = __shfl_xor(n_best, o, 64);
+			if (oj >= 0) {
+				if (best_j < 0 || ov < best) best = ov, best_j = oj, n_best = on;
+				else if (ov == best) n_best += on;
+			}
+		}
+		int32_t max_f = (int32_t)(iy >> 32 & 0xff);
+		int64_t max_j = -1;
+		if (best_j >= 0) {
+			if (n_best > 1) { give_up = true; break; } // the reference's pick depends on its tree's history: the host replays it
+			bool exact;
+			int32_t width;
+			const Anchor aj = a[best_j];
+			int32_t sc = f[best_j] + simple_score_dev(ix, iy, aj.x, aj.y, P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
+			if (width <= bw && sc > max_f) max_f = sc, max_j = best_j;
+			if (!exact && max_dist_inner > 0 && st_in < i0 && y_i > 0) {
+				// ---- the close neighbourhood, nearest query coordinate first ----
+				int n_c = 0;
+				for (int64_t base = st_in; base < i0; base += 64) {
+					const int64_t j = base + lane;
+					bool in = false;
+					int32_t y_j = 0;
+					if (j < i0) { y_j = (int32_t)a[j].y; in = y_j <= y_i - 1 && y_j >= y_i - max_dist_inner; }
+					const unsigned long long m = __ballot(in);
+					if (in) { const int d = n_c + popc_below(m, lane); if (d < RMQ_NEAR_CAP) s_near[d] = (uint64_t)(uint32_t)y_j << 32 | (uint64_t)(uint32_t)j; }
+					n_c += __popcll(m);
+				}
+				if (n_c > RMQ_NEAR_CAP) { give_up = true; break; }
+				int n_pad = 64;
+				while (n_pad < n_c) n_pad <<= 1;
+				for (int k = n_c + lane; k < n_pad; k += 64) s_near[k] = 0; // pads sort last (descending order; y >= 0 and every real key is > 0 unless (0, 0), which ties harmlessly)
+				__syncthreads();
+				for (int k2 = 2; k2 <= n_pad; k2 <<= 1)
+					for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+						for (int e = lane; e < n_pad; e += 64) {
+							const int partner = e ^ j2;
+							if (partner > e) {
+								const uint64_t u0 = s_near[e], u1 = s_near[partner];
+								const bool desc = (e & k2) == 0; // descending runs first
+								if (desc ? u0 < u1 : u0 > u1) s_near[e] = u1, s_near[partner] = u0;
+							}
+						}
+						__syncthreads();
+					}
+				int32_t n_skip = 0;
+				bool broke = false;
+				for (int base = 0; base < n_c && !broke; base += 64) {
+					const int c = base + lane;
+					int32_t scc = INT32_MIN, pj = -1;
+					int64_t j = -1;
+					if (c < n_c) {
+						j = (int64_t)(uint32_t)s_near[c];
+						bool ex;
+						int32_t wd;
+						const Anchor cj = a[j];
+						const int32_t v = simple_score_dev(ix, iy, cj.x, cj.y, P.chn_pen_gap, P.chn_pen_skip, &ex, &wd);
+						if (wd <= bw) scc = f[j] + v, pj = p[j];
+					}
+					const bool has = scc != INT32_MIN;
+					int32_t pm = has ? scc : INT32_MIN; // exclusive prefix maximum in visiting order
+					for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(pm, o, 64); if (lane >= o) pm = v > pm ? v : pm; }
+					int32_t excl = __shfl_up(pm, 1, 64);
+					if (lane == 0) excl = INT32_MIN;
+					excl = excl > max_f ? excl : max_f;
+					const bool improve = has && scc > excl;
+					if (has && pj >= 0) t[pj] = (int32_t)i; // marks left by candidates visited earlier (:349)
+					__threadfence_block();
+					const bool marked = has && !improve && t[j] == (int32_t)i;
+					unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
+					int stop_lane = 64;
+					while (ev) {
+						const int b = __ffsll((long long)ev) - 1;
+						ev &= ev - 1;
+						if (imp >> b & 1) { if (n_skip > 0) --n_skip; }
+						else if (++n_skip > P.max_chain_skip) { stop_lane = b; break; }
+					}
+					if (stop_lane < 64) broke = true, imp &= (1ull << stop_lane) - 1ull;
+					if (imp) {
+						const int last = 63 - __clzll((long long)imp);
+						max_f = __shfl(scc, last, 64);
+						max_j = __shfl(j, last, 64);
+					}
+				}
+				__syncthreads();
+			}
+		}
+		if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
+		__threadfence_block();
+	}
+	if (lane == 0) B.tie_flag[r] = give_up ? 1u : 0u; // reused: 1 = the host chains this read (rmq_chain.cpp)
+	if (give_up) for (int64_t i = lane; i < n; i += 64) f[i] = INT32_MIN, p[i] = -1; // no chain ends: the backtrack leaves the read empty
+}
+
+void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
+{
+	hipLaunchKernelGGL(chain_rmq_kernel, dim3(B.n_reads), dim3(64), 0, (hipStream_t)stream, B, P);
+	HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Chain backtrack + compaction (mg_chain_backtrack lchain.c:27-76, mg_chain_bk_end :9-25, compact_a :78-111), one wavefront
 // per read.  Chain ends are visited in the order the reference's unstable radix sort leaves them in (equal scores are common),
 // so that sort is replayed exactly (tie_exact_replay, all buckets); the walk itself is sequential (lane 0) and latency-bound,

@@ -135,7 +135,7 @@ private:
 			if (stop_.load()) return;
 		}
 	}
-	Slot slots_[16];
+	Slot slots_[64]; // more than the driver threads a context can have at once (16 replicas x 5 lanes would queue; 8 x 5 fit)
 	std::atomic<int> n_open_{0}, n_sleeping_{0}, n_workers_{0};
 	std::atomic<bool> stop_{false};
 	std::mutex mu_;

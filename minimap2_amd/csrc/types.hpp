@@ -54,6 +54,8 @@ struct ReadChains {
 	std::vector<Anchor> a;          // anchors of all chains, chain by chain
 	std::vector<uint64_t> mini_pos; // q_span<<32 | q_pos of every minimizer that was looked up and kept (seed.c:124)
 	int rep_len = 0;
+	bool chained = true;            // false: a_p / n_a are the read's SORTED anchors and the caller still has to chain them (MM_F_RMQ on a backend without,
+	                                // or a read its RMQ kernel handed back)
 };
 
 } // namespace mm2amd

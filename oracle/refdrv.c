@@ -206,3 +206,70 @@ double refdrv_map_pairs(const mm_idx_t *mi, const mm_mapopt_t *opt, int n_pairs,
 	free(m.tbuf);
 	return t0;
 }
+
+/* ---- order-independent digests of a minimizer index, to compare a 3 Gb index built by the reference's own mm_idx_gen with the
+ * tables the device builder produced without holding both in Python: sum over the distinct minimizers of a hash of
+ * (minimizer, its positions in ascending order), plus the counts.  refdrv_idx_digest walks the reference's private buckets
+ * (index.c:19-33, :93-110); refdrv_flat_digest does the same over flat (keys, val_off, pos) tables. ---- */
+static inline uint64_t dg_mix(uint64_t h) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33; return h; }
+
+typedef struct { const mm_idx_t *mi; uint64_t *sum, *n_keys, *n_pos; } dg_ref_t;
+
+static void dg_ref_bucket(void *data, long i, int tid)
+{
+	dg_ref_t *d = (dg_ref_t*)data;
+	const mm_idx_bucket_t *b = &d->mi->B[i];
+	idxhash_t *h = (idxhash_t*)b->h;
+	khint_t k;
+	uint64_t sum = 0, nk = 0, np = 0;
+	(void)tid;
+	if (h == 0) return;
+	for (k = 0; k < kh_end(h); ++k) {
+		uint64_t key, acc;
+		if (!kh_exist(h, k)) continue;
+		key = (kh_key(h, k) >> 1) << d->mi->b | (uint64_t)i; /* the minimizer hash: bucket index in the low bits (index.c:98) */
+		acc = dg_mix(key);
+		if (kh_key(h, k) & 1) acc = dg_mix(acc ^ kh_val(h, k)), ++np;
+		else {
+			const uint64_t *p = &b->p[kh_val(h, k) >> 32];
+			uint32_t n = (uint32_t)kh_val(h, k), j;
+			for (j = 0; j < n; ++j) acc = dg_mix(acc ^ p[j]);
+			np += n;
+		}
+		sum += acc, ++nk;
+	}
+	__sync_fetch_and_add(d->sum, sum), __sync_fetch_and_add(d->n_keys, nk), __sync_fetch_and_add(d->n_pos, np);
+}
+
+void refdrv_idx_digest(const mm_idx_t *mi, int n_threads, uint64_t out[3])
+{
+	dg_ref_t d;
+	out[0] = out[1] = out[2] = 0;
+	d.mi = mi, d.sum = &out[0], d.n_keys = &out[1], d.n_pos = &out[2];
+	kt_for(n_threads, dg_ref_bucket, &d, 1L << mi->b);
+}
+
+typedef struct { const uint64_t *keys, *pos; const uint32_t *val_off; uint64_t n_keys, *sum; } dg_flat_t;
+
+static void dg_flat_chunk(void *data, long c, int tid)
+{
+	dg_flat_t *d = (dg_flat_t*)data;
+	uint64_t i, e = ((uint64_t)c + 1) << 20, sum = 0;
+	(void)tid;
+	if (e > d->n_keys) e = d->n_keys;
+	for (i = (uint64_t)c << 20; i < e; ++i) {
+		uint64_t acc = dg_mix(d->keys[i]);
+		uint32_t j;
+		for (j = d->val_off[i]; j < d->val_off[i + 1]; ++j) acc = dg_mix(acc ^ d->pos[j]);
+		sum += acc;
+	}
+	__sync_fetch_and_add(d->sum, sum);
+}
+
+void refdrv_flat_digest(uint64_t n_keys, const uint64_t *keys, const uint32_t *val_off, const uint64_t *pos, int n_threads, uint64_t out[3])
+{
+	dg_flat_t d;
+	out[0] = 0, out[1] = n_keys, out[2] = n_keys ? val_off[n_keys] : 0;
+	d.keys = keys, d.pos = pos, d.val_off = val_off, d.n_keys = n_keys, d.sum = &out[0];
+	kt_for(n_threads, dg_flat_chunk, &d, (long)((n_keys + (1 << 20) - 1) >> 20));
+}

@@ -102,7 +102,7 @@ public:
 			c.rep_len = rep_len;
 			c.mini_pos.assign(mp, mp + n_mp);
 			if (p.anchors_only) {
-				c.u.clear();
+				c.u.clear(), c.chained = false;
 				c.a.resize(n_a);
 				if (n_a) memcpy(c.a.data(), a, n_a * sizeof(ora128_t));
 				c.view_own();
@@ -187,6 +187,8 @@ private:
 } // namespace
 
 Backend *make_backend(const FlatIndex &fi, void * /*device_tables*/, int /*n_threads*/, int /*device*/, int /*replica*/, int /*tables_device*/) { return new CheckBackend(fi); }
+void *backend_build_index_tables(FlatIndex &, int, int *) { return nullptr; } // the check backend looks minimizers up in the host tables
+void backend_free_index_tables(void *) {}
 int backend_device_count() { return 16; } // replicas of the check backend are plain objects: any count goes
 const char *backend_name() { return "cpu-check(oracle)"; }
 // the check library has no device-built index objects

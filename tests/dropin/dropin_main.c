@@ -22,7 +22,7 @@ int main(int argc, char *argv[])
 	mm_idxopt_t iopt;
 	mm_mapopt_t mopt;
 	const char *preset = 0;
-	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, staged = 0, old_best_n = -1;
+	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, staged = 0, one_by_one = 0, old_best_n = -1;
 	const char *alt_fn = 0, *junc_fn = 0, *jump_fn = 0, *pass1_fn = 0, *spsc_fn = 0;
 	float spsc_scale = 0.7f;
 	int64_t batch = 500000000;
@@ -43,6 +43,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-s") == 0) mopt.min_dp_max = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--seed") == 0) mopt.seed = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--stats") == 0) print_stats = 1;
+		else if (strcmp(argv[k], "--one-by-one") == 0) one_by_one = 1; /* mm_gpu_map / mm_gpu_map_frag per fragment instead of one mm_gpu_map_batch */
 		else if (strcmp(argv[k], "-O") == 0) { char *s; mopt.q = mopt.q2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.q2 = strtol(s + 1, &s, 10); }
 		else if (strcmp(argv[k], "-E") == 0) { char *s; mopt.e = mopt.e2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.e2 = strtol(s + 1, &s, 10); }
 		else if (strcmp(argv[k], "-A") == 0) mopt.a = atoi(argv[++k]);
@@ -171,7 +172,17 @@ int main(int argc, char *argv[])
 			int j, f;
 			for (i = 1, j = 0, n_frag = 0; i <= n_seq; ++i)
 				if (i == n_seq || !frag_mode || !mm_qname_same(seq[i-1].name, seq[i].name)) n_seg[n_frag] = i - j, seg_off[n_frag++] = j, j = i;
-			if (staged) {
+			if (one_by_one) {
+				for (f = 0; f < n_frag; ++f) {
+					struct mm_tbuf_s tb = { 0, 0, 0 };
+					int o = seg_off[f], qlens[2];
+					const char *seqs[2];
+					for (i = 0; i < n_seg[f]; ++i) qlens[i] = seq[o + i].l_seq, seqs[i] = seq[o + i].seq;
+					if (n_seg[f] == 1) reg[o] = (mm_reg1_t*)mm_gpu_map(mi, qlens[0], seqs[0], &n_reg[o], &tb, &mopt, seq[o].name);
+					else mm_gpu_map_frag(mi, n_seg[f], qlens, seqs, &n_reg[o], (void**)&reg[o], &tb, &mopt, seq[o].name);
+					for (i = 0; i < n_seg[f]; ++i) rep_len[o + i] = tb.rep_len, frag_gap[o + i] = tb.frag_gap;
+				}
+			} else if (staged) {
 				if (mm_gpu_batch_stage(n_frag, seg_off, n_seg, seq) != 0 || mm_gpu_map_staged(n_reg, (void**)reg, rep_len, frag_gap) != 0) {
 					fprintf(stderr, "staged mapping: %s\n", mm2amd_last_error());
 					return 2;

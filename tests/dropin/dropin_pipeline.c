@@ -1,0 +1,139 @@
+/* tests/dropin/dropin_pipeline.c -- TEST / MEASUREMENT INFRASTRUCTURE (not part of the product library).
+ *
+ * The reference's three-step mini-batch pipeline (worker_pipeline, map.c:541-643, run by kt_pipeline) with its step 1 replaced by
+ * the GPU dispatcher and its step 2 by the library's parallel output stage -- INTEGRATION.md section 1 as a program:
+ *   step 0  mm_bseq_read3: the reference's own FASTA/FASTQ reader (map.c:543-575)
+ *   step 1  mm_gpu_map_batch instead of kt_for(worker_for) (map.c:576)
+ *   step 2  mm_gpu_format_batch instead of the mm_write_sam3 / mm_write_paf4 loop (map.c:585-623), then the frees of :624-636
+ * kt_pipeline (the reference's, kthread.c:130) runs the steps of consecutive mini-batches on three threads, so parsing batch k+1,
+ * mapping batch k and formatting batch k-1 overlap exactly as in the reference.  It prints the reference's own progress stamps
+ * ("[M::worker_pipeline::<real>*<cpu/real>] mapped <n> sequences", map.c:638-639; "[M::main::...] loaded/built the index" after the
+ * index is in memory, main.c:456-459), so tools/e2e_wall.py reads the same interval off both programs.
+ *
+ * usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch_bases] ref.fa|ref.mmi reads.fa     (single-end reads) */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "minimap.h"
+#include "mmpriv.h"
+#include "bseq.h"
+#include "kthread.h"
+#include "mm2amd.h"
+
+static int64_t parse_num(const char *str) /* main.c:103-111: 500M, 4g, 200k */
+{
+	char *q;
+	double x = strtod(str, &q);
+	if (*q == 'G' || *q == 'g') x *= 1e9;
+	else if (*q == 'M' || *q == 'm') x *= 1e6;
+	else if (*q == 'K' || *q == 'k') x *= 1e3;
+	return (int64_t)(x + .499);
+}
+
+typedef struct {
+	mm_bseq_file_t *fp;
+	const mm_idx_t *mi;
+	const mm_mapopt_t *opt;
+	int64_t batch;
+	int n_processed, failed;
+} pipeline_t;
+
+typedef struct {
+	pipeline_t *p;
+	int n_seq;
+	mm_bseq1_t *seq;
+	int *n_reg, *seg_off, *n_seg, *rep_len, *frag_gap;
+	mm_reg1_t **reg;
+} step_t;
+
+static void *worker(void *shared, int step, void *in)
+{
+	pipeline_t *p = (pipeline_t*)shared;
+	int i, j;
+	if (step == 0) {
+		step_t *s = (step_t*)calloc(1, sizeof(step_t));
+		const int with_qual = (p->opt->flag & MM_F_OUT_SAM) && !(p->opt->flag & MM_F_NO_QUAL);
+		s->seq = mm_bseq_read3(p->fp, p->batch, with_qual, !!(p->opt->flag & MM_F_COPY_COMMENT), 0, &s->n_seq);
+		if (s->seq == 0) { free(s); return 0; }
+		s->p = p;
+		for (i = 0; i < s->n_seq; ++i) s->seq[i].rid = p->n_processed++;
+		s->n_reg = (int*)calloc(5 * (size_t)s->n_seq, sizeof(int));
+		s->seg_off = s->n_reg + s->n_seq, s->n_seg = s->seg_off + s->n_seq, s->rep_len = s->n_seg + s->n_seq, s->frag_gap = s->rep_len + s->n_seq;
+		s->reg = (mm_reg1_t**)calloc(s->n_seq, sizeof(mm_reg1_t*));
+		for (i = 0; i < s->n_seq; ++i) s->seg_off[i] = i, s->n_seg[i] = 1;
+		return s;
+	} else if (step == 1) {
+		step_t *s = (step_t*)in;
+		if (mm_gpu_map_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap) != 0) {
+			fprintf(stderr, "mm_gpu_map_batch: %s\n", mm2amd_last_error());
+			p->failed = 1;
+		}
+		return s;
+	} else {
+		step_t *s = (step_t*)in;
+		char *text = 0;
+		size_t text_len = 0;
+		if (!p->failed && mm_gpu_format_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &text, &text_len) != 0) {
+			fprintf(stderr, "mm_gpu_format_batch: %s\n", mm2amd_last_error());
+			p->failed = 1;
+		}
+		if (text) fwrite(text, 1, text_len, stdout), free(text);
+		for (i = 0; i < s->n_seq; ++i) {
+			mm_bseq1_t *t = &s->seq[i];
+			for (j = 0; j < s->n_reg[i]; ++j) free(s->reg[i][j].p);
+			free(s->reg[i]);
+			free(t->seq); free(t->name);
+			if (t->qual) free(t->qual);
+			if (t->comment) free(t->comment);
+		}
+		fprintf(stderr, "[M::worker_pipeline::%.3f*%.2f] mapped %d sequences\n", realtime() - mm_realtime0, cputime() / (realtime() - mm_realtime0), s->n_seq);
+		free(s->reg); free(s->n_reg); free(s->seq); free(s);
+	}
+	return 0;
+}
+
+int main(int argc, char *argv[])
+{
+	mm_idxopt_t iopt;
+	mm_mapopt_t mopt;
+	mm_idx_reader_t *rd;
+	mm_idx_t *mi;
+	int n_threads = 3, k = 1, rc = 0;
+	int64_t batch = 500000000;
+	mm_realtime0 = realtime();
+	mm_set_opt(0, &iopt, &mopt);
+	for (; k < argc && argv[k][0] == '-' && argv[k][1]; ++k) {
+		if (strcmp(argv[k], "-x") == 0) { if (mm_set_opt(argv[++k], &iopt, &mopt) < 0) { fprintf(stderr, "unknown preset\n"); return 1; } }
+		else if (strcmp(argv[k], "-a") == 0) mopt.flag |= MM_F_OUT_SAM | MM_F_CIGAR;
+		else if (strcmp(argv[k], "-c") == 0) mopt.flag |= MM_F_OUT_CG | MM_F_CIGAR; /* main.c:238 */
+		else if (strcmp(argv[k], "-t") == 0) n_threads = atoi(argv[++k]);
+		else if (strcmp(argv[k], "-K") == 0) batch = parse_num(argv[++k]);
+		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
+	}
+	if (argc - k < 2) { fprintf(stderr, "usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch] ref reads\n"); return 1; }
+	if (mm_check_opt(&iopt, &mopt) < 0) return 1;
+	rd = mm_idx_reader_open(argv[k], &iopt, 0);
+	if (rd == 0) { fprintf(stderr, "failed to open %s\n", argv[k]); return 1; }
+	while ((mi = mm_idx_reader_read(rd, n_threads)) != 0) {
+		pipeline_t pl;
+		if (mopt.flag & MM_F_OUT_SAM) mm_write_sam_hdr(mm_idx_reader_eof(rd) ? mi : 0, 0, MM_VERSION, 0, 0);
+		fprintf(stderr, "[M::main::%.3f*%.2f] loaded/built the index for %d target sequence(s)\n", realtime() - mm_realtime0, cputime() / (realtime() - mm_realtime0), mi->n_seq);
+		mm_mapopt_update(&mopt, mi);
+		setenv("MM2AMD_MALLOPT", "1", 0);
+		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
+		fprintf(stderr, "[M::main::%.3f*%.2f] device mirror of the index ready (%d replica(s))\n", realtime() - mm_realtime0, cputime() / (realtime() - mm_realtime0), mm_gpu_n_replicas());
+		memset(&pl, 0, sizeof pl);
+		pl.fp = mm_bseq_open(argv[k + 1]);
+		if (pl.fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
+		pl.mi = mi, pl.opt = &mopt, pl.batch = batch;
+		kt_pipeline(3, worker, &pl, 3); /* map.c:669: pl_threads = n_threads == 1 ? 1 : 3 (2 with --2-io-threads off) */
+		rc |= pl.failed;
+		mm_bseq_close(pl.fp);
+		mm_gpu_destroy();
+		mm_idx_destroy(mi);
+	}
+	mm_idx_reader_close(rd);
+	if (fflush(stdout) == EOF) return 1;
+	fprintf(stderr, "[M::main] Real time: %.3f sec; CPU: %.3f sec\n", realtime() - mm_realtime0, cputime());
+	return rc ? 2 : 0;
+}

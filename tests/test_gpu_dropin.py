@@ -120,6 +120,25 @@ def test_rmq_presets_identical(tmp_path):
     assert want == got
 
 
+def test_rmq_chain_kernel_against_host_chainer_and_reference(tmp_path):
+    # chain_rmq_kernel (seed_chain.hip) = rmq_chain.cpp on the host (MM2AMD_RMQ_ON_HOST=1) = the reference: accurate and noisy reads (the noisy
+    # ones walk the close neighbourhood for most anchors), reads full of repeats (equal priorities: handed back to the host), a small size cap
+    ref_o, reads_o, _, _ = synth.make("ont", str(tmp_path / "o"), 3, 150, 61)
+    ref_h, reads_h, _, _ = synth.make("hifi", str(tmp_path / "h"), 3, 100, 62)
+    ref_w, reads_w = synth.make_weird(str(tmp_path / "w"))
+    for ref, reads, extra in ((ref_o, reads_o, ["-x", "lr:hqae", "-a"]), (ref_o, reads_o, ["-x", "asm20", "-c"]), (ref_h, reads_h, ["-x", "lr:hqae", "-c", "--cs"]),
+                              (ref_h, reads_h, ["-x", "asm5", "-a", "--cap-kalloc=0"]), (ref_w, reads_w, ["-x", "lr:hqae", "-a"]), (ref_w, reads_w, ["-x", "asm20", "-c"])):
+        extra = [e for e in extra if not e.startswith("--cap")]
+        want, _ = _run([REF_BIN, "-t", "8"] + extra + [ref, reads])
+        got, _ = _run([DROPIN, "-t", "8"] + extra + [ref, reads])
+        env = dict(os.environ, MM2AMD_RMQ_ON_HOST="1")
+        p = subprocess.run([DROPIN, "-t", "8"] + extra + [ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0
+        host = b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG"))
+        assert host == want, ("host chainer", extra)
+        assert got == want, ("device chainer", extra)
+
+
 def test_alt_contigs_identical(tmp_path):
     ref, rd, alt = synth.make_alt(str(tmp_path))
     for extra in (["-a", "--alt", alt], ["-c", "--alt", alt]):
@@ -177,4 +196,13 @@ def test_two_replicas_on_one_device_identical(tmp_path):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     got = b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG"))
     assert "replicas=2" in p.stderr.decode(), p.stderr.decode()[-500:]
+    assert got == want
+
+
+def test_three_step_pipeline_driver_identical(tmp_path):
+    # tests/dropin/dropin_pipeline.c on the GPU library: parse / map / format of consecutive mini-batches overlap (kt_pipeline)
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 4, 150, 53)
+    want, _ = _run([REF_BIN, "-x", "map-ont", "-a", "-t", "8", ref, reads])
+    got, err = _run([os.path.join(HERE, "_build", "dropin_pipeline_gpu"), "-x", "map-ont", "-a", "-t", "8", "-K", "300k", ref, reads])
+    assert err.count("[M::worker_pipeline::") >= 3
     assert got == want

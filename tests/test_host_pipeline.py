@@ -336,6 +336,36 @@ def test_staged_calls_equal_the_batch_call(tmp_path):  # mm_gpu_batch_stage + mm
     assert G.strip_pg(a) == G.strip_pg(b) and a.count(b"\n") > 100
 
 
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+def test_three_step_pipeline_driver_equals_the_reference(tmp_path):
+    """tests/dropin/dropin_pipeline.c: the reference's kt_pipeline with step 1 = mm_gpu_map_batch and step 2 = mm_gpu_format_batch (the
+    output stage of batch k beside the mapping of batch k+1: the two calls hold the context shared, not exclusively)."""
+    import synth
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 2, 50, 27)
+    exe = os.path.join(HERE, "_build", "dropin_pipeline_check")
+    for args in (["-x", "map-ont", "-a", "-K", "60k"], ["-x", "map-ont", "-c", "-K", "2M"]):
+        want = subprocess.run([G.REF_BIN] + args + ["-t", "4", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        p = subprocess.run([exe] + args + ["-t", "4", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        assert G.strip_pg(want) == G.strip_pg(p.stdout)
+        assert b"[M::worker_pipeline::" in p.stderr and b"loaded/built the index" in p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
+def test_batch_of_one_calls_with_the_reference_signatures(tmp_path):
+    """mm_gpu_map / mm_gpu_map_frag (the reference's mm_map / mm_map_frag signatures, include/mm2amd.h): every fragment mapped by a call of
+    its own, single reads and read pairs, rep_len / frag_gap through the mm_tbuf_t -- same records as the reference."""
+    import synth
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 1, 12, 29)
+    _pair(["-x", "map-ont", "-a"], ref, rd)
+    got = subprocess.run([CHECK, "-x", "map-ont", "-a", "--one-by-one", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    want = subprocess.run([G.REF_BIN, "-x", "map-ont", "-a", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(got) == G.strip_pg(want)
+    ref, f1, f2, _ = synth.make_pairs(str(tmp_path / "pe"), n_pairs=25)
+    got = subprocess.run([CHECK, "-x", "sr", "-a", "--one-by-one", ref, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    want = subprocess.run([G.REF_BIN, "-x", "sr", "-a", ref, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(got) == G.strip_pg(want)
+
+
 def test_in_process_replicas_equal_one_mapper(tmp_path):
     """mm_gpu_init_multi's dispatcher (capi_map.cpp: shard_by_bases, one Mapper per replica on its own host thread, results into the
     caller's arrays): 1, 2 and 5 replicas print the same records -- long reads, staged calls, read pairs (joint, and mates mapped

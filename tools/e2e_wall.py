@@ -1,0 +1,160 @@
+"""SURVEY.md 8(d) primary figure and BASELINE.json's condition "SAM diff == 0", at full size, as programs:
+
+    minimap2 -ax map-ont -t$(nproc) ref.mmi reads.fa      (the unmodified reference, oracle/_ref/minimap2_ref)
+    dropin_pipeline_gpu -x map-ont -a ref.mmi reads.fa     (the reference's reader + kt_pipeline around mm_gpu_map_batch and
+                                                            mm_gpu_format_batch: tests/dropin/dropin_pipeline.c)
+
+on BASELINE.json configs[1] (100 k synthetic ~10 kb reads, 12 % error, 3 Gb synthetic reference; the generators are bench.py's), both
+from the same .mmi.  Reports, from each program's own stamps (index.c:132 / main.c:456 "loaded/built the index" .. the last
+"[M::worker_pipeline::..] mapped", map.c:638): the mapping-phase wall with parsing and SAM output overlapped, the total wall, and
+whether the two SAM streams are byte-identical apart from @PG.  Also compares, once, the full-size index the DEVICE builds
+(mm2amd_idx_str) with the one the reference's mm_idx_gen built (the .mmi): order-independent digests over (minimizer, position list)
+by oracle/refdrv.c.
+
+    python tools/e2e_wall.py [--ref-mb 3000] [--reads 100000] [--out gpurun_out/r02_e2e_wall.json]
+
+Test / measurement infrastructure: runs oracle/_ref binaries; nothing here is part of the product."""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def stamps(err):
+    loaded = mapped = ready = None
+    for line in err.splitlines():
+        m = re.match(r"\[M::(main|mm_idx_stat|worker_pipeline)::([0-9.]+)\*", line)
+        if not m:
+            continue
+        t = float(m.group(2))
+        if m.group(1) == "worker_pipeline":
+            mapped = t
+        elif "device mirror" in line:
+            ready = t
+        elif loaded is None and ("loaded/built the index" in line or m.group(1) == "mm_idx_stat"):
+            loaded = t
+    return loaded, ready, mapped
+
+
+def run(cmd, out_path):
+    t = time.time()
+    with open(out_path, "wb") as fo:
+        p = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
+    wall = time.time() - t
+    err = p.stderr.decode(errors="replace")
+    if p.returncode != 0:
+        raise RuntimeError("%s failed:\n%s" % (cmd[0], err[-2000:]))
+    return wall, err
+
+
+def digest_without_pg(path):
+    h, n = hashlib.md5(), 0
+    with open(path, "rb") as f:
+        for line in f:
+            if not line.startswith(b"@PG"):
+                h.update(line)
+                n += 1
+    return h.hexdigest(), n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref-mb", type=float, default=3000.0)
+    ap.add_argument("--reads", type=int, default=100000)
+    ap.add_argument("--dir", default="/tmp/e2e")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r02_e2e_wall.json"))
+    ap.add_argument("--skip-index-check", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(a.dir, exist_ok=True)
+    import torch
+    import bench
+    import reflib
+    dev = torch.device("cuda", 0)
+    ncpu = os.cpu_count() or 1
+    total = int(a.ref_mb * 1e6)
+    n_contig = max(1, min(24, total // 1000000))
+    codes, per = bench.gen_reference(torch, dev, 11, total, n_contig)
+    refs = bench.reference_ascii(torch, dev, codes, per, n_contig)
+    reads = bench.gen_reads(torch, dev, 1000, codes, per, n_contig, a.reads, 10000, 1000, 0.12)
+    del codes
+    torch.cuda.empty_cache()
+    names = ["chr%d" % (i + 1) for i in range(n_contig)]
+    ref_fa, reads_fa, mmi = (os.path.join(a.dir, x) for x in ("ref.fa", "reads.fa", "ref.mmi"))
+    with open(ref_fa, "wb") as f:
+        for nm, s in zip(names, refs):
+            f.write(b">" + nm.encode() + b"\n" + s + b"\n")
+    with open(reads_fa, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">read%d\n" % i + s + b"\n")
+    bases = sum(len(s) for s in reads)
+    res = {"workload": "map-ont: %d synthetic ~10 kb reads (12%% error, %.3f Gbases) vs %d Mb synthetic ref (%d contigs), -a" % (a.reads, bases / 1e9, total // 1000000, n_contig),
+           "host_threads": ncpu}
+    REF = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
+    OURS = os.path.join(ROOT, "tests", "_build", "dropin_pipeline_gpu")
+    t = time.time()
+    subprocess.run([REF, "-x", "map-ont", "-t", str(ncpu), "-d", mmi, ref_fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res["reference_index_build_s"] = round(time.time() - t, 1)
+    w_ref, e_ref = run([REF, "-ax", "map-ont", "-t", str(ncpu), mmi, reads_fa], os.path.join(a.dir, "ref.sam"))
+    w_our, e_our = run([OURS, "-x", "map-ont", "-a", "-t", str(min(64, ncpu)), mmi, reads_fa], os.path.join(a.dir, "ours.sam"))
+    for key, w, e in (("reference", w_ref, e_ref), ("gpu_dropin", w_our, e_our)):
+        loaded, ready, mapped = stamps(e)
+        res[key] = {"total_wall_s": round(w, 2), "index_in_memory_at_s": loaded, "last_batch_done_at_s": mapped,
+                    "mapping_phase_s": round(mapped - loaded, 2) if loaded is not None and mapped is not None else None,
+                    "gbases_per_s_mapping_phase": round(bases / (mapped - loaded) / 1e9, 4) if loaded is not None and mapped is not None else None}
+        if ready is not None:
+            res[key]["device_mirror_ready_at_s"] = ready
+            res[key]["mapping_phase_after_init_s"] = round(mapped - ready, 2)
+            res[key]["gbases_per_s_after_init"] = round(bases / (mapped - ready) / 1e9, 4)
+    d_ref, n_ref = digest_without_pg(os.path.join(a.dir, "ref.sam"))
+    d_our, n_our = digest_without_pg(os.path.join(a.dir, "ours.sam"))
+    res["sam_lines"] = [n_ref, n_our]
+    res["sam_identical_without_pg"] = d_ref == d_our
+    res["sam_bytes"] = os.path.getsize(os.path.join(a.dir, "ref.sam"))
+    res["speedup_mapping_phase"] = round(res["reference"]["mapping_phase_s"] / res["gpu_dropin"]["mapping_phase_s"], 2) if res["reference"]["mapping_phase_s"] and res["gpu_dropin"]["mapping_phase_s"] else None
+    print(json.dumps(res), flush=True)
+    if not a.skip_index_check:
+        import minimap2_amd as mm
+        import numpy as np
+        D = C.CDLL(reflib.REFDRV_SO)
+        R = C.CDLL(reflib.REF_SO)
+        R.mm_idx_reader_open.restype = C.c_void_p
+        R.mm_idx_reader_open.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p]
+        R.mm_idx_reader_read.restype = C.c_void_p
+        R.mm_idx_reader_read.argtypes = [C.c_void_p, C.c_int]
+        io, mo = mm.IdxOpt(), mm.MapOpt()
+        R.mm_set_opt(None, C.byref(io), C.byref(mo))
+        R.mm_set_opt(b"map-ont", C.byref(io), C.byref(mo))
+        rd = R.mm_idx_reader_open(mmi.encode(), C.byref(io), None)
+        mi = R.mm_idx_reader_read(rd, ncpu)
+        dg_ref = (C.c_uint64 * 3)()
+        D.refdrv_idx_digest.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        D.refdrv_idx_digest(mi, ncpu, dg_ref)
+        R.mm_idx_destroy.argtypes = [C.c_void_p]
+        R.mm_idx_destroy(mi)
+        t = time.time()
+        al = mm.Aligner(refs, preset="map-ont", names=names, n_threads=min(64, ncpu))
+        t_build = time.time() - t
+        S, keys, val_off, pos = reflib.export_index(al)
+        dg_dev = (C.c_uint64 * 3)()
+        D.refdrv_flat_digest.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        D.refdrv_flat_digest(len(keys), keys.ctypes.data, val_off.ctypes.data, pos.ctypes.data, ncpu, dg_dev)
+        al.close()
+        res["index_check"] = {"reference_mm_idx_gen": {"digest": "%016x" % dg_ref[0], "distinct_minimizers": int(dg_ref[1]), "positions": int(dg_ref[2])},
+                              "device_built": {"digest": "%016x" % dg_dev[0], "distinct_minimizers": int(dg_dev[1]), "positions": int(dg_dev[2]), "build_s": round(t_build, 2)},
+                              "identical": list(dg_ref) == list(dg_dev)}
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
