@@ -241,7 +241,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		if (need_state) d_state.ensure(need_state, 1.0);
 		bool any_side = false;
 		for (int tier = kFirstExact; tier < kFirstSplice; ++tier) any_side |= plan[tier].end != plan[tier].beg;
-		if (any_side) {
+		const bool use_side = any_side && !splice && !getenv("MM2AMD_NO_SIDE_STREAM"); // (spliced alignment: both groups hold matrices of tens of MB per job -- one after the other, each with the whole scratch budget) // read per run: bench.py's un-overlapped pass wants every launch on one stream
+		if (use_side) {
 			if (!side) {
 				int lo_prio = 0, hi_prio = 0;
 				HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
@@ -259,7 +260,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
 			if (P.end == P.beg || group_of(tier) != 1 - pass) continue;
-			const bool on_side = group_of(tier) == 1;
+			const bool on_side = use_side && group_of(tier) == 1;
 			hipStream_t stream_ = on_side ? side : stream;
 			KswLaunch L;
 			L.jobs = d_jobs.p + P.beg, L.res = d_res.p + P.beg, L.n_jobs = (int32_t)(P.end - P.beg);
@@ -278,7 +279,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			if (prof) prof->end(stream_, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
 		}
-		if (any_side) {
+		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));
 			HIP_CHECK(hipStreamWaitEvent(stream, ev_side_done, 0));
 		}

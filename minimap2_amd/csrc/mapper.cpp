@@ -125,7 +125,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 		// equal shares instead of full sub-batches plus a remainder, and at least two of them when there is enough work to overlap
 		// (a rank of an 8-GPU job gets an eighth of the batch: 125 Mbases map 6 % faster as 2 x 62 than as 100 + 25)
 		long n_sub = (long)((tot + (uint64_t)sub_bases - 1) / (uint64_t)sub_bases);
-		if (n_sub < 2 && tot >= 40000000) n_sub = 2;
+		if (n_sub < 2 && tot >= 40000000 && !(opt_.flag & F_SPLICE)) n_sub = 2; // not for spliced reads: their DP launch classes need the whole batch's jobs to hide their tails
 		if (n_sub > 0) sub_bases = (long)((tot + (uint64_t)n_sub - 1) / (uint64_t)n_sub);
 		for (long lo = 0, hi; lo < m_all; lo = hi) {
 			long bases = 0;
