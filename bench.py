@@ -26,7 +26,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-os.environ.setdefault("MM2AMD_MALLOPT", "1")  # the bench owns its process: let the library keep freed host memory (INTEGRATION.md section 3)
+os.environ.setdefault("MM2AMD_MALLOPT", "1")  # the bench owns its process: let the library keep freed host memory (INTEGRATION.md section 5)
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
@@ -372,6 +372,12 @@ def main():
                 "alg_bytes_per_launch": round(fam_bytes / max(fam_launch, 1), 1),
                 "note": "integer DP: bound by VALU issue, not by HBM (see 'valu'; DESIGN.md section 4); hbm figures = algorithmic bytes of the timed steps / HIP-event time of the family on its launch streams (lanes overlap); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())}}
+        inst = {}  # the family's launches per compiled instantiation (what a rocprofv3 kernel trace lists as one kernel name)
+        for k, v in same.items():
+            a_ = inst.setdefault(k.split("[")[0], [0.0, 0])
+            a_[0] += v["ms"]
+            a_[1] += v["launches"]
+        roof["avg_launch_ms_by_instantiation"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(inst.items())}
         if prof1:
             vfam = "ksw_gapfill_kernel" if any(family(k) == "ksw_gapfill_kernel" for k in prof1) else fam
             one = {k: v for k, v in prof1.items() if family(k) == vfam}

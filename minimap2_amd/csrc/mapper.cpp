@@ -62,7 +62,7 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	// The host stages allocate and free hundreds of MB of per-read records per sub-batch from hundreds of threads; letting glibc
 	// hand that memory back to the kernel every time turns into page-fault and mmap-lock storms (the reference sidesteps the same
 	// problem with its own kalloc arenas).  MM2AMD_MALLOPT=1 keeps freed memory in the process instead.  It is opt-in because it
-	// changes malloc behaviour of the whole embedding process (bench.py and the drop-in driver set it; INTEGRATION.md section 3).
+	// changes malloc behaviour of the whole embedding process (bench.py and the drop-in driver set it; INTEGRATION.md section 5).
 	if (const char *e = getenv("MM2AMD_MALLOPT")) if (atoi(e) > 0) {
 		mallopt(M_MMAP_THRESHOLD, 32 << 20);
 		mallopt(M_TRIM_THRESHOLD, 1 << 30);

@@ -148,7 +148,7 @@ int main(int argc, char *argv[])
 		if (pass1_fn) mm_idx_jjump_read(mi, pass1_fn, MM_JUNC_MISC, 5); /* main.c:478 */
 		if (spsc_fn) mm_idx_spsc_read2(mi, spsc_fn, mm_max_spsc_bonus(&mopt), spsc_scale); /* main.c:483 */
 		if (alt_fn) mm_idx_alt_read(mi, alt_fn); /* main.c:480 */
-		setenv("MM2AMD_MALLOPT", "1", 0); /* this driver owns its process: let the library tune glibc malloc (INTEGRATION.md section 3) */
+		setenv("MM2AMD_MALLOPT", "1", 0); /* this driver owns its process: let the library tune glibc malloc (INTEGRATION.md section 5) */
 		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
 		/* one read file, or two for paired-end reads (worker_pipeline step 0, map.c:545-569) */
 		/* without MM_F_FRAG_MODE several query files are mapped one after the other (main.c:493-500) */
