@@ -382,10 +382,18 @@ def main():
             vfam = "ksw_gapfill_kernel" if any(family(k) == "ksw_gapfill_kernel" for k in prof1) else fam
             one = {k: v for k, v in prof1.items() if family(k) == vfam}
             ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
-            peak_cells = 1024 * 2.4e9 * 128 / (72 * 2.0)
-            roof["valu"] = {"bound": "valu", "kernel": vfam, "cells_per_s": round(cells1 / max(ms1 * 1e-3, 1e-12), 1), "issue_peak_cells_per_s": round(peak_cells, 1),
-                            "frac": round(cells1 / max(ms1 * 1e-3, 1e-12) / peak_cells, 4), "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
-                            "basis": "one extra pass with a single lane (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / (72 VALU instructions x 2 cycles), i.e. every lane useful (the measured lane utilisation of the anti-diagonal sweep is 0.73)"}
+            # issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU mix in the ISA (50 packed VOP3P, 6 DPP moves,
+            # 21 other VALU) priced with the SATURATED per-instruction costs of tools/valu_issue_bench.hip (profiles/r02_valu_issue_bench_v4.txt:
+            # packed / VOP3 4.37 cycles per wave64 instruction and SIMD, DPP 4.2, the rest ~3.4 on average) = 316 cycles
+            row_cycles = 50 * 4.37 + 6 * 4.2 + 21 * 3.4
+            peak_cells = 1024 * 2.4e9 * 128 / row_cycles
+            nominal = 1024 * 2.4e9 * 128 / (77 * 2.0)
+            rate = cells1 / max(ms1 * 1e-3, 1e-12)
+            roof["valu"] = {"bound": "valu", "kernel": vfam, "cells_per_s": round(rate, 1), "issue_peak_cells_per_s": round(peak_cells, 1),
+                            "frac": round(rate / peak_cells, 4), "lane_utilisation": 0.727, "frac_at_measured_lane_utilisation": round(rate / peak_cells / 0.727, 4),
+                            "nominal_2cycle_peak_cells_per_s": round(nominal, 1), "frac_nominal": round(rate / nominal, 4),
+                            "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
+                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / 316 cycles (the hot loop's 77 VALU instructions at their measured saturated issue costs, every lane useful); lane_utilisation = cells / (128 x executed register-set rows), counted by an instrumented build; nominal = the same 77 instructions at the guide's 2 cycles per wave64 instruction"}
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
             roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1)
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -67,6 +67,89 @@ __device__ __forceinline__ uint32_t gf_sext8(uint32_t v)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The arithmetic of one register set and anti-diagonal (128 cells), in an instruction order of our own.  gfx950 needs one wait
+// state between a packed op and a dependent one; the compiler covers it with an s_nop after nearly every instruction of a
+// dependent chain (19 per row when the body is written as separate statements).  Here the 50 packed operations are ordered so
+// that no instruction reads its predecessor's result -- the four gap candidates, the substitution score, the direction index and
+// the continuation flags are independent strands woven together, the maximum is a tree -- and emitted as three blocks the
+// compiler cannot reorder; two wait states remain (around the maximum every later value depends on).
+//   in : x1 = tv ^ qv, o1 = tv | qv (base codes), xp / vp / x2p (left neighbour's x, v, x2), u / y / y2 (this column's)
+//   out: u, v, x, y, x2, y2 updated; d = direction byte per half
+// Same operations as ksw2_extd2_sse.c:165-272 on the valid cells; see the kernel header for the encoding of d.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y,
+                                        uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCH, uint32_t S_MISD, uint32_t S_SCN, uint32_t S_Q, uint32_t S_Q2,
+                                        uint32_t S_QE, uint32_t S_QE2)
+{
+	uint32_t a, b, a2, b2, z, z4, m, n, w, tA, tB;
+	asm volatile(
+		"v_pk_add_u16 %[a], %[xp], %[vp]\n\t"
+		"v_pk_min_u16 %[m], %[x1], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_add_u16 %[b], %[y], %[u]\n\t"
+		"v_pk_add_u16 %[a2], %[x2p], %[vp]\n\t"
+		"v_pk_mad_u16 %[z], %[m], %[misd], %[mch]\n\t"
+		"v_pk_add_u16 %[b2], %[y2], %[u]\n\t"
+		"v_pk_max_i16 %[tA], %[a], %[b]\n\t"
+		"v_pk_lshrrev_b16 %[n], 2, %[o1] op_sel_hi:[0,1]\n\t"
+		"v_pk_max_i16 %[tB], %[a2], %[b2]\n\t"
+		"v_pk_sub_u16 %[w], %[scn], %[z]\n\t"
+		"v_pk_max_i16 %[tA], %[tA], %[tB]\n\t"
+		"v_pk_mad_u16 %[z], %[n], %[w], %[z]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_max_i16 %[z4], %[z], %[tA]\n\t"
+		"s_nop 0"
+		: [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [b2] "=&v"(b2), [z] "=&v"(z), [z4] "=&v"(z4), [m] "=&v"(m), [n] "=&v"(n), [w] "=&v"(w), [tA] "=&v"(tA), [tB] "=&v"(tB)
+		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCH), [misd] "s"(S_MISD), [scn] "s"(S_SCN));
+	uint32_t zc, d0, d1, d2, d3, t1, t2, e, un, vn;
+	asm volatile(
+		"v_pk_sub_u16 %[d0], %[z4], %[z]\n\t"
+		"v_pk_sub_u16 %[d1], %[z4], %[a]\n\t"
+		"v_pk_sub_u16 %[d2], %[z4], %[b]\n\t"
+		"v_pk_sub_u16 %[d3], %[z4], %[a2]\n\t"
+		"v_pk_min_i16 %[zc], %[z4], %[mch]\n\t"
+		"v_pk_min_u16 %[d0], %[d0], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[d1], %[d1], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[d2], %[d2], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[d3], %[d3], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[un], %[zc], %[vp]\n\t"
+		"v_pk_sub_u16 %[vn], %[zc], %[u]\n\t"
+		"v_pk_sub_u16 %[t1], %[zc], %[q]\n\t"
+		"v_pk_sub_u16 %[t2], %[zc], %[q2]\n\t"
+		"v_pk_add_u16 %[e], %[d3], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[a], %[a], %[t1]\n\t"
+		"v_pk_sub_u16 %[b], %[b], %[t1]\n\t"
+		"v_pk_mad_u16 %[e], %[d2], %[e], 1 op_sel_hi:[1,1,0]\n\t"
+		"v_pk_sub_u16 %[a2], %[a2], %[t2]\n\t"
+		"v_pk_sub_u16 %[b2], %[b2], %[t2]\n\t"
+		"v_pk_mad_u16 %[e], %[d1], %[e], 1 op_sel_hi:[1,1,0]\n\t"
+		"v_pk_max_i16 %[a], %[a], 0 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[b], %[b], 0 op_sel_hi:[1,0]\n\t"
+		"v_pk_mul_lo_u16 %[e], %[d0], %[e]\n\t"
+		"v_pk_max_i16 %[a2], %[a2], 0 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[b2], %[b2], 0 op_sel_hi:[1,0]"
+		: [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [un] "=&v"(un), [vn] "=&v"(vn),
+		  [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
+		: [z4] "v"(z4), [z] "v"(z), [vp] "v"(vp), [u] "v"(u), [mch] "v"(P_MCH), [q] "s"(S_Q), [q2] "s"(S_Q2));
+	uint32_t fa, fb, fa2, fb2, xn, yn, x2n, y2n;
+	asm volatile(
+		"v_pk_min_u16 %[fa], %[a], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[xn], %[a], %[qe]\n\t"
+		"v_pk_min_u16 %[fb], %[b], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fa], 8, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[yn], %[b], %[qe]\n\t"
+		"v_pk_min_u16 %[fa2], %[a2], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fb], 16, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[x2n], %[a2], %[qe2]\n\t"
+		"v_pk_min_u16 %[fb2], %[b2], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fa2], 32, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[y2n], %[b2], %[qe2]\n\t"
+		"v_pk_mad_u16 %[e], %[fb2], 64, %[e] op_sel_hi:[1,0,1]"
+		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n), [e] "+v"(e)
+		: [a] "v"(a), [b] "v"(b), [a2] "v"(a2), [b2] "v"(b2), [qe] "s"(S_QE), [qe2] "s"(S_QE2));
+	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Two jobs per wavefront, packed 16-bit arithmetic.
 //
 // Every quantity of the row loop fits in 8 bits, and gfx950 executes 2 x 16-bit packed integer ops per lane and instruction, so
@@ -211,28 +294,10 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 						uint32_t qa = (uint32_t)(qb_addr + r - cb - c * 64) - (uint32_t)lane;
 						qa = qa < qb_last ? qa : qb_last;
 						const uint32_t qv = (uint32_t)s_qflat[qa] | (uint32_t)s_qflat[qa + QCAP] << 16, tv = T[c];
-						// substitution score: match / mismatch, overridden by sc_N when either base is ambiguous (code 4: bit 2)
-						uint32_t z = gf_mad_vsv(gf_minu1(tv ^ qv), S_MISD, P_MCH);
-						z = pk_mad(pk_shr2(tv | qv), gf_rsub_s(S_SCN, z), z);
-						const uint32_t ut = U[c];
-						uint32_t a = pk_add(xp, vp), b = pk_add(Y[c], ut), a2 = pk_add(x2p, vp), b2 = pk_add(Y2[c], ut);
-						const uint32_t z1 = pk_max(z, a), z2 = pk_max(z1, b), z3 = pk_max(z2, a2), z4 = pk_max(z3, b2);
-						// d = index of the first of (s, a, b, a2, b2) equal to the maximum
-						const uint32_t ne_s = gf_minu1(pk_sub(z4, z)), ne_a = gf_minu1(pk_sub(z4, a));
-						const uint32_t ne_b = gf_minu1(pk_sub(z4, b)), ne_a2 = gf_minu1(pk_sub(z4, a2));
-						uint32_t d = pk_mul(ne_s, gf_mad_vv1(ne_a, gf_mad_vv1(ne_b, gf_add1(ne_a2))));
-						z = pk_min(z4, P_MCH);
-						U[c] = pk_sub(z, vp), V[c] = pk_sub(z, ut);
-						uint32_t tmp = gf_sub_s(z, S_Q);
-						a = pk_sub(a, tmp), b = pk_sub(b, tmp);
-						tmp = gf_sub_s(z, S_Q2);
-						a2 = pk_sub(a2, tmp), b2 = pk_sub(b2, tmp);
-						const uint32_t ma = gf_max0(a), mb = gf_max0(b), ma2 = gf_max0(a2), mb2 = gf_max0(b2);
-						d = gf_mad8(gf_minu1(ma), d);   // a > 0: the gap can be extended (continuation bits 0x08..0x40, :261-272)
-						d = gf_mad16(gf_minu1(mb), d);
-						d = gf_mad32(gf_minu1(ma2), d);
-						d = gf_mad64(gf_minu1(mb2), d);
-						X[c] = gf_sub_s(ma, S_QE), Y[c] = gf_sub_s(mb, S_QE), X2[c] = gf_sub_s(ma2, S_QE2), Y2[c] = gf_sub_s(mb2, S_QE2);
+						// substitution score (match / mismatch, sc_N when either base is ambiguous: code 4 = bit 2), the five candidates, the
+						// direction index d = first of (s, a, b, a2, b2) equal to the maximum, the continuation bits 0x08..0x40 (:235-272)
+						uint32_t d;
+						gf_cell(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, S_MISD, S_SCN, S_Q, S_Q2, S_QE, S_QE2);
 						if (par == 0) DE[c] = d;
 						else {
 							const uint32_t t = (uint32_t)(cb + c * 64 + lane);

@@ -266,8 +266,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.jobs = d_jobs.p + P.beg, L.res = d_res.p + P.beg, L.n_jobs = (int32_t)(P.end - P.beg);
 			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
 			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
-			L.cigar_tmp = on_side ? d_cigar_tmp2.p : d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap;
-			L.dir_pool = on_side ? d_dir2.p : d_dir.p, L.slot_bytes = P.slot_bytes;
+			L.cigar_tmp = group_of(tier) ? d_cigar_tmp2.p : d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap; // each group has its scratch, whichever stream it runs on
+			L.dir_pool = group_of(tier) ? d_dir2.p : d_dir.p, L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
 			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc_dev;
 			L.state_pool = P.hbm ? d_state.p : nullptr;

@@ -100,7 +100,7 @@ def test_splice(tmp_path, args):
     import synth
     if not os.path.exists(G.REF_BIN):
         pytest.skip("needs oracle/_ref")
-    ref, reads, _, _ = synth.make("cdna", str(tmp_path), 2.0, 150, 106)
+    ref, reads, _, _ = synth.make("cdna", str(tmp_path), 2.0, 60 if args[1] == "splice" and "-u" not in args and "-G" not in args else 45, 106)  # the oracle-backed splice DP is slow: CPU suite time
     out = _pair(args, ref, reads)
     assert any(b"N" in l.split(b"\t")[5] for l in out.split(b"\n") if l and not l.startswith(b"@") and b"\t" in l) or "-c" in args
 
@@ -470,7 +470,7 @@ def test_device_sdust_header_against_the_reference():
 @pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="needs the compiled reference")
 def test_pass1_junctions_mix_with_annotation(tmp_path):  # --pass1: MM_JUNC_MISC jumps with a score filter (main.c:478), annotated ones win (jump.c:90-95)
     import synth
-    ref, rd, bed = synth.make_junctions(str(tmp_path))
+    ref, rd, bed = synth.make_junctions(str(tmp_path), n_reads=40)
     lines = [l for l in open(bed).read().split("\n") if l]
     p1, anno = str(tmp_path / "pass1.bed"), str(tmp_path / "anno.bed")
     open(p1, "w").write("\n".join("\t".join(l.split("\t")[:4] + ["9" if i % 3 else "3"] + l.split("\t")[5:]) for i, l in enumerate(lines) if i % 2 == 0) + "\n")

@@ -1,7 +1,14 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-timeout 300 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/r02_bench_full_v4.json 2> $O/r02_bench_full_v4.log; python -c "
-import json; d=json.load(open('$O/r02_bench_full_v4.json')); print('full', d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['valu'])"
-timeout 500 python $R/bench.py --preset map-hifi --reads 200000 --steps 2 --warmup 1 --cpu-sample 20000 > $O/r02_bench_hifi_v1.json 2> $O/r02_bench_hifi_v1.log; python -c "
-import json; d=json.load(open('$O/r02_bench_hifi_v1.json')); print('hifi', d['value'], d['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['hits_identical_to_gpu'])"; tail -2 $O/r02_bench_hifi_v1.log | cut -c1-300
-timeout 400 python $R/bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r02_bench_splice_v2.json 2> $O/r02_bench_splice_v2.log; python -c "
-import json; d=json.load(open('$O/r02_bench_splice_v2.json')); print('splice', d['value'], d['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['hits_identical_to_gpu'])"
+run() { n=$1; shift
+  env "$@" timeout 200 python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/sz_$n.json 2> $O/sz_$n.log
+  python -c "
+import json; d=json.load(open('$O/sz_$n.json')); print('$n', d['value'], d['ms_per_step'])"
+}
+run sub200M MM2AMD_SUBBATCH_BASES=200000000
+run sub125M MM2AMD_SUBBATCH_BASES=125000000
+run sub100M A=1
+# two in-process replicas on one device, with the parity check of the cpu_baseline leg
+MM2AMD_GPUS=2 MM2AMD_DEVICE_IDS=0,0 timeout 300 python $R/bench.py --reads 30000 --steps 2 --warmup 1 --cpu-sample 6000 > $O/rep2.json 2> $O/rep2.log; python -c "
+import json; d=json.load(open('$O/rep2.json')); print('2 replicas on one device', d['value'], d['ms_per_step'], d['cpu_baseline']['hits_identical_to_gpu'])"
+# the torchrun path (strong scaling, one batch sharded over the ranks) with two ranks sharing the one GPU (gloo: plumbing check)
+MM2AMD_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 $R/bench.py --gpus 2 --steps 2 --warmup 1 --reads 20000 --ref-mb 500 > $O/tr2.json 2> $O/tr2.log; tail -1 $O/tr2.json | cut -c1-700; tail -3 $O/tr2.log | cut -c1-300

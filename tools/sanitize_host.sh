@@ -33,7 +33,9 @@ for san in address,undefined thread; do
 	export LD_LIBRARY_PATH="$ROOT/oracle:$O"
 	D="$W/data"
 	while read -r args; do
-		ASAN_OPTIONS=detect_leaks=1 LSAN_OPTIONS=suppressions=$W/lsan.supp:print_suppressions=0 "$O/dropin_check" $args > "$O/out.txt" 2> "$O/err.txt"
+		envs=""
+		while [[ "$args" == *=*\ * && "${args%% *}" == *=* ]]; do envs="$envs ${args%% *}"; args="${args#* }"; done # leading VAR=value words
+		env $envs ASAN_OPTIONS=detect_leaks=1 LSAN_OPTIONS=suppressions=$W/lsan.supp:print_suppressions=0 "$O/dropin_check" $args > "$O/out.txt" 2> "$O/err.txt"
 		rc=$?
 		n=$(grep -c "ERROR: \|runtime error\|WARNING: ThreadSanitizer" "$O/err.txt")
 		echo "$san rc=$rc reports=$n :: $args"
@@ -52,6 +54,19 @@ for san in address,undefined thread; do
 -x splice:sr -a -t 8 -j $D/rna/introns.bed $D/rna/ref.fa $D/rna/r1.fa $D/rna/r2.fa
 -x map-ont -a -t 8 -T 10 $D/weird/ref.fa $D/weird/reads.fa
 -x map-ont -c -t 8 --qstrand --cs $D/ont/ref.fa $D/ont/reads.fa
+MM2AMD_GPUS=3 -x map-ont -a -t 9 -K 200k $D/ont/ref.fa $D/ont/reads.fa
+MM2AMD_GPUS=2 -x sr -a -t 8 --staged --format-lib $D/pe/ref.fa $D/pe/r1.fa $D/pe/r2.fa
+-x asm20 -c -t 8 $D/ont/ref.fa $D/ont/reads.fa
+-x lr:hqae -a -t 8 $D/weird/ref.fa $D/weird/reads.fa
+-x map-ont -a -t 4 --one-by-one $D/ont/ref.fa $D/ont/reads.fa
 EOF2
+	# the three-step pipeline driver: mm_gpu_format_batch of batch k beside mm_gpu_map_batch of batch k+1
+	gcc -O1 -g -DHAVE_KALLOC -I/root/reference -I"$ROOT/include" -c "$ROOT/tests/dropin/dropin_pipeline.c" -o "$O/dropin_pipeline.o" || exit 1
+	g++ -fsanitize=$san -o "$O/dropin_pipeline_check" "$O/dropin_pipeline.o" "$ROOT/oracle/_ref/libminimap2_ref.a" -L"$O" -lmm2amd_check -L"$ROOT/oracle" -loracle -lm -lz -lpthread || exit 1
+	ASAN_OPTIONS=detect_leaks=1 LSAN_OPTIONS=suppressions=$W/lsan.supp:print_suppressions=0 "$O/dropin_pipeline_check" -x map-ont -a -t 8 -K 100k $D/ont/ref.fa $D/ont/reads.fa > "$O/out.txt" 2> "$O/err.txt"
+	rc=$?
+	n=$(grep -c "ERROR: \|runtime error\|WARNING: ThreadSanitizer" "$O/err.txt")
+	echo "$san rc=$rc reports=$n :: dropin_pipeline -x map-ont -a -K 100k"
+	if [ $rc -ne 0 ] || [ "$n" -ne 0 ]; then fail=1; head -30 "$O/err.txt"; fi
 done
 exit $fail

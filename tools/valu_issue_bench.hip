@@ -202,6 +202,20 @@ static void run(int n_cu, uint32_t *d_out, unsigned long long *d_cyc, uint8_t *d
 		const double ns = (double)wl[wl.size() / 2] / g_wall_hz * 1e9 / n_instr, ticks = (double)mt[mt.size() / 2] / n_instr;
 		fprintf(fp, " | W=%d %6.3f ns %6.3f tk", wps[wi], ns, ticks);
 	}
+	{ // aggregate: 16 blocks per CU queued (more than can be resident), total wave-instructions / (SIMDs x wall time): no residency assumption
+		const int blocks = n_cu * 16;
+		hipEvent_t e0, e1;
+		CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters / 8);
+		CHECK(hipEventRecord(e0));
+		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters);
+		CHECK(hipEventRecord(e1));
+		CHECK(hipDeviceSynchronize());
+		float ms = 0;
+		CHECK(hipEventElapsedTime(&ms, e0, e1));
+		const double per_simd = (double)blocks * 4 / (n_cu * 4.0) * (double)iters * per_iter; // wave-instructions per SIMD
+		fprintf(fp, " | saturated %6.3f ns", ms * 1e6 / per_simd);
+	}
 	fprintf(fp, "\n");
 	fflush(fp);
 }
@@ -213,12 +227,12 @@ int main()
 	const int n_cu = p.multiProcessorCount;
 	printf("device %s, %d CUs, clockRate %d kHz; ITERS %d; blocks of 256 threads (one wave per SIMD), W blocks per CU\n", p.gcnArchName, n_cu, p.clockRate, ITERS);
 	uint32_t *d_out; unsigned long long *d_cyc; uint8_t *d_scratch;
-	const size_t n_waves = (size_t)n_cu * 4 * 8;
+	const size_t n_waves = (size_t)n_cu * 4 * 16;
 	CHECK(hipMalloc(&d_out, n_waves * 64 * 4)); CHECK(hipMalloc(&d_cyc, n_waves * 16)); CHECK(hipMalloc(&d_scratch, n_waves * 65536));
 	FILE *fp = stdout;
 	int wall_khz = 100000;
 	if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && wall_khz > 0) g_wall_hz = wall_khz * 1e3;
-	printf("wall_clock64 rate %d kHz; columns: W waves per SIMD -> ns and s_memtime ticks per wave-instruction per SIMD (median wave)\n", wall_khz);
+	printf("wall_clock64 rate %d kHz; columns: W waves per SIMD -> ns and s_memtime ticks per wave-instruction per SIMD (median wave); saturated: 16 blocks per CU queued, total instructions / (SIMDs x event wall time)\n", wall_khz);
 	for (int k = 0; k < 40; ++k) hipLaunchKernelGGL((bench_kernel<K_PK_ADD>), dim3(n_cu * 4), dim3(256), 0, 0, d_out, d_cyc, d_scratch, ITERS); // clocks up
 	CHECK(hipDeviceSynchronize());
 	run<K_ADD_U32>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
