@@ -356,7 +356,9 @@ def main():
     # instruction = 2 cycles on a SIMD-32, 1024 SIMDs at 2.4 GHz, every lane useful).
     roof = None
     if prof:
-        family = lambda k: k.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_gapfill_kernel<512>[t256], ...) count together
+        GAPFILL = "ksw_stream_kernel+ksw_gapfill_kernel"  # the gap-fill DP: the streaming kernel (targets <= 512) and the strip kernel (the rest) share one cell body
+        base = lambda k: k.split("[")[0].split("<")[0]
+        family = lambda k: GAPFILL if base(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel") else base(k)  # launch classes of one kernel count together
         src = prof1 or prof  # dominance by un-overlapped cost when we have it
         fam_total = {}
         for k, v in src.items():
@@ -379,7 +381,7 @@ def main():
             a_[1] += v["launches"]
         roof["avg_launch_ms_by_instantiation"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(inst.items())}
         if prof1:
-            vfam = "ksw_gapfill_kernel" if any(family(k) == "ksw_gapfill_kernel" for k in prof1) else fam
+            vfam = GAPFILL if any(family(k) == GAPFILL for k in prof1) else fam
             one = {k: v for k, v in prof1.items() if family(k) == vfam}
             ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
             # issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU mix in the ISA (50 packed VOP3P, 6 DPP moves,

@@ -29,125 +29,12 @@
 #include "hip_util.hpp"
 #include "ksw_dev.hpp"
 #include "ksw_pk.hpp"
+#include "ksw_gapfill_dev.hpp"
 
 namespace mm2amd {
 
 constexpr int GF_NC = 4;          // register sets of 64 columns
 constexpr int GF_STRIP = 64 * GF_NC;
-
-// ---------------------------------------------------------------------------------------------------------
-// Packed 16-bit VOP3P with the operand kinds that keep VGPRs free: small constants are inline constants (op_sel_hi clear on
-// that operand: the low half feeds both lanes of the pair), launch-uniform scores sit in SGPRs (one constant-bus operand per
-// instruction on gfx9).  Only the match score needs a VGPR copy (it meets a second SGPR operand in one instruction).
-// ---------------------------------------------------------------------------------------------------------
-#define GF_V_C(name, ins, cst) \
-	__device__ __forceinline__ uint32_t name(uint32_t a) { uint32_t r; asm(ins " %0, %1, " #cst " op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
-GF_V_C(gf_minu1, "v_pk_min_u16", 1)
-GF_V_C(gf_max0, "v_pk_max_i16", 0)
-GF_V_C(gf_add1, "v_pk_add_u16", 1)
-#define GF_V_S(name, ins) \
-	__device__ __forceinline__ uint32_t name(uint32_t a, uint32_t s) { uint32_t r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
-GF_V_S(gf_sub_s, "v_pk_sub_u16")
-__device__ __forceinline__ uint32_t gf_rsub_s(uint32_t s, uint32_t a) { uint32_t r; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "s"(s), "v"(a)); return r; }
-__device__ __forceinline__ uint32_t gf_mad_vsv(uint32_t a, uint32_t s, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r; }
-__device__ __forceinline__ uint32_t gf_mad_vv1(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, 1 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
-#define GF_MADC(name, cst) \
-	__device__ __forceinline__ uint32_t name(uint32_t a, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, " #cst ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c)); return r; }
-GF_MADC(gf_mad8, 8)
-GF_MADC(gf_mad16, 16)
-GF_MADC(gf_mad32, 32)
-GF_MADC(gf_mad64, 64)
-__device__ __forceinline__ uint32_t gf_ror1(uint32_t v) { uint32_t r; asm("v_mov_b32_dpp %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); return r; } // every lane has a source: no old operand
-// sign-extend the low byte of each 16-bit half
-__device__ __forceinline__ uint32_t gf_sext8(uint32_t v)
-{
-	uint32_t r;
-	asm("v_pk_lshlrev_b16 %0, 8, %1 op_sel_hi:[0,1]\n\tv_pk_ashrrev_i16 %0, 8, %0 op_sel_hi:[0,1]" : "=&v"(r) : "v"(v));
-	return r;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The arithmetic of one register set and anti-diagonal (128 cells), in an instruction order of our own.  gfx950 needs one wait
-// state between a packed op and a dependent one; the compiler covers it with an s_nop after nearly every instruction of a
-// dependent chain (19 per row when the body is written as separate statements).  Here the 50 packed operations are ordered so
-// that no instruction reads its predecessor's result -- the four gap candidates, the substitution score, the direction index and
-// the continuation flags are independent strands woven together, the maximum is a tree -- and emitted as three blocks the
-// compiler cannot reorder; two wait states remain (around the maximum every later value depends on).
-//   in : x1 = tv ^ qv, o1 = tv | qv (base codes), xp / vp / x2p (left neighbour's x, v, x2), u / y / y2 (this column's)
-//   out: u, v, x, y, x2, y2 updated; d = direction byte per half
-// Same operations as ksw2_extd2_sse.c:165-272 on the valid cells; see the kernel header for the encoding of d.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y,
-                                        uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCH, uint32_t S_MISD, uint32_t S_SCN, uint32_t S_Q, uint32_t S_Q2,
-                                        uint32_t S_QE, uint32_t S_QE2)
-{
-	uint32_t a, b, a2, b2, z, z4, m, n, w, tA, tB;
-	asm volatile(
-		"v_pk_add_u16 %[a], %[xp], %[vp]\n\t"
-		"v_pk_min_u16 %[m], %[x1], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_add_u16 %[b], %[y], %[u]\n\t"
-		"v_pk_add_u16 %[a2], %[x2p], %[vp]\n\t"
-		"v_pk_mad_u16 %[z], %[m], %[misd], %[mch]\n\t"
-		"v_pk_add_u16 %[b2], %[y2], %[u]\n\t"
-		"v_pk_max_i16 %[tA], %[a], %[b]\n\t"
-		"v_pk_lshrrev_b16 %[n], 2, %[o1] op_sel_hi:[0,1]\n\t"
-		"v_pk_max_i16 %[tB], %[a2], %[b2]\n\t"
-		"v_pk_sub_u16 %[w], %[scn], %[z]\n\t"
-		"v_pk_max_i16 %[tA], %[tA], %[tB]\n\t"
-		"v_pk_mad_u16 %[z], %[n], %[w], %[z]\n\t"
-		"s_nop 0\n\t"
-		"v_pk_max_i16 %[z4], %[z], %[tA]\n\t"
-		"s_nop 0"
-		: [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [b2] "=&v"(b2), [z] "=&v"(z), [z4] "=&v"(z4), [m] "=&v"(m), [n] "=&v"(n), [w] "=&v"(w), [tA] "=&v"(tA), [tB] "=&v"(tB)
-		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCH), [misd] "s"(S_MISD), [scn] "s"(S_SCN));
-	uint32_t zc, d0, d1, d2, d3, t1, t2, e, un, vn;
-	asm volatile(
-		"v_pk_sub_u16 %[d0], %[z4], %[z]\n\t"
-		"v_pk_sub_u16 %[d1], %[z4], %[a]\n\t"
-		"v_pk_sub_u16 %[d2], %[z4], %[b]\n\t"
-		"v_pk_sub_u16 %[d3], %[z4], %[a2]\n\t"
-		"v_pk_min_i16 %[zc], %[z4], %[mch]\n\t"
-		"v_pk_min_u16 %[d0], %[d0], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_min_u16 %[d1], %[d1], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_min_u16 %[d2], %[d2], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_min_u16 %[d3], %[d3], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_sub_u16 %[un], %[zc], %[vp]\n\t"
-		"v_pk_sub_u16 %[vn], %[zc], %[u]\n\t"
-		"v_pk_sub_u16 %[t1], %[zc], %[q]\n\t"
-		"v_pk_sub_u16 %[t2], %[zc], %[q2]\n\t"
-		"v_pk_add_u16 %[e], %[d3], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_sub_u16 %[a], %[a], %[t1]\n\t"
-		"v_pk_sub_u16 %[b], %[b], %[t1]\n\t"
-		"v_pk_mad_u16 %[e], %[d2], %[e], 1 op_sel_hi:[1,1,0]\n\t"
-		"v_pk_sub_u16 %[a2], %[a2], %[t2]\n\t"
-		"v_pk_sub_u16 %[b2], %[b2], %[t2]\n\t"
-		"v_pk_mad_u16 %[e], %[d1], %[e], 1 op_sel_hi:[1,1,0]\n\t"
-		"v_pk_max_i16 %[a], %[a], 0 op_sel_hi:[1,0]\n\t"
-		"v_pk_max_i16 %[b], %[b], 0 op_sel_hi:[1,0]\n\t"
-		"v_pk_mul_lo_u16 %[e], %[d0], %[e]\n\t"
-		"v_pk_max_i16 %[a2], %[a2], 0 op_sel_hi:[1,0]\n\t"
-		"v_pk_max_i16 %[b2], %[b2], 0 op_sel_hi:[1,0]"
-		: [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [un] "=&v"(un), [vn] "=&v"(vn),
-		  [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
-		: [z4] "v"(z4), [z] "v"(z), [vp] "v"(vp), [u] "v"(u), [mch] "v"(P_MCH), [q] "s"(S_Q), [q2] "s"(S_Q2));
-	uint32_t fa, fb, fa2, fb2, xn, yn, x2n, y2n;
-	asm volatile(
-		"v_pk_min_u16 %[fa], %[a], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_sub_u16 %[xn], %[a], %[qe]\n\t"
-		"v_pk_min_u16 %[fb], %[b], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_mad_u16 %[e], %[fa], 8, %[e] op_sel_hi:[1,0,1]\n\t"
-		"v_pk_sub_u16 %[yn], %[b], %[qe]\n\t"
-		"v_pk_min_u16 %[fa2], %[a2], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_mad_u16 %[e], %[fb], 16, %[e] op_sel_hi:[1,0,1]\n\t"
-		"v_pk_sub_u16 %[x2n], %[a2], %[qe2]\n\t"
-		"v_pk_min_u16 %[fb2], %[b2], 1 op_sel_hi:[1,0]\n\t"
-		"v_pk_mad_u16 %[e], %[fa2], 32, %[e] op_sel_hi:[1,0,1]\n\t"
-		"v_pk_sub_u16 %[y2n], %[b2], %[qe2]\n\t"
-		"v_pk_mad_u16 %[e], %[fb2], 64, %[e] op_sel_hi:[1,0,1]"
-		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n), [e] "+v"(e)
-		: [a] "v"(a), [b] "v"(b), [a2] "v"(a2), [b2] "v"(b2), [qe] "s"(S_QE), [qe2] "s"(S_QE2));
-	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Two jobs per wavefront, packed 16-bit arithmetic.
@@ -375,32 +262,14 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 		if ((lane == 0 || (lane == 32 && hasB))) {
 			if (g.n > 0) g.c[g.n - 1] = g.last;
 			if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
-			// update_max_zdrop (align.c:46-59) over the alignment, start to end (g.c holds the operations last first)
-			int32_t score = 0, mx = INT32_MIN, mx_i = -1, mx_j = -1, ci = 0, cj = 0;
-			const int gq = L.sc.q, ge = L.sc.e, gq2 = L.sc.q2, ge2 = L.sc.e2;
-			auto track = [&](int32_t sc, int pi, int pj) {
-				if (sc < mx) {
-					const int li = pi - mx_i, lj = pj - mx_j, diff = li > lj ? li - lj : lj - li, zz = mx - sc - diff * ge;
-					if (zz > zd_max) zd_max = zz, zd_t0 = mx_i, zd_t1 = pi, zd_q0 = mx_j, zd_q1 = pj;
-				} else mx = sc, mx_i = pi, mx_j = pj;
-			};
-			for (int k = g.n - 1; k >= 0; --k) {
-				const uint32_t op = g.c[k] & 0xf, len = g.c[k] >> 4;
-				if (op == 0) {
-					for (uint32_t l = 0; l < len; ++l) {
-						const int tb_ = my_tb[ci + l], qb_ = my_qb[cj + l], sm = s_mat[tb_ * 5 + qb_];
-						score += sm, dp_score += ((tb_ | qb_) & 4) ? sc_N : sm; // the DP prices ambiguous bases by sc_N (ksw2_extd2_sse.c:71)
-						track(score, ci + (int)l, cj + (int)l);
-					}
-					ci += len, cj += len;
-				} else {
-					const int c1 = gq + ge * (int)len, c2 = gq2 + ge2 * (int)len;
-					dp_score -= c1 < c2 ? c1 : c2;
-					score -= c1;
-					if (op == 1) cj += len; else ci += len;
-					track(score, ci, cj);
-				}
-			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		{ // mm_test_zdrop's walk over both alignments (align.c:46-84) and their scores under the DP's own costs, 32 lanes each
+			const uint32_t third = L.cigar_tmp_cap / 3u; // a job's scratch: its operations (last first), then two prefix arrays
+			const GfZdrop z = gf_zdrop_scan(!isB || hasB, g.n, g.c, g.c + third, g.c + 2u * third, [&](int i) { return (int)my_tb[i]; }, [&](int j) { return (int)my_qb[j]; },
+			                                s_mat, L.sc.q, L.sc.e, L.sc.q2, L.sc.e2, sc_N);
+			zd_max = z.zd_max, zd_t0 = z.t0, zd_t1 = z.t1, zd_q0 = z.q0, zd_q1 = z.q1, dp_score += z.dp_sum;
 		}
 		__threadfence_block();
 		// pack the CIGARs into the pool in forward order, job A then job B, all lanes copying

@@ -1,0 +1,244 @@
+// Device helpers of the register-resident gap-fill kernels (ksw_gapfill.hip, ksw_stream.hip): packed 16-bit VOP3P with the operand
+// kinds that keep VGPRs free, and the hand-ordered arithmetic of one register set and anti-diagonal (gf_cell).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "ksw_pk.hpp"
+
+namespace mm2amd {
+
+// ---------------------------------------------------------------------------------------------------------
+// Packed 16-bit VOP3P with the operand kinds that keep VGPRs free: small constants are inline constants (op_sel_hi clear on
+// that operand: the low half feeds both lanes of the pair), launch-uniform scores sit in SGPRs (one constant-bus operand per
+// instruction on gfx9).  Only the match score needs a VGPR copy (it meets a second SGPR operand in one instruction).
+// ---------------------------------------------------------------------------------------------------------
+#define GF_V_C(name, ins, cst) \
+	__device__ __forceinline__ uint32_t name(uint32_t a) { uint32_t r; asm(ins " %0, %1, " #cst " op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
+GF_V_C(gf_minu1, "v_pk_min_u16", 1)
+GF_V_C(gf_max0, "v_pk_max_i16", 0)
+GF_V_C(gf_add1, "v_pk_add_u16", 1)
+#define GF_V_S(name, ins) \
+	__device__ __forceinline__ uint32_t name(uint32_t a, uint32_t s) { uint32_t r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
+GF_V_S(gf_sub_s, "v_pk_sub_u16")
+__device__ __forceinline__ uint32_t gf_rsub_s(uint32_t s, uint32_t a) { uint32_t r; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "s"(s), "v"(a)); return r; }
+__device__ __forceinline__ uint32_t gf_mad_vsv(uint32_t a, uint32_t s, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t gf_mad_vv1(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, 1 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define GF_MADC(name, cst) \
+	__device__ __forceinline__ uint32_t name(uint32_t a, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, " #cst ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c)); return r; }
+GF_MADC(gf_mad8, 8)
+GF_MADC(gf_mad16, 16)
+GF_MADC(gf_mad32, 32)
+GF_MADC(gf_mad64, 64)
+__device__ __forceinline__ uint32_t gf_ror1(uint32_t v) { uint32_t r; asm("v_mov_b32_dpp %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); return r; } // every lane has a source: no old operand
+// sign-extend the low byte of each 16-bit half
+__device__ __forceinline__ uint32_t gf_sext8(uint32_t v)
+{
+	uint32_t r;
+	asm("v_pk_lshlrev_b16 %0, 8, %1 op_sel_hi:[0,1]\n\tv_pk_ashrrev_i16 %0, 8, %0 op_sel_hi:[0,1]" : "=&v"(r) : "v"(v));
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The arithmetic of one register set and anti-diagonal (128 cells), in an instruction order of our own.  gfx950 needs one wait
+// state between a packed op and a dependent one; the compiler covers it with an s_nop after nearly every instruction of a
+// dependent chain (19 per row when the body is written as separate statements).  Here the 50 packed operations are ordered so
+// that no instruction reads its predecessor's result -- the four gap candidates, the substitution score, the direction index and
+// the continuation flags are independent strands woven together, the maximum is a tree -- and emitted as three blocks the
+// compiler cannot reorder; two wait states remain (around the maximum every later value depends on).
+//   in : x1 = tv ^ qv, o1 = tv | qv (base codes), xp / vp / x2p (left neighbour's x, v, x2), u / y / y2 (this column's)
+//   out: u, v, x, y, x2, y2 updated; d = direction byte per half
+// Same operations as ksw2_extd2_sse.c:165-272 on the valid cells; see the kernel header for the encoding of d.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y,
+                                        uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCH, uint32_t S_MISD, uint32_t S_SCN, uint32_t S_Q, uint32_t S_Q2,
+                                        uint32_t S_QE, uint32_t S_QE2)
+{
+	uint32_t a, b, a2, b2, z, z4, m, n, w, tA, tB;
+	asm volatile(
+		"v_pk_add_u16 %[a], %[xp], %[vp]\n\t"
+		"v_pk_min_u16 %[m], %[x1], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_add_u16 %[b], %[y], %[u]\n\t"
+		"v_pk_add_u16 %[a2], %[x2p], %[vp]\n\t"
+		"v_pk_mad_u16 %[z], %[m], %[misd], %[mch]\n\t"
+		"v_pk_add_u16 %[b2], %[y2], %[u]\n\t"
+		"v_pk_max_i16 %[tA], %[a], %[b]\n\t"
+		"v_pk_lshrrev_b16 %[n], 2, %[o1] op_sel_hi:[0,1]\n\t"
+		"v_pk_max_i16 %[tB], %[a2], %[b2]\n\t"
+		"v_pk_sub_u16 %[w], %[scn], %[z]\n\t"
+		"v_pk_max_i16 %[tA], %[tA], %[tB]\n\t"
+		"v_pk_mad_u16 %[z], %[n], %[w], %[z]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_max_i16 %[z4], %[z], %[tA]\n\t"
+		"s_nop 0"
+		: [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [b2] "=&v"(b2), [z] "=&v"(z), [z4] "=&v"(z4), [m] "=&v"(m), [n] "=&v"(n), [w] "=&v"(w), [tA] "=&v"(tA), [tB] "=&v"(tB)
+		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCH), [misd] "s"(S_MISD), [scn] "s"(S_SCN));
+	uint32_t zc, d0, d1, d2, d3, t1, t2, e, un, vn;
+	asm volatile(
+		"v_pk_sub_u16 %[d0], %[z4], %[z]\n\t"
+		"v_pk_sub_u16 %[d1], %[z4], %[a]\n\t"
+		"v_pk_sub_u16 %[d2], %[z4], %[b]\n\t"
+		"v_pk_sub_u16 %[d3], %[z4], %[a2]\n\t"
+		"v_pk_min_i16 %[zc], %[z4], %[mch]\n\t"
+		"v_pk_min_u16 %[d0], %[d0], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[d1], %[d1], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[d2], %[d2], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[d3], %[d3], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[un], %[zc], %[vp]\n\t"
+		"v_pk_sub_u16 %[vn], %[zc], %[u]\n\t"
+		"v_pk_sub_u16 %[t1], %[zc], %[q]\n\t"
+		"v_pk_sub_u16 %[t2], %[zc], %[q2]\n\t"
+		"v_pk_add_u16 %[e], %[d3], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[a], %[a], %[t1]\n\t"
+		"v_pk_sub_u16 %[b], %[b], %[t1]\n\t"
+		"v_pk_mad_u16 %[e], %[d2], %[e], 1 op_sel_hi:[1,1,0]\n\t"
+		"v_pk_sub_u16 %[a2], %[a2], %[t2]\n\t"
+		"v_pk_sub_u16 %[b2], %[b2], %[t2]\n\t"
+		"v_pk_mad_u16 %[e], %[d1], %[e], 1 op_sel_hi:[1,1,0]\n\t"
+		"v_pk_max_i16 %[a], %[a], 0 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[b], %[b], 0 op_sel_hi:[1,0]\n\t"
+		"v_pk_mul_lo_u16 %[e], %[d0], %[e]\n\t"
+		"v_pk_max_i16 %[a2], %[a2], 0 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[b2], %[b2], 0 op_sel_hi:[1,0]"
+		: [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [un] "=&v"(un), [vn] "=&v"(vn),
+		  [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
+		: [z4] "v"(z4), [z] "v"(z), [vp] "v"(vp), [u] "v"(u), [mch] "v"(P_MCH), [q] "s"(S_Q), [q2] "s"(S_Q2));
+	uint32_t fa, fb, fa2, fb2, xn, yn, x2n, y2n;
+	asm volatile(
+		"v_pk_min_u16 %[fa], %[a], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[xn], %[a], %[qe]\n\t"
+		"v_pk_min_u16 %[fb], %[b], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fa], 8, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[yn], %[b], %[qe]\n\t"
+		"v_pk_min_u16 %[fa2], %[a2], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fb], 16, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[x2n], %[a2], %[qe2]\n\t"
+		"v_pk_min_u16 %[fb2], %[b2], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fa2], 32, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[y2n], %[b2], %[qe2]\n\t"
+		"v_pk_mad_u16 %[e], %[fb2], 64, %[e] op_sel_hi:[1,0,1]"
+		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n), [e] "+v"(e)
+		: [a] "v"(a), [b] "v"(b), [a2] "v"(a2), [b2] "v"(b2), [qe] "s"(S_QE), [qe2] "s"(S_QE2));
+	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
+}
+
+// ---- mm_test_zdrop's walk over a finished alignment (align.c:46-84), by the 32 lanes of a half-wave ----
+// The reference walks the CIGAR from the start: a running score (substitution scores base by base, -(q + e * len) per gap), the
+// running maximum with the position of its LAST occurrence, and, at every step below the maximum, the drop
+// max - score - |advance on the target - advance on the query| * e; it reports the FIRST step with the largest positive drop
+// (update_max_zdrop, align.c:46-59).  A "step" is one aligned base pair or one whole gap.  Here the steps are cut into 32 consecutive
+// segments, one per lane: (1) prefix sums over the operations (steps, target and query advance) give every operation its first
+// step and position; (2) each lane walks its segment once for the segment's score sum and its highest prefix, a scan over the lanes
+// turns these into the score and the running maximum (value, position; the later of equals) each segment starts from; (3) a second
+// walk applies the reference's test step by step, and the largest drop of the lowest lane wins.  The same walks sum the alignment's
+// score under the DP's own costs (dual affine: the cheaper of the two gap costs; ambiguous bases by sc_N, ksw2_extd2_sse.c:71) =
+// the corner cell the reference reports (:366-383).  Both half-waves of a wave run it at once, each on its own job (have = the
+// half has one); ops = the half's operations LAST FIRST (n_ops of them), pA / pB = n_ops + 1 words of scratch each.
+struct GfZdrop { int32_t zd_max, t0, t1, q0, q1, dp_sum; };
+
+template <class TB, class QB>
+__device__ __forceinline__ GfZdrop gf_zdrop_scan(bool have, int n_ops, const uint32_t *ops, uint32_t *pA, uint32_t *pB, TB tb_at, QB qb_at,
+                                                 const int8_t *s_mat, int gq, int ge, int gq2, int ge2, int sc_N)
+{
+	const int lane = (int)(threadIdx.x & 63), hl = lane & 31;
+	if (!have) n_ops = 0;
+	const int n_other = __shfl_xor(n_ops, 32, 64), n_max = n_ops > n_other ? n_ops : n_other; // the loops with shuffles run the same count in both halves
+	// (1) first step and position of every operation
+	int S = 0, tot_i = 0, tot_j = 0;
+	for (int f0 = 0; f0 < n_max; f0 += 32) {
+		const int f = f0 + hl;
+		const bool ok = f < n_ops;
+		const uint32_t w = ok ? ops[n_ops - 1 - f] : 0u, op = w & 0xf;
+		const int len = (int)(w >> 4);
+		int st = ok ? (op == 0 ? len : 1) : 0, di = ok && op != 1 ? len : 0, dj = ok && op != 2 ? len : 0;
+		const int st0 = st, di0 = di, dj0 = dj;
+#pragma unroll
+		for (int d = 1; d < 32; d <<= 1) {
+			const int a = __shfl_up(st, d, 32), b = __shfl_up(di, d, 32), c = __shfl_up(dj, d, 32);
+			if (hl >= d) st += a, di += b, dj += c;
+		}
+		if (ok) pA[f] = (uint32_t)(S + st - st0), pB[f] = (uint32_t)(tot_i + di - di0) | (uint32_t)(tot_j + dj - dj0) << 16;
+		S += __shfl(st, 31, 32), tot_i += __shfl(di, 31, 32), tot_j += __shfl(dj, 31, 32);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	// the lane's segment of steps, and the operation its first step lies in
+	const int seg = (S + 31) >> 5, lo = hl * seg < S ? hl * seg : S, hi = lo + seg < S ? lo + seg : S;
+	int f_lo = 0;
+	if (lo < hi) {
+		int l = 0, r = n_ops - 1;
+		while (l < r) {
+			const int mid = (l + r + 1) >> 1;
+			if ((int)pA[mid] <= lo) l = mid; else r = mid - 1;
+		}
+		f_lo = l;
+	}
+	// one step after the other: body(score change, DP-score change, target position, query position)
+	auto walk = [&](auto body) {
+		if (lo >= hi) return;
+		int f = f_lo;
+		uint32_t w = ops[n_ops - 1 - f], op = w & 0xf;
+		int len = (int)(w >> 4), first = (int)pA[f], cnt = op == 0 ? len : 1;
+		const uint32_t b0 = pB[f];
+		int ci = (int)(b0 & 0xffffu), cj = (int)(b0 >> 16);
+		for (int s = lo; s < hi; ++s) {
+			if (s >= first + cnt) { // next operation
+				if (op != 1) ci += len;
+				if (op != 2) cj += len;
+				first += cnt, ++f;
+				w = ops[n_ops - 1 - f], op = w & 0xf, len = (int)(w >> 4), cnt = op == 0 ? len : 1;
+			}
+			if (op == 0) {
+				const int o = s - first, tb = tb_at(ci + o), qb = qb_at(cj + o), sm = s_mat[tb * 5 + qb];
+				body(sm, ((tb | qb) & 4) ? sc_N : sm, ci + o, cj + o);
+			} else {
+				const int c1 = gq + ge * len, c2 = gq2 + ge2 * len;
+				body(-c1, -(c1 < c2 ? c1 : c2), op == 2 ? ci + len : ci, op == 1 ? cj + len : cj);
+			}
+		}
+	};
+	// (2) per segment: score sum, DP-score sum, highest prefix (the later of equals) relative to the segment's start
+	int sum = 0, dp = 0, rel = INT32_MIN, rel_i = -1, rel_j = -1;
+	walk([&](int d, int dd, int pi, int pj) {
+		sum += d, dp += dd;
+		if (sum >= rel) rel = sum, rel_i = pi, rel_j = pj;
+	});
+	int incl = sum;
+#pragma unroll
+	for (int d = 1; d < 32; d <<= 1) {
+		const int a = __shfl_up(incl, d, 32);
+		if (hl >= d) incl += a;
+	}
+#pragma unroll
+	for (int d = 16; d >= 1; d >>= 1) dp += __shfl_xor(dp, d, 32);
+	const int start = incl - sum;
+	int mx = rel == INT32_MIN ? INT32_MIN : start + rel, mx_i = rel_i, mx_j = rel_j; // inclusive running maximum over the lanes: the later of equals
+#pragma unroll
+	for (int d = 1; d < 32; d <<= 1) {
+		const int a = __shfl_up(mx, d, 32), b = __shfl_up(mx_i, d, 32), c = __shfl_up(mx_j, d, 32);
+		if (hl >= d && a > mx) mx = a, mx_i = b, mx_j = c;
+	}
+	{ // what the segment starts from: the maximum over the lanes before it
+		const int a = __shfl_up(mx, 1, 32), b = __shfl_up(mx_i, 1, 32), c = __shfl_up(mx_j, 1, 32);
+		mx = hl ? a : INT32_MIN, mx_i = hl ? b : -1, mx_j = hl ? c : -1;
+	}
+	// (3) update_max_zdrop over the segment
+	GfZdrop z = { 0, -1, -1, -1, -1, dp };
+	int score = start;
+	walk([&](int d, int, int pi, int pj) {
+		score += d;
+		if (score < mx) {
+			const int li = pi - mx_i, lj = pj - mx_j, diff = li > lj ? li - lj : lj - li, zz = mx - score - diff * ge;
+			if (zz > z.zd_max) z.zd_max = zz, z.t0 = mx_i, z.t1 = pi, z.q0 = mx_j, z.q1 = pj;
+		} else mx = score, mx_i = pi, mx_j = pj;
+	});
+	int best = z.zd_max;
+#pragma unroll
+	for (int d = 16; d >= 1; d >>= 1) { const int a = __shfl_xor(best, d, 32); best = a > best ? a : best; }
+	const unsigned long long bal = __ballot(z.zd_max == best);
+	const uint32_t mine = lane >= 32 ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+	const int src = __builtin_ctz(mine); // the first step with the largest drop lies in the lowest such lane
+	z.zd_max = best, z.t0 = __shfl(z.t0, src, 32), z.t1 = __shfl(z.t1, src, 32), z.q0 = __shfl(z.q0, src, 32), z.q1 = __shfl(z.q1, src, 32);
+	return z;
+}
+
+} // namespace mm2amd

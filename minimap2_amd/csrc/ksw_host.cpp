@@ -36,6 +36,7 @@ inline size_t dir_limit(int dc) { return dc == kDirClasses - 1 ? SIZE_MAX : (siz
 constexpr int kFastMaxQ = 1024, kFastMaxTAny = 3072;
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: <= 96 VGPRs -> 5 waves/SIMD
 inline int fast_waves(int tier) { return kFastQCap[tier] > 512 ? 4 : 6; } // waves per SIMD the gap-fill kernel is compiled for (= blocks of four waves per CU)
+inline int stream_sets(int tier) { return tier == 0 ? 4 : tier == 1 ? 8 : 0; } // classes the streaming kernel takes (query <= 512, target <= 64 * sets); 0: the strip kernel
 inline int fast_tier(const KswJob &j) { int t = j.qlen <= 512 && j.tlen <= 1536 ? 0 : 3; while (j.tlen > kFastMaxT[t]) ++t; return t; }
 
 // A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
@@ -60,6 +61,9 @@ inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
 void ksw_gapfill_launch(const KswLaunch &L, int n_slots, int qcap, void *stream); // ksw_gapfill.hip
+void ksw_stream_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream);  // ksw_stream.hip
+size_t ksw_stream_slot_bytes(int n_sets);
+int ksw_stream_waves(int n_sets);
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
@@ -74,6 +78,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	// classified and histogrammed by one pool thread (which also gathers the per-class sizing figures), a short serial prefix
 	// turns the histograms into stable scatter offsets, and the chunks scatter in parallel.
 	constexpr int NB = 256; // cost buckets per tier
+	const bool stream_on = !getenv("MM2AMD_NO_STREAM"); // diagnostic: every gap fill through the strip kernel
 	constexpr size_t CH = 32768;
 	const size_t NBINS = (size_t)(sc.single == 2 ? kNTiers : kFirstSplice) * NB; // the splice classes only exist in splice mode
 	int min_sc = sc.mat[1];
@@ -121,6 +126,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
 			int cb = fast && j.tlen <= 512 && j.qlen <= 512 ? (int)(std::sqrt(cost) * 0.25) : (int)(8.0 * std::log2(cost + 1.0)); // small gap fills: cost <= 1024*512; other classes: any (9 % steps)
 			if (sfast) cb = (int)(12.0 * std::log2((double)(j.qlen + j.tlen))); // the two jobs of a wave advance row by row: order by row count (6 % steps)
+			// the streaming kernel computes, row by row, the register sets its jobs in flight reach: jobs of one width class (64-column
+			// sets) together, the widest first; within a class the longest queries first (short ones fill the launch's tail)
+			if (fast && stream_on && stream_sets(tier)) cb = (((j.tlen + 63) / 64 - 1) & 3) * 64 + std::min(63, j.qlen / 8);
 			if (cb >= NB) cb = NB - 1;
 			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
 			bucket[i] = bk;
@@ -200,6 +208,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		Plan plan[kNTiers];
 		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
 		auto group_of = [](int tier) { return tier >= kFirstExact && tier < kFirstSplice ? 1 : 0; };
+		const int max_slots_env = getenv("MM2AMD_KSW_MAX_SLOTS") ? atoi(getenv("MM2AMD_KSW_MAX_SLOTS")) : 0; // tests: few persistent waves, so that each takes many jobs
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			Plan &P = plan[tier];
 			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
@@ -210,7 +219,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes, P.cells = cls[tier].cells;
 			// the gap-fill kernel keeps ONE matrix per wave for its two jobs, as many rows as the longer and as many columns as the wider
 			// of the two needs (two rows x two jobs per dword): a pair's two slots together must hold (rows / 2 + 1) x columns dwords
-			if (tier < kFirstExact) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
+			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
+			if (tier < kFirstExact) P.tmp_cap = 3 * (P.tmp_cap + 2); // the operations, and two prefix arrays over them for the half-wave's Z-drop walk (gf_zdrop_scan)
+			if (tier < kFirstExact) P.slot_bytes = n_stream ? ksw_stream_slot_bytes(n_stream) : (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			P.hbm = !fast && rc == kHbmRing;
 			P.ring = fast ? 64 : P.hbm ? cls[tier].max_ring : kRingSize[rc];
@@ -222,6 +233,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
 			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
+			else if (n_stream) blocks_per_cu = ksw_stream_waves(n_stream);
 			else if (fast) blocks_per_cu = fast_waves(tier);
 			else if (P.hbm) blocks_per_cu = 4;
 			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
@@ -230,6 +242,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const size_t per_slot = fast && !(sfast && kSpliceSelf[sclass]) ? 2 : 1; // the paired gap-fill kernels run two jobs per wave
 			P.n_slots = std::min<size_t>((P.end - P.beg + per_slot - 1) / per_slot, (size_t)n_cu * blocks_per_cu * wpb);
 			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
+			if (max_slots_env > 0) P.n_slots = std::min<size_t>(P.n_slots, (size_t)max_slots_env);
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
 			if (P.hbm) need_state = std::max(need_state, P.n_slots * region);
@@ -273,11 +286,14 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.state_pool = P.hbm ? d_state.p : nullptr;
 			L.single_affine = single_affine, L.splice = splice;
 			if (prof) prof->begin(stream_);
-			if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
+			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
+			if (n_stream) ksw_stream_launch(L, (int)P.n_slots, n_stream, stream_);
+			else if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
-			if (prof) prof->end(stream_, tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+			static const char *kStreamNames[2] = { "ksw_stream_kernel<4>[t256]", "ksw_stream_kernel<8>[t512]" };
+			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
 		}
 		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));

@@ -128,6 +128,41 @@ def test_register_resident_gap_fill_kernel(preset):
     assert fast == exact
 
 
+@pytest.mark.parametrize("preset", list(PRESETS))
+def test_streaming_gap_fill_kernel(preset, monkeypatch):
+    """ksw_stream.hip runs the jobs of a wavefront back to back through the lanes (job k+1's first anti-diagonals fill the lanes job
+    k's last ones have left): with four persistent waves, each half-wave streams ~200 jobs of every shape the two classes take
+    (query <= 512, target <= 256 / <= 512) -- narrow after wide, long after short, single cells, N bases, unrelated sequences --
+    against the lane-exact oracle; then the same jobs one pair per wave, and through the strip kernel"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(83)
+    jobs = []
+    for it in range(1600):
+        kind = it % 8
+        if kind == 0:
+            q, t = rng.integers(0, 4, int(rng.integers(1, 513)), dtype=np.uint8), rng.integers(0, 4, int(rng.integers(1, 513)), dtype=np.uint8)
+        elif kind == 1:
+            q, t = rng.integers(0, 4, int(rng.integers(1, 6)), dtype=np.uint8), rng.integers(0, 4, int(rng.integers(1, 513)), dtype=np.uint8)
+        elif kind == 2:
+            q, t = rng.integers(0, 4, int(rng.integers(1, 513)), dtype=np.uint8), rng.integers(0, 4, int(rng.integers(1, 6)), dtype=np.uint8)
+        else:
+            q, t = random_pair(rng, int(rng.choice([1, 2, 30, 63, 64, 65, 100, 128, 200, 255, 256, 257, 300, 400, 511, 512])) if kind == 3 else int(rng.integers(1, 513)),
+                               float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.03])), int(rng.choice([0, 0, 0, 40, -40, 150, -150])))
+            q, t = q[:512], t[:512]
+        if len(q) == 0 or len(t) == 0:
+            continue
+        jobs.append((q, t, int(rng.choice([30001, -1])), 400, -1, 0x08))
+    monkeypatch.setenv("MM2AMD_KSW_MAX_SLOTS", "4")
+    _run(jobs, preset)
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    mat = ts_mat(a, b, 1, 0)
+    streamed = mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+    monkeypatch.delenv("MM2AMD_KSW_MAX_SLOTS")
+    assert mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2) == streamed
+    monkeypatch.setenv("MM2AMD_NO_STREAM", "1")
+    assert mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2) == streamed
+
+
 @pytest.mark.parametrize("preset", ["ont", "asm5"])
 def test_gap_fill_kernel_column_strips(preset):
     """ksw_gapfill.hip sweeps targets wider than 256 columns in strips of 256 (boundary column handed over through LDS), with two
