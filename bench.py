@@ -356,9 +356,7 @@ def main():
     # instruction = 2 cycles on a SIMD-32, 1024 SIMDs at 2.4 GHz, every lane useful).
     roof = None
     if prof:
-        GAPFILL = "ksw_stream_kernel+ksw_gapfill_kernel"  # the gap-fill DP: the streaming kernel (targets <= 512) and the strip kernel (the rest) share one cell body
-        base = lambda k: k.split("[")[0].split("<")[0]
-        family = lambda k: GAPFILL if base(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel") else base(k)  # launch classes of one kernel count together
+        family = lambda k: k.split("[")[0].split("<")[0]  # launch classes of one kernel (ksw_stream_kernel<4>[t256], ...) count together
         src = prof1 or prof  # dominance by un-overlapped cost when we have it
         fam_total = {}
         for k, v in src.items():
@@ -381,22 +379,28 @@ def main():
             a_[1] += v["launches"]
         roof["avg_launch_ms_by_instantiation"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(inst.items())}
         if prof1:
-            vfam = GAPFILL if any(family(k) == GAPFILL for k in prof1) else fam
+            # the register-resident gap-fill DP: the streaming kernel (targets <= 512: >95 % of the cells), else the strip kernel (MM2AMD_NO_STREAM)
+            vfam = next((f for f in ("ksw_stream_kernel", "ksw_gapfill_kernel") if any(family(k) == f for k in prof1)), fam)
             one = {k: v for k, v in prof1.items() if family(k) == vfam}
             ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
-            # issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU mix in the ISA (50 packed VOP3P, 6 DPP moves,
-            # 21 other VALU) priced with the SATURATED per-instruction costs of tools/valu_issue_bench.hip (profiles/r02_valu_issue_bench_v4.txt:
-            # packed / VOP3 4.37 cycles per wave64 instruction and SIMD, DPP 4.2, the rest ~3.4 on average) = 316 cycles
-            row_cycles = 50 * 4.37 + 6 * 4.2 + 21 * 3.4
+            # issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU mix in the ISA priced with the SATURATED
+            # per-instruction costs of tools/valu_issue_bench.hip (profiles/r02_valu_issue_bench_v4.txt: packed VOP3P / VOP3 4.37 cycles per
+            # wave64 instruction and SIMD, DPP 4.2, the rest ~3.4 on average).  Streaming kernel: 50 packed + 6 DPP + 9 other = 65
+            # instructions, 274 cycles; strip kernel: 50 + 6 + 21 = 77 instructions, 316 cycles.  Lane utilisation = cells / (128 x executed
+            # register-set rows), counted by the MM2AMD_GF_COUNT build (profiles/r02_stream_lane_utilisation.txt; strip kernel: round-2 count).
+            n_packed, n_dpp, n_other, lane_util = (50, 6, 9, 0.865) if vfam == "ksw_stream_kernel" else (50, 6, 21, 0.727)
+            row_cycles = n_packed * 4.37 + n_dpp * 4.2 + n_other * 3.4
             peak_cells = 1024 * 2.4e9 * 128 / row_cycles
-            nominal = 1024 * 2.4e9 * 128 / (77 * 2.0)
+            nominal = 1024 * 2.4e9 * 128 / ((n_packed + n_dpp + n_other) * 2.0)
             rate = cells1 / max(ms1 * 1e-3, 1e-12)
             roof["valu"] = {"bound": "valu", "kernel": vfam, "cells_per_s": round(rate, 1), "issue_peak_cells_per_s": round(peak_cells, 1),
-                            "frac": round(rate / peak_cells, 4), "lane_utilisation": 0.727, "frac_at_measured_lane_utilisation": round(rate / peak_cells / 0.727, 4),
+                            "frac": round(rate / peak_cells, 4), "lane_utilisation": lane_util, "frac_at_measured_lane_utilisation": round(rate / peak_cells / lane_util, 4),
                             "nominal_2cycle_peak_cells_per_s": round(nominal, 1), "frac_nominal": round(rate / nominal, 4),
                             "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
-                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / 316 cycles (the hot loop's 77 VALU instructions at their measured saturated issue costs, every lane useful); lane_utilisation = cells / (128 x executed register-set rows), counted by an instrumented build; nominal = the same 77 instructions at the guide's 2 cycles per wave64 instruction"}
+                            "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
+                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles (the hot loop's %d VALU instructions at their measured saturated issue costs, every lane useful); lane_utilisation = cells / (128 x executed register-set rows), counted by an instrumented build; nominal = the same instructions at the guide's 2 cycles per wave64 instruction; the launch also traces back and Z-drop-scans every job, which the peak does not price" % (round(row_cycles), n_packed + n_dpp + n_other)}
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
+            roof["unoverlapped_gcells_per_s"] = {k: round(v["units"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["units"] > 0}  # DP kernels: cells of the launch class / its time
             roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1)
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name):
     n = name.split("(")[0].replace("void ", "").replace("mm2amd::", "")
-    return n.split("<")[0] if n.startswith(("ksw_gapfill_kernel", "ksw_splice_kernel", "ksw_extd2_kernel")) else n
+    return n.split("<")[0] if n.startswith(("ksw_stream_kernel", "ksw_gapfill_kernel", "ksw_splice_kernel", "ksw_extd2_kernel")) else n
 
 
 def collect(counter, args):
