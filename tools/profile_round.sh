@@ -1,15 +1,18 @@
-# Round-end evidence in one gpurun call: GPU test suite, smoke(), the three bench lines, rocprofv3 kernel summaries, PMC traffic.
-# usage (from the dev container): gpurun --timeout 2400 -- 'bash tools/profile_round.sh v5'
-V=${1:-vX}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
-(cd $R && timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/r01_pytest_gpu_$V.log; python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> $O/r01_pytest_gpu_$V.log 2>&1)
-python $R/bench.py > $O/r01_bench_full_$V.json 2> $O/r01_bench_full_$V.log
-rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --no-cpu-baseline > $O/r01_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
-python $R/tools/rocpd_summary.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) > $O/r01_bench_full_kernel_stats_$V.txt; rm -rf $O/prof_ont
-cd $R; python tools/pmc_traffic.py --reads 20000 > $O/pmc_ont.log 2>&1; python tools/pmc_traffic.py --preset splice --reads 10000 > $O/pmc_spl.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; cd /tmp
-python $R/bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r01_bench_splice_$V.json 2> $O/r01_bench_splice_$V.log
-rocprofv3 --kernel-trace --stats -d $O/prof_spl -o bench -- python $R/bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --no-cpu-baseline > $O/r01_bench_splice_${V}_under_rocprof.json 2> $O/prof_spl.log
-python $R/tools/rocpd_summary.py $(ls $O/prof_spl/*.db $O/prof_spl/*/*.db 2>/dev/null | head -1) > $O/r01_bench_splice_kernel_stats_$V.txt; rm -rf $O/prof_spl
-cat $O/r01_pytest_gpu_$V.log; python -c "
+# Round-end evidence in one gpurun call: smoke(), the bench lines, the rocprofv3 kernel summary of the headline command.
+# usage (from the dev container): gpurun --timeout 1500 -- 'bash tools/profile_round.sh v5'
+V=${1:-vX}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+(cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/r02_smoke_$V.log 2>&1; tail -1 $O/r02_smoke_$V.log)
+timeout 400 python $R/bench.py --steps 10 --warmup 3 > $O/r02_bench_full_$V.json 2> $O/r02_bench_full_$V.log
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/r02_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
+python $R/tools/rocpd_summary.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) > $O/r02_bench_full_kernel_stats_$V.txt; rm -rf $O/prof_ont
+timeout 400 python $R/bench.py --preset map-hifi --reads 200000 --steps 2 --warmup 1 --cpu-sample 20000 > $O/r02_bench_hifi_$V.json 2> $O/r02_bench_hifi_$V.log
+timeout 400 python $R/bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r02_bench_splice_$V.json 2> $O/r02_bench_splice_$V.log
+timeout 400 python $R/bench.py --preset sr --reads 1000000 --steps 2 --warmup 1 --cpu-sample 100000 > $O/r02_bench_sr_$V.json 2> $O/r02_bench_sr_$V.log
+python -c "
 import json,sys
-for f in ['r01_bench_full_$V.json','r01_bench_splice_$V.json']:
-    d=json.load(open('$O/'+f)); print(f, d['value'], d['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['hits_identical_to_gpu'], d['roofline']['achieved'], d['roofline']['traffic'])"
+for f in ['r02_bench_full_$V.json','r02_bench_full_${V}_under_rocprof.json','r02_bench_hifi_$V.json','r02_bench_splice_$V.json','r02_bench_sr_$V.json']:
+    try:
+        d=json.loads(open('$O/'+f).read().strip().split('\n')[-1]); c=d.get('cpu_baseline') or {}; r=d['roofline']
+        print(f, d['value'], d['ms_per_step'], c.get('value'), c.get('hits_identical_to_gpu'), r['kernel'], r['achieved'], r['traffic'], (r.get('valu') or {}).get('frac'))
+    except Exception as e: print(f, 'FAILED', e)"
+head -12 $O/r02_bench_full_kernel_stats_$V.txt
