@@ -1,2 +1,3 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-timeout 700 python $R/tools/e2e_wall.py --skip-index-check --out $O/r02_e2e_wall_v3.json > $O/e2e.log 2>&1; tail -2 $O/e2e.log | cut -c1-1500
+MM2AMD_TRACE=/tmp/trace.tsv timeout 200 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/tr.json 2> $O/tr.log
+python $R/tools/trace_gantt.py /tmp/trace.tsv 2 > $O/trace_gantt.txt; head -3 $O/trace_gantt.txt; tail -70 $O/trace_gantt.txt
