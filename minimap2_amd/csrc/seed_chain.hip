@@ -145,12 +145,29 @@ __global__ void __launch_bounds__(256) sketch_wave_kernel(SeedChainBuffers B, in
 	int64_t chunk = (len + 63) / 64;
 	if (chunk < 32) chunk = 32;
 	const int64_t cs = (int64_t)lane * chunk, ce = cs + chunk < len ? cs + chunk : len;
+	// One pass: the lane's minimizers go to a staging area of its own -- the seed arrays of the slots of its stretch, unused until
+	// seed_collect (at most one minimizer per base, and a lane emits owned positions only) -- and are then moved to their place in the
+	// read's list, which a scan of the lanes' counts gives.  (Counting first and sketching a second time to emit cost 45 % of the kernel.)
 	uint32_t n = 0;
-	if (cs < len) sketch_chunk<false>(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t) { ++n; });
+	const uint64_t slot0 = B.mz_off[r] + (uint64_t)cs;
+	uint32_t *const t_xl = B.sd_n + slot0, *const t_xh = B.sd_off + slot0, *const t_yl = B.sd_aoff + slot0, *const t_yh = B.sd_qpos + slot0;
+	if (cs < len)
+		sketch_chunk<false>(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t x, uint64_t y) {
+			t_xl[n] = (uint32_t)x, t_xh[n] = (uint32_t)(x >> 32), t_yl[n] = (uint32_t)y, t_yh[n] = (uint32_t)(y >> 32);
+			++n;
+		});
 	uint32_t incl = n;
 	for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-	uint64_t *ox = B.mz_x + B.mz_off[r] + (incl - n), *oy = B.mz_y + B.mz_off[r] + (incl - n);
-	if (n) sketch_chunk<false>(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t x, uint64_t y) { *ox++ = x; *oy++ = y; });
+	uint64_t *const ox = B.mz_x + B.mz_off[r] + (incl - n), *const oy = B.mz_y + B.mz_off[r] + (incl - n);
+	for (uint32_t i = 0; i < n; i += 4) { // four at a time: the loads of a group are in flight together
+		uint64_t x[4], y[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (i + u < n) x[u] = (uint64_t)t_xh[i + u] << 32 | t_xl[i + u], y[u] = (uint64_t)t_yh[i + u] << 32 | t_yl[i + u];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (i + u < n) ox[i + u] = x[u], oy[i + u] = y[u];
+	}
 	if (lane == 63) B.mz_cnt[r] = incl;
 }
 
