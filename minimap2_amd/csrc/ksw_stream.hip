@@ -4,19 +4,23 @@
 // An anti-diagonal sweep of a q x t matrix with lane = target column keeps lane t busy for q consecutive rows (t .. t + q - 1) of the
 // q + t - 1 the job takes: the ramps at both ends leave register sets partly empty, and over the gap fills of a read batch only
 // 73 % of the computed lanes hold a cell.  Here lane t moves on to column t of the NEXT job in the row after
-// its last cell of the current one: job k+1 starts at row R[k+1] = R[k] + max(q[k], t[k]), its first anti-diagonals fill the lanes
-// job k's last ones have left, and a lane idles only while the job it is on is narrower than the lane's column (counted: 0.73 ->
-// 0.87 of the computed lanes hold a cell).  Everything a lane needs changes hands when the next job's first anti-diagonal reaches
-// it -- the "edge": its target base (T <- s_tn), and u / y / y2, which take their border values there exactly as on the first use
-// of a column in the one-job kernel (ksw2_extd2_sse.c:156-163); x / v / x2 arrive from the left neighbour as always, lane 0 takes
-// the matrix border.  The query bytes of the jobs in flight sit in an LDS ring addressed by row - column, the direction bytes
-// ([row r: half A, half B][row r + 1: A, B] per lane) in a ring of the last 1024 or 2048 rows in HBM; a job is traced back (and scanned
-// for mm_test_zdrop) right after its last row, while its successor is already under way.  Two independent streams share a wave in
-// the halves of the packed registers, as in ksw_gapfill.hip; the arithmetic of a cell is the same gf_cell.
+// its last cell of the current one.  A wave works on PAIRS of jobs (one per half of the packed 16-bit registers, consecutive in the
+// launch order, started on the same row -- so that both finish together and are traced back by the two half-waves at once): pair
+// k+1 starts at row R[k+1] = R[k] + max(q, t over pair k), its first anti-diagonals fill the lanes pair k's last ones have left,
+// and a lane idles only while the jobs it is on are narrower or shorter than its column and the pair's longest side (counted:
+// 0.73 -> 0.86 / 0.87 of the computed lanes hold a cell).  Everything a lane needs changes hands when the next pair's first
+// anti-diagonal reaches it -- the "edge": its target bases (T <- s_tn), and u / y / y2, which take their border values there
+// exactly as on the first use of a column in the one-job kernel (ksw2_extd2_sse.c:156-163); x / v / x2 arrive from the left
+// neighbour as always, lane 0 takes the matrix border of the pair it is on.  The query bytes of the pairs in flight sit in an LDS
+// ring addressed by row - column (both halves in one 16-bit load), the direction bytes ([row r: half A, half B][row r + 1: A, B]
+// per lane) in a ring of the last 1024 or 2048 rows in HBM; a pair is traced back (and walked for mm_test_zdrop, gf_zdrop_scan)
+// right after its last row, while its successor is already under way.  The arithmetic of a cell is the same gf_cell.
 //
-// At most two jobs per half are in flight (cur, nxt): nxt is promoted once all of its columns have seen its edge and cur has been
-// traced back; only then is the job after it fetched (its targets need the Tn registers).  Eligibility and exactness are those of
-// ksw_gapfill.hip; this kernel takes the classes with query <= 512 and target <= 64 * NC, the strip kernel the rest.
+// At most two pairs are in flight (cur, nxt): nxt is promoted once all of its columns have seen its edge and cur has been traced
+// back; only then is the pair after it fetched (its targets need the s_tn buffer).  Per row pair a bit mask names the register sets
+// that hold a valid cell of either pair; the others are skipped.  Eligibility and exactness are those of ksw_gapfill.hip; this
+// kernel takes the classes with query <= 512 and target <= 64 * NC, the strip kernel the rest.  tests/test_gpu_ksw.py streams
+// hundreds of jobs of every shape through each half-wave (MM2AMD_KSW_MAX_SLOTS) against the lane-exact oracle.
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "ksw_dev.hpp"
@@ -25,12 +29,12 @@
 
 namespace mm2amd {
 
-constexpr int ST_QRING = 2048;    // query bytes kept per half: two jobs in flight plus the bubble between them stay below 1100 rows
+constexpr int ST_QRING = 2048;    // query positions kept per wave: two pairs in flight plus the bubble between them stay below 1100 rows
 constexpr int st_rows(int n_sets) { return n_sets <= 4 ? 1024 : 2048; } // direction rows kept per wave: a job spans query + target - 1 <= 767 (4 sets) or 1023 (8) rows and is traced back within two rows of its last
 #ifndef ST_W4
 #define ST_W4 4
 #endif
-constexpr int ST_TCAP = 512;      // target bytes of the job being scanned
+constexpr int ST_TCAP = 512;      // target bytes of the jobs being walked for the Z-drop
 
 // A job record read through a vector load sits in VGPRs, and everything computed from it (row counters, branch conditions) would
 // follow it there: the fields are wave-uniform, say so.
