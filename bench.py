@@ -402,6 +402,13 @@ def main():
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
             roof["unoverlapped_gcells_per_s"] = {k: round(v["units"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["units"] > 0}  # DP kernels: cells of the launch class / its time
             roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1)
+            try:  # index probes per second of seed_collect_kernel (one mm_idx_get per query minimizer; the launch accounts 36 B per minimizer at the expected density 2 / (w + 1))
+                sc1 = prof1.get("seed_collect_kernel")
+                if sc1 and sc1["ms"] > 0:
+                    roof["index_probes"] = {"per_step": round(sc1["alg_bytes"] / 36.0), "per_s_unoverlapped": round(sc1["alg_bytes"] / 36.0 / (sc1["ms"] * 1e-3), 1),
+                                            "basis": "minimizers probed (read bases x 2 / (w + 1)) / un-overlapped seed_collect_kernel time; a probe = bucket_start + keys + val_off + position list, 2-3 dependent sector reads"}
+            except Exception:
+                pass
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
