@@ -23,7 +23,7 @@
 //     contiguous per register set and store instruction, a quarter of the store instructions of byte stores and full lines
 //     (round 1 stored 64-byte row segments: 1.9x write amplification in the PMC counters).
 //
-// Since ksw_stream.hip the gap fills with query <= 512 and target <= 512 (98 % of the cells of long-read mapping) take the streaming
+// Since ksw_stream.hip the gap fills with query <= 512 and target <= 512 (97 % of the DP cells of the map-ont benchmark) take the streaming
 // kernel, which runs the same cell body (gf_cell) with the jobs of a wave back to back through the lanes; this kernel keeps the
 // longer ones (queries <= 1024, targets <= 3072) and is the A/B partner of the streaming kernel (MM2AMD_NO_STREAM=1).  The Z-drop
 // walk over a finished alignment is gf_zdrop_scan (ksw_gapfill_dev.hpp), shared by both.
