@@ -1,0 +1,143 @@
+"""The schedule of the streaming gap-fill kernel (minimap2_amd/csrc/ksw_stream.hip) as a specification: the kernel's control logic --
+pairs fetched at R = max(R_cur + max(q, t over the pair), row), promotion of the next pair once every column of it has started and the
+current one has been traced back, the per-row-pair mask of register sets with a valid cell, the edge at which a lane changes pair,
+the finish after the pair's last anti-diagonal -- restated in Python and run over job lists of every shape (the launch order of the
+host, and adversarial orders).  Checked: every cell (job, column, query row) is computed exactly once, on anti-diagonal R + column +
+row, by a lane that is on that job, in a register set the mask names; its left neighbour's cell was computed the row before; when a
+pair is traced back its direction rows are still in the ring of ST_ROWS rows; the query positions of the pairs in flight never share
+a slot of the ST_QRING ring.  The device code is checked against the oracle on the GPU (tests/test_gpu_ksw.py); this pins the
+invariants its ring sizes and its promotion rule rest on."""
+import numpy as np
+import pytest
+
+ST_QRING = 2048
+
+
+def run_schedule(jobs, NC):
+    """jobs: list of (q, t) with q <= 512, t <= 64 * NC, consumed as consecutive pairs.  Returns the number of executed register-set rows."""
+    ST_ROWS = 1024 if NC <= 4 else 2048
+    n = len(jobs)
+    nxt_id = 0
+    cv = nv = False
+    cR = nR = 0
+    cur = [None, None]  # job ids of the halves (None: no job)
+    nxt = [None, None]
+    owner = [[None] * (NC * 64) for _ in range(2)]  # which job each lane of each half is on
+    computed = {}  # (job, column, query row) -> anti-diagonal
+    ring_owner = [dict() for _ in range(2)]  # query ring slot -> (job, query position) of jobs still needed
+    set_rows = 0
+
+    def dims(ids, k):
+        return [jobs[i][k] if i is not None else 0 for i in ids]
+
+    def fetch(R):
+        nonlocal nxt_id, nv, nR, nxt
+        nv = nxt_id < n
+        if not nv:
+            return
+        nR = R
+        nxt = [nxt_id, nxt_id + 1 if nxt_id + 1 < n else None]
+        nxt_id += 2
+        for h in range(2):
+            if nxt[h] is None:
+                continue
+            for i in range(jobs[nxt[h]][0]):  # the query bytes into the ring: the slot must not hold a position still needed
+                slot = (R + i) & (ST_QRING - 1)
+                assert slot not in ring_owner[h], ("query ring collision", nxt[h], ring_owner[h][slot])
+                ring_owner[h][slot] = (nxt[h], i)
+
+    fetch(0)
+    r0 = 0
+    while cv or nv:
+        if nv and not cv and r0 >= nR + max(dims(nxt, 1)):
+            cv, cR, cur = True, nR, list(nxt)
+            step = max(dims(cur, 0) + dims(cur, 1))
+            fetch(max(cR + step, r0))
+        need = 0
+        for h in range(2):
+            if cv and cur[h] is not None:
+                q, t = jobs[cur[h]]
+                lo, hi = max(r0 - cR - q + 1, 0), t - 1
+                if lo <= hi:
+                    need |= ((2 << (hi >> 6)) - 1) & ~((1 << (lo >> 6)) - 1)
+            if nv and r0 + 1 >= nR and nxt[h] is not None:
+                q, t = jobs[nxt[h]]
+                lo, hi = max(r0 - nR - q + 1, 0), min(r0 + 1 - nR, t - 1)
+                if lo <= hi:
+                    need |= ((2 << (hi >> 6)) - 1) & ~((1 << (lo >> 6)) - 1)
+        for r in (r0, r0 + 1):
+            started = nv and r >= nR
+            edge = r - nR if started else -1
+            for h in range(2):
+                if started and nxt[h] is not None and 0 <= edge < jobs[nxt[h]][1]:
+                    assert need >> (edge >> 6) & 1, "the edge lies in a skipped register set"
+                    owner[h][edge] = (nxt[h], nR)
+            for c in range(NC):
+                if not need >> c & 1:
+                    continue
+                set_rows += 1
+                for h in range(2):
+                    for t in range(c * 64, c * 64 + 64):
+                        if owner[h][t] is None:
+                            continue
+                        j, R = owner[h][t]
+                        q, tl = jobs[j]
+                        i = r - R - t
+                        if 0 <= i < q and t < tl:
+                            assert (j, t, i) not in computed
+                            if t > 0:
+                                assert computed.get((j, t - 1, i)) == r - 1, "left neighbour not computed the row before"
+                            if i > 0:
+                                assert computed.get((j, t, i - 1)) == r - 1
+                            computed[(j, t, i)] = r
+        if cv:
+            rows = max(a + b for a, b in zip(dims(cur, 0), dims(cur, 1)))
+            if r0 + 1 >= cR + rows - 2:
+                for h in range(2):
+                    if cur[h] is None:
+                        continue
+                    q, t = jobs[cur[h]]
+                    for tt in range(t):
+                        for i in range(q):
+                            rr = computed.pop((cur[h], tt, i))  # every cell exactly once ...
+                            assert rr == cR + tt + i
+                            assert ((r0 + 1) >> 1) - (rr >> 1) < ST_ROWS // 2, "direction row overwritten before the traceback"
+                    for i in range(q):  # the query is needed until here (Z-drop walk)
+                        assert ring_owner[h].pop((cR + i) & (ST_QRING - 1)) == (cur[h], i)
+                cv = False
+        r0 += 2
+        assert r0 < 4 * sum(a + b for a, b in jobs) + 4096, "the schedule does not terminate"
+    assert not computed and not any(ring_owner)
+    return set_rows
+
+
+def host_order(jobs):
+    """ksw_host.cpp: width class (64-column sets) first, the widest first; then the longest queries first"""
+    return sorted(jobs, key=lambda j: (-((j[1] + 63) // 64), -(j[0] // 8)))
+
+
+@pytest.mark.parametrize("NC", [4, 8])
+def test_streaming_schedule_invariants(NC):
+    rng = np.random.default_rng(7 + NC)
+    tmax = 64 * NC
+    shapes = [(1, 1), (512, tmax), (1, tmax), (512, 1), (2, 2), (64, 64), (65, 63), (512, 64), (3, tmax - 1), (511, tmax), (200, 65)]
+    for trial in range(12):
+        jobs = [shapes[int(k)] for k in rng.integers(0, len(shapes), 9)]
+        jobs += [(int(rng.integers(1, 513)), int(rng.integers(1, tmax + 1))) for _ in range(int(rng.integers(4, 12)))]
+        if trial % 3 == 0:
+            jobs = host_order(jobs)
+        elif trial % 3 == 1:
+            jobs = host_order(jobs)[::-1]  # narrow and short first: the worst case for the bubbles between pairs
+        if trial % 4 == 0:
+            jobs = jobs[:-1] if len(jobs) % 2 == 0 else jobs  # odd launches: the last pair has one job
+        run_schedule(jobs, NC)
+
+
+def test_lane_utilisation_of_typical_gap_fills():
+    """250 x 250-ish gap fills (the ONT workload's shape): the streamed sweep keeps ~0.85 of the computed lanes busy, the one-pair
+    sweep of the strip kernel 0.73 (counted on the GPU, 0.856 / 0.727)"""
+    rng = np.random.default_rng(11)
+    jobs = host_order([(int(rng.integers(200, 300)), int(rng.integers(200, 257))) for _ in range(40)])
+    rows = run_schedule(jobs, 4)
+    util = sum(q * t for q, t in jobs) / (128.0 * rows)
+    assert 0.80 < util < 0.95, util
