@@ -289,6 +289,17 @@ def test_device_heap_order_header_against_oracle():
     assert out[0] == b"OK" and int(out[2]) > 1000
 
 
+def test_device_sketch_header_against_oracle():
+    """minimap2_amd/csrc/sketch_dev.hpp (the minimizer automaton the sketch kernels run per stretch of a read) compiled for the host:
+    the stretches' outputs concatenate to mm_sketch's list, and a stretch reports owned positions only, each at most once (what the
+    one-pass staging of sketch_wave_kernel relies on) -- N runs, homopolymers, repeats, strand-symmetric k-mers, HPC."""
+    exe = os.path.join(HERE, "_build", "sketch_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/sketch_test not built")
+    out = subprocess.run([exe, "400"], stdout=subprocess.PIPE, check=True).stdout.split()
+    assert out[0] == b"OK" and int(out[2]) > 100000
+
+
 PE_CASES = [(["-x", "sr", "-a"], 2), (["-x", "sr", "-a"], 1), (["-x", "sr"], 2), (["-x", "sr", "-c"], 1), (["-x", "sr", "-a", "-F", "400"], 2),
             (["-x", "sr", "-a", "--heap-sort=no"], 2), (["-x", "sr", "-a", "-f", "2,20"], 1), (["-x", "sr", "-a", "-p", "0.3", "-N", "4"], 1),
             (["-x", "sr", "-a", "-g", "300", "-r", "50"], 2), (["-x", "sr", "-k", "15", "-w", "5", "-a"], 2), (["-x", "sr", "-a", "-A", "1", "-B", "3"], 2),
