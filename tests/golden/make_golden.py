@@ -29,6 +29,29 @@ CASES = {
 }
 
 
+# The reference's OWN test inputs (/root/reference/test, vendored unchanged under tests/golden/ref_fixtures/ because the GPU box has no
+# /root/reference): name -> (target, query, args).  mt_sam is BASELINE.json configs[0] (one record, pos 577, MAPQ 60);
+# inv_paf exercises the Z-drop split and the inversion rescue (align.c:916-971: tp:A:I records); x3s_paf the spliced alignment the
+# reference documents in test/x3s-aln.txt:1 (cg:Z:69M134N65M).
+FIXDIR = os.path.join(HERE, "ref_fixtures")
+FIXTURE_CASES = {
+    "mt_sam": ("MT-human.fa", "MT-orang.fa", ["-a"]),
+    "mt_paf_cs": ("MT-human.fa", "MT-orang.fa", ["-c", "--cs"]),
+    "inv_paf": ("t-inv.fa", "q-inv.fa", ["-c"]),
+    "inv_sam": ("t-inv.fa", "q-inv.fa", ["-a"]),
+    "x3s_paf": ("x3s-ref.fa", "x3s-qry.fa", ["-x", "splice", "-c"]),
+    "x3s_sam": ("x3s-ref.fa", "x3s-qry.fa", ["-x", "splice", "-a"]),
+    "tiny_paf": ("t2.fa", "q2.fa", ["-c"]),
+}
+
+
+def run_fixture(binary, case, extra=(), env=None):
+    t, q, args = FIXTURE_CASES[case]
+    p = subprocess.run([binary] + list(args) + list(extra) + ["-t", "2", os.path.join(FIXDIR, t), os.path.join(FIXDIR, q)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return strip_pg(p.stdout), p.stderr.decode()
+
+
 def md5(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
 
@@ -52,5 +75,9 @@ if __name__ == "__main__":
             out, m = run_case(REF_BIN, case, tmp)
         open(os.path.join(HERE, case + ".out"), "wb").write(out)
         meta[case] = m
+        print(case, len(out.split(b"\n")), "lines")
+    for case in FIXTURE_CASES:
+        out, _ = run_fixture(REF_BIN, case)
+        open(os.path.join(HERE, case + ".out"), "wb").write(out)
         print(case, len(out.split(b"\n")), "lines")
     json.dump(meta, open(os.path.join(HERE, "inputs.json"), "w"), indent=1, sort_keys=True)

@@ -40,6 +40,41 @@ def test_prebuilt_binaries_present():
     assert os.path.exists(DROPIN), "tests/_build/dropin_gpu must be built in the dev container (make -C tests/cpucheck)"
 
 
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as G  # noqa: E402
+
+
+@pytest.mark.parametrize("case", list(G.FIXTURE_CASES))
+def test_reference_fixtures_through_hip(case):
+    """the reference's own test inputs (vendored: tests/golden/ref_fixtures/) through the HIP path: MT-human x MT-orang -a = BASELINE.json
+    configs[0] (one record, pos 577, MAPQ 60), t-inv x q-inv -c (Z-drop split + inversion rescue, align.c:916-971), x3s -x splice
+    (cg:Z:69M134N65M, test/x3s-aln.txt:1); == committed golden == the compiled reference"""
+    want = open(os.path.join(HERE, "golden", case + ".out"), "rb").read()
+    got, err = G.run_fixture(DROPIN, case, ["--stats"])
+    assert "backend=hip:gfx950" in err, err[-500:]
+    assert got == want
+    ref, _ = G.run_fixture(REF_BIN, case)
+    assert ref == want
+    if case == "mt_sam":
+        assert b"\t577\t60\t" in got
+    if case == "inv_paf":
+        assert got.count(b"tp:A:I") == 2
+    if case == "x3s_paf":
+        assert b"cg:Z:69M134N65M" in got
+
+
+def test_one_by_one_calls_on_gpu(tmp_path):
+    """mm_gpu_map / mm_gpu_map_frag (the reference's mm_map / mm_map_frag signatures, map.c:380-397): a batch of one per call through
+    the HIP path == one mm_gpu_map_batch == the reference"""
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 1, 12, 71)
+    want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "4", "-a", ref, reads])
+    got, err = _run([DROPIN, "-x", "map-ont", "-t", "4", "-a", "--one-by-one", "--stats", ref, reads])
+    assert "backend=hip:gfx950" in err
+    assert got == want
+    got, _ = G.run_fixture(DROPIN, "inv_paf", ["--one-by-one"])
+    assert got == open(os.path.join(HERE, "golden", "inv_paf.out"), "rb").read()
+
+
 def test_ont_sam_identical(tmp_path):
     assert _compare(tmp_path, "ont", "map-ont", 8, 400, 11, ["-a"]) > 1000
 

@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 
 SPLICE = {}  # filled by the fixture: the same reference serves the spliced-alignment test
+HIFI = {}    # ... and the map-hifi test
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +42,7 @@ def world():
     pick = torch.randint(0, genes["ex_st"].shape[0], (n_cdna,), device=dev, generator=g3)  # the generator's first draw
     span_lo = genes["ex_st"][pick][:, 0].cpu().tolist()
     span_hi = (genes["ex_st"][pick] + genes["ex_len"][pick]).max(1).values.cpu().tolist()
+    HIFI.update(reads=[("hifi%d" % i, r) for i, r in enumerate(bench.gen_reads(torch, dev, 5151, codes, per, n_contig, 4000, 15000, 1500, 0.005))])
     SPLICE.update(refs=refs, per=per, reads=[("cdna%d" % i, s) for i, s in enumerate(cdna)], spans=list(zip(span_lo, span_hi)))
     # reads with known origin: same generator as bench.py, but we keep the placement
     g = torch.Generator(device=dev)
@@ -166,5 +168,49 @@ def test_splice_full_size_properties_and_sample_parity(world):
             got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
             al.free_raw(n_reg, reg)
             assert got == want
+    finally:
+        al.close()
+
+
+def test_hifi_full_size_properties_and_sample_parity(world):
+    """BASELINE.json configs[3] at full reference size: ~15 kb reads at 0.5 % error (the generator and parameters bench.py uses for its
+    200 k-read map-hifi line) against the 3 Gb reference with -x map-hifi (k19 w19, ksw_extd2 with the HiFi costs).  Properties: every
+    read maps with MAPQ 60 over > 95 % of its length and its CIGAR consumes exactly the spans its hit reports; hit records identical
+    to the reference's mm_map on a 2 000-read sample."""
+    import minimap2_amd as mm
+    from minimap2_amd import shard
+    _, _, _, names = world
+    al = mm.Aligner(SPLICE["refs"], preset="map-hifi", names=names, n_threads=32, sam=True)
+    try:
+        reads = HIFI["reads"]
+        hits = al.map_batch(reads)
+        n_good = 0
+        for (nm, seq), h in zip(reads, hits):
+            assert h, nm
+            p = h[0]
+            q_used = sum(x >> 4 for x in p.cigar if (x & 0xf) in (0, 1, 7, 8))
+            r_used = sum(x >> 4 for x in p.cigar if (x & 0xf) in (0, 2, 3, 7, 8))
+            assert q_used == p.q_en - p.q_st and r_used == p.r_en - p.r_st, nm
+            n_good += p.mapq == 60 and p.q_en - p.q_st > 0.95 * len(seq)
+        assert n_good >= 0.995 * len(reads)
+        if not os.path.exists(reflib.REFDRV_SO):
+            pytest.skip("oracle/_ref/librefdrv.so not present")
+        L = mm.lib()
+        st = al.index_stat()
+        S, keys, val_off, pos = reflib.export_index(al)
+        drv = reflib.RefDriver(st["w"], st["k"], st["flag"], names, al.lens, S, keys, val_off, pos, 64)
+        del keys, val_off, pos
+        mo = drv.map_opt("map-hifi", extra_flag=mm.F_OUT_SAM)
+        assert mo.mid_occ == al.map_opt.mid_occ
+        sample = reads[:2000]
+        _, nr, rg = drv.map(mo, sample, 64)
+        want = shard.pack_hits(L, nr, rg).numpy().tobytes()
+        L.mm2amd_free_regs(len(nr), nr, rg)
+        drv.close()
+        al.stage(sample)
+        n_reg, reg, _ = al.run(raw=True)
+        got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
+        al.free_raw(n_reg, reg)
+        assert got == want
     finally:
         al.close()

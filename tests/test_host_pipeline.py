@@ -54,16 +54,25 @@ def _pair(args, a, b):
     return outs[0]
 
 
-@pytest.mark.skipif(not os.path.isdir(REFTEST), reason="reference test data only exists in the dev container")
-def test_reference_fixture_mt():  # BASELINE.json configs[0]
-    out = _pair(["-a"], os.path.join(REFTEST, "MT-human.fa"), os.path.join(REFTEST, "MT-orang.fa"))
-    assert b"\t577\t60\t" in out  # one record, pos 577, MAPQ 60
-
-
-@pytest.mark.skipif(not os.path.isdir(REFTEST), reason="reference test data only exists in the dev container")
-def test_reference_fixture_inversion():
-    out = _pair(["-c"], os.path.join(REFTEST, "t-inv.fa"), os.path.join(REFTEST, "q-inv.fa"))
-    assert b"tp:A:I" in out  # the inversion rescue path (align.c:916-971)
+@pytest.mark.parametrize("case", list(G.FIXTURE_CASES))
+def test_reference_fixtures(case):
+    """the reference's OWN test inputs (test/MT-*.fa = BASELINE.json configs[0], test/t-inv.fa x q-inv.fa, test/x3s-*.fa; vendored under
+    tests/golden/ref_fixtures/): host pipeline + oracle backend == committed golden == the compiled reference when it is present"""
+    want = open(os.path.join(HERE, "golden", case + ".out"), "rb").read()
+    got, _ = G.run_fixture(CHECK, case)
+    assert got == want
+    if os.path.exists(G.REF_BIN):
+        ref, _ = G.run_fixture(G.REF_BIN, case)
+        assert ref == want, "golden fixture no longer matches the compiled reference"
+    if os.path.isdir(REFTEST):  # the vendored copies are the reference's files, byte for byte
+        for f in G.FIXTURE_CASES[case][:2]:
+            assert open(os.path.join(G.FIXDIR, f), "rb").read() == open(os.path.join(REFTEST, f), "rb").read()
+    if case == "mt_sam":
+        assert b"\t577\t60\t" in want  # SURVEY.md 8(c): one record, pos 577, MAPQ 60
+    if case == "inv_paf":
+        assert want.count(b"tp:A:I") == 2  # the inversion rescue path (align.c:916-971)
+    if case == "x3s_paf":
+        assert b"cg:Z:69M134N65M" in want and b"ts:A:+" in want  # test/x3s-aln.txt:1
 
 
 def test_empty_and_tiny_reads(tmp_path):

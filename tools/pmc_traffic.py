@@ -53,6 +53,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--ref-mb", type=float, default=3000)
+    ap.add_argument("--out", default=None, help="where to write the JSON (default: profiles/pmc_traffic.json; on the GPU box give a path under gpurun_out/)")
     ap.add_argument("--preset", default="map-ont", help="map-ont (default) or splice; results of a run are merged into the existing JSON")
     a = ap.parse_args()
     fetch = collect("FETCH_SIZE", a)
@@ -69,5 +70,5 @@ if __name__ == "__main__":
         n = max(fl, wl, 1)
         out[f] = {"fetch_bytes_per_launch": fb * 1024 / n, "fetch_bytes_x2": 2 * fb * 1024 / n, "write_bytes_per_launch": wb * 1024 / n, "launches": n,
                   "note": "%s: per launch at %d reads vs %d Mb; FETCH_SIZE/WRITE_SIZE in KiB -> bytes; x2 = gfx950 wide-read correction; WRITE_SIZE uncalibrated" % (a.preset, a.reads, a.ref_mb)}
-    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    json.dump(out, open(a.out or path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

@@ -4,8 +4,8 @@
 //   hipcc --offload-arch=gfx950 -O2 -o tools/build/valu_issue_bench tools/valu_issue_bench.hip && tools/build/valu_issue_bench
 //
 // Every wave runs ITERS x 16 copies of one instruction on 8 independent registers (no dependency stalls with >= 2 waves per
-// SIMD) between two s_memtime reads; the table gives shader cycles per wave-instruction PER SIMD at 1, 2 and 4 waves per SIMD
-// (blocks of 256 threads = one wave on each SIMD of a CU; W blocks per CU).  A full-rate wave64 VALU instruction on CDNA4 is 2
+// SIMD) between two s_memtime reads and records where it ran (HW_ID, XCC_ID); the table gives shader cycles per wave-instruction
+// PER SIMD from per-SIMD accounting -- the waves that actually shared a SIMD, not an assumed count -- at 1..16 blocks per CU.  A full-rate wave64 VALU instruction on CDNA4 is 2
 // cycles (SIMD-32, /opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling").  The result is what DESIGN.md section 4 prices the
 // DP kernels' VALU-issue roof with; the output of a run is kept under profiles/.
 #include <hip/hip_runtime.h>
@@ -15,6 +15,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <map>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -177,44 +178,74 @@ __global__ void __launch_bounds__(256, 2) bench_kernel(uint32_t *out, unsigned l
 	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 	out[tid] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ b;
 	const unsigned long long w1 = wall_clock64();
-	if ((threadIdx.x & 63) == 0) cyc[tid >> 6] = t1 - t0, cyc[(size_t)gridDim.x * 4 + (tid >> 6)] = w1 - w0;
+	// where the wave ran: HW_ID (gfx9: wave 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13) and the XCD it is on
+	uint32_t hw_id, xcc_id;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+	if ((threadIdx.x & 63) == 0) {
+		unsigned long long *rec = cyc + (size_t)(tid >> 6) * 5;
+		rec[0] = t0, rec[1] = t1, rec[2] = w0, rec[3] = w1, rec[4] = (unsigned long long)(xcc_id & 0xf) << 32 | (hw_id & 0xffffu);
+	}
 }
 
 static double g_wall_hz = 1e8;
 
+// Per-SIMD accounting (no assumption about how many waves share a SIMD): every wave records its s_memtime interval, its wall_clock64
+// interval and where it ran (HW_ID + XCC_ID).  For each SIMD that ran waves: window = latest end - earliest start of its waves (s_memtime
+// ticks of that XCD), issued = waves x instructions per wave, co-residency = sum of the waves' durations / window.  Reported: the MEDIAN
+// SIMD's ticks per wave-instruction, the median measured co-residency, and the shader clock the ticks ran at (ticks / wall ns).
+struct SimdStat { double tk_per_instr, ns_per_instr, resid, ghz; int simds; double waves_min, waves_med, waves_max; };
+
+static SimdStat per_simd(const std::vector<unsigned long long> &rec, size_t n_waves, double instr_per_wave)
+{
+	struct Acc { unsigned long long t_lo = ~0ull, t_hi = 0, w_lo = ~0ull, w_hi = 0; double dur = 0; int n = 0; };
+	std::map<unsigned long long, Acc> simd;
+	for (size_t w = 0; w < n_waves; ++w) {
+		const unsigned long long *r = &rec[w * 5];
+		const unsigned long long key = (r[4] >> 32) << 16 | (r[4] & 0xfff0ull); // XCD | SE, SH, CU, pipe, SIMD (the wave slot, bits 3:0, dropped)
+		Acc &a = simd[key];
+		a.t_lo = std::min(a.t_lo, r[0]), a.t_hi = std::max(a.t_hi, r[1]), a.w_lo = std::min(a.w_lo, r[2]), a.w_hi = std::max(a.w_hi, r[3]);
+		a.dur += (double)(r[1] - r[0]), ++a.n;
+	}
+	std::vector<double> tk, ns, resid, ghz, nw;
+	for (auto &kv : simd) {
+		const Acc &a = kv.second;
+		const double win = (double)(a.t_hi - a.t_lo), wall_ns = (double)(a.w_hi - a.w_lo) / g_wall_hz * 1e9;
+		tk.push_back(win / (a.n * instr_per_wave)), ns.push_back(wall_ns / (a.n * instr_per_wave)), resid.push_back(a.dur / win), ghz.push_back(win / wall_ns), nw.push_back(a.n);
+	}
+	auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+	SimdStat st;
+	st.tk_per_instr = med(tk), st.ns_per_instr = med(ns), st.resid = med(resid), st.ghz = med(ghz), st.simds = (int)simd.size();
+	std::sort(nw.begin(), nw.end());
+	st.waves_min = nw.front(), st.waves_med = nw[nw.size() / 2], st.waves_max = nw.back();
+	return st;
+}
+
 template <int KIND>
 static void run(int n_cu, uint32_t *d_out, unsigned long long *d_cyc, uint8_t *d_scratch, double per_iter, FILE *fp)
 {
-	const int wps[4] = { 1, 2, 4, 8 };
+	const int wps[5] = { 1, 2, 4, 8, 16 }; // blocks per CU launched; 16 = more than can be resident: the queued ("saturated") case
 	const bool slow = KIND == K_ST_BYTE || KIND == K_ST_DWORD || KIND == K_ST_DWORDX4 || KIND == K_LDS_U8 || KIND == K_LDS_B32 || KIND == K_MIX_DP || KIND == K_MIX_NOP || KIND == K_MIX_SALU || KIND == K_READLANE_DPP_PAIR;
 	const int iters = slow ? ITERS / 16 : ITERS;
 	fprintf(fp, "%-50s", kNames[KIND]);
-	for (int wi = 0; wi < 4; ++wi) {
+	for (int wi = 0; wi < 5; ++wi) {
 		const int blocks = n_cu * wps[wi];
-		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters / 8); // warm-up
-		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters);
-		CHECK(hipDeviceSynchronize());
-		std::vector<unsigned long long> c((size_t)blocks * 8);
-		CHECK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
-		std::vector<unsigned long long> mt(c.begin(), c.begin() + (size_t)blocks * 4), wl(c.begin() + (size_t)blocks * 4, c.end());
-		std::sort(mt.begin(), mt.end()); std::sort(wl.begin(), wl.end());
-		const double n_instr = (double)iters * per_iter * wps[wi]; // wave-instructions one SIMD issues while a wave runs
-		const double ns = (double)wl[wl.size() / 2] / g_wall_hz * 1e9 / n_instr, ticks = (double)mt[mt.size() / 2] / n_instr;
-		fprintf(fp, " | W=%d %6.3f ns %6.3f tk", wps[wi], ns, ticks);
-	}
-	{ // aggregate: 16 blocks per CU queued (more than can be resident), total wave-instructions / (SIMDs x wall time): no residency assumption
-		const int blocks = n_cu * 16;
 		hipEvent_t e0, e1;
 		CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters / 8);
+		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters / 8); // warm-up
 		CHECK(hipEventRecord(e0));
 		hipLaunchKernelGGL((bench_kernel<KIND>), dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_scratch, iters);
 		CHECK(hipEventRecord(e1));
 		CHECK(hipDeviceSynchronize());
 		float ms = 0;
 		CHECK(hipEventElapsedTime(&ms, e0, e1));
-		const double per_simd = (double)blocks * 4 / (n_cu * 4.0) * (double)iters * per_iter; // wave-instructions per SIMD
-		fprintf(fp, " | saturated %6.3f ns", ms * 1e6 / per_simd);
+		std::vector<unsigned long long> c((size_t)blocks * 4 * 5);
+		CHECK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
+		const SimdStat st = per_simd(c, (size_t)blocks * 4, (double)iters * per_iter);
+		const double ev_ns = ms * 1e6 / ((double)blocks * 4 / (n_cu * 4.0) * (double)iters * per_iter); // event wall time x SIMDs / total wave-instructions
+		fprintf(fp, " | B=%-2d %6.3f tk %6.3f ns (event %6.3f ns) resid %4.1f waves/SIMD %g/%g/%g @%.2f GHz", wps[wi], st.tk_per_instr, st.ns_per_instr, ev_ns, st.resid,
+		        st.waves_min, st.waves_med, st.waves_max, st.ghz);
+		CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
 	}
 	fprintf(fp, "\n");
 	fflush(fp);
@@ -228,11 +259,13 @@ int main()
 	printf("device %s, %d CUs, clockRate %d kHz; ITERS %d; blocks of 256 threads (one wave per SIMD), W blocks per CU\n", p.gcnArchName, n_cu, p.clockRate, ITERS);
 	uint32_t *d_out; unsigned long long *d_cyc; uint8_t *d_scratch;
 	const size_t n_waves = (size_t)n_cu * 4 * 16;
-	CHECK(hipMalloc(&d_out, n_waves * 64 * 4)); CHECK(hipMalloc(&d_cyc, n_waves * 16)); CHECK(hipMalloc(&d_scratch, n_waves * 65536));
+	CHECK(hipMalloc(&d_out, n_waves * 64 * 4)); CHECK(hipMalloc(&d_cyc, n_waves * 5 * 8)); CHECK(hipMalloc(&d_scratch, n_waves * 65536));
 	FILE *fp = stdout;
 	int wall_khz = 100000;
 	if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && wall_khz > 0) g_wall_hz = wall_khz * 1e3;
-	printf("wall_clock64 rate %d kHz; columns: W waves per SIMD -> ns and s_memtime ticks per wave-instruction per SIMD (median wave); saturated: 16 blocks per CU queued, total instructions / (SIMDs x event wall time)\n", wall_khz);
+	printf("wall_clock64 rate %d kHz.  Columns: B blocks of 256 threads launched per CU (B=16 exceeds what can be resident: queued) -> s_memtime ticks and wall ns per wave64 instruction PER SIMD\n"
+	       "(median SIMD; window of the SIMD's waves / instructions they issued), the same from the HIP-event time of the launch, measured co-residency (sum of wave durations / window), waves that\n"
+	       "ran on a SIMD (min/median/max over SIMDs, from HW_ID + XCC_ID), shader clock during the launch (s_memtime ticks per wall ns)\n", wall_khz);
 	for (int k = 0; k < 40; ++k) hipLaunchKernelGGL((bench_kernel<K_PK_ADD>), dim3(n_cu * 4), dim3(256), 0, 0, d_out, d_cyc, d_scratch, ITERS); // clocks up
 	CHECK(hipDeviceSynchronize());
 	run<K_ADD_U32>(n_cu, d_out, d_cyc, d_scratch, 16, fp);
