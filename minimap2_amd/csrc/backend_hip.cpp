@@ -39,7 +39,9 @@ struct Lane {
 	DevBuf<uint32_t> d_mz_cnt, d_sd_n, d_sd_off, d_sd_aoff, d_sd_qpos, d_sd_info, d_n_anchor, d_n_minipos, d_n_seedhit, d_tie;
 	DevBuf<int32_t> d_rep_len, d_f, d_p, d_t;
 	DevBuf<Anchor> d_anchors;
-	DevBuf<uint8_t> d_sort_tmp, d_tbytes;
+	DevBuf<uint8_t> d_tbytes;
+	DevBuf<uint32_t> d_sort_list;
+	PinBuf<uint32_t> h_sort_list;
 	PinBuf<Anchor> h_anchors, h_redo;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
@@ -116,7 +118,6 @@ public:
 	}
 	bool supports_rmq() const override { return getenv("MM2AMD_RMQ_ON_HOST") == nullptr; } // chain_rmq_kernel; MM2AMD_RMQ_ON_HOST=1: A/B against rmq_chain.cpp
 	void set_active_lanes(int n) override { active_lanes_ = std::max(1, std::min(n, n_lanes_)); }
-	long max_reads_per_call() const override { return 1L << (31 - rid_bits_); } // the anchor sort's composite key: read | strand | rid | rpos in 64 bits
 
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
 	{
@@ -260,16 +261,24 @@ public:
 		ln.d_skey_in.ensure(n_a + 1), ln.d_sval_in.ensure(n_a + 1), ln.d_skey_out.ensure(n_a + 1), ln.d_sval_out.ensure(n_a + 1), ln.d_tie.ensure(n);
 		B.sort_key_in = ln.d_skey_in.p, B.sort_val_in = ln.d_sval_in.p, B.sort_key_out = ln.d_skey_out.p, B.sort_val_out = ln.d_sval_out.p, B.tie_flag = ln.d_tie.p;
 		B.rid_bits = rid_bits_;
-		int read_bits = 1;
-		while ((1ull << read_bits) < n) ++read_bits;
-		const int end_bit = 33 + rid_bits_ + read_bits;
-		const size_t sort_tmp = anchor_sort_temp_bytes(n_a, end_bit);
-		ln.d_sort_tmp.ensure(sort_tmp + 16);
+		// the per-read anchor sort's launch classes (by anchors per read): the reads of a class are listed together
+		int n_class[kAnchorSortClasses] = { 0 }, class_first[kAnchorSortClasses + 1] = { 0 };
+		double a_class[kAnchorSortClasses] = { 0 };
+		for (size_t i = 0; i < n; ++i) if (h_na[i]) { const int c = anchor_sort_class(h_na[i], rid_bits_); ++n_class[c], a_class[c] += h_na[i]; }
+		for (int c = 0; c < kAnchorSortClasses; ++c) class_first[c + 1] = class_first[c] + n_class[c];
+		uint32_t *h_list = ln.h_sort_list.ensure(n + 1);
+		{
+			int fill[kAnchorSortClasses];
+			for (int c = 0; c < kAnchorSortClasses; ++c) fill[c] = class_first[c];
+			for (size_t i = 0; i < n; ++i) if (h_na[i]) h_list[fill[anchor_sort_class(h_na[i], rid_bits_)]++] = (uint32_t)i;
+		}
+		ln.d_sort_list.ensure(n + 1);
+		if (class_first[kAnchorSortClasses]) HIP_CHECK(hipMemcpyAsync(ln.d_sort_list.p, h_list, (size_t)class_first[kAnchorSortClasses] * 4, hipMemcpyHostToDevice, st));
 		B.a_off = ln.d_a_off.p, B.mp_off = ln.d_mp_off.p, B.anchors = ln.d_anchors.p, B.mini_pos = ln.d_minipos.p;
 		B.f = ln.d_f.p, B.p = ln.d_p.p, B.t = ln.d_t.p;
 		// 3. anchors: expand, sort, chain
 		kp.begin(st); launch_seed_expand(B, I_, P, st); kp.end(st, "seed_expand_kernel", 24.0 * n_a);
-		launch_anchor_sort(B, I_, P, n_a, end_bit, ln.d_sort_tmp.p, sort_tmp, st, &kp);
+		launch_anchor_sort(B, I_, P, ln.d_sort_list.p, n_class, a_class, st, &kp);
 		if (const char *dump = getenv("MM2AMD_SEED_DUMP")) { // diagnostics: every read's sorted anchors, as the reference's --print-seeds prints them (map.c:255-260)
 			std::vector<Anchor> all(n_a + 1);
 			HIP_CHECK(hipStreamSynchronize(st));

@@ -9,6 +9,18 @@
 #include <atomic>
 #include <chrono>
 
+// A kernel's dynamic LDS as an array `name` of T.  (MM2AMD_WAVE_EMU: tests/cpucheck/wave_emu builds the .hip sources for the host.)
+// MM2_LOCKSTEP(): a point where the code relies on a wavefront executing in lock step -- every lane's loads above it happen before any
+// lane's stores below it, because they are the same instructions.  Nothing on the hardware; the emulator, whose lanes run one after
+// the other between cross-lane operations, makes them meet here.
+#ifdef MM2AMD_WAVE_EMU
+#define MM2_DYN_LDS(T, name) T *const name = (T *)wave_emu::dyn_shared()
+#define MM2_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+#else
+#define MM2_DYN_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#define MM2_LOCKSTEP() ((void)0)
+#endif
+
 namespace mm2amd {
 
 struct HipError : std::runtime_error {

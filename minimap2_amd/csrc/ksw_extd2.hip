@@ -147,7 +147,7 @@ template <bool LDS_STATE, int MODE>
 __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 {
 	constexpr bool SINGLE = MODE == 1, SPLICE = MODE == 2;
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+	MM2_DYN_LDS(uint8_t, lds_raw);
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
 	const int slot = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
 	const size_t region = (ksw_lds_per_wave(L.ring, L.max_Q16) + 15) / 16 * 16;
@@ -353,12 +353,18 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 					const int qoff = qlen - 1 - r;
 					if (!(flag & KSW_GENERIC_SC)) {
 						const int total = ((en0 - st0) / 16 + 1) * 16;
-						for (int i = lane; i < total; i += 64) {
-							const int idx = st0 + i;
-							const int a = idx < T16 ? TG[idx & RM] : QR[idx - T16], b = QR[qoff + idx];
-							const int sc = (a == m - 1 || b == m - 1) ? sc_N : a == b ? sc_mch : sc_mis;
-							if (idx < T16) ((uint8_t *)&B[idx & RM])[2] = (uint8_t)sc;
-							else if (frontier < idx - T16 + RS) TG[(idx - T16) & RM] = (uint8_t)sc;
+						for (int i0 = 0; i0 < total; i0 += 64) {
+							const int i = i0 + lane, idx = st0 + i;
+							int sc = 0;
+							if (i < total) {
+								const int a = idx < T16 ? TG[idx & RM] : QR[idx - T16], b = QR[qoff + idx];
+								sc = (a == m - 1 || b == m - 1) ? sc_N : a == b ? sc_mch : sc_mis;
+							}
+							MM2_LOCKSTEP(); // the overshoot below writes into the target copy other lanes of this step have just read
+							if (i < total) {
+								if (idx < T16) ((uint8_t *)&B[idx & RM])[2] = (uint8_t)sc;
+								else if (frontier < idx - T16 + RS) TG[(idx - T16) & RM] = (uint8_t)sc;
+							}
 						}
 					} else {
 						for (int t = st0 + lane; t <= en0; t += 64)
@@ -371,14 +377,18 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 				const int n_chunk = (en - st + 64) >> 6;
 				for (int c = n_chunk - 1; c >= 0; --c) {
 					const int t = st + (c << 6) + lane;
+					const int tk = t & RM;
+					uint32_t a_cur = 0, b_cur = 0;
+					int xt1 = x1, vt1 = v1, x2t1 = x21;
 					if (t <= en) {
-						const int tk = t & RM;
-						const uint32_t a_cur = A[tk], b_cur = B[tk];
-						int xt1 = x1, vt1 = v1, x2t1 = x21;
+						a_cur = A[tk], b_cur = B[tk];
 						if (t > st) {
 							const uint32_t a_prev = A[(t - 1) & RM], b_prev = B[(t - 1) & RM];
 							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
 						}
+					}
+					MM2_LOCKSTEP(); // every lane of the chunk has read row r-1 (its own position and its left neighbour's) before any lane stores row r
+					if (t <= en) {
 						if (SINGLE) { // ksw2_extz2_sse.c:34-55 with the left/right variants at :186-204 / :213-231 (and :164-170 score-only)
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24);
 							int z = sx8(sx8(b_cur >> 16) + qe2s);

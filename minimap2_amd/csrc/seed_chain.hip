@@ -17,7 +17,6 @@
 #include "sdust_core.hpp"
 #include "sketch_dev.hpp"
 #include "kernel_prof.hpp"
-#include <hipcub/hipcub.hpp>
 
 namespace mm2amd {
 
@@ -134,7 +133,7 @@ __global__ void __launch_bounds__(64) sketch_kernel(SeedChainBuffers B, int w, i
 
 __global__ void __launch_bounds__(256) sketch_wave_kernel(SeedChainBuffers B, int w, int k)
 {
-	extern __shared__ __attribute__((aligned(16))) uint64_t ring[]; // per wave: bx[w][64] then by[w][64], lane-interleaved (conflict-free)
+	MM2_DYN_LDS(uint64_t, ring); // per wave: bx[w][64] then by[w][64], lane-interleaved (conflict-free)
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int r = blockIdx.x * 4 + wave;
 	if (r >= B.n_reads) return;
@@ -467,7 +466,6 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 	const int qlen = (int)(B.seq_off[r + 1] - B.seq_off[r]);
 	HIT_RULES_SETUP();
 	uint64_t *akey = B.sort_key_in + B.a_off[r], *aval = B.sort_val_in + B.a_off[r];
-	const uint64_t read_tag = (uint64_t)r << (33 + B.rid_bits); // composite sort key: read | strand | rid | rpos (see launch_anchor_sort)
 	uint64_t *mp = B.mini_pos + B.mp_off[r];
 	for (int i = lane; i < n_m0; i += 64) {
 		const uint32_t ao = sd_aoff[i];
@@ -495,7 +493,7 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 			if (info & SD_SEG1) p.y |= 1ULL << ref::SEED_SEG_SHIFT;
 			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
 			if (is_self) p.y |= ref::SEED_SELF;
-			akey[ao + w] = read_tag | (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL);
+			akey[ao + w] = (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL); // compact sort key: strand | rid | rpos (anchor_sort_kernel)
 			aval[ao + w] = p.y;
 			++w;
 		}
@@ -509,13 +507,18 @@ void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const Seed
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Anchor sort (map.c:202: radix_sort_128x by x, an UNSTABLE in-place sort whose tie order is observable)
+// Anchor sort (map.c:202: radix_sort_128x by x, an UNSTABLE in-place sort whose tie order is observable), one workgroup per read.
 //
-// All anchors of the sub-batch are sorted at once by a composite 64-bit key  read | strand | rid | rpos  -- within a read this
-// is the order of x = strand<<63 | rid<<32 | rpos -- with the device-wide radix sort.  Where a read has no two anchors with the
-// same x the sorted order is unique and therefore equal to the reference's.  Reads that do have equal x (the same reference
-// position hit from two query positions; ~0.1 % of ONT reads) are re-sorted from their original order by a permutation-exact
-// replay of the reference's algorithm (exact_rsort.hpp), run by one lane on an LDS-resident copy.
+// The anchors of a read are contiguous, so the read is the unit: its (x key, original index) pairs go into LDS -- one 64-bit word per
+// anchor, compact key (strand | rid | rpos: 33 + rid_bits bits) above a 13-bit index -- and are sorted there by a bitonic network
+// whose compare-exchanges all point the same way, so that positions past the end behave as +infinity and a read of n anchors costs
+// n log^2 n, not that of the next power of two.  One trip through LDS instead of seven radix passes over all anchors through HBM.
+// Where no two anchors of the read share x, the sorted order is unique and therefore the reference's.  Where they do (the same
+// reference position hit from two query positions: tandem repeats inside the read), the order of the equal anchors is whatever the
+// reference's in-place MSD radix sort (ksort.h:101-151) leaves, which depends on the whole array: the same workgroup then reloads the
+// read in its ORIGINAL order and replays that sort permutation-exactly (tie_exact_replay), restricted to the chain of buckets that
+// lead to duplicated keys, and rewrites the anchors that carry one.  Reads with more anchors than the LDS classes hold run the same
+// code on global scratch with a larger workgroup (whole contigs as queries; rare).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t key_to_x(uint64_t key, int rid_bits)
 {
@@ -523,82 +526,139 @@ __device__ __forceinline__ uint64_t key_to_x(uint64_t key, int rid_bits)
 	return (key >> (32 + rid_bits) & 1ULL) << 63 | low;
 }
 
-__global__ void __launch_bounds__(256) anchor_finalize_kernel(SeedChainBuffers B, uint64_t n_a)
-{
-	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_a; i += stride) {
-		const uint64_t key = B.sort_key_out[i];
-		Anchor a;
-		a.x = key_to_x(key, B.rid_bits), a.y = B.sort_val_out[i];
-		B.anchors[i] = a;
-		if (i > 0 && B.sort_key_out[i - 1] == key) B.tie_flag[key >> (33 + B.rid_bits)] = 1u;
-	}
-}
-
-constexpr int TIE_LDS_CAP = 8192;   // anchors of one read whose (key, index) pairs fit the LDS-resident replay
-constexpr int TIE_MAX_KEYS = 64;    // distinct tied keys tracked per read; more => every bucket is replayed
-constexpr int TIE_STACK = 2304;     // replay-all worst case: 255 siblings on each of 8 levels, plus one
+constexpr int AS_IDX_BITS = 13;                 // index bits of a packed element
+constexpr int AS_LDS_MAX = 7168;                // anchors of the largest LDS class: 56 KB of elements + 5 KB of tables stay below 64 KB per read
+constexpr int TIE_MAX_KEYS = 64;                // distinct duplicated keys tracked per read; more => every bucket is replayed
+constexpr int AS_STACK = (1 << AS_IDX_BITS) / 65 + 2; // the frames of a replay are disjoint ranges of more than 64 elements
 
 struct TieFrame { int32_t b, e, shift; };
 
-// Wave-cooperative, permutation-exact replay of radix_sort_128x (ksort.h:101-151) restricted to what can matter.
-//
-// K[0..n) / I[0..n) hold the keys in the ORIGINAL (pre-sort) order and their original indices.  The reference's MSD radix
-// sort partitions a range by one key byte with an in-place cycle-leader walk (sequential, replayed here by lane 0; the byte
-// histogram before it is computed by all lanes), then recurses into buckets of more than 64 elements and insertion-sorts
-// (stably) the smaller ones.  Sibling buckets are independent, and a bucket that contains no duplicated key ends in the unique
-// sorted order whatever its incoming order was -- which the device-wide sort already produced.  So only the chain of buckets
-// leading to duplicated keys is replayed; everything else is skipped.  Afterwards the elements with duplicated keys sit at
-// their final positions in K/I.
-__device__ void tie_exact_replay(uint64_t *K, uint32_t *I, int32_t n, const uint64_t *tied, int n_tied, bool replay_all,
-                                 uint32_t *cnt, uint32_t *head, uint32_t *start, TieFrame *stack, int stack_cap, int lane)
+// What the sort and the replay move: the x of an anchor and the anchor's index in the read's original order.
+struct PackedStore { // one LDS word per anchor: compact key << 13 | index
+	uint64_t *E;
+	int rid_bits;
+	typedef uint64_t Elem;
+	__device__ __forceinline__ uint64_t xk(Elem e) const { return key_to_x(e >> AS_IDX_BITS, rid_bits); }
+	__device__ __forceinline__ uint64_t xkey(int32_t i) const { return xk(E[i]); }
+	__device__ __forceinline__ uint32_t index(int32_t i) const { return (uint32_t)E[i] & ((1u << AS_IDX_BITS) - 1u); }
+	__device__ __forceinline__ void set(int32_t i, uint64_t composite, uint32_t idx) { E[i] = composite << AS_IDX_BITS | idx; }
+	__device__ __forceinline__ Elem get(int32_t i) const { return E[i]; }
+	__device__ __forceinline__ void put(int32_t i, Elem e) { E[i] = e; }
+	__device__ __forceinline__ void order(int32_t i, int32_t l) { const uint64_t a = E[i], b = E[l]; if (a > b) E[i] = b, E[l] = a; } // ascending (key, index)
+};
+struct SplitElem { uint64_t k; uint32_t i; };
+struct SplitStore { // key and index in arrays of their own: global scratch, or the chain-end sort's LDS arrays
+	uint64_t *K;
+	uint32_t *I;
+	int rid_bits; // < 0: set() takes x itself
+	typedef SplitElem Elem;
+	__device__ __forceinline__ uint64_t xk(const Elem &e) const { return e.k; }
+	__device__ __forceinline__ uint64_t xkey(int32_t i) const { return K[i]; }
+	__device__ __forceinline__ uint32_t index(int32_t i) const { return I[i]; }
+	__device__ __forceinline__ void set(int32_t i, uint64_t composite, uint32_t idx) { K[i] = rid_bits < 0 ? composite : key_to_x(composite, rid_bits), I[i] = idx; }
+	__device__ __forceinline__ Elem get(int32_t i) const { return Elem{K[i], I[i]}; }
+	__device__ __forceinline__ void put(int32_t i, const Elem &e) { K[i] = e.k, I[i] = e.i; }
+	__device__ __forceinline__ void order(int32_t i, int32_t l)
+	{
+		const uint64_t a = K[i], b = K[l];
+		const uint32_t ai = I[i], bi = I[l];
+		if (a > b || (a == b && ai > bi)) K[i] = b, K[l] = a, I[i] = bi, I[l] = ai;
+	}
+};
+
+// Bitonic sorting network over s[0..n), ascending, by the whole workgroup.  Every stage first mirrors each block of k elements onto
+// itself (i <-> block end - i) and then halves distances k/4 .. 1, and every compare-exchange puts the smaller element at the lower
+// position -- so virtual elements at positions >= n, being +infinity, never move and their pairs are simply skipped.
+template <class S>
+__device__ void bitonic_sort(S s, int32_t n)
 {
+	if (n < 2) return;
+	const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
+	int lp = 1;
+	while ((1 << lp) < n) ++lp;
+	for (int lk = 1; lk <= lp; ++lk) {
+		const int32_t k = 1 << lk, hk = k >> 1;
+		for (int32_t t = tid;; t += nt) { // mirror: pair t of block b = t / (k/2)
+			const int32_t blk = t >> (lk - 1), q = t & (hk - 1), i = blk * k + q, l = blk * k + k - 1 - q;
+			if (i >= n) break;
+			if (l < n) s.order(i, l);
+		}
+		__syncthreads();
+		for (int32_t j = k >> 2; j > 0; j >>= 1) {
+			for (int32_t t = tid;; t += nt) {
+				const int32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+				if (i >= n) break;
+				if (l < n) s.order(i, l);
+			}
+			__syncthreads();
+		}
+	}
+}
+
+// Workgroup-cooperative, permutation-exact replay of radix_sort_128x (ksort.h:101-151) restricted to what can matter.
+//
+// s[0..n) holds the keys in the ORIGINAL (pre-sort) order with their original indices.  The reference's MSD radix sort partitions a
+// range by one key byte with an in-place cycle-leader walk (sequential, replayed here by thread 0; the byte histogram before it is
+// computed by all threads), then recurses into buckets of more than 64 elements and insertion-sorts (stably) the smaller ones.
+// Sibling buckets are independent, and a bucket that contains no duplicated key ends in the unique sorted order whatever its
+// incoming order was -- which the network above already produced.  So only the chain of buckets leading to duplicated keys is
+// replayed (child_mask: the children of the current range that hold one); everything else is skipped.  Afterwards the elements with
+// duplicated keys sit at their final positions.  Control flow is uniform over the workgroup: every decision is read from shared
+// memory after a barrier.
+template <class S>
+__device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tied, bool replay_all, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask,
+                                 TieFrame *stack, int stack_cap)
+{
+	const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
 	auto insertion = [&](int32_t b, int32_t e) { // rs_insertsort (ksort.h:105-115): stable
 		for (int32_t i = b + 1; i < e; ++i)
-			if (K[i] < K[i - 1]) {
-				const uint64_t tk = K[i];
-				const uint32_t ti = I[i];
+			if (s.xkey(i) < s.xkey(i - 1)) {
+				const typename S::Elem te = s.get(i);
+				const uint64_t tk = s.xk(te);
 				int32_t j;
-				for (j = i; j > b && tk < K[j - 1]; --j) K[j] = K[j - 1], I[j] = I[j - 1];
-				K[j] = tk, I[j] = ti;
+				for (j = i; j > b && tk < s.xkey(j - 1); --j) s.put(j, s.get(j - 1));
+				s.put(j, te);
 			}
 	};
 	if (n <= 64) { // radix_sort top level (ksort.h:149)
-		if (lane == 0) insertion(0, n);
+		if (tid == 0) insertion(0, n);
 		__syncthreads();
 		return;
 	}
 	int sp = 0;
-	if (lane == 0) stack[0] = TieFrame{0, n, 56};
+	if (tid == 0) stack[0] = TieFrame{0, n, 56};
 	sp = 1;
 	__syncthreads();
 	while (sp > 0) {
 		const TieFrame fr = stack[--sp];
 		const int32_t len = fr.e - fr.b;
-		for (int k = lane; k < 256; k += 64) cnt[k] = 0;
+		for (int k = tid; k < 256; k += nt) cnt[k] = 0;
+		if (tid < 8) child_mask[tid] = 0;
 		__syncthreads();
-		for (int32_t i = fr.b + lane; i < fr.e; i += 64) atomicAdd(&cnt[K[i] >> fr.shift & 255], 1u);
+		for (int32_t i = fr.b + tid; i < fr.e; i += nt) atomicAdd(&cnt[s.xkey(i) >> fr.shift & 255], 1u);
+		if (!replay_all && fr.shift > 0) { // duplicated keys inside this range share its bits above the byte being partitioned
+			const uint64_t prefix = fr.shift >= 56 ? 0 : s.xkey(fr.b) >> (fr.shift + 8);
+			for (int t = tid; t < n_tied; t += nt)
+				if ((fr.shift >= 56 ? 0 : tied[t] >> (fr.shift + 8)) == prefix) { const uint32_t d = (uint32_t)(tied[t] >> fr.shift & 255); atomicOr(&child_mask[d >> 5], 1u << (d & 31)); }
+		}
 		__syncthreads();
-		if (lane == 0) {
+		if (tid == 0) {
 			uint32_t acc = 0, mx = 0;
 			for (int k = 0; k < 256; ++k) { start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; } // cnt becomes the bucket end
 			if ((int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
-				uint64_t *kb = K + fr.b;
-				uint32_t *ib = I + fr.b;
 				for (int k = 0; k < 256;) {
 					if (head[k] != cnt[k]) {
-						int l = (int)(kb[head[k]] >> fr.shift & 255);
+						int l = (int)(s.xkey(fr.b + (int32_t)head[k]) >> fr.shift & 255);
 						if (l != k) {
-							uint64_t tk = kb[head[k]], sk;
-							uint32_t ti = ib[head[k]], si;
+							typename S::Elem te = s.get(fr.b + (int32_t)head[k]), se;
 							do {
-								sk = tk, si = ti;
-								tk = kb[head[l]], ti = ib[head[l]];
-								kb[head[l]] = sk, ib[head[l]] = si;
+								se = te;
+								te = s.get(fr.b + (int32_t)head[l]);
+								s.put(fr.b + (int32_t)head[l], se);
 								++head[l];
-								l = (int)(tk >> fr.shift & 255);
+								l = (int)(s.xk(te) >> fr.shift & 255);
 							} while (l != k);
-							kb[head[k]] = tk, ib[head[k]] = ti;
+							s.put(fr.b + (int32_t)head[k], te);
 							++head[k];
 						} else ++head[k];
 					} else ++k;
@@ -608,70 +668,72 @@ __device__ void tie_exact_replay(uint64_t *K, uint32_t *I, int32_t n, const uint
 		__syncthreads();
 		if (fr.shift == 0) continue;
 		const int ns = fr.shift > 8 ? fr.shift - 8 : 0;
-		for (int k = 0; k < 256; ++k) { // children (uniform control flow across the wave)
+		for (int k = 0; k < 256; ++k) { // children (uniform control flow across the workgroup)
 			const int32_t cb = fr.b + (int32_t)start[k], ce = fr.b + (int32_t)cnt[k];
 			if (ce - cb <= 1) continue;
-			bool has = replay_all;
-			if (!has) {
-				const uint64_t prefix = K[cb] >> fr.shift;
-				bool mine = false;
-				for (int t = lane; t < n_tied; t += 64) mine |= (tied[t] >> fr.shift) == prefix;
-				has = __ballot(mine) != 0ull;
-			}
-			if (!has) continue;
+			if (!replay_all && !(child_mask[k >> 5] >> (k & 31) & 1u)) continue;
 			if (ce - cb > 64) {
-				if (sp < stack_cap) { if (lane == 0) stack[sp] = TieFrame{cb, ce, ns}; ++sp; } // cannot overflow: callers size the stack for n/65 frames per level
-			} else if (lane == 0) insertion(cb, ce);
+				if (sp < stack_cap) { if (tid == 0) stack[sp] = TieFrame{cb, ce, ns}; ++sp; } // cannot overflow: the frames are disjoint ranges of more than 64 elements
+			} else if (tid == 0) insertion(cb, ce);
 		}
 		__syncthreads();
 	}
 }
 
-__global__ void __launch_bounds__(64) anchor_tie_fix_kernel(SeedChainBuffers B)
+template <int THREADS, bool IN_LDS>
+__global__ void __launch_bounds__(THREADS) anchor_sort_kernel(SeedChainBuffers B, const uint32_t *list, int heap_sort)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t tie_lds[];
-	uint64_t *lK = (uint64_t *)tie_lds;
-	uint32_t *lI = (uint32_t *)(lK + TIE_LDS_CAP);
-	uint32_t *cnt = lI + TIE_LDS_CAP, *head = cnt + 256, *start = head + 256;
-	uint64_t *tied = (uint64_t *)(start + 256);
-	TieFrame *stack = (TieFrame *)(tied + TIE_MAX_KEYS);
+	MM2_DYN_LDS(uint64_t, as_lds); // IN_LDS: the read's packed elements
+	__shared__ uint32_t cnt[256], head[256], start[256], child_mask[8];
+	__shared__ uint64_t tied[TIE_MAX_KEYS];
+	__shared__ TieFrame lstack[AS_STACK];
 	__shared__ uint32_t n_tied_s;
-	const int lane = threadIdx.x;
-	for (int r = blockIdx.x; r < B.n_reads; r += gridDim.x) {
-		if (!B.tie_flag[r]) continue;
-		const uint64_t ao = B.a_off[r];
-		const int32_t n = (int32_t)(B.a_off[r + 1] - ao);
-		// 1. the duplicated keys, from the sorted output
-		if (lane == 0) n_tied_s = 0;
+	const int32_t tid = (int32_t)threadIdx.x;
+	const int r = (int)list[blockIdx.x];
+	const uint64_t ao = B.a_off[r];
+	const int32_t n = (int32_t)(B.a_off[r + 1] - ao);
+	const uint64_t *kin = B.sort_key_in + ao, *vin = B.sort_val_in + ao;
+	Anchor *out = B.anchors + ao;
+	if (n == 0) return;
+	auto run = [&](auto s, TieFrame *stack, int stack_cap) {
+		// 1. (key, original index) pairs, sorted by (key, index)
+		for (int32_t i = tid; i < n; i += THREADS) s.set(i, kin[i], (uint32_t)i);
+		if (tid == 0) n_tied_s = 0;
 		__syncthreads();
-		const uint64_t *so = B.sort_key_out + ao;
-		for (int32_t i = lane; i + 1 < n; i += 64)
-			if (so[i] == so[i + 1] && (i == 0 || so[i - 1] != so[i])) {
+		bitonic_sort(s, n);
+		// 2. the anchors in sorted order; which keys occur more than once
+		for (int32_t i = tid; i < n; i += THREADS) {
+			const uint64_t x = s.xkey(i);
+			Anchor a;
+			a.x = x, a.y = vin[s.index(i)];
+			out[i] = a;
+			if (i + 1 < n && s.xkey(i + 1) == x && (i == 0 || s.xkey(i - 1) != x)) {
 				const uint32_t slot = atomicAdd(&n_tied_s, 1u);
-				if (slot < TIE_MAX_KEYS) tied[slot] = key_to_x(so[i], B.rid_bits);
+				if (slot < (uint32_t)TIE_MAX_KEYS) tied[slot] = x;
 			}
-		__syncthreads();
-		const uint32_t n_tied_all = n_tied_s;
-		const bool replay_all = n_tied_all > TIE_MAX_KEYS;
-		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
-		// 2. keys in original order + their indices; large reads use the (no longer needed) sorted arrays as scratch
-		uint64_t *K = n <= TIE_LDS_CAP ? lK : B.sort_key_out + ao;
-		uint32_t *I = n <= TIE_LDS_CAP ? lI : (uint32_t *)(B.sort_val_out + ao);
-		__syncthreads();
-		for (int32_t i = lane; i < n; i += 64) K[i] = key_to_x(B.sort_key_in[ao + i], B.rid_bits), I[i] = (uint32_t)i;
-		__threadfence_block();
-		__syncthreads();
-		tie_exact_replay(K, I, n, tied, n_tied, replay_all, cnt, head, start, stack, TIE_STACK, lane);
-		__threadfence_block();
-		__syncthreads();
-		// 3. elements carrying a duplicated key are now at their final positions
-		for (int32_t i = lane; i < n; i += 64) {
-			const uint64_t x = K[i];
-			bool dup = replay_all;
-			for (int t = 0; t < n_tied && !dup; ++t) dup = tied[t] == x;
-			if (dup) { Anchor a; a.x = x, a.y = B.sort_val_in[ao + I[i]]; B.anchors[ao + i] = a; }
 		}
 		__syncthreads();
+		const uint32_t n_tied_all = n_tied_s;
+		if (n_tied_all == 0) return;
+		if (tid == 0) B.tie_flag[r] = 1u;
+		if (heap_sort) return; // MM_F_HEAP_SORT: anchor_heap_order_kernel lays down the heap merge's order instead
+		// 3. the reference's own permutation of the duplicated keys, from the original order
+		const bool replay_all = n_tied_all > (uint32_t)TIE_MAX_KEYS;
+		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
+		for (int32_t i = tid; i < n; i += THREADS) s.set(i, kin[i], (uint32_t)i);
+		__syncthreads();
+		tie_exact_replay(s, n, tied, n_tied, replay_all, cnt, head, start, child_mask, stack, stack_cap);
+		for (int32_t i = tid; i < n; i += THREADS) {
+			const uint64_t x = s.xkey(i);
+			bool dup = replay_all;
+			for (int t = 0; t < n_tied && !dup; ++t) dup = tied[t] == x;
+			if (dup) { Anchor a; a.x = x, a.y = vin[s.index(i)]; out[i] = a; }
+		}
+	};
+	if (IN_LDS) run(PackedStore{as_lds, B.rid_bits}, lstack, AS_STACK);
+	else { // the sorted-pair arrays are free until the backtrack: keys, then indices and the frame stack in the value array
+		uint32_t *I = (uint32_t *)(B.sort_val_out + ao);
+		run(SplitStore{B.sort_key_out + ao, I, B.rid_bits}, (TieFrame *)(I + n), (int)((size_t)n * 4 / sizeof(TieFrame)));
 	}
 }
 
@@ -717,44 +779,40 @@ __global__ void __launch_bounds__(64) anchor_heap_order_kernel(SeedChainBuffers 
 	}
 }
 
-size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit)
+// the launch classes: reads in `list` are grouped by class, class c holds n_class[c] of them (backend: anchor_sort_class)
+const int kAnchorSortCap[kAnchorSortClasses] = { 1024, 2048, 4096, AS_LDS_MAX, 0 }; // anchors per read an LDS class holds; the last class sorts on global scratch
+
+int anchor_sort_class(uint64_t n_anchors, int rid_bits)
 {
-	size_t bytes = 0;
-	HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-	                                             (int64_t)n_a, 0, end_bit, (hipStream_t)0));
-	return bytes;
+	if (33 + rid_bits + AS_IDX_BITS > 64) return kAnchorSortClasses - 1; // (more than 2^18 reference sequences: the key does not pack)
+	for (int c = 0; c + 1 < kAnchorSortClasses; ++c) if (n_anchors <= (uint64_t)kAnchorSortCap[c]) return c;
+	return kAnchorSortClasses - 1;
 }
 
-void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream,
+void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, const uint32_t *d_list, const int *n_class, const double *anchors_in_class, void *stream,
                         KernelProfiler *kp)
 {
 	hipStream_t s = (hipStream_t)stream;
 	KernelProfiler none;
 	if (!kp) kp = &none;
 	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
-	if (n_a == 0) return;
-	kp->begin(s);
-	HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint64_t *)B.sort_key_in, B.sort_key_out, (const uint64_t *)B.sort_val_in, B.sort_val_out,
-	                                             (int64_t)n_a, 0, end_bit, s));
-	kp->end(s, "anchor_radix_sort(rocprim)", 32.0 * n_a);
-	const unsigned grid = (unsigned)std::min<uint64_t>((n_a + 255) / 256, 65536);
-	kp->begin(s);
-	hipLaunchKernelGGL(anchor_finalize_kernel, dim3(grid), dim3(256), 0, s, B, n_a);
-	kp->end(s, "anchor_finalize_kernel", 32.0 * n_a);
-	if (P.flag & ref::F_HEAP_SORT) { // equal-x order of the heap merge instead of the radix sort's
+	static const char *kNames[kAnchorSortClasses] = { "anchor_sort_kernel[n1k]", "anchor_sort_kernel[n2k]", "anchor_sort_kernel[n4k]", "anchor_sort_kernel[n7k]", "anchor_sort_kernel[global]" };
+	const int heap = (P.flag & ref::F_HEAP_SORT) ? 1 : 0;
+	int first = 0;
+	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
+		if (n_class[c] == 0) continue;
+		kp->begin(s);
+		if (c + 1 < kAnchorSortClasses) hipLaunchKernelGGL((anchor_sort_kernel<64, true>), dim3(n_class[c]), dim3(64), (size_t)kAnchorSortCap[c] * 8, s, B, d_list + first, heap);
+		else hipLaunchKernelGGL((anchor_sort_kernel<1024, false>), dim3(n_class[c]), dim3(1024), 0, s, B, d_list + first, heap);
+		kp->end(s, kNames[c], 32.0 * anchors_in_class[c]); // 16 B per anchor in, 16 B out (nothing else leaves LDS)
+		HIP_CHECK(hipGetLastError());
+	}
+	if (heap) { // equal-x order of the heap merge instead of the radix sort's
 		kp->begin(s);
 		hipLaunchKernelGGL(anchor_heap_order_kernel, dim3(std::min((B.n_reads + 63) / 64, 4096)), dim3(64), 0, s, B, I, P);
 		kp->end(s, "anchor_heap_order_kernel", 0.0);
 		HIP_CHECK(hipGetLastError());
-		return;
 	}
-	const size_t lds = (size_t)12 * TIE_LDS_CAP + 3 * 256 * 4 + TIE_MAX_KEYS * 8 + TIE_STACK * sizeof(TieFrame) + 64;
-	static bool attr_set = false;
-	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_tie_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-	kp->begin(s);
-	hipLaunchKernelGGL(anchor_tie_fix_kernel, dim3(std::min(B.n_reads, 512)), dim3(64), lds, s, B);
-	kp->end(s, "anchor_tie_fix_kernel", 0.0);
-	HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -806,12 +864,24 @@ __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t
 // isolated hits.  Isolation is a purely local test, so each block of 64 anchors settles its isolated members in parallel and
 // only the members of real clusters (the true chains) go through the sequential rules, restarting from that known state at
 // every cluster head.
-template <bool PAIRS>
+// The look-back window lives in LDS: per wavefront a ring of the last CF_RING anchors -- x, y, chain score f, predecessor p and the
+// "already reached through a better predecessor" mark t of lchain.c:186 -- filled as the blocks of 64 anchors go by.  An anchor
+// older than the ring (a look-back of more than ~450 anchors: tandem repeats, very dense windows) is read from the global arrays
+// as before; where an index lives is a function of the index and the current block only, so marks and scores are never split
+// between the two.  RING = false keeps everything in global memory (A/B checks: MM2AMD_CHAIN_FILL_GLOBAL=1).
+constexpr int CF_RING = 512;
+
+template <bool PAIRS, bool RING>
 __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
 {
+	constexpr int RN = RING ? CF_RING : 1, RM = RN - 1;
+	__shared__ uint64_t s_x[4][RN], s_y[4][RN];
+	__shared__ int32_t s_f[4][RN], s_p[4][RN], s_t[4][RN];
 	const int wave = threadIdx.x >> 6, lane = lane_id();
 	const int r = blockIdx.x * 4 + wave;
 	if (r >= B.n_reads) return;
+	uint64_t *const rx = s_x[wave], *const ry = s_y[wave];
+	int32_t *const rf = s_f[wave], *const rp = s_p[wave], *const rt = s_t[wave];
 	const Anchor *a = B.anchors + B.a_off[r];
 	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
 	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
@@ -832,12 +902,22 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	bool last_iso = false;           // ... and whether it was isolated
 	for (int64_t blk = 0; blk < n; blk += 64) {
 		const int64_t g = blk + lane;
+		// indices >= ring_lo are in the ring while this block is worked on (the block itself has just entered it)
+		const int64_t ring_lo = RING ? (blk + 64 > CF_RING ? blk + 64 - CF_RING : 0) : INT64_MAX;
+		auto ax = [&](int64_t j) { return j >= ring_lo ? rx[j & RM] : a[j].x; };
+		auto ay = [&](int64_t j) { return j >= ring_lo ? ry[j & RM] : a[j].y; };
+		auto af = [&](int64_t j) { return j >= ring_lo ? rf[j & RM] : f[j]; };
+		auto ap = [&](int64_t j) { return j >= ring_lo ? rp[j & RM] : p[j]; };
 		uint64_t bx = 0, by = 0;
 		if (g < n) { const Anchor v = a[g]; bx = v.x, by = v.y; }
 		uint64_t px = __shfl_up(bx, 1, 64), py = __shfl_up(by, 1, 64); // a[g-1]
 		if (lane == 0) px = last_x, py = last_y;
 		const bool iso = g < n && (g == 0 || (bx >> 32 != px >> 32 || bx > px + (uint64_t)(int64_t)max_dist_x));
 		if (iso) f[g] = (int32_t)(by >> 32 & 0xff), p[g] = -1;
+		if (RING && g < n) {
+			rx[g & RM] = bx, ry[g & RM] = by, rt[g & RM] = -1;
+			if (iso) rf[g & RM] = (int32_t)(by >> 32 & 0xff), rp[g & RM] = -1;
+		}
 		__threadfence_block(); // cluster members read their head's f through memory
 		unsigned long long todo = __ballot(g < n && !iso);
 		const unsigned long long iso_mask = __ballot(iso);
@@ -855,7 +935,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 			while (st < i) {
 				const int64_t c = st + lane;
 				bool stop = true; // lanes past i stop the scan
-				if (c < i) { const uint64_t cx = a[c].x; stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)max_dist_x); }
+				if (c < i) { const uint64_t cx = ax(c); stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)max_dist_x); }
 				const unsigned long long m = __ballot(stop);
 				if (m) { st += __ffsll((long long)m) - 1; break; }
 				st += 64;
@@ -870,8 +950,8 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				const int64_t j = base - lane;
 				int32_t sc = INT32_MIN, pj = -1;
 				if (j >= st) {
-					sc = link_score<PAIRS>(ix, iy, a[j].x, a[j].y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
-					if (sc != INT32_MIN) sc += f[j], pj = p[j];
+					sc = link_score<PAIRS>(ix, iy, ax(j), ay(j), max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
+					if (sc != INT32_MIN) sc += af(j), pj = ap(j);
 				}
 				const bool has = sc != INT32_MIN;
 				// exclusive prefix maximum in processing order (lane 0 first)
@@ -882,9 +962,10 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				excl = excl > max_f ? excl : max_f;
 				const bool improve = has && sc > excl;
 				// marks left by predecessors examined earlier in this iteration (lchain.c:186)
-				if (has && pj >= 0) t[pj] = (int32_t)i;
+				if (has && pj >= 0) { if (pj >= ring_lo) rt[pj & RM] = (int32_t)i; else t[pj] = (int32_t)i; }
 				__threadfence_block();
-				const bool marked = has && !improve && t[j >= st ? j : st] == (int32_t)i;
+				const int64_t jm = j >= st ? j : st;
+				const bool marked = has && !improve && (jm >= ring_lo ? rt[jm & RM] : t[jm]) == (int32_t)i;
 				unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
 				int stop_lane = 64;
 				while (ev) { // the skip counter is inherently sequential; events are sparse
@@ -911,17 +992,20 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				long long best = INT64_MIN; // (f, j): larger f first, then larger j
 				for (int64_t base = i - 1; base >= st; base -= 64) {
 					const int64_t j = base - lane;
-					if (j >= st) { const long long key = (long long)f[j] << 32 | (long long)(uint32_t)j; best = key > best ? key : best; }
+					if (j >= st) { const long long key = (long long)af(j) << 32 | (long long)(uint32_t)j; best = key > best ? key : best; }
 				}
 				for (int o = 32; o > 0; o >>= 1) { const long long v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
 				max_ii = best == INT64_MIN ? -1 : (int64_t)(uint32_t)(best & 0xffffffffLL);
-				if (max_ii >= 0) { const Anchor m = a[max_ii]; mii_x = m.x, mii_y = m.y, mii_f = (int32_t)(best >> 32); }
+				if (max_ii >= 0) mii_x = ax(max_ii), mii_y = ay(max_ii), mii_f = (int32_t)(best >> 32);
 			}
 			if (max_ii >= 0 && max_ii < end_j) {
 				const int32_t tmp = link_score<PAIRS>(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
 				if (tmp != INT32_MIN && max_f < tmp + mii_f) max_f = tmp + mii_f, max_j = max_ii;
 			}
-			if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
+			if (lane == 0) {
+				f[i] = max_f, p[i] = (int32_t)max_j;
+				if (RING) rf[i & RM] = max_f, rp[i & RM] = (int32_t)max_j;
+			}
 			__threadfence_block();
 			if (max_ii < 0 || (ix - mii_x <= (uint64_t)(int64_t)max_dist_x && mii_f < max_f)) max_ii = i, mii_x = ix, mii_y = iy, mii_f = max_f;
 		}
@@ -934,8 +1018,16 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
-	if (B.unit_first) hipLaunchKernelGGL(chain_fill_kernel<true>, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
-	else hipLaunchKernelGGL(chain_fill_kernel<false>, dim3((B.n_reads + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, P);
+	static const bool in_global = getenv("MM2AMD_CHAIN_FILL_GLOBAL") != nullptr; // A/B checks: no LDS ring
+	const dim3 grid((B.n_reads + 3) / 4), block(256);
+	hipStream_t s = (hipStream_t)stream;
+	if (B.unit_first) {
+		if (in_global) hipLaunchKernelGGL((chain_fill_kernel<true, false>), grid, block, 0, s, B, P);
+		else hipLaunchKernelGGL((chain_fill_kernel<true, true>), grid, block, 0, s, B, P);
+	} else {
+		if (in_global) hipLaunchKernelGGL((chain_fill_kernel<false, false>), grid, block, 0, s, B, P);
+		else hipLaunchKernelGGL((chain_fill_kernel<false, true>), grid, block, 0, s, B, P);
+	}
 	HIP_CHECK(hipGetLastError());
 }
 
@@ -1145,16 +1237,16 @@ void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void 
 constexpr int BT_LDS_CAP = 1024; // chain ends (or chains) whose sort runs in LDS
 constexpr int BT_STACK = 320;
 
-__device__ void bt_sort(uint64_t *K, uint32_t *I, int32_t n, uint32_t *cnt, uint32_t *head, uint32_t *start, TieFrame *stack, int stack_cap, int lane)
+__device__ void bt_sort(uint64_t *K, uint32_t *I, int32_t n, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask, TieFrame *stack, int stack_cap)
 {
-	tie_exact_replay(K, I, n, nullptr, 0, true, cnt, head, start, stack, stack_cap, lane);
+	tie_exact_replay(SplitStore{K, I, -1}, n, nullptr, 0, true, cnt, head, start, child_mask, stack, stack_cap);
 }
 
 __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B, int min_cnt, int min_sc, int max_drop)
 {
 	__shared__ uint64_t lK[BT_LDS_CAP];
 	__shared__ uint32_t lI[BT_LDS_CAP];
-	__shared__ uint32_t cnt[256], head[256], start[256];
+	__shared__ uint32_t cnt[256], head[256], start[256], child_mask[8];
 	__shared__ TieFrame stack[BT_STACK];
 	__shared__ int32_t s_nu, s_nv;
 	__shared__ uint64_t s_aoff, s_uoff;
@@ -1191,7 +1283,7 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	// scratch region (v holds at most n 32-bit entries in a region of n 64-bit ones; u[] can need all n entries when min_cnt < 2)
 	TieFrame *big_stack = (TieFrame *)(B.sort_val_in + ao + ((size_t)n + 1) / 2);
 	const int big_cap = (int)(((size_t)n - ((size_t)n + 1) / 2) * 8 / sizeof(TieFrame));
-	bt_sort(K, I, n_z, cnt, head, start, n_z <= BT_LDS_CAP ? stack : big_stack, n_z <= BT_LDS_CAP ? BT_STACK : big_cap, lane); // radix_sort_128x(z, z + n_z), lchain.c:41
+	bt_sort(K, I, n_z, cnt, head, start, child_mask, n_z <= BT_LDS_CAP ? stack : big_stack, n_z <= BT_LDS_CAP ? BT_STACK : big_cap); // radix_sort_128x(z, z + n_z), lchain.c:41
 	__threadfence_block();
 	__syncthreads();
 	// ---- walk the ends best-first, claim anchors (lchain.c:57-72 with mg_chain_bk_end inlined) ----
@@ -1238,7 +1330,7 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	}
 	__threadfence_block();
 	__syncthreads();
-	bt_sort(K2, I2, n_u, cnt, head, start, n_u <= BT_LDS_CAP ? stack : big_stack, n_u <= BT_LDS_CAP ? BT_STACK : big_cap, lane); // radix_sort_128x(w, w + n_u), lchain.c:99
+	bt_sort(K2, I2, n_u, cnt, head, start, child_mask, n_u <= BT_LDS_CAP ? stack : big_stack, n_u <= BT_LDS_CAP ? BT_STACK : big_cap); // radix_sort_128x(w, w + n_u), lchain.c:99
 	__threadfence_block();
 	__syncthreads();
 	Anchor *oa = B.bt_out_a + s_aoff;

@@ -44,9 +44,10 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	const uint64_t *a_off;    // n_reads+1 anchor offsets
 	const uint64_t *mp_off;   // n_reads+1 mini_pos offsets
 	Anchor *anchors;
-	uint64_t *sort_key_in, *sort_val_in, *sort_key_out, *sort_val_out; // anchors as (composite key, y) pairs before / after the device sort
+	uint64_t *sort_key_in, *sort_val_in; // anchors as (compact key: strand | rid | rpos, y) pairs in seed order, before the per-read sort
+	uint64_t *sort_key_out, *sort_val_out; // per-read scratch of the same size: the sort of reads beyond the LDS classes, RMQ priorities, the backtrack's sorts
 	uint32_t *tie_flag;       // n_reads: set when a read has two anchors with equal x
-	int rid_bits;             // bits needed for a reference sequence id in the composite key
+	int rid_bits;             // bits needed for a reference sequence id in the compact sort key
 	uint64_t *mini_pos;
 	int32_t *f, *p, *t;       // chaining DP arrays, indexed like anchors
 	// chain backtrack results: dense outputs handed out by two atomic cursors ([0] anchors, [1] chains)
@@ -63,9 +64,12 @@ void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *st
 void launch_dust_filter(const SeedChainBuffers &B, void *stream); // regions in sd_n / sd_off / sd_aoff (see seed_chain.hip)
 void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
 void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
-size_t anchor_sort_temp_bytes(uint64_t n_a, int end_bit);
 class KernelProfiler;
-void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, uint64_t n_a, int end_bit, void *tmp, size_t tmp_bytes, void *stream,
+// the per-read anchor sort's launch classes (by anchors per read; the last one sorts on global scratch): `list` holds the reads grouped
+// by class, n_class[c] of them in class c, carrying anchors_in_class[c] anchors
+constexpr int kAnchorSortClasses = 5;
+int anchor_sort_class(uint64_t n_anchors, int rid_bits);
+void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, const uint32_t *d_list, const int *n_class, const double *anchors_in_class, void *stream,
                         KernelProfiler *kp);
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);

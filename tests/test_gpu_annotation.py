@@ -14,7 +14,7 @@ import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
-DROPIN = os.path.join(HERE, "_build", "dropin_gpu")
+DROPIN = os.path.join(HERE, "_build", "dropin_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_gpu")  # MM2AMD_EMU=1: tests/conftest.py
 
 
 def _run(cmd):

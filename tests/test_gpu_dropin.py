@@ -14,7 +14,7 @@ import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
-DROPIN = os.path.join(HERE, "_build", "dropin_gpu")
+DROPIN = os.path.join(HERE, "_build", "dropin_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_gpu")  # MM2AMD_EMU=1: tests/conftest.py
 
 
 def _run(cmd):
@@ -238,6 +238,6 @@ def test_three_step_pipeline_driver_identical(tmp_path):
     # tests/dropin/dropin_pipeline.c on the GPU library: parse / map / format of consecutive mini-batches overlap (kt_pipeline)
     ref, reads, _, _ = synth.make("ont", str(tmp_path), 4, 150, 53)
     want, _ = _run([REF_BIN, "-x", "map-ont", "-a", "-t", "8", ref, reads])
-    got, err = _run([os.path.join(HERE, "_build", "dropin_pipeline_gpu"), "-x", "map-ont", "-a", "-t", "8", "-K", "300k", ref, reads])
+    got, err = _run([os.path.join(HERE, "_build", "dropin_pipeline_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_pipeline_gpu"), "-x", "map-ont", "-a", "-t", "8", "-K", "300k", ref, reads])
     assert err.count("[M::worker_pipeline::") >= 3
     assert got == want

@@ -10,7 +10,7 @@ sys.path.insert(0, HERE)
 import test_option_fuzz as F  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-DROPIN = os.path.join(HERE, "_build", "dropin_gpu")
+DROPIN = os.path.join(HERE, "_build", "dropin_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_gpu")  # MM2AMD_EMU=1: tests/conftest.py
 N = int(os.environ.get("MM2AMD_FUZZ_SEEDS", "24"))
 
 inputs = F.inputs  # the module-scoped fixture
