@@ -3,14 +3,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--ref-mb 3000] [--reads 100000] [--scaling strong|weak]
 
-One "step" = one pass of the hot path (mm_gpu_map_staged: encode -> sketch -> seed -> sort -> chain -> extend -> hits)
-over one batch of --reads synthetic ONT-like reads, already resident in HBM when the clock starts.  The workload
-is BASELINE.json configs[1]: uniform-random reference of --ref-mb megabases in 24 contigs, reads ~N(10 kb, 1 kb) with 12 %
+One "step" = one mini-batch of --reads synthetic ONT-like reads through the reference's three pipeline steps (map.c:541-643) as this library
+replaces them: hand-over of the reads' host buffers (mm_gpu_batch_stage_queued: pinned-memory packing + H2D, run beside the mapping
+of the batch before), the hot path (mm_gpu_map_staged: encode -> sketch -> seed -> sort -> chain -> extend -> hits), the output stage
+(mm_gpu_format_batch_view: SAM text of the batch, run beside the mapping of the batch after).  ALL of it is inside the clock; `value` is
+whole-job throughput with the hand-over and the formatting in it.  config.resident_gbases_per_s is the mapping call alone on a batch that is
+already resident in HBM (what rounds 1-2 reported).  The workload is BASELINE.json configs[1]: uniform-random reference of --ref-mb megabases in 24 contigs, reads ~N(10 kb, 1 kb) with 12 %
 error (1/3 substitution, 1/3 insertion, 1/3 deletion), preset map-ont, CIGAR output.  N > 1 (one process per GPU under
 torch.distributed.run): every rank builds the same index replica; with --scaling strong (the default: BASELINE.json configs[2],
 "same workload sharded across 8 GPUs") all ranks generate the SAME batch and each maps its contiguous, base-balanced share
 (minimap2_amd/shard.py: split_by_bases); with --scaling weak every rank maps a batch of --reads of its own.  The packed hit
-records are gathered to rank 0 over RCCL inside the timed region.
+records are gathered to rank 0 over RCCL inside the timed region (pinned buffers), and every rank formats the SAM text of its own shard.
 
 Rank 0 prints ONE JSON line.  "roofline" is the dominant kernel's algorithmic bytes / its HIP-event time on the launch
 stream; "cpu_baseline" is the UNMODIFIED reference's mm_map on all host cores over a bounded sample of the same batch
@@ -203,10 +206,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+    emu = os.environ.get("MM2AMD_EMU") == "1"  # plumbing check of this script in a container without a GPU: tests/_build/libmm2amd_emu.so (tests/conftest.py), data generated on the CPU
     dev_id = local_rank % max(torch.cuda.device_count(), 1)
     os.environ.setdefault("MM2AMD_DEVICE", str(dev_id))
-    torch.cuda.set_device(dev_id)
-    dev = torch.device("cuda", dev_id)
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest
+        conftest.use_emulated_library()
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a_, **k_: None
+        torch.cuda.empty_cache = lambda: None
+    else:
+        torch.cuda.set_device(dev_id)
+        dev = torch.device("cuda", dev_id)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         if backend == "nccl":
@@ -267,72 +279,92 @@ def main():
 
     L = mm.lib()
     n_mapped = n_hits = 0
+    base = mm.Batch(named)  # the reader's product: mm_bseq1_t records over host buffers (built once; every step maps a rotation of it)
+    gbuf = shard.GatherBuffers() if (world > 1 or os.environ.get("MM2AMD_BENCH_FORCE_GATHER")) else None
+    step_done = []
 
-    def one_step(step):
+    def on_mapped(b, n_reg, reg, rep_len):  # output thread: the final hit gather to rank 0, then this rank formats its own shard
         nonlocal n_mapped, n_hits
-        k = (step * 997) % len(named)  # same pool of reads every step, rotated; nothing is cached between steps
-        al.stage(named[k:] + named[:k])
+        if gbuf is not None:
+            shard.gather_payloads(shard.pack_hits(L, n_reg, reg, gbuf), dst=0, device=comm_dev, bufs=gbuf)
+        nr = np.frombuffer(n_reg, dtype=np.int32, count=len(b.items))
+        n_mapped, n_hits = int((nr > 0).sum()), int(nr.sum())
+
+    def run_steps(steps):
+        """One pass of the three-step pipeline over len(steps) batches, ALL of it inside the clock: hand-over of the reads (pinned-memory
+        packing + H2D, beside the mapping of the batch before), mapping, hit gather (N > 1), SAM formatting (beside the mapping of the
+        batch after).  Same pool of reads every step, rotated; nothing is cached between steps."""
+        batches = [base.rotated((st * 997) % max(len(named), 1)) for st in steps]
+        del step_done[:]
         barrier()
         t = time.time()
-        n_reg, reg, _ = al.run(raw=True)
-        if world > 1 or os.environ.get("MM2AMD_BENCH_FORCE_GATHER"):  # final hit gather to the formatting rank
-            payload = shard.pack_hits(L, n_reg, reg).to(comm_dev)
-            shard.gather_payloads(payload, dst=0, device=comm_dev)
+        al.pipeline(batches, text=True, on_mapped=on_mapped, on_text=lambda b_, addr, ln: step_done.append((time.time(), ln)))
         barrier()
+        return time.time() - t
+
+    if a.warmup > 0:
+        dt = run_steps(range(a.warmup))
+        log("rank %d warmup (%d steps): %.3f s  stats=%s" % (rank, a.warmup, dt, {k: round(v, 3) for k, v in al.last_stats().items()}))
+    mm.profile_enable(True)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    total_t = run_steps(range(a.warmup, a.warmup + a.steps))
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    sam_bytes_per_step = step_done[-1][1] if step_done else 0
+    log("rank %d: %d steps in %.3f s (%.3f s per step; last batch's text %d bytes)  stats=%s" % (rank, a.steps, total_t, total_t / max(a.steps, 1), sam_bytes_per_step, {k: round(v, 3) for k, v in al.last_stats().items()}))
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
+    log("rank %d: host CPU time per step %.2f core-seconds (%d threads; hand-over, host stages of the mapping, hit gather, formatting)" % (rank, host_cpu_s, n_threads))
+    prof = mm.profile_get()
+    mm.profile_enable(False)
+
+    def one_step(step, staged_outside=True):
+        """one batch without the pipeline: hand-over, then the mapping alone inside the clock (staged_outside) or both"""
+        b = base.rotated((step * 997) % max(len(named), 1))
+        t = time.time()
+        al.stage(b)
+        if staged_outside:
+            barrier()
+            t = time.time()
+        n_reg, reg, _ = al.run(raw=True)
         dt = time.time() - t
-        n_mapped = sum(1 for i in range(len(n_reg)) if n_reg[i] > 0)
-        n_hits = sum(n_reg)
         al.free_raw(n_reg, reg)
         return dt
 
-    for s in range(a.warmup):
-        dt = one_step(s)
-        log("rank %d warmup %d: %.3f s  stats=%s" % (rank, s, dt, {k: round(v, 3) for k, v in al.last_stats().items()}))
-    mm.profile_enable(True)
-    times = []
-    import resource
-    ru0 = resource.getrusage(resource.RUSAGE_SELF)
-    for s in range(a.steps):
-        times.append(one_step(a.warmup + s))
-        log("rank %d step %d: %.3f s  stats=%s" % (rank, s, times[-1], {k: round(v, 3) for k, v in al.last_stats().items()}))
-    ru1 = resource.getrusage(resource.RUSAGE_SELF)
-    host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
-    log("rank %d: host CPU time per step %.2f core-seconds (%d threads)" % (rank, host_cpu_s, n_threads))
-    prof = mm.profile_get()
-    mm.profile_enable(False)
+    # side figures (rank 0, N = 1): the mapping call alone with the batch already resident (rounds 1-2's headline), and hand-over + mapping
+    # one after the other (no pipeline)
+    resident = pcie = None
+    if world == 1:
+        resident = min(one_step(a.warmup + a.steps + i) for i in range(2))
+        pcie = one_step(a.warmup + a.steps + 2, staged_outside=False)
     # un-overlapped kernel times: one more pass over the same batch with ONE lane (sub-batches one after the other, so no two
     # kernels of the path run at the same time and HIP-event spans are costs); feeds roofline.valu and roofline.unoverlapped_ms
     prof1 = None
-    if rank == 0:
+    t_one = None
+    if rank == 0 and world == 1:
         os.environ["MM2AMD_ACTIVE_LANES"] = "1"
         os.environ["MM2AMD_NO_SIDE_STREAM"] = "1"  # the lane-exact DP launches after the gap-fill kernel instead of beside it
         mm.profile_enable(True)
-        t_one = one_step(a.warmup + a.steps) if world == 1 else None
-        prof1 = mm.profile_get() if world == 1 else None
+        t_one = one_step(a.warmup + a.steps)
+        prof1 = mm.profile_get()
         mm.profile_enable(False)
         del os.environ["MM2AMD_ACTIVE_LANES"], os.environ["MM2AMD_NO_SIDE_STREAM"]
-    # the boundary hands over host buffers: one pass with the hand-over (pack + H2D of the reads) inside the clock
-    pcie = None
-    if world == 1:
-        t = time.time()
-        al.stage(named)
-        n_reg, reg, _ = al.run(raw=True)
-        pcie = time.time() - t
-        al.free_raw(n_reg, reg)
-    # host output stage, outside the timed region: SAM text of one batch's hits on the pool threads
     fmt = None
-    try:
-        al.stage(named)
-        n_reg, reg, rep = al.run(raw=True)
-        t = time.time()
-        text = al.format_raw(n_reg, reg, rep)
-        dt = time.time() - t
-        al.free_raw(n_reg, reg)
-        fmt = {"sam_bytes": len(text), "seconds": round(dt, 3), "GB_per_s": round(len(text) / dt / 1e9, 3), "threads": n_threads}
-        del text
-    except Exception as e:
-        fmt = {"error": str(e)}
-    total_t = sum(times)
+    if world == 1:  # the output stage on its own (it runs beside the mapping in the timed region)
+        try:
+            b = base
+            al.stage(b)
+            n_reg, reg, rep = al.run(raw=True)
+            out, out_len = C.c_void_p(), C.c_size_t()
+            best = 1e9
+            for _ in range(2):
+                t = time.time()
+                mm._check(L.mm_gpu_format_batch_view(b.n, b.seg_off, b.n_seg, b.arr, n_reg, reg, rep, C.byref(out), C.byref(out_len)))
+                best = min(best, time.time() - t)
+            al.free_raw(n_reg, reg)
+            fmt = {"sam_bytes": out_len.value, "seconds": round(best, 3), "GB_per_s": round(out_len.value / best / 1e9, 3), "threads": n_threads, "inside_the_clock": True}
+        except Exception as e:
+            fmt = {"error": str(e)}
+    cpu_all = [host_cpu_s]
     if world > 1:
         tt = torch.tensor([total_t], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -340,6 +372,9 @@ def main():
         bb = torch.tensor([batch_bases], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(bb, op=dist.ReduceOp.SUM)
         all_bases = float(bb.item())
+        cc = [torch.zeros(1, dtype=torch.float64, device=comm_dev) for _ in range(world)]
+        dist.all_gather(cc, torch.tensor([host_cpu_s], dtype=torch.float64, device=comm_dev))
+        cpu_all = [round(float(x.item()), 2) for x in cc]
     else:
         all_bases = float(batch_bases)
 
@@ -383,25 +418,38 @@ def main():
             vfam = next((f for f in ("ksw_stream_kernel", "ksw_gapfill_kernel") if any(family(k) == f for k in prof1)), fam)
             one = {k: v for k, v in prof1.items() if family(k) == vfam}
             ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
-            # issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU mix in the ISA priced with the SATURATED
-            # per-instruction costs of tools/valu_issue_bench.hip (profiles/r02_valu_issue_bench_v4.txt: packed VOP3P / VOP3 4.37 cycles per
-            # wave64 instruction and SIMD, DPP 4.2, the rest ~3.4 on average).  Streaming kernel: 50 packed + 6 DPP + 9 other = 65
-            # instructions, 274 cycles; strip kernel: 50 + 6 + 21 = 77 instructions, 316 cycles.  Lane utilisation = cells / (128 x executed
-            # register-set rows), counted by the MM2AMD_GF_COUNT build (profiles/r02_stream_lane_utilisation.txt; strip kernel: round-2 count).
-            n_packed, n_dpp, n_other, lane_util = (50, 6, 9, 0.865) if vfam == "ksw_stream_kernel" else (50, 6, 21, 0.727)
-            row_cycles = n_packed * 4.37 + n_dpp * 4.2 + n_other * 3.4
+            # Issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU instructions as counted in the ISA (hipcc -S,
+            # gfx950: streaming kernel 51 packed VOP3P + 6 DPP moves + 1 v_perm (VOP3) + 6 VOP2 = 64; strip kernel 50 + 6 + 21 others), priced
+            # with the per-SIMD issue-rate table profiles/r03_valu_issue_bench_v1.txt -- waves that shared a SIMD found through HW_ID, columns
+            # B=8 and B=16 agree: VOP3P / VOP3 / DPP 4.1 cycles per wave64 instruction, VOP2 2.2.  valu_busy is the hardware's own figure for
+            # the same thing: 4 x SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) of profiles/r03_pmc_sq_v1.json.  Lane utilisation =
+            # cells / (128 x executed register-set rows), counted by the MM2AMD_GF_COUNT build (profiles/r02_stream_lane_utilisation.txt).
+            if vfam == "ksw_stream_kernel":
+                n_slow, n_vop2, lane_util = 51 + 6 + 1, 6, 0.865
+            else:
+                n_slow, n_vop2, lane_util = 50 + 6 + 11, 10, 0.727
+            row_cycles = n_slow * 4.1 + n_vop2 * 2.2
             peak_cells = 1024 * 2.4e9 * 128 / row_cycles
-            nominal = 1024 * 2.4e9 * 128 / ((n_packed + n_dpp + n_other) * 2.0)
+            nominal = 1024 * 2.4e9 * 128 / ((n_slow + n_vop2) * 2.0)
             rate = cells1 / max(ms1 * 1e-3, 1e-12)
+            busy = None
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq_v1.json")))["kernels"]
+                act = sum(v["SQ_ACTIVE_INST_VALU"] for k, v in sq.items() if k.startswith(vfam))
+                gui = sum(v["GRBM_GUI_ACTIVE"] for k, v in sq.items() if k.startswith(vfam)) / 8.0
+                busy = round(4.0 * act / (1024.0 * gui), 4)
+            except Exception:
+                pass
             roof["valu"] = {"bound": "valu", "kernel": vfam, "cells_per_s": round(rate, 1), "issue_peak_cells_per_s": round(peak_cells, 1),
                             "frac": round(rate / peak_cells, 4), "lane_utilisation": lane_util, "frac_at_measured_lane_utilisation": round(rate / peak_cells / lane_util, 4),
+                            "valu_busy_sq_counters": busy,
                             "nominal_2cycle_peak_cells_per_s": round(nominal, 1), "frac_nominal": round(rate / nominal, 4),
                             "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
                             "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
-                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles (the hot loop's %d VALU instructions at their measured saturated issue costs, every lane useful); lane_utilisation = cells / (128 x executed register-set rows), counted by an instrumented build; nominal = the same instructions at the guide's 2 cycles per wave64 instruction; the launch also traces back and Z-drop-scans every job, which the peak does not price" % (round(row_cycles), n_packed + n_dpp + n_other)}
+                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles: the hot loop's %d VALU instructions per register-set row (ISA count) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) from profiles/r03_pmc_sq_v1.json (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction" % (round(row_cycles), n_slow + n_vop2)}
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
             roof["unoverlapped_gcells_per_s"] = {k: round(v["units"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["units"] > 0}  # DP kernels: cells of the launch class / its time
-            roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1)
+            roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1) if t_one else None
             try:  # index probes per second of seed_collect_kernel (one mm_idx_get per query minimizer; the launch accounts 36 B per minimizer at the expected density 2 / (w + 1))
                 sc1 = prof1.get("seed_collect_kernel")
                 if sc1 and sc1["ms"] > 0:
@@ -467,8 +515,12 @@ def main():
            "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
            "config": {"workload": "%s: %d synthetic %s %s (%g%% error) vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, ("read pairs, " + rl) if pairs else ("~" + rl), "per GPU" if (world > 1 and not strong) else "per step", err * 100, total // 1000000),
                       "reads_per_step": a.reads * (world if (world > 1 and not strong) else 1), "reads_this_rank": len(reads), "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads, "host_cpu_s_per_step": round(host_cpu_s, 2),
-                      "parallelism": "replicated index, %s, RCCL hit gather" % ("one batch sharded %d-way by bases" % world if strong else "%d independent batches" % world) if world > 1 else "1 GPU",
-                      "pcie_inclusive_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
+                      "parallelism": "replicated index, %s, RCCL hit gather to rank 0, every rank formats its shard" % ("one batch sharded %d-way by bases" % world if strong else "%d independent batches" % world) if world > 1 else "1 GPU",
+                      "clock": "pipeline of hand-over | mapping | SAM formatting over the timed steps, all three inside the clock (map.c:541-643)",
+                      "host_cpu_s_per_step_per_rank": cpu_all,
+                      "sam_bytes_per_step_this_rank": sam_bytes_per_step,
+                      "resident_gbases_per_s": round(batch_bases / resident / 1e9, 5) if resident else None,
+                      "handover_then_map_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},
            "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
     print(json.dumps(out), flush=True)

@@ -156,6 +156,12 @@ void mm_gpu_map_frag(const mm2amd_idx_t *mi, int n_segs, const int *qlens, const
  * seg_off / n_seg the batch was staged with, describe the result arrays; seq must stay valid in between. */
 int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq);
 int mm_gpu_map_staged(int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
+/* The pipeline form of the hand-over (kt_pipeline, map.c:541-577: step 0 of batch k+1 runs beside step 1 of batch k): the library keeps two
+ * resident batches, so this call may run on another thread WHILE mm_gpu_map_staged maps the previous batch -- pinned-memory packing and H2D
+ * then cost no mapping time.  It waits (instead of replacing, as mm_gpu_batch_stage does) while an earlier staged batch has not been taken
+ * over by a mapping call yet: every staged batch is mapped exactly once, in staging order.  seq must stay valid until its batch is mapped. */
+int mm_gpu_batch_stage_queued(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq);
+void mm_gpu_batch_discard(void);                 /* drop a staged batch that will not be mapped (a pipeline shutting down) */
 
 /* Host output stage: replaces the record-writing loop of the reference's pipeline step 2
  * (map.c:585-623: mm_write_sam3, format.c:522, or mm_write_paf4, format.c:425, per hit, then mm_err_puts) for one mini-batch.
@@ -167,6 +173,12 @@ int mm_gpu_map_staged(int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap
  * options given to mm_gpu_init. */
 int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq, const int *n_reg, void *const *reg,
                         const int *rep_len, char **out, size_t *out_len);
+/* The same text in a buffer the library owns and reuses: *out stays valid until the next mm_gpu_format_batch_view call (or mm_gpu_destroy);
+ * the caller writes it out (fwrite / write) and does not free it.  For pipeline step 2, which one thread runs at a time: a gigabyte of
+ * records per mini-batch is then formatted into memory that is already mapped, instead of into a fresh block whose page faults cost more
+ * than the formatting. */
+int mm_gpu_format_batch_view(int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq, const int *n_reg, void *const *reg,
+                             const int *rep_len, const char **out, size_t *out_len);
 
 /* free() every reg[i][j].p and reg[i] (what the reference's step 2 does, map.c:629-631); for non-C callers. */
 void mm2amd_free_regs(int n_frag, int *n_reg, MM2AMD_REG_PP reg);

@@ -93,6 +93,8 @@ def _bind(L):
     L.mm_gpu_map_batch.argtypes = [C.c_int, ip, ip, vp, ip, C.POINTER(vp), ip, ip]
     L.mm_gpu_batch_stage.argtypes = [C.c_int, ip, ip, vp]
     L.mm_gpu_map_staged.argtypes = [ip, C.POINTER(vp), ip, ip]
+    L.mm_gpu_batch_stage_queued.argtypes = [C.c_int, ip, ip, vp]
+    L.mm_gpu_batch_discard.restype = None
     L.mm2amd_free_regs.argtypes = [C.c_int, ip, C.POINTER(vp)]
     L.mm2amd_free_regs.restype = None
     L.mm2amd_last_stats.argtypes = [C.POINTER(C.c_double), C.c_int]
@@ -130,6 +132,7 @@ def _bind(L):
         L.mm2amd_idxopt_init.argtypes = [vp]
         L.mm2amd_mapopt_init.argtypes = [vp]
         L.mm_gpu_format_batch.argtypes = [C.c_int, ip, ip, vp, ip, C.POINTER(vp), ip, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.mm_gpu_format_batch_view.argtypes = [C.c_int, ip, ip, vp, ip, C.POINTER(vp), ip, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.mm2amd_profile_enable.argtypes = [C.c_int]
         L.mm2amd_profile_enable.restype = None
         L.mm2amd_profile_get.argtypes = [C.POINTER(KernelStat), C.c_int]
@@ -239,6 +242,52 @@ def _regs_to_alignments(n, regs, names, lens):
     return out
 
 
+class Batch(object):
+    """A mini-batch of reads as the reference's reader hands it to the mapping step: an array of mm_bseq1_t records over host buffers
+    (bseq.h:14-17) plus the fragment table (seg_off, n_seg; map.c:560-575).  reads: list of (name, sequence), of sequences, or of
+    (name, sequence1, sequence2) for read pairs.  Building one is the reader's work, not part of the hand-over."""
+
+    def __init__(self, reads=None):
+        self.n = 0
+        self.items, self.arr, self.seg_off, self.n_seg = [], None, None, None
+        if reads is None:
+            return
+        self.n = len(reads)
+        seg_off, n_seg = [], []
+        for i, r in enumerate(reads):
+            r = r if isinstance(r, tuple) else ("read%d" % i, r)
+            nb = r[0].encode() if isinstance(r[0], str) else r[0]
+            seg_off.append(len(self.items)), n_seg.append(len(r) - 1)
+            for q in r[1:]:
+                self.items.append((nb, q.encode() if isinstance(q, str) else bytes(q)))
+        self.arr = (Bseq1 * max(1, len(self.items)))()
+        for k, (nb, sb) in enumerate(self.items):
+            self.arr[k].l_seq, self.arr[k].rid, self.arr[k].name, self.arr[k].seq = len(sb), k, nb, sb
+        self.seg_off, self.n_seg = (C.c_int * max(1, self.n))(*seg_off), (C.c_int * max(1, self.n))(*n_seg)
+        self.bases = sum(len(sb) for _, sb in self.items)
+
+    def rotated(self, k):
+        """the same reads starting at fragment k (fragments k.., then 0..k-1): new record and fragment tables over the SAME sequence
+        buffers, made with two memmoves -- what a reader producing that order would have handed over"""
+        if self.n == 0 or k % self.n == 0:
+            return self
+        k %= self.n
+        b = Batch()
+        b.n, b.items, b.bases = self.n, self.items, self.bases  # (items keeps the byte strings alive)
+        m = len(self.items)
+        first = self.seg_off[k]  # records of fragments k.. start here
+        b.arr = (Bseq1 * max(1, m))()
+        sz = C.sizeof(Bseq1)
+        C.memmove(b.arr, C.byref(self.arr, first * sz), (m - first) * sz)
+        C.memmove(C.byref(b.arr, (m - first) * sz), self.arr, first * sz)
+        import numpy as np
+        ns = np.frombuffer(self.n_seg, dtype=np.int32, count=self.n)
+        ns = np.concatenate([ns[k:], ns[:k]])
+        so = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int32)
+        b.n_seg, b.seg_off = (C.c_int * self.n).from_buffer_copy(ns.tobytes()), (C.c_int * self.n).from_buffer_copy(so.tobytes())
+        return b
+
+
 class Aligner(object):
     """Index built on the GPU from in-memory sequences + batched mapping; mirrors mappy.Aligner(seq=..., preset=...).
 
@@ -306,22 +355,87 @@ class Aligner(object):
     # -- batch interface: stage() + run() == map_batch() ------------------------------------------------
     def stage(self, reads):
         """reads: list of (name, sequence), of sequences (bytes/str), or of (name, sequence1, sequence2) for read pairs (mapped as
-        two-segment fragments, mm_map_frag with n_segs == 2).  Copies them to the GPU."""
+        two-segment fragments, mm_map_frag with n_segs == 2), or a Batch.  Copies them to the GPU."""
         self._active()
-        n = len(reads)
-        items, seg_off, n_seg = [], [], []
-        for i, r in enumerate(reads):
-            r = r if isinstance(r, tuple) else ("read%d" % i, r)
-            nb = r[0].encode() if isinstance(r[0], str) else r[0]
-            seg_off.append(len(items)), n_seg.append(len(r) - 1)
-            for s in r[1:]:
-                items.append((nb, s.encode() if isinstance(s, str) else bytes(s)))
-        arr = (Bseq1 * max(1, len(items)))()
-        for k, (nb, sb) in enumerate(items):
-            arr[k].l_seq, arr[k].rid, arr[k].name, arr[k].seq = len(sb), k, nb, sb
-        seg_off_a, n_seg_a = (C.c_int * max(1, n))(*seg_off), (C.c_int * max(1, n))(*n_seg)
-        _check(lib().mm_gpu_batch_stage(n, seg_off_a, n_seg_a, arr))
-        self._staged = (n, arr, items, seg_off_a, n_seg_a)
+        b = reads if isinstance(reads, Batch) else Batch(reads)
+        _check(lib().mm_gpu_batch_stage(b.n, b.seg_off, b.n_seg, b.arr))
+        self._staged = (b.n, b.arr, b.items, b.seg_off, b.n_seg)
+
+    def pipeline(self, batches, text=True, on_mapped=None, on_text=None):
+        """The reference's three-step pipeline (map.c:541-643) over an iterable of Batch objects, every step on a thread of its own so
+        that the steps of successive batches overlap: hand-over (mm_gpu_batch_stage_queued: pack + H2D beside the mapping of the batch
+        before), mapping (mm_gpu_map_staged), output stage (mm_gpu_format_batch_view: SAM / PAF text of the batch in a reused buffer).
+        on_mapped(batch, n_reg, reg, rep_len) runs on the output thread before formatting (e.g. the multi-GPU hit gather);
+        on_text(batch, address, length) receives the text (valid until the next batch's).  Hit records are freed after on_text.
+        Returns the number of text bytes produced."""
+        import queue
+        import threading
+        self._active()
+        L = lib()
+        q_staged, q_mapped = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+        errors, total = [], [0]
+
+        def stager():
+            try:
+                for b in batches:
+                    if errors:
+                        break
+                    _check(L.mm_gpu_batch_stage_queued(b.n, b.seg_off, b.n_seg, b.arr))
+                    q_staged.put(b)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+            q_staged.put(None)
+
+        def mapper():
+            try:
+                while True:
+                    b = q_staged.get()
+                    if b is None:
+                        break
+                    m = max(1, len(b.items))
+                    n_reg, reg, rep_len, frag_gap = (C.c_int * m)(), (C.c_void_p * m)(), (C.c_int * m)(), (C.c_int * m)()
+                    _check(L.mm_gpu_map_staged(n_reg, reg, rep_len, frag_gap))
+                    q_mapped.put((b, n_reg, reg, rep_len))
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                while True:  # let the stager finish: its staged batches are dropped
+                    L.mm_gpu_batch_discard()
+                    try:
+                        if q_staged.get(timeout=0.05) is None:
+                            break
+                    except queue.Empty:
+                        pass
+            q_mapped.put(None)
+
+        def output():
+            while True:
+                it = q_mapped.get()
+                if it is None:
+                    break
+                b, n_reg, reg, rep_len = it
+                try:
+                    if not errors:
+                        if on_mapped:
+                            on_mapped(b, n_reg, reg, rep_len)
+                        if text:
+                            out, out_len = C.c_void_p(), C.c_size_t()
+                            _check(L.mm_gpu_format_batch_view(b.n, b.seg_off, b.n_seg, b.arr, n_reg, reg, rep_len, C.byref(out), C.byref(out_len)))
+                            total[0] += out_len.value
+                            if on_text:
+                                on_text(b, out.value, out_len.value)
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+                L.mm2amd_free_regs(len(n_reg), n_reg, reg)
+
+        th = [threading.Thread(target=f) for f in (stager, mapper, output)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        self._staged = None
+        if errors:
+            raise errors[0]
+        return total[0]
 
     def run(self, raw=False):
         """Maps the staged batch.  Returns one list of alignments per read, or a pair of lists for a read pair.  raw=True returns

@@ -41,7 +41,12 @@ public:
 	virtual ~Backend() {}
 	// Make the batch's sequences resident; the nt4 forward|reverse-complement pool places read i at
 	// qpool_off[i] (2*len bytes).  Must be called before seed_chain()/ksw() of that batch.
+	// begin_batch() prepares the NEXT batch; activate_batch() makes it the one seed_chain()/ksw() work on.  A backend that says
+	// stages_beside_mapping() keeps two resident sets, and begin_batch() of batch k+1 may then run (on another thread) while batch k is
+	// being mapped -- the hand-over costs no mapping time (pipeline step 0 beside step 1, map.c:541-577).
 	virtual void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) = 0;
+	virtual void activate_batch() {}
+	virtual bool stages_beside_mapping() const { return false; }
 	// sketch -> seed lookup -> anchor sort -> chaining DP -> chains, for reads [lo, hi) of the batch (out[i] is read lo+i)
 	// `lane` selects one of n_lanes() independent sets of work buffers (one host thread per lane at a time); host-side parts use
 	// up to n_threads pool threads.

@@ -88,7 +88,7 @@ public:
 		}
 	}
 
-	~HipBackend() override { (void)hipSetDevice(dev_); }
+	~HipBackend() override { (void)hipSetDevice(dev_); if (stage_stream_) (void)hipStreamDestroy(stage_stream_); }
 	int n_lanes() const override { return n_lanes_; }
 	void enable_name_rules() override
 	{
@@ -122,6 +122,19 @@ public:
 	void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) override
 	{
 		HIP_CHECK(hipSetDevice(dev_)); // HIP's current device is per thread, and the mapper drives every lane from a thread of its own
+		Resident &R = res_[1 - cur_]; // the set that is not being mapped
+		if (!stage_stream_) HIP_CHECK(hipStreamCreateWithFlags(&stage_stream_, hipStreamNonBlocking));
+		hipStream_t stream_ = stage_stream_;
+		std::vector<uint64_t> &seq_off_ = R.seq_off, &unit_off_ = R.unit_off;
+		std::vector<int32_t> &unit_first_ = R.unit_first, &name_key_ = R.name_key;
+		bool &has_pairs_ = R.has_pairs, &have_read_names_ = R.have_read_names;
+		size_t &n_units_ = R.n_units;
+		PinBuf<char> &h_ascii_ = R.h_ascii;
+		DevBuf<char> &d_ascii_ = R.d_ascii;
+		DevBuf<uint8_t> &d_qpool_ = R.d_qpool;
+		DevBuf<uint64_t> &d_seq_off_ = R.d_seq_off, &d_unit_off_ = R.d_unit_off;
+		DevBuf<int32_t> &d_unit_first_ = R.d_unit_first, &d_name_key_ = R.d_name_key;
+		std::vector<const char *> &read_names_ = R.read_names;
 		const size_t n = reads.size();
 		// fragment-level offsets (what seeding and chaining see: a pair is one query, the concatenation of its two reads) ...
 		seq_off_.resize(n + 1);
@@ -179,6 +192,8 @@ public:
 		}
 		HIP_CHECK(hipStreamSynchronize(stream_)); // the batch is resident; everything after this is the hot path
 	}
+	void activate_batch() override { cur_ = 1 - cur_; }
+	bool stages_beside_mapping() const override { return true; }
 
 	void seed_chain(const SeedChainParams &P, long lo, long hi, int lane_id, int n_threads, std::vector<ReadChains> &out) override
 	{
@@ -186,6 +201,16 @@ public:
 		Lane &ln = *lanes_.at(lane_id);
 		hipStream_t st = ln.stream;
 		SeedChainBuffers &B = ln.B;
+		const Resident &R = res_[cur_];
+		const std::vector<uint64_t> &seq_off_ = R.seq_off, &unit_off_ = R.unit_off;
+		const std::vector<int32_t> &unit_first_ = R.unit_first;
+		const bool has_pairs_ = R.has_pairs, have_read_names_ = R.have_read_names;
+		const DevBuf<char> &d_ascii_ = R.d_ascii;
+		const DevBuf<uint8_t> &d_qpool_ = R.d_qpool;
+		const DevBuf<uint64_t> &d_seq_off_ = R.d_seq_off, &d_unit_off_ = R.d_unit_off;
+		const DevBuf<int32_t> &d_unit_first_ = R.d_unit_first, &d_name_key_ = R.d_name_key;
+		const PinBuf<char> &h_ascii_ = R.h_ascii;
+		const std::vector<const char *> &read_names_ = R.read_names;
 		const size_t n = (size_t)(hi - lo);
 		out.clear();
 		out.resize(n);
@@ -391,7 +416,7 @@ public:
 			HIP_CHECK(hipMemcpyAsync(ln.d_tbytes.p, sc.tbytes, sc.n_tbytes, hipMemcpyHostToDevice, ln.stream));
 			d_tbytes = ln.d_tbytes.p;
 		}
-		ln.ksw.run(jobs, d_qpool_.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
+		ln.ksw.run(jobs, res_[cur_].d_qpool.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id, replica_).collect();
 	}
 
@@ -403,28 +428,37 @@ private:
 	DeviceIndexTables own_;
 	DeviceIndexTables *T_ = nullptr;
 	std::vector<std::unique_ptr<Lane>> lanes_;
-	// the resident batch (shared by all lanes, read-only during run)
-	DevBuf<char> d_ascii_;
-	DevBuf<uint8_t> d_qpool_;
-	DevBuf<uint64_t> d_seq_off_;
-	// pairs: unit = one read of a pair (or a single read); see begin_batch
-	bool has_pairs_ = false;
-	size_t n_units_ = 0;
-	std::vector<uint64_t> unit_off_;
-	std::vector<int32_t> unit_first_;
-	DevBuf<uint64_t> d_unit_off_;
-	DevBuf<int32_t> d_unit_first_;
+	// The resident batch (shared by all lanes, read-only during run).  Two sets: begin_batch() fills the one that is NOT being mapped, so the
+	// hand-over of batch k+1 (pack into pinned memory, H2D) runs beside the mapping of batch k; activate_batch() swaps them.
+	struct Resident {
+		DevBuf<char> d_ascii;
+		DevBuf<uint8_t> d_qpool;
+		DevBuf<uint64_t> d_seq_off;
+		PinBuf<char> h_ascii;
+		std::vector<uint64_t> seq_off;
+		// pairs: unit = one read of a pair (or a single read); see begin_batch
+		bool has_pairs = false;
+		size_t n_units = 0;
+		std::vector<uint64_t> unit_off;
+		std::vector<int32_t> unit_first;
+		DevBuf<uint64_t> d_unit_off;
+		DevBuf<int32_t> d_unit_first;
+		// all-vs-all name rules: two ranks per read (see skip_hit in seed_chain.hip)
+		bool have_read_names = false;
+		std::vector<int32_t> name_key;
+		DevBuf<int32_t> d_name_key;
+		std::vector<const char *> read_names; // MM2AMD_SEED_DUMP only
+	};
+	Resident res_[2];
+	int cur_ = 0;
+	hipStream_t stage_stream_ = nullptr; // the hand-over's copies (the device's shared stream serves set-up only)
 	// all-vs-all name rules
-	bool name_rules_ = false, have_read_names_ = false;
+	bool name_rules_ = false;
 	const std::vector<std::string> *fi_names_ = nullptr;
 	const std::vector<uint32_t> *fi_seq_len_ = nullptr;
 	std::vector<std::string> sorted_names_;
-	std::vector<int32_t> name_key_;
-	std::vector<const char *> read_names_; // MM2AMD_SEED_DUMP only
-	DevBuf<int32_t> d_name_rank_, d_name_key_;
+	DevBuf<int32_t> d_name_rank_;
 	DevBuf<uint32_t> d_ref_len_;
-	PinBuf<char> h_ascii_;
-	std::vector<uint64_t> seq_off_;
 };
 
 } // namespace

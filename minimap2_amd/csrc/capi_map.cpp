@@ -1,6 +1,7 @@
 // Drop-in boundary: the entry points a minimap2 build calls instead of kt_for(worker_for) (map.c:576).
 // Declared in include/mm2amd.h; the backend (HIP in the product) is supplied by make_backend().
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -44,21 +45,36 @@ struct Replica {
 	int device = -1;
 	std::unique_ptr<Backend> be;
 	std::unique_ptr<Mapper> mapper;
-	std::vector<ReadView> staged;     // this replica's share of the staged batch
-	long lo = 0, hi = 0;              // ... = fragments [lo, hi) of the mapper-side fragment list
+};
+
+// A batch as handed over by mm_gpu_batch_stage*: the mapper-side fragments (views into the caller's sequences and into `flipped`), where
+// their results go, and the replicas' shares (replica r maps fragments [cut[r], cut[r+1])).
+struct StagedBatch {
+	std::vector<ReadView> views;
+	std::vector<OutSlot> slots;
+	std::vector<std::string> flipped;
+	std::vector<long> cut;
 };
 
 struct MapContext {
 	FlatIndex fi_own;                 // index flattened from a reference mm_idx_t (mm_gpu_init)
 	const FlatIndex *fi = nullptr;    // the index in use (fi_own, or the one inside an mm2amd_index_t)
 	ref::MapOpt opt;
-	std::vector<ReadView> staged;
-	std::vector<OutSlot> staged_slots;
-	std::vector<std::string> staged_flipped;
-	bool has_staged = false;
+	// Two batches: the one being (or last) mapped and the one staged next.  stage_mu guards which is which; a staging call fills
+	// batch[1 - cur] and sets `pending`, the next mapping call takes it over (cur flips, pending clears, stage_cv wakes a queued stager).
+	StagedBatch batch[2];
+	int cur = 0;
+	bool pending = false, has_current = false;
+	std::mutex stage_mu;
+	std::condition_variable stage_cv;
+	bool stages_beside_mapping = false; // every replica's backend keeps two resident sets
+	std::mutex stats_mu;
+	FormatScratch fmt;                // mm_gpu_format_batch_view's reusable text buffers
+	std::mutex fmt_mu;
 	int n_threads = 1;
 	uint64_t generation = 0;
-	const void *mi_ptr = nullptr;     // the reference index this context mirrors (mm_gpu_init; the batch-of-one calls compare it)
+	const void *mi_ptr = nullptr;     // the reference index this context mirrors (mm_gpu_init; the batch-of-one calls compare it ...
+	uint64_t mi_stamp[4] = { 0, 0, 0, 0 }; // ... and these fields of it: an index changed in place or another one at a recycled address is not mistaken for it)
 	void *built_tables = nullptr;     // minimizer tables the backend built for fi_own (mm_gpu_init); freed with the context
 	std::vector<Replica> reps;
 	~MapContext() { reps.clear(); if (built_tables) backend_free_index_tables(built_tables); }
@@ -102,40 +118,51 @@ void for_each_replica(MapContext &c, F &&f)
 	for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
-void run_replicas(MapContext &c, std::vector<ReadResult> &out, size_t n_frag_mapper)
+void run_replicas(MapContext &c, const StagedBatch &bt, std::vector<ReadResult> &out)
 {
 	std::vector<std::vector<ReadResult>> part(c.reps.size());
 	for_each_replica(c, [&](Replica &rp) { rp.mapper->run(part[&rp - c.reps.data()]); });
 	out.clear();
-	out.resize(n_frag_mapper);
-	c.stats = MapperStats();
+	out.resize(bt.views.size());
+	MapperStats sum;
 	for (size_t r = 0; r < c.reps.size(); ++r) {
-		for (long i = c.reps[r].lo; i < c.reps[r].hi; ++i) out[i] = std::move(part[r][i - c.reps[r].lo]);
+		for (long i = bt.cut[r]; i < bt.cut[r + 1]; ++i) out[i] = std::move(part[r][i - bt.cut[r]]);
 		const MapperStats &s = c.reps[r].mapper->stats;
-		c.stats.t_seed_chain += s.t_seed_chain, c.stats.t_host_pre += s.t_host_pre, c.stats.t_plan += s.t_plan, c.stats.t_ksw += s.t_ksw, c.stats.t_consume += s.t_consume;
-		c.stats.t_finish += s.t_finish, c.stats.n_jobs += s.n_jobs, c.stats.n_rounds += s.n_rounds, c.stats.dp_cells += s.dp_cells;
+		sum.t_seed_chain += s.t_seed_chain, sum.t_host_pre += s.t_host_pre, sum.t_plan += s.t_plan, sum.t_ksw += s.t_ksw, sum.t_consume += s.t_consume;
+		sum.t_finish += s.t_finish, sum.n_jobs += s.n_jobs, sum.n_rounds += s.n_rounds, sum.dp_cells += s.dp_cells;
 	}
+	std::lock_guard<std::mutex> lk(c.stats_mu);
+	c.stats = sum;
 }
 
-void stage_replicas(MapContext &c, const std::vector<ReadView> &reads, const std::vector<OutSlot> &slots)
+// hand the batch's shares to the replicas' mappers (which copy the sequences to their devices); call with stage_mu held
+void stage_replicas(MapContext &c, StagedBatch &bt)
 {
-	std::vector<long> cut;
-	shard_by_bases(reads, slots, (int)c.reps.size(), cut);
-	for (size_t r = 0; r < c.reps.size(); ++r) {
-		Replica &rp = c.reps[r];
-		rp.lo = cut[r], rp.hi = cut[r + 1];
-		rp.staged.assign(reads.begin() + rp.lo, reads.begin() + rp.hi);
-	}
-	for_each_replica(c, [&](Replica &rp) { rp.mapper->stage(rp.staged); });
+	shard_by_bases(bt.views, bt.slots, (int)c.reps.size(), bt.cut);
+	for_each_replica(c, [&](Replica &rp) {
+		const size_t r = (size_t)(&rp - c.reps.data());
+		std::vector<ReadView> share(bt.views.begin() + bt.cut[r], bt.views.begin() + bt.cut[r + 1]);
+		rp.mapper->stage(share);
+	});
+}
+
+// the staged batch becomes the current one; call with stage_mu held
+void take_staged(MapContext &c)
+{
+	for (Replica &rp : c.reps) rp.mapper->take();
+	c.cur = 1 - c.cur, c.pending = false, c.has_current = true;
+	c.stage_cv.notify_all();
 }
 
 int build_context(std::unique_ptr<MapContext> &c, void *device_tables, int tables_device, int n_threads, int n_gpus, const int *device_ids)
 {
+	if (n_gpus <= 0 && device_ids) return capi_fail(MM2AMD_EINVAL, "[mm2amd] device_ids given without n_gpus: how many entries does the array hold?");
 	if (n_gpus <= 0) { n_gpus = 1; if (const char *e = getenv("MM2AMD_GPUS")) n_gpus = std::max(1, atoi(e)); }
 	std::vector<int> env_ids;
 	if (!device_ids && getenv("MM2AMD_DEVICE_IDS")) { // "0,0" or "3,2,1,0": ordinals for the replicas when the caller names none
 		for (const char *p = getenv("MM2AMD_DEVICE_IDS"); *p;) { env_ids.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
-		if ((int)env_ids.size() >= n_gpus) device_ids = env_ids.data();
+		if ((int)env_ids.size() < n_gpus) return capi_fail(MM2AMD_EINVAL, "[mm2amd] MM2AMD_DEVICE_IDS names fewer devices than replicas were asked for");
+		device_ids = env_ids.data();
 	}
 	if (n_gpus > 16) return capi_fail(MM2AMD_EINVAL, "[mm2amd] at most 16 replicas per context");
 	if (!device_ids && n_gpus > 1 && n_gpus > backend_device_count()) return capi_fail(MM2AMD_ENODEV, "[mm2amd] more GPUs requested than this process can see");
@@ -149,9 +176,13 @@ int build_context(std::unique_ptr<MapContext> &c, void *device_tables, int table
 		rp.be.reset(make_backend(*c->fi, device_tables, per, rp.device, r, tables_device));
 		rp.mapper.reset(new Mapper(*c->fi, c->opt, *rp.be, per));
 	}
+	c->stages_beside_mapping = true;
+	for (Replica &rp : c->reps) c->stages_beside_mapping &= rp.mapper->stages_beside_mapping();
 	c->generation = ++g_generation;
 	return 0;
 }
+
+uint64_t g_stamp_hash(const ref::Idx *mi) { return (uint64_t)mi->k | (uint64_t)mi->w << 8 | (uint64_t)(uint32_t)mi->flag << 16 | (uint64_t)mi->n_seq << 32; }
 }
 
 extern "C" {
@@ -172,14 +203,16 @@ int mm_gpu_init_multi(const void *mi, const void *opt, int n_threads, int n_gpus
 		c->fi = &c->fi_own;
 		int tables_device = -1;
 		if (on_device) {
-			int first = -1;
+			int first = -1; // the device the first replica will run on: the tables are built where they are used
 			if (device_ids && n_gpus > 0) first = device_ids[0];
-			else if (n_gpus > 1 || (n_gpus <= 0 && getenv("MM2AMD_GPUS") && atoi(getenv("MM2AMD_GPUS")) > 1)) first = getenv("MM2AMD_DEVICE_IDS") ? atoi(getenv("MM2AMD_DEVICE_IDS")) : 0;
+			else if (!device_ids && getenv("MM2AMD_DEVICE_IDS")) first = atoi(getenv("MM2AMD_DEVICE_IDS"));
+			else if (n_gpus > 1 || (n_gpus <= 0 && getenv("MM2AMD_GPUS") && atoi(getenv("MM2AMD_GPUS")) > 1)) first = 0;
 			c->built_tables = backend_build_index_tables(c->fi_own, first, &tables_device);
 			if (!c->built_tables) c->fi_own.from_reference(rmi, true); // a backend that works from host tables
 		}
 		if (int rc = build_context(c, c->built_tables, tables_device, n_threads, n_gpus, device_ids)) return rc;
 		c->mi_ptr = mi;
+		c->mi_stamp[0] = g_stamp_hash(rmi), c->mi_stamp[1] = (uint64_t)(uintptr_t)rmi->S, c->mi_stamp[2] = (uint64_t)(uintptr_t)rmi->seq, c->mi_stamp[3] = (uint64_t)rmi->n_alt;
 		g_ctx = std::move(c);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -334,17 +367,31 @@ static void hand_over(const std::vector<OutSlot> &slots, std::vector<ReadResult>
 	}, 256);
 }
 
-int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const void *seq_)
+// The hand-over of a batch (pipeline step 0: the reads are copied to the GPU).  `queued`: wait until the previously staged batch has been
+// taken over by a mapping call instead of replacing it -- the form a pipeline uses, where staging batch k+1 runs beside the mapping
+// of batch k and every staged batch is mapped exactly once, in order (kt_pipeline's ordering rule, kthread.c:107-112).
+static int stage_batch(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, bool queued)
 {
 	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
-	std::lock_guard<std::mutex> lk_map(g_map_mu);
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_batch_stage called before mm_gpu_init");
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_batch_stage: bad arguments");
+	MapContext &c = *g_ctx;
+	std::unique_lock<std::mutex> lk_map(g_map_mu, std::defer_lock);
+	std::unique_lock<std::mutex> lk_st(c.stage_mu, std::defer_lock);
+	for (;;) { // lock order: mapping before staging; a queued hand-over waits for the staged batch to be taken, holding neither
+		if (!c.stages_beside_mapping) lk_map.lock(); // a backend with one resident set: the hand-over waits for the mapping call in flight
+		lk_st.lock();
+		if (!queued || !c.pending) break;
+		if (lk_map.owns_lock()) lk_map.unlock();
+		c.stage_cv.wait(lk_st, [&] { return !c.pending; });
+		lk_st.unlock();
+	}
 	try {
-		g_ctx->has_staged = false;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, g_ctx->staged, g_ctx->staged_slots, g_ctx->staged_flipped)) return rc;
-		stage_replicas(*g_ctx, g_ctx->staged, g_ctx->staged_slots);
-		g_ctx->has_staged = true;
+		c.pending = false;
+		StagedBatch &bt = c.batch[1 - c.cur];
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, bt.views, bt.slots, bt.flipped)) return rc;
+		stage_replicas(c, bt);
+		c.pending = true;
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());
@@ -353,16 +400,36 @@ int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const v
 	}
 }
 
+int mm_gpu_batch_stage(int n_frag, const int *seg_off, const int *n_seg, const void *seq_) { return stage_batch(n_frag, seg_off, n_seg, seq_, false); }
+int mm_gpu_batch_stage_queued(int n_frag, const int *seg_off, const int *n_seg, const void *seq_) { return stage_batch(n_frag, seg_off, n_seg, seq_, true); }
+
+// drops a staged batch that will not be mapped (a pipeline shutting down after an error), so that a queued hand-over is not left waiting
+void mm_gpu_batch_discard(void)
+{
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
+	if (!g_ctx) return;
+	std::lock_guard<std::mutex> lk_st(g_ctx->stage_mu);
+	g_ctx->pending = false;
+	g_ctx->stage_cv.notify_all();
+}
+
 int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
 	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	std::lock_guard<std::mutex> lk_map(g_map_mu);
-	if (!g_ctx || !g_ctx->has_staged) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_staged: no staged batch");
+	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_staged: no staged batch");
 	if (!n_reg || !reg) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_staged: bad arguments");
+	MapContext &c = *g_ctx;
 	try {
+		{
+			std::lock_guard<std::mutex> lk_st(c.stage_mu);
+			if (c.pending) take_staged(c);                       // the batch staged last ...
+			else if (!c.has_current) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_staged: no staged batch");
+		}                                                        // ... or, when nothing new was staged, the current one again
+		const StagedBatch &bt = c.batch[c.cur];
 		std::vector<ReadResult> out;
-		run_replicas(*g_ctx, out, g_ctx->staged.size());
-		hand_over(g_ctx->staged_slots, out, n_reg, reg, rep_len, frag_gap);
+		run_replicas(c, bt, out);
+		hand_over(bt.slots, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());
@@ -383,6 +450,25 @@ int mm_gpu_format_batch(int n_frag, const int *seg_off, const int *n_seg, const 
 	try {
 		*out = format_batch(*g_ctx->fi, g_ctx->opt, g_ctx->n_threads, n_frag, seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, out_len);
 		if (!*out) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm_gpu_format_batch: out of memory");
+		return 0;
+	} catch (const std::exception &e) {
+		return capi_fail(MM2AMD_EINVAL, e.what());
+	}
+}
+
+int mm_gpu_format_batch_view(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const int *n_reg, void *const *reg, const int *rep_len, const char **out, size_t *out_len)
+{
+	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
+	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_format_batch_view called before mm_gpu_init");
+	if (n_frag < 0 || !out || !out_len || (n_frag > 0 && (!seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch_view: bad arguments");
+	for (int i = 0; i < n_frag; ++i)
+		if (n_seg && n_seg[i] != 1 && n_seg[i] != 2) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch_view: fragments of one or two segments only");
+	const std::string why = format_check(g_ctx->opt);
+	if (!why.empty()) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch_view: " + why);
+	std::lock_guard<std::mutex> lk_fmt(g_ctx->fmt_mu); // one formatting call at a time uses the buffers (pipeline step 2)
+	try {
+		*out = format_batch_view(*g_ctx->fi, g_ctx->opt, g_ctx->n_threads, n_frag, seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, g_ctx->fmt, out_len);
+		if (!*out) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm_gpu_format_batch_view: out of memory");
 		return 0;
 	} catch (const std::exception &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());
@@ -483,16 +569,22 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 	std::lock_guard<std::mutex> lk_map(g_map_mu);
 	if (!g_ctx) return capi_fail(MM2AMD_ESTATE, "[mm2amd] mm_gpu_map_batch called before mm_gpu_init");
 	if (n_frag < 0 || (n_frag > 0 && (!seg_off || !n_seg || !seq_ || !n_reg || !reg))) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch: bad arguments");
+	MapContext &c = *g_ctx;
 	try {
-		std::vector<ReadView> reads;
-		std::vector<OutSlot> slots;
-		std::vector<std::string> flipped;
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, g_ctx->opt, reads, slots, flipped)) return rc;
+		StagedBatch *bt;
+		{ // hand-over and take-over in one go (a batch staged but not yet mapped is replaced)
+			std::lock_guard<std::mutex> lk_st(c.stage_mu);
+			c.pending = false;
+			bt = &c.batch[1 - c.cur];
+			if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, bt->views, bt->slots, bt->flipped)) return rc;
+			stage_replicas(c, *bt);
+			c.pending = true;
+			take_staged(c);
+		}
 		std::vector<ReadResult> out;
-		g_ctx->has_staged = false; // the replicas' staged shares are replaced
-		stage_replicas(*g_ctx, reads, slots);
-		run_replicas(*g_ctx, out, reads.size());
-		hand_over(slots, out, n_reg, reg, rep_len, frag_gap);
+		run_replicas(c, *bt, out);
+		hand_over(bt->slots, out, n_reg, reg, rep_len, frag_gap);
+		c.has_current = false; // the views point into the caller's buffers, which this call does not own beyond its return
 		return 0;
 	} catch (const std::invalid_argument &e) {
 		return capi_fail(MM2AMD_EINVAL, e.what());
@@ -507,11 +599,19 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 // (mi, opt) differ from the live one.  b, when given, receives rep_len / frag_gap like the reference's mm_tbuf_t (minimap.h:207-210).
 struct TbufView { void *km; int rep_len, frag_gap; };
 
+// These calls use the ONE process-wide context: g_single_mu is held from the check of (mi, opt) to the end of the mapping, so two threads
+// that pass different options or indexes cannot map with each other's context (they rebuild it in turn, which costs seconds: batch-of-one
+// callers should stick to one (mi, opt)).  The context is matched on the index's address AND on fields of it (k, w, flag, n_seq, n_alt,
+// the sequence arrays), so an index freed and another allocated at the same address, or one changed in place, is not mistaken for it.
+static std::mutex g_single_mu;
+
 static int ensure_context_for(const void *mi, const void *opt)
 {
 	{
 		std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
-		if (g_ctx && g_ctx->mi_ptr == mi && memcmp(&g_ctx->opt, opt, sizeof(ref::MapOpt)) == 0) return 0;
+		const ref::Idx *rmi = (const ref::Idx *)mi;
+		if (g_ctx && g_ctx->mi_ptr == mi && memcmp(&g_ctx->opt, opt, sizeof(ref::MapOpt)) == 0 && g_ctx->mi_stamp[0] == g_stamp_hash(rmi) &&
+		    g_ctx->mi_stamp[1] == (uint64_t)(uintptr_t)rmi->S && g_ctx->mi_stamp[2] == (uint64_t)(uintptr_t)rmi->seq && g_ctx->mi_stamp[3] == (uint64_t)rmi->n_alt) return 0;
 	}
 	return mm_gpu_init(mi, opt, 0);
 }
@@ -520,6 +620,7 @@ void mm_gpu_map_frag(const void *mi, int n_segs, const int *qlens, const char **
 {
 	for (int s = 0; s < n_segs; ++s) n_regs[s] = 0, regs[s] = nullptr;
 	if (!mi || !opt || n_segs < 1 || n_segs > 2) { capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_frag: one or two segments, non-null index and options"); return; }
+	std::lock_guard<std::mutex> lk_single(g_single_mu);
 	if (ensure_context_for(mi, opt) != 0) return;
 	ref::Bseq1 rec[2];
 	for (int s = 0; s < n_segs; ++s) {
@@ -564,6 +665,7 @@ int mm2amd_last_stats(double *v, int n)
 {
 	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	if (!g_ctx) return 0;
+	std::lock_guard<std::mutex> lk_stats(g_ctx->stats_mu);
 	const MapperStats &s = g_ctx->stats;
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
 	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2) };

@@ -411,23 +411,55 @@ static void format_range(const FlatIndex &fi, const MapOpt &opt, const int *seg_
 	}
 }
 
+struct FormatScratch::Impl { std::vector<Text> parts; };
+FormatScratch::FormatScratch() : impl(new Impl) {}
+FormatScratch::~FormatScratch() { delete impl; free(buf); }
+
+// the chunks' texts (64 fragments each, formatted by one pool thread each) and where each starts in the concatenation
+static size_t format_parts(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n, const int *seg_off, const int *n_seg, const Bseq1 *seq, const int *n_reg,
+                           void *const *reg, const int *rep_len, std::vector<Text> &parts, std::vector<size_t> &off)
+{
+	const long chunk = 64, n_chunks = (n + chunk - 1) / chunk;
+	if ((long)parts.size() < n_chunks) parts.resize(n_chunks);
+	parallel_for(n_threads, n_chunks, [&](long c, int) {
+		const long lo = c * chunk, hi = std::min(n, lo + chunk);
+		parts[c].s.clear(); // keeps its capacity: a reused scratch formats into memory it already owns
+		format_range(fi, opt, seg_off, n_seg, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
+	}, 1);
+	off.assign(n_chunks + 1, 0);
+	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].s.size();
+	return off[n_chunks];
+}
+
 char *format_batch(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const Bseq1 *seq, const int *n_reg,
                    void *const *reg, const int *rep_len, size_t *out_len)
 {
-	const long n = n_frag, chunk = 64, n_chunks = (n + chunk - 1) / chunk;
-	std::vector<Text> parts(n_chunks);
-	parallel_for(n_threads, n_chunks, [&](long c, int) {
-		const long lo = c * chunk, hi = std::min(n, lo + chunk);
-		format_range(fi, opt, seg_off, n_seg, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
-	}, 1);
-	std::vector<size_t> off(n_chunks + 1, 0);
-	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].s.size();
-	char *out = (char *)malloc(off[n_chunks] + 1);
+	std::vector<Text> parts;
+	std::vector<size_t> off;
+	const size_t total = format_parts(fi, opt, n_threads, n_frag, seg_off, n_seg, seq, n_reg, reg, rep_len, parts, off);
+	char *out = (char *)malloc(total + 1);
 	if (!out) return nullptr;
-	parallel_for(n_threads, n_chunks, [&](long c, int) { memcpy(out + off[c], parts[c].s.data(), parts[c].s.size()); }, 8);
-	out[off[n_chunks]] = 0;
-	*out_len = off[n_chunks];
+	parallel_for(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(out + off[c], parts[c].s.data(), parts[c].s.size()); }, 8);
+	out[total] = 0;
+	*out_len = total;
 	return out;
+}
+
+const char *format_batch_view(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const Bseq1 *seq, const int *n_reg,
+                              void *const *reg, const int *rep_len, FormatScratch &fs, size_t *out_len)
+{
+	std::vector<size_t> off;
+	const size_t total = format_parts(fi, opt, n_threads, n_frag, seg_off, n_seg, seq, n_reg, reg, rep_len, fs.impl->parts, off);
+	if (fs.cap < total + 1) { // grow-only: in the steady state of a pipeline no page of this buffer is new
+		free(fs.buf);
+		fs.cap = (total + 1) + (total + 1) / 4;
+		fs.buf = (char *)malloc(fs.cap);
+		if (!fs.buf) { fs.cap = 0; return nullptr; }
+	}
+	parallel_for(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(fs.buf + off[c], fs.impl->parts[c].s.data(), fs.impl->parts[c].s.size()); }, 8);
+	fs.buf[total] = 0;
+	*out_len = total;
+	return fs.buf;
 }
 
 } // namespace mm2amd

@@ -13,4 +13,18 @@ std::string format_check(const ref::MapOpt &opt);
 char *format_batch(const FlatIndex &fi, const ref::MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const ref::Bseq1 *seq, const int *n_reg,
                    void *const *reg, const int *rep_len, size_t *out_len);
 
+// The same into memory that is reused from call to call (owned by `fs`; the returned pointer is valid until the next call with it)
+struct FormatScratch {
+	struct Impl;
+	Impl *impl;
+	char *buf = nullptr;
+	size_t cap = 0;
+	FormatScratch();
+	~FormatScratch();
+	FormatScratch(const FormatScratch &) = delete;
+	FormatScratch &operator=(const FormatScratch &) = delete;
+};
+const char *format_batch_view(const FlatIndex &fi, const ref::MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const ref::Bseq1 *seq, const int *n_reg,
+                              void *const *reg, const int *rep_len, FormatScratch &fs, size_t *out_len);
+
 } // namespace mm2amd

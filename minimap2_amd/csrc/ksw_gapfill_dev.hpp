@@ -7,6 +7,7 @@
 
 namespace mm2amd {
 
+#ifndef MM2AMD_WAVE_EMU // (the emulator build takes these from tests/cpucheck/wave_emu/ksw_pk_emu.hpp, through ksw_pk.hpp)
 // ---------------------------------------------------------------------------------------------------------
 // Packed 16-bit VOP3P with the operand kinds that keep VGPRs free: small constants are inline constants (op_sel_hi clear on
 // that operand: the low half feeds both lanes of the pair), launch-uniform scores sit in SGPRs (one constant-bus operand per
@@ -120,6 +121,8 @@ __device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, u
 		: [a] "v"(a), [b] "v"(b), [a2] "v"(a2), [b2] "v"(b2), [qe] "s"(S_QE), [qe2] "s"(S_QE2));
 	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
+
+#endif // MM2AMD_WAVE_EMU
 
 // ---- mm_test_zdrop's walk over a finished alignment (align.c:46-84), by the 32 lanes of a half-wave ----
 // The reference walks the CIGAR from the start: a running score (substitution scores base by base, -(q + e * len) per gap), the

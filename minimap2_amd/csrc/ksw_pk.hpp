@@ -22,6 +22,11 @@ __device__ __forceinline__ void fast_cig_push(FastCig &g, uint32_t op, int len) 
 	} else g.last += (uint32_t)len << 4;
 }
 
+#ifdef MM2AMD_WAVE_EMU // tests/cpucheck/wave_emu: the instructions below as plain C++ on the two halves
+} // namespace mm2amd
+#include "ksw_pk_emu.hpp"
+namespace mm2amd {
+#else
 #define MM2_PK2(name, ins) \
 	__device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b) { uint32_t r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 MM2_PK2(pk_add, "v_pk_add_u16")
@@ -35,6 +40,7 @@ __device__ __forceinline__ uint32_t pk_shr2(uint32_t a) { uint32_t r; asm("v_pk_
 __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | (uint32_t)v << 16; }
 // a uniform constant pinned in a VGPR (the asm wrappers take VGPR operands; without this every use re-copies it from an SGPR)
 __device__ __forceinline__ uint32_t pk2v(int v) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(pk2(v))); return r; }
+#endif
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
 __device__ __forceinline__ uint32_t dpp_shr1u(uint32_t carry_in, uint32_t v) { return (uint32_t)dpp_shr1((int)carry_in, (int)v); }
 

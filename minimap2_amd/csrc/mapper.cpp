@@ -72,21 +72,32 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 
 void Mapper::stage(const std::vector<ReadView> &reads)
 {
-	n_staged_ = (long)reads.size();
-	live_.clear(), live_id_.clear(), qoff_.clear();
+	Staged &S = sets_[1 - cur_set_];
+	S.n = (long)reads.size();
+	S.live.clear(), S.live_id.clear(), S.qoff.clear();
 	// which reads are mapped at all (map.c:243-244)
-	for (long i = 0; i < n_staged_; ++i)
-		if (reads[i].total() > 0 && !(opt_.max_qlen > 0 && reads[i].total() > opt_.max_qlen)) live_.push_back(reads[i]), live_id_.push_back(i);
-	if (!live_.empty()) be_.begin_batch(live_, qoff_);
+	for (long i = 0; i < S.n; ++i)
+		if (reads[i].total() > 0 && !(opt_.max_qlen > 0 && reads[i].total() > opt_.max_qlen)) S.live.push_back(reads[i]), S.live_id.push_back(i);
+	be_.begin_batch(S.live, S.qoff); // (an empty batch too: the backend's sets and ours swap together)
+	pending_ = true;
+}
+
+void Mapper::take()
+{
+	if (!pending_) return;
+	cur_set_ = 1 - cur_set_;
+	be_.activate_batch();
+	pending_ = false;
 }
 
 void Mapper::run(std::vector<ReadResult> &out)
 {
-	const long n = n_staged_;
+	take();
+	const long n = sets_[cur_set_].n;
 	out.clear();
 	out.resize(n);
 	stats = MapperStats();
-	const std::vector<ReadView> &live = live_;
+	const std::vector<ReadView> &live = sets_[cur_set_].live;
 	const long m_all = (long)live.size();
 	if (m_all == 0) return;
 	double t0 = now();
@@ -175,9 +186,9 @@ void Mapper::run(std::vector<ReadResult> &out)
 
 void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, std::vector<ReadResult> &out, MapperStats &stats)
 {
-	const std::vector<ReadView> &live = live_;
-	const std::vector<long> &live_id = live_id_;
-	const std::vector<uint64_t> &qoff = qoff_;
+	const std::vector<ReadView> &live = sets_[cur_set_].live;
+	const std::vector<long> &live_id = sets_[cur_set_].live_id;
+	const std::vector<uint64_t> &qoff = sets_[cur_set_].qoff;
 	{
 		const long m = hi - lo;
 		double t0 = now();

@@ -28,9 +28,13 @@ public:
 	Mapper(const FlatIndex &fi, const ref::MapOpt &opt, Backend &be, int n_threads);
 	void map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out) { stage(reads); run(out); }
 	// the two halves of map_batch: stage() makes the batch resident on the device (the hand-over the reference's pipeline
-	// step 0 performs), run() is the hot path proper.  The ReadViews must stay valid until run() returns.
+	// step 0 performs), run() is the hot path proper.  The ReadViews must stay valid until run() returns.  stage() prepares the
+	// NEXT batch and run() takes it over: with a backend that stages beside mapping, stage() of batch k+1 may be called from
+	// another thread while run() of batch k is under way (the caller orders them: every stage() is followed by one take()+run()).
 	void stage(const std::vector<ReadView> &reads);
+	void take();                                      // the staged batch becomes the one run() maps (run() calls it when a batch is pending)
 	void run(std::vector<ReadResult> &out);
+	bool stages_beside_mapping() const { return be_.stages_beside_mapping(); }
 	MapperStats stats;
 private:
 	struct DriverScratch {
@@ -58,10 +62,10 @@ private:
 	ref::MapOpt opt_;
 	Backend &be_;
 	int n_threads_;
-	long n_staged_ = 0;
-	std::vector<ReadView> live_;
-	std::vector<long> live_id_;
-	std::vector<uint64_t> qoff_;
+	struct Staged { long n = 0; std::vector<ReadView> live; std::vector<long> live_id; std::vector<uint64_t> qoff; };
+	Staged sets_[2];
+	int cur_set_ = 0;
+	bool pending_ = false; // a staged batch run() has not taken over yet
 };
 
 uint32_t read_hash(const char *qname, int qlen, const ref::MapOpt &opt); // map.c:246-248

@@ -26,12 +26,36 @@ def split_by_bases(lens, world_size):
     return b
 
 
-def pack_hits(L, n_reg, reg):
-    """ctypes (n_reg, reg) arrays -> uint8 torch tensor holding the flat payload (mm2amd_pack_regs)."""
+class GatherBuffers(object):
+    """Reused buffers of the per-batch hit gather: a pinned host buffer the payload is packed into and (on the formatting rank) received
+    into, device send / receive buffers for the RCCL gather.  They only grow; after the first batches a gather allocates nothing."""
+
+    def __init__(self):
+        self.pack = self.send = self.recv = self.host = None
+
+    @staticmethod
+    def _grow(t, n, **kw):
+        if t is None or t.numel() < n:
+            t = torch.empty(int(n * 1.25) + 64, dtype=torch.uint8, **kw)
+        return t
+
+    def pack_buffer(self, n):
+        pin = torch.cuda.is_available()
+        self.pack = self._grow(self.pack, n, pin_memory=pin)
+        return self.pack
+
+
+def pack_hits(L, n_reg, reg, bufs=None):
+    """ctypes (n_reg, reg) arrays -> uint8 torch tensor holding the flat payload (mm2amd_pack_regs); with `bufs` into its pinned buffer"""
     n = len(n_reg)
     need = L.mm2amd_pack_regs(n, n_reg, reg, None, 0)
     if need < 0:
         raise RuntimeError(L.mm2amd_last_error().decode())
+    if bufs is not None:
+        t = bufs.pack_buffer(max(int(need), 1))
+        got = L.mm2amd_pack_regs(n, n_reg, reg, C.c_void_p(t.data_ptr()), need)
+        assert got == need
+        return t[:need]
     buf = np.empty(max(int(need), 1), dtype=np.uint8)
     got = L.mm2amd_pack_regs(n, n_reg, reg, buf.ctypes.data_as(C.c_void_p), need)
     assert got == need
@@ -50,10 +74,11 @@ def unpack_hits(L, payload, n_frag):
     return n_reg, reg
 
 
-def gather_payloads(payload, dst=0, device=None):
+def gather_payloads(payload, dst=0, device=None, bufs=None):
     """The final hit gather: every rank contributes one uint8 payload, rank `dst` receives them in rank order.
-    Sizes travel in one all_gather; the data in one gather of equally padded buffers (one xGMI hop per peer).
-    Returns the list of payload tensors on dst, None elsewhere."""
+    Sizes travel in one all_gather; the data in one gather of equally padded buffers (one xGMI hop per peer).  With `bufs`
+    (GatherBuffers) the device buffers are reused from batch to batch and the received payloads land in one pinned host buffer.
+    Returns the list of payload tensors on dst (host tensors when `bufs` is given and the device is a GPU), None elsewhere."""
     if not dist.is_initialized():  # single process: the gather is the identity
         return [payload]
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -63,10 +88,30 @@ def gather_payloads(payload, dst=0, device=None):
     dist.all_gather(sizes, size)
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
-    send = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    send[:payload.numel()] = payload.to(dev)
-    recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+    on_gpu = torch.device(dev).type == "cuda"
+    if bufs is not None:
+        bufs.send = GatherBuffers._grow(bufs.send, cap, device=dev)
+        send = bufs.send[:cap]
+    else:
+        send = torch.empty(cap, dtype=torch.uint8, device=dev)
+    send[:payload.numel()].copy_(payload, non_blocking=True)
+    recv = None
+    if rank == dst:
+        if bufs is not None:
+            bufs.recv = GatherBuffers._grow(bufs.recv, cap * world, device=dev)
+            recv = list(bufs.recv[:cap * world].view(world, cap).unbind(0))
+        else:
+            recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.gather(send, recv, dst=dst)
     if rank != dst:
         return None
+    if bufs is not None and on_gpu:  # device -> one pinned host buffer, the payloads back to back
+        bufs.host = GatherBuffers._grow(bufs.host, sum(sizes), pin_memory=True)
+        out, o = [], 0
+        for r in range(world):
+            bufs.host[o:o + sizes[r]].copy_(recv[r][:sizes[r]], non_blocking=True)
+            out.append(bufs.host[o:o + sizes[r]])
+            o += sizes[r]
+        torch.cuda.current_stream().synchronize()
+        return out
     return [recv[r][:sizes[r]] for r in range(world)]

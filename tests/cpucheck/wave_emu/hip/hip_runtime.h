@@ -26,6 +26,10 @@
 #define __shared__ static thread_local
 #define __launch_bounds__(...)
 
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
 namespace wave_emu {

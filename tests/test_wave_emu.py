@@ -1,0 +1,105 @@
+"""The kernels' OWN source on the CPU: tests/_build/libmm2amd_emu.so is the product -- every .hip file of minimap2_amd/csrc included -- built
+for the host under the wave emulator (tests/cpucheck/wave_emu: HIP threads as fibers that meet at cross-lane operations; only the gfx950
+inline-assembly helpers are restated, wave_emu/ksw_pk_emu.hpp).  These cases run it end to end against the unmodified reference, so a kernel
+that drifts from the reference is caught in a container without a GPU; the same cases and many more run on the hardware (`-m gpu`).
+`MM2AMD_EMU=1 pytest -m gpu` runs the whole GPU suite on the emulator (tests/conftest.py)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as G  # noqa: E402
+import reflib  # noqa: E402
+import synth  # noqa: E402
+
+EMU_SO = os.path.join(HERE, "_build", "libmm2amd_emu.so")
+DROPIN_EMU = os.path.join(HERE, "_build", "dropin_emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if os.path.exists("/root/reference/minimap.h") or not os.path.exists(EMU_SO):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpucheck")], stdout=subprocess.DEVNULL)
+    import minimap2_amd as mm
+    saved = mm._lib
+    mm._lib = mm._bind(C.CDLL(EMU_SO))
+    yield mm
+    mm._lib = saved
+
+
+def _reads(seed, n, mean, err, ref_len=600000):
+    rng = np.random.default_rng(seed)
+    contigs = synth.gen_reference(rng, ref_len, 2)
+    reads = synth.gen_reads(rng, contigs, n, mean, mean // 4, err)
+    return [synth.ACGT[c].tobytes() for c in contigs], [("read%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+
+
+@pytest.mark.parametrize("preset,n,mean,err", [("map-ont", 10, 5000, 0.12), ("map-hifi", 6, 9000, 0.005), ("lr:hqae", 5, 6000, 0.02)])
+def test_kernels_source_against_reference(emu, preset, n, mean, err):
+    """sketch, seed collection, per-read LDS anchor sort, chaining with the LDS window (or the RMQ chainer), backtrack, the three DP kernels"""
+    refs, rds = _reads(31, n, mean, err)
+    al = emu.Aligner(refs, preset=preset, names=["chr1", "chr2"], n_threads=4)
+    try:
+        hits = al.map_batch(rds)
+    finally:
+        al.close()
+    assert sum(1 for h in hits if h) >= n - 1
+    if not os.path.exists(reflib.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    assert [[a.key() for a in h] for h in hits] == reflib.ref_map_reads(refs, rds, preset)
+
+
+def test_duplicated_anchor_keys_replayed(emu, tmp_path):
+    """reads full of tandem repeats: equal anchor keys, the unstable radix sort's permutation replayed in LDS (anchor_sort_kernel)"""
+    if not os.path.exists(G.REF_BIN) or not os.path.exists(DROPIN_EMU):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    ref, rd = synth.make_weird(str(tmp_path))
+    want = subprocess.run([G.REF_BIN, "-x", "map-ont", "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    got = subprocess.run([DROPIN_EMU, "-x", "map-ont", "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert G.strip_pg(got) == G.strip_pg(want)
+
+
+@pytest.mark.parametrize("case", ["mt_sam", "inv_paf", "x3s_paf"])
+def test_reference_fixtures_through_the_kernels_source(case):
+    if not os.path.exists(DROPIN_EMU):
+        pytest.skip("tests/_build/dropin_emu needs the reference headers to build (dev container only)")
+    got, err = G.run_fixture(DROPIN_EMU, case, ["--stats"])
+    assert "backend=hip:gfx950" in err
+    assert got == open(os.path.join(HERE, "golden", case + ".out"), "rb").read()
+
+
+def test_pipeline_equals_batch_by_batch(emu):
+    """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
+    (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
+    refs, rds = _reads(37, 12, 3000, 0.1, 300000)
+    al = emu.Aligner(refs, preset="map-ont", names=["chr1", "chr2"], n_threads=4, sam=True)
+    try:
+        base = emu.Batch(rds)
+        batches = [base.rotated(k) for k in (0, 5, 9, 2)] + [emu.Batch(rds[:3]), emu.Batch([])]
+        want = []
+        for b in batches:
+            al.stage(b)
+            n_reg, reg, rep = al.run(raw=True)
+            want.append(al.format_raw(n_reg, reg, rep))
+            al.free_raw(n_reg, reg)
+        got = []
+        total = al.pipeline(batches, on_text=lambda b, addr, ln: got.append(C.string_at(addr, ln)))
+        assert got == want and total == sum(len(t) for t in want)
+        assert len(want[0]) > 10000 and want[1] != want[0]
+        # a batch handed over and then replaced is never mapped; mapping the staged batch twice gives the same records
+        al.stage(batches[1])
+        al.stage(batches[4])
+        a = al.run(raw=True)
+        ta = al.format_raw(*a)
+        al.free_raw(a[0], a[1])
+        assert ta == want[4]
+    finally:
+        al.close()
