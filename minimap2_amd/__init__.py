@@ -299,6 +299,7 @@ class Aligner(object):
 
     def __init__(self, seq, preset=None, names=None, k=None, w=None, n_threads=0, cigar=True, sam=False, n_gpus=0, device_ids=None):
         L = lib()
+        self._generation, self._idx, self._staged = 0, None, None  # close() must work on a half-built object
         seqs = [seq] if isinstance(seq, (bytes, str)) else list(seq)
         self._seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
         n = len(self._seqs)

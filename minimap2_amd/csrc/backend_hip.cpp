@@ -88,7 +88,12 @@ public:
 		}
 	}
 
-	~HipBackend() override { (void)hipSetDevice(dev_); if (stage_stream_) (void)hipStreamDestroy(stage_stream_); }
+	~HipBackend() override
+	{
+		(void)hipSetDevice(dev_);
+		if (stage_stream_) (void)hipStreamDestroy(stage_stream_);
+		for (int l = 0; l < n_lanes_; ++l) kernel_profiler(l, replica_).drop_events();
+	}
 	int n_lanes() const override { return n_lanes_; }
 	void enable_name_rules() override
 	{

@@ -5,11 +5,10 @@
 namespace mm2amd {
 
 namespace {
-int device_count()
+int device_count() // asked once: the answer does not change while the process lives
 {
-	int n = 0;
-	const hipError_t e = hipGetDeviceCount(&n);
-	if (e != hipSuccess || n <= 0) throw HipError("[mm2amd] no HIP device visible: this library has no CPU path");
+	static const int n = [] { int v = 0; return hipGetDeviceCount(&v) == hipSuccess ? v : 0; }();
+	if (n <= 0) throw HipError("[mm2amd] no HIP device visible: this library has no CPU path");
 	return n;
 }
 }

@@ -45,6 +45,9 @@ public:
 		pending_.clear();
 	}
 	void reset() { collect(); stats_.clear(); }
+	// the pooled events belong to the device that was current when they were created: a context being torn down drops them, so that a
+	// later context on another device does not record them on its streams
+	void drop_events() { collect(); for (hipEvent_t e : free_) (void)hipEventDestroy(e); free_.clear(); }
 	const std::map<std::string, KernelStat> &stats() const { return stats_; }
 private:
 	struct Pending { hipEvent_t e0, e1; const char *name = nullptr; double bytes = 0, units = 0; };

@@ -209,6 +209,12 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
 		auto group_of = [](int tier) { return tier >= kFirstExact && tier < kFirstSplice ? 1 : 0; };
 		const int max_slots_env = getenv("MM2AMD_KSW_MAX_SLOTS") ? atoi(getenv("MM2AMD_KSW_MAX_SLOTS")) : 0; // tests: few persistent waves, so that each takes many jobs
+		// Two groups run concurrently only when there are lane-exact launches and the mode allows it; then each gets half of this lane's
+		// scratch budget and buffers of its own.  Otherwise the groups run one after the other and SHARE one buffer sized for the larger.
+		bool any_side = false;
+		for (int tier = kFirstExact; tier < kFirstSplice; ++tier) any_side |= tier_beg[tier + 1] != tier_beg[tier];
+		const bool use_side = any_side && !splice && !getenv("MM2AMD_NO_SIDE_STREAM"); // (spliced alignment: both groups hold matrices of tens of MB per job -- one after the other, each with the whole scratch budget) // read per run: bench.py's un-overlapped pass wants every launch on one stream
+		const size_t group_budget = use_side ? dir_budget / 2 : dir_budget;
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			Plan &P = plan[tier];
 			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
@@ -241,7 +247,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const int wpb = P.wpb;
 			const size_t per_slot = fast && !(sfast && kSpliceSelf[sclass]) ? 2 : 1; // the paired gap-fill kernels run two jobs per wave
 			P.n_slots = std::min<size_t>((P.end - P.beg + per_slot - 1) / per_slot, (size_t)n_cu * blocks_per_cu * wpb);
-			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, dir_budget / (P.slot_bytes * per_slot)));
+			P.n_slots = std::min<size_t>(P.n_slots, std::max<size_t>(1, group_budget / (P.slot_bytes * per_slot)));
 			if (max_slots_env > 0) P.n_slots = std::min<size_t>(P.n_slots, (size_t)max_slots_env);
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
@@ -249,12 +255,18 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		}
 		for (size_t &need_dir : need_dir_g)
 			if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
-		d_dir.ensure(need_dir_g[0], 1.0), d_dir2.ensure(need_dir_g[1], 1.0);
-		d_cigar_tmp.ensure(need_tmp_g[0], 1.0), d_cigar_tmp2.ensure(need_tmp_g[1], 1.0);
+		uint8_t *dir_g[2];
+		uint32_t *tmp_g[2];
+		if (use_side) {
+			d_dir.ensure(need_dir_g[0], 1.0), d_dir2.ensure(need_dir_g[1], 1.0);
+			d_cigar_tmp.ensure(need_tmp_g[0], 1.0), d_cigar_tmp2.ensure(need_tmp_g[1], 1.0);
+			dir_g[0] = d_dir.p, dir_g[1] = d_dir2.p, tmp_g[0] = d_cigar_tmp.p, tmp_g[1] = d_cigar_tmp2.p;
+		} else {
+			d_dir.ensure(std::max(need_dir_g[0], need_dir_g[1]), 1.0);
+			d_cigar_tmp.ensure(std::max(need_tmp_g[0], need_tmp_g[1]), 1.0);
+			dir_g[0] = dir_g[1] = d_dir.p, tmp_g[0] = tmp_g[1] = d_cigar_tmp.p;
+		}
 		if (need_state) d_state.ensure(need_state, 1.0);
-		bool any_side = false;
-		for (int tier = kFirstExact; tier < kFirstSplice; ++tier) any_side |= plan[tier].end != plan[tier].beg;
-		const bool use_side = any_side && !splice && !getenv("MM2AMD_NO_SIDE_STREAM"); // (spliced alignment: both groups hold matrices of tens of MB per job -- one after the other, each with the whole scratch budget) // read per run: bench.py's un-overlapped pass wants every launch on one stream
 		if (use_side) {
 			if (!side) {
 				int lo_prio = 0, hi_prio = 0;
@@ -279,8 +291,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			L.jobs = d_jobs.p + P.beg, L.res = d_res.p + P.beg, L.n_jobs = (int32_t)(P.end - P.beg);
 			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
 			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
-			L.cigar_tmp = group_of(tier) ? d_cigar_tmp2.p : d_cigar_tmp.p, L.cigar_tmp_cap = (uint32_t)P.tmp_cap; // each group has its scratch, whichever stream it runs on
-			L.dir_pool = group_of(tier) ? d_dir2.p : d_dir.p, L.slot_bytes = P.slot_bytes;
+			L.cigar_tmp = tmp_g[group_of(tier)], L.cigar_tmp_cap = (uint32_t)P.tmp_cap; // concurrent groups have scratch of their own
+			L.dir_pool = dir_g[group_of(tier)], L.slot_bytes = P.slot_bytes;
 			L.counter = d_counter.p + tier;
 			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc_dev;
 			L.state_pool = P.hbm ? d_state.p : nullptr;
