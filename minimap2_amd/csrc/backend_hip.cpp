@@ -150,7 +150,7 @@ public:
 		qpool_off.resize(n);
 		for (size_t i = 0; i < n; ++i) qpool_off[i] = 2 * seq_off_[i];
 		char *h = h_ascii_.ensure(total + 1);
-		parallel_for(n_threads_, (long)n, [&](long i, int) {
+		parallel_for_side(n_threads_, (long)n, [&](long i, int) {
 			memcpy(h + seq_off_[i], reads[i].seq, reads[i].len);
 			if (reads[i].paired()) memcpy(h + seq_off_[i] + reads[i].len, reads[i].seq2, reads[i].len2);
 		}, 64);
@@ -186,7 +186,7 @@ public:
 		}
 		if (have_read_names_) {
 			name_key_.resize(2 * n);
-			parallel_for(n_threads_, (long)n, [&](long i, int) {
+			parallel_for_side(n_threads_, (long)n, [&](long i, int) {
 				const std::string q(reads[i].name);
 				const size_t lb = (size_t)(std::lower_bound(sorted_names_.begin(), sorted_names_.end(), q) - sorted_names_.begin());
 				name_key_[i] = (int32_t)lb;

@@ -6,6 +6,8 @@
 // every chunk is formatted into its own buffer by one pool thread, and the buffers are concatenated in input order.
 // Single-segment fragments only (the mapper's scope); no read-group tag (-R is CLI state of the reference).
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <cassert>
 #include <cstdio>
 #include <cstring>
@@ -421,11 +423,18 @@ static size_t format_parts(const FlatIndex &fi, const MapOpt &opt, int n_threads
 {
 	const long chunk = 64, n_chunks = (n + chunk - 1) / chunk;
 	if ((long)parts.size() < n_chunks) parts.resize(n_chunks);
-	parallel_for(n_threads, n_chunks, [&](long c, int) {
+	static const bool trace = getenv("MM2AMD_FMT_TRACE") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	std::atomic<long long> busy_ns{0};
+	parallel_for_side(n_threads, n_chunks, [&](long c, int) {
+		const auto c0 = std::chrono::steady_clock::now();
 		const long lo = c * chunk, hi = std::min(n, lo + chunk);
 		parts[c].s.clear(); // keeps its capacity: a reused scratch formats into memory it already owns
 		format_range(fi, opt, seg_off, n_seg, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
+		if (trace) busy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count();
 	}, 1);
+	if (trace) fprintf(stderr, "[mm2amd] format: %ld chunks, wall %.3f s, summed chunk time %.3f s on %d threads\n", n_chunks,
+	                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), busy_ns.load() * 1e-9, n_threads);
 	off.assign(n_chunks + 1, 0);
 	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].s.size();
 	return off[n_chunks];
@@ -439,7 +448,7 @@ char *format_batch(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n
 	const size_t total = format_parts(fi, opt, n_threads, n_frag, seg_off, n_seg, seq, n_reg, reg, rep_len, parts, off);
 	char *out = (char *)malloc(total + 1);
 	if (!out) return nullptr;
-	parallel_for(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(out + off[c], parts[c].s.data(), parts[c].s.size()); }, 8);
+	parallel_for_side(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(out + off[c], parts[c].s.data(), parts[c].s.size()); }, 8);
 	out[total] = 0;
 	*out_len = total;
 	return out;
@@ -456,7 +465,7 @@ const char *format_batch_view(const FlatIndex &fi, const MapOpt &opt, int n_thre
 		fs.buf = (char *)malloc(fs.cap);
 		if (!fs.buf) { fs.cap = 0; return nullptr; }
 	}
-	parallel_for(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(fs.buf + off[c], fs.impl->parts[c].s.data(), fs.impl->parts[c].s.size()); }, 8);
+	parallel_for_side(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(fs.buf + off[c], fs.impl->parts[c].s.data(), fs.impl->parts[c].s.size()); }, 8);
 	fs.buf[total] = 0;
 	*out_len = total;
 	return fs.buf;

@@ -230,6 +230,29 @@ __device__ __forceinline__ uint32_t idx_lookup(const DevIndex &I, uint64_t hash,
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int popc_below(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
 
+// Cross-lane moves as DPP / v_readlane instead of ds_bpermute (what __shfl compiles to: an LDS-crossbar round trip per call, and the
+// chaining loops make dozens of dependent ones per step).  gfx9 DPP controls: row_shr:n 0x110+n, wave_shr:1 0x138, row_bcast:15 / 31 0x142 / 0x143.
+__device__ __forceinline__ int32_t wave_prefix_max_i32(int32_t v) // inclusive prefix maximum over the lanes, lane 0 first
+{
+	int32_t o;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v; // lane 15 of rows 0 / 2 into rows 1 / 3
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v; // lane 31 into the upper half
+	return v;
+}
+__device__ __forceinline__ int32_t wave_shr1_i32(int32_t first, int32_t v) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); } // lane i <- v[i-1], lane 0 <- first
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t first, uint64_t v)
+{
+	return (uint64_t)(uint32_t)wave_shr1_i32((int32_t)(uint32_t)first, (int32_t)(uint32_t)v) | (uint64_t)(uint32_t)wave_shr1_i32((int32_t)(uint32_t)(first >> 32), (int32_t)(uint32_t)(v >> 32)) << 32;
+}
+__device__ __forceinline__ int32_t lane_get_i32(int32_t v, int l) { return __builtin_amdgcn_readlane(v, l); } // l wave-uniform
+__device__ __forceinline__ uint64_t lane_get_u64(uint64_t v, int l)
+{
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(v >> 32), l) << 32;
+}
 constexpr int HIST_N = 2048;
 constexpr uint32_t SD_TANDEM = 1u << 8, SD_FLT = 1u << 9, SD_SEG1 = 1u << 31; // SD_SEG1: the seed comes from the second read of a pair
 
@@ -510,7 +533,7 @@ void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const Seed
 // Anchor sort (map.c:202: radix_sort_128x by x, an UNSTABLE in-place sort whose tie order is observable), one workgroup per read.
 //
 // The anchors of a read are contiguous, so the read is the unit: its (x key, original index) pairs go into LDS -- one 64-bit word per
-// anchor, compact key (strand | rid | rpos: 33 + rid_bits bits) above a 13-bit index -- and are sorted there by a bitonic network
+// anchor, compact key (strand | rid | rpos: 33 + rid_bits bits) above a 14-bit index -- and are sorted there by a bitonic network
 // whose compare-exchanges all point the same way, so that positions past the end behave as +infinity and a read of n anchors costs
 // n log^2 n, not that of the next power of two.  One trip through LDS instead of seven radix passes over all anchors through HBM.
 // Where no two anchors of the read share x, the sorted order is unique and therefore the reference's.  Where they do (the same
@@ -526,8 +549,8 @@ __device__ __forceinline__ uint64_t key_to_x(uint64_t key, int rid_bits)
 	return (key >> (32 + rid_bits) & 1ULL) << 63 | low;
 }
 
-constexpr int AS_IDX_BITS = 13;                 // index bits of a packed element
-constexpr int AS_LDS_MAX = 7168;                // anchors of the largest LDS class: 56 KB of elements + 5 KB of tables stay below 64 KB per read
+constexpr int AS_IDX_BITS = 14;                 // index bits of a packed element
+constexpr int AS_LDS_MAX = 10240;               // anchors of the largest LDS class (80 KB of elements: one read per CU at a time, sorted by 1024 threads)
 constexpr int TIE_MAX_KEYS = 64;                // distinct duplicated keys tracked per read; more => every bucket is replayed
 constexpr int AS_STACK = (1 << AS_IDX_BITS) / 65 + 2; // the frames of a replay are disjoint ranges of more than 64 elements
 
@@ -576,18 +599,19 @@ __device__ void bitonic_sort(S s, int32_t n)
 	const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
 	int lp = 1;
 	while ((1 << lp) < n) ++lp;
+	const int32_t n_pairs = 1 << (lp - 1); // pairs of the padded network; a pair whose upper element lies past the end is skipped
 	for (int lk = 1; lk <= lp; ++lk) {
 		const int32_t k = 1 << lk, hk = k >> 1;
-		for (int32_t t = tid;; t += nt) { // mirror: pair t of block b = t / (k/2)
+#pragma unroll 4
+		for (int32_t t = tid; t < n_pairs; t += nt) { // mirror: pair t of block b = t / (k/2)
 			const int32_t blk = t >> (lk - 1), q = t & (hk - 1), i = blk * k + q, l = blk * k + k - 1 - q;
-			if (i >= n) break;
 			if (l < n) s.order(i, l);
 		}
 		__syncthreads();
 		for (int32_t j = k >> 2; j > 0; j >>= 1) {
-			for (int32_t t = tid;; t += nt) {
+#pragma unroll 4
+			for (int32_t t = tid; t < n_pairs; t += nt) {
 				const int32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-				if (i >= n) break;
 				if (l < n) s.order(i, l);
 			}
 			__syncthreads();
@@ -780,11 +804,17 @@ __global__ void __launch_bounds__(64) anchor_heap_order_kernel(SeedChainBuffers 
 }
 
 // the launch classes: reads in `list` are grouped by class, class c holds n_class[c] of them (backend: anchor_sort_class)
-const int kAnchorSortCap[kAnchorSortClasses] = { 1024, 2048, 4096, AS_LDS_MAX, 0 }; // anchors per read an LDS class holds; the last class sorts on global scratch
+// anchors per read an LDS class holds (the last class sorts on global scratch) and the workgroup that sorts it: a step of the network is
+// bound by LDS latency and the barrier, not by issue, so a read gets as many threads as its LDS footprint leaves room for per CU
+// (a 10 kb ONT read has ~7 k anchors against a 3 Gb reference: 57 KB, two workgroups of 512 threads per CU)
+const int kAnchorSortCap[kAnchorSortClasses] = { 1024, 2048, 4096, 7168, AS_LDS_MAX, 0 };
+const int kAnchorSortThreads[kAnchorSortClasses] = { 256, 256, 512, 512, 1024, 1024 };
 
 int anchor_sort_class(uint64_t n_anchors, int rid_bits)
 {
-	if (33 + rid_bits + AS_IDX_BITS > 64) return kAnchorSortClasses - 1; // (more than 2^18 reference sequences: the key does not pack)
+	static const int force = getenv("MM2AMD_SORT_MIN_CLASS") ? atoi(getenv("MM2AMD_SORT_MIN_CLASS")) : 0; // tests: small reads through the large classes' workgroups
+	if (33 + rid_bits + AS_IDX_BITS > 64) return kAnchorSortClasses - 1; // (more than 2^17 reference sequences: the key does not pack)
+	if (force > 0) { for (int c = std::min(force, kAnchorSortClasses - 1); c + 1 < kAnchorSortClasses; ++c) if (n_anchors <= (uint64_t)kAnchorSortCap[c]) return c; return kAnchorSortClasses - 1; }
 	for (int c = 0; c + 1 < kAnchorSortClasses; ++c) if (n_anchors <= (uint64_t)kAnchorSortCap[c]) return c;
 	return kAnchorSortClasses - 1;
 }
@@ -796,14 +826,19 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	KernelProfiler none;
 	if (!kp) kp = &none;
 	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
-	static const char *kNames[kAnchorSortClasses] = { "anchor_sort_kernel[n1k]", "anchor_sort_kernel[n2k]", "anchor_sort_kernel[n4k]", "anchor_sort_kernel[n7k]", "anchor_sort_kernel[global]" };
+	static const char *kNames[kAnchorSortClasses] = { "anchor_sort_kernel[n1k]", "anchor_sort_kernel[n2k]", "anchor_sort_kernel[n4k]", "anchor_sort_kernel[n7k]", "anchor_sort_kernel[n10k]", "anchor_sort_kernel[global]" };
+	static bool attr_set = false;
+	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8)); attr_set = true; }
 	const int heap = (P.flag & ref::F_HEAP_SORT) ? 1 : 0;
 	int first = 0;
 	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
 		if (n_class[c] == 0) continue;
 		kp->begin(s);
-		if (c + 1 < kAnchorSortClasses) hipLaunchKernelGGL((anchor_sort_kernel<64, true>), dim3(n_class[c]), dim3(64), (size_t)kAnchorSortCap[c] * 8, s, B, d_list + first, heap);
-		else hipLaunchKernelGGL((anchor_sort_kernel<1024, false>), dim3(n_class[c]), dim3(1024), 0, s, B, d_list + first, heap);
+		const size_t lds = (size_t)kAnchorSortCap[c] * 8;
+		if (c + 1 == kAnchorSortClasses) hipLaunchKernelGGL((anchor_sort_kernel<1024, false>), dim3(n_class[c]), dim3(1024), 0, s, B, d_list + first, heap);
+		else if (kAnchorSortThreads[c] == 256) hipLaunchKernelGGL((anchor_sort_kernel<256, true>), dim3(n_class[c]), dim3(256), lds, s, B, d_list + first, heap);
+		else if (kAnchorSortThreads[c] == 512) hipLaunchKernelGGL((anchor_sort_kernel<512, true>), dim3(n_class[c]), dim3(512), lds, s, B, d_list + first, heap);
+		else hipLaunchKernelGGL((anchor_sort_kernel<1024, true>), dim3(n_class[c]), dim3(1024), lds, s, B, d_list + first, heap);
 		kp->end(s, kNames[c], 32.0 * anchors_in_class[c]); // 16 B per anchor in, 16 B out (nothing else leaves LDS)
 		HIP_CHECK(hipGetLastError());
 	}
@@ -866,10 +901,10 @@ __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t
 // every cluster head.
 // The look-back window lives in LDS: per wavefront a ring of the last CF_RING anchors -- x, y, chain score f, predecessor p and the
 // "already reached through a better predecessor" mark t of lchain.c:186 -- filled as the blocks of 64 anchors go by.  An anchor
-// older than the ring (a look-back of more than ~450 anchors: tandem repeats, very dense windows) is read from the global arrays
+// older than the ring (a look-back of more than ~200 anchors: tandem repeats, very dense windows) is read from the global arrays
 // as before; where an index lives is a function of the index and the current block only, so marks and scores are never split
 // between the two.  RING = false keeps everything in global memory (A/B checks: MM2AMD_CHAIN_FILL_GLOBAL=1).
-constexpr int CF_RING = 512;
+constexpr int CF_RING = 256;
 
 template <bool PAIRS, bool RING>
 __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
@@ -910,8 +945,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 		auto ap = [&](int64_t j) { return j >= ring_lo ? rp[j & RM] : p[j]; };
 		uint64_t bx = 0, by = 0;
 		if (g < n) { const Anchor v = a[g]; bx = v.x, by = v.y; }
-		uint64_t px = __shfl_up(bx, 1, 64), py = __shfl_up(by, 1, 64); // a[g-1]
-		if (lane == 0) px = last_x, py = last_y;
+		const uint64_t px = wave_shr1_u64(last_x, bx), py = wave_shr1_u64(last_y, by); // a[g-1]
 		const bool iso = g < n && (g == 0 || (bx >> 32 != px >> 32 || bx > px + (uint64_t)(int64_t)max_dist_x));
 		if (iso) f[g] = (int32_t)(by >> 32 & 0xff), p[g] = -1;
 		if (RING && g < n) {
@@ -925,10 +959,10 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 			const int bl = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
 			const int64_t i = blk + bl;
-			const uint64_t ix = __shfl(bx, bl, 64), iy = __shfl(by, bl, 64);
+			const uint64_t ix = lane_get_u64(bx, bl), iy = lane_get_u64(by, bl);
 			const bool head_before = bl == 0 ? last_iso : (iso_mask >> (bl - 1) & 1) != 0; // a[i-1] isolated: a cluster starts here
 			if (head_before) { // the state the sequential loop is in right after an isolated anchor (see above)
-				const uint64_t hx = __shfl(px, bl, 64), hy = __shfl(py, bl, 64);
+				const uint64_t hx = lane_get_u64(px, bl), hy = lane_get_u64(py, bl);
 				st = i - 1, max_ii = i - 1, mii_x = hx, mii_y = hy, mii_f = (int32_t)(hy >> 32 & 0xff);
 			}
 			// advance the window start (lchain.c:172): first st in [st,i) on the same target/strand within max_dist_x
@@ -955,10 +989,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				}
 				const bool has = sc != INT32_MIN;
 				// exclusive prefix maximum in processing order (lane 0 first)
-				int32_t pm = has ? sc : INT32_MIN;
-				for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(pm, o, 64); if (lane >= o) pm = v > pm ? v : pm; }
-				int32_t excl = __shfl_up(pm, 1, 64);
-				if (lane == 0) excl = INT32_MIN;
+				int32_t excl = wave_shr1_i32(INT32_MIN, wave_prefix_max_i32(has ? sc : INT32_MIN));
 				excl = excl > max_f ? excl : max_f;
 				const bool improve = has && sc > excl;
 				// marks left by predecessors examined earlier in this iteration (lchain.c:186)
@@ -981,7 +1012,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				}
 				if (imp) { // improvements are increasing, so the last one before the stop holds the running maximum
 					const int last = 63 - __clzll((long long)imp);
-					max_f = __shfl(sc, last, 64);
+					max_f = lane_get_i32(sc, last);
 					max_j = base - last;
 				}
 			}
@@ -1011,7 +1042,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 		}
 		// carry the block's last anchor (and whether it was isolated) into the next block
 		const int last_lane = (int)((n - blk < 64 ? n - blk : 64) - 1);
-		last_x = __shfl(bx, last_lane, 64), last_y = __shfl(by, last_lane, 64);
+		last_x = lane_get_u64(bx, last_lane), last_y = lane_get_u64(by, last_lane);
 		last_iso = (iso_mask >> last_lane & 1) != 0;
 	}
 }
@@ -1234,8 +1265,12 @@ void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void 
 // Per-read scratch lives in arrays that are dead by now (the pre/post-sort key/value arrays and t[]); results go to dense
 // output arrays through two atomic cursors.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int BT_LDS_CAP = 1024; // chain ends (or chains) whose sort runs in LDS
-constexpr int BT_STACK = 320;
+#ifndef MM2AMD_BT_LDS_CAP
+#define MM2AMD_BT_LDS_CAP 512
+#endif
+constexpr int BT_LDS_CAP = MM2AMD_BT_LDS_CAP; // chain ends (or chains) whose sort runs in LDS (tools/sanitize_emu.sh builds with a tiny one, so that every read takes the global-scratch path)
+constexpr int BT_STACK = BT_LDS_CAP / 65 + 2; // frames are disjoint ranges of more than 64 elements
+constexpr int BT_PATH_CAP = 2048;             // anchors of a walk recorded in LDS (longer chains chase on through global memory)
 
 __device__ void bt_sort(uint64_t *K, uint32_t *I, int32_t n, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask, TieFrame *stack, int stack_cap)
 {
@@ -1248,6 +1283,7 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	__shared__ uint32_t lI[BT_LDS_CAP];
 	__shared__ uint32_t cnt[256], head[256], start[256], child_mask[8];
 	__shared__ TieFrame stack[BT_STACK];
+	__shared__ int32_t path[BT_PATH_CAP];
 	__shared__ int32_t s_nu, s_nv;
 	__shared__ uint64_t s_aoff, s_uoff;
 	const int lane = threadIdx.x;
@@ -1287,31 +1323,59 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	__threadfence_block();
 	__syncthreads();
 	// ---- walk the ends best-first, claim anchors (lchain.c:57-72 with mg_chain_bk_end inlined) ----
-	if (lane == 0) {
-		int32_t n_v = 0, n_u = 0;
-		for (int32_t k = n_z - 1; k >= 0; --k) {
-			const int32_t zi = (int32_t)I[k], zx = (int32_t)K[k];
-			if (t[zi] != 0) continue;
-			// where the chain is cut: an anchor already claimed, or a score drop of more than max_drop below the running peak
-			int32_t i = zi, end_i = -1, max_i = zi, max_s = 0;
-			do {
-				t[i] = 2;
-				end_i = i = p[i];
-				const int32_t sc = i < 0 ? zx : zx - f[i];
-				if (sc > max_s) max_s = sc, max_i = i;
-				else if (max_s - sc > max_drop) break;
-			} while (i >= 0 && t[i] == 0);
-			for (i = zi; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
-			const int32_t n_v0 = n_v;
-			for (i = zi; i != max_i; i = p[i]) v[n_v++] = i, t[i] = 1;
-			const int32_t sc = i < 0 ? zx : zx - f[i];
-			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)(n_v - n_v0);
-			else n_v = n_v0;
+	// Most ends lie on a chain that a better end has already claimed, so the ends are screened 64 at a time (one load of t[] per lane
+	// instead of one dependent load after the other); only an end that is still free is walked.  The walk is ONE pointer chase by lane 0
+	// -- p, f and t of the next anchor are three independent loads, one round trip per step -- that records the path in LDS; where the
+	// chain is cut is known when it ends (the reference marks the path, finds the cut, unmarks, and walks again to collect), and the
+	// anchors up to the cut are then claimed by all lanes at once.  p[i] < i, so a walk never meets its own anchors: no marks needed.
+	int32_t n_v = 0, n_u_acc = 0; // identical in all lanes
+	for (int32_t k0 = n_z - 1; k0 >= 0; k0 -= 64) {
+		const int32_t k = k0 - lane;
+		int32_t zi = 0, zx = 0;
+		if (k >= 0) zi = (int32_t)I[k], zx = (int32_t)K[k];
+		unsigned long long todo = __ballot(k >= 0 && t[zi] == 0);
+		while (todo) {
+			const int src = __ffsll((long long)todo) - 1; // lowest lane = largest k: the best-scoring end first
+			const int32_t czi = __shfl(zi, src, 64), czx = __shfl(zx, src, 64);
+			int32_t keep = 0, max_s = 0;
+			if (lane == 0) {
+				int32_t i = czi, pi = p[czi], len = 0;
+				for (;;) {
+					if (len < BT_PATH_CAP) path[len] = i;
+					++len;
+					const int32_t nxt = pi;
+					int32_t fn = 0, tn = 0, pn = -1;
+					if (nxt >= 0) fn = f[nxt], tn = t[nxt], pn = p[nxt];
+					const int32_t sc = nxt < 0 ? czx : czx - fn;
+					if (sc > max_s) max_s = sc, keep = len; // the cut moves to just before nxt: the len anchors walked so far are kept
+					else if (max_s - sc > max_drop) break;
+					if (nxt < 0 || tn != 0) break;          // the chain's start, or an anchor another chain has claimed
+					i = nxt, pi = pn;
+				}
+			}
+			keep = __builtin_amdgcn_readfirstlane(keep), max_s = __builtin_amdgcn_readfirstlane(max_s);
+			WAVE_SYNC();
+			const int32_t n_rec = keep < BT_PATH_CAP ? keep : BT_PATH_CAP;
+			for (int32_t q = lane; q < n_rec; q += 64) { const int32_t idx = path[q]; v[n_v + q] = idx, t[idx] = 1; }
+			if (keep > BT_PATH_CAP && lane == 0) { // longer than the recorded part (whole contigs as queries): chase on from its last anchor
+				int32_t i = p[path[BT_PATH_CAP - 1]];
+				for (int32_t q = BT_PATH_CAP; q < keep; ++q) { v[n_v + q] = i, t[i] = 1; i = p[i]; }
+			}
+			if (max_s >= min_sc && keep > 0 && keep >= min_cnt) { // (a rejected chain keeps its anchors claimed, lchain.c:66-67)
+				if (lane == 0) u[n_u_acc] = (uint64_t)(uint32_t)max_s << 32 | (uint64_t)(uint32_t)keep;
+				++n_u_acc, n_v += keep;
+			}
+			__threadfence_block();
+			WAVE_SYNC();
+			todo &= ~((2ull << src) - 1ull);
+			todo = __ballot((todo >> lane & 1ull) != 0 && t[zi] == 0); // which of the block's remaining ends are still free
 		}
-		s_nu = n_u, s_nv = n_v;
+	}
+	if (lane == 0) {
+		s_nu = n_u_acc, s_nv = n_v;
 		s_aoff = n_v ? atomicAdd((unsigned long long *)&B.bt_cursor[0], (unsigned long long)n_v) : 0;
-		s_uoff = n_u ? atomicAdd((unsigned long long *)&B.bt_cursor[1], (unsigned long long)n_u) : 0;
-		B.bt_nu[r] = n_u, B.bt_nv[r] = n_v, B.bt_aoff[r] = s_aoff, B.bt_uoff[r] = s_uoff;
+		s_uoff = n_u_acc ? atomicAdd((unsigned long long *)&B.bt_cursor[1], (unsigned long long)n_u_acc) : 0;
+		B.bt_nu[r] = n_u_acc, B.bt_nv[r] = n_v, B.bt_aoff[r] = s_aoff, B.bt_uoff[r] = s_uoff;
 	}
 	__threadfence_block();
 	__syncthreads();

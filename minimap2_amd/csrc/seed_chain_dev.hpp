@@ -67,7 +67,7 @@ void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const Seed
 class KernelProfiler;
 // the per-read anchor sort's launch classes (by anchors per read; the last one sorts on global scratch): `list` holds the reads grouped
 // by class, n_class[c] of them in class c, carrying anchors_in_class[c] anchors
-constexpr int kAnchorSortClasses = 5;
+constexpr int kAnchorSortClasses = 6;
 int anchor_sort_class(uint64_t n_anchors, int rid_bits);
 void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, const uint32_t *d_list, const int *n_class, const double *anchors_in_class, void *stream,
                         KernelProfiler *kp);

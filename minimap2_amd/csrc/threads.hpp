@@ -19,10 +19,13 @@ namespace mm2amd {
 
 class ThreadPool {
 public:
-	static ThreadPool &instance()
+	// pool 0: the mapper's host stages; pool 1: the pipeline's other steps (hand-over packing, output formatting), which run BESIDE
+	// the mapping of another batch and must not take its workers (a mapping loop waiting behind millisecond-long formatting chunks
+	// leaves the GPU idle)
+	static ThreadPool &instance(int which = 0)
 	{
-		static ThreadPool p;
-		return p;
+		static ThreadPool p[2];
+		return p[which ? 1 : 0];
 	}
 	// Runs fn(i, tid) for i in [0,n) on up to n_threads threads (the caller is one of them); tid < n_threads.
 	void run(int n_threads, long n, const std::function<void(long, int)> &fn, long chunk)
@@ -146,7 +149,12 @@ private:
 // Runs fn(i, tid) for i in [0,n) on n_threads threads with dynamic chunking; rethrows the first exception.
 inline void parallel_for(int n_threads, long n, const std::function<void(long, int)> &fn, long chunk = 16)
 {
-	ThreadPool::instance().run(n_threads, n, fn, chunk);
+	ThreadPool::instance(0).run(n_threads, n, fn, chunk);
+}
+// the same on the pool of the pipeline's side steps (hand-over, output stage)
+inline void parallel_for_side(int n_threads, long n, const std::function<void(long, int)> &fn, long chunk = 16)
+{
+	ThreadPool::instance(1).run(n_threads, n, fn, chunk);
 }
 
 } // namespace mm2amd

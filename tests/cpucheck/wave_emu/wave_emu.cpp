@@ -107,14 +107,17 @@ void complete(Wave &wv)
 	case OP_DPP:
 		for (int l = 0; l < 64; ++l) {
 			if (!(m >> l & 1)) continue;
-			const int ctrl = (int)wv.arg[l];
+			const int ctrl = (int)wv.arg[l] & 0xffff, row_mask = (int)wv.arg[l] >> 16 & 0xf;
 			const uint32_t old = (uint32_t)(wv.val[l] >> 32);
 			int src = -1;
+			if (!(row_mask >> (l >> 4) & 1)) { out[l] = old; continue; }
 			if (ctrl == 0x138) src = l - 1;                                   // wave_shr:1
 			else if (ctrl == 0x13c) src = (l + 63) & 63;                       // wave_ror:1
 			else if (ctrl == 0x130) src = l + 1 < 64 ? l + 1 : -1;             // wave_shl:1
 			else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl & 15; src = (l & 15) >= n ? l - n : -1; } // row_shr:n
 			else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl & 15; src = (l & 15) + n < 16 ? l + n : -1; } // row_shl:n
+			else if (ctrl == 0x142) src = l >= 16 ? (l & ~15) - 1 : -1;        // row_bcast:15: lane 15 of the row before
+			else if (ctrl == 0x143) src = l >= 32 ? (l & ~31) - 1 : -1;        // row_bcast:31: lane 31 to the upper half
 			else { fprintf(stderr, "[wave_emu] DPP control 0x%x is not emulated\n", ctrl); abort(); }
 			out[l] = src >= 0 && (m >> src & 1) ? (uint32_t)wv.val[src] : old;
 		}

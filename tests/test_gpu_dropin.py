@@ -75,6 +75,19 @@ def test_one_by_one_calls_on_gpu(tmp_path):
     assert got == open(os.path.join(HERE, "golden", "inv_paf.out"), "rb").read()
 
 
+def test_anchor_sort_classes_and_chain_fill_variants(tmp_path):
+    """anchor_sort_kernel's launch classes (256 / 512 / 1024 threads in LDS, 1024 threads on global scratch: MM2AMD_SORT_MIN_CLASS pushes small
+    reads through the large ones) with and without duplicated keys, and chain_fill_kernel with its LDS window against the all-global variant"""
+    ref, reads, _, _ = synth.make("ont", str(tmp_path / "o"), 4, 150, 19)
+    ref_w, reads_w = synth.make_weird(str(tmp_path / "w"))
+    for r, q, extra in ((ref, reads, ["-x", "map-ont", "-a"]), (ref_w, reads_w, ["-x", "map-ont", "-c"])):
+        want, _ = _run([REF_BIN, "-t", "8"] + extra + [r, q])
+        for env in ({"MM2AMD_SORT_MIN_CLASS": "2"}, {"MM2AMD_SORT_MIN_CLASS": "4"}, {"MM2AMD_SORT_MIN_CLASS": "5"}, {"MM2AMD_CHAIN_FILL_GLOBAL": "1"}):
+            p = subprocess.run([DROPIN, "-t", "8"] + extra + [r, q], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert p.returncode == 0, p.stderr.decode()[-1000:]
+            assert b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")) == want, env
+
+
 def test_ont_sam_identical(tmp_path):
     assert _compare(tmp_path, "ont", "map-ont", 8, 400, 11, ["-a"]) > 1000
 
