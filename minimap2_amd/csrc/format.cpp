@@ -29,7 +29,10 @@ constexpr int64_t F_OUT_CG = 0x020, F_OUT_CS = 0x040, F_OUT_CS_LONG = 0x800, F_L
 	F_OUT_JUNC = 0x10000000000LL;
 const char kCigarOps[] = "MIDNSHP=XB";
 
-struct Text { // append-only byte buffer
+// append-only byte buffer.  One per chunk of fragments, in a vector, each filled by a different pool thread: the object is padded to
+// two cache lines, because std::string updates its length field on EVERY appended byte and neighbouring objects sharing a line made 64
+// threads on two sockets ping-pong it -- 20-40 ns per byte instead of 1.3 (profiles/r03: 25-50 core-seconds per Gbase of reads).
+struct alignas(128) Text {
 	std::string s;
 	void ch(char c) { s.push_back(c); }
 	void str(const char *p) { s.append(p); }

@@ -243,6 +243,16 @@ __device__ __forceinline__ int32_t wave_prefix_max_i32(int32_t v) // inclusive p
 	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v; // lane 31 into the upper half
 	return v;
 }
+__device__ __forceinline__ uint32_t wave_prefix_add_u32(uint32_t v) // inclusive prefix sum over the lanes
+{
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x111, 0xf, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x112, 0xf, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x114, 0xf, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x118, 0xf, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x142, 0xa, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x143, 0xc, 0xf, false);
+	return v;
+}
 __device__ __forceinline__ int32_t wave_shr1_i32(int32_t first, int32_t v) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); } // lane i <- v[i-1], lane 0 <- first
 __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t first, uint64_t v)
 {
@@ -533,15 +543,15 @@ void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const Seed
 // Anchor sort (map.c:202: radix_sort_128x by x, an UNSTABLE in-place sort whose tie order is observable), one workgroup per read.
 //
 // The anchors of a read are contiguous, so the read is the unit: its (x key, original index) pairs go into LDS -- one 64-bit word per
-// anchor, compact key (strand | rid | rpos: 33 + rid_bits bits) above a 14-bit index -- and are sorted there by a bitonic network
-// whose compare-exchanges all point the same way, so that positions past the end behave as +infinity and a read of n anchors costs
-// n log^2 n, not that of the next power of two.  One trip through LDS instead of seven radix passes over all anchors through HBM.
+// anchor, compact key (strand | rid | rpos: 33 + rid_bits bits) above a 14-bit index -- and are sorted there by a stable LSD radix sort
+// (lds_radix_sort: five 8-bit passes for a 38-bit key, elements held in registers between a pass's read and write, so one LDS buffer
+// suffices).  One trip through LDS instead of seven radix passes over all anchors through HBM.
 // Where no two anchors of the read share x, the sorted order is unique and therefore the reference's.  Where they do (the same
 // reference position hit from two query positions: tandem repeats inside the read), the order of the equal anchors is whatever the
 // reference's in-place MSD radix sort (ksort.h:101-151) leaves, which depends on the whole array: the same workgroup then reloads the
 // read in its ORIGINAL order and replays that sort permutation-exactly (tie_exact_replay), restricted to the chain of buckets that
-// lead to duplicated keys, and rewrites the anchors that carry one.  Reads with more anchors than the LDS classes hold run the same
-// code on global scratch with a larger workgroup (whole contigs as queries; rare).
+// lead to duplicated keys, and rewrites the anchors that carry one.  Reads with more anchors than the LDS classes hold (whole contigs
+// as queries; rare) are sorted on global scratch by a comparison network (bitonic_sort) and replayed there.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t key_to_x(uint64_t key, int rid_bits)
 {
@@ -616,6 +626,72 @@ __device__ void bitonic_sort(S s, int32_t n)
 			}
 			__syncthreads();
 		}
+	}
+}
+
+// LSD radix sort of the packed elements E[0..n) in LDS by the key above the index bits, 8 bits per pass, stable, by a workgroup of T
+// threads; ONE buffer: a pass reads every element into registers (R per lane), ranks it, and writes it back to its new place after a
+// barrier.  The array is cut into one contiguous segment per wavefront and a segment is walked in rounds of 64 consecutive elements
+// (lane = position), so "earlier in the array" is (wave, round, lane) order and an element's rank among those with its digit is
+//   base[digit][wave]  (digits below it, and its digit in the waves before: a scan over the per-wave counters)
+// + count of its digit in the wave's earlier rounds  (the wave's counter when the round reaches it)
+// + lanes below it in its round with the same digit  (the lanes holding a digit are found with eight ballots).
+// Five passes for a 38-bit key: ~3 % of the LDS traffic of a comparison network over the same array.
+template <int T, int R>
+__device__ void lds_radix_sort(uint64_t *E, int32_t n, int key_bits, uint32_t *tab /* [T / 64][256] */, uint32_t *dig_tot /* [256] */)
+{
+	static_assert(T >= 256 && T % 64 == 0, "the 256 digits are scanned by the first 256 threads");
+	constexpr int NW = T / 64;
+	const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int32_t seg = (n + NW - 1) / NW, w0 = w * seg, w1 = w0 + seg < n ? w0 + seg : n; // seg <= R * 64 (the launch classes see to it)
+	uint32_t *const mine = tab + w * 256;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	for (int shift = AS_IDX_BITS; shift < AS_IDX_BITS + key_bits; shift += 8) {
+		uint64_t x[R];
+		uint32_t rk[R];
+		for (int k = lane; k < 256; k += 64) mine[k] = 0;
+		WAVE_SYNC();
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			const int32_t i = w0 + r * 64 + lane;
+			const bool ok = i < w1;
+			x[r] = ok ? E[i] : 0ull;
+			const uint32_t d = (uint32_t)(x[r] >> shift) & 255u;
+			unsigned long long same = __ballot(ok); // the valid lanes of this round that hold the same digit
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const unsigned long long bal = __ballot((d >> b & 1u) != 0);
+				same &= (d >> b & 1u) ? bal : ~bal;
+			}
+			const uint32_t before = (uint32_t)__popcll(same & below);
+			uint32_t old = 0;
+			if (ok) old = mine[d];
+			MM2_LOCKSTEP(); // every lane has read its digit's counter before the digit's first lane moves it on
+			if (ok && before == 0) mine[d] = old + (uint32_t)__popcll(same);
+			WAVE_SYNC();
+			rk[r] = old + before;
+		}
+		__syncthreads();
+		if (tid < 256) { // a digit's counts over the waves become the waves' offsets inside the digit; its total goes to the scan
+			uint32_t acc = 0;
+#pragma unroll
+			for (int ww = 0; ww < NW; ++ww) { const uint32_t c = tab[ww * 256 + tid]; tab[ww * 256 + tid] = acc; acc += c; }
+			dig_tot[tid] = acc;
+		}
+		__syncthreads();
+		if (w == 0) { // exclusive scan of the 256 totals: four per lane
+			const uint32_t a0 = dig_tot[lane * 4], a1 = dig_tot[lane * 4 + 1], a2 = dig_tot[lane * 4 + 2], a3 = dig_tot[lane * 4 + 3];
+			const uint32_t sum = a0 + a1 + a2 + a3, excl = wave_prefix_add_u32(sum) - sum;
+			MM2_LOCKSTEP();
+			dig_tot[lane * 4] = excl, dig_tot[lane * 4 + 1] = excl + a0, dig_tot[lane * 4 + 2] = excl + a0 + a1, dig_tot[lane * 4 + 3] = excl + a0 + a1 + a2;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			const int32_t i = w0 + r * 64 + lane;
+			if (i < w1) { const uint32_t d = (uint32_t)(x[r] >> shift) & 255u; E[dig_tot[d] + mine[d] + rk[r]] = x[r]; }
+		}
+		__syncthreads();
 	}
 }
 
@@ -704,14 +780,16 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 	}
 }
 
-template <int THREADS, bool IN_LDS>
-__global__ void __launch_bounds__(THREADS) anchor_sort_kernel(SeedChainBuffers B, const uint32_t *list, int heap_sort)
+template <int THREADS, int ROUNDS, bool IN_LDS>
+__global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS <= 7) ? 2 : 1) anchor_sort_kernel( // (the 7 k class: two workgroups per CU, 64 VGPRs)SeedChainBuffers B, const uint32_t *list, int heap_sort)
 {
 	MM2_DYN_LDS(uint64_t, as_lds); // IN_LDS: the read's packed elements
-	__shared__ uint32_t cnt[256], head[256], start[256], child_mask[8];
+	__shared__ uint32_t tab[(THREADS / 64) * 256]; // the radix passes' per-wave digit counters; afterwards the replay's three 256-entry tables
+	__shared__ uint32_t dig_tot[256], child_mask[8];
 	__shared__ uint64_t tied[TIE_MAX_KEYS];
 	__shared__ TieFrame lstack[AS_STACK];
 	__shared__ uint32_t n_tied_s;
+	uint32_t *const cnt = tab, *const head = tab + 256, *const start = tab + 512;
 	const int32_t tid = (int32_t)threadIdx.x;
 	const int r = (int)list[blockIdx.x];
 	const uint64_t ao = B.a_off[r];
@@ -724,7 +802,8 @@ __global__ void __launch_bounds__(THREADS) anchor_sort_kernel(SeedChainBuffers B
 		for (int32_t i = tid; i < n; i += THREADS) s.set(i, kin[i], (uint32_t)i);
 		if (tid == 0) n_tied_s = 0;
 		__syncthreads();
-		bitonic_sort(s, n);
+		if constexpr (IN_LDS) lds_radix_sort<THREADS, ROUNDS>(as_lds, n, 33 + B.rid_bits, tab, dig_tot); // stable: equal keys stay in index order
+		else bitonic_sort(s, n);
 		// 2. the anchors in sorted order; which keys occur more than once
 		for (int32_t i = tid; i < n; i += THREADS) {
 			const uint64_t x = s.xkey(i);
@@ -804,11 +883,10 @@ __global__ void __launch_bounds__(64) anchor_heap_order_kernel(SeedChainBuffers 
 }
 
 // the launch classes: reads in `list` are grouped by class, class c holds n_class[c] of them (backend: anchor_sort_class)
-// anchors per read an LDS class holds (the last class sorts on global scratch) and the workgroup that sorts it: a step of the network is
-// bound by LDS latency and the barrier, not by issue, so a read gets as many threads as its LDS footprint leaves room for per CU
-// (a 10 kb ONT read has ~7 k anchors against a 3 Gb reference: 57 KB, two workgroups of 512 threads per CU)
+// anchors per read an LDS class holds (the last class sorts on global scratch with the comparison network) and the workgroup that sorts
+// it (a 10 kb ONT read has ~7 k anchors against a 3 Gb reference: 56 KB of elements + 20 KB of tables, two workgroups of 1024 threads per CU)
 const int kAnchorSortCap[kAnchorSortClasses] = { 1024, 2048, 4096, 7168, AS_LDS_MAX, 0 };
-const int kAnchorSortThreads[kAnchorSortClasses] = { 256, 256, 512, 512, 1024, 1024 };
+// workgroups: 256, 256, 512, 1024, 1024 threads (4, 8, 8, 7, 10 rounds of 64 elements per wave); 1024 for the global class
 
 int anchor_sort_class(uint64_t n_anchors, int rid_bits)
 {
@@ -828,17 +906,20 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
 	static const char *kNames[kAnchorSortClasses] = { "anchor_sort_kernel[n1k]", "anchor_sort_kernel[n2k]", "anchor_sort_kernel[n4k]", "anchor_sort_kernel[n7k]", "anchor_sort_kernel[n10k]", "anchor_sort_kernel[global]" };
 	static bool attr_set = false;
-	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8)); attr_set = true; }
+	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8)); attr_set = true; }
 	const int heap = (P.flag & ref::F_HEAP_SORT) ? 1 : 0;
 	int first = 0;
 	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
 		if (n_class[c] == 0) continue;
 		kp->begin(s);
 		const size_t lds = (size_t)kAnchorSortCap[c] * 8;
-		if (c + 1 == kAnchorSortClasses) hipLaunchKernelGGL((anchor_sort_kernel<1024, false>), dim3(n_class[c]), dim3(1024), 0, s, B, d_list + first, heap);
-		else if (kAnchorSortThreads[c] == 256) hipLaunchKernelGGL((anchor_sort_kernel<256, true>), dim3(n_class[c]), dim3(256), lds, s, B, d_list + first, heap);
-		else if (kAnchorSortThreads[c] == 512) hipLaunchKernelGGL((anchor_sort_kernel<512, true>), dim3(n_class[c]), dim3(512), lds, s, B, d_list + first, heap);
-		else hipLaunchKernelGGL((anchor_sort_kernel<1024, true>), dim3(n_class[c]), dim3(1024), lds, s, B, d_list + first, heap);
+		const dim3 grid(n_class[c]);
+		if (c == 0) hipLaunchKernelGGL((anchor_sort_kernel<256, 4, true>), grid, dim3(256), lds, s, B, d_list + first, heap);
+		else if (c == 1) hipLaunchKernelGGL((anchor_sort_kernel<256, 8, true>), grid, dim3(256), lds, s, B, d_list + first, heap);
+		else if (c == 2) hipLaunchKernelGGL((anchor_sort_kernel<512, 8, true>), grid, dim3(512), lds, s, B, d_list + first, heap);
+		else if (c == 3) hipLaunchKernelGGL((anchor_sort_kernel<1024, 7, true>), grid, dim3(1024), lds, s, B, d_list + first, heap);
+		else if (c == 4) hipLaunchKernelGGL((anchor_sort_kernel<1024, 10, true>), grid, dim3(1024), lds, s, B, d_list + first, heap);
+		else hipLaunchKernelGGL((anchor_sort_kernel<1024, 1, false>), grid, dim3(1024), 0, s, B, d_list + first, heap);
 		kp->end(s, kNames[c], 32.0 * anchors_in_class[c]); // 16 B per anchor in, 16 B out (nothing else leaves LDS)
 		HIP_CHECK(hipGetLastError());
 	}
