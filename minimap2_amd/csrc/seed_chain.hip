@@ -781,7 +781,7 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 }
 
 template <int THREADS, int ROUNDS, bool IN_LDS>
-__global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS <= 7) ? 2 : 1) anchor_sort_kernel( // (the 7 k class: two workgroups per CU, 64 VGPRs)SeedChainBuffers B, const uint32_t *list, int heap_sort)
+__global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS <= 7) ? 8 : 4) /* (waves per SIMD) the 7 k class: two workgroups of 1024 per CU, 64 VGPRs */ anchor_sort_kernel(SeedChainBuffers B, const uint32_t *list, int heap_sort)
 {
 	MM2_DYN_LDS(uint64_t, as_lds); // IN_LDS: the read's packed elements
 	__shared__ uint32_t tab[(THREADS / 64) * 256]; // the radix passes' per-wave digit counters; afterwards the replay's three 256-entry tables
