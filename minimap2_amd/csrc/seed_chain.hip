@@ -1114,12 +1114,15 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				const int32_t tmp = link_score<PAIRS>(ix, iy, mii_x, mii_y, max_dist_x, max_dist_y, bw, P.chn_pen_gap, P.chn_pen_skip, P.is_cdna, n_seg);
 				if (tmp != INT32_MIN && max_f < tmp + mii_f) max_f = tmp + mii_f, max_j = max_ii;
 			}
-			if (lane == 0) {
-				f[i] = max_f, p[i] = (int32_t)max_j;
-				if (RING) rf[i & RM] = max_f, rp[i & RM] = (int32_t)max_j;
-			}
-			__threadfence_block();
+			// The member's result: with the ring it stays in LDS until the block is done (a global store here would have to be waited
+			// for before the next member reads it back through the fence: microseconds per anchor of a chain)
+			if (RING) { if (lane == 0) rf[i & RM] = max_f, rp[i & RM] = (int32_t)max_j; WAVE_SYNC(); }
+			else { if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j; __threadfence_block(); }
 			if (max_ii < 0 || (ix - mii_x <= (uint64_t)(int64_t)max_dist_x && mii_f < max_f)) max_ii = i, mii_x = ix, mii_y = iy, mii_f = max_f;
+		}
+		if (RING) { // the block's chain scores and predecessors go to the global arrays in one coalesced store (isolated anchors have theirs already)
+			if (g < n && !iso) f[g] = rf[g & RM], p[g] = rp[g & RM];
+			__threadfence_block(); // a later block reads them from there once they have left the ring
 		}
 		// carry the block's last anchor (and whether it was isolated) into the next block
 		const int last_lane = (int)((n - blk < 64 ? n - blk : 64) - 1);
