@@ -298,9 +298,14 @@ def main():
         del step_done[:]
         barrier()
         t = time.time()
-        al.pipeline(batches, text=True, on_mapped=on_mapped, on_text=lambda b_, addr, ln: step_done.append((time.time(), ln)))
+        trace = []
+        al.pipeline(batches, text=True, on_mapped=on_mapped, on_text=lambda b_, addr, ln: step_done.append((time.time(), ln)), trace=trace)
         barrier()
-        return time.time() - t
+        dt = time.time() - t
+        if rank == 0 and os.environ.get("MM2AMD_BENCH_TRACE"):  # when each step of each batch ran, relative to the start of the clock
+            for name, k, a0, a1 in sorted(trace, key=lambda x: x[2]):
+                log("  %-6s batch %2d  %7.3f .. %7.3f  (%.3f s)" % (name, k, a0 - t, a1 - t, a1 - a0))
+        return dt
 
     if a.warmup > 0:
         dt = run_steps(range(a.warmup))

@@ -362,15 +362,17 @@ class Aligner(object):
         _check(lib().mm_gpu_batch_stage(b.n, b.seg_off, b.n_seg, b.arr))
         self._staged = (b.n, b.arr, b.items, b.seg_off, b.n_seg)
 
-    def pipeline(self, batches, text=True, on_mapped=None, on_text=None):
+    def pipeline(self, batches, text=True, on_mapped=None, on_text=None, trace=None):
         """The reference's three-step pipeline (map.c:541-643) over an iterable of Batch objects, every step on a thread of its own so
         that the steps of successive batches overlap: hand-over (mm_gpu_batch_stage_queued: pack + H2D beside the mapping of the batch
         before), mapping (mm_gpu_map_staged), output stage (mm_gpu_format_batch_view: SAM / PAF text of the batch in a reused buffer).
         on_mapped(batch, n_reg, reg, rep_len) runs on the output thread before formatting (e.g. the multi-GPU hit gather);
         on_text(batch, address, length) receives the text (valid until the next batch's).  Hit records are freed after on_text.
+        trace: a list that receives (step, batch number, start, end) wall-clock intervals of the three steps.
         Returns the number of text bytes produced."""
         import queue
         import threading
+        import time
         self._active()
         L = lib()
         q_staged, q_mapped = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
@@ -378,10 +380,13 @@ class Aligner(object):
 
         def stager():
             try:
-                for b in batches:
+                for k, b in enumerate(batches):
                     if errors:
                         break
+                    t0 = time.time()
                     _check(L.mm_gpu_batch_stage_queued(b.n, b.seg_off, b.n_seg, b.arr))
+                    if trace is not None:
+                        trace.append(("stage", k, t0, time.time()))
                     q_staged.put(b)
             except Exception as e:  # noqa: BLE001
                 errors.append(e)
@@ -389,13 +394,18 @@ class Aligner(object):
 
         def mapper():
             try:
+                k = 0
                 while True:
                     b = q_staged.get()
                     if b is None:
                         break
                     m = max(1, len(b.items))
                     n_reg, reg, rep_len, frag_gap = (C.c_int * m)(), (C.c_void_p * m)(), (C.c_int * m)(), (C.c_int * m)()
+                    t0 = time.time()
                     _check(L.mm_gpu_map_staged(n_reg, reg, rep_len, frag_gap))
+                    if trace is not None:
+                        trace.append(("map", k, t0, time.time()))
+                    k += 1
                     q_mapped.put((b, n_reg, reg, rep_len))
             except Exception as e:  # noqa: BLE001
                 errors.append(e)
@@ -409,11 +419,14 @@ class Aligner(object):
             q_mapped.put(None)
 
         def output():
+            k = -1
             while True:
                 it = q_mapped.get()
                 if it is None:
                     break
                 b, n_reg, reg, rep_len = it
+                k += 1
+                t0 = time.time()
                 try:
                     if not errors:
                         if on_mapped:
@@ -426,7 +439,10 @@ class Aligner(object):
                                 on_text(b, out.value, out_len.value)
                 except Exception as e:  # noqa: BLE001
                     errors.append(e)
+                t1 = time.time()
                 L.mm2amd_free_regs(len(n_reg), n_reg, reg)
+                if trace is not None:
+                    trace.append(("output", k, t0, t1)), trace.append(("free", k, t1, time.time()))
 
         th = [threading.Thread(target=f) for f in (stager, mapper, output)]
         for t in th:

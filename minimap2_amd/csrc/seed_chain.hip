@@ -907,7 +907,8 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	static const char *kNames[kAnchorSortClasses] = { "anchor_sort_kernel[n1k]", "anchor_sort_kernel[n2k]", "anchor_sort_kernel[n4k]", "anchor_sort_kernel[n7k]", "anchor_sort_kernel[n10k]", "anchor_sort_kernel[global]" };
 	static bool attr_set = false;
 	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8)); attr_set = true; }
-	const int heap = (P.flag & ref::F_HEAP_SORT) ? 1 : 0;
+	static const bool no_replay = getenv("MM2AMD_SORT_NO_REPLAY") != nullptr; // TIMING ONLY (tools/r03_call5.sh): reads with duplicated keys keep the sorted order -- not the reference's
+	const int heap = (P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0;
 	int first = 0;
 	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
 		if (n_class[c] == 0) continue;
@@ -923,7 +924,7 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 		kp->end(s, kNames[c], 32.0 * anchors_in_class[c]); // 16 B per anchor in, 16 B out (nothing else leaves LDS)
 		HIP_CHECK(hipGetLastError());
 	}
-	if (heap) { // equal-x order of the heap merge instead of the radix sort's
+	if (P.flag & ref::F_HEAP_SORT) { // equal-x order of the heap merge instead of the radix sort's
 		kp->begin(s);
 		hipLaunchKernelGGL(anchor_heap_order_kernel, dim3(std::min((B.n_reads + 63) / 64, 4096)), dim3(64), 0, s, B, I, P);
 		kp->end(s, "anchor_heap_order_kernel", 0.0);
