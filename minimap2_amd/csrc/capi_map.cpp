@@ -478,12 +478,14 @@ int mm_gpu_format_batch_view(int n_frag, const int *seg_off, const int *n_seg, c
 void mm2amd_free_regs(int n_frag, int *n_reg, void **reg)
 {
 	if (!n_reg || !reg) return;
-	for (int i = 0; i < n_frag; ++i) {
+	int nt = 1;
+	{ std::shared_lock<std::shared_mutex> lk(g_ctx_mu); if (g_ctx) nt = std::min(g_ctx->n_threads, 16); }
+	parallel_for_side(nt, n_frag, [&](long i, int) { // (a mini-batch holds a few hundred thousand libc blocks: tenths of a second on one thread)
 		ref::Reg1 *r = (ref::Reg1 *)reg[i];
 		for (int j = 0; j < n_reg[i]; ++j) free(r[j].p);
 		free(r);
 		reg[i] = nullptr, n_reg[i] = 0;
-	}
+	}, 2048);
 }
 
 // ---- hit records as one flat byte payload: the unit of the multi-GPU gather ----

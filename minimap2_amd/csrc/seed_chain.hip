@@ -258,6 +258,15 @@ __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t first, uint64_t v)
 {
 	return (uint64_t)(uint32_t)wave_shr1_i32((int32_t)(uint32_t)first, (int32_t)(uint32_t)v) | (uint64_t)(uint32_t)wave_shr1_i32((int32_t)(uint32_t)(first >> 32), (int32_t)(uint32_t)(v >> 32)) << 32;
 }
+__device__ __forceinline__ uint32_t lane_set_u32(uint32_t reg, int l, uint32_t v) // reg with lane l <- v; l and v wave-uniform (v_writelane_b32)
+{
+#ifdef MM2AMD_WAVE_EMU
+	return (int)(threadIdx.x & 63u) == (l & 63) ? v : reg;
+#else
+	asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(v), "s"(l) : "m0"); // (gfx9: one SGPR per VALU instruction; the lane select goes through M0)
+	return reg;
+#endif
+}
 __device__ __forceinline__ int32_t lane_get_i32(int32_t v, int l) { return __builtin_amdgcn_readlane(v, l); } // l wave-uniform
 __device__ __forceinline__ uint64_t lane_get_u64(uint64_t v, int l)
 {
@@ -742,26 +751,57 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 				if ((fr.shift >= 56 ? 0 : tied[t] >> (fr.shift + 8)) == prefix) { const uint32_t d = (uint32_t)(tied[t] >> fr.shift & 255); atomicOr(&child_mask[d >> 5], 1u << (d & 31)); }
 		}
 		__syncthreads();
-		if (tid == 0) {
+		if (tid < 64) {
+			// The cycle-leader walk (ksort.h:126-138) is one dependent chain -- where the next element comes from is decided by the
+			// last one moved -- so it runs on the first wavefront as scalar code: every lane computes the same values, the heads
+			// and ends of the 256 buckets sit in registers (bucket k: lane k & 63 of register k >> 6, read and advanced with
+			// v_readlane / v_writelane), and an element costs one LDS round trip instead of the four a table in LDS would.
+			uint32_t c[4], h[4], en[4];
 			uint32_t acc = 0, mx = 0;
-			for (int k = 0; k < 256; ++k) { start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; } // cnt becomes the bucket end
-			if ((int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				c[q] = cnt[q * 64 + tid];
+				const uint32_t incl = wave_prefix_add_u32(c[q]);
+				h[q] = acc + incl - c[q], en[q] = acc + incl;
+				acc += (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
+				mx = c[q] > mx ? c[q] : mx;
+			}
+			mx = (uint32_t)__builtin_amdgcn_readlane(wave_prefix_max_i32((int32_t)mx), 63);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) start[q * 64 + tid] = h[q], cnt[q * 64 + tid] = en[q]; // cnt becomes the bucket end
+			auto rd = [&](const uint32_t *r, int k) { // register k >> 6, lane k & 63; k is wave-uniform
+				const int q = k >> 6;
+				const uint32_t v = q == 0 ? r[0] : q == 1 ? r[1] : q == 2 ? r[2] : r[3];
+				return (uint32_t)__builtin_amdgcn_readlane((int32_t)v, k & 63);
+			};
+			auto bump = [&](int k, uint32_t v) { // head of bucket k <- v
+				const int q = k >> 6;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) if (u == q) h[u] = lane_set_u32(h[u], k & 63, v);
+			};
+			auto digit = [&](const typename S::Elem &e) { return __builtin_amdgcn_readfirstlane((int)(s.xk(e) >> fr.shift & 255)); };
+			if ((int32_t)mx != len) { // not all in one bucket
 				for (int k = 0; k < 256;) {
-					if (head[k] != cnt[k]) {
-						int l = (int)(s.xkey(fr.b + (int32_t)head[k]) >> fr.shift & 255);
-						if (l != k) {
-							typename S::Elem te = s.get(fr.b + (int32_t)head[k]), se;
-							do {
-								se = te;
-								te = s.get(fr.b + (int32_t)head[l]);
-								s.put(fr.b + (int32_t)head[l], se);
-								++head[l];
-								l = (int)(s.xk(te) >> fr.shift & 255);
-							} while (l != k);
-							s.put(fr.b + (int32_t)head[k], te);
-							++head[k];
-						} else ++head[k];
-					} else ++k;
+					const uint32_t hk = rd(h, k);
+					if (hk == rd(en, k)) { ++k; continue; }
+					typename S::Elem te = s.get(fr.b + (int32_t)hk);
+					int l = digit(te);
+					if (l != k) {
+						typename S::Elem se;
+						do {
+							se = te;
+							const uint32_t hl = rd(h, l);
+							te = s.get(fr.b + (int32_t)hl);
+							MM2_LOCKSTEP();
+							if (tid == 0) s.put(fr.b + (int32_t)hl, se);
+							bump(l, hl + 1);
+							WAVE_SYNC();
+							l = digit(te);
+						} while (l != k);
+						if (tid == 0) s.put(fr.b + (int32_t)hk, te);
+						WAVE_SYNC();
+					}
+					bump(k, hk + 1);
 				}
 			}
 		}
