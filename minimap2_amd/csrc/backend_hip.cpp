@@ -135,7 +135,6 @@ public:
 		bool &has_pairs_ = R.has_pairs, &have_read_names_ = R.have_read_names;
 		size_t &n_units_ = R.n_units;
 		PinBuf<char> &h_ascii_ = R.h_ascii;
-		DevBuf<char> &d_ascii_ = R.d_ascii;
 		DevBuf<uint8_t> &d_qpool_ = R.d_qpool;
 		DevBuf<uint64_t> &d_seq_off_ = R.d_seq_off, &d_unit_off_ = R.d_unit_off;
 		DevBuf<int32_t> &d_unit_first_ = R.d_unit_first, &d_name_key_ = R.d_name_key;
@@ -154,7 +153,9 @@ public:
 			memcpy(h + seq_off_[i], reads[i].seq, reads[i].len);
 			if (reads[i].paired()) memcpy(h + seq_off_[i] + reads[i].len, reads[i].seq2, reads[i].len2);
 		}, 64);
-		d_ascii_.ensure(total + 1);
+		// The ASCII bases stay in the pinned host buffer: encode_kernel reads them from there, once, sub-batch by sub-batch (zero-copy
+		// over PCIe, spread over the mapping step).  A bulk H2D copy of the next batch beside the mapping of the current one made the
+		// mapping's own small, latency-critical copies queue behind it (profiles/r03: mapping calls 25 % slower in the pipeline).
 		d_qpool_.ensure(2 * total + 16);
 		d_seq_off_.ensure(n + 1);
 		// ... and unit-level offsets (what encoding and sketching see: every read of a pair on its own, so that no k-mer spans the
@@ -175,7 +176,6 @@ public:
 			HIP_CHECK(hipMemcpyAsync(d_unit_off_.p, unit_off_.data(), (n_units_ + 1) * 8, hipMemcpyHostToDevice, stream_));
 			HIP_CHECK(hipMemcpyAsync(d_unit_first_.p, unit_first_.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream_));
 		}
-		HIP_CHECK(hipMemcpyAsync(d_ascii_.p, h, total, hipMemcpyHostToDevice, stream_));
 		HIP_CHECK(hipMemcpyAsync(d_seq_off_.p, seq_off_.data(), (n + 1) * 8, hipMemcpyHostToDevice, stream_));
 		read_names_.clear();
 		if (getenv("MM2AMD_SEED_DUMP")) for (size_t i = 0; i < n; ++i) read_names_.push_back(reads[i].name);
@@ -210,7 +210,6 @@ public:
 		const std::vector<uint64_t> &seq_off_ = R.seq_off, &unit_off_ = R.unit_off;
 		const std::vector<int32_t> &unit_first_ = R.unit_first;
 		const bool has_pairs_ = R.has_pairs, have_read_names_ = R.have_read_names;
-		const DevBuf<char> &d_ascii_ = R.d_ascii;
 		const DevBuf<uint8_t> &d_qpool_ = R.d_qpool;
 		const DevBuf<uint64_t> &d_seq_off_ = R.d_seq_off, &d_unit_off_ = R.d_unit_off;
 		const DevBuf<int32_t> &d_unit_first_ = R.d_unit_first, &d_name_key_ = R.d_name_key;
@@ -221,7 +220,7 @@ public:
 		out.resize(n);
 		if (n == 0) return;
 		B = SeedChainBuffers();
-		B.n_reads = (int)n, B.seq_off = d_seq_off_.p + lo, B.ascii = d_ascii_.p, B.qpool = d_qpool_.p;
+		B.n_reads = (int)n, B.seq_off = d_seq_off_.p + lo, B.ascii = h_ascii_.p, B.qpool = d_qpool_.p; // (pinned host memory, device-visible)
 		if (have_read_names_) B.name_lb = d_name_key_.p + lo, B.name_eq = d_name_key_.p + seq_off_.size() - 1 + lo;
 		KernelProfiler &kp = kernel_profiler(lane_id, replica_);
 		double tt = Trace::now();
@@ -436,7 +435,6 @@ private:
 	// The resident batch (shared by all lanes, read-only during run).  Two sets: begin_batch() fills the one that is NOT being mapped, so the
 	// hand-over of batch k+1 (pack into pinned memory, H2D) runs beside the mapping of batch k; activate_batch() swaps them.
 	struct Resident {
-		DevBuf<char> d_ascii;
 		DevBuf<uint8_t> d_qpool;
 		DevBuf<uint64_t> d_seq_off;
 		PinBuf<char> h_ascii;

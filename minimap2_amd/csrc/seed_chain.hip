@@ -38,15 +38,27 @@ static void upload_tables(hipStream_t s)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) encode_kernel(SeedChainBuffers B)
 {
+	// B.ascii is the batch's pinned HOST buffer (read over PCIe, once): 16 bytes per lane and load, 1 KiB per wavefront request
 	const int r = blockIdx.x;
 	const uint64_t o = B.seq_off[r];
 	const int64_t len = (int64_t)(B.seq_off[r + 1] - o);
 	const char *src = B.ascii + o;
 	uint8_t *f = B.qpool + 2 * o;
-	for (int64_t j = threadIdx.x; j < len; j += blockDim.x) {
-		const uint8_t c = c_nt4[(uint8_t)src[j]];
-		f[j] = c;
-		f[2 * len - 1 - j] = c < 4 ? 3 - c : 4;
+	const int64_t mis = (int64_t)((uintptr_t)src & 15u); // the read starts this far into its first aligned 16-byte word
+	const uint4 *w = (const uint4 *)(src - mis);         // (the buffer is page-aligned and padded: whole words are readable)
+	const int64_t n_words = (mis + len + 15) >> 4;
+	for (int64_t c = threadIdx.x; c < n_words; c += blockDim.x) {
+		const uint4 v = w[c];
+		const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int b = 0; b < 16; ++b) {
+			const int64_t j = (c << 4) + b - mis;
+			if (j >= 0 && j < len) {
+				const uint8_t code = c_nt4[q[b >> 2] >> ((b & 3) * 8) & 0xffu];
+				f[j] = code;
+				f[2 * len - 1 - j] = code < 4 ? 3 - code : 4;
+			}
+		}
 	}
 }
 
@@ -257,15 +269,6 @@ __device__ __forceinline__ int32_t wave_shr1_i32(int32_t first, int32_t v) { ret
 __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t first, uint64_t v)
 {
 	return (uint64_t)(uint32_t)wave_shr1_i32((int32_t)(uint32_t)first, (int32_t)(uint32_t)v) | (uint64_t)(uint32_t)wave_shr1_i32((int32_t)(uint32_t)(first >> 32), (int32_t)(uint32_t)(v >> 32)) << 32;
-}
-__device__ __forceinline__ uint32_t lane_set_u32(uint32_t reg, int l, uint32_t v) // reg with lane l <- v; l and v wave-uniform (v_writelane_b32)
-{
-#ifdef MM2AMD_WAVE_EMU
-	return (int)(threadIdx.x & 63u) == (l & 63) ? v : reg;
-#else
-	asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(v), "s"(l) : "m0"); // (gfx9: one SGPR per VALU instruction; the lane select goes through M0)
-	return reg;
-#endif
 }
 __device__ __forceinline__ int32_t lane_get_i32(int32_t v, int l) { return __builtin_amdgcn_readlane(v, l); } // l wave-uniform
 __device__ __forceinline__ uint64_t lane_get_u64(uint64_t v, int l)
@@ -751,57 +754,29 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 				if ((fr.shift >= 56 ? 0 : tied[t] >> (fr.shift + 8)) == prefix) { const uint32_t d = (uint32_t)(tied[t] >> fr.shift & 255); atomicOr(&child_mask[d >> 5], 1u << (d & 31)); }
 		}
 		__syncthreads();
-		if (tid < 64) {
-			// The cycle-leader walk (ksort.h:126-138) is one dependent chain -- where the next element comes from is decided by the
-			// last one moved -- so it runs on the first wavefront as scalar code: every lane computes the same values, the heads
-			// and ends of the 256 buckets sit in registers (bucket k: lane k & 63 of register k >> 6, read and advanced with
-			// v_readlane / v_writelane), and an element costs one LDS round trip instead of the four a table in LDS would.
-			uint32_t c[4], h[4], en[4];
+		if (tid == 0) {
+			// (measured: the same walk as wave-scalar code with the bucket heads in registers -- v_readlane / v_writelane instead of the LDS
+			// tables -- was 35 % slower: the chain is one LDS round trip per element either way, and the scalar round trips cost more than
+			// the table reads they replace)
 			uint32_t acc = 0, mx = 0;
-#pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				c[q] = cnt[q * 64 + tid];
-				const uint32_t incl = wave_prefix_add_u32(c[q]);
-				h[q] = acc + incl - c[q], en[q] = acc + incl;
-				acc += (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
-				mx = c[q] > mx ? c[q] : mx;
-			}
-			mx = (uint32_t)__builtin_amdgcn_readlane(wave_prefix_max_i32((int32_t)mx), 63);
-#pragma unroll
-			for (int q = 0; q < 4; ++q) start[q * 64 + tid] = h[q], cnt[q * 64 + tid] = en[q]; // cnt becomes the bucket end
-			auto rd = [&](const uint32_t *r, int k) { // register k >> 6, lane k & 63; k is wave-uniform
-				const int q = k >> 6;
-				const uint32_t v = q == 0 ? r[0] : q == 1 ? r[1] : q == 2 ? r[2] : r[3];
-				return (uint32_t)__builtin_amdgcn_readlane((int32_t)v, k & 63);
-			};
-			auto bump = [&](int k, uint32_t v) { // head of bucket k <- v
-				const int q = k >> 6;
-#pragma unroll
-				for (int u = 0; u < 4; ++u) if (u == q) h[u] = lane_set_u32(h[u], k & 63, v);
-			};
-			auto digit = [&](const typename S::Elem &e) { return __builtin_amdgcn_readfirstlane((int)(s.xk(e) >> fr.shift & 255)); };
-			if ((int32_t)mx != len) { // not all in one bucket
+			for (int k = 0; k < 256; ++k) { start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; } // cnt becomes the bucket end
+			if ((int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
 				for (int k = 0; k < 256;) {
-					const uint32_t hk = rd(h, k);
-					if (hk == rd(en, k)) { ++k; continue; }
-					typename S::Elem te = s.get(fr.b + (int32_t)hk);
-					int l = digit(te);
-					if (l != k) {
-						typename S::Elem se;
-						do {
-							se = te;
-							const uint32_t hl = rd(h, l);
-							te = s.get(fr.b + (int32_t)hl);
-							MM2_LOCKSTEP();
-							if (tid == 0) s.put(fr.b + (int32_t)hl, se);
-							bump(l, hl + 1);
-							WAVE_SYNC();
-							l = digit(te);
-						} while (l != k);
-						if (tid == 0) s.put(fr.b + (int32_t)hk, te);
-						WAVE_SYNC();
-					}
-					bump(k, hk + 1);
+					if (head[k] != cnt[k]) {
+						int l = (int)(s.xkey(fr.b + (int32_t)head[k]) >> fr.shift & 255);
+						if (l != k) {
+							typename S::Elem te = s.get(fr.b + (int32_t)head[k]), se;
+							do {
+								se = te;
+								te = s.get(fr.b + (int32_t)head[l]);
+								s.put(fr.b + (int32_t)head[l], se);
+								++head[l];
+								l = (int)(s.xk(te) >> fr.shift & 255);
+							} while (l != k);
+							s.put(fr.b + (int32_t)head[k], te);
+							++head[k];
+						} else ++head[k];
+					} else ++k;
 				}
 			}
 		}
@@ -1119,13 +1094,27 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 				__threadfence_block();
 				const int64_t jm = j >= st ? j : st;
 				const bool marked = has && !improve && (jm >= ring_lo ? rt[jm & RM] : t[jm]) == (int32_t)i;
-				unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
+				unsigned long long imp = __ballot(improve);
+				const unsigned long long mk = __ballot(marked);
+				// The skip counter (lchain.c:181-185) walks the candidates in order: +1 for one already reached through a better predecessor,
+				// -1 (not below 0) for an improvement, stop when it exceeds max_skip.  Improvements are few, so the walk goes from one
+				// improvement to the next and counts the marked candidates between them with a population count.
 				int stop_lane = 64;
-				while (ev) { // the skip counter is inherently sequential; events are sparse
-					const int b = __ffsll((long long)ev) - 1;
-					ev &= ev - 1;
-					if (imp >> b & 1) { if (n_skip > 0) --n_skip; }
-					else if (++n_skip > P.max_chain_skip) { stop_lane = b; break; }
+				for (int pos = 0; pos < 64;) {
+					const unsigned long long later = imp >> pos;
+					const int ni = later ? pos + (__ffsll((long long)later) - 1) : 64;               // the next improvement at or after pos
+					unsigned long long seg = (mk >> pos) << pos;                                       // marked candidates in [pos, ni)
+					if (ni < 64) seg &= (1ull << ni) - 1ull;
+					const int c = __popcll(seg);
+					if (n_skip + c > P.max_chain_skip) { // the counter overflows inside this stretch: at its (max_skip - n_skip + 1)-th marked candidate
+						for (int k = P.max_chain_skip - n_skip; k > 0; --k) seg &= seg - 1;
+						stop_lane = __ffsll((long long)seg) - 1;
+						break;
+					}
+					n_skip += c;
+					if (ni == 64) break;
+					if (n_skip > 0) --n_skip;
+					pos = ni + 1;
 				}
 				if (stop_lane < 64) {
 					broke = true;
