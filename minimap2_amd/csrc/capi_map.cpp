@@ -467,7 +467,7 @@ int mm_gpu_format_batch_view(int n_frag, const int *seg_off, const int *n_seg, c
 	if (!why.empty()) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch_view: " + why);
 	std::lock_guard<std::mutex> lk_fmt(g_ctx->fmt_mu); // one formatting call at a time uses the buffers (pipeline step 2)
 	try {
-		*out = format_batch_view(*g_ctx->fi, g_ctx->opt, g_ctx->n_threads, n_frag, seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, g_ctx->fmt, out_len);
+		*out = format_batch_view(*g_ctx->fi, g_ctx->opt, std::max(1, g_ctx->n_threads / 2), n_frag, // (beside the mapping of the next batch: half the threads) seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, g_ctx->fmt, out_len);
 		if (!*out) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm_gpu_format_batch_view: out of memory");
 		return 0;
 	} catch (const std::exception &e) {
