@@ -202,7 +202,6 @@ def main():
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     backend = os.environ.get("MM2AMD_BENCH_BACKEND", "nccl")  # "gloo": ranks share whatever GPUs exist (plumbing tests only)
     ncpu = os.cpu_count() or 1
-    n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
 
     import torch
     import torch.distributed as dist
@@ -228,6 +227,8 @@ def main():
 
     import minimap2_amd as mm
     from minimap2_amd import shard
+    ncpu = min(ncpu, mm.host_cpus())  # a container's CPU quota counts (cgroup cpu.max): threads beyond it only take time from each other
+    n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
 
     t0 = time.time()
     total = int(a.ref_mb * 1e6)

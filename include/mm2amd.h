@@ -24,6 +24,7 @@ extern "C" {
 
 const char *mm2amd_last_error(void);
 int mm2amd_version(void);                 /* ABI version, currently 1 */
+int mm2amd_host_cpus(void);                     /* CPUs this process may use: hardware threads capped by the container's CPU quota (cgroup cpu.max); what n_threads <= 0 resolves against */
 int mm2amd_device_count(void);            /* number of visible HIP devices, or negative error */
 
 /* ------------------------------------------------------------------------------------------------

@@ -139,6 +139,11 @@ def _bind(L):
     return L
 
 
+def host_cpus():
+    """CPUs this process may use: hardware threads capped by the container's CPU quota"""
+    return int(lib().mm2amd_host_cpus())
+
+
 def _libc_free(p):
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]

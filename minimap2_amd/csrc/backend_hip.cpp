@@ -108,7 +108,7 @@ public:
 		d_name_rank_.ensure(nm.size()), d_ref_len_.ensure(nm.size());
 		HIP_CHECK(hipMemcpyAsync(d_name_rank_.p, rank.data(), nm.size() * 4, hipMemcpyHostToDevice, stream_));
 		HIP_CHECK(hipMemcpyAsync(d_ref_len_.p, fi_seq_len_->data(), nm.size() * 4, hipMemcpyHostToDevice, stream_));
-		HIP_CHECK(hipStreamSynchronize(stream_));
+		stream_wait(stream_);
 		I_.name_rank = d_name_rank_.p, I_.seq_len = d_ref_len_.p;
 		name_rules_ = true;
 	}
@@ -118,7 +118,7 @@ public:
 		if (I_.seq_len) return;
 		d_ref_len_.ensure(fi_seq_len_->size());
 		HIP_CHECK(hipMemcpyAsync(d_ref_len_.p, fi_seq_len_->data(), fi_seq_len_->size() * 4, hipMemcpyHostToDevice, stream_));
-		HIP_CHECK(hipStreamSynchronize(stream_));
+		stream_wait(stream_);
 		I_.seq_len = d_ref_len_.p;
 	}
 	bool supports_rmq() const override { return getenv("MM2AMD_RMQ_ON_HOST") == nullptr; } // chain_rmq_kernel; MM2AMD_RMQ_ON_HOST=1: A/B against rmq_chain.cpp
@@ -195,7 +195,7 @@ public:
 			d_name_key_.ensure(2 * n);
 			HIP_CHECK(hipMemcpyAsync(d_name_key_.p, name_key_.data(), 2 * n * 4, hipMemcpyHostToDevice, stream_));
 		}
-		HIP_CHECK(hipStreamSynchronize(stream_)); // the batch is resident; everything after this is the hot path
+		stream_wait(stream_); // the batch is resident; everything after this is the hot path
 	}
 	void activate_batch() override { cur_ = 1 - cur_; }
 	bool stages_beside_mapping() const override { return true; }
@@ -274,7 +274,7 @@ public:
 		HIP_CHECK(hipMemcpyAsync(h_na, ln.d_n_anchor.p, n * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_nmp, ln.d_n_minipos.p, n * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_rep, ln.d_rep_len.p, n * 4, hipMemcpyDeviceToHost, st));
-		HIP_CHECK(hipStreamSynchronize(st));
+		stream_wait(st);
 		Trace::get().add(lane_id, "gpu:sketch+collect", tt, Trace::now()); tt = Trace::now();
 		std::vector<uint64_t> &a_off = ln.a_off, &mp_off = ln.mp_off;
 		a_off.resize(n + 1), mp_off.resize(n + 1);
@@ -310,7 +310,7 @@ public:
 		launch_anchor_sort(B, I_, P, ln.d_sort_list.p, n_class, a_class, st, &kp);
 		if (const char *dump = getenv("MM2AMD_SEED_DUMP")) { // diagnostics: every read's sorted anchors, as the reference's --print-seeds prints them (map.c:255-260)
 			std::vector<Anchor> all(n_a + 1);
-			HIP_CHECK(hipStreamSynchronize(st));
+			stream_wait(st);
 			if (n_a) HIP_CHECK(hipMemcpy(all.data(), ln.d_anchors.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost));
 			static std::mutex dump_mu;
 			std::lock_guard<std::mutex> lk(dump_mu);
@@ -331,7 +331,7 @@ public:
 			uint64_t *hmp = ln.h_minipos.ensure(n_mp + 1);
 			if (n_a) HIP_CHECK(hipMemcpyAsync(ha, ln.d_anchors.p, n_a * sizeof(Anchor), hipMemcpyDeviceToHost, st));
 			if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipStreamSynchronize(st));
+			stream_wait(st);
 			Trace::get().add(lane_id, "gpu:expand+sort, d2h:anchors", tt, Trace::now());
 			kp.collect();
 			parallel_for(n_threads, (long)n, [&](long i, int) {
@@ -363,7 +363,7 @@ public:
 		HIP_CHECK(hipMemcpyAsync(h_uoff, ln.d_bt_uoff.p, n * 8, hipMemcpyDeviceToHost, st));
 		if (h_tie) HIP_CHECK(hipMemcpyAsync(h_tie, ln.d_tie.p, n * 4, hipMemcpyDeviceToHost, st));
 		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
-		HIP_CHECK(hipStreamSynchronize(st));
+		stream_wait(st);
 		Trace::get().add(lane_id, "gpu:expand..backtrack", tt, Trace::now()); tt = Trace::now();
 		const uint64_t n_v = h_cur[0], n_u = h_cur[1];
 		Anchor *ha = ln.h_anchors.ensure(n_v + 1);
@@ -380,7 +380,7 @@ public:
 			const size_t cnt = (size_t)(a_off[rd.first + 1] - a_off[rd.first]);
 			if (cnt) HIP_CHECK(hipMemcpyAsync(h_redo + rd.second, ln.d_anchors.p + a_off[rd.first], cnt * sizeof(Anchor), hipMemcpyDeviceToHost, st));
 		}
-		HIP_CHECK(hipStreamSynchronize(st));
+		stream_wait(st);
 		Trace::get().add(lane_id, "d2h:chains", tt, Trace::now()); tt = Trace::now();
 		kp.collect();
 		TraceScope ts(lane_id, "host:chains->vectors");

@@ -16,6 +16,7 @@
 #include "threads.hpp"
 
 namespace mm2amd {
+int effective_cpus(); // capi_common.cpp
 // backend_hip.cpp in the product: `device` < 0 = the process's default device; `replica` numbers the backends of one context;
 // `tables_device` is where `device_tables` live (a backend on another device copies them)
 Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads, int device, int replica, int tables_device);
@@ -166,7 +167,7 @@ int build_context(std::unique_ptr<MapContext> &c, void *device_tables, int table
 	}
 	if (n_gpus > 16) return capi_fail(MM2AMD_EINVAL, "[mm2amd] at most 16 replicas per context");
 	if (!device_ids && n_gpus > 1 && n_gpus > backend_device_count()) return capi_fail(MM2AMD_ENODEV, "[mm2amd] more GPUs requested than this process can see");
-	if (n_threads <= 0) n_threads = std::min(64 * n_gpus, (int)std::thread::hardware_concurrency()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU
+	if (n_threads <= 0) n_threads = std::min(64 * n_gpus, effective_cpus()); // the host stages stop scaling (and start contending) beyond ~64 threads per GPU; a CPU quota counts
 	c->n_threads = n_threads;
 	const int per = std::max(1, n_threads / n_gpus);
 	c->reps.resize(n_gpus);
@@ -467,7 +468,8 @@ int mm_gpu_format_batch_view(int n_frag, const int *seg_off, const int *n_seg, c
 	if (!why.empty()) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_format_batch_view: " + why);
 	std::lock_guard<std::mutex> lk_fmt(g_ctx->fmt_mu); // one formatting call at a time uses the buffers (pipeline step 2)
 	try {
-		*out = format_batch_view(*g_ctx->fi, g_ctx->opt, std::max(1, g_ctx->n_threads / 2), n_frag, // (beside the mapping of the next batch: half the threads) seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, g_ctx->fmt, out_len);
+		// (this step runs beside the mapping of the next batch: half the threads)
+		*out = format_batch_view(*g_ctx->fi, g_ctx->opt, std::max(1, g_ctx->n_threads / 2), n_frag, seg_off, n_seg, (const ref::Bseq1 *)seq_, n_reg, reg, rep_len, g_ctx->fmt, out_len);
 		if (!*out) return capi_fail(MM2AMD_ENOMEM, "[mm2amd] mm_gpu_format_batch_view: out of memory");
 		return 0;
 	} catch (const std::exception &e) {

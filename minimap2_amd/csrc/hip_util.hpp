@@ -37,6 +37,31 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define HIP_CHECK(x) ::mm2amd::hip_check((x), #x, __FILE__, __LINE__)
 
+// Wait for a stream WITHOUT spinning.  hipStreamSynchronize busy-waits; five lane drivers doing that cost five cores for the whole step,
+// and a process under a CPU quota (a container: cpu.max) pays for them with the time of its working threads -- the hot path's host side
+// then is quota-bound, not GPU-bound (profiles/r03: 16 CPUs of quota, 10 core-seconds per step).  An event created with
+// hipEventBlockingSync makes the waiter sleep until the interrupt.
+inline void stream_wait(hipStream_t s)
+{
+	struct PerDevice { int dev = -1; hipEvent_t ev = nullptr; };
+	thread_local PerDevice cache[4]; // a host thread drives the lanes of one replica: one device, rarely more
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	PerDevice *slot = nullptr;
+	for (PerDevice &c : cache) if (c.dev == dev) { slot = &c; break; }
+	if (!slot) {
+		for (PerDevice &c : cache) if (c.dev < 0) { slot = &c; break; }
+		if (!slot) { HIP_CHECK(hipStreamSynchronize(s)); return; }
+		HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventBlockingSync | hipEventDisableTiming));
+		slot->dev = dev;
+	}
+	HIP_CHECK(hipEventRecord(slot->ev, s));
+	HIP_CHECK(hipEventSynchronize(slot->ev));
+}
+
+// CPUs this process may actually use: the smaller of the hardware thread count and the container's CPU quota (cgroup v2 cpu.max, v1 cfs quota)
+int effective_cpus(); // capi_common.cpp
+
 struct AllocStats { std::atomic<long> dev_allocs{0}, pin_allocs{0}; std::atomic<double> dummy{0}; std::atomic<long long> dev_bytes{0}, pin_bytes{0}; std::atomic<long long> ns{0}; };
 inline AllocStats &alloc_stats() { static AllocStats s; return s; }
 

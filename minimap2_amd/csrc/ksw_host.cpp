@@ -21,7 +21,10 @@ constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice 
 // kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip): two jobs per wave with 2 or 4 register sets of
 // 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves of 4 sets (512 positions per
 // sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
-constexpr int kSpliceClasses = 3, kNTiers = kFirstSplice + kSpliceClasses * kDirClasses;
+constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
+// kFirstExt, kFirstExt + 1: the register-resident extension kernel (ksw_ext.hip): the two extensions per read whose band cannot bind,
+// left-aligned (right extensions) and right-aligned (left extensions: KSW_EZ_RIGHT); two jobs per wave.
+constexpr int kNTiers = kFirstExt + 2, kExtMaxQ = 512, kExtMaxT = 256;
 const int kSpliceSets[kSpliceClasses] = { 2, 4, 4 };
 const bool kSpliceSelf[kSpliceClasses] = { false, false, true };
 const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
@@ -57,6 +60,16 @@ inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
 	if (j.reserved) return false; // windows with annotated splice sites (KswScoring::juncs) are priced by the lane-exact kernel only
 	return j.qlen > 0 && j.tlen > 0;
 }
+// An extension (align.c:791, :883: KSW_EZ_EXTZ_ONLY; left extensions also KSW_EZ_RIGHT | KSW_EZ_REV_CIGAR) may take the register-resident
+// extension kernel when its band cannot bind, with default substitution scores and dual-affine costs: exact row maxima, Z-drop and end
+// bonus are computed there (ksw_ext.hip).
+inline bool ext_eligible(const KswJob &j, bool scoring_ok)
+{
+	const int f = j.flag & 0x1fff;
+	if (!scoring_ok || (j.flag & KSWJ_SKIP) || (f != KSW_EXTZ_ONLY && f != (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR))) return false;
+	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.tlen > kExtMaxT) return false;
+	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
+}
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
 
@@ -65,6 +78,7 @@ void ksw_stream_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream
 size_t ksw_stream_slot_bytes(int n_sets);
 int ksw_stream_waves(int n_sets);
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
+void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, void *stream);               // ksw_ext.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                     const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
@@ -80,7 +94,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	constexpr int NB = 256; // cost buckets per tier
 	const bool stream_on = !getenv("MM2AMD_NO_STREAM"); // diagnostic: every gap fill through the strip kernel
 	constexpr size_t CH = 32768;
-	const size_t NBINS = (size_t)(sc.single == 2 ? kNTiers : kFirstSplice) * NB; // the splice classes only exist in splice mode
+	const size_t NBINS = (size_t)kNTiers * NB;
+	static const bool ext_on = !getenv("MM2AMD_NO_EXT_KERNEL"); // diagnostic: every extension through the lane-exact kernel
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
@@ -103,11 +118,12 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		for (size_t i = (size_t)c * CH; i < e; ++i) {
 			const KswJob &j = jobs[i];
 			int tier, ring_need = 64;
-			const bool fast = fast_eligible(j, scoring_ok), sfast = splice_fast_eligible(j, splice_ok);
+			const bool fast = fast_eligible(j, scoring_ok), sfast = splice_fast_eligible(j, splice_ok), xfast = ext_on && ext_eligible(j, scoring_ok);
 			const bool live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
-			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
+			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast || xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 			if (fast) tier = fast_tier(j);
+			else if (xfast) tier = kFirstExt + ((j.flag & KSW_RIGHT) ? 1 : 0);
 			else if (sfast) {
 				int nc = 0, dc = 0;
 				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
@@ -144,7 +160,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (!(j.flag & KSW_SCORE_ONLY)) {
 				if (db > 160 * 1024) cs.alg_bytes += (double)db;
 				cs.slot_bytes = std::max(cs.slot_bytes, db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
-				if (fast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
+				if (fast || xfast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
 				st.sum_len += (size_t)j.qlen + j.tlen;
 			}
 		}
@@ -220,7 +236,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
-			const bool sfast = tier >= kFirstSplice, fast = tier < kFirstExact || sfast; // the register-resident kernels
+			const bool xfast = tier >= kFirstExt, sfast = tier >= kFirstSplice && !xfast, fast = tier < kFirstExact || sfast || xfast; // the register-resident kernels
 			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
 			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes, P.cells = cls[tier].cells;
 			// the gap-fill kernel keeps ONE matrix per wave for its two jobs, as many rows as the longer and as many columns as the wider
@@ -228,6 +244,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
 			if (tier < kFirstExact) P.tmp_cap = 3 * (P.tmp_cap + 2); // the operations, and two prefix arrays over them for the half-wave's Z-drop walk (gf_zdrop_scan)
 			if (tier < kFirstExact) P.slot_bytes = n_stream ? ksw_stream_slot_bytes(n_stream) : (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
+			if (xfast) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol; // one matrix per wave for its two jobs, as in the gap-fill kernel
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			P.hbm = !fast && rc == kHbmRing;
 			P.ring = fast ? 64 : P.hbm ? cls[tier].max_ring : kRingSize[rc];
@@ -238,7 +255,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (P.hbm) P.wpb = 4;
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
+			if (xfast) blocks_per_cu = 4;
+			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (n_stream) blocks_per_cu = ksw_stream_waves(n_stream);
 			else if (fast) blocks_per_cu = fast_waves(tier);
 			else if (P.hbm) blocks_per_cu = 4;
@@ -301,11 +319,12 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
 			if (n_stream) ksw_stream_launch(L, (int)P.n_slots, n_stream, stream_);
 			else if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
+			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, tier == kFirstExt + 1, stream_);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			static const char *kStreamNames[2] = { "ksw_stream_kernel<4>[t256]", "ksw_stream_kernel<8>[t512]" };
-			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstExt ? (tier == kFirstExt ? "ksw_ext_kernel[left-aligned]" : "ksw_ext_kernel[right-aligned]") : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
 		}
 		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));
@@ -314,13 +333,13 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		uint32_t cursor[2];
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		stream_wait(stream);
 		Trace::get().add(lane, "gpu:ksw", tt, Trace::now()); tt = Trace::now();
 		if (cursor[1] == 0) {
 			uint32_t *hc = cigar_host.ensure((size_t)cursor[0] + 1);
 			if (cursor[0]) {
 				HIP_CHECK(hipMemcpyAsync(hc, d_cigar.p, (size_t)cursor[0] * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipStreamSynchronize(stream));
+				stream_wait(stream);
 			}
 			*cigar_out = hc, *n_cigar_out = cursor[0];
 			Trace::get().add(lane, "d2h:cigar", tt, Trace::now()); tt = Trace::now();

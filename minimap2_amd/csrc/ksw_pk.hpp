@@ -12,6 +12,19 @@ __device__ __forceinline__ int dpp_shr1(int carry_in, int v) // lane i <- v[i-1]
 	return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+// inclusive prefix maximum over the lanes (lane 63 holds the wave's maximum): gfx9 DPP row shifts and row broadcasts, no LDS crossbar
+__device__ __forceinline__ int32_t wave_prefix_max_i32_ext(int32_t v)
+{
+	int32_t o;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;
+	o = __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;
+	return v;
+}
+
 struct FastCig { uint32_t *c; int n; uint32_t last; };
 __device__ __forceinline__ void fast_cig_push(FastCig &g, uint32_t op, int len) // ksw_push_cigar (ksw2.h:114-124)
 {

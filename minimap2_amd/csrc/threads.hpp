@@ -126,7 +126,7 @@ private:
 			if (try_help()) continue;
 			// nothing to do: spin briefly (the next loop of the same sub-batch is usually microseconds away), then sleep
 			bool found = false;
-			for (int spin = 0; spin < 4000 && !found; ++spin) {
+			for (int spin = 0; spin < 400 && !found; ++spin) { // (a few microseconds: spinning is paid for out of the process's CPU quota)
 				if (stop_.load(std::memory_order_relaxed)) return;
 				if (n_open_.load(std::memory_order_acquire) > 0) found = true; else cpu_relax();
 			}

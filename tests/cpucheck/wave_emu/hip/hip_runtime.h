@@ -114,7 +114,7 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
 typedef struct wave_emu_stream *hipStream_t;
 typedef struct wave_emu_event { double t; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipEventBlockingSync = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { char name[64]; char gcnArchName[64]; int multiProcessorCount; int clockRate; size_t totalGlobalMem; };
 inline const char *hipGetErrorString(hipError_t) { return "wave_emu"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -142,6 +142,7 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipE
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 double wave_emu_now();
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = wave_emu_now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
