@@ -351,6 +351,7 @@ def main():
         os.environ["MM2AMD_NO_SIDE_STREAM"] = "1"  # the lane-exact DP launches after the gap-fill kernel instead of beside it
         mm.profile_enable(True)
         t_one = one_step(a.warmup + a.steps)
+        log("un-overlapped pass (one lane): %.3f s; process CPU seconds while each stage ran: %s" % (t_one, {k: round(v, 2) for k, v in al.last_stats().items() if k.startswith("cpu_")}))
         prof1 = mm.profile_get()
         mm.profile_enable(False)
         del os.environ["MM2AMD_ACTIVE_LANES"], os.environ["MM2AMD_NO_SIDE_STREAM"]

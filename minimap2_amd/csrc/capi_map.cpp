@@ -131,6 +131,7 @@ void run_replicas(MapContext &c, const StagedBatch &bt, std::vector<ReadResult> 
 		const MapperStats &s = c.reps[r].mapper->stats;
 		sum.t_seed_chain += s.t_seed_chain, sum.t_host_pre += s.t_host_pre, sum.t_plan += s.t_plan, sum.t_ksw += s.t_ksw, sum.t_consume += s.t_consume;
 		sum.t_finish += s.t_finish, sum.n_jobs += s.n_jobs, sum.n_rounds += s.n_rounds, sum.dp_cells += s.dp_cells;
+		sum.c_seed_chain += s.c_seed_chain, sum.c_host_pre += s.c_host_pre, sum.c_plan += s.c_plan, sum.c_ksw += s.c_ksw, sum.c_consume += s.c_consume, sum.c_finish += s.c_finish;
 	}
 	std::lock_guard<std::mutex> lk(c.stats_mu);
 	c.stats = sum;

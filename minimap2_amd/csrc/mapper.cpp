@@ -1,4 +1,5 @@
 #include <chrono>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <malloc.h>
@@ -29,6 +30,7 @@ inline uint32_t x31_hash(const char *s) // __ac_X31_hash_string, khash.h:383-388
 	return h;
 }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double cpu_now() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 }
 
 uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
@@ -174,6 +176,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 		std::lock_guard<std::mutex> lk(stats_mu);
 		stats.t_seed_chain += st.t_seed_chain, stats.t_host_pre += st.t_host_pre, stats.t_plan += st.t_plan, stats.t_ksw += st.t_ksw;
 		stats.t_consume += st.t_consume, stats.t_finish += st.t_finish, stats.n_jobs += st.n_jobs, stats.n_rounds += st.n_rounds, stats.dp_cells += st.dp_cells;
+		stats.c_seed_chain += st.c_seed_chain, stats.c_host_pre += st.c_host_pre, stats.c_plan += st.c_plan, stats.c_ksw += st.c_ksw, stats.c_consume += st.c_consume, stats.c_finish += st.c_finish;
 	};
 	std::vector<std::thread> th;
 	for (int l = 1; l < n_drivers; ++l) th.emplace_back(driver, l);
@@ -191,7 +194,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 	const std::vector<uint64_t> &qoff = sets_[cur_set_].qoff;
 	{
 		const long m = hi - lo;
-		double t0 = now();
+		double t0 = now(), c0 = cpu_now();
 		std::vector<ReadChains> &chains = ds.chains;
 		be_.seed_chain(sp, lo, hi, lane, n_threads_, chains);
 		if (opt_.max_occ > opt_.mid_occ && !(opt_.flag & F_RMQ)) {
@@ -227,6 +230,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 		}
 		stats.t_seed_chain += now() - t0; t0 = now();
+		stats.c_seed_chain += cpu_now() - c0; c0 = cpu_now();
 
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
 		// A two-segment fragment (paired-end reads) is seeded and chained as one query -- the concatenation of its segments -- and
@@ -327,6 +331,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		});
 		Trace::get().add(lane, "host:pre", t0, now());
 		stats.t_host_pre += now() - t0;
+		stats.c_host_pre += cpu_now() - c0;
 
 		if (!(opt_.flag & F_CIGAR)) return; // no base-level alignment asked for
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
@@ -343,7 +348,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(mu, 1);
 		for (int round = 0;; ++round) {
-			t0 = now();
+			t0 = now(), c0 = cpu_now();
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				per_read_jobs[i].clear();
 				if (active[i]) al[tid]->schedule(ra[i], per_read_jobs[i]);
@@ -388,19 +393,22 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			Trace::get().add(lane, "host:plan", t0, now());
 			stats.t_plan += now() - t0; t0 = now();
+			stats.c_plan += cpu_now() - c0; c0 = cpu_now();
 			be_.ksw(jobs, sc, lane, n_threads_, kres, &cigars);
 			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
 			stats.t_ksw += now() - t0; t0 = now();
+			stats.c_ksw += cpu_now() - c0; c0 = cpu_now();
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
 			Trace::get().add(lane, "host:consume", t0, now());
 			stats.t_consume += now() - t0;
+			stats.c_consume += cpu_now() - c0;
 			if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");
 		}
 
 		// ---- final hit selection and MAPQ (map.c:215-225, :339-342), pairing (map.c:353-354) ----
-		t0 = now();
+		t0 = now(), c0 = cpu_now();
 		parallel_for(n_threads_, m, [&](long i, int tid) {
 			ReadResult &res = out[live_id[lo + i]];
 			const ReadView &rv = live[lo + i];
@@ -427,6 +435,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		});
 		Trace::get().add(lane, "host:finish", t0, now());
 		stats.t_finish += now() - t0;
+		stats.c_finish += cpu_now() - c0;
 	}
 }
 

@@ -19,6 +19,9 @@ struct ReadResult {
 
 struct MapperStats { // wall-clock seconds per stage of the last map_batch (for bench / DESIGN.md)
 	double t_seed_chain = 0, t_host_pre = 0, t_plan = 0, t_ksw = 0, t_consume = 0, t_finish = 0;
+	// process CPU seconds spent while each stage ran (all threads): meaningful when ONE lane drives the sub-batches one after the other
+	// (MM2AMD_ACTIVE_LANES=1: bench.py's un-overlapped pass) -- where the host side's cores go when the process runs under a CPU quota
+	double c_seed_chain = 0, c_host_pre = 0, c_plan = 0, c_ksw = 0, c_consume = 0, c_finish = 0;
 	long n_jobs = 0, n_rounds = 0;
 	double dp_cells = 0;
 };
