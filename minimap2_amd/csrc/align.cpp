@@ -5,6 +5,10 @@
 #include <cstring>
 #include <stdexcept>
 #include "align.hpp"
+#include "host_prof.hpp"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "chain_host.hpp"
 
 namespace mm2amd {
@@ -351,34 +355,93 @@ void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t
 	int qshift, tshift;
 	int32_t toff = 0, qoff = 0;
 	double s = 0.0, max = 0.0;
-	fix_cigar(r, qseq, tseq, &qshift, &tshift);
+	{ hostprof::Scope hp(hostprof::FIX_CIGAR); fix_cigar(r, qseq, tseq, &qshift, &tshift); }
+	hostprof::Scope hp(hostprof::EXTRA_SCAN);
+	const int32_t match_sc = mat[0];
+	const bool uniform_match = match_sc >= 0 && mat[6] == match_sc && mat[12] == match_sc && mat[18] == match_sc; // every A/C/G/T match scores the same and not below zero
 	qseq += qshift, tseq += tshift;
-	r.blen = r.mlen = 0, r.is_spliced = 0;
-	for (uint32_t k = 0; k < p->n_cigar; ++k) {
-		const uint32_t op = p->cigar[k] & 0xf, len = p->cigar[k] >> 4;
+	// (running totals in locals: `r` and `p` may alias the CIGAR as far as the compiler knows, which would put five stores into every step)
+	int32_t blen = 0, mlen = 0, n_ambi_all = 0, spliced = 0;
+	const uint32_t n_cigar = p->n_cigar, *const cigar = p->cigar;
+	static thread_local struct GapCost { int q = INT32_MIN, e = INT32_MIN; double c[64]; } gc; // q + e * log2(1 + len) of the short gaps, by the reference's own expression
+	if (log_gap && (gc.q != q || gc.e != e)) {
+		gc.q = q, gc.e = e;
+		for (int len = 0; len < 64; ++len) gc.c[len] = q + (double)e * fast_log2(1.0 + len);
+	}
+	for (uint32_t k = 0; k < n_cigar; ++k) {
+		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
+			// The reference walks the run base by base in doubles: s += score; clamp at 0; track the maximum (align.c:268-277).  Every value
+			// here is an integer plus gap costs that are multiples of 2^-23 (fast_log2 returns a float >= 1), far below 2^29 in size, so
+			// each double addition is exact and the walk can be done on integer prefix sums: with `lo`/`hi` the smallest / largest prefix
+			// of the run, no clamp happens iff s + lo >= 0, and then the maximum candidate is s + hi.  A run that does clamp (start of an
+			// alignment) is walked again the reference's way.
 			int n_ambi = 0, n_diff = 0;
+			const uint8_t *qr = qseq + qoff, *tr = tseq + toff;
+			int32_t acc = 0, lo = INT32_MAX, hi = INT32_MIN;
+#if defined(__SSE2__)
+			if (uniform_match) { // 16 columns at a time: between two columns that are not plain matches the prefix only rises
+				for (uint32_t l0 = 0; l0 < len; l0 += 16) {
+					const uint32_t m = len - l0 < 16 ? len - l0 : 16, lane_mask = m == 16 ? 0xffffu : (1u << m) - 1;
+					const __m128i vq = _mm_loadu_si128((const __m128i *)(qr + l0)), vt = _mm_loadu_si128((const __m128i *)(tr + l0)); // reads up to 15 bytes past the run: both buffers are padded
+					const uint32_t eq = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(vq, vt));
+					const uint32_t amb = (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi8(_mm_or_si128(vq, vt), _mm_set1_epi8(3))) & lane_mask;
+					uint32_t special = (~eq | amb) & lane_mask; // mismatches and ambiguous columns
+					n_ambi += __builtin_popcount(amb), n_diff += __builtin_popcount(special & ~amb);
+					uint32_t done = 0; // columns of this block already added
+					while (special) {
+						const uint32_t c = (uint32_t)__builtin_ctz(special);
+						special &= special - 1;
+						if (c > done) { // plain matches before it: the first is the lowest, the last the highest
+							lo = lo < acc + match_sc ? lo : acc + match_sc;
+							acc += (int32_t)(c - done) * match_sc;
+							hi = hi > acc ? hi : acc;
+						}
+						acc += mat[tr[l0 + c] * 5 + qr[l0 + c]];
+						lo = lo < acc ? lo : acc, hi = hi > acc ? hi : acc;
+						done = c + 1;
+					}
+					if (m > done) {
+						lo = lo < acc + match_sc ? lo : acc + match_sc;
+						acc += (int32_t)(m - done) * match_sc;
+						hi = hi > acc ? hi : acc;
+					}
+				}
+			} else
+#endif
 			for (uint32_t l = 0; l < len; ++l) {
-				const int cq = qseq[qoff + l], ct = tseq[toff + l];
-				if (ct > 3 || cq > 3) ++n_ambi;
-				else if (ct != cq) ++n_diff;
-				s += mat[ct * 5 + cq];
-				if (s < 0) s = 0;
-				else max = max > s ? max : s;
+				const int cq = qr[l], ct = tr[l], amb = (ct > 3) | (cq > 3);
+				n_ambi += amb, n_diff += (ct != cq) & !amb;
+				acc += mat[ct * 5 + cq];
+				lo = lo < acc ? lo : acc, hi = hi > acc ? hi : acc;
 			}
-			r.blen += len - n_ambi, r.mlen += len - (n_ambi + n_diff), p->n_ambi += n_ambi;
+			if (len > 0) {
+				if (s + (double)lo >= 0) {
+					const double top = s + (double)hi;
+					max = max > top ? max : top;
+					s += (double)acc;
+				} else {
+					for (uint32_t l = 0; l < len; ++l) {
+						s += mat[tr[l] * 5 + qr[l]];
+						if (s < 0) s = 0;
+						else max = max > s ? max : s;
+					}
+				}
+			}
+			blen += len - n_ambi, mlen += len - (n_ambi + n_diff), n_ambi_all += n_ambi;
 			toff += len, qoff += len;
 		} else if (op == 1 || op == 2) {
 			int n_ambi = 0;
 			const uint8_t *sq = op == 1 ? qseq + qoff : tseq + toff;
-			for (uint32_t l = 0; l < len; ++l) if (sq[l] > 3) ++n_ambi;
-			r.blen += len - n_ambi, p->n_ambi += n_ambi;
-			if (log_gap) s -= q + (double)e * fast_log2(1.0 + len);
+			for (uint32_t l = 0; l < len; ++l) n_ambi += sq[l] > 3;
+			blen += len - n_ambi, n_ambi_all += n_ambi;
+			if (log_gap) s -= len < 64 ? gc.c[len] : q + (double)e * fast_log2(1.0 + len);
 			else s -= q + e;
 			if (s < 0) s = 0;
 			if (op == 1) qoff += len; else toff += len;
-		} else if (op == 3) r.is_spliced = 1, toff += len;
+		} else if (op == 3) spliced = 1, toff += len;
 	}
+	r.blen = blen, r.mlen = mlen, r.is_spliced = spliced, p->n_ambi += n_ambi_all;
 	p->dp_max = p->dp_max0 = (int32_t)(max + .499);
 	assert(qoff == r.qe - r.qs && toff == r.re - r.rs);
 	if (is_eqx) cigar_to_eqx(r, qseq, tseq);
@@ -578,15 +641,24 @@ Aligner::Aligner(const MapOpt &opt, const FlatIndex &fi) : opt_(opt), fi_(fi)
 void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs, Anchor *a, uint64_t qpool_fwd, uint64_t qpool_rev, uint8_t *q4)
 {
 	ra.qlen = qlen, ra.qpool_off = qpool_fwd, ra.qpool_rev = qpool_rev, ra.a = a;
-	ra.q4 = q4;
-	for (int i = 0; i < qlen; ++i) {
-		const uint8_t c = kNt4Table[(uint8_t)seq[i]];
-		ra.q4[i] = c;
-		ra.q4[2 * (size_t)qlen - 1 - i] = c < 4 ? 3 - c : 4;
-	}
+	ra.q4 = q4, ra.seq = seq, ra.q4_ready[0] = ra.q4_ready[1] = false;
 	ra.n_a = squeeze_anchors(regs, a);
 	ra.tasks.clear(); ra.order.clear();
 	for (size_t i = 0; i < regs.size(); ++i) add_region(ra, regs[i], -1);
+}
+
+const uint8_t *strand_codes(ReadAlign &ra, int strand)
+{
+	uint8_t *dst = ra.q4 + (size_t)strand * ra.qlen;
+	if (ra.q4_ready[strand]) return dst;
+	hostprof::Scope hp(hostprof::Q4_ENCODE);
+	static const struct RcTable { uint8_t t[256]; RcTable() { for (int c = 0; c < 256; ++c) t[c] = kNt4Table[c] < 4 ? 3 - kNt4Table[c] : 4; } } rc;
+	const int n = ra.qlen;
+	const uint8_t *src = (const uint8_t *)ra.seq;
+	if (strand == 0) for (int i = 0; i < n; ++i) dst[i] = kNt4Table[src[i]];
+	else for (int i = 0; i < n; ++i) dst[i] = rc.t[src[n - 1 - i]];
+	ra.q4_ready[strand] = true;
+	return dst;
 }
 
 // One region to align: one task, or one task per assumed transcript strand (align.c:1068-1077).  order_pos < 0 appends.
@@ -635,7 +707,7 @@ void Aligner::join_strands(ReadAlign &ra, int lead_ti)
 }
 
 // ksw_ll_i16 score of an anchor's k-mer extended by anchor_ext_len on both sides (mm_seed_ext_score, align.c:591-616)
-static int seed_ext_score(const MapOpt &opt, const FlatIndex &fi, const int8_t *mat, int qlen, const uint8_t *q4, const Anchor &a, std::vector<uint8_t> &tbuf)
+static int seed_ext_score(const MapOpt &opt, const FlatIndex &fi, const int8_t *mat, int qlen, ReadAlign &ra, const Anchor &a, std::vector<uint8_t> &tbuf)
 {
 	const int q_span = span_of(a), ext_len = opt.anchor_ext_len;
 	const uint32_t rid = (uint32_t)(a.x << 1 >> 33);
@@ -646,33 +718,33 @@ static int seed_ext_score(const MapOpt &opt, const FlatIndex &fi, const int8_t *
 	qe = qe + ext_len < qlen ? qe + ext_len : qlen;
 	tbuf.resize(re - rs);
 	fi.getseq(rid, rs, re, tbuf.data());
-	return ll_local_score(qe - qs, q4 + (size_t)(a.x >> 63) * qlen + qs, re - rs, tbuf.data(), mat, opt.q, opt.e, &q_off, &t_off);
+	return ll_local_score(qe - qs, strand_codes(ra, (int)(a.x >> 63)) + qs, re - rs, tbuf.data(), mat, opt.q, opt.e, &q_off, &t_off);
 }
 
 // boundary exons held by one weak anchor far from the rest are dropped (mm_fix_bad_ends_splice, align.c:618-636)
-static void trim_bad_ends_splice(const MapOpt &opt, const FlatIndex &fi, const Reg &r, const int8_t *mat, int qlen, const uint8_t *q4, const Anchor *a,
+static void trim_bad_ends_splice(const MapOpt &opt, const FlatIndex &fi, const Reg &r, const int8_t *mat, int qlen, ReadAlign &ra, const Anchor *a,
                                  std::vector<uint8_t> &tbuf, int32_t *as1, int32_t *cnt1)
 {
 	*as1 = r.as, *cnt1 = r.cnt;
 	if (r.cnt < 3) return;
 	double log_gap = log((double)((int32_t)a[r.as + 1].x - (int32_t)a[r.as].x));
 	if (span_of(a[r.as]) < log_gap + opt.anchor_ext_shift) {
-		const int score = seed_ext_score(opt, fi, mat, qlen, q4, a[r.as], tbuf);
+		const int score = seed_ext_score(opt, fi, mat, qlen, ra, a[r.as], tbuf);
 		if ((double)score / mat[0] < log_gap + opt.anchor_ext_shift) ++(*as1), --(*cnt1);
 	}
 	log_gap = log((double)((int32_t)a[r.as + r.cnt - 1].x - (int32_t)a[r.as + r.cnt - 2].x));
 	if (span_of(a[r.as + r.cnt - 1]) < log_gap + opt.anchor_ext_shift) {
-		const int score = seed_ext_score(opt, fi, mat, qlen, q4, a[r.as + r.cnt - 1], tbuf);
+		const int score = seed_ext_score(opt, fi, mat, qlen, ra, a[r.as + r.cnt - 1], tbuf);
 		if ((double)score / mat[0] < log_gap + opt.anchor_ext_shift) --(*cnt1);
 	}
 }
 
 // where an anchor's window boundary sits: the middle of the k-mer, or for HPC indices the start of the
 // homopolymer run holding the anchor's last base (mm_adjust_minier, align.c:418-433)
-static void anchor_boundary(const FlatIndex &fi, const uint8_t *q4, int qlen, const Anchor &a, int32_t *r, int32_t *q)
+static void anchor_boundary(const FlatIndex &fi, ReadAlign &ra, int qlen, const Anchor &a, int32_t *r, int32_t *q)
 {
 	if (fi.flag & I_HPC) {
-		const uint8_t *qseq = q4 + (size_t)(a.x >> 63) * qlen;
+		const uint8_t *qseq = strand_codes(ra, (int)(a.x >> 63));
 		int i, c;
 		*q = (int32_t)a.y;
 		for (i = *q - 1, c = qseq[*q]; i > 0; --i) if (qseq[i] != c) break;
@@ -709,13 +781,13 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 		re = (int32_t)a[as1 + cnt1 - 1].x + 1, qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
 	} else {
 		if (!(opt_.flag & F_NO_END_FLT)) {
-			if (is_splice) trim_bad_ends_splice(opt_, fi_, r, mat_, qlen, ra.q4, a, tbuf_, &as1, &cnt1);
+			if (is_splice) trim_bad_ends_splice(opt_, fi_, r, mat_, qlen, ra, a, tbuf_, &as1, &cnt1);
 			else trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
 		} else as1 = r.as, cnt1 = r.cnt;
 		drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
 		join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
-		anchor_boundary(fi_, ra.q4, qlen, a[as1], &rs, &qs);
-		anchor_boundary(fi_, ra.q4, qlen, a[as1 + cnt1 - 1], &re, &qe);
+		anchor_boundary(fi_, ra, qlen, a[as1], &rs, &qs);
+		anchor_boundary(fi_, ra, qlen, a[as1 + cnt1 - 1], &re, &qe);
 	}
 	assert(cnt1 > 0);
 	t.ksw_flag = 0;
@@ -814,7 +886,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	for (int32_t i = is_sr ? cnt1 - 1 : 1; i < cnt1; ++i) { // a short read has one window, from its first seed to its last (align.c:803)
 		if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
 		if (is_sr) re = (int32_t)a[as1 + i].x + 1, qe = (int32_t)a[as1 + i].y + 1;
-		else anchor_boundary(fi_, ra.q4, qlen, a[as1 + i], &re, &qe);
+		else anchor_boundary(fi_, ra, qlen, a[as1 + i], &re, &qe);
 		if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt_.min_ksw_len && re - rs >= opt_.min_ksw_len)) {
 			Window w; w.kind = W_GAP, w.qs = qs, w.qe = qe, w.rs = rs, w.re = re, w.anchor_i = i;
 			w.bw = bw_long_;
@@ -824,7 +896,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 			if (is_sr_rna && qe - qs != re - rs) { // mm_align_sr_rna's own preconditions (align.c:376-384): a short query whose two ends match the window's ends
 				const int32_t ql = qe - qs, tl = re - rs, ilen = opt_.q2 * 2;
 				if (ql <= 100 && ql * 2 + ilen <= tl) {
-					const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : rev) * qlen + qs;
+					const uint8_t *qseq = strand_codes(ra, qstrand_ ? 0 : rev) + qs;
 					tbuf_.resize(tl);
 					fi_.getseq2(qstrand_ && rev, rid, rs, re, tbuf_.data());
 					int32_t ll = 0, lr = 0;
@@ -836,7 +908,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 			if (is_sr || (is_sr_rna && qe - qs == re - rs)) { // align.c:823-833: the seeds lie on one diagonal; if the ungapped alignment beats any gapped one, it is the result
 				assert(qe - qs == re - rs);
 				const int32_t len = qe - qs, max_gapped_score = (len - 2) * opt_.a - 2 * (opt_.q + opt_.e);
-				const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : rev) * qlen + qs;
+				const uint8_t *qseq = strand_codes(ra, qstrand_ ? 0 : rev) + qs;
 				tbuf_.resize(len);
 				fi_.getseq2(qstrand_ && rev, rid, rs, re, tbuf_.data());
 				int32_t score = 0;
@@ -970,8 +1042,9 @@ void Aligner::schedule(ReadAlign &ra, std::vector<KswJob> &jobs)
 			continue;
 		}
 		if (!t.planned) {
-			plan_region(ra, t);
+			{ hostprof::Scope hp(hostprof::PLAN_REGION); plan_region(ra, t); }
 			if (t.done) continue;
+			hostprof::Scope hp(hostprof::ADD_JOBS);
 			for (Window &w : t.win) {
 				if (w.saved >= 0) continue; // resolved while planning (the ungapped short-read case)
 				if (w.kind == W_LEFT) add_job(ra, t, w, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, t.r.split_inv ? opt_.zdrop_inv : opt_.zdrop, opt_.end_bonus, jobs);
@@ -1007,6 +1080,7 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 	{
 		RegionTask &t = ra.tasks[ti];
 		Reg &r = t.r;
+		hostprof::Scope hp(hostprof::CONSUME_WINDOWS);
 		while (t.next_win < t.win.size()) {
 			Window &w = t.win[t.next_win];
 			if (w.job < 0 && w.saved < 0) return true; // its job has not run yet
@@ -1049,7 +1123,7 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 					return true;
 				}
 				if (!w.pass2) { // the approximate pass: test it (align.c:843)
-					const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : t.rev) * qlen + w.qs;
+					const uint8_t *qseq = strand_codes(ra, qstrand_ ? 0 : t.rev) + w.qs;
 					int code;
 					if (ez.zd_max != KSW_ZD_NONE) { // the kernel scanned its own alignment; sequences are only needed for the rare inversion check
 						ZdropScan z;
@@ -1112,6 +1186,7 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 				++t.next_win;
 			}
 		}
+		hp.stop();
 		finalize_region(ra, t);
 	}
 	if (opt_.flag & F_SPLICE) {
@@ -1147,9 +1222,12 @@ void Aligner::finalize_region(ReadAlign &ra, RegionTask &t)
 	if (!t.rev || qstrand_) r.qs = t.qs1, r.qe = t.qe1; // align.c:894
 	else r.qs = qlen - t.qe1, r.qe = qlen - t.qs1;
 	if (r.p) {
-		tbuf_.resize(t.re1 - t.rs1);
-		fi_.getseq2(qstrand_ && t.rev, t.rid, t.rs1, t.re1, tbuf_.data());
-		const uint8_t *qseq = ra.q4 + (size_t)(qstrand_ ? 0 : r.rev) * qlen + t.qs1;
+		{
+			hostprof::Scope hp(hostprof::GETSEQ);
+			tbuf_.resize((size_t)(t.re1 - t.rs1) + 16); // update_extra compares 16 columns per load
+			fi_.getseq2(qstrand_ && t.rev, t.rid, t.rs1, t.re1, tbuf_.data());
+		}
+		const uint8_t *qseq = strand_codes(ra, qstrand_ ? 0 : r.rev) + t.qs1;
 		update_extra(r, qseq, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX, !(opt_.flag & (F_SR | F_SR_RNA)));
 		if (t.rev && r.p->trans_strand) r.p->trans_strand ^= 3; // align.c:907-908
 	}
@@ -1173,7 +1251,7 @@ void Aligner::try_inversion(ReadAlign &ra, int prev_ti, int ti, int pos_in_order
 	const int strand = r1.rev ? 0 : 1;                      // the query is read on the strand opposite to the flanks
 	const int q0 = r1.rev ? r2.qe : qlen - r2.qs;
 	std::vector<uint8_t> qrev(ql), trev(tl);
-	const uint8_t *qseq = ra.q4 + (size_t)strand * qlen + q0;
+	const uint8_t *qseq = strand_codes(ra, strand) + q0;
 	for (int i = 0; i < ql; ++i) qrev[i] = qseq[ql - 1 - i];
 	fi_.getseq(r1.rid, r1.re, r2.rs, trev.data());
 	std::reverse(trev.begin(), trev.end());
@@ -1217,15 +1295,16 @@ void Aligner::consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const 
 	if (ri.rev == 0) ri.qs = t.inv_r2_qe + t.inv_qoff, ri.qe = ri.qs + ez.max_q + 1;
 	else ri.qe = t.inv_r2_qs - t.inv_qoff, ri.qs = ri.qe - (ez.max_q + 1);
 	ri.rs = t.inv_r1_re + t.inv_toff, ri.re = ri.rs + ez.max_t + 1;
-	tbuf_.resize(w.re - w.rs);
+	tbuf_.resize((size_t)(w.re - w.rs) + 16);
 	fi_.getseq(rid, w.rs, w.re, tbuf_.data());
-	update_extra(ri, ra.q4 + (size_t)t.rev * ra.qlen + w.qs, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX,
+	update_extra(ri, strand_codes(ra, t.rev) + w.qs, tbuf_.data(), mat_, (int8_t)opt_.q, (int8_t)opt_.e, opt_.flag & F_EQX,
 	             !(opt_.flag & (F_SR | F_SR_RNA)));
 	if (slot != ra.order.end()) *slot = ti;
 }
 
 void Aligner::finish_read(ReadAlign &ra, RegVec &out)
 {
+	hostprof::Scope hp(hostprof::FINISH_READ);
 	out.clear();
 	for (int ti : ra.order)
 		if (ti >= 0) out.push_back(ra.tasks[ti].r);

@@ -60,6 +60,8 @@ struct ReadAlign {        // per-read alignment state
 	int qlen = 0;
 	uint64_t qpool_off = 0, qpool_rev = 0;       // where this read's nt4 forward / reverse-complement bytes start in the device query pool
 	uint8_t *q4 = nullptr;                       // fwd (qlen) then reverse complement (qlen), nt4 codes; 2*qlen bytes owned by the caller
+	const char *seq = nullptr;                   // the read as given (owned by the caller, alive for the read's rounds)
+	bool q4_ready[2] = {false, false};           // a strand is encoded when something first looks at it (strand_codes): most reads use one
 	Anchor *a = nullptr;             // the read's chained anchors (modified in place; owned by the caller)
 	int n_a = 0;
 	std::vector<RegionTask> tasks;               // in creation order
@@ -67,6 +69,9 @@ struct ReadAlign {        // per-read alignment state
 	std::vector<uint8_t> tbytes;                 // composed targets of this round's jobs without KSWJ_T_PACKED (KswScoring::tbytes; a job's t_off indexes it)
 	std::vector<uint32_t> juncs;                 // annotated splice sites inside this round's DP windows (KswScoring::juncs entries; a job's tag indexes it)
 };
+
+// nt4 codes of one strand of the read (0 forward, 1 reverse complement), encoded on first use
+const uint8_t *strand_codes(ReadAlign &ra, int strand);
 
 class Aligner {
 public:

@@ -4,6 +4,7 @@
 //     bucket_start[hash >> key_shift]  ->  run of distinct keys (sorted)  ->  val_off[]  ->  pos[]
 // so a lookup costs one dependent load per level and touches 1-2 sectors per level.
 #pragma once
+#include <cstring>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -60,10 +61,12 @@ struct FlatIndex {
 		uint64_t o = seq_off[rid] + st;
 		const uint64_t oe = seq_off[rid] + en;
 		for (; o < oe && (o & 7); ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
-		for (; o + 8 <= oe; o += 8, out += 8) {
-			const uint32_t w = S[o >> 3];
-			out[0] = w & 0xf, out[1] = w >> 4 & 0xf, out[2] = w >> 8 & 0xf, out[3] = w >> 12 & 0xf;
-			out[4] = w >> 16 & 0xf, out[5] = w >> 20 & 0xf, out[6] = w >> 24 & 0xf, out[7] = w >> 28;
+		for (; o + 8 <= oe; o += 8, out += 8) { // eight nibbles spread to eight bytes (little endian: base 0 is the low nibble and the first byte)
+			uint64_t x = S[o >> 3];
+			x = (x | x << 16) & 0x0000FFFF0000FFFFull;
+			x = (x | x << 8) & 0x00FF00FF00FF00FFull;
+			x = (x | x << 4) & 0x0F0F0F0F0F0F0F0Full;
+			memcpy(out, &x, 8);
 		}
 		for (; o < oe; ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
 	}

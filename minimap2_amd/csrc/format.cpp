@@ -11,10 +11,15 @@
 #include <cassert>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 #include "format.hpp"
 #include "threads.hpp"
+#include "host_prof.hpp"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace mm2amd {
 
@@ -33,20 +38,60 @@ const char kCigarOps[] = "MIDNSHP=XB";
 // two cache lines, because std::string updates its length field on EVERY appended byte and neighbouring objects sharing a line made 64
 // threads on two sockets ping-pong it -- 20-40 ns per byte instead of 1.3 (profiles/r03: 25-50 core-seconds per Gbase of reads).
 struct alignas(128) Text {
-	std::string s;
-	void ch(char c) { s.push_back(c); }
-	void str(const char *p) { s.append(p); }
-	void str(const char *p, size_t n) { s.append(p, n); }
+	char *p = nullptr;
+	size_t n = 0, cap = 0;
+	Text() = default;
+	Text(Text &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
+	Text(const Text &) = delete;
+	Text &operator=(const Text &) = delete;
+	~Text() { free(p); }
+	void clear() { n = 0; }
+	size_t size() const { return n; }
+	const char *data() const { return p; }
+	char *need(size_t k) // room for k more bytes; returns where they go (the caller advances n)
+	{
+		if (n + k > cap) {
+			size_t c = cap ? cap : 4096;
+			while (c < n + k) c += c / 2 + 64;
+			char *q = (char *)realloc(p, c);
+			if (!q) throw std::bad_alloc();
+			p = q, cap = c;
+		}
+		return p + n;
+	}
+	void ch(char c) { *need(1) = c, ++n; }
+	void str(const char *s) { str(s, strlen(s)); }
+	void str(const char *s, size_t l) { memcpy(need(l), s, l), n += l; }
+	static char *put_u64(char *w, uint64_t x) // decimal digits of x at w; returns the end
+	{
+		char buf[20];
+		int l = 0;
+		do buf[l++] = (char)('0' + x % 10), x /= 10; while (x);
+		while (l) *w++ = buf[--l];
+		return w;
+	}
+	static char *put_u32(char *w, uint32_t x) // the common case: CIGAR lengths and flags, one to three digits
+	{
+		if (x < 10) { *w++ = (char)('0' + x); return w; }
+		if (x < 100) { w[0] = (char)('0' + x / 10), w[1] = (char)('0' + x % 10); return w + 2; }
+		if (x < 1000) { w[0] = (char)('0' + x / 100), w[1] = (char)('0' + x / 10 % 10), w[2] = (char)('0' + x % 10); return w + 3; }
+		return put_u64(w, x);
+	}
 	void num(int64_t v)
 	{
-		char buf[24];
-		int l = 0;
-		uint64_t x = v < 0 ? (uint64_t)(-v) : (uint64_t)v;
-		do buf[l++] = (char)('0' + x % 10), x /= 10; while (x);
-		if (v < 0) buf[l++] = '-';
-		while (l) s.push_back(buf[--l]);
+		char *w = need(21);
+		if (v < 0) *w++ = '-';
+		const uint64_t x = v < 0 ? (uint64_t)(-v) : (uint64_t)v;
+		w = x <= UINT32_MAX ? put_u32(w, (uint32_t)x) : put_u64(w, x);
+		n = (size_t)(w - p);
 	}
 	void tag(const char *name, int64_t v) { ch('\t'), str(name), num(v); } // "\tNM:i:" + value
+	void cigar(const uint32_t *c, uint32_t n_cigar) // <len><op> per entry
+	{
+		char *w = need((size_t)n_cigar * 11);
+		for (uint32_t k = 0; k < n_cigar; ++k) w = put_u32(w, c[k] >> 4), *w++ = kCigarOps[c[k] & 0xf];
+		n = (size_t)(w - p);
+	}
 };
 
 struct Seqs { std::vector<uint8_t> q, t; std::string tmp; }; // per-thread scratch for cs/ds/MD
@@ -219,11 +264,32 @@ void put_paf(Text &o, const FlatIndex &fi, const Bseq1 &t, const Reg1 *r, int64_
 	if (rep_len >= 0) o.tag("rl:i:", rep_len);
 	if (r->p && (flag & F_OUT_CG)) {
 		o.str("\tcg:Z:");
-		for (uint32_t k = 0; k < r->p->n_cigar; ++k) o.num(r->p->cigar[k] >> 4), o.ch(kCigarOps[r->p->cigar[k] & 0xf]);
+		o.cigar(r->p->cigar, r->p->n_cigar);
 	}
 	if (r->p && (flag & (F_OUT_CS | F_OUT_DS | F_OUT_MD))) put_cs_or_md(o, fi, t, *r, flag, sq);
 	if ((flag & F_COPY_COMMENT) && t.comment) o.ch('\t'), o.str(t.comment);
 }
+
+#if defined(__x86_64__)
+// Reverse complement, 16 bases per step, for blocks made of A/C/G/T/N in either case: the low nibbles of these five letters differ
+// (1, 3, 7, 4, 14), so one byte shuffle maps a letter to its complement and another checks that the block holds nothing else.
+static bool have_ssse3() { static const bool v = __builtin_cpu_supports("ssse3"); return v; }
+__attribute__((target("ssse3"))) static int revcomp_blocks(const char *seq, int l, char *w)
+{
+	const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+	const __m128i self = _mm_setr_epi8(0, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 'N', 0);
+	const __m128i other = _mm_setr_epi8(0, 'T', 0, 'G', 'A', 0, 0, 'C', 0, 0, 0, 0, 0, 0, 'N', 0);
+	const __m128i low = _mm_set1_epi8(0x0f), upper = _mm_set1_epi8((char)0xdf), lower_bit = _mm_set1_epi8(0x20);
+	int i = 0;
+	for (; i + 16 <= l; i += 16) {
+		const __m128i v = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(seq + l - 16 - i)), rev);
+		const __m128i nib = _mm_and_si128(v, low), up = _mm_and_si128(v, upper);
+		if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_shuffle_epi8(self, nib), up)) != 0xffff) break;
+		_mm_storeu_si128((__m128i *)(w + i), _mm_or_si128(_mm_shuffle_epi8(other, nib), _mm_and_si128(v, lower_bit)));
+	}
+	return i;
+}
+#endif
 
 void put_seq(Text &o, const char *seq, int l, bool rev, bool comp) // sam_write_sq (format.c:470-482)
 {
@@ -235,7 +301,16 @@ void put_seq(Text &o, const char *seq, int l, bool rev, bool comp) // sam_write_
 		return t;
 	}();
 	if (!rev) { o.str(seq, l); return; }
-	for (int i = 0; i < l; ++i) { const int c = (unsigned char)seq[l - 1 - i]; o.ch(c < 128 && comp ? kComp[c] : (char)c); }
+	char *w = o.need((size_t)l);
+	if (comp) {
+		int i = 0;
+#if defined(__x86_64__)
+		if (have_ssse3()) i = revcomp_blocks(seq, l, w); // whole 16-base blocks of plain A/C/G/T/N (either case); stops at the first block holding anything else
+#endif
+		for (; i < l; ++i) { const int c = (unsigned char)seq[l - 1 - i]; w[i] = c < 128 ? kComp[c] : (char)c; }
+	}
+	else for (int i = 0; i < l; ++i) w[i] = seq[l - 1 - i];
+	o.n += (size_t)l;
 }
 
 void put_sam_cigar(Text &o, int sam_flag, bool in_tag, int qlen, const Reg1 &r, int64_t flag) // write_sam_cigar (format.c:494-520)
@@ -252,7 +327,7 @@ void put_sam_cigar(Text &o, int sam_flag, bool in_tag, int qlen, const Reg1 &r, 
 	} else {
 		const char c = hard ? 'H' : 'S';
 		if (clip0) o.num(clip0), o.ch(c);
-		for (uint32_t k = 0; k < r.p->n_cigar; ++k) o.num(r.p->cigar[k] >> 4), o.ch(kCigarOps[r.p->cigar[k] & 0xf]);
+		o.cigar(r.p->cigar, r.p->n_cigar);
 		if (clip1) o.num(clip1), o.ch(c);
 	}
 }
@@ -394,6 +469,7 @@ static void format_range(const FlatIndex &fi, const MapOpt &opt, const int *seg_
 {
 	Seqs sq;
 	const int64_t flag = opt.flag;
+	hostprof::Scope hp(hostprof::FORMAT_RANGE);
 	for (long f = lo; f < hi; ++f) {
 		const int seg_st = seg_off ? seg_off[f] : (int)f, ns = n_seg ? n_seg[f] : 1;
 		for (int i = seg_st; i < seg_st + ns; ++i) {
@@ -432,14 +508,14 @@ static size_t format_parts(const FlatIndex &fi, const MapOpt &opt, int n_threads
 	parallel_for_side(n_threads, n_chunks, [&](long c, int) {
 		const auto c0 = std::chrono::steady_clock::now();
 		const long lo = c * chunk, hi = std::min(n, lo + chunk);
-		parts[c].s.clear(); // keeps its capacity: a reused scratch formats into memory it already owns
+		parts[c].clear(); // keeps its capacity: a reused scratch formats into memory it already owns
 		format_range(fi, opt, seg_off, n_seg, seq, n_reg, reg, rep_len, lo, hi, parts[c]);
 		if (trace) busy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count();
 	}, 1);
 	if (trace) fprintf(stderr, "[mm2amd] format: %ld chunks, wall %.3f s, summed chunk time %.3f s on %d threads\n", n_chunks,
 	                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), busy_ns.load() * 1e-9, n_threads);
 	off.assign(n_chunks + 1, 0);
-	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].s.size();
+	for (long c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + parts[c].size();
 	return off[n_chunks];
 }
 
@@ -451,7 +527,7 @@ char *format_batch(const FlatIndex &fi, const MapOpt &opt, int n_threads, long n
 	const size_t total = format_parts(fi, opt, n_threads, n_frag, seg_off, n_seg, seq, n_reg, reg, rep_len, parts, off);
 	char *out = (char *)malloc(total + 1);
 	if (!out) return nullptr;
-	parallel_for_side(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(out + off[c], parts[c].s.data(), parts[c].s.size()); }, 8);
+	parallel_for_side(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(out + off[c], parts[c].data(), parts[c].size()); }, 8);
 	out[total] = 0;
 	*out_len = total;
 	return out;
@@ -468,7 +544,7 @@ const char *format_batch_view(const FlatIndex &fi, const MapOpt &opt, int n_thre
 		fs.buf = (char *)malloc(fs.cap);
 		if (!fs.buf) { fs.cap = 0; return nullptr; }
 	}
-	parallel_for_side(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(fs.buf + off[c], fs.impl->parts[c].s.data(), fs.impl->parts[c].s.size()); }, 8);
+	parallel_for_side(n_threads, (long)off.size() - 1, [&](long c, int) { memcpy(fs.buf + off[c], fs.impl->parts[c].data(), fs.impl->parts[c].size()); }, 8);
 	fs.buf[total] = 0;
 	*out_len = total;
 	return fs.buf;

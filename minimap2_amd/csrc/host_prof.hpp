@@ -1,0 +1,52 @@
+// Cycle accounting of the host stages' inner pieces (MM2AMD_HOST_PROF=1 prints the table when the mapping context is dropped): the GPU box
+// gives the process a CPU quota, so a batch's wall time is bounded below by its host CPU seconds -- this is how they are attributed.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#if defined(__x86_64__)
+#include <x86intrin.h>
+#endif
+
+namespace mm2amd {
+namespace hostprof {
+enum Piece { Q4_ENCODE, CHAINS_TO_HITS, PLAN_REGION, ADD_JOBS, CONSUME_WINDOWS, GETSEQ, FIX_CIGAR, EXTRA_SCAN, FINISH_READ, HAND_OVER, KSW_CLASSIFY, KSW_SCATTER, KSW_UNPERM, FORMAT_RANGE, N_PIECES };
+inline const char *name(int k)
+{
+	static const char *n[N_PIECES] = {"q4_encode", "chains_to_hits", "plan_region", "add_jobs", "consume_windows", "getseq", "fix_cigar", "extra_scan", "finish_read", "hand_over",
+	                                  "ksw_classify", "ksw_scatter", "ksw_unperm", "format_range"};
+	return n[k];
+}
+struct Table {
+	std::atomic<uint64_t> cyc[N_PIECES], cnt[N_PIECES];
+	bool on;
+	Table() : on(getenv("MM2AMD_HOST_PROF") != nullptr) { for (int k = 0; k < N_PIECES; ++k) cyc[k] = 0, cnt[k] = 0; }
+	~Table() { report(); }
+	void report()
+	{
+		if (!on) return;
+		for (int k = 0; k < N_PIECES; ++k)
+			if (cnt[k]) fprintf(stderr, "[mm2amd] host piece %-16s %12.0f kcycles  %10llu calls  %8.0f cycles/call\n", name(k), cyc[k] * 1e-3, (unsigned long long)cnt[k].load(), (double)cyc[k] / cnt[k]);
+	}
+};
+inline Table &table() { static Table t; return t; }
+struct Scope {
+	int k; uint64_t t0 = 0; bool on;
+	explicit Scope(int piece) : k(piece), on(table().on)
+	{
+#if defined(__x86_64__)
+		if (on) t0 = __rdtsc();
+#endif
+	}
+	void stop()
+	{
+#if defined(__x86_64__)
+		if (on) table().cyc[k].fetch_add(__rdtsc() - t0, std::memory_order_relaxed), table().cnt[k].fetch_add(1, std::memory_order_relaxed);
+#endif
+		on = false;
+	}
+	~Scope() { stop(); }
+};
+} // namespace hostprof
+} // namespace mm2amd

@@ -2,6 +2,7 @@
 #include <numeric>
 #include <cstring>
 #include "ksw_host.hpp"
+#include "host_prof.hpp"
 #include "kernel_prof.hpp"
 #include "threads.hpp"
 #include "trace.hpp"
@@ -112,6 +113,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	chunk_hist.assign(n_chunks * NBINS, 0);
 	std::vector<ChunkStat> cstat(n_chunks);
 	parallel_for(n_threads, (long)n_chunks, [&](long c, int) {
+		hostprof::Scope hp(hostprof::KSW_CLASSIFY);
 		ChunkStat st;
 		uint32_t *hist = &chunk_hist[(size_t)c * NBINS];
 		const size_t e = std::min(n, ((size_t)c + 1) * CH);
@@ -188,6 +190,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	}
 	KswJob *sj = sorted.ensure(n);
 	parallel_for(n_threads, (long)n_chunks, [&](long c, int) {
+		hostprof::Scope hp(hostprof::KSW_SCATTER);
 		uint32_t *off = &chunk_hist[(size_t)c * NBINS];
 		const size_t e = std::min(n, ((size_t)c + 1) * CH);
 		for (size_t i = (size_t)c * CH; i < e; ++i) { const uint32_t pos = off[bucket[i]]++; perm[i] = pos; sj[pos] = jobs[i]; } // perm[i] = launch position of job i
@@ -348,7 +351,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		if (attempt > 0) throw std::runtime_error("[mm2amd] CIGAR pool overflow even at worst-case size");
 		pool_cap = sum_len + 16;
 	}
-	parallel_for(n_threads, (long)n, [&](long i, int) { res[i] = tr[perm[i]]; }, 4096);
+	{
+		hostprof::Scope hp(hostprof::KSW_UNPERM);
+		parallel_for(n_threads, (long)n, [&](long i, int) { res[i] = tr[perm[i]]; }, 4096);
+	}
 	Trace::get().add(lane, "host:ksw-unperm", tt, Trace::now());
 }
 

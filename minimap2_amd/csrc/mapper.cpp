@@ -5,6 +5,7 @@
 #include <malloc.h>
 #include <stdexcept>
 #include "mapper.hpp"
+#include "host_prof.hpp"
 #include "chain_host.hpp"
 #include "threads.hpp"
 #include "trace.hpp"
@@ -254,9 +255,10 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			ds.q4_off[unit0[i]] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len;
 			if (live[lo + i].paired()) ds.q4_off[unit0[i] + 1] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len2;
 		}
-		if (ds.q4.size() < q4_total) ds.q4.resize(q4_total + q4_total / 4);
+		if (ds.q4.size() < q4_total + 16) ds.q4.resize(q4_total + q4_total / 4 + 16); // (16 bytes of slack: update_extra compares 16 columns per load)
 		const bool is_sr = (opt_.flag & (F_SR | F_SR_RNA)) != 0;
 		parallel_for(n_threads_, m, [&](long i, int) {
+			hostprof::Scope hp(hostprof::CHAINS_TO_HITS);
 			ReadChains &c = chains[i];
 			const ReadView &rv = live[lo + i];
 			const int qlen = rv.total(), n_segs = rv.paired() ? 2 : 1, qlens[2] = { rv.len, rv.len2 };
