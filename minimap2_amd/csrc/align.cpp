@@ -643,7 +643,7 @@ void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs,
 	ra.qlen = qlen, ra.qpool_off = qpool_fwd, ra.qpool_rev = qpool_rev, ra.a = a;
 	ra.q4 = q4, ra.seq = seq, ra.q4_ready[0] = ra.q4_ready[1] = false;
 	ra.n_a = squeeze_anchors(regs, a);
-	ra.tasks.clear(); ra.order.clear();
+	ra.tasks.clear(); ra.order.clear(); ra.finish_queue.clear();
 	for (size_t i = 0; i < regs.size(); ++i) add_region(ra, regs[i], -1);
 }
 
@@ -1073,6 +1073,77 @@ bool Aligner::consume(ReadAlign &ra, const KswRes *res, const uint32_t *cigar_po
 	return pending;
 }
 
+// A consumed window's CIGAR: appended right away (host mode), or recorded for the device's region_finish
+void Aligner::take_piece(RegionTask &t, const Window &w, const KswRes &ez, const uint32_t *cg, const uint32_t *cigar_pool)
+{
+	if (!t.host_mode && w.saved >= 0) materialize(t, cigar_pool); // a result kept from an earlier step is not in the round's pool
+	if (t.host_mode) { append_cigar(t.r, (uint32_t)ez.n_cigar, cg); return; }
+	const uint32_t n = (uint32_t)ez.n_cigar;
+	t.pieces.push_back(FinPiece{ ez.cigar_off, n });
+	// the container's growth, as enlarge_cigar / append_cigar would have done it
+	if (t.sim_cap == 0) t.sim_cap = roundup32(n + kExtraWords);
+	else if (t.sim_n + n + kExtraWords > t.sim_cap) t.sim_cap = roundup32(t.sim_n + n + kExtraWords);
+	t.sim_n += t.sim_n > 0 && t.sim_last_op == (cg[0] & 0xf) ? n - 1 : n;
+	t.sim_last_op = cg[n - 1] & 0xf;
+}
+
+// The region goes on in the reference's way: append what was recorded (the pieces address the CURRENT round's pool) and carry the score over
+void Aligner::materialize(RegionTask &t, const uint32_t *cigar_pool)
+{
+	if (t.host_mode) return;
+	t.host_mode = true;
+	for (const FinPiece &pc : t.pieces) append_cigar(t.r, pc.n, cigar_pool + pc.off);
+	t.pieces.clear();
+	if (!t.r.p && (t.dropped || t.dp_acc != 0)) { // (the reference creates the container when a Z-drop cuts a region that has no CIGAR yet, align.c:849)
+		const uint32_t cap = roundup32(kExtraWords);
+		t.r.p = (Extra *)calloc(cap, 4);
+		t.r.p->capacity = cap;
+	}
+	if (t.r.p) t.r.p->dp_score += t.dp_acc;
+	t.dp_acc = 0;
+}
+
+void Aligner::describe_finish(const ReadAlign &ra, int ti, FinRegion &fr) const
+{
+	const RegionTask &t = ra.tasks[ti];
+	fr.q_pos = (t.r.rev ? ra.qpool_rev : ra.qpool_off) + (uint64_t)t.qs1;
+	fr.t_pos = fi_.seq_off[t.rid] + (uint64_t)t.rs1;
+	fr.n_pieces = (uint32_t)t.pieces.size();
+	fr.q_len = t.qe1 - t.qs1, fr.t_len = t.re1 - t.rs1;
+}
+
+bool Aligner::complete_finished(ReadAlign &ra, const FinResult *results, const FinRegion *regions, const uint32_t *cigars)
+{
+	hostprof::Scope hp(hostprof::COMPLETE_FINISHED);
+	const std::vector<int> queue = ra.finish_queue; // (after_finalize may queue nothing, but it does touch ra.tasks)
+	ra.finish_queue.clear();
+	for (size_t k = 0; k < queue.size(); ++k) {
+		const int ti = queue[k];
+		const FinResult &f = results[k];
+		if (f.n_cigar < 0) throw std::runtime_error("[mm2amd] region_finish: a stitched CIGAR does not cover its windows");
+		{
+			RegionTask &t = ra.tasks[ti];
+			Reg &r = t.r;
+			const uint32_t cap = t.sim_cap; // >= the stitched length + header, and mm_fix_cigar only shortens
+			if ((uint32_t)f.n_cigar + kExtraWords > cap) throw std::runtime_error("[mm2amd] region_finish: CIGAR longer than its windows' CIGARs");
+			r.p = (Extra *)calloc(cap, 4);
+			r.p->capacity = cap;
+			r.p->n_cigar = (uint32_t)f.n_cigar;
+			memcpy(r.p->cigar, cigars + regions[k].out_off, (size_t)f.n_cigar * 4);
+			r.p->dp_score = t.dp_acc, r.p->dp_max = r.p->dp_max0 = f.dp_max, r.p->n_ambi = (uint32_t)f.n_ambi;
+			r.blen = f.blen, r.mlen = f.mlen, r.is_spliced = f.is_spliced;
+			if (f.qshift) { if (r.rev) r.qe -= f.qshift; else r.qs += f.qshift; } // mm_fix_cigar's dropped leading gap (align.c:171-180)
+			r.rs += f.tshift;
+			t.pieces.clear(), t.dp_acc = 0, t.awaiting_finish = false;
+			t.saved.clear();
+			t.done = true;
+		}
+		after_finalize(ra, ti);
+	}
+	for (const RegionTask &t : ra.tasks) if (!t.done) return true;
+	return false;
+}
+
 bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool)
 {
 	Anchor *a = ra.a;
@@ -1081,13 +1152,15 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 		RegionTask &t = ra.tasks[ti];
 		Reg &r = t.r;
 		hostprof::Scope hp(hostprof::CONSUME_WINDOWS);
+		if (!device_finish_) t.host_mode = true;
+		auto add_score = [&](int32_t v) { if (t.host_mode) r.p->dp_score += v; else t.dp_acc += v; };
 		while (t.next_win < t.win.size()) {
 			Window &w = t.win[t.next_win];
-			if (w.job < 0 && w.saved < 0) return true; // its job has not run yet
+			if (w.job < 0 && w.saved < 0) { materialize(t, cigar_pool); return true; } // its job has not run yet
 			const KswRes &ez = w.saved >= 0 ? t.saved[w.saved].res : res[w.job];
 			const uint32_t *cg = w.saved >= 0 ? t.saved[w.saved].cigar.data() : cigar_pool + ez.cigar_off;
 			if (w.kind == W_LEFT) {
-				if (ez.n_cigar > 0) { append_cigar(r, ez.n_cigar, cg); r.p->dp_score += ez.max; }
+				if (ez.n_cigar > 0) { take_piece(t, w, ez, cg, cigar_pool); add_score(ez.max); }
 				t.rs1 = w.re - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
 				t.qs1 = w.qe - (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
 				++t.next_win;
@@ -1120,10 +1193,11 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 						}
 					}
 					w.job = -1, w.saved = -1;
+					materialize(t, cigar_pool);
 					return true;
 				}
 				if (!w.pass2) { // the approximate pass: test it (align.c:843)
-					const uint8_t *qseq = strand_codes(ra, qstrand_ ? 0 : t.rev) + w.qs;
+					auto qseq_of = [&]() { return strand_codes(ra, qstrand_ ? 0 : t.rev) + w.qs; }; // (encodes the strand: only when the test needs the bases)
 					int code;
 					if (ez.zd_max != KSW_ZD_NONE) { // the kernel scanned its own alignment; sequences are only needed for the rare inversion check
 						ZdropScan z;
@@ -1131,12 +1205,12 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 						if (z.max_zdrop > opt_.zdrop_inv) {
 							tbuf_.resize(w.re - w.rs);
 							fi_.getseq2(qstrand_ && t.rev, t.rid, w.rs, w.re, tbuf_.data());
-							code = zdrop_decide(opt_, z, qseq, tbuf_.data(), mat_);
+							code = zdrop_decide(opt_, z, qseq_of(), tbuf_.data(), mat_);
 						} else code = z.max_zdrop > opt_.zdrop ? 1 : 0;
 					} else {
 						tbuf_.resize(w.re - w.rs);
 						fi_.getseq2(qstrand_ && t.rev, t.rid, w.rs, w.re, tbuf_.data());
-						code = test_zdrop(opt_, qseq, tbuf_.data(), ez.n_cigar, cg, mat_);
+						code = test_zdrop(opt_, qseq_of(), tbuf_.data(), ez.n_cigar, cg, mat_);
 					}
 					if (code != 0) {
 						// keep the results of the later windows of this region: they belong to this round
@@ -1151,12 +1225,13 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 							}
 						}
 						w.pass2 = true, w.zdrop_code = code, w.job = -1, w.saved = -1;
+						materialize(t, cigar_pool);
 						return true;
 					}
 				}
-				if (ez.n_cigar > 0) append_cigar(r, ez.n_cigar, cg);
+				if (ez.n_cigar > 0) take_piece(t, w, ez, cg, cigar_pool);
 				if (ez.zdropped) { // truncated: cut the region here, maybe split off the rest (align.c:848-868)
-					if (!r.p) {
+					if (t.host_mode && !r.p) {
 						const uint32_t cap = roundup32(kExtraWords);
 						r.p = (Extra *)calloc(cap, 4);
 						r.p->capacity = cap;
@@ -1166,7 +1241,7 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 						if ((int32_t)a[t.as1 + j].x <= w.rs + ez.max_t) break;
 					t.dropped = true;
 					if (j < 0) j = 0;
-					r.p->dp_score += ez.max;
+					add_score(ez.max);
 					t.re1 = w.rs + (ez.max_t + 1);
 					t.qe1 = w.qs + (ez.max_q + 1);
 					if (t.cnt1 - (j + 1) >= opt_.min_cnt) {
@@ -1176,19 +1251,39 @@ bool Aligner::consume_region(ReadAlign &ra, int ti, const KswRes *res, const uin
 					t.next_win = t.win.size();
 					break;
 				}
-				r.p->dp_score += ez.score;
+				add_score(ez.score);
 				t.re1 = w.re, t.qe1 = w.qe;
 				++t.next_win;
 			} else { // W_RIGHT; only reached when nothing was dropped (align.c:874)
-				if (ez.n_cigar > 0) { append_cigar(r, ez.n_cigar, cg); r.p->dp_score += ez.max; }
+				if (ez.n_cigar > 0) { take_piece(t, w, ez, cg, cigar_pool); add_score(ez.max); }
 				t.re1 = w.rs + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
 				t.qe1 = w.qs + (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
 				++t.next_win;
 			}
 		}
 		hp.stop();
+		if (!t.host_mode && device_finish_ && !qstrand_ && !(opt_.flag & F_EQX)) { // every window came back in this round: the device stitches and finishes it
+			size_t n_ops = 0;
+			for (const FinPiece &pc : t.pieces) n_ops += pc.n;
+			if (n_ops > 0 && n_ops <= (size_t)kFinMaxOps) {
+				const int qlen = ra.qlen;
+				r.rs = t.rs1, r.re = t.re1;
+				if (!t.rev) r.qs = t.qs1, r.qe = t.qe1; // align.c:894
+				else r.qs = qlen - t.qe1, r.qe = qlen - t.qs1;
+				t.awaiting_finish = true;
+				ra.finish_queue.push_back(ti);
+				return true;
+			}
+		}
+		materialize(t, cigar_pool);
 		finalize_region(ra, t);
 	}
+	return after_finalize(ra, ti);
+}
+
+// what follows a region's completion in mm_align_skeleton (align.c:1078-1108); returns whether it created more work
+bool Aligner::after_finalize(ReadAlign &ra, int ti)
+{
 	if (opt_.flag & F_SPLICE) {
 		const int twin = ra.tasks[ti].twin;
 		if (twin >= 0) { // two strand attempts: the second one to finish picks the winner (align.c:1078-1096)

@@ -10,6 +10,7 @@
 #include "hits.hpp"
 #include "flat_index.hpp"
 #include "ksw_dev.hpp"
+#include "region_finish.hpp"
 
 namespace mm2amd {
 
@@ -52,6 +53,13 @@ struct RegionTask {
 	bool lead = true;
 	bool chain_ungapped = false;                 // the chain spans equally many query and reference bases (splice:sr rule, align.c:1072)
 	std::vector<SavedResult> saved;              // results carried over a round boundary (only when a region stalls)
+	// A region whose windows all come back in one round is finished on the device (region_finish.hip): consuming its windows only RECORDS
+	// their CIGARs (position in the round's pool) and sums their scores; a region that stalls appends what was recorded and goes on in the
+	// reference's way (host_mode).
+	std::vector<FinPiece> pieces;
+	uint32_t sim_cap = 0, sim_n = 0, sim_last_op = 0; // what mm_extra_t::capacity and n_cigar would be had the pieces been appended one by one (align.c:305-334): the hand-over carries `capacity`
+	int32_t dp_acc = 0;
+	bool host_mode = false, awaiting_finish = false;
 	// inversion-rescue tasks only (mm_align1_inv): where the extension starts and what it is anchored to
 	int32_t inv_q0 = 0, inv_t0 = 0, inv_r2_qs = 0, inv_r2_qe = 0, inv_r1_re = 0, inv_qoff = 0, inv_toff = 0;
 };
@@ -68,6 +76,7 @@ struct ReadAlign {        // per-read alignment state
 	std::vector<int> order;                      // output order: indices into tasks (inversions included)
 	std::vector<uint8_t> tbytes;                 // composed targets of this round's jobs without KSWJ_T_PACKED (KswScoring::tbytes; a job's t_off indexes it)
 	std::vector<uint32_t> juncs;                 // annotated splice sites inside this round's DP windows (KswScoring::juncs entries; a job's tag indexes it)
+	std::vector<int> finish_queue;               // tasks of this round waiting for the device's region_finish (Aligner::consume fills, complete_finished drains)
 };
 
 // nt4 codes of one strand of the read (0 forward, 1 reverse complement), encoded on first use
@@ -83,6 +92,12 @@ public:
 	void schedule(ReadAlign &ra, std::vector<KswJob> &jobs);
 	// Consume results; returns true when the read still has unfinished work (another round needed).
 	bool consume(ReadAlign &ra, const KswRes *res, const uint32_t *cigar_pool);
+	// With device_finish(true), consume() leaves the regions it could finish in ra.finish_queue; the caller sends them through
+	// Backend::finish_regions (describe_finish fills one record per queued task) and hands the results back: complete_finished() does what
+	// follows a region's completion (strand choice, split-off tails, inversion rescue) and returns whether the read still has unfinished work.
+	void device_finish(bool on) { device_finish_ = on; }
+	void describe_finish(const ReadAlign &ra, int ti, FinRegion &fr) const; // everything but piece0 / out_off
+	bool complete_finished(ReadAlign &ra, const FinResult *results, const FinRegion *regions, const uint32_t *cigars);
 	// Collect the regions in output order and run the post-alignment steps of mm_align_skeleton (:1110-1118).
 	void finish_read(ReadAlign &ra, RegVec &out);
 
@@ -97,6 +112,10 @@ private:
 	bool consume_region(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
 	void consume_inversion(ReadAlign &ra, int ti, const KswRes *res, const uint32_t *cigar_pool);
 	void finalize_region(ReadAlign &ra, RegionTask &t);
+	bool after_finalize(ReadAlign &ra, int ti);
+	void take_piece(RegionTask &t, const Window &w, const KswRes &ez, const uint32_t *cg, const uint32_t *cigar_pool);
+	void materialize(RegionTask &t, const uint32_t *cigar_pool);
+	bool device_finish_ = false;
 	void try_inversion(ReadAlign &ra, int prev_ti, int ti, int pos_in_order);
 
 	const ref::MapOpt &opt_;

@@ -7,6 +7,7 @@
 #include "types.hpp"
 #include "flat_index.hpp"
 #include "ksw_dev.hpp"
+#include "region_finish.hpp"
 
 namespace mm2amd {
 
@@ -66,6 +67,12 @@ public:
 	// batched extension DP (ksw_extd2 semantics); *cigar points at the batch's packed CIGARs (backend-owned, valid until the next
 	// call), addressed by res[i].cigar_off
 	virtual void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) = 0;
+	// The regions' last step on the device (region_finish.hpp): stitches the windows' CIGARs of this lane's LAST ksw() call (pieces address its
+	// pool), left-aligns and counts as mm_update_extra does.  results[i] belongs to regions[i]; its CIGAR is at *cigars + regions[i].out_off
+	// (backend-owned, valid until the lane's next call).  out_words = room needed in the output pool.
+	virtual bool finishes_regions() const { return false; }
+	virtual void finish_regions(int /*lane*/, const std::vector<FinRegion> & /*regions*/, const std::vector<FinPiece> & /*pieces*/, size_t /*out_words*/, const int8_t * /*mat25*/,
+	                            int /*q*/, int /*e*/, bool /*log_gap*/, std::vector<FinResult> & /*results*/, const uint32_t ** /*cigars*/) {}
 };
 
 } // namespace mm2amd

@@ -42,6 +42,8 @@ struct Lane {
 	DevBuf<uint8_t> d_tbytes;
 	DevBuf<uint32_t> d_sort_list;
 	PinBuf<uint32_t> h_sort_list;
+	DevBuf<FinRegion> d_fin_regions; DevBuf<FinPiece> d_fin_pieces; DevBuf<uint32_t> d_fin_out; DevBuf<FinResult> d_fin_res; // region_finish.hip
+	PinBuf<FinRegion> h_fin_regions; PinBuf<FinPiece> h_fin_pieces; PinBuf<uint32_t> h_fin_out; PinBuf<FinResult> h_fin_res;
 	PinBuf<Anchor> h_anchors, h_redo;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
@@ -422,6 +424,39 @@ public:
 		}
 		ln.ksw.run(jobs, res_[cur_].d_qpool.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id, replica_).collect();
+	}
+
+	bool finishes_regions() const override { static const bool off = getenv("MM2AMD_HOST_FINISH") != nullptr; return !off; } // (diagnostic: the host's mm_update_extra instead)
+	void finish_regions(int lane_id, const std::vector<FinRegion> &regions, const std::vector<FinPiece> &pieces, size_t out_words, const int8_t *mat25, int q, int e, bool log_gap,
+	                    std::vector<FinResult> &results, const uint32_t **cigars) override
+	{
+		HIP_CHECK(hipSetDevice(dev_));
+		Lane &ln = *lanes_.at(lane_id);
+		const size_t n = regions.size();
+		results.resize(n);
+		*cigars = nullptr;
+		if (n == 0) return;
+		memcpy(ln.h_fin_regions.ensure(n), regions.data(), n * sizeof(FinRegion));
+		memcpy(ln.h_fin_pieces.ensure(pieces.size() + 1), pieces.data(), pieces.size() * sizeof(FinPiece));
+		ln.d_fin_regions.ensure(n), ln.d_fin_pieces.ensure(pieces.size() + 1), ln.d_fin_out.ensure(out_words + 1), ln.d_fin_res.ensure(n);
+		ln.h_fin_out.ensure(out_words + 1), ln.h_fin_res.ensure(n);
+		HIP_CHECK(hipMemcpyAsync(ln.d_fin_regions.p, ln.h_fin_regions.p, n * sizeof(FinRegion), hipMemcpyHostToDevice, ln.stream));
+		HIP_CHECK(hipMemcpyAsync(ln.d_fin_pieces.p, ln.h_fin_pieces.p, pieces.size() * sizeof(FinPiece), hipMemcpyHostToDevice, ln.stream));
+		FinParams P;
+		P.regions = ln.d_fin_regions.p, P.n_regions = (int)n, P.pieces = ln.d_fin_pieces.p, P.cigar_pool = ln.ksw.d_cigar.p, P.out_pool = ln.d_fin_out.p, P.results = ln.d_fin_res.p;
+		P.qpool = res_[cur_].d_qpool.p, P.S = T_->S.p;
+		memcpy(P.mat, mat25, 25);
+		P.q = (int8_t)q, P.e = (int8_t)e, P.log_gap = log_gap ? 1 : 0;
+		KernelProfiler &prof = kernel_profiler(lane_id, replica_);
+		prof.begin(ln.stream);
+		region_finish_launch(P, ln.stream);
+		prof.end(ln.stream, "region_finish_kernel", (double)out_words * 8.0 + (double)n * (sizeof(FinRegion) + sizeof(FinResult)), (double)n);
+		HIP_CHECK(hipMemcpyAsync(ln.h_fin_res.p, ln.d_fin_res.p, n * sizeof(FinResult), hipMemcpyDeviceToHost, ln.stream));
+		HIP_CHECK(hipMemcpyAsync(ln.h_fin_out.p, ln.d_fin_out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
+		stream_wait(ln.stream);
+		memcpy(results.data(), ln.h_fin_res.p, n * sizeof(FinResult));
+		*cigars = ln.h_fin_out.p;
+		prof.collect();
 	}
 
 private:

@@ -673,7 +673,8 @@ int mm2amd_last_stats(double *v, int n)
 	std::lock_guard<std::mutex> lk_stats(g_ctx->stats_mu);
 	const MapperStats &s = g_ctx->stats;
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
-	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2) };
+	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2),
+	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -11,11 +11,11 @@
 
 namespace mm2amd {
 namespace hostprof {
-enum Piece { Q4_ENCODE, CHAINS_TO_HITS, PLAN_REGION, ADD_JOBS, CONSUME_WINDOWS, GETSEQ, FIX_CIGAR, EXTRA_SCAN, FINISH_READ, HAND_OVER, KSW_CLASSIFY, KSW_SCATTER, KSW_UNPERM, FORMAT_RANGE, N_PIECES };
+enum Piece { Q4_ENCODE, CHAINS_TO_HITS, PLAN_REGION, ADD_JOBS, CONSUME_WINDOWS, GETSEQ, FIX_CIGAR, EXTRA_SCAN, FINISH_READ, HAND_OVER, KSW_CLASSIFY, KSW_SCATTER, KSW_UNPERM, FORMAT_RANGE, GEN_REGS, PARENT_SELECT, EST_ERR, BEGIN_READ, COMPLETE_FINISHED, N_PIECES };
 inline const char *name(int k)
 {
 	static const char *n[N_PIECES] = {"q4_encode", "chains_to_hits", "plan_region", "add_jobs", "consume_windows", "getseq", "fix_cigar", "extra_scan", "finish_read", "hand_over",
-	                                  "ksw_classify", "ksw_scatter", "ksw_unperm", "format_range"};
+	                                  "ksw_classify", "ksw_scatter", "ksw_unperm", "format_range", "gen_regs", "parent_select", "est_err", "begin_read", "complete_finished"};
 	return n[k];
 }
 struct Table {

@@ -4,9 +4,9 @@
 // Two extensions per read, small (a 10 kb ONT read's flanks: query ~50, target ~100) but with everything the gap fills do not need: the
 // EXACT maximum of every anti-diagonal with the reference's tie order (:325-358), the best scores on the last query row and target column,
 // the Z-drop test on every row (ksw2.h:171-187), the end bonus, tracebacks that start at the best cell, right-aligned gaps.  They used to
-// take the lane-exact kernel (ksw_extd2.hip): 3 % of the DP cells, a quarter of the kernel time.  When the band cannot bind (w >= qlen +
-// tlen) only valid cells matter (ksw_gapfill.hip explains why), so they run here on the register-resident layout instead: lane = target
-// column, four register sets of 64 columns (targets up to 256), two jobs per wavefront in the halves of packed 16-bit registers, the same
+// take the lane-exact kernel (ksw_extd2.hip): 3 % of the DP cells, a quarter of the kernel time.  When the band cannot bind (w + 1 >=
+// max(qlen, tlen): ksw_host.cpp, band_cannot_bind) only valid cells matter (ksw_gapfill.hip explains why), so they run here on the register-resident layout instead: lane = target
+// column, four, eight or twelve register sets of 64 columns (targets up to 256 / 512 / 768), two jobs per wavefront in the halves of packed 16-bit registers, the same
 // cell arithmetic (gf_cell; gf_cell_right for KSW_EZ_RIGHT) and direction dwords.  On top of it every column keeps its cell's score H as a
 // 32-bit register per job: H += v down a column, H(left neighbour, row before) + u where a column starts (:329-357) -- mathematically the
 // scores the reference recovers from its difference arrays; the row maximum is a DPP reduction, its position is picked among the lanes that
@@ -21,7 +21,7 @@ namespace mm2amd {
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-constexpr int EX_NC = 4, EX_QCAP = 512; // targets up to 64 * EX_NC columns, queries up to EX_QCAP
+constexpr int EX_QCAP = 512; // queries up to EX_QCAP; targets up to 64 * NC columns (NC register sets: 4, 8 or 12)
 
 // One register set and anti-diagonal with RIGHT-aligned gaps (ksw2_extd2_sse.c:282-320): the LAST of (s, a, b, a2, b2) that reaches the
 // maximum names the state (ties go to the gap states), and a gap continues when its value is >= 0, not > 0.  Same operands and results
@@ -52,8 +52,8 @@ __device__ __forceinline__ void gf_cell_right(uint32_t x1, uint32_t o1, uint32_t
 
 struct ExtState { int max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, done; };
 
-template <bool RIGHT>
-__global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
+template <bool RIGHT, int NC>
+__global__ void __launch_bounds__(256, NC > 4 ? 2 : 4) ksw_ext_kernel(KswLaunch L) // (eight sets: ~190 VGPRs, two workgroups per CU)
 {
 	__shared__ uint8_t s_q[4][2][EX_QCAP]; // query bytes of the pair
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
 		for (int i = lane; i < qlen[1]; i += 64) qb[EX_QCAP + i] = L.qpool[(JB.flag & KSWJ_Q_REVERSED) ? JB.q_off - (uint64_t)i : JB.q_off + (uint64_t)i];
 		WAVE_SYNC();
 
-		uint32_t T[EX_NC], U[EX_NC], V[EX_NC], X[EX_NC], Y[EX_NC], X2[EX_NC], Y2[EX_NC], DE[EX_NC];
-		int32_t H[2][EX_NC];
+		uint32_t T[NC], U[NC], V[NC], X[NC], Y[NC], X2[NC], Y2[NC], DE[NC];
+		int32_t H[2][NC];
 #pragma unroll
-		for (int c = 0; c < EX_NC; ++c) {
+		for (int c = 0; c < NC; ++c) {
 			const int t = c * 64 + lane;
 			uint32_t bA = 4, bB = 4;
 			if (t < tlen[0]) {
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
 				const int edge_set = r >> 6, edge_lane = r & 63;
 				const uint32_t edge_halves = (topA ? 0xffffu : 0u) | (topB ? 0xffff0000u : 0u);
 #pragma unroll
-				for (int c = EX_NC - 1; c >= 0; --c) { // from the highest set down: set c still sees row r - 1 in set c - 1
+				for (int c = NC - 1; c >= 0; --c) { // from the highest set down: set c still sees row r - 1 in set c - 1
 					if (c * 64 > hi2 || c * 64 + 63 < lo2) continue;
 					uint32_t cV = S_BND, cX = S_NQE, cX2 = S_NQE2;
 					if (c > 0) cV = gf_ror1(V[c - 1]), cX = gf_ror1(X[c - 1]), cX2 = gf_ror1(X2[c - 1]);
@@ -171,14 +171,14 @@ __global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
 					int32_t hleft = 0;             // H of the cell left of it on the row before
 					if (edge && r > 0) {
 #pragma unroll
-						for (int c = 0; c < EX_NC; ++c) {
+						for (int c = 0; c < NC; ++c) {
 							if (edge_lane > 0 && c == edge_set) hleft = __builtin_amdgcn_readlane(H[h][c], edge_lane - 1);
 							if (edge_lane == 0 && c + 1 == edge_set) hleft = __builtin_amdgcn_readlane(H[h][c], 63);
 						}
 					}
 					int32_t best = INT32_MIN;
 #pragma unroll
-					for (int c = 0; c < EX_NC; ++c) {
+					for (int c = 0; c < NC; ++c) {
 						if (c < (st0 >> 6) || c > (en0 >> 6)) continue;
 						const int t = c * 64 + lane;
 						const int32_t dv = (int32_t)(int16_t)(V[c] >> (16 * h)), du = (int32_t)(int16_t)(U[c] >> (16 * h));
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
 					const int en1 = st0 + ((en0 - st0) & ~3), nq = (en1 - st0) >> 2;
 					int best_rank = INT32_MAX, max_t = en0;
 #pragma unroll
-					for (int c = 0; c < EX_NC; ++c) {
+					for (int c = 0; c < NC; ++c) {
 						if (c < (st0 >> 6) || c > (en0 >> 6)) continue;
 						const int t = c * 64 + lane;
 						unsigned long long cand = __ballot(t >= st0 && t <= en0 && H[h][c] == max_H);
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
 					}
 					int32_t Hen = 0, Hst = 0;
 #pragma unroll
-					for (int c = 0; c < EX_NC; ++c) {
+					for (int c = 0; c < NC; ++c) {
 						if (c == (en0 >> 6)) Hen = __builtin_amdgcn_readlane(H[h][c], en0 & 63);
 						if (c == (st0 >> 6)) Hst = __builtin_amdgcn_readlane(H[h][c], st0 & 63);
 					}
@@ -307,13 +307,21 @@ __global__ void __launch_bounds__(256, 4) ksw_ext_kernel(KswLaunch L)
 	}
 }
 
-void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, void *stream)
+void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream)
 {
 	if (L.n_jobs <= 0) return;
 	const int n_blocks = (n_slots + 3) / 4;
 	hipStream_t s = (hipStream_t)stream;
-	if (right) hipLaunchKernelGGL((ksw_ext_kernel<true>), dim3(n_blocks), dim3(256), 0, s, L);
-	else hipLaunchKernelGGL((ksw_ext_kernel<false>), dim3(n_blocks), dim3(256), 0, s, L);
+	if (n_sets <= 4) {
+		if (right) hipLaunchKernelGGL((ksw_ext_kernel<true, 4>), dim3(n_blocks), dim3(256), 0, s, L);
+		else hipLaunchKernelGGL((ksw_ext_kernel<false, 4>), dim3(n_blocks), dim3(256), 0, s, L);
+	} else if (n_sets <= 8) {
+		if (right) hipLaunchKernelGGL((ksw_ext_kernel<true, 8>), dim3(n_blocks), dim3(256), 0, s, L);
+		else hipLaunchKernelGGL((ksw_ext_kernel<false, 8>), dim3(n_blocks), dim3(256), 0, s, L);
+	} else {
+		if (right) hipLaunchKernelGGL((ksw_ext_kernel<true, 12>), dim3(n_blocks), dim3(256), 0, s, L);
+		else hipLaunchKernelGGL((ksw_ext_kernel<false, 12>), dim3(n_blocks), dim3(256), 0, s, L);
+	}
 	HIP_CHECK(hipGetLastError());
 }
 

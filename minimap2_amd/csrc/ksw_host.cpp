@@ -25,7 +25,9 @@ constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice 
 constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
 // kFirstExt, kFirstExt + 1: the register-resident extension kernel (ksw_ext.hip): the two extensions per read whose band cannot bind,
 // left-aligned (right extensions) and right-aligned (left extensions: KSW_EZ_RIGHT); two jobs per wave.
-constexpr int kNTiers = kFirstExt + 2, kExtMaxQ = 512, kExtMaxT = 256;
+static const char *const kExtNames[6] = {"ksw_ext_kernel[left-aligned]", "ksw_ext_kernel[right-aligned]", "ksw_ext_kernel[left-aligned,t512]", "ksw_ext_kernel[right-aligned,t512]",
+                                         "ksw_ext_kernel[left-aligned,t768]", "ksw_ext_kernel[right-aligned,t768]"};
+constexpr int kNTiers = kFirstExt + 6, kExtMaxQ = 512, kExtMaxT = 768; // + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512, + 4/5: up to 768
 const int kSpliceSets[kSpliceClasses] = { 2, 4, 4 };
 const bool kSpliceSelf[kSpliceClasses] = { false, false, true };
 const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
@@ -43,13 +45,18 @@ inline int fast_waves(int tier) { return kFastQCap[tier] > 512 ? 4 : 6; } // wav
 inline int stream_sets(int tier) { return tier == 0 ? 4 : tier == 1 ? 8 : 0; } // classes the streaming kernel takes (query <= 512, target <= 64 * sets); 0: the strip kernel
 inline int fast_tier(const KswJob &j) { int t = j.qlen <= 512 && j.tlen <= 1536 ? 0 : 3; while (j.tlen > kFastMaxT[t]) ++t; return t; }
 
+// ksw_extd2_sse limits anti-diagonal r to t in [max(0, r - qlen + 1, (r - w + 1) >> 1), min(tlen - 1, r, (r + w) >> 1)] (ksw2_extd2_sse.c:139-146).
+// The band terms never decide when (r - w + 1) >> 1 <= max(0, r - qlen + 1) and (r + w) >> 1 >= min(r, tlen - 1) for every r, i.e. when
+// w >= qlen - 1 and w >= tlen - 1: the row limits, and with them every boundary value the reference picks (:148-163), are then those of an
+// unbanded call.  (Rounds 1-2 used the sufficient w >= qlen + tlen, which sent every extension longer than 375 + 376 to the lane-exact kernel.)
+inline bool band_cannot_bind(const KswJob &j) { return j.w < 0 || ((int64_t)j.w + 1 >= j.qlen && (int64_t)j.w + 1 >= j.tlen); }
 // A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
 // score (the gap-fill call, align.c:838), default substitution scores, and a band that cannot bind.
 inline bool fast_eligible(const KswJob &j, bool scoring_ok)
 {
 	if (!scoring_ok || (j.flag & 0x1fff) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
 	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastMaxQ || j.tlen > kFastMaxTAny) return false;
-	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
+	return band_cannot_bind(j);
 }
 // The splice gap fill (align.c:840 with -x splice) may take the register-resident splice kernel: global alignment with the
 // approximate score, default substitution scores, forward CIGAR, no junction scores; the scoring must
@@ -69,7 +76,7 @@ inline bool ext_eligible(const KswJob &j, bool scoring_ok)
 	const int f = j.flag & 0x1fff;
 	if (!scoring_ok || (j.flag & KSWJ_SKIP) || (f != KSW_EXTZ_ONLY && f != (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR))) return false;
 	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.tlen > kExtMaxT) return false;
-	return j.w < 0 || (int64_t)j.w >= (int64_t)j.qlen + j.tlen;
+	return band_cannot_bind(j);
 }
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 }
@@ -79,7 +86,7 @@ void ksw_stream_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream
 size_t ksw_stream_slot_bytes(int n_sets);
 int ksw_stream_waves(int n_sets);
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
-void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, void *stream);               // ksw_ext.hip
+void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);               // ksw_ext.hip
 
 void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                     const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
@@ -125,7 +132,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast || xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 			if (fast) tier = fast_tier(j);
-			else if (xfast) tier = kFirstExt + ((j.flag & KSW_RIGHT) ? 1 : 0);
+			else if (xfast) tier = kFirstExt + (j.tlen > 512 ? 4 : j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
 			else if (sfast) {
 				int nc = 0, dc = 0;
 				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
@@ -258,7 +265,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (P.hbm) P.wpb = 4;
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (xfast) blocks_per_cu = 4;
+			if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (8 and 12 register sets: 174 / ~250 VGPRs)
 			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (n_stream) blocks_per_cu = ksw_stream_waves(n_stream);
 			else if (fast) blocks_per_cu = fast_waves(tier);
@@ -322,12 +329,12 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
 			if (n_stream) ksw_stream_launch(L, (int)P.n_slots, n_stream, stream_);
 			else if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
-			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, tier == kFirstExt + 1, stream_);
+			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, ((tier - kFirstExt) & 1) != 0, 4 * ((tier - kFirstExt) / 2 + 1), stream_);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			static const char *kStreamNames[2] = { "ksw_stream_kernel<4>[t256]", "ksw_stream_kernel<8>[t512]" };
-			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstExt ? (tier == kFirstExt ? "ksw_ext_kernel[left-aligned]" : "ksw_ext_kernel[right-aligned]") : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstExt ? kExtNames[tier - kFirstExt] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
 		}
 		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));

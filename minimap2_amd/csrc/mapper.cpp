@@ -162,7 +162,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 		// per-sub-batch arrays, so that steady-state batches allocate (and page-fault) nothing
 		DriverScratch &ds = *scratch_.at(lane);
 		std::vector<std::unique_ptr<Aligner>> &al = ds.al;
-		if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)); }
+		if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)), p->device_finish(be_.finishes_regions()); }
 		try {
 			for (;;) {
 				const size_t si = next_sub.fetch_add(1);
@@ -292,17 +292,19 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			chain_gaps(sp, qlen, &gap_ref, &gap_qry);
 			res.frag_gap = gap_ref, res.rep_len = c.rep_len; // map.c:317-318
 			RegVec &r0 = regs0[i];
-			gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, (opt_.flag & F_QSTRAND) != 0, r0);
+			{ hostprof::Scope hp2(hostprof::GEN_REGS); gen_regs(hash, qlen, c.u_p, c.n_u, c.a_p, (opt_.flag & F_QSTRAND) != 0, r0); }
 			if (fi_.n_alt) { // mm_mark_alt + re-sort with ALT hits handicapped (map.c:321-324)
 				for (Reg &r : r0) if (fi_.is_alt[r.rid]) r.is_alt = 1;
 				hit_sort(r0, opt_.alt_drop);
 			}
 			if (!(opt_.flag & F_ALL_CHAINS)) { // chain_post (map.c:206-213)
+				hostprof::Scope hp2(hostprof::PARENT_SELECT);
 				set_parent(opt_.mask_level, opt_.mask_len, r0, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
 				if (n_segs <= 1) select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, true, (int)(opt_.max_gap * 0.8), r0);
 				else select_sub_multi(opt_.pri_ratio, 0.2f, 0.7f, gap_ref, fi_.k * 2, opt_.best_n, n_segs, qlens, r0);
 			}
 			if (!(opt_.flag & (F_SR | F_QSTRAND))) { // map.c:333-336
+				hostprof::Scope hp2(hostprof::EST_ERR);
 				est_err(fi_, qlen, r0, c.a_p, c.mp_p, c.n_mp);
 				filter_strand_retained(r0);
 			}
@@ -312,6 +314,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 					set_mapq(res.regs, opt_.min_chain_score, opt_.a, res.rep_len, is_sr, opt_.flag & F_SPLICE);
 					return;
 				}
+				hostprof::Scope hp2(hostprof::BEGIN_READ);
 				aligner.begin_read(ra[u0], rv.seq, qlen, r0, c.a_p, qoff[lo + i], qoff[lo + i] + (uint64_t)qlen, ds.q4.data() + ds.q4_off[u0]);
 				return;
 			}
@@ -403,6 +406,40 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
+			// the regions whose windows all came back: stitched, left-aligned and counted on the device (region_finish.hip), then completed here
+			if (be_.finishes_regions()) {
+				std::vector<FinRegion> &fregs = ds.fin_regions;
+				std::vector<FinPiece> &fpieces = ds.fin_pieces;
+				std::vector<size_t> &fbase = ds.fin_base; // first queued region of each unit
+				fbase.resize(mu + 1);
+				fbase[0] = 0;
+				for (long i = 0; i < mu; ++i) fbase[i + 1] = fbase[i] + ra[i].finish_queue.size();
+				if (fbase[mu] > 0) {
+					fregs.resize(fbase[mu]);
+					size_t n_pieces = 0, out_words = 0;
+					for (long i = 0; i < mu; ++i)
+						for (size_t k = 0; k < ra[i].finish_queue.size(); ++k) {
+							FinRegion &fr = fregs[fbase[i] + k];
+							al[0]->describe_finish(ra[i], ra[i].finish_queue[k], fr);
+							fr.piece0 = (uint32_t)n_pieces, fr.out_off = (uint32_t)out_words;
+							n_pieces += fr.n_pieces;
+							for (const FinPiece &pc : ra[i].tasks[ra[i].finish_queue[k]].pieces) out_words += pc.n;
+						}
+					if (out_words >= (1ull << 32)) throw std::runtime_error("[mm2amd] region_finish: CIGAR pool of a sub-batch exceeds 32-bit offsets");
+					fpieces.resize(n_pieces);
+					parallel_for(n_threads_, mu, [&](long i, int) {
+						for (size_t k = 0; k < ra[i].finish_queue.size(); ++k) {
+							const std::vector<FinPiece> &src = ra[i].tasks[ra[i].finish_queue[k]].pieces;
+							memcpy(&fpieces[fregs[fbase[i] + k].piece0], src.data(), src.size() * sizeof(FinPiece));
+						}
+					}, 256);
+					const uint32_t *fin_cigars = nullptr;
+					be_.finish_regions(lane, fregs, fpieces, out_words, aligner.mat(), opt_.q, opt_.e, !(opt_.flag & (F_SR | F_SR_RNA)), ds.fin_results, &fin_cigars);
+					parallel_for(n_threads_, mu, [&](long i, int tid) {
+						if (!ra[i].finish_queue.empty()) active[i] = al[tid]->complete_finished(ra[i], ds.fin_results.data() + fbase[i], fregs.data() + fbase[i], fin_cigars) ? 1 : 0;
+					});
+				}
+			}
 			Trace::get().add(lane, "host:consume", t0, now());
 			stats.t_consume += now() - t0;
 			stats.c_consume += cpu_now() - c0;

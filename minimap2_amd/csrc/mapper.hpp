@@ -58,6 +58,10 @@ private:
 		std::vector<uint8_t> q4;
 		std::vector<uint64_t> q4_off;
 		std::vector<std::unique_ptr<Aligner>> al;
+		std::vector<FinRegion> fin_regions;      // the round's regions for Backend::finish_regions, their windows' CIGARs, the results
+		std::vector<FinPiece> fin_pieces;
+		std::vector<FinResult> fin_results;
+		std::vector<size_t> fin_base;
 	};
 	std::vector<std::unique_ptr<DriverScratch>> scratch_;
 	void process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, std::vector<ReadResult> &out, MapperStats &st);

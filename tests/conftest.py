@@ -24,7 +24,7 @@ EMU = os.environ.get("MM2AMD_EMU") == "1"
 
 
 def emu_lib_path():
-    return os.path.join(ROOT, "tests", "_build", "libmm2amd_emu.so")
+    return os.environ.get("MM2AMD_EMU_LIB") or os.path.join(ROOT, "tests", "_build", "libmm2amd_emu.so")  # (MM2AMD_EMU_LIB: e.g. tools/sanitize_emu.sh's AddressSanitizer build)
 
 
 def use_emulated_library():

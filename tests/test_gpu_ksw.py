@@ -109,7 +109,8 @@ def test_register_resident_gap_fill_kernel(preset):
                            int(rng.choice([0, 0, 0, 40, -40, 200, -200])))
         if len(q) > 1024 or len(t) > 768:
             continue
-        w = int(rng.choice([30001, len(q) + len(t), len(q) + len(t) + 5, -1]))
+        tight = max(len(q), len(t)) - 1  # the smallest band that cannot bind (ksw_host.cpp: band_cannot_bind); one less can
+        w = int(rng.choice([30001, len(q) + len(t), len(q) + len(t) + 5, -1, tight, tight, max(tight - 1, 0)]))
         jobs.append((q, t, w, 400, -1, 0x08))
     # not eligible (band could bind / other flags): must still be exact
     for it in range(40):
@@ -337,7 +338,7 @@ def test_splice_gap_fill_kernel(sc, monkeypatch):
 
 @pytest.mark.parametrize("preset", list(PRESETS))
 def test_extension_calls(preset):
-    """the two extension calls of mm_align1 (right extension 0x40, left extension 0xC2) at every size up to 512 x 1024: Z-drops
+    """the two extension calls of mm_align1 (right extension 0x40, left extension 0xC2) at every size up to 768 x 1024: Z-drops
     (unrelated tails), end bonuses that decide between the best local end and the query end, N bases, extreme aspect ratios,
     bands that can and cannot clip a row -- against the lane-exact oracle"""
     import minimap2_amd as mm
@@ -345,18 +346,19 @@ def test_extension_calls(preset):
     jobs = []
 
     def add(q, t, flag=None):
-        q, t = q[:1024], t[:512]
+        q, t = q[:1024], t[:768]
         if len(q) == 0 or len(t) == 0:
             return
-        w = int(rng.choice([751, -1, max(len(q), len(t) - 1), 30001])) if max(len(q), len(t) - 1) <= 751 else -1
+        tight = max(len(q), len(t)) - 1  # the smallest band that cannot bind; one less can (those jobs take the lane-exact kernel)
+        w = int(rng.choice([751, -1, tight, tight, max(tight - 1, 0), 30001]))
         f = int(rng.choice([0x40, 0xC2])) if flag is None else flag
         jobs.append((q, t, w, int(rng.choice([-1, 30, 100, 400])), int(rng.choice([-1, 0, 10, 100])), f))
 
-    for tl in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 511, 512):
+    for tl in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 511, 512, 513, 600, 700, 752, 753, 767, 768):
         for rep in range(4):
             t = rng.integers(0, 4, tl, dtype=np.uint8)
             if rep == 0:
-                add(t.copy(), t)
+                add(t.copy()[:512], t)
             elif rep == 1:
                 q, _ = random_pair(rng, tl, 0.15, 0.02)
                 add(q, t)
@@ -367,7 +369,7 @@ def test_extension_calls(preset):
                 k = max(1, len(q) // 2)
                 add(np.concatenate([q[:k], rng.integers(0, 4, len(q) - k + 20, dtype=np.uint8)]), t)
     for it in range(400):
-        q, t = random_pair(rng, int(rng.integers(1, 400)), float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.03])),
+        q, t = random_pair(rng, int(rng.integers(1, 600)), float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.03])),
                            int(rng.choice([0, 0, 0, 30, -30, 120, -120])))
         add(q, t)
     for it in range(30):  # not eligible (the band can clip): still exact

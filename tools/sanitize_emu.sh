@@ -10,11 +10,14 @@ pids=()
 for f in align backend_hip capi_common capi_index capi_kernels capi_map chain_host device_ctx flat_index format hits ksw_host ksw_ll mapper options rmq_chain tables; do
   g++ $FLAGS -c $CSRC/$f.cpp -o $OUT/$f.o & pids+=($!)
 done
-for f in seed_chain index_build ksw_extd2 ksw_gapfill ksw_stream ksw_splice ksw_ext; do
+for f in seed_chain index_build ksw_extd2 ksw_gapfill ksw_stream ksw_splice ksw_ext region_finish; do
   g++ $FLAGS -x c++ -c $CSRC/$f.hip -o $OUT/$f.hip.o & pids+=($!)
 done
 g++ $FLAGS -c $EMU/wave_emu.cpp -o $OUT/wave_emu.o & pids+=($!)
 gcc -O1 -g -fsanitize=address -DHAVE_KALLOC -I/root/reference -I$ROOT/include -c $ROOT/tests/dropin/dropin_main.c -o $OUT/dropin_main.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 g++ -fsanitize=address -o $OUT/dropin_emu_asan $OUT/*.o $ROOT/oracle/_ref/libminimap2_ref.a -L$ROOT/oracle -loracle -Wl,-rpath,$ROOT/oracle -lm -lz -lpthread
-echo built $OUT/dropin_emu_asan
+# the same objects as a shared library, for the Python-driven GPU cases:
+#   LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 MM2AMD_EMU=1 MM2AMD_EMU_LIB=tests/_build/emu_asan/libmm2amd_emu_asan.so python -m pytest -m gpu tests/test_gpu_ksw.py -k extension
+g++ -shared -fsanitize=address -o $OUT/libmm2amd_emu_asan.so $(ls $OUT/*.o | grep -v dropin_main) -L$ROOT/oracle -loracle -Wl,-rpath,$ROOT/oracle -lpthread
+echo built $OUT/dropin_emu_asan $OUT/libmm2amd_emu_asan.so
