@@ -227,7 +227,10 @@ def main():
 
     import minimap2_amd as mm
     from minimap2_amd import shard
-    ncpu = min(ncpu, mm.host_cpus())  # a container's CPU quota counts (cgroup cpu.max): threads beyond it only take time from each other
+    # A container's CPU quota counts (cgroup cpu.max): the host stages cannot use more CPU seconds per second than it grants, and pool threads
+    # beyond it spend the quota on waking up and spinning (32 threads on a 16-CPU quota: 10.6 core-seconds per step instead of 7-8, and the step
+    # is then bounded by exactly that: profiles/README.md, r03_bench_full_v18).
+    ncpu = min(ncpu, mm.host_cpus())
     n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
 
     t0 = time.time()

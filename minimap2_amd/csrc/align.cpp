@@ -1,6 +1,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -1134,6 +1135,9 @@ bool Aligner::complete_finished(ReadAlign &ra, const FinResult *results, const F
 			r.blen = f.blen, r.mlen = f.mlen, r.is_spliced = f.is_spliced;
 			if (f.qshift) { if (r.rev) r.qe -= f.qshift; else r.qs += f.qshift; } // mm_fix_cigar's dropped leading gap (align.c:171-180)
 			r.rs += f.tshift;
+			if (getenv("MM2AMD_FIN_CHECK") && (r.qs < 0 || r.qe > ra.qlen || r.qs >= r.qe))
+				fprintf(stderr, "[mm2amd] FIN_CHECK bad query range: qs %d qe %d qlen %d rev %d | qs1 %d qe1 %d rs1 %d re1 %d | qshift %d tshift %d n_cigar %d | has_left %d win0 kind %d qs %d qe %d job %d\n", r.qs, r.qe, ra.qlen,
+				        (int)r.rev, t.qs1, t.qe1, t.rs1, t.re1, f.qshift, f.tshift, f.n_cigar, (int)t.has_left, t.win.empty() ? -1 : (int)t.win[0].kind, t.win.empty() ? 0 : t.win[0].qs, t.win.empty() ? 0 : t.win[0].qe, t.win.empty() ? 0 : t.win[0].job);
 			t.pieces.clear(), t.dp_acc = 0, t.awaiting_finish = false;
 			t.saved.clear();
 			t.done = true;

@@ -426,7 +426,9 @@ public:
 		kernel_profiler(lane_id, replica_).collect();
 	}
 
-	bool finishes_regions() const override { static const bool off = getenv("MM2AMD_HOST_FINISH") != nullptr; return !off; } // (diagnostic: the host's mm_update_extra instead)
+	// Opt-in (MM2AMD_DEVICE_FINISH=1): on the benchmark box the kernel (94 ms of latency-bound launches per 1-Gbase step) costs the pipeline more than the
+	// 1.2 host core-seconds it saves -- 1.42-1.46 against 1.52-1.55 Gbases/s in A/B runs on one box (profiles/README.md); read per call so that tests can switch it
+	bool finishes_regions() const override { const char *e = getenv("MM2AMD_DEVICE_FINISH"); return e && *e && *e != '0'; }
 	void finish_regions(int lane_id, const std::vector<FinRegion> &regions, const std::vector<FinPiece> &pieces, size_t out_words, const int8_t *mat25, int q, int e, bool log_gap,
 	                    std::vector<FinResult> &results, const uint32_t **cigars) override
 	{
@@ -456,6 +458,21 @@ public:
 		stream_wait(ln.stream);
 		memcpy(results.data(), ln.h_fin_res.p, n * sizeof(FinResult));
 		*cigars = ln.h_fin_out.p;
+		static const bool check = getenv("MM2AMD_FIN_CHECK") != nullptr; // diagnostic: every returned CIGAR must cover its windows
+		if (check)
+			for (size_t i = 0; i < n; ++i) {
+				const FinResult &f = results[i];
+				long q = f.qshift, t = f.tshift;
+				for (int k = 0; k < f.n_cigar; ++k) {
+					const uint32_t c = ln.h_fin_out.p[regions[i].out_off + k], op = c & 0xf, len = c >> 4;
+					if (op == 0 || op == 7 || op == 8) q += len, t += len;
+					else if (op == 1) q += len;
+					else if (op == 2 || op == 3) t += len;
+				}
+				if (f.n_cigar < 0 || q != regions[i].q_len || t != regions[i].t_len)
+					fprintf(stderr, "[mm2amd] FIN_CHECK lane %d region %zu of %zu: n_cigar %d qshift %d tshift %d covers %ld/%ld of %d/%d (pieces %u from %u, out_off %u)\n", lane_id, i, n,
+					        f.n_cigar, f.qshift, f.tshift, q, t, regions[i].q_len, regions[i].t_len, regions[i].n_pieces, regions[i].piece0, regions[i].out_off);
+			}
 		prof.collect();
 	}
 

@@ -6,7 +6,7 @@
 // the Z-drop test on every row (ksw2.h:171-187), the end bonus, tracebacks that start at the best cell, right-aligned gaps.  They used to
 // take the lane-exact kernel (ksw_extd2.hip): 3 % of the DP cells, a quarter of the kernel time.  When the band cannot bind (w + 1 >=
 // max(qlen, tlen): ksw_host.cpp, band_cannot_bind) only valid cells matter (ksw_gapfill.hip explains why), so they run here on the register-resident layout instead: lane = target
-// column, four, eight or twelve register sets of 64 columns (targets up to 256 / 512 / 768), two jobs per wavefront in the halves of packed 16-bit registers, the same
+// column, four or eight register sets of 64 columns (targets up to 256 / 512), two jobs per wavefront in the halves of packed 16-bit registers, the same
 // cell arithmetic (gf_cell; gf_cell_right for KSW_EZ_RIGHT) and direction dwords.  On top of it every column keeps its cell's score H as a
 // 32-bit register per job: H += v down a column, H(left neighbour, row before) + u where a column starts (:329-357) -- mathematically the
 // scores the reference recovers from its difference arrays; the row maximum is a DPP reduction, its position is picked among the lanes that
@@ -21,7 +21,7 @@ namespace mm2amd {
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-constexpr int EX_QCAP = 512; // queries up to EX_QCAP; targets up to 64 * NC columns (NC register sets: 4, 8 or 12)
+constexpr int EX_QCAP = 512; // queries up to EX_QCAP; targets up to 64 * NC columns (NC register sets: 4 or 8)
 
 // One register set and anti-diagonal with RIGHT-aligned gaps (ksw2_extd2_sse.c:282-320): the LAST of (s, a, b, a2, b2) that reaches the
 // maximum names the state (ties go to the gap states), and a gap continues when its value is >= 0, not > 0.  Same operands and results
@@ -315,12 +315,9 @@ void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, voi
 	if (n_sets <= 4) {
 		if (right) hipLaunchKernelGGL((ksw_ext_kernel<true, 4>), dim3(n_blocks), dim3(256), 0, s, L);
 		else hipLaunchKernelGGL((ksw_ext_kernel<false, 4>), dim3(n_blocks), dim3(256), 0, s, L);
-	} else if (n_sets <= 8) {
+	} else {
 		if (right) hipLaunchKernelGGL((ksw_ext_kernel<true, 8>), dim3(n_blocks), dim3(256), 0, s, L);
 		else hipLaunchKernelGGL((ksw_ext_kernel<false, 8>), dim3(n_blocks), dim3(256), 0, s, L);
-	} else {
-		if (right) hipLaunchKernelGGL((ksw_ext_kernel<true, 12>), dim3(n_blocks), dim3(256), 0, s, L);
-		else hipLaunchKernelGGL((ksw_ext_kernel<false, 12>), dim3(n_blocks), dim3(256), 0, s, L);
 	}
 	HIP_CHECK(hipGetLastError());
 }

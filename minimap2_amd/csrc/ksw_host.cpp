@@ -25,9 +25,11 @@ constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice 
 constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
 // kFirstExt, kFirstExt + 1: the register-resident extension kernel (ksw_ext.hip): the two extensions per read whose band cannot bind,
 // left-aligned (right extensions) and right-aligned (left extensions: KSW_EZ_RIGHT); two jobs per wave.
-static const char *const kExtNames[6] = {"ksw_ext_kernel[left-aligned]", "ksw_ext_kernel[right-aligned]", "ksw_ext_kernel[left-aligned,t512]", "ksw_ext_kernel[right-aligned,t512]",
-                                         "ksw_ext_kernel[left-aligned,t768]", "ksw_ext_kernel[right-aligned,t768]"};
-constexpr int kNTiers = kFirstExt + 6, kExtMaxQ = 512, kExtMaxT = 768; // + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512, + 4/5: up to 768
+static const char *const kExtNames[4] = {"ksw_ext_kernel[left-aligned]", "ksw_ext_kernel[right-aligned]", "ksw_ext_kernel[left-aligned,t512]", "ksw_ext_kernel[right-aligned,t512]"};
+// + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512 (eight register sets; these launches hold a few hundred long jobs and are as
+// latency-bound as the lane-exact kernel's: they run beside it on the side stream).  Twelve sets (targets up to 768) were measured and dropped: 5 Gcells/s,
+// three times the time the lane-exact kernel needs for the same jobs.
+constexpr int kNTiers = kFirstExt + 4, kExtMaxQ = 512, kExtMaxT = 512;
 const int kSpliceSets[kSpliceClasses] = { 2, 4, 4 };
 const bool kSpliceSelf[kSpliceClasses] = { false, false, true };
 const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
@@ -132,7 +134,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast || xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 			if (fast) tier = fast_tier(j);
-			else if (xfast) tier = kFirstExt + (j.tlen > 512 ? 4 : j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
+			else if (xfast) tier = kFirstExt + (j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
 			else if (sfast) {
 				int nc = 0, dc = 0;
 				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
@@ -233,12 +235,12 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4; bool hbm = false; double alg_bytes = 0, cells = 0; };
 		Plan plan[kNTiers];
 		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
-		auto group_of = [](int tier) { return tier >= kFirstExact && tier < kFirstSplice ? 1 : 0; };
+		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || tier >= kFirstExt + 2 ? 1 : 0; };
 		const int max_slots_env = getenv("MM2AMD_KSW_MAX_SLOTS") ? atoi(getenv("MM2AMD_KSW_MAX_SLOTS")) : 0; // tests: few persistent waves, so that each takes many jobs
 		// Two groups run concurrently only when there are lane-exact launches and the mode allows it; then each gets half of this lane's
 		// scratch budget and buffers of its own.  Otherwise the groups run one after the other and SHARE one buffer sized for the larger.
 		bool any_side = false;
-		for (int tier = kFirstExact; tier < kFirstSplice; ++tier) any_side |= tier_beg[tier + 1] != tier_beg[tier];
+		for (int tier = 0; tier < kNTiers; ++tier) any_side |= group_of(tier) == 1 && tier_beg[tier + 1] != tier_beg[tier];
 		const bool use_side = any_side && !splice && !getenv("MM2AMD_NO_SIDE_STREAM"); // (spliced alignment: both groups hold matrices of tens of MB per job -- one after the other, each with the whole scratch budget) // read per run: bench.py's un-overlapped pass wants every launch on one stream
 		const size_t group_budget = use_side ? dir_budget / 2 : dir_budget;
 		for (int tier = 0; tier < kNTiers; ++tier) {
@@ -265,7 +267,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			if (P.hbm) P.wpb = 4;
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (8 and 12 register sets: 174 / ~250 VGPRs)
+			if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (eight register sets: 174 VGPRs)
 			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (n_stream) blocks_per_cu = ksw_stream_waves(n_stream);
 			else if (fast) blocks_per_cu = fast_waves(tier);

@@ -153,6 +153,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 	if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) n_drivers = std::max(1, std::min(n_drivers, atoi(e))); // read per run: bench.py takes its un-overlapped kernel times with one lane
 	while ((int)scratch_.size() < n_drivers) scratch_.emplace_back(new DriverScratch);
 	be_.set_active_lanes(n_drivers);
+	device_finish_ = be_.finishes_regions(); // one answer for the whole batch
 	std::atomic<size_t> next_sub(0);
 	std::mutex stats_mu;
 	std::exception_ptr first_err;
@@ -162,7 +163,8 @@ void Mapper::run(std::vector<ReadResult> &out)
 		// per-sub-batch arrays, so that steady-state batches allocate (and page-fault) nothing
 		DriverScratch &ds = *scratch_.at(lane);
 		std::vector<std::unique_ptr<Aligner>> &al = ds.al;
-		if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)), p->device_finish(be_.finishes_regions()); }
+		if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)); }
+		for (auto &p : al) p->device_finish(device_finish_);
 		try {
 			for (;;) {
 				const size_t si = next_sub.fetch_add(1);
@@ -407,7 +409,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
 			// the regions whose windows all came back: stitched, left-aligned and counted on the device (region_finish.hip), then completed here
-			if (be_.finishes_regions()) {
+			if (device_finish_) {
 				std::vector<FinRegion> &fregs = ds.fin_regions;
 				std::vector<FinPiece> &fpieces = ds.fin_pieces;
 				std::vector<size_t> &fbase = ds.fin_base; // first queued region of each unit

@@ -73,6 +73,7 @@ private:
 	Staged sets_[2];
 	int cur_set_ = 0;
 	bool pending_ = false; // a staged batch run() has not taken over yet
+	bool device_finish_ = false; // the regions of the batch being mapped are finished by Backend::finish_regions
 };
 
 uint32_t read_hash(const char *qname, int qlen, const ref::MapOpt &opt); // map.c:246-248

@@ -20,6 +20,7 @@ namespace mm2amd {
 #define FIN_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 namespace {
+constexpr int FIN_WIN = 1024, FIN_BACK = 128; // stage B: codes staged per round, of which this many lie behind the walking lane
 // mg_log2 (mmpriv.h:139-147), float arithmetic as written there (compiled with -ffp-contract=off)
 __device__ __forceinline__ float fin_log2(float x)
 {
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 	__shared__ int32_t s_cnt[2][32][8];
 	__shared__ int32_t s_hdr[2][8];
 	__shared__ int8_t s_mat[32];
+	__shared__ __attribute__((aligned(8))) uint8_t s_qw[2][FIN_WIN], s_tw[2][FIN_WIN];
 	const int lane = threadIdx.x & 63, h = lane >> 5, hl = lane & 31;
 	const int id = blockIdx.x * 2 + h;
 	const bool have = id < P.n_regions;
@@ -89,80 +91,124 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 		}
 	}
 
-	// ---- B: mm_fix_cigar (align.c:105-181), one lane per half ----
-	if (hl == 0) {
-		int32_t qshift = 0, tshift = 0;
-		bool bad = false;
-		if (n > 1) {
-			int32_t toff = 0, qoff = 0;
-			bool shrink = false;
-			ByteWindow qlo, qhi;
-			CodeWindow tlo, thi;
-			uint32_t prev = 0, cur = cg[0], next = cg[1]; // cg[k - 1], cg[k], cg[k + 1] as this pass sees them (it rewrites the neighbours)
-			for (uint32_t k = 0; k < n; ++k) {
-				const uint32_t op = cur & 0xf, len = cur >> 4;
-				if (len == 0) shrink = true;
-				if (op == 0) toff += len, qoff += len;
-				else if (op == 1 || op == 2) {
-					if (k > 0 && k < n - 1 && (prev & 0xf) == 0 && (next & 0xf) == 0) {
-						int l;
-						const int prev_len = (int)(prev >> 4);
-						if (op == 1) { for (l = 0; l < prev_len; ++l) if (qb(qlo, qoff - 1 - l) != qb(qhi, qoff + (int32_t)len - 1 - l)) break; }
-						else { for (l = 0; l < prev_len; ++l) if (tb(tlo, toff - 1 - l) != tb(thi, toff + (int32_t)len - 1 - l)) break; }
-						if (l > 0) {
-							prev -= (uint32_t)l << 4, next += (uint32_t)l << 4, qoff -= l, toff -= l;
-							cg[k - 1] = prev, cg[k + 1] = next;
+	// ---- B: mm_fix_cigar (align.c:105-181), one lane per half.  Its first pass compares a few bases at every indel; fetched one by one they
+	//      are ~1400 dependent global loads per region and were four fifths of this kernel's time.  The pass therefore runs in rounds: the 32
+	//      lanes of the half copy the next FIN_WIN query and reference codes into LDS (coalesced), the walking lane goes on until an indel
+	//      reaches past them.  A comparison that falls outside the window (a left-alignment longer than FIN_BACK bases) reads global memory. ----
+	{
+		int32_t toff = 0, qoff = 0; // the walking lane's position; the other lanes only see them through s_hdr
+		bool shrink = false;
+		uint32_t k = 0, prev = 0, cur = 0, next = 0; // cg[k - 1], cg[k], cg[k + 1] as this pass sees them (it rewrites the neighbours)
+		ByteWindow qfar;
+		CodeWindow tfar;
+		if (hl == 0 && n > 1) cur = cg[0], next = cg[1];
+		const bool walks = n > 1; // uniform in the half
+		for (;;) {
+			// where the next round starts (uniform in the wave: both halves take part in the barriers)
+			if (hl == 0) s_hdr[h][4] = walks && k < n ? 1 : 0, s_hdr[h][5] = qoff, s_hdr[h][6] = toff;
+			FIN_SYNC();
+			if (!s_hdr[0][4] && !s_hdr[1][4]) break;
+			const int32_t wq0 = s_hdr[h][5] > FIN_BACK ? s_hdr[h][5] - FIN_BACK : 0, wt0 = s_hdr[h][6] > FIN_BACK ? s_hdr[h][6] - FIN_BACK : 0;
+			if (s_hdr[h][4]) { // eight consecutive codes per lane and block of 256: four wide loads, all in flight together
+#pragma unroll
+				for (int b = 0; b < FIN_WIN / 256; ++b) {
+					const int i0 = b * 256 + hl * 8;
+					uint64_t qv = 0, tv = 0;
+					if (wq0 + i0 < R.q_len) {
+						const uint64_t a = R.q_pos + (uint64_t)(wq0 + i0);
+						const uint64_t lo = *(const uint64_t *)(P.qpool + (a & ~7ull)), hi = *(const uint64_t *)(P.qpool + (a & ~7ull) + 8);
+						const int sh = (int)(a & 7) * 8;
+						qv = sh ? lo >> sh | hi << (64 - sh) : lo;
+					}
+					if (wt0 + i0 < R.t_len) {
+						const uint64_t o = R.t_pos + (uint64_t)(wt0 + i0);
+						const uint64_t two = (uint64_t)P.S[o >> 3] | (uint64_t)P.S[(o >> 3) + 1] << 32;
+						uint64_t x = (uint32_t)(two >> ((o & 7) << 2)); // eight 4-bit codes -> eight bytes
+						x = (x | x << 16) & 0x0000FFFF0000FFFFull;
+						x = (x | x << 8) & 0x00FF00FF00FF00FFull;
+						tv = (x | x << 4) & 0x0F0F0F0F0F0F0F0Full;
+					}
+					*(uint64_t *)&s_qw[h][i0] = qv, *(uint64_t *)&s_tw[h][i0] = tv;
+				}
+			}
+			FIN_SYNC();
+			if (hl == 0 && s_hdr[h][4]) {
+				auto qat = [&](int32_t i) -> int { return i >= wq0 && i < wq0 + FIN_WIN ? (int)s_qw[h][i - wq0] : qb(qfar, i); };
+				auto tat = [&](int32_t i) -> int { return i >= wt0 && i < wt0 + FIN_WIN ? (int)s_tw[h][i - wt0] : tb(tfar, i); };
+				for (; k < n; ++k) {
+					const uint32_t op = cur & 0xf, len = cur >> 4;
+					if ((op == 1 && qoff + (int32_t)len > wq0 + FIN_WIN && qoff > wq0 + FIN_BACK) || (op == 2 && toff + (int32_t)len > wt0 + FIN_WIN && toff > wt0 + FIN_BACK))
+						break; // the indel reaches past the window, and a new window would start further on: next round
+					if (len == 0) shrink = true;
+					if (op == 0) toff += len, qoff += len;
+					else if (op == 1 || op == 2) {
+						if (k > 0 && k < n - 1 && (prev & 0xf) == 0 && (next & 0xf) == 0) {
+							int l;
+							const int prev_len = (int)(prev >> 4);
+							if (op == 1) { for (l = 0; l < prev_len; ++l) if (qat(qoff - 1 - l) != qat(qoff + (int32_t)len - 1 - l)) break; }
+							else { for (l = 0; l < prev_len; ++l) if (tat(toff - 1 - l) != tat(toff + (int32_t)len - 1 - l)) break; }
+							if (l > 0) {
+								prev -= (uint32_t)l << 4, next += (uint32_t)l << 4, qoff -= l, toff -= l;
+								cg[k - 1] = prev, cg[k + 1] = next;
+							}
+							if (l == prev_len) shrink = true;
 						}
-						if (l == prev_len) shrink = true;
-					}
-					if (op == 1) qoff += len; else toff += len;
-				} else if (op == 3) toff += len;
-				prev = cur, cur = next, next = k + 2 < n ? cg[k + 2] : 0u;
-			}
-			bad = qoff != R.q_len || toff != R.t_len;
-			for (uint32_t k = 0; k + 2 < n; ++k) { // runs like 5I6D7I become one I and one D
-				const uint32_t c0 = cg[k];
-				if ((c0 & 0xf) == 0) continue;
-				if ((c0 & 0xf) + (cg[k + 1] & 0xf) == 3) {
-					uint32_t l, s[3] = {0, 0, 0};
-					for (l = k; l < n; ++l) {
-						const uint32_t c = cg[l], op = c & 0xf;
-						if (op == 1 || op == 2 || c >> 4 == 0) s[op] += c >> 4;
-						else break;
-					}
-					if (s[1] > 0 && s[2] > 0 && l - k > 2) {
-						cg[k] = s[1] << 4 | 1;
-						cg[k + 1] = s[2] << 4 | 2;
-						for (k += 2; k < l; ++k) cg[k] &= 0xf;
-						shrink = true;
-					}
-					k = l;
+						if (op == 1) qoff += len; else toff += len;
+					} else if (op == 3) toff += len;
+					prev = cur, cur = next, next = k + 2 < n ? cg[k + 2] : 0u;
 				}
 			}
-			if (shrink) {
-				uint32_t l = 0;
-				for (uint32_t k = 0; k < n; ++k) { const uint32_t c = cg[k]; if (c >> 4 != 0) cg[l++] = c; }
-				n = l;
-				l = 0;
-				if (n > 0) {
-					uint32_t c = cg[0]; // the running operation: equal neighbours add up
-					for (uint32_t k = 0; k < n; ++k) {
-						if (k == n - 1) { cg[l++] = c; break; }
-						const uint32_t nx = cg[k + 1];
-						if ((c & 0xf) != (nx & 0xf)) cg[l++] = c, c = nx;
-						else c = nx + (c >> 4 << 4);
-					}
-				}
-				n = l;
-			}
-			if (n > 0 && ((cg[0] & 0xf) == 1 || (cg[0] & 0xf) == 2)) { // an alignment never starts with a gap
-				const int32_t l = (int32_t)(cg[0] >> 4);
-				if ((cg[0] & 0xf) == 1) qshift = l; else tshift = l;
-				--n;
-				for (uint32_t k = 0; k < n; ++k) cg[k] = cg[k + 1];
-			}
+			FIN_SYNC(); // (the window is rewritten next round)
 		}
-		s_hdr[h][0] = (int32_t)n, s_hdr[h][1] = qshift, s_hdr[h][2] = tshift, s_hdr[h][3] = bad ? 1 : 0;
+		if (hl == 0) {
+			int32_t qshift = 0, tshift = 0;
+			bool bad = false;
+			if (n > 1) {
+				bad = qoff != R.q_len || toff != R.t_len;
+				for (uint32_t k2 = 0; k2 + 2 < n; ++k2) { // runs like 5I6D7I become one I and one D
+					const uint32_t c0 = cg[k2];
+					if ((c0 & 0xf) == 0) continue;
+					if ((c0 & 0xf) + (cg[k2 + 1] & 0xf) == 3) {
+						uint32_t l, sum[3] = {0, 0, 0};
+						for (l = k2; l < n; ++l) {
+							const uint32_t c = cg[l], op = c & 0xf;
+							if (op == 1 || op == 2 || c >> 4 == 0) sum[op] += c >> 4;
+							else break;
+						}
+						if (sum[1] > 0 && sum[2] > 0 && l - k2 > 2) {
+							cg[k2] = sum[1] << 4 | 1;
+							cg[k2 + 1] = sum[2] << 4 | 2;
+							for (k2 += 2; k2 < l; ++k2) cg[k2] &= 0xf;
+							shrink = true;
+						}
+						k2 = l;
+					}
+				}
+				if (shrink) {
+					uint32_t l = 0;
+					for (uint32_t k2 = 0; k2 < n; ++k2) { const uint32_t c = cg[k2]; if (c >> 4 != 0) cg[l++] = c; }
+					n = l;
+					l = 0;
+					if (n > 0) {
+						uint32_t c = cg[0]; // the running operation: equal neighbours add up
+						for (uint32_t k2 = 0; k2 < n; ++k2) {
+							if (k2 == n - 1) { cg[l++] = c; break; }
+							const uint32_t nx = cg[k2 + 1];
+							if ((c & 0xf) != (nx & 0xf)) cg[l++] = c, c = nx;
+							else c = nx + (c >> 4 << 4);
+						}
+					}
+					n = l;
+				}
+				if (n > 0 && ((cg[0] & 0xf) == 1 || (cg[0] & 0xf) == 2)) { // an alignment never starts with a gap
+					const int32_t l = (int32_t)(cg[0] >> 4);
+					if ((cg[0] & 0xf) == 1) qshift = l; else tshift = l;
+					--n;
+					for (uint32_t k2 = 0; k2 < n; ++k2) cg[k2] = cg[k2 + 1];
+				}
+			}
+			s_hdr[h][0] = (int32_t)n, s_hdr[h][1] = qshift, s_hdr[h][2] = tshift, s_hdr[h][3] = bad ? 1 : 0;
+		}
 	}
 	FIN_SYNC();
 	n = (uint32_t)s_hdr[h][0];

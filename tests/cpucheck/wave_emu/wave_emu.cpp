@@ -266,3 +266,32 @@ void launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>
 }
 
 } // namespace wave_emu
+
+// MM2AMD_EMU_BACKTRACE=1: a crash inside the emulated product prints its C++ stack (development aid; run pytest with -p no:faulthandler)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void crash_backtrace(int sig)
+{
+	void *frames[64];
+	const int n = backtrace(frames, 64);
+	const char msg[] = "[wave_emu] fatal signal, stack:\n";
+	(void)!write(2, msg, sizeof msg - 1);
+	backtrace_symbols_fd(frames, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+struct CrashHandlers {
+	CrashHandlers()
+	{
+		if (!getenv("MM2AMD_EMU_BACKTRACE")) return;
+		static char alt[1 << 16]; // the faulting thread may be on a small fiber stack
+		stack_t ss; ss.ss_sp = alt, ss.ss_size = sizeof alt, ss.ss_flags = 0;
+		sigaltstack(&ss, nullptr);
+		struct sigaction sa;
+		sa.sa_handler = crash_backtrace, sigemptyset(&sa.sa_mask), sa.sa_flags = SA_ONSTACK;
+		sigaction(SIGSEGV, &sa, nullptr), sigaction(SIGABRT, &sa, nullptr), sigaction(SIGBUS, &sa, nullptr);
+	}
+} crash_handlers;
+}

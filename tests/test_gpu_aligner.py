@@ -142,11 +142,17 @@ def test_profile_counters_and_substeps():
     refs = [synth.ACGT[c].tobytes() for c in contigs]
     rds = [("read%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
     al = mm.Aligner(refs, preset="map-ont", n_threads=8)
-    mm.profile_enable(True)
-    whole = [[a.key() for a in h] for h in al.map_batch(rds)]
-    prof = mm.profile_get()
-    mm.profile_enable(False)
-    assert any(k.startswith("ksw_extd2_kernel") for k in prof) and "chain_fill_kernel" in prof
+    plain = [[a.key() for a in h] for h in al.map_batch(rds)]
+    os.environ["MM2AMD_DEVICE_FINISH"] = "1"  # the regions' last step (mm_update_extra) on the device: the same hits
+    try:
+        mm.profile_enable(True)
+        whole = [[a.key() for a in h] for h in al.map_batch(rds)]
+        prof = mm.profile_get()
+        mm.profile_enable(False)
+    finally:
+        del os.environ["MM2AMD_DEVICE_FINISH"]
+    assert whole == plain
+    assert any(k.startswith("ksw_ext") for k in prof) and any(k.startswith("ksw_stream_kernel") for k in prof) and "chain_fill_kernel" in prof and "region_finish_kernel" in prof
     assert all(v["ms"] > 0 and v["launches"] >= 1 for v in prof.values())
     os.environ["MM2AMD_SUBBATCH_BASES"] = "50000"  # several sub-batches must give the same answer as one
     try:
