@@ -95,7 +95,9 @@ void Mapper::take()
 
 void Mapper::run(std::vector<ReadResult> &out)
 {
-	take();
+	// (No take() here: the caller has taken the batch it wants mapped, under the lock that also orders the hand-overs.  A take at this point
+	// raced with the hand-over of the NEXT batch -- when that finished between the caller's take and this line, run() mapped the next batch's
+	// reads against the caller's records of this one: tests/test_wave_emu.py::test_pipeline_equals_batch_by_batch with tiny batches.)
 	const long n = sets_[cur_set_].n;
 	out.clear();
 	out.resize(n);

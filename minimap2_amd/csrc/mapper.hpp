@@ -35,7 +35,7 @@ public:
 	// NEXT batch and run() takes it over: with a backend that stages beside mapping, stage() of batch k+1 may be called from
 	// another thread while run() of batch k is under way (the caller orders them: every stage() is followed by one take()+run()).
 	void stage(const std::vector<ReadView> &reads);
-	void take();                                      // the staged batch becomes the one run() maps (run() calls it when a batch is pending)
+	void take();                                      // the staged batch becomes the one run() maps; the caller calls it, under the lock that orders the hand-overs (run() does not)
 	void run(std::vector<ReadResult> &out);
 	bool stages_beside_mapping() const { return be_.stages_beside_mapping(); }
 	MapperStats stats;

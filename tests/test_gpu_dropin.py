@@ -63,6 +63,22 @@ def test_reference_fixtures_through_hip(case):
         assert b"cg:Z:69M134N65M" in got
 
 
+@pytest.mark.parametrize("case", ["mt_sam", "inv_sam", "x3s_sam"])
+def test_regions_finished_on_the_device(case, tmp_path):
+    """MM2AMD_DEVICE_FINISH=1: region_finish_kernel instead of the host's mm_update_extra / mm_fix_cigar (align.c:105-181, :254-303): the
+    reference's fixtures, and for the first one a batch of synthetic ONT reads against the compiled reference"""
+    want = open(os.path.join(HERE, "golden", case + ".out"), "rb").read()
+    env = dict(os.environ, MM2AMD_DEVICE_FINISH="1")
+    got, err = G.run_fixture(DROPIN, case, ["--stats"], env=env)
+    assert "backend=hip:gfx950" in err, err[-500:]
+    assert got == want
+    if case == "mt_sam":
+        ref, reads, _, _ = synth.make("ont", str(tmp_path), 1.0, 60, 211)
+        ours = subprocess.run([DROPIN, "-x", "map-ont", "-t", "4", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=env).stdout
+        theirs = subprocess.run([REF_BIN, "-x", "map-ont", "-t", "4", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        assert G.strip_pg(ours) == G.strip_pg(theirs)
+
+
 def test_one_by_one_calls_on_gpu(tmp_path):
     """mm_gpu_map / mm_gpu_map_frag (the reference's mm_map / mm_map_frag signatures, map.c:380-397): a batch of one per call through
     the HIP path == one mm_gpu_map_batch == the reference"""

@@ -76,6 +76,46 @@ def test_reference_fixtures_through_the_kernels_source(case):
     assert got == open(os.path.join(HERE, "golden", case + ".out"), "rb").read()
 
 
+@pytest.mark.parametrize("case", ["mt_sam", "inv_paf", "x3s_paf"])
+def test_regions_finished_on_the_device(case, emu, monkeypatch):
+    """MM2AMD_DEVICE_FINISH=1: region_finish_kernel (windows' CIGARs stitched in LDS, mm_fix_cigar, the score walk as a 32-lane reduction) instead
+    of the host's mm_update_extra: the reference's fixtures (a Z-drop split with an inversion, a spliced alignment) and the packed hit records,
+    mm_extra_t::capacity included, of synthetic ONT reads"""
+    if not os.path.exists(DROPIN_EMU):
+        pytest.skip("needs tests/_build/dropin_emu")
+    env = dict(os.environ, MM2AMD_DEVICE_FINISH="1")
+    got, _ = G.run_fixture(DROPIN_EMU, case, env=env)
+    assert got == open(os.path.join(G.HERE, case + ".out"), "rb").read()
+    if case != "mt_sam" or not os.path.exists(reflib.REFDRV_SO):
+        return
+    from minimap2_amd import shard
+    monkeypatch.setenv("MM2AMD_DEVICE_FINISH", "1")
+    refs, rds = _reads(43, 24, 7000, 0.12, 600000)
+    al = emu.Aligner(refs, preset="map-ont", names=["chr1", "chr2"], n_threads=4, sam=True)
+    try:
+        L = emu.lib()
+        st = al.index_stat()
+        S, keys, val_off, pos = reflib.export_index(al)
+        drv = reflib.RefDriver(st["w"], st["k"], st["flag"], ["chr1", "chr2"], al.lens, S, keys, val_off, pos, 4)
+        mo = drv.map_opt("map-ont", extra_flag=emu.F_OUT_SAM)
+        _, nr, rg = drv.map(mo, rds, 4)
+        want = shard.pack_hits(L, nr, rg).numpy().tobytes()
+        L.mm2amd_free_regs(len(nr), nr, rg)
+        drv.close()
+        al.stage(rds)
+        n_reg, reg, _ = al.run(raw=True)
+        got = shard.pack_hits(L, n_reg, reg).numpy().tobytes()
+        al.free_raw(n_reg, reg)
+        emu.profile_enable(True)
+        al.map_batch(rds[:4])
+        prof = emu.profile_get()
+        emu.profile_enable(False)
+    finally:
+        al.close()
+    assert got == want
+    assert "region_finish_kernel" in prof
+
+
 def test_pipeline_equals_batch_by_batch(emu):
     """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
     (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
