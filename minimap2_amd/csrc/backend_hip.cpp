@@ -449,6 +449,9 @@ public:
 		P.qpool = res_[cur_].d_qpool.p, P.S = T_->S.p;
 		memcpy(P.mat, mat25, 25);
 		P.q = (int8_t)q, P.e = (int8_t)e, P.log_gap = log_gap ? 1 : 0;
+		uint32_t longest = 1; // (a region's room in the output pool is the sum of its pieces: the next region's offset minus its own)
+		for (size_t i = 0; i < n; ++i) longest = std::max<uint32_t>(longest, (uint32_t)((i + 1 < n ? regions[i + 1].out_off : (uint32_t)out_words) - regions[i].out_off));
+		P.cap_ops = (int)std::min<uint32_t>((longest + 63) & ~63u, (uint32_t)kFinMaxOps);
 		KernelProfiler &prof = kernel_profiler(lane_id, replica_);
 		prof.begin(ln.stream);
 		region_finish_launch(P, ln.stream);

@@ -38,7 +38,7 @@ struct CodeWindow { int64_t blk = -4; uint32_t w = 0; };  // the packed-referenc
 
 __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 {
-	__shared__ uint32_t s_cg[2][kFinMaxOps];
+	MM2_DYN_LDS(uint32_t, s_cg_all); // 2 x P.cap_ops: the launch's longest stitched CIGAR decides how many waves a CU holds, not the cap
 	__shared__ long long s_tup[2][32][4];
 	__shared__ int32_t s_cnt[2][32][8];
 	__shared__ int32_t s_hdr[2][8];
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 	FinRegion R;
 	R.q_pos = R.t_pos = 0, R.piece0 = R.n_pieces = R.out_off = 0, R.q_len = R.t_len = 0;
 	if (have) R = P.regions[id];
-	uint32_t *const cg = s_cg[h];
+	uint32_t *const cg = s_cg_all + (size_t)h * (size_t)P.cap_ops;
 	if (lane < 25) s_mat[lane] = P.mat[lane];
 	auto qb = [&](ByteWindow &c, int32_t i) -> int {
 		const uint64_t a = R.q_pos + (uint64_t)(int64_t)i;
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 void region_finish_launch(const FinParams &P, void *stream)
 {
 	if (P.n_regions <= 0) return;
-	hipLaunchKernelGGL(region_finish_kernel, dim3((P.n_regions + 1) / 2), dim3(64), 0, (hipStream_t)stream, P);
+	hipLaunchKernelGGL(region_finish_kernel, dim3((P.n_regions + 1) / 2), dim3(64), (size_t)2 * (size_t)P.cap_ops * sizeof(uint32_t), (hipStream_t)stream, P);
 	HIP_CHECK(hipGetLastError());
 }
 

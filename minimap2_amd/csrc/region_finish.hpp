@@ -8,7 +8,7 @@
 
 namespace mm2amd {
 
-constexpr int kFinMaxOps = 4096; // CIGAR operations of a region the kernel stages in LDS (a 10 kb ONT read has ~1400); longer ones are finished on the host
+constexpr int kFinMaxOps = 7168; // CIGAR operations of a region the kernel can stage in LDS (two regions per 64 KB workgroup; a 10 kb ONT read has ~1400); longer ones are finished on the host
 
 struct FinRegion {        // one region whose windows all came back in the current round
 	uint64_t q_pos;       // first aligned query base in the device query pool (strand block of the read + qs1)
@@ -30,6 +30,7 @@ struct FinParams {
 	int8_t mat[25];
 	int8_t q, e;
 	int log_gap;                  // gap cost q + e * log2(1 + len) (long reads) or q + e
+	int cap_ops;                  // LDS slots per region: >= the longest stitched CIGAR of the launch (sum of its pieces), <= kFinMaxOps
 };
 
 void region_finish_launch(const FinParams &P, void *stream);
