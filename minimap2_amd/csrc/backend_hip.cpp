@@ -426,8 +426,9 @@ public:
 		kernel_profiler(lane_id, replica_).collect();
 	}
 
-	// Opt-in (MM2AMD_DEVICE_FINISH=1): on the benchmark box the kernel (94 ms of latency-bound launches per 1-Gbase step) costs the pipeline more than the
-	// 1.2 host core-seconds it saves -- 1.42-1.46 against 1.52-1.55 Gbases/s in A/B runs on one box (profiles/README.md); read per call so that tests can switch it
+	// Opt-in (MM2AMD_DEVICE_FINISH=1): it saves 1.4 host core-seconds per 1-Gbase step (8.2 -> 6.8) for 56 ms of latency-bound launches; on a single GPU with a
+	// 16-CPU quota the pipeline comes out 1 % slower with it (1.486 / 1.487 against 1.504 / 1.499 Gbases/s, A/B on one box: profiles/README.md).  Read per
+	// call, so that tests can switch it.
 	bool finishes_regions() const override { const char *e = getenv("MM2AMD_DEVICE_FINISH"); return e && *e && *e != '0'; }
 	void finish_regions(int lane_id, const std::vector<FinRegion> &regions, const std::vector<FinPiece> &pieces, size_t out_words, const int8_t *mat25, int q, int e, bool log_gap,
 	                    std::vector<FinResult> &results, const uint32_t **cigars) override

@@ -367,7 +367,8 @@ void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const
 	const int32_t n = n_mini_pos;
 	if (n == 0) return;
 	uint64_t sum_k = 0;
-	for (int32_t i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
+	if (!(fi.flag & ref::I_HPC) && (uint64_t)n * (uint64_t)fi.k < (1u << 24)) sum_k = (uint64_t)n * (uint64_t)fi.k; // every span is k: the float quotient below is exactly k
+	else for (int32_t i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
 	const float avg_k = (float)sum_k / n;
 	for (Reg &r : regs) {
 		r.div = -1.0f;

@@ -31,6 +31,14 @@ struct Table {
 	}
 };
 inline Table &table() { static Table t; return t; }
+// Every thread adds into counters of its own (a shared table's cache lines bounced between 16 threads and cost more CPU than some of the pieces
+// it measured); a thread's counters are folded into the table when the thread ends and when the report is printed from it.
+struct Local {
+	uint64_t cyc[N_PIECES] = {0}, cnt[N_PIECES] = {0};
+	void flush() { for (int k = 0; k < N_PIECES; ++k) if (cnt[k]) table().cyc[k].fetch_add(cyc[k], std::memory_order_relaxed), table().cnt[k].fetch_add(cnt[k], std::memory_order_relaxed), cyc[k] = cnt[k] = 0; }
+	~Local() { flush(); }
+};
+inline Local &local() { static thread_local Local l; return l; }
 struct Scope {
 	int k; uint64_t t0 = 0; bool on;
 	explicit Scope(int piece) : k(piece), on(table().on)
@@ -42,7 +50,11 @@ struct Scope {
 	void stop()
 	{
 #if defined(__x86_64__)
-		if (on) table().cyc[k].fetch_add(__rdtsc() - t0, std::memory_order_relaxed), table().cnt[k].fetch_add(1, std::memory_order_relaxed);
+		if (on) {
+			Local &l = local();
+			l.cyc[k] += __rdtsc() - t0, ++l.cnt[k];
+			if ((l.cnt[k] & 1023) == 0) l.flush(); // (pool threads live as long as the process: fold now and then)
+		}
 #endif
 		on = false;
 	}
