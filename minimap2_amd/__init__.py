@@ -521,7 +521,7 @@ class Aligner(object):
         v = (C.c_double * 24)()
         k = lib().mm2amd_last_stats(v, 24)
         names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells", "dev_allocs", "pin_allocs",
-                 "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish"]
+                 "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish", "n_long_join_dev", "n_long_join_host"]
         return dict(zip(names, list(v)[:k]))
 
 

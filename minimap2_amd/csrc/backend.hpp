@@ -25,6 +25,12 @@ struct SeedChainParams {          // what mm_map_frag_core passes to seeding and
 	int anchors_only = 0;         // 1: stop after the anchor sort and return every read's sorted anchors (n_u = 0): the caller chains them (a backend without an RMQ chainer)
 	int rmq = 0;                  // 1: chain with mg_lchain_rmq's rules (MM_F_RMQ, map.c:275-277) instead of mg_lchain_dp's
 	int rmq_inner_dist = 0, rmq_size_cap = 0; // mm_mapopt_t::rmq_inner_dist / rmq_size_cap
+	// long-join re-chaining of long reads (map.c:283-292): a read with more than one chain whose first chain leaves much of the read uncovered
+	// (or covers a tenth of it) has its chained anchors sorted by reference position again and chained by mg_lchain_rmq with bw_long.
+	// long_join = 1: seed_chain() does it for single-segment reads and says so in ReadChains::long_join_done; reads its RMQ kernel hands
+	// back keep their first chains for the caller's host chainer.
+	int long_join = 0, bw_long = 0, rmq_rescue_size = 0;
+	float rmq_rescue_ratio = 0;
 };
 
 // the two chaining distance limits of a read of qlen bases (map.c:262-271): the query-side limit grows with the read for short
@@ -61,6 +67,7 @@ public:
 	virtual void enable_seq_len() {} // --qstrand: seed_chain() needs the reference sequence lengths (reverse-strand anchors in query-strand coordinates)
 	virtual bool supports_junctions() const { return true; } // KswScoring::juncs honoured by ksw()
 	virtual bool supports_sdust() const { return true; }
+	virtual bool supports_long_join() const { return false; } // SeedChainParams::long_join honoured by seed_chain()
 	virtual bool supports_rmq() const { return false; }    // SeedChainParams::rmq honoured by seed_chain(); otherwise the mapper asks for anchors_only and chains on the host
 	virtual bool supports_byte_targets() const { return true; } // KswScoring::tbytes honoured by ksw() (splice:sr)     // SeedChainParams::sdust_thres honoured by seed_chain()
 	virtual long max_reads_per_call() const { return 1L << 30; } // upper bound on hi - lo the backend accepts in seed_chain()

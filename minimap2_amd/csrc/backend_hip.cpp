@@ -42,6 +42,13 @@ struct Lane {
 	DevBuf<uint8_t> d_tbytes;
 	DevBuf<uint32_t> d_sort_list;
 	PinBuf<uint32_t> h_sort_list;
+	DevBuf<Anchor> d_lj_out_a;                 // long-join re-chaining (second backtrack's anchors; the first one's are its input)
+	DevBuf<uint64_t> d_lj_src;
+	PinBuf<Anchor> h_lj_a;
+	PinBuf<uint64_t> h_lj_u, h_lj_off, h_lj_aoff, h_lj_uoff;
+	PinBuf<int32_t> h_lj_nu, h_lj_nv;
+	PinBuf<uint32_t> h_lj_tie, h_lj_list;
+	PinBuf<unsigned long long> h_lj_cursor;
 	DevBuf<FinRegion> d_fin_regions; DevBuf<FinPiece> d_fin_pieces; DevBuf<uint32_t> d_fin_out; DevBuf<FinResult> d_fin_res; // region_finish.hip
 	PinBuf<FinRegion> h_fin_regions; PinBuf<FinPiece> h_fin_pieces; PinBuf<uint32_t> h_fin_out; PinBuf<FinResult> h_fin_res;
 	PinBuf<Anchor> h_anchors, h_redo;
@@ -399,6 +406,85 @@ public:
 			c.u_p = nullptr, c.n_u = 0, c.chained = false;
 			c.a_p = h_redo + rd.second, c.n_a = (int64_t)(a_off[rd.first + 1] - a_off[rd.first]);
 		}
+		if (P.long_join && !has_pairs_ && !getenv("MM2AMD_LONG_JOIN_ON_HOST")) long_join(P, lo, n, ln, kp, out, ha, hu, h_nu, h_nv, h_aoff, h_uoff); // (the diagnostic switch: every re-chain through rmq_chain.cpp)
+	}
+
+	// map.c:283-292 on the device.  Which reads re-chain is decided here from the first chains (the reference's two conditions); their CHAINED
+	// anchors -- still in the backtrack's device output -- go through the per-read sort (by reference position, the reference's tie order),
+	// chain_rmq_kernel with bw_long, and the backtrack again.  A read the RMQ kernel hands back (a range minimum that is not unique, an
+	// over-full neighbourhood) keeps its first chains and long_join_done unset: the caller re-chains it with rmq_chain.cpp.
+	void long_join(const SeedChainParams &P, long lo, size_t n, Lane &ln, KernelProfiler &kp, std::vector<ReadChains> &out, const Anchor *ha, const uint64_t *hu,
+	               const int32_t *h_nu, const int32_t *h_nv, const uint64_t *h_aoff, const uint64_t *h_uoff)
+	{
+		hipStream_t st = ln.stream;
+		const std::vector<uint64_t> &seq_off = res_[cur_].seq_off;
+		std::vector<uint32_t> sel;
+		for (size_t i = 0; i < n; ++i) {
+			ReadChains &c = out[i];
+			if (!c.chained) continue; // (an RMQ preset's hand-back: the caller chains it first and asks the question itself)
+			c.long_join_done = true;
+			if (h_nu[i] <= 1) continue;
+			const int qlen = (int)(seq_off[lo + i + 1] - seq_off[lo + i]);
+			const int32_t a0 = (int32_t)ha[h_aoff[i]].y, a1 = (int32_t)ha[h_aoff[i] + (uint64_t)((int32_t)hu[h_uoff[i]] - 1)].y;
+			if (qlen - (a1 - a0) > P.rmq_rescue_size || a1 - a0 > qlen * P.rmq_rescue_ratio) sel.push_back((uint32_t)i);
+		}
+		const size_t n2 = sel.size();
+		if (n2 == 0) return;
+		// the re-chain list as a batch of its own, in the first pass's (now dead) device buffers; only the backtrack's anchors must survive
+		uint64_t *h_off = ln.h_lj_off.ensure(2 * (n2 + 1));
+		uint64_t *h_src = h_off + n2 + 1;
+		h_off[0] = 0;
+		for (size_t k = 0; k < n2; ++k) h_off[k + 1] = h_off[k] + (uint64_t)h_nv[sel[k]], h_src[k] = h_aoff[sel[k]];
+		const uint64_t n_a2 = h_off[n2];
+		SeedChainBuffers B2 = ln.B;
+		B2.n_reads = (int)n2, B2.seq_off = nullptr, B2.mz_cnt = nullptr, B2.unit_first = nullptr;
+		ln.d_lj_src.ensure(n2 + 1), ln.d_lj_out_a.ensure(n_a2 + 1);
+		HIP_CHECK(hipMemcpyAsync(ln.d_a_off.p, h_off, (n2 + 1) * 8, hipMemcpyHostToDevice, st));
+		HIP_CHECK(hipMemcpyAsync(ln.d_lj_src.p, h_src, n2 * 8, hipMemcpyHostToDevice, st));
+		B2.a_off = ln.d_a_off.p;
+		int n_class[kAnchorSortClasses] = { 0 }, class_first[kAnchorSortClasses + 1] = { 0 };
+		double a_class[kAnchorSortClasses] = { 0 };
+		for (size_t k = 0; k < n2; ++k) { const int c = anchor_sort_class((uint64_t)h_nv[sel[k]], rid_bits_); ++n_class[c], a_class[c] += h_nv[sel[k]]; }
+		for (int c = 0; c < kAnchorSortClasses; ++c) class_first[c + 1] = class_first[c] + n_class[c];
+		uint32_t *h_list = ln.h_lj_list.ensure(n2 + 1);
+		{
+			int fill[kAnchorSortClasses];
+			for (int c = 0; c < kAnchorSortClasses; ++c) fill[c] = class_first[c];
+			for (size_t k = 0; k < n2; ++k) h_list[fill[anchor_sort_class((uint64_t)h_nv[sel[k]], rid_bits_)]++] = (uint32_t)k;
+		}
+		HIP_CHECK(hipMemcpyAsync(ln.d_sort_list.p, h_list, n2 * 4, hipMemcpyHostToDevice, st));
+		kp.begin(st); launch_rechain_gather(B2, ln.d_bt_out_a.p, ln.d_lj_src.p, st); kp.end(st, "rechain_gather_kernel", 32.0 * n_a2);
+		SeedChainParams P2 = P;
+		P2.rmq = 1, P2.bw = P.bw_long, P2.flag &= ~(int64_t)ref::F_HEAP_SORT; // (the heap-merge order belongs to the seeding; this sort is radix_sort_128x)
+		launch_anchor_sort(B2, I_, P2, ln.d_sort_list.p, n_class, a_class, st, &kp);
+		kp.begin(st); launch_chain_rmq(B2, P2, st); kp.end(st, "chain_rmq_kernel[long-join]", 32.0 * n_a2);
+		B2.bt_out_a = ln.d_lj_out_a.p; // (chains, counts and offsets reuse the first pass's arrays: they have been copied out)
+		kp.begin(st); launch_chain_backtrack(B2, P2, st); kp.end(st, "chain_backtrack_kernel[long-join]", 8.0 * n_a2);
+		unsigned long long *h_cur = ln.h_lj_cursor.ensure(2);
+		int32_t *nu2 = ln.h_lj_nu.ensure(n2), *nv2 = ln.h_lj_nv.ensure(n2);
+		uint64_t *aoff2 = ln.h_lj_aoff.ensure(n2), *uoff2 = ln.h_lj_uoff.ensure(n2);
+		uint32_t *tie2 = ln.h_lj_tie.ensure(n2);
+		HIP_CHECK(hipMemcpyAsync(h_cur, ln.d_bt_cursor.p, 16, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(nu2, ln.d_bt_nu.p, n2 * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(nv2, ln.d_bt_nv.p, n2 * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(aoff2, ln.d_bt_aoff.p, n2 * 8, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(uoff2, ln.d_bt_uoff.p, n2 * 8, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(tie2, ln.d_tie.p, n2 * 4, hipMemcpyDeviceToHost, st));
+		stream_wait(st);
+		const uint64_t n_v2 = h_cur[0], n_u2 = h_cur[1];
+		Anchor *ha2 = ln.h_lj_a.ensure(n_v2 + 1);
+		uint64_t *hu2 = ln.h_lj_u.ensure(n_u2 + 1);
+		if (n_v2) HIP_CHECK(hipMemcpyAsync(ha2, ln.d_lj_out_a.p, n_v2 * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+		if (n_u2) HIP_CHECK(hipMemcpyAsync(hu2, ln.d_bt_out_u.p, n_u2 * 8, hipMemcpyDeviceToHost, st));
+		stream_wait(st);
+		kp.collect();
+		for (size_t k = 0; k < n2; ++k) {
+			ReadChains &c = out[sel[k]];
+			if (tie2[k]) { c.long_join_done = false; continue; } // the host's tie-exact tree does this one
+			c.u_p = hu2 + uoff2[k], c.n_u = nu2[k];
+			c.a_p = ha2 + aoff2[k], c.n_a = nv2[k];
+			c.long_joined = true;
+		}
 	}
 
 	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int lane_id, int n_threads, std::vector<KswRes> &res, const uint32_t **cigar) override
@@ -429,6 +515,7 @@ public:
 	// Opt-in (MM2AMD_DEVICE_FINISH=1): it saves 1.4 host core-seconds per 1-Gbase step (8.2 -> 6.8) for 56 ms of latency-bound launches; on a single GPU with a
 	// 16-CPU quota the pipeline comes out 1 % slower with it (1.486 / 1.487 against 1.504 / 1.499 Gbases/s, A/B on one box: profiles/README.md).  Read per
 	// call, so that tests can switch it.
+	bool supports_long_join() const override { return true; }
 	bool finishes_regions() const override { const char *e = getenv("MM2AMD_DEVICE_FINISH"); return e && *e && *e != '0'; }
 	void finish_regions(int lane_id, const std::vector<FinRegion> &regions, const std::vector<FinPiece> &pieces, size_t out_words, const int8_t *mat25, int q, int e, bool log_gap,
 	                    std::vector<FinResult> &results, const uint32_t **cigars) override

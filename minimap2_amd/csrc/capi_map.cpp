@@ -132,6 +132,7 @@ void run_replicas(MapContext &c, const StagedBatch &bt, std::vector<ReadResult> 
 		sum.t_seed_chain += s.t_seed_chain, sum.t_host_pre += s.t_host_pre, sum.t_plan += s.t_plan, sum.t_ksw += s.t_ksw, sum.t_consume += s.t_consume;
 		sum.t_finish += s.t_finish, sum.n_jobs += s.n_jobs, sum.n_rounds += s.n_rounds, sum.dp_cells += s.dp_cells;
 		sum.c_seed_chain += s.c_seed_chain, sum.c_host_pre += s.c_host_pre, sum.c_plan += s.c_plan, sum.c_ksw += s.c_ksw, sum.c_consume += s.c_consume, sum.c_finish += s.c_finish;
+		sum.n_long_join_dev += s.n_long_join_dev, sum.n_long_join_host += s.n_long_join_host;
 	}
 	std::lock_guard<std::mutex> lk(c.stats_mu);
 	c.stats = sum;
@@ -674,7 +675,7 @@ int mm2amd_last_stats(double *v, int n)
 	const MapperStats &s = g_ctx->stats;
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
 	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2),
-	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
+	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish, (double)s.n_long_join_dev, (double)s.n_long_join_host }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -124,6 +124,9 @@ void Mapper::run(std::vector<ReadResult> &out)
 	sp.rmq = (opt_.flag & F_RMQ) && be_.supports_rmq() ? 1 : 0;
 	sp.anchors_only = (opt_.flag & F_RMQ) && !sp.rmq ? 1 : 0;
 	sp.rmq_inner_dist = opt_.rmq_inner_dist, sp.rmq_size_cap = opt_.rmq_size_cap;
+	// map.c:283-292: long-join re-chaining, by the backend when it can (reads it leaves alone are re-chained in process_sub)
+	sp.long_join = opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && be_.supports_long_join() ? 1 : 0;
+	sp.bw_long = opt_.bw_long, sp.rmq_rescue_size = opt_.rmq_rescue_size, sp.rmq_rescue_ratio = opt_.rmq_rescue_ratio;
 
 	// Sub-batches bound the device working set (anchors and DP scratch scale with the number of reads in flight) and are the
 	// unit of pipelining: each of the backend's lanes is driven by one host thread that takes the next sub-batch through all of
@@ -182,6 +185,7 @@ void Mapper::run(std::vector<ReadResult> &out)
 		stats.t_seed_chain += st.t_seed_chain, stats.t_host_pre += st.t_host_pre, stats.t_plan += st.t_plan, stats.t_ksw += st.t_ksw;
 		stats.t_consume += st.t_consume, stats.t_finish += st.t_finish, stats.n_jobs += st.n_jobs, stats.n_rounds += st.n_rounds, stats.dp_cells += st.dp_cells;
 		stats.c_seed_chain += st.c_seed_chain, stats.c_host_pre += st.c_host_pre, stats.c_plan += st.c_plan, stats.c_ksw += st.c_ksw, stats.c_consume += st.c_consume, stats.c_finish += st.c_finish;
+		stats.n_long_join_dev += st.n_long_join_dev, stats.n_long_join_host += st.n_long_join_host;
 	};
 	std::vector<std::thread> th;
 	for (int l = 1; l < n_drivers; ++l) th.emplace_back(driver, l);
@@ -229,9 +233,10 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				for (long i = 0; i < m; ++i) chains[i].take_ownership(); // the backend's buffers are about to be reused
 				SeedChainParams sp2 = sp;
 				sp2.mid_occ = opt_.max_occ;
+				sp2.long_join = 0; // map.c:293: this branch is the ELSE of the long-join: its chains are final
 				std::vector<ReadChains> second;
 				be_.seed_chain(sp2, lo, hi, lane, n_threads_, second);
-				for (long i : again) { chains[i] = second[i]; chains[i].take_ownership(); }
+				for (long i : again) { chains[i] = second[i]; chains[i].take_ownership(); chains[i].long_join_done = true; }
 			}
 		}
 		stats.t_seed_chain += now() - t0; t0 = now();
@@ -261,6 +266,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		}
 		if (ds.q4.size() < q4_total + 16) ds.q4.resize(q4_total + q4_total / 4 + 16); // (16 bytes of slack: update_extra compares 16 columns per load)
 		const bool is_sr = (opt_.flag & (F_SR | F_SR_RNA)) != 0;
+		std::atomic<long> n_lj_dev{0}, n_lj_host{0};
 		parallel_for(n_threads_, m, [&](long i, int) {
 			hostprof::Scope hp(hostprof::CHAINS_TO_HITS);
 			ReadChains &c = chains[i];
@@ -278,7 +284,8 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 				c.u.swap(u2), c.a.swap(out_a);
 				c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
 			}
-			if (opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && n_segs == 1 && c.n_u > 1) { // long-join re-chaining (map.c:283-292)
+			if (c.long_joined) ++n_lj_dev;
+			if (!c.long_join_done && opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && n_segs == 1 && c.n_u > 1) { // long-join re-chaining (map.c:283-292): the reads the backend left alone
 				const int32_t st = (int32_t)c.a_p[0].y, en = (int32_t)c.a_p[(int32_t)c.u_p[0] - 1].y;
 				if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {
 					ChainScratch sc;
@@ -290,6 +297,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 					          sp.chn_pen_gap, sp.chn_pen_skip, (int64_t)a2.size(), a2.data(), u2, out_a, sc);
 					c.u.swap(u2), c.a.swap(out_a);
 					c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
+					++n_lj_host;
 				}
 			}
 			int gap_ref, gap_qry;
@@ -339,6 +347,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 		});
 		Trace::get().add(lane, "host:pre", t0, now());
+		stats.n_long_join_dev += n_lj_dev.load(), stats.n_long_join_host += n_lj_host.load();
 		stats.t_host_pre += now() - t0;
 		stats.c_host_pre += cpu_now() - c0;
 

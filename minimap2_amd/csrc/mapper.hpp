@@ -24,12 +24,13 @@ struct MapperStats { // wall-clock seconds per stage of the last map_batch (for 
 	double c_seed_chain = 0, c_host_pre = 0, c_plan = 0, c_ksw = 0, c_consume = 0, c_finish = 0;
 	long n_jobs = 0, n_rounds = 0;
 	double dp_cells = 0;
+	long n_long_join_dev = 0, n_long_join_host = 0; // reads re-chained by the long-join rule (map.c:283-292): on the device / by the host's tie-exact tree
 };
 
 class Mapper {
 public:
 	Mapper(const FlatIndex &fi, const ref::MapOpt &opt, Backend &be, int n_threads);
-	void map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out) { stage(reads); run(out); }
+	void map_batch(const std::vector<ReadView> &reads, std::vector<ReadResult> &out) { stage(reads); take(); run(out); }
 	// the two halves of map_batch: stage() makes the batch resident on the device (the hand-over the reference's pipeline
 	// step 0 performs), run() is the hot path proper.  The ReadViews must stay valid until run() returns.  stage() prepares the
 	// NEXT batch and run() takes it over: with a backend that stages beside mapping, stage() of batch k+1 may be called from

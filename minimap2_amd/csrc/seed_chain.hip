@@ -1522,6 +1522,29 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	}
 }
 
+// Long-join re-chaining (map.c:283-292) starts from the read's CHAINED anchors (the backtrack's compacted output, chain by chain) sorted by
+// reference position again: read r of the re-chain list takes src_off[r] .. of `src` to slot a_off[r] .. of the sort's (key, value) input, in
+// that order -- the order the reference's unstable radix_sort_128x starts from, which the per-read sort replays where keys are equal.
+__global__ void __launch_bounds__(256) rechain_gather_kernel(SeedChainBuffers B, const Anchor *src, const uint64_t *src_off)
+{
+	const int r = blockIdx.x;
+	const uint64_t ao = B.a_off[r], so = src_off[r];
+	const int64_t n = (int64_t)(B.a_off[r + 1] - ao);
+	const uint64_t low_mask = (1ULL << (32 + B.rid_bits)) - 1ULL;
+	for (int64_t i = threadIdx.x; i < n; i += 256) {
+		const Anchor a = src[so + (uint64_t)i];
+		B.sort_key_in[ao + (uint64_t)i] = (a.x >> 63) << (32 + B.rid_bits) | (a.x & low_mask); // the compact key seed_expand_kernel writes: strand | rid | rpos
+		B.sort_val_in[ao + (uint64_t)i] = a.y;
+	}
+}
+
+void launch_rechain_gather(const SeedChainBuffers &B, const Anchor *src, const uint64_t *src_off, void *stream)
+{
+	if (B.n_reads <= 0) return;
+	hipLaunchKernelGGL(rechain_gather_kernel, dim3(B.n_reads), dim3(256), 0, (hipStream_t)stream, B, src, src_off);
+	HIP_CHECK(hipGetLastError());
+}
+
 void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
 	const int max_drop = P.is_cdna ? INT32_MAX : P.bw;

@@ -73,5 +73,6 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
                         KernelProfiler *kp);
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
 void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
+void launch_rechain_gather(const SeedChainBuffers &B, const Anchor *src, const uint64_t *src_off, void *stream); // long-join: chained anchors -> the per-read sort's input
 
 } // namespace mm2amd

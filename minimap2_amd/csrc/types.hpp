@@ -54,6 +54,8 @@ struct ReadChains {
 	std::vector<Anchor> a;          // anchors of all chains, chain by chain
 	std::vector<uint64_t> mini_pos; // q_span<<32 | q_pos of every minimizer that was looked up and kept (seed.c:124)
 	int rep_len = 0;
+	bool long_join_done = false;    // the long-join re-chaining question (map.c:283-292) has been settled for this read: asked and answered no, or re-chained by the backend
+	bool long_joined = false;       // ... and the chains are the re-chained ones
 	bool chained = true;            // false: a_p / n_a are the read's SORTED anchors and the caller still has to chain them (MM_F_RMQ on a backend without,
 	                                // or a read its RMQ kernel handed back)
 };

@@ -452,3 +452,15 @@ if __name__ == "__main__":
     a = ap.parse_args()
     ref, rd, _, _ = make(a.kind, a.outdir, a.ref_mb, a.reads, a.seed)
     print(ref, rd)
+
+
+def gen_duplicated_reference(rng, n_elem=40, elem_len=6000, div=0.03):
+    """a contig in which every stretch of elem_len bases exists twice (the second copy diverged by `div` and separated by random spacers):
+    a long read from it chains on both copies, so it has more than one chain and takes the long-join re-chaining of map.c:283-292"""
+    parts = [rng.integers(0, 4, elem_len, dtype=np.uint8) for _ in range(n_elem)]
+    for c in range(n_elem):
+        e = parts[c].copy()
+        mut = rng.random(len(e)) < div
+        e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+        parts.append(np.concatenate([rng.integers(0, 4, int(rng.integers(100, 2000)), dtype=np.uint8), e]))
+    return np.concatenate(parts)

@@ -163,6 +163,39 @@ def test_profile_counters_and_substeps():
     assert parts == whole
 
 
+def test_long_join_rechain_on_the_device():
+    """map.c:283-292 on the GPU: a repeat-bearing reference (every 6 kb stretch exists twice) gives every read more than one chain; the
+    re-chaining runs on the device (rechain_gather_kernel, anchor_sort_kernel, chain_rmq_kernel, chain_backtrack_kernel), the share is in
+    mm2amd_last_stats, and the hits equal the compiled reference's and the host tree's (MM2AMD_LONG_JOIN_ON_HOST=1)"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(56)
+    contig = synth.gen_duplicated_reference(rng)
+    refs = [synth.ACGT[contig].tobytes(), synth.ACGT[rng.integers(0, 4, 200000, dtype=np.uint8)].tobytes()]
+    reads = synth.gen_reads(rng, [contig], 200, 9000, 3000, 0.08)
+    rds = [("rep%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    al = mm.Aligner(refs, preset="map-ont", n_threads=8)
+    try:
+        mm.profile_enable(True)
+        got = [[a.key() for a in h] for h in al.map_batch(rds)]
+        prof = mm.profile_get()
+        mm.profile_enable(False)
+        st = al.last_stats()
+        os.environ["MM2AMD_LONG_JOIN_ON_HOST"] = "1"
+        try:
+            on_host = [[a.key() for a in h] for h in al.map_batch(rds)]
+            st_host = al.last_stats()
+        finally:
+            del os.environ["MM2AMD_LONG_JOIN_ON_HOST"]
+    finally:
+        al.close()
+    assert st["n_long_join_dev"] + st["n_long_join_host"] >= 0.1 * len(rds) and st["n_long_join_dev"] > 0
+    assert st_host["n_long_join_dev"] == 0 and st_host["n_long_join_host"] == st["n_long_join_dev"] + st["n_long_join_host"]
+    assert "chain_rmq_kernel[long-join]" in prof and "rechain_gather_kernel" in prof
+    assert on_host == got
+    if os.path.exists(reflib.REF_SO):
+        assert got == reflib.ref_map_reads(refs, rds, "map-ont")
+
+
 def test_repeat_rich_reference_ties_and_long_anchor_lists():
     """a reference with many diverged copies of one element: thousands of anchors per read, equal-x ties, high-occurrence seeds"""
     import minimap2_amd as mm

@@ -116,6 +116,32 @@ def test_regions_finished_on_the_device(case, emu, monkeypatch):
     assert "region_finish_kernel" in prof
 
 
+def test_long_join_rechain_on_the_device(emu, monkeypatch):
+    """map.c:283-292 on the device (the kernels' source under the emulator): reads with more than one chain have their chained anchors sorted
+    by reference position again (the per-read LDS sort, replaying the reference's tie order), chained by chain_rmq_kernel with bw_long and
+    backtracked again; a repeat-bearing reference makes every read take that path; the share is reported by mm2amd_last_stats; the same
+    reads through the host's tie-exact tree (MM2AMD_LONG_JOIN_ON_HOST=1) give the same hits"""
+    rng = np.random.default_rng(55)
+    contig = synth.gen_duplicated_reference(rng)
+    refs = [synth.ACGT[contig].tobytes(), synth.ACGT[rng.integers(0, 4, 200000, dtype=np.uint8)].tobytes()]
+    reads = synth.gen_reads(rng, [contig], 30, 9000, 3000, 0.08)
+    rds = [("rep%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    al = emu.Aligner(refs, preset="map-ont", n_threads=4)
+    try:
+        got = [[a.key() for a in h] for h in al.map_batch(rds)]
+        st = al.last_stats()
+        monkeypatch.setenv("MM2AMD_LONG_JOIN_ON_HOST", "1")
+        on_host = [[a.key() for a in h] for h in al.map_batch(rds)]
+        st_host = al.last_stats()
+    finally:
+        al.close()
+    assert st["n_long_join_dev"] >= 0.1 * len(rds) and st["n_long_join_host"] == 0
+    assert st_host["n_long_join_dev"] == 0 and st_host["n_long_join_host"] == st["n_long_join_dev"]
+    assert on_host == got
+    if os.path.exists(reflib.REF_SO):
+        assert got == reflib.ref_map_reads(refs, rds, "map-ont")
+
+
 def test_pipeline_equals_batch_by_batch(emu):
     """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
     (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
