@@ -719,8 +719,10 @@ __device__ void lds_radix_sort(uint64_t *E, int32_t n, int key_bits, uint32_t *t
 // memory after a barrier.
 template <class S>
 __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tied, bool replay_all, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask,
-                                 TieFrame *stack, int stack_cap)
+                                 TieFrame *stack, int stack_cap, uint32_t *two_scratch = nullptr, int two_cap = 0)
 {
+	// two_scratch / two_cap: LDS words for the two-bucket closed form below (20 control words, then two_cap positions as 16-bit entries); none: always walk
+	constexpr int TWO_PER = 10; // elements a thread holds in registers in the closed form
 	const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
 	auto insertion = [&](int32_t b, int32_t e) { // rs_insertsort (ksort.h:105-115): stable
 		for (int32_t i = b + 1; i < e; ++i)
@@ -758,9 +760,15 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 			// (measured: the same walk as wave-scalar code with the bucket heads in registers -- v_readlane / v_writelane instead of the LDS
 			// tables -- was 35 % slower: the chain is one LDS round trip per element either way, and the scalar round trips cost more than
 			// the table reads they replace)
-			uint32_t acc = 0, mx = 0;
-			for (int k = 0; k < 256; ++k) { start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; } // cnt becomes the bucket end
-			if ((int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
+			uint32_t acc = 0, mx = 0, n_nonempty = 0, dA = 0, dB = 0;
+			for (int k = 0; k < 256; ++k) {
+				if (cnt[k]) { if (n_nonempty == 0) dA = (uint32_t)k; else dB = (uint32_t)k; ++n_nonempty; }
+				start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; // cnt becomes the bucket end
+			}
+			// exactly two buckets (always so at the top: the strand bit): the walk's result has a closed form, computed by all threads below
+			const bool two = two_scratch && n_nonempty == 2 && len <= nt * TWO_PER && (int32_t)(cnt[dA] - start[dA] < cnt[dB] - start[dB] ? cnt[dA] - start[dA] : cnt[dB] - start[dB]) <= two_cap;
+			if (two_scratch) two_scratch[0] = two ? 1u : 0u, two_scratch[1] = dA, two_scratch[2] = dB, two_scratch[3] = cnt[dA] - start[dA];
+			if (!two && (int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
 				for (int k = 0; k < 256;) {
 					if (head[k] != cnt[k]) {
 						int l = (int)(s.xkey(fr.b + (int32_t)head[k]) >> fr.shift & 255);
@@ -781,6 +789,78 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 			}
 		}
 		__syncthreads();
+		if (two_scratch && two_scratch[0]) {
+#ifdef MM2AMD_WAVE_EMU
+			if (tid == 0 && getenv("MM2AMD_TWO_BUCKET_TRACE")) fprintf(stderr, "[mm2amd] two-bucket closed form: %d elements at shift %d\n", (int)len, (int)fr.shift);
+#endif
+			// Two buckets A < B, regions [b, b + cA) and [b + cA, e).  The walk (ksort.h:126-138) handles A first: an element of B found in A's region
+			// ("x_j", the j-th such) starts a cycle that puts it at B's head; B's own elements met there move one slot on, one after the other,
+			// until an element of A ("z_j") turns up in B's region, which takes x_j's slot.  So: A's region keeps its own elements and z_j replaces
+			// x_j; B's region becomes  x_1 B_0 x_2 B_1 ... x_m B_{m-1} B_m  (B_i: B's elements between z_i and z_{i+1}): x_1 at offset 0, x_j right
+			// after z_{j-1}'s old slot, B's elements before z_m shifted by one, those after it where they were.
+			const uint32_t dA = two_scratch[1], dB = two_scratch[2];
+			const int32_t cA = (int32_t)two_scratch[3], regB = fr.b + cA;
+			uint16_t *const posx = (uint16_t *)(two_scratch + 20);
+			uint32_t *const wave_tot = two_scratch + 4; // words 4..19: one per wave (a workgroup has at most 16)
+			const int32_t per = (len + nt - 1) / nt, p0 = fr.b + tid * per, p1 = p0 + per < fr.e ? p0 + per : fr.e;
+			typename S::Elem el[TWO_PER], prev_el = typename S::Elem();
+			uint32_t fmask = 0, mine = 0; // foreign flags of the thread's own positions
+			bool prev_foreign = false;
+			for (int k = 0; k < TWO_PER; ++k) {
+				const int32_t p = p0 + k;
+				if (p < p1) {
+					el[k] = s.get(p);
+					const uint32_t d = (uint32_t)(s.xk(el[k]) >> fr.shift & 255);
+					if (d == (p < regB ? dB : dA)) fmask |= 1u << k, ++mine;
+				}
+			}
+			if (p0 < p1 && p0 > regB) { prev_el = s.get(p0 - 1); prev_foreign = (uint32_t)(s.xk(prev_el) >> fr.shift & 255) == dA; }
+			// exclusive rank of the thread's first position among all foreign elements of the frame
+			const uint32_t incl = wave_prefix_add_u32(mine);
+			const int wv = tid >> 6, n_wv = (nt + 63) >> 6;
+			if ((tid & 63) == 63) wave_tot[wv] = incl;
+			__syncthreads();
+			uint32_t base = incl - mine, total = 0;
+			for (int w2 = 0; w2 < n_wv; ++w2) { const uint32_t t = wave_tot[w2]; if (w2 < wv) base += t; total += t; }
+			const uint32_t m = total >> 1; // as many x's as z's
+			{
+				uint32_t r = base;
+				for (int k = 0; k < TWO_PER; ++k) if (fmask >> k & 1u) { const int32_t p = p0 + k; if (p < regB) posx[r] = (uint16_t)(p - fr.b); ++r; }
+			}
+			__syncthreads();
+			// what every slot of B's region receives, and where every z goes: read now, written after the barrier
+			typename S::Elem nv[TWO_PER];
+			uint32_t wmask = 0;
+			int32_t zdst[TWO_PER];
+			{
+				uint32_t r = base;
+				for (int k = 0; k < TWO_PER; ++k) {
+					const int32_t p = p0 + k;
+					zdst[k] = -1;
+					if (p >= p1) break;
+					const bool foreign = fmask >> k & 1u;
+					if (p >= regB) {
+						const uint32_t cz = r - m; // z's strictly before p
+						const bool pf = k > 0 ? (fmask >> (k - 1) & 1u) && p - 1 >= regB : prev_foreign; // is the slot before a z?
+						if (cz < m) {
+							if (p == regB) nv[k] = s.get(fr.b + (int32_t)posx[0]), wmask |= 1u << k;
+							else if (pf) nv[k] = s.get(fr.b + (int32_t)posx[cz]), wmask |= 1u << k;
+							else nv[k] = k > 0 ? el[k - 1] : prev_el, wmask |= 1u << k;
+						}
+						if (foreign) zdst[k] = fr.b + (int32_t)posx[cz]; // z_{cz + 1} takes x_{cz + 1}'s slot
+					}
+					if (foreign) ++r;
+				}
+			}
+			__syncthreads();
+			for (int k = 0; k < TWO_PER; ++k) {
+				const int32_t p = p0 + k;
+				if (p >= p1) break;
+				if (wmask >> k & 1u) s.put(p, nv[k]);
+				if (zdst[k] >= 0) s.put(zdst[k], el[k]);
+			}
+			__syncthreads();
+		}
 		if (fr.shift == 0) continue;
 		const int ns = fr.shift > 8 ? fr.shift - 8 : 0;
 		for (int k = 0; k < 256; ++k) { // children (uniform control flow across the workgroup)
@@ -834,13 +914,13 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS 
 		const uint32_t n_tied_all = n_tied_s;
 		if (n_tied_all == 0) return;
 		if (tid == 0) B.tie_flag[r] = 1u;
-		if (heap_sort) return; // MM_F_HEAP_SORT: anchor_heap_order_kernel lays down the heap merge's order instead
+		if (heap_sort & 1) return; // MM_F_HEAP_SORT: anchor_heap_order_kernel lays down the heap merge's order instead
 		// 3. the reference's own permutation of the duplicated keys, from the original order
 		const bool replay_all = n_tied_all > (uint32_t)TIE_MAX_KEYS;
 		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
 		for (int32_t i = tid; i < n; i += THREADS) s.set(i, kin[i], (uint32_t)i);
 		__syncthreads();
-		tie_exact_replay(s, n, tied, n_tied, replay_all, cnt, head, start, child_mask, stack, stack_cap);
+		tie_exact_replay(s, n, tied, n_tied, replay_all, cnt, head, start, child_mask, stack, stack_cap, IN_LDS && !(heap_sort & 2) ? tab + 768 : nullptr, IN_LDS ? ((THREADS / 64) * 256 - 768 - 20) * 2 : 0);
 		for (int32_t i = tid; i < n; i += THREADS) {
 			const uint64_t x = s.xkey(i);
 			bool dup = replay_all;
@@ -923,7 +1003,8 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	static bool attr_set = false;
 	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8)); attr_set = true; }
 	static const bool no_replay = getenv("MM2AMD_SORT_NO_REPLAY") != nullptr; // TIMING ONLY (tools/r03_call5.sh): reads with duplicated keys keep the sorted order -- not the reference's
-	const int heap = (P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0;
+	const bool walk_only = getenv("MM2AMD_NO_TWO_BUCKET") != nullptr; // A/B checks: every partition of the replay by the sequential walk (read per launch)
+	const int heap = ((P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0) | (walk_only ? 2 : 0);
 	int first = 0;
 	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
 		if (n_class[c] == 0) continue;

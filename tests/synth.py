@@ -464,3 +464,18 @@ def gen_duplicated_reference(rng, n_elem=40, elem_len=6000, div=0.03):
         e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
         parts.append(np.concatenate([rng.integers(0, 4, int(rng.integers(100, 2000)), dtype=np.uint8), e]))
     return np.concatenate(parts)
+
+
+def gen_tandem_reads(rng, contigs, n, mean, err, dup_len=400):
+    """reads with a stretch of dup_len bases repeated in tandem (a duplication the reference does not have): the two copies' minimizers hit
+    the same reference positions, so the read's anchor list has pairs of equal keys and the sort's tie order becomes observable (ksort.h:101-151)"""
+    out = []
+    for r in gen_reads(rng, contigs, n, mean, mean // 5, 0.0):
+        if len(r) > 3 * dup_len:
+            k = int(rng.integers(dup_len, len(r) - 2 * dup_len))
+            r = np.concatenate([r[:k + dup_len], r[k:]])
+        sub = rng.random(len(r)) < err
+        r = r.copy()
+        r[sub] = (r[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
+        out.append(r)
+    return out

@@ -196,6 +196,36 @@ def test_long_join_rechain_on_the_device():
         assert got == reflib.ref_map_reads(refs, rds, "map-ont")
 
 
+def test_two_bucket_partition_closed_form(tmp_path):
+    """anchor_sort_kernel's replay of the reference's unstable radix sort: partitions with exactly two buckets (the strand bit at the top) by
+    the block-wide closed form instead of the one-thread walk; reads with a tandem duplication (pairs of equal anchor keys): the anchors in
+    order (MM2AMD_SEED_DUMP) equal with and without it (MM2AMD_NO_TWO_BUCKET=1), the hits equal the compiled reference's"""
+    import minimap2_amd as mm
+    rng = np.random.default_rng(92)
+    contigs = synth.gen_reference(rng, 2000000, 2)
+    reads = synth.gen_tandem_reads(rng, contigs, 150, 9000, 0.08)
+    refs = [synth.ACGT[c].tobytes() for c in contigs]
+    rds = [("tan%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    dumps = []
+    for k, env in enumerate(({}, {"MM2AMD_NO_TWO_BUCKET": "1"})):
+        dump = str(tmp_path / ("seeds%d.txt" % k))
+        os.environ["MM2AMD_SEED_DUMP"] = dump
+        os.environ.update(env)
+        try:
+            al = mm.Aligner(refs, preset="map-ont", names=["chr1", "chr2"], n_threads=8)
+            got = [[a.key() for a in h] for h in al.map_batch(rds)]
+            al.close()
+        finally:
+            del os.environ["MM2AMD_SEED_DUMP"]
+            for e in env:
+                del os.environ[e]
+        dumps.append((open(dump).read(), got))
+    assert dumps[0][0] == dumps[1][0] and dumps[0][0].count("SD\t") > 10000
+    assert dumps[0][1] == dumps[1][1]
+    if os.path.exists(reflib.REF_SO):
+        assert dumps[0][1] == reflib.ref_map_reads(refs, rds, "map-ont")
+
+
 def test_repeat_rich_reference_ties_and_long_anchor_lists():
     """a reference with many diverged copies of one element: thousands of anchors per read, equal-x ties, high-occurrence seeds"""
     import minimap2_amd as mm

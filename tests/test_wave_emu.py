@@ -142,6 +142,42 @@ def test_long_join_rechain_on_the_device(emu, monkeypatch):
         assert got == reflib.ref_map_reads(refs, rds, "map-ont")
 
 
+def test_two_bucket_partition_closed_form(emu, monkeypatch):
+    """the replay of the reference's unstable anchor sort (ksort.h:101-151): where a partition has exactly two buckets (always so at the top:
+    the strand bit) its result is computed by all threads from prefix counts instead of walked by one; reads with a tandem duplication have
+    equal anchor keys on both strands' buckets -- hits equal to the walk's (MM2AMD_NO_TWO_BUCKET=1) and to the compiled reference's"""
+    rng = np.random.default_rng(91)
+    contigs = synth.gen_reference(rng, 400000, 2)
+    reads = synth.gen_tandem_reads(rng, contigs, 24, 7000, 0.06)
+    refs = [synth.ACGT[c].tobytes() for c in contigs]
+    rds = [("tan%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
+    al = emu.Aligner(refs, preset="map-ont", names=["chr1", "chr2"], n_threads=4)
+    try:
+        got = [[a.key() for a in h] for h in al.map_batch(rds)]
+    finally:
+        al.close()
+    assert sum(1 for h in got if h) >= len(rds) - 1
+    if os.path.exists(reflib.REF_SO):
+        assert got == reflib.ref_map_reads(refs, rds, "map-ont")
+    if os.path.exists(DROPIN_EMU) and os.path.exists(G.REF_BIN):  # the anchors themselves, in order (--print-seeds, map.c:255-260), walk against closed form
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            ref_fa, rd_fa = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fa")
+            open(ref_fa, "w").write("".join(">chr%d\n%s\n" % (i + 1, r.decode()) for i, r in enumerate(refs)))
+            open(rd_fa, "w").write("".join(">%s\n%s\n" % (n, r.decode()) for n, r in rds))
+            outs = []
+            for env in ({}, {"MM2AMD_NO_TWO_BUCKET": "1"}):
+                dump = os.path.join(tmp, "seeds%d.txt" % len(outs))
+                subprocess.run([DROPIN_EMU, "-x", "map-ont", "-t", "2", "-c", ref_fa, rd_fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True,
+                               env=dict(os.environ, MM2AMD_SEED_DUMP=dump, **env))
+                outs.append(open(dump).read())
+            assert outs[0] == outs[1] and outs[0].count("SD\t") > 1000
+            want = subprocess.run([G.REF_BIN, "-x", "map-ont", "-t", "1", "-c", "--print-seeds", ref_fa, rd_fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.decode()
+            want_sd = [l for l in want.split("\n") if l.startswith("SD\t")]
+            got_sd = [l for l in outs[0].split("\n") if l.startswith("SD\t")]
+            assert got_sd == want_sd
+
+
 def test_pipeline_equals_batch_by_batch(emu):
     """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
     (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
