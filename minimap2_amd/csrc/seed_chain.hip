@@ -717,12 +717,12 @@ __device__ void lds_radix_sort(uint64_t *E, int32_t n, int key_bits, uint32_t *t
 // replayed (child_mask: the children of the current range that hold one); everything else is skipped.  Afterwards the elements with
 // duplicated keys sit at their final positions.  Control flow is uniform over the workgroup: every decision is read from shared
 // memory after a barrier.
-template <class S>
-__device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tied, bool replay_all, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask,
+template <class S, int TWO_PER = 1>
+__device__ __forceinline__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tied, bool replay_all, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask,
                                  TieFrame *stack, int stack_cap, uint32_t *two_scratch = nullptr, int two_cap = 0)
 {
 	// two_scratch / two_cap: LDS words for the two-bucket closed form below (20 control words, then two_cap positions as 16-bit entries); none: always walk
-	constexpr int TWO_PER = 10; // elements a thread holds in registers in the closed form
+	// TWO_PER: elements a thread holds in registers in the closed form (the caller's class: anchors per read / threads)
 	const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
 	auto insertion = [&](int32_t b, int32_t e) { // rs_insertsort (ksort.h:105-115): stable
 		for (int32_t i = b + 1; i < e; ++i)
@@ -806,8 +806,10 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 			typename S::Elem el[TWO_PER], prev_el = typename S::Elem();
 			uint32_t fmask = 0, mine = 0; // foreign flags of the thread's own positions
 			bool prev_foreign = false;
+#pragma unroll
 			for (int k = 0; k < TWO_PER; ++k) {
 				const int32_t p = p0 + k;
+				el[k] = typename S::Elem();
 				if (p < p1) {
 					el[k] = s.get(p);
 					const uint32_t d = (uint32_t)(s.xk(el[k]) >> fr.shift & 255);
@@ -825,39 +827,38 @@ __device__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tie
 			const uint32_t m = total >> 1; // as many x's as z's
 			{
 				uint32_t r = base;
+#pragma unroll
 				for (int k = 0; k < TWO_PER; ++k) if (fmask >> k & 1u) { const int32_t p = p0 + k; if (p < regB) posx[r] = (uint16_t)(p - fr.b); ++r; }
 			}
 			__syncthreads();
-			// what every slot of B's region receives, and where every z goes: read now, written after the barrier
-			typename S::Elem nv[TWO_PER];
-			uint32_t wmask = 0;
-			int32_t zdst[TWO_PER];
-			{
+			{ // B's region (every element was read above; the x's still sit in A's region: the z's move there after the next barrier)
 				uint32_t r = base;
+#pragma unroll
 				for (int k = 0; k < TWO_PER; ++k) {
 					const int32_t p = p0 + k;
-					zdst[k] = -1;
-					if (p >= p1) break;
-					const bool foreign = fmask >> k & 1u;
-					if (p >= regB) {
+					if (p < p1 && p >= regB) {
 						const uint32_t cz = r - m; // z's strictly before p
-						const bool pf = k > 0 ? (fmask >> (k - 1) & 1u) && p - 1 >= regB : prev_foreign; // is the slot before a z?
 						if (cz < m) {
-							if (p == regB) nv[k] = s.get(fr.b + (int32_t)posx[0]), wmask |= 1u << k;
-							else if (pf) nv[k] = s.get(fr.b + (int32_t)posx[cz]), wmask |= 1u << k;
-							else nv[k] = k > 0 ? el[k - 1] : prev_el, wmask |= 1u << k;
+							const bool pf = k > 0 ? (fmask >> (k > 0 ? k - 1 : 0) & 1u) && p - 1 >= regB : prev_foreign; // is the slot before a z?
+							if (p == regB) s.put(p, s.get(fr.b + (int32_t)posx[0]));
+							else if (pf) s.put(p, s.get(fr.b + (int32_t)posx[cz]));
+							else s.put(p, k > 0 ? el[k > 0 ? k - 1 : 0] : prev_el);
 						}
-						if (foreign) zdst[k] = fr.b + (int32_t)posx[cz]; // z_{cz + 1} takes x_{cz + 1}'s slot
 					}
-					if (foreign) ++r;
+					if (fmask >> k & 1u) ++r;
 				}
 			}
 			__syncthreads();
-			for (int k = 0; k < TWO_PER; ++k) {
-				const int32_t p = p0 + k;
-				if (p >= p1) break;
-				if (wmask >> k & 1u) s.put(p, nv[k]);
-				if (zdst[k] >= 0) s.put(zdst[k], el[k]);
+			{ // z_{cz + 1} takes x_{cz + 1}'s slot
+				uint32_t r = base;
+#pragma unroll
+				for (int k = 0; k < TWO_PER; ++k) {
+					const int32_t p = p0 + k;
+					if (fmask >> k & 1u) {
+						if (p >= regB) s.put(fr.b + (int32_t)posx[r - m], el[k]);
+						++r;
+					}
+				}
 			}
 			__syncthreads();
 		}
@@ -920,7 +921,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS 
 		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
 		for (int32_t i = tid; i < n; i += THREADS) s.set(i, kin[i], (uint32_t)i);
 		__syncthreads();
-		tie_exact_replay(s, n, tied, n_tied, replay_all, cnt, head, start, child_mask, stack, stack_cap, IN_LDS && !(heap_sort & 2) ? tab + 768 : nullptr, IN_LDS ? ((THREADS / 64) * 256 - 768 - 20) * 2 : 0);
+		tie_exact_replay<decltype(s), ROUNDS>(s, n, tied, n_tied, replay_all, cnt, head, start, child_mask, stack, stack_cap, IN_LDS && !(heap_sort & 2) ? tab + 768 : nullptr, IN_LDS ? ((THREADS / 64) * 256 - 768 - 20) * 2 : 0);
 		for (int32_t i = tid; i < n; i += THREADS) {
 			const uint64_t x = s.xkey(i);
 			bool dup = replay_all;
