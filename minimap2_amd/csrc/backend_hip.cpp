@@ -512,11 +512,17 @@ public:
 		kernel_profiler(lane_id, replica_).collect();
 	}
 
-	// Opt-in (MM2AMD_DEVICE_FINISH=1): it saves 1.4 host core-seconds per 1-Gbase step (8.2 -> 6.8) for 56 ms of latency-bound launches; on a single GPU with a
-	// 16-CPU quota the pipeline comes out 1 % slower with it (1.486 / 1.487 against 1.504 / 1.499 Gbases/s, A/B on one box: profiles/README.md).  Read per
-	// call, so that tests can switch it.
+	// MM2AMD_DEVICE_FINISH=1 / =0 decides; unset: the device finishes the regions when this mapper has fewer than 12 host threads.  The kernel saves
+	// 1.4 host core-seconds per 1-Gbase step (8.2 -> 6.8) for 56 ms of latency-bound launches: with 16 threads for one GPU the pipeline comes out
+	// 1 % slower with it (1.486 / 1.487 against 1.504 / 1.499 Gbases/s, A/B on one box: profiles/README.md); a rank of a multi-GPU job that shares
+	// the node's CPU quota with seven others (two threads each under a 16-CPU quota) is bounded by exactly those core-seconds.  Read per batch.
 	bool supports_long_join() const override { return true; }
-	bool finishes_regions() const override { const char *e = getenv("MM2AMD_DEVICE_FINISH"); return e && *e && *e != '0'; }
+	bool finishes_regions() const override
+	{
+		const char *e = getenv("MM2AMD_DEVICE_FINISH");
+		if (e && *e) return *e != '0';
+		return n_threads_ < 12;
+	}
 	void finish_regions(int lane_id, const std::vector<FinRegion> &regions, const std::vector<FinPiece> &pieces, size_t out_words, const int8_t *mat25, int q, int e, bool log_gap,
 	                    std::vector<FinResult> &results, const uint32_t **cigars) override
 	{

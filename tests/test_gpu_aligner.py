@@ -142,8 +142,12 @@ def test_profile_counters_and_substeps():
     refs = [synth.ACGT[c].tobytes() for c in contigs]
     rds = [("read%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(reads)]
     al = mm.Aligner(refs, preset="map-ont", n_threads=8)
-    plain = [[a.key() for a in h] for h in al.map_batch(rds)]
-    os.environ["MM2AMD_DEVICE_FINISH"] = "1"  # the regions' last step (mm_update_extra) on the device: the same hits
+    os.environ["MM2AMD_DEVICE_FINISH"] = "0"  # the regions' last step (mm_update_extra) on the host ...
+    try:
+        plain = [[a.key() for a in h] for h in al.map_batch(rds)]
+    finally:
+        del os.environ["MM2AMD_DEVICE_FINISH"]
+    os.environ["MM2AMD_DEVICE_FINISH"] = "1"  # ... and on the device: the same hits
     try:
         mm.profile_enable(True)
         whole = [[a.key() for a in h] for h in al.map_batch(rds)]
