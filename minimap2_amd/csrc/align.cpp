@@ -10,6 +10,9 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "chain_host.hpp"
 
 namespace mm2amd {
@@ -648,14 +651,59 @@ void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs,
 	for (size_t i = 0; i < regs.size(); ++i) add_region(ra, regs[i], -1);
 }
 
+#if defined(__x86_64__)
+// nt4 codes of 16 bases per step (kNt4Table: A/a 0, C/c 1, G/g 2, T/t/U/u 3, the bytes 0..3 themselves, anything else 4): the letters' low
+// nibbles differ (A 1, C 3, G 7, T 4, U 5), so one byte shuffle proposes the code and another names the letter the nibble stands for, which
+// the byte (case bit cleared) must equal.  `rev`: the block is the reverse complement of the 16 bases ENDING at src + 16.
+__attribute__((target("ssse3"))) static inline __m128i nt4_block(__m128i c, bool rev)
+{
+	const __m128i expect = _mm_setr_epi8(0, 'A', 0, 'C', 'T', 'U', 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0);
+	const __m128i code = _mm_setr_epi8(4, 0, 4, 1, 3, 3, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4);
+	if (rev) c = _mm_shuffle_epi8(c, _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0));
+	const __m128i nib = _mm_and_si128(c, _mm_set1_epi8(0x0f)), up = _mm_and_si128(c, _mm_set1_epi8((char)0xdf));
+	const __m128i letter = _mm_cmpeq_epi8(_mm_shuffle_epi8(expect, nib), up);                     // a letter of the alphabet, either case
+	const __m128i raw = _mm_cmpeq_epi8(_mm_and_si128(c, _mm_set1_epi8((char)0xfc)), _mm_setzero_si128()); // the bytes 0..3
+	__m128i v = _mm_or_si128(_mm_and_si128(letter, _mm_shuffle_epi8(code, nib)), _mm_and_si128(raw, c));
+	const __m128i known = _mm_or_si128(letter, raw);
+	if (rev) v = _mm_xor_si128(v, _mm_set1_epi8(3)); // complement: 3 - code
+	return _mm_or_si128(_mm_and_si128(known, v), _mm_andnot_si128(known, _mm_set1_epi8(4)));
+}
+__attribute__((target("ssse3"))) static void nt4_encode_ssse3(const uint8_t *src, int n, uint8_t *dst, bool rev)
+{
+	int i = 0;
+	if (!rev) for (; i + 16 <= n; i += 16) _mm_storeu_si128((__m128i *)(dst + i), nt4_block(_mm_loadu_si128((const __m128i *)(src + i)), false));
+	else for (; i + 16 <= n; i += 16) _mm_storeu_si128((__m128i *)(dst + i), nt4_block(_mm_loadu_si128((const __m128i *)(src + n - 16 - i)), true));
+	for (; i < n; ++i) { const uint8_t c = kNt4Table[rev ? src[n - 1 - i] : src[i]]; dst[i] = !rev ? c : c < 4 ? 3 - c : 4; }
+}
+static bool nt4_ssse3_ok() // the CPU has it, and it agrees with the table on every byte value (checked once)
+{
+	static const bool ok = [] {
+		if (!__builtin_cpu_supports("ssse3")) return false;
+		uint8_t src[272], a[272], b[272];
+		for (int i = 0; i < 272; ++i) src[i] = (uint8_t)(i * 7 + (i >> 4));
+		for (int i = 0; i < 256; ++i) src[i] = (uint8_t)i;
+		for (int rev = 0; rev < 2; ++rev) {
+			nt4_encode_ssse3(src, 272, a, rev != 0);
+			for (int i = 0; i < 272; ++i) { const uint8_t c = kNt4Table[rev ? src[271 - i] : src[i]]; b[i] = !rev ? c : c < 4 ? 3 - c : 4; }
+			if (memcmp(a, b, 272) != 0) return false;
+		}
+		return true;
+	}();
+	return ok;
+}
+#endif
+
 const uint8_t *strand_codes(ReadAlign &ra, int strand)
 {
 	uint8_t *dst = ra.q4 + (size_t)strand * ra.qlen;
 	if (ra.q4_ready[strand]) return dst;
 	hostprof::Scope hp(hostprof::Q4_ENCODE);
-	static const struct RcTable { uint8_t t[256]; RcTable() { for (int c = 0; c < 256; ++c) t[c] = kNt4Table[c] < 4 ? 3 - kNt4Table[c] : 4; } } rc;
 	const int n = ra.qlen;
 	const uint8_t *src = (const uint8_t *)ra.seq;
+#if defined(__x86_64__)
+	if (nt4_ssse3_ok()) { nt4_encode_ssse3(src, n, dst, strand != 0); ra.q4_ready[strand] = true; return dst; }
+#endif
+	static const struct RcTable { uint8_t t[256]; RcTable() { for (int c = 0; c < 256; ++c) t[c] = kNt4Table[c] < 4 ? 3 - kNt4Table[c] : 4; } } rc;
 	if (strand == 0) for (int i = 0; i < n; ++i) dst[i] = kNt4Table[src[i]];
 	else for (int i = 0; i < n; ++i) dst[i] = rc.t[src[n - 1 - i]];
 	ra.q4_ready[strand] = true;

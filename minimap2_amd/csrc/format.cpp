@@ -88,8 +88,15 @@ struct alignas(128) Text {
 	void tag(const char *name, int64_t v) { ch('\t'), str(name), num(v); } // "\tNM:i:" + value
 	void cigar(const uint32_t *c, uint32_t n_cigar) // <len><op> per entry
 	{
-		char *w = need((size_t)n_cigar * 11);
-		for (uint32_t k = 0; k < n_cigar; ++k) w = put_u32(w, c[k] >> 4), *w++ = kCigarOps[c[k] & 0xf];
+		// lengths below 1000 (all but a handful per read) from a table: four bytes stored, the digit count added -- no branch on the number of digits
+		static const struct Small { uint32_t chars[1000]; uint8_t len[1000]; Small() { for (uint32_t x = 0; x < 1000; ++x) { char b[8] = {0}; len[x] = (uint8_t)(put_u32(b, x) - b); memcpy(&chars[x], b, 4); } } } small;
+		char *w = need((size_t)n_cigar * 11 + 4);
+		for (uint32_t k = 0; k < n_cigar; ++k) {
+			const uint32_t x = c[k] >> 4;
+			if (x < 1000) memcpy(w, &small.chars[x], 4), w += small.len[x];
+			else w = put_u32(w, x);
+			*w++ = kCigarOps[c[k] & 0xf];
+		}
 		n = (size_t)(w - p);
 	}
 };
