@@ -1479,7 +1479,7 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	__shared__ uint32_t lI[BT_LDS_CAP];
 	__shared__ uint32_t cnt[256], head[256], start[256], child_mask[8];
 	__shared__ TieFrame stack[BT_STACK];
-	__shared__ int32_t path[BT_PATH_CAP];
+	__shared__ uint16_t path[BT_PATH_CAP]; // anchor indices within the read, 16 bits each (reads with more than 65536 anchors record nothing: pcap below) -- 13 KB of LDS per wave instead of 17.5: eleven reads per CU instead of nine
 	__shared__ int32_t s_nu, s_nv;
 	__shared__ uint64_t s_aoff, s_uoff;
 	const int lane = threadIdx.x;
@@ -1525,6 +1525,7 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	// chain is cut is known when it ends (the reference marks the path, finds the cut, unmarks, and walks again to collect), and the
 	// anchors up to the cut are then claimed by all lanes at once.  p[i] < i, so a walk never meets its own anchors: no marks needed.
 	int32_t n_v = 0, n_u_acc = 0; // identical in all lanes
+	const int32_t pcap = n <= 65536 ? BT_PATH_CAP : 0; // how much of a walk is recorded
 	for (int32_t k0 = n_z - 1; k0 >= 0; k0 -= 64) {
 		const int32_t k = k0 - lane;
 		int32_t zi = 0, zx = 0;
@@ -1537,7 +1538,7 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 			if (lane == 0) {
 				int32_t i = czi, pi = p[czi], len = 0;
 				for (;;) {
-					if (len < BT_PATH_CAP) path[len] = i;
+					if (len < pcap) path[len] = (uint16_t)i;
 					++len;
 					const int32_t nxt = pi;
 					int32_t fn = 0, tn = 0, pn = -1;
@@ -1551,11 +1552,11 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 			}
 			keep = __builtin_amdgcn_readfirstlane(keep), max_s = __builtin_amdgcn_readfirstlane(max_s);
 			WAVE_SYNC();
-			const int32_t n_rec = keep < BT_PATH_CAP ? keep : BT_PATH_CAP;
+			const int32_t n_rec = keep < pcap ? keep : pcap;
 			for (int32_t q = lane; q < n_rec; q += 64) { const int32_t idx = path[q]; v[n_v + q] = idx, t[idx] = 1; }
-			if (keep > BT_PATH_CAP && lane == 0) { // longer than the recorded part (whole contigs as queries): chase on from its last anchor
-				int32_t i = p[path[BT_PATH_CAP - 1]];
-				for (int32_t q = BT_PATH_CAP; q < keep; ++q) { v[n_v + q] = i, t[i] = 1; i = p[i]; }
+			if (keep > pcap && lane == 0) { // longer than the recorded part (whole contigs as queries): chase on from its last anchor
+				int32_t i = pcap > 0 ? p[path[pcap - 1]] : czi;
+				for (int32_t q = pcap; q < keep; ++q) { v[n_v + q] = i, t[i] = 1; i = p[i]; }
 			}
 			if (max_s >= min_sc && keep > 0 && keep >= min_cnt) { // (a rejected chain keeps its anchors claimed, lchain.c:66-67)
 				if (lane == 0) u[n_u_acc] = (uint64_t)(uint32_t)max_s << 32 | (uint64_t)(uint32_t)keep;
