@@ -286,6 +286,7 @@ def main():
     base = mm.Batch(named)  # the reader's product: mm_bseq1_t records over host buffers (built once; every step maps a rotation of it)
     gbuf = shard.GatherBuffers() if (world > 1 or os.environ.get("MM2AMD_BENCH_FORCE_GATHER")) else None
     step_done = []
+    last_text = []  # (batch, address, length) of the last text the output stage produced: valid until the next mm_gpu_format_batch_view
 
     def on_mapped(b, n_reg, reg, rep_len):  # output thread: the final hit gather to rank 0, then this rank formats its own shard
         nonlocal n_mapped, n_hits
@@ -303,7 +304,10 @@ def main():
         barrier()
         t = time.time()
         trace = []
-        al.pipeline(batches, text=True, on_mapped=on_mapped, on_text=lambda b_, addr, ln: step_done.append((time.time(), ln)), trace=trace)
+        def on_text(b_, addr, ln):  # output thread, inside the clock: only remember where the text is
+            step_done.append((time.time(), ln))
+            last_text[:] = [(b_, addr, ln)]
+        al.pipeline(batches, text=True, on_mapped=on_mapped, on_text=on_text, trace=trace)
         barrier()
         dt = time.time() - t
         if rank == 0 and os.environ.get("MM2AMD_BENCH_TRACE"):  # when each step of each batch ran, relative to the start of the clock
@@ -320,6 +324,29 @@ def main():
     total_t = run_steps(range(a.warmup, a.warmup + a.steps))
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     sam_bytes_per_step = step_done[-1][1] if step_done else 0
+    # Parity of the timed path itself: the SAM text the pipeline produced for the LAST TIMED step -- still in the library's
+    # reused buffer; hashed here, after the clock has stopped -- against the text of the same batch mapped outside the pipeline (mm_gpu_batch_stage +
+    # mm_gpu_map_staged + mm_gpu_format_batch, the path the -m gpu suite pins to the compiled reference).
+    def text_hash(addr, ln):
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        view = (C.c_char * ln).from_address(addr) if ln else b""
+        h.update(memoryview(view))
+        return h.hexdigest()
+    pipeline_text_identical = None
+    step_text_lengths = sorted({ln for _, ln in step_done})
+    if last_text and world == 1:
+        b_last, addr, ln = last_text[0]
+        h_pipe = text_hash(addr, ln)
+        al.stage(b_last)
+        n_reg, reg, rep = al.run(raw=True)
+        out, out_len = C.c_void_p(), C.c_size_t()
+        mm._check(L.mm_gpu_format_batch(b_last.n, b_last.seg_off, b_last.n_seg, b_last.arr, n_reg, reg, rep, C.byref(out), C.byref(out_len)))
+        h_plain = text_hash(out.value, out_len.value)
+        mm._libc_free(out)
+        al.free_raw(n_reg, reg)
+        pipeline_text_identical = bool(h_pipe == h_plain and ln == out_len.value and ln > 0)
+        log("text of the last timed step: %d bytes, blake2b %s (pipeline) vs %s (stage + run + format): %s" % (ln, h_pipe, h_plain, "identical" if pipeline_text_identical else "DIFFERENT"))
     log("rank %d: %d steps in %.3f s (%.3f s per step; last batch's text %d bytes)  stats=%s" % (rank, a.steps, total_t, total_t / max(a.steps, 1), sam_bytes_per_step, {k: round(v, 3) for k, v in al.last_stats().items()}))
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
     log("rank %d: host CPU time per step %.2f core-seconds (%d threads; hand-over, host stages of the mapping, hit gather, formatting)" % (rank, host_cpu_s, n_threads))
@@ -416,7 +443,11 @@ def main():
                 "traffic": None, "avg_launch_ms": round(fam_ms / max(fam_launch, 1), 4), "launches": fam_launch,
                 "alg_bytes_per_launch": round(fam_bytes / max(fam_launch, 1), 1),
                 "note": "integer DP: bound by VALU issue, not by HBM (see 'valu'; DESIGN.md section 4); hbm figures = algorithmic bytes of the timed steps / HIP-event time of the family on its launch streams (lanes overlap); traffic = PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE per launch, profiles/pmc_traffic.json",
-                "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())}}
+                "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items())},
+                # per launch class over the timed steps: algorithmic bytes as each launch accounts them (backend_hip.cpp, ksw_host.cpp; the per-unit
+                # figures are DESIGN.md section 4's) and the launches -- traffic / algorithmic is recomputable from this record and profiles/pmc_traffic.json
+                "kernels_alg_bytes": {k: round(v["alg_bytes"], 1) for k, v in sorted(prof.items())},
+                "kernels_launches": {k: v["launches"] for k, v in sorted(prof.items())}}
         inst = {}  # the family's launches per compiled instantiation (what a rocprofv3 kernel trace lists as one kernel name)
         for k, v in same.items():
             a_ = inst.setdefault(k.split("[")[0], [0.0, 0])
@@ -458,6 +489,8 @@ def main():
                             "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
                             "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles: the hot loop's %d VALU instructions per register-set row (ISA count) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) from profiles/r03_pmc_sq_v1.json (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction" % (round(row_cycles), n_slow + n_vop2)}
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
+            roof["unoverlapped_alg_bytes"] = {k: round(v["alg_bytes"], 1) for k, v in sorted(prof1.items())}
+            roof["unoverlapped_alg_gb_per_s"] = {k: round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["alg_bytes"] > 0}
             roof["unoverlapped_gcells_per_s"] = {k: round(v["units"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["units"] > 0}  # DP kernels: cells of the launch class / its time
             roof["unoverlapped_step_ms"] = round(t_one * 1e3, 1) if t_one else None
             try:  # index probes per second of seed_collect_kernel (one mm_idx_get per query minimizer; the launch accounts 36 B per minimizer at the expected density 2 / (w + 1))
@@ -529,6 +562,7 @@ def main():
                       "clock": "pipeline of hand-over | mapping | SAM formatting over the timed steps, all three inside the clock (map.c:541-643)",
                       "host_cpu_s_per_step_per_rank": cpu_all,
                       "sam_bytes_per_step_this_rank": sam_bytes_per_step,
+                      "pipeline_text_identical": pipeline_text_identical, "timed_steps_text_bytes": step_text_lengths,
                       "resident_gbases_per_s": round(batch_bases / resident / 1e9, 5) if resident else None,
                       "handover_then_map_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},

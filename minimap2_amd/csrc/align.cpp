@@ -657,7 +657,9 @@ void Aligner::begin_read(ReadAlign &ra, const char *seq, int qlen, RegVec &regs,
 // the byte (case bit cleared) must equal.  `rev`: the block is the reverse complement of the 16 bases ENDING at src + 16.
 __attribute__((target("ssse3"))) static inline __m128i nt4_block(__m128i c, bool rev)
 {
-	const __m128i expect = _mm_setr_epi8(0, 'A', 0, 'C', 'T', 'U', 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0);
+	// (unused nibbles expect 0x20, a value `up` -- the byte with its case bit 0x20 cleared -- can never take: with 0 there, the bytes 0x00 and 0x20
+	// passed for letters of code 4)
+	const __m128i expect = _mm_setr_epi8(0x20, 'A', 0x20, 'C', 'T', 'U', 0x20, 'G', 0x20, 0x20, 0x20, 0x20, 0x20, 0x20, 0x20, 0x20);
 	const __m128i code = _mm_setr_epi8(4, 0, 4, 1, 3, 3, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4);
 	if (rev) c = _mm_shuffle_epi8(c, _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0));
 	const __m128i nib = _mm_and_si128(c, _mm_set1_epi8(0x0f)), up = _mm_and_si128(c, _mm_set1_epi8((char)0xdf));
@@ -665,7 +667,7 @@ __attribute__((target("ssse3"))) static inline __m128i nt4_block(__m128i c, bool
 	const __m128i raw = _mm_cmpeq_epi8(_mm_and_si128(c, _mm_set1_epi8((char)0xfc)), _mm_setzero_si128()); // the bytes 0..3
 	__m128i v = _mm_or_si128(_mm_and_si128(letter, _mm_shuffle_epi8(code, nib)), _mm_and_si128(raw, c));
 	const __m128i known = _mm_or_si128(letter, raw);
-	if (rev) v = _mm_xor_si128(v, _mm_set1_epi8(3)); // complement: 3 - code
+	if (rev) v = _mm_xor_si128(v, _mm_and_si128(_mm_cmplt_epi8(v, _mm_set1_epi8(4)), _mm_set1_epi8(3))); // complement: 3 - code, where there is a code
 	return _mm_or_si128(_mm_and_si128(known, v), _mm_andnot_si128(known, _mm_set1_epi8(4)));
 }
 __attribute__((target("ssse3"))) static void nt4_encode_ssse3(const uint8_t *src, int n, uint8_t *dst, bool rev)
@@ -685,7 +687,10 @@ static bool nt4_ssse3_ok() // the CPU has it, and it agrees with the table on ev
 		for (int rev = 0; rev < 2; ++rev) {
 			nt4_encode_ssse3(src, 272, a, rev != 0);
 			for (int i = 0; i < 272; ++i) { const uint8_t c = kNt4Table[rev ? src[271 - i] : src[i]]; b[i] = !rev ? c : c < 4 ? 3 - c : 4; }
-			if (memcmp(a, b, 272) != 0) return false;
+			if (memcmp(a, b, 272) != 0) {
+				fprintf(stderr, "[mm2amd] the SSSE3 read encoder disagrees with the nt4 table: using the scalar encoder\n");
+				return false;
+			}
 		}
 		return true;
 	}();
@@ -695,7 +700,7 @@ static bool nt4_ssse3_ok() // the CPU has it, and it agrees with the table on ev
 
 const uint8_t *strand_codes(ReadAlign &ra, int strand)
 {
-	uint8_t *dst = ra.q4 + (size_t)strand * ra.qlen;
+	uint8_t *dst = ra.q4 + (size_t)strand * q4_stride(ra.qlen);
 	if (ra.q4_ready[strand]) return dst;
 	hostprof::Scope hp(hostprof::Q4_ENCODE);
 	const int n = ra.qlen;
@@ -1183,7 +1188,8 @@ bool Aligner::complete_finished(ReadAlign &ra, const FinResult *results, const F
 			r.blen = f.blen, r.mlen = f.mlen, r.is_spliced = f.is_spliced;
 			if (f.qshift) { if (r.rev) r.qe -= f.qshift; else r.qs += f.qshift; } // mm_fix_cigar's dropped leading gap (align.c:171-180)
 			r.rs += f.tshift;
-			if (getenv("MM2AMD_FIN_CHECK") && (r.qs < 0 || r.qe > ra.qlen || r.qs >= r.qe))
+			static const bool fin_check = getenv("MM2AMD_FIN_CHECK") != nullptr; // (once, not per region)
+			if (fin_check && (r.qs < 0 || r.qe > ra.qlen || r.qs >= r.qe))
 				fprintf(stderr, "[mm2amd] FIN_CHECK bad query range: qs %d qe %d qlen %d rev %d | qs1 %d qe1 %d rs1 %d re1 %d | qshift %d tshift %d n_cigar %d | has_left %d win0 kind %d qs %d qe %d job %d\n", r.qs, r.qe, ra.qlen,
 				        (int)r.rev, t.qs1, t.qe1, t.rs1, t.re1, f.qshift, f.tshift, f.n_cigar, (int)t.has_left, t.win.empty() ? -1 : (int)t.win[0].kind, t.win.empty() ? 0 : t.win[0].qs, t.win.empty() ? 0 : t.win[0].qe, t.win.empty() ? 0 : t.win[0].job);
 			t.pieces.clear(), t.dp_acc = 0, t.awaiting_finish = false;

@@ -64,10 +64,14 @@ struct RegionTask {
 	int32_t inv_q0 = 0, inv_t0 = 0, inv_r2_qs = 0, inv_r2_qe = 0, inv_r1_re = 0, inv_qoff = 0, inv_toff = 0;
 };
 
+// A read's host-side nt4 codes: forward block, then reverse complement, each q4_stride(qlen) bytes -- the strand's codes plus >= 15 bytes of
+// its own, so that update_extra's 16-byte loads past a run's end never touch a block another thread may be encoding.
+inline uint64_t q4_stride(int qlen) { return ((uint64_t)qlen + 15 + 15) & ~(uint64_t)15; }
+
 struct ReadAlign {        // per-read alignment state
 	int qlen = 0;
 	uint64_t qpool_off = 0, qpool_rev = 0;       // where this read's nt4 forward / reverse-complement bytes start in the device query pool
-	uint8_t *q4 = nullptr;                       // fwd (qlen) then reverse complement (qlen), nt4 codes; 2*qlen bytes owned by the caller
+	uint8_t *q4 = nullptr;                       // fwd then reverse complement, nt4 codes, q4_stride(qlen) bytes each; owned by the caller
 	const char *seq = nullptr;                   // the read as given (owned by the caller, alive for the read's rounds)
 	bool q4_ready[2] = {false, false};           // a strand is encoded when something first looks at it (strand_codes): most reads use one
 	Anchor *a = nullptr;             // the read's chained anchors (modified in place; owned by the caller)

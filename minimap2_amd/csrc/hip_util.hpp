@@ -43,7 +43,7 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 // hipEventBlockingSync makes the waiter sleep until the interrupt.
 inline void stream_wait(hipStream_t s)
 {
-	struct PerDevice { int dev = -1; hipEvent_t ev = nullptr; };
+	struct PerDevice { int dev = -1; hipEvent_t ev = nullptr; ~PerDevice() { if (ev) (void)hipEventDestroy(ev); } }; // (destroyed when the thread ends)
 	thread_local PerDevice cache[4]; // a host thread drives the lanes of one replica: one device, rarely more
 	int dev = 0;
 	HIP_CHECK(hipGetDevice(&dev));

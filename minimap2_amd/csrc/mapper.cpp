@@ -261,10 +261,10 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		uint64_t q4_total = 0;
 		ds.q4_off.resize(mu + 1);
 		for (long i = 0; i < m; ++i) {
-			ds.q4_off[unit0[i]] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len;
-			if (live[lo + i].paired()) ds.q4_off[unit0[i] + 1] = q4_total, q4_total += 2 * (uint64_t)live[lo + i].len2;
+			ds.q4_off[unit0[i]] = q4_total, q4_total += 2 * q4_stride(live[lo + i].len);
+			if (live[lo + i].paired()) ds.q4_off[unit0[i] + 1] = q4_total, q4_total += 2 * q4_stride(live[lo + i].len2);
 		}
-		if (ds.q4.size() < q4_total + 16) ds.q4.resize(q4_total + q4_total / 4 + 16); // (16 bytes of slack: update_extra compares 16 columns per load)
+		if (ds.q4.size() < q4_total + 16) ds.q4.resize(q4_total + q4_total / 4 + 16); // (every strand block is followed by >= 15 bytes of its own: update_extra compares 16 columns per load, q4_stride)
 		const bool is_sr = (opt_.flag & (F_SR | F_SR_RNA)) != 0;
 		std::atomic<long> n_lj_dev{0}, n_lj_host{0};
 		parallel_for(n_threads_, m, [&](long i, int) {

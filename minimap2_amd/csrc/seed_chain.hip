@@ -1001,8 +1001,9 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	if (!kp) kp = &none;
 	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
 	static const char *kNames[kAnchorSortClasses] = { "anchor_sort_kernel[n1k]", "anchor_sort_kernel[n2k]", "anchor_sort_kernel[n4k]", "anchor_sort_kernel[n7k]", "anchor_sort_kernel[n10k]", "anchor_sort_kernel[global]" };
-	static bool attr_set = false;
-	if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8)); attr_set = true; }
+	// (function attributes are per device and lane drivers of several replicas call this concurrently: set it before every launch that needs it,
+	// as ksw_extd2.hip does -- a table write in the runtime, microseconds)
+	if (n_class[4] > 0) HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8));
 	static const bool no_replay = getenv("MM2AMD_SORT_NO_REPLAY") != nullptr; // TIMING ONLY (tools/r03_call5.sh): reads with duplicated keys keep the sorted order -- not the reference's
 	const bool walk_only = getenv("MM2AMD_NO_TWO_BUCKET") != nullptr; // A/B checks: every partition of the replay by the sequential walk (read per launch)
 	const int heap = ((P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0) | (walk_only ? 2 : 0);

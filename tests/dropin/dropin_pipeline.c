@@ -3,14 +3,18 @@
  * The reference's three-step mini-batch pipeline (worker_pipeline, map.c:541-643, run by kt_pipeline) with its step 1 replaced by
  * the GPU dispatcher and its step 2 by the library's parallel output stage -- INTEGRATION.md section 1 as a program:
  *   step 0  mm_bseq_read3: the reference's own FASTA/FASTQ reader (map.c:543-575)
- *   step 1  mm_gpu_map_batch instead of kt_for(worker_for) (map.c:576)
- *   step 2  mm_gpu_format_batch instead of the mm_write_sam3 / mm_write_paf4 loop (map.c:585-623), then the frees of :624-636
+ *           + mm_gpu_batch_stage_queued: the batch just read is handed to the library (pinned-memory packing + H2D beside the mapping
+ *             of the batch before)
+ *   step 1  mm_gpu_map_staged instead of kt_for(worker_for) (map.c:576)
+ *   step 2  mm_gpu_format_batch_view instead of the mm_write_sam3 / mm_write_paf4 loop (map.c:585-623), then the frees of :624-636
+ * -- the same three entry points, in the same places, as minimap2_amd.Aligner.pipeline() and therefore as bench.py's clock
+ * (--one-call: step 1 = mm_gpu_map_batch, step 2 = mm_gpu_format_batch, the un-pipelined pair, for A/B).
  * kt_pipeline (the reference's, kthread.c:130) runs the steps of consecutive mini-batches on three threads, so parsing batch k+1,
  * mapping batch k and formatting batch k-1 overlap exactly as in the reference.  It prints the reference's own progress stamps
  * ("[M::worker_pipeline::<real>*<cpu/real>] mapped <n> sequences", map.c:638-639; "[M::main::...] loaded/built the index" after the
  * index is in memory, main.c:456-459), so tools/e2e_wall.py reads the same interval off both programs.
  *
- * usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch_bases] ref.fa|ref.mmi reads.fa     (single-end reads) */
+ * usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch_bases] [--one-call] ref.fa|ref.mmi reads.fa     (single-end reads) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,7 +39,7 @@ typedef struct {
 	const mm_idx_t *mi;
 	const mm_mapopt_t *opt;
 	int64_t batch;
-	int n_processed, failed;
+	int n_processed, failed, one_call;
 } pipeline_t;
 
 typedef struct {
@@ -61,23 +65,38 @@ static void *worker(void *shared, int step, void *in)
 		s->seg_off = s->n_reg + s->n_seq, s->n_seg = s->seg_off + s->n_seq, s->rep_len = s->n_seg + s->n_seq, s->frag_gap = s->rep_len + s->n_seq;
 		s->reg = (mm_reg1_t**)calloc(s->n_seq, sizeof(mm_reg1_t*));
 		for (i = 0; i < s->n_seq; ++i) s->seg_off[i] = i, s->n_seg[i] = 1;
+		if (!p->one_call && !p->failed && mm_gpu_batch_stage_queued(s->n_seq, s->seg_off, s->n_seg, s->seq) != 0) { /* end of step 0 */
+			fprintf(stderr, "mm_gpu_batch_stage_queued: %s\n", mm2amd_last_error());
+			p->failed = 1;
+		}
 		return s;
 	} else if (step == 1) {
 		step_t *s = (step_t*)in;
-		if (mm_gpu_map_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap) != 0) {
-			fprintf(stderr, "mm_gpu_map_batch: %s\n", mm2amd_last_error());
+		if (p->failed) { if (!p->one_call) mm_gpu_batch_discard(); return s; }
+		if ((p->one_call? mm_gpu_map_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)
+		                : mm_gpu_map_staged(s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)) != 0) {
+			fprintf(stderr, "%s: %s\n", p->one_call? "mm_gpu_map_batch" : "mm_gpu_map_staged", mm2amd_last_error());
 			p->failed = 1;
 		}
 		return s;
 	} else {
 		step_t *s = (step_t*)in;
 		char *text = 0;
+		const char *view = 0;
 		size_t text_len = 0;
-		if (!p->failed && mm_gpu_format_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &text, &text_len) != 0) {
-			fprintf(stderr, "mm_gpu_format_batch: %s\n", mm2amd_last_error());
-			p->failed = 1;
+		if (p->failed) ;
+		else if (p->one_call) {
+			if (mm_gpu_format_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &text, &text_len) != 0) {
+				fprintf(stderr, "mm_gpu_format_batch: %s\n", mm2amd_last_error());
+				p->failed = 1;
+			}
+			if (text) fwrite(text, 1, text_len, stdout), free(text);
+		} else { /* the library owns and reuses the buffer: nothing to free */
+			if (mm_gpu_format_batch_view(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &view, &text_len) != 0) {
+				fprintf(stderr, "mm_gpu_format_batch_view: %s\n", mm2amd_last_error());
+				p->failed = 1;
+			} else fwrite(view, 1, text_len, stdout);
 		}
-		if (text) fwrite(text, 1, text_len, stdout), free(text);
 		for (i = 0; i < s->n_seq; ++i) {
 			mm_bseq1_t *t = &s->seq[i];
 			for (j = 0; j < s->n_reg[i]; ++j) free(s->reg[i][j].p);
@@ -98,7 +117,7 @@ int main(int argc, char *argv[])
 	mm_mapopt_t mopt;
 	mm_idx_reader_t *rd;
 	mm_idx_t *mi;
-	int n_threads = 3, k = 1, rc = 0;
+	int n_threads = 3, k = 1, rc = 0, one_call = 0;
 	int64_t batch = 500000000;
 	mm_realtime0 = realtime();
 	mm_set_opt(0, &iopt, &mopt);
@@ -108,6 +127,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-c") == 0) mopt.flag |= MM_F_OUT_CG | MM_F_CIGAR; /* main.c:238 */
 		else if (strcmp(argv[k], "-t") == 0) n_threads = atoi(argv[++k]);
 		else if (strcmp(argv[k], "-K") == 0) batch = parse_num(argv[++k]);
+		else if (strcmp(argv[k], "--one-call") == 0) one_call = 1;
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
 	if (argc - k < 2) { fprintf(stderr, "usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch] ref reads\n"); return 1; }
@@ -125,7 +145,7 @@ int main(int argc, char *argv[])
 		memset(&pl, 0, sizeof pl);
 		pl.fp = mm_bseq_open(argv[k + 1]);
 		if (pl.fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
-		pl.mi = mi, pl.opt = &mopt, pl.batch = batch;
+		pl.mi = mi, pl.opt = &mopt, pl.batch = batch, pl.one_call = one_call;
 		kt_pipeline(3, worker, &pl, 3); /* map.c:669: pl_threads = n_threads == 1 ? 1 : 3 (2 with --2-io-threads off) */
 		rc |= pl.failed;
 		mm_bseq_close(pl.fp);

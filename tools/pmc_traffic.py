@@ -25,13 +25,26 @@ def family(name):
     return n.split("<")[0] if n.startswith(("ksw_stream_kernel", "ksw_gapfill_kernel", "ksw_splice_kernel", "ksw_extd2_kernel")) else n
 
 
+ALG = {}  # family -> [algorithmic bytes, launches] from the bench line of the last pass
+
+
 def collect(counter, args):
+    ALG.clear()
     out = os.path.join(ROOT, "gpurun_out", "pmc_" + counter)
     subprocess.run(["rm", "-rf", out])
-    env = dict(os.environ, MM2AMD_LANES="1", TMPDIR="/tmp")
+    env = dict(os.environ, MM2AMD_LANES="1", TMPDIR="/tmp", MM2AMD_DEVICE_FINISH="1")  # (region_finish_kernel on, so that it is counted too)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--reads", str(args.reads), "--ref-mb", str(args.ref_mb), "--preset", args.preset]
-    subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    try:  # the bench line of the same run: algorithmic bytes and launches per launch class, as the launches account them
+        line = json.loads(p.stdout.decode().strip().split("\n")[-1])
+        for k, b in line["roofline"]["kernels_alg_bytes"].items():
+            f = family(k.split("[")[0])
+            a = ALG.setdefault(f, [0.0, 0])
+            a[0] += b
+            a[1] += line["roofline"]["kernels_launches"][k]
+    except Exception as e:  # noqa: BLE001
+        print("no bench line from the %s pass: %s" % (counter, e), file=sys.stderr)
     db = sqlite3.connect(glob.glob(os.path.join(out, "*.db"))[0])
     cols = [c[1] for c in db.execute("pragma table_info('counters_collection')")]
     name_col = "kernel_name" if "kernel_name" in cols else "name"
@@ -59,16 +72,23 @@ if __name__ == "__main__":
     fetch = collect("FETCH_SIZE", a)
     write = collect("WRITE_SIZE", a)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    out = json.load(open(path)) if os.path.exists(path) else {}  # kernels this run does not exercise keep their entries
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    # a map-ont run replaces every entry but the splice kernel's (which it does not exercise); a splice run only adds that one
+    out = {k: v for k, v in old.items() if (k.startswith("ksw_splice") if a.preset == "map-ont" else True)}
     for f in sorted(set(fetch) | set(write)):
-        if not any(f.startswith(p) for p in ("ksw_", "chain_", "seed_", "sketch", "anchor_", "encode")):
+        if not any(f.startswith(p) for p in ("ksw_", "chain_", "seed_", "sketch", "anchor_", "encode", "region_", "rechain_")):
             continue
         if a.preset != "map-ont" and not f.startswith("ksw_splice"):
             continue  # a splice run only contributes the kernel that the map-ont run does not exercise
         fb, fl = fetch.get(f, [0.0, 0])
         wb, wl = write.get(f, [0.0, 0])
         n = max(fl, wl, 1)
+        alg = ALG.get(f) or ALG.get({"sketch_wave_kernel": "sketch_kernel"}.get(f, f))
+        alg_per = alg[0] / max(alg[1], 1) if alg else None
+        traffic = 2 * fb * 1024 / n + wb * 1024 / n
         out[f] = {"fetch_bytes_per_launch": fb * 1024 / n, "fetch_bytes_x2": 2 * fb * 1024 / n, "write_bytes_per_launch": wb * 1024 / n, "launches": n,
+                  "alg_bytes_per_launch": alg_per, "traffic_over_algorithmic": round(traffic / alg_per, 2) if alg_per else None,
+                  "commit": os.environ.get("MM2AMD_COMMIT"),
                   "note": "%s: per launch at %d reads vs %d Mb; FETCH_SIZE/WRITE_SIZE in KiB -> bytes; x2 = gfx950 wide-read correction; WRITE_SIZE uncalibrated" % (a.preset, a.reads, a.ref_mb)}
     json.dump(out, open(a.out or path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

@@ -1,0 +1,35 @@
+# Round 4: one gpurun call = a list of steps.   usage: gpurun --timeout N -- 'bash tools/r04_call.sh TAG step [step ...]'
+#   suite          the whole -m gpu suite                     suite:<expr>   pytest -k <expr>
+#   bench          the driver's command (20 steps, 5 warm-up)  bench:<K>      K steps, 3 warm-up
+#   prof           rocprofv3 --kernel-trace --stats of bench (5 steps), summary -> r04_bench_full_kernel_stats_TAG.txt
+#   pmc            tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes) -> gpurun_out/pmc_traffic_TAG.json
+#   smoke          __graft_entry__.smoke()
+#   sh:<command>   anything else, from the repo root
+V=$1; shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
+line() { python - "$1" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); c=d.get('cpu_baseline') or {}; r=d['roofline']; u=r.get('unoverlapped_ms') or {}
+    print(sys.argv[1].split('/')[-1], d['value'], 'ms/step', d['ms_per_step'], 'resident', d['config'].get('resident_gbases_per_s'), 'cpu_s', d['config']['host_cpu_s_per_step'],
+          'text_identical', d['config'].get('pipeline_text_identical'), 'ref', c.get('value'), c.get('hits_identical_to_gpu'), 'valu', (r.get('valu') or {}).get('frac'))
+    fam={}
+    for k,v in u.items(): fam[k.split('[')[0].split('<')[0]]=fam.get(k.split('[')[0].split('<')[0],0)+v
+    print('  unoverlapped ms:', {k:round(v,1) for k,v in sorted(fam.items())}, 'sum %.0f'%sum(u.values()))
+except Exception as e: print(sys.argv[1], 'FAILED', e)
+PY
+}
+for S in "$@"; do
+  cd $R
+  case "$S" in
+    suite)   (timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -12) > $O/r04_pytest_gpu_$V.log; tail -3 $O/r04_pytest_gpu_$V.log ;;
+    suite:*) (timeout 1200 python -m pytest tests -x -q -m gpu -k "${S#suite:}" 2>&1 | tail -12) > $O/r04_pytest_gpu_k_$V.log; tail -3 $O/r04_pytest_gpu_k_$V.log ;;
+    bench)   cd /tmp; timeout 900 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/r04_bench_full_$V.json 2> $O/r04_bench_full_$V.log; line $O/r04_bench_full_$V.json ;;
+    bench:*) cd /tmp; timeout 900 python $R/bench.py --steps ${S#bench:} --warmup 3 > $O/r04_bench_full_$V.json 2> $O/r04_bench_full_$V.log; line $O/r04_bench_full_$V.json ;;
+    prof)    cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/r04_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
+             python $R/tools/rocpd_summary.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) > $O/r04_bench_full_kernel_stats_$V.txt; rm -rf $O/prof_ont; head -14 $O/r04_bench_full_kernel_stats_$V.txt ;;
+    pmc)     cd /tmp; MM2AMD_COMMIT=$V timeout 900 python $R/tools/pmc_traffic.py --out $O/pmc_traffic_$V.json > $O/pmc_traffic_$V.log 2>&1; tail -3 $O/pmc_traffic_$V.log | cut -c1-300 ;;
+    smoke)   python -c "import __graft_entry__ as g; g.smoke()" > $O/r04_smoke_$V.log 2>&1; tail -1 $O/r04_smoke_$V.log ;;
+    sh:*)    bash -c "${S#sh:}" ;;
+  esac
+done
