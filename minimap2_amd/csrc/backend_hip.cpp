@@ -249,8 +249,12 @@ public:
 		B.sd_n = ln.d_sd_n.p - base0, B.sd_off = ln.d_sd_off.p - base0, B.sd_aoff = ln.d_sd_aoff.p - base0, B.sd_qpos = ln.d_sd_qpos.p - base0, B.sd_info = ln.d_sd_info.p - base0;
 		const double est_mz = 2.0 * L / (P.w + 1);
 		Bu.mz_cnt = B.mz_cnt, Bu.mz_off = Bu.seq_off, Bu.mz_x = B.mz_x, Bu.mz_y = B.mz_y;
-		Bu.sd_n = B.sd_n, Bu.sd_off = B.sd_off, Bu.sd_aoff = B.sd_aoff, Bu.sd_qpos = B.sd_qpos; // the sketch kernel stages its output there (free until seed_collect; -T uploads its regions after the kernel, in stream order)
-		kp.begin(st); launch_sketch(Bu, P, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
+		int max_len = 0; // sizes the sketch kernel's LDS tile
+		for (size_t u = 0; u < n_unit; ++u) {
+			const uint64_t l_u = has_pairs_ ? unit_off_[ulo + u + 1] - unit_off_[ulo + u] : seq_off_[lo + u + 1] - seq_off_[lo + u];
+			max_len = (int)std::max<uint64_t>((uint64_t)max_len, l_u);
+		}
+		kp.begin(st); launch_sketch(Bu, P, max_len, st); kp.end(st, "sketch_kernel", L + 16.0 * est_mz);
 		if (has_pairs_) // seed_collect joins the minimizer lists of a pair's two units (collect_minimizers, map.c:59-72); indices are batch-wide
 			B.unit_first = d_unit_first_.p + lo, B.unit_off = d_unit_off_.p, B.unit_cnt = ln.d_mz_cnt.p - ulo, B.mz_cnt = nullptr;
 		if (P.sdust_thres > 0) { // -T: drop minimizers in low-complexity regions (the seed arrays are still unused: they carry the regions)

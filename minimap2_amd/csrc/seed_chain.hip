@@ -143,52 +143,133 @@ __global__ void __launch_bounds__(64) sketch_kernel(SeedChainBuffers B, int w, i
 	B.mz_cnt[r] = n_out;
 }
 
-__global__ void __launch_bounds__(256) sketch_wave_kernel(SeedChainBuffers B, int w, int k)
+// One wavefront per read, everything between the read's bases and its minimizer list in LDS (round 4; the round-2 kernel let every lane
+// stream its own stretch of bases from HBM and stage its minimizers through scattered 4-byte stores: with 4096 waves x 64 lanes each
+// holding lines of their own the L2 cannot merge anything, and the kernel moved 16x its algorithmic bytes):
+//   load   the tile's bases (a whole read up to tile_cap bases; longer reads in equal tiles) with coalesced 16-byte loads, packed to 2 bits
+//          per base + an ambiguity mask (sketch_dev.hpp: sk_pack16)
+//   sketch every lane runs the window automaton over its stretch of the tile (sketch_chunk_core: warm-up of w + k + 8 bases before it, ring
+//          of the last w slots lane-interleaved in LDS) and marks the positions it reports in a bit mask: the reference reports a position
+//          at most once and in increasing order (tests/test_oracle_seedchain.py), so the marks ARE the list
+//   emit   the marks are compacted 64 mask words at a time into a position list; 64 lanes at a time rebuild a position's record from the
+//          packed bases (sk_minimizer_at: the k-mer is a funnel shift, its reverse complement a bit reversal) and write mz_x / mz_y once,
+//          coalesced, at the read's running offset
+// LDS per wave: ring 768 w + packed bases and masks 0.5 B per base of tile_cap (w = 10, tile_cap 12 K: 14 KB; eleven reads per CU).
+__device__ __forceinline__ uint32_t wave_prefix_add_u32(uint32_t v); // (below, with the other cross-lane helpers)
+struct SketchLds {
+	int ring_bytes, pk_words, tile_cap, per_wave; // bytes of the ring (also the emit phase's position list), dwords of packed bases (+ 2 in front), bases per tile, bytes per wave
+};
+__host__ __device__ inline SketchLds sketch_lds_layout(int w, int tile_cap)
 {
-	MM2_DYN_LDS(uint64_t, ring); // per wave: bx[w][64] then by[w][64], lane-interleaved (conflict-free)
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int r = blockIdx.x * 4 + wave;
-	if (r >= B.n_reads) return;
+	SketchLds L;
+	L.tile_cap = tile_cap;
+	L.ring_bytes = 64 * w * 12;
+	if (L.ring_bytes < 1024) L.ring_bytes = 1024;
+	L.pk_words = (tile_cap + 256) / 16;
+	L.per_wave = L.ring_bytes + (L.pk_words + 2) * 4 + L.pk_words * 2 + tile_cap / 8; // ring | 2 pad dwords + packed bases | ambiguity halves | marks
+	L.per_wave = (L.per_wave + 15) & ~15;
+	return L;
+}
+constexpr int SK_WARM_LDS = 128, SK_TAIL_LDS = 128; // bases resident before / after a tile (warm-up; the automaton's run past the stretch's end)
+
+template <bool K32>
+__global__ void __launch_bounds__(64) sketch_wave_kernel(SeedChainBuffers B, int w, int k, int tile_cap)
+{
+	MM2_DYN_LDS(uint64_t, lds);
+	const int lane = threadIdx.x;
+	const int r = blockIdx.x;
+	const SketchLds L = sketch_lds_layout(w, tile_cap);
+	uint64_t *const bx = lds + lane;                                   // bx[slot * 64 + lane]
+	uint32_t *const by = (uint32_t *)(lds + (size_t)w * 64) + lane;    // by[slot * 64 + lane]
+	uint32_t *const pk = (uint32_t *)((uint8_t *)lds + L.ring_bytes) + 2;
+	uint16_t *const amb = (uint16_t *)(pk + L.pk_words);
+	uint32_t *const marks = (uint32_t *)(amb + L.pk_words);
+	uint16_t *const list = (uint16_t *)lds;                            // emit phase: the ring is dead by then
+	const int list_cap = L.ring_bytes / 2;
 	const uint64_t o = B.seq_off[r];
 	const int64_t len = (int64_t)(B.seq_off[r + 1] - o);
 	const uint8_t *seq = B.qpool + 2 * o;
-	uint64_t *bx = ring + (size_t)wave * 2 * w * 64 + lane, *by = bx + (size_t)w * 64;
-	int64_t chunk = (len + 63) / 64;
-	if (chunk < 32) chunk = 32;
-	const int64_t cs = (int64_t)lane * chunk, ce = cs + chunk < len ? cs + chunk : len;
-	// One pass: the lane's minimizers go to a staging area of its own -- the seed arrays of the slots of its stretch, unused until
-	// seed_collect (at most one minimizer per base, and a lane emits owned positions only) -- and are then moved to their place in the
-	// read's list, which a scan of the lanes' counts gives.  (Counting first and sketching a second time to emit cost 45 % of the kernel.)
-	uint32_t n = 0;
-	const uint64_t slot0 = B.mz_off[r] + (uint64_t)cs;
-	uint32_t *const t_xl = B.sd_n + slot0, *const t_xh = B.sd_off + slot0, *const t_yl = B.sd_aoff + slot0, *const t_yh = B.sd_qpos + slot0;
-	if (cs < len)
-		sketch_chunk<false>(seq, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t x, uint64_t y) {
-			t_xl[n] = (uint32_t)x, t_xh[n] = (uint32_t)(x >> 32), t_yl[n] = (uint32_t)y, t_yh[n] = (uint32_t)(y >> 32);
-			++n;
-		});
-	uint32_t incl = n;
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-	uint64_t *const ox = B.mz_x + B.mz_off[r] + (incl - n), *const oy = B.mz_y + B.mz_off[r] + (incl - n);
-	for (uint32_t i = 0; i < n; i += 4) { // four at a time: the loads of a group are in flight together
-		uint64_t x[4], y[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u)
-			if (i + u < n) x[u] = (uint64_t)t_xh[i + u] << 32 | t_xl[i + u], y[u] = (uint64_t)t_yh[i + u] << 32 | t_yl[i + u];
-#pragma unroll
-		for (int u = 0; u < 4; ++u)
-			if (i + u < n) ox[i + u] = x[u], oy[i + u] = y[u];
+	uint64_t *const ox = B.mz_x + B.mz_off[r], *const oy = B.mz_y + B.mz_off[r];
+	if (lane == 0) pk[-1] = pk[-2] = 0;
+	const int64_t n_tiles = len > tile_cap ? (len + tile_cap - 1) / tile_cap : 1;
+	const int64_t tile = n_tiles > 1 ? ((len + n_tiles - 1) / n_tiles + 63) & ~(int64_t)63 : len;
+	uint32_t n_out = 0;
+	for (int64_t t0 = 0; t0 < len; t0 += tile) {
+		const int64_t t1 = t0 + tile < len ? t0 + tile : len;
+		const int64_t lo = t0 >= SK_WARM_LDS ? t0 - SK_WARM_LDS : 0;                       // (t0 is a multiple of 64, so lo is one of 16)
+		const int64_t hi = t1 + SK_TAIL_LDS < len ? t1 + SK_TAIL_LDS : len;
+		// ---- load: 16 bases per lane and step
+		for (int64_t c = lo + 16 * lane; c < hi; c += 16 * 64) {
+			struct __attribute__((packed, aligned(1))) Q16 { uint32_t v[4]; };
+			const Q16 q = *(const Q16 *)(seq + c); // (up to 15 bytes past the read's last base: its reverse-complement block follows)
+			uint32_t packed, flags;
+			sk_pack16(q.v, &packed, &flags);
+			pk[(c - lo) >> 4] = packed, amb[(c - lo) >> 4] = (uint16_t)flags;
+		}
+		for (int64_t i = lane; i < (t1 - t0 + 31) >> 5; i += 64) marks[i] = 0;
+		WAVE_SYNC();
+		// ---- sketch
+		int64_t chunk = (t1 - t0 + 63) / 64;
+		if (chunk < 32) chunk = 32;
+		const int64_t cs = t0 + (int64_t)lane * chunk, ce = cs + chunk < t1 ? cs + chunk : t1;
+		if (cs < t1) {
+			uint32_t wpk = 0, wamb = 0;
+			int64_t wcur = -1;
+			auto base_at = [&](int64_t i) -> int {
+				if (i >= lo && i < hi) {
+					const int64_t rel = i - lo;
+					if ((rel >> 4) != wcur) wcur = rel >> 4, wpk = pk[wcur], wamb = amb[wcur];
+					return (wamb >> (rel & 15) & 1u) ? 4 : (int)(wpk >> (30 - 2 * (int)(rel & 15)) & 3u);
+				}
+				return (int)seq[i]; // a restart that reaches far back, or a stretch of symmetric k-mers past the tail: rare
+			};
+			sketch_chunk_core<false, K32, uint32_t>(base_at, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t y) {
+				const uint32_t rel = (uint32_t)((int64_t)((uint32_t)y >> 1) - t0);
+				atomicOr(&marks[rel >> 5], 1u << (rel & 31));
+			}, (int64_t)(w + k + 8));
+		}
+		WAVE_SYNC();
+		// ---- emit: rounds of up to 64 mask words (2048 positions), bounded by the list's capacity
+		const int n_words = (int)((t1 - t0 + 31) >> 5);
+		int words_per_round = list_cap / 32;
+		if (words_per_round > 64) words_per_round = 64;
+		for (int w0 = 0; w0 < n_words; w0 += words_per_round) {
+			uint32_t m = lane < words_per_round && w0 + lane < n_words ? marks[w0 + lane] : 0u;
+			const uint32_t cnt = (uint32_t)__popc(m);
+			const uint32_t incl = wave_prefix_add_u32(cnt);
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
+			uint32_t at = incl - cnt;
+			while (m) { // (positions relative to the tile: < 2^16 by tile_cap)
+				list[at++] = (uint16_t)(((w0 + lane) << 5) + __builtin_ctz(m));
+				m &= m - 1;
+			}
+			WAVE_SYNC();
+			for (uint32_t e = lane; e < total; e += 64) {
+				const int64_t pos = t0 + (int64_t)list[e];
+				uint64_t x, y;
+				sk_minimizer_at(pk, pos - lo, pos, k, &x, &y);
+				ox[n_out + e] = x, oy[n_out + e] = y;
+			}
+			n_out += total;
+			WAVE_SYNC();
+		}
 	}
-	if (lane == 63) B.mz_cnt[r] = incl;
+	if (lane == 0) B.mz_cnt[r] = n_out;
 }
 
-void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
+void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, int max_len, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
 	if (!P.is_hpc && P.w <= 32) {
-		const size_t lds = (size_t)4 * 2 * P.w * 64 * 8;
-		if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)sketch_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(sketch_wave_kernel, dim3((B.n_reads + 3) / 4), dim3(256), lds, s, B, P.w, P.k);
+		// a tile holds the sub-batch's longest read if that takes no more than 16 K bases (positions within a tile are 16-bit in the emit phase's list;
+		// LDS: 0.5 B per base): 10 kb ONT reads are one tile, longer reads are cut into equal tiles
+		int tile_cap = (std::max(max_len, 1024) + 1023) & ~1023;
+		if (tile_cap > 16384) tile_cap = 16384;
+		static const int force_tile = getenv("MM2AMD_SKETCH_TILE") ? atoi(getenv("MM2AMD_SKETCH_TILE")) : 0; // tests: several tiles per read
+		if (force_tile >= 64) tile_cap = force_tile & ~63;
+		const SketchLds L = sketch_lds_layout(P.w, tile_cap);
+		if (2 * P.k <= 32) hipLaunchKernelGGL((sketch_wave_kernel<true>), dim3(B.n_reads), dim3(64), (size_t)L.per_wave, s, B, P.w, P.k, tile_cap);
+		else hipLaunchKernelGGL((sketch_wave_kernel<false>), dim3(B.n_reads), dim3(64), (size_t)L.per_wave, s, B, P.w, P.k, tile_cap);
 	} else {
 		const dim3 grid((B.n_reads + 63) / 64), block(64);
 		if (P.w <= 32) hipLaunchKernelGGL((sketch_kernel<32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);

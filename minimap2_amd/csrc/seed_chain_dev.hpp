@@ -60,7 +60,7 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 
 void launch_encode(const SeedChainBuffers &B, void *stream);
 void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void *stream); // mg_lchain_rmq's fill; tie_flag[r] = 1: read r is left to the host
-void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, void *stream);
+void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, int max_len, void *stream); // max_len: the longest read (unit) of the launch
 void launch_dust_filter(const SeedChainBuffers &B, void *stream); // regions in sd_n / sd_off / sd_aoff (see seed_chain.hip)
 void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);
 void launch_seed_expand(const SeedChainBuffers &B, const DevIndex &I, const SeedChainParams &P, void *stream);

@@ -68,11 +68,53 @@ static long check(const std::string &s, int w, int k, int64_t chunk, uint32_t ri
 	return (long)n_want;
 }
 
+// sketch_wave_kernel's configuration of the same automaton: bases from the 2-bit packed copy (sk_pack16 / sk_base_at), y halves in the ring,
+// warm-up of w + k + 8, 32-bit k-mer registers when 2k <= 32 -- and every reported record rebuilt from the packed bases alone
+// (sk_minimizer_at), as the kernel's emit phase does from its position marks.
+template <bool K32>
+static long check_packed(const std::string &s, int w, int k, int64_t chunk)
+{
+	const int len = (int)s.size();
+	std::vector<uint8_t> nt4(len + 32, 4);
+	for (int i = 0; i < len; ++i) nt4[i] = s[i] == 'A' ? 0 : s[i] == 'C' ? 1 : s[i] == 'G' ? 2 : s[i] == 'T' ? 3 : 4;
+	const int n_words = (len + 15) / 16 + 1;
+	std::vector<uint32_t> store(n_words + 2, 0);
+	std::vector<uint16_t> amb(n_words, 0);
+	uint32_t *pk = store.data() + 2;
+	for (int c = 0; c < len; c += 16) {
+		uint32_t q[4], packed, flags;
+		memcpy(q, nt4.data() + c, 16);
+		sk_pack16(q, &packed, &flags);
+		pk[c >> 4] = packed, amb[c >> 4] = (uint16_t)flags;
+	}
+	for (int i = 0; i < len; ++i) if (sk_base_at(pk, amb.data(), i) != nt4[i]) { fprintf(stderr, "packed base %d differs\n", i); exit(1); }
+	std::vector<ora128_t> want(len + 1);
+	const int64_t n_want = ora_sketch(s.c_str(), len, w, k, 0, 0, want.data(), len + 1);
+	std::vector<uint64_t> bx(256), gx, gy;
+	std::vector<uint32_t> by(256);
+	auto base_at = [&](int64_t i) -> int { return sk_base_at(pk, amb.data(), i); };
+	for (int64_t cs = 0; cs < len; cs += chunk) {
+		const int64_t ce = cs + chunk < len ? cs + chunk : len;
+		sketch_chunk_core<false, K32, uint32_t>(base_at, len, cs, ce, w, k, 0u, bx.data(), by.data(), 1, [&](uint64_t x, uint64_t y) { gx.push_back(x), gy.push_back(y); }, (int64_t)(w + k + 8));
+	}
+	if ((int64_t)gx.size() != n_want) { fprintf(stderr, "packed: w=%d k=%d len=%d chunk=%ld: %zu minimizers, reference %ld\n", w, k, len, (long)chunk, gx.size(), (long)n_want); exit(1); }
+	for (int64_t i = 0; i < n_want; ++i) {
+		if (gx[i] != want[i].x || gy[i] != want[i].y) { fprintf(stderr, "packed: w=%d k=%d len=%d chunk=%ld: minimizer %ld differs\n", w, k, len, (long)chunk, (long)i); exit(1); }
+		if (i > 0 && gy[i] <= gy[i - 1]) { fprintf(stderr, "positions not increasing at %ld\n", (long)i); exit(1); } // what lets a bit mask carry the list
+		uint64_t x, y;
+		const int64_t pos = (int64_t)((uint32_t)gy[i] >> 1);
+		sk_minimizer_at(pk, pos, pos, k, &x, &y);
+		if (x != gx[i] || y != gy[i]) { fprintf(stderr, "packed: w=%d k=%d len=%d: record of position %ld rebuilt as %llx/%llx, automaton %llx/%llx\n", w, k, len, (long)pos, (unsigned long long)x, (unsigned long long)y, (unsigned long long)gx[i], (unsigned long long)gy[i]); exit(1); }
+	}
+	return (long)n_want;
+}
+
 int main(int argc, char **argv)
 {
 	const int n_case = argc > 1 ? atoi(argv[1]) : 300;
 	std::mt19937_64 rng(20260922);
 	static const int WK[][2] = { { 10, 15 }, { 19, 19 }, { 11, 21 }, { 5, 15 }, { 1, 11 }, { 32, 28 } };
+	static const int WK2[][2] = { { 10, 15 }, { 19, 19 }, { 10, 16 }, { 5, 14 }, { 4, 8 }, { 32, 28 }, { 11, 21 }, { 3, 17 } }; // even k: strand-symmetric k-mers exist
 	long total = 0;
 	for (int c = 0; c < n_case; ++c) {
 		const int len = c % 7 == 0 ? 1 + (int)(rng() % 80) : 200 + (int)(rng() % 6000);
@@ -83,6 +125,10 @@ int main(int argc, char **argv)
 		total += check<false>(s, w, k, chunk, 0u);
 		total += check<false>(s, w, k, 1 + (int64_t)(rng() % 300), (uint32_t)(c & 3)); // arbitrary cuts, as the index build makes them
 		if (c % 3 == 0) total += check<true>(s, w, k, 64 + (int64_t)(rng() % 500), (uint32_t)(c & 3));
+		const int w2 = WK2[c % 8][0], k2 = WK2[c % 8][1];
+		const int64_t chunk2 = c & 1 ? chunk : 32 + (int64_t)(rng() % 200);
+		total += 2 * k2 <= 32 ? check_packed<true>(s, w2, k2, chunk2) : check_packed<false>(s, w2, k2, chunk2);
+		if (2 * k2 <= 32) total += check_packed<false>(s, w2, k2, chunk2); // the wide registers on a narrow k
 	}
 	printf("OK %d %ld\n", n_case, total);
 	return 0;
