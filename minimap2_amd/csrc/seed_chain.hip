@@ -202,8 +202,9 @@ __global__ void __launch_bounds__(64) sketch_wave_kernel(SeedChainBuffers B, int
 		for (int64_t c = lo + 16 * lane; c < hi; c += 16 * 64) {
 			struct __attribute__((packed, aligned(1))) Q16 { uint32_t v[4]; };
 			const Q16 q = *(const Q16 *)(seq + c); // (up to 15 bytes past the read's last base: its reverse-complement block follows)
+			const uint32_t qv[4] = { q.v[0], q.v[1], q.v[2], q.v[3] };
 			uint32_t packed, flags;
-			sk_pack16(q.v, &packed, &flags);
+			sk_pack16(qv, &packed, &flags);
 			pk[(c - lo) >> 4] = packed, amb[(c - lo) >> 4] = (uint16_t)flags;
 		}
 		for (int64_t i = lane; i < (t1 - t0 + 31) >> 5; i += 64) marks[i] = 0;
@@ -580,9 +581,16 @@ void launch_seed_collect(const SeedChainBuffers &B, const DevIndex &I, const See
 	HIP_CHECK(hipGetLastError());
 }
 
-// anchors and mini_pos from the kept seeds (map.c:176-200, seed.c:124); one wavefront per read
+// anchors and mini_pos from the kept seeds (map.c:176-200, seed.c:124); one wavefront per read.
+// Round 4: the wave expands 64 seeds at a time COOPERATIVELY -- the seeds' hit counts are prefix-summed over the lanes, every lane then takes
+// one (seed, hit) candidate of the flattened list (which seed: the seeds mark their first candidate in a 64-entry LDS row, a prefix maximum
+// spreads the marks), candidates that pass skip_seed are compacted by ballot, and consecutive lanes write consecutive anchors: 64 x 8 B
+// per store instruction.  (Lane-per-seed, each lane walking its own seed's hits, wrote every anchor as two scattered 8-byte stores: 10x the
+// algorithmic bytes, PMC round 3.)  The position lists themselves stay what they are: one 64-byte sector per seed for the typical one or
+// two hits.
 __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, DevIndex I, SeedChainParams P)
 {
+	__shared__ uint32_t s_head[4][64], s_start[4][64], s_off[4][64], s_info[4][64], s_qp[4][64];
 	const int wave = threadIdx.x >> 6, lane = lane_id();
 	const int r = blockIdx.x * 4 + wave;
 	if (r >= B.n_reads) return;
@@ -593,36 +601,61 @@ __global__ void __launch_bounds__(256) seed_expand_kernel(SeedChainBuffers B, De
 	HIT_RULES_SETUP();
 	uint64_t *akey = B.sort_key_in + B.a_off[r], *aval = B.sort_val_in + B.a_off[r];
 	uint64_t *mp = B.mini_pos + B.mp_off[r];
-	for (int i = lane; i < n_m0; i += 64) {
-		const uint32_t ao = sd_aoff[i];
-		if (ao == 0xffffffffu) continue;
-		const uint32_t info = sd_info[i], span = info & 0xff, qp = sd_qpos[i], cnt = sd_n[i];
-		mp[info << 1 >> 11] = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
-		const uint64_t *cr = I.pos + sd_off[i];
-		uint32_t w = 0; // anchors written for this seed
-		for (uint32_t c = 0; c < cnt; ++c) {
-			const uint64_t rr = cr[c];
-			const uint32_t rpos = (uint32_t)rr >> 1;
-			bool is_self = false;
-			if (hit_rules && skip_hit(P.flag, rr, qp, qlen, nm_lb, nm_eq, I, &is_self)) continue;
-			Anchor p;
-			if ((rr & 1) == (qp & 1)) { // same strand
-				p.x = (rr & 0xffffffff00000000ULL) | rpos;
-				p.y = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
-			} else if (!(P.flag & ref::F_QSTRAND)) {
-				p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
-				p.y = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1);
-			} else { // --qstrand (map.c:192-196): the reference coordinate is flipped, the query's is kept
-				p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | (uint32_t)((int)I.seq_len[rr >> 32] - ((int)rpos + 1 - (int)span) - 1);
-				p.y = (uint64_t)span << 32 | (uint64_t)(qp >> 1);
-			}
-			if (info & SD_SEG1) p.y |= 1ULL << ref::SEED_SEG_SHIFT;
-			if (info & SD_TANDEM) p.y |= ref::SEED_TANDEM;
-			if (is_self) p.y |= ref::SEED_SELF;
-			akey[ao + w] = (p.x >> 63) << (32 + B.rid_bits) | (p.x & 0x7fffffffffffffffULL); // compact sort key: strand | rid | rpos (anchor_sort_kernel)
-			aval[ao + w] = p.y;
-			++w;
+	uint32_t *head = s_head[wave], *c_start = s_start[wave], *c_off = s_off[wave], *c_info = s_info[wave], *c_qp = s_qp[wave];
+	uint32_t n_out = 0; // anchors of the read written so far == sd_aoff of the next kept seed (seed_collect_kernel counted with the same rules)
+	for (int base = 0; base < n_m0; base += 64) {
+		const int i = base + lane;
+		const bool kept = i < n_m0 && sd_aoff[i] != 0xffffffffu;
+		uint32_t cnt = 0, info = 0, qp = 0, off = 0;
+		if (kept) {
+			cnt = sd_n[i], info = sd_info[i], qp = sd_qpos[i], off = sd_off[i];
+			mp[info << 1 >> 11] = (uint64_t)(info & 0xff) << 32 | (uint64_t)(qp >> 1);
 		}
+		const uint32_t incl = wave_prefix_add_u32(cnt), start = incl - cnt;
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
+		c_start[lane] = start, c_off[lane] = off, c_info[lane] = info, c_qp[lane] = qp;
+		int32_t carry = 0; // (seed lane + 1) that owns the candidate before the group's first
+		for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+			head[lane] = 0;
+			WAVE_SYNC();
+			if (cnt > 0 && start - e0 < 64u) head[start - e0] = (uint32_t)lane + 1u; // (start >= e0 by the unsigned compare)
+			WAVE_SYNC();
+			int32_t v = (int32_t)head[lane];
+			if (lane == 0 && v == 0) v = carry;
+			v = wave_prefix_max_i32(v);
+			carry = __builtin_amdgcn_readlane(v, 63);
+			const uint32_t e = e0 + (uint32_t)lane;
+			bool pass = e < total;
+			uint64_t kx = 0, ky = 0;
+			if (pass) {
+				const int sl = v - 1;
+				const uint32_t s_inf = c_info[sl], s_q = c_qp[sl], span = s_inf & 0xff;
+				const uint64_t rr = I.pos[(uint64_t)c_off[sl] + (e - c_start[sl])];
+				const uint32_t rpos = (uint32_t)rr >> 1;
+				bool is_self = false;
+				if (hit_rules && skip_hit(P.flag, rr, s_q, qlen, nm_lb, nm_eq, I, &is_self)) pass = false;
+				uint64_t px, py;
+				if ((rr & 1) == (s_q & 1)) { // same strand
+					px = (rr & 0xffffffff00000000ULL) | rpos;
+					py = (uint64_t)span << 32 | (uint64_t)(s_q >> 1);
+				} else if (!(P.flag & ref::F_QSTRAND)) {
+					px = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | rpos;
+					py = (uint64_t)span << 32 | (uint64_t)(uint32_t)(qlen - ((int)(s_q >> 1) + 1 - (int)span) - 1);
+				} else { // --qstrand (map.c:192-196): the reference coordinate is flipped, the query's is kept
+					px = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | (uint32_t)((int)I.seq_len[rr >> 32] - ((int)rpos + 1 - (int)span) - 1);
+					py = (uint64_t)span << 32 | (uint64_t)(s_q >> 1);
+				}
+				if (s_inf & SD_SEG1) py |= 1ULL << ref::SEED_SEG_SHIFT;
+				if (s_inf & SD_TANDEM) py |= ref::SEED_TANDEM;
+				if (is_self) py |= ref::SEED_SELF;
+				kx = (px >> 63) << (32 + B.rid_bits) | (px & 0x7fffffffffffffffULL); // compact sort key: strand | rid | rpos (anchor_sort_kernel)
+				ky = py;
+			}
+			const unsigned long long pm = __ballot(pass);
+			if (pass) { const uint32_t d = n_out + (uint32_t)popc_below(pm, lane); akey[d] = kx, aval[d] = ky; }
+			n_out += (uint32_t)__popcll(pm);
+		}
+		WAVE_SYNC(); // (the next chunk rewrites the seeds' LDS rows)
 	}
 }
 

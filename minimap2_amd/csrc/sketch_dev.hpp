@@ -189,8 +189,14 @@ __device__ __forceinline__ uint64_t sk_kmer_at(const uint32_t *pk, int64_t r, in
 // the reverse-strand register of the same k bases: kmer1 = (kmer1 >> 2) | (3 ^ c) << 2(k-1), i.e. the digits of kmer0 reversed and complemented
 __device__ __forceinline__ uint64_t sk_revcomp(uint64_t kmer0, int k)
 {
-	uint64_t y = __builtin_bitreverse64(kmer0); // digits reversed, the two bits of a digit swapped
+#if defined(__has_builtin) && __has_builtin(__builtin_bitreverse64)
+	uint64_t y = __builtin_bitreverse64(kmer0); // (v_bfrev_b32 twice) digits reversed, the two bits of a digit swapped
 	y = (y >> 1 & 0x5555555555555555ULL) | (y & 0x5555555555555555ULL) << 1;
+#else // host builds with a compiler that lacks the builtin: digits, nibbles, bytes
+	uint64_t y = (kmer0 >> 2 & 0x3333333333333333ULL) | (kmer0 & 0x3333333333333333ULL) << 2;
+	y = (y >> 4 & 0x0f0f0f0f0f0f0f0fULL) | (y & 0x0f0f0f0f0f0f0f0fULL) << 4;
+	y = __builtin_bswap64(y);
+#endif
 	return (y >> (64 - 2 * k)) ^ ((k < 32 ? 1ULL << 2 * k : 0ULL) - 1ULL);
 }
 // the minimizer record of position p (rid 0, no HPC): what the automaton held when it put p's k-mer into the ring (sketch.c:108-113)
