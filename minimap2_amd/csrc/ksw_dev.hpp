@@ -100,6 +100,6 @@ __host__ __device__ inline size_t ksw_dir_bytes(int qlen, int tlen, int w)
 }
 
 // host launcher (ksw_extd2.hip); n_slots persistent waves, waves_per_block in {1,4}
-void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream /* hipStream_t */);
+void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, int team, void *stream /* hipStream_t */);
 
 } // namespace mm2amd

@@ -1,8 +1,12 @@
 // Batched dual-affine extension DP for gfx950 -- the device counterpart of the reference's
 // ksw_extd2_sse (/root/reference/ksw2_extd2_sse.c:34-401) and ksw_backtrack (ksw2.h:130-162).
 //
-// Mapping.  One wavefront owns one DP job at a time (persistent waves pull jobs from a queue head with
-// one atomic per job).  An anti-diagonal r is swept by the 64 lanes in chunks of 64 target positions t;
+// Mapping.  A TEAM of 1, 4 or 8 wavefronts owns one DP job at a time (persistent teams pull jobs from a queue head with
+// one atomic per job; TEAM > 1: the team is the workgroup, round 4).  An anti-diagonal r is swept in chunks of 64 target positions t,
+// one chunk per wave and round (highest chunks first: a round reads row r-1 at its positions and their left neighbours, meets at a
+// barrier, then stores row r), the score fill and the exact row maximum are strided over all the team's lanes, a barrier separates
+// the passes.  A band-751 anti-diagonal is twelve chunks: one wave took 3 passes x 12 chunks per row and a 500 x 1000 extension held its
+// launch for 6 ms (rounds 1-3: 24 % of the kernel time for 3 % of the cells); eight waves take two rounds per pass.
 // the per-position difference state (u,v,x,y | x2,y2,s) lives in LDS as two packed dwords per t, the
 // target/reversed-query bytes next to it, so a row costs 4 ds_read_b32 + 2 ds_write_b32 per cell and no
 // HBM traffic except the 1 B/cell direction byte.  No MFMA: this is int8 max/add with data-dependent
@@ -137,22 +141,28 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 // slab of HBM instead: slower, but it takes jobs of any length (very long gaps on real genomes), so that no input makes the
 // library give up.
 // ordering between the lanes of the wave: LDS needs a wavefront fence, the HBM-resident state a workgroup-scope one
-#define STATE_SYNC() do { if (LDS_STATE) { WAVE_SYNC(); } else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } } while (0)
+#define STATE_SYNC() do { if (TEAM > 1) { __syncthreads(); } else if (LDS_STATE) { WAVE_SYNC(); } else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } } while (0)
 // MODE 1 (SINGLE): the single-affine recurrences of ksw_extz2_sse (ksw2_extz2_sse.c:25-311) instead of the dual-affine ones:
 // scores shifted by 2(q+e), unsigned second maximum and clamp (:49-50), zero-initialised state, two gap states only.
 // MODE 2 (SPLICE): the splice-aware recurrences of ksw_exts2_sse (ksw2_exts2_sse.c:33-465): no band, the second gap state is an
 // intron on the target (x2 only; opening costs q2, extension nothing) priced per position by donor/acceptor bytes that take the
 // place of y2 and of the spare byte in the second state dword; no clamp; Z-drop without the diagonal term; N in the CIGAR.
-template <bool LDS_STATE, int MODE>
-__global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
+template <bool LDS_STATE, int MODE, int TEAM>
+__global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaunch L)
 {
 	constexpr bool SINGLE = MODE == 1, SPLICE = MODE == 2;
+	static_assert(TEAM == 1 || LDS_STATE, "a team shares its state through LDS");
+	constexpr int NT = 64 * TEAM; // lanes working on one job
 	MM2_DYN_LDS(uint8_t, lds_raw);
+	__shared__ long long s_best[TEAM > 1 ? TEAM : 1];
+	__shared__ int s_team[4]; // job id; then CIGAR length and offset from the wave that traced back
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
-	const int slot = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+	const int tid = TEAM > 1 ? (int)threadIdx.x : lane, twave = TEAM > 1 ? wave_in_block : 0; // within the team
+	const int slot = TEAM > 1 ? (int)blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
 	const size_t region = (ksw_lds_per_wave(L.ring, L.max_Q16) + 15) / 16 * 16;
 	uint8_t *my;
-	if (LDS_STATE) my = lds_raw + (size_t)wave_in_block * region;
+	if (TEAM > 1) my = lds_raw;
+	else if (LDS_STATE) my = lds_raw + (size_t)wave_in_block * region;
 	else my = L.state_pool + (size_t)slot * region;
 	uint8_t *dir = L.dir_pool + (size_t)slot * L.slot_bytes;
 	const int m = L.sc.m;
@@ -160,8 +170,15 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 
 	for (;;) {
 		int jid = 0;
-		if (lane == 0) jid = atomicAdd(L.counter, 1);
-		jid = __builtin_amdgcn_readfirstlane(jid);
+		if (TEAM > 1) {
+			if (threadIdx.x == 0) s_team[0] = atomicAdd(L.counter, 1);
+			__syncthreads();
+			jid = s_team[0];
+			__syncthreads(); // (everyone has it before the next fetch overwrites it)
+		} else {
+			if (lane == 0) jid = atomicAdd(L.counter, 1);
+			jid = __builtin_amdgcn_readfirstlane(jid);
+		}
 		if (jid >= L.n_jobs) break;
 		const KswJob J = L.jobs[jid];
 		const int qlen = J.qlen, tlen = J.tlen, flag = J.flag;
@@ -241,7 +258,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 			// (:107-128; splice: donor / acceptor costs from the neighbouring bases, ksw2_exts2_sse.c:120-194).
 			int frontier = -1;
 			auto admit = [&](int upto) {
-				for (int t = frontier + 1 + lane; t <= upto; t += 64) {
+				for (int t = frontier + 1 + tid; t <= upto; t += NT) {
 					const int k = t & RM;
 					uint32_t bv = SINGLE ? 0u : SPLICE ? (uint32_t)(nqe2 & 0xff) : pack4(nqe2, nqe2, 0, 0);
 					if (sp_strand) {
@@ -312,7 +329,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 			};
 
 			// ---- per-job initialisation (ksw2_extd2_sse.c:107-128) ----
-			for (int i = lane; i < Q16 + 16; i += 64) {
+			for (int i = tid; i < Q16 + 16; i += NT) {
 				uint8_t c = 0;
 				if (i < qlen) { // qr[i] = query[qlen-1-i]
 					int k = qlen - 1 - i;
@@ -341,9 +358,9 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 					uint32_t a = A[(st - 1) & RM], b = B[(st - 1) & RM];
 					x1 = sx8(a >> 16), v1 = sx8(a >> 8), x21 = sx8(b);
 				}
-				if (en >= r && lane == 0) {
+				if (en >= r && tid == 0) {
 					A[r & RM] = (A[r & RM] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24; // u[r], y[r]
-					if (!SPLICE) B[r & RM] = (B[r & RM] & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;          // y2[r]
+					if (!SPLICE) ((uint8_t *)&B[r & RM])[1] = (uint8_t)init2;                                  // y2[r] (a byte store: the team's other waves are writing s[], byte 2, meanwhile)
 				}
 				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes, and past
 				// T16 the reference reads the start of qr[] as target bytes and writes into the first bytes of the target
@@ -353,8 +370,13 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 					const int qoff = qlen - 1 - r;
 					if (!(flag & KSW_GENERIC_SC)) {
 						const int total = ((en0 - st0) / 16 + 1) * 16;
-						for (int i0 = 0; i0 < total; i0 += 64) {
-							const int i = i0 + lane, idx = st0 + i;
+						// (a row whose chunks run past T16 writes into the target copy that lower chunks read: the team leaves such a row -- the last
+						// few of a job -- to its first wave, which keeps the one-wave order: chunks ascending, a step's loads before its stores)
+						const bool solo = TEAM > 1 && st0 + total > T16;
+						const int fstep = solo ? 64 : NT, ftid = solo ? lane : tid;
+						if (!solo || twave == 0)
+						for (int i0 = 0; i0 < total; i0 += fstep) {
+							const int i = i0 + ftid, idx = st0 + i;
 							int sc = 0;
 							if (i < total) {
 								const int a = idx < T16 ? TG[idx & RM] : QR[idx - T16], b = QR[qoff + idx];
@@ -367,16 +389,17 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							}
 						}
 					} else {
-						for (int t = st0 + lane; t <= en0; t += 64)
+						for (int t = st0 + tid; t <= en0; t += NT)
 							((uint8_t *)&B[t & RM])[2] = (uint8_t)L.sc.mat[TG[t & RM] * m + QR[qoff + t]];
 					}
 				}
 				STATE_SYNC();
-				// one sweep over [st,en], highest chunk first so that lane t still sees row r-1 at t-1
+				// one sweep over [st,en], highest chunks first so that lane t still sees row r-1 at t-1: TEAM chunks per round, one per wave
 				uint8_t *pr = dir + (size_t)r * ncol;
 				const int n_chunk = (en - st + 64) >> 6;
-				for (int c = n_chunk - 1; c >= 0; --c) {
-					const int t = st + (c << 6) + lane;
+				for (int c_hi = n_chunk - 1; c_hi >= 0; c_hi -= TEAM) {
+					const int c = c_hi - twave;
+					const int t = c >= 0 ? st + (c << 6) + lane : en + 1;
 					const int tk = t & RM;
 					uint32_t a_cur = 0, b_cur = 0;
 					int xt1 = x1, vt1 = v1, x2t1 = x21;
@@ -387,7 +410,8 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
 						}
 					}
-					MM2_LOCKSTEP(); // every lane of the chunk has read row r-1 (its own position and its left neighbour's) before any lane stores row r
+					if (TEAM > 1) __syncthreads(); // every lane of the round has read row r-1 (its own position and its left neighbour's) before any lane stores row r
+					else MM2_LOCKSTEP();
 					if (t <= en) {
 						if (SINGLE) { // ksw2_extz2_sse.c:34-55 with the left/right variants at :186-204 / :213-231 (and :164-170 score-only)
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24);
@@ -493,7 +517,7 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 						// candidate order: en0 first, then the 4-lane strided scan of [st0,en1), then the tail [en1,en0)
 						long long best = (long long)Hen << 32 | 0x7fffffffLL;
 						const int nq = (en1 - st0) >> 2;
-						for (int t = st0 + lane; t < en0; t += 64) {
+						for (int t = st0 + tid; t < en0; t += NT) {
 							const int h = H[t & RM] + dv(A[t & RM]);
 							H[t & RM] = h;
 							const int k = t - st0;
@@ -502,6 +526,13 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							best = key > best ? key : best;
 						}
 						best = wave_max_i64(best);
+						if (TEAM > 1) { // the waves' maxima meet in LDS (keys are unique by rank, so the order of the combination does not matter)
+							if (lane == 0) s_best[twave] = best;
+							__syncthreads();
+							best = s_best[0];
+#pragma unroll
+							for (int k = 1; k < TEAM; ++k) best = s_best[k] > best ? s_best[k] : best;
+						}
 						max_H = (int)(best >> 32);
 						{
 							const int rank = 0x7fffffff - (int)(best & 0x7fffffffLL);
@@ -509,11 +540,11 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 							else if (rank < 1 + 4 * (nq + 1)) { const int k = rank - 1; max_t = st0 + (k % (nq + 1)) * 4 + k / (nq + 1); }
 							else max_t = en1 + (rank - 1 - 4 * (nq + 1));
 						}
-						if (lane == 0) H[en0 & RM] = Hen;
+						if (tid == 0) H[en0 & RM] = Hen;
 						STATE_SYNC();
 					} else {
 						max_H = dv(A[0]) - h00, max_t = 0;
-						if (lane == 0) H[0] = max_H;
+						if (tid == 0) H[0] = max_H;
 						STATE_SYNC();
 					}
 					const int Hen0 = H[en0 & RM], Hst0 = H[st0 & RM];
@@ -532,33 +563,37 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 					// the single-affine code tests the drop only from the second anti-diagonal on (ksw2_extz2_sse.c:291 sits inside r > 0)
 					if ((flag & KSW_APPROX_DROP) && (!SINGLE || r > 0) && zdrop_test(ez, H0, r, last_H0_t, J.zdrop, zd_e)) break;
 					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+					if (TEAM > 1) __syncthreads(); // (the next row's border write to A[r + 1] must not overtake a slower wave's reads above)
 				}
 				last_st = st, last_en = en;
 			}
 			// ---- traceback (:385-399) ----
 			if (with_cigar) {
-				__threadfence_block(); // the direction bytes were written by all lanes of this wave
+				__threadfence_block(); // the direction bytes were written by all lanes of this wave (team: of this workgroup)
+				if (TEAM > 1) __syncthreads();
 				if (!ez.zdropped && (flag & KSW_EXTZ_ONLY) && ez.mqe + J.end_bonus > ez.max) ez.reach_end = 1;
 				const int min_intron = SPLICE ? long_thres : 0;
-				if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, min_intron, g, lane);
-				else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, min_intron, g, lane);
-				else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, min_intron, g, lane);
-				if (lane == 0 && g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
-				// pack the CIGAR into the pool: forward order unless the caller asked for the traceback order (:153-155 of ksw2.h)
-				const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
-				cig_off = __builtin_amdgcn_readfirstlane(cig_off);
-				__threadfence_block();
-				if (n_cig > 0) {
-					if ((unsigned long long)cig_off + (unsigned)n_cig > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
-					else {
-						const bool keep_order = flag & KSW_REV_CIGAR;
-						for (int k = lane; k < n_cig; k += 64) L.cigar_pool[cig_off + k] = g.c[keep_order ? k : n_cig - 1 - k];
+				if (twave == 0) { // the team's first wave walks back and packs; the others wait at the barrier below
+					if (!ez.zdropped && !(flag & KSW_EXTZ_ONLY)) traceback(dir, ncol, qlen, tlen, w, tlen - 1, qlen - 1, min_intron, g, lane);
+					else if (ez.reach_end) traceback(dir, ncol, qlen, tlen, w, ez.mqe_t, qlen - 1, min_intron, g, lane);
+					else if (ez.max_t >= 0 && ez.max_q >= 0) traceback(dir, ncol, qlen, tlen, w, ez.max_t, ez.max_q, min_intron, g, lane);
+					if (lane == 0 && g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n);
+					// pack the CIGAR into the pool: forward order unless the caller asked for the traceback order (:153-155 of ksw2.h)
+					const int n_cig = __builtin_amdgcn_readfirstlane(g.n);
+					cig_off = __builtin_amdgcn_readfirstlane(cig_off);
+					__threadfence_block();
+					if (n_cig > 0) {
+						if ((unsigned long long)cig_off + (unsigned)n_cig > L.cigar_pool_cap) { if (lane == 0) L.cigar_cursor[1] = 1; }
+						else {
+							const bool keep_order = flag & KSW_REV_CIGAR;
+							for (int k = lane; k < n_cig; k += 64) L.cigar_pool[cig_off + k] = g.c[keep_order ? k : n_cig - 1 - k];
+						}
 					}
 				}
 			}
 			STATE_SYNC();
 		}
-		if (lane == 0) {
+		if (tid == 0) {
 			KswRes R;
 			R.max = ez.max, R.zdropped = ez.zdropped, R.max_q = ez.max_q, R.max_t = ez.max_t;
 			R.mqe = ez.mqe, R.mqe_t = ez.mqe_t, R.mte = ez.mte, R.mte_q = ez.mte_q;
@@ -572,31 +607,37 @@ __global__ void __launch_bounds__(256) ksw_extd2_kernel(KswLaunch L)
 #undef STATE_SYNC
 
 namespace {
-template <bool LDS_STATE, int MODE>
+template <bool LDS_STATE, int MODE, int TEAM>
 void launch_mode(const KswLaunch &L, int n_blocks, int waves_per_block, size_t lds, hipStream_t stream)
 {
-	if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<LDS_STATE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL((ksw_extd2_kernel<LDS_STATE, MODE>), dim3(n_blocks), dim3(64 * waves_per_block), lds, stream, L);
+	if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)ksw_extd2_kernel<LDS_STATE, MODE, TEAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((ksw_extd2_kernel<LDS_STATE, MODE, TEAM>), dim3(n_blocks), dim3(64 * (TEAM > 1 ? TEAM : waves_per_block)), lds, stream, L);
 	HIP_CHECK(hipGetLastError());
 }
-template <bool LDS_STATE>
+template <bool LDS_STATE, int TEAM>
 void launch_any(const KswLaunch &L, int n_blocks, int waves_per_block, size_t lds, hipStream_t stream)
 {
-	if (L.splice) launch_mode<LDS_STATE, 2>(L, n_blocks, waves_per_block, lds, stream);
-	else if (L.single_affine) launch_mode<LDS_STATE, 1>(L, n_blocks, waves_per_block, lds, stream);
-	else launch_mode<LDS_STATE, 0>(L, n_blocks, waves_per_block, lds, stream);
+	if (L.splice) launch_mode<LDS_STATE, 2, TEAM>(L, n_blocks, waves_per_block, lds, stream);
+	else if (L.single_affine) launch_mode<LDS_STATE, 1, TEAM>(L, n_blocks, waves_per_block, lds, stream);
+	else launch_mode<LDS_STATE, 0, TEAM>(L, n_blocks, waves_per_block, lds, stream);
 }
 }
 
-void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, void *stream)
+// team: wavefronts per job (1: n_slots waves, waves_per_block of them in a block, each with a job of its own; 4 / 8: n_slots workgroups of one job each)
+void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, int team, void *stream)
 {
 	if (L.n_jobs <= 0) return;
 	const size_t region = (ksw_lds_per_wave(L.ring, L.max_Q16) + 15) / 16 * 16;
-	const size_t lds = region * waves_per_block;
-	const int n_blocks = (n_slots + waves_per_block - 1) / waves_per_block;
-	if (L.state_pool) { launch_any<false>(L, n_blocks, waves_per_block, 0, (hipStream_t)stream); return; } // state in HBM: any job length
+	if (L.state_pool) { // state in HBM: any job length, a wave per job
+		launch_any<false, 1>(L, (n_slots + waves_per_block - 1) / waves_per_block, waves_per_block, 0, (hipStream_t)stream);
+		return;
+	}
+	const size_t lds = team > 1 ? region : region * waves_per_block;
+	const int n_blocks = team > 1 ? n_slots : (n_slots + waves_per_block - 1) / waves_per_block;
 	if (lds > 160 * 1024) throw std::runtime_error("[mm2amd] ksw_extd2: job class does not fit LDS");
-	launch_any<true>(L, n_blocks, waves_per_block, lds, (hipStream_t)stream);
+	if (team == 8) launch_any<true, 8>(L, n_blocks, 1, lds, (hipStream_t)stream);
+	else if (team == 4) launch_any<true, 4>(L, n_blocks, 1, lds, (hipStream_t)stream);
+	else launch_any<true, 1>(L, n_blocks, waves_per_block, lds, (hipStream_t)stream);
 }
 
 } // namespace mm2amd

@@ -15,10 +15,10 @@ namespace {
 // Launch classes.  0..5: the register-resident gap-fill kernel (ksw_gapfill.hip), classed by query capacity (512 / 1024 bytes of
 // LDS per job: eight / four waves per SIMD) and by target length (one strip of 256 columns, up to 2-4 strips, more), so that the
 // two jobs of a wave have the same strip count and a class's direction-matrix slots are not sized by its rare giants.
-// 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 512..8192 positions in
+// 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 256..8192 positions in
 // LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
 // direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
-constexpr int kFirstExact = 6, kRingClasses = 6, kDirClasses = 11, kFirstSplice = kFirstExact + kRingClasses * kDirClasses;
+constexpr int kFirstExact = 6, kRingClasses = 7, kDirClasses = 11, kFirstSplice = kFirstExact + kRingClasses * kDirClasses;
 // kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip): two jobs per wave with 2 or 4 register sets of
 // 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves of 4 sets (512 positions per
 // sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
@@ -38,8 +38,12 @@ const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 4 };
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 const int kFastQCap[kFirstExact] = { 512, 512, 512, 1024, 1024, 1024 };
 const int kFastMaxT[kFirstExact] = { 256, 512, 1536, 256, 1024, 3072 };   // <= 3 * query capacity: the kernel's LDS holds the target bytes for the Z-drop scan
-const int kRingSize[kRingClasses] = { 512, 1024, 2048, 4096, 8192, 0 };
-const int kRingWaves[kRingClasses] = { 4, 4, 1, 1, 1, 4 }; // waves per block
+const int kRingSize[kRingClasses] = { 256, 512, 1024, 2048, 4096, 8192, 0 };
+const int kRingWaves[kRingClasses] = { 4, 4, 4, 1, 1, 1, 4 }; // waves per block where a wave has a job of its own
+// wavefronts per job (round 4): anti-diagonals of up to 192 cells stay with one wave; wider ones are swept by a workgroup of 4 or 8 waves, one job
+// per workgroup (a band-751 anti-diagonal is twelve 64-lane chunks: one wave needed three passes of twelve chunks per row, and the ~3 k such
+// extensions of a step held their launches for as long as the longest one took)
+const int kRingTeam[kRingClasses] = { 1, 4, 8, 8, 8, 8, 1 };
 inline size_t dir_limit(int dc) { return dc == kDirClasses - 1 ? SIZE_MAX : (size_t)256 << (10 + dc); } // 256 KB, 512 KB, ... 128 MB, any
 constexpr int kFastMaxQ = 1024, kFastMaxTAny = 3072;
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: <= 96 VGPRs -> 5 waves/SIMD
@@ -232,7 +236,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		// back on the caller's stream, the lane-exact kernel's classes back to back on a side stream of higher priority (a few long
 		// banded extensions per read: launches with a long tail and few busy CUs, which would otherwise sit between the gap-fill
 		// kernel and the copy-back of every sub-batch).  One scratch allocation per group serves all of its launches.
-		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4; bool hbm = false; double alg_bytes = 0, cells = 0; };
+		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4, team = 1; bool hbm = false; double alg_bytes = 0, cells = 0; };
 		Plan plan[kNTiers];
 		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
 		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || tier >= kFirstExt + 2 ? 1 : 0; };
@@ -265,6 +269,9 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			const size_t region = (ksw_lds_per_wave(P.ring, P.max_Q16) + 15) / 16 * 16;
 			if (!fast && !P.hbm && region > 160 * 1024) P.hbm = true; // a very long query next to a wide window: state goes to HBM
 			if (P.hbm) P.wpb = 4;
+			static const bool no_team = getenv("MM2AMD_KSW_NO_TEAM") != nullptr; // A/B checks: every lane-exact job on one wave
+			P.team = fast || P.hbm || no_team ? 1 : kRingTeam[rc];
+			if (P.team > 1) P.wpb = 1; // the workgroup IS the slot
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
 			if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (eight register sets: 174 VGPRs)
@@ -272,7 +279,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			else if (n_stream) blocks_per_cu = ksw_stream_waves(n_stream);
 			else if (fast) blocks_per_cu = fast_waves(tier);
 			else if (P.hbm) blocks_per_cu = 4;
-			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / P.wpb);
+			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / (P.wpb * P.team));
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
 			const int wpb = P.wpb;
 			const size_t per_slot = fast && !(sfast && kSpliceSelf[sclass]) ? 2 : 1; // the paired gap-fill kernels run two jobs per wave
@@ -310,7 +317,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		}
 		static const char *kFastNames[kFirstExact] = { "ksw_gapfill_kernel<512>[t256]", "ksw_gapfill_kernel<512>[t512]", "ksw_gapfill_kernel<512>[t1536]",
 		                                               "ksw_gapfill_kernel<1024>[t256]", "ksw_gapfill_kernel<1024>[t1024]", "ksw_gapfill_kernel<1024>[t3072]" };
-		static const char *kRingNames[kRingClasses] = { "ksw_extd2_kernel[r512]", "ksw_extd2_kernel[r1k]", "ksw_extd2_kernel[r2k]", "ksw_extd2_kernel[r4k]", "ksw_extd2_kernel[r8k]", "ksw_extd2_kernel[hbm]" };
+		static const char *kRingNames[kRingClasses] = { "ksw_extd2_kernel[r256]", "ksw_extd2_kernel[r512]", "ksw_extd2_kernel[r1k]", "ksw_extd2_kernel[r2k]", "ksw_extd2_kernel[r4k]", "ksw_extd2_kernel[r8k]", "ksw_extd2_kernel[hbm]" };
 		for (int pass = 0; pass < 2; ++pass) // the side-stream group first: its long jobs should start as early as possible
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
@@ -333,7 +340,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			else if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
 			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, ((tier - kFirstExt) & 1) != 0, 4 * ((tier - kFirstExt) / 2 + 1), stream_);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
-			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, stream_);
+			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, P.team, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			static const char *kStreamNames[2] = { "ksw_stream_kernel<4>[t256]", "ksw_stream_kernel<8>[t512]" };
 			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstExt ? kExtNames[tier - kFirstExt] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);

@@ -172,7 +172,7 @@ __host__ __device__ inline SketchLds sketch_lds_layout(int w, int tile_cap)
 }
 constexpr int SK_WARM_LDS = 128, SK_TAIL_LDS = 128; // bases resident before / after a tile (warm-up; the automaton's run past the stretch's end)
 
-template <bool K32>
+template <bool K32, int W>
 __global__ void __launch_bounds__(64) sketch_wave_kernel(SeedChainBuffers B, int w, int k, int tile_cap)
 {
 	MM2_DYN_LDS(uint64_t, lds);
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(64) sketch_wave_kernel(SeedChainBuffers B, int
 				}
 				return (int)seq[i]; // a restart that reaches far back, or a stretch of symmetric k-mers past the tail: rare
 			};
-			sketch_chunk_core<false, K32, uint32_t>(base_at, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t y) {
+			sketch_chunk_core<false, K32, uint32_t, W>(base_at, len, cs, ce, w, k, 0u, bx, by, 64, [&](uint64_t, uint64_t y) {
 				const uint32_t rel = (uint32_t)((int64_t)((uint32_t)y >> 1) - t0);
 				atomicOr(&marks[rel >> 5], 1u << (rel & 31));
 			}, (int64_t)(w + k + 8));
@@ -269,8 +269,18 @@ void launch_sketch(const SeedChainBuffers &B, const SeedChainParams &P, int max_
 		static const int force_tile = getenv("MM2AMD_SKETCH_TILE") ? atoi(getenv("MM2AMD_SKETCH_TILE")) : 0; // tests: several tiles per read
 		if (force_tile >= 64) tile_cap = force_tile & ~63;
 		const SketchLds L = sketch_lds_layout(P.w, tile_cap);
-		if (2 * P.k <= 32) hipLaunchKernelGGL((sketch_wave_kernel<true>), dim3(B.n_reads), dim3(64), (size_t)L.per_wave, s, B, P.w, P.k, tile_cap);
-		else hipLaunchKernelGGL((sketch_wave_kernel<false>), dim3(B.n_reads), dim3(64), (size_t)L.per_wave, s, B, P.w, P.k, tile_cap);
+		// the presets' window sizes are compiled in (the ring scans unroll: sketch_dev.hpp), any other w runs the generic instantiation
+#define MM2_SKETCH_LAUNCH(K32_, W_) hipLaunchKernelGGL((sketch_wave_kernel<K32_, W_>), dim3(B.n_reads), dim3(64), (size_t)L.per_wave, s, B, P.w, P.k, tile_cap)
+		static const bool generic_only = getenv("MM2AMD_SKETCH_GENERIC") != nullptr; // tests: the runtime-w instantiation on the presets too
+		const bool k32 = 2 * P.k <= 32;
+		if (generic_only) { if (k32) MM2_SKETCH_LAUNCH(true, 0); else MM2_SKETCH_LAUNCH(false, 0); }
+		else if (k32 && P.w == 10) MM2_SKETCH_LAUNCH(true, 10);      // map-ont, map-pb, ava-*
+		else if (k32 && P.w == 5) MM2_SKETCH_LAUNCH(true, 5);        // splice
+		else if (!k32 && P.w == 19) MM2_SKETCH_LAUNCH(false, 19);    // map-hifi, lr:hq, asm*
+		else if (!k32 && P.w == 10) MM2_SKETCH_LAUNCH(false, 10);    // asm20
+		else if (k32) MM2_SKETCH_LAUNCH(true, 0);
+		else MM2_SKETCH_LAUNCH(false, 0);
+#undef MM2_SKETCH_LAUNCH
 	} else {
 		const dim3 grid((B.n_reads + 63) / 64), block(64);
 		if (P.w <= 32) hipLaunchKernelGGL((sketch_kernel<32>), grid, block, 0, s, B, P.w, P.k, P.is_hpc);

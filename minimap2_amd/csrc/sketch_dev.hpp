@@ -44,7 +44,10 @@ template <> struct SketchKmerType<true> { typedef uint32_t type; };
 //   K32         2k <= 32: k-mer registers and hash in 32-bit arithmetic
 //   warm0       bases of warm-up before cs on the first attempt (at least w + k; more = fewer restarts where symmetric k-mers or Ns
 //               delay the synchronised state)
-template <bool HPC, bool K32, typename YT, typename BaseAt, typename Emit>
+//   W           the window size when it is known at compile time (0: use w): the ring scans then unroll into W loads issued together and a
+//               compare chain over registers -- with a runtime trip count every slot costs a dependent LDS round trip, and since some lane of
+//               a wavefront loses its minimum at almost every base, the whole wave pays for that scan at almost every base
+template <bool HPC, bool K32, typename YT, int W = 0, typename BaseAt, typename Emit>
 __device__ __forceinline__ void sketch_chunk_core(BaseAt base_at, int64_t len, int64_t cs, int64_t ce, int w, int k, uint32_t rid,
                                                   uint64_t *bx, YT *by, int stride, Emit emit, int64_t warm0)
 {
@@ -113,7 +116,16 @@ __device__ __forceinline__ void sketch_chunk_core(BaseAt base_at, int64_t len, i
 				if (l >= w + k) synced = true; // state now depends only on the last w+k slots
 			} else l = 0, tq_front = tq_count = 0, hpc_span = 0;
 			bx[buf_pos * stride] = ix, by[buf_pos * stride] = (YT)iy;
-			if (l == w + k - 1 && min_x != UINT64_MAX) { // first full window (:117-122)
+			if (W > 0 && l == w + k - 1 && min_x != UINT64_MAX) { // first full window (:117-122), oldest slot first; the newest (buf_pos) is not looked at
+#pragma unroll
+				for (int a = 0; a < (W > 0 ? W - 1 : 0); ++a) {
+					int j = buf_pos + 1 + a;
+					if (j >= W) j -= W;
+					const uint64_t xj = bx[j * stride];
+					const YT yj = by[j * stride];
+					if (min_x == xj && yj != (YT)min_y) MM2_EMIT(xj, (uint64_t)yj);
+				}
+			} else if (W == 0 && l == w + k - 1 && min_x != UINT64_MAX) {
 				for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j * stride] && by[j * stride] != (YT)min_y) MM2_EMIT(bx[j * stride], (uint64_t)by[j * stride]);
 				for (int j = 0; j < buf_pos; ++j)     if (min_x == bx[j * stride] && by[j * stride] != (YT)min_y) MM2_EMIT(bx[j * stride], (uint64_t)by[j * stride]);
 			}
@@ -123,14 +135,37 @@ __device__ __forceinline__ void sketch_chunk_core(BaseAt base_at, int64_t len, i
 			} else if (buf_pos == min_pos) {
 				if (l >= w + k - 1 && min_x != UINT64_MAX) MM2_EMIT(min_x, min_y);
 				min_x = UINT64_MAX;
+				if (W > 0) { // the ring in age order (oldest first, the slot just written last) into registers, then the same two scans
+					uint64_t xs[W > 0 ? W : 1];
+					YT ys[W > 0 ? W : 1];
+#pragma unroll
+					for (int a = 0; a < W; ++a) {
+						int j = buf_pos + 1 + a;
+						if (j >= W) j -= W;
+						xs[a] = bx[j * stride], ys[a] = by[j * stride];
+					}
+					int min_a = 0, n_eq = 0;
+#pragma unroll
+					for (int a = 0; a < W; ++a) {
+						n_eq = min_x == xs[a] ? n_eq + 1 : min_x > xs[a] ? 1 : n_eq;
+						if (min_x >= xs[a]) min_x = xs[a], min_y = (uint64_t)ys[a], min_a = a;
+					}
+					min_pos = buf_pos + 1 + min_a;
+					if (min_pos >= W) min_pos -= W;
+					if (n_eq > 1 && l >= w + k - 1 && min_x != UINT64_MAX) { // other slots with the minimum's hash (rare)
+#pragma unroll
+						for (int a = 0; a < W; ++a) if (min_x == xs[a] && (YT)min_y != ys[a]) MM2_EMIT(xs[a], (uint64_t)ys[a]);
+					}
+				} else {
 				for (int j = buf_pos + 1; j < w; ++j) if (min_x >= bx[j * stride]) min_x = bx[j * stride], min_y = (uint64_t)by[j * stride], min_pos = j;
 				for (int j = 0; j <= buf_pos; ++j)    if (min_x >= bx[j * stride]) min_x = bx[j * stride], min_y = (uint64_t)by[j * stride], min_pos = j;
 				if (l >= w + k - 1 && min_x != UINT64_MAX) {
 					for (int j = buf_pos + 1; j < w; ++j) if (min_x == bx[j * stride] && (YT)min_y != by[j * stride]) MM2_EMIT(bx[j * stride], (uint64_t)by[j * stride]);
 					for (int j = 0; j <= buf_pos; ++j)    if (min_x == bx[j * stride] && (YT)min_y != by[j * stride]) MM2_EMIT(bx[j * stride], (uint64_t)by[j * stride]);
 				}
+				}
 			}
-			if (++buf_pos == w) buf_pos = 0;
+			if (++buf_pos == (W > 0 ? W : w)) buf_pos = 0;
 		}
 		if (restart) { warm = warm * 4 + 1024; continue; }
 		if (min_x != UINT64_MAX) MM2_EMIT(min_x, min_y); // end of the sequence, or an early exit with nothing owned pending

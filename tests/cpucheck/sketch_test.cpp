@@ -71,7 +71,7 @@ static long check(const std::string &s, int w, int k, int64_t chunk, uint32_t ri
 // sketch_wave_kernel's configuration of the same automaton: bases from the 2-bit packed copy (sk_pack16 / sk_base_at), y halves in the ring,
 // warm-up of w + k + 8, 32-bit k-mer registers when 2k <= 32 -- and every reported record rebuilt from the packed bases alone
 // (sk_minimizer_at), as the kernel's emit phase does from its position marks.
-template <bool K32>
+template <bool K32, int W = 0>
 static long check_packed(const std::string &s, int w, int k, int64_t chunk)
 {
 	const int len = (int)s.size();
@@ -95,7 +95,7 @@ static long check_packed(const std::string &s, int w, int k, int64_t chunk)
 	auto base_at = [&](int64_t i) -> int { return sk_base_at(pk, amb.data(), i); };
 	for (int64_t cs = 0; cs < len; cs += chunk) {
 		const int64_t ce = cs + chunk < len ? cs + chunk : len;
-		sketch_chunk_core<false, K32, uint32_t>(base_at, len, cs, ce, w, k, 0u, bx.data(), by.data(), 1, [&](uint64_t x, uint64_t y) { gx.push_back(x), gy.push_back(y); }, (int64_t)(w + k + 8));
+		sketch_chunk_core<false, K32, uint32_t, W>(base_at, len, cs, ce, w, k, 0u, bx.data(), by.data(), 1, [&](uint64_t x, uint64_t y) { gx.push_back(x), gy.push_back(y); }, (int64_t)(w + k + 8));
 	}
 	if ((int64_t)gx.size() != n_want) { fprintf(stderr, "packed: w=%d k=%d len=%d chunk=%ld: %zu minimizers, reference %ld\n", w, k, len, (long)chunk, gx.size(), (long)n_want); exit(1); }
 	for (int64_t i = 0; i < n_want; ++i) {
@@ -129,6 +129,12 @@ int main(int argc, char **argv)
 		const int64_t chunk2 = c & 1 ? chunk : 32 + (int64_t)(rng() % 200);
 		total += 2 * k2 <= 32 ? check_packed<true>(s, w2, k2, chunk2) : check_packed<false>(s, w2, k2, chunk2);
 		if (2 * k2 <= 32) total += check_packed<false>(s, w2, k2, chunk2); // the wide registers on a narrow k
+		// the instantiations with the window size compiled in (unrolled ring scans)
+		if (w2 == 10 && k2 == 15) total += check_packed<true, 10>(s, 10, 15, chunk2);
+		if (w2 == 10 && k2 == 16) total += check_packed<true, 10>(s, 10, 16, chunk2);
+		if (w2 == 19) total += check_packed<false, 19>(s, 19, k2, chunk2);
+		if (w2 == 5) total += check_packed<true, 5>(s, 5, k2, chunk2);
+		if (c % 8 == 7) total += check_packed<false, 10>(s, 10, 20, chunk2);
 	}
 	printf("OK %d %ld\n", n_case, total);
 	return 0;
