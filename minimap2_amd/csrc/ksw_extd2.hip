@@ -155,8 +155,9 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 	constexpr int NT = 64 * TEAM; // lanes working on one job
 	MM2_DYN_LDS(uint8_t, lds_raw);
 	__shared__ long long s_best[TEAM > 1 ? TEAM : 1];
-	__shared__ int s_team[4]; // job id; then CIGAR length and offset from the wave that traced back
+	__shared__ int s_team_all[TEAM > 1 ? 4 : 16]; // per job in flight (TEAM == 1: one per wave of the block): [0] the job id, [1] H(en0), [2] H(st0) of the row just swept
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+	int *const s_team = s_team_all + (TEAM > 1 ? 0 : 4 * wave_in_block);
 	const int tid = TEAM > 1 ? (int)threadIdx.x : lane, twave = TEAM > 1 ? wave_in_block : 0; // within the team
 	const int slot = TEAM > 1 ? (int)blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
 	const size_t region = (ksw_lds_per_wave(L.ring, L.max_Q16) + 15) / 16 * 16;
@@ -358,25 +359,27 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 					uint32_t a = A[(st - 1) & RM], b = B[(st - 1) & RM];
 					x1 = sx8(a >> 16), v1 = sx8(a >> 8), x21 = sx8(b);
 				}
-				if (en >= r && tid == 0) {
-					A[r & RM] = (A[r & RM] & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24; // u[r], y[r]
-					if (!SPLICE) ((uint8_t *)&B[r & RM])[1] = (uint8_t)init2;                                  // y2[r] (a byte store: the team's other waves are writing s[], byte 2, meanwhile)
-				}
-				// substitution scores in 16-byte chunks from st0 (:165-184); overshoot lands in later s[] lanes, and past
-				// T16 the reference reads the start of qr[] as target bytes and writes into the first bytes of the target
-				// copy (its arrays are contiguous: s | sf | qr).  Such a write only matters while position idx-T16 can
-				// still be read, which is exactly while it still owns its slot.
-				{
-					const int qoff = qlen - 1 - r;
-					if (!(flag & KSW_GENERIC_SC)) {
-						const int total = ((en0 - st0) / 16 + 1) * 16;
-						// (a row whose chunks run past T16 writes into the target copy that lower chunks read: the team leaves such a row -- the last
-						// few of a job -- to its first wave, which keeps the one-wave order: chunks ascending, a step's loads before its stores)
-						const bool solo = TEAM > 1 && st0 + total > T16;
-						const int fstep = solo ? 64 : NT, ftid = solo ? lane : tid;
-						if (!solo || twave == 0)
-						for (int i0 = 0; i0 < total; i0 += fstep) {
-							const int i = i0 + ftid, idx = st0 + i;
+				// score differences as they read back from a state dword: signed bytes (dual-affine) or unsigned bytes minus (q+e) (single, :236-262)
+				auto du = [&](uint32_t w) { return SINGLE ? (int)(w & 0xff) - qe : sx8((int)w); };
+				auto dv = [&](uint32_t w) { return SINGLE ? (int)(w >> 8 & 0xff) - qe : sx8((int)(w >> 8)); };
+				const int zd_e = SINGLE ? e : SPLICE ? 0 : e2, h00 = SINGLE ? qe : qe_in;
+				// Substitution scores (:165-184): the reference fills s[] in 16-byte chunks from st0 BEFORE the sweep -- total bytes, up to 15 past
+				// en0; positions of [st, en] outside that stretch keep what an earlier row left there (they are lanes of the block-aligned
+				// interval that hold no valid cell, but valid cells of later rows read what they compute).  Round 4: a lane of the sweep computes the score
+				// of its own position when it lies in the row's stretch and carries it in the state dword it is about to store (no separate pass, no
+				// barrier in between); positions of the stretch beyond en get theirs from the wave that sweeps the top chunk.  Past T16 the reference
+				// reads the start of qr[] as target bytes and writes into the first bytes of the target copy (its arrays are contiguous: s | sf | qr;
+				// such a write only matters while position idx-T16 still owns its slot): those rows -- a job's last few -- keep the separate pass, made
+				// by the team's first wave in the one-wave order (chunks ascending, a step's loads before its stores).
+				const int qoff = qlen - 1 - r;
+				const bool generic_sc = (flag & KSW_GENERIC_SC) != 0;
+				const int total = ((en0 - st0) / 16 + 1) * 16;
+				const bool sep_fill = !generic_sc && st0 + total > T16;
+				const int f1 = generic_sc ? en0 + 1 : st0 + total; // scores of [st0, f1) are fresh this row
+				if (sep_fill) {
+					if (twave == 0)
+						for (int i0 = 0; i0 < total; i0 += 64) {
+							const int i = i0 + lane, idx = st0 + i;
 							int sc = 0;
 							if (i < total) {
 								const int a = idx < T16 ? TG[idx & RM] : QR[idx - T16], b = QR[qoff + idx];
@@ -388,31 +391,43 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 								else if (frontier < idx - T16 + RS) TG[(idx - T16) & RM] = (uint8_t)sc;
 							}
 						}
-					} else {
-						for (int t = st0 + tid; t <= en0; t += NT)
-							((uint8_t *)&B[t & RM])[2] = (uint8_t)L.sc.mat[TG[t & RM] * m + QR[qoff + t]];
-					}
+					STATE_SYNC();
 				}
-				STATE_SYNC();
-				// one sweep over [st,en], highest chunks first so that lane t still sees row r-1 at t-1: TEAM chunks per round, one per wave
+				auto fresh_score = [&](int t) -> int {
+					const int a = TG[t & RM], b = QR[qoff + t];
+					return generic_sc ? (int)L.sc.mat[a * m + b] : (a == m - 1 || b == m - 1) ? sc_N : a == b ? sc_mch : sc_mis;
+				};
+				// one sweep over [st,en], highest chunks first so that lane t still sees row r-1 at t-1: TEAM chunks per round, one per wave.  The exact
+				// row maximum (:325-365) rides along: H(t) += v(t) for st0 <= t < en0 as the lane stores v, H(en0) from its left neighbour's old H and u,
+				// every lane keeps its best (score, rank in the reference's scan order) key.
 				uint8_t *pr = dir + (size_t)r * ncol;
 				const int n_chunk = (en - st + 64) >> 6;
+				const bool exact_max = !approx_max;
+				const int en1 = st0 + (en0 - st0) / 4 * 4, nq = (en1 - st0) >> 2; // the reference's 4-lane strided scan of [st0,en1), then the tail [en1,en0); en0 itself first
+				long long best = INT64_MIN; // below every key
 				for (int c_hi = n_chunk - 1; c_hi >= 0; c_hi -= TEAM) {
 					const int c = c_hi - twave;
 					const int t = c >= 0 ? st + (c << 6) + lane : en + 1;
 					const int tk = t & RM;
 					uint32_t a_cur = 0, b_cur = 0;
-					int xt1 = x1, vt1 = v1, x2t1 = x21;
+					int xt1 = x1, vt1 = v1, x2t1 = x21, h_cur = 0, h_left = 0;
 					if (t <= en) {
 						a_cur = A[tk], b_cur = B[tk];
+						if (t == r) { // the row's border column (:148-163): u[r], y[r] (and y2[r]) take their border values
+							a_cur = (a_cur & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24;
+							if (!SPLICE) b_cur = (b_cur & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;
+						}
 						if (t > st) {
 							const uint32_t a_prev = A[(t - 1) & RM], b_prev = B[(t - 1) & RM];
 							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
 						}
+						if (!sep_fill && t >= st0 && t < f1) b_cur = (b_cur & 0xff00ffffu) | (uint32_t)(fresh_score(t) & 0xff) << 16;
+						if (exact_max) { h_cur = H[tk]; if (t == en0 && en0 > 0) h_left = H[(t - 1) & RM]; }
 					}
 					if (TEAM > 1) __syncthreads(); // every lane of the round has read row r-1 (its own position and its left neighbour's) before any lane stores row r
 					else MM2_LOCKSTEP();
 					if (t <= en) {
+						uint32_t a_new = 0;
 						if (SINGLE) { // ksw2_extz2_sse.c:34-55 with the left/right variants at :186-204 / :213-231 (and :164-170 score-only)
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24);
 							int z = sx8(sx8(b_cur >> 16) + qe2s);
@@ -433,7 +448,7 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 								xn = 0 > a ? 0 : a; d |= 0 > a ? 0 : 0x08;
 								yn = 0 > b ? 0 : b; d |= 0 > b ? 0 : 0x10;
 							}
-							A[tk] = pack4(un, vn, xn, yn);
+							a_new = pack4(un, vn, xn, yn); A[tk] = a_new;
 							if (with_cigar) pr[t - st] = (uint8_t)d;
 						} else if (SPLICE) { // ksw2_exts2_sse.c:37-64 with the variants at :283-285 (score only), :312-348 (left), :355-392 (right)
 							const int ut = sx8(a_cur), yt = sx8(a_cur >> 24), dn = sx8(b_cur >> 8), ac = sx8(b_cur >> 24);
@@ -463,7 +478,7 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 								yn = (b > 0 ? b : 0) - qe;      d |= b >= 0 ? 0x10 : 0;
 								x2n = (a2 > dn ? a2 : dn) - q2; d |= a2 >= dn ? 0x20 : 0;
 							}
-							A[tk] = pack4(un, vn, xn, yn);
+							a_new = pack4(un, vn, xn, yn); A[tk] = a_new;
 							B[tk] = (b_cur & 0xffffff00u) | (uint32_t)(x2n & 0xff);
 							if (with_cigar) pr[t - st] = (uint8_t)d;
 						} else {
@@ -497,61 +512,56 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 								x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 >= 0 ? 0x20 : 0;
 								y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 >= 0 ? 0x40 : 0;
 							}
-							A[tk] = pack4(un, vn, xn, yn);
+							a_new = pack4(un, vn, xn, yn); A[tk] = a_new;
 							B[tk] = (b_cur & 0xffff0000u) | (uint32_t)(x2n & 0xff) | (uint32_t)(y2n & 0xff) << 8;
 							if (with_cigar) pr[t - st] = (uint8_t)d;
 						}
-					}
-				}
-				STATE_SYNC();
-				// score differences read back from the state: signed bytes (dual-affine) or unsigned bytes minus (q+e) (single, :236-262)
-				auto du = [&](uint32_t w) { return SINGLE ? (int)(w & 0xff) - qe : sx8((int)w); };
-				auto dv = [&](uint32_t w) { return SINGLE ? (int)(w >> 8 & 0xff) - qe : sx8((int)(w >> 8)); };
-				const int zd_e = SINGLE ? e : SPLICE ? 0 : e2, h00 = SINGLE ? qe : qe_in;
-				if (!approx_max) { // exact row maximum in the reference's scan order (:325-365)
-					int max_H, max_t;
-					if (r > 0) {
-						const int Hen = en0 > 0 ? H[(en0 - 1) & RM] + du(A[en0 & RM]) : H[en0 & RM] + dv(A[en0 & RM]);
-						const int en1 = st0 + (en0 - st0) / 4 * 4;
-						STATE_SYNC();
-						// candidate order: en0 first, then the 4-lane strided scan of [st0,en1), then the tail [en1,en0)
-						long long best = (long long)Hen << 32 | 0x7fffffffLL;
-						const int nq = (en1 - st0) >> 2;
-						for (int t = st0 + tid; t < en0; t += NT) {
-							const int h = H[t & RM] + dv(A[t & RM]);
-							H[t & RM] = h;
-							const int k = t - st0;
-							const int rank = t < en1 ? 1 + (k & 3) * (nq + 1) + (k >> 2) : 1 + 4 * (nq + 1) + (t - en1);
+						if (SINGLE && !sep_fill && t >= st0 && t < f1) ((uint8_t *)&B[tk])[2] = (uint8_t)(b_cur >> 16); // (the single-affine cell stores no second state dword)
+						if (exact_max && t >= st0 && t <= en0) {
+							int h, rank;
+							if (t == en0) { // candidate 0 of the scan; for r == 0 the first cell's own score (:361-364)
+								h = r == 0 ? dv(a_new) - h00 : en0 > 0 ? h_left + du(a_new) : h_cur + dv(a_new);
+								rank = 0;
+								s_team[1] = h; // H(en0) for the end-of-target / end-of-query bookkeeping below
+								if (st0 == en0) s_team[2] = h;
+							} else {
+								h = h_cur + dv(a_new);
+								const int k = t - st0;
+								rank = t < en1 ? 1 + (k & 3) * (nq + 1) + (k >> 2) : 1 + 4 * (nq + 1) + (t - en1);
+								if (t == st0) s_team[2] = h;
+							}
+							H[tk] = h;
 							const long long key = (long long)h << 32 | (long long)(0x7fffffff - rank);
 							best = key > best ? key : best;
 						}
-						best = wave_max_i64(best);
-						if (TEAM > 1) { // the waves' maxima meet in LDS (keys are unique by rank, so the order of the combination does not matter)
-							if (lane == 0) s_best[twave] = best;
-							__syncthreads();
-							best = s_best[0];
-#pragma unroll
-							for (int k = 1; k < TEAM; ++k) best = s_best[k] > best ? s_best[k] : best;
-						}
-						max_H = (int)(best >> 32);
-						{
-							const int rank = 0x7fffffff - (int)(best & 0x7fffffffLL);
-							if (rank == 0) max_t = en0;
-							else if (rank < 1 + 4 * (nq + 1)) { const int k = rank - 1; max_t = st0 + (k % (nq + 1)) * 4 + k / (nq + 1); }
-							else max_t = en1 + (rank - 1 - 4 * (nq + 1));
-						}
-						if (tid == 0) H[en0 & RM] = Hen;
-						STATE_SYNC();
-					} else {
-						max_H = dv(A[0]) - h00, max_t = 0;
-						if (tid == 0) H[0] = max_H;
-						STATE_SYNC();
 					}
-					const int Hen0 = H[en0 & RM], Hst0 = H[st0 & RM];
+					if (!sep_fill && c == n_chunk - 1) // the stretch's scores beyond en: read by later rows only
+						for (int p2 = en + 1 + lane; p2 < f1; p2 += 64) ((uint8_t *)&B[p2 & RM])[2] = (uint8_t)fresh_score(p2);
+				}
+				if (exact_max) { // the lanes' keys -> the row's maximum and where the reference's scan finds it
+					best = wave_max_i64(best);
+					if (TEAM > 1 && lane == 0) s_best[twave] = best;
+				}
+				STATE_SYNC(); // row r is complete: state, H, the team's keys
+				if (exact_max) {
+					if (TEAM > 1) {
+						best = s_best[0];
+#pragma unroll
+						for (int k = 1; k < TEAM; ++k) best = s_best[k] > best ? s_best[k] : best;
+					}
+					const int max_H = (int)(best >> 32);
+					int max_t;
+					{
+						const int rank = 0x7fffffff - (int)(best & 0x7fffffffLL);
+						if (rank == 0) max_t = en0;
+						else if (rank < 1 + 4 * (nq + 1)) { const int k = rank - 1; max_t = st0 + (k % (nq + 1)) * 4 + k / (nq + 1); }
+						else max_t = en1 + (rank - 1 - 4 * (nq + 1));
+					}
+					const int Hen0 = s_team[1], Hst0 = s_team[2];
 					if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en0;
 					if (r - st0 == qlen - 1 && Hst0 > ez.mqe) ez.mqe = Hst0, ez.mqe_t = st0;
 					if (zdrop_test(ez, max_H, r, max_t, J.zdrop, zd_e)) break;
-					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[(tlen - 1) & RM];
+					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = Hen0;
 				} else { // follow one cell (:366-383)
 					if (r > 0) {
 						if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
@@ -563,7 +573,6 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 					// the single-affine code tests the drop only from the second anti-diagonal on (ksw2_extz2_sse.c:291 sits inside r > 0)
 					if ((flag & KSW_APPROX_DROP) && (!SINGLE || r > 0) && zdrop_test(ez, H0, r, last_H0_t, J.zdrop, zd_e)) break;
 					if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
-					if (TEAM > 1) __syncthreads(); // (the next row's border write to A[r + 1] must not overtake a slower wave's reads above)
 				}
 				last_st = st, last_en = en;
 			}

@@ -81,7 +81,8 @@ inline bool ext_eligible(const KswJob &j, bool scoring_ok)
 {
 	const int f = j.flag & 0x1fff;
 	if (!scoring_ok || (j.flag & KSWJ_SKIP) || (f != KSW_EXTZ_ONLY && f != (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR))) return false;
-	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.tlen > kExtMaxT) return false;
+	static const int max_t = getenv("MM2AMD_EXT_MAX_T") ? atoi(getenv("MM2AMD_EXT_MAX_T")) : kExtMaxT; // A/B: longer targets to the lane-exact kernel's workgroups
+	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.tlen > max_t) return false;
 	return band_cannot_bind(j);
 }
 inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
