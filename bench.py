@@ -320,9 +320,30 @@ def main():
         log("rank %d warmup (%d steps): %.3f s  stats=%s" % (rank, a.warmup, dt, {k: round(v, 3) for k, v in al.last_stats().items()}))
     mm.profile_enable(True)
     import resource
+
+    def thread_cpu():
+        """CPU seconds of every thread this process has or had... of every LIVE thread, by OS thread name (/proc/self/task/*/stat: utime + stime);
+        the library names its own threads (mm2pool: the host stages' workers, mm2side: hand-over packing / formatting workers, mm2lane: lane drivers,
+        mm2-stager / -mapper / -output: the pipeline's three steps), the HIP runtime's threads keep the interpreter's name."""
+        out, tck = {}, float(os.sysconf("SC_CLK_TCK"))
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    st_ = open("/proc/self/task/%s/stat" % tid).read()
+                except OSError:
+                    continue
+                nm, rest = st_[st_.index("(") + 1:st_.rindex(")")], st_[st_.rindex(")") + 2:].split()
+                out[nm] = out.get(nm, 0.0) + (int(rest[11]) + int(rest[12])) / tck
+        except OSError:
+            pass
+        return out
+    tc0 = thread_cpu()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     total_t = run_steps(range(a.warmup, a.warmup + a.steps))
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    tc1 = thread_cpu()
+    # (threads that ended inside the window -- the lane drivers of every batch, the pipeline's three -- are not in tc1: their share is the remainder)
+    cpu_by_thread = {k: round((v - tc0.get(k, 0.0)) / max(a.steps, 1), 3) for k, v in sorted(tc1.items()) if v - tc0.get(k, 0.0) >= 0.005 * max(a.steps, 1)}
     sam_bytes_per_step = step_done[-1][1] if step_done else 0
     # Parity of the timed path itself (VERDICT r3 item 1d): the SAM text the pipeline produced for the LAST TIMED step -- still in the library's
     # reused buffer; hashed here, after the clock has stopped -- against the text of the same batch mapped outside the pipeline (mm_gpu_batch_stage +
@@ -348,6 +369,7 @@ def main():
         pipeline_text_identical = bool(h_pipe == h_plain and ln == out_len.value and ln > 0)
         log("text of the last timed step: %d bytes, blake2b %s (pipeline) vs %s (stage + run + format): %s" % (ln, h_pipe, h_plain, "identical" if pipeline_text_identical else "DIFFERENT"))
     log("rank %d: %d steps in %.3f s (%.3f s per step; last batch's text %d bytes)  stats=%s" % (rank, a.steps, total_t, total_t / max(a.steps, 1), sam_bytes_per_step, {k: round(v, 3) for k, v in al.last_stats().items()}))
+    drv_cpu_last_batch = {k: round(v, 3) for k, v in al.last_stats().items() if k.startswith("drv_cpu_")}  # the lane drivers' own CPU seconds per stage, last timed batch
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
     log("rank %d: host CPU time per step %.2f core-seconds (%d threads; hand-over, host stages of the mapping, hit gather, formatting)" % (rank, host_cpu_s, n_threads))
     prof = mm.profile_get()
@@ -376,12 +398,14 @@ def main():
     # kernels of the path run at the same time and HIP-event spans are costs); feeds roofline.valu and roofline.unoverlapped_ms
     prof1 = None
     t_one = None
+    stage_cpu = None
     if rank == 0 and world == 1:
         os.environ["MM2AMD_ACTIVE_LANES"] = "1"
         os.environ["MM2AMD_NO_SIDE_STREAM"] = "1"  # the lane-exact DP launches after the gap-fill kernel instead of beside it
         mm.profile_enable(True)
         t_one = one_step(a.warmup + a.steps)
-        log("un-overlapped pass (one lane): %.3f s; process CPU seconds while each stage ran: %s" % (t_one, {k: round(v, 2) for k, v in al.last_stats().items() if k.startswith("cpu_")}))
+        stage_cpu = {k: round(v, 3) for k, v in al.last_stats().items() if k.startswith("cpu_") or k.startswith("drv_cpu_")}
+        log("un-overlapped pass (one lane): %.3f s; process CPU seconds while each stage ran: %s" % (t_one, stage_cpu))
         prof1 = mm.profile_get()
         mm.profile_enable(False)
         del os.environ["MM2AMD_ACTIVE_LANES"], os.environ["MM2AMD_NO_SIDE_STREAM"]
@@ -561,6 +585,9 @@ def main():
                       "parallelism": "replicated index, %s, RCCL hit gather to rank 0, every rank formats its shard" % ("one batch sharded %d-way by bases" % world if strong else "%d independent batches" % world) if world > 1 else "1 GPU",
                       "clock": "pipeline of hand-over | mapping | SAM formatting over the timed steps, all three inside the clock (map.c:541-643)",
                       "host_cpu_s_per_step_per_rank": cpu_all,
+                      "host_cpu_s_per_step_by_thread_name": cpu_by_thread,
+                      "host_cpu_s_per_stage_one_lane_pass": stage_cpu,
+                      "lane_driver_cpu_s_last_timed_batch": drv_cpu_last_batch,
                       "sam_bytes_per_step_this_rank": sam_bytes_per_step,
                       "pipeline_text_identical": pipeline_text_identical, "timed_steps_text_bytes": step_text_lengths,
                       "resident_gbases_per_s": round(batch_bases / resident / 1e9, 5) if resident else None,

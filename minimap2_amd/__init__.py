@@ -449,7 +449,15 @@ class Aligner(object):
                 if trace is not None:
                     trace.append(("output", k, t0, t1)), trace.append(("free", k, t1, time.time()))
 
-        th = [threading.Thread(target=f) for f in (stager, mapper, output)]
+        def named(f, nm):  # the OS-level thread name (/proc/<pid>/task/*/comm): bench.py attributes CPU seconds by it
+            def g():
+                try:
+                    C.CDLL(None).prctl(15, nm, 0, 0, 0)  # PR_SET_NAME
+                except Exception:  # noqa: BLE001
+                    pass
+                f()
+            return g
+        th = [threading.Thread(target=named(f, nm)) for f, nm in ((stager, b"mm2-stager"), (mapper, b"mm2-mapper"), (output, b"mm2-output"))]
         for t in th:
             t.start()
         for t in th:
@@ -518,10 +526,11 @@ class Aligner(object):
             self.free_raw(n_reg, reg)
 
     def last_stats(self):
-        v = (C.c_double * 24)()
-        k = lib().mm2amd_last_stats(v, 24)
+        v = (C.c_double * 32)()
+        k = lib().mm2amd_last_stats(v, 32)
         names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells", "dev_allocs", "pin_allocs",
-                 "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish", "n_long_join_dev", "n_long_join_host"]
+                 "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish", "n_long_join_dev", "n_long_join_host",
+                 "drv_cpu_seed_chain", "drv_cpu_host_pre", "drv_cpu_plan", "drv_cpu_ksw", "drv_cpu_consume", "drv_cpu_finish", "n_early_sub"]
         return dict(zip(names, list(v)[:k]))
 
 

@@ -53,6 +53,11 @@ public:
 	// being mapped -- the hand-over costs no mapping time (pipeline step 0 beside step 1, map.c:541-577).
 	virtual void begin_batch(const std::vector<ReadView> &reads, std::vector<uint64_t> &qpool_off) = 0;
 	virtual void activate_batch() {}
+	// Two batches can be under way at once (round 4: the lanes start on the staged batch while the last sub-batches of the current one finish):
+	// current_set() names the resident set activate_batch() made current, bind_lane() tells a lane which set its next seed_chain() / ksw() /
+	// finish_regions() calls work on.  A backend with one resident set has nothing to tell apart.
+	virtual int current_set() const { return 0; }
+	virtual void bind_lane(int /*lane*/, int /*set*/) {}
 	virtual bool stages_beside_mapping() const { return false; }
 	// sketch -> seed lookup -> anchor sort -> chaining DP -> chains, for reads [lo, hi) of the batch (out[i] is read lo+i)
 	// `lane` selects one of n_lanes() independent sets of work buffers (one host thread per lane at a time); host-side parts use

@@ -32,6 +32,7 @@ namespace {
 
 struct Lane {
 	int id = 0;
+	int set = 0; // the resident set (HipBackend::res_) this lane's calls work on: Backend::bind_lane
 	hipStream_t stream = nullptr;
 	SeedChainBuffers B{};
 	KswRunner ksw;
@@ -207,6 +208,8 @@ public:
 		stream_wait(stream_); // the batch is resident; everything after this is the hot path
 	}
 	void activate_batch() override { cur_ = 1 - cur_; }
+	int current_set() const override { return cur_; }
+	void bind_lane(int lane, int set) override { lanes_.at(lane)->set = set; }
 	bool stages_beside_mapping() const override { return true; }
 
 	void seed_chain(const SeedChainParams &P, long lo, long hi, int lane_id, int n_threads, std::vector<ReadChains> &out) override
@@ -215,7 +218,7 @@ public:
 		Lane &ln = *lanes_.at(lane_id);
 		hipStream_t st = ln.stream;
 		SeedChainBuffers &B = ln.B;
-		const Resident &R = res_[cur_];
+		const Resident &R = res_[ln.set];
 		const std::vector<uint64_t> &seq_off_ = R.seq_off, &unit_off_ = R.unit_off;
 		const std::vector<int32_t> &unit_first_ = R.unit_first;
 		const bool has_pairs_ = R.has_pairs, have_read_names_ = R.have_read_names;
@@ -421,7 +424,7 @@ public:
 	               const int32_t *h_nu, const int32_t *h_nv, const uint64_t *h_aoff, const uint64_t *h_uoff)
 	{
 		hipStream_t st = ln.stream;
-		const std::vector<uint64_t> &seq_off = res_[cur_].seq_off;
+		const std::vector<uint64_t> &seq_off = res_[ln.set].seq_off;
 		std::vector<uint32_t> sel;
 		for (size_t i = 0; i < n; ++i) {
 			ReadChains &c = out[i];
@@ -512,7 +515,7 @@ public:
 			HIP_CHECK(hipMemcpyAsync(ln.d_tbytes.p, sc.tbytes, sc.n_tbytes, hipMemcpyHostToDevice, ln.stream));
 			d_tbytes = ln.d_tbytes.p;
 		}
-		ln.ksw.run(jobs, res_[cur_].d_qpool.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
+		ln.ksw.run(jobs, res_[ln.set].d_qpool.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id, replica_).collect();
 	}
 
@@ -544,7 +547,7 @@ public:
 		HIP_CHECK(hipMemcpyAsync(ln.d_fin_pieces.p, ln.h_fin_pieces.p, pieces.size() * sizeof(FinPiece), hipMemcpyHostToDevice, ln.stream));
 		FinParams P;
 		P.regions = ln.d_fin_regions.p, P.n_regions = (int)n, P.pieces = ln.d_fin_pieces.p, P.cigar_pool = ln.ksw.d_cigar.p, P.out_pool = ln.d_fin_out.p, P.results = ln.d_fin_res.p;
-		P.qpool = res_[cur_].d_qpool.p, P.S = T_->S.p;
+		P.qpool = res_[ln.set].d_qpool.p, P.S = T_->S.p;
 		memcpy(P.mat, mat25, 25);
 		P.q = (int8_t)q, P.e = (int8_t)e, P.log_gap = log_gap ? 1 : 0;
 		uint32_t longest = 1; // (a region's room in the output pool is the sum of its pieces: the next region's offset minus its own)

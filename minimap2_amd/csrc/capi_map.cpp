@@ -113,7 +113,7 @@ void for_each_replica(MapContext &c, F &&f)
 {
 	std::vector<std::thread> th;
 	std::vector<std::exception_ptr> err(c.reps.size());
-	for (size_t r = 1; r < c.reps.size(); ++r) th.emplace_back([&, r] { try { f(c.reps[r]); } catch (...) { err[r] = std::current_exception(); } });
+	for (size_t r = 1; r < c.reps.size(); ++r) th.emplace_back([&, r] { name_thread("mm2replica"); try { f(c.reps[r]); } catch (...) { err[r] = std::current_exception(); } });
 	try { f(c.reps[0]); } catch (...) { err[0] = std::current_exception(); }
 	for (auto &t : th) t.join();
 	for (auto &e : err) if (e) std::rethrow_exception(e);
@@ -132,6 +132,8 @@ void run_replicas(MapContext &c, const StagedBatch &bt, std::vector<ReadResult> 
 		sum.t_seed_chain += s.t_seed_chain, sum.t_host_pre += s.t_host_pre, sum.t_plan += s.t_plan, sum.t_ksw += s.t_ksw, sum.t_consume += s.t_consume;
 		sum.t_finish += s.t_finish, sum.n_jobs += s.n_jobs, sum.n_rounds += s.n_rounds, sum.dp_cells += s.dp_cells;
 		sum.c_seed_chain += s.c_seed_chain, sum.c_host_pre += s.c_host_pre, sum.c_plan += s.c_plan, sum.c_ksw += s.c_ksw, sum.c_consume += s.c_consume, sum.c_finish += s.c_finish;
+		sum.n_early_sub += s.n_early_sub;
+		sum.d_seed_chain += s.d_seed_chain, sum.d_host_pre += s.d_host_pre, sum.d_plan += s.d_plan, sum.d_ksw += s.d_ksw, sum.d_consume += s.d_consume, sum.d_finish += s.d_finish;
 		sum.n_long_join_dev += s.n_long_join_dev, sum.n_long_join_host += s.n_long_join_host;
 	}
 	std::lock_guard<std::mutex> lk(c.stats_mu);
@@ -139,13 +141,13 @@ void run_replicas(MapContext &c, const StagedBatch &bt, std::vector<ReadResult> 
 }
 
 // hand the batch's shares to the replicas' mappers (which copy the sequences to their devices); call with stage_mu held
-void stage_replicas(MapContext &c, StagedBatch &bt)
+void stage_replicas(MapContext &c, StagedBatch &bt, bool queued = false)
 {
 	shard_by_bases(bt.views, bt.slots, (int)c.reps.size(), bt.cut);
 	for_each_replica(c, [&](Replica &rp) {
 		const size_t r = (size_t)(&rp - c.reps.data());
 		std::vector<ReadView> share(bt.views.begin() + bt.cut[r], bt.views.begin() + bt.cut[r + 1]);
-		rp.mapper->stage(share);
+		rp.mapper->stage(share, queued); // queued: a pipeline's hand-over -- mapped exactly once, next; the lanes may start on it early
 	});
 }
 
@@ -393,7 +395,7 @@ static int stage_batch(int n_frag, const int *seg_off, const int *n_seg, const v
 		c.pending = false;
 		StagedBatch &bt = c.batch[1 - c.cur];
 		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, bt.views, bt.slots, bt.flipped)) return rc;
-		stage_replicas(c, bt);
+		stage_replicas(c, bt, queued);
 		c.pending = true;
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -412,6 +414,7 @@ void mm_gpu_batch_discard(void)
 	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
 	if (!g_ctx) return;
 	std::lock_guard<std::mutex> lk_st(g_ctx->stage_mu);
+	for (Replica &rp : g_ctx->reps) rp.mapper->discard(); // (sub-batches of it the lanes had started on are awaited and dropped)
 	g_ctx->pending = false;
 	g_ctx->stage_cv.notify_all();
 }
@@ -675,7 +678,8 @@ int mm2amd_last_stats(double *v, int n)
 	const MapperStats &s = g_ctx->stats;
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
 	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2),
-	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish, (double)s.n_long_join_dev, (double)s.n_long_join_host }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
+	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish, (double)s.n_long_join_dev, (double)s.n_long_join_host,
+	                     s.d_seed_chain, s.d_host_pre, s.d_plan, s.d_ksw, s.d_consume, s.d_finish, (double)s.n_early_sub }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -1,6 +1,7 @@
 // Small HIP runtime helpers shared by the product's translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -37,10 +38,11 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define HIP_CHECK(x) ::mm2amd::hip_check((x), #x, __FILE__, __LINE__)
 
-// Wait for a stream WITHOUT spinning.  hipStreamSynchronize busy-waits; five lane drivers doing that cost five cores for the whole step,
-// and a process under a CPU quota (a container: cpu.max) pays for them with the time of its working threads -- the hot path's host side
-// then is quota-bound, not GPU-bound (profiles/r03: 16 CPUs of quota, 10 core-seconds per step).  An event created with
-// hipEventBlockingSync makes the waiter sleep until the interrupt.
+// Wait for a stream WITHOUT spinning.  hipStreamSynchronize busy-waits, and so does hipEventSynchronize -- also on an event created with
+// hipEventBlockingSync (round 3 relied on that flag; tools/wait_cost.hip, profiles/r04_wait_cost_v8.txt: 100 % of a core for the whole wait with
+// either, on this ROCm).  Five lane drivers waiting that way cost 2.5 core-seconds per 1-Gbase step, paid out of the container's CPU quota
+// with the time of the working threads.  So: record an event and POLL it (hipEventQuery) between short sleeps -- 1 % of a core; the
+// sleeps start at 20 us and grow to 200 us, waits here are milliseconds long.
 inline void stream_wait(hipStream_t s)
 {
 	struct PerDevice { int dev = -1; hipEvent_t ev = nullptr; ~PerDevice() { if (ev) (void)hipEventDestroy(ev); } }; // (destroyed when the thread ends)
@@ -52,11 +54,20 @@ inline void stream_wait(hipStream_t s)
 	if (!slot) {
 		for (PerDevice &c : cache) if (c.dev < 0) { slot = &c; break; }
 		if (!slot) { HIP_CHECK(hipStreamSynchronize(s)); return; }
-		HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventBlockingSync | hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
 		slot->dev = dev;
 	}
 	HIP_CHECK(hipEventRecord(slot->ev, s));
-	HIP_CHECK(hipEventSynchronize(slot->ev));
+	long ns = 20000;
+	for (int it = 0;; ++it) {
+		const hipError_t e = hipEventQuery(slot->ev);
+		if (e == hipSuccess) return;
+		if (e != hipErrorNotReady) HIP_CHECK(e);
+		if (it < 4) continue; // (work that is all but done: a few queries back to back)
+		timespec ts = { 0, ns };
+		nanosleep(&ts, nullptr);
+		if (ns < 200000) ns += ns / 2;
+	}
 }
 
 // CPUs this process may actually use: the smaller of the hardware thread count and the container's CPU quota (cgroup v2 cpu.max, v1 cfs quota)

@@ -350,8 +350,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			HIP_CHECK(hipEventRecord(ev_side_done, side));
 			HIP_CHECK(hipStreamWaitEvent(stream, ev_side_done, 0));
 		}
-		uint32_t cursor[2];
-		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, sizeof cursor, hipMemcpyDeviceToHost, stream));
+		// (into PINNED memory: an asynchronous copy to pageable memory -- a stack array here until round 4 -- makes the runtime wait for the stream inside
+		// the call, spinning: the lane drivers spent the whole duration of the DP kernels on a core each, 1.2 core-seconds per step)
+		uint32_t *cursor = h_cursor.ensure(2);
+		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
 		stream_wait(stream);
 		Trace::get().add(lane, "gpu:ksw", tt, Trace::now()); tt = Trace::now();

@@ -20,6 +20,7 @@ struct KswRunner {
 	PinBuf<KswJob> sorted;            // jobs in launch order (tier, then decreasing cost), pinned for the H2D copy
 	PinBuf<KswRes> tmp_res;
 	PinBuf<uint32_t> cigar_host;      // the batch's CIGARs as the kernel packed them
+	PinBuf<uint32_t> h_cursor;        // the CIGAR pool's cursor and overflow flag, read back after the launches
 	std::vector<uint32_t> perm, bucket, chunk_hist;
 	int n_threads = 1, lane = 0;
 	bool disable_fast = false;       // route every job through the lane-exact kernel (MM2AMD_KSW_EXACT_ONLY=1; for A/B checks)

@@ -32,6 +32,7 @@ inline uint32_t x31_hash(const char *s) // __ac_X31_hash_string, khash.h:383-388
 }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 double cpu_now() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+double thr_now() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 }
 
 uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
@@ -73,8 +74,13 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 	}
 }
 
-void Mapper::stage(const std::vector<ReadView> &reads)
+void Mapper::stage(const std::vector<ReadView> &reads, bool may_start_early)
 {
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		cancel_next_locked(lk); // (a staged batch the lanes had started on is being replaced: not a pipeline's pattern, but it must not corrupt anything)
+		pending_ = false, early_ok_ = false;
+	}
 	Staged &S = sets_[1 - cur_set_];
 	S.n = (long)reads.size();
 	S.live.clear(), S.live_id.clear(), S.qoff.clear();
@@ -82,33 +88,69 @@ void Mapper::stage(const std::vector<ReadView> &reads)
 	for (long i = 0; i < S.n; ++i)
 		if (reads[i].total() > 0 && !(opt_.max_qlen > 0 && reads[i].total() > opt_.max_qlen)) S.live.push_back(reads[i]), S.live_id.push_back(i);
 	be_.begin_batch(S.live, S.qoff); // (an empty batch too: the backend's sets and ours swap together)
-	pending_ = true;
+	static const bool no_early = getenv("MM2AMD_NO_EARLY_START") != nullptr; // A/B checks: every batch starts at its own run() call
+	{
+		std::lock_guard<std::mutex> lk(mu_);
+		pending_ = true, early_ok_ = may_start_early && !no_early && be_.stages_beside_mapping();
+	}
+	cv_work_.notify_all(); // idle lanes of a batch on its last sub-batches may begin with this one
 }
 
-void Mapper::take()
+void Mapper::take_locked()
 {
-	if (!pending_) return;
 	cur_set_ = 1 - cur_set_;
 	be_.activate_batch();
 	pending_ = false;
 }
 
-void Mapper::run(std::vector<ReadResult> &out)
+void Mapper::take()
 {
-	// (No take() here: the caller has taken the batch it wants mapped, under the lock that also orders the hand-overs.  A take at this point
-	// raced with the hand-over of the NEXT batch -- when that finished between the caller's take and this line, run() mapped the next batch's
-	// reads against the caller's records of this one: tests/test_wave_emu.py::test_pipeline_equals_batch_by_batch with tiny batches.)
-	const long n = sets_[cur_set_].n;
-	out.clear();
-	out.resize(n);
-	stats = MapperStats();
-	const std::vector<ReadView> &live = sets_[cur_set_].live;
+	std::lock_guard<std::mutex> lk(mu_);
+	if (next_run_) { next_adopted_ = true; return; } // the lanes have taken it already; from here on it is the caller's batch (a hand-over that follows must not drop it)
+	if (pending_) take_locked();
+}
+
+void Mapper::discard()
+{
+	std::unique_lock<std::mutex> lk(mu_);
+	cancel_next_locked(lk);
+	pending_ = false, early_ok_ = false;
+}
+
+// drops a batch the lanes started early: no further sub-batch of it is handed out, those under way are awaited
+void Mapper::cancel_next_locked(std::unique_lock<std::mutex> &lk)
+{
+	if (!next_run_ || next_adopted_) return;
+	next_run_->cancelled = true;
+	std::shared_ptr<BatchRun> b = next_run_;
+	cv_done_.wait(lk, [&] { return b->n_done == b->n_taken; });
+	next_run_.reset();
+	cur_set_ = 1 - cur_set_; // un-take: the set that was staged is the staged set again (and about to be refilled or forgotten)
+	be_.activate_batch();
+}
+
+Mapper::~Mapper()
+{
+	{
+		std::lock_guard<std::mutex> lk(mu_);
+		stop_ = true;
+	}
+	cv_work_.notify_all();
+	for (std::thread &t : drivers_) t.join();
+}
+
+// the batch in sets_[set] cut into sub-batches, with everything a lane needs to take one through its stages
+std::shared_ptr<Mapper::BatchRun> Mapper::make_run(int set)
+{
+	std::shared_ptr<BatchRun> bp(new BatchRun);
+	BatchRun &b = *bp;
+	b.set = set, b.be_set = be_.current_set();
+	b.out.resize(sets_[set].n);
+	const std::vector<ReadView> &live = sets_[set].live;
 	const long m_all = (long)live.size();
-	if (m_all == 0) return;
-	double t0 = now();
 
 	// chaining parameters (map.c:262-274); single segment, not sr
-	SeedChainParams sp;
+	SeedChainParams &sp = b.sp;
 	sp.k = fi_.k, sp.w = fi_.w, sp.is_hpc = fi_.flag & I_HPC;
 	sp.sdust_thres = opt_.sdust_thres;
 	sp.mid_occ = sp.q_mid_occ = opt_.mid_occ, sp.max_max_occ = opt_.max_max_occ, sp.occ_dist = opt_.occ_dist, sp.q_occ_frac = opt_.q_occ_frac;
@@ -133,8 +175,8 @@ void Mapper::run(std::vector<ReadResult> &out)
 	// its stages, so the GPU stages of one sub-batch overlap the host stages of the others.
 	long sub_bases = 100000000;
 	if (const char *e = getenv("MM2AMD_SUBBATCH_BASES")) sub_bases = atol(e) > 0 ? atol(e) : sub_bases;
-	std::vector<std::pair<long, long>> subs;
-	{
+	std::vector<std::pair<long, long>> &subs = b.subs;
+	if (m_all > 0) {
 		long max_reads = be_.max_reads_per_call(), sub_reads = 25000; // bound the read count too, so that a second lane overlaps the host stages; larger sub-batches keep the DP launches' tails short
 		uint64_t tot = 0;
 		for (long i = 0; i < m_all; ++i) tot += (uint64_t)live[i].total();
@@ -154,56 +196,109 @@ void Mapper::run(std::vector<ReadResult> &out)
 			subs.emplace_back(lo, hi);
 		}
 	}
-	int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), subs.size());
+	int n_drivers = (int)std::min<size_t>((size_t)std::max(1, be_.n_lanes()), std::max<size_t>(1, subs.size()));
 	if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) n_drivers = std::max(1, std::min(n_drivers, atoi(e))); // read per run: bench.py takes its un-overlapped kernel times with one lane
-	while ((int)scratch_.size() < n_drivers) scratch_.emplace_back(new DriverScratch);
-	be_.set_active_lanes(n_drivers);
-	device_finish_ = be_.finishes_regions(); // one answer for the whole batch
-	std::atomic<size_t> next_sub(0);
-	std::mutex stats_mu;
-	std::exception_ptr first_err;
-	auto driver = [&](int lane) {
-		MapperStats st; // this driver's share, merged at the end
-		// per-lane state that lives as long as the mapper: one Aligner per pool thread (they hold scratch buffers) and the big
-		// per-sub-batch arrays, so that steady-state batches allocate (and page-fault) nothing
-		DriverScratch &ds = *scratch_.at(lane);
-		std::vector<std::unique_ptr<Aligner>> &al = ds.al;
-		if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)); }
-		for (auto &p : al) p->device_finish(device_finish_);
-		try {
-			for (;;) {
-				const size_t si = next_sub.fetch_add(1);
-				if (si >= subs.size()) break;
-				process_sub(sp, subs[si].first, subs[si].second, lane, al, ds, out, st);
-			}
-		} catch (...) {
-			std::lock_guard<std::mutex> lk(stats_mu);
-			if (!first_err) first_err = std::current_exception();
-			next_sub.store(subs.size());
-		}
-		std::lock_guard<std::mutex> lk(stats_mu);
-		stats.t_seed_chain += st.t_seed_chain, stats.t_host_pre += st.t_host_pre, stats.t_plan += st.t_plan, stats.t_ksw += st.t_ksw;
-		stats.t_consume += st.t_consume, stats.t_finish += st.t_finish, stats.n_jobs += st.n_jobs, stats.n_rounds += st.n_rounds, stats.dp_cells += st.dp_cells;
-		stats.c_seed_chain += st.c_seed_chain, stats.c_host_pre += st.c_host_pre, stats.c_plan += st.c_plan, stats.c_ksw += st.c_ksw, stats.c_consume += st.c_consume, stats.c_finish += st.c_finish;
-		stats.n_long_join_dev += st.n_long_join_dev, stats.n_long_join_host += st.n_long_join_host;
-	};
-	std::vector<std::thread> th;
-	for (int l = 1; l < n_drivers; ++l) th.emplace_back(driver, l);
-	driver(0);
-	for (auto &t : th) t.join();
-	Trace::get().flush();
-	if (first_err) std::rethrow_exception(first_err);
-	(void)t0;
+	b.n_drivers = n_drivers;
+	b.device_finish = be_.finishes_regions(); // one answer for the whole batch
+	return bp;
 }
 
-void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, std::vector<ReadResult> &out, MapperStats &stats)
+void Mapper::ensure_drivers(int n)
 {
-	const std::vector<ReadView> &live = sets_[cur_set_].live;
-	const std::vector<long> &live_id = sets_[cur_set_].live_id;
-	const std::vector<uint64_t> &qoff = sets_[cur_set_].qoff;
+	while ((int)scratch_.size() < n) scratch_.emplace_back(new DriverScratch);
+	while ((int)drivers_.size() < n) { const int lane = (int)drivers_.size(); drivers_.emplace_back([this, lane] { driver_loop(lane); }); }
+}
+
+// A lane's thread: takes the next sub-batch of the batch run() waits for; when that batch has none left and the next one has been handed over
+// by a pipeline (stage(.., may_start_early)), starts on that one -- its run() call then finds part of the work done.
+void Mapper::driver_loop(int lane)
+{
+	name_thread("mm2lane");
+	for (;;) {
+		std::shared_ptr<BatchRun> b;
+		size_t si = 0;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			for (;;) {
+				if (stop_) return;
+				if (cur_run_ && lane < cur_run_->n_drivers && !cur_run_->cancelled && cur_run_->next_sub < cur_run_->subs.size()) { b = cur_run_; break; }
+				if (!next_run_ && cur_run_ && pending_ && early_ok_ && lane < lane_cap_) { // the staged batch: ours from here on
+					take_locked();
+					early_ok_ = false;
+					next_run_ = make_run(cur_set_);
+				}
+				if (next_run_ && lane < next_run_->n_drivers && !next_run_->cancelled && next_run_->next_sub < next_run_->subs.size()) { b = next_run_; break; }
+				cv_work_.wait(lk);
+			}
+			si = b->next_sub++;
+			++b->n_taken;
+			if (b != cur_run_) ++b->stats.n_early_sub;
+		}
+		MapperStats st; // this sub-batch's share, merged below
+		std::exception_ptr err;
+		try {
+			// per-lane state that lives as long as the mapper: one Aligner per pool thread (they hold scratch buffers) and the big
+			// per-sub-batch arrays, so that steady-state batches allocate (and page-fault) nothing
+			DriverScratch &ds = *scratch_.at(lane);
+			std::vector<std::unique_ptr<Aligner>> &al = ds.al;
+			if (al.empty()) { al.resize(n_threads_); for (auto &p : al) p.reset(new Aligner(opt_, fi_)); }
+			for (auto &p : al) p->device_finish(b->device_finish);
+			process_sub(*b, b->subs[si].first, b->subs[si].second, lane, al, ds, st);
+		} catch (...) {
+			err = std::current_exception();
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			MapperStats &stats = b->stats;
+			stats.t_seed_chain += st.t_seed_chain, stats.t_host_pre += st.t_host_pre, stats.t_plan += st.t_plan, stats.t_ksw += st.t_ksw;
+			stats.t_consume += st.t_consume, stats.t_finish += st.t_finish, stats.n_jobs += st.n_jobs, stats.n_rounds += st.n_rounds, stats.dp_cells += st.dp_cells;
+			stats.c_seed_chain += st.c_seed_chain, stats.c_host_pre += st.c_host_pre, stats.c_plan += st.c_plan, stats.c_ksw += st.c_ksw, stats.c_consume += st.c_consume, stats.c_finish += st.c_finish;
+			stats.n_long_join_dev += st.n_long_join_dev, stats.n_long_join_host += st.n_long_join_host;
+			stats.d_seed_chain += st.d_seed_chain, stats.d_host_pre += st.d_host_pre, stats.d_plan += st.d_plan, stats.d_ksw += st.d_ksw, stats.d_consume += st.d_consume, stats.d_finish += st.d_finish;
+			if (err) { if (!b->err) b->err = err; b->cancelled = true; } // no further sub-batch of it is handed out
+			++b->n_done;
+		}
+		cv_done_.notify_all();
+	}
+}
+
+void Mapper::run(std::vector<ReadResult> &out)
+{
+	// (No take() here: the caller has taken the batch it wants mapped, under the lock that also orders the hand-overs.  A take at this point
+	// raced with the hand-over of the NEXT batch -- when that finished between the caller's take and this line, run() mapped the next batch's
+	// reads against the caller's records of this one: tests/test_wave_emu.py::test_pipeline_equals_batch_by_batch with tiny batches.)
+	std::shared_ptr<BatchRun> b;
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		if (next_run_ && next_adopted_) b = next_run_, next_run_.reset(), next_adopted_ = false; // the lanes have started on it
+		else b = make_run(cur_set_);
+		cur_run_ = b;
+		be_.set_active_lanes(b->n_drivers);
+		lane_cap_ = std::max(1, be_.n_lanes());
+		if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) lane_cap_ = std::max(1, std::min(lane_cap_, atoi(e)));
+		ensure_drivers(std::max(lane_cap_, b->n_drivers)); // (lanes beyond this batch's sub-batches exist too: they are the ones free to start on the next batch)
+		cv_work_.notify_all();
+		cv_done_.wait(lk, [&] { return b->n_done == b->n_taken && (b->cancelled || b->next_sub >= b->subs.size()); });
+		cur_run_.reset();
+		stats = b->stats;
+	}
+	Trace::get().flush();
+	out.swap(b->out);
+	if (b->err) std::rethrow_exception(b->err);
+}
+
+void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, MapperStats &stats)
+{
+	const SeedChainParams &sp = batch.sp;
+	std::vector<ReadResult> &out = batch.out;
+	const bool device_finish_ = batch.device_finish;
+	const std::vector<ReadView> &live = sets_[batch.set].live;
+	const std::vector<long> &live_id = sets_[batch.set].live_id;
+	const std::vector<uint64_t> &qoff = sets_[batch.set].qoff;
+	be_.bind_lane(lane, batch.be_set); // the lane's kernels read this batch's resident set (two batches can be under way: a batch's tail and the next one's start)
 	{
 		const long m = hi - lo;
-		double t0 = now(), c0 = cpu_now();
+		double t0 = now(), c0 = cpu_now(), d0 = thr_now();
 		std::vector<ReadChains> &chains = ds.chains;
 		be_.seed_chain(sp, lo, hi, lane, n_threads_, chains);
 		if (opt_.max_occ > opt_.mid_occ && !(opt_.flag & F_RMQ)) {
@@ -240,7 +335,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 		}
 		stats.t_seed_chain += now() - t0; t0 = now();
-		stats.c_seed_chain += cpu_now() - c0; c0 = cpu_now();
+		stats.c_seed_chain += cpu_now() - c0; c0 = cpu_now(); stats.d_seed_chain += thr_now() - d0; d0 = thr_now();
 
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
 		// A two-segment fragment (paired-end reads) is seeded and chained as one query -- the concatenation of its segments -- and
@@ -349,7 +444,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		Trace::get().add(lane, "host:pre", t0, now());
 		stats.n_long_join_dev += n_lj_dev.load(), stats.n_long_join_host += n_lj_host.load();
 		stats.t_host_pre += now() - t0;
-		stats.c_host_pre += cpu_now() - c0;
+		stats.c_host_pre += cpu_now() - c0; stats.d_host_pre += thr_now() - d0; d0 = thr_now();
 
 		if (!(opt_.flag & F_CIGAR)) return; // no base-level alignment asked for
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
@@ -366,7 +461,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(mu, 1);
 		for (int round = 0;; ++round) {
-			t0 = now(), c0 = cpu_now();
+			t0 = now(), c0 = cpu_now(), d0 = thr_now();
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				per_read_jobs[i].clear();
 				if (active[i]) al[tid]->schedule(ra[i], per_read_jobs[i]);
@@ -411,11 +506,11 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			Trace::get().add(lane, "host:plan", t0, now());
 			stats.t_plan += now() - t0; t0 = now();
-			stats.c_plan += cpu_now() - c0; c0 = cpu_now();
+			stats.c_plan += cpu_now() - c0; c0 = cpu_now(); stats.d_plan += thr_now() - d0; d0 = thr_now();
 			be_.ksw(jobs, sc, lane, n_threads_, kres, &cigars);
 			stats.n_jobs += (long)jobs.size(), ++stats.n_rounds;
 			stats.t_ksw += now() - t0; t0 = now();
-			stats.c_ksw += cpu_now() - c0; c0 = cpu_now();
+			stats.c_ksw += cpu_now() - c0; c0 = cpu_now(); stats.d_ksw += thr_now() - d0; d0 = thr_now();
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
 				if (active[i]) active[i] = al[tid]->consume(ra[i], kres.data() + job_base[i], cigars) ? 1 : 0;
 			});
@@ -455,12 +550,12 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 			}
 			Trace::get().add(lane, "host:consume", t0, now());
 			stats.t_consume += now() - t0;
-			stats.c_consume += cpu_now() - c0;
+			stats.c_consume += cpu_now() - c0; stats.d_consume += thr_now() - d0; d0 = thr_now();
 			if (round > 1000) throw std::runtime_error("[mm2amd] alignment rounds did not converge");
 		}
 
 		// ---- final hit selection and MAPQ (map.c:215-225, :339-342), pairing (map.c:353-354) ----
-		t0 = now(), c0 = cpu_now();
+		t0 = now(), c0 = cpu_now(), d0 = thr_now();
 		parallel_for(n_threads_, m, [&](long i, int tid) {
 			ReadResult &res = out[live_id[lo + i]];
 			const ReadView &rv = live[lo + i];
@@ -487,7 +582,7 @@ void Mapper::process_sub(const SeedChainParams &sp, long lo, long hi, int lane, 
 		});
 		Trace::get().add(lane, "host:finish", t0, now());
 		stats.t_finish += now() - t0;
-		stats.c_finish += cpu_now() - c0;
+		stats.c_finish += cpu_now() - c0; stats.d_finish += thr_now() - d0; d0 = thr_now();
 	}
 }
 

@@ -14,8 +14,13 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+#include <pthread.h>
+#include <time.h>
 
 namespace mm2amd {
+
+// names this thread for /proc/<pid>/task/*/comm (bench.py attributes the process's CPU seconds to thread groups by these names)
+inline void name_thread(const char *name) { pthread_setname_np(pthread_self(), name); }
 
 class ThreadPool {
 public:
@@ -24,9 +29,10 @@ public:
 	// leaves the GPU idle)
 	static ThreadPool &instance(int which = 0)
 	{
-		static ThreadPool p[2];
-		return p[which ? 1 : 0];
+		static ThreadPool main_pool(false), side_pool(true);
+		return which ? side_pool : main_pool;
 	}
+	explicit ThreadPool(bool side) : side_(side) {}
 	// Runs fn(i, tid) for i in [0,n) on up to n_threads threads (the caller is one of them); tid < n_threads.
 	void run(int n_threads, long n, const std::function<void(long, int)> &fn, long chunk)
 	{
@@ -42,15 +48,22 @@ public:
 		}
 		s->fn = &fn, s->n = n, s->chunk = chunk, s->err = nullptr;
 		s->next.store(0, std::memory_order_relaxed), s->next_tid.store(1, std::memory_order_relaxed);
-		s->helpers_wanted.store(std::min<int>(want - 1, n_workers_.load()), std::memory_order_relaxed);
+		const int helpers = std::min<int>(want - 1, n_workers_.load());
+		s->helpers_wanted.store(helpers, std::memory_order_relaxed);
 		s->open.store(true, std::memory_order_release);
-		n_open_.fetch_add(1, std::memory_order_release);
-		if (n_sleeping_.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
+		n_wanted_.fetch_add(helpers, std::memory_order_release);
+		if (n_sleeping_.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(mu_); if (helpers >= n_sleeping_.load()) cv_.notify_all(); else for (int k = 0; k < helpers; ++k) cv_.notify_one(); }
 		work(*s, 0);
 		// the range is exhausted: no helper can claim another chunk; wait for those still inside their last one
 		s->open.store(false, std::memory_order_release);
-		n_open_.fetch_sub(1, std::memory_order_release);
-		while (s->active.load(std::memory_order_acquire) != 0) cpu_relax();
+		{ // helpers that never came are no longer wanted
+			const int left = s->helpers_wanted.exchange(0, std::memory_order_acq_rel);
+			if (left > 0) n_wanted_.fetch_sub(left, std::memory_order_release);
+		}
+		for (int spin = 0; s->active.load(std::memory_order_acquire) != 0; ++spin) { // (a helper's last chunk can be milliseconds long: do not pay for the wait out of the CPU quota)
+			if (spin < 2000) cpu_relax();
+			else { timespec ts = { 0, 20000 }; nanosleep(&ts, nullptr); }
+		}
 		std::exception_ptr err = s->err;
 		s->err = nullptr;
 		s->in_use.store(false, std::memory_order_release);
@@ -103,9 +116,15 @@ private:
 		for (Slot &s : slots_) {
 			if (!s.open.load(std::memory_order_acquire) || s.helpers_wanted.load(std::memory_order_relaxed) <= 0) continue;
 			s.active.fetch_add(1, std::memory_order_acq_rel); // announce first, then re-check: run() closes before it waits for active == 0
-			if (s.open.load(std::memory_order_acquire) && s.helpers_wanted.fetch_sub(1, std::memory_order_acq_rel) > 0) {
-				work(s, s.next_tid.fetch_add(1, std::memory_order_relaxed));
-				helped = true;
+			if (s.open.load(std::memory_order_acquire)) {
+				// take one of the places still wanted (run() zeroes the count when it closes; never below zero, so that n_wanted_ stays the sum)
+				int w = s.helpers_wanted.load(std::memory_order_relaxed);
+				while (w > 0 && !s.helpers_wanted.compare_exchange_weak(w, w - 1, std::memory_order_acq_rel)) {}
+				if (w > 0) {
+					n_wanted_.fetch_sub(1, std::memory_order_release);
+					work(s, s.next_tid.fetch_add(1, std::memory_order_relaxed));
+					helped = true;
+				}
 			}
 			s.active.fetch_sub(1, std::memory_order_acq_rel);
 		}
@@ -122,24 +141,28 @@ private:
 	}
 	void loop()
 	{
+		name_thread(side_ ? "mm2side" : "mm2pool");
 		for (;;) {
 			if (try_help()) continue;
-			// nothing to do: spin briefly (the next loop of the same sub-batch is usually microseconds away), then sleep
+			// nothing to do: spin briefly (the next loop of the same sub-batch is usually microseconds away), then sleep.  "Something to do" = a
+			// loop that still wants helpers (round 4: it used to be "a loop is open", and idle workers polled and yielded for as long as any
+			// driver was inside a loop's last chunks -- CPU seconds out of the quota that the host stages needed)
 			bool found = false;
 			for (int spin = 0; spin < 400 && !found; ++spin) { // (a few microseconds: spinning is paid for out of the process's CPU quota)
 				if (stop_.load(std::memory_order_relaxed)) return;
-				if (n_open_.load(std::memory_order_acquire) > 0) found = true; else cpu_relax();
+				if (n_wanted_.load(std::memory_order_acquire) > 0) found = true; else cpu_relax();
 			}
-			if (found) { if (!try_help()) std::this_thread::yield(); continue; }
+			if (found) continue;
 			std::unique_lock<std::mutex> lk(mu_);
 			n_sleeping_.fetch_add(1, std::memory_order_acq_rel);
-			cv_.wait(lk, [&] { return stop_.load() || n_open_.load(std::memory_order_acquire) > 0; });
+			cv_.wait(lk, [&] { return stop_.load() || n_wanted_.load(std::memory_order_acquire) > 0; });
 			n_sleeping_.fetch_sub(1, std::memory_order_acq_rel);
 			if (stop_.load()) return;
 		}
 	}
 	Slot slots_[64]; // more than the driver threads a context can have at once (16 replicas x 5 lanes would queue; 8 x 5 fit)
-	std::atomic<int> n_open_{0}, n_sleeping_{0}, n_workers_{0};
+	std::atomic<int> n_wanted_{0}, n_sleeping_{0}, n_workers_{0}; // n_wanted_: helpers the open loops still want, over all slots
+	const bool side_;
 	std::atomic<bool> stop_{false};
 	std::mutex mu_;
 	std::condition_variable cv_;

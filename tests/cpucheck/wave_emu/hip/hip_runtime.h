@@ -110,7 +110,7 @@ inline unsigned atomicExch(unsigned *p, unsigned v) { return __atomic_exchange_n
 
 // ---- the runtime API the product's host code calls; "device memory" is host memory, every stream is synchronous ----
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorNotReady = 600 };
 typedef struct wave_emu_stream *hipStream_t;
 typedef struct wave_emu_event { double t; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -143,6 +143,7 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 double wave_emu_now();
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = wave_emu_now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; } // (launches run to completion inside the launch call)
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }

@@ -119,6 +119,46 @@ def test_pipeline_of_tiny_batches_equals_batch_by_batch():
     assert sum(len(t) for t in want) > 100000
 
 
+@pytest.mark.timeout(3600 if EMU else 900)
+def test_pipeline_early_start_across_batches(monkeypatch):
+    """Round 4: the lanes start on the next handed-over batch while the current batch's last sub-batches finish (Mapper::stage(may_start_early)).
+    Batches of a few hundred reads cut into sub-batches of 40 reads (a dozen per batch, five lanes): pipeline text == batch by batch, early starts
+    counted; then the same batches with MM2AMD_NO_EARLY_START-equivalent un-pipelined calls."""
+    import minimap2_amd as mm
+    monkeypatch.setenv("MM2AMD_SUBBATCH_READS", "8" if EMU else "40")
+    rng = np.random.default_rng(9)
+    contigs = synth.gen_reference(rng, 2000000, 2)
+    pool = synth.gen_reads(rng, contigs, 60 if EMU else 900, 2500, 600, 0.1, min_len=300)
+    refs = [synth.ACGT[c].tobytes() for c in contigs]
+    rds = [("r%d" % i, synth.ACGT[r].tobytes()) for i, r in enumerate(pool)]
+    n_batches = 6 if EMU else 24
+    batches = []
+    for k in range(n_batches):
+        m = 0 if k == 3 else int(rng.integers(20, 50) if EMU else rng.integers(200, 520))
+        pick = rng.integers(0, len(rds), m)
+        batches.append(mm.Batch([rds[i] for i in pick]))
+    al = mm.Aligner(refs, preset="map-ont", names=["chr1", "chr2"], n_threads=8, sam=True)
+    try:
+        want = []
+        for b in batches:
+            al.stage(b)
+            n_reg, reg, rep = al.run(raw=True)
+            want.append(al.format_raw(n_reg, reg, rep))
+            al.free_raw(n_reg, reg)
+        n_early = [0]
+        def on_mapped(b, n_reg, reg, rep_len):
+            n_early[0] += int(al.last_stats()["n_early_sub"])
+        for rep_no in range(2 if EMU else 3):
+            got = []
+            total = al.pipeline(batches, on_text=lambda b, addr, ln: got.append(C.string_at(addr, ln)), on_mapped=on_mapped)
+            bad = [k for k in range(n_batches) if got[k] != want[k]]
+            assert not bad, "pass %d: batches %s differ (of %d)" % (rep_no, bad[:10], n_batches)
+            assert total == sum(len(t) for t in want)
+        assert n_early[0] > 0, "no sub-batch was started before its batch's mapping call"
+    finally:
+        al.close()
+
+
 def _sam(cmd, env=None):
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, (cmd, p.stderr.decode()[-2000:])

@@ -205,3 +205,42 @@ def test_pipeline_equals_batch_by_batch(emu):
         assert ta == want[4]
     finally:
         al.close()
+
+
+def test_pipeline_early_start_equals_batch_by_batch(emu, monkeypatch):
+    """Round 4: lanes that run out of sub-batches of the batch being mapped start on the batch the pipeline has handed over next, before that
+    batch's own mm_gpu_map_staged call (Mapper::stage(may_start_early)).  Batches cut into sub-batches of three reads, so that every batch has
+    a tail: the text of every batch equals stage + run + format of the same batch, in several passes, early starts did happen, and the same
+    with MM2AMD_NO_EARLY_START-style un-pipelined calls in between (a re-run of the current batch, a replaced hand-over)."""
+    monkeypatch.setenv("MM2AMD_SUBBATCH_READS", "3")
+    refs, rds = _reads(41, 14, 2500, 0.1, 300000)
+    al = emu.Aligner(refs, preset="map-ont", names=["chr1", "chr2"], n_threads=4, sam=True)
+    try:
+        base = emu.Batch(rds)
+        batches = [base.rotated(k) for k in (0, 3, 7)] + [emu.Batch(rds[:2]), emu.Batch([]), base.rotated(11), emu.Batch(rds[4:9])]
+        want = []
+        for b in batches:
+            al.stage(b)
+            n_reg, reg, rep = al.run(raw=True)
+            want.append(al.format_raw(n_reg, reg, rep))
+            al.free_raw(n_reg, reg)
+            assert al.last_stats()["n_early_sub"] == 0  # (an un-queued hand-over never starts early)
+        n_early = 0
+        for _ in range(3):
+            got = []
+            def on_text(b, addr, ln):
+                got.append(C.string_at(addr, ln))
+            def on_mapped(b, n_reg, reg, rep_len):
+                nonlocal n_early
+                n_early += int(al.last_stats()["n_early_sub"])
+            total = al.pipeline(batches, on_text=on_text, on_mapped=on_mapped)
+            assert got == want and total == sum(len(t) for t in want)
+            # between two pipelines: the un-pipelined calls still work on a context whose lanes have been running ahead
+            al.stage(batches[1])
+            al.stage(batches[3])
+            a = al.run(raw=True)
+            assert al.format_raw(*a) == want[3]
+            al.free_raw(a[0], a[1])
+        assert n_early > 0, "no sub-batch was started before its batch's mapping call"
+    finally:
+        al.close()
