@@ -194,6 +194,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=0, help="mean read length (0: 10000 for map-ont, 15000 otherwise)")
     ap.add_argument("--err", type=float, default=-1.0, help="per-base error rate (<0: 0.12 for map-ont, 0.005 otherwise)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
+    ap.add_argument("--as-rank-of", type=int, default=0, help="N > 1 (one GPU): after the N=1 measurement, map what ONE rank of an N-GPU strong-scaling job maps -- a 1/N base-balanced "
+                    "share of every batch, with host_cpus()/N threads, hit packing included -- and report config.as_rank_of: the share's rate, N x that rate, its ratio to the N=1 rate "
+                    "(predicted strong scaling if the ranks do not contend) and the host core-seconds per Gbase, which is what bounds the N-GPU line under a shared CPU quota")
+    ap.add_argument("--timed-only", action="store_true", help="profiling runs: nothing after the timed steps (no resident / one-lane / formatting / CPU passes), so that the end of a kernel trace IS the timed pipeline")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -356,7 +360,7 @@ def main():
         return h.hexdigest()
     pipeline_text_identical = None
     step_text_lengths = sorted({ln for _, ln in step_done})
-    if last_text and world == 1:
+    if last_text and world == 1 and not a.timed_only:
         b_last, addr, ln = last_text[0]
         h_pipe = text_hash(addr, ln)
         al.stage(b_last)
@@ -391,7 +395,7 @@ def main():
     # side figures (rank 0, N = 1): the mapping call alone with the batch already resident (rounds 1-2's headline), and hand-over + mapping
     # one after the other (no pipeline)
     resident = pcie = None
-    if world == 1:
+    if world == 1 and not a.timed_only:
         resident = min(one_step(a.warmup + a.steps + i) for i in range(2))
         pcie = one_step(a.warmup + a.steps + 2, staged_outside=False)
     # un-overlapped kernel times: one more pass over the same batch with ONE lane (sub-batches one after the other, so no two
@@ -399,7 +403,7 @@ def main():
     prof1 = None
     t_one = None
     stage_cpu = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.timed_only:
         os.environ["MM2AMD_ACTIVE_LANES"] = "1"
         os.environ["MM2AMD_NO_SIDE_STREAM"] = "1"  # the lane-exact DP launches after the gap-fill kernel instead of beside it
         mm.profile_enable(True)
@@ -410,7 +414,7 @@ def main():
         mm.profile_enable(False)
         del os.environ["MM2AMD_ACTIVE_LANES"], os.environ["MM2AMD_NO_SIDE_STREAM"]
     fmt = None
-    if world == 1:  # the output stage on its own (it runs beside the mapping in the timed region)
+    if world == 1 and not a.timed_only:  # the output stage on its own (it runs beside the mapping in the timed region)
         try:
             b = base
             al.stage(b)
@@ -534,7 +538,7 @@ def main():
                 pass
 
     cpu = None
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and not a.timed_only:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import reflib
@@ -576,6 +580,44 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "Gbases/s", "cores": ncpu, "kind": "reference", "sample": "unavailable: %s" % e}
 
+    as_rank = None
+    if a.as_rank_of > 1 and world == 1:
+        N = a.as_rank_of
+        try:
+            al.close()
+            thr_share = max(1, n_threads // N)
+            cut = shard.split_by_bases([sum(len(x) for x in r[1:]) for r in named], N)
+            share = named[cut[0]:cut[1]]
+            share_bases = sum(sum(len(x) for x in r[1:]) for r in share)
+            al = mm.Aligner(refs, preset=a.preset, names=names, n_threads=thr_share, sam=True)
+            base_s = mm.Batch(share)
+            gb_s = shard.GatherBuffers()
+            def on_mapped_s(b, n_reg, reg, rep_len):  # a rank's part of the hit gather: the records packed into the pinned buffer (the transfer itself needs peers)
+                shard.pack_hits(L, n_reg, reg, gb_s)
+            def pipe_s(steps):
+                bs = [base_s.rotated((st * 997) % max(len(share), 1)) for st in steps]
+                barrier()
+                t = time.time()
+                al.pipeline(bs, text=True, on_mapped=on_mapped_s)
+                barrier()
+                return time.time() - t
+            pipe_s(range(max(a.warmup, 2)))
+            k_s = max(a.steps, 8)
+            ru_a = resource.getrusage(resource.RUSAGE_SELF)
+            t_s = pipe_s(range(100, 100 + k_s))
+            ru_b = resource.getrusage(resource.RUSAGE_SELF)
+            cpu_s_share = (ru_b.ru_utime - ru_a.ru_utime + ru_b.ru_stime - ru_a.ru_stime) / k_s
+            rate_s = share_bases * k_s / t_s / 1e9
+            as_rank = {"n_gpus": N, "reads_this_rank": len(share), "share_gbases": round(share_bases / 1e9, 4), "host_threads": thr_share, "steps": k_s,
+                       "ms_per_step": round(t_s / k_s * 1e3, 2), "share_gbases_per_s": round(rate_s, 5), "n_x_share_gbases_per_s": round(N * rate_s, 4),
+                       "predicted_strong_scaling": round(N * rate_s / value, 3), "host_cpu_s_per_gbase": round(cpu_s_share / max(share_bases / 1e9, 1e-12), 3),
+                       "host_cpu_s_per_gbase_n1": round(host_cpu_s / max(batch_bases / 1e9, 1e-12), 3),
+                       "cpu_quota_of_this_box": ncpu,
+                       "cpu_bound_gbases_per_s_if_n_ranks_share_this_quota": round(ncpu / max(cpu_s_share / max(share_bases / 1e9, 1e-12), 1e-9), 3),
+                       "note": "one rank's share of every batch on one GPU with 1/N of this box's CPU quota; N ranks that do not contend for CPU, PCIe or the formatting rank reach N x the share rate; under ONE shared quota of this size the job is bounded by quota / core-seconds per Gbase"}
+            log("as rank of %d: %s" % (N, as_rank))
+        except Exception as e:  # a side figure, never required
+            as_rank = {"error": str(e)}
     rl = "2 x %d b reads" % mean_len if pairs else "%d kb reads" % (mean_len // 1000)
     out = {"metric": "aligned Gbases/sec (%s, %s, -a)" % (a.preset, rl), "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None,
@@ -592,7 +634,8 @@ def main():
                       "pipeline_text_identical": pipeline_text_identical, "timed_steps_text_bytes": step_text_lengths,
                       "resident_gbases_per_s": round(batch_bases / resident / 1e9, 5) if resident else None,
                       "handover_then_map_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
-                      "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits},
+                      "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits, "as_rank_of": as_rank,
+                      "cpu_quota": ncpu},
            "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
     print(json.dumps(out), flush=True)
     al.close()

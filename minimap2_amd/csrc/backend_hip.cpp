@@ -87,7 +87,8 @@ public:
 		I_.name_rank = nullptr, I_.seq_len = nullptr;
 		fi_names_ = &fi.names, fi_seq_len_ = &fi.seq_len; // fi outlives the backend (it is the mapper's index)
 		while ((1ull << rid_bits_) < fi.n_seq) ++rid_bits_;
-		n_lanes_ = 5; // sub-batches in flight; beyond ~5 the GPU is saturated
+		n_lanes_ = 8; // sub-batches in flight.  Rounds 1-3: 5 (more made no difference while the lanes' waits spun on the CPU quota); with the lanes starting
+		              // on the next batch early, 8-10 keep seeding, sorting and DP kernels of different sub-batches on the GPU together: +3-4 % (profiles/r04, call 16)
 		if (const char *e = getenv("MM2AMD_LANES")) n_lanes_ = std::max(1, std::min(kMaxProfLanes, atoi(e)));
 		for (int i = 0; i < n_lanes_; ++i) {
 			lanes_.emplace_back(new Lane);

@@ -63,7 +63,7 @@ private:
 	std::map<std::string, KernelStat> stats_;
 };
 
-constexpr int kMaxProfLanes = 8, kMaxReplicas = 16;
+constexpr int kMaxProfLanes = 16, kMaxReplicas = 16;
 KernelProfiler &kernel_profiler(int lane = 0, int replica = 0); // device_ctx.cpp; one per backend lane of every replica (each is used by one host thread at a time)
 
 } // namespace mm2amd

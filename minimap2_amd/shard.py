@@ -76,8 +76,10 @@ def unpack_hits(L, payload, n_frag):
 
 def gather_payloads(payload, dst=0, device=None, bufs=None):
     """The final hit gather: every rank contributes one uint8 payload, rank `dst` receives them in rank order.
-    Sizes travel in one all_gather; the data in one gather of equally padded buffers (one xGMI hop per peer).  With `bufs`
-    (GatherBuffers) the device buffers are reused from batch to batch and the received payloads land in one pinned host buffer.
+    Sizes travel in one all_gather; the data as UNPADDED point-to-point transfers, grouped into one RCCL launch (batch_isend_irecv: every peer
+    sends exactly its bytes over its own xGMI link straight into its slice of one contiguous receive buffer -- round 3 gathered buffers padded
+    to the largest payload).  With `bufs` (GatherBuffers) the device buffers are reused from batch to batch and the received payloads reach
+    the host in ONE copy into a pinned buffer.
     Returns the list of payload tensors on dst (host tensors when `bufs` is given and the device is a GPU), None elsewhere."""
     if not dist.is_initialized():  # single process: the gather is the identity
         return [payload]
@@ -87,31 +89,39 @@ def gather_payloads(payload, dst=0, device=None, bufs=None):
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size)
     sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
     on_gpu = torch.device(dev).type == "cuda"
-    if bufs is not None:
-        bufs.send = GatherBuffers._grow(bufs.send, cap, device=dev)
-        send = bufs.send[:cap]
-    else:
-        send = torch.empty(cap, dtype=torch.uint8, device=dev)
-    send[:payload.numel()].copy_(payload, non_blocking=True)
-    recv = None
-    if rank == dst:
-        if bufs is not None:
-            bufs.recv = GatherBuffers._grow(bufs.recv, cap * world, device=dev)
-            recv = list(bufs.recv[:cap * world].view(world, cap).unbind(0))
-        else:
-            recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.gather(send, recv, dst=dst)
+    n = payload.numel()
     if rank != dst:
+        if n > 0:
+            if bufs is not None:
+                bufs.send = GatherBuffers._grow(bufs.send, n, device=dev)
+                send = bufs.send[:n]
+            else:
+                send = torch.empty(n, dtype=torch.uint8, device=dev)
+            send.copy_(payload, non_blocking=True)
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, dst)]):
+                req.wait()
+            if on_gpu:  # (the pinned pack buffer and the send buffer are reused by the next batch: the copy and the send must have left them)
+                torch.cuda.current_stream().synchronize()
         return None
-    if bufs is not None and on_gpu:  # device -> one pinned host buffer, the payloads back to back
-        bufs.host = GatherBuffers._grow(bufs.host, sum(sizes), pin_memory=True)
-        out, o = [], 0
-        for r in range(world):
-            bufs.host[o:o + sizes[r]].copy_(recv[r][:sizes[r]], non_blocking=True)
-            out.append(bufs.host[o:o + sizes[r]])
-            o += sizes[r]
+    total = sum(sizes)
+    offs = [0]
+    for r in range(world):
+        offs.append(offs[-1] + sizes[r])
+    if bufs is not None:
+        bufs.recv = GatherBuffers._grow(bufs.recv, max(total, 1), device=dev)
+        recv = bufs.recv[:max(total, 1)]
+    else:
+        recv = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    ops = [dist.P2POp(dist.irecv, recv[offs[r]:offs[r + 1]], r) for r in range(world) if r != dst and sizes[r] > 0]
+    if n > 0:
+        recv[offs[dst]:offs[dst + 1]].copy_(payload, non_blocking=True)
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if bufs is not None and on_gpu:  # device -> one pinned host buffer, the payloads back to back, one copy
+        bufs.host = GatherBuffers._grow(bufs.host, max(total, 1), pin_memory=True)
+        bufs.host[:total].copy_(recv[:total], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        return out
-    return [recv[r][:sizes[r]] for r in range(world)]
+        return [bufs.host[offs[r]:offs[r + 1]] for r in range(world)]
+    return [recv[offs[r]:offs[r + 1]] for r in range(world)]

@@ -26,9 +26,9 @@ for S in "$@"; do
     suite:*) (timeout 1200 python -m pytest tests -x -q -m gpu -k "${S#suite:}" 2>&1 | tail -12) > $O/r04_pytest_gpu_k_$V.log; tail -3 $O/r04_pytest_gpu_k_$V.log ;;
     bench)   cd /tmp; timeout 900 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/r04_bench_full_$V.json 2> $O/r04_bench_full_$V.log; line $O/r04_bench_full_$V.json ;;
     bench:*) cd /tmp; timeout 900 python $R/bench.py --steps ${S#bench:} --warmup 3 > $O/r04_bench_full_$V.json 2> $O/r04_bench_full_$V.log; line $O/r04_bench_full_$V.json ;;
-    prof)    cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/r04_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
+    prof)    cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 8 --warmup 2 --timed-only > $O/r04_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
              python $R/tools/rocpd_summary.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) > $O/r04_bench_full_kernel_stats_$V.txt
-             python $R/tools/exposed_time.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) 2.5 > $O/r04_exposed_time_$V.txt 2>&1; cat $O/r04_exposed_time_$V.txt; rm -rf $O/prof_ont; head -14 $O/r04_bench_full_kernel_stats_$V.txt ;;
+             python $R/tools/exposed_time.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) 3.0 > $O/r04_exposed_time_$V.txt 2>&1; cat $O/r04_exposed_time_$V.txt; rm -rf $O/prof_ont; head -14 $O/r04_bench_full_kernel_stats_$V.txt ;;
     pmc)     cd /tmp; MM2AMD_COMMIT=$V timeout 900 python $R/tools/pmc_traffic.py --out $O/pmc_traffic_$V.json > $O/pmc_traffic_$V.log 2>&1; tail -3 $O/pmc_traffic_$V.log | cut -c1-300 ;;
     smoke)   python -c "import __graft_entry__ as g; g.smoke()" > $O/r04_smoke_$V.log 2>&1; tail -1 $O/r04_smoke_$V.log ;;
     sh:*)    bash -c "${S#sh:}" ;;
