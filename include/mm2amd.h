@@ -61,6 +61,23 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
                            int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
 
+/* Batched mm_update_extra (align.c:254-303, with mm_append_cigar :320-334 and mm_fix_cigar :105-181): a region's window CIGARs are stitched,
+ * indels left-aligned, I/D clusters merged, empty operations and a leading gap dropped, and the block / match lengths, ambiguous bases and
+ * the best-scoring segment (dp_max) counted -- region_finish_kernel, one wavefront per region.  query / target: nt4 codes (0-3, 4 = N) of
+ * the aligned stretches; piece[i] / piece_len[i]: the windows' CIGARs in alignment order.  cigar_pool must hold the sum of all piece lengths
+ * (MM2AMD_ENOMEM otherwise).  Results are those of the reference for every input the reference accepts (its asserts hold: the operations
+ * cover exactly qlen and tlen); n_cigar < 0 marks a region whose operations do not. */
+typedef struct {
+	const uint8_t *query, *target;
+	int32_t qlen, tlen;
+	int32_t n_pieces;
+	const uint32_t *const *piece;
+	const int32_t *piece_len;
+} mm2amd_fin_job_t;
+typedef struct { int32_t n_cigar, blen, mlen, n_ambi, dp_max, qshift, tshift, is_spliced; uint32_t cigar_off; } mm2amd_fin_res_t;
+int mm2amd_update_extra_batch(int n_jobs, const mm2amd_fin_job_t *jobs, const int8_t *mat25, int8_t q, int8_t e, int log_gap,
+                              mm2amd_fin_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
+
 /* Batched ksw_extz2_sse (ksw2_extz2_sse.c:25, ksw2.h:70-71): single-affine gap cost; same contract as above. */
 int mm2amd_ksw_extz2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);

@@ -23,6 +23,16 @@ class KswJob(C.Structure):  # mm2amd_ksw_job_t
                 ("zdrop", C.c_int32), ("end_bonus", C.c_int32), ("flag", C.c_int32)]
 
 
+class FinJob(C.Structure):  # mm2amd_fin_job_t
+    _fields_ = [("query", C.c_void_p), ("target", C.c_void_p), ("qlen", C.c_int32), ("tlen", C.c_int32), ("n_pieces", C.c_int32),
+                ("piece", C.POINTER(C.POINTER(C.c_uint32))), ("piece_len", C.POINTER(C.c_int32))]
+
+
+class FinRes(C.Structure):  # mm2amd_fin_res_t
+    _fields_ = [("n_cigar", C.c_int32), ("blen", C.c_int32), ("mlen", C.c_int32), ("n_ambi", C.c_int32), ("dp_max", C.c_int32), ("qshift", C.c_int32),
+                ("tshift", C.c_int32), ("is_spliced", C.c_int32), ("cigar_off", C.c_uint32)]
+
+
 class KswRes(C.Structure):  # mm2amd_ksw_res_t
     _fields_ = [(n, C.c_int32) for n in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score",
                                          "n_cigar", "reach_end")] + [("cigar_off", C.c_uint32)]
@@ -114,6 +124,8 @@ def _bind(L):
         L.mm2amd_ksw_exts2_batch.restype = C.c_int
         L.mm2amd_ksw_exts2_batch.argtypes = [C.c_int, C.POINTER(KswJob), C.c_int8, C.c_char_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
                                              C.POINTER(KswRes), C.POINTER(C.c_uint32), C.c_size_t]
+        L.mm2amd_update_extra_batch.restype = C.c_int
+        L.mm2amd_update_extra_batch.argtypes = [C.c_int, C.POINTER(FinJob), C.c_char_p, C.c_int8, C.c_int8, C.c_int, C.POINTER(FinRes), C.POINTER(C.c_uint32), C.c_size_t]
         L.mm2amd_idx_str.restype = vp
         L.mm2amd_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.mm2amd_idx_destroy.argtypes = [vp]
@@ -165,6 +177,32 @@ def lib(path=None):
 def _check(rc, L=None):
     if rc != 0:
         raise Mm2AmdError("mm2amd error %d: %s" % (rc, (L or lib()).mm2amd_last_error().decode()))
+
+
+def update_extra_batch(jobs, mat, q, e, log_gap):
+    """jobs: list of (query_codes, target_codes, [piece, ...]) -- nt4 codes 0..4 of the aligned stretches and the windows' CIGARs (sequences of
+    len << 4 | op) in alignment order.  Returns a list of (cigar_tuple, blen, mlen, n_ambi, dp_max, qshift, tshift, is_spliced) -- what the
+    reference's mm_update_extra (align.c:254-303) leaves in the hit record -- or None for a region whose operations do not cover its stretches."""
+    n = len(jobs)
+    arr = (FinJob * max(n, 1))()
+    keep, tot = [], 0
+    for i, (qs, ts, pieces) in enumerate(jobs):
+        qb, tb = bytes(qs), bytes(ts)
+        parr = [(C.c_uint32 * max(len(p_), 1))(*p_) for p_ in pieces]
+        pp = (C.POINTER(C.c_uint32) * max(len(pieces), 1))(*[C.cast(a, C.POINTER(C.c_uint32)) for a in parr])
+        pl = (C.c_int32 * max(len(pieces), 1))(*[len(p_) for p_ in pieces])
+        keep.append((qb, tb, parr, pp, pl))
+        arr[i].query, arr[i].target = C.cast(C.c_char_p(qb), C.c_void_p), C.cast(C.c_char_p(tb), C.c_void_p)
+        arr[i].qlen, arr[i].tlen, arr[i].n_pieces, arr[i].piece, arr[i].piece_len = len(qb), len(tb), len(pieces), pp, pl
+        tot += sum(len(p_) for p_ in pieces)
+    res = (FinRes * max(n, 1))()
+    pool = (C.c_uint32 * max(tot, 1))()
+    _check(lib().mm2amd_update_extra_batch(n, arr, bytes(mat), q, e, 1 if log_gap else 0, res, pool, max(tot, 1)))
+    out = []
+    for i in range(n):
+        r = res[i]
+        out.append(None if r.n_cigar < 0 else (tuple(pool[r.cigar_off:r.cigar_off + r.n_cigar]), r.blen, r.mlen, r.n_ambi, r.dp_max, r.qshift, r.tshift, r.is_spliced))
+    return out
 
 
 def ksw_extz2_batch(jobs, mat, gapo, gape):

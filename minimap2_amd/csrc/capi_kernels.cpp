@@ -8,6 +8,7 @@
 #include "device_ctx.hpp"
 #include "ksw_host.hpp"
 #include "kernel_prof.hpp"
+#include "region_finish.hpp"
 #include <map>
 
 namespace mm2amd { int capi_fail(int code, const std::string &msg); }
@@ -118,6 +119,80 @@ int mm2amd_ksw_exts2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
 {
 	return ksw_batch(2, noncan, n_jobs, jobs, m, mat, gapo, gape, gapo2, 0, res, cigar_pool, cigar_pool_cap);
+}
+
+int mm2amd_update_extra_batch(int n_jobs, const mm2amd_fin_job_t *jobs, const int8_t *mat25, int8_t q, int8_t e, int log_gap,
+                              mm2amd_fin_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
+{
+	if (n_jobs < 0 || (n_jobs > 0 && (!jobs || !res)) || !mat25) return fail(MM2AMD_EINVAL, "[mm2amd] update_extra_batch: bad arguments");
+	if (n_jobs == 0) return 0;
+	return guarded([&]() -> int {
+		DeviceCtx &dc = device_ctx();
+		std::lock_guard<std::mutex> lk(dc.mu);
+		ensure_device(dc);
+		std::vector<FinRegion> regs(n_jobs);
+		std::vector<FinPiece> pieces;
+		std::vector<uint32_t> cig;
+		size_t qtot = 0, ttot = 0, out_words = 0;
+		uint32_t longest = 1;
+		for (int i = 0; i < n_jobs; ++i) {
+			const mm2amd_fin_job_t &j = jobs[i];
+			if (j.qlen < 0 || j.tlen < 0 || j.n_pieces < 0 || (j.n_pieces > 0 && (!j.piece || !j.piece_len))) return fail(MM2AMD_EINVAL, "[mm2amd] update_extra_batch: bad job");
+			FinRegion &r = regs[i];
+			r.q_pos = qtot, r.t_pos = ttot, r.piece0 = (uint32_t)pieces.size(), r.n_pieces = (uint32_t)j.n_pieces, r.out_off = (uint32_t)out_words;
+			r.q_len = j.qlen, r.t_len = j.tlen;
+			uint32_t sum = 0;
+			for (int k = 0; k < j.n_pieces; ++k) {
+				if (j.piece_len[k] < 0) return fail(MM2AMD_EINVAL, "[mm2amd] update_extra_batch: negative piece length");
+				pieces.push_back(FinPiece{ (uint32_t)cig.size(), (uint32_t)j.piece_len[k] });
+				cig.insert(cig.end(), j.piece[k], j.piece[k] + j.piece_len[k]);
+				sum += (uint32_t)j.piece_len[k];
+			}
+			if (sum > (uint32_t)kFinMaxOps) return fail(MM2AMD_EINVAL, "[mm2amd] update_extra_batch: a region has more CIGAR operations than the kernel stages in LDS");
+			longest = std::max(longest, sum);
+			out_words += sum;
+			qtot += ((size_t)j.qlen + 15) & ~(size_t)7, ttot += ((size_t)j.tlen + 15) & ~(size_t)7; // (the kernel reads aligned 8-byte / 8-code blocks)
+		}
+		if (out_words > cigar_pool_cap) return fail(MM2AMD_ENOMEM, "[mm2amd] update_extra_batch: cigar_pool too small (the sum of the piece lengths suffices)");
+		std::vector<uint8_t> hq(qtot + 16, 0);
+		std::vector<uint32_t> hS(ttot / 8 + 4, 0);
+		for (int i = 0; i < n_jobs; ++i) {
+			const mm2amd_fin_job_t &j = jobs[i];
+			if (j.qlen) memcpy(&hq[regs[i].q_pos], j.query, (size_t)j.qlen);
+			for (int32_t t = 0; t < j.tlen; ++t) { const uint64_t o = regs[i].t_pos + (uint64_t)t; hS[o >> 3] |= (uint32_t)(j.target[t] & 0xf) << ((o & 7) << 2); }
+		}
+		DevBuf<uint8_t> d_q;
+		DevBuf<uint32_t> d_S, d_cig, d_out;
+		DevBuf<FinRegion> d_regs;
+		DevBuf<FinPiece> d_pieces;
+		DevBuf<FinResult> d_res;
+		d_q.ensure(hq.size()), d_S.ensure(hS.size()), d_cig.ensure(cig.size() + 1), d_out.ensure(out_words + 1), d_regs.ensure(n_jobs), d_pieces.ensure(pieces.size() + 1), d_res.ensure(n_jobs);
+		HIP_CHECK(hipMemcpyAsync(d_q.p, hq.data(), hq.size(), hipMemcpyHostToDevice, dc.stream));
+		HIP_CHECK(hipMemcpyAsync(d_S.p, hS.data(), hS.size() * 4, hipMemcpyHostToDevice, dc.stream));
+		if (!cig.empty()) HIP_CHECK(hipMemcpyAsync(d_cig.p, cig.data(), cig.size() * 4, hipMemcpyHostToDevice, dc.stream));
+		HIP_CHECK(hipMemcpyAsync(d_regs.p, regs.data(), (size_t)n_jobs * sizeof(FinRegion), hipMemcpyHostToDevice, dc.stream));
+		if (!pieces.empty()) HIP_CHECK(hipMemcpyAsync(d_pieces.p, pieces.data(), pieces.size() * sizeof(FinPiece), hipMemcpyHostToDevice, dc.stream));
+		FinParams P;
+		P.regions = d_regs.p, P.n_regions = n_jobs, P.pieces = d_pieces.p, P.cigar_pool = d_cig.p, P.out_pool = d_out.p, P.results = d_res.p;
+		P.qpool = d_q.p, P.S = d_S.p;
+		memcpy(P.mat, mat25, 25);
+		P.q = q, P.e = e, P.log_gap = log_gap ? 1 : 0;
+		P.cap_ops = (int)std::min<uint32_t>((longest + 63) & ~63u, (uint32_t)kFinMaxOps);
+		region_finish_launch(P, dc.stream);
+		std::vector<FinResult> hr(n_jobs);
+		std::vector<uint32_t> ho(out_words + 1);
+		HIP_CHECK(hipMemcpyAsync(hr.data(), d_res.p, (size_t)n_jobs * sizeof(FinResult), hipMemcpyDeviceToHost, dc.stream));
+		if (out_words) HIP_CHECK(hipMemcpyAsync(ho.data(), d_out.p, out_words * 4, hipMemcpyDeviceToHost, dc.stream));
+		HIP_CHECK(hipStreamSynchronize(dc.stream));
+		for (int i = 0; i < n_jobs; ++i) {
+			const FinResult &f = hr[i];
+			mm2amd_fin_res_t &o = res[i];
+			o.n_cigar = f.n_cigar, o.blen = f.blen, o.mlen = f.mlen, o.n_ambi = f.n_ambi, o.dp_max = f.dp_max, o.qshift = f.qshift, o.tshift = f.tshift, o.is_spliced = f.is_spliced;
+			o.cigar_off = regs[i].out_off;
+		}
+		if (out_words) memcpy(cigar_pool, ho.data(), out_words * 4);
+		return 0;
+	});
 }
 
 long long mm2amd_alloc_counter(int which)

@@ -1,0 +1,30 @@
+/* TEST INFRASTRUCTURE ONLY (oracle/Makefile -> oracle/_ref/librefalign.so; never linked into the product).
+ *
+ * The reference's mm_append_cigar / mm_fix_cigar / mm_update_extra (align.c:320-334, :105-181, :254-303) are `static`: to pin the
+ * device's region_finish_kernel against the UNMODIFIED reference on CIGARs no DP would emit (empty operations, I/D clusters, leading
+ * gaps, indels that left-align through whole matches), this translation unit compiles the reference's align.c where it lies
+ * (-I$(REF); nothing is copied) and adds one entry point that calls those functions.  The two external functions align.c defines are
+ * renamed so that the shim can sit beside libminimap2_ref.a. */
+#define mm_enlarge_cigar refshim_mm_enlarge_cigar
+#define mm_align_skeleton refshim_mm_align_skeleton
+#include "align.c"
+
+/* pieces: a region's window CIGARs in alignment order.  Returns the number of CIGAR operations left; res8 = { blen, mlen, n_ambi, dp_max,
+ * qshift, tshift, is_spliced, capacity }. */
+int refshim_update_extra(int n_pieces, const uint32_t *const *pieces, const int32_t *piece_len, int qlen, const uint8_t *qseq, int tlen, const uint8_t *tseq,
+                         const int8_t *mat, int gq, int ge, int log_gap, uint32_t *cigar_out, int32_t *res8)
+{
+	mm_reg1_t r;
+	int i, n;
+	memset(&r, 0, sizeof r);
+	r.qs = 0, r.qe = qlen, r.rs = 0, r.re = tlen, r.rev = 0;
+	for (i = 0; i < n_pieces; ++i) mm_append_cigar(&r, (uint32_t)piece_len[i], pieces[i]);
+	memset(res8, 0, 8 * sizeof(int32_t));
+	if (r.p == 0) return 0;
+	mm_update_extra(&r, qseq, tseq, mat, (int8_t)gq, (int8_t)ge, 0, log_gap);
+	n = (int)r.p->n_cigar;
+	memcpy(cigar_out, r.p->cigar, (size_t)n * 4);
+	res8[0] = r.blen, res8[1] = r.mlen, res8[2] = (int32_t)r.p->n_ambi, res8[3] = r.p->dp_max, res8[4] = r.qs, res8[5] = r.rs, res8[6] = r.is_spliced, res8[7] = (int32_t)r.p->capacity;
+	free(r.p);
+	return n;
+}

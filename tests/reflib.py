@@ -403,3 +403,22 @@ def export_index(al):
     rc = mm.lib().mm2amd_idx_export(al._idx, None, keys.ctypes.data, val_off.ctypes.data, pos.ctypes.data, S.ctypes.data)
     assert rc == 0, mm.lib().mm2amd_last_error()
     return S, keys, val_off, pos
+
+
+REFALIGN_SO = os.path.join(os.path.dirname(REF_SO), "librefalign.so")  # oracle/ref_align_shim.c: the reference's static mm_update_extra behind one entry point
+
+
+def ref_update_extra(qs, ts, pieces, mat, q, e, log_gap):
+    """the UNMODIFIED reference's mm_append_cigar + mm_fix_cigar + mm_update_extra (align.c:320-334, :105-181, :254-303) on a region given as its windows' CIGARs;
+    returns (cigar_tuple, blen, mlen, n_ambi, dp_max, qshift, tshift, is_spliced), the layout of minimap2_amd.update_extra_batch"""
+    L = C.CDLL(REFALIGN_SO)
+    qb, tb = bytes(qs), bytes(ts)
+    parr = [(C.c_uint32 * max(len(p), 1))(*p) for p in pieces]
+    pp = (C.POINTER(C.c_uint32) * max(len(pieces), 1))(*[C.cast(a, C.POINTER(C.c_uint32)) for a in parr])
+    pl = (C.c_int32 * max(len(pieces), 1))(*[len(p) for p in pieces])
+    tot = sum(len(p) for p in pieces)
+    out = (C.c_uint32 * max(tot, 1))()
+    res = (C.c_int32 * 8)()
+    L.refshim_update_extra.restype = C.c_int
+    n = L.refshim_update_extra(len(pieces), pp, pl, len(qb), qb, len(tb), tb, bytes(mat), q, e, 1 if log_gap else 0, out, res)
+    return (tuple(out[:n]), res[0], res[1], res[2], res[3], res[4], res[5], res[6])

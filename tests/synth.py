@@ -272,6 +272,28 @@ def make_weird(outdir, seed=71):
     return ref, rd
 
 
+def make_repeats(outdir, seed=91, n_reads=40, mean=4000, err=0.1, genome=400000):
+    """Noisy reads over a reference peppered with short tandem repeats and homopolymer runs (every ~150 bases a run of 4..40 copies of a
+    1..6-mer): the indels of their alignments fall into repeats, where mm_fix_cigar (align.c:105-181) left-aligns them as far as the
+    repeat goes -- often through the whole match before them (empty operations, merged neighbours), one shift feeding the next.
+    Returns (ref.fa, reads.fa)."""
+    rng = np.random.default_rng(seed)
+    contigs = gen_reference(rng, genome, 2)
+    for c in contigs:
+        p = int(rng.integers(50, 200))
+        while p + 300 < len(c):
+            unit = rng.integers(0, 4, int(rng.integers(1, 7)), dtype=np.uint8)
+            L = int(len(unit) * rng.integers(4, 41))
+            c[p:p + L] = np.tile(unit, L // len(unit) + 1)[:L]
+            p += L + int(rng.integers(60, 240))
+    reads = gen_reads(rng, contigs, n_reads, mean, mean // 4, err)
+    os.makedirs(outdir, exist_ok=True)
+    ref, rd = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa")
+    write_fasta(ref, ["c1", "c2"], contigs)
+    write_fasta(rd, ["rp%d" % i for i in range(n_reads)], reads)
+    return ref, rd
+
+
 def make_overlaps(outdir, seed=81, n_reads=60, genome=120000):
     """An all-vs-all read set: noisy reads drawn densely from a small genome (every read overlaps several others, on either
     strand), names in an order unrelated to position, two reads sharing one name, one read contained in another, a read

@@ -14,6 +14,7 @@ import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
+EMU = os.environ.get("MM2AMD_EMU") == "1"
 DROPIN = os.path.join(HERE, "_build", "dropin_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_gpu")  # MM2AMD_EMU=1: tests/conftest.py
 
 
@@ -77,6 +78,19 @@ def test_regions_finished_on_the_device(case, tmp_path):
         ours = subprocess.run([DROPIN, "-x", "map-ont", "-t", "4", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=env).stdout
         theirs = subprocess.run([REF_BIN, "-x", "map-ont", "-t", "4", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
         assert G.strip_pg(ours) == G.strip_pg(theirs)
+
+
+@pytest.mark.parametrize("preset,err", [("map-ont", 0.1), ("map-hifi", 0.02), ("lr:hq", 0.05)])
+def test_device_finish_on_repeat_rich_reads(preset, err, tmp_path):
+    """region_finish_kernel (round 4: one wave per region, mm_fix_cigar's left alignment as a prefix scan, two compactions) on reads whose indels
+    sit in tandem repeats and homopolymers: SAM == the compiled reference with the regions finished on the device and on the host"""
+    ref, reads = synth.make_repeats(str(tmp_path), seed=93, n_reads=12 if EMU else 400, mean=3000 if EMU else 6000, err=err, genome=200000 if EMU else 2000000)
+    theirs = subprocess.run([REF_BIN, "-x", preset, "-t", "8", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    for fin in ("1", "0"):
+        env = dict(os.environ, MM2AMD_DEVICE_FINISH=fin)
+        ours = subprocess.run([DROPIN, "-x", preset, "-t", "8", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=env).stdout
+        assert G.strip_pg(ours) == G.strip_pg(theirs), "MM2AMD_DEVICE_FINISH=%s" % fin
+    assert theirs.count(b"\n") > (12 if EMU else 400)
 
 
 def test_one_by_one_calls_on_gpu(tmp_path):

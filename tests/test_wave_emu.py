@@ -244,3 +244,37 @@ def test_pipeline_early_start_equals_batch_by_batch(emu, monkeypatch):
         assert n_early > 0, "no sub-batch was started before its batch's mapping call"
     finally:
         al.close()
+
+
+@pytest.mark.parametrize("preset,err", [("map-ont", 0.1), ("map-hifi", 0.02)])
+def test_device_finish_on_repeat_rich_reads(preset, err, tmp_path):
+    """region_finish_kernel (round 4: one wave per region, mm_fix_cigar's left alignment as a prefix scan over x -> min(m, L + x), empty operations
+    and equal neighbours removed by two compactions) on reads whose indels sit in tandem repeats and homopolymers -- shifts through whole
+    matches, chains of shifts, leading gaps: SAM == the compiled reference, == the host's mm_update_extra"""
+    if not os.path.exists(G.REF_BIN) or not os.path.exists(DROPIN_EMU):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    ref, rd = synth.make_repeats(str(tmp_path), seed=91 if preset == "map-ont" else 92, n_reads=16, mean=3000, err=err, genome=200000)
+    want = subprocess.run([G.REF_BIN, "-x", preset, "-t", "2", "-a", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    outs = []
+    for fin in ("1", "0"):
+        outs.append(subprocess.run([DROPIN_EMU, "-x", preset, "-t", "2", "-a", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True,
+                                   env=dict(os.environ, MM2AMD_DEVICE_FINISH=fin, MM2AMD_FIN_CHECK="1")).stdout)
+    assert G.strip_pg(outs[0]) == G.strip_pg(want)
+    assert G.strip_pg(outs[1]) == G.strip_pg(want)
+    assert want.count(b"\n") > 16
+
+
+def test_update_extra_kernel_equals_the_reference(emu):
+    """region_finish_kernel's source through the kernel-level C ABI against the reference's own static mm_update_extra (oracle/ref_align_shim.c) on
+    adversarial CIGARs: tests/test_gpu_update_extra.py's generator, the CPU suite's share"""
+    import test_gpu_update_extra as T
+    if not os.path.exists(reflib.REFALIGN_SO):
+        pytest.skip("oracle/_ref/librefalign.so not built")
+    rng = np.random.default_rng(5)
+    mat = reflib.ts_mat(2, 4)
+    jobs = [T.random_region(rng, int(rng.choice([1, 2, 3, 8, 40, 150])), int(rng.choice([1, 2, 4])), float(rng.choice([0.0, 0.03, 0.1])), float(rng.choice([0.0, 0.02, 0.1]))) for _ in range(150)]
+    jobs += [(b"", b"", []), (b"\0\0\0\1", b"\0\1", [[2 << 4 | 1], [2 << 4]])]
+    for log_gap in (1, 0):
+        got = emu.update_extra_batch(jobs, mat, 4, 2, log_gap)
+        for i, (qs, ts, pieces) in enumerate(jobs):
+            assert got[i] == reflib.ref_update_extra(qs, ts, pieces, mat, 4, 2, log_gap), i
