@@ -527,9 +527,11 @@ public:
 	bool supports_long_join() const override { return true; }
 	bool finishes_regions() const override
 	{
+		// Round 4: on by default.  The kernel costs 18 ms per 1-Gbase step (round 3: 56) and takes 1.5 host core-seconds per step off the host (5.5 -> 3.9):
+		// at 16 threads the pipeline's rate is the same either way, with fewer it is higher.  MM2AMD_DEVICE_FINISH=0: the host's mm_update_extra (A/B checks).
 		const char *e = getenv("MM2AMD_DEVICE_FINISH");
 		if (e && *e) return *e != '0';
-		return n_threads_ < 12;
+		return true;
 	}
 	void finish_regions(int lane_id, const std::vector<FinRegion> &regions, const std::vector<FinPiece> &pieces, size_t out_words, const int8_t *mat25, int q, int e, bool log_gap,
 	                    std::vector<FinResult> &results, const uint32_t **cigars) override
