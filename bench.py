@@ -29,6 +29,12 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# The mapper drives eight lanes, each with a stream for the register-resident kernels and one for the lane-exact ones, plus the hand-over's stream.
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default -- and launches that share a queue run
+# one after the other: with 4, on average 3.4 kernels were in flight and the seeding kernels of one lane waited behind the DP kernels of another
+# (profiles/r04: 1.85 -> 2.01 Gbases/s with 16).  Read when the runtime initialises, i.e. before the first HIP call of the process: set here, before
+# torch touches the device; libmm2amd.so does the same for processes whose first HIP call is its own (capi_common.cpp); INTEGRATION.md section 5.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("MM2AMD_MALLOPT", "1")  # the bench owns its process: let the library keep freed host memory
 sys.path.insert(0, ROOT)
 

@@ -1,5 +1,6 @@
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include "../../include/mm2amd.h"
@@ -25,6 +26,12 @@ int effective_cpus()
 	}();
 	return n;
 }
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); launches that share a queue run one after
+// the other.  A mapper drives 8 lanes x 2 streams + the hand-over's: with 4 queues a lane's seeding kernels wait behind another lane's DP kernels
+// (bench.py: 1.85 -> 2.01 Gbases/s with 16).  The runtime reads the variable when it initialises, at the process's first HIP call -- so a
+// process whose first HIP call is this library's gets the setting from here (never overriding the user's); one that has initialised HIP before
+// loading the library (a Python process that imported torch and touched the device) sets it itself: INTEGRATION.md section 5.
+namespace { struct HwQueueDefault { HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_hw_queue_default; }
 static thread_local std::string g_last_error;
 void capi_set_error(const std::string &msg) { g_last_error = msg; }
 int capi_fail(int code, const std::string &msg) { g_last_error = msg; return code; }

@@ -277,7 +277,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 			int blocks_per_cu;
 			if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (eight register sets: 174 VGPRs)
 			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
-			else if (n_stream) blocks_per_cu = ksw_stream_waves(n_stream);
+			else if (n_stream) { static const int sb = getenv("MM2AMD_STREAM_BLOCKS") ? atoi(getenv("MM2AMD_STREAM_BLOCKS")) : 0; blocks_per_cu = sb > 0 ? sb : ksw_stream_waves(n_stream); } // (experiments: fewer resident blocks leave LDS to the other lanes' kernels)
 			else if (fast) blocks_per_cu = fast_waves(tier);
 			else if (P.hbm) blocks_per_cu = 4;
 			else blocks_per_cu = (int)std::min<size_t>((160 * 1024) / (region * P.wpb), kMaxWavesPerCU / (P.wpb * P.team));
