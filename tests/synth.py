@@ -272,7 +272,7 @@ def make_weird(outdir, seed=71):
     return ref, rd
 
 
-def make_repeats(outdir, seed=91, n_reads=40, mean=4000, err=0.1, genome=400000):
+def make_tandem_reads(outdir, seed=91, n_reads=40, mean=4000, err=0.1, genome=400000):
     """Noisy reads over a reference peppered with short tandem repeats and homopolymer runs (every ~150 bases a run of 4..40 copies of a
     1..6-mer): the indels of their alignments fall into repeats, where mm_fix_cigar (align.c:105-181) left-aligns them as far as the
     repeat goes -- often through the whole match before them (empty operations, merged neighbours), one shift feeding the next.

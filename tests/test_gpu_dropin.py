@@ -84,7 +84,7 @@ def test_regions_finished_on_the_device(case, tmp_path):
 def test_device_finish_on_repeat_rich_reads(preset, err, tmp_path):
     """region_finish_kernel (round 4: one wave per region, mm_fix_cigar's left alignment as a prefix scan, two compactions) on reads whose indels
     sit in tandem repeats and homopolymers: SAM == the compiled reference with the regions finished on the device and on the host"""
-    ref, reads = synth.make_repeats(str(tmp_path), seed=93, n_reads=12 if EMU else 400, mean=3000 if EMU else 6000, err=err, genome=200000 if EMU else 2000000)
+    ref, reads = synth.make_tandem_reads(str(tmp_path), seed=93, n_reads=12 if EMU else 400, mean=3000 if EMU else 6000, err=err, genome=200000 if EMU else 2000000)
     theirs = subprocess.run([REF_BIN, "-x", preset, "-t", "8", "-a", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     for fin in ("1", "0"):
         env = dict(os.environ, MM2AMD_DEVICE_FINISH=fin)

@@ -253,7 +253,7 @@ def test_device_finish_on_repeat_rich_reads(preset, err, tmp_path):
     matches, chains of shifts, leading gaps: SAM == the compiled reference, == the host's mm_update_extra"""
     if not os.path.exists(G.REF_BIN) or not os.path.exists(DROPIN_EMU):
         pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
-    ref, rd = synth.make_repeats(str(tmp_path), seed=91 if preset == "map-ont" else 92, n_reads=16, mean=3000, err=err, genome=200000)
+    ref, rd = synth.make_tandem_reads(str(tmp_path), seed=91 if preset == "map-ont" else 92, n_reads=16, mean=3000, err=err, genome=200000)
     want = subprocess.run([G.REF_BIN, "-x", preset, "-t", "2", "-a", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     outs = []
     for fin in ("1", "0"):
