@@ -75,9 +75,10 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-	const uint32_t S_MISD = pk2(sc_mis - sc_mch), S_SCN = pk2(sc_N), S_Q = pk2(q), S_Q2 = pk2(q2), S_QE = pk2(qe), S_QE2 = pk2(qe2);
-	const uint32_t S_NQE = pk2(nqe), S_NQE2 = pk2(nqe2);
-	const uint32_t P_MCH = pk2v(sc_mch);
+	// the keyed cell (gf_cell_k, ksw_gapfill_dev.hpp): every score difference times 8, the gap states carry their candidate's tag in the low bits
+	const uint32_t S_MISD = pk2(8 * (sc_mis - sc_mch)), S_SCN = pk2(8 * sc_N + GF_K_TS), S_MCH8 = pk2(8 * sc_mch), S_Q = pk2(8 * q), S_Q2 = pk2(8 * q2), S_QE = pk2(8 * qe), S_QE2 = pk2(8 * qe2);
+	const uint32_t S_NQE_X = pk2(8 * nqe + GF_K_TA), S_NQE_Y = pk2(8 * nqe + GF_K_TB), S_NQE2_X = pk2(8 * nqe2 + GF_K_TA2), S_NQE2_Y = pk2(8 * nqe2 + GF_K_TB2);
+	const uint32_t P_MCH = pk2v(8 * sc_mch + GF_K_TS);
 	const uint32_t lane4 = (uint32_t)lane * 4u;
 	uint8_t *const qb = s_q[wave_in_block][0];             // qbB = qb + QCAP
 	const uint8_t *const s_qflat = &s_q[0][0][0];
@@ -152,18 +153,19 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 				for (int par = 0; par < 2; ++par) {
 					const int r = r0 + par;
 					// value of v[-1] / u[r] on the matrix border (ksw2_extd2_sse.c:148-163): depends on r only, so it is shared
-					const int bnd = r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+					const int bnd = 8 * (r == 0 ? nqe : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
 					const uint32_t S_BND = pk2(bnd);
 					const bool topA = r < tlenA && r < n_rowsA, topB = r < tlenB && r < n_rowsB; // the anti-diagonal still starts a new column (t = r)
 					const int edge_set = (r - cb) >> 6, edge_lane = r & 63;                      // (r - cb) >> 6 is outside 0..3 when column r is not in this strip
 					const uint32_t edge_halves = (topA ? 0xffffu : 0u) | (topB ? 0xffff0000u : 0u);
 					// column cb - 1 (the matrix border, or the previous strip's last column at the same query position)
-					uint32_t c0V = S_BND, c0X = S_NQE, c0X2 = S_NQE2;
+					uint32_t c0V = S_BND, c0X = S_NQE_X, c0X2 = S_NQE2_X;
 					if (s > 0) {
 						const uint32_t bi = (uint32_t)(r - cb) < (uint32_t)QCAP ? (uint32_t)(r - cb) : (uint32_t)(QCAP - 1);
 						const uint32_t pv = bV[bi], px = bX[bi], px2 = bX2[bi];
-						c0V = gf_sext8(__builtin_amdgcn_perm(0u, pv, 0x0c010c00u)), c0X = gf_sext8(__builtin_amdgcn_perm(0u, px, 0x0c010c00u));
-						c0X2 = gf_sext8(__builtin_amdgcn_perm(0u, px2, 0x0c010c00u));
+						// (the boundary holds the differences themselves, one byte per job: times 8 and tagged again here)
+						c0V = gf_mad8(gf_sext8(__builtin_amdgcn_perm(0u, pv, 0x0c010c00u)), 0u), c0X = gf_mad8(gf_sext8(__builtin_amdgcn_perm(0u, px, 0x0c010c00u)), pk2(GF_K_TA));
+						c0X2 = gf_mad8(gf_sext8(__builtin_amdgcn_perm(0u, px2, 0x0c010c00u)), pk2(GF_K_TA2));
 					}
 					// register sets from the highest down, so that set c still sees row r-1 in set c-1 when it fetches its carry-ins
 #pragma unroll
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 						const uint32_t vp = dpp_shr1u(cV, V[c]), xp = dpp_shr1u(cX, X[c]), x2p = dpp_shr1u(cX2, X2[c]);
 						if (edge_halves && edge_set == c) { // u[r], y[r], y2[r] take their border values on first use (:156-163)
 							const uint32_t em = lane == edge_lane ? edge_halves : 0u;
-							U[c] = bfi(em, S_BND, U[c]), Y[c] = bfi(em, S_NQE, Y[c]), Y2[c] = bfi(em, S_NQE2, Y2[c]);
+							U[c] = bfi(em, S_BND, U[c]), Y[c] = bfi(em, S_NQE_Y, Y[c]), Y2[c] = bfi(em, S_NQE2_Y, Y2[c]);
 						}
 						// Every lane of the set computes, active or not: a column's registers are only ever read while the column (or its
 						// right neighbour's next cell) is valid -- a column that has not started yet gets u,y,y2 from the border and x,v from
@@ -186,10 +188,10 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 						uint32_t qa = (uint32_t)(qb_addr + r - cb - c * 64) - (uint32_t)lane;
 						qa = qa < qb_last ? qa : qb_last;
 						const uint32_t qv = (uint32_t)s_qflat[qa] | (uint32_t)s_qflat[qa + QCAP] << 16, tv = T[c];
-						// substitution score (match / mismatch, sc_N when either base is ambiguous: code 4 = bit 2), the five candidates, the
-						// direction index d = first of (s, a, b, a2, b2) equal to the maximum, the continuation bits 0x08..0x40 (:235-272)
+						// substitution score (match / mismatch, sc_N when either base is ambiguous: code 4 = bit 2), the five candidates as keys, the
+						// direction = the tag of the maximum = first of (s, a, b, a2, b2) equal to it, the continuation bits (:235-272; gf_cell_k)
 						uint32_t d;
-						gf_cell(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, S_MISD, S_SCN, S_Q, S_Q2, S_QE, S_QE2);
+						gf_cell_k(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, S_MISD, S_SCN, S_MCH8, S_Q, S_Q2, S_QE, S_QE2);
 						if (par == 0) DE[c] = d;
 						else {
 							const uint32_t t = (uint32_t)(cb + c * 64 + lane);
@@ -200,9 +202,9 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 					if (more) { // leave the strip's last column for the next strip: entry r - (cb + 255) = the query position of that cell
 						const uint32_t bi = (uint32_t)(r - (cb + GF_STRIP - 1));
 						if (bi < (uint32_t)QCAP && lane == 63) {
-							bV[bi] = (uint16_t)__builtin_amdgcn_perm(0u, V[GF_NC - 1], 0x0c0c0200u);
-							bX[bi] = (uint16_t)__builtin_amdgcn_perm(0u, X[GF_NC - 1], 0x0c0c0200u);
-							bX2[bi] = (uint16_t)__builtin_amdgcn_perm(0u, X2[GF_NC - 1], 0x0c0c0200u);
+							bV[bi] = (uint16_t)__builtin_amdgcn_perm(0u, gf_asr3(V[GF_NC - 1]), 0x0c0c0200u); // key >> 3 (arithmetic) = the difference: the tag falls off
+							bX[bi] = (uint16_t)__builtin_amdgcn_perm(0u, gf_asr3(X[GF_NC - 1]), 0x0c0c0200u);
+							bX2[bi] = (uint16_t)__builtin_amdgcn_perm(0u, gf_asr3(X2[GF_NC - 1]), 0x0c0c0200u);
 						}
 					}
 				}
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 				const int ii = i - hl * di, jj = j - hl * dj;
 				const bool valid = live && ii >= 0 && jj >= 0;
 				const int rr = ii + jj;
-				const int tmp = valid ? my_dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)] : 0;
+				const int tmp = valid ? gf_k_decode(my_dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)]) : 0;
 				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
 				const unsigned long long bal = __ballot(cont);
 				const uint32_t mine = isB ? (uint32_t)(bal >> 32) : (uint32_t)bal;

@@ -39,6 +39,8 @@ __device__ __forceinline__ uint32_t gf_sext8(uint32_t v)
 	return r;
 }
 
+__device__ __forceinline__ uint32_t gf_asr3(uint32_t v) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 3, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(v)); return r; } // key -> difference
+
 // ---------------------------------------------------------------------------------------------------------
 // The arithmetic of one register set and anti-diagonal (128 cells), in an instruction order of our own.  gfx950 needs one wait
 // state between a packed op and a dependent one; the compiler covers it with an s_nop after nearly every instruction of a
@@ -122,6 +124,93 @@ __device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, u
 	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// gf_cell_k: the same cell with KEYED candidates (round 4).  A third of gf_cell's packed operations only name the direction: four
+// differences against the maximum, four normalisations to 0/1, and a multiply-add chain that turns them into "the first of (s, a, b,
+// a2, b2) that reaches the maximum" (ksw2_extd2_sse.c:235-243) -- packed compares do not exist.  Here every score difference is kept
+// times 8, and the low three bits of a candidate carry a tag that falls with its rank in that order (s 7, a 6, b 5, a2 4, b2 3): the
+// signed maximum of the five KEYS is the maximum value and, among equals, the first candidate, so the direction is the key's low bits
+// (one 32-bit AND on both halves, VOP2: half the issue cost of a packed op) and the twelve operations are gone.  The tags ride in the
+// stored gap states: x carries 6, y 5, x2 4, y2 3 (a = x + v, so the sum has x's tag; u and v carry none), the substitution score gets
+// its 7 from the constants, the gap-open clamp max(., 0) becomes max(., tag), and "the gap continues" (value > 0) becomes key >= 8:
+// min_u16(key, 8 + tag) is tag or 8 + tag, summed with weights 1, 2, 4, 8.  The byte stored per cell is therefore
+//   (7 - d) + 8 fa + 16 fb + 32 fa2 + 64 fb2 + GF_K_BIAS,   GF_K_BIAS = 6 + 2*5 + 4*4 + 8*3 (at most 183),
+// and the traceback -- the only reader -- takes the bias off and flips the low bits (gf_k_decode).  No value leaves the range of a
+// 16-bit half: the reference's 8-bit quantities times 8.  38 packed + 2 VOP2 operations per register set and row instead of 50.
+//   in : x1, o1 as gf_cell; xp (tag 6), vp, x2p (tag 4), u, y (tag 5), y2 (tag 3) -- all times 8
+//   constants: P_MCHT = 8 mch + 7 (VGPR), S_MISD8 = 8 (mis - mch), S_SCNT = 8 sc_N + 7, S_MCH8, S_Q8, S_Q28, S_QE8, S_QE28 = 8 x the cost
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GF_K_TS = 7, GF_K_TA = 6, GF_K_TB = 5, GF_K_TA2 = 4, GF_K_TB2 = 3;
+constexpr int GF_K_BIAS = GF_K_TA + 2 * GF_K_TB + 4 * GF_K_TA2 + 8 * GF_K_TB2;
+__device__ __forceinline__ int gf_k_decode(int byte) { return ((byte - GF_K_BIAS) ^ 7) & 0xff; } // -> the reference's direction byte (d | flags << 3)
+__device__ __forceinline__ void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y,
+                                          uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCHT, uint32_t S_MISD8, uint32_t S_SCNT, uint32_t S_MCH8,
+                                          uint32_t S_Q8, uint32_t S_Q28, uint32_t S_QE8, uint32_t S_QE28)
+{
+	uint32_t a, b, a2, b2, z, z4, m, n, w, tA, tB;
+	asm volatile(
+		"v_pk_add_u16 %[a], %[xp], %[vp]\n\t"
+		"v_pk_min_u16 %[m], %[x1], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_add_u16 %[b], %[y], %[u]\n\t"
+		"v_pk_add_u16 %[a2], %[x2p], %[vp]\n\t"
+		"v_pk_mad_u16 %[z], %[m], %[misd], %[mch]\n\t"
+		"v_pk_add_u16 %[b2], %[y2], %[u]\n\t"
+		"v_pk_max_i16 %[tA], %[a], %[b]\n\t"
+		"v_pk_lshrrev_b16 %[n], 2, %[o1] op_sel_hi:[0,1]\n\t"
+		"v_pk_max_i16 %[tB], %[a2], %[b2]\n\t"
+		"v_pk_sub_u16 %[w], %[scn], %[z]\n\t"
+		"v_pk_max_i16 %[tA], %[tA], %[tB]\n\t"
+		"v_pk_mad_u16 %[z], %[n], %[w], %[z]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_max_i16 %[z4], %[z], %[tA]\n\t"
+		"s_nop 0"
+		: [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [b2] "=&v"(b2), [z] "=&v"(z), [z4] "=&v"(z4), [m] "=&v"(m), [n] "=&v"(n), [w] "=&v"(w), [tA] "=&v"(tA), [tB] "=&v"(tB)
+		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCHT), [misd] "s"(S_MISD8), [scn] "s"(S_SCNT));
+	uint32_t zv, zc, t1, t2, e, un, vn;
+	asm volatile(
+		"v_and_b32 %[zv], 0xfff8fff8, %[z4]\n\t"
+		"v_and_b32 %[e], 0x70007, %[z4]\n\t"
+		"v_pk_min_i16 %[zc], %[zv], %[mch8]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_sub_u16 %[un], %[zc], %[vp]\n\t"
+		"v_pk_sub_u16 %[vn], %[zc], %[u]\n\t"
+		"v_pk_sub_u16 %[t1], %[zc], %[q]\n\t"
+		"v_pk_sub_u16 %[t2], %[zc], %[q2]\n\t"
+		"v_pk_sub_u16 %[a], %[a], %[t1]\n\t"
+		"v_pk_sub_u16 %[b], %[b], %[t1]\n\t"
+		"v_pk_sub_u16 %[a2], %[a2], %[t2]\n\t"
+		"v_pk_sub_u16 %[b2], %[b2], %[t2]\n\t"
+		"v_pk_max_i16 %[a], %[a], 6 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[b], %[b], 5 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[a2], %[a2], 4 op_sel_hi:[1,0]\n\t"
+		"v_pk_max_i16 %[b2], %[b2], 3 op_sel_hi:[1,0]"
+		: [zv] "=&v"(zv), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [un] "=&v"(un), [vn] "=&v"(vn),
+		  [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
+		: [z4] "v"(z4), [vp] "v"(vp), [u] "v"(u), [mch8] "s"(S_MCH8), [q] "s"(S_Q8), [q2] "s"(S_Q28));
+	uint32_t fa, fb, fa2, fb2, xn, yn, x2n, y2n;
+	asm volatile(
+		"v_pk_min_u16 %[fa], %[a], 14 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[xn], %[a], %[qe]\n\t"
+		"v_pk_min_u16 %[fb], %[b], 13 op_sel_hi:[1,0]\n\t"
+		"v_pk_add_u16 %[e], %[e], %[fa]\n\t"
+		"v_pk_sub_u16 %[yn], %[b], %[qe]\n\t"
+		"v_pk_min_u16 %[fa2], %[a2], 12 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fb], 2, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[x2n], %[a2], %[qe2]\n\t"
+		"v_pk_min_u16 %[fb2], %[b2], 11 op_sel_hi:[1,0]\n\t"
+		"v_pk_mad_u16 %[e], %[fa2], 4, %[e] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[y2n], %[b2], %[qe2]\n\t"
+		"v_pk_mad_u16 %[e], %[fb2], 8, %[e] op_sel_hi:[1,0,1]"
+		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n), [e] "+v"(e)
+		: [a] "v"(a), [b] "v"(b), [a2] "v"(a2), [b2] "v"(b2), [qe] "s"(S_QE8), [qe2] "s"(S_QE28));
+	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
+}
+static_assert(GF_K_TA == 6 && GF_K_TB == 5 && GF_K_TA2 == 4 && GF_K_TB2 == 3 && GF_K_TS == 7, "the tags are written into gf_cell_k's instructions");
+
+#else
+constexpr int GF_K_TS = 7, GF_K_TA = 6, GF_K_TB = 5, GF_K_TA2 = 4, GF_K_TB2 = 3;
+constexpr int GF_K_BIAS = GF_K_TA + 2 * GF_K_TB + 4 * GF_K_TA2 + 8 * GF_K_TB2;
+inline int gf_k_decode(int byte) { return ((byte - GF_K_BIAS) ^ 7) & 0xff; }
 #endif // MM2AMD_WAVE_EMU
 
 // ---- mm_test_zdrop's walk over a finished alignment (align.c:46-84), by the 32 lanes of a half-wave ----

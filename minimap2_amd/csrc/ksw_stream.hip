@@ -14,7 +14,8 @@
 // neighbour as always, lane 0 takes the matrix border of the pair it is on.  The query bytes of the pairs in flight sit in an LDS
 // ring addressed by row - column (both halves in one 16-bit load), the direction bytes ([row r: half A, half B][row r + 1: A, B]
 // per lane) in a ring of the last 1024 or 2048 rows in HBM; a pair is traced back (and walked for mm_test_zdrop, gf_zdrop_scan)
-// right after its last row, while its successor is already under way.  The arithmetic of a cell is the same gf_cell.
+// right after its last row, while its successor is already under way.  The arithmetic of a cell is gf_cell_k: the strip kernel's cell with keyed
+// candidates (differences times 8, the direction read off the maximum's low bits: ksw_gapfill_dev.hpp), 38 packed operations instead of 50.
 //
 // At most two pairs are in flight (cur, nxt): nxt is promoted once all of its columns have seen its edge and cur has been traced
 // back; only then is the pair after it fetched (its targets need the s_tn buffer).  Per row pair a bit mask names the register sets
@@ -71,15 +72,16 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-	const uint32_t S_MISD = pk2(sc_mis - sc_mch), S_SCN = pk2(sc_N), S_Q = pk2(q), S_Q2 = pk2(q2), S_QE = pk2(qe), S_QE2 = pk2(qe2);
-	const uint32_t S_NQE = pk2(nqe), S_NQE2 = pk2(nqe2);
-	const uint32_t P_MCH = pk2v(sc_mch);
+	// the keyed cell (gf_cell_k, ksw_gapfill_dev.hpp): every score difference times 8, the gap states carry their candidate's tag in the low bits
+	const uint32_t S_MISD = pk2(8 * (sc_mis - sc_mch)), S_SCN = pk2(8 * sc_N + GF_K_TS), S_MCH8 = pk2(8 * sc_mch), S_Q = pk2(8 * q), S_Q2 = pk2(8 * q2), S_QE = pk2(8 * qe), S_QE2 = pk2(8 * qe2);
+	const uint32_t S_NQE_X = pk2(8 * nqe + GF_K_TA), S_NQE_Y = pk2(8 * nqe + GF_K_TB), S_NQE2_X = pk2(8 * nqe2 + GF_K_TA2), S_NQE2_Y = pk2(8 * nqe2 + GF_K_TB2);
+	const uint32_t P_MCH = pk2v(8 * sc_mch + GF_K_TS);
 	const uint32_t lane4 = (uint32_t)lane * 4u;
 	constexpr int ncol = NC * 64, ST_ROWS = st_rows(NC);
 	uint8_t *const dir = L.dir_pool + (size_t)(2 * slot) * L.slot_bytes; // (ST_ROWS / 2) x ncol dwords
 	uint8_t *const qring = (uint8_t *)&s_qr[wave_in_block][0];
 	const uint32_t qring_off = (uint32_t)wave_in_block * (2u * ST_QRING), lane2 = (uint32_t)lane * 2u; // rings are 4 KB apart: offset | position
-	auto border = [&](int i) { return i == 0 ? nqe : i < long_thres ? -e : i == long_thres ? long_diff : -e2; }; // v[-1] / u[i] on the matrix border (:148-163)
+	auto border = [&](int i) { return 8 * (i == 0 ? nqe : i < long_thres ? -e : i == long_thres ? long_diff : -e2); }; // v[-1] / u[i] on the matrix border (:148-163), times 8
 
 	// the two PAIRS of jobs in flight (a pair = one job per half, consecutive in the launch order, started on the same row): cur (all
 	// its columns started) and nxt (its edge is sweeping the lanes, or it has not started); a half without a job has q = t = 0
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 				const int ii = i - hl * di, jj = j - hl * dj;
 				const bool valid = live && ii >= 0 && jj >= 0;
 				const int rr = my_R + ii + jj;
-				const int tmp = valid ? my_dir[((size_t)((rr >> 1) & (ST_ROWS / 2 - 1)) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)] : 0;
+				const int tmp = valid ? gf_k_decode(my_dir[((size_t)((rr >> 1) & (ST_ROWS / 2 - 1)) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)]) : 0;
 				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
 				const unsigned long long bal = __ballot(cont);
 				const uint32_t mine = isB ? (uint32_t)(bal >> 32) : (uint32_t)bal;
@@ -260,20 +262,20 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 #ifdef MM2AMD_GF_COUNT
 				++n_setrows;
 #endif
-				uint32_t cV = S_BND, cX = S_NQE, cX2 = S_NQE2; // column -1: the matrix border
+				uint32_t cV = S_BND, cX = S_NQE_X, cX2 = S_NQE2_X; // column -1: the matrix border
 				if (c > 0) cV = gf_ror1(V[c - 1]), cX = gf_ror1(X[c - 1]), cX2 = gf_ror1(X2[c - 1]); // lane 0 <- lane 63 of the previous set
 				const uint32_t vp = dpp_shr1u(cV, V[c]), xp = dpp_shr1u(cX, X[c]), x2p = dpp_shr1u(cX2, X2[c]);
 				if (edge_halves && (edge >> 6) == c) { // the lane takes up the next pair: target bases, and u / y / y2 from the border (:156-163)
 					const int t = c * 64 + lane;
 					const uint32_t em = t == edge ? edge_halves : 0u;
 					const uint32_t tn = (uint32_t)s_tn[wave_in_block][0][t] | (uint32_t)s_tn[wave_in_block][1][t] << 16;
-					U[c] = bfi(em, S_BND, U[c]), Y[c] = bfi(em, S_NQE, Y[c]), Y2[c] = bfi(em, S_NQE2, Y2[c]), T[c] = bfi(em, tn, T[c]);
+					U[c] = bfi(em, S_BND, U[c]), Y[c] = bfi(em, S_NQE_Y, Y[c]), Y2[c] = bfi(em, S_NQE2_Y, Y2[c]), T[c] = bfi(em, tn, T[c]);
 				}
 				// query position of this column's cell = row - column, in the ring (byte offset 2 * position; both halves in one 16-bit load)
 				const uint32_t qa = (((uint32_t)(2 * r - 128 * c) - lane2) & (uint32_t)(2 * ST_QRING - 2)) | qring_off;
 				const uint32_t qv = __builtin_amdgcn_perm(0u, (uint32_t)*(const uint16_t *)((const uint8_t *)&s_qr[0][0] + qa), 0x0c010c00u), tv = T[c];
 				uint32_t d;
-				gf_cell(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, S_MISD, S_SCN, S_Q, S_Q2, S_QE, S_QE2);
+				gf_cell_k(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, S_MISD, S_SCN, S_MCH8, S_Q, S_Q2, S_QE, S_QE2);
 				if (par == 0) DE[c] = d;
 				else // (idle lanes store too: their direction bytes are never read)
 					*(uint32_t *)((uint8_t *)prow + c * 256 + lane4) = __builtin_amdgcn_perm(d, DE[c], 0x06040200u); // [even A, even B, odd A, odd B]
