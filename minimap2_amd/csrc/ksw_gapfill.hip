@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	// the keyed cell (gf_cell_k, ksw_gapfill_dev.hpp): every score difference times 8, the gap states carry their candidate's tag in the low bits
-	const uint32_t S_MISD = pk2(8 * (sc_mis - sc_mch)), S_SCN = pk2(8 * sc_N + GF_K_TS), S_MCH8 = pk2(8 * sc_mch), S_Q = pk2(8 * q), S_Q2 = pk2(8 * q2), S_QE = pk2(8 * qe), S_QE2 = pk2(8 * qe2);
-	const uint32_t S_NQE_X = pk2(8 * nqe + GF_K_TA), S_NQE_Y = pk2(8 * nqe + GF_K_TB), S_NQE2_X = pk2(8 * nqe2 + GF_K_TA2), S_NQE2_Y = pk2(8 * nqe2 + GF_K_TB2);
+	const GfK K = gf_k_consts(sc_mch, sc_mis, sc_N, q, e, q2, e2);
+	const uint32_t S_NQE_X = K.nqe_x, S_NQE_Y = K.nqe_y, S_NQE2_X = K.nqe2_x, S_NQE2_Y = K.nqe2_y;
 	const uint32_t P_MCH = pk2v(8 * sc_mch + GF_K_TS);
 	const uint32_t lane4 = (uint32_t)lane * 4u;
 	uint8_t *const qb = s_q[wave_in_block][0];             // qbB = qb + QCAP
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 						// substitution score (match / mismatch, sc_N when either base is ambiguous: code 4 = bit 2), the five candidates as keys, the
 						// direction = the tag of the maximum = first of (s, a, b, a2, b2) equal to it, the continuation bits (:235-272; gf_cell_k)
 						uint32_t d;
-						gf_cell_k(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, S_MISD, S_SCN, S_MCH8, S_Q, S_Q2, S_QE, S_QE2);
+						gf_cell_k(tv ^ qv, tv | qv, xp, vp, x2p, U[c], V[c], X[c], Y[c], X2[c], Y2[c], d, P_MCH, K);
 						if (par == 0) DE[c] = d;
 						else {
 							const uint32_t t = (uint32_t)(cb + c * 64 + lane);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 				const int ii = i - hl * di, jj = j - hl * dj;
 				const bool valid = live && ii >= 0 && jj >= 0;
 				const int rr = ii + jj;
-				const int tmp = valid ? gf_k_decode(my_dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)]) : 0;
+				const int tmp = valid ? gf_k_decode(my_dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)], K.bias) : 0;
 				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
 				const unsigned long long bal = __ballot(cont);
 				const uint32_t mine = isB ? (uint32_t)(bal >> 32) : (uint32_t)bal;

@@ -124,6 +124,8 @@ __device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, u
 	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
 
+#endif // MM2AMD_WAVE_EMU (the instruction wrappers above)
+
 // ---------------------------------------------------------------------------------------------------------
 // gf_cell_k: the same cell with KEYED candidates (round 4).  A third of gf_cell's packed operations only name the direction: four
 // differences against the maximum, four normalisations to 0/1, and a multiply-add chain that turns them into "the first of (s, a, b,
@@ -132,20 +134,43 @@ __device__ __forceinline__ void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, u
 // signed maximum of the five KEYS is the maximum value and, among equals, the first candidate, so the direction is the key's low bits
 // (one 32-bit AND on both halves, VOP2: half the issue cost of a packed op) and the twelve operations are gone.  The tags ride in the
 // stored gap states: x carries 6, y 5, x2 4, y2 3 (a = x + v, so the sum has x's tag; u and v carry none), the substitution score gets
-// its 7 from the constants, the gap-open clamp max(., 0) becomes max(., tag), and "the gap continues" (value > 0) becomes key >= 8:
-// min_u16(key, 8 + tag) is tag or 8 + tag, summed with weights 1, 2, 4, 8.  The byte stored per cell is therefore
-//   (7 - d) + 8 fa + 16 fb + 32 fa2 + 64 fb2 + GF_K_BIAS,   GF_K_BIAS = 6 + 2*5 + 4*4 + 8*3 (at most 183),
+// its 7 from the constants.  The gap states are stored as the reference stores them, x = max(a - (z - q), 0) - (q + e), in one step:
+// max(a - (z + e), tag - 8 (q + e)) -- the clamp and the subtraction folded into the constant ka (kb, ka2, kb2) -- and "the gap
+// continues" (a - (z - q) > 0) is x >= ka + 8: min_i16(x, ka + 8) is ka or ka + 8, summed with weights 1, 2, 4, 8.  The byte stored per
+// cell is therefore   (7 - d) + 8 fa + 16 fb + 32 fa2 + 64 fb2 + bias (mod 256),   bias = ka + 2 kb + 4 ka2 + 8 kb2,
 // and the traceback -- the only reader -- takes the bias off and flips the low bits (gf_k_decode).  No value leaves the range of a
-// 16-bit half: the reference's 8-bit quantities times 8.  38 packed + 2 VOP2 operations per register set and row instead of 50.
-//   in : x1, o1 as gf_cell; xp (tag 6), vp, x2p (tag 4), u, y (tag 5), y2 (tag 3) -- all times 8
-//   constants: P_MCHT = 8 mch + 7 (VGPR), S_MISD8 = 8 (mis - mch), S_SCNT = 8 sc_N + 7, S_MCH8, S_Q8, S_Q28, S_QE8, S_QE28 = 8 x the cost
+// 16-bit half: the reference's 8-bit quantities times 8.  34 packed + 2 VOP2 operations per register set and row instead of 50.
+//   in : x1, o1 as gf_cell; xp (tag 6), vp, x2p (tag 4), u, y (tag 5), y2 (tag 3) -- all times 8;  u is updated in place
 // ---------------------------------------------------------------------------------------------------------
 constexpr int GF_K_TS = 7, GF_K_TA = 6, GF_K_TB = 5, GF_K_TA2 = 4, GF_K_TB2 = 3;
-constexpr int GF_K_BIAS = GF_K_TA + 2 * GF_K_TB + 4 * GF_K_TA2 + 8 * GF_K_TB2;
-__device__ __forceinline__ int gf_k_decode(int byte) { return ((byte - GF_K_BIAS) ^ 7) & 0xff; } // -> the reference's direction byte (d | flags << 3)
+// the launch's constants of the keyed cell, all as both halves of a dword (pk2): built once per kernel by gf_k_consts
+struct GfK {
+	uint32_t mcht;                  // 8 mch + 7 (VGPR: it meets an SGPR operand in its instruction)
+	uint32_t misd8, scnt, mch8;     // 8 (mis - mch), 8 sc_N + 7, 8 mch
+	uint32_t e8, e28;               // 8 e, 8 e2: z - q + (q + e) = z + e is what a gap candidate is measured against when the state is stored as x = max(., 0) - (q + e)
+	uint32_t ka, kb, ka2, kb2;      // the clamp of a stored gap state: tag - 8 (q + e)  (x, y) / tag - 8 (q2 + e2)  (x2, y2)
+	uint32_t ka8, kb8, ka28, kb28;  // the same plus 8: "the gap continues" is state >= clamp + 8
+	uint32_t nqe_x, nqe_y, nqe2_x, nqe2_y; // border values of x / y / x2 / y2: -(q + e), -(q2 + e2) times 8, tagged (= ka, kb, ka2, kb2)
+	int bias;                       // what the stored byte carries on top of (7 - d) + 8 fa + 16 fb + 32 fa2 + 64 fb2, mod 256
+};
+__device__ __forceinline__ uint32_t gf_pk2(int v) { return ((uint32_t)v & 0xffffu) | (uint32_t)v << 16; }
+__device__ __forceinline__ GfK gf_k_consts(int sc_mch, int sc_mis, int sc_N, int q, int e, int q2, int e2) // (q, e) = the cheaper pair to open, as the kernels swap them
+{
+	GfK k;
+	const int qe8 = 8 * (q + e), qe28 = 8 * (q2 + e2);
+	k.mcht = 0, k.misd8 = gf_pk2(8 * (sc_mis - sc_mch)), k.scnt = gf_pk2(8 * sc_N + GF_K_TS), k.mch8 = gf_pk2(8 * sc_mch);
+	k.e8 = gf_pk2(8 * e), k.e28 = gf_pk2(8 * e2);
+	const int ka = GF_K_TA - qe8, kb = GF_K_TB - qe8, ka2 = GF_K_TA2 - qe28, kb2 = GF_K_TB2 - qe28;
+	k.ka = gf_pk2(ka), k.kb = gf_pk2(kb), k.ka2 = gf_pk2(ka2), k.kb2 = gf_pk2(kb2);
+	k.ka8 = gf_pk2(ka + 8), k.kb8 = gf_pk2(kb + 8), k.ka28 = gf_pk2(ka2 + 8), k.kb28 = gf_pk2(kb2 + 8);
+	k.nqe_x = k.ka, k.nqe_y = k.kb, k.nqe2_x = k.ka2, k.nqe2_y = k.kb2;
+	k.bias = (ka + 2 * kb + 4 * ka2 + 8 * kb2) & 0xff;
+	return k;
+}
+__device__ __forceinline__ int gf_k_decode(int byte, int bias) { return ((byte - bias) ^ 7) & 0xff; } // -> the reference's direction byte (d | flags << 3)
+#ifndef MM2AMD_WAVE_EMU
 __device__ __forceinline__ void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y,
-                                          uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCHT, uint32_t S_MISD8, uint32_t S_SCNT, uint32_t S_MCH8,
-                                          uint32_t S_Q8, uint32_t S_Q28, uint32_t S_QE8, uint32_t S_QE28)
+                                          uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCHT, const GfK &K)
 {
 	uint32_t a, b, a2, b2, z, z4, m, n, w, tA, tB;
 	asm volatile(
@@ -165,53 +190,44 @@ __device__ __forceinline__ void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp,
 		"v_pk_max_i16 %[z4], %[z], %[tA]\n\t"
 		"s_nop 0"
 		: [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [b2] "=&v"(b2), [z] "=&v"(z), [z4] "=&v"(z4), [m] "=&v"(m), [n] "=&v"(n), [w] "=&v"(w), [tA] "=&v"(tA), [tB] "=&v"(tB)
-		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCHT), [misd] "s"(S_MISD8), [scn] "s"(S_SCNT));
-	uint32_t zv, zc, t1, t2, e, un, vn;
+		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCHT), [misd] "s"(K.misd8), [scn] "s"(K.scnt));
+	uint32_t zv, zc, t1, t2, e, vn, xn, yn, x2n, y2n;
 	asm volatile(
 		"v_and_b32 %[zv], 0xfff8fff8, %[z4]\n\t"
 		"v_and_b32 %[e], 0x70007, %[z4]\n\t"
 		"v_pk_min_i16 %[zc], %[zv], %[mch8]\n\t"
 		"s_nop 0\n\t"
-		"v_pk_sub_u16 %[un], %[zc], %[vp]\n\t"
 		"v_pk_sub_u16 %[vn], %[zc], %[u]\n\t"
-		"v_pk_sub_u16 %[t1], %[zc], %[q]\n\t"
-		"v_pk_sub_u16 %[t2], %[zc], %[q2]\n\t"
+		"v_pk_add_u16 %[t1], %[zc], %[e8]\n\t"
+		"v_pk_add_u16 %[t2], %[zc], %[e28]\n\t"
+		"v_pk_sub_u16 %[u], %[zc], %[vp]\n\t"
 		"v_pk_sub_u16 %[a], %[a], %[t1]\n\t"
 		"v_pk_sub_u16 %[b], %[b], %[t1]\n\t"
 		"v_pk_sub_u16 %[a2], %[a2], %[t2]\n\t"
 		"v_pk_sub_u16 %[b2], %[b2], %[t2]\n\t"
-		"v_pk_max_i16 %[a], %[a], 6 op_sel_hi:[1,0]\n\t"
-		"v_pk_max_i16 %[b], %[b], 5 op_sel_hi:[1,0]\n\t"
-		"v_pk_max_i16 %[a2], %[a2], 4 op_sel_hi:[1,0]\n\t"
-		"v_pk_max_i16 %[b2], %[b2], 3 op_sel_hi:[1,0]"
-		: [zv] "=&v"(zv), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [un] "=&v"(un), [vn] "=&v"(vn),
-		  [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
-		: [z4] "v"(z4), [vp] "v"(vp), [u] "v"(u), [mch8] "s"(S_MCH8), [q] "s"(S_Q8), [q2] "s"(S_Q28));
-	uint32_t fa, fb, fa2, fb2, xn, yn, x2n, y2n;
+		"v_pk_max_i16 %[xn], %[a], %[ka]\n\t"
+		"v_pk_max_i16 %[yn], %[b], %[kb]\n\t"
+		"v_pk_max_i16 %[x2n], %[a2], %[ka2]\n\t"
+		"v_pk_max_i16 %[y2n], %[b2], %[kb2]"
+		: [zv] "=&v"(zv), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [vn] "=&v"(vn), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n),
+		  [u] "+v"(u), [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
+		: [z4] "v"(z4), [vp] "v"(vp), [mch8] "s"(K.mch8), [e8] "s"(K.e8), [e28] "s"(K.e28), [ka] "s"(K.ka), [kb] "s"(K.kb), [ka2] "s"(K.ka2), [kb2] "s"(K.kb2));
+	uint32_t fa, fb, fa2, fb2;
 	asm volatile(
-		"v_pk_min_u16 %[fa], %[a], 14 op_sel_hi:[1,0]\n\t"
-		"v_pk_sub_u16 %[xn], %[a], %[qe]\n\t"
-		"v_pk_min_u16 %[fb], %[b], 13 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_i16 %[fa], %[xn], %[ka8]\n\t"
+		"v_pk_min_i16 %[fb], %[yn], %[kb8]\n\t"
+		"v_pk_min_i16 %[fa2], %[x2n], %[ka28]\n\t"
+		"v_pk_mad_u16 %[fa], %[fb], 2, %[fa] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_min_i16 %[fb2], %[y2n], %[kb28]\n\t"
 		"v_pk_add_u16 %[e], %[e], %[fa]\n\t"
-		"v_pk_sub_u16 %[yn], %[b], %[qe]\n\t"
-		"v_pk_min_u16 %[fa2], %[a2], 12 op_sel_hi:[1,0]\n\t"
-		"v_pk_mad_u16 %[e], %[fb], 2, %[e] op_sel_hi:[1,0,1]\n\t"
-		"v_pk_sub_u16 %[x2n], %[a2], %[qe2]\n\t"
-		"v_pk_min_u16 %[fb2], %[b2], 11 op_sel_hi:[1,0]\n\t"
-		"v_pk_mad_u16 %[e], %[fa2], 4, %[e] op_sel_hi:[1,0,1]\n\t"
-		"v_pk_sub_u16 %[y2n], %[b2], %[qe2]\n\t"
-		"v_pk_mad_u16 %[e], %[fb2], 8, %[e] op_sel_hi:[1,0,1]"
-		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n), [e] "+v"(e)
-		: [a] "v"(a), [b] "v"(b), [a2] "v"(a2), [b2] "v"(b2), [qe] "s"(S_QE8), [qe2] "s"(S_QE28));
-	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
+		"v_pk_mad_u16 %[fa2], %[fb2], 2, %[fa2] op_sel_hi:[1,0,1]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_mad_u16 %[e], %[fa2], 4, %[e] op_sel_hi:[1,0,1]"
+		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [e] "+v"(e)
+		: [xn] "v"(xn), [yn] "v"(yn), [x2n] "v"(x2n), [y2n] "v"(y2n), [ka8] "s"(K.ka8), [kb8] "s"(K.kb8), [ka28] "s"(K.ka28), [kb28] "s"(K.kb28));
+	v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
-static_assert(GF_K_TA == 6 && GF_K_TB == 5 && GF_K_TA2 == 4 && GF_K_TB2 == 3 && GF_K_TS == 7, "the tags are written into gf_cell_k's instructions");
-
-#else
-constexpr int GF_K_TS = 7, GF_K_TA = 6, GF_K_TB = 5, GF_K_TA2 = 4, GF_K_TB2 = 3;
-constexpr int GF_K_BIAS = GF_K_TA + 2 * GF_K_TB + 4 * GF_K_TA2 + 8 * GF_K_TB2;
-inline int gf_k_decode(int byte) { return ((byte - GF_K_BIAS) ^ 7) & 0xff; }
-#endif // MM2AMD_WAVE_EMU
+#endif // MM2AMD_WAVE_EMU (the emulator's twin: ksw_pk_emu.hpp)
 
 // ---- mm_test_zdrop's walk over a finished alignment (align.c:46-84), by the 32 lanes of a half-wave ----
 // The reference walks the CIGAR from the start: a running score (substitution scores base by base, -(q + e * len) per gap), the

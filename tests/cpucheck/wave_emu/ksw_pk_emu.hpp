@@ -67,31 +67,33 @@ inline void gf_cell(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t
 	e = pk_mad(fb2, pk_emu::both(64), e);
 	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
-// gf_cell_k: the keyed cell (values times 8, candidate tags in the low three bits), the same operations as its three assembly blocks
+// gf_cell_k: the keyed cell (values times 8, candidate tags in the low three bits, the clamp and -(q + e) folded into one constant), the same
+// operations as its three assembly blocks; K = GfK (ksw_gapfill_dev.hpp, declared after this header is read)
+template <class KT>
 inline void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y, uint32_t &x2, uint32_t &y2, uint32_t &d,
-                      uint32_t P_MCHT, uint32_t S_MISD8, uint32_t S_SCNT, uint32_t S_MCH8, uint32_t S_Q8, uint32_t S_Q28, uint32_t S_QE8, uint32_t S_QE28)
+                      uint32_t P_MCHT, const KT &K)
 {
 	using pk_emu::both;
 	uint32_t a = pk_add(xp, vp), m = pk_minu(x1, both(1)), b = pk_add(y, u), a2 = pk_add(x2p, vp);
-	uint32_t z = pk_mad(m, S_MISD8, P_MCHT);
-	uint32_t b2 = pk_add(y2, u), tA = pk_max(a, b), n = pk_shr2(o1), tB = pk_max(a2, b2), w = pk_sub(S_SCNT, z);
+	uint32_t z = pk_mad(m, K.misd8, P_MCHT);
+	uint32_t b2 = pk_add(y2, u), tA = pk_max(a, b), n = pk_shr2(o1), tB = pk_max(a2, b2), w = pk_sub(K.scnt, z);
 	tA = pk_max(tA, tB);
 	z = pk_mad(n, w, z);
 	const uint32_t z4 = pk_max(z, tA);
 	const uint32_t zv = z4 & 0xfff8fff8u;
 	uint32_t e = z4 & 0x00070007u;
-	const uint32_t zc = pk_min(zv, S_MCH8);
-	const uint32_t un = pk_sub(zc, vp), vn = pk_sub(zc, u), t1 = pk_sub(zc, S_Q8), t2 = pk_sub(zc, S_Q28);
+	const uint32_t zc = pk_min(zv, K.mch8);
+	const uint32_t vn = pk_sub(zc, u), t1 = pk_add(zc, K.e8), t2 = pk_add(zc, K.e28);
+	u = pk_sub(zc, vp);
 	a = pk_sub(a, t1), b = pk_sub(b, t1), a2 = pk_sub(a2, t2), b2 = pk_sub(b2, t2);
-	a = pk_max(a, both(6)), b = pk_max(b, both(5)), a2 = pk_max(a2, both(4)), b2 = pk_max(b2, both(3));
-	const uint32_t fa = pk_minu(a, both(14)), xn = pk_sub(a, S_QE8), fb = pk_minu(b, both(13));
+	const uint32_t xn = pk_max(a, K.ka), yn = pk_max(b, K.kb), x2n = pk_max(a2, K.ka2), y2n = pk_max(b2, K.kb2);
+	uint32_t fa = pk_min(xn, K.ka8), fa2 = pk_min(x2n, K.ka28);
+	const uint32_t fb = pk_min(yn, K.kb8);
+	fa = pk_mad(fb, both(2), fa);
+	const uint32_t fb2 = pk_min(y2n, K.kb28);
 	e = pk_add(e, fa);
-	const uint32_t yn = pk_sub(b, S_QE8), fa2 = pk_minu(a2, both(12));
-	e = pk_mad(fb, both(2), e);
-	const uint32_t x2n = pk_sub(a2, S_QE28), fb2 = pk_minu(b2, both(11));
+	fa2 = pk_mad(fb2, both(2), fa2);
 	e = pk_mad(fa2, both(4), e);
-	const uint32_t y2n = pk_sub(b2, S_QE28);
-	e = pk_mad(fb2, both(8), e);
-	u = un, v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
+	v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
 } // namespace mm2amd
