@@ -494,16 +494,16 @@ def main():
             one = {k: v for k, v in prof1.items() if family(k) == vfam}
             ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
             # Issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU instructions as counted in the ISA (hipcc -S,
-            # gfx950: streaming kernel 39 packed VOP3P (the keyed cell's 38 and the store's share) + 6 DPP moves + 1 v_perm (VOP3) + 8 VOP2 = 54 -- 51 + 6 + 1 + 6
-            # = 64 with round 3's cell; strip kernel 38 + 6 + 11 others + 12 VOP2), priced
+            # gfx950: streaming kernel 35 packed VOP3P (the keyed cell's 34 and the store's share) + 6 DPP moves + 1 v_perm (VOP3) + 7 VOP2 = 49 -- 51 + 6 + 1 + 6
+            # = 64 with round 3's cell; strip kernel 34 + 6 + 11 others + 12 VOP2), priced
             # with the per-SIMD issue-rate table profiles/r03_valu_issue_bench_v1.txt -- waves that shared a SIMD found through HW_ID, columns
             # B=8 and B=16 agree: VOP3P / VOP3 / DPP 4.1 cycles per wave64 instruction, VOP2 2.2.  valu_busy is the hardware's own figure for
             # the same thing: 4 x SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) of profiles/r03_pmc_sq_v1.json.  Lane utilisation =
             # cells / (128 x executed register-set rows), counted by the MM2AMD_GF_COUNT build (profiles/r02_stream_lane_utilisation.txt).
             if vfam == "ksw_stream_kernel":
-                n_slow, n_vop2, lane_util = 39 + 6 + 1, 8, 0.865
+                n_slow, n_vop2, lane_util = 35 + 6 + 1, 7, 0.865
             else:
-                n_slow, n_vop2, lane_util = 38 + 6 + 11, 12, 0.727
+                n_slow, n_vop2, lane_util = 34 + 6 + 11, 12, 0.727
             row_cycles = n_slow * 4.1 + n_vop2 * 2.2
             peak_cells = 1024 * 2.4e9 * 128 / row_cycles
             nominal = 1024 * 2.4e9 * 128 / ((n_slow + n_vop2) * 2.0)

@@ -239,42 +239,14 @@ __global__ void __launch_bounds__(256, NC > 4 ? 2 : 4) ksw_ext_kernel(KswLaunch 
 			if (reach_end) i = zz.mqe_t, j = my_qlen - 1;
 			else if (zz.max_t >= 0 && zz.max_q >= 0) i = zz.max_t, j = zz.max_q;
 		}
-		const uint8_t *my_dir = dir + hsel;
 		FastCig g = { L.cigar_tmp + (size_t)(2 * slot + hsel) * L.cigar_tmp_cap, 0, 0u };
 		uint32_t cig_off = 0;
-		{
-			const int hl = lane & 31;
-			int state = 0;
-			const bool start = i >= 0 && j >= 0;
-			bool live = start; // uniform within a half
-			while (__ballot(live) != 0ull) {
-				const int di = (state == 2 || state == 4) ? 0 : 1, dj = (state == 1 || state == 3) ? 0 : 1;
-				const int ii = i - hl * di, jj = j - hl * dj;
-				const bool valid = live && ii >= 0 && jj >= 0;
+		{ // each half-wave follows its job's path (gf_traceback, ksw_gapfill_dev.hpp)
+			const size_t hoff = (size_t)hsel;
+			gf_traceback(i >= 0 && j >= 0, i, j, [&](int ii, int jj) {
 				const int rr = ii + jj;
-				const int tmp = valid ? my_dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)] : 0;
-				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
-				const unsigned long long bal = __ballot(cont);
-				const uint32_t mine = isB ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-				const int run = mine == 0xffffffffu ? 32 : __builtin_ctz(~mine);
-				const int head = __shfl(tmp, lane & 32, 64); // the cell the half stands on
-				if (live) {
-					if (run > 0) {
-						fast_cig_push(g, state == 0 ? 0u : (state == 1 || state == 3) ? 2u : 1u, run);
-						i -= run * di, j -= run * dj;
-					} else { // the run ends on this cell: it names the next state (ksw2.h:141-144)
-						state = head & 7;
-						if (state == 0) fast_cig_push(g, 0, 1), --i, --j;
-						else if (state == 1 || state == 3) fast_cig_push(g, 2, 1), --i;
-						else fast_cig_push(g, 1, 1), --j;
-					}
-					live = i >= 0 && j >= 0;
-				}
-			}
-			if (start) {
-				if (i >= 0) fast_cig_push(g, 2, i + 1);
-				if (j >= 0) fast_cig_push(g, 1, j + 1);
-			}
+				return (int)dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1) + hoff];
+			}, g);
 		}
 		if ((lane & 31) == 0 && have_job) {
 			if (g.n > 0) g.c[g.n - 1] = g.last;

@@ -227,44 +227,16 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 		__threadfence_block();
 		const bool isB = lane >= 32;
 		const int my_qlen = isB ? qlenB : qlenA, my_tlen = isB ? tlenB : tlenA;
-		const uint8_t *my_dir = dir + (isB ? 1 : 0), *my_qb = isB ? qb + QCAP : qb, *my_tb = isB ? tbB : tbA;
+		const uint8_t *my_qb = isB ? qb + QCAP : qb, *my_tb = isB ? tbB : tbA;
 		FastCig g = { L.cigar_tmp + (size_t)(2 * slot + (isB ? 1 : 0)) * L.cigar_tmp_cap, 0, 0u };
 		uint32_t cig_off = 0;
 		int32_t zd_max = 0, zd_t0 = -1, zd_t1 = -1, zd_q0 = -1, zd_q1 = -1, dp_score = qe - qe_in;
-		{ // Each half-wave follows its job's path: lane k of the half looks k cells ahead along the current run (match diagonal or
-		  // gap) and one ballot tells how far the run goes, so a read's typical 8-base match runs cost one load round, not eight.
-			const bool have = !isB || hasB;
-			const int hl = lane & 31;
-			int i = my_tlen - 1, j = my_qlen - 1, state = 0;
-			bool live = have && i >= 0 && j >= 0; // uniform within a half
-			while (__ballot(live) != 0ull) {
-				const int di = (state == 2 || state == 4) ? 0 : 1, dj = (state == 1 || state == 3) ? 0 : 1;
-				const int ii = i - hl * di, jj = j - hl * dj;
-				const bool valid = live && ii >= 0 && jj >= 0;
+		{ // each half-wave follows its job's path (gf_traceback, ksw_gapfill_dev.hpp)
+			const size_t hoff = isB ? 1 : 0;
+			gf_traceback(!isB || hasB, my_tlen - 1, my_qlen - 1, [&](int ii, int jj) {
 				const int rr = ii + jj;
-				const int tmp = valid ? gf_k_decode(my_dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)], K.bias) : 0;
-				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
-				const unsigned long long bal = __ballot(cont);
-				const uint32_t mine = isB ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-				const int run = mine == 0xffffffffu ? 32 : __builtin_ctz(~mine);
-				const int head = __shfl(tmp, lane & 32, 64); // the cell the half stands on
-				if (live) {
-					if (run > 0) {
-						fast_cig_push(g, state == 0 ? 0u : (state == 1 || state == 3) ? 2u : 1u, run);
-						i -= run * di, j -= run * dj;
-					} else { // the run ends on this cell: it names the next state (ksw2.h:141-144)
-						state = head & 7;
-						if (state == 0) fast_cig_push(g, 0, 1), --i, --j;
-						else if (state == 1 || state == 3) fast_cig_push(g, 2, 1), --i;
-						else fast_cig_push(g, 1, 1), --j;
-					}
-					live = i >= 0 && j >= 0;
-				}
-			}
-			if (have) {
-				if (i >= 0) fast_cig_push(g, 2, i + 1);
-				if (j >= 0) fast_cig_push(g, 1, j + 1);
-			}
+				return gf_k_decode(dir[((size_t)(rr >> 1) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1) + hoff], K.bias);
+			}, g);
 		}
 		if ((lane == 0 || (lane == 32 && hasB))) {
 			if (g.n > 0) g.c[g.n - 1] = g.last;

@@ -229,6 +229,58 @@ __device__ __forceinline__ void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp,
 }
 #endif // MM2AMD_WAVE_EMU (the emulator's twin: ksw_pk_emu.hpp)
 
+// ---- ksw_backtrack (ksw2.h:130-162) with every cell inside the matrix, by the 32 lanes of a half-wave; both halves of a wave at once ----
+// Lane k of the half looks k cells ahead along the run of the current state (the match diagonal, or a gap) and one ballot tells how far the
+// run goes, so a read's typical 8-base match runs cost one load round, not eight.  Round 4: the cell that ENDS the run was loaded by lane
+// `run` in the same round -- it names the next state (:141-144) and is consumed in the same iteration, so a one-base indel between two match
+// runs costs two rounds of dependent loads instead of three; and the CIGAR pusher is written without branches on the operation (every lane of
+// the half keeps the same (i, j, state, CIGAR tail); lane 0 of the half stores).  A fifth of the gap-fill kernels' instructions were this
+// loop, its four inlined pushers diverging between the two halves.
+//   start: the half has a job and (i, j) is inside the matrix;  dir_at(ii, jj) -> the reference's direction byte of cell (target ii, query jj)
+__device__ __forceinline__ void gf_cig_push(FastCig &g, uint32_t op, int len, bool writer) // ksw_push_cigar (ksw2.h:114-124); len may be 0
+{
+	const bool same = g.n > 0 && op == (g.last & 0xf);
+	const bool fresh = len > 0 && !same;
+	if (fresh && g.n > 0 && writer) g.c[g.n - 1] = g.last;
+	g.last = fresh ? (uint32_t)len << 4 | op : g.last + ((uint32_t)len << 4);
+	g.n += fresh ? 1 : 0;
+}
+template <class DIR>
+__device__ __forceinline__ void gf_traceback(bool start, int i, int j, DIR dir_at, FastCig &g)
+{
+	const int lane = (int)(threadIdx.x & 63), hl = lane & 31, hbase = lane & 32;
+	const bool writer = hl == 0;
+	int state = 0;
+	bool live = start && i >= 0 && j >= 0; // uniform within a half
+	while (__ballot(live) != 0ull) {
+		const int di = (state == 2 || state == 4) ? 0 : 1, dj = (state == 1 || state == 3) ? 0 : 1;
+		const int ii = i - hl * di, jj = j - hl * dj;
+		const bool valid = live && ii >= 0 && jj >= 0;
+		const int tmp = valid ? dir_at(ii, jj) : 0;
+		const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
+		const unsigned long long bal = __ballot(cont);
+		const uint32_t mine = hbase ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+		const int run = mine == 0xffffffffu ? 32 : __builtin_ctz(~mine);
+		const int stop = __shfl(tmp, hbase + (run & 31), 64); // the cell that ended the run (meaningful when run < 32 and it lies inside the matrix)
+		if (live) {
+			int ni = i - run * di, nj = j - run * dj;
+			const uint32_t op1 = state == 0 ? 0u : dj == 0 ? 2u : 1u;
+			const bool step = run < 32 && ni >= 0 && nj >= 0;
+			const int ns = step ? (stop & 7) : state;
+			const int si = (ns == 2 || ns == 4) ? 0 : 1, sj = (ns == 1 || ns == 3) ? 0 : 1;
+			const uint32_t op2 = ns == 0 ? 0u : sj == 0 ? 2u : 1u;
+			gf_cig_push(g, op1, run, writer);
+			gf_cig_push(g, op2, step ? 1 : 0, writer);
+			i = step ? ni - si : ni, j = step ? nj - sj : nj, state = ns;
+			live = i >= 0 && j >= 0;
+		}
+	}
+	if (start) {
+		if (i >= 0) gf_cig_push(g, 2u, i + 1, writer);
+		if (j >= 0) gf_cig_push(g, 1u, j + 1, writer);
+	}
+}
+
 // ---- mm_test_zdrop's walk over a finished alignment (align.c:46-84), by the 32 lanes of a half-wave ----
 // The reference walks the CIGAR from the start: a running score (substitution scores base by base, -(q + e * len) per gap), the
 // running maximum with the position of its LAST occurrence, and, at every step below the maximum, the drop

@@ -142,42 +142,16 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		const uint8_t *my_dir = dir + h, *my_ring = qring + h, *my_tb = &s_tb[wave_in_block][h][0];
+		const uint8_t *my_ring = qring + h, *my_tb = &s_tb[wave_in_block][h][0];
 		FastCig g = { L.cigar_tmp + (size_t)(2 * slot + h) * L.cigar_tmp_cap, 0, 0u };
 		uint32_t cig_off = 0;
 		int32_t zd_max = 0, zd_t0 = -1, zd_t1 = -1, zd_q0 = -1, zd_q1 = -1, dp_score = qe - qe_in; // the reference's score offset when the second cost pair is the cheaper one (:68 vs :78)
-		{ // lane k of the half looks k cells ahead along the current run (match diagonal or gap); one ballot tells how far the run goes
-			const int hl = lane & 31;
-			int i = my_t - 1, j = my_q - 1, state = 0;
-			bool live = have && i >= 0 && j >= 0; // uniform within a half
-			while (__ballot(live) != 0ull) {
-				const int di = (state == 2 || state == 4) ? 0 : 1, dj = (state == 1 || state == 3) ? 0 : 1;
-				const int ii = i - hl * di, jj = j - hl * dj;
-				const bool valid = live && ii >= 0 && jj >= 0;
-				const int rr = my_R + ii + jj;
-				const int tmp = valid ? gf_k_decode(my_dir[((size_t)((rr >> 1) & (ST_ROWS / 2 - 1)) * (size_t)ncol + (size_t)ii) * 4u + (size_t)((rr & 1) << 1)], K.bias) : 0;
-				const bool cont = valid && (state == 0 ? (tmp & 7) == 0 : (tmp >> (state + 2) & 1) != 0);
-				const unsigned long long bal = __ballot(cont);
-				const uint32_t mine = isB ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-				const int run = mine == 0xffffffffu ? 32 : __builtin_ctz(~mine);
-				const int head = __shfl(tmp, lane & 32, 64); // the cell the half stands on
-				if (live) {
-					if (run > 0) {
-						fast_cig_push(g, state == 0 ? 0u : (state == 1 || state == 3) ? 2u : 1u, run);
-						i -= run * di, j -= run * dj;
-					} else { // the run ends on this cell: it names the next state (ksw2.h:141-144)
-						state = head & 7;
-						if (state == 0) fast_cig_push(g, 0, 1), --i, --j;
-						else if (state == 1 || state == 3) fast_cig_push(g, 2, 1), --i;
-						else fast_cig_push(g, 1, 1), --j;
-					}
-					live = i >= 0 && j >= 0;
-				}
-			}
-			if (have) {
-				if (i >= 0) fast_cig_push(g, 2, i + 1);
-				if (j >= 0) fast_cig_push(g, 1, j + 1);
-			}
+		{ // ring offsets fit 32 bits; the half's byte (A: 0, B: 1) is part of the offset, so the base stays wave-uniform
+			const uint32_t hoff = (uint32_t)h;
+			gf_traceback(have, my_t - 1, my_q - 1, [&](int ii, int jj) {
+				const uint32_t rr = (uint32_t)(my_R + ii + jj);
+				return gf_k_decode(dir[(((rr >> 1) & (uint32_t)(ST_ROWS / 2 - 1)) * (uint32_t)ncol + (uint32_t)ii) * 4u + ((rr & 1u) << 1) + hoff], K.bias);
+			}, g);
 		}
 		if ((lane & 31) == 0 && have) {
 			if (g.n > 0) g.c[g.n - 1] = g.last;

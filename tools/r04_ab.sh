@@ -16,9 +16,17 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 }
+# (VARIANT.so may be a comma-separated list: A B C A B C ...; the output files are named A, B, C, ...)
+NAMES=(B C D E F)
+IFS=',' read -ra VARS <<< "$B"
 for i in $(seq 1 $N); do
-  for W in A B; do
-    if [ $W = A ]; then cp /tmp/libmm2amd_A.so $R/minimap2_amd/libmm2amd.so; else cp $R/$B $R/minimap2_amd/libmm2amd.so; fi
+  cp /tmp/libmm2amd_A.so $R/minimap2_amd/libmm2amd.so
+  (cd /tmp; timeout 600 python $R/bench.py $ARGS > $O/r04_ab_${V}_A$i.json 2> $O/r04_ab_${V}_A$i.log)
+  show $O/r04_ab_${V}_A$i.json
+  k=0
+  for X in "${VARS[@]}"; do
+    W=${NAMES[$k]}; k=$((k+1))
+    cp $R/$X $R/minimap2_amd/libmm2amd.so
     (cd /tmp; timeout 600 python $R/bench.py $ARGS > $O/r04_ab_${V}_$W$i.json 2> $O/r04_ab_${V}_$W$i.log)
     show $O/r04_ab_${V}_$W$i.json
   done
