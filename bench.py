@@ -498,7 +498,7 @@ def main():
             # = 64 with round 3's cell; strip kernel 34 + 6 + 11 others + 12 VOP2), priced
             # with the per-SIMD issue-rate table profiles/r03_valu_issue_bench_v1.txt -- waves that shared a SIMD found through HW_ID, columns
             # B=8 and B=16 agree: VOP3P / VOP3 / DPP 4.1 cycles per wave64 instruction, VOP2 2.2.  valu_busy is the hardware's own figure for
-            # the same thing: 4 x SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) of profiles/r03_pmc_sq_v1.json.  Lane utilisation =
+            # the same thing: 4 x SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) of profiles/r04_pmc_sq_v34.json (r03_pmc_sq_v1.json: round 3's cell).  Lane utilisation =
             # cells / (128 x executed register-set rows), counted by the MM2AMD_GF_COUNT build (profiles/r02_stream_lane_utilisation.txt).
             if vfam == "ksw_stream_kernel":
                 n_slow, n_vop2, lane_util = 35 + 6 + 1, 7, 0.865
@@ -510,7 +510,7 @@ def main():
             rate = cells1 / max(ms1 * 1e-3, 1e-12)
             busy = None
             try:
-                sq = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq_v1.json")))["kernels"]
+                sq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq_v34.json")))["kernels"]  # (collected with the keyed cell: the kernels the line times)
                 act = sum(v["SQ_ACTIVE_INST_VALU"] for k, v in sq.items() if k.startswith(vfam))
                 gui = sum(v["GRBM_GUI_ACTIVE"] for k, v in sq.items() if k.startswith(vfam)) / 8.0
                 busy = round(4.0 * act / (1024.0 * gui), 4)
@@ -522,7 +522,7 @@ def main():
                             "nominal_2cycle_peak_cells_per_s": round(nominal, 1), "frac_nominal": round(rate / nominal, 4),
                             "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
                             "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
-                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles: the hot loop's %d VALU instructions per register-set row (ISA count) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) from profiles/r03_pmc_sq_v1.json (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction" % (round(row_cycles), n_slow + n_vop2)}
+                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles: the hot loop's %d VALU instructions per register-set row (ISA count) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) from profiles/r04_pmc_sq_v34.json (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction" % (round(row_cycles), n_slow + n_vop2)}
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
             roof["unoverlapped_alg_bytes"] = {k: round(v["alg_bytes"], 1) for k, v in sorted(prof1.items())}
             roof["unoverlapped_alg_gb_per_s"] = {k: round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["alg_bytes"] > 0}
