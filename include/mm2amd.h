@@ -78,6 +78,14 @@ typedef struct { int32_t n_cigar, blen, mlen, n_ambi, dp_max, qshift, tshift, is
 int mm2amd_update_extra_batch(int n_jobs, const mm2amd_fin_job_t *jobs, const int8_t *mat25, int8_t q, int8_t e, int log_gap,
                               mm2amd_fin_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);
 
+/* The two device-wide primitives of the index build (device_sort.hip), exposed for testing.  mm2amd_sort_pairs_u64: n (key, value) pairs
+ * sorted in place by key bits [0, bits), stably -- what radix_sort_128x (ksort.h:101-151, instantiated at sketch.c:13 and called per bucket
+ * at index.c:236) yields for pairs whose input order is ascending in the value: rs_hist / rs_chunk_scan / rs_block_offsets / rs_scatter
+ * kernels, one LSD pass per 8 bits.  mm2amd_exclusive_sum_u32: out[i] = in[0] + ... + in[i-1] mod 2^32 for i in [0, n], i.e. out holds
+ * n + 1 entries (the running offsets of index.c:249-268).  n < 2^32 for both. */
+int mm2amd_sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int bits);
+int mm2amd_exclusive_sum_u32(const uint32_t *in, uint32_t *out, uint64_t n);
+
 /* Batched ksw_extz2_sse (ksw2_extz2_sse.c:25, ksw2.h:70-71): single-affine gap cost; same contract as above. */
 int mm2amd_ksw_extz2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, const int8_t *mat, int8_t gapo, int8_t gape,
                            mm2amd_ksw_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap);

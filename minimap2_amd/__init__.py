@@ -126,6 +126,8 @@ def _bind(L):
                                              C.POINTER(KswRes), C.POINTER(C.c_uint32), C.c_size_t]
         L.mm2amd_update_extra_batch.restype = C.c_int
         L.mm2amd_update_extra_batch.argtypes = [C.c_int, C.POINTER(FinJob), C.c_char_p, C.c_int8, C.c_int8, C.c_int, C.POINTER(FinRes), C.POINTER(C.c_uint32), C.c_size_t]
+        L.mm2amd_sort_pairs_u64.argtypes = [vp, vp, C.c_uint64, C.c_int]
+        L.mm2amd_exclusive_sum_u32.argtypes = [vp, vp, C.c_uint64]
         L.mm2amd_idx_str.restype = vp
         L.mm2amd_idx_str.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.mm2amd_idx_destroy.argtypes = [vp]
@@ -202,6 +204,25 @@ def update_extra_batch(jobs, mat, q, e, log_gap):
     for i in range(n):
         r = res[i]
         out.append(None if r.n_cigar < 0 else (tuple(pool[r.cigar_off:r.cigar_off + r.n_cigar]), r.blen, r.mlen, r.n_ambi, r.dp_max, r.qshift, r.tshift, r.is_spliced))
+    return out
+
+
+def sort_pairs_u64(keys, vals, bits=64):
+    """(keys, vals) -- numpy uint64 arrays of equal length -- sorted by key bits [0, bits), stably, on the device (the index build's sort,
+    device_sort.hip).  Returns new arrays."""
+    import numpy as np
+    k, v = np.ascontiguousarray(keys, dtype=np.uint64).copy(), np.ascontiguousarray(vals, dtype=np.uint64).copy()
+    assert k.shape == v.shape and k.ndim == 1
+    _check(lib().mm2amd_sort_pairs_u64(k.ctypes.data, v.ctypes.data, k.size, bits))
+    return k, v
+
+
+def exclusive_sum_u32(a):
+    """numpy uint32 array of n entries -> n + 1 running sums mod 2^32, on the device (device_sort.hip)"""
+    import numpy as np
+    x = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.empty(x.size + 1, dtype=np.uint32)
+    _check(lib().mm2amd_exclusive_sum_u32(x.ctypes.data, out.ctypes.data, x.size))
     return out
 
 

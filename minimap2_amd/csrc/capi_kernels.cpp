@@ -9,6 +9,7 @@
 #include "ksw_host.hpp"
 #include "kernel_prof.hpp"
 #include "region_finish.hpp"
+#include "device_sort.hpp"
 #include <map>
 
 namespace mm2amd { int capi_fail(int code, const std::string &msg); }
@@ -191,6 +192,43 @@ int mm2amd_update_extra_batch(int n_jobs, const mm2amd_fin_job_t *jobs, const in
 			o.cigar_off = regs[i].out_off;
 		}
 		if (out_words) memcpy(cigar_pool, ho.data(), out_words * 4);
+		return 0;
+	});
+}
+
+int mm2amd_sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int bits)
+{
+	if ((n > 0 && (!keys || !vals)) || bits < 0 || bits > 64 || n >= (1ull << 32)) return fail(MM2AMD_EINVAL, "[mm2amd] sort_pairs_u64: bad arguments (n < 2^32, 0 <= bits <= 64)");
+	if (n == 0) return 0;
+	return guarded([&]() -> int {
+		DeviceCtx &dc = device_ctx();
+		std::lock_guard<std::mutex> lk(dc.mu);
+		ensure_device(dc);
+		DevBuf<uint64_t> k0, v0, k1, v1;
+		k0.ensure(n, 1.0), v0.ensure(n, 1.0), k1.ensure(n, 1.0), v1.ensure(n, 1.0);
+		HIP_CHECK(hipMemcpyAsync(k0.p, keys, n * 8, hipMemcpyHostToDevice, dc.stream));
+		HIP_CHECK(hipMemcpyAsync(v0.p, vals, n * 8, hipMemcpyHostToDevice, dc.stream));
+		const int where = device_sort_pairs_u64(k0.p, v0.p, k1.p, v1.p, n, bits, dc.stream);
+		HIP_CHECK(hipMemcpyAsync(keys, where ? k1.p : k0.p, n * 8, hipMemcpyDeviceToHost, dc.stream));
+		HIP_CHECK(hipMemcpyAsync(vals, where ? v1.p : v0.p, n * 8, hipMemcpyDeviceToHost, dc.stream));
+		HIP_CHECK(hipStreamSynchronize(dc.stream));
+		return 0;
+	});
+}
+
+int mm2amd_exclusive_sum_u32(const uint32_t *in, uint32_t *out, uint64_t n)
+{
+	if (!out || (n > 0 && !in) || n >= (1ull << 32)) return fail(MM2AMD_EINVAL, "[mm2amd] exclusive_sum_u32: bad arguments (n < 2^32)");
+	return guarded([&]() -> int {
+		DeviceCtx &dc = device_ctx();
+		std::lock_guard<std::mutex> lk(dc.mu);
+		ensure_device(dc);
+		DevBuf<uint32_t> d;
+		d.ensure(n + 1, 1.0);
+		if (n) HIP_CHECK(hipMemcpyAsync(d.p, in, n * 4, hipMemcpyHostToDevice, dc.stream));
+		device_exclusive_sum_u32(d.p, d.p, n, dc.stream);
+		HIP_CHECK(hipMemcpyAsync(out, d.p, (n + 1) * 4, hipMemcpyDeviceToHost, dc.stream));
+		HIP_CHECK(hipStreamSynchronize(dc.stream));
 		return 0;
 	});
 }

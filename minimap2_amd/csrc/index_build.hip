@@ -7,14 +7,16 @@
 //                 stretch alone (hard part 7), so a lane that starts early enough before its
 //                 chunk reaches the true state before its first owned position; each lane emits only minimizers
 //                 whose position lies in its own chunk, which partitions the reference's output exactly.
-//   3. sort     : (hash, position) pairs by hash then position (two stable LSD radix passes, rocPRIM)
-//   4. tables   : distinct keys, value offsets, top-bits direct table
+//   3. sort     : (hash, position) pairs by hash, stably, so that positions stay ascending within a hash (device_sort.hip: a hand-written
+//                 device-wide LSD radix sort over the 2k hash bits)
+//   4. tables   : distinct keys, value offsets (heads of the runs of equal hashes, ranked by a tile count + prefix sum), top-bits direct table
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <vector>
 #include "hip_util.hpp"
 #include "index_build.hpp"
+#include "device_sort.hpp"
+#include "device_sort_dev.hpp"
 #include "sketch_dev.hpp"
 
 namespace mm2amd {
@@ -71,18 +73,57 @@ __global__ void __launch_bounds__(64) idx_sketch_kernel(const uint8_t *nt4, cons
 	if (!EMIT) cnt[ci] = n_out;
 }
 
-__global__ void __launch_bounds__(256) idx_mark_heads_kernel(const uint64_t *hash, uint64_t n, uint32_t *is_head)
+// A head is the first pair of a run of equal hashes: one per distinct minimizer, in sorted order.  Tiles of kSortTile pairs; wave w of
+// a tile owns its pairs [1024 w, 1024 (w+1)) and visits them 64 at a time, so a ballot ranks the heads of a round.
+__global__ void __launch_bounds__(kSortThreads) idx_count_heads_kernel(const uint64_t *hash, uint64_t n, uint32_t *tile_cnt)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) is_head[i] = (i == 0 || hash[i] != hash[i - 1]) ? 1u : 0u;
+	__shared__ uint32_t sh[4];
+	const int tid = threadIdx.x;
+	const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+	uint32_t c = 0;
+#pragma unroll
+	for (int r = 0; r < kSortItems; ++r) {
+		const uint64_t i = base + (uint64_t)(r * kSortThreads + tid);
+		if (i < n && (i == 0 || hash[i] != hash[i - 1])) ++c;
+	}
+	uint32_t total;
+	(void)block_exclusive_sum(c, sh, total);
+	if (tid == 0) tile_cnt[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(256) idx_scatter_keys_kernel(const uint64_t *hash, const uint32_t *is_head, const uint32_t *rank, uint64_t n,
-                                                                uint64_t *keys, uint32_t *val_off, uint64_t n_keys)
+// keys[] = the distinct hashes, val_off[] = where each one's run of positions starts; tile_off = exclusive prefix sum of the tiles' head counts
+__global__ void __launch_bounds__(kSortThreads) idx_scatter_keys_kernel(const uint64_t *hash, uint64_t n, const uint32_t *tile_off, uint64_t *keys, uint32_t *val_off, uint64_t n_keys)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && is_head[i]) { keys[rank[i]] = hash[i]; val_off[rank[i]] = (uint32_t)i; }
-	if (i == 0) val_off[n_keys] = (uint32_t)n;
+	__shared__ uint32_t sh[4];
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint64_t base = (uint64_t)blockIdx.x * kSortTile + (uint64_t)(w * (kSortItems * 64) + lane);
+	uint64_t key[kSortItems];
+	uint32_t heads = 0, wave_cnt = 0;
+#pragma unroll
+	for (int r = 0; r < kSortItems; ++r) {
+		const uint64_t i = base + (uint64_t)(r * 64);
+		key[r] = i < n ? hash[i] : 0;
+		const bool head = i < n && (i == 0 || hash[i - 1] != key[r]);
+		heads |= (uint32_t)head << r;
+		wave_cnt += (uint32_t)__popcll(__ballot(head));
+	}
+	if (lane == 0) sh[w] = wave_cnt;
+	__syncthreads();
+	uint32_t run = tile_off[blockIdx.x];
+	for (int i = 0; i < w; ++i) run += sh[i];
+	const uint64_t below = (1ull << lane) - 1;
+#pragma unroll
+	for (int r = 0; r < kSortItems; ++r) {
+		const bool head = heads >> r & 1;
+		const uint64_t bal = __ballot(head);
+		if (head) {
+			const uint32_t rank = run + (uint32_t)__popcll(bal & below);
+			keys[rank] = key[r];
+			val_off[rank] = (uint32_t)(base + (uint64_t)(r * 64));
+		}
+		run += (uint32_t)__popcll(bal);
+	}
+	if (blockIdx.x == 0 && tid == 0) val_off[n_keys] = (uint32_t)n;
 }
 
 __global__ void __launch_bounds__(256) idx_bucket_start_kernel(const uint64_t *keys, uint64_t n_keys, int key_shift, uint64_t n_buckets, uint32_t *bucket_start)
@@ -212,38 +253,25 @@ void DeviceIndexBuilder::tables_from_nt4(FlatIndex &fi, DeviceIndexTables &T, De
 	d_nt4.release();
 	// 3. sort by (hash, pos): positions are already ascending within a chunk and chunks are in (rid, start) order, so the
 	//    pairs are sorted by pos; one stable sort by hash finishes the job (index.c:236 + :265 yield the same order).
-	{
-		size_t tmp_bytes = 0;
-		hipcub::DoubleBuffer<uint64_t> kb(d_hash.p, d_hash2.p), vb(d_pos.p, d_pos2.p);
-		HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, (int64_t)n_mz, 0, 2 * k, stream));
-		DevBuf<uint8_t> d_tmp;
-		d_tmp.ensure(tmp_bytes + 16, 1.0);
-		HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, kb, vb, (int64_t)n_mz, 0, 2 * k, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-		if (kb.Current() != d_hash.p) std::swap(d_hash.p, d_hash2.p), std::swap(d_hash.cap, d_hash2.cap);
-		if (vb.Current() != d_pos.p) std::swap(d_pos.p, d_pos2.p), std::swap(d_pos.cap, d_pos2.cap);
-	}
+	if (device_sort_pairs_u64(d_hash.p, d_pos.p, d_hash2.p, d_pos2.p, n_mz, 2 * k, stream) == 1)
+		std::swap(d_hash.p, d_hash2.p), std::swap(d_hash.cap, d_hash2.cap), std::swap(d_pos.p, d_pos2.p), std::swap(d_pos.cap, d_pos2.cap);
 	d_hash2.release(), d_pos2.release();
 	// 4. tables
-	DevBuf<uint32_t> d_head, d_rank;
-	d_head.ensure(n_mz + 1, 1.0), d_rank.ensure(n_mz + 1, 1.0);
-	const unsigned gb = (unsigned)((n_mz + 255) / 256);
+	const uint64_t n_tiles = (n_mz + kSortTile - 1) / kSortTile;
+	DevBuf<uint32_t> d_tile;
+	d_tile.ensure(n_tiles + 2, 1.0);
 	uint64_t n_keys = 0;
 	if (n_mz) {
-		hipLaunchKernelGGL(idx_mark_heads_kernel, dim3(gb), dim3(256), 0, stream, d_hash.p, n_mz, d_head.p);
-		size_t tmp_bytes = 0;
-		HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_head.p, d_rank.p, (int64_t)n_mz, stream));
-		DevBuf<uint8_t> d_tmp;
-		d_tmp.ensure(tmp_bytes + 16, 1.0);
-		HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_head.p, d_rank.p, (int64_t)n_mz, stream));
-		uint32_t last_rank = 0, last_head = 0;
-		HIP_CHECK(hipMemcpyAsync(&last_rank, d_rank.p + n_mz - 1, 4, hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(&last_head, d_head.p + n_mz - 1, 4, hipMemcpyDeviceToHost, stream));
+		hipLaunchKernelGGL(idx_count_heads_kernel, dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, d_hash.p, n_mz, d_tile.p);
+		HIP_CHECK(hipGetLastError());
+		device_exclusive_sum_u32(d_tile.p, d_tile.p, n_tiles, stream);
+		uint32_t total = 0;
+		HIP_CHECK(hipMemcpyAsync(&total, d_tile.p + n_tiles, 4, hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
-		n_keys = (uint64_t)last_rank + last_head;
+		n_keys = total;
 	}
 	T.keys.ensure(n_keys + 1, 1.0), T.val_off.ensure(n_keys + 2, 1.0);
-	if (n_mz) hipLaunchKernelGGL(idx_scatter_keys_kernel, dim3(gb), dim3(256), 0, stream, d_hash.p, d_head.p, d_rank.p, n_mz, T.keys.p, T.val_off.p, n_keys);
+	if (n_mz) hipLaunchKernelGGL(idx_scatter_keys_kernel, dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, d_hash.p, n_mz, (const uint32_t *)d_tile.p, T.keys.p, T.val_off.p, n_keys);
 	else HIP_CHECK(hipMemsetAsync(T.val_off.p, 0, 4, stream));
 	HIP_CHECK(hipGetLastError());
 	// hand the sorted positions over

@@ -278,3 +278,23 @@ def test_update_extra_kernel_equals_the_reference(emu):
         got = emu.update_extra_batch(jobs, mat, 4, 2, log_gap)
         for i, (qs, ts, pieces) in enumerate(jobs):
             assert got[i] == reflib.ref_update_extra(qs, ts, pieces, mat, 4, 2, log_gap), i
+
+
+def test_device_sort_and_prefix_sum_kernels(emu):
+    """the index build's hand-written device-wide radix sort and prefix sum (device_sort.hip) against numpy; tests/test_gpu_device_sort.py's
+    checks at sizes around the tile and the chunk of tiles, the CPU suite's share"""
+    import test_gpu_device_sort as T
+    rng = np.random.default_rng(2)
+    for n, bits in ((0, 30), (1, 30), (4097, 30), (4096 * 3 + 11, 64), (128 * 4096 + 1, 30), (129 * 4096 + 7, 13)):
+        keys = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+        vals = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+        k, v = emu.sort_pairs_u64(keys, vals, bits)
+        wk, wv = T.want_sorted(keys, vals, bits)
+        assert np.array_equal(k, wk) and np.array_equal(v, wv), (n, bits)
+    dup = rng.integers(0, 5, 70000, dtype=np.uint64) << np.uint64(9)
+    k, v = emu.sort_pairs_u64(dup, np.arange(dup.size, dtype=np.uint64), 30)
+    assert np.array_equal(v, np.argsort(dup, kind="stable").astype(np.uint64))
+    for n in (0, 1, 4096, 4097, 4096 * 4096 + 5):
+        a = rng.integers(0, 1 << 32 if n < 10000 else 7, n, dtype=np.uint64).astype(np.uint32)
+        want = np.concatenate([[0], np.cumsum(a.astype(np.uint64))]).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+        assert np.array_equal(emu.exclusive_sum_u32(a).astype(np.uint64), want), n
