@@ -499,9 +499,10 @@ def main():
             # with the per-SIMD issue-rate table profiles/r03_valu_issue_bench_v1.txt -- waves that shared a SIMD found through HW_ID, columns
             # B=8 and B=16 agree: VOP3P / VOP3 / DPP 4.1 cycles per wave64 instruction, VOP2 2.2.  valu_busy is the hardware's own figure for
             # the same thing: 4 x SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) of profiles/r04_pmc_sq_v34.json (r03_pmc_sq_v1.json: round 3's cell).  Lane utilisation =
-            # cells / (128 x executed register-set rows), counted by the MM2AMD_GF_COUNT build (profiles/r02_stream_lane_utilisation.txt).
+            # cells / (128 x executed register-set rows), counted by the MM2AMD_GF_COUNT build: at HEAD on the wave emulator (a property of the schedule and the job mix:
+            # profiles/r04_stream_lane_utilisation_emu.txt, 0.860 / 0.882 for the two classes; round 2 on the MI355X: 0.856 / 0.87, profiles/r02_stream_lane_utilisation.txt).
             if vfam == "ksw_stream_kernel":
-                n_slow, n_vop2, lane_util = 35 + 6 + 1, 7, 0.865
+                n_slow, n_vop2, lane_util = 35 + 6 + 1, 7, 0.872
             else:
                 n_slow, n_vop2, lane_util = 34 + 6 + 11, 12, 0.727
             row_cycles = n_slow * 4.1 + n_vop2 * 2.2

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 		__builtin_amdgcn_wave_barrier();
 	};
 
-#ifdef MM2AMD_GF_COUNT // measurement build (tools/build_variant.sh): executed register-set rows against cells, printed by two sample waves
+#ifdef MM2AMD_GF_COUNT // measurement build (tools/build_variant.sh, tools/lane_utilisation_emu.sh): executed register-set rows against cells, printed by two sample waves (=2: by every wave)
 	long long n_setrows = 0, n_cells = 0;
 #endif
 	fetch(0);
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 		}
 	}
 #ifdef MM2AMD_GF_COUNT
-	if (lane == 0 && (slot == 0 || slot == 1001)) printf("GFCOUNT stream<%d> slot %d: %lld register-set rows, %lld cells, lane utilisation %.3f\n", NC, slot, n_setrows, n_cells, (double)n_cells / (128.0 * (double)n_setrows));
+	if (lane == 0 && (slot == 0 || slot == 1001 || MM2AMD_GF_COUNT + 0 == 2)) printf("GFCOUNT stream<%d> slot %d: %lld register-set rows, %lld cells, lane utilisation %.3f\n", NC, slot, n_setrows, n_cells, (double)n_cells / (128.0 * (double)n_setrows));
 #endif
 }
 

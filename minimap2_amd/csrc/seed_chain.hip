@@ -411,7 +411,7 @@ __device__ __forceinline__ bool skip_hit(int64_t flag, uint64_t rr, uint32_t qp,
 
 __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, DevIndex I, SeedChainParams P)
 {
-	__shared__ uint32_t s_hist[4][HIST_N];
+	__shared__ __attribute__((aligned(8))) uint32_t s_hist[4][HIST_N];
 	const int wave = threadIdx.x >> 6, lane = lane_id();
 	const int r = blockIdx.x * 4 + wave;
 	if (r >= B.n_reads) return;
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 	if (n_high > 0) {
 		if (P.occ_dist > 0 && P.max_max_occ > P.mid_occ) {
 			if (n_m0 > 1 && lane == 0) { // rare, sequential: keep ~1 low-occurrence seed per occ_dist bases in each high-occurrence streak
-				uint64_t hb[128];
+				uint64_t *const hb = (uint64_t *)hist; // 128 heap entries in the wave's histogram row, which the query-side filter above is done with (a private array was 1 KB of scratch per lane)
 				int last0 = -1;
 				for (int i = 0; i <= n_m0; ++i) {
 					if (i == n_m0 || sd_n[i] <= (uint32_t)P.mid_occ) {
@@ -524,6 +524,9 @@ __global__ void __launch_bounds__(256) seed_collect_kernel(SeedChainBuffers B, D
 							int keep = (int)((double)(pe - ps) / P.occ_dist + .499), j, kk;
 							if (keep > 0) {
 								if (keep > 128) keep = 128;
+#ifdef MM2AMD_WAVE_EMU
+								if (getenv("MM2AMD_OCC_HEAP_TRACE")) fprintf(stderr, "[mm2amd] occurrence-filter heap: read %d keeps %d of %d seeds\n", r, keep, en - st);
+#endif
 								for (j = st, kk = 0; j < en && kk < keep; ++j, ++kk) hb[kk] = (uint64_t)sd_n[j] << 32 | (uint32_t)j;
 								for (int q = kk >> 1; q-- > 0;) heap_down(hb, q, kk);
 								for (; j < en; ++j)
