@@ -72,3 +72,26 @@ def test_exclusive_sum():
         got = mm.exclusive_sum_u32(a)
         want = np.concatenate([[0], np.cumsum(a.astype(np.uint64))]).astype(np.uint64) & np.uint64(0xFFFFFFFF)
         assert np.array_equal(got.astype(np.uint64), want), n
+
+
+@pytest.mark.timeout(900)
+def test_sort_full_size_properties():
+    """At the index build's own scale (hundreds of millions of pairs: tens of thousands of tiles, hundreds of chunks) numpy's argsort is too slow to be
+    the checker; size-independent properties are not: the masked keys come out non-decreasing, every output pair is an input pair
+    (keys_in[vals_out] == keys_out, the values being the input indices), and within equal keys the indices increase strictly -- stability, and with
+    the gather identity it also makes the output a permutation of the input."""
+    import os
+    n = int(os.environ.get("MM2AMD_SORT_FULL_N", 3000000 if os.environ.get("MM2AMD_EMU") == "1" else 200000000))  # (MM2AMD_SORT_FULL_N=300000000 on the emulator: 73 k tiles, 573 chunks, passes in 4.5 minutes)
+    bits = 30
+    rng = np.random.default_rng(17)
+    keys = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+    m = keys[3::7].size
+    keys[0:7 * m:7] = keys[3::7]  # plenty of equal keys
+    k, v = mm.sort_pairs_u64(keys, np.arange(n, dtype=np.uint64), bits)
+    mask = np.uint64((1 << bits) - 1)
+    km = k & mask
+    assert np.all(km[1:] >= km[:-1])
+    assert np.array_equal(keys[v], k)
+    same = km[1:] == km[:-1]
+    assert np.all(v[1:][same] > v[:-1][same])
+    assert int(same.sum()) > n // 10
