@@ -227,7 +227,8 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 	KswRes *tr = tmp_res.ensure(n);
 
 	// CIGARs are much shorter than qlen+tlen; start with a quarter of the worst case and retry in full on overflow
-	size_t pool_cap = std::min<size_t>(sum_len, sum_len / 4 + 64 * n) + 16;
+	static const int pool_div = getenv("MM2AMD_CIGAR_POOL_DIV") ? std::max(1, atoi(getenv("MM2AMD_CIGAR_POOL_DIV"))) : 0; // tests: a first pool that is too small, so that the retry runs
+	size_t pool_cap = (pool_div ? sum_len / pool_div : std::min<size_t>(sum_len, sum_len / 4 + 64 * n)) + 16;
 	for (int attempt = 0;; ++attempt) {
 		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
 		d_cigar.ensure(pool_cap);

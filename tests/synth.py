@@ -272,6 +272,30 @@ def make_weird(outdir, seed=71):
     return ref, rd
 
 
+def make_palindromes(outdir, seed=83):
+    """A reference with islands whose k-mers equal their own reverse complement for even k -- (AT)n, (ACGT)n, (AATT)n: such k-mers are
+    skipped by mm_sketch without consuming a window slot (sketch.c:108), so a lane of the sketch kernels that starts inside an island
+    cannot warm its window up from a fixed stretch -- and reads inside, across and next to the islands.  Returns (ref.fa, reads.fa)."""
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    c = gen_reference(rng, 300000, 1)[0]
+    units = [np.array(u, dtype=np.uint8) for u in ([0, 3], [0, 1, 2, 3], [0, 0, 3, 3], [1, 2])]
+    islands = []
+    for i, L in enumerate((600, 1500, 3000, 5000, 900, 2500, 150, 40)):
+        st = 20000 + 33000 * i
+        c[st:st + L] = np.tile(units[i % 4], L)[:L]
+        islands.append((st, L))
+    reads = gen_reads(rng, [c], 25, 5000, 1500, 0.06, min_len=1500)
+    for st, L in islands:
+        for a, b in ((st - 1500, st + L + 1500), (st + L // 3, st + L + 2500), (st - 2500, st + 2 * L // 3), (st + 5, st + L - 5)):
+            seg = c[max(a, 0):b]
+            reads.append(mutate_read(rng, seg if len(reads) % 2 else COMP[seg[::-1]], 0.04))
+    ref, rd = os.path.join(outdir, "ref.fa"), os.path.join(outdir, "reads.fa")
+    write_fasta(ref, ["c1"], [c])
+    write_fasta(rd, ["r%d" % i for i in range(len(reads))], reads)
+    return ref, rd
+
+
 def make_tandem_reads(outdir, seed=91, n_reads=40, mean=4000, err=0.1, genome=400000):
     """Noisy reads over a reference peppered with short tandem repeats and homopolymer runs (every ~150 bases a run of 4..40 copies of a
     1..6-mer): the indels of their alignments fall into repeats, where mm_fix_cigar (align.c:105-181) left-aligns them as far as the

@@ -233,6 +233,45 @@ def test_rechain_with_raised_occurrence_cap_identical(tmp_path):
         assert want == got
 
 
+def test_wide_minimizer_windows_identical(tmp_path):
+    """-w beyond 32: the window automaton with the 256-slot ring (sketch_kernel<256> per read, idx_sketch_kernel<.., 256, ..> for the index) -- plain and
+    homopolymer-compressed; no preset has such a window, and the emulator's line coverage showed that no case had one"""
+    ref, rd = synth.make_weird(str(tmp_path))
+    for extra in (["-c", "-k", "17", "-w", "40"], ["-c", "-H", "-k", "15", "-w", "50"], ["-a", "-k", "21", "-w", "33"]):
+        want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        got, _ = _run([DROPIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        assert want == got, extra
+
+
+def test_self_complementary_kmers_identical(tmp_path):
+    """even k on (AT)n / (ACGT)n / (AATT)n islands: k-mers that equal their reverse complement take no window slot (sketch.c:108), the sketch
+    kernels' lanes that start inside an island have to reach back beyond their fixed warm-up stretch (sketch_wave_kernel's base_at fallback; the
+    emulator's line coverage showed that no case reached it)"""
+    ref, rd = synth.make_palindromes(str(tmp_path))
+    for extra in (["-c", "-k", "16", "-w", "10"], ["-a", "-k", "14", "-w", "5"], ["-c", "-k", "20", "-w", "19"], ["-c", "-H", "-k", "16", "-w", "10"], ["-c"]):
+        want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        got, _ = _run([DROPIN, "-x", "map-ont", "-t", "8"] + extra + [ref, rd])
+        assert want == got, extra
+    # tiles of 256 bases (sketch_wave_kernel cuts reads longer than 16 kb into tiles; MM2AMD_SKETCH_TILE forces small ones): tile borders inside the islands,
+    # where the warm-up needs bases further back than the 128 a tile keeps resident before its start
+    want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "8", "-c", "-k", "16", "-w", "10", ref, rd])
+    p = subprocess.run([DROPIN, "-x", "map-ont", "-t", "8", "-c", "-k", "16", "-w", "10", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM2AMD_SKETCH_TILE="256"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout == want
+
+
+@pytest.mark.parametrize("kind,preset,n", [("ont", "map-ont", 40), ("cdna", "splice", 60), ("hifi", "map-hifi", 20)])
+def test_cigar_pool_overflow_retry_identical(kind, preset, n, tmp_path):
+    """The DP kernels write their CIGARs into one pool sized at a quarter of the worst case; a kernel whose CIGAR does not fit sets a flag instead of
+    writing (ksw_stream / ksw_gapfill / ksw_ext / ksw_extd2 / ksw_splice: `cigar_pool_cap`), and the batch's DP runs again with the worst-case pool
+    (ksw_host.cpp).  No ordinary input overflows a quarter, so no case reached the flag or the retry: MM2AMD_CIGAR_POOL_DIV makes the first pool 1/300."""
+    ref, rd, _, _ = synth.make(kind, str(tmp_path), 2, n, 9)
+    want, _ = _run([REF_BIN, "-x", preset, "-t", "8", "-c", ref, rd])
+    p = subprocess.run([DROPIN, "-x", preset, "-t", "8", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM2AMD_CIGAR_POOL_DIV="300"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout == want
+
+
 def test_edge_case_reads_identical(tmp_path):
     # tiny reads around k, all-N, IUPAC, lower case, low-complexity islands, a homopolymer, a whole-contig read, a chimera ...
     ref, rd = synth.make_weird(str(tmp_path))

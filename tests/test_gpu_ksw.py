@@ -194,7 +194,10 @@ def test_gap_fill_kernel_column_strips(preset):
 
 
 def test_jobs_longer_than_lds_use_the_hbm_state_kernel():
-    """targets beyond the ~11 k positions the LDS-resident kernel holds: banded extension across a long gap and a long thin global job"""
+    """long jobs: a banded extension across a long gap and long thin global jobs (their state window is as wide as their widest anti-diagonal, so
+    they still fit an LDS ring), and jobs whose anti-diagonals are wider than the largest LDS ring (8192 slots: query, target AND band beyond
+    8128) -- the only ones that reach ksw_extd2_kernel<false, ...>, the instantiation with its per-position state in HBM ('ksw_extd2_kernel[hbm]';
+    the emulator's line coverage showed that no case did)"""
     rng = np.random.default_rng(21)
     jobs = []
     t = rng.integers(0, 4, 15000, dtype=np.uint8)
@@ -204,6 +207,17 @@ def test_jobs_longer_than_lds_use_the_hbm_state_kernel():
     q2, t2 = random_pair(rng, 12500, 0.1)
     jobs.append((q2[:12000], t2[:12800], 751, 400, -1, 0xC2))
     _run(jobs, "ont")
+    import minimap2_amd as mm
+    q3, t3 = random_pair(np.random.default_rng(22), 8400, 0.1)
+    wide = [(q3[:8300], t3[:8350], 30001, 400, -1, 0x08), (q3[:8200], t3[:8400], 9000, 400, 10, 0x40), (q3[:8250], t3[:8300], 8200, 400, -1, 0xC2)]
+    mm.lib().mm2amd_profile_enable(1)
+    try:
+        _run(wide, "ont")
+        stats = (mm.KernelStat * 64)()
+        names = [stats[i].name.decode() for i in range(mm.lib().mm2amd_profile_get(stats, 64))]
+    finally:
+        mm.lib().mm2amd_profile_enable(0)
+    assert "ksw_extd2_kernel[hbm]" in names, names
 
 
 @pytest.mark.parametrize("sc", [(2, 4, 4, 2), (1, 4, 6, 2), (1, 9, 16, 2), (1, 2, 2, 1)])

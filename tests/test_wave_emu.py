@@ -298,3 +298,14 @@ def test_device_sort_and_prefix_sum_kernels(emu):
         a = rng.integers(0, 1 << 32 if n < 10000 else 7, n, dtype=np.uint64).astype(np.uint32)
         want = np.concatenate([[0], np.cumsum(a.astype(np.uint64))]).astype(np.uint64) & np.uint64(0xFFFFFFFF)
         assert np.array_equal(emu.exclusive_sum_u32(a).astype(np.uint64), want), n
+
+
+def test_cigar_pool_overflow_flag_and_retry(tmp_path):
+    """the DP kernels' CIGAR-pool overflow flag and ksw_host.cpp's retry with the worst-case pool (tests/test_gpu_dropin.py's case, the CPU suite's share):
+    a first pool of 1/300 of the worst case overflows on any input"""
+    if not os.path.exists(G.REF_BIN) or not os.path.exists(DROPIN_EMU):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    ref, rd, _, _ = synth.make("ont", str(tmp_path), 1, 12, 9)
+    want = subprocess.run([G.REF_BIN, "-x", "map-ont", "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    got = subprocess.run([DROPIN_EMU, "-x", "map-ont", "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=dict(os.environ, MM2AMD_CIGAR_POOL_DIV="300")).stdout
+    assert G.strip_pg(got) == G.strip_pg(want)

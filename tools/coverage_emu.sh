@@ -10,7 +10,7 @@ CPP="align backend_hip capi_common capi_index capi_kernels capi_map chain_host d
 HIP="seed_chain index_build device_sort ksw_extd2 ksw_gapfill ksw_stream ksw_splice ksw_ext region_finish"
 if [ "$1" = build ]; then
   mkdir -p $OUT; rm -f $OUT/*.gcda
-  FLAGS="-std=c++17 -O1 -g --coverage -fPIC -ffp-contract=off -Wno-unknown-pragmas -I$EMU -I$ROOT/include"
+  FLAGS="-std=c++17 -O2 -g --coverage -fPIC -ffp-contract=off -Wno-unknown-pragmas -I$EMU -I$ROOT/include"
   pids=()
   for f in $CPP; do g++ $FLAGS -c $CSRC/$f.cpp -o $OUT/$f.o & pids+=($!); done
   for f in $HIP; do g++ $FLAGS -x c++ -c $CSRC/$f.hip -o $OUT/$f.hip.o & pids+=($!); done
@@ -26,15 +26,31 @@ if [ "$1" = build ]; then
 elif [ "$1" = report ]; then
   cd $OUT
   for f in $HIP; do gcov -o $OUT $f.hip.gcda >/dev/null 2>&1 || true; done
-  for f in $HIP; do
-    g=$OUT/$f.hip.gcov
+  for f in $CPP; do gcov -o $OUT $f.gcda >/dev/null 2>&1 || true; done
+  for f in $CPP; do
+    g=$OUT/$f.cpp.gcov
     [ -f $g ] || continue
-    awk -F: -v name=$f.hip '{c=$1; gsub(/ /,"",c); if (c=="#####") miss++; else if (c!="-" && c!="=====") hit++} END {printf "%-22s %5d of %5d executable lines reached (%.1f %%)\n", name, hit, hit+miss, 100*hit/(hit+miss)}' $g
+    awk -F: -v name=$f.cpp '{c=$1; gsub(/ /,"",c); if (c=="#####") miss++; else if (c!="-" && c!="=====") hit++} END {printf "%-22s %5d of %5d executable lines reached (%.1f %%)\n", name, hit, hit+miss, 100*hit/(hit+miss)}' $g
   done
-  for f in $HIP; do
-    g=$OUT/$f.hip.gcov
-    [ -f $g ] || continue
-    echo "---- $f.hip: lines no test reached"
-    grep -n "^ *#####:" $g | sed -e 's/^[0-9]*: *#####: *//' | cut -c1-180
-  done
+  python3 - $OUT $HIP <<'PY'
+import re, sys
+out, files = sys.argv[1], sys.argv[2:]
+rows = []
+for f in files:
+    try: lines = open("%s/%s.hip.gcov" % (out, f), errors="replace").read().split("\n")
+    except OSError: continue
+    hit, text = {}, {}
+    for l in lines:  # "count: lineno: source"; template instantiations repeat their lines in blocks of their own: a line counts as reached when any occurrence ran
+        m = re.match(r"^\s*([^:]+):\s*(\d+):(.*)$", l)
+        if not m: continue
+        c, n, src = m.group(1).strip().rstrip("*"), int(m.group(2)), m.group(3)
+        if n == 0 or c == "-": continue
+        text[n] = src
+        hit[n] = hit.get(n, False) or (c not in ("#####", "=====") and c != "0")
+    rows.append((f, sum(hit.values()), len(hit), [(n, text[n]) for n in sorted(hit) if not hit[n]]))
+for f, h, t, _ in rows: print("%-22s %5d of %5d executable lines reached in some instantiation (%.1f %%)" % (f + ".hip", h, t, 100.0 * h / max(t, 1)))
+for f, h, t, miss in rows:
+    print("---- %s.hip: lines no test reached" % f)
+    for n, src in miss: print("%5d:%s" % (n, src[:170]))
+PY
 fi
