@@ -269,9 +269,12 @@ def main():
             torch.cuda.empty_cache()
     del codes
     torch.cuda.empty_cache()
+    whole_named = None
     if strong:  # this rank's share: contiguous, balanced by bases (pairs stay together: both mates in one entry)
         cut = shard.split_by_bases([len(r) + (len(mates[i]) if pairs else 0) for i, r in enumerate(reads)], world)
         first_read = cut[rank]
+        if rank == 0 and not a.timed_only:  # the whole batch, for the check that the N ranks' output IS the N = 1 output (after the clock)
+            whole_named = [("read%d" % i, s, mates[i]) for i, s in enumerate(reads)] if pairs else [("read%d" % i, s) for i, s in enumerate(reads)]
         reads = reads[cut[rank]:cut[rank + 1]]
         if pairs:
             mates = mates[cut[rank]:cut[rank + 1]]
@@ -300,8 +303,8 @@ def main():
 
     def on_mapped(b, n_reg, reg, rep_len):  # output thread: the final hit gather to rank 0, then this rank formats its own shard
         nonlocal n_mapped, n_hits
-        if gbuf is not None:
-            shard.gather_payloads(shard.pack_hits(L, n_reg, reg, gbuf), dst=0, device=comm_dev, bufs=gbuf)
+        if gbuf is not None:  # hit records + the reads' rep_len (the rl:i tag of mm_write_sam3): what the formatting rank needs to write the shard's records
+            shard.gather_payloads(shard.pack_hits(L, n_reg, reg, gbuf, tail=rep_len), dst=0, device=comm_dev, bufs=gbuf)
         nr = np.frombuffer(n_reg, dtype=np.int32, count=len(b.items))
         n_mapped, n_hits = int((nr > 0).sum()), int(nr.sum())
 
@@ -378,6 +381,61 @@ def main():
         al.free_raw(n_reg, reg)
         pipeline_text_identical = bool(h_pipe == h_plain and ln == out_len.value and ln > 0)
         log("text of the last timed step: %d bytes, blake2b %s (pipeline) vs %s (stage + run + format): %s" % (ln, h_pipe, h_plain, "identical" if pipeline_text_identical else "DIFFERENT"))
+    # N > 1 (strong scaling): is what the N ranks produce the N = 1 output?  One more batch through the SAME path (pipeline, hit gather to rank 0, every rank
+    # formats its shard), after the clock and un-rotated, so that the ranks' shards in rank order are the whole batch in input order (map.c:585-623 prints one
+    # ordered stream).  Rank 0 then maps the whole batch alone and compares (a) the ranks' texts, in rank order, with the corresponding slices of its own text
+    # (digests and lengths travel, not the text) and (b) the text it formats from the GATHERED hit records with its own.
+    text_identical_to_n1 = None
+    n1_check = None
+    if strong and not a.timed_only:
+        ver = {}
+        def on_mapped_v(b, n_reg, reg, rep_len):
+            parts = shard.gather_payloads(shard.pack_hits(L, n_reg, reg, gbuf, tail=rep_len), dst=0, device=comm_dev, bufs=gbuf)
+            if rank == 0:
+                ver["parts"] = [np.array(p_.cpu().numpy(), copy=True) for p_ in parts]  # (the gather's buffers are reused)
+        def on_text_v(b_, addr, ln):
+            ver["text"] = (text_hash(addr, ln), int(ln))
+        barrier()
+        al.pipeline([base], text=True, on_mapped=on_mapped_v, on_text=on_text_v)
+        shard_texts = [None] * world
+        dist.all_gather_object(shard_texts, ver.get("text"))
+        if rank == 0:
+            try:
+                wb = mm.Batch(whole_named)
+                al.stage(wb)
+                n_reg, reg, rep = al.run(raw=True)
+                out, out_len = C.c_void_p(), C.c_size_t()
+                mm._check(L.mm_gpu_format_batch(wb.n, wb.seg_off, wb.n_seg, wb.arr, n_reg, reg, rep, C.byref(out), C.byref(out_len)))
+                h_n1, off, ok_shards = text_hash(out.value, out_len.value), 0, True
+                for h_, ln_ in shard_texts:  # (a) rank r's text == bytes [off, off + ln) of the N = 1 text
+                    ok_shards = ok_shards and off + ln_ <= out_len.value and text_hash(out.value + off, ln_) == h_
+                    off += ln_
+                ok_shards = bool(ok_shards and off == out_len.value and out_len.value > 0)
+                mm._libc_free(out)
+                al.free_raw(n_reg, reg)
+                # (b) the gathered payloads: every rank's hit records then its rep_len array; unpacked in rank order they are the whole batch's hits
+                n_all = len(whole_named)
+                n_reg_g, reg_g, rep_g = (C.c_int * n_all)(), (C.c_void_p * n_all)(), (C.c_int * n_all)()
+                for r_ in range(world):
+                    m_ = cut[r_ + 1] - cut[r_]
+                    part = ver["parts"][r_]
+                    part = part[:part.size - 4 * (max(1, m_) - m_)]  # (an empty shard's arrays have one unused entry)
+                    nr_, rg_ = shard.unpack_hits(L, part[:part.size - 4 * m_], m_)
+                    n_reg_g[cut[r_]:cut[r_ + 1]] = nr_[:m_]
+                    reg_g[cut[r_]:cut[r_ + 1]] = rg_[:m_]
+                    rep_g[cut[r_]:cut[r_ + 1]] = np.frombuffer(part[part.size - 4 * m_:].tobytes(), dtype=np.int32).tolist()
+                out2, out2_len = C.c_void_p(), C.c_size_t()
+                mm._check(L.mm_gpu_format_batch(wb.n, wb.seg_off, wb.n_seg, wb.arr, n_reg_g, reg_g, rep_g, C.byref(out2), C.byref(out2_len)))
+                h_g = text_hash(out2.value, out2_len.value)
+                mm._libc_free(out2)
+                L.mm2amd_free_regs(n_all, n_reg_g, reg_g)
+                text_identical_to_n1 = bool(ok_shards and h_g == h_n1)
+                n1_check = {"n1_text_bytes": int(out_len.value), "n1_text_blake2b": h_n1, "shard_text_bytes": [ln_ for _, ln_ in shard_texts],
+                            "shard_texts_equal_n1_slices": ok_shards, "text_from_gathered_hits_blake2b": h_g, "text_from_gathered_hits_equals_n1": bool(h_g == h_n1)}
+                log("N=%d output vs N=1 on the same batch: shard texts %s, text formatted from the gathered hits %s" % (world, "identical" if ok_shards else "DIFFERENT", "identical" if h_g == h_n1 else "DIFFERENT"))
+            except Exception as e:  # reported, never hidden
+                text_identical_to_n1, n1_check = False, {"error": str(e)}
+        barrier()
     log("rank %d: %d steps in %.3f s (%.3f s per step; last batch's text %d bytes)  stats=%s" % (rank, a.steps, total_t, total_t / max(a.steps, 1), sam_bytes_per_step, {k: round(v, 3) for k, v in al.last_stats().items()}))
     drv_cpu_last_batch = {k: round(v, 3) for k, v in al.last_stats().items() if k.startswith("drv_cpu_")}  # the lane drivers' own CPU seconds per stage, last timed batch
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
@@ -640,6 +698,7 @@ def main():
                       "lane_driver_cpu_s_last_timed_batch": drv_cpu_last_batch,
                       "sam_bytes_per_step_this_rank": sam_bytes_per_step,
                       "pipeline_text_identical": pipeline_text_identical, "timed_steps_text_bytes": step_text_lengths,
+                      "text_identical_to_n1": text_identical_to_n1, "n1_check": n1_check,
                       "resident_gbases_per_s": round(batch_bases / resident / 1e9, 5) if resident else None,
                       "handover_then_map_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits, "as_rank_of": as_rank,

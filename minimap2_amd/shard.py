@@ -45,21 +45,27 @@ class GatherBuffers(object):
         return self.pack
 
 
-def pack_hits(L, n_reg, reg, bufs=None):
-    """ctypes (n_reg, reg) arrays -> uint8 torch tensor holding the flat payload (mm2amd_pack_regs); with `bufs` into its pinned buffer"""
+def pack_hits(L, n_reg, reg, bufs=None, tail=None):
+    """ctypes (n_reg, reg) arrays -> uint8 torch tensor holding the flat payload (mm2amd_pack_regs); with `bufs` into its pinned buffer.
+    tail: a ctypes int array of one entry per fragment (mm_tbuf_t::rep_len, which the SAM writer's rl:i tag needs) appended after the records."""
     n = len(n_reg)
     need = L.mm2amd_pack_regs(n, n_reg, reg, None, 0)
     if need < 0:
         raise RuntimeError(L.mm2amd_last_error().decode())
+    extra = 4 * n if tail is not None else 0
     if bufs is not None:
-        t = bufs.pack_buffer(max(int(need), 1))
+        t = bufs.pack_buffer(max(int(need) + extra, 1))
         got = L.mm2amd_pack_regs(n, n_reg, reg, C.c_void_p(t.data_ptr()), need)
         assert got == need
-        return t[:need]
-    buf = np.empty(max(int(need), 1), dtype=np.uint8)
+        if extra:
+            C.memmove(t.data_ptr() + need, tail, extra)
+        return t[:need + extra]
+    buf = np.empty(max(int(need) + extra, 1), dtype=np.uint8)
     got = L.mm2amd_pack_regs(n, n_reg, reg, buf.ctypes.data_as(C.c_void_p), need)
     assert got == need
-    return torch.from_numpy(buf[:need])
+    if extra:
+        C.memmove(buf.ctypes.data + need, tail, extra)
+    return torch.from_numpy(buf[:need + extra])
 
 
 def unpack_hits(L, payload, n_frag):

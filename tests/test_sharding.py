@@ -104,3 +104,32 @@ def test_two_rank_gather_equals_single_process():
         p.join(60)
         assert p.exitcode == 0
     assert same and roundtrip and n_hits >= 20
+
+
+EMU_SO = os.path.join(HERE, "_build", "libmm2amd_emu.so")
+
+
+@pytest.mark.skipif(not os.path.exists(EMU_SO), reason="needs tests/_build/libmm2amd_emu.so (the product's sources under the wave emulator)")
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_n_ranks_produce_the_n1_text(world):
+    """bench.py --gpus N, exactly as the driver launches it (torch.distributed.run, one process per rank), on the wave emulator with gloo:
+    the ranks' SAM texts in rank order must be the text one rank writes for the whole batch, and so must the text rank 0 formats from the
+    gathered hit records (map.c:585-623 prints ONE ordered stream; BASELINE.json: "SAM diff == 0" at 1/2/4/8)."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MM2AMD_BENCH_BACKEND="gloo", MM2AMD_EMU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--ref-mb", "1", "--reads", "25", "--read-len", "3000", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd="/tmp")
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads(p.stdout.decode().strip().split("\n")[-1])
+    c = line["config"]
+    assert line["n_gpus"] == world and line["scaling"] == "strong"
+    assert c["text_identical_to_n1"] is True, c["n1_check"]
+    chk = c["n1_check"]
+    assert chk["shard_texts_equal_n1_slices"] and chk["text_from_gathered_hits_equals_n1"]
+    assert len(chk["shard_text_bytes"]) == world and sum(chk["shard_text_bytes"]) == chk["n1_text_bytes"] > 0
