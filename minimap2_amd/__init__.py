@@ -589,7 +589,8 @@ class Aligner(object):
         k = lib().mm2amd_last_stats(v, 32)
         names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells", "dev_allocs", "pin_allocs",
                  "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish", "n_long_join_dev", "n_long_join_host",
-                 "drv_cpu_seed_chain", "drv_cpu_host_pre", "drv_cpu_plan", "drv_cpu_ksw", "drv_cpu_consume", "drv_cpu_finish", "n_early_sub"]
+                 "drv_cpu_seed_chain", "drv_cpu_host_pre", "drv_cpu_plan", "drv_cpu_ksw", "drv_cpu_consume", "drv_cpu_finish", "n_early_sub",
+                 "n_region_reads_dev", "n_region_reads_host"]
         return dict(zip(names, list(v)[:k]))
 
 

@@ -1461,10 +1461,15 @@ void Aligner::finish_read(ReadAlign &ra, RegVec &out)
 	out.clear();
 	for (int ti : ra.order)
 		if (ti >= 0) out.push_back(ra.tasks[ti].r);
-	filter_regs(opt_, ra.qlen, out);
-	if (!(opt_.flag & (F_SR | F_SR_RNA | F_ALL_CHAINS)) && !opt_.split_prefix && ra.qlen >= opt_.rank_min_len) {
-		update_dp_max(ra.qlen, out, opt_.rank_frac, opt_.a, opt_.b);
-		filter_regs(opt_, ra.qlen, out);
+	finish_regs(ra.qlen, out);
+}
+
+void Aligner::finish_regs(int qlen, RegVec &out) const // align.c:1110-1118
+{
+	filter_regs(opt_, qlen, out);
+	if (!(opt_.flag & (F_SR | F_SR_RNA | F_ALL_CHAINS)) && !opt_.split_prefix && qlen >= opt_.rank_min_len) {
+		update_dp_max(qlen, out, opt_.rank_frac, opt_.a, opt_.b);
+		filter_regs(opt_, qlen, out);
 	}
 	hit_sort(out, opt_.alt_drop);
 }

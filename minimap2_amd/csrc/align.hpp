@@ -104,6 +104,7 @@ public:
 	bool complete_finished(ReadAlign &ra, const FinResult *results, const FinRegion *regions, const uint32_t *cigars);
 	// Collect the regions in output order and run the post-alignment steps of mm_align_skeleton (:1110-1118).
 	void finish_read(ReadAlign &ra, RegVec &out);
+	void finish_regs(int qlen, RegVec &out) const; // ... its second half: `out` holds the read's aligned regions in output order
 
 	const int8_t *mat() const { return mat_; }
 private:

@@ -52,6 +52,16 @@ struct Lane {
 	PinBuf<unsigned long long> h_lj_cursor;
 	DevBuf<FinRegion> d_fin_regions; DevBuf<FinPiece> d_fin_pieces; DevBuf<uint32_t> d_fin_out; DevBuf<FinResult> d_fin_res; // region_finish.hip
 	PinBuf<FinRegion> h_fin_regions; PinBuf<FinPiece> h_fin_pieces; PinBuf<uint32_t> h_fin_out; PinBuf<FinResult> h_fin_res;
+	// align_regions (region_dev.hpp): the lane's last seed_chain() in device terms, the hit / window / piece arrays, the results' host copies
+	long rg_lo = 0; size_t rg_n = 0; uint64_t rg_n_v = 0, rg_n_v2 = 0, rg_n_u = 0, rg_n_u2 = 0;
+	std::vector<int8_t> rg_src; std::vector<uint64_t> rg_aoff, rg_uoff; std::vector<int32_t> rg_nu, rg_nv;
+	DevBuf<uint64_t> d_lj_out_u;
+	DevBuf<RgnRead> d_rg_reads; PinBuf<RgnRead> h_rg_reads;
+	DevBuf<Anchor> d_rg_sq; DevBuf<ref::Reg1> d_rg_regs; DevBuf<RgnAux> d_rg_aux; DevBuf<RgnReadOut> d_rg_rout; DevBuf<unsigned int> d_rg_cur;
+	DevBuf<RgnPlan> d_rg_plan; DevBuf<RgnWin> d_rg_win; DevBuf<KswJob> d_rg_jobs; DevBuf<int32_t> d_rg_sites; DevBuf<FinRegion> d_rg_fin; DevBuf<FinPiece> d_rg_pieces;
+	DevBuf<FinResult> d_rg_finres; DevBuf<uint32_t> d_rg_out;
+	PinBuf<ref::Reg1> h_rg_regs; PinBuf<RgnAux> h_rg_aux; PinBuf<RgnReadOut> h_rg_rout; PinBuf<unsigned int> h_rg_cur; PinBuf<RgnPlan> h_rg_plan; PinBuf<KswJob> h_rg_jobs;
+	PinBuf<FinRegion> h_rg_fin; PinBuf<FinResult> h_rg_finres; PinBuf<uint32_t> h_rg_out;
 	PinBuf<Anchor> h_anchors, h_redo;
 	PinBuf<int32_t> h_rep, h_nu, h_nv;
 	PinBuf<uint64_t> h_minipos, h_off, h_u, h_aoff, h_uoff;
@@ -85,7 +95,7 @@ public:
 		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
 		I_.name_rank = nullptr, I_.seq_len = nullptr;
-		fi_names_ = &fi.names, fi_seq_len_ = &fi.seq_len; // fi outlives the backend (it is the mapper's index)
+		fi_names_ = &fi.names, fi_seq_len_ = &fi.seq_len, fi_seq_off_ = &fi.seq_off; // fi outlives the backend (it is the mapper's index)
 		while ((1ull << rid_bits_) < fi.n_seq) ++rid_bits_;
 		n_lanes_ = 8; // sub-batches in flight.  Rounds 1-3: 5 (more made no difference while the lanes' waits spun on the CPU quota); with the lanes starting
 		              // on the next batch early, 8-10 keep seeding, sorting and DP kernels of different sub-batches on the GPU together: +3-4 % (profiles/r04, call 16)
@@ -409,9 +419,11 @@ public:
 			c.a_p = ha + h_aoff[i], c.n_a = h_nv[i];
 			c.chained = true;
 		}, 64);
+		ln.rg_lo = lo, ln.rg_n = n, ln.rg_n_v = n_v, ln.rg_n_u = n_u, ln.rg_n_v2 = ln.rg_n_u2 = 0;
+		for (size_t i = 0; i < n; ++i) out[i].dev_src = 0, out[i].dev_a_off = h_aoff[i], out[i].dev_u_off = h_uoff[i];
 		for (const auto &rd : redo) {
 			ReadChains &c = out[rd.first];
-			c.u_p = nullptr, c.n_u = 0, c.chained = false;
+			c.u_p = nullptr, c.n_u = 0, c.chained = false, c.dev_src = -1;
 			c.a_p = h_redo + rd.second, c.n_a = (int64_t)(a_off[rd.first + 1] - a_off[rd.first]);
 		}
 		if (P.long_join && !has_pairs_ && !getenv("MM2AMD_LONG_JOIN_ON_HOST")) long_join(P, lo, n, ln, kp, out, ha, hu, h_nu, h_nv, h_aoff, h_uoff); // (the diagnostic switch: every re-chain through rmq_chain.cpp)
@@ -466,7 +478,8 @@ public:
 		P2.rmq = 1, P2.bw = P.bw_long, P2.flag &= ~(int64_t)ref::F_HEAP_SORT; // (the heap-merge order belongs to the seeding; this sort is radix_sort_128x)
 		launch_anchor_sort(B2, I_, P2, ln.d_sort_list.p, n_class, a_class, st, &kp);
 		kp.begin(st); launch_chain_rmq(B2, P2, st); kp.end(st, "chain_rmq_kernel[long-join]", 32.0 * n_a2);
-		B2.bt_out_a = ln.d_lj_out_a.p; // (chains, counts and offsets reuse the first pass's arrays: they have been copied out)
+		ln.d_lj_out_u.ensure((P2.min_cnt >= 2 ? n_a2 / 2 : n_a2) + n2 + 1);
+		B2.bt_out_a = ln.d_lj_out_a.p, B2.bt_out_u = ln.d_lj_out_u.p; // (counts and offsets reuse the first pass's arrays: they have been copied out; the first pass's chains stay for align_regions)
 		kp.begin(st); launch_chain_backtrack(B2, P2, st); kp.end(st, "chain_backtrack_kernel[long-join]", 8.0 * n_a2);
 		unsigned long long *h_cur = ln.h_lj_cursor.ensure(2);
 		int32_t *nu2 = ln.h_lj_nu.ensure(n2), *nv2 = ln.h_lj_nv.ensure(n2);
@@ -483,7 +496,8 @@ public:
 		Anchor *ha2 = ln.h_lj_a.ensure(n_v2 + 1);
 		uint64_t *hu2 = ln.h_lj_u.ensure(n_u2 + 1);
 		if (n_v2) HIP_CHECK(hipMemcpyAsync(ha2, ln.d_lj_out_a.p, n_v2 * sizeof(Anchor), hipMemcpyDeviceToHost, st));
-		if (n_u2) HIP_CHECK(hipMemcpyAsync(hu2, ln.d_bt_out_u.p, n_u2 * 8, hipMemcpyDeviceToHost, st));
+		if (n_u2) HIP_CHECK(hipMemcpyAsync(hu2, ln.d_lj_out_u.p, n_u2 * 8, hipMemcpyDeviceToHost, st));
+		ln.rg_n_v2 = n_v2, ln.rg_n_u2 = n_u2;
 		stream_wait(st);
 		kp.collect();
 		for (size_t k = 0; k < n2; ++k) {
@@ -492,6 +506,7 @@ public:
 			c.u_p = hu2 + uoff2[k], c.n_u = nu2[k];
 			c.a_p = ha2 + aoff2[k], c.n_a = nv2[k];
 			c.long_joined = true;
+			c.dev_src = 1, c.dev_a_off = aoff2[k], c.dev_u_off = uoff2[k];
 		}
 	}
 
@@ -518,6 +533,129 @@ public:
 		}
 		ln.ksw.run(jobs, res_[ln.set].d_qpool.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id, replica_).collect();
+	}
+
+	// region_dev.hpp: chains -> hits -> windows -> DP -> consume -> finish on the device, for the reads of this lane's last seed_chain()
+	bool aligns_regions() const override
+	{
+		const char *e = getenv("MM2AMD_DEVICE_REGIONS"); // =0: the host's chains -> hits, window planning and consumption (A/B checks)
+		return !(e && *e == '0');
+	}
+	void align_regions(int lane_id, const RgnOpts &O, const KswScoring &sc, bool log_gap, const std::vector<ReadChains> &chains, const std::vector<RegionReadIn> &in, int n_threads,
+	                   RegionBatchOut &out) override
+	{
+		HIP_CHECK(hipSetDevice(dev_));
+		Lane &ln = *lanes_.at(lane_id);
+		hipStream_t st = ln.stream;
+		const Resident &R = res_[ln.set];
+		const size_t n = ln.rg_n;
+		out = RegionBatchOut();
+		if (n == 0 || chains.size() < n || in.size() < n) return;
+		if (!d_ref_off_.p) { // once: the reference sequences' offsets and lengths
+			std::lock_guard<std::mutex> lk(ref_mu_);
+			if (!d_ref_off_.p) {
+				d_ref_off_.ensure(fi_seq_off_->size() + 1), d_ref_len2_.ensure(fi_seq_len_->size() + 1);
+				HIP_CHECK(hipMemcpyAsync(d_ref_off_.p, fi_seq_off_->data(), fi_seq_off_->size() * 8, hipMemcpyHostToDevice, st));
+				HIP_CHECK(hipMemcpyAsync(d_ref_len2_.p, fi_seq_len_->data(), fi_seq_len_->size() * 4, hipMemcpyHostToDevice, st));
+				stream_wait(st);
+			}
+		}
+		KernelProfiler &kp = kernel_profiler(lane_id, replica_);
+		double tt = Trace::now();
+		// the reads in device terms
+		RgnRead *hr = ln.h_rg_reads.ensure(n);
+		uint64_t sq = 0, n_chain = 0;
+		int max_nu = 1;
+		for (size_t i = 0; i < n; ++i) {
+			const ReadChains &c = chains[i];
+			RgnRead &r = hr[i];
+			const bool skip = in[i].skip || c.dev_src < 0 || !c.chained;
+			r.a_off = c.dev_a_off, r.u_off = c.dev_u_off, r.sq_off = sq, r.mp_off = ln.mp_off[i];
+			r.qpool_fwd = 2 * R.seq_off[ln.rg_lo + i];
+			r.n_u = skip ? 0 : c.n_u, r.n_a = skip ? 0 : (int32_t)c.n_a, r.n_mp = (int32_t)(ln.mp_off[i + 1] - ln.mp_off[i]);
+			r.qlen = (int32_t)(R.seq_off[ln.rg_lo + i + 1] - R.seq_off[ln.rg_lo + i]);
+			r.hash = in[i].hash, r.src = skip ? RGN_SRC_SKIP : (c.dev_src == 1 ? RGN_SRC_LJ : 0);
+			if (!skip) sq += (uint64_t)c.n_a, n_chain += (uint64_t)c.n_u, max_nu = std::max(max_nu, (int)c.n_u);
+		}
+		const uint32_t max_regs = (uint32_t)n_chain;
+		const uint64_t max_jobs64 = sq + 2 * n_chain + 1;
+		if (max_jobs64 >= (1ull << 31)) throw std::runtime_error("[mm2amd] align_regions: a sub-batch with more than 2^31 anchors");
+		RgnBuffers B{};
+		B.n_reads = (int)n;
+		ln.d_rg_reads.ensure(n), ln.d_rg_rout.ensure(n), ln.d_rg_cur.ensure(RGN_CUR_N);
+		ln.d_rg_sq.ensure(sq + 1), ln.d_rg_sites.ensure(sq + 1);
+		ln.d_rg_regs.ensure(max_regs + 1), ln.d_rg_aux.ensure(max_regs + 1), ln.d_rg_plan.ensure(max_regs + 1), ln.d_rg_fin.ensure(max_regs + 1), ln.d_rg_finres.ensure(max_regs + 1);
+		ln.d_rg_win.ensure(max_jobs64), ln.d_rg_jobs.ensure(max_jobs64), ln.d_rg_pieces.ensure(max_jobs64);
+		HIP_CHECK(hipMemcpyAsync(ln.d_rg_reads.p, hr, n * sizeof(RgnRead), hipMemcpyHostToDevice, st));
+		HIP_CHECK(hipMemsetAsync(ln.d_rg_cur.p, 0, RGN_CUR_N * sizeof(unsigned int), st));
+		B.reads = ln.d_rg_reads.p;
+		B.a_src[0] = ln.d_bt_out_a.p, B.a_src[1] = ln.d_lj_out_a.p, B.u_src[0] = ln.d_bt_out_u.p, B.u_src[1] = ln.d_lj_out_u.p;
+		B.mini_pos = ln.d_minipos.p, B.sq_a = ln.d_rg_sq.p, B.regs = ln.d_rg_regs.p, B.aux = ln.d_rg_aux.p, B.rout = ln.d_rg_rout.p, B.cursors = ln.d_rg_cur.p;
+		B.ref_len = d_ref_len2_.p, B.ref_off = d_ref_off_.p, B.max_regs = max_regs;
+		B.lds_chains = std::min(256, (max_nu + 63) / 64 * 64);
+		B.plan = ln.d_rg_plan.p, B.win = ln.d_rg_win.p, B.jobs = ln.d_rg_jobs.p, B.gap_sites = ln.d_rg_sites.p, B.max_jobs = (uint32_t)max_jobs64;
+		B.fin = ln.d_rg_fin.p, B.pieces = ln.d_rg_pieces.p;
+		kp.begin(st); launch_chain_regs(B, O, st); kp.end(st, "chain_regs_kernel", 32.0 * (double)sq + 80.0 * (double)n_chain);
+		kp.begin(st); launch_region_plan(B, O, st); kp.end(st, "region_plan_kernel", 16.0 * (double)sq);
+		unsigned int *cur = ln.h_rg_cur.ensure(RGN_CUR_N);
+		HIP_CHECK(hipMemcpyAsync(cur, ln.d_rg_cur.p, RGN_CUR_N * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+		stream_wait(st);
+		const uint32_t n_regs = std::min<uint32_t>(cur[RGN_CUR_REGS], max_regs);
+		const size_t n_jobs = std::min<size_t>(cur[RGN_CUR_JOBS], (size_t)max_jobs64);
+		Trace::get().add(lane_id, "gpu:regs+plan", tt, Trace::now()); tt = Trace::now();
+		// the DP: the job records cross once for the host's launch planning (classes, order, scratch sizes); the results stay on the device
+		const uint32_t *d_cigar = nullptr;
+		size_t n_cig = 0;
+		if (n_jobs) {
+			KswJob *hj = ln.h_rg_jobs.ensure(n_jobs);
+			HIP_CHECK(hipMemcpyAsync(hj, ln.d_rg_jobs.p, n_jobs * sizeof(KswJob), hipMemcpyDeviceToHost, st));
+			stream_wait(st);
+			for (size_t j = 0; j < n_jobs; ++j) out.dp_cells += (double)hj[j].qlen * hj[j].tlen;
+			ln.ksw.n_threads = n_threads, ln.ksw.prof = &kp, ln.ksw.lane = lane_id;
+			size_t dir_gb = 160;
+			if (const char *e = getenv("MM2AMD_DIR_BUDGET_GB")) dir_gb = atol(e) > 0 ? (size_t)atol(e) : dir_gb;
+			ln.ksw.dir_budget = std::min<size_t>((dir_gb << 30) / (size_t)active_lanes_, (size_t)96 << 30);
+			ln.ksw.run_jobs(hj, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st);
+		}
+		tt = Trace::now();
+		B.res = ln.ksw.d_res.p, B.perm = ln.ksw.d_perm.p;
+		kp.begin(st); launch_region_consume(B, O, d_cigar, st); kp.end(st, "region_consume_kernel", 68.0 * (double)n_jobs);
+		HIP_CHECK(hipMemcpyAsync(cur, ln.d_rg_cur.p, RGN_CUR_N * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+		stream_wait(st);
+		const size_t out_words = cur[RGN_CUR_OUT];
+		ln.d_rg_out.ensure(out_words + 1);
+		if (n_regs && cur[RGN_CUR_N_FIN]) {
+			FinParams P;
+			P.regions = ln.d_rg_fin.p, P.n_regions = (int)n_regs, P.pieces = ln.d_rg_pieces.p, P.cigar_pool = d_cigar, P.out_pool = ln.d_rg_out.p, P.results = ln.d_rg_finres.p;
+			P.qpool = R.d_qpool.p, P.S = T_->S.p;
+			memcpy(P.mat, sc.mat, 25);
+			P.q = sc.q, P.e = sc.e, P.log_gap = log_gap ? 1 : 0;
+			P.cap_ops = (int)std::min<uint32_t>((std::max<uint32_t>(cur[RGN_CUR_MAX_OPS], 1u) + 63) & ~63u, (uint32_t)kFinMaxOps);
+			kp.begin(st);
+			region_finish_launch(P, st);
+			kp.end(st, "region_finish_kernel", (double)out_words * 8.0 + (double)cur[RGN_CUR_N_FIN] * (sizeof(FinRegion) + sizeof(FinResult)), (double)cur[RGN_CUR_N_FIN]);
+		}
+		RgnReadOut *h_rout = ln.h_rg_rout.ensure(n);
+		ref::Reg1 *h_regs = ln.h_rg_regs.ensure(n_regs + 1);
+		RgnAux *h_aux = ln.h_rg_aux.ensure(n_regs + 1);
+		RgnPlan *h_plan = ln.h_rg_plan.ensure(n_regs + 1);
+		FinRegion *h_fin = ln.h_rg_fin.ensure(n_regs + 1);
+		FinResult *h_finres = ln.h_rg_finres.ensure(n_regs + 1);
+		uint32_t *h_out = ln.h_rg_out.ensure(out_words + 1);
+		HIP_CHECK(hipMemcpyAsync(h_rout, ln.d_rg_rout.p, n * sizeof(RgnReadOut), hipMemcpyDeviceToHost, st));
+		if (n_regs) {
+			HIP_CHECK(hipMemcpyAsync(h_regs, ln.d_rg_regs.p, n_regs * sizeof(ref::Reg1), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(h_aux, ln.d_rg_aux.p, n_regs * sizeof(RgnAux), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(h_plan, ln.d_rg_plan.p, n_regs * sizeof(RgnPlan), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(h_fin, ln.d_rg_fin.p, n_regs * sizeof(FinRegion), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(h_finres, ln.d_rg_finres.p, n_regs * sizeof(FinResult), hipMemcpyDeviceToHost, st));
+		}
+		if (out_words) HIP_CHECK(hipMemcpyAsync(h_out, ln.d_rg_out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		stream_wait(st);
+		Trace::get().add(lane_id, "gpu:consume+finish, d2h:hits", tt, Trace::now());
+		kp.collect();
+		out.reads = h_rout, out.regs = h_regs, out.aux = h_aux, out.plan = h_plan, out.fin = h_fin, out.fin_res = h_finres, out.cigars = h_out;
+		out.n_regs = n_regs, out.n_jobs = n_jobs;
 	}
 
 	// MM2AMD_DEVICE_FINISH=1 / =0 decides; unset: the device finishes the regions when this mapper has fewer than 12 host threads.  The kernel saves
@@ -618,6 +756,10 @@ private:
 	bool name_rules_ = false;
 	const std::vector<std::string> *fi_names_ = nullptr;
 	const std::vector<uint32_t> *fi_seq_len_ = nullptr;
+	const std::vector<uint64_t> *fi_seq_off_ = nullptr;
+	DevBuf<uint64_t> d_ref_off_;
+	DevBuf<uint32_t> d_ref_len2_;
+	std::mutex ref_mu_;
 	std::vector<std::string> sorted_names_;
 	DevBuf<int32_t> d_name_rank_;
 	DevBuf<uint32_t> d_ref_len_;

@@ -135,6 +135,7 @@ void run_replicas(MapContext &c, const StagedBatch &bt, std::vector<ReadResult> 
 		sum.n_early_sub += s.n_early_sub;
 		sum.d_seed_chain += s.d_seed_chain, sum.d_host_pre += s.d_host_pre, sum.d_plan += s.d_plan, sum.d_ksw += s.d_ksw, sum.d_consume += s.d_consume, sum.d_finish += s.d_finish;
 		sum.n_long_join_dev += s.n_long_join_dev, sum.n_long_join_host += s.n_long_join_host;
+		sum.n_region_reads_dev += s.n_region_reads_dev, sum.n_region_reads_host += s.n_region_reads_host;
 	}
 	std::lock_guard<std::mutex> lk(c.stats_mu);
 	c.stats = sum;
@@ -679,7 +680,8 @@ int mm2amd_last_stats(double *v, int n)
 	const double a[] = { s.t_seed_chain, s.t_host_pre, s.t_plan, s.t_ksw, s.t_consume, s.t_finish, (double)s.n_jobs, (double)s.n_rounds, s.dp_cells,
 	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2),
 	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish, (double)s.n_long_join_dev, (double)s.n_long_join_host,
-	                     s.d_seed_chain, s.d_host_pre, s.d_plan, s.d_ksw, s.d_consume, s.d_finish, (double)s.n_early_sub }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
+	                     s.d_seed_chain, s.d_host_pre, s.d_plan, s.d_ksw, s.d_consume, s.d_finish, (double)s.n_early_sub,
+	                     (double)s.n_region_reads_dev, (double)s.n_region_reads_host }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -95,10 +95,10 @@ int ksw_stream_waves(int n_sets);
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
 void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);               // ksw_ext.hip
 
-void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-                    const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
+void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
+                         const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
 {
-	const size_t n = jobs.size();
+	const bool resident = res == nullptr; // the results stay on the device (ksw_host.hpp)
 	*cigar_out = nullptr, *n_cigar_out = 0;
 	if (n == 0) return;
 	double tt = Trace::now();
@@ -224,7 +224,13 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		HIP_CHECK(hipMemcpyAsync(d_juncs.p, sc.juncs, sc.n_juncs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		sc_dev.juncs = d_juncs.p;
 	}
-	KswRes *tr = tmp_res.ensure(n);
+	KswRes *tr = resident ? nullptr : tmp_res.ensure(n);
+	if (resident) { // the consumer on the device finds job i's result through the launch order
+		uint32_t *hp = h_perm.ensure(n);
+		memcpy(hp, perm.data(), n * sizeof(uint32_t));
+		d_perm.ensure(n);
+		HIP_CHECK(hipMemcpyAsync(d_perm.p, hp, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+	}
 
 	// CIGARs are much shorter than qlen+tlen; start with a quarter of the worst case and retry in full on overflow
 	static const int pool_div = getenv("MM2AMD_CIGAR_POOL_DIV") ? std::max(1, atoi(getenv("MM2AMD_CIGAR_POOL_DIV"))) : 0; // tests: a first pool that is too small, so that the retry runs
@@ -355,9 +361,10 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		// the call, spinning: the lane drivers spent the whole duration of the DP kernels on a core each, 1.2 core-seconds per step)
 		uint32_t *cursor = h_cursor.ensure(2);
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
+		if (!resident) HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
 		stream_wait(stream);
 		Trace::get().add(lane, "gpu:ksw", tt, Trace::now()); tt = Trace::now();
+		if (cursor[1] == 0 && resident) { *cigar_out = d_cigar.p, *n_cigar_out = cursor[0]; break; }
 		if (cursor[1] == 0) {
 			uint32_t *hc = cigar_host.ensure((size_t)cursor[0] + 1);
 			if (cursor[0]) {
@@ -371,7 +378,7 @@ void KswRunner::run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, con
 		if (attempt > 0) throw std::runtime_error("[mm2amd] CIGAR pool overflow even at worst-case size");
 		pool_cap = sum_len + 16;
 	}
-	{
+	if (!resident) {
 		hostprof::Scope hp(hostprof::KSW_UNPERM);
 		parallel_for(n_threads, (long)n, [&](long i, int) { res[i] = tr[perm[i]]; }, 4096);
 	}

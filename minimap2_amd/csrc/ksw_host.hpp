@@ -31,7 +31,14 @@ struct KswRunner {
 	// Pools are device pointers.  Results land in res[i] (input order); the CIGARs stay in this runner's pinned buffer
 	// (*cigar_out, valid until the next run) and are addressed by res[i].cigar_off / n_cigar.
 	void run(const std::vector<KswJob> &jobs, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-	         const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream);
+	         const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
+	{ run_jobs(jobs.data(), jobs.size(), d_qpool, d_tpool, d_S, sc, res, cigar_out, n_cigar_out, stream); }
+	// res == nullptr: the results STAY on the device for a consumer there (region_consume_kernel): d_res in launch order, d_perm[i] = launch
+	// position of job i, the CIGARs in d_cigar; nothing but the pool's cursor comes back.  *n_cigar_out = entries used in d_cigar.
+	void run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
+	              const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream);
+	DevBuf<uint32_t> d_perm;
+	PinBuf<uint32_t> h_perm;
 };
 
 } // namespace mm2amd

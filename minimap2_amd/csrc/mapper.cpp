@@ -1,5 +1,6 @@
 #include <chrono>
 #include <ctime>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <malloc.h>
@@ -35,6 +36,20 @@ double cpu_now() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); re
 double thr_now() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 }
 
+// Backend::align_regions takes single-segment reads of the plain long-read configurations: dual- or single-affine DNA alignment with CIGARs.  What it leaves
+// to the host path -- each a rule the device kernels do not carry: spliced and short-read alignment (two strands per region, ungapped shortcuts, composed
+// targets), query-strand coordinates, =/X CIGARs, chains reported as hits, ALT contigs, junction / jump annotation, homopolymer-compressed minimizers (the
+// window boundary walks the sequences), and the re-seeding of reads without chains (-f x,y: map.c:293-316).
+bool region_path_supported(const MapOpt &opt, int idx_flag, int n_alt, bool has_annotation)
+{
+	if (!(opt.flag & F_CIGAR)) return false;
+	if (opt.flag & (F_SPLICE | F_SR | F_SR_RNA | F_QSTRAND | F_EQX | F_ALL_CHAINS)) return false;
+	if (n_alt > 0 || has_annotation || (idx_flag & I_HPC)) return false;
+	if (opt.max_occ > opt.mid_occ && !(opt.flag & F_RMQ)) return false;
+	if (opt.split_prefix) return false;
+	return true;
+}
+
 uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 {
 	uint32_t h = qname && !(opt.flag & F_NO_HASH_NAME) ? x31_hash(qname) : 0;
@@ -44,6 +59,18 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
+	{ // what the device's chains -> hits -> windows path reads from the options (region_dev.hpp)
+		RgnOpts &O = rgn_opts_;
+		O.flag = opt.flag, O.max_sw_mat = opt.max_sw_mat, O.k = fi.k;
+		O.mask_level = opt.mask_level, O.pri_ratio = opt.pri_ratio, O.mask_len = opt.mask_len, O.best_n = opt.best_n;
+		O.sub_diff = opt.a * 2 + opt.b, O.min_strand_sc = (int)(opt.max_gap * 0.8);
+		O.max_gap = opt.max_gap, O.min_cnt = opt.min_cnt, O.min_chain_score = opt.min_chain_score, O.bw = opt.bw;
+		O.bw_ext = (int)(opt.bw * 1.5 + 1.), O.bw_gap = (int)(opt.bw_long * 1.5 + 1.);
+		if (O.bw_gap < O.bw_ext) O.bw_gap = O.bw_ext;
+		O.a = opt.a, O.b = opt.b, O.q = opt.q, O.e = opt.e, O.zdrop = opt.zdrop, O.zdrop_inv = opt.zdrop_inv, O.end_bonus = opt.end_bonus, O.min_ksw_len = opt.min_ksw_len;
+		O.transition = opt.transition;
+		rgn_ok_ = region_path_supported(opt, fi.flag, fi.n_alt, fi.has_junc || fi.has_jump || fi.has_spsc);
+	}
 	// MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
 	if (opt.flag & F_QSTRAND) { // reverse-strand hits in query-strand coordinates: DP targets are composed (reverse-complemented) into the byte pool
 		if (!be.supports_byte_targets()) throw std::invalid_argument("[mm2amd] --qstrand needs a backend with composed DP targets");
@@ -200,6 +227,7 @@ std::shared_ptr<Mapper::BatchRun> Mapper::make_run(int set)
 	if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) n_drivers = std::max(1, std::min(n_drivers, atoi(e))); // read per run: bench.py takes its un-overlapped kernel times with one lane
 	b.n_drivers = n_drivers;
 	b.device_finish = be_.finishes_regions(); // one answer for the whole batch
+	b.device_regions = rgn_ok_ && b.device_finish && be_.aligns_regions();
 	return bp;
 }
 
@@ -254,6 +282,7 @@ void Mapper::driver_loop(int lane)
 			stats.t_consume += st.t_consume, stats.t_finish += st.t_finish, stats.n_jobs += st.n_jobs, stats.n_rounds += st.n_rounds, stats.dp_cells += st.dp_cells;
 			stats.c_seed_chain += st.c_seed_chain, stats.c_host_pre += st.c_host_pre, stats.c_plan += st.c_plan, stats.c_ksw += st.c_ksw, stats.c_consume += st.c_consume, stats.c_finish += st.c_finish;
 			stats.n_long_join_dev += st.n_long_join_dev, stats.n_long_join_host += st.n_long_join_host;
+			stats.n_region_reads_dev += st.n_region_reads_dev, stats.n_region_reads_host += st.n_region_reads_host;
 			stats.d_seed_chain += st.d_seed_chain, stats.d_host_pre += st.d_host_pre, stats.d_plan += st.d_plan, stats.d_ksw += st.d_ksw, stats.d_consume += st.d_consume, stats.d_finish += st.d_finish;
 			if (err) { if (!b->err) b->err = err; b->cancelled = true; } // no further sub-batch of it is handed out
 			++b->n_done;
@@ -285,6 +314,38 @@ void Mapper::run(std::vector<ReadResult> &out)
 	Trace::get().flush();
 	out.swap(b->out);
 	if (b->err) std::rethrow_exception(b->err);
+}
+
+// A read the device finished (Backend::align_regions): its hit records as mm_align_skeleton leaves them (align.c:1048-1108) -- the records of
+// chain_regs_kernel with the coordinates region_consume_kernel set, mm_est_err's divergence from the kernel's counts (libm's pow stays here),
+// the CIGAR container as mm_update_extra left it (region_finish_kernel), in a libc block the caller frees.
+void Mapper::device_hits(const Backend::RegionBatchOut &rb, const ReadChains &c, long i, int qlen, RegVec &regs) const
+{
+	regs.clear();
+	const RgnReadOut &ro = rb.reads[i];
+	if (ro.n_regs <= 0) return;
+	regs.reserve((size_t)ro.n_regs);
+	const float avg_k = c.n_mp > 0 ? (float)((uint64_t)c.n_mp * (uint64_t)fi_.k) / c.n_mp : 0.0f; // esterr.c:37-40 (every span is k: no HPC on this path)
+	constexpr uint32_t kHdr = sizeof(Extra) / 4;
+	for (int32_t p = 0; p < ro.n_regs; ++p) {
+		const uint32_t slot = ro.reg0 + (uint32_t)p;
+		Reg r = rb.regs[slot];
+		const RgnAux &x = rb.aux[slot];
+		const RgnPlan &pl = rb.plan[slot];
+		const FinResult &f = rb.fin_res[slot];
+		r.div = x.n_tot < 0 ? -1.0f : x.n_match >= x.n_tot ? 0.0f : (float)(1.0 - pow((double)x.n_match / x.n_tot, 1.0 / avg_k)); // esterr.c:61
+		if (pl.status != 0 || f.n_cigar < 0 || (uint32_t)f.n_cigar + kHdr > pl.capacity) throw std::runtime_error("[mm2amd] align_regions: a finished region without a consistent CIGAR");
+		r.p = (Extra *)calloc(pl.capacity, 4);
+		r.p->capacity = pl.capacity;
+		r.p->n_cigar = (uint32_t)f.n_cigar;
+		memcpy(r.p->cigar, rb.cigars + rb.fin[slot].out_off, (size_t)f.n_cigar * 4);
+		r.p->dp_score = pl.dp_score, r.p->dp_max = r.p->dp_max0 = f.dp_max, r.p->n_ambi = (uint32_t)f.n_ambi;
+		r.blen = f.blen, r.mlen = f.mlen, r.is_spliced = f.is_spliced;
+		if (f.qshift) { if (r.rev) r.qe -= f.qshift; else r.qs += f.qshift; } // mm_fix_cigar's dropped leading gap (align.c:171-180)
+		r.rs += f.tshift;
+		regs.push_back(r);
+	}
+	(void)qlen;
 }
 
 void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, MapperStats &stats)
@@ -337,10 +398,39 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 		stats.t_seed_chain += now() - t0; t0 = now();
 		stats.c_seed_chain += cpu_now() - c0; c0 = cpu_now(); stats.d_seed_chain += thr_now() - d0; d0 = thr_now();
 
+		// ---- chains -> hits -> DP windows -> DP -> finished regions on the device (region_dev.hpp), for every read it can decide alone ----
+		const bool is_sr = (opt_.flag & (F_SR | F_SR_RNA)) != 0;
+		KswScoring sc;
+		Aligner aligner(opt_, fi_);
+		memcpy(sc.mat, aligner.mat(), 25);
+		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.noncan = (int8_t)opt_.noncan;
+		sc.single = (opt_.flag & F_SPLICE) ? 2 : (opt_.q == opt_.q2 && opt_.e == opt_.e2) ? 1 : 0; // which DP mm_align_pair picks (align.c:352-360)
+		Backend::RegionBatchOut rb;
+		std::vector<uint8_t> &on_dev = ds.on_dev;
+		on_dev.assign((size_t)m, 0);
+		if (batch.device_regions) {
+			std::vector<Backend::RegionReadIn> &in = ds.rg_in;
+			in.resize((size_t)m);
+			const bool host_long_join = opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0;
+			parallel_for(n_threads_, m, [&](long i, int) {
+				const ReadChains &c = chains[i];
+				const ReadView &rv = live[lo + i];
+				// the host keeps: pairs, reads the backend did not chain, reads whose long-join question (map.c:283-292) is still open
+				in[i].skip = rv.paired() || !c.chained || c.dev_src < 0 || (host_long_join && !c.long_join_done && c.n_u > 1);
+				in[i].hash = read_hash(rv.name, rv.total(), opt_);
+			}, 1024);
+			be_.align_regions(lane, rgn_opts_, sc, !is_sr, chains, in, n_threads_, rb);
+			long n_dev = 0;
+			for (long i = 0; i < m; ++i) on_dev[i] = !in[i].skip && rb.reads[i].flags == 0, n_dev += on_dev[i];
+			stats.n_region_reads_dev += n_dev, stats.n_region_reads_host += m - n_dev;
+			stats.n_jobs += (long)rb.n_jobs, stats.dp_cells += rb.dp_cells, stats.n_rounds += rb.n_jobs ? 1 : 0;
+			stats.t_ksw += now() - t0; t0 = now();
+			stats.c_ksw += cpu_now() - c0; c0 = cpu_now(); stats.d_ksw += thr_now() - d0; d0 = thr_now();
+		} else stats.n_region_reads_host += m;
+
 		// ---- host: chains -> hits, primary/secondary marking, divergence (map.c:283-336) ----
 		// A two-segment fragment (paired-end reads) is seeded and chained as one query -- the concatenation of its segments -- and
 		// then split: each segment becomes an alignment UNIT of its own (map.c:343-351); a plain read is one unit.
-		Aligner aligner(opt_, fi_);
 		std::vector<ReadAlign> &ra = ds.ra;
 		std::vector<RegVec> &regs0 = ds.regs0;
 		std::vector<long> &unit0 = ds.unit0;
@@ -360,7 +450,6 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			if (live[lo + i].paired()) ds.q4_off[unit0[i] + 1] = q4_total, q4_total += 2 * q4_stride(live[lo + i].len2);
 		}
 		if (ds.q4.size() < q4_total + 16) ds.q4.resize(q4_total + q4_total / 4 + 16); // (every strand block is followed by >= 15 bytes of its own: update_extra compares 16 columns per load, q4_stride)
-		const bool is_sr = (opt_.flag & (F_SR | F_SR_RNA)) != 0;
 		std::atomic<long> n_lj_dev{0}, n_lj_host{0};
 		parallel_for(n_threads_, m, [&](long i, int) {
 			hostprof::Scope hp(hostprof::CHAINS_TO_HITS);
@@ -369,6 +458,14 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			const int qlen = rv.total(), n_segs = rv.paired() ? 2 : 1, qlens[2] = { rv.len, rv.len2 };
 			const long u0 = unit0[i];
 			ReadResult &res = out[live_id[lo + i]];
+			if (c.long_joined) ++n_lj_dev;
+			if (on_dev[i]) { // the device has this read's hits already: nothing to prepare
+				int gap_ref, gap_qry;
+				chain_gaps(sp, qlen, &gap_ref, &gap_qry);
+				res.frag_gap = gap_ref, res.rep_len = c.rep_len; // map.c:317-318
+				ra[u0].tasks.clear(), ra[u0].order.clear(), ra[u0].finish_queue.clear();
+				return;
+			}
 			const uint32_t hash = read_hash(rv.name, qlen, opt_);
 			if ((opt_.flag & F_RMQ) && !c.chained) { // mg_lchain_rmq as the primary chainer (map.c:275-277), for the reads the backend did not chain
 				ChainScratch sc;
@@ -379,7 +476,6 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 				c.u.swap(u2), c.a.swap(out_a);
 				c.u_p = c.u.data(), c.n_u = (int32_t)c.u.size(), c.a_p = c.a.data(), c.n_a = (int64_t)c.a.size();
 			}
-			if (c.long_joined) ++n_lj_dev;
 			if (!c.long_join_done && opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && n_segs == 1 && c.n_u > 1) { // long-join re-chaining (map.c:283-292): the reads the backend left alone
 				const int32_t st = (int32_t)c.a_p[0].y, en = (int32_t)c.a_p[(int32_t)c.u_p[0] - 1].y;
 				if (qlen - (en - st) > opt_.rmq_rescue_size || en - st > qlen * opt_.rmq_rescue_ratio) {
@@ -448,10 +544,6 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 
 		if (!(opt_.flag & F_CIGAR)) return; // no base-level alignment asked for
 		// ---- rounds of plan -> batched DP -> consume (mm_align_skeleton, align.c:1048-1120) ----
-		KswScoring sc;
-		memcpy(sc.mat, aligner.mat(), 25);
-		sc.m = 5, sc.q = (int8_t)opt_.q, sc.e = (int8_t)opt_.e, sc.q2 = (int8_t)opt_.q2, sc.e2 = (int8_t)opt_.e2, sc.noncan = (int8_t)opt_.noncan;
-		sc.single = (opt_.flag & F_SPLICE) ? 2 : (opt_.q == opt_.q2 && opt_.e == opt_.e2) ? 1 : 0; // which DP mm_align_pair picks (align.c:352-360)
 		std::vector<std::vector<KswJob>> &per_read_jobs = ds.per_read_jobs;
 		if ((long)per_read_jobs.size() < mu) per_read_jobs.resize(mu);
 		std::vector<size_t> &job_base = ds.job_base;
@@ -460,6 +552,7 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 		std::vector<KswRes> &kres = ds.kres;
 		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(mu, 1);
+		for (long i = 0; i < m; ++i) if (on_dev[i]) active[unit0[i]] = 0; // (a read the device finished is a single unit)
 		for (int round = 0;; ++round) {
 			t0 = now(), c0 = cpu_now(), d0 = thr_now();
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
@@ -562,7 +655,8 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			const int n_segs = rv.paired() ? 2 : 1;
 			for (int s = 0; s < n_segs; ++s) {
 				RegVec &regs = s == 0 ? res.regs : res.regs2;
-				al[tid]->finish_read(ra[unit0[i] + s], regs);
+				if (on_dev[i]) device_hits(rb, chains[i], i, rv.len, regs), al[tid]->finish_regs(rv.len, regs);
+				else al[tid]->finish_read(ra[unit0[i] + s], regs);
 				if (!(opt_.flag & F_ALL_CHAINS)) {
 					set_parent(opt_.mask_level, opt_.mask_len, regs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);
 					select_sub(opt_.pri_ratio, fi_.k * 2, opt_.best_n, false, (int)(opt_.max_gap * 0.8), regs);

@@ -33,6 +33,7 @@ struct MapperStats { // wall-clock seconds per stage of the last map_batch (for 
 	long n_jobs = 0, n_rounds = 0;
 	double dp_cells = 0;
 	long n_early_sub = 0; // sub-batches of this batch that a lane started before the batch's own run() call (Mapper::stage may_start_early)
+	long n_region_reads_dev = 0, n_region_reads_host = 0; // reads whose hits, windows and DP results were handled on the device (Backend::align_regions) / by the host path (a hand-back, or a configuration the device path does not take)
 	long n_long_join_dev = 0, n_long_join_host = 0; // reads re-chained by the long-join rule (map.c:283-292): on the device / by the host's tie-exact tree
 };
 
@@ -77,12 +78,14 @@ private:
 		std::vector<FinPiece> fin_pieces;
 		std::vector<FinResult> fin_results;
 		std::vector<size_t> fin_base;
+		std::vector<Backend::RegionReadIn> rg_in;   // Backend::align_regions: per read the hash of map.c:246-248 and whether the host keeps it
+		std::vector<uint8_t> on_dev;                // per read: finished by the device path
 	};
 	std::vector<std::unique_ptr<DriverScratch>> scratch_;
 	// One batch on its way through the lanes: its resident set (ours and the backend's), its sub-batches and who has taken them, its results.
 	struct BatchRun {
 		int set = 0, be_set = 0, n_drivers = 1;
-		bool device_finish = false, cancelled = false;
+		bool device_finish = false, device_regions = false, cancelled = false;
 		SeedChainParams sp;
 		std::vector<std::pair<long, long>> subs;
 		size_t next_sub = 0, n_done = 0, n_taken = 0; // guarded by mu_
@@ -90,6 +93,7 @@ private:
 		MapperStats stats;
 		std::exception_ptr err;
 	};
+	void device_hits(const Backend::RegionBatchOut &rb, const ReadChains &c, long i, int qlen, RegVec &regs) const;
 	void process_sub(BatchRun &b, long lo, long hi, int lane, std::vector<std::unique_ptr<Aligner>> &al, DriverScratch &ds, MapperStats &st);
 	std::shared_ptr<BatchRun> make_run(int set);  // call with mu_ held
 	void take_locked();                           // the staged batch becomes the current set; call with mu_ held
@@ -106,6 +110,8 @@ private:
 	ref::MapOpt opt_;
 	Backend &be_;
 	int n_threads_;
+	RgnOpts rgn_opts_{};
+	bool rgn_ok_ = false; // the options and the index allow Backend::align_regions (region_path_supported)
 	struct Staged { long n = 0; std::vector<ReadView> live; std::vector<long> live_id; std::vector<uint64_t> qoff; };
 	Staged sets_[2];
 	int cur_set_ = 0;

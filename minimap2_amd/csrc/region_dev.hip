@@ -1,0 +1,720 @@
+// chain_regs_kernel / region_plan_kernel / region_consume_kernel: see region_dev.hpp.
+//
+// These stages are short, branchy and integer: a 10 kb read has one or two chains of ~700 anchors and ~40 DP windows.  They are bound by the
+// latency of dependent loads, not by bandwidth or issue -- what matters is that tens of thousands of reads / regions are in flight at once and
+// that nothing crosses PCIe.  Algorithmic bytes: 16 B per chained anchor read twice (coordinates + fuzzy lengths, window walk) and written once
+// (squeeze), 80 B per hit record, 48 + 24 B written per DP window, 68 B read per DP result.
+#include <hip/hip_runtime.h>
+#include "hip_util.hpp"
+#include "region_dev.hpp"
+
+namespace mm2amd {
+
+namespace {
+
+using ref::Reg1;
+
+__device__ __forceinline__ uint64_t rg_mix64(uint64_t key) // hash64 of hit.c:40-50 (the invertible integer hash without a mask)
+{
+	key = (~key + (key << 21));
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4));
+	key = key ^ key >> 28;
+	key = (key + (key << 31));
+	return key;
+}
+__device__ __forceinline__ int rg_span(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
+__device__ __forceinline__ int32_t rg_x(const Anchor &a) { return (int32_t)a.x; }
+__device__ __forceinline__ int32_t rg_y(const Anchor &a) { return (int32_t)a.y; }
+__device__ __forceinline__ uint32_t rg_roundup32(uint32_t x) { --x; x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16; return ++x; }
+
+#define RG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ __forceinline__ int rg_wave_sum(int v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+__device__ __forceinline__ int rg_wave_min(int v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+	return v;
+}
+
+// position of an anchor's k-mer on the read as given (esterr.c:7-14)
+__device__ __forceinline__ int32_t rg_fwd_qpos(int32_t qlen, const Anchor &a)
+{
+	int32_t x = rg_y(a);
+	if (a.x >> 63) x = qlen - 1 - (x + 1 - rg_span(a));
+	return x;
+}
+
+// ---- the hit-record rules of hit.c, on records held in LDS (one lane walks: tens of records, each step depends on the one before) ----
+
+// Which hits are secondary to which (hit.c:125-186).  Hit i (in score order) is tested against the hits that are primary so far: the part of
+// its query interval no primary covers, then the first primary it overlaps by more than mask_level of the shorter of the two.
+__device__ void rg_mark_parents(Reg1 *r, int n, uint64_t *cov, int16_t *prim, const RgnOpts &O, bool with_dp, const int32_t *dp_max, int32_t *dp_max2)
+{
+	if (n <= 0) return;
+	const bool hard = (O.flag & ref::F_HARD_MLEVEL) != 0;
+	for (int i = 0; i < n; ++i) r[i].id = i;
+	int n_prim = 1;
+	prim[0] = 0, r[0].parent = 0;
+	for (int i = 1; i < n; ++i) {
+		const int si = r[i].qs, ei = r[i].qe, len_i = ei - si;
+		int uncov = 0;
+		bool touches = hard; // (with a hard mask level the uncovered length stays 0 and every primary is tested)
+		if (!hard) {
+			int n_cov = 0;
+			for (int j = 0; j < n_prim; ++j) {
+				int sj = r[prim[j]].qs, ej = r[prim[j]].qe;
+				if (ej <= si || sj >= ei) continue;
+				sj = sj < si ? si : sj, ej = ej > ei ? ei : ej;
+				// insertion into the sorted list of clipped intervals (the reference sorts them with radix_sort_64: plain integers, any sort gives the same list)
+				const uint64_t v = (uint64_t)sj << 32 | (uint32_t)ej;
+				int p = n_cov++;
+				while (p > 0 && cov[p - 1] > v) cov[p] = cov[p - 1], --p;
+				cov[p] = v;
+			}
+			if (n_cov > 0) {
+				touches = true;
+				int x = si;
+				for (int c = 0; c < n_cov; ++c) {
+					const int cs = (int)(cov[c] >> 32), ce = (int32_t)cov[c];
+					if (cs > x) uncov += cs - x;
+					x = ce > x ? ce : x;
+				}
+				if (ei > x) uncov += ei - x;
+			}
+		}
+		int owner = -1;
+		if (touches)
+			for (int j = 0; j < n_prim && owner < 0; ++j) {
+				const Reg1 &rp = r[prim[j]];
+				const int sj = rp.qs, ej = rp.qe, len_j = ej - sj;
+				if (ej <= si || sj >= ei) continue;
+				const int mn = len_j < len_i ? len_j : len_i, mx = len_j > len_i ? len_j : len_i;
+				const int lo = si > sj ? si : sj, hi = ei < ej ? ei : ej, ol = hi > lo ? hi - lo : 0;
+				if ((float)ol / mn - (float)uncov / mx > O.mask_level && uncov <= O.mask_len) owner = j;
+			}
+		if (owner < 0) { prim[n_prim++] = (int16_t)i, r[i].parent = i, r[i].n_sub = 0; continue; }
+		const int pi = prim[owner];
+		Reg1 &rp = r[pi];
+		const int sj = rp.qs, ej = rp.qe, len_j = ej - sj;
+		const int mn = len_j < len_i ? len_j : len_i;
+		const int lo = si > sj ? si : sj, hi = ei < ej ? ei : ej, ol = hi > lo ? hi - lo : 0;
+		int sci = r[i].score; // (no ALT contigs on this path: mm_alt_score never applies)
+		bool counts = r[i].cnt >= rp.cnt;
+		r[i].parent = rp.parent;
+		rp.subsc = rp.subsc > sci ? rp.subsc : sci;
+		if (with_dp && (rp.rid != r[i].rid || rp.rs != r[i].rs || rp.re != r[i].re || ol != mn)) { // both aligned, and not the same alignment found twice
+			sci = dp_max[i];
+			dp_max2[pi] = dp_max2[pi] > sci ? dp_max2[pi] : sci;
+			if (dp_max[pi] - dp_max[i] <= O.sub_diff) counts = true;
+		}
+		if (counts) ++rp.n_sub;
+	}
+}
+
+// ids follow positions after a compaction; parents that were dropped leave orphans (mm_sync_regs, hit.c:231-253, with mm_set_sam_pri)
+__device__ void rg_renumber(Reg1 *r, int n, int16_t *where, int where_n)
+{
+	for (int i = 0; i < where_n; ++i) where[i] = -1;
+	for (int i = 0; i < n; ++i) if (r[i].id >= 0) where[r[i].id] = (int16_t)i;
+	int n_pri = 0;
+	for (int i = 0; i < n; ++i) {
+		Reg1 &x = r[i];
+		x.id = i;
+		if (x.parent == ref::PARENT_TMP_PRI) x.parent = i;
+		else if (x.parent >= 0 && where[x.parent] >= 0) x.parent = where[x.parent];
+		else x.parent = ref::PARENT_UNSET;
+	}
+	for (int i = 0; i < n; ++i) {
+		if (r[i].id == r[i].parent) { ++n_pri; r[i].sam_pri = n_pri == 1; }
+		else r[i].sam_pri = 0;
+	}
+}
+
+// Which secondaries are kept (mm_select_sub, hit.c:255-281).  Returns the new count; `aux` (per-hit side values) is compacted alongside.
+__device__ int rg_select_secondaries(Reg1 *r, int n, int16_t *where, bool check_strand, const RgnOpts &O, int32_t *aux0, int32_t *aux1)
+{
+	if (!(O.pri_ratio > 0.0f) || n <= 0) return n;
+	int n_2nd = 0, k = 0;
+	for (int i = 0; i < n; ++i) { // decisions first (`where` holds them): a hit is compared with its parent where the parent still is
+		const int p = r[i].parent;
+		bool keep = false;
+		if (p == i || r[i].inv) keep = true;
+		else if ((r[i].score >= r[p].score * O.pri_ratio || r[i].score + O.k * 2 >= r[p].score) && n_2nd < O.best_n) {
+			const bool same = r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re;
+			if (!same) keep = true, ++n_2nd; // (an identical hit found twice is dropped)
+		} else if (check_strand && n_2nd < O.best_n && r[i].score > O.min_strand_sc && r[i].rev != r[p].rev) {
+			r[i].strand_retained = 1;
+			keep = true, ++n_2nd;
+		}
+		where[i] = keep ? 1 : 0;
+	}
+	for (int i = 0; i < n; ++i)
+		if (where[i]) {
+			if (k < i) { r[k] = r[i]; if (aux0) aux0[k] = aux0[i]; if (aux1) aux1[k] = aux1[i]; }
+			++k;
+		}
+	if (k != n) rg_renumber(r, k, where, n);
+	return k;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// chain_regs_kernel
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// LDS per read (C = lds_chains): hit records 80 C, sort keys 8 C, interval list 8 C, chain starts / order / primaries / id map 4 x 2..4 C
+__global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
+{
+	MM2_DYN_LDS(uint64_t, s_raw);
+	const int C = B.lds_chains, lane = threadIdx.x, rd_i = blockIdx.x;
+	Reg1 *s_reg = (Reg1 *)s_raw;                       // C hit records (80 B each: a multiple of 8)
+	uint64_t *s_key = s_raw + (size_t)C * 10;          // C sort keys, later (as << 32 | index) of the squeeze
+	uint64_t *s_cov = s_key + C;                       // C clipped intervals
+	int32_t *s_start = (int32_t *)(s_cov + C);         // C chain starts (in the read's chained anchors), later the squeezed starts
+	int32_t *s_nm = s_start + C, *s_nt = s_nm + C;     // C + C: mm_est_err's counts
+	int16_t *s_ord = (int16_t *)(s_nt + C);            // C: chain at each rank
+	int16_t *s_prim = s_ord + C, *s_where = s_prim + C;
+	__shared__ int32_t s_hdr[4];
+
+	const RgnRead rd = B.reads[rd_i];
+	RgnReadOut out;
+	out.reg0 = 0, out.n_regs = 0, out.n_a_sq = 0, out.flags = 0;
+	const int n = rd.n_u;
+	if ((rd.src & RGN_SRC_SKIP) || n > C || n == 0) {
+		if (rd.src & RGN_SRC_SKIP) out.flags = RGN_F_SKIPPED;
+		else if (n > C) out.flags = RGN_F_MANY_CHAINS;
+		if (lane == 0) B.rout[rd_i] = out;
+		return;
+	}
+	const Anchor *a = B.a_src[rd.src & RGN_SRC_LJ] + rd.a_off;
+	const uint64_t *u = B.u_src[rd.src & RGN_SRC_LJ] + rd.u_off;
+	const int qlen = rd.qlen;
+
+	// chain starts: the chains' anchors lie back to back in chain order
+	if (lane == 0) { int acc = 0; for (int i = 0; i < n; ++i) { s_start[i] = acc; acc += (int32_t)u[i]; } }
+	RG_SYNC();
+	// sort key of mm_gen_regs (hit.c:60-66): the chain record with its low word scrambled by a hash of the first anchor and the read
+	for (int i = lane; i < n; i += 64) {
+		const Anchor f = a[s_start[i]];
+		const uint32_t h = (uint32_t)rg_mix64((rg_mix64(f.x) + rg_mix64(f.y)) ^ rd.hash);
+		s_key[i] = u[i] ^ h;
+	}
+	RG_SYNC();
+	// descending order by counting; equal keys (2^-32 per pair of equal scores) are ordered by the reference's unstable sort: the host replays it
+	int tie = 0;
+	for (int i = lane; i < n; i += 64) {
+		const uint64_t me = s_key[i];
+		int rank = 0;
+		for (int j = 0; j < n; ++j) { const uint64_t o = s_key[j]; rank += o > me; tie |= (o == me && j != i); }
+		s_ord[rank] = (int16_t)i;
+	}
+	if (__ballot(tie)) {
+		out.flags = RGN_F_SORT_TIE;
+		if (lane == 0) B.rout[rd_i] = out;
+		return;
+	}
+	RG_SYNC();
+	// the hit records (hit.c:68-86 with mm_reg_set_coor, :24-38)
+	for (int p = lane; p < n; p += 64) {
+		const int c = s_ord[p], st = s_start[c];
+		const uint64_t key = s_key[c];
+		Reg1 r;
+		__builtin_memset(&r, 0, sizeof r);
+		r.id = p, r.parent = ref::PARENT_UNSET;
+		r.score = r.score0 = (int32_t)(key >> 32);
+		r.hash = (uint32_t)key;
+		r.cnt = (int32_t)u[c], r.as = st;
+		r.div = -1.0f;
+		const Anchor f = a[st], l = a[st + r.cnt - 1];
+		const int span = rg_span(f);
+		r.rev = f.x >> 63;
+		r.rid = (int32_t)(f.x << 1 >> 33);
+		r.rs = rg_x(f) + 1 > span ? rg_x(f) + 1 - span : 0;
+		r.re = rg_x(l) + 1;
+		if (!r.rev) r.qs = rg_y(f) + 1 - span, r.qe = rg_y(l) + 1;
+		else r.qs = qlen - (rg_y(l) + 1), r.qe = qlen - (rg_y(f) + 1 - span);
+		s_reg[p] = r;
+	}
+	RG_SYNC();
+	// fuzzy match / block lengths (mm_cal_fuzzy_len, hit.c:5-22): a sum over consecutive anchor pairs -- all lanes, hit after hit
+	for (int p = 0; p < n; ++p) {
+		const int st = s_reg[p].as, cnt = s_reg[p].cnt;
+		int ml = 0, bl = 0;
+		for (int i = 1 + lane; i < cnt; i += 64) {
+			const Anchor c = a[st + i], b = a[st + i - 1];
+			const int span = rg_span(c), tl = rg_x(c) - rg_x(b), ql = rg_y(c) - rg_y(b);
+			bl += tl > ql ? tl : ql;
+			ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
+		}
+		ml = rg_wave_sum(ml), bl = rg_wave_sum(bl);
+		if (lane == 0) { const int s0 = rg_span(a[st]); s_reg[p].mlen = ml + s0, s_reg[p].blen = bl + s0; }
+	}
+	RG_SYNC();
+	// parents, secondaries (chain_post, map.c:206-213)
+	if (lane == 0) {
+		int m = n;
+		if (!(O.flag & ref::F_ALL_CHAINS)) {
+			rg_mark_parents(s_reg, n, s_cov, s_prim, O, false, nullptr, nullptr);
+			m = rg_select_secondaries(s_reg, n, s_where, true, O, nullptr, nullptr);
+		}
+		int retained = 0;
+		for (int p = 0; p < m; ++p) retained |= s_reg[p].strand_retained;
+		s_hdr[0] = m, s_hdr[1] = retained;
+	}
+	RG_SYNC();
+	const int m = s_hdr[0];
+	if (s_hdr[1]) { // mm_filter_strand_retained (hit.c:283-299) compares divergences: libm's pow decides, on the host
+		out.flags = RGN_F_STRAND_RETAINED;
+		if (lane == 0) B.rout[rd_i] = out;
+		return;
+	}
+	// mm_est_err's counts (esterr.c:30-64): how many of the minimizers between a hit's first and last anchor are anchors of the hit.  The
+	// reference walks the read's minimizer positions and the chain together; both ascend strictly, so "anchor k is found after anchor k - 1"
+	// is one binary search per anchor, and the walk stops at the first anchor that is not found.
+	const uint64_t *mp = B.mini_pos + rd.mp_off;
+	const int n_mp = rd.n_mp;
+	const float avg_k = n_mp > 0 ? (float)((uint64_t)n_mp * (uint64_t)O.k) / n_mp : 0.0f; // (every span is k without HPC: the quotient the reference computes from the sum)
+	for (int p = 0; p < m; ++p) {
+		const Reg1 r = s_reg[p];
+		int n_match = 0, n_tot = -1;
+		if (n_mp > 0 && r.cnt > 0) {
+			const int32_t x0 = rg_fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1] : a[r.as]);
+			int32_t L = 0, R = n_mp - 1, st = -1;
+			while (L <= R) { // (the reference's own search: with distinct positions any search finds the same entry)
+				const int32_t mid = (int32_t)(((uint64_t)L + R) >> 1), y = (int32_t)mp[mid];
+				if (y < x0) L = mid + 1;
+				else if (y > x0) R = mid - 1;
+				else { st = mid; break; }
+			}
+			if (st >= 0) {
+				int kfail = r.cnt;
+				for (int k = 1 + lane; k < r.cnt; k += 64) {
+					const int32_t x = rg_fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k]);
+					int lo = st + 1, hi = n_mp; // first entry at a position >= x
+					while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int32_t)mp[mid] < x) lo = mid + 1; else hi = mid; }
+					if (!(lo < n_mp && (int32_t)mp[lo] == x)) kfail = kfail < k ? kfail : k;
+				}
+				kfail = rg_wave_min(kfail);
+				n_match = kfail; // the first anchor and anchors 1 .. kfail - 1
+				int en = st;
+				if (kfail > 1) {
+					const int32_t x = rg_fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - kfail] : a[r.as + kfail - 1]);
+					int lo = st + 1, hi = n_mp;
+					while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int32_t)mp[mid] < x) lo = mid + 1; else hi = mid; }
+					en = lo;
+				}
+				n_tot = en - st + 1;
+				if (r.qs > avg_k && r.rs > avg_k) ++n_tot;
+				if (qlen - r.qs > avg_k && (int32_t)B.ref_len[r.rid] - r.re > avg_k) ++n_tot;
+			}
+		}
+		if (lane == 0) s_nm[p] = n_match, s_nt[p] = n_tot;
+	}
+	RG_SYNC();
+	// the surviving hits' anchors squeezed together, in anchor order (mm_squeeze_a, hit.c:322-340)
+	if (lane == 0) {
+		for (int p = 0; p < m; ++p) { // insertion sort of (as, index): distinct starts
+			const uint64_t v = (uint64_t)s_reg[p].as << 32 | (uint32_t)p;
+			int q = p;
+			while (q > 0 && s_key[q - 1] > v) s_key[q] = s_key[q - 1], --q;
+			s_key[q] = v;
+		}
+		int acc = 0;
+		for (int q = 0; q < m; ++q) { const int p = (int32_t)(uint32_t)s_key[q]; s_start[p] = acc; acc += s_reg[p].cnt; }
+		s_hdr[2] = acc;
+		s_hdr[3] = (int32_t)atomicAdd(&B.cursors[RGN_CUR_REGS], (unsigned)m);
+	}
+	RG_SYNC();
+	const uint32_t reg0 = (uint32_t)s_hdr[3];
+	Anchor *sq = B.sq_a + rd.sq_off;
+	for (int p = 0; p < m; ++p) {
+		const int src = s_reg[p].as, dst = s_start[p], cnt = s_reg[p].cnt;
+		for (int i = lane; i < cnt; i += 64) sq[dst + i] = a[src + i];
+	}
+	RG_SYNC();
+	if (reg0 + (uint32_t)m <= B.max_regs) {
+		if (lane == 0) for (int p = 0; p < m; ++p) s_reg[p].as = s_start[p];
+		RG_SYNC();
+		uint32_t *dst = (uint32_t *)(B.regs + reg0);
+		const uint32_t *srcw = (const uint32_t *)s_reg;
+		for (int w = lane; w < m * 20; w += 64) dst[w] = srcw[w];
+		for (int p = lane; p < m; p += 64) {
+			RgnAux x; x.n_match = s_nm[p], x.n_tot = s_nt[p];
+			B.aux[reg0 + p] = x;
+			RgnPlan pl;
+			__builtin_memset(&pl, 0, sizeof pl);
+			pl.read = (uint32_t)rd_i, pl.status = -1;
+			B.plan[reg0 + p] = pl;
+		}
+	} else out.flags = RGN_F_MANY_CHAINS; // (cannot happen: the host sizes the arrays by the chain count)
+	out.reg0 = reg0, out.n_regs = m, out.n_a_sq = s_hdr[2];
+	if (lane == 0) B.rout[rd_i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// region_plan_kernel: one region per thread
+// ---------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int rg_gap_at(const Anchor *a, int i) // query advance minus reference advance between anchors i - 1 and i
+{
+	return (rg_y(a[i]) - rg_y(a[i - 1])) - (int32_t)(a[i].x - a[i - 1].x);
+}
+
+// the anchors before which the two sequences drift apart by more than min_gap (collect_long_gaps, align.c:435-452); none when there is only one
+__device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K)
+{
+	int n = 0;
+	for (int i = 1; i < cnt1; ++i) { const int g = rg_gap_at(a, i); if (g < -min_gap || g > min_gap) K[n++] = i; }
+	return n <= 1 ? 0 : n;
+}
+
+// runs of seeds between an insertion and a deletion that cancel each other are bad seeds (mm_filter_bad_seeds, align.c:454-489)
+__device__ void rg_drop_compensating(Anchor *a, int cnt1, int32_t *K, int diff_thres, int max_ext_len, int max_ext_cnt)
+{
+	const int n = rg_gap_sites(a, cnt1, 10, K);
+	if (n == 0) return;
+	int best = 0, best_st = -1, best_en = -1;
+	for (int k = 0;; ++k) {
+		if (k == n || k >= best_en) {
+			if (best_en > 0) for (int i = K[best_st]; i < K[best_en]; ++i) a[i].y |= ref::SEED_IGNORE;
+			best = 0, best_st = best_en = -1;
+			if (k == n) break;
+		}
+		const int i = K[k];
+		int gap = rg_gap_at(a, i), n_ins = 0, n_del = 0, top = 0, top_l = -1;
+		if (gap > 0) n_ins += gap; else n_del -= gap;
+		const int q0 = rg_y(a[i - 1]), r0 = rg_x(a[i - 1]);
+		for (int l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+			const int j = K[l];
+			if (rg_y(a[j]) - q0 > max_ext_len || rg_x(a[j]) - r0 > max_ext_len) break;
+			gap = rg_gap_at(a, j);
+			if (gap > 0) n_ins += gap; else n_del -= gap;
+			const int both = n_ins + n_del, net = n_ins > n_del ? n_ins - n_del : n_del - n_ins, diff = both - net;
+			if (top < diff) top = diff, top_l = l;
+		}
+		if (top > diff_thres && top > best) best = top, best_st = k, best_en = top_l;
+	}
+}
+
+// clusters of long gaps close to each other are bridged by ONE long window (mm_filter_bad_seeds_alt, align.c:491-525)
+__device__ void rg_join_gap_clusters(Anchor *a, int cnt1, int32_t *K, int max_ext)
+{
+	const int n = rg_gap_sites(a, cnt1, 30, K);
+	for (int k = 0; k < n;) {
+		const int i = K[k];
+		int l, gap1 = rg_gap_at(a, i);
+		int re1 = rg_x(a[i]), qe1 = rg_y(a[i]);
+		gap1 = gap1 > 0 ? gap1 : -gap1;
+		for (l = k + 1; l < n; ++l) {
+			const int j = K[l];
+			if (rg_y(a[j]) - qe1 > max_ext || rg_x(a[j]) - re1 > max_ext) break;
+			int gap2 = rg_gap_at(a, j);
+			const int sp = rg_span(a[j - 1]);
+			const int rs2 = rg_x(a[j - 1]) + sp, qs2 = rg_y(a[j - 1]) + sp;
+			const int room = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+			gap2 = gap2 > 0 ? gap2 : -gap2;
+			if (room > gap1 + gap2) break;
+			re1 = rg_x(a[j]), qe1 = rg_y(a[j]);
+			gap1 = gap2;
+		}
+		if (l > k + 1) {
+			const int end = K[l - 1];
+			for (int j = K[k]; j < end; ++j) a[j].y |= ref::SEED_IGNORE;
+			a[end].y |= ref::SEED_LONG_JOIN;
+		}
+		k = l;
+	}
+}
+
+// seeds at a chain's ends that sit off the diagonal of what follows are not aligned from (mm_fix_bad_ends, align.c:527-561); a = the read's anchors
+__device__ void rg_trim_ends(const Reg1 &r, const Anchor *a, int bw, int min_match, int32_t *as, int32_t *cnt)
+{
+	*as = r.as, *cnt = r.cnt;
+	if (r.cnt < 3) return;
+	int32_t m, l;
+	m = l = rg_span(a[r.as]);
+	for (int32_t i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
+		const int32_t sp = rg_span(a[i]);
+		if (a[i].y & ref::SEED_LONG_JOIN) break;
+		const int32_t lr = rg_x(a[i]) - rg_x(a[i - 1]), lq = rg_y(a[i]) - rg_y(a[i - 1]);
+		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+		if (mx - mn > l >> 1) *as = i;
+		l += mn;
+		m += mn < sp ? mn : sp;
+		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+	}
+	*cnt = r.as + r.cnt - *as;
+	m = l = rg_span(a[r.as + r.cnt - 1]);
+	for (int32_t i = r.as + r.cnt - 2; i > *as; --i) {
+		const int32_t sp = rg_span(a[i + 1]);
+		if (a[i + 1].y & ref::SEED_LONG_JOIN) break;
+		const int32_t lr = rg_x(a[i + 1]) - rg_x(a[i]), lq = rg_y(a[i + 1]) - rg_y(a[i]);
+		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+		if (mx - mn > l >> 1) *cnt = i + 1 - *as;
+		l += mn;
+		m += mn < sp ? mn : sp;
+		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+	}
+}
+
+// how far a gapped extension of l query bases can reach on the reference (align.c:716-718)
+__device__ __forceinline__ int rg_ext_reach(int l, const RgnOpts &O)
+{
+	l += l * O.a > O.q ? (l * O.a - O.q) / O.e : 0;
+	return l < O.max_gap ? l : O.max_gap;
+}
+
+struct RgnJobCtx { uint64_t q_fwd, q_rev, t_base; int rev, gen_flag; };
+
+__device__ __forceinline__ void rg_emit(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, uint32_t idx, int kind, int qs, int qe, int rs, int re, int bw, int anchor_i,
+                                        int flag, int zdrop, int end_bonus)
+{
+	RgnWin w;
+	w.qs = qs, w.qe = qe, w.rs = rs, w.re = re, w.anchor_i = anchor_i, w.kind = kind;
+	B.win[idx] = w;
+	const bool reversed = kind == 0; // the left extension runs backwards from the first anchor (align.c:787-788)
+	KswJob j;
+	j.qlen = qe - qs, j.tlen = re - rs;
+	j.w = bw, j.zdrop = zdrop, j.end_bonus = end_bonus;
+	flag |= X.gen_flag;
+	if (O.max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > O.max_sw_mat) flag |= KSWJ_SKIP; // align.c:349-351
+	const uint64_t qbase = X.rev ? X.q_rev : X.q_fwd;
+	j.q_off = reversed ? qbase + (uint64_t)qe - 1 : qbase + (uint64_t)qs;
+	j.t_off = reversed ? X.t_base + (uint64_t)re - 1 : X.t_base + (uint64_t)rs;
+	j.flag = flag | KSWJ_T_PACKED | (reversed ? (KSWJ_Q_REVERSED | KSWJ_T_REVERSED) : 0);
+	j.tag = 0, j.reserved = 0;
+	B.jobs[idx] = j;
+}
+
+} // namespace
+
+__global__ void __launch_bounds__(64) region_plan_kernel(RgnBuffers B, RgnOpts O)
+{
+	const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+	const uint32_t n_regs = B.cursors[RGN_CUR_REGS] < B.max_regs ? B.cursors[RGN_CUR_REGS] : B.max_regs;
+	if (slot >= n_regs) return;
+	const Reg1 r = B.regs[slot];
+	RgnPlan pl = B.plan[slot];
+	const RgnRead rd = B.reads[pl.read];
+	const RgnReadOut ro = B.rout[pl.read];
+	Anchor *a = B.sq_a + rd.sq_off;               // the READ's squeezed anchors: the extension limits look at its other hits' anchors too
+	const int qlen = rd.qlen, n_a = ro.n_a_sq;
+	pl.status = 0, pl.n_win = 0;
+	if (r.cnt == 0) { pl.status = RGN_F_NO_CIGAR; B.plan[slot] = pl; return; }
+	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+	const int32_t ref_len = (int32_t)B.ref_len[rid];
+	int32_t as1 = r.as, cnt1 = r.cnt;
+	if (!(O.flag & ref::F_NO_END_FLT)) rg_trim_ends(r, a, O.bw, O.min_chain_score * 2, &as1, &cnt1);
+	int32_t *K = B.gap_sites + rd.sq_off + as1;
+	rg_drop_compensating(a + as1, cnt1, K, 40, O.max_gap >> 1, 10);
+	rg_join_gap_clusters(a + as1, cnt1, K, O.max_gap >> 1);
+	// a window boundary sits in the middle of an anchor's k-mer (mm_adjust_minier without HPC, align.c:429-432)
+	const int half = O.k >> 1;
+	int32_t rs = rg_x(a[as1]) - half, qs = rg_y(a[as1]) - half;
+	int32_t re = rg_x(a[as1 + cnt1 - 1]) - half, qe = rg_y(a[as1 + cnt1 - 1]) - half;
+
+	// how far the two extensions may reach (align.c:706-767)
+	int32_t rs0, qs0, re0, qe0, rs1 = 0, qs1 = 0, re1, qe1, l;
+	{
+		const Anchor f = a[r.as];
+		rs0 = rg_x(f) + 1 - rg_span(f), qs0 = rg_y(f) + 1 - rg_span(f);
+		if (rs0 < 0) rs0 = 0;
+		l = 0;
+		for (int32_t i = r.as - 1; i >= 0 && a[i].x >> 32 == f.x >> 32; --i) { // earlier seeds on the same sequence and strand bound the extension
+			const int32_t x = rg_x(a[i]) + 1 - rg_span(a[i]), y = rg_y(a[i]) + 1 - rg_span(a[i]);
+			if (x < rs0 && y < qs0 && ++l > O.min_cnt) {
+				l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+				rs1 = rs0 - l, qs1 = qs0 - l;
+				if (rs1 < 0) rs1 = 0;
+				break;
+			}
+		}
+		if (qs > 0 && rs > 0) {
+			l = qs < O.max_gap ? qs : O.max_gap;
+			qs1 = qs1 > qs - l ? qs1 : qs - l;
+			qs0 = qs0 < qs1 ? qs0 : qs1;
+			l = rg_ext_reach(l, O);
+			l = l < rs ? l : rs;
+			rs1 = rs1 > rs - l ? rs1 : rs - l;
+			rs0 = rs0 < rs1 ? rs0 : rs1;
+			rs0 = rs0 < rs ? rs0 : rs;
+		} else rs0 = rs, qs0 = qs;
+		const Anchor t = a[r.as + r.cnt - 1];
+		re0 = rg_x(t) + 1, qe0 = rg_y(t) + 1;
+		re1 = ref_len, qe1 = qlen;
+		l = 0;
+		for (int32_t i = r.as + r.cnt; i < n_a && a[i].x >> 32 == f.x >> 32; ++i) {
+			const int32_t x = rg_x(a[i]) + 1, y = rg_y(a[i]) + 1;
+			if (x > re0 && y > qe0 && ++l > O.min_cnt) {
+				l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+				re1 = re0 + l, qe1 = qe0 + l;
+				break;
+			}
+		}
+		if (qe < qlen && re < ref_len) {
+			l = qlen - qe < O.max_gap ? qlen - qe : O.max_gap;
+			qe1 = qe1 < qe + l ? qe1 : qe + l;
+			qe0 = qe0 > qe1 ? qe0 : qe1;
+			l = rg_ext_reach(l, O);
+			l = l < ref_len - re ? l : ref_len - re;
+			re1 = re1 < re + l ? re1 : re + l;
+			re0 = re0 > re1 ? re0 : re1;
+		} else re0 = re, qe0 = qe;
+		if (f.y & ref::SEED_SELF) { // an overlap with itself must not extend across the diagonal (align.c:760-767)
+			int room = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs;
+			if (r.rs - rs0 > room) rs0 = r.rs - room;
+			if (r.qs - qs0 > room) qs0 = r.qs - room;
+			room = r.qe > r.re ? r.qe - r.re : r.re - r.qe;
+			if (re0 - r.re > room) re0 = r.re + room;
+			if (qe0 - r.qe > room) qe0 = r.qe + room;
+		}
+	}
+	// the windows, in the order the reference aligns them (align.c:779-890): counted first, so that the region's jobs are one dense run
+	const bool has_left = qs > 0 && rs > 0;
+	int n_gap_win = 0;
+	{
+		int32_t cs = rs, cq = qs;
+		for (int32_t i = 1; i < cnt1; ++i) {
+			const uint64_t y = a[as1 + i].y;
+			if ((y & (ref::SEED_IGNORE | ref::SEED_TANDEM)) && i != cnt1 - 1) continue;
+			const int32_t e_r = rg_x(a[as1 + i]) - half, e_q = (int32_t)y - half;
+			if (i == cnt1 - 1 || (y & ref::SEED_LONG_JOIN) || (e_q - cq >= O.min_ksw_len && e_r - cs >= O.min_ksw_len)) ++n_gap_win, cs = e_r, cq = e_q;
+		}
+	}
+	// (the right extension exists when the LAST gap window's end -- the last anchor's boundary, or the first one's when there is a single anchor -- lies inside the limits)
+	const bool has_right = qe < qe0 && re < re0;
+	const int n_win = (has_left ? 1 : 0) + n_gap_win + (has_right ? 1 : 0);
+	const uint32_t job0 = atomicAdd(&B.cursors[RGN_CUR_JOBS], (unsigned)n_win);
+	pl.job0 = job0, pl.n_win = n_win, pl.as1 = as1, pl.cnt1 = cnt1, pl.rid = rid, pl.rev = rev, pl.rs = rs, pl.qs = qs, pl.has_left = has_left, pl.has_right = has_right;
+	if (job0 + (uint32_t)n_win > B.max_jobs) { pl.status = RGN_F_MULTI_ROUND, pl.n_win = 0; B.plan[slot] = pl; return; } // (cannot happen: sized by anchors + 2 per chain)
+	RgnJobCtx X;
+	X.q_fwd = rd.qpool_fwd, X.q_rev = rd.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
+	X.gen_flag = O.transition != 0 && O.b != O.transition ? KSW_GENERIC_SC : 0; // align.c:347-348
+	uint32_t idx = job0;
+	if (has_left) rg_emit(B, O, X, idx++, 0, qs0, qs, rs0, rs, O.bw_ext, 0, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, r.split_inv ? O.zdrop_inv : O.zdrop, O.end_bonus);
+	{
+		int32_t cs = rs, cq = qs;
+		for (int32_t i = 1; i < cnt1; ++i) {
+			const uint64_t y = a[as1 + i].y;
+			if ((y & (ref::SEED_IGNORE | ref::SEED_TANDEM)) && i != cnt1 - 1) continue;
+			const int32_t e_r = rg_x(a[as1 + i]) - half, e_q = (int32_t)y - half;
+			if (i == cnt1 - 1 || (y & ref::SEED_LONG_JOIN) || (e_q - cq >= O.min_ksw_len && e_r - cs >= O.min_ksw_len)) {
+				int bw = O.bw_gap;
+				if (y & ref::SEED_LONG_JOIN) bw = e_q - cq > e_r - cs ? e_q - cq : e_r - cs;
+				rg_emit(B, O, X, idx++, 1, cq, e_q, cs, e_r, bw, i, KSW_APPROX_MAX, O.zdrop, -1);
+				cs = e_r, cq = e_q;
+			}
+		}
+	}
+	if (has_right) rg_emit(B, O, X, idx++, 2, qe, qe0, re, re0, O.bw_ext, 0, KSW_EXTZ_ONLY, O.zdrop, O.end_bonus);
+	B.plan[slot] = pl;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// region_consume_kernel: one region per thread
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) region_consume_kernel(RgnBuffers B, RgnOpts O, const uint32_t *cigar_pool)
+{
+	const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+	const uint32_t n_regs = B.cursors[RGN_CUR_REGS] < B.max_regs ? B.cursors[RGN_CUR_REGS] : B.max_regs;
+	if (slot >= n_regs) return;
+	RgnPlan pl = B.plan[slot];
+	FinRegion fr;
+	__builtin_memset(&fr, 0, sizeof fr);
+	if (pl.status != 0 || pl.n_win <= 0) {
+		if (pl.status == 0) pl.status = RGN_F_NO_CIGAR;
+		B.fin[slot] = fr, B.plan[slot] = pl;
+		atomicOr(&B.rout[pl.read].flags, (unsigned)pl.status);
+		return;
+	}
+	const RgnRead rd = B.reads[pl.read];
+	int32_t rs1 = pl.rs, qs1 = pl.qs, re1 = pl.rs, qe1 = pl.qs; // no left extension: the alignment starts at the first anchor (align.c:800-801)
+	int32_t dp = 0;
+	uint32_t cap = 0, n_ops = 0, last_op = 0, n_pieces = 0, sum_ops = 0;
+	int status = 0;
+	const bool inv_test_off = (O.flag & (ref::F_SPLICE | ref::F_SR | ref::F_FOR_ONLY | ref::F_REV_ONLY)) != 0;
+	for (int k = 0; k < pl.n_win && status == 0; ++k) {
+		const uint32_t job = pl.job0 + (uint32_t)k;
+		const RgnWin w = B.win[job];
+		const KswRes ez = B.res[B.perm[job]];
+		bool take = ez.n_cigar > 0;
+		if (w.kind == 1) { // a gap fill: the approximate pass is tested first (align.c:843; mm_test_zdrop on the kernel's own scan of its alignment)
+			if (ez.zd_max == KSW_ZD_NONE) { status = RGN_F_MULTI_ROUND; break; } // (a job no register-resident kernel took: the host scans its CIGAR)
+			const bool maybe_inv = !inv_test_off && ez.zd_max > O.zdrop_inv && ez.zd_q1 - ez.zd_q0 < O.max_gap && ez.zd_t1 - ez.zd_t0 < O.max_gap;
+			if (maybe_inv || ez.zd_max > O.zdrop) { status = RGN_F_MULTI_ROUND; break; } // second pass, maybe an inversion: the host's rounds
+			if (ez.zdropped) { status = RGN_F_MULTI_ROUND; break; }                     // truncated: cut and split (align.c:848-868)
+			dp += ez.score;
+			re1 = w.re, qe1 = w.qe;
+		} else if (w.kind == 0) {
+			if (take) dp += ez.max;
+			rs1 = w.re - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+			qs1 = w.qe - (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
+		} else {
+			if (take) dp += ez.max;
+			re1 = w.rs + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+			qe1 = w.qs + (ez.reach_end ? w.qe - w.qs : ez.max_q + 1);
+		}
+		if (take) {
+			const uint32_t n = (uint32_t)ez.n_cigar;
+			FinPiece pc; pc.off = ez.cigar_off, pc.n = n;
+			B.pieces[pl.job0 + n_pieces++] = pc;
+			sum_ops += n;
+			// mm_extra_t's growth, as mm_append_cigar would have done it window by window (align.c:305-334): the hand-over carries `capacity`
+			if (cap == 0) cap = rg_roundup32(n + 7);
+			else if (n_ops + n + 7 > cap) cap = rg_roundup32(n_ops + n + 7);
+			n_ops += n_ops > 0 && last_op == (cigar_pool[ez.cigar_off] & 0xf) ? n - 1 : n;
+			last_op = cigar_pool[ez.cigar_off + n - 1] & 0xf;
+		}
+	}
+	if (status == 0 && sum_ops == 0) status = RGN_F_NO_CIGAR;
+	if (status == 0 && sum_ops > (uint32_t)kFinMaxOps) status = RGN_F_LONG_CIGAR;
+	pl.status = status, pl.dp_score = dp, pl.capacity = cap;
+	if (status == 0) {
+		Reg1 r = B.regs[slot];
+		r.rs = rs1, r.re = re1;
+		if (!pl.rev) r.qs = qs1, r.qe = qe1; // align.c:894
+		else r.qs = rd.qlen - qe1, r.qe = rd.qlen - qs1;
+		B.regs[slot] = r;
+		fr.q_pos = (pl.rev ? rd.qpool_fwd + (uint64_t)rd.qlen : rd.qpool_fwd) + (uint64_t)qs1;
+		fr.t_pos = B.ref_off[pl.rid] + (uint64_t)rs1;
+		fr.piece0 = pl.job0, fr.n_pieces = n_pieces;
+		fr.out_off = atomicAdd(&B.cursors[RGN_CUR_OUT], sum_ops);
+		fr.q_len = qe1 - qs1, fr.t_len = re1 - rs1;
+		atomicMax(&B.cursors[RGN_CUR_MAX_OPS], sum_ops);
+		atomicAdd(&B.cursors[RGN_CUR_N_FIN], 1u);
+	} else atomicOr(&B.rout[pl.read].flags, (unsigned)status);
+	B.fin[slot] = fr, B.plan[slot] = pl;
+}
+
+void launch_chain_regs(const RgnBuffers &B, const RgnOpts &O, void *stream)
+{
+	if (B.n_reads <= 0) return;
+	const size_t C = (size_t)B.lds_chains;
+	const size_t lds = C * (80 + 8 + 8 + 4 * 3 + 2 * 3) + 64;
+	hipLaunchKernelGGL(chain_regs_kernel, dim3(B.n_reads), dim3(64), lds, (hipStream_t)stream, B, O);
+	HIP_CHECK(hipGetLastError());
+}
+void launch_region_plan(const RgnBuffers &B, const RgnOpts &O, void *stream)
+{
+	if (B.max_regs == 0) return;
+	hipLaunchKernelGGL(region_plan_kernel, dim3((B.max_regs + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, O);
+	HIP_CHECK(hipGetLastError());
+}
+void launch_region_consume(const RgnBuffers &B, const RgnOpts &O, const uint32_t *cigar_pool, void *stream)
+{
+	if (B.max_regs == 0) return;
+	hipLaunchKernelGGL(region_consume_kernel, dim3((B.max_regs + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, O, cigar_pool);
+	HIP_CHECK(hipGetLastError());
+}
+
+} // namespace mm2amd

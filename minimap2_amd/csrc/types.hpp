@@ -56,6 +56,10 @@ struct ReadChains {
 	int rep_len = 0;
 	bool long_join_done = false;    // the long-join re-chaining question (map.c:283-292) has been settled for this read: asked and answered no, or re-chained by the backend
 	bool long_joined = false;       // ... and the chains are the re-chained ones
+	// where the backend keeps this read's chains on the device (Backend::align_regions): -1 not there; 0 the first backtrack's arrays, 1 the
+	// long-join re-chain's; offsets into the arrays' anchors / chain records
+	int8_t dev_src = -1;
+	uint64_t dev_a_off = 0, dev_u_off = 0;
 	bool chained = true;            // false: a_p / n_a are the read's SORTED anchors and the caller still has to chain them (MM_F_RMQ on a backend without,
 	                                // or a read its RMQ kernel handed back)
 };

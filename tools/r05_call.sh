@@ -5,6 +5,7 @@
 #   pmc            tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes) -> gpurun_out/pmc_traffic_TAG.json
 #   rank8          bench.py --as-rank-of 8 (8 steps): one rank's share under 1/8 of the CPU quota
 #   pmcsq          tools/pmc_sq.py (SQ counters of the DP kernels)   hifi / splice   BASELINE.json configs[3] / [4], driver-shaped line
+#   benchenv:NAME:VAR=VAL   8 steps with an environment variable set (A/B inside one call) -> r05_bench_NAME_TAG.json
 #   smoke          __graft_entry__.smoke()
 #   sh:<command>   anything else, from the repo root
 V=$1; shift
@@ -28,6 +29,7 @@ for S in "$@"; do
     suite:*) (timeout 1200 python -m pytest tests -x -q -m gpu -k "${S#suite:}" 2>&1 | tail -12) > $O/r05_pytest_gpu_k_$V.log; tail -3 $O/r05_pytest_gpu_k_$V.log ;;
     bench)   cd /tmp; timeout 900 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_full_$V.json 2> $O/r05_bench_full_$V.log; line $O/r05_bench_full_$V.json ;;
     bench:*) cd /tmp; timeout 900 python $R/bench.py --steps ${S#bench:} --warmup 3 > $O/r05_bench_full_$V.json 2> $O/r05_bench_full_$V.log; line $O/r05_bench_full_$V.json ;;
+    benchenv:*) X=${S#benchenv:}; NM=${X%%:*}; EV=${X#*:}; cd /tmp; env $EV timeout 900 python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline > $O/r05_bench_${NM}_$V.json 2> $O/r05_bench_${NM}_$V.log; line $O/r05_bench_${NM}_$V.json ;;
     prof)    cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 8 --warmup 2 --timed-only > $O/r05_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
              python $R/tools/rocpd_summary.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) > $O/r05_bench_full_kernel_stats_$V.txt
              python $R/tools/exposed_time.py $(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1) 3.0 > $O/r05_exposed_time_$V.txt 2>&1; cat $O/r05_exposed_time_$V.txt; rm -rf $O/prof_ont; head -14 $O/r05_bench_full_kernel_stats_$V.txt ;;
