@@ -30,6 +30,9 @@ struct SeedChainParams {          // what mm_map_frag_core passes to seeding and
 	// (or covers a tenth of it) has its chained anchors sorted by reference position again and chained by mg_lchain_rmq with bw_long.
 	// long_join = 1: seed_chain() does it for single-segment reads and says so in ReadChains::long_join_done; reads its RMQ kernel hands
 	// back keep their first chains for the caller's host chainer.
+	// 1: the caller takes the chains through align_regions(): seed_chain() leaves the chained anchors and the minimizer positions on the device
+	// (ReadChains::a_p / mp_p null, the counts set); fetch_chains() brings the reads the host has to see
+	int lazy_chains = 0;
 	int long_join = 0, bw_long = 0, rmq_rescue_size = 0;
 	float rmq_rescue_ratio = 0;
 };
@@ -96,6 +99,9 @@ public:
 	virtual bool aligns_regions() const { return false; }
 	virtual void align_regions(int /*lane*/, const RgnOpts & /*O*/, const KswScoring & /*sc*/, bool /*log_gap*/, const std::vector<ReadChains> & /*chains*/, const std::vector<RegionReadIn> & /*in*/,
 	                           int /*n_threads*/, RegionBatchOut & /*out*/) {}
+	// the chained anchors and minimizer positions of the listed reads of this lane's last seed_chain(.., lazy_chains) come to the host
+	// (one gather kernel, two copies); chains[i].a_p / mp_p point at them until the lane's next seed_chain()
+	virtual void fetch_chains(int /*lane*/, const std::vector<long> & /*reads*/, std::vector<ReadChains> & /*chains*/) {}
 	virtual bool finishes_regions() const { return false; }
 	virtual void finish_regions(int /*lane*/, const std::vector<FinRegion> & /*regions*/, const std::vector<FinPiece> & /*pieces*/, size_t /*out_words*/, const int8_t * /*mat25*/,
 	                            int /*q*/, int /*e*/, bool /*log_gap*/, std::vector<FinResult> & /*results*/, const uint32_t ** /*cigars*/) {}

@@ -56,6 +56,9 @@ struct Lane {
 	long rg_lo = 0; size_t rg_n = 0; uint64_t rg_n_v = 0, rg_n_v2 = 0, rg_n_u = 0, rg_n_u2 = 0;
 	std::vector<int8_t> rg_src; std::vector<uint64_t> rg_aoff, rg_uoff; std::vector<int32_t> rg_nu, rg_nv;
 	DevBuf<uint64_t> d_lj_out_u;
+	bool rg_lazy = false;
+	DevBuf<int32_t> d_span; PinBuf<int32_t> h_span;
+	DevBuf<RgnGather> d_gather; PinBuf<RgnGather> h_gather; DevBuf<Anchor> d_fetch_a; DevBuf<uint64_t> d_fetch_mp; PinBuf<Anchor> h_fetch_a; PinBuf<uint64_t> h_fetch_mp;
 	DevBuf<RgnRead> d_rg_reads; PinBuf<RgnRead> h_rg_reads;
 	DevBuf<Anchor> d_rg_sq; DevBuf<ref::Reg1> d_rg_regs; DevBuf<RgnAux> d_rg_aux; DevBuf<RgnReadOut> d_rg_rout; DevBuf<unsigned int> d_rg_cur;
 	DevBuf<RgnPlan> d_rg_plan; DevBuf<RgnWin> d_rg_win; DevBuf<KswJob> d_rg_jobs; DevBuf<int32_t> d_rg_sites; DevBuf<FinRegion> d_rg_fin; DevBuf<FinPiece> d_rg_pieces;
@@ -389,13 +392,20 @@ public:
 		HIP_CHECK(hipMemcpyAsync(h_aoff, ln.d_bt_aoff.p, n * 8, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(h_uoff, ln.d_bt_uoff.p, n * 8, hipMemcpyDeviceToHost, st));
 		if (h_tie) HIP_CHECK(hipMemcpyAsync(h_tie, ln.d_tie.p, n * 4, hipMemcpyDeviceToHost, st));
-		if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
+		const bool lazy = P.lazy_chains != 0 && !P.anchors_only; // the chains stay on the device for align_regions()
+		ln.rg_lazy = lazy;
+		int32_t *h_span = nullptr;
+		if (lazy) { // ... and of the anchors only what the long-join question needs comes back
+			ln.d_span.ensure(2 * n), h_span = ln.h_span.ensure(2 * n);
+			launch_first_chain_span((int)n, ln.d_bt_out_a.p, ln.d_bt_out_u.p, ln.d_bt_aoff.p, ln.d_bt_uoff.p, ln.d_bt_nu.p, ln.d_span.p, st);
+			HIP_CHECK(hipMemcpyAsync(h_span, ln.d_span.p, 2 * n * 4, hipMemcpyDeviceToHost, st));
+		} else if (n_mp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_minipos.p, n_mp * 8, hipMemcpyDeviceToHost, st));
 		stream_wait(st);
 		Trace::get().add(lane_id, "gpu:expand..backtrack", tt, Trace::now()); tt = Trace::now();
 		const uint64_t n_v = h_cur[0], n_u = h_cur[1];
 		Anchor *ha = ln.h_anchors.ensure(n_v + 1);
 		uint64_t *hu = ln.h_u.ensure(n_u + 1);
-		if (n_v) HIP_CHECK(hipMemcpyAsync(ha, ln.d_bt_out_a.p, n_v * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+		if (n_v && !lazy) HIP_CHECK(hipMemcpyAsync(ha, ln.d_bt_out_a.p, n_v * sizeof(Anchor), hipMemcpyDeviceToHost, st));
 		if (n_u) HIP_CHECK(hipMemcpyAsync(hu, ln.d_bt_out_u.p, n_u * 8, hipMemcpyDeviceToHost, st));
 		// reads the RMQ kernel left to the host (a tie in a range minimum, an over-full neighbourhood, a whole contig): their sorted
 		// anchors travel as they are and ReadChains::chained stays false -- the mapper chains them with rmq_chain.cpp
@@ -414,9 +424,9 @@ public:
 		parallel_for(n_threads, (long)n, [&](long i, int) {
 			ReadChains &c = out[i];
 			c.rep_len = h_rep[i];
-			c.mp_p = hmp + mp_off[i], c.n_mp = (int32_t)(mp_off[i + 1] - mp_off[i]);
+			c.mp_p = lazy ? nullptr : hmp + mp_off[i], c.n_mp = (int32_t)(mp_off[i + 1] - mp_off[i]);
 			c.u_p = hu + h_uoff[i], c.n_u = h_nu[i];
-			c.a_p = ha + h_aoff[i], c.n_a = h_nv[i];
+			c.a_p = lazy ? nullptr : ha + h_aoff[i], c.n_a = h_nv[i];
 			c.chained = true;
 		}, 64);
 		ln.rg_lo = lo, ln.rg_n = n, ln.rg_n_v = n_v, ln.rg_n_u = n_u, ln.rg_n_v2 = ln.rg_n_u2 = 0;
@@ -426,7 +436,7 @@ public:
 			c.u_p = nullptr, c.n_u = 0, c.chained = false, c.dev_src = -1;
 			c.a_p = h_redo + rd.second, c.n_a = (int64_t)(a_off[rd.first + 1] - a_off[rd.first]);
 		}
-		if (P.long_join && !has_pairs_ && !getenv("MM2AMD_LONG_JOIN_ON_HOST")) long_join(P, lo, n, ln, kp, out, ha, hu, h_nu, h_nv, h_aoff, h_uoff); // (the diagnostic switch: every re-chain through rmq_chain.cpp)
+		if (P.long_join && !has_pairs_ && !getenv("MM2AMD_LONG_JOIN_ON_HOST")) long_join(P, lo, n, ln, kp, out, ha, hu, h_nu, h_nv, h_aoff, h_uoff, h_span); // (the diagnostic switch: every re-chain through rmq_chain.cpp)
 	}
 
 	// map.c:283-292 on the device.  Which reads re-chain is decided here from the first chains (the reference's two conditions); their CHAINED
@@ -434,8 +444,9 @@ public:
 	// chain_rmq_kernel with bw_long, and the backtrack again.  A read the RMQ kernel hands back (a range minimum that is not unique, an
 	// over-full neighbourhood) keeps its first chains and long_join_done unset: the caller re-chains it with rmq_chain.cpp.
 	void long_join(const SeedChainParams &P, long lo, size_t n, Lane &ln, KernelProfiler &kp, std::vector<ReadChains> &out, const Anchor *ha, const uint64_t *hu,
-	               const int32_t *h_nu, const int32_t *h_nv, const uint64_t *h_aoff, const uint64_t *h_uoff)
+	               const int32_t *h_nu, const int32_t *h_nv, const uint64_t *h_aoff, const uint64_t *h_uoff, const int32_t *h_span)
 	{
+		const bool lazy = h_span != nullptr; // (the chained anchors stayed on the device: the first chain's ends came back on their own)
 		hipStream_t st = ln.stream;
 		const std::vector<uint64_t> &seq_off = res_[ln.set].seq_off;
 		std::vector<uint32_t> sel;
@@ -445,7 +456,7 @@ public:
 			c.long_join_done = true;
 			if (h_nu[i] <= 1) continue;
 			const int qlen = (int)(seq_off[lo + i + 1] - seq_off[lo + i]);
-			const int32_t a0 = (int32_t)ha[h_aoff[i]].y, a1 = (int32_t)ha[h_aoff[i] + (uint64_t)((int32_t)hu[h_uoff[i]] - 1)].y;
+			const int32_t a0 = lazy ? h_span[2 * i] : (int32_t)ha[h_aoff[i]].y, a1 = lazy ? h_span[2 * i + 1] : (int32_t)ha[h_aoff[i] + (uint64_t)((int32_t)hu[h_uoff[i]] - 1)].y;
 			if (qlen - (a1 - a0) > P.rmq_rescue_size || a1 - a0 > qlen * P.rmq_rescue_ratio) sel.push_back((uint32_t)i);
 		}
 		const size_t n2 = sel.size();
@@ -495,7 +506,7 @@ public:
 		const uint64_t n_v2 = h_cur[0], n_u2 = h_cur[1];
 		Anchor *ha2 = ln.h_lj_a.ensure(n_v2 + 1);
 		uint64_t *hu2 = ln.h_lj_u.ensure(n_u2 + 1);
-		if (n_v2) HIP_CHECK(hipMemcpyAsync(ha2, ln.d_lj_out_a.p, n_v2 * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+		if (n_v2 && !lazy) HIP_CHECK(hipMemcpyAsync(ha2, ln.d_lj_out_a.p, n_v2 * sizeof(Anchor), hipMemcpyDeviceToHost, st));
 		if (n_u2) HIP_CHECK(hipMemcpyAsync(hu2, ln.d_lj_out_u.p, n_u2 * 8, hipMemcpyDeviceToHost, st));
 		ln.rg_n_v2 = n_v2, ln.rg_n_u2 = n_u2;
 		stream_wait(st);
@@ -504,7 +515,7 @@ public:
 			ReadChains &c = out[sel[k]];
 			if (tie2[k]) { c.long_join_done = false; continue; } // the host's tie-exact tree does this one
 			c.u_p = hu2 + uoff2[k], c.n_u = nu2[k];
-			c.a_p = ha2 + aoff2[k], c.n_a = nv2[k];
+			c.a_p = lazy ? nullptr : ha2 + aoff2[k], c.n_a = nv2[k];
 			c.long_joined = true;
 			c.dev_src = 1, c.dev_a_off = aoff2[k], c.dev_u_off = uoff2[k];
 		}
@@ -533,6 +544,35 @@ public:
 		}
 		ln.ksw.run(jobs, res_[ln.set].d_qpool.p, d_tbytes, T_->S.p, sc, res.data(), cigar, &n_cig, ln.stream);
 		kernel_profiler(lane_id, replica_).collect();
+	}
+
+	void fetch_chains(int lane_id, const std::vector<long> &reads, std::vector<ReadChains> &chains) override
+	{
+		if (reads.empty()) return;
+		HIP_CHECK(hipSetDevice(dev_));
+		Lane &ln = *lanes_.at(lane_id);
+		hipStream_t st = ln.stream;
+		RgnGather *g = ln.h_gather.ensure(reads.size());
+		uint64_t na = 0, nmp = 0;
+		for (size_t k = 0; k < reads.size(); ++k) {
+			const ReadChains &c = chains[reads[k]];
+			RgnGather &G = g[k];
+			G.a_src = c.dev_a_off, G.a_dst = na, G.mp_src = ln.mp_off[reads[k]], G.mp_dst = nmp;
+			G.n_a = (int32_t)c.n_a, G.n_mp = c.n_mp, G.src = c.dev_src == 1 ? 1u : 0u, G.pad = 0;
+			na += (uint64_t)c.n_a, nmp += (uint64_t)c.n_mp;
+		}
+		ln.d_gather.ensure(reads.size()), ln.d_fetch_a.ensure(na + 1), ln.d_fetch_mp.ensure(nmp + 1);
+		Anchor *ha = ln.h_fetch_a.ensure(na + 1);
+		uint64_t *hmp = ln.h_fetch_mp.ensure(nmp + 1);
+		HIP_CHECK(hipMemcpyAsync(ln.d_gather.p, g, reads.size() * sizeof(RgnGather), hipMemcpyHostToDevice, st));
+		launch_gather_chains((int)reads.size(), ln.d_gather.p, ln.d_bt_out_a.p, ln.d_lj_out_a.p, ln.d_minipos.p, ln.d_fetch_a.p, ln.d_fetch_mp.p, st);
+		if (na) HIP_CHECK(hipMemcpyAsync(ha, ln.d_fetch_a.p, na * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+		if (nmp) HIP_CHECK(hipMemcpyAsync(hmp, ln.d_fetch_mp.p, nmp * 8, hipMemcpyDeviceToHost, st));
+		stream_wait(st);
+		for (size_t k = 0; k < reads.size(); ++k) {
+			ReadChains &c = chains[reads[k]];
+			c.a_p = ha + g[k].a_dst, c.mp_p = hmp + g[k].mp_dst;
+		}
 	}
 
 	// region_dev.hpp: chains -> hits -> windows -> DP -> consume -> finish on the device, for the reads of this lane's last seed_chain()

@@ -361,7 +361,14 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 		const long m = hi - lo;
 		double t0 = now(), c0 = cpu_now(), d0 = thr_now();
 		std::vector<ReadChains> &chains = ds.chains;
-		be_.seed_chain(sp, lo, hi, lane, n_threads_, chains);
+		SeedChainParams sp_lazy = sp;
+		bool lazy = false;
+		if (batch.device_regions) { // the chains stay on the device when no read of the sub-batch is a pair (a pair's chains are cut per segment on the host)
+			lazy = true;
+			for (long i = lo; i < hi && lazy; ++i) lazy = !live[i].paired();
+			sp_lazy.lazy_chains = lazy ? 1 : 0;
+		}
+		be_.seed_chain(sp_lazy, lo, hi, lane, n_threads_, chains);
 		if (opt_.max_occ > opt_.mid_occ && !(opt_.flag & F_RMQ)) {
 			// map.c:293-316 for single-segment reads: a read that found no chain although it has repetitive minimizers is seeded
 			// again with the occurrence cap raised to max_occ and chained again.  Rare (only with -f x,y): the whole sub-batch is
@@ -422,6 +429,11 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			be_.align_regions(lane, rgn_opts_, sc, !is_sr, chains, in, n_threads_, rb);
 			long n_dev = 0;
 			for (long i = 0; i < m; ++i) on_dev[i] = !in[i].skip && rb.reads[i].flags == 0, n_dev += on_dev[i];
+			if (lazy) { // the hand-backs' chains come to the host now
+				std::vector<long> back;
+				for (long i = 0; i < m; ++i) if (!on_dev[i] && chains[i].chained && chains[i].dev_src >= 0) back.push_back(i);
+				be_.fetch_chains(lane, back, chains);
+			}
 			stats.n_region_reads_dev += n_dev, stats.n_region_reads_host += m - n_dev;
 			stats.n_jobs += (long)rb.n_jobs, stats.dp_cells += rb.dp_cells, stats.n_rounds += rb.n_jobs ? 1 : 0;
 			stats.t_ksw += now() - t0; t0 = now();

@@ -696,6 +696,38 @@ __global__ void __launch_bounds__(64) region_consume_kernel(RgnBuffers B, RgnOpt
 	B.fin[slot] = fr, B.plan[slot] = pl;
 }
 
+__global__ void __launch_bounds__(256) first_chain_span_kernel(int n_reads, const Anchor *a, const uint64_t *u, const uint64_t *a_off, const uint64_t *u_off, const int32_t *n_u, int32_t *span)
+{
+	const int r = (int)(blockIdx.x * 256u + threadIdx.x);
+	if (r >= n_reads) return;
+	int32_t y0 = 0, y1 = 0;
+	if (n_u[r] > 0) {
+		const int32_t cnt = (int32_t)u[u_off[r]];
+		y0 = (int32_t)a[a_off[r]].y, y1 = (int32_t)a[a_off[r] + (uint64_t)(cnt - 1)].y;
+	}
+	span[2 * r] = y0, span[2 * r + 1] = y1;
+}
+void launch_first_chain_span(int n_reads, const Anchor *a, const uint64_t *u, const uint64_t *a_off, const uint64_t *u_off, const int32_t *n_u, int32_t *span, void *stream)
+{
+	if (n_reads <= 0) return;
+	hipLaunchKernelGGL(first_chain_span_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_reads, a, u, a_off, u_off, n_u, span);
+	HIP_CHECK(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) gather_chains_kernel(const RgnGather *g, const Anchor *a0, const Anchor *a1, const uint64_t *mp, Anchor *a_out, uint64_t *mp_out)
+{
+	const RgnGather G = g[blockIdx.x];
+	const Anchor *src = (G.src ? a1 : a0) + G.a_src;
+	for (int i = threadIdx.x; i < G.n_a; i += 256) a_out[G.a_dst + i] = src[i];
+	for (int i = threadIdx.x; i < G.n_mp; i += 256) mp_out[G.mp_dst + i] = mp[G.mp_src + i];
+}
+void launch_gather_chains(int n, const RgnGather *g, const Anchor *a0, const Anchor *a1, const uint64_t *mp, Anchor *a_out, uint64_t *mp_out, void *stream)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(gather_chains_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, g, a0, a1, mp, a_out, mp_out);
+	HIP_CHECK(hipGetLastError());
+}
+
 void launch_chain_regs(const RgnBuffers &B, const RgnOpts &O, void *stream)
 {
 	if (B.n_reads <= 0) return;

@@ -105,6 +105,11 @@ struct RgnBuffers {           // device pointers of one sub-batch
 	FinPiece *pieces;         // a region's pieces at [job0, job0 + n_win)
 };
 
+// span[2 r], span[2 r + 1]: query positions of the first and the last anchor of read r's first chain (what the long-join question of map.c:283-292 asks)
+void launch_first_chain_span(int n_reads, const Anchor *a, const uint64_t *u, const uint64_t *a_off, const uint64_t *u_off, const int32_t *n_u, int32_t *span, void *stream);
+// the listed slices of two source arrays packed back to back (a hand-back's anchors and minimizer positions on their way to the host)
+struct RgnGather { uint64_t a_src, a_dst, mp_src, mp_dst; int32_t n_a, n_mp; uint32_t src, pad; };
+void launch_gather_chains(int n, const RgnGather *g, const Anchor *a0, const Anchor *a1, const uint64_t *mp, Anchor *a_out, uint64_t *mp_out, void *stream);
 void launch_chain_regs(const RgnBuffers &B, const RgnOpts &O, void *stream);
 void launch_region_plan(const RgnBuffers &B, const RgnOpts &O, void *stream);
 void launch_region_consume(const RgnBuffers &B, const RgnOpts &O, const uint32_t *cigar_pool, void *stream); // cigar_pool: the DP batch's CIGARs (KswRes::cigar_off)

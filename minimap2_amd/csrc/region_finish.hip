@@ -81,7 +81,10 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 	const int lane = (int)threadIdx.x;
 	const int id = (int)blockIdx.x;
 	const FinRegion R = P.regions[id];
-	if (R.n_pieces == 0) return; // (a slot of a region that is not finished here: region_consume_kernel's hand-backs)
+	if (R.n_pieces == 0) { // nothing to stitch (an empty region; a slot region_consume_kernel handed back to the host): an empty result
+		if (lane == 0) { FinResult z; __builtin_memset(&z, 0, sizeof z); P.results[id] = z; }
+		return;
+	}
 	uint32_t *cg = s_all, *aux = s_all + (size_t)P.cap_ops;
 	if (lane < 25) s_mat[lane] = P.mat[lane];
 	auto qb = [&](ByteWindow &c, int32_t i) -> int {
