@@ -339,6 +339,7 @@ def main():
         the library names its own threads (mm2pool: the host stages' workers, mm2side: hand-over packing / formatting workers, mm2lane: lane drivers,
         mm2-stager / -mapper / -output: the pipeline's three steps), the HIP runtime's threads keep the interpreter's name."""
         out, tck = {}, float(os.sysconf("SC_CLK_TCK"))
+        by_tid.clear()
         try:
             for tid in os.listdir("/proc/self/task"):
                 try:
@@ -347,14 +348,19 @@ def main():
                     continue
                 nm, rest = st_[st_.index("(") + 1:st_.rindex(")")], st_[st_.rindex(")") + 2:].split()
                 out[nm] = out.get(nm, 0.0) + (int(rest[11]) + int(rest[12])) / tck
+                by_tid[tid] = (nm, (int(rest[11]) + int(rest[12])) / tck)
         except OSError:
             pass
         return out
+    by_tid = {}
     tc0 = thread_cpu()
+    tid0 = dict(by_tid)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     total_t = run_steps(range(a.warmup, a.warmup + a.steps))
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     tc1 = thread_cpu()
+    # the busiest single threads of the timed steps (thread name, CPU seconds per step): tells a runtime helper that spins from a pool that works
+    top_threads = sorted(((nm, round((v - tid0.get(t_, (nm, 0.0))[1]) / max(a.steps, 1), 3)) for t_, (nm, v) in by_tid.items()), key=lambda x: -x[1])[:8]
     # (threads that ended inside the window -- the lane drivers of every batch, the pipeline's three -- are not in tc1: their share is the remainder)
     cpu_by_thread = {k: round((v - tc0.get(k, 0.0)) / max(a.steps, 1), 3) for k, v in sorted(tc1.items()) if v - tc0.get(k, 0.0) >= 0.005 * max(a.steps, 1)}
     sam_bytes_per_step = step_done[-1][1] if step_done else 0
@@ -559,17 +565,45 @@ def main():
             # the same thing: 4 x SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) of profiles/r04_pmc_sq_v34.json (r03_pmc_sq_v1.json: round 3's cell).  Lane utilisation =
             # cells / (128 x executed register-set rows), counted by the MM2AMD_GF_COUNT build: at HEAD on the wave emulator (a property of the schedule and the job mix:
             # profiles/r04_stream_lane_utilisation_emu.txt, 0.860 / 0.882 for the two classes; round 2 on the MI355X: 0.856 / 0.87, profiles/r02_stream_lane_utilisation.txt).
-            if vfam == "ksw_stream_kernel":
-                n_slow, n_vop2, lane_util = 35 + 6 + 1, 7, 0.872
-            else:
-                n_slow, n_vop2, lane_util = 34 + 6 + 11, 12, 0.727
-            row_cycles = n_slow * 4.1 + n_vop2 * 2.2
-            peak_cells = 1024 * 2.4e9 * 128 / row_cycles
-            nominal = 1024 * 2.4e9 * 128 / ((n_slow + n_vop2) * 2.0)
-            rate = cells1 / max(ms1 * 1e-3, 1e-12)
-            busy = None
+            # (round 5) the counts come from profiles/isa_row_counts.json -- tools/isa_row_counts.py: the hot loops' VALU instructions per register-set row, by
+            # encoding class, counted in the gfx950 assembly of the sources whose SHA-256 the file carries; nothing typed in here.  Launch classes of the
+            # family (the 4- and the 8-set instantiation) are priced separately and combined by their cells.
+            isa = {}
             try:
-                sq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq_v34.json")))["kernels"]  # (collected with the keyed cell: the kernels the line times)
+                isa = json.load(open(os.path.join(ROOT, "profiles", "isa_row_counts.json")))
+            except Exception:
+                pass
+            def sources_now():
+                import hashlib
+                h = hashlib.sha256()
+                for f_ in isa.get("sources", []):
+                    h.update(open(os.path.join(ROOT, "minimap2_amd", "csrc", f_), "rb").read())
+                return h.hexdigest()
+            try:
+                isa_current = bool(isa) and sources_now() == isa.get("sources_sha256")
+            except Exception:
+                isa_current = False
+            lane_util = (isa.get("lane_utilisation") or {}).get(vfam, 0.872 if vfam == "ksw_stream_kernel" else 0.727)
+            t_issue = t_nominal = 0.0  # seconds the family's cells take at the issue peak / at the guide's 2 cycles per instruction
+            rows = {}
+            for k, v in one.items():
+                inst = k.split("[")[0]  # ksw_stream_kernel<4>, ksw_gapfill_kernel<512>, ...
+                key = next((kk for kk in (isa.get("kernels") or {}) if kk.startswith(inst.rstrip(">") + ",")), None)
+                c = (isa["kernels"][key]["per_register_set_row"] if key else {"vop3p": 35.0, "dpp": 6.0, "vop3": 1.0, "sdwa": 0.0, "vop2": 7.0})
+                n_slow, n_vop2 = c["vop3p"] + c["dpp"] + c["vop3"] + c["sdwa"], c["vop2"]
+                rc = n_slow * 4.1 + n_vop2 * 2.2
+                rows[k] = {"isa_key": key, "valu_per_register_set_row": round(n_slow + n_vop2, 2), "issue_cycles_per_row": round(rc, 1)}
+                t_issue += v["units"] / (1024 * 2.4e9 * 128 / rc)
+                t_nominal += v["units"] / (1024 * 2.4e9 * 128 / ((n_slow + n_vop2) * 2.0))
+            rate = cells1 / max(ms1 * 1e-3, 1e-12)
+            peak_cells = cells1 / max(t_issue, 1e-12)
+            nominal = cells1 / max(t_nominal, 1e-12)
+            busy, busy_src = None, None
+            try:
+                import glob as _glob
+                cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r05_pmc_sq_*.json"))) or [os.path.join(ROOT, "profiles", "r04_pmc_sq_v34.json")]
+                busy_src = os.path.basename(cand[-1])
+                sq = json.load(open(cand[-1]))["kernels"]  # (one --pmc pass at 20 k-read launches: tools/pmc_sq.py)
                 act = sum(v["SQ_ACTIVE_INST_VALU"] for k, v in sq.items() if k.startswith(vfam))
                 gui = sum(v["GRBM_GUI_ACTIVE"] for k, v in sq.items() if k.startswith(vfam)) / 8.0
                 busy = round(4.0 * act / (1024.0 * gui), 4)
@@ -577,11 +611,12 @@ def main():
                 pass
             roof["valu"] = {"bound": "valu", "kernel": vfam, "cells_per_s": round(rate, 1), "issue_peak_cells_per_s": round(peak_cells, 1),
                             "frac": round(rate / peak_cells, 4), "lane_utilisation": lane_util, "frac_at_measured_lane_utilisation": round(rate / peak_cells / lane_util, 4),
-                            "valu_busy_sq_counters": busy,
+                            "valu_busy_sq_counters": busy, "valu_busy_source": busy_src,
                             "nominal_2cycle_peak_cells_per_s": round(nominal, 1), "frac_nominal": round(rate / nominal, 4),
                             "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
+                            "rows": rows, "isa_counts": {"file": "profiles/isa_row_counts.json", "commit": isa.get("commit"), "made_from_the_sources_this_run_uses": isa_current},
                             "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
-                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / %d cycles: the hot loop's %d VALU instructions per register-set row (ISA count) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) from profiles/r04_pmc_sq_v34.json (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction" % (round(row_cycles), n_slow + n_vop2)}
+                            "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / the issue cycles of one register-set row: the hot loop's VALU instructions per row by encoding class (profiles/isa_row_counts.json, counted in the assembly by tools/isa_row_counts.py) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction"}
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
             roof["unoverlapped_alg_bytes"] = {k: round(v["alg_bytes"], 1) for k, v in sorted(prof1.items())}
             roof["unoverlapped_alg_gb_per_s"] = {k: round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["alg_bytes"] > 0}
@@ -599,7 +634,8 @@ def main():
             try:
                 t = json.load(open(tj)).get(fam)
                 if t:
-                    roof["traffic"] = round(t["fetch_bytes_x2"] + t["write_bytes_per_launch"], 1)
+                    roof["traffic"] = round(t.get("traffic_bytes_per_launch", t["fetch_bytes_x2"] + t["write_bytes_per_launch"]), 1)
+                    roof["traffic_source"] = {"file": "profiles/pmc_traffic.json", "commit": t.get("commit"), "fetch_factor": t.get("fetch_factor", 2.0)}
             except Exception:
                 pass
 
@@ -693,7 +729,7 @@ def main():
                       "parallelism": "replicated index, %s, RCCL hit gather to rank 0, every rank formats its shard" % ("one batch sharded %d-way by bases" % world if strong else "%d independent batches" % world) if world > 1 else "1 GPU",
                       "clock": "pipeline of hand-over | mapping | SAM formatting over the timed steps, all three inside the clock (map.c:541-643)",
                       "host_cpu_s_per_step_per_rank": cpu_all,
-                      "host_cpu_s_per_step_by_thread_name": cpu_by_thread,
+                      "host_cpu_s_per_step_by_thread_name": cpu_by_thread, "host_cpu_s_per_step_busiest_threads": top_threads,
                       "host_cpu_s_per_stage_one_lane_pass": stage_cpu,
                       "lane_driver_cpu_s_last_timed_batch": drv_cpu_last_batch,
                       "sam_bytes_per_step_this_rank": sam_bytes_per_step,

@@ -66,7 +66,9 @@ int mm2amd_ksw_extd2_batch(int n_jobs, const mm2amd_ksw_job_t *jobs, int8_t m, c
  * the best-scoring segment (dp_max) counted -- region_finish_kernel, one wavefront per region.  query / target: nt4 codes (0-3, 4 = N) of
  * the aligned stretches; piece[i] / piece_len[i]: the windows' CIGARs in alignment order.  cigar_pool must hold the sum of all piece lengths
  * (MM2AMD_ENOMEM otherwise).  Results are those of the reference for every input the reference accepts (its asserts hold: the operations
- * cover exactly qlen and tlen); n_cigar < 0 marks a region whose operations do not. */
+ * cover exactly qlen and tlen); n_cigar < 0 marks a region whose operations do not.  A region of more than MM2AMD_FIN_MAX_OPS operations (the
+ * kernel stages a region's CIGAR in LDS) is refused with MM2AMD_EINVAL: the mapper finishes such regions with its host routine. */
+#define MM2AMD_FIN_MAX_OPS 7168
 typedef struct {
 	const uint8_t *query, *target;
 	int32_t qlen, tlen;

@@ -811,7 +811,8 @@ Backend *make_backend(const FlatIndex &fi, void *device_tables, int n_threads, i
 {
 	return new HipBackend(fi, (DeviceIndexTables *)device_tables, n_threads, device, replica, tables_device);
 }
-int backend_device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+void apply_hw_queue_default(); // capi_common.cpp
+int backend_device_count() { apply_hw_queue_default(); int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 void *backend_build_index_tables(FlatIndex &fi, int device, int *on_device)
 {

@@ -31,7 +31,13 @@ int effective_cpus()
 // (bench.py: 1.85 -> 2.01 Gbases/s with 16).  The runtime reads the variable when it initialises, at the process's first HIP call -- so a
 // process whose first HIP call is this library's gets the setting from here (never overriding the user's); one that has initialised HIP before
 // loading the library (a Python process that imported torch and touched the device) sets it itself: INTEGRATION.md section 5.
-namespace { struct HwQueueDefault { HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_hw_queue_default; }
+// Round 5: set on the library's first way to the device (device_ctx / the device count), not by a static initializer at load time -- loading the
+// library no longer touches the process environment; MM2AMD_KEEP_HW_QUEUES=1 leaves the variable alone altogether.
+void apply_hw_queue_default()
+{
+	static const bool once = [] { if (!getenv("MM2AMD_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0); return true; }();
+	(void)once;
+}
 static thread_local std::string g_last_error;
 void capi_set_error(const std::string &msg) { g_last_error = msg; }
 int capi_fail(int code, const std::string &msg) { g_last_error = msg; return code; }

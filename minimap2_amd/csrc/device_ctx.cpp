@@ -23,8 +23,11 @@ int default_device()
 	return id;
 }
 
+void apply_hw_queue_default(); // capi_common.cpp
+
 DeviceCtx &device_ctx(int id)
 {
+	apply_hw_queue_default(); // (before this process's first HIP call, when that call is ours)
 	static DeviceCtx d[kMaxDevices];
 	if (id < 0) id = default_device();
 	if (id >= kMaxDevices) throw HipError("[mm2amd] device ordinal beyond the supported range");

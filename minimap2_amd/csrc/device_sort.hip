@@ -173,7 +173,9 @@ __global__ void __launch_bounds__(kSortThreads) xs_reduce_kernel(const uint32_t 
 	if (tid == 0) sums[blockIdx.x] = total;
 }
 
-// tile b of `in` scanned into `out`, starting from carry[b] (nullptr: 0); the last tile also writes out[n] = the total
+// tile b of `in` scanned into `out`, starting from carry[b] (nullptr: 0); the last tile also writes out[n] = the total.
+// `in` may BE `out` (the recursion over the tile sums scans them in place): every item of the tile is loaded into registers before the first store of the
+// tile, and tiles do not overlap -- the loads-then-stores order below is what makes the aliasing safe; keep it.
 __global__ void __launch_bounds__(kSortThreads) xs_apply_kernel(const uint32_t *in, uint32_t *out, uint64_t n, const uint32_t *carry)
 {
 	__shared__ uint32_t sh[4];
@@ -216,7 +218,7 @@ void device_exclusive_sum_u32(const uint32_t *in, uint32_t *out, uint64_t n, hip
 	device_exclusive_sum_u32(sums.p, sums.p, n_tiles, stream);
 	hipLaunchKernelGGL(xs_apply_kernel, dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, in, out, n, (const uint32_t *)sums.p);
 	HIP_CHECK(hipGetLastError());
-	HIP_CHECK(hipStreamSynchronize(stream)); // `sums` is freed on return
+	stream_wait(stream); // `sums` is freed on return (stream_wait sleeps between polls: hipStreamSynchronize spins a core, hip_util.hpp)
 }
 
 int device_sort_pairs_u64(uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, uint64_t n, int bits, hipStream_t stream)
@@ -242,7 +244,7 @@ int device_sort_pairs_u64(uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1
 		HIP_CHECK(hipGetLastError());
 		cur ^= 1;
 	}
-	HIP_CHECK(hipStreamSynchronize(stream)); // the tables are freed on return
+	stream_wait(stream); // the tables are freed on return
 	return cur;
 }
 

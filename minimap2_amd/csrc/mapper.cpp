@@ -59,6 +59,11 @@ uint32_t read_hash(const char *qname, int qlen, const MapOpt &opt)
 
 Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_threads) : fi_(fi), opt_(opt), be_(be), n_threads_(n_threads < 1 ? 1 : n_threads)
 {
+	{ // one scratch object per lane the backend has, made before any lane thread exists
+		const size_t cap = (size_t)std::max(16, be.n_lanes());
+		scratch_.reserve(cap), drivers_.reserve(cap);
+		for (int i = 0; i < std::max(1, be.n_lanes()); ++i) scratch_.emplace_back(new DriverScratch);
+	}
 	{ // what the device's chains -> hits -> windows path reads from the options (region_dev.hpp)
 		RgnOpts &O = rgn_opts_;
 		O.flag = opt.flag, O.max_sw_mat = opt.max_sw_mat, O.k = fi.k;
@@ -233,6 +238,7 @@ std::shared_ptr<Mapper::BatchRun> Mapper::make_run(int set)
 
 void Mapper::ensure_drivers(int n)
 {
+	// (scratch_ never reallocates: the constructor reserved the backend's lane count, and lane threads read scratch_.at(lane) without the lock)
 	while ((int)scratch_.size() < n) scratch_.emplace_back(new DriverScratch);
 	while ((int)drivers_.size() < n) { const int lane = (int)drivers_.size(); drivers_.emplace_back([this, lane] { driver_loop(lane); }); }
 }
@@ -302,9 +308,11 @@ void Mapper::run(std::vector<ReadResult> &out)
 		if (next_run_ && next_adopted_) b = next_run_, next_run_.reset(), next_adopted_ = false; // the lanes have started on it
 		else b = make_run(cur_set_);
 		cur_run_ = b;
-		be_.set_active_lanes(b->n_drivers);
 		lane_cap_ = std::max(1, be_.n_lanes());
 		if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) lane_cap_ = std::max(1, std::min(lane_cap_, atoi(e)));
+		// shared budgets (the DP kernels' direction-matrix scratch, which only grows) are split among the lanes that CAN work at once: with a queued
+		// hand-over the lanes this batch leaves idle start on the next one, so a batch of one or two sub-batches does not have the GPU to itself
+		be_.set_active_lanes(be_.stages_beside_mapping() ? std::max(lane_cap_, b->n_drivers) : b->n_drivers);
 		ensure_drivers(std::max(lane_cap_, b->n_drivers)); // (lanes beyond this batch's sub-batches exist too: they are the ones free to start on the next batch)
 		cv_work_.notify_all();
 		cv_done_.wait(lk, [&] { return b->n_done == b->n_taken && (b->cancelled || b->next_sub >= b->subs.size()); });

@@ -76,7 +76,7 @@ if __name__ == "__main__":
     # a map-ont run replaces every entry but the splice kernel's (which it does not exercise); a splice run only adds that one
     out = {k: v for k, v in old.items() if (k.startswith("ksw_splice") if a.preset == "map-ont" else True)}
     for f in sorted(set(fetch) | set(write)):
-        if not any(f.startswith(p) for p in ("ksw_", "chain_", "seed_", "sketch", "anchor_", "encode", "region_", "rechain_")):
+        if not any(f.startswith(p) for p in ("ksw_", "chain_", "seed_", "sketch", "anchor_", "encode", "region_", "rechain_", "first_chain", "gather_chains")):
             continue
         if a.preset != "map-ont" and not f.startswith("ksw_splice"):
             continue  # a splice run only contributes the kernel that the map-ont run does not exercise
@@ -85,8 +85,12 @@ if __name__ == "__main__":
         n = max(fl, wl, 1)
         alg = ALG.get(f) or ALG.get({"sketch_wave_kernel": "sketch_kernel"}.get(f, f))
         alg_per = alg[0] / max(alg[1], 1) if alg else None
-        traffic = 2 * fb * 1024 / n + wb * 1024 / n
+        # gfx950: FETCH_SIZE reports half the bytes of coalesced dword / qword / dwordx4 streams (x2 correction: profiles/r03_pmc_calibration.json) but a
+        # whole 64-byte sector for a random 8-byte probe (x1): the index-probing kernel is priced without the correction
+        ff = 1.0 if f in ("seed_collect_kernel",) else 2.0
+        traffic = ff * fb * 1024 / n + wb * 1024 / n
         out[f] = {"fetch_bytes_per_launch": fb * 1024 / n, "fetch_bytes_x2": 2 * fb * 1024 / n, "write_bytes_per_launch": wb * 1024 / n, "launches": n,
+                  "fetch_factor": ff, "traffic_bytes_per_launch": traffic,
                   "alg_bytes_per_launch": alg_per, "traffic_over_algorithmic": round(traffic / alg_per, 2) if alg_per else None,
                   "commit": os.environ.get("MM2AMD_COMMIT"),
                   "note": "%s: per launch at %d reads vs %d Mb; FETCH_SIZE/WRITE_SIZE in KiB -> bytes; x2 = gfx950 wide-read correction; WRITE_SIZE uncalibrated" % (a.preset, a.reads, a.ref_mb)}
