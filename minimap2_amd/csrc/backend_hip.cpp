@@ -643,19 +643,24 @@ public:
 		const uint32_t n_regs = std::min<uint32_t>(cur[RGN_CUR_REGS], max_regs);
 		const size_t n_jobs = std::min<size_t>(cur[RGN_CUR_JOBS], (size_t)max_jobs64);
 		Trace::get().add(lane_id, "gpu:regs+plan", tt, Trace::now()); tt = Trace::now();
-		// the DP: the job records cross once for the host's launch planning (classes, order, scratch sizes); the results stay on the device
 		const uint32_t *d_cigar = nullptr;
 		size_t n_cig = 0;
-		if (n_jobs) {
-			KswJob *hj = ln.h_rg_jobs.ensure(n_jobs);
-			HIP_CHECK(hipMemcpyAsync(hj, ln.d_rg_jobs.p, n_jobs * sizeof(KswJob), hipMemcpyDeviceToHost, st));
-			stream_wait(st);
-			for (size_t j = 0; j < n_jobs; ++j) out.dp_cells += (double)hj[j].qlen * hj[j].tlen;
+		if (n_jobs) { // the DP: the job records stay where region_plan_kernel wrote them; launch classes, order and sizes are made on the device (ksw_order.hip)
 			ln.ksw.n_threads = n_threads, ln.ksw.prof = &kp, ln.ksw.lane = lane_id;
 			size_t dir_gb = 160;
 			if (const char *e = getenv("MM2AMD_DIR_BUDGET_GB")) dir_gb = atol(e) > 0 ? (size_t)atol(e) : dir_gb;
 			ln.ksw.dir_budget = std::min<size_t>((dir_gb << 30) / (size_t)active_lanes_, (size_t)96 << 30);
-			ln.ksw.run_jobs(hj, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st);
+			static const bool host_order = getenv("MM2AMD_KSW_ORDER_ON_HOST") != nullptr; // A/B checks: the job records cross for the host's ordering
+			if (host_order) {
+				KswJob *hj = ln.h_rg_jobs.ensure(n_jobs);
+				HIP_CHECK(hipMemcpyAsync(hj, ln.d_rg_jobs.p, n_jobs * sizeof(KswJob), hipMemcpyDeviceToHost, st));
+				stream_wait(st);
+				for (size_t j = 0; j < n_jobs; ++j) out.dp_cells += (double)hj[j].qlen * hj[j].tlen;
+				ln.ksw.run_jobs(hj, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st);
+			} else {
+				ln.ksw.run_jobs(nullptr, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st, ln.d_rg_jobs.p);
+				out.dp_cells += ln.ksw.last_cells;
+			}
 		}
 		tt = Trace::now();
 		B.res = ln.ksw.d_res.p, B.perm = ln.ksw.d_perm.p;

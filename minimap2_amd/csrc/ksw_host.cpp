@@ -2,6 +2,7 @@
 #include <numeric>
 #include <cstring>
 #include "ksw_host.hpp"
+#include "ksw_classify.hpp"
 #include "host_prof.hpp"
 #include "kernel_prof.hpp"
 #include "threads.hpp"
@@ -12,80 +13,25 @@
 namespace mm2amd {
 
 namespace {
-// Launch classes.  0..5: the register-resident gap-fill kernel (ksw_gapfill.hip), classed by query capacity (512 / 1024 bytes of
-// LDS per job: eight / four waves per SIMD) and by target length (one strip of 256 columns, up to 2-4 strips, more), so that the
-// two jobs of a wave have the same strip count and a class's direction-matrix slots are not sized by its rare giants.
-// 6..: the lane-exact kernel (ksw_extd2.hip), classed by (a) the size of its state window -- rings of 256..8192 positions in
-// LDS, 13 B per position, or any size in HBM; a job needs min(qlen, tlen, band) + 64 positions -- and (b) the size of its
-// direction matrix, because every persistent wave owns a scratch slot as large as the biggest matrix of its class.
-constexpr int kFirstExact = 6, kRingClasses = 7, kDirClasses = 11, kFirstSplice = kFirstExact + kRingClasses * kDirClasses;
-// kFirstSplice..: the register-resident splice gap-fill kernel (ksw_splice.hip): two jobs per wave with 2 or 4 register sets of
-// 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves of 4 sets (512 positions per
-// sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
-constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
-// kFirstExt, kFirstExt + 1: the register-resident extension kernel (ksw_ext.hip): the two extensions per read whose band cannot bind,
-// left-aligned (right extensions) and right-aligned (left extensions: KSW_EZ_RIGHT); two jobs per wave.
+// (the launch classes themselves: ksw_classify.hpp)
 static const char *const kExtNames[4] = {"ksw_ext_kernel[left-aligned]", "ksw_ext_kernel[right-aligned]", "ksw_ext_kernel[left-aligned,t512]", "ksw_ext_kernel[right-aligned,t512]"};
 // + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512 (eight register sets; these launches hold a few hundred long jobs and are as
 // latency-bound as the lane-exact kernel's: they run beside it on the side stream).  Twelve sets (targets up to 768) were measured and dropped: 5 Gcells/s,
 // three times the time the lane-exact kernel needs for the same jobs.
-constexpr int kNTiers = kFirstExt + 4, kExtMaxQ = 512, kExtMaxT = 512;
 const int kSpliceSets[kSpliceClasses] = { 2, 4, 4 };
 const bool kSpliceSelf[kSpliceClasses] = { false, false, true };
-const int kSpliceMaxQ[kSpliceClasses] = { 128, 256, 1 << 30 };
 const int kSpliceWaves[kSpliceClasses] = { 4, 4, 4 };             // waves per block (splice_wpb in ksw_splice.hip)
 const int kSpliceBlocksPerCU[kSpliceClasses] = { 4, 4, 4 };
-constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 const int kFastQCap[kFirstExact] = { 512, 512, 512, 1024, 1024, 1024 };
-const int kFastMaxT[kFirstExact] = { 256, 512, 1536, 256, 1024, 3072 };   // <= 3 * query capacity: the kernel's LDS holds the target bytes for the Z-drop scan
 const int kRingSize[kRingClasses] = { 256, 512, 1024, 2048, 4096, 8192, 0 };
 const int kRingWaves[kRingClasses] = { 4, 4, 4, 1, 1, 1, 4 }; // waves per block where a wave has a job of its own
 // wavefronts per job (round 4): anti-diagonals of up to 192 cells stay with one wave; wider ones are swept by a workgroup of 4 or 8 waves, one job
 // per workgroup (a band-751 anti-diagonal is twelve 64-lane chunks: one wave needed three passes of twelve chunks per row, and the ~3 k such
 // extensions of a step held their launches for as long as the longest one took)
 const int kRingTeam[kRingClasses] = { 1, 4, 8, 8, 8, 8, 1 };
-inline size_t dir_limit(int dc) { return dc == kDirClasses - 1 ? SIZE_MAX : (size_t)256 << (10 + dc); } // 256 KB, 512 KB, ... 128 MB, any
-constexpr int kFastMaxQ = 1024, kFastMaxTAny = 3072;
 constexpr int kMaxWavesPerCU = 20;    // exact kernel: <= 96 VGPRs -> 5 waves/SIMD
 inline int fast_waves(int tier) { return kFastQCap[tier] > 512 ? 4 : 6; } // waves per SIMD the gap-fill kernel is compiled for (= blocks of four waves per CU)
-inline int stream_sets(int tier) { return tier == 0 ? 4 : tier == 1 ? 8 : 0; } // classes the streaming kernel takes (query <= 512, target <= 64 * sets); 0: the strip kernel
-inline int fast_tier(const KswJob &j) { int t = j.qlen <= 512 && j.tlen <= 1536 ? 0 : 3; while (j.tlen > kFastMaxT[t]) ++t; return t; }
-
-// ksw_extd2_sse limits anti-diagonal r to t in [max(0, r - qlen + 1, (r - w + 1) >> 1), min(tlen - 1, r, (r + w) >> 1)] (ksw2_extd2_sse.c:139-146).
-// The band terms never decide when (r - w + 1) >> 1 <= max(0, r - qlen + 1) and (r + w) >> 1 >= min(r, tlen - 1) for every r, i.e. when
-// w >= qlen - 1 and w >= tlen - 1: the row limits, and with them every boundary value the reference picks (:148-163), are then those of an
-// unbanded call.  (Rounds 1-2 used the sufficient w >= qlen + tlen, which sent every extension longer than 375 + 376 to the lane-exact kernel.)
-inline bool band_cannot_bind(const KswJob &j) { return j.w < 0 || ((int64_t)j.w + 1 >= j.qlen && (int64_t)j.w + 1 >= j.tlen); }
-// A job may take the register-resident kernel when nothing but valid cells can matter: global alignment with the approximate
-// score (the gap-fill call, align.c:838), default substitution scores, and a band that cannot bind.
-inline bool fast_eligible(const KswJob &j, bool scoring_ok)
-{
-	if (!scoring_ok || (j.flag & 0x1fff) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
-	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kFastMaxQ || j.tlen > kFastMaxTAny) return false;
-	return band_cannot_bind(j);
-}
-// The splice gap fill (align.c:840 with -x splice) may take the register-resident splice kernel: global alignment with the
-// approximate score, default substitution scores, forward CIGAR, no junction scores; the scoring must
-// keep every intermediate of a valid cell inside 8 bits (what the reference's int8 lanes assume).
-inline bool splice_fast_eligible(const KswJob &j, bool scoring_ok)
-{
-	constexpr int kSpliceBits = KSW_SPLICE_FOR | KSW_SPLICE_REV | KSW_SPLICE_FLANK | KSW_SPLICE_CMPLX;
-	if (!scoring_ok || ((j.flag & 0x1fff) & ~kSpliceBits) != KSW_APPROX_MAX || (j.flag & KSWJ_SKIP)) return false;
-	if (j.reserved) return false; // windows with annotated splice sites (KswScoring::juncs) are priced by the lane-exact kernel only
-	return j.qlen > 0 && j.tlen > 0;
-}
-// An extension (align.c:791, :883: KSW_EZ_EXTZ_ONLY; left extensions also KSW_EZ_RIGHT | KSW_EZ_REV_CIGAR) may take the register-resident
-// extension kernel when its band cannot bind, with default substitution scores and dual-affine costs: exact row maxima, Z-drop and end
-// bonus are computed there (ksw_ext.hip).
-inline bool ext_eligible(const KswJob &j, bool scoring_ok)
-{
-	const int f = j.flag & 0x1fff;
-	if (!scoring_ok || (j.flag & KSWJ_SKIP) || (f != KSW_EXTZ_ONLY && f != (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR))) return false;
-	static const int max_t = getenv("MM2AMD_EXT_MAX_T") ? atoi(getenv("MM2AMD_EXT_MAX_T")) : kExtMaxT; // A/B: longer targets to the lane-exact kernel's workgroups
-	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.tlen > max_t) return false;
-	return band_cannot_bind(j);
-}
-inline int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
+inline int stream_sets(int tier) { return ksw_stream_sets(tier); }
 }
 
 void ksw_gapfill_launch(const KswLaunch &L, int n_slots, int qcap, void *stream); // ksw_gapfill.hip
@@ -96,21 +42,24 @@ void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, v
 void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);               // ksw_ext.hip
 
 void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-                         const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream)
+                         const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream, const KswJob *d_jobs_in)
 {
 	const bool resident = res == nullptr; // the results stay on the device (ksw_host.hpp)
+	if (d_jobs_in && !resident) throw std::invalid_argument("[mm2amd] KswRunner: jobs on the device go with results on the device");
 	*cigar_out = nullptr, *n_cigar_out = 0;
 	if (n == 0) return;
 	double tt = Trace::now();
 	// launch order: tier ascending, then cost (rows * row width) roughly descending (longest-job-first for the persistent
-	// waves).  An exact order is not needed, so a counting sort on sqrt(cost) does it: jobs are cut into chunks, each chunk is
-	// classified and histogrammed by one pool thread (which also gathers the per-class sizing figures), a short serial prefix
-	// turns the histograms into stable scatter offsets, and the chunks scatter in parallel.
-	constexpr int NB = 256; // cost buckets per tier
+	// waves).  An exact order is not needed, so a counting sort on sqrt(cost) does it.  Jobs that were born on the device (d_jobs_in:
+	// region_plan_kernel's) are classed, counted and ordered THERE (ksw_order.hip) and only the per-class sizing figures come back; jobs from the
+	// host are cut into chunks, each chunk classified and histogrammed by one pool thread, a short serial prefix turns the histograms into stable
+	// scatter offsets, and the chunks scatter in parallel.
+	constexpr int NB = kOrderBuckets; // cost buckets per tier
 	const bool stream_on = !getenv("MM2AMD_NO_STREAM"); // diagnostic: every gap fill through the strip kernel
 	constexpr size_t CH = 32768;
 	const size_t NBINS = (size_t)kNTiers * NB;
 	static const bool ext_on = !getenv("MM2AMD_NO_EXT_KERNEL"); // diagnostic: every extension through the lane-exact kernel
+	static const int ext_max_t = getenv("MM2AMD_EXT_MAX_T") ? atoi(getenv("MM2AMD_EXT_MAX_T")) : kExtMaxT; // A/B: longer targets to the lane-exact kernel's workgroups
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
@@ -119,8 +68,31 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	for (int t = 0; t < sc.m * sc.m; ++t) max_abs = std::max<int>(max_abs, std::abs((int)sc.mat[t]));
 	const bool splice_ok = sc.m == 5 && !disable_fast && splice && -min_sc <= 2 * (sc.q + sc.e) && sc.q2 > sc.q + sc.e && sc.e > 0 && sc.q >= 0 && sc.noncan >= 0 &&
 	                       sc.q + sc.e + sc.q2 + sc.noncan + max_abs <= 100;
+	KswClassCtx cctx;
+	cctx.scoring_ok = scoring_ok, cctx.splice_ok = splice_ok, cctx.splice = splice, cctx.stream_on = stream_on, cctx.ext_on = ext_on, cctx.ext_max_t = ext_max_t;
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
 	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0, cells = 0; };
+	size_t sum_len = 0;
+	ClassStat cls[kNTiers];
+	size_t tier_beg[kNTiers + 1];
+	d_jobs.ensure(n);
+	if (d_jobs_in) { // the ordering on the device; nothing of the jobs crosses PCIe
+		d_perm.ensure(n), d_order_work.ensure(ksw_order_work_words(n)), d_order_out.ensure(1);
+		KswOrderResult *ho = h_order_out.ensure(1);
+		ksw_order_device(d_jobs_in, n, cctx, d_jobs.p, d_perm.p, d_order_work.p, d_order_out.p, stream);
+		HIP_CHECK(hipMemcpyAsync(ho, d_order_out.p, sizeof(KswOrderResult), hipMemcpyDeviceToHost, stream));
+		stream_wait(stream);
+		for (int t = 0; t < kNTiers; ++t) {
+			const KswClassStat &c = ho->cls[t];
+			cls[t].slot_bytes = std::max<size_t>(16, (size_t)c.slot_bytes), cls[t].tmp_cap = std::max<size_t>(16, (size_t)c.tmp_cap);
+			cls[t].max_ring = std::max(64, (int)c.max_ring), cls[t].max_Q16 = std::max(16, (int)c.max_Q16), cls[t].max_rows = std::max(1, (int)c.max_rows), cls[t].max_ncol = std::max(64, (int)c.max_ncol);
+			cls[t].alg_bytes = (double)c.alg_bytes, cls[t].cells = (double)c.cells;
+			sum_len += (size_t)c.sum_len;
+		}
+		for (int t = 0; t <= kNTiers; ++t) tier_beg[t] = ho->tier_beg[t];
+		last_cells = 0;
+		for (int t = 0; t < kNTiers; ++t) last_cells += cls[t].cells;
+	} else {
 	struct ChunkStat { ClassStat cls[kNTiers]; size_t sum_len = 0; bool too_big = false; };
 	const size_t n_chunks = (n + CH - 1) / CH;
 	bucket.resize(n), perm.resize(n);
@@ -133,57 +105,29 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		const size_t e = std::min(n, ((size_t)c + 1) * CH);
 		for (size_t i = (size_t)c * CH; i < e; ++i) {
 			const KswJob &j = jobs[i];
-			int tier, ring_need = 64;
-			const bool fast = fast_eligible(j, scoring_ok), sfast = splice_fast_eligible(j, splice_ok), xfast = ext_on && ext_eligible(j, scoring_ok);
-			const bool live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
-			const size_t db = !live || (j.flag & KSW_SCORE_ONLY) ? 0 : fast || xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
-			                  sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
-			if (fast) tier = fast_tier(j);
-			else if (xfast) tier = kFirstExt + (j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
-			else if (sfast) {
-				int nc = 0, dc = 0;
-				while (j.qlen > kSpliceMaxQ[nc]) ++nc;
-				while (db > dir_limit(dc)) ++dc;
-				tier = kFirstSplice + nc * kDirClasses + dc;
-			} else {
-				int width = std::min(j.qlen, j.tlen); // widest anti-diagonal
-				if (!splice && j.w >= 0 && j.w + 2 < width) width = j.w + 2;
-				ring_need = pow2ceil((live ? width : 0) + 64);
-				int rc = 0, dc = 0;
-				while (rc < kHbmRing && ring_need > kRingSize[rc]) ++rc;
-				while (db > dir_limit(dc)) ++dc;
-				if (!splice) dc = dc == 0 ? 0 : dc <= 3 ? 3 : dc <= 6 ? 6 : kDirClasses - 1; // banded matrices vary little: 256 KB / 2 MB / 16 MB / any, fewer and fuller launches
-				tier = kFirstExact + rc * kDirClasses + dc;
-			}
-			const double cost = (j.flag & KSWJ_SKIP) ? 0.0 : (double)(j.qlen + j.tlen) * (double)std::min(std::min(j.qlen, j.tlen), j.w < 0 || splice ? INT32_MAX : j.w + 1);
-			int cb = fast && j.tlen <= 512 && j.qlen <= 512 ? (int)(std::sqrt(cost) * 0.25) : (int)(8.0 * std::log2(cost + 1.0)); // small gap fills: cost <= 1024*512; other classes: any (9 % steps)
-			if (sfast) cb = (int)(12.0 * std::log2((double)(j.qlen + j.tlen))); // the two jobs of a wave advance row by row: order by row count (6 % steps)
-			// the streaming kernel computes, row by row, the register sets its jobs in flight reach: jobs of one width class (64-column
-			// sets) together, the widest first; within a class the longest queries first (short ones fill the launch's tail)
-			if (fast && stream_on && stream_sets(tier)) cb = (((j.tlen + 63) / 64 - 1) & 3) * 64 + std::min(63, j.qlen / 8);
-			if (cb >= NB) cb = NB - 1;
-			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - cb));
+			KswClassOut o;
+			ksw_classify(j, cctx, o);
+			const int tier = o.tier;
+			const uint32_t bk = (uint32_t)(tier * NB + (NB - 1 - o.cb));
 			bucket[i] = bk;
 			++hist[bk];
 			// sizing and accounting for the class (query bytes + packed target + job/result records; the 1 B/cell
 			// direction matrix only counts when it cannot stay on chip, i.e. exceeds 160 KB of LDS)
 			ClassStat &cs = st.cls[tier];
 			cs.alg_bytes += sizeof(KswJob) + sizeof(KswRes);
-			if (!live) continue;
+			if (!o.live) continue;
 			cs.alg_bytes += (double)j.qlen + ((j.flag & KSWJ_T_PACKED) ? 0.5 : 1.0) * j.tlen;
 			cs.cells += (double)j.qlen * (double)j.tlen;
-			cs.max_ring = std::max(cs.max_ring, ring_need), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
+			cs.max_ring = std::max(cs.max_ring, o.ring_need), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
 			if (!(j.flag & KSW_SCORE_ONLY)) {
-				if (db > 160 * 1024) cs.alg_bytes += (double)db;
-				cs.slot_bytes = std::max(cs.slot_bytes, db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
-				if (fast || xfast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
+				if (o.db > 160 * 1024) cs.alg_bytes += (double)o.db;
+				cs.slot_bytes = std::max(cs.slot_bytes, o.db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
+				if (o.fast || o.xfast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
 				st.sum_len += (size_t)j.qlen + j.tlen;
 			}
 		}
 		cstat[c] = st;
 	}, 1);
-	size_t sum_len = 0;
-	ClassStat cls[kNTiers];
 	for (const ChunkStat &st : cstat) {
 		sum_len += st.sum_len;
 		for (int t = 0; t < kNTiers; ++t) {
@@ -193,7 +137,6 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			cls[t].max_rows = std::max(cls[t].max_rows, st.cls[t].max_rows), cls[t].max_ncol = std::max(cls[t].max_ncol, st.cls[t].max_ncol);
 		}
 	}
-	size_t tier_beg[kNTiers + 1];
 	{
 		uint32_t acc = 0;
 		for (size_t b = 0; b < NBINS; ++b) {
@@ -209,14 +152,20 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		const size_t e = std::min(n, ((size_t)c + 1) * CH);
 		for (size_t i = (size_t)c * CH; i < e; ++i) { const uint32_t pos = off[bucket[i]]++; perm[i] = pos; sj[pos] = jobs[i]; } // perm[i] = launch position of job i
 	}, 1);
+	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
+	if (resident) { // the consumer on the device finds job i's result through the launch order
+		uint32_t *hp = h_perm.ensure(n);
+		memcpy(hp, perm.data(), n * sizeof(uint32_t));
+		d_perm.ensure(n);
+		HIP_CHECK(hipMemcpyAsync(d_perm.p, hp, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+	}
+	}
 
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
-	d_jobs.ensure(n);
 	d_res.ensure(n);
 	d_counter.ensure(128);
 	static_assert(kNTiers <= 128, "one queue counter per launch class");
 	d_cursor.ensure(2);
-	HIP_CHECK(hipMemcpyAsync(d_jobs.p, sj, n * sizeof(KswJob), hipMemcpyHostToDevice, stream));
 	KswScoring sc_dev = sc; // the junction entries travel with the jobs
 	sc_dev.juncs = nullptr, sc_dev.tbytes = nullptr;
 	if (sc.n_juncs) {
@@ -225,12 +174,6 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		sc_dev.juncs = d_juncs.p;
 	}
 	KswRes *tr = resident ? nullptr : tmp_res.ensure(n);
-	if (resident) { // the consumer on the device finds job i's result through the launch order
-		uint32_t *hp = h_perm.ensure(n);
-		memcpy(hp, perm.data(), n * sizeof(uint32_t));
-		d_perm.ensure(n);
-		HIP_CHECK(hipMemcpyAsync(d_perm.p, hp, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-	}
 
 	// CIGARs are much shorter than qlen+tlen; start with a quarter of the worst case and retry in full on overflow
 	static const int pool_div = getenv("MM2AMD_CIGAR_POOL_DIV") ? std::max(1, atoi(getenv("MM2AMD_CIGAR_POOL_DIV"))) : 0; // tests: a first pool that is too small, so that the retry runs

@@ -4,6 +4,7 @@
 #include <vector>
 #include "hip_util.hpp"
 #include "ksw_dev.hpp"
+#include "ksw_classify.hpp"
 
 namespace mm2amd {
 
@@ -35,10 +36,15 @@ struct KswRunner {
 	{ run_jobs(jobs.data(), jobs.size(), d_qpool, d_tpool, d_S, sc, res, cigar_out, n_cigar_out, stream); }
 	// res == nullptr: the results STAY on the device for a consumer there (region_consume_kernel): d_res in launch order, d_perm[i] = launch
 	// position of job i, the CIGARs in d_cigar; nothing but the pool's cursor comes back.  *n_cigar_out = entries used in d_cigar.
+	// d_jobs_in (with res == nullptr): the n job records are ON THE DEVICE already (region_plan_kernel's): they are classed and ordered there
+	// (ksw_order.hip), `jobs` is not read, and only the per-class sizing figures come to the host.  last_cells = the DP cells of that batch.
 	void run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
-	              const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream);
-	DevBuf<uint32_t> d_perm;
+	              const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream, const KswJob *d_jobs_in = nullptr);
+	DevBuf<uint32_t> d_perm, d_order_work;
 	PinBuf<uint32_t> h_perm;
+	DevBuf<struct KswOrderResult> d_order_out;
+	PinBuf<struct KswOrderResult> h_order_out;
+	double last_cells = 0;
 };
 
 } // namespace mm2amd
