@@ -331,7 +331,7 @@ def main():
     if a.warmup > 0:
         dt = run_steps(range(a.warmup))
         log("rank %d warmup (%d steps): %.3f s  stats=%s" % (rank, a.warmup, dt, {k: round(v, 3) for k, v in al.last_stats().items()}))
-    mm.profile_enable(True)
+    mm.profile_enable(not os.environ.get("MM2AMD_BENCH_NO_PROFILE"))  # (experiments: the timed steps without the per-kernel HIP events; the line then has no roofline)
     import resource
 
     def thread_cpu():

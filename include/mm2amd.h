@@ -169,6 +169,11 @@ int mm_gpu_init_multi(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_
 int mm_gpu_init_index_multi(const mm2amd_index_t *idx, const mm2amd_mapopt_t *opt, int n_threads, int n_gpus, const int *device_ids);
 int mm_gpu_n_replicas(void);                     /* replicas of the live context (0: none) */
 
+/* SURVEY.md 8(b)(2) as written -- the batch call that names its index and options: the device context for (mi, *opt) is built on first use
+ * and rebuilt when either changes (as mm_gpu_map does), then this is mm_gpu_map_batch. */
+int mm_gpu_map_batch_with(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq,
+                          int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
+
 /* Batch-of-one calls with the reference's signatures: mm_gpu_map for mm_map (map.c:380-392, minimap.h:375-376), mm_gpu_map_frag for
  * mm_map_frag (map.c:227-378, minimap.h:378-379; n_segs 1 or 2).  Results as the reference returns them (libc blocks; NULL / 0 when
  * nothing maps or on failure -- mm2amd_last_error() tells which); b, when not NULL, receives rep_len and frag_gap (mm_tbuf_t,

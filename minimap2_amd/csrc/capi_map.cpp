@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -420,6 +421,23 @@ void mm_gpu_batch_discard(void)
 	g_ctx->stage_cv.notify_all();
 }
 
+namespace {
+// MM2AMD_INJECT_BATCH_FAILURE=k (test knob): the k-th mapping call of the process (1-based) fails AFTER its batch has been mapped, the way a device
+// fault reported at the end of a batch would -- the outputs stay untouched, MM2AMD_EHIP comes back, the context stays usable: what the hook's
+// per-batch fallback to the reference's own kt_for(worker_for) relies on (tests/test_gpu_dropin.py).
+bool inject_batch_failure()
+{
+	static const long k = getenv("MM2AMD_INJECT_BATCH_FAILURE") ? atol(getenv("MM2AMD_INJECT_BATCH_FAILURE")) : 0;
+	static std::atomic<long> calls{0};
+	return k > 0 && ++calls == k;
+}
+void free_results(std::vector<ReadResult> &out)
+{
+	for (ReadResult &r : out) { for (Reg &x : r.regs) free(x.p); for (Reg &x : r.regs2) free(x.p); }
+	out.clear();
+}
+}
+
 int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
 	std::shared_lock<std::shared_mutex> lk(g_ctx_mu);
@@ -436,6 +454,7 @@ int mm_gpu_map_staged(int *n_reg, void **reg, int *rep_len, int *frag_gap)
 		const StagedBatch &bt = c.batch[c.cur];
 		std::vector<ReadResult> out;
 		run_replicas(c, bt, out);
+		if (inject_batch_failure()) { free_results(out); throw std::runtime_error("[mm2amd] MM2AMD_INJECT_BATCH_FAILURE: this batch is reported as failed (test knob)"); }
 		hand_over(bt.slots, out, n_reg, reg, rep_len, frag_gap);
 		return 0;
 	} catch (const std::invalid_argument &e) {
@@ -593,6 +612,7 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 		}
 		std::vector<ReadResult> out;
 		run_replicas(c, *bt, out);
+		if (inject_batch_failure()) { free_results(out); throw std::runtime_error("[mm2amd] MM2AMD_INJECT_BATCH_FAILURE: this batch is reported as failed (test knob)"); }
 		hand_over(bt->slots, out, n_reg, reg, rep_len, frag_gap);
 		c.has_current = false; // the views point into the caller's buffers, which this call does not own beyond its return
 		return 0;
@@ -644,6 +664,18 @@ void mm_gpu_map_frag(const void *mi, int n_segs, const int *qlens, const char **
 		return;
 	}
 	if (b) ((TbufView *)b)->rep_len = rep_len[0], ((TbufView *)b)->frag_gap = frag_gap[0];
+}
+
+// SURVEY.md 8(b)(2) as written: the batch call that names its index and options.  The context for (mi, *opt) is built on first use and rebuilt
+// when either changes (as mm_gpu_map does); then this is mm_gpu_map_batch.
+int mm_gpu_map_batch_with(const void *mi, const void *opt, int n_frag, const int *seg_off, const int *n_seg, const void *seq, int *n_reg, void **reg, int *rep_len, int *frag_gap)
+{
+	if (!mi || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch_with: non-null index and options");
+	{
+		std::lock_guard<std::mutex> lk_single(g_single_mu);
+		if (int rc = ensure_context_for(mi, opt)) return rc;
+	}
+	return mm_gpu_map_batch(n_frag, seg_off, n_seg, seq, n_reg, reg, rep_len, frag_gap);
 }
 
 void *mm_gpu_map(const void *mi, int qlen, const char *seq, int *n_regs, void *b, const void *opt, const char *qname)

@@ -39,7 +39,7 @@ typedef struct {
 	const mm_idx_t *mi;
 	const mm_mapopt_t *opt;
 	int64_t batch;
-	int n_processed, failed, one_call;
+	int n_processed, failed, one_call, n_threads;
 } pipeline_t;
 
 typedef struct {
@@ -49,6 +49,30 @@ typedef struct {
 	int *n_reg, *seg_off, *n_seg, *rep_len, *frag_gap;
 	mm_reg1_t **reg;
 } step_t;
+
+/* SURVEY.md 8(b) "error conventions": a mini-batch the GPU dispatcher fails on (its outputs are untouched) is mapped by the reference's own per-read
+ * path -- what kt_for(worker_for) does for single-segment reads (map.c:425-474): mm_map_frag per read with a thread-local buffer. */
+typedef struct { void *km; int rep_len, frag_gap; } tbuf_view_t; /* struct mm_tbuf_s (map.c:24-27): worker_for reads rep_len / frag_gap out of it (map.c:448-449) */
+typedef struct { step_t *s; mm_tbuf_t **buf; } cpu_fallback_t;
+static void cpu_fallback_one(void *data, long i, int tid)
+{
+	cpu_fallback_t *f = (cpu_fallback_t*)data;
+	step_t *s = f->s;
+	const char *seq = s->seq[i].seq;
+	int qlen = s->seq[i].l_seq;
+	mm_map_frag(s->p->mi, 1, &qlen, &seq, &s->n_reg[i], &s->reg[i], f->buf[tid], s->p->opt, s->seq[i].name);
+	s->rep_len[i] = ((tbuf_view_t*)f->buf[tid])->rep_len, s->frag_gap[i] = ((tbuf_view_t*)f->buf[tid])->frag_gap;
+}
+static void cpu_fallback(step_t *s, int n_threads)
+{
+	cpu_fallback_t f;
+	int t;
+	f.s = s, f.buf = (mm_tbuf_t**)calloc(n_threads, sizeof(mm_tbuf_t*));
+	for (t = 0; t < n_threads; ++t) f.buf[t] = mm_tbuf_init();
+	kt_for(n_threads, cpu_fallback_one, &f, s->n_seq);
+	for (t = 0; t < n_threads; ++t) mm_tbuf_destroy(f.buf[t]);
+	free(f.buf);
+}
 
 static void *worker(void *shared, int step, void *in)
 {
@@ -75,8 +99,8 @@ static void *worker(void *shared, int step, void *in)
 		if (p->failed) { if (!p->one_call) mm_gpu_batch_discard(); return s; }
 		if ((p->one_call? mm_gpu_map_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)
 		                : mm_gpu_map_staged(s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)) != 0) {
-			fprintf(stderr, "%s: %s\n", p->one_call? "mm_gpu_map_batch" : "mm_gpu_map_staged", mm2amd_last_error());
-			p->failed = 1;
+			fprintf(stderr, "[WARNING] %s: %s; this mini-batch is mapped by the reference's own path\n", p->one_call? "mm_gpu_map_batch" : "mm_gpu_map_staged", mm2amd_last_error());
+			cpu_fallback(s, p->n_threads);
 		}
 		return s;
 	} else {
@@ -145,7 +169,7 @@ int main(int argc, char *argv[])
 		memset(&pl, 0, sizeof pl);
 		pl.fp = mm_bseq_open(argv[k + 1]);
 		if (pl.fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
-		pl.mi = mi, pl.opt = &mopt, pl.batch = batch, pl.one_call = one_call;
+		pl.mi = mi, pl.opt = &mopt, pl.batch = batch, pl.one_call = one_call, pl.n_threads = n_threads;
 		kt_pipeline(3, worker, &pl, 3); /* map.c:669: pl_threads = n_threads == 1 ? 1 : 3 (2 with --2-io-threads off) */
 		rc |= pl.failed;
 		mm_bseq_close(pl.fp);

@@ -323,3 +323,18 @@ def test_three_step_pipeline_driver_identical(tmp_path):
     got, err = _run([os.path.join(HERE, "_build", "dropin_pipeline_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_pipeline_gpu"), "-x", "map-ont", "-a", "-t", "8", "-K", "300k", ref, reads])
     assert err.count("[M::worker_pipeline::") >= 3
     assert got == want
+
+
+def test_failed_batch_falls_back_to_the_reference_path(tmp_path):
+    """SURVEY.md 8(b) "error conventions": a mini-batch the dispatcher fails on leaves its outputs untouched, and the hook maps it with the reference's
+    own per-read path (tests/dropin/dropin_pipeline.c: kt_for over mm_map_frag).  MM2AMD_INJECT_BATCH_FAILURE=2 makes the
+    second mapping call of the process report a failure after its batch was mapped: the stream must still equal the reference's, and the
+    batches after it must map on the GPU again."""
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 2, 60, 21)
+    pipe = os.path.join(HERE, "_build", "dropin_pipeline_emu" if EMU else "dropin_pipeline_gpu")
+    want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "4", "-a", ref, reads])
+    p = subprocess.run([pipe, "-x", "map-ont", "-t", "4", "-a", "-K", "100k", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, MM2AMD_INJECT_BATCH_FAILURE="2"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stderr.decode().count("mapped by the reference's own path") == 1
+    assert b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")) == want
