@@ -58,6 +58,9 @@ inline void stream_wait(hipStream_t s)
 		slot->dev = dev;
 	}
 	HIP_CHECK(hipEventRecord(slot->ev, s));
+	// (round 5: the sleeps grow to 500 us -- MM2AMD_WAIT_MAX_US -- instead of 200: a lane waits 300-400 ms per sub-batch in half a dozen waits, and eight
+	// lanes polling at 5 kHz were a measurable share of the lane threads' CPU seconds; half a millisecond late on a wait of tens of milliseconds is noise)
+	static const long max_ns = [] { const char *e = getenv("MM2AMD_WAIT_MAX_US"); const long us = e ? atol(e) : 500; return (us < 20 ? 20 : us) * 1000L; }();
 	long ns = 20000;
 	for (int it = 0;; ++it) {
 		const hipError_t e = hipEventQuery(slot->ev);
@@ -66,7 +69,7 @@ inline void stream_wait(hipStream_t s)
 		if (it < 4) continue; // (work that is all but done: a few queries back to back)
 		timespec ts = { 0, ns };
 		nanosleep(&ts, nullptr);
-		if (ns < 200000) ns += ns / 2;
+		if (ns < max_ns) ns += ns / 2;
 	}
 }
 

@@ -5,6 +5,7 @@
 #include <cstring>
 #include "hits.hpp"
 #include "chain_host.hpp"
+#include "hit_rules.hpp"
 
 namespace mm2amd {
 
@@ -24,12 +25,7 @@ uint64_t mix64_full(uint64_t key) // hit.c:40-50 (unmasked variant of the sketch
 
 inline int span_of(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
 
-int alt_score(int score, float alt_diff_frac) // hit.c:99-104
-{
-	if (score < 0) return score;
-	score = (int)(score * (1.0 - alt_diff_frac) + .499);
-	return score > 0 ? score : 1;
-}
+inline int alt_score(int score, float alt_diff_frac) { return hr_alt_score(score, alt_diff_frac); }
 
 } // namespace
 
@@ -104,62 +100,10 @@ void set_parent(float mask_level, int mask_len, RegVec &r, int sub_diff, bool ha
 {
 	const int n = (int)r.size();
 	if (n <= 0) return;
-	for (int i = 0; i < n; ++i) r[i].id = i;
-	std::vector<uint64_t> cov(n);
-	std::vector<int> prim(n); // indices of hits that are primary so far
-	int n_prim = 1;
-	prim[0] = 0, r[0].parent = 0;
-	for (int i = 1; i < n; ++i) {
-		Reg &ri = r[i];
-		const int si = ri.qs, ei = ri.qe;
-		int n_cov = 0, uncov_len = 0, j = 0;
-		bool scan = true;
-		if (!hard_mask_level) {
-			for (j = 0; j < n_prim; ++j) { // query intervals of primaries overlapping hit i, clipped to it
-				const Reg &rp = r[prim[j]];
-				int sj = rp.qs, ej = rp.qe;
-				if (ej <= si || sj >= ei) continue;
-				if (sj < si) sj = si;
-				if (ej > ei) ej = ei;
-				cov[n_cov++] = (uint64_t)sj << 32 | (uint32_t)ej;
-			}
-			if (n_cov == 0) scan = false, j = n_prim; // overlaps nothing: a new primary
-			else {
-				int x = si;
-				sort_u64(cov.data(), cov.data() + n_cov);
-				for (int c = 0; c < n_cov; ++c) {
-					if ((int)(cov[c] >> 32) > x) uncov_len += (int)(cov[c] >> 32) - x;
-					x = (int32_t)cov[c] > x ? (int32_t)cov[c] : x;
-				}
-				if (ei > x) uncov_len += ei - x;
-			}
-		}
-		if (scan) {
-			for (j = 0; j < n_prim; ++j) {
-				Reg &rp = r[prim[j]];
-				const int sj = rp.qs, ej = rp.qe;
-				if (ej <= si || sj >= ei) continue;
-				const int mn = ej - sj < ei - si ? ej - sj : ei - si, mx = ej - sj > ei - si ? ej - sj : ei - si;
-				const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
-				if ((float)ol / mn - (float)uncov_len / mx > mask_level && uncov_len <= mask_len) { // hit i is secondary to rp
-					int cnt_sub = 0, sci = ri.score;
-					ri.parent = rp.parent;
-					if (!rp.is_alt && ri.is_alt) sci = alt_score(sci, alt_diff_frac);
-					rp.subsc = rp.subsc > sci ? rp.subsc : sci;
-					if (ri.cnt >= rp.cnt) cnt_sub = 1;
-					if (rp.p && ri.p && (rp.rid != ri.rid || rp.rs != ri.rs || rp.re != ri.re || ol != mn)) {
-						sci = ri.p->dp_max;
-						if (!rp.is_alt && ri.is_alt) sci = alt_score(sci, alt_diff_frac);
-						rp.p->dp_max2 = rp.p->dp_max2 > sci ? rp.p->dp_max2 : sci;
-						if (rp.p->dp_max - ri.p->dp_max <= sub_diff) cnt_sub = 1;
-					}
-					if (cnt_sub) ++rp.n_sub;
-					break;
-				}
-			}
-		}
-		if (j == n_prim) prim[n_prim++] = i, ri.parent = i, ri.n_sub = 0;
-	}
+	thread_local std::vector<uint64_t> cov;
+	thread_local std::vector<int32_t> prim;
+	cov.resize(n), prim.resize(n);
+	hr_mark_parents(r.data(), n, cov.data(), prim.data(), mask_level, mask_len, sub_diff, hard_mask_level, alt_diff_frac); // hit_rules.hpp: the device kernel's formulation
 }
 
 void hit_sort(RegVec &r, float alt_diff_frac)
@@ -189,14 +133,7 @@ void hit_sort(RegVec &r, float alt_diff_frac)
 	r.swap(t);
 }
 
-int set_sam_pri(RegVec &r)
-{
-	int n_pri = 0;
-	for (Reg &x : r)
-		if (x.id == x.parent) { ++n_pri; x.sam_pri = (n_pri == 1); }
-		else x.sam_pri = 0;
-	return n_pri;
-}
+int set_sam_pri(RegVec &r) { return hr_mark_sam_primary(r.data(), (int)r.size()); }
 
 void sync_regs(RegVec &r)
 {
@@ -204,38 +141,21 @@ void sync_regs(RegVec &r)
 	if (n <= 0) return;
 	int max_id = -1;
 	for (const Reg &x : r) max_id = max_id > x.id ? max_id : x.id;
-	std::vector<int> where(max_id + 1, -1);
-	for (int i = 0; i < n; ++i)
-		if (r[i].id >= 0) where[r[i].id] = i;
-	for (int i = 0; i < n; ++i) {
-		Reg &x = r[i];
-		x.id = i;
-		if (x.parent == ref::PARENT_TMP_PRI) x.parent = i;
-		else if (x.parent >= 0 && where[x.parent] >= 0) x.parent = where[x.parent];
-		else x.parent = ref::PARENT_UNSET;
-	}
-	set_sam_pri(r);
+	thread_local std::vector<int32_t> where;
+	where.resize((size_t)max_id + 1);
+	hr_renumber(r.data(), n, where.data(), max_id + 1);
 }
 
 void select_sub(float pri_ratio, int min_diff, int best_n, bool check_strand, int min_strand_sc, RegVec &r)
 {
 	if (!(pri_ratio > 0.0f) || r.empty()) return;
 	const int n = (int)r.size();
-	int n_2nd = 0, k = 0;
-	std::vector<uint8_t> keep(n, 0);
+	thread_local std::vector<uint8_t> keep;
+	keep.resize(n);
+	hr_select_secondaries(r.data(), n, keep.data(), pri_ratio, min_diff, best_n, check_strand, min_strand_sc);
+	int k = 0;
 	for (int i = 0; i < n; ++i) {
-		const int p = r[i].parent;
-		if (p == i || r[i].inv) keep[i] = 1;
-		else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
-			if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re))
-				keep[i] = 1, ++n_2nd;
-		} else if (check_strand && n_2nd < best_n && r[i].score > min_strand_sc && r[i].rev != r[p].rev) {
-			r[i].strand_retained = 1;
-			keep[i] = 1, ++n_2nd;
-		}
-	}
-	for (int i = 0; i < n; ++i) {
-		if (keep[i]) r[k++] = r[i];
+		if (keep[i]) { if (k < i) r[k] = r[i]; ++k; }
 		else if (r[i].p) free(r[i].p);
 	}
 	r.resize(k);
@@ -353,15 +273,6 @@ void set_mapq(RegVec &regs, int min_chain_sc, int match_sc, int rep_len, bool is
 	}
 }
 
-namespace {
-inline int32_t fwd_qpos(int32_t qlen, const Anchor &a) // esterr.c:7-14
-{
-	int32_t x = (int32_t)a.y;
-	if (a.x >> 63) x = qlen - 1 - (x + 1 - span_of(a));
-	return x;
-}
-}
-
 void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const uint64_t *mini_pos, int32_t n_mini_pos)
 {
 	const int32_t n = n_mini_pos;
@@ -370,28 +281,13 @@ void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const
 	if (!(fi.flag & ref::I_HPC) && (uint64_t)n * (uint64_t)fi.k < (1u << 24)) sum_k = (uint64_t)n * (uint64_t)fi.k; // every span is k: the float quotient below is exactly k
 	else for (int32_t i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
 	const float avg_k = (float)sum_k / n;
-	for (Reg &r : regs) {
+	for (Reg &r : regs) { // per hit: the counts by hit_rules.hpp (the device kernel's formulation: one search per anchor), libm's pow here
 		r.div = -1.0f;
 		if (r.cnt == 0) continue;
-		// locate the hit's first minimizer (in read order) in mini_pos by binary search
-		const int32_t x0 = fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1] : a[r.as]);
-		int32_t L = 0, R = n - 1, st = -1;
-		while (L <= R) {
-			const int32_t m = (int32_t)(((uint64_t)L + R) >> 1), y = (int32_t)mini_pos[m];
-			if (y < x0) L = m + 1;
-			else if (y > x0) R = m - 1;
-			else { st = m; break; }
-		}
+		const int st = hr_first_minimizer(mini_pos, n, hr_chain_qpos(r, a, qlen, 0));
 		if (st < 0) continue;
-		int32_t en = st, n_match = 1, k = 1;
-		const int32_t l_ref = (int32_t)fi.seq_len[r.rid];
-		for (int32_t j = st + 1; j < n && k < r.cnt; ++j) {
-			const int32_t x = fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k]);
-			if (x == (int32_t)mini_pos[j]) ++k, en = j, ++n_match;
-		}
-		int32_t n_tot = en - st + 1;
-		if (r.qs > avg_k && r.rs > avg_k) ++n_tot;
-		if (qlen - r.qs > avg_k && l_ref - r.re > avg_k) ++n_tot;
+		int32_t n_match, n_tot;
+		hr_est_err_totals(r, a, qlen, mini_pos, n, st, hr_first_miss(r, a, qlen, mini_pos, n, st, 1, 1), avg_k, (int32_t)fi.seq_len[r.rid], &n_match, &n_tot);
 		r.div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
 	}
 }

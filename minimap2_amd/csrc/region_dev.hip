@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "region_dev.hpp"
+#include "hit_rules.hpp"
 
 namespace mm2amd {
 
@@ -45,133 +46,12 @@ __device__ __forceinline__ int rg_wave_min(int v)
 	return v;
 }
 
-// position of an anchor's k-mer on the read as given (esterr.c:7-14)
-__device__ __forceinline__ int32_t rg_fwd_qpos(int32_t qlen, const Anchor &a)
-{
-	int32_t x = rg_y(a);
-	if (a.x >> 63) x = qlen - 1 - (x + 1 - rg_span(a));
-	return x;
-}
-
-// ---- the hit-record rules of hit.c, on records held in LDS (one lane walks: tens of records, each step depends on the one before) ----
-
-// Which hits are secondary to which (hit.c:125-186).  Hit i (in score order) is tested against the hits that are primary so far: the part of
-// its query interval no primary covers, then the first primary it overlaps by more than mask_level of the shorter of the two.
-__device__ void rg_mark_parents(Reg1 *r, int n, uint64_t *cov, int16_t *prim, const RgnOpts &O, bool with_dp, const int32_t *dp_max, int32_t *dp_max2)
-{
-	if (n <= 0) return;
-	const bool hard = (O.flag & ref::F_HARD_MLEVEL) != 0;
-	for (int i = 0; i < n; ++i) r[i].id = i;
-	int n_prim = 1;
-	prim[0] = 0, r[0].parent = 0;
-	for (int i = 1; i < n; ++i) {
-		const int si = r[i].qs, ei = r[i].qe, len_i = ei - si;
-		int uncov = 0;
-		bool touches = hard; // (with a hard mask level the uncovered length stays 0 and every primary is tested)
-		if (!hard) {
-			int n_cov = 0;
-			for (int j = 0; j < n_prim; ++j) {
-				int sj = r[prim[j]].qs, ej = r[prim[j]].qe;
-				if (ej <= si || sj >= ei) continue;
-				sj = sj < si ? si : sj, ej = ej > ei ? ei : ej;
-				// insertion into the sorted list of clipped intervals (the reference sorts them with radix_sort_64: plain integers, any sort gives the same list)
-				const uint64_t v = (uint64_t)sj << 32 | (uint32_t)ej;
-				int p = n_cov++;
-				while (p > 0 && cov[p - 1] > v) cov[p] = cov[p - 1], --p;
-				cov[p] = v;
-			}
-			if (n_cov > 0) {
-				touches = true;
-				int x = si;
-				for (int c = 0; c < n_cov; ++c) {
-					const int cs = (int)(cov[c] >> 32), ce = (int32_t)cov[c];
-					if (cs > x) uncov += cs - x;
-					x = ce > x ? ce : x;
-				}
-				if (ei > x) uncov += ei - x;
-			}
-		}
-		int owner = -1;
-		if (touches)
-			for (int j = 0; j < n_prim && owner < 0; ++j) {
-				const Reg1 &rp = r[prim[j]];
-				const int sj = rp.qs, ej = rp.qe, len_j = ej - sj;
-				if (ej <= si || sj >= ei) continue;
-				const int mn = len_j < len_i ? len_j : len_i, mx = len_j > len_i ? len_j : len_i;
-				const int lo = si > sj ? si : sj, hi = ei < ej ? ei : ej, ol = hi > lo ? hi - lo : 0;
-				if ((float)ol / mn - (float)uncov / mx > O.mask_level && uncov <= O.mask_len) owner = j;
-			}
-		if (owner < 0) { prim[n_prim++] = (int16_t)i, r[i].parent = i, r[i].n_sub = 0; continue; }
-		const int pi = prim[owner];
-		Reg1 &rp = r[pi];
-		const int sj = rp.qs, ej = rp.qe, len_j = ej - sj;
-		const int mn = len_j < len_i ? len_j : len_i;
-		const int lo = si > sj ? si : sj, hi = ei < ej ? ei : ej, ol = hi > lo ? hi - lo : 0;
-		int sci = r[i].score; // (no ALT contigs on this path: mm_alt_score never applies)
-		bool counts = r[i].cnt >= rp.cnt;
-		r[i].parent = rp.parent;
-		rp.subsc = rp.subsc > sci ? rp.subsc : sci;
-		if (with_dp && (rp.rid != r[i].rid || rp.rs != r[i].rs || rp.re != r[i].re || ol != mn)) { // both aligned, and not the same alignment found twice
-			sci = dp_max[i];
-			dp_max2[pi] = dp_max2[pi] > sci ? dp_max2[pi] : sci;
-			if (dp_max[pi] - dp_max[i] <= O.sub_diff) counts = true;
-		}
-		if (counts) ++rp.n_sub;
-	}
-}
-
-// ids follow positions after a compaction; parents that were dropped leave orphans (mm_sync_regs, hit.c:231-253, with mm_set_sam_pri)
-__device__ void rg_renumber(Reg1 *r, int n, int16_t *where, int where_n)
-{
-	for (int i = 0; i < where_n; ++i) where[i] = -1;
-	for (int i = 0; i < n; ++i) if (r[i].id >= 0) where[r[i].id] = (int16_t)i;
-	int n_pri = 0;
-	for (int i = 0; i < n; ++i) {
-		Reg1 &x = r[i];
-		x.id = i;
-		if (x.parent == ref::PARENT_TMP_PRI) x.parent = i;
-		else if (x.parent >= 0 && where[x.parent] >= 0) x.parent = where[x.parent];
-		else x.parent = ref::PARENT_UNSET;
-	}
-	for (int i = 0; i < n; ++i) {
-		if (r[i].id == r[i].parent) { ++n_pri; r[i].sam_pri = n_pri == 1; }
-		else r[i].sam_pri = 0;
-	}
-}
-
-// Which secondaries are kept (mm_select_sub, hit.c:255-281).  Returns the new count; `aux` (per-hit side values) is compacted alongside.
-__device__ int rg_select_secondaries(Reg1 *r, int n, int16_t *where, bool check_strand, const RgnOpts &O, int32_t *aux0, int32_t *aux1)
-{
-	if (!(O.pri_ratio > 0.0f) || n <= 0) return n;
-	int n_2nd = 0, k = 0;
-	for (int i = 0; i < n; ++i) { // decisions first (`where` holds them): a hit is compared with its parent where the parent still is
-		const int p = r[i].parent;
-		bool keep = false;
-		if (p == i || r[i].inv) keep = true;
-		else if ((r[i].score >= r[p].score * O.pri_ratio || r[i].score + O.k * 2 >= r[p].score) && n_2nd < O.best_n) {
-			const bool same = r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re;
-			if (!same) keep = true, ++n_2nd; // (an identical hit found twice is dropped)
-		} else if (check_strand && n_2nd < O.best_n && r[i].score > O.min_strand_sc && r[i].rev != r[p].rev) {
-			r[i].strand_retained = 1;
-			keep = true, ++n_2nd;
-		}
-		where[i] = keep ? 1 : 0;
-	}
-	for (int i = 0; i < n; ++i)
-		if (where[i]) {
-			if (k < i) { r[k] = r[i]; if (aux0) aux0[k] = aux0[i]; if (aux1) aux1[k] = aux1[i]; }
-			++k;
-		}
-	if (k != n) rg_renumber(r, k, where, n);
-	return k;
-}
-
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // chain_regs_kernel
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// LDS per read (C = lds_chains): hit records 80 C, sort keys 8 C, interval list 8 C, chain starts / order / primaries / id map 4 x 2..4 C
+// LDS per read (C = lds_chains): hit records 80 C, sort keys 8 C, interval list 8 C, five 32-bit arrays, the order and the keep flags: 119 C bytes
 __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 {
 	MM2_DYN_LDS(uint64_t, s_raw);
@@ -181,8 +61,9 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	uint64_t *s_cov = s_key + C;                       // C clipped intervals
 	int32_t *s_start = (int32_t *)(s_cov + C);         // C chain starts (in the read's chained anchors), later the squeezed starts
 	int32_t *s_nm = s_start + C, *s_nt = s_nm + C;     // C + C: mm_est_err's counts
-	int16_t *s_ord = (int16_t *)(s_nt + C);            // C: chain at each rank
-	int16_t *s_prim = s_ord + C, *s_where = s_prim + C;
+	int32_t *s_prim = s_nt + C, *s_where = s_prim + C; // C + C: the primaries so far; the id map of a compaction
+	int16_t *s_ord = (int16_t *)(s_where + C);         // C: chain at each rank
+	uint8_t *s_keep = (uint8_t *)(s_ord + C);          // C
 	__shared__ int32_t s_hdr[4];
 
 	const RgnRead rd = B.reads[rd_i];
@@ -263,8 +144,13 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	if (lane == 0) {
 		int m = n;
 		if (!(O.flag & ref::F_ALL_CHAINS)) {
-			rg_mark_parents(s_reg, n, s_cov, s_prim, O, false, nullptr, nullptr);
-			m = rg_select_secondaries(s_reg, n, s_where, true, O, nullptr, nullptr);
+			hr_mark_parents(s_reg, n, s_cov, s_prim, O.mask_level, O.mask_len, O.sub_diff, (O.flag & ref::F_HARD_MLEVEL) != 0, 0.0f);
+			if (O.pri_ratio > 0.0f) {
+				hr_select_secondaries(s_reg, n, s_keep, O.pri_ratio, O.k * 2, O.best_n, true, O.min_strand_sc);
+				m = 0;
+				for (int i = 0; i < n; ++i) if (s_keep[i]) { if (m < i) s_reg[m] = s_reg[i]; ++m; }
+				if (m != n) hr_renumber(s_reg, m, s_where, n);
+			}
 		}
 		int retained = 0;
 		for (int p = 0; p < m; ++p) retained |= s_reg[p].strand_retained;
@@ -287,34 +173,10 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 		const Reg1 r = s_reg[p];
 		int n_match = 0, n_tot = -1;
 		if (n_mp > 0 && r.cnt > 0) {
-			const int32_t x0 = rg_fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1] : a[r.as]);
-			int32_t L = 0, R = n_mp - 1, st = -1;
-			while (L <= R) { // (the reference's own search: with distinct positions any search finds the same entry)
-				const int32_t mid = (int32_t)(((uint64_t)L + R) >> 1), y = (int32_t)mp[mid];
-				if (y < x0) L = mid + 1;
-				else if (y > x0) R = mid - 1;
-				else { st = mid; break; }
-			}
+			const int st = hr_first_minimizer(mp, n_mp, hr_chain_qpos(r, a, qlen, 0));
 			if (st >= 0) {
-				int kfail = r.cnt;
-				for (int k = 1 + lane; k < r.cnt; k += 64) {
-					const int32_t x = rg_fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k]);
-					int lo = st + 1, hi = n_mp; // first entry at a position >= x
-					while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int32_t)mp[mid] < x) lo = mid + 1; else hi = mid; }
-					if (!(lo < n_mp && (int32_t)mp[lo] == x)) kfail = kfail < k ? kfail : k;
-				}
-				kfail = rg_wave_min(kfail);
-				n_match = kfail; // the first anchor and anchors 1 .. kfail - 1
-				int en = st;
-				if (kfail > 1) {
-					const int32_t x = rg_fwd_qpos(qlen, r.rev ? a[r.as + r.cnt - kfail] : a[r.as + kfail - 1]);
-					int lo = st + 1, hi = n_mp;
-					while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int32_t)mp[mid] < x) lo = mid + 1; else hi = mid; }
-					en = lo;
-				}
-				n_tot = en - st + 1;
-				if (r.qs > avg_k && r.rs > avg_k) ++n_tot;
-				if (qlen - r.qs > avg_k && (int32_t)B.ref_len[r.rid] - r.re > avg_k) ++n_tot;
+				const int kfail = rg_wave_min(hr_first_miss(r, a, qlen, mp, n_mp, st, 1 + lane, 64));
+				hr_est_err_totals(r, a, qlen, mp, n_mp, st, kfail, avg_k, (int32_t)B.ref_len[r.rid], &n_match, &n_tot);
 			}
 		}
 		if (lane == 0) s_nm[p] = n_match, s_nt[p] = n_tot;
@@ -732,7 +594,7 @@ void launch_chain_regs(const RgnBuffers &B, const RgnOpts &O, void *stream)
 {
 	if (B.n_reads <= 0) return;
 	const size_t C = (size_t)B.lds_chains;
-	const size_t lds = C * (80 + 8 + 8 + 4 * 3 + 2 * 3) + 64;
+	const size_t lds = C * (80 + 8 + 8 + 4 * 5 + 2 + 1) + 64;
 	hipLaunchKernelGGL(chain_regs_kernel, dim3(B.n_reads), dim3(64), lds, (hipStream_t)stream, B, O);
 	HIP_CHECK(hipGetLastError());
 }
