@@ -12,6 +12,47 @@ namespace mm2amd {
 
 MM2_HD inline int hr_span(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
 
+MM2_HD inline uint64_t hr_mix64(uint64_t key) // hash64 of hit.c:40-50 (the invertible integer hash without a mask)
+{
+	key = (~key + (key << 21));
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4));
+	key = key ^ key >> 28;
+	key = (key + (key << 31));
+	return key;
+}
+// sort key of a chain among its read's chains (mm_gen_regs, hit.c:60-66): the chain record (score << 32 | anchors) with its low word scrambled by
+// a hash of the chain's first anchor and the read's own hash -- equal scores come in an order that differs from read to read
+MM2_HD inline uint64_t hr_chain_key(uint64_t u, const Anchor &first, uint32_t read_hash) { return u ^ (uint32_t)hr_mix64((hr_mix64(first.x) + hr_mix64(first.y)) ^ read_hash); }
+
+// a new hit record for the chain of `cnt` anchors that starts at anchor `as` (hit.c:68-86 with mm_reg_set_coor, :24-38); fuzzy lengths not yet set
+MM2_HD inline void hr_new_hit(ref::Reg1 &r, int id, uint64_t key, int32_t as, int32_t cnt, int32_t qlen, const Anchor *a, bool is_qstrand)
+{
+	__builtin_memset(&r, 0, sizeof r);
+	r.id = id, r.parent = ref::PARENT_UNSET;
+	r.score = r.score0 = (int32_t)(key >> 32);
+	r.hash = (uint32_t)key;
+	r.cnt = cnt, r.as = as;
+	r.div = -1.0f;
+	const Anchor f = a[as], l = a[as + cnt - 1];
+	const int span = hr_span(f);
+	r.rev = f.x >> 63;
+	r.rid = (int32_t)(f.x << 1 >> 33);
+	r.rs = (int32_t)f.x + 1 > span ? (int32_t)f.x + 1 - span : 0;
+	r.re = (int32_t)l.x + 1;
+	if (!r.rev || is_qstrand) r.qs = (int32_t)f.y + 1 - span, r.qe = (int32_t)l.y + 1;
+	else r.qs = qlen - ((int32_t)l.y + 1), r.qe = qlen - ((int32_t)f.y + 1 - span);
+}
+// what one pair of consecutive anchors adds to a chain's fuzzy block / match lengths (mm_cal_fuzzy_len, hit.c:5-22); the first anchor adds its span to both
+MM2_HD inline void hr_fuzzy_step(const Anchor &cur, const Anchor &prev, int *bl, int *ml)
+{
+	const int span = hr_span(cur), tl = (int32_t)cur.x - (int32_t)prev.x, ql = (int32_t)cur.y - (int32_t)prev.y;
+	*bl += tl > ql ? tl : ql;
+	*ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
+}
+
 // a hit on an ALT contig competes with a handicap (mm_alt_score, hit.c:99-104)
 MM2_HD inline int hr_alt_score(int score, float alt_diff_frac)
 {

@@ -11,73 +11,37 @@ namespace mm2amd {
 
 namespace {
 
-uint64_t mix64_full(uint64_t key) // hit.c:40-50 (unmasked variant of the sketch hash)
-{
-	key = (~key + (key << 21));
-	key = key ^ key >> 24;
-	key = ((key + (key << 3)) + (key << 8));
-	key = key ^ key >> 14;
-	key = ((key + (key << 2)) + (key << 4));
-	key = key ^ key >> 28;
-	key = (key + (key << 31));
-	return key;
-}
-
 inline int span_of(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
 
 inline int alt_score(int score, float alt_diff_frac) { return hr_alt_score(score, alt_diff_frac); }
 
 } // namespace
 
+// coordinates and fuzzy lengths of a hit from its anchors [as, as + cnt) (mm_reg_set_coor, hit.c:24-38): hit_rules.hpp's pieces, every other field kept
 void reg_set_coor(Reg &r, int32_t qlen, const Anchor *a, bool is_qstrand)
 {
-	const int32_t k = r.as, q_span = span_of(a[k]);
-	r.rev = a[k].x >> 63;
-	r.rid = (int32_t)(a[k].x << 1 >> 33);
-	r.rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
-	r.re = (int32_t)a[k + r.cnt - 1].x + 1;
-	if (!r.rev || is_qstrand) {
-		r.qs = (int32_t)a[k].y + 1 - q_span;
-		r.qe = (int32_t)a[k + r.cnt - 1].y + 1;
-	} else {
-		r.qs = qlen - ((int32_t)a[k + r.cnt - 1].y + 1);
-		r.qe = qlen - ((int32_t)a[k].y + 1 - q_span);
-	}
-	// fuzzy matching/block lengths from anchor spacing (hit.c:8-22)
-	r.mlen = r.blen = 0;
-	if (r.cnt <= 0) return;
-	r.mlen = r.blen = span_of(a[r.as]);
-	for (int i = r.as + 1; i < r.as + r.cnt; ++i) {
-		const int span = span_of(a[i]);
-		const int tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-		r.blen += tl > ql ? tl : ql;
-		r.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
-	}
+	Reg t;
+	hr_new_hit(t, r.id, 0, r.as, r.cnt, qlen, a, is_qstrand);
+	r.rev = t.rev, r.rid = t.rid, r.rs = t.rs, r.re = t.re, r.qs = t.qs, r.qe = t.qe;
+	int bl = span_of(a[r.as]), ml = bl;
+	for (int i = r.as + 1; i < r.as + r.cnt; ++i) hr_fuzzy_step(a[i], a[i - 1], &bl, &ml);
+	r.blen = bl, r.mlen = ml;
 }
 
+// the read's chains as hit records, best first (mm_gen_regs, hit.c:52-88).  Equal keys are ordered by the reference's unstable sort, replayed here
+// (the device path hands such reads back for exactly that)
 void gen_regs(uint32_t hash, int qlen, const uint64_t *u, int n_u, const Anchor *a, bool is_qstrand, RegVec &out)
 {
 	out.clear();
 	if (n_u <= 0) return;
-	std::vector<Anchor> z(n_u);
-	for (int i = 0, k = 0; i < n_u; ++i) { // sort key: chain score, ties broken by a per-read hash of the first anchor
-		const uint32_t h = (uint32_t)mix64_full((mix64_full(a[k].x) + mix64_full(a[k].y)) ^ hash);
-		z[i].x = u[i] ^ h;
-		z[i].y = (uint64_t)k << 32 | (uint32_t)u[i];
-		k += (int32_t)u[i];
-	}
+	std::vector<Anchor> z(n_u); // x: the sort key; y: first anchor << 32 | anchors
+	for (int i = 0, k = 0; i < n_u; k += (int32_t)u[i], ++i) z[i].x = hr_chain_key(u[i], a[k], hash), z[i].y = (uint64_t)k << 32 | (uint32_t)u[i];
 	sort_by_x(z.data(), z.data() + n_u);
-	std::reverse(z.begin(), z.end());
 	out.resize(n_u);
-	for (int i = 0; i < n_u; ++i) {
-		Reg &r = out[i];
-		memset(&r, 0, sizeof(Reg));
-		r.id = i, r.parent = ref::PARENT_UNSET;
-		r.score = r.score0 = (int32_t)(z[i].x >> 32);
-		r.hash = (uint32_t)z[i].x;
-		r.cnt = (int32_t)z[i].y, r.as = (int32_t)(z[i].y >> 32);
-		r.div = -1.0f;
-		reg_set_coor(r, qlen, a, is_qstrand);
+	for (int i = 0; i < n_u; ++i) { // descending
+		const Anchor &c = z[n_u - 1 - i];
+		hr_new_hit(out[i], i, c.x, (int32_t)(c.y >> 32), (int32_t)c.y, qlen, a, is_qstrand);
+		reg_set_coor(out[i], qlen, a, is_qstrand);
 	}
 }
 

@@ -15,17 +15,6 @@ namespace {
 
 using ref::Reg1;
 
-__device__ __forceinline__ uint64_t rg_mix64(uint64_t key) // hash64 of hit.c:40-50 (the invertible integer hash without a mask)
-{
-	key = (~key + (key << 21));
-	key = key ^ key >> 24;
-	key = ((key + (key << 3)) + (key << 8));
-	key = key ^ key >> 14;
-	key = ((key + (key << 2)) + (key << 4));
-	key = key ^ key >> 28;
-	key = (key + (key << 31));
-	return key;
-}
 __device__ __forceinline__ int rg_span(const Anchor &a) { return (int)(a.y >> 32 & 0xff); }
 __device__ __forceinline__ int32_t rg_x(const Anchor &a) { return (int32_t)a.x; }
 __device__ __forceinline__ int32_t rg_y(const Anchor &a) { return (int32_t)a.y; }
@@ -85,9 +74,7 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	RG_SYNC();
 	// sort key of mm_gen_regs (hit.c:60-66): the chain record with its low word scrambled by a hash of the first anchor and the read
 	for (int i = lane; i < n; i += 64) {
-		const Anchor f = a[s_start[i]];
-		const uint32_t h = (uint32_t)rg_mix64((rg_mix64(f.x) + rg_mix64(f.y)) ^ rd.hash);
-		s_key[i] = u[i] ^ h;
+		s_key[i] = hr_chain_key(u[i], a[s_start[i]], rd.hash);
 	}
 	RG_SYNC();
 	// descending order by counting; equal keys (2^-32 per pair of equal scores) are ordered by the reference's unstable sort: the host replays it
@@ -106,23 +93,9 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	RG_SYNC();
 	// the hit records (hit.c:68-86 with mm_reg_set_coor, :24-38)
 	for (int p = lane; p < n; p += 64) {
-		const int c = s_ord[p], st = s_start[c];
-		const uint64_t key = s_key[c];
+		const int c = s_ord[p];
 		Reg1 r;
-		__builtin_memset(&r, 0, sizeof r);
-		r.id = p, r.parent = ref::PARENT_UNSET;
-		r.score = r.score0 = (int32_t)(key >> 32);
-		r.hash = (uint32_t)key;
-		r.cnt = (int32_t)u[c], r.as = st;
-		r.div = -1.0f;
-		const Anchor f = a[st], l = a[st + r.cnt - 1];
-		const int span = rg_span(f);
-		r.rev = f.x >> 63;
-		r.rid = (int32_t)(f.x << 1 >> 33);
-		r.rs = rg_x(f) + 1 > span ? rg_x(f) + 1 - span : 0;
-		r.re = rg_x(l) + 1;
-		if (!r.rev) r.qs = rg_y(f) + 1 - span, r.qe = rg_y(l) + 1;
-		else r.qs = qlen - (rg_y(l) + 1), r.qe = qlen - (rg_y(f) + 1 - span);
+		hr_new_hit(r, p, s_key[c], s_start[c], (int32_t)u[c], qlen, a, false);
 		s_reg[p] = r;
 	}
 	RG_SYNC();
@@ -130,12 +103,7 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	for (int p = 0; p < n; ++p) {
 		const int st = s_reg[p].as, cnt = s_reg[p].cnt;
 		int ml = 0, bl = 0;
-		for (int i = 1 + lane; i < cnt; i += 64) {
-			const Anchor c = a[st + i], b = a[st + i - 1];
-			const int span = rg_span(c), tl = rg_x(c) - rg_x(b), ql = rg_y(c) - rg_y(b);
-			bl += tl > ql ? tl : ql;
-			ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
-		}
+		for (int i = 1 + lane; i < cnt; i += 64) hr_fuzzy_step(a[st + i], a[st + i - 1], &bl, &ml);
 		ml = rg_wave_sum(ml), bl = rg_wave_sum(bl);
 		if (lane == 0) { const int s0 = rg_span(a[st]); s_reg[p].mlen = ml + s0, s_reg[p].blen = bl + s0; }
 	}
