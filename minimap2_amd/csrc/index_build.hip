@@ -296,6 +296,24 @@ void DeviceIndexBuilder::tables_from_nt4(FlatIndex &fi, DeviceIndexTables &T, De
 	HIP_CHECK(hipMemcpyAsync(T.occ_hist.data(), d_hist.p, n_bins * 8, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	fi.bucket_bits = T.bucket_bits, fi.key_shift = T.key_shift;
+	T.make_slots(stream);
+}
+
+__global__ void __launch_bounds__(256) idx_make_slots_kernel(const uint64_t *keys, const uint32_t *val_off, uint64_t n_keys, IdxSlot *slots)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) {
+		IdxSlot s;
+		s.key = keys[i], s.off = val_off[i], s.cnt = val_off[i + 1] - val_off[i];
+		slots[i] = s;
+	}
+}
+void DeviceIndexTables::make_slots(hipStream_t stream)
+{
+	slots.ensure(n_keys + 1, 1.0);
+	if (n_keys) hipLaunchKernelGGL(idx_make_slots_kernel, dim3((unsigned)std::min<uint64_t>((n_keys + 255) / 256, 16384)), dim3(256), 0, stream, keys.p, val_off.p, n_keys, slots.p);
+	HIP_CHECK(hipGetLastError());
+	stream_wait(stream);
 }
 
 void DeviceIndexTables::upload(const FlatIndex &fi, hipStream_t stream)
@@ -310,6 +328,7 @@ void DeviceIndexTables::upload(const FlatIndex &fi, hipStream_t stream)
 	n_keys = fi.keys.size(), n_pos = fi.pos.size(), bucket_bits = fi.bucket_bits, key_shift = fi.key_shift;
 	occ_hist.assign(1 << 16, 0);
 	for (size_t i = 0; i < fi.keys.size(); ++i) { uint32_t c = fi.val_off[i + 1] - fi.val_off[i]; ++occ_hist[c < occ_hist.size() ? c : occ_hist.size() - 1]; }
+	make_slots(stream);
 }
 
 void DeviceIndexTables::clone_from(const DeviceIndexTables &src, int src_device, int dst_device)
@@ -322,6 +341,7 @@ void DeviceIndexTables::clone_from(const DeviceIndexTables &src, int src_device,
 	pos.ensure(n_pos + 1, 1.0), cp(pos.p, src.pos.p, n_pos * 8);
 	const size_t s_words = src.S.cap; // the packed reference as allocated (its exact length lives in the host index)
 	S.ensure(s_words + 1, 1.0), cp(S.p, src.S.p, s_words * 4);
+	slots.ensure(n_keys + 1, 1.0), cp(slots.p, src.slots.p, n_keys * sizeof(IdxSlot));
 	HIP_CHECK(hipDeviceSynchronize());
 }
 

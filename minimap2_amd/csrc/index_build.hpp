@@ -8,9 +8,16 @@
 namespace mm2amd {
 
 // The flat minimizer tables of flat_index.hpp living in HBM, plus the 4-bit packed reference.
+// One probe record per distinct minimizer: the key, where its positions start and how many there are -- the key scan of a bucket and the count
+// come out of ONE 64-byte sector (round 5; keys[] and val_off[] stay for the export and the occurrence statistics, the probes of seed_collect_kernel
+// read this: bucket_start -> slot instead of bucket_start -> keys -> val_off, val_off + 1)
+struct alignas(16) IdxSlot { uint64_t key; uint32_t off, cnt; };
+
 struct DeviceIndexTables {
 	DevBuf<uint32_t> bucket_start, val_off, S;
 	DevBuf<uint64_t> keys, pos;
+	DevBuf<IdxSlot> slots;
+	void make_slots(hipStream_t stream); // from keys / val_off
 	uint64_t n_keys = 0, n_pos = 0;
 	int bucket_bits = 0, key_shift = 0;
 	std::vector<unsigned long long> occ_hist; // occ_hist[c] = number of distinct minimizers occurring c times (last bin: >=)

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "seed_chain_dev.hpp"
+#include "index_build.hpp"
 #include "heap_order.hpp"
 #include "sdust_core.hpp"
 #include "sketch_dev.hpp"
@@ -326,8 +327,12 @@ __device__ __forceinline__ uint32_t idx_lookup(const DevIndex &I, uint64_t hash,
 	const uint64_t b = hash >> I.key_shift;
 	if (b >= (1ull << I.bucket_bits)) return 0;
 	const uint32_t s = I.bucket_start[b], e = I.bucket_start[b + 1];
-	for (uint32_t i = s; i < e; ++i)
-		if (I.keys[i] == hash) { *off = I.val_off[i]; return I.val_off[i + 1] - I.val_off[i]; }
+	// (round 5) one 16-byte record per key -- key, first position, count -- so the bucket's key scan and the answer come out of the same sector:
+	// two dependent sector reads per probe (bucket_start, slots) instead of three to four (bucket_start, keys, val_off[i], val_off[i + 1])
+	for (uint32_t i = s; i < e; ++i) {
+		const IdxSlot k = I.slots[i];
+		if (k.key == hash) { *off = k.off; return k.cnt; }
+	}
 	return 0;
 }
 

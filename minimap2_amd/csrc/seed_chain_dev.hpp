@@ -11,6 +11,7 @@ struct DevIndex {             // device mirror of FlatIndex
 	const uint32_t *bucket_start;
 	const uint64_t *keys;
 	const uint32_t *val_off;
+	const struct IdxSlot *slots; // (key, first position, count) per distinct minimizer: what a probe reads (index_build.hpp)
 	const uint64_t *pos;
 	const uint32_t *S;
 	int bucket_bits, key_shift;
