@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--ref-mb", type=float, default=3000.0)
     ap.add_argument("--reads", type=int, default=100000)
     ap.add_argument("--dir", default="/tmp/e2e")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r02_e2e_wall.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_e2e_wall.json"))
     ap.add_argument("--skip-index-check", action="store_true")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
@@ -84,7 +84,10 @@ def main():
     n_contig = max(1, min(24, total // 1000000))
     codes, per = bench.gen_reference(torch, dev, 11, total, n_contig)
     refs = bench.reference_ascii(torch, dev, codes, per, n_contig)
-    reads = bench.gen_reads(torch, dev, 1000, codes, per, n_contig, a.reads, 10000, 1000, 0.12)
+    reads, chunk = [], max(1, min(a.reads, 100000))  # in chunks of at most ~1 Gbase, as bench.py generates them (32-bit index arithmetic inside a call)
+    for c0 in range(0, a.reads, chunk):
+        reads += bench.gen_reads(torch, dev, 1000 + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), 10000, 1000, 0.12)
+        torch.cuda.empty_cache()
     del codes
     torch.cuda.empty_cache()
     names = ["chr%d" % (i + 1) for i in range(n_contig)]
