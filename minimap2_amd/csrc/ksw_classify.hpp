@@ -122,7 +122,7 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 struct KswClassStat { unsigned long long slot_bytes, tmp_cap, alg_bytes, cells, sum_len; unsigned int max_ring, max_Q16, max_rows, max_ncol, n_jobs, pad; };
 
 // what the host needs to plan the launches when the ordering ran on the device
-struct KswOrderResult { KswClassStat cls[kNTiers]; unsigned int tier_beg[kNTiers + 1]; };
+struct KswOrderResult { KswClassStat cls[kNTiers]; unsigned int tier_beg[kNTiers + 1]; unsigned int ticket; };
 // d_jobs (n records, device) -> d_sorted in launch order, d_perm[i] = launch position of job i; *h_out (pinned) is valid after the stream has been waited for.
 // d_work: scratch of ksw_order_work_words(n) 32-bit words.
 size_t ksw_order_work_words(size_t n);

@@ -1,6 +1,6 @@
 // The DP batch's launch order made on the device (ksw_classify.hpp): when the job records are born there (region_plan_kernel), nothing of them
 // crosses PCIe -- the jobs are classed and counted (one pass: class x cost-bucket histogram by atomics, per-class sizing figures reduced in LDS
-// first), the histogram is scanned by one workgroup, and a second pass scatters the records into launch order.  The order inside a bucket is
+// first), the histogram is scanned by the pass's last workgroup, and a second pass scatters the records into launch order.  The order inside a bucket is
 // whatever the atomics give: the launch order is a scheduling hint (longest jobs first), results do not depend on it.
 // Algorithmic bytes: 48 B read twice + 48 B written + 4 B per job.
 #include <hip/hip_runtime.h>
@@ -56,19 +56,24 @@ __global__ void __launch_bounds__(256) ksw_order_count_kernel(const KswJob *jobs
 		atomicMax(&c.slot_bytes, s_max64[t][0]), atomicMax(&c.tmp_cap, s_max64[t][1]);
 		atomicMax(&c.max_ring, s_max[t][0]), atomicMax(&c.max_Q16, s_max[t][1]), atomicMax(&c.max_rows, s_max[t][2]), atomicMax(&c.max_ncol, s_max[t][3]);
 	}
-}
-
-// exclusive scan of the class x bucket histogram by one workgroup: hist[b] becomes the first launch position of bin b; tier_beg[t] = that of class t
-__global__ void __launch_bounds__(1024) ksw_order_scan_kernel(uint32_t *hist, KswOrderResult *out)
-{
-	__shared__ uint32_t s_part[1024];
-	constexpr int PER = (kBins + 1023) / 1024;
+	// The workgroup that finishes LAST turns the histogram into launch positions (exclusive scan; hist[b] becomes the first position of bin b,
+	// tier_beg[t] that of class t).  A kernel of its own for this one-workgroup job waited milliseconds for a CU behind the persistent DP kernels of the
+	// other lanes (rocprofv3, call 8: 2.4 ms on average, 23 ms at worst, eight times per step).
+	__shared__ uint32_t s_part[256];
+	__shared__ int s_last;
+	__syncthreads();
+	__threadfence(); // (this workgroup's counts and figures are out before its ticket is)
+	if (threadIdx.x == 0) s_last = atomicAdd(&out->ticket, 1u) == gridDim.x - 1;
+	__syncthreads();
+	if (!s_last) return;
+	__threadfence();
+	constexpr int PER = (kBins + 255) / 256;
 	const int tid = threadIdx.x, b0 = tid * PER;
 	uint32_t sum = 0;
-	for (int k = 0; k < PER; ++k) if (b0 + k < kBins) sum += hist[b0 + k];
+	for (int k = 0; k < PER; ++k) if (b0 + k < kBins) sum += atomicAdd(&hist[b0 + k], 0u); // (the counts were made by atomics: read them where they live)
 	s_part[tid] = sum;
 	__syncthreads();
-	for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
+	for (int d = 1; d < 256; d <<= 1) { // Hillis-Steele inclusive scan of the 256 partial sums
 		const uint32_t v = tid >= d ? s_part[tid - d] : 0;
 		__syncthreads();
 		s_part[tid] += v;
@@ -78,12 +83,11 @@ __global__ void __launch_bounds__(1024) ksw_order_scan_kernel(uint32_t *hist, Ks
 	for (int k = 0; k < PER; ++k) {
 		const int b = b0 + k;
 		if (b >= kBins) break;
-		const uint32_t v = hist[b];
-		hist[b] = acc;
+		const uint32_t v = atomicExch(&hist[b], acc);
 		if (b % kOrderBuckets == 0) out->tier_beg[b / kOrderBuckets] = acc;
 		acc += v;
 	}
-	if (tid == 1023) out->tier_beg[kNTiers] = s_part[1023];
+	if (tid == 255) out->tier_beg[kNTiers] = s_part[255];
 }
 
 __global__ void __launch_bounds__(256) ksw_order_scatter_kernel(const KswJob *jobs, uint32_t n, uint32_t *hist, const uint32_t *bucket, KswJob *sorted, uint32_t *perm)
@@ -107,7 +111,6 @@ void ksw_order_device(const KswJob *d_jobs, size_t n, const KswClassCtx &C, KswJ
 	if (n == 0) return;
 	const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
 	hipLaunchKernelGGL(ksw_order_count_kernel, dim3(grid), dim3(256), 0, st, d_jobs, (uint32_t)n, C, hist, bucket, d_out);
-	hipLaunchKernelGGL(ksw_order_scan_kernel, dim3(1), dim3(1024), 0, st, hist, d_out);
 	hipLaunchKernelGGL(ksw_order_scatter_kernel, dim3(grid), dim3(256), 0, st, d_jobs, (uint32_t)n, hist, bucket, d_sorted, d_perm);
 	HIP_CHECK(hipGetLastError());
 }

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <malloc.h>
 #include <stdexcept>
+#include <new>
 #include "mapper.hpp"
 #include "host_prof.hpp"
 #include "chain_host.hpp"
@@ -343,7 +344,9 @@ void Mapper::device_hits(const Backend::RegionBatchOut &rb, const ReadChains &c,
 		const FinResult &f = rb.fin_res[slot];
 		r.div = x.n_tot < 0 ? -1.0f : x.n_match >= x.n_tot ? 0.0f : (float)(1.0 - pow((double)x.n_match / x.n_tot, 1.0 / avg_k)); // esterr.c:61
 		if (pl.status != 0 || f.n_cigar < 0 || (uint32_t)f.n_cigar + kHdr > pl.capacity) throw std::runtime_error("[mm2amd] align_regions: a finished region without a consistent CIGAR");
-		r.p = (Extra *)calloc(pl.capacity, 4);
+		r.p = (Extra *)malloc((size_t)pl.capacity * 4); // (the header is set below, the operations copied; what lies beyond them is as undefined as after the reference's realloc)
+		if (!r.p) throw std::bad_alloc();
+		memset(r.p, 0, sizeof(Extra));
 		r.p->capacity = pl.capacity;
 		r.p->n_cigar = (uint32_t)f.n_cigar;
 		memcpy(r.p->cigar, rb.cigars + rb.fin[slot].out_off, (size_t)f.n_cigar * 4);
