@@ -8,6 +8,7 @@
 #include "threads.hpp"
 #include "trace.hpp"
 #include <atomic>
+#include <mutex>
 #include <cmath>
 
 namespace mm2amd {
@@ -197,7 +198,21 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		bool any_side = false;
 		for (int tier = 0; tier < kNTiers; ++tier) any_side |= group_of(tier) == 1 && tier_beg[tier + 1] != tier_beg[tier];
 		const bool use_side = any_side && !splice && !getenv("MM2AMD_NO_SIDE_STREAM"); // (spliced alignment: both groups hold matrices of tens of MB per job -- one after the other, each with the whole scratch budget) // read per run: bench.py's un-overlapped pass wants every launch on one stream
-		const size_t group_budget = use_side ? dir_budget / 2 : dir_budget;
+		// What this lane may spend on direction matrices: its share of the budget -- and never more than the device has free beside what the lane already
+		// holds (the share is computed from the batch's own lane count, but with a queued hand-over the other lanes work on the next batch at the
+		// same time, and scratch only grows).  Query and growth are serialised among the lanes, so two lanes cannot both take the same free memory.
+		static std::mutex grow_mu;
+		std::unique_lock<std::mutex> grow_lk(grow_mu);
+		size_t budget_now = dir_budget;
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+				const size_t mine = (d_dir.cap + d_dir2.cap) * sizeof(uint8_t), reserve = (size_t)12 << 30; // (room for the other lanes' per-sub-batch arrays)
+				const size_t avail = free_b + mine > reserve ? free_b + mine - reserve : 0;
+				budget_now = std::min(budget_now, std::max<size_t>(avail, (size_t)1 << 30));
+			}
+		}
+		const size_t group_budget = use_side ? budget_now / 2 : budget_now;
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			Plan &P = plan[tier];
 			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
@@ -255,6 +270,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			dir_g[0] = dir_g[1] = d_dir.p, tmp_g[0] = tmp_g[1] = d_cigar_tmp.p;
 		}
 		if (need_state) d_state.ensure(need_state, 1.0);
+		grow_lk.unlock();
 		if (use_side) {
 			if (!side) {
 				int lo_prio = 0, hi_prio = 0;

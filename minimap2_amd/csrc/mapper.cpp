@@ -311,9 +311,9 @@ void Mapper::run(std::vector<ReadResult> &out)
 		cur_run_ = b;
 		lane_cap_ = std::max(1, be_.n_lanes());
 		if (const char *e = getenv("MM2AMD_ACTIVE_LANES")) lane_cap_ = std::max(1, std::min(lane_cap_, atoi(e)));
-		// shared budgets (the DP kernels' direction-matrix scratch, which only grows) are split among the lanes that CAN work at once: with a queued
-		// hand-over the lanes this batch leaves idle start on the next one, so a batch of one or two sub-batches does not have the GPU to itself
-		be_.set_active_lanes(be_.stages_beside_mapping() ? std::max(lane_cap_, b->n_drivers) : b->n_drivers);
+		// shared budgets (the DP kernels' direction-matrix scratch) are split among this batch's lanes; lanes that start on the NEXT batch early find
+		// their share bounded by what the device still has free (KswRunner::run_jobs: the scratch only grows, so the bound is taken where it grows)
+		be_.set_active_lanes(b->n_drivers);
 		ensure_drivers(std::max(lane_cap_, b->n_drivers)); // (lanes beyond this batch's sub-batches exist too: they are the ones free to start on the next batch)
 		cv_work_.notify_all();
 		cv_done_.wait(lk, [&] { return b->n_done == b->n_taken && (b->cancelled || b->next_sub >= b->subs.size()); });

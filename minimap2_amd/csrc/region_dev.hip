@@ -200,18 +200,25 @@ __device__ __forceinline__ int rg_gap_at(const Anchor *a, int i) // query advanc
 	return (rg_y(a[i]) - rg_y(a[i - 1])) - (int32_t)(a[i].x - a[i - 1].x);
 }
 
-// the anchors before which the two sequences drift apart by more than min_gap (collect_long_gaps, align.c:435-452); none when there is only one
-__device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K)
+// the anchors before which the two sequences drift apart by more than min_gap (collect_long_gaps, align.c:435-452); none when there is only one.
+// All lanes: 64 anchors per step, the sites compacted in order by a ballot.  Every lane returns the count.
+__device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K, int lane)
 {
 	int n = 0;
-	for (int i = 1; i < cnt1; ++i) { const int g = rg_gap_at(a, i); if (g < -min_gap || g > min_gap) K[n++] = i; }
+	for (int i0 = 1; i0 < cnt1; i0 += 64) {
+		const int i = i0 + lane;
+		bool site = false;
+		if (i < cnt1) { const int g = rg_gap_at(a, i); site = g < -min_gap || g > min_gap; }
+		const unsigned long long m = __ballot(site);
+		if (site) K[n + __popcll(m & ((1ull << lane) - 1ull))] = i;
+		n += __popcll(m);
+	}
 	return n <= 1 ? 0 : n;
 }
 
 // runs of seeds between an insertion and a deletion that cancel each other are bad seeds (mm_filter_bad_seeds, align.c:454-489)
-__device__ void rg_drop_compensating(Anchor *a, int cnt1, int32_t *K, int diff_thres, int max_ext_len, int max_ext_cnt)
+__device__ void rg_drop_compensating(Anchor *a, int n, const int32_t *K, int diff_thres, int max_ext_len, int max_ext_cnt) // n, K: rg_gap_sites(.., 10, ..)
 {
-	const int n = rg_gap_sites(a, cnt1, 10, K);
 	if (n == 0) return;
 	int best = 0, best_st = -1, best_en = -1;
 	for (int k = 0;; ++k) {
@@ -237,9 +244,8 @@ __device__ void rg_drop_compensating(Anchor *a, int cnt1, int32_t *K, int diff_t
 }
 
 // clusters of long gaps close to each other are bridged by ONE long window (mm_filter_bad_seeds_alt, align.c:491-525)
-__device__ void rg_join_gap_clusters(Anchor *a, int cnt1, int32_t *K, int max_ext)
+__device__ void rg_join_gap_clusters(Anchor *a, int n, const int32_t *K, int max_ext) // n, K: rg_gap_sites(.., 30, ..)
 {
-	const int n = rg_gap_sites(a, cnt1, 30, K);
 	for (int k = 0; k < n;) {
 		const int i = K[k];
 		int l, gap1 = rg_gap_at(a, i);
@@ -328,9 +334,48 @@ __device__ __forceinline__ void rg_emit(const RgnBuffers &B, const RgnOpts &O, c
 
 } // namespace
 
-__global__ void __launch_bounds__(64) region_plan_kernel(RgnBuffers B, RgnOpts O)
+// The window walk of mm_align1 (align.c:803-846) by the wave: the walk's state is where the last window ended; 64 anchors are tested against it at once, the first
+// one that closes a window is found by a ballot, and the lanes after it are tested again against the new state.  emit == false only counts.
+template <bool EMIT>
+__device__ int rg_walk_windows(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, const Anchor *a, int cnt1, int half, int32_t rs, int32_t qs, uint32_t idx0, int lane)
 {
-	const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+	int32_t cs = rs, cq = qs;
+	int n = 0;
+	for (int i0 = 1; i0 < cnt1; i0 += 64) {
+		const int i = i0 + lane;
+		uint64_t y = 0;
+		int32_t e_r = 0, e_q = 0;
+		bool cand = false;
+		if (i < cnt1) {
+			const Anchor c = a[i];
+			y = c.y, e_r = rg_x(c) - half, e_q = (int32_t)y - half;
+			cand = !((y & (ref::SEED_IGNORE | ref::SEED_TANDEM)) && i != cnt1 - 1);
+		}
+		unsigned long long live = ~0ull; // lanes not yet passed by a closed window
+		for (;;) {
+			const bool close = cand && (i == cnt1 - 1 || (y & ref::SEED_LONG_JOIN) || (e_q - cq >= O.min_ksw_len && e_r - cs >= O.min_ksw_len));
+			const unsigned long long m = __ballot(close) & live;
+			if (!m) break;
+			const int f = __builtin_ctzll(m);
+			const int32_t n_r = __shfl(e_r, f, 64), n_q = __shfl(e_q, f, 64);
+			if (EMIT && lane == f) {
+				int bw = O.bw_gap;
+				if (y & ref::SEED_LONG_JOIN) bw = e_q - cq > e_r - cs ? e_q - cq : e_r - cs;
+				rg_emit(B, O, X, idx0 + (uint32_t)n, 1, cq, e_q, cs, e_r, bw, i, KSW_APPROX_MAX, O.zdrop, -1);
+			}
+			cs = n_r, cq = n_q, ++n;
+			live = f == 63 ? 0ull : ~0ull << (f + 1);
+		}
+	}
+	return n;
+}
+
+// one wavefront per region: the lanes share the passes over the region's anchors (gap sites, window walk); the short sequential rules (end trimming, the
+// two long-gap filters over the site lists, the extension limits) are walked by lane 0
+__global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts O)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6);
 	const uint32_t n_regs = B.cursors[RGN_CUR_REGS] < B.max_regs ? B.cursors[RGN_CUR_REGS] : B.max_regs;
 	if (slot >= n_regs) return;
 	const Reg1 r = B.regs[slot];
@@ -340,22 +385,34 @@ __global__ void __launch_bounds__(64) region_plan_kernel(RgnBuffers B, RgnOpts O
 	Anchor *a = B.sq_a + rd.sq_off;               // the READ's squeezed anchors: the extension limits look at its other hits' anchors too
 	const int qlen = rd.qlen, n_a = ro.n_a_sq;
 	pl.status = 0, pl.n_win = 0;
-	if (r.cnt == 0) { pl.status = RGN_F_NO_CIGAR; B.plan[slot] = pl; return; }
+	if (r.cnt == 0) { pl.status = RGN_F_NO_CIGAR; if (lane == 0) B.plan[slot] = pl; return; }
 	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 	const int32_t ref_len = (int32_t)B.ref_len[rid];
 	int32_t as1 = r.as, cnt1 = r.cnt;
-	if (!(O.flag & ref::F_NO_END_FLT)) rg_trim_ends(r, a, O.bw, O.min_chain_score * 2, &as1, &cnt1);
+	if (!(O.flag & ref::F_NO_END_FLT)) {
+		if (lane == 0) rg_trim_ends(r, a, O.bw, O.min_chain_score * 2, &as1, &cnt1);
+		as1 = __shfl(as1, 0, 64), cnt1 = __shfl(cnt1, 0, 64);
+	}
 	int32_t *K = B.gap_sites + rd.sq_off + as1;
-	rg_drop_compensating(a + as1, cnt1, K, 40, O.max_gap >> 1, 10);
-	rg_join_gap_clusters(a + as1, cnt1, K, O.max_gap >> 1);
+	{
+		const int n10 = rg_gap_sites(a + as1, cnt1, 10, K, lane);
+		RG_SYNC();
+		if (lane == 0) rg_drop_compensating(a + as1, n10, K, 40, O.max_gap >> 1, 10);
+		RG_SYNC();
+		const int n30 = rg_gap_sites(a + as1, cnt1, 30, K, lane);
+		RG_SYNC();
+		if (lane == 0) rg_join_gap_clusters(a + as1, n30, K, O.max_gap >> 1);
+		RG_SYNC(); // (the flags lane 0 set in the anchors are read by all lanes below)
+	}
 	// a window boundary sits in the middle of an anchor's k-mer (mm_adjust_minier without HPC, align.c:429-432)
 	const int half = O.k >> 1;
-	int32_t rs = rg_x(a[as1]) - half, qs = rg_y(a[as1]) - half;
-	int32_t re = rg_x(a[as1 + cnt1 - 1]) - half, qe = rg_y(a[as1 + cnt1 - 1]) - half;
+	const int32_t rs = rg_x(a[as1]) - half, qs = rg_y(a[as1]) - half;
+	const int32_t re = rg_x(a[as1 + cnt1 - 1]) - half, qe = rg_y(a[as1 + cnt1 - 1]) - half;
 
-	// how far the two extensions may reach (align.c:706-767)
-	int32_t rs0, qs0, re0, qe0, rs1 = 0, qs1 = 0, re1, qe1, l;
-	{
+	// how far the two extensions may reach (align.c:706-767): lane 0
+	int32_t rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
+	if (lane == 0) {
+		int32_t rs1 = 0, qs1 = 0, re1, qe1, l;
 		const Anchor f = a[r.as];
 		rs0 = rg_x(f) + 1 - rg_span(f), qs0 = rg_y(f) + 1 - rg_span(f);
 		if (rs0 < 0) rs0 = 0;
@@ -409,45 +466,26 @@ __global__ void __launch_bounds__(64) region_plan_kernel(RgnBuffers B, RgnOpts O
 			if (qe0 - r.qe > room) qe0 = r.qe + room;
 		}
 	}
+	rs0 = __shfl(rs0, 0, 64), qs0 = __shfl(qs0, 0, 64), re0 = __shfl(re0, 0, 64), qe0 = __shfl(qe0, 0, 64);
 	// the windows, in the order the reference aligns them (align.c:779-890): counted first, so that the region's jobs are one dense run
-	const bool has_left = qs > 0 && rs > 0;
-	int n_gap_win = 0;
-	{
-		int32_t cs = rs, cq = qs;
-		for (int32_t i = 1; i < cnt1; ++i) {
-			const uint64_t y = a[as1 + i].y;
-			if ((y & (ref::SEED_IGNORE | ref::SEED_TANDEM)) && i != cnt1 - 1) continue;
-			const int32_t e_r = rg_x(a[as1 + i]) - half, e_q = (int32_t)y - half;
-			if (i == cnt1 - 1 || (y & ref::SEED_LONG_JOIN) || (e_q - cq >= O.min_ksw_len && e_r - cs >= O.min_ksw_len)) ++n_gap_win, cs = e_r, cq = e_q;
-		}
-	}
-	// (the right extension exists when the LAST gap window's end -- the last anchor's boundary, or the first one's when there is a single anchor -- lies inside the limits)
-	const bool has_right = qe < qe0 && re < re0;
-	const int n_win = (has_left ? 1 : 0) + n_gap_win + (has_right ? 1 : 0);
-	const uint32_t job0 = atomicAdd(&B.cursors[RGN_CUR_JOBS], (unsigned)n_win);
-	pl.job0 = job0, pl.n_win = n_win, pl.as1 = as1, pl.cnt1 = cnt1, pl.rid = rid, pl.rev = rev, pl.rs = rs, pl.qs = qs, pl.has_left = has_left, pl.has_right = has_right;
-	if (job0 + (uint32_t)n_win > B.max_jobs) { pl.status = RGN_F_MULTI_ROUND, pl.n_win = 0; B.plan[slot] = pl; return; } // (cannot happen: sized by anchors + 2 per chain)
 	RgnJobCtx X;
 	X.q_fwd = rd.qpool_fwd, X.q_rev = rd.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
 	X.gen_flag = O.transition != 0 && O.b != O.transition ? KSW_GENERIC_SC : 0; // align.c:347-348
+	const bool has_left = qs > 0 && rs > 0;
+	const int n_gap_win = rg_walk_windows<false>(B, O, X, a + as1, cnt1, half, rs, qs, 0, lane);
+	// (the right extension exists when the LAST gap window's end -- the last anchor's boundary, or the first one's when there is a single anchor -- lies inside the limits)
+	const bool has_right = qe < qe0 && re < re0;
+	const int n_win = (has_left ? 1 : 0) + n_gap_win + (has_right ? 1 : 0);
+	uint32_t job0 = 0;
+	if (lane == 0) job0 = atomicAdd(&B.cursors[RGN_CUR_JOBS], (unsigned)n_win);
+	job0 = (uint32_t)__shfl((int)job0, 0, 64);
+	pl.job0 = job0, pl.n_win = n_win, pl.as1 = as1, pl.cnt1 = cnt1, pl.rid = rid, pl.rev = rev, pl.rs = rs, pl.qs = qs, pl.has_left = has_left, pl.has_right = has_right;
+	if (job0 + (uint32_t)n_win > B.max_jobs) { pl.status = RGN_F_MULTI_ROUND, pl.n_win = 0; if (lane == 0) B.plan[slot] = pl; return; } // (cannot happen: sized by anchors + 2 per chain)
 	uint32_t idx = job0;
-	if (has_left) rg_emit(B, O, X, idx++, 0, qs0, qs, rs0, rs, O.bw_ext, 0, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, r.split_inv ? O.zdrop_inv : O.zdrop, O.end_bonus);
-	{
-		int32_t cs = rs, cq = qs;
-		for (int32_t i = 1; i < cnt1; ++i) {
-			const uint64_t y = a[as1 + i].y;
-			if ((y & (ref::SEED_IGNORE | ref::SEED_TANDEM)) && i != cnt1 - 1) continue;
-			const int32_t e_r = rg_x(a[as1 + i]) - half, e_q = (int32_t)y - half;
-			if (i == cnt1 - 1 || (y & ref::SEED_LONG_JOIN) || (e_q - cq >= O.min_ksw_len && e_r - cs >= O.min_ksw_len)) {
-				int bw = O.bw_gap;
-				if (y & ref::SEED_LONG_JOIN) bw = e_q - cq > e_r - cs ? e_q - cq : e_r - cs;
-				rg_emit(B, O, X, idx++, 1, cq, e_q, cs, e_r, bw, i, KSW_APPROX_MAX, O.zdrop, -1);
-				cs = e_r, cq = e_q;
-			}
-		}
-	}
-	if (has_right) rg_emit(B, O, X, idx++, 2, qe, qe0, re, re0, O.bw_ext, 0, KSW_EXTZ_ONLY, O.zdrop, O.end_bonus);
-	B.plan[slot] = pl;
+	if (has_left) { if (lane == 0) rg_emit(B, O, X, idx, 0, qs0, qs, rs0, rs, O.bw_ext, 0, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, r.split_inv ? O.zdrop_inv : O.zdrop, O.end_bonus); ++idx; }
+	idx += (uint32_t)rg_walk_windows<true>(B, O, X, a + as1, cnt1, half, rs, qs, idx, lane);
+	if (has_right && lane == 0) rg_emit(B, O, X, idx, 2, qe, qe0, re, re0, O.bw_ext, 0, KSW_EXTZ_ONLY, O.zdrop, O.end_bonus);
+	if (lane == 0) B.plan[slot] = pl;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -569,7 +607,7 @@ void launch_chain_regs(const RgnBuffers &B, const RgnOpts &O, void *stream)
 void launch_region_plan(const RgnBuffers &B, const RgnOpts &O, void *stream)
 {
 	if (B.max_regs == 0) return;
-	hipLaunchKernelGGL(region_plan_kernel, dim3((B.max_regs + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, O);
+	hipLaunchKernelGGL(region_plan_kernel, dim3((B.max_regs + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, O);
 	HIP_CHECK(hipGetLastError());
 }
 void launch_region_consume(const RgnBuffers &B, const RgnOpts &O, const uint32_t *cigar_pool, void *stream)

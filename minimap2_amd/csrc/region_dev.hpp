@@ -10,7 +10,7 @@
 //                        match / block lengths by a wave reduction over the chain's anchors), parent / secondary marking, secondary selection,
 //                        the minimizer counts mm_est_err needs (a merge of the chain's anchors with the read's minimizer positions, done as
 //                        one binary search per anchor), and the anchors of the hits that survive squeezed together (hit.c:322-340);
-//   region_plan_kernel   one region per thread-of-work: seed clean-up (align.c:435-561), extension limits (:695-767), the window walk (:779-890);
+//   region_plan_kernel   one wavefront per region: seed clean-up (align.c:435-561), extension limits (:695-767), the window walk (:779-890);
 //                        emits one KswJob per window, densely, in the order the reference would have called ksw2;
 //   region_consume_kernel one region: walks its windows' KswRes in the reference's order (extension end points, the Z-drop test on the
 //                        kernels' own scan, score bookkeeping, mm_extra_t's capacity rule) and writes the FinRegion / FinPiece records

@@ -130,3 +130,16 @@ def test_unsupported_configurations_stay_on_the_host():
     got, st = _map(refs, rds, "splice", names)
     assert got == reflib.ref_map_reads(refs, rds, "splice", names=names)
     assert st["n_region_reads_dev"] == 0
+
+
+def test_long_reads_beyond_the_finish_kernels_lds_are_handed_back():
+    """a 60 kb read's stitched CIGAR has more operations than region_finish_kernel stages in LDS (MM2AMD_FIN_MAX_OPS): the device hands the read back
+    and the host path finishes it; shorter reads beside it stay on the device"""
+    rng = np.random.default_rng(36)
+    contigs = synth.gen_reference(rng, 1200000, 2)
+    reads = synth.gen_reads(rng, contigs, 3, 60000, 2000, 0.1, min_len=50000) + synth.gen_reads(rng, contigs, 12, 4000, 1000, 0.1)
+    refs, names = [synth.ACGT[c].tobytes() for c in contigs], ["chr1", "chr2"]
+    rds = _codes_to_reads(reads)
+    got, st = _map(refs, rds, "map-ont", names)
+    assert got == reflib.ref_map_reads(refs, rds, "map-ont", names=names)
+    assert st["n_region_reads_host"] >= 2 and st["n_region_reads_dev"] >= 10, st
