@@ -38,7 +38,7 @@ for S in "$@"; do
     rank8)   cd /tmp; timeout 900 python $R/bench.py --gpus 1 --steps 8 --warmup 3 --no-cpu-baseline --as-rank-of 8 > $O/r05_bench_rank8_$V.json 2> $O/r05_bench_rank8_$V.log; line $O/r05_bench_rank8_$V.json
              python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().split(chr(10))[-1]); print('  as_rank_of', d['config']['as_rank_of'])" $O/r05_bench_rank8_$V.json ;;
     pmcsq)   cd /tmp; PMC_SQ_TAG=$V timeout 600 python $R/tools/pmc_sq.py SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE > $O/r05_pmc_sq_$V.txt 2>&1; mv $O/pmc_sq_$V.json $O/r05_pmc_sq_$V.json; tail -8 $O/r05_pmc_sq_$V.txt | cut -c1-200 ;;
-    hifi)    cd /tmp; timeout 900 python $R/bench.py --preset map-hifi --reads 200000 --steps 3 --warmup 1 > $O/r05_bench_hifi_$V.json 2> $O/r05_bench_hifi_$V.log; line $O/r05_bench_hifi_$V.json ;;
+    hifi)    cd /tmp; timeout 900 python $R/bench.py --preset map-hifi --reads 200000 --steps 3 --warmup 2 > $O/r05_bench_hifi_$V.json 2> $O/r05_bench_hifi_$V.log; line $O/r05_bench_hifi_$V.json ;;
     splice)  cd /tmp; timeout 900 python $R/bench.py --preset splice --reads 50000 --steps 3 --warmup 1 > $O/r05_bench_splice_$V.json 2> $O/r05_bench_splice_$V.log; line $O/r05_bench_splice_$V.json ;;
     e2e:*)   cd /tmp; df -h /tmp | tail -1; timeout 1500 python $R/tools/e2e_wall.py --reads ${S#e2e:} --out $O/r05_e2e_wall_$V.json > $O/r05_e2e_wall_$V.log 2>&1; tail -1 $O/r05_e2e_wall_$V.log | cut -c1-1500; rm -rf /tmp/e2e ;;
     smoke)   python -c "import __graft_entry__ as g; g.smoke()" > $O/r05_smoke_$V.log 2>&1; tail -1 $O/r05_smoke_$V.log ;;

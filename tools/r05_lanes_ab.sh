@@ -7,10 +7,9 @@ d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); c=d['config']
 print(sys.argv[1].split('/')[-1], d['value'], 'ms/step', d['ms_per_step'], 'resident', c.get('resident_gbases_per_s'), 'cpu_s', c['host_cpu_s_per_step'])
 PY
 }
-H="--preset map-hifi --reads 200000 --steps 3 --warmup 1"
-run hifi_l4 "$H" MM2AMD_LANES=4
-run hifi_l6 "$H" MM2AMD_LANES=6
-run hifi_l8_w100 "$H" MM2AMD_WAIT_MAX_US=100
-run ont_l6 "--steps 8 --warmup 3" MM2AMD_LANES=6
-run ont_l8_w100 "--steps 8 --warmup 3" MM2AMD_WAIT_MAX_US=100
-run ont_l8 "--steps 8 --warmup 3" MM2AMD_X=1
+H="--preset map-hifi --reads 200000 --steps 3 --warmup 2"
+run hifi_stag45 "$H" MM2AMD_LANE_STAGGER_MS=45
+run hifi_stag0 "$H" MM2AMD_X=1
+run hifi_stag90 "$H" MM2AMD_LANE_STAGGER_MS=90
+run ont_stag45 "--steps 8 --warmup 3" MM2AMD_LANE_STAGGER_MS=45
+run ont_stag0 "--steps 8 --warmup 3" MM2AMD_X=1
