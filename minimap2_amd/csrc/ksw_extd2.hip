@@ -148,7 +148,7 @@ __device__ void traceback(const uint8_t *dir, size_t ncol, int qlen, int tlen, i
 // intron on the target (x2 only; opening costs q2, extension nothing) priced per position by donor/acceptor bytes that take the
 // place of y2 and of the spare byte in the second state dword; no clamp; Z-drop without the diagonal term; N in the CIGAR.
 template <bool LDS_STATE, int MODE, int TEAM>
-__global__ void __launch_bounds__(TEAM > 8 ? 1024 : TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaunch L)
+__global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaunch L)
 {
 	constexpr bool SINGLE = MODE == 1, SPLICE = MODE == 2;
 	static_assert(TEAM == 1 || LDS_STATE, "a team shares its state through LDS");
@@ -644,8 +644,7 @@ void ksw_extd2_launch(const KswLaunch &L, int n_slots, int waves_per_block, int 
 	const size_t lds = team > 1 ? region : region * waves_per_block;
 	const int n_blocks = team > 1 ? n_slots : (n_slots + waves_per_block - 1) / waves_per_block;
 	if (lds > 160 * 1024) throw std::runtime_error("[mm2amd] ksw_extd2: job class does not fit LDS");
-	if (team == 16) launch_any<true, 16>(L, n_blocks, 1, lds, (hipStream_t)stream);
-	else if (team == 8) launch_any<true, 8>(L, n_blocks, 1, lds, (hipStream_t)stream);
+	if (team == 8) launch_any<true, 8>(L, n_blocks, 1, lds, (hipStream_t)stream);
 	else if (team == 4) launch_any<true, 4>(L, n_blocks, 1, lds, (hipStream_t)stream);
 	else launch_any<true, 1>(L, n_blocks, waves_per_block, lds, (hipStream_t)stream);
 }

@@ -237,8 +237,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			if (P.hbm) P.wpb = 4;
 			static const bool no_team = getenv("MM2AMD_KSW_NO_TEAM") != nullptr; // A/B checks: every lane-exact job on one wave
 			P.team = fast || P.hbm || no_team ? 1 : kRingTeam[rc];
-			static const bool team16 = getenv("MM2AMD_KSW_TEAM16") != nullptr; // A/B: a band-751 row (twelve chunks) in ONE round of a sixteen-wave workgroup instead of two rounds of eight
-			if (team16 && P.team == 8 && rc >= 2) P.team = 16;
+			// (round 5, measured and dropped: a sixteen-wave workgroup sweeps a band-751 row -- twelve chunks -- in one round instead of two, and its barriers cost more
+			// than the round saves: r1k 57 -> 72 ms per step, profiles/r05_bench_team16_v15.json against _team8_)
 			if (P.team > 1) P.wpb = 1; // the workgroup IS the slot
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
