@@ -405,42 +405,27 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 				const bool exact_max = !approx_max;
 				const int en1 = st0 + (en0 - st0) / 4 * 4, nq = (en1 - st0) >> 2; // the reference's 4-lane strided scan of [st0,en1), then the tail [en1,en0); en0 itself first
 				long long best = INT64_MIN; // below every key
-				// (round 5) a team takes MR rounds of chunks per barrier: the loads of all of them (row r-1 at a position and at its left neighbour), ONE barrier, then the
-				// stores of all of them -- a band-751 row (twelve chunks, eight waves) cost two load|barrier|store rounds before
-				constexpr int MR = TEAM > 1 ? 4 : 1;
-				for (int c_top = n_chunk - 1; c_top >= 0; c_top -= TEAM * MR) {
-					int t_m[MR], xt1_m[MR], vt1_m[MR], x2t1_m[MR], h_cur_m[MR], h_left_m[MR];
-					uint32_t a_cur_m[MR], b_cur_m[MR];
-#pragma unroll
-					for (int k = 0; k < MR; ++k) {
-						const int c = c_top - k * TEAM - twave;
-						const int t = c >= 0 ? st + (c << 6) + lane : en + 1;
-						const int tk = t & RM;
-						uint32_t a_cur = 0, b_cur = 0;
-						int xt1 = x1, vt1 = v1, x2t1 = x21, h_cur = 0, h_left = 0;
-						if (t <= en) {
-							a_cur = A[tk], b_cur = B[tk];
-							if (t == r) { // the row's border column (:148-163): u[r], y[r] (and y2[r]) take their border values
-								a_cur = (a_cur & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24;
-								if (!SPLICE) b_cur = (b_cur & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;
-							}
-							if (t > st) {
-								const uint32_t a_prev = A[(t - 1) & RM], b_prev = B[(t - 1) & RM];
-								xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
-							}
-							if (!sep_fill && t >= st0 && t < f1) b_cur = (b_cur & 0xff00ffffu) | (uint32_t)(fresh_score(t) & 0xff) << 16;
-							if (exact_max) { h_cur = H[tk]; if (t == en0 && en0 > 0) h_left = H[(t - 1) & RM]; }
+				for (int c_hi = n_chunk - 1; c_hi >= 0; c_hi -= TEAM) {
+					const int c = c_hi - twave;
+					const int t = c >= 0 ? st + (c << 6) + lane : en + 1;
+					const int tk = t & RM;
+					uint32_t a_cur = 0, b_cur = 0;
+					int xt1 = x1, vt1 = v1, x2t1 = x21, h_cur = 0, h_left = 0;
+					if (t <= en) {
+						a_cur = A[tk], b_cur = B[tk];
+						if (t == r) { // the row's border column (:148-163): u[r], y[r] (and y2[r]) take their border values
+							a_cur = (a_cur & 0x00ffff00u) | (uint32_t)(bnd & 0xff) | (uint32_t)(init1 & 0xff) << 24;
+							if (!SPLICE) b_cur = (b_cur & 0xffff00ffu) | (uint32_t)(init2 & 0xff) << 8;
 						}
-						t_m[k] = t, a_cur_m[k] = a_cur, b_cur_m[k] = b_cur, xt1_m[k] = xt1, vt1_m[k] = vt1, x2t1_m[k] = x2t1, h_cur_m[k] = h_cur, h_left_m[k] = h_left;
+						if (t > st) {
+							const uint32_t a_prev = A[(t - 1) & RM], b_prev = B[(t - 1) & RM];
+							xt1 = sx8(a_prev >> 16), vt1 = sx8(a_prev >> 8), x2t1 = sx8(b_prev);
+						}
+						if (!sep_fill && t >= st0 && t < f1) b_cur = (b_cur & 0xff00ffffu) | (uint32_t)(fresh_score(t) & 0xff) << 16;
+						if (exact_max) { h_cur = H[tk]; if (t == en0 && en0 > 0) h_left = H[(t - 1) & RM]; }
 					}
-					if (TEAM > 1) __syncthreads(); // every lane of these rounds has read row r-1 (its own position and its left neighbour's) before any lane stores row r
+					if (TEAM > 1) __syncthreads(); // every lane of the round has read row r-1 (its own position and its left neighbour's) before any lane stores row r
 					else MM2_LOCKSTEP();
-#pragma unroll
-					for (int k = 0; k < MR; ++k) {
-					const int c = c_top - k * TEAM - twave;
-					const int t = t_m[k], tk = t & RM;
-					const uint32_t a_cur = a_cur_m[k], b_cur = b_cur_m[k];
-					const int xt1 = xt1_m[k], vt1 = vt1_m[k], x2t1 = x2t1_m[k], h_cur = h_cur_m[k], h_left = h_left_m[k];
 					if (t <= en) {
 						uint32_t a_new = 0;
 						if (SINGLE) { // ksw2_extz2_sse.c:34-55 with the left/right variants at :186-204 / :213-231 (and :164-170 score-only)
@@ -552,7 +537,6 @@ __global__ void __launch_bounds__(TEAM > 4 ? 512 : 256) ksw_extd2_kernel(KswLaun
 					}
 					if (!sep_fill && c == n_chunk - 1) // the stretch's scores beyond en: read by later rows only
 						for (int p2 = en + 1 + lane; p2 < f1; p2 += 64) ((uint8_t *)&B[p2 & RM])[2] = (uint8_t)fresh_score(p2);
-					}
 				}
 				if (exact_max) { // the lanes' keys -> the row's maximum and where the reference's scan finds it
 					best = wave_max_i64(best);
