@@ -591,13 +591,14 @@ public:
 		const size_t n = ln.rg_n;
 		out = RegionBatchOut();
 		if (n == 0 || chains.size() < n || in.size() < n) return;
-		if (!d_ref_off_.p) { // once: the reference sequences' offsets and lengths
+		if (!ref_ready_.load(std::memory_order_acquire)) { // once: the reference sequences' offsets and lengths (the flag is set after the copies have landed)
 			std::lock_guard<std::mutex> lk(ref_mu_);
-			if (!d_ref_off_.p) {
+			if (!ref_ready_.load(std::memory_order_relaxed)) {
 				d_ref_off_.ensure(fi_seq_off_->size() + 1), d_ref_len2_.ensure(fi_seq_len_->size() + 1);
 				HIP_CHECK(hipMemcpyAsync(d_ref_off_.p, fi_seq_off_->data(), fi_seq_off_->size() * 8, hipMemcpyHostToDevice, st));
 				HIP_CHECK(hipMemcpyAsync(d_ref_len2_.p, fi_seq_len_->data(), fi_seq_len_->size() * 4, hipMemcpyHostToDevice, st));
 				stream_wait(st);
+				ref_ready_.store(true, std::memory_order_release);
 			}
 		}
 		KernelProfiler &kp = kernel_profiler(lane_id, replica_);
@@ -805,6 +806,7 @@ private:
 	DevBuf<uint64_t> d_ref_off_;
 	DevBuf<uint32_t> d_ref_len2_;
 	std::mutex ref_mu_;
+	std::atomic<bool> ref_ready_{false};
 	std::vector<std::string> sorted_names_;
 	DevBuf<int32_t> d_name_rank_;
 	DevBuf<uint32_t> d_ref_len_;
