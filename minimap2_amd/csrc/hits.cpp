@@ -176,64 +176,65 @@ int squeeze_anchors(RegVec &regs, Anchor *a)
 	return as;
 }
 
+namespace {
+// What mm_set_mapq2 (hit.c:432-485) gives one primary hit.  A product of damping factors times the log of the hit's strength, minus a term for the number of
+// near-equal secondaries; single-precision throughout, in the reference's operation order (every intermediate rounds as its float expression does), libm's logf.
+struct MapqContext { float share_unique; int floor_sub, match_sc; bool short_reads, spliced_short, lone_spliced; };
+
+int mapq_of(const Reg &h, const MapqContext &c)
+{
+	const float weak_score = (h.score > 100 ? 1.0f : 0.01f * h.score) * c.share_unique; // few bases chained, or much of the read is repetitive
+	const float few_seeds = h.cnt > 10 ? 1.0f : 0.1f * h.cnt;
+	const float damp = weak_score < few_seeds ? weak_score : few_seeds;
+	const int runner_up = h.subsc > c.floor_sub ? h.subsc : c.floor_sub; // the best secondary chain, at least the chaining threshold
+	int q;
+	if (h.p && h.p->dp_max2 > 0 && h.p->dp_max > 0) { // aligned, with an aligned competitor
+		const float identity = (float)h.mlen / h.blen;
+		const float rel = c.spliced_short ? (float)h.p->dp_max2 / h.p->dp_max : (float)h.p->dp_max2 * runner_up / h.p->dp_max / h.score0;
+		q = (int)(identity * damp * 40.0f * (1.0f - rel * rel) * logf((float)h.p->dp_max / c.match_sc));
+		if (!c.short_reads) { // long reads: never more than the score gap to the competitor allows
+			const int by_gap = (int)(6.02f * identity * identity * (h.p->dp_max - h.p->dp_max2) / c.match_sc + .499f);
+			q = q < by_gap ? q : by_gap;
+		}
+		if (c.spliced_short && h.is_spliced && c.lone_spliced) q += 10;
+	} else {
+		const float rel = (float)runner_up / h.score0;
+		if (h.p) q = (int)((float)h.mlen / h.blen * damp * 40.0f * (1.0f - rel) * logf((float)h.p->dp_max / c.match_sc));
+		else q = (int)(damp * 40.0f * (1.0f - rel) * logf(h.score));
+	}
+	q -= (int)(4.343f * logf(h.n_sub + 1) + .499f);
+	q = q > 0 ? (q < 60 ? q : 60) : 0;
+	return h.p && h.p->dp_max > h.p->dp_max2 && q == 0 ? 1 : q; // an alignment that beats its competitor is never reported as ambiguous
+}
+}
+
 void set_mapq(RegVec &regs, int min_chain_sc, int match_sc, int rep_len, bool is_sr, bool is_splice)
 {
-	static const float q_coef = 40.0f;
 	const int n = (int)regs.size();
 	if (n == 0) return;
-	int64_t sum_sc = 0;
-	int n_2nd_splice = 0;
-	for (const Reg &r : regs) {
-		if (r.parent == r.id) sum_sc += r.score;
-		else if (r.is_spliced) ++n_2nd_splice;
-	}
-	const float uniq_ratio = (float)sum_sc / (sum_sc + rep_len);
-	for (Reg &r : regs) {
-		if (r.inv) { r.mapq = 0; continue; }
-		if (r.parent != r.id) { r.mapq = 0; continue; }
-		int mapq;
-		const float pen_s1 = (r.score > 100 ? 1.0f : 0.01f * r.score) * uniq_ratio;
-		float pen_cm = r.cnt > 10 ? 1.0f : 0.1f * r.cnt;
-		pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
-		const int subsc = r.subsc > min_chain_sc ? r.subsc : min_chain_sc;
-		if (r.p && r.p->dp_max2 > 0 && r.p->dp_max > 0) {
-			float x;
-			const float identity = (float)r.mlen / r.blen;
-			if (is_sr && is_splice) x = (float)r.p->dp_max2 / r.p->dp_max;
-			else x = (float)r.p->dp_max2 * subsc / r.p->dp_max / r.score0;
-			mapq = (int)(identity * pen_cm * q_coef * (1.0f - x * x) * logf((float)r.p->dp_max / match_sc));
-			if (!is_sr) {
-				const int mapq_alt = (int)(6.02f * identity * identity * (r.p->dp_max - r.p->dp_max2) / match_sc + .499f);
-				mapq = mapq < mapq_alt ? mapq : mapq_alt;
-			}
-			if (is_splice && is_sr && r.is_spliced && n_2nd_splice == 0) mapq += 10;
-		} else {
-			const float x = (float)subsc / r.score0;
-			if (r.p) {
-				const float identity = (float)r.mlen / r.blen;
-				mapq = (int)(identity * pen_cm * q_coef * (1.0f - x) * logf((float)r.p->dp_max / match_sc));
-			} else mapq = (int)(pen_cm * q_coef * (1.0f - x) * logf(r.score));
-		}
-		mapq -= (int)(4.343f * logf(r.n_sub + 1) + .499f);
-		mapq = mapq > 0 ? mapq : 0;
-		r.mapq = mapq < 60 ? mapq : 60;
-		if (r.p && r.p->dp_max > r.p->dp_max2 && r.mapq == 0) r.mapq = 1;
-	}
-	// inversions inherit the lower MAPQ of their two neighbours on the reference (hit.c:406-430)
-	if (n < 3) return;
+	int64_t primary_score = 0;
+	int spliced_secondaries = 0;
 	bool any_inv = false;
-	for (const Reg &r : regs) any_inv |= r.inv;
-	if (!any_inv) return;
-	std::vector<Anchor> aux;
+	for (const Reg &r : regs) {
+		if (r.parent == r.id) primary_score += r.score;
+		else if (r.is_spliced) ++spliced_secondaries;
+		any_inv |= r.inv;
+	}
+	MapqContext c;
+	c.share_unique = (float)primary_score / (primary_score + rep_len);
+	c.floor_sub = min_chain_sc, c.match_sc = match_sc, c.short_reads = is_sr, c.spliced_short = is_sr && is_splice, c.lone_spliced = spliced_secondaries == 0;
+	for (Reg &r : regs) r.mapq = r.inv || r.parent != r.id ? 0 : (uint32_t)mapq_of(r, c);
+	// an inversion takes the lower MAPQ of its two neighbours along the reference (mm_set_inv_mapq, hit.c:406-430)
+	if (n < 3 || !any_inv) return;
+	std::vector<Anchor> by_pos;
 	for (int i = 0; i < n; ++i)
-		if (regs[i].parent == i || regs[i].parent < 0) aux.push_back(Anchor{(uint64_t)regs[i].rid << 32 | (uint32_t)regs[i].rs, (uint64_t)i});
-	sort_by_x(aux.data(), aux.data() + aux.size());
-	for (int i = 1; i < (int)aux.size() - 1; ++i) {
-		Reg &inv = regs[aux[i].y];
-		if (inv.inv) {
-			const Reg &l = regs[aux[i - 1].y], &rr = regs[aux[i + 1].y];
-			inv.mapq = l.mapq < rr.mapq ? l.mapq : rr.mapq;
-		}
+		if (regs[i].parent == i || regs[i].parent < 0) by_pos.push_back(Anchor{(uint64_t)regs[i].rid << 32 | (uint32_t)regs[i].rs, (uint64_t)i});
+	sort_by_x(by_pos.data(), by_pos.data() + by_pos.size());
+	for (size_t i = 1; i + 1 < by_pos.size(); ++i) {
+		Reg &mid = regs[by_pos[i].y];
+		if (!mid.inv) continue;
+		const uint32_t left = regs[by_pos[i - 1].y].mapq, right = regs[by_pos[i + 1].y].mapq;
+		mid.mapq = left < right ? left : right;
 	}
 }
 
