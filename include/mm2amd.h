@@ -229,6 +229,7 @@ uint64_t mm_gpu_context_generation(void);        /* of the live context; 0: none
 int mm_gpu_destroy_if(uint64_t generation);      /* 1: it was the live context and is gone now; 0: left alone */
 
 const char *mm2amd_backend_name(void);           /* "hip:gfx950" in the product library */
+int mm2amd_format_fraction(double v, char *buf); /* diagnostics: the output stage's "%.4f" (de:f / dv:f tags; no printf: exact integer arithmetic) into buf[>= 16]; returns the length */
 int mm2amd_last_stats(double *v, int n);         /* per-stage wall times of the last batch (diagnostics) */
 
 /* Per-kernel timing (HIP events on the launch stream) and algorithmic bytes, accumulated while enabled. */

@@ -702,6 +702,7 @@ int mm_gpu_destroy_if(uint64_t generation)
 }
 
 const char *mm2amd_backend_name(void) { return backend_name(); }
+int mm2amd_format_fraction(double v, char *buf) { return buf ? format_fraction_for_test(v, buf) : 0; }
 
 int mm2amd_last_stats(double *v, int n)
 {

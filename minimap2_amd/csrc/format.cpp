@@ -86,18 +86,27 @@ struct alignas(128) Text {
 		n = (size_t)(w - p);
 	}
 	void tag(const char *name, int64_t v) { ch('\t'), str(name), num(v); } // "\tNM:i:" + value
+	// (round 5) the writer of a CIGAR's text also counts its gaps -- what the de:f tag of the same record needs (mm_count_gaps): the record's second and third
+	// walk over the 1400 operations of a 10 kb read were a third of the formatting time
+	struct GapCount { const uint32_t *c = nullptr; uint32_t n = 0; int n_gap = 0, n_gapo = 0; };
+	static GapCount &last_gaps() { thread_local GapCount g; return g; }
 	void cigar(const uint32_t *c, uint32_t n_cigar) // <len><op> per entry
 	{
+		int n_gap = 0, n_gapo = 0;
 		// lengths below 1000 (all but a handful per read) from a table: four bytes stored, the digit count added -- no branch on the number of digits
 		static const struct Small { uint32_t chars[1000]; uint8_t len[1000]; Small() { for (uint32_t x = 0; x < 1000; ++x) { char b[8] = {0}; len[x] = (uint8_t)(put_u32(b, x) - b); memcpy(&chars[x], b, 4); } } } small;
 		char *w = need((size_t)n_cigar * 11 + 4);
 		for (uint32_t k = 0; k < n_cigar; ++k) {
-			const uint32_t x = c[k] >> 4;
+			const uint32_t x = c[k] >> 4, op = c[k] & 0xf;
 			if (x < 1000) memcpy(w, &small.chars[x], 4), w += small.len[x];
 			else w = put_u32(w, x);
-			*w++ = kCigarOps[c[k] & 0xf];
+			*w++ = kCigarOps[op];
+			const uint32_t is_gap = (op - 1u) < 2u; // I or D
+			n_gapo += (int)is_gap, n_gap += (int)(is_gap ? x : 0u);
 		}
 		n = (size_t)(w - p);
+		GapCount &g = last_gaps();
+		g.c = c, g.n = n_cigar, g.n_gap = n_gap, g.n_gapo = n_gapo;
 	}
 };
 
@@ -107,6 +116,8 @@ void count_gaps(const Reg1 &r, int *n_gap, int *n_gapo) // mm_count_gaps (align.
 {
 	*n_gap = *n_gapo = 0;
 	if (!r.p) return;
+	const Text::GapCount &g = Text::last_gaps();
+	if (g.c == r.p->cigar && g.n == r.p->n_cigar) { *n_gap = g.n_gap, *n_gapo = g.n_gapo; return; } // counted while this record's CIGAR text was written
 	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
 		const int op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
 		if (op == 1 || op == 2) ++*n_gapo, *n_gap += len;
@@ -121,9 +132,36 @@ double event_identity(const Reg1 &r) // mm_event_identity (align.c:997-1003)
 	return (double)r.mlen / (r.blen + r.p->n_ambi - n_gap + n_gapo);
 }
 
+// "%.4f" of v in [0, 1] exactly as printf rounds it: the double is M x 2^-k, so v x 10^4 = M x 10^4 / 2^k is an exact 67-bit quotient and remainder -- round to
+// nearest, ties to even on the exact value (what glibc's printf does with its big-number arithmetic).  Anything else goes to snprintf.
+bool put_fraction_exact(Text &o, double v)
+{
+	if (!(v >= 0.0 && v <= 1.0)) return false;
+	uint64_t bits;
+	memcpy(&bits, &v, 8);
+	const int be = (int)(bits >> 52 & 0x7ff);
+	uint64_t M = bits & ((1ull << 52) - 1);
+	int k; // v = M x 2^-k
+	if (be == 0) k = 1074; else M |= 1ull << 52, k = 1075 - be;
+	unsigned q;
+	if (k <= 0) q = (unsigned)(M << -k) * 10000u; // (v == 1.0: M = 2^52, k = 52 -- never here; kept for completeness)
+	else if (k >= 120) q = 0; // below 2^-67: rounds to 0.0000
+	else {
+		const unsigned __int128 N = (unsigned __int128)M * 10000u, one = (unsigned __int128)1 << k;
+		const unsigned __int128 quo = N >> k, rem = N & (one - 1), half = one >> 1;
+		q = (unsigned)quo;
+		if (rem > half || (rem == half && (q & 1u))) ++q;
+	}
+	char *w = o.need(8);
+	w[0] = (char)('0' + q / 10000), w[1] = '.';
+	w[2] = (char)('0' + q / 1000 % 10), w[3] = (char)('0' + q / 100 % 10), w[4] = (char)('0' + q / 10 % 10), w[5] = (char)('0' + q % 10);
+	o.n += 6;
+	return true;
+}
 void put_fraction(Text &o, double v) // "0" or %.4f (format.c:413-414, :418-419)
 {
 	if (v == 0.0) { o.ch('0'); return; }
+	if (put_fraction_exact(o, v)) return;
 	char buf[16];
 	snprintf(buf, 16, "%.4f", v);
 	o.str(buf);
@@ -141,7 +179,7 @@ void put_tags(Text &o, const Reg1 &r) // write_tags
 	if (r.p) {
 		o.str("\tde:f:");
 		const double div = 1.0 - event_identity(r);
-		if (div == 0.0) o.ch('0'); else put_fraction(o, 1.0 - event_identity(r));
+		if (div == 0.0) o.ch('0'); else put_fraction(o, div);
 	} else if (r.div >= 0.0f && r.div <= 1.0f) {
 		o.str("\tdv:f:");
 		if (r.div == 0.0f) o.ch('0'); else put_fraction(o, r.div);
@@ -471,12 +509,23 @@ std::string format_check(const MapOpt &opt)
 }
 
 // the records of fragments [lo, hi), in order (map.c:585-623)
+// mm2amd_format_fraction (diagnostics, include/mm2amd.h): "%.4f" as the output stage writes it
+int format_fraction_for_test(double v, char *buf)
+{
+	Text t;
+	put_fraction(t, v);
+	memcpy(buf, t.data(), t.size());
+	buf[t.size()] = 0;
+	return (int)t.size();
+}
+
 static void format_range(const FlatIndex &fi, const MapOpt &opt, const int *seg_off, const int *n_seg, const Bseq1 *seq, const int *n_reg, void *const *reg,
                          const int *rep_len, long lo, long hi, Text &o)
 {
 	Seqs sq;
 	const int64_t flag = opt.flag;
 	hostprof::Scope hp(hostprof::FORMAT_RANGE);
+	Text::last_gaps() = Text::GapCount(); // (the gap counts kept from a record's CIGAR text are only good while the batch's blocks are alive)
 	for (long f = lo; f < hi; ++f) {
 		const int seg_st = seg_off ? seg_off[f] : (int)f, ns = n_seg ? n_seg[f] : 1;
 		for (int i = seg_st; i < seg_st + ns; ++i) {

@@ -27,4 +27,6 @@ struct FormatScratch {
 const char *format_batch_view(const FlatIndex &fi, const ref::MapOpt &opt, int n_threads, long n_frag, const int *seg_off, const int *n_seg, const ref::Bseq1 *seq, const int *n_reg,
                               void *const *reg, const int *rep_len, FormatScratch &fs, size_t *out_len);
 
+int format_fraction_for_test(double v, char *buf); // "%.4f" as the output stage writes it (mm2amd_format_fraction)
+
 } // namespace mm2amd

@@ -165,3 +165,23 @@ def test_python_stage_run_marshalling_with_a_fake_library(monkeypatch):
     calls["generation"] = 8  # another Aligner / mm_gpu_init replaced the process-wide context: this one must say so, not map on the wrong index
     with pytest.raises(mm.Mm2AmdError, match="no longer the process's active mapper"):
         al.map_batch([("a", b"ACGT")])
+
+
+def test_output_stage_fraction_equals_printf():
+    """the de:f / dv:f tags: "%.4f" written with exact integer arithmetic instead of printf -- every value must come out as printf rounds it
+    (round half to even on the exact binary value), ties included"""
+    import ctypes as C
+    import numpy as np
+    import minimap2_amd as mm
+    L = mm.lib()  # (a host routine: no GPU needed)
+    L.mm2amd_format_fraction.argtypes = [C.c_double, C.c_char_p]
+    L.mm2amd_format_fraction.restype = C.c_int
+    buf = C.create_string_buffer(32)
+    rng = np.random.default_rng(5)
+    vals = list(rng.random(200000)) + list(rng.random(20000) * 1e-3) + [1.0, 0.5, 0.25, 0.03125, 0.09375, 0.00005, 0.00015, 1e-300, 5e-324, 0.99995, 0.999949999, 0.12345, 0.12355]
+    vals += [(2 * j + 1) / 2.0 ** k for k in range(1, 30) for j in range(0, min(2 ** (k - 1), 40))]  # dyadic fractions: the only exact ties
+    vals += [float(np.nextafter(x, 0.0)) for x in (0.00005, 0.12345, 0.5)] + [float(np.nextafter(x, 1.0)) for x in (0.00005, 0.12345, 0.5)]
+    for v in vals:
+        n = L.mm2amd_format_fraction(float(v), buf)
+        want = "0" if v == 0.0 else "%.4f" % v
+        assert buf.value[:n].decode() == want, (v, buf.value, want)
