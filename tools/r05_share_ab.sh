@@ -7,7 +7,5 @@ d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); a=d['config']['a
 print(sys.argv[1].split('/')[-1], 'N1', d['value'], d['ms_per_step'], 'share ms', a['ms_per_step'], 'pred', a['predicted_strong_scaling'], 'cpu/Gb', a['host_cpu_s_per_gbase'])
 PY
 }
-run sb100 MM2AMD_X=1
-run sb32 MM2AMD_SUBBATCH_BASES=32000000
-run sb16 MM2AMD_SUBBATCH_BASES=16000000
-run sb50 MM2AMD_SUBBATCH_BASES=50000000
+run four_a MM2AMD_X=1
+run four_b MM2AMD_X=1
