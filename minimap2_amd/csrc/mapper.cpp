@@ -222,7 +222,8 @@ std::shared_ptr<Mapper::BatchRun> Mapper::make_run(int set)
 		if (n_sub < 2 && tot >= 40000000 && !(opt_.flag & F_SPLICE)) n_sub = 2; // not for spliced reads: their DP launch classes need the whole batch's jobs to hide their tails
 		// (round 5) with the per-read host stages on the device a sub-batch has no host work to hide, only kernel latencies to overlap: a batch of an eighth of
 		// a Gbase -- a rank's share of an 8-GPU job -- maps 4 % faster as four sub-batches than as two (72 against 75 ms, profiles/r05_share_*_v18.json)
-		if (n_sub < 4 && tot >= 80000000 && rgn_ok_ && be_.aligns_regions()) n_sub = 4;
+		static const long min_subs = getenv("MM2AMD_MIN_SUBBATCHES") ? atol(getenv("MM2AMD_MIN_SUBBATCHES")) : 4; // (A/B checks)
+		if (n_sub < min_subs && tot >= 80000000 && rgn_ok_ && be_.aligns_regions()) n_sub = min_subs;
 		if (n_sub > 0) sub_bases = (long)((tot + (uint64_t)n_sub - 1) / (uint64_t)n_sub);
 		// (Staggering the first round's shares so that the lanes fall out of step was measured: 25 % slower.  The lanes' lockstep -- all
 		// seeding, then all in the DP -- is the better regime while the DP kernels are persistent waves that fill every SIMD.)

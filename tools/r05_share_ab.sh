@@ -7,5 +7,8 @@ d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); a=d['config']['a
 print(sys.argv[1].split('/')[-1], 'N1', d['value'], d['ms_per_step'], 'share ms', a['ms_per_step'], 'pred', a['predicted_strong_scaling'], 'cpu/Gb', a['host_cpu_s_per_gbase'])
 PY
 }
-run four_a MM2AMD_X=1
-run four_b MM2AMD_X=1
+run two_1 MM2AMD_MIN_SUBBATCHES=2
+run four_1 MM2AMD_MIN_SUBBATCHES=4
+run two_2 MM2AMD_MIN_SUBBATCHES=2
+run four_2 MM2AMD_MIN_SUBBATCHES=4
+run six_1 MM2AMD_MIN_SUBBATCHES=6
