@@ -617,6 +617,14 @@ def main():
                             "rows": rows, "isa_counts": {"file": "profiles/isa_row_counts.json", "commit": isa.get("commit"), "made_from_the_sources_this_run_uses": isa_current},
                             "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
                             "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / the issue cycles of one register-set row: the hot loop's VALU instructions per row by encoding class (profiles/isa_row_counts.json, counted in the assembly by tools/isa_row_counts.py) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction"}
+            # the same family without the other lanes beside it (the one-lane pass): per-launch durations in the timed steps depend on how many of the eight lanes'
+            # launches of this kernel coincide -- the kernel is VALU-bound, eight coinciding launches each take eight times as long -- so `frac` moves between 0.04
+            # and 0.06 at an unchanged step time; this one does not
+            fam1 = {k: v for k, v in prof1.items() if family(k) == fam}
+            if fam1:
+                ms_f, by_f = sum(v["ms"] for v in fam1.values()), sum(v["alg_bytes"] for v in fam1.values())
+                roof["achieved_unoverlapped"] = round(by_f / max(ms_f * 1e-3, 1e-12) / 1e9, 3)
+                roof["frac_unoverlapped"] = round(by_f / max(ms_f * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS, 6)
             roof["unoverlapped_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof1.items())}
             roof["unoverlapped_alg_bytes"] = {k: round(v["alg_bytes"], 1) for k, v in sorted(prof1.items())}
             roof["unoverlapped_alg_gb_per_s"] = {k: round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in sorted(prof1.items()) if v["alg_bytes"] > 0}
