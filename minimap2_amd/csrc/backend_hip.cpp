@@ -5,6 +5,7 @@
 // seed_chain()/ksw() on independent LANES: each lane owns a HIP stream and its device/pinned work buffers, so several host
 // driver threads can keep different sub-batches in flight and the GPU stages of one overlap the host stages of another.
 #include <atomic>
+#include <condition_variable>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -659,7 +660,10 @@ public:
 				for (size_t j = 0; j < n_jobs; ++j) out.dp_cells += (double)hj[j].qlen * hj[j].tlen;
 				ln.ksw.run_jobs(hj, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st);
 			} else {
-				ln.ksw.run_jobs(nullptr, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st, ln.d_rg_jobs.p);
+				{
+					DpGate gate(*this); // at most MM2AMD_DP_GATE lanes (default 4) in their DP launches at once
+					ln.ksw.run_jobs(nullptr, n_jobs, R.d_qpool.p, nullptr, T_->S.p, sc, nullptr, &d_cigar, &n_cig, st, ln.d_rg_jobs.p);
+				}
 				out.dp_cells += ln.ksw.last_cells;
 			}
 		}
@@ -768,6 +772,19 @@ public:
 	}
 
 private:
+	// At most dp_gate_ lanes between the ordering of their DP batch and its last kernel (0: no limit).  The DP kernels are VALU-bound persistent launches: eight that
+	// coincide share the SIMDs round-robin and ALL finish late; admitted four at a time the first ones finish early and their lanes go on to consume, finish and the next
+	// sub-batch's seeding while the others compute.  Measured (calls 23-24, 8-step runs in one call each): no gate 2.24-2.28 Gbases/s with 47-52 ms per streaming
+	// launch, four lanes 2.30 / 2.30 with 29-34 ms, two lanes 2.22-2.28 with 18-21 ms, one lane 2.08.  (Round 2's stage gates serialised ALL GPU stages of the lanes
+	// and lost 7-18 %; this one leaves seeding, chaining and the region kernels free to run beside the DP.)
+	struct DpGate {
+		HipBackend &b;
+		explicit DpGate(HipBackend &be) : b(be) { if (b.dp_gate_ > 0) { std::unique_lock<std::mutex> lk(b.gate_mu_); b.gate_cv_.wait(lk, [&] { return b.gate_in_ < b.dp_gate_; }); ++b.gate_in_; } }
+		~DpGate() { if (b.dp_gate_ > 0) { { std::lock_guard<std::mutex> lk(b.gate_mu_); --b.gate_in_; } b.gate_cv_.notify_one(); } }
+	};
+	int dp_gate_ = getenv("MM2AMD_DP_GATE") ? atoi(getenv("MM2AMD_DP_GATE")) : 4, gate_in_ = 0;
+	std::mutex gate_mu_;
+	std::condition_variable gate_cv_;
 	hipStream_t stream_ = nullptr;
 	int n_threads_ = 1, n_cu_ = 256, n_lanes_ = 1, rid_bits_ = 1, dev_ = 0, replica_ = 0;
 	std::atomic<int> active_lanes_{1};
