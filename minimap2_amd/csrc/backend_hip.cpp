@@ -634,6 +634,7 @@ public:
 		B.a_src[0] = ln.d_bt_out_a.p, B.a_src[1] = ln.d_lj_out_a.p, B.u_src[0] = ln.d_bt_out_u.p, B.u_src[1] = ln.d_lj_out_u.p;
 		B.mini_pos = ln.d_minipos.p, B.sq_a = ln.d_rg_sq.p, B.regs = ln.d_rg_regs.p, B.aux = ln.d_rg_aux.p, B.rout = ln.d_rg_rout.p, B.cursors = ln.d_rg_cur.p;
 		B.ref_len = d_ref_len2_.p, B.ref_off = d_ref_off_.p, B.max_regs = max_regs;
+		B.qpool = R.d_qpool.p, B.S = T_->S.p;
 		B.lds_chains = std::min(256, (max_nu + 63) / 64 * 64);
 		B.plan = ln.d_rg_plan.p, B.win = ln.d_rg_win.p, B.jobs = ln.d_rg_jobs.p, B.gap_sites = ln.d_rg_sites.p, B.max_jobs = (uint32_t)max_jobs64;
 		B.fin = ln.d_rg_fin.p, B.pieces = ln.d_rg_pieces.p;

@@ -39,13 +39,14 @@ double thr_now() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); ret
 
 // Backend::align_regions takes single-segment reads of the plain long-read configurations: dual- or single-affine DNA alignment with CIGARs.  What it leaves
 // to the host path -- each a rule the device kernels do not carry: spliced and short-read alignment (two strands per region, ungapped shortcuts, composed
-// targets), query-strand coordinates, =/X CIGARs, chains reported as hits, ALT contigs, junction / jump annotation, homopolymer-compressed minimizers (the
-// window boundary walks the sequences), and the re-seeding of reads without chains (-f x,y: map.c:293-316).
+// targets), query-strand coordinates, =/X CIGARs, chains reported as hits, ALT contigs, junction / jump annotation, and the re-seeding of reads without chains
+// (-f x,y: map.c:293-316).
 bool region_path_supported(const MapOpt &opt, int idx_flag, int n_alt, bool has_annotation)
 {
 	if (!(opt.flag & F_CIGAR)) return false;
 	if (opt.flag & (F_SPLICE | F_SR | F_SR_RNA | F_QSTRAND | F_EQX | F_ALL_CHAINS)) return false;
-	if (n_alt > 0 || has_annotation || (idx_flag & I_HPC)) return false;
+	if (n_alt > 0 || has_annotation) return false;
+	(void)idx_flag; // (round 5, late: homopolymer-compressed indices take the device path too -- region_plan_kernel's window boundaries, the summed minimizer spans)
 	if (opt.max_occ > opt.mid_occ && !(opt.flag & F_RMQ)) return false;
 	if (opt.split_prefix) return false;
 	return true;
@@ -74,7 +75,7 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 		O.bw_ext = (int)(opt.bw * 1.5 + 1.), O.bw_gap = (int)(opt.bw_long * 1.5 + 1.);
 		if (O.bw_gap < O.bw_ext) O.bw_gap = O.bw_ext;
 		O.a = opt.a, O.b = opt.b, O.q = opt.q, O.e = opt.e, O.zdrop = opt.zdrop, O.zdrop_inv = opt.zdrop_inv, O.end_bonus = opt.end_bonus, O.min_ksw_len = opt.min_ksw_len;
-		O.transition = opt.transition;
+		O.transition = opt.transition, O.hpc = (fi.flag & I_HPC) ? 1 : 0;
 		rgn_ok_ = region_path_supported(opt, fi.flag, fi.n_alt, fi.has_junc || fi.has_jump || fi.has_spsc);
 	}
 	// MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
@@ -338,7 +339,8 @@ void Mapper::device_hits(const Backend::RegionBatchOut &rb, const ReadChains &c,
 	const RgnReadOut &ro = rb.reads[i];
 	if (ro.n_regs <= 0) return;
 	regs.reserve((size_t)ro.n_regs);
-	const float avg_k = c.n_mp > 0 ? (float)((uint64_t)c.n_mp * (uint64_t)fi_.k) / c.n_mp : 0.0f; // esterr.c:37-40 (every span is k: no HPC on this path)
+	const float avg_k = ro.avg_k; // esterr.c:37-40: the mean minimizer span, as chain_regs_kernel computed it (with an HPC index the spans are summed: the positions stay on the device)
+	(void)c;
 	constexpr uint32_t kHdr = sizeof(Extra) / 4;
 	for (int32_t p = 0; p < ro.n_regs; ++p) {
 		const uint32_t slot = ro.reg0 + (uint32_t)p;

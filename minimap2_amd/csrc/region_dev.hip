@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 
 	const RgnRead rd = B.reads[rd_i];
 	RgnReadOut out;
-	out.reg0 = 0, out.n_regs = 0, out.n_a_sq = 0, out.flags = 0;
+	out.reg0 = 0, out.n_regs = 0, out.n_a_sq = 0, out.flags = 0, out.avg_k = 0.0f, out.pad = 0;
 	const int n = rd.n_u;
 	if ((rd.src & RGN_SRC_SKIP) || n > C || n == 0) {
 		if (rd.src & RGN_SRC_SKIP) out.flags = RGN_F_SKIPPED;
@@ -136,7 +136,14 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	// is one binary search per anchor, and the walk stops at the first anchor that is not found.
 	const uint64_t *mp = B.mini_pos + rd.mp_off;
 	const int n_mp = rd.n_mp;
-	const float avg_k = n_mp > 0 ? (float)((uint64_t)n_mp * (uint64_t)O.k) / n_mp : 0.0f; // (every span is k without HPC: the quotient the reference computes from the sum)
+	// (esterr.c:37-40: the mean minimizer span -- k for every one of them without HPC; with it the spans are summed, by all lanes)
+	uint64_t sum_k = (uint64_t)n_mp * (uint64_t)O.k;
+	if (O.hpc) {
+		int part = 0;
+		for (int i = lane; i < n_mp; i += 64) part += (int)(mp[i] >> 32 & 0xff);
+		sum_k = (uint64_t)(uint32_t)rg_wave_sum(part);
+	}
+	const float avg_k = n_mp > 0 ? (float)sum_k / n_mp : 0.0f;
 	for (int p = 0; p < m; ++p) {
 		const Reg1 r = s_reg[p];
 		int n_match = 0, n_tot = -1;
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 			B.plan[reg0 + p] = pl;
 		}
 	} else out.flags = RGN_F_MANY_CHAINS; // (cannot happen: the host sizes the arrays by the chain count)
-	out.reg0 = reg0, out.n_regs = m, out.n_a_sq = s_hdr[2];
+	out.reg0 = reg0, out.n_regs = m, out.n_a_sq = s_hdr[2], out.avg_k = avg_k;
 	if (lane == 0) B.rout[rd_i] = out;
 }
 
@@ -312,6 +319,24 @@ __device__ __forceinline__ int rg_ext_reach(int l, const RgnOpts &O)
 
 struct RgnJobCtx { uint64_t q_fwd, q_rev, t_base; int rev, gen_flag; };
 
+// where an anchor's window boundary sits (mm_adjust_minier, align.c:418-433): the middle of the k-mer -- or, with a homopolymer-compressed index, the start of the
+// homopolymer run that holds the anchor's last base, on the query strand being aligned and on the reference
+__device__ __forceinline__ void rg_boundary(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, const Anchor &c, int32_t *r, int32_t *q)
+{
+	if (!O.hpc) { *r = rg_x(c) - (O.k >> 1), *q = rg_y(c) - (O.k >> 1); return; }
+	const uint8_t *qs = B.qpool + (X.rev ? X.q_rev : X.q_fwd);
+	int32_t i = rg_y(c);
+	const int cq = qs[i];
+	for (--i; i > 0; --i) if (qs[i] != cq) break;
+	*q = i + 1;
+	const int64_t x = rg_x(c);
+	auto base = [&](int64_t p) -> int { const uint64_t o = X.t_base + (uint64_t)p; return (int)(B.S[o >> 3] >> ((o & 7) << 2) & 0xf); };
+	const int cb = base(x);
+	int64_t j = x - 1;
+	for (; j >= 0; --j) if (base(j) != cb) break;
+	*r = rg_x(c) + 1 - (int32_t)(x - j);
+}
+
 __device__ __forceinline__ void rg_emit(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, uint32_t idx, int kind, int qs, int qe, int rs, int re, int bw, int anchor_i,
                                         int flag, int zdrop, int end_bonus)
 {
@@ -337,7 +362,7 @@ __device__ __forceinline__ void rg_emit(const RgnBuffers &B, const RgnOpts &O, c
 // The window walk of mm_align1 (align.c:803-846) by the wave: the walk's state is where the last window ended; 64 anchors are tested against it at once, the first
 // one that closes a window is found by a ballot, and the lanes after it are tested again against the new state.  emit == false only counts.
 template <bool EMIT>
-__device__ int rg_walk_windows(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, const Anchor *a, int cnt1, int half, int32_t rs, int32_t qs, uint32_t idx0, int lane)
+__device__ int rg_walk_windows(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, const Anchor *a, int cnt1, int32_t rs, int32_t qs, uint32_t idx0, int lane)
 {
 	int32_t cs = rs, cq = qs;
 	int n = 0;
@@ -348,8 +373,9 @@ __device__ int rg_walk_windows(const RgnBuffers &B, const RgnOpts &O, const RgnJ
 		bool cand = false;
 		if (i < cnt1) {
 			const Anchor c = a[i];
-			y = c.y, e_r = rg_x(c) - half, e_q = (int32_t)y - half;
+			y = c.y;
 			cand = !((y & (ref::SEED_IGNORE | ref::SEED_TANDEM)) && i != cnt1 - 1);
+			if (cand) rg_boundary(B, O, X, c, &e_r, &e_q);
 		}
 		unsigned long long live = ~0ull; // lanes not yet passed by a closed window
 		for (;;) {
@@ -404,10 +430,12 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 		if (lane == 0) rg_join_gap_clusters(a + as1, n30, K, O.max_gap >> 1);
 		RG_SYNC(); // (the flags lane 0 set in the anchors are read by all lanes below)
 	}
-	// a window boundary sits in the middle of an anchor's k-mer (mm_adjust_minier without HPC, align.c:429-432)
-	const int half = O.k >> 1;
-	const int32_t rs = rg_x(a[as1]) - half, qs = rg_y(a[as1]) - half;
-	const int32_t re = rg_x(a[as1 + cnt1 - 1]) - half, qe = rg_y(a[as1 + cnt1 - 1]) - half;
+	RgnJobCtx X;
+	X.q_fwd = rd.qpool_fwd, X.q_rev = rd.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
+	X.gen_flag = O.transition != 0 && O.b != O.transition ? KSW_GENERIC_SC : 0; // align.c:347-348
+	int32_t rs, qs, re, qe; // the boundaries of the first and the last anchor (mm_adjust_minier, align.c:418-433)
+	rg_boundary(B, O, X, a[as1], &rs, &qs);
+	rg_boundary(B, O, X, a[as1 + cnt1 - 1], &re, &qe);
 
 	// how far the two extensions may reach (align.c:706-767): lane 0
 	int32_t rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
@@ -468,11 +496,8 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 	}
 	rs0 = __shfl(rs0, 0, 64), qs0 = __shfl(qs0, 0, 64), re0 = __shfl(re0, 0, 64), qe0 = __shfl(qe0, 0, 64);
 	// the windows, in the order the reference aligns them (align.c:779-890): counted first, so that the region's jobs are one dense run
-	RgnJobCtx X;
-	X.q_fwd = rd.qpool_fwd, X.q_rev = rd.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
-	X.gen_flag = O.transition != 0 && O.b != O.transition ? KSW_GENERIC_SC : 0; // align.c:347-348
 	const bool has_left = qs > 0 && rs > 0;
-	const int n_gap_win = rg_walk_windows<false>(B, O, X, a + as1, cnt1, half, rs, qs, 0, lane);
+	const int n_gap_win = rg_walk_windows<false>(B, O, X, a + as1, cnt1, rs, qs, 0, lane);
 	// (the right extension exists when the LAST gap window's end -- the last anchor's boundary, or the first one's when there is a single anchor -- lies inside the limits)
 	const bool has_right = qe < qe0 && re < re0;
 	const int n_win = (has_left ? 1 : 0) + n_gap_win + (has_right ? 1 : 0);
@@ -483,7 +508,7 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 	if (job0 + (uint32_t)n_win > B.max_jobs) { pl.status = RGN_F_MULTI_ROUND, pl.n_win = 0; if (lane == 0) B.plan[slot] = pl; return; } // (cannot happen: sized by anchors + 2 per chain)
 	uint32_t idx = job0;
 	if (has_left) { if (lane == 0) rg_emit(B, O, X, idx, 0, qs0, qs, rs0, rs, O.bw_ext, 0, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, r.split_inv ? O.zdrop_inv : O.zdrop, O.end_bonus); ++idx; }
-	idx += (uint32_t)rg_walk_windows<true>(B, O, X, a + as1, cnt1, half, rs, qs, idx, lane);
+	idx += (uint32_t)rg_walk_windows<true>(B, O, X, a + as1, cnt1, rs, qs, idx, lane);
 	if (has_right && lane == 0) rg_emit(B, O, X, idx, 2, qe, qe0, re, re0, O.bw_ext, 0, KSW_EXTZ_ONLY, O.zdrop, O.end_bonus);
 	if (lane == 0) B.plan[slot] = pl;
 }

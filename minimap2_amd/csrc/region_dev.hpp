@@ -37,6 +37,7 @@ struct RgnOpts {              // uniform over a launch: what the per-read code r
 	int max_gap, min_cnt, min_chain_score, bw;
 	int bw_ext, bw_gap;       // (int)(bw * 1.5 + 1.), and the same of bw_long, at least bw_ext (align.c:676-678)
 	int a, b, q, e, zdrop, zdrop_inv, end_bonus, min_ksw_len, transition;
+	int hpc;                  // mm_idx_t::flag & MM_I_HPC: window boundaries sit at the start of a homopolymer run (mm_adjust_minier, align.c:418-428), minimizer spans vary
 };
 
 enum : uint32_t {             // RgnRead::src
@@ -57,7 +58,7 @@ struct RgnRead {              // per read of the sub-batch, made by the host fro
 	uint32_t hash, src;       // map.c:246-248; RGN_SRC_*
 };
 
-struct RgnReadOut { uint32_t reg0; int32_t n_regs, n_a_sq; uint32_t flags; };
+struct RgnReadOut { uint32_t reg0; int32_t n_regs, n_a_sq; uint32_t flags; float avg_k; uint32_t pad; }; // avg_k: the mean minimizer span mm_est_err divides by (esterr.c:37-40)
 
 struct RgnAux { int32_t n_match, n_tot; };   // mm_est_err's counts (esterr.c:46-60); n_tot < 0: the hit keeps div = -1
 
@@ -90,6 +91,8 @@ struct RgnBuffers {           // device pointers of one sub-batch
 	unsigned int *cursors;    // RGN_CUR_*
 	const uint32_t *ref_len;  // reference sequence lengths and offsets (bases) in the packed sequence
 	const uint64_t *ref_off;
+	const uint8_t *qpool;     // the reads' nt4 codes (forward | reverse complement) and the packed reference: what an HPC window boundary looks at
+	const uint32_t *S;
 	uint32_t max_regs;        // capacity of regs / aux / plan / fin
 	int lds_chains;           // chains per read the kernel keeps in LDS (multiple of 64)
 	// planning

@@ -143,3 +143,19 @@ def test_long_reads_beyond_the_finish_kernels_lds_are_handed_back():
     got, st = _map(refs, rds, "map-ont", names)
     assert got == reflib.ref_map_reads(refs, rds, "map-ont", names=names)
     assert st["n_region_reads_host"] >= 2 and st["n_region_reads_dev"] >= 10, st
+
+
+def test_homopolymer_compressed_index_on_the_device():
+    """map-pb (an HPC index): the window boundaries sit at homopolymer-run starts (mm_adjust_minier, align.c:418-428) and mm_est_err's mean span is a sum
+    over the read's minimizers -- both on the device since round 5; the reads must be finished there and equal the reference's hits"""
+    rng = np.random.default_rng(37)
+    contigs = synth.gen_reference(rng, 1000000, 2)
+    for c in contigs:  # homopolymer runs, so that compressed and plain coordinates differ
+        for p in rng.integers(0, len(c) - 20, 4000):
+            c[p:p + int(rng.integers(2, 9))] = c[p]
+    reads = synth.gen_reads(rng, contigs, 40, 5000, 1500, 0.1)
+    refs, names = [synth.ACGT[c].tobytes() for c in contigs], ["chr1", "chr2"]
+    rds = _codes_to_reads(reads)
+    got, st = _map(refs, rds, "map-pb", names)
+    assert got == reflib.ref_map_reads(refs, rds, "map-pb", names=names)
+    assert st["n_region_reads_dev"] >= 0.8 * len(rds), st
