@@ -22,7 +22,7 @@ int main(int argc, char *argv[])
 	mm_idxopt_t iopt;
 	mm_mapopt_t mopt;
 	const char *preset = 0;
-	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, staged = 0, one_by_one = 0, old_best_n = -1;
+	int n_threads = 3, i, k = 1, print_stats = 0, format_lib = 0, staged = 0, one_by_one = 0, batch_with = 0, old_best_n = -1;
 	const char *alt_fn = 0, *junc_fn = 0, *jump_fn = 0, *pass1_fn = 0, *spsc_fn = 0;
 	float spsc_scale = 0.7f;
 	int64_t batch = 500000000;
@@ -43,6 +43,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "-s") == 0) mopt.min_dp_max = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--seed") == 0) mopt.seed = atoi(argv[++k]);
 		else if (strcmp(argv[k], "--stats") == 0) print_stats = 1;
+		else if (strcmp(argv[k], "--batch-with") == 0) batch_with = 1; /* no mm_gpu_init: every batch through mm_gpu_map_batch_with(mi, &mopt, ...), which builds the context on first use */
 		else if (strcmp(argv[k], "--one-by-one") == 0) one_by_one = 1; /* mm_gpu_map / mm_gpu_map_frag per fragment instead of one mm_gpu_map_batch */
 		else if (strcmp(argv[k], "-O") == 0) { char *s; mopt.q = mopt.q2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.q2 = strtol(s + 1, &s, 10); }
 		else if (strcmp(argv[k], "-E") == 0) { char *s; mopt.e = mopt.e2 = strtol(argv[++k], &s, 10); if (*s == ',') mopt.e2 = strtol(s + 1, &s, 10); }
@@ -149,7 +150,9 @@ int main(int argc, char *argv[])
 		if (spsc_fn) mm_idx_spsc_read2(mi, spsc_fn, mm_max_spsc_bonus(&mopt), spsc_scale); /* main.c:483 */
 		if (alt_fn) mm_idx_alt_read(mi, alt_fn); /* main.c:480 */
 		setenv("MM2AMD_MALLOPT", "1", 0); /* this driver owns its process: let the library tune glibc malloc */
-		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
+		if (batch_with) {
+			/* the context comes from the first mm_gpu_map_batch_with call (default host pool) */
+		} else if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
 		/* one read file, or two for paired-end reads (worker_pipeline step 0, map.c:545-569) */
 		/* without MM_F_FRAG_MODE several query files are mapped one after the other (main.c:493-500) */
 		int n_files = argc - (k + 1) >= 2 ? 2 : 1, file0;
@@ -185,6 +188,11 @@ int main(int argc, char *argv[])
 			} else if (staged) {
 				if (mm_gpu_batch_stage(n_frag, seg_off, n_seg, seq) != 0 || mm_gpu_map_staged(n_reg, (void**)reg, rep_len, frag_gap) != 0) {
 					fprintf(stderr, "staged mapping: %s\n", mm2amd_last_error());
+					return 2;
+				}
+			} else if (batch_with) {
+				if (mm_gpu_map_batch_with(mi, &mopt, n_frag, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {
+					fprintf(stderr, "mm_gpu_map_batch_with: %s\n", mm2amd_last_error());
 					return 2;
 				}
 			} else if (mm_gpu_map_batch(n_frag, seg_off, n_seg, seq, n_reg, (void**)reg, rep_len, frag_gap) != 0) {

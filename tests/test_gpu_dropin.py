@@ -105,6 +105,18 @@ def test_one_by_one_calls_on_gpu(tmp_path):
     assert got == open(os.path.join(HERE, "golden", "inv_paf.out"), "rb").read()
 
 
+def test_batch_call_that_names_its_index_and_options(tmp_path):
+    """mm_gpu_map_batch_with(mi, opt, ...) (SURVEY.md 8(b)(2) as written; include/mm2amd.h): no mm_gpu_init, the context is built by the
+    first batch and reused by the following ones == the reference, single reads and read pairs"""
+    ref, reads, _, _ = synth.make("ont", str(tmp_path), 1, 40, 72)
+    want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "4", "-a", "-K", "100000", ref, reads])
+    got, err = _run([DROPIN, "-x", "map-ont", "-t", "4", "-a", "-K", "100000", "--batch-with", "--stats", ref, reads])
+    assert err.count("backend=hip:gfx950") >= 2  # several mini-batches through the one context
+    assert got == want
+    got, _ = G.run_fixture(DROPIN, "inv_paf", ["--batch-with"])
+    assert got == open(os.path.join(HERE, "golden", "inv_paf.out"), "rb").read()
+
+
 def test_anchor_sort_classes_and_chain_fill_variants(tmp_path):
     """anchor_sort_kernel's launch classes (256 / 512 / 1024 threads in LDS, 1024 threads on global scratch: MM2AMD_SORT_MIN_CLASS pushes small
     reads through the large ones) with and without duplicated keys, and chain_fill_kernel with its LDS window against the all-global variant"""
@@ -333,7 +345,7 @@ def test_failed_batch_falls_back_to_the_reference_path(tmp_path):
     ref, reads, _, _ = synth.make("ont", str(tmp_path), 2, 60, 21)
     pipe = os.path.join(HERE, "_build", "dropin_pipeline_emu" if EMU else "dropin_pipeline_gpu")
     want, _ = _run([REF_BIN, "-x", "map-ont", "-t", "4", "-a", ref, reads])
-    p = subprocess.run([pipe, "-x", "map-ont", "-t", "4", "-a", "-K", "100k", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    p = subprocess.run([pipe, "-x", "map-ont", "-t", "4", "-a", "-K", "100000", ref, reads], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=dict(os.environ, MM2AMD_INJECT_BATCH_FAILURE="2"))
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert p.stderr.decode().count("mapped by the reference's own path") == 1
