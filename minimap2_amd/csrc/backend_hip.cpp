@@ -318,8 +318,9 @@ public:
 		HIP_CHECK(hipMemcpyAsync(ln.d_a_off.p, h_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
 		HIP_CHECK(hipMemcpyAsync(ln.d_mp_off.p, h_off + n + 1, (n + 1) * 8, hipMemcpyHostToDevice, st));
 		ln.d_anchors.ensure(n_a + 1), ln.d_minipos.ensure(n_mp + 1), ln.d_f.ensure(n_a + 1), ln.d_p.ensure(n_a + 1), ln.d_t.ensure(n_a + 1);
-		ln.d_skey_in.ensure(n_a + 1), ln.d_sval_in.ensure(n_a + 1), ln.d_skey_out.ensure(n_a + 1), ln.d_sval_out.ensure(n_a + 1), ln.d_tie.ensure(n);
+		ln.d_skey_in.ensure(n_a + 1), ln.d_sval_in.ensure(n_a + 1), ln.d_skey_out.ensure(n_a + 1), ln.d_sval_out.ensure(n_a + 1), ln.d_tie.ensure(2 * n + 1);
 		B.sort_key_in = ln.d_skey_in.p, B.sort_val_in = ln.d_sval_in.p, B.sort_key_out = ln.d_skey_out.p, B.sort_val_out = ln.d_sval_out.p, B.tie_flag = ln.d_tie.p;
+		B.tie_list = ln.d_tie.p + n, B.tie_count = ln.d_tie.p + 2 * n;
 		B.rid_bits = rid_bits_;
 		// the per-read anchor sort's launch classes (by anchors per read): the reads of a class are listed together
 		int n_class[kAnchorSortClasses] = { 0 }, class_first[kAnchorSortClasses + 1] = { 0 };
@@ -339,6 +340,14 @@ public:
 		// 3. anchors: expand, sort, chain
 		kp.begin(st); launch_seed_expand(B, I_, P, st); kp.end(st, "seed_expand_kernel", 24.0 * n_a);
 		launch_anchor_sort(B, I_, P, ln.d_sort_list.p, n_class, a_class, st, &kp);
+		if (getenv("MM2AMD_TIE_COUNT")) { // diagnostics: how many reads of this sub-batch had two anchors with the same x (the replayed ones)
+			std::vector<uint32_t> tf(n);
+			stream_wait(st);
+			HIP_CHECK(hipMemcpy(tf.data(), ln.d_tie.p, n * 4, hipMemcpyDeviceToHost));
+			size_t n_tied = 0;
+			for (size_t i = 0; i < n; ++i) n_tied += tf[i] != 0;
+			fprintf(stderr, "[mm2amd] anchor sort: %zu of %zu reads have duplicated keys (%d / %d / %d reads in the 7 k / 10 k / global classes)\n", n_tied, n, n_class[3], n_class[4], n_class[5]);
+		}
 		if (const char *dump = getenv("MM2AMD_SEED_DUMP")) { // diagnostics: every read's sorted anchors, as the reference's --print-seeds prints them (map.c:255-260)
 			std::vector<Anchor> all(n_a + 1);
 			stream_wait(st);

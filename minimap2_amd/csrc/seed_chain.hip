@@ -839,6 +839,16 @@ __device__ void lds_radix_sort(uint64_t *E, int32_t n, int key_bits, uint32_t *t
 	}
 }
 
+// LDS of the replay's tape walk (anchor_sort_ties_kernel): see "the walk over tapes" in tie_exact_replay
+struct TapeScratch { // (passed by value: the kernel's LDS pointers stay LDS pointers -- ds_read / ds_write, not flat accesses -- after inlining)
+	uint16_t *pos = nullptr;  // [cap] a tape entry's position in the range being partitioned
+	uint16_t *via = nullptr;  // [cap] the entry whose slot the entry's element ends up taking
+	uint8_t *dig = nullptr;   // [cap] the bucket the entry's element belongs to
+	uint32_t *tab = nullptr;  // [3 * 256 + 32]: first entry / end / entries taken before the bucket's own turn, per bucket; a control word; one word per wave; the buckets with a tape, one bit each
+	int cap = 0;              // 0: no tapes, partitions are walked by one thread (tapes need a workgroup of at least 256 threads)
+};
+constexpr int TAPE_MIN_LEN = 96; // shorter ranges: the one-thread walk costs less than the tape's passes
+
 // Workgroup-cooperative, permutation-exact replay of radix_sort_128x (ksort.h:101-151) restricted to what can matter.
 //
 // s[0..n) holds the keys in the ORIGINAL (pre-sort) order with their original indices.  The reference's MSD radix sort partitions a
@@ -851,7 +861,7 @@ __device__ void lds_radix_sort(uint64_t *E, int32_t n, int key_bits, uint32_t *t
 // memory after a barrier.
 template <class S, int TWO_PER = 1>
 __device__ __forceinline__ void tie_exact_replay(S s, int32_t n, const uint64_t *tied, int n_tied, bool replay_all, uint32_t *cnt, uint32_t *head, uint32_t *start, uint32_t *child_mask,
-                                 TieFrame *stack, int stack_cap, uint32_t *two_scratch = nullptr, int two_cap = 0)
+                                 TieFrame *stack, int stack_cap, uint32_t *two_scratch = nullptr, int two_cap = 0, const TapeScratch tape = TapeScratch())
 {
 	// two_scratch / two_cap: LDS words for the two-bucket closed form below (20 control words, then two_cap positions as 16-bit entries); none: always walk
 	// TWO_PER: elements a thread holds in registers in the closed form (the caller's class: anchors per read / threads)
@@ -888,19 +898,33 @@ __device__ __forceinline__ void tie_exact_replay(S s, int32_t n, const uint64_t 
 				if ((fr.shift >= 56 ? 0 : tied[t] >> (fr.shift + 8)) == prefix) { const uint32_t d = (uint32_t)(tied[t] >> fr.shift & 255); atomicOr(&child_mask[d >> 5], 1u << (d & 31)); }
 		}
 		__syncthreads();
-		if (tid == 0) {
+		if (tid < 64) { // the first wavefront: bucket starts and ends from the 256 counts, four per lane (one thread's loop over them cost 70 k cycles a range)
+			const int l4 = tid * 4;
+			const uint32_t a0 = cnt[l4], a1 = cnt[l4 + 1], a2 = cnt[l4 + 2], a3 = cnt[l4 + 3];
+			const uint32_t sum = a0 + a1 + a2 + a3, excl = wave_prefix_add_u32(sum) - sum;
+			const uint32_t m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
+			const uint32_t mx = (uint32_t)lane_get_i32(wave_prefix_max_i32((int32_t)(m01 > m23 ? m01 : m23)), 63);
+			const uint32_t n_nonempty = (uint32_t)lane_get_i32((int32_t)wave_prefix_add_u32((a0 != 0) + (a1 != 0) + (a2 != 0) + (a3 != 0)), 63);
+			const unsigned long long nz = __ballot(sum != 0); // (not 0: the range is not empty)
+			const int first_lane = __builtin_ffsll((long long)nz) - 1, last_lane = 63 - __builtin_clzll(nz);
+			const uint32_t dA = (uint32_t)lane_get_i32(l4 + (a0 ? 0 : a1 ? 1 : a2 ? 2 : 3), first_lane); // the first and the last bucket in use
+			const uint32_t dB = (uint32_t)lane_get_i32(l4 + (a3 ? 3 : a2 ? 2 : a1 ? 1 : 0), last_lane);
+			MM2_LOCKSTEP();
+			start[l4] = head[l4] = excl, cnt[l4] = excl + a0; // cnt becomes the bucket end
+			start[l4 + 1] = head[l4 + 1] = excl + a0, cnt[l4 + 1] = excl + a0 + a1;
+			start[l4 + 2] = head[l4 + 2] = excl + a0 + a1, cnt[l4 + 2] = excl + a0 + a1 + a2;
+			start[l4 + 3] = head[l4 + 3] = excl + a0 + a1 + a2, cnt[l4 + 3] = excl + sum;
+			WAVE_SYNC();
+		  if (tid == 0) {
 			// (measured: the same walk as wave-scalar code with the bucket heads in registers -- v_readlane / v_writelane instead of the LDS
 			// tables -- was 35 % slower: the chain is one LDS round trip per element either way, and the scalar round trips cost more than
 			// the table reads they replace)
-			uint32_t acc = 0, mx = 0, n_nonempty = 0, dA = 0, dB = 0;
-			for (int k = 0; k < 256; ++k) {
-				if (cnt[k]) { if (n_nonempty == 0) dA = (uint32_t)k; else dB = (uint32_t)k; ++n_nonempty; }
-				start[k] = head[k] = acc; acc += cnt[k]; mx = cnt[k] > mx ? cnt[k] : mx; cnt[k] = acc; // cnt becomes the bucket end
-			}
 			// exactly two buckets (always so at the top: the strand bit): the walk's result has a closed form, computed by all threads below
 			const bool two = two_scratch && n_nonempty == 2 && len <= nt * TWO_PER && (int32_t)(cnt[dA] - start[dA] < cnt[dB] - start[dB] ? cnt[dA] - start[dA] : cnt[dB] - start[dB]) <= two_cap;
 			if (two_scratch) two_scratch[0] = two ? 1u : 0u, two_scratch[1] = dA, two_scratch[2] = dB, two_scratch[3] = cnt[dA] - start[dA];
-			if (!two && (int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
+			const bool by_tape = tape.cap > 0 && !two && (int32_t)mx != len && len >= TAPE_MIN_LEN && len <= nt * TWO_PER && len <= tape.cap;
+			if (tape.cap > 0) tape.tab[768] = by_tape ? 1u : 0u;
+			if (!two && !by_tape && (int32_t)mx != len) { // not all in one bucket: the cycle-leader walk (ksort.h:126-138)
 				for (int k = 0; k < 256;) {
 					if (head[k] != cnt[k]) {
 						int l = (int)(s.xkey(fr.b + (int32_t)head[k]) >> fr.shift & 255);
@@ -919,6 +943,7 @@ __device__ __forceinline__ void tie_exact_replay(S s, int32_t n, const uint64_t 
 					} else ++k;
 				}
 			}
+		  }
 		}
 		__syncthreads();
 		if (two_scratch && two_scratch[0]) {
@@ -994,17 +1019,145 @@ __device__ __forceinline__ void tie_exact_replay(S s, int32_t n, const uint64_t 
 			}
 			__syncthreads();
 		}
+		if (tape.cap > 0 && tape.tab[768]) {
+			// The walk over tapes.  What the cycle-leader walk (ksort.h:126-138) does, bucket by bucket: in bucket l's part of the range call the
+			// elements that belong elsewhere foreign; their (position, bucket) pairs, in position order, are l's TAPE.  The walk is then: at the
+			// base bucket k (0, 1, 2, ... in turn) take the next entry of k's tape, follow the element to its bucket d, where it takes the place
+			// of the next entry of d's tape, whose element travels on the same way, until one that belongs to k turns up and closes the cycle
+			// in the slot the cycle started from.  In a bucket that is not the base an arriving element is put at the bucket's head and the
+			// bucket's own elements between the head and the displaced foreign one each move one slot on (x_1 N_0 x_2 N_1 ...: the j-th arrival
+			// lands right after the (j-1)-th foreign slot, the first at the bucket's start); in the base bucket own elements stay and an arrival
+			// takes the foreign slot itself.  So the only sequential part is which entry's slot each travelling element consumes -- one LDS round
+			// trip per element over byte-sized tapes (thread 0) -- and the tapes before it and all the moves after it are done by the whole
+			// workgroup.
+#ifdef MM2AMD_WAVE_EMU
+			if (tid == 0 && getenv("MM2AMD_TWO_BUCKET_TRACE")) fprintf(stderr, "[mm2amd] tape walk: %d elements at shift %d\n", (int)len, (int)fr.shift);
+#endif
+			uint16_t *const tpos = tape.pos, *const via = tape.via;
+			uint8_t *const tdig = tape.dig;
+			uint32_t *const ent = head; // per bucket: next entry of its tape << 8 | that entry's bucket
+			uint32_t *const Fs = tape.tab, *const Fe = tape.tab + 256, *const m1 = tape.tab + 512, *const wave_tot = tape.tab + 769, *const has_tape = tape.tab + 785;
+			const int32_t per = (len + nt - 1) / nt, p0 = fr.b + tid * per, p1 = p0 + per < fr.e ? p0 + per : fr.e;
+			typename S::Elem el[TWO_PER];
+			uint32_t rg[TWO_PER]; // the bucket whose part of the range the position lies in
+			uint32_t fmask = 0, mine = 0;
+			if (tid < 256) Fs[tid] = 0, Fe[tid] = 0;
+			if (tid < 8) has_tape[tid] = 0;
+			{
+				int32_t reg = 0;
+				if (p0 < p1) { // first bucket whose end lies beyond the position (empty buckets end where they start)
+					const uint32_t q0 = (uint32_t)(p0 - fr.b);
+					int lo = 0, hi = 255;
+					while (lo < hi) { const int mid = (lo + hi) >> 1; if (cnt[mid] > q0) hi = mid; else lo = mid + 1; }
+					reg = lo;
+				}
+#pragma unroll
+				for (int k = 0; k < TWO_PER; ++k) {
+					const int32_t p = p0 + k;
+					el[k] = typename S::Elem();
+					rg[k] = 0;
+					if (p < p1) {
+						while (cnt[reg] <= (uint32_t)(p - fr.b)) ++reg;
+						rg[k] = (uint32_t)reg;
+						el[k] = s.get(p);
+						if ((uint32_t)(s.xk(el[k]) >> fr.shift & 255) != (uint32_t)reg) fmask |= 1u << k, ++mine;
+					}
+				}
+			}
+			const uint32_t incl = wave_prefix_add_u32(mine);
+			const int wv = tid >> 6, n_wv = (nt + 63) >> 6;
+			if ((tid & 63) == 63) wave_tot[wv] = incl;
+			__syncthreads();
+			uint32_t base = incl - mine, total = 0;
+			for (int w2 = 0; w2 < n_wv; ++w2) { const uint32_t t = wave_tot[w2]; if (w2 < wv) base += t; total += t; }
+			{
+				uint32_t r = base;
+#pragma unroll
+				for (int k = 0; k < TWO_PER; ++k) {
+					const int32_t p = p0 + k;
+					if (p < p1) {
+						const uint32_t q = (uint32_t)(p - fr.b);
+						if (q == start[rg[k]]) Fs[rg[k]] = r;
+						if (fmask >> k & 1u) { tpos[r] = (uint16_t)q, tdig[r] = (uint8_t)(s.xk(el[k]) >> fr.shift & 255); ++r; }
+						if (q + 1 == cnt[rg[k]]) Fe[rg[k]] = r;
+					}
+				}
+			}
+			__syncthreads();
+			if (tid < 256) {
+				ent[tid] = Fs[tid] << 8 | (Fs[tid] < Fe[tid] ? (uint32_t)tdig[Fs[tid]] : 0u);
+				m1[tid] = Fs[tid]; // (stays so for a bucket without foreign elements: nothing arrives there)
+				if (Fs[tid] < Fe[tid]) atomicOr(&has_tape[tid >> 5], 1u << (tid & 31));
+			}
+			__syncthreads();
+			if (tid == 0) {
+				const uint32_t last = total ? total - 1 : 0;
+				for (uint32_t kw = 0; kw < 8; ++kw)
+				for (uint32_t km = has_tape[kw]; km; km &= km - 1) { // the base bucket, in bucket order
+					const uint32_t k = kw * 32 + (uint32_t)__builtin_ctz(km);
+					uint32_t wk = ent[k];
+					const uint32_t fe = Fe[k];
+					m1[k] = wk >> 8; // entries before this one were taken by arrivals while an earlier bucket was the base
+					while ((wk >> 8) < fe) {
+						const uint32_t e0 = wk >> 8, nk = e0 + 1;
+						uint32_t dst = wk & 255u, src = e0;
+						uint32_t w2 = ent[dst]; // (dst != k: the entry is foreign to k)
+						wk = nk << 8 | (nk < fe ? (uint32_t)tdig[nk] : 0u);
+						for (;;) {
+							const uint32_t t = w2 >> 8, nxt = w2 & 255u; // the element of entry src takes entry t's slot; t's element belongs to nxt (!= dst)
+							uint32_t w3 = 0;
+							if (nxt != k) w3 = ent[nxt]; // the next step waits for this one only (issued before the stores below): one LDS round trip per element
+							const uint32_t nd = tdig[t < last ? t + 1 : t];
+							via[src] = (uint16_t)t;
+							ent[dst] = (t + 1) << 8 | nd;
+							src = t;
+							if (nxt == k) break;
+							dst = nxt, w2 = w3;
+						}
+						via[src] = (uint16_t)e0; // the cycle closes in the slot it started from
+					}
+				}
+			}
+			__syncthreads();
+			{
+				uint32_t r = base;
+				int32_t dpos[TWO_PER];
+#pragma unroll
+				for (int k = 0; k < TWO_PER; ++k) {
+					const int32_t p = p0 + k;
+					dpos[k] = -1;
+					if (p < p1) {
+						const uint32_t q = (uint32_t)(p - fr.b);
+						if (fmask >> k & 1u) {
+							const uint32_t d = (uint32_t)(s.xk(el[k]) >> fr.shift & 255), t = via[r];
+							if (t < m1[d]) dpos[k] = t == Fs[d] ? (int32_t)start[d] : (int32_t)tpos[t - 1] + 1; // arrived before d was the base
+							else dpos[k] = (int32_t)tpos[t];
+							++r;
+						} else dpos[k] = (int32_t)q + (r < m1[rg[k]] ? 1 : 0); // an own element moves one slot on if a foreign slot after it was taken early
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < TWO_PER; ++k) if (dpos[k] >= 0 && dpos[k] != p0 + k - fr.b) s.put(fr.b + dpos[k], el[k]);
+			}
+			__syncthreads();
+		}
 		if (fr.shift == 0) continue;
 		const int ns = fr.shift > 8 ? fr.shift - 8 : 0;
-		for (int k = 0; k < 256; ++k) { // children (uniform control flow across the workgroup)
+		// children: a thread per bucket -- the small ones are insertion-sorted side by side, the others join the stack (in any order: the ranges
+		// are disjoint and what happens in one does not depend on the others)
+		if (tid == 0) head[0] = (uint32_t)sp; // (the heads are dead after the walk)
+		__syncthreads();
+		for (int k = tid; k < 256; k += nt) {
 			const int32_t cb = fr.b + (int32_t)start[k], ce = fr.b + (int32_t)cnt[k];
 			if (ce - cb <= 1) continue;
 			if (!replay_all && !(child_mask[k >> 5] >> (k & 31) & 1u)) continue;
 			if (ce - cb > 64) {
-				if (sp < stack_cap) { if (tid == 0) stack[sp] = TieFrame{cb, ce, ns}; ++sp; } // cannot overflow: the frames are disjoint ranges of more than 64 elements
-			} else if (tid == 0) insertion(cb, ce);
+				const uint32_t slot = atomicAdd(&head[0], 1u);
+				if ((int)slot < stack_cap) stack[slot] = TieFrame{cb, ce, ns}; // cannot overflow: the frames are disjoint ranges of more than 64 elements
+			} else insertion(cb, ce);
 		}
 		__syncthreads();
+		sp = (int)head[0] < stack_cap ? (int)head[0] : stack_cap; // (two barriers away from the next range's scan, which writes the heads again)
 	}
 }
 
@@ -1045,9 +1198,16 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS 
 		}
 		__syncthreads();
 		const uint32_t n_tied_all = n_tied_s;
+#ifdef MM2AMD_WAVE_EMU
+		if (tid == 0 && getenv("MM2AMD_TIE_TRACE")) fprintf(stderr, "[mm2amd] anchor sort: read %d, %d anchors, %u duplicated keys\n", r, (int)n, n_tied_all);
+#endif
 		if (n_tied_all == 0) return;
 		if (tid == 0) B.tie_flag[r] = 1u;
 		if (heap_sort & 1) return; // MM_F_HEAP_SORT: anchor_heap_order_kernel lays down the heap merge's order instead
+		if (IN_LDS && (heap_sort & 4)) { // the few reads with duplicated keys are replayed together afterwards (anchor_sort_ties_kernel): no read holds this launch up
+			if (tid == 0) B.tie_list[atomicAdd(B.tie_count, 1u)] = (uint32_t)r;
+			return;
+		}
 		// 3. the reference's own permutation of the duplicated keys, from the original order
 		const bool replay_all = n_tied_all > (uint32_t)TIE_MAX_KEYS;
 		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
@@ -1065,6 +1225,56 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 1024 && IN_LDS && ROUNDS 
 	else { // the sorted-pair arrays are free until the backtrack: keys, then indices and the frame stack in the value array
 		uint32_t *I = (uint32_t *)(B.sort_val_out + ao);
 		run(SplitStore{B.sort_key_out + ao, I, B.rid_bits}, (TieFrame *)(I + n), (int)((size_t)n * 4 / sizeof(TieFrame)));
+	}
+}
+
+// The reads anchor_sort_kernel found duplicated keys in (B.tie_list; about one in 200 ONT reads against a random 3 Gb reference), replayed
+// together: a workgroup per read with the tape scratch beside the read's elements, so a replay costs one LDS round trip per element of its
+// sequential walk and the sorting launch does not wait for it.  (Measured before the split: the replays, sitting at random places in the
+// sorting launches, made them 29 + 22 ms per step un-overlapped against 12 + 6 ms for the sorting alone.)
+constexpr int AST_THREADS = 1024, AST_PER = AS_LDS_MAX / AST_THREADS;
+constexpr size_t AST_LDS_BYTES = (size_t)AS_LDS_MAX * (8 + 2 + 2 + 1);
+__global__ void __launch_bounds__(AST_THREADS, 4) anchor_sort_ties_kernel(SeedChainBuffers B, int mode)
+{
+	MM2_DYN_LDS(uint64_t, ast_lds); // the read's packed elements, then the tape arrays
+	__shared__ uint32_t tab[768], tape_tab[768 + 32], child_mask[8];
+	__shared__ uint64_t tied[TIE_MAX_KEYS];
+	__shared__ TieFrame lstack[AS_STACK];
+	__shared__ uint32_t n_tied_s;
+	const int32_t tid = (int32_t)threadIdx.x;
+	TapeScratch tape;
+	tape.pos = (uint16_t *)(ast_lds + AS_LDS_MAX), tape.via = tape.pos + AS_LDS_MAX, tape.dig = (uint8_t *)(tape.via + AS_LDS_MAX), tape.tab = tape_tab, tape.cap = AS_LDS_MAX;
+	const uint32_t n_list = *B.tie_count;
+	for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+		const int r = (int)B.tie_list[li];
+		const uint64_t ao = B.a_off[r];
+		const int32_t n = (int32_t)(B.a_off[r + 1] - ao);
+		const uint64_t *kin = B.sort_key_in + ao, *vin = B.sort_val_in + ao;
+		Anchor *out = B.anchors + ao;
+		PackedStore s{ast_lds, B.rid_bits};
+		__syncthreads(); // (the previous read's last pass over the shared arrays)
+		if (tid == 0) n_tied_s = 0;
+		__syncthreads();
+		for (int32_t i = tid; i < n; i += AST_THREADS) { // the duplicated keys, from the sorted anchors
+			const uint64_t x = out[i].x;
+			if (i + 1 < n && out[i + 1].x == x && (i == 0 || out[i - 1].x != x)) {
+				const uint32_t slot = atomicAdd(&n_tied_s, 1u);
+				if (slot < (uint32_t)TIE_MAX_KEYS) tied[slot] = x;
+			}
+			s.set(i, kin[i], (uint32_t)i); // the read in its original order
+		}
+		__syncthreads();
+		const uint32_t n_tied_all = n_tied_s;
+		const bool replay_all = n_tied_all > (uint32_t)TIE_MAX_KEYS;
+		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
+		tie_exact_replay<PackedStore, AST_PER>(s, n, tied, n_tied, replay_all, tab, tab + 256, tab + 512, child_mask, lstack, AS_STACK,
+		                                       (mode & 2) ? nullptr : (uint32_t *)tape.via, AS_LDS_MAX - 40, (mode & 8) ? TapeScratch() : tape);
+		for (int32_t i = tid; i < n; i += AST_THREADS) {
+			const uint64_t x = s.xkey(i);
+			bool dup = replay_all;
+			for (int t = 0; t < n_tied && !dup; ++t) dup = tied[t] == x;
+			if (dup) { Anchor a; a.x = x, a.y = vin[s.index(i)]; out[i] = a; }
+		}
 	}
 }
 
@@ -1138,7 +1348,10 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	if (n_class[4] > 0) HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_kernel<1024, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS_MAX * 8));
 	static const bool no_replay = getenv("MM2AMD_SORT_NO_REPLAY") != nullptr; // TIMING ONLY (tools/r03_call5.sh): reads with duplicated keys keep the sorted order -- not the reference's
 	const bool walk_only = getenv("MM2AMD_NO_TWO_BUCKET") != nullptr; // A/B checks: every partition of the replay by the sequential walk (read per launch)
-	const int heap = ((P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0) | (walk_only ? 2 : 0);
+	static const bool replay_inline = getenv("MM2AMD_TIE_REPLAY_INLINE") != nullptr; // A/B checks: the replay inside the sorting launch, as before round 5
+	const bool no_tape = getenv("MM2AMD_NO_TAPE_WALK") != nullptr;                   // A/B checks: the replay's partitions by the one-thread walk
+	const int heap = ((P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0) | (walk_only ? 2 : 0) | (replay_inline ? 0 : 4) | (no_tape ? 8 : 0);
+	if (heap & 4) HIP_CHECK(hipMemsetAsync(B.tie_count, 0, 4, s));
 	int first = 0;
 	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
 		if (n_class[c] == 0) continue;
@@ -1152,6 +1365,14 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 		else if (c == 4) hipLaunchKernelGGL((anchor_sort_kernel<1024, 10, true>), grid, dim3(1024), lds, s, B, d_list + first, heap);
 		else hipLaunchKernelGGL((anchor_sort_kernel<1024, 1, false>), grid, dim3(1024), 0, s, B, d_list + first, heap);
 		kp->end(s, kNames[c], 32.0 * anchors_in_class[c]); // 16 B per anchor in, 16 B out (nothing else leaves LDS)
+		HIP_CHECK(hipGetLastError());
+	}
+	const int n_lds = n_class[0] + n_class[1] + n_class[2] + n_class[3] + n_class[4];
+	if ((heap & 4) && !(heap & 1) && n_lds > 0) {
+		kp->begin(s);
+		HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_ties_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AST_LDS_BYTES));
+		hipLaunchKernelGGL(anchor_sort_ties_kernel, dim3(std::min(n_lds, 256)), dim3(AST_THREADS), AST_LDS_BYTES, s, B, heap);
+		kp->end(s, "anchor_sort_kernel[ties]", 0.0);
 		HIP_CHECK(hipGetLastError());
 	}
 	if (P.flag & ref::F_HEAP_SORT) { // equal-x order of the heap merge instead of the radix sort's

@@ -48,6 +48,7 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	uint64_t *sort_key_in, *sort_val_in; // anchors as (compact key: strand | rid | rpos, y) pairs in seed order, before the per-read sort
 	uint64_t *sort_key_out, *sort_val_out; // per-read scratch of the same size: the sort of reads beyond the LDS classes, RMQ priorities, the backtrack's sorts
 	uint32_t *tie_flag;       // n_reads: set when a read has two anchors with equal x
+	uint32_t *tie_list, *tie_count; // those reads (of the LDS classes), in the order their sorting workgroups found out; how many: anchor_sort_ties_kernel's work list
 	int rid_bits;             // bits needed for a reference sequence id in the compact sort key
 	uint64_t *mini_pos;
 	int32_t *f, *p, *t;       // chaining DP arrays, indexed like anchors

@@ -117,6 +117,21 @@ def test_batch_call_that_names_its_index_and_options(tmp_path):
     assert got == open(os.path.join(HERE, "golden", "inv_paf.out"), "rb").read()
 
 
+def test_partitions_walked_over_tapes(tmp_path):
+    """anchor_sort_ties_kernel (reads with equal anchor keys replayed together; partitions into many buckets walked over tapes): the anchors in
+    order == the reference's --print-seeds == the one-thread walk's == the in-launch replay's, reads of the 4 k, 7 k and 10 k classes"""
+    import tie_cases
+    for k, (seed, n_reads, mean) in enumerate(((93, 16, 8000), (94, 10, 16000))):
+        d = tmp_path / str(k)
+        d.mkdir()
+        want, got = tie_cases.many_bucket_tie_case(DROPIN, REF_BIN, str(d), seed, n_reads, mean)
+        assert len(want) > 40000
+        if EMU:
+            assert got["tapes"][1].count("tape walk") >= 16
+        for name in got:
+            assert got[name][0] == want, (seed, name)
+
+
 def test_anchor_sort_classes_and_chain_fill_variants(tmp_path):
     """anchor_sort_kernel's launch classes (256 / 512 / 1024 threads in LDS, 1024 threads on global scratch: MM2AMD_SORT_MIN_CLASS pushes small
     reads through the large ones) with and without duplicated keys, and chain_fill_kernel with its LDS window against the all-global variant"""

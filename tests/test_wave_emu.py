@@ -178,6 +178,21 @@ def test_two_bucket_partition_closed_form(emu, monkeypatch):
             assert got_sd == want_sd
 
 
+def test_partitions_walked_over_tapes(tmp_path):
+    """anchor_sort_ties_kernel: the reads with equal anchor keys replayed together after the sorting launch, a partition into more than two
+    buckets as a walk over byte-sized tapes (one LDS round trip per element by one thread, everything else by the workgroup): the anchors in
+    order equal the reference's --print-seeds, and the one-thread walk's and the in-launch replay's"""
+    if not os.path.exists(DROPIN_EMU) or not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    import tie_cases
+    want, got = tie_cases.many_bucket_tie_case(DROPIN_EMU, G.REF_BIN, str(tmp_path), 93, 8, 8000)
+    assert len(want) > 20000
+    assert got["tapes"][1].count("tape walk") >= 16 and "at shift 32" in got["tapes"][1] and "at shift 8" in got["tapes"][1]
+    assert "tape walk" not in got["walk"][1] and "tape walk" not in got["inline"][1]
+    for name in got:
+        assert got[name][0] == want, name
+
+
 def test_pipeline_equals_batch_by_batch(emu):
     """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
     (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
