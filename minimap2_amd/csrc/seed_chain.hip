@@ -1244,9 +1244,13 @@ __global__ void __launch_bounds__(AST_THREADS, 4) anchor_sort_ties_kernel(SeedCh
 	const int32_t tid = (int32_t)threadIdx.x;
 	TapeScratch tape;
 	tape.pos = (uint16_t *)(ast_lds + AS_LDS_MAX), tape.via = tape.pos + AS_LDS_MAX, tape.dig = (uint8_t *)(tape.via + AS_LDS_MAX), tape.tab = tape_tab, tape.cap = AS_LDS_MAX;
-	const uint32_t n_list = *B.tie_count;
+	// two workgroups per read, one per strand: the partition at the top is by the strand bit, what follows in one half does not depend on the
+	// other, and a workgroup given only its strand's duplicated keys replays only that half (mode & 16: one workgroup does both)
+	const bool split = !(mode & 16);
+	const uint32_t n_list = *B.tie_count * (split ? 2u : 1u);
 	for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-		const int r = (int)B.tie_list[li];
+		const int r = (int)B.tie_list[split ? li >> 1 : li];
+		const uint64_t strand = li & 1u;
 		const uint64_t ao = B.a_off[r];
 		const int32_t n = (int32_t)(B.a_off[r + 1] - ao);
 		const uint64_t *kin = B.sort_key_in + ao, *vin = B.sort_val_in + ao;
@@ -1257,7 +1261,7 @@ __global__ void __launch_bounds__(AST_THREADS, 4) anchor_sort_ties_kernel(SeedCh
 		__syncthreads();
 		for (int32_t i = tid; i < n; i += AST_THREADS) { // the duplicated keys, from the sorted anchors
 			const uint64_t x = out[i].x;
-			if (i + 1 < n && out[i + 1].x == x && (i == 0 || out[i - 1].x != x)) {
+			if (i + 1 < n && out[i + 1].x == x && (i == 0 || out[i - 1].x != x) && (!split || x >> 63 == strand)) { // (the other workgroup rewrites y's only)
 				const uint32_t slot = atomicAdd(&n_tied_s, 1u);
 				if (slot < (uint32_t)TIE_MAX_KEYS) tied[slot] = x;
 			}
@@ -1265,7 +1269,8 @@ __global__ void __launch_bounds__(AST_THREADS, 4) anchor_sort_ties_kernel(SeedCh
 		}
 		__syncthreads();
 		const uint32_t n_tied_all = n_tied_s;
-		const bool replay_all = n_tied_all > (uint32_t)TIE_MAX_KEYS;
+		if (n_tied_all == 0) continue; // nothing duplicated on this strand
+		const bool replay_all = n_tied_all > (uint32_t)TIE_MAX_KEYS; // (then every bucket of both strands is replayed and rewritten: the same values the other workgroup writes)
 		const int n_tied = replay_all ? TIE_MAX_KEYS : (int)n_tied_all;
 		tie_exact_replay<PackedStore, AST_PER>(s, n, tied, n_tied, replay_all, tab, tab + 256, tab + 512, child_mask, lstack, AS_STACK,
 		                                       (mode & 2) ? nullptr : (uint32_t *)tape.via, AS_LDS_MAX - 40, (mode & 8) ? TapeScratch() : tape);
@@ -1350,7 +1355,8 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	const bool walk_only = getenv("MM2AMD_NO_TWO_BUCKET") != nullptr; // A/B checks: every partition of the replay by the sequential walk (read per launch)
 	static const bool replay_inline = getenv("MM2AMD_TIE_REPLAY_INLINE") != nullptr; // A/B checks: the replay inside the sorting launch, as before round 5
 	const bool no_tape = getenv("MM2AMD_NO_TAPE_WALK") != nullptr;                   // A/B checks: the replay's partitions by the one-thread walk
-	const int heap = ((P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0) | (walk_only ? 2 : 0) | (replay_inline ? 0 : 4) | (no_tape ? 8 : 0);
+	const bool no_split = getenv("MM2AMD_TIE_NO_STRAND_SPLIT") != nullptr;           // A/B checks: one workgroup per read replays both strands' halves
+	const int heap = ((P.flag & ref::F_HEAP_SORT) || no_replay ? 1 : 0) | (walk_only ? 2 : 0) | (replay_inline ? 0 : 4) | (no_tape ? 8 : 0) | (no_split ? 16 : 0);
 	if (heap & 4) HIP_CHECK(hipMemsetAsync(B.tie_count, 0, 4, s));
 	int first = 0;
 	for (int c = 0; c < kAnchorSortClasses; first += n_class[c], ++c) {
@@ -1371,7 +1377,7 @@ void launch_anchor_sort(const SeedChainBuffers &B, const DevIndex &I, const Seed
 	if ((heap & 4) && !(heap & 1) && n_lds > 0) {
 		kp->begin(s);
 		HIP_CHECK(hipFuncSetAttribute((const void *)anchor_sort_ties_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AST_LDS_BYTES));
-		hipLaunchKernelGGL(anchor_sort_ties_kernel, dim3(std::min(n_lds, 256)), dim3(AST_THREADS), AST_LDS_BYTES, s, B, heap);
+		hipLaunchKernelGGL(anchor_sort_ties_kernel, dim3(std::min(2 * n_lds, 512)), dim3(AST_THREADS), AST_LDS_BYTES, s, B, heap);
 		kp->end(s, "anchor_sort_kernel[ties]", 0.0);
 		HIP_CHECK(hipGetLastError());
 	}

@@ -7,7 +7,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/tests/_build/emu_cov; EMU=$ROOT/tests/cpucheck/wave_emu; CSRC=$ROOT/minimap2_amd/csrc
 CPP="align backend_hip capi_common capi_index capi_kernels capi_map chain_host device_ctx flat_index format hits ksw_host ksw_ll mapper options rmq_chain tables"
-HIP="seed_chain index_build device_sort ksw_extd2 ksw_gapfill ksw_stream ksw_splice ksw_ext region_finish"
+HIP="seed_chain index_build device_sort ksw_extd2 ksw_gapfill ksw_stream ksw_splice ksw_ext region_finish region_dev ksw_order"
 if [ "$1" = build ]; then
   mkdir -p $OUT; rm -f $OUT/*.gcda
   FLAGS="-std=c++17 -O2 -g --coverage -fPIC -ffp-contract=off -Wno-unknown-pragmas -I$EMU -I$ROOT/include"
