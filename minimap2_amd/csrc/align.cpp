@@ -239,117 +239,142 @@ void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar) // align.c:32
 	}
 }
 
-// left-align indels, merge I/D clusters, drop empty ops and a leading gap (mm_fix_cigar, align.c:105-181)
+// What mm_fix_cigar (align.c:105-181) leaves of a CIGAR, formulated the way region_finish_kernel does it (region_finish.hip, step B) rather than as one
+// in-place walk: (1) how far each gap slides is a property of the sequence it skips and of the room in the match before it, worked out against the
+// CIGAR as it came and applied afterwards; (2) clusters of insertions and deletions; (3) packing; (4) the leading gap.  qshift / tshift: bases a
+// dropped leading insertion / deletion took off the query / target start.
+namespace {
+inline uint32_t cg_op(uint32_t c) { return c & 0xfu; }
+inline uint32_t cg_len(uint32_t c) { return c >> 4; }
+inline bool cg_is_gap(uint32_t c) { return cg_op(c) == 1 || cg_op(c) == 2; }
+
+// a gap of g bases that starts at seq[at] can move one base to the left whenever the base that enters it on the left equals the base that leaves it on
+// the right: how many such moves in a row, at most `room` (the bases of the match before it)
+inline uint32_t gap_slide(const uint8_t *seq, uint32_t at, uint32_t g, uint32_t room)
+{
+	uint32_t moved = 0;
+	while (moved < room && seq[at - 1 - moved] == seq[at + g - 1 - moved]) ++moved;
+	return moved;
+}
+} // namespace
+
 static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
 {
-	Extra *p = r.p;
-	int32_t toff = 0, qoff = 0;
-	bool shrink = false;
+	Extra *const p = r.p;
+	uint32_t *const cg = p->cigar;
 	*qshift = *tshift = 0;
 	if (p->n_cigar <= 1) return;
-	for (uint32_t k = 0; k < p->n_cigar; ++k) {
-		const uint32_t op = p->cigar[k] & 0xf, len = p->cigar[k] >> 4;
-		if (len == 0) shrink = true;
-		if (op == 0) toff += len, qoff += len;
-		else if (op == 1 || op == 2) {
-			if (k > 0 && k < p->n_cigar - 1 && (p->cigar[k - 1] & 0xf) == 0 && (p->cigar[k + 1] & 0xf) == 0) {
-				int l;
-				const int prev_len = p->cigar[k - 1] >> 4;
-				if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
-				else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
-				if (l > 0) p->cigar[k - 1] -= l << 4, p->cigar[k + 1] += l << 4, qoff -= l, toff -= l;
-				if (l == prev_len) shrink = true;
+	uint32_t n = p->n_cigar;
+	bool repack = false; // an empty operation came in or was made: step (3) runs
+	{ // (1) a gap between two matches gives bases of the match before it to the match after it; that match may in turn lend them to the next gap.
+	  //     Operation k starts where the incoming CIGAR puts it: slides before it move bases between matches that both lie before it.
+		thread_local std::vector<uint32_t> slide;
+		slide.assign(n, 0);
+		uint32_t q_at = 0, t_at = 0;
+		for (uint32_t k = 0; k < n; ++k) {
+			const uint32_t op = cg_op(cg[k]), len = cg_len(cg[k]);
+			if (len == 0) repack = true;
+			if (cg_is_gap(cg[k]) && k > 0 && k + 1 < n && cg_op(cg[k - 1]) == 0 && cg_op(cg[k + 1]) == 0) {
+				const uint32_t room = cg_len(cg[k - 1]) + (k >= 2 ? slide[k - 2] : 0);
+				slide[k] = op == 1 ? gap_slide(qseq, q_at, len, room) : gap_slide(tseq, t_at, len, room);
+				if (slide[k] == room) repack = true; // the match before it is used up
 			}
-			if (op == 1) qoff += len; else toff += len;
-		} else if (op == 3) toff += len;
-	}
-	assert(qoff == r.qe - r.qs && toff == r.re - r.rs);
-	for (uint32_t k = 0; k + 2 < p->n_cigar; ++k) { // runs like 5I6D7I become one I and one D
-		if ((p->cigar[k] & 0xf) > 0 && (p->cigar[k] & 0xf) + (p->cigar[k + 1] & 0xf) == 3) {
-			uint32_t l, s[3] = {0, 0, 0};
-			for (l = k; l < p->n_cigar; ++l) {
-				const uint32_t op = p->cigar[l] & 0xf;
-				if (op == 1 || op == 2 || p->cigar[l] >> 4 == 0) s[op] += p->cigar[l] >> 4;
-				else break;
-			}
-			if (s[1] > 0 && s[2] > 0 && l - k > 2) {
-				p->cigar[k] = s[1] << 4 | 1;
-				p->cigar[k + 1] = s[2] << 4 | 2;
-				for (k += 2; k < l; ++k) p->cigar[k] &= 0xf;
-				shrink = true;
-			}
-			k = l;
+			if (op == 0) q_at += len, t_at += len;
+			else if (op == 1) q_at += len;
+			else if (op == 2 || op == 3) t_at += len;
 		}
+		assert((int32_t)q_at == r.qe - r.qs && (int32_t)t_at == r.re - r.rs);
+		for (uint32_t k = 1; k + 1 < n; ++k)
+			if (slide[k]) cg[k - 1] -= slide[k] << 4, cg[k + 1] += slide[k] << 4;
 	}
-	if (shrink) {
-		uint32_t l = 0;
-		for (uint32_t k = 0; k < p->n_cigar; ++k)
-			if (p->cigar[k] >> 4 != 0) p->cigar[l++] = p->cigar[k];
-		p->n_cigar = l;
-		l = 0;
-		for (uint32_t k = 0; k < p->n_cigar; ++k)
-			if (k == p->n_cigar - 1 || (p->cigar[k] & 0xf) != (p->cigar[k + 1] & 0xf)) p->cigar[l++] = p->cigar[k];
-			else p->cigar[k + 1] += p->cigar[k] >> 4 << 4;
-		p->n_cigar = l;
+	// (2) a run of insertions and deletions (empty operations inside it do not end it) that opens with one of each, has both kinds and more than two
+	//     members becomes one insertion and one deletion
+	for (uint32_t k = 0; k + 2 < n;) {
+		if (!(cg_is_gap(cg[k]) && cg_is_gap(cg[k + 1]) && cg_op(cg[k]) != cg_op(cg[k + 1]))) { ++k; continue; }
+		uint32_t end = k, bases[3] = {0, 0, 0};
+		while (end < n && (cg_is_gap(cg[end]) || cg_len(cg[end]) == 0)) {
+			if (cg_is_gap(cg[end])) bases[cg_op(cg[end])] += cg_len(cg[end]);
+			++end;
+		}
+		if (bases[1] > 0 && bases[2] > 0 && end - k > 2) {
+			cg[k] = bases[1] << 4 | 1, cg[k + 1] = bases[2] << 4 | 2;
+			for (uint32_t j = k + 2; j < end; ++j) cg[j] &= 0xfu;
+			repack = true;
+		}
+		k = end + 1; // (the operation that ended the run is neither a gap nor empty: no run opens there)
 	}
-	if ((p->cigar[0] & 0xf) == 1 || (p->cigar[0] & 0xf) == 2) { // an alignment never starts with a gap
-		const int32_t l = p->cigar[0] >> 4;
-		if ((p->cigar[0] & 0xf) == 1) {
-			if (r.rev) r.qe -= l; else r.qs += l;
-			*qshift = l;
-		} else r.rs += l, *tshift = l;
-		--p->n_cigar;
-		memmove(p->cigar, p->cigar + 1, p->n_cigar * 4);
+	if (repack) { // (3) empty operations go, then neighbours of one kind join
+		uint32_t kept = 0;
+		for (uint32_t k = 0; k < n; ++k)
+			if (cg_len(cg[k]) != 0) cg[kept++] = cg[k];
+		n = kept, kept = 0;
+		for (uint32_t k = 0; k < n; ++k) {
+			if (k + 1 < n && cg_op(cg[k]) == cg_op(cg[k + 1])) cg[k + 1] += cg_len(cg[k]) << 4;
+			else cg[kept++] = cg[k];
+		}
+		n = kept;
 	}
+	if (cg_is_gap(cg[0])) { // (4) an alignment does not open with a gap: its bases leave the aligned interval instead
+		const int32_t bases = (int32_t)cg_len(cg[0]);
+		if (cg_op(cg[0]) == 1) {
+			if (r.rev) r.qe -= bases; else r.qs += bases;
+			*qshift = bases;
+		} else r.rs += bases, *tshift = bases;
+		--n;
+		memmove(cg, cg + 1, (size_t)n * 4);
+	}
+	p->n_cigar = n;
 }
 
-static void cigar_to_eqx(Reg &r, const uint8_t *qseq, const uint8_t *tseq) // mm_update_cigar_eqx, align.c:183-252
+// MM_F_EQX (mm_update_cigar_eqx, align.c:183-252): every match operation cut into stretches of equal and of unequal columns.  The stretches are
+// visited by one routine, once to count them and once to write them.  (As in the reference, a CIGAR whose matches are one stretch each is relabelled
+// in place as all-equal.)
+namespace {
+template <class Visit> // visit(stretch length, equal?) for the stretches of a match of len columns that starts at q / t
+inline void match_stretches(const uint8_t *q, const uint8_t *t, uint32_t len, Visit visit)
+{
+	for (uint32_t at = 0; at < len;) {
+		const bool equal = q[at] == t[at];
+		uint32_t end = at + 1;
+		while (end < len && (q[end] == t[end]) == equal) ++end;
+		visit(end - at, equal);
+		at = end;
+	}
+}
+template <class OnMatch, class OnOther> // the CIGAR's operations with their places in the two sequences
+inline void walk_cigar(const Extra *p, OnMatch on_match, OnOther on_other)
+{
+	uint32_t q_at = 0, t_at = 0;
+	for (uint32_t k = 0; k < p->n_cigar; ++k) {
+		const uint32_t op = cg_op(p->cigar[k]), len = cg_len(p->cigar[k]);
+		if (op == 0) { on_match(q_at, t_at, len); q_at += len, t_at += len; continue; }
+		on_other(p->cigar[k]);
+		if (op == 1) q_at += len;
+		else if (op == 2 || op == 3) t_at += len;
+	}
+}
+} // namespace
+
+static void cigar_to_eqx(Reg &r, const uint8_t *qseq, const uint8_t *tseq)
 {
 	if (!r.p) return;
-	uint32_t n_eqx = 0, n_m = 0, toff = 0, qoff = 0;
-	for (uint32_t k = 0; k < r.p->n_cigar; ++k) {
-		uint32_t op = r.p->cigar[k] & 0xf, len = r.p->cigar[k] >> 4, l;
-		if (op == 0) {
-			while (len > 0) {
-				for (l = 0; l < len && qseq[qoff + l] == tseq[toff + l]; ++l) {}
-				if (l > 0) { ++n_eqx; len -= l; toff += l; qoff += l; }
-				for (l = 0; l < len && qseq[qoff + l] != tseq[toff + l]; ++l) {}
-				if (l > 0) { ++n_eqx; len -= l; toff += l; qoff += l; }
-			}
-			++n_m;
-		} else if (op == 1) qoff += len;
-		else if (op == 2 || op == 3) toff += len;
-	}
-	if (n_eqx == n_m) {
+	uint32_t n_stretch = 0, n_match = 0;
+	walk_cigar(r.p, [&](uint32_t q, uint32_t t, uint32_t len) { ++n_match; match_stretches(qseq + q, tseq + t, len, [&](uint32_t, bool) { ++n_stretch; }); }, [](uint32_t) {});
+	if (n_stretch == n_match) {
 		for (uint32_t k = 0; k < r.p->n_cigar; ++k)
-			if ((r.p->cigar[k] & 0xf) == 0) r.p->cigar[k] = (r.p->cigar[k] >> 4) << 4 | 7;
+			if (cg_op(r.p->cigar[k]) == 0) r.p->cigar[k] = cg_len(r.p->cigar[k]) << 4 | 7;
 		return;
 	}
-	uint32_t cap = roundup32(r.p->n_cigar + (n_eqx - n_m) + (uint32_t)sizeof(Extra));
-	Extra *p = (Extra *)calloc(cap, 4);
-	memcpy(p, r.p, sizeof(Extra));
-	p->capacity = cap;
+	const uint32_t cap = roundup32(r.p->n_cigar + (n_stretch - n_match) + (uint32_t)sizeof(Extra));
+	Extra *const grown = (Extra *)calloc(cap, 4);
+	memcpy(grown, r.p, sizeof(Extra));
+	grown->capacity = cap;
 	uint32_t m = 0;
-	toff = qoff = 0;
-	for (uint32_t k = 0; k < r.p->n_cigar; ++k) {
-		uint32_t op = r.p->cigar[k] & 0xf, len = r.p->cigar[k] >> 4, l;
-		if (op == 0) {
-			while (len > 0) {
-				for (l = 0; l < len && qseq[qoff + l] == tseq[toff + l]; ++l) {}
-				if (l > 0) p->cigar[m++] = l << 4 | 7;
-				len -= l, toff += l, qoff += l;
-				for (l = 0; l < len && qseq[qoff + l] != tseq[toff + l]; ++l) {}
-				if (l > 0) p->cigar[m++] = l << 4 | 8;
-				len -= l, toff += l, qoff += l;
-			}
-			continue;
-		} else if (op == 1) qoff += len;
-		else if (op == 2 || op == 3) toff += len;
-		p->cigar[m++] = r.p->cigar[k];
-	}
-	p->n_cigar = m;
+	walk_cigar(r.p, [&](uint32_t q, uint32_t t, uint32_t len) { match_stretches(qseq + q, tseq + t, len, [&](uint32_t l, bool equal) { grown->cigar[m++] = l << 4 | (equal ? 7u : 8u); }); },
+	           [&](uint32_t c) { grown->cigar[m++] = c; });
+	grown->n_cigar = m;
 	free(r.p);
-	r.p = p;
+	r.p = grown;
 }
 
 void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, bool is_eqx, bool log_gap)

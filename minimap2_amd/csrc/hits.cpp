@@ -70,31 +70,43 @@ void set_parent(float mask_level, int mask_len, RegVec &r, int sub_diff, bool ha
 	hr_mark_parents(r.data(), n, cov.data(), prim.data(), mask_level, mask_len, sub_diff, hard_mask_level, alt_diff_frac); // hit_rules.hpp: the device kernel's formulation
 }
 
+namespace {
+// The hits a predicate keeps, in order; the alignments of the others are released.  Returns true if any went.
+template <class Keep>
+bool keep_hits(RegVec &r, Keep keep, bool release = true)
+{
+	size_t w = 0;
+	for (size_t i = 0; i < r.size(); ++i) {
+		if (keep(i)) { if (w != i) r[w] = r[i]; ++w; }
+		else if (release && r[i].p) free(r[i].p), r[i].p = nullptr;
+	}
+	const bool any = w != r.size();
+	r.resize(w);
+	return any;
+}
+} // namespace
+
+// mm_hit_sort (hit.c:188-218): hits from best to worst by (alignment score if aligned, else chain score; ALT hits marked down) with the hash as the
+// tie-breaker; hits that were dropped earlier (no anchors left and not an inversion) go.  The order among equal keys is the unstable radix sort's,
+// so the sort itself is exact_rsort.hpp's replay of it, on (key, position) pairs.
 void hit_sort(RegVec &r, float alt_diff_frac)
 {
-	const int n = (int)r.size();
-	if (n <= 1) return;
-	std::vector<Anchor> aux;
-	aux.reserve(n);
-	int has_cigar = 0, no_cigar = 0;
-	for (int i = 0; i < n; ++i) {
-		if (r[i].inv || r[i].cnt > 0) { // cnt==0 marks a soft-deleted hit
-			int score;
-			if (r[i].p) score = r[i].p->dp_max, has_cigar = 1;
-			else score = r[i].score, no_cigar = 1;
-			if (r[i].is_alt) score = alt_score(score, alt_diff_frac);
-			aux.push_back(Anchor{(uint64_t)score << 32 | r[i].hash, (uint64_t)i});
-		} else if (r[i].p) {
-			free(r[i].p);
-			r[i].p = nullptr;
-		}
+	if (r.size() <= 1) return;
+	thread_local std::vector<Anchor> ranked;
+	ranked.clear();
+	for (size_t i = 0; i < r.size(); ++i) {
+		Reg &h = r[i];
+		const bool live = h.inv || h.cnt > 0;
+		if (!live) { free(h.p); h.p = nullptr; continue; }
+		const int raw = h.p ? h.p->dp_max : h.score; // (all hits are aligned or none is)
+		const int score = h.is_alt ? alt_score(raw, alt_diff_frac) : raw;
+		ranked.push_back(Anchor{(uint64_t)score << 32 | h.hash, (uint64_t)i});
 	}
-	assert(has_cigar + no_cigar == 1);
-	(void)has_cigar; (void)no_cigar;
-	sort_by_x(aux.data(), aux.data() + aux.size());
-	RegVec t(aux.size());
-	for (int i = (int)aux.size() - 1; i >= 0; --i) t[aux.size() - 1 - i] = r[aux[i].y];
-	r.swap(t);
+	sort_by_x(ranked.data(), ranked.data() + ranked.size());
+	RegVec best_first;
+	best_first.reserve(ranked.size());
+	for (size_t k = ranked.size(); k-- > 0;) best_first.push_back(r[ranked[k].y]);
+	r.swap(best_first);
 }
 
 int set_sam_pri(RegVec &r) { return hr_mark_sam_primary(r.data(), (int)r.size()); }
@@ -113,67 +125,51 @@ void sync_regs(RegVec &r)
 void select_sub(float pri_ratio, int min_diff, int best_n, bool check_strand, int min_strand_sc, RegVec &r)
 {
 	if (!(pri_ratio > 0.0f) || r.empty()) return;
-	const int n = (int)r.size();
 	thread_local std::vector<uint8_t> keep;
-	keep.resize(n);
-	hr_select_secondaries(r.data(), n, keep.data(), pri_ratio, min_diff, best_n, check_strand, min_strand_sc);
-	int k = 0;
-	for (int i = 0; i < n; ++i) {
-		if (keep[i]) { if (k < i) r[k] = r[i]; ++k; }
-		else if (r[i].p) free(r[i].p);
-	}
-	r.resize(k);
-	if (k != n) sync_regs(r);
+	keep.resize(r.size());
+	hr_select_secondaries(r.data(), (int)r.size(), keep.data(), pri_ratio, min_diff, best_n, check_strand, min_strand_sc);
+	if (keep_hits(r, [&](size_t i) { return keep[i] != 0; })) sync_regs(r);
 }
 
+// mm_filter_strand_retained (hit.c:283-299): a hit kept only for being on the other strand stays if it is not much more diverged than its parent
 void filter_strand_retained(RegVec &r)
 {
-	const int n = (int)r.size();
-	std::vector<uint8_t> keep(n);
-	for (int i = 0; i < n; ++i) {
-		const int p = r[i].parent;
-		keep[i] = (!r[i].strand_retained || r[i].div < r[p].div * 5.0f || r[i].div < 0.01f);
+	thread_local std::vector<uint8_t> stays;
+	stays.resize(r.size());
+	for (size_t i = 0; i < r.size(); ++i) { // (decided for all hits before any moves: parents are looked up by position)
+		const Reg &h = r[i];
+		stays[i] = !h.strand_retained || h.div < r[h.parent].div * 5.0f || h.div < 0.01f;
 	}
-	int k = 0;
-	for (int i = 0; i < n; ++i)
-		if (keep[i]) { if (k < i) r[k] = r[i]; ++k; }
-	r.resize(k);
+	keep_hits(r, [&](size_t i) { return stays[i] != 0; }, false);
 }
 
+// mm_filter_regs (hit.c:301-320): what a hit needs to be reported -- enough anchors (unless it is an inversion or one segment's share of a chain), and,
+// once aligned, enough matching bases, a high enough alignment score, and not both ends of the read hanging off by more than max_clip_ratio
 void filter_regs(const ref::MapOpt &opt, int qlen, RegVec &regs)
 {
-	int k = 0;
-	for (size_t i = 0; i < regs.size(); ++i) {
-		Reg &r = regs[i];
-		bool flt = false;
-		if (!r.inv && !r.seg_split && r.cnt < opt.min_cnt) flt = true;
-		if (r.p) {
-			if (r.mlen < opt.min_chain_score) flt = true;
-			else if (r.p->dp_max < opt.min_dp_max) flt = true;
-			else if (r.qs > qlen * opt.max_clip_ratio && qlen - r.qe > qlen * opt.max_clip_ratio) flt = true;
-			if (flt) free(r.p);
-		}
-		if (!flt) { if (k < (int)i) regs[k] = regs[i]; ++k; }
-	}
-	regs.resize(k);
+	auto reportable = [&](const Reg &h) {
+		if (!h.inv && !h.seg_split && h.cnt < opt.min_cnt) return false;
+		if (!h.p) return true;
+		if (h.mlen < opt.min_chain_score || h.p->dp_max < opt.min_dp_max) return false;
+		return !(h.qs > qlen * opt.max_clip_ratio && qlen - h.qe > qlen * opt.max_clip_ratio);
+	};
+	keep_hits(regs, [&](size_t i) { return reportable(regs[i]); });
 }
 
+// mm_squeeze_a (hit.c:322-340): the anchors the hits still own, moved to the front of the array in the order they lie in it; returns how many
 int squeeze_anchors(RegVec &regs, Anchor *a)
 {
-	const int n = (int)regs.size();
-	int as = 0;
-	std::vector<uint64_t> aux(n);
-	for (int i = 0; i < n; ++i) aux[i] = (uint64_t)regs[i].as << 32 | (uint32_t)i;
-	sort_u64(aux.data(), aux.data() + n);
-	for (int i = 0; i < n; ++i) {
-		Reg &r = regs[(int32_t)aux[i]];
-		if (r.as != as) {
-			memmove(&a[as], &a[r.as], (size_t)r.cnt * sizeof(Anchor));
-			r.as = as;
-		}
-		as += r.cnt;
+	thread_local std::vector<uint64_t> by_start; // anchor offset << 32 | hit: offsets are distinct, any sort gives the one order
+	by_start.resize(regs.size());
+	for (size_t i = 0; i < regs.size(); ++i) by_start[i] = (uint64_t)regs[i].as << 32 | (uint32_t)i;
+	std::sort(by_start.begin(), by_start.end());
+	int32_t packed = 0;
+	for (const uint64_t e : by_start) {
+		Reg &h = regs[(uint32_t)e];
+		if (h.as != packed) memmove(a + packed, a + h.as, (size_t)h.cnt * sizeof(Anchor)), h.as = packed;
+		packed += h.cnt;
 	}
-	return as;
+	return packed;
 }
 
 namespace {
@@ -258,49 +254,50 @@ void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const
 }
 
 namespace {
-void count_gaps(const Reg &r, int32_t &n_gap, int32_t &n_gapo) // align.c:983-995
+// the gap operations of a hit's CIGAR: how many, and how many bases they span (mm_count_gaps, align.c:983-995)
+struct GapTally { int32_t opens = 0, bases = 0; };
+template <class PerGap>
+GapTally tally_gaps(const Reg &h, PerGap per_gap)
 {
-	n_gap = n_gapo = 0;
-	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
-		const int32_t op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
-		if (op == 1 || op == 2) ++n_gapo, n_gap += len;
+	GapTally g;
+	for (uint32_t k = 0; k < h.p->n_cigar; ++k) {
+		const uint32_t op = h.p->cigar[k] & 0xf;
+		if (op != 1 && op != 2) continue;
+		const int32_t len = (int32_t)(h.p->cigar[k] >> 4);
+		++g.opens, g.bases += len;
+		per_gap(len);
 	}
+	return g;
 }
-}
+} // namespace
 
+// mm_update_dp_max (align.c:1005-1046), for reads with several aligned hits whose two best scores are close and whose best hit covers most of the read:
+// the hits are ranked again by a score recomputed from their own columns under a mismatch penalty fitted to the best hit's divergence (one event per gap,
+// at least 2 %) and a logarithmic gap cost.  Double arithmetic in the reference's order.
 void update_dp_max(int qlen, RegVec &regs, float frac, int a, int b)
 {
-	const int n = (int)regs.size();
-	if (n < 2) return;
-	int32_t max = -1, max2 = -1, max_i = -1;
-	for (int i = 0; i < n; ++i) {
-		const Reg &r = regs[i];
-		if (!r.p) continue;
-		if (r.p->dp_max > max) max2 = max, max = r.p->dp_max, max_i = i;
-		else if (r.p->dp_max > max2) max2 = r.p->dp_max;
+	if (regs.size() < 2) return;
+	int32_t top = -1, second = -1;
+	const Reg *best = nullptr;
+	for (const Reg &h : regs) {
+		if (!h.p) continue;
+		if (h.p->dp_max > top) second = top, top = h.p->dp_max, best = &h;
+		else if (h.p->dp_max > second) second = h.p->dp_max;
 	}
-	if (max_i < 0 || max < 0 || max2 < 0) return;
-	if (regs[max_i].qe - regs[max_i].qs < (double)qlen * frac) return;
-	if (max2 < (double)max * frac) return;
-	int32_t n_gap, n_gapo;
-	count_gaps(regs[max_i], n_gap, n_gapo);
-	const Reg &rm = regs[max_i];
-	double div = 1. - (double)rm.mlen / (rm.blen + rm.p->n_ambi - n_gap + n_gapo); // 1 - mm_event_identity (align.c:997-1003)
+	if (!best || top < 0 || second < 0) return;
+	if (best->qe - best->qs < (double)qlen * frac || second < (double)top * frac) return;
+	const GapTally bg = tally_gaps(*best, [](int32_t) {});
+	double div = 1. - (double)best->mlen / (best->blen + best->p->n_ambi - bg.bases + bg.opens); // 1 - mm_event_identity (align.c:997-1003)
 	if (div < 0.02) div = 0.02;
-	double b2 = 0.5 / div;
-	if (b2 * a < b) b2 = (double)a / b;
-	for (Reg &r : regs) {
-		if (!r.p) continue;
-		// rescore the alignment with a divergence-adapted mismatch penalty and log gap cost (align.c:1005-1020)
-		int32_t gaps = 0;
+	double mis = 0.5 / div; // the mismatch penalty in units of the match score
+	if (mis * a < b) mis = (double)a / b;
+	for (Reg &h : regs) {
+		if (!h.p) continue;
 		double gap_cost = 0.0;
-		for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
-			const int32_t op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
-			if (op == 1 || op == 2) gap_cost += b2 + (double)fast_log2(1.0 + len), gaps += len;
-		}
-		const int32_t n_mis = r.blen + r.p->n_ambi - r.mlen - gaps;
-		r.p->dp_max = (int32_t)(a * (r.mlen - b2 * n_mis - gap_cost) + .499);
-		if (r.p->dp_max < 0) r.p->dp_max = 0;
+		const GapTally g = tally_gaps(h, [&](int32_t len) { gap_cost += mis + (double)fast_log2(1.0 + len); });
+		const int32_t n_mis = h.blen + h.p->n_ambi - h.mlen - g.bases;
+		const int32_t rescored = (int32_t)(a * (h.mlen - mis * n_mis - gap_cost) + .499);
+		h.p->dp_max = rescored < 0 ? 0 : rescored;
 	}
 }
 
@@ -311,172 +308,163 @@ void update_dp_max(int qlen, RegVec &regs, float frac, int a, int b)
 // ---------------------------------------------------------------------------------------------------------
 namespace mm2amd {
 
-// mm_seg_gen (hit.c:342-396): the chains of a fragment, found on the concatenation of its segments, are cut into one set of
-// chains per segment; anchors are copied with the query coordinate made relative to their own segment.
+// mm_seg_gen (hit.c:342-396): the chains of a fragment were found on the concatenation of its segments; every segment gets the chains that have anchors
+// on it -- with the fragment chain's score and its own anchor count -- and those anchors, their query coordinate counted from the segment's own start
+// (from its end for reverse-strand anchors, whose coordinate runs backwards over the concatenation).
 void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, const Anchor *a, RegVec *regs, std::vector<Anchor> *seg_a)
 {
-	const int n_regs0 = (int)regs0.size();
-	int acc_qlen[3] = {0, 0, 0}, qlen_sum;
-	for (int s = 1; s < n_segs; ++s) acc_qlen[s] = acc_qlen[s - 1] + qlens[s - 1];
-	qlen_sum = acc_qlen[n_segs - 1] + qlens[n_segs - 1];
-	std::vector<uint64_t> u[2];
-	size_t n_a[2] = {0, 0};
-	for (int s = 0; s < n_segs; ++s) {
-		u[s].resize(n_regs0);
-		for (int i = 0; i < n_regs0; ++i) u[s][i] = (uint64_t)regs0[i].score << 32;
-	}
-	for (int i = 0; i < n_regs0; ++i)
-		for (int j = 0; j < regs0[i].cnt; ++j) {
-			const int sid = (int)((a[regs0[i].as + j].y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT);
-			++u[sid][i], ++n_a[sid];
+	auto seg_of = [](const Anchor &x) { return (int)((x.y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT); };
+	int before[2] = {0, 0}, total = 0; // bases of the fragment before a segment; all of them
+	for (int s = 0; s < n_segs; ++s) before[s] = total, total += qlens[s];
+	const size_t n_chain = regs0.size();
+	std::vector<int32_t> on_seg[2]; // anchors of every fragment chain on the segment
+	for (int s = 0; s < n_segs; ++s) on_seg[s].assign(n_chain, 0), seg_a[s].clear();
+	for (size_t c = 0; c < n_chain; ++c)
+		for (int j = 0; j < regs0[c].cnt; ++j) {
+			Anchor x = a[regs0[c].as + j];
+			const int s = seg_of(x);
+			++on_seg[s][c];
+			x.y -= x.x >> 63 ? (uint64_t)(total - (qlens[s] + before[s])) : (uint64_t)before[s];
+			seg_a[s].push_back(x); // (chain by chain, so a segment's anchors of one chain stay together, in order)
 		}
 	for (int s = 0; s < n_segs; ++s) {
-		size_t k = 0;
-		for (int i = 0; i < n_regs0; ++i) if ((int32_t)u[s][i] != 0) u[s][k++] = u[s][i]; // chains with no anchor on this segment vanish
-		u[s].resize(k);
-		seg_a[s].clear();
-		seg_a[s].reserve(n_a[s]);
-	}
-	for (int i = 0; i < n_regs0; ++i)
-		for (int j = 0; j < regs0[i].cnt; ++j) {
-			Anchor a1 = a[regs0[i].as + j];
-			const int sid = (int)((a1.y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT);
-			a1.y -= a1.x >> 63 ? (uint64_t)(qlen_sum - (qlens[sid] + acc_qlen[sid])) : (uint64_t)acc_qlen[sid];
-			seg_a[sid].push_back(a1);
-		}
-	for (int s = 0; s < n_segs; ++s) {
-		gen_regs(hash, qlens[s], u[s].data(), (int)u[s].size(), seg_a[s].data(), false, regs[s]);
-		for (Reg &r : regs[s]) r.seg_split = 1, r.seg_id = (uint32_t)s;
+		std::vector<uint64_t> u; // score << 32 | anchors, as the chaining step hands chains over
+		for (size_t c = 0; c < n_chain; ++c)
+			if (on_seg[s][c]) u.push_back((uint64_t)regs0[c].score << 32 | (uint32_t)on_seg[s][c]);
+		gen_regs(hash, qlens[s], u.data(), (int)u.size(), seg_a[s].data(), false, regs[s]);
+		for (Reg &h : regs[s]) h.seg_split = 1, h.seg_id = (uint32_t)s;
 	}
 }
 
-// mm_select_sub_multi (pe.c:6-50)
+// mm_select_sub_multi (pe.c:6-50): which secondary chains of a fragment stay.  A secondary within min_diff of its parent always does; otherwise it has to
+// reach a share of the parent's score that depends on where it lies: next to the parent on the reference (a pair's other placement) a small one, a chain
+// confined to one read against a parent that spans both a large one, else the usual ratio.  At most best_n secondaries.
 void select_sub_multi(float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs, const int *qlens, RegVec &r)
 {
 	if (!(pri_ratio > 0.0f) || r.empty()) return;
-	const int n = (int)r.size(), max_dist = n_segs == 2 ? qlens[0] + qlens[1] + max_gap_ref : 0;
-	int n_2nd = 0, k = 0;
-	std::vector<uint8_t> keep(n, 0);
-	for (int i = 0; i < n; ++i) {
-		int to_keep = 0;
-		if (r[i].parent == i) to_keep = 1;
-		else if (r[i].score + min_diff >= r[r[i].parent].score) to_keep = 1;
-		else {
-			const Reg &p = r[r[i].parent], &q = r[i];
-			if (p.rev == q.rev && p.rid == q.rid && q.re - p.rs < max_dist && p.re - q.rs < max_dist) { // child and parent are close on the reference
-				if (q.score >= p.score * pri1) to_keep = 1;
-			} else {
-				const int is_par_both = (n_segs == 2 && p.qs < qlens[0] && p.qe > qlens[0]);
-				const int is_chi_both = (n_segs == 2 && q.qs < qlens[0] && q.qe > qlens[0]);
-				if (is_chi_both || is_chi_both == is_par_both) {
-					if (q.score >= p.score * pri_ratio) to_keep = 1;
-				} else if (q.score >= p.score * pri2) to_keep = 1;
-			}
-		}
-		if (to_keep && r[i].parent != i && n_2nd++ >= best_n) to_keep = 0;
-		keep[i] = (uint8_t)to_keep;
+	const int reach = n_segs == 2 ? qlens[0] + qlens[1] + max_gap_ref : 0;
+	auto spans_both = [&](const Reg &h) { return n_segs == 2 && h.qs < qlens[0] && h.qe > qlens[0]; };
+	auto share_needed = [&](const Reg &par, const Reg &sec) {
+		const bool beside = par.rev == sec.rev && par.rid == sec.rid && sec.re - par.rs < reach && par.re - sec.rs < reach;
+		if (beside) return pri1;
+		return spans_both(sec) || spans_both(sec) == spans_both(par) ? pri_ratio : pri2;
+	};
+	thread_local std::vector<uint8_t> stays;
+	stays.assign(r.size(), 0);
+	int n_secondary = 0;
+	for (size_t i = 0; i < r.size(); ++i) {
+		const Reg &h = r[i];
+		if (h.parent == (int)i) { stays[i] = 1; continue; }
+		const Reg &par = r[h.parent];
+		const bool good = h.score + min_diff >= par.score || h.score >= par.score * share_needed(par, h);
+		stays[i] = good && n_secondary++ < best_n;
 	}
-	for (int i = 0; i < n; ++i) {
-		if (keep[i]) r[k++] = r[i];
-		else if (r[i].p) free(r[i].p);
-	}
-	r.resize(k);
-	if (k != n) sync_regs(r);
-}
-
-// mm_set_pe_thru (pe.c:52-71)
-static void set_pe_thru(const int *qlens, RegVec *regs)
-{
-	int n_pri[2] = {0, 0}, pri[2] = {-1, -1};
-	for (int s = 0; s < 2; ++s)
-		for (int i = 0; i < (int)regs[s].size(); ++i)
-			if (regs[s][i].id == regs[s][i].parent) ++n_pri[s], pri[s] = i;
-	if (n_pri[0] == 1 && n_pri[1] == 1) {
-		Reg &p = regs[0][pri[0]], &q = regs[1][pri[1]];
-		if (p.rid == q.rid && p.rev == q.rev && abs(p.rs - q.rs) < 3 && abs(p.re - q.re) < 3
-		    && ((p.qs == 0 && qlens[1] - q.qe == 0) || (q.qs == 0 && qlens[0] - p.qe == 0)))
-			p.pe_thru = q.pe_thru = 1;
-	}
+	if (keep_hits(r, [&](size_t i) { return stays[i] != 0; })) sync_regs(r);
 }
 
 namespace {
-struct PairEnt { int s, rev; uint64_t key; Reg *r; };
-struct PairKey { uint64_t operator()(const PairEnt &e) const { return e.key; } };
+// the position of a segment's only primary hit, -1 if it has none or several
+int sole_primary(const RegVec &regs)
+{
+	int at = -1, n = 0;
+	for (size_t i = 0; i < regs.size(); ++i)
+		if (regs[i].id == regs[i].parent) at = (int)i, ++n;
+	return n == 1 ? at : -1;
 }
 
-// mm_pair (pe.c:81-182): choose the best properly oriented pair of hits within max_gap_ref and adjust primaries / MAPQ
+// mm_set_pe_thru (pe.c:52-71): both reads cover the same stretch of the reference end to end (the fragment is no longer than a read)
+void mark_read_through(const int *qlens, RegVec *regs)
+{
+	const int i0 = sole_primary(regs[0]), i1 = sole_primary(regs[1]);
+	if (i0 < 0 || i1 < 0) return;
+	Reg &p = regs[0][i0], &q = regs[1][i1];
+	const bool same_place = p.rid == q.rid && p.rev == q.rev && abs(p.rs - q.rs) < 3 && abs(p.re - q.re) < 3;
+	const bool end_to_end = (p.qs == 0 && qlens[1] - q.qe == 0) || (q.qs == 0 && qlens[0] - p.qe == 0);
+	if (same_place && end_to_end) p.pe_thru = q.pe_thru = 1;
+}
+
+// One hit of either read as mm_pair (pe.c:81-182) looks at it: ordered along the reference; the lowest key bit says whether the hit can CLOSE a pair
+// (reverse hit of read 1 / forward hit of read 2) or OPEN one
+struct End { int seg, rev; uint64_t key; Reg *hit; };
+struct EndKey { uint64_t operator()(const End &e) const { return e.key; } };
+inline int pair_dp(const End &x, const End &y) { return x.hit->p->dp_max + y.hit->p->dp_max; }
+} // namespace
+
+// mm_pair (pe.c:81-182): the best pair of hits, one per read, properly oriented and no further apart than max_gap_ref, becomes the fragment's placement;
+// the MAPQ of its two hits is raised towards a pair-level MAPQ computed from how far the best pair is ahead of the next.
 void pair_hits(int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int *qlens, RegVec *regs)
 {
-	std::vector<PairEnt> a;
-	int dp_thres = 0, segs = 0;
+	// the ends, sorted by (sequence, start, closes-a-pair); a pair must beat the sum of the reads' best scores minus the bonus
+	std::vector<End> ends;
+	int bar = 0;
 	for (int s = 0; s < 2; ++s) {
-		int max = 0;
-		for (Reg &r : regs[s]) {
-			PairEnt e;
-			e.s = s, e.r = &r, e.rev = r.rev;
-			e.key = (uint64_t)r.rid << 32 | (uint64_t)(int64_t)(r.rs << 1 | (s ^ e.rev)); // pe.c:97: int operands widened into the key
-			max = max > r.p->dp_max ? max : r.p->dp_max;
-			a.push_back(e);
-			segs |= 1 << s;
+		if (regs[s].empty()) return; // only one read is mapped
+		int top = 0;
+		for (Reg &h : regs[s]) {
+			ends.push_back(End{s, (int)h.rev, (uint64_t)h.rid << 32 | (uint64_t)(int64_t)(h.rs << 1 | (s ^ (int)h.rev)), &h}); // pe.c:97: int operands widened into the key
+			top = top > h.p->dp_max ? top : h.p->dp_max;
 		}
-		dp_thres += max;
+		bar += top;
 	}
-	if (segs != 3) return; // only one end is mapped
-	dp_thres -= pe_bonus;
-	if (dp_thres < 0) dp_thres = 0;
-	const int n = (int)a.size();
-	{ RsortScratch sc; exact_radix_sort(a.data(), a.data() + n, PairKey(), sc); } // radix_sort_pair: the unstable sort, replayed exactly
-	int64_t max = -1;
-	int max_idx[2] = {-1, -1}, last[2] = {-1, -1};
-	std::vector<uint64_t> sc;
+	bar = bar > pe_bonus ? bar - pe_bonus : 0;
+	const int n = (int)ends.size();
+	{ RsortScratch scratch; exact_radix_sort(ends.data(), ends.data() + n, EndKey(), scratch); } // radix_sort_pair: the unstable sort, replayed exactly
+	// every closing end looks back over the opening ends of its strand, nearest first, until one is too far away
+	int64_t best = -1;
+	int best_at[2] = {-1, -1}, last_open[2] = {-1, -1};
+	std::vector<uint64_t> found; // (dp sum << 32) + (hash sum) of every pair over the bar
 	for (int i = 0; i < n; ++i) {
-		if (a[i].key & 1) { // reverse first read or forward second read
-			if (last[a[i].rev] < 0) continue;
-			Reg *r = a[i].r, *q = a[last[a[i].rev]].r;
-			if (r->rid != q->rid || r->rs - q->re > max_gap_ref) continue;
-			for (int j = last[a[i].rev]; j >= 0; --j) {
-				if (a[j].rev != a[i].rev || a[j].s == a[i].s) continue;
-				q = a[j].r;
-				if (r->rid != q->rid || r->rs - q->re > max_gap_ref) break;
-				if (r->p->dp_max + q->p->dp_max < dp_thres) continue;
-				const int64_t score = (int64_t)(r->p->dp_max + q->p->dp_max) << 32 | (r->hash + q->hash);
-				if (score > max) max = score, max_idx[a[j].s] = j, max_idx[a[i].s] = i;
-				sc.push_back((uint64_t)score);
-			}
-		} else last[a[i].rev] = i; // forward first read or reverse second read
+		const End &c = ends[i];
+		if (!(c.key & 1)) { last_open[c.rev] = i; continue; }
+		const int from = last_open[c.rev];
+		if (from < 0) continue;
+		auto in_reach = [&](const End &o) { return c.hit->rid == o.hit->rid && c.hit->rs - o.hit->re <= max_gap_ref; };
+		if (!in_reach(ends[from])) continue;
+		for (int j = from; j >= 0; --j) {
+			const End &o = ends[j];
+			if (o.rev != c.rev || o.seg == c.seg) continue;
+			if (!in_reach(o)) break;
+			if (pair_dp(c, o) < bar) continue;
+			const int64_t score = (int64_t)pair_dp(c, o) << 32 | (c.hit->hash + o.hit->hash);
+			if (score > best) best = score, best_at[o.seg] = j, best_at[c.seg] = i;
+			found.push_back((uint64_t)score);
+		}
 	}
-	if (sc.size() > 1) sort_u64(sc.data(), sc.data() + sc.size());
-	if (!sc.empty() && max > 0) { // found at least one pair
-		Reg *r[2] = { a[max_idx[0]].r, a[max_idx[1]].r };
-		r[0]->proper_frag = r[1]->proper_frag = 1;
-		for (int s = 0; s < 2; ++s) {
-			if (r[s]->id != r[s]->parent) { // lift to primary and update the parents
-				Reg &p = regs[s][r[s]->parent];
-				for (Reg &x : regs[s]) if (x.parent == p.id) x.parent = r[s]->id;
-				p.mapq = 0;
+	if (found.size() > 1) sort_u64(found.data(), found.data() + found.size());
+	if (!found.empty() && best > 0) {
+		Reg *mate[2] = { ends[best_at[0]].hit, ends[best_at[1]].hit };
+		for (int s = 0; s < 2; ++s) { // the pair's hits become their reads' primaries
+			Reg &h = *mate[s];
+			h.proper_frag = 1;
+			if (h.id != h.parent) {
+				Reg &old_primary = regs[s][h.parent];
+				for (Reg &x : regs[s]) if (x.parent == old_primary.id) x.parent = h.id;
+				old_primary.mapq = 0;
 			}
-			if (!r[s]->sam_pri) {
+			if (!h.sam_pri) {
 				for (Reg &x : regs[s]) x.sam_pri = 0;
-				r[s]->sam_pri = 1;
+				h.sam_pri = 1;
 			}
 		}
-		int mapq_pe = r[0]->mapq > r[1]->mapq ? r[0]->mapq : r[1]->mapq, n_sub = 0;
-		for (uint64_t v : sc) if ((v >> 32) + sub_diff >= (uint64_t)max >> 32) ++n_sub;
-		if (sc.size() > 1) {
-			const int mapq_pe_alt = (int)(6.02f * ((max >> 32) - (sc[sc.size() - 2] >> 32)) / match_sc - 4.343f * logf(n_sub));
-			mapq_pe = mapq_pe < mapq_pe_alt ? mapq_pe : mapq_pe_alt;
+		// pair-level MAPQ: the better of the two hits', capped by the lead over the runner-up pair; single precision as in the reference
+		const uint64_t best_dp = (uint64_t)best >> 32;
+		const bool has_runner_up = found.size() > 1;
+		const uint64_t runner_up_dp = has_runner_up ? found[found.size() - 2] >> 32 : 0;
+		int n_near = 0;
+		for (const uint64_t v : found) if ((v >> 32) + sub_diff >= best_dp) ++n_near;
+		int mapq_pair = mate[0]->mapq > mate[1]->mapq ? mate[0]->mapq : mate[1]->mapq;
+		if (has_runner_up) {
+			const int by_lead = (int)(6.02f * ((best >> 32) - (found[found.size() - 2] >> 32)) / match_sc - 4.343f * logf(n_near));
+			mapq_pair = mapq_pair < by_lead ? mapq_pair : by_lead;
 		}
-		if ((int)r[0]->mapq < mapq_pe) r[0]->mapq = (int)(.2f * r[0]->mapq + .8f * mapq_pe + .499f);
-		if ((int)r[1]->mapq < mapq_pe) r[1]->mapq = (int)(.2f * r[1]->mapq + .8f * mapq_pe + .499f);
-		if (sc.size() == 1) {
-			if (r[0]->mapq < 2) r[0]->mapq = 2;
-			if (r[1]->mapq < 2) r[1]->mapq = 2;
-		} else if ((uint64_t)max >> 32 > sc[sc.size() - 2] >> 32) {
-			if (r[0]->mapq < 1) r[0]->mapq = 1;
-			if (r[1]->mapq < 1) r[1]->mapq = 1;
+		const uint32_t floor_q = !has_runner_up ? 2 : best_dp > runner_up_dp ? 1 : 0;
+		for (int s = 0; s < 2; ++s) {
+			Reg &h = *mate[s];
+			if ((int)h.mapq < mapq_pair) h.mapq = (int)(.2f * h.mapq + .8f * mapq_pair + .499f);
+			if (h.mapq < floor_q) h.mapq = floor_q;
 		}
 	}
-	set_pe_thru(qlens, regs);
+	mark_read_through(qlens, regs);
 }
 
 } // namespace mm2amd
