@@ -12,8 +12,8 @@ def many_bucket_tie_case(dropin, ref_bin, tmp, seed, n_reads, mean_len):
     """Reads with a tandem duplication (pairs of equal anchor keys) against 24 reference sequences with short minimizers (-k 11 -w 5): a few
     thousand anchors per read spread over all sequences and both strands, so the replay of the reference's unstable sort (ksort.h:101-151)
     partitions ranges of hundreds to thousands of elements into 24 (by sequence) and up to 256 (by position byte) buckets.  Returns the
-    reference's SD lines and, per mode of the replay (default: reads with equal keys replayed together, partitions walked over tapes;
-    the same with the one-thread walk; the replay inside the sorting launch), the SD lines of the device path and its stderr."""
+    reference's SD lines and, per mode of the replay (default: reads with equal keys replayed together, partitions walked over tapes, a workgroup per strand;
+    one workgroup for both strands; the one-thread walk; the replay inside the sorting launch), the SD lines of the device path and its stderr."""
     rng = np.random.default_rng(seed)
     contigs = synth.gen_reference(rng, 2400000, 24)
     reads = synth.gen_tandem_reads(rng, contigs, n_reads, mean_len, 0.06)
@@ -24,7 +24,7 @@ def many_bucket_tie_case(dropin, ref_bin, tmp, seed, n_reads, mean_len):
     want = subprocess.run([ref_bin] + args + ["-t", "1", "--print-seeds", ref_fa, rd_fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.decode()
     want_sd = [l for l in want.split("\n") if l.startswith("SD\t")]
     got = {}
-    for name, env in (("tapes", {}), ("walk", {"MM2AMD_NO_TAPE_WALK": "1"}), ("inline", {"MM2AMD_TIE_REPLAY_INLINE": "1"})):
+    for name, env in (("tapes", {}), ("one_workgroup", {"MM2AMD_TIE_NO_STRAND_SPLIT": "1"}), ("walk", {"MM2AMD_NO_TAPE_WALK": "1"}), ("inline", {"MM2AMD_TIE_REPLAY_INLINE": "1"})):
         dump = os.path.join(tmp, "seeds_%s.txt" % name)
         p = subprocess.run([dropin] + args + ["-t", "2", ref_fa, rd_fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                            env=dict(os.environ, MM2AMD_SEED_DUMP=dump, MM2AMD_TWO_BUCKET_TRACE="1", **env))
