@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include "../../minimap2_amd/csrc/backend.hpp"
 #include "../../oracle/oracle.h"
@@ -122,6 +123,46 @@ public:
 			free(a); free(mp);
 		}
 	}
+	// MM2AMD_CHECK_BAND_STATS=file (measurement): for every gap-fill window, how many cells of its q x t rectangle can NO alignment
+	// at least as good as a known one pass through?  The known one is the best global alignment inside a narrow band (16 + the length difference: what a
+	// cheap first pass would give); a path through cell (i, j) scores at most  a * (min(i, j) + min(q - i, t - j)) - gap(|i - j|) - gap(|(q - i) - (t - j)|)
+	// (all other columns matching, the unavoidable gaps at the dual affine cost).  One line per window: qlen tlen w score narrow_score cells_below_narrow
+	// cells_below_optimum, then the symmetric band that holds the remaining cells, its cells, and whether the reference's routine gives the same result in it.
+	const char *band_stats_ = getenv("MM2AMD_CHECK_BAND_STATS");
+	void band_stats(const KswJob &j, const KswScoring &sc, const uint8_t *q, const uint8_t *t, int score)
+	{
+		const int ql = j.qlen, tl = j.tlen, diff = ql > tl ? ql - tl : tl - ql;
+		ora_ez_t ezn;
+		std::vector<uint32_t> cg((size_t)ql + tl + 8);
+		ora_ksw_extd2(ql, q, tl, t, sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, 16 + diff, -1, -1, KSW_APPROX_MAX, &ezn, cg.data(), (int)cg.size());
+		const int a = sc.mat[0];
+		auto gap = [&](int d) { if (d == 0) return 0; const int g1 = sc.q + sc.e * d, g2 = sc.q2 + sc.e2 * d; return g1 < g2 ? g1 : g2; };
+		long below_narrow = 0, below_opt = 0;
+		int reach = 0; // the widest |i - j| among the cells that are not excluded
+		for (int i = 0; i <= ql; ++i)
+			for (int k = 0; k <= tl; ++k) {
+				const int before = i < k ? i : k, after = ql - i < tl - k ? ql - i : tl - k;
+				const int d0 = i > k ? i - k : k - i, d1 = (ql - i) > (tl - k) ? (ql - i) - (tl - k) : (tl - k) - (ql - i);
+				const int ub = a * (before + after) - gap(d0) - gap(d1);
+				below_narrow += ub < ezn.score, below_opt += ub < score;
+				if (ub >= ezn.score && d0 > reach) reach = d0;
+			}
+		// the reference's own routine with the band that holds those cells (+ 2): the same score and CIGAR as with the window's band?  cells of that band
+		const int w2 = reach + 2;
+		ora_ez_t ez2, ez1;
+		std::vector<uint32_t> cg2((size_t)ql + tl + 8);
+		ora_ksw_extd2(ql, q, tl, t, sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez1, cg.data(), (int)cg.size());
+		ora_ksw_extd2(ql, q, tl, t, sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, w2, j.zdrop, j.end_bonus, j.flag & 0x1fff, &ez2, cg2.data(), (int)cg2.size());
+		const bool same = ez1.score == ez2.score && ez1.n_cigar == ez2.n_cigar && ez1.zdropped == ez2.zdropped && memcmp(cg.data(), cg2.data(), (size_t)ez1.n_cigar * 4) == 0;
+		long band_cells = 0;
+		for (int i = 0; i < ql; ++i) { const int lo = i - w2 > 0 ? i - w2 : 0, hi = i + w2 < tl - 1 ? i + w2 : tl - 1; if (hi >= lo) band_cells += hi - lo + 1; }
+		static std::mutex mu;
+		std::lock_guard<std::mutex> lk(mu);
+		if (FILE *fp = fopen(band_stats_, "a")) {
+			fprintf(fp, "%d\t%d\t%d\t%d\t%d\t%ld\t%ld\t%d\t%ld\t%d\n", ql, tl, j.w, score, ezn.score, below_narrow, below_opt, w2, band_cells, same ? 1 : 0);
+			fclose(fp);
+		}
+	}
 	void ksw(const std::vector<KswJob> &jobs, const KswScoring &sc, int /*lane*/, int /*n_threads*/, std::vector<KswRes> &res, const uint32_t **cigar_out) override
 	{
 		std::vector<uint32_t> &cigar = cigar_store_;
@@ -168,6 +209,7 @@ public:
 				else ora_ksw_extd2(j.qlen, q.data(), j.tlen, t.data(), sc.m, sc.mat, sc.q, sc.e, sc.q2, sc.e2, j.w, j.zdrop, j.end_bonus, j.flag & 0x1fff,
 				                   &ez, cg.data(), (int)cg.size());
 			}
+			if (band_stats_ && !sc.single && !(j.flag & KSWJ_SKIP) && (j.flag & 0x1fff) == KSW_APPROX_MAX && j.qlen > 0 && j.tlen > 0) band_stats(j, sc, q.data(), t.data(), ez.score);
 			r.max = ez.max, r.zdropped = ez.zdropped, r.max_q = ez.max_q, r.max_t = ez.max_t, r.mqe = ez.mqe, r.mqe_t = ez.mqe_t;
 			r.mte = ez.mte, r.mte_q = ez.mte_q, r.score = ez.score, r.n_cigar = ez.n_cigar, r.reach_end = ez.reach_end;
 			r.cigar_off = (uint32_t)cigar.size();
