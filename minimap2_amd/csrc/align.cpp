@@ -273,7 +273,7 @@ static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qsh
 		uint32_t q_at = 0, t_at = 0;
 		for (uint32_t k = 0; k < n; ++k) {
 			const uint32_t op = cg_op(cg[k]), len = cg_len(cg[k]);
-			if (len == 0) repack = true;
+			if (len + (k > 0 ? slide[k - 1] : 0) == 0) repack = true; // empty as the reference's walk meets it: after the gap before it has slid (a match it lent bases to is no longer empty)
 			if (cg_is_gap(cg[k]) && k > 0 && k + 1 < n && cg_op(cg[k - 1]) == 0 && cg_op(cg[k + 1]) == 0) {
 				const uint32_t room = cg_len(cg[k - 1]) + (k >= 2 ? slide[k - 2] : 0);
 				slide[k] = op == 1 ? gap_slide(qseq, q_at, len, room) : gap_slide(tseq, t_at, len, room);

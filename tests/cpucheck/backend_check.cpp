@@ -243,3 +243,42 @@ extern "C" long long mm2amd_alloc_counter(int) { return 0; }
 namespace mm2amd {
 
 } // namespace mm2amd
+
+// TEST HOOK (not part of the product's ABI): the HOST's append_cigar + update_extra (align.cpp: the twin of mm_append_cigar, mm_fix_cigar and
+// mm_update_extra the host path uses where region_finish_kernel does not run) on jobs in mm2amd_update_extra_batch's layout, so that the adversarial
+// CIGARs of tests/test_gpu_update_extra.py can be put to it and to the reference's own routine (oracle/ref_align_shim.c) side by side.
+#include "../../minimap2_amd/csrc/align.hpp"
+#include "mm2amd.h"
+extern "C" int check_update_extra_host(int n_jobs, const mm2amd_fin_job_t *jobs, const int8_t *mat25, int8_t q, int8_t e, int log_gap, int eqx,
+                                       mm2amd_fin_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_cap)
+{
+	using namespace mm2amd;
+	size_t used = 0;
+	for (int i = 0; i < n_jobs; ++i) {
+		const mm2amd_fin_job_t &j = jobs[i];
+		mm2amd_fin_res_t &o = res[i];
+		memset(&o, 0, sizeof o);
+		Reg r{};
+		r.qs = 0, r.qe = j.qlen, r.rs = 0, r.re = j.tlen, r.rev = 0;
+		int64_t qsum = 0, tsum = 0;
+		for (int k = 0; k < j.n_pieces; ++k) {
+			for (int w = 0; w < j.piece_len[k]; ++w) {
+				const uint32_t c = j.piece[k][w], op = c & 0xf, len = c >> 4;
+				if (op == 0 || op == 7 || op == 8) qsum += len, tsum += len; else if (op == 1) qsum += len; else if (op == 2 || op == 3) tsum += len;
+			}
+			if (j.piece_len[k] > 0) append_cigar(r, (uint32_t)j.piece_len[k], j.piece[k]);
+		}
+		if (qsum != j.qlen || tsum != j.tlen || !r.p) { o.n_cigar = -1; free(r.p); continue; }
+		std::vector<uint8_t> qb((size_t)j.qlen + 32, 4), tb((size_t)j.tlen + 32, 4); // (update_extra compares 16 columns per load)
+		if (j.qlen) memcpy(qb.data(), j.query, (size_t)j.qlen);
+		if (j.tlen) memcpy(tb.data(), j.target, (size_t)j.tlen);
+		update_extra(r, qb.data(), tb.data(), mat25, q, e, eqx != 0, log_gap != 0);
+		o.n_cigar = (int32_t)r.p->n_cigar, o.blen = r.blen, o.mlen = r.mlen, o.n_ambi = (int32_t)r.p->n_ambi, o.dp_max = r.p->dp_max;
+		o.qshift = r.qs, o.tshift = r.rs, o.is_spliced = r.is_spliced, o.cigar_off = (uint32_t)used;
+		if (used + r.p->n_cigar > cigar_pool_cap) { free(r.p); return -1; }
+		memcpy(cigar_pool + used, r.p->cigar, (size_t)r.p->n_cigar * 4);
+		used += r.p->n_cigar;
+		free(r.p);
+	}
+	return 0;
+}
