@@ -478,6 +478,19 @@ def test_rmq_chainer_breaks_ties_like_the_reference():
     assert out[0] == b"OK" and int(out[2]) > 500000
 
 
+def test_host_hit_rules_against_the_reference_functions():
+    """minimap2_amd/csrc/hits.cpp -- parents, secondaries, SAM primary, MAPQ, the filters, the rescoring, the hit sort, chains -> hits, the fragment
+    split, the anchor squeeze, a fragment's secondaries, the pairing of two reads' hits -- against the reference's own functions (hit.c, pe.c, align.c's
+    mm_update_dp_max) on random hit lists built to make the rules bite: equal scores and hashes, nested query intervals, dead hits, ALT hits, both reads'
+    hits interleaved on the reference (tests/cpucheck/hits_test.cpp; it also checks that its cases reach the rules)."""
+    exe = os.path.join(HERE, "_build", "hits_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/hits_test not built (needs the compiled reference)")
+    p = subprocess.run([exe, "3000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    assert p.stdout.split()[0] == b"OK"
+
+
 def test_device_sdust_header_against_the_reference():
     """minimap2_amd/csrc/sdust_core.hpp (what dust_filter_kernel runs per read) compiled for the host, vs the reference's sdust()."""
     exe = os.path.join(HERE, "_build", "sdust_test")
