@@ -33,12 +33,13 @@ void mm_update_dp_max(int qlen, int n_regs, Reg *regs, float frac, int a, int b)
 SegRef *mm_seg_gen(void *km, uint32_t hash, int n_segs, const int *qlens, int n_regs0, const Reg *regs0, int *n_regs, Reg **regs, const Anchor *a);
 void mm_seg_free(void *km, int n_segs, SegRef *segs);
 void mm_pair(void *km, int max_gap_ref, int dp_bonus, int sub_diff, int match_sc, const int *qlens, int *n_regs, Reg **regs);
+void mm_est_err(const ref::Idx *mi, int qlen, int n_regs, Reg *regs, const Anchor *a, int32_t n, const uint64_t *mini_pos);
 }
 
 static std::mt19937_64 rng(20260923);
 static int rnd(int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); } // inclusive
 static bool coin(int one_in) { return rng() % (uint64_t)one_in == 0; }
-static long n_paired, n_rescored, n_sorted_out, n_multi_dropped, n_secondary_dropped, n_mapq_nonzero; // did the cases reach the rules they are for?
+static long n_div_pos, n_div_skipped, n_paired, n_rescored, n_sorted_out, n_multi_dropped, n_secondary_dropped, n_mapq_nonzero; // did the cases reach the rules they are for?
 
 static ref::Extra *make_extra(int n_cigar, int dp_max)
 {
@@ -209,6 +210,48 @@ int main(int argc, char **argv)
 			same("squeeze_anchors", it, kept.data(), (int)kept.size(), kept2.data(), (int)kept2.size());
 			free(theirs);
 		}
+		{ // divergence from the minimizers a chain misses (esterr.c:30-64): chains over random subsets of the read's minimizers, both strands, spans of k or (homopolymer-compressed) of their own
+			const int k = rnd(11, 19), n_mini = rnd(1, 400), n_seq = 3;
+			const bool hpc = coin(3);
+			std::vector<uint64_t> mini((size_t)n_mini);
+			int pos = k;
+			for (int i = 0; i < n_mini; ++i) { const int span = hpc ? k + rnd(0, 20) : k; pos += rnd(1, 12); mini[(size_t)i] = (uint64_t)span << 32 | (uint32_t)pos; }
+			const int rlen = pos + rnd(1, 60);
+			mm2amd::FlatIndex fi;
+			fi.k = k, fi.w = 10, fi.flag = hpc ? ref::I_HPC : 0, fi.n_seq = n_seq;
+			ref::IdxSeq seqs[3];
+			memset(seqs, 0, sizeof seqs);
+			for (int i = 0; i < n_seq; ++i) { const uint32_t l = (uint32_t)rnd(500, 200000); fi.seq_len.push_back(l), seqs[i].len = l; }
+			ref::Idx mi;
+			memset(&mi, 0, sizeof mi);
+			mi.k = k, mi.w = 10, mi.flag = fi.flag, mi.n_seq = n_seq, mi.seq = seqs;
+			const int n_hit = rnd(1, 8);
+			RegVec a((size_t)n_hit);
+			std::vector<Anchor> anchors;
+			for (Reg &h : a) {
+				memset(&h, 0, sizeof h);
+				h.rev = (uint32_t)rnd(0, 1), h.rid = rnd(0, n_seq - 1), h.as = (int32_t)anchors.size();
+				std::vector<int> pick;
+				for (int i = rnd(0, n_mini - 1); i < n_mini && (int)pick.size() < 60; i += rnd(1, 4)) pick.push_back(i);
+				if (coin(10)) pick.clear(); // a hit that lost its anchors
+				h.cnt = (int32_t)pick.size();
+				for (int c = 0; c < h.cnt; ++c) {
+					const uint64_t m = mini[(size_t)pick[(size_t)(h.rev ? h.cnt - 1 - c : c)]];
+					const int span = (int)(m >> 32 & 0xff), p = (int)(uint32_t)m;
+					Anchor x;
+					x.x = (uint64_t)h.rev << 63 | (uint64_t)h.rid << 32 | (uint32_t)(1000 + (int)anchors.size());
+					x.y = (uint64_t)span << 32 | (uint32_t)(h.rev ? rlen - 1 - (p + 1 - span) : p);
+					if (coin(40)) x.y += 1; // a position that is no minimizer's: the first one makes the reference give the hit up, a later one is a miss
+					anchors.push_back(x);
+				}
+				h.qs = rnd(0, rlen - 1), h.qe = rlen - rnd(0, 30), h.rs = rnd(0, 40), h.re = (int32_t)fi.seq_len[(size_t)h.rid] - rnd(0, 40);
+			}
+			RegVec b = a;
+			mm2amd::est_err(fi, rlen, a, anchors.data(), mini.data(), n_mini);
+			mm_est_err(&mi, rlen, n_hit, b.data(), anchors.data(), n_mini, mini.data());
+			same("est_err", it, a.data(), n_hit, b.data(), n_hit);
+			for (const Reg &h : a) n_div_pos += h.div > 0.0f, n_div_skipped += h.div < 0.0f;
+		}
 		{ // a fragment's secondaries; the two reads' hits paired (pe.c:6-50, :81-182)
 			const int qlens[2] = { rnd(80, 250), rnd(80, 250) };
 			RegVec f = random_hits(n, qlens[0] + qlens[1], false);
@@ -243,8 +286,8 @@ int main(int argc, char **argv)
 			for (int s = 0; s < 2; ++s) same("pair_hits", it, ends[s].data(), (int)ends[s].size(), ends2[s].data(), n_ends[s]), release(ends[s]), release(ends2[s]);
 		}
 	}
-	if (n_case >= 500 && (n_paired < n_case / 20 || n_rescored < n_case / 50 || n_sorted_out < n_case / 50 || n_multi_dropped < n_case / 50 || n_secondary_dropped < n_case / 50 || n_mapq_nonzero < n_case / 20))
+	if (n_case >= 500 && (n_paired < n_case / 20 || n_rescored < n_case / 50 || n_sorted_out < n_case / 50 || n_multi_dropped < n_case / 50 || n_secondary_dropped < n_case / 50 || n_mapq_nonzero < n_case / 20 || n_div_pos < n_case || n_div_skipped < n_case / 20))
 		fail("coverage", n_case, "the random cases no longer reach a rule they are for");
-	printf("OK %d (pairs found %ld, rescored %ld, dead hits sorted out %ld, secondaries dropped %ld + %ld, MAPQ between 1 and 59: %ld)\n", n_case, n_paired, n_rescored, n_sorted_out, n_secondary_dropped, n_multi_dropped, n_mapq_nonzero);
+	printf("OK %d (pairs found %ld, rescored %ld, dead hits sorted out %ld, secondaries dropped %ld + %ld, MAPQ between 1 and 59: %ld, divergence estimated %ld / given up %ld)\n", n_case, n_paired, n_rescored, n_sorted_out, n_secondary_dropped, n_multi_dropped, n_mapq_nonzero, n_div_pos, n_div_skipped);
 	return 0;
 }
