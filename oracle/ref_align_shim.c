@@ -28,3 +28,24 @@ int refshim_update_extra(int n_pieces, const uint32_t *const *pieces, const int3
 	free(r.p);
 	return n;
 }
+
+/* The same with MM_F_EQX's mm_update_cigar_eqx (align.c:183-252, also static) applied: matches cut into = and X stretches, which can leave MORE operations
+ * than came in -- cigar_out holds cigar_cap words; returns -(operations) if that is too few. */
+int refshim_update_extra_eqx(int n_pieces, const uint32_t *const *pieces, const int32_t *piece_len, int qlen, const uint8_t *qseq, int tlen, const uint8_t *tseq,
+                             const int8_t *mat, int gq, int ge, int log_gap, uint32_t *cigar_out, int cigar_cap, int32_t *res8)
+{
+	mm_reg1_t r;
+	int i, n;
+	memset(&r, 0, sizeof r);
+	r.qs = 0, r.qe = qlen, r.rs = 0, r.re = tlen, r.rev = 0;
+	for (i = 0; i < n_pieces; ++i) mm_append_cigar(&r, (uint32_t)piece_len[i], pieces[i]);
+	memset(res8, 0, 8 * sizeof(int32_t));
+	if (r.p == 0) return 0;
+	mm_update_extra(&r, qseq, tseq, mat, (int8_t)gq, (int8_t)ge, 1, log_gap);
+	n = (int)r.p->n_cigar;
+	if (n > cigar_cap) { free(r.p); return -n; }
+	memcpy(cigar_out, r.p->cigar, (size_t)n * 4);
+	res8[0] = r.blen, res8[1] = r.mlen, res8[2] = (int32_t)r.p->n_ambi, res8[3] = r.p->dp_max, res8[4] = r.qs, res8[5] = r.rs, res8[6] = r.is_spliced, res8[7] = (int32_t)r.p->capacity;
+	free(r.p);
+	return n;
+}

@@ -408,7 +408,7 @@ def export_index(al):
 REFALIGN_SO = os.path.join(os.path.dirname(REF_SO), "librefalign.so")  # oracle/ref_align_shim.c: the reference's static mm_update_extra behind one entry point
 
 
-def ref_update_extra(qs, ts, pieces, mat, q, e, log_gap):
+def ref_update_extra(qs, ts, pieces, mat, q, e, log_gap, eqx=False):
     """the UNMODIFIED reference's mm_append_cigar + mm_fix_cigar + mm_update_extra (align.c:320-334, :105-181, :254-303) on a region given as its windows' CIGARs;
     returns (cigar_tuple, blen, mlen, n_ambi, dp_max, qshift, tshift, is_spliced), the layout of minimap2_amd.update_extra_batch"""
     L = C.CDLL(REFALIGN_SO)
@@ -419,6 +419,13 @@ def ref_update_extra(qs, ts, pieces, mat, q, e, log_gap):
     tot = sum(len(p) for p in pieces)
     out = (C.c_uint32 * max(tot, 1))()
     res = (C.c_int32 * 8)()
+    if eqx:  # MM_F_EQX: mm_update_cigar_eqx on top (the match stretches can outnumber the operations that came in)
+        cap = tot + len(qb) + 8
+        out = (C.c_uint32 * cap)()
+        L.refshim_update_extra_eqx.restype = C.c_int
+        n = L.refshim_update_extra_eqx(len(pieces), pp, pl, len(qb), qb, len(tb), tb, bytes(mat), q, e, 1 if log_gap else 0, out, cap, res)
+        assert n >= 0
+        return (tuple(out[:n]), res[0], res[1], res[2], res[3], res[4], res[5], res[6])
     L.refshim_update_extra.restype = C.c_int
     n = L.refshim_update_extra(len(pieces), pp, pl, len(qb), qb, len(tb), tb, bytes(mat), q, e, 1 if log_gap else 0, out, res)
     return (tuple(out[:n]), res[0], res[1], res[2], res[3], res[4], res[5], res[6])
