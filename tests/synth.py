@@ -525,3 +525,62 @@ def gen_tandem_reads(rng, contigs, n, mean, err, dup_len=400):
         r[sub] = (r[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
         out.append(r)
     return out
+
+
+def gen_sv_reads(rng, contig, n_each):
+    """Reads with what real long reads have and single-base error models do not: (1) insertions and deletions of 30-160 bases, alone and in clusters a few
+    dozen bases apart (mm_filter_bad_seeds / _alt, align.c:447-525: seeds between such gaps are dropped, clusters bridged by one long window); (2) a
+    deletion or an insertion of 6-9 kb (beyond the chaining gap, within the long-join bandwidth); (3) one of 24-60 kb (beyond it: two hits on one strand,
+    each one's extension bounded by the other's seeds, align.c:706-767); (4) reads at the very ends of the sequence; (5) short error-free reads.  codes."""
+    c, L = contig, len(contig)
+    rnd_seq = lambda k: rng.integers(0, 4, k, dtype=np.uint8)
+    reads = []
+    for i in range(n_each):
+        a = int(rng.integers(20000, L - 60000))
+        seg, parts, p = c[a:a + 14000], [], 0
+        for _ in range(int(rng.integers(2, 6))):
+            step = int(rng.integers(150, 2500)); parts.append(seg[p:p + step]); p += step
+            k = int(rng.integers(30, 160))
+            if rng.random() < 0.5: p += k
+            else: parts.append(rnd_seq(k))
+            if rng.random() < 0.6:
+                step = int(rng.integers(20, 120)); parts.append(seg[p:p + step]); p += step
+                k = int(rng.integers(30, 120))
+                if rng.random() < 0.5: p += k
+                else: parts.append(rnd_seq(k))
+        parts.append(seg[p:])
+        reads.append(np.concatenate(parts))
+        b = int(rng.integers(20000, L - 60000))
+        if i % 2 == 0: reads.append(np.concatenate([c[b:b + 5000], c[b + 5000 + int(rng.integers(6000, 9000)):][:5000]]))
+        else: reads.append(np.concatenate([c[b:b + 5000], rnd_seq(int(rng.integers(6000, 8000))), c[b + 5000:b + 10000]]))
+        d = int(rng.integers(20000, L - 120000))
+        reads.append(np.concatenate([c[d:d + 6000], c[d + 6000 + int(rng.integers(30000, 60000)):][:6000]]))
+        reads.append(np.concatenate([c[d:d + 5000], rnd_seq(int(rng.integers(24000, 30000))), c[d + 5000:d + 10000]]))
+        reads.append(c[:int(rng.integers(6000, 9000))].copy())
+        reads.append(c[L - int(rng.integers(6000, 9000)):].copy())
+    out = []
+    for k, r in enumerate(reads):
+        r = mutate_read(rng, r, 0.05)
+        out.append(COMP[r[::-1]] if k % 3 == 1 else r)
+    for k in range(4 * n_each):
+        e = int(rng.integers(1000, L - 5000))
+        r = c[e:e + int(rng.integers(1500, 3000))].copy()
+        out.append(COMP[r[::-1]] if k % 2 else r)
+    return out
+
+
+def gen_inverted_copy_case(rng, n_reads):
+    """A 12 kb segment with partial INVERTED copies elsewhere (7 kb on the same sequence, 6 kb on the other): reads over the segment get a secondary chain on
+    the other strand that the score ratio would drop and mm_select_sub's strand rule retains (hit.c:255-281), to be judged by its divergence later
+    (mm_filter_strand_retained, hit.c:283-299).  Returns (contigs, reads) as codes."""
+    contigs = gen_reference(rng, 600000, 2)
+    c, c2 = contigs[0].copy(), contigs[1].copy()
+    S = c[100000:112000].copy()
+    c[200000:207000] = COMP[S[:7000][::-1]]
+    c2[50000:56000] = COMP[S[3000:9000][::-1]]
+    reads = []
+    for k in range(n_reads):
+        st = 100000 + int(rng.integers(-1500, 1500))
+        r = mutate_read(rng, c[st:st + int(rng.integers(11000, 14000))], 0.04)
+        reads.append(COMP[r[::-1]] if k % 2 else r)
+    return [c, c2], reads

@@ -193,6 +193,40 @@ def test_partitions_walked_over_tapes(tmp_path):
         assert got[name][0] == want, name
 
 
+def _dropin_case(tmp_path, name, contigs, reads, runs):
+    """SAM of tests/_build/dropin_emu == the compiled reference's, per (preset, environment)"""
+    d = tmp_path / name
+    d.mkdir()
+    ref_fa, rd_fa = str(d / "ref.fa"), str(d / "reads.fa")
+    open(ref_fa, "w").write("".join(">chr%d\n%s\n" % (i + 1, synth.ACGT[c].tobytes().decode()) for i, c in enumerate(contigs)))
+    open(rd_fa, "w").write("".join(">%s%d\n%s\n" % (name, i, synth.ACGT[r].tobytes().decode()) for i, r in enumerate(reads)))
+    wants = {}
+    for preset, env in runs:
+        if preset not in wants:
+            wants[preset] = G.strip_pg(subprocess.run([G.REF_BIN, "-x", preset, "-t", "2", "-a", ref_fa, rd_fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout)
+        p = subprocess.run([DROPIN_EMU, "-x", preset, "-t", "2", "-a", ref_fa, rd_fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        assert G.strip_pg(p.stdout) == wants[preset], (name, preset, env)
+    return wants
+
+
+def test_structural_variants_through_the_region_kernels(tmp_path):
+    """what real long reads have and a single-base error model does not: 30-160 base insertions / deletions alone and in clusters (the device twins of
+    mm_filter_bad_seeds / mm_filter_bad_seeds_alt in region_plan_kernel), gaps beyond the chaining gap and beyond the long-join bandwidth (two hits on one
+    strand, each extension bounded by the other's seeds), reads at the ends of a sequence, error-free reads; and partial inverted copies (the strand rule's
+    hand-back in chain_regs_kernel).  tools/coverage_emu.sh showed these lines of region_dev.hip unreached by everything else.  SAM == the reference's on the
+    device path and on the host's"""
+    if not os.path.exists(DROPIN_EMU) or not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    rng = np.random.default_rng(61)
+    contigs = synth.gen_reference(rng, 800000, 2)
+    reads = synth.gen_sv_reads(rng, contigs[0], 2)
+    w = _dropin_case(tmp_path, "sv", contigs, reads, [("map-ont", {}), ("map-ont", {"MM2AMD_DEVICE_REGIONS": "0"}), ("map-pb", {})])
+    assert sum(1 for l in w["map-ont"].split(b"\n") if l and not l.startswith(b"@")) > len(reads)  # supplementary alignments: the far-apart hits
+    contigs, reads = synth.gen_inverted_copy_case(np.random.default_rng(62), 6)
+    _dropin_case(tmp_path, "inv", contigs, reads, [("map-ont", {}), ("map-hifi", {})])
+
+
 def test_pipeline_equals_batch_by_batch(emu):
     """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
     (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
