@@ -193,6 +193,18 @@ def test_partitions_walked_over_tapes(tmp_path):
         assert got[name][0] == want, name
 
 
+def test_equal_keys_in_reads_beyond_the_lds_classes(tmp_path):
+    """reads of ~30 kb: more than 10240 anchors, sorted on global scratch by the comparison network and, having equal keys, replayed there by their own
+    workgroup (tie_exact_replay over the split key / index arrays: the one-thread walk, the wave-wide bucket scan, children side by side) -- the path
+    tools/coverage_emu.sh showed no other case took; anchors in order == the reference's --print-seeds"""
+    if not os.path.exists(DROPIN_EMU) or not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    import tie_cases
+    want, got = tie_cases.many_bucket_tie_case(DROPIN_EMU, G.REF_BIN, str(tmp_path), 99, 3, 30000, modes=("tapes",))
+    assert len(want) > 3 * 10240
+    assert got["tapes"][0] == want
+
+
 def _dropin_case(tmp_path, name, contigs, reads, runs):
     """SAM of tests/_build/dropin_emu == the compiled reference's, per (preset, environment)"""
     d = tmp_path / name

@@ -8,7 +8,7 @@ import numpy as np
 import synth
 
 
-def many_bucket_tie_case(dropin, ref_bin, tmp, seed, n_reads, mean_len):
+def many_bucket_tie_case(dropin, ref_bin, tmp, seed, n_reads, mean_len, modes=None):
     """Reads with a tandem duplication (pairs of equal anchor keys) against 24 reference sequences with short minimizers (-k 11 -w 5): a few
     thousand anchors per read spread over all sequences and both strands, so the replay of the reference's unstable sort (ksort.h:101-151)
     partitions ranges of hundreds to thousands of elements into 24 (by sequence) and up to 256 (by position byte) buckets.  Returns the
@@ -25,6 +25,8 @@ def many_bucket_tie_case(dropin, ref_bin, tmp, seed, n_reads, mean_len):
     want_sd = [l for l in want.split("\n") if l.startswith("SD\t")]
     got = {}
     for name, env in (("tapes", {}), ("one_workgroup", {"MM2AMD_TIE_NO_STRAND_SPLIT": "1"}), ("walk", {"MM2AMD_NO_TAPE_WALK": "1"}), ("inline", {"MM2AMD_TIE_REPLAY_INLINE": "1"})):
+        if modes is not None and name not in modes:
+            continue
         dump = os.path.join(tmp, "seeds_%s.txt" % name)
         p = subprocess.run([dropin] + args + ["-t", "2", ref_fa, rd_fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                            env=dict(os.environ, MM2AMD_SEED_DUMP=dump, MM2AMD_TWO_BUCKET_TRACE="1", **env))
