@@ -446,7 +446,7 @@ def main():
     drv_cpu_last_batch = {k: round(v, 3) for k, v in al.last_stats().items() if k.startswith("drv_cpu_")}  # the lane drivers' own CPU seconds per stage, last timed batch
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(a.steps, 1)
     log("rank %d: host CPU time per step %.2f core-seconds (%d threads; hand-over, host stages of the mapping, hit gather, formatting)" % (rank, host_cpu_s, n_threads))
-    prof = mm.profile_get()
+    prof = {k: v for k, v in mm.profile_get().items() if v["launches"] > 0}  # (entries without launches are counts that go with a kernel: see extra1 below)
     mm.profile_enable(False)
 
     def one_step(step, staged_outside=True):
@@ -471,6 +471,7 @@ def main():
     # un-overlapped kernel times: one more pass over the same batch with ONE lane (sub-batches one after the other, so no two
     # kernels of the path run at the same time and HIP-event spans are costs); feeds roofline.valu and roofline.unoverlapped_ms
     prof1 = None
+    extra1 = {}
     t_one = None
     stage_cpu = None
     if rank == 0 and world == 1 and not a.timed_only:
@@ -481,6 +482,8 @@ def main():
         stage_cpu = {k: round(v, 3) for k, v in al.last_stats().items() if k.startswith("cpu_") or k.startswith("drv_cpu_")}
         log("un-overlapped pass (one lane): %.3f s; process CPU seconds while each stage ran: %s" % (t_one, stage_cpu))
         prof1 = mm.profile_get()
+        extra1 = {k: v for k, v in prof1.items() if v["launches"] == 0}  # counts that go with a kernel without being a launch (band_cells_computed<NB>)
+        prof1 = {k: v for k, v in prof1.items() if v["launches"] > 0}
         mm.profile_enable(False)
         del os.environ["MM2AMD_ACTIVE_LANES"], os.environ["MM2AMD_NO_SIDE_STREAM"]
     fmt = None
@@ -554,9 +557,19 @@ def main():
         roof["avg_launch_ms_by_instantiation"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(inst.items())}
         if prof1:
             # the register-resident gap-fill DP: the streaming kernel (targets <= 512: >95 % of the cells), else the strip kernel (MM2AMD_NO_STREAM)
-            vfam = next((f for f in ("ksw_stream_kernel", "ksw_gapfill_kernel") if any(family(k) == f for k in prof1)), fam)
-            one = {k: v for k, v in prof1.items() if family(k) == vfam}
+            # (round 6: or the banded kernel, ksw_band.hip -- whichever of the three costs most)
+            dp_fams = {f: sum(v["ms"] for k, v in prof1.items() if family(k) == f) for f in ("ksw_band_kernel", "ksw_stream_kernel", "ksw_gapfill_kernel")}
+            vfam = max(dp_fams, key=dp_fams.get) if max(dp_fams.values()) > 0 else fam
+            one = {k: v for k, v in prof1.items() if family(k) == vfam and v["units"] > 0}
             ms1, cells1 = sum(v["ms"] for v in one.values()), sum(v["units"] for v in one.values())
+            rect_cells1 = cells1
+            if vfam == "ksw_band_kernel":
+                # the banded kernel's launches account the cells of the RECTANGLES they stand for (what the reference computes); the issue roofline counts the
+                # cells it computes: rows x 64 lanes x register sets x 2 jobs (band_cells_computed<NB>, ksw_host.cpp)
+                comp = {k.replace("ksw_band_kernel", "band_cells_computed").split("[")[0]: k for k in one}
+                for ck, k in comp.items():
+                    one[k] = dict(one[k], units=extra1.get(ck, {}).get("units", 0.0))
+                cells1 = sum(v["units"] for v in one.values())
             # Issue cost of one register-set row (128 cells) of the kernel's hot loop: its VALU instructions as counted in the ISA (hipcc -S,
             # gfx950: streaming kernel 35 packed VOP3P (the keyed cell's 34 and the store's share) + 6 DPP moves + 1 v_perm (VOP3) + 7 VOP2 = 49 -- 51 + 6 + 1 + 6
             # = 64 with round 3's cell; strip kernel 34 + 6 + 11 others + 12 VOP2), priced
@@ -583,7 +596,7 @@ def main():
                 isa_current = bool(isa) and sources_now() == isa.get("sources_sha256")
             except Exception:
                 isa_current = False
-            lane_util = (isa.get("lane_utilisation") or {}).get(vfam, 0.872 if vfam == "ksw_stream_kernel" else 0.727)
+            lane_util = (isa.get("lane_utilisation") or {}).get(vfam, 0.872 if vfam == "ksw_stream_kernel" else 1.0 if vfam == "ksw_band_kernel" else 0.727)  # (banded kernel: every lane of every row counted as computed)
             t_issue = t_nominal = 0.0  # seconds the family's cells take at the issue peak / at the guide's 2 cycles per instruction
             rows = {}
             for k, v in one.items():
@@ -596,12 +609,12 @@ def main():
                 t_issue += v["units"] / (1024 * 2.4e9 * 128 / rc)
                 t_nominal += v["units"] / (1024 * 2.4e9 * 128 / ((n_slow + n_vop2) * 2.0))
             rate = cells1 / max(ms1 * 1e-3, 1e-12)
-            peak_cells = cells1 / max(t_issue, 1e-12)
-            nominal = cells1 / max(t_nominal, 1e-12)
+            peak_cells = cells1 / max(t_issue, 1e-12) if cells1 else 1.0
+            nominal = cells1 / max(t_nominal, 1e-12) if cells1 else 1.0
             busy, busy_src = None, None
             try:
                 import glob as _glob
-                cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r05_pmc_sq_*.json"))) or [os.path.join(ROOT, "profiles", "r04_pmc_sq_v34.json")]
+                cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r06_pmc_sq_*.json"))) or sorted(_glob.glob(os.path.join(ROOT, "profiles", "r05_pmc_sq_*.json")))
                 busy_src = os.path.basename(cand[-1])
                 sq = json.load(open(cand[-1]))["kernels"]  # (one --pmc pass at 20 k-read launches: tools/pmc_sq.py)
                 act = sum(v["SQ_ACTIVE_INST_VALU"] for k, v in sq.items() if k.startswith(vfam))
@@ -614,8 +627,9 @@ def main():
                             "valu_busy_sq_counters": busy, "valu_busy_source": busy_src,
                             "nominal_2cycle_peak_cells_per_s": round(nominal, 1), "frac_nominal": round(rate / nominal, 4),
                             "unoverlapped_ms_per_step": round(ms1, 2), "cells_per_step": cells1,
+                            "rectangle_cells_per_step": rect_cells1, "rectangle_cells_per_s": round(rect_cells1 / max(ms1 * 1e-3, 1e-12), 1),  # the cells of the windows as the reference computes them (== cells_per_step except for the banded kernel)
                             "rows": rows, "isa_counts": {"file": "profiles/isa_row_counts.json", "commit": isa.get("commit"), "made_from_the_sources_this_run_uses": isa_current},
-                            "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
+                            "gap_fill_family_unoverlapped_ms_per_step": round(sum(v["ms"] for k, v in prof1.items() if family(k) in ("ksw_band_kernel", "ksw_stream_kernel", "ksw_gapfill_kernel")), 2),
                             "basis": "one extra pass with a single lane and no side stream (no concurrent kernels); peak = 1024 SIMDs x 2.4 GHz x 128 cells / the issue cycles of one register-set row: the hot loop's VALU instructions per row by encoding class (profiles/isa_row_counts.json, counted in the assembly by tools/isa_row_counts.py) at the per-SIMD issue rates of profiles/r03_valu_issue_bench_v1.txt (VOP3P / VOP3 / DPP 4.1 cycles, VOP2 2.2), every lane useful; valu_busy_sq_counters = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) (the SIMDs' issue cycles that carried a VALU instruction, traceback and Z-drop walk included); nominal = the same instructions at the guide's 2 cycles per wave64 instruction"}
             # the same family without the other lanes beside it (the one-lane pass): per-launch durations in the timed steps depend on how many of the eight lanes'
             # launches of this kernel coincide -- the kernel is VALU-bound, eight coinciding launches each take eight times as long -- so `frac` moves between 0.04
@@ -746,7 +760,9 @@ def main():
                       "resident_gbases_per_s": round(batch_bases / resident / 1e9, 5) if resident else None,
                       "handover_then_map_gbases_per_s": round(batch_bases / pcie / 1e9, 5) if pcie else None,
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits, "as_rank_of": as_rank,
-                      "cpu_quota": ncpu},
+                      "cpu_quota": ncpu,
+                      # the banded gap fill (ksw_band.hip), counted over the whole process: windows tried in 128 / 256 diagonals, sent on to the wider band, recomputed as rectangles
+                      "banded_gap_fill": {k: int(v) for k, v in al.last_stats().items() if k.startswith("n_band")}},
            "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
     print(json.dumps(out), flush=True)
     al.close()

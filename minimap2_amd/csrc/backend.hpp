@@ -26,6 +26,7 @@ struct SeedChainParams {          // what mm_map_frag_core passes to seeding and
 	int anchors_only = 0;         // 1: stop after the anchor sort and return every read's sorted anchors (n_u = 0): the caller chains them (a backend without an RMQ chainer)
 	int rmq = 0;                  // 1: chain with mg_lchain_rmq's rules (MM_F_RMQ, map.c:275-277) instead of mg_lchain_dp's
 	int rmq_inner_dist = 0, rmq_size_cap = 0; // mm_mapopt_t::rmq_inner_dist / rmq_size_cap
+	int rmq_dev_max_anchors = 1 << 17; // reads with more anchors are handed back to the host's RMQ chainer (one wavefront walks a read's anchors one by one, microseconds each: whole contigs are faster on a host thread); MM2AMD_RMQ_DEV_MAX_ANCHORS lowers it for tests
 	// long-join re-chaining of long reads (map.c:283-292): a read with more than one chain whose first chain leaves much of the read uncovered
 	// (or covers a tenth of it) has its chained anchors sorted by reference position again and chained by mg_lchain_rmq with bw_long.
 	// long_join = 1: seed_chain() does it for single-segment reads and says so in ReadChains::long_join_done; reads its RMQ kernel hands

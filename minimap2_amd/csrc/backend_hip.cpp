@@ -426,6 +426,10 @@ public:
 		for (const auto &rd : redo) {
 			const size_t cnt = (size_t)(a_off[rd.first + 1] - a_off[rd.first]);
 			if (cnt) HIP_CHECK(hipMemcpyAsync(h_redo + rd.second, ln.d_anchors.p + a_off[rd.first], cnt * sizeof(Anchor), hipMemcpyDeviceToHost, st));
+			//  with the chains left on the device the minimizer positions stay there too -- but a handed-back read is chained and finished by the
+			// host path, whose mm_est_err walks them: its slice comes along
+			const size_t n_pos = (size_t)(mp_off[rd.first + 1] - mp_off[rd.first]);
+			if (lazy && n_pos) HIP_CHECK(hipMemcpyAsync(hmp + mp_off[rd.first], ln.d_minipos.p + mp_off[rd.first], n_pos * 8, hipMemcpyDeviceToHost, st));
 		}
 		stream_wait(st);
 		Trace::get().add(lane_id, "d2h:chains", tt, Trace::now()); tt = Trace::now();
@@ -444,6 +448,7 @@ public:
 		for (const auto &rd : redo) {
 			ReadChains &c = out[rd.first];
 			c.u_p = nullptr, c.n_u = 0, c.chained = false, c.dev_src = -1;
+			c.mp_p = hmp + mp_off[rd.first];
 			c.a_p = h_redo + rd.second, c.n_a = (int64_t)(a_off[rd.first + 1] - a_off[rd.first]);
 		}
 		if (P.long_join && !has_pairs_ && !getenv("MM2AMD_LONG_JOIN_ON_HOST")) long_join(P, lo, n, ln, kp, out, ha, hu, h_nu, h_nv, h_aoff, h_uoff, h_span); // (the diagnostic switch: every re-chain through rmq_chain.cpp)

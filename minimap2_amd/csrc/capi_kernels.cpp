@@ -236,7 +236,9 @@ int mm2amd_exclusive_sum_u32(const uint32_t *in, uint32_t *out, uint64_t n)
 long long mm2amd_alloc_counter(int which)
 {
 	AllocStats &a = alloc_stats();
-	return which == 0 ? a.dev_allocs.load() : which == 1 ? a.pin_allocs.load() : a.ns.load();
+	BandCounters &b = band_counters();
+	return which == 0 ? a.dev_allocs.load() : which == 1 ? a.pin_allocs.load() : which == 2 ? a.ns.load() : which == 3 ? (long long)b.n_band1.load() : which == 4 ? (long long)b.n_band2.load() :
+	       which == 5 ? (long long)b.n_widened.load() : (long long)b.n_retried.load();
 }
 
 void mm2amd_profile_enable(int on)

@@ -33,7 +33,7 @@ int capi_fail(int code, const std::string &msg);
 
 using namespace mm2amd;
 
-extern "C" long long mm2amd_alloc_counter(int which); // device allocations, pinned allocations, nanoseconds spent in them
+extern "C" long long mm2amd_alloc_counter(int which); // device allocations, pinned allocations, nanoseconds spent in them; 3..6: the banded gap fill's windows tried in 128 / 256 diagonals, widened, recomputed as rectangles (process-wide)
 
 namespace {
 // Where the results of one mapper fragment go: reads o .. o+n_out-1 of the caller's arrays; flip_len[j] >= 0 when read o+j was
@@ -671,10 +671,10 @@ void mm_gpu_map_frag(const void *mi, int n_segs, const int *qlens, const char **
 int mm_gpu_map_batch_with(const void *mi, const void *opt, int n_frag, const int *seg_off, const int *n_seg, const void *seq, int *n_reg, void **reg, int *rep_len, int *frag_gap)
 {
 	if (!mi || !opt) return capi_fail(MM2AMD_EINVAL, "[mm2amd] mm_gpu_map_batch_with: non-null index and options");
-	{
-		std::lock_guard<std::mutex> lk_single(g_single_mu);
-		if (int rc = ensure_context_for(mi, opt)) return rc;
-	}
+	//  the lock is held until the batch is mapped, as in mm_gpu_map_frag: a second thread naming another (mi, opt) rebuilds the ONE context only
+	// after this batch has come back -- otherwise this batch could be mapped against the other thread's index and options
+	std::lock_guard<std::mutex> lk_single(g_single_mu);
+	if (int rc = ensure_context_for(mi, opt)) return rc;
 	return mm_gpu_map_batch(n_frag, seg_off, n_seg, seq, n_reg, reg, rep_len, frag_gap);
 }
 
@@ -714,7 +714,8 @@ int mm2amd_last_stats(double *v, int n)
 	                     (double)mm2amd_alloc_counter(0), (double)mm2amd_alloc_counter(1), (double)mm2amd_alloc_counter(2),
 	                     s.c_seed_chain, s.c_host_pre, s.c_plan, s.c_ksw, s.c_consume, s.c_finish, (double)s.n_long_join_dev, (double)s.n_long_join_host,
 	                     s.d_seed_chain, s.d_host_pre, s.d_plan, s.d_ksw, s.d_consume, s.d_finish, (double)s.n_early_sub,
-	                     (double)s.n_region_reads_dev, (double)s.n_region_reads_host }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
+	                     (double)s.n_region_reads_dev, (double)s.n_region_reads_host,
+	                     (double)mm2amd_alloc_counter(3), (double)mm2amd_alloc_counter(4), (double)mm2amd_alloc_counter(5), (double)mm2amd_alloc_counter(6) }; // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -78,6 +78,10 @@ int effective_cpus(); // capi_common.cpp
 
 struct AllocStats { std::atomic<long> dev_allocs{0}, pin_allocs{0}; std::atomic<double> dummy{0}; std::atomic<long long> dev_bytes{0}, pin_bytes{0}; std::atomic<long long> ns{0}; };
 inline AllocStats &alloc_stats() { static AllocStats s; return s; }
+// how the banded gap-fill kernel's launch classes fared since the process started (ksw_host.cpp): windows tried in 128 / 256 diagonals, sent on to the wider
+// band, computed again as the full rectangle
+struct BandCounters { std::atomic<unsigned long long> n_band1{0}, n_band2{0}, n_widened{0}, n_retried{0}; };
+inline BandCounters &band_counters() { static BandCounters s; return s; }
 
 // Grow-only device buffer; contents are NOT preserved across a grow.
 template <typename T>

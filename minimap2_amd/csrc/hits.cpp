@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "hits.hpp"
+#include <stdexcept>
 #include "chain_host.hpp"
 #include "hit_rules.hpp"
 
@@ -238,6 +239,7 @@ void est_err(const FlatIndex &fi, int qlen, RegVec &regs, const Anchor *a, const
 {
 	const int32_t n = n_mini_pos;
 	if (n == 0) return;
+	if (!mini_pos) throw std::logic_error("[mm2amd] est_err: the read's minimizer positions were left on the device"); // (a caller that forgot to fetch them must not read through null)
 	uint64_t sum_k = 0;
 	if (!(fi.flag & ref::I_HPC) && (uint64_t)n * (uint64_t)fi.k < (1u << 24)) sum_k = (uint64_t)n * (uint64_t)fi.k; // every span is k: the float quotient below is exactly k
 	else for (int32_t i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;

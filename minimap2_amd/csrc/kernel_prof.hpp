@@ -31,6 +31,8 @@ public:
 		p.name = name, p.bytes = alg_bytes, p.units = units;
 		HIP_CHECK(hipEventRecord(p.e1, s));
 	}
+	// a count that goes with a kernel but is no launch of its own (the banded DP kernel: the cells it computed, beside the cells of the rectangles it replaced)
+	void add_units(const char *name, double units) { if (enabled_flag()) stats_[name].units += units; }
 	// call after the stream has been synchronised
 	void collect()
 	{

@@ -7,6 +7,7 @@
 #include <cmath>
 #include "ksw_dev.hpp"
 #include "exact_rsort.hpp" // MM2_HD
+#include "ksw_band.hpp"
 
 namespace mm2amd {
 
@@ -22,13 +23,20 @@ constexpr int kFirstExact = 6, kRingClasses = 7, kDirClasses = 11, kFirstSplice 
 // sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
 constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
 // kFirstExt..: the register-resident extension kernel (ksw_ext.hip): + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512
-constexpr int kNTiers = kFirstExt + 4, kExtMaxQ = 512, kExtMaxT = 512;
+constexpr int kFirstBand = kFirstExt + 4, kExtMaxQ = 512, kExtMaxT = 512;
+// kFirstBand..: the banded gap-fill kernel (ksw_band.hip, round 6): + 0: a band of 128 diagonals (one register set), + 1: 256 diagonals (two).  A gap fill
+// of the streaming kernel's classes goes here when the score its length lets one expect would prove the band sufficient (ksw_band.hpp); what the
+// kernel cannot prove is computed again in the wider band or as the full rectangle, so the choice is a matter of speed only.
+constexpr int kBandClasses = 2, kNTiers = kFirstBand + kBandClasses, kBandMaxQ = 512, kBandMaxT = 512;
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 constexpr int kFastMaxQ = 1024, kFastMaxTAny = 3072;
 constexpr int kOrderBuckets = 256; // cost buckets per class
 
 struct KswClassCtx { // uniform over a batch
 	int scoring_ok, splice_ok, splice, stream_on, ext_on, ext_max_t;
+	// the banded kernel: on / off; the scores the acceptance test works with; the share of the best possible score (sc_max per base of the shorter side, in
+	// 1/256) a window is EXPECTED to reach -- the classes are chosen with it, the kernel's test uses the score actually found
+	int band_on = 0, sc_max = 0, gq = 0, ge = 0, gq2 = 0, ge2 = 0, band_rho256 = 128;
 };
 struct KswClassOut {
 	int tier, cb;            // launch class, cost bucket (higher = launched earlier)
@@ -78,6 +86,17 @@ MM2_HD inline bool ksw_ext_eligible(const KswJob &j, bool scoring_ok, int max_t)
 	return ksw_band_cannot_bind(j);
 }
 MM2_HD inline int ksw_pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
+MM2_HD inline int ksw_band_sets(int tier) { return tier == kFirstBand ? 1 : tier == kFirstBand + 1 ? 2 : 0; }
+// the narrowest band class whose acceptance test the window's expected score passes: 1 or 2 register sets, 0 = none (the rectangle is the better bet)
+MM2_HD inline int ksw_band_choice(const KswJob &j, const KswClassCtx &C)
+{
+	if (!C.band_on || j.qlen > kBandMaxQ || j.tlen > kBandMaxT) return 0;
+	const int mn = j.qlen < j.tlen ? j.qlen : j.tlen, D = j.tlen - j.qlen;
+	const int expect = (int)(((int64_t)C.band_rho256 * C.sc_max * mn) >> 8) - band_gap_cost(D < 0 ? -D : D, C.gq, C.ge, C.gq2, C.ge2);
+	for (int nb = 1; nb <= kBandClasses; ++nb)
+		if (band_holds_corners(j.qlen, j.tlen, 128 * nb) && expect > band_outside_bound(j.qlen, j.tlen, 128 * nb, C.sc_max, C.gq, C.ge, C.gq2, C.ge2)) return nb;
+	return 0;
+}
 
 MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassOut &o)
 {
@@ -87,7 +106,9 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 	o.live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
 	o.db = !o.live || (j.flag & KSW_SCORE_ONLY) ? 0 : o.fast || o.xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 	       o.sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
-	if (o.fast) o.tier = ksw_fast_tier(j);
+	const int band_sets = o.fast ? ksw_band_choice(j, C) : 0;
+	if (band_sets) o.tier = kFirstBand + band_sets - 1, o.db = (size_t)(j.qlen + j.tlen - 1) * (size_t)(64 * band_sets);
+	else if (o.fast) o.tier = ksw_fast_tier(j);
 	else if (o.xfast) o.tier = kFirstExt + (j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
 	else if (o.sfast) {
 		int nc = 0, dc = 0;
@@ -112,6 +133,7 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 	// the streaming kernel computes, row by row, the register sets its jobs in flight reach: jobs of one width class (64-column
 	// sets) together, the widest first; within a class the longest queries first (short ones fill the launch's tail)
 	if (o.fast && C.stream_on && ksw_stream_sets(o.tier)) cb = (((j.tlen + 63) / 64 - 1) & 3) * 64 + (j.qlen / 8 < 63 ? j.qlen / 8 : 63);
+	if (band_sets) cb = (j.qlen + j.tlen) >> 2; // the two jobs of a wave advance row by row: order by row count
 	if (cb >= kOrderBuckets) cb = kOrderBuckets - 1;
 	if (cb < 0) cb = 0;
 	o.cb = cb;

@@ -84,6 +84,18 @@ struct KswLaunch {
 	bool single_affine = false;    // ksw_extz2 recurrences (q2/e2 ignored) instead of ksw_extd2
 	bool splice = false;           // ksw_exts2 recurrences (no band, intron state, N operations)
 	uint8_t *state_pool = nullptr; // when set: per-slot state slabs in HBM (ksw_lds_per_wave bytes each) instead of LDS
+	// Launches fed by a list made on the device (round 6; ksw_band.hip, ksw_stream.hip): position k of the queue is job list[k] of `jobs` / `res`, and
+	// *n_list (read by the kernel) says how many there are -- the banded kernel's rejects, re-run without a host round trip.
+	const uint32_t *list = nullptr;
+	const int32_t *n_list = nullptr;
+	// The banded kernel's two ways out for a window whose band it could not prove sufficient: a wider band (widen_W diagonals) or the full rectangle.
+	// Entries are list_base + the job's index in this launch, i.e. positions in the batch's launch order.
+	uint32_t *widen_list = nullptr, *retry_list = nullptr;
+	int32_t *widen_count = nullptr, *retry_count = nullptr;
+	int32_t widen_W = 0;
+	uint32_t list_base = 0;
+	unsigned long long *band_acc = nullptr; // [0] += score found + the corners' unavoidable gap, [1] += best possible score, over the windows a first attempt computed
+	int32_t band_reject = 0;       // tests: 1 = no result of this launch is accepted, 2 = ... and none goes to the wider band
 	KswScoring sc;
 };
 

@@ -227,6 +227,67 @@ __device__ __forceinline__ void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp,
 		: [xn] "v"(xn), [yn] "v"(yn), [x2n] "v"(x2n), [y2n] "v"(y2n), [ka8] "s"(K.ka8), [kb8] "s"(K.kb8), [ka28] "s"(K.ka28), [kb28] "s"(K.kb28));
 	v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
+// gf_cell_k2: gf_cell_k with every input by value and every output separate (round 6, the banded kernel: on odd rows a lane's (u, y, y2) arrive in registers that must
+// survive the cell -- the DPP moves' destination, whose last lane keeps the band's edge constant from row to row -- and go out into the lane's own).  Same
+// instructions in the same order; u's new value gets a register of its own instead of replacing the old one.
+__device__ __forceinline__ void gf_cell_k2(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t u, uint32_t y, uint32_t y2, uint32_t &un, uint32_t &v, uint32_t &x, uint32_t &yo,
+                                           uint32_t &x2, uint32_t &y2o, uint32_t &d, uint32_t P_MCHT, const GfK &K)
+{
+	uint32_t a, b, a2, b2, z, z4, m, n, w, tA, tB;
+	asm volatile(
+		"v_pk_add_u16 %[a], %[xp], %[vp]\n\t"
+		"v_pk_min_u16 %[m], %[x1], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_add_u16 %[b], %[y], %[u]\n\t"
+		"v_pk_add_u16 %[a2], %[x2p], %[vp]\n\t"
+		"v_pk_mad_u16 %[z], %[m], %[misd], %[mch]\n\t"
+		"v_pk_add_u16 %[b2], %[y2], %[u]\n\t"
+		"v_pk_max_i16 %[tA], %[a], %[b]\n\t"
+		"v_pk_lshrrev_b16 %[n], 2, %[o1] op_sel_hi:[0,1]\n\t"
+		"v_pk_max_i16 %[tB], %[a2], %[b2]\n\t"
+		"v_pk_sub_u16 %[w], %[scn], %[z]\n\t"
+		"v_pk_max_i16 %[tA], %[tA], %[tB]\n\t"
+		"v_pk_mad_u16 %[z], %[n], %[w], %[z]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_max_i16 %[z4], %[z], %[tA]\n\t"
+		"s_nop 0"
+		: [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [b2] "=&v"(b2), [z] "=&v"(z), [z4] "=&v"(z4), [m] "=&v"(m), [n] "=&v"(n), [w] "=&v"(w), [tA] "=&v"(tA), [tB] "=&v"(tB)
+		: [xp] "v"(xp), [vp] "v"(vp), [x2p] "v"(x2p), [x1] "v"(x1), [o1] "v"(o1), [u] "v"(u), [y] "v"(y), [y2] "v"(y2), [mch] "v"(P_MCHT), [misd] "s"(K.misd8), [scn] "s"(K.scnt));
+	uint32_t zv, zc, t1, t2, e, vn, xn, yn, x2n, y2n, u_new;
+	asm volatile(
+		"v_and_b32 %[zv], 0xfff8fff8, %[z4]\n\t"
+		"v_and_b32 %[e], 0x70007, %[z4]\n\t"
+		"v_pk_min_i16 %[zc], %[zv], %[mch8]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_sub_u16 %[vn], %[zc], %[u]\n\t"
+		"v_pk_add_u16 %[t1], %[zc], %[e8]\n\t"
+		"v_pk_add_u16 %[t2], %[zc], %[e28]\n\t"
+		"v_pk_sub_u16 %[un], %[zc], %[vp]\n\t"
+		"v_pk_sub_u16 %[a], %[a], %[t1]\n\t"
+		"v_pk_sub_u16 %[b], %[b], %[t1]\n\t"
+		"v_pk_sub_u16 %[a2], %[a2], %[t2]\n\t"
+		"v_pk_sub_u16 %[b2], %[b2], %[t2]\n\t"
+		"v_pk_max_i16 %[xn], %[a], %[ka]\n\t"
+		"v_pk_max_i16 %[yn], %[b], %[kb]\n\t"
+		"v_pk_max_i16 %[x2n], %[a2], %[ka2]\n\t"
+		"v_pk_max_i16 %[y2n], %[b2], %[kb2]"
+		: [zv] "=&v"(zv), [zc] "=&v"(zc), [t1] "=&v"(t1), [t2] "=&v"(t2), [e] "=&v"(e), [vn] "=&v"(vn), [xn] "=&v"(xn), [yn] "=&v"(yn), [x2n] "=&v"(x2n), [y2n] "=&v"(y2n),
+		  [un] "=&v"(u_new), [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2), [b2] "+v"(b2)
+		: [z4] "v"(z4), [vp] "v"(vp), [u] "v"(u), [mch8] "s"(K.mch8), [e8] "s"(K.e8), [e28] "s"(K.e28), [ka] "s"(K.ka), [kb] "s"(K.kb), [ka2] "s"(K.ka2), [kb2] "s"(K.kb2));
+	uint32_t fa, fb, fa2, fb2;
+	asm volatile(
+		"v_pk_min_i16 %[fa], %[xn], %[ka8]\n\t"
+		"v_pk_min_i16 %[fb], %[yn], %[kb8]\n\t"
+		"v_pk_min_i16 %[fa2], %[x2n], %[ka28]\n\t"
+		"v_pk_mad_u16 %[fa], %[fb], 2, %[fa] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_min_i16 %[fb2], %[y2n], %[kb28]\n\t"
+		"v_pk_add_u16 %[e], %[e], %[fa]\n\t"
+		"v_pk_mad_u16 %[fa2], %[fb2], 2, %[fa2] op_sel_hi:[1,0,1]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_mad_u16 %[e], %[fa2], 4, %[e] op_sel_hi:[1,0,1]"
+		: [fa] "=&v"(fa), [fb] "=&v"(fb), [fa2] "=&v"(fa2), [fb2] "=&v"(fb2), [e] "+v"(e)
+		: [xn] "v"(xn), [yn] "v"(yn), [x2n] "v"(x2n), [y2n] "v"(y2n), [ka8] "s"(K.ka8), [kb8] "s"(K.kb8), [ka28] "s"(K.ka28), [kb28] "s"(K.kb28));
+	un = u_new, v = vn, x = xn, yo = yn, x2 = x2n, y2o = y2n, d = e;
+}
 #endif // MM2AMD_WAVE_EMU (the emulator's twin: ksw_pk_emu.hpp)
 
 // ---- ksw_backtrack (ksw2.h:130-162) with every cell inside the matrix, by the 32 lanes of a half-wave; both halves of a wave at once ----

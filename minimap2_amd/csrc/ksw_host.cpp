@@ -41,6 +41,9 @@ size_t ksw_stream_slot_bytes(int n_sets);
 int ksw_stream_waves(int n_sets);
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
 void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);               // ksw_ext.hip
+void ksw_band_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream);    // ksw_band.hip
+int ksw_band_waves(int n_sets);
+size_t ksw_band_slot_bytes(int n_sets, int max_rows);
 
 void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
                          const KswScoring &sc, KswRes *res, const uint32_t **cigar_out, size_t *n_cigar_out, hipStream_t stream, const KswJob *d_jobs_in)
@@ -71,8 +74,18 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	                       sc.q + sc.e + sc.q2 + sc.noncan + max_abs <= 100;
 	KswClassCtx cctx;
 	cctx.scoring_ok = scoring_ok, cctx.splice_ok = splice_ok, cctx.splice = splice, cctx.stream_on = stream_on, cctx.ext_on = ext_on, cctx.ext_max_t = ext_max_t;
+	// the banded gap fill (ksw_band.hip): which windows try a band first is decided from the score their length lets one expect -- a share of the best possible
+	// score that follows what the kernel's accepted windows actually reached (band_rho; MM2AMD_BAND_RHO pins it) -- never the results
+	static const bool band_env_off = getenv("MM2AMD_NO_BAND") != nullptr;
+	static const double rho_env = getenv("MM2AMD_BAND_RHO") ? atof(getenv("MM2AMD_BAND_RHO")) : -1.0;
+	cctx.band_on = scoring_ok && stream_on && !band_env_off;
+	cctx.sc_max = 0;
+	for (int t = 0; t < sc.m * sc.m; ++t) cctx.sc_max = std::max<int>(cctx.sc_max, sc.mat[t]);
+	cctx.gq = sc.q, cctx.ge = sc.e, cctx.gq2 = sc.q2, cctx.ge2 = sc.e2;
+	cctx.band_rho256 = (int)(256.0 * (rho_env >= 0 ? rho_env : band_rho));
+	const int band_reject = getenv("MM2AMD_BAND_REJECT") ? atoi(getenv("MM2AMD_BAND_REJECT")) : 0; // tests: 1 = every first attempt fails (the lists and their launches run), 2 = ... straight to the rectangle
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
-	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0, cells = 0; };
+	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0, cells = 0, sum_len = 0; };
 	size_t sum_len = 0;
 	ClassStat cls[kNTiers];
 	size_t tier_beg[kNTiers + 1];
@@ -87,7 +100,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			const KswClassStat &c = ho->cls[t];
 			cls[t].slot_bytes = std::max<size_t>(16, (size_t)c.slot_bytes), cls[t].tmp_cap = std::max<size_t>(16, (size_t)c.tmp_cap);
 			cls[t].max_ring = std::max(64, (int)c.max_ring), cls[t].max_Q16 = std::max(16, (int)c.max_Q16), cls[t].max_rows = std::max(1, (int)c.max_rows), cls[t].max_ncol = std::max(64, (int)c.max_ncol);
-			cls[t].alg_bytes = (double)c.alg_bytes, cls[t].cells = (double)c.cells;
+			cls[t].alg_bytes = (double)c.alg_bytes, cls[t].cells = (double)c.cells, cls[t].sum_len = (double)c.sum_len;
 			sum_len += (size_t)c.sum_len;
 		}
 		for (int t = 0; t <= kNTiers; ++t) tier_beg[t] = ho->tier_beg[t];
@@ -124,7 +137,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 				if (o.db > 160 * 1024) cs.alg_bytes += (double)o.db;
 				cs.slot_bytes = std::max(cs.slot_bytes, o.db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
 				if (o.fast || o.xfast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
-				st.sum_len += (size_t)j.qlen + j.tlen;
+				st.sum_len += (size_t)j.qlen + j.tlen, cs.sum_len += (double)j.qlen + j.tlen;
 			}
 		}
 		cstat[c] = st;
@@ -132,7 +145,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	for (const ChunkStat &st : cstat) {
 		sum_len += st.sum_len;
 		for (int t = 0; t < kNTiers; ++t) {
-			cls[t].alg_bytes += st.cls[t].alg_bytes, cls[t].cells += st.cls[t].cells;
+			cls[t].alg_bytes += st.cls[t].alg_bytes, cls[t].cells += st.cls[t].cells, cls[t].sum_len += st.cls[t].sum_len;
 			cls[t].slot_bytes = std::max(cls[t].slot_bytes, st.cls[t].slot_bytes), cls[t].tmp_cap = std::max(cls[t].tmp_cap, st.cls[t].tmp_cap);
 			cls[t].max_ring = std::max(cls[t].max_ring, st.cls[t].max_ring), cls[t].max_Q16 = std::max(cls[t].max_Q16, st.cls[t].max_Q16);
 			cls[t].max_rows = std::max(cls[t].max_rows, st.cls[t].max_rows), cls[t].max_ncol = std::max(cls[t].max_ncol, st.cls[t].max_ncol);
@@ -164,8 +177,9 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_res.ensure(n);
-	d_counter.ensure(128);
+	d_counter.ensure(128 + 8);
 	static_assert(kNTiers <= 128, "one queue counter per launch class");
+	int32_t *const d_band_ctl = d_counter.p + 128; // the banded kernel's lists: [0] windows for the wider band, [1] for the rectangle, [2] / [3] the queue heads of the launches that take them, [4..7] two 64-bit sums over the windows the first attempts computed: score found (less the corners' gap), best possible score
 	d_cursor.ensure(2);
 	KswScoring sc_dev = sc; // the junction entries travel with the jobs
 	sc_dev.juncs = nullptr, sc_dev.tbytes = nullptr;
@@ -182,7 +196,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	for (int attempt = 0;; ++attempt) {
 		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
 		d_cigar.ensure(pool_cap);
-		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, 128 * sizeof(int32_t), stream));
+		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, (128 + 8) * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
 		// size every launch class first.  The launches form two groups that run CONCURRENTLY: the register-resident kernels back to
 		// back on the caller's stream, the lane-exact kernel's classes back to back on a side stream of higher priority (a few long
@@ -191,7 +205,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4, team = 1; bool hbm = false; double alg_bytes = 0, cells = 0; };
 		Plan plan[kNTiers];
 		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
-		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || tier >= kFirstExt + 2 ? 1 : 0; };
+		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || (tier >= kFirstExt + 2 && tier < kFirstBand) ? 1 : 0; };
 		const int max_slots_env = getenv("MM2AMD_KSW_MAX_SLOTS") ? atoi(getenv("MM2AMD_KSW_MAX_SLOTS")) : 0; // tests: few persistent waves, so that each takes many jobs
 		// Two groups run concurrently only when there are lane-exact launches and the mode allows it; then each gets half of this lane's
 		// scratch budget and buffers of its own.  Otherwise the groups run one after the other and SHARE one buffer sized for the larger.
@@ -218,13 +232,15 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
 			P.beg = tier_beg[tier], P.end = tier_beg[tier + 1];
 			if (P.end == P.beg) continue;
-			const bool xfast = tier >= kFirstExt, sfast = tier >= kFirstSplice && !xfast, fast = tier < kFirstExact || sfast || xfast; // the register-resident kernels
+			const int band_sets = ksw_band_sets(tier);
+			const bool xfast = tier >= kFirstExt && !band_sets, sfast = tier >= kFirstSplice && tier < kFirstExt, fast = tier < kFirstExact || sfast || xfast || band_sets; // the register-resident kernels
 			const int rc = fast ? 0 : (tier - kFirstExact) / kDirClasses;
 			P.slot_bytes = cls[tier].slot_bytes, P.tmp_cap = cls[tier].tmp_cap, P.max_Q16 = cls[tier].max_Q16, P.alg_bytes = cls[tier].alg_bytes, P.cells = cls[tier].cells;
 			// the gap-fill kernel keeps ONE matrix per wave for its two jobs, as many rows as the longer and as many columns as the wider
 			// of the two needs (two rows x two jobs per dword): a pair's two slots together must hold (rows / 2 + 1) x columns dwords
 			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
-			if (tier < kFirstExact) P.tmp_cap = 3 * (P.tmp_cap + 2); // the operations, and two prefix arrays over them for the half-wave's Z-drop walk (gf_zdrop_scan)
+			if (tier < kFirstExact || band_sets) P.tmp_cap = 3 * (P.tmp_cap + 2); // the operations, and two prefix arrays over them for the half-wave's Z-drop walk (gf_zdrop_scan)
+			if (band_sets) P.slot_bytes = ksw_band_slot_bytes(band_sets, cls[tier].max_rows);
 			if (tier < kFirstExact) P.slot_bytes = n_stream ? ksw_stream_slot_bytes(n_stream) : (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
 			if (xfast) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol; // one matrix per wave for its two jobs, as in the gap-fill kernel
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
@@ -242,7 +258,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			if (P.team > 1) P.wpb = 1; // the workgroup IS the slot
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
-			if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (eight register sets: 174 VGPRs)
+			if (band_sets) blocks_per_cu = ksw_band_waves(band_sets);
+			else if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (eight register sets: 174 VGPRs)
 			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (n_stream) { static const int sb = getenv("MM2AMD_STREAM_BLOCKS") ? atoi(getenv("MM2AMD_STREAM_BLOCKS")) : 0; blocks_per_cu = sb > 0 ? sb : ksw_stream_waves(n_stream); } // (experiments: fewer resident blocks leave LDS to the other lanes' kernels)
 			else if (fast) blocks_per_cu = fast_waves(tier);
@@ -257,6 +274,27 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			P.n_slots = (P.n_slots + wpb - 1) / wpb * wpb;
 			need_dir = std::max(need_dir, P.n_slots * P.slot_bytes * per_slot), need_tmp = std::max(need_tmp, P.n_slots * P.tmp_cap * per_slot);
 			if (P.hbm) need_state = std::max(need_state, P.n_slots * region);
+		}
+		// The banded kernel's rejects are computed again by launches that read their job lists on the device: band-128 rejects whose score would pass in a band of
+		// 256 diagonals by the two-set instantiation, everything else by the streaming kernel's eight-set class (the full rectangle; query and target <= 512).
+		// Their grids are sized for the most the lists can hold; a wave that finds its list empty leaves at once.
+		struct ListPlan { size_t n_slots = 0, slot_bytes = 16, tmp_cap = 16; } widen_plan, retry_plan;
+		const size_t n_band1 = plan[kFirstBand].end - plan[kFirstBand].beg, n_band2 = plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg;
+		if (n_band1 + n_band2) {
+			d_band_lists.ensure(2 * (n_band1 + n_band2) + 2);
+			const int rows_max = std::max(cls[kFirstBand].max_rows, cls[kFirstBand + 1].max_rows);
+			const size_t tmp_max = 3 * (std::max(cls[kFirstBand].tmp_cap, cls[kFirstBand + 1].tmp_cap) + 2);
+			auto size_list = [&](ListPlan &lp, size_t n_max, size_t slot_bytes, int blocks_per_cu) {
+				if (n_max == 0) return;
+				lp.slot_bytes = (slot_bytes + 255) / 256 * 256, lp.tmp_cap = tmp_max;
+				lp.n_slots = std::min<size_t>((n_max + 1) / 2, (size_t)n_cu * blocks_per_cu * 4);
+				lp.n_slots = std::min<size_t>(lp.n_slots, std::max<size_t>(1, group_budget / (lp.slot_bytes * 2)));
+				if (max_slots_env > 0) lp.n_slots = std::min<size_t>(lp.n_slots, (size_t)max_slots_env);
+				lp.n_slots = (lp.n_slots + 3) / 4 * 4;
+				need_dir_g[0] = std::max(need_dir_g[0], lp.n_slots * lp.slot_bytes * 2), need_tmp_g[0] = std::max(need_tmp_g[0], lp.n_slots * lp.tmp_cap * 2);
+			};
+			size_list(widen_plan, n_band1, ksw_band_slot_bytes(2, rows_max), ksw_band_waves(2));
+			size_list(retry_plan, n_band1 + n_band2, ksw_stream_slot_bytes(8), ksw_stream_waves(8));
 		}
 		for (size_t &need_dir : need_dir_g)
 			if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
@@ -303,16 +341,45 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			L.ring = P.ring, L.max_Q16 = P.max_Q16, L.sc = sc_dev;
 			L.state_pool = P.hbm ? d_state.p : nullptr;
 			L.single_affine = single_affine, L.splice = splice;
+			const int band_sets = ksw_band_sets(tier);
+			if (band_sets) { // what this launch cannot prove goes onto the lists (positions in the batch's launch order)
+				const size_t n_band = (plan[kFirstBand].end - plan[kFirstBand].beg) + (plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg);
+				L.widen_list = band_sets == 1 ? d_band_lists.p : nullptr, L.widen_count = d_band_ctl + 0, L.widen_W = 256;
+				L.retry_list = d_band_lists.p + n_band + 1, L.retry_count = d_band_ctl + 1, L.list_base = (uint32_t)P.beg, L.band_reject = band_reject;
+				L.band_acc = (unsigned long long *)(d_band_ctl + 4);
+			}
 			if (prof) prof->begin(stream_);
 			const int n_stream = tier < kFirstExact && stream_on ? stream_sets(tier) : 0;
-			if (n_stream) ksw_stream_launch(L, (int)P.n_slots, n_stream, stream_);
+			if (band_sets) ksw_band_launch(L, (int)P.n_slots, band_sets, stream_);
+			else if (n_stream) ksw_stream_launch(L, (int)P.n_slots, n_stream, stream_);
 			else if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
 			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, ((tier - kFirstExt) & 1) != 0, 4 * ((tier - kFirstExt) / 2 + 1), stream_);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, P.team, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			static const char *kStreamNames[2] = { "ksw_stream_kernel<4>[t256]", "ksw_stream_kernel<8>[t512]" };
-			if (prof) prof->end(stream_, n_stream ? kStreamNames[tier] : tier >= kFirstExt ? kExtNames[tier - kFirstExt] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+			static const char *kBandNames[kBandClasses] = { "ksw_band_kernel<1>[w128]", "ksw_band_kernel<2>[w256]" };
+			static const char *kBandCells[kBandClasses] = { "band_cells_computed<1>", "band_cells_computed<2>" }; // rows x lanes of the band: what the VALU roofline counts (units of the launch itself: the rectangles' cells)
+			if (prof && band_sets) prof->add_units(kBandCells[band_sets - 1], cls[tier].sum_len * 64.0 * band_sets);
+			if (prof) prof->end(stream_, band_sets ? kBandNames[band_sets - 1] : n_stream ? kStreamNames[tier] : tier >= kFirstExt ? kExtNames[tier - kFirstExt] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+		}
+		// ---- the banded kernel's rejects (the lists are complete when the stream gets here) ----
+		for (int which = 0; which < 2; ++which) {
+			const ListPlan &lp = which ? retry_plan : widen_plan;
+			if (lp.n_slots == 0) continue;
+			const size_t n_band = (plan[kFirstBand].end - plan[kFirstBand].beg) + (plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg);
+			KswLaunch L;
+			L.jobs = d_jobs.p, L.res = d_res.p, L.n_jobs = 0;
+			L.list = which ? d_band_lists.p + n_band + 1 : d_band_lists.p, L.n_list = d_band_ctl + which, L.counter = d_band_ctl + 2 + which;
+			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
+			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
+			L.cigar_tmp = tmp_g[0], L.cigar_tmp_cap = (uint32_t)lp.tmp_cap, L.dir_pool = dir_g[0], L.slot_bytes = lp.slot_bytes;
+			L.ring = 64, L.max_Q16 = 16, L.sc = sc_dev;
+			if (!which) L.retry_list = d_band_lists.p + n_band + 1, L.retry_count = d_band_ctl + 1, L.list_base = 0, L.band_reject = band_reject > 1 ? band_reject : 0;
+			if (prof) prof->begin(stream);
+			if (which) ksw_stream_launch(L, (int)lp.n_slots, 8, stream);
+			else ksw_band_launch(L, (int)lp.n_slots, 2, stream);
+			if (prof) prof->end(stream, which ? "ksw_stream_kernel<8>[band rejects]" : "ksw_band_kernel<2>[widened]", 0.0, 0.0);
 		}
 		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));
@@ -320,11 +387,22 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		}
 		// (into PINNED memory: an asynchronous copy to pageable memory -- a stack array here until round 4 -- makes the runtime wait for the stream inside
 		// the call, spinning: the lane drivers spent the whole duration of the DP kernels on a core each, 1.2 core-seconds per step)
-		uint32_t *cursor = h_cursor.ensure(2);
+		uint32_t *cursor = h_cursor.ensure(2 + 8);
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (widen_plan.n_slots + retry_plan.n_slots) HIP_CHECK(hipMemcpyAsync(cursor + 2, d_band_ctl, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
 		if (!resident) HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
 		stream_wait(stream);
 		Trace::get().add(lane, "gpu:ksw", tt, Trace::now()); tt = Trace::now();
+		if (cursor[1] == 0 && widen_plan.n_slots + retry_plan.n_slots) { // how the band classes fared: counts for the caller, and the expected score share follows the accepted windows
+			band_stats.n_band1 += n_band1, band_stats.n_band2 += n_band2, band_stats.n_widened += cursor[2], band_stats.n_retried += cursor[3];
+			band_counters().n_band1 += n_band1, band_counters().n_band2 += n_band2, band_counters().n_widened += cursor[2], band_counters().n_retried += cursor[3];
+			unsigned long long acc[2];
+			memcpy(acc, cursor + 2 + 4, sizeof acc);
+			const double got = (double)acc[0], best = (double)acc[1];
+			static const bool band_debug = getenv("MM2AMD_BAND_DEBUG") != nullptr;
+			if (band_debug) fprintf(stderr, "[mm2amd] band: %zu + %zu windows tried, %u widened, %u to the rectangle, score share %.3f (expected %.3f)\n", n_band1, n_band2, cursor[2], cursor[3], best > 0 ? got / best : 0.0, cctx.band_rho256 / 256.0);
+			if (best >= 100000.0) band_rho = std::min(1.0, std::max(0.05, 0.75 * band_rho + 0.25 * (got / best - 0.03)));
+		}
 		if (cursor[1] == 0 && resident) { *cigar_out = d_cigar.p, *n_cigar_out = cursor[0]; break; }
 		if (cursor[1] == 0) {
 			uint32_t *hc = cigar_host.ensure((size_t)cursor[0] + 1);

@@ -45,6 +45,11 @@ struct KswRunner {
 	DevBuf<struct KswOrderResult> d_order_out;
 	PinBuf<struct KswOrderResult> h_order_out;
 	double last_cells = 0;
+	// the banded gap fill (ksw_band.hip): its two lists (windows for the wider band | for the rectangle), how its classes fared, and the share of the best
+	// possible score a window is expected to reach (starts at what 12 %-error reads give; follows the accepted windows of the batches before)
+	DevBuf<uint32_t> d_band_lists;
+	struct BandStats { unsigned long long n_band1 = 0, n_band2 = 0, n_widened = 0, n_retried = 0; } band_stats;
+	double band_rho = 0.5;
 };
 
 } // namespace mm2amd

@@ -62,7 +62,9 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 	const int slot = blockIdx.x * 4 + wave_in_block;
 	if (threadIdx.x < 25) s_mat[threadIdx.x] = L.sc.mat[threadIdx.x];
 	__syncthreads();
-	const int m = L.sc.m, n_jobs = st_uni(L.n_jobs); // (a value, not a kernel-argument load the compiler may repeat inside a divergent branch)
+	// (a value, not a kernel-argument load the compiler may repeat inside a divergent branch); a launch fed by a device-made list (the banded kernel's
+	// rejects, ksw_band.hip) reads its job count here and maps queue positions through the list
+	const int m = L.sc.m, n_jobs = L.n_list ? st_uni(*L.n_list) : st_uni(L.n_jobs);
 	int q = L.sc.q, e = L.sc.e, q2 = L.sc.q2, e2 = L.sc.e2;
 	const int qe_in = q + e; // before the swap (ksw2_extd2_sse.c:68 vs :78)
 	if (q2 + e2 < q + e) { int t = q; q = q2, q2 = t; t = e, e = e2, e2 = t; }
@@ -103,7 +105,8 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 		for (int h = 0; h < 2; ++h) {
 			nj[h] = id + h, nq[h] = nt[h] = 0;
 			if (id + h >= n_jobs) continue; // the last pair of an odd launch
-			const KswJob J = uniform_job(L.jobs[id + h]);
+			if (L.list) nj[h] = st_uni((int)L.list[id + h]);
+			const KswJob J = uniform_job(L.jobs[nj[h]]);
 			nq[h] = J.qlen, nt[h] = J.tlen;
 #pragma unroll
 			for (int c = 0; c < NC; ++c) {
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_stream_kernel(KswLaunch L)
 
 void ksw_stream_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream)
 {
-	if (L.n_jobs <= 0) return;
+	if (L.n_jobs <= 0 && !L.n_list) return;
 	const int n_blocks = (n_slots + 3) / 4;
 	hipStream_t s = (hipStream_t)stream;
 	if (n_sets == 4) hipLaunchKernelGGL((ksw_stream_kernel<4, ST_W4>), dim3(n_blocks), dim3(256), 0, s, L);

@@ -200,6 +200,7 @@ std::shared_ptr<Mapper::BatchRun> Mapper::make_run(int set)
 	sp.rmq = (opt_.flag & F_RMQ) && be_.supports_rmq() ? 1 : 0;
 	sp.anchors_only = (opt_.flag & F_RMQ) && !sp.rmq ? 1 : 0;
 	sp.rmq_inner_dist = opt_.rmq_inner_dist, sp.rmq_size_cap = opt_.rmq_size_cap;
+	if (const char *e = getenv("MM2AMD_RMQ_DEV_MAX_ANCHORS")) sp.rmq_dev_max_anchors = atoi(e); // tests: force the hand-back of RMQ-preset reads
 	// map.c:283-292: long-join re-chaining, by the backend when it can (reads it leaves alone are re-chained in process_sub)
 	sp.long_join = opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && be_.supports_long_join() ? 1 : 0;
 	sp.bw_long = opt_.bw_long, sp.rmq_rescue_size = opt_.rmq_rescue_size, sp.rmq_rescue_ratio = opt_.rmq_rescue_ratio;
@@ -342,6 +343,13 @@ void Mapper::device_hits(const Backend::RegionBatchOut &rb, const ReadChains &c,
 	const float avg_k = ro.avg_k; // esterr.c:37-40: the mean minimizer span, as chain_regs_kernel computed it (with an HPC index the spans are summed: the positions stay on the device)
 	(void)c;
 	constexpr uint32_t kHdr = sizeof(Extra) / 4;
+	//  every slot of the read is checked BEFORE the first block is allocated, and an allocation that fails mid-read frees what the read already holds:
+	// an exception out of here must not leave libc blocks behind in a vector nobody hands to the caller
+	for (int32_t p = 0; p < ro.n_regs; ++p) {
+		const uint32_t slot = ro.reg0 + (uint32_t)p;
+		if (rb.plan[slot].status != 0 || rb.fin_res[slot].n_cigar < 0 || (uint32_t)rb.fin_res[slot].n_cigar + kHdr > rb.plan[slot].capacity)
+			throw std::runtime_error("[mm2amd] align_regions: a finished region without a consistent CIGAR");
+	}
 	for (int32_t p = 0; p < ro.n_regs; ++p) {
 		const uint32_t slot = ro.reg0 + (uint32_t)p;
 		Reg r = rb.regs[slot];
@@ -349,9 +357,8 @@ void Mapper::device_hits(const Backend::RegionBatchOut &rb, const ReadChains &c,
 		const RgnPlan &pl = rb.plan[slot];
 		const FinResult &f = rb.fin_res[slot];
 		r.div = x.n_tot < 0 ? -1.0f : x.n_match >= x.n_tot ? 0.0f : (float)(1.0 - pow((double)x.n_match / x.n_tot, 1.0 / avg_k)); // esterr.c:61
-		if (pl.status != 0 || f.n_cigar < 0 || (uint32_t)f.n_cigar + kHdr > pl.capacity) throw std::runtime_error("[mm2amd] align_regions: a finished region without a consistent CIGAR");
 		r.p = (Extra *)malloc((size_t)pl.capacity * 4); // (the header is set below, the operations copied; what lies beyond them is as undefined as after the reference's realloc)
-		if (!r.p) throw std::bad_alloc();
+		if (!r.p) { for (Reg &done : regs) free(done.p); regs.clear(); throw std::bad_alloc(); }
 		memset(r.p, 0, sizeof(Extra));
 		r.p->capacity = pl.capacity;
 		r.p->n_cigar = (uint32_t)f.n_cigar;

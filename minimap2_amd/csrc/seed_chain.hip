@@ -1636,7 +1636,6 @@ void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void
 //     before it: its chain successors have larger query coordinates).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int RMQ_NEAR_CAP = 4096; // anchors of the narrow window scored per anchor; more: the read goes to the host
-constexpr int64_t RMQ_DEV_MAX_ANCHORS = 1 << 17; // one wavefront walks a read's anchors one by one (microseconds each): whole contigs are faster on a host thread
 
 __device__ __forceinline__ int32_t simple_score_dev(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, float pen_gap, float pen_skip, bool *exact, int32_t *width) // comput_sc_simple, lchain.c:229-248
 {
@@ -1669,7 +1668,7 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 	for (int64_t i = lane; i < n; i += 64) t[i] = 0;
 	__threadfence_block();
 	int64_t i0 = 0, st = 0, st_in = 0;
-	bool give_up = n > RMQ_DEV_MAX_ANCHORS;
+	bool give_up = n > (int64_t)P.rmq_dev_max_anchors; // (whole contigs: backend.hpp)
 	for (int64_t i = 0; i < n && !give_up; ++i) {
 		const Anchor ai = a[i];
 		const uint64_t ix = ai.x, iy = ai.y;

@@ -64,7 +64,7 @@ template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { return w
 inline unsigned long long __ballot(int pred) { return wave_emu::collective(wave_emu::OP_BALLOT, pred ? 1 : 0, 0, 64); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)wave_emu::collective(wave_emu::OP_FIRST, (uint32_t)v, 0, 64); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)wave_emu::collective(wave_emu::OP_READLANE, (uint32_t)v, lane, 64); }
-// v_mov_b32_dpp: only the controls the kernels use -- 0x138 wave_shr:1 (lane 0 keeps `old`), 0x13c wave_ror:1, 0x111..0x11f row_shr:n,
+// v_mov_b32_dpp: only the controls the kernels use -- 0x138 wave_shr:1 (lane 0 keeps `old`), 0x13c wave_ror:1, 0x130 wave_shl:1 (lane 63 keeps `old`), 0x134 wave_rol:1, 0x111..0x11f row_shr:n,
 // 0x142 / 0x143 row_bcast:15 / 31; a lane whose row is not in row_mask, or that has no source lane, keeps `old` (bound_ctrl clear)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {

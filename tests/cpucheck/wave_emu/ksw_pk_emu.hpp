@@ -96,4 +96,12 @@ inline void gf_cell_k(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32
 	e = pk_mad(fa2, both(4), e);
 	v = vn, x = xn, y = yn, x2 = x2n, y2 = y2n, d = e;
 }
+template <class KT>
+inline void gf_cell_k2(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t u, uint32_t y, uint32_t y2, uint32_t &un, uint32_t &v, uint32_t &x, uint32_t &yo, uint32_t &x2, uint32_t &y2o,
+                       uint32_t &d, uint32_t P_MCHT, const KT &K)
+{
+	uint32_t uu = u, yy = y, yy2 = y2, vv, xx, xx2;
+	gf_cell_k(x1, o1, xp, vp, x2p, uu, vv, xx, yy, xx2, yy2, d, P_MCHT, K);
+	un = uu, v = vv, x = xx, yo = yy, x2 = xx2, y2o = yy2;
+}
 } // namespace mm2amd

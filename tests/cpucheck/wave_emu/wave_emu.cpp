@@ -114,6 +114,7 @@ void complete(Wave &wv)
 			if (ctrl == 0x138) src = l - 1;                                   // wave_shr:1
 			else if (ctrl == 0x13c) src = (l + 63) & 63;                       // wave_ror:1
 			else if (ctrl == 0x130) src = l + 1 < 64 ? l + 1 : -1;             // wave_shl:1
+			else if (ctrl == 0x134) src = (l + 1) & 63;                        // wave_rol:1
 			else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl & 15; src = (l & 15) >= n ? l - n : -1; } // row_shr:n
 			else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl & 15; src = (l & 15) + n < 16 ? l + n : -1; } // row_shl:n
 			else if (ctrl == 0x142) src = l >= 16 ? (l & ~15) - 1 : -1;        // row_bcast:15: lane 15 of the row before

@@ -82,6 +82,22 @@ def test_rearranged_reads_are_handed_back_and_identical(preset, err):
     assert st["n_region_reads_dev"] >= 16, st   # ... the plain reads beside them in the same sub-batch do not
 
 
+def test_rmq_reads_handed_back_by_the_chaining_kernel_keep_their_minimizers(monkeypatch):
+    """with the chains left on the device, a read chain_rmq_kernel hands back (more anchors than one wavefront should walk -- a whole contig
+    against its reference -- a tied range minimum, an over-full neighbourhood) is chained and finished by the host path, whose mm_est_err walks the read's
+    minimizer positions: they must come to the host with the read's anchors.  MM2AMD_RMQ_DEV_MAX_ANCHORS lowers the kernel's limit so that every read is one."""
+    monkeypatch.setenv("MM2AMD_RMQ_DEV_MAX_ANCHORS", "50")
+    rng = np.random.default_rng(36)
+    contigs = synth.gen_reference(rng, 900000, 2)
+    reads = synth.gen_reads(rng, contigs, 24, 6000, 1500, 0.03)
+    refs, names = [synth.ACGT[c].tobytes() for c in contigs], ["chr1", "chr2"]
+    rds = _codes_to_reads(reads)
+    got, st = _map(refs, rds, "asm20", names)
+    assert got == reflib.ref_map_reads(refs, rds, "asm20", names=names)
+    assert st["n_region_reads_host"] >= len(rds) - 2, st  # the hand-backs went through the host path
+    assert all(len(h) >= 1 for h in got)
+
+
 def test_repeat_rich_reference_many_chains():
     """a reference with multi-copy segments: reads get several chains, primaries with secondaries (mm_set_parent / mm_select_sub on the device),
     equal-scoring copies"""

@@ -1,0 +1,27 @@
+# Round-6 GPU calls (one gpurun call each): bash tools/r06_call.sh <tag> <what...>
+#   ksw    : the kernel-level GPU cases (tests/test_gpu_ksw.py)
+#   ab     : the headline bench with and without the banded gap fill, short (no CPU baseline)
+#   bench  : the headline bench as the driver runs it
+#   tests  : the whole GPU suite
+V=${1:-vX}; shift; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R; export TMPDIR=/tmp
+for what in "$@"; do
+case $what in
+ksw)   timeout 900 python -m pytest tests/test_gpu_ksw.py -x -q -m gpu > $O/r06_pytest_ksw_$V.log 2>&1; tail -3 $O/r06_pytest_ksw_$V.log ;;
+tests) timeout 2400 python -m pytest tests -x -q -m gpu > $O/r06_pytest_gpu_$V.log 2>&1; tail -3 $O/r06_pytest_gpu_$V.log ;;
+ab)    MM2AMD_BAND_DEBUG=1 timeout 500 python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_band_$V.json 2> $O/r06_bench_band_$V.log
+       MM2AMD_NO_BAND=1 timeout 500 python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_noband_$V.json 2> $O/r06_bench_noband_$V.log
+       grep -h "band:" $O/r06_bench_band_$V.log | tail -3
+       python - <<P
+import json
+for f in ['r06_bench_band_$V.json','r06_bench_noband_$V.json']:
+    try:
+        d=json.loads(open('$O/'+f).read().strip().split('\n')[-1]); r=d['roofline']
+        print(f, d['value'], d['ms_per_step'], r['kernel'], r.get('unoverlapped_step_ms'))
+        u=r.get('unoverlapped_ms') or {}
+        print('   ', {k: v for k, v in u.items() if k.startswith('ksw')})
+    except Exception as e: print(f, 'FAILED', e)
+P
+       ;;
+bench) timeout 900 python bench.py > $O/r06_bench_full_$V.json 2> $O/r06_bench_full_$V.log; tail -c 600 $O/r06_bench_full_$V.json ;;
+esac
+done
