@@ -594,6 +594,17 @@ class Aligner(object):
         return dict(zip(names, list(v)[:k]))
 
 
+def band_counters():
+    """The banded gap-fill kernel's windows since the process started (ksw_band.hip): tried in a band of 128 / 256 diagonals, sent on to the wider band,
+    computed again as full rectangles.  (Zeros in a library without the kernels.)"""
+    L = lib()
+    if not hasattr(L, "mm2amd_alloc_counter"):
+        return {"band128": 0, "band256": 0, "widened": 0, "rectangle": 0}
+    L.mm2amd_alloc_counter.restype = C.c_longlong
+    L.mm2amd_alloc_counter.argtypes = [C.c_int]
+    return {"band128": L.mm2amd_alloc_counter(3), "band256": L.mm2amd_alloc_counter(4), "widened": L.mm2amd_alloc_counter(5), "rectangle": L.mm2amd_alloc_counter(6)}
+
+
 def profile_enable(on=True):
     lib().mm2amd_profile_enable(1 if on else 0)
 

@@ -88,8 +88,9 @@ struct alignas(128) Text {
 	void tag(const char *name, int64_t v) { ch('\t'), str(name), num(v); } // "\tNM:i:" + value
 	// (round 5) the writer of a CIGAR's text also counts its gaps -- what the de:f tag of the same record needs (mm_count_gaps): the record's second and third
 	// walk over the 1400 operations of a 10 kb read were a third of the formatting time
-	struct GapCount { const uint32_t *c = nullptr; uint32_t n = 0; int n_gap = 0, n_gapo = 0; };
-	static GapCount &last_gaps() { thread_local GapCount g; return g; }
+	// (round 6) the counts belong to the Text they were made for, not to the thread: whoever writes a record's tags into this object finds what the
+	// same object's cigar() counted, keyed by the CIGAR's address and length; a caller with a fresh Text finds nothing and counts itself
+	struct GapCount { const uint32_t *c = nullptr; uint32_t n = 0; int n_gap = 0, n_gapo = 0; } gaps;
 	void cigar(const uint32_t *c, uint32_t n_cigar) // <len><op> per entry
 	{
 		int n_gap = 0, n_gapo = 0;
@@ -105,18 +106,17 @@ struct alignas(128) Text {
 			n_gapo += (int)is_gap, n_gap += (int)(is_gap ? x : 0u);
 		}
 		n = (size_t)(w - p);
-		GapCount &g = last_gaps();
-		g.c = c, g.n = n_cigar, g.n_gap = n_gap, g.n_gapo = n_gapo;
+		gaps.c = c, gaps.n = n_cigar, gaps.n_gap = n_gap, gaps.n_gapo = n_gapo;
 	}
 };
 
 struct Seqs { std::vector<uint8_t> q, t; std::string tmp; }; // per-thread scratch for cs/ds/MD
 
-void count_gaps(const Reg1 &r, int *n_gap, int *n_gapo) // mm_count_gaps (align.c:985-995)
+void count_gaps(const Text &o, const Reg1 &r, int *n_gap, int *n_gapo) // mm_count_gaps (align.c:985-995)
 {
 	*n_gap = *n_gapo = 0;
 	if (!r.p) return;
-	const Text::GapCount &g = Text::last_gaps();
+	const Text::GapCount &g = o.gaps;
 	if (g.c == r.p->cigar && g.n == r.p->n_cigar) { *n_gap = g.n_gap, *n_gapo = g.n_gapo; return; } // counted while this record's CIGAR text was written
 	for (uint32_t i = 0; i < r.p->n_cigar; ++i) {
 		const int op = r.p->cigar[i] & 0xf, len = r.p->cigar[i] >> 4;
@@ -124,11 +124,11 @@ void count_gaps(const Reg1 &r, int *n_gap, int *n_gapo) // mm_count_gaps (align.
 	}
 }
 
-double event_identity(const Reg1 &r) // mm_event_identity (align.c:997-1003)
+double event_identity(const Text &o, const Reg1 &r) // mm_event_identity (align.c:997-1003)
 {
 	if (!r.p) return -1.0f;
 	int n_gap, n_gapo;
-	count_gaps(r, &n_gap, &n_gapo);
+	count_gaps(o, r, &n_gap, &n_gapo);
 	return (double)r.mlen / (r.blen + r.p->n_ambi - n_gap + n_gapo);
 }
 
@@ -178,7 +178,7 @@ void put_tags(Text &o, const Reg1 &r) // write_tags
 	if (r.parent == r.id) o.tag("s2:i:", r.subsc);
 	if (r.p) {
 		o.str("\tde:f:");
-		const double div = 1.0 - event_identity(r);
+		const double div = 1.0 - event_identity(o, r);
 		if (div == 0.0) o.ch('0'); else put_fraction(o, div);
 	} else if (r.div >= 0.0f && r.div <= 1.0f) {
 		o.str("\tdv:f:");
@@ -525,7 +525,7 @@ static void format_range(const FlatIndex &fi, const MapOpt &opt, const int *seg_
 	Seqs sq;
 	const int64_t flag = opt.flag;
 	hostprof::Scope hp(hostprof::FORMAT_RANGE);
-	Text::last_gaps() = Text::GapCount(); // (the gap counts kept from a record's CIGAR text are only good while the batch's blocks are alive)
+	o.gaps = Text::GapCount(); // (the gap counts kept from a record's CIGAR text are only good while the batch's blocks are alive)
 	for (long f = lo; f < hi; ++f) {
 		const int seg_st = seg_off ? seg_off[f] : (int)f, ns = n_seg ? n_seg[f] : 1;
 		for (int i = seg_st; i < seg_st + ns; ++i) {

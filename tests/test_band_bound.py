@@ -33,3 +33,14 @@ def test_gap_fill_cells_outside_the_provable_band(tmp_path):
     cells = (q + 1) * (t + 1)
     assert below_narrow.sum() > 0.5 * cells.sum()       # most of the rectangle is provably off every optimal path
     assert band_cells.sum() < 0.5 * (q * t).sum()
+
+
+def test_the_banded_kernels_acceptance_bound_is_sound_and_tight():
+    """ksw_band.hpp's band_outside_bound against brute force over every alignment path that touches a cell outside the band (tests/cpucheck/band_bound_test.cpp):
+    never exceeded -- the banded kernel may accept a result whose score is above it -- and reached exactly, so the kernel's comparison has to be strict."""
+    exe = os.path.join(HERE, "_build", "band_bound_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/band_bound_test not built")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert b"sound on" in p.stdout

@@ -156,8 +156,11 @@ def test_profile_counters_and_substeps():
     finally:
         del os.environ["MM2AMD_DEVICE_FINISH"]
     assert whole == plain
-    assert any(k.startswith("ksw_ext") for k in prof) and any(k.startswith("ksw_stream_kernel") for k in prof) and "chain_fill_kernel" in prof and "region_finish_kernel" in prof
-    assert all(v["ms"] > 0 and v["launches"] >= 1 for v in prof.values())
+    assert any(k.startswith("ksw_ext") for k in prof) and any(k.startswith("ksw_band_kernel") for k in prof) and "chain_fill_kernel" in prof and "region_finish_kernel" in prof
+    assert any(k.startswith("ksw_stream_kernel") for k in prof)  # (the launch that takes the banded kernel's rejects)
+    counts = {k: v for k, v in prof.items() if v["launches"] == 0}  # counts that go with a kernel without being a launch: the banded kernel's computed cells
+    assert all(k.startswith("band_cells_computed") and v["units"] > 0 for k, v in counts.items()) and counts
+    assert all(v["ms"] > 0 for v in prof.values() if v["launches"] >= 1)
     os.environ["MM2AMD_SUBBATCH_BASES"] = "50000"  # several sub-batches must give the same answer as one
     try:
         parts = [[a.key() for a in h] for h in al.map_batch(rds)]

@@ -393,3 +393,97 @@ def test_extension_calls(preset):
     a, b, go, ge, go2, ge2 = PRESETS[preset]
     got = mm.ksw_extd2_batch(jobs, ts_mat(a, b, 1, 0), go, ge, go2, ge2)
     assert sum(r[1] for r in got) > 10 and sum(r[9] for r in got) > 10  # Z-drops and reach_end both occur
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The banded gap-fill kernel (ksw_band.hip, round 6).  What the kernel ACCEPTS must be what the reference's unbanded ksw_extd2_sse gives (the mapper's call:
+# align.c:810-844, a band that cannot bind); what it cannot prove goes to the wider band or to the full rectangle and must come back the same.
+# ---------------------------------------------------------------------------------------------------------
+def _band_delta(fn):
+    import minimap2_amd as mm
+    before = mm.band_counters()
+    out = fn()
+    after = mm.band_counters()
+    return out, {k: after[k] - before[k] for k in after}
+
+
+def _gap_cost(l, go, ge, go2, ge2):
+    return 0 if l <= 0 else min(go + ge * l, go2 + ge2 * l)
+
+
+def _edge_walkers(rng, a, go, ge, go2, ge2, W):
+    """windows whose best alignment runs along ONE diagonal off the corners' own: a gap of d target bases first, a perfect (or nearly perfect) stretch,
+    a gap of d query bases last.  With d on the band's last diagonal the band must still find it; one further out it must notice that it cannot -- and with
+    a perfect stretch the alignment outside scores exactly the bound the acceptance test uses (ksw_band.hpp): the test is strict, so that tie is a reject."""
+    jobs = []
+    for upper in (True, False):
+        for off in (-2, -1, 0, 1, 3):
+            for mut in (0, 3):
+                m = int(rng.integers(120, 260))
+                # D = 0 here: c = W / 4, diagonals [-W/2, W/2 - 1]; the first diagonal outside: W/2 above, W/2 + 1 below
+                d = (W // 2 if upper else W // 2 + 1) + off
+                if d + m > 512:
+                    continue
+                core = rng.integers(0, 4, m, dtype=np.uint8)
+                other = core.copy()
+                for _ in range(mut):
+                    p = int(rng.integers(0, m))
+                    other[p] = (other[p] + 1) % 4
+                g1, g2 = rng.integers(0, 4, d, dtype=np.uint8), rng.integers(0, 4, d, dtype=np.uint8)
+                if upper:   # the target runs ahead: i - j = d on the stretch
+                    t, q = np.concatenate([g1, core]), np.concatenate([other, g2])
+                else:
+                    q, t = np.concatenate([g1, core]), np.concatenate([other, g2])
+                jobs.append((q, t, 30001, 400, -1, 0x08))
+    return jobs
+
+
+@pytest.mark.parametrize("preset", list(PRESETS))
+def test_banded_gap_fill_equals_the_unbanded_reference(preset, monkeypatch):
+    import minimap2_amd as mm
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    mat = ts_mat(a, b, 1, 0)
+    rng = np.random.default_rng(601)
+    jobs = []
+    for it in range(700):
+        kind = it % 7
+        L = int(rng.integers(1, 513))
+        if kind == 0:   # unrelated sequences: low scores, nothing provable
+            q, t = rng.integers(0, 4, L, dtype=np.uint8), rng.integers(0, 4, int(rng.integers(1, 513)), dtype=np.uint8)
+        elif kind == 1:  # a long indel: the corners' diagonals far apart
+            q, t = random_pair(rng, L, float(rng.choice([0.02, 0.12])), 0.0, int(rng.choice([40, -40, 90, -90, 130, -130, 250])))
+        else:
+            q, t = random_pair(rng, L, float(rng.choice([0.0, 0.03, 0.08, 0.12, 0.2, 0.35])), float(rng.choice([0, 0, 0.03])), int(rng.choice([0, 0, 0, 8, -8, 25, -25])))
+        if len(q) > 512 or len(t) > 512:
+            continue
+        jobs.append((q, t, 30001, 400, -1, 0x08))
+    for W in (128, 256):
+        jobs += _edge_walkers(rng, a, go, ge, go2, ge2, W)
+    have_ref = os.path.exists(reflib.REF_SO)
+    want = [(reflib.ref_extd2 if have_ref else ora_extd2)(q, t, mat, go, ge, go2, ge2, w, zd, eb, fl) for (q, t, w, zd, eb, fl) in jobs]
+
+    def run():
+        return mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+
+    got, n = _band_delta(run)
+    assert got == want
+    assert n["band128"] + n["band256"] > len(jobs) // 3, n  # the kernel was used ...
+    first = n
+    # ... and so were its ways out, when the launch classes are told to expect the impossible (every window tries the narrowest band first)
+    monkeypatch.setenv("MM2AMD_BAND_RHO", "1.0")
+    got, n = _band_delta(run)
+    assert got == want
+    assert n["band128"] > first["band128"] and n["widened"] > 0 and n["rectangle"] > 0, n
+    # few persistent waves: each takes dozens of pairs, the lists are long
+    monkeypatch.setenv("MM2AMD_KSW_MAX_SLOTS", "4")
+    got, n = _band_delta(run)
+    assert got == want
+    monkeypatch.delenv("MM2AMD_BAND_RHO")
+    # nothing accepted at the first attempt: every window through a list-fed launch (1: band-128 rejects try 256 diagonals; 2: straight to the rectangle)
+    for mode in ("1", "2"):
+        monkeypatch.setenv("MM2AMD_BAND_REJECT", mode)
+        got, n = _band_delta(run)
+        assert got == want, mode
+        assert n["widened"] + n["rectangle"] >= n["band128"] + n["band256"], (mode, n)
+    monkeypatch.delenv("MM2AMD_BAND_REJECT")
+    monkeypatch.setenv("MM2AMD_NO_BAND", "1")  # (read once per process: a no-op if the library has run before; the A/B partner is MM2AMD_BAND_REJECT=2)

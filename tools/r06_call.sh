@@ -22,6 +22,6 @@ for f in ['r06_bench_band_$V.json','r06_bench_noband_$V.json']:
     except Exception as e: print(f, 'FAILED', e)
 P
        ;;
-bench) timeout 900 python bench.py > $O/r06_bench_full_$V.json 2> $O/r06_bench_full_$V.log; tail -c 600 $O/r06_bench_full_$V.json ;;
+bench) timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06_bench_full_$V.json 2> $O/r06_bench_full_$V.log; tail -c 600 $O/r06_bench_full_$V.json ;;
 esac
 done
