@@ -6,6 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 #include "align.hpp"
+#include "region_rules.hpp"
 #include "host_prof.hpp"
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -224,19 +225,15 @@ void jump_split(const FlatIndex &fi, const MapOpt &opt, int32_t qlen, const char
 	jump_right(fi, opt, qlen, qseq, r, ts_strand);
 }
 
-void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar) // align.c:320-334
+void append_cigar(Reg &r, uint32_t n_cigar, const uint32_t *cigar) // what mm_append_cigar (align.c:320-334) leaves: a first operation of the tail's kind is absorbed by the tail
 {
 	if (n_cigar == 0) return;
 	enlarge_cigar(r, n_cigar);
-	Extra *p = r.p;
-	if (p->n_cigar > 0 && (p->cigar[p->n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
-		p->cigar[p->n_cigar - 1] += cigar[0] >> 4 << 4;
-		if (n_cigar > 1) memcpy(p->cigar + p->n_cigar, cigar + 1, (n_cigar - 1) * 4);
-		p->n_cigar += n_cigar - 1;
-	} else {
-		memcpy(p->cigar + p->n_cigar, cigar, n_cigar * 4);
-		p->n_cigar += n_cigar;
-	}
+	Extra &x = *r.p;
+	const uint32_t absorbed = x.n_cigar > 0 && ((x.cigar[x.n_cigar - 1] ^ cigar[0]) & 0xf) == 0 ? 1u : 0u;
+	if (absorbed) x.cigar[x.n_cigar - 1] += cigar[0] & ~0xfu;
+	std::copy(cigar + absorbed, cigar + n_cigar, x.cigar + x.n_cigar);
+	x.n_cigar += n_cigar - absorbed;
 }
 
 // What mm_fix_cigar (align.c:105-181) leaves of a CIGAR, formulated the way region_finish_kernel does it (region_finish.hip, step B) rather than as one
@@ -531,128 +528,12 @@ int test_zdrop(const MapOpt &opt, const uint8_t *qseq, const uint8_t *tseq, uint
 // ---------------------------------------------------------------------------------------------------------
 // Seed clean-up before window selection (align.c:435-561)
 // ---------------------------------------------------------------------------------------------------------
-static inline int gap_at(const Anchor *a, int i) // query advance minus target advance between anchors i-1 and i
-{
-	return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - (int32_t)(a[i].x - a[i - 1].x);
-}
-
-static void long_gap_sites(int as1, int cnt1, const Anchor *a, int min_gap, std::vector<int> &K) // collect_long_gaps, align.c:435-452
+// (the rules themselves: region_rules.hpp, shared with region_plan_kernel)
+static void long_gap_sites(const Anchor *chain, int cnt1, int min_gap, std::vector<int32_t> &K) // collect_long_gaps, align.c:435-452: nothing unless there are two
 {
 	K.clear();
-	int n = 0;
-	for (int i = 1; i < cnt1; ++i) { const int g = gap_at(a + as1, i); if (g < -min_gap || g > min_gap) ++n; }
-	if (n <= 1) return;
-	for (int i = 1; i < cnt1; ++i) { const int g = gap_at(a + as1, i); if (g < -min_gap || g > min_gap) K.push_back(i); }
-}
-
-static void drop_compensating_gap_seeds(int as1, int cnt1, Anchor *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) // mm_filter_bad_seeds, align.c:454-489
-{
-	std::vector<int> K;
-	long_gap_sites(as1, cnt1, a, min_gap, K);
-	const int n = (int)K.size();
-	if (n == 0) return;
-	int max = 0, max_st = -1, max_en = -1;
-	for (int k = 0;; ++k) {
-		if (k == n || k >= max_en) {
-			if (max_en > 0)
-				for (int i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= SEED_IGNORE;
-			max = 0, max_st = max_en = -1;
-			if (k == n) break;
-		}
-		const int i = K[k];
-		int gap = gap_at(a + as1, i), n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1;
-		if (gap > 0) n_ins += gap; else n_del += -gap;
-		const int qs = (int32_t)a[as1 + i - 1].y, rs = (int32_t)a[as1 + i - 1].x;
-		for (int l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
-			const int j = K[l];
-			if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
-			gap = gap_at(a + as1, j);
-			if (gap > 0) n_ins += gap; else n_del += -gap;
-			const int diff = n_ins + n_del - abs(n_ins - n_del);
-			if (max_diff < diff) max_diff = diff, max_diff_l = l;
-		}
-		if (max_diff > diff_thres && max_diff > max) max = max_diff, max_st = k, max_en = max_diff_l;
-	}
-}
-
-static void join_over_gap_clusters(int as1, int cnt1, Anchor *a, int min_gap, int max_ext) // mm_filter_bad_seeds_alt, align.c:491-525
-{
-	std::vector<int> K;
-	long_gap_sites(as1, cnt1, a, min_gap, K);
-	const int n = (int)K.size();
-	for (int k = 0; k < n;) {
-		const int i = K[k];
-		int l, gap1 = gap_at(a + as1, i);
-		int re1 = (int32_t)a[as1 + i].x, qe1 = (int32_t)a[as1 + i].y;
-		gap1 = gap1 > 0 ? gap1 : -gap1;
-		for (l = k + 1; l < n; ++l) {
-			const int j = K[l];
-			if ((int32_t)a[as1 + j].y - qe1 > max_ext || (int32_t)a[as1 + j].x - re1 > max_ext) break;
-			int gap2 = gap_at(a + as1, j);
-			const int span_pre = span_of(a[as1 + j - 1]);
-			const int rs2 = (int32_t)a[as1 + j - 1].x + span_pre, qs2 = (int32_t)a[as1 + j - 1].y + span_pre;
-			const int m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
-			gap2 = gap2 > 0 ? gap2 : -gap2;
-			if (m > gap1 + gap2) break;
-			re1 = (int32_t)a[as1 + j].x, qe1 = (int32_t)a[as1 + j].y;
-			gap1 = gap2;
-		}
-		if (l > k + 1) {
-			const int end = K[l - 1];
-			for (int j = K[k]; j < end; ++j) a[as1 + j].y |= SEED_IGNORE;
-			a[as1 + end].y |= SEED_LONG_JOIN;
-		}
-		k = l;
-	}
-}
-
-// the best-scoring run of consecutive seeds on one diagonal (mm_max_stretch, align.c:563-589): what a short read is aligned from
-static void longest_ungapped_run(const Reg &r, const Anchor *a, int32_t *as, int32_t *cnt)
-{
-	*as = r.as, *cnt = r.cnt;
-	if (r.cnt < 2) return;
-	int32_t max_score = -1, max_i = -1, max_len = 0, score = span_of(a[r.as]), len = 1, i;
-	for (i = r.as + 1; i < r.as + r.cnt; ++i) {
-		const int32_t q_span = span_of(a[i]);
-		const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-		if (lq == lr) score += lq < q_span ? lq : q_span, ++len;
-		else {
-			if (score > max_score) max_score = score, max_len = len, max_i = i - len;
-			score = q_span, len = 1;
-		}
-	}
-	if (score > max_score) max_score = score, max_len = len, max_i = i - len;
-	*as = max_i, *cnt = max_len;
-}
-
-static void trim_bad_ends(const Reg &r, const Anchor *a, int bw, int min_match, int32_t *as, int32_t *cnt) // mm_fix_bad_ends, align.c:527-561
-{
-	*as = r.as, *cnt = r.cnt;
-	if (r.cnt < 3) return;
-	int32_t m, l;
-	m = l = span_of(a[r.as]);
-	for (int32_t i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
-		const int32_t q_span = span_of(a[i]);
-		if (a[i].y & SEED_LONG_JOIN) break;
-		const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
-		if (mx - mn > l >> 1) *as = i;
-		l += mn;
-		m += mn < q_span ? mn : q_span;
-		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
-	}
-	*cnt = r.as + r.cnt - *as;
-	m = l = span_of(a[r.as + r.cnt - 1]);
-	for (int32_t i = r.as + r.cnt - 2; i > *as; --i) {
-		const int32_t q_span = span_of(a[i + 1]);
-		if (a[i + 1].y & SEED_LONG_JOIN) break;
-		const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
-		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
-		if (mx - mn > l >> 1) *cnt = i + 1 - *as;
-		l += mn;
-		m += mn < q_span ? mn : q_span;
-		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
-	}
+	for (int i = 1; i < cnt1; ++i) if (rr_is_long_gap(chain, i, min_gap)) K.push_back(i);
+	if (K.size() <= 1) K.clear();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -855,16 +736,19 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 	int32_t as1, cnt1, rs, qs, re, qe, rs0, qs0, re0, qe0, rs1, qs1, re1, qe1, l;
 
 	if (is_sr) { // align.c:664-669: a short read is aligned from its best run of seeds on one diagonal
-		longest_ungapped_run(r, a, &as1, &cnt1);
+		rr_best_diagonal_run(r, a, &as1, &cnt1); // mm_max_stretch, align.c:563-589
 		rs = (int32_t)a[as1].x + 1 - span_of(a[as1]), qs = (int32_t)a[as1].y + 1 - span_of(a[as1]);
 		re = (int32_t)a[as1 + cnt1 - 1].x + 1, qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
 	} else {
 		if (!(opt_.flag & F_NO_END_FLT)) {
 			if (is_splice) trim_bad_ends_splice(opt_, fi_, r, mat_, qlen, ra, a, tbuf_, &as1, &cnt1);
-			else trim_bad_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1);
+			else rr_trim_ends(r, a, opt_.bw, opt_.min_chain_score * 2, &as1, &cnt1); // mm_fix_bad_ends, align.c:527-561
 		} else as1 = r.as, cnt1 = r.cnt;
-		drop_compensating_gap_seeds(as1, cnt1, a, 10, 40, opt_.max_gap >> 1, 10);
-		join_over_gap_clusters(as1, cnt1, a, 30, opt_.max_gap >> 1);
+		std::vector<int32_t> &K = gap_sites_;
+		long_gap_sites(a + as1, cnt1, 10, K);
+		rr_drop_compensating_gaps(a + as1, K.data(), (int)K.size(), 40, opt_.max_gap >> 1, 10); // mm_filter_bad_seeds, align.c:454-489
+		long_gap_sites(a + as1, cnt1, 30, K);
+		rr_join_gap_clusters(a + as1, K.data(), (int)K.size(), opt_.max_gap >> 1);               // mm_filter_bad_seeds_alt, align.c:491-525
 		anchor_boundary(fi_, ra, qlen, a[as1], &rs, &qs);
 		anchor_boundary(fi_, ra, qlen, a[as1 + cnt1 - 1], &re, &qe);
 	}
@@ -878,77 +762,36 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 		if (fi_.has_spsc) t.ksw_flag |= KSW_SPLICE_SCORE; // align.c:688
 	}
 
-	// how far the two extensions may reach (align.c:695-767)
-	if (is_sr) { // the whole read, and as much reference as its unaligned ends could span with gaps (align.c:696-704)
+	// how far the two extensions may reach (align.c:695-767): region_rules.hpp, one routine for both ends on coordinates that face the end
+	if (is_sr) { // the whole read, and as much reference as its unaligned ends could span with gaps
 		qs0 = 0, qe0 = qlen;
-		l = qs;
-		l += l * opt_.a + opt_.end_bonus > opt_.q ? (l * opt_.a + opt_.end_bonus - opt_.q) / opt_.e : 0;
-		rs0 = rs - l > 0 ? rs - l : 0;
-		l = qlen - qe;
-		l += l * opt_.a + opt_.end_bonus > opt_.q ? (l * opt_.a + opt_.end_bonus - opt_.q) / opt_.e : 0;
-		re0 = re + l < ref_len ? re + l : ref_len;
-		rs1 = qs1 = re1 = qe1 = 0;
+		rs0 = std::max<int32_t>(rs - rr_sr_reach(qs, opt_.a, opt_.q, opt_.e, opt_.end_bonus), 0);
+		re0 = std::min<int32_t>(re + rr_sr_reach(qlen - qe, opt_.a, opt_.q, opt_.e, opt_.end_bonus), ref_len);
 	} else {
-	rs0 = (int32_t)a[r.as].x + 1 - span_of(a[r.as]);
-	qs0 = (int32_t)a[r.as].y + 1 - span_of(a[r.as]);
-	if (rs0 < 0) rs0 = 0;
-	assert(qs0 >= 0);
-	rs1 = qs1 = 0;
-	l = 0;
-	for (int32_t i = r.as - 1; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) { // earlier seeds on the same target/strand bound the extension
-		const int32_t x = (int32_t)a[i].x + 1 - span_of(a[i]), y = (int32_t)a[i].y + 1 - span_of(a[i]);
-		if (x < rs0 && y < qs0) {
-			if (++l > opt_.min_cnt) {
-				l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
-				rs1 = rs0 - l, qs1 = qs0 - l;
-				if (rs1 < 0) rs1 = 0;
-				break;
-			}
-		}
+		const RrExtScoring S = { opt_.a, opt_.q, opt_.e, opt_.max_gap, opt_.min_cnt };
+		const Anchor &first = a[r.as], &last = a[r.as + r.cnt - 1];
+		assert(rr_y(first) + 1 - rr_span(first) >= 0);
+		rr_extension_limit(rr_x(first) + 1 - rr_span(first), rr_y(first) + 1 - rr_span(first), rs, qs,
+			[&](int k, int32_t *nt, int32_t *nq) { // earlier seeds of the read on the same target and strand
+				const int32_t i = r.as - 1 - k;
+				if (i < 0 || !rr_same_target(a[i], first)) return false;
+				*nt = rr_x(a[i]) + 1 - rr_span(a[i]), *nq = rr_y(a[i]) + 1 - rr_span(a[i]);
+				return true;
+			}, S, true, &rs0, &qs0);
+		int32_t far_t, far_q; // the right end, in distances from the sequences' ends
+		rr_extension_limit(ref_len - (rr_x(last) + 1), qlen - (rr_y(last) + 1), ref_len - re, qlen - qe,
+			[&](int k, int32_t *nt, int32_t *nq) { // later seeds
+				const int32_t i = r.as + r.cnt + k;
+				if (i >= ra.n_a || !rr_same_target(a[i], first)) return false;
+				*nt = ref_len - (rr_x(a[i]) + 1), *nq = qlen - (rr_y(a[i]) + 1);
+				return true;
+			}, S, false, &far_t, &far_q);
+		re0 = ref_len - far_t, qe0 = qlen - far_q;
 	}
-	if (qs > 0 && rs > 0) {
-		l = qs < opt_.max_gap ? qs : opt_.max_gap;
-		qs1 = qs1 > qs - l ? qs1 : qs - l;
-		qs0 = qs0 < qs1 ? qs0 : qs1;
-		l += l * opt_.a > opt_.q ? (l * opt_.a - opt_.q) / opt_.e : 0;
-		l = l < opt_.max_gap ? l : opt_.max_gap;
-		l = l < rs ? l : rs;
-		rs1 = rs1 > rs - l ? rs1 : rs - l;
-		rs0 = rs0 < rs1 ? rs0 : rs1;
-		rs0 = rs0 < rs ? rs0 : rs;
-	} else rs0 = rs, qs0 = qs;
-	re0 = (int32_t)a[r.as + r.cnt - 1].x + 1;
-	qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
-	re1 = ref_len, qe1 = qlen;
-	l = 0;
-	for (int32_t i = r.as + r.cnt; i < ra.n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
-		const int32_t x = (int32_t)a[i].x + 1, y = (int32_t)a[i].y + 1;
-		if (x > re0 && y > qe0) {
-			if (++l > opt_.min_cnt) {
-				l = x - re0 > y - qe0 ? x - re0 : y - qe0;
-				re1 = re0 + l, qe1 = qe0 + l;
-				break;
-			}
-		}
-	}
-	if (qe < qlen && re < ref_len) {
-		l = qlen - qe < opt_.max_gap ? qlen - qe : opt_.max_gap;
-		qe1 = qe1 < qe + l ? qe1 : qe + l;
-		qe0 = qe0 > qe1 ? qe0 : qe1;
-		l += l * opt_.a > opt_.q ? (l * opt_.a - opt_.q) / opt_.e : 0;
-		l = l < opt_.max_gap ? l : opt_.max_gap;
-		l = l < ref_len - re ? l : ref_len - re;
-		re1 = re1 < re + l ? re1 : re + l;
-		re0 = re0 > re1 ? re0 : re1;
-	} else re0 = re, qe0 = qe;
-	}
-	if (a[r.as].y & SEED_SELF) {
-		int max_ext = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs;
-		if (r.rs - rs0 > max_ext) rs0 = r.rs - max_ext;
-		if (r.qs - qs0 > max_ext) qs0 = r.qs - max_ext;
-		max_ext = r.qe > r.re ? r.qe - r.re : r.re - r.qe;
-		if (re0 - r.re > max_ext) re0 = r.re + max_ext;
-		if (qe0 - r.qe > max_ext) qe0 = r.qe + max_ext;
+	if (a[r.as].y & SEED_SELF) { // a hit overlapping itself stays on its side of the diagonal (align.c:760-767)
+		const int32_t room_l = std::abs(r.qs - r.rs), room_r = std::abs(r.qe - r.re);
+		rs0 = rr_self_limit(rs0, r.rs, room_l), qs0 = rr_self_limit(qs0, r.qs, room_l);
+		re0 = ref_len - rr_self_limit(ref_len - re0, ref_len - r.re, room_r), qe0 = qlen - rr_self_limit(qlen - qe0, qlen - r.qe, room_r);
 	}
 	assert(re0 > rs0);
 	t.as1 = as1, t.cnt1 = cnt1;

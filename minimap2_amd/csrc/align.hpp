@@ -128,6 +128,7 @@ private:
 	int8_t mat_[25];
 	int bw_, bw_long_;
 	std::vector<uint8_t> tbuf_;
+	std::vector<int32_t> gap_sites_; // the chain's long-gap anchors (region_rules.hpp), reused from read to read
 };
 
 // mm_extra_t management (align.c:305-334)

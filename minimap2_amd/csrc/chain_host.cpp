@@ -4,28 +4,24 @@
 
 namespace mm2amd {
 
-namespace {
-
-// Walk back from chain end z[k] and decide where the chain is cut (mg_chain_bk_end, lchain.c:9-25):
-// stop at an anchor already claimed, or when the score has dropped by more than max_drop below its running peak.
-int64_t chain_cut(int32_t max_drop, const Anchor *z, const int32_t *f, const int32_t *p, int32_t *t, int64_t k)
+// Where the chain that ends at anchor `end` (chaining score `total`) is cut (what mg_chain_bk_end, lchain.c:9-25, returns): following the predecessor links, the
+// chain's score SINCE an anchor is total - f[that anchor]; the cut goes to the anchor where that gain peaks, and the walk gives up once the gain has fallen
+// max_drop below its peak or reaches an anchor another chain has claimed (t != 0).  Links only point backwards, so no anchor is seen twice and nothing needs
+// marking on the way (the reference marks and unmarks).  Returns the anchor BEFORE the chain's first (-1: the chain starts the read's anchors).
+int64_t chain_cut(int32_t max_drop, int32_t total, int64_t end, const int32_t *f, const int32_t *p, const int32_t *t)
 {
-	int64_t i = (int64_t)z[k].y, end_i = -1, max_i = i;
-	int32_t max_s = 0;
-	if (i < 0 || t[i] != 0) return i;
-	do {
-		int32_t s;
-		t[i] = 2;
-		end_i = i = p[i];
-		s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
-		if (s > max_s) max_s = s, max_i = i;
-		else if (max_s - s > max_drop) break;
-	} while (i >= 0 && t[i] == 0);
-	for (i = (int64_t)z[k].y; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
-	return max_i;
+	if (end < 0 || t[end] != 0) return end;
+	int64_t cut = end;
+	int32_t peak = 0;
+	for (int64_t i = end;;) {
+		i = p[i];
+		const int32_t gain = i < 0 ? total : total - f[i];
+		if (gain > peak) peak = gain, cut = i;
+		else if (peak - gain > max_drop) break;
+		if (i < 0 || t[i] != 0) break;
+	}
+	return cut;
 }
-
-} // namespace
 
 void chain_backtrack_compact(int64_t n, const Anchor *a, const int32_t *f, const int32_t *p, int min_cnt, int min_sc, int max_drop,
                              std::vector<uint64_t> &u, std::vector<Anchor> &out, ChainScratch &sc)
@@ -44,7 +40,7 @@ void chain_backtrack_compact(int64_t n, const Anchor *a, const int32_t *f, const
 	for (int64_t k = n_z - 1; k >= 0; --k) { // (lchain.c:57-72; the counting pre-pass :43-56 computes the same thing)
 		if (sc.t[sc.z[k].y] != 0) continue;
 		const size_t n_v0 = sc.v.size();
-		const int64_t end_i = chain_cut(max_drop, sc.z.data(), f, p, sc.t.data(), k);
+		const int64_t end_i = chain_cut(max_drop, (int32_t)sc.z[k].x, (int64_t)sc.z[k].y, f, p, sc.t.data());
 		int64_t i;
 		for (i = (int64_t)sc.z[k].y; i != end_i; i = p[i]) sc.v.push_back((int32_t)i), sc.t[i] = 1;
 		const int32_t s = i < 0 ? (int32_t)sc.z[k].x : (int32_t)sc.z[k].x - f[i];

@@ -34,4 +34,7 @@ inline float fast_log2(float x)
 	return l;
 }
 
+// where the chain ending at anchor `end` with score `total` is cut (chain_host.cpp; exposed for tests/cpucheck/region_rules_test.cpp)
+int64_t chain_cut(int32_t max_drop, int32_t total, int64_t end, const int32_t *f, const int32_t *p, const int32_t *t);
+
 } // namespace mm2amd

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "hip_util.hpp"
 #include "region_dev.hpp"
+#include "region_rules.hpp"
 #include "hit_rules.hpp"
 
 namespace mm2amd {
@@ -202,11 +203,6 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 // ---------------------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ int rg_gap_at(const Anchor *a, int i) // query advance minus reference advance between anchors i - 1 and i
-{
-	return (rg_y(a[i]) - rg_y(a[i - 1])) - (int32_t)(a[i].x - a[i - 1].x);
-}
-
 // the anchors before which the two sequences drift apart by more than min_gap (collect_long_gaps, align.c:435-452); none when there is only one.
 // All lanes: 64 anchors per step, the sites compacted in order by a ballot.  Every lane returns the count.
 __device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K, int lane)
@@ -215,7 +211,7 @@ __device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K, 
 	for (int i0 = 1; i0 < cnt1; i0 += 64) {
 		const int i = i0 + lane;
 		bool site = false;
-		if (i < cnt1) { const int g = rg_gap_at(a, i); site = g < -min_gap || g > min_gap; }
+		if (i < cnt1) site = rr_is_long_gap(a, i, min_gap);
 		const unsigned long long m = __ballot(site);
 		if (site) K[n + __popcll(m & ((1ull << lane) - 1ull))] = i;
 		n += __popcll(m);
@@ -223,99 +219,7 @@ __device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K, 
 	return n <= 1 ? 0 : n;
 }
 
-// runs of seeds between an insertion and a deletion that cancel each other are bad seeds (mm_filter_bad_seeds, align.c:454-489)
-__device__ void rg_drop_compensating(Anchor *a, int n, const int32_t *K, int diff_thres, int max_ext_len, int max_ext_cnt) // n, K: rg_gap_sites(.., 10, ..)
-{
-	if (n == 0) return;
-	int best = 0, best_st = -1, best_en = -1;
-	for (int k = 0;; ++k) {
-		if (k == n || k >= best_en) {
-			if (best_en > 0) for (int i = K[best_st]; i < K[best_en]; ++i) a[i].y |= ref::SEED_IGNORE;
-			best = 0, best_st = best_en = -1;
-			if (k == n) break;
-		}
-		const int i = K[k];
-		int gap = rg_gap_at(a, i), n_ins = 0, n_del = 0, top = 0, top_l = -1;
-		if (gap > 0) n_ins += gap; else n_del -= gap;
-		const int q0 = rg_y(a[i - 1]), r0 = rg_x(a[i - 1]);
-		for (int l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
-			const int j = K[l];
-			if (rg_y(a[j]) - q0 > max_ext_len || rg_x(a[j]) - r0 > max_ext_len) break;
-			gap = rg_gap_at(a, j);
-			if (gap > 0) n_ins += gap; else n_del -= gap;
-			const int both = n_ins + n_del, net = n_ins > n_del ? n_ins - n_del : n_del - n_ins, diff = both - net;
-			if (top < diff) top = diff, top_l = l;
-		}
-		if (top > diff_thres && top > best) best = top, best_st = k, best_en = top_l;
-	}
-}
-
-// clusters of long gaps close to each other are bridged by ONE long window (mm_filter_bad_seeds_alt, align.c:491-525)
-__device__ void rg_join_gap_clusters(Anchor *a, int n, const int32_t *K, int max_ext) // n, K: rg_gap_sites(.., 30, ..)
-{
-	for (int k = 0; k < n;) {
-		const int i = K[k];
-		int l, gap1 = rg_gap_at(a, i);
-		int re1 = rg_x(a[i]), qe1 = rg_y(a[i]);
-		gap1 = gap1 > 0 ? gap1 : -gap1;
-		for (l = k + 1; l < n; ++l) {
-			const int j = K[l];
-			if (rg_y(a[j]) - qe1 > max_ext || rg_x(a[j]) - re1 > max_ext) break;
-			int gap2 = rg_gap_at(a, j);
-			const int sp = rg_span(a[j - 1]);
-			const int rs2 = rg_x(a[j - 1]) + sp, qs2 = rg_y(a[j - 1]) + sp;
-			const int room = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
-			gap2 = gap2 > 0 ? gap2 : -gap2;
-			if (room > gap1 + gap2) break;
-			re1 = rg_x(a[j]), qe1 = rg_y(a[j]);
-			gap1 = gap2;
-		}
-		if (l > k + 1) {
-			const int end = K[l - 1];
-			for (int j = K[k]; j < end; ++j) a[j].y |= ref::SEED_IGNORE;
-			a[end].y |= ref::SEED_LONG_JOIN;
-		}
-		k = l;
-	}
-}
-
-// seeds at a chain's ends that sit off the diagonal of what follows are not aligned from (mm_fix_bad_ends, align.c:527-561); a = the read's anchors
-__device__ void rg_trim_ends(const Reg1 &r, const Anchor *a, int bw, int min_match, int32_t *as, int32_t *cnt)
-{
-	*as = r.as, *cnt = r.cnt;
-	if (r.cnt < 3) return;
-	int32_t m, l;
-	m = l = rg_span(a[r.as]);
-	for (int32_t i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
-		const int32_t sp = rg_span(a[i]);
-		if (a[i].y & ref::SEED_LONG_JOIN) break;
-		const int32_t lr = rg_x(a[i]) - rg_x(a[i - 1]), lq = rg_y(a[i]) - rg_y(a[i - 1]);
-		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
-		if (mx - mn > l >> 1) *as = i;
-		l += mn;
-		m += mn < sp ? mn : sp;
-		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
-	}
-	*cnt = r.as + r.cnt - *as;
-	m = l = rg_span(a[r.as + r.cnt - 1]);
-	for (int32_t i = r.as + r.cnt - 2; i > *as; --i) {
-		const int32_t sp = rg_span(a[i + 1]);
-		if (a[i + 1].y & ref::SEED_LONG_JOIN) break;
-		const int32_t lr = rg_x(a[i + 1]) - rg_x(a[i]), lq = rg_y(a[i + 1]) - rg_y(a[i]);
-		const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
-		if (mx - mn > l >> 1) *cnt = i + 1 - *as;
-		l += mn;
-		m += mn < sp ? mn : sp;
-		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
-	}
-}
-
-// how far a gapped extension of l query bases can reach on the reference (align.c:716-718)
-__device__ __forceinline__ int rg_ext_reach(int l, const RgnOpts &O)
-{
-	l += l * O.a > O.q ? (l * O.a - O.q) / O.e : 0;
-	return l < O.max_gap ? l : O.max_gap;
-}
+// (the two long-gap filters, the end trimming and the extension limits: region_rules.hpp -- one definition for this kernel and for align.cpp)
 
 struct RgnJobCtx { uint64_t q_fwd, q_rev, t_base; int rev, gen_flag; };
 
@@ -416,18 +320,18 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 	const int32_t ref_len = (int32_t)B.ref_len[rid];
 	int32_t as1 = r.as, cnt1 = r.cnt;
 	if (!(O.flag & ref::F_NO_END_FLT)) {
-		if (lane == 0) rg_trim_ends(r, a, O.bw, O.min_chain_score * 2, &as1, &cnt1);
+		if (lane == 0) rr_trim_ends(r, a, O.bw, O.min_chain_score * 2, &as1, &cnt1); // mm_fix_bad_ends, align.c:527-561
 		as1 = __shfl(as1, 0, 64), cnt1 = __shfl(cnt1, 0, 64);
 	}
 	int32_t *K = B.gap_sites + rd.sq_off + as1;
 	{
 		const int n10 = rg_gap_sites(a + as1, cnt1, 10, K, lane);
 		RG_SYNC();
-		if (lane == 0) rg_drop_compensating(a + as1, n10, K, 40, O.max_gap >> 1, 10);
+		if (lane == 0) rr_drop_compensating_gaps(a + as1, K, n10, 40, O.max_gap >> 1, 10); // mm_filter_bad_seeds, align.c:454-489
 		RG_SYNC();
 		const int n30 = rg_gap_sites(a + as1, cnt1, 30, K, lane);
 		RG_SYNC();
-		if (lane == 0) rg_join_gap_clusters(a + as1, n30, K, O.max_gap >> 1);
+		if (lane == 0) rr_join_gap_clusters(a + as1, K, n30, O.max_gap >> 1);               // mm_filter_bad_seeds_alt, align.c:491-525
 		RG_SYNC(); // (the flags lane 0 set in the anchors are read by all lanes below)
 	}
 	RgnJobCtx X;
@@ -437,61 +341,31 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 	rg_boundary(B, O, X, a[as1], &rs, &qs);
 	rg_boundary(B, O, X, a[as1 + cnt1 - 1], &re, &qe);
 
-	// how far the two extensions may reach (align.c:706-767): lane 0
+	// how far the two extensions may reach (align.c:706-767; region_rules.hpp: one routine for both ends, on coordinates that face the end): lane 0
 	int32_t rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
 	if (lane == 0) {
-		int32_t rs1 = 0, qs1 = 0, re1, qe1, l;
-		const Anchor f = a[r.as];
-		rs0 = rg_x(f) + 1 - rg_span(f), qs0 = rg_y(f) + 1 - rg_span(f);
-		if (rs0 < 0) rs0 = 0;
-		l = 0;
-		for (int32_t i = r.as - 1; i >= 0 && a[i].x >> 32 == f.x >> 32; --i) { // earlier seeds on the same sequence and strand bound the extension
-			const int32_t x = rg_x(a[i]) + 1 - rg_span(a[i]), y = rg_y(a[i]) + 1 - rg_span(a[i]);
-			if (x < rs0 && y < qs0 && ++l > O.min_cnt) {
-				l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
-				rs1 = rs0 - l, qs1 = qs0 - l;
-				if (rs1 < 0) rs1 = 0;
-				break;
-			}
-		}
-		if (qs > 0 && rs > 0) {
-			l = qs < O.max_gap ? qs : O.max_gap;
-			qs1 = qs1 > qs - l ? qs1 : qs - l;
-			qs0 = qs0 < qs1 ? qs0 : qs1;
-			l = rg_ext_reach(l, O);
-			l = l < rs ? l : rs;
-			rs1 = rs1 > rs - l ? rs1 : rs - l;
-			rs0 = rs0 < rs1 ? rs0 : rs1;
-			rs0 = rs0 < rs ? rs0 : rs;
-		} else rs0 = rs, qs0 = qs;
-		const Anchor t = a[r.as + r.cnt - 1];
-		re0 = rg_x(t) + 1, qe0 = rg_y(t) + 1;
-		re1 = ref_len, qe1 = qlen;
-		l = 0;
-		for (int32_t i = r.as + r.cnt; i < n_a && a[i].x >> 32 == f.x >> 32; ++i) {
-			const int32_t x = rg_x(a[i]) + 1, y = rg_y(a[i]) + 1;
-			if (x > re0 && y > qe0 && ++l > O.min_cnt) {
-				l = x - re0 > y - qe0 ? x - re0 : y - qe0;
-				re1 = re0 + l, qe1 = qe0 + l;
-				break;
-			}
-		}
-		if (qe < qlen && re < ref_len) {
-			l = qlen - qe < O.max_gap ? qlen - qe : O.max_gap;
-			qe1 = qe1 < qe + l ? qe1 : qe + l;
-			qe0 = qe0 > qe1 ? qe0 : qe1;
-			l = rg_ext_reach(l, O);
-			l = l < ref_len - re ? l : ref_len - re;
-			re1 = re1 < re + l ? re1 : re + l;
-			re0 = re0 > re1 ? re0 : re1;
-		} else re0 = re, qe0 = qe;
-		if (f.y & ref::SEED_SELF) { // an overlap with itself must not extend across the diagonal (align.c:760-767)
-			int room = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs;
-			if (r.rs - rs0 > room) rs0 = r.rs - room;
-			if (r.qs - qs0 > room) qs0 = r.qs - room;
-			room = r.qe > r.re ? r.qe - r.re : r.re - r.qe;
-			if (re0 - r.re > room) re0 = r.re + room;
-			if (qe0 - r.qe > room) qe0 = r.qe + room;
+		const RrExtScoring S = { O.a, O.q, O.e, O.max_gap, O.min_cnt };
+		const Anchor first = a[r.as], last = a[r.as + r.cnt - 1];
+		rr_extension_limit(rr_x(first) + 1 - rr_span(first), rr_y(first) + 1 - rr_span(first), rs, qs,
+			[&](int k, int32_t *nt, int32_t *nq) { // the read's earlier seeds on the same sequence and strand
+				const int32_t i = r.as - 1 - k;
+				if (i < 0 || !rr_same_target(a[i], first)) return false;
+				*nt = rr_x(a[i]) + 1 - rr_span(a[i]), *nq = rr_y(a[i]) + 1 - rr_span(a[i]);
+				return true;
+			}, S, true, &rs0, &qs0);
+		int32_t far_t, far_q; // the right end, in distances from the sequences' ends
+		rr_extension_limit(ref_len - (rr_x(last) + 1), qlen - (rr_y(last) + 1), ref_len - re, qlen - qe,
+			[&](int k, int32_t *nt, int32_t *nq) { // its later ones
+				const int32_t i = r.as + r.cnt + k;
+				if (i >= n_a || !rr_same_target(a[i], first)) return false;
+				*nt = ref_len - (rr_x(a[i]) + 1), *nq = qlen - (rr_y(a[i]) + 1);
+				return true;
+			}, S, false, &far_t, &far_q);
+		re0 = ref_len - far_t, qe0 = qlen - far_q;
+		if (first.y & ref::SEED_SELF) { // an overlap with itself must not extend across the diagonal (align.c:760-767)
+			const int32_t room_l = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs, room_r = r.qe > r.re ? r.qe - r.re : r.re - r.qe;
+			rs0 = rr_self_limit(rs0, r.rs, room_l), qs0 = rr_self_limit(qs0, r.qs, room_l);
+			re0 = ref_len - rr_self_limit(ref_len - re0, ref_len - r.re, room_r), qe0 = qlen - rr_self_limit(qlen - qe0, qlen - r.qe, room_r);
 		}
 	}
 	rs0 = __shfl(rs0, 0, 64), qs0 = __shfl(qs0, 0, 64), re0 = __shfl(re0, 0, 64), qe0 = __shfl(qe0, 0, 64);

@@ -49,3 +49,42 @@ int refshim_update_extra_eqx(int n_pieces, const uint32_t *const *pieces, const 
 	free(r.p);
 	return n;
 }
+
+/* Round 6: the chain -> window rules of mm_align1 that are static functions of their own (align.c:454-561), for tests/cpucheck/region_rules_test.cpp --
+ * minimap2_amd/csrc/region_rules.hpp is pinned to them routine by routine.  a: the read's anchors (mm128_t), modified in place like the reference does. */
+void refshim_filter_bad_seeds(int as1, int cnt1, void *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt)
+{
+	mm_filter_bad_seeds(0, as1, cnt1, (mm128_t*)a, min_gap, diff_thres, max_ext_len, max_ext_cnt);
+}
+void refshim_filter_bad_seeds_alt(int as1, int cnt1, void *a, int min_gap, int max_ext)
+{
+	mm_filter_bad_seeds_alt(0, as1, cnt1, (mm128_t*)a, min_gap, max_ext);
+}
+void refshim_fix_bad_ends(int as, int cnt, int mlen, const void *a, int bw, int min_match, int32_t *as1, int32_t *cnt1)
+{
+	mm_reg1_t r;
+	memset(&r, 0, sizeof r);
+	r.as = as, r.cnt = cnt, r.mlen = mlen;
+	mm_fix_bad_ends(&r, (const mm128_t*)a, bw, min_match, as1, cnt1);
+}
+/* mm_append_cigar on its own (align.c:320-334): head then tail; returns the operations of the result */
+int refshim_append_cigar(int n_head, const uint32_t *head, int n_tail, const uint32_t *tail, uint32_t *out)
+{
+	mm_reg1_t r;
+	int n;
+	memset(&r, 0, sizeof r);
+	mm_append_cigar(&r, (uint32_t)n_head, head);
+	mm_append_cigar(&r, (uint32_t)n_tail, tail);
+	if (r.p == 0) return 0;
+	n = (int)r.p->n_cigar;
+	memcpy(out, r.p->cigar, (size_t)n * 4);
+	free(r.p);
+	return n;
+}
+void refshim_max_stretch(int as, int cnt, const void *a, int32_t *as1, int32_t *cnt1)
+{
+	mm_reg1_t r;
+	memset(&r, 0, sizeof r);
+	r.as = as, r.cnt = cnt;
+	mm_max_stretch(&r, (const mm128_t*)a, as1, cnt1);
+}

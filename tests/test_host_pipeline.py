@@ -491,6 +491,19 @@ def test_host_hit_rules_against_the_reference_functions():
     assert p.stdout.split()[0] == b"OK"
 
 
+def test_region_rules_against_the_reference_statics():
+    """minimap2_amd/csrc/region_rules.hpp -- the two long-gap seed filters, the end trimming (what region_plan_kernel and align.cpp both call) -- plus
+    chain_host.cpp's chain_cut and align.cpp's append_cigar, against the reference's own STATIC functions (mm_filter_bad_seeds, mm_filter_bad_seeds_alt,
+    mm_fix_bad_ends, mm_append_cigar, mg_chain_bk_end: compiled where they lie by oracle/ref_align_shim.c and ref_lchain_shim.c) on 40 000 random chains
+    built to reach the rules (tests/cpucheck/region_rules_test.cpp; it fails if a rule never took effect)."""
+    exe = os.path.join(HERE, "_build", "region_rules_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/region_rules_test not built (needs the compiled reference)")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    assert b"== the reference's statics" in p.stdout
+
+
 def test_device_sdust_header_against_the_reference():
     """minimap2_amd/csrc/sdust_core.hpp (what dust_filter_kernel runs per read) compiled for the host, vs the reference's sdust()."""
     exe = os.path.join(HERE, "_build", "sdust_test")

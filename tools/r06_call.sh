@@ -23,5 +23,19 @@ for f in ['r06_bench_band_$V.json','r06_bench_noband_$V.json']:
 P
        ;;
 bench) timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06_bench_full_$V.json 2> $O/r06_bench_full_$V.log; tail -c 600 $O/r06_bench_full_$V.json ;;
+others) # the other BASELINE configurations: map-hifi, splice, sr
+       timeout 500 python bench.py --preset map-hifi --reads 200000 --steps 3 --warmup 2 --cpu-sample 20000 > $O/r06_bench_hifi_$V.json 2> $O/r06_bench_hifi_$V.log
+       timeout 500 python bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r06_bench_splice_$V.json 2> $O/r06_bench_splice_$V.log
+       timeout 500 python bench.py --preset sr --reads 1000000 --steps 2 --warmup 1 --cpu-sample 100000 > $O/r06_bench_sr_$V.json 2> $O/r06_bench_sr_$V.log
+       python - <<P
+import json
+for f in ['r06_bench_hifi_$V.json','r06_bench_splice_$V.json','r06_bench_sr_$V.json']:
+    try:
+        d=json.loads(open('$O/'+f).read().strip().split('\n')[-1]); c=d.get('cpu_baseline') or {}; r=d['roofline']
+        print(f, d['value'], d['ms_per_step'], 'cpu', c.get('value'), c.get('hits_identical_to_gpu'), r['kernel'], 'host cpu s/step', d['config']['host_cpu_s_per_step'], d['config'].get('banded_gap_fill'))
+        print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:8]})
+    except Exception as e: print(f, 'FAILED', e)
+P
+       ;;
 esac
 done
