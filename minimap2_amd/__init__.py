@@ -590,7 +590,8 @@ class Aligner(object):
         names = ["t_seed_chain", "t_host_pre", "t_plan", "t_ksw", "t_consume", "t_finish", "n_jobs", "n_rounds", "dp_cells", "dev_allocs", "pin_allocs",
                  "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish", "n_long_join_dev", "n_long_join_host",
                  "drv_cpu_seed_chain", "drv_cpu_host_pre", "drv_cpu_plan", "drv_cpu_ksw", "drv_cpu_consume", "drv_cpu_finish", "n_early_sub",
-                 "n_region_reads_dev", "n_region_reads_host", "n_band128", "n_band256", "n_band_widened", "n_band_rectangle"]
+                 "n_region_reads_dev", "n_region_reads_host", "n_band128", "n_band256", "n_band_widened", "n_band_rectangle",
+                 "arena_dev_bytes", "arena_pin_bytes", "arena_dev_used", "arena_pin_used"]
         return dict(zip(names, list(v)[:k]))
 
 

@@ -111,6 +111,14 @@ public:
 			lanes_.back()->ksw.n_cu = n_cu_;
 			lanes_.back()->ksw.disable_fast = getenv("MM2AMD_KSW_EXACT_ONLY") != nullptr;
 		}
+		// the lanes' work buffers come out of arenas (hip_util.hpp): the first chunks are taken now, before any batch -- what a 100 000-read batch of long reads
+		// settles at -- but never more than a quarter of what the device has free
+		{
+			size_t free_b = 0, total_b = 0, want = arena_env_gb("MM2AMD_ARENA_DEV_GB", 24) << 30;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, free_b / 4);
+			dev_arena().reserve(want);
+			pin_arena().reserve(arena_env_gb("MM2AMD_ARENA_PIN_GB", 4) << 30);
+		}
 	}
 
 	~HipBackend() override

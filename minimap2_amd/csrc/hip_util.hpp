@@ -9,6 +9,10 @@
 #include <string>
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <mutex>
+#include <vector>
+#include <iterator>
 
 // A kernel's dynamic LDS as an array `name` of T.  (MM2AMD_WAVE_EMU: tests/cpucheck/wave_emu builds the .hip sources for the host.)
 // MM2_LOCKSTEP(): a point where the code relies on a wavefront executing in lock step -- every lane's loads above it happen before any
@@ -83,6 +87,113 @@ inline AllocStats &alloc_stats() { static AllocStats s; return s; }
 struct BandCounters { std::atomic<unsigned long long> n_band1{0}, n_band2{0}, n_widened{0}, n_retried{0}; };
 inline BandCounters &band_counters() { static BandCounters s; return s; }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Arenas behind DevBuf / PinBuf (round 6).  The work buffers of the lanes are grow-only vectors that find their sizes during the first batches: ~550 hipMalloc and
+// ~240 hipHostMalloc calls, the pinned ones at 185 ms per GB (tools/alloc_cost.hip) -- the first batch of a process cost seconds.  Now the buffers are carved out
+// of a few large chunks per device (first fit over an offset-ordered free list, neighbours merged on release): a buffer that grows hands its old block back
+// and the next one reuses it -- pages are pinned once --, and mm_gpu_init reserves the first chunks before any batch arrives (MM2AMD_ARENA_DEV_GB /
+// MM2AMD_ARENA_PIN_GB; 0 = nothing ahead of need).  Requests of more than half a chunk get an allocation of their own, as before.  MM2AMD_NO_ARENA=1 (and the
+// emulator build, where AddressSanitizer should see every buffer's own bounds) allocates every buffer directly.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+class MemArena {
+public:
+	MemArena(bool pinned, size_t chunk_bytes) : pinned_(pinned), chunk_bytes_(chunk_bytes) {}
+	~MemArena() { for (Chunk &c : chunks_) raw_free(c.base); for (auto &kv : solo_) raw_free(kv.first); }
+	static bool enabled()
+	{
+#ifdef MM2AMD_WAVE_EMU
+		static const bool on = getenv("MM2AMD_ARENA") != nullptr;
+#else
+		static const bool on = getenv("MM2AMD_NO_ARENA") == nullptr;
+#endif
+		return on;
+	}
+	void *alloc(size_t bytes)
+	{
+		bytes = (bytes + 255) & ~(size_t)255;
+		if (bytes == 0) bytes = 256;
+		std::lock_guard<std::mutex> lk(mu_);
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		if (!enabled() || bytes > chunk_bytes_ / 2) { char *p = raw_alloc(bytes); solo_[p] = bytes; return p; }
+		for (int pass = 0; pass < 2; ++pass) {
+			for (Chunk &c : chunks_) {
+				if (c.dev != dev) continue;
+				for (auto it = c.free_.begin(); it != c.free_.end(); ++it) {
+					if (it->second < bytes) continue;
+					const size_t off = it->first, len = it->second;
+					c.free_.erase(it);
+					if (len > bytes) c.free_[off + bytes] = len - bytes;
+					c.used[off] = bytes;
+					return c.base + off;
+				}
+			}
+			if (pass == 0) add_chunk(dev);
+		}
+		throw HipError("[mm2amd] MemArena: a fresh chunk did not hold the request");
+	}
+	void release(void *p)
+	{
+		if (!p) return;
+		std::lock_guard<std::mutex> lk(mu_);
+		auto so = solo_.find((char *)p);
+		if (so != solo_.end()) { raw_free(so->first); solo_.erase(so); return; }
+		for (Chunk &c : chunks_) {
+			if ((char *)p < c.base || (char *)p >= c.base + c.size) continue;
+			const size_t off = (size_t)((char *)p - c.base);
+			auto u = c.used.find(off);
+			if (u == c.used.end()) return; // (not ours, or released twice: leave it)
+			size_t len = u->second, beg = off;
+			c.used.erase(u);
+			auto nx = c.free_.lower_bound(beg);
+			if (nx != c.free_.end() && nx->first == beg + len) { len += nx->second; nx = c.free_.erase(nx); }
+			if (nx != c.free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == beg) { beg = pv->first, len += pv->second; c.free_.erase(pv); } }
+			c.free_[beg] = len;
+			return;
+		}
+	}
+	size_t held_bytes() { std::lock_guard<std::mutex> lk(mu_); size_t n = 0; for (const Chunk &c : chunks_) n += c.size; return n; }                 // in chunks (all devices)
+	size_t used_bytes() { std::lock_guard<std::mutex> lk(mu_); size_t n = 0; for (const Chunk &c : chunks_) for (auto &u : c.used) n += u.second; return n; } // handed out of them
+	// hold at least `bytes` in chunks on the current device (context set-up: the first batch then finds its memory there)
+	void reserve(size_t bytes)
+	{
+		if (!enabled()) return;
+		std::lock_guard<std::mutex> lk(mu_);
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		size_t have = 0;
+		for (const Chunk &c : chunks_) if (c.dev == dev) have += c.size;
+		while (have < bytes) { add_chunk(dev); have += chunk_bytes_; }
+	}
+private:
+	struct Chunk { char *base; size_t size; int dev; std::map<size_t, size_t> free_, used; };
+	char *raw_alloc(size_t bytes)
+	{
+		void *p = nullptr;
+		const auto t0_ = std::chrono::steady_clock::now();
+		if (pinned_) { HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); alloc_stats().pin_allocs++, alloc_stats().pin_bytes += (long long)bytes; }
+		else { HIP_CHECK(hipMalloc(&p, bytes)); alloc_stats().dev_allocs++, alloc_stats().dev_bytes += (long long)bytes; }
+		alloc_stats().ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+		return (char *)p;
+	}
+	void raw_free(char *p) { if (pinned_) (void)hipHostFree(p); else (void)hipFree(p); }
+	void add_chunk(int dev)
+	{
+		Chunk c;
+		c.base = raw_alloc(chunk_bytes_), c.size = chunk_bytes_, c.dev = dev;
+		c.free_[0] = chunk_bytes_;
+		chunks_.push_back(std::move(c));
+	}
+	const bool pinned_;
+	const size_t chunk_bytes_;
+	std::mutex mu_;
+	std::vector<Chunk> chunks_;
+	std::map<char *, size_t> solo_;
+};
+inline size_t arena_env_gb(const char *name, size_t dflt) { const char *e = getenv(name); return e ? (size_t)atol(e) : dflt; }
+inline MemArena &dev_arena() { static MemArena *a = new MemArena(false, (size_t)4 << 30); return *a; }  // (never destroyed: buffers in static objects may outlive any order of destruction; the process' exit frees the memory)
+inline MemArena &pin_arena() { static MemArena *a = new MemArena(true, (size_t)1 << 30); return *a; }
+
 // Grow-only device buffer; contents are NOT preserved across a grow.
 template <typename T>
 struct DevBuf {
@@ -91,21 +202,18 @@ struct DevBuf {
 	DevBuf() = default;
 	DevBuf(const DevBuf &) = delete;
 	DevBuf &operator=(const DevBuf &) = delete;
-	~DevBuf() { if (p) (void)hipFree(p); }
+	~DevBuf() { if (p) dev_arena().release(p); }
 	T *ensure(size_t n, double slack = 1.25)
 	{
 		if (n > cap) {
-			if (p) HIP_CHECK(hipFree(p));
+			if (p) dev_arena().release(p);
 			p = nullptr;
 			cap = (size_t)(n * slack) + 64;
-			const auto t0_ = std::chrono::steady_clock::now();
-			HIP_CHECK(hipMalloc((void **)&p, cap * sizeof(T)));
-			alloc_stats().dev_allocs++, alloc_stats().dev_bytes += (long long)(cap * sizeof(T));
-			alloc_stats().ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+			p = (T *)dev_arena().alloc(cap * sizeof(T));
 		}
 		return p;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	void release() { if (p) dev_arena().release(p); p = nullptr; cap = 0; }
 };
 
 // Grow-only pinned host buffer.
@@ -116,17 +224,14 @@ struct PinBuf {
 	PinBuf() = default;
 	PinBuf(const PinBuf &) = delete;
 	PinBuf &operator=(const PinBuf &) = delete;
-	~PinBuf() { if (p) (void)hipHostFree(p); }
+	~PinBuf() { if (p) pin_arena().release(p); }
 	T *ensure(size_t n, double slack = 1.25)
 	{
 		if (n > cap) {
-			if (p) HIP_CHECK(hipHostFree(p));
+			if (p) pin_arena().release(p);
 			p = nullptr;
 			cap = (size_t)(n * slack) + 64;
-			const auto t0_ = std::chrono::steady_clock::now();
-			HIP_CHECK(hipHostMalloc((void **)&p, cap * sizeof(T), hipHostMallocDefault));
-			alloc_stats().pin_allocs++, alloc_stats().pin_bytes += (long long)(cap * sizeof(T));
-			alloc_stats().ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+			p = (T *)pin_arena().alloc(cap * sizeof(T));
 		}
 		return p;
 	}

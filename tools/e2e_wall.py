@@ -30,14 +30,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def stamps(err):
-    loaded = mapped = ready = None
+    """loaded: the index is in memory; ready: the device mirror is (drop-in only); mapped: every "[M::worker_pipeline::t*..] mapped" stamp, one per mini-batch"""
+    loaded = ready = None
+    mapped = []
     for line in err.splitlines():
         m = re.match(r"\[M::(main|mm_idx_stat|worker_pipeline)::([0-9.]+)\*", line)
         if not m:
             continue
         t = float(m.group(2))
         if m.group(1) == "worker_pipeline":
-            mapped = t
+            mapped.append(t)
         elif "device mirror" in line:
             ready = t
         elif loaded is None and ("loaded/built the index" in line or m.group(1) == "mm_idx_stat"):
@@ -45,25 +47,61 @@ def stamps(err):
     return loaded, ready, mapped
 
 
-def run(cmd, out_path):
+def run(cmd, out_path=None):
+    """runs cmd; its standard output (SAM) is hashed on the fly without the @PG line -- a 10-Gbase run writes 13 GB of text per program, which need not touch a disk --
+    and kept in out_path only when one is given.  Returns wall seconds, stderr text, (md5, lines, bytes)."""
+    import threading
     t = time.time()
-    with open(out_path, "wb") as fo:
-        p = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, bufsize=1 << 24)
+    err_chunks = []
+    th = threading.Thread(target=lambda: err_chunks.append(p.stderr.read()))
+    th.start()
+    h, n, nb = hashlib.md5(), 0, 0
+    fo = open(out_path, "wb") if out_path else None
+    header, tail = True, b""
+    while True:
+        buf = p.stdout.read(1 << 24)
+        if not buf:
+            break
+        nb += len(buf)
+        if fo:
+            fo.write(buf)
+        if not header:
+            h.update(buf)
+            n += buf.count(b"\n")
+            continue
+        data = tail + buf  # still in the header: line by line, the @PG line left out of the digest; from the first record on, whole blocks
+        pos = 0
+        while header:
+            if pos >= len(data):
+                tail = b""
+                break
+            if data[pos:pos + 1] != b"@":
+                header = False
+                break
+            e = data.find(b"\n", pos)
+            if e < 0:
+                tail = data[pos:]
+                break
+            if not data.startswith(b"@PG", pos):
+                h.update(data[pos:e + 1])
+                n += 1
+            pos = e + 1
+        if not header:
+            h.update(data[pos:])
+            n += data.count(b"\n", pos)
+            tail = b""
+    if header and tail:
+        h.update(tail)
+    p.wait()
+    th.join()
+    if fo:
+        fo.close()
     wall = time.time() - t
-    err = p.stderr.decode(errors="replace")
+    err = b"".join(err_chunks).decode(errors="replace")
     if p.returncode != 0:
         raise RuntimeError("%s failed:\n%s" % (cmd[0], err[-2000:]))
-    return wall, err
-
-
-def digest_without_pg(path):
-    h, n = hashlib.md5(), 0
-    with open(path, "rb") as f:
-        for line in f:
-            if not line.startswith(b"@PG"):
-                h.update(line)
-                n += 1
-    return h.hexdigest(), n
+    return wall, err, (h.hexdigest(), n, nb)
 
 
 def main():
@@ -71,7 +109,7 @@ def main():
     ap.add_argument("--ref-mb", type=float, default=3000.0)
     ap.add_argument("--reads", type=int, default=100000)
     ap.add_argument("--dir", default="/tmp/e2e")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_e2e_wall.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_e2e_wall.json"))
     ap.add_argument("--skip-index-check", action="store_true")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
@@ -106,23 +144,30 @@ def main():
     t = time.time()
     subprocess.run([REF, "-x", "map-ont", "-t", str(ncpu), "-d", mmi, ref_fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     res["reference_index_build_s"] = round(time.time() - t, 1)
-    w_ref, e_ref = run([REF, "-ax", "map-ont", "-t", str(ncpu), mmi, reads_fa], os.path.join(a.dir, "ref.sam"))
-    w_our, e_our = run([OURS, "-x", "map-ont", "-a", "-t", str(min(64, ncpu)), mmi, reads_fa], os.path.join(a.dir, "ours.sam"))
+    keep = a.reads <= 200000  # small runs keep the two SAM files for inspection
+    w_ref, e_ref, dg_r = run([REF, "-ax", "map-ont", "-t", str(ncpu), mmi, reads_fa], os.path.join(a.dir, "ref.sam") if keep else None)
+    w_our, e_our, dg_o = run([OURS, "-x", "map-ont", "-a", "-t", str(min(64, ncpu)), mmi, reads_fa], os.path.join(a.dir, "ours.sam") if keep else None)
     for key, w, e in (("reference", w_ref, e_ref), ("gpu_dropin", w_our, e_our)):
-        loaded, ready, mapped = stamps(e)
-        res[key] = {"total_wall_s": round(w, 2), "index_in_memory_at_s": loaded, "last_batch_done_at_s": mapped,
+        loaded, ready, mapped_all = stamps(e)
+        mapped = mapped_all[-1] if mapped_all else None
+        res[key] = {"total_wall_s": round(w, 2), "index_in_memory_at_s": loaded, "last_batch_done_at_s": mapped, "mini_batches": len(mapped_all),
                     "mapping_phase_s": round(mapped - loaded, 2) if loaded is not None and mapped is not None else None,
                     "gbases_per_s_mapping_phase": round(bases / (mapped - loaded) / 1e9, 4) if loaded is not None and mapped is not None else None}
         if ready is not None:
             res[key]["device_mirror_ready_at_s"] = ready
+            res[key]["device_mirror_s"] = round(ready - loaded, 2)
             res[key]["mapping_phase_after_init_s"] = round(mapped - ready, 2)
             res[key]["gbases_per_s_after_init"] = round(bases / (mapped - ready) / 1e9, 4)
-    d_ref, n_ref = digest_without_pg(os.path.join(a.dir, "ref.sam"))
-    d_our, n_our = digest_without_pg(os.path.join(a.dir, "ours.sam"))
-    res["sam_lines"] = [n_ref, n_our]
-    res["sam_identical_without_pg"] = d_ref == d_our
-    res["sam_bytes"] = os.path.getsize(os.path.join(a.dir, "ref.sam"))
+            if len(mapped_all) >= 3:  # the time split the round-5 verdict asked for: mirror | first mini-batch | the rest (the reader and the writer run beside the mapping)
+                res[key]["first_mini_batch_done_after_init_s"] = round(mapped_all[0] - ready, 2)
+                res[key]["steady_s_per_mini_batch"] = round((mapped_all[-1] - mapped_all[0]) / (len(mapped_all) - 1), 3)
+                res[key]["steady_gbases_per_s"] = round(bases * (len(mapped_all) - 1) / len(mapped_all) / (mapped_all[-1] - mapped_all[0]) / 1e9, 4)
+    res["sam_lines"] = [dg_r[1], dg_o[1]]
+    res["sam_identical_without_pg"] = dg_r[0] == dg_o[0]
+    res["sam_md5_without_pg"] = [dg_r[0], dg_o[0]]
+    res["sam_bytes"] = dg_r[2]
     res["speedup_mapping_phase"] = round(res["reference"]["mapping_phase_s"] / res["gpu_dropin"]["mapping_phase_s"], 2) if res["reference"]["mapping_phase_s"] and res["gpu_dropin"]["mapping_phase_s"] else None
+    res["commit"] = os.environ.get("MM2AMD_COMMIT")
     print(json.dumps(res), flush=True)
     if not a.skip_index_check:
         import minimap2_amd as mm

@@ -23,6 +23,14 @@ for f in ['r06_bench_band_$V.json','r06_bench_noband_$V.json']:
 P
        ;;
 bench) timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06_bench_full_$V.json 2> $O/r06_bench_full_$V.log; tail -c 600 $O/r06_bench_full_$V.json ;;
+e2e)   # SURVEY 8(d)'s primary figure at scale: the reference's reader and writer around the GPU path, 10 Gbases, SAM digest vs the minimap2 binary, index digest vs mm_idx_gen
+       timeout 2400 python tools/e2e_wall.py --reads ${E2E_READS:-1000000} --out $O/r06_e2e_wall_$V.json > $O/r06_e2e_wall_$V.log 2>&1; tail -c 1500 $O/r06_e2e_wall_$V.log ;;
+arena) # the first batches with and without the arenas behind the work buffers
+       for m in arena noarena; do
+         if [ $m = noarena ]; then export MM2AMD_NO_ARENA=1; else unset MM2AMD_NO_ARENA; fi
+         timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --timed-only > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
+         grep -h "warmup\|steps in" $O/r06_bench_${m}_$V.log | cut -c1-330
+       done; unset MM2AMD_NO_ARENA ;;
 others) # the other BASELINE configurations: map-hifi, splice, sr
        timeout 500 python bench.py --preset map-hifi --reads 200000 --steps 3 --warmup 2 --cpu-sample 20000 > $O/r06_bench_hifi_$V.json 2> $O/r06_bench_hifi_$V.log
        timeout 500 python bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r06_bench_splice_$V.json 2> $O/r06_bench_splice_$V.log
