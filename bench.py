@@ -159,6 +159,89 @@ def gen_reads(torch, dev, seed, codes, per, n_contig, n_reads, mean_len, sd_len,
     return mutate_reads(torch, dev, g, src, bounds, err)
 
 
+def plant_repeats(torch, dev, seed, codes, per, n_contig, frac):
+    """--workload repeats: copies of sequence families written over the uniform reference until about `frac` of it is repeat --
+    short interspersed elements (300 b units, hundreds to thousands of copies, 8-15 % diverged), long ones (6 kb, tens to hundreds of copies, 2-6 %),
+    segmental duplications (20-60 kb, 2-4 copies, 0.5-2 %) and tandem arrays (units of 20-200 b repeated head to tail over 1-5 kb).  Reads from such a
+    reference get several chains, secondaries with equal scores, minimizers above mid_occ, anchors with equal keys (the tie replays) and the long-join
+    re-chaining -- what the headline's i.i.d. reference never asks of the device path.  Returns the number of bases written."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    total = per * n_contig
+    budget = int(total * frac)
+    written = 0
+    classes = [(300, 300, 200, 3000, 0.08, 0.15, 0.45), (6000, 6000, 20, 300, 0.02, 0.06, 0.30), (20000, 60000, 2, 4, 0.005, 0.02, 0.20)]  # unit min / max, copies min / max, divergence min / max, share of the budget
+    for lo, hi, c_lo, c_hi, d_lo, d_hi, share in classes:
+        left = int(budget * share)
+        while left > 0:
+            L = int(torch.randint(lo, hi + 1, (1,), device=dev, generator=g).item())
+            C = int(torch.randint(c_lo, c_hi + 1, (1,), device=dev, generator=g).item())
+            C = max(2, min(C, left // L + 1))
+            unit = torch.randint(0, 4, (L,), dtype=torch.uint8, device=dev, generator=g)
+            div = d_lo + (d_hi - d_lo) * float(torch.rand(1, device=dev, generator=g).item())
+            cid = torch.randint(0, n_contig, (C,), device=dev, generator=g)
+            st = (torch.rand(C, device=dev, generator=g, dtype=torch.float64) * float(per - L)).long()
+            rev = torch.rand(C, device=dev, generator=g) < 0.5
+            cop = unit[None, :].repeat(C, 1)
+            sub = torch.rand(C, L, device=dev, generator=g) < div
+            cop = torch.where(sub, (cop + torch.randint(1, 4, (C, L), device=dev, generator=g, dtype=torch.uint8)) & 3, cop)
+            cop = torch.where(rev[:, None], 3 - cop.flip(1), cop)
+            idx = (cid * per + st)[:, None] + torch.arange(L, device=dev)[None, :]
+            codes[idx.reshape(-1)] = cop.reshape(-1)
+            left -= L * C
+            written += L * C
+    left = int(budget * 0.05)  # tandem arrays
+    while left > 0:
+        u = int(torch.randint(20, 201, (1,), device=dev, generator=g).item())
+        n = int(torch.randint(1000, 5001, (1,), device=dev, generator=g).item())
+        unit = torch.randint(0, 4, (u,), dtype=torch.uint8, device=dev, generator=g)
+        arr = unit.repeat(n // u + 1)[:n]
+        sub = torch.rand(n, device=dev, generator=g) < 0.03
+        arr = torch.where(sub, (arr + torch.randint(1, 4, (n,), device=dev, generator=g, dtype=torch.uint8)) & 3, arr)
+        c = int(torch.randint(0, n_contig, (1,), device=dev, generator=g).item())
+        p0 = int(torch.randint(0, per - n, (1,), device=dev, generator=g).item())
+        codes[c * per + p0:c * per + p0 + n] = arr
+        left -= n
+        written += n
+    return written
+
+
+def gen_reads_sv(torch, dev, seed, codes, per, n_contig, n_reads, mean_len, sd_len, err, sv_frac):
+    """gen_reads with a structural difference in a share sv_frac of the reads: a deletion (the read skips w reference bases), an insertion (w random bases) or an
+    inversion (w bases reverse-complemented in place), w in 300..1500, somewhere in the read's middle -- the gap fill over it trips the Z-drop test, the region
+    needs a second DP round, a split, maybe the inversion rescue (align.c:846-870, :916-971)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lens = torch.clamp((torch.randn(n_reads, device=dev, generator=g) * sd_len + mean_len).long(), 4000, per // 2)
+    cid = torch.randint(0, n_contig, (n_reads,), device=dev, generator=g)
+    kind = torch.where(torch.rand(n_reads, device=dev, generator=g) < sv_frac, torch.randint(1, 4, (n_reads,), device=dev, generator=g), torch.zeros(n_reads, dtype=torch.long, device=dev))  # 0 none, 1 deletion, 2 insertion, 3 inversion
+    w = torch.randint(300, 1501, (n_reads,), device=dev, generator=g) * (kind > 0)
+    p = 1200 + (torch.rand(n_reads, device=dev, generator=g) * (lens - 2400 - w).clamp(min=1).float()).long()
+    span = lens + torch.where(kind == 1, w, torch.zeros_like(w)) - torch.where(kind == 2, w, torch.zeros_like(w))  # reference bases under the read
+    st = (torch.rand(n_reads, device=dev, generator=g, dtype=torch.float64) * (per - span - 1).clamp(min=1).double()).long()
+    rev = torch.rand(n_reads, device=dev, generator=g) < 0.5
+    bounds = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(lens, 0)])
+    n = int(bounds[-1].item())
+    rid = torch.repeat_interleave(torch.arange(n_reads, device=dev), lens)
+    j = torch.arange(n, device=dev) - bounds[:-1][rid]      # position in the read as sequenced from the + strand copy
+    k_, w_, p_ = kind[rid], w[rid], p[rid]
+    inside = (j >= p_) & (j < p_ + w_)
+    off = torch.where((k_ == 1) & (j >= p_), j + w_, j)                                   # deletion: skip w reference bases at p
+    off = torch.where((k_ == 2) & (j >= p_ + w_), j - w_, off)                            # insertion: the bases after it come from w earlier
+    off = torch.where((k_ == 3) & inside, p_ + (p_ + w_ - 1 - j), off)                    # inversion: read backwards inside the segment
+    src = codes[(cid * per + st)[rid] + off]
+    src = torch.where((k_ == 3) & inside, 3 - src, src)
+    src = torch.where((k_ == 2) & inside, torch.randint(0, 4, (n,), device=dev, generator=g, dtype=torch.uint8), src)
+    del off, inside, k_, w_, p_
+    # the read as a whole from either strand
+    revb = rev[rid]
+    dst = bounds[:-1][rid] + torch.where(revb, lens[rid] - 1 - j, j)
+    out = torch.empty_like(src)
+    out[dst] = torch.where(revb, 3 - src, src)
+    del src, dst, j, rid
+    return mutate_reads(torch, dev, g, out, bounds, err), int((kind > 0).sum().item())
+
+
 def gen_pairs(torch, dev, seed, codes, per, n_contig, n_pairs, read_len, err):
     """Illumina-like read pairs (FR): fragments of ~N(450, 60) bases placed uniformly, a read of read_len bases from each end (the
     second one reverse-complemented), the fragment taken from either strand, substitutions only at rate err.  Returns
@@ -203,6 +286,8 @@ def main():
     ap.add_argument("--as-rank-of", type=int, default=0, help="N > 1 (one GPU): after the N=1 measurement, map what ONE rank of an N-GPU strong-scaling job maps -- a 1/N base-balanced "
                     "share of every batch, with host_cpus()/N threads, hit packing included -- and report config.as_rank_of: the share's rate, N x that rate, its ratio to the N=1 rate "
                     "(predicted strong scaling if the ranks do not contend) and the host core-seconds per Gbase, which is what bounds the N-GPU line under a shared CPU quota")
+    ap.add_argument("--workload", default="plain", choices=["plain", "repeats"], help="plain: BASELINE.json's i.i.d. reference (the headline); repeats: a tenth of the reference is planted repeat families "
+                    "(interspersed, segmental duplications, tandem arrays) and 5 %% of the reads carry a deletion / insertion / inversion -- a side figure: how much of the batch leaves the device path")
     ap.add_argument("--timed-only", action="store_true", help="profiling runs: nothing after the timed steps (no resident / one-lane / formatting / CPU passes), so that the end of a kernel trace IS the timed pipeline")
     a = ap.parse_args()
 
@@ -249,6 +334,10 @@ def main():
     codes, per = gen_reference(torch, dev, 11, total, n_contig)
     total = per * n_contig
     genes = plant_genes(torch, dev, 12, codes, per, n_contig, max(100, min(20000, total // 150000))) if a.preset == "splice" else None
+    n_repeat_bases = n_sv_reads = 0
+    if a.workload == "repeats":
+        n_repeat_bases = plant_repeats(torch, dev, 13, codes, per, n_contig, 0.10)
+        log("rank %d: %.1f Mb of planted repeats" % (rank, n_repeat_bases / 1e6))
     refs = reference_ascii(torch, dev, codes, per, n_contig)
     names = ["chr%d" % (i + 1) for i in range(n_contig)]
     log("rank %d: reference %d Mb in %d contigs generated in %.1f s" % (rank, total // 1000000, n_contig, time.time() - t0))
@@ -265,7 +354,12 @@ def main():
     else:  # in chunks of at most ~1 Gbase: the index arithmetic of one call is 32-bit in places
         reads, chunk = [], max(1, min(a.reads, int(1.0e9 // mean_len)))
         for c0 in range(0, a.reads, chunk):
-            reads += gen_reads(torch, dev, rseed + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), mean_len, mean_len // 10, err)
+            if a.workload == "repeats":
+                rr, nsv = gen_reads_sv(torch, dev, rseed + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), mean_len, mean_len // 10, err, 0.05)
+                reads += rr
+                n_sv_reads += nsv
+            else:
+                reads += gen_reads(torch, dev, rseed + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), mean_len, mean_len // 10, err)
             torch.cuda.empty_cache()
     del codes
     torch.cuda.empty_cache()
@@ -746,7 +840,8 @@ def main():
     out = {"metric": "aligned Gbases/sec (%s, %s, -a)" % (a.preset, rl), "value": round(value, 5), "unit": "Gbases/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(total_t / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None,
            "dtype": "int8 (ksw2 difference DP) / int32+f32 (chaining)", "data": "synthetic",
-           "config": {"workload": "%s: %d synthetic %s %s (%g%% error) vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, ("read pairs, " + rl) if pairs else ("~" + rl), "per GPU" if (world > 1 and not strong) else "per step", err * 100, total // 1000000),
+           "config": {"workload": "%s: %d synthetic %s %s (%g%% error) vs %d Mb synthetic ref (24 contigs), -a" % (a.preset, a.reads, ("read pairs, " + rl) if pairs else ("~" + rl), "per GPU" if (world > 1 and not strong) else "per step", err * 100, total // 1000000) +
+                                  (" -- SIDE FIGURE, not BASELINE's workload: %.0f Mb of the reference are planted repeat families (interspersed elements, segmental duplications, tandem arrays), %d of the reads carry a 300-1500 b deletion / insertion / inversion" % (n_repeat_bases / 1e6, n_sv_reads) if a.workload == "repeats" else ""),
                       "reads_per_step": a.reads * (world if (world > 1 and not strong) else 1), "reads_this_rank": len(reads), "ref_mb": total // 1000000, "batch_gbases": round(batch_bases / 1e9, 4), "host_threads_per_rank": n_threads, "host_cpu_s_per_step": round(host_cpu_s, 2),
                       "parallelism": "replicated index, %s, RCCL hit gather to rank 0, every rank formats its shard" % ("one batch sharded %d-way by bases" % world if strong else "%d independent batches" % world) if world > 1 else "1 GPU",
                       "clock": "pipeline of hand-over | mapping | SAM formatting over the timed steps, all three inside the clock (map.c:541-643)",
@@ -762,7 +857,10 @@ def main():
                       "index_build_s": round(t_index, 2), "reads_mapped": n_mapped, "hits": n_hits, "as_rank_of": as_rank,
                       "cpu_quota": ncpu,
                       # the banded gap fill (ksw_band.hip), counted over the whole process: windows tried in 128 / 256 diagonals, sent on to the wider band, recomputed as rectangles
-                      "banded_gap_fill": {k: int(v) for k, v in al.last_stats().items() if k.startswith("n_band")}},
+                      "banded_gap_fill": {k: int(v) for k, v in al.last_stats().items() if k.startswith("n_band")},
+                      # how much of the last batch left the device path (hand-backs go through the host's plan / consume rounds), long-join re-chains on the device / by the host's tie-exact tree
+                      "device_path_last_batch": {k: int(v) for k, v in al.last_stats().items() if k.startswith("n_region_reads") or k.startswith("n_long_join") or k in ("n_jobs", "n_rounds")},
+                      "arenas": {k: int(v) for k, v in al.last_stats().items() if k.startswith("arena_") or k in ("dev_allocs", "pin_allocs")}},
            "roofline": roof, "cpu_baseline": cpu, "output_stage": fmt}
     print(json.dumps(out), flush=True)
     al.close()

@@ -112,25 +112,32 @@ public:
 	{
 		bytes = (bytes + 255) & ~(size_t)255;
 		if (bytes == 0) bytes = 256;
-		std::lock_guard<std::mutex> lk(mu_);
 		int dev = 0;
 		(void)hipGetDevice(&dev);
-		if (!enabled() || bytes > chunk_bytes_ / 2) { char *p = raw_alloc(bytes); solo_[p] = bytes; return p; }
-		for (int pass = 0; pass < 2; ++pass) {
-			for (Chunk &c : chunks_) {
-				if (c.dev != dev) continue;
-				for (auto it = c.free_.begin(); it != c.free_.end(); ++it) {
-					if (it->second < bytes) continue;
-					const size_t off = it->first, len = it->second;
-					c.free_.erase(it);
-					if (len > bytes) c.free_[off + bytes] = len - bytes;
-					c.used[off] = bytes;
-					return c.base + off;
+		if (!enabled() || bytes > chunk_bytes_ / 2) { // an allocation of its own -- made OUTSIDE the lock: a multi-GB hipMalloc must not hold up the other lanes' small requests
+			char *p = raw_alloc(bytes);
+			std::lock_guard<std::mutex> lk(mu_);
+			solo_[p] = bytes;
+			return p;
+		}
+		for (int pass = 0;; ++pass) {
+			{
+				std::lock_guard<std::mutex> lk(mu_);
+				for (Chunk &c : chunks_) {
+					if (c.dev != dev) continue;
+					for (auto it = c.free_.begin(); it != c.free_.end(); ++it) {
+						if (it->second < bytes) continue;
+						const size_t off = it->first, len = it->second;
+						c.free_.erase(it);
+						if (len > bytes) c.free_[off + bytes] = len - bytes;
+						c.used[off] = bytes;
+						return c.base + off;
+					}
 				}
 			}
-			if (pass == 0) add_chunk(dev);
+			if (pass >= 2) throw HipError("[mm2amd] MemArena: fresh chunks did not hold the request");
+			add_chunk(dev); // (outside the lock as well; two lanes that run dry together each add one)
 		}
-		throw HipError("[mm2amd] MemArena: a fresh chunk did not hold the request");
 	}
 	void release(void *p)
 	{
@@ -158,12 +165,14 @@ public:
 	void reserve(size_t bytes)
 	{
 		if (!enabled()) return;
-		std::lock_guard<std::mutex> lk(mu_);
 		int dev = 0;
 		(void)hipGetDevice(&dev);
-		size_t have = 0;
-		for (const Chunk &c : chunks_) if (c.dev == dev) have += c.size;
-		while (have < bytes) { add_chunk(dev); have += chunk_bytes_; }
+		for (;;) {
+			size_t have = 0;
+			{ std::lock_guard<std::mutex> lk(mu_); for (const Chunk &c : chunks_) if (c.dev == dev) have += c.size; }
+			if (have >= bytes) return;
+			add_chunk(dev);
+		}
 	}
 private:
 	struct Chunk { char *base; size_t size; int dev; std::map<size_t, size_t> free_, used; };
@@ -177,11 +186,12 @@ private:
 		return (char *)p;
 	}
 	void raw_free(char *p) { if (pinned_) (void)hipHostFree(p); else (void)hipFree(p); }
-	void add_chunk(int dev)
+	void add_chunk(int dev) // call WITHOUT the lock
 	{
 		Chunk c;
 		c.base = raw_alloc(chunk_bytes_), c.size = chunk_bytes_, c.dev = dev;
 		c.free_[0] = chunk_bytes_;
+		std::lock_guard<std::mutex> lk(mu_);
 		chunks_.push_back(std::move(c));
 	}
 	const bool pinned_;

@@ -122,7 +122,10 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 		int rc = 0, dc = 0;
 		while (rc < kHbmRing && o.ring_need > ksw_ring_size(rc)) ++rc;
 		while (o.db > ksw_dir_limit(dc)) ++dc;
-		if (!splice) dc = dc == 0 ? 0 : dc <= 3 ? 3 : dc <= 6 ? 6 : kDirClasses - 1; // banded matrices vary little: 256 KB / 2 MB / 16 MB / any, fewer and fuller launches
+		// banded matrices vary little, and a launch of this kernel lasts as long as its longest job whatever it holds (a few hundred long extensions, microseconds per
+		// row): ONE launch per ring class for everything up to 16 MB (round 5: 256 KB / 2 MB / 16 MB apart -- four launches per sub-batch and ring class, each ~3 ms of
+		// latency; the slots are sized by the class's largest matrix, 1-2 MB on long-read batches), the rare giants on their own
+		if (!splice) dc = dc <= 6 ? 6 : kDirClasses - 1;
 		o.tier = kFirstExact + rc * kDirClasses + dc;
 	}
 	// launch order inside a class: cost (rows * row width) roughly descending -- longest-job-first for the persistent waves

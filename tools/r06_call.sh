@@ -31,6 +31,16 @@ arena) # the first batches with and without the arenas behind the work buffers
          timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --timed-only > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
          grep -h "warmup\|steps in" $O/r06_bench_${m}_$V.log | cut -c1-330
        done; unset MM2AMD_NO_ARENA ;;
+rccl)  timeout 300 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_aligner.py -x -q -m gpu > $O/r06_pytest_rccl_$V.log 2>&1; tail -3 $O/r06_pytest_rccl_$V.log ;;
+repeats) # the side figure on a repeat- and SV-bearing reference: how much of a batch leaves the device path
+       timeout 900 python bench.py --workload repeats --steps 6 --warmup 3 --cpu-sample 20000 > $O/r06_bench_repeats_$V.json 2> $O/r06_bench_repeats_$V.log
+       python - <<P
+import json
+d=json.loads(open('$O/r06_bench_repeats_$V.json').read().strip().split('\n')[-1]); c=d['config']; r=d['roofline']
+print('repeats', d['value'], d['ms_per_step'], c['device_path_last_batch'], c['banded_gap_fill'], (d.get('cpu_baseline') or {}).get('hits_identical_to_gpu'), (d.get('cpu_baseline') or {}).get('value'))
+print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:12]})
+P
+       ;;
 others) # the other BASELINE configurations: map-hifi, splice, sr
        timeout 500 python bench.py --preset map-hifi --reads 200000 --steps 3 --warmup 2 --cpu-sample 20000 > $O/r06_bench_hifi_$V.json 2> $O/r06_bench_hifi_$V.log
        timeout 500 python bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r06_bench_splice_$V.json 2> $O/r06_bench_splice_$V.log
