@@ -111,13 +111,18 @@ public:
 			lanes_.back()->ksw.n_cu = n_cu_;
 			lanes_.back()->ksw.disable_fast = getenv("MM2AMD_KSW_EXACT_ONLY") != nullptr;
 		}
-		// the lanes' work buffers come out of arenas (hip_util.hpp): the first chunks are taken now, before any batch -- what a 100 000-read batch of long reads
-		// settles at -- but never more than a quarter of what the device has free
+		// the lanes' work buffers come out of arenas (hip_util.hpp): the first chunks are taken now, before any batch, by a thread of its own -- the index tables are
+		// still on their way to the device, and what a 100 000-read batch of long reads settles at (116 GB in eight lanes' buffers, 30 ms per GB of hipMalloc, 185 ms
+		// per GB of pinned memory) is seconds of allocation that the first batch would otherwise pay for; never more than half of what the device has free
 		{
-			size_t free_b = 0, total_b = 0, want = arena_env_gb("MM2AMD_ARENA_DEV_GB", 24) << 30;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, free_b / 4);
-			dev_arena().reserve(want);
-			pin_arena().reserve(arena_env_gb("MM2AMD_ARENA_PIN_GB", 4) << 30);
+			size_t free_b = 0, total_b = 0, want = arena_env_gb("MM2AMD_ARENA_DEV_GB", 112) << 30;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, free_b / 2);
+			const size_t want_pin = arena_env_gb("MM2AMD_ARENA_PIN_GB", 4) << 30;
+			const int dev = dev_;
+			if (MemArena::enabled() && (want || want_pin)) std::thread([dev, want, want_pin] {
+				if (hipSetDevice(dev) != hipSuccess) return;
+				try { pin_arena().reserve(want_pin); dev_arena().reserve(want); } catch (...) {} // (a reservation that fails leaves the buffers to allocate as they grow)
+			}).detach();
 		}
 	}
 

@@ -22,8 +22,10 @@ constexpr int kFirstExact = 6, kRingClasses = 7, kDirClasses = 11, kFirstSplice 
 // 64 QUERY positions (queries up to 128 / 256), or one job per wave using both register halves of 4 sets (512 positions per
 // sweep over the target, longer queries in several sweeps); classed by direction-matrix size like the exact kernel.
 constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kDirClasses;
-// kFirstExt..: the register-resident extension kernel (ksw_ext.hip): + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512
-constexpr int kFirstBand = kFirstExt + 4, kExtMaxQ = 512, kExtMaxT = 512;
+// kFirstExt..: the register-resident extension kernels.  Round 6 (ksw_extq.hip, the query across the lanes): + 0/1: queries up to 128 (left- / right-aligned gaps),
+// + 2/3: up to 256, + 4/5: up to 512, targets up to kExtqMaxT.  MM2AMD_EXT_BY_TARGET=1 (A/B): round 3's ksw_ext.hip, the target across the lanes: + 0/1: targets up to 256,
+// + 2/3: up to 512, queries up to 512.
+constexpr int kExtClasses = 6, kFirstBand = kFirstExt + kExtClasses, kExtMaxQ = 512, kExtMaxT = 512, kExtqMaxT = 2048;
 // kFirstBand..: the banded gap-fill kernel (ksw_band.hip, round 6): + 0: a band of 128 diagonals (one register set), + 1: 256 diagonals (two).  A gap fill
 // of the streaming kernel's classes goes here when the score its length lets one expect would prove the band sufficient (ksw_band.hpp); what the
 // kernel cannot prove is computed again in the wider band or as the full rectangle, so the choice is a matter of speed only.
@@ -34,6 +36,7 @@ constexpr int kOrderBuckets = 256; // cost buckets per class
 
 struct KswClassCtx { // uniform over a batch
 	int scoring_ok, splice_ok, splice, stream_on, ext_on, ext_max_t;
+	int ext_by_target = 0; // 1: the extension classes of ksw_ext.hip (A/B)
 	// the banded kernel: on / off; the scores the acceptance test works with; the share of the best possible score (sc_max per base of the shorter side, in
 	// 1/256) a window is EXPECTED to reach -- the classes are chosen with it, the kernel's test uses the score actually found
 	int band_on = 0, sc_max = 0, gq = 0, ge = 0, gq2 = 0, ge2 = 0, band_rho256 = 128;
@@ -104,12 +107,14 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 	o.ring_need = 64;
 	o.fast = ksw_fast_eligible(j, C.scoring_ok != 0), o.sfast = ksw_splice_fast_eligible(j, C.splice_ok != 0), o.xfast = C.ext_on && ksw_ext_eligible(j, C.scoring_ok != 0, C.ext_max_t);
 	o.live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
-	o.db = !o.live || (j.flag & KSW_SCORE_ONLY) ? 0 : o.fast || o.xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
+	o.db = !o.live || (j.flag & KSW_SCORE_ONLY) ? 0 : o.xfast && !C.ext_by_target ? (size_t)(j.qlen + j.tlen - 1) * (size_t)(j.qlen > 256 ? 512 : j.qlen > 128 ? 256 : 128) :
+	       o.fast || o.xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 	       o.sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 	const int band_sets = o.fast ? ksw_band_choice(j, C) : 0;
 	if (band_sets) o.tier = kFirstBand + band_sets - 1, o.db = (size_t)(j.qlen + j.tlen - 1) * (size_t)(64 * band_sets);
 	else if (o.fast) o.tier = ksw_fast_tier(j);
-	else if (o.xfast) o.tier = kFirstExt + (j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
+	else if (o.xfast && C.ext_by_target) o.tier = kFirstExt + (j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
+	else if (o.xfast) o.tier = kFirstExt + (j.qlen > 256 ? 4 : j.qlen > 128 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
 	else if (o.sfast) {
 		int nc = 0, dc = 0;
 		while (j.qlen > ksw_splice_max_q(nc)) ++nc;

@@ -23,32 +23,7 @@ namespace mm2amd {
 
 constexpr int EX_QCAP = 512; // queries up to EX_QCAP; targets up to 64 * NC columns (NC register sets: 4 or 8)
 
-// One register set and anti-diagonal with RIGHT-aligned gaps (ksw2_extd2_sse.c:282-320): the LAST of (s, a, b, a2, b2) that reaches the
-// maximum names the state (ties go to the gap states), and a gap continues when its value is >= 0, not > 0.  Same operands and results
-// as gf_cell; written with the one-instruction helpers (this variant serves 1.5 % of the cells).
-__device__ __forceinline__ void gf_cell_right(uint32_t x1, uint32_t o1, uint32_t xp, uint32_t vp, uint32_t x2p, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y,
-                                              uint32_t &x2, uint32_t &y2, uint32_t &d, uint32_t P_MCH, uint32_t P_MISD, uint32_t P_SCN, uint32_t P_Q, uint32_t P_Q2,
-                                              uint32_t P_QE, uint32_t P_QE2)
-{
-	const uint32_t ONE = pk2(1);
-	uint32_t a = pk_add(xp, vp), b = pk_add(y, u), a2 = pk_add(x2p, vp), b2 = pk_add(y2, u);
-	uint32_t z = pk_mad(pk_minu(x1, ONE), P_MISD, P_MCH);           // match / mismatch
-	z = pk_mad(pk_shr2(o1), pk_sub(P_SCN, z), z);                   // sc_N when either base is ambiguous (code 4 = bit 2)
-	const uint32_t z4 = pk_max(pk_max(pk_max(z, a), pk_max(b, a2)), b2);
-	// state = 4 - d4 * (1 + d3 * (1 + d2 * (1 + d1))), d_i = 1 when candidate i is below the maximum: the last candidate equal to it
-	const uint32_t d1 = pk_minu(pk_sub(z4, a), ONE), d2 = pk_minu(pk_sub(z4, b), ONE), d3 = pk_minu(pk_sub(z4, a2), ONE), d4 = pk_minu(pk_sub(z4, b2), ONE);
-	uint32_t e = pk_add(d1, ONE);
-	e = pk_mad(d2, e, ONE);
-	e = pk_mad(d3, e, ONE);
-	e = pk_sub(pk2(4), pk_mul(d4, e));
-	const uint32_t zc = pk_min(z4, P_MCH);
-	const uint32_t un = pk_sub(zc, vp), vn = pk_sub(zc, u), t1 = pk_sub(zc, P_Q), t2 = pk_sub(zc, P_Q2);
-	a = pk_sub(a, t1), b = pk_sub(b, t1), a2 = pk_sub(a2, t2), b2 = pk_sub(b2, t2);
-	auto ge0 = [&](uint32_t w) { return pk_minu(pk_max(pk_add(w, ONE), 0u), ONE); }; // 1 where the signed half is >= 0
-	e = pk_mad(ge0(a), pk2(8), e), e = pk_mad(ge0(b), pk2(16), e), e = pk_mad(ge0(a2), pk2(32), e), e = pk_mad(ge0(b2), pk2(64), e);
-	x = pk_sub(pk_max(a, 0u), P_QE), y = pk_sub(pk_max(b, 0u), P_QE), x2 = pk_sub(pk_max(a2, 0u), P_QE2), y2 = pk_sub(pk_max(b2, 0u), P_QE2);
-	u = un, v = vn, d = e;
-}
+// (gf_cell_right, the cell with right-aligned gaps: ksw_gapfill_dev.hpp -- shared with ksw_extq.hip)
 
 struct ExtState { int max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, done; };
 

@@ -16,6 +16,8 @@ namespace mm2amd {
 namespace {
 // (the launch classes themselves: ksw_classify.hpp)
 static const char *const kExtNames[4] = {"ksw_ext_kernel[left-aligned]", "ksw_ext_kernel[right-aligned]", "ksw_ext_kernel[left-aligned,t512]", "ksw_ext_kernel[right-aligned,t512]"};
+static const char *const kExtqNames[kExtClasses] = {"ksw_extq_kernel[left-aligned,q128]", "ksw_extq_kernel[right-aligned,q128]", "ksw_extq_kernel[left-aligned,q256]", "ksw_extq_kernel[right-aligned,q256]",
+                                                    "ksw_extq_kernel[left-aligned,q512]", "ksw_extq_kernel[right-aligned,q512]"};
 // + 0/1: targets up to 256 (left- / right-aligned gaps), + 2/3: up to 512 (eight register sets; these launches hold a few hundred long jobs and are as
 // latency-bound as the lane-exact kernel's: they run beside it on the side stream).  Twelve sets (targets up to 768) were measured and dropped: 5 Gcells/s,
 // three times the time the lane-exact kernel needs for the same jobs.
@@ -41,6 +43,7 @@ size_t ksw_stream_slot_bytes(int n_sets);
 int ksw_stream_waves(int n_sets);
 void ksw_splice_launch(const KswLaunch &L, int n_slots, int n_sets, bool self, void *stream); // ksw_splice.hip
 void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);               // ksw_ext.hip
+void ksw_extq_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);              // ksw_extq.hip
 void ksw_band_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream);    // ksw_band.hip
 int ksw_band_waves(int n_sets);
 size_t ksw_band_slot_bytes(int n_sets, int max_rows);
@@ -63,7 +66,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	constexpr size_t CH = 32768;
 	const size_t NBINS = (size_t)kNTiers * NB;
 	static const bool ext_on = !getenv("MM2AMD_NO_EXT_KERNEL"); // diagnostic: every extension through the lane-exact kernel
-	static const int ext_max_t = getenv("MM2AMD_EXT_MAX_T") ? atoi(getenv("MM2AMD_EXT_MAX_T")) : kExtMaxT; // A/B: longer targets to the lane-exact kernel's workgroups
+	static const bool ext_by_target = getenv("MM2AMD_EXT_BY_TARGET") != nullptr; // A/B: round 3's extension kernel (the target across the lanes, targets <= 512) instead of ksw_extq.hip
+	static const int ext_max_t = getenv("MM2AMD_EXT_MAX_T") ? atoi(getenv("MM2AMD_EXT_MAX_T")) : ext_by_target ? kExtMaxT : kExtqMaxT; // A/B: longer targets to the lane-exact kernel's workgroups
 	int min_sc = sc.mat[1];
 	for (int t = 1; t < sc.m * sc.m; ++t) min_sc = std::min<int>(min_sc, sc.mat[t]);
 	const bool single_affine = sc.single == 1, splice = sc.single == 2; // the gap-fill kernel is dual-affine only
@@ -74,10 +78,11 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	                       sc.q + sc.e + sc.q2 + sc.noncan + max_abs <= 100;
 	KswClassCtx cctx;
 	cctx.scoring_ok = scoring_ok, cctx.splice_ok = splice_ok, cctx.splice = splice, cctx.stream_on = stream_on, cctx.ext_on = ext_on, cctx.ext_max_t = ext_max_t;
+	cctx.ext_by_target = ext_by_target;
 	// the banded gap fill (ksw_band.hip): which windows try a band first is decided from the score their length lets one expect -- a share of the best possible
 	// score that follows what the kernel's accepted windows actually reached (band_rho; MM2AMD_BAND_RHO pins it) -- never the results
-	static const bool band_env_off = getenv("MM2AMD_NO_BAND") != nullptr;
-	static const double rho_env = getenv("MM2AMD_BAND_RHO") ? atof(getenv("MM2AMD_BAND_RHO")) : -1.0;
+	const bool band_env_off = getenv("MM2AMD_NO_BAND") != nullptr; // (read per batch: tests switch it)
+	const double rho_env = getenv("MM2AMD_BAND_RHO") ? atof(getenv("MM2AMD_BAND_RHO")) : -1.0;
 	cctx.band_on = scoring_ok && stream_on && !band_env_off;
 	cctx.sc_max = 0;
 	for (int t = 0; t < sc.m * sc.m; ++t) cctx.sc_max = std::max<int>(cctx.sc_max, sc.mat[t]);
@@ -205,7 +210,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4, team = 1; bool hbm = false; double alg_bytes = 0, cells = 0; };
 		Plan plan[kNTiers];
 		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
-		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || (tier >= kFirstExt + 2 && tier < kFirstBand) ? 1 : 0; };
+		// (the extension classes with a few hundred long jobs per launch -- queries beyond 256; with MM2AMD_EXT_BY_TARGET targets beyond 256 -- run beside the lane-exact kernel's)
+		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || (tier >= kFirstExt + (ext_by_target ? 2 : 4) && tier < kFirstBand) ? 1 : 0; };
 		const int max_slots_env = getenv("MM2AMD_KSW_MAX_SLOTS") ? atoi(getenv("MM2AMD_KSW_MAX_SLOTS")) : 0; // tests: few persistent waves, so that each takes many jobs
 		// Two groups run concurrently only when there are lane-exact launches and the mode allows it; then each gets half of this lane's
 		// scratch budget and buffers of its own.  Otherwise the groups run one after the other and SHARE one buffer sized for the larger.
@@ -242,7 +248,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			if (tier < kFirstExact || band_sets) P.tmp_cap = 3 * (P.tmp_cap + 2); // the operations, and two prefix arrays over them for the half-wave's Z-drop walk (gf_zdrop_scan)
 			if (band_sets) P.slot_bytes = ksw_band_slot_bytes(band_sets, cls[tier].max_rows);
 			if (tier < kFirstExact) P.slot_bytes = n_stream ? ksw_stream_slot_bytes(n_stream) : (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol;
-			if (xfast) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)cls[tier].max_ncol; // one matrix per wave for its two jobs, as in the gap-fill kernel
+			const int extq_sets = xfast && !ext_by_target ? 2 << ((tier - kFirstExt) >> 1) : 0; // ksw_extq.hip: 2 / 4 / 8 register sets of 64 query positions
+			if (xfast) P.slot_bytes = (size_t)(cls[tier].max_rows + 3) * (size_t)(extq_sets ? 64 * extq_sets : cls[tier].max_ncol); // one matrix per wave for its two jobs, as in the gap-fill kernel
 			P.slot_bytes = (P.slot_bytes + 255) / 256 * 256;
 			P.hbm = !fast && rc == kHbmRing;
 			P.ring = fast ? 64 : P.hbm ? cls[tier].max_ring : kRingSize[rc];
@@ -259,7 +266,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			if (!fast && !P.hbm && region * P.wpb > 160 * 1024) P.wpb = 1;
 			int blocks_per_cu;
 			if (band_sets) blocks_per_cu = ksw_band_waves(band_sets);
-			else if (xfast) blocks_per_cu = tier - kFirstExt >= 2 ? 2 : 4; // (eight register sets: 174 VGPRs)
+			else if (xfast) blocks_per_cu = (extq_sets ? extq_sets > 4 : tier - kFirstExt >= 2) ? 2 : 4; // (eight register sets: 174 VGPRs)
 			else if (sfast) blocks_per_cu = kSpliceBlocksPerCU[sclass];
 			else if (n_stream) { static const int sb = getenv("MM2AMD_STREAM_BLOCKS") ? atoi(getenv("MM2AMD_STREAM_BLOCKS")) : 0; blocks_per_cu = sb > 0 ? sb : ksw_stream_waves(n_stream); } // (experiments: fewer resident blocks leave LDS to the other lanes' kernels)
 			else if (fast) blocks_per_cu = fast_waves(tier);
@@ -353,6 +360,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			if (band_sets) ksw_band_launch(L, (int)P.n_slots, band_sets, stream_);
 			else if (n_stream) ksw_stream_launch(L, (int)P.n_slots, n_stream, stream_);
 			else if (tier < kFirstExact) ksw_gapfill_launch(L, (int)P.n_slots, kFastQCap[tier], stream_);
+			else if (tier >= kFirstExt && !ext_by_target) ksw_extq_launch(L, (int)P.n_slots, ((tier - kFirstExt) & 1) != 0, 2 << ((tier - kFirstExt) >> 1), stream_);
 			else if (tier >= kFirstExt) ksw_ext_launch(L, (int)P.n_slots, ((tier - kFirstExt) & 1) != 0, 4 * ((tier - kFirstExt) / 2 + 1), stream_);
 			else if (tier >= kFirstSplice) ksw_splice_launch(L, (int)P.n_slots, kSpliceSets[(tier - kFirstSplice) / kDirClasses], kSpliceSelf[(tier - kFirstSplice) / kDirClasses], stream_);
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, P.team, stream_);
@@ -361,7 +369,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			static const char *kBandNames[kBandClasses] = { "ksw_band_kernel<1>[w128]", "ksw_band_kernel<2>[w256]" };
 			static const char *kBandCells[kBandClasses] = { "band_cells_computed<1>", "band_cells_computed<2>" }; // rows x lanes of the band: what the VALU roofline counts (units of the launch itself: the rectangles' cells)
 			if (prof && band_sets) prof->add_units(kBandCells[band_sets - 1], cls[tier].sum_len * 64.0 * band_sets);
-			if (prof) prof->end(stream_, band_sets ? kBandNames[band_sets - 1] : n_stream ? kStreamNames[tier] : tier >= kFirstExt ? kExtNames[tier - kFirstExt] : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+			if (prof) prof->end(stream_, band_sets ? kBandNames[band_sets - 1] : n_stream ? kStreamNames[tier] : tier >= kFirstExt ? (ext_by_target ? kExtNames[(tier - kFirstExt) & 3] : kExtqNames[tier - kFirstExt]) : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
 		}
 		// ---- the banded kernel's rejects (the lists are complete when the stream gets here) ----
 		for (int which = 0; which < 2; ++which) {

@@ -486,4 +486,40 @@ def test_banded_gap_fill_equals_the_unbanded_reference(preset, monkeypatch):
         assert got == want, mode
         assert n["widened"] + n["rectangle"] >= n["band128"] + n["band256"], (mode, n)
     monkeypatch.delenv("MM2AMD_BAND_REJECT")
-    monkeypatch.setenv("MM2AMD_NO_BAND", "1")  # (read once per process: a no-op if the library has run before; the A/B partner is MM2AMD_BAND_REJECT=2)
+    monkeypatch.setenv("MM2AMD_NO_BAND", "1")  # the rectangles only: the A/B partner
+    got, n = _band_delta(run)
+    assert got == want and n["band128"] + n["band256"] == 0, n
+
+
+@pytest.mark.parametrize("preset", ["ont", "hifi", "swap"])
+def test_extension_kernel_with_the_query_across_the_lanes(preset, monkeypatch):
+    """ksw_extq.hip (round 6): extension calls (KSW_EZ_EXTZ_ONLY, left extensions also RIGHT | REV_CIGAR) whose band cannot bind, classed by QUERY length (128 / 256 / 512
+    positions in 2 / 4 / 8 register sets) with targets up to 2048 streaming through the lanes -- every register-set boundary on the query, targets shorter than, about twice and
+    many times as long as the query (the shape of an end extension: align.c:716-718), Z-drops that fire early, late and never, end bonuses, N bases -- against the lane-exact
+    oracle; then the same jobs through round 3's kernel (the target across the lanes) and through the lane-exact kernel."""
+    import minimap2_amd as mm
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    mat = ts_mat(a, b, 1, 0)
+    rng = np.random.default_rng(905)
+    jobs = []
+    for ql in (1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 383, 384, 385, 447, 448, 449, 500, 511, 512):
+        for shape in range(4):
+            q, t = random_pair(rng, ql, float(rng.choice([0.0, 0.05, 0.12, 0.3])), float(rng.choice([0, 0, 0.03])))
+            q = q[:512]
+            if shape == 1:    # the end-extension shape: the target about twice the query
+                t = np.concatenate([t, rng.integers(0, 4, int(rng.integers(ql // 2, ql + 60)), dtype=np.uint8)])
+            elif shape == 2:  # a long target: the query is used up early, the Z-drop decides
+                t = np.concatenate([t, rng.integers(0, 4, int(rng.integers(500, 1500)), dtype=np.uint8)])
+            elif shape == 3:  # a short one: the target ends first
+                t = t[:max(1, len(t) // 3)]
+            t = t[:2048]
+            for flag in (0x40, 0xC2):
+                w = max(len(q), len(t))  # cannot bind
+                jobs.append((q, t, int(rng.choice([w, w + 7, 30001])), int(rng.choice([-1, 100, 400, 2000])), int(rng.choice([-1, 10, 40])), flag))
+    _run(jobs, preset)
+    fast = mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+    monkeypatch.setenv("MM2AMD_KSW_MAX_SLOTS", "4")  # few persistent waves: each takes many pairs
+    assert mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2) == fast
+    monkeypatch.delenv("MM2AMD_KSW_MAX_SLOTS")
+    monkeypatch.setenv("MM2AMD_KSW_EXACT_ONLY", "1")
+    assert mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2) == fast

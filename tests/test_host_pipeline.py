@@ -504,6 +504,16 @@ def test_region_rules_against_the_reference_statics():
     assert b"== the reference's statics" in p.stdout
 
 
+def test_local_score_of_the_inversion_test_against_the_reference():
+    """minimap2_amd/csrc/ksw_ll.cpp (the anti-diagonal form of round 6, the lane-by-lane form behind it) against the reference's ksw_ll_i16: score and both end
+    coordinates on 30 000 sequence pairs under random scorings (tests/cpucheck/ksw_ll_test.cpp)."""
+    exe = os.path.join(HERE, "_build", "ksw_ll_test")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/ksw_ll_test not built (needs the compiled reference)")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout.startswith(b"OK"), p.stderr.decode()[-600:]
+
+
 def test_device_sdust_header_against_the_reference():
     """minimap2_amd/csrc/sdust_core.hpp (what dust_filter_kernel runs per read) compiled for the host, vs the reference's sdust()."""
     exe = os.path.join(HERE, "_build", "sdust_test")

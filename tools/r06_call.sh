@@ -31,6 +31,17 @@ arena) # the first batches with and without the arenas behind the work buffers
          timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --timed-only > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
          grep -h "warmup\|steps in" $O/r06_bench_${m}_$V.log | cut -c1-330
        done; unset MM2AMD_NO_ARENA ;;
+abext) # the extension kernel with the query across the lanes against round 3's (the target across the lanes)
+       for m in extq bytarget; do
+         if [ $m = bytarget ]; then export MM2AMD_EXT_BY_TARGET=1; else unset MM2AMD_EXT_BY_TARGET; fi
+         timeout 600 python bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_${m}_$V.json').read().strip().split('\n')[-1]); r=d['roofline']
+print('$m', d['value'], d['ms_per_step'], r['kernel'], r.get('unoverlapped_step_ms'))
+print('   ', {k: v for k, v in (r.get('unoverlapped_ms') or {}).items() if k.startswith('ksw')})
+P
+       done; unset MM2AMD_EXT_BY_TARGET ;;
 rccl)  timeout 300 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_aligner.py -x -q -m gpu > $O/r06_pytest_rccl_$V.log 2>&1; tail -3 $O/r06_pytest_rccl_$V.log ;;
 repeats) # the side figure on a repeat- and SV-bearing reference: how much of a batch leaves the device path
        timeout 900 python bench.py --workload repeats --steps 6 --warmup 3 --cpu-sample 20000 > $O/r06_bench_repeats_$V.json 2> $O/r06_bench_repeats_$V.log
