@@ -95,15 +95,16 @@ __attribute__((target_clones("avx2", "default"))) // (16 scores per vector instr
 #if defined(__GNUC__) && !defined(__clang__)
 __attribute__((optimize("O3", "tree-vectorize")))
 #endif
-bool ll_sweep(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t mat[25], int goe_, int ge_, int16_t *row_max, int row_of, int16_t *row_vals, int16_t *keep = nullptr)
+bool ll_sweep(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t mat[25], int goe_, int ge_, int16_t *row_max, int row_of, int16_t *row_vals, int16_t *keep,
+              int16_t *work /* 8 * (tlen + 2), zeroed */, uint8_t *qrev /* qlen */)
 {
 	// three score diagonals (r - 2, r - 1, r) and two of each gap state; one slot of padding below index 0 and one above the last: a neighbour outside the matrix
 	// reads as zero there (every array starts zeroed, and the slot just past a diagonal's last cell is cleared when the diagonal is written)
+	// (no containers in here: the function is cloned per instruction set, and the clones must not carry template instantiations of their own)
 	const size_t W = (size_t)tlen + 2;
-	std::vector<int16_t> buf(W * 7, 0), sub((size_t)tlen + 1);
-	std::vector<uint8_t> qrev((size_t)qlen);
+	int16_t *const sub = work + 7 * W;
 	for (int j = 0; j < qlen; ++j) qrev[j] = query[qlen - 1 - j];
-	int16_t *H2 = buf.data() + 1, *H1 = H2 + W, *H0 = H1 + W, *E1 = H0 + W, *E0 = E1 + W, *F1 = E0 + W, *F0 = F1 + W;
+	int16_t *H2 = work + 1, *H1 = H2 + W, *H0 = H1 + W, *E1 = H0 + W, *E0 = E1 + W, *F1 = E0 + W, *F0 = F1 + W;
 	// a plain DNA matrix (one score for a match, one for a mismatch, one whenever either base is ambiguous) is scored by comparisons; anything else by look-up
 	bool simple = true;
 	for (int x = 0; x < 5 && simple; ++x)
@@ -116,8 +117,8 @@ bool ll_sweep(int qlen, const uint8_t *query, int tlen, const uint8_t *target, c
 	int16_t top = 0;
 	for (int r = 0; r <= last_r; ++r) {
 		const int lo = r - qlen + 1 > 0 ? r - qlen + 1 : 0, hi = r < tlen - 1 ? r : tlen - 1;
-		const uint8_t *__restrict tq = target, *__restrict qq = qrev.data() + (qlen - 1 - r); // query[r - i] = qrev[qlen - 1 - r + i]
-		int16_t *__restrict sb = sub.data();
+		const uint8_t *__restrict tq = target, *__restrict qq = qrev + (qlen - 1 - r); // query[r - i] = qrev[qlen - 1 - r + i]
+		int16_t *__restrict sb = sub;
 		if (simple) for (int i = lo; i <= hi; ++i) { const uint8_t x = tq[i], y = qq[i]; sb[i] = (x | y) >= 4 ? sc_n : x == y ? sc_mch : sc_mis; }
 		else for (int i = lo; i <= hi; ++i) sb[i] = mat[tq[i] * 5 + qq[i]];
 		const int16_t *__restrict h1 = H1, *__restrict h2 = H2, *__restrict e1 = E1, *__restrict f1 = F1;
@@ -160,11 +161,13 @@ int ll_local_score(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 	std::vector<int16_t> row_max((size_t)tlen, 0), row((size_t)qlen, 0);
 	const size_t n_cells = (size_t)qlen * (size_t)tlen;
 	std::vector<int16_t> all(n_cells <= ((size_t)24 << 20) ? n_cells : 0); // up to 48 MB: one sweep that keeps every score; beyond that a second sweep recomputes the row
-	if (!ll_sweep(qlen, query, tlen, target, mat, gapo + gape, gape, row_max.data(), -1, nullptr, all.empty() ? nullptr : all.data())) return ll_local_score_striped(qlen, query, tlen, target, mat, gapo, gape, qe, te);
+	std::vector<int16_t> work((size_t)8 * ((size_t)tlen + 2), 0);
+	std::vector<uint8_t> qrev((size_t)qlen);
+	if (!ll_sweep(qlen, query, tlen, target, mat, gapo + gape, gape, row_max.data(), -1, nullptr, all.empty() ? nullptr : all.data(), work.data(), qrev.data())) return ll_local_score_striped(qlen, query, tlen, target, mat, gapo, gape, qe, te);
 	int gmax = 0;
 	for (int i = 0; i < tlen; ++i) if (row_max[i] >= gmax) gmax = row_max[i], *te = i; // the LAST row that reaches the running maximum (ksw2_ll_sse.c:143-146)
 	if (gmax == 0) { *qe = 8 * ((qlen + 7) / 8) - 1; return 0; } // nothing scores: the striped scan's last slot holds the "maximum" too, padding included (:149-151)
-	if (all.empty()) ll_sweep(qlen, query, tlen, target, mat, gapo + gape, gape, nullptr, *te, row.data());
+	if (all.empty()) { std::fill(work.begin(), work.end(), (int16_t)0); ll_sweep(qlen, query, tlen, target, mat, gapo + gape, gape, nullptr, *te, row.data(), nullptr, work.data(), qrev.data()); }
 	else { // H(te, j) sits on diagonal te + j at index te - lo(te + j); diagonal r starts at the sum of the lengths before it
 		size_t off = 0;
 		for (int r = 0; r < *te + qlen; ++r) {
