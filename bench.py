@@ -751,6 +751,10 @@ def main():
                 t = json.load(open(tj)).get(fam)
                 if t:
                     roof["traffic"] = round(t.get("traffic_bytes_per_launch", t["fetch_bytes_x2"] + t["write_bytes_per_launch"]), 1)
+                    # traffic and the algorithmic bytes it is compared with come from the SAME launches (the counter passes' own bench line: tools/pmc_traffic.py, 20 k-read
+                    # launches, one lane); `alg_bytes_per_launch` above is this run's launch size -- the two are not to be divided by each other
+                    roof["traffic_over_algorithmic"] = t.get("traffic_over_algorithmic")
+                    roof["traffic_alg_bytes_per_launch_of_the_counter_pass"] = t.get("alg_bytes_per_launch")
                     roof["traffic_source"] = {"file": "profiles/pmc_traffic.json", "commit": t.get("commit"), "fetch_factor": t.get("fetch_factor", 2.0)}
             except Exception:
                 pass

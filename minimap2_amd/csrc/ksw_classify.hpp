@@ -37,6 +37,7 @@ constexpr int kOrderBuckets = 256; // cost buckets per class
 struct KswClassCtx { // uniform over a batch
 	int scoring_ok, splice_ok, splice, stream_on, ext_on, ext_max_t;
 	int ext_by_target = 0; // 1: the extension classes of ksw_ext.hip (A/B)
+	int ext_max_q = 512;   // longer queries go to the lane-exact kernel (see ksw_host.cpp for why 256 is the default with ksw_extq.hip)
 	// the banded kernel: on / off; the scores the acceptance test works with; the share of the best possible score (sc_max per base of the shorter side, in
 	// 1/256) a window is EXPECTED to reach -- the classes are chosen with it, the kernel's test uses the score actually found
 	int band_on = 0, sc_max = 0, gq = 0, ge = 0, gq2 = 0, ge2 = 0, band_rho256 = 128;
@@ -81,11 +82,11 @@ MM2_HD inline bool ksw_splice_fast_eligible(const KswJob &j, bool scoring_ok)
 // An extension (align.c:791, :883: KSW_EZ_EXTZ_ONLY; left extensions also KSW_EZ_RIGHT | KSW_EZ_REV_CIGAR) may take the register-resident
 // extension kernel when its band cannot bind, with default substitution scores and dual-affine costs: exact row maxima, Z-drop and end
 // bonus are computed there (ksw_ext.hip).
-MM2_HD inline bool ksw_ext_eligible(const KswJob &j, bool scoring_ok, int max_t)
+MM2_HD inline bool ksw_ext_eligible(const KswJob &j, bool scoring_ok, int max_t, int max_q = kExtMaxQ)
 {
 	const int f = j.flag & 0x1fff;
 	if (!scoring_ok || (j.flag & KSWJ_SKIP) || (f != KSW_EXTZ_ONLY && f != (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR))) return false;
-	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.tlen > max_t) return false;
+	if (j.qlen <= 0 || j.tlen <= 0 || j.qlen > kExtMaxQ || j.qlen > max_q || j.tlen > max_t) return false;
 	return ksw_band_cannot_bind(j);
 }
 MM2_HD inline int ksw_pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
@@ -105,7 +106,7 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 {
 	const bool splice = C.splice != 0;
 	o.ring_need = 64;
-	o.fast = ksw_fast_eligible(j, C.scoring_ok != 0), o.sfast = ksw_splice_fast_eligible(j, C.splice_ok != 0), o.xfast = C.ext_on && ksw_ext_eligible(j, C.scoring_ok != 0, C.ext_max_t);
+	o.fast = ksw_fast_eligible(j, C.scoring_ok != 0), o.sfast = ksw_splice_fast_eligible(j, C.splice_ok != 0), o.xfast = C.ext_on && ksw_ext_eligible(j, C.scoring_ok != 0, C.ext_max_t, C.ext_max_q);
 	o.live = !(j.flag & KSWJ_SKIP) && j.qlen > 0 && j.tlen > 0;
 	o.db = !o.live || (j.flag & KSW_SCORE_ONLY) ? 0 : o.xfast && !C.ext_by_target ? (size_t)(j.qlen + j.tlen - 1) * (size_t)(j.qlen > 256 ? 512 : j.qlen > 128 ? 256 : 128) :
 	       o.fast || o.xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :

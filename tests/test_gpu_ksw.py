@@ -516,8 +516,11 @@ def test_extension_kernel_with_the_query_across_the_lanes(preset, monkeypatch):
             for flag in (0x40, 0xC2):
                 w = max(len(q), len(t))  # cannot bind
                 jobs.append((q, t, int(rng.choice([w, w + 7, 30001])), int(rng.choice([-1, 100, 400, 2000])), int(rng.choice([-1, 10, 40])), flag))
+    monkeypatch.setenv("MM2AMD_EXT_MAX_Q", "512")  # (by default queries beyond 256 stay with the lane-exact kernel: ksw_host.cpp says why; here the eight-set class runs too)
     _run(jobs, preset)
     fast = mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+    monkeypatch.delenv("MM2AMD_EXT_MAX_Q")
+    assert mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2) == fast
     monkeypatch.setenv("MM2AMD_KSW_MAX_SLOTS", "4")  # few persistent waves: each takes many pairs
     assert mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2) == fast
     monkeypatch.delenv("MM2AMD_KSW_MAX_SLOTS")

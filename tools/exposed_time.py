@@ -15,15 +15,15 @@ LATENCY = ("ksw_extd2_kernel", "region_finish_kernel", "chain_rmq_kernel")  # pl
 def fam(name):
     n = name.split("(")[0]
     base = n.split("<")[0].split(" ")[-1].replace("mm2amd::", "")
-    if base == "ksw_ext_kernel":
-        return "ksw_ext_kernel<..,8>" if ", 8>" in n or ",8>" in n else "ksw_ext_kernel<..,4>"
+    if base in ("ksw_ext_kernel", "ksw_extq_kernel"):
+        return base + "<..,8>" if ", 8>" in n or ",8>" in n else base + "<..,4>"
     if base == "ksw_gapfill_kernel":
         return "ksw_gapfill_kernel"
     return base
 
 
 def is_latency(f):
-    return f in LATENCY or f == "ksw_ext_kernel<..,8>"
+    return f in LATENCY or f in ("ksw_ext_kernel<..,8>", "ksw_extq_kernel<..,8>")
 
 
 def main():

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name):
     n = name.split("(")[0].replace("void ", "").replace("mm2amd::", "")
-    return n.split("<")[0] if n.startswith(("ksw_stream_kernel", "ksw_gapfill_kernel", "ksw_splice_kernel", "ksw_extd2_kernel")) else n
+    return n.split("<")[0] if n.startswith(("ksw_stream_kernel", "ksw_gapfill_kernel", "ksw_splice_kernel", "ksw_extd2_kernel", "ksw_band_kernel", "ksw_extq_kernel", "ksw_ext_kernel", "anchor_sort_kernel", "chain_fill_kernel", "sketch_wave_kernel")) else n
 
 
 ALG = {}  # family -> [algorithmic bytes, launches] from the bench line of the last pass
@@ -83,7 +83,7 @@ if __name__ == "__main__":
         fb, fl = fetch.get(f, [0.0, 0])
         wb, wl = write.get(f, [0.0, 0])
         n = max(fl, wl, 1)
-        alg = ALG.get(f) or ALG.get({"sketch_wave_kernel": "sketch_kernel"}.get(f, f))
+        alg = ALG.get(f) or ALG.get({"sketch_wave_kernel": "sketch_kernel", "anchor_sort_ties_kernel": "anchor_sort_kernel"}.get(f, f))
         alg_per = alg[0] / max(alg[1], 1) if alg else None
         # gfx950: FETCH_SIZE reports half the bytes of coalesced dword / qword / dwordx4 streams (x2 correction: profiles/r03_pmc_calibration.json) but a
         # whole 64-byte sector for a random 8-byte probe (x1): the index-probing kernel is priced without the correction

@@ -42,6 +42,15 @@ print('$m', d['value'], d['ms_per_step'], r['kernel'], r.get('unoverlapped_step_
 print('   ', {k: v for k, v in (r.get('unoverlapped_ms') or {}).items() if k.startswith('ksw')})
 P
        done; unset MM2AMD_EXT_BY_TARGET ;;
+prof)  # evidence at HEAD in one call: rocprofv3 kernel stats of the headline command, the exposed-time split, HBM traffic (FETCH / WRITE passes) and the SQ counters
+       cd /tmp
+       timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --timed-only > $O/r06_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
+       DB=$(ls $O/prof_ont/*.db $O/prof_ont/*/*.db 2>/dev/null | head -1)
+       python $R/tools/rocpd_summary.py $DB > $O/r06_bench_full_kernel_stats_$V.txt; python $R/tools/exposed_time.py $DB 1.5 > $O/r06_exposed_time_$V.txt; rm -rf $O/prof_ont
+       head -14 $O/r06_bench_full_kernel_stats_$V.txt; head -12 $O/r06_exposed_time_$V.txt
+       cd $R
+       timeout 900 python tools/pmc_traffic.py --out $O/pmc_traffic_$V.json > $O/pmc_traffic_$V.log 2>&1; tail -c 300 $O/pmc_traffic_$V.log
+       PMC_SQ_TAG=r06_$V timeout 600 python tools/pmc_sq.py SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE > $O/r06_pmc_sq_$V.txt 2>&1; grep "ksw_band\|ksw_extq\|ksw_extd2" $O/r06_pmc_sq_$V.txt | head -8 ;;
 rccl)  timeout 300 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_aligner.py -x -q -m gpu > $O/r06_pytest_rccl_$V.log 2>&1; tail -3 $O/r06_pytest_rccl_$V.log ;;
 repeats) # the side figure on a repeat- and SV-bearing reference: how much of a batch leaves the device path
        timeout 900 python bench.py --workload repeats --steps 6 --warmup 3 --cpu-sample 20000 > $O/r06_bench_repeats_$V.json 2> $O/r06_bench_repeats_$V.log
