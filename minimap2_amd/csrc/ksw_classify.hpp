@@ -37,6 +37,7 @@ constexpr int kOrderBuckets = 256; // cost buckets per class
 struct KswClassCtx { // uniform over a batch
 	int scoring_ok, splice_ok, splice, stream_on, ext_on, ext_max_t;
 	int ext_by_target = 0; // 1: the extension classes of ksw_ext.hip (A/B)
+	int merge_rings = 1;   // the lane-exact kernel's ring classes 512 / 1024 / 2048 as ONE launch class (ring 2048): see ksw_classify()
 	int ext_max_q = 512;   // longer queries go to the lane-exact kernel (see ksw_host.cpp for why 256 is the default with ksw_extq.hip)
 	// the banded kernel: on / off; the scores the acceptance test works with; the share of the best possible score (sc_max per base of the shorter side, in
 	// 1/256) a window is EXPECTED to reach -- the classes are chosen with it, the kernel's test uses the score actually found
@@ -127,6 +128,10 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 		o.ring_need = ksw_pow2ceil((o.live ? width : 0) + 64);
 		int rc = 0, dc = 0;
 		while (rc < kHbmRing && o.ring_need > ksw_ring_size(rc)) ++rc;
+		// a launch of this kernel holds a few hundred long extensions and lasts as long as its longest job, microseconds per row: three ring classes were three such
+		// launches one after the other per sub-batch.  One class at the largest of the three rings (26 KB of LDS per job: five workgroups per CU, far more than a launch
+		// has jobs) is one launch (MM2AMD_KSW_SPLIT_RINGS=1: apart, A/B).
+		if (C.merge_rings && !splice && rc >= 1 && rc <= 3) rc = 3;
 		while (o.db > ksw_dir_limit(dc)) ++dc;
 		// banded matrices vary little, and a launch of this kernel lasts as long as its longest job whatever it holds (a few hundred long extensions, microseconds per
 		// row): ONE launch per ring class for everything up to 16 MB (round 5: 256 KB / 2 MB / 16 MB apart -- four launches per sub-batch and ring class, each ~3 ms of

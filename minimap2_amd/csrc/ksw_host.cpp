@@ -84,6 +84,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	// ksw_extq.hip is a launch of a few hundred pairs at 2.5 us per row of its own: 40 ms per step and direction.  MM2AMD_EXT_MAX_Q=512 brings the class back (A/B).
 	const int ext_max_q = getenv("MM2AMD_EXT_MAX_Q") ? atoi(getenv("MM2AMD_EXT_MAX_Q")) : ext_by_target ? kExtMaxQ : 256;
 	cctx.ext_max_q = ext_max_q;
+	cctx.merge_rings = getenv("MM2AMD_KSW_SPLIT_RINGS") ? 0 : 1;
 	// the banded gap fill (ksw_band.hip): which windows try a band first is decided from the score their length lets one expect -- a share of the best possible
 	// score that follows what the kernel's accepted windows actually reached (band_rho; MM2AMD_BAND_RHO pins it) -- never the results
 	const bool band_env_off = getenv("MM2AMD_NO_BAND") != nullptr; // (read per batch: tests switch it)

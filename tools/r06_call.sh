@@ -31,6 +31,24 @@ arena) # the first batches with and without the arenas behind the work buffers
          timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --timed-only > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
          grep -h "warmup\|steps in" $O/r06_bench_${m}_$V.log | cut -c1-330
        done; unset MM2AMD_NO_ARENA ;;
+rank8) # one rank's share of an eight-rank strong-scaling job on this one GPU with an eighth of the CPU quota (the prediction of DESIGN.md section 6)
+       timeout 600 python bench.py --as-rank-of 8 --steps 8 --warmup 3 --no-cpu-baseline > $O/r06_bench_rank8_$V.json 2> $O/r06_bench_rank8_$V.log
+       python -c "
+import json; d=json.loads(open('$O/r06_bench_rank8_$V.json').read().strip().split('\n')[-1]); print('rank8', d['value'], d['config']['as_rank_of'])" ;;
+repsplit) MM2AMD_KSW_SPLIT_RINGS=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_split_$V.json 2> $O/r06_bench_repeats_split_$V.log
+       python -c "
+import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().strip().split('\n')[-1]); print('repeats, ring classes apart', d['value'], d['ms_per_step'])" ;;
+abring) # the lane-exact kernel's ring classes 512 / 1024 / 2048 merged into one launch class against apart
+       for m in merged split; do
+         if [ $m = split ]; then export MM2AMD_KSW_SPLIT_RINGS=1; else unset MM2AMD_KSW_SPLIT_RINGS; fi
+         timeout 600 python bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_rings_${m}_$V.json 2> $O/r06_bench_rings_${m}_$V.log
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_rings_${m}_$V.json').read().strip().split('\n')[-1]); r=d['roofline']
+print('$m', d['value'], d['ms_per_step'], r['kernel'], r.get('unoverlapped_step_ms'))
+print('   ', {k: v for k, v in (r.get('unoverlapped_ms') or {}).items() if k.startswith('ksw_ext')})
+P
+       done; unset MM2AMD_KSW_SPLIT_RINGS ;;
 abext) # the extension kernel with the query across the lanes against round 3's (the target across the lanes)
        for m in extq bytarget; do
          if [ $m = bytarget ]; then export MM2AMD_EXT_BY_TARGET=1; else unset MM2AMD_EXT_BY_TARGET; fi
