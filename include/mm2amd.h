@@ -170,7 +170,9 @@ int mm_gpu_init_index_multi(const mm2amd_index_t *idx, const mm2amd_mapopt_t *op
 int mm_gpu_n_replicas(void);                     /* replicas of the live context (0: none) */
 
 /* SURVEY.md 8(b)(2) as written -- the batch call that names its index and options: the device context for (mi, *opt) is built on first use
- * and rebuilt when either changes (as mm_gpu_map does), then this is mm_gpu_map_batch. */
+ * and rebuilt when either changes (as mm_gpu_map does), then this is mm_gpu_map_batch.  Calls of mm_gpu_map_batch_with, mm_gpu_map and mm_gpu_map_frag
+ * are SERIALISED among themselves from the (mi, opt) check to the end of the mapping: there is one context per process, and a thread naming another
+ * index or other options rebuilds it only after the batch under way has come back (a rebuild costs seconds -- callers should stick to one pair). */
 int mm_gpu_map_batch_with(const mm2amd_idx_t *mi, const mm2amd_mapopt_t *opt, int n_frag, const int *seg_off, const int *n_seg, MM2AMD_BSEQ_PTR seq,
                           int *n_reg, MM2AMD_REG_PP reg, int *rep_len, int *frag_gap);
 

@@ -96,7 +96,7 @@ public:
 		n_threads_ = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
 		if (!T_) { own_.upload(fi, stream_); T_ = &own_; }
 		else if (tables_device >= 0 && tables_device != dev_) { own_.clone_from(*T_, tables_device, dev_); T_ = &own_; }
-		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.slots = T_->slots.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
+		I_.bucket_start = T_->bucket_start.p, I_.keys = T_->keys.p, I_.val_off = T_->val_off.p, I_.slots = T_->slots.p, I_.first = getenv("MM2AMD_NO_FIRST_SLOT") ? nullptr : T_->first.p, I_.pos = T_->pos.p, I_.S = T_->S.p;
 		I_.bucket_bits = T_->bucket_bits, I_.key_shift = T_->key_shift;
 		I_.name_rank = nullptr, I_.seq_len = nullptr;
 		fi_names_ = &fi.names, fi_seq_len_ = &fi.seq_len, fi_seq_off_ = &fi.seq_off; // fi outlives the backend (it is the mapper's index)

@@ -308,10 +308,24 @@ __global__ void __launch_bounds__(256) idx_make_slots_kernel(const uint64_t *key
 		slots[i] = s;
 	}
 }
+__global__ void __launch_bounds__(256) idx_make_first_kernel(const uint32_t *bucket_start, const IdxSlot *slots, uint64_t n_buckets, IdxSlot *first)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += stride) {
+		const uint32_t s = bucket_start[b], e = bucket_start[b + 1];
+		IdxSlot f;
+		f.key = kIdxNoKey, f.off = 0, f.cnt = 0;
+		if (s < e) { f = slots[s]; if (e - s > 1) f.cnt |= kIdxMoreKeys; }
+		first[b] = f;
+	}
+}
 void DeviceIndexTables::make_slots(hipStream_t stream)
 {
 	slots.ensure(n_keys + 1, 1.0);
 	if (n_keys) hipLaunchKernelGGL(idx_make_slots_kernel, dim3((unsigned)std::min<uint64_t>((n_keys + 255) / 256, 16384)), dim3(256), 0, stream, keys.p, val_off.p, n_keys, slots.p);
+	const uint64_t n_buckets = 1ull << bucket_bits;
+	first.ensure(n_buckets + 1, 1.0);
+	hipLaunchKernelGGL(idx_make_first_kernel, dim3((unsigned)std::min<uint64_t>((n_buckets + 255) / 256, 16384)), dim3(256), 0, stream, bucket_start.p, slots.p, n_buckets, first.p);
 	HIP_CHECK(hipGetLastError());
 	stream_wait(stream);
 }
@@ -342,6 +356,7 @@ void DeviceIndexTables::clone_from(const DeviceIndexTables &src, int src_device,
 	const size_t s_words = src.S.cap; // the packed reference as allocated (its exact length lives in the host index)
 	S.ensure(s_words + 1, 1.0), cp(S.p, src.S.p, s_words * 4);
 	slots.ensure(n_keys + 1, 1.0), cp(slots.p, src.slots.p, n_keys * sizeof(IdxSlot));
+	first.ensure(((size_t)1 << bucket_bits) + 1, 1.0), cp(first.p, src.first.p, ((size_t)1 << bucket_bits) * sizeof(IdxSlot));
 	HIP_CHECK(hipDeviceSynchronize());
 }
 

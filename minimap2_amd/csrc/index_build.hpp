@@ -12,12 +12,17 @@ namespace mm2amd {
 // come out of ONE 64-byte sector (round 5; keys[] and val_off[] stay for the export and the occurrence statistics, the probes of seed_collect_kernel
 // read this: bucket_start -> slot instead of bucket_start -> keys -> val_off, val_off + 1)
 struct alignas(16) IdxSlot { uint64_t key; uint32_t off, cnt; };
+// Round 6: one such record PER BUCKET as well -- the bucket's first key inline, its count's top bit set when the bucket holds more keys, an impossible key when it
+// holds none.  A probe reads this one record first: an empty bucket, a bucket whose only key is another one, and a hit on a bucket's first key (three probes in four
+// at the index' load factor of 0.65 keys per bucket) are answered by ONE sector read instead of two dependent ones (bucket_start, then the slots).
+constexpr uint32_t kIdxMoreKeys = 1u << 31;
+constexpr uint64_t kIdxNoKey = ~0ull; // (a minimizer key is hash << 8 | span: never all ones)
 
 struct DeviceIndexTables {
 	DevBuf<uint32_t> bucket_start, val_off, S;
 	DevBuf<uint64_t> keys, pos;
-	DevBuf<IdxSlot> slots;
-	void make_slots(hipStream_t stream); // from keys / val_off
+	DevBuf<IdxSlot> slots, first;          // per distinct minimizer | per bucket (above)
+	void make_slots(hipStream_t stream); // from keys / val_off (and bucket_start)
 	uint64_t n_keys = 0, n_pos = 0;
 	int bucket_bits = 0, key_shift = 0;
 	std::vector<unsigned long long> occ_hist; // occ_hist[c] = number of distinct minimizers occurring c times (last bin: >=)

@@ -145,7 +145,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			cs.cells += (double)j.qlen * (double)j.tlen;
 			cs.max_ring = std::max(cs.max_ring, o.ring_need), cs.max_Q16 = std::max(cs.max_Q16, r16(j.qlen));
 			if (!(j.flag & KSW_SCORE_ONLY)) {
-				if (o.db > 160 * 1024) cs.alg_bytes += (double)o.db;
+				if (o.db > 160 * 1024 || ksw_band_sets(tier)) cs.alg_bytes += (double)o.db; // (the banded kernel's direction bytes -- 64 NB per row and job -- go through HBM whatever their size: two waves per CU is what keeping them in LDS would cost)
 				cs.slot_bytes = std::max(cs.slot_bytes, o.db), cs.tmp_cap = std::max(cs.tmp_cap, (size_t)j.qlen + j.tlen);
 				if (o.fast || o.xfast) cs.max_rows = std::max(cs.max_rows, j.qlen + j.tlen - 1), cs.max_ncol = std::max(cs.max_ncol, (j.tlen + 63) & ~63);
 				st.sum_len += (size_t)j.qlen + j.tlen, cs.sum_len += (double)j.qlen + j.tlen;

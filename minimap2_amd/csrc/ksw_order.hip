@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) ksw_order_count_kernel(const KswJob *jobs
 			atomicMax(&s_max[t][0], (unsigned int)o.ring_need);
 			atomicMax(&s_max[t][1], (unsigned int)((j.qlen + 15) / 16 * 16));
 			if (!(j.flag & KSW_SCORE_ONLY)) {
-				if (o.db > 160 * 1024) alg += (unsigned long long)o.db;
+				if (o.db > 160 * 1024 || ksw_band_sets(o.tier)) alg += (unsigned long long)o.db; // (the banded kernel's direction bytes always travel: ksw_host.cpp)
 				atomicMax(&s_max64[t][0], (unsigned long long)o.db);
 				atomicMax(&s_max64[t][1], (unsigned long long)j.qlen + (unsigned long long)j.tlen);
 				if (o.fast || o.xfast) { atomicMax(&s_max[t][2], (unsigned int)(j.qlen + j.tlen - 1)); atomicMax(&s_max[t][3], (unsigned int)((j.tlen + 63) & ~63)); }

@@ -326,7 +326,14 @@ __device__ __forceinline__ uint32_t idx_lookup(const DevIndex &I, uint64_t hash,
 {
 	const uint64_t b = hash >> I.key_shift;
 	if (b >= (1ull << I.bucket_bits)) return 0;
-	const uint32_t s = I.bucket_start[b], e = I.bucket_start[b + 1];
+	uint32_t skip = 0;
+	if (I.first) { // (round 6) the bucket's own record: empty, a single other key, or the key itself -- one sector read; only a bucket with more keys goes on
+		const IdxSlot f = I.first[b];
+		if (f.key == hash) { *off = f.off; return f.cnt & ~kIdxMoreKeys; }
+		if (!(f.cnt & kIdxMoreKeys)) return 0;
+		skip = 1; // (its first key has been looked at)
+	}
+	const uint32_t s = I.bucket_start[b] + skip, e = I.bucket_start[b + 1];
 	// (round 5) one 16-byte record per key -- key, first position, count -- so the bucket's key scan and the answer come out of the same sector:
 	// two dependent sector reads per probe (bucket_start, slots) instead of three to four (bucket_start, keys, val_off[i], val_off[i + 1])
 	for (uint32_t i = s; i < e; ++i) {

@@ -12,6 +12,7 @@ struct DevIndex {             // device mirror of FlatIndex
 	const uint64_t *keys;
 	const uint32_t *val_off;
 	const struct IdxSlot *slots; // (key, first position, count) per distinct minimizer: what a probe reads (index_build.hpp)
+	const struct IdxSlot *first; // the same per BUCKET: its first key inline (round 6); null: probes go through bucket_start only
 	const uint64_t *pos;
 	const uint32_t *S;
 	int bucket_bits, key_shift;

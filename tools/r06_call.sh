@@ -38,6 +38,16 @@ import json; d=json.loads(open('$O/r06_bench_rank8_$V.json').read().strip().spli
 repsplit) MM2AMD_KSW_SPLIT_RINGS=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_split_$V.json 2> $O/r06_bench_repeats_split_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().strip().split('\n')[-1]); print('repeats, ring classes apart', d['value'], d['ms_per_step'])" ;;
+abfirst) # index probes through the per-bucket first-key record against bucket_start -> slots only
+       for m in first nofirst; do
+         if [ $m = nofirst ]; then export MM2AMD_NO_FIRST_SLOT=1; else unset MM2AMD_NO_FIRST_SLOT; fi
+         timeout 600 python bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_${m}_$V.json').read().strip().split('\n')[-1]); r=d['roofline']
+print('$m', d['value'], d['ms_per_step'], r.get('unoverlapped_step_ms'), 'seed_collect', (r.get('unoverlapped_ms') or {}).get('seed_collect_kernel'), r.get('index_probes', {}).get('per_s_unoverlapped'), 'index build', d['config']['index_build_s'])
+P
+       done; unset MM2AMD_NO_FIRST_SLOT ;;
 abring) # the lane-exact kernel's ring classes 512 / 1024 / 2048 merged into one launch class against apart
        for m in merged split; do
          if [ $m = split ]; then export MM2AMD_KSW_SPLIT_RINGS=1; else unset MM2AMD_KSW_SPLIT_RINGS; fi
