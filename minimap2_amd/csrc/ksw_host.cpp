@@ -215,9 +215,18 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		// kernel and the copy-back of every sub-batch).  One scratch allocation per group serves all of its launches.
 		struct Plan { size_t beg = 0, end = 0, slot_bytes = 16, tmp_cap = 16, n_slots = 0; int ring = 64, max_Q16 = 16, wpb = 4, team = 1; bool hbm = false; double alg_bytes = 0, cells = 0; };
 		Plan plan[kNTiers];
-		size_t need_dir_g[2] = { 16, 16 }, need_tmp_g[2] = { 16, 16 }, need_state = 0;
+		size_t need_dir_g[3] = { 16, 16, 16 }, need_tmp_g[3] = { 16, 16, 16 }, need_state = 0;
 		// (the extension classes with a few hundred long jobs per launch -- queries beyond 256; with MM2AMD_EXT_BY_TARGET targets beyond 256 -- run beside the lane-exact kernel's)
-		auto group_of = [](int tier) { return (tier >= kFirstExact && tier < kFirstSplice) || (tier >= kFirstExt + (ext_by_target ? 2 : 4) && tier < kFirstBand) ? 1 : 0; };
+		// Round 6, group 2 (MEASURED AND OFF: MM2AMD_SIDE2=1 turns it on): the strip kernel's classes (gap fills beyond 512 x 512: a few long jobs per launch, 3-7 ms of
+		// latency each on a handful of CUs) on a stream of their own beside the banded kernel's launches instead of in front of them.  One call, A B: the step 270 -> 319 ms,
+		// one rank's share of eight 51.5 -> 66.3 ms (profiles/r06_bench_side2_v14.json / _noside2_): a third queue per lane -- 24 in all -- costs the banded launches more
+		// than the strip kernel's latency was worth.
+		static const bool side2_off = getenv("MM2AMD_SIDE2") == nullptr;
+		const bool strip_on_side2 = !side2_off && stream_on && !splice && !getenv("MM2AMD_NO_SIDE_STREAM");
+		auto group_of = [strip_on_side2](int tier) {
+			if ((tier >= kFirstExact && tier < kFirstSplice) || (tier >= kFirstExt + (ext_by_target ? 2 : 4) && tier < kFirstBand)) return 1;
+			return strip_on_side2 && tier < kFirstExact && !ksw_stream_sets(tier) ? 2 : 0;
+		};
 		const int max_slots_env = getenv("MM2AMD_KSW_MAX_SLOTS") ? atoi(getenv("MM2AMD_KSW_MAX_SLOTS")) : 0; // tests: few persistent waves, so that each takes many jobs
 		// Two groups run concurrently only when there are lane-exact launches and the mode allows it; then each gets half of this lane's
 		// scratch budget and buffers of its own.  Otherwise the groups run one after the other and SHARE one buffer sized for the larger.
@@ -233,12 +242,15 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-				const size_t mine = (d_dir.cap + d_dir2.cap) * sizeof(uint8_t), reserve = (size_t)12 << 30; // (room for the other lanes' per-sub-batch arrays)
+				const size_t mine = (d_dir.cap + d_dir2.cap + d_dir3.cap) * sizeof(uint8_t), reserve = (size_t)12 << 30; // (room for the other lanes' per-sub-batch arrays)
 				const size_t avail = free_b + mine > reserve ? free_b + mine - reserve : 0;
 				budget_now = std::min(budget_now, std::max<size_t>(avail, (size_t)1 << 30));
 			}
 		}
-		const size_t group_budget = use_side ? budget_now / 2 : budget_now;
+		bool any_side2 = false;
+		for (int tier = 0; tier < kNTiers; ++tier) any_side2 |= group_of(tier) == 2 && tier_beg[tier + 1] != tier_beg[tier];
+		const bool use_side2 = any_side2; // (group_of only names group 2 when the mode allows it)
+		const size_t group_budget = budget_now / (size_t)(1 + (use_side ? 1 : 0) + (use_side2 ? 1 : 0));
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			Plan &P = plan[tier];
 			size_t &need_dir = need_dir_g[group_of(tier)], &need_tmp = need_tmp_g[group_of(tier)];
@@ -311,8 +323,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		}
 		for (size_t &need_dir : need_dir_g)
 			if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
-		uint8_t *dir_g[2];
-		uint32_t *tmp_g[2];
+		uint8_t *dir_g[3];
+		uint32_t *tmp_g[3];
 		if (use_side) {
 			d_dir.ensure(need_dir_g[0], 1.0), d_dir2.ensure(need_dir_g[1], 1.0);
 			d_cigar_tmp.ensure(need_tmp_g[0], 1.0), d_cigar_tmp2.ensure(need_tmp_g[1], 1.0);
@@ -321,6 +333,11 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			d_dir.ensure(std::max(need_dir_g[0], need_dir_g[1]), 1.0);
 			d_cigar_tmp.ensure(std::max(need_tmp_g[0], need_tmp_g[1]), 1.0);
 			dir_g[0] = dir_g[1] = d_dir.p, tmp_g[0] = tmp_g[1] = d_cigar_tmp.p;
+		}
+		dir_g[2] = dir_g[0], tmp_g[2] = tmp_g[0];
+		if (use_side2) {
+			d_dir3.ensure(need_dir_g[2], 1.0), d_cigar_tmp3.ensure(need_tmp_g[2], 1.0);
+			dir_g[2] = d_dir3.p, tmp_g[2] = d_cigar_tmp3.p;
 		}
 		if (need_state) d_state.ensure(need_state, 1.0);
 		grow_lk.unlock();
@@ -335,15 +352,24 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			HIP_CHECK(hipEventRecord(ev_ready, stream)); // job records uploaded, queue heads and cursors zeroed
 			HIP_CHECK(hipStreamWaitEvent(side, ev_ready, 0));
 		}
+		if (use_side2) {
+			if (!side2) {
+				HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+				HIP_CHECK(hipEventCreateWithFlags(&ev_ready2, hipEventDisableTiming));
+				HIP_CHECK(hipEventCreateWithFlags(&ev_side2_done, hipEventDisableTiming));
+			}
+			HIP_CHECK(hipEventRecord(ev_ready2, stream));
+			HIP_CHECK(hipStreamWaitEvent(side2, ev_ready2, 0));
+		}
 		static const char *kFastNames[kFirstExact] = { "ksw_gapfill_kernel<512>[t256]", "ksw_gapfill_kernel<512>[t512]", "ksw_gapfill_kernel<512>[t1536]",
 		                                               "ksw_gapfill_kernel<1024>[t256]", "ksw_gapfill_kernel<1024>[t1024]", "ksw_gapfill_kernel<1024>[t3072]" };
 		static const char *kRingNames[kRingClasses] = { "ksw_extd2_kernel[r256]", "ksw_extd2_kernel[r512]", "ksw_extd2_kernel[r1k]", "ksw_extd2_kernel[r2k]", "ksw_extd2_kernel[r4k]", "ksw_extd2_kernel[r8k]", "ksw_extd2_kernel[hbm]" };
-		for (int pass = 0; pass < 2; ++pass) // the side-stream group first: its long jobs should start as early as possible
+		for (int pass = 0; pass < 3; ++pass) // the side-stream groups first: their long jobs should start as early as possible
 		for (int tier = 0; tier < kNTiers; ++tier) {
 			const Plan &P = plan[tier];
-			if (P.end == P.beg || group_of(tier) != 1 - pass) continue;
+			if (P.end == P.beg || group_of(tier) != (pass == 0 ? 1 : pass == 1 ? 2 : 0)) continue;
 			const bool on_side = use_side && group_of(tier) == 1;
-			hipStream_t stream_ = on_side ? side : stream;
+			hipStream_t stream_ = on_side ? side : use_side2 && group_of(tier) == 2 ? side2 : stream;
 			KswLaunch L;
 			L.jobs = d_jobs.p + P.beg, L.res = d_res.p + P.beg, L.n_jobs = (int32_t)(P.end - P.beg);
 			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
@@ -398,6 +424,10 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));
 			HIP_CHECK(hipStreamWaitEvent(stream, ev_side_done, 0));
+		}
+		if (use_side2) {
+			HIP_CHECK(hipEventRecord(ev_side2_done, side2));
+			HIP_CHECK(hipStreamWaitEvent(stream, ev_side2_done, 0));
 		}
 		// (into PINNED memory: an asynchronous copy to pageable memory -- a stack array here until round 4 -- makes the runtime wait for the stream inside
 		// the call, spinning: the lane drivers spent the whole duration of the DP kernels on a core each, 1.2 core-seconds per step)

@@ -12,11 +12,17 @@ struct KswRunner {
 	DevBuf<KswJob> d_jobs;
 	DevBuf<KswRes> d_res;
 	DevBuf<uint32_t> d_cigar, d_cigar_tmp, d_cursor, d_juncs;
-	DevBuf<uint8_t> d_dir, d_dir2, d_state;   // direction-matrix scratch of the two concurrent launch groups (ksw_host.cpp)
-	DevBuf<uint32_t> d_cigar_tmp2;
+	DevBuf<uint8_t> d_dir, d_dir2, d_dir3, d_state;   // direction-matrix scratch of the concurrent launch groups (ksw_host.cpp)
+	DevBuf<uint32_t> d_cigar_tmp2, d_cigar_tmp3;
+	hipStream_t side2 = nullptr;              // round 6: the strip kernel's few long gap fills, beside the banded kernel's launches
+	hipEvent_t ev_ready2 = nullptr, ev_side2_done = nullptr;
 	hipStream_t side = nullptr;               // the lane-exact kernel's launches run here, beside the register-resident kernels on the caller's stream
 	hipEvent_t ev_ready = nullptr, ev_side_done = nullptr;
-	~KswRunner() { if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_ready); (void)hipEventDestroy(ev_side_done); } }
+	~KswRunner()
+	{
+		if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_ready); (void)hipEventDestroy(ev_side_done); }
+		if (side2) { (void)hipStreamDestroy(side2); (void)hipEventDestroy(ev_ready2); (void)hipEventDestroy(ev_side2_done); }
+	}
 	DevBuf<int32_t> d_counter;
 	PinBuf<KswJob> sorted;            // jobs in launch order (tier, then decreasing cost), pinned for the H2D copy
 	PinBuf<KswRes> tmp_res;

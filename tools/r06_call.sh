@@ -35,9 +35,21 @@ rank8) # one rank's share of an eight-rank strong-scaling job on this one GPU wi
        timeout 600 python bench.py --as-rank-of 8 --steps 8 --warmup 3 --no-cpu-baseline > $O/r06_bench_rank8_$V.json 2> $O/r06_bench_rank8_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_rank8_$V.json').read().strip().split('\n')[-1]); print('rank8', d['value'], d['config']['as_rank_of'])" ;;
+rank8trace) MM2AMD_TRACE=$O/r06_rank8_trace_$V.tsv timeout 600 python bench.py --as-rank-of 8 --steps 3 --warmup 2 --no-cpu-baseline > $O/r06_bench_rank8t_$V.json 2> $O/r06_bench_rank8t_$V.log
+       python tools/trace_summary.py $O/r06_rank8_trace_$V.tsv 0.5; python tools/trace_ascii.py $O/r06_rank8_trace_$V.tsv --win 0.2 --res 1 2>/dev/null | head -40; tail -c 3000000 $O/r06_rank8_trace_$V.tsv > $O/r06_rank8_trace_tail_$V.tsv; rm -f $O/r06_rank8_trace_$V.tsv ;;
 repsplit) MM2AMD_KSW_SPLIT_RINGS=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_split_$V.json 2> $O/r06_bench_repeats_split_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().strip().split('\n')[-1]); print('repeats, ring classes apart', d['value'], d['ms_per_step'])" ;;
+abside2) # the strip kernel's gap fills on a stream of their own against in front of the banded kernel's launches: whole batch and one rank's share of eight
+       for m in side2 noside2; do
+         if [ $m = side2 ]; then export MM2AMD_SIDE2=1; else unset MM2AMD_SIDE2; fi
+         timeout 600 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --as-rank-of 8 > $O/r06_bench_${m}_$V.json 2> $O/r06_bench_${m}_$V.log
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_${m}_$V.json').read().strip().split('\n')[-1]); r=d['roofline']; a=d['config']['as_rank_of']
+print('$m', d['value'], d['ms_per_step'], 'share ms', a['ms_per_step'], 'predicted', a['predicted_strong_scaling'])
+P
+       done; unset MM2AMD_SIDE2 ;;
 abfirst) # index probes through the per-bucket first-key record against bucket_start -> slots only
        for m in first nofirst; do
          if [ $m = nofirst ]; then export MM2AMD_NO_FIRST_SLOT=1; else unset MM2AMD_NO_FIRST_SLOT; fi
