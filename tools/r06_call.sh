@@ -40,6 +40,19 @@ rank8trace) MM2AMD_TRACE=$O/r06_rank8_trace_$V.tsv timeout 600 python bench.py -
 repsplit) MM2AMD_KSW_SPLIT_RINGS=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_split_$V.json 2> $O/r06_bench_repeats_split_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().strip().split('\n')[-1]); print('repeats, ring classes apart', d['value'], d['ms_per_step'])" ;;
+rmqcap) # heavy reads' long-join re-chaining on the host's tree instead of one wavefront walking 100 000 anchors
+       for cap in 131072 30000 8000; do
+         MM2AMD_RMQ_DEV_MAX_ANCHORS=$cap timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_cap${cap}_$V.json 2> $O/r06_bench_repeats_cap${cap}_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_repeats_cap${cap}_$V.json').read().strip().split('\n')[-1]); u=d['roofline']['unoverlapped_ms']; print('cap $cap:', d['value'], d['ms_per_step'], 'host cpu', d['config']['host_cpu_s_per_step'], 'rmq[lj]', u.get('chain_rmq_kernel[long-join]'), d['config']['device_path_last_batch'])"
+       done ;;
+sweep) # lanes x DP gate
+       for cfg in "8 4" "8 3" "8 6" "6 4" "10 4" "10 6" "12 6"; do
+         set -- $cfg
+         MM2AMD_LANES=$1 MM2AMD_DP_GATE=$2 timeout 600 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --timed-only > $O/r06_bench_l$1_g$2_$V.json 2> $O/r06_bench_l$1_g$2_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_l$1_g$2_$V.json').read().strip().split('\n')[-1]); print('lanes $1 gate $2:', d['value'], d['ms_per_step'])"
+       done ;;
 abside2) # the strip kernel's gap fills on a stream of their own against in front of the banded kernel's launches: whole batch and one rank's share of eight
        for m in side2 noside2; do
          if [ $m = side2 ]; then export MM2AMD_SIDE2=1; else unset MM2AMD_SIDE2; fi
