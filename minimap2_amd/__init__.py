@@ -591,7 +591,7 @@ class Aligner(object):
                  "alloc_ns", "cpu_seed_chain", "cpu_host_pre", "cpu_plan", "cpu_ksw", "cpu_consume", "cpu_finish", "n_long_join_dev", "n_long_join_host",
                  "drv_cpu_seed_chain", "drv_cpu_host_pre", "drv_cpu_plan", "drv_cpu_ksw", "drv_cpu_consume", "drv_cpu_finish", "n_early_sub",
                  "n_region_reads_dev", "n_region_reads_host", "n_band128", "n_band256", "n_band_widened", "n_band_rectangle",
-                 "arena_dev_bytes", "arena_pin_bytes", "arena_dev_used", "arena_pin_used"]
+                 "arena_dev_bytes", "arena_pin_bytes", "arena_dev_used", "arena_pin_used", "n_band512", "n_band_rectangle_big"]
         return dict(zip(names, list(v)[:k]))
 
 
@@ -600,10 +600,11 @@ def band_counters():
     computed again as full rectangles.  (Zeros in a library without the kernels.)"""
     L = lib()
     if not hasattr(L, "mm2amd_alloc_counter"):
-        return {"band128": 0, "band256": 0, "widened": 0, "rectangle": 0}
+        return {"band128": 0, "band256": 0, "widened": 0, "rectangle": 0, "band512": 0, "rectangle_big": 0}
     L.mm2amd_alloc_counter.restype = C.c_longlong
     L.mm2amd_alloc_counter.argtypes = [C.c_int]
-    return {"band128": L.mm2amd_alloc_counter(3), "band256": L.mm2amd_alloc_counter(4), "widened": L.mm2amd_alloc_counter(5), "rectangle": L.mm2amd_alloc_counter(6)}
+    return {"band128": L.mm2amd_alloc_counter(3), "band256": L.mm2amd_alloc_counter(4), "widened": L.mm2amd_alloc_counter(5), "rectangle": L.mm2amd_alloc_counter(6),
+            "band512": L.mm2amd_alloc_counter(11), "rectangle_big": L.mm2amd_alloc_counter(12)}
 
 
 def profile_enable(on=True):

@@ -239,7 +239,8 @@ long long mm2amd_alloc_counter(int which)
 	BandCounters &b = band_counters();
 	return which == 0 ? a.dev_allocs.load() : which == 1 ? a.pin_allocs.load() : which == 2 ? a.ns.load() : which == 3 ? (long long)b.n_band1.load() : which == 4 ? (long long)b.n_band2.load() :
 	       which == 5 ? (long long)b.n_widened.load() : which == 6 ? (long long)b.n_retried.load() :
-	       which == 7 ? (long long)dev_arena().held_bytes() : which == 8 ? (long long)pin_arena().held_bytes() : which == 9 ? (long long)dev_arena().used_bytes() : (long long)pin_arena().used_bytes();
+	       which == 7 ? (long long)dev_arena().held_bytes() : which == 8 ? (long long)pin_arena().held_bytes() : which == 9 ? (long long)dev_arena().used_bytes() : which == 10 ? (long long)pin_arena().used_bytes() :
+	       which == 11 ? (long long)b.n_band4.load() : (long long)b.n_retried_big.load();
 }
 
 void mm2amd_profile_enable(int on)

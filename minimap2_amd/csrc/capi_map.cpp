@@ -716,7 +716,8 @@ int mm2amd_last_stats(double *v, int n)
 	                     s.d_seed_chain, s.d_host_pre, s.d_plan, s.d_ksw, s.d_consume, s.d_finish, (double)s.n_early_sub,
 	                     (double)s.n_region_reads_dev, (double)s.n_region_reads_host,
 	                     (double)mm2amd_alloc_counter(3), (double)mm2amd_alloc_counter(4), (double)mm2amd_alloc_counter(5), (double)mm2amd_alloc_counter(6),
-	                     (double)mm2amd_alloc_counter(7), (double)mm2amd_alloc_counter(8), (double)mm2amd_alloc_counter(9), (double)mm2amd_alloc_counter(10) }; // (the arenas behind the work buffers: bytes held in chunks, device / pinned; bytes handed out of them) // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
+	                     (double)mm2amd_alloc_counter(7), (double)mm2amd_alloc_counter(8), (double)mm2amd_alloc_counter(9), (double)mm2amd_alloc_counter(10),
+	                     (double)mm2amd_alloc_counter(11), (double)mm2amd_alloc_counter(12) }; // (the arenas behind the work buffers: bytes held in chunks, device / pinned; bytes handed out of them) // (process CPU seconds while a lane was in the stage: lanes overlap, so these attribute, they do not add up)
 	int k = 0;
 	for (; k < n && k < (int)(sizeof a / sizeof a[0]); ++k) v[k] = a[k];
 	return k;

@@ -84,7 +84,7 @@ struct AllocStats { std::atomic<long> dev_allocs{0}, pin_allocs{0}; std::atomic<
 inline AllocStats &alloc_stats() { static AllocStats s; return s; }
 // how the banded gap-fill kernel's launch classes fared since the process started (ksw_host.cpp): windows tried in 128 / 256 diagonals, sent on to the wider
 // band, computed again as the full rectangle
-struct BandCounters { std::atomic<unsigned long long> n_band1{0}, n_band2{0}, n_widened{0}, n_retried{0}; };
+struct BandCounters { std::atomic<unsigned long long> n_band1{0}, n_band2{0}, n_band4{0}, n_widened{0}, n_retried{0}, n_retried_big{0}; };
 inline BandCounters &band_counters() { static BandCounters s; return s; }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@
 // After its last row a pair is traced back and scanned exactly as in the other two kernels (gf_traceback, gf_zdrop_scan); the scan's score under the DP's own
 // costs IS the corner score, and band_outside_bound (ksw_band.hpp, where the argument is) tells whether that score proves the band sufficient.  If so the
 // result is the rectangle's and is written; if not, nothing is written and the job's index goes onto a list: `widen` (a launch of this kernel with a wider
-// band, when the score found says that one would do) or `retry` (the streaming kernel's full rectangle).  The lists are consumed by launches whose job count is
+// band, when the score found says that one would do) or `retry` / `big` (the full rectangle: the streaming kernel's up to 512 x 512, the strip kernel's beyond).  The lists are consumed by launches whose job count is
 // read on the device -- no host round trip.  tests/test_gpu_ksw.py: every accepted result against the reference's unbanded ksw_extd2_sse, with the acceptance
 // forced to fail, with repeats that put equally good alignments far from the diagonal, and through the list-driven launches.
 #include <hip/hip_runtime.h>
@@ -34,7 +34,9 @@
 
 namespace mm2amd {
 
-constexpr int bd_slots(int n_sets) { return 512 + 64 * n_sets + 8; } // bases kept per pair and sequence: (qlen + tlen) / 2 + 64 NB + 2 slots are in use (query, target <= 512; 4 B per slot, two arrays: 4.6 / 5.1 KB of LDS per wave)
+// bases kept per pair and sequence: (qlen + tlen) / 2 + 64 NB + 2 slots are in use (query, target <= HALF; 4 B per slot, two arrays: 4.6 / 5.1 KB of LDS per wave with
+// one / two register sets and windows up to 512 x 512, 10.3 KB with four sets and windows up to 1024 x 1024)
+constexpr int bd_slots(int n_sets, int half) { return half + 64 * n_sets + 8; }
 
 __device__ __forceinline__ uint32_t bd_shl1(uint32_t carry_in, uint32_t v) // lane i <- v[i + 1], lane 63 <- carry_in
 {
@@ -50,11 +52,11 @@ __device__ __forceinline__ uint64_t bd_uni64(uint64_t v)
 	return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
 }
 
-template <int NB, int WAVES>
+template <int NB, int WAVES, int HALF>
 __global__ void __launch_bounds__(256, WAVES) ksw_band_kernel(KswLaunch L)
 {
-	__shared__ uint32_t s_q[4][bd_slots(NB)];     // slot s: query base j = s - QOFF + c of each half (A | B << 16: as the cell wants it -- one LDS load per row, nothing to unpack); 4 where there is none
-	__shared__ uint32_t s_t[4][bd_slots(NB)];     // slot s: target base i = s - c
+	__shared__ uint32_t s_q[4][bd_slots(NB, HALF)];     // slot s: query base j = s - QOFF + c of each half (A | B << 16: as the cell wants it -- one LDS load per row, nothing to unpack); 4 where there is none
+	__shared__ uint32_t s_t[4][bd_slots(NB, HALF)];     // slot s: target base i = s - c
 	__shared__ int8_t s_mat[32];
 	constexpr int W = 128 * NB, NL = 64 * NB, QOFF = NL;
 	const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
@@ -97,8 +99,8 @@ __global__ void __launch_bounds__(256, WAVES) ksw_band_kernel(KswLaunch L)
 		const int cA = band_c(qlenA, tlenA, W), cB = band_c(qlenB, tlenB, W);
 		const int n_rowsA = qlenA + tlenA - 1, n_rowsB = hasB ? qlenB + tlenB - 1 : 0;
 		// a window whose corners the band does not hold, or that is longer than the LDS arrays, is not computed at all: it fails the acceptance below
-		const bool fitA = band_holds_corners(qlenA, tlenA, W) && (n_rowsA + 1) / 2 + NL + 2 <= bd_slots(NB);
-		const bool fitB = hasB && band_holds_corners(qlenB, tlenB, W) && (n_rowsB + 1) / 2 + NL + 2 <= bd_slots(NB);
+		const bool fitA = band_holds_corners(qlenA, tlenA, W) && (n_rowsA + 1) / 2 + NL + 2 <= bd_slots(NB, HALF);
+		const bool fitB = hasB && band_holds_corners(qlenB, tlenB, W) && (n_rowsB + 1) / 2 + NL + 2 <= bd_slots(NB, HALF);
 		const int rows_run = (fitA ? n_rowsA : 0) > (fitB ? n_rowsB : 0) ? (fitA ? n_rowsA : 0) : (fitB ? n_rowsB : 0);
 
 		// ---- the pair's bases into LDS ----
@@ -240,9 +242,10 @@ __global__ void __launch_bounds__(256, WAVES) ksw_band_kernel(KswLaunch L)
 			if (accept) { if (g.n > 0) cig_off = atomicAdd(&L.cigar_cursor[0], (uint32_t)g.n); }
 			else {
 				// a band twice as wide is worth a launch when the score found here would be accepted there (it can only be higher there)
-				const bool widen = L.widen_list && band_holds_corners(my_q, my_t, L.widen_W) && (my_q + my_t) / 2 + L.widen_W / 2 + 2 <= bd_slots(L.widen_W / 128) &&
+				const bool widen = L.widen_list && band_holds_corners(my_q, my_t, L.widen_W) && (my_q + my_t) / 2 + L.widen_W / 2 + 2 <= L.widen_slots &&
 				                   (have ? dp_sum : INT32_MIN) > band_outside_bound(my_q, my_t, L.widen_W, sc_max, q, e, q2, e2) && L.band_reject < 2;
 				if (widen) L.widen_list[atomicAdd(L.widen_count, 1)] = L.list_base + (uint32_t)my_id;
+				else if (my_q > L.retry_max || my_t > L.retry_max) L.big_list[atomicAdd(L.big_count, 1)] = L.list_base + (uint32_t)my_id;
 				else L.retry_list[atomicAdd(L.retry_count, 1)] = L.list_base + (uint32_t)my_id;
 			}
 		}
@@ -278,13 +281,15 @@ void ksw_band_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream)
 	if (L.n_jobs <= 0 && !L.n_list) return;
 	const int n_blocks = (n_slots + 3) / 4;
 	hipStream_t s = (hipStream_t)stream;
-	if (n_sets == 1) hipLaunchKernelGGL((ksw_band_kernel<1, 8>), dim3(n_blocks), dim3(256), 0, s, L);
-	else if (n_sets == 2) hipLaunchKernelGGL((ksw_band_kernel<2, 6>), dim3(n_blocks), dim3(256), 0, s, L);
+	if (n_sets == 1) hipLaunchKernelGGL((ksw_band_kernel<1, 8, 512>), dim3(n_blocks), dim3(256), 0, s, L);
+	else if (n_sets == 2) hipLaunchKernelGGL((ksw_band_kernel<2, 6, 512>), dim3(n_blocks), dim3(256), 0, s, L);
+	else if (n_sets == 4) hipLaunchKernelGGL((ksw_band_kernel<4, 3, 1024>), dim3(n_blocks), dim3(256), 0, s, L);
 	else throw std::runtime_error("[mm2amd] ksw_band_launch: unsupported register-set count");
 	HIP_CHECK(hipGetLastError());
 }
 
-int ksw_band_waves(int n_sets) { return n_sets == 1 ? 8 : 6; } // blocks of four waves per CU the instantiation is compiled for
+int ksw_band_waves(int n_sets) { return n_sets == 1 ? 8 : n_sets == 2 ? 6 : 3; } // blocks of four waves per CU the instantiation is compiled for (four sets: 41 KB of LDS per block)
+int ksw_band_slots(int n_sets) { return bd_slots(n_sets, n_sets == 4 ? 1024 : 512); } // base slots per sequence a wave holds: a window needs (qlen + tlen) / 2 + 64 n_sets + 2
 size_t ksw_band_slot_bytes(int n_sets, int max_rows) { return (size_t)((max_rows + 3) / 2) * (size_t)(n_sets * 64) * 4 / 2; } // per job slot; a wave's matrix is two of them
 
 } // namespace mm2amd

@@ -26,10 +26,10 @@ constexpr int kSpliceClasses = 3, kFirstExt = kFirstSplice + kSpliceClasses * kD
 // + 2/3: up to 256, + 4/5: up to 512, targets up to kExtqMaxT.  MM2AMD_EXT_BY_TARGET=1 (A/B): round 3's ksw_ext.hip, the target across the lanes: + 0/1: targets up to 256,
 // + 2/3: up to 512, queries up to 512.
 constexpr int kExtClasses = 6, kFirstBand = kFirstExt + kExtClasses, kExtMaxQ = 512, kExtMaxT = 512, kExtqMaxT = 2048;
-// kFirstBand..: the banded gap-fill kernel (ksw_band.hip, round 6): + 0: a band of 128 diagonals (one register set), + 1: 256 diagonals (two).  A gap fill
-// of the streaming kernel's classes goes here when the score its length lets one expect would prove the band sufficient (ksw_band.hpp); what the
+// kFirstBand..: the banded gap-fill kernel (ksw_band.hip, round 6): + 0: a band of 128 diagonals (one register set), + 1: 256 diagonals (two), both for windows up to
+// 512 x 512; + 2: 512 diagonals (four sets), windows up to 1024 x 1024.  A gap fill goes here when the score its length lets one expect would prove the band sufficient (ksw_band.hpp); what the
 // kernel cannot prove is computed again in the wider band or as the full rectangle, so the choice is a matter of speed only.
-constexpr int kBandClasses = 2, kNTiers = kFirstBand + kBandClasses, kBandMaxQ = 512, kBandMaxT = 512;
+constexpr int kBandClasses = 3, kNTiers = kFirstBand + kBandClasses, kBandMaxSmall = 512, kBandMaxBig = 1024;
 constexpr int kHbmRing = kRingClasses - 1; // the last ring class keeps its state in HBM and takes any width
 constexpr int kFastMaxQ = 1024, kFastMaxTAny = 3072;
 constexpr int kOrderBuckets = 256; // cost buckets per class
@@ -42,6 +42,7 @@ struct KswClassCtx { // uniform over a batch
 	// the banded kernel: on / off; the scores the acceptance test works with; the share of the best possible score (sc_max per base of the shorter side, in
 	// 1/256) a window is EXPECTED to reach -- the classes are chosen with it, the kernel's test uses the score actually found
 	int band_on = 0, sc_max = 0, gq = 0, ge = 0, gq2 = 0, ge2 = 0, band_rho256 = 128;
+	int band_max = kBandMaxBig; // windows up to this on either side may try a band (512: the four-set class is off, A/B)
 };
 struct KswClassOut {
 	int tier, cb;            // launch class, cost bucket (higher = launched earlier)
@@ -91,14 +92,16 @@ MM2_HD inline bool ksw_ext_eligible(const KswJob &j, bool scoring_ok, int max_t,
 	return ksw_band_cannot_bind(j);
 }
 MM2_HD inline int ksw_pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
-MM2_HD inline int ksw_band_sets(int tier) { return tier == kFirstBand ? 1 : tier == kFirstBand + 1 ? 2 : 0; }
-// the narrowest band class whose acceptance test the window's expected score passes: 1 or 2 register sets, 0 = none (the rectangle is the better bet)
+MM2_HD inline int ksw_band_sets(int tier) { return tier == kFirstBand ? 1 : tier == kFirstBand + 1 ? 2 : tier == kFirstBand + 2 ? 4 : 0; }
+MM2_HD inline int ksw_band_class(int sets) { return sets == 4 ? 2 : sets - 1; } // register sets -> class index
+// the narrowest band class whose acceptance test the window's expected score passes: 1, 2 or 4 register sets, 0 = none (the rectangle is the better bet)
 MM2_HD inline int ksw_band_choice(const KswJob &j, const KswClassCtx &C)
 {
-	if (!C.band_on || j.qlen > kBandMaxQ || j.tlen > kBandMaxT) return 0;
+	if (!C.band_on || j.qlen > C.band_max || j.tlen > C.band_max) return 0;
+	const bool big = j.qlen > kBandMaxSmall || j.tlen > kBandMaxSmall;
 	const int mn = j.qlen < j.tlen ? j.qlen : j.tlen, D = j.tlen - j.qlen;
 	const int expect = (int)(((int64_t)C.band_rho256 * C.sc_max * mn) >> 8) - band_gap_cost(D < 0 ? -D : D, C.gq, C.ge, C.gq2, C.ge2);
-	for (int nb = 1; nb <= kBandClasses; ++nb)
+	for (int nb = big ? 4 : 1; nb <= (big ? 4 : 2); nb *= 2) // (a window of at most 512 x 512 that 256 diagonals are not expected to do for: the rectangle there is two sweeps of the four sets)
 		if (band_holds_corners(j.qlen, j.tlen, 128 * nb) && expect > band_outside_bound(j.qlen, j.tlen, 128 * nb, C.sc_max, C.gq, C.ge, C.gq2, C.ge2)) return nb;
 	return 0;
 }
@@ -113,7 +116,7 @@ MM2_HD inline void ksw_classify(const KswJob &j, const KswClassCtx &C, KswClassO
 	       o.fast || o.xfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.tlen + 63) & ~63) :
 	       o.sfast ? (size_t)(j.qlen + j.tlen - 1) * (size_t)((j.qlen + 63) & ~63) : ksw_dir_bytes(j.qlen, j.tlen, splice ? -1 : j.w);
 	const int band_sets = o.fast ? ksw_band_choice(j, C) : 0;
-	if (band_sets) o.tier = kFirstBand + band_sets - 1, o.db = (size_t)(j.qlen + j.tlen - 1) * (size_t)(64 * band_sets);
+	if (band_sets) o.tier = kFirstBand + ksw_band_class(band_sets), o.db = (size_t)(j.qlen + j.tlen - 1) * (size_t)(64 * band_sets);
 	else if (o.fast) o.tier = ksw_fast_tier(j);
 	else if (o.xfast && C.ext_by_target) o.tier = kFirstExt + (j.tlen > 256 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);
 	else if (o.xfast) o.tier = kFirstExt + (j.qlen > 256 ? 4 : j.qlen > 128 ? 2 : 0) + ((j.flag & KSW_RIGHT) ? 1 : 0);

@@ -88,11 +88,12 @@ struct KswLaunch {
 	// *n_list (read by the kernel) says how many there are -- the banded kernel's rejects, re-run without a host round trip.
 	const uint32_t *list = nullptr;
 	const int32_t *n_list = nullptr;
-	// The banded kernel's two ways out for a window whose band it could not prove sufficient: a wider band (widen_W diagonals) or the full rectangle.
-	// Entries are list_base + the job's index in this launch, i.e. positions in the batch's launch order.
-	uint32_t *widen_list = nullptr, *retry_list = nullptr;
-	int32_t *widen_count = nullptr, *retry_count = nullptr;
-	int32_t widen_W = 0;
+	// The banded kernel's ways out for a window whose band it could not prove sufficient: a wider band (widen_W diagonals; widen_slots = the base slots a wave of
+	// the launch that takes the list holds per sequence) or the full rectangle -- retry_list for windows of at most retry_max x retry_max (the streaming kernel's
+	// largest class), big_list for the others (the strip kernel).  Entries are list_base + the job's index in this launch, i.e. positions in the batch's launch order.
+	uint32_t *widen_list = nullptr, *retry_list = nullptr, *big_list = nullptr;
+	int32_t *widen_count = nullptr, *retry_count = nullptr, *big_count = nullptr;
+	int32_t widen_W = 0, widen_slots = 0, retry_max = 512;
 	uint32_t list_base = 0;
 	unsigned long long *band_acc = nullptr; // [0] += score found + the corners' unavoidable gap, [1] += best possible score, over the windows a first attempt computed
 	int32_t band_reject = 0;       // tests: 1 = no result of this launch is accepted, 2 = ... and none goes to the wider band

@@ -87,14 +87,17 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 	uint16_t *const bV = s_b[wave_in_block][0], *const bX = s_b[wave_in_block][1], *const bX2 = s_b[wave_in_block][2];
 	uint8_t *const tbA = (uint8_t *)bV, *const tbB = tbA + 3 * QCAP; // after the DP (each job's target is at most 3 * QCAP bases)
 
+	const int n_avail = L.n_list ? __builtin_amdgcn_readfirstlane(*L.n_list) : L.n_jobs;
 	for (;;) {
 		int pid = 0;
 		if (lane == 0) pid = atomicAdd(L.counter, 1);
 		pid = __builtin_amdgcn_readfirstlane(pid);
-		if (2 * pid >= L.n_jobs) break;
-		const int jidA = 2 * pid, jidB = 2 * pid + 1;
-		const bool hasB = jidB < L.n_jobs;
-		const KswJob JA = L.jobs[jidA], JB = L.jobs[hasB ? jidB : jidA];
+		if (2 * pid >= n_avail) break;
+		const bool hasB = 2 * pid + 1 < n_avail;
+		// (a launch that works off a list -- the banded kernel's rejects, ksw_dev.hpp -- finds its jobs through it)
+		const int jidA = L.list ? __builtin_amdgcn_readfirstlane((int)L.list[2 * pid]) : 2 * pid;
+		const int jidB = !hasB ? jidA : L.list ? __builtin_amdgcn_readfirstlane((int)L.list[2 * pid + 1]) : 2 * pid + 1;
+		const KswJob JA = L.jobs[jidA], JB = L.jobs[jidB];
 		const int qlenA = JA.qlen, tlenA = JA.tlen, qlenB = hasB ? JB.qlen : 0, tlenB = hasB ? JB.tlen : 0;
 		const int tmax = tlenA > tlenB ? tlenA : tlenB, qmax = qlenA > qlenB ? qlenA : qlenB;
 		const int ncol = (tmax + 63) & ~63;  // columns of the shared direction matrix: dword (r >> 1) * ncol + t = [row r: A, B][row r + 1: A, B]
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(256, WAVES) ksw_gapfill_kernel(KswLaunch L)
 
 void ksw_gapfill_launch(const KswLaunch &L, int n_slots, int qcap, void *stream)
 {
-	if (L.n_jobs <= 0) return;
+	if (L.n_jobs <= 0 && !L.n_list) return;
 	const int n_blocks = (n_slots + 3) / 4;
 	hipStream_t s = (hipStream_t)stream;
 	if (qcap <= 512) hipLaunchKernelGGL((ksw_gapfill_kernel<512, 6>), dim3(n_blocks), dim3(256), 0, s, L);

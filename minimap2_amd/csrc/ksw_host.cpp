@@ -46,6 +46,7 @@ void ksw_ext_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, voi
 void ksw_extq_launch(const KswLaunch &L, int n_slots, bool right, int n_sets, void *stream);              // ksw_extq.hip
 void ksw_band_launch(const KswLaunch &L, int n_slots, int n_sets, void *stream);    // ksw_band.hip
 int ksw_band_waves(int n_sets);
+int ksw_band_slots(int n_sets);
 size_t ksw_band_slot_bytes(int n_sets, int max_rows);
 
 void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, const uint8_t *d_tpool, const uint32_t *d_S,
@@ -94,6 +95,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	for (int t = 0; t < sc.m * sc.m; ++t) cctx.sc_max = std::max<int>(cctx.sc_max, sc.mat[t]);
 	cctx.gq = sc.q, cctx.ge = sc.e, cctx.gq2 = sc.q2, cctx.ge2 = sc.e2;
 	cctx.band_rho256 = (int)(256.0 * (rho_env >= 0 ? rho_env : band_rho));
+	if (getenv("MM2AMD_BAND_MAX")) cctx.band_max = atoi(getenv("MM2AMD_BAND_MAX")); // A/B: 512 = no four-set class (windows beyond 512 x 512 as rectangles, as before it existed)
 	const int band_reject = getenv("MM2AMD_BAND_REJECT") ? atoi(getenv("MM2AMD_BAND_REJECT")) : 0; // tests: 1 = every first attempt fails (the lists and their launches run), 2 = ... straight to the rectangle
 	auto r16 = [](int v) { return (v + 15) / 16 * 16; };
 	struct ClassStat { size_t slot_bytes = 16, tmp_cap = 16; int max_ring = 64, max_Q16 = 16, max_rows = 1, max_ncol = 64; double alg_bytes = 0, cells = 0, sum_len = 0; };
@@ -188,9 +190,9 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_res.ensure(n);
-	d_counter.ensure(128 + 8);
+	d_counter.ensure(128 + 16);
 	static_assert(kNTiers <= 128, "one queue counter per launch class");
-	int32_t *const d_band_ctl = d_counter.p + 128; // the banded kernel's lists: [0] windows for the wider band, [1] for the rectangle, [2] / [3] the queue heads of the launches that take them, [4..7] two 64-bit sums over the windows the first attempts computed: score found (less the corners' gap), best possible score
+	int32_t *const d_band_ctl = d_counter.p + 128; // the banded kernel's lists: [0] windows for the wider band, [1] for the rectangle, [2] / [3] the queue heads of the launches that take them, [4..7] two 64-bit sums over the windows the first attempts computed: score found (less the corners' gap), best possible score, [8] windows beyond 512 x 512 for the rectangle (the strip kernel), [9] their launch's queue head
 	d_cursor.ensure(2);
 	KswScoring sc_dev = sc; // the junction entries travel with the jobs
 	sc_dev.juncs = nullptr, sc_dev.tbytes = nullptr;
@@ -207,7 +209,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	for (int attempt = 0;; ++attempt) {
 		if (pool_cap >= (1ull << 32)) throw std::runtime_error("[mm2amd] ksw batch too large for a 32-bit CIGAR pool; split the batch");
 		d_cigar.ensure(pool_cap);
-		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, (128 + 8) * sizeof(int32_t), stream));
+		HIP_CHECK(hipMemsetAsync(d_counter.p, 0, (128 + 16) * sizeof(int32_t), stream));
 		HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 2 * sizeof(uint32_t), stream));
 		// size every launch class first.  The launches form two groups that run CONCURRENTLY: the register-resident kernels back to
 		// back on the caller's stream, the lane-exact kernel's classes back to back on a side stream of higher priority (a few long
@@ -303,23 +305,27 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		// The banded kernel's rejects are computed again by launches that read their job lists on the device: band-128 rejects whose score would pass in a band of
 		// 256 diagonals by the two-set instantiation, everything else by the streaming kernel's eight-set class (the full rectangle; query and target <= 512).
 		// Their grids are sized for the most the lists can hold; a wave that finds its list empty leaves at once.
-		struct ListPlan { size_t n_slots = 0, slot_bytes = 16, tmp_cap = 16; } widen_plan, retry_plan;
-		const size_t n_band1 = plan[kFirstBand].end - plan[kFirstBand].beg, n_band2 = plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg;
-		if (n_band1 + n_band2) {
-			d_band_lists.ensure(2 * (n_band1 + n_band2) + 2);
+		// The four-set class (windows beyond 512 x 512) hands its rejects to the strip kernel; its launch gets a wave per eight windows of the class (rejects are
+		// the exception, and a matrix slot of this kernel is 2 MB per job).
+		struct ListPlan { size_t n_slots = 0, slot_bytes = 16, tmp_cap = 16; } widen_plan, retry_plan, big_plan;
+		const size_t n_band1 = plan[kFirstBand].end - plan[kFirstBand].beg, n_band2 = plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg, n_band4 = plan[kFirstBand + 2].end - plan[kFirstBand + 2].beg;
+		const size_t n_band = n_band1 + n_band2; // lists: [0, n_band] wider band, [n_band + 1, 2 n_band + 1] rectangle, [2 n_band + 2, ...] rectangle of the big ones
+		if (n_band + n_band4) {
+			d_band_lists.ensure(2 * n_band + n_band4 + 3);
 			const int rows_max = std::max(cls[kFirstBand].max_rows, cls[kFirstBand + 1].max_rows);
-			const size_t tmp_max = 3 * (std::max(cls[kFirstBand].tmp_cap, cls[kFirstBand + 1].tmp_cap) + 2);
-			auto size_list = [&](ListPlan &lp, size_t n_max, size_t slot_bytes, int blocks_per_cu) {
+			auto size_list = [&](ListPlan &lp, size_t n_max, size_t slot_bytes, int blocks_per_cu, size_t tmp_cap) {
 				if (n_max == 0) return;
-				lp.slot_bytes = (slot_bytes + 255) / 256 * 256, lp.tmp_cap = tmp_max;
+				lp.slot_bytes = (slot_bytes + 255) / 256 * 256, lp.tmp_cap = 3 * (tmp_cap + 2);
 				lp.n_slots = std::min<size_t>((n_max + 1) / 2, (size_t)n_cu * blocks_per_cu * 4);
 				lp.n_slots = std::min<size_t>(lp.n_slots, std::max<size_t>(1, group_budget / (lp.slot_bytes * 2)));
 				if (max_slots_env > 0) lp.n_slots = std::min<size_t>(lp.n_slots, (size_t)max_slots_env);
 				lp.n_slots = (lp.n_slots + 3) / 4 * 4;
 				need_dir_g[0] = std::max(need_dir_g[0], lp.n_slots * lp.slot_bytes * 2), need_tmp_g[0] = std::max(need_tmp_g[0], lp.n_slots * lp.tmp_cap * 2);
 			};
-			size_list(widen_plan, n_band1, ksw_band_slot_bytes(2, rows_max), ksw_band_waves(2));
-			size_list(retry_plan, n_band1 + n_band2, ksw_stream_slot_bytes(8), ksw_stream_waves(8));
+			const size_t tmp_small = std::max(cls[kFirstBand].tmp_cap, cls[kFirstBand + 1].tmp_cap);
+			size_list(widen_plan, n_band1, ksw_band_slot_bytes(2, rows_max), ksw_band_waves(2), tmp_small);
+			size_list(retry_plan, n_band, ksw_stream_slot_bytes(8), ksw_stream_waves(8), tmp_small);
+			size_list(big_plan, n_band4 ? std::max<size_t>(128, n_band4 / 4) : 0, (size_t)(cls[kFirstBand + 2].max_rows + 3) * (size_t)cls[kFirstBand + 2].max_ncol, fast_waves(4), cls[kFirstBand + 2].tmp_cap);
 		}
 		for (size_t &need_dir : need_dir_g)
 			if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation
@@ -382,9 +388,9 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			L.single_affine = single_affine, L.splice = splice;
 			const int band_sets = ksw_band_sets(tier);
 			if (band_sets) { // what this launch cannot prove goes onto the lists (positions in the batch's launch order)
-				const size_t n_band = (plan[kFirstBand].end - plan[kFirstBand].beg) + (plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg);
-				L.widen_list = band_sets == 1 ? d_band_lists.p : nullptr, L.widen_count = d_band_ctl + 0, L.widen_W = 256;
+				L.widen_list = band_sets == 1 ? d_band_lists.p : nullptr, L.widen_count = d_band_ctl + 0, L.widen_W = 256, L.widen_slots = ksw_band_slots(2);
 				L.retry_list = d_band_lists.p + n_band + 1, L.retry_count = d_band_ctl + 1, L.list_base = (uint32_t)P.beg, L.band_reject = band_reject;
+				L.big_list = d_band_lists.p + 2 * n_band + 2, L.big_count = d_band_ctl + 8, L.retry_max = kBandMaxSmall;
 				L.band_acc = (unsigned long long *)(d_band_ctl + 4);
 			}
 			if (prof) prof->begin(stream_);
@@ -398,28 +404,29 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			else ksw_extd2_launch(L, (int)P.n_slots, P.wpb, P.team, stream_);
 			static const char *kSpliceNames[kSpliceClasses] = { "ksw_splice_kernel<2,pair>", "ksw_splice_kernel<4,pair>", "ksw_splice_kernel<4,strips>" };
 			static const char *kStreamNames[2] = { "ksw_stream_kernel<4>[t256]", "ksw_stream_kernel<8>[t512]" };
-			static const char *kBandNames[kBandClasses] = { "ksw_band_kernel<1>[w128]", "ksw_band_kernel<2>[w256]" };
-			static const char *kBandCells[kBandClasses] = { "band_cells_computed<1>", "band_cells_computed<2>" }; // rows x lanes of the band: what the VALU roofline counts (units of the launch itself: the rectangles' cells)
-			if (prof && band_sets) prof->add_units(kBandCells[band_sets - 1], cls[tier].sum_len * 64.0 * band_sets);
-			if (prof) prof->end(stream_, band_sets ? kBandNames[band_sets - 1] : n_stream ? kStreamNames[tier] : tier >= kFirstExt ? (ext_by_target ? kExtNames[(tier - kFirstExt) & 3] : kExtqNames[tier - kFirstExt]) : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
+			static const char *kBandNames[kBandClasses] = { "ksw_band_kernel<1>[w128]", "ksw_band_kernel<2>[w256]", "ksw_band_kernel<4>[w512]" };
+			static const char *kBandCells[kBandClasses] = { "band_cells_computed<1>", "band_cells_computed<2>", "band_cells_computed<4>" }; // rows x lanes of the band: what the VALU roofline counts (units of the launch itself: the rectangles' cells)
+			if (prof && band_sets) prof->add_units(kBandCells[ksw_band_class(band_sets)], cls[tier].sum_len * 64.0 * band_sets);
+			if (prof) prof->end(stream_, band_sets ? kBandNames[ksw_band_class(band_sets)] : n_stream ? kStreamNames[tier] : tier >= kFirstExt ? (ext_by_target ? kExtNames[(tier - kFirstExt) & 3] : kExtqNames[tier - kFirstExt]) : tier >= kFirstSplice ? kSpliceNames[(tier - kFirstSplice) / kDirClasses] : tier < kFirstExact ? kFastNames[tier] : P.hbm ? kRingNames[kHbmRing] : kRingNames[(tier - kFirstExact) / kDirClasses], P.alg_bytes, P.cells);
 		}
 		// ---- the banded kernel's rejects (the lists are complete when the stream gets here) ----
-		for (int which = 0; which < 2; ++which) {
-			const ListPlan &lp = which ? retry_plan : widen_plan;
+		for (int which = 0; which < 3; ++which) {
+			const ListPlan &lp = which == 2 ? big_plan : which ? retry_plan : widen_plan;
 			if (lp.n_slots == 0) continue;
-			const size_t n_band = (plan[kFirstBand].end - plan[kFirstBand].beg) + (plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg);
 			KswLaunch L;
 			L.jobs = d_jobs.p, L.res = d_res.p, L.n_jobs = 0;
-			L.list = which ? d_band_lists.p + n_band + 1 : d_band_lists.p, L.n_list = d_band_ctl + which, L.counter = d_band_ctl + 2 + which;
+			L.list = which == 2 ? d_band_lists.p + 2 * n_band + 2 : which ? d_band_lists.p + n_band + 1 : d_band_lists.p;
+			L.n_list = which == 2 ? d_band_ctl + 8 : d_band_ctl + which, L.counter = which == 2 ? d_band_ctl + 9 : d_band_ctl + 2 + which;
 			L.qpool = d_qpool, L.tpool = d_tpool, L.S = d_S;
 			L.cigar_pool = d_cigar.p, L.cigar_pool_cap = (uint32_t)pool_cap, L.cigar_cursor = d_cursor.p;
 			L.cigar_tmp = tmp_g[0], L.cigar_tmp_cap = (uint32_t)lp.tmp_cap, L.dir_pool = dir_g[0], L.slot_bytes = lp.slot_bytes;
 			L.ring = 64, L.max_Q16 = 16, L.sc = sc_dev;
 			if (!which) L.retry_list = d_band_lists.p + n_band + 1, L.retry_count = d_band_ctl + 1, L.list_base = 0, L.band_reject = band_reject > 1 ? band_reject : 0;
 			if (prof) prof->begin(stream);
-			if (which) ksw_stream_launch(L, (int)lp.n_slots, 8, stream);
+			if (which == 2) ksw_gapfill_launch(L, (int)lp.n_slots, 1024, stream);
+			else if (which) ksw_stream_launch(L, (int)lp.n_slots, 8, stream);
 			else ksw_band_launch(L, (int)lp.n_slots, 2, stream);
-			if (prof) prof->end(stream, which ? "ksw_stream_kernel<8>[band rejects]" : "ksw_band_kernel<2>[widened]", 0.0, 0.0);
+			if (prof) prof->end(stream, which == 2 ? "ksw_gapfill_kernel<1024>[band rejects]" : which ? "ksw_stream_kernel<8>[band rejects]" : "ksw_band_kernel<2>[widened]", 0.0, 0.0);
 		}
 		if (use_side) {
 			HIP_CHECK(hipEventRecord(ev_side_done, side));
@@ -431,20 +438,21 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		}
 		// (into PINNED memory: an asynchronous copy to pageable memory -- a stack array here until round 4 -- makes the runtime wait for the stream inside
 		// the call, spinning: the lane drivers spent the whole duration of the DP kernels on a core each, 1.2 core-seconds per step)
-		uint32_t *cursor = h_cursor.ensure(2 + 8);
+		uint32_t *cursor = h_cursor.ensure(2 + 16);
 		HIP_CHECK(hipMemcpyAsync(cursor, d_cursor.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (widen_plan.n_slots + retry_plan.n_slots) HIP_CHECK(hipMemcpyAsync(cursor + 2, d_band_ctl, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+		const bool any_band = widen_plan.n_slots + retry_plan.n_slots + big_plan.n_slots != 0;
+		if (any_band) HIP_CHECK(hipMemcpyAsync(cursor + 2, d_band_ctl, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
 		if (!resident) HIP_CHECK(hipMemcpyAsync(tr, d_res.p, n * sizeof(KswRes), hipMemcpyDeviceToHost, stream));
 		stream_wait(stream);
 		Trace::get().add(lane, "gpu:ksw", tt, Trace::now()); tt = Trace::now();
-		if (cursor[1] == 0 && widen_plan.n_slots + retry_plan.n_slots) { // how the band classes fared: counts for the caller, and the expected score share follows the accepted windows
-			band_stats.n_band1 += n_band1, band_stats.n_band2 += n_band2, band_stats.n_widened += cursor[2], band_stats.n_retried += cursor[3];
-			band_counters().n_band1 += n_band1, band_counters().n_band2 += n_band2, band_counters().n_widened += cursor[2], band_counters().n_retried += cursor[3];
+		if (cursor[1] == 0 && any_band) { // how the band classes fared: counts for the caller, and the expected score share follows the accepted windows
+			band_stats.n_band1 += n_band1, band_stats.n_band2 += n_band2, band_stats.n_band4 += n_band4, band_stats.n_widened += cursor[2], band_stats.n_retried += cursor[3], band_stats.n_retried_big += cursor[2 + 8];
+			band_counters().n_band1 += n_band1, band_counters().n_band2 += n_band2, band_counters().n_band4 += n_band4, band_counters().n_widened += cursor[2], band_counters().n_retried += cursor[3], band_counters().n_retried_big += cursor[2 + 8];
 			unsigned long long acc[2];
 			memcpy(acc, cursor + 2 + 4, sizeof acc);
 			const double got = (double)acc[0], best = (double)acc[1];
 			static const bool band_debug = getenv("MM2AMD_BAND_DEBUG") != nullptr;
-			if (band_debug) fprintf(stderr, "[mm2amd] band: %zu + %zu windows tried, %u widened, %u to the rectangle, score share %.3f (expected %.3f)\n", n_band1, n_band2, cursor[2], cursor[3], best > 0 ? got / best : 0.0, cctx.band_rho256 / 256.0);
+			if (band_debug) fprintf(stderr, "[mm2amd] band: %zu + %zu + %zu windows tried, %u widened, %u + %u to the rectangle, score share %.3f (expected %.3f)\n", n_band1, n_band2, n_band4, cursor[2], cursor[3], cursor[2 + 8], best > 0 ? got / best : 0.0, cctx.band_rho256 / 256.0);
 			if (best >= 100000.0) band_rho = std::min(1.0, std::max(0.05, 0.75 * band_rho + 0.25 * (got / best - 0.03)));
 		}
 		if (cursor[1] == 0 && resident) { *cigar_out = d_cigar.p, *n_cigar_out = cursor[0]; break; }

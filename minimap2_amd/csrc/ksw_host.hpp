@@ -54,7 +54,7 @@ struct KswRunner {
 	// the banded gap fill (ksw_band.hip): its two lists (windows for the wider band | for the rectangle), how its classes fared, and the share of the best
 	// possible score a window is expected to reach (starts at what 12 %-error reads give; follows the accepted windows of the batches before)
 	DevBuf<uint32_t> d_band_lists;
-	struct BandStats { unsigned long long n_band1 = 0, n_band2 = 0, n_widened = 0, n_retried = 0; } band_stats;
+	struct BandStats { unsigned long long n_band1 = 0, n_band2 = 0, n_band4 = 0, n_widened = 0, n_retried = 0, n_retried_big = 0; } band_stats;
 	double band_rho = 0.5;
 };
 

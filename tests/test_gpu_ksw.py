@@ -411,7 +411,7 @@ def _gap_cost(l, go, ge, go2, ge2):
     return 0 if l <= 0 else min(go + ge * l, go2 + ge2 * l)
 
 
-def _edge_walkers(rng, a, go, ge, go2, ge2, W):
+def _edge_walkers(rng, a, go, ge, go2, ge2, W, cap=512, stretch=(120, 260)):
     """windows whose best alignment runs along ONE diagonal off the corners' own: a gap of d target bases first, a perfect (or nearly perfect) stretch,
     a gap of d query bases last.  With d on the band's last diagonal the band must still find it; one further out it must notice that it cannot -- and with
     a perfect stretch the alignment outside scores exactly the bound the acceptance test uses (ksw_band.hpp): the test is strict, so that tie is a reject."""
@@ -419,10 +419,10 @@ def _edge_walkers(rng, a, go, ge, go2, ge2, W):
     for upper in (True, False):
         for off in (-2, -1, 0, 1, 3):
             for mut in (0, 3):
-                m = int(rng.integers(120, 260))
+                m = int(rng.integers(*stretch))
                 # D = 0 here: c = W / 4, diagonals [-W/2, W/2 - 1]; the first diagonal outside: W/2 above, W/2 + 1 below
                 d = (W // 2 if upper else W // 2 + 1) + off
-                if d + m > 512:
+                if d + m > cap:
                     continue
                 core = rng.integers(0, 4, m, dtype=np.uint8)
                 other = core.copy()
@@ -489,6 +489,64 @@ def test_banded_gap_fill_equals_the_unbanded_reference(preset, monkeypatch):
     monkeypatch.setenv("MM2AMD_NO_BAND", "1")  # the rectangles only: the A/B partner
     got, n = _band_delta(run)
     assert got == want and n["band128"] + n["band256"] == 0, n
+
+
+@pytest.mark.parametrize("preset", ["ont", "swap"])
+def test_banded_gap_fill_of_windows_beyond_512(preset, monkeypatch):
+    """The four-set class of ksw_band.hip: 512 diagonals for windows with a side in 513..1024 (what the strip kernel computed as rectangles of two to sixteen
+    256-column strips).  Accepted results against the reference's unbanded ksw_extd2_sse; walkers on and next to the band's last diagonal; the class's way out
+    -- a list-fed launch of the strip kernel -- with every first attempt rejected and with few persistent waves; and the class switched off."""
+    import minimap2_amd as mm
+    a, b, go, ge, go2, ge2 = PRESETS[preset]
+    mat = ts_mat(a, b, 1, 0)
+    rng = np.random.default_rng(977)
+    jobs = []
+    for it in range(120):
+        kind = it % 6
+        L = int(rng.integers(400, 1025))
+        if kind == 0:   # unrelated sequences: nothing provable
+            q, t = rng.integers(0, 4, L, dtype=np.uint8), rng.integers(0, 4, int(rng.integers(513, 1025)), dtype=np.uint8)
+        elif kind == 1:  # a long indel: the corners' diagonals far apart
+            q, t = random_pair(rng, L, float(rng.choice([0.02, 0.12])), 0.0, int(rng.choice([90, -90, 250, -250, 400, -400, 500])))
+        else:
+            q, t = random_pair(rng, L, float(rng.choice([0.0, 0.03, 0.08, 0.12, 0.2, 0.35])), float(rng.choice([0, 0, 0.03])), int(rng.choice([0, 0, 0, 8, -8, 60, -60])))
+        q, t = q[:1024], t[:1024]
+        if len(q) <= 512 and len(t) <= 512:
+            continue
+        jobs.append((q, t, 30001, 400, -1, 0x08))
+    for ql, tl in ((1024, 1024), (513, 1), (1, 513), (1024, 513), (513, 1024), (1024, 2), (700, 1024)):  # the corners of the class
+        q, t = random_pair(rng, max(ql, tl), 0.05)
+        q, t = np.resize(q, ql), np.resize(t, tl)
+        jobs.append((q, t, 30001, 400, -1, 0x08))
+    walkers = _edge_walkers(rng, a, go, ge, go2, ge2, 512, cap=1024, stretch=(300, 760))
+    assert len(walkers) >= 12
+    jobs += walkers
+    have_ref = os.path.exists(reflib.REF_SO)
+    want = [(reflib.ref_extd2 if have_ref else ora_extd2)(q, t, mat, go, ge, go2, ge2, w, zd, eb, fl) for (q, t, w, zd, eb, fl) in jobs]
+
+    def run():
+        return mm.ksw_extd2_batch(jobs, mat, go, ge, go2, ge2)
+
+    got, n = _band_delta(run)
+    assert got == want
+    assert n["band512"] > len(jobs) // 3 and n["band128"] + n["band256"] == 0, n
+    monkeypatch.setenv("MM2AMD_BAND_RHO", "1.0")  # every window tries the band; the hopeless ones come back through the strip kernel's list
+    got, n = _band_delta(run)
+    assert got == want
+    assert n["band512"] >= len(jobs) - 8 and n["rectangle_big"] > 0, n
+    monkeypatch.setenv("MM2AMD_KSW_MAX_SLOTS", "4")
+    got, n = _band_delta(run)
+    assert got == want
+    monkeypatch.setenv("MM2AMD_BAND_REJECT", "1")  # nothing accepted: every window through the list-fed strip kernel
+    got, n = _band_delta(run)
+    assert got == want
+    assert n["rectangle_big"] == n["band512"] > 0, n
+    monkeypatch.delenv("MM2AMD_BAND_REJECT")
+    monkeypatch.delenv("MM2AMD_KSW_MAX_SLOTS")
+    monkeypatch.delenv("MM2AMD_BAND_RHO")
+    monkeypatch.setenv("MM2AMD_BAND_MAX", "512")  # the class off: the A/B partner
+    got, n = _band_delta(run)
+    assert got == want and n["band512"] == 0, n
 
 
 @pytest.mark.parametrize("preset", ["ont", "hifi", "swap"])

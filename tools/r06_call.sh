@@ -40,6 +40,13 @@ rank8trace) MM2AMD_TRACE=$O/r06_rank8_trace_$V.tsv timeout 600 python bench.py -
 repsplit) MM2AMD_KSW_SPLIT_RINGS=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_split_$V.json 2> $O/r06_bench_repeats_split_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().strip().split('\n')[-1]); print('repeats, ring classes apart', d['value'], d['ms_per_step'])" ;;
+srsweep) # short reads are host-bound: lanes / sub-batch size
+       for cfg in "8 100000000" "8 40000000" "8 25000000" "12 25000000" "16 15000000"; do
+         set -- $cfg
+         MM2AMD_LANES=$1 MM2AMD_SUBBATCH_BASES=$2 timeout 600 python bench.py --preset sr --reads 1000000 --steps 3 --warmup 1 --no-cpu-baseline --timed-only > $O/r06_bench_sr_l$1_s$2_$V.json 2> $O/r06_bench_sr_l$1_s$2_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_sr_l$1_s$2_$V.json').read().strip().split('\n')[-1]); print('sr lanes $1 sub-batch bases $2:', d['value'], d['ms_per_step'], d['config']['host_cpu_s_per_step'])"
+       done ;;
 rmqcap) # heavy reads' long-join re-chaining on the host's tree instead of one wavefront walking 100 000 anchors
        for cap in 131072 30000 8000; do
          MM2AMD_RMQ_DEV_MAX_ANCHORS=$cap timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_cap${cap}_$V.json 2> $O/r06_bench_repeats_cap${cap}_$V.log

@@ -10,7 +10,7 @@ pids=()
 for f in align backend_hip capi_common capi_index capi_kernels capi_map chain_host device_ctx flat_index format hits ksw_host ksw_ll mapper options rmq_chain tables; do
   g++ $FLAGS -c $CSRC/$f.cpp -o $OUT/$f.o & pids+=($!)
 done
-for f in seed_chain index_build device_sort ksw_extd2 ksw_gapfill ksw_stream ksw_splice ksw_ext region_finish region_dev ksw_order; do
+for f in seed_chain index_build device_sort ksw_extd2 ksw_gapfill ksw_stream ksw_band ksw_splice ksw_ext ksw_extq region_finish region_dev ksw_order; do
   g++ $FLAGS -x c++ -c $CSRC/$f.hip -o $OUT/$f.hip.o & pids+=($!)
 done
 g++ $FLAGS -c $EMU/wave_emu.cpp -o $OUT/wave_emu.o & pids+=($!)
