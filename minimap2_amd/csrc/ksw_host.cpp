@@ -305,8 +305,8 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		// The banded kernel's rejects are computed again by launches that read their job lists on the device: band-128 rejects whose score would pass in a band of
 		// 256 diagonals by the two-set instantiation, everything else by the streaming kernel's eight-set class (the full rectangle; query and target <= 512).
 		// Their grids are sized for the most the lists can hold; a wave that finds its list empty leaves at once.
-		// The four-set class (windows beyond 512 x 512) hands its rejects to the strip kernel; its launch gets a wave per eight windows of the class (rejects are
-		// the exception, and a matrix slot of this kernel is 2 MB per job).
+		// The four-set class (windows beyond 512 x 512) hands its rejects to the strip kernel; its launch gets a wave per four windows of the class (a matrix slot of
+		// this kernel is 2 MB per job; with a wave per sixteen the repeats workload's 6 % rejects took 86 ms per step, call v18).
 		struct ListPlan { size_t n_slots = 0, slot_bytes = 16, tmp_cap = 16; } widen_plan, retry_plan, big_plan;
 		const size_t n_band1 = plan[kFirstBand].end - plan[kFirstBand].beg, n_band2 = plan[kFirstBand + 1].end - plan[kFirstBand + 1].beg, n_band4 = plan[kFirstBand + 2].end - plan[kFirstBand + 2].beg;
 		const size_t n_band = n_band1 + n_band2; // lists: [0, n_band] wider band, [n_band + 1, 2 n_band + 1] rectangle, [2 n_band + 2, ...] rectangle of the big ones
@@ -325,7 +325,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 			const size_t tmp_small = std::max(cls[kFirstBand].tmp_cap, cls[kFirstBand + 1].tmp_cap);
 			size_list(widen_plan, n_band1, ksw_band_slot_bytes(2, rows_max), ksw_band_waves(2), tmp_small);
 			size_list(retry_plan, n_band, ksw_stream_slot_bytes(8), ksw_stream_waves(8), tmp_small);
-			size_list(big_plan, n_band4 ? std::max<size_t>(128, n_band4 / 4) : 0, (size_t)(cls[kFirstBand + 2].max_rows + 3) * (size_t)cls[kFirstBand + 2].max_ncol, fast_waves(4), cls[kFirstBand + 2].tmp_cap);
+			size_list(big_plan, n_band4 ? std::max<size_t>(256, n_band4 / 2) : 0, (size_t)(cls[kFirstBand + 2].max_rows + 3) * (size_t)cls[kFirstBand + 2].max_ncol, fast_waves(4), cls[kFirstBand + 2].tmp_cap);
 		}
 		for (size_t &need_dir : need_dir_g)
 			if (need_dir > ((size_t)1 << 30)) need_dir = (need_dir + ((size_t)2 << 30) - 1) >> 31 << 31; // big scratch grows in 2 GB steps: a slightly larger batch must not cost a 30 GB reallocation

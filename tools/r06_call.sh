@@ -40,6 +40,21 @@ rank8trace) MM2AMD_TRACE=$O/r06_rank8_trace_$V.tsv timeout 600 python bench.py -
 repsplit) MM2AMD_KSW_SPLIT_RINGS=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_split_$V.json 2> $O/r06_bench_repeats_split_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().strip().split('\n')[-1]); print('repeats, ring classes apart', d['value'], d['ms_per_step'])" ;;
+abband4) # windows beyond 512 x 512 in a band of 512 diagonals (the four-set class) against the strip kernel's rectangles: the headline and the repeats workload
+       for m in band4 noband4; do
+         if [ $m = noband4 ]; then export MM2AMD_BAND_MAX=512; else unset MM2AMD_BAND_MAX; fi
+         for w in hifi repeats; do
+           wl=""; [ $w = repeats ] && wl="--workload repeats"
+           MM2AMD_BAND_DEBUG=1 timeout 900 python bench.py $wl --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_${w}_${m}_$V.json 2> $O/r06_bench_${w}_${m}_$V.log
+           grep -h "band:" $O/r06_bench_${w}_${m}_$V.log | tail -2 | cut -c1-200
+           python - <<P
+import json
+d=json.loads(open('$O/r06_bench_${w}_${m}_$V.json').read().strip().split('\n')[-1]); r=d['roofline']; u=r.get('unoverlapped_ms') or {}
+print('$w $m', d['value'], d['ms_per_step'], 'unoverlapped', r.get('unoverlapped_step_ms'), {k: v for k, v in u.items() if k.startswith('ksw_band') or k.startswith('ksw_gapfill') or k.startswith('ksw_stream')})
+print('    ', d['config'].get('banded_gap_fill'))
+P
+         done
+       done; unset MM2AMD_BAND_MAX ;;
 srsweep) # short reads are host-bound: lanes / sub-batch size
        for cfg in "8 100000000" "8 40000000" "8 25000000" "12 25000000" "16 15000000"; do
          set -- $cfg
