@@ -188,6 +188,27 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 	}
 	}
 
+	if (getenv("MM2AMD_KSW_CLASS_DEBUG")) { // diagnostics: what each launch class of this batch holds; the lane-exact classes by kind of job
+		stream_wait(stream);
+		for (int t = 0; t < kNTiers; ++t) {
+			const size_t nt = tier_beg[t + 1] - tier_beg[t];
+			if (!nt) continue;
+			fprintf(stderr, "[mm2amd] ksw class %d: %zu jobs, longest %zu rows, mean %.0f rows, %.3g cells, ring %d\n", t, nt, cls[t].tmp_cap, cls[t].sum_len / (double)nt, cls[t].cells, cls[t].max_ring);
+			if (t < kFirstExact || t >= kFirstSplice) continue;
+			std::vector<KswJob> hj(nt);
+			HIP_CHECK(hipMemcpy(hj.data(), d_jobs.p + tier_beg[t], nt * sizeof(KswJob), hipMemcpyDeviceToHost));
+			struct Kind { size_t n = 0; double rows = 0; int longest = 0, max_q = 0, max_t = 0; } kinds[6];
+			static const char *names[6] = { "extension, band cannot bind, query <= 512", "extension, band cannot bind, longer", "extension, band binds", "gap fill, band binds", "gap fill, too long", "other" };
+			for (const KswJob &j : hj) {
+				const int f = j.flag & 0x1fff;
+				const bool ext = f == KSW_EXTZ_ONLY || f == (KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR), nobind = ksw_band_cannot_bind(j);
+				Kind &k = kinds[ext ? (nobind ? (j.qlen <= 512 ? 0 : 1) : 2) : f == KSW_APPROX_MAX ? (nobind ? 4 : 3) : 5];
+				++k.n, k.rows += j.qlen + j.tlen, k.longest = std::max(k.longest, j.qlen + j.tlen), k.max_q = std::max(k.max_q, j.qlen), k.max_t = std::max(k.max_t, j.tlen);
+			}
+			for (int k = 0; k < 6; ++k)
+				if (kinds[k].n) fprintf(stderr, "[mm2amd]     %-44s %7zu jobs, mean %6.0f rows, longest %6d, longest query %6d, target %6d\n", names[k], kinds[k].n, kinds[k].rows / kinds[k].n, kinds[k].longest, kinds[k].max_q, kinds[k].max_t);
+		}
+	}
 	Trace::get().add(lane, "host:ksw-order", tt, Trace::now()); tt = Trace::now();
 	d_res.ensure(n);
 	d_counter.ensure(128 + 16);

@@ -74,7 +74,7 @@ def main():
             asm = open(tmp.name).read()
         for name, body in kernels_of(asm):
             dem = subprocess.run(["c++filt", name], stdout=subprocess.PIPE).stdout.decode().strip()
-            m = re.search(r"(ksw_\w+_kernel)<(\d+), *(\d+)>", dem)
+            m = re.search(r"(ksw_\w+_kernel)<(\d+), *(\d+)(?:, *\d+)?>", dem)  # (the banded kernel has a third argument: the window size its LDS arrays are laid out for)
             if not m:
                 continue
             # register sets per row: the streaming kernel's first template argument; the strip kernel always sweeps four sets of 64 columns
