@@ -1,3 +1,4 @@
+import os
 """SQ counters per kernel family (one rocprofv3 --pmc pass; counters given on the command line).
     python tools/pmc_sq.py SQ_WAVE_CYCLES SQ_INSTS_VALU ... [--reads N]"""
 import glob, os, sqlite3, subprocess, sys
@@ -26,7 +27,7 @@ for kn, cn, v in db.execute("select %s, %s, sum(%s) from counters_collection gro
 for k in sorted(res):
     print(k, " ".join("%s=%.6g" % (c, res[k].get(c, 0)) for c in args))
 import json
-json.dump({"cmd": "MM2AMD_LANES=1 rocprofv3 --pmc %s --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --reads %s" % (" ".join(args), reads),
+json.dump({"commit": os.environ.get("MM2AMD_COMMIT"), "cmd": "MM2AMD_LANES=1 rocprofv3 --pmc %s --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --reads %s" % (" ".join(args), reads),
            "note": "sums over all dispatches of a kernel; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles per wave (MI355X_MICROARCH.md)", "kernels": res},
           open(os.path.join(ROOT, "gpurun_out", "pmc_sq_%s.json" % os.environ.get("PMC_SQ_TAG", "last")), "w"), indent=1, sort_keys=True)
 subprocess.run(["rm", "-rf", out])
