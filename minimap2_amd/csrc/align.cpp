@@ -799,6 +799,7 @@ void Aligner::plan_region(ReadAlign &ra, RegionTask &t)
 
 	// the windows, in the order the reference aligns them (align.c:779-890)
 	t.win.clear();
+	t.win.reserve(4); // (left extension, a gap fill or two, right extension: one allocation instead of the growth steps 1, 2, 4 -- a short read's whole plan)
 	t.has_left = t.has_right = false;
 	if (qs > 0 && rs > 0) {
 		Window w; w.kind = W_LEFT, w.qs = qs0, w.qe = qs, w.rs = rs0, w.re = rs, w.bw = bw_, w.anchor_i = 0;

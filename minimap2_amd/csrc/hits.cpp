@@ -35,7 +35,8 @@ void gen_regs(uint32_t hash, int qlen, const uint64_t *u, int n_u, const Anchor 
 {
 	out.clear();
 	if (n_u <= 0) return;
-	std::vector<Anchor> z(n_u); // x: the sort key; y: first anchor << 32 | anchors
+	thread_local std::vector<Anchor> z; // x: the sort key; y: first anchor << 32 | anchors  (kept per thread: a short read has a chain or two, and this ran three times per read pair)
+	z.resize(n_u);
 	for (int i = 0, k = 0; i < n_u; k += (int32_t)u[i], ++i) z[i].x = hr_chain_key(u[i], a[k], hash), z[i].y = (uint64_t)k << 32 | (uint32_t)u[i];
 	sort_by_x(z.data(), z.data() + n_u);
 	out.resize(n_u);
@@ -319,7 +320,8 @@ void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, c
 	int before[2] = {0, 0}, total = 0; // bases of the fragment before a segment; all of them
 	for (int s = 0; s < n_segs; ++s) before[s] = total, total += qlens[s];
 	const size_t n_chain = regs0.size();
-	std::vector<int32_t> on_seg[2]; // anchors of every fragment chain on the segment
+	thread_local std::vector<int32_t> on_seg[2]; // anchors of every fragment chain on the segment
+	thread_local std::vector<uint64_t> u;        // score << 32 | anchors, as the chaining step hands chains over
 	for (int s = 0; s < n_segs; ++s) on_seg[s].assign(n_chain, 0), seg_a[s].clear();
 	for (size_t c = 0; c < n_chain; ++c)
 		for (int j = 0; j < regs0[c].cnt; ++j) {
@@ -330,7 +332,7 @@ void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, c
 			seg_a[s].push_back(x); // (chain by chain, so a segment's anchors of one chain stay together, in order)
 		}
 	for (int s = 0; s < n_segs; ++s) {
-		std::vector<uint64_t> u; // score << 32 | anchors, as the chaining step hands chains over
+		u.clear();
 		for (size_t c = 0; c < n_chain; ++c)
 			if (on_seg[s][c]) u.push_back((uint64_t)regs0[c].score << 32 | (uint32_t)on_seg[s][c]);
 		gen_regs(hash, qlens[s], u.data(), (int)u.size(), seg_a[s].data(), false, regs[s]);
