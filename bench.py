@@ -283,6 +283,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=0, help="mean read length (0: 10000 for map-ont, 15000 otherwise)")
     ap.add_argument("--err", type=float, default=-1.0, help="per-base error rate (<0: 0.12 for map-ont, 0.005 otherwise)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0: sized for ~10 s)")
+    ap.add_argument("--as-rank-threads", type=int, default=0, help="--as-rank-of: host threads of the one rank (0: this box's CPUs / N, i.e. N ranks under ONE quota of this box's size; e.g. 16: a node that gives every rank what this box has)")
     ap.add_argument("--as-rank-of", type=int, default=0, help="N > 1 (one GPU): after the N=1 measurement, map what ONE rank of an N-GPU strong-scaling job maps -- a 1/N base-balanced "
                     "share of every batch, with host_cpus()/N threads, hit packing included -- and report config.as_rank_of: the share's rate, N x that rate, its ratio to the N=1 rate "
                     "(predicted strong scaling if the ranks do not contend) and the host core-seconds per Gbase, which is what bounds the N-GPU line under a shared CPU quota")
@@ -807,7 +808,7 @@ def main():
         N = a.as_rank_of
         try:
             al.close()
-            thr_share = max(1, n_threads // N)
+            thr_share = a.as_rank_threads if a.as_rank_threads > 0 else max(1, n_threads // N)
             cut = shard.split_by_bases([sum(len(x) for x in r[1:]) for r in named], N)
             share = named[cut[0]:cut[1]]
             share_bases = sum(sum(len(x) for x in r[1:]) for r in share)

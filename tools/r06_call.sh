@@ -43,7 +43,7 @@ import json; d=json.loads(open('$O/r06_bench_repeats_split_$V.json').read().stri
 abband4) # windows beyond 512 x 512 in a band of 512 diagonals (the four-set class) against the strip kernel's rectangles: the headline and the repeats workload
        for m in band4 noband4; do
          if [ $m = noband4 ]; then export MM2AMD_BAND_MAX=512; else unset MM2AMD_BAND_MAX; fi
-         for w in hifi repeats; do
+         for w in ont repeats; do
            wl=""; [ $w = repeats ] && wl="--workload repeats"
            MM2AMD_BAND_DEBUG=1 timeout 900 python bench.py $wl --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_${w}_${m}_$V.json 2> $O/r06_bench_${w}_${m}_$V.log
            grep -h "band:" $O/r06_bench_${w}_${m}_$V.log | tail -2 | cut -c1-200
@@ -55,6 +55,12 @@ print('    ', d['config'].get('banded_gap_fill'))
 P
          done
        done; unset MM2AMD_BAND_MAX ;;
+rank8subs) # one rank's share of eight: how many sub-batches (= lanes in flight) its 12.5 k reads are cut into
+       for n in 4 6 8 12 16; do
+         MM2AMD_MIN_SUBBATCHES=$n timeout 600 python bench.py --as-rank-of 8 --steps 8 --warmup 3 --no-cpu-baseline > $O/r06_bench_rank8_subs${n}_$V.json 2> $O/r06_bench_rank8_subs${n}_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_rank8_subs${n}_$V.json').read().strip().split('\n')[-1]); a=d['config']['as_rank_of']; print('min sub-batches $n:', d['value'], 'share ms', a['ms_per_step'], 'predicted', a['predicted_strong_scaling'], 'host cpu s/Gbase', a['host_cpu_s_per_gbase'])"
+       done ;;
 srsweep) # short reads are host-bound: lanes / sub-batch size
        for cfg in "8 100000000" "8 40000000" "8 25000000" "12 25000000" "16 15000000"; do
          set -- $cfg
