@@ -479,6 +479,7 @@ void KswRunner::run_jobs(const KswJob *jobs, size_t n, const uint8_t *d_qpool, c
 		if (cursor[1] == 0 && resident) { *cigar_out = d_cigar.p, *n_cigar_out = cursor[0]; break; }
 		if (cursor[1] == 0) {
 			uint32_t *hc = cigar_host.ensure((size_t)cursor[0] + 1);
+			Trace::get().add(lane, "host:cigar-buffer", tt, Trace::now()); tt = Trace::now();
 			if (cursor[0]) {
 				HIP_CHECK(hipMemcpyAsync(hc, d_cigar.p, (size_t)cursor[0] * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 				stream_wait(stream);

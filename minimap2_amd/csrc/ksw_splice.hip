@@ -25,6 +25,7 @@
 #include "hip_util.hpp"
 #include "ksw_dev.hpp"
 #include "ksw_pk.hpp"
+#include <type_traits>
 
 namespace mm2amd {
 
@@ -62,6 +63,94 @@ __device__ __forceinline__ int acceptor_class(const SpliceParams &P, int c0, int
 }
 }
 
+// One register set and anti-diagonal of the recurrence (ksw2_exts2_sse.c:249-348, the left-aligned variant gap fills use), both packed halves: target entry (tv, dn, ac),
+// query bases qv, (u, y) of the left neighbour one row up (up, yp); v, x, x2 in / out, u, y, d out.  The interior rows' loop (splice_lean_rows below) uses it: the general
+// row body further down writes the same operations with the one-instruction helpers.  As in ksw_gapfill_dev.hpp no instruction reads the result of the packed instruction
+// right before it, and an instruction takes at most one scalar operand.
+struct SpliceK { uint32_t misd, scn, q, q2, qe; }; // packed launch constants that stay in SGPRs
+#ifndef MM2AMD_WAVE_EMU
+__device__ __forceinline__ void splice_cell(uint32_t tv, uint32_t dn, uint32_t ac, uint32_t qv, uint32_t up, uint32_t yp, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y, uint32_t &x2,
+                                            uint32_t &d, uint32_t P_MCH, const SpliceK &K)
+{
+	uint32_t m, n, a, b, a2, t1, z, z3; // m: tv ^ qv, then "bases differ", then N score - z;  n: tv | qv, then "a base is N";  t1: a2 + acceptor, then the gap candidates' maximum
+	asm volatile(
+		"v_xor_b32 %[m], %[tv], %[qv]\n\t"
+		"v_or_b32 %[n], %[tv], %[qv]\n\t"
+		"v_pk_add_u16 %[a], %[x], %[v]\n\t"
+		"v_pk_min_u16 %[m], %[m], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_add_u16 %[b], %[yp], %[up]\n\t"
+		"v_pk_lshrrev_b16 %[n], 2, %[n] op_sel_hi:[0,1]\n\t"
+		"v_pk_mad_u16 %[z], %[m], %[misd], %[mch]\n\t"
+		"v_pk_add_u16 %[a2], %[x2], %[v]\n\t"
+		"v_pk_max_i16 %[z3], %[a], %[b]\n\t"
+		"v_pk_sub_u16 %[m], %[scn], %[z]\n\t"
+		"v_pk_add_u16 %[t1], %[a2], %[ac]\n\t"
+		"v_pk_mad_u16 %[z], %[n], %[m], %[z]\n\t"
+		"v_pk_max_i16 %[t1], %[z3], %[t1]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_max_i16 %[z3], %[z], %[t1]\n\t"
+		"s_nop 0"
+		: [m] "=&v"(m), [n] "=&v"(n), [a] "=&v"(a), [b] "=&v"(b), [a2] "=&v"(a2), [t1] "=&v"(t1), [z] "=&v"(z), [z3] "=&v"(z3)
+		: [tv] "v"(tv), [qv] "v"(qv), [x] "v"(x), [v] "v"(v), [x2] "v"(x2), [yp] "v"(yp), [up] "v"(up), [ac] "v"(ac), [mch] "v"(P_MCH), [misd] "s"(K.misd), [scn] "s"(K.scn));
+	uint32_t es, ea, eb, un, vn, tq, tq2, ma, mb, m2; // ea ends as the direction byte; tq / tq2 / es end as the three "goes on" flags; a / b / a2 end as the new x / y / x2
+	asm volatile(
+		"v_pk_sub_u16 %[es], %[z3], %[z]\n\t"
+		"v_pk_sub_u16 %[ea], %[z3], %[a]\n\t"
+		"v_pk_sub_u16 %[eb], %[z3], %[b]\n\t"
+		"v_pk_sub_u16 %[un], %[z3], %[v]\n\t"
+		"v_pk_min_u16 %[es], %[es], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[ea], %[ea], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[eb], %[eb], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[vn], %[z3], %[up]\n\t"
+		"v_pk_sub_u16 %[tq], %[z3], %[pq]\n\t"
+		"v_pk_add_u16 %[eb], %[eb], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[tq2], %[z3], %[pq2]\n\t"
+		"v_pk_sub_u16 %[a], %[a], %[tq]\n\t"
+		"v_pk_mad_u16 %[ea], %[ea], %[eb], 1 op_sel_hi:[1,1,0]\n\t"
+		"v_pk_sub_u16 %[b], %[b], %[tq]\n\t"
+		"v_pk_sub_u16 %[a2], %[a2], %[tq2]\n\t"
+		"v_pk_mul_lo_u16 %[ea], %[es], %[ea]\n\t"
+		"v_pk_max_i16 %[ma], %[a], 0\n\t"
+		"v_pk_max_i16 %[mb], %[b], 0\n\t"
+		"v_pk_max_i16 %[m2], %[a2], %[dn]\n\t"
+		"v_pk_min_u16 %[tq], %[ma], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_min_u16 %[tq2], %[mb], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[es], %[m2], %[dn]\n\t"
+		"v_pk_sub_u16 %[a], %[ma], %[pqe]\n\t"
+		"v_pk_mad_u16 %[ea], %[tq], 8, %[ea] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_min_u16 %[es], %[es], 1 op_sel_hi:[1,0]\n\t"
+		"v_pk_sub_u16 %[b], %[mb], %[pqe]\n\t"
+		"v_pk_mad_u16 %[ea], %[tq2], 16, %[ea] op_sel_hi:[1,0,1]\n\t"
+		"v_pk_sub_u16 %[a2], %[m2], %[pq2]\n\t"
+		"v_pk_mad_u16 %[ea], %[es], 32, %[ea] op_sel_hi:[1,0,1]"
+		: [es] "=&v"(es), [ea] "=&v"(ea), [eb] "=&v"(eb), [un] "=&v"(un), [vn] "=&v"(vn), [tq] "=&v"(tq), [tq2] "=&v"(tq2), [ma] "=&v"(ma), [mb] "=&v"(mb), [m2] "=&v"(m2),
+		  [a] "+v"(a), [b] "+v"(b), [a2] "+v"(a2)
+		: [z3] "v"(z3), [z] "v"(z), [v] "v"(v), [up] "v"(up), [dn] "v"(dn), [pq] "s"(K.q), [pq2] "s"(K.q2), [pqe] "s"(K.qe));
+	u = un, v = vn, x = a, y = b, x2 = a2, d = ea;
+}
+__device__ __forceinline__ uint32_t splice_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13c /* wave_ror:1 */, 0xf, 0xf, false); }
+#else // the emulator's twin: the same operations through the helpers
+inline void splice_cell(uint32_t tv, uint32_t dn, uint32_t ac, uint32_t qv, uint32_t up, uint32_t yp, uint32_t &u, uint32_t &v, uint32_t &x, uint32_t &y, uint32_t &x2, uint32_t &d, uint32_t P_MCH, const SpliceK &K)
+{
+	const uint32_t ONE = 0x00010001u;
+	uint32_t z = pk_mad(pk_minu(tv ^ qv, ONE), K.misd, P_MCH);
+	z = pk_mad(pk_shr2(tv | qv), pk_sub(K.scn, z), z);
+	const uint32_t vt = v;
+	uint32_t a = pk_add(x, vt), b = pk_add(yp, up), a2 = pk_add(x2, vt);
+	const uint32_t a2a = pk_add(a2, ac);
+	const uint32_t z3 = pk_max(pk_max(pk_max(z, a), b), a2a);
+	const uint32_t ne_s = pk_minu(pk_sub(z3, z), ONE), ne_a = pk_minu(pk_sub(z3, a), ONE), ne_b = pk_minu(pk_sub(z3, b), ONE);
+	uint32_t dd = pk_mul(ne_s, pk_mad(ne_a, pk_add(ne_b, ONE), ONE));
+	u = pk_sub(z3, vt), v = pk_sub(z3, up);
+	const uint32_t tmp = pk_sub(z3, K.q);
+	a = pk_sub(a, tmp), b = pk_sub(b, tmp), a2 = pk_sub(a2, pk_sub(z3, K.q2));
+	const uint32_t ma = pk_max(a, 0u), mb = pk_max(b, 0u), m2 = pk_max(a2, dn);
+	dd = pk_mad(pk_minu(ma, ONE), pk_emu::both(8), dd), dd = pk_mad(pk_minu(mb, ONE), pk_emu::both(16), dd), dd = pk_mad(pk_minu(pk_sub(m2, dn), ONE), pk_emu::both(32), dd);
+	x = pk_sub(ma, K.qe), y = pk_sub(mb, K.qe), x2 = pk_sub(m2, K.q2), d = dd;
+}
+inline uint32_t splice_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13c, 0xf, 0xf, false); }
+#endif
+
 constexpr int splice_ring(int nc, bool self) { int need = (self ? 128 : 64) * nc + 64, p = 128; while (p < need) p <<= 1; return p; }
 constexpr int splice_wpb(int nc, bool self) { const int b = splice_ring(nc, self) * (self ? 8 : 16); return b * 4 <= 65536 ? 4 : b * 2 <= 65536 ? 2 : 1; }
 
@@ -83,9 +172,11 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 	int long_thres = (q2 - q) / e - 1; // ksw2_exts2_sse.c:98-101
 	if (q2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * e - (q2 - q);
-	const uint32_t P_ONE = pk2v(1), P_ZERO = pk2v(0), P_MCH = pk2v(sc_mch), P_MISD = pk2v(sc_mis - sc_mch), P_SCN = pk2v(sc_N);
-	const uint32_t P_Q = pk2v(q), P_Q2 = pk2v(q2), P_QE = pk2v(qe), P_NQE = pk2(-qe), P_NQ2 = pk2(-q2);
-	const uint32_t P_8 = pk2v(8), P_16 = pk2v(16), P_32 = pk2v(32);
+	// (only the match score is pinned in a VGPR: the interior rows' cell takes its other constants as scalar or inline operands; the general row body, which runs on
+	// the rows near the matrix' corners only, lets the compiler copy them where its one-instruction helpers want a VGPR)
+	const uint32_t P_ONE = pk2(1), P_ZERO = pk2(0), P_MCH = pk2v(sc_mch), P_MISD = pk2(sc_mis - sc_mch), P_SCN = pk2(sc_N);
+	const uint32_t P_Q = pk2(q), P_Q2 = pk2(q2), P_QE = pk2(qe), P_NQE = pk2(-qe), P_NQ2 = pk2(-q2);
+	const uint32_t P_8 = pk2(8), P_16 = pk2(16), P_32 = pk2(32);
 
 	for (;;) {
 		int pid = 0;
@@ -152,6 +243,72 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 		int frontier = -1; // target positions <= frontier are in the ring
 		uint32_t hand_in = 0, hand_out = 0;
 		const int n_rowsA = qlenA + tlenA - 1, n_rowsB = hasB ? qlenB + tlenB - 1 : 0, n_rows = n_rowsA > n_rowsB ? n_rowsA : n_rowsB;
+		// ---- the interior rows [R0, R1): every query position of both jobs has a cell (the anti-diagonal has left the first query row's start and not reached the last
+		//      target column), no column starts, the border terms are at their constants (ksw2_exts2_sse.c:234-247 with r > long_thres).  With a target as long as an intron
+		//      that is nearly every row, and none of what the general row body below derives per row -- ranges, masks, edge patches, the sets in use -- changes there.
+		const int qwide = SELF ? (qlenA < QOFF ? qlenA : QOFF) : (qlenA > qlenB ? qlenA : qlenB);
+		const int n_act = (qwide - 1) / 64 + 1;                                                     // register sets in use
+		const int nsA = SELF ? n_act : qsA >> 6, nsB = SELF ? (qlenA > QOFF ? (qlenA - QOFF + 63) >> 6 : 0) : hasB ? qsB >> 6 : 0; // sets whose bytes a job's matrix has columns for
+		int R0 = qlenA > qlenB ? qlenA : qlenB, R1 = (hasB && tlenB < tlenA ? tlenB : tlenA) - 1;
+		if (R0 < long_thres + 1 - QB) R0 = long_thres + 1 - QB;
+		const SpliceK KC = { pk2(sc_mis - sc_mch), pk2(sc_N), pk2(q), pk2(q2), pk2(qe) };
+		auto lean_rows = [&](auto na_tag, int r0, int r1) {
+			constexpr int NA = decltype(na_tag)::value;
+			uint32_t hacc = 0;              // (u, u) of query position 0 summed over the block's rows (at most 64 rows of a few units each: no 16-bit overflow)
+			uint32_t up0 = 0, yp0 = P_NQE;  // paired jobs: lane 0 keeps the border's (u, y) through the shifts (wave_shr:1 never writes it)
+			uint32_t ra = (uint32_t)(r0 - lane) & RM;
+			uint8_t *pA = dirA + (size_t)(r0 + QB) * qsA + QB + lane, *pB = SELF ? pA + QOFF : dirB + (size_t)r0 * qsB + lane;
+			for (int r = r0; r < r1; ++r) {
+				uint32_t sU = 0, sY = 0;
+				if (SELF) { // query position QOFF continues the low halves' last lane; position 0 has the border or the previous strip to its left
+					uint32_t lU = 0, lY = P_NQE & 0xffffu;
+					if (pass > 0) { const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hand_in, r & 63); lU = h & 0xffffu, lY = h >> 16; }
+					sU = splice_ror1(U[NC - 1]) << 16 | lU, sY = splice_ror1(Y[NC - 1]) << 16 | lY;
+				}
+				// set c's left neighbour at lane 0 is the last lane of set c - 1, one row up: all of them rotated into place before any set computes (a DPP move may not
+				// follow the write of its source by less than two instructions)
+				uint32_t cU[NA], cY[NA];
+#pragma unroll
+				for (int c = 1; c < NA; ++c) cU[c] = splice_ror1(U[c - 1]), cY[c] = splice_ror1(Y[c - 1]);
+				// a set's target entries are read while the set before it computes (the LDS round trip is as long as a cell)
+				uint4 te_n = make_uint4(0u, 0u, 0u, 0u);
+				uint2 el_n = make_uint2(0u, 0u), eh_n = make_uint2(0u, 0u);
+				if (SELF) el_n = ring2[(ra - 64u * (NA - 1)) & RM], eh_n = ring2[(ra - 64u * (NA - 1) - QOFF) & RM];
+				else te_n = ring[(ra - 64u * (NA - 1)) & RM];
+#pragma unroll
+				for (int c = NA - 1; c >= 0; --c) { // highest set first: set c - 1 still holds row r - 1
+					uint32_t up, yp;
+					if (c > 0) up = dpp_shr1u(cU[c], U[c]), yp = dpp_shr1u(cY[c], Y[c]);
+					else if (SELF) up = dpp_shr1u(sU, U[0]), yp = dpp_shr1u(sY, Y[0]);
+					else up = up0 = dpp_shr1u(up0, U[0]), yp = yp0 = dpp_shr1u(yp0, Y[0]);
+					uint32_t tv, dn, ac, d;
+					if (SELF) {
+						const uint2 el = el_n, eh = eh_n;
+						if (c > 0) el_n = ring2[(ra - 64u * (c - 1)) & RM], eh_n = ring2[(ra - 64u * (c - 1) - QOFF) & RM];
+						tv = __builtin_amdgcn_perm(eh.x, el.x, 0x05040100u), dn = __builtin_amdgcn_perm(eh.x, el.x, 0x07060302u), ac = __builtin_amdgcn_perm(eh.y, el.y, 0x05040100u);
+					} else {
+						const uint4 te = te_n;
+						if (c > 0) te_n = ring[(ra - 64u * (c - 1)) & RM];
+						tv = te.x, dn = te.y, ac = te.z;
+					}
+					splice_cell(tv, dn, ac, Q[c], up, yp, U[c], V[c], X[c], Y[c], X2[c], d, P_MCH, KC);
+					if (c < nsA) pA[c * 64] = (uint8_t)d;          // (a set's lanes beyond the query fall into the row's padding)
+					if (c < nsB) pB[c * 64] = (uint8_t)(d >> 16);
+				}
+				if (!SELF || pass == 0) hacc = pk_add(hacc, U[0]);
+				if (hand_on) { // as in the general row body
+					const int th = r - (STRIP - 1);
+					const uint32_t hv = (U[NC - 1] >> 16) | (Y[NC - 1] & 0xffff0000u);
+					const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hv, 63);
+					if (lane == (th & 63)) hand_out = h;
+					if ((th & 63) == 63) handover[(th & ~63) + lane] = hand_out;
+				}
+				ra = (ra + 1) & RM, pA += qsA, pB += SELF ? qsA : qsB;
+			}
+			const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)hacc, 0);
+			H0A += (int16_t)hs;
+			if (!SELF) H0B += (int16_t)(hs >> 16);
+		};
 		for (int r = 0; r < n_rows; ++r) { // r: anti-diagonal within the strip; the matrix's anti-diagonal is r + QB
 			if (r > frontier) { // admit the next 64 target positions (wave-uniform)
 				const int t = frontier + 1 + lane;
@@ -163,6 +320,15 @@ __global__ void __launch_bounds__(64 * splice_wpb(NC, SELF), (NC <= 4 ? 4 : 2) *
 				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				if (SELF && pass > 0) hand_in = t < tlenA ? handover[t] : 0u; // (u | y << 16) left of this strip, for target positions r..r+63
+			}
+			if (r >= R0 && r < R1) { // interior rows up to the next admission
+				const int stop = R1 < frontier + 1 ? R1 : frontier + 1;
+				if (NC >= 4 && n_act == 4) lean_rows(std::integral_constant<int, 4>(), r, stop);
+				else if (NC >= 4 && n_act == 3) lean_rows(std::integral_constant<int, 3>(), r, stop);
+				else if (n_act == 2) lean_rows(std::integral_constant<int, 2>(), r, stop);
+				else lean_rows(std::integral_constant<int, 1>(), r, stop);
+				r = stop - 1;
+				continue;
 			}
 			// query positions with a valid cell on this anti-diagonal, per job: j in [max(0, r-tlen+1), min(qlen-1, r)]
 			int jloA = r - tlenA + 1 > 0 ? r - tlenA + 1 : 0, jhiA = r < qlenA - 1 ? r : qlenA - 1;

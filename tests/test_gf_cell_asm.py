@@ -15,8 +15,8 @@ HDR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "minimap2_a
 PRESETS = {"ont": (2, 4, 4, 2, 24, 1), "hifi": (1, 4, 6, 2, 26, 1), "swap": (2, 4, 24, 1, 4, 2), "asm5": (1, 19, 39, 3, 81, 1), "asm20": (1, 4, 6, 2, 26, 1), "sr": (2, 8, 12, 2, 24, 1)}
 
 
-def _function(name):
-    src = open(HDR).read()
+def _function(name, path=HDR):
+    src = open(path).read()
     m = re.search(r"__device__ __forceinline__ void %s\(" % name, src)
     assert m, name
     body = src[m.start():]
@@ -61,6 +61,9 @@ OPS2 = {
 }
 
 
+OPS32 = {"v_and_b32": lambda a, b: a & b, "v_xor_b32": lambda a, b: a ^ b, "v_or_b32": lambda a, b: a | b}
+
+
 def _run(blocks, env):
     """interpret; env maps C variable names to 32-bit values.  Returns the number of packed / 32-bit VALU instructions."""
     n_pk = n_32 = 0
@@ -88,8 +91,8 @@ def _run(blocks, env):
             src_names = [binds[re.match(r"%\[(\w+)\]", t).group(1)] for t in srcs if t.startswith("%")]
             assert not (prev_pk and prev_dst in src_names), "%s reads the result of the packed instruction right before it" % line
             d = binds[re.match(r"%\[(\w+)\]", dst).group(1)]
-            if op == "v_and_b32":
-                env[d] = val(srcs[0]) & val(srcs[1])
+            if op in OPS32:
+                env[d] = OPS32[op](val(srcs[0]), val(srcs[1]))
                 n_32 += 1
                 prev_dst, prev_pk = d, False
                 continue
