@@ -41,6 +41,8 @@ def run(name, jobs):
 run("q 65..128", make(65, 128, n))
 run("q 129..256", make(129, 256, n))
 run("q 200..256", make(200, 256, n))
+run("q 257..384", make(257, 384, n // 2))
+run("q 340..384", make(340, 384, n // 2))
 run("q 257..512", make(257, 512, n // 2))
 run("q 450..512", make(450, 512, n // 2))
 run("q 513..1024", make(513, 1024, n // 4))

@@ -156,5 +156,16 @@ for f in ['r06_bench_hifi_$V.json','r06_bench_splice_$V.json','r06_bench_sr_$V.j
     except Exception as e: print(f, 'FAILED', e)
 P
        ;;
+splice) # the splice gap-fill kernel: its kernel-level cases, the per-class microbenchmark, the splice configuration
+       timeout 600 python -m pytest tests/test_gpu_ksw.py -x -q -m gpu -k splice 2>&1 | tail -2
+       timeout 300 python tools/ksw_splice_microbench.py 16384 8000 > $O/r06_splice_micro_$V.txt 2>&1; cat $O/r06_splice_micro_$V.txt
+       MM2AMD_KSW_CLASS_DEBUG=${SPLICE_CLASS_DEBUG:-0} timeout 500 python bench.py --preset splice --reads 50000 --steps 2 --warmup 1 --cpu-sample 3000 > $O/r06_bench_splice_$V.json 2> $O/r06_bench_splice_$V.log
+       python - <<P
+import json
+d=json.loads(open('$O/r06_bench_splice_$V.json').read().strip().split('\\n')[-1]); c=d.get('cpu_baseline') or {}; r=d['roofline']
+print('splice', d['value'], d['ms_per_step'], 'cpu', c.get('value'), c.get('hits_identical_to_gpu'), 'host cpu s/step', d['config']['host_cpu_s_per_step'])
+print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:6]})
+P
+       ;;
 esac
 done
