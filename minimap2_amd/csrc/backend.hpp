@@ -87,15 +87,16 @@ public:
 	// The regions' last step on the device (region_finish.hpp): stitches the windows' CIGARs of this lane's LAST ksw() call (pieces address its
 	// pool), left-aligns and counts as mm_update_extra does.  results[i] belongs to regions[i]; its CIGAR is at *cigars + regions[i].out_off
 	// (backend-owned, valid until the lane's next call).  out_words = room needed in the output pool.
-	// The whole base-level alignment of a sub-batch's single-segment reads on the device (region_dev.hpp): the chains of this lane's LAST
+	// The whole base-level alignment of a sub-batch's reads (round 6: and of short-read pairs, segment by segment) on the device (region_dev.hpp): the chains of this lane's LAST
 	// seed_chain() call become hit records, DP windows, DP results and finished regions without crossing PCIe; what comes back are the finished
 	// hit records (host views, valid until the lane's next align_regions()).  in[i].skip: the host keeps read i.  A read whose RgnReadOut::flags
 	// is non-zero goes through the host path from its chains.
-	struct RegionReadIn { uint32_t hash; bool skip; };
+	struct RegionReadIn { uint32_t hash; bool skip; int32_t gap_ref = 0; }; // gap_ref: the fragment's max_chain_gap_ref (map.c:264-270; two-segment fragments only)
 	struct RegionBatchOut {
 		const RgnReadOut *reads = nullptr; const ref::Reg1 *regs = nullptr; const RgnAux *aux = nullptr; const RgnPlan *plan = nullptr;
 		const FinRegion *fin = nullptr; const FinResult *fin_res = nullptr; const uint32_t *cigars = nullptr;
 		uint32_t n_regs = 0; size_t n_jobs = 0; double dp_cells = 0;
+		int rout_stride = 1; // reads[] holds one entry per read, or (2: the sub-batch has two-segment fragments) two, one per segment
 	};
 	virtual bool aligns_regions() const { return false; }
 	virtual void align_regions(int /*lane*/, const RgnOpts & /*O*/, const KswScoring & /*sc*/, bool /*log_gap*/, const std::vector<ReadChains> & /*chains*/, const std::vector<RegionReadIn> & /*in*/,

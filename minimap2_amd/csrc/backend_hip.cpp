@@ -635,6 +635,7 @@ public:
 		RgnRead *hr = ln.h_rg_reads.ensure(n);
 		uint64_t sq = 0, n_chain = 0;
 		int max_nu = 1;
+		const int stride = R.has_pairs ? 2 : 1; // two-segment fragments: their chains are cut per segment on the device (chain_regs_kernel), a segment is a read of its own from there on
 		for (size_t i = 0; i < n; ++i) {
 			const ReadChains &c = chains[i];
 			RgnRead &r = hr[i];
@@ -643,15 +644,25 @@ public:
 			r.qpool_fwd = 2 * R.seq_off[ln.rg_lo + i];
 			r.n_u = skip ? 0 : c.n_u, r.n_a = skip ? 0 : (int32_t)c.n_a, r.n_mp = (int32_t)(ln.mp_off[i + 1] - ln.mp_off[i]);
 			r.qlen = (int32_t)(R.seq_off[ln.rg_lo + i + 1] - R.seq_off[ln.rg_lo + i]);
+			r.qlen2 = 0, r.gap_ref = in[i].gap_ref;
+			if (R.has_pairs) {
+				const int32_t u0 = R.unit_first[ln.rg_lo + i];
+				if (R.unit_first[ln.rg_lo + i + 1] - u0 == 2) r.qlen = (int32_t)(R.unit_off[u0 + 1] - R.unit_off[u0]), r.qlen2 = (int32_t)(R.unit_off[u0 + 2] - R.unit_off[u0 + 1]);
+			}
 			r.hash = in[i].hash, r.src = skip ? RGN_SRC_SKIP : (c.dev_src == 1 ? RGN_SRC_LJ : 0);
-			if (!skip) sq += (uint64_t)c.n_a, n_chain += (uint64_t)c.n_u, max_nu = std::max(max_nu, (int)c.n_u);
+			if (!skip) {
+				const uint64_t k = r.qlen2 > 0 ? 2 : 1; // (a chain can have anchors on both segments: each segment's slice is as long as the fragment's chained anchors)
+				sq += k * (uint64_t)c.n_a, n_chain += k * (uint64_t)c.n_u, max_nu = std::max(max_nu, (int)c.n_u);
+			}
 		}
+		if (n_chain >= (1ull << 31)) throw std::runtime_error("[mm2amd] align_regions: a sub-batch with more than 2^31 chains");
 		const uint32_t max_regs = (uint32_t)n_chain;
-		const uint64_t max_jobs64 = sq + 2 * n_chain + 1;
+		const uint64_t max_jobs64 = std::max<uint64_t>(sq + 2 * n_chain + 1, 3 * n_chain + 1); // (one window per anchor at most, two extensions; short reads: three pieces per hit)
 		if (max_jobs64 >= (1ull << 31)) throw std::runtime_error("[mm2amd] align_regions: a sub-batch with more than 2^31 anchors");
 		RgnBuffers B{};
 		B.n_reads = (int)n;
-		ln.d_rg_reads.ensure(n), ln.d_rg_rout.ensure(n), ln.d_rg_cur.ensure(RGN_CUR_N);
+		B.rout_stride = stride;
+		ln.d_rg_reads.ensure(n), ln.d_rg_rout.ensure(n * (size_t)stride), ln.d_rg_cur.ensure(RGN_CUR_N);
 		ln.d_rg_sq.ensure(sq + 1), ln.d_rg_sites.ensure(sq + 1);
 		ln.d_rg_regs.ensure(max_regs + 1), ln.d_rg_aux.ensure(max_regs + 1), ln.d_rg_plan.ensure(max_regs + 1), ln.d_rg_fin.ensure(max_regs + 1), ln.d_rg_finres.ensure(max_regs + 1);
 		ln.d_rg_win.ensure(max_jobs64), ln.d_rg_jobs.ensure(max_jobs64), ln.d_rg_pieces.ensure(max_jobs64);
@@ -713,14 +724,14 @@ public:
 			region_finish_launch(P, st);
 			kp.end(st, "region_finish_kernel", (double)out_words * 8.0 + (double)cur[RGN_CUR_N_FIN] * (sizeof(FinRegion) + sizeof(FinResult)), (double)cur[RGN_CUR_N_FIN]);
 		}
-		RgnReadOut *h_rout = ln.h_rg_rout.ensure(n);
+		RgnReadOut *h_rout = ln.h_rg_rout.ensure(n * (size_t)stride);
 		ref::Reg1 *h_regs = ln.h_rg_regs.ensure(n_regs + 1);
 		RgnAux *h_aux = ln.h_rg_aux.ensure(n_regs + 1);
 		RgnPlan *h_plan = ln.h_rg_plan.ensure(n_regs + 1);
 		FinRegion *h_fin = ln.h_rg_fin.ensure(n_regs + 1);
 		FinResult *h_finres = ln.h_rg_finres.ensure(n_regs + 1);
 		uint32_t *h_out = ln.h_rg_out.ensure(out_words + 1);
-		HIP_CHECK(hipMemcpyAsync(h_rout, ln.d_rg_rout.p, n * sizeof(RgnReadOut), hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h_rout, ln.d_rg_rout.p, n * (size_t)stride * sizeof(RgnReadOut), hipMemcpyDeviceToHost, st));
 		if (n_regs) {
 			HIP_CHECK(hipMemcpyAsync(h_regs, ln.d_rg_regs.p, n_regs * sizeof(ref::Reg1), hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipMemcpyAsync(h_aux, ln.d_rg_aux.p, n_regs * sizeof(RgnAux), hipMemcpyDeviceToHost, st));
@@ -733,7 +744,7 @@ public:
 		Trace::get().add(lane_id, "gpu:consume+finish, d2h:hits", tt, Trace::now());
 		kp.collect();
 		out.reads = h_rout, out.regs = h_regs, out.aux = h_aux, out.plan = h_plan, out.fin = h_fin, out.fin_res = h_finres, out.cigars = h_out;
-		out.n_regs = n_regs, out.n_jobs = n_jobs;
+		out.n_regs = n_regs, out.n_jobs = n_jobs, out.rout_stride = stride;
 	}
 
 	// MM2AMD_DEVICE_FINISH=1 / =0 decides; unset: the device finishes the regions when this mapper has fewer than 12 host threads.  The kernel saves

@@ -171,6 +171,34 @@ MM2_HD inline void hr_select_secondaries(ref::Reg1 *r, int n, uint8_t *keep, flo
 	}
 }
 
+// Which secondary chains of a FRAGMENT are kept (mm_select_sub_multi, pe.c:6-50): keep[i] for every hit.  A secondary within min_diff of its parent always stays;
+// otherwise it has to reach a share of the parent's score that depends on where it lies: next to the parent on the reference (a pair's other placement) pri1, a chain
+// confined to one read against a parent that spans both pri2, else the usual ratio.  At most best_n secondaries (a good one beyond the cap still counts).
+MM2_HD inline void hr_select_secondaries_multi(const ref::Reg1 *r, int n, uint8_t *keep, float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs, int qlen0, int qlen1)
+{
+	const int reach = n_segs == 2 ? qlen0 + qlen1 + max_gap_ref : 0;
+	int n_secondary = 0;
+	for (int i = 0; i < n; ++i) {
+		const ref::Reg1 &h = r[i];
+		if (h.parent == i) { keep[i] = 1; continue; }
+		const ref::Reg1 &par = r[h.parent];
+		const bool sec_both = n_segs == 2 && h.qs < qlen0 && h.qe > qlen0, par_both = n_segs == 2 && par.qs < qlen0 && par.qe > qlen0;
+		const bool beside = par.rev == h.rev && par.rid == h.rid && h.re - par.rs < reach && par.re - h.rs < reach;
+		const float share = beside ? pri1 : (sec_both || sec_both == par_both) ? pri_ratio : pri2;
+		const bool good = h.score + min_diff >= par.score || h.score >= par.score * share;
+		keep[i] = good && n_secondary++ < best_n ? 1 : 0;
+	}
+}
+
+// Which segment of its fragment an anchor lies on, and the anchor as its segment sees it (mm_seg_gen, hit.c:342-396): the query coordinate counted from the segment's
+// own start -- from its end for reverse-strand anchors, whose coordinate runs backwards over the concatenation.  before: bases of the fragment before the segment.
+MM2_HD inline int hr_anchor_seg(const Anchor &x) { return (int)((x.y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT); }
+MM2_HD inline Anchor hr_seg_anchor(Anchor x, int total, int before, int seg_len)
+{
+	x.y -= x.x >> 63 ? (uint64_t)(total - (seg_len + before)) : (uint64_t)before;
+	return x;
+}
+
 // position of an anchor's k-mer on the read as given (get_for_qpos, esterr.c:7-14)
 MM2_HD inline int32_t hr_fwd_qpos(int32_t qlen, const Anchor &a)
 {

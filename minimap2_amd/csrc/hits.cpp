@@ -316,7 +316,7 @@ namespace mm2amd {
 // (from its end for reverse-strand anchors, whose coordinate runs backwards over the concatenation).
 void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, const Anchor *a, RegVec *regs, std::vector<Anchor> *seg_a)
 {
-	auto seg_of = [](const Anchor &x) { return (int)((x.y & ref::SEED_SEG_MASK) >> ref::SEED_SEG_SHIFT); };
+	auto seg_of = [](const Anchor &x) { return hr_anchor_seg(x); };
 	int before[2] = {0, 0}, total = 0; // bases of the fragment before a segment; all of them
 	for (int s = 0; s < n_segs; ++s) before[s] = total, total += qlens[s];
 	const size_t n_chain = regs0.size();
@@ -325,11 +325,10 @@ void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, c
 	for (int s = 0; s < n_segs; ++s) on_seg[s].assign(n_chain, 0), seg_a[s].clear();
 	for (size_t c = 0; c < n_chain; ++c)
 		for (int j = 0; j < regs0[c].cnt; ++j) {
-			Anchor x = a[regs0[c].as + j];
+			const Anchor x = a[regs0[c].as + j];
 			const int s = seg_of(x);
 			++on_seg[s][c];
-			x.y -= x.x >> 63 ? (uint64_t)(total - (qlens[s] + before[s])) : (uint64_t)before[s];
-			seg_a[s].push_back(x); // (chain by chain, so a segment's anchors of one chain stay together, in order)
+			seg_a[s].push_back(hr_seg_anchor(x, total, before[s], qlens[s])); // (chain by chain, so a segment's anchors of one chain stay together, in order)
 		}
 	for (int s = 0; s < n_segs; ++s) {
 		u.clear();
@@ -346,23 +345,9 @@ void seg_gen(uint32_t hash, int n_segs, const int *qlens, const RegVec &regs0, c
 void select_sub_multi(float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs, const int *qlens, RegVec &r)
 {
 	if (!(pri_ratio > 0.0f) || r.empty()) return;
-	const int reach = n_segs == 2 ? qlens[0] + qlens[1] + max_gap_ref : 0;
-	auto spans_both = [&](const Reg &h) { return n_segs == 2 && h.qs < qlens[0] && h.qe > qlens[0]; };
-	auto share_needed = [&](const Reg &par, const Reg &sec) {
-		const bool beside = par.rev == sec.rev && par.rid == sec.rid && sec.re - par.rs < reach && par.re - sec.rs < reach;
-		if (beside) return pri1;
-		return spans_both(sec) || spans_both(sec) == spans_both(par) ? pri_ratio : pri2;
-	};
 	thread_local std::vector<uint8_t> stays;
 	stays.assign(r.size(), 0);
-	int n_secondary = 0;
-	for (size_t i = 0; i < r.size(); ++i) {
-		const Reg &h = r[i];
-		if (h.parent == (int)i) { stays[i] = 1; continue; }
-		const Reg &par = r[h.parent];
-		const bool good = h.score + min_diff >= par.score || h.score >= par.score * share_needed(par, h);
-		stays[i] = good && n_secondary++ < best_n;
-	}
+	hr_select_secondaries_multi(r.data(), (int)r.size(), stays.data(), pri_ratio, pri1, pri2, max_gap_ref, min_diff, best_n, n_segs, qlens[0], n_segs > 1 ? qlens[1] : 0); // hit_rules.hpp: the device kernel's formulation
 	if (keep_hits(r, [&](size_t i) { return stays[i] != 0; })) sync_regs(r);
 }
 

@@ -44,10 +44,11 @@ double thr_now() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); ret
 bool region_path_supported(const MapOpt &opt, int idx_flag, int n_alt, bool has_annotation)
 {
 	if (!(opt.flag & F_CIGAR)) return false;
-	if (opt.flag & (F_SPLICE | F_SR | F_SR_RNA | F_QSTRAND | F_EQX | F_ALL_CHAINS)) return false;
+	if (opt.flag & (F_SPLICE | F_SR_RNA | F_QSTRAND | F_EQX | F_ALL_CHAINS)) return false;
 	if (n_alt > 0 || has_annotation) return false;
 	(void)idx_flag; // (round 5, late: homopolymer-compressed indices take the device path too -- region_plan_kernel's window boundaries, the summed minimizer spans)
-	if (opt.max_occ > opt.mid_occ && !(opt.flag & F_RMQ)) return false;
+	// (round 6: short reads and their pairs take the device path -- the best diagonal run, the ungapped window, the fragment's chains cut per segment)
+	if (opt.max_occ > opt.mid_occ && !(opt.flag & (F_RMQ | F_SR))) return false; // (the second seeding of map.c:293-316: process_sub keeps the reads concerned on the host; only the short-read path is arranged for it)
 	if (opt.split_prefix) return false;
 	return true;
 }
@@ -76,6 +77,8 @@ Mapper::Mapper(const FlatIndex &fi, const MapOpt &opt, Backend &be, int n_thread
 		if (O.bw_gap < O.bw_ext) O.bw_gap = O.bw_ext;
 		O.a = opt.a, O.b = opt.b, O.q = opt.q, O.e = opt.e, O.zdrop = opt.zdrop, O.zdrop_inv = opt.zdrop_inv, O.end_bonus = opt.end_bonus, O.min_ksw_len = opt.min_ksw_len;
 		O.transition = opt.transition, O.hpc = (fi.flag & I_HPC) ? 1 : 0;
+		O.sc_ambi = opt.sc_ambi;
+		gen_score_matrix(opt, O.mat);
 		rgn_ok_ = region_path_supported(opt, fi.flag, fi.n_alt, fi.has_junc || fi.has_jump || fi.has_spsc);
 	}
 	// MM_F_INDEPEND_SEG / MM_F_WEAK_PAIRING are resolved at the boundary (capi_map.cpp)
@@ -393,11 +396,11 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			sp_lazy.lazy_chains = lazy ? 1 : 0;
 		}
 		be_.seed_chain(sp_lazy, lo, hi, lane, n_threads_, chains);
+		std::vector<long> again; // reads to be seeded a second time (below, after the device has taken the others)
 		if (opt_.max_occ > opt_.mid_occ && !(opt_.flag & F_RMQ)) {
 			// map.c:293-316 for single-segment reads: a read that found no chain although it has repetitive minimizers is seeded
 			// again with the occurrence cap raised to max_occ and chained again.  Rare (only with -f x,y): the whole sub-batch is
 			// seeded a second time and the results of the reads concerned replace the first ones.
-			std::vector<long> again;
 			for (long i = 0; i < m; ++i) {
 				const ReadChains &c = chains[i];
 				if (c.rep_len <= 0) continue;
@@ -416,16 +419,18 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 				}
 				if (rechain) again.push_back(i);
 			}
-			if (!again.empty()) {
-				for (long i = 0; i < m; ++i) chains[i].take_ownership(); // the backend's buffers are about to be reused
-				SeedChainParams sp2 = sp;
-				sp2.mid_occ = opt_.max_occ;
-				sp2.long_join = 0; // map.c:293: this branch is the ELSE of the long-join: its chains are final
-				std::vector<ReadChains> second;
-				be_.seed_chain(sp2, lo, hi, lane, n_threads_, second);
-				for (long i : again) { chains[i] = second[i]; chains[i].take_ownership(); chains[i].long_join_done = true; }
-			}
 		}
+		auto seed_again = [&](const std::vector<uint8_t> *on_device) {
+			if (again.empty()) return;
+			for (long i = 0; i < m; ++i) if (!on_device || !(*on_device)[i]) chains[i].take_ownership(); // the backend's buffers are about to be reused (a read the device finished needs its chains no more)
+			SeedChainParams sp2 = sp;
+			sp2.mid_occ = opt_.max_occ;
+			sp2.long_join = 0; // map.c:293: this branch is the ELSE of the long-join: its chains are final
+			std::vector<ReadChains> second;
+			be_.seed_chain(sp2, lo, hi, lane, n_threads_, second);
+			for (long i : again) { chains[i] = second[i]; chains[i].take_ownership(); chains[i].long_join_done = true; }
+		};
+		if (!batch.device_regions) seed_again(nullptr);
 		stats.t_seed_chain += now() - t0; t0 = now();
 		stats.c_seed_chain += cpu_now() - c0; c0 = cpu_now(); stats.d_seed_chain += thr_now() - d0; d0 = thr_now();
 
@@ -443,21 +448,26 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			std::vector<Backend::RegionReadIn> &in = ds.rg_in;
 			in.resize((size_t)m);
 			const bool host_long_join = opt_.bw_long > opt_.bw && (opt_.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0;
+			const bool pairs_on_device = (opt_.flag & F_SR) != 0; // (two-segment fragments of the other presets go through mm_est_err on the fragment first, map.c:333: the host's)
 			parallel_for(n_threads_, m, [&](long i, int) {
 				const ReadChains &c = chains[i];
 				const ReadView &rv = live[lo + i];
-				// the host keeps: pairs, reads the backend did not chain, reads whose long-join question (map.c:283-292) is still open
-				in[i].skip = rv.paired() || !c.chained || c.dev_src < 0 || (host_long_join && !c.long_join_done && c.n_u > 1);
+				// the host keeps: pairs (but the short-read path's), reads the backend did not chain, reads whose long-join question (map.c:283-292) is still open
+				in[i].skip = (rv.paired() && !pairs_on_device) || !c.chained || c.dev_src < 0 || (host_long_join && !c.long_join_done && c.n_u > 1);
 				in[i].hash = read_hash(rv.name, rv.total(), opt_);
+				int gap_qry;
+				chain_gaps(sp, rv.total(), &in[i].gap_ref, &gap_qry);
 			}, 1024);
+			for (long i : again) in[i].skip = true; // (seeded again below: the host path takes them from their second chains)
 			be_.align_regions(lane, rgn_opts_, sc, !is_sr, chains, in, n_threads_, rb);
 			long n_dev = 0;
-			for (long i = 0; i < m; ++i) on_dev[i] = !in[i].skip && rb.reads[i].flags == 0, n_dev += on_dev[i];
+			for (long i = 0; i < m; ++i) on_dev[i] = !in[i].skip && rb.reads[(size_t)i * (size_t)rb.rout_stride].flags == 0, n_dev += on_dev[i];
 			if (lazy) { // the hand-backs' chains come to the host now
 				std::vector<long> back;
 				for (long i = 0; i < m; ++i) if (!on_dev[i] && chains[i].chained && chains[i].dev_src >= 0) back.push_back(i);
 				be_.fetch_chains(lane, back, chains);
 			}
+			seed_again(&on_dev);
 			stats.n_region_reads_dev += n_dev, stats.n_region_reads_host += m - n_dev;
 			stats.n_jobs += (long)rb.n_jobs, stats.dp_cells += rb.dp_cells, stats.n_rounds += rb.n_jobs ? 1 : 0;
 			stats.t_ksw += now() - t0; t0 = now();
@@ -499,7 +509,7 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 				int gap_ref, gap_qry;
 				chain_gaps(sp, qlen, &gap_ref, &gap_qry);
 				res.frag_gap = gap_ref, res.rep_len = c.rep_len; // map.c:317-318
-				ra[u0].tasks.clear(), ra[u0].order.clear(), ra[u0].finish_queue.clear();
+				for (long k = u0; k < unit0[i + 1]; ++k) ra[k].tasks.clear(), ra[k].order.clear(), ra[k].finish_queue.clear();
 				return;
 			}
 			const uint32_t hash = read_hash(rv.name, qlen, opt_);
@@ -588,7 +598,7 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 		std::vector<KswRes> &kres = ds.kres;
 		const uint32_t *cigars = nullptr;
 		std::vector<uint8_t> active(mu, 1);
-		for (long i = 0; i < m; ++i) if (on_dev[i]) active[unit0[i]] = 0; // (a read the device finished is a single unit)
+		for (long i = 0; i < m; ++i) if (on_dev[i]) for (long k = unit0[i]; k < unit0[i + 1]; ++k) active[k] = 0; // (a read the device finished; both segments of a pair)
 		for (int round = 0;; ++round) {
 			t0 = now(), c0 = cpu_now(), d0 = thr_now();
 			parallel_for(n_threads_, mu, [&](long i, int tid) {
@@ -691,7 +701,7 @@ void Mapper::process_sub(BatchRun &batch, long lo, long hi, int lane, std::vecto
 			const int n_segs = rv.paired() ? 2 : 1;
 			for (int s = 0; s < n_segs; ++s) {
 				RegVec &regs = s == 0 ? res.regs : res.regs2;
-				if (on_dev[i]) device_hits(rb, chains[i], i, rv.len, regs), al[tid]->finish_regs(rv.len, regs);
+				if (on_dev[i]) device_hits(rb, chains[i], i * rb.rout_stride + s, s == 0 ? rv.len : rv.len2, regs), al[tid]->finish_regs(s == 0 ? rv.len : rv.len2, regs);
 				else al[tid]->finish_read(ra[unit0[i] + s], regs);
 				if (!(opt_.flag & F_ALL_CHAINS)) {
 					set_parent(opt_.mask_level, opt_.mask_len, regs, opt_.a * 2 + opt_.b, opt_.flag & F_HARD_MLEVEL, opt_.alt_drop);

@@ -41,7 +41,8 @@ __device__ __forceinline__ int rg_wave_min(int v)
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // chain_regs_kernel
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// LDS per read (C = lds_chains): hit records 80 C, sort keys 8 C, interval list 8 C, five 32-bit arrays, the order and the keep flags: 119 C bytes
+// LDS per read (C = lds_chains): hit records 80 C, sort keys 8 C, interval list 8 C, five 32-bit arrays, the order and the keep flags: 119 C bytes;
+// with two-segment fragments in the launch another 80 C for a segment's hit records
 __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 {
 	MM2_DYN_LDS(uint64_t, s_raw);
@@ -54,21 +55,25 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	int32_t *s_prim = s_nt + C, *s_where = s_prim + C; // C + C: the primaries so far; the id map of a compaction
 	int16_t *s_ord = (int16_t *)(s_where + C);         // C: chain at each rank
 	uint8_t *s_keep = (uint8_t *)(s_ord + C);          // C
+	Reg1 *s_seg = (Reg1 *)(s_raw + ((size_t)C * 119 + 7) / 8); // C hit records of one segment (two-segment fragments only)
 	__shared__ int32_t s_hdr[4];
 
 	const RgnRead rd = B.reads[rd_i];
+	RgnReadOut *const rout = B.rout + (size_t)rd_i * (size_t)B.rout_stride;
 	RgnReadOut out;
 	out.reg0 = 0, out.n_regs = 0, out.n_a_sq = 0, out.flags = 0, out.avg_k = 0.0f, out.pad = 0;
 	const int n = rd.n_u;
+	const bool is_sr = (O.flag & ref::F_SR) != 0, paired = rd.qlen2 > 0;
+	if (paired && lane == 0) rout[0] = out, rout[1] = out;
 	if ((rd.src & RGN_SRC_SKIP) || n > C || n == 0) {
 		if (rd.src & RGN_SRC_SKIP) out.flags = RGN_F_SKIPPED;
 		else if (n > C) out.flags = RGN_F_MANY_CHAINS;
-		if (lane == 0) B.rout[rd_i] = out;
+		if (lane == 0) rout[0] = out;
 		return;
 	}
 	const Anchor *a = B.a_src[rd.src & RGN_SRC_LJ] + rd.a_off;
 	const uint64_t *u = B.u_src[rd.src & RGN_SRC_LJ] + rd.u_off;
-	const int qlen = rd.qlen;
+	const int qlen = rd.qlen + rd.qlen2; // (a fragment's chains were found on the concatenation of its segments)
 
 	// chain starts: the chains' anchors lie back to back in chain order
 	if (lane == 0) { int acc = 0; for (int i = 0; i < n; ++i) { s_start[i] = acc; acc += (int32_t)u[i]; } }
@@ -88,7 +93,7 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	}
 	if (__ballot(tie)) {
 		out.flags = RGN_F_SORT_TIE;
-		if (lane == 0) B.rout[rd_i] = out;
+		if (lane == 0) rout[0] = out;
 		return;
 	}
 	RG_SYNC();
@@ -115,7 +120,8 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 		if (!(O.flag & ref::F_ALL_CHAINS)) {
 			hr_mark_parents(s_reg, n, s_cov, s_prim, O.mask_level, O.mask_len, O.sub_diff, (O.flag & ref::F_HARD_MLEVEL) != 0, 0.0f);
 			if (O.pri_ratio > 0.0f) {
-				hr_select_secondaries(s_reg, n, s_keep, O.pri_ratio, O.k * 2, O.best_n, true, O.min_strand_sc);
+				if (paired) hr_select_secondaries_multi(s_reg, n, s_keep, O.pri_ratio, 0.2f, 0.7f, rd.gap_ref, O.k * 2, O.best_n, 2, rd.qlen, rd.qlen2); // map.c:211
+				else hr_select_secondaries(s_reg, n, s_keep, O.pri_ratio, O.k * 2, O.best_n, true, O.min_strand_sc);
 				m = 0;
 				for (int i = 0; i < n; ++i) if (s_keep[i]) { if (m < i) s_reg[m] = s_reg[i]; ++m; }
 				if (m != n) hr_renumber(s_reg, m, s_where, n);
@@ -127,16 +133,101 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 	}
 	RG_SYNC();
 	const int m = s_hdr[0];
-	if (s_hdr[1]) { // mm_filter_strand_retained (hit.c:283-299) compares divergences: libm's pow decides, on the host
+	if (s_hdr[1] && !is_sr) { // mm_filter_strand_retained (hit.c:283-299) compares divergences: libm's pow decides, on the host (short reads skip the filter, map.c:333)
 		out.flags = RGN_F_STRAND_RETAINED;
-		if (lane == 0) B.rout[rd_i] = out;
+		if (lane == 0) rout[0] = out;
+		return;
+	}
+	if (paired) {
+		// ---- two segments (mm_seg_gen, hit.c:342-396): every segment gets the chains that have anchors on it -- with the fragment chain's score and its own anchor
+		// count -- and those anchors in its own coordinates, chain by chain; its hit records are made and ranked like a read's, parents marked again (map.c:346) ----
+		for (int sg = 0; sg < 2; ++sg) {
+			const int before = sg ? rd.qlen : 0, seg_len = sg ? rd.qlen2 : rd.qlen;
+			Anchor *sq = B.sq_a + rd.sq_off + (sg ? (uint64_t)rd.n_a : 0ull);
+			int acc = 0;
+			for (int c = 0; c < m; ++c) {
+				const int st = s_reg[c].as, cnt = s_reg[c].cnt;
+				int n_on = 0;
+				for (int i0 = 0; i0 < cnt; i0 += 64) {
+					const int i = i0 + lane;
+					bool on = false;
+					Anchor x; x.x = x.y = 0;
+					if (i < cnt) { x = a[st + i]; on = hr_anchor_seg(x) == sg; }
+					const unsigned long long mk = __ballot(on);
+					if (on) sq[acc + n_on + __popcll(mk & ((1ull << lane) - 1ull))] = hr_seg_anchor(x, qlen, before, seg_len);
+					n_on += __popcll(mk);
+				}
+				if (lane == 0) s_nm[c] = n_on, s_nt[c] = acc;
+				acc += n_on;
+			}
+			RG_SYNC();
+			if (lane == 0) { int ns = 0; for (int c = 0; c < m; ++c) if (s_nm[c] > 0) s_where[ns++] = c; s_hdr[0] = ns; }
+			RG_SYNC();
+			const int ns = s_hdr[0];
+			for (int i = lane; i < ns; i += 64) {
+				const int c = s_where[i];
+				s_key[i] = hr_chain_key((uint64_t)s_reg[c].score << 32 | (uint32_t)s_nm[c], sq[s_nt[c]], rd.hash);
+			}
+			RG_SYNC();
+			int tie2 = 0;
+			for (int i = lane; i < ns; i += 64) {
+				const uint64_t me = s_key[i];
+				int rank = 0;
+				for (int j = 0; j < ns; ++j) { const uint64_t o = s_key[j]; rank += o > me; tie2 |= (o == me && j != i); }
+				s_ord[rank] = (int16_t)i;
+			}
+			if (__ballot(tie2)) { // (segment 0's records may be out already: the flag in the read's first entry makes the host take the whole fragment)
+				if (lane == 0) atomicOr(&rout[0].flags, (unsigned)RGN_F_SORT_TIE);
+				return;
+			}
+			RG_SYNC();
+			for (int p = lane; p < ns; p += 64) {
+				const int i = s_ord[p], c = s_where[i];
+				Reg1 r;
+				hr_new_hit(r, p, s_key[i], s_nt[c], s_nm[c], seg_len, sq, false);
+				r.seg_split = 1, r.seg_id = (uint32_t)sg;
+				s_seg[p] = r;
+			}
+			RG_SYNC();
+			for (int p = 0; p < ns; ++p) {
+				const int st = s_seg[p].as, cnt = s_seg[p].cnt;
+				int ml = 0, bl = 0;
+				for (int i = 1 + lane; i < cnt; i += 64) hr_fuzzy_step(sq[st + i], sq[st + i - 1], &bl, &ml);
+				ml = rg_wave_sum(ml), bl = rg_wave_sum(bl);
+				if (lane == 0) { const int s0 = rg_span(sq[st]); s_seg[p].mlen = ml + s0, s_seg[p].blen = bl + s0; }
+			}
+			RG_SYNC();
+			if (lane == 0) {
+				if (!(O.flag & ref::F_ALL_CHAINS)) hr_mark_parents(s_seg, ns, s_cov, s_prim, O.mask_level, O.mask_len, O.sub_diff, (O.flag & ref::F_HARD_MLEVEL) != 0, 0.0f);
+				s_hdr[3] = (int32_t)atomicAdd(&B.cursors[RGN_CUR_REGS], (unsigned)ns);
+			}
+			RG_SYNC();
+			const uint32_t reg0 = (uint32_t)s_hdr[3];
+			RgnReadOut so = out;
+			if (reg0 + (uint32_t)ns <= B.max_regs) {
+				uint32_t *dst = (uint32_t *)(B.regs + reg0);
+				const uint32_t *srcw = (const uint32_t *)s_seg;
+				for (int w = lane; w < ns * 20; w += 64) dst[w] = srcw[w];
+				for (int p = lane; p < ns; p += 64) {
+					RgnAux x; x.n_match = 0, x.n_tot = -1;
+					B.aux[reg0 + p] = x;
+					RgnPlan pl;
+					__builtin_memset(&pl, 0, sizeof pl);
+					pl.read = (uint32_t)rd_i, pl.status = -1, pl.seg = sg;
+					B.plan[reg0 + p] = pl;
+				}
+			} else if (lane == 0) atomicOr(&rout[0].flags, (unsigned)RGN_F_MANY_CHAINS);
+			so.reg0 = reg0, so.n_regs = ns, so.n_a_sq = acc;
+			if (lane == 0) rout[sg].reg0 = so.reg0, rout[sg].n_regs = so.n_regs, rout[sg].n_a_sq = so.n_a_sq; // (the flags of entry 0 may have been raised already: fields one by one)
+			RG_SYNC();
+		}
 		return;
 	}
 	// mm_est_err's counts (esterr.c:30-64): how many of the minimizers between a hit's first and last anchor are anchors of the hit.  The
 	// reference walks the read's minimizer positions and the chain together; both ascend strictly, so "anchor k is found after anchor k - 1"
 	// is one binary search per anchor, and the walk stops at the first anchor that is not found.
 	const uint64_t *mp = B.mini_pos + rd.mp_off;
-	const int n_mp = rd.n_mp;
+	const int n_mp = is_sr ? 0 : rd.n_mp; // (short reads: no divergence estimate, map.c:333)
 	// (esterr.c:37-40: the mean minimizer span -- k for every one of them without HPC; with it the spans are summed, by all lanes)
 	uint64_t sum_k = (uint64_t)n_mp * (uint64_t)O.k;
 	if (O.hpc) {
@@ -195,7 +286,7 @@ __global__ void __launch_bounds__(64) chain_regs_kernel(RgnBuffers B, RgnOpts O)
 		}
 	} else out.flags = RGN_F_MANY_CHAINS; // (cannot happen: the host sizes the arrays by the chain count)
 	out.reg0 = reg0, out.n_regs = m, out.n_a_sq = s_hdr[2], out.avg_k = avg_k;
-	if (lane == 0) B.rout[rd_i] = out;
+	if (lane == 0) rout[0] = out;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -222,6 +313,53 @@ __device__ int rg_gap_sites(const Anchor *a, int cnt1, int min_gap, int32_t *K, 
 // (the two long-gap filters, the end trimming and the extension limits: region_rules.hpp -- one definition for this kernel and for align.cpp)
 
 struct RgnJobCtx { uint64_t q_fwd, q_rev, t_base; int rev, gen_flag; };
+
+// a region's read as the window rules see it: the read itself, or one segment of a fragment (its own length, query block and squeezed anchors)
+struct RgnUnit { int32_t qlen, n_a; uint64_t qpool_fwd, sq_off; };
+__device__ __forceinline__ RgnUnit rg_unit(const RgnBuffers &B, const RgnRead &rd, uint32_t read, int seg)
+{
+	RgnUnit u;
+	u.qlen = seg ? rd.qlen2 : rd.qlen;
+	u.qpool_fwd = rd.qpool_fwd + (seg ? 2ull * (uint64_t)rd.qlen : 0ull);
+	u.sq_off = rd.sq_off + (seg ? (uint64_t)rd.n_a : 0ull);
+	u.n_a = B.rout[(size_t)read * (size_t)B.rout_stride + (size_t)seg].n_a_sq;
+	return u;
+}
+
+// A short read's one gap window lies on one diagonal (align.c:823-833): the score of its ungapped alignment, and the largest drop of the running score below its
+// running maximum -- what mm_test_zdrop (align.c:59-84) finds on a CIGAR of one M.  All lanes, 64 columns per step; every lane returns both.
+__device__ void rg_ungapped(const RgnBuffers &B, const RgnOpts &O, const RgnJobCtx &X, int32_t qs, int32_t rs, int32_t len, int lane, int32_t *score, int32_t *max_drop)
+{
+	const uint8_t *q = B.qpool + (X.rev ? X.q_rev : X.q_fwd) + (uint64_t)qs;
+	const int amb = O.sc_ambi > 0 ? -O.sc_ambi : O.sc_ambi;
+	int32_t sum = 0, run = 0, run_max = INT32_MIN, drop = 0;
+	for (int32_t j0 = 0; j0 < len; j0 += 64) {
+		const int32_t j = j0 + lane;
+		int s1 = 0, s2 = 0;
+		if (j < len) {
+			const int cq = q[j];
+			const uint64_t o = X.t_base + (uint64_t)(rs + j);
+			const int ct = (int)(B.S[o >> 3] >> ((o & 7) << 2) & 0xf);
+			s1 = cq >= 4 || ct >= 4 ? amb : cq == ct ? O.a : -O.b;
+			s2 = O.mat[(ct > 4 ? 4 : ct) * 5 + (cq > 4 ? 4 : cq)];
+		}
+		sum += s1;
+		int pre = s2;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(pre, d, 64); if (lane >= d) pre += t; }
+		const int sc = run + pre;
+		int mx = j < len ? sc : INT32_MIN;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(mx, d, 64); if (lane >= d) mx = t > mx ? t : mx; }
+		mx = mx > run_max ? mx : run_max;
+		if (j < len && mx - sc > drop) drop = mx - sc;
+		run = __shfl(sc, 63, 64), run_max = __shfl(mx, 63, 64);
+	}
+	sum = rg_wave_sum(sum);
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(drop, d, 64); drop = o > drop ? o : drop; }
+	*score = sum, *max_drop = drop;
+}
 
 // where an anchor's window boundary sits (mm_adjust_minier, align.c:418-433): the middle of the k-mer -- or, with a homopolymer-compressed index, the start of the
 // homopolymer run that holds the anchor's last base, on the query strand being aligned and on the reference
@@ -311,19 +449,64 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 	const Reg1 r = B.regs[slot];
 	RgnPlan pl = B.plan[slot];
 	const RgnRead rd = B.reads[pl.read];
-	const RgnReadOut ro = B.rout[pl.read];
-	Anchor *a = B.sq_a + rd.sq_off;               // the READ's squeezed anchors: the extension limits look at its other hits' anchors too
-	const int qlen = rd.qlen, n_a = ro.n_a_sq;
-	pl.status = 0, pl.n_win = 0;
+	const RgnUnit U = rg_unit(B, rd, pl.read, pl.seg);
+	Anchor *a = B.sq_a + U.sq_off;                // the READ's squeezed anchors: the extension limits look at its other hits' anchors too
+	const int qlen = U.qlen, n_a = U.n_a;
+	pl.status = 0, pl.n_win = 0, pl.ug_len = 0, pl.ug_score = 0;
 	if (r.cnt == 0) { pl.status = RGN_F_NO_CIGAR; if (lane == 0) B.plan[slot] = pl; return; }
 	const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
 	const int32_t ref_len = (int32_t)B.ref_len[rid];
 	int32_t as1 = r.as, cnt1 = r.cnt;
+	if (O.flag & ref::F_SR) {
+		// ---- a short read (align.c:664-669, :696-704, :803-833): aligned from its best run of seeds on one diagonal -- one gap window from the run's first seed to its
+		// last, an M if the ungapped alignment beats any gapped one --, the extensions over the whole read and as much reference as its unaligned ends could span ----
+		if (lane == 0) rr_best_diagonal_run(r, a, &as1, &cnt1); // mm_max_stretch, align.c:563-589
+		as1 = __shfl(as1, 0, 64), cnt1 = __shfl(cnt1, 0, 64);
+		const Anchor f = a[as1], l = a[as1 + cnt1 - 1];
+		const int32_t rs = rg_x(f) + 1 - rg_span(f), qs = rg_y(f) + 1 - rg_span(f), re = rg_x(l) + 1, qe = rg_y(l) + 1;
+		int32_t qs0 = 0, qe0 = qlen;
+		int32_t rs0 = rs - rr_sr_reach(qs, O.a, O.q, O.e, O.end_bonus), re0 = re + rr_sr_reach(qlen - qe, O.a, O.q, O.e, O.end_bonus);
+		rs0 = rs0 > 0 ? rs0 : 0, re0 = re0 < ref_len ? re0 : ref_len;
+		if (a[r.as].y & ref::SEED_SELF) { // align.c:760-767
+			const int32_t room_l = r.qs > r.rs ? r.qs - r.rs : r.rs - r.qs, room_r = r.qe > r.re ? r.qe - r.re : r.re - r.qe;
+			rs0 = rr_self_limit(rs0, r.rs, room_l), qs0 = rr_self_limit(qs0, r.qs, room_l);
+			re0 = ref_len - rr_self_limit(ref_len - re0, ref_len - r.re, room_r), qe0 = qlen - rr_self_limit(qlen - qe0, qlen - r.qe, room_r);
+		}
+		RgnJobCtx X;
+		X.q_fwd = U.qpool_fwd, X.q_rev = U.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
+		X.gen_flag = O.transition != 0 && O.b != O.transition ? KSW_GENERIC_SC : 0;
+		const int32_t len = qe - qs;
+		int32_t ug = 0, drop = 0;
+		bool ungapped = false;
+		if (len == re - rs && len > 0) {
+			rg_ungapped(B, O, X, qs, rs, len, lane, &ug, &drop);
+			ungapped = ug > (len - 2) * O.a - 2 * (O.q + O.e);
+		}
+		const bool has_left = qs > 0 && rs > 0, has_right = qe < qe0 && re < re0;
+		const int n_win = (has_left ? 1 : 0) + (ungapped ? 0 : 1) + (has_right ? 1 : 0);
+		uint32_t job0 = 0, piece0 = 0;
+		if (lane == 0) job0 = atomicAdd(&B.cursors[RGN_CUR_JOBS], (unsigned)n_win), piece0 = atomicAdd(&B.cursors[RGN_CUR_PIECES], 3u);
+		job0 = (uint32_t)__shfl((int)job0, 0, 64), piece0 = (uint32_t)__shfl((int)piece0, 0, 64);
+		pl.job0 = job0, pl.piece0 = piece0, pl.n_win = n_win, pl.as1 = as1, pl.cnt1 = cnt1, pl.rid = rid, pl.rev = rev, pl.rs = rs, pl.qs = qs, pl.has_left = has_left, pl.has_right = has_right;
+		if (ungapped) {
+			pl.ug_len = len, pl.ug_score = ug;
+			if (drop > O.zdrop) pl.status = RGN_F_MULTI_ROUND; // (the Z-drop test of the M trips: a second, exact pass -- the host's rounds; align.c:843-844)
+		}
+		if (job0 + (uint32_t)n_win > B.max_jobs || piece0 + 3u > B.max_jobs) pl.status = RGN_F_MULTI_ROUND, pl.n_win = 0;
+		if (pl.status == 0 && lane == 0) {
+			uint32_t idx = job0;
+			if (has_left) rg_emit(B, O, X, idx++, 0, qs0, qs, rs0, rs, O.bw_ext, 0, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, r.split_inv ? O.zdrop_inv : O.zdrop, O.end_bonus);
+			if (!ungapped) rg_emit(B, O, X, idx++, 1, qs, qe, rs, re, O.bw_gap, cnt1 - 1, KSW_APPROX_MAX, O.zdrop, -1);
+			if (has_right) rg_emit(B, O, X, idx, 2, qe, qe0, re, re0, O.bw_ext, 0, KSW_EXTZ_ONLY, O.zdrop, O.end_bonus);
+		}
+		if (lane == 0) B.plan[slot] = pl;
+		return;
+	}
 	if (!(O.flag & ref::F_NO_END_FLT)) {
 		if (lane == 0) rr_trim_ends(r, a, O.bw, O.min_chain_score * 2, &as1, &cnt1); // mm_fix_bad_ends, align.c:527-561
 		as1 = __shfl(as1, 0, 64), cnt1 = __shfl(cnt1, 0, 64);
 	}
-	int32_t *K = B.gap_sites + rd.sq_off + as1;
+	int32_t *K = B.gap_sites + U.sq_off + as1;
 	{
 		const int n10 = rg_gap_sites(a + as1, cnt1, 10, K, lane);
 		RG_SYNC();
@@ -335,7 +518,7 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 		RG_SYNC(); // (the flags lane 0 set in the anchors are read by all lanes below)
 	}
 	RgnJobCtx X;
-	X.q_fwd = rd.qpool_fwd, X.q_rev = rd.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
+	X.q_fwd = U.qpool_fwd, X.q_rev = U.qpool_fwd + (uint64_t)qlen, X.t_base = B.ref_off[rid], X.rev = rev;
 	X.gen_flag = O.transition != 0 && O.b != O.transition ? KSW_GENERIC_SC : 0; // align.c:347-348
 	int32_t rs, qs, re, qe; // the boundaries of the first and the last anchor (mm_adjust_minier, align.c:418-433)
 	rg_boundary(B, O, X, a[as1], &rs, &qs);
@@ -378,7 +561,7 @@ __global__ void __launch_bounds__(256) region_plan_kernel(RgnBuffers B, RgnOpts 
 	uint32_t job0 = 0;
 	if (lane == 0) job0 = atomicAdd(&B.cursors[RGN_CUR_JOBS], (unsigned)n_win);
 	job0 = (uint32_t)__shfl((int)job0, 0, 64);
-	pl.job0 = job0, pl.n_win = n_win, pl.as1 = as1, pl.cnt1 = cnt1, pl.rid = rid, pl.rev = rev, pl.rs = rs, pl.qs = qs, pl.has_left = has_left, pl.has_right = has_right;
+	pl.job0 = job0, pl.piece0 = job0, pl.n_win = n_win, pl.as1 = as1, pl.cnt1 = cnt1, pl.rid = rid, pl.rev = rev, pl.rs = rs, pl.qs = qs, pl.has_left = has_left, pl.has_right = has_right;
 	if (job0 + (uint32_t)n_win > B.max_jobs) { pl.status = RGN_F_MULTI_ROUND, pl.n_win = 0; if (lane == 0) B.plan[slot] = pl; return; } // (cannot happen: sized by anchors + 2 per chain)
 	uint32_t idx = job0;
 	if (has_left) { if (lane == 0) rg_emit(B, O, X, idx, 0, qs0, qs, rs0, rs, O.bw_ext, 0, KSW_EXTZ_ONLY | KSW_RIGHT | KSW_REV_CIGAR, r.split_inv ? O.zdrop_inv : O.zdrop, O.end_bonus); ++idx; }
@@ -398,21 +581,39 @@ __global__ void __launch_bounds__(64) region_consume_kernel(RgnBuffers B, RgnOpt
 	RgnPlan pl = B.plan[slot];
 	FinRegion fr;
 	__builtin_memset(&fr, 0, sizeof fr);
-	if (pl.status != 0 || pl.n_win <= 0) {
+	if (pl.status != 0 || (pl.n_win <= 0 && pl.ug_len <= 0)) {
 		if (pl.status == 0) pl.status = RGN_F_NO_CIGAR;
 		B.fin[slot] = fr, B.plan[slot] = pl;
-		atomicOr(&B.rout[pl.read].flags, (unsigned)pl.status);
+		atomicOr(&B.rout[(size_t)pl.read * (size_t)B.rout_stride].flags, (unsigned)pl.status);
 		return;
 	}
 	const RgnRead rd = B.reads[pl.read];
+	const RgnUnit U = rg_unit(B, rd, pl.read, pl.seg);
 	int32_t rs1 = pl.rs, qs1 = pl.qs, re1 = pl.rs, qe1 = pl.qs; // no left extension: the alignment starts at the first anchor (align.c:800-801)
 	int32_t dp = 0;
 	uint32_t cap = 0, n_ops = 0, last_op = 0, n_pieces = 0, sum_ops = 0;
 	int status = 0;
 	const bool inv_test_off = (O.flag & (ref::F_SPLICE | ref::F_SR | ref::F_FOR_ONLY | ref::F_REV_ONLY)) != 0;
-	for (int k = 0; k < pl.n_win && status == 0; ++k) {
+	bool ug_todo = pl.ug_len > 0; // a short read's ungapped gap window: between the left extension and the right one, an M of its own (no DP job)
+	for (int k = 0; k <= pl.n_win && status == 0; ++k) {
 		const uint32_t job = pl.job0 + (uint32_t)k;
-		const RgnWin w = B.win[job];
+		RgnWin w;
+		w.kind = 2;
+		if (k < pl.n_win) w = B.win[job];
+		if (ug_todo && w.kind == 2) {
+			ug_todo = false;
+			dp += pl.ug_score;
+			re1 = pl.rs + pl.ug_len, qe1 = pl.qs + pl.ug_len;
+			const uint32_t word = (uint32_t)pl.ug_len << 4; // MM_CIGAR_MATCH
+			FinPiece pc; pc.off = word, pc.n = kFinLiteral;
+			B.pieces[pl.piece0 + n_pieces++] = pc;
+			sum_ops += 1;
+			if (cap == 0) cap = rg_roundup32(1 + 7);
+			else if (n_ops + 1 + 7 > cap) cap = rg_roundup32(n_ops + 1 + 7);
+			n_ops += n_ops > 0 && last_op == 0 ? 0 : 1;
+			last_op = 0;
+		}
+		if (k == pl.n_win) break;
 		const KswRes ez = B.res[B.perm[job]];
 		bool take = ez.n_cigar > 0;
 		if (w.kind == 1) { // a gap fill: the approximate pass is tested first (align.c:843; mm_test_zdrop on the kernel's own scan of its alignment)
@@ -434,7 +635,7 @@ __global__ void __launch_bounds__(64) region_consume_kernel(RgnBuffers B, RgnOpt
 		if (take) {
 			const uint32_t n = (uint32_t)ez.n_cigar;
 			FinPiece pc; pc.off = ez.cigar_off, pc.n = n;
-			B.pieces[pl.job0 + n_pieces++] = pc;
+			B.pieces[pl.piece0 + n_pieces++] = pc;
 			sum_ops += n;
 			// mm_extra_t's growth, as mm_append_cigar would have done it window by window (align.c:305-334): the hand-over carries `capacity`
 			if (cap == 0) cap = rg_roundup32(n + 7);
@@ -450,16 +651,16 @@ __global__ void __launch_bounds__(64) region_consume_kernel(RgnBuffers B, RgnOpt
 		Reg1 r = B.regs[slot];
 		r.rs = rs1, r.re = re1;
 		if (!pl.rev) r.qs = qs1, r.qe = qe1; // align.c:894
-		else r.qs = rd.qlen - qe1, r.qe = rd.qlen - qs1;
+		else r.qs = U.qlen - qe1, r.qe = U.qlen - qs1;
 		B.regs[slot] = r;
-		fr.q_pos = (pl.rev ? rd.qpool_fwd + (uint64_t)rd.qlen : rd.qpool_fwd) + (uint64_t)qs1;
+		fr.q_pos = (pl.rev ? U.qpool_fwd + (uint64_t)U.qlen : U.qpool_fwd) + (uint64_t)qs1;
 		fr.t_pos = B.ref_off[pl.rid] + (uint64_t)rs1;
-		fr.piece0 = pl.job0, fr.n_pieces = n_pieces;
+		fr.piece0 = pl.piece0, fr.n_pieces = n_pieces;
 		fr.out_off = atomicAdd(&B.cursors[RGN_CUR_OUT], sum_ops);
 		fr.q_len = qe1 - qs1, fr.t_len = re1 - rs1;
 		atomicMax(&B.cursors[RGN_CUR_MAX_OPS], sum_ops);
 		atomicAdd(&B.cursors[RGN_CUR_N_FIN], 1u);
-	} else atomicOr(&B.rout[pl.read].flags, (unsigned)status);
+	} else atomicOr(&B.rout[(size_t)pl.read * (size_t)B.rout_stride].flags, (unsigned)status);
 	B.fin[slot] = fr, B.plan[slot] = pl;
 }
 
@@ -499,7 +700,7 @@ void launch_chain_regs(const RgnBuffers &B, const RgnOpts &O, void *stream)
 {
 	if (B.n_reads <= 0) return;
 	const size_t C = (size_t)B.lds_chains;
-	const size_t lds = C * (80 + 8 + 8 + 4 * 5 + 2 + 1) + 64;
+	const size_t lds = C * (80 + 8 + 8 + 4 * 5 + 2 + 1) + 64 + (B.rout_stride == 2 ? C * 80 + 8 : 0);
 	hipLaunchKernelGGL(chain_regs_kernel, dim3(B.n_reads), dim3(64), lds, (hipStream_t)stream, B, O);
 	HIP_CHECK(hipGetLastError());
 }

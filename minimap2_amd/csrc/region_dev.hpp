@@ -38,6 +38,8 @@ struct RgnOpts {              // uniform over a launch: what the per-read code r
 	int bw_ext, bw_gap;       // (int)(bw * 1.5 + 1.), and the same of bw_long, at least bw_ext (align.c:676-678)
 	int a, b, q, e, zdrop, zdrop_inv, end_bonus, min_ksw_len, transition;
 	int hpc;                  // mm_idx_t::flag & MM_I_HPC: window boundaries sit at the start of a homopolymer run (mm_adjust_minier, align.c:418-428), minimizer spans vary
+	int sc_ambi;              // short reads: the ungapped score of the one gap window (align.c:823-833)
+	int8_t mat[25];           // ... and the scoring matrix its Z-drop test walks (mm_test_zdrop, align.c:59-84)
 };
 
 enum : uint32_t {             // RgnRead::src
@@ -56,8 +58,12 @@ struct RgnRead {              // per read of the sub-batch, made by the host fro
 	uint64_t qpool_fwd;       // its forward nt4 block in the query pool; the reverse complement follows at + qlen
 	int32_t n_u, n_a, n_mp, qlen;
 	uint32_t hash, src;       // map.c:246-248; RGN_SRC_*
+	// a two-segment fragment (a read pair; round 6): the chains were found on the concatenation of the segments (qlen + qlen2 bases) and are cut per segment
+	// (mm_seg_gen, hit.c:342-396); segment 1's query block follows segment 0's (at + 2 qlen), its squeezed anchors at sq_off + n_a.  qlen2 = 0: a single read
+	int32_t qlen2, gap_ref;   // gap_ref: max_chain_gap_ref of the fragment (map.c:264-270), what mm_select_sub_multi calls "beside"
 };
 
+// One per read -- per SEGMENT when the launch holds fragments (RgnBuffers::rout_stride == 2: entry 2 * read + segment; a hand-back's flags in the read's first entry)
 struct RgnReadOut { uint32_t reg0; int32_t n_regs, n_a_sq; uint32_t flags; float avg_k; uint32_t pad; }; // avg_k: the mean minimizer span mm_est_err divides by (esterr.c:37-40)
 
 struct RgnAux { int32_t n_match, n_tot; };   // mm_est_err's counts (esterr.c:46-60); n_tot < 0: the hit keeps div = -1
@@ -72,6 +78,9 @@ struct RgnPlan {              // one per hit record (same index): what region_pl
 	int32_t dp_score;         // consume: mm_extra_t::dp_score
 	uint32_t capacity;        // consume: what mm_extra_t::capacity would be had the windows' CIGARs been appended one by one (align.c:305-334)
 	int32_t status;           // consume: 0 = finished by region_finish_kernel; > 0: RGN_F_* (the read goes back to the host)
+	uint32_t piece0;          // where the region's pieces go (cursors[RGN_CUR_PIECES]): one per window, plus one for a short read's ungapped window
+	int32_t seg;              // which segment of its fragment the region belongs to
+	int32_t ug_len, ug_score; // short reads: the one gap window lies on one diagonal and its ungapped alignment beats any gapped one (align.c:823-833): no DP job, a single M
 };
 
 struct RgnWin { int32_t qs, qe, rs, re, anchor_i, kind; }; // one DP window = one job (same index); kind: WindowKind
@@ -94,6 +103,7 @@ struct RgnBuffers {           // device pointers of one sub-batch
 	const uint8_t *qpool;     // the reads' nt4 codes (forward | reverse complement) and the packed reference: what an HPC window boundary looks at
 	const uint32_t *S;
 	uint32_t max_regs;        // capacity of regs / aux / plan / fin
+	int rout_stride;          // 1, or 2 when the launch holds two-segment fragments (rout per segment)
 	int lds_chains;           // chains per read the kernel keeps in LDS (multiple of 64)
 	// planning
 	RgnPlan *plan;

@@ -109,8 +109,11 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 			uint32_t first = 0, lastw = 0;
 			if (pi < R.n_pieces) {
 				pc = P.pieces[R.piece0 + pi];
-				if (pc.n) first = P.cigar_pool[pc.off], lastw = P.cigar_pool[pc.off + pc.n - 1];
+				if (pc.n == kFinLiteral) first = lastw = pc.off;
+				else if (pc.n) first = P.cigar_pool[pc.off], lastw = P.cigar_pool[pc.off + pc.n - 1];
 			}
+			const bool literal = pc.n == kFinLiteral;
+			if (literal) pc.n = 1;
 			const bool nonempty = pc.n > 0;
 			const unsigned long long ne = __ballot(nonempty), below = ne & ((1ull << lane) - 1ull);
 			const int prev_lane = below ? 63 - __builtin_clzll(below) : -1;
@@ -120,11 +123,12 @@ __global__ void __launch_bounds__(64) region_finish_kernel(FinParams P)
 			const uint32_t join = nonempty && prev_last == (int)(first & 0xf) ? 1u : 0u;
 			const uint32_t contrib = nonempty ? pc.n - join : 0u;
 			const uint32_t incl = fin_scan_add(contrib, lane), start = n + incl - contrib;
-			s_pc[lane][0] = pc.off, s_pc[lane][1] = pc.n, s_pc[lane][2] = start, s_pc[lane][3] = join;
+			s_pc[lane][0] = pc.off, s_pc[lane][1] = literal ? kFinLiteral : pc.n, s_pc[lane][2] = start, s_pc[lane][3] = join;
 			FIN_SYNC();
 			const uint32_t cnt = R.n_pieces - p0 < 64u ? R.n_pieces - p0 : 64u;
 			for (uint32_t q = 0; q < cnt; ++q) {
 				const uint32_t off = s_pc[q][0], nn = s_pc[q][1], st = s_pc[q][2], jn = s_pc[q][3];
+				if (nn == kFinLiteral) { if (lane == 0 && !jn) cg[st] = off; continue; }
 				const uint32_t *src = P.cigar_pool + off;
 				for (uint32_t j = (uint32_t)lane + jn; j < nn; j += 64) cg[st + j - jn] = src[j];
 			}

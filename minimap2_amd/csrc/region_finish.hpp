@@ -17,7 +17,8 @@ struct FinRegion {        // one region whose windows all came back in the curre
 	uint32_t out_off;     // where the stitched CIGAR goes in the output pool (room for the sum of the pieces)
 	int32_t q_len, t_len; // query / reference bases the CIGAR must cover
 };
-struct FinPiece { uint32_t off, n; }; // a window's CIGAR in the DP batch's pool (KswRes::cigar_off, n_cigar)
+struct FinPiece { uint32_t off, n; }; // a window's CIGAR in the DP batch's pool (KswRes::cigar_off, n_cigar); n == kFinLiteral: ONE operation, and `off` is the CIGAR word itself (a short read's ungapped window)
+constexpr uint32_t kFinLiteral = 0x80000000u;
 struct FinResult { int32_t n_cigar, blen, mlen, n_ambi, dp_max, qshift, tshift, is_spliced; }; // n_cigar < 0: the CIGAR does not cover the windows (a bug: the host throws)
 struct FinParams {
 	const FinRegion *regions; int n_regions;

@@ -167,5 +167,19 @@ print('splice', d['value'], d['ms_per_step'], 'cpu', c.get('value'), c.get('hits
 print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:6]})
 P
        ;;
+srdev) # short reads and pairs through the device region path (chains -> hits per segment -> windows -> DP -> consume -> finish) against the host's plan / consume rounds
+       timeout 900 python -m pytest tests/test_gpu_shortreads.py tests/test_gpu_regions.py -x -q -m gpu 2>&1 | tail -3
+       for m in dev host; do
+         if [ $m = host ]; then export MM2AMD_DEVICE_REGIONS=0; else unset MM2AMD_DEVICE_REGIONS; fi
+         cs="--no-cpu-baseline"; [ $m = dev ] && cs="--cpu-sample 100000"
+         timeout 600 python bench.py --preset sr --reads 1000000 --steps 3 --warmup 1 $cs > $O/r06_bench_sr_${m}_$V.json 2> $O/r06_bench_sr_${m}_$V.log
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_sr_${m}_$V.json').read().strip().split('\\n')[-1]); c=d.get('cpu_baseline') or {}; r=d['roofline']; g=d['config']
+print('sr $m', d['value'], d['ms_per_step'], 'cpu', c.get('value'), c.get('hits_identical_to_gpu'), 'host cpu s/step', g['host_cpu_s_per_step'], g.get('device_path_last_batch'))
+print('   ', g.get('host_cpu_s_per_stage_one_lane_pass'))
+print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:10]})
+P
+       done; unset MM2AMD_DEVICE_REGIONS ;;
 esac
 done
