@@ -118,3 +118,65 @@ def test_python_map_pairs_equals_the_reference_sam(tmp_path):
     want = b"\n".join(l for l in _run([REF_BIN, "-t", "4", "-x", "sr", "-a", ref, f1, f2]).split(b"\n") if not l.startswith(b"@"))
     assert got.rstrip(b"\n") == want.rstrip(b"\n")
     assert len(hits) == 10 and all(len(h) == 2 for h in hits)
+
+
+def _fasta(path):
+    names, seqs = [], []
+    for line in open(path, "rb"):
+        (names if line.startswith(b">") else seqs).append(line.strip().lstrip(b">"))
+    return names, seqs
+
+
+def _pairs_text(rs, rn, triples):
+    import minimap2_amd as mm
+    al = mm.Aligner(rs, preset="sr", names=[x.decode() for x in rn], sam=True, n_threads=4)
+    try:
+        text = al.map_pairs(triples, text=True)
+        st = al.last_stats()
+    finally:
+        al.close()
+    return text, st
+
+
+def test_read_pairs_take_the_device_region_path(tmp_path, monkeypatch):
+    """Round 6: a pair's chains are cut per segment on the device (mm_seg_gen in chain_regs_kernel), each segment planned from its best run of seeds on one diagonal, the
+    ungapped window settled without a DP job (region_plan_kernel), consumed and finished there: nearly every pair must be finished on the device, the SAM records must be
+    the reference's, and MM2AMD_DEVICE_REGIONS=0 (the host's plan / consume rounds) must print the same text."""
+    ref, f1, f2, _ = synth.make_pairs(str(tmp_path), seed=99, n_pairs=600, genome=600000)
+    rn, rs = _fasta(ref)
+    n1, s1 = _fasta(f1)
+    _, s2 = _fasta(f2)
+    triples = [(nm, a, b) for nm, a, b in zip(n1, s1, s2)]
+    got, st = _pairs_text(rs, rn, triples)
+    want = b"\n".join(l for l in _run([REF_BIN, "-t", "4", "-x", "sr", "-a", ref, f1, f2]).split(b"\n") if not l.startswith(b"@"))
+    assert got.rstrip(b"\n") == want.rstrip(b"\n")
+    assert st["n_region_reads_dev"] >= 0.9 * len(triples), st
+    monkeypatch.setenv("MM2AMD_DEVICE_REGIONS", "0")
+    host, st_host = _pairs_text(rs, rn, triples)
+    assert host == got and st_host["n_region_reads_dev"] == 0
+
+
+def test_single_end_short_reads_take_the_device_region_path(tmp_path, monkeypatch):
+    import minimap2_amd as mm
+    ref, rd = synth.make_short(str(tmp_path), seed=98, n_reads=800, genome=600000)
+    rn, rs = _fasta(ref)
+    n1, s1 = _fasta(rd)
+
+    def run():
+        al = mm.Aligner(rs, preset="sr", names=[x.decode() for x in rn], sam=True, n_threads=4)
+        try:
+            al.stage(list(zip([x.decode() for x in n1], s1)))
+            n_reg, reg, rep_len = al.run(raw=True)
+            try:
+                return al.format_raw(n_reg, reg, rep_len), al.last_stats()
+            finally:
+                al.free_raw(n_reg, reg)
+        finally:
+            al.close()
+    got, st = run()
+    want = b"\n".join(l for l in _run([REF_BIN, "-t", "4", "-x", "sr", "-a", ref, rd]).split(b"\n") if not l.startswith(b"@"))
+    assert got.rstrip(b"\n") == want.rstrip(b"\n")
+    assert st["n_region_reads_dev"] >= 0.8 * len(s1), st  # (reads too short to seed have no chain: the device has nothing to do for them either)
+    monkeypatch.setenv("MM2AMD_DEVICE_REGIONS", "0")
+    host, st_host = run()
+    assert host == got and st_host["n_region_reads_dev"] == 0
