@@ -54,7 +54,7 @@ struct Replica {
 struct StagedBatch {
 	std::vector<ReadView> views;
 	std::vector<OutSlot> slots;
-	std::vector<std::string> flipped;
+	std::string flipped; // the mates handed over reverse-complemented (pe_ori), back to back
 	std::vector<long> cut;
 };
 
@@ -265,7 +265,7 @@ int mm_gpu_n_replicas(void)
 }
 
 // mm_revcomp_bseq (mmpriv.h) on a copy: complement table of bseq.c:11-28 (IUPAC codes, case kept, other bytes unchanged)
-static void revcomp_into(const char *seq, int len, std::string &out)
+static void revcomp_into(const char *seq, int len, char *out)
 {
 	static const struct Table {
 		unsigned char t[256];
@@ -276,7 +276,6 @@ static void revcomp_into(const char *seq, int len, std::string &out)
 			for (int i = 0; from[i]; ++i) t[(unsigned char)from[i]] = (unsigned char)to[i], t[(unsigned char)(from[i] + 32)] = (unsigned char)(to[i] + 32);
 		}
 	} tab;
-	out.resize(len);
 	for (int i = 0; i < len; ++i) out[len - 1 - i] = (char)tab.t[(unsigned char)seq[i]];
 }
 
@@ -284,20 +283,31 @@ static void revcomp_into(const char *seq, int len, std::string &out)
 // orientation: worker_for reverse-complements a mate in place according to pe_ori before mapping and back afterwards
 // (map.c:436-442, 457-473); here the flipped copy lives in `flipped` and the caller's buffers are left alone.  With
 // MM_F_INDEPEND_SEG the two reads of a pair are mapped as two single reads (map.c:443-448), still in flipped orientation.
-static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const ref::MapOpt &opt, std::vector<ReadView> &reads,
-                         std::vector<OutSlot> &slots, std::vector<std::string> &flipped)
+static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const void *seq_, const ref::MapOpt &opt, int n_threads, std::vector<ReadView> &reads,
+                         std::vector<OutSlot> &slots, std::string &flipped)
 {
 	const ref::Bseq1 *seq = (const ref::Bseq1 *)seq_;
 	const int pe_ori = opt.pe_ori;
 	const bool independent = (opt.flag & ref::F_INDEPEND_SEG) != 0;
-	reads.clear(), slots.clear(), flipped.clear();
-	size_t n_flip = 0;
+	reads.clear(), slots.clear();
+	// the flipped mates in one pool (round 6: a million pairs were a million strings, filled one after the other by the hand-over's own thread -- 0.15 s of a
+	// 0.25 s step); where each goes is known from the lengths, the copies themselves are made by the side pool below
+	struct Flip { const char *src; int len; size_t at; };
+	std::vector<Flip> flips;
+	size_t flip_bytes = 0;
 	for (int i = 0; i < n_frag; ++i) {
 		if (n_seg[i] != 1 && n_seg[i] != 2) return capi_fail(MM2AMD_EINVAL, "[mm2amd] fragments of more than two segments are not implemented");
-		if (n_seg[i] == 2) n_flip += (pe_ori >> 1 & 1) + (pe_ori & 1);
+		if (n_seg[i] == 2) {
+			if (pe_ori >> 1 & 1) flip_bytes += (size_t)seq[seg_off[i]].l_seq;
+			if (pe_ori & 1) flip_bytes += (size_t)seq[seg_off[i] + 1].l_seq;
+		}
 	}
-	flipped.resize(n_flip); // sized first: the views point into it
-	n_flip = 0;
+	flipped.resize(flip_bytes + 1); // sized first: the views point into it
+	char *const pool = &flipped[0];
+	if (flip_bytes) flips.reserve((size_t)n_frag);
+	size_t at = 0;
+	auto flip = [&](const char *src, int len) { const char *dst = pool + at; flips.push_back(Flip{src, len, at}); at += (size_t)len; return dst; };
+	reads.reserve((size_t)n_frag), slots.reserve((size_t)n_frag);
 	for (int i = 0; i < n_frag; ++i) {
 		const int o = seg_off[i];
 		const ref::Bseq1 &s = seq[o];
@@ -307,8 +317,8 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 		if (n_seg[i] == 2) {
 			const ref::Bseq1 &s2 = seq[o + 1];
 			const char *q2 = s2.seq;
-			if (pe_ori >> 1 & 1) { revcomp_into(s.seq, s.l_seq, flipped[n_flip]); v.seq = flipped[n_flip++].data(); sl.flip_len[0] = s.l_seq; }
-			if (pe_ori & 1) { revcomp_into(s2.seq, s2.l_seq, flipped[n_flip]); q2 = flipped[n_flip++].data(); sl.flip_len[1] = s2.l_seq; }
+			if (pe_ori >> 1 & 1) { v.seq = flip(s.seq, s.l_seq); sl.flip_len[0] = s.l_seq; }
+			if (pe_ori & 1) { q2 = flip(s2.seq, s2.l_seq); sl.flip_len[1] = s2.l_seq; }
 			const bool weak = !independent && (opt.flag & ref::F_WEAK_PAIRING) && pe_ori >= 0 && (opt.flag & ref::F_CIGAR); // mm_map_frag, map.c:382-387
 			if (independent || weak) {
 				ReadView v2;
@@ -325,6 +335,7 @@ static int collect_views(int n_frag, const int *seg_off, const int *n_seg, const
 		}
 		reads.push_back(v), slots.push_back(sl);
 	}
+	parallel_for_side(n_threads, (long)flips.size(), [&](long k, int) { revcomp_into(flips[k].src, flips[k].len, pool + flips[k].at); }, 1024);
 	return 0;
 }
 
@@ -396,7 +407,7 @@ static int stage_batch(int n_frag, const int *seg_off, const int *n_seg, const v
 	try {
 		c.pending = false;
 		StagedBatch &bt = c.batch[1 - c.cur];
-		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, bt.views, bt.slots, bt.flipped)) return rc;
+		if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, c.n_threads, bt.views, bt.slots, bt.flipped)) return rc;
 		stage_replicas(c, bt, queued);
 		c.pending = true;
 		return 0;
@@ -605,7 +616,7 @@ int mm_gpu_map_batch(int n_frag, const int *seg_off, const int *n_seg, const voi
 			std::lock_guard<std::mutex> lk_st(c.stage_mu);
 			c.pending = false;
 			bt = &c.batch[1 - c.cur];
-			if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, bt->views, bt->slots, bt->flipped)) return rc;
+			if (int rc = collect_views(n_frag, seg_off, n_seg, seq_, c.opt, c.n_threads, bt->views, bt->slots, bt->flipped)) return rc;
 			stage_replicas(c, *bt);
 			c.pending = true;
 			take_staged(c);

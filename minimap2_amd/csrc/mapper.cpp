@@ -221,6 +221,12 @@ std::shared_ptr<Mapper::BatchRun> Mapper::make_run(int set)
 		if (m_all > 0 && tot / (uint64_t)m_all < 1000) sub_reads = 400000; // Illumina-sized reads: 25 k of them are a few Mbases, far too little work per kernel launch -- let the base budget decide
 		if (const char *e = getenv("MM2AMD_SUBBATCH_READS")) sub_reads = atol(e) > 0 ? atol(e) : sub_reads;
 		if (sub_reads < max_reads) max_reads = sub_reads;
+		if (m_all > 0 && tot / (uint64_t)m_all < 1000 && !getenv("MM2AMD_SUBBATCH_READS")) {
+			// (round 6) short reads are cut by the read cap, not by bases: equal shares in whole rounds of the lanes (a million pairs were ten shares of 100 000 on
+			// eight lanes -- a round of eight, then a round of two)
+			const long lanes = std::max(1, be_.n_lanes()), rounds = (m_all + lanes * max_reads - 1) / (lanes * max_reads);
+			max_reads = std::max<long>(1, (m_all + rounds * lanes - 1) / (rounds * lanes));
+		}
 		// equal shares instead of full sub-batches plus a remainder, and at least two of them when there is enough work to overlap
 		// (a rank of an 8-GPU job gets an eighth of the batch: 125 Mbases map 6 % faster as 2 x 62 than as 100 + 25)
 		long n_sub = (long)((tot + (uint64_t)sub_bases - 1) / (uint64_t)sub_bases);

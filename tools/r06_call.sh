@@ -181,5 +181,17 @@ print('   ', g.get('host_cpu_s_per_stage_one_lane_pass'))
 print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:10]})
 P
        done; unset MM2AMD_DEVICE_REGIONS ;;
+srtrace) # where a short-read step's time goes: the lanes' timeline
+       MM2AMD_TRACE=$O/r06_sr_trace_$V.tsv timeout 600 python bench.py --preset sr --reads 1000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/r06_bench_srt_$V.json 2> $O/r06_bench_srt_$V.log
+       python tools/trace_summary.py $O/r06_sr_trace_$V.tsv 0.5 > $O/r06_sr_trace_summary_$V.txt 2>&1; head -60 $O/r06_sr_trace_summary_$V.txt
+       python tools/trace_ascii.py $O/r06_sr_trace_$V.tsv --win 0.6 --res 4 2>/dev/null | head -50 > $O/r06_sr_trace_ascii_$V.txt; rm -f $O/r06_sr_trace_$V.tsv ;;
+srsubs) # short-read pairs: shares per batch (reads per sub-batch)
+       for n in default 100000 62500 41667 31250; do
+         if [ $n = default ]; then unset MM2AMD_SUBBATCH_READS; else export MM2AMD_SUBBATCH_READS=$n; fi
+         MM2AMD_BENCH_TRACE=1 timeout 600 python bench.py --preset sr --reads 1000000 --steps 6 --warmup 2 --no-cpu-baseline --timed-only > $O/r06_bench_sr_subs${n}_$V.json 2> $O/r06_bench_sr_subs${n}_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_sr_subs${n}_$V.json').read().strip().split('\\n')[-1]); print('sr sub-batch reads $n:', d['value'], d['ms_per_step'], d['config']['host_cpu_s_per_step'])"
+         grep -h "stage  batch  4\|map    batch  3\|output batch  3\|free   batch  3" $O/r06_bench_sr_subs${n}_$V.log | tail -4 | cut -c1-100
+       done; unset MM2AMD_SUBBATCH_READS ;;
 esac
 done
