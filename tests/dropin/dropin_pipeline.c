@@ -35,7 +35,8 @@ static int64_t parse_num(const char *str) /* main.c:103-111: 500M, 4g, 200k */
 }
 
 typedef struct {
-	mm_bseq_file_t *fp;
+	mm_bseq_file_t *fp[2];
+	int n_fp;
 	const mm_idx_t *mi;
 	const mm_mapopt_t *opt;
 	int64_t batch;
@@ -44,7 +45,7 @@ typedef struct {
 
 typedef struct {
 	pipeline_t *p;
-	int n_seq;
+	int n_seq, n_frag; /* fragments (map.c:556-563): a read pair is one fragment of two segments, a plain read a fragment of one */
 	mm_bseq1_t *seq;
 	int *n_reg, *seg_off, *n_seg, *rep_len, *frag_gap;
 	mm_reg1_t **reg;
@@ -58,10 +59,12 @@ static void cpu_fallback_one(void *data, long i, int tid)
 {
 	cpu_fallback_t *f = (cpu_fallback_t*)data;
 	step_t *s = f->s;
-	const char *seq = s->seq[i].seq;
-	int qlen = s->seq[i].l_seq;
-	mm_map_frag(s->p->mi, 1, &qlen, &seq, &s->n_reg[i], &s->reg[i], f->buf[tid], s->p->opt, s->seq[i].name);
-	s->rep_len[i] = ((tbuf_view_t*)f->buf[tid])->rep_len, s->frag_gap[i] = ((tbuf_view_t*)f->buf[tid])->frag_gap;
+	const int off = s->seg_off[i], n = s->n_seg[i];
+	const char *seqs[2];
+	int qlens[2], j;
+	for (j = 0; j < n; ++j) seqs[j] = s->seq[off + j].seq, qlens[j] = s->seq[off + j].l_seq;
+	mm_map_frag(s->p->mi, n, qlens, seqs, &s->n_reg[off], &s->reg[off], f->buf[tid], s->p->opt, s->seq[off].name);
+	for (j = 0; j < n; ++j) s->rep_len[off + j] = ((tbuf_view_t*)f->buf[tid])->rep_len, s->frag_gap[off + j] = ((tbuf_view_t*)f->buf[tid])->frag_gap;
 }
 static void cpu_fallback(step_t *s, int n_threads)
 {
@@ -69,7 +72,7 @@ static void cpu_fallback(step_t *s, int n_threads)
 	int t;
 	f.s = s, f.buf = (mm_tbuf_t**)calloc(n_threads, sizeof(mm_tbuf_t*));
 	for (t = 0; t < n_threads; ++t) f.buf[t] = mm_tbuf_init();
-	kt_for(n_threads, cpu_fallback_one, &f, s->n_seq);
+	kt_for(n_threads, cpu_fallback_one, &f, s->n_frag);
 	for (t = 0; t < n_threads; ++t) mm_tbuf_destroy(f.buf[t]);
 	free(f.buf);
 }
@@ -81,15 +84,21 @@ static void *worker(void *shared, int step, void *in)
 	if (step == 0) {
 		step_t *s = (step_t*)calloc(1, sizeof(step_t));
 		const int with_qual = (p->opt->flag & MM_F_OUT_SAM) && !(p->opt->flag & MM_F_NO_QUAL);
-		s->seq = mm_bseq_read3(p->fp, p->batch, with_qual, !!(p->opt->flag & MM_F_COPY_COMMENT), 0, &s->n_seq);
+		const int frag_mode = p->n_fp > 1 || !!(p->opt->flag & MM_F_FRAG_MODE); /* map.c:549-554 */
+		if (p->n_fp > 1) s->seq = mm_bseq_read_frag2(p->n_fp, p->fp, p->batch, with_qual, !!(p->opt->flag & MM_F_COPY_COMMENT), &s->n_seq);
+		else s->seq = mm_bseq_read3(p->fp[0], p->batch, with_qual, !!(p->opt->flag & MM_F_COPY_COMMENT), frag_mode, &s->n_seq);
 		if (s->seq == 0) { free(s); return 0; }
 		s->p = p;
 		for (i = 0; i < s->n_seq; ++i) s->seq[i].rid = p->n_processed++;
 		s->n_reg = (int*)calloc(5 * (size_t)s->n_seq, sizeof(int));
 		s->seg_off = s->n_reg + s->n_seq, s->n_seg = s->seg_off + s->n_seq, s->rep_len = s->n_seg + s->n_seq, s->frag_gap = s->rep_len + s->n_seq;
 		s->reg = (mm_reg1_t**)calloc(s->n_seq, sizeof(mm_reg1_t*));
-		for (i = 0; i < s->n_seq; ++i) s->seg_off[i] = i, s->n_seg[i] = 1;
-		if (!p->one_call && !p->failed && mm_gpu_batch_stage_queued(s->n_seq, s->seg_off, s->n_seg, s->seq) != 0) { /* end of step 0 */
+		for (i = 1, j = 0; i <= s->n_seq; ++i) /* map.c:556-563: consecutive records of one name are one fragment */
+			if (i == s->n_seq || !frag_mode || !mm_qname_same(s->seq[i - 1].name, s->seq[i].name)) {
+				s->n_seg[s->n_frag] = i - j, s->seg_off[s->n_frag++] = j;
+				j = i;
+			}
+		if (!p->one_call && !p->failed && mm_gpu_batch_stage_queued(s->n_frag, s->seg_off, s->n_seg, s->seq) != 0) { /* end of step 0 */
 			fprintf(stderr, "mm_gpu_batch_stage_queued: %s\n", mm2amd_last_error());
 			p->failed = 1;
 		}
@@ -97,7 +106,7 @@ static void *worker(void *shared, int step, void *in)
 	} else if (step == 1) {
 		step_t *s = (step_t*)in;
 		if (p->failed) { if (!p->one_call) mm_gpu_batch_discard(); return s; }
-		if ((p->one_call? mm_gpu_map_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)
+		if ((p->one_call? mm_gpu_map_batch(s->n_frag, s->seg_off, s->n_seg, s->seq, s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)
 		                : mm_gpu_map_staged(s->n_reg, (void**)s->reg, s->rep_len, s->frag_gap)) != 0) {
 			fprintf(stderr, "[WARNING] %s: %s; this mini-batch is mapped by the reference's own path\n", p->one_call? "mm_gpu_map_batch" : "mm_gpu_map_staged", mm2amd_last_error());
 			cpu_fallback(s, p->n_threads);
@@ -110,13 +119,13 @@ static void *worker(void *shared, int step, void *in)
 		size_t text_len = 0;
 		if (p->failed) ;
 		else if (p->one_call) {
-			if (mm_gpu_format_batch(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &text, &text_len) != 0) {
+			if (mm_gpu_format_batch(s->n_frag, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &text, &text_len) != 0) {
 				fprintf(stderr, "mm_gpu_format_batch: %s\n", mm2amd_last_error());
 				p->failed = 1;
 			}
 			if (text) fwrite(text, 1, text_len, stdout), free(text);
 		} else { /* the library owns and reuses the buffer: nothing to free */
-			if (mm_gpu_format_batch_view(s->n_seq, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &view, &text_len) != 0) {
+			if (mm_gpu_format_batch_view(s->n_frag, s->seg_off, s->n_seg, s->seq, s->n_reg, (void *const*)s->reg, s->rep_len, &view, &text_len) != 0) {
 				fprintf(stderr, "mm_gpu_format_batch_view: %s\n", mm2amd_last_error());
 				p->failed = 1;
 			} else fwrite(view, 1, text_len, stdout);
@@ -154,7 +163,7 @@ int main(int argc, char *argv[])
 		else if (strcmp(argv[k], "--one-call") == 0) one_call = 1;
 		else { fprintf(stderr, "unknown option %s\n", argv[k]); return 1; }
 	}
-	if (argc - k < 2) { fprintf(stderr, "usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch] ref reads\n"); return 1; }
+	if (argc - k < 2) { fprintf(stderr, "usage: dropin_pipeline [-x preset] [-a|-c] [-t threads] [-K batch] ref reads [mates]\n"); return 1; }
 	if (mm_check_opt(&iopt, &mopt) < 0) return 1;
 	rd = mm_idx_reader_open(argv[k], &iopt, 0);
 	if (rd == 0) { fprintf(stderr, "failed to open %s\n", argv[k]); return 1; }
@@ -167,12 +176,14 @@ int main(int argc, char *argv[])
 		if (mm_gpu_init(mi, &mopt, n_threads) != 0) { fprintf(stderr, "mm_gpu_init: %s\n", mm2amd_last_error()); return 2; }
 		fprintf(stderr, "[M::main::%.3f*%.2f] device mirror of the index ready (%d replica(s))\n", realtime() - mm_realtime0, cputime() / (realtime() - mm_realtime0), mm_gpu_n_replicas());
 		memset(&pl, 0, sizeof pl);
-		pl.fp = mm_bseq_open(argv[k + 1]);
-		if (pl.fp == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1]); return 1; }
+		for (pl.n_fp = 0; pl.n_fp < 2 && k + 1 + pl.n_fp < argc; ++pl.n_fp) { /* one file, or the two files of paired-end reads (map.c:650-667) */
+			pl.fp[pl.n_fp] = mm_bseq_open(argv[k + 1 + pl.n_fp]);
+			if (pl.fp[pl.n_fp] == 0) { fprintf(stderr, "failed to open %s\n", argv[k + 1 + pl.n_fp]); return 1; }
+		}
 		pl.mi = mi, pl.opt = &mopt, pl.batch = batch, pl.one_call = one_call, pl.n_threads = n_threads;
 		kt_pipeline(3, worker, &pl, 3); /* map.c:669: pl_threads = n_threads == 1 ? 1 : 3 (2 with --2-io-threads off) */
 		rc |= pl.failed;
-		mm_bseq_close(pl.fp);
+		{ int f; for (f = 0; f < pl.n_fp; ++f) mm_bseq_close(pl.fp[f]); }
 		mm_gpu_destroy();
 		mm_idx_destroy(mi);
 	}

@@ -180,3 +180,13 @@ def test_single_end_short_reads_take_the_device_region_path(tmp_path, monkeypatc
     monkeypatch.setenv("MM2AMD_DEVICE_REGIONS", "0")
     host, st_host = run()
     assert host == got and st_host["n_region_reads_dev"] == 0
+
+
+def test_read_pairs_through_the_pipeline_binding(tmp_path):
+    """tests/dropin/dropin_pipeline.c (the hook inside the reference's own three-step kt_pipeline) with the reference's fragment reader in
+    step 0 -- two files or one interleaved file, mini-batches that cut the input several times: the SAM stream must be the minimap2 binary's."""
+    ref, f1, f2, inter = synth.make_pairs(str(tmp_path), seed=321, n_pairs=3000, genome=500000)
+    pipe = os.path.join(HERE, "_build", "dropin_pipeline_emu" if os.environ.get("MM2AMD_EMU") == "1" else "dropin_pipeline_gpu")
+    for files in ([f1, f2], [inter]):
+        for k in ("500M", "100k"):
+            assert _run([REF_BIN, "-t", "4", "-ax", "sr", "-K", k, ref] + files) == _run([pipe, "-x", "sr", "-a", "-t", "4", "-K", k, ref] + files), (files, k)

@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--dir", default="/tmp/e2e")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_e2e_wall.json"))
     ap.add_argument("--skip-index-check", action="store_true")
+    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "sr"], help="sr: --reads read PAIRS of 2 x 150 b in two files (round 6: pairs take the device region path)")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     import torch
@@ -127,9 +128,14 @@ def main():
     n_contig = max(1, min(24, total // 1000000))
     codes, per = bench.gen_reference(torch, dev, 11, total, n_contig)
     refs = bench.reference_ascii(torch, dev, codes, per, n_contig)
-    reads, chunk = [], max(1, min(a.reads, 100000))  # in chunks of at most ~1 Gbase, as bench.py generates them (32-bit index arithmetic inside a call)
+    reads, mates, chunk = [], [], max(1, min(a.reads, 100000))  # in chunks of at most ~1 Gbase, as bench.py generates them (32-bit index arithmetic inside a call)
     for c0 in range(0, a.reads, chunk):
-        reads += bench.gen_reads(torch, dev, 1000 + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), 10000, 1000, 0.12)
+        if a.preset == "sr":
+            r1, r2 = bench.gen_pairs(torch, dev, 1000 + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), 150, 0.005)
+            reads += r1
+            mates += r2
+        else:
+            reads += bench.gen_reads(torch, dev, 1000 + 7919 * (c0 // chunk), codes, per, n_contig, min(chunk, a.reads - c0), 10000, 1000, 0.12)
         torch.cuda.empty_cache()
     del codes
     torch.cuda.empty_cache()
@@ -141,17 +147,25 @@ def main():
     with open(reads_fa, "wb") as f:
         for i, s in enumerate(reads):
             f.write(b">read%d\n" % i + s + b"\n")
-    bases = sum(len(s) for s in reads)
-    res = {"workload": "map-ont: %d synthetic ~10 kb reads (12%% error, %.3f Gbases) vs %d Mb synthetic ref (%d contigs), -a" % (a.reads, bases / 1e9, total // 1000000, n_contig),
+    read_files = [reads_fa]
+    if mates:
+        mates_fa = os.path.join(a.dir, "mates.fa")
+        with open(mates_fa, "wb") as f:
+            for i, s in enumerate(mates):
+                f.write(b">read%d\n" % i + s + b"\n")
+        read_files.append(mates_fa)
+    bases = sum(len(s) for s in reads) + sum(len(s) for s in mates)
+    res = {"workload": ("sr: %d synthetic read pairs of 2 x 150 b (0.5%% substitutions, %.3f Gbases) vs %d Mb synthetic ref (%d contigs), -a" if mates else
+                        "map-ont: %d synthetic ~10 kb reads (12%% error, %.3f Gbases) vs %d Mb synthetic ref (%d contigs), -a") % (a.reads, bases / 1e9, total // 1000000, n_contig),
            "host_threads": ncpu}
     REF = os.path.join(ROOT, "oracle", "_ref", "minimap2_ref")
     OURS = os.path.join(ROOT, "tests", "_build", "dropin_pipeline_gpu")
     t = time.time()
-    subprocess.run([REF, "-x", "map-ont", "-t", str(ncpu), "-d", mmi, ref_fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([REF, "-x", a.preset, "-t", str(ncpu), "-d", mmi, ref_fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     res["reference_index_build_s"] = round(time.time() - t, 1)
     keep = a.reads <= 200000  # small runs keep the two SAM files for inspection
-    w_ref, e_ref, dg_r = run([REF, "-ax", "map-ont", "-t", str(ncpu), mmi, reads_fa], os.path.join(a.dir, "ref.sam") if keep else None)
-    w_our, e_our, dg_o = run([OURS, "-x", "map-ont", "-a", "-t", str(min(64, ncpu)), mmi, reads_fa], os.path.join(a.dir, "ours.sam") if keep else None)
+    w_ref, e_ref, dg_r = run([REF, "-ax", a.preset, "-t", str(ncpu), mmi] + read_files, os.path.join(a.dir, "ref.sam") if keep else None)
+    w_our, e_our, dg_o = run([OURS, "-x", a.preset, "-a", "-t", str(min(64, ncpu)), mmi] + read_files, os.path.join(a.dir, "ours.sam") if keep else None)
     for key, w, e in (("reference", w_ref, e_ref), ("gpu_dropin", w_our, e_our)):
         loaded, ready, mapped_all = stamps(e)
         mapped = mapped_all[-1] if mapped_all else None
@@ -174,7 +188,7 @@ def main():
     res["speedup_mapping_phase"] = round(res["reference"]["mapping_phase_s"] / res["gpu_dropin"]["mapping_phase_s"], 2) if res["reference"]["mapping_phase_s"] and res["gpu_dropin"]["mapping_phase_s"] else None
     res["commit"] = os.environ.get("MM2AMD_COMMIT")
     print(json.dumps(res), flush=True)
-    if not a.skip_index_check:
+    if not a.skip_index_check and a.preset == "map-ont":
         import minimap2_amd as mm
         import numpy as np
         D = C.CDLL(reflib.REFDRV_SO)

@@ -193,5 +193,7 @@ srsubs) # short-read pairs: shares per batch (reads per sub-batch)
 import json; d=json.loads(open('$O/r06_bench_sr_subs${n}_$V.json').read().strip().split('\\n')[-1]); print('sr sub-batch reads $n:', d['value'], d['ms_per_step'], d['config']['host_cpu_s_per_step'])"
          grep -h "stage  batch  4\|map    batch  3\|output batch  3\|free   batch  3" $O/r06_bench_sr_subs${n}_$V.log | tail -4 | cut -c1-100
        done; unset MM2AMD_SUBBATCH_READS ;;
+e2esr) # short-read pairs end to end: the reference's fragment reader and writer around the GPU path (dropin_pipeline_gpu), SAM digest vs the minimap2 binary
+       timeout 2400 python tools/e2e_wall.py --preset sr --reads ${E2E_PAIRS:-4000000} --dir /tmp/e2esr --out $O/r06_e2e_wall_sr_$V.json > $O/r06_e2e_wall_sr_$V.log 2>&1; tail -c 1800 $O/r06_e2e_wall_sr_$V.log ;;
 esac
 done
