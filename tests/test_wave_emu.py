@@ -239,6 +239,23 @@ def test_structural_variants_through_the_region_kernels(tmp_path):
     _dropin_case(tmp_path, "inv", contigs, reads, [("map-ont", {}), ("map-hifi", {})])
 
 
+def test_short_reads_and_pairs_through_the_region_kernels(tmp_path):
+    """round 6: `-x sr` on the device region path, the kernels' own source under the wave emulator -- a pair's chains cut per segment in chain_regs_kernel (mm_seg_gen,
+    mm_select_sub_multi), the best diagonal run, the ungapped window and its Z-drop walk in region_plan_kernel, the literal piece in region_finish_kernel.  Pairs (two
+    files), single-end reads, a small Z-drop (the ungapped window's walk trips it: the fragment goes to the host's rounds) and the host's stages instead of the device's:
+    SAM == the compiled reference's every time"""
+    if not os.path.exists(DROPIN_EMU) or not os.path.exists(G.REF_BIN):
+        pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
+    ref, f1, f2, _ = synth.make_pairs(str(tmp_path), seed=131, n_pairs=500, genome=300000)
+    ref2, rd = synth.make_short(str(tmp_path / "se") if (tmp_path / "se").mkdir() is None else "", seed=132, n_reads=400, genome=300000)
+    for args, files, env in ((["-x", "sr", "-a"], [ref, f1, f2], {}), (["-x", "sr", "-a"], [ref, f1, f2], {"MM2AMD_DEVICE_REGIONS": "0"}), (["-x", "sr", "-a", "-z", "5"], [ref, f1, f2], {}),
+                             (["-x", "sr", "-c"], [ref2, rd], {}), (["-x", "sr", "-a", "-f", "2,10"], [ref, f1, f2], {})):
+        want = G.strip_pg(subprocess.run([G.REF_BIN, "-t", "2"] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout)
+        p = subprocess.run([DROPIN_EMU, "-t", "2"] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        assert G.strip_pg(p.stdout) == want, (args, env)
+
+
 def test_pipeline_equals_batch_by_batch(emu):
     """hand-over of batch k+1 beside the mapping of batch k (mm_gpu_batch_stage_queued) and the output stage into the reused buffer
     (mm_gpu_format_batch_view) give the text of stage + run + format, batch by batch"""
