@@ -44,6 +44,8 @@ struct Lane {
 	DevBuf<uint8_t> d_tbytes;
 	DevBuf<uint32_t> d_sort_list;
 	PinBuf<uint32_t> h_sort_list;
+	DevBuf<uint32_t> d_pieces;                 // the chaining kernels' work list when a read of the launch is cut into pieces (make_pieces)
+	PinBuf<uint32_t> h_pieces, h_lj_pieces;
 	DevBuf<Anchor> d_lj_out_a;                 // long-join re-chaining (second backtrack's anchors; the first one's are its input)
 	DevBuf<uint64_t> d_lj_src;
 	PinBuf<Anchor> h_lj_a;
@@ -396,8 +398,10 @@ public:
 			}, 64);
 			return;
 		}
+		make_pieces(B, ln, ln.h_pieces, n, [&](size_t i) { return (uint64_t)h_na[i]; }, P.rmq ? rmq_piece_len() : fill_piece_len(), st);
 		if (P.rmq) { kp.begin(st); launch_chain_rmq(B, P, st); kp.end(st, "chain_rmq_kernel", 32.0 * n_a); }
 		else { kp.begin(st); launch_chain_fill(B, P, st); kp.end(st, "chain_fill_kernel", 24.0 * n_a); }
+		B.pieces = nullptr, B.n_pieces = 0;
 		// 4. chains: backtrack + compaction on the device, then only the chained anchors travel to the host
 		ln.d_bt_cursor.ensure(2), ln.d_bt_out_a.ensure(n_a + 1), ln.d_bt_out_u.ensure((P.min_cnt >= 2 ? n_a / 2 : n_a) + n + 1); // a chain has at least max(1, min_cnt) anchors (lchain.c:66)
 		ln.d_bt_nu.ensure(n), ln.d_bt_nv.ensure(n), ln.d_bt_aoff.ensure(n), ln.d_bt_uoff.ensure(n);
@@ -467,6 +471,35 @@ public:
 		if (P.long_join && !has_pairs_ && !getenv("MM2AMD_LONG_JOIN_ON_HOST")) long_join(P, lo, n, ln, kp, out, ha, hu, h_nu, h_nv, h_aoff, h_uoff, h_span); // (the diagnostic switch: every re-chain through rmq_chain.cpp)
 	}
 
+	// The chaining kernels give a wavefront to a read.  A read with far more anchors than the others (it crosses a multi-copy element of the reference) makes the whole
+	// launch wait for its wavefront, so when a read has more than `len` anchors the launch gets a work list instead: every read's ceil(anchors / len) pieces (seed_chain.hip:
+	// chain_piece_bounds moves the cuts to cluster heads, where the sequential rules restart), the reads with several pieces first.  Launches without such a read --
+	// every launch of the uniform benchmark -- keep the plain read-per-wavefront grid.  MM2AMD_CHAIN_PIECE / MM2AMD_RMQ_PIECE: the piece lengths (tests set small ones; 0 = never cut).
+	static int fill_piece_len() { const char *e = getenv("MM2AMD_CHAIN_PIECE"); return e ? atoi(e) : 4096; }
+	static int rmq_piece_len() { const char *e = getenv("MM2AMD_RMQ_PIECE"); return e ? atoi(e) : 512; }
+	template <class Count>
+	static void make_pieces(SeedChainBuffers &B, Lane &ln, PinBuf<uint32_t> &hbuf, size_t n, Count count, int len, hipStream_t st)
+	{
+		B.pieces = nullptr, B.n_pieces = 0, B.piece_len = len;
+		if (len <= 0) return;
+		size_t n_p = 0;
+		bool any = false;
+		for (size_t i = 0; i < n; ++i) { const uint64_t c = count(i); n_p += (size_t)((c + len - 1) / len); any |= c > (uint64_t)len; }
+		if (!any || n_p > (size_t)INT32_MAX) return;
+		uint32_t *h = hbuf.ensure(2 * n_p);
+		size_t k = 0;
+		for (int pass = 0; pass < 2; ++pass) // reads with several pieces first: their wavefronts start with the launch
+			for (size_t i = 0; i < n; ++i) {
+				const uint64_t c = count(i), m = (c + len - 1) / len;
+				if (m == 0 || (m > 1) != (pass == 0)) continue;
+				for (uint64_t q = 0; q < m; ++q) h[2 * k] = (uint32_t)i, h[2 * k + 1] = (uint32_t)q, ++k;
+			}
+		ln.d_pieces.ensure(2 * n_p);
+		HIP_CHECK(hipMemcpyAsync(ln.d_pieces.p, h, 2 * n_p * 4, hipMemcpyHostToDevice, st));
+		B.pieces = ln.d_pieces.p, B.n_pieces = (int)n_p;
+		if (getenv("MM2AMD_PIECE_DEBUG")) fprintf(stderr, "[mm2amd] chaining work list: %zu reads in %zu pieces of %d anchors\n", n, n_p, len);
+	}
+
 	// map.c:283-292 on the device.  Which reads re-chain is decided here from the first chains (the reference's two conditions); their CHAINED
 	// anchors -- still in the backtrack's device output -- go through the per-read sort (by reference position, the reference's tie order),
 	// chain_rmq_kernel with bw_long, and the backtrack again.  A read the RMQ kernel hands back (a range minimum that is not unique, an
@@ -516,6 +549,7 @@ public:
 		SeedChainParams P2 = P;
 		P2.rmq = 1, P2.bw = P.bw_long, P2.flag &= ~(int64_t)ref::F_HEAP_SORT; // (the heap-merge order belongs to the seeding; this sort is radix_sort_128x)
 		launch_anchor_sort(B2, I_, P2, ln.d_sort_list.p, n_class, a_class, st, &kp);
+		make_pieces(B2, ln, ln.h_lj_pieces, n2, [&](size_t k) { return (uint64_t)h_nv[sel[k]]; }, rmq_piece_len(), st);
 		kp.begin(st); launch_chain_rmq(B2, P2, st); kp.end(st, "chain_rmq_kernel[long-join]", 32.0 * n_a2);
 		ln.d_lj_out_u.ensure((P2.min_cnt >= 2 ? n_a2 / 2 : n_a2) + n2 + 1);
 		B2.bt_out_a = ln.d_lj_out_a.p, B2.bt_out_u = ln.d_lj_out_u.p; // (counts and offsets reuse the first pass's arrays: they have been copied out; the first pass's chains stay for align_regions)

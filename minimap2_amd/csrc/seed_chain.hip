@@ -1452,6 +1452,30 @@ __device__ __forceinline__ int32_t link_score(uint64_t ix, uint64_t iy, uint64_t
 // between the two.  RING = false keeps everything in global memory (A/B checks: MM2AMD_CHAIN_FILL_GLOBAL=1).
 constexpr int CF_RING = 256;
 
+// A read with very many anchors (one that crosses a multi-copy element of the reference brings a hundred times the usual number) is cut into PIECES
+// worked on by wavefronts of their own.  The cut points are isolated anchors -- cluster heads, after which the sequential rules restart from a known
+// state (above for mg_lchain_dp; mg_lchain_rmq's trees are empty there) -- so every piece computes exactly what the one walk over the read would:
+// piece k of a read covers [first isolated anchor at or after k * len, first isolated anchor at or after (k + 1) * len), piece 0 starts at 0, the
+// last one ends at n.  A cluster longer than a piece leaves the pieces it spans empty.  The test is the kernels' own (the look-back window of
+// anchor g is empty when a[g-1] is on another target/strand or more than max_dist upstream).
+__device__ __forceinline__ int64_t chain_first_head(const Anchor *a, int64_t n, int64_t from, int32_t max_dist, int lane)
+{
+	for (int64_t base = from; base < n; base += 64) {
+		const int64_t g = base + lane;
+		bool head = false;
+		if (g < n) { const uint64_t gx = a[g].x, px = a[g - 1].x; head = gx >> 32 != px >> 32 || gx > px + (uint64_t)(int64_t)max_dist; } // (from >= 1)
+		const unsigned long long m = __ballot(head);
+		if (m) return base + (__ffsll((long long)m) - 1);
+	}
+	return n;
+}
+
+__device__ __forceinline__ void chain_piece_bounds(const Anchor *a, int64_t n, int64_t k, int64_t len, int32_t max_dist, int lane, int64_t *lo, int64_t *hi)
+{
+	*lo = k == 0 ? 0 : (k * len < n ? chain_first_head(a, n, k * len, max_dist, lane) : n);
+	*hi = (k + 1) * len < n ? chain_first_head(a, n, (k + 1) * len, max_dist, lane) : n;
+}
+
 template <bool PAIRS, bool RING>
 __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
 {
@@ -1459,12 +1483,14 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	__shared__ uint64_t s_x[4][RN], s_y[4][RN];
 	__shared__ int32_t s_f[4][RN], s_p[4][RN], s_t[4][RN];
 	const int wave = threadIdx.x >> 6, lane = lane_id();
-	const int r = blockIdx.x * 4 + wave;
-	if (r >= B.n_reads) return;
+	const int w = blockIdx.x * 4 + wave;
+	// a wavefront's work: a read -- or, when the host listed pieces (a read with very many anchors: its clusters are independent, see chain_piece_bounds), one piece of a read
+	if (w >= (B.pieces ? B.n_pieces : B.n_reads)) return;
+	const int r = B.pieces ? (int)B.pieces[2 * w] : w;
 	uint64_t *const rx = s_x[wave], *const ry = s_y[wave];
 	int32_t *const rf = s_f[wave], *const rp = s_p[wave], *const rt = s_t[wave];
 	const Anchor *a = B.anchors + B.a_off[r];
-	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	const int64_t n_all = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
 	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
 	int32_t max_dist_x, max_dist_y;
 	chain_gaps(P, (int)(B.seq_off[r + 1] - B.seq_off[r]), &max_dist_x, &max_dist_y);
@@ -1473,18 +1499,21 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	const int32_t bw = P.bw;
 	if (max_dist_x < bw) max_dist_x = bw;
 	if (max_dist_y < bw && !P.is_cdna) max_dist_y = bw;
-	for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+	int64_t lo = 0, n = n_all; // the anchors [lo, n) of the read are this wavefront's
+	if (B.pieces) chain_piece_bounds(a, n_all, (int64_t)B.pieces[2 * w + 1], (int64_t)B.piece_len, max_dist_x, lane, &lo, &n);
+	if (lo >= n) return;
+	for (int64_t i = lo + lane; i < n; i += 64) t[i] = 0;
 	__threadfence_block();
 
-	int64_t st = 0, max_ii = -1;
+	int64_t st = lo, max_ii = -1;
 	uint64_t mii_x = 0, mii_y = 0;   // a[max_ii]
 	int32_t mii_f = 0;               // f[max_ii]
 	uint64_t last_x = 0, last_y = 0; // the anchor just before the current block
 	bool last_iso = false;           // ... and whether it was isolated
-	for (int64_t blk = 0; blk < n; blk += 64) {
+	for (int64_t blk = lo; blk < n; blk += 64) {
 		const int64_t g = blk + lane;
 		// indices >= ring_lo are in the ring while this block is worked on (the block itself has just entered it)
-		const int64_t ring_lo = RING ? (blk + 64 > CF_RING ? blk + 64 - CF_RING : 0) : INT64_MAX;
+		const int64_t ring_lo = RING ? (blk + 64 - lo > CF_RING ? blk + 64 - CF_RING : lo) : INT64_MAX;
 		auto ax = [&](int64_t j) { return j >= ring_lo ? rx[j & RM] : a[j].x; };
 		auto ay = [&](int64_t j) { return j >= ring_lo ? ry[j & RM] : a[j].y; };
 		auto af = [&](int64_t j) { return j >= ring_lo ? rf[j & RM] : f[j]; };
@@ -1492,7 +1521,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 		uint64_t bx = 0, by = 0;
 		if (g < n) { const Anchor v = a[g]; bx = v.x, by = v.y; }
 		const uint64_t px = wave_shr1_u64(last_x, bx), py = wave_shr1_u64(last_y, by); // a[g-1]
-		const bool iso = g < n && (g == 0 || (bx >> 32 != px >> 32 || bx > px + (uint64_t)(int64_t)max_dist_x));
+		const bool iso = g < n && (g == lo || (bx >> 32 != px >> 32 || bx > px + (uint64_t)(int64_t)max_dist_x)); // (a piece starts at an isolated anchor)
 		if (iso) f[g] = (int32_t)(by >> 32 & 0xff), p[g] = -1;
 		if (RING && g < n) {
 			rx[g & RM] = bx, ry[g & RM] = by, rt[g & RM] = -1;
@@ -1613,7 +1642,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
 	static const bool in_global = getenv("MM2AMD_CHAIN_FILL_GLOBAL") != nullptr; // A/B checks: no LDS ring
-	const dim3 grid((B.n_reads + 3) / 4), block(256);
+	const dim3 grid(((B.pieces ? B.n_pieces : B.n_reads) + 3) / 4), block(256);
 	hipStream_t s = (hipStream_t)stream;
 	if (B.unit_first) {
 		if (in_global) hipLaunchKernelGGL((chain_fill_kernel<true, false>), grid, block, 0, s, B, P);
@@ -1643,6 +1672,7 @@ void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void
 //     before it: its chain successors have larger query coordinates).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int RMQ_NEAR_CAP = 4096; // anchors of the narrow window scored per anchor; more: the read goes to the host
+constexpr int RMQ_NEAR_SMALL = 1024; // ... of the first launch; what does not fit goes to a second one (MM2AMD_RMQ_NEAR_TINY=1: 64, for tests of that hand-over)
 
 __device__ __forceinline__ int32_t simple_score_dev(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, float pen_gap, float pen_skip, bool *exact, int32_t *width) // comput_sc_simple, lchain.c:229-248
 {
@@ -1659,12 +1689,19 @@ __device__ __forceinline__ int32_t simple_score_dev(uint64_t ix, uint64_t iy, ui
 	return sc;
 }
 
+// Launched twice: NEAR = RMQ_NEAR_SMALL for every read (8 KB of LDS per wavefront instead of 32: four times the wavefronts per CU, and the kernel is a chain of
+// dependent look-ups), then NEAR = RMQ_NEAR_CAP for the reads whose neighbourhood did not fit (flag bit 1).  tie_flag[r], zeroed by the launcher: bit 0 = the
+// host chains this read, bit 1 = the second launch does; chain_backtrack_kernel leaves bit 0 only.  With pieces (chain_piece_bounds) a read's wavefronts
+// share its flag; the second launch redoes every piece of a flagged read (pieces are independent, their results do not depend on who computes them).
+template <int NEAR>
 __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedChainParams P)
 {
-	__shared__ uint64_t s_near[RMQ_NEAR_CAP];
-	const int lane = threadIdx.x, r = blockIdx.x;
+	__shared__ uint64_t s_near[NEAR];
+	const int lane = threadIdx.x, w = blockIdx.x;
+	const int r = B.pieces ? (int)B.pieces[2 * w] : w;
 	const Anchor *a = B.anchors + B.a_off[r];
-	const int64_t n = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	const int64_t n_all = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	if (NEAR == RMQ_NEAR_CAP) { if ((atomicOr(&B.tie_flag[r], 0u) & 3u) != 2u) return; } // the second launch: only what the first one left to it (a sibling piece may have given the read up since)
 	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
 	double *pri = (double *)(B.sort_key_out + B.a_off[r]); // dead since the anchor sort; the backtrack reuses it afterwards
 	int32_t max_dist = P.max_gap, max_dist_inner = P.rmq_inner_dist;
@@ -1672,11 +1709,15 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 	if (max_dist < bw) max_dist = bw;
 	if (max_dist_inner < 0) max_dist_inner = 0;
 	if (max_dist_inner > max_dist) max_dist_inner = max_dist;
-	for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+	int64_t lo = 0, n = n_all; // the anchors [lo, n) of the read are this wavefront's
+	if (B.pieces) chain_piece_bounds(a, n_all, (int64_t)B.pieces[2 * w + 1], (int64_t)B.piece_len, max_dist, lane, &lo, &n);
+	if (lo >= n) return;
+	for (int64_t i = lo + lane; i < n; i += 64) t[i] = 0;
 	__threadfence_block();
-	int64_t i0 = 0, st = 0, st_in = 0;
-	bool give_up = n > (int64_t)P.rmq_dev_max_anchors; // (whole contigs: backend.hpp)
-	for (int64_t i = 0; i < n && !give_up; ++i) {
+	int64_t i0 = lo, st = lo, st_in = lo;
+	bool give_up = n_all > (int64_t)P.rmq_dev_max_anchors; // (whole contigs: backend.hpp)
+	bool overflow = false;
+	for (int64_t i = lo; i < n && !give_up; ++i) {
 		const Anchor ai = a[i];
 		const uint64_t ix = ai.x, iy = ai.y;
 		const int32_t y_i = (int32_t)iy;
@@ -1744,10 +1785,10 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 					int32_t y_j = 0;
 					if (j < i0) { y_j = (int32_t)a[j].y; in = y_j <= y_i - 1 && y_j >= y_i - max_dist_inner; }
 					const unsigned long long m = __ballot(in);
-					if (in) { const int d = n_c + popc_below(m, lane); if (d < RMQ_NEAR_CAP) s_near[d] = (uint64_t)(uint32_t)y_j << 32 | (uint64_t)(uint32_t)j; }
+					if (in) { const int d = n_c + popc_below(m, lane); if (d < NEAR) s_near[d] = (uint64_t)(uint32_t)y_j << 32 | (uint64_t)(uint32_t)j; }
 					n_c += __popcll(m);
 				}
-				if (n_c > RMQ_NEAR_CAP) { give_up = true; break; }
+				if (n_c > NEAR) { if (NEAR == RMQ_NEAR_CAP) give_up = true; else overflow = true; break; }
 				int n_pad = 64;
 				while (n_pad < n_c) n_pad <<= 1;
 				for (int k = n_c + lane; k < n_pad; k += 64) s_near[k] = 0; // pads sort last (descending order; y >= 0 and every real key is > 0 unless (0, 0), which ties harmlessly)
@@ -1809,13 +1850,17 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 		if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
 		__threadfence_block();
 	}
-	if (lane == 0) B.tie_flag[r] = give_up ? 1u : 0u; // reused: 1 = the host chains this read (rmq_chain.cpp)
-	if (give_up) for (int64_t i = lane; i < n; i += 64) f[i] = INT32_MIN, p[i] = -1; // no chain ends: the backtrack leaves the read empty
+	if (lane == 0 && (give_up || overflow)) atomicOr(&B.tie_flag[r], give_up ? 1u : 2u); // reused: bit 0 = the host chains this read (rmq_chain.cpp); the backtrack leaves such a read empty
 }
 
 void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
-	hipLaunchKernelGGL(chain_rmq_kernel, dim3(B.n_reads), dim3(64), 0, (hipStream_t)stream, B, P);
+	hipStream_t s = (hipStream_t)stream;
+	const dim3 grid(B.pieces ? B.n_pieces : B.n_reads);
+	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
+	if (getenv("MM2AMD_RMQ_NEAR_TINY")) hipLaunchKernelGGL(chain_rmq_kernel<64>, grid, dim3(64), 0, s, B, P); // tests: most reads go on to the second launch
+	else hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_SMALL>, grid, dim3(64), 0, s, B, P);
+	hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_CAP>, grid, dim3(64), 0, s, B, P);
 	HIP_CHECK(hipGetLastError());
 }
 
@@ -1839,7 +1884,7 @@ __device__ void bt_sort(uint64_t *K, uint32_t *I, int32_t n, uint32_t *cnt, uint
 	tie_exact_replay(SplitStore{K, I, -1}, n, nullptr, 0, true, cnt, head, start, child_mask, stack, stack_cap);
 }
 
-__global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B, int min_cnt, int min_sc, int max_drop)
+__global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B, int min_cnt, int min_sc, int max_drop, int rmq)
 {
 	__shared__ uint64_t lK[BT_LDS_CAP];
 	__shared__ uint32_t lI[BT_LDS_CAP];
@@ -1855,6 +1900,11 @@ __global__ void __launch_bounds__(64) chain_backtrack_kernel(SeedChainBuffers B,
 	const Anchor *a = B.anchors + ao;
 	const int32_t *f = B.f + ao, *p = B.p + ao;
 	int32_t *t = B.t + ao;
+	if (rmq) { // chain_rmq_kernel's flag: a read it gave up (bit 0) stays empty here and is chained by the host; bit 1 was between its two launches
+		const uint32_t fl = B.tie_flag[r];
+		if (lane == 0 && fl != (fl & 1u)) B.tie_flag[r] = fl & 1u;
+		if (fl & 1u) { if (lane == 0) B.bt_nu[r] = 0, B.bt_nv[r] = 0, B.bt_aoff[r] = 0, B.bt_uoff[r] = 0; return; }
+	}
 	if (n == 0) { if (lane == 0) B.bt_nu[r] = 0, B.bt_nv[r] = 0, B.bt_aoff[r] = 0, B.bt_uoff[r] = 0; return; }
 	// ---- chain ends z = {(f[i], i) : f[i] >= min_sc} in index order (lchain.c:35-40) ----
 	int32_t n_z = 0;
@@ -1998,7 +2048,7 @@ void launch_chain_backtrack(const SeedChainBuffers &B, const SeedChainParams &P,
 {
 	const int max_drop = P.is_cdna ? INT32_MAX : P.bw;
 	HIP_CHECK(hipMemsetAsync(B.bt_cursor, 0, 16, (hipStream_t)stream));
-	hipLaunchKernelGGL(chain_backtrack_kernel, dim3(B.n_reads), dim3(64), 0, (hipStream_t)stream, B, P.min_cnt, P.min_chain_score, max_drop);
+	hipLaunchKernelGGL(chain_backtrack_kernel, dim3(B.n_reads), dim3(64), 0, (hipStream_t)stream, B, P.min_cnt, P.min_chain_score, max_drop, P.rmq);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -53,6 +53,10 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	int rid_bits;             // bits needed for a reference sequence id in the compact sort key
 	uint64_t *mini_pos;
 	int32_t *f, *p, *t;       // chaining DP arrays, indexed like anchors
+	// the chaining kernels' work list (null: one wavefront per read): (read, piece number) pairs, a piece = piece_len anchors moved to the next cluster
+	// heads (seed_chain.hip: chain_piece_bounds); made by the host when a read of the launch has more than piece_len anchors, heaviest reads first
+	const uint32_t *pieces = nullptr;
+	int n_pieces = 0, piece_len = 0;
 	// chain backtrack results: dense outputs handed out by two atomic cursors ([0] anchors, [1] chains)
 	unsigned long long *bt_cursor;
 	Anchor *bt_out_a;         // compacted anchors of all chains, chain by chain, read by read (in completion order)

@@ -123,6 +123,22 @@ print('$m', d['value'], d['ms_per_step'], r['kernel'], r.get('unoverlapped_step_
 print('   ', {k: v for k, v in (r.get('unoverlapped_ms') or {}).items() if k.startswith('ksw')})
 P
        done; unset MM2AMD_EXT_BY_TARGET ;;
+pieces) # heavy reads chained in pieces (and chain_rmq_kernel's small first launch) against a wavefront per read: the repeats workload, then the headline
+       for m in pieces nopieces; do
+         if [ $m = nopieces ]; then export MM2AMD_CHAIN_PIECE=0 MM2AMD_RMQ_PIECE=0; else unset MM2AMD_CHAIN_PIECE MM2AMD_RMQ_PIECE; fi
+         MM2AMD_PIECE_DEBUG=1 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_${m}_$V.json 2> $O/r06_bench_repeats_${m}_$V.log
+         grep -h "work list" $O/r06_bench_repeats_${m}_$V.log | sort | uniq -c | sort -rn | head -4
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_repeats_${m}_$V.json').read().strip().split('\n')[-1]); c=d['config']; r=d['roofline']
+print('repeats $m', d['value'], d['ms_per_step'], 'host cpu', c['host_cpu_s_per_step'], c['device_path_last_batch'])
+print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:10]})
+P
+       done; unset MM2AMD_CHAIN_PIECE MM2AMD_RMQ_PIECE
+       timeout 600 python bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_ont_pieces_$V.json 2> $O/r06_bench_ont_pieces_$V.log
+       python -c "
+import json; d=json.loads(open('$O/r06_bench_ont_pieces_$V.json').read().strip().split('\n')[-1]); print('ont', d['value'], d['ms_per_step'])" ;;
+chain) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_aligner.py tests/test_gpu_regions.py -x -q -m gpu > $O/r06_pytest_chain_$V.log 2>&1; tail -3 $O/r06_pytest_chain_$V.log ;;
 prof)  # evidence at HEAD in one call: rocprofv3 kernel stats of the headline command, the exposed-time split, HBM traffic (FETCH / WRITE passes) and the SQ counters
        cd /tmp
        timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_ont -o bench -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --timed-only > $O/r06_bench_full_${V}_under_rocprof.json 2> $O/prof_ont.log
