@@ -1476,10 +1476,10 @@ __device__ __forceinline__ void chain_piece_bounds(const Anchor *a, int64_t n, i
 	*hi = (k + 1) * len < n ? chain_first_head(a, n, (k + 1) * len, max_dist, lane) : n;
 }
 
-template <bool PAIRS, bool RING>
+template <bool PAIRS, int RING> // RING: entries of the LDS window per wavefront (CF_RING; 128: 14 KB per workgroup, eight workgroups per CU instead of five -- measured), 0 = none
 __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, SeedChainParams P)
 {
-	constexpr int RN = RING ? CF_RING : 1, RM = RN - 1;
+	constexpr int RN = RING ? RING : 1, RM = RN - 1;
 	__shared__ uint64_t s_x[4][RN], s_y[4][RN];
 	__shared__ int32_t s_f[4][RN], s_p[4][RN], s_t[4][RN];
 	const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1513,7 +1513,7 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 	for (int64_t blk = lo; blk < n; blk += 64) {
 		const int64_t g = blk + lane;
 		// indices >= ring_lo are in the ring while this block is worked on (the block itself has just entered it)
-		const int64_t ring_lo = RING ? (blk + 64 - lo > CF_RING ? blk + 64 - CF_RING : lo) : INT64_MAX;
+		const int64_t ring_lo = RING ? (blk + 64 - lo > RN ? blk + 64 - RN : lo) : INT64_MAX;
 		auto ax = [&](int64_t j) { return j >= ring_lo ? rx[j & RM] : a[j].x; };
 		auto ay = [&](int64_t j) { return j >= ring_lo ? ry[j & RM] : a[j].y; };
 		auto af = [&](int64_t j) { return j >= ring_lo ? rf[j & RM] : f[j]; };
@@ -1641,15 +1641,18 @@ __global__ void __launch_bounds__(256) chain_fill_kernel(SeedChainBuffers B, See
 
 void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
-	static const bool in_global = getenv("MM2AMD_CHAIN_FILL_GLOBAL") != nullptr; // A/B checks: no LDS ring
+	const char *ring_env = getenv("MM2AMD_CHAIN_RING"); // A/B: 0 = no LDS window (MM2AMD_CHAIN_FILL_GLOBAL=1 is the older name), 128 = the smaller one
+	const int ring = getenv("MM2AMD_CHAIN_FILL_GLOBAL") ? 0 : ring_env ? atoi(ring_env) : CF_RING;
 	const dim3 grid(((B.pieces ? B.n_pieces : B.n_reads) + 3) / 4), block(256);
 	hipStream_t s = (hipStream_t)stream;
 	if (B.unit_first) {
-		if (in_global) hipLaunchKernelGGL((chain_fill_kernel<true, false>), grid, block, 0, s, B, P);
-		else hipLaunchKernelGGL((chain_fill_kernel<true, true>), grid, block, 0, s, B, P);
+		if (ring == 0) hipLaunchKernelGGL((chain_fill_kernel<true, 0>), grid, block, 0, s, B, P);
+		else if (ring == 128) hipLaunchKernelGGL((chain_fill_kernel<true, 128>), grid, block, 0, s, B, P);
+		else hipLaunchKernelGGL((chain_fill_kernel<true, CF_RING>), grid, block, 0, s, B, P);
 	} else {
-		if (in_global) hipLaunchKernelGGL((chain_fill_kernel<false, false>), grid, block, 0, s, B, P);
-		else hipLaunchKernelGGL((chain_fill_kernel<false, true>), grid, block, 0, s, B, P);
+		if (ring == 0) hipLaunchKernelGGL((chain_fill_kernel<false, 0>), grid, block, 0, s, B, P);
+		else if (ring == 128) hipLaunchKernelGGL((chain_fill_kernel<false, 128>), grid, block, 0, s, B, P);
+		else hipLaunchKernelGGL((chain_fill_kernel<false, CF_RING>), grid, block, 0, s, B, P);
 	}
 	HIP_CHECK(hipGetLastError());
 }
@@ -1694,10 +1697,11 @@ __device__ __forceinline__ int32_t simple_score_dev(uint64_t ix, uint64_t iy, ui
 // host chains this read, bit 1 = the second launch does; chain_backtrack_kernel leaves bit 0 only.  With pieces (chain_piece_bounds) a read's wavefronts
 // share its flag; the second launch redoes every piece of a flagged read (pieces are independent, their results do not depend on who computes them).
 template <int NEAR>
-__global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedChainParams P)
+__global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedChainParams P, uint64_t *timing)
 {
 	__shared__ uint64_t s_near[NEAR];
 	const int lane = threadIdx.x, w = blockIdx.x;
+	const uint64_t t_begin = timing ? wall_clock64() : 0; // (MM2AMD_RMQ_TIMING=1: what each wavefront of a launch spent, 100 MHz ticks)
 	const int r = B.pieces ? (int)B.pieces[2 * w] : w;
 	const Anchor *a = B.anchors + B.a_off[r];
 	const int64_t n_all = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
@@ -1850,6 +1854,7 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 		if (lane == 0) f[i] = max_f, p[i] = (int32_t)max_j;
 		__threadfence_block();
 	}
+	if (timing && lane == 0 && (int)w < (1 << 20)) timing[2 * w] = wall_clock64() - t_begin, timing[2 * w + 1] = (uint64_t)(n - lo) << 32 | (uint32_t)r;
 	if (lane == 0 && (give_up || overflow)) atomicOr(&B.tie_flag[r], give_up ? 1u : 2u); // reused: bit 0 = the host chains this read (rmq_chain.cpp); the backtrack leaves such a read empty
 }
 
@@ -1858,9 +1863,26 @@ void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void 
 	hipStream_t s = (hipStream_t)stream;
 	const dim3 grid(B.pieces ? B.n_pieces : B.n_reads);
 	HIP_CHECK(hipMemsetAsync(B.tie_flag, 0, (size_t)B.n_reads * 4, s));
-	if (getenv("MM2AMD_RMQ_NEAR_TINY")) hipLaunchKernelGGL(chain_rmq_kernel<64>, grid, dim3(64), 0, s, B, P); // tests: most reads go on to the second launch
-	else hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_SMALL>, grid, dim3(64), 0, s, B, P);
-	hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_CAP>, grid, dim3(64), 0, s, B, P);
+	uint64_t *timing = nullptr;
+	const int n_w = (int)grid.x < (1 << 20) ? (int)grid.x : 1 << 20;
+	if (getenv("MM2AMD_RMQ_TIMING")) { HIP_CHECK(hipMalloc((void **)&timing, (size_t)n_w * 16)); HIP_CHECK(hipMemsetAsync(timing, 0, (size_t)n_w * 16, s)); }
+	if (getenv("MM2AMD_RMQ_NEAR_TINY")) hipLaunchKernelGGL(chain_rmq_kernel<64>, grid, dim3(64), 0, s, B, P, timing); // tests: most reads go on to the second launch
+	else hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_SMALL>, grid, dim3(64), 0, s, B, P, timing);
+	if (timing) { // diagnostics: the launch's wavefronts by time spent -- is it the heaviest one or their sum that the launch waits for?
+		std::vector<uint64_t> h((size_t)n_w * 2);
+		HIP_CHECK(hipStreamSynchronize(s));
+		HIP_CHECK(hipMemcpy(h.data(), timing, h.size() * 8, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipFree(timing));
+		std::vector<int> order(n_w);
+		for (int i = 0; i < n_w; ++i) order[i] = i;
+		std::sort(order.begin(), order.end(), [&](int x, int y) { return h[2 * x] > h[2 * y]; });
+		double sum = 0, anchors = 0;
+		for (int i = 0; i < n_w; ++i) sum += (double)h[2 * i], anchors += (double)(h[2 * i + 1] >> 32);
+		fprintf(stderr, "[mm2amd] chain_rmq_kernel: %d wavefronts (%d reads), %.0f anchors, %.1f ms of wavefront time in all; the longest:", n_w, B.n_reads, anchors, sum / 1e5);
+		for (int i = 0; i < 6 && i < n_w; ++i) fprintf(stderr, " %.2f ms / %llu anchors (read %u)", (double)h[2 * order[i]] / 1e5, (unsigned long long)(h[2 * order[i] + 1] >> 32), (unsigned)h[2 * order[i] + 1]);
+		fprintf(stderr, "\n");
+	}
+	hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_CAP>, grid, dim3(64), 0, s, B, P, (uint64_t *)nullptr);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -214,3 +214,55 @@ def test_hifi_full_size_properties_and_sample_parity(world):
         assert got == want
     finally:
         al.close()
+
+
+def test_full_size_index_equals_the_reference_binarys(world, tmp_path_factory):
+    """the 3 Gb index as built on the device (index_build.hip) against the one the UNMODIFIED reference builds from the same sequences (`minimap2 -d`: mm_idx_gen,
+    index.c:397-470): the same distinct minimizers with the same position lists -- order-independent digests over (minimizer, positions) computed by
+    oracle/_ref/librefdrv.so on the reference's mm_idx_t (read back from its .mmi) and on the tables exported from the device.  The sample-parity cases above adopt
+    OUR tables into an mm_idx_t, so an index-build error would be invisible to them (verdict r5); this is the full-size check in the driver-run suite"""
+    import subprocess
+    import minimap2_amd as mm
+    al, named, truth, names = world
+    if not (os.path.exists(reflib.REFDRV_SO) and os.path.exists(reflib.REF_BIN) and os.path.exists(reflib.REF_SO)):
+        pytest.skip("oracle/_ref not present")
+    d = tmp_path_factory.mktemp("idx")
+    fa, mmi = str(d / "ref.fa"), str(d / "ref.mmi")
+    ncpu = min(len(os.sched_getaffinity(0)), 32)
+    try:
+        with open(fa, "wb") as f:
+            for nm, s in zip(names, SPLICE["refs"]):
+                f.write(b">" + nm.encode() + b"\n")
+                f.write(s)
+                f.write(b"\n")
+        subprocess.run([reflib.REF_BIN, "-x", "map-ont", "-t", str(ncpu), "-d", mmi, fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.remove(fa)
+        D, R = C.CDLL(reflib.REFDRV_SO), C.CDLL(reflib.REF_SO)
+        R.mm_idx_reader_open.restype = C.c_void_p
+        R.mm_idx_reader_open.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p]
+        R.mm_idx_reader_read.restype = C.c_void_p
+        R.mm_idx_reader_read.argtypes = [C.c_void_p, C.c_int]
+        R.mm_idx_reader_close.argtypes = [C.c_void_p]
+        R.mm_idx_destroy.argtypes = [C.c_void_p]
+        io, mo = mm.IdxOpt(), mm.MapOpt()
+        R.mm_set_opt(None, C.byref(io), C.byref(mo))
+        R.mm_set_opt(b"map-ont", C.byref(io), C.byref(mo))
+        rd = R.mm_idx_reader_open(mmi.encode(), C.byref(io), None)
+        assert rd
+        mi = R.mm_idx_reader_read(rd, ncpu)
+        assert mi
+        dg_ref = (C.c_uint64 * 3)()
+        D.refdrv_idx_digest.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        D.refdrv_idx_digest(mi, ncpu, dg_ref)
+        R.mm_idx_destroy(mi)
+        R.mm_idx_reader_close(rd)
+    finally:
+        for p in (fa, mmi):
+            if os.path.exists(p):
+                os.remove(p)
+    S, keys, val_off, pos = reflib.export_index(al)
+    dg_dev = (C.c_uint64 * 3)()
+    D.refdrv_flat_digest.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    D.refdrv_flat_digest(len(keys), keys.ctypes.data, val_off.ctypes.data, pos.ctypes.data, ncpu, dg_dev)
+    assert dg_ref[1] > 100 * 1000 * 1000 and dg_ref[2] > 500 * 1000 * 1000  # (distinct minimizers, positions of a 3 Gb reference at k 15, w 10)
+    assert list(dg_dev) == list(dg_ref)

@@ -138,6 +138,20 @@ P
        timeout 600 python bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/r06_bench_ont_pieces_$V.json 2> $O/r06_bench_ont_pieces_$V.log
        python -c "
 import json; d=json.loads(open('$O/r06_bench_ont_pieces_$V.json').read().strip().split('\n')[-1]); print('ont', d['value'], d['ms_per_step'])" ;;
+ring)  # chain_fill_kernel's LDS window of 128 entries (eight workgroups per CU) against 256 (five); then what chain_rmq_kernel's wavefronts spend (MM2AMD_RMQ_TIMING)
+       for m in 256 128; do
+         for w in repeats ont; do
+           wl=""; [ $w = repeats ] && wl="--workload repeats"
+           MM2AMD_CHAIN_RING=$m timeout 900 python bench.py $wl --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_${w}_ring${m}_$V.json 2> $O/r06_bench_${w}_ring${m}_$V.log
+           python - <<P
+import json
+d=json.loads(open('$O/r06_bench_${w}_ring${m}_$V.json').read().strip().split('\n')[-1]); u=d['roofline'].get('unoverlapped_ms') or {}
+print('$w ring $m', d['value'], d['ms_per_step'], 'chain_fill', u.get('chain_fill_kernel'))
+P
+         done
+       done
+       MM2AMD_RMQ_TIMING=1 MM2AMD_LANES=1 timeout 900 python bench.py --workload repeats --steps 1 --warmup 1 --no-cpu-baseline --timed-only > $O/r06_bench_repeats_rmqtiming_$V.json 2> $O/r06_bench_repeats_rmqtiming_$V.log
+       grep -h "chain_rmq_kernel:" $O/r06_bench_repeats_rmqtiming_$V.log | tail -12 | cut -c1-420 ;;
 chain) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_aligner.py tests/test_gpu_regions.py -x -q -m gpu > $O/r06_pytest_chain_$V.log 2>&1; tail -3 $O/r06_pytest_chain_$V.log ;;
 prof)  # evidence at HEAD in one call: rocprofv3 kernel stats of the headline command, the exposed-time split, HBM traffic (FETCH / WRITE passes) and the SQ counters
        cd /tmp
