@@ -1716,6 +1716,7 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 	int64_t lo = 0, n = n_all; // the anchors [lo, n) of the read are this wavefront's
 	if (B.pieces) chain_piece_bounds(a, n_all, (int64_t)B.pieces[2 * w + 1], (int64_t)B.piece_len, max_dist, lane, &lo, &n);
 	if (lo >= n) return;
+	if (B.pieces && B.piece_dense > 0 && n - lo >= (int64_t)B.piece_dense) return; // a long cluster: chain_rmq_wide_kernel's
 	for (int64_t i = lo + lane; i < n; i += 64) t[i] = 0;
 	__threadfence_block();
 	int64_t i0 = lo, st = lo, st_in = lo;
@@ -1858,6 +1859,200 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 	if (lane == 0 && (give_up || overflow)) atomicOr(&B.tie_flag[r], give_up ? 1u : 2u); // reused: bit 0 = the host chains this read (rmq_chain.cpp); the backtrack leaves such a read empty
 }
 
+// The same rules for a LONG CLUSTER, by a whole workgroup.  A piece that spans many anchors without a cluster head in it (the read's main chain: a thousand anchors; a tandem
+// array: thousands at one locus) is where a wavefront's time goes: every anchor scans a window of hundreds to thousands of candidates for the range minimum and sorts
+// a neighbourhood of up to RMQ_NEAR_CAP -- tens of microseconds per anchor, and the launch waited 100-280 ms for one such wavefront (MM2AMD_RMQ_TIMING).
+// The walk over the anchors stays sequential; what is parallel inside it is spread over THREADS lanes: the window scan (per-wavefront minima combined through LDS, equal
+// minima adding up as in the one-wavefront form), the gathering of the neighbourhood (slots handed out by an LDS counter: the sort that follows makes the order of arrival
+// irrelevant, the keys are distinct), the bitonic sort.  The scoring of the sorted candidates with its skip rule runs on the first wavefront alone, as in chain_rmq_kernel --
+// it ends after a few dozen candidates.  Every branch around a barrier is taken by the whole workgroup: the values deciding it are read from memory all wavefronts see alike
+// (written before the last barrier) or combined through LDS.  Pieces shorter than len_lo or from len_hi on are other launches'.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) chain_rmq_wide_kernel(SeedChainBuffers B, SeedChainParams P, int len_lo, int len_hi)
+{
+	constexpr int NW = THREADS / 64;
+	__shared__ uint64_t s_near[RMQ_NEAR_CAP];
+	__shared__ double s_best[NW];
+	__shared__ int64_t s_bj[NW];
+	__shared__ int s_nb[NW];
+	__shared__ int s_cnt;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = blockIdx.x;
+	const int r = (int)B.pieces[2 * w];
+	const Anchor *a = B.anchors + B.a_off[r];
+	const int64_t n_all = (int64_t)(B.a_off[r + 1] - B.a_off[r]);
+	int32_t *f = B.f + B.a_off[r], *p = B.p + B.a_off[r], *t = B.t + B.a_off[r];
+	double *pri = (double *)(B.sort_key_out + B.a_off[r]);
+	int32_t max_dist = P.max_gap, max_dist_inner = P.rmq_inner_dist;
+	const int32_t bw = P.bw, cap = P.rmq_size_cap;
+	if (max_dist < bw) max_dist = bw;
+	if (max_dist_inner < 0) max_dist_inner = 0;
+	if (max_dist_inner > max_dist) max_dist_inner = max_dist;
+	int64_t lo = 0, n = n_all;
+	chain_piece_bounds(a, n_all, (int64_t)B.pieces[2 * w + 1], (int64_t)B.piece_len, max_dist, lane, &lo, &n); // (every wavefront for itself: the same answer)
+	if (lo >= n || n - lo < (int64_t)len_lo || n - lo >= (int64_t)len_hi) return;
+#ifdef MM2AMD_WAVE_EMU // (the emulator's cases check that this path is the one they ran)
+	if (tid == 0 && getenv("MM2AMD_PIECE_DEBUG")) fprintf(stderr, "[mm2amd] chain_rmq_wide_kernel<%d>: read %d, anchors %lld..%lld\n", THREADS, r, (long long)lo, (long long)n);
+#endif
+	for (int64_t i = lo + tid; i < n; i += THREADS) t[i] = 0;
+	__threadfence_block();
+	__syncthreads();
+	int64_t i0 = lo, st = lo, st_in = lo;
+	bool give_up = n_all > (int64_t)P.rmq_dev_max_anchors;
+	for (int64_t i = lo; i < n && !give_up; ++i) {
+		const Anchor ai = a[i];
+		const uint64_t ix = ai.x, iy = ai.y;
+		const int32_t y_i = (int32_t)iy;
+		if (i0 < i && a[i0].x != ix) {
+			for (int64_t j = i0 + tid; j < i; j += THREADS) pri[j] = -((double)f[j] + 0.5 * (double)P.chn_pen_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y));
+			i0 = i;
+			__threadfence_block();
+			__syncthreads();
+		}
+		auto advance = [&](int64_t s0, int32_t dist) { // (each wavefront walks for itself)
+			int64_t s = s0;
+			while (s < i) {
+				const int64_t c = s + lane;
+				bool stop = true;
+				if (c < i) { const uint64_t cx = a[c].x; stop = !(ix >> 32 != cx >> 32 || ix > cx + (uint64_t)(int64_t)dist); }
+				const unsigned long long m = __ballot(stop);
+				if (m) { s += __ffsll((long long)m) - 1; break; }
+				s += 64;
+			}
+			if (s > i) s = i;
+			if (i0 - s > (int64_t)cap) s = i0 - cap;
+			return s;
+		};
+		st = advance(st, max_dist);
+		if (max_dist_inner > 0) st_in = advance(st_in, max_dist_inner);
+		// ---- range minimum over [st, i0): per lane, per wavefront, then over the wavefronts ----
+		double best = 0;
+		int64_t best_j = -1;
+		int n_best = 0;
+		for (int64_t base = st; base < i0; base += THREADS) {
+			const int64_t j = base + tid;
+			if (j < i0) {
+				const int32_t y_j = (int32_t)a[j].y;
+				if ((y_j > y_i - max_dist && y_j < y_i) || (y_j == y_i && j == 0)) {
+					const double v = pri[j];
+					if (best_j < 0 || v < best) best = v, best_j = j, n_best = 1;
+					else if (v == best) ++n_best;
+				}
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1) {
+			const double ov = __shfl_xor(best, o, 64);
+			const int64_t oj = __shfl_xor(best_j, o, 64);
+			const int on = __shfl_xor(n_best, o, 64);
+			if (oj >= 0) {
+				if (best_j < 0 || ov < best) best = ov, best_j = oj, n_best = on;
+				else if (ov == best) n_best += on;
+			}
+		}
+		if (lane == 0) s_best[wv] = best, s_bj[wv] = best_j, s_nb[wv] = n_best;
+		__syncthreads();
+		best = 0, best_j = -1, n_best = 0;
+		for (int k = 0; k < NW; ++k) {
+			const double ov = s_best[k];
+			const int64_t oj = s_bj[k];
+			const int on = s_nb[k];
+			if (oj >= 0) {
+				if (best_j < 0 || ov < best) best = ov, best_j = oj, n_best = on;
+				else if (ov == best) n_best += on;
+			}
+		}
+		int32_t max_f = (int32_t)(iy >> 32 & 0xff);
+		int64_t max_j = -1;
+		if (best_j >= 0) {
+			if (n_best > 1) { give_up = true; break; }
+			bool exact;
+			int32_t width;
+			const Anchor aj = a[best_j];
+			int32_t sc = f[best_j] + simple_score_dev(ix, iy, aj.x, aj.y, P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
+			if (width <= bw && sc > max_f) max_f = sc, max_j = best_j;
+			if (!exact && max_dist_inner > 0 && st_in < i0 && y_i > 0) {
+				// ---- the close neighbourhood ----
+				if (tid == 0) s_cnt = 0;
+				__syncthreads();
+				for (int64_t base = st_in; base < i0; base += THREADS) {
+					const int64_t j = base + tid;
+					bool in = false;
+					int32_t y_j = 0;
+					if (j < i0) { y_j = (int32_t)a[j].y; in = y_j <= y_i - 1 && y_j >= y_i - max_dist_inner; }
+					const unsigned long long m = __ballot(in);
+					int first = 0;
+					if (lane == 0 && m) first = atomicAdd(&s_cnt, (int)__popcll(m));
+					first = __shfl(first, 0, 64);
+					if (in) { const int d = first + popc_below(m, lane); if (d < RMQ_NEAR_CAP) s_near[d] = (uint64_t)(uint32_t)y_j << 32 | (uint64_t)(uint32_t)j; }
+				}
+				__syncthreads();
+				const int n_c = s_cnt;
+				if (n_c > RMQ_NEAR_CAP) { give_up = true; break; }
+				int n_pad = 64;
+				while (n_pad < n_c) n_pad <<= 1;
+				for (int k = n_c + tid; k < n_pad; k += THREADS) s_near[k] = 0;
+				__syncthreads();
+				for (int k2 = 2; k2 <= n_pad; k2 <<= 1)
+					for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+						for (int e = tid; e < n_pad; e += THREADS) {
+							const int partner = e ^ j2;
+							if (partner > e) {
+								const uint64_t u0 = s_near[e], u1 = s_near[partner];
+								const bool desc = (e & k2) == 0;
+								if (desc ? u0 < u1 : u0 > u1) s_near[e] = u1, s_near[partner] = u0;
+							}
+						}
+						__syncthreads();
+					}
+				if (wv == 0) { // the sorted candidates, 64 at a time, first wavefront only (no barrier in here)
+					int32_t n_skip = 0;
+					bool broke = false;
+					for (int base = 0; base < n_c && !broke; base += 64) {
+						const int c = base + lane;
+						int32_t scc = INT32_MIN, pj = -1;
+						int64_t j = -1;
+						if (c < n_c) {
+							j = (int64_t)(uint32_t)s_near[c];
+							bool ex;
+							int32_t wd;
+							const Anchor cj = a[j];
+							const int32_t v = simple_score_dev(ix, iy, cj.x, cj.y, P.chn_pen_gap, P.chn_pen_skip, &ex, &wd);
+							if (wd <= bw) scc = f[j] + v, pj = p[j];
+						}
+						const bool has = scc != INT32_MIN;
+						int32_t pm = has ? scc : INT32_MIN;
+						for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(pm, o, 64); if (lane >= o) pm = v > pm ? v : pm; }
+						int32_t excl = __shfl_up(pm, 1, 64);
+						if (lane == 0) excl = INT32_MIN;
+						excl = excl > max_f ? excl : max_f;
+						const bool improve = has && scc > excl;
+						if (has && pj >= 0) t[pj] = (int32_t)i;
+						__threadfence_block();
+						const bool marked = has && !improve && t[j] == (int32_t)i;
+						unsigned long long imp = __ballot(improve), mk = __ballot(marked), ev = imp | mk;
+						int stop_lane = 64;
+						while (ev) {
+							const int b = __ffsll((long long)ev) - 1;
+							ev &= ev - 1;
+							if (imp >> b & 1) { if (n_skip > 0) --n_skip; }
+							else if (++n_skip > P.max_chain_skip) { stop_lane = b; break; }
+						}
+						if (stop_lane < 64) broke = true, imp &= (1ull << stop_lane) - 1ull;
+						if (imp) {
+							const int last = 63 - __clzll((long long)imp);
+							max_f = __shfl(scc, last, 64);
+							max_j = __shfl(j, last, 64);
+						}
+					}
+				}
+			}
+		}
+		if (tid == 0) f[i] = max_f, p[i] = (int32_t)max_j; // (the first wavefront holds the scored neighbourhood's result)
+		__threadfence_block();
+		__syncthreads();
+	}
+	if (tid == 0 && give_up) atomicOr(&B.tie_flag[r], 1u);
+}
+
 void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
@@ -1881,6 +2076,10 @@ void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void 
 		fprintf(stderr, "[mm2amd] chain_rmq_kernel: %d wavefronts (%d reads), %.0f anchors, %.1f ms of wavefront time in all; the longest:", n_w, B.n_reads, anchors, sum / 1e5);
 		for (int i = 0; i < 6 && i < n_w; ++i) fprintf(stderr, " %.2f ms / %llu anchors (read %u)", (double)h[2 * order[i]] / 1e5, (unsigned long long)(h[2 * order[i] + 1] >> 32), (unsigned)h[2 * order[i] + 1]);
 		fprintf(stderr, "\n");
+	}
+	if (B.pieces && B.piece_dense > 0) { // the long clusters, by workgroups of 4 and (four times the length on) 16 wavefronts
+		hipLaunchKernelGGL(chain_rmq_wide_kernel<256>, grid, dim3(256), 0, s, B, P, B.piece_dense, 4 * B.piece_dense);
+		hipLaunchKernelGGL(chain_rmq_wide_kernel<1024>, grid, dim3(1024), 0, s, B, P, 4 * B.piece_dense, INT32_MAX);
 	}
 	hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_CAP>, grid, dim3(64), 0, s, B, P, (uint64_t *)nullptr);
 	HIP_CHECK(hipGetLastError());

@@ -408,9 +408,14 @@ def test_chaining_in_pieces_equals_whole_reads(tmp_path):
         want = subprocess.run([G.REF_BIN, "-x", preset, "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
         assert want.count(b"\n") >= len(reads)
         for env in ({"MM2AMD_CHAIN_PIECE": "0", "MM2AMD_RMQ_PIECE": "0"}, {"MM2AMD_CHAIN_PIECE": "7", "MM2AMD_RMQ_PIECE": "5"}, {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32"},
-                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_NEAR_TINY": "1"}, {"MM2AMD_RMQ_NEAR_TINY": "1"}):
+                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_NEAR_TINY": "1"}, {"MM2AMD_RMQ_NEAR_TINY": "1"},
+                    # the RMQ kernel's long clusters by workgroups of 4 / 16 wavefronts (chain_rmq_wide_kernel): pieces of 40 anchors or more, of 8 or more, none
+                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_DENSE": "40"}, {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "16", "MM2AMD_RMQ_DENSE": "8", "MM2AMD_RMQ_NEAR_TINY": "1"},
+                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_DENSE": "0"}):
             p = subprocess.run([DROPIN_EMU, "-x", preset, "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM2AMD_PIECE_DEBUG="1", **env))
             assert p.returncode == 0, p.stderr.decode()[-800:]
             assert p.stdout == want, (preset, env)
+            if env.get("MM2AMD_RMQ_DENSE", "0") != "0":
+                assert b"chain_rmq_wide_kernel<1024>" in p.stderr and (env["MM2AMD_RMQ_DENSE"] != "40" or b"chain_rmq_wide_kernel<256>" in p.stderr), (preset, env)
             if "MM2AMD_CHAIN_PIECE" in env:  # (the default piece lengths cut some of these reads' re-chains too)
                 assert (b"chaining work list" in p.stderr) == (env["MM2AMD_CHAIN_PIECE"] != "0"), (preset, env)

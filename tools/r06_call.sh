@@ -152,6 +152,19 @@ P
        done
        MM2AMD_RMQ_TIMING=1 MM2AMD_LANES=1 timeout 900 python bench.py --workload repeats --steps 1 --warmup 1 --no-cpu-baseline --timed-only > $O/r06_bench_repeats_rmqtiming_$V.json 2> $O/r06_bench_repeats_rmqtiming_$V.log
        grep -h "chain_rmq_kernel:" $O/r06_bench_repeats_rmqtiming_$V.log | tail -12 | cut -c1-420 ;;
+wide)  # chain_rmq_kernel's long clusters by workgroups (chain_rmq_wide_kernel) against by one wavefront: the repeats workload, with the per-wavefront timing of one lane
+       for m in wide nowide; do
+         if [ $m = nowide ]; then export MM2AMD_RMQ_DENSE=0; else unset MM2AMD_RMQ_DENSE; fi
+         timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_${m}_$V.json 2> $O/r06_bench_repeats_${m}_$V.log
+         python - <<P
+import json
+d=json.loads(open('$O/r06_bench_repeats_${m}_$V.json').read().strip().split('\n')[-1]); c=d['config']; r=d['roofline']
+print('repeats $m', d['value'], d['ms_per_step'], 'host cpu', c['host_cpu_s_per_step'], c['device_path_last_batch'])
+print('   ', {k: v for k, v in sorted((r.get('unoverlapped_ms') or {}).items(), key=lambda kv: -kv[1])[:10]})
+P
+       done; unset MM2AMD_RMQ_DENSE
+       MM2AMD_RMQ_TIMING=1 MM2AMD_LANES=1 timeout 900 python bench.py --workload repeats --steps 1 --warmup 1 --no-cpu-baseline --timed-only > $O/r06_bench_repeats_rmqtiming_$V.json 2> $O/r06_bench_repeats_rmqtiming_$V.log
+       grep -h "chain_rmq_kernel:" $O/r06_bench_repeats_rmqtiming_$V.log | tail -4 | cut -c1-420 ;;
 chain) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_aligner.py tests/test_gpu_regions.py -x -q -m gpu > $O/r06_pytest_chain_$V.log 2>&1; tail -3 $O/r06_pytest_chain_$V.log ;;
 prof)  # evidence at HEAD in one call: rocprofv3 kernel stats of the headline command, the exposed-time split, HBM traffic (FETCH / WRITE passes) and the SQ counters
        cd /tmp
