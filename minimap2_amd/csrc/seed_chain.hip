@@ -2078,8 +2078,10 @@ void launch_chain_rmq(const SeedChainBuffers &B, const SeedChainParams &P, void 
 		fprintf(stderr, "\n");
 	}
 	if (B.pieces && B.piece_dense > 0) { // the long clusters, by workgroups of 4 and (four times the length on) 16 wavefronts
-		hipLaunchKernelGGL(chain_rmq_wide_kernel<256>, grid, dim3(256), 0, s, B, P, B.piece_dense, 4 * B.piece_dense);
-		hipLaunchKernelGGL(chain_rmq_wide_kernel<1024>, grid, dim3(1024), 0, s, B, P, 4 * B.piece_dense, INT32_MAX);
+		const char *e = getenv("MM2AMD_RMQ_DENSE_BIG"); // (A/B: from how many times piece_dense on a workgroup has 16 wavefronts)
+		const int big = B.piece_dense * (e && atoi(e) > 0 ? atoi(e) : 4);
+		hipLaunchKernelGGL(chain_rmq_wide_kernel<256>, grid, dim3(256), 0, s, B, P, B.piece_dense, big);
+		hipLaunchKernelGGL(chain_rmq_wide_kernel<1024>, grid, dim3(1024), 0, s, B, P, big, INT32_MAX);
 	}
 	hipLaunchKernelGGL(chain_rmq_kernel<RMQ_NEAR_CAP>, grid, dim3(64), 0, s, B, P, (uint64_t *)nullptr);
 	HIP_CHECK(hipGetLastError());

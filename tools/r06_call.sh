@@ -165,6 +165,13 @@ P
        done; unset MM2AMD_RMQ_DENSE
        MM2AMD_RMQ_TIMING=1 MM2AMD_LANES=1 timeout 900 python bench.py --workload repeats --steps 1 --warmup 1 --no-cpu-baseline --timed-only > $O/r06_bench_repeats_rmqtiming_$V.json 2> $O/r06_bench_repeats_rmqtiming_$V.log
        grep -h "chain_rmq_kernel:" $O/r06_bench_repeats_rmqtiming_$V.log | tail -4 | cut -c1-420 ;;
+widesweep) # from how many anchors a cluster goes to a workgroup, and from how many to sixteen wavefronts
+       for cfg in "1024 4" "1024 2" "512 4" "512 2" "768 3"; do
+         set -- $cfg
+         MM2AMD_RMQ_DENSE=$1 MM2AMD_RMQ_DENSE_BIG=$2 timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_dense$1x$2_$V.json 2> $O/r06_bench_repeats_dense$1x$2_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_repeats_dense$1x$2_$V.json').read().strip().split('\n')[-1]); u=d['roofline']['unoverlapped_ms']; print('dense $1 big x$2:', d['value'], d['ms_per_step'], 'rmq[lj]', u.get('chain_rmq_kernel[long-join]'))"
+       done ;;
 chain) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_aligner.py tests/test_gpu_regions.py -x -q -m gpu > $O/r06_pytest_chain_$V.log 2>&1; tail -3 $O/r06_pytest_chain_$V.log ;;
 prof)  # evidence at HEAD in one call: rocprofv3 kernel stats of the headline command, the exposed-time split, HBM traffic (FETCH / WRITE passes) and the SQ counters
        cd /tmp
