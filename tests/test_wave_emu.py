@@ -393,25 +393,24 @@ def test_chaining_in_pieces_equals_whole_reads(tmp_path):
     """round 6: a read with very many anchors is chained by several wavefronts, each from one cluster head to another (seed_chain.hip: chain_piece_bounds; the
     host lists the pieces: backend_hip.cpp make_pieces), and chain_rmq_kernel runs with a small neighbourhood buffer first and a second launch for what did not fit.
     The kernels' own source under the wave emulator on a reference of diverged copies (every read crosses several: many clusters, long-join re-chaining):
-    mg_lchain_dp + the long-join RMQ (map-ont) and mg_lchain_rmq as the primary chainer (asm20), pieces of 7 / 5 and 64 / 32 anchors, never cut, the tiny first buffer --
-    PAF with CIGARs identical every time, and identical to the compiled reference's"""
+    mg_lchain_dp + the long-join RMQ (map-ont) and mg_lchain_rmq as the primary chainer (asm20), pieces of 7 / 5 and 64 / 32 anchors, never cut, the tiny first buffer, the
+    RMQ chainer's long clusters on workgroups of 4 and 16 wavefronts (chain_rmq_wide_kernel) -- PAF with CIGARs identical every time, and identical to the compiled reference's"""
     if not os.path.exists(DROPIN_EMU) or not os.path.exists(G.REF_BIN):
         pytest.skip("needs oracle/_ref and tests/_build/dropin_emu")
     rng = np.random.default_rng(77)
     contig = synth.gen_duplicated_reference(rng)
     other = rng.integers(0, 4, 200000, dtype=np.uint8)
-    reads = synth.gen_reads(rng, [contig], 24, 9000, 3000, 0.08) + synth.gen_reads(rng, [other], 6, 5000, 1000, 0.05)
+    reads = synth.gen_reads(rng, [contig], 12, 9000, 3000, 0.08) + synth.gen_reads(rng, [other], 3, 5000, 1000, 0.05)
     ref, rd = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
     synth.write_fasta(ref, ["dup", "plain"], [contig, other])
     synth.write_fasta(rd, ["r%d" % i for i in range(len(reads))], reads)
     for preset in ("map-ont", "asm20"):
         want = subprocess.run([G.REF_BIN, "-x", preset, "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
         assert want.count(b"\n") >= len(reads)
-        for env in ({"MM2AMD_CHAIN_PIECE": "0", "MM2AMD_RMQ_PIECE": "0"}, {"MM2AMD_CHAIN_PIECE": "7", "MM2AMD_RMQ_PIECE": "5"}, {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32"},
-                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_NEAR_TINY": "1"}, {"MM2AMD_RMQ_NEAR_TINY": "1"},
-                    # the RMQ kernel's long clusters by workgroups of 4 / 16 wavefronts (chain_rmq_wide_kernel): pieces of 40 anchors or more, of 8 or more, none
-                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_DENSE": "40"}, {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "16", "MM2AMD_RMQ_DENSE": "8", "MM2AMD_RMQ_NEAR_TINY": "1"},
-                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_DENSE": "0"}):
+        for env in ({"MM2AMD_CHAIN_PIECE": "0", "MM2AMD_RMQ_PIECE": "0"}, {"MM2AMD_CHAIN_PIECE": "7", "MM2AMD_RMQ_PIECE": "5", "MM2AMD_RMQ_DENSE": "0"},
+                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_NEAR_TINY": "1", "MM2AMD_RMQ_DENSE": "0"}, {"MM2AMD_RMQ_NEAR_TINY": "1"},
+                    # the RMQ kernel's long clusters by workgroups of 4 / 16 wavefronts (chain_rmq_wide_kernel): pieces of 40 anchors or more, of 8 or more
+                    {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "32", "MM2AMD_RMQ_DENSE": "40"}, {"MM2AMD_CHAIN_PIECE": "64", "MM2AMD_RMQ_PIECE": "16", "MM2AMD_RMQ_DENSE": "8", "MM2AMD_RMQ_NEAR_TINY": "1"}):
             p = subprocess.run([DROPIN_EMU, "-x", preset, "-t", "2", "-c", ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM2AMD_PIECE_DEBUG="1", **env))
             assert p.returncode == 0, p.stderr.decode()[-800:]
             assert p.stdout == want, (preset, env)
