@@ -20,7 +20,7 @@ import reflib  # noqa: E402
 import synth  # noqa: E402
 
 EMU_SO = os.path.join(HERE, "_build", "libmm2amd_emu.so")
-DROPIN_EMU = os.path.join(HERE, "_build", "dropin_emu")
+DROPIN_EMU = os.environ.get("MM2AMD_DROPIN_EMU") or os.path.join(HERE, "_build", "dropin_emu")  # (MM2AMD_DROPIN_EMU: e.g. tools/sanitize_emu.sh's AddressSanitizer build)
 
 
 @pytest.fixture(scope="module")
