@@ -481,6 +481,7 @@ public:
 	static void make_pieces(SeedChainBuffers &B, Lane &ln, PinBuf<uint32_t> &hbuf, size_t n, Count count, int len, hipStream_t st)
 	{
 		B.pieces = nullptr, B.n_pieces = 0, B.piece_len = len;
+		{ const char *e = getenv("MM2AMD_RMQ_RANK_MAX"); B.rmq_rank_max = e ? std::min(256, std::max(0, atoi(e))) : 256; }
 		{ const char *e = getenv("MM2AMD_RMQ_DENSE"); B.piece_dense = e ? atoi(e) : 1024; } // (the RMQ kernel's long clusters go to workgroups: seed_chain.hip chain_rmq_wide_kernel; tests set it low, 0 = off)
 		if (len <= 0) return;
 		size_t n_p = 0;

@@ -1675,6 +1675,7 @@ void launch_chain_fill(const SeedChainBuffers &B, const SeedChainParams &P, void
 //     before it: its chain successors have larger query coordinates).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int RMQ_NEAR_CAP = 4096; // anchors of the narrow window scored per anchor; more: the read goes to the host
+constexpr int RMQ_RANK_MAX = 256;   // neighbourhoods up to this many anchors are sorted by counting (SeedChainBuffers::rmq_rank_max <= this: 0 = always the bitonic network, A/B)
 constexpr int RMQ_NEAR_SMALL = 1024; // ... of the first launch; what does not fit goes to a second one (MM2AMD_RMQ_NEAR_TINY=1: 64, for tests of that hand-over)
 
 __device__ __forceinline__ int32_t simple_score_dev(uint64_t ix, uint64_t iy, uint64_t jx, uint64_t jy, float pen_gap, float pen_skip, bool *exact, int32_t *width) // comput_sc_simple, lchain.c:229-248
@@ -1700,6 +1701,7 @@ template <int NEAR>
 __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedChainParams P, uint64_t *timing)
 {
 	__shared__ uint64_t s_near[NEAR];
+	__shared__ uint64_t s_rank[RMQ_RANK_MAX];
 	const int lane = threadIdx.x, w = blockIdx.x;
 	const uint64_t t_begin = timing ? wall_clock64() : 0; // (MM2AMD_RMQ_TIMING=1: what each wavefront of a launch spent, 100 MHz ticks)
 	const int r = B.pieces ? (int)B.pieces[2 * w] : w;
@@ -1794,6 +1796,18 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 					n_c += __popcll(m);
 				}
 				if (n_c > NEAR) { if (NEAR == RMQ_NEAR_CAP) give_up = true; else overflow = true; break; }
+				const uint64_t *sorted = s_near;
+				if (n_c <= B.rmq_rank_max) { // a small neighbourhood (the usual one): every key's place is the number of larger keys (they are distinct) -- one pass over LDS instead of the bitonic network's dozens
+					__syncthreads();
+					for (int e = lane; e < n_c; e += 64) {
+						const uint64_t key = s_near[e];
+						int rank = 0;
+						for (int k = 0; k < n_c; ++k) rank += s_near[k] > key;
+						s_rank[rank] = key;
+					}
+					sorted = s_rank;
+					__syncthreads();
+				} else {
 				int n_pad = 64;
 				while (n_pad < n_c) n_pad <<= 1;
 				for (int k = n_c + lane; k < n_pad; k += 64) s_near[k] = 0; // pads sort last (descending order; y >= 0 and every real key is > 0 unless (0, 0), which ties harmlessly)
@@ -1810,6 +1824,7 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 						}
 						__syncthreads();
 					}
+				}
 				int32_t n_skip = 0;
 				bool broke = false;
 				for (int base = 0; base < n_c && !broke; base += 64) {
@@ -1817,7 +1832,7 @@ __global__ void __launch_bounds__(64) chain_rmq_kernel(SeedChainBuffers B, SeedC
 					int32_t scc = INT32_MIN, pj = -1;
 					int64_t j = -1;
 					if (c < n_c) {
-						j = (int64_t)(uint32_t)s_near[c];
+						j = (int64_t)(uint32_t)sorted[c];
 						bool ex;
 						int32_t wd;
 						const Anchor cj = a[j];
@@ -1872,6 +1887,7 @@ __global__ void __launch_bounds__(THREADS) chain_rmq_wide_kernel(SeedChainBuffer
 {
 	constexpr int NW = THREADS / 64;
 	__shared__ uint64_t s_near[RMQ_NEAR_CAP];
+	__shared__ uint64_t s_rank[RMQ_RANK_MAX];
 	__shared__ double s_best[NW];
 	__shared__ int64_t s_bj[NW];
 	__shared__ int s_nb[NW];
@@ -1987,6 +2003,17 @@ __global__ void __launch_bounds__(THREADS) chain_rmq_wide_kernel(SeedChainBuffer
 				__syncthreads();
 				const int n_c = s_cnt;
 				if (n_c > RMQ_NEAR_CAP) { give_up = true; break; }
+				const uint64_t *sorted = s_near;
+				if (n_c <= B.rmq_rank_max) { // (as in chain_rmq_kernel: a key's place is the number of larger keys; one barrier instead of the network's dozens)
+					for (int e = tid; e < n_c; e += THREADS) {
+						const uint64_t key = s_near[e];
+						int rank = 0;
+						for (int k = 0; k < n_c; ++k) rank += s_near[k] > key;
+						s_rank[rank] = key;
+					}
+					sorted = s_rank;
+					__syncthreads();
+				} else {
 				int n_pad = 64;
 				while (n_pad < n_c) n_pad <<= 1;
 				for (int k = n_c + tid; k < n_pad; k += THREADS) s_near[k] = 0;
@@ -2003,6 +2030,7 @@ __global__ void __launch_bounds__(THREADS) chain_rmq_wide_kernel(SeedChainBuffer
 						}
 						__syncthreads();
 					}
+				}
 				if (wv == 0) { // the sorted candidates, 64 at a time, first wavefront only (no barrier in here)
 					int32_t n_skip = 0;
 					bool broke = false;
@@ -2011,7 +2039,7 @@ __global__ void __launch_bounds__(THREADS) chain_rmq_wide_kernel(SeedChainBuffer
 						int32_t scc = INT32_MIN, pj = -1;
 						int64_t j = -1;
 						if (c < n_c) {
-							j = (int64_t)(uint32_t)s_near[c];
+							j = (int64_t)(uint32_t)sorted[c];
 							bool ex;
 							int32_t wd;
 							const Anchor cj = a[j];

@@ -57,6 +57,7 @@ struct SeedChainBuffers {     // all device pointers; per-read slices addressed 
 	// heads (seed_chain.hip: chain_piece_bounds); made by the host when a read of the launch has more than piece_len anchors, heaviest reads first
 	const uint32_t *pieces = nullptr;
 	int n_pieces = 0, piece_len = 0;
+	int rmq_rank_max = 256;   // chain_rmq_kernel: neighbourhoods up to this many anchors are sorted by counting larger keys (at most 256; 0: always the bitonic network -- MM2AMD_RMQ_RANK_MAX)
 	int piece_dense = 0;      // chain_rmq_kernel: a piece of this many anchors or more (a cluster that long) is chain_rmq_wide_kernel's; 0 = none is
 	// chain backtrack results: dense outputs handed out by two atomic cursors ([0] anchors, [1] chains)
 	unsigned long long *bt_cursor;

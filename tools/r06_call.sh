@@ -172,6 +172,22 @@ widesweep) # from how many anchors a cluster goes to a workgroup, and from how m
          python -c "
 import json; d=json.loads(open('$O/r06_bench_repeats_dense$1x$2_$V.json').read().strip().split('\n')[-1]); u=d['roofline']['unoverlapped_ms']; print('dense $1 big x$2:', d['value'], d['ms_per_step'], 'rmq[lj]', u.get('chain_rmq_kernel[long-join]'))"
        done ;;
+profrep) # the repeats workload's kernels one lane at a time under rocprofv3: which of the chaining launches lasts
+       cd /tmp
+       MM2AMD_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_rep -o bench -- python $R/bench.py --workload repeats --steps 2 --warmup 1 --no-cpu-baseline --timed-only > $O/r06_bench_repeats_${V}_under_rocprof.json 2> $O/prof_rep.log
+       DB=$(ls $O/prof_rep/*.db $O/prof_rep/*/*.db 2>/dev/null | head -1)
+       python $R/tools/rocpd_summary.py $DB > $O/r06_bench_repeats_kernel_stats_$V.txt; rm -rf $O/prof_rep
+       head -24 $O/r06_bench_repeats_kernel_stats_$V.txt | cut -c1-200
+       cd $R ;;
+rank)  # the RMQ chainer's small neighbourhoods sorted by counting larger keys against the bitonic network
+       for m in 256 0; do
+         MM2AMD_RMQ_RANK_MAX=$m timeout 900 python bench.py --workload repeats --steps 4 --warmup 2 --no-cpu-baseline > $O/r06_bench_repeats_rank${m}_$V.json 2> $O/r06_bench_repeats_rank${m}_$V.log
+         python -c "
+import json; d=json.loads(open('$O/r06_bench_repeats_rank${m}_$V.json').read().strip().split('\n')[-1]); u=d['roofline']['unoverlapped_ms']; print('rank max $m:', d['value'], d['ms_per_step'], 'rmq[lj]', u.get('chain_rmq_kernel[long-join]'), d['config']['device_path_last_batch'])"
+       done
+       timeout 500 python bench.py --preset map-hifi --reads 200000 --steps 3 --warmup 2 --cpu-sample 20000 > $O/r06_bench_hifi_$V.json 2> $O/r06_bench_hifi_$V.log
+       python -c "
+import json; d=json.loads(open('$O/r06_bench_hifi_$V.json').read().strip().split('\n')[-1]); print('hifi', d['value'], d['ms_per_step'], (d.get('cpu_baseline') or {}).get('hits_identical_to_gpu'))" ;;
 chain) timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_aligner.py tests/test_gpu_regions.py -x -q -m gpu > $O/r06_pytest_chain_$V.log 2>&1; tail -3 $O/r06_pytest_chain_$V.log ;;
 prof)  # evidence at HEAD in one call: rocprofv3 kernel stats of the headline command, the exposed-time split, HBM traffic (FETCH / WRITE passes) and the SQ counters
        cd /tmp
